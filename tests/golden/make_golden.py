@@ -1,0 +1,390 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors in this directory FROM THE REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference, which never travels to the GPU
+box).  It imports the reference's own ``CoarseGrainingVAE.{modules,conv,cgvae,data}``
+unmodified and records inputs / parameters / outputs / gradients as small ``.npz`` files.
+
+Third-party pieces the reference imports but that are not installed here:
+  * ``torch_scatter`` 2.0.9 (requirements.txt:18): a stand-in module implementing its
+    published semantics (zeros -> scatter_add_ with broadcast index; mean = sum/clamp(cnt,1))
+    is registered in ``sys.modules``.  This is the one unpinned boundary (see oracle header).
+  * ``ase`` / ``ase.neighborlist`` (data.py:8-9, import-time only, never called on this
+    path): empty stub modules.
+  * numpy>=2 rejects ``np.cumsum([0, LongTensor([n]), ...])`` (data.py:259-260): the data
+    module's ``np`` is proxied so that cumsum maps its elements through ``int()``.
+
+Usage:  python tests/golden/make_golden.py            (rewrites tests/golden/*.npz)
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+
+
+# ------------------------------------------------------------------ shims for absent deps
+def _install_shims():
+    ts = types.ModuleType("torch_scatter")
+
+    def scatter_sum(src, index, dim=0, out=None, dim_size=None):
+        assert dim == 0 and out is None
+        if dim_size is None:
+            dim_size = int(index.max()) + 1 if index.numel() else 0
+        idx = index.reshape([-1] + [1] * (src.dim() - 1)).expand_as(src)
+        res = torch.zeros((dim_size,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+        return res.scatter_add_(0, idx, src)
+
+    def scatter_mean(src, index, dim=0, out=None, dim_size=None):
+        total = scatter_sum(src, index, dim, None, dim_size)
+        ones = torch.ones(index.shape[0], dtype=src.dtype, device=src.device)
+        cnt = scatter_sum(ones, index, 0, None, total.shape[0]).clamp_(min=1)
+        return total / cnt.reshape([-1] + [1] * (src.dim() - 1))
+
+    ts.scatter_sum = scatter_sum
+    ts.scatter_add = scatter_sum
+    ts.scatter_mean = scatter_mean
+    sys.modules["torch_scatter"] = ts
+
+    ase = types.ModuleType("ase")
+    ase.Atoms = object
+    nl = types.ModuleType("ase.neighborlist")
+    nl.neighbor_list = None
+    ase.neighborlist = nl
+    sys.modules["ase"] = ase
+    sys.modules["ase.neighborlist"] = nl
+
+
+class _NumpyProxy:
+    def __getattr__(self, name):
+        return getattr(np, name)
+
+    @staticmethod
+    def cumsum(a, *args, **kw):
+        return np.cumsum([int(t) for t in a], *args, **kw)
+
+
+def load_reference():
+    _install_shims()
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import warnings
+    warnings.filterwarnings("ignore")
+    import CoarseGrainingVAE.conv as conv
+    import CoarseGrainingVAE.cgvae as cgvae
+    import CoarseGrainingVAE.modules as modules
+    import CoarseGrainingVAE.data as data
+    data.np = _NumpyProxy()
+    return modules, conv, cgvae, data
+
+
+# ------------------------------------------------------------------ helpers
+def T(x):
+    return x.detach().cpu().numpy()
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: (T(v) if torch.is_tensor(v) else np.asarray(v)) for k, v in arrays.items()})
+    print(f"wrote {path}  ({os.path.getsize(path)/1024:.1f} KiB, {len(arrays)} arrays)")
+
+
+def random_graph(n, p, gen):
+    """undirected pairs (i<j) row-major, like get_neighbor_list(undirected=True)."""
+    m = torch.rand(n, n, generator=gen) < p
+    m = torch.triu(m, diagonal=1)
+    return torch.nonzero(m)
+
+
+def params_of(mod, prefix="p."):
+    return {prefix + k: v for k, v in mod.state_dict().items()}
+
+
+def grads_of(mod, prefix="g."):
+    return {prefix + k: (p.grad if p.grad is not None else torch.zeros(0)) for k, p in mod.named_parameters()}
+
+
+# ------------------------------------------------------------------ G1: blocks
+def g1_blocks(modules, conv):
+    for F, R, tag in ((8, 8, "F8R8"), (24, 10, "F24R10")):
+        gen = torch.Generator().manual_seed(1000 + F)
+        N, cutoff = 40, 6.0
+        xyz = torch.rand(N, 3, generator=gen) * 5.0
+        und = random_graph(N, 0.25, gen)
+        nbrs, _ = conv.make_directed(und)
+        r_ij = xyz[nbrs[:, 1]] - xyz[nbrs[:, 0]]
+
+        # --- DistanceEmbed (modules.py:175-197)
+        torch.manual_seed(7)
+        de = modules.DistanceEmbed(n_rbf=R, cutoff=cutoff, feat_dim=3 * F, dropout=0.0)
+        de.block[1].bias.data.normal_()
+        dist = torch.cat([torch.rand(30, generator=gen) * 7.0, torch.tensor([0.0, cutoff, cutoff * 1.5])])
+        save(f"g1_distance_embed_{tag}", dist=dist, cutoff=cutoff, R=R, out=de(dist), **params_of(de))
+
+        # --- EquiMessageBlock (conv.py:487-563)
+        torch.manual_seed(11)
+        blk = conv.EquiMessageBlock(feat_dim=F, activation="swish", n_rbf=R, cutoff=cutoff, dropout=0.0)
+        for p in blk.parameters():       # biases are zero-initialised: make them count
+            if p.dim() == 1:
+                p.data.normal_(0, 0.3)
+        s = torch.randn(N, F, generator=gen, requires_grad=True)
+        v = torch.randn(N, F, 3, generator=gen, requires_grad=True)
+        ds, dv = blk(s, v, r_ij, nbrs)
+        gs = torch.randn(ds.shape, generator=gen)
+        gv = torch.randn(dv.shape, generator=gen)
+        (ds * gs).sum().add((dv * gv).sum()).backward()
+        save(f"g1_equi_message_{tag}", s=s, v=v, r_ij=r_ij, nbrs=nbrs, cutoff=cutoff, R=R, ds=ds, dv=dv,
+             gout_s=gs, gout_v=gv, gin_s=s.grad, gin_v=v.grad, **params_of(blk), **grads_of(blk))
+
+        # --- ContractiveMessageBlock (conv.py:677-733)
+        torch.manual_seed(13)
+        n_cg = 5
+        mapping = torch.sort(torch.randint(0, n_cg, (N,), generator=gen)).values
+        mapping[:n_cg] = torch.arange(n_cg)          # every bead non-empty
+        mapping = torch.sort(mapping).values
+        cg_xyz = torch.stack([xyz[mapping == b].mean(0) for b in range(n_cg)])
+        r_iI = xyz - cg_xyz[mapping]
+        cblk = conv.ContractiveMessageBlock(feat_dim=F, activation="swish", n_rbf=R, cutoff=20.0, dropout=0.0)
+        for p in cblk.parameters():
+            if p.dim() == 1:
+                p.data.normal_(0, 0.3)
+        s2 = torch.randn(N, F, generator=gen, requires_grad=True)
+        v2 = torch.randn(N, F, 3, generator=gen, requires_grad=True)
+        dS, dV = cblk(s2, v2, r_iI, mapping)
+        gS = torch.randn(dS.shape, generator=gen)
+        gV = torch.randn(dV.shape, generator=gen)
+        (dS * gS).sum().add((dV * gV).sum()).backward()
+        save(f"g1_contractive_{tag}", s=s2, v=v2, r_iI=r_iI, mapping=mapping, cutoff=20.0, R=R, dS=dS, dV=dV,
+             gout_S=gS, gout_V=gV, gin_s=s2.grad, gin_v=v2.grad, **params_of(cblk), **grads_of(cblk))
+
+        # --- EquiMessagePsuedo (conv.py:165-242) on a small "CG" graph
+        torch.manual_seed(17)
+        Ncg = 7
+        cgx = torch.rand(Ncg, 3, generator=gen) * 4.0
+        cg_und = random_graph(Ncg, 0.6, gen)
+        cg_nbrs, _ = conv.make_directed(cg_und)
+        assert cg_nbrs.shape[0] != 3                  # torch.cross default-dim trap
+        r_cg = cgx[cg_nbrs[:, 1]] - cgx[cg_nbrs[:, 0]]
+        pblk = conv.EquiMessagePsuedo(feat_dim=F, activation="swish", n_rbf=R, cutoff=cutoff, dropout=0.0)
+        for p in pblk.parameters():
+            if p.dim() == 1:
+                p.data.normal_(0, 0.3)
+        S = torch.randn(Ncg, F, generator=gen, requires_grad=True)
+        Sb = torch.randn(Ncg, F, generator=gen, requires_grad=True)
+        V = torch.randn(Ncg, F, 3, generator=gen, requires_grad=True)
+        Vb = torch.randn(Ncg, F, 3, generator=gen, requires_grad=True)
+        dh, dhb, dvv, dvb = pblk(S, Sb, V, Vb, r_cg, cg_nbrs)
+        g = [torch.randn(t.shape, generator=gen) for t in (dh, dhb, dvv, dvb)]
+        sum((o * gg).sum() for o, gg in zip((dh, dhb, dvv, dvb), g)).backward()
+        save(f"g1_equi_pseudo_{tag}", s=S, sbar=Sb, v=V, vbar=Vb, r_ij=r_cg, nbrs=cg_nbrs, cutoff=cutoff, R=R,
+             dh=dh, dhbar=dhb, dv=dvv, dvbar=dvb, gout_h=g[0], gout_hbar=g[1], gout_v=g[2], gout_vbar=g[3],
+             gin_s=S.grad, gin_sbar=Sb.grad, gin_v=V.grad, gin_vbar=Vb.grad, **params_of(pblk), **grads_of(pblk))
+
+        # --- UpdateBlock (conv.py:566-616)
+        torch.manual_seed(19)
+        ub = conv.UpdateBlock(feat_dim=F, activation="swish", dropout=0.0)
+        for p in ub.parameters():
+            if p.dim() == 1:
+                p.data.normal_(0, 0.3)
+        su = torch.randn(Ncg, F, generator=gen, requires_grad=True)
+        vu = torch.randn(Ncg, F, 3, generator=gen, requires_grad=True)
+        dsu, dvu = ub(su, vu)
+        gsu = torch.randn(dsu.shape, generator=gen)
+        gvu = torch.randn(dvu.shape, generator=gen)
+        (dsu * gsu).sum().add((dvu * gvu).sum()).backward()
+        save(f"g1_update_{tag}", s=su, v=vu, ds=dsu, dv=dvu, gout_s=gsu, gout_v=gvu, gin_s=su.grad, gin_v=vu.grad,
+             **params_of(ub), **grads_of(ub))
+
+
+# ------------------------------------------------------------------ G2: model level
+def build_reference_model(cgvae, F, R, atom_cutoff, cg_cutoff, enc_nconv, dec_nconv, n_cgs, det, seed=123):
+    """scripts/run_ala.py:184-209, in that order, after torch.manual_seed(123) (run_ala.py:36-37)."""
+    from torch import nn
+    torch.manual_seed(seed)
+    atom_mu = nn.Sequential(nn.Linear(F, F), nn.ReLU(), nn.Linear(F, F))
+    atom_sigma = nn.Sequential(nn.Linear(F, F), nn.ReLU(), nn.Linear(F, F))
+    decoder = cgvae.EquivariantPsuedoDecoder(n_atom_basis=F, n_rbf=R, cutoff=atom_cutoff, num_conv=dec_nconv,
+                                             activation="swish", breaksym=(n_cgs == 3))
+    encoder = cgvae.EquiEncoder(n_conv=enc_nconv, n_atom_basis=F, n_rbf=R, cutoff=cg_cutoff,
+                                activation="swish", cg_mp=False, dir_mp=False)
+    prior = cgvae.CGprior(n_conv=enc_nconv, n_atom_basis=F, n_rbf=R, cutoff=cg_cutoff, activation="swish",
+                          dir_mp=False)
+    return cgvae.CGequiVAE(encoder, decoder, atom_mu, atom_sigma, n_cgs, feature_dim=F, prior_net=prior,
+                           det=det, equivariant=True)
+
+
+def synthetic_frames(data, n_frames, n_atoms, n_cgs, box, atom_cutoff, cg_cutoff, seed):
+    """SURVEY.md 8(d) synthetic inputs, graphs and batch built by the REFERENCE's data.py."""
+    gen = torch.Generator().manual_seed(seed)
+    mapping = (torch.arange(n_atoms) * n_cgs) // n_atoms
+    bonds = torch.stack([torch.arange(n_atoms - 1), torch.arange(1, n_atoms)], dim=1)
+    props = {k: [] for k in ("nxyz", "CG_nxyz", "num_atoms", "num_CGs", "CG_mapping", "bond_edge_list")}
+    for _ in range(n_frames):
+        xyz = torch.rand(n_atoms, 3, generator=gen) * box
+        z = torch.randint(1, 9, (n_atoms,), generator=gen).float()
+        cg = torch.stack([xyz[mapping == b].mean(0) for b in range(n_cgs)])
+        props["nxyz"].append(torch.cat([z[:, None], xyz], dim=1))
+        props["CG_nxyz"].append(torch.cat([torch.arange(n_cgs).float()[:, None], cg], dim=1))
+        props["num_atoms"].append(torch.LongTensor([n_atoms]))
+        props["num_CGs"].append(torch.LongTensor([n_cgs]))
+        props["CG_mapping"].append(mapping.clone())
+        props["bond_edge_list"].append(bonds.clone())
+    import contextlib
+    import io
+    ds = data.CGDataset(props)
+    with contextlib.redirect_stdout(io.StringIO()):
+        ds.generate_neighbor_list(atom_cutoff=atom_cutoff, cg_cutoff=cg_cutoff, device="cpu", undirected=True)
+    frames = [ds[i] for i in range(n_frames)]
+    per_frame = [{k: v.clone() for k, v in f.items()} for f in frames]
+    batch = data.CG_collate([{k: v.clone() for k, v in f.items()} for f in frames])
+    return per_frame, batch
+
+
+def ref_loss(out, batch, beta, gamma):
+    """scripts/utils.py:81-86,117-141 (scripts/ cannot be imported: formulas re-typed in the harness)."""
+    mu, sigma, pmu, pstd, xyz, xr = out
+    kl = 0.5 * ((sigma.pow(2) / pstd.pow(2)).sum(-1) + ((mu - pmu).pow(2) / pstd).sum(-1)
+                + torch.log(pstd.pow(2)).sum(-1) - torch.log(sigma.pow(2)).sum(-1) - sigma.shape[-1]).mean()
+    recon = (xr - xyz).pow(2).mean()
+    e = batch["bond_edge_list"]
+    gen = ((xr[e[:, 0]] - xr[e[:, 1]]).pow(2).sum(-1) + 1e-6).sqrt()
+    dat = ((xyz[e[:, 0]] - xyz[e[:, 1]]).pow(2).sum(-1) + 1e-6).sqrt()
+    graph = (gen - dat).pow(2).mean()
+    return recon + kl * beta + graph * gamma, kl, recon, graph
+
+
+def g2_model(cgvae, data):
+    cases = (
+        dict(tag="ncg3", n_cgs=3, F=24, R=8, atom_cutoff=8.5, cg_cutoff=9.5, enc=2, dec=3, box=6.0, beta=0.05, gamma=25.0),
+        dict(tag="ncg6", n_cgs=6, F=24, R=10, atom_cutoff=4.5, cg_cutoff=25.0, enc=2, dec=2, box=7.0, beta=0.05, gamma=50.0),
+    )
+    for c in cases:
+        per_frame, batch = synthetic_frames(data, 2, 22, c["n_cgs"], c["box"], c["atom_cutoff"], c["cg_cutoff"], seed=0)
+        model = build_reference_model(cgvae, c["F"], c["R"], c["atom_cutoff"], c["cg_cutoff"], c["enc"], c["dec"],
+                                      c["n_cgs"], det=False)
+        # non-trivial biases so that every bias path is exercised
+        torch.manual_seed(5)
+        for name, p in model.named_parameters():
+            if p.dim() == 1:
+                p.data.normal_(0, 0.1)
+        # capture eps: the reference draws it with randn_like inside reparametrize (cgvae.py:445-449)
+        n_beads = batch["CG_nxyz"].shape[0]
+        eps = torch.randn(n_beads, c["F"], generator=torch.Generator().manual_seed(99))
+        model.reparametrize = lambda mu, sigma, _e=eps: _e.mul(sigma).add_(mu)
+        out = model(batch)
+        loss, kl, recon, graph = ref_loss(out, batch, c["beta"], c["gamma"])
+        loss.backward()
+        sd = {"p." + k: v for k, v in model.state_dict().items()}
+        grads = {"g." + k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+        live = sorted(k for k, p in model.named_parameters() if p.grad is not None)
+        # deterministic variant too
+        model.det = True
+        out_det = model(batch)
+        arrays = dict(
+            F=c["F"], R=c["R"], atom_cutoff=c["atom_cutoff"], cg_cutoff=c["cg_cutoff"], enc_nconv=c["enc"],
+            dec_nconv=c["dec"], n_cgs=c["n_cgs"], beta=c["beta"], gamma=c["gamma"], eps=eps,
+            mu=out[0], sigma=out[1], prior_mu=out[2], prior_std=out[3], xyz=out[4], xyz_recon=out[5],
+            det_xyz_recon=out_det[5], det_mu=out_det[0],
+            loss=loss, kl=kl, recon=recon, graph=graph, live_params=np.array(live),
+        )
+        arrays.update({"b." + k: v for k, v in batch.items()})
+        for i, f in enumerate(per_frame):
+            arrays.update({f"f{i}." + k: v for k, v in f.items()})
+        arrays.update(sd)
+        arrays.update(grads)
+        save(f"g2_model_{c['tag']}", **arrays)
+
+
+# ------------------------------------------------------------------ G3-G5 and init pin
+def ulp_step(x, k):
+    a = np.float32(x)
+    for _ in range(abs(k)):
+        a = np.nextafter(a, np.float32(np.inf if k > 0 else -np.inf))
+    return float(a)
+
+
+def g3_radius(data):
+    arrays = {}
+    gen = torch.Generator().manual_seed(3)
+    cases = {}
+    cases["n1"] = (torch.rand(1, 3, generator=gen), 5.0)
+    cases["n2_in"] = (torch.tensor([[0.0, 0.0, 0.0], [3.0, 4.0, 0.0]]), 5.0)        # exactly at cutoff
+    cases["n2_out"] = (torch.tensor([[0.0, 0.0, 0.0], [3.0, 4.0, ulp_step(0.0, 1)]]), 5.0)
+    pts = [[0.0, 0.0, 0.0]]
+    for k in (-2, -1, 0, 1, 2):                                                       # cutoff +- k ulp on one axis
+        pts.append([ulp_step(8.5, k), 0.0, 0.0])
+    pts += [[1.0, 1.0, 1.0], [1.0, 1.0, 1.0]]                                         # coincident points
+    cases["ulp"] = (torch.tensor(pts), 8.5)
+    cases["n22"] = (torch.rand(22, 3, generator=gen) * 9.0, 4.0)
+    cases["n64"] = (torch.rand(64, 3, generator=gen) * 14.0, 6.5)
+    cases["n166"] = (torch.rand(166, 3, generator=gen) * 14.0, 12.0)
+    # near-cutoff stress: many pairs within a few ulp of the cutoff along random directions
+    base = torch.rand(40, 3, generator=gen) * 2.0
+    dirs = torch.nn.functional.normalize(torch.randn(40, 3, generator=gen), dim=1)
+    far = base + dirs * 4.0
+    cases["shell"] = (torch.cat([base, far]), 4.0)
+    for name, (xyz, cut) in cases.items():
+        for und in (True, False):
+            nl = data.get_neighbor_list(xyz.numpy(), "cpu", cut, undirected=und)
+            arrays[f"{name}.xyz"] = xyz
+            arrays[f"{name}.cutoff"] = cut
+            arrays[f"{name}.{'und' if und else 'dir'}"] = nl
+    save("g3_radius_graph", **arrays)
+
+
+def g4_make_directed(conv):
+    und = torch.tensor([[0, 1], [0, 3], [1, 2], [2, 3]])
+    already = torch.tensor([[0, 1], [1, 0], [2, 1], [1, 2]])
+    rev_only = torch.tensor([[1, 0], [3, 0], [2, 1]])
+    empty = torch.zeros(0, 2, dtype=torch.long)
+    arrays = {}
+    for name, t in (("und", und), ("already", already), ("rev_only", rev_only), ("empty", empty)):
+        out, flag = conv.make_directed(t)
+        arrays[name + ".in"] = t
+        arrays[name + ".out"] = out
+        arrays[name + ".flag"] = np.array(flag)
+    save("g4_make_directed", **arrays)
+
+
+def g5_scatter():
+    import torch_scatter as ts
+    gen = torch.Generator().manual_seed(5)
+    idx = torch.tensor([0, 0, 2, 5, 5, 5, 2, 0])            # unsorted, segments 1,3,4 empty
+    src2 = torch.randn(8, 6, generator=gen)
+    src3 = torch.randn(8, 4, 3, generator=gen)
+    save("g5_scatter", index=idx, src2=src2, src3=src3,
+         add2=ts.scatter_add(src2, idx, dim=0, dim_size=7), add3=ts.scatter_add(src3, idx, dim=0),
+         mean2=ts.scatter_mean(src2, idx, dim=0), mean3=ts.scatter_mean(src3, idx, dim=0, dim_size=7))
+
+
+def g7_init(cgvae):
+    """Pin parameter names, shapes and the same-seed init stream (run_ala.py:36-41, 184-209)."""
+    arrays = {}
+    for tag, n_cgs, F, R, enc, dec in (("ncg3", 3, 12, 8, 2, 2), ("ncg6", 6, 16, 10, 1, 3)):
+        m = build_reference_model(cgvae, F, R, 8.5, 9.5, enc, dec, n_cgs, det=False, seed=123)
+        sd = m.state_dict()
+        arrays[f"{tag}.names"] = np.array(list(sd.keys()))
+        arrays[f"{tag}.shapes"] = np.array([",".join(map(str, v.shape)) for v in sd.values()])
+        arrays[f"{tag}.sum"] = np.array([float(v.double().sum()) for v in sd.values()])
+        arrays[f"{tag}.abssum"] = np.array([float(v.double().abs().sum()) for v in sd.values()])
+        arrays[f"{tag}.cfg"] = np.array([n_cgs, F, R, enc, dec])
+    save("g7_init", **arrays)
+
+
+def main():
+    modules, conv, cgvae, data = load_reference()
+    torch.set_num_threads(1)          # bit-stable sums
+    g1_blocks(modules, conv)
+    g2_model(cgvae, data)
+    g3_radius(data)
+    g4_make_directed(conv)
+    g5_scatter()
+    g7_init(cgvae)
+
+
+if __name__ == "__main__":
+    main()
