@@ -1,0 +1,103 @@
+"""ctypes binding of libcgvae_hip.so (C ABI: include/cgvae_hip.h).
+
+There is deliberately no fallback: if the shared library is missing or a call fails, the
+product path raises.  Only raw device pointers, sizes and the current HIP stream cross the
+boundary; torch is used for allocation and stream bookkeeping only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+import threading
+
+import torch
+
+from . import ktimer
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libcgvae_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "cgvae_hip.h")
+
+_lock = threading.Lock()
+_lib = None
+
+_p, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol the header declares (tests check it)
+PROTOTYPES = {
+    "cgv_version": (_i, []),
+    "cgv_last_error_string": (C.c_char_p, []),
+    "cgv_rbf_supported": (_i, [_i]),
+    "cgv_geom_stride": (_i, [_i]),
+    "cgv_radius_graph_count": (_i, [_p, _p, _i, _i, _f, _i, _p, _p, _p]),
+    "cgv_radius_graph_emit": (_i, [_p, _p, _i, _i, _f, _i, _p, _p, _p]),
+    "cgv_csr_workspace_bytes": (_sz, [_i]),
+    "cgv_csr_build": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "cgv_edge_geometry": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _f, _p, _p, _p]),
+    "cgv_segment_reduce": (_i, [_p, _p, _p, _i, _i, _i, _p, _p]),
+    "cgv_segment_broadcast": (_i, [_p, _p, _p, _i, _i, _i, _p, _p]),
+    "cgv_equi_msg_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "cgv_equi_msg_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
+    "cgv_equi_msg_bwd": (_i, [_p] * 13 + [_i, _i, _i, _p, _sz, _p]),
+    "cgv_optim_state_floats": (_i, []),
+    "cgv_optim_partial_floats": (_i, []),
+    "cgv_adam_clip_step": (_i, [_p, _p, _p, _p, C.c_int64, _f, _f, _f, _f, _f, _f, _p, _f, _p, _p, _p]),
+}
+
+
+def header_symbols():
+    """Names of all functions declared in include/cgvae_hip.h."""
+    text = open(HEADER_PATH).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cgv_[a-z0-9_]+)\s*\(", text)))
+
+
+def load():
+    """Load the library once; raise loudly when it is absent (no CPU / eager fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m coarsegrainingvae_amd.build` "
+                "(hipcc --offload-arch=gfx950).  There is no fallback path.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        if lib.cgv_version() < 100:
+            raise RuntimeError("libcgvae_hip.so is older than this package")
+        _lib = lib
+    return _lib
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    """Device pointer of a contiguous tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("coarsegrainingvae_amd kernels need device (hip) tensors; there is no CPU path")
+    if not t.is_contiguous():
+        raise RuntimeError("tensor handed to the C ABI must be contiguous")
+    return t.data_ptr()
+
+
+def call(name: str, *args, tag=None):
+    """Invoke a status-returning entry point; raise RuntimeError on any non-zero code.
+    ``tag`` names the launch for the optional HIP-event timer (ktimer.py)."""
+    lib = load()
+    tok = ktimer.begin(tag) if tag is not None else None
+    rc = getattr(lib, name)(*args)
+    ktimer.end(tok)
+    if rc != 0:
+        msg = lib.cgv_last_error_string().decode("utf-8", "replace")
+        raise RuntimeError(f"{name} failed with code {rc}: {msg}")

@@ -1,0 +1,156 @@
+"""Message / update blocks with the reference's class names, constructor arguments, forward
+signatures and parameter names (CoarseGrainingVAE/conv.py), running on the fused HIP kernels.
+
+Per block the reference launches ~40 ATen kernels over materialised ``[E,3F]`` / ``[E,F,3]``
+tensors; here a block is: two node-level GEMMs (hipBLASLt through ``F.linear``) + ONE fused
+edge kernel (gather -> filter -> product -> segmented reduction).  The ``plan`` / ``geom``
+keyword arguments let the model build the CSR views and edge geometry once per batch and
+share them across layers; without them the blocks build them on the fly, so the reference
+call ``block(s_j, v_j, r_ij, nbrs)`` works unchanged.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import ops
+from .graph import EdgeGeometry, EdgePlan, make_directed  # noqa: F401  (make_directed re-exported)
+from .primitives import Dense, DistanceEmbed, to_module
+
+
+def preprocess_r(r_ij):
+    """dist / unit of edge vectors with the conv.py copy's epsilon (1e-8 per component,
+    conv.py:25-29).  Host-visible helper; the kernels compute this inside K6."""
+    dist = ((r_ij ** 2 + 1e-8).sum(-1)) ** 0.5
+    return dist, r_ij / dist.reshape(-1, 1)
+
+
+class InvariantMessage(nn.Module):
+    """Node MLP + distance filter parameters (conv.py:31-75).  ``forward`` keeps the reference's
+    unfused semantics (returns the ``[E, out]`` message tensor) for API completeness; the blocks
+    below never call it -- they hand ``node_features`` and the filter to the fused kernel."""
+
+    def __init__(self, in_feat_dim, out_feat_dim, activation, n_rbf, cutoff, dropout):
+        super().__init__()
+        self.inv_dense = nn.Sequential(
+            Dense(in_features=in_feat_dim, out_features=in_feat_dim, bias=True, dropout_rate=dropout,
+                  activation=to_module(activation)),
+            Dense(in_features=in_feat_dim, out_features=out_feat_dim, bias=True, dropout_rate=dropout))
+        self.dist_embed = DistanceEmbed(n_rbf=n_rbf, cutoff=cutoff, feat_dim=out_feat_dim, dropout=dropout)
+        # unused by forward in the reference too (conv.py:56-61), kept for state_dict fidelity
+        self.dist_filter = Dense(in_features=in_feat_dim, out_features=out_feat_dim, bias=True, dropout_rate=0.0)
+        self.offset = torch.linspace(0.0, cutoff, in_feat_dim)
+        self.n_rbf, self.cutoff = n_rbf, cutoff
+
+    def node_features(self, s_j):
+        return self.inv_dense(s_j)
+
+    def forward(self, s_j, dist, nbrs):
+        return self.inv_dense(s_j)[nbrs[:, 1]] * self.dist_embed(dist)
+
+
+def _resolve(plan, geom, nbrs, n_nodes, r_ij, n_rbf, cutoff):
+    if plan is None:
+        plan = EdgePlan.from_nbrs(nbrs, n_nodes)
+    if geom is None:
+        geom = EdgeGeometry(plan, n_rbf, cutoff, r_edges=r_ij)
+    return plan, geom
+
+
+class EquiMessageBlock(nn.Module):
+    """conv.py:487-563.  forward(s_j [N,F], v_j [N,F,3], r_ij [E,3], nbrs [E,2]) -> (ds, dv)."""
+
+    def __init__(self, feat_dim, activation, n_rbf, cutoff, dropout):
+        super().__init__()
+        self.inv_message = InvariantMessage(in_feat_dim=feat_dim, out_feat_dim=feat_dim * 3, activation=activation,
+                                            n_rbf=n_rbf, cutoff=cutoff, dropout=dropout)
+        # attention heads exist in the reference's state_dict but never run (conv.py:502-503, 535-551)
+        self.h_att = nn.Sequential(nn.Linear(feat_dim, feat_dim), nn.ReLU(), nn.Linear(feat_dim, feat_dim))
+        self.v_att = nn.Sequential(nn.Linear(feat_dim, feat_dim), nn.ReLU(), nn.Linear(feat_dim, feat_dim))
+        self.with_dv = True     # set False to skip the (dead) vector channel explicitly
+
+    def forward(self, s_j, v_j, r_ij, nbrs, edge_wgt=None, plan: Optional[EdgePlan] = None,
+                geom: Optional[EdgeGeometry] = None):
+        if edge_wgt is not None:
+            raise NotImplementedError("edge_wgt is never passed on the run_ala path (conv.py:527-533)")
+        im = self.inv_message
+        plan, geom = _resolve(plan, geom, nbrs, s_j.shape[0], r_ij, im.n_rbf, im.cutoff)
+        Wd, bd = im.dist_embed.filter_params()
+        return ops.equi_message(im.node_features(s_j), v_j, Wd, bd, plan, geom, self.with_dv)
+
+
+class ContractiveMessageBlock(nn.Module):
+    """conv.py:677-733.  forward(s_i [N,F], v_i [N,F,3], r_iI [N,3], mapping [N]) -> (dS, dV) on beads."""
+
+    def __init__(self, feat_dim, activation, n_rbf, cutoff, dropout):
+        super().__init__()
+        self.inv_dense = nn.Sequential(
+            Dense(in_features=feat_dim, out_features=feat_dim, bias=True, dropout_rate=dropout,
+                  activation=to_module(activation)),
+            Dense(in_features=feat_dim, out_features=3 * feat_dim, bias=True, dropout_rate=dropout))
+        self.dist_embed = DistanceEmbed(n_rbf=n_rbf, cutoff=cutoff, feat_dim=3 * feat_dim, dropout=dropout)
+        self.n_rbf, self.cutoff = n_rbf, cutoff
+        self.with_dv = True
+
+    def forward(self, s_i, v_i, r_iI, mapping, plan: Optional[EdgePlan] = None,
+                geom: Optional[EdgeGeometry] = None):
+        if plan is None:
+            n_beads = int(mapping.max().item()) + 1      # dim_size inferred like torch_scatter does
+            plan = EdgePlan.from_mapping(mapping, n_beads)
+        if geom is None:
+            geom = EdgeGeometry(plan, self.n_rbf, self.cutoff, r_edges=r_iI)
+        Wd, bd = self.dist_embed.filter_params()
+        return ops.equi_message(self.inv_dense(s_i), v_i, Wd, bd, plan, geom, self.with_dv)
+
+
+class EquiMessagePsuedo(nn.Module):
+    """conv.py:165-242.  forward(s_j, sbar_j, v_j, vbar_j, r_ij, nbrs) -> (dh, dhbar, dv, dvbar)."""
+
+    def __init__(self, feat_dim, activation, n_rbf, cutoff, dropout):
+        super().__init__()
+        self.inv_message = InvariantMessage(in_feat_dim=feat_dim, out_feat_dim=feat_dim * 9, activation=activation,
+                                            n_rbf=n_rbf, cutoff=cutoff, dropout=dropout)
+
+    def forward(self, s_j, sbar_j, v_j, vbar_j, r_ij, nbrs, edge_wgt=None, plan: Optional[EdgePlan] = None,
+                geom: Optional[EdgeGeometry] = None):
+        if edge_wgt is not None:
+            raise NotImplementedError("edge_wgt is never passed on the run_ala path")
+        im = self.inv_message
+        plan, geom = _resolve(plan, geom, nbrs, s_j.shape[0], r_ij, im.n_rbf, im.cutoff)
+        Wd, bd = im.dist_embed.filter_params()
+        return ops.pseudo_message(im.node_features(s_j), s_j, sbar_j, v_j, vbar_j, Wd, bd, plan, geom)
+
+
+class UpdateBlock(nn.Module):
+    """conv.py:566-616.  forward(s_i [N,F], v_i [N,F,3]) -> (ds, dv)."""
+
+    def __init__(self, feat_dim, activation, dropout):
+        super().__init__()
+        self.u_mat = Dense(in_features=feat_dim, out_features=feat_dim, bias=False)
+        self.v_mat = Dense(in_features=feat_dim, out_features=feat_dim, bias=False)
+        self.s_dense = nn.Sequential(
+            Dense(in_features=2 * feat_dim, out_features=feat_dim, bias=True, dropout_rate=dropout,
+                  activation=to_module(activation)),
+            Dense(in_features=feat_dim, out_features=3 * feat_dim, bias=True, dropout_rate=dropout))
+
+    def forward(self, s_i, v_i):
+        return ops.update_block(s_i, v_i, self.u_mat.weight, self.v_mat.weight, self.s_dense)
+
+
+class PseudoUpdateBlock(nn.Module):
+    """conv.py:619-673.  Constructed by the decoder (cgvae.py:74-79) but its call is commented
+    out in the reference (cgvae.py:116-120): parameters only, for state_dict fidelity."""
+
+    def __init__(self, feat_dim, activation, dropout):
+        super().__init__()
+        self.u_mat = Dense(in_features=feat_dim, out_features=feat_dim, bias=False)
+        self.v_mat = Dense(in_features=feat_dim, out_features=feat_dim, bias=False)
+        self.s_dense = nn.Sequential(
+            Dense(in_features=2 * feat_dim, out_features=feat_dim, bias=True, dropout_rate=dropout,
+                  activation=to_module(activation)),
+            Dense(in_features=feat_dim, out_features=3 * feat_dim, bias=True, dropout_rate=dropout))
+
+    def forward(self, s_i, v_i):
+        raise NotImplementedError("PseudoUpdateBlock is never executed on the run_ala path (cgvae.py:116-120)")

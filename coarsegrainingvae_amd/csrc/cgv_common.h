@@ -1,0 +1,61 @@
+// Shared helpers for libcgvae_hip.so (gfx950 only: wave64, no portability layers).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "cgvae_hip.h"
+
+namespace cgv {
+
+void set_error(const char* fmt, ...);   // thread-local message (api.cpp)
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+
+#define CGV_REQUIRE(cond, msg)                         \
+  do {                                                 \
+    if (!(cond)) {                                     \
+      cgv::set_error("%s: %s", __func__, msg);         \
+      return CGV_E_BADARG;                             \
+    }                                                  \
+  } while (0)
+
+constexpr int WAVE = 64;
+
+__host__ __device__ inline int geom_stride(int R) { return (R + 4 + 3) & ~3; }
+
+// 12-byte vector with 4-byte alignment: one global_load_dwordx3 / global_store_dwordx3.
+struct __attribute__((packed, aligned(4))) f3 {
+  float x, y, z;
+};
+
+__device__ inline f3 ld3(const float* p) { return *reinterpret_cast<const f3*>(p); }
+__device__ inline void st3(float* p, float x, float y, float z) {
+  f3 t{x, y, z};
+  *reinterpret_cast<f3*>(p) = t;
+}
+
+// Dispatch a runtime n_rbf onto the compiled template instances.
+#define CGV_RBF_LIST(X) X(4) X(6) X(8) X(10) X(12) X(16) X(20)
+
+#define CGV_DISPATCH_RBF(R_runtime, CALL)                                   \
+  switch (R_runtime) {                                                      \
+    case 4: { constexpr int RBF = 4; CALL; } break;                         \
+    case 6: { constexpr int RBF = 6; CALL; } break;                         \
+    case 8: { constexpr int RBF = 8; CALL; } break;                         \
+    case 10: { constexpr int RBF = 10; CALL; } break;                       \
+    case 12: { constexpr int RBF = 12; CALL; } break;                       \
+    case 16: { constexpr int RBF = 16; CALL; } break;                       \
+    case 20: { constexpr int RBF = 20; CALL; } break;                       \
+    default:                                                                \
+      cgv::set_error("%s: n_rbf=%d has no compiled kernel", __func__, R_runtime); \
+      return CGV_E_UNSUPPORTED;                                             \
+  }
+
+}  // namespace cgv

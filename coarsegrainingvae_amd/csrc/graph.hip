@@ -1,0 +1,193 @@
+// K0 radius graph and K7 CSR plan (see include/cgvae_hip.h).
+//
+// K0 restates get_neighbor_list (reference CoarseGrainingVAE/data.py:65-82) for a batch of
+// frames: same membership rule bit for bit, same output order, no O(n^2) host loop.
+// K7 turns the reference's unsorted scatter index (conv.py:10-20 make_directed output) into
+// destination- and source-sorted CSR views so the fused kernels reduce without atomics.
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include "cgv_common.h"
+
+namespace cgv {
+
+// ------------------------------------------------------------------ K0 radius graph
+// One wave per row i.  Lanes test 64 candidate j at a time; __ballot + popcount give each
+// hit its rank, so a row's edges come out in ascending j exactly like torch.nonzero.
+__device__ inline bool pair_hit(const float* __restrict__ xyz, int i, int j, float s_star) {
+  // (dx*dx + dy*dy) + dz*dz with every operation individually rounded (no fma contraction):
+  // bitwise what `.pow(2).sum(dim=2)` produces on the host.
+  float dx = __fsub_rn(xyz[3 * j + 0], xyz[3 * i + 0]);
+  float dy = __fsub_rn(xyz[3 * j + 1], xyz[3 * i + 1]);
+  float dz = __fsub_rn(xyz[3 * j + 2], xyz[3 * i + 2]);
+  float s = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+  return s <= s_star;
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(256) void radius_rows(const float* __restrict__ xyz,
+                                                   const int* __restrict__ frame_of_node_ptr,  // frame_ptr
+                                                   int n_frames, int n_nodes, float s_star, int undirected,
+                                                   int* __restrict__ counts, const int* __restrict__ offsets,
+                                                   int64_t* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= n_nodes) return;
+  // locate the frame of this row (binary search in frame_ptr; uniform per wave)
+  int lo = 0, hi = n_frames;
+  while (hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if (frame_of_node_ptr[mid] <= row) lo = mid; else hi = mid;
+  }
+  const int f_beg = frame_of_node_ptr[lo], f_end = frame_of_node_ptr[lo + 1];
+  const int j_beg = undirected ? row + 1 : f_beg;
+  int total = 0;
+  int64_t* dst = EMIT ? out + 2 * (int64_t)offsets[row] : nullptr;
+  for (int j0 = j_beg; j0 < f_end; j0 += 64) {
+    const int j = j0 + lane;
+    bool hit = (j < f_end) && (j != row) && pair_hit(xyz, row, j, s_star);
+    unsigned long long m = __ballot(hit);
+    if (EMIT && hit) {
+      int rank = total + __popcll(m & ((1ull << lane) - 1ull));
+      dst[2 * rank + 0] = row;
+      dst[2 * rank + 1] = j;
+    }
+    total += __popcll(m);
+  }
+  if (!EMIT && lane == 0) counts[row] = total;
+}
+
+// single-block exclusive scan (n up to a few million is fine: it runs once per dataset batch)
+__global__ __launch_bounds__(1024) void exclusive_scan_i32(const int* __restrict__ in, int* __restrict__ out, int n) {
+  __shared__ int wave_tot[16];
+  __shared__ int carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    int i = base + tid;
+    int x = (i < n) ? in[i] : 0;
+    int incl = x;
+    for (int d = 1; d < 64; d <<= 1) {
+      int y = __shfl_up(incl, d);
+      if (lane >= d) incl += y;
+    }
+    if (lane == 63) wave_tot[w] = incl;
+    __syncthreads();
+    int wave_off = 0;
+    for (int k = 0; k < w; ++k) wave_off += wave_tot[k];
+    int carry = carry_s;
+    if (i < n) out[i] = carry + wave_off + incl - x;
+    __syncthreads();
+    if (tid == 1023) carry_s = carry + wave_off + incl;
+    __syncthreads();
+  }
+  if (tid == 0) out[n] = carry_s;
+}
+
+// ------------------------------------------------------------------ K7 CSR plan
+__global__ void csr_keys(const int64_t* __restrict__ key, int stride, int n, int* __restrict__ keys,
+                         int* __restrict__ vals) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  keys[e] = key ? (int)key[(int64_t)e * stride] : e;
+  vals[e] = e;
+}
+
+__global__ void csr_gather(const int64_t* __restrict__ other, int stride, const int* __restrict__ eid, int n,
+                           int* __restrict__ out) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  int e = eid[p];
+  out[p] = other ? (int)other[(int64_t)e * stride] : e;
+}
+
+// rowptr[i] = first sorted position whose key >= i  (i in [0, n_rows])
+__global__ void csr_rowptr(const int* __restrict__ sorted_keys, int n, int n_rows, int* __restrict__ rowptr) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n_rows) return;
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (sorted_keys[mid] < i) lo = mid + 1; else hi = mid;
+  }
+  rowptr[i] = lo;
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static hipError_t sort_temp_bytes(int n, size_t* bytes) {
+  int* k = nullptr;
+  *bytes = 0;
+  return rocprim::radix_sort_pairs(nullptr, *bytes, k, k, k, k, (size_t)(n > 0 ? n : 1), 0, 32, (hipStream_t)0);
+}
+
+static int sorted_view(const int64_t* key, const int64_t* other, int stride, int E, int n_rows, int* rowptr, int* eid,
+                       int* key_sorted, int* other_sorted, char* ws, size_t ws_bytes, hipStream_t st) {
+  int* keys_in = reinterpret_cast<int*>(ws);
+  int* vals_in = reinterpret_cast<int*>(ws + align256(sizeof(int) * (size_t)E));
+  char* temp = ws + 2 * align256(sizeof(int) * (size_t)E);
+  size_t temp_bytes = ws_bytes - 2 * align256(sizeof(int) * (size_t)E);
+  const int T = 256, B = (E + T - 1) / T;
+  if (E > 0) {
+    hipLaunchKernelGGL(csr_keys, dim3(B), dim3(T), 0, st, key, stride, E, keys_in, vals_in);
+    int bits = 1;
+    while ((1ll << bits) < (long long)(n_rows > 1 ? n_rows : 2)) ++bits;
+    hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, key_sorted, vals_in, eid, (size_t)E, 0, bits, st);
+    if (e != hipSuccess) {
+      set_error("cgv_csr_build: radix sort failed: %s", hipGetErrorString(e));
+      return (int)e;
+    }
+    hipLaunchKernelGGL(csr_gather, dim3(B), dim3(T), 0, st, other, stride, eid, E, other_sorted);
+  }
+  hipLaunchKernelGGL(csr_rowptr, dim3((n_rows + 1 + T - 1) / T), dim3(T), 0, st, key_sorted, E, n_rows, rowptr);
+  return check_launch("cgv_csr_build");
+}
+
+}  // namespace cgv
+
+extern "C" {
+
+int cgv_radius_graph_count(const float* xyz, const int32_t* frame_ptr, int n_frames, int n_nodes, float s_star,
+                           int undirected, int32_t* counts, int32_t* offsets, void* stream) {
+  CGV_REQUIRE(xyz && frame_ptr && counts && offsets && n_frames >= 0 && n_nodes >= 0, "bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (n_nodes > 0)
+    hipLaunchKernelGGL(cgv::radius_rows<false>, dim3((n_nodes + 3) / 4), dim3(256), 0, st, xyz, frame_ptr, n_frames,
+                       n_nodes, s_star, undirected, counts, (const int*)nullptr, (int64_t*)nullptr);
+  hipLaunchKernelGGL(cgv::exclusive_scan_i32, dim3(1), dim3(1024), 0, st, counts, offsets, n_nodes);
+  return cgv::check_launch("cgv_radius_graph_count");
+}
+
+int cgv_radius_graph_emit(const float* xyz, const int32_t* frame_ptr, int n_frames, int n_nodes, float s_star,
+                          int undirected, const int32_t* offsets, int64_t* nbr_out, void* stream) {
+  CGV_REQUIRE(xyz && frame_ptr && offsets && nbr_out && n_frames >= 0 && n_nodes >= 0, "bad argument");
+  if (n_nodes == 0) return 0;
+  hipLaunchKernelGGL(cgv::radius_rows<true>, dim3((n_nodes + 3) / 4), dim3(256), 0, (hipStream_t)stream, xyz, frame_ptr,
+                     n_frames, n_nodes, s_star, undirected, (int*)nullptr, offsets, nbr_out);
+  return cgv::check_launch("cgv_radius_graph_emit");
+}
+
+size_t cgv_csr_workspace_bytes(int n_edges) {
+  size_t temp = 0;
+  if (cgv::sort_temp_bytes(n_edges, &temp) != hipSuccess) temp = (size_t)n_edges * 16 + (1 << 20);
+  return 2 * cgv::align256(sizeof(int) * (size_t)(n_edges > 0 ? n_edges : 1)) + cgv::align256(temp) + 256;
+}
+
+int cgv_csr_build(const int64_t* dst, const int64_t* src, int stride, int n_edges, int n_dst, int n_src,
+                  int32_t* rowptr_d, int32_t* eid_d, int32_t* dst_d, int32_t* src_d, int32_t* rowptr_s, int32_t* eid_s,
+                  int32_t* dst_s, int32_t* src_s, void* workspace, size_t workspace_bytes, void* stream) {
+  CGV_REQUIRE(n_edges >= 0 && n_dst >= 0 && n_src >= 0 && stride >= 1, "bad size");
+  CGV_REQUIRE(rowptr_d && rowptr_s && workspace, "null output");
+  CGV_REQUIRE(n_edges == 0 || (dst && eid_d && dst_d && src_d && eid_s && dst_s && src_s), "null edge array");
+  if (workspace_bytes < cgv_csr_workspace_bytes(n_edges)) {
+    cgv::set_error("cgv_csr_build: workspace too small");
+    return CGV_E_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  char* ws = reinterpret_cast<char*>(workspace);
+  int rc = cgv::sorted_view(dst, src, stride, n_edges, n_dst, rowptr_d, eid_d, dst_d, src_d, ws, workspace_bytes, st);
+  if (rc) return rc;
+  return cgv::sorted_view(src, dst, stride, n_edges, n_src, rowptr_s, eid_s, src_s, dst_s, ws, workspace_bytes, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,132 @@
+// Fused optimiser step over a flat parameter arena: global-norm clip + Adam in three launches,
+// with the clip coefficient, the bias corrections, the step counter and the skip decision kept
+// on the device (no host round trip, graph-capturable).
+//
+// Replaces, for the parameters that receive gradients (reference scripts/utils.py:145-157):
+//     if loss >= 200*gamma or isnan(loss): skip
+//     clip_grad_norm_(params, 0.01)  ->  g *= min(1, max_norm / (||g||_2 + 1e-6))
+//     Adam.step()                    ->  torch.optim.Adam defaults (no amsgrad / weight decay)
+// Traffic per step: g twice (norm + update), p/m/v read + written once: 9 floats per parameter
+// instead of ~17 for separate clip (read, read+write) and multi-pass foreach Adam.
+#include "cgv_common.h"
+
+namespace cgv {
+
+// state[] layout (device floats)
+enum { ST_STEP = 0, ST_NORM = 1, ST_CLIP = 2, ST_BC1 = 3, ST_BC2SQRT = 4, ST_SKIP = 5, ST_NSKIPPED = 6 };
+
+__device__ inline float wave_sum(float x) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) x += __shfl_xor(x, d);
+  return x;
+}
+
+__global__ __launch_bounds__(256) void sumsq_partial(const float* __restrict__ g, int64_t n, float* __restrict__ partial) {
+  __shared__ float ws[4];
+  float acc = 0.f;
+  const int64_t n4 = n >> 2;
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 x = g4[i];
+    acc = fmaf(x.x, x.x, fmaf(x.y, x.y, fmaf(x.z, x.z, fmaf(x.w, x.w, acc))));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    float x = g[(n4 << 2) + threadIdx.x];
+    acc = fmaf(x, x, acc);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+
+__global__ __launch_bounds__(256) void optim_finalize(const float* __restrict__ partial, int nb, float grad_scale,
+                                                      float max_norm, float beta1, float beta2,
+                                                      const float* __restrict__ loss, float skip_threshold,
+                                                      float* __restrict__ state) {
+  __shared__ double ws[4];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nb; i += blockDim.x) acc += (double)partial[i];
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  const double total = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+  const float norm = (float)sqrt(total) * fabsf(grad_scale);
+  bool skip = false;
+  if (loss) {
+    const float l = *loss;
+    skip = (l >= skip_threshold) || (l != l);                 // utils.py:145
+  }
+  state[ST_NORM] = norm;
+  state[ST_SKIP] = skip ? 1.f : 0.f;
+  if (skip) {
+    state[ST_NSKIPPED] += 1.f;
+    return;
+  }
+  float coef = max_norm / (norm + 1e-6f);                      // torch.nn.utils.clip_grad_norm_
+  if (coef > 1.f) coef = 1.f;
+  state[ST_CLIP] = coef * grad_scale;
+  const double step = (double)state[ST_STEP] + 1.0;
+  state[ST_STEP] = (float)step;
+  state[ST_BC1] = (float)(1.0 - pow((double)beta1, step));
+  state[ST_BC2SQRT] = (float)sqrt(1.0 - pow((double)beta2, step));
+}
+
+__global__ __launch_bounds__(256) void adam_update(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
+                                                   float beta1, float beta2, float eps,
+                                                   const float* __restrict__ state) {
+  if (state[ST_SKIP] != 0.f) return;
+  const float clip = state[ST_CLIP];
+  const float step_size = lr / state[ST_BC1];
+  const float inv_bc2 = 1.0f / state[ST_BC2SQRT];
+  const int64_t n4 = n >> 2;
+  float4* p4 = reinterpret_cast<float4*>(p);
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  float4* m4 = reinterpret_cast<float4*>(m);
+  float4* v4 = reinterpret_cast<float4*>(v);
+  auto upd = [&](float& pp, float gg, float& mm, float& vv) {
+    gg *= clip;
+    mm = fmaf(1.f - beta1, gg - mm, mm);                       // exp_avg.lerp_(grad, 1 - beta1)
+    vv = fmaf(1.f - beta2, gg * gg, beta2 * vv);               // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
+    const float denom = sqrtf(vv) * inv_bc2 + eps;
+    pp -= step_size * (mm / denom);
+  };
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
+    upd(pp.x, gg.x, mm.x, vv.x);
+    upd(pp.y, gg.y, mm.y, vv.y);
+    upd(pp.z, gg.z, mm.z, vv.z);
+    upd(pp.w, gg.w, mm.w, vv.w);
+    p4[i] = pp; m4[i] = mm; v4[i] = vv;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t i = (n4 << 2) + threadIdx.x;
+    upd(p[i], g[i], m[i], v[i]);
+  }
+}
+
+}  // namespace cgv
+
+extern "C" {
+
+int cgv_optim_state_floats(void) { return 8; }
+int cgv_optim_partial_floats(void) { return 2048; }
+
+int cgv_adam_clip_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                       float eps, float max_norm, float grad_scale, const float* loss, float skip_threshold,
+                       float* state, float* partial, void* stream) {
+  CGV_REQUIRE(p && g && m && v && state && partial && n >= 0, "bad argument");
+  CGV_REQUIRE(((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v)) & 15) == 0, "arena must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = 2048;
+  hipLaunchKernelGGL(cgv::sumsq_partial, dim3(nb), dim3(256), 0, st, g, n, partial);
+  hipLaunchKernelGGL(cgv::optim_finalize, dim3(1), dim3(256), 0, st, partial, nb, grad_scale, max_norm, beta1, beta2,
+                     loss, skip_threshold, state);
+  hipLaunchKernelGGL(cgv::adam_update, dim3(nb), dim3(256), 0, st, p, g, m, v, n, lr, beta1, beta2, eps, state);
+  return cgv::check_launch("cgv_adam_clip_step");
+}
+
+}  // extern "C"

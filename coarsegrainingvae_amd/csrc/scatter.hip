@@ -1,0 +1,128 @@
+// K1: segment reduction = torch_scatter.scatter_add / scatter_mean over a CSR view of the
+// index (reference call sites: cgvae.py:297-298, 479; conv.py:553-561 when used unfused).
+//
+// HBM-streaming kernel: every src row is read exactly once as float4 (16 B/lane, 1 KiB per
+// wave instruction), 8 rows in flight per thread; one workgroup owns (segment, 1024-channel
+// tile) so the output is written once, no atomics, fixed summation order.
+// Algorithmic bytes per launch: 4*E*C (src) + 4*E (perm/index) + 4*Nseg*C (out).
+#include "cgv_common.h"
+
+namespace cgv {
+
+template <int VEC>
+struct vec_t;
+template <> struct vec_t<4> { using type = float4; };
+template <> struct vec_t<2> { using type = float2; };
+template <> struct vec_t<1> { using type = float; };
+
+template <int VEC> __device__ inline void vzero(typename vec_t<VEC>::type& a);
+template <> __device__ inline void vzero<4>(float4& a) { a = make_float4(0.f, 0.f, 0.f, 0.f); }
+template <> __device__ inline void vzero<2>(float2& a) { a = make_float2(0.f, 0.f); }
+template <> __device__ inline void vzero<1>(float& a) { a = 0.f; }
+__device__ inline void vadd(float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+__device__ inline void vadd(float2& a, const float2& b) { a.x += b.x; a.y += b.y; }
+__device__ inline void vadd(float& a, const float& b) { a += b; }
+__device__ inline void vscale(float4& a, float s) { a.x *= s; a.y *= s; a.z *= s; a.w *= s; }
+__device__ inline void vscale(float2& a, float s) { a.x *= s; a.y *= s; }
+__device__ inline void vscale(float& a, float s) { a *= s; }
+
+// grid = (n_seg, ceil(C / (BLOCK*VEC))); rows summed in CSR order.
+template <int VEC, int BLOCK, int UNROLL>
+__global__ __launch_bounds__(BLOCK) void segment_reduce_k(const float* __restrict__ src, const int* __restrict__ rowptr,
+                                                          const int* __restrict__ perm, int C, int mean,
+                                                          float* __restrict__ out) {
+  using V = typename vec_t<VEC>::type;
+  const int seg = blockIdx.x;
+  const int c = (blockIdx.y * BLOCK + threadIdx.x) * VEC;
+  if (c >= C) return;
+  const int beg = rowptr[seg], end = rowptr[seg + 1];
+  V acc;
+  vzero<VEC>(acc);
+  int p = beg;
+  for (; p + UNROLL <= end; p += UNROLL) {
+    V x[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int row = perm ? perm[p + u] : p + u;
+      x[u] = *reinterpret_cast<const V*>(src + (size_t)row * C + c);
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) vadd(acc, x[u]);
+  }
+  for (; p < end; ++p) {
+    const int row = perm ? perm[p] : p;
+    vadd(acc, *reinterpret_cast<const V*>(src + (size_t)row * C + c));
+  }
+  if (mean) {
+    const int len = end - beg;
+    vscale(acc, 1.0f / (float)(len > 1 ? len : 1));
+  }
+  *reinterpret_cast<V*>(out + (size_t)seg * C + c) = acc;
+}
+
+template <int VEC, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void segment_broadcast_k(const float* __restrict__ gout,
+                                                             const int* __restrict__ rowptr,
+                                                             const int* __restrict__ perm, int C, int mean,
+                                                             float* __restrict__ gsrc) {
+  using V = typename vec_t<VEC>::type;
+  const int seg = blockIdx.x;
+  const int c = (blockIdx.y * BLOCK + threadIdx.x) * VEC;
+  if (c >= C) return;
+  const int beg = rowptr[seg], end = rowptr[seg + 1];
+  V g = *reinterpret_cast<const V*>(gout + (size_t)seg * C + c);
+  if (mean) {
+    const int len = end - beg;
+    vscale(g, 1.0f / (float)(len > 1 ? len : 1));
+  }
+  for (int p = beg; p < end; ++p) {
+    const int row = perm ? perm[p] : p;
+    *reinterpret_cast<V*>(gsrc + (size_t)row * C + c) = g;
+  }
+}
+
+}  // namespace cgv
+
+extern "C" {
+
+int cgv_segment_reduce(const float* src, const int32_t* rowptr, const int32_t* perm, int n_seg, int channels, int mean,
+                       float* out, void* stream) {
+  CGV_REQUIRE(n_seg >= 0 && channels > 0, "bad size");
+  if (n_seg == 0) return 0;
+  CGV_REQUIRE(src && rowptr && out, "null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  constexpr int BLOCK = 256, UNROLL = 8;
+  const bool a16 = (((uintptr_t)src | (uintptr_t)out) & 15) == 0;
+  if (channels % 4 == 0 && a16) {
+    dim3 grid(n_seg, (channels / 4 + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL((cgv::segment_reduce_k<4, BLOCK, UNROLL>), grid, dim3(BLOCK), 0, st, src, rowptr, perm, channels,
+                       mean, out);
+  } else {
+    dim3 grid(n_seg, (channels + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL((cgv::segment_reduce_k<1, BLOCK, UNROLL>), grid, dim3(BLOCK), 0, st, src, rowptr, perm, channels,
+                       mean, out);
+  }
+  return cgv::check_launch("cgv_segment_reduce");
+}
+
+int cgv_segment_broadcast(const float* gout, const int32_t* rowptr, const int32_t* perm, int n_seg, int channels,
+                          int mean, float* gsrc, void* stream) {
+  CGV_REQUIRE(n_seg >= 0 && channels > 0, "bad size");
+  if (n_seg == 0) return 0;
+  CGV_REQUIRE(gout && rowptr && gsrc, "null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  constexpr int BLOCK = 256;
+  const bool a16 = (((uintptr_t)gout | (uintptr_t)gsrc) & 15) == 0;
+  if (channels % 4 == 0 && a16) {
+    dim3 grid(n_seg, (channels / 4 + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL((cgv::segment_broadcast_k<4, BLOCK>), grid, dim3(BLOCK), 0, st, gout, rowptr, perm, channels,
+                       mean, gsrc);
+  } else {
+    dim3 grid(n_seg, (channels + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL((cgv::segment_broadcast_k<1, BLOCK>), grid, dim3(BLOCK), 0, st, gout, rowptr, perm, channels,
+                       mean, gsrc);
+  }
+  return cgv::check_launch("cgv_segment_broadcast");
+}
+
+}  // extern "C"

@@ -1,0 +1,156 @@
+"""Batch layout of the reference (CoarseGrainingVAE/data.py): ``CGDataset``, ``CG_collate``,
+``batch_to`` -- plus ``prepare_batch`` (one-time graph plans per batch) and the synthetic
+frame generator the benchmarks use (no trajectories are available offline).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset as TorchDataset
+
+from .graph import BatchGraph, radius_graph
+
+_KEYS = ("nxyz", "CG_nxyz", "num_atoms", "num_CGs", "CG_mapping", "bond_edge_list")
+
+
+def batch_to(batch, device):
+    """data.py:16-20; non-tensor entries (the cached graph bundle) pass through."""
+    return {k: (v.to(device) if hasattr(v, "to") else v) for k, v in batch.items()}
+
+
+def CG_collate(dicts: List[Dict[str, torch.Tensor]]) -> Dict[str, torch.Tensor]:
+    """Concatenate frames into one disjoint-union graph (data.py:255-289): atom-indexed lists
+    are offset by the cumulative atom count, bead-indexed ones by the cumulative bead count.
+    Unlike the reference this does not mutate its inputs."""
+    atoms0 = np.cumsum([0] + [int(d["num_atoms"]) for d in dicts])[:-1]
+    beads0 = np.cumsum([0] + [int(d["num_CGs"]) for d in dicts])[:-1]
+    atom_keys, bead_keys = ("nbr_list", "bond_edge_list"), ("CG_mapping", "CG_nbr_list")
+    batch = {}
+    for key, first in dicts[0].items():
+        vals = [d[key] for d in dicts]
+        if key in atom_keys:
+            vals = [v + int(o) for v, o in zip(vals, atoms0)]
+        elif key in bead_keys:
+            vals = [v + int(o) for v, o in zip(vals, beads0)]
+        if isinstance(first, str):
+            batch[key] = vals
+        elif hasattr(first, "shape") and len(first.shape) > 0:
+            batch[key] = torch.cat(vals, dim=0)
+        else:
+            batch[key] = torch.stack(vals, dim=0)
+    return batch
+
+
+def prepare_batch(batch: Dict[str, torch.Tensor], device=None) -> Dict[str, torch.Tensor]:
+    """Move a collated batch to the device and attach its :class:`BatchGraph` (directed lists,
+    CSR plans, bead ranks) under ``'_graph'`` so ``CGequiVAE.forward`` runs without host syncs."""
+    if device is not None:
+        batch = batch_to(batch, device)
+    batch["_graph"] = BatchGraph(batch["nxyz"][:, 1:], batch["CG_nxyz"][:, 1:], batch["CG_mapping"],
+                                 batch["nbr_list"], batch["CG_nbr_list"])
+    return batch
+
+
+class CGDataset(TorchDataset):
+    """Per-frame dict store (data.py:186-252)."""
+
+    def __init__(self, props, check_props=True):
+        self.props = props
+
+    def __len__(self):
+        return len(self.props["nxyz"])
+
+    def __getitem__(self, idx):
+        return {key: val[idx] for key, val in self.props.items()}
+
+    def generate_neighbor_list(self, atom_cutoff, cg_cutoff, device="cuda", undirected=True, use_bond=False):
+        """data.py:207-252 with the per-frame Python loop replaced by one batched K0 launch per
+        graph kind (all frames at once, then split back into per-frame frame-local lists)."""
+        if use_bond:
+            self.props["nbr_list"] = self.props["bond_edge_list"]
+        else:
+            self.props["nbr_list"] = _batched_radius(self.props["nxyz"], atom_cutoff, device, undirected)
+        if cg_cutoff is not None:
+            self.props["CG_nbr_list"] = _batched_radius(self.props["CG_nxyz"], cg_cutoff, device, undirected)
+        else:
+            self.props["CG_nbr_list"] = [
+                _bond_cg_graph(b, m, int(na), int(nc)) for b, m, na, nc in
+                zip(self.props["bond_edge_list"], self.props["CG_mapping"], self.props["num_atoms"],
+                    self.props["num_CGs"])]
+
+
+def _batched_radius(nxyz_list, cutoff, device, undirected):
+    sizes = [int(t.shape[0]) for t in nxyz_list]
+    fp = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32)
+    xyz = torch.cat([t[:, 1:4] for t in nxyz_list], dim=0).float().to(device)
+    nbrs = radius_graph(xyz, fp.to(device), cutoff, undirected).cpu()
+    # split by frame (rows are sorted by i, hence by frame) and make ids frame-local
+    frame_of = torch.bucketize(nbrs[:, 0], fp[1:].long(), right=True)
+    counts = torch.bincount(frame_of, minlength=len(sizes)).tolist()
+    out, start = [], 0
+    for k, c in enumerate(counts):
+        out.append(nbrs[start:start + c] - int(fp[k]))
+        start += c
+    return out
+
+
+def _bond_cg_graph(bond, mapping, n_atoms, n_cgs):
+    """CG adjacency from bond connectivity (data.py:227-248)."""
+    adj = torch.zeros(n_atoms, n_atoms)
+    adj[bond[:, 0], bond[:, 1]] = 1
+    adj[bond[:, 1], bond[:, 0]] = 1
+    assign = torch.zeros(n_atoms, n_cgs)
+    assign[torch.arange(n_atoms), mapping] = 1
+    cg = (assign.t() @ adj @ assign).nonzero()
+    return cg[cg[:, 0] != cg[:, 1]]
+
+
+# ----------------------------------------------------------------------------- synthetic data
+WORKLOADS = {
+    # name: n_atoms, n_cgs, box, atom_cutoff, cg_cutoff, enc_nconv, dec_nconv, n_rbf, batch, beta, gamma
+    "dipeptide": dict(n_atoms=22, n_cgs=3, box=6.0, atom_cutoff=8.5, cg_cutoff=9.5, enc_nconv=4, dec_nconv=5,
+                      n_rbf=8, batch=32, beta=0.05, gamma=25.0),
+    "chignolin": dict(n_atoms=166, n_cgs=6, box=14.0, atom_cutoff=12.0, cg_cutoff=25.0, enc_nconv=2, dec_nconv=9,
+                      n_rbf=10, batch=2, beta=0.05, gamma=50.0),
+    "protein2000": dict(n_atoms=2000, n_cgs=64, box=27.1, atom_cutoff=12.0, cg_cutoff=25.0, enc_nconv=2, dec_nconv=9,
+                        n_rbf=10, batch=1, beta=0.05, gamma=50.0),
+}
+
+
+def synthetic_frames(n_frames: int, n_atoms: int, n_cgs: int, box: float, seed: int = 0,
+                     spatial_sort: bool = False) -> Dict[str, list]:
+    """Random-coordinate frames in the per-frame dict format of the reference's ``build_dataset``
+    (datasets.py:495-501): xyz ~ U[0,box)^3, Z ~ U{1..8}, contiguous equal-size beads,
+    CG_xyz = bead mean, chain bonds (a, a+1).  No neighbour lists yet."""
+    gen = torch.Generator().manual_seed(seed)
+    mapping = (torch.arange(n_atoms) * n_cgs) // n_atoms
+    bonds = torch.stack([torch.arange(n_atoms - 1), torch.arange(1, n_atoms)], dim=1)
+    props = {k: [] for k in _KEYS}
+    for _ in range(n_frames):
+        xyz = torch.rand(n_atoms, 3, generator=gen) * box
+        z = torch.randint(1, 9, (n_atoms,), generator=gen).float()
+        if spatial_sort:   # spatially coherent beads for large graphs (Morton-like key)
+            cell = (xyz / box * 8).long().clamp_(0, 7)
+            order = torch.argsort(cell[:, 0] * 64 + cell[:, 1] * 8 + cell[:, 2], stable=True)
+            xyz, z = xyz[order], z[order]
+        cg = torch.zeros(n_cgs, 3).index_add_(0, mapping, xyz) / torch.bincount(mapping, minlength=n_cgs)[:, None]
+        props["nxyz"].append(torch.cat([z[:, None], xyz], dim=1))
+        props["CG_nxyz"].append(torch.cat([torch.arange(n_cgs).float()[:, None], cg], dim=1))
+        props["num_atoms"].append(torch.LongTensor([n_atoms]))
+        props["num_CGs"].append(torch.LongTensor([n_cgs]))
+        props["CG_mapping"].append(mapping.clone())
+        props["bond_edge_list"].append(bonds.clone())
+    return props
+
+
+def synthetic_batch(workload: str, n_frames: Optional[int] = None, seed: int = 0, device="cuda"):
+    """One collated, device-resident, graph-prepared batch of a named workload."""
+    w = WORKLOADS[workload]
+    n_frames = n_frames or w["batch"]
+    ds = CGDataset(synthetic_frames(n_frames, w["n_atoms"], w["n_cgs"], w["box"], seed,
+                                    spatial_sort=(workload == "protein2000")))
+    ds.generate_neighbor_list(w["atom_cutoff"], w["cg_cutoff"], device=device, undirected=True)
+    batch = CG_collate([ds[i] for i in range(n_frames)])
+    return prepare_batch(batch, device)

@@ -1,0 +1,226 @@
+"""Graph construction and per-batch edge plans (host side of K0 / K6 / K7).
+
+Mirrors the reference's ``get_neighbor_list`` (CoarseGrainingVAE/data.py:65-82) and
+``make_directed`` (CoarseGrainingVAE/conv.py:10-20) and adds what the fused kernels need and
+the reference never builds: destination/source-sorted CSR views of the directed edge list
+(:class:`EdgePlan`) and the per-edge geometry records (:class:`EdgeGeometry`) that the
+reference recomputes inside every block (conv.py:25-29, modules.py:148-172, 52-58).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_I32 = torch.int32
+
+
+# ----------------------------------------------------------------------------- K0
+def cutoff_threshold_sq(cutoff: float) -> float:
+    """Largest fp32 ``s`` with ``torch.sqrt(s) <= float32(cutoff)`` on THIS host.
+
+    The reference tests ``sqrt(s) <= cutoff`` with the host's (not correctly rounded) fp32 sqrt
+    (data.py:71-75).  Comparing the bit-reproducible squared sum against this threshold keeps
+    the device edge list bit-identical without depending on any device sqrt.
+    Monotonicity of the host sqrt around the threshold is asserted.
+    """
+    c = np.float32(cutoff)
+    if not np.isfinite(c) or c < 0:
+        raise ValueError("cutoff must be a finite non-negative number")
+    guess = np.float32(c) * np.float32(c)
+    bits = int(np.array(guess, dtype=np.float32).view(np.uint32))
+    lo, hi = max(bits - 64, 0), bits + 64
+
+    pattern = np.arange(lo, hi + 1, dtype=np.uint32).view(np.float32).copy()
+    # evaluated through the same vectorised torch.sqrt the reference's dense [n,n] call uses
+    window = (torch.sqrt(torch.from_numpy(pattern)) <= torch.tensor(c)).tolist()
+    if not window[0] or window[-1]:
+        raise RuntimeError("cutoff threshold search window does not bracket the cutoff")
+    k = max(i for i, w in enumerate(window) if w)
+    if not all(window[: k + 1]) or any(window[k + 1:]):
+        raise RuntimeError("host sqrt is not monotone around the cutoff")
+    return float(np.array([lo + k], dtype=np.uint32).view(np.float32)[0])
+
+
+def radius_graph(xyz: torch.Tensor, frame_ptr: torch.Tensor, cutoff: float, undirected: bool = True) -> torch.Tensor:
+    """Batched radius graph on the device: ``[E,2]`` int64, batch-global node ids, the exact
+    edge set and order of per-frame ``get_neighbor_list`` + ``CG_collate`` offsets
+    (data.py:65-82, 262-270).  ``frame_ptr`` is the ``[B+1]`` int32 prefix sum of atoms per frame.
+    One host read-back (the edge count is data dependent)."""
+    xyz = xyz.contiguous().float()
+    n = xyz.shape[0]
+    frame_ptr = frame_ptr.to(device=xyz.device, dtype=_I32).contiguous()
+    n_frames = frame_ptr.numel() - 1
+    s_star = cutoff_threshold_sq(cutoff)
+    counts = torch.empty(max(n, 1), dtype=_I32, device=xyz.device)
+    offsets = torch.empty(n + 1, dtype=_I32, device=xyz.device)
+    st = _lib.stream_ptr()
+    _lib.call("cgv_radius_graph_count", _lib.ptr(xyz), _lib.ptr(frame_ptr), n_frames, n, s_star, int(undirected),
+              _lib.ptr(counts), _lib.ptr(offsets), st)
+    n_edges = int(offsets[n].item())
+    out = torch.empty(n_edges, 2, dtype=torch.int64, device=xyz.device)
+    if n_edges:
+        _lib.call("cgv_radius_graph_emit", _lib.ptr(xyz), _lib.ptr(frame_ptr), n_frames, n, s_star, int(undirected),
+                  _lib.ptr(offsets), _lib.ptr(out), st)
+    return out
+
+
+def get_neighbor_list(xyz, device="cuda", cutoff: float = 5, undirected: bool = True) -> torch.Tensor:
+    """Drop-in for the reference's ``get_neighbor_list(xyz, device, cutoff, undirected)``
+    (data.py:65) for one frame; runs K0 on the device."""
+    xyz = torch.as_tensor(np.asarray(xyz.cpu() if torch.is_tensor(xyz) else xyz), dtype=torch.float32).to(device)
+    fp = torch.tensor([0, xyz.shape[0]], dtype=_I32, device=xyz.device)
+    return radius_graph(xyz, fp, cutoff, undirected)
+
+
+# ----------------------------------------------------------------------------- a3
+def make_directed(nbr_list: torch.Tensor) -> Tuple[torch.Tensor, bool]:
+    """conv.py:10-20 semantics: a list that already holds both i>j and j>i pairs is returned
+    unchanged, otherwise the flipped pairs are appended.  One fused host read-back instead of
+    the reference's two ``.item()`` calls."""
+    if nbr_list.shape[0] == 0:
+        flags = (False, False)
+    else:
+        gt = nbr_list[:, 0] > nbr_list[:, 1]
+        lt = nbr_list[:, 1] > nbr_list[:, 0]
+        flags = tuple(torch.stack([gt.any(), lt.any()]).tolist())
+    directed = bool(flags[0] and flags[1])
+    if directed:
+        return nbr_list, True
+    return torch.cat([nbr_list, nbr_list.flip(1)], dim=0), False
+
+
+# ----------------------------------------------------------------------------- K7
+class EdgePlan:
+    """Destination- and source-sorted CSR views of a directed edge list (stable order).
+
+    ``dst`` is the receiver / scatter index (``nbrs[:,0]``), ``src`` the gathered node
+    (``nbrs[:,1]``) -- conv.py:68, 553-561.  All arrays are int32 device tensors.
+    """
+
+    __slots__ = ("n_dst", "n_src", "n_edges", "rowptr_d", "eid_d", "dst_d", "src_d", "rowptr_s", "eid_s",
+                 "dst_s", "src_s", "device", "__weakref__")
+
+    def __init__(self, dst: torch.Tensor, src: Optional[torch.Tensor], stride: int, n_edges: int, n_dst: int,
+                 n_src: int):
+        dev = dst.device
+        self.device, self.n_dst, self.n_src, self.n_edges = dev, int(n_dst), int(n_src), int(n_edges)
+        E = max(self.n_edges, 1)
+        mk = lambda n: torch.empty(n, dtype=_I32, device=dev)
+        self.rowptr_d, self.rowptr_s = mk(self.n_dst + 1), mk(self.n_src + 1)
+        self.eid_d, self.dst_d, self.src_d = mk(E), mk(E), mk(E)
+        self.eid_s, self.dst_s, self.src_s = mk(E), mk(E), mk(E)
+        lib = _lib.load()
+        ws_bytes = int(lib.cgv_csr_workspace_bytes(self.n_edges))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        _lib.call("cgv_csr_build", _lib.ptr(dst), _lib.ptr(src), stride, self.n_edges, self.n_dst, self.n_src,
+                  _lib.ptr(self.rowptr_d), _lib.ptr(self.eid_d), _lib.ptr(self.dst_d), _lib.ptr(self.src_d),
+                  _lib.ptr(self.rowptr_s), _lib.ptr(self.eid_s), _lib.ptr(self.dst_s), _lib.ptr(self.src_s),
+                  _lib.ptr(ws), ws_bytes, _lib.stream_ptr())
+
+    @classmethod
+    def from_nbrs(cls, nbrs: torch.Tensor, n_nodes: int) -> "EdgePlan":
+        """Plan for a directed ``[E,2]`` int64 edge list on a graph with ``n_nodes`` nodes."""
+        if nbrs.dtype != torch.int64:
+            nbrs = nbrs.long()
+        nbrs = nbrs.contiguous()
+        if nbrs.shape[0] == 0:
+            dummy = torch.zeros(2, dtype=torch.int64, device=nbrs.device)
+            return cls(dummy, dummy[1:], 2, 0, n_nodes, n_nodes)
+        # dst = column 0, src = column 1, element stride 2
+        return cls(nbrs.view(-1), nbrs.view(-1)[1:], 2, nbrs.shape[0], n_nodes, n_nodes)
+
+    @classmethod
+    def from_mapping(cls, mapping: torch.Tensor, n_beads: int) -> "EdgePlan":
+        """Atom -> bead contraction (conv.py:725-731): edge a has dst = mapping[a], src = a."""
+        mapping = mapping.long().contiguous()
+        return cls(mapping, None, 1, mapping.shape[0], n_beads, mapping.shape[0])
+
+
+# ----------------------------------------------------------------------------- K6
+def rbf_coefficients(n_rbf: int, cutoff: float, device) -> torch.Tensor:
+    """``n * pi / cutoff`` exactly as modules.py:144,155 computes it (fp32 tensor arithmetic)."""
+    n = torch.arange(1, n_rbf + 1).float()
+    return (n * np.pi / cutoff).to(device)
+
+
+class EdgeGeometry:
+    """Per-edge records ``[a_0..a_{R-1}, env, ux, uy, uz]`` in both CSR orders."""
+
+    __slots__ = ("geom_d", "geom_s", "n_rbf", "cutoff", "stride")
+
+    def __init__(self, plan: EdgePlan, n_rbf: int, cutoff: float, r_edges: Optional[torch.Tensor] = None,
+                 pos_dst: Optional[torch.Tensor] = None, pos_src: Optional[torch.Tensor] = None):
+        lib = _lib.load()
+        if not lib.cgv_rbf_supported(n_rbf):
+            raise RuntimeError(f"n_rbf={n_rbf} has no compiled kernel (see CGV_RBF_LIST in csrc/cgv_common.h)")
+        self.n_rbf, self.cutoff = int(n_rbf), float(cutoff)
+        self.stride = int(lib.cgv_geom_stride(n_rbf))
+        dev = plan.device
+        E = max(plan.n_edges, 1)
+        self.geom_d = torch.empty(E, self.stride, dtype=torch.float32, device=dev)
+        self.geom_s = torch.empty(E, self.stride, dtype=torch.float32, device=dev)
+        coef = rbf_coefficients(n_rbf, cutoff, dev)
+        st = _lib.stream_ptr()
+        if r_edges is not None:
+            if r_edges.requires_grad:
+                raise RuntimeError("gradients w.r.t. edge vectors are not part of this path (coordinates are data)")
+            r_edges = r_edges.detach().contiguous().float()
+            pd = ps = None
+        else:
+            pd, ps = pos_dst.detach().contiguous().float(), pos_src.detach().contiguous().float()
+        for eid, dst, src, out in ((plan.eid_d, plan.dst_d, plan.src_d, self.geom_d),
+                                   (plan.eid_s, plan.dst_s, plan.src_s, self.geom_s)):
+            _lib.call("cgv_edge_geometry", _lib.ptr(r_edges), _lib.ptr(eid), _lib.ptr(pd), _lib.ptr(ps),
+                      _lib.ptr(dst), _lib.ptr(src), plan.n_edges, self.n_rbf, self.cutoff, _lib.ptr(coef),
+                      _lib.ptr(out), st)
+
+
+# ----------------------------------------------------------------------------- per-batch bundle
+class BatchGraph:
+    """Everything topological / geometric the model derives from one collated batch, built once
+    (at collate time via ``data.prepare_batch`` or lazily in ``CGequiVAE.forward``) instead of in
+    every forward with host syncs as the reference does (conv.py:10-20 x4, cgvae.py:451-460):
+
+      atom : plan of the directed atom graph          (EquiEncoder, cgvae.py:270, 276)
+      cg   : plan of the directed bead graph          (CGprior, EquivariantPsuedoDecoder)
+      a2b  : atom -> bead contraction plan            (ContractiveMessageBlock, scatter_mean)
+      chan : rank of each atom inside its bead        (CG2ChannelIdx, cgvae.py:451-460)
+    Geometry records are cached per (graph, n_rbf, cutoff): the reference's encoder, prior and
+    decoder use different RBF cutoffs on the same edges (run_ala.py:196-206).
+    """
+
+    def __init__(self, xyz, cg_xyz, mapping, nbr_list, cg_nbr_list):
+        self.xyz = xyz.detach().contiguous().float()
+        self.cg_xyz = cg_xyz.detach().contiguous().float()
+        n, n_cg = self.xyz.shape[0], self.cg_xyz.shape[0]
+        self.mapping = mapping.long()
+        self.atom_nbrs, _ = make_directed(nbr_list)
+        self.cg_nbrs, _ = make_directed(cg_nbr_list)
+        self.atom = EdgePlan.from_nbrs(self.atom_nbrs, n)
+        self.cg = EdgePlan.from_nbrs(self.cg_nbrs, n_cg)
+        self.a2b = EdgePlan.from_mapping(self.mapping, n_cg)
+        # rank inside the bead = position in the (stable) bead-sorted order minus the bead's start
+        p = self.a2b
+        rank_sorted = torch.arange(n, device=self.xyz.device, dtype=torch.int64) - p.rowptr_d[p.dst_d[:n].long()].long()
+        self.chan = torch.empty(n, dtype=torch.int64, device=self.xyz.device)
+        self.chan[p.eid_d[:n].long()] = rank_sorted
+        self._geom = {}
+
+    def geometry(self, which: str, n_rbf: int, cutoff: float) -> EdgeGeometry:
+        key = (which, int(n_rbf), float(cutoff))
+        g = self._geom.get(key)
+        if g is None:
+            if which == "atom":
+                g = EdgeGeometry(self.atom, n_rbf, cutoff, pos_dst=self.xyz, pos_src=self.xyz)
+            elif which == "cg":
+                g = EdgeGeometry(self.cg, n_rbf, cutoff, pos_dst=self.cg_xyz, pos_src=self.cg_xyz)
+            elif which == "a2b":   # r_iI = xyz - cg_xyz[mapping]  (cgvae.py:280)
+                g = EdgeGeometry(self.a2b, n_rbf, cutoff, pos_dst=self.cg_xyz, pos_src=self.xyz)
+            else:
+                raise KeyError(which)
+            self._geom[key] = g
+        return g

@@ -1,0 +1,241 @@
+"""Model assembly with the reference's public surface (CoarseGrainingVAE/cgvae.py):
+``EquiEncoder``, ``CGprior``, ``EquivariantPsuedoDecoder``, ``CGequiVAE`` -- same constructor
+arguments, ``forward(batch)`` 6-tuple, ``get_inputs``, ``decoder``, ``prior_net``,
+``reparametrize`` and state_dict keys, so reference ``model.pt`` files load unchanged.
+
+What differs is where the time goes: per batch ONE :class:`~.graph.BatchGraph` (directed
+edge lists, CSR views, edge geometry per cutoff, bead ranks) replaces the per-forward host
+syncs, and every message block is node GEMMs + one fused HIP edge kernel.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import ops
+from .blocks import (ContractiveMessageBlock, EquiMessageBlock, EquiMessagePsuedo, PseudoUpdateBlock, UpdateBlock)
+from .graph import BatchGraph, EdgePlan, make_directed
+from .primitives import Dense, DistanceEmbed, to_module
+
+
+class EquivariantPsuedoDecoder(nn.Module):
+    """cgvae.py:52-125.  NB run_ala.py:196-197 passes ``cutoff=atom_cutoff`` here."""
+
+    def __init__(self, n_atom_basis, n_rbf, cutoff, num_conv, activation, breaksym=False):
+        super().__init__()
+        self.message_blocks = nn.ModuleList(
+            [EquiMessagePsuedo(feat_dim=n_atom_basis, activation=activation, n_rbf=n_rbf, cutoff=cutoff, dropout=0.0)
+             for _ in range(num_conv)])
+        self.update_blocks = nn.ModuleList(
+            [UpdateBlock(feat_dim=n_atom_basis, activation=activation, dropout=0.0) for _ in range(num_conv)])
+        self.pseudo_update_blocks = nn.ModuleList(
+            [PseudoUpdateBlock(feat_dim=n_atom_basis, activation=activation, dropout=0.0) for _ in range(num_conv)])
+        self.breaksym = breaksym
+        self.n_atom_basis = n_atom_basis
+        self.n_rbf, self.cutoff = n_rbf, cutoff
+
+    def forward(self, cg_xyz, CG_nbr_list, mapping, S, graph: Optional[BatchGraph] = None):
+        if graph is not None:
+            nbrs, plan = graph.cg_nbrs, graph.cg
+            geom = graph.geometry("cg", self.n_rbf, self.cutoff)
+            r_ij = None
+        else:
+            nbrs, _ = make_directed(CG_nbr_list)
+            plan = EdgePlan.from_nbrs(nbrs, S.shape[0])
+            r_ij = cg_xyz[nbrs[:, 1]] - cg_xyz[nbrs[:, 0]]
+            geom = None
+        n, F = S.shape
+        V = torch.zeros(n, F, 3, device=S.device)
+        Sbar = torch.ones(n, F, device=S.device) if self.breaksym else torch.zeros(n, F, device=S.device)
+        Vbar = torch.zeros(n, F, 3, device=S.device)
+        for message_block, update_block in zip(self.message_blocks, self.update_blocks):
+            if geom is None:      # build once, share across layers
+                from .graph import EdgeGeometry
+                geom = EdgeGeometry(plan, self.n_rbf, self.cutoff, r_edges=r_ij)
+            dS, dSbar, dV, dVbar = message_block(S, Sbar, V, Vbar, r_ij, nbrs, plan=plan, geom=geom)
+            S = S + dS
+            Sbar = Sbar + dSbar
+            V = V + dV
+            Vbar = Vbar + dVbar
+            dS_u, dV_u = update_block(S, V)
+            S = S + dS_u
+            V = V + dV_u
+        return S, V
+
+
+class EquiEncoder(nn.Module):
+    """cgvae.py:194-331.  NB run_ala.py:199-201 passes ``cutoff=cg_cutoff`` (RBF range) while the
+    edges come from the atom-cutoff radius graph; the atom->bead blocks use cutoff 20.0."""
+
+    def __init__(self, n_conv, n_atom_basis, n_rbf, activation, cutoff, dir_mp=False, cg_mp=False):
+        super().__init__()
+        F = n_atom_basis
+        self.atom_embed = nn.Embedding(100, F, padding_idx=0)
+        mk_msg = lambda: EquiMessageBlock(feat_dim=F, activation=activation, n_rbf=n_rbf, cutoff=cutoff, dropout=0.0)
+        mk_upd = lambda: UpdateBlock(feat_dim=F, activation=activation, dropout=0.0)
+        # registration order = the reference's, for key order and same-seed init
+        self.dist_embed = DistanceEmbed(n_rbf=n_rbf, cutoff=cutoff, feat_dim=F, dropout=0.0)           # unused
+        self.message_blocks = nn.ModuleList([mk_msg() for _ in range(n_conv)])
+        self.update_blocks = nn.ModuleList([mk_upd() for _ in range(n_conv)])                           # unused
+        self.cg_message_blocks = nn.ModuleList([mk_msg() for _ in range(n_conv)])                       # unused
+        self.cg_update_blocks = nn.ModuleList([mk_upd() for _ in range(n_conv)])                        # unused
+        self.cgmessage_layers = nn.ModuleList(
+            [ContractiveMessageBlock(feat_dim=F, activation=activation, n_rbf=n_rbf, cutoff=20.0, dropout=0.0)
+             for _ in range(n_conv)])
+        self.atom2CGcouplings = nn.ModuleList(                                                          # unused
+            [nn.Sequential(Dense(in_features=F, out_features=F, bias=True, activation=to_module(activation)),
+                           Dense(in_features=F, out_features=F, bias=True)) for _ in range(n_conv)])
+        self.n_conv, self.dir_mp, self.cg_mp, self.n_atom_basis = n_conv, dir_mp, cg_mp, F
+        self.n_rbf, self.cutoff = n_rbf, cutoff
+        self.skip_dead_vector_channel = False
+
+    def set_skip_dead_vector_channel(self, flag: bool):
+        """Explicit, reported option: the encoder's vector channel never reaches its outputs
+        (update blocks are commented out in the reference, cgvae.py:290-293, and V is not
+        returned), so skipping it leaves (H, h) bit-identical.  Default: compute it."""
+        self.skip_dead_vector_channel = bool(flag)
+        for blk in list(self.message_blocks) + list(self.cgmessage_layers):
+            blk.with_dv = not flag
+
+    def forward(self, z, xyz, cg_xyz, mapping, nbr_list, cg_nbr_list, graph: Optional[BatchGraph] = None):
+        if graph is None:
+            if self.dir_mp:
+                raise NotImplementedError("dir_mp=True is never used by run_ala.py (run_ala.py:201)")
+            graph = BatchGraph(xyz, cg_xyz, mapping, nbr_list, cg_nbr_list)
+        geom = graph.geometry("atom", self.n_rbf, self.cutoff)
+        geom_c = graph.geometry("a2b", self.n_rbf, 20.0)
+        h = self.atom_embed(z.long())
+        v = torch.zeros(h.shape[0], h.shape[1], 3, device=h.device)
+        H = V = None
+        for i in range(self.n_conv):
+            ds, dv = self.message_blocks[i](h, v, None, graph.atom_nbrs, plan=graph.atom, geom=geom)
+            h = h + ds
+            v = v + dv
+            if i == 0:
+                H = ops.scatter_mean(h, graph.mapping, plan=graph.a2b)
+                V = ops.scatter_mean(v, graph.mapping, plan=graph.a2b)
+            dH, dV = self.cgmessage_layers[i](h, v, None, graph.mapping, plan=graph.a2b, geom=geom_c)
+            H = H + dH
+            V = V + dV
+        return H, h
+
+
+class CGprior(nn.Module):
+    """cgvae.py:334-403."""
+
+    def __init__(self, n_conv, n_atom_basis, n_rbf, activation, cutoff, dir_mp=False):
+        super().__init__()
+        F = n_atom_basis
+        self.atom_embed = nn.Embedding(100, F, padding_idx=0)
+        self.dist_embed = DistanceEmbed(n_rbf=n_rbf, cutoff=cutoff, feat_dim=F, dropout=0.0)           # unused
+        self.message_blocks = nn.ModuleList(
+            [EquiMessageBlock(feat_dim=F, activation=activation, n_rbf=n_rbf, cutoff=cutoff, dropout=0.0)
+             for _ in range(n_conv)])
+        self.update_blocks = nn.ModuleList(
+            [UpdateBlock(feat_dim=F, activation=activation, dropout=0.0) for _ in range(n_conv)])        # unused
+        self.mu = nn.Sequential(nn.Linear(F, F), nn.Tanh(), nn.Linear(F, F))
+        self.sigma = nn.Sequential(nn.Linear(F, F), nn.Tanh(), nn.Linear(F, F))
+        self.n_conv, self.dir_mp = n_conv, dir_mp
+        self.n_rbf, self.cutoff = n_rbf, cutoff
+
+    def set_skip_dead_vector_channel(self, flag: bool):
+        for blk in self.message_blocks:
+            blk.with_dv = not flag
+
+    def forward(self, cg_z, cg_xyz, cg_nbr_list, graph: Optional[BatchGraph] = None):
+        if graph is not None:
+            nbrs, plan = graph.cg_nbrs, graph.cg
+            geom = graph.geometry("cg", self.n_rbf, self.cutoff)
+        else:
+            from .graph import EdgeGeometry
+            nbrs, _ = make_directed(cg_nbr_list)
+            plan = EdgePlan.from_nbrs(nbrs, cg_xyz.shape[0])
+            geom = EdgeGeometry(plan, self.n_rbf, self.cutoff, pos_dst=cg_xyz, pos_src=cg_xyz)
+        h = self.atom_embed(cg_z.long())
+        v = torch.zeros(h.shape[0], h.shape[1], 3, device=h.device)
+        for blk in self.message_blocks:
+            ds, dv = blk(h, v, None, nbrs, plan=plan, geom=geom)
+            h = h + ds
+            v = v + dv
+        H_mu = self.mu(h)
+        H_std = 1e-9 + torch.exp(self.sigma(h) / 2)
+        return H_mu, H_std
+
+
+class CGequiVAE(nn.Module):
+    """cgvae.py:406-513."""
+
+    def __init__(self, encoder, equivaraintconv, atom_munet, atom_sigmanet, n_cgs, feature_dim, prior_net=None,
+                 det=False, equivariant=True, offset=True):
+        super().__init__()
+        self.encoder = encoder
+        self.equivaraintconv = equivaraintconv
+        self.atom_munet = atom_munet
+        self.atom_sigmanet = atom_sigmanet
+        self.n_cgs = n_cgs
+        self.prior_net = prior_net
+        self.det = det
+        self.offset = offset
+        self.equivariant = equivariant
+        if not equivariant:
+            self.euclidean = nn.Linear(self.encoder.n_atom_basis, self.encoder.n_atom_basis * 3)
+
+    def get_inputs(self, batch):
+        xyz = batch["nxyz"][:, 1:]
+        cg_xyz = batch["CG_nxyz"][:, 1:]
+        cg_z = batch["CG_nxyz"][:, 0]
+        z = batch["nxyz"][:, 0]
+        return (z, cg_z, xyz, cg_xyz, batch["nbr_list"], batch["CG_nbr_list"], batch["CG_mapping"],
+                batch["num_CGs"])
+
+    def reparametrize(self, mu, sigma, eps: Optional[torch.Tensor] = None):
+        """z = mu + eps * sigma (cgvae.py:445-449).  ``eps`` may be supplied (parity runs draw it
+        on the host generator); otherwise it is drawn on the device."""
+        if eps is None:
+            eps = torch.randn_like(sigma)
+        return eps.mul(sigma).add_(mu)
+
+    def CG2ChannelIdx(self, CG_mapping):
+        """Rank of each atom inside its bead (cgvae.py:451-460) without the per-bead host loop."""
+        n_beads = int(CG_mapping.max().item()) + 1
+        plan = EdgePlan.from_mapping(CG_mapping, n_beads)
+        n = CG_mapping.shape[0]
+        rank = torch.arange(n, device=CG_mapping.device) - plan.rowptr_d[plan.dst_d[:n].long()].long()
+        out = torch.empty(n, dtype=torch.int64, device=CG_mapping.device)
+        out[plan.eid_d[:n].long()] = rank
+        return out
+
+    def decoder(self, cg_xyz, CG_nbr_list, S_I, s_i, mapping, num_CGs, graph: Optional[BatchGraph] = None):
+        cg_s, cg_v = self.equivaraintconv(cg_xyz, CG_nbr_list, mapping, S_I, graph=graph)
+        if graph is not None:
+            chan, plan = graph.chan, graph.a2b
+        else:
+            chan = self.CG2ChannelIdx(mapping)
+            plan = EdgePlan.from_mapping(mapping, cg_xyz.shape[0])
+        if not self.equivariant:
+            dv = self.euclidean(cg_s).reshape(cg_s.shape[0], cg_s.shape[1], 3)
+            xyz_rel = dv[mapping, chan, :]
+        else:
+            xyz_rel = cg_v[mapping, chan, :]
+        if self.offset:
+            xyz_rel = xyz_rel - ops.scatter_mean(xyz_rel, mapping, plan=plan)[mapping]
+        return xyz_rel + cg_xyz[mapping]
+
+    def forward(self, batch, eps: Optional[torch.Tensor] = None):
+        z, cg_z, xyz, cg_xyz, nbr_list, CG_nbr_list, mapping, num_CGs = self.get_inputs(batch)
+        graph = batch.get("_graph")
+        if graph is None:
+            graph = BatchGraph(xyz, cg_xyz, mapping, nbr_list, CG_nbr_list)
+        S_I, s_i = self.encoder(z, xyz, cg_xyz, mapping, nbr_list, CG_nbr_list, graph=graph)
+        if self.prior_net:
+            H_prior_mu, H_prior_sigma = self.prior_net(cg_z, cg_xyz, CG_nbr_list, graph=graph)
+        else:
+            H_prior_mu, H_prior_sigma = None, None
+        mu = self.atom_munet(S_I)
+        logvar = self.atom_sigmanet(S_I)
+        sigma = 1e-12 + torch.exp(logvar / 2)
+        z_sample = S_I if self.det else self.reparametrize(mu, sigma, eps)
+        xyz_recon = self.decoder(cg_xyz, CG_nbr_list, z_sample, s_i, mapping, num_CGs, graph=graph)
+        return mu, sigma, H_prior_mu, H_prior_sigma, xyz, xyz_recon

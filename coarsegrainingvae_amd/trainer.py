@@ -1,0 +1,151 @@
+"""Training step engine: flat parameter arena, fused clip+Adam, data-parallel gradient exchange.
+
+The reference's step (scripts/utils.py:110-157) is: forward, loss, ``.item()`` skip test,
+``zero_grad``, ``backward``, ``clip_grad_norm_(0.01)``, ``Adam.step()`` over ~160 separate
+tensors.  Here the parameters that actually receive gradients (51-68 M of the model's 150 M --
+SURVEY 8a note 8) live in ONE contiguous fp32 arena with matching gradient / moment arenas, so
+
+  * zeroing gradients is one memset, the global norm one reduction, clip+Adam one fused HIP
+    launch (csrc/optim.hip) with the skip decision taken on the device -> no host sync per step;
+  * data parallelism is one process per GPU, frames sharded across ranks (a batch is a disjoint
+    union of per-frame graphs, data.py:259-270), and the only collective is a SUM all-reduce of
+    the gradient arena in a few large buckets over RCCL/xGMI, plus one scalar for the skip rule
+    (the decision must be identical on every rank).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+from . import _lib
+from .train import CLIP_NORM, loss_terms
+
+_ALIGN = 64        # floats: every parameter starts on a 256-byte boundary inside the arena
+
+
+class ParamArena:
+    """Contiguous storage for a list of parameters and their gradients (views are re-pointed)."""
+
+    def __init__(self, params: List[torch.nn.Parameter]):
+        self.params = params
+        dev = params[0].device
+        offs, total = [], 0
+        for p in params:
+            offs.append(total)
+            total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.offsets, self.numel = offs, total
+        self.p = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.g = torch.zeros(total, dtype=torch.float32, device=dev)
+        for p, o in zip(params, offs):
+            n = p.numel()
+            self.p[o:o + n].copy_(p.data.reshape(-1))
+            if p.grad is not None:
+                self.g[o:o + n].copy_(p.grad.reshape(-1))
+            p.data = self.p[o:o + n].view_as(p)
+            p.grad = self.g[o:o + n].view_as(p)
+
+    def zero_grad(self):
+        self.g.zero_()
+
+
+class GradSync:
+    """SUM all-reduce of the gradient arena in large buckets (default 64 MiB: a handful of
+    collectives per step; xGMI rings are per-link bound, so few large messages beat many small
+    ones).  Averaging is folded into the optimiser kernel's ``grad_scale`` (or applied here for
+    the unfused path)."""
+
+    def __init__(self, world_size: int, group=None, bucket_bytes: int = 64 << 20):
+        import torch.distributed as dist
+        self.dist, self.world, self.group = dist, world_size, group
+        self.bucket = max(bucket_bytes // 4, 1)
+
+    def all_reduce_flat(self, flat: torch.Tensor):
+        works = []
+        for start in range(0, flat.numel(), self.bucket):
+            works.append(self.dist.all_reduce(flat[start:start + self.bucket], op=self.dist.ReduceOp.SUM,
+                                              group=self.group, async_op=True))
+        for w in works:
+            w.wait()
+
+    def mean_scalar(self, x: torch.Tensor) -> torch.Tensor:
+        y = x.detach().clone().reshape(1)
+        self.dist.all_reduce(y, op=self.dist.ReduceOp.SUM, group=self.group)
+        return (y / self.world).reshape(())
+
+
+class Trainer:
+    """One object per process (= per GPU).  ``step(batch)`` runs a full training iteration."""
+
+    def __init__(self, model, lr: float, beta: float, gamma: float, world_size: int = 1, group=None,
+                 fused_optimizer: bool = True, betas=(0.9, 0.999), eps: float = 1e-8, max_norm: float = CLIP_NORM):
+        self.model, self.lr, self.beta, self.gamma = model, lr, beta, gamma
+        self.betas, self.eps, self.max_norm = betas, eps, max_norm
+        self.world = world_size
+        self.sync = GradSync(world_size, group) if world_size > 1 else None
+        self.fused = fused_optimizer
+        self.arena: Optional[ParamArena] = None
+        self.torch_opt = None
+        self.last_loss = None
+        self.last_terms = None
+        self.steps_skipped_host = 0
+
+    # ------------------------------------------------------------------ setup after the first backward
+    def _build_arena(self):
+        live = [p for p in self.model.parameters() if p.grad is not None]
+        if not live:
+            raise RuntimeError("no parameter received a gradient")
+        self.arena = ParamArena(live)
+        dev = self.arena.p.device
+        if self.fused:
+            if dev.type != "cuda":
+                raise RuntimeError("the fused optimiser is a HIP kernel: it needs device tensors")
+            lib = _lib.load()
+            self.m = torch.zeros_like(self.arena.p)
+            self.v = torch.zeros_like(self.arena.p)
+            self.state = torch.zeros(lib.cgv_optim_state_floats(), dtype=torch.float32, device=dev)
+            self.partial = torch.empty(lib.cgv_optim_partial_floats(), dtype=torch.float32, device=dev)
+        else:
+            self.torch_opt = torch.optim.Adam(live, lr=self.lr, betas=self.betas, eps=self.eps)
+
+    # ------------------------------------------------------------------ one iteration
+    def step(self, batch, eps: Optional[torch.Tensor] = None, train: bool = True):
+        out = self.model(batch, eps=eps) if eps is not None else self.model(batch)
+        loss, kl, recon, graph = loss_terms(out, batch, self.beta, self.gamma)
+        self.last_loss, self.last_terms, self.last_out = loss.detach(), (kl.detach(), recon.detach(), graph.detach()), out
+        decision = self.last_loss if self.sync is None else self.sync.mean_scalar(self.last_loss)
+        threshold = self.gamma * 200.0
+
+        if not self.fused:
+            lv = float(decision)                                     # host sync, like utils.py:145
+            if lv >= threshold or lv != lv:
+                self.steps_skipped_host += 1
+                return self.last_loss
+        if self.arena is None:
+            loss.backward()
+            self._build_arena()
+        else:
+            self.arena.zero_grad()
+            loss.backward()
+        if not train:                                               # validation: backward only (utils.py:160)
+            return self.last_loss
+        if self.sync is not None:
+            self.sync.all_reduce_flat(self.arena.g)
+        scale = 1.0 / self.world
+        if self.fused:
+            a = self.arena
+            _lib.call("cgv_adam_clip_step", _lib.ptr(a.p), _lib.ptr(a.g), _lib.ptr(self.m), _lib.ptr(self.v),
+                      a.numel, self.lr, self.betas[0], self.betas[1], self.eps, self.max_norm, scale,
+                      _lib.ptr(decision.reshape(1).float().contiguous()), threshold, _lib.ptr(self.state),
+                      _lib.ptr(self.partial), _lib.stream_ptr())
+        else:
+            if self.world > 1:
+                self.arena.g.mul_(scale)
+            torch.nn.utils.clip_grad_norm_(self.arena.params, self.max_norm)
+            self.torch_opt.step()
+        return self.last_loss
+
+    def skipped_steps(self) -> int:
+        if self.fused and self.arena is not None:
+            return int(self.state[6].item())
+        return self.steps_skipped_host

@@ -1,0 +1,164 @@
+/*
+ * cgvae_hip.h -- C ABI of libcgvae_hip.so: the MI355X (gfx950) kernels behind the
+ * CoarseGrainingVAE message-passing hot path.
+ *
+ * The reference (wwang2/CoarseGrainingVAE) is pure Python: it has no FFI layer.  Its seam
+ * for this path is (i) torch_scatter.scatter_add / scatter_mean and (ii) the forward()
+ * signatures of the message blocks in CoarseGrainingVAE/conv.py.  Every entry point below
+ * names the reference lines it replaces; INTEGRATION.md shows the ctypes stub a reference
+ * maintainer would add to bind them.
+ *
+ * Conventions (all functions):
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless marked [host];
+ *   - the caller owns every buffer (inputs, outputs, workspaces); the library never
+ *     allocates or frees device memory and keeps no pointer after it returns;
+ *   - tensors are contiguous, fp32 / int32 / int64 exactly as declared;
+ *   - `stream` is a hipStream_t (NULL = default stream); launches are asynchronous and the
+ *     library never synchronises the device;
+ *   - return value: 0 = success; < 0 = CGV_E_* argument error; > 0 = hipError_t of a launch;
+ *     cgv_last_error_string() gives a thread-local description;
+ *   - re-entrant, no global mutable state (autograd calls backward from worker threads).
+ *
+ * Notation: F = n_basis, R = n_rbf, E = directed edges, Nd / Ns = destination / source
+ * node counts (equal for the atom and bead graphs; Nd = beads, Ns = atoms for the
+ * atom->bead contraction).
+ *
+ * Edge geometry record ("geom"), one per edge, stride cgv_geom_stride(R) floats:
+ *   [0..R)   a_n   = rbf_n(d) * env(d)          modules.py:148-172, 52-58
+ *   [R]      env   = 0.5 (cos(pi d / cut) + 1)  (0 for d >= cut)
+ *   [R+1..R+4) unit = r / d, d = sqrt(sum_k (r_k^2 + 1e-8))   conv.py:25-29
+ * so that the distance filter of modules.py:192-197 is
+ *   w[c] = sum_n Wd[c][n] * a_n + bd[c] * env.
+ */
+#ifndef CGVAE_HIP_H
+#define CGVAE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CGV_VERSION 100 /* 0.1.0 */
+
+#define CGV_E_BADARG (-1)      /* null pointer / negative size */
+#define CGV_E_UNSUPPORTED (-2) /* e.g. n_rbf outside the compiled set */
+#define CGV_E_WORKSPACE (-3)   /* workspace too small */
+
+int cgv_version(void);
+const char* cgv_last_error_string(void);
+
+/* n_rbf values with a compiled kernel: returns 1 if supported. */
+int cgv_rbf_supported(int n_rbf);
+/* floats per edge-geometry record for this n_rbf (R + 4 rounded up to a multiple of 4). */
+int cgv_geom_stride(int n_rbf);
+
+/* ---------------------------------------------------------------------------------------
+ * K0  radius graph -- replaces get_neighbor_list, CoarseGrainingVAE/data.py:65-82, batched
+ * over frames (the Python loop of data.py:207-252).  Pair (i,j) of one frame is an edge iff
+ *   s = (dx*dx + dy*dy) + dz*dz  <=  s_star          (no FMA contraction, fp32)
+ * where s_star is the largest fp32 whose host sqrt is <= cutoff (computed by the caller with
+ * the host's own sqrt, see graph.py) -- this makes membership bit-identical to the reference's
+ * `sqrt(s) <= cutoff` without depending on the device sqrt.  Output order is the reference's
+ * (torch.nonzero, row-major: i ascending, then j ascending), node ids are batch-global like
+ * CG_collate produces (data.py:262-270).  undirected != 0 keeps j > i only (data.py:79-80).
+ * Two calls because the edge count is data dependent:
+ *   1. cgv_radius_graph_count -> counts[n_nodes] and offsets[n_nodes+1] (exclusive scan;
+ *      offsets[n_nodes] = E).  The caller reads E back and allocates.
+ *   2. cgv_radius_graph_emit  -> nbr_out[E][2] int64.
+ * ------------------------------------------------------------------------------------- */
+int cgv_radius_graph_count(const float* xyz /*[n_nodes,3]*/, const int32_t* frame_ptr /*[n_frames+1]*/,
+                           int n_frames, int n_nodes, float s_star, int undirected,
+                           int32_t* counts /*[n_nodes]*/, int32_t* offsets /*[n_nodes+1]*/, void* stream);
+int cgv_radius_graph_emit(const float* xyz, const int32_t* frame_ptr, int n_frames, int n_nodes, float s_star,
+                          int undirected, const int32_t* offsets /*[n_nodes+1]*/, int64_t* nbr_out /*[E,2]*/,
+                          void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * K7  CSR plan of a directed edge list.  The reference scatters with an UNSORTED index
+ * (nbrs[:,0] after make_directed, conv.py:10-20,553-561); the kernels here reduce over
+ * destination-sorted segments instead (no atomics, deterministic).  Builds, with a stable
+ * sort (ties keep the original edge order):
+ *   dst-sorted view : rowptr_d[Nd+1], eid_d[E] (original edge id), dst_d[E], src_d[E]
+ *   src-sorted view : rowptr_s[Ns+1], eid_s[E], dst_s[E], src_s[E]      (for backward)
+ * dst/src are int64 arrays read with element stride `stride` (nbrs[E,2]: dst=nbrs,
+ * src=nbrs+1, stride=2).  src == NULL means src[e] = e (atom->bead contraction with
+ * dst = CG_mapping, conv.py:725-731).
+ * ------------------------------------------------------------------------------------- */
+size_t cgv_csr_workspace_bytes(int n_edges);
+int cgv_csr_build(const int64_t* dst, const int64_t* src, int stride, int n_edges, int n_dst, int n_src,
+                  int32_t* rowptr_d, int32_t* eid_d, int32_t* dst_d, int32_t* src_d,
+                  int32_t* rowptr_s, int32_t* eid_s, int32_t* dst_s, int32_t* src_s,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * K6  edge geometry -- replaces preprocess_r (conv.py:25-29), PainnRadialBasis
+ * (modules.py:148-172) and CosineEnvelope (modules.py:52-58), computed ONCE per graph and
+ * cutoff and shared by every layer (the reference recomputes it in each block).
+ * For sorted position p:  r = r_edges[eid[p]]                      if r_edges != NULL
+ *                         r = pos_src[src[p]] - pos_dst[dst[p]]    otherwise
+ * coef[n] = (n+1)*pi/cutoff and pi_f = (float)pi exactly as the host computes them.
+ * ------------------------------------------------------------------------------------- */
+int cgv_edge_geometry(const float* r_edges /*[E,3] or NULL*/, const int32_t* eid /*[E]*/,
+                      const float* pos_dst /*[Nd,3]*/, const float* pos_src /*[Ns,3]*/,
+                      const int32_t* dst /*[E]*/, const int32_t* src /*[E]*/, int n_edges, int n_rbf,
+                      float cutoff, const float* coef /*[R]*/, float* geom /*[E,stride]*/, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * K1  segment reduction -- replaces torch_scatter.scatter_add / scatter_mean (requirements.txt:18;
+ * call sites cgvae.py:297-298,479; conv.py:553-561 when used unfused).
+ *   out[s, :] = sum_{p in [rowptr[s], rowptr[s+1])} src[perm ? perm[p] : p, :]   (/ max(len,1) if mean)
+ * `src` is [n_rows, C]; perm (eid_d of the CSR plan) handles an unsorted index.
+ * ------------------------------------------------------------------------------------- */
+int cgv_segment_reduce(const float* src, const int32_t* rowptr, const int32_t* perm, int n_seg, int channels,
+                       int mean, float* out /*[n_seg,C]*/, void* stream);
+/* backward of the above: gsrc[perm?perm[p]:p, :] = gout[seg(p), :] (* 1/max(len,1) if mean) */
+int cgv_segment_broadcast(const float* gout, const int32_t* rowptr, const int32_t* perm, int n_seg, int channels,
+                          int mean, float* gsrc /*[n_rows,C]*/, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * K2 / K4  fused EquiMessageBlock (conv.py:505-563 incl. InvariantMessage 63-75 and
+ * DistanceEmbed modules.py:192-197) and, with the atom->bead plan, ContractiveMessageBlock
+ * (conv.py:703-733).  phi = inv_dense(s) is computed by the caller (node-level GEMMs).
+ *   m_k(e,f) = phi[src(e), kF+f] * w[kF+f](e)
+ *   ds[i,f]   = sum_{e: dst(e)=i} m_1
+ *   dv[i,f,:] = sum_e ( m_2 * unit_e + m_0 * v[src(e), f, :] )
+ * No [E, .] tensor is ever written.  with_dv = 0 skips the vector channel (explicit option;
+ * the encoder never consumes it -- SURVEY 8a note a12) and leaves dv untouched.
+ * ------------------------------------------------------------------------------------- */
+int cgv_equi_msg_fwd(const float* phi /*[Ns,3F]*/, const float* v /*[Ns,F,3]*/, const float* geom_d,
+                     const int32_t* rowptr_d, const int32_t* src_d, const float* Wd /*[3F,R]*/,
+                     const float* bd /*[3F]*/, float* ds /*[Nd,F]*/, float* dv /*[Nd,F,3]*/, int n_dst,
+                     int n_feat, int n_rbf, int with_dv, void* stream);
+/* Backward.  gs / gv are the upstream gradients at the receivers (gv == NULL when dv is not
+ * consumed).  Traverses the src-sorted view; writes g_phi [Ns,3F], g_v [Ns,F,3] (only if gv),
+ * gWd [3F,R], gbd [3F] completely (zeros where nothing flows).  Deterministic two-stage
+ * reduction for gWd/gbd through `workspace`. */
+size_t cgv_equi_msg_bwd_workspace_bytes(int n_src, int n_feat, int n_rbf);
+int cgv_equi_msg_bwd(const float* phi, const float* v, const float* geom_s, const int32_t* rowptr_s,
+                     const int32_t* dst_s, const float* Wd, const float* bd, const float* gs /*[Nd,F] or NULL*/,
+                     const float* gv /*[Nd,F,3] or NULL*/, float* g_phi, float* g_v, float* gWd, float* gbd,
+                     int n_src, int n_feat, int n_rbf, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Fused optimiser step over a flat fp32 arena of the parameters that receive gradients --
+ * replaces the skip rule, clip_grad_norm_(params, 0.01) and Adam.step() of
+ * scripts/utils.py:145-157 (torch.optim.Adam defaults: no amsgrad, no weight decay).
+ *   skip   = loss >= skip_threshold || isnan(loss)         (loss == NULL: never skip)
+ *   norm   = |grad_scale| * ||g||_2 ;  coef = min(1, max_norm / (norm + 1e-6))
+ *   g' = g * coef * grad_scale ; m,v,p updated as Adam does ; step counter += 1
+ * `state` is cgv_optim_state_floats() device floats, zero-initialised by the caller once:
+ *   [0] step  [1] last grad norm  [2] clip*scale  [3] 1-b1^t  [4] sqrt(1-b2^t)  [5] skipped?  [6] #skipped
+ * `partial` is cgv_optim_partial_floats() device floats of scratch.  No host synchronisation.
+ * ------------------------------------------------------------------------------------- */
+int cgv_optim_state_floats(void);
+int cgv_optim_partial_floats(void);
+int cgv_adam_clip_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                       float eps, float max_norm, float grad_scale, const float* loss /*[1] or NULL*/,
+                       float skip_threshold, float* state, float* partial, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CGVAE_HIP_H */

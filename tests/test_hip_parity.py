@@ -1,0 +1,382 @@
+"""GPU parity: the HIP path (through the C ABI) against (a) golden vectors produced by the
+reference, (b) the CPU oracle on the same seeded inputs, (c) size-independent properties.
+Tolerance: north_star's 1e-4 relative fp32 (norm-relative, written below); integer/index
+work (edge lists, CSR plans) is bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+import coarsegrainingvae_amd as cg
+from coarsegrainingvae_amd.graph import EdgeGeometry, EdgePlan
+from oracle import cgvae_oracle as O
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+REL = 1e-4        # BASELINE.json: "within 1e-4 relative fp32"
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def dev(a):
+    return t(a).to(DEV)
+
+
+def rel_err(got, ref):
+    got = got.detach().cpu().double().numpy() if torch.is_tensor(got) else np.asarray(got, dtype=np.float64)
+    ref = ref.detach().cpu().double().numpy() if torch.is_tensor(ref) else np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    return float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30))
+
+
+def assert_close(got, ref, what="", tol=REL):
+    e = rel_err(got, ref)
+    assert e <= tol, f"{what}: relative error {e:.3e} > {tol:.1e}"
+
+
+def load_block(block, g):
+    sd = {k[2:]: t(v) for k, v in g.items() if k.startswith("p.")}
+    block.load_state_dict(sd, strict=True)
+    return block.to(DEV)
+
+
+def check_param_grads(block, g, tol=REL):
+    for name, p in block.named_parameters():
+        ref = g["g." + name]
+        if ref.size == 0:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+        else:
+            assert p.grad is not None, name
+            assert_close(p.grad, ref, "grad " + name, tol)
+
+
+# --------------------------------------------------------------------------- K7 / K6 / K1
+def test_csr_plan_is_a_stable_sort():
+    gen = torch.Generator().manual_seed(0)
+    n, E = 37, 900
+    nbrs = torch.randint(0, n, (E, 2), generator=gen)
+    plan = EdgePlan.from_nbrs(nbrs.to(DEV), n)
+    for key_col, rowptr, eid, dst, src in ((0, plan.rowptr_d, plan.eid_d, plan.dst_d, plan.src_d),
+                                           (1, plan.rowptr_s, plan.eid_s, plan.dst_s, plan.src_s)):
+        order = np.argsort(nbrs[:, key_col].numpy(), kind="stable")
+        assert np.array_equal(eid.cpu().numpy(), order)
+        assert np.array_equal(dst.cpu().numpy(), nbrs[order, 0].numpy())
+        assert np.array_equal(src.cpu().numpy(), nbrs[order, 1].numpy())
+        want = np.searchsorted(nbrs[order, key_col].numpy(), np.arange(n + 1), side="left")
+        assert np.array_equal(rowptr.cpu().numpy(), want)
+    empty = EdgePlan.from_nbrs(torch.zeros(0, 2, dtype=torch.long, device=DEV), 5)
+    assert empty.rowptr_d.cpu().tolist() == [0] * 6
+    mp = EdgePlan.from_mapping(torch.tensor([2, 0, 0, 1, 2, 2], device=DEV), 4)
+    assert mp.rowptr_d.cpu().tolist() == [0, 2, 3, 6, 6]
+    assert mp.src_d.cpu().tolist() == [1, 2, 3, 0, 4, 5]
+    assert mp.rowptr_s.cpu().tolist() == list(range(7)) and mp.dst_s.cpu().tolist() == [2, 0, 0, 1, 2, 2]
+
+
+@pytest.mark.parametrize("R,cutoff", [(8, 6.0), (10, 3.0), (10, 25.0)])
+def test_edge_geometry_matches_oracle(R, cutoff):
+    gen = torch.Generator().manual_seed(1)
+    n = 50
+    xyz = torch.rand(n, 3, generator=gen) * 5
+    xyz[7] = xyz[3]                                       # coincident pair: d = sqrt(3e-8)
+    und = O.get_neighbor_list(xyz, 4.5, True)
+    nbrs, _ = O.make_directed(und)
+    nbrs = torch.cat([nbrs, torch.tensor([[3, 7], [7, 3]])])
+    r = xyz[nbrs[:, 1]] - xyz[nbrs[:, 0]]
+    dist, unit = O.preprocess_r(r)
+    env = O.cosine_envelope(dist, cutoff)
+    want = torch.cat([O.painn_rbf(dist, R, cutoff) * env[:, None], env[:, None], unit], dim=1)
+    plan = EdgePlan.from_nbrs(nbrs.to(DEV), n)
+    for geom in (EdgeGeometry(plan, R, cutoff, r_edges=r.to(DEV)),
+                 EdgeGeometry(plan, R, cutoff, pos_dst=xyz.to(DEV), pos_src=xyz.to(DEV))):
+        got_d = geom.geom_d[:, :R + 4].cpu()
+        got_s = geom.geom_s[:, :R + 4].cpu()
+        assert_close(got_d, want[plan.eid_d.cpu().long()], "geom_d", 2e-6)
+        assert_close(got_s, want[plan.eid_s.cpu().long()], "geom_s", 2e-6)
+    assert (want[:, :R].abs().sum(1) == 0).any() or cutoff > 4.5      # beyond-cutoff rows exercised for cutoff 3.0
+
+
+def test_scatter_matches_reference_semantics():
+    g = load_golden("g5_scatter")
+    idx = dev(g["index"])
+    assert_close(cg.scatter_add(dev(g["src2"]), idx, dim=0, dim_size=7), g["add2"], "add2", 1e-6)
+    assert_close(cg.scatter_add(dev(g["src3"]), idx, dim=0), g["add3"], "add3", 1e-6)
+    assert_close(cg.scatter_mean(dev(g["src2"]), idx, dim=0), g["mean2"], "mean2", 1e-6)
+    assert_close(cg.scatter_mean(dev(g["src3"]), idx, dim=0, dim_size=7), g["mean3"], "mean3", 1e-6)
+
+
+@pytest.mark.parametrize("E,C,n", [(5000, 1800, 97), (300, 7, 11), (1, 4, 3), (4096, 600, 1)])
+def test_scatter_add_and_grad_vs_fp64(E, C, n):
+    gen = torch.Generator().manual_seed(E)
+    src = torch.randn(E, C, generator=gen)
+    idx = torch.randint(0, n, (E,), generator=gen)
+    want = torch.zeros(n, C, dtype=torch.float64).index_add_(0, idx, src.double())
+    x = src.to(DEV).requires_grad_(True)
+    out = cg.scatter_add(x, idx.to(DEV), dim_size=n)
+    assert_close(out, want, "scatter_add", 1e-6)
+    gout = torch.randn(n, C, generator=gen)
+    out.backward(gout.to(DEV))
+    assert torch.equal(x.grad.cpu(), gout[idx])
+    mean = cg.scatter_mean(src.to(DEV), idx.to(DEV), dim_size=n)
+    cnt = torch.bincount(idx, minlength=n).clamp(min=1)[:, None]
+    assert_close(mean, want / cnt, "scatter_mean", 1e-6)
+
+
+# --------------------------------------------------------------------------- K2 / K4 blocks vs golden
+@pytest.mark.parametrize("tag", ["F8R8", "F24R10"])
+def test_equi_message_block_golden(tag):
+    g = load_golden(f"g1_equi_message_{tag}")
+    F = g["s"].shape[1]
+    blk = load_block(cg.EquiMessageBlock(F, "swish", int(g["R"]), float(g["cutoff"]), 0.0), g)
+    s = dev(g["s"]).requires_grad_(True)
+    v = dev(g["v"]).requires_grad_(True)
+    ds, dv = blk(s, v, dev(g["r_ij"]), dev(g["nbrs"]))
+    assert_close(ds, g["ds"], "ds")
+    assert_close(dv, g["dv"], "dv")
+    ((ds * dev(g["gout_s"])).sum() + (dv * dev(g["gout_v"])).sum()).backward()
+    assert_close(s.grad, g["gin_s"], "grad s")
+    assert_close(v.grad, g["gin_v"], "grad v")
+    check_param_grads(blk, g)
+
+
+@pytest.mark.parametrize("tag", ["F8R8", "F24R10"])
+def test_equi_message_block_scalar_only_backward(tag):
+    """gv = None path (the encoder's case: the vector channel is never consumed)."""
+    g = load_golden(f"g1_equi_message_{tag}")
+    F = g["s"].shape[1]
+    P = {"blk." + k[2:]: t(v).clone().requires_grad_(True) for k, v in g.items() if k.startswith("p.")}
+    s0 = t(g["s"]).requires_grad_(True)
+    ds0, _ = O.equi_message_block(s0, t(g["v"]), t(g["r_ij"]), t(g["nbrs"]), P, "blk", O.swish, int(g["R"]),
+                                  float(g["cutoff"]))
+    (ds0 * t(g["gout_s"])).sum().backward()
+    for with_dv in (True, False):
+        blk = load_block(cg.EquiMessageBlock(F, "swish", int(g["R"]), float(g["cutoff"]), 0.0), g)
+        blk.with_dv = with_dv
+        s = dev(g["s"]).requires_grad_(True)
+        ds, dv = blk(s, dev(g["v"]), dev(g["r_ij"]), dev(g["nbrs"]))
+        assert_close(ds, g["ds"], "ds")
+        if not with_dv:
+            assert float(dv.abs().max()) == 0.0
+        (ds * dev(g["gout_s"])).sum().backward()
+        assert_close(s.grad, s0.grad, "grad s (scalar only)")
+        for name, p in blk.named_parameters():
+            ref = P["blk." + name].grad
+            if ref is None:
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            else:
+                assert_close(p.grad, ref, "grad " + name)
+
+
+@pytest.mark.parametrize("tag", ["F8R8", "F24R10"])
+def test_contractive_block_golden(tag):
+    g = load_golden(f"g1_contractive_{tag}")
+    F = g["s"].shape[1]
+    blk = load_block(cg.ContractiveMessageBlock(F, "swish", int(g["R"]), float(g["cutoff"]), 0.0), g)
+    s = dev(g["s"]).requires_grad_(True)
+    v = dev(g["v"]).requires_grad_(True)
+    dS, dV = blk(s, v, dev(g["r_iI"]), dev(g["mapping"]))
+    assert_close(dS, g["dS"], "dS")
+    assert_close(dV, g["dV"], "dV")
+    ((dS * dev(g["gout_S"])).sum() + (dV * dev(g["gout_V"])).sum()).backward()
+    assert_close(s.grad, g["gin_s"], "grad s")
+    assert_close(v.grad, g["gin_v"], "grad v")
+    check_param_grads(blk, g)
+
+
+@pytest.mark.parametrize("tag", ["F8R8", "F24R10"])
+def test_equi_pseudo_block_golden(tag):
+    g = load_golden(f"g1_equi_pseudo_{tag}")
+    F = g["s"].shape[1]
+    blk = load_block(cg.EquiMessagePsuedo(F, "swish", int(g["R"]), float(g["cutoff"]), 0.0), g)
+    ins = [dev(g[k]).requires_grad_(True) for k in ("s", "sbar", "v", "vbar")]
+    outs = blk(*ins, dev(g["r_ij"]), dev(g["nbrs"]))
+    for o, k in zip(outs, ("dh", "dhbar", "dv", "dvbar")):
+        assert_close(o, g[k], k)
+    sum((o * dev(g["gout_" + k])).sum() for o, k in zip(outs, ("h", "hbar", "v", "vbar"))).backward()
+    for x, k in zip(ins, ("s", "sbar", "v", "vbar")):
+        assert_close(x.grad, g["gin_" + k], "grad " + k)
+    check_param_grads(blk, g)
+
+
+@pytest.mark.parametrize("tag", ["F8R8", "F24R10"])
+def test_update_block_golden(tag):
+    g = load_golden(f"g1_update_{tag}")
+    F = g["s"].shape[1]
+    blk = load_block(cg.UpdateBlock(F, "swish", 0.0), g)
+    s = dev(g["s"]).requires_grad_(True)
+    v = dev(g["v"]).requires_grad_(True)
+    ds, dv = blk(s, v)
+    assert_close(ds, g["ds"], "ds")
+    assert_close(dv, g["dv"], "dv")
+    ((ds * dev(g["gout_s"])).sum() + (dv * dev(g["gout_v"])).sum()).backward()
+    assert_close(s.grad, g["gin_s"], "grad s")
+    assert_close(v.grad, g["gin_v"], "grad v")
+    check_param_grads(blk, g)
+
+
+# --------------------------------------------------------------------------- model level vs golden
+def _golden_model(g, det=False):
+    m = cg.build_model(int(g["F"]), int(g["R"]), float(g["atom_cutoff"]), float(g["cg_cutoff"]),
+                       int(g["enc_nconv"]), int(g["dec_nconv"]), int(g["n_cgs"]), det=det, seed=None)
+    m.load_state_dict({k[2:]: t(v) for k, v in g.items() if k.startswith("p.")}, strict=True)
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize("tag", ["ncg3", "ncg6"])
+@pytest.mark.parametrize("prepared", [True, False])
+def test_model_forward_loss_and_grads_golden(tag, prepared):
+    g = load_golden(f"g2_model_{tag}")
+    model = _golden_model(g)
+    batch = {k[2:]: dev(v) for k, v in g.items() if k.startswith("b.")}
+    if prepared:
+        batch = cg.prepare_batch(batch)
+    out = model(batch, eps=dev(g["eps"]))
+    for o, k in zip(out, ("mu", "sigma", "prior_mu", "prior_std", "xyz", "xyz_recon")):
+        assert_close(o, g[k], k)
+    loss, kl, recon, graph = cg.loss_terms(out, batch, float(g["beta"]), float(g["gamma"]))
+    for o, k in zip((loss, kl, recon, graph), ("loss", "kl", "recon", "graph")):
+        assert_close(o, g[k], k)
+    loss.backward()
+    live = set(g["live_params"].tolist())
+    for name, p in model.named_parameters():
+        if name in live:
+            assert p.grad is not None, name
+            assert_close(p.grad, g["g." + name], "grad " + name, 2e-4)
+        else:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+    det = _golden_model(g, det=True)
+    out_det = det(batch)
+    assert_close(out_det[5], g["det_xyz_recon"], "det xyz_recon")
+
+
+@pytest.mark.parametrize("tag", ["ncg3"])
+def test_skip_dead_vector_channel_is_output_neutral(tag):
+    g = load_golden(f"g2_model_{tag}")
+    model = _golden_model(g, det=True)
+    batch = cg.prepare_batch({k[2:]: dev(v) for k, v in g.items() if k.startswith("b.")})
+    ref = [o.clone() for o in model(batch)]
+    model.encoder.set_skip_dead_vector_channel(True)
+    model.prior_net.set_skip_dead_vector_channel(True)
+    for a, b in zip(model(batch), ref):
+        assert torch.equal(a, b)
+
+
+# --------------------------------------------------------------------------- K0 radius graph
+def test_radius_graph_bit_exact_golden():
+    g = load_golden("g3_radius_graph")
+    for name in sorted({k.split(".")[0] for k in g}):
+        xyz, cut = g[name + ".xyz"], float(g[name + ".cutoff"])
+        for und, key in ((True, "und"), (False, "dir")):
+            got = cg.get_neighbor_list(xyz, DEV, cut, undirected=und).cpu().numpy()
+            assert got.dtype == np.int64 and np.array_equal(got, g[f"{name}.{key}"]), (name, key)
+
+
+def test_radius_graph_batched_matches_oracle_per_frame():
+    gen = torch.Generator().manual_seed(4)
+    sizes = [22, 1, 166, 64, 2]
+    frames = [torch.rand(n, 3, generator=gen) * 12.0 for n in sizes]
+    fp = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32)
+    for cutoff, und in ((8.5, True), (12.0, False), (3.0, True)):
+        got = cg.radius_graph(torch.cat(frames).to(DEV), fp.to(DEV), cutoff, und).cpu()
+        want = torch.cat([O.get_neighbor_list(x, cutoff, und) + int(o) for x, o in zip(frames, fp[:-1])])
+        assert torch.equal(got, want)
+
+
+# --------------------------------------------------------------------------- full-size parity vs live oracle
+def _oracle_params_from(model):
+    return {k: v.detach().cpu().clone().requires_grad_(v.dtype == torch.float32) for k, v in model.state_dict().items()}
+
+
+def test_full_width_block_vs_oracle_F600():
+    """EquiMessageBlock at the real width (F=600, R=8, dipeptide-like graph) against the oracle."""
+    torch.manual_seed(0)
+    F, R, cutoff, n = 600, 8, 9.5, 66
+    gen = torch.Generator().manual_seed(2)
+    xyz = torch.rand(n, 3, generator=gen) * 6.0
+    nbrs, _ = O.make_directed(O.get_neighbor_list(xyz, 8.5, True))
+    r = xyz[nbrs[:, 1]] - xyz[nbrs[:, 0]]
+    blk = cg.EquiMessageBlock(F, "swish", R, cutoff, 0.0)
+    for p in blk.parameters():
+        if p.dim() == 1:
+            p.data.normal_(0, 0.2)
+    P = {"b." + k: v.detach().clone().requires_grad_(True) for k, v in blk.state_dict().items()}
+    s = torch.randn(n, F, generator=gen)
+    v = torch.randn(n, F, 3, generator=gen)
+    gs, gv = torch.randn(n, F, generator=gen), torch.randn(n, F, 3, generator=gen)
+    s0, v0 = s.clone().requires_grad_(True), v.clone().requires_grad_(True)
+    ds0, dv0 = O.equi_message_block(s0, v0, r, nbrs, P, "b", O.swish, R, cutoff)
+    ((ds0 * gs).sum() + (dv0 * gv).sum()).backward()
+    blk = blk.to(DEV)
+    s1, v1 = s.to(DEV).requires_grad_(True), v.to(DEV).requires_grad_(True)
+    ds1, dv1 = blk(s1, v1, r.to(DEV), nbrs.to(DEV))
+    ((ds1 * gs.to(DEV)).sum() + (dv1 * gv.to(DEV)).sum()).backward()
+    assert_close(ds1, ds0, "ds")
+    assert_close(dv1, dv0, "dv")
+    assert_close(s1.grad, s0.grad, "grad s")
+    assert_close(v1.grad, v0.grad, "grad v")
+    for name, p in blk.named_parameters():
+        ref = P["b." + name].grad
+        if ref is not None:
+            assert_close(p.grad, ref, "grad " + name)
+
+
+@pytest.mark.parametrize("workload,n_frames,F", [("dipeptide", 4, 600), ("chignolin", 1, 128)])
+def test_model_step_vs_live_oracle(workload, n_frames, F):
+    """Whole model (run_ala wiring) on synthetic frames: outputs, ELBO terms and gradients
+    against the CPU oracle run live on the host cores."""
+    w = cg.data.WORKLOADS[workload]
+    batch = cg.synthetic_batch(workload, n_frames=n_frames, seed=0, device=DEV)
+    model = cg.build_model(F, w["n_rbf"], w["atom_cutoff"], w["cg_cutoff"], w["enc_nconv"], w["dec_nconv"],
+                           w["n_cgs"], seed=123)
+    hp = O.Hyper(F, w["n_rbf"], w["atom_cutoff"], w["cg_cutoff"], w["enc_nconv"], w["dec_nconv"], w["n_cgs"])
+    P = _oracle_params_from(model)
+    cpu_batch = {k: v.cpu() for k, v in batch.items() if torch.is_tensor(v)}
+    # the device radius graph must equal the oracle's, bit for bit
+    start = 0
+    for k in range(n_frames):
+        fr = cpu_batch["nxyz"][start:start + w["n_atoms"], 1:]
+        want = O.get_neighbor_list(fr, w["atom_cutoff"], True) + start
+        sel = (cpu_batch["nbr_list"][:, 0] >= start) & (cpu_batch["nbr_list"][:, 0] < start + w["n_atoms"])
+        assert torch.equal(cpu_batch["nbr_list"][sel], want)
+        start += w["n_atoms"]
+    eps = torch.randn(cpu_batch["CG_nxyz"].shape[0], F, generator=torch.Generator().manual_seed(9))
+    out0 = O.model_forward(cpu_batch, P, hp, eps=eps)
+    loss0, kl0, recon0, graph0 = O.loss_terms(out0, cpu_batch, w["beta"], w["gamma"])
+    loss0.backward()
+    model = model.to(DEV)
+    out1 = model(batch, eps=eps.to(DEV))
+    loss1, kl1, recon1, graph1 = cg.loss_terms(out1, batch, w["beta"], w["gamma"])
+    loss1.backward()
+    for a, b, k in zip(out1, out0, ("mu", "sigma", "prior_mu", "prior_std", "xyz", "xyz_recon")):
+        assert_close(a, b, k)
+    for a, b, k in ((loss1, loss0, "loss"), (kl1, kl0, "kl"), (recon1, recon0, "recon"), (graph1, graph0, "graph")):
+        assert_close(a, b, k)
+    n_live = 0
+    for name, p in model.named_parameters():
+        ref = P[name].grad
+        if ref is None or float(ref.abs().max()) == 0.0:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+        else:
+            n_live += 1
+            assert_close(p.grad, ref, "grad " + name, 5e-4)
+    assert n_live > 50
+
+
+def test_rotation_equivariance_and_translation_invariance():
+    """Properties the reference never tested: xyz_recon rotates with the input, mu does not move."""
+    w = cg.data.WORKLOADS["dipeptide"]
+    batch = cg.synthetic_batch("dipeptide", n_frames=2, seed=3, device=DEV)
+    model = cg.build_model(64, w["n_rbf"], w["atom_cutoff"], w["cg_cutoff"], 2, 2, w["n_cgs"], det=True).to(DEV)
+    out = model(batch)
+    Q, _ = torch.linalg.qr(torch.randn(3, 3, generator=torch.Generator().manual_seed(1)))
+    if torch.det(Q) < 0:
+        Q[:, 0] = -Q[:, 0]
+    Q = Q.to(DEV)
+    shift = torch.tensor([1.5, -2.0, 0.7], device=DEV)
+    b2 = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items() if k != "_graph"}
+    b2["nxyz"][:, 1:] = batch["nxyz"][:, 1:] @ Q.T + shift
+    b2["CG_nxyz"][:, 1:] = batch["CG_nxyz"][:, 1:] @ Q.T + shift
+    out2 = model(cg.prepare_batch(b2))
+    assert_close(out2[0], out[0], "mu invariance", 1e-4)
+    assert_close(out2[5], out[5] @ Q.T + shift, "xyz_recon equivariance", 1e-4)

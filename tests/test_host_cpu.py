@@ -1,0 +1,117 @@
+"""CPU-side checks of the product package: the C-ABI library loads and exports every symbol
+the header declares, host logic (collate, thresholds, state_dict layout) matches the
+reference's golden vectors, and the product refuses to run without device tensors."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import coarsegrainingvae_amd as cg
+from coarsegrainingvae_amd import _lib
+from coarsegrainingvae_amd.graph import cutoff_threshold_sq
+from conftest import load_golden
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_library_loads_and_exports_every_header_symbol():
+    assert os.path.exists(_lib.LIB_PATH), "run `python -m coarsegrainingvae_amd.build` first"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    declared = _lib.header_symbols()
+    assert len(declared) >= 14
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/cgvae_hip.h but not exported"
+    assert sorted(_lib.PROTOTYPES) == declared, "ctypes prototypes out of sync with the header"
+    loaded = _lib.load()
+    assert loaded.cgv_version() >= 100
+    assert loaded.cgv_geom_stride(8) == 12 and loaded.cgv_geom_stride(10) == 16
+    assert loaded.cgv_rbf_supported(8) and loaded.cgv_rbf_supported(10) and not loaded.cgv_rbf_supported(9)
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    lib = _lib.load()
+    rc = lib.cgv_equi_msg_fwd(None, None, None, None, None, None, None, None, None, 4, 8, 8, 1, None)
+    assert rc == -1 and b"null" in lib.cgv_last_error_string()
+    with pytest.raises(RuntimeError, match="cgv_segment_reduce failed"):
+        _lib.call("cgv_segment_reduce", None, None, None, 3, 8, 0, None, None)
+
+
+def test_product_fails_loudly_on_cpu_tensors():
+    blk = cg.EquiMessageBlock(feat_dim=8, activation="swish", n_rbf=8, cutoff=5.0, dropout=0.0)
+    s, v = torch.randn(5, 8), torch.randn(5, 8, 3)
+    nbrs = torch.tensor([[0, 1], [1, 0], [2, 3], [3, 2]])
+    r = torch.randn(4, 3)
+    with pytest.raises(RuntimeError):
+        blk(s, v, r, nbrs)
+    with pytest.raises(RuntimeError):
+        cg.scatter_add(torch.randn(4, 3), torch.tensor([0, 1, 1, 0]), dim_size=2)
+
+
+@pytest.mark.parametrize("tag", ["ncg3", "ncg6"])
+def test_collate_matches_reference(tag):
+    g = load_golden(f"g2_model_{tag}")
+    frames, i = [], 0
+    while f"f{i}.nxyz" in g:
+        frames.append({k.split(".", 1)[1]: t(v) for k, v in g.items() if k.startswith(f"f{i}.")})
+        i += 1
+    keep = [{k: v.clone() for k, v in f.items()} for f in frames]
+    batch = cg.CG_collate(frames)
+    for k, v in batch.items():
+        assert np.array_equal(v.numpy(), g["b." + k]) and v.numpy().dtype == g["b." + k].dtype, k
+    for f, k0 in zip(frames, keep):          # inputs untouched (the reference mutates them)
+        for k in f:
+            assert torch.equal(f[k], k0[k])
+
+
+def test_make_directed_matches_reference():
+    g = load_golden("g4_make_directed")
+    for name in ("und", "already", "rev_only", "empty"):
+        out, flag = cg.make_directed(t(g[name + ".in"]))
+        assert np.array_equal(out.numpy(), g[name + ".out"]) and flag == bool(g[name + ".flag"])
+    again, _ = cg.make_directed(cg.make_directed(t(g["und.in"]))[0])       # idempotent
+    assert np.array_equal(again.numpy(), g["und.out"])
+
+
+@pytest.mark.parametrize("cutoff", [4.0, 6.5, 8.5, 9.5, 12.0, 25.0, 0.1, 3.3333])
+def test_cutoff_threshold_reproduces_host_sqrt_rule(cutoff):
+    s_star = np.float32(cutoff_threshold_sq(cutoff))
+    rng = np.random.default_rng(0)
+    c2 = np.float32(cutoff) ** 2
+    x = (c2 * (1 + rng.uniform(-4e-6, 4e-6, 100000))).astype(np.float32)
+    ref = (torch.sqrt(torch.from_numpy(x)) <= cutoff).numpy()
+    assert np.array_equal(ref, x <= s_star)
+    assert ref.any() and not ref.all()
+
+
+@pytest.mark.parametrize("tag", ["ncg3", "ncg6"])
+def test_state_dict_layout_and_same_seed_init(tag):
+    g = load_golden("g7_init")
+    n_cgs, F, R, enc, dec = (int(x) for x in g[f"{tag}.cfg"])
+    m = cg.build_model(F, R, 8.5, 9.5, enc, dec, n_cgs, seed=123)
+    sd = m.state_dict()
+    assert list(sd.keys()) == g[f"{tag}.names"].tolist()
+    assert [",".join(map(str, v.shape)) for v in sd.values()] == g[f"{tag}.shapes"].tolist()
+    sums = np.array([float(v.double().sum()) for v in sd.values()])
+    np.testing.assert_allclose(sums, g[f"{tag}.sum"], rtol=1e-9, atol=1e-9)
+
+
+def test_reference_state_dict_loads():
+    g = load_golden("g2_model_ncg3")
+    m = cg.build_model(int(g["F"]), int(g["R"]), float(g["atom_cutoff"]), float(g["cg_cutoff"]),
+                       int(g["enc_nconv"]), int(g["dec_nconv"]), int(g["n_cgs"]), seed=None)
+    sd = {k[2:]: t(v) for k, v in g.items() if k.startswith("p.")}
+    missing, unexpected = m.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+
+
+def test_kl_and_loss_match_reference_terms():
+    g = load_golden("g2_model_ncg6")
+    out = tuple(t(g[k]) for k in ("mu", "sigma", "prior_mu", "prior_std", "xyz", "xyz_recon"))
+    batch = {"bond_edge_list": t(g["b.bond_edge_list"])}
+    loss, kl, recon, graph = cg.loss_terms(out, batch, float(g["beta"]), float(g["gamma"]))
+    for got, key in ((loss, "loss"), (kl, "kl"), (recon, "recon"), (graph, "graph")):
+        np.testing.assert_allclose(got.numpy(), g[key], rtol=1e-5)
