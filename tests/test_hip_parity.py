@@ -114,13 +114,13 @@ def test_scatter_add_and_grad_vs_fp64(E, C, n):
     want = torch.zeros(n, C, dtype=torch.float64).index_add_(0, idx, src.double())
     x = src.to(DEV).requires_grad_(True)
     out = cg.scatter_add(x, idx.to(DEV), dim_size=n)
-    assert_close(out, want, "scatter_add", 1e-6)
+    assert_close(out, want, "scatter_add", 1e-5)   # fp32 running sum of up to 4096 rows vs fp64
     gout = torch.randn(n, C, generator=gen)
     out.backward(gout.to(DEV))
     assert torch.equal(x.grad.cpu(), gout[idx])
     mean = cg.scatter_mean(src.to(DEV), idx.to(DEV), dim_size=n)
     cnt = torch.bincount(idx, minlength=n).clamp(min=1)[:, None]
-    assert_close(mean, want / cnt, "scatter_mean", 1e-6)
+    assert_close(mean, want / cnt, "scatter_mean", 1e-5)
 
 
 # --------------------------------------------------------------------------- K2 / K4 blocks vs golden
