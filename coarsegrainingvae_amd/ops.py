@@ -132,76 +132,114 @@ def scatter_mean(src: torch.Tensor, index: torch.Tensor, dim: int = 0, dim_size:
     return segment_reduce(src, plan or _index_plan(index, dim_size), mean=True)
 
 
-# ----------------------------------------------------------------------------- K3 (interim composition)
-def _edge_filter(Wd, bd, geom_rows, n_rbf):
-    """w[e, c] = sum_n Wd[c,n] a_n(e) + bd[c] env(e) from the K6 records (modules.py:192-197)."""
-    return geom_rows[:, :n_rbf] @ Wd.t() + geom_rows[:, n_rbf:n_rbf + 1] * bd
+# ----------------------------------------------------------------------------- K3
+class _PseudoMessage(torch.autograd.Function):
+    """dh, dhbar, dv, dvbar of EquiMessagePsuedo from phi = inv_dense(s) (conv.py:190-242)."""
+
+    @staticmethod
+    def forward(ctx, phi, s, sbar, v, vbar, Wd, bd, plan: EdgePlan, geom: EdgeGeometry):
+        phi, s, sbar, v, vbar, Wd, bd = (_c(t) for t in (phi, s, sbar, v, vbar, Wd, bd))
+        n, F = s.shape
+        if plan.n_dst != n or plan.n_src != n or phi.shape != (n, 9 * F) or Wd.shape != (9 * F, geom.n_rbf):
+            raise RuntimeError("shape mismatch between node features, filter weights and the edge plan")
+        dh, dhbar = torch.empty_like(s), torch.empty_like(s)
+        dv, dvbar = torch.empty_like(v), torch.empty_like(v)
+        _lib.call("cgv_pseudo_msg_fwd", _lib.ptr(phi), _lib.ptr(s), _lib.ptr(sbar), _lib.ptr(v), _lib.ptr(vbar),
+                  _lib.ptr(geom.geom_d), _lib.ptr(plan.rowptr_d), _lib.ptr(plan.src_d), _lib.ptr(Wd), _lib.ptr(bd),
+                  _lib.ptr(dh), _lib.ptr(dhbar), _lib.ptr(dv), _lib.ptr(dvbar), n, F, geom.n_rbf, _lib.stream_ptr(),
+                  tag=f"pseudo_msg_fwd:Nd{n}:E{plan.n_edges}:dv1")
+        ctx.save_for_backward(phi, s, sbar, v, vbar, Wd, bd)
+        ctx.plan, ctx.geom = plan, geom
+        ctx.set_materialize_grads(False)
+        return dh, dhbar, dv, dvbar
+
+    @staticmethod
+    def backward(ctx, gh, ghb, gv, gvb):
+        phi, s, sbar, v, vbar, Wd, bd = ctx.saved_tensors
+        plan, geom = ctx.plan, ctx.geom
+        if gh is None and ghb is None and gv is None and gvb is None:
+            return (None,) * 9
+        gh, ghb, gv, gvb = _c(gh), _c(ghb), _c(gv), _c(gvb)
+        n, F = s.shape
+        g_phi = torch.empty_like(phi)
+        g_s, g_sbar = torch.empty_like(s), torch.empty_like(s)
+        g_v, g_vbar = torch.empty_like(v), torch.empty_like(v)
+        gWd, gbd = torch.empty_like(Wd), torch.empty_like(bd)
+        lib = _lib.load()
+        ws_bytes = int(lib.cgv_pseudo_msg_bwd_workspace_bytes(n, F, geom.n_rbf))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=s.device)
+        _lib.call("cgv_pseudo_msg_bwd", _lib.ptr(phi), _lib.ptr(s), _lib.ptr(sbar), _lib.ptr(v), _lib.ptr(vbar),
+                  _lib.ptr(geom.geom_d), _lib.ptr(plan.rowptr_d), _lib.ptr(plan.src_d),
+                  _lib.ptr(geom.geom_s), _lib.ptr(plan.rowptr_s), _lib.ptr(plan.dst_s), _lib.ptr(Wd), _lib.ptr(bd),
+                  _lib.ptr(gh), _lib.ptr(ghb), _lib.ptr(gv), _lib.ptr(gvb),
+                  _lib.ptr(g_phi), _lib.ptr(g_s), _lib.ptr(g_sbar), _lib.ptr(g_v), _lib.ptr(g_vbar),
+                  _lib.ptr(gWd), _lib.ptr(gbd), n, F, geom.n_rbf, _lib.ptr(ws), ws_bytes, _lib.stream_ptr(),
+                  tag=f"pseudo_msg_bwd:Nd{n}:E{plan.n_edges}:gv1")
+        return g_phi, g_s, g_sbar, g_v, g_vbar, gWd, gbd, None, None
 
 
 def pseudo_message(phi, s, sbar, v, vbar, Wd, bd, plan: EdgePlan, geom: EdgeGeometry):
-    """EquiMessagePsuedo after the node MLP (conv.py:190-242) on the destination-sorted view.
-    Device tensor-op composition around the K6 geometry and the K1 segment reduction; the bead
-    graph is tiny (Ecg <= a few thousand)."""
-    R, F = geom.n_rbf, s.shape[1]
-    E = plan.n_edges
-    g = geom.geom_d[:E]
-    i, j = plan.dst_d[:E].long(), plan.src_d[:E].long()
-    q = (phi[j] * _edge_filter(Wd, bd, g, R)).reshape(E, 9, F)
-    unit = g[:, R + 1:R + 4].unsqueeze(1)
-    vi, vj, vbi, vbj = v[i], v[j], vbar[i], vbar[j]
-    sbi = sbar[i].unsqueeze(-1)
-    qs = [q[:, k, :].unsqueeze(-1) for k in range(9)]
-    d_s = q[:, 0, :] * s[i]
-    d_sbar = (vi * vbj).sum(-1)
-    d_v = qs[1] * unit + qs[2] * vj + qs[3] * torch.linalg.cross(vi, vbj, dim=-1) + qs[4] * sbi * vbj
-    d_vbar = qs[5] * vbj + qs[6] * sbi * vj + qs[7] * torch.linalg.cross(vi, vj, dim=-1) \
-        + qs[8] * torch.linalg.cross(vbi, vbj, dim=-1)
-    seg = _SortedSegments(plan)
-    return seg(d_s), seg(d_sbar), seg(d_v), seg(d_vbar)
+    return _PseudoMessage.apply(phi, s, sbar, v, vbar, Wd, bd, plan, geom)
 
 
-class _SortedSegments:
-    """Segment sums of rows that are already in destination-sorted order (perm = identity)."""
-
-    def __init__(self, plan: EdgePlan):
-        self.plan = plan
-
-    def __call__(self, rows):
-        return _SortedReduce.apply(rows, self.plan)
-
-
-class _SortedReduce(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, rows, plan):
-        rows = _c(rows)
-        flat = rows.reshape(rows.shape[0], -1)
-        C = flat.shape[1]
-        out = torch.empty((plan.n_dst, C), dtype=_F32, device=rows.device)
-        _lib.call("cgv_segment_reduce", _lib.ptr(flat), _lib.ptr(plan.rowptr_d), None, plan.n_dst, C, 0,
-                  _lib.ptr(out), _lib.stream_ptr())
-        ctx.plan, ctx.shape = plan, tuple(rows.shape)
-        return out.reshape((plan.n_dst,) + tuple(rows.shape[1:]))
+# ----------------------------------------------------------------------------- K5
+class _UpdateNormStack(torch.autograd.Function):
+    """stack = [ s | ||Vv||_eps ]  (conv.py:600-601) -- one launch instead of pow/add/sum/sqrt/cat."""
 
     @staticmethod
-    def backward(ctx, gout):
-        plan = ctx.plan
-        gout = _c(gout).reshape(plan.n_dst, -1)
-        C = gout.shape[1]
-        g = torch.empty((ctx.shape[0], C), dtype=_F32, device=gout.device)
-        _lib.call("cgv_segment_broadcast", _lib.ptr(gout), _lib.ptr(plan.rowptr_d), None, plan.n_dst, C, 0,
-                  _lib.ptr(g), _lib.stream_ptr())
-        return g.reshape(ctx.shape), None
+    def forward(ctx, s, Vv):
+        s, Vv = _c(s), _c(Vv)
+        n, F = s.shape
+        stack = torch.empty(n, 2 * F, dtype=_F32, device=s.device)
+        _lib.call("cgv_update_norm_stack_fwd", _lib.ptr(s), _lib.ptr(Vv), _lib.ptr(stack), n, F, _lib.stream_ptr())
+        ctx.save_for_backward(Vv, stack)
+        return stack
+
+    @staticmethod
+    def backward(ctx, gstack):
+        Vv, stack = ctx.saved_tensors
+        n, F = stack.shape[0], stack.shape[1] // 2
+        g_s = torch.empty(n, F, dtype=_F32, device=stack.device)
+        gVv = torch.empty_like(Vv)
+        _lib.call("cgv_update_norm_stack_bwd", _lib.ptr(_c(gstack)), _lib.ptr(Vv), _lib.ptr(stack), _lib.ptr(g_s),
+                  _lib.ptr(gVv), n, F, _lib.stream_ptr())
+        return g_s, gVv
 
 
-# ----------------------------------------------------------------------------- K5 (interim composition)
+class _UpdateGate(torch.autograd.Function):
+    """ds, dv from U, Vv and the gates a = (a_vv, a_sv, a_ss)  (conv.py:603-614)."""
+
+    @staticmethod
+    def forward(ctx, U, Vv, a):
+        U, Vv, a = _c(U), _c(Vv), _c(a)
+        n, _, F = U.shape
+        ds = torch.empty(n, F, dtype=_F32, device=U.device)
+        dv = torch.empty(n, F, 3, dtype=_F32, device=U.device)
+        _lib.call("cgv_update_gate_fwd", _lib.ptr(U), _lib.ptr(Vv), _lib.ptr(a), _lib.ptr(ds), _lib.ptr(dv), n, F,
+                  _lib.stream_ptr())
+        ctx.save_for_backward(U, Vv, a)
+        ctx.set_materialize_grads(False)
+        return ds, dv
+
+    @staticmethod
+    def backward(ctx, g_ds, g_dv):
+        U, Vv, a = ctx.saved_tensors
+        if g_ds is None and g_dv is None:
+            return None, None, None
+        n, _, F = U.shape
+        gU, gVv, ga = torch.empty_like(U), torch.empty_like(Vv), torch.empty_like(a)
+        _lib.call("cgv_update_gate_bwd", _lib.ptr(U), _lib.ptr(Vv), _lib.ptr(a), _lib.ptr(_c(g_ds)), _lib.ptr(_c(g_dv)),
+                  _lib.ptr(gU), _lib.ptr(gVv), _lib.ptr(ga), n, F, _lib.stream_ptr())
+        return gU, gVv, ga
+
+
 def update_block(s, v, u_weight, v_weight, s_dense):
-    """UpdateBlock.forward (conv.py:588-616): four K=F GEMMs + gating."""
+    """UpdateBlock.forward (conv.py:588-616): four K=F GEMMs (hipBLASLt) around two fused
+    element-wise kernels; v is re-laid out once as [N,3,F] rows for the channel-mixing GEMMs."""
     n, F = s.shape
-    vt = v.transpose(1, 2).reshape(-1, F)                       # [3N, F], row = node*3 + xyz
-    U = torch.nn.functional.linear(vt, u_weight).reshape(n, 3, F)
-    Vv = torch.nn.functional.linear(vt, v_weight).reshape(n, 3, F)
-    vnorm = ((Vv ** 2 + 1e-10).sum(1)) ** 0.5
-    a = s_dense(torch.cat([s, vnorm], dim=-1)).reshape(n, 3, F)
-    dv = (U * a[:, 0:1, :]).transpose(1, 2)
-    ds = (U * Vv).sum(1) * a[:, 1, :] + a[:, 2, :]
-    return ds, dv
+    vt = v.transpose(1, 2).reshape(-1, F)                       # [3N, F], row = node*3 + xyz (conv.py:591)
+    U = torch.nn.functional.linear(vt, u_weight).view(n, 3, F)
+    Vv = torch.nn.functional.linear(vt, v_weight).view(n, 3, F)
+    stack = _UpdateNormStack.apply(s, Vv)
+    a = s_dense(stack).view(n, 3, F)
+    return _UpdateGate.apply(U, Vv, a)

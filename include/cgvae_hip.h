@@ -142,6 +142,47 @@ int cgv_equi_msg_bwd(const float* phi, const float* v, const float* geom_s, cons
                      int n_src, int n_feat, int n_rbf, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * K3  fused EquiMessagePsuedo (conv.py:180-242), i = dst (receiver), j = src, q_k = phi[j,kF+f] w_k
+ * with k = 0..8 (phi is [N,9F]), u = unit_e:
+ *   dh    = sum q0 s_i                 dhbar = sum (v_i . vbar_j)      (no filter, conv.py:206)
+ *   dv    = sum q1 u + q2 v_j + q3 (v_i x vbar_j) + q4 sbar_i vbar_j
+ *   dvbar = sum q5 vbar_j + q6 sbar_i v_j + q7 (v_i x v_j) + q8 (vbar_i x vbar_j)
+ * Backward needs both CSR views (receiver-side sums on the dst-sorted one, source-side sums,
+ * g_phi and the filter gradients on the src-sorted one); any upstream gradient may be NULL.
+ * All outputs are written completely.  Derivation: csrc/pseudo_msg.hip.
+ * ------------------------------------------------------------------------------------- */
+int cgv_pseudo_msg_fwd(const float* phi /*[N,9F]*/, const float* s, const float* sbar, const float* v,
+                       const float* vbar, const float* geom_d, const int32_t* rowptr_d, const int32_t* src_d,
+                       const float* Wd /*[9F,R]*/, const float* bd /*[9F]*/, float* dh, float* dhbar, float* dv,
+                       float* dvbar, int n_nodes, int n_feat, int n_rbf, void* stream);
+size_t cgv_pseudo_msg_bwd_workspace_bytes(int n_nodes, int n_feat, int n_rbf);
+int cgv_pseudo_msg_bwd(const float* phi, const float* s, const float* sbar, const float* v, const float* vbar,
+                       const float* geom_d, const int32_t* rowptr_d, const int32_t* src_d,
+                       const float* geom_s, const int32_t* rowptr_s, const int32_t* dst_s,
+                       const float* Wd, const float* bd,
+                       const float* gh, const float* ghbar, const float* gv, const float* gvbar,
+                       float* g_phi /*[N,9F]*/, float* g_s, float* g_sbar, float* g_v, float* g_vbar,
+                       float* gWd /*[9F,R]*/, float* gbd /*[9F]*/, int n_nodes, int n_feat, int n_rbf,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * K5  UpdateBlock element-wise core (conv.py:588-616); the four K=F GEMMs stay with the caller
+ * (hipBLASLt).  U, Vv = u_mat / v_mat applied to v, laid out [N,3,F] (row = node*3 + xyz);
+ * a = s_dense(stack) viewed [N,3,F] = (a_vv, a_sv, a_ss).
+ *   norm_stack: stack[n] = [ s[n,:] | sqrt(sum_k (Vv[n,k,:]^2 + 1e-10)) ]          conv.py:600-601
+ *   gate      : dv[n,f,k] = U[n,k,f] a_vv ;  ds[n,f] = (sum_k U Vv) a_sv + a_ss     conv.py:607-614
+ * and their backward kernels (g_ds / g_dv may be NULL).
+ * ------------------------------------------------------------------------------------- */
+int cgv_update_norm_stack_fwd(const float* s /*[N,F]*/, const float* Vv /*[N,3,F]*/, float* stack /*[N,2F]*/,
+                              int n_nodes, int n_feat, void* stream);
+int cgv_update_norm_stack_bwd(const float* gstack, const float* Vv, const float* stack, float* g_s, float* gVv,
+                              int n_nodes, int n_feat, void* stream);
+int cgv_update_gate_fwd(const float* U, const float* Vv, const float* a, float* ds /*[N,F]*/, float* dv /*[N,F,3]*/,
+                        int n_nodes, int n_feat, void* stream);
+int cgv_update_gate_bwd(const float* U, const float* Vv, const float* a, const float* g_ds, const float* g_dv,
+                        float* gU, float* gVv, float* ga, int n_nodes, int n_feat, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Fused optimiser step over a flat fp32 arena of the parameters that receive gradients --
  * replaces the skip rule, clip_grad_norm_(params, 0.01) and Adam.step() of
  * scripts/utils.py:145-157 (torch.optim.Adam defaults: no amsgrad, no weight decay).
