@@ -89,6 +89,8 @@ class Trainer:
         self.last_loss = None
         self.last_terms = None
         self.steps_skipped_host = 0
+        self._graph = None            # captured hipGraph of one full step (capture())
+        self._graph_batch = None
 
     # ------------------------------------------------------------------ setup after the first backward
     def _build_arena(self):
@@ -108,8 +110,41 @@ class Trainer:
         else:
             self.torch_opt = torch.optim.Adam(live, lr=self.lr, betas=self.betas, eps=self.eps)
 
-    # ------------------------------------------------------------------ one iteration
+    # ------------------------------------------------------------------ hipGraph capture of the whole step
+    def capture(self, batch, warmup: int = 2):
+        """Capture forward + loss + backward (+ all-reduce) + clip/Adam on ``batch`` into one
+        hipGraph.  Every kernel of the step reads sizes that are fixed for a given molecule
+        (N atoms, beads, bonds) and takes its edge structure from device memory (CSR plans), so
+        the step is host-sync free and replayable: ``step(batch)`` on the captured batch object
+        becomes a single graph launch instead of ~1000 eager launches (the kernels are
+        microseconds long at the dipeptide / chignolin sizes -- SURVEY 8f item 1).
+        To train on a new batch of the same shapes, copy it into the captured batch's tensors /
+        plan arrays in place (``data.copy_batch_into``) and replay."""
+        if not self.fused:
+            raise RuntimeError("graph capture needs the fused (sync-free) optimiser path")
+        if self.arena is None:
+            self._step_eager(batch)                        # builds the arena (first backward)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._step_eager(batch)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._step_eager(batch)
+        self._graph, self._graph_batch = graph, batch
+        return graph
+
     def step(self, batch, eps: Optional[torch.Tensor] = None, train: bool = True):
+        if self._graph is not None and batch is self._graph_batch and eps is None and train:
+            self._graph.replay()
+            return self.last_loss
+        return self._step_eager(batch, eps, train)
+
+    # ------------------------------------------------------------------ one iteration
+    def _step_eager(self, batch, eps: Optional[torch.Tensor] = None, train: bool = True):
         out = self.model(batch, eps=eps) if eps is not None else self.model(batch)
         loss, kl, recon, graph = loss_terms(out, batch, self.beta, self.gamma)
         self.last_loss, self.last_terms, self.last_out = loss.detach(), (kl.detach(), recon.detach(), graph.detach()), out
