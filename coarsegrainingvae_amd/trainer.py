@@ -147,7 +147,9 @@ class Trainer:
     def _step_eager(self, batch, eps: Optional[torch.Tensor] = None, train: bool = True):
         out = self.model(batch, eps=eps) if eps is not None else self.model(batch)
         loss, kl, recon, graph = loss_terms(out, batch, self.beta, self.gamma)
-        self.last_loss, self.last_terms, self.last_out = loss.detach(), (kl.detach(), recon.detach(), graph.detach()), out
+        self.last_loss, self.last_terms = loss.detach(), (kl.detach(), recon.detach(), graph.detach())
+        # detached: a retained autograd graph would pin AccumulateGrad nodes to this step's stream
+        self.last_out = tuple(o.detach() if o is not None else None for o in out)
         decision = self.last_loss if self.sync is None else self.sync.mean_scalar(self.last_loss)
         threshold = self.gamma * 200.0
 
