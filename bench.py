@@ -53,12 +53,63 @@ def parse_tag(tag: str):
     return kind, int(nd[2:]), int(e[1:]), int(flag[2:])
 
 
+def scatter_add_roofline(batch, F, reps=20):
+    """Metric 2: standalone K1 segment scatter-add on the shape the reference reduces in every
+    encoder layer, [E, F, 3] -> [N, F, 3] with the (unsorted) receiver index nbrs[:, 0]
+    (conv.py:553-556).  Algorithmic bytes = 4 E C + 4 E + 4 N C, C = 3F."""
+    g = batch["_graph"]
+    E, N, C = g.atom.n_edges, g.atom.n_dst, 3 * F
+    src = torch.randn(E, F, 3, device=g.xyz.device)
+    idx = g.atom_nbrs[:, 0].contiguous()
+    for _ in range(3):
+        out = cg.scatter_add(src, idx, dim_size=N, plan=g.atom)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in ev:
+        a.record()
+        out = cg.scatter_add(src, idx, dim_size=N, plan=g.atom)
+        b.record()
+    torch.cuda.synchronize()
+    us = 1e3 * sum(a.elapsed_time(b) for a, b in ev) / reps
+    by = 4 * E * C + 4 * E + 4 * N * C
+    del src, out
+    return {"kernel": "segment_reduce_k<4,256,8>", "shape": f"[{E},{F},3]->[{N},{F},3]", "bound": "hbm",
+            "achieved": by / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "avg_us": us, "algorithmic_bytes": by, "traffic": None}
+
+
+def optimizer_roofline(trainer, reps=5):
+    """Fused clip+Adam over the live-parameter arena: g read twice, p/m/v read and written once."""
+    if not trainer.fused or trainer.arena is None:
+        return None
+    a = trainer.arena
+    n = a.numel
+    from coarsegrainingvae_amd import _lib
+    scratch_p, scratch_m, scratch_v = a.p.clone(), trainer.m.clone(), trainer.v.clone()
+    state = trainer.state.clone()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for s, e in ev:
+        s.record()
+        _lib.call("cgv_adam_clip_step", _lib.ptr(scratch_p), _lib.ptr(a.g), _lib.ptr(scratch_m), _lib.ptr(scratch_v), n,
+                  1e-4, 0.9, 0.999, 1e-8, 0.01, 1.0, None, 0.0, _lib.ptr(state), _lib.ptr(trainer.partial),
+                  _lib.stream_ptr())
+        e.record()
+    torch.cuda.synchronize()
+    us = 1e3 * sum(s.elapsed_time(e) for s, e in ev[1:]) / (reps - 1)
+    by = 4 * n * 9
+    return {"kernel": "sumsq_partial+optim_finalize+adam_update", "params": n, "bound": "hbm",
+            "achieved": by / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "avg_us": us, "algorithmic_bytes": by}
+
+
 def cpu_baseline(workload: str, F: int, n_frames: int, steps: int):
     """The CPU oracle (oracle/cgvae_oracle.py, an op-for-op restatement of the reference's
     unfused torch path) timed on this box's host cores: the same full training step."""
     from oracle import cgvae_oracle as O
     w = WORKLOADS[workload]
-    threads = torch.get_num_threads()
+    # 8 threads is the fastest setting for this op mix on the GPU box's host (tools/cpu_threads_probe.py:
+    # 8 -> 2.36 s/step, 16 -> 2.39, 32 -> 3.46, 64 -> 5.39 on chignolin) and the survey's own core count
+    threads = min(8, os.cpu_count() or 8)
+    torch.set_num_threads(threads)
     hp = O.Hyper(F, w["n_rbf"], w["atom_cutoff"], w["cg_cutoff"], w["enc_nconv"], w["dec_nconv"], w["n_cgs"])
     P = O.require_grad(O.init_params(hp, seed=123))
     frames = cg.data.synthetic_frames(n_frames, w["n_atoms"], w["n_cgs"], w["box"], seed=0)
@@ -139,23 +190,40 @@ def main():
 
     if rank == 0:
         loss = float(trainer.last_loss)
-        # dominant fused edge kernel of the step, by total event time
+        R = w["n_rbf"]
+        n_atoms_total = int(batch["nxyz"].shape[0])
+
+        def edge_kernel_roofline(tag):
+            """Algorithmic bytes / flops of one fused edge-kernel launch:
+            fwd bytes = 4 Ns (3F phi + 3F v) + 4 Nd 4F (ds, dv) + E (16 + 4R) + 4*3F*(R+1), flops = E F (6R + 20);
+            scalar-only variants (dv0 / gv0) touch one filter slice: flops = E F (2R + 4) fwd, E F (4R + 8) bwd."""
+            kind, nd, ne, flag = parse_tag(tag)
+            ns = n_atoms_total if nd != n_atoms_total and ne == n_atoms_total else nd
+            k = 9 if kind.startswith("pseudo") else 3
+            if kind.endswith("fwd"):
+                by = 4 * ns * (k * F + 3 * F) + 4 * nd * 4 * F + ne * (16 + 4 * R) + 4 * k * F * (R + 1)
+                fl = ne * F * ((6 * R + 20) if flag else (2 * R + 4)) * (k // 3)
+            else:
+                by = 4 * ns * (k * F + F + k * F) + ne * (16 + 4 * R) + 2 * 4 * k * F * (R + 1)
+                fl = ne * F * ((12 * R + 40) if flag else (4 * R + 8)) * (k // 3)
+            us = ksum[tag]["avg_us"]
+            return {"kernel": tag, "bound": "mfma", "achieved": fl / (us * 1e-6) / 1e12, "peak": F32_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": fl / (us * 1e-6) / 1e12 / F32_PEAK_TFLOPS, "traffic": None,
+                    "avg_us": us, "launches": ksum[tag]["launches"], "algorithmic_flops": fl,
+                    "hbm": {"algorithmic_bytes": by, "achieved_GBps": by / (us * 1e-6) / 1e9,
+                            "peak_GBps": HBM_PEAK_GBS, "frac": by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}}
+
         roofline, extra = None, {}
         if ksum:
-            tag = max(ksum, key=lambda k: ksum[k]["total_ms"])
-            kind, nd, ne, flag = parse_tag(tag)
-            R = w["n_rbf"]
-            n_src = int(batch["nxyz"].shape[0]) if kind.startswith("equi") else nd
-            bytes_alg = 4 * n_src * (3 * F + 3 * F) + 4 * nd * 4 * F + ne * (16 + 4 * R) + 4 * 3 * F * (R + 1)
-            flops = ne * F * (6 * R + 20) * (1 if flag else 0.3)
-            us = ksum[tag]["avg_us"]
-            roofline = {"kernel": tag, "bound": "mfma", "achieved": flops / (us * 1e-6) / 1e12,
-                        "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": flops / (us * 1e-6) / 1e12 / F32_PEAK_TFLOPS, "traffic": None,
-                        "avg_us": us, "launches": ksum[tag]["launches"],
-                        "hbm": {"algorithmic_bytes": bytes_alg, "achieved_GBps": bytes_alg / (us * 1e-6) / 1e9,
-                                "peak_GBps": HBM_PEAK_GBS, "frac": bytes_alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}}
-            extra["kernels"] = {k: {"avg_us": round(v["avg_us"], 2), "launches": v["launches"]} for k, v in ksum.items()}
+            # the path's dominant hand-written kernel: the fused EquiMessageBlock forward on the atom graph
+            fwd_tags = [k for k in ksum if k.startswith("equi_msg_fwd")]
+            tag = max(fwd_tags, key=lambda k: ksum[k]["total_ms"])
+            roofline = edge_kernel_roofline(tag)
+            extra["kernels"] = {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv)
+                                    for kk, vv in edge_kernel_roofline(k).items() if kk in ("avg_us", "launches", "frac")}
+                                for k in ksum}
+        extra["scatter_add"] = scatter_add_roofline(batch, F)
+        extra["optimizer_step"] = optimizer_roofline(trainer)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             steps_cpu = args.cpu_steps or (4 if args.workload == "chignolin" else 6)

@@ -1,0 +1,137 @@
+"""Data-parallel path on CPU: 2 processes over gloo.  N-rank training on frame shards must
+equal single-rank training on the concatenated batch (equal-size shards), the skip decision
+must be taken on the all-reduced loss, and the flat arena must keep state_dict semantics.
+The model under the Trainer here is the CPU oracle wrapped as an nn.Module (tests may use it);
+the Trainer / GradSync / ParamArena code is the product's."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from coarsegrainingvae_amd.data import CG_collate, synthetic_frames
+from coarsegrainingvae_amd.trainer import ParamArena, Trainer
+from oracle import cgvae_oracle as O
+
+HP = dict(F=16, R=8, atom_cutoff=8.5, cg_cutoff=9.5, enc=2, dec=2, n_cgs=3)
+BETA, GAMMA = 0.05, 25.0
+
+
+class OracleModule(torch.nn.Module):
+    def __init__(self, seed=123):
+        super().__init__()
+        self.hp = O.Hyper(HP["F"], HP["R"], HP["atom_cutoff"], HP["cg_cutoff"], HP["enc"], HP["dec"], HP["n_cgs"], det=True)
+        P = O.init_params(self.hp, seed=seed)
+        self.names = list(P.keys())
+        self.plist = torch.nn.ParameterList([torch.nn.Parameter(P[k]) for k in self.names])
+
+    def forward(self, batch, eps=None):
+        P = dict(zip(self.names, self.plist))
+        return O.model_forward(batch, P, self.hp, eps)
+
+
+def frames(n, seed=0):
+    props = synthetic_frames(n, 22, HP["n_cgs"], 6.0, seed=seed)
+    out = []
+    for k in range(n):
+        f = {key: val[k] for key, val in props.items()}
+        f["nbr_list"] = O.get_neighbor_list(f["nxyz"][:, 1:4], HP["atom_cutoff"], True)
+        f["CG_nbr_list"] = O.get_neighbor_list(f["CG_nxyz"][:, 1:4], HP["cg_cutoff"], True)
+        out.append(f)
+    return out
+
+
+def run_single(n_steps, lr):
+    torch.set_num_threads(1)
+    model = OracleModule()
+    tr = Trainer(model, lr=lr, beta=BETA, gamma=GAMMA, fused_optimizer=False)
+    batch = CG_collate(frames(4))
+    losses = [float(tr.step(batch)) for _ in range(n_steps)]
+    return [p.detach().clone() for p in model.plist], losses
+
+
+def _worker(rank, world, port, n_steps, lr, gamma, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model = OracleModule()
+        tr = Trainer(model, lr=lr, beta=BETA, gamma=gamma, world_size=world, fused_optimizer=False)
+        fr = frames(4)
+        batch = CG_collate(fr[2 * rank: 2 * rank + 2])
+        losses = [float(tr.step(batch)) for _ in range(n_steps)]
+        q.put((rank, [p.detach().clone().numpy() for p in model.plist], losses, tr.skipped_steps()))
+    finally:
+        dist.destroy_process_group()
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def run_dp(n_steps, lr, gamma=GAMMA):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_steps, lr, gamma, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_training_equals_single_rank_on_concatenated_batch():
+    ref_params, ref_losses = run_single(3, lr=1e-3)
+    res = run_dp(3, lr=1e-3)
+    (r0, p0, l0, s0), (r1, p1, l1, s1) = res
+    assert s0 == 0 and s1 == 0
+    for a, b in zip(p0, p1):                       # replicas stay in lock-step
+        assert np.array_equal(a, b)
+    worst = 0.0
+    for a, ref in zip(p0, ref_params):
+        ref = ref.numpy()
+        worst = max(worst, float(np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-12)))
+    assert worst < 2e-5, worst
+    # global loss of the first step = mean of the two shard losses (equal-size shards)
+    assert abs(0.5 * (l0[0] + l1[0]) - ref_losses[0]) <= 1e-5 * abs(ref_losses[0])
+
+
+@pytest.mark.timeout(600)
+def test_skip_rule_uses_the_all_reduced_loss():
+    # threshold 200*gamma far below the loss -> every rank must skip every step, parameters untouched
+    init = [p.detach().clone().numpy() for p in OracleModule().plist]
+    res = run_dp(2, lr=1e-3, gamma=1e-4)
+    for rank, params, losses, skipped in res:
+        assert skipped == 2
+        for a, b in zip(params, init):
+            assert np.array_equal(a, b)
+
+
+def test_param_arena_keeps_module_semantics():
+    torch.manual_seed(0)
+    lin = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Tanh(), torch.nn.Linear(7, 3))
+    ref = {k: v.clone() for k, v in lin.state_dict().items()}
+    x = torch.randn(4, 5)
+    lin(x).sum().backward()
+    g_ref = [p.grad.clone() for p in lin.parameters()]
+    arena = ParamArena(list(lin.parameters()))
+    for k, v in lin.state_dict().items():
+        assert torch.equal(v, ref[k])
+    for p, g in zip(lin.parameters(), g_ref):
+        assert torch.equal(p.grad, g) and p.grad.data_ptr() >= arena.g.data_ptr()
+    arena.zero_grad()
+    lin(x).sum().backward()                        # accumulates in place into the arena views
+    for p, g in zip(lin.parameters(), g_ref):
+        assert torch.allclose(p.grad, g)
+    assert float(arena.g.abs().sum()) > 0
+    assert all(o % 64 == 0 for o in arena.offsets)
