@@ -17,7 +17,7 @@ from torch import nn
 from . import ops
 from .blocks import (ContractiveMessageBlock, EquiMessageBlock, EquiMessagePsuedo, PseudoUpdateBlock, UpdateBlock)
 from .graph import BatchGraph, EdgePlan, make_directed
-from .primitives import Dense, DistanceEmbed, to_module
+from .primitives import Dense, DistanceEmbed, Linear, to_module
 
 
 class EquivariantPsuedoDecoder(nn.Module):
@@ -135,8 +135,8 @@ class CGprior(nn.Module):
              for _ in range(n_conv)])
         self.update_blocks = nn.ModuleList(
             [UpdateBlock(feat_dim=F, activation=activation, dropout=0.0) for _ in range(n_conv)])        # unused
-        self.mu = nn.Sequential(nn.Linear(F, F), nn.Tanh(), nn.Linear(F, F))
-        self.sigma = nn.Sequential(nn.Linear(F, F), nn.Tanh(), nn.Linear(F, F))
+        self.mu = nn.Sequential(Linear(F, F), nn.Tanh(), Linear(F, F))
+        self.sigma = nn.Sequential(Linear(F, F), nn.Tanh(), Linear(F, F))
         self.n_conv, self.dir_mp = n_conv, dir_mp
         self.n_rbf, self.cutoff = n_rbf, cutoff
 
@@ -180,7 +180,7 @@ class CGequiVAE(nn.Module):
         self.offset = offset
         self.equivariant = equivariant
         if not equivariant:
-            self.euclidean = nn.Linear(self.encoder.n_atom_basis, self.encoder.n_atom_basis * 3)
+            self.euclidean = Linear(self.encoder.n_atom_basis, self.encoder.n_atom_basis * 3)
 
     def get_inputs(self, batch):
         xyz = batch["nxyz"][:, 1:]

@@ -13,6 +13,7 @@ import torch
 
 from . import _lib
 from .graph import EdgeGeometry, EdgePlan
+from .primitives import linear as _linear
 
 _F32 = torch.float32
 
@@ -25,6 +26,19 @@ def _c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     return t.contiguous()
 
 
+def _filter_grad_targets(params, Wd, bd):
+    """Where the kernels write gWd / gbd: straight into the arena views of arena-managed
+    parameters (first write of the step), else into fresh tensors returned to autograd."""
+    pW, pb = params
+    direct = all(getattr(p, "_cgv_direct", False) and p.grad is not None and p._cgv_pending and p.grad.is_contiguous()
+                 for p in (pW, pb))
+    if direct:
+        pW._cgv_pending = pb._cgv_pending = False
+        return pW.grad, pb.grad, None, None
+    gWd, gbd = torch.empty_like(Wd), torch.empty_like(bd)
+    return gWd, gbd, gWd, gbd
+
+
 # ----------------------------------------------------------------------------- K2 / K4
 class _EquiMessage(torch.autograd.Function):
     """ds, dv of EquiMessageBlock / ContractiveMessageBlock from phi = inv_dense(s)
@@ -32,6 +46,7 @@ class _EquiMessage(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, phi, v, Wd, bd, plan: EdgePlan, geom: EdgeGeometry, with_dv: bool):
+        filter_params = (Wd, bd)
         phi, v, Wd, bd = _c(phi), _c(v), _c(Wd), _c(bd)
         F = phi.shape[1] // 3
         if phi.shape[0] != plan.n_src or v.shape != (plan.n_src, F, 3) or Wd.shape != (3 * F, geom.n_rbf):
@@ -44,6 +59,7 @@ class _EquiMessage(torch.autograd.Function):
                   geom.n_rbf, int(with_dv), _lib.stream_ptr(),
                   tag=f"equi_msg_fwd:Nd{plan.n_dst}:E{plan.n_edges}:dv{int(with_dv)}")
         ctx.save_for_backward(phi, v, Wd, bd)
+        ctx.filter_params = filter_params
         ctx.plan, ctx.geom, ctx.with_dv = plan, geom, with_dv
         ctx.set_materialize_grads(False)
         return ds, dv
@@ -61,8 +77,7 @@ class _EquiMessage(torch.autograd.Function):
         gs, gv = _c(gs), _c(gv)
         g_phi = torch.empty_like(phi)
         g_v = torch.empty_like(v) if gv is not None else None
-        gWd = torch.empty_like(Wd)
-        gbd = torch.empty_like(bd)
+        gWd, gbd, ret_W, ret_b = _filter_grad_targets(ctx.filter_params, Wd, bd)
         lib = _lib.load()
         ws_bytes = int(lib.cgv_equi_msg_bwd_workspace_bytes(plan.n_src, F, geom.n_rbf))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
@@ -70,7 +85,7 @@ class _EquiMessage(torch.autograd.Function):
                   _lib.ptr(plan.dst_s), _lib.ptr(Wd), _lib.ptr(bd), _lib.ptr(gs), _lib.ptr(gv), _lib.ptr(g_phi),
                   _lib.ptr(g_v), _lib.ptr(gWd), _lib.ptr(gbd), plan.n_src, F, geom.n_rbf, _lib.ptr(ws), ws_bytes,
                   _lib.stream_ptr(), tag=f"equi_msg_bwd:Nd{plan.n_dst}:E{plan.n_edges}:gv{int(gv is not None)}")
-        return g_phi, g_v, gWd, gbd, None, None, None
+        return g_phi, g_v, ret_W, ret_b, None, None, None
 
 
 def equi_message(phi, v, Wd, bd, plan: EdgePlan, geom: EdgeGeometry, with_dv: bool = True):
@@ -138,6 +153,7 @@ class _PseudoMessage(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, phi, s, sbar, v, vbar, Wd, bd, plan: EdgePlan, geom: EdgeGeometry):
+        ctx.filter_params = (Wd, bd)
         phi, s, sbar, v, vbar, Wd, bd = (_c(t) for t in (phi, s, sbar, v, vbar, Wd, bd))
         n, F = s.shape
         if plan.n_dst != n or plan.n_src != n or phi.shape != (n, 9 * F) or Wd.shape != (9 * F, geom.n_rbf):
@@ -164,7 +180,7 @@ class _PseudoMessage(torch.autograd.Function):
         g_phi = torch.empty_like(phi)
         g_s, g_sbar = torch.empty_like(s), torch.empty_like(s)
         g_v, g_vbar = torch.empty_like(v), torch.empty_like(v)
-        gWd, gbd = torch.empty_like(Wd), torch.empty_like(bd)
+        gWd, gbd, ret_W, ret_b = _filter_grad_targets(ctx.filter_params, Wd, bd)
         lib = _lib.load()
         ws_bytes = int(lib.cgv_pseudo_msg_bwd_workspace_bytes(n, F, geom.n_rbf))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=s.device)
@@ -175,7 +191,7 @@ class _PseudoMessage(torch.autograd.Function):
                   _lib.ptr(g_phi), _lib.ptr(g_s), _lib.ptr(g_sbar), _lib.ptr(g_v), _lib.ptr(g_vbar),
                   _lib.ptr(gWd), _lib.ptr(gbd), n, F, geom.n_rbf, _lib.ptr(ws), ws_bytes, _lib.stream_ptr(),
                   tag=f"pseudo_msg_bwd:Nd{n}:E{plan.n_edges}:gv1")
-        return g_phi, g_s, g_sbar, g_v, g_vbar, gWd, gbd, None, None
+        return g_phi, g_s, g_sbar, g_v, g_vbar, ret_W, ret_b, None, None
 
 
 def pseudo_message(phi, s, sbar, v, vbar, Wd, bd, plan: EdgePlan, geom: EdgeGeometry):
@@ -238,8 +254,8 @@ def update_block(s, v, u_weight, v_weight, s_dense):
     element-wise kernels; v is re-laid out once as [N,3,F] rows for the channel-mixing GEMMs."""
     n, F = s.shape
     vt = v.transpose(1, 2).reshape(-1, F)                       # [3N, F], row = node*3 + xyz (conv.py:591)
-    U = torch.nn.functional.linear(vt, u_weight).view(n, 3, F)
-    Vv = torch.nn.functional.linear(vt, v_weight).view(n, 3, F)
+    U = _linear(vt, u_weight).view(n, 3, F)
+    Vv = _linear(vt, v_weight).view(n, 3, F)
     stack = _UpdateNormStack.apply(s, Vv)
     a = s_dense(stack).view(n, 3, F)
     return _UpdateGate.apply(U, Vv, a)

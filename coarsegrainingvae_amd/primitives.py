@@ -38,6 +38,69 @@ def to_module(activation: str) -> nn.Module:
     return layer_types[activation]()
 
 
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T + b with a backward that can write the weight / bias gradients straight into the
+    trainer's gradient arena (``param.grad`` is a view of it, trainer.py) instead of producing
+    temporaries that autograd then adds in: per step that removes one [out,in] allocation and one
+    read-modify-write pass per layer (~160 launches and ~0.8 GB of traffic at n_basis=600)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.params = (weight, bias)
+        return Fn.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        w_param, b_param = ctx.params
+        gx = gy.matmul(weight) if ctx.needs_input_grad[0] else None
+        x2, gy2 = x.reshape(-1, x.shape[-1]), gy.reshape(-1, gy.shape[-1])
+        gw = gb = None
+        if ctx.needs_input_grad[1]:
+            gw = _direct_grad(w_param, lambda out: torch.mm(gy2.t(), x2, out=out), lambda: gy2.t().mm(x2))
+        if b_param is not None and ctx.needs_input_grad[2]:
+            gb = _direct_grad(b_param, lambda out: torch.sum(gy2, 0, out=out), lambda: gy2.sum(0))
+        return gx, gw, gb
+
+
+def _direct_grad(param, write_into, compute):
+    """Arena-managed parameter (trainer.ParamArena sets ``_cgv_direct``): the first gradient of a
+    step is written in place into ``param.grad`` (no zero-fill needed), later ones are added.
+    Otherwise return the gradient to autograd as usual."""
+    if getattr(param, "_cgv_direct", False) and param.grad is not None:
+        if param._cgv_pending:
+            write_into(param.grad)
+            param._cgv_pending = False
+        else:
+            param.grad.add_(compute())
+        return None
+    return compute()
+
+
+def mark_direct_grad(*params):
+    """Declare that these parameters' gradients are produced by a backward that honours
+    ``_direct_grad`` (so the arena may skip zero-filling them)."""
+    for p in params:
+        if p is not None:
+            p._cgv_direct_ok = True
+
+
+def linear(x, weight, bias=None):
+    return _LinearFn.apply(x, weight, bias)
+
+
+class Linear(nn.Linear):
+    """torch.nn.Linear (same init, same parameter names) on the arena-aware linear function."""
+
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__(in_features, out_features, bias)
+        mark_direct_grad(self.weight, self.bias)
+
+    def forward(self, x):
+        return _LinearFn.apply(x, self.weight, self.bias)
+
+
 class Dense(nn.Linear):
     """Linear layer with xavier-uniform weights, zero bias, optional activation
     (modules.py:75-114).  ``nn.Linear.__init__`` calls ``reset_parameters`` exactly once, so the
@@ -49,6 +112,7 @@ class Dense(nn.Linear):
         self.activation = activation
         self.dropout = nn.Dropout(p=dropout_rate)   # parameter-free; kept so module trees line up
         self.dropout_rate = dropout_rate
+        mark_direct_grad(self.weight, self.bias)
 
     def reset_parameters(self):
         nn.init.xavier_uniform_(self.weight)
@@ -56,7 +120,7 @@ class Dense(nn.Linear):
             nn.init.zeros_(self.bias)
 
     def forward(self, inputs):
-        y = Fn.linear(inputs, self.weight, self.bias)
+        y = _LinearFn.apply(inputs, self.weight, self.bias)
         if self.dropout_rate > 0.0:
             y = self.dropout(y)
         return self.activation(y) if self.activation is not None else y

@@ -44,9 +44,18 @@ class ParamArena:
                 self.g[o:o + n].copy_(p.grad.reshape(-1))
             p.data = self.p[o:o + n].view_as(p)
             p.grad = self.g[o:o + n].view_as(p)
+            # parameters whose backward writes .grad in place (primitives._direct_grad) need no zero-fill
+            p._cgv_direct = bool(getattr(p, "_cgv_direct_ok", False))
+            p._cgv_pending = True
+        self.accumulated = [p for p in params if not p._cgv_direct]
 
     def zero_grad(self):
-        self.g.zero_()
+        """Start of a step: direct-write parameters are only flagged 'pending' (their first
+        gradient overwrites); the few autograd-accumulated ones (embeddings) are zeroed."""
+        for p in self.params:
+            p._cgv_pending = True
+        for p in self.accumulated:
+            p.grad.zero_()
 
 
 class GradSync:
