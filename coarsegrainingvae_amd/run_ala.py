@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""``run_ala.py`` command-line surface of the reference (scripts/run_ala.py:417-482) on the
+MI355X hot path.  Every flag keeps its name, type and default.  What is in scope here is the
+training loop of one fold: model wiring (run_ala.py:184-209), Adam + ReduceLROnPlateau +
+early stopping (211-215, 232-284) and the CSV log columns (228-229, 252-258).
+
+Out of scope: trajectory download / mdtraj loading, CG-mapping
+learners, k-fold evaluation metrics.  Since no trajectories exist offline, frames come from
+``--synthetic`` (uniform random coordinates of the dataset's shape) -- the only
+flag added, together with ``-device`` accepting ``cuda:N`` strings besides the reference's int.
+
+    python -m coarsegrainingvae_amd.run_ala -logdir out -device 0 -dataset chignolin -n_cgs 6 \
+        -batch_size 2 -ndata 64 -nepochs 3 -atom_cutoff 12.0 -cg_cutoff 25.0 -beta 0.05 -gamma 50.0 \
+        -dec_nconv 9 -enc_nconv 2 -lr 0.0001 -n_basis 600 -n_rbf 10 --synthetic
+Multi-GPU: launch with ``python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1``;
+each rank trains on its shard of every batch (frames are independent graphs).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from datetime import date
+
+import numpy as np
+import torch
+
+from . import data as cgdata
+from .train import build_model, optim_dict
+from .trainer import Trainer
+
+DATASET_SHAPES = {"dipeptide": 22, "chignolin": 166, "pentapeptide": 94}   # atoms per frame
+
+
+def build_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser()
+    p.add_argument("-logdir", type=str)
+    p.add_argument("-device", type=str, default="0")        # reference: int CUDA ordinal (run_ala.py:421)
+    p.add_argument("-n_cgs", type=int)
+    p.add_argument("-lr", type=float, default=2e-4)
+    p.add_argument("-dataset", type=str, default="dipeptide")
+    p.add_argument("-n_basis", type=int, default=512)
+    p.add_argument("-n_rbf", type=int, default=10)
+    p.add_argument("-activation", type=str, default="swish")
+    p.add_argument("-cg_method", type=str, default="minimal")
+    p.add_argument("-atom_cutoff", type=float, default=4.0)
+    p.add_argument("-optimizer", type=str, default="adam")
+    p.add_argument("-cg_cutoff", type=float, default=4.0)
+    p.add_argument("-enc_nconv", type=int, default=4)
+    p.add_argument("-dec_nconv", type=int, default=4)
+    p.add_argument("-batch_size", type=int, default=64)
+    p.add_argument("-nepochs", type=int, default=2)
+    p.add_argument("-ndata", type=int, default=200)
+    p.add_argument("-nsamples", type=int, default=200)
+    p.add_argument("-n_ensemble", type=int, default=16)
+    p.add_argument("-nevals", type=int, default=36)
+    p.add_argument("-edgeorder", type=int, default=2)
+    p.add_argument("-auxcutoff", type=float, default=0.0)
+    p.add_argument("-beta", type=float, default=0.001)
+    p.add_argument("-gamma", type=float, default=0.01)
+    p.add_argument("-eta", type=float, default=0.01)
+    p.add_argument("-kappa", type=float, default=0.01)
+    p.add_argument("-threshold", type=float, default=1e-3)
+    p.add_argument("-nsplits", type=int, default=5)
+    p.add_argument("-patience", type=int, default=5)
+    p.add_argument("-factor", type=float, default=0.6)
+    p.add_argument("-mapshuffle", type=float, default=0.0)
+    p.add_argument("-cgae_reg_weight", type=float, default=0.25)
+    p.add_argument("--dec_type", type=str, default="EquivariantDecoder")
+    for flag in ("cross", "graph_eval", "shuffle", "cg_mp", "tqdm_flag", "det", "cg_radius_graph", "invariantdec",
+                 "reflectiontest"):
+        p.add_argument("--" + flag, action="store_true", default=False)
+    p.add_argument("--synthetic", action="store_true", default=False,
+                   help="random-coordinate frames of the dataset's shape (no trajectories offline)")
+    return p
+
+
+def annotate_job(task, job_name, n_cg):
+    """scripts/utils.py:22-24."""
+    return "{}_{}_{}_N{}".format(job_name, date.today().strftime("%m-%d"), task, n_cg)
+
+
+def resolve_logdir(params):
+    """Log-directory naming of run_ala.py:466-481."""
+    task = "recon" if params["det"] else "sample"
+    stem = params["cg_method"] + ("_invariantdec_" if params["invariantdec"] else "_") + task + \
+        "_ndata{}".format(params["ndata"])
+    name = annotate_job(stem, params["logdir"], params["n_cgs"])
+    if params["cross"]:
+        name += "_cross"
+    if params["reflectiontest"]:
+        name += "_reflectiontest"
+    return name
+
+
+class EarlyStopping:
+    """scripts/utils.py:54-79."""
+
+    def __init__(self, patience=5, min_delta=0):
+        self.patience, self.min_delta, self.counter, self.best_loss, self.early_stop = patience, min_delta, 0, None, False
+
+    def __call__(self, val_loss):
+        if self.best_loss is None:
+            self.best_loss = val_loss
+        elif self.best_loss - val_loss > self.min_delta:
+            self.best_loss, self.counter = val_loss, 0
+        elif self.best_loss - val_loss < self.min_delta:
+            self.counter += 1
+            if self.counter >= self.patience:
+                self.early_stop = True
+
+
+def _device(arg: str) -> torch.device:
+    local = os.environ.get("LOCAL_RANK")
+    if local is not None:
+        return torch.device("cuda", int(local))
+    return torch.device("cuda", int(arg)) if arg.isdigit() else torch.device(arg)
+
+
+def _batches(dataset, indices, batch_size, rank, world, device):
+    """Collate `batch_size` frames per step and give this rank its equal-size shard."""
+    for start in range(0, len(indices) - batch_size + 1, batch_size):
+        chunk = indices[start:start + batch_size]
+        shard = chunk[rank::world] if world > 1 else chunk
+        yield cgdata.prepare_batch(cgdata.CG_collate([dataset[i] for i in shard]), device)
+
+
+def run(params) -> dict:
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    device = _device(str(params["device"]))
+    torch.cuda.set_device(device)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+        if params["batch_size"] % world:
+            raise SystemExit("-batch_size must be divisible by the number of GPUs (equal-size shards)")
+    if not params["synthetic"]:
+        raise SystemExit("only --synthetic data is available in this build: trajectory ingestion "
+                         "(mdtraj/mdshare, datasets.py) is outside the hot path (SURVEY.md 2.1 row 7)")
+    if params["dataset"] not in DATASET_SHAPES:
+        raise SystemExit(f"unknown -dataset {params['dataset']}; known shapes: {sorted(DATASET_SHAPES)}")
+    seed = 123                                                          # run_ala.py:36-41
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    beta = 0.0 if params["det"] else params["beta"]                      # run_ala.py:117-121
+    n_atoms = DATASET_SHAPES[params["dataset"]]
+    box = {"dipeptide": 6.0, "chignolin": 14.0, "pentapeptide": 11.0}[params["dataset"]]
+    props = cgdata.synthetic_frames(params["ndata"], n_atoms, params["n_cgs"], box, seed=0)
+    dataset = cgdata.CGDataset(props)
+    # --cg_radius_graph has the reference's inverted sense: set => CG graph from bonds (run_ala.py:64-67)
+    dataset.generate_neighbor_list(params["atom_cutoff"], None if params["cg_radius_graph"] else params["cg_cutoff"],
+                                   device=device, undirected=True)
+    n_train = int(0.9 * len(dataset))                                    # 10 % validation (run_ala.py:146-156)
+    order = np.random.permutation(len(dataset)) if params["shuffle"] else np.arange(len(dataset))
+    train_idx, val_idx = order[:n_train].tolist(), order[n_train:].tolist()
+
+    model = build_model(params["n_basis"], params["n_rbf"], params["atom_cutoff"], params["cg_cutoff"],
+                        params["enc_nconv"], params["dec_nconv"], params["n_cgs"], activation=params["activation"],
+                        det=params["det"], invariantdec=params["invariantdec"], cg_mp=params["cg_mp"], seed=seed).to(device)
+    if params["optimizer"] not in optim_dict:
+        raise SystemExit("-optimizer must be one of " + ", ".join(optim_dict))
+    if params["optimizer"] != "adam":
+        raise SystemExit("the fused optimiser step implements Adam (the reference's documented runs use adam)")
+    trainer = Trainer(model, lr=params["lr"], beta=beta, gamma=params["gamma"], world_size=world)
+    min_lr, best, bad_epochs = 5e-8, None, 0                              # ReduceLROnPlateau(patience=2), run_ala.py:212-214
+    early = EarlyStopping(patience=params["patience"])
+    logdir = resolve_logdir(params) if params["logdir"] else None
+    if rank == 0 and logdir:
+        os.makedirs(logdir, exist_ok=True)
+        with open(os.path.join(logdir, "modelparams.json"), "w") as f:
+            json.dump({**params, "mapping": props["CG_mapping"][0].tolist()}, f, indent=4)
+    log_rows, failed = [], False
+    columns = ["epoch", "lr", "train_loss", "val_loss", "train_recon", "val_recon", "train_KL", "val_KL",
+               "train_graph", "val_graph"]
+    t_start = time.time()
+    frames_seen = 0
+    for epoch in range(params["nepochs"]):
+        stats = {}
+        for mode, idx in (("train", train_idx), ("val", val_idx)):
+            tot, kls, recs, grs = [], [], [], []
+            for batch in _batches(dataset, idx, params["batch_size"], rank, world, device):
+                loss = trainer.step(batch, train=(mode == "train"))
+                kl, recon, graph = trainer.last_terms
+                tot.append(loss), kls.append(kl), recs.append(recon), grs.append(graph)
+                frames_seen += params["batch_size"] if mode == "train" else 0
+            mean = lambda xs: float(torch.stack(xs).mean()) if xs else float("nan")     # one sync per epoch
+            stats.update({f"{mode}_loss": mean(tot), f"{mode}_KL": mean(kls), f"{mode}_recon": mean(recs),
+                          f"{mode}_graph": mean(grs)})
+        stats.update({"epoch": epoch, "lr": trainer.lr})
+        log_rows.append(stats)
+        if rank == 0:
+            print(" ".join(f"{k}={stats[k]:.5g}" for k in columns), flush=True)
+            if logdir:
+                with open(os.path.join(logdir, "train_log.csv"), "w") as f:
+                    f.write(",".join(columns) + "\n")
+                    for r in log_rows:
+                        f.write(",".join(str(r[c]) for c in columns) + "\n")
+        val = stats["val_loss"]
+        if np.isnan(stats["val_recon"]):                                  # run_ala.py:278-281
+            failed = True
+            break
+        if best is None or val < best * (1 - params["threshold"]):
+            best, bad_epochs = val, 0
+        else:
+            bad_epochs += 1
+            if bad_epochs > 2:
+                trainer.lr = max(trainer.lr * params["factor"], min_lr)
+                bad_epochs = 0
+        if trainer.lr <= min_lr * 1.5:
+            break
+        early(val)
+        if early.early_stop:
+            break
+    elapsed = time.time() - t_start
+    if rank == 0 and logdir:
+        torch.save(model.state_dict(), os.path.join(logdir, "model.pt"))    # run_ala.py:355-357
+        if failed:
+            with open(os.path.join(logdir, "FAILED.txt"), "w") as f:
+                print("TRAINING FAILED", file=f)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    return {"epochs": len(log_rows), "seconds": elapsed, "train_frames_per_s": frames_seen / max(elapsed, 1e-9),
+            "final": log_rows[-1] if log_rows else None, "failed": failed, "skipped_steps": trainer.skipped_steps()}
+
+
+def main(argv=None):
+    params = vars(build_parser().parse_args(argv))
+    params["savemodel"] = True                                            # run_ala.py:464
+    summary = run(params)
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(json.dumps(summary))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])
