@@ -27,4 +27,5 @@ int cgv_rbf_supported(int R) {
   }
 }
 int cgv_geom_stride(int R) { return cgv::geom_stride(R); }
+int cgv_geom_unit_offset(int R) { return cgv::geom_unit_offset(R); }
 }

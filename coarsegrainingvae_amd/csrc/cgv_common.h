@@ -28,7 +28,12 @@ inline int check_launch(const char* what) {
 
 constexpr int WAVE = 64;
 
-__host__ __device__ inline int geom_stride(int R) { return (R + 4 + 3) & ~3; }
+// Edge-geometry record layout (floats):  [0,R) a_n ; [R] env ; pad to even ; [U,U+6) ux,uy,uz,ux,uy,uz
+// The unit vector is stored twice so that every adjacent pair (ux,uy) (uz,ux) (uy,uz) is an
+// aligned 64-bit scalar-register pair: the packed-fp32 kernels (v_pk_fma_f32, two channels per
+// lane) use them directly as broadcast operands for their AoS (x0,y0)(z0,x1)(y1,z1) accumulators.
+__host__ __device__ constexpr int geom_unit_offset(int R) { return (R + 2) & ~1; }
+__host__ __device__ constexpr int geom_stride(int R) { return (geom_unit_offset(R) + 6 + 3) & ~3; }
 
 // 12-byte vector with 4-byte alignment: one global_load_dwordx3 / global_store_dwordx3.
 struct __attribute__((packed, aligned(4))) f3 {

@@ -6,78 +6,175 @@
 //     m_k(e,f) = phi[j, kF+f] * w_k(e,f)
 //     ds[i,f]   = sum_e m_1                dv[i,f,:] = sum_e ( m_2 * unit_e + m_0 * v[j,f,:] )
 // The reference materialises ~10 tensors of shape [E,3F] / [E,F,3] per layer and reduces them
-// with an unsorted scatter_add.  Here one wave owns (destination node, 64 channels): it walks
-// the node's CSR segment, gathers phi[j]/v[j] rows coalesced along channels (L2-resident),
+// with an unsorted scatter_add.  Here a wave owns (receiver node, 128 channels): it walks the
+// node's CSR segment, gathers phi[j] / v[j] rows coalesced along channels (L2 resident),
 // rebuilds the filter from the per-edge geometry record held in SGPRs (the record address is
-// wave-uniform -> scalar loads), and accumulates in VGPRs.  Nothing of size E*F is written.
+// wave-uniform -> scalar loads) and accumulates in VGPRs.  Nothing of size E*F is written.
 //
-// Mapping: thread <-> channel f, so every global access is a contiguous 256 B (phi) or 768 B
-// (v, dwordx3) wave transaction; the 3*(R+1) filter weights of the channel live in registers
-// for the whole segment.
+// What bounds it (rocprofv3 PMC, chignolin layer, E = 41.5k, F = 600): the kernel is VALU-issue
+// bound, not HBM bound -- a plain wave64 v_fma_f32 occupies its SIMD for 4 cycles, and the
+// filter rebuild is 3(R+1) FMAs per (edge, channel).  So each lane carries TWO adjacent channels
+// as 2-wide vectors: every FMA below is a v_pk_fma_f32 (same issue cost, two channels), loads are
+// 8 B / 24 B per lane, and the (x0,y0)(z0,x1)(y1,z1) layout of two channels' xyz triples lines up
+// with the doubled unit vector in the geometry record (cgv_common.h), so the vector channel needs
+// no register shuffles.  MFMA was considered and rejected: the contraction is K = n_rbf+1 = 9..11
+// deep and fp32; v_mfma_f32_16x16x4_f32 runs at exactly the packed-VALU rate (MI355X_MICROARCH.md),
+// so it could not beat this formulation.
+//
+// Scheduling: 1-D grid, XCD-aware (block b -> XCD b % 8 gets a contiguous node range, so an XCD's
+// gathers stay inside a few frames and its phi/v working set fits the 4 MiB L2); on high-degree
+// graphs the 4 waves of a block split one node's segment and meet in LDS.
 #include "cgv_common.h"
 
 namespace cgv {
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f2 splat(float x) { return f2{x, x}; }
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 ld2(const float* p) { return *reinterpret_cast<const f2*>(p); }
+__device__ __forceinline__ void st2(float* p, f2 x) { *reinterpret_cast<f2*>(p) = x; }
+__device__ __forceinline__ f2 lo2(f2 a) { return __builtin_shufflevector(a, a, 0, 0); }
+__device__ __forceinline__ f2 hi2(f2 a) { return __builtin_shufflevector(a, a, 1, 1); }
+
+// filter of two adjacent channels: W[n] = (Wd[c][n], Wd[c+1][n]), W[R] = (bd[c], bd[c+1])
 template <int R>
-__device__ __forceinline__ float filter(const float (&W)[R + 1], const float* __restrict__ g) {
-  float w = W[R] * g[R];
+__device__ __forceinline__ f2 filter2(const f2 (&W)[R + 1], const float* __restrict__ g) {
+  f2 w = W[R] * splat(g[R]);
 #pragma unroll
-  for (int n = 0; n < R; ++n) w = fmaf(W[n], g[n], w);
+  for (int n = 0; n < R; ++n) w = fma2(W[n], splat(g[n]), w);
   return w;
 }
 
 template <int R>
-__device__ __forceinline__ void load_filter_row(float (&W)[R + 1], const float* __restrict__ Wd,
-                                                const float* __restrict__ bd, int c) {
+__device__ __forceinline__ void load_filter_rows2(f2 (&W)[R + 1], const float* __restrict__ Wd,
+                                                  const float* __restrict__ bd, int c, int c1) {
 #pragma unroll
-  for (int n = 0; n < R; ++n) W[n] = Wd[(size_t)c * R + n];
-  W[R] = bd[c];
+  for (int n = 0; n < R; ++n) W[n] = f2{Wd[(size_t)c * R + n], Wd[(size_t)c1 * R + n]};
+  W[R] = f2{bd[c], bd[c1]};
+}
+
+// Lane -> channel pair.  F even: lanes own (c, c+1) with 8-byte vector accesses.  F odd: the last
+// lane's second channel is a duplicate of its first (PAIR = false -> scalar memory accesses).
+struct ChanPair {
+  int c, c1;       // the two channels (c1 == c + 1, or == c when duplicated)
+  bool live, live1;
+};
+__device__ __forceinline__ ChanPair chan_pair(int tile, int lane, int F) {
+  ChanPair p;
+  const int raw = tile * 128 + 2 * lane;
+  p.live = raw < F;
+  p.live1 = raw + 1 < F;
+  const int last = F >= 2 ? ((F - 2) & ~1) : 0;              // clamp: idle lanes read valid rows, never store
+  p.c = p.live ? raw : last;
+  p.c1 = p.live ? (p.live1 ? raw + 1 : raw) : (F >= 2 ? last + 1 : 0);
+  return p;
+}
+
+template <bool PAIR>
+__device__ __forceinline__ f2 ldpair(const float* base, const ChanPair& cp) {
+  if constexpr (PAIR) return ld2(base + cp.c);
+  else return f2{base[cp.c], base[cp.c1]};
+}
+// xyz triples of the two channels as (x0,y0)(z0,x1)(y1,z1)
+template <bool PAIR>
+__device__ __forceinline__ void ldvec(const float* row /* [F,3] of one node */, const ChanPair& cp, f2& A, f2& B, f2& C) {
+  if constexpr (PAIR) {
+    const float* p = row + (size_t)cp.c * 3;
+    A = ld2(p); B = ld2(p + 2); C = ld2(p + 4);
+  } else {
+    const float* p = row + (size_t)cp.c * 3;
+    const float* q = row + (size_t)cp.c1 * 3;
+    A = f2{p[0], p[1]}; B = f2{p[2], q[0]}; C = f2{q[1], q[2]};
+  }
+}
+template <bool PAIR>
+__device__ __forceinline__ void stvec(float* row, const ChanPair& cp, f2 A, f2 B, f2 C) {
+  if constexpr (PAIR) {
+    float* p = row + (size_t)cp.c * 3;
+    st2(p, A); st2(p + 2, B); st2(p + 4, C);
+  } else {
+    float* p = row + (size_t)cp.c * 3;
+    p[0] = A.x; p[1] = A.y; p[2] = B.x;
+    if (cp.live1) { float* q = row + (size_t)cp.c1 * 3; q[0] = B.y; q[1] = C.x; q[2] = C.y; }
+  }
+}
+template <bool PAIR>
+__device__ __forceinline__ void stpair(float* base, const ChanPair& cp, f2 x) {
+  if constexpr (PAIR) st2(base + cp.c, x);
+  else { base[cp.c] = x.x; if (cp.live1) base[cp.c1] = x.y; }
 }
 
 // ------------------------------------------------------------------ forward
-// grid = (n_dst, ceil(F / BLOCK)), block = BLOCK threads (BLOCK/64 waves, each its own 64 channels)
-template <int R, bool WITH_DV, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void equi_msg_fwd_k(const float* __restrict__ phi, const float* __restrict__ v,
-                                                        const float* __restrict__ geom,
-                                                        const int* __restrict__ rowptr, const int* __restrict__ src,
-                                                        const float* __restrict__ Wd, const float* __restrict__ bd,
-                                                        float* __restrict__ ds, float* __restrict__ dv, int F) {
-  constexpr int GS = (R + 4 + 3) & ~3;
-  const int node = blockIdx.x;
-  const int f_raw = blockIdx.y * BLOCK + threadIdx.x;
-  const bool live = f_raw < F;
-  const int f = live ? f_raw : F - 1;     // clamp: idle lanes load valid addresses, never store
+// grid = 8 * nodes_per_xcd * tiles blocks (tiles = ceil(F/128)), block = 64 * SPLIT threads.
+template <int R, bool WITH_DV, int SPLIT, bool PAIR>
+__global__ __launch_bounds__(64 * SPLIT) void equi_msg_fwd_k(const float* __restrict__ phi, const float* __restrict__ v,
+                                                             const float* __restrict__ geom,
+                                                             const int* __restrict__ rowptr, const int* __restrict__ src,
+                                                             const float* __restrict__ Wd, const float* __restrict__ bd,
+                                                             float* __restrict__ ds, float* __restrict__ dv, int F,
+                                                             int n_dst, int nodes_per_xcd, int tiles) {
+  constexpr int GS = geom_stride(R), U = geom_unit_offset(R);
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int local = slot / tiles;
+  const int node = xcd * nodes_per_xcd + local;
+  const int tile = slot - local * tiles;
+  if (node >= n_dst || local >= nodes_per_xcd) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const ChanPair cp = chan_pair(tile, lane, F);
 
-  float W0[R + 1], W1[R + 1], W2[R + 1];
-  load_filter_row<R>(W1, Wd, bd, F + f);
+  f2 W0[R + 1], W1[R + 1], W2[R + 1];
+  load_filter_rows2<R>(W1, Wd, bd, F + cp.c, F + cp.c1);
   if constexpr (WITH_DV) {
-    load_filter_row<R>(W0, Wd, bd, f);
-    load_filter_row<R>(W2, Wd, bd, 2 * F + f);
+    load_filter_rows2<R>(W0, Wd, bd, cp.c, cp.c1);
+    load_filter_rows2<R>(W2, Wd, bd, 2 * F + cp.c, 2 * F + cp.c1);
   }
 
-  float acc_s = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
-  const int beg = rowptr[node], end = rowptr[node + 1];
+  f2 acc_s = splat(0.f), accA = splat(0.f), accB = splat(0.f), accC = splat(0.f);
+  int beg = rowptr[node], end = rowptr[node + 1];
+  if constexpr (SPLIT > 1) {
+    const int len = (end - beg + SPLIT - 1) / SPLIT;
+    beg = min(beg + wave * len, end);
+    end = min(beg + len, end);
+  }
 #pragma unroll 2
   for (int e = beg; e < end; ++e) {
     const float* __restrict__ g = geom + (size_t)e * GS;   // wave-uniform -> s_load
     const int j = src[e];
     const float* __restrict__ prow = phi + (size_t)j * 3 * F;
-    const float p1 = prow[F + f];
-    acc_s = fmaf(p1, filter<R>(W1, g), acc_s);
+    const f2 p1 = ldpair<PAIR>(prow + F, cp);
+    acc_s = fma2(p1, filter2<R>(W1, g), acc_s);
     if constexpr (WITH_DV) {
-      const float p0 = prow[f];
-      const float p2 = prow[2 * F + f];
-      const f3 vj = ld3(v + ((size_t)j * F + f) * 3);
-      const float m0 = p0 * filter<R>(W0, g);
-      const float m2 = p2 * filter<R>(W2, g);
-      ax = fmaf(m2, g[R + 1], fmaf(m0, vj.x, ax));
-      ay = fmaf(m2, g[R + 2], fmaf(m0, vj.y, ay));
-      az = fmaf(m2, g[R + 3], fmaf(m0, vj.z, az));
+      const f2 p0 = ldpair<PAIR>(prow, cp);
+      const f2 p2 = ldpair<PAIR>(prow + 2 * F, cp);
+      f2 A, B, C;
+      ldvec<PAIR>(v + (size_t)j * F * 3, cp, A, B, C);
+      const f2 m0 = p0 * filter2<R>(W0, g);
+      const f2 m2 = p2 * filter2<R>(W2, g);
+      const f2 u01 = f2{g[U], g[U + 1]}, u20 = f2{g[U + 2], g[U + 3]}, u12 = f2{g[U + 4], g[U + 5]};
+      accA = fma2(lo2(m2), u01, fma2(lo2(m0), A, accA));
+      accB = fma2(m2, u20, fma2(m0, B, accB));
+      accC = fma2(hi2(m2), u12, fma2(hi2(m0), C, accC));
     }
   }
-  if (live) {
-    ds[(size_t)node * F + f] = acc_s;
-    if (WITH_DV) st3(dv + ((size_t)node * F + f) * 3, ax, ay, az);
+  if constexpr (SPLIT > 1) {
+    __shared__ float red[(SPLIT - 1) * 8 * 64];
+    if (wave > 0) {
+      float* r = red + (wave - 1) * 8 * 64 + lane;
+      r[0] = acc_s.x; r[64] = acc_s.y; r[128] = accA.x; r[192] = accA.y;
+      r[256] = accB.x; r[320] = accB.y; r[384] = accC.x; r[448] = accC.y;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 0; w < SPLIT - 1; ++w) {
+      const float* r = red + w * 8 * 64 + lane;
+      acc_s += f2{r[0], r[64]}; accA += f2{r[128], r[192]}; accB += f2{r[256], r[320]}; accC += f2{r[384], r[448]};
+    }
+  }
+  if (cp.live) {
+    stpair<PAIR>(ds + (size_t)node * F, cp, acc_s);
+    if constexpr (WITH_DV) stvec<PAIR>(dv + (size_t)node * F * 3, cp, accA, accB, accC);
   }
 }
 
@@ -85,116 +182,164 @@ __global__ __launch_bounds__(BLOCK) void equi_msg_fwd_k(const float* __restrict_
 // Upstream gs[i,f], gv[i,f,:] at the receivers.  With gq_1 = gs, gq_2 = gv.unit, gq_0 = gv.v_j:
 //     g_phi[j,kF+f] = sum_{e: src(e)=j} gq_k * w_k          g_v[j,f,:] = sum_e m_0 * gv_i
 //     gWd[kF+f][n]  = sum_e gq_k * phi[j,kF+f] * a_n(e)      gbd[kF+f]  = sum_e gq_k * phi * env
-// One wave owns (chunk of source nodes, 64 channels) and walks the SRC-sorted view, so g_phi
-// and g_v are plain stores; gWd/gbd accumulate in registers over the whole chunk and leave as
-// one partial per block (LDS reduction over the block's waves), summed by a second kernel in a
-// fixed order -> deterministic, no atomics.
-// grid = (n_chunks, ceil(F/64)), block = 64*WAVES; wave w of chunk c takes nodes c*npc + w, +WAVES, ...
-template <int R, bool HAS_GV, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void equi_msg_bwd_k(
+// A block owns (chunk of source nodes, 128 channels) and walks the SRC-sorted view, so g_phi and
+// g_v are plain stores; gWd/gbd accumulate in registers over the whole chunk and leave as ONE
+// partial per block (LDS reduction over its 4 waves), summed by a second kernel in a fixed order:
+// deterministic, no atomics.  SPLIT: the 4 waves share one node (slices of its segment) instead
+// of taking different nodes -- for high-degree graphs.
+// grid = 8 * chunks_per_xcd * tiles, block = 256.
+constexpr int BWD_WAVES = 4;
+
+template <int R, bool HAS_GV, bool SPLIT, bool PAIR>
+__global__ __launch_bounds__(64 * BWD_WAVES) void equi_msg_bwd_k(
     const float* __restrict__ phi, const float* __restrict__ v, const float* __restrict__ geom,
     const int* __restrict__ rowptr, const int* __restrict__ dst, const float* __restrict__ Wd,
     const float* __restrict__ bd, const float* __restrict__ gs, const float* __restrict__ gv,
     float* __restrict__ g_phi, float* __restrict__ g_v, float* __restrict__ part, int F, int n_src,
-    int nodes_per_chunk) {
-  constexpr int GS = (R + 4 + 3) & ~3;
+    int nodes_per_chunk, int chunks_per_xcd, int tiles) {
+  constexpr int GS = geom_stride(R), U = geom_unit_offset(R);
   constexpr int K = HAS_GV ? 3 : 1;           // live filter slices (k = 1 only without gv)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int f_raw = blockIdx.y * 64 + lane;
-  const bool live = f_raw < F;
-  const int f = live ? f_raw : F - 1;
+  constexpr int NRED = K * (R + 1) * 2;       // filter-gradient floats per lane
+  constexpr int NACC = SPLIT ? (HAS_GV ? 12 : 2) : 0;
+  __shared__ float red[(BWD_WAVES - 1) * (NRED + NACC) * 64];
 
-  float W[K][R + 1], G[K][R + 1];
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int local = slot / tiles;
+  const int chunk = xcd * chunks_per_xcd + local;
+  const int tile = slot - local * tiles;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const ChanPair cp = chan_pair(tile, lane, F);
+
+  f2 W[K][R + 1], G[K][R + 1];
   if constexpr (HAS_GV) {
-    load_filter_row<R>(W[0], Wd, bd, f);
-    load_filter_row<R>(W[1], Wd, bd, F + f);
-    load_filter_row<R>(W[2], Wd, bd, 2 * F + f);
+    load_filter_rows2<R>(W[0], Wd, bd, cp.c, cp.c1);
+    load_filter_rows2<R>(W[1], Wd, bd, F + cp.c, F + cp.c1);
+    load_filter_rows2<R>(W[2], Wd, bd, 2 * F + cp.c, 2 * F + cp.c1);
   } else {
-    load_filter_row<R>(W[0], Wd, bd, F + f);
+    load_filter_rows2<R>(W[0], Wd, bd, F + cp.c, F + cp.c1);
   }
 #pragma unroll
   for (int k = 0; k < K; ++k)
 #pragma unroll
-    for (int n = 0; n <= R; ++n) G[k][n] = 0.f;
+    for (int n = 0; n <= R; ++n) G[k][n] = splat(0.f);
 
-  const int n_beg = blockIdx.x * nodes_per_chunk;
+  const int n_beg = chunk * nodes_per_chunk;
   const int n_end = min(n_beg + nodes_per_chunk, n_src);
-  for (int j = n_beg + wave; j < n_end; j += WAVES) {
+  const int j0 = SPLIT ? n_beg : n_beg + wave;
+  const int jstep = SPLIT ? 1 : BWD_WAVES;
+  for (int j = j0; j < n_end; j += jstep) {
     const float* __restrict__ prow = phi + (size_t)j * 3 * F;
-    const float p1 = prow[F + f];
-    float p0 = 0.f, p2 = 0.f;
-    f3 vj{0.f, 0.f, 0.f};
+    const f2 p1 = ldpair<PAIR>(prow + F, cp);
+    f2 p0 = splat(0.f), p2 = splat(0.f), vA = splat(0.f), vB = splat(0.f), vC = splat(0.f);
     if constexpr (HAS_GV) {
-      p0 = prow[f];
-      p2 = prow[2 * F + f];
-      vj = ld3(v + ((size_t)j * F + f) * 3);
+      p0 = ldpair<PAIR>(prow, cp);
+      p2 = ldpair<PAIR>(prow + 2 * F, cp);
+      ldvec<PAIR>(v + (size_t)j * F * 3, cp, vA, vB, vC);
     }
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, bx = 0.f, by = 0.f, bz = 0.f;
-    const int beg = rowptr[j], end = rowptr[j + 1];
+    f2 a0 = splat(0.f), a1 = splat(0.f), a2 = splat(0.f), bA = splat(0.f), bB = splat(0.f), bC = splat(0.f);
+    int beg = rowptr[j], end = rowptr[j + 1];
+    if constexpr (SPLIT) {
+      const int len = (end - beg + BWD_WAVES - 1) / BWD_WAVES;
+      beg = min(beg + wave * len, end);
+      end = min(beg + len, end);
+    }
 #pragma unroll 2
     for (int e = beg; e < end; ++e) {
       const float* __restrict__ g = geom + (size_t)e * GS;
       const int i = dst[e];
-      const float gq1 = gs ? gs[(size_t)i * F + f] : 0.f;
+      const f2 gq1 = gs ? ldpair<PAIR>(gs + (size_t)i * F, cp) : splat(0.f);
       if constexpr (HAS_GV) {
-        const f3 gvi = ld3(gv + ((size_t)i * F + f) * 3);
-        const float w0 = filter<R>(W[0], g), w1 = filter<R>(W[1], g), w2 = filter<R>(W[2], g);
-        const float gq0 = gvi.x * vj.x + gvi.y * vj.y + gvi.z * vj.z;
-        const float gq2 = gvi.x * g[R + 1] + gvi.y * g[R + 2] + gvi.z * g[R + 3];
-        a0 = fmaf(gq0, w0, a0);
-        a1 = fmaf(gq1, w1, a1);
-        a2 = fmaf(gq2, w2, a2);
-        const float m0 = p0 * w0;
-        bx = fmaf(m0, gvi.x, bx);
-        by = fmaf(m0, gvi.y, by);
-        bz = fmaf(m0, gvi.z, bz);
-        const float t0 = gq0 * p0, t1 = gq1 * p1, t2 = gq2 * p2;
+        f2 gA, gB, gC;
+        ldvec<PAIR>(gv + (size_t)i * F * 3, cp, gA, gB, gC);
+        const f2 w0 = filter2<R>(W[0], g), w1 = filter2<R>(W[1], g), w2 = filter2<R>(W[2], g);
+        const f2 u01 = f2{g[U], g[U + 1]}, u20 = f2{g[U + 2], g[U + 3]}, u12 = f2{g[U + 4], g[U + 5]};
+        const f2 PA = gA * vA, PB = gB * vB, PC = gC * vC;          // (x0x0,y0y0)(z0z0,x1x1)(y1y1,z1z1)
+        const f2 QA = gA * u01, QB = gB * u20, QC = gC * u12;
+        const f2 gq0 = f2{PA.x + PA.y + PB.x, PB.y + PC.x + PC.y};  // gv_i . v_j per channel
+        const f2 gq2 = f2{QA.x + QA.y + QB.x, QB.y + QC.x + QC.y};  // gv_i . unit
+        a0 = fma2(gq0, w0, a0);
+        a1 = fma2(gq1, w1, a1);
+        a2 = fma2(gq2, w2, a2);
+        const f2 m0 = p0 * w0;
+        bA = fma2(lo2(m0), gA, bA);
+        bB = fma2(m0, gB, bB);
+        bC = fma2(hi2(m0), gC, bC);
+        const f2 t0 = gq0 * p0, t1 = gq1 * p1, t2 = gq2 * p2;
 #pragma unroll
         for (int n = 0; n <= R; ++n) {
-          G[0][n] = fmaf(t0, g[n], G[0][n]);
-          G[1][n] = fmaf(t1, g[n], G[1][n]);
-          G[2][n] = fmaf(t2, g[n], G[2][n]);
+          const f2 gn = splat(g[n]);
+          G[0][n] = fma2(t0, gn, G[0][n]);
+          G[1][n] = fma2(t1, gn, G[1][n]);
+          G[2][n] = fma2(t2, gn, G[2][n]);
         }
       } else {
-        a1 = fmaf(gq1, filter<R>(W[0], g), a1);
-        const float t1 = gq1 * p1;
+        a1 = fma2(gq1, filter2<R>(W[0], g), a1);
+        const f2 t1 = gq1 * p1;
 #pragma unroll
-        for (int n = 0; n <= R; ++n) G[0][n] = fmaf(t1, g[n], G[0][n]);
+        for (int n = 0; n <= R; ++n) G[0][n] = fma2(t1, splat(g[n]), G[0][n]);
       }
     }
-    if (live) {
+    if constexpr (SPLIT) {       // the 4 waves hold partial sums of the SAME node: combine in LDS
+      float* acc = red + (BWD_WAVES - 1) * NRED * 64;
+      if (wave > 0) {
+        float* r = acc + (wave - 1) * NACC * 64 + lane;
+        r[0] = a1.x; r[64] = a1.y;
+        if constexpr (HAS_GV) {
+          r[128] = a0.x; r[192] = a0.y; r[256] = a2.x; r[320] = a2.y;
+          r[384] = bA.x; r[448] = bA.y; r[512] = bB.x; r[576] = bB.y; r[640] = bC.x; r[704] = bC.y;
+        }
+      }
+      __syncthreads();
+      if (wave == 0) {
+#pragma unroll
+        for (int w = 0; w < BWD_WAVES - 1; ++w) {
+          const float* r = acc + w * NACC * 64 + lane;
+          a1 += f2{r[0], r[64]};
+          if constexpr (HAS_GV) {
+            a0 += f2{r[128], r[192]}; a2 += f2{r[256], r[320]};
+            bA += f2{r[384], r[448]}; bB += f2{r[512], r[576]}; bC += f2{r[640], r[704]};
+          }
+        }
+      }
+      __syncthreads();           // acc region is reused by the next node
+    }
+    if (cp.live && (!SPLIT || wave == 0)) {
       float* __restrict__ grow = g_phi + (size_t)j * 3 * F;
-      grow[f] = a0;
-      grow[F + f] = a1;
-      grow[2 * F + f] = a2;
-      if constexpr (HAS_GV) st3(g_v + ((size_t)j * F + f) * 3, bx, by, bz);
+      stpair<PAIR>(grow, cp, a0);
+      stpair<PAIR>(grow + F, cp, a1);
+      stpair<PAIR>(grow + 2 * F, cp, a2);
+      if constexpr (HAS_GV) stvec<PAIR>(g_v + (size_t)j * F * 3, cp, bA, bB, bC);
     }
   }
 
   // block partial of the filter-weight gradient: part[chunk][k][n][F]  (channel fastest -> coalesced)
-  __shared__ float red[WAVES > 1 ? (WAVES - 1) * K * (R + 1) * 64 : 1];
-  if (WAVES > 1) {
-    if (wave > 0) {
-#pragma unroll
-      for (int k = 0; k < K; ++k)
-#pragma unroll
-        for (int n = 0; n <= R; ++n) red[(((wave - 1) * K + k) * (R + 1) + n) * 64 + lane] = G[k][n];
-    }
-    __syncthreads();
-    if (wave == 0) {
-      for (int w = 0; w < WAVES - 1; ++w)
-#pragma unroll
-        for (int k = 0; k < K; ++k)
-#pragma unroll
-          for (int n = 0; n <= R; ++n) G[k][n] += red[((w * K + k) * (R + 1) + n) * 64 + lane];
-    }
-  }
-  if (wave == 0 && live) {
-    float* __restrict__ out = part + (size_t)blockIdx.x * K * (R + 1) * F;
+  if (wave > 0) {
+    float* r = red + (wave - 1) * NRED * 64 + lane;
 #pragma unroll
     for (int k = 0; k < K; ++k)
 #pragma unroll
-      for (int n = 0; n <= R; ++n) out[((size_t)k * (R + 1) + n) * F + f] = G[k][n];
+      for (int n = 0; n <= R; ++n) {
+        r[((k * (R + 1) + n) * 2 + 0) * 64] = G[k][n].x;
+        r[((k * (R + 1) + n) * 2 + 1) * 64] = G[k][n].y;
+      }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    for (int w = 0; w < BWD_WAVES - 1; ++w) {
+      const float* r = red + w * NRED * 64 + lane;
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int n = 0; n <= R; ++n)
+          G[k][n] += f2{r[((k * (R + 1) + n) * 2 + 0) * 64], r[((k * (R + 1) + n) * 2 + 1) * 64]};
+    }
+    if (cp.live) {
+      float* __restrict__ out = part + (size_t)chunk * K * (R + 1) * F;
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int n = 0; n <= R; ++n) stpair<PAIR>(out + ((size_t)k * (R + 1) + n) * F, cp, G[k][n]);
+    }
   }
 }
 
@@ -211,18 +356,38 @@ __global__ __launch_bounds__(256) void equi_msg_bwd_reduce(const float* __restri
   if (k >= 0) {
     const size_t stride = (size_t)K * (R + 1) * F;
     const float* p = part + ((size_t)k * (R + 1) + n) * F + f;
-    for (int c = 0; c < n_chunks; ++c) acc += p[c * stride];
+    int c = 0;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;               // 4 independent chains (fixed order)
+    for (; c + 4 <= n_chunks; c += 4) {
+      a0 += p[(size_t)c * stride];
+      a1 += p[(size_t)(c + 1) * stride];
+      a2 += p[(size_t)(c + 2) * stride];
+      a3 += p[(size_t)(c + 3) * stride];
+    }
+    for (; c < n_chunks; ++c) a0 += p[(size_t)c * stride];
+    acc = (a0 + a1) + (a2 + a3);
   }
   const int c_out = kk * F + f;
   if (n < R) gWd[(size_t)c_out * R + n] = acc; else gbd[c_out] = acc;
 }
 
-static inline int bwd_chunks(int n_src) {
-  // enough chunks to fill the chip, few enough that the partial buffer stays small
-  int c = n_src < 96 ? n_src : 96;
-  return c > 0 ? c : 1;
+constexpr int BWD_MAX_CHUNKS = 384;
+
+struct BwdShape {
+  bool split;
+  int npc, chunks, cpx;
+};
+static inline BwdShape bwd_shape(int n_src, long long n_edges_hint) {
+  BwdShape s;
+  s.split = n_edges_hint >= 48LL * (n_src > 0 ? n_src : 1);
+  const int min_npc = s.split ? 1 : BWD_WAVES;
+  int npc = (n_src + BWD_MAX_CHUNKS - 1) / BWD_MAX_CHUNKS;
+  if (npc < min_npc) npc = min_npc;
+  s.npc = npc;
+  s.chunks = n_src > 0 ? (n_src + npc - 1) / npc : 1;
+  s.cpx = (s.chunks + 7) / 8;
+  return s;
 }
-constexpr int BWD_WAVES = 4;
 
 }  // namespace cgv
 
@@ -230,33 +395,43 @@ extern "C" {
 
 int cgv_equi_msg_fwd(const float* phi, const float* v, const float* geom_d, const int32_t* rowptr_d,
                      const int32_t* src_d, const float* Wd, const float* bd, float* ds, float* dv, int n_dst,
-                     int n_feat, int n_rbf, int with_dv, void* stream) {
+                     int n_feat, int n_rbf, int with_dv, int64_t n_edges_hint, void* stream) {
   CGV_REQUIRE(n_dst >= 0 && n_feat > 0, "bad size");
   if (n_dst == 0) return 0;
   CGV_REQUIRE(phi && rowptr_d && Wd && bd && ds, "null pointer");
   CGV_REQUIRE(!with_dv || (v && dv), "with_dv needs v and dv");
-  constexpr int BLOCK = 64;
-  dim3 grid(n_dst, (n_feat + BLOCK - 1) / BLOCK), block(BLOCK);
   hipStream_t st = (hipStream_t)stream;
+  const int tiles = (n_feat + 127) / 128;
+  const int npx = (n_dst + 7) / 8;
+  const dim3 grid(8 * npx * tiles);
+  // high-degree graphs (>= 48 edges per receiver on average): 4 waves share a (node, tile)
+  const bool split = n_edges_hint >= 48LL * n_dst;
+  // 8-byte vector accesses need an even channel count and 8-byte aligned bases
+  const bool pair = (n_feat % 2 == 0) &&
+                    ((((uintptr_t)phi | (uintptr_t)v | (uintptr_t)ds | (uintptr_t)dv) & 7) == 0);
+#define CGV_FWD_LAUNCH(DV, SP, PR)                                                                                   \
+  hipLaunchKernelGGL((cgv::equi_msg_fwd_k<RBF, DV, SP, PR>), grid, dim3(64 * SP), 0, st, phi, v, geom_d, rowptr_d, src_d, \
+                     Wd, bd, ds, dv, n_feat, n_dst, npx, tiles)
+#define CGV_FWD_PICK(DV)                                                 \
+  if (pair) { if (split) CGV_FWD_LAUNCH(DV, 4, true); else CGV_FWD_LAUNCH(DV, 1, true); } \
+  else      { if (split) CGV_FWD_LAUNCH(DV, 4, false); else CGV_FWD_LAUNCH(DV, 1, false); }
   CGV_DISPATCH_RBF(n_rbf, {
-    if (with_dv)
-      hipLaunchKernelGGL((cgv::equi_msg_fwd_k<RBF, true, BLOCK>), grid, block, 0, st, phi, v, geom_d, rowptr_d, src_d,
-                         Wd, bd, ds, dv, n_feat);
-    else
-      hipLaunchKernelGGL((cgv::equi_msg_fwd_k<RBF, false, BLOCK>), grid, block, 0, st, phi, v, geom_d, rowptr_d, src_d,
-                         Wd, bd, ds, dv, n_feat);
+    if (with_dv) { CGV_FWD_PICK(true) } else { CGV_FWD_PICK(false) }
   });
+#undef CGV_FWD_PICK
+#undef CGV_FWD_LAUNCH
   return cgv::check_launch("cgv_equi_msg_fwd");
 }
 
 size_t cgv_equi_msg_bwd_workspace_bytes(int n_src, int n_feat, int n_rbf) {
-  return sizeof(float) * (size_t)cgv::bwd_chunks(n_src) * 3 * (n_rbf + 1) * n_feat + 256;
+  (void)n_src;
+  return sizeof(float) * (size_t)(cgv::BWD_MAX_CHUNKS + 8) * 3 * (n_rbf + 1) * n_feat + 256;
 }
 
 int cgv_equi_msg_bwd(const float* phi, const float* v, const float* geom_s, const int32_t* rowptr_s,
                      const int32_t* dst_s, const float* Wd, const float* bd, const float* gs, const float* gv,
                      float* g_phi, float* g_v, float* gWd, float* gbd, int n_src, int n_feat, int n_rbf,
-                     void* workspace, size_t workspace_bytes, void* stream) {
+                     int64_t n_edges_hint, void* workspace, size_t workspace_bytes, void* stream) {
   CGV_REQUIRE(n_src >= 0 && n_feat > 0, "bad size");
   CGV_REQUIRE(phi && rowptr_s && Wd && bd && g_phi && gWd && gbd && workspace, "null pointer");
   CGV_REQUIRE(!gv || (v && g_v), "gv needs v and g_v");
@@ -265,21 +440,27 @@ int cgv_equi_msg_bwd(const float* phi, const float* v, const float* geom_s, cons
     return CGV_E_WORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
-  const int chunks = cgv::bwd_chunks(n_src);
-  const int npc = n_src > 0 ? (n_src + chunks - 1) / chunks : 1;
+  const cgv::BwdShape sh = cgv::bwd_shape(n_src, n_edges_hint);
+  const int tiles = (n_feat + 127) / 128;
   float* part = reinterpret_cast<float*>(workspace);
-  constexpr int WV = cgv::BWD_WAVES;
-  dim3 grid(chunks, (n_feat + 63) / 64), block(64 * WV);
+  const dim3 grid(8 * sh.cpx * tiles), block(64 * cgv::BWD_WAVES);
+  const bool pair = (n_feat % 2 == 0) &&
+                    ((((uintptr_t)phi | (uintptr_t)v | (uintptr_t)gs | (uintptr_t)gv | (uintptr_t)g_phi |
+                       (uintptr_t)g_v | (uintptr_t)part) & 7) == 0);
+#define CGV_BWD_LAUNCH(GV, SP, PR)                                                                                 \
+  hipLaunchKernelGGL((cgv::equi_msg_bwd_k<RBF, GV, SP, PR>), grid, block, 0, st, phi, v, geom_s, rowptr_s, dst_s, Wd, \
+                     bd, gs, gv, g_phi, g_v, part, n_feat, n_src, sh.npc, sh.cpx, tiles)
+#define CGV_BWD_PICK(GV)                                                                   \
+  if (pair) { if (sh.split) CGV_BWD_LAUNCH(GV, true, true); else CGV_BWD_LAUNCH(GV, false, true); } \
+  else      { if (sh.split) CGV_BWD_LAUNCH(GV, true, false); else CGV_BWD_LAUNCH(GV, false, false); }
   CGV_DISPATCH_RBF(n_rbf, {
-    if (gv)
-      hipLaunchKernelGGL((cgv::equi_msg_bwd_k<RBF, true, WV>), grid, block, 0, st, phi, v, geom_s, rowptr_s, dst_s, Wd,
-                         bd, gs, gv, g_phi, g_v, part, n_feat, n_src, npc);
-    else
-      hipLaunchKernelGGL((cgv::equi_msg_bwd_k<RBF, false, WV>), grid, block, 0, st, phi, v, geom_s, rowptr_s, dst_s, Wd,
-                         bd, gs, gv, g_phi, g_v, part, n_feat, n_src, npc);
+    if (gv) { CGV_BWD_PICK(true) } else { CGV_BWD_PICK(false) }
   });
+#undef CGV_BWD_PICK
+#undef CGV_BWD_LAUNCH
+  // chunks beyond sh.chunks (padding to a multiple of 8) still write zero partials: sum them all
   dim3 rgrid((n_feat + 255) / 256, n_rbf + 1, 3);
-  hipLaunchKernelGGL(cgv::equi_msg_bwd_reduce, rgrid, dim3(256), 0, st, part, chunks, gv ? 3 : 1, n_rbf, n_feat, gWd, gbd);
+  hipLaunchKernelGGL(cgv::equi_msg_bwd_reduce, rgrid, dim3(256), 0, st, part, 8 * sh.cpx, gv ? 3 : 1, n_rbf, n_feat, gWd, gbd);
   return cgv::check_launch("cgv_equi_msg_bwd");
 }
 

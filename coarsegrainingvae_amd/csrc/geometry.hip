@@ -41,10 +41,12 @@ __global__ __launch_bounds__(256) void edge_geometry(const float* __restrict__ r
     g[n] = val * env;
   }
   g[R] = env;
-  g[R + 1] = __fdiv_rn(rx, d);   // conv.py:27 unit = r / dist
-  g[R + 2] = __fdiv_rn(ry, d);
-  g[R + 3] = __fdiv_rn(rz, d);
-  for (int k = R + 4; k < GS; ++k) g[k] = 0.0f;
+  const int U = geom_unit_offset(R);
+  for (int k = R + 1; k < U; ++k) g[k] = 0.0f;
+  const float ux = __fdiv_rn(rx, d), uy = __fdiv_rn(ry, d), uz = __fdiv_rn(rz, d);   // conv.py:27 unit = r / dist
+  g[U + 0] = ux; g[U + 1] = uy; g[U + 2] = uz;
+  g[U + 3] = ux; g[U + 4] = uy; g[U + 5] = uz;
+  for (int k = U + 6; k < GS; ++k) g[k] = 0.0f;
 }
 
 }  // namespace cgv

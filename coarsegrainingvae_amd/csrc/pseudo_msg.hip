@@ -61,7 +61,7 @@ __global__ __launch_bounds__(64) void pseudo_fwd_k(const float* __restrict__ phi
                                                    const float* __restrict__ Wd, const float* __restrict__ bd,
                                                    float* __restrict__ dh, float* __restrict__ dhbar,
                                                    float* __restrict__ dv, float* __restrict__ dvbar, int F) {
-  constexpr int GS = (R + 4 + 3) & ~3;
+  constexpr int GS = geom_stride(R), U = geom_unit_offset(R);
   const int i = blockIdx.x;
   const int f_raw = blockIdx.y * 64 + threadIdx.x;
   const bool live = f_raw < F;
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(64) void pseudo_fwd_k(const float* __restrict__ phi
 #pragma unroll
     for (int k = 0; k < 9; ++k) q[k] = pr[(size_t)k * F] * filt<R>(W[k], g);
     const v3 v_j = ldv(v + ((size_t)j * F + f) * 3), vb_j = ldv(vbar + ((size_t)j * F + f) * 3);
-    const v3 u{g[R + 1], g[R + 2], g[R + 3]};
+    const v3 u{g[U], g[U + 1], g[U + 2]};
     ah = fmaf(q[0], s_i, ah);
     ahb += dot(v_i, vb_j);
     axpy(av, q[1], u);
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(64) void pseudo_bwd_recv_k(const float* __restrict_
                                                         const float* __restrict__ gv, const float* __restrict__ gvb,
                                                         float* __restrict__ g_s, float* __restrict__ g_sbar,
                                                         float* __restrict__ g_v, float* __restrict__ g_vbar, int F) {
-  constexpr int GS = (R + 4 + 3) & ~3;
+  constexpr int GS = geom_stride(R), U = geom_unit_offset(R);
   const int i = blockIdx.x;
   const int f_raw = blockIdx.y * 64 + threadIdx.x;
   const bool live = f_raw < F;
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(64) void pseudo_bwd_src_k(
     const float* __restrict__ bd, const float* __restrict__ gh, const float* __restrict__ ghb,
     const float* __restrict__ gv, const float* __restrict__ gvb, float* __restrict__ g_phi,
     float* __restrict__ g_v, float* __restrict__ g_vbar, float* __restrict__ part, int F, int N, int nodes_per_chunk) {
-  constexpr int GS = (R + 4 + 3) & ~3;
+  constexpr int GS = geom_stride(R), U = geom_unit_offset(R);
   __shared__ float G[9 * (R + 1) * 64];
   const int lane = threadIdx.x;
   const int f_raw = blockIdx.y * 64 + lane;
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(64) void pseudo_bwd_src_k(
       const v3 gvb_i = gvb ? ldv(gvb + nf * 3) : v3{0.f, 0.f, 0.f};
       const float s_i = s[nf], sb_i = sbar[nf];
       const v3 v_i = ldv(v + nf * 3), vb_i = ldv(vbar + nf * 3);
-      const v3 u{g[R + 1], g[R + 2], g[R + 3]};
+      const v3 u{g[U], g[U + 1], g[U + 2]};
       float gq[9];
       gq[0] = gh_i * s_i;
       gq[1] = dot(gv_i, u);

@@ -148,9 +148,14 @@ def rbf_coefficients(n_rbf: int, cutoff: float, device) -> torch.Tensor:
 
 
 class EdgeGeometry:
-    """Per-edge records ``[a_0..a_{R-1}, env, ux, uy, uz]`` in both CSR orders."""
+    """Per-edge records ``[a_0..a_{R-1}, env, (pad), ux,uy,uz,ux,uy,uz]`` in both CSR orders."""
 
-    __slots__ = ("geom_d", "geom_s", "n_rbf", "cutoff", "stride")
+    def columns(self, rows: torch.Tensor) -> torch.Tensor:
+        """``[a_0..a_{R-1}, env, ux, uy, uz]`` view of record rows (for tests / inspection)."""
+        R, U = self.n_rbf, self.unit_offset
+        return torch.cat([rows[:, :R + 1], rows[:, U:U + 3]], dim=1)
+
+    __slots__ = ("geom_d", "geom_s", "n_rbf", "cutoff", "stride", "unit_offset")
 
     def __init__(self, plan: EdgePlan, n_rbf: int, cutoff: float, r_edges: Optional[torch.Tensor] = None,
                  pos_dst: Optional[torch.Tensor] = None, pos_src: Optional[torch.Tensor] = None):
@@ -159,6 +164,7 @@ class EdgeGeometry:
             raise RuntimeError(f"n_rbf={n_rbf} has no compiled kernel (see CGV_RBF_LIST in csrc/cgv_common.h)")
         self.n_rbf, self.cutoff = int(n_rbf), float(cutoff)
         self.stride = int(lib.cgv_geom_stride(n_rbf))
+        self.unit_offset = int(lib.cgv_geom_unit_offset(n_rbf))
         dev = plan.device
         E = max(plan.n_edges, 1)
         self.geom_d = torch.empty(E, self.stride, dtype=torch.float32, device=dev)

@@ -121,7 +121,9 @@ def _device(arg: str) -> torch.device:
 
 def _batches(dataset, indices, batch_size, rank, world, device):
     """Collate `batch_size` frames per step and give this rank its equal-size shard."""
-    for start in range(0, len(indices) - batch_size + 1, batch_size):
+    if 0 < len(indices) < batch_size:                     # small validation split: one (world-divisible) batch
+        indices, batch_size = indices[:len(indices) // world * world], len(indices) // world * world
+    for start in range(0, len(indices) - batch_size + 1, max(batch_size, 1)):
         chunk = indices[start:start + batch_size]
         shard = chunk[rank::world] if world > 1 else chunk
         yield cgdata.prepare_batch(cgdata.CG_collate([dataset[i] for i in shard]), device)

@@ -26,7 +26,9 @@
  * Edge geometry record ("geom"), one per edge, stride cgv_geom_stride(R) floats:
  *   [0..R)   a_n   = rbf_n(d) * env(d)          modules.py:148-172, 52-58
  *   [R]      env   = 0.5 (cos(pi d / cut) + 1)  (0 for d >= cut)
- *   [R+1..R+4) unit = r / d, d = sqrt(sum_k (r_k^2 + 1e-8))   conv.py:25-29
+ *   [U..U+6) ux,uy,uz,ux,uy,uz with U = cgv_geom_unit_offset(R) (even); unit = r / d,
+ *            d = sqrt(sum_k (r_k^2 + 1e-8))  conv.py:25-29.  Stored twice so that every adjacent
+ *            pair is an aligned 64-bit scalar operand for the packed-fp32 kernels.
  * so that the distance filter of modules.py:192-197 is
  *   w[c] = sum_n Wd[c][n] * a_n + bd[c] * env.
  */
@@ -51,8 +53,9 @@ const char* cgv_last_error_string(void);
 
 /* n_rbf values with a compiled kernel: returns 1 if supported. */
 int cgv_rbf_supported(int n_rbf);
-/* floats per edge-geometry record for this n_rbf (R + 4 rounded up to a multiple of 4). */
+/* floats per edge-geometry record for this n_rbf, and the offset of its unit-vector block. */
 int cgv_geom_stride(int n_rbf);
+int cgv_geom_unit_offset(int n_rbf);
 
 /* ---------------------------------------------------------------------------------------
  * K0  radius graph -- replaces get_neighbor_list, CoarseGrainingVAE/data.py:65-82, batched
@@ -126,11 +129,14 @@ int cgv_segment_broadcast(const float* gout, const int32_t* rowptr, const int32_
  *   dv[i,f,:] = sum_e ( m_2 * unit_e + m_0 * v[src(e), f, :] )
  * No [E, .] tensor is ever written.  with_dv = 0 skips the vector channel (explicit option;
  * the encoder never consumes it -- SURVEY 8a note a12) and leaves dv untouched.
+ * n_edges_hint (the edge count, or 0) only selects the launch shape: several waves share a
+ * receiver when the average degree is high.  Results do not depend on it beyond fp32
+ * summation order.
  * ------------------------------------------------------------------------------------- */
 int cgv_equi_msg_fwd(const float* phi /*[Ns,3F]*/, const float* v /*[Ns,F,3]*/, const float* geom_d,
                      const int32_t* rowptr_d, const int32_t* src_d, const float* Wd /*[3F,R]*/,
                      const float* bd /*[3F]*/, float* ds /*[Nd,F]*/, float* dv /*[Nd,F,3]*/, int n_dst,
-                     int n_feat, int n_rbf, int with_dv, void* stream);
+                     int n_feat, int n_rbf, int with_dv, int64_t n_edges_hint, void* stream);
 /* Backward.  gs / gv are the upstream gradients at the receivers (gv == NULL when dv is not
  * consumed).  Traverses the src-sorted view; writes g_phi [Ns,3F], g_v [Ns,F,3] (only if gv),
  * gWd [3F,R], gbd [3F] completely (zeros where nothing flows).  Deterministic two-stage
@@ -139,7 +145,8 @@ size_t cgv_equi_msg_bwd_workspace_bytes(int n_src, int n_feat, int n_rbf);
 int cgv_equi_msg_bwd(const float* phi, const float* v, const float* geom_s, const int32_t* rowptr_s,
                      const int32_t* dst_s, const float* Wd, const float* bd, const float* gs /*[Nd,F] or NULL*/,
                      const float* gv /*[Nd,F,3] or NULL*/, float* g_phi, float* g_v, float* gWd, float* gbd,
-                     int n_src, int n_feat, int n_rbf, void* workspace, size_t workspace_bytes, void* stream);
+                     int n_src, int n_feat, int n_rbf, int64_t n_edges_hint, void* workspace,
+                     size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * K3  fused EquiMessagePsuedo (conv.py:180-242), i = dst (receiver), j = src, q_k = phi[j,kF+f] w_k

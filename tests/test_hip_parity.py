@@ -90,8 +90,10 @@ def test_edge_geometry_matches_oracle(R, cutoff):
     plan = EdgePlan.from_nbrs(nbrs.to(DEV), n)
     for geom in (EdgeGeometry(plan, R, cutoff, r_edges=r.to(DEV)),
                  EdgeGeometry(plan, R, cutoff, pos_dst=xyz.to(DEV), pos_src=xyz.to(DEV))):
-        got_d = geom.geom_d[:, :R + 4].cpu()
-        got_s = geom.geom_s[:, :R + 4].cpu()
+        got_d = geom.columns(geom.geom_d).cpu()
+        got_s = geom.columns(geom.geom_s).cpu()
+        U = geom.unit_offset
+        assert torch.equal(geom.geom_d[:, U:U + 3], geom.geom_d[:, U + 3:U + 6])      # unit stored twice
         assert_close(got_d, want[plan.eid_d.cpu().long()], "geom_d", 2e-6)
         assert_close(got_s, want[plan.eid_s.cpu().long()], "geom_s", 2e-6)
     assert (want[:, :R].abs().sum(1) == 0).any() or cutoff > 4.5      # beyond-cutoff rows exercised for cutoff 3.0

@@ -28,13 +28,14 @@ def test_library_loads_and_exports_every_header_symbol():
     assert sorted(_lib.PROTOTYPES) == declared, "ctypes prototypes out of sync with the header"
     loaded = _lib.load()
     assert loaded.cgv_version() >= 100
-    assert loaded.cgv_geom_stride(8) == 12 and loaded.cgv_geom_stride(10) == 16
+    assert loaded.cgv_geom_stride(8) == 16 and loaded.cgv_geom_stride(10) == 20
+    assert loaded.cgv_geom_unit_offset(8) == 10 and loaded.cgv_geom_unit_offset(10) == 12
     assert loaded.cgv_rbf_supported(8) and loaded.cgv_rbf_supported(10) and not loaded.cgv_rbf_supported(9)
 
 
 def test_argument_errors_are_reported_without_a_gpu():
     lib = _lib.load()
-    rc = lib.cgv_equi_msg_fwd(None, None, None, None, None, None, None, None, None, 4, 8, 8, 1, None)
+    rc = lib.cgv_equi_msg_fwd(None, None, None, None, None, None, None, None, None, 4, 8, 8, 1, 0, None)
     assert rc == -1 and b"null" in lib.cgv_last_error_string()
     with pytest.raises(RuntimeError, match="cgv_segment_reduce failed"):
         _lib.call("cgv_segment_reduce", None, None, None, 3, 8, 0, None, None)
