@@ -24,6 +24,7 @@
 // Scheduling: 1-D grid, XCD-aware (block b -> XCD b % 8 gets a contiguous node range, so an XCD's
 // gathers stay inside a few frames and its phi/v working set fits the 4 MiB L2); on high-degree
 // graphs the 4 waves of a block split one node's segment and meet in LDS.
+#include <stdlib.h>
 #include "cgv_common.h"
 
 namespace cgv {
@@ -120,7 +121,8 @@ __global__ __launch_bounds__(64 * SPLIT) void equi_msg_fwd_k(const float* __rest
   const int node = xcd * nodes_per_xcd + local;
   const int tile = slot - local * tiles;
   if (node >= n_dst || local >= nodes_per_xcd) return;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform -> record loads stay scalar
   const ChanPair cp = chan_pair(tile, lane, F);
 
   f2 W0[R + 1], W1[R + 1], W2[R + 1];
@@ -207,7 +209,8 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void equi_msg_bwd_k(
   const int local = slot / tiles;
   const int chunk = xcd * chunks_per_xcd + local;
   const int tile = slot - local * tiles;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform -> record loads stay scalar
   const ChanPair cp = chan_pair(tile, lane, F);
 
   f2 W[K][R + 1], G[K][R + 1];
@@ -345,30 +348,32 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void equi_msg_bwd_k(
 
 // second stage: gWd[c][n] = sum_chunk part[chunk][k][n][f]; c = kk*F + f over all 3 slices.
 // K live slices: K == 3 -> kk = k; K == 1 -> only kk == 1 is live, the rest is written as 0.
-__global__ __launch_bounds__(256) void equi_msg_bwd_reduce(const float* __restrict__ part, int n_chunks, int K, int R,
-                                                           int F, float* __restrict__ gWd, float* __restrict__ gbd) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+// block = (64 channels, 16 chunk slices): slice s sums chunks s, s+16, ... and the 16 partial sums
+// meet in LDS in a fixed order (deterministic).  grid = (ceil(F/64), R+1, 3).
+constexpr int RED_SLICES = 16;
+__global__ __launch_bounds__(64 * RED_SLICES) void equi_msg_bwd_reduce(const float* __restrict__ part, int n_chunks,
+                                                                       int K, int R, int F, float* __restrict__ gWd,
+                                                                       float* __restrict__ gbd) {
+  __shared__ float red[RED_SLICES][64];
+  const int f = blockIdx.x * 64 + threadIdx.x;
+  const int s = threadIdx.y;
   const int n = blockIdx.y;        // 0..R  (R = bias)
   const int kk = blockIdx.z;       // 0..2
-  if (f >= F) return;
-  float acc = 0.f;
   const int k = (K == 3) ? kk : (kk == 1 ? 0 : -1);
-  if (k >= 0) {
+  float acc = 0.f;
+  if (k >= 0 && f < F) {
     const size_t stride = (size_t)K * (R + 1) * F;
     const float* p = part + ((size_t)k * (R + 1) + n) * F + f;
-    int c = 0;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;               // 4 independent chains (fixed order)
-    for (; c + 4 <= n_chunks; c += 4) {
-      a0 += p[(size_t)c * stride];
-      a1 += p[(size_t)(c + 1) * stride];
-      a2 += p[(size_t)(c + 2) * stride];
-      a3 += p[(size_t)(c + 3) * stride];
-    }
-    for (; c < n_chunks; ++c) a0 += p[(size_t)c * stride];
-    acc = (a0 + a1) + (a2 + a3);
+    for (int c = s; c < n_chunks; c += RED_SLICES) acc += p[(size_t)c * stride];
   }
+  red[s][threadIdx.x] = acc;
+  __syncthreads();
+  if (s != 0 || f >= F) return;
+  float tot = 0.f;
+#pragma unroll
+  for (int q = 0; q < RED_SLICES; ++q) tot += red[q][threadIdx.x];
   const int c_out = kk * F + f;
-  if (n < R) gWd[(size_t)c_out * R + n] = acc; else gbd[c_out] = acc;
+  if (n < R) gWd[(size_t)c_out * R + n] = tot; else gbd[c_out] = tot;
 }
 
 constexpr int BWD_MAX_CHUNKS = 384;
@@ -405,7 +410,8 @@ int cgv_equi_msg_fwd(const float* phi, const float* v, const float* geom_d, cons
   const int npx = (n_dst + 7) / 8;
   const dim3 grid(8 * npx * tiles);
   // high-degree graphs (>= 48 edges per receiver on average): 4 waves share a (node, tile)
-  const bool split = n_edges_hint >= 48LL * n_dst;
+  bool split = n_edges_hint >= 48LL * n_dst;
+  if (const char* dbg = getenv("CGV_DEBUG_FWD_SPLIT")) split = dbg[0] == '1';   // experiments only
   // 8-byte vector accesses need an even channel count and 8-byte aligned bases
   const bool pair = (n_feat % 2 == 0) &&
                     ((((uintptr_t)phi | (uintptr_t)v | (uintptr_t)ds | (uintptr_t)dv) & 7) == 0);
@@ -459,8 +465,9 @@ int cgv_equi_msg_bwd(const float* phi, const float* v, const float* geom_s, cons
 #undef CGV_BWD_PICK
 #undef CGV_BWD_LAUNCH
   // chunks beyond sh.chunks (padding to a multiple of 8) still write zero partials: sum them all
-  dim3 rgrid((n_feat + 255) / 256, n_rbf + 1, 3);
-  hipLaunchKernelGGL(cgv::equi_msg_bwd_reduce, rgrid, dim3(256), 0, st, part, 8 * sh.cpx, gv ? 3 : 1, n_rbf, n_feat, gWd, gbd);
+  dim3 rgrid((n_feat + 63) / 64, n_rbf + 1, 3);
+  hipLaunchKernelGGL(cgv::equi_msg_bwd_reduce, rgrid, dim3(64, cgv::RED_SLICES), 0, st, part, 8 * sh.cpx, gv ? 3 : 1, n_rbf,
+                     n_feat, gWd, gbd);
   return cgv::check_launch("cgv_equi_msg_bwd");
 }
 
