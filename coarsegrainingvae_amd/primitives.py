@@ -14,6 +14,8 @@ import torch
 import torch.nn.functional as Fn
 from torch import nn
 
+from . import _lib
+
 
 class Swish(nn.Module):
     """x * sigmoid(x) (modules.py:16-21), as one fused device op."""
@@ -38,37 +40,109 @@ def to_module(activation: str) -> nn.Module:
     return layer_types[activation]()
 
 
+def _skinny_ok(x2, weight):
+    """Bead-level products (M <= 64 rows) go to the weight-streaming HIP kernels (csrc/skinny_gemm.hip);
+    atom-level ones (hundreds of rows) are ordinary GEMMs and stay with hipBLASLt."""
+    if not (x2.is_cuda and x2.dtype == torch.float32 and weight.dtype == torch.float32):
+        return False
+    M, K = x2.shape
+    N = weight.shape[0]
+    return bool(_lib.load().cgv_skinny_supported(M, N, K)) and weight.is_contiguous() and weight.data_ptr() % 16 == 0
+
+
 class _LinearFn(torch.autograd.Function):
-    """y = x W^T + b with a backward that can write the weight / bias gradients straight into the
-    trainer's gradient arena (``param.grad`` is a view of it, trainer.py) instead of producing
-    temporaries that autograd then adds in: per step that removes one [out,in] allocation and one
-    read-modify-write pass per layer (~160 launches and ~0.8 GB of traffic at n_basis=600)."""
+    """y = x W^T + b.  Forward / backward run on the skinny-GEMM kernels when the row count is small,
+    and the backward can write the weight / bias gradients straight into the trainer's gradient
+    arena (``param.grad`` is a view of it, trainer.py) instead of producing temporaries that
+    autograd then adds in: per step that removes one [out,in] allocation and one read-modify-write
+    pass per layer (~160 launches and ~0.8 GB of traffic at n_basis=600)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
-        ctx.save_for_backward(x, weight)
+        x2 = x.reshape(-1, x.shape[-1])
         ctx.params = (weight, bias)
+        ctx.skinny = _skinny_ok(x2, weight) and (bias is None or bias.data_ptr() % 16 == 0)
+        if ctx.skinny:
+            x2 = x2.contiguous()
+            M, K = x2.shape
+            N = weight.shape[0]
+            y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+            _lib.call("cgv_skinny_linear_fwd", _lib.ptr(x2), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(y), M, N, K,
+                      _lib.stream_ptr())
+            ctx.save_for_backward(x2, weight)
+            return y.reshape(x.shape[:-1] + (N,))
+        ctx.save_for_backward(x, weight)
         return Fn.linear(x, weight, bias)
 
     @staticmethod
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
         w_param, b_param = ctx.params
-        gx = gy.matmul(weight) if ctx.needs_input_grad[0] else None
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_b = b_param is not None and ctx.needs_input_grad[2]
         x2, gy2 = x.reshape(-1, x.shape[-1]), gy.reshape(-1, gy.shape[-1])
+        if not ctx.skinny:
+            gx = gy.matmul(weight) if need_x else None
+            gw = _direct_grad(w_param, lambda out: torch.mm(gy2.t(), x2, out=out), lambda: gy2.t().mm(x2)) if need_w else None
+            gb = _direct_grad(b_param, lambda out: torch.sum(gy2, 0, out=out), lambda: gy2.sum(0)) if need_b else None
+            return gx, gw, gb
+        gy2 = gy2.contiguous()
+        M, K = x2.shape
+        N = weight.shape[0]
+        st = _lib.stream_ptr()
+        gx = None
+        if need_x:
+            gx = torch.empty(M, K, dtype=torch.float32, device=gy.device)
+            ws_bytes = int(_lib.load().cgv_skinny_bwd_input_workspace_bytes(M, N, K))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=gy.device)
+            _lib.call("cgv_skinny_linear_bwd_input", _lib.ptr(gy2), _lib.ptr(weight), _lib.ptr(gx), M, N, K, _lib.ptr(ws),
+                      ws_bytes, st)
+            gx = gx.reshape(gy.shape[:-1] + (K,))
         gw = gb = None
-        if ctx.needs_input_grad[1]:
-            gw = _direct_grad(w_param, lambda out: torch.mm(gy2.t(), x2, out=out), lambda: gy2.t().mm(x2))
-        if b_param is not None and ctx.needs_input_grad[2]:
-            gb = _direct_grad(b_param, lambda out: torch.sum(gy2, 0, out=out), lambda: gy2.sum(0))
+        if need_w or need_b:
+            tw, acc_w, gw = _grad_target(w_param, weight) if need_w else (None, False, None)
+            tb, acc_b, gb = _grad_target(b_param, b_param) if need_b else (None, False, None)
+            if tw is None:                                   # bias only (never on this path): plain reduction
+                gb = _direct_grad(b_param, lambda out: torch.sum(gy2, 0, out=out), lambda: gy2.sum(0))
+            else:
+                if tb is not None and acc_b != acc_w:        # mixed first/second write: keep the kernel's flag for W
+                    gb = _direct_grad_after(b_param, gy2.sum(0), acc_b)
+                    tb = None
+                _lib.call("cgv_skinny_linear_bwd_weight", _lib.ptr(gy2), _lib.ptr(x2), _lib.ptr(tw), _lib.ptr(tb), M, N, K,
+                          int(acc_w), st)
         return gx, gw, gb
+
+
+def _is_direct(param):
+    return param is not None and getattr(param, "_cgv_direct", False) and param.grad is not None
+
+
+def _grad_target(param, like):
+    """(tensor the kernel writes, accumulate?, value returned to autograd) for one parameter."""
+    if _is_direct(param) and param.grad.is_contiguous():
+        acc = not param._cgv_pending
+        param._cgv_pending = False
+        return param.grad, acc, None
+    out = torch.empty_like(like)
+    return out, False, out
+
+
+def _direct_grad_after(param, value, accumulate):
+    """Finish a direct-mode gradient whose target was already claimed by ``_grad_target``."""
+    if _is_direct(param):
+        if accumulate:
+            param.grad.add_(value)
+        else:
+            param.grad.copy_(value)
+        return None
+    return value
 
 
 def _direct_grad(param, write_into, compute):
     """Arena-managed parameter (trainer.ParamArena sets ``_cgv_direct``): the first gradient of a
     step is written in place into ``param.grad`` (no zero-fill needed), later ones are added.
     Otherwise return the gradient to autograd as usual."""
-    if getattr(param, "_cgv_direct", False) and param.grad is not None:
+    if _is_direct(param):
         if param._cgv_pending:
             write_into(param.grad)
             param._cgv_pending = False

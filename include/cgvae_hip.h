@@ -190,6 +190,24 @@ int cgv_update_gate_bwd(const float* U, const float* Vv, const float* a, const f
                         float* gU, float* gVv, float* ga, int n_nodes, int n_feat, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Skinny fp32 GEMMs for the node-level Dense / nn.Linear layers on the bead graph
+ * (modules.py:103-114 and their autograd backward): M <= cgv_skinny_max_rows() rows, weight
+ * W[N,K] row-major as torch stores it, N % 4 == 0, K % 4 == 0, 16-byte aligned operands.
+ *   fwd        y[M,N]  = x[M,K] W^T + bias                (bias may be NULL)
+ *   bwd_input  gx[M,K] = gy[M,N] W                        (deterministic split over N via workspace)
+ *   bwd_weight gW[N,K] = gy^T x, gb[N] = sum_m gy[m,:]    (accumulate != 0: added onto gW / gb)
+ * Weight-streaming kernels (v_mfma_f32_16x16x4_f32 is an exact fp32 FMA chain).
+ * ------------------------------------------------------------------------------------- */
+int cgv_skinny_max_rows(void);
+int cgv_skinny_supported(int M, int N, int K);
+int cgv_skinny_linear_fwd(const float* x, const float* W, const float* bias, float* y, int M, int N, int K, void* stream);
+size_t cgv_skinny_bwd_input_workspace_bytes(int M, int N, int K);
+int cgv_skinny_linear_bwd_input(const float* gy, const float* W, float* gx, int M, int N, int K, void* workspace,
+                                size_t workspace_bytes, void* stream);
+int cgv_skinny_linear_bwd_weight(const float* gy, const float* x, float* gW, float* gb /*or NULL*/, int M, int N, int K,
+                                 int accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Fused optimiser step over a flat fp32 arena of the parameters that receive gradients --
  * replaces the skip rule, clip_grad_norm_(params, 0.01) and Adam.step() of
  * scripts/utils.py:145-157 (torch.optim.Adam defaults: no amsgrad, no weight decay).

@@ -436,3 +436,46 @@ def test_direct_gradient_writes_equal_autograd_accumulation():
     (lin(x1).pow(2).sum() + lin(x2).sum()).backward()
     assert_close(lin.weight.grad, ref_w, "weight grad", 1e-5)
     assert_close(lin.bias.grad, ref_b, "bias grad", 1e-5)
+
+
+# --------------------------------------------------------------------------- skinny GEMMs (bead-level Dense layers)
+@pytest.mark.parametrize("M,N,K", [(12, 600, 600), (12, 5400, 600), (36, 600, 600), (12, 600, 1200), (12, 1800, 600),
+                                   (1, 4, 4), (64, 72, 40), (17, 52, 1000), (3, 5400, 24)])
+def test_skinny_linear_fwd_bwd_vs_fp64(M, N, K):
+    gen = torch.Generator().manual_seed(M * 1000 + N + K)
+    x = torch.randn(M, K, generator=gen)
+    W = torch.randn(N, K, generator=gen) / K ** 0.5
+    b = torch.randn(N, generator=gen)
+    gy = torch.randn(M, N, generator=gen)
+    xd, Wd_, bd_ = (t.double().requires_grad_(True) for t in (x, W, b))
+    yd = torch.nn.functional.linear(xd, Wd_, bd_)
+    yd.backward(gy.double())
+    lin = cg.primitives.Linear(K, N).to(DEV)
+    with torch.no_grad():
+        lin.weight.copy_(W)
+        lin.bias.copy_(b)
+    xg = x.to(DEV).requires_grad_(True)
+    y = lin(xg)
+    y.backward(gy.to(DEV))
+    assert_close(y, yd, "y", 2e-6)
+    assert_close(xg.grad, xd.grad, "gx", 2e-6)
+    assert_close(lin.weight.grad, Wd_.grad, "gW", 2e-6)
+    assert_close(lin.bias.grad, bd_.grad, "gb", 2e-6)
+    # no-bias flavour (u_mat / v_mat) on a 3-D input
+    y2 = cg.primitives.linear(xg.detach().reshape(1, M, K), lin.weight.detach())
+    assert_close(y2[0], (xd @ Wd_.t()).detach(), "y no bias", 2e-6)
+
+
+def test_skinny_direct_gradient_accumulation():
+    from coarsegrainingvae_amd.trainer import ParamArena
+    torch.manual_seed(1)
+    lin = cg.primitives.Linear(600, 1800).to(DEV)
+    x1, x2 = torch.randn(12, 600, device=DEV), torch.randn(36, 600, device=DEV)
+    (lin(x1).pow(2).sum() + lin(x2).sum()).backward()
+    ref_w, ref_b = lin.weight.grad.clone(), lin.bias.grad.clone()
+    arena = ParamArena(list(lin.parameters()))
+    arena.g.fill_(float("nan"))
+    arena.zero_grad()
+    (lin(x1).pow(2).sum() + lin(x2).sum()).backward()
+    assert_close(lin.weight.grad, ref_w, "weight grad", 1e-5)
+    assert_close(lin.bias.grad, ref_b, "bias grad", 1e-5)
