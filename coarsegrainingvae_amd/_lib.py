@@ -50,10 +50,11 @@ PROTOTYPES = {
     "cgv_update_gate_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
     "cgv_skinny_max_rows": (_i, []),
     "cgv_skinny_supported": (_i, [_i, _i, _i]),
-    "cgv_skinny_linear_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
-    "cgv_skinny_bwd_input_workspace_bytes": (_sz, [_i, _i, _i]),
-    "cgv_skinny_linear_bwd_input": (_i, [_p, _p, _p, _i, _i, _i, _p, _sz, _p]),
-    "cgv_skinny_linear_bwd_weight": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "cgv_skinny_linear_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "cgv_skinny_linear_bwd_input": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "cgv_wgrad_record_bytes": (_i, []),
+    "cgv_wgrad_plan": (_i, [_i, _i, _i, _p, _p, _p]),
+    "cgv_grouped_wgrad": (_i, [_p, _i, _i, _i, _p]),
     "cgv_optim_state_floats": (_i, []),
     "cgv_optim_partial_floats": (_i, []),
     "cgv_adam_clip_step": (_i, [_p, _p, _p, _p, C.c_int64, _f, _f, _f, _f, _f, _f, _p, _f, _p, _p, _p]),

@@ -1,21 +1,23 @@
 // Skinny fp32 GEMMs for the node-level Dense layers on the bead graph (M = beads or 3*beads
 // rows, 12..64; K, N = n_basis multiples, 600..5400).
 //
-// Reference: Dense / nn.Linear forward (CoarseGrainingVAE/modules.py:103-114) and its autograd
-// backward, called ~220 times per training step of the chignolin config.  With M <= 64 these
-// products are weight-streaming (GEMV-like): the [N,K] weight (1.4 - 13 MB) is read once, the
-// arithmetic is negligible.  hipBLASLt's tiled kernels take 10-24 us for them (profiles/r01c);
-// the kernels below stream the weight once at HBM/L2 speed:
-//   fwd        y[M,N]  = x[M,K] W[N,K]^T + b      v_mfma_f32_16x16x4_f32, W rows as A, x^T as B
-//   bwd_input  gx[M,K] = gy[M,N] W[N,K]           same instruction, W^T as A, split over N
-//   bwd_weight gW[N,K] (+)= gy[M,N]^T x[M,K]      write-bound outer products, packed VALU
-// f32-input MFMA is an exact fp32 FMA chain (bitwise an fmaf loop), so parity is unaffected.
+// Reference: Dense / nn.Linear forward (CoarseGrainingVAE/modules.py:103-114, activation Swish
+// modules.py:16-21) and its autograd backward, ~70 layer-uses per training step of the chignolin
+// config.  With M <= 64 these products are weight-streaming (GEMV-like): the [N,K] weight
+// (1.4 - 13 MB) is read once, the arithmetic is negligible, and what a step pays is mostly the
+// NUMBER of launches (measured: ~4-5 us of GPU time per small kernel inside the captured step
+// graph, profiles/r01d).  So the design goal here is launches, then bytes:
+//   fwd        z = x W^T + b ; y = act(z)          ONE launch (bias + Swish in the epilogue)
+//   bwd_input  gx = (gy * act'(z)) W               ONE launch (activation backward in the operand
+//                                                   load, N-split over 16 waves reduced in LDS --
+//                                                   no partial buffers, no second kernel)
+//   wgrad      gW (+)= (gy * act'(z))^T x, gb      ONE launch PER STEP for all layers: a grouped
+//                                                   kernel over a device table of problems, queued
+//                                                   during backward and flushed before the optimiser
+// Matrix products use v_mfma_f32_16x16x4_f32: exact fp32 FMA chains (bitwise an fmaf loop).
 //
 // MFMA 16x16x4 f32 operand map (cdna_hip_programming.md 3): lane l holds A[i = l&15][k = l>>4],
-// B[k = l>>4][j = l&15]; D: col j = l&15, row i = 4*(l>>4) + reg.  Each lane loads a float4 that
-// is contiguous in memory and feeds its four components to four MFMAs whose k (fwd) or i
-// (bwd_input) index is the component -- any consistent bijection is legal -- so every weight
-// load instruction is 16 rows x 64 B (fwd) or 4 rows x 256 B (bwd_input) of contiguous bytes.
+// B[k = l>>4][j = l&15]; D: col j = l&15, row i = 4*(l>>4) + reg.
 #include "cgv_common.h"
 
 namespace cgv {
@@ -25,51 +27,62 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 ldg4_or_zero(const float* p, bool ok) {
   return ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
 }
+__device__ __forceinline__ float sigmoidf_(float z) { return 1.0f / (1.0f + expf(-z)); }
+// act: 0 = identity, 1 = Swish / SiLU  x * sigmoid(x)
+__device__ __forceinline__ float act_fwd(float z, int act) { return act == 1 ? z * sigmoidf_(z) : z; }
+__device__ __forceinline__ float act_bwd(float z, int act) {
+  if (act != 1) return 1.0f;
+  const float s = sigmoidf_(z);
+  return s * (1.0f + z * (1.0f - s));
+}
 
 // ------------------------------------------------------------------ fwd
-// grid = ceil(N/16) blocks, block = 256 = 4 waves splitting K; MB = ceil(M/16) accumulators.
-template <int MB>
-__global__ __launch_bounds__(256) void skinny_fwd_k(const float* __restrict__ x, const float* __restrict__ W,
-                                                    const float* __restrict__ bias, float* __restrict__ y, int M, int N,
-                                                    int K) {
-  __shared__ float red[3][MB][4][64];
+// Block = 16 output columns n0..n0+15, WAVES waves splitting K in whole 16-float steps.  Lane
+// (i = l&15, q = l>>4) loads W[n0+i, 16 s + 4 q .. +3] (16 rows x 64 contiguous bytes per wave
+// instruction) and the matching x[m, ...] float4; component c feeds MFMA c (k = 16 s + 4 q + c).
+// D: lane holds y[m = 16 mb + (l&15)][n0 + 4 q + r], r = 0..3 -> one 16-byte store per m-block.
+template <int MB, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void skinny_fwd_k(const float* __restrict__ x, const float* __restrict__ W,
+                                                           const float* __restrict__ bias, float* __restrict__ y,
+                                                           float* __restrict__ zout, int M, int N, int K, int act) {
+  __shared__ float red[(WAVES - 1) * MB * 4 * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, q = lane >> 4;
   const int n0 = blockIdx.x * 16;
   const int nrow = n0 + i;
   const bool nok = nrow < N;
   const float* wrow = W + (size_t)(nok ? nrow : 0) * K;
-  // K split into 4 contiguous ranges of whole 16-float steps
   const int steps = (K + 15) / 16;
-  const int per = (steps + 3) / 4;
+  const int per = (steps + WAVES - 1) / WAVES;
   const int s_beg = wave * per, s_end = min(s_beg + per, steps);
   f32x4 acc[MB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
+#pragma unroll 4
   for (int s = s_beg; s < s_end; ++s) {
     const int k = s * 16 + 4 * q;
     const bool kok = k < K;                       // K % 4 == 0: a float4 is entirely in or out
-    const float4 a = ldg4_or_zero(wrow + k, nok && kok);
+    const float4 a = ldg4_or_zero(wrow + (kok ? k : 0), nok && kok);
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
       const int m = mb * 16 + i;
-      const float4 b = ldg4_or_zero(x + (size_t)(m < M ? m : 0) * K + k, m < M && kok);
+      const float4 b = ldg4_or_zero(x + (size_t)(m < M ? m : 0) * K + (kok ? k : 0), m < M && kok);
       acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[mb], 0, 0, 0);
       acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[mb], 0, 0, 0);
       acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[mb], 0, 0, 0);
       acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[mb], 0, 0, 0);
     }
   }
-  if (wave > 0) {
+  if (WAVES > 1) {
+    if (wave > 0) {
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
+      for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) red[wave - 1][mb][r][lane] = acc[mb][r];
+        for (int r = 0; r < 4; ++r) red[(((wave - 1) * MB + mb) * 4 + r) * 64 + lane] = acc[mb][r];
+    }
+    __syncthreads();
+    if (wave != 0) return;
   }
-  __syncthreads();
-  if (wave != 0) return;
-  // D[i = n_local = 4q + r][j = m_local = lane & 15]: 4 consecutive n per lane -> one 16-byte store
   const int n = n0 + 4 * q;
   if (n >= N) return;                              // N % 4 == 0
   float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -78,164 +91,213 @@ __global__ __launch_bounds__(256) void skinny_fwd_k(const float* __restrict__ x,
   for (int mb = 0; mb < MB; ++mb) {
     const int m = mb * 16 + i;
     f32x4 t = acc[mb];
+    for (int w = 0; w < WAVES - 1; ++w)
 #pragma unroll
-    for (int w = 0; w < 3; ++w)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) t[r] += red[w][mb][r][lane];
-    if (m < M) *reinterpret_cast<float4*>(y + (size_t)m * N + n) = make_float4(t[0] + bv.x, t[1] + bv.y, t[2] + bv.z, t[3] + bv.w);
+      for (int r = 0; r < 4; ++r) t[r] += red[((w * MB + mb) * 4 + r) * 64 + lane];
+    if (m < M) {
+      const float4 zv = make_float4(t[0] + bv.x, t[1] + bv.y, t[2] + bv.z, t[3] + bv.w);
+      if (act) {
+        if (zout) *reinterpret_cast<float4*>(zout + (size_t)m * N + n) = zv;
+        *reinterpret_cast<float4*>(y + (size_t)m * N + n) =
+            make_float4(act_fwd(zv.x, act), act_fwd(zv.y, act), act_fwd(zv.z, act), act_fwd(zv.w, act));
+      } else {
+        *reinterpret_cast<float4*>(y + (size_t)m * N + n) = zv;
+      }
+    }
   }
 }
 
 // ------------------------------------------------------------------ bwd_input
-// gx[m, k] = sum_n gy[m, n] W[n, k].  A wave owns 64 consecutive k (four MFMAs per 4-row step of n:
-// component c of the lane's float4 is output row k = k0 + 4 (l&15) + c); the 4 waves of a block
-// and `nsplit` blocks along grid.y split N; partials part[split][M][K] are summed by a second
-// launch in a fixed order.  grid = (ceil(K/64), nsplit), block = 256.
-template <int MB>
-__global__ __launch_bounds__(256) void skinny_bwd_input_k(const float* __restrict__ gy, const float* __restrict__ W,
-                                                          float* __restrict__ part, int M, int N, int K, int n_per_block) {
-  __shared__ float red[3][MB][16][64];
+// gx[m, k] = sum_n g[m, n] W[n, k],  g = gy * act'(z).  Block = 16 output columns k0..k0+15, WAVES
+// waves splitting N in whole 4-row steps.  Lane (i = l&15, q = l>>4): A[i][kk = q] = W[n + q, k0 + i]
+// (4 rows x 64 contiguous bytes per wave instruction), B[kk = q][j = l&15] = g[m = 16 mb + (l&15), n + q].
+// D: lane holds gx[m = 16 mb + (l&15)][k0 + 4 q + r] -> one 16-byte store.  Single launch, the
+// N-split meets in LDS in a fixed order (deterministic).
+template <int MB, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void skinny_bwd_input_k(const float* __restrict__ gy, const float* __restrict__ z,
+                                                                 const float* __restrict__ W, float* __restrict__ gx,
+                                                                 int M, int N, int K, int act) {
+  __shared__ float red[(WAVES - 1) * MB * 4 * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, q = lane >> 4;
-  const int k0 = blockIdx.x * 64;
-  const int k = k0 + 4 * i;
-  const bool kok = k < K;
-  const int nb_beg = blockIdx.y * n_per_block;
-  const int nb_end = min(nb_beg + n_per_block, N);
-  // this wave's quarter of the block's n range, in whole steps of 4 rows
-  const int steps = (nb_end - nb_beg + 3) / 4;
-  const int per = (steps + 3) / 4;
+  const int k0 = blockIdx.x * 16;
+  const int kcol = k0 + i;
+  const bool kok = kcol < K;
+  const int steps = (N + 3) / 4;
+  const int per = (steps + WAVES - 1) / WAVES;
   const int s_beg = wave * per, s_end = min(s_beg + per, steps);
-  f32x4 acc[MB][4];
+  f32x4 acc[MB][2];
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) acc[mb][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int mb = 0; mb < MB; ++mb) acc[mb][0] = acc[mb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int s = s_beg;
+  // two independent accumulator chains per m-block hide the 40-cycle dependent-MFMA latency
 #pragma unroll 2
-  for (int s = s_beg; s < s_end; ++s) {
-    const int n = nb_beg + 4 * s + q;
-    const bool nok = n < nb_end;
-    const float4 a = ldg4_or_zero(W + (size_t)(nok ? n : 0) * K + (kok ? k : 0), nok && kok);
+  for (; s + 2 <= s_end; s += 2) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int n = 4 * (s + h) + q;
+      const bool nok = n < N;
+      const float a = (nok && kok) ? W[(size_t)n * K + kcol] : 0.f;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const int m = mb * 16 + i;
+        float b = 0.f;
+        if (nok && m < M) {
+          b = gy[(size_t)m * N + n];
+          if (act) b *= act_bwd(z[(size_t)m * N + n], act);
+        }
+        acc[mb][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[mb][h], 0, 0, 0);
+      }
+    }
+  }
+  for (; s < s_end; ++s) {
+    const int n = 4 * s + q;
+    const bool nok = n < N;
+    const float a = (nok && kok) ? W[(size_t)n * K + kcol] : 0.f;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
       const int m = mb * 16 + i;
-      const float b = (nok && m < M) ? gy[(size_t)m * N + n] : 0.f;       // B[kk = q][j = m]
-      acc[mb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b, acc[mb][0], 0, 0, 0);
-      acc[mb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b, acc[mb][1], 0, 0, 0);
-      acc[mb][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b, acc[mb][2], 0, 0, 0);
-      acc[mb][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b, acc[mb][3], 0, 0, 0);
+      float b = 0.f;
+      if (nok && m < M) {
+        b = gy[(size_t)m * N + n];
+        if (act) b *= act_bwd(z[(size_t)m * N + n], act);
+      }
+      acc[mb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[mb][0], 0, 0, 0);
     }
   }
-  if (wave > 0) {
+  f32x4 tot[MB];
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
+  for (int mb = 0; mb < MB; ++mb) tot[mb] = acc[mb][0] + acc[mb][1];
+  if (WAVES > 1) {
+    if (wave > 0) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
+      for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[wave - 1][mb][c * 4 + r][lane] = acc[mb][c][r];
+        for (int r = 0; r < 4; ++r) red[(((wave - 1) * MB + mb) * 4 + r) * 64 + lane] = tot[mb][r];
+    }
+    __syncthreads();
+    if (wave != 0) return;
   }
-  __syncthreads();
-  if (wave != 0) return;
-  // MFMA c, register r: output row i' = 4q + r  ->  k = k0 + 4 i' + c = k0 + 16 q + 4 r + c ; column j = m
-  float* out = part + (size_t)blockIdx.y * M * K;
+  const int kk = k0 + 4 * q;
+  if (kk >= K) return;                             // K % 4 == 0
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
     const int m = mb * 16 + i;
+    f32x4 t = tot[mb];
+    for (int w = 0; w < WAVES - 1; ++w)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float t[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        t[c] = acc[mb][c][r];
-#pragma unroll
-        for (int w = 0; w < 3; ++w) t[c] += red[w][mb][c * 4 + r][lane];
-      }
-      const int kk = k0 + 16 * q + 4 * r;
-      if (m < M && kk < K) *reinterpret_cast<float4*>(out + (size_t)m * K + kk) = make_float4(t[0], t[1], t[2], t[3]);
-    }
+      for (int r = 0; r < 4; ++r) t[r] += red[((w * MB + mb) * 4 + r) * 64 + lane];
+    if (m < M) *reinterpret_cast<float4*>(gx + (size_t)m * K + kk) = make_float4(t[0], t[1], t[2], t[3]);
   }
 }
 
-__global__ __launch_bounds__(256) void skinny_sum_partials(const float* __restrict__ part, int nsplit, size_t count4,
-                                                           float* __restrict__ out) {
-  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= count4) return;
-  const float4* p = reinterpret_cast<const float4*>(part) + idx;
-  float4 acc = p[0];
-  for (int s = 1; s < nsplit; ++s) {
-    const float4 t = p[(size_t)s * count4];
-    acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
-  }
-  reinterpret_cast<float4*>(out)[idx] = acc;
-}
+// ------------------------------------------------------------------ grouped weight gradient
+// One launch for every queued layer: problem p (device table) is  gW_p[N,K] (+)= g_p^T x_p,
+// gb_p[n] (+)= sum_m g_p[m,n]  with g_p = gy_p * act'(z_p).  Write-bound: a block produces ROWS
+// rows x one k tile of one problem from an LDS-staged x tile; blocks of all problems are
+// concatenated (block_begin prefix in the table, binary search per block).
+constexpr int WG_ROWS = 16;
 
-// ------------------------------------------------------------------ bwd_weight
-// gW[n, k] (+)= sum_m gy[m, n] x[m, k];  gb[n] (+)= sum_m gy[m, n].  Write-bound: every output
-// float4 is produced by one thread from an LDS-staged x tile (M x tile_w floats) and the block's
-// gy columns; ROWS output rows per block along grid.x, k tiles along grid.y, one float4 of k per
-// thread.
-template <int ROWS>
-__global__ __launch_bounds__(256) void skinny_bwd_weight_k(const float* __restrict__ gy, const float* __restrict__ x,
-                                                           float* __restrict__ gW, float* __restrict__ gb, int M, int N,
-                                                           int K, int tile_w, int accumulate) {
+struct WgradProblem {       // mirrors the 80-byte host record built in python (primitives.WeightGradQueue)
+  const float* gy;
+  const float* x;
+  const float* z;           // pre-activation or NULL
+  float* gW;
+  float* gb;                // or NULL
+  int M, N, K;
+  int accumulate, act;
+  int block_begin;          // first global block index of this problem
+  int tiles_k;              // k tiles per row block
+  int tile_w;               // floats per k tile (multiple of 4)
+  int pad;
+};
+static_assert(sizeof(WgradProblem) == 80, "host/device record layout");
+
+__global__ __launch_bounds__(256) void grouped_wgrad_k(const WgradProblem* __restrict__ table, int n_problems) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  // locate the problem of this block (table is tiny; block_begin ascending)
+  int lo = 0, hi = n_problems - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid].block_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const WgradProblem pr = table[lo];
+  const int local = blockIdx.x - pr.block_begin;
+  const int rb = local / pr.tiles_k, kt = local - rb * pr.tiles_k;
+  const int M = pr.M, N = pr.N, K = pr.K, tile_w = pr.tile_w;
   float* xs = smem;                          // [M][tile_w]
-  float* gs = smem + (size_t)M * tile_w;     // [M][ROWS]
+  float* gs = smem + (size_t)M * tile_w;     // [M][WG_ROWS]
   const int t = threadIdx.x;
-  const int n0 = blockIdx.x * ROWS;
-  const int k = blockIdx.y * tile_w + 4 * t;
+  const int n0 = rb * WG_ROWS;
+  const int k = kt * tile_w + 4 * t;
   const bool kok = 4 * t < tile_w && k < K;
   if (4 * t < tile_w)
     for (int m = 0; m < M; ++m)
-      *reinterpret_cast<float4*>(xs + (size_t)m * tile_w + 4 * t) = ldg4_or_zero(x + (size_t)m * K + (kok ? k : 0), kok);
-  for (int idx = t; idx < M * ROWS; idx += blockDim.x) {
-    const int m = idx / ROWS, r = idx - m * ROWS;
-    gs[idx] = (n0 + r < N) ? gy[(size_t)m * N + n0 + r] : 0.f;
+      *reinterpret_cast<float4*>(xs + (size_t)m * tile_w + 4 * t) = ldg4_or_zero(pr.x + (size_t)m * K + (kok ? k : 0), kok);
+  for (int idx = t; idx < M * WG_ROWS; idx += blockDim.x) {
+    const int m = idx / WG_ROWS, r = idx - m * WG_ROWS;
+    float g = 0.f;
+    if (n0 + r < N) {
+      g = pr.gy[(size_t)m * N + n0 + r];
+      if (pr.act) g *= act_bwd(pr.z[(size_t)m * N + n0 + r], pr.act);
+    }
+    gs[idx] = g;
   }
   __syncthreads();
   if (kok) {
-    float4 acc[ROWS];
+    float4 acc[WG_ROWS];
 #pragma unroll
-    for (int r = 0; r < ROWS; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = 0; r < WG_ROWS; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int m = 0; m < M; ++m) {
       const float4 xv = *reinterpret_cast<const float4*>(xs + (size_t)m * tile_w + 4 * t);
 #pragma unroll
-      for (int r = 0; r < ROWS; ++r) {
-        const float g = gs[m * ROWS + r];              // LDS broadcast
+      for (int r = 0; r < WG_ROWS; ++r) {
+        const float g = gs[m * WG_ROWS + r];              // LDS broadcast
         acc[r].x = fmaf(g, xv.x, acc[r].x); acc[r].y = fmaf(g, xv.y, acc[r].y);
         acc[r].z = fmaf(g, xv.z, acc[r].z); acc[r].w = fmaf(g, xv.w, acc[r].w);
       }
     }
 #pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
+    for (int r = 0; r < WG_ROWS; ++r) {
       if (n0 + r < N) {
-        float4* dst = reinterpret_cast<float4*>(gW + (size_t)(n0 + r) * K + k);
+        float4* dst = reinterpret_cast<float4*>(pr.gW + (size_t)(n0 + r) * K + k);
         float4 o = acc[r];
-        if (accumulate) { const float4 old = *dst; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+        if (pr.accumulate) { const float4 old = *dst; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
         *dst = o;
       }
     }
   }
-  if (gb && blockIdx.y == 0 && t < ROWS && n0 + t < N) {
+  if (pr.gb && kt == 0 && t < WG_ROWS && n0 + t < N) {
     float sum = 0.f;
-    for (int m = 0; m < M; ++m) sum += gs[m * ROWS + t];
-    gb[n0 + t] = accumulate ? gb[n0 + t] + sum : sum;
+    for (int m = 0; m < M; ++m) sum += gs[m * WG_ROWS + t];
+    pr.gb[n0 + t] = pr.accumulate ? pr.gb[n0 + t] + sum : sum;
   }
 }
 
-static inline int bwd_input_splits(int N, int K) {
-  const int kblocks = (K + 63) / 64;
-  int s = (N + 255) / 256;                      // about 256 rows of W per block ...
-  const int want = (160 + kblocks - 1) / kblocks;   // ... but at least ~160 blocks in flight
-  if (s < want) s = want;
-  const int cap = (N + 15) / 16;                // never fewer than 16 rows per block
-  if (s > cap) s = cap;
-  if (s > 32) s = 32;
-  return s < 1 ? 1 : s;
+// k tiling of one problem: as wide as a 60 KiB LDS budget for the x tile allows, <= 256 float4
+static inline void wgrad_tiling(int M, int K, int* tiles_k, int* tile_w) {
+  int max_t4 = (15000 / M) / 4;
+  if (max_t4 > 256) max_t4 = 256;
+  if (max_t4 < 1) max_t4 = 1;
+  const int k4 = K / 4;
+  const int nt = (k4 + max_t4 - 1) / max_t4;
+  const int per = (k4 + nt - 1) / nt;
+  *tiles_k = nt;
+  *tile_w = per * 4;
 }
-static inline int bwd_input_splits(int N) { return bwd_input_splits(N, 64 * 160); }
 
-
+template <int MB>
+static void launch_fwd(dim3 grid, int waves, hipStream_t st, const float* x, const float* W, const float* bias, float* y,
+                       float* z, int M, int N, int K, int act) {
+  if (waves >= 16) hipLaunchKernelGGL((skinny_fwd_k<MB, 16>), grid, dim3(1024), 0, st, x, W, bias, y, z, M, N, K, act);
+  else if (waves >= 8) hipLaunchKernelGGL((skinny_fwd_k<MB, 8>), grid, dim3(512), 0, st, x, W, bias, y, z, M, N, K, act);
+  else hipLaunchKernelGGL((skinny_fwd_k<MB, 4>), grid, dim3(256), 0, st, x, W, bias, y, z, M, N, K, act);
+}
+template <int MB>
+static void launch_bwd_input(dim3 grid, hipStream_t st, const float* gy, const float* z, const float* W, float* gx, int M,
+                             int N, int K, int act) {
+  hipLaunchKernelGGL((skinny_bwd_input_k<MB, 16>), grid, dim3(1024), 0, st, gy, z, W, gx, M, N, K, act);
+}
 
 }  // namespace cgv
 
@@ -247,74 +309,62 @@ int cgv_skinny_supported(int M, int N, int K) {
   return M >= 1 && M <= 64 && N >= 4 && K >= 4 && (N % 4) == 0 && (K % 4) == 0;
 }
 
-int cgv_skinny_linear_fwd(const float* x, const float* W, const float* bias, float* y, int M, int N, int K, void* stream) {
+int cgv_skinny_linear_fwd(const float* x, const float* W, const float* bias, float* y, float* z, int M, int N, int K,
+                          int act, void* stream) {
   CGV_REQUIRE(x && W && y, "null pointer");
+  CGV_REQUIRE(act == 0 || act == 1, "act must be 0 (identity) or 1 (swish)");
   CGV_REQUIRE(cgv_skinny_supported(M, N, K), "unsupported shape (need M <= 64, N % 4 == 0, K % 4 == 0)");
-  CGV_REQUIRE(((((uintptr_t)x | (uintptr_t)W | (uintptr_t)y | (uintptr_t)bias)) & 15) == 0, "operands must be 16-byte aligned");
+  CGV_REQUIRE(((((uintptr_t)x | (uintptr_t)W | (uintptr_t)y | (uintptr_t)bias | (uintptr_t)z)) & 15) == 0,
+              "operands must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid((N + 15) / 16), block(256);
+  const dim3 grid((N + 15) / 16);
+  // enough waves to fill the chip: few column blocks -> split K over more waves per block
+  const int waves = grid.x >= 256 ? 4 : (grid.x >= 96 ? 8 : 16);
   switch ((M + 15) / 16) {
-    case 1: hipLaunchKernelGGL(cgv::skinny_fwd_k<1>, grid, block, 0, st, x, W, bias, y, M, N, K); break;
-    case 2: hipLaunchKernelGGL(cgv::skinny_fwd_k<2>, grid, block, 0, st, x, W, bias, y, M, N, K); break;
-    case 3: hipLaunchKernelGGL(cgv::skinny_fwd_k<3>, grid, block, 0, st, x, W, bias, y, M, N, K); break;
-    default: hipLaunchKernelGGL(cgv::skinny_fwd_k<4>, grid, block, 0, st, x, W, bias, y, M, N, K); break;
+    case 1: cgv::launch_fwd<1>(grid, waves, st, x, W, bias, y, z, M, N, K, act); break;
+    case 2: cgv::launch_fwd<2>(grid, waves, st, x, W, bias, y, z, M, N, K, act); break;
+    case 3: cgv::launch_fwd<3>(grid, waves, st, x, W, bias, y, z, M, N, K, act); break;
+    default: cgv::launch_fwd<4>(grid, waves, st, x, W, bias, y, z, M, N, K, act); break;
   }
   return cgv::check_launch("cgv_skinny_linear_fwd");
 }
 
-size_t cgv_skinny_bwd_input_workspace_bytes(int M, int N, int K) {
-  return sizeof(float) * (size_t)32 * M * K + 256;   /* upper bound on the N-splits */
-}
-
-int cgv_skinny_linear_bwd_input(const float* gy, const float* W, float* gx, int M, int N, int K, void* workspace,
-                                size_t workspace_bytes, void* stream) {
-  CGV_REQUIRE(gy && W && gx && workspace, "null pointer");
+int cgv_skinny_linear_bwd_input(const float* gy, const float* z, const float* W, float* gx, int M, int N, int K, int act,
+                                void* stream) {
+  CGV_REQUIRE(gy && W && gx, "null pointer");
+  CGV_REQUIRE(act == 0 || (act == 1 && z), "act = 1 needs the saved pre-activation z");
   CGV_REQUIRE(cgv_skinny_supported(M, N, K), "unsupported shape (need M <= 64, N % 4 == 0, K % 4 == 0)");
-  CGV_REQUIRE(((((uintptr_t)W | (uintptr_t)gx | (uintptr_t)workspace)) & 15) == 0, "operands must be 16-byte aligned");
-  if (workspace_bytes < cgv_skinny_bwd_input_workspace_bytes(M, N, K)) {
-    cgv::set_error("cgv_skinny_linear_bwd_input: workspace too small");
-    return CGV_E_WORKSPACE;
-  }
+  CGV_REQUIRE((((uintptr_t)gx) & 15) == 0, "gx must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  const int nsplit = cgv::bwd_input_splits(N, K);
-  int npb = (N + nsplit - 1) / nsplit;
-  npb = (npb + 3) & ~3;
-  float* part = reinterpret_cast<float*>(workspace);
-  float* target = nsplit == 1 ? gx : part;
-  const dim3 grid((K + 63) / 64, nsplit), block(256);
+  const dim3 grid((K + 15) / 16);
   switch ((M + 15) / 16) {
-    case 1: hipLaunchKernelGGL(cgv::skinny_bwd_input_k<1>, grid, block, 0, st, gy, W, target, M, N, K, npb); break;
-    case 2: hipLaunchKernelGGL(cgv::skinny_bwd_input_k<2>, grid, block, 0, st, gy, W, target, M, N, K, npb); break;
-    case 3: hipLaunchKernelGGL(cgv::skinny_bwd_input_k<3>, grid, block, 0, st, gy, W, target, M, N, K, npb); break;
-    default: hipLaunchKernelGGL(cgv::skinny_bwd_input_k<4>, grid, block, 0, st, gy, W, target, M, N, K, npb); break;
-  }
-  if (nsplit > 1) {
-    const size_t count4 = (size_t)M * K / 4;
-    hipLaunchKernelGGL(cgv::skinny_sum_partials, dim3((unsigned)((count4 + 255) / 256)), dim3(256), 0, st, part, nsplit,
-                       count4, gx);
+    case 1: cgv::launch_bwd_input<1>(grid, st, gy, z, W, gx, M, N, K, act); break;
+    case 2: cgv::launch_bwd_input<2>(grid, st, gy, z, W, gx, M, N, K, act); break;
+    case 3: cgv::launch_bwd_input<3>(grid, st, gy, z, W, gx, M, N, K, act); break;
+    default: cgv::launch_bwd_input<4>(grid, st, gy, z, W, gx, M, N, K, act); break;
   }
   return cgv::check_launch("cgv_skinny_linear_bwd_input");
 }
 
-int cgv_skinny_linear_bwd_weight(const float* gy, const float* x, float* gW, float* gb, int M, int N, int K,
-                                 int accumulate, void* stream) {
-  CGV_REQUIRE(gy && x && gW, "null pointer");
+int cgv_wgrad_record_bytes(void) { return (int)sizeof(cgv::WgradProblem); }
+
+/* Fills tiles_k / tile_w / block count of one problem (host helper for building the table). */
+int cgv_wgrad_plan(int M, int N, int K, int* tiles_k, int* tile_w, int* n_blocks) {
+  CGV_REQUIRE(tiles_k && tile_w && n_blocks, "null pointer");
   CGV_REQUIRE(cgv_skinny_supported(M, N, K), "unsupported shape (need M <= 64, N % 4 == 0, K % 4 == 0)");
-  CGV_REQUIRE(((((uintptr_t)x | (uintptr_t)gW)) & 15) == 0, "operands must be 16-byte aligned");
-  hipStream_t st = (hipStream_t)stream;
-  constexpr int ROWS = 16;
-  // k tile: as wide as a 60 KiB LDS budget for the x tile allows, at most 256 float4 (one per thread)
-  int max_t4 = (15000 / M) / 4;
-  if (max_t4 > 256) max_t4 = 256;
-  const int k4 = K / 4;
-  const int ntiles = (k4 + max_t4 - 1) / max_t4;
-  const int per_t4 = (k4 + ntiles - 1) / ntiles;
-  const int threads = ((per_t4 + 63) / 64) * 64;
-  const int tile_w = per_t4 * 4;
-  const dim3 grid((N + ROWS - 1) / ROWS, ntiles), block(threads);
-  const size_t lds = sizeof(float) * ((size_t)M * tile_w + (size_t)M * ROWS);
-  hipLaunchKernelGGL(cgv::skinny_bwd_weight_k<ROWS>, grid, block, lds, st, gy, x, gW, gb, M, N, K, tile_w, accumulate);
-  return cgv::check_launch("cgv_skinny_linear_bwd_weight");
+  cgv::wgrad_tiling(M, K, tiles_k, tile_w);
+  *n_blocks = ((N + cgv::WG_ROWS - 1) / cgv::WG_ROWS) * *tiles_k;
+  return 0;
+}
+
+int cgv_grouped_wgrad(const void* table_dev, int n_problems, int total_blocks, int max_lds_floats, void* stream) {
+  CGV_REQUIRE(n_problems >= 0 && total_blocks >= 0, "bad size");
+  if (n_problems == 0 || total_blocks == 0) return 0;
+  CGV_REQUIRE(table_dev, "null table");
+  CGV_REQUIRE(max_lds_floats > 0 && max_lds_floats <= 16000, "LDS request out of range");
+  hipLaunchKernelGGL(cgv::grouped_wgrad_k, dim3(total_blocks), dim3(256), sizeof(float) * (size_t)max_lds_floats,
+                     (hipStream_t)stream, reinterpret_cast<const cgv::WgradProblem*>(table_dev), n_problems);
+  return cgv::check_launch("cgv_grouped_wgrad");
 }
 
 }  // extern "C"

@@ -9,6 +9,9 @@ device tensor ops.  ``DistanceEmbed`` only *owns* the filter parameters the kern
 """
 from __future__ import annotations
 
+import ctypes as C
+import struct
+
 import numpy as np
 import torch
 import torch.nn.functional as Fn
@@ -50,67 +53,154 @@ def _skinny_ok(x2, weight):
     return bool(_lib.load().cgv_skinny_supported(M, N, K)) and weight.is_contiguous() and weight.data_ptr() % 16 == 0
 
 
+ACT_NONE, ACT_SWISH = 0, 1
+
+
+class WeightGradQueue:
+    """Deferred, grouped weight gradients.  While ``collect()`` is active (the trainer wraps
+    ``loss.backward()`` in it), every skinny linear layer only *registers* its weight-gradient
+    problem  gW (+)= (gy * act'(z))^T x ; ``flush()`` then runs ALL of them in one grouped HIP launch
+    (csrc/skinny_gemm.hip: grouped_wgrad_k) writing straight into the gradient arena.  ~66 launches
+    per step become one, and the weight-gradient writes (the largest traffic of the backward pass)
+    stream at HBM speed instead of paying a few microseconds of launch latency each."""
+
+    RECORD = struct.Struct("<5Q9i4x")            # cgv::WgradProblem, 80 bytes
+    MAX_PROBLEMS = 512
+
+    def __init__(self):
+        self.active = False
+        self.items = []
+        self._host = None       # pinned staging buffer
+        self._dev = {}          # device -> table tensor
+        self._captured = []     # (pinned, device) pairs owned by captured graphs
+
+    def collect(self):
+        return _QueueScope(self)
+
+    def enqueue(self, gy, x, z, act, gW, gb, accumulate):
+        self.items.append((gy, x, z, act, gW, gb, accumulate))
+
+    def flush(self):
+        if not self.items:
+            return
+        lib = _lib.load()
+        assert lib.cgv_wgrad_record_bytes() == self.RECORD.size
+        if len(self.items) > self.MAX_PROBLEMS:
+            raise RuntimeError("too many queued weight-gradient problems")
+        dev = self.items[0][0].device
+        nbytes = len(self.items) * self.RECORD.size
+        if torch.cuda.is_current_stream_capturing():
+            # a captured H2D node re-reads its pinned source at every replay: give the graph its own,
+            # never-rewritten staging buffer and table (kept alive with the queue)
+            host = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+            table = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            self._captured.append((host, table))
+        else:
+            if self._host is None:
+                self._host = torch.empty(self.MAX_PROBLEMS * self.RECORD.size, dtype=torch.uint8).pin_memory()
+            if dev not in self._dev:
+                self._dev[dev] = torch.empty(self.MAX_PROBLEMS * self.RECORD.size, dtype=torch.uint8, device=dev)
+            host, table = self._host, self._dev[dev]
+        buf = bytearray()
+        tk, tw, nb = C.c_int(), C.c_int(), C.c_int()
+        block_begin, max_lds = 0, 0
+        for gy, x, z, act, gW, gb, accumulate in self.items:
+            M, N = gy.shape
+            K = x.shape[1]
+            if lib.cgv_wgrad_plan(M, N, K, C.byref(tk), C.byref(tw), C.byref(nb)) != 0:
+                raise RuntimeError(lib.cgv_last_error_string().decode())
+            buf += self.RECORD.pack(gy.data_ptr(), x.data_ptr(), z.data_ptr() if z is not None else 0, gW.data_ptr(),
+                                    gb.data_ptr() if gb is not None else 0, M, N, K, int(accumulate), int(act),
+                                    block_begin, tk.value, tw.value, 0)
+            block_begin += nb.value
+            max_lds = max(max_lds, M * tw.value + M * 16)
+        n = len(self.items)
+        host[: len(buf)].copy_(torch.frombuffer(buf, dtype=torch.uint8))
+        table[: len(buf)].copy_(host[: len(buf)], non_blocking=True)
+        _lib.call("cgv_grouped_wgrad", _lib.ptr(table), n, block_begin, max_lds, _lib.stream_ptr(), tag="grouped_wgrad")
+        self.items = []          # tensors stay alive until here; stream order protects their reuse
+
+
+class _QueueScope:
+    def __init__(self, q):
+        self.q = q
+
+    def __enter__(self):
+        self.q.active = True
+        self.q.items = []
+        return self.q
+
+    def __exit__(self, *exc):
+        self.q.active = False
+
+
+wgrad_queue = WeightGradQueue()
+
+
 class _LinearFn(torch.autograd.Function):
-    """y = x W^T + b.  Forward / backward run on the skinny-GEMM kernels when the row count is small,
-    and the backward can write the weight / bias gradients straight into the trainer's gradient
-    arena (``param.grad`` is a view of it, trainer.py) instead of producing temporaries that
-    autograd then adds in: per step that removes one [out,in] allocation and one read-modify-write
-    pass per layer (~160 launches and ~0.8 GB of traffic at n_basis=600)."""
+    """y = act(x W^T + b), act in {identity, Swish}.  Small row counts run on the skinny-GEMM kernels
+    (bias / activation fused; activation backward fused into the operand loads); the weight / bias
+    gradients are written straight into the trainer's gradient arena (``param.grad`` is a view of
+    it, trainer.py) -- deferred to ONE grouped launch per step when the trainer's queue is active."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, act):
         x2 = x.reshape(-1, x.shape[-1])
         ctx.params = (weight, bias)
+        ctx.act = act
         ctx.skinny = _skinny_ok(x2, weight) and (bias is None or bias.data_ptr() % 16 == 0)
+        N = weight.shape[0]
         if ctx.skinny:
             x2 = x2.contiguous()
             M, K = x2.shape
-            N = weight.shape[0]
             y = torch.empty(M, N, dtype=torch.float32, device=x.device)
-            _lib.call("cgv_skinny_linear_fwd", _lib.ptr(x2), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(y), M, N, K,
-                      _lib.stream_ptr())
-            ctx.save_for_backward(x2, weight)
+            z = torch.empty_like(y) if act else None
+            _lib.call("cgv_skinny_linear_fwd", _lib.ptr(x2), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(y), _lib.ptr(z),
+                      M, N, K, act, _lib.stream_ptr())
+            ctx.save_for_backward(x2, weight, z)
             return y.reshape(x.shape[:-1] + (N,))
-        ctx.save_for_backward(x, weight)
-        return Fn.linear(x, weight, bias)
+        z = Fn.linear(x, weight, bias)
+        if act == ACT_SWISH:
+            ctx.save_for_backward(x, weight, z)
+            return Fn.silu(z)
+        ctx.save_for_backward(x, weight, None)
+        return z
 
     @staticmethod
     def backward(ctx, gy):
-        x, weight = ctx.saved_tensors
+        x, weight, z = ctx.saved_tensors
         w_param, b_param = ctx.params
+        act = ctx.act
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         need_b = b_param is not None and ctx.needs_input_grad[2]
-        x2, gy2 = x.reshape(-1, x.shape[-1]), gy.reshape(-1, gy.shape[-1])
         if not ctx.skinny:
+            if act == ACT_SWISH:
+                sg = torch.sigmoid(z)
+                gy = gy * (sg * (1 + z * (1 - sg)))
+            x2, gy2 = x.reshape(-1, x.shape[-1]), gy.reshape(-1, gy.shape[-1])
             gx = gy.matmul(weight) if need_x else None
             gw = _direct_grad(w_param, lambda out: torch.mm(gy2.t(), x2, out=out), lambda: gy2.t().mm(x2)) if need_w else None
             gb = _direct_grad(b_param, lambda out: torch.sum(gy2, 0, out=out), lambda: gy2.sum(0)) if need_b else None
-            return gx, gw, gb
-        gy2 = gy2.contiguous()
-        M, K = x2.shape
+            return gx, gw, gb, None
+        gy2 = gy.reshape(-1, gy.shape[-1]).contiguous()
+        M, K = x.shape
         N = weight.shape[0]
-        st = _lib.stream_ptr()
         gx = None
         if need_x:
             gx = torch.empty(M, K, dtype=torch.float32, device=gy.device)
-            ws_bytes = int(_lib.load().cgv_skinny_bwd_input_workspace_bytes(M, N, K))
-            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=gy.device)
-            _lib.call("cgv_skinny_linear_bwd_input", _lib.ptr(gy2), _lib.ptr(weight), _lib.ptr(gx), M, N, K, _lib.ptr(ws),
-                      ws_bytes, st)
+            _lib.call("cgv_skinny_linear_bwd_input", _lib.ptr(gy2), _lib.ptr(z), _lib.ptr(weight), _lib.ptr(gx), M, N, K,
+                      act, _lib.stream_ptr())
             gx = gx.reshape(gy.shape[:-1] + (K,))
         gw = gb = None
-        if need_w or need_b:
-            tw, acc_w, gw = _grad_target(w_param, weight) if need_w else (None, False, None)
-            tb, acc_b, gb = _grad_target(b_param, b_param) if need_b else (None, False, None)
-            if tw is None:                                   # bias only (never on this path): plain reduction
-                gb = _direct_grad(b_param, lambda out: torch.sum(gy2, 0, out=out), lambda: gy2.sum(0))
-            else:
-                if tb is not None and acc_b != acc_w:        # mixed first/second write: keep the kernel's flag for W
-                    gb = _direct_grad_after(b_param, gy2.sum(0), acc_b)
-                    tb = None
-                _lib.call("cgv_skinny_linear_bwd_weight", _lib.ptr(gy2), _lib.ptr(x2), _lib.ptr(tw), _lib.ptr(tb), M, N, K,
-                          int(acc_w), st)
-        return gx, gw, gb
+        if need_w:
+            tw, acc_w, gw = _grad_target(w_param, weight)
+            tb, acc_b, gb = _grad_target(b_param, b_param) if need_b else (None, acc_w, None)
+            if tb is not None and acc_b != acc_w:            # never on this model; keep semantics anyway
+                raise RuntimeError("weight and bias of one layer disagree on first-write / accumulate state")
+            wgrad_queue.enqueue(gy2, x, z, act, tw, tb, acc_w)
+            if not (wgrad_queue.active and gw is None and gb is None):
+                wgrad_queue.flush()                          # immediate mode (no trainer / not arena-managed)
+        return gx, gw, gb, None
 
 
 def _is_direct(param):
@@ -125,17 +215,6 @@ def _grad_target(param, like):
         return param.grad, acc, None
     out = torch.empty_like(like)
     return out, False, out
-
-
-def _direct_grad_after(param, value, accumulate):
-    """Finish a direct-mode gradient whose target was already claimed by ``_grad_target``."""
-    if _is_direct(param):
-        if accumulate:
-            param.grad.add_(value)
-        else:
-            param.grad.copy_(value)
-        return None
-    return value
 
 
 def _direct_grad(param, write_into, compute):
@@ -160,8 +239,8 @@ def mark_direct_grad(*params):
             p._cgv_direct_ok = True
 
 
-def linear(x, weight, bias=None):
-    return _LinearFn.apply(x, weight, bias)
+def linear(x, weight, bias=None, act=ACT_NONE):
+    return _LinearFn.apply(x, weight, bias, act)
 
 
 class Linear(nn.Linear):
@@ -172,7 +251,7 @@ class Linear(nn.Linear):
         mark_direct_grad(self.weight, self.bias)
 
     def forward(self, x):
-        return _LinearFn.apply(x, self.weight, self.bias)
+        return _LinearFn.apply(x, self.weight, self.bias, ACT_NONE)
 
 
 class Dense(nn.Linear):
@@ -194,7 +273,9 @@ class Dense(nn.Linear):
             nn.init.zeros_(self.bias)
 
     def forward(self, inputs):
-        y = _LinearFn.apply(inputs, self.weight, self.bias)
+        if isinstance(self.activation, Swish) and self.dropout_rate == 0.0:
+            return _LinearFn.apply(inputs, self.weight, self.bias, ACT_SWISH)      # bias + Swish fused
+        y = _LinearFn.apply(inputs, self.weight, self.bias, ACT_NONE)
         if self.dropout_rate > 0.0:
             y = self.dropout(y)
         return self.activation(y) if self.activation is not None else y

@@ -19,6 +19,7 @@ from typing import List, Optional
 import torch
 
 from . import _lib
+from .primitives import wgrad_queue
 from .train import CLIP_NORM, loss_terms
 
 _ALIGN = 64        # floats: every parameter starts on a 256-byte boundary inside the arena
@@ -172,7 +173,9 @@ class Trainer:
             self._build_arena()
         else:
             self.arena.zero_grad()
-            loss.backward()
+            with wgrad_queue.collect():          # bead-level weight gradients: queued, then ONE grouped launch
+                loss.backward()
+            wgrad_queue.flush()
         if not train:                                               # validation: backward only (utils.py:160)
             return self.last_loss
         if self.sync is not None:

@@ -191,21 +191,28 @@ int cgv_update_gate_bwd(const float* U, const float* Vv, const float* a, const f
 
 /* ---------------------------------------------------------------------------------------
  * Skinny fp32 GEMMs for the node-level Dense / nn.Linear layers on the bead graph
- * (modules.py:103-114 and their autograd backward): M <= cgv_skinny_max_rows() rows, weight
- * W[N,K] row-major as torch stores it, N % 4 == 0, K % 4 == 0, 16-byte aligned operands.
- *   fwd        y[M,N]  = x[M,K] W^T + bias                (bias may be NULL)
- *   bwd_input  gx[M,K] = gy[M,N] W                        (deterministic split over N via workspace)
- *   bwd_weight gW[N,K] = gy^T x, gb[N] = sum_m gy[m,:]    (accumulate != 0: added onto gW / gb)
- * Weight-streaming kernels (v_mfma_f32_16x16x4_f32 is an exact fp32 FMA chain).
+ * (modules.py:103-114, Swish modules.py:16-21, and their autograd backward): M <=
+ * cgv_skinny_max_rows() rows, weight W[N,K] row-major as torch stores it, N % 4 == 0,
+ * K % 4 == 0, 16-byte aligned operands.  act: 0 = identity, 1 = Swish.
+ *   fwd        z = x W^T + bias ; y = act(z)      (bias may be NULL; z [M,N] is written when act != 0)
+ *   bwd_input  gx[M,K] = (gy * act'(z)) W         (single launch, deterministic)
+ *   grouped weight gradients: the caller queues one 80-byte record per layer
+ *       { gy, x, z, gW, gb (pointers), M, N, K, accumulate, act, block_begin, tiles_k, tile_w, pad }
+ *     (tiles_k / tile_w / the block count come from cgv_wgrad_plan; block_begin is the running sum
+ *     of the block counts) and ONE cgv_grouped_wgrad launch computes, for every record,
+ *       gW[N,K] (+)= (gy * act'(z))^T x ,  gb[N] (+)= sum_m (gy * act'(z))[m,:]     (gb may be NULL)
+ *     max_lds_floats = max over records of M*tile_w + 16*M.
+ * v_mfma_f32_16x16x4_f32 is an exact fp32 FMA chain, so these match an fmaf loop bit for bit.
  * ------------------------------------------------------------------------------------- */
 int cgv_skinny_max_rows(void);
 int cgv_skinny_supported(int M, int N, int K);
-int cgv_skinny_linear_fwd(const float* x, const float* W, const float* bias, float* y, int M, int N, int K, void* stream);
-size_t cgv_skinny_bwd_input_workspace_bytes(int M, int N, int K);
-int cgv_skinny_linear_bwd_input(const float* gy, const float* W, float* gx, int M, int N, int K, void* workspace,
-                                size_t workspace_bytes, void* stream);
-int cgv_skinny_linear_bwd_weight(const float* gy, const float* x, float* gW, float* gb /*or NULL*/, int M, int N, int K,
-                                 int accumulate, void* stream);
+int cgv_skinny_linear_fwd(const float* x, const float* W, const float* bias, float* y, float* z /*or NULL*/, int M, int N,
+                          int K, int act, void* stream);
+int cgv_skinny_linear_bwd_input(const float* gy, const float* z /*or NULL*/, const float* W, float* gx, int M, int N, int K,
+                                int act, void* stream);
+int cgv_wgrad_record_bytes(void);
+int cgv_wgrad_plan(int M, int N, int K, int* tiles_k /*[host]*/, int* tile_w /*[host]*/, int* n_blocks /*[host]*/);
+int cgv_grouped_wgrad(const void* table_dev, int n_problems, int total_blocks, int max_lds_floats, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Fused optimiser step over a flat fp32 arena of the parameters that receive gradients --

@@ -479,3 +479,27 @@ def test_skinny_direct_gradient_accumulation():
     (lin(x1).pow(2).sum() + lin(x2).sum()).backward()
     assert_close(lin.weight.grad, ref_w, "weight grad", 1e-5)
     assert_close(lin.bias.grad, ref_b, "bias grad", 1e-5)
+
+
+@pytest.mark.parametrize("M,F", [(12, 600), (36, 200), (332, 64)])
+def test_dense_with_fused_swish_vs_fp64(M, F):
+    """Dense(activation=swish): bias + Swish fused into the GEMM epilogue, Swish' into the backward
+    operand loads (M <= 64), or the hipBLASLt + tensor-op path (M = 332)."""
+    gen = torch.Generator().manual_seed(M + F)
+    dense = cg.Dense(F, 2 * F, activation=cg.Swish())
+    with torch.no_grad():
+        dense.bias.normal_(0, 0.5, generator=gen)
+    x = torch.randn(M, F, generator=gen)
+    gy = torch.randn(M, 2 * F, generator=gen)
+    xd = x.double().requires_grad_(True)
+    Wd_, bd_ = dense.weight.detach().double().requires_grad_(True), dense.bias.detach().double().requires_grad_(True)
+    yd = torch.nn.functional.silu(torch.nn.functional.linear(xd, Wd_, bd_))
+    yd.backward(gy.double())
+    dense = dense.to(DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    y = dense(xg)
+    y.backward(gy.to(DEV))
+    assert_close(y, yd, "y", 3e-6)
+    assert_close(xg.grad, xd.grad, "gx", 3e-6)
+    assert_close(dense.weight.grad, Wd_.grad, "gW", 3e-6)
+    assert_close(dense.bias.grad, bd_.grad, "gb", 3e-6)
