@@ -73,6 +73,14 @@ class WeightGradQueue:
         self._host = None       # pinned staging buffer
         self._dev = {}          # device -> table tensor
         self._captured = []     # (pinned, device) pairs owned by captured graphs
+        self._capture_slot = None
+
+    def prepare_capture(self, device):
+        """Allocate the (pinned, device) table pair the next captured flush will use -- pinned
+        allocation is not allowed while a stream is capturing."""
+        n = self.MAX_PROBLEMS * self.RECORD.size
+        self._capture_slot = (torch.empty(n, dtype=torch.uint8).pin_memory(),
+                              torch.empty(n, dtype=torch.uint8, device=device))
 
     def collect(self):
         return _QueueScope(self)
@@ -88,13 +96,14 @@ class WeightGradQueue:
         if len(self.items) > self.MAX_PROBLEMS:
             raise RuntimeError("too many queued weight-gradient problems")
         dev = self.items[0][0].device
-        nbytes = len(self.items) * self.RECORD.size
         if torch.cuda.is_current_stream_capturing():
-            # a captured H2D node re-reads its pinned source at every replay: give the graph its own,
-            # never-rewritten staging buffer and table (kept alive with the queue)
-            host = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
-            table = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            self._captured.append((host, table))
+            # a captured H2D node re-reads its pinned source at every replay: the graph gets its own,
+            # never-rewritten staging buffer and table, allocated BEFORE capture (prepare_capture)
+            if self._capture_slot is None:
+                raise RuntimeError("call wgrad_queue.prepare_capture(device) before capturing a step")
+            host, table = self._capture_slot
+            self._captured.append(self._capture_slot)
+            self._capture_slot = None
         else:
             if self._host is None:
                 self._host = torch.empty(self.MAX_PROBLEMS * self.RECORD.size, dtype=torch.uint8).pin_memory()

@@ -142,6 +142,7 @@ class Trainer:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
+        wgrad_queue.prepare_capture(self.arena.p.device)
         with torch.cuda.graph(graph):
             self._step_eager(batch)
         self._graph, self._graph_batch = graph, batch
