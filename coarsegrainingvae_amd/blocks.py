@@ -114,13 +114,15 @@ class EquiMessagePsuedo(nn.Module):
                                             n_rbf=n_rbf, cutoff=cutoff, dropout=dropout)
 
     def forward(self, s_j, sbar_j, v_j, vbar_j, r_ij, nbrs, edge_wgt=None, plan: Optional[EdgePlan] = None,
-                geom: Optional[EdgeGeometry] = None):
+                geom: Optional[EdgeGeometry] = None, residual: bool = False):
+        """``residual=True`` (used by the decoder loop) returns the updated states
+        ``(S + dS, Sbar + dSbar, V + dV, Vbar + dVbar)`` from the same launch instead of the deltas."""
         if edge_wgt is not None:
             raise NotImplementedError("edge_wgt is never passed on the run_ala path")
         im = self.inv_message
         plan, geom = _resolve(plan, geom, nbrs, s_j.shape[0], r_ij, im.n_rbf, im.cutoff)
         Wd, bd = im.dist_embed.filter_params()
-        return ops.pseudo_message(im.node_features(s_j), s_j, sbar_j, v_j, vbar_j, Wd, bd, plan, geom)
+        return ops.pseudo_message(im.node_features(s_j), s_j, sbar_j, v_j, vbar_j, Wd, bd, plan, geom, residual)
 
 
 class UpdateBlock(nn.Module):
@@ -135,8 +137,9 @@ class UpdateBlock(nn.Module):
                   activation=to_module(activation)),
             Dense(in_features=feat_dim, out_features=3 * feat_dim, bias=True, dropout_rate=dropout))
 
-    def forward(self, s_i, v_i):
-        return ops.update_block(s_i, v_i, self.u_mat.weight, self.v_mat.weight, self.s_dense)
+    def forward(self, s_i, v_i, residual: bool = False):
+        """``residual=True`` (decoder loop) returns (s_i + ds, v_i + dv) from the same launches."""
+        return ops.update_block(s_i, v_i, self.u_mat.weight, self.v_mat.weight, self.s_dense, residual)
 
 
 class PseudoUpdateBlock(nn.Module):

@@ -60,7 +60,8 @@ __global__ __launch_bounds__(64) void pseudo_fwd_k(const float* __restrict__ phi
                                                    const int* __restrict__ rowptr, const int* __restrict__ src,
                                                    const float* __restrict__ Wd, const float* __restrict__ bd,
                                                    float* __restrict__ dh, float* __restrict__ dhbar,
-                                                   float* __restrict__ dv, float* __restrict__ dvbar, int F) {
+                                                   float* __restrict__ dv, float* __restrict__ dvbar, int F,
+                                                   int residual) {
   constexpr int GS = geom_stride(R), U = geom_unit_offset(R);
   const int i = blockIdx.x;
   const int f_raw = blockIdx.y * 64 + threadIdx.x;
@@ -93,6 +94,11 @@ __global__ __launch_bounds__(64) void pseudo_fwd_k(const float* __restrict__ phi
     axpy(avb, q[7], cross(v_i, v_j));
     axpy(avb, q[8], cross(vb_i, vb_j));
   }
+  if (residual) {      // emit the updated state S + dS, ... directly (cgvae.py:108-111): the receiver's values are in registers
+    ah += s_i; ahb += sb_i;
+    av.x += v_i.x; av.y += v_i.y; av.z += v_i.z;
+    avb.x += vb_i.x; avb.y += vb_i.y; avb.z += vb_i.z;
+  }
   if (live) {
     dh[(size_t)i * F + f] = ah;
     dhbar[(size_t)i * F + f] = ahb;
@@ -110,7 +116,8 @@ __global__ __launch_bounds__(64) void pseudo_bwd_recv_k(const float* __restrict_
                                                         const float* __restrict__ gh, const float* __restrict__ ghb,
                                                         const float* __restrict__ gv, const float* __restrict__ gvb,
                                                         float* __restrict__ g_s, float* __restrict__ g_sbar,
-                                                        float* __restrict__ g_v, float* __restrict__ g_vbar, int F) {
+                                                        float* __restrict__ g_v, float* __restrict__ g_vbar, int F,
+                                                        int residual) {
   constexpr int GS = geom_stride(R), U = geom_unit_offset(R);
   const int i = blockIdx.x;
   const int f_raw = blockIdx.y * 64 + threadIdx.x;
@@ -147,6 +154,11 @@ __global__ __launch_bounds__(64) void pseudo_bwd_recv_k(const float* __restrict_
     axpy(av, q3, cross(vb_j, gv_i));
     axpy(av, q7, cross(v_j, gvb_i));
     axpy(avb, q8, cross(vb_j, gvb_i));
+  }
+  if (residual) {      // outputs were state + delta: the upstream gradient also flows straight through
+    as += gh_i; asb += ghb_i;
+    av.x += gv_i.x; av.y += gv_i.y; av.z += gv_i.z;
+    avb.x += gvb_i.x; avb.y += gvb_i.y; avb.z += gvb_i.z;
   }
   if (live) {
     g_s[nf] = as;
@@ -270,7 +282,7 @@ extern "C" {
 int cgv_pseudo_msg_fwd(const float* phi, const float* s, const float* sbar, const float* v, const float* vbar,
                        const float* geom_d, const int32_t* rowptr_d, const int32_t* src_d, const float* Wd,
                        const float* bd, float* dh, float* dhbar, float* dv, float* dvbar, int n_nodes, int n_feat,
-                       int n_rbf, void* stream) {
+                       int n_rbf, int residual, void* stream) {
   CGV_REQUIRE(n_nodes >= 0 && n_feat > 0, "bad size");
   if (n_nodes == 0) return 0;
   CGV_REQUIRE(phi && s && sbar && v && vbar && rowptr_d && Wd && bd && dh && dhbar && dv && dvbar, "null pointer");
@@ -278,7 +290,7 @@ int cgv_pseudo_msg_fwd(const float* phi, const float* s, const float* sbar, cons
   hipStream_t st = (hipStream_t)stream;
   CGV_DISPATCH_RBF(n_rbf, {
     hipLaunchKernelGGL((cgv::pseudo_fwd_k<RBF>), grid, dim3(64), 0, st, phi, s, sbar, v, vbar, geom_d, rowptr_d, src_d,
-                       Wd, bd, dh, dhbar, dv, dvbar, n_feat);
+                       Wd, bd, dh, dhbar, dv, dvbar, n_feat, residual);
   });
   return cgv::check_launch("cgv_pseudo_msg_fwd");
 }
@@ -292,7 +304,7 @@ int cgv_pseudo_msg_bwd(const float* phi, const float* s, const float* sbar, cons
                        const int32_t* rowptr_s, const int32_t* dst_s, const float* Wd, const float* bd, const float* gh,
                        const float* ghbar, const float* gv, const float* gvbar, float* g_phi, float* g_s, float* g_sbar,
                        float* g_v, float* g_vbar, float* gWd, float* gbd, int n_nodes, int n_feat, int n_rbf,
-                       void* workspace, size_t workspace_bytes, void* stream) {
+                       int residual, void* workspace, size_t workspace_bytes, void* stream) {
   CGV_REQUIRE(n_nodes >= 0 && n_feat > 0, "bad size");
   CGV_REQUIRE(phi && s && sbar && v && vbar && rowptr_d && rowptr_s && Wd && bd, "null input");
   CGV_REQUIRE(g_phi && g_s && g_sbar && g_v && g_vbar && gWd && gbd && workspace, "null output");
@@ -308,7 +320,7 @@ int cgv_pseudo_msg_bwd(const float* phi, const float* s, const float* sbar, cons
   CGV_DISPATCH_RBF(n_rbf, {
     if (n_nodes > 0)
       hipLaunchKernelGGL((cgv::pseudo_bwd_recv_k<RBF>), gridA, dim3(64), 0, st, phi, v, vbar, geom_d, rowptr_d, src_d, Wd,
-                         bd, gh, ghbar, gv, gvbar, g_s, g_sbar, g_v, g_vbar, n_feat);
+                         bd, gh, ghbar, gv, gvbar, g_s, g_sbar, g_v, g_vbar, n_feat, residual);
     hipLaunchKernelGGL((cgv::pseudo_bwd_src_k<RBF>), gridB, dim3(64), 0, st, phi, s, sbar, v, vbar, geom_s, rowptr_s,
                        dst_s, Wd, bd, gh, ghbar, gv, gvbar, g_phi, g_v, g_vbar, part, n_feat, n_nodes, npc);
   });

@@ -109,61 +109,64 @@ __global__ __launch_bounds__(64 * WAVES) void skinny_fwd_k(const float* __restri
 
 // ------------------------------------------------------------------ bwd_input
 // gx[m, k] = sum_n g[m, n] W[n, k],  g = gy * act'(z).  Block = 16 output columns k0..k0+15, WAVES
-// waves splitting N in whole 4-row steps.  Lane (i = l&15, q = l>>4): A[i][kk = q] = W[n + q, k0 + i]
-// (4 rows x 64 contiguous bytes per wave instruction), B[kk = q][j = l&15] = g[m = 16 mb + (l&15), n + q].
+// waves splitting N.  Lane (i = l&15, q = l>>4): A[i][kk = q] = W[n + q, k0 + i] (4 rows x 64
+// contiguous bytes per wave instruction), B[kk = q][j = l&15] = g[m = 16 mb + (l&15), n + q].
+// The B operand is staged per wave through LDS in 64-column chunks: g is read from global memory
+// row by row (one fully coalesced 256-byte load per row -- reading it in MFMA layout instead costs
+// 16 cache lines per instruction and made the texture path the bottleneck: 17 us -> see DESIGN.md),
+// the activation derivative is applied once, and the MFMA-layout reads come from LDS.
 // D: lane holds gx[m = 16 mb + (l&15)][k0 + 4 q + r] -> one 16-byte store.  Single launch, the
 // N-split meets in LDS in a fixed order (deterministic).
+constexpr int BI_CHUNK = 64;      // columns of g per staging round (16 MFMA steps)
+constexpr int BI_LD = 68;         // LDS row stride in floats (2-way bank conflicts at worst)
+
 template <int MB, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void skinny_bwd_input_k(const float* __restrict__ gy, const float* __restrict__ z,
                                                                  const float* __restrict__ W, float* __restrict__ gx,
                                                                  int M, int N, int K, int act) {
   __shared__ float red[(WAVES - 1) * MB * 4 * 64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ float stage[WAVES][MB * 16 * BI_LD];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, q = lane >> 4;
   const int k0 = blockIdx.x * 16;
   const int kcol = k0 + i;
   const bool kok = kcol < K;
-  const int steps = (N + 3) / 4;
-  const int per = (steps + WAVES - 1) / WAVES;
-  const int s_beg = wave * per, s_end = min(s_beg + per, steps);
+  // this wave's contiguous slice of N, in whole chunks
+  const int chunks = (N + BI_CHUNK - 1) / BI_CHUNK;
+  const int per = (chunks + WAVES - 1) / WAVES;
+  const int c_beg = wave * per, c_end = min(c_beg + per, chunks);
+  float* sg = stage[wave];
   f32x4 acc[MB][2];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) acc[mb][0] = acc[mb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-  int s = s_beg;
-  // two independent accumulator chains per m-block hide the 40-cycle dependent-MFMA latency
-#pragma unroll 2
-  for (; s + 2 <= s_end; s += 2) {
+  for (int c = c_beg; c < c_end; ++c) {
+    const int nb = c * BI_CHUNK;
+    // stage g[:, nb .. nb+63] (rows >= M are zero)
+    const int n_l = nb + lane;
+    const bool nl_ok = n_l < N;
+    for (int m = 0; m < MB * 16; ++m) {
+      float g = 0.f;
+      if (m < M && nl_ok) {
+        g = gy[(size_t)m * N + n_l];
+        if (act) g *= act_bwd(z[(size_t)m * N + n_l], act);
+      }
+      sg[m * BI_LD + lane] = g;
+    }
+    // weight loads of the 16 steps of this chunk: independent, all in flight together
+    float a[16];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int n = 4 * (s + h) + q;
-      const bool nok = n < N;
-      const float a = (nok && kok) ? W[(size_t)n * K + kcol] : 0.f;
+    for (int h = 0; h < 16; ++h) {
+      const int n = nb + 4 * h + q;
+      a[h] = (n < N && kok) ? W[(size_t)n * K + kcol] : 0.f;
+    }
+#pragma unroll
+    for (int h = 0; h < 16; ++h)
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
-        const int m = mb * 16 + i;
-        float b = 0.f;
-        if (nok && m < M) {
-          b = gy[(size_t)m * N + n];
-          if (act) b *= act_bwd(z[(size_t)m * N + n], act);
-        }
-        acc[mb][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[mb][h], 0, 0, 0);
+        const float b = sg[(mb * 16 + i) * BI_LD + 4 * h + q];
+        acc[mb][h & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[h], b, acc[mb][h & 1], 0, 0, 0);
       }
-    }
-  }
-  for (; s < s_end; ++s) {
-    const int n = 4 * s + q;
-    const bool nok = n < N;
-    const float a = (nok && kok) ? W[(size_t)n * K + kcol] : 0.f;
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-      const int m = mb * 16 + i;
-      float b = 0.f;
-      if (nok && m < M) {
-        b = gy[(size_t)m * N + n];
-        if (act) b *= act_bwd(z[(size_t)m * N + n], act);
-      }
-      acc[mb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[mb][0], 0, 0, 0);
-    }
   }
   f32x4 tot[MB];
 #pragma unroll
@@ -296,7 +299,8 @@ static void launch_fwd(dim3 grid, int waves, hipStream_t st, const float* x, con
 template <int MB>
 static void launch_bwd_input(dim3 grid, hipStream_t st, const float* gy, const float* z, const float* W, float* gx, int M,
                              int N, int K, int act) {
-  hipLaunchKernelGGL((skinny_bwd_input_k<MB, 16>), grid, dim3(1024), 0, st, gy, z, W, gx, M, N, K, act);
+  constexpr int WAVES = MB == 1 ? 16 : (MB <= 3 ? 8 : 4);      // LDS: the per-wave staging area scales with MB
+  hipLaunchKernelGGL((skinny_bwd_input_k<MB, WAVES>), grid, dim3(64 * WAVES), 0, st, gy, z, W, gx, M, N, K, act);
 }
 
 }  // namespace cgv

@@ -38,7 +38,8 @@ __global__ __launch_bounds__(256) void update_norm_stack_bwd(const float* __rest
 }
 
 __global__ __launch_bounds__(256) void update_gate_fwd(const float* __restrict__ U, const float* __restrict__ Vv,
-                                                       const float* __restrict__ a, float* __restrict__ ds,
+                                                       const float* __restrict__ a, const float* __restrict__ s_res,
+                                                       const float* __restrict__ v_res, float* __restrict__ ds,
                                                        float* __restrict__ dv, int N, int F) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= N * F) return;
@@ -47,8 +48,15 @@ __global__ __launch_bounds__(256) void update_gate_fwd(const float* __restrict__
   const float ux = U[b], uy = U[b + F], uz = U[b + 2 * F];
   const float vx = Vv[b], vy = Vv[b + F], vz = Vv[b + 2 * F];
   const float a_vv = a[b], a_sv = a[b + F], a_ss = a[b + 2 * F];
-  st3(dv + (size_t)idx * 3, ux * a_vv, uy * a_vv, uz * a_vv);
-  ds[idx] = (ux * vx + uy * vy + uz * vz) * a_sv + a_ss;
+  float ox = ux * a_vv, oy = uy * a_vv, oz = uz * a_vv;
+  float os = (ux * vx + uy * vy + uz * vz) * a_sv + a_ss;
+  if (s_res) {         // emit S + dS_update, V + dV_update (cgvae.py:122-123) from the same launch
+    const f3 r = ld3(v_res + (size_t)idx * 3);
+    ox += r.x; oy += r.y; oz += r.z;
+    os += s_res[idx];
+  }
+  st3(dv + (size_t)idx * 3, ox, oy, oz);
+  ds[idx] = os;
 }
 
 __global__ __launch_bounds__(256) void update_gate_bwd(const float* __restrict__ U, const float* __restrict__ Vv,
@@ -100,10 +108,11 @@ int cgv_update_norm_stack_bwd(const float* gstack, const float* Vv, const float*
   CGV_EW_LAUNCH(cgv::update_norm_stack_bwd, gstack, Vv, stack, g_s, gVv);
 }
 
-int cgv_update_gate_fwd(const float* U, const float* Vv, const float* a, float* ds, float* dv, int n_nodes, int n_feat,
-                        void* stream) {
+int cgv_update_gate_fwd(const float* U, const float* Vv, const float* a, const float* s_res, const float* v_res, float* ds,
+                        float* dv, int n_nodes, int n_feat, void* stream) {
   CGV_REQUIRE(U && Vv && a && ds && dv, "null pointer");
-  CGV_EW_LAUNCH(cgv::update_gate_fwd, U, Vv, a, ds, dv);
+  CGV_REQUIRE((s_res == nullptr) == (v_res == nullptr), "s_res and v_res go together");
+  CGV_EW_LAUNCH(cgv::update_gate_fwd, U, Vv, a, s_res, v_res, ds, dv);
 }
 
 int cgv_update_gate_bwd(const float* U, const float* Vv, const float* a, const float* g_ds, const float* g_dv,

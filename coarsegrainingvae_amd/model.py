@@ -54,14 +54,10 @@ class EquivariantPsuedoDecoder(nn.Module):
             if geom is None:      # build once, share across layers
                 from .graph import EdgeGeometry
                 geom = EdgeGeometry(plan, self.n_rbf, self.cutoff, r_edges=r_ij)
-            dS, dSbar, dV, dVbar = message_block(S, Sbar, V, Vbar, r_ij, nbrs, plan=plan, geom=geom)
-            S = S + dS
-            Sbar = Sbar + dSbar
-            V = V + dV
-            Vbar = Vbar + dVbar
-            dS_u, dV_u = update_block(S, V)
-            S = S + dS_u
-            V = V + dV_u
+            # S += dS, Sbar += dSbar, V += dV, Vbar += dVbar (cgvae.py:108-111) fused into the message kernel,
+            # S += dS_update, V += dV_update (cgvae.py:122-123) into the update block's gate kernel
+            S, Sbar, V, Vbar = message_block(S, Sbar, V, Vbar, r_ij, nbrs, plan=plan, geom=geom, residual=True)
+            S, V = update_block(S, V, residual=True)
         return S, V
 
 

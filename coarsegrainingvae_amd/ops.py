@@ -152,8 +152,9 @@ class _PseudoMessage(torch.autograd.Function):
     """dh, dhbar, dv, dvbar of EquiMessagePsuedo from phi = inv_dense(s) (conv.py:190-242)."""
 
     @staticmethod
-    def forward(ctx, phi, s, sbar, v, vbar, Wd, bd, plan: EdgePlan, geom: EdgeGeometry):
+    def forward(ctx, phi, s, sbar, v, vbar, Wd, bd, plan: EdgePlan, geom: EdgeGeometry, residual: bool):
         ctx.filter_params = (Wd, bd)
+        ctx.residual = bool(residual)
         phi, s, sbar, v, vbar, Wd, bd = (_c(t) for t in (phi, s, sbar, v, vbar, Wd, bd))
         n, F = s.shape
         if plan.n_dst != n or plan.n_src != n or phi.shape != (n, 9 * F) or Wd.shape != (9 * F, geom.n_rbf):
@@ -162,7 +163,7 @@ class _PseudoMessage(torch.autograd.Function):
         dv, dvbar = torch.empty_like(v), torch.empty_like(v)
         _lib.call("cgv_pseudo_msg_fwd", _lib.ptr(phi), _lib.ptr(s), _lib.ptr(sbar), _lib.ptr(v), _lib.ptr(vbar),
                   _lib.ptr(geom.geom_d), _lib.ptr(plan.rowptr_d), _lib.ptr(plan.src_d), _lib.ptr(Wd), _lib.ptr(bd),
-                  _lib.ptr(dh), _lib.ptr(dhbar), _lib.ptr(dv), _lib.ptr(dvbar), n, F, geom.n_rbf, _lib.stream_ptr(),
+                  _lib.ptr(dh), _lib.ptr(dhbar), _lib.ptr(dv), _lib.ptr(dvbar), n, F, geom.n_rbf, int(residual), _lib.stream_ptr(),
                   tag=f"pseudo_msg_fwd:Nd{n}:E{plan.n_edges}:dv1")
         ctx.save_for_backward(phi, s, sbar, v, vbar, Wd, bd)
         ctx.plan, ctx.geom = plan, geom
@@ -174,7 +175,7 @@ class _PseudoMessage(torch.autograd.Function):
         phi, s, sbar, v, vbar, Wd, bd = ctx.saved_tensors
         plan, geom = ctx.plan, ctx.geom
         if gh is None and ghb is None and gv is None and gvb is None:
-            return (None,) * 9
+            return (None,) * 10
         gh, ghb, gv, gvb = _c(gh), _c(ghb), _c(gv), _c(gvb)
         n, F = s.shape
         g_phi = torch.empty_like(phi)
@@ -189,13 +190,14 @@ class _PseudoMessage(torch.autograd.Function):
                   _lib.ptr(geom.geom_s), _lib.ptr(plan.rowptr_s), _lib.ptr(plan.dst_s), _lib.ptr(Wd), _lib.ptr(bd),
                   _lib.ptr(gh), _lib.ptr(ghb), _lib.ptr(gv), _lib.ptr(gvb),
                   _lib.ptr(g_phi), _lib.ptr(g_s), _lib.ptr(g_sbar), _lib.ptr(g_v), _lib.ptr(g_vbar),
-                  _lib.ptr(gWd), _lib.ptr(gbd), n, F, geom.n_rbf, _lib.ptr(ws), ws_bytes, _lib.stream_ptr(),
+                  _lib.ptr(gWd), _lib.ptr(gbd), n, F, geom.n_rbf, int(ctx.residual), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(),
                   tag=f"pseudo_msg_bwd:Nd{n}:E{plan.n_edges}:gv1")
-        return g_phi, g_s, g_sbar, g_v, g_vbar, ret_W, ret_b, None, None
+        return g_phi, g_s, g_sbar, g_v, g_vbar, ret_W, ret_b, None, None, None
 
 
-def pseudo_message(phi, s, sbar, v, vbar, Wd, bd, plan: EdgePlan, geom: EdgeGeometry):
-    return _PseudoMessage.apply(phi, s, sbar, v, vbar, Wd, bd, plan, geom)
+def pseudo_message(phi, s, sbar, v, vbar, Wd, bd, plan: EdgePlan, geom: EdgeGeometry, residual: bool = False):
+    """residual=False: the four deltas (the block's reference API); True: the updated states."""
+    return _PseudoMessage.apply(phi, s, sbar, v, vbar, Wd, bd, plan, geom, residual)
 
 
 # ----------------------------------------------------------------------------- K5
@@ -223,17 +225,19 @@ class _UpdateNormStack(torch.autograd.Function):
 
 
 class _UpdateGate(torch.autograd.Function):
-    """ds, dv from U, Vv and the gates a = (a_vv, a_sv, a_ss)  (conv.py:603-614)."""
+    """ds, dv from U, Vv and the gates a = (a_vv, a_sv, a_ss)  (conv.py:603-614); with ``s`` / ``v``
+    given, the updated states s + ds, v + dv (cgvae.py:122-123) from the same launch."""
 
     @staticmethod
-    def forward(ctx, U, Vv, a):
+    def forward(ctx, U, Vv, a, s, v):
         U, Vv, a = _c(U), _c(Vv), _c(a)
         n, _, F = U.shape
         ds = torch.empty(n, F, dtype=_F32, device=U.device)
         dv = torch.empty(n, F, 3, dtype=_F32, device=U.device)
-        _lib.call("cgv_update_gate_fwd", _lib.ptr(U), _lib.ptr(Vv), _lib.ptr(a), _lib.ptr(ds), _lib.ptr(dv), n, F,
-                  _lib.stream_ptr())
+        _lib.call("cgv_update_gate_fwd", _lib.ptr(U), _lib.ptr(Vv), _lib.ptr(a), _lib.ptr(_c(s)), _lib.ptr(_c(v)),
+                  _lib.ptr(ds), _lib.ptr(dv), n, F, _lib.stream_ptr())
         ctx.save_for_backward(U, Vv, a)
+        ctx.residual = s is not None
         ctx.set_materialize_grads(False)
         return ds, dv
 
@@ -241,21 +245,23 @@ class _UpdateGate(torch.autograd.Function):
     def backward(ctx, g_ds, g_dv):
         U, Vv, a = ctx.saved_tensors
         if g_ds is None and g_dv is None:
-            return None, None, None
+            return None, None, None, None, None
         n, _, F = U.shape
         gU, gVv, ga = torch.empty_like(U), torch.empty_like(Vv), torch.empty_like(a)
         _lib.call("cgv_update_gate_bwd", _lib.ptr(U), _lib.ptr(Vv), _lib.ptr(a), _lib.ptr(_c(g_ds)), _lib.ptr(_c(g_dv)),
                   _lib.ptr(gU), _lib.ptr(gVv), _lib.ptr(ga), n, F, _lib.stream_ptr())
-        return gU, gVv, ga
+        # residual inputs: the upstream gradients pass straight through
+        return gU, gVv, ga, (g_ds if ctx.residual else None), (g_dv if ctx.residual else None)
 
 
-def update_block(s, v, u_weight, v_weight, s_dense):
-    """UpdateBlock.forward (conv.py:588-616): four K=F GEMMs (hipBLASLt) around two fused
-    element-wise kernels; v is re-laid out once as [N,3,F] rows for the channel-mixing GEMMs."""
+def update_block(s, v, u_weight, v_weight, s_dense, residual: bool = False):
+    """UpdateBlock.forward (conv.py:588-616): four K=F GEMMs around two fused element-wise
+    kernels; v is re-laid out once as [N,3,F] rows for the channel-mixing GEMMs.
+    ``residual=True`` returns (s + ds, v + dv) instead of the deltas."""
     n, F = s.shape
     vt = v.transpose(1, 2).reshape(-1, F)                       # [3N, F], row = node*3 + xyz (conv.py:591)
     U = _linear(vt, u_weight).view(n, 3, F)
     Vv = _linear(vt, v_weight).view(n, 3, F)
     stack = _UpdateNormStack.apply(s, Vv)
     a = s_dense(stack).view(n, 3, F)
-    return _UpdateGate.apply(U, Vv, a)
+    return _UpdateGate.apply(U, Vv, a, s if residual else None, v if residual else None)

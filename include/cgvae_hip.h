@@ -157,11 +157,13 @@ int cgv_equi_msg_bwd(const float* phi, const float* v, const float* geom_s, cons
  * Backward needs both CSR views (receiver-side sums on the dst-sorted one, source-side sums,
  * g_phi and the filter gradients on the src-sorted one); any upstream gradient may be NULL.
  * All outputs are written completely.  Derivation: csrc/pseudo_msg.hip.
+ * residual != 0: the outputs are the UPDATED states s + dh, sbar + dhbar, v + dv, vbar + dvbar
+ * (the residual adds of cgvae.py:108-111 fused in), and the backward adds the pass-through term.
  * ------------------------------------------------------------------------------------- */
 int cgv_pseudo_msg_fwd(const float* phi /*[N,9F]*/, const float* s, const float* sbar, const float* v,
                        const float* vbar, const float* geom_d, const int32_t* rowptr_d, const int32_t* src_d,
                        const float* Wd /*[9F,R]*/, const float* bd /*[9F]*/, float* dh, float* dhbar, float* dv,
-                       float* dvbar, int n_nodes, int n_feat, int n_rbf, void* stream);
+                       float* dvbar, int n_nodes, int n_feat, int n_rbf, int residual, void* stream);
 size_t cgv_pseudo_msg_bwd_workspace_bytes(int n_nodes, int n_feat, int n_rbf);
 int cgv_pseudo_msg_bwd(const float* phi, const float* s, const float* sbar, const float* v, const float* vbar,
                        const float* geom_d, const int32_t* rowptr_d, const int32_t* src_d,
@@ -170,7 +172,7 @@ int cgv_pseudo_msg_bwd(const float* phi, const float* s, const float* sbar, cons
                        const float* gh, const float* ghbar, const float* gv, const float* gvbar,
                        float* g_phi /*[N,9F]*/, float* g_s, float* g_sbar, float* g_v, float* g_vbar,
                        float* gWd /*[9F,R]*/, float* gbd /*[9F]*/, int n_nodes, int n_feat, int n_rbf,
-                       void* workspace, size_t workspace_bytes, void* stream);
+                       int residual, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * K5  UpdateBlock element-wise core (conv.py:588-616); the four K=F GEMMs stay with the caller
@@ -178,13 +180,15 @@ int cgv_pseudo_msg_bwd(const float* phi, const float* s, const float* sbar, cons
  * a = s_dense(stack) viewed [N,3,F] = (a_vv, a_sv, a_ss).
  *   norm_stack: stack[n] = [ s[n,:] | sqrt(sum_k (Vv[n,k,:]^2 + 1e-10)) ]          conv.py:600-601
  *   gate      : dv[n,f,k] = U[n,k,f] a_vv ;  ds[n,f] = (sum_k U Vv) a_sv + a_ss     conv.py:607-614
- * and their backward kernels (g_ds / g_dv may be NULL).
+ * and their backward kernels (g_ds / g_dv may be NULL).  gate_fwd with s_res / v_res emits
+ * s + ds and v + dv (the residual adds of cgvae.py:122-123) instead of the deltas.
  * ------------------------------------------------------------------------------------- */
 int cgv_update_norm_stack_fwd(const float* s /*[N,F]*/, const float* Vv /*[N,3,F]*/, float* stack /*[N,2F]*/,
                               int n_nodes, int n_feat, void* stream);
 int cgv_update_norm_stack_bwd(const float* gstack, const float* Vv, const float* stack, float* g_s, float* gVv,
                               int n_nodes, int n_feat, void* stream);
-int cgv_update_gate_fwd(const float* U, const float* Vv, const float* a, float* ds /*[N,F]*/, float* dv /*[N,F,3]*/,
+int cgv_update_gate_fwd(const float* U, const float* Vv, const float* a, const float* s_res /*[N,F] or NULL*/,
+                        const float* v_res /*[N,F,3] or NULL*/, float* ds /*[N,F]*/, float* dv /*[N,F,3]*/,
                         int n_nodes, int n_feat, void* stream);
 int cgv_update_gate_bwd(const float* U, const float* Vv, const float* a, const float* g_ds, const float* g_dv,
                         float* gU, float* gVv, float* ga, int n_nodes, int n_feat, void* stream);
