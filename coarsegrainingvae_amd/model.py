@@ -175,8 +175,16 @@ class CGequiVAE(nn.Module):
         self.det = det
         self.offset = offset
         self.equivariant = equivariant
+        # set by the data-parallel trainer: called (from the autograd thread) as soon as the decoder's
+        # backward has finished, i.e. when ~80 % of the gradient bytes are final (trainer.py)
+        self.decoder_backward_done = None
         if not equivariant:
             self.euclidean = Linear(self.encoder.n_atom_basis, self.encoder.n_atom_basis * 3)
+
+    def _fire_decoder_done(self, grad):
+        if self.decoder_backward_done is not None:
+            self.decoder_backward_done()
+        return grad
 
     def get_inputs(self, batch):
         xyz = batch["nxyz"][:, 1:]
@@ -233,5 +241,8 @@ class CGequiVAE(nn.Module):
         logvar = self.atom_sigmanet(S_I)
         sigma = 1e-12 + torch.exp(logvar / 2)
         z_sample = S_I if self.det else self.reparametrize(mu, sigma, eps)
+        if self.decoder_backward_done is not None and z_sample.requires_grad:
+            z_sample = z_sample.view_as(z_sample)          # private node: the hook fires when the decoder is done
+            z_sample.register_hook(self._fire_decoder_done)
         xyz_recon = self.decoder(cg_xyz, CG_nbr_list, z_sample, s_i, mapping, num_CGs, graph=graph)
         return mu, sigma, H_prior_mu, H_prior_sigma, xyz, xyz_recon

@@ -60,23 +60,33 @@ class ParamArena:
 
 
 class GradSync:
-    """SUM all-reduce of the gradient arena in large buckets (default 64 MiB: a handful of
+    """SUM all-reduce of gradient-arena ranges in large buckets (default 64 MiB: a handful of
     collectives per step; xGMI rings are per-link bound, so few large messages beat many small
-    ones).  Averaging is folded into the optimiser kernel's ``grad_scale`` (or applied here for
+    ones).  Collectives are issued asynchronously: the communication stream waits for what the
+    calling stream has queued and the caller only blocks in ``wait()``, so a range that is final
+    early (the decoder's, ~80 % of the bytes) travels while the rest of backward still runs.
+    Averaging is folded into the optimiser kernel's ``grad_scale`` (or applied by the caller for
     the unfused path)."""
 
     def __init__(self, world_size: int, group=None, bucket_bytes: int = 64 << 20):
         import torch.distributed as dist
         self.dist, self.world, self.group = dist, world_size, group
         self.bucket = max(bucket_bytes // 4, 1)
+        self.pending = []
+
+    def all_reduce_range(self, flat: torch.Tensor, lo: int, hi: int):
+        for start in range(lo, hi, self.bucket):
+            self.pending.append(self.dist.all_reduce(flat[start:min(start + self.bucket, hi)],
+                                                     op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait(self):
+        for w in self.pending:
+            w.wait()
+        self.pending = []
 
     def all_reduce_flat(self, flat: torch.Tensor):
-        works = []
-        for start in range(0, flat.numel(), self.bucket):
-            works.append(self.dist.all_reduce(flat[start:start + self.bucket], op=self.dist.ReduceOp.SUM,
-                                              group=self.group, async_op=True))
-        for w in works:
-            w.wait()
+        self.all_reduce_range(flat, 0, flat.numel())
+        self.wait()
 
     def mean_scalar(self, x: torch.Tensor) -> torch.Tensor:
         y = x.detach().clone().reshape(1)
@@ -95,6 +105,8 @@ class Trainer:
         self.sync = GradSync(world_size, group) if world_size > 1 else None
         self.fused = fused_optimizer
         self.arena: Optional[ParamArena] = None
+        self.early_range = None       # arena range all-reduced while backward still runs (data parallel)
+        self._early_sent = False
         self.torch_opt = None
         self.last_loss = None
         self.last_terms = None
@@ -109,6 +121,15 @@ class Trainer:
             raise RuntimeError("no parameter received a gradient")
         self.arena = ParamArena(live)
         dev = self.arena.p.device
+        # arena range of the decoder's parameters (contiguous: model.parameters() order) -- the bucket whose
+        # gradients are final first in backward and can be all-reduced under the encoder's backward
+        names = {id(p): n for n, p in self.model.named_parameters()}
+        dec = [k for k, p in enumerate(live) if names.get(id(p), "").startswith("equivaraintconv.")]
+        self.early_range = None
+        if dec and dec == list(range(dec[0], dec[-1] + 1)):
+            lo = self.arena.offsets[dec[0]]
+            hi = self.arena.offsets[dec[-1] + 1] if dec[-1] + 1 < len(live) else self.arena.numel
+            self.early_range = (lo, hi)
         if self.fused:
             if dev.type != "cuda":
                 raise RuntimeError("the fused optimiser is a HIP kernel: it needs device tensors")
@@ -156,6 +177,10 @@ class Trainer:
 
     # ------------------------------------------------------------------ one iteration
     def _step_eager(self, batch, eps: Optional[torch.Tensor] = None, train: bool = True):
+        # data parallel: ask the model to signal the end of the decoder's backward (hook registered in forward)
+        overlap = self.sync is not None and train and self.arena is not None and self.early_range is not None
+        self._early_sent = False
+        self.model.decoder_backward_done = self._decoder_done if overlap else None
         out = self.model(batch, eps=eps) if eps is not None else self.model(batch)
         loss, kl, recon, graph = loss_terms(out, batch, self.beta, self.gamma)
         self.last_loss, self.last_terms = loss.detach(), (kl.detach(), recon.detach(), graph.detach())
@@ -177,10 +202,18 @@ class Trainer:
             with wgrad_queue.collect():          # bead-level weight gradients: queued, then ONE grouped launch
                 loss.backward()
             wgrad_queue.flush()
+            self.model.decoder_backward_done = None
         if not train:                                               # validation: backward only (utils.py:160)
             return self.last_loss
         if self.sync is not None:
-            self.sync.all_reduce_flat(self.arena.g)
+            a = self.arena
+            if getattr(self, "_early_sent", False):                 # decoder range already in flight
+                lo, hi = self.early_range
+                self.sync.all_reduce_range(a.g, 0, lo)
+                self.sync.all_reduce_range(a.g, hi, a.numel)
+            else:
+                self.sync.all_reduce_range(a.g, 0, a.numel)
+            self.sync.wait()
         scale = 1.0 / self.world
         if self.fused:
             a = self.arena
@@ -194,6 +227,16 @@ class Trainer:
             torch.nn.utils.clip_grad_norm_(self.arena.params, self.max_norm)
             self.torch_opt.step()
         return self.last_loss
+
+    def _decoder_done(self):
+        """Autograd-thread callback (model.decoder_backward_done): the decoder's gradients are final.
+        Materialise its queued weight gradients and start their all-reduce; backward continues."""
+        if self._early_sent:
+            return
+        self._early_sent = True
+        wgrad_queue.flush()
+        lo, hi = self.early_range
+        self.sync.all_reduce_range(self.arena.g, lo, hi)
 
     def skipped_steps(self) -> int:
         if self.fused and self.arena is not None:

@@ -21,16 +21,50 @@ BETA, GAMMA = 0.05, 25.0
 
 
 class OracleModule(torch.nn.Module):
+    """The oracle's functional model behind an nn.Module with the product model's top-level layout
+    (``encoder`` / ``equivaraintconv`` / ... parameter groups and the ``decoder_backward_done`` hook),
+    so the Trainer's early all-reduce of the decoder bucket is exercised on CPU."""
+
+    GROUPS = ("encoder", "equivaraintconv", "atom_munet", "atom_sigmanet", "prior_net")
+
     def __init__(self, seed=123):
         super().__init__()
         self.hp = O.Hyper(HP["F"], HP["R"], HP["atom_cutoff"], HP["cg_cutoff"], HP["enc"], HP["dec"], HP["n_cgs"], det=True)
         P = O.init_params(self.hp, seed=seed)
         self.names = list(P.keys())
-        self.plist = torch.nn.ParameterList([torch.nn.Parameter(P[k]) for k in self.names])
+        self.index = {}
+        for g in self.GROUPS:
+            keys = [k for k in self.names if k.startswith(g + ".")]
+            setattr(self, g, torch.nn.ParameterList([torch.nn.Parameter(P[k]) for k in keys]))
+            for j, k in enumerate(keys):
+                self.index[k] = (g, j)
+        self.decoder_backward_done = None
+        self.fired = 0
+
+    @property
+    def plist(self):
+        return [getattr(self, g)[j] for g, j in (self.index[k] for k in self.names)]
+
+    def _fire(self, grad):
+        if self.decoder_backward_done is not None:
+            self.fired += 1
+            self.decoder_backward_done()
+        return grad
 
     def forward(self, batch, eps=None):
         P = dict(zip(self.names, self.plist))
-        return O.model_forward(batch, P, self.hp, eps)
+        hp = self.hp
+        xyz, z = batch["nxyz"][:, 1:], batch["nxyz"][:, 0]
+        cg_xyz, cg_z = batch["CG_nxyz"][:, 1:], batch["CG_nxyz"][:, 0]
+        H, _ = O.encoder_forward(z, xyz, cg_xyz, batch["CG_mapping"], batch["nbr_list"], batch["CG_nbr_list"], P, hp)
+        pmu, pstd = O.prior_forward(cg_z, cg_xyz, batch["CG_nbr_list"], P, hp)
+        mu = O.linear(torch.relu(O.linear(H, P, "atom_munet.0")), P, "atom_munet.2")
+        sigma = 1e-12 + torch.exp(O.linear(torch.relu(O.linear(H, P, "atom_sigmanet.0")), P, "atom_sigmanet.2") / 2)
+        zs = H.view_as(H)                                   # det=True: z = H (cgvae.py:504-507)
+        if self.decoder_backward_done is not None:
+            zs.register_hook(self._fire)
+        recon = O.decode(cg_xyz, batch["CG_nbr_list"], zs, batch["CG_mapping"], P, hp)
+        return mu, sigma, pmu, pstd, xyz, recon
 
 
 def frames(n, seed=0):
@@ -64,7 +98,8 @@ def _worker(rank, world, port, n_steps, lr, gamma, q):
         fr = frames(4)
         batch = CG_collate(fr[2 * rank: 2 * rank + 2])
         losses = [float(tr.step(batch)) for _ in range(n_steps)]
-        q.put((rank, [p.detach().clone().numpy() for p in model.plist], losses, tr.skipped_steps()))
+        early = (tr.early_range is not None, model.fired)
+        q.put((rank, [p.detach().clone().numpy() for p in model.plist], losses, tr.skipped_steps(), early))
     finally:
         dist.destroy_process_group()
 
@@ -82,7 +117,7 @@ def run_dp(n_steps, lr, gamma=GAMMA):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, n_steps, lr, gamma, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -93,8 +128,10 @@ def run_dp(n_steps, lr, gamma=GAMMA):
 def test_two_rank_training_equals_single_rank_on_concatenated_batch():
     ref_params, ref_losses = run_single(3, lr=1e-3)
     res = run_dp(3, lr=1e-3)
-    (r0, p0, l0, s0), (r1, p1, l1, s1) = res
+    (r0, p0, l0, s0, e0), (r1, p1, l1, s1, e1) = res
     assert s0 == 0 and s1 == 0
+    # steps 2 and 3 sent the decoder bucket early (step 1 builds the arena)
+    assert e0 == (True, 2) and e1 == (True, 2)
     for a, b in zip(p0, p1):                       # replicas stay in lock-step
         assert np.array_equal(a, b)
     worst = 0.0
@@ -111,7 +148,7 @@ def test_skip_rule_uses_the_all_reduced_loss():
     # threshold 200*gamma far below the loss -> every rank must skip every step, parameters untouched
     init = [p.detach().clone().numpy() for p in OracleModule().plist]
     res = run_dp(2, lr=1e-3, gamma=1e-4)
-    for rank, params, losses, skipped in res:
+    for rank, params, losses, skipped, _early in res:
         assert skipped == 2
         for a, b in zip(params, init):
             assert np.array_equal(a, b)
