@@ -172,7 +172,12 @@ def main():
             trainer.step(batch)
         ksum = kt.summary()
     if use_graph:
-        trainer.capture(batch)
+        try:
+            trainer.capture(batch)
+        except Exception as exc:                     # keep measuring (eager launches) rather than lose the run
+            print(f"[bench] hipGraph capture failed on rank {rank}: {exc!r}; falling back to eager steps", file=sys.stderr)
+            use_graph = False
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         trainer.step(batch)
     barrier()

@@ -98,11 +98,13 @@ class Trainer:
     """One object per process (= per GPU).  ``step(batch)`` runs a full training iteration."""
 
     def __init__(self, model, lr: float, beta: float, gamma: float, world_size: int = 1, group=None,
-                 fused_optimizer: bool = True, betas=(0.9, 0.999), eps: float = 1e-8, max_norm: float = CLIP_NORM):
+                 fused_optimizer: bool = True, betas=(0.9, 0.999), eps: float = 1e-8, max_norm: float = CLIP_NORM,
+                 always_sync: bool = False):
         self.model, self.lr, self.beta, self.gamma = model, lr, beta, gamma
         self.betas, self.eps, self.max_norm = betas, eps, max_norm
         self.world = world_size
-        self.sync = GradSync(world_size, group) if world_size > 1 else None
+        # always_sync: run the collective path even with one rank (exercises RCCL + graph capture in tests)
+        self.sync = GradSync(world_size, group) if (world_size > 1 or always_sync) else None
         self.fused = fused_optimizer
         self.arena: Optional[ParamArena] = None
         self.early_range = None       # arena range all-reduced while backward still runs (data parallel)
@@ -164,7 +166,9 @@ class Trainer:
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         wgrad_queue.prepare_capture(self.arena.p.device)
-        with torch.cuda.graph(graph):
+        # with RCCL in the step, other threads (the process group's watchdog) legitimately touch the runtime
+        mode = "thread_local" if self.sync is not None else "global"
+        with torch.cuda.graph(graph, capture_error_mode=mode):
             self._step_eager(batch)
         self._graph, self._graph_batch = graph, batch
         return graph

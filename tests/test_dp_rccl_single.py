@@ -1,0 +1,48 @@
+"""The data-parallel code path on a real GPU with a 1-rank RCCL group: gradient all-reduce
+(early decoder bucket + remainder) eagerly and inside the captured hipGraph.  Runs in a
+subprocess so the process group does not leak into the pytest process."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+SCRIPT = r"""
+import os, sys, torch
+sys.path.insert(0, os.environ["CGV_ROOT"])
+import torch.distributed as dist
+import coarsegrainingvae_amd as cg
+from coarsegrainingvae_amd.trainer import Trainer
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+w = cg.data.WORKLOADS["dipeptide"]
+batch = cg.synthetic_batch("dipeptide", n_frames=4, seed=5, device="cuda")
+def run(always_sync, graph):
+    model = cg.build_model(64, w["n_rbf"], w["atom_cutoff"], w["cg_cutoff"], 2, 2, w["n_cgs"], det=True, seed=123).cuda()
+    tr = Trainer(model, lr=1e-3, beta=w["beta"], gamma=w["gamma"], world_size=1, always_sync=always_sync)
+    losses = [float(tr.step(batch)) for _ in range(3)]
+    if graph:
+        tr.capture(batch, warmup=0)
+    for _ in range(2):
+        tr.step(batch); losses.append(float(tr.last_loss))
+    return losses, tr
+ref, _ = run(False, False)
+eager, tr_e = run(True, False)
+graph, tr_g = run(True, True)
+assert tr_e.early_range is not None and tr_g._graph is not None
+for a, b, c in zip(ref, eager, graph):
+    assert abs(a - b) <= 1e-5 * abs(a) and abs(a - c) <= 1e-5 * abs(a), (ref, eager, graph)
+dist.destroy_process_group()
+print("RCCL_PATH_OK", ref[-1])
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_rccl_gradient_exchange_eager_and_captured():
+    env = dict(os.environ, CGV_ROOT=ROOT)
+    res = subprocess.run([sys.executable, "-c", SCRIPT], env=env, capture_output=True, text=True, timeout=500)
+    assert res.returncode == 0 and "RCCL_PATH_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]
