@@ -88,6 +88,18 @@ class GradSync:
         self.all_reduce_range(flat, 0, flat.numel())
         self.wait()
 
+    def drain(self):
+        """Before stream capture: the process group's watchdog thread polls the events of eager
+        collectives; an event query from another thread while a stream captures aborts the process.
+        Wait until nothing is left for it to poll."""
+        import time
+        pg = self.group if self.group is not None else self.dist.group.WORLD
+        try:
+            pg._wait_for_pending_works()
+        except Exception:
+            time.sleep(1.0)
+        time.sleep(0.3)
+
     def mean_scalar(self, x: torch.Tensor) -> torch.Tensor:
         y = x.detach().clone().reshape(1)
         self.dist.all_reduce(y, op=self.dist.ReduceOp.SUM, group=self.group)
@@ -164,6 +176,8 @@ class Trainer:
                 self._step_eager(batch)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if self.sync is not None:
+            self.sync.drain()
         graph = torch.cuda.CUDAGraph()
         wgrad_queue.prepare_capture(self.arena.p.device)
         # with RCCL in the step, other threads (the process group's watchdog) legitimately touch the runtime
