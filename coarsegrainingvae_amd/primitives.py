@@ -73,14 +73,15 @@ class WeightGradQueue:
         self._host = None       # pinned staging buffer
         self._dev = {}          # device -> table tensor
         self._captured = []     # (pinned, device) pairs owned by captured graphs
-        self._capture_slot = None
+        self._capture_slots = []
 
-    def prepare_capture(self, device):
-        """Allocate the (pinned, device) table pair the next captured flush will use -- pinned
-        allocation is not allowed while a stream is capturing."""
+    def prepare_capture(self, device, flushes: int = 4):
+        """Allocate the (pinned, device) table pairs the flushes of the next captured step will use
+        (one per flush: two with data parallelism) -- pinned allocation is not allowed while a
+        stream is capturing."""
         n = self.MAX_PROBLEMS * self.RECORD.size
-        self._capture_slot = (torch.empty(n, dtype=torch.uint8).pin_memory(),
-                              torch.empty(n, dtype=torch.uint8, device=device))
+        self._capture_slots = [(torch.empty(n, dtype=torch.uint8).pin_memory(),
+                                torch.empty(n, dtype=torch.uint8, device=device)) for _ in range(flushes)]
 
     def collect(self):
         return _QueueScope(self)
@@ -99,11 +100,10 @@ class WeightGradQueue:
         if torch.cuda.is_current_stream_capturing():
             # a captured H2D node re-reads its pinned source at every replay: the graph gets its own,
             # never-rewritten staging buffer and table, allocated BEFORE capture (prepare_capture)
-            if self._capture_slot is None:
+            if not self._capture_slots:
                 raise RuntimeError("call wgrad_queue.prepare_capture(device) before capturing a step")
-            host, table = self._capture_slot
-            self._captured.append(self._capture_slot)
-            self._capture_slot = None
+            host, table = slot = self._capture_slots.pop()
+            self._captured.append(slot)
         else:
             if self._host is None:
                 self._host = torch.empty(self.MAX_PROBLEMS * self.RECORD.size, dtype=torch.uint8).pin_memory()
