@@ -145,13 +145,21 @@ __global__ __launch_bounds__(64 * WAVES) void skinny_bwd_input_k(const float* __
     // stage g[:, nb .. nb+63] (rows >= M are zero)
     const int n_l = nb + lane;
     const bool nl_ok = n_l < N;
-    for (int m = 0; m < MB * 16; ++m) {
-      float g = 0.f;
-      if (m < M && nl_ok) {
-        g = gy[(size_t)m * N + n_l];
-        if (act) g *= act_bwd(z[(size_t)m * N + n_l], act);
+    // (loads of 16 rows are issued together, then written: a load -> LDS-store loop would serialise
+    //  one memory latency per row -- measured 25-38 us per call before this was batched)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      float g[16], zz[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mb * 16 + r;
+        const bool ok = m < M && nl_ok;
+        g[r] = ok ? gy[(size_t)m * N + n_l] : 0.f;
+        zz[r] = (ok && act) ? z[(size_t)m * N + n_l] : 0.f;
       }
-      sg[m * BI_LD + lane] = g;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        sg[(mb * 16 + r) * BI_LD + lane] = act ? g[r] * act_bwd(zz[r], act) : g[r];
     }
     // weight loads of the 16 steps of this chunk: independent, all in flight together
     float a[16];
