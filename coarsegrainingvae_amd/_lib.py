@@ -55,6 +55,8 @@ PROTOTYPES = {
     "cgv_wgrad_record_bytes": (_i, []),
     "cgv_wgrad_plan": (_i, [_i, _i, _i, _p, _p, _p]),
     "cgv_grouped_wgrad": (_i, [_p, _i, _i, _i, _p]),
+    "cgv_elbo_fwd": (_i, [_p] * 7 + [_i, _i, _i, _i, _f, _f] + [_p] * 6 + [_p]),
+    "cgv_elbo_scale": (_i, [_p, _p, _p, _p, _p, _i, _p, _i, _p]),
     "cgv_optim_state_floats": (_i, []),
     "cgv_optim_partial_floats": (_i, []),
     "cgv_adam_clip_step": (_i, [_p, _p, _p, _p, C.c_int64, _f, _f, _f, _f, _f, _f, _p, _f, _p, _p, _p]),

@@ -1,0 +1,139 @@
+// Fused ELBO loss of the reference training loop (scripts/utils.py:81-86 KL, 117-141 loss), forward
+// and gradient in one launch each instead of ~40 + ~80 tensor-op launches per step:
+//   KL     = 0.5 * mean_I [ sum_f s1^2/s2^2 + (m1-m2)^2/s2 + log s2^2 - log s1^2 ] - 0.5 F      (sic: / s2, not s2^2)
+//   recon  = mean( (xr - x)^2 )
+//   graph  = mean_b ( (|xr_a - xr_b|_eps - |x_a - x_b|_eps)^2 ),  |d|_eps = sqrt(d.d + 1e-6)
+//   loss   = recon + beta * KL + gamma * graph
+// One 1024-thread block: the tensors are a few thousand elements; sums run in double in a fixed
+// order (deterministic).  The same launch stores d loss / d{mu, sigma, prior_mu, prior_std, xyz_recon};
+// backward scales them by the upstream scalar (elbo_scale).
+#include "cgv_common.h"
+
+namespace cgv {
+
+__device__ inline double block_sum(double x, double* sh) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) x += __shfl_xor(x, d);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[w] = x;
+  __syncthreads();
+  double t = 0.0;
+  for (int k = 0; k < (int)(blockDim.x >> 6); ++k) t += sh[k];
+  return t;
+}
+
+__global__ __launch_bounds__(1024) void elbo_fwd(const float* __restrict__ mu, const float* __restrict__ sigma,
+                                                 const float* __restrict__ pmu, const float* __restrict__ pstd,
+                                                 const float* __restrict__ xyz, const float* __restrict__ xr,
+                                                 const int64_t* __restrict__ bonds, int n_beads, int F, int n_atoms,
+                                                 int n_bonds, float beta, float gamma, float* __restrict__ out /*[4]*/,
+                                                 float* __restrict__ g_mu, float* __restrict__ g_sigma,
+                                                 float* __restrict__ g_pmu, float* __restrict__ g_pstd,
+                                                 float* __restrict__ g_xr) {
+  __shared__ double sh[16];
+  const int t = threadIdx.x, T = blockDim.x;
+  // ---- KL and its gradients (mean over beads of per-bead sums)
+  const int nk = n_beads * F;
+  const float ck = 0.5f * beta / (float)n_beads;
+  double kl = 0.0;
+  for (int idx = t; idx < nk; idx += T) {
+    const float m1 = mu[idx], s1 = sigma[idx], m2 = pmu[idx], s2 = pstd[idx];
+    const float s1s = s1 * s1, s2s = s2 * s2, dm = m1 - m2;
+    kl += (double)(s1s / s2s + dm * dm / s2 + logf(s2s) - logf(s1s));
+    g_mu[idx] = ck * (2.f * dm / s2);
+    g_pmu[idx] = -ck * (2.f * dm / s2);
+    g_sigma[idx] = ck * (2.f * s1 / s2s - 2.f / s1);
+    g_pstd[idx] = ck * (-2.f * s1s / (s2s * s2) - dm * dm / s2s + 2.f / s2);
+  }
+  kl = block_sum(kl, sh);
+  const double kl_val = 0.5 * (kl / (double)n_beads - (double)F);
+  // ---- reconstruction MSE
+  const int nr = n_atoms * 3;
+  double rec = 0.0;
+  for (int idx = t; idx < nr; idx += T) {
+    const float d = xr[idx] - xyz[idx];
+    rec += (double)(d * d);
+    g_xr[idx] = 2.f * d / (float)nr;
+  }
+  rec = block_sum(rec, sh);
+  const double rec_val = rec / (double)(nr > 0 ? nr : 1);
+  // ---- bond-graph term: value per bond ...
+  double gr = 0.0;
+  for (int b = t; b < n_bonds; b += T) {
+    const int a0 = (int)bonds[2 * b], a1 = (int)bonds[2 * b + 1];
+    float dg = 1e-6f, dd = 1e-6f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float eg = xr[3 * a0 + k] - xr[3 * a1 + k], ed = xyz[3 * a0 + k] - xyz[3 * a1 + k];
+      dg += eg * eg; dd += ed * ed;
+    }
+    const float diff = sqrtf(dg) - sqrtf(dd);
+    gr += (double)(diff * diff);
+  }
+  gr = block_sum(gr, sh);
+  const double gr_val = n_bonds > 0 ? gr / (double)n_bonds : 0.0;
+  // ... and its gradient, gathered per atom (every thread owns atoms and walks the bond list: no atomics)
+  if (gamma != 0.f && n_bonds > 0) {
+    const float cg = gamma * 2.f / (float)n_bonds;
+    __syncthreads();                       // g_xr holds the recon part
+    for (int a = t; a < n_atoms; a += T) {
+      float gx = 0.f, gy = 0.f, gz = 0.f;
+      for (int b = 0; b < n_bonds; ++b) {
+        const int a0 = (int)bonds[2 * b], a1 = (int)bonds[2 * b + 1];
+        if (a0 != a && a1 != a) continue;
+        const float ex = xr[3 * a0] - xr[3 * a1], ey = xr[3 * a0 + 1] - xr[3 * a1 + 1], ez = xr[3 * a0 + 2] - xr[3 * a1 + 2];
+        const float fx = xyz[3 * a0] - xyz[3 * a1], fy = xyz[3 * a0 + 1] - xyz[3 * a1 + 1], fz = xyz[3 * a0 + 2] - xyz[3 * a1 + 2];
+        const float lg = sqrtf(ex * ex + ey * ey + ez * ez + 1e-6f), ld = sqrtf(fx * fx + fy * fy + fz * fz + 1e-6f);
+        float c = cg * (lg - ld) / lg;
+        if (a1 == a) c = (a0 == a) ? 0.f : -c;        // d/d xr_a1 = -d/d xr_a0 ; self bonds contribute nothing
+        gx += c * ex; gy += c * ey; gz += c * ez;
+      }
+      g_xr[3 * a] += gx; g_xr[3 * a + 1] += gy; g_xr[3 * a + 2] += gz;
+    }
+  }
+  if (t == 0) {
+    out[0] = (float)(rec_val + (double)beta * kl_val + (double)gamma * gr_val);
+    out[1] = (float)kl_val;
+    out[2] = (float)rec_val;
+    out[3] = gamma != 0.f ? (float)gr_val : 0.f;          // utils.py:134-135: zero when gamma == 0
+  }
+}
+
+// grads *= upstream scalar (device); all five tensors in one launch
+__global__ __launch_bounds__(256) void elbo_scale(const float* __restrict__ g_loss, float* g0, float* g1, float* g2,
+                                                  float* g3, int nk, float* g4, int nr) {
+  const float s = *g_loss;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < nk) { g0[idx] *= s; g1[idx] *= s; g2[idx] *= s; g3[idx] *= s; }
+  if (idx < nr) g4[idx] *= s;
+}
+
+}  // namespace cgv
+
+extern "C" {
+
+int cgv_elbo_fwd(const float* mu, const float* sigma, const float* prior_mu, const float* prior_std, const float* xyz,
+                 const float* xyz_recon, const int64_t* bonds, int n_beads, int n_feat, int n_atoms, int n_bonds,
+                 float beta, float gamma, float* out4, float* g_mu, float* g_sigma, float* g_prior_mu, float* g_prior_std,
+                 float* g_xyz_recon, void* stream) {
+  CGV_REQUIRE(mu && sigma && prior_mu && prior_std && xyz && xyz_recon && out4, "null input");
+  CGV_REQUIRE(g_mu && g_sigma && g_prior_mu && g_prior_std && g_xyz_recon, "null gradient buffer");
+  CGV_REQUIRE(n_beads > 0 && n_feat > 0 && n_atoms > 0 && n_bonds >= 0 && (n_bonds == 0 || bonds), "bad size");
+  hipLaunchKernelGGL(cgv::elbo_fwd, dim3(1), dim3(1024), 0, (hipStream_t)stream, mu, sigma, prior_mu, prior_std, xyz,
+                     xyz_recon, bonds, n_beads, n_feat, n_atoms, n_bonds, beta, gamma, out4, g_mu, g_sigma, g_prior_mu,
+                     g_prior_std, g_xyz_recon);
+  return cgv::check_launch("cgv_elbo_fwd");
+}
+
+int cgv_elbo_scale(const float* g_loss, float* g_mu, float* g_sigma, float* g_prior_mu, float* g_prior_std, int n_bead_elems,
+                   float* g_xyz_recon, int n_atom_elems, void* stream) {
+  CGV_REQUIRE(g_loss && g_mu && g_sigma && g_prior_mu && g_prior_std && g_xyz_recon, "null pointer");
+  const int n = n_bead_elems > n_atom_elems ? n_bead_elems : n_atom_elems;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(cgv::elbo_scale, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, g_loss, g_mu, g_sigma,
+                     g_prior_mu, g_prior_std, n_bead_elems, g_xyz_recon, n_atom_elems);
+  return cgv::check_launch("cgv_elbo_scale");
+}
+
+}  // extern "C"

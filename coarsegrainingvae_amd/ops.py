@@ -265,3 +265,40 @@ def update_block(s, v, u_weight, v_weight, s_dense, residual: bool = False):
     stack = _UpdateNormStack.apply(s, Vv)
     a = s_dense(stack).view(n, 3, F)
     return _UpdateGate.apply(U, Vv, a, s if residual else None, v if residual else None)
+
+
+# ----------------------------------------------------------------------------- fused ELBO loss
+class _Elbo(torch.autograd.Function):
+    """(loss, KL, recon, graph) of scripts/utils.py:117-141 in one launch; gradients come from the same launch."""
+
+    @staticmethod
+    def forward(ctx, mu, sigma, pmu, pstd, xyz, xyz_recon, bonds, beta, gamma):
+        mu, sigma, pmu, pstd, xyz, xr = (_c(t) for t in (mu, sigma, pmu, pstd, xyz, xyz_recon))
+        bonds = bonds.contiguous()
+        if bonds.dtype != torch.int64:
+            bonds = bonds.long()
+        n_beads, F = mu.shape
+        n_atoms = xr.shape[0]
+        out = torch.empty(4, dtype=_F32, device=mu.device)
+        grads = [torch.empty_like(t) for t in (mu, sigma, pmu, pstd, xr)]
+        _lib.call("cgv_elbo_fwd", _lib.ptr(mu), _lib.ptr(sigma), _lib.ptr(pmu), _lib.ptr(pstd), _lib.ptr(xyz), _lib.ptr(xr),
+                  _lib.ptr(bonds) if bonds.shape[0] else None, n_beads, F, n_atoms, bonds.shape[0], float(beta),
+                  float(gamma), _lib.ptr(out), *[_lib.ptr(g) for g in grads], _lib.stream_ptr())
+        ctx.grads = grads
+        ctx.mark_non_differentiable(out)
+        loss = out[0].clone()
+        return loss, out
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_terms):
+        g = ctx.grads
+        ctx.grads = None
+        gl = _c(g_loss.reshape(1))
+        _lib.call("cgv_elbo_scale", _lib.ptr(gl), _lib.ptr(g[0]), _lib.ptr(g[1]), _lib.ptr(g[2]), _lib.ptr(g[3]),
+                  g[0].numel(), _lib.ptr(g[4]), g[4].numel(), _lib.stream_ptr())
+        return g[0], g[1], g[2], g[3], None, g[4], None, None, None
+
+
+def elbo_loss(mu, sigma, prior_mu, prior_std, xyz, xyz_recon, bonds, beta, gamma):
+    """Returns (loss, terms) with terms = [loss, KL, recon, graph] (detached)."""
+    return _Elbo.apply(mu, sigma, prior_mu, prior_std, xyz, xyz_recon, bonds, beta, gamma)

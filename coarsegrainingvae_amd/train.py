@@ -28,8 +28,15 @@ def KL(mu1, std1, mu2, std2):
 
 def loss_terms(out, batch, beta, gamma):
     """loss = recon + beta*KL + gamma*graph (scripts/utils.py:117-141); everything stays on the
-    device (the reference moves the bond indices to the CPU, utils.py:127-128)."""
+    device (the reference moves the bond indices to the CPU, utils.py:127-128).  With a prior net
+    and device tensors this is ONE fused HIP launch (csrc/elbo.hip); the tensor-op composition
+    below is the same formula for the remaining cases."""
     S_mu, S_sigma, H_prior_mu, H_prior_sigma, xyz, xyz_recon = out
+    if S_mu is not None and H_prior_mu is not None and xyz_recon.is_cuda:
+        from . import ops
+        loss, terms = ops.elbo_loss(S_mu, S_sigma, H_prior_mu, H_prior_sigma, xyz, xyz_recon, batch["bond_edge_list"],
+                                    beta, gamma)
+        return loss, terms[1], terms[2], terms[3]
     loss_kl = KL(S_mu, S_sigma, H_prior_mu, H_prior_sigma) if S_mu is not None else xyz.new_zeros(())
     loss_recon = (xyz_recon - xyz).pow(2).mean()
     if gamma != 0.0:

@@ -219,6 +219,21 @@ int cgv_wgrad_plan(int M, int N, int K, int* tiles_k /*[host]*/, int* tile_w /*[
 int cgv_grouped_wgrad(const void* table_dev, int n_problems, int total_blocks, int max_lds_floats, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Fused ELBO loss -- replaces KL (scripts/utils.py:81-86, incl. its (mu1-mu2)^2 / std2 term) and the
+ * loss assembly of scripts/utils.py:117-141:  loss = recon + beta*KL + gamma*graph with
+ *   recon = mean((xr - x)^2),  graph = mean_b((|xr_a - xr_b|_eps - |x_a - x_b|_eps)^2), eps = 1e-6 inside the sqrt.
+ * out4 = { loss, KL, recon, graph }.  The same launch stores d loss / d{mu, sigma, prior_mu, prior_std,
+ * xyz_recon}; cgv_elbo_scale multiplies them by the upstream scalar (device pointer) in backward.
+ * bonds: int64 [n_bonds, 2] batch-global atom ids (bond_edge_list of CG_collate).
+ * ------------------------------------------------------------------------------------- */
+int cgv_elbo_fwd(const float* mu, const float* sigma, const float* prior_mu, const float* prior_std, const float* xyz,
+                 const float* xyz_recon, const int64_t* bonds, int n_beads, int n_feat, int n_atoms, int n_bonds,
+                 float beta, float gamma, float* out4, float* g_mu, float* g_sigma, float* g_prior_mu, float* g_prior_std,
+                 float* g_xyz_recon, void* stream);
+int cgv_elbo_scale(const float* g_loss, float* g_mu, float* g_sigma, float* g_prior_mu, float* g_prior_std, int n_bead_elems,
+                   float* g_xyz_recon, int n_atom_elems, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Fused optimiser step over a flat fp32 arena of the parameters that receive gradients --
  * replaces the skip rule, clip_grad_norm_(params, 0.01) and Adam.step() of
  * scripts/utils.py:145-157 (torch.optim.Adam defaults: no amsgrad, no weight decay).
