@@ -72,13 +72,15 @@ class EquiMessageBlock(nn.Module):
         self.with_dv = True     # set False to skip the (dead) vector channel explicitly
 
     def forward(self, s_j, v_j, r_ij, nbrs, edge_wgt=None, plan: Optional[EdgePlan] = None,
-                geom: Optional[EdgeGeometry] = None):
+                geom: Optional[EdgeGeometry] = None, residual: bool = False):
+        """``residual=True`` returns the updated states (s_j + ds, v_j + dv) from the same launch."""
         if edge_wgt is not None:
             raise NotImplementedError("edge_wgt is never passed on the run_ala path (conv.py:527-533)")
         im = self.inv_message
         plan, geom = _resolve(plan, geom, nbrs, s_j.shape[0], r_ij, im.n_rbf, im.cutoff)
         Wd, bd = im.dist_embed.filter_params()
-        return ops.equi_message(im.node_features(s_j), v_j, Wd, bd, plan, geom, self.with_dv)
+        return ops.equi_message(im.node_features(s_j), v_j, Wd, bd, plan, geom, self.with_dv,
+                                s_j if residual else None, v_j if residual else None)
 
 
 class ContractiveMessageBlock(nn.Module):
@@ -95,14 +97,16 @@ class ContractiveMessageBlock(nn.Module):
         self.with_dv = True
 
     def forward(self, s_i, v_i, r_iI, mapping, plan: Optional[EdgePlan] = None,
-                geom: Optional[EdgeGeometry] = None):
+                geom: Optional[EdgeGeometry] = None, residual=None):
+        """``residual=(H, V)`` (bead-shaped) returns (H + dS, V + dV) from the same launch."""
         if plan is None:
             n_beads = int(mapping.max().item()) + 1      # dim_size inferred like torch_scatter does
             plan = EdgePlan.from_mapping(mapping, n_beads)
         if geom is None:
             geom = EdgeGeometry(plan, self.n_rbf, self.cutoff, r_edges=r_iI)
         Wd, bd = self.dist_embed.filter_params()
-        return ops.equi_message(self.inv_dense(s_i), v_i, Wd, bd, plan, geom, self.with_dv)
+        s_res, v_res = residual if residual is not None else (None, None)
+        return ops.equi_message(self.inv_dense(s_i), v_i, Wd, bd, plan, geom, self.with_dv, s_res, v_res)
 
 
 class EquiMessagePsuedo(nn.Module):

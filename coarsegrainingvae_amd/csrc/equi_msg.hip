@@ -114,7 +114,9 @@ __global__ __launch_bounds__(64 * SPLIT) void equi_msg_fwd_k(const float* __rest
                                                              const int* __restrict__ rowptr, const int* __restrict__ src,
                                                              const float* __restrict__ Wd, const float* __restrict__ bd,
                                                              float* __restrict__ ds, float* __restrict__ dv, int F,
-                                                             int n_dst, int nodes_per_xcd, int tiles) {
+                                                             int n_dst, int nodes_per_xcd, int tiles,
+                                                             const float* __restrict__ s_res,
+                                                             const float* __restrict__ v_res) {
   constexpr int GS = geom_stride(R), U = geom_unit_offset(R);
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int local = slot / tiles;
@@ -175,8 +177,16 @@ __global__ __launch_bounds__(64 * SPLIT) void equi_msg_fwd_k(const float* __rest
     }
   }
   if (cp.live) {
+    if (s_res) acc_s += ldpair<PAIR>(s_res + (size_t)node * F, cp);      // emit h + ds (cgvae.py:287, 309, 391)
     stpair<PAIR>(ds + (size_t)node * F, cp, acc_s);
-    if constexpr (WITH_DV) stvec<PAIR>(dv + (size_t)node * F * 3, cp, accA, accB, accC);
+    if constexpr (WITH_DV) {
+      if (v_res) {
+        f2 rA, rB, rC;
+        ldvec<PAIR>(v_res + (size_t)node * F * 3, cp, rA, rB, rC);
+        accA += rA; accB += rB; accC += rC;
+      }
+      stvec<PAIR>(dv + (size_t)node * F * 3, cp, accA, accB, accC);
+    }
   }
 }
 
@@ -400,7 +410,8 @@ extern "C" {
 
 int cgv_equi_msg_fwd(const float* phi, const float* v, const float* geom_d, const int32_t* rowptr_d,
                      const int32_t* src_d, const float* Wd, const float* bd, float* ds, float* dv, int n_dst,
-                     int n_feat, int n_rbf, int with_dv, int64_t n_edges_hint, void* stream) {
+                     int n_feat, int n_rbf, int with_dv, int64_t n_edges_hint, const float* s_res, const float* v_res,
+                     void* stream) {
   CGV_REQUIRE(n_dst >= 0 && n_feat > 0, "bad size");
   if (n_dst == 0) return 0;
   CGV_REQUIRE(phi && rowptr_d && Wd && bd && ds, "null pointer");
@@ -414,10 +425,10 @@ int cgv_equi_msg_fwd(const float* phi, const float* v, const float* geom_d, cons
   if (const char* dbg = getenv("CGV_DEBUG_FWD_SPLIT")) split = dbg[0] == '1';   // experiments only
   // 8-byte vector accesses need an even channel count and 8-byte aligned bases
   const bool pair = (n_feat % 2 == 0) &&
-                    ((((uintptr_t)phi | (uintptr_t)v | (uintptr_t)ds | (uintptr_t)dv) & 7) == 0);
+                    ((((uintptr_t)phi | (uintptr_t)v | (uintptr_t)ds | (uintptr_t)dv | (uintptr_t)s_res | (uintptr_t)v_res) & 7) == 0);
 #define CGV_FWD_LAUNCH(DV, SP, PR)                                                                                   \
   hipLaunchKernelGGL((cgv::equi_msg_fwd_k<RBF, DV, SP, PR>), grid, dim3(64 * SP), 0, st, phi, v, geom_d, rowptr_d, src_d, \
-                     Wd, bd, ds, dv, n_feat, n_dst, npx, tiles)
+                     Wd, bd, ds, dv, n_feat, n_dst, npx, tiles, s_res, v_res)
 #define CGV_FWD_PICK(DV)                                                 \
   if (pair) { if (split) CGV_FWD_LAUNCH(DV, 4, true); else CGV_FWD_LAUNCH(DV, 1, true); } \
   else      { if (split) CGV_FWD_LAUNCH(DV, 4, false); else CGV_FWD_LAUNCH(DV, 1, false); }

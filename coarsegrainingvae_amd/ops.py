@@ -45,18 +45,21 @@ class _EquiMessage(torch.autograd.Function):
     (reference conv.py:512-561 and 709-731 after the node MLP)."""
 
     @staticmethod
-    def forward(ctx, phi, v, Wd, bd, plan: EdgePlan, geom: EdgeGeometry, with_dv: bool):
+    def forward(ctx, phi, v, Wd, bd, plan: EdgePlan, geom: EdgeGeometry, with_dv: bool, s_res, v_res):
         filter_params = (Wd, bd)
-        phi, v, Wd, bd = _c(phi), _c(v), _c(Wd), _c(bd)
+        phi, v, Wd, bd, s_res, v_res = _c(phi), _c(v), _c(Wd), _c(bd), _c(s_res), _c(v_res)
+        ctx.residual = (s_res is not None, v_res is not None)
         F = phi.shape[1] // 3
         if phi.shape[0] != plan.n_src or v.shape != (plan.n_src, F, 3) or Wd.shape != (3 * F, geom.n_rbf):
             raise RuntimeError("shape mismatch between node features, filter weights and the edge plan")
         ds = torch.empty(plan.n_dst, F, dtype=_F32, device=phi.device)
-        dv = torch.empty(plan.n_dst, F, 3, dtype=_F32, device=phi.device) if with_dv else \
-            torch.zeros(plan.n_dst, F, 3, dtype=_F32, device=phi.device)
+        if with_dv:
+            dv = torch.empty(plan.n_dst, F, 3, dtype=_F32, device=phi.device)
+        else:       # vector channel skipped: delta = 0, i.e. the residual passes through unchanged
+            dv = v_res.clone() if v_res is not None else torch.zeros(plan.n_dst, F, 3, dtype=_F32, device=phi.device)
         _lib.call("cgv_equi_msg_fwd", _lib.ptr(phi), _lib.ptr(v), _lib.ptr(geom.geom_d), _lib.ptr(plan.rowptr_d),
                   _lib.ptr(plan.src_d), _lib.ptr(Wd), _lib.ptr(bd), _lib.ptr(ds), _lib.ptr(dv), plan.n_dst, F,
-                  geom.n_rbf, int(with_dv), plan.n_edges, _lib.stream_ptr(),
+                  geom.n_rbf, int(with_dv), plan.n_edges, _lib.ptr(s_res), _lib.ptr(v_res), _lib.stream_ptr(),
                   tag=f"equi_msg_fwd:Nd{plan.n_dst}:E{plan.n_edges}:dv{int(with_dv)}")
         ctx.save_for_backward(phi, v, Wd, bd)
         ctx.filter_params = filter_params
@@ -68,12 +71,16 @@ class _EquiMessage(torch.autograd.Function):
     def backward(ctx, gs, gv):
         phi, v, Wd, bd = ctx.saved_tensors
         plan, geom = ctx.plan, ctx.geom
-        if not ctx.with_dv:
-            gv = None
         F = phi.shape[1] // 3
         dev = phi.device
+        # residual inputs: the upstream gradients pass straight through (before gv is masked for the
+        # skipped vector channel, whose output was the residual itself)
+        g_sres = gs if ctx.residual[0] else None
+        g_vres = gv if ctx.residual[1] else None
+        if not ctx.with_dv:
+            gv = None
         if gs is None and gv is None:
-            return (None,) * 7
+            return (None,) * 7 + (g_sres, g_vres)
         gs, gv = _c(gs), _c(gv)
         g_phi = torch.empty_like(phi)
         g_v = torch.empty_like(v) if gv is not None else None
@@ -85,11 +92,12 @@ class _EquiMessage(torch.autograd.Function):
                   _lib.ptr(plan.dst_s), _lib.ptr(Wd), _lib.ptr(bd), _lib.ptr(gs), _lib.ptr(gv), _lib.ptr(g_phi),
                   _lib.ptr(g_v), _lib.ptr(gWd), _lib.ptr(gbd), plan.n_src, F, geom.n_rbf, plan.n_edges, _lib.ptr(ws), ws_bytes,
                   _lib.stream_ptr(), tag=f"equi_msg_bwd:Nd{plan.n_dst}:E{plan.n_edges}:gv{int(gv is not None)}")
-        return g_phi, g_v, ret_W, ret_b, None, None, None
+        return g_phi, g_v, ret_W, ret_b, None, None, None, g_sres, g_vres
 
 
-def equi_message(phi, v, Wd, bd, plan: EdgePlan, geom: EdgeGeometry, with_dv: bool = True):
-    return _EquiMessage.apply(phi, v, Wd, bd, plan, geom, with_dv)
+def equi_message(phi, v, Wd, bd, plan: EdgePlan, geom: EdgeGeometry, with_dv: bool = True, s_res=None, v_res=None):
+    """(ds, dv); with ``s_res`` / ``v_res`` (receiver-shaped) the updated states s_res + ds, v_res + dv."""
+    return _EquiMessage.apply(phi, v, Wd, bd, plan, geom, with_dv, s_res, v_res)
 
 
 # ----------------------------------------------------------------------------- K1

@@ -129,6 +129,8 @@ int cgv_segment_broadcast(const float* gout, const int32_t* rowptr, const int32_
  *   dv[i,f,:] = sum_e ( m_2 * unit_e + m_0 * v[src(e), f, :] )
  * No [E, .] tensor is ever written.  with_dv = 0 skips the vector channel (explicit option;
  * the encoder never consumes it -- SURVEY 8a note a12) and leaves dv untouched.
+ * s_res / v_res (optional): the outputs become s_res + ds and v_res + dv, i.e. the residual adds
+ * of cgvae.py:287-288, 309-310, 391-392 fused into the store.
  * n_edges_hint (the edge count, or 0) only selects the launch shape: several waves share a
  * receiver when the average degree is high.  Results do not depend on it beyond fp32
  * summation order.
@@ -136,7 +138,8 @@ int cgv_segment_broadcast(const float* gout, const int32_t* rowptr, const int32_
 int cgv_equi_msg_fwd(const float* phi /*[Ns,3F]*/, const float* v /*[Ns,F,3]*/, const float* geom_d,
                      const int32_t* rowptr_d, const int32_t* src_d, const float* Wd /*[3F,R]*/,
                      const float* bd /*[3F]*/, float* ds /*[Nd,F]*/, float* dv /*[Nd,F,3]*/, int n_dst,
-                     int n_feat, int n_rbf, int with_dv, int64_t n_edges_hint, void* stream);
+                     int n_feat, int n_rbf, int with_dv, int64_t n_edges_hint,
+                     const float* s_res /*[Nd,F] or NULL*/, const float* v_res /*[Nd,F,3] or NULL*/, void* stream);
 /* Backward.  gs / gv are the upstream gradients at the receivers (gv == NULL when dv is not
  * consumed).  Traverses the src-sorted view; writes g_phi [Ns,3F], g_v [Ns,F,3] (only if gv),
  * gWd [3F,R], gbd [3F] completely (zeros where nothing flows).  Deterministic two-stage
