@@ -44,10 +44,12 @@ PROTOTYPES = {
     "cgv_pseudo_msg_fwd": (_i, [_p] * 14 + [_i, _i, _i, _i, _p]),
     "cgv_pseudo_msg_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "cgv_pseudo_msg_bwd": (_i, [_p] * 24 + [_i, _i, _i, _i, _p, _sz, _p]),
-    "cgv_update_norm_stack_fwd": (_i, [_p, _p, _p, _i, _i, _p]),
-    "cgv_update_norm_stack_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _p]),
-    "cgv_update_gate_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
-    "cgv_update_gate_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
+    "cgv_update_rows_from_vec": (_i, [_p, _p, _i, _i, _p]),
+    "cgv_update_vec_from_rows": (_i, [_p, _p, _p, _i, _i, _p]),
+    "cgv_update_norm_stack_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "cgv_update_norm_stack_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "cgv_update_gate_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "cgv_update_gate_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "cgv_skinny_max_rows": (_i, []),
     "cgv_skinny_supported": (_i, [_i, _i, _i]),
     "cgv_skinny_linear_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),

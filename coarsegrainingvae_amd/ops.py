@@ -217,7 +217,7 @@ class _UpdateNormStack(torch.autograd.Function):
         s, Vv = _c(s), _c(Vv)
         n, F = s.shape
         stack = torch.empty(n, 2 * F, dtype=_F32, device=s.device)
-        _lib.call("cgv_update_norm_stack_fwd", _lib.ptr(s), _lib.ptr(Vv), _lib.ptr(stack), n, F, _lib.stream_ptr())
+        _lib.call("cgv_update_norm_stack_fwd", _lib.ptr(s), _lib.ptr(Vv), _lib.ptr(stack), n, F, F, _lib.stream_ptr())
         ctx.save_for_backward(Vv, stack)
         return stack
 
@@ -227,8 +227,8 @@ class _UpdateNormStack(torch.autograd.Function):
         n, F = stack.shape[0], stack.shape[1] // 2
         g_s = torch.empty(n, F, dtype=_F32, device=stack.device)
         gVv = torch.empty_like(Vv)
-        _lib.call("cgv_update_norm_stack_bwd", _lib.ptr(_c(gstack)), _lib.ptr(Vv), _lib.ptr(stack), _lib.ptr(g_s),
-                  _lib.ptr(gVv), n, F, _lib.stream_ptr())
+        _lib.call("cgv_update_norm_stack_bwd", _lib.ptr(_c(gstack)), _lib.ptr(Vv), _lib.ptr(stack), None, _lib.ptr(g_s),
+                  _lib.ptr(gVv), n, F, F, 0, _lib.stream_ptr())
         return g_s, gVv
 
 
@@ -243,7 +243,7 @@ class _UpdateGate(torch.autograd.Function):
         ds = torch.empty(n, F, dtype=_F32, device=U.device)
         dv = torch.empty(n, F, 3, dtype=_F32, device=U.device)
         _lib.call("cgv_update_gate_fwd", _lib.ptr(U), _lib.ptr(Vv), _lib.ptr(a), _lib.ptr(_c(s)), _lib.ptr(_c(v)),
-                  _lib.ptr(ds), _lib.ptr(dv), n, F, _lib.stream_ptr())
+                  _lib.ptr(ds), _lib.ptr(dv), n, F, F, _lib.stream_ptr())
         ctx.save_for_backward(U, Vv, a)
         ctx.residual = s is not None
         ctx.set_materialize_grads(False)
@@ -257,15 +257,120 @@ class _UpdateGate(torch.autograd.Function):
         n, _, F = U.shape
         gU, gVv, ga = torch.empty_like(U), torch.empty_like(Vv), torch.empty_like(a)
         _lib.call("cgv_update_gate_bwd", _lib.ptr(U), _lib.ptr(Vv), _lib.ptr(a), _lib.ptr(_c(g_ds)), _lib.ptr(_c(g_dv)),
-                  _lib.ptr(gU), _lib.ptr(gVv), _lib.ptr(ga), n, F, _lib.stream_ptr())
+                  _lib.ptr(gU), _lib.ptr(gVv), _lib.ptr(ga), n, F, F, _lib.stream_ptr())
         # residual inputs: the upstream gradients pass straight through
         return gU, gVv, ga, (g_ds if ctx.residual else None), (g_dv if ctx.residual else None)
+
+
+def _adjacent(first, second):
+    """second starts exactly where first ends (both contiguous, same dtype/device)."""
+    return (first is not None and second is not None and first.is_contiguous() and second.is_contiguous()
+            and second.data_ptr() == first.data_ptr() + first.numel() * first.element_size())
+
+
+class _UpdateBlockFused(torch.autograd.Function):
+    """Whole UpdateBlock (conv.py:588-616, + the residual adds of cgvae.py:122-123) as ONE autograd
+    node with a hand-written backward: 6 launches forward, 6 backward (the tensor-op composition
+    needs 7 + 11, most of them gradient-accumulation adds and copies).  u_mat and v_mat are
+    applied as ONE product with the concatenated weight [u_mat; v_mat] -- the two parameters sit
+    next to each other in the trainer's arena -- and all weight gradients go to the grouped queue.
+    Used when the block runs on the bead graph under the trainer (arena-managed parameters);
+    ``update_block`` falls back to the composition otherwise."""
+
+    @staticmethod
+    def usable(s, v, u_w, v_w, d0, d1):
+        from .primitives import Swish, _is_direct
+        if not (s.is_cuda and s.dtype == _F32 and v.dtype == _F32):
+            return False
+        n, F = s.shape
+        lib = _lib.load()
+        if not (lib.cgv_skinny_supported(3 * n, 2 * F, F) and lib.cgv_skinny_supported(n, F, 2 * F)
+                and lib.cgv_skinny_supported(n, 3 * F, F)):
+            return False
+        if not isinstance(d0.activation, Swish) or d1.activation is not None or d0.dropout_rate or d1.dropout_rate:
+            return False
+        params = (u_w, v_w, d0.weight, d0.bias, d1.weight, d1.bias)
+        if not all(_is_direct(p) and p.grad.is_contiguous() for p in params):
+            return False
+        return _adjacent(u_w, v_w) and _adjacent(u_w.grad, v_w.grad) and u_w.data_ptr() % 16 == 0
+
+    @staticmethod
+    def forward(ctx, s, v, u_w, v_w, W0, b0, W1, b1, residual):
+        s, v = _c(s), _c(v)
+        n, F = s.shape
+        dev, st = s.device, _lib.stream_ptr()
+        new = lambda *shape: torch.empty(*shape, dtype=_F32, device=dev)
+        Wuv = torch.as_strided(u_w.detach(), (2 * F, F), (F, 1))
+        vt, UV, stack = new(3 * n, F), new(3 * n, 2 * F), new(n, 2 * F)
+        z0, a0, a = new(n, F), new(n, F), new(n, 3 * F)
+        ds, dv = new(n, F), new(n, F, 3)
+        _lib.call("cgv_update_rows_from_vec", _lib.ptr(v), _lib.ptr(vt), n, F, st)
+        _lib.call("cgv_skinny_linear_fwd", _lib.ptr(vt), _lib.ptr(Wuv), None, _lib.ptr(UV), None, 3 * n, 2 * F, F, 0, st)
+        U_ptr, Vv_ptr = UV.data_ptr(), UV.data_ptr() + 4 * F
+        _lib.call("cgv_update_norm_stack_fwd", _lib.ptr(s), Vv_ptr, _lib.ptr(stack), n, F, 2 * F, st)
+        _lib.call("cgv_skinny_linear_fwd", _lib.ptr(stack), _lib.ptr(W0), _lib.ptr(b0), _lib.ptr(a0), _lib.ptr(z0), n, F,
+                  2 * F, 1, st)
+        _lib.call("cgv_skinny_linear_fwd", _lib.ptr(a0), _lib.ptr(W1), _lib.ptr(b1), _lib.ptr(a), None, n, 3 * F, F, 0, st)
+        _lib.call("cgv_update_gate_fwd", U_ptr, Vv_ptr, _lib.ptr(a), _lib.ptr(s) if residual else None,
+                  _lib.ptr(v) if residual else None, _lib.ptr(ds), _lib.ptr(dv), n, F, 2 * F, st)
+        ctx.save_for_backward(vt, UV, stack, z0, a0, a, W0, W1)
+        ctx.params = (u_w, v_w, W0, b0, W1, b1)
+        ctx.residual = bool(residual)
+        ctx.set_materialize_grads(False)
+        return ds, dv
+
+    @staticmethod
+    def backward(ctx, g_ds, g_dv):
+        from .primitives import _grad_target, wgrad_queue
+        if g_ds is None and g_dv is None:
+            return (None,) * 9
+        vt, UV, stack, z0, a0, a, W0d, W1d = ctx.saved_tensors
+        u_w, v_w, W0, b0, W1, b1 = ctx.params
+        n, F = stack.shape[0], stack.shape[1] // 2
+        dev, st = stack.device, _lib.stream_ptr()
+        new = lambda *shape: torch.empty(*shape, dtype=_F32, device=dev)
+        g_ds, g_dv = _c(g_ds), _c(g_dv)
+        U_ptr, Vv_ptr = UV.data_ptr(), UV.data_ptr() + 4 * F
+        gUV, ga = new(3 * n, 2 * F), new(n, 3 * F)
+        gU_ptr, gVv_ptr = gUV.data_ptr(), gUV.data_ptr() + 4 * F
+        _lib.call("cgv_update_gate_bwd", U_ptr, Vv_ptr, _lib.ptr(a), _lib.ptr(g_ds), _lib.ptr(g_dv), gU_ptr, gVv_ptr,
+                  _lib.ptr(ga), n, F, 2 * F, st)
+        g_a0, g_stack, g_s, g_vt, g_v = new(n, F), new(n, 2 * F), new(n, F), new(3 * n, F), new(n, F, 3)
+        _lib.call("cgv_skinny_linear_bwd_input", _lib.ptr(ga), None, _lib.ptr(W1d), _lib.ptr(g_a0), n, 3 * F, F, 0, st)
+        _lib.call("cgv_skinny_linear_bwd_input", _lib.ptr(g_a0), _lib.ptr(z0), _lib.ptr(W0d), _lib.ptr(g_stack), n, F,
+                  2 * F, 1, st)
+        _lib.call("cgv_update_norm_stack_bwd", _lib.ptr(g_stack), Vv_ptr, _lib.ptr(stack),
+                  _lib.ptr(g_ds) if ctx.residual else None, _lib.ptr(g_s), gVv_ptr, n, F, 2 * F, 1, st)
+        Wuv = torch.as_strided(u_w.detach(), (2 * F, F), (F, 1))
+        _lib.call("cgv_skinny_linear_bwd_input", _lib.ptr(gUV), None, _lib.ptr(Wuv), _lib.ptr(g_vt), 3 * n, 2 * F, F, 0, st)
+        _lib.call("cgv_update_vec_from_rows", _lib.ptr(g_vt), _lib.ptr(g_dv) if ctx.residual else None, _lib.ptr(g_v),
+                  n, F, st)
+        # weight gradients -> grouped launch (direct targets; the [u_mat; v_mat] pair is one problem)
+        tu, acc_u, _ = _grad_target(u_w, u_w)
+        tv, acc_v, _ = _grad_target(v_w, v_w)
+        if acc_u != acc_v:
+            raise RuntimeError("u_mat / v_mat disagree on first-write / accumulate state")
+        wgrad_queue.enqueue(gUV, vt, None, 0, torch.as_strided(tu, (2 * F, F), (F, 1)), None, acc_u)
+        t1, acc1, _ = _grad_target(W1, W1)
+        tb1, accb1, _ = _grad_target(b1, b1)
+        wgrad_queue.enqueue(ga, a0, None, 0, t1, tb1, acc1)
+        t0, acc0, _ = _grad_target(W0, W0)
+        tb0, accb0, _ = _grad_target(b0, b0)
+        wgrad_queue.enqueue(g_a0, stack, z0, 1, t0, tb0, acc0)
+        if acc1 != accb1 or acc0 != accb0:
+            raise RuntimeError("weight and bias of one layer disagree on first-write / accumulate state")
+        if not wgrad_queue.active:
+            wgrad_queue.flush()
+        return g_s, g_v, None, None, None, None, None, None, None
 
 
 def update_block(s, v, u_weight, v_weight, s_dense, residual: bool = False):
     """UpdateBlock.forward (conv.py:588-616): four K=F GEMMs around two fused element-wise
     kernels; v is re-laid out once as [N,3,F] rows for the channel-mixing GEMMs.
     ``residual=True`` returns (s + ds, v + dv) instead of the deltas."""
+    d0, d1 = s_dense[0], s_dense[1]
+    if _UpdateBlockFused.usable(s, v, u_weight, v_weight, d0, d1):
+        return _UpdateBlockFused.apply(s, v, u_weight, v_weight, d0.weight, d0.bias, d1.weight, d1.bias, residual)
     n, F = s.shape
     vt = v.transpose(1, 2).reshape(-1, F)                       # [3N, F], row = node*3 + xyz (conv.py:591)
     U = _linear(vt, u_weight).view(n, 3, F)

@@ -178,23 +178,29 @@ int cgv_pseudo_msg_bwd(const float* phi, const float* s, const float* sbar, cons
                        int residual, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
- * K5  UpdateBlock element-wise core (conv.py:588-616); the four K=F GEMMs stay with the caller
- * (hipBLASLt).  U, Vv = u_mat / v_mat applied to v, laid out [N,3,F] (row = node*3 + xyz);
- * a = s_dense(stack) viewed [N,3,F] = (a_vv, a_sv, a_ss).
- *   norm_stack: stack[n] = [ s[n,:] | sqrt(sum_k (Vv[n,k,:]^2 + 1e-10)) ]          conv.py:600-601
- *   gate      : dv[n,f,k] = U[n,k,f] a_vv ;  ds[n,f] = (sum_k U Vv) a_sv + a_ss     conv.py:607-614
- * and their backward kernels (g_ds / g_dv may be NULL).  gate_fwd with s_res / v_res emits
- * s + ds and v + dv (the residual adds of cgvae.py:122-123) instead of the deltas.
+ * K5  UpdateBlock element-wise core (conv.py:588-616); the K=F products are separate launches
+ * (skinny GEMMs below / hipBLASLt).  U, Vv = u_mat / v_mat applied to v as rows r = node*3 + xyz with row
+ * stride `ld` floats (ld = F for separate buffers, 2F when both are column halves of one product with
+ * the concatenated weights [u_mat; v_mat]); a = s_dense(stack) viewed [N,3,F] = (a_vv, a_sv, a_ss).
+ *   rows_from_vec : rows[n,k,f] = v[n,f,k]                                          conv.py:591
+ *   vec_from_rows : vec[n,f,k] = rows[n,k,f] (+ res[n,f,k])                         (its backward, + residual pass-through)
+ *   norm_stack    : stack[n] = [ s[n,:] | sqrt(sum_k (Vv[n,k,:]^2 + 1e-10)) ]       conv.py:600-601
+ *   gate          : dv[n,f,k] = U[n,k,f] a_vv ; ds[n,f] = (sum_k U Vv) a_sv + a_ss  conv.py:607-614
+ *                   with s_res / v_res: s + ds and v + dv (cgvae.py:122-123) instead of the deltas
+ * and the backward kernels (g_ds / g_dv / g_res may be NULL; norm_stack_bwd can accumulate onto gVv).
  * ------------------------------------------------------------------------------------- */
-int cgv_update_norm_stack_fwd(const float* s /*[N,F]*/, const float* Vv /*[N,3,F]*/, float* stack /*[N,2F]*/,
-                              int n_nodes, int n_feat, void* stream);
-int cgv_update_norm_stack_bwd(const float* gstack, const float* Vv, const float* stack, float* g_s, float* gVv,
-                              int n_nodes, int n_feat, void* stream);
+int cgv_update_rows_from_vec(const float* v /*[N,F,3]*/, float* rows /*[N,3,F]*/, int n_nodes, int n_feat, void* stream);
+int cgv_update_vec_from_rows(const float* rows, const float* res /*[N,F,3] or NULL*/, float* vec, int n_nodes, int n_feat,
+                             void* stream);
+int cgv_update_norm_stack_fwd(const float* s /*[N,F]*/, const float* Vv, float* stack /*[N,2F]*/, int n_nodes, int n_feat,
+                              int ld, void* stream);
+int cgv_update_norm_stack_bwd(const float* gstack, const float* Vv, const float* stack, const float* g_res /*[N,F] or NULL*/,
+                              float* g_s, float* gVv, int n_nodes, int n_feat, int ld, int accumulate, void* stream);
 int cgv_update_gate_fwd(const float* U, const float* Vv, const float* a, const float* s_res /*[N,F] or NULL*/,
                         const float* v_res /*[N,F,3] or NULL*/, float* ds /*[N,F]*/, float* dv /*[N,F,3]*/,
-                        int n_nodes, int n_feat, void* stream);
+                        int n_nodes, int n_feat, int ld, void* stream);
 int cgv_update_gate_bwd(const float* U, const float* Vv, const float* a, const float* g_ds, const float* g_dv,
-                        float* gU, float* gVv, float* ga, int n_nodes, int n_feat, void* stream);
+                        float* gU, float* gVv, float* ga, int n_nodes, int n_feat, int ld, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Skinny fp32 GEMMs for the node-level Dense / nn.Linear layers on the bead graph

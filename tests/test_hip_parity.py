@@ -503,3 +503,44 @@ def test_dense_with_fused_swish_vs_fp64(M, F):
     assert_close(xg.grad, xd.grad, "gx", 3e-6)
     assert_close(dense.weight.grad, Wd_.grad, "gW", 3e-6)
     assert_close(dense.bias.grad, bd_.grad, "gb", 3e-6)
+
+
+def test_fused_update_block_equals_composition():
+    """The single-node UpdateBlock path (arena-managed parameters, merged [u_mat; v_mat] product, grouped
+    weight gradients) against the tensor-op composition and the fp64 oracle formulas."""
+    from coarsegrainingvae_amd.trainer import ParamArena
+    from coarsegrainingvae_amd.ops import _UpdateBlockFused
+    torch.manual_seed(3)
+    n, F = 12, 600
+    blk = cg.UpdateBlock(F, "swish", 0.0).to(DEV)
+    with torch.no_grad():
+        for p in blk.parameters():
+            if p.dim() == 1:
+                p.normal_(0, 0.2)
+    s = torch.randn(n, F, device=DEV)
+    v = torch.randn(n, F, 3, device=DEV)
+    gs, gv = torch.randn(n, F, device=DEV), torch.randn(n, F, 3, device=DEV)
+
+    def run(residual):
+        for p in blk.parameters():
+            if p.grad is not None:
+                p._cgv_pending = True if getattr(p, "_cgv_direct", False) else None
+        s1, v1 = s.clone().requires_grad_(True), v.clone().requires_grad_(True)
+        ds, dv = blk(s1, v1, residual=residual)
+        ((ds * gs).sum() + (dv * gv).sum()).backward()
+        return ds.detach(), dv.detach(), s1.grad, v1.grad, [p.grad.clone() for p in blk.parameters()]
+
+    ref = {r: run(r) for r in (False, True)}                       # composition (no arena yet)
+    for p in blk.parameters():
+        p.grad = None
+    _ = run(False)
+    arena = ParamArena(list(blk.parameters()))
+    assert _UpdateBlockFused.usable(s, v, blk.u_mat.weight, blk.v_mat.weight, blk.s_dense[0], blk.s_dense[1])
+    for residual in (False, True):
+        arena.g.fill_(float("nan"))
+        arena.zero_grad()
+        got = run(residual)
+        for a, b, name in zip(got[:4], ref[residual][:4], ("ds", "dv", "g_s", "g_v")):
+            assert_close(a, b, f"{name} residual={residual}", 2e-5)
+        for a, b, (name, _) in zip(got[4], ref[residual][4], blk.named_parameters()):
+            assert_close(a, b, f"grad {name} residual={residual}", 2e-5)
