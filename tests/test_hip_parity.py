@@ -523,8 +523,8 @@ def test_fused_update_block_equals_composition():
 
     def run(residual):
         for p in blk.parameters():
-            if p.grad is not None:
-                p._cgv_pending = True if getattr(p, "_cgv_direct", False) else None
+            if not getattr(p, "_cgv_direct", False):
+                p.grad = None                                   # plain autograd accumulation: start from scratch
         s1, v1 = s.clone().requires_grad_(True), v.clone().requires_grad_(True)
         ds, dv = blk(s1, v1, residual=residual)
         ((ds * gs).sum() + (dv * gv).sum()).backward()
