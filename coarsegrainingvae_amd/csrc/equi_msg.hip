@@ -72,6 +72,22 @@ __device__ __forceinline__ ChanPair chan_pair(int tile, int lane, int F) {
   return p;
 }
 
+// "scalar base + 32-bit lane byte offset" loads: with a wave-uniform row pointer and a loop-invariant
+// per-lane byte offset the compiler emits global_load ... v_off, s[base] (saddr form) -- no per-edge
+// 64-bit vector address arithmetic (PMC before this: 29 SALU + ~10 address VALU instructions per edge)
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+// Row gathers go through a buffer descriptor (SRSRC): address = base + lane byte offset (VGPR, loop
+// invariant) + row byte offset (SGPR, one s_mul per edge).  The generic pointer form costs 29 scalar
+// + ~10 vector address instructions per edge (PMC: SQ_INSTS_SALU) -- the address math, not the FMAs,
+// was what the SIMDs were issuing.  Rows are < 2 GiB apart by the host-side check in the launcher.
+__device__ __forceinline__ rsrc_t make_rsrc(const float* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ f2 ld2_buf(rsrc_t r, unsigned voff_bytes, unsigned soff_bytes) {
+  return __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(r, voff_bytes, soff_bytes, 0));
+}
+
 template <bool PAIR>
 __device__ __forceinline__ f2 ldpair(const float* base, const ChanPair& cp) {
   if constexpr (PAIR) return ld2(base + cp.c);
@@ -141,18 +157,29 @@ __global__ __launch_bounds__(64 * SPLIT) void equi_msg_fwd_k(const float* __rest
     beg = min(beg + wave * len, end);
     end = min(beg + len, end);
   }
+  const unsigned row_bytes = 12u * (unsigned)F;              // bytes per node row of phi [3F] AND of v [F,3]
+  const unsigned oc = 4u * (unsigned)cp.c, oF = 4u * (unsigned)F, ov = 12u * (unsigned)cp.c;
+  const rsrc_t r_phi = make_rsrc(phi), r_v = make_rsrc(WITH_DV ? v : phi);
 #pragma unroll 2
   for (int e = beg; e < end; ++e) {
     const float* __restrict__ g = geom + (size_t)e * GS;   // wave-uniform -> s_load
     const int j = src[e];
+    const unsigned soff = (unsigned)j * row_bytes;            // uniform: SGPR
     const float* __restrict__ prow = phi + (size_t)j * 3 * F;
-    const f2 p1 = ldpair<PAIR>(prow + F, cp);
+    f2 p1;
+    if constexpr (PAIR) p1 = ld2_buf(r_phi, oc + oF, soff); else p1 = ldpair<PAIR>(prow + F, cp);
     acc_s = fma2(p1, filter2<R>(W1, g), acc_s);
     if constexpr (WITH_DV) {
-      const f2 p0 = ldpair<PAIR>(prow, cp);
-      const f2 p2 = ldpair<PAIR>(prow + 2 * F, cp);
-      f2 A, B, C;
-      ldvec<PAIR>(v + (size_t)j * F * 3, cp, A, B, C);
+      f2 p0, p2, A, B, C;
+      if constexpr (PAIR) {
+        p0 = ld2_buf(r_phi, oc, soff);
+        p2 = ld2_buf(r_phi, oc + 2u * oF, soff);
+        A = ld2_buf(r_v, ov, soff); B = ld2_buf(r_v, ov + 8u, soff); C = ld2_buf(r_v, ov + 16u, soff);
+      } else {
+        p0 = ldpair<PAIR>(prow, cp);
+        p2 = ldpair<PAIR>(prow + 2 * F, cp);
+        ldvec<PAIR>(v + (size_t)j * F * 3, cp, A, B, C);
+      }
       const f2 m0 = p0 * filter2<R>(W0, g);
       const f2 m2 = p2 * filter2<R>(W2, g);
       const f2 u01 = f2{g[U], g[U + 1]}, u20 = f2{g[U + 2], g[U + 3]}, u12 = f2{g[U + 4], g[U + 5]};
@@ -236,6 +263,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void equi_msg_bwd_k(
 #pragma unroll
     for (int n = 0; n <= R; ++n) G[k][n] = splat(0.f);
 
+  const rsrc_t r_gs = make_rsrc(gs ? gs : phi), r_gv = make_rsrc(HAS_GV ? gv : phi);
   const int n_beg = chunk * nodes_per_chunk;
   const int n_end = min(n_beg + nodes_per_chunk, n_src);
   const int j0 = SPLIT ? n_beg : n_beg + wave;
@@ -260,10 +288,19 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void equi_msg_bwd_k(
     for (int e = beg; e < end; ++e) {
       const float* __restrict__ g = geom + (size_t)e * GS;
       const int i = dst[e];
-      const f2 gq1 = gs ? ldpair<PAIR>(gs + (size_t)i * F, cp) : splat(0.f);
+      f2 gq1 = splat(0.f);
+      if (gs) {
+        if constexpr (PAIR) gq1 = ld2_buf(r_gs, 4u * (unsigned)cp.c, (unsigned)i * 4u * (unsigned)F);
+        else gq1 = ldpair<PAIR>(gs + (size_t)i * F, cp);
+      }
       if constexpr (HAS_GV) {
         f2 gA, gB, gC;
-        ldvec<PAIR>(gv + (size_t)i * F * 3, cp, gA, gB, gC);
+        if constexpr (PAIR) {
+          const unsigned ov = 12u * (unsigned)cp.c, so = (unsigned)i * 12u * (unsigned)F;
+          gA = ld2_buf(r_gv, ov, so); gB = ld2_buf(r_gv, ov + 8u, so); gC = ld2_buf(r_gv, ov + 16u, so);
+        } else {
+          ldvec<PAIR>(gv + (size_t)i * F * 3, cp, gA, gB, gC);
+        }
         const f2 w0 = filter2<R>(W[0], g), w1 = filter2<R>(W[1], g), w2 = filter2<R>(W[2], g);
         const f2 u01 = f2{g[U], g[U + 1]}, u20 = f2{g[U + 2], g[U + 3]}, u12 = f2{g[U + 4], g[U + 5]};
         const f2 PA = gA * vA, PB = gB * vB, PC = gC * vC;          // (x0x0,y0y0)(z0z0,x1x1)(y1y1,z1z1)
@@ -410,8 +447,8 @@ extern "C" {
 
 int cgv_equi_msg_fwd(const float* phi, const float* v, const float* geom_d, const int32_t* rowptr_d,
                      const int32_t* src_d, const float* Wd, const float* bd, float* ds, float* dv, int n_dst,
-                     int n_feat, int n_rbf, int with_dv, int64_t n_edges_hint, const float* s_res, const float* v_res,
-                     void* stream) {
+                     int n_feat, int n_rbf, int with_dv, int64_t n_edges_hint, int64_t n_rows_hint, const float* s_res,
+                     const float* v_res, void* stream) {
   CGV_REQUIRE(n_dst >= 0 && n_feat > 0, "bad size");
   if (n_dst == 0) return 0;
   CGV_REQUIRE(phi && rowptr_d && Wd && bd && ds, "null pointer");
@@ -423,8 +460,9 @@ int cgv_equi_msg_fwd(const float* phi, const float* v, const float* geom_d, cons
   // high-degree graphs (>= 48 edges per receiver on average): 4 waves share a (node, tile)
   bool split = n_edges_hint >= 48LL * n_dst;
   if (const char* dbg = getenv("CGV_DEBUG_FWD_SPLIT")) split = dbg[0] == '1';   // experiments only
-  // 8-byte vector accesses need an even channel count and 8-byte aligned bases
-  const bool pair = (n_feat % 2 == 0) &&
+  // 8-byte vector accesses need an even channel count and 8-byte aligned bases; the buffer-descriptor
+  // gathers need every row within 2 GiB of the base (n_rows_hint = rows of phi / v, 0 = unknown)
+  const bool pair = (n_feat % 2 == 0) && n_rows_hint > 0 && (uint64_t)n_rows_hint * 12u * (uint64_t)n_feat < 0x7fffffffull &&
                     ((((uintptr_t)phi | (uintptr_t)v | (uintptr_t)ds | (uintptr_t)dv | (uintptr_t)s_res | (uintptr_t)v_res) & 7) == 0);
 #define CGV_FWD_LAUNCH(DV, SP, PR)                                                                                   \
   hipLaunchKernelGGL((cgv::equi_msg_fwd_k<RBF, DV, SP, PR>), grid, dim3(64 * SP), 0, st, phi, v, geom_d, rowptr_d, src_d, \
@@ -448,7 +486,7 @@ size_t cgv_equi_msg_bwd_workspace_bytes(int n_src, int n_feat, int n_rbf) {
 int cgv_equi_msg_bwd(const float* phi, const float* v, const float* geom_s, const int32_t* rowptr_s,
                      const int32_t* dst_s, const float* Wd, const float* bd, const float* gs, const float* gv,
                      float* g_phi, float* g_v, float* gWd, float* gbd, int n_src, int n_feat, int n_rbf,
-                     int64_t n_edges_hint, void* workspace, size_t workspace_bytes, void* stream) {
+                     int64_t n_edges_hint, int64_t n_rows_hint, void* workspace, size_t workspace_bytes, void* stream) {
   CGV_REQUIRE(n_src >= 0 && n_feat > 0, "bad size");
   CGV_REQUIRE(phi && rowptr_s && Wd && bd && g_phi && gWd && gbd && workspace, "null pointer");
   CGV_REQUIRE(!gv || (v && g_v), "gv needs v and g_v");
@@ -461,7 +499,7 @@ int cgv_equi_msg_bwd(const float* phi, const float* v, const float* geom_s, cons
   const int tiles = (n_feat + 127) / 128;
   float* part = reinterpret_cast<float*>(workspace);
   const dim3 grid(8 * sh.cpx * tiles), block(64 * cgv::BWD_WAVES);
-  const bool pair = (n_feat % 2 == 0) &&
+  const bool pair = (n_feat % 2 == 0) && n_rows_hint > 0 && (uint64_t)n_rows_hint * 12u * (uint64_t)n_feat < 0x7fffffffull &&
                     ((((uintptr_t)phi | (uintptr_t)v | (uintptr_t)gs | (uintptr_t)gv | (uintptr_t)g_phi |
                        (uintptr_t)g_v | (uintptr_t)part) & 7) == 0);
 #define CGV_BWD_LAUNCH(GV, SP, PR)                                                                                 \

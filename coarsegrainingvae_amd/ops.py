@@ -59,7 +59,7 @@ class _EquiMessage(torch.autograd.Function):
             dv = v_res.clone() if v_res is not None else torch.zeros(plan.n_dst, F, 3, dtype=_F32, device=phi.device)
         _lib.call("cgv_equi_msg_fwd", _lib.ptr(phi), _lib.ptr(v), _lib.ptr(geom.geom_d), _lib.ptr(plan.rowptr_d),
                   _lib.ptr(plan.src_d), _lib.ptr(Wd), _lib.ptr(bd), _lib.ptr(ds), _lib.ptr(dv), plan.n_dst, F,
-                  geom.n_rbf, int(with_dv), plan.n_edges, _lib.ptr(s_res), _lib.ptr(v_res), _lib.stream_ptr(),
+                  geom.n_rbf, int(with_dv), plan.n_edges, plan.n_src, _lib.ptr(s_res), _lib.ptr(v_res), _lib.stream_ptr(),
                   tag=f"equi_msg_fwd:Nd{plan.n_dst}:E{plan.n_edges}:dv{int(with_dv)}")
         ctx.save_for_backward(phi, v, Wd, bd)
         ctx.filter_params = filter_params
@@ -90,7 +90,7 @@ class _EquiMessage(torch.autograd.Function):
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         _lib.call("cgv_equi_msg_bwd", _lib.ptr(phi), _lib.ptr(v), _lib.ptr(geom.geom_s), _lib.ptr(plan.rowptr_s),
                   _lib.ptr(plan.dst_s), _lib.ptr(Wd), _lib.ptr(bd), _lib.ptr(gs), _lib.ptr(gv), _lib.ptr(g_phi),
-                  _lib.ptr(g_v), _lib.ptr(gWd), _lib.ptr(gbd), plan.n_src, F, geom.n_rbf, plan.n_edges, _lib.ptr(ws), ws_bytes,
+                  _lib.ptr(g_v), _lib.ptr(gWd), _lib.ptr(gbd), plan.n_src, F, geom.n_rbf, plan.n_edges, plan.n_dst, _lib.ptr(ws), ws_bytes,
                   _lib.stream_ptr(), tag=f"equi_msg_bwd:Nd{plan.n_dst}:E{plan.n_edges}:gv{int(gv is not None)}")
         return g_phi, g_v, ret_W, ret_b, None, None, None, g_sres, g_vres
 

@@ -131,6 +131,8 @@ int cgv_segment_broadcast(const float* gout, const int32_t* rowptr, const int32_
  * the encoder never consumes it -- SURVEY 8a note a12) and leaves dv untouched.
  * s_res / v_res (optional): the outputs become s_res + ds and v_res + dv, i.e. the residual adds
  * of cgvae.py:287-288, 309-310, 391-392 fused into the store.
+ * n_rows_hint = number of rows of the gathered arrays (Ns forward, Nd backward; 0 = unknown): enables
+ * the buffer-descriptor gather path when every row lies within 2 GiB of its base.
  * n_edges_hint (the edge count, or 0) only selects the launch shape: several waves share a
  * receiver when the average degree is high.  Results do not depend on it beyond fp32
  * summation order.
@@ -138,7 +140,7 @@ int cgv_segment_broadcast(const float* gout, const int32_t* rowptr, const int32_
 int cgv_equi_msg_fwd(const float* phi /*[Ns,3F]*/, const float* v /*[Ns,F,3]*/, const float* geom_d,
                      const int32_t* rowptr_d, const int32_t* src_d, const float* Wd /*[3F,R]*/,
                      const float* bd /*[3F]*/, float* ds /*[Nd,F]*/, float* dv /*[Nd,F,3]*/, int n_dst,
-                     int n_feat, int n_rbf, int with_dv, int64_t n_edges_hint,
+                     int n_feat, int n_rbf, int with_dv, int64_t n_edges_hint, int64_t n_rows_hint,
                      const float* s_res /*[Nd,F] or NULL*/, const float* v_res /*[Nd,F,3] or NULL*/, void* stream);
 /* Backward.  gs / gv are the upstream gradients at the receivers (gv == NULL when dv is not
  * consumed).  Traverses the src-sorted view; writes g_phi [Ns,3F], g_v [Ns,F,3] (only if gv),
@@ -148,7 +150,7 @@ size_t cgv_equi_msg_bwd_workspace_bytes(int n_src, int n_feat, int n_rbf);
 int cgv_equi_msg_bwd(const float* phi, const float* v, const float* geom_s, const int32_t* rowptr_s,
                      const int32_t* dst_s, const float* Wd, const float* bd, const float* gs /*[Nd,F] or NULL*/,
                      const float* gv /*[Nd,F,3] or NULL*/, float* g_phi, float* g_v, float* gWd, float* gbd,
-                     int n_src, int n_feat, int n_rbf, int64_t n_edges_hint, void* workspace,
+                     int n_src, int n_feat, int n_rbf, int64_t n_edges_hint, int64_t n_rows_hint, void* workspace,
                      size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------

@@ -35,7 +35,7 @@ def test_library_loads_and_exports_every_header_symbol():
 
 def test_argument_errors_are_reported_without_a_gpu():
     lib = _lib.load()
-    rc = lib.cgv_equi_msg_fwd(None, None, None, None, None, None, None, None, None, 4, 8, 8, 1, 0, None, None, None)
+    rc = lib.cgv_equi_msg_fwd(None, None, None, None, None, None, None, None, None, 4, 8, 8, 1, 0, 0, None, None, None)
     assert rc == -1 and b"null" in lib.cgv_last_error_string()
     with pytest.raises(RuntimeError, match="cgv_segment_reduce failed"):
         _lib.call("cgv_segment_reduce", None, None, None, 3, 8, 0, None, None)
