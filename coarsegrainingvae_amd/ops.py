@@ -114,10 +114,15 @@ class _SegmentReduce(torch.autograd.Function):
         _lib.call("cgv_segment_reduce", _lib.ptr(flat), _lib.ptr(plan.rowptr_d), _lib.ptr(plan.eid_d), plan.n_dst, C,
                   int(mean), _lib.ptr(out), _lib.stream_ptr())
         ctx.plan, ctx.mean, ctx.shape = plan, mean, tuple(src.shape)
+        # a reduction nobody differentiates (the encoder's V) must not turn into a zero gradient that
+        # drags the full vector-channel backward of the producing block along
+        ctx.set_materialize_grads(False)
         return out.reshape((plan.n_dst,) + tuple(src.shape[1:]))
 
     @staticmethod
     def backward(ctx, gout):
+        if gout is None:
+            return None, None, None
         plan = ctx.plan
         gout = _c(gout).reshape(plan.n_dst, -1)
         C = gout.shape[1]
