@@ -229,6 +229,16 @@ def main():
                                 for k in ksum}
         extra["scatter_add"] = scatter_add_roofline(batch, F)
         extra["optimizer_step"] = optimizer_roofline(trainer)
+        # HBM traffic per launch from the committed PMC passes (separate rocprofv3 --pmc runs of this
+        # same workload; cannot be collected inside the timed run) -- null when no entry matches
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.workload, {})
+            if F == 600 and frames == w["batch"]:
+                for obj in (roofline, extra["scatter_add"], extra["optimizer_step"]):
+                    if obj and obj["kernel"] in pmc:
+                        obj["traffic"] = pmc[obj["kernel"]]["traffic_bytes"]
+        except (OSError, ValueError):
+            pass
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             steps_cpu = args.cpu_steps or (4 if args.workload == "chignolin" else 6)
