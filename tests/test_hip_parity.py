@@ -544,3 +544,115 @@ def test_fused_update_block_equals_composition():
             assert_close(a, b, f"{name} residual={residual}", 2e-5)
         for a, b, (name, _) in zip(got[4], ref[residual][4], blk.named_parameters()):
             assert_close(a, b, f"grad {name} residual={residual}", 2e-5)
+
+
+# --------------------------------------------------------------------------- edge cases the fused kernels must survive
+def _block_vs_oracle(F, R, n, nbrs, xyz, with_gv=True, seed=0, tol=REL):
+    gen = torch.Generator().manual_seed(seed)
+    cutoff = 6.0
+    r = xyz[nbrs[:, 1]] - xyz[nbrs[:, 0]] if nbrs.shape[0] else torch.zeros(0, 3)
+    blk = cg.EquiMessageBlock(F, "swish", R, cutoff, 0.0)
+    with torch.no_grad():
+        for p in blk.parameters():
+            if p.dim() == 1:
+                p.normal_(0, 0.3, generator=gen)
+    P = {"b." + k: v.detach().clone().requires_grad_(True) for k, v in blk.state_dict().items()}
+    s, v = torch.randn(n, F, generator=gen), torch.randn(n, F, 3, generator=gen)
+    gs, gv = torch.randn(n, F, generator=gen), torch.randn(n, F, 3, generator=gen)
+    s0, v0 = s.clone().requires_grad_(True), v.clone().requires_grad_(True)
+    ds0, dv0 = O.equi_message_block(s0, v0, r, nbrs, P, "b", O.swish, R, cutoff)
+    ((ds0 * gs).sum() + ((dv0 * gv).sum() if with_gv else 0.0)).backward()
+    blk = blk.to(DEV)
+    s1, v1 = s.to(DEV).requires_grad_(True), v.to(DEV).requires_grad_(True)
+    ds1, dv1 = blk(s1, v1, r.to(DEV), nbrs.to(DEV))
+    ((ds1 * gs.to(DEV)).sum() + ((dv1 * gv.to(DEV)).sum() if with_gv else 0.0)).backward()
+    assert_close(ds1, ds0, "ds", tol) if float(ds0.abs().max()) > 0 else None
+    assert_close(dv1, dv0, "dv", tol) if float(dv0.abs().max()) > 0 else None
+    assert_close(s1.grad, s0.grad, "grad s", tol) if float(s0.grad.abs().max()) > 0 else None
+    if with_gv and float(v0.grad.abs().max()) > 0:
+        assert_close(v1.grad, v0.grad, "grad v", tol)
+    for name, p in blk.named_parameters():
+        ref = P["b." + name].grad
+        if ref is not None and float(ref.abs().max()) > 0:
+            assert_close(p.grad, ref, "grad " + name, tol)
+    return ds1, dv1
+
+
+@pytest.mark.parametrize("F,R", [(7, 8), (1, 4), (129, 10), (130, 6), (600, 12), (66, 16), (34, 20)])
+@pytest.mark.parametrize("with_gv", [True, False])
+def test_equi_message_odd_widths_and_all_rbf_counts(F, R, with_gv):
+    """Odd channel counts take the scalar-access (PAIR = false) instantiation; every compiled n_rbf runs."""
+    gen = torch.Generator().manual_seed(F)
+    n = 23
+    xyz = torch.rand(n, 3, generator=gen) * 4.0
+    nbrs, _ = O.make_directed(O.get_neighbor_list(xyz, 3.0, True))
+    _block_vs_oracle(F, R, n, nbrs, xyz, with_gv, seed=F + R)
+
+
+def test_equi_message_degenerate_graphs():
+    gen = torch.Generator().manual_seed(11)
+    F, R, n = 24, 8, 9
+    xyz = torch.rand(n, 3, generator=gen) * 4.0
+    # (a) no edges at all: outputs are exactly zero, gradients flow nowhere
+    empty = torch.zeros(0, 2, dtype=torch.long)
+    ds, dv = _block_vs_oracle(F, R, n, empty, xyz)
+    assert float(ds.abs().max()) == 0.0 and float(dv.abs().max()) == 0.0
+    # (b) isolated nodes, a self-contained pair, duplicated edges, one high-degree hub (asymmetric list)
+    nbrs = torch.tensor([[0, 1], [1, 0], [0, 1], [5, 2], [5, 3], [5, 4], [5, 6], [5, 7], [5, 0], [2, 5]])
+    _block_vs_oracle(F, R, n, nbrs, xyz)
+    # (c) coincident atoms (distance = sqrt(3e-8)) and an edge beyond the RBF cutoff
+    xyz2 = xyz.clone()
+    xyz2[1] = xyz2[0]
+    xyz2[8] = xyz2[0] + 50.0
+    nbrs2 = torch.tensor([[0, 1], [1, 0], [0, 8], [8, 0], [2, 3], [3, 2]])
+    _block_vs_oracle(F, R, n, nbrs2, xyz2)
+
+
+def test_ragged_batch_model_parity():
+    """Frames of different sizes in one batch (CG_collate offsets, per-frame plans) against the oracle."""
+    F, R = 32, 8
+    atom_cutoff, cg_cutoff, n_cgs = 4.0, 9.5, 3
+    gen = torch.Generator().manual_seed(2)
+    frames = []
+    for n_atoms in (9, 22, 5):
+        xyz = torch.rand(n_atoms, 3, generator=gen) * 5.0
+        z = torch.randint(1, 9, (n_atoms,), generator=gen).float()
+        mapping = (torch.arange(n_atoms) * n_cgs) // n_atoms
+        cgx = torch.stack([xyz[mapping == b].mean(0) for b in range(n_cgs)])
+        f = {"nxyz": torch.cat([z[:, None], xyz], 1), "CG_nxyz": torch.cat([torch.arange(n_cgs).float()[:, None], cgx], 1),
+             "num_atoms": torch.LongTensor([n_atoms]), "num_CGs": torch.LongTensor([n_cgs]), "CG_mapping": mapping,
+             "bond_edge_list": torch.stack([torch.arange(n_atoms - 1), torch.arange(1, n_atoms)], 1)}
+        f["nbr_list"] = O.get_neighbor_list(xyz, atom_cutoff, True)
+        f["CG_nbr_list"] = O.get_neighbor_list(cgx, cg_cutoff, True)
+        frames.append(f)
+    cpu_batch = O.cg_collate(frames)
+    assert torch.equal(cg.CG_collate(frames)["nbr_list"], cpu_batch["nbr_list"])
+    model = cg.build_model(F, R, atom_cutoff, cg_cutoff, 2, 2, n_cgs, det=True, seed=5)
+    hp = O.Hyper(F, R, atom_cutoff, cg_cutoff, 2, 2, n_cgs, det=True)
+    P = _oracle_params_from(model)
+    out0 = O.model_forward(cpu_batch, P, hp)
+    loss0 = O.loss_terms(out0, cpu_batch, 0.05, 25.0)[0]
+    loss0.backward()
+    model = model.to(DEV)
+    batch = cg.prepare_batch({k: v.to(DEV) for k, v in cg.CG_collate(frames).items()})
+    out1 = model(batch)
+    loss1 = cg.loss_terms(out1, batch, 0.05, 25.0)[0]
+    loss1.backward()
+    assert_close(out1[5], out0[5], "xyz_recon")
+    assert_close(loss1, loss0, "loss")
+    for name, p in model.named_parameters():
+        ref = P[name].grad
+        if ref is not None and float(ref.abs().max()) > 0:
+            assert_close(p.grad, ref, "grad " + name, 5e-4)
+
+
+def test_batched_radius_graph_dataset_path():
+    """CGDataset.generate_neighbor_list (one batched K0 launch per graph kind) == per-frame oracle lists."""
+    props = cg.data.synthetic_frames(5, 22, 3, 6.0, seed=4)
+    ds = cg.CGDataset(props)
+    ds.generate_neighbor_list(4.0, 9.5, device=DEV, undirected=True)
+    for k in range(5):
+        assert torch.equal(ds.props["nbr_list"][k], O.get_neighbor_list(props["nxyz"][k][:, 1:4], 4.0, True))
+        assert torch.equal(ds.props["CG_nbr_list"][k], O.get_neighbor_list(props["CG_nxyz"][k][:, 1:4], 9.5, True))
+    ds.generate_neighbor_list(4.0, None, device=DEV)                 # --cg_radius_graph: bead graph from bonds
+    assert ds.props["CG_nbr_list"][0].shape[1] == 2
