@@ -217,6 +217,163 @@ __global__ __launch_bounds__(64 * SPLIT) void equi_msg_fwd_k(const float* __rest
   }
 }
 
+// ------------------------------------------------------------------ forward, matrix-core variant
+// The filter rebuild  w_k(e, c) = sum_n a_n(e) Wd[kF+c][n] + env(e) bd[kF+c]  is a [edges x (R+1)] x
+// [(R+1) x channels] product: 3(R+1) of the ~45 FMAs per (edge, channel).  f32 MFMA has the SAME peak as
+// packed VALU (MI355X_MICROARCH.md), so it cannot make the product itself faster -- but it runs on the
+// separate matrix pipe, concurrently with the VALU.  Here a wave takes 16 edges of its receiver and
+// 64 channels at a time:  A[i = edge][k = rbf] = geometry record (one dword per lane and k-step),
+// B[k = rbf][j = channel] = filter weights (loop-invariant registers), D[edge][channel] = w.
+// v_mfma_f32_16x16x4_f32 leaves lane (j = l&15, q = l>>4) with w of channel j for edges 4q..4q+3, so
+// the VALU part (gather phi / v of those 4 edges' sources, multiply, accumulate) follows in the same
+// lane without any shuffle; the 4 edge groups q meet through two __shfl_xor at the end of the segment.
+// VALU work drops from ~45 to ~10 instructions per (edge, channel); the matrix pipe carries the rest.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float ld1_buf(rsrc_t r, unsigned voff_bytes) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff_bytes, 0u, 0));
+}
+
+template <int R, bool WITH_DV, int SPLIT>
+__global__ __launch_bounds__(64 * SPLIT) void equi_msg_fwd_mfma_k(
+    const float* __restrict__ phi, const float* __restrict__ v, const float* __restrict__ geom,
+    const int* __restrict__ rowptr, const int* __restrict__ src, const float* __restrict__ Wd,
+    const float* __restrict__ bd, float* __restrict__ ds, float* __restrict__ dv, int F, int n_dst, int nodes_per_xcd,
+    int tiles, const float* __restrict__ s_res, const float* __restrict__ v_res) {
+  constexpr int GS = geom_stride(R), U = geom_unit_offset(R);
+  constexpr int KS = (R + 1 + 3) / 4;           // k-steps of 4 over the R+1 filter terms
+  constexpr int NK = WITH_DV ? 3 : 1;           // filter slices evaluated
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int local = slot / tiles;
+  const int node = xcd * nodes_per_xcd + local;
+  const int tile = slot - local * tiles;
+  if (node >= n_dst || local >= nodes_per_xcd) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15, q = lane >> 4;
+  const int c0 = tile * 64;
+
+  // B operands: Wb[kk][nb][ks] = filter term (4 ks + q) of channel c0 + 16 nb + j in slice k
+  float Wb[NK][4][KS];
+#pragma unroll
+  for (int kk = 0; kk < NK; ++kk) {
+    const int k = WITH_DV ? kk : 1;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      const int c = c0 + 16 * nb + j;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int n = 4 * ks + q;
+        float w = 0.f;
+        if (c < F) {
+          if (n < R) w = Wd[(size_t)(k * F + c) * R + n];
+          else if (n == R) w = bd[k * F + c];
+        }
+        Wb[kk][nb][ks] = w;
+      }
+    }
+  }
+  // per-lane byte offsets of its 4 channels (clamped: lanes beyond F read a valid channel, their B is 0)
+  unsigned cb[4];
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) cb[nb] = (unsigned)min(c0 + 16 * nb + j, F - 1);
+  const unsigned row_bytes = 12u * (unsigned)F;
+  const rsrc_t r_phi = make_rsrc(phi), r_v = make_rsrc(WITH_DV ? v : phi);
+
+  float as[4] = {0.f, 0.f, 0.f, 0.f};
+  float ax[4] = {0.f, 0.f, 0.f, 0.f}, ay[4] = {0.f, 0.f, 0.f, 0.f}, az[4] = {0.f, 0.f, 0.f, 0.f};
+  int beg = rowptr[node], end = rowptr[node + 1];
+  if constexpr (SPLIT > 1) {
+    const int len = (((end - beg + SPLIT - 1) / SPLIT) + 15) & ~15;      // whole 16-edge tiles per wave
+    beg = min(beg + wave * len, end);
+    end = min(beg + len, end);
+  }
+  for (int t0 = beg; t0 < end; t0 += 16) {
+    // A operand: lane (i = l&15, kq = l>>4) supplies record entry 4 ks + kq of edge t0 + i (0 past the end)
+    const int eA = t0 + j;
+    const bool okA = eA < end;
+    float a[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) a[ks] = (okA && 4 * ks + q <= R) ? geom[(size_t)eA * GS + 4 * ks + q] : 0.f;
+    f32x4 D[NK][4];
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk)
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        D[kk][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+          D[kk][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], Wb[kk][nb][ks], D[kk][nb], 0, 0, 0);
+      }
+    // VALU part: this lane's 4 edges t0 + 4 q + r (rows past the end have w == 0: only addresses are clamped)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int e = min(t0 + 4 * q + r, end - 1);
+      const unsigned base = (unsigned)src[e] * row_bytes;
+      float ux = 0.f, uy = 0.f, uz = 0.f;
+      if constexpr (WITH_DV) {
+        const f3 u = ld3(geom + (size_t)e * GS + U);
+        ux = u.x; uy = u.y; uz = u.z;
+      }
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        const unsigned oc = base + 4u * cb[nb];
+        const float p1 = ld1_buf(r_phi, oc + 4u * (unsigned)F);
+        as[nb] = fmaf(p1, D[WITH_DV ? 1 : 0][nb][r], as[nb]);
+        if constexpr (WITH_DV) {
+          const float p0 = ld1_buf(r_phi, oc);
+          const float p2 = ld1_buf(r_phi, oc + 8u * (unsigned)F);
+          const unsigned ovv = base + 12u * cb[nb];
+          const float vx = ld1_buf(r_v, ovv), vy = ld1_buf(r_v, ovv + 4u), vz = ld1_buf(r_v, ovv + 8u);
+          const float m0 = p0 * D[0][nb][r], m2 = p2 * D[2][nb][r];
+          ax[nb] = fmaf(m2, ux, fmaf(m0, vx, ax[nb]));
+          ay[nb] = fmaf(m2, uy, fmaf(m0, vy, ay[nb]));
+          az[nb] = fmaf(m2, uz, fmaf(m0, vz, az[nb]));
+        }
+      }
+    }
+  }
+  // the 4 edge groups (lanes l, l^16, l^32, l^48) hold partial sums of the same channels
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) {
+    as[nb] += __shfl_xor(as[nb], 16); as[nb] += __shfl_xor(as[nb], 32);
+    if constexpr (WITH_DV) {
+      ax[nb] += __shfl_xor(ax[nb], 16); ax[nb] += __shfl_xor(ax[nb], 32);
+      ay[nb] += __shfl_xor(ay[nb], 16); ay[nb] += __shfl_xor(ay[nb], 32);
+      az[nb] += __shfl_xor(az[nb], 16); az[nb] += __shfl_xor(az[nb], 32);
+    }
+  }
+  // lane (j, q) finishes channel c0 + 16 q + j  (nb = q): 64 consecutive channels per wave store
+  float os = q == 0 ? as[0] : (q == 1 ? as[1] : (q == 2 ? as[2] : as[3]));
+  float ox = q == 0 ? ax[0] : (q == 1 ? ax[1] : (q == 2 ? ax[2] : ax[3]));
+  float oy = q == 0 ? ay[0] : (q == 1 ? ay[1] : (q == 2 ? ay[2] : ay[3]));
+  float oz = q == 0 ? az[0] : (q == 1 ? az[1] : (q == 2 ? az[2] : az[3]));
+  if constexpr (SPLIT > 1) {
+    __shared__ float red[(SPLIT - 1) * 4 * 64];
+    if (wave > 0) {
+      float* rr = red + (wave - 1) * 4 * 64 + lane;
+      rr[0] = os; rr[64] = ox; rr[128] = oy; rr[192] = oz;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 0; w < SPLIT - 1; ++w) {
+      const float* rr = red + w * 4 * 64 + lane;
+      os += rr[0]; ox += rr[64]; oy += rr[128]; oz += rr[192];
+    }
+  }
+  const int c = c0 + 16 * q + j;
+  if (c < F) {
+    const size_t o = (size_t)node * F + c;
+    if (s_res) os += s_res[o];
+    ds[o] = os;
+    if constexpr (WITH_DV) {
+      if (v_res) { const f3 t = ld3(v_res + o * 3); ox += t.x; oy += t.y; oz += t.z; }
+      st3(dv + o * 3, ox, oy, oz);
+    }
+  }
+}
+
 // ------------------------------------------------------------------ backward
 // Upstream gs[i,f], gv[i,f,:] at the receivers.  With gq_1 = gs, gq_2 = gv.unit, gq_0 = gv.v_j:
 //     g_phi[j,kF+f] = sum_{e: src(e)=j} gq_k * w_k          g_v[j,f,:] = sum_e m_0 * gv_i
@@ -470,6 +627,23 @@ int cgv_equi_msg_fwd(const float* phi, const float* v, const float* geom_d, cons
 #define CGV_FWD_PICK(DV)                                                 \
   if (pair) { if (split) CGV_FWD_LAUNCH(DV, 4, true); else CGV_FWD_LAUNCH(DV, 1, true); } \
   else      { if (split) CGV_FWD_LAUNCH(DV, 4, false); else CGV_FWD_LAUNCH(DV, 1, false); }
+  // matrix-core variant: segments long enough to fill 16-edge tiles, rows addressable through a buffer
+  // descriptor.  CGV_FWD_KERNEL=valu|mfma overrides (A/B measurements only).
+  bool use_mfma = split && n_rows_hint > 0 && (uint64_t)n_rows_hint * 12u * (uint64_t)n_feat < 0x7fffffffull;
+  if (const char* dbg = getenv("CGV_FWD_KERNEL")) use_mfma = use_mfma ? dbg[0] != 'v' : (dbg[0] == 'm' && n_rows_hint > 0);
+  if (use_mfma) {
+    const int tiles64 = (n_feat + 63) / 64;
+    const dim3 grid64(8 * npx * tiles64);
+    CGV_DISPATCH_RBF(n_rbf, {
+      if (with_dv)
+        hipLaunchKernelGGL((cgv::equi_msg_fwd_mfma_k<RBF, true, 4>), grid64, dim3(256), 0, st, phi, v, geom_d, rowptr_d, src_d,
+                           Wd, bd, ds, dv, n_feat, n_dst, npx, tiles64, s_res, v_res);
+      else
+        hipLaunchKernelGGL((cgv::equi_msg_fwd_mfma_k<RBF, false, 4>), grid64, dim3(256), 0, st, phi, v, geom_d, rowptr_d,
+                           src_d, Wd, bd, ds, dv, n_feat, n_dst, npx, tiles64, s_res, v_res);
+    });
+    return cgv::check_launch("cgv_equi_msg_fwd");
+  }
   CGV_DISPATCH_RBF(n_rbf, {
     if (with_dv) { CGV_FWD_PICK(true) } else { CGV_FWD_PICK(false) }
   });
