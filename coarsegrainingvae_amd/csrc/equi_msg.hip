@@ -629,8 +629,13 @@ int cgv_equi_msg_fwd(const float* phi, const float* v, const float* geom_d, cons
   else      { if (split) CGV_FWD_LAUNCH(DV, 4, false); else CGV_FWD_LAUNCH(DV, 1, false); }
   // matrix-core variant: segments long enough to fill 16-edge tiles, rows addressable through a buffer
   // descriptor.  CGV_FWD_KERNEL=valu|mfma overrides (A/B measurements only).
-  bool use_mfma = split && n_rows_hint > 0 && (uint64_t)n_rows_hint * 12u * (uint64_t)n_feat < 0x7fffffffull;
-  if (const char* dbg = getenv("CGV_FWD_KERNEL")) use_mfma = use_mfma ? dbg[0] != 'v' : (dbg[0] == 'm' && n_rows_hint > 0);
+  // Measured (chignolin layer): 71 us against 55 us for the packed-VALU kernel -- with 173 VGPRs only two
+  // waves fit a SIMD and the per-lane dword gathers (4 source rows per instruction) load the texture path
+  // more than the VALU kernel's 8-byte row gathers; the kernel is gather-latency bound, not FMA bound.
+  // Kept as an opt-in A/B variant: CGV_FWD_KERNEL=mfma.
+  bool use_mfma = false;
+  if (const char* dbg = getenv("CGV_FWD_KERNEL"))
+    use_mfma = dbg[0] == 'm' && n_rows_hint > 0 && (uint64_t)n_rows_hint * 12u * (uint64_t)n_feat < 0x7fffffffull;
   if (use_mfma) {
     const int tiles64 = (n_feat + 63) / 64;
     const dim3 grid64(8 * npx * tiles64);

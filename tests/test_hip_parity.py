@@ -656,3 +656,27 @@ def test_batched_radius_graph_dataset_path():
         assert torch.equal(ds.props["CG_nbr_list"][k], O.get_neighbor_list(props["CG_nxyz"][k][:, 1:4], 9.5, True))
     ds.generate_neighbor_list(4.0, None, device=DEV)                 # --cg_radius_graph: bead graph from bonds
     assert ds.props["CG_nbr_list"][0].shape[1] == 2
+
+
+@pytest.mark.parametrize("F,R", [(7, 8), (24, 10), (129, 10), (600, 10), (66, 16), (34, 20), (20, 4)])
+@pytest.mark.parametrize("with_gv", [True, False])
+def test_equi_message_matrix_core_forward(F, R, with_gv, monkeypatch):
+    """The MFMA variant of the fused forward, forced on (CGV_FWD_KERNEL is an A/B switch of the launcher)."""
+    monkeypatch.setenv("CGV_FWD_KERNEL", "mfma")
+    gen = torch.Generator().manual_seed(F * 3 + R)
+    n = 40
+    xyz = torch.rand(n, 3, generator=gen) * 4.0
+    nbrs, _ = O.make_directed(O.get_neighbor_list(xyz, 3.2, True))
+    nbrs = torch.cat([nbrs, torch.tensor([[5, 2], [5, 3], [5, 2]])])          # asymmetric extras, a duplicate
+    _block_vs_oracle(F, R, n, nbrs, xyz, with_gv, seed=F + R)
+
+
+def test_equi_message_high_degree_split_path():
+    """Dense graph (degree 79 > 48): the launcher picks the split-segment kernels (4 waves per receiver)."""
+    gen = torch.Generator().manual_seed(8)
+    n = 80
+    xyz = torch.rand(n, 3, generator=gen) * 3.0
+    nbrs, _ = O.make_directed(O.get_neighbor_list(xyz, 9.0, True))
+    assert nbrs.shape[0] >= 48 * n
+    _block_vs_oracle(48, 10, n, nbrs, xyz, True, seed=1)
+    _block_vs_oracle(48, 10, n, nbrs, xyz, False, seed=2)
