@@ -55,6 +55,34 @@ __device__ __forceinline__ void load_filter_rows2(f2 (&W)[R + 1], const float* _
   W[R] = f2{bd[c], bd[c1]};
 }
 
+// Filter rows of a block's 128-channel tile, staged through LDS.  Reading them straight from global
+// memory in register layout (lane c takes Wd[c][n]: lanes 2R floats apart) costs ~40 cache lines per
+// load instruction and 66 instructions per wave -- 2640 line requests per wave, which at 6720 waves was
+// HALF of the kernel's time (the texture path was saturated by the prologue, not by the edge loop).
+// Staged: the tile's rows are contiguous (128 R floats per slice) -> coalesced float4 loads once per
+// block, then conflict-tolerant LDS reads.  Needs F and R even (16-byte aligned slices).
+template <int R, int NSL>
+__device__ __forceinline__ void stage_filter_tile(float* __restrict__ wt /*[NSL][128*R]*/, const float* __restrict__ Wd,
+                                                  const int (&slice)[NSL], int F, int c0) {
+  const int cw = min(128, F - c0);                 // valid channels of this tile
+  const int n4 = cw * R / 4;                       // float4 per slice
+#pragma unroll
+  for (int k = 0; k < NSL; ++k) {
+    const float4* g = reinterpret_cast<const float4*>(Wd + (size_t)(slice[k] * F + c0) * R);
+    float4* d = reinterpret_cast<float4*>(wt + k * 128 * R);
+    for (int t = threadIdx.x; t < n4; t += blockDim.x) d[t] = g[t];
+  }
+  __syncthreads();
+}
+template <int R>
+__device__ __forceinline__ void read_filter_rows2(f2 (&W)[R + 1], const float* __restrict__ wt_slice,
+                                                  const float* __restrict__ bd, int cl /*even, tile-local*/,
+                                                  int c_global) {
+#pragma unroll
+  for (int n = 0; n < R; ++n) W[n] = f2{wt_slice[cl * R + n], wt_slice[(cl + 1) * R + n]};
+  W[R] = ld2(bd + c_global);
+}
+
 // Lane -> channel pair.  F even: lanes own (c, c+1) with 8-byte vector accesses.  F odd: the last
 // lane's second channel is a duplicate of its first (PAIR = false -> scalar memory accesses).
 struct ChanPair {
@@ -86,6 +114,16 @@ __device__ __forceinline__ rsrc_t make_rsrc(const float* p) {
 }
 __device__ __forceinline__ f2 ld2_buf(rsrc_t r, unsigned voff_bytes, unsigned soff_bytes) {
   return __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(r, voff_bytes, soff_bytes, 0));
+}
+
+// xyz triples of two neighbouring channels = 24 contiguous bytes per lane.  As three b64 loads every
+// instruction walks the wave's whole 1536-byte span (12 lines) for a third of its bytes; two b96 loads
+// walk it twice instead of three times (tools/probes/k2_probe.cpp: 59.5 -> 47.4 us for the whole kernel).
+typedef float f3v __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ void ldvec_buf(rsrc_t r, unsigned voff_bytes, unsigned soff_bytes, f2& A, f2& B, f2& C) {
+  const f3v x = __builtin_bit_cast(f3v, __builtin_amdgcn_raw_buffer_load_b96(r, voff_bytes, soff_bytes, 0));
+  const f3v y = __builtin_bit_cast(f3v, __builtin_amdgcn_raw_buffer_load_b96(r, voff_bytes + 12u, soff_bytes, 0));
+  A = f2{x.x, x.y}; B = f2{x.z, y.x}; C = f2{y.y, y.z};
 }
 
 template <bool PAIR>
@@ -144,10 +182,27 @@ __global__ __launch_bounds__(64 * SPLIT) void equi_msg_fwd_k(const float* __rest
   const ChanPair cp = chan_pair(tile, lane, F);
 
   f2 W0[R + 1], W1[R + 1], W2[R + 1];
-  load_filter_rows2<R>(W1, Wd, bd, F + cp.c, F + cp.c1);
-  if constexpr (WITH_DV) {
-    load_filter_rows2<R>(W0, Wd, bd, cp.c, cp.c1);
-    load_filter_rows2<R>(W2, Wd, bd, 2 * F + cp.c, 2 * F + cp.c1);
+  if constexpr (PAIR) {
+    constexpr int NSL = WITH_DV ? 3 : 1;
+    __shared__ __attribute__((aligned(16))) float wt[NSL * 128 * R];
+    int sl[NSL];
+#pragma unroll
+    for (int k = 0; k < NSL; ++k) sl[k] = WITH_DV ? k : 1;
+    stage_filter_tile<R, NSL>(wt, Wd, sl, F, tile * 128);
+    const int cl = cp.c - tile * 128;              // even; clamped lanes stay inside the staged tile
+    if constexpr (WITH_DV) {
+      read_filter_rows2<R>(W0, wt, bd, cl, cp.c);
+      read_filter_rows2<R>(W1, wt + 128 * R, bd, cl, F + cp.c);
+      read_filter_rows2<R>(W2, wt + 2 * 128 * R, bd, cl, 2 * F + cp.c);
+    } else {
+      read_filter_rows2<R>(W1, wt, bd, cl, F + cp.c);
+    }
+  } else {
+    load_filter_rows2<R>(W1, Wd, bd, F + cp.c, F + cp.c1);
+    if constexpr (WITH_DV) {
+      load_filter_rows2<R>(W0, Wd, bd, cp.c, cp.c1);
+      load_filter_rows2<R>(W2, Wd, bd, 2 * F + cp.c, 2 * F + cp.c1);
+    }
   }
 
   f2 acc_s = splat(0.f), accA = splat(0.f), accB = splat(0.f), accC = splat(0.f);
@@ -160,26 +215,63 @@ __global__ __launch_bounds__(64 * SPLIT) void equi_msg_fwd_k(const float* __rest
   const unsigned row_bytes = 12u * (unsigned)F;              // bytes per node row of phi [3F] AND of v [F,3]
   const unsigned oc = 4u * (unsigned)cp.c, oF = 4u * (unsigned)F, ov = 12u * (unsigned)cp.c;
   const rsrc_t r_phi = make_rsrc(phi), r_v = make_rsrc(WITH_DV ? v : phi);
+  if constexpr (PAIR) {
+    // Software-pipelined walk (the probe in tools/gather_probe.py showed the time does not depend on WHERE
+    // the gathers hit -- the waves were serialising scalar-load latency, gather latency and FMAs per edge):
+    // record e+1 and source index e+2 are requested, and the gathers of edge e+1 issued, before the FMAs of
+    // edge e run, so both latencies hide behind ~200 cycles of packed math of this very wave.
+    constexpr int NG = U + 6;                        // record floats actually used
+    if (beg < end) {
+      float gc[NG], gn[NG];
+#pragma unroll
+      for (int t = 0; t < NG; ++t) gc[t] = geom[(size_t)beg * GS + t];
+      unsigned so_c = (unsigned)src[beg] * row_bytes;
+      unsigned so_n = (unsigned)src[min(beg + 1, end - 1)] * row_bytes;
+      f2 c_p0 = splat(0.f), c_p1, c_p2 = splat(0.f), c_A = splat(0.f), c_B = splat(0.f), c_C = splat(0.f);
+      c_p1 = ld2_buf(r_phi, oc + oF, so_c);
+      if constexpr (WITH_DV) {
+        c_p0 = ld2_buf(r_phi, oc, so_c); c_p2 = ld2_buf(r_phi, oc + 2u * oF, so_c);
+        ldvec_buf(r_v, ov, so_c, c_A, c_B, c_C);
+      }
 #pragma unroll 2
+      for (int e = beg; e < end; ++e) {
+        const int e1 = min(e + 1, end - 1), e2 = min(e + 2, end - 1);
+#pragma unroll
+        for (int t = 0; t < NG; ++t) gn[t] = geom[(size_t)e1 * GS + t];          // scalar prefetch: record e+1
+        const unsigned so_nn = (unsigned)src[e2] * row_bytes;                     // and source index e+2
+        f2 n_p0 = splat(0.f), n_p1, n_p2 = splat(0.f), n_A = splat(0.f), n_B = splat(0.f), n_C = splat(0.f);
+        n_p1 = ld2_buf(r_phi, oc + oF, so_n);                                     // gathers of edge e+1
+        if constexpr (WITH_DV) {
+          n_p0 = ld2_buf(r_phi, oc, so_n); n_p2 = ld2_buf(r_phi, oc + 2u * oF, so_n);
+          ldvec_buf(r_v, ov, so_n, n_A, n_B, n_C);
+        }
+        acc_s = fma2(c_p1, filter2<R>(W1, gc), acc_s);
+        if constexpr (WITH_DV) {
+          const f2 m0 = c_p0 * filter2<R>(W0, gc);
+          const f2 m2 = c_p2 * filter2<R>(W2, gc);
+          const f2 u01 = f2{gc[U], gc[U + 1]}, u20 = f2{gc[U + 2], gc[U + 3]}, u12 = f2{gc[U + 4], gc[U + 5]};
+          accA = fma2(lo2(m2), u01, fma2(lo2(m0), c_A, accA));
+          accB = fma2(m2, u20, fma2(m0, c_B, accB));
+          accC = fma2(hi2(m2), u12, fma2(hi2(m0), c_C, accC));
+        }
+#pragma unroll
+        for (int t = 0; t < NG; ++t) gc[t] = gn[t];
+        so_n = so_nn;
+        c_p0 = n_p0; c_p1 = n_p1; c_p2 = n_p2; c_A = n_A; c_B = n_B; c_C = n_C;
+      }
+    }
+  } else {
   for (int e = beg; e < end; ++e) {
     const float* __restrict__ g = geom + (size_t)e * GS;   // wave-uniform -> s_load
     const int j = src[e];
-    const unsigned soff = (unsigned)j * row_bytes;            // uniform: SGPR
     const float* __restrict__ prow = phi + (size_t)j * 3 * F;
-    f2 p1;
-    if constexpr (PAIR) p1 = ld2_buf(r_phi, oc + oF, soff); else p1 = ldpair<PAIR>(prow + F, cp);
+    const f2 p1 = ldpair<PAIR>(prow + F, cp);
     acc_s = fma2(p1, filter2<R>(W1, g), acc_s);
     if constexpr (WITH_DV) {
-      f2 p0, p2, A, B, C;
-      if constexpr (PAIR) {
-        p0 = ld2_buf(r_phi, oc, soff);
-        p2 = ld2_buf(r_phi, oc + 2u * oF, soff);
-        A = ld2_buf(r_v, ov, soff); B = ld2_buf(r_v, ov + 8u, soff); C = ld2_buf(r_v, ov + 16u, soff);
-      } else {
-        p0 = ldpair<PAIR>(prow, cp);
-        p2 = ldpair<PAIR>(prow + 2 * F, cp);
-        ldvec<PAIR>(v + (size_t)j * F * 3, cp, A, B, C);
-      }
+      f2 A, B, C;
+      const f2 p0 = ldpair<PAIR>(prow, cp);
+      const f2 p2 = ldpair<PAIR>(prow + 2 * F, cp);
+      ldvec<PAIR>(v + (size_t)j * F * 3, cp, A, B, C);
       const f2 m0 = p0 * filter2<R>(W0, g);
       const f2 m2 = p2 * filter2<R>(W2, g);
       const f2 u01 = f2{g[U], g[U + 1]}, u20 = f2{g[U + 2], g[U + 3]}, u12 = f2{g[U + 4], g[U + 5]};
@@ -187,6 +279,7 @@ __global__ __launch_bounds__(64 * SPLIT) void equi_msg_fwd_k(const float* __rest
       accB = fma2(m2, u20, fma2(m0, B, accB));
       accC = fma2(hi2(m2), u12, fma2(hi2(m0), C, accC));
     }
+  }
   }
   if constexpr (SPLIT > 1) {
     __shared__ float red[(SPLIT - 1) * 8 * 64];
@@ -408,7 +501,16 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void equi_msg_bwd_k(
   const ChanPair cp = chan_pair(tile, lane, F);
 
   f2 W[K][R + 1], G[K][R + 1];
-  if constexpr (HAS_GV) {
+  if constexpr (PAIR) {
+    __shared__ __attribute__((aligned(16))) float wt[K * 128 * R];
+    int sl[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) sl[k] = HAS_GV ? k : 1;
+    stage_filter_tile<R, K>(wt, Wd, sl, F, tile * 128);
+    const int cl = cp.c - tile * 128;
+#pragma unroll
+    for (int k = 0; k < K; ++k) read_filter_rows2<R>(W[k], wt + k * 128 * R, bd, cl, sl[k] * F + cp.c);
+  } else if constexpr (HAS_GV) {
     load_filter_rows2<R>(W[0], Wd, bd, cp.c, cp.c1);
     load_filter_rows2<R>(W[1], Wd, bd, F + cp.c, F + cp.c1);
     load_filter_rows2<R>(W[2], Wd, bd, 2 * F + cp.c, 2 * F + cp.c1);
@@ -454,7 +556,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void equi_msg_bwd_k(
         f2 gA, gB, gC;
         if constexpr (PAIR) {
           const unsigned ov = 12u * (unsigned)cp.c, so = (unsigned)i * 12u * (unsigned)F;
-          gA = ld2_buf(r_gv, ov, so); gB = ld2_buf(r_gv, ov + 8u, so); gC = ld2_buf(r_gv, ov + 16u, so);
+          ldvec_buf(r_gv, ov, so, gA, gB, gC);
         } else {
           ldvec<PAIR>(gv + (size_t)i * F * 3, cp, gA, gB, gC);
         }
@@ -619,8 +721,10 @@ int cgv_equi_msg_fwd(const float* phi, const float* v, const float* geom_d, cons
   if (const char* dbg = getenv("CGV_DEBUG_FWD_SPLIT")) split = dbg[0] == '1';   // experiments only
   // 8-byte vector accesses need an even channel count and 8-byte aligned bases; the buffer-descriptor
   // gathers need every row within 2 GiB of the base (n_rows_hint = rows of phi / v, 0 = unknown)
-  const bool pair = (n_feat % 2 == 0) && n_rows_hint > 0 && (uint64_t)n_rows_hint * 12u * (uint64_t)n_feat < 0x7fffffffull &&
-                    ((((uintptr_t)phi | (uintptr_t)v | (uintptr_t)ds | (uintptr_t)dv | (uintptr_t)s_res | (uintptr_t)v_res) & 7) == 0);
+  const bool pair = (n_feat % 2 == 0) && (n_rbf % 2 == 0) && n_rows_hint > 0 &&
+                    (uint64_t)n_rows_hint * 12u * (uint64_t)n_feat < 0x7fffffffull &&
+                    ((((uintptr_t)phi | (uintptr_t)v | (uintptr_t)ds | (uintptr_t)dv | (uintptr_t)s_res | (uintptr_t)v_res) & 7) == 0) &&
+                    ((((uintptr_t)Wd) & 15) == 0) && ((((uintptr_t)bd) & 7) == 0);
 #define CGV_FWD_LAUNCH(DV, SP, PR)                                                                                   \
   hipLaunchKernelGGL((cgv::equi_msg_fwd_k<RBF, DV, SP, PR>), grid, dim3(64 * SP), 0, st, phi, v, geom_d, rowptr_d, src_d, \
                      Wd, bd, ds, dv, n_feat, n_dst, npx, tiles, s_res, v_res)
@@ -678,9 +782,11 @@ int cgv_equi_msg_bwd(const float* phi, const float* v, const float* geom_s, cons
   const int tiles = (n_feat + 127) / 128;
   float* part = reinterpret_cast<float*>(workspace);
   const dim3 grid(8 * sh.cpx * tiles), block(64 * cgv::BWD_WAVES);
-  const bool pair = (n_feat % 2 == 0) && n_rows_hint > 0 && (uint64_t)n_rows_hint * 12u * (uint64_t)n_feat < 0x7fffffffull &&
+  const bool pair = (n_feat % 2 == 0) && (n_rbf % 2 == 0) && n_rows_hint > 0 &&
+                    (uint64_t)n_rows_hint * 12u * (uint64_t)n_feat < 0x7fffffffull &&
                     ((((uintptr_t)phi | (uintptr_t)v | (uintptr_t)gs | (uintptr_t)gv | (uintptr_t)g_phi |
-                       (uintptr_t)g_v | (uintptr_t)part) & 7) == 0);
+                       (uintptr_t)g_v | (uintptr_t)part) & 7) == 0) &&
+                    ((((uintptr_t)Wd) & 15) == 0) && ((((uintptr_t)bd) & 7) == 0);
 #define CGV_BWD_LAUNCH(GV, SP, PR)                                                                                 \
   hipLaunchKernelGGL((cgv::equi_msg_bwd_k<RBF, GV, SP, PR>), grid, block, 0, st, phi, v, geom_s, rowptr_s, dst_s, Wd, \
                      bd, gs, gv, g_phi, g_v, part, n_feat, n_src, sh.npc, sh.cpx, tiles)
