@@ -108,98 +108,151 @@ __global__ __launch_bounds__(64 * WAVES) void skinny_fwd_k(const float* __restri
 }
 
 // ------------------------------------------------------------------ bwd_input
-// gx[m, k] = sum_n g[m, n] W[n, k],  g = gy * act'(z).  Block = 16 output columns k0..k0+15, WAVES
-// waves splitting N.  Lane (i = l&15, q = l>>4): A[i][kk = q] = W[n + q, k0 + i] (4 rows x 64
-// contiguous bytes per wave instruction), B[kk = q][j = l&15] = g[m = 16 mb + (l&15), n + q].
-// The B operand is staged per wave through LDS in 64-column chunks: g is read from global memory
-// row by row (one fully coalesced 256-byte load per row -- reading it in MFMA layout instead costs
-// 16 cache lines per instruction and made the texture path the bottleneck: 17 us -> see DESIGN.md),
-// the activation derivative is applied once, and the MFMA-layout reads come from LDS.
-// D: lane holds gx[m = 16 mb + (l&15)][k0 + 4 q + r] -> one 16-byte store.  Single launch, the
-// N-split meets in LDS in a fixed order (deterministic).
-constexpr int BI_CHUNK = 64;      // columns of g per staging round (16 MFMA steps)
-constexpr int BI_LD = 68;         // LDS row stride in floats (2-way bank conflicts at worst)
+// gx[m, k] = sum_n g[m, n] W[n, k],  g = gy * act'(z).  The weight is read in ROW-contiguous
+// pieces: block (kt, ns) owns 64 columns k0..k0+63 (256 contiguous bytes per weight row) and the
+// row slice [ns*rpb, ns*rpb + rpb); wave w of 4 takes rows 4w..4w+3 of every group of 16.
+// Lane (j = l&15, q = l>>4) loads the float4 W[n + q, k0 + 4j .. +3]; component c is the B operand
+// B[kk = q][col j] of MFMA c, A[i = j][kk = q] = g[m = 16 mb + j][n + q] comes from an LDS stage
+// of g (coalesced row reads, activation derivative applied once).  D_c: lane holds
+// gx[m = 16 mb + 4 q + r][k0 + 4 j + c] -> the 4 MFMAs give one 16-byte store per r.
+// The first version gave each block a 16-column strip over ALL rows: 38 blocks, each touching
+// every page of the weight 64 bytes at a time -- 11-22 us per call (profiles/r01l), 48 calls a
+// step.  Here ~300 blocks each read a compact [rpb x 256 B] piece with every load in flight at
+// once; the row slices meet in a second, tiny launch that sums the ns partials in index order
+// (deterministic).  A single-launch "last block reduces" variant behind an agent-scope acq_rel counter
+// was measured at 30-85 us: every __threadfence writes back / invalidates the XCD's whole L2.
+constexpr int BI_COLS = 64;       // weight columns per block
+constexpr int BI_ROUND = 64;      // weight rows per staging round (4 waves x 4 steps x 4 rows)
+constexpr int BI_LD = 68;         // LDS row stride of the g stage
 
-template <int MB, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void skinny_bwd_input_k(const float* __restrict__ gy, const float* __restrict__ z,
-                                                                 const float* __restrict__ W, float* __restrict__ gx,
-                                                                 int M, int N, int K, int act) {
-  __shared__ float red[(WAVES - 1) * MB * 4 * 64];
-  __shared__ float stage[WAVES][MB * 16 * BI_LD];
+template <int MB>
+__global__ __launch_bounds__(256) void skinny_bwd_input_k(const float* __restrict__ gy, const float* __restrict__ z,
+                                                          const float* __restrict__ W, float* __restrict__ gx,
+                                                          float* __restrict__ part, int M, int N, int K, int act, int KT,
+                                                          int NS, int rpb) {
+  __shared__ __attribute__((aligned(16))) float sm[3 * MB * 16 * 64];      // g stage, then the wave reduction
+  const int kt = blockIdx.x % KT, ns = blockIdx.x / KT;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int i = lane & 15, q = lane >> 4;
-  const int k0 = blockIdx.x * 16;
-  const int kcol = k0 + i;
-  const bool kok = kcol < K;
-  // this wave's contiguous slice of N, in whole chunks
-  const int chunks = (N + BI_CHUNK - 1) / BI_CHUNK;
-  const int per = (chunks + WAVES - 1) / WAVES;
-  const int c_beg = wave * per, c_end = min(c_beg + per, chunks);
-  float* sg = stage[wave];
-  f32x4 acc[MB][2];
+  const int j = lane & 15, q = lane >> 4;
+  const int kcol = kt * BI_COLS + 4 * j;
+  const bool kok = kcol < K;                                               // K % 4 == 0
+  const int n_beg = ns * rpb, n_end = min(n_beg + rpb, N);
+  f32x4 acc[MB][4];
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb) acc[mb][0] = acc[mb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int c = c_beg; c < c_end; ++c) {
-    const int nb = c * BI_CHUNK;
-    // stage g[:, nb .. nb+63] (rows >= M are zero)
-    const int n_l = nb + lane;
-    const bool nl_ok = n_l < N;
-    // (loads of 16 rows are issued together, then written: a load -> LDS-store loop would serialise
-    //  one memory latency per row -- measured 25-38 us per call before this was batched)
+  for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-      float g[16], zz[16];
+    for (int c = 0; c < 4; ++c) acc[mb][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int nb = n_beg; nb < n_end; nb += BI_ROUND) {
+    float4 wv[4];                                                          // weights first: the long latency
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mb * 16 + r;
-        const bool ok = m < M && nl_ok;
-        g[r] = ok ? gy[(size_t)m * N + n_l] : 0.f;
-        zz[r] = (ok && act) ? z[(size_t)m * N + n_l] : 0.f;
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        sg[(mb * 16 + r) * BI_LD + lane] = act ? g[r] * act_bwd(zz[r], act) : g[r];
+    for (int s = 0; s < 4; ++s) {
+      const int row = nb + 16 * s + 4 * wave + q;
+      const bool ok = row < n_end && kok;
+      wv[s] = ldg4_or_zero(W + (size_t)(ok ? row : 0) * K + (ok ? kcol : 0), ok);
     }
-    // weight loads of the 16 steps of this chunk: independent, all in flight together
-    float a[16];
+    float g[MB * 4], zz[MB * 4];
 #pragma unroll
-    for (int h = 0; h < 16; ++h) {
-      const int n = nb + 4 * h + q;
-      a[h] = (n < N && kok) ? W[(size_t)n * K + kcol] : 0.f;
+    for (int t = 0; t < MB * 4; ++t) {                                     // g[:, nb .. nb+63], row m = 4t + wave
+      const int m = 4 * t + wave, n = nb + lane;
+      const bool ok = m < M && n < n_end;
+      g[t] = ok ? gy[(size_t)m * N + n] : 0.f;
+      zz[t] = (ok && act) ? z[(size_t)m * N + n] : 0.f;
     }
+    if (nb != n_beg) __syncthreads();                                      // readers of the previous round
 #pragma unroll
-    for (int h = 0; h < 16; ++h)
+    for (int t = 0; t < MB * 4; ++t) sm[(4 * t + wave) * BI_LD + lane] = act ? g[t] * act_bwd(zz[t], act) : g[t];
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
-        const float b = sg[(mb * 16 + i) * BI_LD + 4 * h + q];
-        acc[mb][h & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[h], b, acc[mb][h & 1], 0, 0, 0);
+        const float a = sm[(mb * 16 + j) * BI_LD + 16 * s + 4 * wave + q];
+        acc[mb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wv[s].x, acc[mb][0], 0, 0, 0);
+        acc[mb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wv[s].y, acc[mb][1], 0, 0, 0);
+        acc[mb][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wv[s].z, acc[mb][2], 0, 0, 0);
+        acc[mb][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wv[s].w, acc[mb][3], 0, 0, 0);
       }
   }
-  f32x4 tot[MB];
+  __syncthreads();
+  if (wave > 0) {
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb) tot[mb] = acc[mb][0] + acc[mb][1];
-  if (WAVES > 1) {
-    if (wave > 0) {
+    for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
+      for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[(((wave - 1) * MB + mb) * 4 + r) * 64 + lane] = tot[mb][r];
+        for (int r = 0; r < 4; ++r) sm[((((wave - 1) * MB + mb) * 4 + r) * 4 + c) * 64 + lane] = acc[mb][c][r];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  float4 tot[MB][4];                                                       // [mb][r] = gx[16 mb + 4 q + r][kcol .. +3]
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float t[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        t[c] = acc[mb][c][r];
+#pragma unroll
+        for (int w = 0; w < 3; ++w) t[c] += sm[(((w * MB + mb) * 4 + r) * 4 + c) * 64 + lane];
+      }
+      tot[mb][r] = make_float4(t[0], t[1], t[2], t[3]);
     }
-    __syncthreads();
-    if (wave != 0) return;
-  }
-  const int kk = k0 + 4 * q;
-  if (kk >= K) return;                             // K % 4 == 0
+  if (NS > 1) {                     // row slices meet in skinny_bwd_input_reduce_k (next launch on the stream)
+    float* mine = part + ((size_t)ns * M) * K;
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb) {
-    const int m = mb * 16 + i;
-    f32x4 t = tot[mb];
-    for (int w = 0; w < WAVES - 1; ++w)
+    for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) t[r] += red[((w * MB + mb) * 4 + r) * 64 + lane];
-    if (m < M) *reinterpret_cast<float4*>(gx + (size_t)m * K + kk) = make_float4(t[0], t[1], t[2], t[3]);
+      for (int r = 0; r < 4; ++r) {
+        const int m = mb * 16 + 4 * q + r;
+        if (m < M && kok) *reinterpret_cast<float4*>(mine + (size_t)m * K + kcol) = tot[mb][r];
+      }
+    return;
   }
+  if (!kok) return;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = mb * 16 + 4 * q + r;
+      if (m < M) *reinterpret_cast<float4*>(gx + (size_t)m * K + kcol) = tot[mb][r];
+    }
+}
+
+// gx[i] = sum_p part[p][i] (i over M*K/4 float4s), p ascending: deterministic.  4 lanes share one output
+// float4 and take every 4th slice, then combine by two xor-shuffles.
+__global__ __launch_bounds__(256) void skinny_bwd_input_reduce_k(const float* __restrict__ part, float* __restrict__ gx,
+                                                                 int n4, int NS) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int i = t >> 2, sub = t & 3;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4) {
+    const float4* p4 = reinterpret_cast<const float4*>(part) + i;
+#pragma unroll 4
+    for (int p = sub; p < NS; p += 4) {
+      const float4 v = p4[(size_t)p * n4];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+#pragma unroll
+  for (int d = 1; d <= 2; d <<= 1) {
+    acc.x += __shfl_xor(acc.x, d); acc.y += __shfl_xor(acc.y, d);
+    acc.z += __shfl_xor(acc.z, d); acc.w += __shfl_xor(acc.w, d);
+  }
+  if (i < n4 && sub == 0) reinterpret_cast<float4*>(gx)[i] = acc;
+}
+
+// row slicing of one bwd_input problem: ~320 blocks when a workspace is available
+static inline void bwd_input_plan(int N, int K, bool split, int* KT, int* NS, int* rpb) {
+  *KT = (K + BI_COLS - 1) / BI_COLS;
+  if (!split) { *NS = 1; *rpb = N; return; }
+  const int want = (320 + *KT - 1) / *KT;
+  int r = (N + want - 1) / want;
+  r = (r + 15) / 16 * 16;
+  if (r < 32) r = 32;
+  *rpb = r;
+  *NS = (N + r - 1) / r;
 }
 
 // ------------------------------------------------------------------ grouped weight gradient
@@ -305,10 +358,14 @@ static void launch_fwd(dim3 grid, int waves, hipStream_t st, const float* x, con
   else hipLaunchKernelGGL((skinny_fwd_k<MB, 4>), grid, dim3(256), 0, st, x, W, bias, y, z, M, N, K, act);
 }
 template <int MB>
-static void launch_bwd_input(dim3 grid, hipStream_t st, const float* gy, const float* z, const float* W, float* gx, int M,
-                             int N, int K, int act) {
-  constexpr int WAVES = MB == 1 ? 16 : (MB <= 3 ? 8 : 4);      // LDS: the per-wave staging area scales with MB
-  hipLaunchKernelGGL((skinny_bwd_input_k<MB, WAVES>), grid, dim3(64 * WAVES), 0, st, gy, z, W, gx, M, N, K, act);
+static void launch_bwd_input(hipStream_t st, const float* gy, const float* z, const float* W, float* gx, float* part,
+                             int M, int N, int K, int act, int KT, int NS, int rpb) {
+  hipLaunchKernelGGL((skinny_bwd_input_k<MB>), dim3(KT * NS), dim3(256), 0, st, gy, z, W, gx, part, M, N, K, act, KT, NS,
+                     rpb);
+  if (NS > 1) {
+    const int n4 = M * K / 4;
+    hipLaunchKernelGGL(skinny_bwd_input_reduce_k, dim3((4 * n4 + 255) / 256), dim3(256), 0, st, part, gx, n4, NS);
+  }
 }
 
 }  // namespace cgv
@@ -341,19 +398,29 @@ int cgv_skinny_linear_fwd(const float* x, const float* W, const float* bias, flo
   return cgv::check_launch("cgv_skinny_linear_fwd");
 }
 
+size_t cgv_skinny_bwd_input_workspace_bytes(int M, int N, int K) {
+  if (!cgv_skinny_supported(M, N, K)) return 0;
+  int KT, NS, rpb;
+  cgv::bwd_input_plan(N, K, true, &KT, &NS, &rpb);
+  return NS > 1 ? sizeof(float) * (size_t)NS * M * K : 0;
+}
+
 int cgv_skinny_linear_bwd_input(const float* gy, const float* z, const float* W, float* gx, int M, int N, int K, int act,
-                                void* stream) {
+                                void* ws, size_t ws_bytes, void* stream) {
   CGV_REQUIRE(gy && W && gx, "null pointer");
   CGV_REQUIRE(act == 0 || (act == 1 && z), "act = 1 needs the saved pre-activation z");
   CGV_REQUIRE(cgv_skinny_supported(M, N, K), "unsupported shape (need M <= 64, N % 4 == 0, K % 4 == 0)");
-  CGV_REQUIRE((((uintptr_t)gx) & 15) == 0, "gx must be 16-byte aligned");
+  CGV_REQUIRE(((((uintptr_t)gx) | ((uintptr_t)W) | ((uintptr_t)ws)) & 15) == 0, "gx, W, ws must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid((K + 15) / 16);
+  int KT, NS, rpb;
+  cgv::bwd_input_plan(N, K, ws != nullptr, &KT, &NS, &rpb);
+  if (NS > 1) CGV_REQUIRE(ws_bytes >= cgv_skinny_bwd_input_workspace_bytes(M, N, K), "workspace too small");
+  float* part = reinterpret_cast<float*>(ws);
   switch ((M + 15) / 16) {
-    case 1: cgv::launch_bwd_input<1>(grid, st, gy, z, W, gx, M, N, K, act); break;
-    case 2: cgv::launch_bwd_input<2>(grid, st, gy, z, W, gx, M, N, K, act); break;
-    case 3: cgv::launch_bwd_input<3>(grid, st, gy, z, W, gx, M, N, K, act); break;
-    default: cgv::launch_bwd_input<4>(grid, st, gy, z, W, gx, M, N, K, act); break;
+    case 1: cgv::launch_bwd_input<1>(st, gy, z, W, gx, part, M, N, K, act, KT, NS, rpb); break;
+    case 2: cgv::launch_bwd_input<2>(st, gy, z, W, gx, part, M, N, K, act, KT, NS, rpb); break;
+    case 3: cgv::launch_bwd_input<3>(st, gy, z, W, gx, part, M, N, K, act, KT, NS, rpb); break;
+    default: cgv::launch_bwd_input<4>(st, gy, z, W, gx, part, M, N, K, act, KT, NS, rpb); break;
   }
   return cgv::check_launch("cgv_skinny_linear_bwd_input");
 }

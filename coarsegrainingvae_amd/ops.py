@@ -13,7 +13,7 @@ import torch
 
 from . import _lib
 from .graph import EdgeGeometry, EdgePlan
-from .primitives import linear as _linear
+from .primitives import linear as _linear, skinny_bwd_input
 
 _F32 = torch.float32
 
@@ -341,13 +341,12 @@ class _UpdateBlockFused(torch.autograd.Function):
         _lib.call("cgv_update_gate_bwd", U_ptr, Vv_ptr, _lib.ptr(a), _lib.ptr(g_ds), _lib.ptr(g_dv), gU_ptr, gVv_ptr,
                   _lib.ptr(ga), n, F, 2 * F, st)
         g_a0, g_stack, g_s, g_vt, g_v = new(n, F), new(n, 2 * F), new(n, F), new(3 * n, F), new(n, F, 3)
-        _lib.call("cgv_skinny_linear_bwd_input", _lib.ptr(ga), None, _lib.ptr(W1d), _lib.ptr(g_a0), n, 3 * F, F, 0, st)
-        _lib.call("cgv_skinny_linear_bwd_input", _lib.ptr(g_a0), _lib.ptr(z0), _lib.ptr(W0d), _lib.ptr(g_stack), n, F,
-                  2 * F, 1, st)
+        skinny_bwd_input(ga, None, W1d, g_a0, n, 3 * F, F, 0, st)
+        skinny_bwd_input(g_a0, z0, W0d, g_stack, n, F, 2 * F, 1, st)
         _lib.call("cgv_update_norm_stack_bwd", _lib.ptr(g_stack), Vv_ptr, _lib.ptr(stack),
                   _lib.ptr(g_ds) if ctx.residual else None, _lib.ptr(g_s), gVv_ptr, n, F, 2 * F, 1, st)
         Wuv = torch.as_strided(u_w.detach(), (2 * F, F), (F, 1))
-        _lib.call("cgv_skinny_linear_bwd_input", _lib.ptr(gUV), None, _lib.ptr(Wuv), _lib.ptr(g_vt), 3 * n, 2 * F, F, 0, st)
+        skinny_bwd_input(gUV, None, Wuv, g_vt, 3 * n, 2 * F, F, 0, st)
         _lib.call("cgv_update_vec_from_rows", _lib.ptr(g_vt), _lib.ptr(g_dv) if ctx.residual else None, _lib.ptr(g_v),
                   n, F, st)
         # weight gradients -> grouped launch (direct targets; the [u_mat; v_mat] pair is one problem)

@@ -197,8 +197,7 @@ class _LinearFn(torch.autograd.Function):
         gx = None
         if need_x:
             gx = torch.empty(M, K, dtype=torch.float32, device=gy.device)
-            _lib.call("cgv_skinny_linear_bwd_input", _lib.ptr(gy2), _lib.ptr(z), _lib.ptr(weight), _lib.ptr(gx), M, N, K,
-                      act, _lib.stream_ptr())
+            skinny_bwd_input(gy2, z, weight, gx, M, N, K, act)
             gx = gx.reshape(gy.shape[:-1] + (K,))
         gw = gb = None
         if need_w:
@@ -210,6 +209,15 @@ class _LinearFn(torch.autograd.Function):
             if not (wgrad_queue.active and gw is None and gb is None):
                 wgrad_queue.flush()                          # immediate mode (no trainer / not arena-managed)
         return gx, gw, gb, None
+
+
+def skinny_bwd_input(gy2, z, weight, gx, M, N, K, act, stream=None):
+    """gx[M,K] = (gy2 * act'(z)) @ weight through cgv_skinny_linear_bwd_input with its row-split workspace."""
+    lib = _lib.load()
+    nbytes = lib.cgv_skinny_bwd_input_workspace_bytes(M, N, K)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=gx.device)
+    _lib.call("cgv_skinny_linear_bwd_input", _lib.ptr(gy2), _lib.ptr(z) if z is not None else None, _lib.ptr(weight),
+              _lib.ptr(gx), M, N, K, act, ws.data_ptr(), nbytes, stream if stream is not None else _lib.stream_ptr())
 
 
 def _is_direct(param):

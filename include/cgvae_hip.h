@@ -210,7 +210,11 @@ int cgv_update_gate_bwd(const float* U, const float* Vv, const float* a, const f
  * cgv_skinny_max_rows() rows, weight W[N,K] row-major as torch stores it, N % 4 == 0,
  * K % 4 == 0, 16-byte aligned operands.  act: 0 = identity, 1 = Swish.
  *   fwd        z = x W^T + bias ; y = act(z)      (bias may be NULL; z [M,N] is written when act != 0)
- *   bwd_input  gx[M,K] = (gy * act'(z)) W         (single launch, deterministic)
+ *   bwd_input  gx[M,K] = (gy * act'(z)) W         (deterministic).  With a workspace of
+ *              cgv_skinny_bwd_input_workspace_bytes bytes (contents ignored) the weight rows are
+ *              split over ~320 blocks whose partial sums a second small launch adds in a fixed
+ *              order; with ws = NULL one block per 64 output columns walks all rows (one launch,
+ *              slow, same result up to summation order).
  *   grouped weight gradients: the caller queues one 80-byte record per layer
  *       { gy, x, z, gW, gb (pointers), M, N, K, accumulate, act, block_begin, tiles_k, tile_w, pad }
  *     (tiles_k / tile_w / the block count come from cgv_wgrad_plan; block_begin is the running sum
@@ -223,8 +227,9 @@ int cgv_skinny_max_rows(void);
 int cgv_skinny_supported(int M, int N, int K);
 int cgv_skinny_linear_fwd(const float* x, const float* W, const float* bias, float* y, float* z /*or NULL*/, int M, int N,
                           int K, int act, void* stream);
+size_t cgv_skinny_bwd_input_workspace_bytes(int M, int N, int K);
 int cgv_skinny_linear_bwd_input(const float* gy, const float* z /*or NULL*/, const float* W, float* gx, int M, int N, int K,
-                                int act, void* stream);
+                                int act, void* ws /*or NULL*/, size_t ws_bytes, void* stream);
 int cgv_wgrad_record_bytes(void);
 int cgv_wgrad_plan(int M, int N, int K, int* tiles_k /*[host]*/, int* tile_w /*[host]*/, int* n_blocks /*[host]*/);
 int cgv_grouped_wgrad(const void* table_dev, int n_problems, int total_blocks, int max_lds_floats, void* stream);

@@ -466,6 +466,41 @@ def test_skinny_linear_fwd_bwd_vs_fp64(M, N, K):
     assert_close(y2[0], (xd @ Wd_.t()).detach(), "y no bias", 2e-6)
 
 
+@pytest.mark.parametrize("M,N,K,act", [(12, 1800, 600, 0), (12, 600, 1200, 1), (36, 1200, 600, 0), (64, 5400, 24, 1)])
+def test_skinny_bwd_input_row_split_is_deterministic_and_rearms(M, N, K, act):
+    """The row-split bwd_input meets in a workspace: repeated launches must agree bit for bit (fixed summation
+    order, no stale partial ever read), and the one-block-per-column-tile flavour (no workspace) must agree
+    to rounding."""
+    from coarsegrainingvae_amd import _lib
+    gen = torch.Generator().manual_seed(N + K)
+    gy = torch.randn(M, N, generator=gen).to(DEV)
+    z = torch.randn(M, N, generator=gen).to(DEV)
+    W = (torch.randn(N, K, generator=gen) / N ** 0.5).to(DEV)
+    lib = _lib.load()
+    nbytes = lib.cgv_skinny_bwd_input_workspace_bytes(M, N, K)
+    assert nbytes > 0
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    outs = []
+    for _ in range(4):
+        gx = torch.full((M, K), float("nan"), device=DEV)
+        ws.fill_(255)                                      # NaN bit patterns: stale partials must never be read
+        _lib.call("cgv_skinny_linear_bwd_input", gy.data_ptr(), z.data_ptr() if act else None, W.data_ptr(),
+                  gx.data_ptr(), M, N, K, act, ws.data_ptr(), nbytes, _lib.stream_ptr())
+        outs.append(gx)
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    g = gy.double()
+    if act:
+        sg = torch.sigmoid(z.double())
+        g = g * (sg * (1 + z.double() * (1 - sg)))
+    assert_close(outs[0], g @ W.double(), "gx split", 2e-6)
+    gx1 = torch.full((M, K), float("nan"), device=DEV)
+    _lib.call("cgv_skinny_linear_bwd_input", gy.data_ptr(), z.data_ptr() if act else None, W.data_ptr(), gx1.data_ptr(),
+              M, N, K, act, None, 0, _lib.stream_ptr())
+    assert_close(gx1, g @ W.double(), "gx single", 2e-6)
+
+
 def test_skinny_direct_gradient_accumulation():
     from coarsegrainingvae_amd.trainer import ParamArena
     torch.manual_seed(1)
