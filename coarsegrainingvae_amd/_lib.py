@@ -57,6 +57,7 @@ PROTOTYPES = {
     "cgv_skinny_linear_bwd_input": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
     "cgv_wgrad_record_bytes": (_i, []),
     "cgv_wgrad_plan": (_i, [_i, _i, _i, _p, _p, _p]),
+    "cgv_wgrad_lds_floats": (_i, [_i, _i]),
     "cgv_grouped_wgrad": (_i, [_p, _i, _i, _i, _p]),
     "cgv_elbo_fwd": (_i, [_p] * 7 + [_i, _i, _i, _i, _f, _f] + [_p] * 6 + [_p]),
     "cgv_elbo_scale": (_i, [_p, _p, _p, _p, _p, _i, _p, _i, _p]),

@@ -94,13 +94,26 @@ __global__ __launch_bounds__(256) void adam_update(float* __restrict__ p, const 
     const float denom = sqrtf(vv) * inv_bc2 + eps;
     pp -= step_size * (mm / denom);
   };
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-    float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
-    upd(pp.x, gg.x, mm.x, vv.x);
-    upd(pp.y, gg.y, mm.y, vv.y);
-    upd(pp.z, gg.z, mm.z, vv.z);
-    upd(pp.w, gg.w, mm.w, vv.w);
-    p4[i] = pp; m4[i] = mm; v4[i] = vv;
+  // streaming pass: nothing here is read again before the next step's kernels have flushed the caches, so
+  // g / m / v go around them (nontemporal) and two float4 per array are in flight per thread
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  auto ldnt = [](const float4* q) { const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(q)); return make_float4(t.x, t.y, t.z, t.w); };
+  auto stnt = [](float4* q, float4 x) { __builtin_nontemporal_store(f4v{x.x, x.y, x.z, x.w}, reinterpret_cast<f4v*>(q)); };
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + stride < n4; i += 2 * stride) {
+    const int64_t j = i + stride;
+    float4 pa = p4[i], ga = ldnt(g4 + i), ma = ldnt(m4 + i), va = ldnt(v4 + i);
+    float4 pb = p4[j], gb = ldnt(g4 + j), mb = ldnt(m4 + j), vb = ldnt(v4 + j);
+    upd(pa.x, ga.x, ma.x, va.x); upd(pa.y, ga.y, ma.y, va.y); upd(pa.z, ga.z, ma.z, va.z); upd(pa.w, ga.w, ma.w, va.w);
+    upd(pb.x, gb.x, mb.x, vb.x); upd(pb.y, gb.y, mb.y, vb.y); upd(pb.z, gb.z, mb.z, vb.z); upd(pb.w, gb.w, mb.w, vb.w);
+    p4[i] = pa; stnt(m4 + i, ma); stnt(v4 + i, va);
+    p4[j] = pb; stnt(m4 + j, mb); stnt(v4 + j, vb);
+  }
+  if (i < n4) {
+    float4 pp = p4[i], gg = ldnt(g4 + i), mm = ldnt(m4 + i), vv = ldnt(v4 + i);
+    upd(pp.x, gg.x, mm.x, vv.x); upd(pp.y, gg.y, mm.y, vv.y); upd(pp.z, gg.z, mm.z, vv.z); upd(pp.w, gg.w, mm.w, vv.w);
+    p4[i] = pp; stnt(m4 + i, mm); stnt(v4 + i, vv);
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const int64_t i = (n4 << 2) + threadIdx.x;

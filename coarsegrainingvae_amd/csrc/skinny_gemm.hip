@@ -260,7 +260,9 @@ static inline void bwd_input_plan(int N, int K, bool split, int* KT, int* NS, in
 // gb_p[n] (+)= sum_m g_p[m,n]  with g_p = gy_p * act'(z_p).  Write-bound: a block produces ROWS
 // rows x one k tile of one problem from an LDS-staged x tile; blocks of all problems are
 // concatenated (block_begin prefix in the table, binary search per block).
-constexpr int WG_ROWS = 16;
+constexpr int WG_ROWS = 16;        // rows of gW per pass = float4 accumulators per thread
+constexpr int WG_PASSES = 4;       // passes per block: 64 rows of gW share one LDS-staged x tile
+constexpr int WG_BLOCK_ROWS = WG_ROWS * WG_PASSES;
 
 struct WgradProblem {       // mirrors the 80-byte host record built in python (primitives.WeightGradQueue)
   const float* gy;
@@ -290,16 +292,26 @@ __global__ __launch_bounds__(256) void grouped_wgrad_k(const WgradProblem* __res
   const int rb = local / pr.tiles_k, kt = local - rb * pr.tiles_k;
   const int M = pr.M, N = pr.N, K = pr.K, tile_w = pr.tile_w;
   float* xs = smem;                          // [M][tile_w]
-  float* gs = smem + (size_t)M * tile_w;     // [M][WG_ROWS]
+  float* gs = smem + (size_t)M * tile_w;     // [M][WG_BLOCK_ROWS]
   const int t = threadIdx.x;
-  const int n0 = rb * WG_ROWS;
+  const int n0 = rb * WG_BLOCK_ROWS;
   const int k = kt * tile_w + 4 * t;
   const bool kok = 4 * t < tile_w && k < K;
-  if (4 * t < tile_w)
-    for (int m = 0; m < M; ++m)
-      *reinterpret_cast<float4*>(xs + (size_t)m * tile_w + 4 * t) = ldg4_or_zero(pr.x + (size_t)m * K + (kok ? k : 0), kok);
-  for (int idx = t; idx < M * WG_ROWS; idx += blockDim.x) {
-    const int m = idx / WG_ROWS, r = idx - m * WG_ROWS;
+  if (4 * t < tile_w) {                      // x tile; 4 rows of loads in flight before the LDS stores
+    const float* xp = pr.x + (kok ? k : 0);
+    int m = 0;
+    for (; m + 4 <= M; m += 4) {
+      const float4 a = ldg4_or_zero(xp + (size_t)m * K, kok), b = ldg4_or_zero(xp + (size_t)(m + 1) * K, kok);
+      const float4 c = ldg4_or_zero(xp + (size_t)(m + 2) * K, kok), d = ldg4_or_zero(xp + (size_t)(m + 3) * K, kok);
+      *reinterpret_cast<float4*>(xs + (size_t)m * tile_w + 4 * t) = a;
+      *reinterpret_cast<float4*>(xs + (size_t)(m + 1) * tile_w + 4 * t) = b;
+      *reinterpret_cast<float4*>(xs + (size_t)(m + 2) * tile_w + 4 * t) = c;
+      *reinterpret_cast<float4*>(xs + (size_t)(m + 3) * tile_w + 4 * t) = d;
+    }
+    for (; m < M; ++m) *reinterpret_cast<float4*>(xs + (size_t)m * tile_w + 4 * t) = ldg4_or_zero(xp + (size_t)m * K, kok);
+  }
+  for (int idx = t; idx < M * WG_BLOCK_ROWS; idx += 256) {       // g tile, coalesced along n
+    const int m = idx / WG_BLOCK_ROWS, r = idx - m * WG_BLOCK_ROWS;
     float g = 0.f;
     if (n0 + r < N) {
       g = pr.gy[(size_t)m * N + n0 + r];
@@ -309,38 +321,48 @@ __global__ __launch_bounds__(256) void grouped_wgrad_k(const WgradProblem* __res
   }
   __syncthreads();
   if (kok) {
-    float4 acc[WG_ROWS];
+    for (int pass = 0; pass < WG_PASSES; ++pass) {
+      const int nr = n0 + pass * WG_ROWS;
+      if (nr >= N) break;
+      float4 acc[WG_ROWS];
 #pragma unroll
-    for (int r = 0; r < WG_ROWS; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int m = 0; m < M; ++m) {
-      const float4 xv = *reinterpret_cast<const float4*>(xs + (size_t)m * tile_w + 4 * t);
+      for (int r = 0; r < WG_ROWS; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int m = 0; m < M; ++m) {
+        const float4 xv = *reinterpret_cast<const float4*>(xs + (size_t)m * tile_w + 4 * t);
+        const float4* g4 = reinterpret_cast<const float4*>(gs + m * WG_BLOCK_ROWS + pass * WG_ROWS);   // LDS broadcast
+#pragma unroll
+        for (int i = 0; i < WG_ROWS / 4; ++i) {
+          const float4 gv = g4[i];
+          const float gg[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            float4& a = acc[4 * i + c];
+            a.x = fmaf(gg[c], xv.x, a.x); a.y = fmaf(gg[c], xv.y, a.y);
+            a.z = fmaf(gg[c], xv.z, a.z); a.w = fmaf(gg[c], xv.w, a.w);
+          }
+        }
+      }
 #pragma unroll
       for (int r = 0; r < WG_ROWS; ++r) {
-        const float g = gs[m * WG_ROWS + r];              // LDS broadcast
-        acc[r].x = fmaf(g, xv.x, acc[r].x); acc[r].y = fmaf(g, xv.y, acc[r].y);
-        acc[r].z = fmaf(g, xv.z, acc[r].z); acc[r].w = fmaf(g, xv.w, acc[r].w);
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < WG_ROWS; ++r) {
-      if (n0 + r < N) {
-        float4* dst = reinterpret_cast<float4*>(pr.gW + (size_t)(n0 + r) * K + k);
-        float4 o = acc[r];
-        if (pr.accumulate) { const float4 old = *dst; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
-        *dst = o;
+        if (nr + r < N) {
+          float4* dst = reinterpret_cast<float4*>(pr.gW + (size_t)(nr + r) * K + k);
+          float4 o = acc[r];
+          if (pr.accumulate) { const float4 old = *dst; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+          *dst = o;
+        }
       }
     }
   }
-  if (pr.gb && kt == 0 && t < WG_ROWS && n0 + t < N) {
+  if (pr.gb && kt == 0 && t < WG_BLOCK_ROWS && n0 + t < N) {
     float sum = 0.f;
-    for (int m = 0; m < M; ++m) sum += gs[m * WG_ROWS + t];
+    for (int m = 0; m < M; ++m) sum += gs[m * WG_BLOCK_ROWS + t];
     pr.gb[n0 + t] = pr.accumulate ? pr.gb[n0 + t] + sum : sum;
   }
 }
 
-// k tiling of one problem: as wide as a 60 KiB LDS budget for the x tile allows, <= 256 float4
+// k tiling of one problem: as wide as a 60 KiB LDS budget for the x + g tiles allows, <= 256 float4
 static inline void wgrad_tiling(int M, int K, int* tiles_k, int* tile_w) {
-  int max_t4 = (15000 / M) / 4;
+  int max_t4 = (15360 / M - WG_BLOCK_ROWS) / 4;
   if (max_t4 > 256) max_t4 = 256;
   if (max_t4 < 1) max_t4 = 1;
   const int k4 = K / 4;
@@ -432,9 +454,11 @@ int cgv_wgrad_plan(int M, int N, int K, int* tiles_k, int* tile_w, int* n_blocks
   CGV_REQUIRE(tiles_k && tile_w && n_blocks, "null pointer");
   CGV_REQUIRE(cgv_skinny_supported(M, N, K), "unsupported shape (need M <= 64, N % 4 == 0, K % 4 == 0)");
   cgv::wgrad_tiling(M, K, tiles_k, tile_w);
-  *n_blocks = ((N + cgv::WG_ROWS - 1) / cgv::WG_ROWS) * *tiles_k;
+  *n_blocks = ((N + cgv::WG_BLOCK_ROWS - 1) / cgv::WG_BLOCK_ROWS) * *tiles_k;
   return 0;
 }
+
+int cgv_wgrad_lds_floats(int M, int tile_w) { return M * (tile_w + cgv::WG_BLOCK_ROWS); }
 
 int cgv_grouped_wgrad(const void* table_dev, int n_problems, int total_blocks, int max_lds_floats, void* stream) {
   CGV_REQUIRE(n_problems >= 0 && total_blocks >= 0, "bad size");

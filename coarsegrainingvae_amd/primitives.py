@@ -122,7 +122,7 @@ class WeightGradQueue:
                                     gb.data_ptr() if gb is not None else 0, M, N, K, int(accumulate), int(act),
                                     block_begin, tk.value, tw.value, 0)
             block_begin += nb.value
-            max_lds = max(max_lds, M * tw.value + M * 16)
+            max_lds = max(max_lds, lib.cgv_wgrad_lds_floats(M, tw.value))
         n = len(self.items)
         host[: len(buf)].copy_(torch.frombuffer(buf, dtype=torch.uint8))
         table[: len(buf)].copy_(host[: len(buf)], non_blocking=True)

@@ -220,7 +220,7 @@ int cgv_update_gate_bwd(const float* U, const float* Vv, const float* a, const f
  *     (tiles_k / tile_w / the block count come from cgv_wgrad_plan; block_begin is the running sum
  *     of the block counts) and ONE cgv_grouped_wgrad launch computes, for every record,
  *       gW[N,K] (+)= (gy * act'(z))^T x ,  gb[N] (+)= sum_m (gy * act'(z))[m,:]     (gb may be NULL)
- *     max_lds_floats = max over records of M*tile_w + 16*M.
+ *     max_lds_floats = max over records of cgv_wgrad_lds_floats(M, tile_w).
  * v_mfma_f32_16x16x4_f32 is an exact fp32 FMA chain, so these match an fmaf loop bit for bit.
  * ------------------------------------------------------------------------------------- */
 int cgv_skinny_max_rows(void);
@@ -232,6 +232,7 @@ int cgv_skinny_linear_bwd_input(const float* gy, const float* z /*or NULL*/, con
                                 int act, void* ws /*or NULL*/, size_t ws_bytes, void* stream);
 int cgv_wgrad_record_bytes(void);
 int cgv_wgrad_plan(int M, int N, int K, int* tiles_k /*[host]*/, int* tile_w /*[host]*/, int* n_blocks /*[host]*/);
+int cgv_wgrad_lds_floats(int M, int tile_w);
 int cgv_grouped_wgrad(const void* table_dev, int n_problems, int total_blocks, int max_lds_floats, void* stream);
 
 /* ---------------------------------------------------------------------------------------
