@@ -372,6 +372,40 @@ static inline void wgrad_tiling(int M, int K, int* tiles_k, int* tile_w) {
   *tile_w = per * 4;
 }
 
+// ------------------------------------------------------------------ Dense backward prologue (any M)
+// g = gy * act'(z) (stored when g_out != NULL) and gb[n] (+)= sum_m g[m, n] in one pass: replaces the
+// sigmoid / mul / add tensor ops and the separate column-sum reduction of the library-GEMM path
+// (encoder Dense layers, M = atoms).  Block = 64 columns x 16 row groups, fixed summation order.
+__global__ __launch_bounds__(1024) void dense_grad_prepare_k(const float* __restrict__ gy, const float* __restrict__ z,
+                                                             float* __restrict__ g_out, float* __restrict__ gb, int M,
+                                                             int N, int act, int accumulate) {
+  __shared__ float4 red[64][16];
+  const int c4 = threadIdx.x & 15, rg = threadIdx.x >> 4;          // 16 float4 column groups x 64 row groups
+  const int n = blockIdx.x * 64 + 4 * c4;
+  float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (n < N) {                                                     // N % 4 == 0
+#pragma unroll 8
+    for (int m = rg; m < M; m += 64) {
+      const size_t at = (size_t)m * N + n;
+      float4 g = *reinterpret_cast<const float4*>(gy + at);
+      if (act) {
+        const float4 zz = *reinterpret_cast<const float4*>(z + at);
+        g.x *= act_bwd(zz.x, act); g.y *= act_bwd(zz.y, act); g.z *= act_bwd(zz.z, act); g.w *= act_bwd(zz.w, act);
+        if (g_out) *reinterpret_cast<float4*>(g_out + at) = g;
+      }
+      sum.x += g.x; sum.y += g.y; sum.z += g.z; sum.w += g.w;
+    }
+  }
+  red[rg][c4] = sum;
+  __syncthreads();
+  if (rg < 4 && n < N && gb) {                                     // thread (rg, c4) finishes column n + rg
+    float t = 0.f;
+#pragma unroll 16
+    for (int k = 0; k < 64; ++k) t += reinterpret_cast<const float*>(&red[k][c4])[rg];
+    gb[n + rg] = accumulate ? gb[n + rg] + t : t;
+  }
+}
+
 template <int MB>
 static void launch_fwd(dim3 grid, int waves, hipStream_t st, const float* x, const float* W, const float* bias, float* y,
                        float* z, int M, int N, int K, int act) {
@@ -445,6 +479,18 @@ int cgv_skinny_linear_bwd_input(const float* gy, const float* z, const float* W,
     default: cgv::launch_bwd_input<4>(st, gy, z, W, gx, part, M, N, K, act, KT, NS, rpb); break;
   }
   return cgv::check_launch("cgv_skinny_linear_bwd_input");
+}
+
+int cgv_dense_grad_prepare(const float* gy, const float* z, float* g_out, float* gb, int M, int N, int act, int accumulate,
+                           void* stream) {
+  CGV_REQUIRE(gy && M >= 0 && N > 0, "bad argument");
+  CGV_REQUIRE(act == 0 || (act == 1 && z), "act = 1 needs the saved pre-activation z");
+  CGV_REQUIRE(gb || (act && g_out), "nothing to compute");
+  CGV_REQUIRE((N % 4) == 0 && ((((uintptr_t)gy | (uintptr_t)z | (uintptr_t)g_out)) & 15) == 0, "need N % 4 == 0, 16-byte aligned");
+  if (M == 0 && !gb) return 0;
+  hipLaunchKernelGGL(cgv::dense_grad_prepare_k, dim3((N + 63) / 64), dim3(1024), 0, (hipStream_t)stream, gy, z, g_out, gb, M,
+                     N, act, accumulate);
+  return cgv::check_launch("cgv_dense_grad_prepare");
 }
 
 int cgv_wgrad_record_bytes(void) { return (int)sizeof(cgv::WgradProblem); }

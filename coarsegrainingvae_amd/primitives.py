@@ -183,10 +183,23 @@ class _LinearFn(torch.autograd.Function):
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         need_b = b_param is not None and ctx.needs_input_grad[2]
         if not ctx.skinny:
+            x2, gy2 = x.reshape(-1, x.shape[-1]), gy.reshape(-1, gy.shape[-1])
+            if gy.is_cuda and gy2.shape[1] % 4 == 0:
+                # one launch: Swish' applied + bias column sums (was sigmoid / mul / add tensor ops + a reduction)
+                gy2 = gy2.contiguous()
+                g2 = torch.empty_like(gy2) if act == ACT_SWISH else gy2
+                tb, acc_b, gb = _grad_target(b_param, b_param) if need_b else (None, False, None)
+                if act == ACT_SWISH or need_b:
+                    _lib.call("cgv_dense_grad_prepare", _lib.ptr(gy2), _lib.ptr(z.reshape(gy2.shape)) if act else None,
+                              _lib.ptr(g2) if act == ACT_SWISH else None, _lib.ptr(tb), gy2.shape[0], gy2.shape[1], act,
+                              int(acc_b), _lib.stream_ptr())
+                gx = g2.matmul(weight).reshape(x.shape) if need_x else None
+                gw = _direct_grad(w_param, lambda out: torch.mm(g2.t(), x2, out=out), lambda: g2.t().mm(x2)) if need_w else None
+                return gx, gw, gb, None
             if act == ACT_SWISH:
                 sg = torch.sigmoid(z)
                 gy = gy * (sg * (1 + z * (1 - sg)))
-            x2, gy2 = x.reshape(-1, x.shape[-1]), gy.reshape(-1, gy.shape[-1])
+                gy2 = gy.reshape(-1, gy.shape[-1])
             gx = gy.matmul(weight) if need_x else None
             gw = _direct_grad(w_param, lambda out: torch.mm(gy2.t(), x2, out=out), lambda: gy2.t().mm(x2)) if need_w else None
             gb = _direct_grad(b_param, lambda out: torch.sum(gy2, 0, out=out), lambda: gy2.sum(0)) if need_b else None

@@ -230,6 +230,12 @@ int cgv_skinny_linear_fwd(const float* x, const float* W, const float* bias, flo
 size_t cgv_skinny_bwd_input_workspace_bytes(int M, int N, int K);
 int cgv_skinny_linear_bwd_input(const float* gy, const float* z /*or NULL*/, const float* W, float* gx, int M, int N, int K,
                                 int act, void* ws /*or NULL*/, size_t ws_bytes, void* stream);
+/* Dense backward prologue for any row count (the library-GEMM path of the atom-level layers):
+ *   g = gy * act'(z)  (stored to g_out [M,N] when act != 0 and g_out != NULL)  and
+ *   gb[n] (+)= sum_m g[m,n]  (gb may be NULL) -- one launch, fixed summation order.
+ * Replaces the tensor-op chain of modules.py:16-21's autograd backward plus the bias column sum. */
+int cgv_dense_grad_prepare(const float* gy, const float* z /*or NULL*/, float* g_out /*or NULL*/, float* gb /*or NULL*/,
+                           int M, int N, int act, int accumulate, void* stream);
 int cgv_wgrad_record_bytes(void);
 int cgv_wgrad_plan(int M, int N, int K, int* tiles_k /*[host]*/, int* tile_w /*[host]*/, int* n_blocks /*[host]*/);
 int cgv_wgrad_lds_floats(int M, int tile_w);
