@@ -56,6 +56,10 @@ PROTOTYPES = {
     "cgv_skinny_bwd_input_workspace_bytes": (_sz, [_i, _i, _i]),
     "cgv_skinny_linear_bwd_input": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
     "cgv_dense_grad_prepare": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "cgv_tile_supported": (_i, [_i, _i, _i]),
+    "cgv_tile_linear_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "cgv_tile_linear_bwd_input": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "cgv_tile_linear_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "cgv_wgrad_record_bytes": (_i, []),
     "cgv_wgrad_plan": (_i, [_i, _i, _i, _p, _p, _p]),
     "cgv_wgrad_lds_floats": (_i, [_i, _i]),

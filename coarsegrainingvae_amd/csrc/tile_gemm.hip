@@ -1,0 +1,299 @@
+// Tiled fp32 GEMMs for the Dense / nn.Linear layers whose row count is beyond the skinny kernels
+// (M > 64: the atom-level layers of the encoder, M = atoms of the batch = 332 on the chignolin
+// config; every bead-level layer of the dipeptide config, M = 96).
+//
+// Reference: Dense / nn.Linear forward (CoarseGrainingVAE/modules.py:103-114, Swish modules.py:16-21)
+// and its autograd backward.  These products are small (0.24 - 0.72 GFLOP): a library GEMM spends
+// 13-18 us on each (profiles/r01l: hipBLASLt MT32x32 tiles walk K in ~19 dependent LDS rounds),
+// plus separate bias / activation / column-sum launches.  Here each block splits the REDUCTION
+// over its 4 waves (a quarter of the dependent chain each), operands go from L2 straight into
+// MFMA layout with 16-byte loads (the whole working set, <= 4 MB, is L2 resident; no LDS staging),
+// and the wave partials meet in LDS.  Bias + Swish are fused into the forward epilogue.
+//
+//   fwd        z = x W^T + b ; y = act(z)     tile 32 x 32, K split over the waves
+//   bwd_input  gx = g W                       tile (16 | 32) x 64, N split over the waves
+//   wgrad      gW (+)= g^T x                  tile 16 x 64, M split over the waves
+// (g = gy * act'(z) and the bias gradient come from cgv_dense_grad_prepare.)
+//
+// v_mfma_f32_16x16x4_f32 operand map (cdna_hip_programming.md 3): lane l holds A[i = l&15][k = l>>4],
+// B[k = l>>4][j = l&15]; D: col j = l&15, row i = 4*(l>>4) + reg.  A float4 loaded along the
+// reduction axis feeds 4 consecutive MFMAs: component c of lane group q stands for reduction index
+// 4q + c of the 16-wide step -- any bijection works as long as A and B use the same one.
+#include "cgv_common.h"
+
+namespace cgv {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float4 ld4z(const float* p, bool ok) {
+  return ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__device__ __forceinline__ float tg_sigmoid(float z) { return 1.0f / (1.0f + expf(-z)); }
+
+#define CGV_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// ------------------------------------------------------------------ fwd
+// grid (ceil(N/32), ceil(M/32)), 256 threads.  Wave w walks k-steps w, w+4, ... (16 floats each).
+// Lane (i = l&15, q = l>>4): A_mb = x[m0 + 16 mb + i][k + 4q ..+3], B_nb = W[n0 + 16 nb + i][k + 4q ..+3].
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void tile_fwd_k(const float* __restrict__ x, const float* __restrict__ W,
+                                                  const float* __restrict__ bias, float* __restrict__ y,
+                                                  float* __restrict__ zout, int M, int N, int K, int act) {
+  __shared__ float red[WAVES - 1][4][4][64];         // [wave-1][sub-tile][reg][lane]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, q = lane >> 4;
+  const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+  const float* xr[2];
+  const float* wr[2];
+  bool xok[2], wok[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int m = m0 + 16 * t + i, n = n0 + 16 * t + i;
+    xok[t] = m < M; wok[t] = n < N;
+    xr[t] = x + (size_t)(xok[t] ? m : 0) * K + 4 * q;
+    wr[t] = W + (size_t)(wok[t] ? n : 0) * K + 4 * q;
+  }
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int steps = (K + 15) / 16;
+#pragma unroll 4
+  for (int s = wave; s < steps; s += WAVES) {
+    const int k = 16 * s;
+    const bool kok = k + 4 * q < K;                  // K % 4 == 0: a float4 is entirely in or out
+    const float4 a0 = ld4z(xr[0] + (kok ? k : 0), kok && xok[0]), a1 = ld4z(xr[1] + (kok ? k : 0), kok && xok[1]);
+    const float4 b0 = ld4z(wr[0] + (kok ? k : 0), kok && wok[0]), b1 = ld4z(wr[1] + (kok ? k : 0), kok && wok[1]);
+    acc[0][0] = CGV_MFMA(a0.x, b0.x, acc[0][0]); acc[0][1] = CGV_MFMA(a0.x, b1.x, acc[0][1]);
+    acc[1][0] = CGV_MFMA(a1.x, b0.x, acc[1][0]); acc[1][1] = CGV_MFMA(a1.x, b1.x, acc[1][1]);
+    acc[0][0] = CGV_MFMA(a0.y, b0.y, acc[0][0]); acc[0][1] = CGV_MFMA(a0.y, b1.y, acc[0][1]);
+    acc[1][0] = CGV_MFMA(a1.y, b0.y, acc[1][0]); acc[1][1] = CGV_MFMA(a1.y, b1.y, acc[1][1]);
+    acc[0][0] = CGV_MFMA(a0.z, b0.z, acc[0][0]); acc[0][1] = CGV_MFMA(a0.z, b1.z, acc[0][1]);
+    acc[1][0] = CGV_MFMA(a1.z, b0.z, acc[1][0]); acc[1][1] = CGV_MFMA(a1.z, b1.z, acc[1][1]);
+    acc[0][0] = CGV_MFMA(a0.w, b0.w, acc[0][0]); acc[0][1] = CGV_MFMA(a0.w, b1.w, acc[0][1]);
+    acc[1][0] = CGV_MFMA(a1.w, b0.w, acc[1][0]); acc[1][1] = CGV_MFMA(a1.w, b1.w, acc[1][1]);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave - 1][t][r][lane] = acc[t >> 1][t & 1][r];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  // D of sub-tile (mb, nb): lane holds y[m0 + 16 mb + 4 q + r][n0 + 16 nb + i]
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int mb = t >> 1, nb = t & 1;
+    const int n = n0 + 16 * nb + i;
+    if (n >= N) continue;
+    const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + 16 * mb + 4 * q + r;
+      if (m >= M) continue;
+      float zv = acc[mb][nb][r];
+#pragma unroll
+      for (int w = 0; w < WAVES - 1; ++w) zv += red[w][t][r][lane];
+      zv += bv;
+      if (act) {
+        if (zout) zout[(size_t)m * N + n] = zv;
+        zv = zv * tg_sigmoid(zv);
+      }
+      y[(size_t)m * N + n] = zv;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ bwd_input
+// gx[m, k] = sum_n g[m, n] W[n, k].  grid (ceil(K/64), ceil(M/(16 MB))), 256 threads; wave w walks n-steps
+// w, w+4, ... (16 rows of W each).  Lane (j = l&15, q = l>>4): A_mb = g[m0 + 16 mb + j][n + 4q ..+3];
+// for c = 0..3 one float4 B_c = W[n + 4q + c][k0 + 4j ..+3] (4 rows x 256 contiguous bytes per
+// instruction); MFMA (c, s) uses A.comp(c) and B_c.comp(s) and accumulates D_s = gx[..][k0 + 4j + s].
+template <int MB, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void tile_bwd_input_k(const float* __restrict__ g, const float* __restrict__ W,
+                                                        float* __restrict__ gx, int M, int N, int K) {
+  __shared__ float red[WAVES - 1][MB * 4][4][64];    // [wave-1][mb*4 + s][reg][lane]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15, q = lane >> 4;
+  const int k0 = blockIdx.x * 64, m0 = blockIdx.y * (16 * MB);
+  const int kcol = k0 + 4 * j;
+  const bool kok = kcol < K;
+  const float* gr[MB];
+  bool gok[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int m = m0 + 16 * mb + j;
+    gok[mb] = m < M;
+    gr[mb] = g + (size_t)(gok[mb] ? m : 0) * N + 4 * q;
+  }
+  f32x4 acc[MB][4];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc[mb][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int steps = (N + 15) / 16;
+#pragma unroll 4
+  for (int st = wave; st < steps; st += WAVES) {
+    const int n = 16 * st;
+    const bool nok = n + 4 * q < N;                  // N % 4 == 0: rows n + 4q .. + 3 are all in or all out
+    float4 a[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) a[mb] = ld4z(gr[mb] + (nok ? n : 0), nok && gok[mb]);
+    float4 b[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const bool ok = nok && kok;
+      b[c] = ld4z(W + (size_t)(ok ? n + 4 * q + c : 0) * K + (ok ? kcol : 0), ok);
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const float ac[4] = {a[mb].x, a[mb].y, a[mb].z, a[mb].w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        acc[mb][0] = CGV_MFMA(ac[c], b[c].x, acc[mb][0]);
+        acc[mb][1] = CGV_MFMA(ac[c], b[c].y, acc[mb][1]);
+        acc[mb][2] = CGV_MFMA(ac[c], b[c].z, acc[mb][2]);
+        acc[mb][3] = CGV_MFMA(ac[c], b[c].w, acc[mb][3]);
+      }
+    }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int t = 0; t < MB * 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave - 1][t][r][lane] = acc[t >> 2][t & 3][r];
+  }
+  __syncthreads();
+  if (wave != 0 || !kok) return;
+  // D_s of m-block mb: lane holds gx[m0 + 16 mb + 4 q + r][k0 + 4 j + s] -> one float4 (s = 0..3) per r
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + 16 * mb + 4 * q + r;
+      if (m >= M) continue;
+      float o[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int t = mb * 4 + s;
+        o[s] = acc[mb][s][r];
+#pragma unroll
+        for (int w = 0; w < WAVES - 1; ++w) o[s] += red[w][t][r][lane];
+      }
+      *reinterpret_cast<float4*>(gx + (size_t)m * K + kcol) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// ------------------------------------------------------------------ wgrad
+// gW[n, k] (+)= sum_m g[m, n] x[m, k].  grid (ceil(K/64), ceil(N/16)), 256 threads; wave w walks m-steps
+// w, w+4, ... (4 rows each).  Lane (i = l&15, q = l>>4): A = g[m + q][n0 + i] (4 rows x 64 contiguous bytes),
+// B = x[m + q][k0 + 4 i ..+3] (4 rows x 256 bytes); MFMA s uses B.comp(s): D_s = gW[n0 + ..][k0 + 4 j + s].
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void tile_wgrad_k(const float* __restrict__ g, const float* __restrict__ x,
+                                                    float* __restrict__ gW, int M, int N, int K, int accumulate) {
+  __shared__ float red[WAVES - 1][4][4][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, q = lane >> 4;
+  const int k0 = blockIdx.x * 64, n0 = blockIdx.y * 16;
+  const int ncol = n0 + i, kcol = k0 + 4 * i;
+  const bool nok = ncol < N, kok = kcol < K;
+  f32x4 acc[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int steps = (M + 3) / 4;
+#pragma unroll 8
+  for (int st = wave; st < steps; st += WAVES) {
+    const int m = 4 * st + q;
+    const bool mok = m < M;
+    const float a = (mok && nok) ? g[(size_t)m * N + ncol] : 0.f;
+    const float4 b = ld4z(x + (size_t)(mok && kok ? m : 0) * K + (kok ? kcol : 0), mok && kok);
+    acc[0] = CGV_MFMA(a, b.x, acc[0]);
+    acc[1] = CGV_MFMA(a, b.y, acc[1]);
+    acc[2] = CGV_MFMA(a, b.z, acc[2]);
+    acc[3] = CGV_MFMA(a, b.w, acc[3]);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave - 1][s][r][lane] = acc[s][r];
+  }
+  __syncthreads();
+  if (wave != 0 || !kok) return;
+  // D_s: lane holds gW[n0 + 4 q + r][k0 + 4 i + s]
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int n = n0 + 4 * q + r;
+    if (n >= N) continue;
+    float o[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      o[s] = acc[s][r];
+#pragma unroll
+      for (int w = 0; w < WAVES - 1; ++w) o[s] += red[w][s][r][lane];
+    }
+    float4* dst = reinterpret_cast<float4*>(gW + (size_t)n * K + kcol);
+    float4 v = make_float4(o[0], o[1], o[2], o[3]);
+    if (accumulate) { const float4 old = *dst; v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w; }
+    *dst = v;
+  }
+}
+
+}  // namespace cgv
+
+extern "C" {
+
+int cgv_tile_supported(int M, int N, int K) {
+  return M >= 1 && N >= 4 && K >= 4 && (N % 4) == 0 && (K % 4) == 0 && (int64_t)M * N < (1ll << 31) &&
+         (int64_t)M * K < (1ll << 31) && (int64_t)N * K < (1ll << 31);
+}
+
+int cgv_tile_linear_fwd(const float* x, const float* W, const float* bias, float* y, float* z, int M, int N, int K, int act,
+                        void* stream) {
+  CGV_REQUIRE(x && W && y, "null pointer");
+  CGV_REQUIRE(act == 0 || act == 1, "act must be 0 (identity) or 1 (swish)");
+  CGV_REQUIRE(cgv_tile_supported(M, N, K), "unsupported shape (need N % 4 == 0, K % 4 == 0)");
+  CGV_REQUIRE(((((uintptr_t)x | (uintptr_t)W)) & 15) == 0, "x and W must be 16-byte aligned");
+  const dim3 grid((N + 31) / 32, (M + 31) / 32);
+  // few tiles: split the reduction over more waves so every SIMD has loads in flight
+  if (grid.x * grid.y >= 1024)
+    hipLaunchKernelGGL((cgv::tile_fwd_k<4>), grid, dim3(256), 0, (hipStream_t)stream, x, W, bias, y, z, M, N, K, act);
+  else
+    hipLaunchKernelGGL((cgv::tile_fwd_k<8>), grid, dim3(512), 0, (hipStream_t)stream, x, W, bias, y, z, M, N, K, act);
+  return cgv::check_launch("cgv_tile_linear_fwd");
+}
+
+int cgv_tile_linear_bwd_input(const float* g, const float* W, float* gx, int M, int N, int K, void* stream) {
+  CGV_REQUIRE(g && W && gx, "null pointer");
+  CGV_REQUIRE(cgv_tile_supported(M, N, K), "unsupported shape (need N % 4 == 0, K % 4 == 0)");
+  CGV_REQUIRE(((((uintptr_t)g | (uintptr_t)W | (uintptr_t)gx)) & 15) == 0, "operands must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int kt = (K + 63) / 64;
+  const int blocks32 = kt * ((M + 31) / 32);
+  if (blocks32 >= 512)                    // enough 32-row tiles to fill the chip: halve the weight re-reads
+    hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 4>), dim3(kt, (M + 31) / 32), dim3(256), 0, st, g, W, gx, M, N, K);
+  else if (M <= 128)                      // few rows, (possibly) huge weight: re-reading W per 16-row tile dominates
+    hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 8>), dim3(kt, (M + 31) / 32), dim3(512), 0, st, g, W, gx, M, N, K);
+  else
+    hipLaunchKernelGGL((cgv::tile_bwd_input_k<1, 8>), dim3(kt, (M + 15) / 16), dim3(512), 0, st, g, W, gx, M, N, K);
+  return cgv::check_launch("cgv_tile_linear_bwd_input");
+}
+
+int cgv_tile_linear_wgrad(const float* g, const float* x, float* gW, int M, int N, int K, int accumulate, void* stream) {
+  CGV_REQUIRE(g && x && gW, "null pointer");
+  CGV_REQUIRE(cgv_tile_supported(M, N, K), "unsupported shape (need N % 4 == 0, K % 4 == 0)");
+  CGV_REQUIRE(((((uintptr_t)x | (uintptr_t)gW)) & 15) == 0, "x and gW must be 16-byte aligned");
+  const dim3 grid((K + 63) / 64, (N + 15) / 16);
+  if (grid.x * grid.y >= 1024 || M <= 128)
+    hipLaunchKernelGGL((cgv::tile_wgrad_k<4>), grid, dim3(256), 0, (hipStream_t)stream, g, x, gW, M, N, K, accumulate);
+  else
+    hipLaunchKernelGGL((cgv::tile_wgrad_k<8>), grid, dim3(512), 0, (hipStream_t)stream, g, x, gW, M, N, K, accumulate);
+  return cgv::check_launch("cgv_tile_linear_wgrad");
+}
+
+}  // extern "C"

@@ -43,14 +43,23 @@ def to_module(activation: str) -> nn.Module:
     return layer_types[activation]()
 
 
-def _skinny_ok(x2, weight):
-    """Bead-level products (M <= 64 rows) go to the weight-streaming HIP kernels (csrc/skinny_gemm.hip);
-    atom-level ones (hundreds of rows) are ordinary GEMMs and stay with hipBLASLt."""
+def _gemm_mode(x2, weight, bias):
+    """Which kernels a Dense / Linear product runs on:
+    "skinny"  M <= 64 rows (bead level): weight-streaming HIP kernels, csrc/skinny_gemm.hip;
+    "tile"    more rows (atom level, or big bead batches): reduction-split MFMA tiles, csrc/tile_gemm.hip;
+    "library" shapes neither takes (widths not a multiple of 4, unaligned views) or CPU tensors: torch ops."""
     if not (x2.is_cuda and x2.dtype == torch.float32 and weight.dtype == torch.float32):
-        return False
+        return "library"
+    if not (weight.is_contiguous() and weight.data_ptr() % 16 == 0):
+        return "library"
     M, K = x2.shape
     N = weight.shape[0]
-    return bool(_lib.load().cgv_skinny_supported(M, N, K)) and weight.is_contiguous() and weight.data_ptr() % 16 == 0
+    lib = _lib.load()
+    if lib.cgv_skinny_supported(M, N, K) and (bias is None or bias.data_ptr() % 16 == 0):
+        return "skinny"
+    if M > 0 and lib.cgv_tile_supported(M, N, K):
+        return "tile"
+    return "library"
 
 
 ACT_NONE, ACT_SWISH = 0, 1
@@ -148,7 +157,8 @@ wgrad_queue = WeightGradQueue()
 
 class _LinearFn(torch.autograd.Function):
     """y = act(x W^T + b), act in {identity, Swish}.  Small row counts run on the skinny-GEMM kernels
-    (bias / activation fused; activation backward fused into the operand loads); the weight / bias
+    (bias / activation fused; activation backward fused into the operand loads), larger ones on the
+    reduction-split MFMA tiles (bias / activation fused into the forward epilogue); the weight / bias
     gradients are written straight into the trainer's gradient arena (``param.grad`` is a view of
     it, trainer.py) -- deferred to ONE grouped launch per step when the trainer's queue is active."""
 
@@ -157,15 +167,17 @@ class _LinearFn(torch.autograd.Function):
         x2 = x.reshape(-1, x.shape[-1])
         ctx.params = (weight, bias)
         ctx.act = act
-        ctx.skinny = _skinny_ok(x2, weight) and (bias is None or bias.data_ptr() % 16 == 0)
+        ctx.mode = mode = _gemm_mode(x2, weight, bias)
         N = weight.shape[0]
-        if ctx.skinny:
+        if mode != "library":
             x2 = x2.contiguous()
+            if x2.data_ptr() % 16:
+                x2 = x2.clone()
             M, K = x2.shape
             y = torch.empty(M, N, dtype=torch.float32, device=x.device)
             z = torch.empty_like(y) if act else None
-            _lib.call("cgv_skinny_linear_fwd", _lib.ptr(x2), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(y), _lib.ptr(z),
-                      M, N, K, act, _lib.stream_ptr())
+            _lib.call("cgv_skinny_linear_fwd" if mode == "skinny" else "cgv_tile_linear_fwd", _lib.ptr(x2), _lib.ptr(weight),
+                      _lib.ptr(bias), _lib.ptr(y), _lib.ptr(z), M, N, K, act, _lib.stream_ptr())
             ctx.save_for_backward(x2, weight, z)
             return y.reshape(x.shape[:-1] + (N,))
         z = Fn.linear(x, weight, bias)
@@ -182,24 +194,11 @@ class _LinearFn(torch.autograd.Function):
         act = ctx.act
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         need_b = b_param is not None and ctx.needs_input_grad[2]
-        if not ctx.skinny:
-            x2, gy2 = x.reshape(-1, x.shape[-1]), gy.reshape(-1, gy.shape[-1])
-            if gy.is_cuda and gy2.shape[1] % 4 == 0:
-                # one launch: Swish' applied + bias column sums (was sigmoid / mul / add tensor ops + a reduction)
-                gy2 = gy2.contiguous()
-                g2 = torch.empty_like(gy2) if act == ACT_SWISH else gy2
-                tb, acc_b, gb = _grad_target(b_param, b_param) if need_b else (None, False, None)
-                if act == ACT_SWISH or need_b:
-                    _lib.call("cgv_dense_grad_prepare", _lib.ptr(gy2), _lib.ptr(z.reshape(gy2.shape)) if act else None,
-                              _lib.ptr(g2) if act == ACT_SWISH else None, _lib.ptr(tb), gy2.shape[0], gy2.shape[1], act,
-                              int(acc_b), _lib.stream_ptr())
-                gx = g2.matmul(weight).reshape(x.shape) if need_x else None
-                gw = _direct_grad(w_param, lambda out: torch.mm(g2.t(), x2, out=out), lambda: g2.t().mm(x2)) if need_w else None
-                return gx, gw, gb, None
+        if ctx.mode == "library":
             if act == ACT_SWISH:
                 sg = torch.sigmoid(z)
                 gy = gy * (sg * (1 + z * (1 - sg)))
-                gy2 = gy.reshape(-1, gy.shape[-1])
+            x2, gy2 = x.reshape(-1, x.shape[-1]), gy.reshape(-1, gy.shape[-1])
             gx = gy.matmul(weight) if need_x else None
             gw = _direct_grad(w_param, lambda out: torch.mm(gy2.t(), x2, out=out), lambda: gy2.t().mm(x2)) if need_w else None
             gb = _direct_grad(b_param, lambda out: torch.sum(gy2, 0, out=out), lambda: gy2.sum(0)) if need_b else None
@@ -207,12 +206,29 @@ class _LinearFn(torch.autograd.Function):
         gy2 = gy.reshape(-1, gy.shape[-1]).contiguous()
         M, K = x.shape
         N = weight.shape[0]
-        gx = None
+        st = _lib.stream_ptr()
+        gx = gw = gb = None
+        if ctx.mode == "tile":
+            # g = gy * Swish'(z) and the bias column sums in one launch, then two reduction-split MFMA GEMMs
+            if gy2.data_ptr() % 16:
+                gy2 = gy2.clone()
+            g2 = torch.empty_like(gy2) if act == ACT_SWISH else gy2
+            tb, acc_b, gb = _grad_target(b_param, b_param) if need_b else (None, False, None)
+            if act == ACT_SWISH or need_b:
+                _lib.call("cgv_dense_grad_prepare", _lib.ptr(gy2), _lib.ptr(z), _lib.ptr(g2) if act == ACT_SWISH else None,
+                          _lib.ptr(tb), M, N, act, int(acc_b), st)
+            if need_x:
+                gx = torch.empty(M, K, dtype=torch.float32, device=gy.device)
+                _lib.call("cgv_tile_linear_bwd_input", _lib.ptr(g2), _lib.ptr(weight), _lib.ptr(gx), M, N, K, st)
+                gx = gx.reshape(gy.shape[:-1] + (K,))
+            if need_w:
+                tw, acc_w, gw = _grad_target(w_param, weight)
+                _lib.call("cgv_tile_linear_wgrad", _lib.ptr(g2), _lib.ptr(x), _lib.ptr(tw), M, N, K, int(acc_w), st)
+            return gx, gw, gb, None
         if need_x:
             gx = torch.empty(M, K, dtype=torch.float32, device=gy.device)
             skinny_bwd_input(gy2, z, weight, gx, M, N, K, act)
             gx = gx.reshape(gy.shape[:-1] + (K,))
-        gw = gb = None
         if need_w:
             tw, acc_w, gw = _grad_target(w_param, weight)
             tb, acc_b, gb = _grad_target(b_param, b_param) if need_b else (None, acc_w, None)

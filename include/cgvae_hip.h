@@ -236,6 +236,16 @@ int cgv_skinny_linear_bwd_input(const float* gy, const float* z /*or NULL*/, con
  * Replaces the tensor-op chain of modules.py:16-21's autograd backward plus the bias column sum. */
 int cgv_dense_grad_prepare(const float* gy, const float* z /*or NULL*/, float* g_out /*or NULL*/, float* gb /*or NULL*/,
                            int M, int N, int act, int accumulate, void* stream);
+/* Tiled fp32 GEMMs for the same layers at any row count (atom-level layers, M = atoms of the batch):
+ * the reduction axis of every block is split over its 4 waves, operands are loaded from L2 directly in
+ * MFMA layout, bias + Swish are fused into the forward epilogue.  Need N % 4 == 0, K % 4 == 0 and
+ * 16-byte aligned x / W / g / gx / gW.  g is the activation-corrected upstream gradient
+ * (cgv_dense_grad_prepare).  Exact fp32 FMA chains; deterministic. */
+int cgv_tile_supported(int M, int N, int K);
+int cgv_tile_linear_fwd(const float* x, const float* W, const float* bias /*or NULL*/, float* y, float* z /*or NULL*/, int M,
+                        int N, int K, int act, void* stream);
+int cgv_tile_linear_bwd_input(const float* g, const float* W, float* gx, int M, int N, int K, void* stream);
+int cgv_tile_linear_wgrad(const float* g, const float* x, float* gW, int M, int N, int K, int accumulate, void* stream);
 int cgv_wgrad_record_bytes(void);
 int cgv_wgrad_plan(int M, int N, int K, int* tiles_k /*[host]*/, int* tile_w /*[host]*/, int* n_blocks /*[host]*/);
 int cgv_wgrad_lds_floats(int M, int tile_w);

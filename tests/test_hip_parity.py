@@ -440,7 +440,10 @@ def test_direct_gradient_writes_equal_autograd_accumulation():
 
 # --------------------------------------------------------------------------- skinny GEMMs (bead-level Dense layers)
 @pytest.mark.parametrize("M,N,K", [(12, 600, 600), (12, 5400, 600), (36, 600, 600), (12, 600, 1200), (12, 1800, 600),
-                                   (1, 4, 4), (64, 72, 40), (17, 52, 1000), (3, 5400, 24)])
+                                   (1, 4, 4), (64, 72, 40), (17, 52, 1000), (3, 5400, 24),
+                                   # beyond 64 rows: the reduction-split tile kernels (csrc/tile_gemm.hip)
+                                   (332, 600, 600), (332, 1800, 600), (96, 600, 1200), (65, 52, 1000), (100, 36, 28),
+                                   (1000, 64, 64)])
 def test_skinny_linear_fwd_bwd_vs_fp64(M, N, K):
     gen = torch.Generator().manual_seed(M * 1000 + N + K)
     x = torch.randn(M, K, generator=gen)
@@ -505,13 +508,13 @@ def test_skinny_direct_gradient_accumulation():
     from coarsegrainingvae_amd.trainer import ParamArena
     torch.manual_seed(1)
     lin = cg.primitives.Linear(600, 1800).to(DEV)
-    x1, x2 = torch.randn(12, 600, device=DEV), torch.randn(36, 600, device=DEV)
-    (lin(x1).pow(2).sum() + lin(x2).sum()).backward()
+    x1, x2, x3 = torch.randn(12, 600, device=DEV), torch.randn(36, 600, device=DEV), torch.randn(100, 600, device=DEV)
+    (lin(x1).pow(2).sum() + lin(x2).sum() + lin(x3).pow(2).sum()).backward()       # skinny, skinny, tile
     ref_w, ref_b = lin.weight.grad.clone(), lin.bias.grad.clone()
     arena = ParamArena(list(lin.parameters()))
     arena.g.fill_(float("nan"))
     arena.zero_grad()
-    (lin(x1).pow(2).sum() + lin(x2).sum()).backward()
+    (lin(x1).pow(2).sum() + lin(x2).sum() + lin(x3).pow(2).sum()).backward()
     assert_close(lin.weight.grad, ref_w, "weight grad", 1e-5)
     assert_close(lin.bias.grad, ref_b, "bias grad", 1e-5)
 

@@ -2,5 +2,5 @@
 set -e
 cd "$GRAFT_REPO_ROOT"
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Icoarsegrainingvae_amd/csrc tools/probes/gemm_probe.cpp \
-  coarsegrainingvae_amd/csrc/skinny_gemm.hip coarsegrainingvae_amd/csrc/api.cpp -o /tmp/gemm_probe 2>&1 | grep -v warning | head -5
+  coarsegrainingvae_amd/csrc/skinny_gemm.hip coarsegrainingvae_amd/csrc/tile_gemm.hip coarsegrainingvae_amd/csrc/api.cpp -o /tmp/gemm_probe 2>&1 | grep -v warning | head -5
 /tmp/gemm_probe
