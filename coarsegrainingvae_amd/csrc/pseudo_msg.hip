@@ -52,6 +52,44 @@ __device__ __forceinline__ void load_row(float (&W)[R + 1], const float* __restr
   W[R] = bd[c];
 }
 
+// Filter rows of the block's 64 channels through LDS: Wd[(k F + f0 + c) R + n] is contiguous over (c, n), so a
+// row set is 64 R floats read with coalesced float4 loads (all in flight at once) instead of one 40-byte-
+// strided load per (k, n) -- 99 such loads, 20 cache lines each, were ~1/3 of these kernels' time.
+template <int R>
+__device__ __forceinline__ bool filter_rows_stageable(const float* Wd, int F) {
+  return ((F * R) & 3) == 0 && ((64 * R) & 3) == 0 && (reinterpret_cast<uintptr_t>(Wd) & 15) == 0;
+}
+template <int R, int NK>
+__device__ __forceinline__ void stage_filter_rows(float* __restrict__ wt, const float* __restrict__ Wd, const int (&ks)[NK],
+                                                  int F, int f0, int lane) {
+  constexpr int NT = (64 * R / 4 + 63) / 64;
+  const int n4 = min(64, F - f0) * R / 4;
+  float4 tmp[NK][NT];
+#pragma unroll
+  for (int kk = 0; kk < NK; ++kk) {
+    const float4* src = reinterpret_cast<const float4*>(Wd + ((size_t)ks[kk] * F + f0) * R);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int idx = lane + 64 * t;
+      tmp[kk][t] = idx < n4 ? src[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+#pragma unroll
+  for (int kk = 0; kk < NK; ++kk)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int idx = lane + 64 * t;
+      if (idx < 64 * R / 4) reinterpret_cast<float4*>(wt + kk * 64 * R)[idx] = tmp[kk][t];
+    }
+  __syncthreads();
+}
+template <int R>
+__device__ __forceinline__ void read_row(float (&W)[R + 1], const float* __restrict__ wt_k, int cl, float bias) {
+#pragma unroll
+  for (int n = 0; n < R; ++n) W[n] = wt_k[cl * R + n];
+  W[R] = bias;
+}
+
 // ------------------------------------------------------------------ forward: grid (N, ceil(F/64)), one wave per block
 template <int R>
 __global__ __launch_bounds__(64) void pseudo_fwd_k(const float* __restrict__ phi, const float* __restrict__ s,
@@ -68,12 +106,21 @@ __global__ __launch_bounds__(64) void pseudo_fwd_k(const float* __restrict__ phi
   const bool live = f_raw < F;
   const int f = live ? f_raw : F - 1;
   float W[9][R + 1];
+  __shared__ __attribute__((aligned(16))) float wt[9 * 64 * R];
+  if (filter_rows_stageable<R>(Wd, F)) {
+    const int ks[9] = {0, 1, 2, 3, 4, 5, 6, 7, 8};
+    stage_filter_rows<R, 9>(wt, Wd, ks, F, blockIdx.y * 64, threadIdx.x);
 #pragma unroll
-  for (int k = 0; k < 9; ++k) load_row<R>(W[k], Wd, bd, k * F + f);
+    for (int k = 0; k < 9; ++k) read_row<R>(W[k], wt + k * 64 * R, f - blockIdx.y * 64, bd[k * F + f]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) load_row<R>(W[k], Wd, bd, k * F + f);
+  }
   const float s_i = s[(size_t)i * F + f], sb_i = sbar[(size_t)i * F + f];
   const v3 v_i = ldv(v + ((size_t)i * F + f) * 3), vb_i = ldv(vbar + ((size_t)i * F + f) * 3);
   float ah = 0.f, ahb = 0.f;
   v3 av{0.f, 0.f, 0.f}, avb{0.f, 0.f, 0.f};
+#pragma unroll 2
   for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
     const float* __restrict__ g = geom + (size_t)e * GS;
     const int j = src[e];
@@ -125,18 +172,32 @@ __global__ __launch_bounds__(64) void pseudo_bwd_recv_k(const float* __restrict_
   const int f = live ? f_raw : F - 1;
   // filters needed on the receiver side: k = 0, 3, 4, 6, 7, 8
   float W0[R + 1], W3[R + 1], W4[R + 1], W6[R + 1], W7[R + 1], W8[R + 1];
-  load_row<R>(W0, Wd, bd, 0 * F + f);
-  load_row<R>(W3, Wd, bd, 3 * F + f);
-  load_row<R>(W4, Wd, bd, 4 * F + f);
-  load_row<R>(W6, Wd, bd, 6 * F + f);
-  load_row<R>(W7, Wd, bd, 7 * F + f);
-  load_row<R>(W8, Wd, bd, 8 * F + f);
+  __shared__ __attribute__((aligned(16))) float wt[6 * 64 * R];
+  if (filter_rows_stageable<R>(Wd, F)) {
+    const int ks[6] = {0, 3, 4, 6, 7, 8};
+    stage_filter_rows<R, 6>(wt, Wd, ks, F, blockIdx.y * 64, threadIdx.x);
+    const int cl = f - blockIdx.y * 64;
+    read_row<R>(W0, wt + 0 * 64 * R, cl, bd[0 * F + f]);
+    read_row<R>(W3, wt + 1 * 64 * R, cl, bd[3 * F + f]);
+    read_row<R>(W4, wt + 2 * 64 * R, cl, bd[4 * F + f]);
+    read_row<R>(W6, wt + 3 * 64 * R, cl, bd[6 * F + f]);
+    read_row<R>(W7, wt + 4 * 64 * R, cl, bd[7 * F + f]);
+    read_row<R>(W8, wt + 5 * 64 * R, cl, bd[8 * F + f]);
+  } else {
+    load_row<R>(W0, Wd, bd, 0 * F + f);
+    load_row<R>(W3, Wd, bd, 3 * F + f);
+    load_row<R>(W4, Wd, bd, 4 * F + f);
+    load_row<R>(W6, Wd, bd, 6 * F + f);
+    load_row<R>(W7, Wd, bd, 7 * F + f);
+    load_row<R>(W8, Wd, bd, 8 * F + f);
+  }
   const size_t nf = (size_t)i * F + f;
   const float gh_i = gh ? gh[nf] : 0.f, ghb_i = ghb ? ghb[nf] : 0.f;
   const v3 gv_i = gv ? ldv(gv + nf * 3) : v3{0.f, 0.f, 0.f};
   const v3 gvb_i = gvb ? ldv(gvb + nf * 3) : v3{0.f, 0.f, 0.f};
   float as = 0.f, asb = 0.f;
   v3 av{0.f, 0.f, 0.f}, avb{0.f, 0.f, 0.f};
+#pragma unroll 2
   for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
     const float* __restrict__ g = geom + (size_t)e * GS;
     const int j = src[e];
@@ -169,9 +230,9 @@ __global__ __launch_bounds__(64) void pseudo_bwd_recv_k(const float* __restrict_
 }
 
 // ------------------------------------------------------------------ backward pass B (source side + filter grads)
-// grid (n_chunks, ceil(F/64)); one wave per block walks its chunk of source nodes; the 9*(R+1)
-// filter-gradient accumulators of each channel live in a private LDS column (no conflicts:
-// lane l only ever touches bank l), everything else in registers.
+// grid (n_chunks, ceil(F/64)); one wave per block walks its chunk of source nodes.  Everything lives in
+// registers, including the 9*(R+1) filter-gradient accumulators of the lane's channel (a lone wave per
+// SIMD may use the whole 512-VGPR file; in LDS they cost two LDS operations per FMA).
 template <int R>
 __global__ __launch_bounds__(64) void pseudo_bwd_src_k(
     const float* __restrict__ phi, const float* __restrict__ s, const float* __restrict__ sbar,
@@ -181,16 +242,35 @@ __global__ __launch_bounds__(64) void pseudo_bwd_src_k(
     const float* __restrict__ gv, const float* __restrict__ gvb, float* __restrict__ g_phi,
     float* __restrict__ g_v, float* __restrict__ g_vbar, float* __restrict__ part, int F, int N, int nodes_per_chunk) {
   constexpr int GS = geom_stride(R), U = geom_unit_offset(R);
-  __shared__ float G[9 * (R + 1) * 64];
   const int lane = threadIdx.x;
   const int f_raw = blockIdx.y * 64 + lane;
   const bool live = f_raw < F;
   const int f = live ? f_raw : F - 1;
-  float W[9][R + 1];
+  // filter rows stay in LDS here (row c of set k at wt[(k*64 + c) * R]): with the 99 gradient accumulators in
+  // registers there is no room for another 99 weights without accumulator-register shuffling
+  float G[9][R + 1], bias[9];
+  __shared__ __attribute__((aligned(16))) float wt[9 * 64 * R];
+  const int cl = lane;                       // private row: staged from global, or copied there by this lane
+  if (filter_rows_stageable<R>(Wd, F)) {
+    const int ks[9] = {0, 1, 2, 3, 4, 5, 6, 7, 8};
+    stage_filter_rows<R, 9>(wt, Wd, ks, F, blockIdx.y * 64, lane);
+  }
+  const bool staged = filter_rows_stageable<R>(Wd, F);
+  const int rl = staged ? f - blockIdx.y * 64 : lane;
+  if (!staged) {
 #pragma unroll
-  for (int k = 0; k < 9; ++k) load_row<R>(W[k], Wd, bd, k * F + f);
+    for (int k = 0; k < 9; ++k)
 #pragma unroll
-  for (int t = 0; t < 9 * (R + 1); ++t) G[t * 64 + lane] = 0.f;
+      for (int n = 0; n < R; ++n) wt[(k * 64 + lane) * R + n] = Wd[((size_t)k * F + f) * R + n];
+    __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) bias[k] = bd[k * F + f];
+  (void)cl;
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int n = 0; n <= R; ++n) G[k][n] = 0.f;
 
   const int n_beg = blockIdx.x * nodes_per_chunk, n_end = min(n_beg + nodes_per_chunk, N);
   for (int j = n_beg; j < n_end; ++j) {
@@ -201,6 +281,7 @@ __global__ __launch_bounds__(64) void pseudo_bwd_src_k(
     const size_t jf = (size_t)j * F + f;
     const v3 v_j = ldv(v + jf * 3), vb_j = ldv(vbar + jf * 3);
     v3 av{0.f, 0.f, 0.f}, avb{0.f, 0.f, 0.f};
+#pragma unroll 2
     for (int e = rowptr[j]; e < rowptr[j + 1]; ++e) {
       const float* __restrict__ g = geom + (size_t)e * GS;
       const int i = dst[e];
@@ -224,11 +305,15 @@ __global__ __launch_bounds__(64) void pseudo_bwd_src_k(
       float w[9];
 #pragma unroll
       for (int k = 0; k < 9; ++k) {
-        w[k] = filt<R>(W[k], g);
+        const float* __restrict__ wr = wt + (k * 64 + rl) * R;
+        float wk = bias[k] * g[R];
+#pragma unroll
+        for (int n = 0; n < R; ++n) wk = fmaf(wr[n], g[n], wk);
+        w[k] = wk;
         a[k] = fmaf(gq[k], w[k], a[k]);
         const float t = gq[k] * p[k];
 #pragma unroll
-        for (int n = 0; n <= R; ++n) G[(k * (R + 1) + n) * 64 + lane] += t * g[n];
+        for (int n = 0; n <= R; ++n) G[k][n] = fmaf(t, g[n], G[k][n]);
       }
       const float q2 = p[2] * w[2], q3 = p[3] * w[3], q4 = p[4] * w[4], q5 = p[5] * w[5], q6 = p[6] * w[6],
                   q7 = p[7] * w[7], q8 = p[8] * w[8];
@@ -253,7 +338,9 @@ __global__ __launch_bounds__(64) void pseudo_bwd_src_k(
   if (live) {
     float* __restrict__ out = part + (size_t)blockIdx.x * 9 * (R + 1) * F;
 #pragma unroll
-    for (int t = 0; t < 9 * (R + 1); ++t) out[(size_t)t * F + f] = G[t * 64 + lane];
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+      for (int n = 0; n <= R; ++n) out[(size_t)(k * (R + 1) + n) * F + f] = G[k][n];
   }
 }
 

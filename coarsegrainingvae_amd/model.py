@@ -222,13 +222,9 @@ class CGequiVAE(nn.Module):
             chan = self.CG2ChannelIdx(mapping)
             plan = EdgePlan.from_mapping(mapping, cg_xyz.shape[0])
         if not self.equivariant:
-            dv = self.euclidean(cg_s).reshape(cg_s.shape[0], cg_s.shape[1], 3)
-            xyz_rel = dv[mapping, chan, :]
-        else:
-            xyz_rel = cg_v[mapping, chan, :]
-        if self.offset:
-            xyz_rel = xyz_rel - ops.scatter_mean(xyz_rel, mapping, plan=plan)[mapping]
-        return xyz_rel + cg_xyz[mapping]
+            cg_v = self.euclidean(cg_s).reshape(cg_s.shape[0], cg_s.shape[1], 3)
+        # xyz_rel = cg_v[mapping, chan]; -= scatter_mean(xyz_rel, mapping)[mapping] (offset); += cg_xyz[mapping]
+        return ops.reconstruct(cg_v, cg_xyz, chan, plan, self.offset)
 
     def forward(self, batch, eps: Optional[torch.Tensor] = None):
         z, cg_z, xyz, cg_xyz, nbr_list, CG_nbr_list, mapping, num_CGs = self.get_inputs(batch)

@@ -160,6 +160,40 @@ def scatter_mean(src: torch.Tensor, index: torch.Tensor, dim: int = 0, dim_size:
     return segment_reduce(src, plan or _index_plan(index, dim_size), mean=True)
 
 
+# ----------------------------------------------------------------------------- decoder tail
+class _Reconstruct(torch.autograd.Function):
+    """xyz_recon from the bead vector channels (cgvae.py:462-481) in one launch each way."""
+
+    @staticmethod
+    def forward(ctx, v, cg_xyz, chan, plan: EdgePlan, offset: bool):
+        v, cg_xyz = _c(v), _c(cg_xyz)
+        n_beads, F = v.shape[0], v.shape[1]
+        n_atoms = chan.shape[0]
+        xyz = torch.empty(n_atoms, 3, dtype=torch.float32, device=v.device)
+        _lib.call("cgv_reconstruct_fwd", _lib.ptr(v), _lib.ptr(cg_xyz), _lib.ptr(plan.rowptr_d), _lib.ptr(plan.eid_d),
+                  _lib.ptr(chan), n_beads, F, int(offset), _lib.ptr(xyz), _lib.stream_ptr())
+        ctx.plan, ctx.chan, ctx.offset, ctx.shape = plan, chan, offset, (n_beads, F)
+        return xyz
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        n_beads, F = ctx.shape
+        g_v = torch.empty(n_beads, F, 3, dtype=torch.float32, device=g.device)
+        g_cg = torch.empty(n_beads, 3, dtype=torch.float32, device=g.device) if ctx.needs_input_grad[1] else None
+        plan = ctx.plan
+        _lib.call("cgv_reconstruct_bwd", _lib.ptr(g), _lib.ptr(plan.rowptr_d), _lib.ptr(plan.eid_d), _lib.ptr(ctx.chan),
+                  n_beads, F, int(ctx.offset), _lib.ptr(g_v), _lib.ptr(g_cg), _lib.stream_ptr())
+        return g_v, g_cg, None, None, None
+
+
+def reconstruct(v, cg_xyz, chan, plan: EdgePlan, offset: bool = True):
+    """``v[mapping, chan] - scatter_mean(...)[mapping] + cg_xyz[mapping]`` (``plan`` = EdgePlan.from_mapping(mapping))."""
+    if int(plan.n_dst) != v.shape[0] or chan.dtype != torch.int64 or not chan.is_contiguous():
+        raise ValueError("reconstruct: plan / chan do not match the bead tensor")
+    return _Reconstruct.apply(v, cg_xyz, chan, plan, bool(offset))
+
+
 # ----------------------------------------------------------------------------- K3
 class _PseudoMessage(torch.autograd.Function):
     """dh, dhbar, dv, dvbar of EquiMessagePsuedo from phi = inv_dense(s) (conv.py:190-242)."""

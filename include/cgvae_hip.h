@@ -252,6 +252,18 @@ int cgv_wgrad_lds_floats(int M, int tile_w);
 int cgv_grouped_wgrad(const void* table_dev, int n_problems, int total_blocks, int max_lds_floats, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Decoder tail (cgvae.py:462-481):  xyz[a] = v[mapping[a], chan[a], :] - [offset] mean over the bead of the
+ * same + cg_xyz[mapping[a]].  rowptr [n_beads+1] / atom [n_atoms]: bead -> atoms CSR (the dst-sorted view of
+ * the contraction plan: cgv_csr_build on mapping, rowptr_d / eid_d); chan int64 [n_atoms] = rank of the atom
+ * inside its bead (CG2ChannelIdx, cgvae.py:451-460), chan < n_feat.  bwd writes ALL of g_v [n_beads,F,3]
+ * (zeros outside the addressed slots) and, when not NULL, g_cg_xyz [n_beads,3].
+ * ------------------------------------------------------------------------------------- */
+int cgv_reconstruct_fwd(const float* v, const float* cg_xyz, const int32_t* rowptr, const int32_t* atom, const int64_t* chan,
+                        int n_beads, int n_feat, int offset, float* xyz /*[n_atoms,3]*/, void* stream);
+int cgv_reconstruct_bwd(const float* g_xyz, const int32_t* rowptr, const int32_t* atom, const int64_t* chan, int n_beads,
+                        int n_feat, int offset, float* g_v, float* g_cg_xyz /*or NULL*/, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Fused ELBO loss -- replaces KL (scripts/utils.py:81-86, incl. its (mu1-mu2)^2 / std2 term) and the
  * loss assembly of scripts/utils.py:117-141:  loss = recon + beta*KL + gamma*graph with
  *   recon = mean((xr - x)^2),  graph = mean_b((|xr_a - xr_b|_eps - |x_a - x_b|_eps)^2), eps = 1e-6 inside the sqrt.

@@ -438,6 +438,40 @@ def test_direct_gradient_writes_equal_autograd_accumulation():
     assert_close(lin.bias.grad, ref_b, "bias grad", 1e-5)
 
 
+# --------------------------------------------------------------------------- decoder tail
+@pytest.mark.parametrize("offset", [True, False])
+def test_reconstruct_matches_indexing_ops(offset):
+    """cgvae.py:462-481 as tensor ops (advanced-index gathers + scatter_mean) vs the fused launch, values and
+    gradients; ragged beads including an empty one."""
+    from coarsegrainingvae_amd.graph import EdgePlan
+    gen = torch.Generator().manual_seed(5)
+    sizes = [7, 1, 0, 23, 70, 4]                      # atoms per bead (bead 2 is empty, bead 4 spans > one wave)
+    n_beads, F = len(sizes), 96
+    mapping = torch.cat([torch.full((n,), b, dtype=torch.int64) for b, n in enumerate(sizes)])
+    perm = torch.randperm(mapping.numel(), generator=gen)
+    mapping = mapping[perm].to(DEV)                   # atoms of a bead are not contiguous in general
+    n_atoms = mapping.numel()
+    model_chan = cg.CGequiVAE.CG2ChannelIdx(None, mapping)
+    v = torch.randn(n_beads, F, 3, generator=gen).to(DEV)
+    cg_xyz = torch.randn(n_beads, 3, generator=gen).to(DEV)
+    gout = torch.randn(n_atoms, 3, generator=gen).to(DEV)
+    vd, cd = v.double().requires_grad_(True), cg_xyz.double().requires_grad_(True)
+    rel = vd[mapping, model_chan, :]
+    if offset:
+        cnt = torch.bincount(mapping, minlength=n_beads).clamp(min=1).double().unsqueeze(1)
+        mean = torch.zeros(n_beads, 3, dtype=torch.float64, device=DEV).index_add_(0, mapping, rel) / cnt
+        rel = rel - mean[mapping]
+    ref = rel + cd[mapping]
+    ref.backward(gout.double())
+    plan = EdgePlan.from_mapping(mapping, n_beads)
+    vg, cgx = v.clone().requires_grad_(True), cg_xyz.clone().requires_grad_(True)
+    out = cg.ops.reconstruct(vg, cgx, model_chan, plan, offset)
+    out.backward(gout)
+    assert_close(out, ref, "xyz_recon", 1e-6)
+    assert_close(vg.grad, vd.grad, "g_v", 1e-6)
+    assert_close(cgx.grad, cd.grad, "g_cg_xyz", 1e-6)
+
+
 # --------------------------------------------------------------------------- skinny GEMMs (bead-level Dense layers)
 @pytest.mark.parametrize("M,N,K", [(12, 600, 600), (12, 5400, 600), (36, 600, 600), (12, 600, 1200), (12, 1800, 600),
                                    (1, 4, 4), (64, 72, 40), (17, 52, 1000), (3, 5400, 24),
