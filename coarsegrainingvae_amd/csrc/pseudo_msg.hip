@@ -90,68 +90,69 @@ __device__ __forceinline__ void read_row(float (&W)[R + 1], const float* __restr
   W[R] = bias;
 }
 
-// ------------------------------------------------------------------ forward: grid (N, ceil(F/64)), one wave per block
+// ------------------------------------------------------------------ forward: grid (N, ceil(F/64)), 9 waves per block
+// Wave k owns filter k: q_k = phi[j, kF+f] w_k and the one output term that carries it (k = 0: T_h and the
+// filter-free T_hbar; k = 1..4: the four terms of T_v; k = 5..8: those of T_vb).  The waves' vectors meet in LDS
+// in wave order.  (One wave doing all nine filters: 99 weights per lane, 10.4 us; this: see DESIGN.md.)
 template <int R>
-__global__ __launch_bounds__(64) void pseudo_fwd_k(const float* __restrict__ phi, const float* __restrict__ s,
-                                                   const float* __restrict__ sbar, const float* __restrict__ v,
-                                                   const float* __restrict__ vbar, const float* __restrict__ geom,
-                                                   const int* __restrict__ rowptr, const int* __restrict__ src,
-                                                   const float* __restrict__ Wd, const float* __restrict__ bd,
-                                                   float* __restrict__ dh, float* __restrict__ dhbar,
-                                                   float* __restrict__ dv, float* __restrict__ dvbar, int F,
-                                                   int residual) {
+__global__ __launch_bounds__(576) void pseudo_fwd_k(const float* __restrict__ phi, const float* __restrict__ s,
+                                                    const float* __restrict__ sbar, const float* __restrict__ v,
+                                                    const float* __restrict__ vbar, const float* __restrict__ geom,
+                                                    const int* __restrict__ rowptr, const int* __restrict__ src,
+                                                    const float* __restrict__ Wd, const float* __restrict__ bd,
+                                                    float* __restrict__ dh, float* __restrict__ dhbar,
+                                                    float* __restrict__ dv, float* __restrict__ dvbar, int F,
+                                                    int residual) {
   constexpr int GS = geom_stride(R), U = geom_unit_offset(R);
+  __shared__ float red[8][3][64];
   const int i = blockIdx.x;
-  const int f_raw = blockIdx.y * 64 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int f_raw = blockIdx.y * 64 + lane;
   const bool live = f_raw < F;
   const int f = live ? f_raw : F - 1;
-  float W[9][R + 1];
-  __shared__ __attribute__((aligned(16))) float wt[9 * 64 * R];
-  if (filter_rows_stageable<R>(Wd, F)) {
-    const int ks[9] = {0, 1, 2, 3, 4, 5, 6, 7, 8};
-    stage_filter_rows<R, 9>(wt, Wd, ks, F, blockIdx.y * 64, threadIdx.x);
-#pragma unroll
-    for (int k = 0; k < 9; ++k) read_row<R>(W[k], wt + k * 64 * R, f - blockIdx.y * 64, bd[k * F + f]);
-  } else {
-#pragma unroll
-    for (int k = 0; k < 9; ++k) load_row<R>(W[k], Wd, bd, k * F + f);
-  }
-  const float s_i = s[(size_t)i * F + f], sb_i = sbar[(size_t)i * F + f];
-  const v3 v_i = ldv(v + ((size_t)i * F + f) * 3), vb_i = ldv(vbar + ((size_t)i * F + f) * 3);
+  float W[R + 1];
+  load_row<R>(W, Wd, bd, k * F + f);
+  const size_t nf = (size_t)i * F + f;
+  const float s_i = s[nf], sb_i = sbar[nf];
+  const v3 v_i = ldv(v + nf * 3), vb_i = ldv(vbar + nf * 3);
   float ah = 0.f, ahb = 0.f;
-  v3 av{0.f, 0.f, 0.f}, avb{0.f, 0.f, 0.f};
+  v3 acc{0.f, 0.f, 0.f};
 #pragma unroll 2
   for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
     const float* __restrict__ g = geom + (size_t)e * GS;
     const int j = src[e];
-    const float* __restrict__ pr = phi + (size_t)j * 9 * F + f;
-    float q[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) q[k] = pr[(size_t)k * F] * filt<R>(W[k], g);
-    const v3 v_j = ldv(v + ((size_t)j * F + f) * 3), vb_j = ldv(vbar + ((size_t)j * F + f) * 3);
-    const v3 u{g[U], g[U + 1], g[U + 2]};
-    ah = fmaf(q[0], s_i, ah);
-    ahb += dot(v_i, vb_j);
-    axpy(av, q[1], u);
-    axpy(av, q[2], v_j);
-    axpy(av, q[3], cross(v_i, vb_j));
-    axpy(av, q[4] * sb_i, vb_j);
-    axpy(avb, q[5], vb_j);
-    axpy(avb, q[6] * sb_i, v_j);
-    axpy(avb, q[7], cross(v_i, v_j));
-    axpy(avb, q[8], cross(vb_i, vb_j));
+    const float q = phi[(size_t)j * 9 * F + (size_t)k * F + f] * filt<R>(W, g);
+    const size_t jf = ((size_t)j * F + f) * 3;
+    switch (k) {                                     // wave-uniform
+      case 0: ah = fmaf(q, s_i, ah); ahb += dot(v_i, ldv(vbar + jf)); break;
+      case 1: axpy(acc, q, v3{g[U], g[U + 1], g[U + 2]}); break;
+      case 2: axpy(acc, q, ldv(v + jf)); break;
+      case 3: axpy(acc, q, cross(v_i, ldv(vbar + jf))); break;
+      case 4: axpy(acc, q * sb_i, ldv(vbar + jf)); break;
+      case 5: axpy(acc, q, ldv(vbar + jf)); break;
+      case 6: axpy(acc, q * sb_i, ldv(v + jf)); break;
+      case 7: axpy(acc, q, cross(v_i, ldv(v + jf))); break;
+      default: axpy(acc, q, cross(vb_i, ldv(vbar + jf))); break;
+    }
   }
+  if (k > 0) { red[k - 1][0][lane] = acc.x; red[k - 1][1][lane] = acc.y; red[k - 1][2][lane] = acc.z; }
+  __syncthreads();
+  if (k != 0 || !live) return;
+  v3 av{0.f, 0.f, 0.f}, avb{0.f, 0.f, 0.f};
+#pragma unroll
+  for (int w = 0; w < 4; ++w) { av.x += red[w][0][lane]; av.y += red[w][1][lane]; av.z += red[w][2][lane]; }
+#pragma unroll
+  for (int w = 4; w < 8; ++w) { avb.x += red[w][0][lane]; avb.y += red[w][1][lane]; avb.z += red[w][2][lane]; }
   if (residual) {      // emit the updated state S + dS, ... directly (cgvae.py:108-111): the receiver's values are in registers
     ah += s_i; ahb += sb_i;
     av.x += v_i.x; av.y += v_i.y; av.z += v_i.z;
     avb.x += vb_i.x; avb.y += vb_i.y; avb.z += vb_i.z;
   }
-  if (live) {
-    dh[(size_t)i * F + f] = ah;
-    dhbar[(size_t)i * F + f] = ahb;
-    st3(dv + ((size_t)i * F + f) * 3, av.x, av.y, av.z);
-    st3(dvbar + ((size_t)i * F + f) * 3, avb.x, avb.y, avb.z);
-  }
+  dh[nf] = ah;
+  dhbar[nf] = ahb;
+  st3(dv + nf * 3, av.x, av.y, av.z);
+  st3(dvbar + nf * 3, avb.x, avb.y, avb.z);
 }
 
 // ------------------------------------------------------------------ backward pass A (receiver side)
@@ -230,11 +231,13 @@ __global__ __launch_bounds__(64) void pseudo_bwd_recv_k(const float* __restrict_
 }
 
 // ------------------------------------------------------------------ backward pass B (source side + filter grads)
-// grid (n_chunks, ceil(F/64)); one wave per block walks its chunk of source nodes.  Everything lives in
-// registers, including the 9*(R+1) filter-gradient accumulators of the lane's channel (a lone wave per
-// SIMD may use the whole 512-VGPR file; in LDS they cost two LDS operations per FMA).
+// grid (n_chunks, ceil(F/64)), 9 waves per block: wave k owns filter k -- its weight row, its g_phi slot, its
+// (R+1) filter-gradient accumulators and the terms of the source-side vector gradients that carry q_k.  The
+// one-wave version kept 99 accumulators + 99 weights per lane and walked the edges alone (14 us per call on
+// the 60-edge bead graph, the longest kernel of a decoder layer's backward); here a lane holds 2(R+1) values
+// and nine waves hide each other's gather latency.  The waves' partial vector sums meet in LDS in wave order.
 template <int R>
-__global__ __launch_bounds__(64) void pseudo_bwd_src_k(
+__global__ __launch_bounds__(576) void pseudo_bwd_src_k(
     const float* __restrict__ phi, const float* __restrict__ s, const float* __restrict__ sbar,
     const float* __restrict__ v, const float* __restrict__ vbar, const float* __restrict__ geom,
     const int* __restrict__ rowptr, const int* __restrict__ dst, const float* __restrict__ Wd,
@@ -242,105 +245,82 @@ __global__ __launch_bounds__(64) void pseudo_bwd_src_k(
     const float* __restrict__ gv, const float* __restrict__ gvb, float* __restrict__ g_phi,
     float* __restrict__ g_v, float* __restrict__ g_vbar, float* __restrict__ part, int F, int N, int nodes_per_chunk) {
   constexpr int GS = geom_stride(R), U = geom_unit_offset(R);
-  const int lane = threadIdx.x;
+  __shared__ float red[8][6][64];                    // waves 1..8: (av, avb) partials of the current node
+  const int lane = threadIdx.x & 63;
+  const int k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);          // this wave's filter
   const int f_raw = blockIdx.y * 64 + lane;
   const bool live = f_raw < F;
   const int f = live ? f_raw : F - 1;
-  // filter rows stay in LDS here (row c of set k at wt[(k*64 + c) * R]): with the 99 gradient accumulators in
-  // registers there is no room for another 99 weights without accumulator-register shuffling
-  float G[9][R + 1], bias[9];
-  __shared__ __attribute__((aligned(16))) float wt[9 * 64 * R];
-  const int cl = lane;                       // private row: staged from global, or copied there by this lane
-  if (filter_rows_stageable<R>(Wd, F)) {
-    const int ks[9] = {0, 1, 2, 3, 4, 5, 6, 7, 8};
-    stage_filter_rows<R, 9>(wt, Wd, ks, F, blockIdx.y * 64, lane);
-  }
-  const bool staged = filter_rows_stageable<R>(Wd, F);
-  const int rl = staged ? f - blockIdx.y * 64 : lane;
-  if (!staged) {
+  float W[R + 1], G[R + 1];
+  load_row<R>(W, Wd, bd, k * F + f);
 #pragma unroll
-    for (int k = 0; k < 9; ++k)
-#pragma unroll
-      for (int n = 0; n < R; ++n) wt[(k * 64 + lane) * R + n] = Wd[((size_t)k * F + f) * R + n];
-    __syncthreads();
-  }
-#pragma unroll
-  for (int k = 0; k < 9; ++k) bias[k] = bd[k * F + f];
-  (void)cl;
-#pragma unroll
-  for (int k = 0; k < 9; ++k)
-#pragma unroll
-    for (int n = 0; n <= R; ++n) G[k][n] = 0.f;
+  for (int n = 0; n <= R; ++n) G[n] = 0.f;
 
   const int n_beg = blockIdx.x * nodes_per_chunk, n_end = min(n_beg + nodes_per_chunk, N);
   for (int j = n_beg; j < n_end; ++j) {
-    const float* __restrict__ pr = phi + (size_t)j * 9 * F + f;
-    float p[9], a[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) { p[k] = pr[(size_t)k * F]; a[k] = 0.f; }
+    const float p = phi[(size_t)j * 9 * F + (size_t)k * F + f];
     const size_t jf = (size_t)j * F + f;
     const v3 v_j = ldv(v + jf * 3), vb_j = ldv(vbar + jf * 3);
+    float a = 0.f;
     v3 av{0.f, 0.f, 0.f}, avb{0.f, 0.f, 0.f};
 #pragma unroll 2
     for (int e = rowptr[j]; e < rowptr[j + 1]; ++e) {
       const float* __restrict__ g = geom + (size_t)e * GS;
       const int i = dst[e];
       const size_t nf = (size_t)i * F + f;
-      const float gh_i = gh ? gh[nf] : 0.f, ghb_i = ghb ? ghb[nf] : 0.f;
-      const v3 gv_i = gv ? ldv(gv + nf * 3) : v3{0.f, 0.f, 0.f};
-      const v3 gvb_i = gvb ? ldv(gvb + nf * 3) : v3{0.f, 0.f, 0.f};
-      const float s_i = s[nf], sb_i = sbar[nf];
-      const v3 v_i = ldv(v + nf * 3), vb_i = ldv(vbar + nf * 3);
-      const v3 u{g[U], g[U + 1], g[U + 2]};
-      float gq[9];
-      gq[0] = gh_i * s_i;
-      gq[1] = dot(gv_i, u);
-      gq[2] = dot(gv_i, v_j);
-      gq[3] = dot(gv_i, cross(v_i, vb_j));
-      gq[4] = sb_i * dot(gv_i, vb_j);
-      gq[5] = dot(gvb_i, vb_j);
-      gq[6] = sb_i * dot(gvb_i, v_j);
-      gq[7] = dot(gvb_i, cross(v_i, v_j));
-      gq[8] = dot(gvb_i, cross(vb_i, vb_j));
-      float w[9];
-#pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        const float* __restrict__ wr = wt + (k * 64 + rl) * R;
-        float wk = bias[k] * g[R];
-#pragma unroll
-        for (int n = 0; n < R; ++n) wk = fmaf(wr[n], g[n], wk);
-        w[k] = wk;
-        a[k] = fmaf(gq[k], w[k], a[k]);
-        const float t = gq[k] * p[k];
-#pragma unroll
-        for (int n = 0; n <= R; ++n) G[k][n] = fmaf(t, g[n], G[k][n]);
+      const v3 zero{0.f, 0.f, 0.f};
+      float gq = 0.f;
+      v3 cav = zero, cavb = zero;                    // source-side vectors that get multiplied by q_k
+      switch (k) {                                   // wave-uniform
+        case 0: gq = (gh ? gh[nf] : 0.f) * s[nf]; break;
+        case 1: { const v3 gv_i = gv ? ldv(gv + nf * 3) : zero; gq = dot(gv_i, v3{g[U], g[U + 1], g[U + 2]}); break; }
+        case 2: { const v3 gv_i = gv ? ldv(gv + nf * 3) : zero; gq = dot(gv_i, v_j); cav = gv_i; break; }
+        case 3: { const v3 gv_i = gv ? ldv(gv + nf * 3) : zero; const v3 v_i = ldv(v + nf * 3);
+                  gq = dot(gv_i, cross(v_i, vb_j)); cavb = cross(gv_i, v_i); break; }
+        case 4: { const v3 gv_i = gv ? ldv(gv + nf * 3) : zero; const float sb_i = sbar[nf];
+                  gq = sb_i * dot(gv_i, vb_j); cavb = v3{sb_i * gv_i.x, sb_i * gv_i.y, sb_i * gv_i.z}; break; }
+        case 5: { const v3 gvb_i = gvb ? ldv(gvb + nf * 3) : zero; gq = dot(gvb_i, vb_j); cavb = gvb_i; break; }
+        case 6: { const v3 gvb_i = gvb ? ldv(gvb + nf * 3) : zero; const float sb_i = sbar[nf];
+                  gq = sb_i * dot(gvb_i, v_j); cav = v3{sb_i * gvb_i.x, sb_i * gvb_i.y, sb_i * gvb_i.z}; break; }
+        case 7: { const v3 gvb_i = gvb ? ldv(gvb + nf * 3) : zero; const v3 v_i = ldv(v + nf * 3);
+                  gq = dot(gvb_i, cross(v_i, v_j)); cav = cross(gvb_i, v_i); break; }
+        default: { const v3 gvb_i = gvb ? ldv(gvb + nf * 3) : zero; const v3 vb_i = ldv(vbar + nf * 3);
+                   gq = dot(gvb_i, cross(vb_i, vb_j)); cavb = cross(gvb_i, vb_i); break; }
       }
-      const float q2 = p[2] * w[2], q3 = p[3] * w[3], q4 = p[4] * w[4], q5 = p[5] * w[5], q6 = p[6] * w[6],
-                  q7 = p[7] * w[7], q8 = p[8] * w[8];
-      axpy(av, q2, gv_i);
-      axpy(av, q6 * sb_i, gvb_i);
-      axpy(av, q7, cross(gvb_i, v_i));
-      axpy(avb, ghb_i, v_i);
-      axpy(avb, q3, cross(gv_i, v_i));
-      axpy(avb, q4 * sb_i, gv_i);
-      axpy(avb, q5, gvb_i);
-      axpy(avb, q8, cross(gvb_i, vb_i));
-    }
-    if (live) {
-      float* __restrict__ gp = g_phi + (size_t)j * 9 * F + f;
+      const float w = filt<R>(W, g);
+      a = fmaf(gq, w, a);
+      const float t = gq * p;
 #pragma unroll
-      for (int k = 0; k < 9; ++k) gp[(size_t)k * F] = a[k];
-      const v3 r0 = ldv(g_v + jf * 3), r1 = ldv(g_vbar + jf * 3);          // pass A's receiver-side part
-      st3(g_v + jf * 3, r0.x + av.x, r0.y + av.y, r0.z + av.z);
-      st3(g_vbar + jf * 3, r1.x + avb.x, r1.y + avb.y, r1.z + avb.z);
+      for (int n = 0; n <= R; ++n) G[n] = fmaf(t, g[n], G[n]);
+      const float q = p * w;
+      axpy(av, q, cav);
+      axpy(avb, q, cavb);
+      if (k == 0 && ghb) axpy(avb, ghb[nf], ldv(v + nf * 3));            // the filter-free term ghb_i v_i
     }
+    if (k > 0) {
+      float* r = &red[k - 1][0][lane];
+      r[0] = av.x; r[64] = av.y; r[128] = av.z; r[192] = avb.x; r[256] = avb.y; r[320] = avb.z;
+    }
+    __syncthreads();
+    if (live) g_phi[(size_t)j * 9 * F + (size_t)k * F + f] = a;
+    if (k == 0) {
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8) {
+        const float* r = &red[w8][0][lane];
+        av.x += r[0]; av.y += r[64]; av.z += r[128]; avb.x += r[192]; avb.y += r[256]; avb.z += r[320];
+      }
+      if (live) {
+        const v3 r0 = ldv(g_v + jf * 3), r1 = ldv(g_vbar + jf * 3);        // pass A's receiver-side part
+        st3(g_v + jf * 3, r0.x + av.x, r0.y + av.y, r0.z + av.z);
+        st3(g_vbar + jf * 3, r1.x + avb.x, r1.y + avb.y, r1.z + avb.z);
+      }
+    }
+    __syncthreads();                                 // red is reused by the next node
   }
   if (live) {
     float* __restrict__ out = part + (size_t)blockIdx.x * 9 * (R + 1) * F;
 #pragma unroll
-    for (int k = 0; k < 9; ++k)
-#pragma unroll
-      for (int n = 0; n <= R; ++n) out[(size_t)(k * (R + 1) + n) * F + f] = G[k][n];
+    for (int n = 0; n <= R; ++n) out[(size_t)(k * (R + 1) + n) * F + f] = G[n];
   }
 }
 
@@ -376,7 +356,7 @@ int cgv_pseudo_msg_fwd(const float* phi, const float* s, const float* sbar, cons
   dim3 grid(n_nodes, (n_feat + 63) / 64);
   hipStream_t st = (hipStream_t)stream;
   CGV_DISPATCH_RBF(n_rbf, {
-    hipLaunchKernelGGL((cgv::pseudo_fwd_k<RBF>), grid, dim3(64), 0, st, phi, s, sbar, v, vbar, geom_d, rowptr_d, src_d,
+    hipLaunchKernelGGL((cgv::pseudo_fwd_k<RBF>), grid, dim3(576), 0, st, phi, s, sbar, v, vbar, geom_d, rowptr_d, src_d,
                        Wd, bd, dh, dhbar, dv, dvbar, n_feat, residual);
   });
   return cgv::check_launch("cgv_pseudo_msg_fwd");
@@ -408,7 +388,7 @@ int cgv_pseudo_msg_bwd(const float* phi, const float* s, const float* sbar, cons
     if (n_nodes > 0)
       hipLaunchKernelGGL((cgv::pseudo_bwd_recv_k<RBF>), gridA, dim3(64), 0, st, phi, v, vbar, geom_d, rowptr_d, src_d, Wd,
                          bd, gh, ghbar, gv, gvbar, g_s, g_sbar, g_v, g_vbar, n_feat, residual);
-    hipLaunchKernelGGL((cgv::pseudo_bwd_src_k<RBF>), gridB, dim3(64), 0, st, phi, s, sbar, v, vbar, geom_s, rowptr_s,
+    hipLaunchKernelGGL((cgv::pseudo_bwd_src_k<RBF>), gridB, dim3(576), 0, st, phi, s, sbar, v, vbar, geom_s, rowptr_s,
                        dst_s, Wd, bd, gh, ghbar, gv, gvbar, g_phi, g_v, g_vbar, part, n_feat, n_nodes, npc);
   });
   dim3 rgrid((n_feat + 255) / 256, n_rbf + 1, 9);
