@@ -20,6 +20,13 @@ from .graph import BatchGraph, EdgePlan, make_directed
 from .primitives import Dense, DistanceEmbed, Linear, to_module
 
 
+def _call_then_pass(fn):
+    def hook(grad):
+        fn()
+        return grad
+    return hook
+
+
 class EquivariantPsuedoDecoder(nn.Module):
     """cgvae.py:52-125.  NB run_ala.py:196-197 passes ``cutoff=atom_cutoff`` here."""
 
@@ -36,7 +43,10 @@ class EquivariantPsuedoDecoder(nn.Module):
         self.n_atom_basis = n_atom_basis
         self.n_rbf, self.cutoff = n_rbf, cutoff
 
-    def forward(self, cg_xyz, CG_nbr_list, mapping, S, graph: Optional[BatchGraph] = None):
+    def forward(self, cg_xyz, CG_nbr_list, mapping, S, graph: Optional[BatchGraph] = None, layer_hooks=None):
+        """``layer_hooks``: {layer index L: callable} -- called from the autograd thread when the backward of
+        layers >= L is complete (tensor hook on the state entering layer L); used by the data-parallel trainer
+        to all-reduce finished layer groups while the rest of backward runs."""
         if graph is not None:
             nbrs, plan = graph.cg_nbrs, graph.cg
             geom = graph.geometry("cg", self.n_rbf, self.cutoff)
@@ -50,7 +60,10 @@ class EquivariantPsuedoDecoder(nn.Module):
         V = torch.zeros(n, F, 3, device=S.device)
         Sbar = torch.ones(n, F, device=S.device) if self.breaksym else torch.zeros(n, F, device=S.device)
         Vbar = torch.zeros(n, F, 3, device=S.device)
-        for message_block, update_block in zip(self.message_blocks, self.update_blocks):
+        for layer, (message_block, update_block) in enumerate(zip(self.message_blocks, self.update_blocks)):
+            if layer_hooks and layer in layer_hooks and S.requires_grad:
+                S = S.view_as(S)                              # private node: its hook sees the total gradient of S
+                S.register_hook(_call_then_pass(layer_hooks[layer]))
             if geom is None:      # build once, share across layers
                 from .graph import EdgeGeometry
                 geom = EdgeGeometry(plan, self.n_rbf, self.cutoff, r_edges=r_ij)
@@ -170,9 +183,10 @@ class CGequiVAE(nn.Module):
         self.det = det
         self.offset = offset
         self.equivariant = equivariant
-        # set by the data-parallel trainer: called (from the autograd thread) as soon as the decoder's
-        # backward has finished, i.e. when ~80 % of the gradient bytes are final (trainer.py)
-        self.decoder_backward_done = None
+        # set by the data-parallel trainer: ``bucket_done(i)`` is called (from the autograd thread) as soon as
+        # the gradients of ``backward_buckets()[i]`` are final (trainer.py) -- the decoder holds ~80 % of the bytes
+        self.bucket_done = None
+        self.bucket_layers = 3             # decoder layers per early all-reduce bucket
         self.concurrent_prior = False      # measured: cross-stream joins cost more than the overlap saves (3.72 vs 3.53 ms)
         self._streams = {}
         if not equivariant:
@@ -184,10 +198,24 @@ class CGequiVAE(nn.Module):
             self._streams[key] = torch.cuda.Stream(device=device)
         return self._streams[key]
 
-    def _fire_decoder_done(self, grad):
-        if self.decoder_backward_done is not None:
-            self.decoder_backward_done()
-        return grad
+    def _decoder_groups(self):
+        """Decoder layers in the order their backward finishes: [[8, 7, 6], [5, 4, 3], [2, 1, 0]] for 9 layers."""
+        n = len(self.equivaraintconv.message_blocks)
+        g = max(int(self.bucket_layers), 1)
+        return [list(range(hi, max(hi - g, -1), -1)) for hi in range(n - 1, -1, -g)]
+
+    def backward_buckets(self):
+        """Parameter groups whose gradients become final one after the other during backward; the hooks
+        registered in ``forward`` report each one through ``self.bucket_done(index)``."""
+        dec = self.equivaraintconv
+        return [[p for l in layers for blk in (dec.message_blocks[l], dec.update_blocks[l]) for p in blk.parameters()]
+                for layers in self._decoder_groups()]
+
+    def _fire_bucket(self, index):
+        def fire():
+            if self.bucket_done is not None:
+                self.bucket_done(index)
+        return fire
 
     def get_inputs(self, batch):
         xyz = batch["nxyz"][:, 1:]
@@ -214,8 +242,9 @@ class CGequiVAE(nn.Module):
         out[plan.eid_d[:n].long()] = rank
         return out
 
-    def decoder(self, cg_xyz, CG_nbr_list, S_I, s_i, mapping, num_CGs, graph: Optional[BatchGraph] = None):
-        cg_s, cg_v = self.equivaraintconv(cg_xyz, CG_nbr_list, mapping, S_I, graph=graph)
+    def decoder(self, cg_xyz, CG_nbr_list, S_I, s_i, mapping, num_CGs, graph: Optional[BatchGraph] = None,
+                layer_hooks=None):
+        cg_s, cg_v = self.equivaraintconv(cg_xyz, CG_nbr_list, mapping, S_I, graph=graph, layer_hooks=layer_hooks)
         if graph is not None:
             chan, plan = graph.chan, graph.a2b
         else:
@@ -253,8 +282,14 @@ class CGequiVAE(nn.Module):
         logvar = self.atom_sigmanet(S_I)
         sigma = 1e-12 + torch.exp(logvar / 2)
         z_sample = S_I if self.det else self.reparametrize(mu, sigma, eps)
-        if self.decoder_backward_done is not None and z_sample.requires_grad:
+        layer_hooks = None
+        if self.bucket_done is not None and z_sample.requires_grad:
+            groups = self._decoder_groups()
+            # group i is final once the state entering its lowest layer has its gradient; the last one (layer 0)
+            # when the decoder input has
+            layer_hooks = {layers[-1]: self._fire_bucket(i) for i, layers in enumerate(groups[:-1])}
             z_sample = z_sample.view_as(z_sample)          # private node: the hook fires when the decoder is done
-            z_sample.register_hook(self._fire_decoder_done)
-        xyz_recon = self.decoder(cg_xyz, CG_nbr_list, z_sample, s_i, mapping, num_CGs, graph=graph)
+            z_sample.register_hook(_call_then_pass(self._fire_bucket(len(groups) - 1)))
+        xyz_recon = self.decoder(cg_xyz, CG_nbr_list, z_sample, s_i, mapping, num_CGs, graph=graph,
+                                 layer_hooks=layer_hooks)
         return mu, sigma, H_prior_mu, H_prior_sigma, xyz, xyz_recon

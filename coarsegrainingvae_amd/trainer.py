@@ -119,8 +119,8 @@ class Trainer:
         self.sync = GradSync(world_size, group) if (world_size > 1 or always_sync) else None
         self.fused = fused_optimizer
         self.arena: Optional[ParamArena] = None
-        self.early_range = None       # arena range all-reduced while backward still runs (data parallel)
-        self._early_sent = False
+        self.early_ranges = []        # per model bucket: arena ranges all-reduced while backward still runs
+        self._sent = set()
         self.torch_opt = None
         self.last_loss = None
         self.last_terms = None
@@ -135,15 +135,25 @@ class Trainer:
             raise RuntimeError("no parameter received a gradient")
         self.arena = ParamArena(live)
         dev = self.arena.p.device
-        # arena range of the decoder's parameters (contiguous: model.parameters() order) -- the bucket whose
-        # gradients are final first in backward and can be all-reduced under the encoder's backward
-        names = {id(p): n for n, p in self.model.named_parameters()}
-        dec = [k for k, p in enumerate(live) if names.get(id(p), "").startswith("equivaraintconv.")]
-        self.early_range = None
-        if dec and dec == list(range(dec[0], dec[-1] + 1)):
-            lo = self.arena.offsets[dec[0]]
-            hi = self.arena.offsets[dec[-1] + 1] if dec[-1] + 1 < len(live) else self.arena.numel
-            self.early_range = (lo, hi)
+        # arena ranges of the model's backward buckets (decoder layer groups, in the order their gradients become
+        # final): each is all-reduced as soon as it is, under the rest of backward
+        self.early_ranges = []
+        buckets = self.model.backward_buckets() if hasattr(self.model, "backward_buckets") else []
+        slot = {id(p): k for k, p in enumerate(live)}
+        taken = set()
+        for params in buckets:
+            idx = sorted({slot[id(p)] for p in params if id(p) in slot})
+            if taken.intersection(idx):
+                raise RuntimeError("backward buckets overlap")
+            taken.update(idx)
+            ranges = []
+            for k in idx:                                   # merge neighbours into maximal contiguous runs
+                lo, hi = self.arena.offsets[k], self.arena.offsets[k] + live[k].numel()
+                if ranges and ranges[-1][1] == lo:
+                    ranges[-1] = (ranges[-1][0], hi)
+                else:
+                    ranges.append((lo, hi))
+            self.early_ranges.append(ranges)
         if self.fused:
             if dev.type != "cuda":
                 raise RuntimeError("the fused optimiser is a HIP kernel: it needs device tensors")
@@ -179,7 +189,7 @@ class Trainer:
         if self.sync is not None:
             self.sync.drain()
         graph = torch.cuda.CUDAGraph()
-        wgrad_queue.prepare_capture(self.arena.p.device)
+        wgrad_queue.prepare_capture(self.arena.p.device, flushes=len(self.early_ranges) + 3)
         # with RCCL in the step, other threads (the process group's watchdog) legitimately touch the runtime
         mode = "thread_local" if self.sync is not None else "global"
         with torch.cuda.graph(graph, capture_error_mode=mode):
@@ -196,9 +206,10 @@ class Trainer:
     # ------------------------------------------------------------------ one iteration
     def _step_eager(self, batch, eps: Optional[torch.Tensor] = None, train: bool = True):
         # data parallel: ask the model to signal the end of the decoder's backward (hook registered in forward)
-        overlap = self.sync is not None and train and self.arena is not None and self.early_range is not None
-        self._early_sent = False
-        self.model.decoder_backward_done = self._decoder_done if overlap else None
+        overlap = self.sync is not None and train and self.arena is not None and any(self.early_ranges)
+        self._sent = set()
+        if hasattr(self.model, "bucket_done"):
+            self.model.bucket_done = self._bucket_done if overlap else None
         out = self.model(batch, eps=eps) if eps is not None else self.model(batch)
         loss, kl, recon, graph = loss_terms(out, batch, self.beta, self.gamma)
         self.last_loss, self.last_terms = loss.detach(), (kl.detach(), recon.detach(), graph.detach())
@@ -220,17 +231,14 @@ class Trainer:
             with wgrad_queue.collect():          # bead-level weight gradients: queued, then ONE grouped launch
                 loss.backward()
             wgrad_queue.flush()
-            self.model.decoder_backward_done = None
+            if hasattr(self.model, "bucket_done"):
+                self.model.bucket_done = None
         if not train:                                               # validation: backward only (utils.py:160)
             return self.last_loss
         if self.sync is not None:
             a = self.arena
-            if getattr(self, "_early_sent", False):                 # decoder range already in flight
-                lo, hi = self.early_range
-                self.sync.all_reduce_range(a.g, 0, lo)
-                self.sync.all_reduce_range(a.g, hi, a.numel)
-            else:
-                self.sync.all_reduce_range(a.g, 0, a.numel)
+            for lo, hi in self._unsent_ranges():                    # everything not already in flight
+                self.sync.all_reduce_range(a.g, lo, hi)
             self.sync.wait()
         scale = 1.0 / self.world
         if self.fused:
@@ -246,15 +254,27 @@ class Trainer:
             self.torch_opt.step()
         return self.last_loss
 
-    def _decoder_done(self):
-        """Autograd-thread callback (model.decoder_backward_done): the decoder's gradients are final.
+    def _bucket_done(self, index: int):
+        """Autograd-thread callback (model.bucket_done): the gradients of backward bucket ``index`` are final.
         Materialise its queued weight gradients and start their all-reduce; backward continues."""
-        if self._early_sent:
+        if index in self._sent or index >= len(self.early_ranges):
             return
-        self._early_sent = True
+        self._sent.add(index)
         wgrad_queue.flush()
-        lo, hi = self.early_range
-        self.sync.all_reduce_range(self.arena.g, lo, hi)
+        for lo, hi in self.early_ranges[index]:
+            self.sync.all_reduce_range(self.arena.g, lo, hi)
+
+    def _unsent_ranges(self):
+        """Complement, within the arena, of the ranges of the buckets already sent."""
+        sent = sorted(r for i in self._sent for r in self.early_ranges[i])
+        out, at = [], 0
+        for lo, hi in sent:
+            if lo > at:
+                out.append((at, lo))
+            at = max(at, hi)
+        if at < self.arena.numel:
+            out.append((at, self.arena.numel))
+        return out
 
     def skipped_steps(self) -> int:
         if self.fused and self.arena is not None:

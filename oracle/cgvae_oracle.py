@@ -310,8 +310,9 @@ def prior_forward(cg_z, cg_xyz, cg_nbr_list, P, hp: Hyper, prefix="prior_net"):
     return mu, 1e-9 + torch.exp(sg / 2)
 
 
-def pseudo_decoder_forward(cg_xyz, cg_nbr_list, S, P, hp: Hyper, prefix="equivaraintconv"):
-    """cgvae.py:85-125 (EquivariantPsuedoDecoder.forward; RBF cutoff = atom_cutoff, run_ala.py:196-197)."""
+def pseudo_decoder_forward(cg_xyz, cg_nbr_list, S, P, hp: Hyper, prefix="equivaraintconv", on_layer_input=None):
+    """cgvae.py:85-125 (EquivariantPsuedoDecoder.forward; RBF cutoff = atom_cutoff, run_ala.py:196-197).
+    ``on_layer_input(k, S) -> S`` (tests only) sees the scalar state entering layer k."""
     act = _ACT[hp.activation]
     cg_nbr_list, _ = make_directed(cg_nbr_list)
     r_ij = cg_xyz[cg_nbr_list[:, 1]] - cg_xyz[cg_nbr_list[:, 0]]
@@ -319,6 +320,8 @@ def pseudo_decoder_forward(cg_xyz, cg_nbr_list, S, P, hp: Hyper, prefix="equivar
     Sbar = torch.ones(S.shape[0], S.shape[1]) if hp.breaksym else torch.zeros(S.shape[0], S.shape[1])
     Vbar = torch.zeros(S.shape[0], S.shape[1], 3)
     for k in range(hp.dec_nconv):
+        if on_layer_input is not None:
+            S = on_layer_input(k, S)
         dS, dSbar, dV, dVbar = equi_message_pseudo(S, Sbar, V, Vbar, r_ij, cg_nbr_list, P,
                                                    f"{prefix}.message_blocks.{k}", act, hp.R,
                                                    hp.atom_cutoff)
@@ -341,9 +344,9 @@ def channel_index(mapping: Tensor) -> Tensor:
     return out
 
 
-def decode(cg_xyz, cg_nbr_list, S, mapping, P, hp: Hyper):
+def decode(cg_xyz, cg_nbr_list, S, mapping, P, hp: Hyper, on_layer_input=None):
     """cgvae.py:462-484 (CGequiVAE.decoder)."""
-    cg_s, cg_v = pseudo_decoder_forward(cg_xyz, cg_nbr_list, S, P, hp)
+    cg_s, cg_v = pseudo_decoder_forward(cg_xyz, cg_nbr_list, S, P, hp, on_layer_input=on_layer_input)
     chan = channel_index(mapping)
     if not hp.equivariant:
         dv = linear(cg_s, P, "euclidean").reshape(cg_s.shape[0], cg_s.shape[1], 3)

@@ -22,8 +22,8 @@ BETA, GAMMA = 0.05, 25.0
 
 class OracleModule(torch.nn.Module):
     """The oracle's functional model behind an nn.Module with the product model's top-level layout
-    (``encoder`` / ``equivaraintconv`` / ... parameter groups and the ``decoder_backward_done`` hook),
-    so the Trainer's early all-reduce of the decoder bucket is exercised on CPU."""
+    (``encoder`` / ``equivaraintconv`` / ... parameter groups, ``backward_buckets()`` and the ``bucket_done``
+    hook), so the Trainer's early all-reduce of finished decoder layer groups is exercised on CPU."""
 
     GROUPS = ("encoder", "equivaraintconv", "atom_munet", "atom_sigmanet", "prior_net")
 
@@ -38,18 +38,28 @@ class OracleModule(torch.nn.Module):
             setattr(self, g, torch.nn.ParameterList([torch.nn.Parameter(P[k]) for k in keys]))
             for j, k in enumerate(keys):
                 self.index[k] = (g, j)
-        self.decoder_backward_done = None
+        self.bucket_done = None
         self.fired = 0
+        n = self.hp.dec_nconv
+        self.groups = [[l] for l in range(n - 1, -1, -1)]                  # one decoder layer per bucket
+
+    def backward_buckets(self):
+        def layer_of(k):
+            parts = k.split(".")
+            return int(parts[2]) if parts[0] == "equivaraintconv" and parts[1] in ("message_blocks", "update_blocks") else None
+        return [[getattr(self, g)[j] for k, (g, j) in self.index.items() if layer_of(k) in layers] for layers in self.groups]
 
     @property
     def plist(self):
         return [getattr(self, g)[j] for g, j in (self.index[k] for k in self.names)]
 
-    def _fire(self, grad):
-        if self.decoder_backward_done is not None:
-            self.fired += 1
-            self.decoder_backward_done()
-        return grad
+    def _hook(self, index):
+        def hook(grad):
+            if self.bucket_done is not None:
+                self.fired += 1
+                self.bucket_done(index)
+            return grad
+        return hook
 
     def forward(self, batch, eps=None):
         P = dict(zip(self.names, self.plist))
@@ -61,9 +71,17 @@ class OracleModule(torch.nn.Module):
         mu = O.linear(torch.relu(O.linear(H, P, "atom_munet.0")), P, "atom_munet.2")
         sigma = 1e-12 + torch.exp(O.linear(torch.relu(O.linear(H, P, "atom_sigmanet.0")), P, "atom_sigmanet.2") / 2)
         zs = H.view_as(H)                                   # det=True: z = H (cgvae.py:504-507)
-        if self.decoder_backward_done is not None:
-            zs.register_hook(self._fire)
-        recon = O.decode(cg_xyz, batch["CG_nbr_list"], zs, batch["CG_mapping"], P, hp)
+        on_layer = None
+        if self.bucket_done is not None:
+            zs.register_hook(self._hook(len(self.groups) - 1))
+            lowest = {layers[-1]: i for i, layers in enumerate(self.groups[:-1])}
+
+            def on_layer(k, S):
+                if k in lowest:
+                    S = S.view_as(S)
+                    S.register_hook(self._hook(lowest[k]))
+                return S
+        recon = O.decode(cg_xyz, batch["CG_nbr_list"], zs, batch["CG_mapping"], P, hp, on_layer_input=on_layer)
         return mu, sigma, pmu, pstd, xyz, recon
 
 
@@ -98,7 +116,7 @@ def _worker(rank, world, port, n_steps, lr, gamma, q):
         fr = frames(4)
         batch = CG_collate(fr[2 * rank: 2 * rank + 2])
         losses = [float(tr.step(batch)) for _ in range(n_steps)]
-        early = (tr.early_range is not None, model.fired)
+        early = (len(tr.early_ranges), model.fired)
         q.put((rank, [p.detach().clone().numpy() for p in model.plist], losses, tr.skipped_steps(), early))
     finally:
         dist.destroy_process_group()
@@ -130,8 +148,10 @@ def test_two_rank_training_equals_single_rank_on_concatenated_batch():
     res = run_dp(3, lr=1e-3)
     (r0, p0, l0, s0, e0), (r1, p1, l1, s1, e1) = res
     assert s0 == 0 and s1 == 0
-    # steps 2 and 3 sent the decoder bucket early (step 1 builds the arena)
-    assert e0 == (True, 2) and e1 == (True, 2)
+    # steps 2 and 3 sent every decoder layer group early (step 1 builds the arena)
+    n_buckets = len(OracleModule().groups)
+    assert n_buckets >= 2
+    assert e0 == (n_buckets, 2 * n_buckets) and e1 == (n_buckets, 2 * n_buckets)
     for a, b in zip(p0, p1):                       # replicas stay in lock-step
         assert np.array_equal(a, b)
     worst = 0.0
@@ -152,6 +172,32 @@ def test_skip_rule_uses_the_all_reduced_loss():
         assert skipped == 2
         for a, b in zip(params, init):
             assert np.array_equal(a, b)
+
+
+def test_early_ranges_partition_the_decoder_and_complement_covers_the_rest():
+    """Each arena element must be all-reduced exactly once: the buckets' ranges are disjoint, cover exactly the
+    decoder layers' parameters, and the complement of whatever was sent is what the trainer reduces at the end."""
+    torch.set_num_threads(1)
+    model = OracleModule()
+    tr = Trainer(model, lr=1e-3, beta=BETA, gamma=GAMMA, fused_optimizer=False)
+    tr.step(CG_collate(frames(2)))                 # builds the arena
+    a = tr.arena
+    covered = torch.zeros(a.numel, dtype=torch.int32)
+    for ranges in tr.early_ranges:
+        for lo, hi in ranges:
+            covered[lo:hi] += 1
+    assert int(covered.max()) == 1
+    dec = sum(p.numel() for b in model.backward_buckets() for p in b if p.grad is not None)
+    assert dec <= int(covered.sum()) <= dec + 64 * sum(len(b) for b in model.backward_buckets())   # + alignment padding
+    for sent in (set(), {0}, {0, len(tr.early_ranges) - 1}, set(range(len(tr.early_ranges)))):
+        tr._sent = sent
+        total = covered.clone().zero_()
+        for i in sent:
+            for lo, hi in tr.early_ranges[i]:
+                total[lo:hi] += 1
+        for lo, hi in tr._unsent_ranges():
+            total[lo:hi] += 1
+        assert int(total.min()) == 1 and int(total.max()) == 1
 
 
 def test_param_arena_keeps_module_semantics():
