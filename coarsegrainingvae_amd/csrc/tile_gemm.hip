@@ -33,17 +33,23 @@ __device__ __forceinline__ float tg_sigmoid(float z) { return 1.0f / (1.0f + exp
 #define CGV_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 // ------------------------------------------------------------------ fwd
-// grid (ceil(N/32), ceil(M/32)), 256 threads.  Wave w walks k-steps w, w+4, ... (16 floats each).
-// Lane (i = l&15, q = l>>4): A_mb = x[m0 + 16 mb + i][k + 4q ..+3], B_nb = W[n0 + 16 nb + i][k + 4q ..+3].
-template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void tile_fwd_k(const float* __restrict__ x, const float* __restrict__ W,
-                                                  const float* __restrict__ bias, float* __restrict__ y,
-                                                  float* __restrict__ zout, int M, int N, int K, int act) {
-  __shared__ float red[WAVES - 1][4][4][64];         // [wave-1][sub-tile][reg][lane]
+// Block tile = (32 QM) x (32 QN); wave = (quadrant, k-slice): QM*QN quadrants of 32 x 32 outputs, the K loop of
+// each split over KW waves (wave kq walks k-steps kq, kq+KW, ..., 16 floats each).  Lane (i = l&15, q = l>>4):
+// A_mb = x[m0 + 16 mb + i][k + 4q ..+3], B_nb = W[n0 + 16 nb + i][k + 4q ..+3].  <1,1,8>: 32 x 32 tiles for
+// problems with few tiles (every SIMD needs loads in flight); <2,2,4>: 64 x 64 tiles when there are enough of
+// them -- the four quadrants share operand rows through L1, halving the L2 traffic per flop.
+// Epilogue: all waves drop their accumulators in LDS, then wave kq of a quadrant finishes sub-tile kq (KW >= 4).
+template <int QM, int QN, int KW>
+__global__ __launch_bounds__(64 * QM * QN * KW) void tile_fwd_k(const float* __restrict__ x, const float* __restrict__ W,
+                                                                 const float* __restrict__ bias, float* __restrict__ y,
+                                                                 float* __restrict__ zout, int M, int N, int K, int act) {
+  static_assert(KW >= 4, "the epilogue spreads the 4 sub-tiles of a quadrant over the k-slice waves");
+  __shared__ float red[QM * QN][KW][4][4][64];       // [quadrant][k-slice][sub-tile][reg][lane]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int quad = wave / KW, kq = wave - quad * KW;
   const int i = lane & 15, q = lane >> 4;
-  const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+  const int n0 = blockIdx.x * (32 * QN) + 32 * (quad % QN), m0 = blockIdx.y * (32 * QM) + 32 * (quad / QN);
   const float* xr[2];
   const float* wr[2];
   bool xok[2], wok[2];
@@ -59,13 +65,24 @@ __global__ __launch_bounds__(64 * WAVES) void tile_fwd_k(const float* __restrict
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int steps = (K + 15) / 16;
+  // contiguous k range per wave: consecutive steps read the two 64-byte halves of the same 128-byte lines
+  // (strided assignment fetched every line twice: the block's 8 waves thrash the L1 between the two uses)
+  const int steps = (K + 15) / 16, per = (steps + KW - 1) / KW;
+  const int s_end = min((kq + 1) * per, steps);
 #pragma unroll 4
-  for (int s = wave; s < steps; s += WAVES) {
+  for (int s = kq * per; s < s_end; ++s) {
     const int k = 16 * s;
     const bool kok = k + 4 * q < K;                  // K % 4 == 0: a float4 is entirely in or out
+#if defined(CGV_TILE_ABLATE) && CGV_TILE_ABLATE == 2      /* probe builds only: no operand loads */
+    const float4 a0 = make_float4(k, 1.f, 2.f, 3.f), a1 = a0, b0 = make_float4(1.f, k, 2.f, 3.f), b1 = b0;
+#else
     const float4 a0 = ld4z(xr[0] + (kok ? k : 0), kok && xok[0]), a1 = ld4z(xr[1] + (kok ? k : 0), kok && xok[1]);
     const float4 b0 = ld4z(wr[0] + (kok ? k : 0), kok && wok[0]), b1 = ld4z(wr[1] + (kok ? k : 0), kok && wok[1]);
+#endif
+#if defined(CGV_TILE_ABLATE) && CGV_TILE_ABLATE == 1      /* probe builds only: no MFMAs */
+    acc[0][0][0] += a0.x + a1.y + b0.z + b1.w; acc[1][1][1] += a0.y + a1.x + b0.w + b1.z;
+    continue;
+#endif
     acc[0][0] = CGV_MFMA(a0.x, b0.x, acc[0][0]); acc[0][1] = CGV_MFMA(a0.x, b1.x, acc[0][1]);
     acc[1][0] = CGV_MFMA(a1.x, b0.x, acc[1][0]); acc[1][1] = CGV_MFMA(a1.x, b1.x, acc[1][1]);
     acc[0][0] = CGV_MFMA(a0.y, b0.y, acc[0][0]); acc[0][1] = CGV_MFMA(a0.y, b1.y, acc[0][1]);
@@ -75,35 +92,30 @@ __global__ __launch_bounds__(64 * WAVES) void tile_fwd_k(const float* __restrict
     acc[0][0] = CGV_MFMA(a0.w, b0.w, acc[0][0]); acc[0][1] = CGV_MFMA(a0.w, b1.w, acc[0][1]);
     acc[1][0] = CGV_MFMA(a1.w, b0.w, acc[1][0]); acc[1][1] = CGV_MFMA(a1.w, b1.w, acc[1][1]);
   }
-  if (wave > 0) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+  for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) red[wave - 1][t][r][lane] = acc[t >> 1][t & 1][r];
-  }
+    for (int r = 0; r < 4; ++r) red[quad][kq][t][r][lane] = acc[t >> 1][t & 1][r];
   __syncthreads();
-  if (wave != 0) return;
-  // D of sub-tile (mb, nb): lane holds y[m0 + 16 mb + 4 q + r][n0 + 16 nb + i]
+  if (kq >= 4) return;
+  // sub-tile t = kq = (mb, nb): lane holds y[m0 + 16 mb + 4 q + r][n0 + 16 nb + i]
+  const int t = kq, mb = t >> 1, nb = t & 1;
+  const int n = n0 + 16 * nb + i;
+  if (n >= N) return;
+  const float bv = bias ? bias[n] : 0.f;
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int mb = t >> 1, nb = t & 1;
-    const int n = n0 + 16 * nb + i;
-    if (n >= N) continue;
-    const float bv = bias ? bias[n] : 0.f;
+  for (int r = 0; r < 4; ++r) {
+    const int m = m0 + 16 * mb + 4 * q + r;
+    if (m >= M) continue;
+    float zv = 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = m0 + 16 * mb + 4 * q + r;
-      if (m >= M) continue;
-      float zv = acc[mb][nb][r];
-#pragma unroll
-      for (int w = 0; w < WAVES - 1; ++w) zv += red[w][t][r][lane];
-      zv += bv;
-      if (act) {
-        if (zout) zout[(size_t)m * N + n] = zv;
-        zv = zv * tg_sigmoid(zv);
-      }
-      y[(size_t)m * N + n] = zv;
+    for (int w = 0; w < KW; ++w) zv += red[quad][w][t][r][lane];
+    zv += bv;
+    if (act) {
+      if (zout) zout[(size_t)m * N + n] = zv;
+      zv = zv * tg_sigmoid(zv);
     }
+    y[(size_t)m * N + n] = zv;
   }
 }
 
@@ -135,9 +147,10 @@ __global__ __launch_bounds__(64 * WAVES) void tile_bwd_input_k(const float* __re
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
     for (int s = 0; s < 4; ++s) acc[mb][s] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int steps = (N + 15) / 16;
+  const int steps = (N + 15) / 16, per = (steps + WAVES - 1) / WAVES;       // contiguous n range per wave (see fwd)
+  const int st_end = min((wave + 1) * per, steps);
 #pragma unroll 4
-  for (int st = wave; st < steps; st += WAVES) {
+  for (int st = wave * per; st < st_end; ++st) {
     const int n = 16 * st;
     const bool nok = n + 4 * q < N;                  // N % 4 == 0: rows n + 4q .. + 3 are all in or all out
     float4 a[MB];
@@ -205,9 +218,10 @@ __global__ __launch_bounds__(64 * WAVES) void tile_wgrad_k(const float* __restri
   f32x4 acc[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int steps = (M + 3) / 4;
+  const int steps = (M + 3) / 4, per = (steps + WAVES - 1) / WAVES;
+  const int st_end = min((wave + 1) * per, steps);
 #pragma unroll 8
-  for (int st = wave; st < steps; st += WAVES) {
+  for (int st = wave * per; st < st_end; ++st) {
     const int m = 4 * st + q;
     const bool mok = m < M;
     const float a = (mok && nok) ? g[(size_t)m * N + ncol] : 0.f;
@@ -259,12 +273,14 @@ int cgv_tile_linear_fwd(const float* x, const float* W, const float* bias, float
   CGV_REQUIRE(act == 0 || act == 1, "act must be 0 (identity) or 1 (swish)");
   CGV_REQUIRE(cgv_tile_supported(M, N, K), "unsupported shape (need N % 4 == 0, K % 4 == 0)");
   CGV_REQUIRE(((((uintptr_t)x | (uintptr_t)W)) & 15) == 0, "x and W must be 16-byte aligned");
-  const dim3 grid((N + 31) / 32, (M + 31) / 32);
-  // few tiles: split the reduction over more waves so every SIMD has loads in flight
-  if (grid.x * grid.y >= 1024)
-    hipLaunchKernelGGL((cgv::tile_fwd_k<4>), grid, dim3(256), 0, (hipStream_t)stream, x, W, bias, y, z, M, N, K, act);
-  else
-    hipLaunchKernelGGL((cgv::tile_fwd_k<8>), grid, dim3(512), 0, (hipStream_t)stream, x, W, bias, y, z, M, N, K, act);
+  hipStream_t st = (hipStream_t)stream;
+  const int tiles32 = ((N + 31) / 32) * ((M + 31) / 32);
+  if (tiles32 >= 2048)                    // enough work for several 64 x 64 tiles on every CU (measured: no gain below)
+    hipLaunchKernelGGL((cgv::tile_fwd_k<2, 2, 4>), dim3((N + 63) / 64, (M + 63) / 64), dim3(1024), 0, st, x, W, bias, y, z, M,
+                       N, K, act);
+  else                                    // few tiles: 32 x 32, reduction split 8 ways so every SIMD has loads in flight
+    hipLaunchKernelGGL((cgv::tile_fwd_k<1, 1, 8>), dim3((N + 31) / 32, (M + 31) / 32), dim3(512), 0, st, x, W, bias, y, z, M,
+                       N, K, act);
   return cgv::check_launch("cgv_tile_linear_fwd");
 }
 
@@ -277,8 +293,6 @@ int cgv_tile_linear_bwd_input(const float* g, const float* W, float* gx, int M, 
   const int blocks32 = kt * ((M + 31) / 32);
   if (blocks32 >= 512)                    // enough 32-row tiles to fill the chip: halve the weight re-reads
     hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 4>), dim3(kt, (M + 31) / 32), dim3(256), 0, st, g, W, gx, M, N, K);
-  else if (M <= 128)                      // few rows, (possibly) huge weight: re-reading W per 16-row tile dominates
-    hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 8>), dim3(kt, (M + 31) / 32), dim3(512), 0, st, g, W, gx, M, N, K);
   else
     hipLaunchKernelGGL((cgv::tile_bwd_input_k<1, 8>), dim3(kt, (M + 15) / 16), dim3(512), 0, st, g, W, gx, M, N, K);
   return cgv::check_launch("cgv_tile_linear_bwd_input");
