@@ -121,18 +121,37 @@ static hipError_t sort_temp_bytes(int n, size_t* bytes) {
   return rocprim::radix_sort_pairs(nullptr, *bytes, k, k, k, k, (size_t)(n > 0 ? n : 1), 0, 32, (hipStream_t)0);
 }
 
-static int sorted_view(const int64_t* key, const int64_t* other, int stride, int E, int n_rows, int* rowptr, int* eid,
-                       int* key_sorted, int* other_sorted, char* ws, size_t ws_bytes, hipStream_t st) {
+// keys[p] = key[eid[p]] for the second pass of the two-key sort
+__global__ void csr_regather(const int64_t* __restrict__ key, int stride, const int* __restrict__ eid, int n,
+                             int* __restrict__ keys, int* __restrict__ vals) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const int e = eid[p];
+  keys[p] = (int)key[(int64_t)e * stride];
+  vals[p] = e;
+}
+
+// One sorted view: edges ordered by (key, other, original index).  Two stable LSD passes of the 32-bit radix sort
+// (by ``other`` first, then by ``key``): within a row the partner rows are visited in ascending order.
+static int sorted_view(const int64_t* key, const int64_t* other, int stride, int E, int n_rows, int n_other, int* rowptr,
+                       int* eid, int* key_sorted, int* other_sorted, char* ws, size_t ws_bytes, hipStream_t st) {
   int* keys_in = reinterpret_cast<int*>(ws);
   int* vals_in = reinterpret_cast<int*>(ws + align256(sizeof(int) * (size_t)E));
   char* temp = ws + 2 * align256(sizeof(int) * (size_t)E);
   size_t temp_bytes = ws_bytes - 2 * align256(sizeof(int) * (size_t)E);
   const int T = 256, B = (E + T - 1) / T;
+  auto bits_for = [](int n) { int b = 1; while ((1ll << b) < (long long)(n > 1 ? n : 2)) ++b; return b; };
   if (E > 0) {
-    hipLaunchKernelGGL(csr_keys, dim3(B), dim3(T), 0, st, key, stride, E, keys_in, vals_in);
-    int bits = 1;
-    while ((1ll << bits) < (long long)(n_rows > 1 ? n_rows : 2)) ++bits;
-    hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, key_sorted, vals_in, eid, (size_t)E, 0, bits, st);
+    hipError_t e = hipSuccess;
+    if (other && key) {                            // pass 1: by the partner index (eid <- ids in that order)
+      hipLaunchKernelGGL(csr_keys, dim3(B), dim3(T), 0, st, other, stride, E, keys_in, vals_in);
+      e = rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, key_sorted, vals_in, eid, (size_t)E, 0, bits_for(n_other), st);
+      if (e == hipSuccess) hipLaunchKernelGGL(csr_regather, dim3(B), dim3(T), 0, st, key, stride, eid, E, keys_in, vals_in);
+    } else {
+      hipLaunchKernelGGL(csr_keys, dim3(B), dim3(T), 0, st, key, stride, E, keys_in, vals_in);
+    }
+    if (e == hipSuccess)                           // pass 2 (stable): by the row key
+      e = rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, key_sorted, vals_in, eid, (size_t)E, 0, bits_for(n_rows), st);
     if (e != hipSuccess) {
       set_error("cgv_csr_build: radix sort failed: %s", hipGetErrorString(e));
       return (int)e;
@@ -185,9 +204,9 @@ int cgv_csr_build(const int64_t* dst, const int64_t* src, int stride, int n_edge
   }
   hipStream_t st = (hipStream_t)stream;
   char* ws = reinterpret_cast<char*>(workspace);
-  int rc = cgv::sorted_view(dst, src, stride, n_edges, n_dst, rowptr_d, eid_d, dst_d, src_d, ws, workspace_bytes, st);
+  int rc = cgv::sorted_view(dst, src, stride, n_edges, n_dst, n_src, rowptr_d, eid_d, dst_d, src_d, ws, workspace_bytes, st);
   if (rc) return rc;
-  return cgv::sorted_view(src, dst, stride, n_edges, n_src, rowptr_s, eid_s, src_s, dst_s, ws, workspace_bytes, st);
+  return cgv::sorted_view(src, dst, stride, n_edges, n_src, n_dst, rowptr_s, eid_s, src_s, dst_s, ws, workspace_bytes, st);
 }
 
 }  // extern "C"

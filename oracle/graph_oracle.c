@@ -56,16 +56,31 @@ int64_t orc_make_directed(const int64_t* nbrs, int64_t e, int64_t* out, int* dir
   return 2 * e;
 }
 
-/* Stable counting sort of edge ids by key (what the CSR plan K7 must reproduce bit for bit):
- * rowptr[n_rows+1], perm[e] = edge ids grouped by key in original order. */
-void orc_csr_stable(const int64_t* key, int64_t stride, int64_t e, int n_rows, int32_t* rowptr, int32_t* perm) {
+/* Edge ids ordered by (key, other, original index) -- what the CSR plan K7 must reproduce bit for bit:
+ * rowptr[n_rows+1], perm[e].  other may be NULL (order by key, then original index).  Two stable counting
+ * sorts, least significant key first. */
+static void counting_pass(const int64_t* key, int64_t stride, int64_t e, int n_rows, const int32_t* in, int32_t* out,
+                          int32_t* rowptr) {
   memset(rowptr, 0, sizeof(int32_t) * (size_t)(n_rows + 1));
   for (int64_t k = 0; k < e; ++k) rowptr[key[k * stride] + 1]++;
   for (int r = 0; r < n_rows; ++r) rowptr[r + 1] += rowptr[r];
   int32_t* cursor = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n_rows > 0 ? n_rows : 1));
   memcpy(cursor, rowptr, sizeof(int32_t) * (size_t)n_rows);
-  for (int64_t k = 0; k < e; ++k) perm[cursor[key[k * stride]]++] = (int32_t)k;
+  for (int64_t p = 0; p < e; ++p) {
+    const int32_t id = in ? in[p] : (int32_t)p;
+    out[cursor[key[(int64_t)id * stride]]++] = id;
+  }
   free(cursor);
+}
+
+void orc_csr_sorted(const int64_t* key, const int64_t* other, int64_t stride, int64_t e, int n_rows, int n_other,
+                    int32_t* rowptr, int32_t* perm) {
+  if (!other) { counting_pass(key, stride, e, n_rows, NULL, perm, rowptr); return; }
+  int32_t* first = (int32_t*)malloc(sizeof(int32_t) * (size_t)(e > 0 ? e : 1));
+  int32_t* rp = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n_other + 1));
+  counting_pass(other, stride, e, n_other, NULL, first, rp);
+  counting_pass(key, stride, e, n_rows, first, perm, rowptr);
+  free(first); free(rp);
 }
 
 /* torch_scatter.scatter_add / scatter_mean semantics (requirements.txt:18; third party, restated)

@@ -53,15 +53,23 @@ def check_param_grads(block, g, tol=REL):
 
 
 # --------------------------------------------------------------------------- K7 / K6 / K1
-def test_csr_plan_is_a_stable_sort():
+def test_csr_plan_is_sorted_by_row_then_partner_then_edge_id():
     gen = torch.Generator().manual_seed(0)
     n, E = 37, 900
     nbrs = torch.randint(0, n, (E, 2), generator=gen)
     plan = EdgePlan.from_nbrs(nbrs.to(DEV), n)
     for key_col, rowptr, eid, dst, src in ((0, plan.rowptr_d, plan.eid_d, plan.dst_d, plan.src_d),
                                            (1, plan.rowptr_s, plan.eid_s, plan.dst_s, plan.src_s)):
-        order = np.argsort(nbrs[:, key_col].numpy(), kind="stable")
+        nb = nbrs.numpy()
+        order = np.lexsort((np.arange(E), nb[:, 1 - key_col], nb[:, key_col]))
         assert np.array_equal(eid.cpu().numpy(), order)
+        if key_col == 0:                                  # ... which is what the C oracle defines
+            import ctypes as C
+            from test_oracle_c import _load as load_orc
+            orc = load_orc()
+            rp, perm = np.zeros(n + 1, dtype=np.int32), np.zeros(E, dtype=np.int32)
+            orc.orc_csr_sorted(nb.ctypes.data, nb[:, 1:].ctypes.data, 2, E, n, n, rp.ctypes.data, perm.ctypes.data)
+            assert np.array_equal(perm, order) and np.array_equal(rp, rowptr.cpu().numpy())
         assert np.array_equal(dst.cpu().numpy(), nbrs[order, 0].numpy())
         assert np.array_equal(src.cpu().numpy(), nbrs[order, 1].numpy())
         want = np.searchsorted(nbrs[order, key_col].numpy(), np.arange(n + 1), side="left")

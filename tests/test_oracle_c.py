@@ -14,8 +14,7 @@ from conftest import ROOT, load_golden
 LIB = os.path.join(ROOT, "oracle", "libgraph_oracle.so")
 
 
-@pytest.fixture(scope="module")
-def orc():
+def _load():
     if not os.path.exists(LIB):
         subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-s"], check=True)
     lib = C.CDLL(LIB)
@@ -23,10 +22,15 @@ def orc():
     lib.orc_radius_graph.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p]
     lib.orc_make_directed.restype = C.c_int64
     lib.orc_make_directed.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
-    lib.orc_csr_stable.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
+    lib.orc_csr_sorted.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     lib.orc_scatter_f64.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_void_p]
     lib.orc_channel_index.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
     return lib
+
+
+@pytest.fixture(scope="module")
+def orc():
+    return _load()
 
 
 def radius_c(lib, xyz, cutoff, undirected):
@@ -75,8 +79,12 @@ def test_csr_and_channel_index_c_vs_numpy_and_torch_oracle(orc):
     for col in (0, 1):
         rowptr = np.zeros(n + 1, dtype=np.int32)
         perm = np.zeros(e, dtype=np.int32)
-        orc.orc_csr_stable(nbrs[:, col:].ctypes.data, 2, e, n, rowptr.ctypes.data, perm.ctypes.data)
-        assert np.array_equal(perm, np.argsort(nbrs[:, col], kind="stable"))
+        orc.orc_csr_sorted(nbrs[:, col:].ctypes.data, nbrs[:, 1 - col:].ctypes.data, 2, e, n, n, rowptr.ctypes.data,
+                           perm.ctypes.data)
+        assert np.array_equal(perm, np.lexsort((np.arange(e), nbrs[:, 1 - col], nbrs[:, col])))
+        perm1 = np.zeros(e, dtype=np.int32)
+        orc.orc_csr_sorted(nbrs[:, col:].ctypes.data, None, 2, e, n, 0, rowptr.ctypes.data, perm1.ctypes.data)
+        assert np.array_equal(perm1, np.argsort(nbrs[:, col], kind="stable"))
         assert np.array_equal(rowptr, np.searchsorted(np.sort(nbrs[:, col]), np.arange(n + 1)))
     mapping = np.sort(rng.integers(0, 5, size=40)).astype(np.int64)
     rng.shuffle(mapping)
