@@ -43,14 +43,43 @@ def CG_collate(dicts: List[Dict[str, torch.Tensor]]) -> Dict[str, torch.Tensor]:
     return batch
 
 
-def prepare_batch(batch: Dict[str, torch.Tensor], device=None) -> Dict[str, torch.Tensor]:
+def prepare_batch(batch: Dict[str, torch.Tensor], device=None, edge_slack: float = 0.0) -> Dict[str, torch.Tensor]:
     """Move a collated batch to the device and attach its :class:`BatchGraph` (directed lists,
-    CSR plans, bead ranks) under ``'_graph'`` so ``CGequiVAE.forward`` runs without host syncs."""
+    CSR plans, bead ranks) under ``'_graph'`` so ``CGequiVAE.forward`` runs without host syncs.
+    ``edge_slack`` > 0 reserves that fraction of extra edge capacity (see :func:`copy_batch_into`)."""
     if device is not None:
         batch = batch_to(batch, device)
     batch["_graph"] = BatchGraph(batch["nxyz"][:, 1:], batch["CG_nxyz"][:, 1:], batch["CG_mapping"],
-                                 batch["nbr_list"], batch["CG_nbr_list"])
+                                 batch["nbr_list"], batch["CG_nbr_list"], edge_slack=edge_slack)
     return batch
+
+
+_STATIC_KEYS = ("nxyz", "CG_nxyz", "num_atoms", "num_CGs", "CG_mapping", "bond_edge_list")
+
+
+def copy_batch_into(dst: Dict[str, torch.Tensor], src: Dict[str, torch.Tensor]) -> bool:
+    """Load collated batch ``src`` into the tensors and graph bundle of the prepared batch ``dst`` IN PLACE
+    (same molecules: node counts, atom -> bead map and bond list; edge counts within ``dst``'s capacity).
+    Every device address the training step reads stays the same, so a hipGraph captured on ``dst``
+    (``Trainer.capture``) can be replayed on the new data.  Returns False -- and leaves ``dst`` untouched --
+    when ``src`` does not fit; the caller then runs that batch eagerly."""
+    g = dst.get("_graph")
+    if g is None:
+        return False
+    dev = dst["nxyz"].device
+    src = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in src.items() if k != "_graph"}
+    for k in _STATIC_KEYS:
+        if k not in src or tuple(src[k].shape) != tuple(dst[k].shape):
+            return False
+    if not torch.equal(src["bond_edge_list"], dst["bond_edge_list"]):
+        return False
+    if not g.fits(src["nxyz"][:, 1:], src["CG_nxyz"][:, 1:], src["CG_mapping"], src["nbr_list"], src["CG_nbr_list"]):
+        return False
+    for k in _STATIC_KEYS:
+        dst[k].copy_(src[k])
+    g.update(src["nxyz"][:, 1:], src["CG_nxyz"][:, 1:], src["nbr_list"], src["CG_nbr_list"])
+    dst["nbr_list"], dst["CG_nbr_list"] = src["nbr_list"], src["CG_nbr_list"]
+    return True
 
 
 class CGDataset(TorchDataset):

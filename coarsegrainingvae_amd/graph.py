@@ -101,37 +101,54 @@ class EdgePlan:
     (``nbrs[:,1]``) -- conv.py:68, 553-561.  All arrays are int32 device tensors.
     """
 
-    __slots__ = ("n_dst", "n_src", "n_edges", "rowptr_d", "eid_d", "dst_d", "src_d", "rowptr_s", "eid_s",
+    __slots__ = ("n_dst", "n_src", "n_edges", "capacity", "rowptr_d", "eid_d", "dst_d", "src_d", "rowptr_s", "eid_s",
                  "dst_s", "src_s", "device", "__weakref__")
 
     def __init__(self, dst: torch.Tensor, src: Optional[torch.Tensor], stride: int, n_edges: int, n_dst: int,
-                 n_src: int):
+                 n_src: int, capacity: int = 0):
+        """``capacity`` >= n_edges: room in the edge arrays for a later ``rebuild`` with a different edge list
+        (the arrays keep their addresses, so a captured hipGraph can be replayed on another batch)."""
         dev = dst.device
         self.device, self.n_dst, self.n_src, self.n_edges = dev, int(n_dst), int(n_src), int(n_edges)
-        E = max(self.n_edges, 1)
+        self.capacity = E = max(self.n_edges, int(capacity), 1)
         mk = lambda n: torch.empty(n, dtype=_I32, device=dev)
         self.rowptr_d, self.rowptr_s = mk(self.n_dst + 1), mk(self.n_src + 1)
         self.eid_d, self.dst_d, self.src_d = mk(E), mk(E), mk(E)
         self.eid_s, self.dst_s, self.src_s = mk(E), mk(E), mk(E)
+        self._build(dst, src, stride)
+
+    def _build(self, dst, src, stride):
         lib = _lib.load()
         ws_bytes = int(lib.cgv_csr_workspace_bytes(self.n_edges))
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
         _lib.call("cgv_csr_build", _lib.ptr(dst), _lib.ptr(src), stride, self.n_edges, self.n_dst, self.n_src,
                   _lib.ptr(self.rowptr_d), _lib.ptr(self.eid_d), _lib.ptr(self.dst_d), _lib.ptr(self.src_d),
                   _lib.ptr(self.rowptr_s), _lib.ptr(self.eid_s), _lib.ptr(self.dst_s), _lib.ptr(self.src_s),
                   _lib.ptr(ws), ws_bytes, _lib.stream_ptr())
 
+    def rebuild_from_nbrs(self, nbrs: torch.Tensor):
+        """Re-plan IN PLACE for another directed edge list on the same nodes (at most ``capacity`` edges)."""
+        nbrs = nbrs.long().contiguous()
+        if nbrs.shape[0] > self.capacity:
+            raise ValueError(f"{nbrs.shape[0]} edges exceed the plan's capacity of {self.capacity}")
+        self.n_edges = int(nbrs.shape[0])
+        if self.n_edges == 0:
+            dummy = torch.zeros(2, dtype=torch.int64, device=self.device)
+            self._build(dummy, dummy[1:], 2)
+        else:
+            self._build(nbrs.view(-1), nbrs.view(-1)[1:], 2)
+
     @classmethod
-    def from_nbrs(cls, nbrs: torch.Tensor, n_nodes: int) -> "EdgePlan":
+    def from_nbrs(cls, nbrs: torch.Tensor, n_nodes: int, capacity: int = 0) -> "EdgePlan":
         """Plan for a directed ``[E,2]`` int64 edge list on a graph with ``n_nodes`` nodes."""
         if nbrs.dtype != torch.int64:
             nbrs = nbrs.long()
         nbrs = nbrs.contiguous()
         if nbrs.shape[0] == 0:
             dummy = torch.zeros(2, dtype=torch.int64, device=nbrs.device)
-            return cls(dummy, dummy[1:], 2, 0, n_nodes, n_nodes)
+            return cls(dummy, dummy[1:], 2, 0, n_nodes, n_nodes, capacity)
         # dst = column 0, src = column 1, element stride 2
-        return cls(nbrs.view(-1), nbrs.view(-1)[1:], 2, nbrs.shape[0], n_nodes, n_nodes)
+        return cls(nbrs.view(-1), nbrs.view(-1)[1:], 2, nbrs.shape[0], n_nodes, n_nodes, capacity)
 
     @classmethod
     def from_mapping(cls, mapping: torch.Tensor, n_beads: int) -> "EdgePlan":
@@ -155,7 +172,7 @@ class EdgeGeometry:
         R, U = self.n_rbf, self.unit_offset
         return torch.cat([rows[:, :R + 1], rows[:, U:U + 3]], dim=1)
 
-    __slots__ = ("geom_d", "geom_s", "n_rbf", "cutoff", "stride", "unit_offset")
+    __slots__ = ("geom_d", "geom_s", "n_rbf", "cutoff", "stride", "unit_offset", "coef")
 
     def __init__(self, plan: EdgePlan, n_rbf: int, cutoff: float, r_edges: Optional[torch.Tensor] = None,
                  pos_dst: Optional[torch.Tensor] = None, pos_src: Optional[torch.Tensor] = None):
@@ -166,10 +183,16 @@ class EdgeGeometry:
         self.stride = int(lib.cgv_geom_stride(n_rbf))
         self.unit_offset = int(lib.cgv_geom_unit_offset(n_rbf))
         dev = plan.device
-        E = max(plan.n_edges, 1)
+        E = max(plan.capacity, 1)                    # records for as many edges as the plan can be rebuilt with
         self.geom_d = torch.empty(E, self.stride, dtype=torch.float32, device=dev)
         self.geom_s = torch.empty(E, self.stride, dtype=torch.float32, device=dev)
-        coef = rbf_coefficients(n_rbf, cutoff, dev)
+        self.coef = rbf_coefficients(n_rbf, cutoff, dev)
+        self.rebuild(plan, r_edges=r_edges, pos_dst=pos_dst, pos_src=pos_src)
+
+    def rebuild(self, plan: EdgePlan, r_edges: Optional[torch.Tensor] = None, pos_dst: Optional[torch.Tensor] = None,
+                pos_src: Optional[torch.Tensor] = None):
+        """(Re)compute the records of ``plan``'s current edges into the same buffers."""
+        coef = self.coef
         st = _lib.stream_ptr()
         if r_edges is not None:
             if r_edges.requires_grad:
@@ -199,15 +222,18 @@ class BatchGraph:
     decoder use different RBF cutoffs on the same edges (run_ala.py:196-206).
     """
 
-    def __init__(self, xyz, cg_xyz, mapping, nbr_list, cg_nbr_list):
-        self.xyz = xyz.detach().contiguous().float()
-        self.cg_xyz = cg_xyz.detach().contiguous().float()
+    def __init__(self, xyz, cg_xyz, mapping, nbr_list, cg_nbr_list, edge_slack: float = 0.0):
+        """``edge_slack``: fraction of extra edge capacity in the atom / bead plans and their geometry records, so
+        that ``update`` can re-plan another batch of the same molecules in place (hipGraph replay)."""
+        self.xyz = xyz.detach().contiguous().float().clone()
+        self.cg_xyz = cg_xyz.detach().contiguous().float().clone()
         n, n_cg = self.xyz.shape[0], self.cg_xyz.shape[0]
         self.mapping = mapping.long()
         self.atom_nbrs, _ = make_directed(nbr_list)
         self.cg_nbrs, _ = make_directed(cg_nbr_list)
-        self.atom = EdgePlan.from_nbrs(self.atom_nbrs, n)
-        self.cg = EdgePlan.from_nbrs(self.cg_nbrs, n_cg)
+        cap = lambda e: int(e * (1.0 + edge_slack)) + (64 if edge_slack > 0 else 0)
+        self.atom = EdgePlan.from_nbrs(self.atom_nbrs, n, capacity=cap(self.atom_nbrs.shape[0]))
+        self.cg = EdgePlan.from_nbrs(self.cg_nbrs, n_cg, capacity=cap(self.cg_nbrs.shape[0]))
         self.a2b = EdgePlan.from_mapping(self.mapping, n_cg)
         # rank inside the bead = position in the (stable) bead-sorted order minus the bead's start
         p = self.a2b
@@ -215,6 +241,37 @@ class BatchGraph:
         self.chan = torch.empty(n, dtype=torch.int64, device=self.xyz.device)
         self.chan[p.eid_d[:n].long()] = rank_sorted
         self._geom = {}
+
+    def _positions(self, which: str):
+        if which == "atom":
+            return self.atom, self.xyz, self.xyz
+        if which == "cg":
+            return self.cg, self.cg_xyz, self.cg_xyz
+        if which == "a2b":
+            return self.a2b, self.cg_xyz, self.xyz
+        raise KeyError(which)
+
+    def fits(self, xyz, cg_xyz, mapping, nbr_list, cg_nbr_list) -> bool:
+        """Can ``update`` take this batch?  Same molecules (node counts, atom -> bead map) and edge counts within
+        the capacity reserved by ``edge_slack``.  (Compares the mapping on the device: one small sync.)"""
+        return (tuple(xyz.shape) == tuple(self.xyz.shape) and tuple(cg_xyz.shape) == tuple(self.cg_xyz.shape)
+                and 2 * nbr_list.shape[0] <= self.atom.capacity and 2 * cg_nbr_list.shape[0] <= self.cg.capacity
+                and tuple(mapping.shape) == tuple(self.mapping.shape)
+                and bool(torch.equal(mapping.long().to(self.mapping.device), self.mapping)))
+
+    def update(self, xyz, cg_xyz, nbr_list, cg_nbr_list):
+        """Take another batch of the same molecules IN PLACE: coordinates are copied, both edge plans are re-sorted
+        into their existing arrays and every cached geometry is recomputed into its existing records.  Addresses
+        do not change, so a hipGraph captured on this bundle can be replayed afterwards."""
+        self.xyz.copy_(xyz.detach().float())
+        self.cg_xyz.copy_(cg_xyz.detach().float())
+        self.atom_nbrs, _ = make_directed(nbr_list)
+        self.cg_nbrs, _ = make_directed(cg_nbr_list)
+        self.atom.rebuild_from_nbrs(self.atom_nbrs)
+        self.cg.rebuild_from_nbrs(self.cg_nbrs)
+        for (which, _r, _c), g in self._geom.items():
+            plan, pd, ps = self._positions(which)
+            g.rebuild(plan, pos_dst=pd, pos_src=ps)
 
     def geometry(self, which: str, n_rbf: int, cutoff: float) -> EdgeGeometry:
         key = (which, int(n_rbf), float(cutoff))

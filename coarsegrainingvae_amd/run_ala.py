@@ -72,6 +72,8 @@ def build_parser() -> argparse.ArgumentParser:
     for flag in ("cross", "graph_eval", "shuffle", "cg_mp", "tqdm_flag", "det", "cg_radius_graph", "invariantdec",
                  "reflectiontest"):
         p.add_argument("--" + flag, action="store_true", default=False)
+    p.add_argument("--no_hip_graph", action="store_true", default=False,
+                   help="launch every kernel of every step eagerly instead of replaying one captured hipGraph per step")
     p.add_argument("--synthetic", action="store_true", default=False,
                    help="random-coordinate frames of the dataset's shape (no trajectories offline)")
     return p
@@ -119,14 +121,21 @@ def _device(arg: str) -> torch.device:
     return torch.device("cuda", int(arg)) if arg.isdigit() else torch.device(arg)
 
 
-def _batches(dataset, indices, batch_size, rank, world, device):
-    """Collate `batch_size` frames per step and give this rank its equal-size shard."""
+def _batches(dataset, indices, batch_size, rank, world, device, prepared=None):
+    """Collate `batch_size` frames per step and give this rank its equal-size shard.  ``prepared()`` says whether
+    a captured step exists: then the collated batch is handed over as is (the trainer loads it into the captured
+    batch's buffers and replays); otherwise it gets its own graph bundle, with spare edge capacity so that it
+    can become the captured batch."""
     if 0 < len(indices) < batch_size:                     # small validation split: one (world-divisible) batch
         indices, batch_size = indices[:len(indices) // world * world], len(indices) // world * world
     for start in range(0, len(indices) - batch_size + 1, max(batch_size, 1)):
         chunk = indices[start:start + batch_size]
         shard = chunk[rank::world] if world > 1 else chunk
-        yield cgdata.prepare_batch(cgdata.CG_collate([dataset[i] for i in shard]), device)
+        collated = cgdata.CG_collate([dataset[i] for i in shard])
+        if prepared is not None and prepared():
+            yield cgdata.batch_to(collated, device)
+        else:
+            yield cgdata.prepare_batch(collated, device, edge_slack=0.25 if prepared is not None else 0.0)
 
 
 def run(params) -> dict:
@@ -168,6 +177,7 @@ def run(params) -> dict:
     if params["optimizer"] != "adam":
         raise SystemExit("the fused optimiser step implements Adam (the reference's documented runs use adam)")
     trainer = Trainer(model, lr=params["lr"], beta=beta, gamma=params["gamma"], world_size=world)
+    use_graph = not params.get("no_hip_graph", False)                     # capture the step once, replay it on every batch
     min_lr, best, bad_epochs = 5e-8, None, 0                              # ReduceLROnPlateau(patience=2), run_ala.py:212-214
     early = EarlyStopping(patience=params["patience"])
     logdir = resolve_logdir(params) if params["logdir"] else None
@@ -184,9 +194,13 @@ def run(params) -> dict:
         stats = {}
         for mode, idx in (("train", train_idx), ("val", val_idx)):
             tot, kls, recs, grs = [], [], [], []
-            for batch in _batches(dataset, idx, params["batch_size"], rank, world, device):
-                loss = trainer.step(batch, train=(mode == "train"))
-                kl, recon, graph = trainer.last_terms
+            is_train = mode == "train"
+            ready = (lambda t=is_train: t in trainer._graphs) if use_graph else None
+            for batch in _batches(dataset, idx, params["batch_size"], rank, world, device, prepared=ready):
+                if use_graph and trainer.arena is not None and is_train not in trainer._graphs and "_graph" in batch:
+                    trainer.capture(batch, warmup=0, train=is_train)       # from the second step on: one graph per mode
+                loss = trainer.step(batch, train=is_train).clone()         # (a replay refreshes the result tensors in place)
+                kl, recon, graph = (t.clone() for t in trainer.last_terms)
                 tot.append(loss), kls.append(kl), recs.append(recon), grs.append(graph)
                 frames_seen += params["batch_size"] if mode == "train" else 0
             mean = lambda xs: float(torch.stack(xs).mean()) if xs else float("nan")     # one sync per epoch

@@ -125,8 +125,8 @@ class Trainer:
         self.last_loss = None
         self.last_terms = None
         self.steps_skipped_host = 0
-        self._graph = None            # captured hipGraph of one full step (capture())
-        self._graph_batch = None
+        self._graphs = {}             # train flag -> captured hipGraph of one full step (capture())
+        self.replays = 0
 
     # ------------------------------------------------------------------ setup after the first backward
     def _build_arena(self):
@@ -166,24 +166,34 @@ class Trainer:
             self.torch_opt = torch.optim.Adam(live, lr=self.lr, betas=self.betas, eps=self.eps)
 
     # ------------------------------------------------------------------ hipGraph capture of the whole step
-    def capture(self, batch, warmup: int = 2):
+    def capture(self, batch, warmup: int = 2, train: bool = True):
         """Capture forward + loss + backward (+ all-reduce) + clip/Adam on ``batch`` into one
         hipGraph.  Every kernel of the step reads sizes that are fixed for a given molecule
         (N atoms, beads, bonds) and takes its edge structure from device memory (CSR plans), so
-        the step is host-sync free and replayable: ``step(batch)`` on the captured batch object
-        becomes a single graph launch instead of ~1000 eager launches (the kernels are
-        microseconds long at the dipeptide / chignolin sizes -- SURVEY 8f item 1).
-        To train on a new batch of the same shapes, copy it into the captured batch's tensors /
-        plan arrays in place (``data.copy_batch_into``) and replay."""
+        the step is host-sync free and replayable: ``step(batch)`` becomes a single graph launch
+        instead of ~1000 eager launches (the kernels are microseconds long at the dipeptide /
+        chignolin sizes -- SURVEY 8f item 1).
+        ``step`` on ANOTHER batch of the same molecules loads it into the captured batch's tensors and
+        plan arrays in place (``data.copy_batch_into``; prepare the captured batch with some
+        ``edge_slack``) and replays; batches that do not fit run eagerly.  ``train=False`` captures the
+        validation flavour (forward + backward, no optimiser: scripts/utils.py:159-160)."""
         if not self.fused:
             raise RuntimeError("graph capture needs the fused (sync-free) optimiser path")
         if self.arena is None:
             self._step_eager(batch)                        # builds the arena (first backward)
+        if warmup == 0:
+            # nothing may be built lazily inside the capture (geometry records of this batch: H2D copies): one
+            # forward without gradients, random stream restored, leaves the parameters and the sampling untouched
+            dev = self.arena.p.device
+            rng = torch.cuda.get_rng_state(dev)
+            with torch.no_grad():
+                self.model(batch)
+            torch.cuda.set_rng_state(rng, dev)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                self._step_eager(batch)
+                self._step_eager(batch, train=train)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         if self.sync is not None:
@@ -193,15 +203,39 @@ class Trainer:
         # with RCCL in the step, other threads (the process group's watchdog) legitimately touch the runtime
         mode = "thread_local" if self.sync is not None else "global"
         with torch.cuda.graph(graph, capture_error_mode=mode):
-            self._step_eager(batch)
-        self._graph, self._graph_batch = graph, batch
+            self._step_eager(batch, train=train)
+        # the step's result tensors live in the graph's pool: a replay refreshes them in place
+        self._graphs[bool(train)] = {"graph": graph, "batch": batch, "lr": self.lr,
+                                     "results": (self.last_loss, self.last_terms, self.last_out)}
         return graph
 
+    @property
+    def _graph(self):                                       # the training graph (None until captured)
+        cap = self._graphs.get(True)
+        return cap["graph"] if cap else None
+
     def step(self, batch, eps: Optional[torch.Tensor] = None, train: bool = True):
-        if self._graph is not None and batch is self._graph_batch and eps is None and train:
-            self._graph.replay()
-            return self.last_loss
+        cap = self._graphs.get(bool(train))
+        if cap is not None and eps is None:
+            if train and cap["lr"] != self.lr:              # the learning rate is a launch argument: re-capture
+                self.capture(cap["batch"], warmup=0, train=True)
+                cap = self._graphs[True]
+            if batch is cap["batch"] or self._load(cap["batch"], batch):
+                cap["graph"].replay()
+                self.last_loss, self.last_terms, self.last_out = cap["results"]
+                self.replays += 1
+                return self.last_loss
+        if "_graph" not in batch:
+            from .data import prepare_batch
+            dev = next(self.model.parameters()).device
+            if dev.type == "cuda":
+                batch = prepare_batch(batch, dev)           # to the device; plans / geometry once, not inside the forward
         return self._step_eager(batch, eps, train)
+
+    @staticmethod
+    def _load(captured, batch) -> bool:
+        from .data import copy_batch_into
+        return copy_batch_into(captured, batch)
 
     # ------------------------------------------------------------------ one iteration
     def _step_eager(self, batch, eps: Optional[torch.Tensor] = None, train: bool = True):

@@ -31,8 +31,8 @@ def test_flag_surface_matches_reference():
         a = actions[name]
         assert a.option_strings == ["--" + name] and a.default is False and a.const is True
     assert actions["dec_type"].default == "EquivariantDecoder"
-    assert "device" in actions and "synthetic" in actions
-    assert len(actions) == len(REFERENCE_FLAGS) + len(STORE_TRUE) + 3
+    assert "device" in actions and "synthetic" in actions and "no_hip_graph" in actions     # this build's own switches
+    assert len(actions) == len(REFERENCE_FLAGS) + len(STORE_TRUE) + 4
     # the two documented experiments parse (README.md:57-65)
     ns = parser.parse_args("-logdir x -device 0 -dataset chignolin -n_cgs 6 -batch_size 2 -ndata 5000 -nepochs 100 "
                            "-atom_cutoff 12.0 -cg_cutoff 25.0 -nsplits 5 -beta 0.05 -gamma 50.0 -eta 0.0 -kappa 0.0 "

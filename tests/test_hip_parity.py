@@ -760,3 +760,45 @@ def test_equi_message_high_degree_split_path():
     assert nbrs.shape[0] >= 48 * n
     _block_vs_oracle(48, 10, n, nbrs, xyz, True, seed=1)
     _block_vs_oracle(48, 10, n, nbrs, xyz, False, seed=2)
+
+
+# --------------------------------------------------------------------------- hipGraph replay across batches
+def test_captured_step_replays_on_other_batches():
+    """Trainer.capture on one batch, then step() on OTHER batches of the same molecules: they are loaded into the
+    captured batch's buffers (data.copy_batch_into: coordinates copied, plans re-sorted and geometry recomputed in
+    place) and the graph is replayed.  Must equal an eager trainer fed the same sequence; a batch whose edge
+    count exceeds the reserved capacity runs eagerly."""
+    from coarsegrainingvae_amd.trainer import Trainer
+    w = cg.data.WORKLOADS["dipeptide"]
+
+    def make(seed, box=None):
+        frames = cg.data.synthetic_frames(4, 22, w["n_cgs"], box or w["box"], seed=seed)
+        ds = cg.CGDataset(frames)
+        ds.generate_neighbor_list(ATOM_CUT, w["cg_cutoff"], device=DEV, undirected=True)
+        return cg.CG_collate([ds[i] for i in range(4)])
+
+    ATOM_CUT = 3.5                                            # sparse enough that the edge count differs per batch
+    seqs = [make(1), make(2), make(3), make(2)]
+    assert len({b["nbr_list"].shape[0] for b in seqs}) > 1
+    dense = make(4, box=2.5)                                  # everything within the cutoff: far more edges
+    assert dense["nbr_list"].shape[0] > 1.3 * max(b["nbr_list"].shape[0] for b in seqs)
+
+    def run(use_graph):
+        model = cg.build_model(64, w["n_rbf"], ATOM_CUT, w["cg_cutoff"], 2, 2, w["n_cgs"], det=True, seed=7).to(DEV)
+        tr = Trainer(model, lr=1e-3, beta=w["beta"], gamma=w["gamma"])
+        first = cg.data.prepare_batch({k: v.clone() for k, v in seqs[0].items()}, DEV, edge_slack=0.25)
+        losses = [float(tr.step(first))]                      # builds the arena
+        if use_graph:
+            tr.capture(first, warmup=0)
+        for b in seqs[1:] + [dense, seqs[1]]:
+            losses.append(float(tr.step({k: v.clone() for k, v in b.items()})))
+        losses.append(float(tr.step({k: v.clone() for k, v in seqs[2].items()}, train=False)))
+        return losses, [p.detach().clone() for p in model.parameters()], tr
+
+    ref_losses, ref_params, _ = run(False)
+    losses, params, tr = run(True)
+    assert tr.replays == 4                                    # seqs[1], seqs[2], seqs[1 again], seqs[1]; dense + eval: eager
+    for a, b in zip(losses, ref_losses):
+        assert abs(a - b) <= 1e-5 * abs(b), (losses, ref_losses)
+    for p, q in zip(params, ref_params):
+        assert_close(p, q, "parameter after replayed steps", 1e-5)
