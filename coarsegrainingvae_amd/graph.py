@@ -229,6 +229,7 @@ class BatchGraph:
         self.cg_xyz = cg_xyz.detach().contiguous().float().clone()
         n, n_cg = self.xyz.shape[0], self.cg_xyz.shape[0]
         self.mapping = mapping.long()
+        self.mapping_cpu = None                       # host copy, made on the first ``fits`` that needs it
         self.atom_nbrs, _ = make_directed(nbr_list)
         self.cg_nbrs, _ = make_directed(cg_nbr_list)
         cap = lambda e: int(e * (1.0 + edge_slack)) + (64 if edge_slack > 0 else 0)
@@ -254,19 +255,31 @@ class BatchGraph:
     def fits(self, xyz, cg_xyz, mapping, nbr_list, cg_nbr_list) -> bool:
         """Can ``update`` take this batch?  Same molecules (node counts, atom -> bead map) and edge counts within
         the capacity reserved by ``edge_slack``.  (Compares the mapping on the device: one small sync.)"""
-        return (tuple(xyz.shape) == tuple(self.xyz.shape) and tuple(cg_xyz.shape) == tuple(self.cg_xyz.shape)
+        if not (tuple(xyz.shape) == tuple(self.xyz.shape) and tuple(cg_xyz.shape) == tuple(self.cg_xyz.shape)
                 and 2 * nbr_list.shape[0] <= self.atom.capacity and 2 * cg_nbr_list.shape[0] <= self.cg.capacity
-                and tuple(mapping.shape) == tuple(self.mapping.shape)
-                and bool(torch.equal(mapping.long().to(self.mapping.device), self.mapping)))
+                and tuple(mapping.shape) == tuple(self.mapping.shape)):
+            return False
+        if mapping.is_cuda:
+            return bool(torch.equal(mapping.long(), self.mapping))
+        if self.mapping_cpu is None:
+            self.mapping_cpu = self.mapping.cpu()
+        return bool(torch.equal(mapping.long(), self.mapping_cpu))      # host batch: no device sync
 
-    def update(self, xyz, cg_xyz, nbr_list, cg_nbr_list):
+    def update(self, xyz, cg_xyz, nbr_list, cg_nbr_list, directed: bool = False):
         """Take another batch of the same molecules IN PLACE: coordinates are copied, both edge plans are re-sorted
         into their existing arrays and every cached geometry is recomputed into its existing records.  Addresses
-        do not change, so a hipGraph captured on this bundle can be replayed afterwards."""
-        self.xyz.copy_(xyz.detach().float())
-        self.cg_xyz.copy_(cg_xyz.detach().float())
-        self.atom_nbrs, _ = make_directed(nbr_list)
-        self.cg_nbrs, _ = make_directed(cg_nbr_list)
+        do not change, so a hipGraph captured on this bundle can be replayed afterwards.  ``directed=True``: the
+        lists are device tensors that already hold both directions (``make_directed`` done by the caller)."""
+        dev = self.xyz.device
+        if xyz.data_ptr() != self.xyz.data_ptr():
+            self.xyz.copy_(xyz.detach().float(), non_blocking=True)
+        if cg_xyz.data_ptr() != self.cg_xyz.data_ptr():
+            self.cg_xyz.copy_(cg_xyz.detach().float(), non_blocking=True)
+        if directed:
+            self.atom_nbrs, self.cg_nbrs = nbr_list, cg_nbr_list
+        else:
+            self.atom_nbrs = make_directed(nbr_list)[0].to(dev)
+            self.cg_nbrs = make_directed(cg_nbr_list)[0].to(dev)
         self.atom.rebuild_from_nbrs(self.atom_nbrs)
         self.cg.rebuild_from_nbrs(self.cg_nbrs)
         for (which, _r, _c), g in self._geom.items():

@@ -133,7 +133,7 @@ def _batches(dataset, indices, batch_size, rank, world, device, prepared=None):
         shard = chunk[rank::world] if world > 1 else chunk
         collated = cgdata.CG_collate([dataset[i] for i in shard])
         if prepared is not None and prepared():
-            yield cgdata.batch_to(collated, device)
+            yield collated                                 # host tensors: checked on the host, copied in by the trainer
         else:
             yield cgdata.prepare_batch(collated, device, edge_slack=0.25 if prepared is not None else 0.0)
 
@@ -143,6 +143,9 @@ def run(params) -> dict:
     rank = int(os.environ.get("RANK", "0"))
     device = _device(str(params["device"]))
     torch.cuda.set_device(device)
+    # the host side of a step is a few small tensor ops (collate, make_directed): on a many-core host torch's
+    # default intra-op pool (one thread per core) turns each of them into a ~90 ms thread wake-up storm
+    torch.set_num_threads(min(torch.get_num_threads(), 8))
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
