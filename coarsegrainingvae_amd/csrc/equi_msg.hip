@@ -716,8 +716,8 @@ int cgv_equi_msg_fwd(const float* phi, const float* v, const float* geom_d, cons
   const int tiles = (n_feat + 127) / 128;
   const int npx = (n_dst + 7) / 8;
   const dim3 grid(8 * npx * tiles);
-  // high-degree graphs (>= 48 edges per receiver on average): 4 waves share a (node, tile)
-  bool split = n_edges_hint >= 48LL * n_dst;
+  // >= 16 edges per receiver on average: 4 waves share a (node, tile) (the atom graph: 125; atom -> bead: 28)
+  bool split = n_edges_hint >= 16LL * n_dst;
   if (const char* dbg = getenv("CGV_DEBUG_FWD_SPLIT")) split = dbg[0] == '1';   // experiments only
   // 8-byte vector accesses need an even channel count and 8-byte aligned bases; the buffer-descriptor
   // gathers need every row within 2 GiB of the base (n_rows_hint = rows of phi / v, 0 = unknown)
