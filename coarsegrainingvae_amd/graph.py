@@ -138,6 +138,13 @@ class EdgePlan:
         else:
             self._build(nbrs.view(-1), nbrs.view(-1)[1:], 2)
 
+    def rebuild_from_mapping(self, mapping: torch.Tensor):
+        """Re-plan IN PLACE a ``from_mapping`` plan for another index vector of the same length."""
+        mapping = mapping.long().contiguous()
+        if mapping.shape[0] != self.n_edges:
+            raise ValueError("a mapping plan keeps its length")
+        self._build(mapping, None, 1)
+
     @classmethod
     def from_nbrs(cls, nbrs: torch.Tensor, n_nodes: int, capacity: int = 0) -> "EdgePlan":
         """Plan for a directed ``[E,2]`` int64 edge list on a graph with ``n_nodes`` nodes."""
@@ -242,6 +249,7 @@ class BatchGraph:
         self.chan = torch.empty(n, dtype=torch.int64, device=self.xyz.device)
         self.chan[p.eid_d[:n].long()] = rank_sorted
         self._geom = {}
+        self._embed = {}
 
     def _positions(self, which: str):
         if which == "atom":
@@ -285,6 +293,22 @@ class BatchGraph:
         for (which, _r, _c), g in self._geom.items():
             plan, pd, ps = self._positions(which)
             g.rebuild(plan, pos_dst=pd, pos_src=ps)
+        for (_which, n_types, pad), (plan, idx) in self._embed.items():
+            # ``idx`` is a view of the batch tensor the caller has just refreshed in place (type ids may differ)
+            ids = idx.long()
+            if pad is not None:
+                ids = torch.where(ids == pad, torch.full_like(ids, n_types), ids)
+            plan.rebuild_from_mapping(ids)
+
+    def embed_plan(self, which: str, idx: torch.Tensor, module) -> EdgePlan:
+        """Type-id grouping of the atoms (``"atom"``) or beads (``"cg"``) for the embedding weight gradient; cached:
+        the ids belong to the molecules, which ``update`` keeps."""
+        key = (which, int(module.weight.shape[0]), module.padding_idx)
+        hit = self._embed.get(key)
+        if hit is None:
+            from .ops import embedding_plan
+            hit = self._embed[key] = (embedding_plan(idx, module.weight.shape[0], module.padding_idx), idx)
+        return hit[0]
 
     def geometry(self, which: str, n_rbf: int, cutoff: float) -> EdgeGeometry:
         key = (which, int(n_rbf), float(cutoff))

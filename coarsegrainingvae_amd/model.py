@@ -17,7 +17,7 @@ from torch import nn
 from . import ops
 from .blocks import (ContractiveMessageBlock, EquiMessageBlock, EquiMessagePsuedo, PseudoUpdateBlock, UpdateBlock)
 from .graph import BatchGraph, EdgePlan, make_directed
-from .primitives import Dense, DistanceEmbed, Linear, to_module
+from .primitives import Dense, DistanceEmbed, Linear, mark_direct_grad, to_module
 
 
 def _call_then_pass(fn):
@@ -82,6 +82,7 @@ class EquiEncoder(nn.Module):
         super().__init__()
         F = n_atom_basis
         self.atom_embed = nn.Embedding(100, F, padding_idx=0)
+        mark_direct_grad(self.atom_embed.weight)        # ops.embedding writes the gradient in place
         mk_msg = lambda: EquiMessageBlock(feat_dim=F, activation=activation, n_rbf=n_rbf, cutoff=cutoff, dropout=0.0)
         mk_upd = lambda: UpdateBlock(feat_dim=F, activation=activation, dropout=0.0)
         # registration order = the reference's, for key order and same-seed init
@@ -115,7 +116,7 @@ class EquiEncoder(nn.Module):
             graph = BatchGraph(xyz, cg_xyz, mapping, nbr_list, cg_nbr_list)
         geom = graph.geometry("atom", self.n_rbf, self.cutoff)
         geom_c = graph.geometry("a2b", self.n_rbf, 20.0)
-        h = self.atom_embed(z.long())
+        h = ops.embedding(self.atom_embed, z, graph.embed_plan("atom", z, self.atom_embed) if graph is not None else None)
         v = torch.zeros(h.shape[0], h.shape[1], 3, device=h.device)
         H = V = None
         for i in range(self.n_conv):
@@ -135,6 +136,7 @@ class CGprior(nn.Module):
         super().__init__()
         F = n_atom_basis
         self.atom_embed = nn.Embedding(100, F, padding_idx=0)
+        mark_direct_grad(self.atom_embed.weight)        # ops.embedding writes the gradient in place
         self.dist_embed = DistanceEmbed(n_rbf=n_rbf, cutoff=cutoff, feat_dim=F, dropout=0.0)           # unused
         self.message_blocks = nn.ModuleList(
             [EquiMessageBlock(feat_dim=F, activation=activation, n_rbf=n_rbf, cutoff=cutoff, dropout=0.0)
@@ -159,7 +161,7 @@ class CGprior(nn.Module):
             nbrs, _ = make_directed(cg_nbr_list)
             plan = EdgePlan.from_nbrs(nbrs, cg_xyz.shape[0])
             geom = EdgeGeometry(plan, self.n_rbf, self.cutoff, pos_dst=cg_xyz, pos_src=cg_xyz)
-        h = self.atom_embed(cg_z.long())
+        h = ops.embedding(self.atom_embed, cg_z, graph.embed_plan("cg", cg_z, self.atom_embed) if graph is not None else None)
         v = torch.zeros(h.shape[0], h.shape[1], 3, device=h.device)
         for blk in self.message_blocks:
             h, v = blk(h, v, None, nbrs, plan=plan, geom=geom, residual=True)      # h += ds, v += dv fused (cgvae.py:391-392)

@@ -762,6 +762,24 @@ def test_equi_message_high_degree_split_path():
     _block_vs_oracle(48, 10, n, nbrs, xyz, False, seed=2)
 
 
+def test_embedding_plan_gradient_matches_nn_embedding():
+    """ops.embedding: lookup + plan-based weight gradient (one segment sum) == nn.Embedding incl. padding_idx."""
+    torch.manual_seed(2)
+    emb = torch.nn.Embedding(100, 24, padding_idx=0).to(DEV)
+    idx = torch.randint(0, 9, (57,), device=DEV)
+    idx[3] = 0                                               # a padding row in the batch: its gradient stays zero
+    gout = torch.randn(57, 24, device=DEV)
+    ref = emb(idx)
+    ref.backward(gout)
+    want = emb.weight.grad.clone()
+    emb.weight.grad = None
+    out = cg.ops.embedding(emb, idx.float())                 # ids arrive as the float column of nxyz
+    out.backward(gout)
+    assert torch.equal(out, ref)
+    assert_close(emb.weight.grad, want, "embedding weight grad", 1e-6)
+    assert float(emb.weight.grad[0].abs().max()) == 0.0
+
+
 # --------------------------------------------------------------------------- hipGraph replay across batches
 def test_captured_step_replays_on_other_batches():
     """Trainer.capture on one batch, then step() on OTHER batches of the same molecules: they are loaded into the
