@@ -63,4 +63,26 @@ __device__ inline void st3(float* p, float x, float y, float z) {
       return CGV_E_UNSUPPORTED;                                             \
   }
 
+// Activations of the Dense / nn.Linear kernels (fused into epilogues and operand loads):
+//   0 identity   1 Swish x*sigmoid(x) (modules.py:16-21)   2 tanh   3 ReLU   (nn.Tanh / nn.ReLU of the mu / sigma heads)
+// act_bwd is the derivative as a function of the PRE-activation z.
+constexpr int CGV_ACT_MAX = 3;
+__device__ __forceinline__ float act_sigmoid(float z) { return 1.0f / (1.0f + expf(-z)); }
+__device__ __forceinline__ float act_fwd(float z, int act) {
+  switch (act) {
+    case 1: return z * act_sigmoid(z);
+    case 2: return tanhf(z);
+    case 3: return z > 0.f ? z : 0.f;
+    default: return z;
+  }
+}
+__device__ __forceinline__ float act_bwd(float z, int act) {
+  switch (act) {
+    case 1: { const float s = act_sigmoid(z); return s * (1.0f + z * (1.0f - s)); }
+    case 2: { const float t = tanhf(z); return 1.0f - t * t; }
+    case 3: return z > 0.f ? 1.0f : 0.f;
+    default: return 1.0f;
+  }
+}
+
 }  // namespace cgv

@@ -27,15 +27,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 ldg4_or_zero(const float* p, bool ok) {
   return ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
 }
-__device__ __forceinline__ float sigmoidf_(float z) { return 1.0f / (1.0f + expf(-z)); }
-// act: 0 = identity, 1 = Swish / SiLU  x * sigmoid(x)
-__device__ __forceinline__ float act_fwd(float z, int act) { return act == 1 ? z * sigmoidf_(z) : z; }
-__device__ __forceinline__ float act_bwd(float z, int act) {
-  if (act != 1) return 1.0f;
-  const float s = sigmoidf_(z);
-  return s * (1.0f + z * (1.0f - s));
-}
-
 // ------------------------------------------------------------------ fwd
 // Block = 16 output columns n0..n0+15, WAVES waves splitting K in whole 16-float steps.  Lane
 // (i = l&15, q = l>>4) loads W[n0+i, 16 s + 4 q .. +3] (16 rows x 64 contiguous bytes per wave
@@ -437,7 +428,7 @@ int cgv_skinny_supported(int M, int N, int K) {
 int cgv_skinny_linear_fwd(const float* x, const float* W, const float* bias, float* y, float* z, int M, int N, int K,
                           int act, void* stream) {
   CGV_REQUIRE(x && W && y, "null pointer");
-  CGV_REQUIRE(act == 0 || act == 1, "act must be 0 (identity) or 1 (swish)");
+  CGV_REQUIRE(act >= 0 && act <= cgv::CGV_ACT_MAX, "act must be 0 (identity), 1 (swish), 2 (tanh) or 3 (relu)");
   CGV_REQUIRE(cgv_skinny_supported(M, N, K), "unsupported shape (need M <= 64, N % 4 == 0, K % 4 == 0)");
   CGV_REQUIRE(((((uintptr_t)x | (uintptr_t)W | (uintptr_t)y | (uintptr_t)bias | (uintptr_t)z)) & 15) == 0,
               "operands must be 16-byte aligned");
@@ -464,7 +455,7 @@ size_t cgv_skinny_bwd_input_workspace_bytes(int M, int N, int K) {
 int cgv_skinny_linear_bwd_input(const float* gy, const float* z, const float* W, float* gx, int M, int N, int K, int act,
                                 void* ws, size_t ws_bytes, void* stream) {
   CGV_REQUIRE(gy && W && gx, "null pointer");
-  CGV_REQUIRE(act == 0 || (act == 1 && z), "act = 1 needs the saved pre-activation z");
+  CGV_REQUIRE(act == 0 || (act >= 1 && act <= cgv::CGV_ACT_MAX && z), "act != 0 needs the saved pre-activation z");
   CGV_REQUIRE(cgv_skinny_supported(M, N, K), "unsupported shape (need M <= 64, N % 4 == 0, K % 4 == 0)");
   CGV_REQUIRE(((((uintptr_t)gx) | ((uintptr_t)W) | ((uintptr_t)ws)) & 15) == 0, "gx, W, ws must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
@@ -484,7 +475,7 @@ int cgv_skinny_linear_bwd_input(const float* gy, const float* z, const float* W,
 int cgv_dense_grad_prepare(const float* gy, const float* z, float* g_out, float* gb, int M, int N, int act, int accumulate,
                            void* stream) {
   CGV_REQUIRE(gy && M >= 0 && N > 0, "bad argument");
-  CGV_REQUIRE(act == 0 || (act == 1 && z), "act = 1 needs the saved pre-activation z");
+  CGV_REQUIRE(act == 0 || (act >= 1 && act <= cgv::CGV_ACT_MAX && z), "act != 0 needs the saved pre-activation z");
   CGV_REQUIRE(gb || (act && g_out), "nothing to compute");
   CGV_REQUIRE((N % 4) == 0 && ((((uintptr_t)gy | (uintptr_t)z | (uintptr_t)g_out)) & 15) == 0, "need N % 4 == 0, 16-byte aligned");
   if (M == 0 && !gb) return 0;

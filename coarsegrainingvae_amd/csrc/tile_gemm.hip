@@ -28,7 +28,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 ld4z(const float* p, bool ok) {
   return ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
 }
-__device__ __forceinline__ float tg_sigmoid(float z) { return 1.0f / (1.0f + expf(-z)); }
 
 #define CGV_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
@@ -113,7 +112,7 @@ __global__ __launch_bounds__(64 * QM * QN * KW) void tile_fwd_k(const float* __r
     zv += bv;
     if (act) {
       if (zout) zout[(size_t)m * N + n] = zv;
-      zv = zv * tg_sigmoid(zv);
+      zv = act_fwd(zv, act);
     }
     y[(size_t)m * N + n] = zv;
   }
@@ -270,7 +269,7 @@ int cgv_tile_supported(int M, int N, int K) {
 int cgv_tile_linear_fwd(const float* x, const float* W, const float* bias, float* y, float* z, int M, int N, int K, int act,
                         void* stream) {
   CGV_REQUIRE(x && W && y, "null pointer");
-  CGV_REQUIRE(act == 0 || act == 1, "act must be 0 (identity) or 1 (swish)");
+  CGV_REQUIRE(act >= 0 && act <= cgv::CGV_ACT_MAX, "act must be 0 (identity), 1 (swish), 2 (tanh) or 3 (relu)");
   CGV_REQUIRE(cgv_tile_supported(M, N, K), "unsupported shape (need N % 4 == 0, K % 4 == 0)");
   CGV_REQUIRE(((((uintptr_t)x | (uintptr_t)W)) & 15) == 0, "x and W must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;

@@ -17,7 +17,7 @@ from torch import nn
 from . import ops
 from .blocks import (ContractiveMessageBlock, EquiMessageBlock, EquiMessagePsuedo, PseudoUpdateBlock, UpdateBlock)
 from .graph import BatchGraph, EdgePlan, make_directed
-from .primitives import Dense, DistanceEmbed, Linear, mark_direct_grad, to_module
+from .primitives import Dense, DistanceEmbed, Linear, MLPHead, mark_direct_grad, to_module
 
 
 def _call_then_pass(fn):
@@ -143,8 +143,8 @@ class CGprior(nn.Module):
              for _ in range(n_conv)])
         self.update_blocks = nn.ModuleList(
             [UpdateBlock(feat_dim=F, activation=activation, dropout=0.0) for _ in range(n_conv)])        # unused
-        self.mu = nn.Sequential(Linear(F, F), nn.Tanh(), Linear(F, F))
-        self.sigma = nn.Sequential(Linear(F, F), nn.Tanh(), Linear(F, F))
+        self.mu = MLPHead(Linear(F, F), nn.Tanh(), Linear(F, F))
+        self.sigma = MLPHead(Linear(F, F), nn.Tanh(), Linear(F, F))
         self.n_conv, self.dir_mp = n_conv, dir_mp
         self.n_rbf, self.cutoff = n_rbf, cutoff
 

@@ -62,7 +62,7 @@ def _gemm_mode(x2, weight, bias):
     return "library"
 
 
-ACT_NONE, ACT_SWISH = 0, 1
+ACT_NONE, ACT_SWISH, ACT_TANH, ACT_RELU = 0, 1, 2, 3      # cgv_common.h: act_fwd / act_bwd
 
 
 class WeightGradQueue:
@@ -181,9 +181,9 @@ class _LinearFn(torch.autograd.Function):
             ctx.save_for_backward(x2, weight, z)
             return y.reshape(x.shape[:-1] + (N,))
         z = Fn.linear(x, weight, bias)
-        if act == ACT_SWISH:
+        if act != ACT_NONE:
             ctx.save_for_backward(x, weight, z)
-            return Fn.silu(z)
+            return {ACT_SWISH: Fn.silu, ACT_TANH: torch.tanh, ACT_RELU: torch.relu}[act](z)
         ctx.save_for_backward(x, weight, None)
         return z
 
@@ -198,6 +198,10 @@ class _LinearFn(torch.autograd.Function):
             if act == ACT_SWISH:
                 sg = torch.sigmoid(z)
                 gy = gy * (sg * (1 + z * (1 - sg)))
+            elif act == ACT_TANH:
+                gy = gy * (1 - torch.tanh(z) ** 2)
+            elif act == ACT_RELU:
+                gy = gy * (z > 0).to(gy.dtype)
             x2, gy2 = x.reshape(-1, x.shape[-1]), gy.reshape(-1, gy.shape[-1])
             gx = gy.matmul(weight) if need_x else None
             gw = _direct_grad(w_param, lambda out: torch.mm(gy2.t(), x2, out=out), lambda: gy2.t().mm(x2)) if need_w else None
@@ -212,10 +216,10 @@ class _LinearFn(torch.autograd.Function):
             # g = gy * Swish'(z) and the bias column sums in one launch, then two reduction-split MFMA GEMMs
             if gy2.data_ptr() % 16:
                 gy2 = gy2.clone()
-            g2 = torch.empty_like(gy2) if act == ACT_SWISH else gy2
+            g2 = torch.empty_like(gy2) if act != ACT_NONE else gy2
             tb, acc_b, gb = _grad_target(b_param, b_param) if need_b else (None, False, None)
-            if act == ACT_SWISH or need_b:
-                _lib.call("cgv_dense_grad_prepare", _lib.ptr(gy2), _lib.ptr(z), _lib.ptr(g2) if act == ACT_SWISH else None,
+            if act != ACT_NONE or need_b:
+                _lib.call("cgv_dense_grad_prepare", _lib.ptr(gy2), _lib.ptr(z), _lib.ptr(g2) if act != ACT_NONE else None,
                           _lib.ptr(tb), M, N, act, int(acc_b), st)
             if need_x:
                 gx = torch.empty(M, K, dtype=torch.float32, device=gy.device)
@@ -298,6 +302,21 @@ class Linear(nn.Linear):
 
     def forward(self, x):
         return _LinearFn.apply(x, self.weight, self.bias, ACT_NONE)
+
+
+class MLPHead(nn.Sequential):
+    """``nn.Sequential(Linear, activation, Linear)`` -- the mu / sigma heads (cgvae.py:366-371, run_ala.py:184-189) --
+    with the same child names (``0`` / ``2``: state_dict keys unchanged) and the activation fused into the first
+    product's epilogue and into its backward (no tanh / relu / their-backward launches)."""
+    _CODES = {nn.Tanh: ACT_TANH, nn.ReLU: ACT_RELU, Swish: ACT_SWISH}
+
+    def forward(self, x):
+        mods = list(self)
+        if (len(mods) == 3 and isinstance(mods[0], nn.Linear) and type(mods[1]) in self._CODES
+                and isinstance(mods[2], nn.Linear) and x.is_cuda):
+            y = _LinearFn.apply(x, mods[0].weight, mods[0].bias, self._CODES[type(mods[1])])
+            return mods[2](y)
+        return super().forward(x)
 
 
 class Dense(nn.Linear):

@@ -11,7 +11,7 @@ from torch import nn
 
 from .data import batch_to, prepare_batch
 from .model import CGequiVAE, CGprior, EquiEncoder, EquivariantPsuedoDecoder
-from .primitives import Linear
+from .primitives import Linear, MLPHead
 
 EPS = 1e-6           # scripts/utils.py:15
 CLIP_NORM = 0.01     # scripts/utils.py:156
@@ -55,8 +55,8 @@ def build_model(n_basis, n_rbf, atom_cutoff, cg_cutoff, enc_nconv, dec_nconv, n_
     initial weights as the reference)."""
     if seed is not None:
         torch.manual_seed(seed)
-    atom_mu = nn.Sequential(Linear(n_basis, n_basis), nn.ReLU(), Linear(n_basis, n_basis))
-    atom_sigma = nn.Sequential(Linear(n_basis, n_basis), nn.ReLU(), Linear(n_basis, n_basis))
+    atom_mu = MLPHead(Linear(n_basis, n_basis), nn.ReLU(), Linear(n_basis, n_basis))
+    atom_sigma = MLPHead(Linear(n_basis, n_basis), nn.ReLU(), Linear(n_basis, n_basis))
     decoder = EquivariantPsuedoDecoder(n_atom_basis=n_basis, n_rbf=n_rbf, cutoff=atom_cutoff, num_conv=dec_nconv,
                                        activation=activation, breaksym=(n_cgs == 3))
     encoder = EquiEncoder(n_conv=enc_nconv, n_atom_basis=n_basis, n_rbf=n_rbf, cutoff=cg_cutoff,

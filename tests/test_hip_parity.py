@@ -762,6 +762,32 @@ def test_equi_message_high_degree_split_path():
     _block_vs_oracle(48, 10, n, nbrs, xyz, False, seed=2)
 
 
+@pytest.mark.parametrize("M", [12, 332])
+@pytest.mark.parametrize("act", ["tanh", "relu"])
+def test_mlp_head_fused_activation_vs_fp64(M, act):
+    """MLPHead = Sequential(Linear, Tanh | ReLU, Linear) with the activation fused into the first product
+    (skinny kernels at M = 12, tile kernels at M = 332) against fp64 autograd; state_dict keys as nn.Sequential."""
+    from coarsegrainingvae_amd.primitives import MLPHead
+    torch.manual_seed(M)
+    F = 600
+    head = MLPHead(cg.primitives.Linear(F, F), torch.nn.Tanh() if act == "tanh" else torch.nn.ReLU(), cg.primitives.Linear(F, F))
+    assert sorted(head.state_dict()) == ["0.bias", "0.weight", "2.bias", "2.weight"]
+    x = torch.randn(M, F)
+    gy = torch.randn(M, F)
+    ref = torch.nn.Sequential(torch.nn.Linear(F, F), torch.nn.Tanh() if act == "tanh" else torch.nn.ReLU(), torch.nn.Linear(F, F)).double()
+    ref.load_state_dict({k: v.double() for k, v in head.state_dict().items()})
+    xd = x.double().requires_grad_(True)
+    ref(xd).backward(gy.double())
+    head = head.to(DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    y = head(xg)
+    y.backward(gy.to(DEV))
+    assert_close(y, ref(xd).detach(), "y", 2e-6)
+    assert_close(xg.grad, xd.grad, "gx", 5e-6)
+    for (n, p), (_, q) in zip(head.named_parameters(), ref.named_parameters()):
+        assert_close(p.grad, q.grad, "grad " + n, 5e-6)
+
+
 def test_embedding_plan_gradient_matches_nn_embedding():
     """ops.embedding: lookup + plan-based weight gradient (one segment sum) == nn.Embedding incl. padding_idx."""
     torch.manual_seed(2)
