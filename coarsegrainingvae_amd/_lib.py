@@ -35,10 +35,17 @@ PROTOTYPES = {
     "cgv_radius_graph_emit": (_i, [_p, _p, _i, _i, _f, _i, _p, _p, _p]),
     "cgv_csr_workspace_bytes": (_sz, [_i]),
     "cgv_csr_build": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "cgv_group_plan_workspace_bytes": (_sz, [_i]),
+    "cgv_group_plan_build": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _sz, _p]),
+    "cgv_geom_group_stride": (_i, [_i]),
+    "cgv_geom_group_unit_offset": (_i, [_i]),
+    "cgv_edge_geometry_grouped": (_i, [_p, _p, _p, _p, _p, _i, _i, _f, _p, _p, _p]),
     "cgv_edge_geometry": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _f, _p, _p, _p]),
     "cgv_segment_reduce": (_i, [_p, _p, _p, _i, _i, _i, _p, _p]),
     "cgv_segment_broadcast": (_i, [_p, _p, _p, _i, _i, _i, _p, _p]),
     "cgv_equi_msg_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, C.c_int64, C.c_int64, _p, _p, _p]),
+    "cgv_equi_msg_grouped_supported": (_i, [_i, _i, _i]),
+    "cgv_equi_msg_fwd_grouped": (_i, [_p] * 9 + [_i, _i, _i, _i, C.c_int64, _p, _p, _p]),
     "cgv_equi_msg_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "cgv_equi_msg_bwd": (_i, [_p] * 13 + [_i, _i, _i, C.c_int64, C.c_int64, _p, _sz, _p]),
     "cgv_pseudo_msg_fwd": (_i, [_p] * 14 + [_i, _i, _i, _i, _p]),

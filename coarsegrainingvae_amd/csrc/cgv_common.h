@@ -34,6 +34,12 @@ constexpr int WAVE = 64;
 // lane) use them directly as broadcast operands for their AoS (x0,y0)(z0,x1)(y1,z1) accumulators.
 __host__ __device__ constexpr int geom_unit_offset(int R) { return (R + 2) & ~1; }
 __host__ __device__ constexpr int geom_stride(int R) { return (geom_unit_offset(R) + 6 + 3) & ~3; }
+// Record of the receiver-group order (shared-source forward, equi_msg_grp.hip), R even:
+//   [0,R) a_n ; [R] env ; [R+1] meta.x (int bits) ; [R+2,R+5) ux,uy,uz ; [R+5] meta.y (int bits) ; pad to a multiple of 4
+// meta = cgv_group_plan_build's per-edge words.  At n_rbf = 10 this is exactly one aligned 64-byte scalar load per edge
+// (the doubled-unit layout above needs 80 bytes that straddle cache lines, plus a second array for the meta words).
+__host__ __device__ constexpr int geom_group_unit_offset(int R) { return R + 2; }
+__host__ __device__ constexpr int geom_group_stride(int R) { return (R + 6 + 3) & ~3; }
 
 // 12-byte vector with 4-byte alignment: one global_load_dwordx3 / global_store_dwordx3.
 struct __attribute__((packed, aligned(4))) f3 {

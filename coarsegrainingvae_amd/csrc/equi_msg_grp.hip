@@ -1,0 +1,223 @@
+// K2g: fused EquiMessageBlock forward, shared-source walk.
+//
+// Same math as equi_msg.hip (reference conv.py:505-563, InvariantMessage 63-75, DistanceEmbed
+// modules.py:192-197).  What changes is who shares what.  equi_msg_fwd_k gathers phi[j] / v[j] of the
+// source once per EDGE: 3 KB per (edge, 128-channel wave), 13 GB per layer on the 2000-atom graph, and
+// the kernel sits at the ~11-15 TB/s the L1/L2 gather path delivers for 8- and 12-byte lane fragments,
+// with the packed-FMA pipe 75 % idle (profiles/).  Here RB consecutive receivers (atoms that
+// follow each other in a molecule are neighbours in space, so their neighbour lists overlap almost
+// completely) form a group; the group's edges are walked in (source, receiver) order
+// (cgv_group_plan_build), and a wave keeps RB accumulator sets in registers: a source row is gathered
+// ONCE per group and used for every receiver of the group that sees it -- gather bytes per edge fall by
+// the mean multiplicity (3.0-3.6 of RB = 4 on the dense graphs), the filter FMAs are untouched.
+//
+// Pipeline of one wave: the rows of step t+1 (the next distinct source) are requested before the edges of
+// step t are evaluated (two register buffers that swap roles, no copies), the scalar edge records and
+// the per-edge (slot, step mask, next source) words -- folded into the record, one aligned 64-byte scalar load
+// per edge at n_rbf = 10 -- run two edges ahead.  A step is a statically unrolled
+// sequence of RB slots, each guarded by a wave-uniform test of the step's mask (scalar branch), so every
+// accumulator set has its own code and stays in its registers.
+#include <stdlib.h>
+#include "cgv_common.h"
+#include "equi_msg_dev.h"
+
+namespace cgv {
+
+struct RowBuf { f2 p0, p1, p2, A, B, C; };
+struct Acc { f2 s, A, B, C; };
+
+__device__ __forceinline__ void gather_row(RowBuf& b, rsrc_t r_phi, rsrc_t r_v, unsigned oc, unsigned oF, unsigned ov,
+                                           unsigned so) {
+  b.p1 = ld2_buf(r_phi, oc + oF, so);
+  b.p0 = ld2_buf(r_phi, oc, so);
+  b.p2 = ld2_buf(r_phi, oc + 2u * oF, so);
+  ldvec_buf(r_v, ov, so, b.A, b.B, b.C);
+}
+
+template <int R>
+__device__ __forceinline__ void edge_math(const f2 (&W0)[R + 1], const f2 (&W1)[R + 1], const f2 (&W2)[R + 1],
+                                          const float* __restrict__ gc /* group record: a_n, env, -, ux, uy, uz */,
+                                          const RowBuf& b, Acc& a) {
+  constexpr int U = geom_group_unit_offset(R);
+  a.s = fma2(b.p1, filter2<R>(W1, gc), a.s);
+  const f2 m0 = b.p0 * filter2<R>(W0, gc);
+  const f2 m2 = b.p2 * filter2<R>(W2, gc);
+  const f2 u01 = f2{gc[U], gc[U + 1]}, u20 = f2{gc[U + 2], gc[U]}, u12 = f2{gc[U + 1], gc[U + 2]};
+  a.A = fma2(lo2(m2), u01, fma2(lo2(m0), b.A, a.A));
+  a.B = fma2(m2, u20, fma2(m0, b.B, a.B));
+  a.C = fma2(hi2(m2), u12, fma2(hi2(m0), b.C, a.C));
+}
+
+// grid = 8 * groups_per_xcd * tiles blocks (tiles = ceil(F/128)), block = 64 * SPLIT threads: the SPLIT waves
+// of a block take contiguous slices of the group's edge range and meet in LDS.
+template <int R, int RB, int SPLIT>
+__global__ __launch_bounds__(64 * SPLIT) void equi_msg_fwd_grp_k(
+    const float* __restrict__ phi, const float* __restrict__ v, const float* __restrict__ geom /* group order */,
+    const int* __restrict__ rowptr /* destination CSR */, const int* __restrict__ src_g,
+    const float* __restrict__ Wd, const float* __restrict__ bd, float* __restrict__ ds, float* __restrict__ dv, int F,
+    int n_dst, int groups_per_xcd, int tiles, const float* __restrict__ s_res, const float* __restrict__ v_res) {
+  constexpr int GS = geom_group_stride(R), NG = R + 6, MX = R + 1, MY = R + 5;   // record floats used; meta words
+  constexpr int FILT = 3 * 128 * R, RED = SPLIT * RB * 8 * 64;
+  __shared__ __attribute__((aligned(16))) float smem[FILT > RED ? FILT : RED];
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int local = slot / tiles;
+  const int group = xcd * groups_per_xcd + local;
+  const int tile = slot - local * tiles;
+  const int node0 = group * RB;
+  if (node0 >= n_dst || local >= groups_per_xcd) return;
+  const int node1 = min(node0 + RB, n_dst);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform -> record loads stay scalar
+  const ChanPair cp = chan_pair(tile, lane, F);
+
+  f2 W0[R + 1], W1[R + 1], W2[R + 1];
+  {
+    const int sl[3] = {0, 1, 2};
+    stage_filter_tile<R, 3>(smem, Wd, sl, F, tile * 128);
+    const int cl = cp.c - tile * 128;                // even; clamped lanes stay inside the staged tile
+    read_filter_rows2<R>(W0, smem, bd, cl, cp.c);
+    read_filter_rows2<R>(W1, smem + 128 * R, bd, cl, F + cp.c);
+    read_filter_rows2<R>(W2, smem + 2 * 128 * R, bd, cl, 2 * F + cp.c);
+  }
+
+  Acc acc[RB];
+#pragma unroll
+  for (int k = 0; k < RB; ++k) acc[k].s = acc[k].A = acc[k].B = acc[k].C = splat(0.f);
+
+  int beg = rowptr[node0], end = rowptr[node1];
+  {
+    const int len = (end - beg + SPLIT - 1) / SPLIT;
+    beg = min(beg + wave * len, end);
+    end = min(beg + len, end);
+  }
+  const unsigned row_bytes = 12u * (unsigned)F;              // bytes per node row of phi [3F] AND of v [F,3]
+  const unsigned oc = 4u * (unsigned)cp.c, oF = 4u * (unsigned)F, ov = 12u * (unsigned)cp.c;
+  const rsrc_t r_phi = make_rsrc(phi), r_v = make_rsrc(v);
+
+  if (beg < end) {
+    // records run two edges ahead of the math (measured against one: 654 vs 719 us on the 2000-atom graph).  Scalar
+    // loads return out of order, so every use waits for ALL of them (lgkmcnt(0)): what the second buffer buys is
+    // that the record needed next has already landed when the wait for the newest request starts.
+    float gc[NG], g1[NG], g2[NG];
+    const int last = end - 1;
+#pragma unroll
+    for (int t = 0; t < NG; ++t) gc[t] = geom[(size_t)beg * GS + t];
+#pragma unroll
+    for (int t = 0; t < NG; ++t) g1[t] = geom[(size_t)min(beg + 1, last) * GS + t];
+    int e = beg;
+    RowBuf bufA, bufB;
+    gather_row(bufA, r_phi, r_v, oc, oF, ov, (unsigned)src_g[beg] * row_bytes);
+
+    // one edge of the current step into the accumulators of receiver slot K (a wave-uniform test: scalar branch)
+#define CGV_GRP_EDGE(BUF, K)                                                                      \
+    if (((m >> (K)) & 1) && e < end) {                                                            \
+      const int e2 = min(e + 2, last);                                                            \
+      _Pragma("unroll") for (int t = 0; t < NG; ++t) g2[t] = geom[(size_t)e2 * GS + t];           \
+      edge_math<R>(W0, W1, W2, gc, BUF, acc[(K) % RB]);                                           \
+      _Pragma("unroll") for (int t = 0; t < NG; ++t) { gc[t] = g1[t]; g1[t] = g2[t]; }            \
+      ++e;                                                                                        \
+    }
+#define CGV_GRP_STEP(BUF)                                      \
+    {                                                          \
+      CGV_GRP_EDGE(BUF, 0)                                     \
+      if (RB > 1) { CGV_GRP_EDGE(BUF, 1) }                     \
+      if (RB > 2) { CGV_GRP_EDGE(BUF, 2) CGV_GRP_EDGE(BUF, 3) } \
+    }
+#define CGV_GRP_META_X __float_as_int(gc[MX])
+#define CGV_GRP_META_Y __float_as_int(gc[MY])
+
+    int m = (CGV_GRP_META_X >> 16) & ~((1 << (CGV_GRP_META_X & 0xff)) - 1);      // a slice may start inside a step
+    while (true) {
+      gather_row(bufB, r_phi, r_v, oc, oF, ov, (unsigned)CGV_GRP_META_Y * row_bytes);     // rows of the NEXT step
+      CGV_GRP_STEP(bufA)
+      if (e >= end) break;
+      m = CGV_GRP_META_X >> 16;
+      gather_row(bufA, r_phi, r_v, oc, oF, ov, (unsigned)CGV_GRP_META_Y * row_bytes);
+      CGV_GRP_STEP(bufB)
+      if (e >= end) break;
+      m = CGV_GRP_META_X >> 16;
+    }
+#undef CGV_GRP_EDGE
+#undef CGV_GRP_STEP
+#undef CGV_GRP_META_X
+#undef CGV_GRP_META_Y
+  }
+
+  // every wave deposits its partial sums; wave w then finishes receivers w, w + SPLIT, ... in a fixed order
+  __syncthreads();                                   // all filter reads of the shared buffer are done
+#pragma unroll
+  for (int k = 0; k < RB; ++k) {
+    float* r = smem + ((wave * RB + k) * 8) * 64 + lane;
+    r[0] = acc[k].s.x; r[64] = acc[k].s.y; r[128] = acc[k].A.x; r[192] = acc[k].A.y;
+    r[256] = acc[k].B.x; r[320] = acc[k].B.y; r[384] = acc[k].C.x; r[448] = acc[k].C.y;
+  }
+  __syncthreads();
+  for (int k = wave; k < node1 - node0; k += SPLIT) {
+    f2 s = splat(0.f), A = splat(0.f), B = splat(0.f), C = splat(0.f);
+#pragma unroll
+    for (int w = 0; w < SPLIT; ++w) {
+      const float* r = smem + ((w * RB + k) * 8) * 64 + lane;
+      s += f2{r[0], r[64]}; A += f2{r[128], r[192]}; B += f2{r[256], r[320]}; C += f2{r[384], r[448]};
+    }
+    if (cp.live) {
+      const int node = node0 + k;
+      if (s_res) s += ldpair<true>(s_res + (size_t)node * F, cp);          // emit h + ds (cgvae.py:287, 309, 391)
+      stpair<true>(ds + (size_t)node * F, cp, s);
+      if (v_res) {
+        f2 rA, rB, rC;
+        ldvec<true>(v_res + (size_t)node * F * 3, cp, rA, rB, rC);
+        A += rA; B += rB; C += rC;
+      }
+      stvec<true>(dv + (size_t)node * F * 3, cp, A, B, C);
+    }
+  }
+}
+
+}  // namespace cgv
+
+extern "C" {
+
+int cgv_equi_msg_grouped_supported(int n_feat, int n_rbf, int rb) {
+  bool r_ok = false;
+#define CGV_X(r) r_ok = r_ok || n_rbf == r;
+  CGV_RBF_LIST(CGV_X)
+#undef CGV_X
+  return r_ok && (n_feat % 2 == 0) && (n_rbf % 2 == 0) && (rb == 2 || rb == 4);
+}
+
+int cgv_equi_msg_fwd_grouped(const float* phi, const float* v, const float* geom_g, const int32_t* rowptr_d,
+                             const int32_t* src_g, const float* Wd, const float* bd, float* ds,
+                             float* dv, int n_dst, int n_feat, int n_rbf, int rb, int64_t n_rows, const float* s_res,
+                             const float* v_res, void* stream) {
+  CGV_REQUIRE(n_dst >= 0 && n_feat > 0, "bad size");
+  if (n_dst == 0) return 0;
+  CGV_REQUIRE(phi && v && geom_g && rowptr_d && src_g && Wd && bd && ds && dv, "null pointer");
+  CGV_REQUIRE(cgv_equi_msg_grouped_supported(n_feat, n_rbf, rb), "unsupported shape (need even n_feat / n_rbf, rb in {2,4})");
+  CGV_REQUIRE(n_rows > 0 && (uint64_t)n_rows * 12u * (uint64_t)n_feat < 0x7fffffffull, "rows must lie within 2 GiB");
+  CGV_REQUIRE((((uintptr_t)phi | (uintptr_t)v | (uintptr_t)ds | (uintptr_t)dv | (uintptr_t)s_res | (uintptr_t)v_res |
+                (uintptr_t)bd) & 7) == 0 && ((((uintptr_t)Wd) | ((uintptr_t)geom_g)) & 15) == 0,
+              "operands must be 8-byte (Wd, geom_g: 16-byte) aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int tiles = (n_feat + 127) / 128;
+  const int groups = (n_dst + rb - 1) / rb;
+  const int gpx = (groups + 7) / 8;
+  const dim3 grid(8 * gpx * tiles);
+  // waves per block: 4 (measured on the 2000-atom graph: 4 -> 654 us, 8 -> 942 us: one 8-wave block per CU leaves two
+  // waves per SIMD; 6 -> 1194 us: a wave count that is not a multiple of the 4 SIMDs loads them unevenly).
+  // CGV_GRP_SPLIT=8 is kept for A/B runs.
+  int split = 4;
+  if (const char* dbg = getenv("CGV_GRP_SPLIT")) split = atoi(dbg);
+#define CGV_GRP_LAUNCH(RBV, SP)                                                                                  \
+  hipLaunchKernelGGL((cgv::equi_msg_fwd_grp_k<RBF, RBV, SP>), grid, dim3(64 * SP), 0, st, phi, v, geom_g, rowptr_d, src_g, \
+                     Wd, bd, ds, dv, n_feat, n_dst, gpx, tiles, s_res, v_res)
+#define CGV_GRP_PICK(RBV) \
+  if (split == 8) CGV_GRP_LAUNCH(RBV, 8); else CGV_GRP_LAUNCH(RBV, 4)
+  CGV_DISPATCH_RBF(n_rbf, {
+    if (rb == 2) { CGV_GRP_PICK(2); } else { CGV_GRP_PICK(4); }
+  });
+#undef CGV_GRP_PICK
+#undef CGV_GRP_LAUNCH
+  return cgv::check_launch("cgv_equi_msg_fwd_grouped");
+}
+
+}  // extern "C"

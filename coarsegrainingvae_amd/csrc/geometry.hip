@@ -11,7 +11,7 @@ __global__ __launch_bounds__(256) void edge_geometry(const float* __restrict__ r
                                                      const float* __restrict__ pos_dst, const float* __restrict__ pos_src,
                                                      const int* __restrict__ dst, const int* __restrict__ src, int E, int R,
                                                      int GS, float cutoff, float pi_f, const float* __restrict__ coef,
-                                                     float* __restrict__ geom) {
+                                                     float* __restrict__ geom, const int2* __restrict__ meta) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= E) return;
   float rx, ry, rz;
@@ -41,9 +41,17 @@ __global__ __launch_bounds__(256) void edge_geometry(const float* __restrict__ r
     g[n] = val * env;
   }
   g[R] = env;
+  const float ux = __fdiv_rn(rx, d), uy = __fdiv_rn(ry, d), uz = __fdiv_rn(rz, d);   // conv.py:27 unit = r / dist
+  if (meta) {                                     // receiver-group record (cgv_common.h: geom_group_*)
+    const int2 m = meta[p];
+    g[R + 1] = __int_as_float(m.x);
+    g[R + 2] = ux; g[R + 3] = uy; g[R + 4] = uz;
+    g[R + 5] = __int_as_float(m.y);
+    for (int k = R + 6; k < GS; ++k) g[k] = 0.0f;
+    return;
+  }
   const int U = geom_unit_offset(R);
   for (int k = R + 1; k < U; ++k) g[k] = 0.0f;
-  const float ux = __fdiv_rn(rx, d), uy = __fdiv_rn(ry, d), uz = __fdiv_rn(rz, d);   // conv.py:27 unit = r / dist
   g[U + 0] = ux; g[U + 1] = uy; g[U + 2] = uz;
   g[U + 3] = ux; g[U + 4] = uy; g[U + 5] = uz;
   for (int k = U + 6; k < GS; ++k) g[k] = 0.0f;
@@ -60,6 +68,24 @@ extern "C" int cgv_edge_geometry(const float* r_edges, const int32_t* eid, const
   CGV_REQUIRE((r_edges && eid) || (pos_dst && pos_src && dst && src), "need r_edges+eid or positions+dst+src");
   const float pi_f = 3.14159265358979323846f;
   hipLaunchKernelGGL(cgv::edge_geometry, dim3((n_edges + 255) / 256), dim3(256), 0, (hipStream_t)stream, r_edges, eid,
-                     pos_dst, pos_src, dst, src, n_edges, n_rbf, cgv::geom_stride(n_rbf), cutoff, pi_f, coef, geom);
+                     pos_dst, pos_src, dst, src, n_edges, n_rbf, cgv::geom_stride(n_rbf), cutoff, pi_f, coef, geom,
+                     (const int2*)nullptr);
   return cgv::check_launch("cgv_edge_geometry");
+}
+
+/* Records in receiver-group order with the per-edge meta words folded in (cgv_common.h: geom_group_stride). */
+extern "C" int cgv_geom_group_stride(int n_rbf) { return cgv::geom_group_stride(n_rbf); }
+extern "C" int cgv_geom_group_unit_offset(int n_rbf) { return cgv::geom_group_unit_offset(n_rbf); }
+extern "C" int cgv_edge_geometry_grouped(const float* pos_dst, const float* pos_src, const int32_t* dst_g,
+                                         const int32_t* src_g, const int32_t* meta_g, int n_edges, int n_rbf, float cutoff,
+                                         const float* coef, float* geom_g, void* stream) {
+  CGV_REQUIRE(n_edges >= 0 && n_rbf > 0 && (n_rbf % 2) == 0 && coef, "bad argument (n_rbf must be even)");
+  if (n_edges == 0) return 0;
+  CGV_REQUIRE(geom_g && pos_dst && pos_src && dst_g && src_g && meta_g, "null pointer");
+  CGV_REQUIRE((((uintptr_t)meta_g) & 7) == 0, "meta_g must be 8-byte aligned");
+  const float pi_f = 3.14159265358979323846f;
+  hipLaunchKernelGGL(cgv::edge_geometry, dim3((n_edges + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)nullptr, (const int*)nullptr, pos_dst, pos_src, dst_g, src_g, n_edges, n_rbf,
+                     cgv::geom_group_stride(n_rbf), cutoff, pi_f, coef, geom_g, reinterpret_cast<const int2*>(meta_g));
+  return cgv::check_launch("cgv_edge_geometry_grouped");
 }

@@ -162,6 +162,53 @@ static int sorted_view(const int64_t* key, const int64_t* other, int stride, int
   return check_launch("cgv_csr_build");
 }
 
+
+// ------------------------------------------------------------------ K7b receiver-group order
+// Shared-source walk of the fused message forward (equi_msg_grp.hip): RB consecutive receivers form a group
+// whose edges -- one contiguous range of the destination-sorted view -- are re-ordered by (source, receiver),
+// so that a wave gathers each source row ONCE for all the receivers of the group that see it.
+__global__ void grp_keys_src(const int* __restrict__ src_d, int n, int* __restrict__ keys, int* __restrict__ vals) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  keys[p] = src_d[p];
+  vals[p] = p;
+}
+__global__ void grp_keys_group(const int* __restrict__ dst_d, const int* __restrict__ perm, int n, int rb,
+                               int* __restrict__ keys, int* __restrict__ vals) {
+  int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const int p = perm[q];
+  keys[q] = dst_d[p] / rb;
+  vals[q] = p;
+}
+__global__ void grp_gather(const int* __restrict__ dst_d, const int* __restrict__ src_d, const int* __restrict__ perm, int n,
+                           int* __restrict__ dst_g, int* __restrict__ src_g, int* __restrict__ pos_g) {
+  int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const int p = perm[q];
+  dst_g[q] = dst_d[p];
+  src_g[q] = src_d[p];
+  if (pos_g) pos_g[q] = p;
+}
+// meta[q] = { slot | head << 8 | mask << 16 , source of the NEXT step of this group (own source at the last step) }
+// slot = receiver - group base; a step = a maximal run of edges of one (group, source) pair with strictly increasing
+// receivers (at most RB edges; a duplicated edge opens a new step on the same source), mask = its slots,
+// head = first edge of the step.
+__global__ void grp_meta(const int* __restrict__ dst_g, const int* __restrict__ src_g, int n, int rb,
+                         int2* __restrict__ meta) {
+  int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const int d = dst_g[q], g = d / rb, s = src_g[q];
+  // same step as the edge before it?
+  auto joins = [&](int t) { return t > 0 && src_g[t - 1] == src_g[t] && dst_g[t - 1] / rb == dst_g[t] / rb && dst_g[t - 1] < dst_g[t]; };
+  int mask = 1 << (d - g * rb);
+  for (int t = q; joins(t); --t) mask |= 1 << (dst_g[t - 1] - g * rb);
+  int t = q + 1;
+  for (; t < n && joins(t); ++t) mask |= 1 << (dst_g[t] - g * rb);
+  const int next = (t < n && dst_g[t] / rb == g) ? src_g[t] : s;
+  meta[q] = make_int2((d - g * rb) | (joins(q) ? 0 : 0x100) | (mask << 16), next);
+}
+
 }  // namespace cgv
 
 extern "C" {
@@ -207,6 +254,51 @@ int cgv_csr_build(const int64_t* dst, const int64_t* src, int stride, int n_edge
   int rc = cgv::sorted_view(dst, src, stride, n_edges, n_dst, n_src, rowptr_d, eid_d, dst_d, src_d, ws, workspace_bytes, st);
   if (rc) return rc;
   return cgv::sorted_view(src, dst, stride, n_edges, n_src, n_dst, rowptr_s, eid_s, src_s, dst_s, ws, workspace_bytes, st);
+}
+
+size_t cgv_group_plan_workspace_bytes(int n_edges) {
+  size_t temp = 0;
+  if (cgv::sort_temp_bytes(n_edges, &temp) != hipSuccess) temp = (size_t)n_edges * 16 + (1 << 20);
+  return 4 * cgv::align256(sizeof(int) * (size_t)(n_edges > 0 ? n_edges : 1)) + cgv::align256(temp) + 256;
+}
+
+int cgv_group_plan_build(const int32_t* dst_d, const int32_t* src_d, int n_edges, int n_dst, int n_src, int rb,
+                         int32_t* dst_g, int32_t* src_g, int32_t* pos_g, int32_t* meta_g, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+  CGV_REQUIRE(n_edges >= 0 && n_dst >= 0 && n_src >= 0 && rb >= 1 && rb <= 8, "bad size");
+  if (n_edges == 0) return 0;
+  CGV_REQUIRE(dst_d && src_d && dst_g && src_g && meta_g && workspace, "null pointer");
+  CGV_REQUIRE((((uintptr_t)meta_g) & 7) == 0, "meta_g must be 8-byte aligned");
+  if (workspace_bytes < cgv_group_plan_workspace_bytes(n_edges)) {
+    cgv::set_error("cgv_group_plan_build: workspace too small");
+    return CGV_E_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const size_t E = (size_t)n_edges, slot = cgv::align256(sizeof(int) * E);
+  char* ws = reinterpret_cast<char*>(workspace);
+  int* k_in = reinterpret_cast<int*>(ws);
+  int* v_in = reinterpret_cast<int*>(ws + slot);
+  int* k_out = reinterpret_cast<int*>(ws + 2 * slot);
+  int* v_out = reinterpret_cast<int*>(ws + 3 * slot);
+  char* temp = ws + 4 * slot;
+  size_t temp_bytes = workspace_bytes - 4 * slot;
+  auto bits_for = [](int n) { int b = 1; while ((1ll << b) < (long long)(n > 1 ? n : 2)) ++b; return b; };
+  const int T = 256, B = (n_edges + T - 1) / T;
+  // the destination-sorted view is ordered by (receiver, source, edge id): a stable pass by source, then a stable
+  // pass by group, leaves (group, source, receiver)
+  hipLaunchKernelGGL(cgv::grp_keys_src, dim3(B), dim3(T), 0, st, src_d, n_edges, k_in, v_in);
+  hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, k_in, k_out, v_in, v_out, E, 0, bits_for(n_src), st);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(cgv::grp_keys_group, dim3(B), dim3(T), 0, st, dst_d, v_out, n_edges, rb, k_in, v_in);
+    e = rocprim::radix_sort_pairs(temp, temp_bytes, k_in, k_out, v_in, v_out, E, 0, bits_for((n_dst + rb - 1) / rb), st);
+  }
+  if (e != hipSuccess) {
+    cgv::set_error("cgv_group_plan_build: radix sort failed: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  hipLaunchKernelGGL(cgv::grp_gather, dim3(B), dim3(T), 0, st, dst_d, src_d, v_out, n_edges, dst_g, src_g, pos_g);
+  hipLaunchKernelGGL(cgv::grp_meta, dim3(B), dim3(T), 0, st, dst_g, src_g, n_edges, rb, reinterpret_cast<int2*>(meta_g));
+  return cgv::check_launch("cgv_group_plan_build");
 }
 
 }  // extern "C"

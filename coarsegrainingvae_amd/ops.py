@@ -39,6 +39,18 @@ def _filter_grad_targets(params, Wd, bd):
     return gWd, gbd, gWd, gbd
 
 
+def _grouped_forward_usable(plan, geom, F, tensors8, Wd) -> bool:
+    """The shared-source forward needs the plan's receiver-group order with matching edge records, an even channel
+    count / n_rbf, 8-byte aligned operands (Wd 16-byte) and all rows within 2 GiB of the base."""
+    if not getattr(plan, "group_rb", 0) or getattr(geom, "geom_g", None) is None or plan.n_edges == 0:
+        return False
+    if not _lib.load().cgv_equi_msg_grouped_supported(F, geom.n_rbf, plan.group_rb):
+        return False
+    if plan.n_src * 12 * F >= 0x7fffffff or Wd.data_ptr() % 16:
+        return False
+    return all(t is None or t.data_ptr() % 8 == 0 for t in tensors8)
+
+
 # ----------------------------------------------------------------------------- K2 / K4
 class _EquiMessage(torch.autograd.Function):
     """ds, dv of EquiMessageBlock / ContractiveMessageBlock from phi = inv_dense(s)
@@ -57,10 +69,18 @@ class _EquiMessage(torch.autograd.Function):
             dv = torch.empty(plan.n_dst, F, 3, dtype=_F32, device=phi.device)
         else:       # vector channel skipped: delta = 0, i.e. the residual passes through unchanged
             dv = v_res.clone() if v_res is not None else torch.zeros(plan.n_dst, F, 3, dtype=_F32, device=phi.device)
-        _lib.call("cgv_equi_msg_fwd", _lib.ptr(phi), _lib.ptr(v), _lib.ptr(geom.geom_d), _lib.ptr(plan.rowptr_d),
-                  _lib.ptr(plan.src_d), _lib.ptr(Wd), _lib.ptr(bd), _lib.ptr(ds), _lib.ptr(dv), plan.n_dst, F,
-                  geom.n_rbf, int(with_dv), plan.n_edges, plan.n_src, _lib.ptr(s_res), _lib.ptr(v_res), _lib.stream_ptr(),
-                  tag=f"equi_msg_fwd:Nd{plan.n_dst}:E{plan.n_edges}:dv{int(with_dv)}")
+        tag = f"equi_msg_fwd:Nd{plan.n_dst}:E{plan.n_edges}:dv{int(with_dv)}"
+        if with_dv and _grouped_forward_usable(plan, geom, F, (phi, v, ds, dv, s_res, v_res, bd), Wd):
+            # shared-source walk: groups of plan.group_rb receivers gather every source row once (K2g)
+            _lib.call("cgv_equi_msg_fwd_grouped", _lib.ptr(phi), _lib.ptr(v), _lib.ptr(geom.geom_g), _lib.ptr(plan.rowptr_d),
+                      _lib.ptr(plan.src_g), _lib.ptr(Wd), _lib.ptr(bd), _lib.ptr(ds), _lib.ptr(dv),
+                      plan.n_dst, F, geom.n_rbf, plan.group_rb, plan.n_src, _lib.ptr(s_res), _lib.ptr(v_res),
+                      _lib.stream_ptr(), tag=tag)
+        else:
+            _lib.call("cgv_equi_msg_fwd", _lib.ptr(phi), _lib.ptr(v), _lib.ptr(geom.geom_d), _lib.ptr(plan.rowptr_d),
+                      _lib.ptr(plan.src_d), _lib.ptr(Wd), _lib.ptr(bd), _lib.ptr(ds), _lib.ptr(dv), plan.n_dst, F,
+                      geom.n_rbf, int(with_dv), plan.n_edges, plan.n_src, _lib.ptr(s_res), _lib.ptr(v_res),
+                      _lib.stream_ptr(), tag=tag)
         ctx.save_for_backward(phi, v, Wd, bd)
         ctx.filter_params = filter_params
         ctx.plan, ctx.geom, ctx.with_dv = plan, geom, with_dv

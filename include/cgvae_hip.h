@@ -94,6 +94,19 @@ int cgv_csr_build(const int64_t* dst, const int64_t* src, int stride, int n_edge
                   int32_t* rowptr_d, int32_t* eid_d, int32_t* dst_d, int32_t* src_d,
                   int32_t* rowptr_s, int32_t* eid_s, int32_t* dst_s, int32_t* src_s,
                   void* workspace, size_t workspace_bytes, void* stream);
+/* K7b  receiver-group order of the dst-sorted view, for the shared-source forward (cgv_equi_msg_fwd_grouped):
+ * rb consecutive receivers form a group; the group's edges (one contiguous range of the dst-sorted view, so
+ * rowptr_d still delimits it) are re-ordered by (source, receiver).  Outputs, all [E] in group order:
+ *   dst_g, src_g  receiver / source of the edge      pos_g (or NULL)  its position in the dst-sorted view
+ *   meta_g [E,2]  { slot | head << 8 | mask << 16 , source of the group's NEXT step }: slot = receiver - group
+ *                 base; a step = a maximal run of edges of one (group, source) pair with strictly increasing receivers
+ *                 (a duplicated edge opens a new step); mask = the step's slots; head = first edge of the step; the
+ *                 last step of a group names its own source.
+ * Edge records for this order come from cgv_edge_geometry_grouped (below), which folds meta_g into them. */
+size_t cgv_group_plan_workspace_bytes(int n_edges);
+int cgv_group_plan_build(const int32_t* dst_d, const int32_t* src_d, int n_edges, int n_dst, int n_src, int rb,
+                         int32_t* dst_g, int32_t* src_g, int32_t* pos_g /*or NULL*/, int32_t* meta_g /*[E,2]*/,
+                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * K6  edge geometry -- replaces preprocess_r (conv.py:25-29), PainnRadialBasis
@@ -107,6 +120,14 @@ int cgv_edge_geometry(const float* r_edges /*[E,3] or NULL*/, const int32_t* eid
                       const float* pos_dst /*[Nd,3]*/, const float* pos_src /*[Ns,3]*/,
                       const int32_t* dst /*[E]*/, const int32_t* src /*[E]*/, int n_edges, int n_rbf,
                       float cutoff, const float* coef /*[R]*/, float* geom /*[E,stride]*/, void* stream);
+/* Records of the receiver-group order (K7b), meta words folded in; even n_rbf; stride cgv_geom_group_stride(R) floats:
+ *   [0,R) a_n ; [R] env ; [R+1] meta.x (int bits) ; [R+2,R+5) ux,uy,uz ; [R+5] meta.y (int bits) ; zero padding
+ * (n_rbf = 10: 16 floats = one aligned 64-byte scalar load per edge).  Same fp32 expressions as cgv_edge_geometry. */
+int cgv_geom_group_stride(int n_rbf);
+int cgv_geom_group_unit_offset(int n_rbf);
+int cgv_edge_geometry_grouped(const float* pos_dst /*[Nd,3]*/, const float* pos_src /*[Ns,3]*/, const int32_t* dst_g,
+                              const int32_t* src_g, const int32_t* meta_g /*[E,2]*/, int n_edges, int n_rbf,
+                              float cutoff, const float* coef /*[R]*/, float* geom_g /*[E,group stride]*/, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * K1  segment reduction -- replaces torch_scatter.scatter_add / scatter_mean (requirements.txt:18;
@@ -142,6 +163,18 @@ int cgv_equi_msg_fwd(const float* phi /*[Ns,3F]*/, const float* v /*[Ns,F,3]*/, 
                      const float* bd /*[3F]*/, float* ds /*[Nd,F]*/, float* dv /*[Nd,F,3]*/, int n_dst,
                      int n_feat, int n_rbf, int with_dv, int64_t n_edges_hint, int64_t n_rows_hint,
                      const float* s_res /*[Nd,F] or NULL*/, const float* v_res /*[Nd,F,3] or NULL*/, void* stream);
+/* The same forward (with the vector channel) as a shared-source walk over the receiver-group order
+ * (cgv_group_plan_build with the same rb; geom_g = cgv_edge_geometry_grouped records of that order): a wave keeps rb
+ * accumulator sets and gathers every source row once per group instead of once per edge -- for graphs whose consecutive receivers share
+ * most of their neighbours (molecules: always).  Needs even n_feat / n_rbf, rb in {2, 4}, 8-byte aligned operands
+ * (Wd, geom_g 16-byte), all n_rows rows of phi / v within 2 GiB.  Same results up to fp32 summation order. */
+int cgv_equi_msg_grouped_supported(int n_feat, int n_rbf, int rb);
+int cgv_equi_msg_fwd_grouped(const float* phi /*[Ns,3F]*/, const float* v /*[Ns,F,3]*/, const float* geom_g,
+                             const int32_t* rowptr_d, const int32_t* src_g,
+                             const float* Wd /*[3F,R]*/, const float* bd /*[3F]*/, float* ds /*[Nd,F]*/,
+                             float* dv /*[Nd,F,3]*/, int n_dst, int n_feat, int n_rbf, int rb, int64_t n_rows,
+                             const float* s_res /*[Nd,F] or NULL*/, const float* v_res /*[Nd,F,3] or NULL*/,
+                             void* stream);
 /* Backward.  gs / gv are the upstream gradients at the receivers (gv == NULL when dv is not
  * consumed).  Traverses the src-sorted view; writes g_phi [Ns,3F], g_v [Ns,F,3] (only if gv),
  * gWd [3F,R], gbd [3F] completely (zeros where nothing flows).  Deterministic two-stage

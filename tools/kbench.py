@@ -40,7 +40,7 @@ def main():
     Wd = torch.randn(3 * F, R, device=dev, requires_grad=True)
     bd = torch.randn(3 * F, device=dev, requires_grad=True)
     gs, gv = torch.randn(N, F, device=dev), torch.randn(N, F, 3, device=dev)
-    print(f"{workload}: N={N} E={E} F={F} R={R} avg degree {E / N:.1f}")
+    print(f"{workload}: N={N} E={E} F={F} R={R} avg degree {E / N:.1f} group_rb={plan.group_rb}")
     flops = E * F * (6 * R + 20)
     for with_dv in (True, False):
         us = timeit(lambda: ops.equi_message(phi.detach(), v.detach(), Wd.detach(), bd.detach(), plan, geom, with_dv))
