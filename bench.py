@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=None)
     ap.add_argument("--optimizer", default="fused", choices=["fused", "torch"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one captured hipGraph per step")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "operands", "gradients"],
+                    help="N > 1: all-gather the bead-level layers' operand rows (default) or all-reduce every gradient")
     return ap.parse_args()
 
 
@@ -157,7 +159,7 @@ def main():
     batch = cg.synthetic_batch(args.workload, n_frames=frames, seed=rank, device=dev)
     from coarsegrainingvae_amd.trainer import Trainer
     trainer = Trainer(model, lr=1e-4, beta=w["beta"], gamma=w["gamma"], world_size=world,
-                      fused_optimizer=(args.optimizer == "fused"))
+                      fused_optimizer=(args.optimizer == "fused"), exchange=args.exchange)
 
     def barrier():
         if dist is not None:
@@ -243,6 +245,17 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             steps_cpu = args.cpu_steps or (4 if args.workload == "chignolin" else 6)
             cpu = cpu_baseline(args.workload, F, frames, steps_cpu)
+        dp_step, dp_info = "+allreduce", None
+        if world > 1 and trainer.arena is not None:
+            left = sum(hi - lo for lo, hi in trainer._unsent_ranges()) * 4
+            early = sum(hi - lo for lo, hi in getattr(trainer, "_early_done", [])) * 4
+            if trainer.exchange is not None and trainer.exchange.bytes_gathered:
+                dp_step = "+operand-allgather+allreduce"
+            dp_info = {"exchange": "operands" if trainer.exchange is not None else "gradients",
+                       "gradient_arena_bytes": trainer.arena.numel * 4,
+                       "allgathered_operand_bytes_per_rank": (trainer.exchange.bytes_gathered // world
+                                                              if trainer.exchange is not None else 0),
+                       "allreduced_bytes": left + early, "allreduced_early_bytes": early}
         line = {
             "metric": "train_step_frames_per_sec", "value": value, "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
@@ -250,12 +263,14 @@ def main():
             "config": {"workload": f"{args.workload}: {frames} frames/GPU x {w['n_atoms']} atoms, n_cgs={w['n_cgs']}, "
                                    f"enc_nconv={w['enc_nconv']}, dec_nconv={w['dec_nconv']}, n_basis={F}, n_rbf={w['n_rbf']}, "
                                    f"cutoffs {w['atom_cutoff']}/{w['cg_cutoff']}",
-                       "step": "fwd+loss+bwd" + ("+allreduce" if world > 1 else "") + "+clip+adam",
+                       "step": "fwd+loss+bwd" + (dp_step if world > 1 else "") + "+clip+adam",
                        "global_batch": world * frames, "directed_edges_rank0": int(batch["_graph"].atom.n_edges),
                        "optimizer": args.optimizer, "hip_graph": bool(use_graph), "skip_dead_vector_channel": bool(args.skip_dead_vector_channel),
                        "parallelism": f"dp{world}"},
             "loss": loss, "roofline": roofline, "cpu_baseline": cpu,
         }
+        if dp_info:
+            line["data_parallel"] = dp_info
         if cpu:
             line["speedup_vs_cpu_baseline"] = value / cpu["value"]
         line.update(extra)

@@ -71,6 +71,11 @@ PROTOTYPES = {
     "cgv_wgrad_plan": (_i, [_i, _i, _i, _p, _p, _p]),
     "cgv_wgrad_lds_floats": (_i, [_i, _i]),
     "cgv_grouped_wgrad": (_i, [_p, _i, _i, _i, _p]),
+    "cgv_wgrad_gathered_plan": (_i, [_i, _i, _i, _i, _p, _p]),
+    "cgv_grouped_wgrad_gathered": (_i, [_p, _i, _i, _p]),
+    "cgv_pack_record_bytes": (_i, []),
+    "cgv_pack_plan": (_i, [_i, _i, _i, _p]),
+    "cgv_pack_operands": (_i, [_p, _i, _i, _p]),
     "cgv_reconstruct_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p]),
     "cgv_reconstruct_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p, _p]),
     "cgv_elbo_fwd": (_i, [_p] * 7 + [_i, _i, _i, _i, _f, _f] + [_p] * 6 + [_p]),

@@ -255,7 +255,7 @@ constexpr int WG_ROWS = 16;        // rows of gW per pass = float4 accumulators 
 constexpr int WG_PASSES = 4;       // passes per block: 64 rows of gW share one LDS-staged x tile
 constexpr int WG_BLOCK_ROWS = WG_ROWS * WG_PASSES;
 
-struct WgradProblem {       // mirrors the 80-byte host record built in python (primitives.WeightGradQueue)
+struct WgradProblem {       // mirrors the 88-byte host record built in python (primitives.WeightGradQueue)
   const float* gy;
   const float* x;
   const float* z;           // pre-activation or NULL
@@ -266,9 +266,11 @@ struct WgradProblem {       // mirrors the 80-byte host record built in python (
   int block_begin;          // first global block index of this problem
   int tiles_k;              // k tiles per row block
   int tile_w;               // floats per k tile (multiple of 4)
+  int seg_rows;             // gathered operands (gathered_wgrad_k): rows per rank segment (multiple of 4) ...
+  int seg_stride;           // ... and floats between the segments of consecutive ranks; 0 / 0 = one plain [M, .] block
   int pad;
 };
-static_assert(sizeof(WgradProblem) == 80, "host/device record layout");
+static_assert(sizeof(WgradProblem) == 88, "host/device record layout");
 
 __global__ __launch_bounds__(256) void grouped_wgrad_k(const WgradProblem* __restrict__ table, int n_problems) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -348,6 +350,113 @@ __global__ __launch_bounds__(256) void grouped_wgrad_k(const WgradProblem* __res
     float sum = 0.f;
     for (int m = 0; m < M; ++m) sum += gs[m * WG_BLOCK_ROWS + t];
     pr.gb[n0 + t] = pr.accumulate ? pr.gb[n0 + t] + sum : sum;
+  }
+}
+
+// ------------------------------------------------------------------ grouped weight gradient over GATHERED operands
+// Data-parallel exchange of the bead-level layers (trainer.OperandExchange): a weight gradient g^T x has rank <= rows,
+// and the bead-level layers see 12 rows per GPU against 0.36 - 3.2 M weights, so the ranks all-gather their operand
+// rows (g = gy * act'(z) and x, packed by pack_operands_k) instead of all-reducing gW, and every rank forms the
+// global gradient itself:  gW[N,K] (+)= sum over ALL ranks' rows of g[m,:]^T x[m,:]  -- what a single process would
+// compute on the concatenated batch.  Row m of the problem lives in rank segment m / seg_rows of the gathered buffer:
+//   g_row(m) = gy + (m / seg_rows) * seg_stride + (m % seg_rows) * N        x_row(m) likewise with K.
+// A block owns a 64 x 64 tile of one gW; wave w its rows 16 w .. 16 w + 15.  MFMA 16x16x4 f32 steps over 4 rows
+// (seg_rows % 4 == 0 keeps a step inside one segment): lane (i = l&15, q = l>>4) supplies A = g_row(m0+q)[n0+16w+i]
+// and B_s = x_row(m0+q)[k0 + 4 i + s], so that D_s holds gW[n0+16w+4q+r][k0+4i+s] and leaves as 16-byte stores.
+// Operands stream from L2 (every row is reused by all tiles of its layer); exact fp32 FMA chains, fixed order.
+__global__ __launch_bounds__(256) void gathered_wgrad_k(const WgradProblem* __restrict__ table, int n_problems) {
+  int lo = 0, hi = n_problems - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid].block_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const WgradProblem pr = table[lo];
+  const int local = blockIdx.x - pr.block_begin;
+  const int nb = local / pr.tiles_k, kt = local - nb * pr.tiles_k;
+  const int M = pr.M, N = pr.N, K = pr.K;
+  const int sr = pr.seg_rows > 0 ? pr.seg_rows : M;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, q = lane >> 4;
+  const int n = nb * 64 + 16 * wave + i, kcol = kt * 64 + 4 * i;
+  const bool nok = n < N, kok = kcol < K;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+  for (int seg0 = 0, m0 = 0; m0 < M; ++seg0, m0 += sr) {           // rank segments
+    const float* gseg = pr.gy + (size_t)seg0 * pr.seg_stride + (nok ? n : 0);
+    const float* xseg = pr.x + (size_t)seg0 * pr.seg_stride + (kok ? kcol : 0);
+    const int rows = min(sr, M - m0);
+#pragma unroll 4
+    for (int r0 = 0; r0 < rows; r0 += 4) {
+      const int r = r0 + q;
+      const bool rok = r < rows;
+      const float a = (rok && nok) ? gseg[(size_t)r * N] : 0.f;
+      const float4 b = ldg4_or_zero(xseg + (size_t)(rok ? r : 0) * K, rok && kok);
+      bsum += a;
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.y, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.z, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.w, acc[3], 0, 0, 0);
+    }
+  }
+  if (kok) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = nb * 64 + 16 * wave + 4 * q + r;
+      if (row >= N) continue;
+      float4* dst = reinterpret_cast<float4*>(pr.gW + (size_t)row * K + kcol);
+      float4 o = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+      if (pr.accumulate) { const float4 old = *dst; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+      *dst = o;
+    }
+  }
+  if (pr.gb && kt == 0) {                                           // bias: the 4 row groups q of a step meet by shuffle
+    bsum += __shfl_xor(bsum, 16);
+    bsum += __shfl_xor(bsum, 32);
+    if (q == 0 && nok) pr.gb[n] = pr.accumulate ? pr.gb[n] + bsum : bsum;
+  }
+}
+
+// Packs the operands of queued weight-gradient problems into one contiguous send buffer:
+//   dst_g[M,N] = gy * act'(z)      dst_x[M,K] = x        (float4 granularity; N % 4 == 0, K % 4 == 0)
+struct PackProblem {        // mirrors the 64-byte host record built in python (trainer.OperandExchange)
+  const float* gy;
+  const float* z;           // pre-activation or NULL
+  const float* x;
+  float* dst_g;
+  float* dst_x;
+  int M, N, K, act;
+  int block_begin;
+  int pad[1];
+};
+static_assert(sizeof(PackProblem) == 64, "host/device record layout");
+constexpr int PACK_F4_PER_BLOCK = 1024;
+
+__global__ __launch_bounds__(256) void pack_operands_k(const PackProblem* __restrict__ table, int n_problems) {
+  int lo = 0, hi = n_problems - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid].block_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const PackProblem pr = table[lo];
+  const int ng4 = pr.M * pr.N / 4, nx4 = pr.M * pr.K / 4;
+  const int base = (blockIdx.x - pr.block_begin) * PACK_F4_PER_BLOCK;
+#pragma unroll
+  for (int t = 0; t < PACK_F4_PER_BLOCK / 256; ++t) {
+    const int idx = base + t * 256 + threadIdx.x;
+    if (idx < ng4) {
+      float4 g = reinterpret_cast<const float4*>(pr.gy)[idx];
+      if (pr.act) {
+        const float4 zz = reinterpret_cast<const float4*>(pr.z)[idx];
+        g.x *= act_bwd(zz.x, pr.act); g.y *= act_bwd(zz.y, pr.act); g.z *= act_bwd(zz.z, pr.act); g.w *= act_bwd(zz.w, pr.act);
+      }
+      reinterpret_cast<float4*>(pr.dst_g)[idx] = g;
+    } else if (idx < ng4 + nx4) {
+      reinterpret_cast<float4*>(pr.dst_x)[idx - ng4] = reinterpret_cast<const float4*>(pr.x)[idx - ng4];
+    }
   }
 }
 
@@ -505,6 +614,44 @@ int cgv_grouped_wgrad(const void* table_dev, int n_problems, int total_blocks, i
   hipLaunchKernelGGL(cgv::grouped_wgrad_k, dim3(total_blocks), dim3(256), sizeof(float) * (size_t)max_lds_floats,
                      (hipStream_t)stream, reinterpret_cast<const cgv::WgradProblem*>(table_dev), n_problems);
   return cgv::check_launch("cgv_grouped_wgrad");
+}
+
+/* Weight gradients over gathered operand rows (include/cgvae_hip.h: data-parallel operand exchange). */
+int cgv_wgrad_gathered_plan(int M, int N, int K, int seg_rows, int* tiles_k, int* n_blocks) {
+  CGV_REQUIRE(tiles_k && n_blocks, "null pointer");
+  CGV_REQUIRE(M >= 1 && N >= 4 && K >= 4 && (N % 4) == 0 && (K % 4) == 0, "unsupported shape (need N % 4 == 0, K % 4 == 0)");
+  CGV_REQUIRE(seg_rows == 0 || (seg_rows > 0 && seg_rows % 4 == 0), "rank segments must hold a multiple of 4 rows");
+  *tiles_k = (K + 63) / 64;
+  *n_blocks = ((N + 63) / 64) * *tiles_k;
+  return 0;
+}
+
+int cgv_grouped_wgrad_gathered(const void* table_dev, int n_problems, int total_blocks, void* stream) {
+  CGV_REQUIRE(n_problems >= 0 && total_blocks >= 0, "bad size");
+  if (n_problems == 0 || total_blocks == 0) return 0;
+  CGV_REQUIRE(table_dev, "null table");
+  hipLaunchKernelGGL(cgv::gathered_wgrad_k, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const cgv::WgradProblem*>(table_dev), n_problems);
+  return cgv::check_launch("cgv_grouped_wgrad_gathered");
+}
+
+int cgv_pack_record_bytes(void) { return (int)sizeof(cgv::PackProblem); }
+
+int cgv_pack_plan(int M, int N, int K, int* n_blocks) {
+  CGV_REQUIRE(n_blocks, "null pointer");
+  CGV_REQUIRE(M >= 1 && N >= 4 && K >= 4 && (N % 4) == 0 && (K % 4) == 0, "unsupported shape (need N % 4 == 0, K % 4 == 0)");
+  const long long f4 = (long long)M * (N + K) / 4;
+  *n_blocks = (int)((f4 + cgv::PACK_F4_PER_BLOCK - 1) / cgv::PACK_F4_PER_BLOCK);
+  return 0;
+}
+
+int cgv_pack_operands(const void* table_dev, int n_problems, int total_blocks, void* stream) {
+  CGV_REQUIRE(n_problems >= 0 && total_blocks >= 0, "bad size");
+  if (n_problems == 0 || total_blocks == 0) return 0;
+  CGV_REQUIRE(table_dev, "null table");
+  hipLaunchKernelGGL(cgv::pack_operands_k, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const cgv::PackProblem*>(table_dev), n_problems);
+  return cgv::check_launch("cgv_pack_operands");
 }
 
 }  // extern "C"

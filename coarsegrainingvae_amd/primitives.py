@@ -73,14 +73,12 @@ class WeightGradQueue:
     per step become one, and the weight-gradient writes (the largest traffic of the backward pass)
     stream at HBM speed instead of paying a few microseconds of launch latency each."""
 
-    RECORD = struct.Struct("<5Q9i4x")            # cgv::WgradProblem, 80 bytes
+    RECORD = struct.Struct("<5Q11i4x")           # cgv::WgradProblem, 88 bytes
     MAX_PROBLEMS = 512
 
     def __init__(self):
         self.active = False
         self.items = []
-        self._host = None       # pinned staging buffer
-        self._dev = {}          # device -> table tensor
         self._captured = []     # (pinned, device) pairs owned by captured graphs
         self._capture_slots = []
 
@@ -98,45 +96,61 @@ class WeightGradQueue:
     def enqueue(self, gy, x, z, act, gW, gb, accumulate):
         self.items.append((gy, x, z, act, gW, gb, accumulate))
 
+    def take(self):
+        """Hand the queued problems to the caller (the data-parallel operand exchange) and empty the queue."""
+        items, self.items = self.items, []
+        return items
+
     def flush(self):
-        if not self.items:
-            return
-        lib = _lib.load()
-        assert lib.cgv_wgrad_record_bytes() == self.RECORD.size
-        if len(self.items) > self.MAX_PROBLEMS:
-            raise RuntimeError("too many queued weight-gradient problems")
-        dev = self.items[0][0].device
+        self.launch(self.take())
+
+    def upload(self, buf: bytes, device):
+        """Device copy of a host-built record table.  Inside a stream capture the (pinned, device) pair comes from
+        the slots allocated by ``prepare_capture`` and is kept alive with the graph."""
         if torch.cuda.is_current_stream_capturing():
             # a captured H2D node re-reads its pinned source at every replay: the graph gets its own,
             # never-rewritten staging buffer and table, allocated BEFORE capture (prepare_capture)
             if not self._capture_slots:
-                raise RuntimeError("call wgrad_queue.prepare_capture(device) before capturing a step")
+                raise RuntimeError("call wgrad_queue.prepare_capture(device) with enough slots before capturing a step")
             host, table = slot = self._capture_slots.pop()
             self._captured.append(slot)
         else:
-            if self._host is None:
-                self._host = torch.empty(self.MAX_PROBLEMS * self.RECORD.size, dtype=torch.uint8).pin_memory()
-            if dev not in self._dev:
-                self._dev[dev] = torch.empty(self.MAX_PROBLEMS * self.RECORD.size, dtype=torch.uint8, device=dev)
-            host, table = self._host, self._dev[dev]
+            # eager launches: a fresh pinned block and table per upload (both come from caching allocators, which
+            # hold a block back until the copy that reads it has run) -- several tables can be in flight per step
+            n = (len(buf) + 255) // 256 * 256
+            host = torch.empty(n, dtype=torch.uint8, pin_memory=True)
+            table = torch.empty(n, dtype=torch.uint8, device=device)
+        if len(buf) > host.numel():
+            raise RuntimeError("record table exceeds the staging buffer")
+        host[: len(buf)].copy_(torch.frombuffer(bytearray(buf), dtype=torch.uint8))
+        table[: len(buf)].copy_(host[: len(buf)], non_blocking=True)
+        return table
+
+    def launch(self, items):
+        """ONE grouped launch for ``items`` (tuples as queued by ``enqueue``), writing into their gW / gb targets."""
+        if not items:
+            return
+        lib = _lib.load()
+        assert lib.cgv_wgrad_record_bytes() == self.RECORD.size
+        if len(items) > self.MAX_PROBLEMS:
+            raise RuntimeError("too many queued weight-gradient problems")
+        dev = items[0][0].device
         buf = bytearray()
         tk, tw, nb = C.c_int(), C.c_int(), C.c_int()
         block_begin, max_lds = 0, 0
-        for gy, x, z, act, gW, gb, accumulate in self.items:
+        for gy, x, z, act, gW, gb, accumulate in items:
             M, N = gy.shape
             K = x.shape[1]
             if lib.cgv_wgrad_plan(M, N, K, C.byref(tk), C.byref(tw), C.byref(nb)) != 0:
                 raise RuntimeError(lib.cgv_last_error_string().decode())
             buf += self.RECORD.pack(gy.data_ptr(), x.data_ptr(), z.data_ptr() if z is not None else 0, gW.data_ptr(),
                                     gb.data_ptr() if gb is not None else 0, M, N, K, int(accumulate), int(act),
-                                    block_begin, tk.value, tw.value, 0)
+                                    block_begin, tk.value, tw.value, 0, 0, 0)
             block_begin += nb.value
             max_lds = max(max_lds, lib.cgv_wgrad_lds_floats(M, tw.value))
-        n = len(self.items)
-        host[: len(buf)].copy_(torch.frombuffer(buf, dtype=torch.uint8))
-        table[: len(buf)].copy_(host[: len(buf)], non_blocking=True)
-        _lib.call("cgv_grouped_wgrad", _lib.ptr(table), n, block_begin, max_lds, _lib.stream_ptr(), tag="grouped_wgrad")
-        self.items = []          # tensors stay alive until here; stream order protects their reuse
+        table = self.upload(bytes(buf), dev)
+        _lib.call("cgv_grouped_wgrad", _lib.ptr(table), len(items), block_begin, max_lds, _lib.stream_ptr(), tag="grouped_wgrad")
+        # the operand tensors stay referenced by ``items`` until here; stream order protects their reuse
 
 
 class _QueueScope:
@@ -234,6 +248,11 @@ class _LinearFn(torch.autograd.Function):
             skinny_bwd_input(gy2, z, weight, gx, M, N, K, act)
             gx = gx.reshape(gy.shape[:-1] + (K,))
         if need_w:
+            # row count / shape of this layer's weight-gradient problem: the data-parallel trainer sorts the layers
+            # whose operand rows are cheaper to exchange than their gradients to the front of the arena
+            w_param._cgv_exch = (M, N, K)
+            if b_param is not None:
+                b_param._cgv_exch = (M, N, K)
             tw, acc_w, gw = _grad_target(w_param, weight)
             tb, acc_b, gb = _grad_target(b_param, b_param) if need_b else (None, acc_w, None)
             if tb is not None and acc_b != acc_w:            # never on this model; keep semantics anyway

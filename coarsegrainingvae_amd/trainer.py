@@ -14,6 +14,8 @@ SURVEY 8a note 8) live in ONE contiguous fp32 arena with matching gradient / mom
 """
 from __future__ import annotations
 
+import ctypes as C
+import struct
 from typing import List, Optional
 
 import torch
@@ -50,6 +52,13 @@ class ParamArena:
             p._cgv_pending = True
         self.accumulated = [p for p in params if not p._cgv_direct]
 
+    def range_of(self, grad_view: torch.Tensor):
+        """(lo, hi) float range of a contiguous view of the gradient arena, or None for any other tensor."""
+        off = grad_view.data_ptr() - self.g.data_ptr()
+        if off < 0 or off % 4 or off // 4 + grad_view.numel() > self.numel or not grad_view.is_contiguous():
+            return None
+        return (off // 4, off // 4 + grad_view.numel())
+
     def zero_grad(self):
         """Start of a step: direct-write parameters are only flagged 'pending' (their first
         gradient overwrites); the few autograd-accumulated ones (embeddings) are zeroed."""
@@ -84,6 +93,20 @@ class GradSync:
             w.wait()
         self.pending = []
 
+    def all_gather(self, recv: torch.Tensor, send: torch.Tensor):
+        """Asynchronous all-gather of equally sized ``send`` buffers into ``recv`` ([world * send.numel()], rank
+        major); returns the work handle (``.wait()`` makes the current stream wait for the result)."""
+        return self.dist.all_gather_into_tensor(recv, send, group=self.group, async_op=True)
+
+    def same_on_all_ranks(self, value: int) -> bool:
+        t = torch.tensor([value, -value], dtype=torch.int64, device=self._device())
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        return int(t[0]) == value and int(t[1]) == -value
+
+    def _device(self):
+        backend = self.dist.get_backend(self.group)
+        return torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+
     def all_reduce_flat(self, flat: torch.Tensor):
         self.all_reduce_range(flat, 0, flat.numel())
         self.wait()
@@ -106,17 +129,167 @@ class GradSync:
         return (y / self.world).reshape(())
 
 
+def subtract_ranges(ranges, holes):
+    """``ranges`` minus ``holes`` (lists of half-open (lo, hi) pairs); the result is sorted and disjoint."""
+    holes = sorted(h for h in holes if h[1] > h[0])
+    out = []
+    for lo, hi in sorted(ranges):
+        at = lo
+        for hlo, hhi in holes:
+            if hhi <= at:
+                continue
+            if hlo >= hi:
+                break
+            if hlo > at:
+                out.append((at, hlo))
+            at = max(at, hhi)
+            if at >= hi:
+                break
+        if at < hi:
+            out.append((at, hi))
+    return out
+
+
+def complement_ranges(done, total):
+    return subtract_ranges([(0, total)], done)
+
+
+class OperandExchange:
+    """Data-parallel exchange of OPERANDS instead of gradients for the bead-level linear layers.
+
+    A weight gradient ``gW = g^T x`` has rank <= rows.  On the chignolin config a rank holds 12 bead rows, while the
+    bead-level weights are 0.36 - 3.2 M elements each (220 MB together): all-reducing them moves ~270 MB per step and
+    rank over xGMI rings that are per-link bound.  Here the ranks all-gather the operand rows instead
+    (``g = gy * act'(z)`` and ``x``: (N + K) * rows floats per layer, ~7 MB per rank and step) and every rank forms the
+    gradient of the CONCATENATED batch itself with one grouped MFMA launch (csrc/skinny_gemm.hip:
+    gathered_wgrad_k) -- the sum a single process would compute (scripts/utils.py:110-157 on the whole batch),
+    bit-identical on every rank, no reduction tree.  The redundant flops (world x the local product) are noise
+    next to the bytes saved.  Layers whose rows are not cheaper than their weights (atom-level layers, big bead
+    batches) and every other parameter keep the gradient all-reduce.
+
+    Protocol per backward bucket: ``submit`` packs the queued problems' operands into one send buffer (one launch)
+    and starts the all-gather on the communication stream; ``complete`` (called at the next bucket boundary, i.e.
+    after ~3 decoder layers of backward, and at the end) waits for the gathers and runs the gathered launches.
+    Needs equally shaped shards on every rank (checked once per buffer size)."""
+
+    PACK = struct.Struct("<5Q5i4x")             # cgv::PackProblem, 64 bytes
+
+    def __init__(self, sync: "GradSync", arena: "ParamArena", queue):
+        self.sync, self.world, self.arena, self.queue = sync, sync.world, arena, queue
+        self.inflight = []
+        self.done_ranges = []                   # arena ranges whose global gradient this step came from gathered rows
+        self._mode = {}                         # gW pointer -> "exchange" | "local" within the current step
+        self._checked = set()
+        self.bytes_gathered = 0                 # per step, this rank's send bytes x world (for reporting)
+
+    # -- which problems are exchanged
+    def eligible(self, item) -> bool:
+        gy, x, z, act, gW, gb, accumulate = item
+        M, N = gy.shape
+        K = x.shape[1]
+        if M % 4 or N % 4 or K % 4 or not gW.is_contiguous():
+            return False
+        if self.arena.range_of(gW) is None or (gb is not None and self.arena.range_of(gb) is None):
+            return False
+        return self.world * M * (N + K) <= N * K            # gathered rows vs the two passes an all-reduce makes
+
+    def begin_step(self):
+        self.done_ranges, self._mode, self.bytes_gathered = [], {}, 0
+
+    def split(self, items):
+        """(exchanged, local) -- a parameter keeps ONE mode within a step."""
+        ex, loc = [], []
+        for it in items:
+            mode = "exchange" if self.eligible(it) else "local"
+            key = it[4].data_ptr()
+            if self._mode.setdefault(key, mode) != mode:
+                raise RuntimeError("one parameter received both exchanged and local weight-gradient contributions")
+            (ex if mode == "exchange" else loc).append(it)
+        return ex, loc
+
+    # -- pack + all-gather
+    def submit(self, items):
+        if not items:
+            return
+        lib = _lib.load()
+        assert lib.cgv_pack_record_bytes() == self.PACK.size
+        dev = items[0][0].device
+        metas, total = [], 0
+        for gy, x, z, act, gW, gb, accumulate in items:
+            M, N = gy.shape
+            K = x.shape[1]
+            off_g = total
+            off_x = off_g + (M * N + 63) // 64 * 64
+            total = off_x + (M * K + 63) // 64 * 64
+            metas.append((M, N, K, off_g, off_x, gW, gb, bool(accumulate)))
+        if total not in self._checked and not torch.cuda.is_current_stream_capturing():
+            if not self.sync.same_on_all_ranks(total):
+                raise RuntimeError("operand exchange needs equally shaped shards on every rank")
+            self._checked.add(total)
+        send = torch.empty(total, dtype=torch.float32, device=dev)
+        recv = torch.empty(self.world * total, dtype=torch.float32, device=dev)
+        buf, block_begin, nb = bytearray(), 0, C.c_int()
+        for (gy, x, z, act, _gW, _gb, _acc), (M, N, K, off_g, off_x, *_rest) in zip(items, metas):
+            if lib.cgv_pack_plan(M, N, K, C.byref(nb)) != 0:
+                raise RuntimeError(lib.cgv_last_error_string().decode())
+            buf += self.PACK.pack(gy.data_ptr(), z.data_ptr() if z is not None else 0, x.data_ptr(),
+                                  send.data_ptr() + 4 * off_g, send.data_ptr() + 4 * off_x, M, N, K, int(act), block_begin)
+            block_begin += nb.value
+        table = self.queue.upload(bytes(buf), dev)
+        _lib.call("cgv_pack_operands", _lib.ptr(table), len(items), block_begin, _lib.stream_ptr(), tag="pack_operands")
+        work = self.sync.all_gather(recv, send)
+        self.inflight.append((work, metas, recv, send, total))
+        self.bytes_gathered += 4 * total * self.world
+        for M, N, K, _og, _ox, gW, gb, _acc in metas:
+            self.done_ranges.append(self.arena.range_of(gW))
+            if gb is not None:
+                self.done_ranges.append(self.arena.range_of(gb))
+
+    # -- gathered weight gradients
+    def complete(self):
+        if not self.inflight:
+            return
+        lib = _lib.load()
+        rec = self.queue.RECORD
+        buf, block_begin, n = bytearray(), 0, 0
+        tk, nb = C.c_int(), C.c_int()
+        dev = self.inflight[0][2].device
+        for work, metas, recv, _send, total in self.inflight:
+            work.wait()                                      # the current stream now waits for the gather
+            for M, N, K, off_g, off_x, gW, gb, accumulate in metas:
+                if lib.cgv_wgrad_gathered_plan(self.world * M, N, K, M, C.byref(tk), C.byref(nb)) != 0:
+                    raise RuntimeError(lib.cgv_last_error_string().decode())
+                buf += rec.pack(recv.data_ptr() + 4 * off_g, recv.data_ptr() + 4 * off_x, 0, gW.data_ptr(),
+                                gb.data_ptr() if gb is not None else 0, self.world * M, N, K, int(accumulate), 0,
+                                block_begin, tk.value, 0, M, total, 0)
+                block_begin += nb.value
+                n += 1
+        if n > self.queue.MAX_PROBLEMS:
+            raise RuntimeError("too many gathered weight-gradient problems")
+        table = self.queue.upload(bytes(buf), dev)
+        _lib.call("cgv_grouped_wgrad_gathered", _lib.ptr(table), n, block_begin, _lib.stream_ptr(), tag="gathered_wgrad")
+        self.inflight = []                                   # buffers: stream order protects their reuse
+
+
 class Trainer:
     """One object per process (= per GPU).  ``step(batch)`` runs a full training iteration."""
 
     def __init__(self, model, lr: float, beta: float, gamma: float, world_size: int = 1, group=None,
                  fused_optimizer: bool = True, betas=(0.9, 0.999), eps: float = 1e-8, max_norm: float = CLIP_NORM,
-                 always_sync: bool = False):
+                 always_sync: bool = False, exchange: str = "auto", sync=None):
+        """``exchange``: what the ranks exchange for the bead-level linear layers -- "operands" (all-gather of the
+        rows that form the weight gradients, see OperandExchange), "gradients" (all-reduce everything), or "auto"
+        (operands on the HIP path).  ``sync``: a GradSync-compatible object to use instead of one built from
+        ``world_size`` / ``group`` (tests substitute a single-process stand-in for N ranks)."""
         self.model, self.lr, self.beta, self.gamma = model, lr, beta, gamma
         self.betas, self.eps, self.max_norm = betas, eps, max_norm
         self.world = world_size
         # always_sync: run the collective path even with one rank (exercises RCCL + graph capture in tests)
-        self.sync = GradSync(world_size, group) if (world_size > 1 or always_sync) else None
+        self.sync = sync if sync is not None else (GradSync(world_size, group) if (world_size > 1 or always_sync) else None)
+        if exchange not in ("auto", "operands", "gradients"):
+            raise ValueError("exchange must be 'auto', 'operands' or 'gradients'")
+        self.exchange_mode = exchange
+        self.exchange: Optional[OperandExchange] = None
         self.fused = fused_optimizer
         self.arena: Optional[ParamArena] = None
         self.early_ranges = []        # per model bucket: arena ranges all-reduced while backward still runs
@@ -133,14 +306,27 @@ class Trainer:
         live = [p for p in self.model.parameters() if p.grad is not None]
         if not live:
             raise RuntimeError("no parameter received a gradient")
+        on_device = live[0].device.type == "cuda"
+        use_exchange = (self.sync is not None and self.fused and on_device and self.exchange_mode != "gradients")
+        if use_exchange:
+            # layers whose operand rows will be exchanged go to the front of the arena, so that what is left for the
+            # gradient all-reduce is a few large contiguous ranges (tags: primitives._LinearFn.backward)
+            world = self.sync.world
+
+            def exchanged(p):
+                t = getattr(p, "_cgv_exch", None)
+                return t is not None and t[0] % 4 == 0 and world * t[0] * (t[1] + t[2]) <= t[1] * t[2]
+            live = sorted(live, key=lambda p: 0 if exchanged(p) else 1)
         self.arena = ParamArena(live)
         dev = self.arena.p.device
+        self.exchange = OperandExchange(self.sync, self.arena, wgrad_queue) if use_exchange else None
         # arena ranges of the model's backward buckets (decoder layer groups, in the order their gradients become
         # final): each is all-reduced as soon as it is, under the rest of backward
         self.early_ranges = []
         buckets = self.model.backward_buckets() if hasattr(self.model, "backward_buckets") else []
         slot = {id(p): k for k, p in enumerate(live)}
         taken = set()
+        ends = self.arena.offsets[1:] + [self.arena.numel]      # a parameter's range includes its alignment padding
         for params in buckets:
             idx = sorted({slot[id(p)] for p in params if id(p) in slot})
             if taken.intersection(idx):
@@ -148,7 +334,7 @@ class Trainer:
             taken.update(idx)
             ranges = []
             for k in idx:                                   # merge neighbours into maximal contiguous runs
-                lo, hi = self.arena.offsets[k], self.arena.offsets[k] + live[k].numel()
+                lo, hi = self.arena.offsets[k], ends[k]
                 if ranges and ranges[-1][1] == lo:
                     ranges[-1] = (ranges[-1][0], hi)
                 else:
@@ -199,7 +385,7 @@ class Trainer:
         if self.sync is not None:
             self.sync.drain()
         graph = torch.cuda.CUDAGraph()
-        wgrad_queue.prepare_capture(self.arena.p.device, flushes=len(self.early_ranges) + 3)
+        wgrad_queue.prepare_capture(self.arena.p.device, flushes=3 * (len(self.early_ranges) + 2))
         # with RCCL in the step, other threads (the process group's watchdog) legitimately touch the runtime
         mode = "thread_local" if self.sync is not None else "global"
         with torch.cuda.graph(graph, capture_error_mode=mode):
@@ -262,17 +448,26 @@ class Trainer:
             self._build_arena()
         else:
             self.arena.zero_grad()
+            use_ex = self.exchange is not None and train and self.sync is not None
+            self._early_done = []
+            if self.exchange is not None:
+                self.exchange.begin_step()
             with wgrad_queue.collect():          # bead-level weight gradients: queued, then ONE grouped launch
                 loss.backward()
-            wgrad_queue.flush()
+            self._flush_queue(use_ex)
             if hasattr(self.model, "bucket_done"):
                 self.model.bucket_done = None
         if not train:                                               # validation: backward only (utils.py:160)
             return self.last_loss
         if self.sync is not None:
             a = self.arena
-            for lo, hi in self._unsent_ranges():                    # everything not already in flight
+            done = list(getattr(self, "_early_done", []))
+            if self.exchange is not None:
+                done += [self._padded(r) for r in self.exchange.done_ranges]
+            for lo, hi in complement_ranges(done, a.numel):         # everything not already in flight or gathered
                 self.sync.all_reduce_range(a.g, lo, hi)
+            if self.exchange is not None:
+                self.exchange.complete()
             self.sync.wait()
         scale = 1.0 / self.world
         if self.fused:
@@ -288,27 +483,48 @@ class Trainer:
             self.torch_opt.step()
         return self.last_loss
 
+    EARLY_MIN_FLOATS = 1 << 18      # ranges below 1 MiB are not worth a collective of their own: they go at the end
+
+    def _padded(self, r):
+        """A parameter's range extended over its alignment padding (zeros), so that neighbours merge."""
+        return (r[0], (r[1] + _ALIGN - 1) // _ALIGN * _ALIGN)
+
+    def _flush_queue(self, use_exchange: bool):
+        """Materialise the queued bead-level weight gradients: locally (one grouped launch), or -- data parallel --
+        by starting the operand exchange for the layers it pays for (OperandExchange) and launching the rest."""
+        items = wgrad_queue.take()
+        if use_exchange:
+            exchanged, local = self.exchange.split(items)
+            wgrad_queue.launch(local)
+            self.exchange.submit(exchanged)
+        else:
+            wgrad_queue.launch(items)
+
     def _bucket_done(self, index: int):
         """Autograd-thread callback (model.bucket_done): the gradients of backward bucket ``index`` are final.
-        Materialise its queued weight gradients and start their all-reduce; backward continues."""
+        Finish the previous bucket's operand exchange, start this one's, and all-reduce what the exchange does not
+        cover; backward continues."""
         if index in self._sent or index >= len(self.early_ranges):
             return
         self._sent.add(index)
-        wgrad_queue.flush()
-        for lo, hi in self.early_ranges[index]:
-            self.sync.all_reduce_range(self.arena.g, lo, hi)
+        ranges = self.early_ranges[index]
+        if self.exchange is not None:
+            self.exchange.complete()                 # the gather started one bucket ago has had time to finish
+            self._flush_queue(True)
+            ranges = subtract_ranges(ranges, [self._padded(r) for r in self.exchange.done_ranges])
+        else:
+            wgrad_queue.flush()
+        for lo, hi in ranges:
+            if hi - lo >= self.EARLY_MIN_FLOATS:
+                self.sync.all_reduce_range(self.arena.g, lo, hi)
+                self._early_done.append((lo, hi))
 
     def _unsent_ranges(self):
-        """Complement, within the arena, of the ranges of the buckets already sent."""
-        sent = sorted(r for i in self._sent for r in self.early_ranges[i])
-        out, at = [], 0
-        for lo, hi in sent:
-            if lo > at:
-                out.append((at, lo))
-            at = max(at, hi)
-        if at < self.arena.numel:
-            out.append((at, self.arena.numel))
-        return out
+        """Ranges of the arena that neither an early all-reduce nor the operand exchange has covered in this step."""
+        done = list(getattr(self, "_early_done", []))
+        if self.exchange is not None:
+            done += [self._padded(r) for r in self.exchange.done_ranges]
+        return complement_ranges(done, self.arena.numel)
 
     def skipped_steps(self) -> int:
         if self.fused and self.arena is not None:

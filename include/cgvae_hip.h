@@ -248,8 +248,8 @@ int cgv_update_gate_bwd(const float* U, const float* Vv, const float* a, const f
  *              split over ~320 blocks whose partial sums a second small launch adds in a fixed
  *              order; with ws = NULL one block per 64 output columns walks all rows (one launch,
  *              slow, same result up to summation order).
- *   grouped weight gradients: the caller queues one 80-byte record per layer
- *       { gy, x, z, gW, gb (pointers), M, N, K, accumulate, act, block_begin, tiles_k, tile_w, pad }
+ *   grouped weight gradients: the caller queues one 88-byte record per layer
+ *       { gy, x, z, gW, gb (pointers), M, N, K, accumulate, act, block_begin, tiles_k, tile_w, seg_rows, seg_stride, pad }
  *     (tiles_k / tile_w / the block count come from cgv_wgrad_plan; block_begin is the running sum
  *     of the block counts) and ONE cgv_grouped_wgrad launch computes, for every record,
  *       gW[N,K] (+)= (gy * act'(z))^T x ,  gb[N] (+)= sum_m (gy * act'(z))[m,:]     (gb may be NULL)
@@ -283,6 +283,23 @@ int cgv_wgrad_record_bytes(void);
 int cgv_wgrad_plan(int M, int N, int K, int* tiles_k /*[host]*/, int* tile_w /*[host]*/, int* n_blocks /*[host]*/);
 int cgv_wgrad_lds_floats(int M, int tile_w);
 int cgv_grouped_wgrad(const void* table_dev, int n_problems, int total_blocks, int max_lds_floats, void* stream);
+/* Data-parallel OPERAND exchange for the same layers.  A weight gradient g^T x has rank <= rows; the bead-level
+ * layers have 12 rows per GPU against 0.36 - 3.2 M weights, so instead of all-reducing gW (270 MB per step on the
+ * chignolin config) the ranks all-gather their operand rows and each forms the global gradient -- exactly what one
+ * process computes on the concatenated batch (the reference's single-process step, scripts/utils.py:110-157).
+ *   cgv_pack_operands: one launch copies, for every 64-byte record
+ *       { gy, z, x, dst_g, dst_x (pointers), M, N, K, act, block_begin, pad }
+ *     dst_g[M,N] = gy * act'(z), dst_x[M,K] = x into the caller's send buffer (block counts: cgv_pack_plan).
+ *   cgv_grouped_wgrad_gathered: the 88-byte record of cgv_grouped_wgrad with act = 0, z = NULL and
+ *     seg_rows (rows per rank, a multiple of 4) / seg_stride (floats between the rank segments of the gathered
+ *     buffer): row m of the problem is row m % seg_rows of segment m / seg_rows; M = ranks * seg_rows (any size).
+ *     tiles_k / the block count come from cgv_wgrad_gathered_plan; tile_w is unused.  64 x 64 output tiles, exact
+ *     fp32 MFMA chains in a fixed order: every rank obtains bit-identical gradients. */
+int cgv_wgrad_gathered_plan(int M, int N, int K, int seg_rows, int* tiles_k /*[host]*/, int* n_blocks /*[host]*/);
+int cgv_grouped_wgrad_gathered(const void* table_dev, int n_problems, int total_blocks, void* stream);
+int cgv_pack_record_bytes(void);
+int cgv_pack_plan(int M, int N, int K, int* n_blocks /*[host]*/);
+int cgv_pack_operands(const void* table_dev, int n_problems, int total_blocks, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Decoder tail (cgvae.py:462-481):  xyz[a] = v[mapping[a], chan[a], :] - [offset] mean over the bead of the

@@ -1,0 +1,162 @@
+"""Data-parallel OPERAND exchange on one GPU.  The collectives are replaced by a single-process stand-in for N
+identical ranks (every rank holds the same shard, so an all-gather is N copies and a SUM all-reduce a factor N):
+N-rank training must then reproduce single-rank training, through the pack kernel, the rank-segmented gathered
+weight-gradient kernel, the arena re-ordering and the range bookkeeping -- eagerly and as a captured hipGraph.
+(The real RCCL calls of this path run in tests/test_dp_rccl_single.py with a 1-rank group.)"""
+import numpy as np
+import pytest
+import torch
+
+import coarsegrainingvae_amd as cg
+from coarsegrainingvae_amd import _lib
+from coarsegrainingvae_amd.trainer import OperandExchange, Trainer
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+class _Done:
+    def wait(self):
+        return True
+
+
+class LoopbackSync:
+    """N identical ranks in one process (GradSync's interface)."""
+
+    def __init__(self, world):
+        self.world, self.group, self.pending = world, None, []
+        self.reduced, self.gathered, self.calls = 0, 0, 0
+
+    def all_reduce_range(self, flat, lo, hi):
+        flat[lo:hi].mul_(float(self.world))
+        self.reduced += hi - lo
+        self.calls += 1
+
+    def wait(self):
+        pass
+
+    def all_gather(self, recv, send):
+        recv.view(self.world, -1).copy_(send.unsqueeze(0).expand(self.world, -1))
+        self.gathered += recv.numel()
+        return _Done()
+
+    def same_on_all_ranks(self, value):
+        return True
+
+    def mean_scalar(self, x):
+        return x.detach().clone().reshape(())
+
+    def drain(self):
+        pass
+
+
+def _setup(workload="chignolin", F=64, frames=2, seed=123):
+    w = cg.data.WORKLOADS[workload]
+    model = cg.build_model(F, w["n_rbf"], w["atom_cutoff"], w["cg_cutoff"], w["enc_nconv"], w["dec_nconv"], w["n_cgs"],
+                           seed=seed).to(DEV)
+    batch = cg.synthetic_batch(workload, n_frames=frames, seed=0, device=DEV)
+    return model, batch, w
+
+
+def _train(world, mode, steps=3, capture=False, F=64):
+    torch.manual_seed(7)
+    model, batch, w = _setup(F=F)
+    sync = LoopbackSync(world) if world > 1 else None
+    tr = Trainer(model, lr=1e-3, beta=w["beta"], gamma=w["gamma"], world_size=world, exchange=mode, sync=sync)
+    eps = torch.randn(batch["CG_nxyz"].shape[0], F, generator=torch.Generator().manual_seed(1)).to(DEV)
+    if capture:
+        model.det = True                       # a captured step draws no eps; det keeps the runs comparable
+        tr.step(batch)
+        tr.capture(batch, warmup=1)
+        for _ in range(steps - 2):
+            tr.step(batch)
+    else:
+        for _ in range(steps):
+            tr.step(batch, eps=eps)
+    torch.cuda.synchronize()
+    return tr, {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+
+def _worst(a, b):
+    worst = 0.0
+    for k in a:
+        ref = b[k].double()
+        worst = max(worst, float((a[k].double() - ref).abs().max() / max(float(ref.abs().max()), 1e-12)))
+    return worst
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_operand_exchange_reproduces_single_rank_training(world):
+    F = 64 if world == 2 else 256                       # the exchange pays when ranks * rows * (N + K) <= N * K
+    _, ref = _train(1, "auto", F=F)
+    tr, got = _train(world, "operands", F=F)
+    assert tr.exchange is not None and tr.sync.gathered > 0
+    assert _worst(got, ref) < 2e-5
+    # the exchanged layers sit at the front of the arena: what is left for the all-reduce is a handful of ranges
+    a = tr.arena
+    done = sorted(tr._padded(r) for r in tr.exchange.done_ranges)
+    assert done[0][0] == 0
+    covered = sum(hi - lo for lo, hi in done)
+    assert covered > 0.5 * a.numel                      # most of the gradient bytes never cross the link ...
+    assert 4 * tr.exchange.bytes_gathered // 4 < 0.5 * 4 * covered          # ... and the rows that do are far fewer
+    assert len(tr._unsent_ranges()) <= 4
+    # gradient all-reduce of everything gives the same training, too
+    tr2, got2 = _train(world, "gradients", F=F)
+    assert tr2.exchange is None and tr2.sync.gathered == 0
+    assert _worst(got2, ref) < 2e-5
+
+
+def test_operand_exchange_inside_a_captured_step():
+    _, ref = _train(1, "auto", steps=4, capture=True, F=256)
+    tr, got = _train(8, "operands", steps=4, capture=True, F=256)
+    assert tr.replays >= 2 and tr.sync.gathered > 0
+    assert _worst(got, ref) < 2e-5
+
+
+@pytest.mark.parametrize("world,M,N,K,act,bias,accumulate", [(8, 12, 600, 600, 1, True, False), (2, 36, 1200, 600, 0, False, False),
+                                                             (3, 4, 68, 132, 2, True, True), (8, 12, 5400, 600, 0, True, False),
+                                                             (5, 96, 64, 64, 3, True, False)])
+def test_pack_and_gathered_wgrad_vs_fp64(world, M, N, K, act, bias, accumulate):
+    """Different rows on every 'rank': pack each rank's operands, lay the send buffers out as an all-gather would,
+    and compare the gathered launch with the fp64 gradient of the concatenated rows."""
+    import ctypes as C
+    from coarsegrainingvae_amd.primitives import wgrad_queue
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(world * 1000 + M + N)
+    pad = lambda n: (n + 63) // 64 * 64
+    total = pad(M * N) + pad(M * K) + 64                      # a second (empty) slot: segments are not back to back
+    recv = torch.zeros(world * total, device=DEV)
+    gys, xs, zs = [], [], []
+    for r in range(world):
+        gy, x, z = (torch.randn(M, N, generator=gen), torch.randn(M, K, generator=gen), torch.randn(M, N, generator=gen))
+        gys.append(gy); xs.append(x); zs.append(z)
+        gyd, xd, zd = gy.to(DEV), x.to(DEV), z.to(DEV)
+        send = recv[r * total:(r + 1) * total]
+        nb = C.c_int()
+        assert lib.cgv_pack_plan(M, N, K, C.byref(nb)) == 0
+        rec = OperandExchange.PACK.pack(gyd.data_ptr(), zd.data_ptr() if act else 0, xd.data_ptr(), send.data_ptr(),
+                                        send.data_ptr() + 4 * pad(M * N), M, N, K, act, 0)
+        table = wgrad_queue.upload(rec, torch.device(DEV))
+        _lib.call("cgv_pack_operands", _lib.ptr(table), 1, nb.value, _lib.stream_ptr())
+    torch.cuda.synchronize()
+    dact = {0: lambda z: torch.ones_like(z), 1: lambda z: torch.sigmoid(z) * (1 + z * (1 - torch.sigmoid(z))),
+            2: lambda z: 1 - torch.tanh(z) ** 2, 3: lambda z: (z > 0).double()}[act]
+    g64 = torch.cat([gy.double() * dact(z.double()) for gy, z in zip(gys, zs)])
+    x64 = torch.cat([x.double() for x in xs])
+    gW0 = torch.randn(N, K, generator=gen)
+    gb0 = torch.randn(N, generator=gen)
+    gW, gb = gW0.to(DEV), gb0.to(DEV)
+    tk, nb = C.c_int(), C.c_int()
+    assert lib.cgv_wgrad_gathered_plan(world * M, N, K, M, C.byref(tk), C.byref(nb)) == 0
+    rec = wgrad_queue.RECORD.pack(recv.data_ptr(), recv.data_ptr() + 4 * pad(M * N), 0, gW.data_ptr(),
+                                  gb.data_ptr() if bias else 0, world * M, N, K, int(accumulate), 0, 0, tk.value, 0, M, total, 0)
+    table = wgrad_queue.upload(rec, torch.device(DEV))
+    _lib.call("cgv_grouped_wgrad_gathered", _lib.ptr(table), 1, nb.value, _lib.stream_ptr())
+    torch.cuda.synchronize()
+    want_W = g64.t() @ x64 + (gW0.double() if accumulate else 0)
+    want_b = g64.sum(0) + (gb0.double() if accumulate else 0)
+    assert float((gW.cpu().double() - want_W).abs().max() / want_W.abs().max()) < 2e-6
+    if bias:
+        assert float((gb.cpu().double() - want_b).abs().max() / want_b.abs().max()) < 2e-6
+    else:
+        assert torch.equal(gb.cpu(), gb0)

@@ -190,7 +190,7 @@ def test_early_ranges_partition_the_decoder_and_complement_covers_the_rest():
     dec = sum(p.numel() for b in model.backward_buckets() for p in b if p.grad is not None)
     assert dec <= int(covered.sum()) <= dec + 64 * sum(len(b) for b in model.backward_buckets())   # + alignment padding
     for sent in (set(), {0}, {0, len(tr.early_ranges) - 1}, set(range(len(tr.early_ranges)))):
-        tr._sent = sent
+        tr._early_done = [r for i in sent for r in tr.early_ranges[i]]
         total = covered.clone().zero_()
         for i in sent:
             for lo, hi in tr.early_ranges[i]:
@@ -218,3 +218,65 @@ def test_param_arena_keeps_module_semantics():
         assert torch.allclose(p.grad, g)
     assert float(arena.g.abs().sum()) > 0
     assert all(o % 64 == 0 for o in arena.offsets)
+
+
+def test_range_algebra_of_the_exchange_bookkeeping():
+    from coarsegrainingvae_amd.trainer import complement_ranges, subtract_ranges
+    assert subtract_ranges([(0, 100)], []) == [(0, 100)]
+    assert subtract_ranges([(0, 100)], [(0, 100)]) == []
+    assert subtract_ranges([(0, 100)], [(10, 20), (15, 30), (90, 200)]) == [(0, 10), (30, 90)]
+    assert subtract_ranges([(0, 10), (20, 30)], [(5, 25)]) == [(0, 5), (25, 30)]
+    assert subtract_ranges([(20, 30), (0, 10)], [(40, 50)]) == [(0, 10), (20, 30)]
+    assert complement_ranges([(64, 128), (0, 64)], 256) == [(128, 256)]
+    assert complement_ranges([], 7) == [(0, 7)]
+    gen = torch.Generator().manual_seed(0)
+    for _ in range(50):                                        # against a bitmap
+        total = 200
+        mk = lambda n: [tuple(sorted(torch.randint(0, total, (2,), generator=gen).tolist())) for _ in range(n)]
+        ranges, holes = mk(4), mk(5)
+        want = torch.zeros(total, dtype=torch.bool)
+        for lo, hi in ranges:
+            want[lo:hi] = True
+        for lo, hi in holes:
+            want[lo:hi] = False
+        got = torch.zeros(total, dtype=torch.int32)
+        for lo, hi in subtract_ranges(ranges, holes):
+            got[lo:hi] += 1
+        # overlapping input ranges may be reported twice; coverage must match
+        assert torch.equal(got > 0, want)
+
+
+def _gather_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from coarsegrainingvae_amd.trainer import GradSync
+        sync = GradSync(world)
+        send = torch.arange(6, dtype=torch.float32) + 100.0 * rank
+        recv = torch.empty(world * 6)
+        sync.all_gather(recv, send).wait()
+        same = sync.same_on_all_ranks(6)
+        differ = sync.same_on_all_ranks(6 + rank)
+        q.put((rank, recv.numpy(), same, differ))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_operand_gather_is_rank_major_and_shape_check_catches_unequal_shards():
+    """What OperandExchange assumes of the collective layer: segment r of the gathered buffer is rank r's send
+    buffer, and unequal buffer sizes across ranks are detected before any all-gather is attempted."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = np.concatenate([np.arange(6) + 100.0 * r for r in range(2)]).astype(np.float32)
+    for rank, recv, same, differ in res:
+        assert np.array_equal(recv, want)
+        assert same is True and differ is False

@@ -1,5 +1,6 @@
-"""The data-parallel code path on a real GPU with a 1-rank RCCL group: gradient all-reduce
-(early decoder bucket + remainder) eagerly and inside the captured hipGraph.  Runs in a
+"""The data-parallel code path on a real GPU with a 1-rank RCCL group: operand exchange (all-gather of the
+bead-level layers' rows) plus gradient all-reduce of the rest, and the all-reduce-everything mode, eagerly and
+inside the captured hipGraph.  Runs in a
 subprocess so the process group does not leak into the pytest process."""
 import os
 import subprocess
@@ -20,10 +21,10 @@ torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 w = cg.data.WORKLOADS["dipeptide"]
 batch = cg.synthetic_batch("dipeptide", n_frames=4, seed=5, device="cuda")
-def run(always_sync, graph):
+def run(always_sync, graph, exchange="auto"):
     model = cg.build_model(64, w["n_rbf"], w["atom_cutoff"], w["cg_cutoff"], 2, 2, w["n_cgs"], det=True, seed=123).cuda()
     model.bucket_layers = 1                      # two decoder layers -> two early all-reduce buckets
-    tr = Trainer(model, lr=1e-3, beta=w["beta"], gamma=w["gamma"], world_size=1, always_sync=always_sync)
+    tr = Trainer(model, lr=1e-3, beta=w["beta"], gamma=w["gamma"], world_size=1, always_sync=always_sync, exchange=exchange)
     losses = [float(tr.step(batch)) for _ in range(3)]
     if graph:
         tr.capture(batch, warmup=0)
@@ -33,9 +34,12 @@ def run(always_sync, graph):
 ref, _ = run(False, False)
 eager, tr_e = run(True, False)
 graph, tr_g = run(True, True)
-assert len(tr_e.early_ranges) >= 2 and all(tr_e.early_ranges) and tr_g._graph is not None
-for a, b, c in zip(ref, eager, graph):
-    assert abs(a - b) <= 1e-5 * abs(a) and abs(a - c) <= 1e-5 * abs(a), (ref, eager, graph)
+allred, tr_a = run(True, True, "gradients")
+assert len(tr_e.early_ranges) >= 2 and all(tr_e.early_ranges) and tr_g._graph is not None and tr_a._graph is not None
+assert tr_e.exchange is not None and tr_e.exchange.bytes_gathered > 0 and tr_g.exchange is not None
+assert tr_a.exchange is None
+for a, b, c, d in zip(ref, eager, graph, allred):
+    assert abs(a - b) <= 1e-5 * abs(a) and abs(a - c) <= 1e-5 * abs(a) and abs(a - d) <= 1e-5 * abs(a), (ref, eager, graph, allred)
 dist.destroy_process_group()
 print("RCCL_PATH_OK", ref[-1])
 """
