@@ -359,12 +359,20 @@ __global__ __launch_bounds__(256) void grouped_wgrad_k(const WgradProblem* __res
 // rows (g = gy * act'(z) and x, packed by pack_operands_k) instead of all-reducing gW, and every rank forms the
 // global gradient itself:  gW[N,K] (+)= sum over ALL ranks' rows of g[m,:]^T x[m,:]  -- what a single process would
 // compute on the concatenated batch.  Row m of the problem lives in rank segment m / seg_rows of the gathered buffer:
-//   g_row(m) = gy + (m / seg_rows) * seg_stride + (m % seg_rows) * N        x_row(m) likewise with K.
-// A block owns a 64 x 64 tile of one gW; wave w its rows 16 w .. 16 w + 15.  MFMA 16x16x4 f32 steps over 4 rows
-// (seg_rows % 4 == 0 keeps a step inside one segment): lane (i = l&15, q = l>>4) supplies A = g_row(m0+q)[n0+16w+i]
-// and B_s = x_row(m0+q)[k0 + 4 i + s], so that D_s holds gW[n0+16w+4q+r][k0+4i+s] and leaves as 16-byte stores.
-// Operands stream from L2 (every row is reused by all tiles of its layer); exact fp32 FMA chains, fixed order.
+//   g_row(m) = gy + (m / seg_rows) * seg_stride + (m % seg_rows) * N        x_row(m) likewise with K
+// (seg_rows % 4 == 0 is required by the host protocol; the kernel itself takes any).
+// A block owns a 64 x 64 tile of one gW; wave w its rows 16 w .. 16 w + 15.  The operand rows of the tile (64 columns
+// of g, 64 of x) are staged through LDS in chunks of GW_CHUNK rows with coalesced 16-byte loads that are all in
+// flight at once (the direct-from-L2 version spent 264 us at 8 x 12 rows on dependent load rounds; this one is
+// bound by the gW stores).  MFMA 16x16x4 f32 steps over 4 rows: lane (i = l&15, q = l>>4) supplies
+// A = g[m0+q][16w+i] and B_s = x[m0+q][4i+s], so that D_s holds gW[n0+16w+4q+r][k0+4i+s] and leaves as 16-byte
+// stores.  LDS strides 80 / 64 floats keep the b32 / b128 reads conflict free.  Exact fp32 FMA chains, fixed order.
+constexpr int GW_CHUNK = 48;        // rows per staged chunk (multiple of 4)
+constexpr int GW_GS = 80, GW_XS = 64;
+
 __global__ __launch_bounds__(256) void gathered_wgrad_k(const WgradProblem* __restrict__ table, int n_problems) {
+  __shared__ __attribute__((aligned(16))) float gs[GW_CHUNK * GW_GS];
+  __shared__ __attribute__((aligned(16))) float xs[GW_CHUNK * GW_XS];
   int lo = 0, hi = n_problems - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -375,37 +383,53 @@ __global__ __launch_bounds__(256) void gathered_wgrad_k(const WgradProblem* __re
   const int nb = local / pr.tiles_k, kt = local - nb * pr.tiles_k;
   const int M = pr.M, N = pr.N, K = pr.K;
   const int sr = pr.seg_rows > 0 ? pr.seg_rows : M;
+  const int n0 = nb * 64, k0 = kt * 64;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, q = lane >> 4;
-  const int n = nb * 64 + 16 * wave + i, kcol = kt * 64 + 4 * i;
-  const bool nok = n < N, kok = kcol < K;
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   f32x4 acc[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
-  for (int seg0 = 0, m0 = 0; m0 < M; ++seg0, m0 += sr) {           // rank segments
-    const float* gseg = pr.gy + (size_t)seg0 * pr.seg_stride + (nok ? n : 0);
-    const float* xseg = pr.x + (size_t)seg0 * pr.seg_stride + (kok ? kcol : 0);
-    const int rows = min(sr, M - m0);
+  const int c4 = threadIdx.x & 15, rr = threadIdx.x >> 4;          // staging: 16 float4 columns x 16 rows per pass
+  const bool gcol = n0 + 4 * c4 < N, xcol = k0 + 4 * c4 < K;
+  for (int m0 = 0; m0 < M; m0 += GW_CHUNK) {
+    const int rows = min(GW_CHUNK, M - m0);
+#pragma unroll
+    for (int r = rr; r < GW_CHUNK; r += 16) {
+      const bool ok = r < rows;
+      const int m = m0 + (ok ? r : 0);
+      const int seg = m / sr, row = m - seg * sr;
+      const size_t base = (size_t)seg * pr.seg_stride;
+      float4 g4 = ldg4_or_zero(pr.gy + base + (size_t)row * N + (gcol ? n0 + 4 * c4 : 0), ok && gcol);
+      if (pr.act) {                                                  // local problems: g = gy * act'(z)
+        const float4 zz = ldg4_or_zero(pr.z + base + (size_t)row * N + (gcol ? n0 + 4 * c4 : 0), ok && gcol);
+        g4.x *= act_bwd(zz.x, pr.act); g4.y *= act_bwd(zz.y, pr.act); g4.z *= act_bwd(zz.z, pr.act); g4.w *= act_bwd(zz.w, pr.act);
+      }
+      const float4 x4 = ldg4_or_zero(pr.x + base + (size_t)row * K + (xcol ? k0 + 4 * c4 : 0), ok && xcol);
+      *reinterpret_cast<float4*>(gs + r * GW_GS + 4 * c4) = g4;
+      *reinterpret_cast<float4*>(xs + r * GW_XS + 4 * c4) = x4;
+    }
+    __syncthreads();
+    const int steps = (rows + 3) / 4;                                // rows beyond the chunk were staged as zeros
 #pragma unroll 4
-    for (int r0 = 0; r0 < rows; r0 += 4) {
-      const int r = r0 + q;
-      const bool rok = r < rows;
-      const float a = (rok && nok) ? gseg[(size_t)r * N] : 0.f;
-      const float4 b = ldg4_or_zero(xseg + (size_t)(rok ? r : 0) * K, rok && kok);
+    for (int st = 0; st < steps; ++st) {
+      const float a = gs[(4 * st + q) * GW_GS + 16 * wave + i];
+      const float4 b = *reinterpret_cast<const float4*>(xs + (4 * st + q) * GW_XS + 4 * i);
       bsum += a;
       acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.x, acc[0], 0, 0, 0);
       acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.y, acc[1], 0, 0, 0);
       acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.z, acc[2], 0, 0, 0);
       acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.w, acc[3], 0, 0, 0);
     }
+    __syncthreads();
   }
-  if (kok) {
+  const int n = n0 + 16 * wave + i, kcol = k0 + 4 * i;
+  if (kcol < K) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = nb * 64 + 16 * wave + 4 * q + r;
+      const int row = n0 + 16 * wave + 4 * q + r;
       if (row >= N) continue;
       float4* dst = reinterpret_cast<float4*>(pr.gW + (size_t)row * K + kcol);
       float4 o = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
@@ -416,7 +440,7 @@ __global__ __launch_bounds__(256) void gathered_wgrad_k(const WgradProblem* __re
   if (pr.gb && kt == 0) {                                           // bias: the 4 row groups q of a step meet by shuffle
     bsum += __shfl_xor(bsum, 16);
     bsum += __shfl_xor(bsum, 32);
-    if (q == 0 && nok) pr.gb[n] = pr.accumulate ? pr.gb[n] + bsum : bsum;
+    if (q == 0 && n < N) pr.gb[n] = pr.accumulate ? pr.gb[n] + bsum : bsum;
   }
 }
 

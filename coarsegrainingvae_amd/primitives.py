@@ -81,6 +81,8 @@ class WeightGradQueue:
         self.items = []
         self._captured = []     # (pinned, device) pairs owned by captured graphs
         self._capture_slots = []
+        import os
+        self.kernel = os.environ.get("CGV_WGRAD_KERNEL", "valu")      # "mfma": A/B switch, see launch()
 
     def prepare_capture(self, device, flushes: int = 4):
         """Allocate the (pinned, device) table pairs the flushes of the next captured step will use
@@ -138,6 +140,21 @@ class WeightGradQueue:
         buf = bytearray()
         tk, tw, nb = C.c_int(), C.c_int(), C.c_int()
         block_begin, max_lds = 0, 0
+        if self.kernel == "mfma":
+            # 64 x 64 MFMA tiles with LDS-staged operand rows (the kernel of the data-parallel operand exchange)
+            for gy, x, z, act, gW, gb, accumulate in items:
+                M, N = gy.shape
+                K = x.shape[1]
+                if lib.cgv_wgrad_gathered_plan(M, N, K, 0, C.byref(tk), C.byref(nb)) != 0:
+                    raise RuntimeError(lib.cgv_last_error_string().decode())
+                buf += self.RECORD.pack(gy.data_ptr(), x.data_ptr(), z.data_ptr() if z is not None else 0, gW.data_ptr(),
+                                        gb.data_ptr() if gb is not None else 0, M, N, K, int(accumulate), int(act),
+                                        block_begin, tk.value, 0, 0, 0, 0)
+                block_begin += nb.value
+            table = self.upload(bytes(buf), dev)
+            _lib.call("cgv_grouped_wgrad_gathered", _lib.ptr(table), len(items), block_begin, _lib.stream_ptr(),
+                      tag="grouped_wgrad")
+            return
         for gy, x, z, act, gW, gb, accumulate in items:
             M, N = gy.shape
             K = x.shape[1]
