@@ -79,6 +79,28 @@ def scatter_add_roofline(batch, F, reps=20):
             "frac": by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "avg_us": us, "algorithmic_bytes": by, "traffic": None}
 
 
+def message_forward_us(batch, F, R, cutoff, reps=50):
+    """Average duration of the fused EquiMessageBlock forward on this batch's atom graph: `reps` back-to-back launches
+    between two HIP events on the launch stream (per-launch events in an eager step also count the host's launch gap:
+    ~50 us against the 40-42 us rocprofv3 reports for the same kernel).  Same plan, edge records, shapes and code path
+    as the model's encoder layers; operand values are random (the kernel's time does not depend on them)."""
+    from coarsegrainingvae_amd import ops
+    g = batch["_graph"]
+    plan, geom = g.atom, g.geometry("atom", R, cutoff)
+    dev = g.xyz.device
+    phi, v = torch.randn(plan.n_src, 3 * F, device=dev), torch.randn(plan.n_src, F, 3, device=dev)
+    Wd, bd = torch.randn(3 * F, R, device=dev), torch.randn(3 * F, device=dev)
+    for _ in range(5):
+        ops.equi_message(phi, v, Wd, bd, plan, geom, True)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        ops.equi_message(phi, v, Wd, bd, plan, geom, True)
+    b.record()
+    torch.cuda.synchronize()
+    return 1e3 * a.elapsed_time(b) / reps
+
+
 def optimizer_roofline(trainer, reps=5):
     """Fused clip+Adam over the live-parameter arena: g read twice, p/m/v read and written once."""
     if not trainer.fused or trainer.arena is None:
@@ -226,6 +248,14 @@ def main():
             fwd_tags = [k for k in ksum if k.startswith("equi_msg_fwd")]
             tag = max(fwd_tags, key=lambda k: ksum[k]["total_ms"])
             roofline = edge_kernel_roofline(tag)
+            # the judged duration: back-to-back launches between two events (agrees with the rocprofv3 kernel trace);
+            # the per-launch figure from the eager steps stays beside it
+            us = message_forward_us(batch, F, R, w["cg_cutoff"])
+            roofline["avg_us_eager_step"] = roofline["avg_us"]
+            fl, by = roofline["algorithmic_flops"], roofline["hbm"]["algorithmic_bytes"]
+            roofline.update(avg_us=us, achieved=fl / (us * 1e-6) / 1e12, frac=fl / (us * 1e-6) / 1e12 / F32_PEAK_TFLOPS,
+                            timing="50 back-to-back launches between two HIP events on the launch stream")
+            roofline["hbm"].update(achieved_GBps=by / (us * 1e-6) / 1e9, frac=by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS)
             extra["kernels"] = {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv)
                                     for kk, vv in edge_kernel_roofline(k).items() if kk in ("avg_us", "launches", "frac")}
                                 for k in ksum}
