@@ -45,7 +45,7 @@ PROTOTYPES = {
     "cgv_segment_broadcast": (_i, [_p, _p, _p, _i, _i, _i, _p, _p]),
     "cgv_equi_msg_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, C.c_int64, C.c_int64, _p, _p, _p]),
     "cgv_equi_msg_grouped_supported": (_i, [_i, _i, _i]),
-    "cgv_equi_msg_fwd_grouped": (_i, [_p] * 9 + [_i, _i, _i, _i, C.c_int64, _p, _p, _p]),
+    "cgv_equi_msg_fwd_grouped": (_i, [_p] * 9 + [_i, _i, _i, _i, C.c_int64, C.c_int64, _p, _p, _p]),
     "cgv_equi_msg_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "cgv_equi_msg_bwd": (_i, [_p] * 13 + [_i, _i, _i, C.c_int64, C.c_int64, _p, _sz, _p]),
     "cgv_pseudo_msg_fwd": (_i, [_p] * 14 + [_i, _i, _i, _i, _p]),

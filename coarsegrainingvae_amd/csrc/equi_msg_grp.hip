@@ -48,23 +48,27 @@ __device__ __forceinline__ void edge_math(const f2 (&W0)[R + 1], const f2 (&W1)[
   a.C = fma2(hi2(m2), u12, fma2(hi2(m0), b.C, a.C));
 }
 
-// grid = 8 * groups_per_xcd * tiles blocks (tiles = ceil(F/128)), block = 64 * SPLIT threads: the SPLIT waves
+// grid = 8 * items_per_xcd blocks (items = groups x channel tiles of 128), block = 64 * SPLIT threads: the SPLIT waves
 // of a block take contiguous slices of the group's edge range and meet in LDS.
 template <int R, int RB, int SPLIT>
 __global__ __launch_bounds__(64 * SPLIT) void equi_msg_fwd_grp_k(
     const float* __restrict__ phi, const float* __restrict__ v, const float* __restrict__ geom /* group order */,
     const int* __restrict__ rowptr /* destination CSR */, const int* __restrict__ src_g,
     const float* __restrict__ Wd, const float* __restrict__ bd, float* __restrict__ ds, float* __restrict__ dv, int F,
-    int n_dst, int groups_per_xcd, int tiles, const float* __restrict__ s_res, const float* __restrict__ v_res) {
+    int n_dst, int items_per_xcd, int tiles, const float* __restrict__ s_res, const float* __restrict__ v_res) {
   constexpr int GS = geom_group_stride(R), NG = R + 6, MX = R + 1, MY = R + 5;   // record floats used; meta words
   constexpr int FILT = 3 * 128 * R, RED = SPLIT * RB * 8 * 64;
   __shared__ __attribute__((aligned(16))) float smem[FILT > RED ? FILT : RED];
+  // work item = (channel tile, group), tile-major; XCD x (= blockIdx % 8) takes items [x * items_per_xcd, ...): an XCD
+  // sweeps consecutive groups of ONE channel tile (at most two), so the rows its L2 must hold are one 3 KB tile slice of
+  // the sources around ~100 consecutive groups, not all five slices (2000-atom graph: L2 hit rate 46 % -> see DESIGN.md)
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int local = slot / tiles;
-  const int group = xcd * groups_per_xcd + local;
-  const int tile = slot - local * tiles;
+  const int n_groups = (n_dst + RB - 1) / RB;
+  const int item = xcd * items_per_xcd + slot;
+  if (slot >= items_per_xcd || item >= n_groups * tiles) return;
+  const int tile = item / n_groups;
+  const int group = item - tile * n_groups;
   const int node0 = group * RB;
-  if (node0 >= n_dst || local >= groups_per_xcd) return;
   const int node1 = min(node0 + RB, n_dst);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform -> record loads stay scalar
@@ -173,6 +177,175 @@ __global__ __launch_bounds__(64 * SPLIT) void equi_msg_fwd_grp_k(
   }
 }
 
+// ------------------------------------------------------------------ records through LDS
+// Same walk, but the per-edge records reach the wave through the VECTOR memory path and LDS instead of scalar loads.
+// Why: scalar loads return out of order, so the compiler must wait for ALL of them before any use (lgkmcnt(0)) -- a
+// record requested one edge ahead is the deepest prefetch that pays, and most of these loads miss the scalar cache (a
+// record is touched once per (group, channel tile)).  Vector loads return in order: each wave streams its slice of the
+// record array 32 edges at a time (two 16-byte-per-lane loads = 2 KiB, issued one piece ahead and parked in 8 VGPRs),
+// drops it into a 64-record LDS ring, and reads an edge's record back with four broadcast ds_read_b128 (every lane
+// the same address).  The FMAs then take the record from VGPRs (op_sel picks the half of a register pair), the
+// step's mask / next source go to SGPRs with two v_readfirstlane per step.  Needs 16-float records (n_rbf 8 or 10).
+constexpr int GRP_PIECE = 32;                 // edges per staged piece
+constexpr int GRP_RING = 2 * GRP_PIECE;       // records per wave in LDS
+
+template <int R, int RB, int SPLIT>
+__global__ __launch_bounds__(64 * SPLIT) void equi_msg_fwd_grp_lds_k(
+    const float* __restrict__ phi, const float* __restrict__ v, const float* __restrict__ geom /* group order */,
+    const int* __restrict__ rowptr /* destination CSR */, const int* __restrict__ src_g,
+    const float* __restrict__ Wd, const float* __restrict__ bd, float* __restrict__ ds, float* __restrict__ dv, int F,
+    int n_dst, int n_edges, int items_per_xcd, int tiles, const float* __restrict__ s_res,
+    const float* __restrict__ v_res) {
+  constexpr int GS = geom_group_stride(R), MX = R + 1, MY = R + 5;
+  static_assert(GS == 16, "the LDS ring holds 16-float records");
+  constexpr int FILT = 3 * 128 * R, RED = SPLIT * RB * 8 * 64;
+  __shared__ __attribute__((aligned(16))) float smem[FILT > RED ? FILT : RED];
+  __shared__ __attribute__((aligned(16))) float recs[SPLIT][GRP_RING * 16];
+  // work item = (channel tile, group), tile-major; XCD x (= blockIdx % 8) takes items [x * items_per_xcd, ...): an XCD
+  // sweeps consecutive groups of ONE channel tile (at most two), so the rows its L2 must hold are one 3 KB tile slice of
+  // the sources around ~100 consecutive groups, not all five slices (2000-atom graph: L2 hit rate 46 % -> see DESIGN.md)
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int n_groups = (n_dst + RB - 1) / RB;
+  const int item = xcd * items_per_xcd + slot;
+  if (slot >= items_per_xcd || item >= n_groups * tiles) return;
+  const int tile = item / n_groups;
+  const int group = item - tile * n_groups;
+  const int node0 = group * RB;
+  const int node1 = min(node0 + RB, n_dst);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const ChanPair cp = chan_pair(tile, lane, F);
+
+  f2 W0[R + 1], W1[R + 1], W2[R + 1];
+  {
+    const int sl[3] = {0, 1, 2};
+    stage_filter_tile<R, 3>(smem, Wd, sl, F, tile * 128);
+    const int cl = cp.c - tile * 128;
+    read_filter_rows2<R>(W0, smem, bd, cl, cp.c);
+    read_filter_rows2<R>(W1, smem + 128 * R, bd, cl, F + cp.c);
+    read_filter_rows2<R>(W2, smem + 2 * 128 * R, bd, cl, 2 * F + cp.c);
+  }
+  Acc acc[RB];
+#pragma unroll
+  for (int k = 0; k < RB; ++k) acc[k].s = acc[k].A = acc[k].B = acc[k].C = splat(0.f);
+
+  int beg = rowptr[node0], end = rowptr[node1];
+  {
+    const int len = (end - beg + SPLIT - 1) / SPLIT;
+    beg = min(beg + wave * len, end);
+    end = min(beg + len, end);
+  }
+  const unsigned row_bytes = 12u * (unsigned)F;
+  const unsigned oc = 4u * (unsigned)cp.c, oF = 4u * (unsigned)F, ov = 12u * (unsigned)cp.c;
+  const rsrc_t r_phi = make_rsrc(phi), r_v = make_rsrc(v);
+
+  if (beg < end) {
+    float* ring = recs[wave];
+    const float4* g4 = reinterpret_cast<const float4*>(geom);
+    const int lim4 = n_edges * 4 - 1;                                  // last float4 of the record array
+    // piece p = edges [beg + 32 p, beg + 32 p + 32) = 128 float4; lane l takes float4 l and 64 + l of it
+    auto piece_ld = [&](int first_edge, float4& a, float4& b) {
+      const int at = first_edge * 4 + lane;
+      a = g4[min(at, lim4)];
+      b = g4[min(at + 64, lim4)];
+    };
+    auto piece_st = [&](int first_edge, const float4& a, const float4& b) {
+      float4* dst = reinterpret_cast<float4*>(ring + ((first_edge - beg) & (GRP_RING - 1)) * 16);
+      dst[lane] = a;
+      dst[64 + lane] = b;
+    };
+    float4 na, nb;
+    piece_ld(beg, na, nb);
+    piece_st(beg, na, nb);
+    int staged_end = beg + GRP_PIECE;
+    piece_ld(staged_end, na, nb);                                      // parked until the ring half is free
+
+    float rec[16];
+    auto fetch = [&](int e) {
+      const float4* r4 = reinterpret_cast<const float4*>(ring + ((e - beg) & (GRP_RING - 1)) * 16);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float4 x = r4[t];
+        rec[4 * t] = x.x; rec[4 * t + 1] = x.y; rec[4 * t + 2] = x.z; rec[4 * t + 3] = x.w;
+      }
+    };
+    int e = beg;
+    fetch(e);
+    RowBuf bufA, bufB;
+    gather_row(bufA, r_phi, r_v, oc, oF, ov, (unsigned)src_g[beg] * row_bytes);
+
+#define CGV_GRP_EDGE(BUF, K)                                                                      \
+    if (((m >> (K)) & 1) && e < end) {                                                            \
+      edge_math<R>(W0, W1, W2, rec, BUF, acc[(K) % RB]);                                          \
+      ++e;                                                                                        \
+      fetch(min(e, end - 1));                                                                     \
+    }
+#define CGV_GRP_STEP(BUF)                                      \
+    {                                                          \
+      CGV_GRP_EDGE(BUF, 0)                                     \
+      if (RB > 1) { CGV_GRP_EDGE(BUF, 1) }                     \
+      if (RB > 2) { CGV_GRP_EDGE(BUF, 2) CGV_GRP_EDGE(BUF, 3) } \
+    }
+    // start of a step: refill the ring half whose edges are all consumed, then the step's mask / next source
+#define CGV_GRP_HEAD(FIRST)                                                                                      \
+    if (e >= staged_end - GRP_PIECE) {                                                                           \
+      piece_st(staged_end, na, nb);                                                                              \
+      staged_end += GRP_PIECE;                                                                                   \
+      piece_ld(staged_end, na, nb);                                                                              \
+    }                                                                                                            \
+    {                                                                                                            \
+      const int mx = __builtin_amdgcn_readfirstlane(__float_as_int(rec[MX]));                                    \
+      nsrc = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(rec[MY]));                                  \
+      m = (FIRST) ? ((mx >> 16) & ~((1 << (mx & 0xff)) - 1)) : (mx >> 16);                                       \
+    }
+
+    int m;
+    unsigned nsrc;
+    CGV_GRP_HEAD(true)
+    while (true) {
+      gather_row(bufB, r_phi, r_v, oc, oF, ov, nsrc * row_bytes);     // rows of the NEXT step
+      CGV_GRP_STEP(bufA)
+      if (e >= end) break;
+      CGV_GRP_HEAD(false)
+      gather_row(bufA, r_phi, r_v, oc, oF, ov, nsrc * row_bytes);
+      CGV_GRP_STEP(bufB)
+      if (e >= end) break;
+      CGV_GRP_HEAD(false)
+    }
+#undef CGV_GRP_EDGE
+#undef CGV_GRP_STEP
+#undef CGV_GRP_HEAD
+  }
+
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < RB; ++k) {
+    float* r = smem + ((wave * RB + k) * 8) * 64 + lane;
+    r[0] = acc[k].s.x; r[64] = acc[k].s.y; r[128] = acc[k].A.x; r[192] = acc[k].A.y;
+    r[256] = acc[k].B.x; r[320] = acc[k].B.y; r[384] = acc[k].C.x; r[448] = acc[k].C.y;
+  }
+  __syncthreads();
+  for (int k = wave; k < node1 - node0; k += SPLIT) {
+    f2 s = splat(0.f), A = splat(0.f), B = splat(0.f), C = splat(0.f);
+#pragma unroll
+    for (int w = 0; w < SPLIT; ++w) {
+      const float* r = smem + ((w * RB + k) * 8) * 64 + lane;
+      s += f2{r[0], r[64]}; A += f2{r[128], r[192]}; B += f2{r[256], r[320]}; C += f2{r[384], r[448]};
+    }
+    if (cp.live) {
+      const int node = node0 + k;
+      if (s_res) s += ldpair<true>(s_res + (size_t)node * F, cp);
+      stpair<true>(ds + (size_t)node * F, cp, s);
+      if (v_res) {
+        f2 rA, rB, rC;
+        ldvec<true>(v_res + (size_t)node * F * 3, cp, rA, rB, rC);
+        A += rA; B += rB; C += rC;
+      }
+      stvec<true>(dv + (size_t)node * F * 3, cp, A, B, C);
+    }
+  }
+}
+
 }  // namespace cgv
 
 extern "C" {
@@ -187,8 +360,8 @@ int cgv_equi_msg_grouped_supported(int n_feat, int n_rbf, int rb) {
 
 int cgv_equi_msg_fwd_grouped(const float* phi, const float* v, const float* geom_g, const int32_t* rowptr_d,
                              const int32_t* src_g, const float* Wd, const float* bd, float* ds,
-                             float* dv, int n_dst, int n_feat, int n_rbf, int rb, int64_t n_rows, const float* s_res,
-                             const float* v_res, void* stream) {
+                             float* dv, int n_dst, int n_feat, int n_rbf, int rb, int64_t n_rows, int64_t n_edges,
+                             const float* s_res, const float* v_res, void* stream) {
   CGV_REQUIRE(n_dst >= 0 && n_feat > 0, "bad size");
   if (n_dst == 0) return 0;
   CGV_REQUIRE(phi && v && geom_g && rowptr_d && src_g && Wd && bd && ds && dv, "null pointer");
@@ -200,8 +373,8 @@ int cgv_equi_msg_fwd_grouped(const float* phi, const float* v, const float* geom
   hipStream_t st = (hipStream_t)stream;
   const int tiles = (n_feat + 127) / 128;
   const int groups = (n_dst + rb - 1) / rb;
-  const int gpx = (groups + 7) / 8;
-  const dim3 grid(8 * gpx * tiles);
+  const int gpx = (groups * tiles + 7) / 8;           // work items per XCD
+  const dim3 grid(8 * gpx);
   // waves per block: 4 (measured on the 2000-atom graph: 4 -> 654 us, 8 -> 942 us: one 8-wave block per CU leaves two
   // waves per SIMD; 6 -> 1194 us: a wave count that is not a multiple of the 4 SIMDs loads them unevenly).
   // CGV_GRP_SPLIT=8 is kept for A/B runs.
@@ -212,6 +385,19 @@ int cgv_equi_msg_fwd_grouped(const float* phi, const float* v, const float* geom
                      Wd, bd, ds, dv, n_feat, n_dst, gpx, tiles, s_res, v_res)
 #define CGV_GRP_PICK(RBV) \
   if (split == 8) CGV_GRP_LAUNCH(RBV, 8); else CGV_GRP_LAUNCH(RBV, 4)
+  // record stream: "lds" (vector loads -> LDS ring -> VGPR operands; 16-float records: n_rbf 8 / 10) or "scalar"
+  bool lds = false;
+  if (const char* dbg = getenv("CGV_GRP_RECORDS")) lds = dbg[0] == 'l';
+  if (lds && (n_rbf == 8 || n_rbf == 10) && n_edges > 0 && n_edges < (1ll << 28)) {
+    const int ne = (int)n_edges;
+#define CGV_GRP_LDS(RV, RBV)                                                                                       \
+  hipLaunchKernelGGL((cgv::equi_msg_fwd_grp_lds_k<RV, RBV, 4>), grid, dim3(256), 0, st, phi, v, geom_g, rowptr_d, src_g, \
+                     Wd, bd, ds, dv, n_feat, n_dst, ne, gpx, tiles, s_res, v_res)
+    if (n_rbf == 10) { if (rb == 2) CGV_GRP_LDS(10, 2); else CGV_GRP_LDS(10, 4); }
+    else             { if (rb == 2) CGV_GRP_LDS(8, 2);  else CGV_GRP_LDS(8, 4); }
+#undef CGV_GRP_LDS
+    return cgv::check_launch("cgv_equi_msg_fwd_grouped");
+  }
   CGV_DISPATCH_RBF(n_rbf, {
     if (rb == 2) { CGV_GRP_PICK(2); } else { CGV_GRP_PICK(4); }
   });

@@ -192,17 +192,17 @@ class EdgePlan:
 
 def receiver_group_size(plan: "EdgePlan") -> int:
     """Receivers per group of the shared-source forward for this plan (0 = plain per-receiver walk).  Dense graphs
-    (>= 16 edges per receiver on average: the atom graphs of every workload) get groups of 4 when that still leaves
-    enough blocks to fill the chip (measured: 2000-atom graph 1187 -> 654 us, dipeptide batch 23 -> 21 us), groups
-    of 2 on small batches (chignolin, 332 atoms: 51 -> 40 us; groups of 4 leave 415 blocks for 256 CUs: 52 us).
-    ``CGV_FWD_GROUP`` = 0 / 2 / 4 overrides (A/B measurements)."""
+    (>= 16 edges per receiver on average: the atom graphs of every workload) get groups of 2: measured against the
+    per-receiver walk 51 -> 42 us (chignolin), 23.4 -> 20.9 us (dipeptide), 1187 -> 613 us (2000 atoms).  Groups of 4
+    gather fewer rows but hold 138 instead of 122 VGPRs (3 instead of 4 waves per SIMD) and halve the block count:
+    48 / 22 / 630 us on the same graphs.  ``CGV_FWD_GROUP`` = 0 / 2 / 4 overrides (A/B: tools/ab_group.sh)."""
     import os
     env = os.environ.get("CGV_FWD_GROUP")
     if env is not None:
         return int(env) if int(env) in (2, 4) else 0
     if plan.n_edges < 16 * max(plan.n_dst, 1) or plan.n_dst < 4:
         return 0
-    return 4 if plan.n_dst >= 600 else 2
+    return 2
 
 
 # ----------------------------------------------------------------------------- K6

@@ -74,7 +74,7 @@ class _EquiMessage(torch.autograd.Function):
             # shared-source walk: groups of plan.group_rb receivers gather every source row once (K2g)
             _lib.call("cgv_equi_msg_fwd_grouped", _lib.ptr(phi), _lib.ptr(v), _lib.ptr(geom.geom_g), _lib.ptr(plan.rowptr_d),
                       _lib.ptr(plan.src_g), _lib.ptr(Wd), _lib.ptr(bd), _lib.ptr(ds), _lib.ptr(dv),
-                      plan.n_dst, F, geom.n_rbf, plan.group_rb, plan.n_src, _lib.ptr(s_res), _lib.ptr(v_res),
+                      plan.n_dst, F, geom.n_rbf, plan.group_rb, plan.n_src, plan.n_edges, _lib.ptr(s_res), _lib.ptr(v_res),
                       _lib.stream_ptr(), tag=tag)
         else:
             _lib.call("cgv_equi_msg_fwd", _lib.ptr(phi), _lib.ptr(v), _lib.ptr(geom.geom_d), _lib.ptr(plan.rowptr_d),

@@ -173,7 +173,7 @@ int cgv_equi_msg_fwd_grouped(const float* phi /*[Ns,3F]*/, const float* v /*[Ns,
                              const int32_t* rowptr_d, const int32_t* src_g,
                              const float* Wd /*[3F,R]*/, const float* bd /*[3F]*/, float* ds /*[Nd,F]*/,
                              float* dv /*[Nd,F,3]*/, int n_dst, int n_feat, int n_rbf, int rb, int64_t n_rows,
-                             const float* s_res /*[Nd,F] or NULL*/, const float* v_res /*[Nd,F,3] or NULL*/,
+                             int64_t n_edges /* records in geom_g */, const float* s_res /*[Nd,F] or NULL*/, const float* v_res /*[Nd,F,3] or NULL*/,
                              void* stream);
 /* Backward.  gs / gv are the upstream gradients at the receivers (gv == NULL when dv is not
  * consumed).  Traverses the src-sorted view; writes g_phi [Ns,3F], g_v [Ns,F,3] (only if gv),

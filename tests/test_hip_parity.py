@@ -960,7 +960,7 @@ def test_shared_source_forward_matches_fp64_and_plain_kernel(F, R, n, box, cut, 
 def test_batch_graph_uses_receiver_groups_on_dense_atom_graphs(monkeypatch):
     batch = cg.synthetic_batch("chignolin", n_frames=1, seed=3, device=DEV)
     g = batch["_graph"]
-    assert g.atom.group_rb == 2 and g.cg.group_rb == 0 and g.a2b.group_rb == 0      # 166 atoms: groups of 2
+    assert g.atom.group_rb == 2 and g.cg.group_rb == 0 and g.a2b.group_rb == 0
     assert g.geometry("atom", 10, 25.0).geom_g is not None
     monkeypatch.setenv("CGV_FWD_GROUP", "0")
     g0 = cg.synthetic_batch("chignolin", n_frames=1, seed=3, device=DEV)["_graph"]
