@@ -9,9 +9,9 @@ from .primitives import (CosineEnvelope, Dense, DistanceEmbed, PainnRadialBasis,
                          shifted_softplus, to_module)
 from .graph import BatchGraph, EdgeGeometry, EdgePlan, get_neighbor_list, make_directed, radius_graph
 from .ops import scatter_add, scatter_mean
-from .blocks import (ContractiveMessageBlock, EquiMessageBlock, EquiMessagePsuedo, InvariantMessage,
+from .blocks import (ContractiveMessageBlock, EquiMessageBlock, EquiMessageCross, EquiMessagePsuedo, InvariantMessage,
                      PseudoUpdateBlock, UpdateBlock, preprocess_r)
-from .model import CGequiVAE, CGprior, EquiEncoder, EquivariantPsuedoDecoder
+from .model import CGequiVAE, CGprior, EquiEncoder, EquivariantDecoder, EquivariantPsuedoDecoder
 from .data import CG_collate, CGDataset, batch_to, prepare_batch, synthetic_batch
 from .train import KL, build_model, loop, loss_terms, train_step
 

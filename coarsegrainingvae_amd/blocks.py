@@ -83,6 +83,39 @@ class EquiMessageBlock(nn.Module):
                                 s_j if residual else None, v_j if residual else None)
 
 
+class EquiMessageCross(nn.Module):
+    """conv.py:343-402 (the message block of ``EquivariantDecoder`` / ``run_pdb.py``).
+    forward(s_j [N,F], v_j [N,F,3], r_ij [E,3], nbrs [E,2]) -> (dh, dv) with FOUR filter slices:
+        dh_i = sum_e m_1          dv_i = sum_e ( m_2 unit_e + m_0 v_j + m_3 (v_i x v_j) ).
+    The receiver's v_i is constant over its edges and the cross product is linear, so
+        sum_e m_3 (v_i x v_j) = v_i x T_i,   T_i = sum_e m_3 v_j,
+    and both reductions are the fused message kernel (K2 / K2g): slices 0-2 as in ``EquiMessageBlock``, slice 3 through
+    the same kernel's ``m_0 v_j`` path with the other two slices zero.  One extra launch and an element-wise cross
+    product instead of a fifth edge kernel; the bead graphs this block runs on are launch-latency bound anyway.
+    (``torch.cross`` without ``dim`` in the reference picks the first size-3 axis: the last one unless E or F is 3.)"""
+
+    def __init__(self, feat_dim, activation, n_rbf, cutoff, dropout):
+        super().__init__()
+        self.inv_message = InvariantMessage(in_feat_dim=feat_dim, out_feat_dim=feat_dim * 4, activation=activation,
+                                            n_rbf=n_rbf, cutoff=cutoff, dropout=dropout)
+
+    def forward(self, s_j, v_j, r_ij, nbrs, edge_wgt=None, plan: Optional[EdgePlan] = None,
+                geom: Optional[EdgeGeometry] = None, residual: bool = False):
+        if edge_wgt is not None:
+            raise NotImplementedError("edge_wgt is always None where the reference calls this block (cgvae.py:182)")
+        im = self.inv_message
+        plan, geom = _resolve(plan, geom, nbrs, s_j.shape[0], r_ij, im.n_rbf, im.cutoff)
+        Wd, bd = im.dist_embed.filter_params()
+        phi = im.node_features(s_j)                                   # [N, 4F]
+        F = s_j.shape[1]
+        dh, dv = ops.equi_message(phi[:, :3 * F], v_j, Wd[:3 * F], bd[:3 * F], plan, geom, True,
+                                  s_j if residual else None, v_j if residual else None)
+        pad_n, pad_w = phi.new_zeros(phi.shape[0], 2 * F), Wd.new_zeros(2 * F, Wd.shape[1])
+        _, T = ops.equi_message(torch.cat([phi[:, 3 * F:], pad_n], dim=1), v_j, torch.cat([Wd[3 * F:], pad_w], dim=0),
+                                torch.cat([bd[3 * F:], bd.new_zeros(2 * F)]), plan, geom, True)
+        return dh, dv + torch.linalg.cross(v_j, T, dim=-1)
+
+
 class ContractiveMessageBlock(nn.Module):
     """conv.py:677-733.  forward(s_i [N,F], v_i [N,F,3], r_iI [N,3], mapping [N]) -> (dS, dV) on beads."""
 

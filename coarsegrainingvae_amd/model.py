@@ -15,7 +15,8 @@ import torch
 from torch import nn
 
 from . import ops
-from .blocks import (ContractiveMessageBlock, EquiMessageBlock, EquiMessagePsuedo, PseudoUpdateBlock, UpdateBlock)
+from .blocks import (ContractiveMessageBlock, EquiMessageBlock, EquiMessageCross, EquiMessagePsuedo, PseudoUpdateBlock,
+                     UpdateBlock)
 from .graph import BatchGraph, EdgePlan, make_directed
 from .primitives import Dense, DistanceEmbed, Linear, MLPHead, mark_direct_grad, to_module
 
@@ -25,6 +26,45 @@ def _call_then_pass(fn):
         fn()
         return grad
     return hook
+
+
+class EquivariantDecoder(nn.Module):
+    """cgvae.py:129-191 (``run_pdb.py:330-333``, ``--dec_type EquivariantDecoder``): per layer one message block
+    (``EquiMessageCross``, or ``EquiMessageBlock`` with ``cross_flag=False``) and one ``UpdateBlock`` on the bead
+    graph, residual adds fused into the kernels' stores.  Same call signature as the pseudo-vector decoder, so it drops
+    into ``CGequiVAE(equivaraintconv=...)``.  (``deg_inv_sqrt``, cgvae.py:173, only feeds a commented-out edge weight.)"""
+
+    def __init__(self, n_atom_basis, n_rbf, cutoff, num_conv, activation, cross_flag=True):
+        super().__init__()
+        block = EquiMessageCross if cross_flag else EquiMessageBlock
+        self.message_blocks = nn.ModuleList(
+            [block(feat_dim=n_atom_basis, activation=activation, n_rbf=n_rbf, cutoff=cutoff, dropout=0.0)
+             for _ in range(num_conv)])
+        self.update_blocks = nn.ModuleList(
+            [UpdateBlock(feat_dim=n_atom_basis, activation=activation, dropout=0.0) for _ in range(num_conv)])
+        self.n_atom_basis = n_atom_basis
+        self.n_rbf, self.cutoff = n_rbf, cutoff
+
+    def forward(self, cg_xyz, CG_nbr_list, mapping, H, graph: Optional[BatchGraph] = None, layer_hooks=None):
+        if graph is not None:
+            nbrs, plan = graph.cg_nbrs, graph.cg
+            geom = graph.geometry("cg", self.n_rbf, self.cutoff)
+            r_ij = None
+        else:
+            nbrs, _ = make_directed(CG_nbr_list)
+            plan = EdgePlan.from_nbrs(nbrs, H.shape[0])
+            r_ij = cg_xyz[nbrs[:, 1]] - cg_xyz[nbrs[:, 0]]
+            from .graph import EdgeGeometry
+            geom = EdgeGeometry(plan, self.n_rbf, self.cutoff, r_edges=r_ij)
+        n, F = H.shape
+        V = torch.zeros(n, F, 3, device=H.device)
+        for layer, (message_block, update_block) in enumerate(zip(self.message_blocks, self.update_blocks)):
+            if layer_hooks and layer in layer_hooks and H.requires_grad:
+                H = H.view_as(H)
+                H.register_hook(_call_then_pass(layer_hooks[layer]))
+            H, V = message_block(H, V, r_ij, nbrs, plan=plan, geom=geom, residual=True)     # H += dH, V += dV
+            H, V = update_block(H, V, residual=True)                                        # cgvae.py:186-189
+        return H, V
 
 
 class EquivariantPsuedoDecoder(nn.Module):

@@ -229,6 +229,43 @@ def _cross(a: Tensor, b: Tensor) -> Tensor:
     return torch.linalg.cross(a, b, dim=dim)
 
 
+def equi_message_cross(s, v, r_ij, nbrs, P, prefix, act, n_rbf, cutoff):
+    """conv.py:361-402 (EquiMessageCross.forward, edge_wgt=None): four filter slices, the fourth drives the cross
+    product of the receiver's and the source's vector channels."""
+    dist, unit = preprocess_r(r_ij)
+    out = invariant_message(s, dist, nbrs, P, prefix + ".inv_message", act, n_rbf, cutoff)
+    n, F = s.shape[0], s.shape[-1]
+    out = out.reshape(out.shape[0], 4, F)                                          # conv.py:372
+    m0 = out[:, 0, :].unsqueeze(-1)
+    m1 = out[:, 1, :]
+    m2 = out[:, 2, :].unsqueeze(-1)
+    m3 = out[:, 3, :].unsqueeze(-1)
+    dv_ij = m2 * unit.unsqueeze(1) + m0 * v[nbrs[:, 1]] + m3 * _cross(v[nbrs[:, 0]], v[nbrs[:, 1]])   # conv.py:379-380
+    dv = scatter_add(dv_ij * 1, nbrs[:, 0], 0, n)                                  # conv.py:392-395
+    dh = scatter_add(m1 * 1, nbrs[:, 0], 0, n)                                     # conv.py:397-400
+    return dh, dv
+
+
+def equivariant_decoder_forward(cg_xyz, cg_nbr_list, H, P, n_conv, n_rbf, cutoff, act=None, cross_flag=True,
+                                prefix="equivaraintconv"):
+    """cgvae.py:165-191 (EquivariantDecoder.forward): message block (EquiMessageCross, or EquiMessageBlock when
+    cross_flag is False) then UpdateBlock per layer, residual adds; ``mapping`` is unused there (deg_inv_sqrt,
+    cgvae.py:173, feeds only a commented-out edge weight)."""
+    act = act or swish
+    cg_nbr_list, _ = make_directed(cg_nbr_list)
+    r_ij = cg_xyz[cg_nbr_list[:, 1]] - cg_xyz[cg_nbr_list[:, 0]]
+    V = torch.zeros(H.shape[0], H.shape[1], 3)
+    message = equi_message_cross if cross_flag else equi_message_block
+    for k in range(n_conv):
+        dH, dV = message(H, V, r_ij, cg_nbr_list, P, f"{prefix}.message_blocks.{k}", act, n_rbf, cutoff)
+        H = H + dH
+        V = V + dV
+        dH_u, dV_u = update_block(H, V, P, f"{prefix}.update_blocks.{k}", act)
+        H = H + dH_u
+        V = V + dV_u
+    return H, V
+
+
 def update_block(s, v, P, prefix, act):
     """conv.py:588-616 (UpdateBlock.forward)."""
     n, F = s.shape

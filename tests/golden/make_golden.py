@@ -375,15 +375,65 @@ def g7_init(cgvae):
     save("g7_init", **arrays)
 
 
+# ------------------------------------------------------------------ G8: EquiMessageCross / EquivariantDecoder
+def g8_cross(conv, cgvae):
+    for F, R, tag in ((8, 8, "F8R8"), (24, 10, "F24R10")):
+        gen = torch.Generator().manual_seed(2000 + F)
+        N, cutoff = 17, 6.0                        # neither E nor F equals 3: torch.cross (no dim) takes the last axis
+        xyz = torch.rand(N, 3, generator=gen) * 5.0
+        und = random_graph(N, 0.4, gen)
+        nbrs, _ = conv.make_directed(und)
+        r_ij = xyz[nbrs[:, 1]] - xyz[nbrs[:, 0]]
+        # --- EquiMessageCross (conv.py:343-402)
+        torch.manual_seed(17)
+        blk = conv.EquiMessageCross(feat_dim=F, activation="swish", n_rbf=R, cutoff=cutoff, dropout=0.0)
+        for p in blk.parameters():
+            if p.dim() == 1:
+                p.data.normal_(0, 0.3)
+        s = torch.randn(N, F, generator=gen, requires_grad=True)
+        v = torch.randn(N, F, 3, generator=gen, requires_grad=True)
+        dh, dv = blk(s, v, r_ij, nbrs)
+        gs = torch.randn(dh.shape, generator=gen)
+        gv = torch.randn(dv.shape, generator=gen)
+        (dh * gs).sum().add((dv * gv).sum()).backward()
+        save(f"g8_equi_cross_{tag}", s=s, v=v, r_ij=r_ij, nbrs=nbrs, cutoff=cutoff, R=R, dh=dh, dv=dv,
+             gout_s=gs, gout_v=gv, gin_s=s.grad, gin_v=v.grad, **params_of(blk), **grads_of(blk))
+    # --- EquivariantDecoder (cgvae.py:129-191), both message flavours
+    for cross in (True, False):
+        F, R, cutoff, n_conv = 24, 10, 9.5, 3
+        gen = torch.Generator().manual_seed(2100 + int(cross))
+        n_cg = 12
+        cg_xyz = torch.rand(n_cg, 3, generator=gen) * 6.0
+        und = random_graph(n_cg, 0.6, gen)
+        torch.manual_seed(19)
+        dec = cgvae.EquivariantDecoder(n_atom_basis=F, n_rbf=R, cutoff=cutoff, num_conv=n_conv, activation="swish",
+                                       cross_flag=cross)
+        for p in dec.parameters():
+            if p.dim() == 1:
+                p.data.normal_(0, 0.2)
+        H = torch.randn(n_cg, F, generator=gen, requires_grad=True)
+        mapping = torch.arange(n_cg)
+        S, V = dec(cg_xyz, und, mapping, H)
+        gS = torch.randn(S.shape, generator=gen)
+        gV = torch.randn(V.shape, generator=gen)
+        (S * gS).sum().add((V * gV).sum()).backward()
+        save(f"g8_equivariant_decoder_{'cross' if cross else 'plain'}", cg_xyz=cg_xyz, nbrs=und, H=H, S=S, V=V, gout_S=gS,
+             gout_V=gV, gin_H=H.grad, cutoff=cutoff, R=R, n_conv=n_conv, **params_of(dec), **grads_of(dec))
+
+
 def main():
     modules, conv, cgvae, data = load_reference()
     torch.set_num_threads(1)          # bit-stable sums
+    if len(sys.argv) > 1 and sys.argv[1] == "g8":     # only the G8 set (leaves the other files untouched)
+        g8_cross(conv, cgvae)
+        return
     g1_blocks(modules, conv)
     g2_model(cgvae, data)
     g3_radius(data)
     g4_make_directed(conv)
     g5_scatter()
     g7_init(cgvae)
+    g8_cross(conv, cgvae)
 
 
 if __name__ == "__main__":

@@ -965,3 +965,71 @@ def test_batch_graph_uses_receiver_groups_on_dense_atom_graphs(monkeypatch):
     monkeypatch.setenv("CGV_FWD_GROUP", "0")
     g0 = cg.synthetic_batch("chignolin", n_frames=1, seed=3, device=DEV)["_graph"]
     assert g0.atom.group_rb == 0 and g0.geometry("atom", 10, 25.0).geom_g is None
+
+
+# --------------------------------------------------------------------------- EquiMessageCross / EquivariantDecoder
+@pytest.mark.parametrize("tag", ["F8R8", "F24R10"])
+def test_equi_message_cross_golden(tag):
+    g = load_golden(f"g8_equi_cross_{tag}")
+    F, R = g["s"].shape[1], int(g["R"])
+    blk = load_block(cg.EquiMessageCross(F, "swish", R, float(g["cutoff"]), 0.0), g)
+    s, v = dev(g["s"]).requires_grad_(True), dev(g["v"]).requires_grad_(True)
+    dh, dv = blk(s, v, dev(g["r_ij"]), dev(g["nbrs"]))
+    assert_close(dh, g["dh"], "dh")
+    assert_close(dv, g["dv"], "dv")
+    ((dh * dev(g["gout_s"])).sum() + (dv * dev(g["gout_v"])).sum()).backward()
+    assert_close(s.grad, g["gin_s"], "grad s")
+    assert_close(v.grad, g["gin_v"], "grad v")
+    check_param_grads(blk, g)
+
+
+@pytest.mark.parametrize("flavour", ["cross", "plain"])
+def test_equivariant_decoder_golden(flavour):
+    g = load_golden(f"g8_equivariant_decoder_{flavour}")
+    F, R = g["H"].shape[1], int(g["R"])
+    dec = load_block(cg.EquivariantDecoder(F, R, float(g["cutoff"]), int(g["n_conv"]), "swish", cross_flag=(flavour == "cross")), g)
+    H = dev(g["H"]).requires_grad_(True)
+    n = H.shape[0]
+    S, V = dec(dev(g["cg_xyz"]), dev(g["nbrs"]), torch.arange(n, device=DEV), H)
+    assert_close(S, g["S"], "S")
+    assert_close(V, g["V"], "V")
+    ((S * dev(g["gout_S"])).sum() + (V * dev(g["gout_V"])).sum()).backward()
+    assert_close(H.grad, g["gin_H"], "grad H")
+    check_param_grads(dec, g)
+
+
+def test_cgvae_trains_with_the_equivariant_decoder():
+    """``CGequiVAE(equivaraintconv=EquivariantDecoder(...))`` (run_pdb.py:330-345): forward equals the oracle's
+    composition of the same blocks, and the trainer steps it (arena, fused optimiser, captured graph)."""
+    from coarsegrainingvae_amd.trainer import Trainer
+    w = cg.data.WORKLOADS["dipeptide"]
+    F, R = 64, w["n_rbf"]
+    torch.manual_seed(123)
+    enc = cg.EquiEncoder(n_conv=2, n_atom_basis=F, n_rbf=R, activation="swish", cutoff=w["cg_cutoff"], dir_mp=False, cg_mp=False)
+    dec = cg.EquivariantDecoder(n_atom_basis=F, n_rbf=R, cutoff=w["atom_cutoff"], num_conv=2, activation="swish")
+    prior = cg.CGprior(n_conv=2, n_atom_basis=F, n_rbf=R, activation="swish", cutoff=w["cg_cutoff"], dir_mp=False)
+    mu = torch.nn.Sequential(torch.nn.Linear(F, F), torch.nn.ReLU(), torch.nn.Linear(F, F))
+    sg = torch.nn.Sequential(torch.nn.Linear(F, F), torch.nn.ReLU(), torch.nn.Linear(F, F))
+    model = cg.CGequiVAE(enc, dec, mu, sg, w["n_cgs"], F, prior_net=prior, det=True).to(DEV)
+    batch = cg.synthetic_batch("dipeptide", n_frames=4, seed=2, device=DEV)
+    # decoder parity against the oracle on the model's own latent (no autograd graph may outlive this block: its
+    # AccumulateGrad nodes would be pinned to this stream and the trainer captures on another one)
+    with torch.no_grad():
+        out = model(batch)
+        assert len(out) == 6 and out[5].shape == batch["nxyz"][:, 1:].shape
+        P = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        g = batch["_graph"]
+        Hlat = model.encoder(batch["nxyz"][:, 0], batch["nxyz"][:, 1:], batch["CG_nxyz"][:, 1:], batch["CG_mapping"],
+                             batch["nbr_list"], batch["CG_nbr_list"], graph=g)[0].cpu()
+        S0, V0 = O.equivariant_decoder_forward(batch["CG_nxyz"][:, 1:].cpu(), batch["CG_nbr_list"].cpu(), Hlat, P, 2, R,
+                                               w["atom_cutoff"])
+        S1, V1 = model.equivaraintconv(batch["CG_nxyz"][:, 1:], batch["CG_nbr_list"], batch["CG_mapping"], Hlat.to(DEV),
+                                       graph=g)
+        assert_close(S1, S0, "decoder S")
+        assert_close(V1, V0, "decoder V")
+    del out, S1, V1
+    tr = Trainer(model, lr=1e-3, beta=w["beta"], gamma=w["gamma"])
+    losses = [float(tr.step(batch)) for _ in range(3)]
+    tr.capture(batch, warmup=0)
+    losses += [float(tr.step(batch)) for _ in range(3)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses

@@ -214,3 +214,43 @@ def test_init_stream_and_state_dict_layout(tag):
     abss = np.array([float(v.double().abs().sum()) for v in P.values()])
     np.testing.assert_allclose(sums, g[f"{tag}.sum"], rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(abss, g[f"{tag}.abssum"], rtol=1e-9, atol=1e-9)
+
+
+# ------------------------------------------------------------------ G8: EquiMessageCross / EquivariantDecoder
+@pytest.mark.parametrize("tag", TAGS)
+def test_equi_message_cross(tag):
+    g = load_golden(f"g8_equi_cross_{tag}")
+    P = {"blk." + k: v for k, v in P_of(g).items()}
+    s = t(g["s"]).requires_grad_(True)
+    v = t(g["v"]).requires_grad_(True)
+    dh, dv = O.equi_message_cross(s, v, t(g["r_ij"]), t(g["nbrs"]), P, "blk", O.swish, int(g["R"]), float(g["cutoff"]))
+    close(dh, g["dh"])
+    close(dv, g["dv"])
+    ((dh * t(g["gout_s"])).sum() + (dv * t(g["gout_v"])).sum()).backward()
+    close(s.grad, g["gin_s"], rtol=1e-5, atol=1e-6)
+    close(v.grad, g["gin_v"], rtol=1e-5, atol=1e-6)
+    for k, p in P.items():
+        ref = g["g." + k[len("blk."):]]
+        if ref.size == 0:
+            assert p.grad is None, k
+        else:
+            close(p.grad, ref, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("flavour", ["cross", "plain"])
+def test_equivariant_decoder(flavour):
+    g = load_golden(f"g8_equivariant_decoder_{flavour}")
+    P = {"dec." + k: v for k, v in P_of(g).items()}
+    H = t(g["H"]).requires_grad_(True)
+    S, V = O.equivariant_decoder_forward(t(g["cg_xyz"]), t(g["nbrs"]), H, P, int(g["n_conv"]), int(g["R"]),
+                                         float(g["cutoff"]), cross_flag=(flavour == "cross"), prefix="dec")
+    close(S, g["S"], rtol=1e-5, atol=1e-5)
+    close(V, g["V"], rtol=1e-5, atol=1e-5)
+    ((S * t(g["gout_S"])).sum() + (V * t(g["gout_V"])).sum()).backward()
+    close(H.grad, g["gin_H"], rtol=1e-4, atol=1e-4)
+    for k, p in P.items():
+        ref = g["g." + k[len("dec."):]]
+        if ref.size == 0:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+        else:
+            close(p.grad, ref, rtol=1e-4, atol=1e-4)
