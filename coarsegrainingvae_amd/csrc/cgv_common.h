@@ -71,14 +71,17 @@ __device__ inline void st3(float* p, float x, float y, float z) {
 
 // Activations of the Dense / nn.Linear kernels (fused into epilogues and operand loads):
 //   0 identity   1 Swish x*sigmoid(x) (modules.py:16-21)   2 tanh   3 ReLU   (nn.Tanh / nn.ReLU of the mu / sigma heads)
+//   4  1e-12 + exp(z/2)   (sigma of the encoder head, cgvae.py:503)      5  1e-9 + exp(z/2)   (prior std, cgvae.py:401)
 // act_bwd is the derivative as a function of the PRE-activation z.
-constexpr int CGV_ACT_MAX = 3;
+constexpr int CGV_ACT_MAX = 5;
 __device__ __forceinline__ float act_sigmoid(float z) { return 1.0f / (1.0f + expf(-z)); }
 __device__ __forceinline__ float act_fwd(float z, int act) {
   switch (act) {
     case 1: return z * act_sigmoid(z);
     case 2: return tanhf(z);
     case 3: return z > 0.f ? z : 0.f;
+    case 4: return 1e-12f + expf(z / 2.0f);
+    case 5: return 1e-9f + expf(z / 2.0f);
     default: return z;
   }
 }
@@ -87,6 +90,8 @@ __device__ __forceinline__ float act_bwd(float z, int act) {
     case 1: { const float s = act_sigmoid(z); return s * (1.0f + z * (1.0f - s)); }
     case 2: { const float t = tanhf(z); return 1.0f - t * t; }
     case 3: return z > 0.f ? 1.0f : 0.f;
+    case 4:
+    case 5: return 0.5f * expf(z / 2.0f);
     default: return 1.0f;
   }
 }

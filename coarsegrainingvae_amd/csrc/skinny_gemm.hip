@@ -561,7 +561,7 @@ int cgv_skinny_supported(int M, int N, int K) {
 int cgv_skinny_linear_fwd(const float* x, const float* W, const float* bias, float* y, float* z, int M, int N, int K,
                           int act, void* stream) {
   CGV_REQUIRE(x && W && y, "null pointer");
-  CGV_REQUIRE(act >= 0 && act <= cgv::CGV_ACT_MAX, "act must be 0 (identity), 1 (swish), 2 (tanh) or 3 (relu)");
+  CGV_REQUIRE(act >= 0 && act <= cgv::CGV_ACT_MAX, "act must be 0 (identity), 1 (swish), 2 (tanh), 3 (relu), 4 / 5 (c + exp(z/2))");
   CGV_REQUIRE(cgv_skinny_supported(M, N, K), "unsupported shape (need M <= 64, N % 4 == 0, K % 4 == 0)");
   CGV_REQUIRE(((((uintptr_t)x | (uintptr_t)W | (uintptr_t)y | (uintptr_t)bias | (uintptr_t)z)) & 15) == 0,
               "operands must be 16-byte aligned");

@@ -269,7 +269,7 @@ int cgv_tile_supported(int M, int N, int K) {
 int cgv_tile_linear_fwd(const float* x, const float* W, const float* bias, float* y, float* z, int M, int N, int K, int act,
                         void* stream) {
   CGV_REQUIRE(x && W && y, "null pointer");
-  CGV_REQUIRE(act >= 0 && act <= cgv::CGV_ACT_MAX, "act must be 0 (identity), 1 (swish), 2 (tanh) or 3 (relu)");
+  CGV_REQUIRE(act >= 0 && act <= cgv::CGV_ACT_MAX, "act must be 0 (identity), 1 (swish), 2 (tanh), 3 (relu), 4 / 5 (c + exp(z/2))");
   CGV_REQUIRE(cgv_tile_supported(M, N, K), "unsupported shape (need N % 4 == 0, K % 4 == 0)");
   CGV_REQUIRE(((((uintptr_t)x | (uintptr_t)W)) & 15) == 0, "x and W must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;

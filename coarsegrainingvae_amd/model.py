@@ -18,7 +18,7 @@ from . import ops
 from .blocks import (ContractiveMessageBlock, EquiMessageBlock, EquiMessageCross, EquiMessagePsuedo, PseudoUpdateBlock,
                      UpdateBlock)
 from .graph import BatchGraph, EdgePlan, make_directed
-from .primitives import Dense, DistanceEmbed, Linear, MLPHead, mark_direct_grad, to_module
+from .primitives import ACT_STD_ENC, ACT_STD_PRIOR, Dense, DistanceEmbed, Linear, MLPHead, mark_direct_grad, to_module
 
 
 def _call_then_pass(fn):
@@ -26,6 +26,19 @@ def _call_then_pass(fn):
         fn()
         return grad
     return hook
+
+
+_CONSTANTS = {}
+
+
+def _constant(shape, value: float, device) -> torch.Tensor:
+    """Read-only initial state (V0 = 0, Sbar0 = 0 / 1, ...): the kernels never write their inputs, so one cached tensor
+    per (shape, value, device) replaces a fill launch per use and step."""
+    key = (tuple(shape), float(value), str(device))
+    t = _CONSTANTS.get(key)
+    if t is None:
+        t = _CONSTANTS[key] = torch.full(tuple(shape), float(value), dtype=torch.float32, device=device)
+    return t
 
 
 class EquivariantDecoder(nn.Module):
@@ -57,7 +70,7 @@ class EquivariantDecoder(nn.Module):
             from .graph import EdgeGeometry
             geom = EdgeGeometry(plan, self.n_rbf, self.cutoff, r_edges=r_ij)
         n, F = H.shape
-        V = torch.zeros(n, F, 3, device=H.device)
+        V = _constant((n, F, 3), 0.0, H.device)
         for layer, (message_block, update_block) in enumerate(zip(self.message_blocks, self.update_blocks)):
             if layer_hooks and layer in layer_hooks and H.requires_grad:
                 H = H.view_as(H)
@@ -97,9 +110,9 @@ class EquivariantPsuedoDecoder(nn.Module):
             r_ij = cg_xyz[nbrs[:, 1]] - cg_xyz[nbrs[:, 0]]
             geom = None
         n, F = S.shape
-        V = torch.zeros(n, F, 3, device=S.device)
-        Sbar = torch.ones(n, F, device=S.device) if self.breaksym else torch.zeros(n, F, device=S.device)
-        Vbar = torch.zeros(n, F, 3, device=S.device)
+        V = _constant((n, F, 3), 0.0, S.device)
+        Sbar = _constant((n, F), 1.0 if self.breaksym else 0.0, S.device)
+        Vbar = V
         for layer, (message_block, update_block) in enumerate(zip(self.message_blocks, self.update_blocks)):
             if layer_hooks and layer in layer_hooks and S.requires_grad:
                 S = S.view_as(S)                              # private node: its hook sees the total gradient of S
@@ -157,7 +170,7 @@ class EquiEncoder(nn.Module):
         geom = graph.geometry("atom", self.n_rbf, self.cutoff)
         geom_c = graph.geometry("a2b", self.n_rbf, 20.0)
         h = ops.embedding(self.atom_embed, z, graph.embed_plan("atom", z, self.atom_embed) if graph is not None else None)
-        v = torch.zeros(h.shape[0], h.shape[1], 3, device=h.device)
+        v = _constant((h.shape[0], h.shape[1], 3), 0.0, h.device)
         H = V = None
         for i in range(self.n_conv):
             # h += ds, v += dv (cgvae.py:287-288) and H += dH, V += dV (cgvae.py:309-310) fused into the kernels
@@ -202,11 +215,14 @@ class CGprior(nn.Module):
             plan = EdgePlan.from_nbrs(nbrs, cg_xyz.shape[0])
             geom = EdgeGeometry(plan, self.n_rbf, self.cutoff, pos_dst=cg_xyz, pos_src=cg_xyz)
         h = ops.embedding(self.atom_embed, cg_z, graph.embed_plan("cg", cg_z, self.atom_embed) if graph is not None else None)
-        v = torch.zeros(h.shape[0], h.shape[1], 3, device=h.device)
+        v = _constant((h.shape[0], h.shape[1], 3), 0.0, h.device)
         for blk in self.message_blocks:
             h, v = blk(h, v, None, nbrs, plan=plan, geom=geom, residual=True)      # h += ds, v += dv fused (cgvae.py:391-392)
         H_mu = self.mu(h)
-        H_std = 1e-9 + torch.exp(self.sigma(h) / 2)
+        if isinstance(self.sigma, MLPHead):
+            H_std = self.sigma(h, out_act=ACT_STD_PRIOR)              # 1e-9 + exp(. / 2) in the product's epilogue (cgvae.py:401)
+        else:
+            H_std = 1e-9 + torch.exp(self.sigma(h) / 2)
         return H_mu, H_std
 
 
@@ -321,8 +337,10 @@ class CGequiVAE(nn.Module):
         else:
             H_prior_mu, H_prior_sigma = None, None
         mu = self.atom_munet(S_I)
-        logvar = self.atom_sigmanet(S_I)
-        sigma = 1e-12 + torch.exp(logvar / 2)
+        if isinstance(self.atom_sigmanet, MLPHead):
+            sigma = self.atom_sigmanet(S_I, out_act=ACT_STD_ENC)      # 1e-12 + exp(logvar / 2) fused (cgvae.py:502-503)
+        else:
+            sigma = 1e-12 + torch.exp(self.atom_sigmanet(S_I) / 2)
         z_sample = S_I if self.det else self.reparametrize(mu, sigma, eps)
         layer_hooks = None
         if self.bucket_done is not None and z_sample.requires_grad:

@@ -63,6 +63,8 @@ def _gemm_mode(x2, weight, bias):
 
 
 ACT_NONE, ACT_SWISH, ACT_TANH, ACT_RELU = 0, 1, 2, 3      # cgv_common.h: act_fwd / act_bwd
+ACT_STD_ENC, ACT_STD_PRIOR = 4, 5                         # 1e-12 + exp(z/2) (cgvae.py:503), 1e-9 + exp(z/2) (cgvae.py:401)
+_STD_EPS = {ACT_STD_ENC: 1e-12, ACT_STD_PRIOR: 1e-9}
 
 
 class WeightGradQueue:
@@ -214,6 +216,8 @@ class _LinearFn(torch.autograd.Function):
         z = Fn.linear(x, weight, bias)
         if act != ACT_NONE:
             ctx.save_for_backward(x, weight, z)
+            if act in _STD_EPS:
+                return _STD_EPS[act] + torch.exp(z / 2)
             return {ACT_SWISH: Fn.silu, ACT_TANH: torch.tanh, ACT_RELU: torch.relu}[act](z)
         ctx.save_for_backward(x, weight, None)
         return z
@@ -233,6 +237,8 @@ class _LinearFn(torch.autograd.Function):
                 gy = gy * (1 - torch.tanh(z) ** 2)
             elif act == ACT_RELU:
                 gy = gy * (z > 0).to(gy.dtype)
+            elif act in _STD_EPS:
+                gy = gy * (0.5 * torch.exp(z / 2))
             x2, gy2 = x.reshape(-1, x.shape[-1]), gy.reshape(-1, gy.shape[-1])
             gx = gy.matmul(weight) if need_x else None
             gw = _direct_grad(w_param, lambda out: torch.mm(gy2.t(), x2, out=out), lambda: gy2.t().mm(x2)) if need_w else None
@@ -346,13 +352,16 @@ class MLPHead(nn.Sequential):
     product's epilogue and into its backward (no tanh / relu / their-backward launches)."""
     _CODES = {nn.Tanh: ACT_TANH, nn.ReLU: ACT_RELU, Swish: ACT_SWISH}
 
-    def forward(self, x):
+    def forward(self, x, out_act: int = ACT_NONE):
+        """``out_act``: activation fused into the LAST product's epilogue and backward -- the ``c + exp(z/2)`` of the
+        sigma / prior-std heads (ACT_STD_ENC / ACT_STD_PRIOR), which as tensor ops cost six launches per head and step."""
         mods = list(self)
         if (len(mods) == 3 and isinstance(mods[0], nn.Linear) and type(mods[1]) in self._CODES
                 and isinstance(mods[2], nn.Linear) and x.is_cuda):
             y = _LinearFn.apply(x, mods[0].weight, mods[0].bias, self._CODES[type(mods[1])])
-            return mods[2](y)
-        return super().forward(x)
+            return _LinearFn.apply(y, mods[2].weight, mods[2].bias, out_act)
+        y = super().forward(x)
+        return y if out_act == ACT_NONE else _STD_EPS[out_act] + torch.exp(y / 2)
 
 
 class Dense(nn.Linear):

@@ -241,7 +241,8 @@ int cgv_update_gate_bwd(const float* U, const float* Vv, const float* a, const f
  * Skinny fp32 GEMMs for the node-level Dense / nn.Linear layers on the bead graph
  * (modules.py:103-114, Swish modules.py:16-21, and their autograd backward): M <=
  * cgv_skinny_max_rows() rows, weight W[N,K] row-major as torch stores it, N % 4 == 0,
- * K % 4 == 0, 16-byte aligned operands.  act: 0 = identity, 1 = Swish, 2 = tanh, 3 = ReLU (nn.Tanh / nn.ReLU of the mu / sigma heads).
+ * K % 4 == 0, 16-byte aligned operands.  act: 0 = identity, 1 = Swish, 2 = tanh, 3 = ReLU (nn.Tanh / nn.ReLU of the mu / sigma heads),
+ * 4 = 1e-12 + exp(z/2) (sigma head, cgvae.py:503), 5 = 1e-9 + exp(z/2) (prior std, cgvae.py:401).
  *   fwd        z = x W^T + bias ; y = act(z)      (bias may be NULL; z [M,N] is written when act != 0)
  *   bwd_input  gx[M,K] = (gy * act'(z)) W         (deterministic).  With a workspace of
  *              cgv_skinny_bwd_input_workspace_bytes bytes (contents ignored) the weight rows are
