@@ -12,7 +12,8 @@ from .ops import scatter_add, scatter_mean
 from .blocks import (ContractiveMessageBlock, EquiMessageBlock, EquiMessageCross, EquiMessagePsuedo, InvariantMessage,
                      PseudoUpdateBlock, UpdateBlock, preprocess_r)
 from .model import CGequiVAE, CGprior, EquiEncoder, EquivariantDecoder, EquivariantPsuedoDecoder
-from .data import CG_collate, CGDataset, batch_to, prepare_batch, synthetic_batch
+from .data import (CG_collate, CGDataset, batch_to, build_dataset, get_high_order_edge, get_higher_order_adj_matrix,
+                   prepare_batch, random_rotation_matrices, synthetic_batch)
 from .train import KL, build_model, loop, loss_terms, train_step
 
 __version__ = "0.1.0"

@@ -130,7 +130,7 @@ def _batched_radius(nxyz_list, cutoff, device, undirected):
     xyz = torch.cat([t[:, 1:4] for t in nxyz_list], dim=0).float().to(device)
     nbrs = radius_graph(xyz, fp.to(device), cutoff, undirected).cpu()
     # split by frame (rows are sorted by i, hence by frame) and make ids frame-local
-    frame_of = torch.bucketize(nbrs[:, 0], fp[1:].long(), right=True)
+    frame_of = torch.bucketize(nbrs[:, 0].contiguous(), fp[1:].long(), right=True)
     counts = torch.bincount(frame_of, minlength=len(sizes)).tolist()
     out, start = [], 0
     for k, c in enumerate(counts):
@@ -148,6 +148,88 @@ def _bond_cg_graph(bond, mapping, n_atoms, n_cgs):
     assign[torch.arange(n_atoms), mapping] = 1
     cg = (assign.t() @ adj @ assign).nonzero()
     return cg[cg[:, 0] != cg[:, 1]]
+
+
+# ----------------------------------------------------------------------------- dataset build (datasets.py:459-506)
+def binarize(x):
+    return torch.where(x > 0, torch.ones_like(x), torch.zeros_like(x))          # data.py:22-23
+
+
+def get_higher_order_adj_matrix(adj, order):
+    """data.py:25-40: entry (i, j) = shortest-path length between i and j if it is <= order, else 0."""
+    eye = torch.eye(adj.size(0), dtype=torch.long, device=adj.device)
+    mats = [eye, binarize(adj + eye)]
+    for i in range(2, order + 1):
+        mats.append(binarize(mats[i - 1] @ mats[1]))
+    order_mat = torch.zeros_like(adj)
+    for i in range(1, order + 1):
+        order_mat += (mats[i] - mats[i - 1]) * i
+    return order_mat
+
+
+def get_high_order_edge(edges, order, natoms):
+    """datasets.py:449-458: pairs (i < j) within ``order`` bonds of each other, row-major."""
+    adj = torch.zeros(natoms, natoms)
+    adj[edges[:, 0], edges[:, 1]] = 1
+    adj[edges[:, 1], edges[:, 0]] = 1
+    return torch.triu(get_higher_order_adj_matrix(adj, order=order)).nonzero()
+
+
+def random_rotation_matrices(n: int, generator=None, device="cpu") -> torch.Tensor:
+    """[n,3,3] rotations drawn like datasets.py:65-71 (``random_rotation``): axis = a normalised standard-normal
+    vector, angle = a whole number of degrees in [-180, 180), rotation about the origin (Rodrigues' formula, what
+    ``ase.Atoms.rotate`` applies).  The reference draws from numpy's / python's global generators; here a torch
+    generator, so a seed reproduces the augmentation -- the streams cannot be made identical."""
+    vec = torch.randn(n, 3, generator=generator, dtype=torch.float64)
+    k = vec / vec.norm(dim=1, keepdim=True)
+    ang = torch.randint(-180, 180, (n,), generator=generator).double() * (np.pi / 180.0)
+    K = torch.zeros(n, 3, 3, dtype=torch.float64)
+    K[:, 0, 1], K[:, 0, 2], K[:, 1, 0] = -k[:, 2], k[:, 1], k[:, 2]
+    K[:, 1, 2], K[:, 2, 0], K[:, 2, 1] = -k[:, 0], -k[:, 1], k[:, 0]
+    s, c = torch.sin(ang)[:, None, None], torch.cos(ang)[:, None, None]
+    R = torch.eye(3, dtype=torch.float64)[None] + s * K + (1 - c) * (K @ K)
+    return R.float().to(device)
+
+
+def build_dataset(mapping, traj, atom_cutoff, cg_cutoff, atomic_nums, bond_edges, order=1, cg_traj=None, rotate=True,
+                  generator=None, device="cuda") -> CGDataset:
+    """datasets.py:459-506 for a whole trajectory at once, on the device: per-frame random rotation (one batched
+    matrix product instead of an ``ase.Atoms`` object per frame), bead coordinates = ``scatter_mean`` of the atoms over
+    ``mapping`` (ONE segment reduction over all frames: K1) unless ``cg_traj`` is given, higher-order bond edges, and
+    the per-frame dict format of ``CGDataset``.  ``bond_edges`` [Eb,2] stands for the mdtraj topology's bond graph
+    (datasets.py:470-472; mdtraj is not a dependency here).  Like the reference, no neighbour lists are generated
+    (datasets.py:504): call ``generate_neighbor_list`` -- one batched radius-graph launch per graph kind (K0)."""
+    from .ops import scatter_mean
+    traj = torch.as_tensor(np.asarray(traj), dtype=torch.float32)
+    if traj.dim() != 3 or traj.shape[2] != 3:
+        raise ValueError("traj must be [frames, atoms, 3]")
+    T, n = traj.shape[0], traj.shape[1]
+    mapping = torch.as_tensor(mapping).long()
+    z = torch.as_tensor(np.asarray(atomic_nums), dtype=torch.float32)
+    if mapping.shape[0] != n or z.shape[0] != n:
+        raise ValueError("mapping / atomic_nums do not match the number of atoms")
+    n_cgs = int(mapping.max()) + 1
+    edges = get_high_order_edge(torch.as_tensor(bond_edges).long(), order, n)
+    xyz = traj.to(device)
+    if rotate:
+        R = random_rotation_matrices(T, generator, device)
+        xyz = torch.bmm(xyz, R.transpose(1, 2))                          # row vectors: x' = R x
+    if cg_traj is not None:
+        cg = torch.as_tensor(np.asarray(cg_traj), dtype=torch.float32).to(device)
+    else:
+        index = (mapping.to(device)[None, :] + n_cgs * torch.arange(T, device=device)[:, None]).reshape(-1)
+        cg = scatter_mean(xyz.reshape(T * n, 3).contiguous(), index, dim=0, dim_size=T * n_cgs).reshape(T, n_cgs, 3)
+    xyz_h, cg_h = xyz.cpu(), cg.cpu()
+    bead_id = torch.arange(cg_h.shape[1]).float()[:, None]
+    props = {
+        "nxyz": [torch.cat([z[:, None], xyz_h[t]], dim=-1) for t in range(T)],
+        "CG_nxyz": [torch.cat([bead_id, cg_h[t]], dim=-1) for t in range(T)],
+        "num_atoms": [torch.LongTensor([n]) for _ in range(T)],
+        "num_CGs": [torch.LongTensor([cg_h.shape[1]]) for _ in range(T)],
+        "CG_mapping": [mapping for _ in range(T)],
+        "bond_edge_list": [edges for _ in range(T)],
+    }
+    return CGDataset(props)
 
 
 # ----------------------------------------------------------------------------- synthetic data

@@ -421,11 +421,37 @@ def g8_cross(conv, cgvae):
              gout_V=gV, gin_H=H.grad, cutoff=cutoff, R=R, n_conv=n_conv, **params_of(dec), **grads_of(dec))
 
 
+# ------------------------------------------------------------------ G9: higher-order bond edges (dataset path)
+def g9_high_order_edges(data):
+    """datasets.py:449-458 (get_high_order_edge) is four lines around data.get_higher_order_adj_matrix (data.py:25-40);
+    datasets.py itself cannot be imported here (mdtraj ...), so those four lines are applied to the reference's own
+    adjacency-power function."""
+    out = {}
+    gen = torch.Generator().manual_seed(9)
+    for case, (n, extra) in enumerate(((6, 0), (22, 3), (40, 6))):
+        chain = torch.stack([torch.arange(n - 1), torch.arange(1, n)], dim=1)
+        more = torch.randint(0, n, (extra, 2), generator=gen)
+        more = more[more[:, 0] != more[:, 1]]
+        edges = torch.cat([chain, more])
+        out[f"c{case}_edges"] = edges
+        out[f"c{case}_n"] = n
+        for order in (1, 2, 3):
+            adj = torch.zeros(n, n)
+            adj[edges[:, 0], edges[:, 1]] = 1
+            adj[edges[:, 1], edges[:, 0]] = 1
+            hi = torch.triu(data.get_higher_order_adj_matrix(adj, order=order)).nonzero()
+            out[f"c{case}_order{order}"] = hi
+    save("g9_high_order_edges", **out)
+
+
 def main():
     modules, conv, cgvae, data = load_reference()
     torch.set_num_threads(1)          # bit-stable sums
     if len(sys.argv) > 1 and sys.argv[1] == "g8":     # only the G8 set (leaves the other files untouched)
         g8_cross(conv, cgvae)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "g9":
+        g9_high_order_edges(data)
         return
     g1_blocks(modules, conv)
     g2_model(cgvae, data)
@@ -434,6 +460,7 @@ def main():
     g5_scatter()
     g7_init(cgvae)
     g8_cross(conv, cgvae)
+    g9_high_order_edges(data)
 
 
 if __name__ == "__main__":

@@ -1033,3 +1033,36 @@ def test_cgvae_trains_with_the_equivariant_decoder():
     tr.capture(batch, warmup=0)
     losses += [float(tr.step(batch)) for _ in range(3)]
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+# --------------------------------------------------------------------------- dataset build on the device
+def test_build_dataset_on_device_matches_reference_semantics():
+    """datasets.py:459-506 batched: rotations preserve every interatomic distance and are the same for the atoms and
+    the beads of a frame, bead coordinates are the scatter_mean of the rotated atoms, the per-frame dicts collate, and
+    the batched radius graphs equal the per-frame rule (data.py:65-82)."""
+    gen = torch.Generator().manual_seed(4)
+    T, n, n_cgs = 7, 22, 3
+    traj = torch.rand(T, n, 3, generator=gen) * 6.0
+    mapping = (torch.arange(n) * n_cgs) // n
+    z = torch.randint(1, 9, (n,), generator=gen)
+    bonds = torch.stack([torch.arange(n - 1), torch.arange(1, n)], dim=1)
+    ds = cg.build_dataset(mapping, traj.numpy(), 8.5, 9.5, z.numpy(), bonds, order=2, generator=torch.Generator().manual_seed(1), device=DEV)
+    assert len(ds) == T and set(ds.props) == {"nxyz", "CG_nxyz", "num_atoms", "num_CGs", "CG_mapping", "bond_edge_list"}
+    for t_ in range(T):
+        f = ds[t_]
+        xyz = f["nxyz"][:, 1:]
+        assert torch.equal(f["nxyz"][:, 0], z.float()) and torch.equal(f["CG_nxyz"][:, 0], torch.arange(n_cgs).float())
+        assert_close(torch.cdist(xyz, xyz), torch.cdist(traj[t_], traj[t_]), "pair distances under rotation", 1e-5)
+        assert_close(xyz.norm(dim=1), traj[t_].norm(dim=1), "rotation about the origin", 1e-5)
+        assert_close(f["CG_nxyz"][:, 1:], O.scatter_mean(xyz, mapping, 0), "bead means", 1e-6)
+        assert torch.equal(f["bond_edge_list"], cg.get_high_order_edge(bonds, 2, n))
+    plain = cg.build_dataset(mapping, traj, 8.5, 9.5, z, bonds, rotate=False, device=DEV)
+    assert torch.equal(plain[3]["nxyz"][:, 1:], traj[3])
+    given = cg.build_dataset(mapping, traj, 8.5, 9.5, z, bonds, cg_traj=torch.zeros(T, n_cgs, 3), rotate=False, device=DEV)
+    assert float(given[0]["CG_nxyz"][:, 1:].abs().max()) == 0.0
+    ds.generate_neighbor_list(8.5, 9.5, device=DEV)
+    for t_ in (0, T - 1):
+        assert torch.equal(ds[t_]["nbr_list"], O.get_neighbor_list(ds[t_]["nxyz"][:, 1:], 8.5, True))
+        assert torch.equal(ds[t_]["CG_nbr_list"], O.get_neighbor_list(ds[t_]["CG_nxyz"][:, 1:], 9.5, True))
+    batch = cg.prepare_batch(cg.CG_collate([ds[i] for i in range(4)]), DEV)
+    assert batch["nxyz"].shape == (4 * n, 4) and batch["CG_nxyz"].shape == (4 * n_cgs, 4)

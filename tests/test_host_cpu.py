@@ -116,3 +116,29 @@ def test_kl_and_loss_match_reference_terms():
     loss, kl, recon, graph = cg.loss_terms(out, batch, float(g["beta"]), float(g["gamma"]))
     for got, key in ((loss, "loss"), (kl, "kl"), (recon, "recon"), (graph, "graph")):
         np.testing.assert_allclose(got.numpy(), g[key], rtol=1e-5)
+
+
+def test_high_order_bond_edges_match_the_reference():
+    """datasets.py:449-458 on top of data.py:25-40, against vectors produced with the reference's own function."""
+    import numpy as np
+    from conftest import load_golden
+    from coarsegrainingvae_amd.data import get_high_order_edge
+    g = load_golden("g9_high_order_edges")
+    for case in range(3):
+        edges, n = torch.from_numpy(g[f"c{case}_edges"]), int(g[f"c{case}_n"])
+        for order in (1, 2, 3):
+            got = get_high_order_edge(edges, order, n)
+            assert np.array_equal(got.numpy(), g[f"c{case}_order{order}"]), (case, order)
+
+
+def test_random_rotation_matrices_are_proper_rotations_about_the_origin():
+    from coarsegrainingvae_amd.data import random_rotation_matrices
+    R = random_rotation_matrices(64, torch.Generator().manual_seed(3)).double()
+    eye = torch.eye(3, dtype=torch.float64)
+    assert float((R @ R.transpose(1, 2) - eye).abs().max()) < 1e-6
+    assert float((torch.linalg.det(R) - 1).abs().max()) < 1e-6
+    # whole-degree angles like random.randrange(-180, 180): trace = 1 + 2 cos(angle)
+    ang = torch.rad2deg(torch.acos(((R.diagonal(dim1=1, dim2=2).sum(-1) - 1) / 2).clamp(-1, 1)))
+    assert float((ang - ang.round()).abs().max()) < 1e-2
+    assert torch.equal(random_rotation_matrices(5, torch.Generator().manual_seed(3)),
+                       random_rotation_matrices(5, torch.Generator().manual_seed(3)))
