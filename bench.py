@@ -173,15 +173,38 @@ def main():
     F = args.n_basis
     frames = args.frames_per_gpu or w["batch"]
 
-    model = cg.build_model(F, w["n_rbf"], w["atom_cutoff"], w["cg_cutoff"], w["enc_nconv"], w["dec_nconv"],
-                           w["n_cgs"], seed=123).to(dev)
-    if args.skip_dead_vector_channel:
-        model.encoder.set_skip_dead_vector_channel(True)
-        model.prior_net.set_skip_dead_vector_channel(True)
     batch = cg.synthetic_batch(args.workload, n_frames=frames, seed=rank, device=dev)
     from coarsegrainingvae_amd.trainer import Trainer
-    trainer = Trainer(model, lr=1e-4, beta=w["beta"], gamma=w["gamma"], world_size=world,
-                      fused_optimizer=(args.optimizer == "fused"), exchange=args.exchange)
+
+    def build(exchange):
+        m = cg.build_model(F, w["n_rbf"], w["atom_cutoff"], w["cg_cutoff"], w["enc_nconv"], w["dec_nconv"],
+                           w["n_cgs"], seed=123).to(dev)
+        if args.skip_dead_vector_channel:
+            m.encoder.set_skip_dead_vector_channel(True)
+            m.prior_net.set_skip_dead_vector_channel(True)
+        return m, Trainer(m, lr=1e-4, beta=w["beta"], gamma=w["gamma"], world_size=world,
+                          fused_optimizer=(args.optimizer == "fused"), exchange=exchange)
+
+    def first_steps(tr):
+        # per-kernel HIP-event timing needs eager launches: done on a few untimed steps (part of warm-up)
+        tr.step(batch)
+        with ktimer.KernelTimer(("equi_msg", "pseudo_msg")) as kt:
+            for _ in range(3):
+                tr.step(batch)
+            return kt.summary()
+
+    model, trainer = build(args.exchange)
+    try:
+        ksum = first_steps(trainer)
+    except Exception as exc:
+        # every rank runs the same code on equally shaped shards, so a failure of the operand exchange hits all of
+        # them at the same point: measure with the plain gradient all-reduce rather than lose the run
+        if world == 1 or args.exchange == "gradients":
+            raise
+        print(f"[bench] operand exchange failed on rank {rank}: {exc!r}; falling back to --exchange gradients", file=sys.stderr)
+        torch.cuda.synchronize()
+        model, trainer = build("gradients")
+        ksum = first_steps(trainer)
 
     def barrier():
         if dist is not None:
@@ -189,12 +212,6 @@ def main():
         torch.cuda.synchronize()
 
     use_graph = (not args.no_graph) and args.optimizer == "fused"
-    # per-kernel HIP-event timing needs eager launches: done on a few untimed steps (part of warm-up)
-    trainer.step(batch)
-    with ktimer.KernelTimer(("equi_msg", "pseudo_msg")) as kt:
-        for _ in range(3):
-            trainer.step(batch)
-        ksum = kt.summary()
     if use_graph:
         try:
             trainer.capture(batch)
