@@ -394,25 +394,38 @@ __global__ __launch_bounds__(256) void gathered_wgrad_k(const WgradProblem* __re
   float bsum = 0.f;
   const int c4 = threadIdx.x & 15, rr = threadIdx.x >> 4;          // staging: 16 float4 columns x 16 rows per pass
   const bool gcol = n0 + 4 * c4 < N, xcol = k0 + 4 * c4 < K;
-  for (int m0 = 0; m0 < M; m0 += GW_CHUNK) {
+  constexpr int NP = GW_CHUNK / 16;                                  // staging passes per chunk
+  float4 gq[NP], xq[NP];
+  // operand rows of one chunk into registers (g already multiplied by act'(z) for local problems)
+  auto chunk_load = [&](int m0) {
     const int rows = min(GW_CHUNK, M - m0);
 #pragma unroll
-    for (int r = rr; r < GW_CHUNK; r += 16) {
+    for (int p = 0; p < NP; ++p) {
+      const int r = rr + 16 * p;
       const bool ok = r < rows;
       const int m = m0 + (ok ? r : 0);
       const int seg = m / sr, row = m - seg * sr;
       const size_t base = (size_t)seg * pr.seg_stride;
-      float4 g4 = ldg4_or_zero(pr.gy + base + (size_t)row * N + (gcol ? n0 + 4 * c4 : 0), ok && gcol);
-      if (pr.act) {                                                  // local problems: g = gy * act'(z)
+      gq[p] = ldg4_or_zero(pr.gy + base + (size_t)row * N + (gcol ? n0 + 4 * c4 : 0), ok && gcol);
+      if (pr.act) {
         const float4 zz = ldg4_or_zero(pr.z + base + (size_t)row * N + (gcol ? n0 + 4 * c4 : 0), ok && gcol);
-        g4.x *= act_bwd(zz.x, pr.act); g4.y *= act_bwd(zz.y, pr.act); g4.z *= act_bwd(zz.z, pr.act); g4.w *= act_bwd(zz.w, pr.act);
+        gq[p].x *= act_bwd(zz.x, pr.act); gq[p].y *= act_bwd(zz.y, pr.act);
+        gq[p].z *= act_bwd(zz.z, pr.act); gq[p].w *= act_bwd(zz.w, pr.act);
       }
-      const float4 x4 = ldg4_or_zero(pr.x + base + (size_t)row * K + (xcol ? k0 + 4 * c4 : 0), ok && xcol);
-      *reinterpret_cast<float4*>(gs + r * GW_GS + 4 * c4) = g4;
-      *reinterpret_cast<float4*>(xs + r * GW_XS + 4 * c4) = x4;
+      xq[p] = ldg4_or_zero(pr.x + base + (size_t)row * K + (xcol ? k0 + 4 * c4 : 0), ok && xcol);
+    }
+  };
+  chunk_load(0);
+  for (int m0 = 0; m0 < M; m0 += GW_CHUNK) {
+    const int rows = min(GW_CHUNK, M - m0);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {                                   // rows beyond the chunk arrive as zeros
+      *reinterpret_cast<float4*>(gs + (rr + 16 * p) * GW_GS + 4 * c4) = gq[p];
+      *reinterpret_cast<float4*>(xs + (rr + 16 * p) * GW_XS + 4 * c4) = xq[p];
     }
     __syncthreads();
-    const int steps = (rows + 3) / 4;                                // rows beyond the chunk were staged as zeros
+    if (m0 + GW_CHUNK < M) chunk_load(m0 + GW_CHUNK);                // the next chunk travels under this chunk's MFMAs
+    const int steps = (rows + 3) / 4;
 #pragma unroll 4
     for (int st = 0; st < steps; ++st) {
       const float a = gs[(4 * st + q) * GW_GS + 16 * wave + i];
