@@ -346,7 +346,7 @@ __global__ __launch_bounds__(64 * SPLIT) void equi_msg_fwd_mfma_k(
 // partial per block (LDS reduction over its 4 waves), summed by a second kernel in a fixed order:
 // deterministic, no atomics.  SPLIT: the 4 waves share one node (slices of its segment) instead
 // of taking different nodes -- for high-degree graphs.
-// grid = 8 * chunks_per_xcd * tiles, block = 256.
+// grid = 8 * chunks_per_xcd * tiles (tile-major work items per XCD), block = 256.
 constexpr int BWD_WAVES = 4;
 
 template <int R, bool HAS_GV, bool SPLIT, bool PAIR>
@@ -362,10 +362,14 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void equi_msg_bwd_k(
   constexpr int NACC = SPLIT ? (HAS_GV ? 12 : 2) : 0;
   __shared__ float red[(BWD_WAVES - 1) * (NRED + NACC) * 64];
 
+  // work item = (channel tile, chunk), tile-major; XCD x (= blockIdx % 8) takes items [x * chunks_per_xcd * tiles, ...):
+  // it sweeps consecutive chunks of one channel tile (as the forward does, equi_msg_grp.hip), so the gs / gv / phi
+  // slices its L2 must hold belong to one 128-channel tile, not to all of them
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int local = slot / tiles;
-  const int chunk = xcd * chunks_per_xcd + local;
-  const int tile = slot - local * tiles;
+  const int n_chunks = 8 * chunks_per_xcd;
+  const int item = xcd * chunks_per_xcd * tiles + slot;
+  const int tile = item / n_chunks;
+  const int chunk = item - tile * n_chunks;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform -> record loads stay scalar
   const ChanPair cp = chan_pair(tile, lane, F);
@@ -413,6 +417,36 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void equi_msg_bwd_k(
       beg = min(beg + wave * len, end);
       end = min(beg + len, end);
     }
+    if constexpr (PAIR && !HAS_GV) {
+      // scalar-only upstream (the model's case: the encoder's vector channel feeds nothing): software-pipelined like
+      // the forward -- record e+1 and receiver index e+2 are requested, and the gs gather of edge e+1 issued, before
+      // the FMAs of edge e run
+      if (gs != nullptr && beg < end) {
+        constexpr int NGB = R + 1;                                     // a_n and env; the unit vector is not needed
+        float gc[NGB], gn[NGB];
+#pragma unroll
+        for (int t = 0; t < NGB; ++t) gc[t] = geom[(size_t)beg * GS + t];
+        const unsigned og = 4u * (unsigned)cp.c, rowb = 4u * (unsigned)F;
+        unsigned so_n = (unsigned)dst[min(beg + 1, end - 1)] * rowb;
+        f2 c_q = ld2_buf(r_gs, og, (unsigned)dst[beg] * rowb);
+#pragma unroll 2
+        for (int e = beg; e < end; ++e) {
+          const int e1 = min(e + 1, end - 1), e2 = min(e + 2, end - 1);
+#pragma unroll
+          for (int t = 0; t < NGB; ++t) gn[t] = geom[(size_t)e1 * GS + t];
+          const unsigned so_nn = (unsigned)dst[e2] * rowb;
+          const f2 n_q = ld2_buf(r_gs, og, so_n);
+          a1 = fma2(c_q, filter2<R>(W[0], gc), a1);
+          const f2 t1 = c_q * p1;
+#pragma unroll
+          for (int n = 0; n <= R; ++n) G[0][n] = fma2(t1, splat(gc[n]), G[0][n]);
+#pragma unroll
+          for (int t = 0; t < NGB; ++t) gc[t] = gn[t];
+          so_n = so_nn;
+          c_q = n_q;
+        }
+      }
+    } else {
 #pragma unroll 2
     for (int e = beg; e < end; ++e) {
       const float* __restrict__ g = geom + (size_t)e * GS;
@@ -457,6 +491,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void equi_msg_bwd_k(
 #pragma unroll
         for (int n = 0; n <= R; ++n) G[0][n] = fma2(t1, splat(g[n]), G[0][n]);
       }
+    }
     }
     if constexpr (SPLIT) {       // the 4 waves hold partial sums of the SAME node: combine in LDS
       float* acc = red + (BWD_WAVES - 1) * NRED * 64;
@@ -561,6 +596,7 @@ struct BwdShape {
 static inline BwdShape bwd_shape(int n_src, long long n_edges_hint) {
   BwdShape s;
   s.split = n_edges_hint >= 48LL * (n_src > 0 ? n_src : 1);
+  if (const char* dbg = getenv("CGV_DEBUG_BWD_SPLIT")) s.split = dbg[0] == '1';   // experiments only
   const int min_npc = s.split ? 1 : BWD_WAVES;
   int npc = (n_src + BWD_MAX_CHUNKS - 1) / BWD_MAX_CHUNKS;
   if (npc < min_npc) npc = min_npc;
