@@ -162,7 +162,10 @@ class EquiEncoder(nn.Module):
         for blk in list(self.message_blocks) + list(self.cgmessage_layers):
             blk.with_dv = not flag
 
-    def forward(self, z, xyz, cg_xyz, mapping, nbr_list, cg_nbr_list, graph: Optional[BatchGraph] = None):
+    def forward(self, z, xyz, cg_xyz, mapping, nbr_list, cg_nbr_list, graph: Optional[BatchGraph] = None, layer_hooks=None):
+        """``layer_hooks``: {layer index L >= 1: callable} -- called from the autograd thread when the backward of the
+        encoder layers >= L is complete (tensor hook on the atom state entering layer L's message block); the
+        data-parallel trainer all-reduces those layers' gradients while the lower layers' backward still runs."""
         if graph is None:
             if self.dir_mp:
                 raise NotImplementedError("dir_mp=True is never used by run_ala.py (run_ala.py:201)")
@@ -174,7 +177,11 @@ class EquiEncoder(nn.Module):
         H = V = None
         for i in range(self.n_conv):
             # h += ds, v += dv (cgvae.py:287-288) and H += dH, V += dV (cgvae.py:309-310) fused into the kernels
-            h, v = self.message_blocks[i](h, v, None, graph.atom_nbrs, plan=graph.atom, geom=geom, residual=True)
+            h_in = h
+            if layer_hooks and i in layer_hooks and h.requires_grad:
+                h_in = h.view_as(h)                       # private node: its gradient is the last one of layers >= i
+                h_in.register_hook(_call_then_pass(layer_hooks[i]))
+            h, v = self.message_blocks[i](h_in, v, None, graph.atom_nbrs, plan=graph.atom, geom=geom, residual=True)
             if i == 0:
                 H = ops.scatter_mean(h, graph.mapping, plan=graph.a2b)
                 V = ops.scatter_mean(v, graph.mapping, plan=graph.a2b)
@@ -265,9 +272,16 @@ class CGequiVAE(nn.Module):
     def backward_buckets(self):
         """Parameter groups whose gradients become final one after the other during backward; the hooks
         registered in ``forward`` report each one through ``self.bucket_done(index)``."""
-        dec = self.equivaraintconv
-        return [[p for l in layers for blk in (dec.message_blocks[l], dec.update_blocks[l]) for p in blk.parameters()]
-                for layers in self._decoder_groups()]
+        dec, enc = self.equivaraintconv, self.encoder
+        buckets = [[p for l in layers for blk in (dec.message_blocks[l], dec.update_blocks[l]) for p in blk.parameters()]
+                   for layers in self._decoder_groups()]
+        # then the encoder's layers from the top down to layer 1 (layer 0 finishes with the backward pass itself)
+        buckets += [[p for blk in (enc.message_blocks[l], enc.cgmessage_layers[l]) for p in blk.parameters()]
+                    for l in self._encoder_layers()]
+        return buckets
+
+    def _encoder_layers(self):
+        return list(range(self.encoder.n_conv - 1, 0, -1))
 
     def _fire_bucket(self, index):
         def fire():
@@ -327,7 +341,11 @@ class CGequiVAE(nn.Module):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 H_prior_mu, H_prior_sigma = self.prior_net(cg_z, cg_xyz, CG_nbr_list, graph=graph)
-        S_I, s_i = self.encoder(z, xyz, cg_xyz, mapping, nbr_list, CG_nbr_list, graph=graph)
+        enc_hooks = None
+        if self.bucket_done is not None:
+            first = len(self._decoder_groups())
+            enc_hooks = {l: self._fire_bucket(first + k) for k, l in enumerate(self._encoder_layers())}
+        S_I, s_i = self.encoder(z, xyz, cg_xyz, mapping, nbr_list, CG_nbr_list, graph=graph, layer_hooks=enc_hooks)
         if side is not None:
             main.wait_stream(side)
             H_prior_mu.record_stream(main)
