@@ -74,6 +74,37 @@ __global__ __launch_bounds__(64 * SPLIT) void equi_msg_fwd_grp_k(
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform -> record loads stay scalar
   const ChanPair cp = chan_pair(tile, lane, F);
 
+  int beg = rowptr[node0], end = rowptr[node1];
+  {
+    const int len = (end - beg + SPLIT - 1) / SPLIT;
+    beg = min(beg + wave * len, end);
+    end = min(beg + len, end);
+  }
+  const unsigned row_bytes = 12u * (unsigned)F;              // bytes per node row of phi [3F] AND of v [F,3]
+  const unsigned oc = 4u * (unsigned)cp.c, oF = 4u * (unsigned)F, ov = 12u * (unsigned)cp.c;
+  const rsrc_t r_phi = make_rsrc(phi), r_v = make_rsrc(v);
+
+  // The slice's first two records and the rows of its first source are requested BEFORE the filter tile is staged:
+  // a block lives for only ~60 edges per wave on the chignolin graph, and rowptr -> record -> source id -> rows ->
+  // filter tile as a serial chain of memory round trips was a third of its life.
+  // Records run two edges ahead of the math (measured against one: 654 vs 719 us on the 2000-atom graph).  Scalar
+  // loads return out of order, so every use waits for ALL of them (lgkmcnt(0)): what the second buffer buys is
+  // that the record needed next has already landed when the wait for the newest request starts.
+  const bool work = beg < end;
+  const int last = end - 1;
+  float gc[NG], g1[NG], g2[NG];
+  RowBuf bufA, bufB;
+  bufA.p0 = bufA.p1 = bufA.p2 = bufA.A = bufA.B = bufA.C = splat(0.f);
+#pragma unroll
+  for (int t = 0; t < NG; ++t) gc[t] = g1[t] = 0.f;
+  if (work) {
+#pragma unroll
+    for (int t = 0; t < NG; ++t) gc[t] = geom[(size_t)beg * GS + t];
+#pragma unroll
+    for (int t = 0; t < NG; ++t) g1[t] = geom[(size_t)min(beg + 1, last) * GS + t];
+    gather_row(bufA, r_phi, r_v, oc, oF, ov, (unsigned)src_g[beg] * row_bytes);
+  }
+
   f2 W0[R + 1], W1[R + 1], W2[R + 1];
   {
     const int sl[3] = {0, 1, 2};
@@ -88,29 +119,8 @@ __global__ __launch_bounds__(64 * SPLIT) void equi_msg_fwd_grp_k(
 #pragma unroll
   for (int k = 0; k < RB; ++k) acc[k].s = acc[k].A = acc[k].B = acc[k].C = splat(0.f);
 
-  int beg = rowptr[node0], end = rowptr[node1];
-  {
-    const int len = (end - beg + SPLIT - 1) / SPLIT;
-    beg = min(beg + wave * len, end);
-    end = min(beg + len, end);
-  }
-  const unsigned row_bytes = 12u * (unsigned)F;              // bytes per node row of phi [3F] AND of v [F,3]
-  const unsigned oc = 4u * (unsigned)cp.c, oF = 4u * (unsigned)F, ov = 12u * (unsigned)cp.c;
-  const rsrc_t r_phi = make_rsrc(phi), r_v = make_rsrc(v);
-
-  if (beg < end) {
-    // records run two edges ahead of the math (measured against one: 654 vs 719 us on the 2000-atom graph).  Scalar
-    // loads return out of order, so every use waits for ALL of them (lgkmcnt(0)): what the second buffer buys is
-    // that the record needed next has already landed when the wait for the newest request starts.
-    float gc[NG], g1[NG], g2[NG];
-    const int last = end - 1;
-#pragma unroll
-    for (int t = 0; t < NG; ++t) gc[t] = geom[(size_t)beg * GS + t];
-#pragma unroll
-    for (int t = 0; t < NG; ++t) g1[t] = geom[(size_t)min(beg + 1, last) * GS + t];
+  if (work) {
     int e = beg;
-    RowBuf bufA, bufB;
-    gather_row(bufA, r_phi, r_v, oc, oF, ov, (unsigned)src_g[beg] * row_bytes);
 
     // one edge of the current step into the accumulators of receiver slot K (a wave-uniform test: scalar branch)
 #define CGV_GRP_EDGE(BUF, K)                                                                      \
