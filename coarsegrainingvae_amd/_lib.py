@@ -78,7 +78,8 @@ PROTOTYPES = {
     "cgv_pack_operands": (_i, [_p, _i, _i, _p]),
     "cgv_reconstruct_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p]),
     "cgv_reconstruct_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p, _p]),
-    "cgv_elbo_fwd": (_i, [_p] * 7 + [_i, _i, _i, _i, _f, _f] + [_p] * 6 + [_p]),
+    "cgv_elbo_workspace_bytes": (_sz, [_i, _i]),
+    "cgv_elbo_fwd": (_i, [_p] * 7 + [_i, _i, _i, _i, _f, _f] + [_p] * 6 + [_p, _sz, _p]),
     "cgv_elbo_scale": (_i, [_p, _p, _p, _p, _p, _i, _p, _i, _p]),
     "cgv_optim_state_floats": (_i, []),
     "cgv_optim_partial_floats": (_i, []),

@@ -23,6 +23,28 @@ __device__ inline double block_sum(double x, double* sh) {
   return t;
 }
 
+// KL terms of a large bead batch on many blocks (dipeptide, 32 frames: 57 600 elements took 2/3 of the single-block
+// kernel's 109 us): element gradients as in elbo_fwd, one double partial sum per block in a fixed order.
+__global__ __launch_bounds__(256) void elbo_kl_k(const float* __restrict__ mu, const float* __restrict__ sigma,
+                                                 const float* __restrict__ pmu, const float* __restrict__ pstd, int nk,
+                                                 float ck, float* __restrict__ g_mu, float* __restrict__ g_sigma,
+                                                 float* __restrict__ g_pmu, float* __restrict__ g_pstd,
+                                                 double* __restrict__ part) {
+  __shared__ double sh[16];
+  double kl = 0.0;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < nk; idx += gridDim.x * blockDim.x) {
+    const float m1 = mu[idx], s1 = sigma[idx], m2 = pmu[idx], s2 = pstd[idx];
+    const float s1s = s1 * s1, s2s = s2 * s2, dm = m1 - m2;
+    kl += (double)(s1s / s2s + dm * dm / s2 + logf(s2s) - logf(s1s));
+    g_mu[idx] = ck * (2.f * dm / s2);
+    g_pmu[idx] = -ck * (2.f * dm / s2);
+    g_sigma[idx] = ck * (2.f * s1 / s2s - 2.f / s1);
+    g_pstd[idx] = ck * (-2.f * s1s / (s2s * s2) - dm * dm / s2s + 2.f / s2);
+  }
+  kl = block_sum(kl, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = kl;
+}
+
 __global__ __launch_bounds__(1024) void elbo_fwd(const float* __restrict__ mu, const float* __restrict__ sigma,
                                                  const float* __restrict__ pmu, const float* __restrict__ pstd,
                                                  const float* __restrict__ xyz, const float* __restrict__ xr,
@@ -30,13 +52,17 @@ __global__ __launch_bounds__(1024) void elbo_fwd(const float* __restrict__ mu, c
                                                  int n_bonds, float beta, float gamma, float* __restrict__ out /*[4]*/,
                                                  float* __restrict__ g_mu, float* __restrict__ g_sigma,
                                                  float* __restrict__ g_pmu, float* __restrict__ g_pstd,
-                                                 float* __restrict__ g_xr) {
+                                                 float* __restrict__ g_xr, const double* __restrict__ kl_part,
+                                                 int n_kl_part) {
   __shared__ double sh[16];
   const int t = threadIdx.x, T = blockDim.x;
-  // ---- KL and its gradients (mean over beads of per-bead sums)
-  const int nk = n_beads * F;
+  // ---- KL and its gradients (mean over beads of per-bead sums); for large bead batches elbo_kl_k has already
+  // produced the gradients and per-block partial sums (added here in block order)
+  const int nk = n_kl_part > 0 ? 0 : n_beads * F;
   const float ck = 0.5f * beta / (float)n_beads;
   double kl = 0.0;
+  if (n_kl_part > 0 && t == 0)
+    for (int b = 0; b < n_kl_part; ++b) kl += kl_part[b];
   for (int idx = t; idx < nk; idx += T) {
     const float m1 = mu[idx], s1 = sigma[idx], m2 = pmu[idx], s2 = pstd[idx];
     const float s1s = s1 * s1, s2s = s2 * s2, dm = m1 - m2;
@@ -129,16 +155,33 @@ __global__ __launch_bounds__(256) void elbo_scale(const float* __restrict__ g_lo
 
 extern "C" {
 
+// KL elements beyond which the KL terms run on their own multi-block launch; partial sums in the workspace
+static inline int elbo_kl_blocks(int n_beads, int n_feat) {
+  const long long nk = (long long)n_beads * n_feat;
+  if (nk < 16384) return 0;
+  const long long b = (nk + 1023) / 1024;
+  return (int)(b > 128 ? 128 : b);
+}
+
+size_t cgv_elbo_workspace_bytes(int n_beads, int n_feat) { return sizeof(double) * (size_t)elbo_kl_blocks(n_beads, n_feat); }
+
 int cgv_elbo_fwd(const float* mu, const float* sigma, const float* prior_mu, const float* prior_std, const float* xyz,
                  const float* xyz_recon, const int64_t* bonds, int n_beads, int n_feat, int n_atoms, int n_bonds,
                  float beta, float gamma, float* out4, float* g_mu, float* g_sigma, float* g_prior_mu, float* g_prior_std,
-                 float* g_xyz_recon, void* stream) {
+                 float* g_xyz_recon, void* workspace, size_t workspace_bytes, void* stream) {
   CGV_REQUIRE(mu && sigma && prior_mu && prior_std && xyz && xyz_recon && out4, "null input");
   CGV_REQUIRE(g_mu && g_sigma && g_prior_mu && g_prior_std && g_xyz_recon, "null gradient buffer");
   CGV_REQUIRE(n_beads > 0 && n_feat > 0 && n_atoms > 0 && n_bonds >= 0 && (n_bonds == 0 || bonds), "bad size");
-  hipLaunchKernelGGL(cgv::elbo_fwd, dim3(1), dim3(1024), 0, (hipStream_t)stream, mu, sigma, prior_mu, prior_std, xyz,
-                     xyz_recon, bonds, n_beads, n_feat, n_atoms, n_bonds, beta, gamma, out4, g_mu, g_sigma, g_prior_mu,
-                     g_prior_std, g_xyz_recon);
+  hipStream_t st = (hipStream_t)stream;
+  int nb = elbo_kl_blocks(n_beads, n_feat);
+  if (nb > 0 && (!workspace || workspace_bytes < sizeof(double) * (size_t)nb || (((uintptr_t)workspace) & 7))) nb = 0;
+  double* part = reinterpret_cast<double*>(workspace);
+  if (nb > 0)
+    hipLaunchKernelGGL(cgv::elbo_kl_k, dim3(nb), dim3(256), 0, st, mu, sigma, prior_mu, prior_std, n_beads * n_feat,
+                       0.5f * beta / (float)n_beads, g_mu, g_sigma, g_prior_mu, g_prior_std, part);
+  hipLaunchKernelGGL(cgv::elbo_fwd, dim3(1), dim3(1024), 0, st, mu, sigma, prior_mu, prior_std, xyz, xyz_recon, bonds,
+                     n_beads, n_feat, n_atoms, n_bonds, beta, gamma, out4, g_mu, g_sigma, g_prior_mu, g_prior_std,
+                     g_xyz_recon, (const double*)part, nb);
   return cgv::check_launch("cgv_elbo_fwd");
 }
 

@@ -500,9 +500,11 @@ class _Elbo(torch.autograd.Function):
         n_atoms = xr.shape[0]
         out = torch.empty(4, dtype=_F32, device=mu.device)
         grads = [torch.empty_like(t) for t in (mu, sigma, pmu, pstd, xr)]
+        nbytes = int(_lib.load().cgv_elbo_workspace_bytes(n_beads, F))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=mu.device) if nbytes else None
         _lib.call("cgv_elbo_fwd", _lib.ptr(mu), _lib.ptr(sigma), _lib.ptr(pmu), _lib.ptr(pstd), _lib.ptr(xyz), _lib.ptr(xr),
                   _lib.ptr(bonds) if bonds.shape[0] else None, n_beads, F, n_atoms, bonds.shape[0], float(beta),
-                  float(gamma), _lib.ptr(out), *[_lib.ptr(g) for g in grads], _lib.stream_ptr())
+                  float(gamma), _lib.ptr(out), *[_lib.ptr(g) for g in grads], _lib.ptr(ws), nbytes, _lib.stream_ptr())
         ctx.grads = grads
         ctx.mark_non_differentiable(out)
         loss = out[0].clone()

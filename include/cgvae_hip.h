@@ -322,10 +322,13 @@ int cgv_reconstruct_bwd(const float* g_xyz, const int32_t* rowptr, const int32_t
  * xyz_recon}; cgv_elbo_scale multiplies them by the upstream scalar (device pointer) in backward.
  * bonds: int64 [n_bonds, 2] batch-global atom ids (bond_edge_list of CG_collate).
  * ------------------------------------------------------------------------------------- */
+/* workspace of cgv_elbo_workspace_bytes bytes (0 for small bead batches): lets the KL terms of a large batch run on
+ * their own multi-block launch; with NULL everything runs in the one-block kernel (same result up to summation order). */
+size_t cgv_elbo_workspace_bytes(int n_beads, int n_feat);
 int cgv_elbo_fwd(const float* mu, const float* sigma, const float* prior_mu, const float* prior_std, const float* xyz,
                  const float* xyz_recon, const int64_t* bonds, int n_beads, int n_feat, int n_atoms, int n_bonds,
                  float beta, float gamma, float* out4, float* g_mu, float* g_sigma, float* g_prior_mu, float* g_prior_std,
-                 float* g_xyz_recon, void* stream);
+                 float* g_xyz_recon, void* workspace /*or NULL*/, size_t workspace_bytes, void* stream);
 int cgv_elbo_scale(const float* g_loss, float* g_mu, float* g_sigma, float* g_prior_mu, float* g_prior_std, int n_bead_elems,
                    float* g_xyz_recon, int n_atom_elems, void* stream);
 
