@@ -131,20 +131,39 @@ class WeightGradQueue:
         return table
 
     def launch(self, items):
-        """ONE grouped launch for ``items`` (tuples as queued by ``enqueue``), writing into their gW / gb targets."""
+        """Grouped launches for ``items`` (tuples as queued by ``enqueue``), writing into their gW / gb targets: ONE for
+        the problems of at most 64 rows (weight-streaming VALU kernel, grouped_wgrad_k) and ONE for those with more
+        (64 x 64 MFMA tiles over LDS-staged operand rows, gathered_wgrad_k -- the atom-level layers, and every
+        bead-level layer of a large batch)."""
         if not items:
             return
         lib = _lib.load()
         assert lib.cgv_wgrad_record_bytes() == self.RECORD.size
         if len(items) > self.MAX_PROBLEMS:
             raise RuntimeError("too many queued weight-gradient problems")
+        small = [it for it in items if self.kernel != "mfma" and lib.cgv_skinny_supported(it[0].shape[0], it[0].shape[1], it[1].shape[1])]
+        ids = {id(it) for it in small}
+        large = [it for it in items if id(it) not in ids]
         dev = items[0][0].device
-        buf = bytearray()
         tk, tw, nb = C.c_int(), C.c_int(), C.c_int()
-        block_begin, max_lds = 0, 0
-        if self.kernel == "mfma":
-            # 64 x 64 MFMA tiles with LDS-staged operand rows (the kernel of the data-parallel operand exchange)
-            for gy, x, z, act, gW, gb, accumulate in items:
+        if small:
+            buf, block_begin, max_lds = bytearray(), 0, 0
+            for gy, x, z, act, gW, gb, accumulate in small:
+                M, N = gy.shape
+                K = x.shape[1]
+                if lib.cgv_wgrad_plan(M, N, K, C.byref(tk), C.byref(tw), C.byref(nb)) != 0:
+                    raise RuntimeError(lib.cgv_last_error_string().decode())
+                buf += self.RECORD.pack(gy.data_ptr(), x.data_ptr(), z.data_ptr() if z is not None else 0, gW.data_ptr(),
+                                        gb.data_ptr() if gb is not None else 0, M, N, K, int(accumulate), int(act),
+                                        block_begin, tk.value, tw.value, 0, 0, 0)
+                block_begin += nb.value
+                max_lds = max(max_lds, lib.cgv_wgrad_lds_floats(M, tw.value))
+            table = self.upload(bytes(buf), dev)
+            _lib.call("cgv_grouped_wgrad", _lib.ptr(table), len(small), block_begin, max_lds, _lib.stream_ptr(),
+                      tag="grouped_wgrad")
+        if large:
+            buf, block_begin = bytearray(), 0
+            for gy, x, z, act, gW, gb, accumulate in large:
                 M, N = gy.shape
                 K = x.shape[1]
                 if lib.cgv_wgrad_gathered_plan(M, N, K, 0, C.byref(tk), C.byref(nb)) != 0:
@@ -154,21 +173,8 @@ class WeightGradQueue:
                                         block_begin, tk.value, 0, 0, 0, 0)
                 block_begin += nb.value
             table = self.upload(bytes(buf), dev)
-            _lib.call("cgv_grouped_wgrad_gathered", _lib.ptr(table), len(items), block_begin, _lib.stream_ptr(),
-                      tag="grouped_wgrad")
-            return
-        for gy, x, z, act, gW, gb, accumulate in items:
-            M, N = gy.shape
-            K = x.shape[1]
-            if lib.cgv_wgrad_plan(M, N, K, C.byref(tk), C.byref(tw), C.byref(nb)) != 0:
-                raise RuntimeError(lib.cgv_last_error_string().decode())
-            buf += self.RECORD.pack(gy.data_ptr(), x.data_ptr(), z.data_ptr() if z is not None else 0, gW.data_ptr(),
-                                    gb.data_ptr() if gb is not None else 0, M, N, K, int(accumulate), int(act),
-                                    block_begin, tk.value, tw.value, 0, 0, 0)
-            block_begin += nb.value
-            max_lds = max(max_lds, lib.cgv_wgrad_lds_floats(M, tw.value))
-        table = self.upload(bytes(buf), dev)
-        _lib.call("cgv_grouped_wgrad", _lib.ptr(table), len(items), block_begin, max_lds, _lib.stream_ptr(), tag="grouped_wgrad")
+            _lib.call("cgv_grouped_wgrad_gathered", _lib.ptr(table), len(large), block_begin, _lib.stream_ptr(),
+                      tag="grouped_wgrad_tiles")
         # the operand tensors stay referenced by ``items`` until here; stream order protects their reuse
 
 
@@ -264,7 +270,11 @@ class _LinearFn(torch.autograd.Function):
                 gx = gx.reshape(gy.shape[:-1] + (K,))
             if need_w:
                 tw, acc_w, gw = _grad_target(w_param, weight)
-                _lib.call("cgv_tile_linear_wgrad", _lib.ptr(g2), _lib.ptr(x), _lib.ptr(tw), M, N, K, int(acc_w), st)
+                if wgrad_queue.active and gw is None and lib_has_rows(M, N, K):
+                    # under the trainer: one grouped MFMA launch for all layers of this kind (primitives.launch)
+                    wgrad_queue.enqueue(g2, x, None, ACT_NONE, tw, None, acc_w)
+                else:
+                    _lib.call("cgv_tile_linear_wgrad", _lib.ptr(g2), _lib.ptr(x), _lib.ptr(tw), M, N, K, int(acc_w), st)
             return gx, gw, gb, None
         if need_x:
             gx = torch.empty(M, K, dtype=torch.float32, device=gy.device)
@@ -284,6 +294,11 @@ class _LinearFn(torch.autograd.Function):
             if not (wgrad_queue.active and gw is None and gb is None):
                 wgrad_queue.flush()                          # immediate mode (no trainer / not arena-managed)
         return gx, gw, gb, None
+
+
+def lib_has_rows(M, N, K) -> bool:
+    """Shapes the grouped MFMA weight-gradient launch takes (any row count; widths in multiples of 4)."""
+    return M >= 1 and N >= 4 and K >= 4 and N % 4 == 0 and K % 4 == 0
 
 
 def skinny_bwd_input(gy2, z, weight, gx, M, N, K, act, stream=None):

@@ -385,7 +385,7 @@ class Trainer:
         if self.sync is not None:
             self.sync.drain()
         graph = torch.cuda.CUDAGraph()
-        wgrad_queue.prepare_capture(self.arena.p.device, flushes=3 * (len(self.early_ranges) + 2))
+        wgrad_queue.prepare_capture(self.arena.p.device, flushes=4 * (len(self.early_ranges) + 2))
         # with RCCL in the step, other threads (the process group's watchdog) legitimately touch the runtime
         mode = "thread_local" if self.sync is not None else "global"
         with torch.cuda.graph(graph, capture_error_mode=mode):
