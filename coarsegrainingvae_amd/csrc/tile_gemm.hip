@@ -125,7 +125,8 @@ __global__ __launch_bounds__(64 * QM * QN * KW) void tile_fwd_k(const float* __r
 // instruction); MFMA (c, s) uses A.comp(c) and B_c.comp(s) and accumulates D_s = gx[..][k0 + 4j + s].
 template <int MB, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void tile_bwd_input_k(const float* __restrict__ g, const float* __restrict__ W,
-                                                        float* __restrict__ gx, int M, int N, int K) {
+                                                        float* __restrict__ gx, int M, int N, int K,
+                                                        const float* __restrict__ z, int act) {
   __shared__ float red[WAVES - 1][MB * 4][4][64];    // [wave-1][mb*4 + s][reg][lane]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -141,6 +142,7 @@ __global__ __launch_bounds__(64 * WAVES) void tile_bwd_input_k(const float* __re
     gok[mb] = m < M;
     gr[mb] = g + (size_t)(gok[mb] ? m : 0) * N + 4 * q;
   }
+  const ptrdiff_t zoff = act ? z - g : 0;            // z has g's layout: the upstream gradient is corrected on the fly
   f32x4 acc[MB][4];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
@@ -154,7 +156,14 @@ __global__ __launch_bounds__(64 * WAVES) void tile_bwd_input_k(const float* __re
     const bool nok = n + 4 * q < N;                  // N % 4 == 0: rows n + 4q .. + 3 are all in or all out
     float4 a[MB];
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) a[mb] = ld4z(gr[mb] + (nok ? n : 0), nok && gok[mb]);
+    for (int mb = 0; mb < MB; ++mb) {
+      a[mb] = ld4z(gr[mb] + (nok ? n : 0), nok && gok[mb]);
+      if (act) {                                     // g = gy * act'(z) (cgv_dense_grad_prepare's job, without its launch)
+        const float4 zz = ld4z(gr[mb] + zoff + (nok ? n : 0), nok && gok[mb]);
+        a[mb].x *= act_bwd(zz.x, act); a[mb].y *= act_bwd(zz.y, act);
+        a[mb].z *= act_bwd(zz.z, act); a[mb].w *= act_bwd(zz.w, act);
+      }
+    }
     float4 b[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -283,18 +292,33 @@ int cgv_tile_linear_fwd(const float* x, const float* W, const float* bias, float
   return cgv::check_launch("cgv_tile_linear_fwd");
 }
 
-int cgv_tile_linear_bwd_input(const float* g, const float* W, float* gx, int M, int N, int K, void* stream) {
-  CGV_REQUIRE(g && W && gx, "null pointer");
-  CGV_REQUIRE(cgv_tile_supported(M, N, K), "unsupported shape (need N % 4 == 0, K % 4 == 0)");
-  CGV_REQUIRE(((((uintptr_t)g | (uintptr_t)W | (uintptr_t)gx)) & 15) == 0, "operands must be 16-byte aligned");
+static int tile_bwd_input_launch(const float* g, const float* z, int act, const float* W, float* gx, int M, int N, int K,
+                                 void* stream, const char* what) {
   hipStream_t st = (hipStream_t)stream;
   const int kt = (K + 63) / 64;
   const int blocks32 = kt * ((M + 31) / 32);
   if (blocks32 >= 512)                    // enough 32-row tiles to fill the chip: halve the weight re-reads
-    hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 4>), dim3(kt, (M + 31) / 32), dim3(256), 0, st, g, W, gx, M, N, K);
+    hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 4>), dim3(kt, (M + 31) / 32), dim3(256), 0, st, g, W, gx, M, N, K, z, act);
   else
-    hipLaunchKernelGGL((cgv::tile_bwd_input_k<1, 8>), dim3(kt, (M + 15) / 16), dim3(512), 0, st, g, W, gx, M, N, K);
-  return cgv::check_launch("cgv_tile_linear_bwd_input");
+    hipLaunchKernelGGL((cgv::tile_bwd_input_k<1, 8>), dim3(kt, (M + 15) / 16), dim3(512), 0, st, g, W, gx, M, N, K, z, act);
+  return cgv::check_launch(what);
+}
+
+int cgv_tile_linear_bwd_input(const float* g, const float* W, float* gx, int M, int N, int K, void* stream) {
+  CGV_REQUIRE(g && W && gx, "null pointer");
+  CGV_REQUIRE(cgv_tile_supported(M, N, K), "unsupported shape (need N % 4 == 0, K % 4 == 0)");
+  CGV_REQUIRE(((((uintptr_t)g | (uintptr_t)W | (uintptr_t)gx)) & 15) == 0, "g, W and gx must be 16-byte aligned");
+  return tile_bwd_input_launch(g, nullptr, 0, W, gx, M, N, K, stream, "cgv_tile_linear_bwd_input");
+}
+
+/* gx = (gy * act'(z)) W with the activation derivative applied in the operand loads (no cgv_dense_grad_prepare pass). */
+int cgv_tile_linear_bwd_input_act(const float* gy, const float* z, const float* W, float* gx, int M, int N, int K, int act,
+                                  void* stream) {
+  CGV_REQUIRE(gy && W && gx, "null pointer");
+  CGV_REQUIRE(act == 0 || (act >= 1 && act <= cgv::CGV_ACT_MAX && z), "act != 0 needs the saved pre-activation z");
+  CGV_REQUIRE(cgv_tile_supported(M, N, K), "unsupported shape (need N % 4 == 0, K % 4 == 0)");
+  CGV_REQUIRE(((((uintptr_t)gy | (uintptr_t)z | (uintptr_t)W | (uintptr_t)gx)) & 15) == 0, "operands must be 16-byte aligned");
+  return tile_bwd_input_launch(gy, act ? z : nullptr, act, W, gx, M, N, K, stream, "cgv_tile_linear_bwd_input_act");
 }
 
 int cgv_tile_linear_wgrad(const float* g, const float* x, float* gW, int M, int N, int K, int accumulate, void* stream) {

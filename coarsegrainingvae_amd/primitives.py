@@ -256,9 +256,28 @@ class _LinearFn(torch.autograd.Function):
         st = _lib.stream_ptr()
         gx = gw = gb = None
         if ctx.mode == "tile":
-            # g = gy * Swish'(z) and the bias column sums in one launch, then two reduction-split MFMA GEMMs
             if gy2.data_ptr() % 16:
                 gy2 = gy2.clone()
+            if (need_w and wgrad_queue.active and _is_direct(w_param) and w_param.grad.is_contiguous()
+                    and (not need_b or (_is_direct(b_param) and b_param.grad.is_contiguous())) and lib_has_rows(M, N, K)):
+                # under the trainer: no prologue launch -- act'(z) is applied in the operand loads of bwd_input and of the
+                # grouped weight-gradient launch, which also sums the bias (primitives.WeightGradQueue.launch)
+                if need_x:
+                    gx = torch.empty(M, K, dtype=torch.float32, device=gy.device)
+                    _lib.call("cgv_tile_linear_bwd_input_act", _lib.ptr(gy2), _lib.ptr(z) if act != ACT_NONE else None,
+                              _lib.ptr(weight), _lib.ptr(gx), M, N, K, act, st)
+                    gx = gx.reshape(gy.shape[:-1] + (K,))
+                w_param._cgv_exch = (M, N, K)
+                tw, acc_w, _ = _grad_target(w_param, weight)
+                tb, acc_b = None, acc_w
+                if need_b:
+                    b_param._cgv_exch = (M, N, K)
+                    tb, acc_b, _ = _grad_target(b_param, b_param)
+                if acc_b != acc_w:
+                    raise RuntimeError("weight and bias of one layer disagree on first-write / accumulate state")
+                wgrad_queue.enqueue(gy2, x, z if act != ACT_NONE else None, act, tw, tb, acc_w)
+                return gx, None, None, None
+            # g = gy * Swish'(z) and the bias column sums in one launch, then two reduction-split MFMA GEMMs
             g2 = torch.empty_like(gy2) if act != ACT_NONE else gy2
             tb, acc_b, gb = _grad_target(b_param, b_param) if need_b else (None, False, None)
             if act != ACT_NONE or need_b:

@@ -279,6 +279,10 @@ int cgv_tile_supported(int M, int N, int K);
 int cgv_tile_linear_fwd(const float* x, const float* W, const float* bias /*or NULL*/, float* y, float* z /*or NULL*/, int M,
                         int N, int K, int act, void* stream);
 int cgv_tile_linear_bwd_input(const float* g, const float* W, float* gx, int M, int N, int K, void* stream);
+/* the same with g = gy * act'(z) formed in the operand loads (saves the cgv_dense_grad_prepare pass when the weight /
+ * bias gradients go to the grouped launch, which applies act' and sums the bias itself) */
+int cgv_tile_linear_bwd_input_act(const float* gy, const float* z /*or NULL*/, const float* W, float* gx, int M, int N, int K,
+                                  int act, void* stream);
 int cgv_tile_linear_wgrad(const float* g, const float* x, float* gW, int M, int N, int K, int accumulate, void* stream);
 int cgv_wgrad_record_bytes(void);
 int cgv_wgrad_plan(int M, int N, int K, int* tiles_k /*[host]*/, int* tile_w /*[host]*/, int* n_blocks /*[host]*/);

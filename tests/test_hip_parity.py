@@ -1066,3 +1066,34 @@ def test_build_dataset_on_device_matches_reference_semantics():
         assert torch.equal(ds[t_]["CG_nbr_list"], O.get_neighbor_list(ds[t_]["CG_nxyz"][:, 1:], 9.5, True))
     batch = cg.prepare_batch(cg.CG_collate([ds[i] for i in range(4)]), DEV)
     assert batch["nxyz"].shape == (4 * n, 4) and batch["CG_nxyz"].shape == (4 * n_cgs, 4)
+
+
+@pytest.mark.parametrize("M,K,N", [(96, 600, 1800), (332, 600, 600), (100, 64, 132)])
+def test_tile_layer_backward_under_the_trainer_queue_vs_fp64(M, K, N):
+    """Arena-managed Dense layer beyond 64 rows with the weight-gradient queue active (what the trainer does): no
+    prologue launch, act'(z) inside bwd_input's operand loads, weight + bias gradients from the grouped MFMA launch."""
+    from coarsegrainingvae_amd.primitives import Swish, wgrad_queue
+    from coarsegrainingvae_amd.trainer import ParamArena
+    gen = torch.Generator().manual_seed(M + N)
+    layer = cg.Dense(K, N, bias=True, activation=Swish()).to(DEV)
+    with torch.no_grad():
+        layer.bias.copy_(torch.randn(N, generator=gen).to(DEV))
+    x = torch.randn(M, K, generator=gen).to(DEV).requires_grad_(True)
+    gout = torch.randn(M, N, generator=gen).to(DEV)
+    layer(x).sum().backward()                                # gradients exist -> the arena can adopt them
+    arena = ParamArena(list(layer.parameters()))
+    for second in (False, True):                             # first write of a step, then accumulation
+        if not second:
+            arena.zero_grad()
+            x.grad = None
+        with wgrad_queue.collect():
+            (layer(x) * gout).sum().backward()
+            assert len(wgrad_queue.items) == 1               # queued, not launched layer by layer
+        wgrad_queue.flush()
+    x64, W64, b64 = x.detach().double().cpu(), layer.weight.detach().double().cpu(), layer.bias.detach().double().cpu()
+    x64.requires_grad_(True); W64.requires_grad_(True); b64.requires_grad_(True)
+    z = x64 @ W64.t() + b64
+    ((z * torch.sigmoid(z)) * gout.double().cpu()).sum().backward()
+    assert_close(x.grad, 2 * x64.grad, "grad x (two passes)", 2e-6)
+    assert_close(layer.weight.grad, 2 * W64.grad, "grad W (write + accumulate)", 2e-6)
+    assert_close(layer.bias.grad, 2 * b64.grad, "grad b (write + accumulate)", 2e-6)
