@@ -19,6 +19,7 @@
 // B[k = l>>4][j = l&15]; D: col j = l&15, row i = 4*(l>>4) + reg.  A float4 loaded along the
 // reduction axis feeds 4 consecutive MFMAs: component c of lane group q stands for reduction index
 // 4q + c of the 16-wide step -- any bijection works as long as A and B use the same one.
+#include <stdlib.h>
 #include "cgv_common.h"
 
 namespace cgv {
@@ -297,8 +298,15 @@ static int tile_bwd_input_launch(const float* g, const float* z, int act, const 
   hipStream_t st = (hipStream_t)stream;
   const int kt = (K + 63) / 64;
   const int blocks32 = kt * ((M + 31) / 32);
+  const int blocks16 = kt * ((M + 15) / 16);
+  int waves = 8;
+  if (const char* dbg = getenv("CGV_BWD_INPUT_WAVES")) waves = atoi(dbg);          // experiments only
+  else if (blocks16 < 128 && N >= 1024) waves = 16;
   if (blocks32 >= 512)                    // enough 32-row tiles to fill the chip: halve the weight re-reads
     hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 4>), dim3(kt, (M + 31) / 32), dim3(256), 0, st, g, W, gx, M, N, K, z, act);
+  else if (waves == 16)                   // few output tiles and a long reduction (96 bead rows x 5400 columns: 60 blocks):
+    // 16 waves per block split it -- 60 blocks of 8 waves left three quarters of the chip idle (17.8 us per call)
+    hipLaunchKernelGGL((cgv::tile_bwd_input_k<1, 16>), dim3(kt, (M + 15) / 16), dim3(1024), 0, st, g, W, gx, M, N, K, z, act);
   else
     hipLaunchKernelGGL((cgv::tile_bwd_input_k<1, 8>), dim3(kt, (M + 15) / 16), dim3(512), 0, st, g, W, gx, M, N, K, z, act);
   return cgv::check_launch(what);
