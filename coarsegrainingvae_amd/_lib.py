@@ -60,6 +60,7 @@ PROTOTYPES = {
     "cgv_skinny_max_rows": (_i, []),
     "cgv_skinny_supported": (_i, [_i, _i, _i]),
     "cgv_skinny_linear_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "cgv_skinny_bwd_input_supported": (_i, [_i, _i, _i]),
     "cgv_skinny_bwd_input_workspace_bytes": (_sz, [_i, _i, _i]),
     "cgv_skinny_linear_bwd_input": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
     "cgv_dense_grad_prepare": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),

@@ -121,7 +121,10 @@ __global__ __launch_bounds__(256) void skinny_bwd_input_k(const float* __restric
                                                           const float* __restrict__ W, float* __restrict__ gx,
                                                           float* __restrict__ part, int M, int N, int K, int act, int KT,
                                                           int NS, int rpb) {
-  __shared__ __attribute__((aligned(16))) float sm[3 * MB * 16 * 64];      // g stage, then the wave reduction
+  // g stage [16 MB rows][BI_LD], then the wave reduction: up to 4 row blocks all three partner waves deposit at once,
+  // beyond that (MB 5..8: 65-128 rows) one wave at a time through a third of the space
+  constexpr int SM_RED = (MB <= 4 ? 3 : 1) * MB * 16 * 64, SM_G = MB * 16 * BI_LD;
+  __shared__ __attribute__((aligned(16))) float sm[SM_RED > SM_G ? SM_RED : SM_G];
   const int kt = blockIdx.x % KT, ns = blockIdx.x / KT;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -166,30 +169,58 @@ __global__ __launch_bounds__(256) void skinny_bwd_input_k(const float* __restric
       }
   }
   __syncthreads();
-  if (wave > 0) {
+  float4 tot[MB][4];                                                       // [mb][r] = gx[16 mb + 4 q + r][kcol .. +3]
+  if constexpr (MB <= 4) {
+    if (wave > 0) {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sm[((((wave - 1) * MB + mb) * 4 + r) * 4 + c) * 64 + lane] = acc[mb][c][r];
+    }
+    __syncthreads();
+    if (wave != 0) return;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
+      for (int r = 0; r < 4; ++r) {
+        float t[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sm[((((wave - 1) * MB + mb) * 4 + r) * 4 + c) * 64 + lane] = acc[mb][c][r];
-  }
-  __syncthreads();
-  if (wave != 0) return;
-  float4 tot[MB][4];                                                       // [mb][r] = gx[16 mb + 4 q + r][kcol .. +3]
+        for (int c = 0; c < 4; ++c) {
+          t[c] = acc[mb][c][r];
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float t[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        t[c] = acc[mb][c][r];
-#pragma unroll
-        for (int w = 0; w < 3; ++w) t[c] += sm[(((w * MB + mb) * 4 + r) * 4 + c) * 64 + lane];
+          for (int w = 0; w < 3; ++w) t[c] += sm[(((w * MB + mb) * 4 + r) * 4 + c) * 64 + lane];
+        }
+        tot[mb][r] = make_float4(t[0], t[1], t[2], t[3]);
       }
-      tot[mb][r] = make_float4(t[0], t[1], t[2], t[3]);
+  } else {
+    for (int w = 1; w < 4; ++w) {                                          // waves 1, 2, 3 in turn (same summation order)
+      if (wave == w) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sm[(((mb * 4 + r) * 4 + c) * 64) + lane] = acc[mb][c][r];
+      }
+      __syncthreads();
+      if (wave == 0) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mb][c][r] += sm[(((mb * 4 + r) * 4 + c) * 64) + lane];
+      }
+      __syncthreads();
     }
+    if (wave != 0) return;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tot[mb][r] = make_float4(acc[mb][0][r], acc[mb][1][r], acc[mb][2][r], acc[mb][3][r]);
+  }
   if (NS > 1) {                     // row slices meet in skinny_bwd_input_reduce_k (next launch on the stream)
     float* mine = part + ((size_t)ns * M) * K;
 #pragma unroll
@@ -591,8 +622,14 @@ int cgv_skinny_linear_fwd(const float* x, const float* W, const float* bias, flo
   return cgv::check_launch("cgv_skinny_linear_fwd");
 }
 
+/* bwd_input alone also takes 65..128 rows (row blocks 5..8): the weight rows are split over ~300 blocks whatever M is,
+ * where the tile kernel has one block per 16 x 64 outputs -- 60 blocks for 96 bead rows (dipeptide batch). */
+int cgv_skinny_bwd_input_supported(int M, int N, int K) {
+  return M >= 1 && M <= 128 && N >= 4 && K >= 4 && (N % 4) == 0 && (K % 4) == 0;
+}
+
 size_t cgv_skinny_bwd_input_workspace_bytes(int M, int N, int K) {
-  if (!cgv_skinny_supported(M, N, K)) return 0;
+  if (!cgv_skinny_bwd_input_supported(M, N, K)) return 0;
   int KT, NS, rpb;
   cgv::bwd_input_plan(N, K, true, &KT, &NS, &rpb);
   return NS > 1 ? sizeof(float) * (size_t)NS * M * K : 0;
@@ -602,7 +639,7 @@ int cgv_skinny_linear_bwd_input(const float* gy, const float* z, const float* W,
                                 void* ws, size_t ws_bytes, void* stream) {
   CGV_REQUIRE(gy && W && gx, "null pointer");
   CGV_REQUIRE(act == 0 || (act >= 1 && act <= cgv::CGV_ACT_MAX && z), "act != 0 needs the saved pre-activation z");
-  CGV_REQUIRE(cgv_skinny_supported(M, N, K), "unsupported shape (need M <= 64, N % 4 == 0, K % 4 == 0)");
+  CGV_REQUIRE(cgv_skinny_bwd_input_supported(M, N, K), "unsupported shape (need M <= 128, N % 4 == 0, K % 4 == 0)");
   CGV_REQUIRE(((((uintptr_t)gx) | ((uintptr_t)W) | ((uintptr_t)ws)) & 15) == 0, "gx, W, ws must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   int KT, NS, rpb;
@@ -613,7 +650,10 @@ int cgv_skinny_linear_bwd_input(const float* gy, const float* z, const float* W,
     case 1: cgv::launch_bwd_input<1>(st, gy, z, W, gx, part, M, N, K, act, KT, NS, rpb); break;
     case 2: cgv::launch_bwd_input<2>(st, gy, z, W, gx, part, M, N, K, act, KT, NS, rpb); break;
     case 3: cgv::launch_bwd_input<3>(st, gy, z, W, gx, part, M, N, K, act, KT, NS, rpb); break;
-    default: cgv::launch_bwd_input<4>(st, gy, z, W, gx, part, M, N, K, act, KT, NS, rpb); break;
+    case 4: cgv::launch_bwd_input<4>(st, gy, z, W, gx, part, M, N, K, act, KT, NS, rpb); break;
+    case 5:
+    case 6: cgv::launch_bwd_input<6>(st, gy, z, W, gx, part, M, N, K, act, KT, NS, rpb); break;
+    default: cgv::launch_bwd_input<8>(st, gy, z, W, gx, part, M, N, K, act, KT, NS, rpb); break;
   }
   return cgv::check_launch("cgv_skinny_linear_bwd_input");
 }

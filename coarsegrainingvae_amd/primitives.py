@@ -264,8 +264,13 @@ class _LinearFn(torch.autograd.Function):
                 # grouped weight-gradient launch, which also sums the bias (primitives.WeightGradQueue.launch)
                 if need_x:
                     gx = torch.empty(M, K, dtype=torch.float32, device=gy.device)
-                    _lib.call("cgv_tile_linear_bwd_input_act", _lib.ptr(gy2), _lib.ptr(z) if act != ACT_NONE else None,
-                              _lib.ptr(weight), _lib.ptr(gx), M, N, K, act, st)
+                    if M <= 128 and N >= 4096 and _lib.load().cgv_skinny_bwd_input_supported(M, N, K):
+                        # few rows, a very long reduction (96 bead rows x 5400 columns): the row-split kernel spreads the
+                        # weight over ~300 blocks (28.5 us + reduce against 43.6 us; tools/bwd_input_bench.py)
+                        skinny_bwd_input(gy2, z if act != ACT_NONE else None, weight, gx, M, N, K, act)
+                    else:
+                        _lib.call("cgv_tile_linear_bwd_input_act", _lib.ptr(gy2), _lib.ptr(z) if act != ACT_NONE else None,
+                                  _lib.ptr(weight), _lib.ptr(gx), M, N, K, act, st)
                     gx = gx.reshape(gy.shape[:-1] + (K,))
                 w_param._cgv_exch = (M, N, K)
                 tw, acc_w, _ = _grad_target(w_param, weight)

@@ -261,6 +261,7 @@ int cgv_skinny_max_rows(void);
 int cgv_skinny_supported(int M, int N, int K);
 int cgv_skinny_linear_fwd(const float* x, const float* W, const float* bias, float* y, float* z /*or NULL*/, int M, int N,
                           int K, int act, void* stream);
+int cgv_skinny_bwd_input_supported(int M, int N, int K);      /* bwd_input alone takes up to 128 rows */
 size_t cgv_skinny_bwd_input_workspace_bytes(int M, int N, int K);
 int cgv_skinny_linear_bwd_input(const float* gy, const float* z /*or NULL*/, const float* W, float* gx, int M, int N, int K,
                                 int act, void* ws /*or NULL*/, size_t ws_bytes, void* stream);

@@ -513,7 +513,8 @@ def test_skinny_linear_fwd_bwd_vs_fp64(M, N, K):
     assert_close(y2[0], (xd @ Wd_.t()).detach(), "y no bias", 2e-6)
 
 
-@pytest.mark.parametrize("M,N,K,act", [(12, 1800, 600, 0), (12, 600, 1200, 1), (36, 1200, 600, 0), (64, 5400, 24, 1)])
+@pytest.mark.parametrize("M,N,K,act", [(12, 1800, 600, 0), (12, 600, 1200, 1), (36, 1200, 600, 0), (64, 5400, 24, 1),
+                                        (96, 5400, 600, 0), (80, 1800, 600, 1), (128, 600, 132, 1), (65, 4100, 64, 0)])
 def test_skinny_bwd_input_row_split_is_deterministic_and_rearms(M, N, K, act):
     """The row-split bwd_input meets in a workspace: repeated launches must agree bit for bit (fixed summation
     order, no stale partial ever read), and the one-block-per-column-tile flavour (no workspace) must agree

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""bwd_input gx = (gy * act'(z)) W for 65..128 rows: row-split skinny kernel (+ reduce) vs the tile kernel.
+Back-to-back launches between two HIP events."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from coarsegrainingvae_amd import _lib
+from coarsegrainingvae_amd.primitives import skinny_bwd_input
+
+def timeit(fn, reps=100):
+    for _ in range(10): fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); a.record()
+    for _ in range(reps): fn()
+    b.record(); torch.cuda.synchronize()
+    return 1e3 * a.elapsed_time(b) / reps
+
+ACT = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+for M in (96, 128, 64):
+    for N, K in ((5400, 600), (600, 600), (1800, 600), (600, 1200), (1200, 600)):
+        gy, z = torch.randn(M, N, device="cuda"), torch.randn(M, N, device="cuda")
+        W = torch.randn(N, K, device="cuda")
+        gx1, gx2 = torch.empty(M, K, device="cuda"), torch.empty(M, K, device="cuda")
+        st = _lib.stream_ptr()
+        t_tile = timeit(lambda: _lib.call("cgv_tile_linear_bwd_input_act", _lib.ptr(gy), _lib.ptr(z), _lib.ptr(W), _lib.ptr(gx1), M, N, K, ACT, st))
+        t_sk = timeit(lambda: skinny_bwd_input(gy, z if ACT else None, W, gx2, M, N, K, ACT))
+        err = float((gx1 - gx2).abs().max() / gx1.abs().max())
+        print(f"M={M:4d} N={N:5d} K={K:5d}: tile {t_tile:6.2f} us   row-split + reduce {t_sk:6.2f} us   rel diff {err:.1e}")
