@@ -213,6 +213,11 @@ class _LinearFn(torch.autograd.Function):
             if x2.data_ptr() % 16:
                 x2 = x2.clone()
             M, K = x2.shape
+            if mode == "tile" and act == ACT_NONE and _library_pays(M, N, K, forward=True):
+                # a plain product (bias in the library's epilogue) big enough for the library GEMM to win
+                y = Fn.linear(x2, weight, bias)
+                ctx.save_for_backward(x2, weight, None)
+                return y.reshape(x.shape[:-1] + (N,))
             y = torch.empty(M, N, dtype=torch.float32, device=x.device)
             z = torch.empty_like(y) if act else None
             _lib.call("cgv_skinny_linear_fwd" if mode == "skinny" else "cgv_tile_linear_fwd", _lib.ptr(x2), _lib.ptr(weight),
@@ -264,7 +269,9 @@ class _LinearFn(torch.autograd.Function):
                 # grouped weight-gradient launch, which also sums the bias (primitives.WeightGradQueue.launch)
                 if need_x:
                     gx = torch.empty(M, K, dtype=torch.float32, device=gy.device)
-                    if M <= 128 and N >= 4096 and _lib.load().cgv_skinny_bwd_input_supported(M, N, K):
+                    if act == ACT_NONE and _library_pays(M, N, K, forward=False):
+                        torch.mm(gy2, weight, out=gx)        # plain product, big enough for the library GEMM to win
+                    elif M <= 128 and N >= 4096 and _lib.load().cgv_skinny_bwd_input_supported(M, N, K):
                         # few rows, a very long reduction (96 bead rows x 5400 columns): the row-split kernel spreads the
                         # weight over ~300 blocks (28.5 us + reduce against 43.6 us; tools/bwd_input_bench.py)
                         skinny_bwd_input(gy2, z if act != ACT_NONE else None, weight, gx, M, N, K, act)
@@ -318,6 +325,15 @@ class _LinearFn(torch.autograd.Function):
             if not (wgrad_queue.active and gw is None and gb is None):
                 wgrad_queue.flush()                          # immediate mode (no trainer / not arena-managed)
         return gx, gw, gb, None
+
+
+def _library_pays(M, N, K, forward: bool) -> bool:
+    """Plain (activation-free) products of the tile-GEMM layers for which the library GEMM (hipBLASLt behind torch) beats
+    the hand-written tiles -- it has a ~18 us floor but reaches 57-98 TF/s where the 32 x 32 L2-fed tiles level off at
+    48 (tools/lib_gemm_bench.py: bwd_input 704 x 1800 x 600: 19 vs 30 us; forward 2000 x 1800 x 600: 44 vs 90 us)."""
+    if forward:
+        return M >= 1024 and N * K >= 1024 * 600
+    return M >= 512 and N * K >= 1024 * 600
 
 
 def lib_has_rows(M, N, K) -> bool:

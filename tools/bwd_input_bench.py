@@ -16,7 +16,7 @@ def timeit(fn, reps=100):
     return 1e3 * a.elapsed_time(b) / reps
 
 ACT = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-for M in (96, 128, 64):
+for M in (tuple(int(a) for a in sys.argv[2:]) or (96, 128, 64)):
     for N, K in ((5400, 600), (600, 600), (1800, 600), (600, 1200), (1200, 600)):
         gy, z = torch.randn(M, N, device="cuda"), torch.randn(M, N, device="cuda")
         W = torch.randn(N, K, device="cuda")
