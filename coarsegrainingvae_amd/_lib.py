@@ -36,7 +36,9 @@ PROTOTYPES = {
     "cgv_csr_workspace_bytes": (_sz, [_i]),
     "cgv_csr_build": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "cgv_group_plan_workspace_bytes": (_sz, [_i]),
-    "cgv_group_plan_build": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _sz, _p]),
+    "cgv_group_plan_build": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _sz, _p]),
+    "cgv_group_plan_radix_workspace_bytes": (_sz, [_i]),
+    "cgv_group_plan_build_radix": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _sz, _p]),
     "cgv_geom_group_stride": (_i, [_i]),
     "cgv_geom_group_unit_offset": (_i, [_i]),
     "cgv_edge_geometry_grouped": (_i, [_p, _p, _p, _p, _p, _i, _i, _f, _p, _p, _p]),

@@ -209,6 +209,68 @@ __global__ void grp_meta(const int* __restrict__ dst_g, const int* __restrict__ 
   meta[q] = make_int2((d - g * rb) | (joins(q) ? 0 : 0x100) | (mask << 16), next);
 }
 
+
+// One launch for the whole receiver-group order (the two radix passes above cost ~20 launches per batch, and the CLI's
+// per-batch preparation is host-launch bound): a group's edges are a contiguous range of the dst-sorted view, so a
+// block ranks them by (source, receiver, position) -- keys are unique, rank = number of smaller keys -- and writes
+// dst_g / src_g / pos_g / meta_g of its range.  Keys sit in LDS up to GRP_LDS_KEYS edges per group (850 on the
+// 2000-atom graph at rb = 2), beyond that they are re-read from global memory.
+constexpr int GRP_LDS_KEYS = 4096;
+
+__global__ __launch_bounds__(256) void grp_build_k(const int* __restrict__ rowptr_d, const int* __restrict__ dst_d,
+                                                   const int* __restrict__ src_d, int n_dst, int rb,
+                                                   int* dst_g, int* src_g, int* pos_g, int2* __restrict__ meta,
+                                                   unsigned long long* spill) {
+  // (dst_g / src_g are written and read back by other threads of the block between barriers: not __restrict__)
+  __shared__ unsigned long long keys[GRP_LDS_KEYS];
+  const int g = blockIdx.x, node0 = g * rb;
+  const int beg = rowptr_d[node0], end = rowptr_d[min(node0 + rb, n_dst)];
+  const int L = end - beg;
+  if (L <= 0) return;
+  unsigned long long* k = L <= GRP_LDS_KEYS ? keys : spill + beg;          // spill: E keys, each group its own range
+  for (int t = threadIdx.x; t < L; t += blockDim.x) {
+    const int p = beg + t;
+    const unsigned hi = (unsigned)src_d[p] * (unsigned)rb + (unsigned)(dst_d[p] - node0);
+    k[t] = ((unsigned long long)hi << 32) | (unsigned)p;
+  }
+  __syncthreads();
+  // sorted position of every element, then the sorted keys replace the unsorted ones
+  for (int t0 = 0; t0 < L; t0 += blockDim.x) {
+    const int t = t0 + threadIdx.x;
+    unsigned long long mine = 0;
+    int rank = 0;
+    if (t < L) {
+      mine = k[t];
+      for (int u = 0; u < L; ++u) rank += k[u] < mine;
+      pos_g[beg + rank] = (int)(unsigned)(mine & 0xffffffffull);          // scratch: the key's low word, in sorted order
+      dst_g[beg + rank] = (int)(mine >> 32);                              // scratch: the key's high word
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int q = beg + threadIdx.x; q < end; q += blockDim.x) src_g[q] = (int)((unsigned)dst_g[q] / (unsigned)rb);
+  __threadfence_block();
+  __syncthreads();
+  // slot / head / mask / next source from the sorted (source, slot) sequence, as in grp_meta
+  for (int q = beg + threadIdx.x; q < end; q += blockDim.x) {
+    const int s = src_g[q];
+    auto slot_of = [&](int t) { return (int)((unsigned)dst_g[t] - (unsigned)src_g[t] * (unsigned)rb); };
+    auto joins = [&](int t) { return t > beg && src_g[t - 1] == src_g[t] && slot_of(t - 1) < slot_of(t); };
+    const int sl = slot_of(q);
+    int mask = 1 << sl;
+    for (int t = q; joins(t); --t) mask |= 1 << slot_of(t - 1);
+    int t = q + 1;
+    for (; t < end && joins(t); ++t) mask |= 1 << slot_of(t);
+    const int next = t < end ? src_g[t] : s;
+    meta[q] = make_int2(sl | (joins(q) ? 0 : 0x100) | (mask << 16), next);
+  }
+  __syncthreads();                                                         // every reader of the key words is done
+  for (int q = beg + threadIdx.x; q < end; q += blockDim.x) {
+    const int sl = (int)((unsigned)dst_g[q] - (unsigned)src_g[q] * (unsigned)rb);
+    dst_g[q] = node0 + sl;
+  }
+}
+
 }  // namespace cgv
 
 extern "C" {
@@ -256,21 +318,21 @@ int cgv_csr_build(const int64_t* dst, const int64_t* src, int stride, int n_edge
   return cgv::sorted_view(src, dst, stride, n_edges, n_src, n_dst, rowptr_s, eid_s, src_s, dst_s, ws, workspace_bytes, st);
 }
 
-size_t cgv_group_plan_workspace_bytes(int n_edges) {
+size_t cgv_group_plan_radix_workspace_bytes(int n_edges) {
   size_t temp = 0;
   if (cgv::sort_temp_bytes(n_edges, &temp) != hipSuccess) temp = (size_t)n_edges * 16 + (1 << 20);
   return 4 * cgv::align256(sizeof(int) * (size_t)(n_edges > 0 ? n_edges : 1)) + cgv::align256(temp) + 256;
 }
 
-int cgv_group_plan_build(const int32_t* dst_d, const int32_t* src_d, int n_edges, int n_dst, int n_src, int rb,
+int cgv_group_plan_build_radix(const int32_t* dst_d, const int32_t* src_d, int n_edges, int n_dst, int n_src, int rb,
                          int32_t* dst_g, int32_t* src_g, int32_t* pos_g, int32_t* meta_g, void* workspace,
                          size_t workspace_bytes, void* stream) {
   CGV_REQUIRE(n_edges >= 0 && n_dst >= 0 && n_src >= 0 && rb >= 1 && rb <= 8, "bad size");
   if (n_edges == 0) return 0;
   CGV_REQUIRE(dst_d && src_d && dst_g && src_g && meta_g && workspace, "null pointer");
   CGV_REQUIRE((((uintptr_t)meta_g) & 7) == 0, "meta_g must be 8-byte aligned");
-  if (workspace_bytes < cgv_group_plan_workspace_bytes(n_edges)) {
-    cgv::set_error("cgv_group_plan_build: workspace too small");
+  if (workspace_bytes < cgv_group_plan_radix_workspace_bytes(n_edges)) {
+    cgv::set_error("cgv_group_plan_build_radix: workspace too small");
     return CGV_E_WORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
@@ -293,11 +355,31 @@ int cgv_group_plan_build(const int32_t* dst_d, const int32_t* src_d, int n_edges
     e = rocprim::radix_sort_pairs(temp, temp_bytes, k_in, k_out, v_in, v_out, E, 0, bits_for((n_dst + rb - 1) / rb), st);
   }
   if (e != hipSuccess) {
-    cgv::set_error("cgv_group_plan_build: radix sort failed: %s", hipGetErrorString(e));
+    cgv::set_error("cgv_group_plan_build_radix: radix sort failed: %s", hipGetErrorString(e));
     return (int)e;
   }
   hipLaunchKernelGGL(cgv::grp_gather, dim3(B), dim3(T), 0, st, dst_d, src_d, v_out, n_edges, dst_g, src_g, pos_g);
   hipLaunchKernelGGL(cgv::grp_meta, dim3(B), dim3(T), 0, st, dst_g, src_g, n_edges, rb, reinterpret_cast<int2*>(meta_g));
+  return cgv::check_launch("cgv_group_plan_build_radix");
+}
+
+size_t cgv_group_plan_workspace_bytes(int n_edges) { return sizeof(unsigned long long) * (size_t)(n_edges > 0 ? n_edges : 1); }
+
+int cgv_group_plan_build(const int32_t* rowptr_d, const int32_t* dst_d, const int32_t* src_d, int n_edges, int n_dst,
+                              int n_src, int rb, int32_t* dst_g, int32_t* src_g, int32_t* pos_g, int32_t* meta_g,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+  CGV_REQUIRE(n_edges >= 0 && n_dst >= 0 && n_src >= 0 && rb >= 1 && rb <= 8, "bad size");
+  if (n_edges == 0 || n_dst == 0) return 0;
+  CGV_REQUIRE(rowptr_d && dst_d && src_d && dst_g && src_g && pos_g && meta_g && workspace, "null pointer");
+  CGV_REQUIRE((((uintptr_t)meta_g | (uintptr_t)workspace) & 7) == 0, "meta_g / workspace must be 8-byte aligned");
+  CGV_REQUIRE((uint64_t)n_src * (uint64_t)rb < (1ull << 32), "n_src * rb must fit 32 bits");
+  if (workspace_bytes < cgv_group_plan_workspace_bytes(n_edges)) {
+    cgv::set_error("cgv_group_plan_build: workspace too small");
+    return CGV_E_WORKSPACE;
+  }
+  const int groups = (n_dst + rb - 1) / rb;
+  hipLaunchKernelGGL(cgv::grp_build_k, dim3(groups), dim3(256), 0, (hipStream_t)stream, rowptr_d, dst_d, src_d, n_dst, rb,
+                     dst_g, src_g, pos_g, reinterpret_cast<int2*>(meta_g), reinterpret_cast<unsigned long long*>(workspace));
   return cgv::check_launch("cgv_group_plan_build");
 }
 

@@ -142,15 +142,23 @@ class EdgePlan:
         self._build_groups()
         return self
 
-    def _build_groups(self):
+    def _build_groups(self, radix: bool = False):
+        """``radix=True``: the two-pass radix construction (tests compare the two)."""
         if self.n_edges == 0:
             return
         lib = _lib.load()
+        if radix:
+            ws_bytes = int(lib.cgv_group_plan_radix_workspace_bytes(self.n_edges))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
+            _lib.call("cgv_group_plan_build_radix", _lib.ptr(self.dst_d), _lib.ptr(self.src_d), self.n_edges, self.n_dst,
+                      self.n_src, self.group_rb, _lib.ptr(self.dst_g), _lib.ptr(self.src_g), _lib.ptr(self.pos_g),
+                      _lib.ptr(self.meta_g), _lib.ptr(ws), ws_bytes, _lib.stream_ptr())
+            return
         ws_bytes = int(lib.cgv_group_plan_workspace_bytes(self.n_edges))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
-        _lib.call("cgv_group_plan_build", _lib.ptr(self.dst_d), _lib.ptr(self.src_d), self.n_edges, self.n_dst, self.n_src,
-                  self.group_rb, _lib.ptr(self.dst_g), _lib.ptr(self.src_g), _lib.ptr(self.pos_g), _lib.ptr(self.meta_g),
-                  _lib.ptr(ws), ws_bytes, _lib.stream_ptr())
+        _lib.call("cgv_group_plan_build", _lib.ptr(self.rowptr_d), _lib.ptr(self.dst_d), _lib.ptr(self.src_d), self.n_edges,
+                  self.n_dst, self.n_src, self.group_rb, _lib.ptr(self.dst_g), _lib.ptr(self.src_g), _lib.ptr(self.pos_g),
+                  _lib.ptr(self.meta_g), _lib.ptr(ws), ws_bytes, _lib.stream_ptr())
 
     def rebuild_from_nbrs(self, nbrs: torch.Tensor):
         """Re-plan IN PLACE for another directed edge list on the same nodes (at most ``capacity`` edges)."""

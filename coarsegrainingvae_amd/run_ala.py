@@ -243,7 +243,8 @@ def run(params) -> dict:
     if world > 1:
         torch.distributed.destroy_process_group()
     return {"epochs": len(log_rows), "seconds": elapsed, "train_frames_per_s": frames_seen / max(elapsed, 1e-9),
-            "final": log_rows[-1] if log_rows else None, "failed": failed, "skipped_steps": trainer.skipped_steps()}
+            "final": log_rows[-1] if log_rows else None, "failed": failed, "skipped_steps": trainer.skipped_steps(),
+            "graph_replays": trainer.replays}
 
 
 def main(argv=None):

@@ -97,16 +97,24 @@ int cgv_csr_build(const int64_t* dst, const int64_t* src, int stride, int n_edge
 /* K7b  receiver-group order of the dst-sorted view, for the shared-source forward (cgv_equi_msg_fwd_grouped):
  * rb consecutive receivers form a group; the group's edges (one contiguous range of the dst-sorted view, so
  * rowptr_d still delimits it) are re-ordered by (source, receiver).  Outputs, all [E] in group order:
- *   dst_g, src_g  receiver / source of the edge      pos_g (or NULL)  its position in the dst-sorted view
+ *   dst_g, src_g  receiver / source of the edge      pos_g  its position in the dst-sorted view
  *   meta_g [E,2]  { slot | head << 8 | mask << 16 , source of the group's NEXT step }: slot = receiver - group
  *                 base; a step = a maximal run of edges of one (group, source) pair with strictly increasing receivers
  *                 (a duplicated edge opens a new step); mask = the step's slots; head = first edge of the step; the
  *                 last step of a group names its own source.
- * Edge records for this order come from cgv_edge_geometry_grouped (below), which folds meta_g into them. */
+ * One launch: a block per group ranks the group's edges by (source, receiver, position) -- at most 2 x degree keys,
+ * in LDS up to 4096 per group.  Edge records for this order come from cgv_edge_geometry_grouped (below), which folds
+ * meta_g into them. */
 size_t cgv_group_plan_workspace_bytes(int n_edges);
-int cgv_group_plan_build(const int32_t* dst_d, const int32_t* src_d, int n_edges, int n_dst, int n_src, int rb,
-                         int32_t* dst_g, int32_t* src_g, int32_t* pos_g /*or NULL*/, int32_t* meta_g /*[E,2]*/,
-                         void* workspace, size_t workspace_bytes, void* stream);
+int cgv_group_plan_build(const int32_t* rowptr_d /*[Nd+1]*/, const int32_t* dst_d, const int32_t* src_d, int n_edges,
+                         int n_dst, int n_src, int rb, int32_t* dst_g, int32_t* src_g, int32_t* pos_g,
+                         int32_t* meta_g /*[E,2]*/, void* workspace, size_t workspace_bytes, void* stream);
+/* The same order from two stable radix passes over all edges (~20 launches against one): kept as the independent
+ * construction the tests compare with. */
+size_t cgv_group_plan_radix_workspace_bytes(int n_edges);
+int cgv_group_plan_build_radix(const int32_t* dst_d, const int32_t* src_d, int n_edges, int n_dst, int n_src, int rb,
+                               int32_t* dst_g, int32_t* src_g, int32_t* pos_g /*or NULL*/, int32_t* meta_g /*[E,2]*/,
+                               void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * K6  edge geometry -- replaces preprocess_r (conv.py:25-29), PainnRadialBasis

@@ -878,7 +878,7 @@ def _group_order_reference(dst_d, src_d, rb):
 
 
 @pytest.mark.parametrize("rb", [2, 4])
-@pytest.mark.parametrize("n,E", [(37, 900), (5, 3), (64, 4000)])
+@pytest.mark.parametrize("n,E", [(37, 900), (5, 3), (64, 4000), (3, 9000)])   # last: > 4096 keys per group (spill path)
 def test_receiver_group_order_is_bit_exact(rb, n, E):
     gen = torch.Generator().manual_seed(n + E + rb)
     nbrs = torch.randint(0, n, (E, 2), generator=gen)              # duplicates and self loops included
@@ -887,6 +887,12 @@ def test_receiver_group_order_is_bit_exact(rb, n, E):
     assert np.array_equal(plan.pos_g[:E].cpu().numpy(), pos)
     assert np.array_equal(plan.dst_g[:E].cpu().numpy(), dg) and np.array_equal(plan.src_g[:E].cpu().numpy(), sg)
     assert np.array_equal(plan.meta_g[:2 * E].cpu().numpy().reshape(E, 2), meta)
+    # the two-pass radix construction gives the same arrays
+    one_launch = [t.clone() for t in (plan.pos_g, plan.dst_g, plan.src_g, plan.meta_g)]
+    plan._build_groups(radix=True)
+    for a, b in zip(one_launch, (plan.pos_g, plan.dst_g, plan.src_g, plan.meta_g)):
+        assert torch.equal(a[:E], b[:E]) if a.numel() != 2 * plan.capacity else torch.equal(a[:2 * E], b[:2 * E])
+    plan._build_groups()
     # an in-place rebuild on another edge list refreshes the group order too
     nbrs2 = torch.randint(0, n, (E + 7, 2), generator=gen)
     plan.rebuild_from_nbrs(nbrs2.to(DEV))
