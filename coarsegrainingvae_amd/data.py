@@ -85,12 +85,17 @@ def copy_batch_into(dst: Dict[str, torch.Tensor], src: Dict[str, torch.Tensor]) 
     if not g.fits(src["nxyz"][:, 1:], src["CG_nxyz"][:, 1:], src["CG_mapping"], src["nbr_list"], src["CG_nbr_list"]):
         return False
     dev = dst["nxyz"].device
+
+    def staged(t):
+        # a pageable host tensor would make every copy wait for the device to drain (the previous replay): go through
+        # pinned memory and let the copy queue behind it instead -- the host then prepares batch k+1 while step k runs
+        return t.pin_memory() if (not t.is_cuda and dev.type == "cuda") else t
     for k in _MOVING_KEYS:
-        dst[k].copy_(src[k])
+        dst[k].copy_(staged(src[k]), non_blocking=True)
     from .graph import make_directed
     # make_directed reads two flags back: on a host list that costs nothing, on a device list it waits for the GPU
-    atom_nbrs = make_directed(src["nbr_list"])[0].to(dev)
-    cg_nbrs = make_directed(src["CG_nbr_list"])[0].to(dev)
+    atom_nbrs = staged(make_directed(src["nbr_list"])[0]).to(dev, non_blocking=True)
+    cg_nbrs = staged(make_directed(src["CG_nbr_list"])[0]).to(dev, non_blocking=True)
     g.update(dst["nxyz"][:, 1:], dst["CG_nxyz"][:, 1:], atom_nbrs, cg_nbrs, directed=True)
     dst["nbr_list"], dst["CG_nbr_list"] = src["nbr_list"], src["CG_nbr_list"]
     return True
