@@ -1104,3 +1104,36 @@ def test_tile_layer_backward_under_the_trainer_queue_vs_fp64(M, K, N):
     assert_close(x.grad, 2 * x64.grad, "grad x (two passes)", 2e-6)
     assert_close(layer.weight.grad, 2 * W64.grad, "grad W (write + accumulate)", 2e-6)
     assert_close(layer.bias.grad, 2 * b64.grad, "grad b (write + accumulate)", 2e-6)
+
+
+def test_shared_source_forward_at_full_size_properties():
+    """BASELINE configs[4] size (2000 atoms, 851k directed edges, F = 600, n_rbf = 10): too large for the CPU oracle in
+    a test, so size-independent properties -- the shared-source walk equals the per-receiver kernel (itself
+    oracle-checked at small sizes), is linear in phi, and summing the outputs over receivers equals the edge-wise
+    total computed from the plan (a checksum that does not depend on the segment structure)."""
+    from coarsegrainingvae_amd import ops
+    w = cg.data.WORKLOADS["protein2000"]
+    g = cg.synthetic_batch("protein2000", seed=1, device=DEV)["_graph"]
+    plan = g.atom
+    assert plan.group_rb == 2 and plan.n_edges > 800000
+    F, R = 600, w["n_rbf"]
+    geom = g.geometry("atom", R, w["cg_cutoff"])
+    gen = torch.Generator().manual_seed(0)
+    phi, v = torch.randn(plan.n_src, 3 * F, generator=gen).to(DEV), torch.randn(plan.n_src, F, 3, generator=gen).to(DEV)
+    Wd, bd = torch.randn(3 * F, R, generator=gen).to(DEV), torch.randn(3 * F, generator=gen).to(DEV)
+    ds, dv = ops.equi_message(phi, v, Wd, bd, plan, geom, True)
+    plain = EdgePlan.from_nbrs(g.atom_nbrs, plan.n_dst)
+    g_plain = EdgeGeometry(plain, R, w["cg_cutoff"], pos_dst=g.xyz, pos_src=g.xyz)
+    ds_p, dv_p = ops.equi_message(phi, v, Wd, bd, plain, g_plain, True)
+    assert_close(ds, ds_p, "ds vs per-receiver kernel", 5e-6)
+    assert_close(dv, dv_p, "dv vs per-receiver kernel", 5e-6)
+    ds2, dv2 = ops.equi_message(-2.0 * phi, v, Wd, bd, plan, geom, True)
+    assert_close(ds2, -2.0 * ds, "linearity in phi (ds)", 1e-6)
+    assert_close(dv2, -2.0 * dv, "linearity in phi (dv)", 1e-6)
+    # checksum: sum_i ds[i, f] = sum_e phi[src_e, F + f] * w_1(e, f), evaluated edge-wise in fp64 on a channel subset
+    E = plan.n_edges
+    ch = torch.arange(0, F, 97, device=DEV)
+    rec = geom.geom_d[:E].double()
+    w1 = rec[:, :R] @ Wd[F + ch].double().t() + rec[:, R:R + 1] * bd[F + ch].double()[None, :]
+    total = (phi[plan.src_d[:E].long()][:, F + ch].double() * w1).sum(0)
+    assert_close(ds[:, ch].double().sum(0), total, "column checksum of ds", 1e-5)
