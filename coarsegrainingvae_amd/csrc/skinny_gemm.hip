@@ -488,6 +488,111 @@ __global__ __launch_bounds__(256) void gathered_wgrad_k(const WgradProblem* __re
   }
 }
 
+// The same with 128 x 128 output tiles (waves as a 2 x 2 grid of 64 x 64 quadrants: 4 row tiles x one 64-column group
+// each): every staged operand row feeds twice the MFMAs, so the L2 -> LDS traffic per gW element halves.  Measured
+// SLOWER than the 64 x 64 kernel on every workload (fewer, bigger blocks: 3 per CU; see primitives.wgrad_tile): opt-in.
+constexpr int GW2_CHUNK = 32;
+constexpr int GW2_GS = 144, GW2_XS = 128;
+
+__global__ __launch_bounds__(256) void gathered_wgrad128_k(const WgradProblem* __restrict__ table, int n_problems) {
+  __shared__ __attribute__((aligned(16))) float gs[GW2_CHUNK * GW2_GS];
+  __shared__ __attribute__((aligned(16))) float xs[GW2_CHUNK * GW2_XS];
+  int lo = 0, hi = n_problems - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid].block_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const WgradProblem pr = table[lo];
+  const int local = blockIdx.x - pr.block_begin;
+  const int nb = local / pr.tiles_k, kt = local - nb * pr.tiles_k;
+  const int M = pr.M, N = pr.N, K = pr.K;
+  const int sr = pr.seg_rows > 0 ? pr.seg_rows : M;
+  const int n0 = nb * 128, k0 = kt * 128;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wn = wave >> 1, wk = wave & 1;                          // quadrant: rows n0 + 64 wn .., columns k0 + 64 wk ..
+  const int i = lane & 15, q = lane >> 4;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  const int c4 = threadIdx.x & 31, rr = threadIdx.x >> 5;           // staging: 32 float4 columns x 8 rows per pass
+  const bool gcol = n0 + 4 * c4 < N, xcol = k0 + 4 * c4 < K;
+  constexpr int NP = GW2_CHUNK / 8;
+  float4 gq[NP], xq[NP];
+  auto chunk_load = [&](int m0) {
+    const int rows = min(GW2_CHUNK, M - m0);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int r = rr + 8 * p;
+      const bool ok = r < rows;
+      const int m = m0 + (ok ? r : 0);
+      const int seg = m / sr, row = m - seg * sr;
+      const size_t base = (size_t)seg * pr.seg_stride;
+      gq[p] = ldg4_or_zero(pr.gy + base + (size_t)row * N + (gcol ? n0 + 4 * c4 : 0), ok && gcol);
+      if (pr.act) {
+        const float4 zz = ldg4_or_zero(pr.z + base + (size_t)row * N + (gcol ? n0 + 4 * c4 : 0), ok && gcol);
+        gq[p].x *= act_bwd(zz.x, pr.act); gq[p].y *= act_bwd(zz.y, pr.act);
+        gq[p].z *= act_bwd(zz.z, pr.act); gq[p].w *= act_bwd(zz.w, pr.act);
+      }
+      xq[p] = ldg4_or_zero(pr.x + base + (size_t)row * K + (xcol ? k0 + 4 * c4 : 0), ok && xcol);
+    }
+  };
+  chunk_load(0);
+  for (int m0 = 0; m0 < M; m0 += GW2_CHUNK) {
+    const int rows = min(GW2_CHUNK, M - m0);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      *reinterpret_cast<float4*>(gs + (rr + 8 * p) * GW2_GS + 4 * c4) = gq[p];
+      *reinterpret_cast<float4*>(xs + (rr + 8 * p) * GW2_XS + 4 * c4) = xq[p];
+    }
+    __syncthreads();
+    if (m0 + GW2_CHUNK < M) chunk_load(m0 + GW2_CHUNK);
+    const int steps = (rows + 3) / 4;
+#pragma unroll 2
+    for (int st = 0; st < steps; ++st) {
+      const float4 b = *reinterpret_cast<const float4*>(xs + (4 * st + q) * GW2_XS + 64 * wk + 4 * i);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float a = gs[(4 * st + q) * GW2_GS + 64 * wn + 16 * t + i];
+        bsum[t] += a;
+        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.x, acc[t][0], 0, 0, 0);
+        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.y, acc[t][1], 0, 0, 0);
+        acc[t][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.z, acc[t][2], 0, 0, 0);
+        acc[t][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.w, acc[t][3], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  const int kcol = k0 + 64 * wk + 4 * i;
+  if (kcol < K) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = n0 + 64 * wn + 16 * t + 4 * q + r;
+        if (row >= N) continue;
+        float4* dst = reinterpret_cast<float4*>(pr.gW + (size_t)row * K + kcol);
+        float4 o = make_float4(acc[t][0][r], acc[t][1][r], acc[t][2][r], acc[t][3][r]);
+        if (pr.accumulate) { const float4 old = *dst; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+        *dst = o;
+      }
+  }
+  if (pr.gb && kt == 0 && wk == 0) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float b = bsum[t];
+      b += __shfl_xor(b, 16);
+      b += __shfl_xor(b, 32);
+      const int n = n0 + 64 * wn + 16 * t + i;
+      if (q == 0 && n < N) pr.gb[n] = pr.accumulate ? pr.gb[n] + b : b;
+    }
+  }
+}
+
 // Packs the operands of queued weight-gradient problems into one contiguous send buffer:
 //   dst_g[M,N] = gy * act'(z)      dst_x[M,K] = x        (float4 granularity; N % 4 == 0, K % 4 == 0)
 struct PackProblem {        // mirrors the 64-byte host record built in python (trainer.OperandExchange)
@@ -695,20 +800,35 @@ int cgv_grouped_wgrad(const void* table_dev, int n_problems, int total_blocks, i
 
 /* Weight gradients over gathered operand rows (include/cgvae_hip.h: data-parallel operand exchange). */
 int cgv_wgrad_gathered_plan(int M, int N, int K, int seg_rows, int* tiles_k, int* n_blocks) {
+  return cgv_wgrad_gathered_plan_tile(M, N, K, seg_rows, 64, tiles_k, n_blocks);
+}
+
+/* tile = 64 or 128: output tile edge of the launch (one value per launch, see cgv_grouped_wgrad_gathered_tile) */
+int cgv_wgrad_gathered_plan_tile(int M, int N, int K, int seg_rows, int tile, int* tiles_k, int* n_blocks) {
   CGV_REQUIRE(tiles_k && n_blocks, "null pointer");
   CGV_REQUIRE(M >= 1 && N >= 4 && K >= 4 && (N % 4) == 0 && (K % 4) == 0, "unsupported shape (need N % 4 == 0, K % 4 == 0)");
   CGV_REQUIRE(seg_rows == 0 || (seg_rows > 0 && seg_rows % 4 == 0), "rank segments must hold a multiple of 4 rows");
-  *tiles_k = (K + 63) / 64;
-  *n_blocks = ((N + 63) / 64) * *tiles_k;
+  CGV_REQUIRE(tile == 64 || tile == 128, "tile must be 64 or 128");
+  *tiles_k = (K + tile - 1) / tile;
+  *n_blocks = ((N + tile - 1) / tile) * *tiles_k;
   return 0;
 }
 
 int cgv_grouped_wgrad_gathered(const void* table_dev, int n_problems, int total_blocks, void* stream) {
+  return cgv_grouped_wgrad_gathered_tile(table_dev, n_problems, total_blocks, 64, stream);
+}
+
+int cgv_grouped_wgrad_gathered_tile(const void* table_dev, int n_problems, int total_blocks, int tile, void* stream) {
   CGV_REQUIRE(n_problems >= 0 && total_blocks >= 0, "bad size");
+  CGV_REQUIRE(tile == 64 || tile == 128, "tile must be 64 or 128");
   if (n_problems == 0 || total_blocks == 0) return 0;
   CGV_REQUIRE(table_dev, "null table");
-  hipLaunchKernelGGL(cgv::gathered_wgrad_k, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
-                     reinterpret_cast<const cgv::WgradProblem*>(table_dev), n_problems);
+  if (tile == 128)
+    hipLaunchKernelGGL(cgv::gathered_wgrad128_k, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const cgv::WgradProblem*>(table_dev), n_problems);
+  else
+    hipLaunchKernelGGL(cgv::gathered_wgrad_k, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const cgv::WgradProblem*>(table_dev), n_problems);
   return cgv::check_launch("cgv_grouped_wgrad_gathered");
 }
 

@@ -163,17 +163,18 @@ class WeightGradQueue:
                       tag="grouped_wgrad")
         if large:
             buf, block_begin = bytearray(), 0
+            tile = wgrad_tile([(gy.shape[0], gy.shape[1], x.shape[1]) for gy, x, *_rest in large])
             for gy, x, z, act, gW, gb, accumulate in large:
                 M, N = gy.shape
                 K = x.shape[1]
-                if lib.cgv_wgrad_gathered_plan(M, N, K, 0, C.byref(tk), C.byref(nb)) != 0:
+                if lib.cgv_wgrad_gathered_plan_tile(M, N, K, 0, tile, C.byref(tk), C.byref(nb)) != 0:
                     raise RuntimeError(lib.cgv_last_error_string().decode())
                 buf += self.RECORD.pack(gy.data_ptr(), x.data_ptr(), z.data_ptr() if z is not None else 0, gW.data_ptr(),
                                         gb.data_ptr() if gb is not None else 0, M, N, K, int(accumulate), int(act),
                                         block_begin, tk.value, 0, 0, 0, 0)
                 block_begin += nb.value
             table = self.upload(bytes(buf), dev)
-            _lib.call("cgv_grouped_wgrad_gathered", _lib.ptr(table), len(large), block_begin, _lib.stream_ptr(),
+            _lib.call("cgv_grouped_wgrad_gathered_tile", _lib.ptr(table), len(large), block_begin, tile, _lib.stream_ptr(),
                       tag="grouped_wgrad_tiles")
         # the operand tensors stay referenced by ``items`` until here; stream order protects their reuse
 
@@ -325,6 +326,15 @@ class _LinearFn(torch.autograd.Function):
             if not (wgrad_queue.active and gw is None and gb is None):
                 wgrad_queue.flush()                          # immediate mode (no trainer / not arena-managed)
         return gx, gw, gb, None
+
+
+def wgrad_tile(shapes) -> int:
+    """Output tile edge of one grouped MFMA weight-gradient launch: 64.  The 128 x 128 variant (gathered_wgrad128_k: half
+    the operand traffic per gW element, 3 instead of 5 blocks per CU) measured slower on every workload -- gathered
+    launches at 8 ranks 265 vs 226 us, atom-level layers 179 vs 101 us, dipeptide step 3.29 vs 3.26 ms -- and stays behind
+    ``CGV_WGRAD_TILE=128`` with its parity test."""
+    import os
+    return 128 if os.environ.get("CGV_WGRAD_TILE") == "128" else 64
 
 
 def _library_pays(M, N, K, forward: bool) -> bool:

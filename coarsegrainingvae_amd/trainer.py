@@ -254,10 +254,12 @@ class OperandExchange:
         buf, block_begin, n = bytearray(), 0, 0
         tk, nb = C.c_int(), C.c_int()
         dev = self.inflight[0][2].device
+        from .primitives import wgrad_tile
+        tile = wgrad_tile([(self.world * m[0], m[1], m[2]) for _w, metas, *_r in self.inflight for m in metas])
         for work, metas, recv, _send, total in self.inflight:
             work.wait()                                      # the current stream now waits for the gather
             for M, N, K, off_g, off_x, gW, gb, accumulate in metas:
-                if lib.cgv_wgrad_gathered_plan(self.world * M, N, K, M, C.byref(tk), C.byref(nb)) != 0:
+                if lib.cgv_wgrad_gathered_plan_tile(self.world * M, N, K, M, tile, C.byref(tk), C.byref(nb)) != 0:
                     raise RuntimeError(lib.cgv_last_error_string().decode())
                 buf += rec.pack(recv.data_ptr() + 4 * off_g, recv.data_ptr() + 4 * off_x, 0, gW.data_ptr(),
                                 gb.data_ptr() if gb is not None else 0, self.world * M, N, K, int(accumulate), 0,
@@ -267,7 +269,8 @@ class OperandExchange:
         if n > self.queue.MAX_PROBLEMS:
             raise RuntimeError("too many gathered weight-gradient problems")
         table = self.queue.upload(bytes(buf), dev)
-        _lib.call("cgv_grouped_wgrad_gathered", _lib.ptr(table), n, block_begin, _lib.stream_ptr(), tag="gathered_wgrad")
+        _lib.call("cgv_grouped_wgrad_gathered_tile", _lib.ptr(table), n, block_begin, tile, _lib.stream_ptr(),
+                  tag="gathered_wgrad")
         self.inflight = []                                   # buffers: stream order protects their reuse
 
 

@@ -311,6 +311,10 @@ int cgv_grouped_wgrad(const void* table_dev, int n_problems, int total_blocks, i
  *     fp32 MFMA chains in a fixed order: every rank obtains bit-identical gradients. */
 int cgv_wgrad_gathered_plan(int M, int N, int K, int seg_rows, int* tiles_k /*[host]*/, int* n_blocks /*[host]*/);
 int cgv_grouped_wgrad_gathered(const void* table_dev, int n_problems, int total_blocks, void* stream);
+/* tile = 64 | 128: edge of the output tiles (records planned with the same tile); 128 x 128 halves the operand traffic
+ * per gW element but measured slower on the shapes of this model -- an opt-in variant */
+int cgv_wgrad_gathered_plan_tile(int M, int N, int K, int seg_rows, int tile, int* tiles_k /*[host]*/, int* n_blocks /*[host]*/);
+int cgv_grouped_wgrad_gathered_tile(const void* table_dev, int n_problems, int total_blocks, int tile, void* stream);
 int cgv_pack_record_bytes(void);
 int cgv_pack_plan(int M, int N, int K, int* n_blocks /*[host]*/);
 int cgv_pack_operands(const void* table_dev, int n_problems, int total_blocks, void* stream);

@@ -113,10 +113,11 @@ def test_operand_exchange_inside_a_captured_step():
     assert _worst(got, ref) < 2e-5
 
 
+@pytest.mark.parametrize("tile", [64, 128])
 @pytest.mark.parametrize("world,M,N,K,act,bias,accumulate", [(8, 12, 600, 600, 1, True, False), (2, 36, 1200, 600, 0, False, False),
                                                              (3, 4, 68, 132, 2, True, True), (8, 12, 5400, 600, 0, True, False),
                                                              (5, 96, 64, 64, 3, True, False)])
-def test_pack_and_gathered_wgrad_vs_fp64(world, M, N, K, act, bias, accumulate):
+def test_pack_and_gathered_wgrad_vs_fp64(world, M, N, K, act, bias, accumulate, tile):
     """Different rows on every 'rank': pack each rank's operands, lay the send buffers out as an all-gather would,
     and compare the gathered launch with the fp64 gradient of the concatenated rows."""
     import ctypes as C
@@ -147,11 +148,11 @@ def test_pack_and_gathered_wgrad_vs_fp64(world, M, N, K, act, bias, accumulate):
     gb0 = torch.randn(N, generator=gen)
     gW, gb = gW0.to(DEV), gb0.to(DEV)
     tk, nb = C.c_int(), C.c_int()
-    assert lib.cgv_wgrad_gathered_plan(world * M, N, K, M, C.byref(tk), C.byref(nb)) == 0
+    assert lib.cgv_wgrad_gathered_plan_tile(world * M, N, K, M, tile, C.byref(tk), C.byref(nb)) == 0
     rec = wgrad_queue.RECORD.pack(recv.data_ptr(), recv.data_ptr() + 4 * pad(M * N), 0, gW.data_ptr(),
                                   gb.data_ptr() if bias else 0, world * M, N, K, int(accumulate), 0, 0, tk.value, 0, M, total, 0)
     table = wgrad_queue.upload(rec, torch.device(DEV))
-    _lib.call("cgv_grouped_wgrad_gathered", _lib.ptr(table), 1, nb.value, _lib.stream_ptr())
+    _lib.call("cgv_grouped_wgrad_gathered_tile", _lib.ptr(table), 1, nb.value, tile, _lib.stream_ptr())
     torch.cuda.synchronize()
     want_W = g64.t() @ x64 + (gW0.double() if accumulate else 0)
     want_b = g64.sum(0) + (gb0.double() if accumulate else 0)
