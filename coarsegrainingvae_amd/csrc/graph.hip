@@ -6,6 +6,7 @@
 // destination- and source-sorted CSR views so the fused kernels reduce without atomics.
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <stdlib.h>
 #include "cgv_common.h"
 
 namespace cgv {
@@ -271,6 +272,77 @@ __global__ __launch_bounds__(256) void grp_build_k(const int* __restrict__ rowpt
   }
 }
 
+
+// ------------------------------------------------------------------ K7 by rows (few launches)
+// The same sorted view -- edges ordered by (row, partner, edge id) -- from five launches instead of the ~23 of two radix
+// passes (the CLI's per-batch preparation is launch bound): count the rows' lengths, scan them into rowptr, drop every
+// edge into its row in arbitrary order, then a block per row ranks the row's unique (partner, edge id) keys in LDS.
+// Deterministic: the final position of an edge depends on the keys only.
+__device__ __forceinline__ int csr_key_of(const int64_t* key, int stride, int e) { return key ? (int)key[(int64_t)e * stride] : e; }
+
+__global__ void csr_count_k(const int64_t* __restrict__ key, int stride, int n, int* __restrict__ count) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) atomicAdd(count + csr_key_of(key, stride, e), 1);
+}
+__global__ void csr_drop_k(const int64_t* __restrict__ key, int stride, int n, const int* __restrict__ rowptr,
+                           int* __restrict__ count, int* __restrict__ tmp) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const int r = csr_key_of(key, stride, e);
+  tmp[rowptr[r] + atomicSub(count + r, 1) - 1] = e;            // the row's slots are handed out last to first
+}
+constexpr int CSR_LDS_KEYS = 2048;
+__global__ __launch_bounds__(128) void csr_row_sort_k(const int64_t* __restrict__ other, int stride,
+                                                      const int* __restrict__ rowptr, const int* __restrict__ tmp,
+                                                      int* __restrict__ eid, int* __restrict__ key_sorted,
+                                                      int* __restrict__ other_sorted, unsigned long long* spill) {
+  __shared__ unsigned long long keys[CSR_LDS_KEYS];
+  const int r = blockIdx.x;
+  const int beg = rowptr[r], L = rowptr[r + 1] - beg;
+  if (L <= 0) return;
+  unsigned long long* k = L <= CSR_LDS_KEYS ? keys : spill + beg;
+  for (int t = threadIdx.x; t < L; t += blockDim.x) {
+    const int e = tmp[beg + t];
+    const unsigned partner = (unsigned)(other ? (int)other[(int64_t)e * stride] : e);
+    k[t] = ((unsigned long long)partner << 32) | (unsigned)e;
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < L; t += blockDim.x) {
+    const unsigned long long mine = k[t];
+    int rank = 0;
+    for (int u = 0; u < L; ++u) rank += k[u] < mine;
+    eid[beg + rank] = (int)(unsigned)(mine & 0xffffffffull);
+    other_sorted[beg + rank] = (int)(mine >> 32);
+    key_sorted[beg + rank] = r;
+  }
+}
+
+static size_t rows_view_bytes(int E, int n_rows_max) {
+  return align256(sizeof(int) * ((size_t)n_rows_max + 1)) + align256(sizeof(int) * (size_t)(E > 0 ? E : 1)) +
+         align256(sizeof(unsigned long long) * (size_t)(E > 0 ? E : 1));
+}
+
+static int rows_view(const int64_t* key, const int64_t* other, int stride, int E, int n_rows, int* rowptr, int* eid,
+                     int* key_sorted, int* other_sorted, char* ws, hipStream_t st) {
+  int* count = reinterpret_cast<int*>(ws);
+  int* tmp = reinterpret_cast<int*>(ws + align256(sizeof(int) * ((size_t)n_rows + 1)));
+  unsigned long long* spill = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(tmp) + align256(sizeof(int) * (size_t)(E > 0 ? E : 1)));
+  const int T = 256, B = (E + T - 1) / T;
+  hipError_t err = hipMemsetAsync(count, 0, sizeof(int) * ((size_t)n_rows + 1), st);
+  if (err != hipSuccess) {
+    set_error("cgv_csr_build: memset failed: %s", hipGetErrorString(err));
+    return (int)err;
+  }
+  if (E > 0) hipLaunchKernelGGL(csr_count_k, dim3(B), dim3(T), 0, st, key, stride, E, count);
+  hipLaunchKernelGGL(exclusive_scan_i32, dim3(1), dim3(1024), 0, st, count, rowptr, n_rows);
+  if (E > 0) {
+    hipLaunchKernelGGL(csr_drop_k, dim3(B), dim3(T), 0, st, key, stride, E, rowptr, count, tmp);
+    hipLaunchKernelGGL(csr_row_sort_k, dim3(n_rows), dim3(128), 0, st, other, stride, rowptr, tmp, eid, key_sorted,
+                       other_sorted, spill);
+  }
+  return check_launch("cgv_csr_build");
+}
+
 }  // namespace cgv
 
 extern "C" {
@@ -296,9 +368,12 @@ int cgv_radius_graph_emit(const float* xyz, const int32_t* frame_ptr, int n_fram
 }
 
 size_t cgv_csr_workspace_bytes(int n_edges) {
+  // n_edges: pass max(edges, destination rows, source rows) -- the by-rows construction keeps one counter per row
   size_t temp = 0;
   if (cgv::sort_temp_bytes(n_edges, &temp) != hipSuccess) temp = (size_t)n_edges * 16 + (1 << 20);
-  return 2 * cgv::align256(sizeof(int) * (size_t)(n_edges > 0 ? n_edges : 1)) + cgv::align256(temp) + 256;
+  const size_t radix = 2 * cgv::align256(sizeof(int) * (size_t)(n_edges > 0 ? n_edges : 1)) + cgv::align256(temp) + 256;
+  const size_t rows = cgv::rows_view_bytes(n_edges, n_edges) + 256;
+  return radix > rows ? radix : rows;
 }
 
 int cgv_csr_build(const int64_t* dst, const int64_t* src, int stride, int n_edges, int n_dst, int n_src,
@@ -307,12 +382,22 @@ int cgv_csr_build(const int64_t* dst, const int64_t* src, int stride, int n_edge
   CGV_REQUIRE(n_edges >= 0 && n_dst >= 0 && n_src >= 0 && stride >= 1, "bad size");
   CGV_REQUIRE(rowptr_d && rowptr_s && workspace, "null output");
   CGV_REQUIRE(n_edges == 0 || (dst && eid_d && dst_d && src_d && eid_s && dst_s && src_s), "null edge array");
+  hipStream_t st = (hipStream_t)stream;
+  char* ws = reinterpret_cast<char*>(workspace);
+  // by rows (5 launches per view) when the workspace has room for the row counters; CGV_CSR_BUILD=radix forces the
+  // two-radix-pass construction (tests compare the two)
+  const int rows_max = n_dst > n_src ? n_dst : n_src;
+  bool by_rows = workspace_bytes >= cgv::rows_view_bytes(n_edges, rows_max) && (((uintptr_t)workspace) & 7) == 0;
+  if (const char* dbg = getenv("CGV_CSR_BUILD")) by_rows = by_rows && dbg[0] != 'r';
+  if (by_rows) {
+    int rc = cgv::rows_view(dst, src, stride, n_edges, n_dst, rowptr_d, eid_d, dst_d, src_d, ws, st);
+    if (rc) return rc;
+    return cgv::rows_view(src, dst, stride, n_edges, n_src, rowptr_s, eid_s, src_s, dst_s, ws, st);
+  }
   if (workspace_bytes < cgv_csr_workspace_bytes(n_edges)) {
     cgv::set_error("cgv_csr_build: workspace too small");
     return CGV_E_WORKSPACE;
   }
-  hipStream_t st = (hipStream_t)stream;
-  char* ws = reinterpret_cast<char*>(workspace);
   int rc = cgv::sorted_view(dst, src, stride, n_edges, n_dst, n_src, rowptr_d, eid_d, dst_d, src_d, ws, workspace_bytes, st);
   if (rc) return rc;
   return cgv::sorted_view(src, dst, stride, n_edges, n_src, n_dst, rowptr_s, eid_s, src_s, dst_s, ws, workspace_bytes, st);

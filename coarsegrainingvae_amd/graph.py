@@ -120,7 +120,7 @@ class EdgePlan:
 
     def _build(self, dst, src, stride):
         lib = _lib.load()
-        ws_bytes = int(lib.cgv_csr_workspace_bytes(self.n_edges))
+        ws_bytes = int(lib.cgv_csr_workspace_bytes(max(self.n_edges, self.n_dst, self.n_src) + 1))      # rows need counters too
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
         _lib.call("cgv_csr_build", _lib.ptr(dst), _lib.ptr(src), stride, self.n_edges, self.n_dst, self.n_src,
                   _lib.ptr(self.rowptr_d), _lib.ptr(self.eid_d), _lib.ptr(self.dst_d), _lib.ptr(self.src_d),

@@ -88,6 +88,9 @@ int cgv_radius_graph_emit(const float* xyz, const int32_t* frame_ptr, int n_fram
  * dst/src are int64 arrays read with element stride `stride` (nbrs[E,2]: dst=nbrs,
  * src=nbrs+1, stride=2).  src == NULL means src[e] = e (atom->bead contraction with
  * dst = CG_mapping, conv.py:725-731).
+ * Construction: by rows -- count, scan, drop, one block per row ranks its unique (partner, edge id) keys: 5 launches per
+ * view -- when the workspace (size it with cgv_csr_workspace_bytes(max(E, Nd, Ns) + 1)) has room for the row counters;
+ * otherwise two stable radix passes per view.  Both give the same arrays.
  * ------------------------------------------------------------------------------------- */
 size_t cgv_csr_workspace_bytes(int n_edges);
 int cgv_csr_build(const int64_t* dst, const int64_t* src, int stride, int n_edges, int n_dst, int n_src,

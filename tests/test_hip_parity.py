@@ -1137,3 +1137,21 @@ def test_shared_source_forward_at_full_size_properties():
     w1 = rec[:, :R] @ Wd[F + ch].double().t() + rec[:, R:R + 1] * bd[F + ch].double()[None, :]
     total = (phi[plan.src_d[:E].long()][:, F + ch].double() * w1).sum(0)
     assert_close(ds[:, ch].double().sum(0), total, "column checksum of ds", 1e-5)
+
+
+@pytest.mark.parametrize("n,E", [(37, 900), (5, 0), (3, 5000), (400, 300), (166, 21000)])
+def test_csr_by_rows_equals_the_radix_construction(n, E, monkeypatch):
+    """K7: the few-launch by-rows construction and the two-radix-pass one give identical arrays (dense rows beyond the
+    LDS key budget, empty rows, no edges, mapping plans)."""
+    gen = torch.Generator().manual_seed(n * 7 + E)
+    nbrs = torch.randint(0, n, (E, 2), generator=gen).to(DEV)
+    mapping = torch.randint(0, max(n // 3, 1), (n,), generator=gen).to(DEV)
+    fields = ("rowptr_d", "eid_d", "dst_d", "src_d", "rowptr_s", "eid_s", "dst_s", "src_s")
+    rows = (EdgePlan.from_nbrs(nbrs, n), EdgePlan.from_mapping(mapping, max(n // 3, 1)))
+    monkeypatch.setenv("CGV_CSR_BUILD", "radix")
+    radix = (EdgePlan.from_nbrs(nbrs, n), EdgePlan.from_mapping(mapping, max(n // 3, 1)))
+    for a, b in zip(rows, radix):
+        for f in fields:
+            x, y = getattr(a, f), getattr(b, f)
+            m = a.n_edges if not f.startswith("rowptr") else x.numel()
+            assert torch.equal(x[:m], y[:m]), f
