@@ -324,17 +324,31 @@ __global__ __launch_bounds__(576) void pseudo_bwd_src_k(
   }
 }
 
-__global__ __launch_bounds__(256) void pseudo_bwd_reduce(const float* __restrict__ part, int n_chunks, int R, int F,
-                                                         float* __restrict__ gWd, float* __restrict__ gbd) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+// gWd[c][n] = sum over chunks of part[chunk][k][n][f] (c = k F + f), gbd likewise for n = R.  Block = 64 channels x 4
+// chunk slices: slice s sums chunks s, s+4, ... and the four partial sums meet in LDS in slice order (deterministic);
+// the serial version (one thread per output walking all 64 chunks of a 96-bead batch) took 17.8 us per layer.
+constexpr int PRED_SLICES = 4;
+__global__ __launch_bounds__(64 * PRED_SLICES) void pseudo_bwd_reduce(const float* __restrict__ part, int n_chunks, int R,
+                                                                      int F, float* __restrict__ gWd,
+                                                                      float* __restrict__ gbd) {
+  __shared__ float red[PRED_SLICES][64];
+  const int f = blockIdx.x * 64 + threadIdx.x;
+  const int sl = threadIdx.y;
   const int n = blockIdx.y, k = blockIdx.z;
-  if (f >= F) return;
-  const size_t stride = (size_t)9 * (R + 1) * F;
-  const float* p = part + ((size_t)k * (R + 1) + n) * F + f;
   float acc = 0.f;
-  for (int c = 0; c < n_chunks; ++c) acc += p[c * stride];
+  if (f < F) {
+    const size_t stride = (size_t)9 * (R + 1) * F;
+    const float* p = part + ((size_t)k * (R + 1) + n) * F + f;
+    for (int c = sl; c < n_chunks; c += PRED_SLICES) acc += p[(size_t)c * stride];
+  }
+  red[sl][threadIdx.x] = acc;
+  __syncthreads();
+  if (sl != 0 || f >= F) return;
+  float tot = 0.f;
+#pragma unroll
+  for (int t = 0; t < PRED_SLICES; ++t) tot += red[t][threadIdx.x];
   const int c_out = k * F + f;
-  if (n < R) gWd[(size_t)c_out * R + n] = acc; else gbd[c_out] = acc;
+  if (n < R) gWd[(size_t)c_out * R + n] = tot; else gbd[c_out] = tot;
 }
 
 static inline int pseudo_chunks(int n) {
@@ -391,8 +405,8 @@ int cgv_pseudo_msg_bwd(const float* phi, const float* s, const float* sbar, cons
     hipLaunchKernelGGL((cgv::pseudo_bwd_src_k<RBF>), gridB, dim3(576), 0, st, phi, s, sbar, v, vbar, geom_s, rowptr_s,
                        dst_s, Wd, bd, gh, ghbar, gv, gvbar, g_phi, g_v, g_vbar, part, n_feat, n_nodes, npc);
   });
-  dim3 rgrid((n_feat + 255) / 256, n_rbf + 1, 9);
-  hipLaunchKernelGGL(cgv::pseudo_bwd_reduce, rgrid, dim3(256), 0, st, part, chunks, n_rbf, n_feat, gWd, gbd);
+  dim3 rgrid((n_feat + 63) / 64, n_rbf + 1, 9);
+  hipLaunchKernelGGL(cgv::pseudo_bwd_reduce, rgrid, dim3(64, cgv::PRED_SLICES), 0, st, part, chunks, n_rbf, n_feat, gWd, gbd);
   return cgv::check_launch("cgv_pseudo_msg_bwd");
 }
 
