@@ -375,6 +375,24 @@ def _adjacent(first, second):
             and second.data_ptr() == first.data_ptr() + first.numel() * first.element_size())
 
 
+def _dense_fwd(x, W, b, y, z, M, N, K, act, st):
+    """z = x W^T + b, y = act(z) on the kernel the Dense layers would pick for this shape (primitives._gemm_mode)."""
+    lib = _lib.load()
+    name = "cgv_skinny_linear_fwd" if lib.cgv_skinny_supported(M, N, K) else "cgv_tile_linear_fwd"
+    _lib.call(name, _lib.ptr(x) if torch.is_tensor(x) else x, _lib.ptr(W), _lib.ptr(b), _lib.ptr(y) if torch.is_tensor(y) else y,
+              _lib.ptr(z), M, N, K, act, st)
+
+
+def _dense_bwd_input(gy, z, W, gx, M, N, K, act, st):
+    """gx = (gy * act'(z)) W: row-split kernel up to 64 rows (and for few rows x very long reductions), tile kernel above."""
+    lib = _lib.load()
+    if lib.cgv_skinny_supported(M, N, K) or (M <= 128 and N >= 4096 and lib.cgv_skinny_bwd_input_supported(M, N, K)):
+        skinny_bwd_input(gy, z, W, gx, M, N, K, act, st)
+    else:
+        _lib.call("cgv_tile_linear_bwd_input_act", _lib.ptr(gy), _lib.ptr(z) if act else None, _lib.ptr(W), _lib.ptr(gx),
+                  M, N, K, act, st)
+
+
 class _UpdateBlockFused(torch.autograd.Function):
     """Whole UpdateBlock (conv.py:588-616, + the residual adds of cgvae.py:122-123) as ONE autograd
     node with a hand-written backward: 6 launches forward, 6 backward (the tensor-op composition
@@ -391,8 +409,8 @@ class _UpdateBlockFused(torch.autograd.Function):
             return False
         n, F = s.shape
         lib = _lib.load()
-        if not (lib.cgv_skinny_supported(3 * n, 2 * F, F) and lib.cgv_skinny_supported(n, F, 2 * F)
-                and lib.cgv_skinny_supported(n, 3 * F, F)):
+        ok = lambda M, N, K: lib.cgv_skinny_supported(M, N, K) or lib.cgv_tile_supported(M, N, K)     # any bead count
+        if not (ok(3 * n, 2 * F, F) and ok(n, F, 2 * F) and ok(n, 3 * F, F)):
             return False
         if not isinstance(d0.activation, Swish) or d1.activation is not None or d0.dropout_rate or d1.dropout_rate:
             return False
@@ -412,12 +430,11 @@ class _UpdateBlockFused(torch.autograd.Function):
         z0, a0, a = new(n, F), new(n, F), new(n, 3 * F)
         ds, dv = new(n, F), new(n, F, 3)
         _lib.call("cgv_update_rows_from_vec", _lib.ptr(v), _lib.ptr(vt), n, F, st)
-        _lib.call("cgv_skinny_linear_fwd", _lib.ptr(vt), _lib.ptr(Wuv), None, _lib.ptr(UV), None, 3 * n, 2 * F, F, 0, st)
+        _dense_fwd(vt, Wuv, None, UV, None, 3 * n, 2 * F, F, 0, st)
         U_ptr, Vv_ptr = UV.data_ptr(), UV.data_ptr() + 4 * F
         _lib.call("cgv_update_norm_stack_fwd", _lib.ptr(s), Vv_ptr, _lib.ptr(stack), n, F, 2 * F, st)
-        _lib.call("cgv_skinny_linear_fwd", _lib.ptr(stack), _lib.ptr(W0), _lib.ptr(b0), _lib.ptr(a0), _lib.ptr(z0), n, F,
-                  2 * F, 1, st)
-        _lib.call("cgv_skinny_linear_fwd", _lib.ptr(a0), _lib.ptr(W1), _lib.ptr(b1), _lib.ptr(a), None, n, 3 * F, F, 0, st)
+        _dense_fwd(stack, W0, b0, a0, z0, n, F, 2 * F, 1, st)
+        _dense_fwd(a0, W1, b1, a, None, n, 3 * F, F, 0, st)
         _lib.call("cgv_update_gate_fwd", U_ptr, Vv_ptr, _lib.ptr(a), _lib.ptr(s) if residual else None,
                   _lib.ptr(v) if residual else None, _lib.ptr(ds), _lib.ptr(dv), n, F, 2 * F, st)
         ctx.save_for_backward(vt, UV, stack, z0, a0, a, W0, W1)
@@ -443,12 +460,12 @@ class _UpdateBlockFused(torch.autograd.Function):
         _lib.call("cgv_update_gate_bwd", U_ptr, Vv_ptr, _lib.ptr(a), _lib.ptr(g_ds), _lib.ptr(g_dv), gU_ptr, gVv_ptr,
                   _lib.ptr(ga), n, F, 2 * F, st)
         g_a0, g_stack, g_s, g_vt, g_v = new(n, F), new(n, 2 * F), new(n, F), new(3 * n, F), new(n, F, 3)
-        skinny_bwd_input(ga, None, W1d, g_a0, n, 3 * F, F, 0, st)
-        skinny_bwd_input(g_a0, z0, W0d, g_stack, n, F, 2 * F, 1, st)
+        _dense_bwd_input(ga, None, W1d, g_a0, n, 3 * F, F, 0, st)
+        _dense_bwd_input(g_a0, z0, W0d, g_stack, n, F, 2 * F, 1, st)
         _lib.call("cgv_update_norm_stack_bwd", _lib.ptr(g_stack), Vv_ptr, _lib.ptr(stack),
                   _lib.ptr(g_ds) if ctx.residual else None, _lib.ptr(g_s), gVv_ptr, n, F, 2 * F, 1, st)
         Wuv = torch.as_strided(u_w.detach(), (2 * F, F), (F, 1))
-        skinny_bwd_input(gUV, None, Wuv, g_vt, 3 * n, 2 * F, F, 0, st)
+        _dense_bwd_input(gUV, None, Wuv, g_vt, 3 * n, 2 * F, F, 0, st)
         _lib.call("cgv_update_vec_from_rows", _lib.ptr(g_vt), _lib.ptr(g_dv) if ctx.residual else None, _lib.ptr(g_v),
                   n, F, st)
         # weight gradients -> grouped launch (direct targets; the [u_mat; v_mat] pair is one problem)

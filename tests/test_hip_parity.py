@@ -588,13 +588,14 @@ def test_dense_with_fused_swish_vs_fp64(M, F):
     assert_close(dense.bias.grad, bd_.grad, "gb", 3e-6)
 
 
-def test_fused_update_block_equals_composition():
+@pytest.mark.parametrize("n,F", [(12, 600), (96, 600), (64, 128)])
+def test_fused_update_block_equals_composition(n, F):
     """The single-node UpdateBlock path (arena-managed parameters, merged [u_mat; v_mat] product, grouped
-    weight gradients) against the tensor-op composition and the fp64 oracle formulas."""
+    weight gradients) against the tensor-op composition and the fp64 oracle formulas; 12 beads run on the skinny
+    kernels, 64 / 96 beads (3n = 192 / 288 rows) on the tile kernels."""
     from coarsegrainingvae_amd.trainer import ParamArena
     from coarsegrainingvae_amd.ops import _UpdateBlockFused
     torch.manual_seed(3)
-    n, F = 12, 600
     blk = cg.UpdateBlock(F, "swish", 0.0).to(DEV)
     with torch.no_grad():
         for p in blk.parameters():
