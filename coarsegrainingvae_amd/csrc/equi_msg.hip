@@ -401,6 +401,9 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void equi_msg_bwd_k(
   const int n_end = min(n_beg + nodes_per_chunk, n_src);
   const int j0 = SPLIT ? n_beg : n_beg + wave;
   const int jstep = SPLIT ? 1 : BWD_WAVES;
+  const int n_edges_total = rowptr[n_src];
+  float warm = 0.f, pend_g = 0.f;                    // cache-warming loads of the scalar-only walk (see there)
+  int pend_i = 0;
   for (int j = j0; j < n_end; j += jstep) {
     const float* __restrict__ prow = phi + (size_t)j * 3 * F;
     const f2 p1 = ldpair<PAIR>(prow + F, cp);
@@ -429,21 +432,34 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void equi_msg_bwd_k(
         const unsigned og = 4u * (unsigned)cp.c, rowb = 4u * (unsigned)F;
         unsigned so_n = (unsigned)dst[min(beg + 1, end - 1)] * rowb;
         f2 c_q = ld2_buf(r_gs, og, (unsigned)dst[beg] * rowb);
+        // The records and receiver indices are streamed exactly once per (node, channel tile) by SCALAR loads, which
+        // wait for all outstanding requests at every use: a deeper scalar prefetch cannot hide more than one edge of
+        // latency, and on graphs whose record array is far beyond L2 (2000 atoms: 68 MB) each of those loads went to
+        // HBM.  Every 64 edges the lanes touch one dword of the 64 records (and receiver indices) that follow the
+        // next 64 -- vector loads, in order, nobody waits for them -- so the scalar loads find their lines in L2.
+        const int e_last = n_edges_total - 1;
+        for (int eb = beg; eb < end; eb += 64) {
+          const int ew = min(eb + 64 + lane, e_last);
+          warm = fmaf(pend_g, 0.f, warm) + (float)(pend_i & 0);
+          pend_g = geom[(size_t)ew * GS];
+          pend_i = dst[ew];
+          const int ee = min(eb + 64, end);
 #pragma unroll 2
-        for (int e = beg; e < end; ++e) {
-          const int e1 = min(e + 1, end - 1), e2 = min(e + 2, end - 1);
+          for (int e = eb; e < ee; ++e) {
+            const int e1 = min(e + 1, end - 1), e2 = min(e + 2, end - 1);
 #pragma unroll
-          for (int t = 0; t < NGB; ++t) gn[t] = geom[(size_t)e1 * GS + t];
-          const unsigned so_nn = (unsigned)dst[e2] * rowb;
-          const f2 n_q = ld2_buf(r_gs, og, so_n);
-          a1 = fma2(c_q, filter2<R>(W[0], gc), a1);
-          const f2 t1 = c_q * p1;
+            for (int t = 0; t < NGB; ++t) gn[t] = geom[(size_t)e1 * GS + t];
+            const unsigned so_nn = (unsigned)dst[e2] * rowb;
+            const f2 n_q = ld2_buf(r_gs, og, so_n);
+            a1 = fma2(c_q, filter2<R>(W[0], gc), a1);
+            const f2 t1 = c_q * p1;
 #pragma unroll
-          for (int n = 0; n <= R; ++n) G[0][n] = fma2(t1, splat(gc[n]), G[0][n]);
+            for (int n = 0; n <= R; ++n) G[0][n] = fma2(t1, splat(gc[n]), G[0][n]);
 #pragma unroll
-          for (int t = 0; t < NGB; ++t) gc[t] = gn[t];
-          so_n = so_nn;
-          c_q = n_q;
+            for (int t = 0; t < NGB; ++t) gc[t] = gn[t];
+            so_n = so_nn;
+            c_q = n_q;
+          }
         }
       }
     } else {
@@ -526,6 +542,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void equi_msg_bwd_k(
     }
   }
 
+  asm volatile("" ::"v"(warm), "v"(pend_g), "v"(pend_i));      // the warming loads must not be optimised away
   // block partial of the filter-weight gradient: part[chunk][k][n][F]  (channel fastest -> coalesced)
   if (wave > 0) {
     float* r = red + (wave - 1) * NRED * 64 + lane;
