@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=None)
     ap.add_argument("--optimizer", default="fused", choices=["fused", "torch"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one captured hipGraph per step")
+    ap.add_argument("--deferred-update", action="store_true",
+                    help="apply each step's Adam pass at the start of the next step, beside the encoder forward "
+                         "(A/B switch; the forked graph replays slower than the in-step update)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "operands", "gradients"],
                     help="N > 1: all-gather the bead-level layers' operand rows (default) or all-reduce every gradient")
     return ap.parse_args()
@@ -182,8 +185,11 @@ def main():
         if args.skip_dead_vector_channel:
             m.encoder.set_skip_dead_vector_channel(True)
             m.prior_net.set_skip_dead_vector_channel(True)
+        # --deferred-update (opt-in, measured slower: DESIGN.md 4): the parameter pass of a step opens the next step,
+        # the decoder's share beside the encoder forward; the last one is flushed after the timed loop
         return m, Trainer(m, lr=1e-4, beta=w["beta"], gamma=w["gamma"], world_size=world,
-                          fused_optimizer=(args.optimizer == "fused"), exchange=exchange)
+                          fused_optimizer=(args.optimizer == "fused"), exchange=exchange,
+                          defer_update=args.deferred_update)
 
     def first_steps(tr):
         # per-kernel HIP-event timing needs eager launches: done on a few untimed steps (part of warm-up)
@@ -227,6 +233,7 @@ def main():
         trainer.step(batch)
     barrier()
     elapsed = time.perf_counter() - t0
+    trainer.flush()                                  # the update of the last timed step (the first one applied a pre-timed one)
     if dist is not None:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -312,7 +319,7 @@ def main():
                                    f"cutoffs {w['atom_cutoff']}/{w['cg_cutoff']}",
                        "step": "fwd+loss+bwd" + (dp_step if world > 1 else "") + "+clip+adam",
                        "global_batch": world * frames, "directed_edges_rank0": int(batch["_graph"].atom.n_edges),
-                       "optimizer": args.optimizer, "hip_graph": bool(use_graph), "skip_dead_vector_channel": bool(args.skip_dead_vector_channel),
+                       "optimizer": args.optimizer, "deferred_update": bool(trainer.defer_update), "hip_graph": bool(use_graph), "skip_dead_vector_channel": bool(args.skip_dead_vector_channel),
                        "parallelism": f"dp{world}"},
             "loss": loss, "roofline": roofline, "cpu_baseline": cpu,
         }

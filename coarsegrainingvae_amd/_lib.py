@@ -90,6 +90,8 @@ PROTOTYPES = {
     "cgv_optim_state_floats": (_i, []),
     "cgv_optim_partial_floats": (_i, []),
     "cgv_adam_clip_step": (_i, [_p, _p, _p, _p, C.c_int64, _f, _f, _f, _f, _f, _f, _p, _f, _p, _p, _p]),
+    "cgv_optim_prepare": (_i, [_p, C.c_int64, _f, _f, _f, _f, _p, _f, _p, _p, _p]),
+    "cgv_adam_apply": (_i, [_p, _p, _p, _p, C.c_int64, _f, _f, _f, _f, _p, _p]),
 }
 
 

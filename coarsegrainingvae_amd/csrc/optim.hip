@@ -129,22 +129,44 @@ extern "C" {
 int cgv_optim_state_floats(void) { return 8; }
 int cgv_optim_partial_floats(void) { return 2048; }
 
-int cgv_adam_clip_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                       float eps, float max_norm, float grad_scale, const float* loss, float skip_threshold,
-                       float* state, float* partial, void* stream) {
-  CGV_REQUIRE(p && g && m && v && state && partial && n >= 0, "bad argument");
-  CGV_REQUIRE(((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v)) & 15) == 0, "arena must be 16-byte aligned");
-  hipStream_t st = (hipStream_t)stream;
-  const int nb = 2048;                               // = cgv_optim_partial_floats(); more blocks measured slower here
-  hipLaunchKernelGGL(cgv::sumsq_partial, dim3(nb), dim3(256), 0, st, g, n, partial);
-  hipLaunchKernelGGL(cgv::optim_finalize, dim3(1), dim3(256), 0, st, partial, nb, grad_scale, max_norm, beta1, beta2,
-                     loss, skip_threshold, state);
+static void launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                        float eps, const float* state, hipStream_t st) {
   // one streaming pass wants many more blocks than CUs: 2048 -> 16384 blocks: 297 -> 268 us on 67.5 M parameters
   // (7.05 TB/s); each thread still moves two float4 per array per trip
   const int64_t want = ((n >> 2) + 511) / 512;
   const int nba = (int)(want < 1 ? 1 : (want > 16384 ? 16384 : want));
   hipLaunchKernelGGL(cgv::adam_update, dim3(nba), dim3(256), 0, st, p, g, m, v, n, lr, beta1, beta2, eps, state);
-  return cgv::check_launch("cgv_adam_clip_step");
+}
+
+int cgv_adam_clip_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                       float eps, float max_norm, float grad_scale, const float* loss, float skip_threshold,
+                       float* state, float* partial, void* stream) {
+  int rc = cgv_optim_prepare(g, n, beta1, beta2, max_norm, grad_scale, loss, skip_threshold, state, partial, stream);
+  if (rc) return rc;
+  return cgv_adam_apply(p, g, m, v, n, lr, beta1, beta2, eps, state, stream);
+}
+
+/* The two halves of cgv_adam_clip_step, so that the parameter pass can be issued per arena range and later than the
+ * norm (trainer: the previous step's update of the decoder's range runs beside the next step's encoder). */
+int cgv_optim_prepare(const float* g, int64_t n, float beta1, float beta2, float max_norm, float grad_scale,
+                      const float* loss, float skip_threshold, float* state, float* partial, void* stream) {
+  CGV_REQUIRE(g && state && partial && n >= 0, "bad argument");
+  CGV_REQUIRE((((uintptr_t)g) & 15) == 0, "arena must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = 2048;                               // = cgv_optim_partial_floats(); more blocks measured slower here
+  hipLaunchKernelGGL(cgv::sumsq_partial, dim3(nb), dim3(256), 0, st, g, n, partial);
+  hipLaunchKernelGGL(cgv::optim_finalize, dim3(1), dim3(256), 0, st, partial, nb, grad_scale, max_norm, beta1, beta2,
+                     loss, skip_threshold, state);
+  return cgv::check_launch("cgv_optim_prepare");
+}
+
+int cgv_adam_apply(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                   const float* state, void* stream) {
+  CGV_REQUIRE(p && g && m && v && state && n >= 0, "bad argument");
+  CGV_REQUIRE(((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v)) & 15) == 0, "range must be 16-byte aligned");
+  if (n == 0) return 0;
+  launch_adam(p, g, m, v, n, lr, beta1, beta2, eps, state, (hipStream_t)stream);
+  return cgv::check_launch("cgv_adam_apply");
 }
 
 }  // extern "C"

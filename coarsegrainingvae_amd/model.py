@@ -251,6 +251,9 @@ class CGequiVAE(nn.Module):
         # set by the data-parallel trainer: ``bucket_done(i)`` is called (from the autograd thread) as soon as
         # the gradients of ``backward_buckets()[i]`` are final (trainer.py) -- the decoder holds ~80 % of the bytes
         self.bucket_done = None
+        # set by the trainer when the previous step's update of the decoder's parameters is still running on a side
+        # stream (Trainer(defer_update=True)): called once, right before the decoder first touches its weights
+        self.before_decoder = None
         self.bucket_layers = 3             # decoder layers per early all-reduce bucket
         self.concurrent_prior = False      # measured: cross-stream joins cost more than the overlap saves (3.72 vs 3.53 ms)
         self._streams = {}
@@ -368,6 +371,9 @@ class CGequiVAE(nn.Module):
             layer_hooks = {layers[-1]: self._fire_bucket(i) for i, layers in enumerate(groups[:-1])}
             z_sample = z_sample.view_as(z_sample)          # private node: the hook fires when the decoder is done
             z_sample.register_hook(_call_then_pass(self._fire_bucket(len(groups) - 1)))
+        if self.before_decoder is not None:
+            self.before_decoder()
+            self.before_decoder = None
         xyz_recon = self.decoder(cg_xyz, CG_nbr_list, z_sample, s_i, mapping, num_CGs, graph=graph,
                                  layer_hooks=layer_hooks)
         return mu, sigma, H_prior_mu, H_prior_sigma, xyz, xyz_recon

@@ -198,9 +198,9 @@ def run(params) -> dict:
         for mode, idx in (("train", train_idx), ("val", val_idx)):
             tot, kls, recs, grs = [], [], [], []
             is_train = mode == "train"
-            ready = (lambda t=is_train: t in trainer._graphs) if use_graph else None
+            ready = (lambda t=is_train: trainer.has_graph(t)) if use_graph else None
             for batch in _batches(dataset, idx, params["batch_size"], rank, world, device, prepared=ready):
-                if use_graph and trainer.arena is not None and is_train not in trainer._graphs and "_graph" in batch:
+                if use_graph and trainer.arena is not None and not trainer.has_graph(is_train) and "_graph" in batch:
                     trainer.capture(batch, warmup=0, train=is_train)       # from the second step on: one graph per mode
                 loss = trainer.step(batch, train=is_train).clone()         # (a replay refreshes the result tensors in place)
                 kl, recon, graph = (t.clone() for t in trainer.last_terms)
@@ -234,6 +234,7 @@ def run(params) -> dict:
         early(val)
         if early.early_stop:
             break
+    trainer.flush()                                                       # the last step's (deferred) parameter update
     elapsed = time.time() - t_start
     if rank == 0 and logdir:
         torch.save(model.state_dict(), os.path.join(logdir, "model.pt"))    # run_ala.py:355-357

@@ -279,12 +279,21 @@ class Trainer:
 
     def __init__(self, model, lr: float, beta: float, gamma: float, world_size: int = 1, group=None,
                  fused_optimizer: bool = True, betas=(0.9, 0.999), eps: float = 1e-8, max_norm: float = CLIP_NORM,
-                 always_sync: bool = False, exchange: str = "auto", sync=None):
+                 always_sync: bool = False, exchange: str = "auto", sync=None, defer_update: bool = False):
         """``exchange``: what the ranks exchange for the bead-level linear layers -- "operands" (all-gather of the
         rows that form the weight gradients, see OperandExchange), "gradients" (all-reduce everything), or "auto"
         (operands on the HIP path).  ``sync``: a GradSync-compatible object to use instead of one built from
         ``world_size`` / ``group`` (tests substitute a single-process stand-in for N ranks)."""
-        self.model, self.lr, self.beta, self.gamma = model, lr, beta, gamma
+        self.model, self._lr, self.beta, self.gamma = model, lr, beta, gamma
+        # defer_update: a step ends with the global norm / clip / skip decision (cgv_optim_prepare); the parameter pass
+        # (cgv_adam_apply) opens the NEXT step -- the non-decoder ranges first, the decoder's range (82 % of the
+        # parameters) on a side stream beside the prior / encoder forward, joined right before the decoder runs.  The
+        # optimiser pass is HBM-bound while those forwards are chains of tiny latency-bound launches, so the two share
+        # the chip.  ``flush()`` applies a pending update (end of training, before reading parameters, lr changes).
+        self.defer_update = bool(defer_update) and fused_optimizer
+        self._pending = False
+        self._side = None
+        self._dec_ranges = None
         self.betas, self.eps, self.max_norm = betas, eps, max_norm
         self.world = world_size
         # always_sync: run the collective path even with one rank (exercises RCCL + graph capture in tests)
@@ -303,6 +312,63 @@ class Trainer:
         self.steps_skipped_host = 0
         self._graphs = {}             # train flag -> captured hipGraph of one full step (capture())
         self.replays = 0
+
+    @property
+    def lr(self):
+        return self._lr
+
+    @lr.setter
+    def lr(self, value):
+        if value != self._lr and self._pending:
+            self.flush()                                   # the pending update belongs to the old learning rate
+        self._lr = value
+
+    def flush(self):
+        """Apply a deferred parameter update now (no-op otherwise)."""
+        if self._pending:
+            self._apply_pending(overlap=False)
+
+    def _adam_apply(self, lo: int, hi: int):
+        a = self.arena
+        _lib.call("cgv_adam_apply", a.p.data_ptr() + 4 * lo, a.g.data_ptr() + 4 * lo, self.m.data_ptr() + 4 * lo,
+                  self.v.data_ptr() + 4 * lo, hi - lo, self._lr, self.betas[0], self.betas[1], self.eps, _lib.ptr(self.state),
+                  _lib.stream_ptr())
+
+    def _apply_pending(self, overlap: bool):
+        a = self.arena
+        dec = self._decoder_ranges() if overlap and hasattr(self.model, "before_decoder") else []
+        if not dec:
+            self._adam_apply(0, a.numel)
+        else:
+            for lo, hi in complement_ranges(dec, a.numel):
+                self._adam_apply(lo, hi)
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=a.p.device)
+            main, side = torch.cuda.current_stream(), self._side
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                for lo, hi in dec:
+                    self._adam_apply(lo, hi)
+            self.model.before_decoder = lambda: torch.cuda.current_stream().wait_stream(side)
+        self._pending = False
+
+    def _decoder_ranges(self):
+        """Arena ranges (padded, merged) of the decoder's parameters."""
+        if self._dec_ranges is None:
+            a = self.arena
+            dec = getattr(self.model, "equivaraintconv", None)
+            ids = {id(p) for p in dec.parameters()} if dec is not None else set()
+            ends = a.offsets[1:] + [a.numel]
+            out = []
+            for k, p in enumerate(a.params):
+                if id(p) in ids:
+                    lo, hi = a.offsets[k], ends[k]
+                    if out and out[-1][1] == lo:
+                        out[-1] = (out[-1][0], hi)
+                    else:
+                        out.append((lo, hi))
+            self._dec_ranges = out
+        return self._dec_ranges
 
     # ------------------------------------------------------------------ setup after the first backward
     def _build_arena(self):
@@ -388,31 +454,47 @@ class Trainer:
         if self.sync is not None:
             self.sync.drain()
         graph = torch.cuda.CUDAGraph()
+        pending_at_start = self._pending              # a deferred update opens the captured step (or does not)
+        if self.defer_update and self._side is None:
+            self._side = torch.cuda.Stream(device=self.arena.p.device)      # streams cannot be created while capturing
         wgrad_queue.prepare_capture(self.arena.p.device, flushes=4 * (len(self.early_ranges) + 2))
         # with RCCL in the step, other threads (the process group's watchdog) legitimately touch the runtime
         mode = "thread_local" if self.sync is not None else "global"
         with torch.cuda.graph(graph, capture_error_mode=mode):
             self._step_eager(batch, train=train)
+        self._pending = pending_at_start                    # recorded, not run: the update it opens with is still due
         # the step's result tensors live in the graph's pool: a replay refreshes them in place
-        self._graphs[bool(train)] = {"graph": graph, "batch": batch, "lr": self.lr,
-                                     "results": (self.last_loss, self.last_terms, self.last_out)}
+        self._graphs[self._graph_key(train, pending_at_start)] = {"graph": graph, "batch": batch, "lr": self.lr,
+                                                                  "results": (self.last_loss, self.last_terms, self.last_out)}
         return graph
+
+    def _graph_key(self, train: bool, pending: bool):
+        """One graph per mode; with deferred updates also per 'does an update open the step' (train steps follow train
+        steps -- pending -- or validation steps -- nothing pending)."""
+        return (bool(train), bool(pending)) if self.defer_update else bool(train)
 
     @property
     def _graph(self):                                       # the training graph (None until captured)
-        cap = self._graphs.get(True)
+        cap = self._graphs.get(self._graph_key(True, True)) or self._graphs.get(self._graph_key(True, False))
         return cap["graph"] if cap else None
 
+    def has_graph(self, train: bool) -> bool:
+        """Is a captured step available for the NEXT step of this mode?"""
+        return self._graph_key(train, self._pending) in self._graphs
+
     def step(self, batch, eps: Optional[torch.Tensor] = None, train: bool = True):
-        cap = self._graphs.get(bool(train))
+        key = self._graph_key(train, self._pending)
+        cap = self._graphs.get(key)
         if cap is not None and eps is None:
-            if train and cap["lr"] != self.lr:              # the learning rate is a launch argument: re-capture
-                self.capture(cap["batch"], warmup=0, train=True)
-                cap = self._graphs[True]
+            if cap["lr"] != self.lr and (train or self.defer_update):    # the learning rate is a launch argument: re-capture
+                self.capture(cap["batch"], warmup=0, train=train)
+                cap = self._graphs[key]
             if batch is cap["batch"] or self._load(cap["batch"], batch):
                 cap["graph"].replay()
                 self.last_loss, self.last_terms, self.last_out = cap["results"]
                 self.replays += 1
+                if self.defer_update:
+                    self._pending = bool(train)              # a training step leaves its update for the next step
                 return self.last_loss
         if "_graph" not in batch:
             from .data import prepare_batch
@@ -429,6 +511,8 @@ class Trainer:
     # ------------------------------------------------------------------ one iteration
     def _step_eager(self, batch, eps: Optional[torch.Tensor] = None, train: bool = True):
         # data parallel: ask the model to signal the end of the decoder's backward (hook registered in forward)
+        if self._pending:
+            self._apply_pending(overlap=True)               # the previous step's update, beside this step's encoder
         overlap = self.sync is not None and train and self.arena is not None and any(self.early_ranges)
         self._sent = set()
         if hasattr(self.model, "bucket_done"):
@@ -475,10 +559,13 @@ class Trainer:
         scale = 1.0 / self.world
         if self.fused:
             a = self.arena
-            _lib.call("cgv_adam_clip_step", _lib.ptr(a.p), _lib.ptr(a.g), _lib.ptr(self.m), _lib.ptr(self.v),
-                      a.numel, self.lr, self.betas[0], self.betas[1], self.eps, self.max_norm, scale,
+            _lib.call("cgv_optim_prepare", _lib.ptr(a.g), a.numel, self.betas[0], self.betas[1], self.max_norm, scale,
                       _lib.ptr(decision.reshape(1).float().contiguous()), threshold, _lib.ptr(self.state),
                       _lib.ptr(self.partial), _lib.stream_ptr())
+            if self.defer_update:
+                self._pending = True                         # applied when the next step opens (or by flush())
+            else:
+                self._adam_apply(0, a.numel)
         else:
             if self.world > 1:
                 self.arena.g.mul_(scale)

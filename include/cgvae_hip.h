@@ -368,6 +368,15 @@ int cgv_optim_partial_floats(void);
 int cgv_adam_clip_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                        float eps, float max_norm, float grad_scale, const float* loss /*[1] or NULL*/,
                        float skip_threshold, float* state, float* partial, void* stream);
+/* Its two halves: cgv_optim_prepare = global norm, skip decision, clip coefficient, bias corrections -> `state`;
+ * cgv_adam_apply = the parameter / moment pass over ONE contiguous range (pointers already offset, 16-byte aligned),
+ * reading `state`.  prepare + apply over the whole arena == cgv_adam_clip_step; apply may be issued per range, on
+ * another stream, and after further kernels (the trainer overlaps the decoder range's update with the next forward). */
+int cgv_optim_prepare(const float* g, int64_t n, float beta1, float beta2, float max_norm, float grad_scale,
+                      const float* loss /*[1] device or NULL*/, float skip_threshold, float* state, float* partial,
+                      void* stream);
+int cgv_adam_apply(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                   const float* state, void* stream);
 
 #ifdef __cplusplus
 }

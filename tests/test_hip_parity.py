@@ -1156,3 +1156,39 @@ def test_csr_by_rows_equals_the_radix_construction(n, E, monkeypatch):
             x, y = getattr(a, f), getattr(b, f)
             m = a.n_edges if not f.startswith("rowptr") else x.numel()
             assert torch.equal(x[:m], y[:m]), f
+
+
+@pytest.mark.parametrize("captured", [False, True])
+def test_deferred_update_equals_in_step_update(captured):
+    """Trainer(defer_update=True): a step ends with the norm / clip / skip decision, its parameter pass opens the next step
+    (decoder range on a side stream beside the encoder forward).  After flush() the parameters, moments and losses are
+    bit-identical to the in-step update -- through eager steps, captured graphs, and train / validation alternation."""
+    from coarsegrainingvae_amd.trainer import Trainer
+    w = cg.data.WORKLOADS["chignolin"]
+
+    def run(defer):
+        model = cg.build_model(64, w["n_rbf"], w["atom_cutoff"], w["cg_cutoff"], 2, 3, w["n_cgs"], det=True, seed=123).to(DEV)
+        batch = cg.synthetic_batch("chignolin", n_frames=2, seed=4, device=DEV)
+        tr = Trainer(model, lr=1e-3, beta=w["beta"], gamma=w["gamma"], defer_update=defer)
+        losses = [float(tr.step(batch)) for _ in range(3)]
+        if captured:
+            tr.capture(batch, warmup=0, train=True)
+        for k in range(6):
+            train = k not in (2, 3)                       # two validation steps in the middle (utils.py:159-160)
+            if captured and not tr.has_graph(train):
+                tr.capture(batch, warmup=0, train=train)
+            losses.append(float(tr.step(batch, train=train)))
+            if k == 4:
+                tr.lr = 5e-4                              # plateau scheduler: the pending update keeps the old rate
+        tr.flush()
+        torch.cuda.synchronize()
+        return losses, {k: v.clone() for k, v in model.state_dict().items()}, tr.m.clone(), tr
+
+    l0, p0, m0, _ = run(False)
+    l1, p1, m1, tr = run(True)
+    assert tr.defer_update and (not captured or tr.replays >= 4)
+    assert l0 == l1
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), k
+    # the moment arenas have the same content (the arena order is the same in both runs)
+    assert torch.equal(m0, m1)
