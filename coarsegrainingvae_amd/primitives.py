@@ -85,6 +85,8 @@ class WeightGradQueue:
         self._capture_slots = []
         import os
         self.kernel = os.environ.get("CGV_WGRAD_KERNEL", "valu")      # "mfma": A/B switch, see launch()
+        self.static_tables = os.environ.get("CGV_TABLE_UPLOAD", "once") != "node"
+        self._deferred = []
 
     def prepare_capture(self, device, flushes: int = 4):
         """Allocate the (pinned, device) table pairs the flushes of the next captured step will use
@@ -111,9 +113,10 @@ class WeightGradQueue:
     def upload(self, buf: bytes, device):
         """Device copy of a host-built record table.  Inside a stream capture the (pinned, device) pair comes from
         the slots allocated by ``prepare_capture`` and is kept alive with the graph."""
-        if torch.cuda.is_current_stream_capturing():
-            # a captured H2D node re-reads its pinned source at every replay: the graph gets its own,
-            # never-rewritten staging buffer and table, allocated BEFORE capture (prepare_capture)
+        capturing = torch.cuda.is_current_stream_capturing()
+        if capturing:
+            # the graph gets its own, never-rewritten staging buffer and table, allocated BEFORE capture
+            # (prepare_capture); CGV_TABLE_UPLOAD=node keeps the copy as a node of the graph (A/B switch)
             if not self._capture_slots:
                 raise RuntimeError("call wgrad_queue.prepare_capture(device) with enough slots before capturing a step")
             host, table = slot = self._capture_slots.pop()
@@ -127,8 +130,21 @@ class WeightGradQueue:
         if len(buf) > host.numel():
             raise RuntimeError("record table exceeds the staging buffer")
         host[: len(buf)].copy_(torch.frombuffer(bytearray(buf), dtype=torch.uint8))
-        table[: len(buf)].copy_(host[: len(buf)], non_blocking=True)
+        if capturing and self.static_tables:
+            self._deferred.append((host, table, len(buf)))          # copied once, by finish_capture()
+        else:
+            table[: len(buf)].copy_(host[: len(buf)], non_blocking=True)
         return table
+
+    def finish_capture(self):
+        """The record tables of a captured step never change between replays (operand and gradient addresses are the
+        graph's own): they are copied to the device ONCE, here, right after the capture, instead of by a host-to-device
+        node in every replay (each such node stalls the replay: DESIGN.md 4)."""
+        for host, table, n in self._deferred:
+            table[:n].copy_(host[:n], non_blocking=True)
+        if self._deferred:
+            torch.cuda.current_stream().synchronize()
+        self._deferred = []
 
     def launch(self, items):
         """Grouped launches for ``items`` (tuples as queued by ``enqueue``), writing into their gW / gb targets: ONE for

@@ -462,6 +462,7 @@ class Trainer:
         mode = "thread_local" if self.sync is not None else "global"
         with torch.cuda.graph(graph, capture_error_mode=mode):
             self._step_eager(batch, train=train)
+        wgrad_queue.finish_capture()                        # record tables: on the device before the first replay
         self._pending = pending_at_start                    # recorded, not run: the update it opens with is still due
         # the step's result tensors live in the graph's pool: a replay refreshes them in place
         self._graphs[self._graph_key(train, pending_at_start)] = {"graph": graph, "batch": batch, "lr": self.lr,
