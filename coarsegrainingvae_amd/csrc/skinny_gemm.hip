@@ -18,6 +18,8 @@
 //
 // MFMA 16x16x4 f32 operand map (cdna_hip_programming.md 3): lane l holds A[i = l&15][k = l>>4],
 // B[k = l>>4][j = l&15]; D: col j = l&15, row i = 4*(l>>4) + reg.
+#include <cstdlib>
+#include <cstring>
 #include "cgv_common.h"
 
 namespace cgv {
@@ -319,20 +321,22 @@ __global__ __launch_bounds__(256) void grouped_wgrad_k(const WgradProblem* __res
   float* gs = smem + (size_t)M * tile_w;     // [M][WG_BLOCK_ROWS]
   const int t = threadIdx.x;
   const int n0 = rb * WG_BLOCK_ROWS;
-  const int k = kt * tile_w + 4 * t;
-  const bool kok = 4 * t < tile_w && k < K;
-  if (4 * t < tile_w) {                      // x tile; 4 rows of loads in flight before the LDS stores
-    const float* xp = pr.x + (kok ? k : 0);
-    int m = 0;
-    for (; m + 4 <= M; m += 4) {
-      const float4 a = ldg4_or_zero(xp + (size_t)m * K, kok), b = ldg4_or_zero(xp + (size_t)(m + 1) * K, kok);
-      const float4 c = ldg4_or_zero(xp + (size_t)(m + 2) * K, kok), d = ldg4_or_zero(xp + (size_t)(m + 3) * K, kok);
-      *reinterpret_cast<float4*>(xs + (size_t)m * tile_w + 4 * t) = a;
-      *reinterpret_cast<float4*>(xs + (size_t)(m + 1) * tile_w + 4 * t) = b;
-      *reinterpret_cast<float4*>(xs + (size_t)(m + 2) * tile_w + 4 * t) = c;
-      *reinterpret_cast<float4*>(xs + (size_t)(m + 3) * tile_w + 4 * t) = d;
+  const int t4 = tile_w >> 2;                                   // float4 columns of the k tile
+  const int kbase = kt * tile_w;
+  // x tile: all 256 threads, 4 float4 in flight each (rows x float4 columns, coalesced along k)
+  for (int base = 0; base < M * t4; base += 1024) {
+    float4 val[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = base + u * 256 + t;
+      const int m = idx / t4, c = idx - m * t4;
+      val[u] = ldg4_or_zero(pr.x + (size_t)(idx < M * t4 ? m : 0) * K + kbase + 4 * c, idx < M * t4 && kbase + 4 * c < K);
     }
-    for (; m < M; ++m) *reinterpret_cast<float4*>(xs + (size_t)m * tile_w + 4 * t) = ldg4_or_zero(xp + (size_t)m * K, kok);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = base + u * 256 + t;
+      if (idx < M * t4) reinterpret_cast<float4*>(xs)[idx] = val[u];
+    }
   }
   for (int idx = t; idx < M * WG_BLOCK_ROWS; idx += 256) {       // g tile, coalesced along n
     const int m = idx / WG_BLOCK_ROWS, r = idx - m * WG_BLOCK_ROWS;
@@ -344,15 +348,20 @@ __global__ __launch_bounds__(256) void grouped_wgrad_k(const WgradProblem* __res
     gs[idx] = g;
   }
   __syncthreads();
-  if (kok) {
-    for (int pass = 0; pass < WG_PASSES; ++pass) {
+  // narrow k tiles leave threads without a column: the 4 row passes are dealt to 2 or 4 thread groups instead
+  const int lanes = t4 <= 64 ? 64 : t4 <= 128 ? 128 : 256;     // threads per group (whole waves)
+  const int groups = 256 / lanes;
+  const int tc = t & (lanes - 1), grp = t / lanes;
+  const int k = kbase + 4 * tc;
+  if (tc < t4 && k < K) {
+    for (int pass = grp; pass < WG_PASSES; pass += groups) {
       const int nr = n0 + pass * WG_ROWS;
       if (nr >= N) break;
       float4 acc[WG_ROWS];
 #pragma unroll
       for (int r = 0; r < WG_ROWS; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int m = 0; m < M; ++m) {
-        const float4 xv = *reinterpret_cast<const float4*>(xs + (size_t)m * tile_w + 4 * t);
+        const float4 xv = *reinterpret_cast<const float4*>(xs + (size_t)m * tile_w + 4 * tc);
         const float4* g4 = reinterpret_cast<const float4*>(gs + m * WG_BLOCK_ROWS + pass * WG_ROWS);   // LDS broadcast
 #pragma unroll
         for (int i = 0; i < WG_ROWS / 4; ++i) {
@@ -633,13 +642,28 @@ __global__ __launch_bounds__(256) void pack_operands_k(const PackProblem* __rest
   }
 }
 
-// k tiling of one problem: as wide as a 60 KiB LDS budget for the x + g tiles allows, <= 256 float4
+// k tiling of one problem: tiles of at most 256 float4 within a 60 KiB LDS budget for the x + g tiles; among the
+// admissible tile counts the one that wastes the fewest lanes -- a tile of t4 float4 columns occupies thread groups of
+// 64 / 128 / 256 lanes (grouped_wgrad_k deals its 4 row passes to 256 / lanes groups), so K = 600 is cut into
+// 3 x 50 columns (78 % of the lanes busy) rather than 1 x 150 (59 %).  CGV_WGRAD_TILING=wide: the widest tile.
 static inline void wgrad_tiling(int M, int K, int* tiles_k, int* tile_w) {
   int max_t4 = (15360 / M - WG_BLOCK_ROWS) / 4;
   if (max_t4 > 256) max_t4 = 256;
   if (max_t4 < 1) max_t4 = 1;
   const int k4 = K / 4;
-  const int nt = (k4 + max_t4 - 1) / max_t4;
+  int nt = (k4 + max_t4 - 1) / max_t4;
+  static const bool wide = [] { const char* e = getenv("CGV_WGRAD_TILING"); return e && !strcmp(e, "wide"); }();
+  if (!wide) {
+    long best_cost = -1;
+    int best = nt;
+    for (int cand = nt; cand <= nt + 8 && cand <= k4; ++cand) {
+      const int per = (k4 + cand - 1) / cand;
+      const int lanes = per <= 64 ? 64 : per <= 128 ? 128 : 256;
+      const long cost = (long)cand * lanes;
+      if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = cand; }
+    }
+    nt = best;
+  }
   const int per = (k4 + nt - 1) / nt;
   *tiles_k = nt;
   *tile_w = per * 4;
