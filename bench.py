@@ -285,6 +285,11 @@ def main():
                                 for k in ksum}
         extra["scatter_add"] = scatter_add_roofline(batch, F)
         extra["optimizer_step"] = optimizer_roofline(trainer)
+        if trainer._rank_hi and extra["optimizer_step"]:
+            # single process: the bead-level layers' gradients are never written (DESIGN.md 3, row O'); the figure
+            # above is the standalone full-arena kernel, the step itself moves 6 floats per rank-update weight
+            extra["optimizer_step"]["rank_update"] = {"weights": trainer._rank_numel, "arena_floats": trainer._rank_hi,
+                                                      "steps": trainer.rank_steps, "fallbacks": trainer.rank_fallbacks}
         # HBM traffic per launch from the committed PMC passes (separate rocprofv3 --pmc runs of this
         # same workload; cannot be collected inside the timed run) -- null when no entry matches
         try:

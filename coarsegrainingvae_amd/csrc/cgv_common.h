@@ -96,4 +96,23 @@ __device__ __forceinline__ float act_bwd(float z, int act) {
   }
 }
 
+
+// ------------------------------------------------------------------ fused optimiser (optim.hip, skinny_gemm.hip)
+// state[] layout (device floats) written by optim_finalize, read by every parameter pass
+enum { ST_STEP = 0, ST_NORM = 1, ST_CLIP = 2, ST_BC1 = 3, ST_BC2SQRT = 4, ST_SKIP = 5, ST_NSKIPPED = 6 };
+
+struct AdamStep {            // per-launch constants of one parameter pass (torch.optim.Adam defaults otherwise)
+  float clip, step_size, inv_bc2, beta1, beta2, eps;
+};
+__device__ __forceinline__ AdamStep adam_step_of(const float* __restrict__ state, float lr, float beta1, float beta2, float eps) {
+  return AdamStep{state[ST_CLIP], lr / state[ST_BC1], 1.0f / state[ST_BC2SQRT], beta1, beta2, eps};
+}
+__device__ __forceinline__ void adam_elem(const AdamStep& a, float& pp, float gg, float& mm, float& vv) {
+  gg *= a.clip;
+  mm = fmaf(1.f - a.beta1, gg - mm, mm);                       // exp_avg.lerp_(grad, 1 - beta1)
+  vv = fmaf(1.f - a.beta2, gg * gg, a.beta2 * vv);             // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
+  const float denom = sqrtf(vv) * a.inv_bc2 + a.eps;
+  pp -= a.step_size * (mm / denom);
+}
+
 }  // namespace cgv

@@ -13,9 +13,6 @@
 
 namespace cgv {
 
-// state[] layout (device floats)
-enum { ST_STEP = 0, ST_NORM = 1, ST_CLIP = 2, ST_BC1 = 3, ST_BC2SQRT = 4, ST_SKIP = 5, ST_NSKIPPED = 6 };
-
 __device__ inline float wave_sum(float x) {
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) x += __shfl_xor(x, d);
@@ -41,13 +38,15 @@ __global__ __launch_bounds__(256) void sumsq_partial(const float* __restrict__ g
   if (threadIdx.x == 0) partial[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
 }
 
-__global__ __launch_bounds__(256) void optim_finalize(const float* __restrict__ partial, int nb, float grad_scale,
+__global__ __launch_bounds__(256) void optim_finalize(const float* __restrict__ partial, int nb,
+                                                      const double* __restrict__ extra, int n_extra, float grad_scale,
                                                       float max_norm, float beta1, float beta2,
                                                       const float* __restrict__ loss, float skip_threshold,
                                                       float* __restrict__ state) {
   __shared__ double ws[4];
   double acc = 0.0;
   for (int i = threadIdx.x; i < nb; i += blockDim.x) acc += (double)partial[i];
+  for (int i = threadIdx.x; i < n_extra; i += blockDim.x) acc += extra[i];     // ||gW||^2 of never-materialised gradients
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d);
   if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
@@ -80,21 +79,13 @@ __global__ __launch_bounds__(256) void adam_update(float* __restrict__ p, const 
                                                    float beta1, float beta2, float eps,
                                                    const float* __restrict__ state) {
   if (state[ST_SKIP] != 0.f) return;
-  const float clip = state[ST_CLIP];
-  const float step_size = lr / state[ST_BC1];
-  const float inv_bc2 = 1.0f / state[ST_BC2SQRT];
+  const AdamStep a = adam_step_of(state, lr, beta1, beta2, eps);
   const int64_t n4 = n >> 2;
   float4* p4 = reinterpret_cast<float4*>(p);
   const float4* g4 = reinterpret_cast<const float4*>(g);
   float4* m4 = reinterpret_cast<float4*>(m);
   float4* v4 = reinterpret_cast<float4*>(v);
-  auto upd = [&](float& pp, float gg, float& mm, float& vv) {
-    gg *= clip;
-    mm = fmaf(1.f - beta1, gg - mm, mm);                       // exp_avg.lerp_(grad, 1 - beta1)
-    vv = fmaf(1.f - beta2, gg * gg, beta2 * vv);               // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
-    const float denom = sqrtf(vv) * inv_bc2 + eps;
-    pp -= step_size * (mm / denom);
-  };
+  auto upd = [&](float& pp, float gg, float& mm, float& vv) { adam_elem(a, pp, gg, mm, vv); };
   // streaming pass: nothing here is read again before the next step's kernels have flushed the caches, so
   // g / m / v go around them (nontemporal) and two float4 per array are in flight per thread
   typedef float f4v __attribute__((ext_vector_type(4)));
@@ -150,13 +141,25 @@ int cgv_adam_clip_step(float* p, const float* g, float* m, float* v, int64_t n, 
  * norm (trainer: the previous step's update of the decoder's range runs beside the next step's encoder). */
 int cgv_optim_prepare(const float* g, int64_t n, float beta1, float beta2, float max_norm, float grad_scale,
                       const float* loss, float skip_threshold, float* state, float* partial, void* stream) {
+  return cgv_optim_prepare_extra(g, n, nullptr, 0, beta1, beta2, max_norm, grad_scale, loss, skip_threshold, state, partial,
+                                 stream);
+}
+
+/* As cgv_optim_prepare over g[0, n), plus n_extra squared norms (doubles) of gradients that live nowhere in g: the
+ * rank-update layers (cgv_wgrad_gram / cgv_grouped_wgrad_adam). */
+int cgv_optim_prepare_extra(const float* g, int64_t n, const double* extra, int n_extra, float beta1, float beta2,
+                            float max_norm, float grad_scale, const float* loss, float skip_threshold, float* state,
+                            float* partial, void* stream) {
   CGV_REQUIRE(g && state && partial && n >= 0, "bad argument");
+  CGV_REQUIRE(n_extra >= 0 && (n_extra == 0 || extra), "bad extra partials");
   CGV_REQUIRE((((uintptr_t)g) & 15) == 0, "arena must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  const int nb = 2048;                               // = cgv_optim_partial_floats(); more blocks measured slower here
+  // 2048 blocks (= cgv_optim_partial_floats()) for a whole arena -- more measured slower; fewer for a short range
+  const int64_t want = ((n >> 2) + 1023) / 1024;
+  const int nb = (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
   hipLaunchKernelGGL(cgv::sumsq_partial, dim3(nb), dim3(256), 0, st, g, n, partial);
-  hipLaunchKernelGGL(cgv::optim_finalize, dim3(1), dim3(256), 0, st, partial, nb, grad_scale, max_norm, beta1, beta2,
-                     loss, skip_threshold, state);
+  hipLaunchKernelGGL(cgv::optim_finalize, dim3(1), dim3(256), 0, st, partial, nb, extra, n_extra, grad_scale, max_norm,
+                     beta1, beta2, loss, skip_threshold, state);
   return cgv::check_launch("cgv_optim_prepare");
 }
 

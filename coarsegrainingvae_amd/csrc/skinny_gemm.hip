@@ -305,8 +305,25 @@ struct WgradProblem {       // mirrors the 88-byte host record built in python (
 };
 static_assert(sizeof(WgradProblem) == 88, "host/device record layout");
 
-__global__ __launch_bounds__(256) void grouped_wgrad_k(const WgradProblem* __restrict__ table, int n_problems) {
+// Rank update (ADAM = true): the tile of gW is never stored -- it goes, clipped, straight into the Adam update of the
+// weights it belongs to.  A bead-level layer sees M = 12 rows against 0.36 - 3.2 M weights: its gradient g^T x has rank
+// <= 12 and costs 12 FMAs per weight to form, against 12 bytes per weight to write it, read it for the norm and read it
+// again in the parameter pass.  The norm comes from the operands instead (wgrad_gram_k), so the step moves 24 bytes per
+// weight of these layers (p, m, v read + written) instead of 36.  The arenas are addressed through gW's offset in the
+// gradient arena: p = arena_p + (gW - arena_g), likewise m and v.
+struct RankUpdateArgs {
+  const float* arena_g;
+  float* arena_p;
+  float* arena_m;
+  float* arena_v;
+  const float* state;
+  float lr, beta1, beta2, eps;
+};
+
+template <bool ADAM>
+__global__ __launch_bounds__(256) void grouped_wgrad_t(const WgradProblem* __restrict__ table, int n_problems, RankUpdateArgs ra) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (ADAM && ra.state[ST_SKIP] != 0.f) return;              // skipped step (utils.py:145): parameters stay
   // locate the problem of this block (table is tiny; block_begin ascending)
   int lo = 0, hi = n_problems - 1;
   while (lo < hi) {
@@ -360,6 +377,24 @@ __global__ __launch_bounds__(256) void grouped_wgrad_k(const WgradProblem* __res
       float4 acc[WG_ROWS];
 #pragma unroll
       for (int r = 0; r < WG_ROWS; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+      // rank update: p / m / v of 4 rows at a time; the first 4 rows' loads are issued before the tile is formed
+      typedef float f4v __attribute__((ext_vector_type(4)));
+      float4 pp[4], mm[4], vv[4];
+      const size_t at = ADAM ? (size_t)(pr.gW - ra.arena_g) + (size_t)nr * K + k : 0;
+      auto load_rows = [&](int r0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (nr + r0 + r < N) {
+            const size_t o = at + (size_t)(r0 + r) * K;
+            pp[r] = *reinterpret_cast<const float4*>(ra.arena_p + o);
+            const f4v tm = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(ra.arena_m + o));
+            const f4v tv = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(ra.arena_v + o));
+            mm[r] = make_float4(tm.x, tm.y, tm.z, tm.w);
+            vv[r] = make_float4(tv.x, tv.y, tv.z, tv.w);
+          }
+        }
+      };
+      if (ADAM) load_rows(0);
       for (int m = 0; m < M; ++m) {
         const float4 xv = *reinterpret_cast<const float4*>(xs + (size_t)m * tile_w + 4 * tc);
         const float4* g4 = reinterpret_cast<const float4*>(gs + m * WG_BLOCK_ROWS + pass * WG_ROWS);   // LDS broadcast
@@ -375,22 +410,187 @@ __global__ __launch_bounds__(256) void grouped_wgrad_k(const WgradProblem* __res
           }
         }
       }
+      if (ADAM) {
+        const AdamStep a = adam_step_of(ra.state, ra.lr, ra.beta1, ra.beta2, ra.eps);
 #pragma unroll
-      for (int r = 0; r < WG_ROWS; ++r) {
-        if (nr + r < N) {
-          float4* dst = reinterpret_cast<float4*>(pr.gW + (size_t)(nr + r) * K + k);
-          float4 o = acc[r];
-          if (pr.accumulate) { const float4 old = *dst; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
-          *dst = o;
+        for (int r0 = 0; r0 < WG_ROWS; r0 += 4) {
+          if (r0) load_rows(r0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (nr + r0 + r < N) {
+              const size_t o = at + (size_t)(r0 + r) * K;
+              const float4 g = acc[r0 + r];
+              adam_elem(a, pp[r].x, g.x, mm[r].x, vv[r].x); adam_elem(a, pp[r].y, g.y, mm[r].y, vv[r].y);
+              adam_elem(a, pp[r].z, g.z, mm[r].z, vv[r].z); adam_elem(a, pp[r].w, g.w, mm[r].w, vv[r].w);
+              *reinterpret_cast<float4*>(ra.arena_p + o) = pp[r];
+              __builtin_nontemporal_store(f4v{mm[r].x, mm[r].y, mm[r].z, mm[r].w}, reinterpret_cast<f4v*>(ra.arena_m + o));
+              __builtin_nontemporal_store(f4v{vv[r].x, vv[r].y, vv[r].z, vv[r].w}, reinterpret_cast<f4v*>(ra.arena_v + o));
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < WG_ROWS; ++r) {
+          if (nr + r < N) {
+            float4* dst = reinterpret_cast<float4*>(pr.gW + (size_t)(nr + r) * K + k);
+            float4 o = acc[r];
+            if (pr.accumulate) { const float4 old = *dst; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+            *dst = o;
+          }
         }
       }
     }
   }
+  if (ADAM) return;                                            // the bias gradient was written by wgrad_gram_k
   if (pr.gb && kt == 0 && t < WG_BLOCK_ROWS && n0 + t < N) {
     float sum = 0.f;
     for (int m = 0; m < M; ++m) sum += gs[m * WG_BLOCK_ROWS + t];
     pr.gb[n0 + t] = pr.accumulate ? pr.gb[n0 + t] + sum : sum;
   }
+}
+
+// ------------------------------------------------------------------ norm of a weight gradient from its operands
+// ||g^T x||_F^2 = sum_{a<=b} c_ab (g_a . g_b)(x_a . x_b),  c = 1 on the diagonal and 2 off it, over the M operand rows
+// (g = gy * act'(z)): the squared norm of a rank-update layer's gradient without forming it.
+//   wgrad_gram_k         grid (GRAM_SLICES, problems): block s takes the column slices s, s + GRAM_SLICES, ... of the
+//                        problem's rows -- first g's N columns, then x's K -- C4 float4 per row at a time, staged in LDS
+//                        (activation derivative applied once, at staging); 8 lanes share a pair's partial dot product
+//                        over the slice (double), the block's slices are summed per pair in LDS and leave as its own
+//                        workspace rows ws[problem][s][g | x][pair].  One global round trip per slice, blocks independent.
+//   wgrad_gram_reduce_k  one block per problem: sums the slices per pair (fixed order) and the pairs' products.
+// The blocks of wgrad_gram_k also write the bias gradient gb[n] (+)= sum_m g[m, n] (a column slice each), which the
+// fused update does not produce.
+constexpr int GRAM_SLICES = 8;
+constexpr int GRAM_WAVES = 8;
+constexpr int GRAM_THREADS = 64 * GRAM_WAVES;
+constexpr int GRAM_F4_PER_THREAD = 6;                                // staged float4 per thread and slice (<= 3072)
+constexpr int GRAM_TILE_F4 = 3200;                                   // rows are padded by one float4 (bank spread)
+constexpr int GRAM_MAX_ROWS = 40;     // beyond, re-forming the tiles and walking M^2 / 2 row pairs stops paying (cgv_rank_update_supported)
+constexpr int GRAM_MAX_PAIRS = GRAM_MAX_ROWS * (GRAM_MAX_ROWS + 1) / 2;                         // 820
+constexpr size_t GRAM_WS_DOUBLES = (size_t)GRAM_SLICES * 2 * GRAM_MAX_PAIRS;                    // per problem
+constexpr size_t GRAM_LDS_BYTES = sizeof(float4) * GRAM_TILE_F4 + sizeof(double) * 2 * GRAM_MAX_PAIRS;   // 64320
+
+__global__ __launch_bounds__(GRAM_THREADS) void wgrad_gram_k(const WgradProblem* __restrict__ table, double* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float4* tile = reinterpret_cast<float4*>(smem);                // [M][C4 + 1]
+  double* sums = reinterpret_cast<double*>(tile + GRAM_TILE_F4); // [g | x][pair]: this block's slices, summed
+  const WgradProblem pr = table[blockIdx.y];
+  const int sl = blockIdx.x;
+  const int M = pr.M, N = pr.N, K = pr.K, act = pr.act;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  double* mine = ws + (size_t)blockIdx.y * GRAM_WS_DOUBLES + (size_t)sl * 2 * GRAM_MAX_PAIRS;
+  for (int i = t; i < 2 * GRAM_MAX_PAIRS; i += GRAM_THREADS) sums[i] = 0.0;
+  if (pr.gb) {                                                  // bias gradient: a column slice per block
+    for (int n = sl * GRAM_THREADS + t; n < N; n += GRAM_SLICES * GRAM_THREADS) {
+      float sum = 0.f;
+#pragma unroll 4
+      for (int m = 0; m < M; ++m) {
+        float g = pr.gy[(size_t)m * N + n];
+        if (act) g *= act_bwd(pr.z[(size_t)m * N + n], act);
+        sum += g;
+      }
+      pr.gb[n] = pr.accumulate ? pr.gb[n] + sum : sum;
+    }
+  }
+  if (M > GRAM_MAX_ROWS) {                                      // unsupported (cgv_rank_update_supported): poison the norm
+    if (t == 0) mine[0] = __builtin_nan("");
+    return;
+  }
+  int C4 = (GRAM_TILE_F4 / M - 1) & ~63;
+  C4 = C4 > 256 ? 256 : C4;
+  const int RS = C4 + 1;                                         // row stride (float4)
+  const int n4 = N >> 2, k4 = K >> 2;
+  const int g_slices = (n4 + C4 - 1) / C4, slices = g_slices + (k4 + C4 - 1) / C4;
+  const int pairs = M * (M + 1) / 2;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto fetch = [&](int slice, float4 (&buf)[GRAM_F4_PER_THREAD]) {
+    const bool is_g = slice < g_slices;
+    const int c0 = (is_g ? slice : slice - g_slices) * C4, cols4 = is_g ? n4 : k4;
+#pragma unroll
+    for (int u = 0; u < GRAM_F4_PER_THREAD; ++u) {
+      const int idx = t + GRAM_THREADS * u;
+      const int m = idx / C4, col4 = c0 + idx - m * C4;
+      buf[u] = zero4;
+      if (m < M && col4 < cols4) {
+        if (is_g) {
+          float4 g = *reinterpret_cast<const float4*>(pr.gy + (size_t)m * N + 4 * col4);
+          if (act) {
+            const float4 z = *reinterpret_cast<const float4*>(pr.z + (size_t)m * N + 4 * col4);
+            g.x *= act_bwd(z.x, act); g.y *= act_bwd(z.y, act); g.z *= act_bwd(z.z, act); g.w *= act_bwd(z.w, act);
+          }
+          buf[u] = g;
+        } else {
+          buf[u] = *reinterpret_cast<const float4*>(pr.x + (size_t)m * K + 4 * col4);
+        }
+      }
+    }
+  };
+  // 8 lanes share a pair (an eighth of the slice's columns each), a wave pass covers 8 pairs
+  const int sub = lane & 7, pl = lane >> 3;
+  float4 buf[GRAM_F4_PER_THREAD];
+  if (sl < slices) fetch(sl, buf);
+  for (int slice = sl; slice < slices; slice += GRAM_SLICES) {
+    __syncthreads();                                             // previous slice consumed (and `sums` zeroed)
+#pragma unroll
+    for (int u = 0; u < GRAM_F4_PER_THREAD; ++u) {
+      const int idx = t + GRAM_THREADS * u;
+      const int m = idx / C4;
+      if (m < M) tile[m * RS + idx - m * C4] = buf[u];
+    }
+    if (slice + GRAM_SLICES < slices) fetch(slice + GRAM_SLICES, buf);       // in flight while this slice is used
+    __syncthreads();
+    double* row = sums + (slice < g_slices ? 0 : GRAM_MAX_PAIRS);
+    for (int base = 8 * w; base < pairs; base += 8 * GRAM_WAVES) {
+      const int pidx = base + pl;
+      const bool live = pidx < pairs;
+      // pair index -> (a <= b), row-major upper triangle: rows before a hold S(a) = a M - a (a - 1) / 2 pairs
+      const int q = live ? pidx : 0;
+      const float disc = (float)((2 * M + 1) * (2 * M + 1) - 8 * q);
+      int a = (int)(((float)(2 * M + 1) - sqrtf(disc)) * 0.5f);
+      a = a < 0 ? 0 : (a > M - 1 ? M - 1 : a);
+      while (a + 1 < M && (a + 1) * M - (a + 1) * a / 2 <= q) ++a;
+      while (a > 0 && a * M - a * (a - 1) / 2 > q) --a;
+      const int b = a + q - (a * M - a * (a - 1) / 2);
+      double acc = 0.0;
+      if (live) {
+        for (int c = sub; c < C4; c += 8) {
+          const float4 u4 = tile[a * RS + c], v4 = tile[b * RS + c];
+          acc += (double)u4.x * v4.x + (double)u4.y * v4.y + (double)u4.z * v4.z + (double)u4.w * v4.w;
+        }
+      }
+      acc += __shfl_xor(acc, 1);
+      acc += __shfl_xor(acc, 2);
+      acc += __shfl_xor(acc, 4);
+      if (live && sub == 0) row[pidx] += acc;                    // this lane owns the pair in every slice of the block
+    }
+  }
+  __syncthreads();
+  for (int i = t; i < 2 * GRAM_MAX_PAIRS; i += GRAM_THREADS) mine[i] = sums[i];
+}
+
+__global__ __launch_bounds__(256) void wgrad_gram_reduce_k(const WgradProblem* __restrict__ table, const double* __restrict__ ws,
+                                                           double* __restrict__ out) {
+  __shared__ double part[4];
+  const int M = table[blockIdx.x].M;
+  const double* mine = ws + (size_t)blockIdx.x * GRAM_WS_DOUBLES;
+  const int pairs = M <= GRAM_MAX_ROWS ? M * (M + 1) / 2 : 1;
+  double local = 0.0;
+  for (int p = threadIdx.x; p < pairs; p += 256) {
+    double gg = 0.0, xx = 0.0;
+    for (int s = 0; s < GRAM_SLICES; ++s) {
+      gg += mine[(size_t)s * 2 * GRAM_MAX_PAIRS + p];
+      xx += mine[(size_t)s * 2 * GRAM_MAX_PAIRS + GRAM_MAX_PAIRS + p];
+    }
+    // diagonal pairs are (a, a): p = a M - a (a - 1) / 2; cheaper to recover a by walking than to store it
+    int a = 0, rem = p;
+    while (rem >= M - a) { rem -= M - a; ++a; }
+    local += (rem == 0 ? 1.0 : 2.0) * gg * (M <= GRAM_MAX_ROWS ? xx : 1.0);
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) local += __shfl_xor(local, d);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
 }
 
 // ------------------------------------------------------------------ grouped weight gradient over GATHERED operands
@@ -644,7 +844,7 @@ __global__ __launch_bounds__(256) void pack_operands_k(const PackProblem* __rest
 
 // k tiling of one problem: tiles of at most 256 float4 within a 60 KiB LDS budget for the x + g tiles; among the
 // admissible tile counts the one that wastes the fewest lanes -- a tile of t4 float4 columns occupies thread groups of
-// 64 / 128 / 256 lanes (grouped_wgrad_k deals its 4 row passes to 256 / lanes groups), so K = 600 is cut into
+// 64 / 128 / 256 lanes (grouped_wgrad_t deals its 4 row passes to 256 / lanes groups), so K = 600 is cut into
 // 3 x 50 columns (78 % of the lanes busy) rather than 1 x 150 (59 %).  CGV_WGRAD_TILING=wide: the widest tile.
 static inline void wgrad_tiling(int M, int K, int* tiles_k, int* tile_w) {
   int max_t4 = (15360 / M - WG_BLOCK_ROWS) / 4;
@@ -817,9 +1017,52 @@ int cgv_grouped_wgrad(const void* table_dev, int n_problems, int total_blocks, i
   if (n_problems == 0 || total_blocks == 0) return 0;
   CGV_REQUIRE(table_dev, "null table");
   CGV_REQUIRE(max_lds_floats > 0 && max_lds_floats <= 16000, "LDS request out of range");
-  hipLaunchKernelGGL(cgv::grouped_wgrad_k, dim3(total_blocks), dim3(256), sizeof(float) * (size_t)max_lds_floats,
-                     (hipStream_t)stream, reinterpret_cast<const cgv::WgradProblem*>(table_dev), n_problems);
+  hipLaunchKernelGGL(cgv::grouped_wgrad_t<false>, dim3(total_blocks), dim3(256), sizeof(float) * (size_t)max_lds_floats,
+                     (hipStream_t)stream, reinterpret_cast<const cgv::WgradProblem*>(table_dev), n_problems,
+                     cgv::RankUpdateArgs{});
   return cgv::check_launch("cgv_grouped_wgrad");
+}
+
+/* Rank-update layers, first half: sumsq[i] = ||gW_i||_F^2 from the operands of record i; bias gradients written.
+ * Records must satisfy cgv_rank_update_supported (M <= 40); workspace: cgv_wgrad_gram_workspace_bytes(n_problems). */
+int cgv_wgrad_gram(const void* table_dev, int n_problems, double* sumsq, void* workspace, size_t workspace_bytes,
+                   void* stream) {
+  CGV_REQUIRE(n_problems >= 0, "bad size");
+  if (n_problems == 0) return 0;
+  CGV_REQUIRE(table_dev && sumsq && workspace, "null pointer");
+  CGV_REQUIRE(workspace_bytes >= cgv_wgrad_gram_workspace_bytes(n_problems), "workspace too small");
+  CGV_REQUIRE((((uintptr_t)workspace) & 7) == 0, "workspace must be 8-byte aligned");
+  const cgv::WgradProblem* table = reinterpret_cast<const cgv::WgradProblem*>(table_dev);
+  hipLaunchKernelGGL(cgv::wgrad_gram_k, dim3(cgv::GRAM_SLICES, n_problems), dim3(cgv::GRAM_THREADS),
+                     cgv::GRAM_LDS_BYTES, (hipStream_t)stream, table, reinterpret_cast<double*>(workspace));
+  hipLaunchKernelGGL(cgv::wgrad_gram_reduce_k, dim3(n_problems), dim3(256), 0, (hipStream_t)stream, table,
+                     reinterpret_cast<const double*>(workspace), sumsq);
+  return cgv::check_launch("cgv_wgrad_gram");
+}
+
+size_t cgv_wgrad_gram_workspace_bytes(int n_problems) {
+  return n_problems > 0 ? (size_t)n_problems * cgv::GRAM_WS_DOUBLES * sizeof(double) : 0;
+}
+
+/* Shapes the rank update takes: the weight-streaming tiling (cgv_skinny_supported) with at most 40 operand rows. */
+int cgv_rank_update_supported(int M, int N, int K) { return cgv_skinny_supported(M, N, K) && M <= cgv::GRAM_MAX_ROWS; }
+
+/* Rank-update layers, second half: the table of cgv_grouped_wgrad, but every gW tile goes through the clipped Adam
+ * update of its weights (state from cgv_optim_prepare_extra) instead of being stored.  Every gW must lie inside the
+ * gradient arena [arena_g, arena_g + arena_floats); p / m / v are the arenas of the same layout; accumulate must be 0. */
+int cgv_grouped_wgrad_adam(const void* table_dev, int n_problems, int total_blocks, int max_lds_floats,
+                           const float* arena_g, float* arena_p, float* arena_m, float* arena_v, float lr, float beta1,
+                           float beta2, float eps, const float* state, void* stream) {
+  CGV_REQUIRE(n_problems >= 0 && total_blocks >= 0, "bad size");
+  if (n_problems == 0 || total_blocks == 0) return 0;
+  CGV_REQUIRE(table_dev && arena_g && arena_p && arena_m && arena_v && state, "null pointer");
+  CGV_REQUIRE(max_lds_floats > 0 && max_lds_floats <= 16000, "LDS request out of range");
+  CGV_REQUIRE(((((uintptr_t)arena_g | (uintptr_t)arena_p | (uintptr_t)arena_m | (uintptr_t)arena_v)) & 15) == 0,
+              "arenas must be 16-byte aligned");
+  hipLaunchKernelGGL(cgv::grouped_wgrad_t<true>, dim3(total_blocks), dim3(256), sizeof(float) * (size_t)max_lds_floats,
+                     (hipStream_t)stream, reinterpret_cast<const cgv::WgradProblem*>(table_dev), n_problems,
+                     cgv::RankUpdateArgs{arena_g, arena_p, arena_m, arena_v, state, lr, beta1, beta2, eps});
+  return cgv::check_launch("cgv_grouped_wgrad_adam");
 }
 
 /* Weight gradients over gathered operand rows (include/cgvae_hip.h: data-parallel operand exchange). */

@@ -480,6 +480,9 @@ class _UpdateBlockFused(torch.autograd.Function):
         t0, acc0, _ = _grad_target(W0, W0)
         tb0, accb0, _ = _grad_target(b0, b0)
         wgrad_queue.enqueue(g_a0, stack, z0, 1, t0, tb0, acc0)
+        # operand rows of these weights' gradient problems (trainer: rank-update layers go to the front of the arena)
+        u_w._cgv_rank = v_w._cgv_rank = (3 * n, 2 * F, F)
+        W1._cgv_rank, W0._cgv_rank = (n, W1.shape[0], W1.shape[1]), (n, W0.shape[0], W0.shape[1])
         if acc1 != accb1 or acc0 != accb0:
             raise RuntimeError("weight and bias of one layer disagree on first-write / accumulate state")
         if not wgrad_queue.active:

@@ -146,6 +146,24 @@ class WeightGradQueue:
             torch.cuda.current_stream().synchronize()
         self._deferred = []
 
+    def small_table(self, items):
+        """(device record table, total blocks, LDS floats) of the weight-streaming VALU kernels (grouped_wgrad_t: plain
+        store or rank update) for problems of at most 64 rows."""
+        lib = _lib.load()
+        tk, tw, nb = C.c_int(), C.c_int(), C.c_int()
+        buf, block_begin, max_lds = bytearray(), 0, 0
+        for gy, x, z, act, gW, gb, accumulate in items:
+            M, N = gy.shape
+            K = x.shape[1]
+            if lib.cgv_wgrad_plan(M, N, K, C.byref(tk), C.byref(tw), C.byref(nb)) != 0:
+                raise RuntimeError(lib.cgv_last_error_string().decode())
+            buf += self.RECORD.pack(gy.data_ptr(), x.data_ptr(), z.data_ptr() if z is not None else 0, gW.data_ptr(),
+                                    gb.data_ptr() if gb is not None else 0, M, N, K, int(accumulate), int(act),
+                                    block_begin, tk.value, tw.value, 0, 0, 0)
+            block_begin += nb.value
+            max_lds = max(max_lds, lib.cgv_wgrad_lds_floats(M, tw.value))
+        return self.upload(bytes(buf), items[0][0].device), block_begin, max_lds
+
     def launch(self, items):
         """Grouped launches for ``items`` (tuples as queued by ``enqueue``), writing into their gW / gb targets: ONE for
         the problems of at most 64 rows (weight-streaming VALU kernel, grouped_wgrad_k) and ONE for those with more
@@ -163,18 +181,7 @@ class WeightGradQueue:
         dev = items[0][0].device
         tk, tw, nb = C.c_int(), C.c_int(), C.c_int()
         if small:
-            buf, block_begin, max_lds = bytearray(), 0, 0
-            for gy, x, z, act, gW, gb, accumulate in small:
-                M, N = gy.shape
-                K = x.shape[1]
-                if lib.cgv_wgrad_plan(M, N, K, C.byref(tk), C.byref(tw), C.byref(nb)) != 0:
-                    raise RuntimeError(lib.cgv_last_error_string().decode())
-                buf += self.RECORD.pack(gy.data_ptr(), x.data_ptr(), z.data_ptr() if z is not None else 0, gW.data_ptr(),
-                                        gb.data_ptr() if gb is not None else 0, M, N, K, int(accumulate), int(act),
-                                        block_begin, tk.value, tw.value, 0, 0, 0)
-                block_begin += nb.value
-                max_lds = max(max_lds, lib.cgv_wgrad_lds_floats(M, tw.value))
-            table = self.upload(bytes(buf), dev)
+            table, block_begin, max_lds = self.small_table(small)
             _lib.call("cgv_grouped_wgrad", _lib.ptr(table), len(small), block_begin, max_lds, _lib.stream_ptr(),
                       tag="grouped_wgrad")
         if large:
@@ -296,7 +303,7 @@ class _LinearFn(torch.autograd.Function):
                         _lib.call("cgv_tile_linear_bwd_input_act", _lib.ptr(gy2), _lib.ptr(z) if act != ACT_NONE else None,
                                   _lib.ptr(weight), _lib.ptr(gx), M, N, K, act, st)
                     gx = gx.reshape(gy.shape[:-1] + (K,))
-                w_param._cgv_exch = (M, N, K)
+                w_param._cgv_exch = w_param._cgv_rank = (M, N, K)
                 tw, acc_w, _ = _grad_target(w_param, weight)
                 tb, acc_b = None, acc_w
                 if need_b:
@@ -331,7 +338,7 @@ class _LinearFn(torch.autograd.Function):
         if need_w:
             # row count / shape of this layer's weight-gradient problem: the data-parallel trainer sorts the layers
             # whose operand rows are cheaper to exchange than their gradients to the front of the arena
-            w_param._cgv_exch = (M, N, K)
+            w_param._cgv_exch = w_param._cgv_rank = (M, N, K)
             if b_param is not None:
                 b_param._cgv_exch = (M, N, K)
             tw, acc_w, gw = _grad_target(w_param, weight)

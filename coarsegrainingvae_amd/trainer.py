@@ -279,7 +279,8 @@ class Trainer:
 
     def __init__(self, model, lr: float, beta: float, gamma: float, world_size: int = 1, group=None,
                  fused_optimizer: bool = True, betas=(0.9, 0.999), eps: float = 1e-8, max_norm: float = CLIP_NORM,
-                 always_sync: bool = False, exchange: str = "auto", sync=None, defer_update: bool = False):
+                 always_sync: bool = False, exchange: str = "auto", sync=None, defer_update: bool = False,
+                 rank_update: bool = True):
         """``exchange``: what the ranks exchange for the bead-level linear layers -- "operands" (all-gather of the
         rows that form the weight gradients, see OperandExchange), "gradients" (all-reduce everything), or "auto"
         (operands on the HIP path).  ``sync``: a GradSync-compatible object to use instead of one built from
@@ -291,6 +292,16 @@ class Trainer:
         # optimiser pass is HBM-bound while those forwards are chains of tiny latency-bound launches, so the two share
         # the chip.  ``flush()`` applies a pending update (end of training, before reading parameters, lr changes).
         self.defer_update = bool(defer_update) and fused_optimizer
+        # rank_update (single process, fused optimiser): the weight gradients of the bead-level layers (<= 64 operand
+        # rows) are never written -- their norm comes from the operands (cgv_wgrad_gram) and each tile of g^T x goes
+        # straight through the Adam update of its weights (cgv_grouped_wgrad_adam).  ``p.grad`` of those weights then
+        # holds stale data; pass rank_update=False to materialise every gradient.
+        self.rank_update = bool(rank_update) and fused_optimizer and not self.defer_update
+        self._rank_hi = 0             # arena floats [0, _rank_hi) belong to rank-update weights
+        self._rank_numel = 0
+        self._rank_step = None        # this step's (table, problems, blocks, lds, items) once the Gram launch is out
+        self.rank_steps = 0           # steps that took the rank-update path / fell back to materialised gradients
+        self.rank_fallbacks = 0
         self._pending = False
         self._side = None
         self._dec_ranges = None
@@ -386,8 +397,22 @@ class Trainer:
                 t = getattr(p, "_cgv_exch", None)
                 return t is not None and t[0] % 4 == 0 and world * t[0] * (t[1] + t[2]) <= t[1] * t[2]
             live = sorted(live, key=lambda p: 0 if exchanged(p) else 1)
+        n_rank = 0
+        if self.rank_update and self.sync is None and on_device:
+            lib = _lib.load()
+
+            def ranked(p):
+                t = getattr(p, "_cgv_rank", None)
+                return t is not None and p.dim() == 2 and bool(lib.cgv_rank_update_supported(t[0], t[1], t[2]))
+            live = sorted(live, key=lambda p: 0 if ranked(p) else 1)       # stable: u_mat / v_mat pairs stay adjacent
+            n_rank = sum(1 for p in live if ranked(p))
         self.arena = ParamArena(live)
         dev = self.arena.p.device
+        if n_rank:
+            self._rank_hi = self.arena.offsets[n_rank] if n_rank < len(live) else self.arena.numel
+            self._rank_numel = sum(p.numel() for p in live[:n_rank])
+            self._rank_sumsq = torch.zeros(wgrad_queue.MAX_PROBLEMS, dtype=torch.float64, device=dev)
+            self._rank_ws = None          # Gram workspace, sized at the first rank-update step
         self.exchange = OperandExchange(self.sync, self.arena, wgrad_queue) if use_exchange else None
         # arena ranges of the model's backward buckets (decoder layer groups, in the order their gradients become
         # final): each is all-reduced as soon as it is, under the rest of backward
@@ -542,7 +567,7 @@ class Trainer:
                 self.exchange.begin_step()
             with wgrad_queue.collect():          # bead-level weight gradients: queued, then ONE grouped launch
                 loss.backward()
-            self._flush_queue(use_ex)
+            self._flush_queue(use_ex, rank=train and self.fused and self.sync is None)
             if hasattr(self.model, "bucket_done"):
                 self.model.bucket_done = None
         if not train:                                               # validation: backward only (utils.py:160)
@@ -560,13 +585,24 @@ class Trainer:
         scale = 1.0 / self.world
         if self.fused:
             a = self.arena
-            _lib.call("cgv_optim_prepare", _lib.ptr(a.g), a.numel, self.betas[0], self.betas[1], self.max_norm, scale,
+            rank, self._rank_step = self._rank_step, None
+            lo = self._rank_hi if rank else 0                # [0, lo): gradients that exist only as operand rows
+            _lib.call("cgv_optim_prepare_extra", a.g.data_ptr() + 4 * lo, a.numel - lo,
+                      _lib.ptr(self._rank_sumsq) if rank else None,
+                      rank[1] if rank else 0,
+                      self.betas[0], self.betas[1], self.max_norm, scale,
                       _lib.ptr(decision.reshape(1).float().contiguous()), threshold, _lib.ptr(self.state),
                       _lib.ptr(self.partial), _lib.stream_ptr())
             if self.defer_update:
                 self._pending = True                         # applied when the next step opens (or by flush())
             else:
-                self._adam_apply(0, a.numel)
+                self._adam_apply(lo, a.numel)
+                if rank:
+                    table, n, blocks, lds, _items = rank
+                    _lib.call("cgv_grouped_wgrad_adam", _lib.ptr(table), n, blocks, lds, _lib.ptr(a.g), _lib.ptr(a.p),
+                              _lib.ptr(self.m), _lib.ptr(self.v), self.lr, self.betas[0], self.betas[1], self.eps,
+                              _lib.ptr(self.state), _lib.stream_ptr(), tag="grouped_wgrad_adam")
+                    self.rank_steps += 1
         else:
             if self.world > 1:
                 self.arena.g.mul_(scale)
@@ -580,7 +616,7 @@ class Trainer:
         """A parameter's range extended over its alignment padding (zeros), so that neighbours merge."""
         return (r[0], (r[1] + _ALIGN - 1) // _ALIGN * _ALIGN)
 
-    def _flush_queue(self, use_exchange: bool):
+    def _flush_queue(self, use_exchange: bool, rank: bool = False):
         """Materialise the queued bead-level weight gradients: locally (one grouped launch), or -- data parallel --
         by starting the operand exchange for the layers it pays for (OperandExchange) and launching the rest."""
         items = wgrad_queue.take()
@@ -588,8 +624,37 @@ class Trainer:
             exchanged, local = self.exchange.split(items)
             wgrad_queue.launch(local)
             self.exchange.submit(exchanged)
+        elif rank and self._rank_hi:
+            wgrad_queue.launch(self._start_rank_update(items))
         else:
             wgrad_queue.launch(items)
+
+    def _start_rank_update(self, items):
+        """Rank-update layers of this step: Gram launch (their gradient norms + bias gradients) now, the fused
+        weight-gradient / Adam launch after the norm is known (``_finish_rank_update``).  Returns the items that are
+        materialised as usual.  Falls back to materialising everything unless the queued problems cover the
+        rank-update weights exactly once (a weight used twice in a step accumulates; an unused one still needs its
+        moments decayed)."""
+        ranked, rest = [], []
+        for it in items:
+            r = self.arena.range_of(it[4])
+            (ranked if r is not None and r[1] <= self._rank_hi and not it[6] else rest).append(it)
+        in_range = [it for it in rest if (self.arena.range_of(it[4]) or (self._rank_hi, 0))[0] < self._rank_hi]
+        lib = _lib.load()
+        fits = all(lib.cgv_rank_update_supported(it[0].shape[0], it[0].shape[1], it[1].shape[1]) for it in ranked)
+        if in_range or not fits or sum(it[4].numel() for it in ranked) != self._rank_numel:
+            self.rank_fallbacks += 1
+            return items
+        table, blocks, lds = wgrad_queue.small_table(ranked)
+        need = int(lib.cgv_wgrad_gram_workspace_bytes(len(ranked)))
+        if self._rank_ws is None or self._rank_ws.numel() < need:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("run one eager step before capturing (rank-update workspace)")
+            self._rank_ws = torch.empty(need, dtype=torch.uint8, device=self.arena.p.device)
+        _lib.call("cgv_wgrad_gram", _lib.ptr(table), len(ranked), _lib.ptr(self._rank_sumsq), _lib.ptr(self._rank_ws),
+                  self._rank_ws.numel(), _lib.stream_ptr(), tag="wgrad_gram")
+        self._rank_step = (table, len(ranked), blocks, lds, ranked)
+        return rest
 
     def _bucket_done(self, index: int):
         """Autograd-thread callback (model.bucket_done): the gradients of backward bucket ``index`` are final.

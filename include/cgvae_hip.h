@@ -378,6 +378,25 @@ int cgv_optim_prepare(const float* g, int64_t n, float beta1, float beta2, float
 int cgv_adam_apply(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                    const float* state, void* stream);
 
+/* Rank-update layers (bead-level Dense / nn.Linear weights: M <= 64 operand rows against 0.36 - 3.2 M weights).  Their
+ * weight gradient gW = g^T x is never written: cgv_wgrad_gram gives its squared Frobenius norm from the operands
+ * (sum over row pairs of (g_a . g_b)(x_a . x_b), in double; sumsq[i] for table record i) and writes the bias gradients;
+ * cgv_optim_prepare_extra is cgv_optim_prepare over the materialised part of the arena plus those norms; and
+ * cgv_grouped_wgrad_adam re-forms each gW tile (the table and tiling of cgv_grouped_wgrad) and applies the clipped Adam
+ * update to the weights, moments addressed through gW's offset in the gradient arena.  Replaces, for these layers,
+ * Dense's autograd weight gradient (CoarseGrainingVAE/modules.py:103-114) + clip_grad_norm_ + Adam.step
+ * (scripts/utils.py:150-157) with 24 instead of 36 bytes of HBM traffic per weight.  Records must have accumulate = 0. */
+int cgv_wgrad_gram(const void* table_dev, int n_problems, double* sumsq, void* workspace, size_t workspace_bytes,
+                   void* stream);
+size_t cgv_wgrad_gram_workspace_bytes(int n_problems);
+int cgv_rank_update_supported(int M, int N, int K);   /* 1 when a layer with M operand rows can take this path (M <= 40) */
+int cgv_optim_prepare_extra(const float* g, int64_t n, const double* extra, int n_extra, float beta1, float beta2,
+                            float max_norm, float grad_scale, const float* loss, float skip_threshold, float* state,
+                            float* partial, void* stream);
+int cgv_grouped_wgrad_adam(const void* table_dev, int n_problems, int total_blocks, int max_lds_floats,
+                           const float* arena_g, float* arena_p, float* arena_m, float* arena_v, float lr, float beta1,
+                           float beta2, float eps, const float* state, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1169,7 +1169,7 @@ def test_deferred_update_equals_in_step_update(captured):
     def run(defer):
         model = cg.build_model(64, w["n_rbf"], w["atom_cutoff"], w["cg_cutoff"], 2, 3, w["n_cgs"], det=True, seed=123).to(DEV)
         batch = cg.synthetic_batch("chignolin", n_frames=2, seed=4, device=DEV)
-        tr = Trainer(model, lr=1e-3, beta=w["beta"], gamma=w["gamma"], defer_update=defer)
+        tr = Trainer(model, lr=1e-3, beta=w["beta"], gamma=w["gamma"], defer_update=defer, rank_update=False)
         losses = [float(tr.step(batch)) for _ in range(3)]
         if captured:
             tr.capture(batch, warmup=0, train=True)
@@ -1192,3 +1192,98 @@ def test_deferred_update_equals_in_step_update(captured):
         assert torch.equal(p0[k], p1[k]), k
     # the moment arenas have the same content (the arena order is the same in both runs)
     assert torch.equal(m0, m1)
+
+
+def test_wgrad_gram_norm_and_fused_adam_vs_fp64():
+    """cgv_wgrad_gram: ||g^T x||_F^2 from the operand rows (+ bias gradient); cgv_grouped_wgrad_adam: the Adam update of
+    the weights from tiles of g^T x that are never stored.  Checked against fp64 torch on the shapes the chignolin and
+    update block produce (12 / 36 / 40 rows, with and without an activation derivative)."""
+    from coarsegrainingvae_amd.primitives import WeightGradQueue
+    lib = cg._lib.load()
+    g = torch.Generator(device=DEV).manual_seed(5)
+    shapes = [(12, 600, 600, 1, True), (12, 1800, 600, 0, True), (36, 1200, 600, 0, False), (40, 200, 328, 2, True),
+              (7, 76, 52, 1, False)]
+    n_total = sum(N * K for _, N, K, _, _ in shapes)
+    arena_g = torch.full((n_total,), float("nan"), device=DEV)           # never read, never written
+    arena_p = torch.randn(n_total, device=DEV, generator=g)
+    arena_m = 0.1 * torch.randn(n_total, device=DEV, generator=g)
+    arena_v = 0.01 * (0.1 + torch.rand(n_total, device=DEV, generator=g))     # away from 0: m / sqrt(v) stays conditioned
+    p0, m0, v0 = arena_p.double().clone(), arena_m.double().clone(), arena_v.double().clone()
+    items, refs, off = [], [], 0
+    for M, N, K, act, bias in shapes:
+        gy = torch.randn(M, N, device=DEV, generator=g)
+        x = torch.randn(M, K, device=DEV, generator=g)
+        z = torch.randn(M, N, device=DEV, generator=g) if act else None
+        gb = torch.full((N,), float("nan"), device=DEV) if bias else None
+        items.append((gy, x, z, act, arena_g[off:off + N * K].view(N, K), gb, False))
+        gd = gy.double()
+        if act:
+            zd = z.double()
+            sg = torch.sigmoid(zd)
+            d = {1: sg * (1 + zd * (1 - sg)), 2: 1 - torch.tanh(zd) ** 2}[act]
+            gd = gd * d
+        refs.append((gd.T @ x.double(), gd.sum(0), off))
+        off += N * K
+    q = WeightGradQueue()
+    table, blocks, lds = q.small_table(items)
+    sumsq = torch.zeros(len(items), dtype=torch.float64, device=DEV)
+    ws = torch.empty(int(lib.cgv_wgrad_gram_workspace_bytes(len(items))), dtype=torch.uint8, device=DEV)
+    cg._lib.call("cgv_wgrad_gram", cg._lib.ptr(table), len(items), cg._lib.ptr(sumsq), cg._lib.ptr(ws), ws.numel(),
+                 cg._lib.stream_ptr())
+    for k, (gw, gbias, _) in enumerate(refs):
+        assert abs(float(sumsq[k]) - float((gw ** 2).sum())) <= 1e-6 * float((gw ** 2).sum())
+        if items[k][5] is not None:
+            assert torch.allclose(items[k][5].double(), gbias, rtol=1e-5, atol=1e-5)
+    # the decision pass on an empty materialised range + these norms, then the fused update
+    state = torch.zeros(lib.cgv_optim_state_floats(), device=DEV)
+    partial = torch.empty(lib.cgv_optim_partial_floats(), device=DEV)
+    lr, b1, b2, eps, max_norm = 1e-3, 0.9, 0.999, 1e-8, 0.01
+    for step in range(2):
+        cg._lib.call("cgv_optim_prepare_extra", arena_g.data_ptr(), 0, cg._lib.ptr(sumsq), len(items), b1, b2, max_norm, 1.0,
+                     None, 0.0, cg._lib.ptr(state), cg._lib.ptr(partial), cg._lib.stream_ptr())
+        cg._lib.call("cgv_grouped_wgrad_adam", cg._lib.ptr(table), len(items), blocks, lds, cg._lib.ptr(arena_g),
+                     cg._lib.ptr(arena_p), cg._lib.ptr(arena_m), cg._lib.ptr(arena_v), lr, b1, b2, eps, cg._lib.ptr(state),
+                     cg._lib.stream_ptr())
+        norm = sum(float((gw ** 2).sum()) for gw, _, _ in refs) ** 0.5
+        assert abs(float(state[1]) - norm) <= 1e-5 * norm
+        clip = min(1.0, max_norm / (norm + 1e-6))
+        for gw, _, o in refs:
+            gflat = (gw * clip).reshape(-1)
+            sl = slice(o, o + gflat.numel())
+            m0[sl] = b1 * m0[sl] + (1 - b1) * gflat
+            v0[sl] = b2 * v0[sl] + (1 - b2) * gflat * gflat
+            bc1, bc2 = 1 - b1 ** (step + 1), 1 - b2 ** (step + 1)
+            p0[sl] -= (lr / bc1) * m0[sl] / (v0[sl].sqrt() / bc2 ** 0.5 + eps)
+    assert torch.isnan(arena_g).all()                                    # the gradient arena was never touched
+    assert torch.allclose(arena_m.double(), m0, rtol=2e-5, atol=1e-9)
+    assert torch.allclose(arena_v.double(), v0, rtol=2e-5, atol=1e-12)
+    err = (arena_p.double() - p0).abs()
+    assert float(err.max()) <= 5e-6, (float(err.max()), int(err.argmax()), [r[2] for r in refs])
+
+
+@pytest.mark.parametrize("captured", [False, True])
+def test_rank_update_training_matches_materialised_gradients(captured):
+    """Trainer(rank_update=True) -- bead-level weight gradients never written -- against rank_update=False: same losses,
+    norms and parameters up to the rounding of the norm (Gram form vs sum of squared entries)."""
+    from coarsegrainingvae_amd.trainer import Trainer
+    w = cg.data.WORKLOADS["chignolin"]
+
+    def run(rank):
+        model = cg.build_model(64, w["n_rbf"], w["atom_cutoff"], w["cg_cutoff"], 2, 3, w["n_cgs"], det=True, seed=123).to(DEV)
+        batch = cg.synthetic_batch("chignolin", n_frames=2, seed=4, device=DEV)
+        tr = Trainer(model, lr=1e-3, beta=w["beta"], gamma=w["gamma"], rank_update=rank)
+        losses = [float(tr.step(batch)) for _ in range(3)]
+        if captured:
+            tr.capture(batch, warmup=0, train=True)
+        for k in range(5):
+            losses.append(float(tr.step(batch, train=(k != 2))))       # one validation step in between
+        norm = float(tr.state[1])
+        return losses, {k: v.clone() for k, v in model.state_dict().items()}, norm, tr
+
+    l0, p0, n0, _ = run(False)
+    l1, p1, n1, tr = run(True)
+    assert tr.rank_steps >= 2 and tr.rank_fallbacks == 0 and tr._rank_hi > 0
+    assert abs(n0 - n1) <= 1e-5 * n0
+    assert np.allclose(l0, l1, rtol=1e-5)
+    for k in p0:
+        assert torch.allclose(p0[k], p1[k], rtol=1e-4, atol=1e-6), k

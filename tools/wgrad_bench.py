@@ -38,6 +38,25 @@ for variant in os.environ.get("VARIANTS", "valu,mfma").split(","):
     torch.cuda.synchronize()
     us = 1e3 * e0.elapsed_time(e1) / reps
     print(f"{variant}: M={M} problems={len(items)} out={out_bytes/1e6:.1f} MB  {us:.1f} us/launch (incl. table upload)  {out_bytes/us/1e6:.2f} TB/s written")
+if os.environ.get("RANK", "1") == "1":
+    from coarsegrainingvae_amd import _lib
+    lib = _lib.load()
+    table, blocks, lds = q.small_table(items)
+    sumsq = torch.zeros(len(items), dtype=torch.float64, device=dev)
+    ws = torch.empty(int(lib.cgv_wgrad_gram_workspace_bytes(len(items))), dtype=torch.uint8, device=dev)
+    def timed(fn, reps=30):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return 1e3 * e0.elapsed_time(e1) / reps
+    us = timed(lambda: _lib.call("cgv_wgrad_gram", _lib.ptr(table), len(items), _lib.ptr(sumsq), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+    print(f"gram: {us:.1f} us/launch over {len(items)} problems")
 # check one problem against torch
 gy, x, z, act, gW, gb, _ = items[-1]
 ref = ((gy * (torch.sigmoid(z) * (1 + z * (1 - torch.sigmoid(z))))).double().T @ x.double())
