@@ -412,7 +412,8 @@ class Trainer:
             self._rank_hi = self.arena.offsets[n_rank] if n_rank < len(live) else self.arena.numel
             self._rank_numel = sum(p.numel() for p in live[:n_rank])
             self._rank_sumsq = torch.zeros(wgrad_queue.MAX_PROBLEMS, dtype=torch.float64, device=dev)
-            self._rank_ws = None          # Gram workspace, sized at the first rank-update step
+            # Gram workspace: a queued problem covers at least one rank-update weight
+            self._rank_ws = torch.empty(int(lib.cgv_wgrad_gram_workspace_bytes(n_rank)), dtype=torch.uint8, device=dev)
         self.exchange = OperandExchange(self.sync, self.arena, wgrad_queue) if use_exchange else None
         # arena ranges of the model's backward buckets (decoder layer groups, in the order their gradients become
         # final): each is all-reduced as soon as it is, under the rest of backward
