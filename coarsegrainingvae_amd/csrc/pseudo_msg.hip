@@ -38,6 +38,8 @@ __device__ __forceinline__ void axpy(v3& acc, float a, const v3& x) {
   acc.x = fmaf(a, x.x, acc.x); acc.y = fmaf(a, x.y, acc.y); acc.z = fmaf(a, x.z, acc.z);
 }
 
+constexpr int PSEUDO_EB = 8;      // edges whose source indices / gathers are issued together (pseudo_fwd_k)
+
 template <int R>
 __device__ __forceinline__ float filt(const float (&W)[R + 1], const float* __restrict__ g) {
   float w = W[R] * g[R];
@@ -119,22 +121,39 @@ __global__ __launch_bounds__(576) void pseudo_fwd_k(const float* __restrict__ ph
   const v3 v_i = ldv(v + nf * 3), vb_i = ldv(vbar + nf * 3);
   float ah = 0.f, ahb = 0.f;
   v3 acc{0.f, 0.f, 0.f};
-#pragma unroll 2
-  for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
-    const float* __restrict__ g = geom + (size_t)e * GS;
-    const int j = src[e];
-    const float q = phi[(size_t)j * 9 * F + (size_t)k * F + f] * filt<R>(W, g);
-    const size_t jf = ((size_t)j * F + f) * 3;
-    switch (k) {                                     // wave-uniform
-      case 0: ah = fmaf(q, s_i, ah); ahb += dot(v_i, ldv(vbar + jf)); break;
-      case 1: axpy(acc, q, v3{g[U], g[U + 1], g[U + 2]}); break;
-      case 2: axpy(acc, q, ldv(v + jf)); break;
-      case 3: axpy(acc, q, cross(v_i, ldv(vbar + jf))); break;
-      case 4: axpy(acc, q * sb_i, ldv(vbar + jf)); break;
-      case 5: axpy(acc, q, ldv(vbar + jf)); break;
-      case 6: axpy(acc, q * sb_i, ldv(v + jf)); break;
-      case 7: axpy(acc, q, cross(v_i, ldv(v + jf))); break;
-      default: axpy(acc, q, cross(vb_i, ldv(vbar + jf))); break;
+  // the bead graph's segments are a handful of edges (5 on the chignolin config) and every load of an edge hangs on
+  // its source index: indices, then gathers, are issued for PSEUDO_EB edges at once (one round trip each instead of
+  // one per edge pair); the terms are still added in edge order
+  const float* __restrict__ vsrc = (k == 2 || k == 6 || k == 7) ? v : vbar;      // the one vector this wave's term reads
+  const int e_beg = rowptr[i], e_end = rowptr[i + 1];
+  for (int eb = e_beg; eb < e_end; eb += PSEUDO_EB) {
+    int jj[PSEUDO_EB];
+    float ph[PSEUDO_EB];
+    v3 vj[PSEUDO_EB];
+#pragma unroll
+    for (int u = 0; u < PSEUDO_EB; ++u) jj[u] = src[min(eb + u, e_end - 1)];
+#pragma unroll
+    for (int u = 0; u < PSEUDO_EB; ++u) {
+      ph[u] = phi[(size_t)jj[u] * 9 * F + (size_t)k * F + f];
+      vj[u] = ldv(vsrc + ((size_t)jj[u] * F + f) * 3);
+    }
+#pragma unroll
+    for (int u = 0; u < PSEUDO_EB; ++u) {
+      if (eb + u < e_end) {
+        const float* __restrict__ g = geom + (size_t)(eb + u) * GS;
+        const float q = ph[u] * filt<R>(W, g);
+        switch (k) {                                   // wave-uniform
+          case 0: ah = fmaf(q, s_i, ah); ahb += dot(v_i, vj[u]); break;
+          case 1: axpy(acc, q, v3{g[U], g[U + 1], g[U + 2]}); break;
+          case 2: axpy(acc, q, vj[u]); break;
+          case 3: axpy(acc, q, cross(v_i, vj[u])); break;
+          case 4: axpy(acc, q * sb_i, vj[u]); break;
+          case 5: axpy(acc, q, vj[u]); break;
+          case 6: axpy(acc, q * sb_i, vj[u]); break;
+          case 7: axpy(acc, q, cross(v_i, vj[u])); break;
+          default: axpy(acc, q, cross(vb_i, vj[u])); break;
+        }
+      }
     }
   }
   if (k > 0) { red[k - 1][0][lane] = acc.x; red[k - 1][1][lane] = acc.y; red[k - 1][2][lane] = acc.z; }
@@ -199,24 +218,41 @@ __global__ __launch_bounds__(64) void pseudo_bwd_recv_k(const float* __restrict_
   const v3 gvb_i = gvb ? ldv(gvb + nf * 3) : v3{0.f, 0.f, 0.f};
   float as = 0.f, asb = 0.f;
   v3 av{0.f, 0.f, 0.f}, avb{0.f, 0.f, 0.f};
-#pragma unroll 2
-  for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
-    const float* __restrict__ g = geom + (size_t)e * GS;
-    const int j = src[e];
-    const float* __restrict__ pr = phi + (size_t)j * 9 * F + f;
-    const v3 v_j = ldv(v + ((size_t)j * F + f) * 3), vb_j = ldv(vbar + ((size_t)j * F + f) * 3);
-    const float q0 = pr[0] * filt<R>(W0, g);
-    const float q3 = pr[(size_t)3 * F] * filt<R>(W3, g);
-    const float q4 = pr[(size_t)4 * F] * filt<R>(W4, g);
-    const float q6 = pr[(size_t)6 * F] * filt<R>(W6, g);
-    const float q7 = pr[(size_t)7 * F] * filt<R>(W7, g);
-    const float q8 = pr[(size_t)8 * F] * filt<R>(W8, g);
-    as = fmaf(gh_i, q0, as);
-    asb = fmaf(q4, dot(gv_i, vb_j), fmaf(q6, dot(gvb_i, v_j), asb));
-    axpy(av, ghb_i, vb_j);
-    axpy(av, q3, cross(vb_j, gv_i));
-    axpy(av, q7, cross(v_j, gvb_i));
-    axpy(avb, q8, cross(vb_j, gvb_i));
+  const int e_beg = rowptr[i], e_end = rowptr[i + 1];
+  constexpr int EB = PSEUDO_EB / 2;                  // 14 gathered values per edge here
+  for (int eb = e_beg; eb < e_end; eb += EB) {       // indices, then gathers, for EB edges at once (see pseudo_fwd_k)
+    int jj[EB];
+    float p0[EB], p3[EB], p4[EB], p6[EB], p7[EB], p8[EB];
+    v3 vjs[EB], vbs[EB];
+#pragma unroll
+    for (int u = 0; u < EB; ++u) jj[u] = src[min(eb + u, e_end - 1)];
+#pragma unroll
+    for (int u = 0; u < EB; ++u) {
+      const float* __restrict__ pr = phi + (size_t)jj[u] * 9 * F + f;
+      p0[u] = pr[0]; p3[u] = pr[(size_t)3 * F]; p4[u] = pr[(size_t)4 * F];
+      p6[u] = pr[(size_t)6 * F]; p7[u] = pr[(size_t)7 * F]; p8[u] = pr[(size_t)8 * F];
+      vjs[u] = ldv(v + ((size_t)jj[u] * F + f) * 3);
+      vbs[u] = ldv(vbar + ((size_t)jj[u] * F + f) * 3);
+    }
+#pragma unroll
+    for (int u = 0; u < EB; ++u) {
+      if (eb + u < e_end) {
+        const float* __restrict__ g = geom + (size_t)(eb + u) * GS;
+        const v3 v_j = vjs[u], vb_j = vbs[u];
+        const float q0 = p0[u] * filt<R>(W0, g);
+        const float q3 = p3[u] * filt<R>(W3, g);
+        const float q4 = p4[u] * filt<R>(W4, g);
+        const float q6 = p6[u] * filt<R>(W6, g);
+        const float q7 = p7[u] * filt<R>(W7, g);
+        const float q8 = p8[u] * filt<R>(W8, g);
+        as = fmaf(gh_i, q0, as);
+        asb = fmaf(q4, dot(gv_i, vb_j), fmaf(q6, dot(gvb_i, v_j), asb));
+        axpy(av, ghb_i, vb_j);
+        axpy(av, q3, cross(vb_j, gv_i));
+        axpy(av, q7, cross(v_j, gvb_i));
+        axpy(avb, q8, cross(vb_j, gvb_i));
+      }
+    }
   }
   if (residual) {      // outputs were state + delta: the upstream gradient also flows straight through
     as += gh_i; asb += ghb_i;
