@@ -119,6 +119,106 @@ __global__ __launch_bounds__(64 * QM * QN * KW) void tile_fwd_k(const float* __r
   }
 }
 
+// ------------------------------------------------------------------ fwd, LDS-staged (shapes with many output tiles)
+// The L2-fed tiles above level off near 50 TF/s: every wave pulls its own operand fragments through the L1 (256 bytes
+// per MFMA).  With several 64 x 64 output tiles per CU there is no need to split the reduction for parallelism, so the
+// block stages 64 x 32 slabs of x and W in LDS once (coalesced 128-byte row segments, the next slab's loads in flight
+// during the current slab's MFMAs, two buffers, one barrier per slab) and its 4 waves (2 x 2 quadrants of 32 x 32) read
+// MFMA fragments from there: rows padded to 36 floats make the 16-row x 4-k-group ds_read_b128 conflict-free.
+// Measured (tools/fwd_lds_ab.sh): 2000 x 5400 x 600: 161 vs 235 us (81 TF/s), 2000 x 1800: 56 vs 90, 704 x 5400: 63 vs
+// 88, 332 x 5400: 36 vs 49; a lone block per CU walks its 19 slabs in ~21 us (1.1 us per slab, the same with a
+// three-slab look-ahead, so not the global loads), which loses to the split-reduction tiles below ~450 output tiles.
+// The product is formed transposed -- W fragments as the A operand, x fragments as B -- so that a lane ends up with
+// 4 consecutive n of one row m: bias, activation and the stores are 16-byte wide.
+constexpr int LT = 64, LBK = 32, LLD = LBK + 4;
+
+__global__ __launch_bounds__(256) void tile_fwd_lds_k(const float* __restrict__ x, const float* __restrict__ W,
+                                                      const float* __restrict__ bias, float* __restrict__ y,
+                                                      float* __restrict__ zout, int M, int N, int K, int act) {
+  __shared__ __attribute__((aligned(16))) float As[2][LT * LLD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][LT * LLD];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int i = lane & 15, q = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * LT, n0 = blockIdx.x * LT;
+  const int sr = t >> 3, sc = 4 * (t & 7);           // staging: rows sr, sr + 32; float4 column sc of the slab
+  const float* xrow[2];
+  const float* wrow[2];
+  bool xok[2], wok[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int m = m0 + sr + 32 * u, n = n0 + sr + 32 * u;
+    xok[u] = m < M; wok[u] = n < N;
+    xrow[u] = x + (size_t)(xok[u] ? m : 0) * K + sc;
+    wrow[u] = W + (size_t)(wok[u] ? n : 0) * K + sc;
+  }
+  float4 ra[2], rb[2];
+  auto fetch = [&](int k0) {
+    const bool kok = k0 + sc < K;                    // K % 4 == 0
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      ra[u] = ld4z(xrow[u] + (kok ? k0 : 0), kok && xok[u]);
+      rb[u] = ld4z(wrow[u] + (kok ? k0 : 0), kok && wok[u]);
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      *reinterpret_cast<float4*>(&As[buf][(sr + 32 * u) * LLD + sc]) = ra[u];
+      *reinterpret_cast<float4*>(&Bs[buf][(sr + 32 * u) * LLD + sc]) = rb[u];
+    }
+  };
+  f32x4 acc[2][2];                                   // [n sub-block a][m sub-block b]: D[n][m]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int slabs = (K + LBK - 1) / LBK;
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  for (int kt = 0; kt < slabs; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < slabs) fetch((kt + 1) * LBK);
+    const float* __restrict__ a_s = As[buf] + (32 * wm + i) * LLD + 4 * q;
+    const float* __restrict__ b_s = Bs[buf] + (32 * wn + i) * LLD + 4 * q;
+#pragma unroll
+    for (int ks = 0; ks < LBK / 16; ++ks) {
+      const float4 x0 = *reinterpret_cast<const float4*>(a_s + 16 * ks), x1 = *reinterpret_cast<const float4*>(a_s + 16 * LLD + 16 * ks);
+      const float4 w0 = *reinterpret_cast<const float4*>(b_s + 16 * ks), w1 = *reinterpret_cast<const float4*>(b_s + 16 * LLD + 16 * ks);
+      acc[0][0] = CGV_MFMA(w0.x, x0.x, acc[0][0]); acc[0][1] = CGV_MFMA(w0.x, x1.x, acc[0][1]);
+      acc[1][0] = CGV_MFMA(w1.x, x0.x, acc[1][0]); acc[1][1] = CGV_MFMA(w1.x, x1.x, acc[1][1]);
+      acc[0][0] = CGV_MFMA(w0.y, x0.y, acc[0][0]); acc[0][1] = CGV_MFMA(w0.y, x1.y, acc[0][1]);
+      acc[1][0] = CGV_MFMA(w1.y, x0.y, acc[1][0]); acc[1][1] = CGV_MFMA(w1.y, x1.y, acc[1][1]);
+      acc[0][0] = CGV_MFMA(w0.z, x0.z, acc[0][0]); acc[0][1] = CGV_MFMA(w0.z, x1.z, acc[0][1]);
+      acc[1][0] = CGV_MFMA(w1.z, x0.z, acc[1][0]); acc[1][1] = CGV_MFMA(w1.z, x1.z, acc[1][1]);
+      acc[0][0] = CGV_MFMA(w0.w, x0.w, acc[0][0]); acc[0][1] = CGV_MFMA(w0.w, x1.w, acc[0][1]);
+      acc[1][0] = CGV_MFMA(w1.w, x0.w, acc[1][0]); acc[1][1] = CGV_MFMA(w1.w, x1.w, acc[1][1]);
+    }
+    if (kt + 1 < slabs) stash(buf ^ 1);              // last read one barrier ago
+    __syncthreads();
+  }
+  // lane: m = m0 + 32 wm + 16 b + i, n = n0 + 32 wn + 16 a + 4 q .. + 3
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int n = n0 + 32 * wn + 16 * a + 4 * q;
+    if (n >= N) continue;                            // N % 4 == 0: the float4 is entirely in or out
+    const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int m = m0 + 32 * wm + 16 * b + i;
+      if (m >= M) continue;
+      float4 zv = make_float4(acc[a][b][0] + bv.x, acc[a][b][1] + bv.y, acc[a][b][2] + bv.z, acc[a][b][3] + bv.w);
+      if (act) {
+        if (zout) *reinterpret_cast<float4*>(zout + (size_t)m * N + n) = zv;
+        zv.x = act_fwd(zv.x, act); zv.y = act_fwd(zv.y, act); zv.z = act_fwd(zv.z, act); zv.w = act_fwd(zv.w, act);
+      }
+      *reinterpret_cast<float4*>(y + (size_t)m * N + n) = zv;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ bwd_input
 // gx[m, k] = sum_n g[m, n] W[n, k].  grid (ceil(K/64), ceil(M/(16 MB))), 256 threads; wave w walks n-steps
 // w, w+4, ... (16 rows of W each).  Lane (j = l&15, q = l>>4): A_mb = g[m0 + 16 mb + j][n + 4q ..+3];
@@ -284,7 +384,13 @@ int cgv_tile_linear_fwd(const float* x, const float* W, const float* bias, float
   CGV_REQUIRE(((((uintptr_t)x | (uintptr_t)W)) & 15) == 0, "x and W must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const int tiles32 = ((N + 31) / 32) * ((M + 31) / 32);
-  if (tiles32 >= 2048)                    // enough work for several 64 x 64 tiles on every CU (measured: no gain below)
+  const int tiles64 = ((N + 63) / 64) * ((M + 63) / 64);
+  static const int lds_min = [] { const char* e = getenv("CGV_TILE_FWD_LDS_MIN"); return e ? atoi(e) : 448; }();
+  const bool aligned16 = ((((uintptr_t)y | (uintptr_t)z | (uintptr_t)bias)) & 15) == 0;
+  if (tiles64 >= lds_min && aligned16)    // several 64 x 64 tiles per CU: the LDS-staged kernel (CGV_TILE_FWD_LDS_MIN: A/B)
+    hipLaunchKernelGGL(cgv::tile_fwd_lds_k, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, st, x, W, bias, y, z, M, N, K,
+                       act);
+  else if (tiles32 >= 2048)                    // enough work for several 64 x 64 tiles on every CU (measured: no gain below)
     hipLaunchKernelGGL((cgv::tile_fwd_k<2, 2, 4>), dim3((N + 63) / 64, (M + 63) / 64), dim3(1024), 0, st, x, W, bias, y, z, M,
                        N, K, act);
   else                                    // few tiles: 32 x 32, reduction split 8 ways so every SIMD has loads in flight

@@ -1287,3 +1287,23 @@ def test_rank_update_training_matches_materialised_gradients(captured):
     assert np.allclose(l0, l1, rtol=1e-5)
     for k in p0:
         assert torch.allclose(p0[k], p1[k], rtol=1e-4, atol=1e-6), k
+
+
+@pytest.mark.parametrize("shape", [(1500, 1400, 600, 1), (1411, 1796, 52, 0), (2000, 1800, 600, 2)])
+def test_tile_forward_lds_staged_kernel_vs_fp64(shape):
+    """cgv_tile_linear_fwd on shapes with >= 448 output tiles of 64 x 64 takes the LDS-staged kernel (tile_fwd_lds_k):
+    ragged row / column / reduction tails, bias + activation epilogue, pre-activation output."""
+    M, N, K, act = shape
+    g = torch.Generator(device=DEV).manual_seed(M + N)
+    x = torch.randn(M, K, device=DEV, generator=g)
+    W = torch.randn(N, K, device=DEV, generator=g) / K ** 0.5
+    b = torch.randn(N, device=DEV, generator=g)
+    y = torch.full((M, N), float("nan"), device=DEV)
+    z = torch.full((M, N), float("nan"), device=DEV)
+    cg._lib.call("cgv_tile_linear_fwd", cg._lib.ptr(x), cg._lib.ptr(W), cg._lib.ptr(b), cg._lib.ptr(y), cg._lib.ptr(z), M, N, K, act,
+                 cg._lib.stream_ptr())
+    zr = x.double() @ W.double().T + b.double()
+    yr = {0: zr, 1: zr * torch.sigmoid(zr), 2: torch.tanh(zr)}[act]
+    assert torch.allclose(y.double(), yr, rtol=1e-5, atol=1e-5)
+    if act:
+        assert torch.allclose(z.double(), zr, rtol=1e-5, atol=1e-5)
