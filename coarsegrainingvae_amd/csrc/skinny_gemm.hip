@@ -51,19 +51,38 @@ __global__ __launch_bounds__(64 * WAVES) void skinny_fwd_k(const float* __restri
   f32x4 acc[MB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-  for (int s = s_beg; s < s_end; ++s) {
-    const int k = s * 16 + 4 * q;
-    const bool kok = k < K;                       // K % 4 == 0: a float4 is entirely in or out
-    const float4 a = ldg4_or_zero(wrow + (kok ? k : 0), nok && kok);
+  // Loads are unconditional (rows / columns clamped into range): rows beyond M or N give products that are never
+  // stored, and the reduction tail is zeroed on W's side only.  A guarded load is a branch: the loop then neither
+  // unrolls nor keeps more than one step's loads in flight (s_waitcnt vmcnt(0) per step), and a wave's 2 - 3 steps
+  // each paid a full memory round trip.
+  const float* xrow[MB];
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-      const int m = mb * 16 + i;
-      const float4 b = ldg4_or_zero(x + (size_t)(m < M ? m : 0) * K + (kok ? k : 0), m < M && kok);
-      acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[mb], 0, 0, 0);
-      acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[mb], 0, 0, 0);
-      acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[mb], 0, 0, 0);
-      acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[mb], 0, 0, 0);
+  for (int mb = 0; mb < MB; ++mb) xrow[mb] = x + (size_t)(mb * 16 + i < M ? mb * 16 + i : 0) * K;
+  constexpr int SB = MB >= 3 ? 2 : 4;             // steps whose loads are issued together (the compiler does not
+  for (int s0 = s_beg; s0 < s_end; s0 += SB) {    // unroll this loop by itself: runtime bounds)
+    float4 a[SB], b[SB][MB];
+#pragma unroll
+    for (int u = 0; u < SB; ++u) {
+      const int k = (s0 + u) * 16 + 4 * q;
+      const bool kok = s0 + u < s_end && k < K;   // K % 4 == 0: a float4 is entirely in or out
+      const int kc = kok ? k : 0;
+      a[u] = *reinterpret_cast<const float4*>(wrow + kc);
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) b[u][mb] = *reinterpret_cast<const float4*>(xrow[mb] + kc);
+    }
+#pragma unroll
+    for (int u = 0; u < SB; ++u) {
+      if (s0 + u < s_end) {                       // wave-uniform
+        const bool kok = (s0 + u) * 16 + 4 * q < K;
+        const float4 w = make_float4(kok ? a[u].x : 0.f, kok ? a[u].y : 0.f, kok ? a[u].z : 0.f, kok ? a[u].w : 0.f);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, b[u][mb].x, acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, b[u][mb].y, acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, b[u][mb].z, acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, b[u][mb].w, acc[mb], 0, 0, 0);
+        }
+      }
     }
   }
   if (WAVES > 1) {

@@ -69,28 +69,36 @@ __global__ __launch_bounds__(64 * QM * QN * KW) void tile_fwd_k(const float* __r
   // (strided assignment fetched every line twice: the block's 8 waves thrash the L1 between the two uses)
   const int steps = (K + 15) / 16, per = (steps + KW - 1) / KW;
   const int s_end = min((kq + 1) * per, steps);
-#pragma unroll 4
-  for (int s = kq * per; s < s_end; ++s) {
-    const int k = 16 * s;
-    const bool kok = k + 4 * q < K;                  // K % 4 == 0: a float4 is entirely in or out
-#if defined(CGV_TILE_ABLATE) && CGV_TILE_ABLATE == 2      /* probe builds only: no operand loads */
-    const float4 a0 = make_float4(k, 1.f, 2.f, 3.f), a1 = a0, b0 = make_float4(1.f, k, 2.f, 3.f), b1 = b0;
-#else
-    const float4 a0 = ld4z(xr[0] + (kok ? k : 0), kok && xok[0]), a1 = ld4z(xr[1] + (kok ? k : 0), kok && xok[1]);
-    const float4 b0 = ld4z(wr[0] + (kok ? k : 0), kok && wok[0]), b1 = ld4z(wr[1] + (kok ? k : 0), kok && wok[1]);
-#endif
-#if defined(CGV_TILE_ABLATE) && CGV_TILE_ABLATE == 1      /* probe builds only: no MFMAs */
-    acc[0][0][0] += a0.x + a1.y + b0.z + b1.w; acc[1][1][1] += a0.y + a1.x + b0.w + b1.z;
-    continue;
-#endif
-    acc[0][0] = CGV_MFMA(a0.x, b0.x, acc[0][0]); acc[0][1] = CGV_MFMA(a0.x, b1.x, acc[0][1]);
-    acc[1][0] = CGV_MFMA(a1.x, b0.x, acc[1][0]); acc[1][1] = CGV_MFMA(a1.x, b1.x, acc[1][1]);
-    acc[0][0] = CGV_MFMA(a0.y, b0.y, acc[0][0]); acc[0][1] = CGV_MFMA(a0.y, b1.y, acc[0][1]);
-    acc[1][0] = CGV_MFMA(a1.y, b0.y, acc[1][0]); acc[1][1] = CGV_MFMA(a1.y, b1.y, acc[1][1]);
-    acc[0][0] = CGV_MFMA(a0.z, b0.z, acc[0][0]); acc[0][1] = CGV_MFMA(a0.z, b1.z, acc[0][1]);
-    acc[1][0] = CGV_MFMA(a1.z, b0.z, acc[1][0]); acc[1][1] = CGV_MFMA(a1.z, b1.z, acc[1][1]);
-    acc[0][0] = CGV_MFMA(a0.w, b0.w, acc[0][0]); acc[0][1] = CGV_MFMA(a0.w, b1.w, acc[0][1]);
-    acc[1][0] = CGV_MFMA(a1.w, b0.w, acc[1][0]); acc[1][1] = CGV_MFMA(a1.w, b1.w, acc[1][1]);
+  // The loads of SB steps are issued together, unconditionally (rows clamped into range: products of rows beyond M / N
+  // are never stored; the reduction tail is zeroed on W's side).  Guarded loads are branches: the compiler neither
+  // unrolled the step loop (`#pragma unroll 4` was refused) nor kept more than one step in flight -- every one of a
+  // wave's ~5 steps waited out its own memory round trip (s_waitcnt vmcnt(0)).
+  constexpr int SB = 3;
+  for (int s0 = kq * per; s0 < s_end; s0 += SB) {
+    float4 a0[SB], a1[SB], b0[SB], b1[SB];
+#pragma unroll
+    for (int u = 0; u < SB; ++u) {
+      const int k = 16 * (s0 + u);
+      const int kc = (s0 + u < s_end && k + 4 * q < K) ? k : 0;      // K % 4 == 0: a float4 is entirely in or out
+      a0[u] = *reinterpret_cast<const float4*>(xr[0] + kc); a1[u] = *reinterpret_cast<const float4*>(xr[1] + kc);
+      b0[u] = *reinterpret_cast<const float4*>(wr[0] + kc); b1[u] = *reinterpret_cast<const float4*>(wr[1] + kc);
+    }
+#pragma unroll
+    for (int u = 0; u < SB; ++u) {
+      if (s0 + u >= s_end) break;                  // wave-uniform
+      const bool kok = 16 * (s0 + u) + 4 * q < K;
+      const float4 w0 = make_float4(kok ? b0[u].x : 0.f, kok ? b0[u].y : 0.f, kok ? b0[u].z : 0.f, kok ? b0[u].w : 0.f);
+      const float4 w1 = make_float4(kok ? b1[u].x : 0.f, kok ? b1[u].y : 0.f, kok ? b1[u].z : 0.f, kok ? b1[u].w : 0.f);
+      const float4 x0 = a0[u], x1 = a1[u];
+      acc[0][0] = CGV_MFMA(x0.x, w0.x, acc[0][0]); acc[0][1] = CGV_MFMA(x0.x, w1.x, acc[0][1]);
+      acc[1][0] = CGV_MFMA(x1.x, w0.x, acc[1][0]); acc[1][1] = CGV_MFMA(x1.x, w1.x, acc[1][1]);
+      acc[0][0] = CGV_MFMA(x0.y, w0.y, acc[0][0]); acc[0][1] = CGV_MFMA(x0.y, w1.y, acc[0][1]);
+      acc[1][0] = CGV_MFMA(x1.y, w0.y, acc[1][0]); acc[1][1] = CGV_MFMA(x1.y, w1.y, acc[1][1]);
+      acc[0][0] = CGV_MFMA(x0.z, w0.z, acc[0][0]); acc[0][1] = CGV_MFMA(x0.z, w1.z, acc[0][1]);
+      acc[1][0] = CGV_MFMA(x1.z, w0.z, acc[1][0]); acc[1][1] = CGV_MFMA(x1.z, w1.z, acc[1][1]);
+      acc[0][0] = CGV_MFMA(x0.w, w0.w, acc[0][0]); acc[0][1] = CGV_MFMA(x0.w, w1.w, acc[0][1]);
+      acc[1][0] = CGV_MFMA(x1.w, w0.w, acc[1][0]); acc[1][1] = CGV_MFMA(x1.w, w1.w, acc[1][1]);
+    }
   }
 #pragma unroll
   for (int t = 0; t < 4; ++t)
@@ -251,35 +259,46 @@ __global__ __launch_bounds__(64 * WAVES) void tile_bwd_input_k(const float* __re
     for (int s = 0; s < 4; ++s) acc[mb][s] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int steps = (N + 15) / 16, per = (steps + WAVES - 1) / WAVES;       // contiguous n range per wave (see fwd)
   const int st_end = min((wave + 1) * per, steps);
-#pragma unroll 4
-  for (int st = wave * per; st < st_end; ++st) {
-    const int n = 16 * st;
-    const bool nok = n + 4 * q < N;                  // N % 4 == 0: rows n + 4q .. + 3 are all in or all out
-    float4 a[MB];
+  // SB steps' loads are issued together and unconditionally (see tile_fwd_k: a guarded load is a branch, and a wave's
+  // 14 - 21 steps each waited out their own memory round trip).  Rows beyond M and columns beyond K are clamped into
+  // range -- their products are never stored -- and the reduction tail (n >= N) is zeroed on g's side.
+  // 3 at 16 waves (1024-thread blocks have 128 VGPRs per lane); 2 otherwise: 4 cost the 8-wave variant its second
+  // resident block per CU (132 VGPRs; 704 rows: 12.7 -> 13.2 us per call, while 332 rows gained)
+  constexpr int SB = WAVES >= 16 ? 3 : 2;
+  const float* wcol = W + (kok ? kcol : 0);
+  for (int st0 = wave * per; st0 < st_end; st0 += SB) {
+    float4 a[SB][MB], zz[SB][MB], b[SB][4];
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-      a[mb] = ld4z(gr[mb] + (nok ? n : 0), nok && gok[mb]);
-      if (act) {                                     // g = gy * act'(z) (cgv_dense_grad_prepare's job, without its launch)
-        const float4 zz = ld4z(gr[mb] + zoff + (nok ? n : 0), nok && gok[mb]);
-        a[mb].x *= act_bwd(zz.x, act); a[mb].y *= act_bwd(zz.y, act);
-        a[mb].z *= act_bwd(zz.z, act); a[mb].w *= act_bwd(zz.w, act);
+    for (int u = 0; u < SB; ++u) {
+      const int n = 16 * (st0 + u);
+      const int nc = (st0 + u < st_end && n + 4 * q < N) ? n : 0;    // N % 4 == 0: rows n + 4q .. + 3 are all in or all out
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        a[u][mb] = *reinterpret_cast<const float4*>(gr[mb] + nc);
+        if (act) zz[u][mb] = *reinterpret_cast<const float4*>(gr[mb] + zoff + nc);     // wave-uniform
       }
-    }
-    float4 b[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const bool ok = nok && kok;
-      b[c] = ld4z(W + (size_t)(ok ? n + 4 * q + c : 0) * K + (ok ? kcol : 0), ok);
+      for (int c = 0; c < 4; ++c) b[u][c] = *reinterpret_cast<const float4*>(wcol + (size_t)(nc + 4 * q + c) * K);
     }
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-      const float ac[4] = {a[mb].x, a[mb].y, a[mb].z, a[mb].w};
+    for (int u = 0; u < SB; ++u) {
+      if (st0 + u >= st_end) break;                  // wave-uniform
+      const bool nok = 16 * (st0 + u) + 4 * q < N;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        acc[mb][0] = CGV_MFMA(ac[c], b[c].x, acc[mb][0]);
-        acc[mb][1] = CGV_MFMA(ac[c], b[c].y, acc[mb][1]);
-        acc[mb][2] = CGV_MFMA(ac[c], b[c].z, acc[mb][2]);
-        acc[mb][3] = CGV_MFMA(ac[c], b[c].w, acc[mb][3]);
+      for (int mb = 0; mb < MB; ++mb) {
+        float4 av = a[u][mb];
+        if (act) {                                   // g = gy * act'(z) (cgv_dense_grad_prepare's job, without its launch)
+          av.x *= act_bwd(zz[u][mb].x, act); av.y *= act_bwd(zz[u][mb].y, act);
+          av.z *= act_bwd(zz[u][mb].z, act); av.w *= act_bwd(zz[u][mb].w, act);
+        }
+        const float ac[4] = {nok ? av.x : 0.f, nok ? av.y : 0.f, nok ? av.z : 0.f, nok ? av.w : 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          acc[mb][0] = CGV_MFMA(ac[c], b[u][c].x, acc[mb][0]);
+          acc[mb][1] = CGV_MFMA(ac[c], b[u][c].y, acc[mb][1]);
+          acc[mb][2] = CGV_MFMA(ac[c], b[u][c].z, acc[mb][2]);
+          acc[mb][3] = CGV_MFMA(ac[c], b[u][c].w, acc[mb][3]);
+        }
       }
     }
   }
