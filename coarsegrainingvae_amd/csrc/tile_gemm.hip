@@ -133,9 +133,10 @@ __global__ __launch_bounds__(64 * QM * QN * KW) void tile_fwd_k(const float* __r
 // block stages 64 x 32 slabs of x and W in LDS once (coalesced 128-byte row segments, the next slab's loads in flight
 // during the current slab's MFMAs, two buffers, one barrier per slab) and its 4 waves (2 x 2 quadrants of 32 x 32) read
 // MFMA fragments from there: rows padded to 36 floats make the 16-row x 4-k-group ds_read_b128 conflict-free.
-// Measured (tools/fwd_lds_ab.sh): 2000 x 5400 x 600: 161 vs 235 us (81 TF/s), 2000 x 1800: 56 vs 90, 704 x 5400: 63 vs
-// 88, 332 x 5400: 36 vs 49; a lone block per CU walks its 19 slabs in ~21 us (1.1 us per slab, the same with a
-// three-slab look-ahead, so not the global loads), which loses to the split-reduction tiles below ~450 output tiles.
+// Measured (tools/fwd_lds_ab.sh) against the L2-fed tiles with batched step loads: 2000 x 5400 x 600: 168 vs 201 us
+// (77 TF/s), 2000 x 1800: 57 vs 70, 2000 x 1200: 43 vs 50; 704 x 5400: 63 vs 59, 332 x 5400: 36 vs 35; a lone block
+// per CU walks its 19 slabs in ~21 us (1.1 us per slab, the same with a three-slab look-ahead, so not the global
+// loads), which loses to the split-reduction tiles: used from 1024 rows and 448 output tiles.
 // The product is formed transposed -- W fragments as the A operand, x fragments as B -- so that a lane ends up with
 // 4 consecutive n of one row m: bias, activation and the stores are 16-byte wide.
 constexpr int LT = 64, LBK = 32, LLD = LBK + 4;
@@ -406,7 +407,9 @@ int cgv_tile_linear_fwd(const float* x, const float* W, const float* bias, float
   const int tiles64 = ((N + 63) / 64) * ((M + 63) / 64);
   static const int lds_min = [] { const char* e = getenv("CGV_TILE_FWD_LDS_MIN"); return e ? atoi(e) : 448; }();
   const bool aligned16 = ((((uintptr_t)y | (uintptr_t)z | (uintptr_t)bias)) & 15) == 0;
-  if (tiles64 >= lds_min && aligned16)    // several 64 x 64 tiles per CU: the LDS-staged kernel (CGV_TILE_FWD_LDS_MIN: A/B)
+  // several 64 x 64 tiles per CU and many row tiles: the LDS-staged kernel (704 x 5400 still favours the L2-fed
+  // tiles, 59 vs 63 us; 2000 x 5400: 168 vs 201, 2000 x 1800: 57 vs 70).  CGV_TILE_FWD_LDS_MIN=1: every shape (tests)
+  if (tiles64 >= lds_min && (M >= 1024 || lds_min <= 1) && aligned16)
     hipLaunchKernelGGL(cgv::tile_fwd_lds_k, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, st, x, W, bias, y, z, M, N, K,
                        act);
   else if (tiles32 >= 2048)                    // enough work for several 64 x 64 tiles on every CU (measured: no gain below)

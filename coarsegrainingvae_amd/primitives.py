@@ -365,7 +365,7 @@ def _library_pays(M, N, K, forward: bool) -> bool:
     the hand-written tiles -- it has a ~18 us floor but reaches 57-98 TF/s where the 32 x 32 L2-fed tiles level off at
     48 (tools/lib_gemm_bench.py: bwd_input 704 x 1800 x 600: 19 vs 30 us; forward 2000 x 1800 x 600: 44 vs 90 us)."""
     if forward:
-        return (M >= 1024 and N * K >= 1024 * 600) or (M >= 640 and N * K >= 1800 * 600)     # 704 x 1800 x 600: 26.7 vs 31.4 us
+        return M >= 1024 and N * K >= 1024 * 600     # 2000 x 1800 x 600: 44 vs 57 us; 704 x 1800 x 600: 26.6 vs 25.3 for the tiles
     return M >= 512 and N * K >= 1024 * 600
 
 
