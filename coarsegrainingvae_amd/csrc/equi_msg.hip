@@ -592,7 +592,14 @@ __global__ __launch_bounds__(64 * RED_SLICES) void equi_msg_bwd_reduce(const flo
   if (k >= 0 && f < F) {
     const size_t stride = (size_t)K * (R + 1) * F;
     const float* p = part + ((size_t)k * (R + 1) + n) * F + f;
-    for (int c = s; c < n_chunks; c += RED_SLICES) acc += p[(size_t)c * stride];
+    constexpr int CB = 8;                            // chunks loaded together (clamped index, surplus zeroed; same order):
+    for (int c0 = s; c0 < n_chunks; c0 += RED_SLICES * CB) {       // the plain loop was one memory round trip per chunk
+      float v[CB];
+#pragma unroll
+      for (int u = 0; u < CB; ++u) v[u] = p[(size_t)min(c0 + RED_SLICES * u, n_chunks - 1) * stride];
+#pragma unroll
+      for (int u = 0; u < CB; ++u) acc += c0 + RED_SLICES * u < n_chunks ? v[u] : 0.f;
+    }
   }
   red[s][threadIdx.x] = acc;
   __syncthreads();

@@ -376,7 +376,14 @@ __global__ __launch_bounds__(64 * PRED_SLICES) void pseudo_bwd_reduce(const floa
   if (f < F) {
     const size_t stride = (size_t)9 * (R + 1) * F;
     const float* p = part + ((size_t)k * (R + 1) + n) * F + f;
-    for (int c = sl; c < n_chunks; c += PRED_SLICES) acc += p[(size_t)c * stride];
+    constexpr int CB = 4;                            // chunks loaded together (clamped index, surplus zeroed; same order)
+    for (int c0 = sl; c0 < n_chunks; c0 += PRED_SLICES * CB) {
+      float v[CB];
+#pragma unroll
+      for (int u = 0; u < CB; ++u) v[u] = p[(size_t)min(c0 + PRED_SLICES * u, n_chunks - 1) * stride];
+#pragma unroll
+      for (int u = 0; u < CB; ++u) acc += c0 + PRED_SLICES * u < n_chunks ? v[u] : 0.f;
+    }
   }
   red[sl][threadIdx.x] = acc;
   __syncthreads();

@@ -272,10 +272,18 @@ __global__ __launch_bounds__(256) void skinny_bwd_input_reduce_k(const float* __
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (i < n4) {
     const float4* p4 = reinterpret_cast<const float4*>(part) + i;
-#pragma unroll 4
-    for (int p = sub; p < NS; p += 4) {
-      const float4 v = p4[(size_t)p * n4];
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    // a lane's 5 - 8 slices are loaded together (slice index clamped, the surplus zeroed afterwards): the runtime-bounded
+    // loop left a remainder of single loads, each a memory round trip of this 4 us launch; summation order unchanged
+    constexpr int RB = 8;
+    for (int p0 = sub; p0 < NS; p0 += 4 * RB) {
+      float4 v[RB];
+#pragma unroll
+      for (int u = 0; u < RB; ++u) v[u] = p4[(size_t)min(p0 + 4 * u, NS - 1) * n4];
+#pragma unroll
+      for (int u = 0; u < RB; ++u) {
+        const bool ok = p0 + 4 * u < NS;
+        acc.x += ok ? v[u].x : 0.f; acc.y += ok ? v[u].y : 0.f; acc.z += ok ? v[u].z : 0.f; acc.w += ok ? v[u].w : 0.f;
+      }
     }
   }
 #pragma unroll
