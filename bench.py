@@ -324,7 +324,7 @@ def main():
                                    f"cutoffs {w['atom_cutoff']}/{w['cg_cutoff']}",
                        "step": "fwd+loss+bwd" + (dp_step if world > 1 else "") + "+clip+adam",
                        "global_batch": world * frames, "directed_edges_rank0": int(batch["_graph"].atom.n_edges),
-                       "optimizer": args.optimizer, "deferred_update": bool(trainer.defer_update), "hip_graph": bool(use_graph), "skip_dead_vector_channel": bool(args.skip_dead_vector_channel),
+                       "optimizer": args.optimizer, "deferred_update": bool(trainer.defer_update), "rank_update": bool(trainer._rank_hi), "hip_graph": bool(use_graph), "skip_dead_vector_channel": bool(args.skip_dead_vector_channel),
                        "parallelism": f"dp{world}"},
             "loss": loss, "roofline": roofline, "cpu_baseline": cpu,
         }
