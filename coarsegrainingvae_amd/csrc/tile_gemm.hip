@@ -79,7 +79,8 @@ __global__ __launch_bounds__(64 * QM * QN * KW) void tile_fwd_k(const float* __r
 #pragma unroll
     for (int u = 0; u < SB; ++u) {
       const int k = 16 * (s0 + u);
-      const int kc = (s0 + u < s_end && k + 4 * q < K) ? k : 0;      // K % 4 == 0: a float4 is entirely in or out
+      // K % 4 == 0: a float4 is entirely in or out; out of range -> the row's first float4 (xr / wr carry + 4 q)
+      const int kc = (s0 + u < s_end && k + 4 * q < K) ? k : -4 * q;
       a0[u] = *reinterpret_cast<const float4*>(xr[0] + kc); a1[u] = *reinterpret_cast<const float4*>(xr[1] + kc);
       b0[u] = *reinterpret_cast<const float4*>(wr[0] + kc); b1[u] = *reinterpret_cast<const float4*>(wr[1] + kc);
     }
@@ -272,14 +273,17 @@ __global__ __launch_bounds__(64 * WAVES) void tile_bwd_input_k(const float* __re
 #pragma unroll
     for (int u = 0; u < SB; ++u) {
       const int n = 16 * (st0 + u);
-      const int nc = (st0 + u < st_end && n + 4 * q < N) ? n : 0;    // N % 4 == 0: rows n + 4q .. + 3 are all in or all out
+      // N % 4 == 0: rows n + 4q .. + 3 are all in or all out; out of range -> g's first float4 of the row (gr carries
+      // + 4 q) and W's rows 0 .. 3, both always there
+      const bool in = st0 + u < st_end && n + 4 * q < N;
+      const int ng = in ? n : -4 * q, nw = in ? n + 4 * q : 0;
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
-        a[u][mb] = *reinterpret_cast<const float4*>(gr[mb] + nc);
-        if (act) zz[u][mb] = *reinterpret_cast<const float4*>(gr[mb] + zoff + nc);     // wave-uniform
+        a[u][mb] = *reinterpret_cast<const float4*>(gr[mb] + ng);
+        if (act) zz[u][mb] = *reinterpret_cast<const float4*>(gr[mb] + zoff + ng);     // wave-uniform
       }
 #pragma unroll
-      for (int c = 0; c < 4; ++c) b[u][c] = *reinterpret_cast<const float4*>(wcol + (size_t)(nc + 4 * q + c) * K);
+      for (int c = 0; c < 4; ++c) b[u][c] = *reinterpret_cast<const float4*>(wcol + (size_t)(nw + c) * K);
     }
 #pragma unroll
     for (int u = 0; u < SB; ++u) {

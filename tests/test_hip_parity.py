@@ -1307,3 +1307,26 @@ def test_tile_forward_lds_staged_kernel_vs_fp64(shape):
     assert torch.allclose(y.double(), yr, rtol=1e-5, atol=1e-5)
     if act:
         assert torch.allclose(z.double(), zr, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("shape", [(100, 8, 8), (70, 12, 4), (333, 20, 8), (96, 4, 24)])
+def test_tile_gemms_with_reductions_shorter_than_a_step(shape):
+    """Tile forward / bwd_input with K (resp. N) below the 16-float step of the kernels: the lanes beyond the reduction
+    read a clamped, in-range address and must contribute nothing -- operands sit at the very end of their allocation
+    neighbourhood and are surrounded by NaNs, so an out-of-row read shows."""
+    M, N, K = shape
+    g = torch.Generator(device=DEV).manual_seed(N * K)
+    def fenced(rows, cols):
+        buf = torch.full((rows * cols + 64,), float("nan"), device=DEV)
+        t = buf[32:32 + rows * cols].view(rows, cols)
+        t.copy_(torch.randn(rows, cols, device=DEV, generator=g))
+        return t
+    x, W, gy = fenced(M, K), fenced(N, K), fenced(M, N)
+    b = torch.randn(N, device=DEV, generator=g)
+    y, z = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    cg._lib.call("cgv_tile_linear_fwd", cg._lib.ptr(x), cg._lib.ptr(W), cg._lib.ptr(b), cg._lib.ptr(y), cg._lib.ptr(z), M, N, K, 0,
+                 cg._lib.stream_ptr())
+    assert torch.allclose(y.double(), x.double() @ W.double().T + b.double(), rtol=1e-5, atol=1e-5)
+    gx = torch.empty(M, K, device=DEV)
+    cg._lib.call("cgv_tile_linear_bwd_input", cg._lib.ptr(gy), cg._lib.ptr(W), cg._lib.ptr(gx), M, N, K, cg._lib.stream_ptr())
+    assert torch.allclose(gx.double(), gy.double() @ W.double(), rtol=1e-5, atol=1e-5)
