@@ -49,9 +49,17 @@ __global__ __launch_bounds__(BLOCK) void segment_reduce_k(const float* __restric
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) vadd(acc, x[u]);
   }
-  for (; p < end; ++p) {
-    const int row = perm ? perm[p] : p;
-    vadd(acc, *reinterpret_cast<const V*>(src + (size_t)row * C + c));
+  if (p < end) {                      // the last < UNROLL rows: one batch of clamped loads (a row-by-row tail is one
+    V x[UNROLL];                      // memory round trip per row: 5 of a 125-row segment's ~20), same summation order
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int pp = min(p + u, end - 1);
+      const int row = perm ? perm[pp] : pp;
+      x[u] = *reinterpret_cast<const V*>(src + (size_t)row * C + c);
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u)
+      if (p + u < end) vadd(acc, x[u]);
   }
   if (mean) {
     const int len = end - beg;
