@@ -382,14 +382,27 @@ __global__ __launch_bounds__(256) void grouped_wgrad_t(const WgradProblem* __res
       if (idx < M * t4) reinterpret_cast<float4*>(xs)[idx] = val[u];
     }
   }
-  for (int idx = t; idx < M * WG_BLOCK_ROWS; idx += 256) {       // g tile, coalesced along n
-    const int m = idx / WG_BLOCK_ROWS, r = idx - m * WG_BLOCK_ROWS;
-    float g = 0.f;
-    if (n0 + r < N) {
-      g = pr.gy[(size_t)m * N + n0 + r];
-      if (pr.act) g *= act_bwd(pr.z[(size_t)m * N + n0 + r], pr.act);
+  // g tile, coalesced along n: M / 4 rounds of 256 elements, 4 rounds' loads in flight (clamped addresses; the plain
+  // loop -- guarded load, activation, store -- was a memory round trip per round before the block could start)
+  for (int base = 0; base < M * WG_BLOCK_ROWS; base += 1024) {
+    float gv[4], zv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = min(base + 256 * u + t, M * WG_BLOCK_ROWS - 1);
+      const int m = idx / WG_BLOCK_ROWS, r = idx - m * WG_BLOCK_ROWS;
+      const size_t at = (size_t)m * N + min(n0 + r, N - 1);
+      gv[u] = pr.gy[at];
+      zv[u] = pr.act ? pr.z[at] : 0.f;                           // block-uniform
     }
-    gs[idx] = g;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = base + 256 * u + t;
+      if (idx < M * WG_BLOCK_ROWS) {
+        const int m = idx / WG_BLOCK_ROWS, r = idx - m * WG_BLOCK_ROWS;
+        float g = pr.act ? gv[u] * act_bwd(zv[u], pr.act) : gv[u];
+        gs[idx] = n0 + r < N ? g : 0.f;
+      }
+    }
   }
   __syncthreads();
   // narrow k tiles leave threads without a column: the 4 row passes are dealt to 2 or 4 thread groups instead
