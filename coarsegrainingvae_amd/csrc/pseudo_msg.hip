@@ -38,7 +38,11 @@ __device__ __forceinline__ void axpy(v3& acc, float a, const v3& x) {
   acc.x = fmaf(a, x.x, acc.x); acc.y = fmaf(a, x.y, acc.y); acc.z = fmaf(a, x.z, acc.z);
 }
 
-constexpr int PSEUDO_EB = 8;      // edges whose source indices / gathers are issued together (pseudo_fwd_k)
+// Edges whose source indices / gathers are issued together in pseudo_fwd_k / pseudo_bwd_recv_k: 8 when the launch has
+// at most one block per CU (the 12-bead chignolin graph: one round trip for a bead's 5 edges), 2 otherwise -- the wider
+// batch costs registers, and a 9-wave block that needs 98 of them runs alone on its CU (96-bead dipeptide graph,
+// 960 blocks: 7.7 -> 12.6 us per call with 8).
+constexpr int PSEUDO_EB_WIDE = 8, PSEUDO_EB_NARROW = 2;
 
 template <int R>
 __device__ __forceinline__ float filt(const float (&W)[R + 1], const float* __restrict__ g) {
@@ -97,7 +101,7 @@ __device__ __forceinline__ void read_row(float (&W)[R + 1], const float* __restr
 // Wave k owns filter k: q_k = phi[j, kF+f] w_k and the one output term that carries it (k = 0: T_h and the
 // filter-free T_hbar; k = 1..4: the four terms of T_v; k = 5..8: those of T_vb).  The waves' vectors meet in LDS
 // in wave order.  (One wave doing all nine filters: 99 weights per lane, 10.4 us; this: see DESIGN.md.)
-template <int R>
+template <int R, int PSEUDO_EB>
 __global__ __launch_bounds__(576) void pseudo_fwd_k(const float* __restrict__ phi, const float* __restrict__ s,
                                                     const float* __restrict__ sbar, const float* __restrict__ v,
                                                     const float* __restrict__ vbar, const float* __restrict__ geom,
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(576) void pseudo_fwd_k(const float* __restrict__ ph
 }
 
 // ------------------------------------------------------------------ backward pass A (receiver side)
-template <int R>
+template <int R, int PSEUDO_EB>
 __global__ __launch_bounds__(64) void pseudo_bwd_recv_k(const float* __restrict__ phi, const float* __restrict__ v,
                                                         const float* __restrict__ vbar, const float* __restrict__ geom,
                                                         const int* __restrict__ rowptr, const int* __restrict__ src,
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(64) void pseudo_bwd_recv_k(const float* __restrict_
   float as = 0.f, asb = 0.f;
   v3 av{0.f, 0.f, 0.f}, avb{0.f, 0.f, 0.f};
   const int e_beg = rowptr[i], e_end = rowptr[i + 1];
-  constexpr int EB = PSEUDO_EB / 2;                  // 14 gathered values per edge here
+  constexpr int EB = PSEUDO_EB > 2 ? PSEUDO_EB / 2 : 2;          // 14 gathered values per edge here
   for (int eb = e_beg; eb < e_end; eb += EB) {       // indices, then gathers, for EB edges at once (see pseudo_fwd_k)
     int jj[EB];
     float p0[EB], p3[EB], p4[EB], p6[EB], p7[EB], p8[EB];
@@ -423,8 +427,12 @@ int cgv_pseudo_msg_fwd(const float* phi, const float* s, const float* sbar, cons
   dim3 grid(n_nodes, (n_feat + 63) / 64);
   hipStream_t st = (hipStream_t)stream;
   CGV_DISPATCH_RBF(n_rbf, {
-    hipLaunchKernelGGL((cgv::pseudo_fwd_k<RBF>), grid, dim3(576), 0, st, phi, s, sbar, v, vbar, geom_d, rowptr_d, src_d,
-                       Wd, bd, dh, dhbar, dv, dvbar, n_feat, residual);
+    if ((long)grid.x * grid.y <= 256)
+      hipLaunchKernelGGL((cgv::pseudo_fwd_k<RBF, cgv::PSEUDO_EB_WIDE>), grid, dim3(576), 0, st, phi, s, sbar, v, vbar, geom_d,
+                         rowptr_d, src_d, Wd, bd, dh, dhbar, dv, dvbar, n_feat, residual);
+    else
+      hipLaunchKernelGGL((cgv::pseudo_fwd_k<RBF, cgv::PSEUDO_EB_NARROW>), grid, dim3(576), 0, st, phi, s, sbar, v, vbar, geom_d,
+                         rowptr_d, src_d, Wd, bd, dh, dhbar, dv, dvbar, n_feat, residual);
   });
   return cgv::check_launch("cgv_pseudo_msg_fwd");
 }
@@ -452,9 +460,12 @@ int cgv_pseudo_msg_bwd(const float* phi, const float* s, const float* sbar, cons
   float* part = reinterpret_cast<float*>(workspace);
   dim3 gridA(n_nodes > 0 ? n_nodes : 1, (n_feat + 63) / 64), gridB(chunks, (n_feat + 63) / 64);
   CGV_DISPATCH_RBF(n_rbf, {
-    if (n_nodes > 0)
-      hipLaunchKernelGGL((cgv::pseudo_bwd_recv_k<RBF>), gridA, dim3(64), 0, st, phi, v, vbar, geom_d, rowptr_d, src_d, Wd,
-                         bd, gh, ghbar, gv, gvbar, g_s, g_sbar, g_v, g_vbar, n_feat, residual);
+    if (n_nodes > 0 && (long)gridA.x * gridA.y <= 256)
+      hipLaunchKernelGGL((cgv::pseudo_bwd_recv_k<RBF, cgv::PSEUDO_EB_WIDE>), gridA, dim3(64), 0, st, phi, v, vbar, geom_d,
+                         rowptr_d, src_d, Wd, bd, gh, ghbar, gv, gvbar, g_s, g_sbar, g_v, g_vbar, n_feat, residual);
+    else if (n_nodes > 0)
+      hipLaunchKernelGGL((cgv::pseudo_bwd_recv_k<RBF, cgv::PSEUDO_EB_NARROW>), gridA, dim3(64), 0, st, phi, v, vbar, geom_d,
+                         rowptr_d, src_d, Wd, bd, gh, ghbar, gv, gvbar, g_s, g_sbar, g_v, g_vbar, n_feat, residual);
     hipLaunchKernelGGL((cgv::pseudo_bwd_src_k<RBF>), gridB, dim3(576), 0, st, phi, s, sbar, v, vbar, geom_s, rowptr_s,
                        dst_s, Wd, bd, gh, ghbar, gv, gvbar, g_phi, g_v, g_vbar, part, n_feat, n_nodes, npc);
   });
