@@ -51,6 +51,7 @@ PROTOTYPES = {
     "cgv_equi_msg_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "cgv_equi_msg_bwd": (_i, [_p] * 13 + [_i, _i, _i, C.c_int64, C.c_int64, _p, _sz, _p]),
     "cgv_pseudo_msg_fwd": (_i, [_p] * 14 + [_i, _i, _i, _i, _p]),
+    "cgv_pseudo_msg_fwd_rows": (_i, [_p] * 15 + [_i, _i, _i, _i, _p]),
     "cgv_pseudo_msg_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "cgv_pseudo_msg_bwd": (_i, [_p] * 24 + [_i, _i, _i, _i, _p, _sz, _p]),
     "cgv_update_rows_from_vec": (_i, [_p, _p, _i, _i, _p]),

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(576) void pseudo_fwd_k(const float* __restrict__ ph
                                                     const float* __restrict__ Wd, const float* __restrict__ bd,
                                                     float* __restrict__ dh, float* __restrict__ dhbar,
                                                     float* __restrict__ dv, float* __restrict__ dvbar, int F,
-                                                    int residual) {
+                                                    int residual, float* __restrict__ dv_rows) {
   constexpr int GS = geom_stride(R), U = geom_unit_offset(R);
   __shared__ float red[8][3][64];
   const int i = blockIdx.x;
@@ -177,6 +177,11 @@ __global__ __launch_bounds__(576) void pseudo_fwd_k(const float* __restrict__ ph
   dhbar[nf] = ahb;
   st3(dv + nf * 3, av.x, av.y, av.z);
   st3(dvbar + nf * 3, avb.x, avb.y, avb.z);
+  if (dv_rows) {       // the same vector as rows [3 i + xyz][f]: the layout the update block's channel mixing reads
+    dv_rows[((size_t)3 * i + 0) * F + f] = av.x;
+    dv_rows[((size_t)3 * i + 1) * F + f] = av.y;
+    dv_rows[((size_t)3 * i + 2) * F + f] = av.z;
+  }
 }
 
 // ------------------------------------------------------------------ backward pass A (receiver side)
@@ -421,6 +426,16 @@ int cgv_pseudo_msg_fwd(const float* phi, const float* s, const float* sbar, cons
                        const float* geom_d, const int32_t* rowptr_d, const int32_t* src_d, const float* Wd,
                        const float* bd, float* dh, float* dhbar, float* dv, float* dvbar, int n_nodes, int n_feat,
                        int n_rbf, int residual, void* stream) {
+  return cgv_pseudo_msg_fwd_rows(phi, s, sbar, v, vbar, geom_d, rowptr_d, src_d, Wd, bd, dh, dhbar, dv, dvbar, nullptr,
+                                 n_nodes, n_feat, n_rbf, residual, stream);
+}
+
+/* As cgv_pseudo_msg_fwd; dv_rows (or NULL) [3 N, F] additionally receives dv as rows 3 i + xyz -- the operand layout
+ * of UpdateBlock's u_mat / v_mat products (conv.py:591), which otherwise costs a transpose launch per decoder layer. */
+int cgv_pseudo_msg_fwd_rows(const float* phi, const float* s, const float* sbar, const float* v, const float* vbar,
+                            const float* geom_d, const int32_t* rowptr_d, const int32_t* src_d, const float* Wd,
+                            const float* bd, float* dh, float* dhbar, float* dv, float* dvbar, float* dv_rows,
+                            int n_nodes, int n_feat, int n_rbf, int residual, void* stream) {
   CGV_REQUIRE(n_nodes >= 0 && n_feat > 0, "bad size");
   if (n_nodes == 0) return 0;
   CGV_REQUIRE(phi && s && sbar && v && vbar && rowptr_d && Wd && bd && dh && dhbar && dv && dvbar, "null pointer");
@@ -429,10 +444,10 @@ int cgv_pseudo_msg_fwd(const float* phi, const float* s, const float* sbar, cons
   CGV_DISPATCH_RBF(n_rbf, {
     if ((long)grid.x * grid.y <= 256)
       hipLaunchKernelGGL((cgv::pseudo_fwd_k<RBF, cgv::PSEUDO_EB_WIDE>), grid, dim3(576), 0, st, phi, s, sbar, v, vbar, geom_d,
-                         rowptr_d, src_d, Wd, bd, dh, dhbar, dv, dvbar, n_feat, residual);
+                         rowptr_d, src_d, Wd, bd, dh, dhbar, dv, dvbar, n_feat, residual, dv_rows);
     else
       hipLaunchKernelGGL((cgv::pseudo_fwd_k<RBF, cgv::PSEUDO_EB_NARROW>), grid, dim3(576), 0, st, phi, s, sbar, v, vbar, geom_d,
-                         rowptr_d, src_d, Wd, bd, dh, dhbar, dv, dvbar, n_feat, residual);
+                         rowptr_d, src_d, Wd, bd, dh, dhbar, dv, dvbar, n_feat, residual, dv_rows);
   });
   return cgv::check_launch("cgv_pseudo_msg_fwd");
 }

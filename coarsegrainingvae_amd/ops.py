@@ -276,9 +276,14 @@ class _PseudoMessage(torch.autograd.Function):
             raise RuntimeError("shape mismatch between node features, filter weights and the edge plan")
         dh, dhbar = torch.empty_like(s), torch.empty_like(s)
         dv, dvbar = torch.empty_like(v), torch.empty_like(v)
-        _lib.call("cgv_pseudo_msg_fwd", _lib.ptr(phi), _lib.ptr(s), _lib.ptr(sbar), _lib.ptr(v), _lib.ptr(vbar),
+        # decoder loop (residual: dv IS the new V): the update block that follows reads V as rows [3 n, F]; the kernel
+        # writes that layout too, pseudo_message() hands it over on the tensor (one transpose launch less per layer)
+        rows = torch.empty(3 * n, F, dtype=_F32, device=s.device) if residual else None
+        _PseudoMessage.last_rows = rows
+        _lib.call("cgv_pseudo_msg_fwd_rows", _lib.ptr(phi), _lib.ptr(s), _lib.ptr(sbar), _lib.ptr(v), _lib.ptr(vbar),
                   _lib.ptr(geom.geom_d), _lib.ptr(plan.rowptr_d), _lib.ptr(plan.src_d), _lib.ptr(Wd), _lib.ptr(bd),
-                  _lib.ptr(dh), _lib.ptr(dhbar), _lib.ptr(dv), _lib.ptr(dvbar), n, F, geom.n_rbf, int(residual), _lib.stream_ptr(),
+                  _lib.ptr(dh), _lib.ptr(dhbar), _lib.ptr(dv), _lib.ptr(dvbar), _lib.ptr(rows) if rows is not None else None,
+                  n, F, geom.n_rbf, int(residual), _lib.stream_ptr(),
                   tag=f"pseudo_msg_fwd:Nd{n}:E{plan.n_edges}:dv1")
         ctx.save_for_backward(phi, s, sbar, v, vbar, Wd, bd)
         ctx.plan, ctx.geom = plan, geom
@@ -312,7 +317,11 @@ class _PseudoMessage(torch.autograd.Function):
 
 def pseudo_message(phi, s, sbar, v, vbar, Wd, bd, plan: EdgePlan, geom: EdgeGeometry, residual: bool = False):
     """residual=False: the four deltas (the block's reference API); True: the updated states."""
-    return _PseudoMessage.apply(phi, s, sbar, v, vbar, Wd, bd, plan, geom, residual)
+    out = _PseudoMessage.apply(phi, s, sbar, v, vbar, Wd, bd, plan, geom, residual)
+    rows, _PseudoMessage.last_rows = getattr(_PseudoMessage, "last_rows", None), None
+    if rows is not None:
+        out[2]._cgv_rows = rows            # V as [3 n, F] rows, for update_block (same values, other layout)
+    return out
 
 
 # ----------------------------------------------------------------------------- K5
@@ -426,10 +435,13 @@ class _UpdateBlockFused(torch.autograd.Function):
         dev, st = s.device, _lib.stream_ptr()
         new = lambda *shape: torch.empty(*shape, dtype=_F32, device=dev)
         Wuv = torch.as_strided(u_w.detach(), (2 * F, F), (F, 1))
-        vt, UV, stack = new(3 * n, F), new(3 * n, 2 * F), new(n, 2 * F)
+        UV, stack = new(3 * n, 2 * F), new(n, 2 * F)
         z0, a0, a = new(n, F), new(n, F), new(n, 3 * F)
         ds, dv = new(n, F), new(n, F, 3)
-        _lib.call("cgv_update_rows_from_vec", _lib.ptr(v), _lib.ptr(vt), n, F, st)
+        vt = getattr(v, "_cgv_rows", None)                     # written by the pseudo-message kernel that produced v
+        if vt is None or vt.shape != (3 * n, F) or vt.device != dev or not vt.is_contiguous():
+            vt = new(3 * n, F)
+            _lib.call("cgv_update_rows_from_vec", _lib.ptr(v), _lib.ptr(vt), n, F, st)
         _dense_fwd(vt, Wuv, None, UV, None, 3 * n, 2 * F, F, 0, st)
         U_ptr, Vv_ptr = UV.data_ptr(), UV.data_ptr() + 4 * F
         _lib.call("cgv_update_norm_stack_fwd", _lib.ptr(s), Vv_ptr, _lib.ptr(stack), n, F, 2 * F, st)

@@ -213,6 +213,12 @@ int cgv_pseudo_msg_fwd(const float* phi /*[N,9F]*/, const float* s, const float*
                        const float* vbar, const float* geom_d, const int32_t* rowptr_d, const int32_t* src_d,
                        const float* Wd /*[9F,R]*/, const float* bd /*[9F]*/, float* dh, float* dhbar, float* dv,
                        float* dvbar, int n_nodes, int n_feat, int n_rbf, int residual, void* stream);
+/* The same launch; dv_rows (or NULL) [3 N, F] additionally receives dv as rows 3 i + xyz, the operand layout of
+ * UpdateBlock's u_mat / v_mat products (conv.py:591) -- saves the transpose launch in front of every decoder update. */
+int cgv_pseudo_msg_fwd_rows(const float* phi, const float* s, const float* sbar, const float* v, const float* vbar,
+                            const float* geom_d, const int32_t* rowptr_d, const int32_t* src_d, const float* Wd,
+                            const float* bd, float* dh, float* dhbar, float* dv, float* dvbar, float* dv_rows,
+                            int n_nodes, int n_feat, int n_rbf, int residual, void* stream);
 size_t cgv_pseudo_msg_bwd_workspace_bytes(int n_nodes, int n_feat, int n_rbf);
 int cgv_pseudo_msg_bwd(const float* phi, const float* s, const float* sbar, const float* v, const float* vbar,
                        const float* geom_d, const int32_t* rowptr_d, const int32_t* src_d,
