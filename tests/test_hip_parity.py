@@ -1330,3 +1330,67 @@ def test_tile_gemms_with_reductions_shorter_than_a_step(shape):
     gx = torch.empty(M, K, device=DEV)
     cg._lib.call("cgv_tile_linear_bwd_input", cg._lib.ptr(gy), cg._lib.ptr(W), cg._lib.ptr(gx), M, N, K, cg._lib.stream_ptr())
     assert torch.allclose(gx.double(), gy.double() @ W.double(), rtol=1e-5, atol=1e-5)
+
+
+def test_rank_update_kernels_on_random_shapes():
+    """cgv_wgrad_gram / cgv_grouped_wgrad_adam over 24 random problems in one table (1 - 40 rows, widths in multiples of
+    4 from 4 to 700, every activation code, with / without bias): norms against fp64, one Adam step against fp64."""
+    from coarsegrainingvae_amd.primitives import WeightGradQueue
+    lib = cg._lib.load()
+    rng = np.random.default_rng(7)
+    g = torch.Generator(device=DEV).manual_seed(11)
+    shapes = []
+    for k in range(24):
+        M = int(rng.integers(1, 41))
+        N, K = 4 * int(rng.integers(1, 176)), 4 * int(rng.integers(1, 176))
+        shapes.append((M, N, K, int(rng.integers(0, 4)), bool(rng.integers(0, 2))))
+    shapes[0] = (40, 700, 4, 1, True)
+    shapes[1] = (1, 4, 700, 0, False)
+    n_total = sum(N * K for _, N, K, _, _ in shapes)
+    arena_g = torch.zeros(n_total, device=DEV)
+    arena_p = torch.randn(n_total, device=DEV, generator=g)
+    arena_m = torch.zeros(n_total, device=DEV)
+    arena_v = torch.zeros(n_total, device=DEV)
+    p0 = arena_p.double().clone()
+    items, refs, off = [], [], 0
+    for M, N, K, act, bias in shapes:
+        gy = torch.randn(M, N, device=DEV, generator=g)
+        x = torch.randn(M, K, device=DEV, generator=g)
+        z = torch.randn(M, N, device=DEV, generator=g) if act else None
+        gb = torch.full((N,), float("nan"), device=DEV) if bias else None
+        items.append((gy, x, z, act, arena_g[off:off + N * K].view(N, K), gb, False))
+        gd = gy.double()
+        if act:
+            zd = z.double()
+            sg = torch.sigmoid(zd)
+            gd = gd * {1: sg * (1 + zd * (1 - sg)), 2: 1 - torch.tanh(zd) ** 2, 3: (zd > 0).double()}[act]
+        refs.append((gd.T @ x.double(), gd.sum(0), off))
+        off += N * K
+    assert all(lib.cgv_rank_update_supported(M, N, K) for M, N, K, _, _ in shapes)
+    table, blocks, lds = WeightGradQueue().small_table(items)
+    sumsq = torch.zeros(len(items), dtype=torch.float64, device=DEV)
+    ws = torch.empty(int(lib.cgv_wgrad_gram_workspace_bytes(len(items))), dtype=torch.uint8, device=DEV)
+    cg._lib.call("cgv_wgrad_gram", cg._lib.ptr(table), len(items), cg._lib.ptr(sumsq), cg._lib.ptr(ws), ws.numel(),
+                 cg._lib.stream_ptr())
+    for k, (gw, gbias, _) in enumerate(refs):
+        want = float((gw ** 2).sum())
+        assert abs(float(sumsq[k]) - want) <= 2e-6 * want + 1e-12, (k, shapes[k])
+        if items[k][5] is not None:
+            assert torch.allclose(items[k][5].double(), gbias, rtol=1e-5, atol=1e-5), (k, shapes[k])
+    state = torch.zeros(lib.cgv_optim_state_floats(), device=DEV)
+    partial = torch.empty(lib.cgv_optim_partial_floats(), device=DEV)
+    lr, b1, b2, eps, max_norm = 1e-2, 0.9, 0.999, 1e-8, 1e9                  # no clipping: the update is lr * sign-like
+    cg._lib.call("cgv_optim_prepare_extra", arena_g.data_ptr(), 0, cg._lib.ptr(sumsq), len(items), b1, b2, max_norm, 1.0,
+                 None, 0.0, cg._lib.ptr(state), cg._lib.ptr(partial), cg._lib.stream_ptr())
+    cg._lib.call("cgv_grouped_wgrad_adam", cg._lib.ptr(table), len(items), blocks, lds, cg._lib.ptr(arena_g), cg._lib.ptr(arena_p),
+                 cg._lib.ptr(arena_m), cg._lib.ptr(arena_v), lr, b1, b2, eps, cg._lib.ptr(state), cg._lib.stream_ptr())
+    for k, (gw, _, o) in enumerate(refs):
+        gflat = gw.reshape(-1)
+        sl = slice(o, o + gflat.numel())
+        m1, v1 = (1 - b1) * gflat, (1 - b2) * gflat * gflat
+        want = p0[sl] - (lr / (1 - b1)) * m1 / (v1.sqrt() / (1 - b2) ** 0.5 + eps)
+        assert torch.allclose(arena_m[sl].double(), m1, rtol=2e-5, atol=3e-6), (k, shapes[k])     # fp32 sums of <= 40 terms
+        # first Adam step: |update| = lr wherever |g| >> eps; compare where the gradient is not tiny
+        big = gflat.abs() > 1e-3
+        assert torch.allclose(arena_p[sl].double()[big], want[big], rtol=1e-5, atol=1e-5), (k, shapes[k])
+    assert float(arena_g.abs().max()) == 0.0                               # never written
