@@ -61,16 +61,30 @@ __global__ __launch_bounds__(1024) void elbo_fwd(const float* __restrict__ mu, c
   const int nk = n_kl_part > 0 ? 0 : n_beads * F;
   const float ck = 0.5f * beta / (float)n_beads;
   double kl = 0.0;
-  if (n_kl_part > 0 && t == 0)
-    for (int b = 0; b < n_kl_part; ++b) kl += kl_part[b];
-  for (int idx = t; idx < nk; idx += T) {
-    const float m1 = mu[idx], s1 = sigma[idx], m2 = pmu[idx], s2 = pstd[idx];
-    const float s1s = s1 * s1, s2s = s2 * s2, dm = m1 - m2;
-    kl += (double)(s1s / s2s + dm * dm / s2 + logf(s2s) - logf(s1s));
-    g_mu[idx] = ck * (2.f * dm / s2);
-    g_pmu[idx] = -ck * (2.f * dm / s2);
-    g_sigma[idx] = ck * (2.f * s1 / s2s - 2.f / s1);
-    g_pstd[idx] = ck * (-2.f * s1s / (s2s * s2) - dm * dm / s2s + 2.f / s2);
+  // one partial per thread (<= 128 of them), summed by block_sum below: a single thread adding them in a loop paid a
+  // memory round trip per partial (57 on the dipeptide batch: most of this kernel's 44 us there)
+  for (int b = t; b < n_kl_part; b += T) kl += kl_part[b];
+  // small bead batches (chignolin: 7200 elements = 7 rounds): 4 rounds' loads in flight instead of one round trip each
+  constexpr int KB = 4;
+  for (int base = 0; base < nk; base += KB * T) {
+    float m1[KB], s1[KB], m2[KB], s2[KB];
+#pragma unroll
+    for (int u = 0; u < KB; ++u) {
+      const int idx = min(base + u * T + t, nk - 1);
+      m1[u] = mu[idx]; s1[u] = sigma[idx]; m2[u] = pmu[idx]; s2[u] = pstd[idx];
+    }
+#pragma unroll
+    for (int u = 0; u < KB; ++u) {
+      const int idx = base + u * T + t;
+      if (idx < nk) {
+        const float s1s = s1[u] * s1[u], s2s = s2[u] * s2[u], dm = m1[u] - m2[u];
+        kl += (double)(s1s / s2s + dm * dm / s2[u] + logf(s2s) - logf(s1s));
+        g_mu[idx] = ck * (2.f * dm / s2[u]);
+        g_pmu[idx] = -ck * (2.f * dm / s2[u]);
+        g_sigma[idx] = ck * (2.f * s1[u] / s2s - 2.f / s1[u]);
+        g_pstd[idx] = ck * (-2.f * s1s / (s2s * s2[u]) - dm * dm / s2s + 2.f / s2[u]);
+      }
+    }
   }
   kl = block_sum(kl, sh);
   const double kl_val = 0.5 * (kl / (double)n_beads - (double)F);
