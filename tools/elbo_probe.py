@@ -1,4 +1,6 @@
 """Time cgv_elbo_fwd with parts of the problem removed (which section dominates?)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from coarsegrainingvae_amd import _lib
 
