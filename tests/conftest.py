@@ -13,6 +13,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no libcgvae_hip.so (build artefacts are not in history): build it once, as
+    # __graft_entry__.build() does -- hipcc cross-compiles gfx950 without a GPU; up-to-date objects are reused
+    from coarsegrainingvae_amd import build as _build
+    if not os.path.exists(_build.LIB):
+        _build.build()
 
 
 def load_golden(name):
