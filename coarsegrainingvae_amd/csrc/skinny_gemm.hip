@@ -675,8 +675,10 @@ __global__ __launch_bounds__(256) void gathered_wgrad_k(const WgradProblem* __re
   const int c4 = threadIdx.x & 15, rr = threadIdx.x >> 4;          // staging: 16 float4 columns x 16 rows per pass
   const bool gcol = n0 + 4 * c4 < N, xcol = k0 + 4 * c4 < K;
   constexpr int NP = GW_CHUNK / 16;                                  // staging passes per chunk
-  float4 gq[NP], xq[NP];
-  // operand rows of one chunk into registers (g already multiplied by act'(z) for local problems)
+  float4 gq[NP], zq[NP], xq[NP];
+  // operand rows of one chunk into registers: the loads only -- g is multiplied by act'(z) when the chunk is stored to
+  // LDS (chunk_finish), so that the next chunk's loads really travel under this chunk's MFMAs (a multiply right behind
+  // the load made the prefetch wait for its data before the first MFMA)
   auto chunk_load = [&](int m0) {
     const int rows = min(GW_CHUNK, M - m0);
 #pragma unroll
@@ -687,17 +689,23 @@ __global__ __launch_bounds__(256) void gathered_wgrad_k(const WgradProblem* __re
       const int seg = m / sr, row = m - seg * sr;
       const size_t base = (size_t)seg * pr.seg_stride;
       gq[p] = ldg4_or_zero(pr.gy + base + (size_t)row * N + (gcol ? n0 + 4 * c4 : 0), ok && gcol);
-      if (pr.act) {
-        const float4 zz = ldg4_or_zero(pr.z + base + (size_t)row * N + (gcol ? n0 + 4 * c4 : 0), ok && gcol);
-        gq[p].x *= act_bwd(zz.x, pr.act); gq[p].y *= act_bwd(zz.y, pr.act);
-        gq[p].z *= act_bwd(zz.z, pr.act); gq[p].w *= act_bwd(zz.w, pr.act);
-      }
+      if (pr.act) zq[p] = ldg4_or_zero(pr.z + base + (size_t)row * N + (gcol ? n0 + 4 * c4 : 0), ok && gcol);
       xq[p] = ldg4_or_zero(pr.x + base + (size_t)row * K + (xcol ? k0 + 4 * c4 : 0), ok && xcol);
+    }
+  };
+  auto chunk_finish = [&]() {
+    if (pr.act) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        gq[p].x *= act_bwd(zq[p].x, pr.act); gq[p].y *= act_bwd(zq[p].y, pr.act);
+        gq[p].z *= act_bwd(zq[p].z, pr.act); gq[p].w *= act_bwd(zq[p].w, pr.act);
+      }
     }
   };
   chunk_load(0);
   for (int m0 = 0; m0 < M; m0 += GW_CHUNK) {
     const int rows = min(GW_CHUNK, M - m0);
+    chunk_finish();
 #pragma unroll
     for (int p = 0; p < NP; ++p) {                                   // rows beyond the chunk arrive as zeros
       *reinterpret_cast<float4*>(gs + (rr + 16 * p) * GW_GS + 4 * c4) = gq[p];
