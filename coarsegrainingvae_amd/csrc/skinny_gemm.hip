@@ -647,7 +647,12 @@ __global__ __launch_bounds__(256) void wgrad_gram_reduce_k(const WgradProblem* _
 // bound by the gW stores).  MFMA 16x16x4 f32 steps over 4 rows: lane (i = l&15, q = l>>4) supplies
 // A = g[m0+q][16w+i] and B_s = x[m0+q][4i+s], so that D_s holds gW[n0+16w+4q+r][k0+4i+s] and leaves as 16-byte
 // stores.  LDS strides 80 / 64 floats keep the b32 / b128 reads conflict free.  Exact fp32 FMA chains, fixed order.
-constexpr int GW_CHUNK = 48;        // rows per staged chunk (multiple of 4)
+#ifndef CGV_GW_CHUNK
+#define CGV_GW_CHUNK 48
+#endif
+// rows per staged chunk (multiple of 16); -DCGV_GW_CHUNK=<n> for A/B builds: 16 / 32 / 48 are within 3 % of each other
+// (chignolin 72 / 76 / 74 us, dipeptide 365 / 360 / 371 us), 96 is 20 % slower (two blocks per CU)
+constexpr int GW_CHUNK = CGV_GW_CHUNK;
 constexpr int GW_GS = 80, GW_XS = 64;
 
 __global__ __launch_bounds__(256) void gathered_wgrad_k(const WgradProblem* __restrict__ table, int n_problems) {
