@@ -105,6 +105,7 @@ __global__ __launch_bounds__(1024) void elbo_fwd(const float* __restrict__ mu, c
   constexpr int CH = 2048;
   __shared__ __attribute__((aligned(16))) int sb_a0[CH], sb_a1[CH];
   __shared__ __attribute__((aligned(16))) float sb_cx[CH], sb_cy[CH], sb_cz[CH];     // d value / d xr_a0
+  __shared__ float sb_part[1024 * 3];                      // slices of an atom's bond sum parked by thread groups 1 .. 3 ((G - 1) per <= 1024 threads)
   const bool want_grad = gamma != 0.f && n_bonds > 0;
   const float cg = n_bonds > 0 ? gamma * 2.f / (float)n_bonds : 0.f;
   double gr = 0.0;
@@ -125,15 +126,11 @@ __global__ __launch_bounds__(1024) void elbo_fwd(const float* __restrict__ mu, c
     for (int b = cnt + t; b < ((cnt + 15) & ~15); b += T) { sb_a0[b] = sb_a1[b] = -1; sb_cx[b] = sb_cy[b] = sb_cz[b] = 0.f; }
     __syncthreads();
     if (want_grad) {
-      for (int a = t; a < n_atoms; a += T) {
-        float gx = 0.f, gy = 0.f, gz = 0.f;
-        // branch-free, 4 bonds per round through five 16-byte reads: every read is unconditional so the LDS
-        // latency pipelines (a scan that branches on each id waits a full LDS round trip per bond: ~30 us
-        // for 330 bonds -- and the compiler re-introduces those branches if the ids are read one by one)
-        // 16 bonds per trip: the 20 reads are issued before the first is used (the runtime-bounded loop is not
-        // pipelined by the compiler; one group of 4 per trip waited out an LDS round trip per group: ~430 cycles,
-        // 15 of this kernel's 28 us on the 330-bond chignolin batch).  Same order of additions.
-        for (int b0 = 0; b0 < cnt; b0 += 16) {
+      // branch-free scan of the staged bonds for one atom: every read is unconditional so the LDS latency pipelines (a
+      // scan that branches on each id waits a full LDS round trip per bond, and the compiler re-introduces those
+      // branches if the ids are read one by one); 16 bonds per trip, the 20 reads issued before the first is used
+      auto scan = [&](int a, int b_lo, int b_hi, float& gx, float& gy, float& gz) {
+        for (int b0 = b_lo; b0 < b_hi; b0 += 16) {
           int4 i0[4], i1[4];
           float4 cx[4], cy[4], cz[4];
 #pragma unroll
@@ -154,7 +151,28 @@ __global__ __launch_bounds__(1024) void elbo_fwd(const float* __restrict__ mu, c
             gz = fmaf(w3, cz[u].w, fmaf(w2, cz[u].z, fmaf(w1, cz[u].y, fmaf(w0, cz[u].x, gz))));
           }
         }
-        g_xr[3 * a] += gx; g_xr[3 * a + 1] += gy; g_xr[3 * a + 2] += gz;
+      };
+      // few atoms (chignolin: 332 of 1024 threads): G thread groups take a slice of the bond range each for the same
+      // atoms and group 0 adds the slices in group order -- the scan is bound by the LDS reads every wave repeats
+      const int G = n_atoms * 2 <= T ? min(4, T / n_atoms) : 1;
+      if (G == 1) {
+        for (int a = t; a < n_atoms; a += T) {
+          float gx = 0.f, gy = 0.f, gz = 0.f;
+          scan(a, 0, cnt, gx, gy, gz);
+          g_xr[3 * a] += gx; g_xr[3 * a + 1] += gy; g_xr[3 * a + 2] += gz;
+        }
+      } else {
+        const int per = T / G, gi = t / per, a = t - gi * per;
+        const int trips = (cnt + 15) / 16, tper = (trips + G - 1) / G;
+        const bool mine = gi < G && a < n_atoms;
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+        if (mine) scan(a, 16 * tper * gi, min(cnt, 16 * tper * (gi + 1)), gx, gy, gz);
+        if (mine && gi > 0) { float* q = sb_part + ((gi - 1) * per + a) * 3; q[0] = gx; q[1] = gy; q[2] = gz; }
+        __syncthreads();
+        if (mine && gi == 0) {
+          for (int g2 = 1; g2 < G; ++g2) { const float* q = sb_part + ((g2 - 1) * per + a) * 3; gx += q[0]; gy += q[1]; gz += q[2]; }
+          g_xr[3 * a] += gx; g_xr[3 * a + 1] += gy; g_xr[3 * a + 2] += gz;
+        }
       }
     }
   }
