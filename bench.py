@@ -3,11 +3,19 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload chignolin|dipeptide|protein2000]
 
-A "step" = forward (encoder + prior + decoder) + loss (recon + beta*KL + gamma*graph) +
-backward (+ gradient all-reduce when N > 1) + clip_grad_norm_(0.01) + Adam, on one synthetic
-batch resident in HBM.  Weak scaling: every rank holds `frames_per_gpu`
-frames; value = frames all ranks processed / max-over-ranks wall time.  Rank 0 prints ONE JSON
-line with `roofline` (dominant kernel, HIP events on the launch stream) and `cpu_baseline`
+A "step" = one pass of the hot path over one batch that is resident in HBM (coordinates + radius-graph neighbour
+lists, as ``CG_collate`` delivers them): the per-batch graph work the reference does inside ``model(batch)``
+(``make_directed`` conv.py:10-20, edge geometry conv.py:25-29 / modules.py:148-197; here: the in-place re-plan of the
+CSR views + edge records) + forward (encoder + prior + decoder) + loss (recon + beta*KL + gamma*graph) + backward
+(+ operand all-gather / gradient all-reduce when N > 1) + clip_grad_norm_(0.01) + Adam.  The timed loop rotates over
+``--rotation`` (default 8) DIFFERENT device-resident batches, so nothing per-batch is hoisted out of the clock; the
+replay-only figure on one fixed batch (what round 1 reported), the host-inclusive figure (collate + H2D inside the clock)
+and a forward+backward-only figure are printed beside it.  Weak scaling: every rank holds ``frames_per_gpu`` frames;
+value = frames all ranks processed / max-over-ranks wall time.
+
+``--gpus N`` without a torchrun environment starts the N ranks itself (one child process per GPU, before this process
+touches the GPU).  Rank 0 prints ONE JSON line with `parity` (one step with host-drawn noise against the CPU oracle),
+`roofline` (fused message-passing kernel, HIP events on the launch stream), `step_roofline`, `cpu_baseline`
 (the CPU oracle, a bounded sample, rank 0 / N=1 only).
 """
 from __future__ import annotations
@@ -15,42 +23,63 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import coarsegrainingvae_amd as cg                       # noqa: E402
-from coarsegrainingvae_amd import ktimer                 # noqa: E402
-from coarsegrainingvae_amd.data import WORKLOADS         # noqa: E402
-
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-F32_PEAK_TFLOPS = 157.3      # f32-input MFMA peak = f32 vector peak (same guide)
+F32_PEAK_TFLOPS = 157.3      # packed-fp32 VALU peak = f32-input MFMA peak (same guide)
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="chignolin", choices=sorted(WORKLOADS))
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="chignolin", choices=["chignolin", "dipeptide", "protein2000"])
     ap.add_argument("--n-basis", type=int, default=600)
     ap.add_argument("--frames-per-gpu", type=int, default=None)
+    ap.add_argument("--rotation", type=int, default=8, help="number of different resident batches the timed loop cycles over")
+    ap.add_argument("--reps", type=int, default=5, help="repetitions of the --steps loop (median and min are reported)")
     ap.add_argument("--skip-dead-vector-channel", action="store_true",
                     help="explicit option: do not compute the encoder's unused vector channel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="only the headline loop (profiling runs)")
     ap.add_argument("--cpu-steps", type=int, default=None)
     ap.add_argument("--optimizer", default="fused", choices=["fused", "torch"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one captured hipGraph per step")
     ap.add_argument("--deferred-update", action="store_true",
                     help="apply each step's Adam pass at the start of the next step, beside the encoder forward "
                          "(A/B switch; the forked graph replays slower than the in-step update)")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="explicit A/B switch (coarsegrainingvae_amd/options.py, cgv_set_option), repeatable")
     ap.add_argument("--exchange", default="auto", choices=["auto", "operands", "gradients"],
                     help="N > 1: all-gather the bead-level layers' operand rows (default) or all-reduce every gradient")
     return ap.parse_args()
+
+
+def spawn_ranks(n: int) -> int:
+    """``bench.py --gpus N`` outside torchrun: start the N ranks as children of this process, which has not touched the
+    GPU (``device_count`` does not initialise it) and never will; their output is passed through."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < n:
+        print(f"[bench] --gpus {n} requested but this node exposes {have} GPU(s)", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def parse_tag(tag: str):
@@ -58,10 +87,33 @@ def parse_tag(tag: str):
     return kind, int(nd[2:]), int(e[1:]), int(flag[2:])
 
 
-def scatter_add_roofline(batch, F, reps=20):
+def timed_loop(fn, steps, reps, barrier, dist, dev):
+    """``reps`` repetitions of EXACTLY ``steps`` calls of ``fn(i)``, each bracketed by barrier + device sync on both
+    sides; per repetition the MAX over ranks.  Returns seconds per repetition."""
+    import torch
+    out = []
+    k = 0
+    for _ in range(reps):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn(k)
+            k += 1
+        barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        out.append(el)
+    return out
+
+
+def scatter_add_roofline(cg, batch, F, reps=20):
     """Metric 2: standalone K1 segment scatter-add on the shape the reference reduces in every
     encoder layer, [E, F, 3] -> [N, F, 3] with the (unsorted) receiver index nbrs[:, 0]
     (conv.py:553-556).  Algorithmic bytes = 4 E C + 4 E + 4 N C, C = 3F."""
+    import torch
     g = batch["_graph"]
     E, N, C = g.atom.n_edges, g.atom.n_dst, 3 * F
     src = torch.randn(E, F, 3, device=g.xyz.device)
@@ -82,22 +134,27 @@ def scatter_add_roofline(batch, F, reps=20):
             "frac": by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "avg_us": us, "algorithmic_bytes": by, "traffic": None}
 
 
-def message_forward_us(batch, F, R, cutoff, reps=50):
-    """Average duration of the fused EquiMessageBlock forward on this batch's atom graph: `reps` back-to-back launches
-    between two HIP events on the launch stream (per-launch events in an eager step also count the host's launch gap:
-    ~50 us against the 40-42 us rocprofv3 reports for the same kernel).  Same plan, edge records, shapes and code path
-    as the model's encoder layers; operand values are random (the kernel's time does not depend on them)."""
+def message_forward_us(batches, F, R, cutoff, reps=48):
+    """Average duration of the fused EquiMessageBlock forward (K2g) on the atom graphs of ``batches``: ``reps`` launches
+    between two HIP events on the launch stream, CYCLING over the batches' plans / edge records and over as many operand
+    sets, so that no launch finds its own inputs in the L2 the way back-to-back launches on one input set do (round 1's
+    38.5 us against 42.8 us in the rocprofv3 trace of the step).  Same code path as the model's encoder layers."""
+    import torch
     from coarsegrainingvae_amd import ops
-    g = batch["_graph"]
-    plan, geom = g.atom, g.geometry("atom", R, cutoff)
-    dev = g.xyz.device
-    phi, v = torch.randn(plan.n_src, 3 * F, device=dev), torch.randn(plan.n_src, F, 3, device=dev)
+    sets = []
+    for b in batches:
+        g = b["_graph"]
+        plan, geom = g.atom, g.geometry("atom", R, cutoff)
+        dev = g.xyz.device
+        sets.append((torch.randn(plan.n_src, 3 * F, device=dev), torch.randn(plan.n_src, F, 3, device=dev), plan, geom))
+    dev = sets[0][0].device
     Wd, bd = torch.randn(3 * F, R, device=dev), torch.randn(3 * F, device=dev)
-    for _ in range(5):
+    for phi, v, plan, geom in sets:
         ops.equi_message(phi, v, Wd, bd, plan, geom, True)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
-    for _ in range(reps):
+    for k in range(reps):
+        phi, v, plan, geom = sets[k % len(sets)]
         ops.equi_message(phi, v, Wd, bd, plan, geom, True)
     b.record()
     torch.cuda.synchronize()
@@ -105,48 +162,83 @@ def message_forward_us(batch, F, R, cutoff, reps=50):
 
 
 def optimizer_roofline(trainer, reps=5):
-    """Fused clip+Adam over the live-parameter arena: g read twice, p/m/v read and written once."""
+    """The optimiser part of the step as the step runs it.  Single process: the bead-level layers take the rank update
+    (norm from the operand rows, tiles of g^T x straight through Adam: p / m / v read and written once = 6 floats per
+    weight, the gradient is never stored), the other parameters the norm + fused clip/Adam pass (g read for the norm and
+    again for the update; the second read of those few MB is served by the caches, so g is counted ONCE: 7 floats per
+    parameter).  Timed on scratch copies of p / m / v with the operand rows of the last step."""
+    import torch
+    from coarsegrainingvae_amd import _lib
     if not trainer.fused or trainer.arena is None:
         return None
     a = trainer.arena
     n = a.numel
-    from coarsegrainingvae_amd import _lib
-    scratch_p, scratch_m, scratch_v = a.p.clone(), trainer.m.clone(), trainer.v.clone()
+    rank = getattr(trainer, "last_rank_step", None)
+    sp, sm, sv = a.p.clone(), trainer.m.clone(), trainer.v.clone()
     state = trainer.state.clone()
+    lo = trainer._rank_hi if rank else 0
+    loss = torch.zeros(1, device=a.p.device)
+
+    def run():
+        if rank:
+            table, nprob, blocks, lds, _items = rank
+            _lib.call("cgv_wgrad_gram", _lib.ptr(table), nprob, _lib.ptr(trainer._rank_sumsq), _lib.ptr(trainer._rank_ws),
+                      trainer._rank_ws.numel(), _lib.stream_ptr())
+        _lib.call("cgv_optim_prepare_extra", a.g.data_ptr() + 4 * lo, n - lo, _lib.ptr(trainer._rank_sumsq) if rank else None,
+                  rank[1] if rank else 0, 0.9, 0.999, 0.01, 1.0, _lib.ptr(loss), 1e30, _lib.ptr(state),
+                  _lib.ptr(trainer.partial), _lib.stream_ptr())
+        _lib.call("cgv_adam_apply", sp.data_ptr() + 4 * lo, a.g.data_ptr() + 4 * lo, sm.data_ptr() + 4 * lo,
+                  sv.data_ptr() + 4 * lo, n - lo, 1e-4, 0.9, 0.999, 1e-8, _lib.ptr(state), _lib.stream_ptr())
+        if rank:
+            table, nprob, blocks, lds, _items = rank
+            _lib.call("cgv_grouped_wgrad_adam", _lib.ptr(table), nprob, blocks, lds, _lib.ptr(a.g), _lib.ptr(sp), _lib.ptr(sm),
+                      _lib.ptr(sv), 1e-4, 0.9, 0.999, 1e-8, _lib.ptr(state), _lib.stream_ptr())
+    run()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
     for s, e in ev:
         s.record()
-        _lib.call("cgv_adam_clip_step", _lib.ptr(scratch_p), _lib.ptr(a.g), _lib.ptr(scratch_m), _lib.ptr(scratch_v), n,
-                  1e-4, 0.9, 0.999, 1e-8, 0.01, 1.0, None, 0.0, _lib.ptr(state), _lib.ptr(trainer.partial),
-                  _lib.stream_ptr())
+        run()
         e.record()
     torch.cuda.synchronize()
-    us = 1e3 * sum(s.elapsed_time(e) for s, e in ev[1:]) / (reps - 1)
-    by = 4 * n * 9
-    return {"kernel": "sumsq_partial+optim_finalize+adam_update", "params": n, "bound": "hbm",
-            "achieved": by / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "avg_us": us, "algorithmic_bytes": by}
+    us = 1e3 * sum(s.elapsed_time(e) for s, e in ev) / reps
+    n_rank = trainer._rank_numel if rank else 0
+    by = 4 * (6 * n_rank + 7 * (n - lo))
+    return {"kernel": ("wgrad_gram+optim_finalize+adam_update+grouped_wgrad_t<true>" if rank
+                       else "sumsq_partial+optim_finalize+adam_update"),
+            "params": n, "rank_update_weights": n_rank, "bound": "hbm", "achieved": by / (us * 1e-6) / 1e9,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "avg_us": us,
+            "algorithmic_bytes": by,
+            "accounting": "6 floats per rank-update weight (p, m, v read + written; gradient never stored), 7 per other "
+                          "parameter (g counted once: its second read hits the caches)", "traffic": None}
 
 
-def cpu_baseline(workload: str, F: int, n_frames: int, steps: int):
-    """The CPU oracle (oracle/cgvae_oracle.py, an op-for-op restatement of the reference's
-    unfused torch path) timed on this box's host cores: the same full training step."""
-    from oracle import cgvae_oracle as O
-    w = WORKLOADS[workload]
-    # 8 threads is the fastest setting for this op mix on the GPU box's host (tools/cpu_threads_probe.py:
-    # 8 -> 2.36 s/step, 16 -> 2.39, 32 -> 3.46, 64 -> 5.39 on chignolin) and the survey's own core count
-    threads = min(8, os.cpu_count() or 8)
-    torch.set_num_threads(threads)
-    hp = O.Hyper(F, w["n_rbf"], w["atom_cutoff"], w["cg_cutoff"], w["enc_nconv"], w["dec_nconv"], w["n_cgs"])
-    P = O.require_grad(O.init_params(hp, seed=123))
-    frames = cg.data.synthetic_frames(n_frames, w["n_atoms"], w["n_cgs"], w["box"], seed=0)
+def oracle_setup(cg, O, workload, F, n_frames, seed=0):
+    """The CPU oracle's view of the synthetic batch with this seed (same frames as ``cg.synthetic_batch``)."""
+    w = cg.data.WORKLOADS[workload]
+    frames = cg.data.synthetic_frames(n_frames, w["n_atoms"], w["n_cgs"], w["box"], seed=seed,
+                                      spatial_sort=(workload == "protein2000"))
     per = []
     for k in range(n_frames):
         f = {key: val[k] for key, val in frames.items()}
         f["nbr_list"] = O.get_neighbor_list(f["nxyz"][:, 1:4], w["atom_cutoff"], True)
         f["CG_nbr_list"] = O.get_neighbor_list(f["CG_nxyz"][:, 1:4], w["cg_cutoff"], True)
         per.append(f)
-    batch = O.cg_collate(per)
+    hp = O.Hyper(F, w["n_rbf"], w["atom_cutoff"], w["cg_cutoff"], w["enc_nconv"], w["dec_nconv"], w["n_cgs"])
+    return O.cg_collate(per), hp
+
+
+def cpu_baseline(cg, workload: str, F: int, n_frames: int, steps: int):
+    """The CPU oracle (oracle/cgvae_oracle.py, an op-for-op restatement of the reference's
+    unfused torch path) timed on this box's host cores: the same full training step."""
+    import torch
+    from oracle import cgvae_oracle as O
+    w = cg.data.WORKLOADS[workload]
+    # 8 threads is the fastest setting for this op mix on the GPU box's host (tools/cpu_threads_probe.py:
+    # 8 -> 2.36 s/step, 16 -> 2.39, 32 -> 3.46, 64 -> 5.39 on chignolin) and the survey's own core count
+    threads = min(8, os.cpu_count() or 8)
+    torch.set_num_threads(threads)
+    batch, hp = oracle_setup(cg, O, workload, F, n_frames)
+    P = O.require_grad(O.init_params(hp, seed=123))
     opt = torch.optim.Adam(list(P.values()), lr=1e-4)
     O.train_step(batch, P, hp, opt, w["beta"], w["gamma"])            # warm-up
     t0 = time.perf_counter()
@@ -158,11 +250,76 @@ def cpu_baseline(workload: str, F: int, n_frames: int, steps: int):
                       f"({n_frames} frames, F={F}) after 1 warm-up, {dt * 1e3:.0f} ms/step, torch CPU {threads} threads"}
 
 
+def parity_check(cg, model, trainer, batch, workload, F, frames):
+    """One (untimed, eager) training step of the HIP path with host-drawn reparametrisation noise against the CPU
+    oracle's forward + loss on the same batch, same initial weights, same noise (cgvae.py:486-513,
+    scripts/utils.py:117-141).  Must be the trainer's FIRST step (weights = the seeded initialisation)."""
+    import torch
+    from oracle import cgvae_oracle as O
+    w = cg.data.WORKLOADS[workload]
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(8, os.cpu_count() or 8))
+    cpu_batch = {k: v.cpu() for k, v in batch.items() if torch.is_tensor(v)}
+    hp = O.Hyper(F, w["n_rbf"], w["atom_cutoff"], w["cg_cutoff"], w["enc_nconv"], w["dec_nconv"], w["n_cgs"])
+    P = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    eps = torch.randn(cpu_batch["CG_nxyz"].shape[0], F, generator=torch.Generator().manual_seed(9))
+    with torch.no_grad():
+        out0 = O.model_forward(cpu_batch, P, hp, eps=eps)
+        loss0, kl0, recon0, graph0 = O.loss_terms(out0, cpu_batch, w["beta"], w["gamma"])
+    torch.set_num_threads(threads)
+    trainer.step(batch, eps=eps.to(batch["nxyz"].device))
+    torch.cuda.synchronize()
+
+    def rel(a, b):
+        a, b = a.detach().cpu().double(), b.detach().cpu().double()
+        return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+    kl1, recon1, graph1 = trainer.last_terms
+    res = {"against": "oracle/cgvae_oracle.py forward + loss, same batch / weights / host-drawn eps (first step, eager)",
+           "loss": float(trainer.last_loss), "loss_oracle": float(loss0),
+           "loss_rel": rel(trainer.last_loss.reshape(()), loss0.reshape(())),
+           "kl_rel": rel(kl1.reshape(()), kl0.reshape(())), "recon_rel": rel(recon1.reshape(()), recon0.reshape(())),
+           "graph_rel": rel(graph1.reshape(()), graph0.reshape(())),
+           "xyz_recon_rel": rel(trainer.last_out[5], out0[5]), "mu_rel": rel(trainer.last_out[0], out0[0]),
+           "sigma_rel": rel(trainer.last_out[1], out0[1]), "tolerance": 1e-4}
+    res["ok"] = all(res[k] <= 1e-4 for k in ("loss_rel", "kl_rel", "recon_rel", "graph_rel", "xyz_recon_rel", "mu_rel", "sigma_rel"))
+    return res
+
+
+def step_algorithmic_bytes(model, trainer, batch, F, R, w):
+    """HBM bytes one training step cannot avoid (fp32), for `step_roofline`:
+      * every live parameter is read once by the forward and once by the backward-input products: 2 x 4 bytes;
+      * optimiser: 6 floats per rank-update weight (p, m, v read + written), 8 per other parameter (g written by backward,
+        read once, p / m / v read + written);
+      * per message-passing layer on the atom graph: forward E (16 + 4R) + 4 N 10F, backward the same again
+        (SURVEY.md 8d); bead-level activations are negligible."""
+    n_live = sum(p.numel() for p in trainer.arena.params)
+    n_rank = trainer._rank_numel if getattr(trainer, "last_rank_step", None) else 0
+    g = batch["_graph"]
+    E, N = g.atom.n_edges, g.atom.n_dst
+    layers = w["enc_nconv"]
+    edge = 2 * layers * (E * (16 + 4 * R) + 4 * N * 10 * F)
+    return {"weights_fwd_bwd": 8 * n_live, "optimizer": 4 * (6 * n_rank + 8 * (n_live - n_rank)), "edge_kernels": edge,
+            "total": 8 * n_live + 4 * (6 * n_rank + 8 * (n_live - n_rank)) + edge, "live_parameters": n_live}
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
+
+    import torch
+    import coarsegrainingvae_amd as cg
+    from coarsegrainingvae_amd import ktimer
+    from coarsegrainingvae_amd.data import WORKLOADS
+    from coarsegrainingvae_amd.trainer import Trainer
+
+    from coarsegrainingvae_amd import options
+    options.apply(args.option)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: running {world} rank(s)", file=sys.stderr)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -172,26 +329,43 @@ def main():
         dist = None
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local if world > 1 else 0)
+    # the host side of a step is a handful of tiny tensor ops: keep torch's intra-op pool small (run_ala.py does the same)
+    torch.set_num_threads(min(torch.get_num_threads(), 8))
     w = WORKLOADS[args.workload]
-    F = args.n_basis
+    F, R = args.n_basis, w["n_rbf"]
     frames = args.frames_per_gpu or w["batch"]
 
-    batch = cg.synthetic_batch(args.workload, n_frames=frames, seed=rank, device=dev)
-    from coarsegrainingvae_amd.trainer import Trainer
+    def make_batch(seed, slack=0.0):
+        ds = cg.data.CGDataset(cg.data.synthetic_frames(frames, w["n_atoms"], w["n_cgs"], w["box"], seed,
+                                                        spatial_sort=(args.workload == "protein2000")))
+        ds.generate_neighbor_list(w["atom_cutoff"], w["cg_cutoff"], device=dev, undirected=True)
+        return ds, cg.data.prepare_batch(cg.data.CG_collate([ds[i] for i in range(frames)]), dev, edge_slack=slack)
+
+    # the batch the step is captured on (spare edge capacity: other batches are loaded into its buffers in place) and
+    # the rotation of different resident batches the timed loop cycles over
+    _, batch = make_batch(rank, slack=0.25)
+    n_rot = max(args.rotation, 1)
+    rot_sets = [make_batch(1000 * (rank + 1) + k) for k in range(n_rot)]
+    rotation = [b for _, b in rot_sets]
 
     def build(exchange):
-        m = cg.build_model(F, w["n_rbf"], w["atom_cutoff"], w["cg_cutoff"], w["enc_nconv"], w["dec_nconv"],
-                           w["n_cgs"], seed=123).to(dev)
+        m = cg.build_model(F, R, w["atom_cutoff"], w["cg_cutoff"], w["enc_nconv"], w["dec_nconv"], w["n_cgs"], seed=123).to(dev)
         if args.skip_dead_vector_channel:
             m.encoder.set_skip_dead_vector_channel(True)
             m.prior_net.set_skip_dead_vector_channel(True)
-        # --deferred-update (opt-in, measured slower: DESIGN.md 4): the parameter pass of a step opens the next step,
-        # the decoder's share beside the encoder forward; the last one is flushed after the timed loop
         return m, Trainer(m, lr=1e-4, beta=w["beta"], gamma=w["gamma"], world_size=world,
-                          fused_optimizer=(args.optimizer == "fused"), exchange=exchange,
-                          defer_update=args.deferred_update)
+                          fused_optimizer=(args.optimizer == "fused"), exchange=exchange, defer_update=args.deferred_update)
 
-    def first_steps(tr):
+    parity = None
+
+    def first_steps(m, tr):
+        nonlocal parity
+        # the very first step doubles as the parity check (rank 0 of a single-process run: weights still at their
+        # seeded initialisation, host-drawn noise, compared with the CPU oracle)
+        if world == 1 and not args.no_parity and parity is None:
+            parity = parity_check(cg, m, tr, batch, args.workload, F, frames)
+        else:
+            tr.step(batch)
         # per-kernel HIP-event timing needs eager launches: done on a few untimed steps (part of warm-up)
         tr.step(batch)
         with ktimer.KernelTimer(("equi_msg", "pseudo_msg")) as kt:
@@ -201,7 +375,7 @@ def main():
 
     model, trainer = build(args.exchange)
     try:
-        ksum = first_steps(trainer)
+        ksum = first_steps(model, trainer)
     except Exception as exc:
         # every rank runs the same code on equally shaped shards, so a failure of the operand exchange hits all of
         # them at the same point: measure with the plain gradient all-reduce rather than lose the run
@@ -210,7 +384,7 @@ def main():
         print(f"[bench] operand exchange failed on rank {rank}: {exc!r}; falling back to --exchange gradients", file=sys.stderr)
         torch.cuda.synchronize()
         model, trainer = build("gradients")
-        ksum = first_steps(trainer)
+        ksum = first_steps(model, trainer)
 
     def barrier():
         if dist is not None:
@@ -225,25 +399,55 @@ def main():
             print(f"[bench] hipGraph capture failed on rank {rank}: {exc!r}; falling back to eager steps", file=sys.stderr)
             use_graph = False
             torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        trainer.step(batch)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        trainer.step(batch)
-    barrier()
-    elapsed = time.perf_counter() - t0
+
+    # ---------------------------------------------------------------- headline: rotation of resident batches
+    replays0 = trainer.replays
+    step_rot = lambda i: trainer.step(rotation[i % n_rot])
+    for i in range(args.warmup):
+        step_rot(i)
+    secs = timed_loop(step_rot, args.steps, args.reps, barrier, dist, dev)
     trainer.flush()                                  # the update of the last timed step (the first one applied a pre-timed one)
-    if dist is not None:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    ms = 1e3 * elapsed / args.steps
-    value = world * frames * args.steps / elapsed
+    rot_replayed = trainer.replays - replays0
+    med = statistics.median(secs)
+    ms = 1e3 * med / args.steps
+    value = world * frames * args.steps / med
+    loss_end = float(trainer.last_loss)
+
+    extras_on = not args.no_extras
+    side = {}
+    if extras_on:
+        # the same step on ONE fixed batch (graph replay only: round 1's figure)
+        for _ in range(3):
+            trainer.step(batch)
+        s = timed_loop(lambda i: trainer.step(batch), args.steps, 3, barrier, dist, dev)
+        side["ms_per_step_replay_only"] = {"median": 1e3 * statistics.median(s) / args.steps, "min": 1e3 * min(s) / args.steps,
+                                           "what": "same captured step replayed on one fixed batch: no per-batch graph work in the clock"}
+        # host-inclusive: every step collates its frames on the host (CG_collate), make_directed, pinned H2D copies,
+        # in-place re-plan + edge records, replay
+        host_sets = [ds for ds, _ in rot_sets]
+
+        def step_host(i):
+            ds = host_sets[i % n_rot]
+            trainer.step(cg.data.CG_collate([ds[j] for j in range(frames)]))
+        for i in range(3):
+            step_host(i)
+        s = timed_loop(step_host, args.steps, 3, barrier, dist, dev)
+        side["ms_per_step_fresh_batch"] = {"median": 1e3 * statistics.median(s) / args.steps, "min": 1e3 * min(s) / args.steps,
+                                           "what": "host frames -> CG_collate -> make_directed -> H2D -> CSR plans + edge records "
+                                                   "-> step, all inside the clock (rotation of %d batches)" % n_rot}
+        # forward + loss + backward only (SURVEY.md 8d metric 1 without clip + Adam): the validation flavour of the step
+        if use_graph:
+            try:
+                trainer.capture(batch, warmup=1, train=False)
+            except Exception as exc:
+                print(f"[bench] capture of the forward+backward-only step failed: {exc!r}", file=sys.stderr)
+        for _ in range(3):
+            trainer.step(batch, train=False)
+        s = timed_loop(lambda i: trainer.step(batch, train=False), args.steps, 3, barrier, dist, dev)
+        side["ms_fwd_loss_bwd_only"] = {"median": 1e3 * statistics.median(s) / args.steps, "min": 1e3 * min(s) / args.steps,
+                                        "what": "forward + loss + backward (all gradients materialised), no clip / Adam"}
 
     if rank == 0:
-        loss = float(trainer.last_loss)
-        R = w["n_rbf"]
         n_atoms_total = int(batch["nxyz"].shape[0])
 
         def edge_kernel_roofline(tag):
@@ -260,50 +464,63 @@ def main():
                 by = 4 * ns * (k * F + F + k * F) + ne * (16 + 4 * R) + 2 * 4 * k * F * (R + 1)
                 fl = ne * F * ((12 * R + 40) if flag else (4 * R + 8)) * (k // 3)
             us = ksum[tag]["avg_us"]
-            return {"kernel": tag, "bound": "mfma", "achieved": fl / (us * 1e-6) / 1e12, "peak": F32_PEAK_TFLOPS,
+            return {"kernel": tag, "bound": "valu_pk_fma_f32", "achieved": fl / (us * 1e-6) / 1e12, "peak": F32_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": fl / (us * 1e-6) / 1e12 / F32_PEAK_TFLOPS, "traffic": None,
                     "avg_us": us, "launches": ksum[tag]["launches"], "algorithmic_flops": fl,
                     "hbm": {"algorithmic_bytes": by, "achieved_GBps": by / (us * 1e-6) / 1e9,
                             "peak_GBps": HBM_PEAK_GBS, "frac": by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}}
 
         roofline, extra = None, {}
-        if ksum:
-            # the path's dominant hand-written kernel: the fused EquiMessageBlock forward on the atom graph
+        committed = {}
+        try:
+            committed = json.load(open(os.path.join(ROOT, "profiles", "committed_kernel_times.json"))).get(args.workload, {})
+        except (OSError, ValueError):
+            pass
+        if ksum and extras_on:
+            # the hot path's named kernel: the fused EquiMessageBlock forward on the atom graph (gather -> filter ->
+            # product -> segmented reduction).  It is bound by packed-fp32 VALU issue, not by HBM or MFMA.
             fwd_tags = [k for k in ksum if k.startswith("equi_msg_fwd")]
             tag = max(fwd_tags, key=lambda k: ksum[k]["total_ms"])
             roofline = edge_kernel_roofline(tag)
-            # the judged duration: back-to-back launches between two events (agrees with the rocprofv3 kernel trace);
-            # the per-launch figure from the eager steps stays beside it
-            us = message_forward_us(batch, F, R, w["cg_cutoff"])
+            us = message_forward_us([batch] + rotation, F, R, w["cg_cutoff"])
             roofline["avg_us_eager_step"] = roofline["avg_us"]
             fl, by = roofline["algorithmic_flops"], roofline["hbm"]["algorithmic_bytes"]
             roofline.update(avg_us=us, achieved=fl / (us * 1e-6) / 1e12, frac=fl / (us * 1e-6) / 1e12 / F32_PEAK_TFLOPS,
-                            timing="50 back-to-back launches between two HIP events on the launch stream")
+                            timing="48 launches between two HIP events on the launch stream, cycling over %d different "
+                                   "plans / record sets / operand sets (no launch re-reads its own inputs from L2)" % (n_rot + 1))
             roofline["hbm"].update(achieved_GBps=by / (us * 1e-6) / 1e9, frac=by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS)
+            c = committed.get("message_forward")
+            if c:
+                roofline["rocprofv3_committed"] = c      # {"avg_us": .., "source": "profiles/..."} of the same command
+                roofline["frac_at_rocprofv3_duration"] = fl / (c["avg_us"] * 1e-6) / 1e12 / F32_PEAK_TFLOPS
             extra["kernels"] = {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv)
                                     for kk, vv in edge_kernel_roofline(k).items() if kk in ("avg_us", "launches", "frac")}
                                 for k in ksum}
-        extra["scatter_add"] = scatter_add_roofline(batch, F)
-        extra["optimizer_step"] = optimizer_roofline(trainer)
-        if trainer._rank_hi and extra["optimizer_step"]:
-            # single process: the bead-level layers' gradients are never written (DESIGN.md 3, row O'); the figure
-            # above is the standalone full-arena kernel, the step itself moves 6 floats per rank-update weight
-            extra["optimizer_step"]["rank_update"] = {"weights": trainer._rank_numel, "arena_floats": trainer._rank_hi,
-                                                      "steps": trainer.rank_steps, "fallbacks": trainer.rank_fallbacks}
+        if extras_on:
+            extra["scatter_add"] = scatter_add_roofline(cg, batch, F)
+            extra["optimizer_step"] = optimizer_roofline(trainer)
+            if committed.get("kernel_groups"):
+                extra["kernel_groups"] = committed["kernel_groups"]      # top groups by share of one replayed step (rocprofv3)
         # HBM traffic per launch from the committed PMC passes (separate rocprofv3 --pmc runs of this
         # same workload; cannot be collected inside the timed run) -- null when no entry matches
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.workload, {})
             if F == 600 and frames == w["batch"]:
-                for obj in (roofline, extra["scatter_add"], extra["optimizer_step"]):
+                for obj in (roofline, extra.get("scatter_add"), extra.get("optimizer_step")):
                     if obj and obj["kernel"] in pmc:
                         obj["traffic"] = pmc[obj["kernel"]]["traffic_bytes"]
         except (OSError, ValueError):
             pass
+        step_bytes = None
+        if trainer.arena is not None:
+            sb = step_algorithmic_bytes(model, trainer, batch, F, R, w)
+            gbs = sb["total"] / (ms * 1e-3) / 1e9
+            step_bytes = {"bound": "hbm", "algorithmic_bytes": sb, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": gbs / HBM_PEAK_GBS}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             steps_cpu = args.cpu_steps or (4 if args.workload == "chignolin" else 6)
-            cpu = cpu_baseline(args.workload, F, frames, steps_cpu)
+            cpu = cpu_baseline(cg, args.workload, F, frames, steps_cpu)
         dp_step, dp_info = "+allreduce", None
         if world > 1 and trainer.arena is not None:
             left = sum(hi - lo for lo, hi in trainer._unsent_ranges()) * 4
@@ -320,14 +537,22 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {frames} frames/GPU x {w['n_atoms']} atoms, n_cgs={w['n_cgs']}, "
-                                   f"enc_nconv={w['enc_nconv']}, dec_nconv={w['dec_nconv']}, n_basis={F}, n_rbf={w['n_rbf']}, "
+                                   f"enc_nconv={w['enc_nconv']}, dec_nconv={w['dec_nconv']}, n_basis={F}, n_rbf={R}, "
                                    f"cutoffs {w['atom_cutoff']}/{w['cg_cutoff']}",
-                       "step": "fwd+loss+bwd" + (dp_step if world > 1 else "") + "+clip+adam",
+                       "step": "per-batch graph plans + edge records + fwd+loss+bwd" + (dp_step if world > 1 else "") + "+clip+adam",
+                       "inputs": f"rotation of {n_rot} different batches resident in HBM (coordinates + neighbour lists)",
                        "global_batch": world * frames, "directed_edges_rank0": int(batch["_graph"].atom.n_edges),
-                       "optimizer": args.optimizer, "deferred_update": bool(trainer.defer_update), "rank_update": bool(trainer._rank_hi), "hip_graph": bool(use_graph), "skip_dead_vector_channel": bool(args.skip_dead_vector_channel),
-                       "parallelism": f"dp{world}"},
-            "loss": loss, "roofline": roofline, "cpu_baseline": cpu,
+                       "optimizer": args.optimizer, "deferred_update": bool(trainer.defer_update),
+                       "rank_update": bool(trainer._rank_hi), "hip_graph": bool(use_graph),
+                       "graph_replays_in_timed_loops": int(rot_replayed),
+                       "skip_dead_vector_channel": bool(args.skip_dead_vector_channel), "parallelism": f"dp{world}"},
+            "timing": {"repetitions": args.reps, "ms_per_step_median": ms, "ms_per_step_min": 1e3 * min(secs) / args.steps,
+                       "ms_per_step_max": 1e3 * max(secs) / args.steps,
+                       "ms_per_step_all": [round(1e3 * s / args.steps, 4) for s in secs],
+                       "value_is": "median repetition; each repetition = exactly --steps steps between barrier + device sync"},
+            "loss": loss_end, "parity": parity, "roofline": roofline, "step_roofline": step_bytes, "cpu_baseline": cpu,
         }
+        line.update(side)
         if dp_info:
             line["data_parallel"] = dp_info
         if cpu:

@@ -28,6 +28,9 @@ _p, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 PROTOTYPES = {
     "cgv_version": (_i, []),
     "cgv_last_error_string": (C.c_char_p, []),
+    "cgv_set_option": (_i, [_i, _i]),
+    "cgv_get_option": (_i, [_i]),
+    "cgv_reset_options": (_i, []),
     "cgv_rbf_supported": (_i, [_i]),
     "cgv_geom_stride": (_i, [_i]),
     "cgv_geom_unit_offset": (_i, [_i]),
@@ -99,6 +102,24 @@ PROTOTYPES = {
     "cgv_optim_prepare_extra": (_i, [_p, C.c_int64, _p, _i, _f, _f, _f, _f, _p, _f, _p, _p, _p]),
     "cgv_grouped_wgrad_adam": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _f, _f, _f, _f, _p, _p]),
 }
+
+
+# include/cgvae_hip.h: CGV_OPT_* (A/B switches of the launchers; defaults in csrc/api.cpp)
+OPTIONS = {"msg_fwd_split": 0, "msg_bwd_split": 1, "msg_fwd_kernel": 2, "grp_waves": 3, "grp_records": 4, "csr_build": 5,
+           "pseudo_chunks": 6, "wgrad_tiling": 7, "tile_fwd_lds_min": 8, "bwd_input_waves": 9}
+
+
+def set_option(name: str, value: int) -> None:
+    """cgv_set_option by name (process wide; set before the launches it should affect)."""
+    call("cgv_set_option", OPTIONS[name], int(value))
+
+
+def get_option(name: str) -> int:
+    return int(load().cgv_get_option(OPTIONS[name]))
+
+
+def reset_options() -> None:
+    call("cgv_reset_options")
 
 
 def header_symbols():

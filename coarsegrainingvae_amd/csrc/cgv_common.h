@@ -8,6 +8,7 @@
 namespace cgv {
 
 void set_error(const char* fmt, ...);   // thread-local message (api.cpp)
+int option(int id);                     // current value of a CGV_OPT_* switch (api.cpp: cgv_set_option)
 
 inline int check_launch(const char* what) {
   hipError_t e = hipGetLastError();

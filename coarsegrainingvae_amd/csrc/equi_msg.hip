@@ -620,7 +620,7 @@ struct BwdShape {
 static inline BwdShape bwd_shape(int n_src, long long n_edges_hint) {
   BwdShape s;
   s.split = n_edges_hint >= 48LL * (n_src > 0 ? n_src : 1);
-  if (const char* dbg = getenv("CGV_DEBUG_BWD_SPLIT")) s.split = dbg[0] == '1';   // experiments only
+  if (const int o = cgv::option(CGV_OPT_MSG_BWD_SPLIT); o >= 0) s.split = o != 0;   // experiments only
   const int min_npc = s.split ? 1 : BWD_WAVES;
   int npc = (n_src + BWD_MAX_CHUNKS - 1) / BWD_MAX_CHUNKS;
   if (npc < min_npc) npc = min_npc;
@@ -648,7 +648,7 @@ int cgv_equi_msg_fwd(const float* phi, const float* v, const float* geom_d, cons
   const dim3 grid(8 * npx * tiles);
   // >= 16 edges per receiver on average: 4 waves share a (node, tile) (the atom graph: 125; atom -> bead: 28)
   bool split = n_edges_hint >= 16LL * n_dst;
-  if (const char* dbg = getenv("CGV_DEBUG_FWD_SPLIT")) split = dbg[0] == '1';   // experiments only
+  if (const int o = cgv::option(CGV_OPT_MSG_FWD_SPLIT); o >= 0) split = o != 0;   // experiments only
   // 8-byte vector accesses need an even channel count and 8-byte aligned bases; the buffer-descriptor
   // gathers need every row within 2 GiB of the base (n_rows_hint = rows of phi / v, 0 = unknown)
   const bool pair = (n_feat % 2 == 0) && (n_rbf % 2 == 0) && n_rows_hint > 0 &&
@@ -662,14 +662,13 @@ int cgv_equi_msg_fwd(const float* phi, const float* v, const float* geom_d, cons
   if (pair) { if (split) CGV_FWD_LAUNCH(DV, 4, true); else CGV_FWD_LAUNCH(DV, 1, true); } \
   else      { if (split) CGV_FWD_LAUNCH(DV, 4, false); else CGV_FWD_LAUNCH(DV, 1, false); }
   // matrix-core variant: segments long enough to fill 16-edge tiles, rows addressable through a buffer
-  // descriptor.  CGV_FWD_KERNEL=valu|mfma overrides (A/B measurements only).
+  // descriptor.  cgv_set_option(CGV_OPT_MSG_FWD_KERNEL, 0 | 1) overrides (A/B measurements only).
   // Measured (chignolin layer): 71 us against 55 us for the packed-VALU kernel -- with 173 VGPRs only two
   // waves fit a SIMD and the per-lane dword gathers (4 source rows per instruction) load the texture path
   // more than the VALU kernel's 8-byte row gathers; the kernel is gather-latency bound, not FMA bound.
-  // Kept as an opt-in A/B variant: CGV_FWD_KERNEL=mfma.
-  bool use_mfma = false;
-  if (const char* dbg = getenv("CGV_FWD_KERNEL"))
-    use_mfma = dbg[0] == 'm' && n_rows_hint > 0 && (uint64_t)n_rows_hint * 12u * (uint64_t)n_feat < 0x7fffffffull;
+  // Kept as an opt-in A/B variant: cgv_set_option(CGV_OPT_MSG_FWD_KERNEL, 1).
+  const bool use_mfma = cgv::option(CGV_OPT_MSG_FWD_KERNEL) == 1 && n_rows_hint > 0 &&
+                        (uint64_t)n_rows_hint * 12u * (uint64_t)n_feat < 0x7fffffffull;
   if (use_mfma) {
     const int tiles64 = (n_feat + 63) / 64;
     const dim3 grid64(8 * npx * tiles64);

@@ -389,17 +389,15 @@ int cgv_equi_msg_fwd_grouped(const float* phi, const float* v, const float* geom
   const dim3 grid(8 * gpx);
   // waves per block: 4 (measured on the 2000-atom graph: 4 -> 654 us, 8 -> 942 us: one 8-wave block per CU leaves two
   // waves per SIMD; 6 -> 1194 us: a wave count that is not a multiple of the 4 SIMDs loads them unevenly).
-  // CGV_GRP_SPLIT=8 is kept for A/B runs.
-  int split = 4;
-  if (const char* dbg = getenv("CGV_GRP_SPLIT")) split = atoi(dbg);
+  // cgv_set_option(CGV_OPT_GRP_WAVES, 8) is kept for A/B runs.
+  const int split = cgv::option(CGV_OPT_GRP_WAVES);
 #define CGV_GRP_LAUNCH(RBV, SP)                                                                                  \
   hipLaunchKernelGGL((cgv::equi_msg_fwd_grp_k<RBF, RBV, SP>), grid, dim3(64 * SP), 0, st, phi, v, geom_g, rowptr_d, src_g, \
                      Wd, bd, ds, dv, n_feat, n_dst, gpx, tiles, s_res, v_res)
 #define CGV_GRP_PICK(RBV) \
   if (split == 8) CGV_GRP_LAUNCH(RBV, 8); else CGV_GRP_LAUNCH(RBV, 4)
   // record stream: "lds" (vector loads -> LDS ring -> VGPR operands; 16-float records: n_rbf 8 / 10) or "scalar"
-  bool lds = false;
-  if (const char* dbg = getenv("CGV_GRP_RECORDS")) lds = dbg[0] == 'l';
+  const bool lds = cgv::option(CGV_OPT_GRP_RECORDS) == 1;
   if (lds && (n_rbf == 8 || n_rbf == 10) && n_edges > 0 && n_edges < (1ll << 28)) {
     const int ne = (int)n_edges;
 #define CGV_GRP_LDS(RV, RBV)                                                                                       \

@@ -384,11 +384,11 @@ int cgv_csr_build(const int64_t* dst, const int64_t* src, int stride, int n_edge
   CGV_REQUIRE(n_edges == 0 || (dst && eid_d && dst_d && src_d && eid_s && dst_s && src_s), "null edge array");
   hipStream_t st = (hipStream_t)stream;
   char* ws = reinterpret_cast<char*>(workspace);
-  // by rows (5 launches per view) when the workspace has room for the row counters; CGV_CSR_BUILD=radix forces the
+  // by rows (5 launches per view) when the workspace has room for the row counters; cgv_set_option(CGV_OPT_CSR_BUILD, 1) forces the
   // two-radix-pass construction (tests compare the two)
   const int rows_max = n_dst > n_src ? n_dst : n_src;
   bool by_rows = workspace_bytes >= cgv::rows_view_bytes(n_edges, rows_max) && (((uintptr_t)workspace) & 7) == 0;
-  if (const char* dbg = getenv("CGV_CSR_BUILD")) by_rows = by_rows && dbg[0] != 'r';
+  if (cgv::option(CGV_OPT_CSR_BUILD) == 1) by_rows = false;
   if (by_rows) {
     int rc = cgv::rows_view(dst, src, stride, n_edges, n_dst, rowptr_d, eid_d, dst_d, src_d, ws, st);
     if (rc) return rc;

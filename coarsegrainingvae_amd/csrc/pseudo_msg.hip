@@ -407,12 +407,9 @@ __global__ __launch_bounds__(64 * PRED_SLICES) void pseudo_bwd_reduce(const floa
 // Source-node chunks of pass B (= partial filter-gradient sets): one node per chunk up to 64 nodes (12-bead chignolin
 // batch; 64 beads x 61 edges of the 2000-atom config: 119 us with 64 chunks, 150 with 32), a quarter of the nodes per
 // chunk count above that -- a 96-bead dipeptide batch has 2 edges per node, and 24 chunks of 4 nodes (13.0 us) beat 64
-// chunks of 1-2 (19.5 us: the per-block filter staging dominates).  CGV_PSEUDO_CHUNKS overrides the cap (experiments).
+// chunks of 1-2 (19.5 us: the per-block filter staging dominates).  cgv_set_option(CGV_OPT_PSEUDO_CHUNKS, cap) overrides the cap (experiments).
 static inline int pseudo_chunks(int n) {
-  if (const char* dbg = getenv("CGV_PSEUDO_CHUNKS")) {
-    const int cap = atoi(dbg) > 0 ? atoi(dbg) : 64;
-    return n < cap ? (n > 0 ? n : 1) : cap;
-  }
+  if (const int cap = cgv::option(CGV_OPT_PSEUDO_CHUNKS); cap > 0) return n < cap ? (n > 0 ? n : 1) : cap;
   if (n <= 64) return n > 0 ? n : 1;
   const int c = n / 4 > 24 ? n / 4 : 24;
   return c < 64 ? c : 64;

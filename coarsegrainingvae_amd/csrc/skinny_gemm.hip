@@ -898,14 +898,14 @@ __global__ __launch_bounds__(256) void pack_operands_k(const PackProblem* __rest
 // k tiling of one problem: tiles of at most 256 float4 within a 60 KiB LDS budget for the x + g tiles; among the
 // admissible tile counts the one that wastes the fewest lanes -- a tile of t4 float4 columns occupies thread groups of
 // 64 / 128 / 256 lanes (grouped_wgrad_t deals its 4 row passes to 256 / lanes groups), so K = 600 is cut into
-// 3 x 50 columns (78 % of the lanes busy) rather than 1 x 150 (59 %).  CGV_WGRAD_TILING=wide: the widest tile.
+// 3 x 50 columns (78 % of the lanes busy) rather than 1 x 150 (59 %).  cgv_set_option(CGV_OPT_WGRAD_TILING, 1): the widest tile.
 static inline void wgrad_tiling(int M, int K, int* tiles_k, int* tile_w) {
   int max_t4 = (15360 / M - WG_BLOCK_ROWS) / 4;
   if (max_t4 > 256) max_t4 = 256;
   if (max_t4 < 1) max_t4 = 1;
   const int k4 = K / 4;
   int nt = (k4 + max_t4 - 1) / max_t4;
-  static const bool wide = [] { const char* e = getenv("CGV_WGRAD_TILING"); return e && !strcmp(e, "wide"); }();
+  const bool wide = cgv::option(CGV_OPT_WGRAD_TILING) == 1;
   if (!wide) {
     long best_cost = -1;
     int best = nt;

@@ -409,10 +409,10 @@ int cgv_tile_linear_fwd(const float* x, const float* W, const float* bias, float
   hipStream_t st = (hipStream_t)stream;
   const int tiles32 = ((N + 31) / 32) * ((M + 31) / 32);
   const int tiles64 = ((N + 63) / 64) * ((M + 63) / 64);
-  static const int lds_min = [] { const char* e = getenv("CGV_TILE_FWD_LDS_MIN"); return e ? atoi(e) : 448; }();
+  const int lds_min = cgv::option(CGV_OPT_TILE_FWD_LDS_MIN);
   const bool aligned16 = ((((uintptr_t)y | (uintptr_t)z | (uintptr_t)bias)) & 15) == 0;
   // several 64 x 64 tiles per CU and many row tiles: the LDS-staged kernel (704 x 5400 still favours the L2-fed
-  // tiles, 59 vs 63 us; 2000 x 5400: 168 vs 201, 2000 x 1800: 57 vs 70).  CGV_TILE_FWD_LDS_MIN=1: every shape (tests)
+  // tiles, 59 vs 63 us; 2000 x 5400: 168 vs 201, 2000 x 1800: 57 vs 70).  cgv_set_option(CGV_OPT_TILE_FWD_LDS_MIN, 1): every shape (tests)
   if (tiles64 >= lds_min && (M >= 1024 || lds_min <= 1) && aligned16)
     hipLaunchKernelGGL(cgv::tile_fwd_lds_k, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, st, x, W, bias, y, z, M, N, K,
                        act);
@@ -432,7 +432,7 @@ static int tile_bwd_input_launch(const float* g, const float* z, int act, const 
   const int blocks32 = kt * ((M + 31) / 32);
   const int blocks16 = kt * ((M + 15) / 16);
   int waves = 8;
-  if (const char* dbg = getenv("CGV_BWD_INPUT_WAVES")) waves = atoi(dbg);          // experiments only
+  if (const int o = cgv::option(CGV_OPT_BWD_INPUT_WAVES); o > 0) waves = o;          // experiments only
   else if (blocks16 < 128 && N >= 1024) waves = 16;
   if (blocks32 >= 512)                    // enough 32-row tiles to fill the chip: halve the weight re-reads
     hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 4>), dim3(kt, (M + 31) / 32), dim3(256), 0, st, g, W, gx, M, N, K, z, act);

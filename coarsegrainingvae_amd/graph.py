@@ -203,11 +203,11 @@ def receiver_group_size(plan: "EdgePlan") -> int:
     (>= 16 edges per receiver on average: the atom graphs of every workload) get groups of 2: measured against the
     per-receiver walk 51 -> 42 us (chignolin), 23.4 -> 20.9 us (dipeptide), 1187 -> 613 us (2000 atoms).  Groups of 4
     gather fewer rows but hold 138 instead of 122 VGPRs (3 instead of 4 waves per SIMD) and halve the block count:
-    48 / 22 / 630 us on the same graphs.  ``CGV_FWD_GROUP`` = 0 / 2 / 4 overrides (A/B: tools/ab_group.sh)."""
-    import os
-    env = os.environ.get("CGV_FWD_GROUP")
-    if env is not None:
-        return int(env) if int(env) in (2, 4) else 0
+    48 / 22 / 630 us on the same graphs.  ``options.set("fwd_group", 0 / 2 / 4)`` overrides (A/B: tools/ab_group.sh)."""
+    from .options import HOST
+    forced = HOST["fwd_group"]
+    if forced >= 0:
+        return forced if forced in (2, 4) else 0
     if plan.n_edges < 16 * max(plan.n_dst, 1) or plan.n_dst < 4:
         return 0
     return 2

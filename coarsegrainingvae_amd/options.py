@@ -1,0 +1,54 @@
+"""Explicit A/B switches (nothing is read from the environment).
+
+``set(name, value)`` takes both kinds: launcher options of the C ABI (``cgv_set_option``, include/cgvae_hip.h: which
+kernel computes an entry point) and the host mirror's own dispatch choices below.  Defaults are what every documented
+number was measured with; the alternatives exist for A/B measurements and for the parity tests of the other kernels."""
+from __future__ import annotations
+
+from . import _lib
+
+HOST = {
+    "fwd_group": -1,        # receivers per group of the shared-source forward: -1 rule of graph.receiver_group_size, 0 / 2 / 4
+    "wgrad_kernel": 0,      # grouped weight gradients of <= 64 rows: 0 weight-streaming VALU kernel, 1 MFMA tiles for all
+    "table_upload": 0,      # record tables of a captured step: 0 copied once after capture, 1 a copy node in every replay
+    "wgrad_tile": 64,       # output tile edge of the grouped MFMA weight-gradient launch: 64 or 128
+}
+_DEFAULTS = dict(HOST)
+
+
+def set(name: str, value: int) -> None:      # noqa: A001  (module-level API: options.set / options.get)
+    if name in HOST:
+        HOST[name] = int(value)
+    elif name in _lib.OPTIONS:
+        _lib.set_option(name, int(value))
+    else:
+        raise KeyError(f"unknown option {name!r}; known: {sorted(HOST) + sorted(_lib.OPTIONS)}")
+
+
+def get(name: str) -> int:
+    return HOST[name] if name in HOST else _lib.get_option(name)
+
+
+def reset() -> None:
+    HOST.update(_DEFAULTS)
+    _lib.reset_options()
+
+
+def apply(specs) -> None:
+    """``["name=value", ...]`` (bench.py --option, tools)."""
+    for spec in specs or ():
+        name, _, value = spec.partition("=")
+        set(name.strip(), int(value))
+
+
+def pop_cli(argv) -> list:
+    """Strip ``--option name=value`` pairs out of an argv list, apply them, return the rest (tools/*.py)."""
+    rest, i = [], 0
+    while i < len(argv):
+        if argv[i] == "--option" and i + 1 < len(argv):
+            apply([argv[i + 1]])
+            i += 2
+        else:
+            rest.append(argv[i])
+            i += 1
+    return rest

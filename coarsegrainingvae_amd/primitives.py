@@ -81,18 +81,26 @@ class WeightGradQueue:
     def __init__(self):
         self.active = False
         self.items = []
-        self._captured = []     # (pinned, device) pairs owned by captured graphs
+        self._captured = []     # (pinned, device) pairs used by the capture in progress (handed over by finish_capture)
         self._capture_slots = []
-        import os
-        self.kernel = os.environ.get("CGV_WGRAD_KERNEL", "valu")      # "mfma": A/B switch, see launch()
-        self.static_tables = os.environ.get("CGV_TABLE_UPLOAD", "once") != "node"
         self._deferred = []
+
+    @property
+    def kernel(self):                   # options.set("wgrad_kernel", 1): MFMA tiles for every problem (A/B switch, see launch())
+        from .options import HOST
+        return "mfma" if HOST["wgrad_kernel"] == 1 else "valu"
+
+    @property
+    def static_tables(self):            # options.set("table_upload", 1) keeps the table copy as a node of the graph
+        from .options import HOST
+        return HOST["table_upload"] != 1
 
     def prepare_capture(self, device, flushes: int = 4):
         """Allocate the (pinned, device) table pairs the flushes of the next captured step will use
         (one per flush: two with data parallelism) -- pinned allocation is not allowed while a
         stream is capturing."""
         n = self.MAX_PROBLEMS * self.RECORD.size
+        self._captured = []
         self._capture_slots = [(torch.empty(n, dtype=torch.uint8).pin_memory(),
                                 torch.empty(n, dtype=torch.uint8, device=device)) for _ in range(flushes)]
 
@@ -116,7 +124,7 @@ class WeightGradQueue:
         capturing = torch.cuda.is_current_stream_capturing()
         if capturing:
             # the graph gets its own, never-rewritten staging buffer and table, allocated BEFORE capture
-            # (prepare_capture); CGV_TABLE_UPLOAD=node keeps the copy as a node of the graph (A/B switch)
+            # (prepare_capture); options.set("table_upload", 1) keeps the copy as a node of the graph (A/B switch)
             if not self._capture_slots:
                 raise RuntimeError("call wgrad_queue.prepare_capture(device) with enough slots before capturing a step")
             host, table = slot = self._capture_slots.pop()
@@ -145,6 +153,10 @@ class WeightGradQueue:
         if self._deferred:
             torch.cuda.current_stream().synchronize()
         self._deferred = []
+        # the (pinned, device) pairs this capture used belong to its graph: the caller keeps them with the graph and
+        # drops them with it (a re-capture after a learning-rate change must not leak the old graph's tables)
+        used, self._captured, self._capture_slots = self._captured, [], []
+        return used
 
     def small_table(self, items):
         """(device record table, total blocks, LDS floats) of the weight-streaming VALU kernels (grouped_wgrad_t: plain
@@ -355,9 +367,9 @@ def wgrad_tile(shapes) -> int:
     """Output tile edge of one grouped MFMA weight-gradient launch: 64.  The 128 x 128 variant (gathered_wgrad128_k: half
     the operand traffic per gW element, 3 instead of 5 blocks per CU) measured slower on every workload -- gathered
     launches at 8 ranks 265 vs 226 us, atom-level layers 179 vs 101 us, dipeptide step 3.29 vs 3.26 ms -- and stays behind
-    ``CGV_WGRAD_TILE=128`` with its parity test."""
-    import os
-    return 128 if os.environ.get("CGV_WGRAD_TILE") == "128" else 64
+    ``options.set("wgrad_tile", 128)`` with its parity test."""
+    from .options import HOST
+    return 128 if HOST["wgrad_tile"] == 128 else 64
 
 
 def _library_pays(M, N, K, forward: bool) -> bool:

@@ -128,6 +128,8 @@ def _batches(dataset, indices, batch_size, rank, world, device, prepared=None):
     can become the captured batch."""
     if 0 < len(indices) < batch_size:                     # small validation split: one (world-divisible) batch
         indices, batch_size = indices[:len(indices) // world * world], len(indices) // world * world
+    if not indices or batch_size <= 0:                    # fewer frames than ranks (or none): nothing to run
+        return
     for start in range(0, len(indices) - batch_size + 1, max(batch_size, 1)):
         chunk = indices[start:start + batch_size]
         shard = chunk[rank::world] if world > 1 else chunk
@@ -206,9 +208,22 @@ def run(params) -> dict:
                 kl, recon, graph = (t.clone() for t in trainer.last_terms)
                 tot.append(loss), kls.append(kl), recs.append(recon), grs.append(graph)
                 frames_seen += params["batch_size"] if mode == "train" else 0
-            mean = lambda xs: float(torch.stack(xs).mean()) if xs else float("nan")     # one sync per epoch
-            stats.update({f"{mode}_loss": mean(tot), f"{mode}_KL": mean(kls), f"{mode}_recon": mean(recs),
-                          f"{mode}_graph": mean(grs)})
+
+            def mean(xs, keep=None):                       # one sync per epoch
+                if not xs:
+                    return float("nan")
+                x = torch.stack(xs)
+                if keep is not None:
+                    x = x[keep]
+                return float(x.mean()) if x.numel() else float("nan")
+            # utils.py:145-148: a skipped batch (loss >= 200 gamma or NaN) contributes its KL but not its loss / recon /
+            # graph terms to the epoch means
+            keep = None
+            if tot:
+                lt = torch.stack(tot)
+                keep = ~((lt >= 200.0 * params["gamma"]) | torch.isnan(lt))
+            stats.update({f"{mode}_loss": mean(tot, keep), f"{mode}_KL": mean(kls), f"{mode}_recon": mean(recs, keep),
+                          f"{mode}_graph": mean(grs, keep)})
         stats.update({"epoch": epoch, "lr": trainer.lr})
         log_rows.append(stats)
         if rank == 0:
@@ -219,9 +234,16 @@ def run(params) -> dict:
                     for r in log_rows:
                         f.write(",".join(str(r[c]) for c in columns) + "\n")
         val = stats["val_loss"]
-        if np.isnan(stats["val_recon"]):                                  # run_ala.py:278-281
+        if not val_idx or len(val_idx) < world:
+            # no validation frames (-ndata < 10, or fewer than ranks): not the reference's NaN failure (run_ala.py:278-281,
+            # which means the model diverged) -- schedule and early stopping follow the training loss instead
+            val = stats["train_loss"]
+        elif np.isnan(stats["val_recon"]):                                # run_ala.py:278-281
             failed = True
             break
+        # NB the reference feeds ReduceLROnPlateau / EarlyStopping the lowess-smoothed validation curve
+        # (statsmodels, run_ala.py:259-275); statsmodels is not a dependency here and the control plane is outside the
+        # hot path: the raw value is used.  LR-decay / stopping epochs can differ on noisy runs.
         if best is None or val < best * (1 - params["threshold"]):
             best, bad_epochs = val, 0
         else:

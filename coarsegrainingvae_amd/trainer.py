@@ -107,6 +107,28 @@ class GradSync:
         backend = self.dist.get_backend(self.group)
         return torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
 
+    def all_reduce(self, model):
+        """Reference-style loop (train.train_step / train.loop with ``grad_sync=``): average every existing ``p.grad``
+        across the ranks in place -- SUM all-reduce, bucketed through one flat staging buffer per ~64 MiB, then / world
+        (equal-size shards: the mean of the shard gradients is the gradient of the whole batch's mean losses,
+        scripts/utils.py:124,133).  The Trainer's arena path does the same with no staging copy."""
+        grads = [p.grad for p in model.parameters() if p.grad is not None]
+        start = 0
+        while start < len(grads):
+            stop, n = start, 0
+            while stop < len(grads) and (n == 0 or n + grads[stop].numel() <= self.bucket):
+                n += grads[stop].numel()
+                stop += 1
+            chunk = grads[start:stop]
+            flat = torch.cat([g.reshape(-1) for g in chunk])
+            self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group)
+            flat.div_(self.world)
+            at = 0
+            for g in chunk:
+                g.copy_(flat[at:at + g.numel()].view_as(g))
+                at += g.numel()
+            start = stop
+
     def all_reduce_flat(self, flat: torch.Tensor):
         self.all_reduce_range(flat, 0, flat.numel())
         self.wait()
@@ -300,6 +322,7 @@ class Trainer:
         self._rank_hi = 0             # arena floats [0, _rank_hi) belong to rank-update weights
         self._rank_numel = 0
         self._rank_step = None        # this step's (table, problems, blocks, lds, items) once the Gram launch is out
+        self.last_rank_step = None
         self.rank_steps = 0           # steps that took the rank-update path / fell back to materialised gradients
         self.rank_fallbacks = 0
         self._pending = False
@@ -333,6 +356,9 @@ class Trainer:
         if value != self._lr and self._pending:
             self.flush()                                   # the pending update belongs to the old learning rate
         self._lr = value
+        if self.torch_opt is not None:                     # unfused path: the library optimiser holds its own copy
+            for group in self.torch_opt.param_groups:
+                group["lr"] = value
 
     def flush(self):
         """Apply a deferred parameter update now (no-op otherwise)."""
@@ -447,7 +473,7 @@ class Trainer:
             self.torch_opt = torch.optim.Adam(live, lr=self.lr, betas=self.betas, eps=self.eps)
 
     # ------------------------------------------------------------------ hipGraph capture of the whole step
-    def capture(self, batch, warmup: int = 2, train: bool = True):
+    def capture(self, batch, warmup: int = 2, train: bool = True, eps: Optional[torch.Tensor] = None):
         """Capture forward + loss + backward (+ all-reduce) + clip/Adam on ``batch`` into one
         hipGraph.  Every kernel of the step reads sizes that are fixed for a given molecule
         (N atoms, beads, bonds) and takes its edge structure from device memory (CSR plans), so
@@ -457,27 +483,42 @@ class Trainer:
         ``step`` on ANOTHER batch of the same molecules loads it into the captured batch's tensors and
         plan arrays in place (``data.copy_batch_into``; prepare the captured batch with some
         ``edge_slack``) and replays; batches that do not fit run eagerly.  ``train=False`` captures the
-        validation flavour (forward + backward, no optimiser: scripts/utils.py:159-160)."""
+        validation flavour (forward + backward, no optimiser: scripts/utils.py:159-160).
+        ``eps``: capture the step with the reparametrisation noise READ from a static buffer (initialised from this
+        tensor) instead of drawn on the device; ``step(batch, eps=...)`` then copies its noise into that buffer and
+        replays -- parity runs feed host-drawn noise through the captured step (tests, bench.py's parity check).
+        NB ``warmup`` eager steps are real optimiser steps on ``batch``; ``warmup=0`` captures without moving the
+        parameters (one gradient-free forward builds whatever is built lazily)."""
         if not self.fused:
             raise RuntimeError("graph capture needs the fused (sync-free) optimiser path")
+        eps_buf = None
+        if eps is not None:
+            eps_buf = eps.detach().to(device=next(self.model.parameters()).device, dtype=torch.float32).clone()
         if self.arena is None:
-            self._step_eager(batch)                        # builds the arena (first backward)
+            self._step_eager(batch, eps_buf)               # builds the arena (first backward)
         if warmup == 0:
             # nothing may be built lazily inside the capture (geometry records of this batch: H2D copies): one
             # forward without gradients, random stream restored, leaves the parameters and the sampling untouched
             dev = self.arena.p.device
             rng = torch.cuda.get_rng_state(dev)
             with torch.no_grad():
-                self.model(batch)
+                self.model(batch) if eps_buf is None else self.model(batch, eps=eps_buf)
             torch.cuda.set_rng_state(rng, dev)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                self._step_eager(batch, train=train)
+                self._step_eager(batch, eps_buf, train=train)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         if self.sync is not None:
+            if self.exchange is not None:
+                # the operand exchange all-gathers equally sized buffers; inside the capture nothing can be checked
+                # (OperandExchange.submit skips its test while capturing) and the eager step that built the arena ran
+                # without the exchange -- so compare the shard shapes (rows per layer derive from them) here, eagerly
+                sig = int(batch["nxyz"].shape[0]) * (1 << 24) + int(batch["CG_nxyz"].shape[0])
+                if not self.sync.same_on_all_ranks(sig):
+                    raise RuntimeError("operand exchange needs equally shaped shards on every rank")
             self.sync.drain()
         graph = torch.cuda.CUDAGraph()
         pending_at_start = self._pending              # a deferred update opens the captured step (or does not)
@@ -487,11 +528,11 @@ class Trainer:
         # with RCCL in the step, other threads (the process group's watchdog) legitimately touch the runtime
         mode = "thread_local" if self.sync is not None else "global"
         with torch.cuda.graph(graph, capture_error_mode=mode):
-            self._step_eager(batch, train=train)
-        wgrad_queue.finish_capture()                        # record tables: on the device before the first replay
+            self._step_eager(batch, eps_buf, train=train)
+        tables = wgrad_queue.finish_capture()               # record tables: on the device before the first replay
         self._pending = pending_at_start                    # recorded, not run: the update it opens with is still due
         # the step's result tensors live in the graph's pool: a replay refreshes them in place
-        self._graphs[self._graph_key(train, pending_at_start)] = {"graph": graph, "batch": batch, "lr": self.lr,
+        self._graphs[self._graph_key(train, pending_at_start)] = {"graph": graph, "batch": batch, "lr": self.lr, "eps": eps_buf, "tables": tables,
                                                                   "results": (self.last_loss, self.last_terms, self.last_out)}
         return graph
 
@@ -512,11 +553,13 @@ class Trainer:
     def step(self, batch, eps: Optional[torch.Tensor] = None, train: bool = True):
         key = self._graph_key(train, self._pending)
         cap = self._graphs.get(key)
-        if cap is not None and eps is None:
+        if cap is not None and (eps is None) == (cap["eps"] is None):
             if cap["lr"] != self.lr and (train or self.defer_update):    # the learning rate is a launch argument: re-capture
-                self.capture(cap["batch"], warmup=0, train=train)
+                self.capture(cap["batch"], warmup=0, train=train, eps=cap["eps"])
                 cap = self._graphs[key]
             if batch is cap["batch"] or self._load(cap["batch"], batch):
+                if eps is not None:
+                    cap["eps"].copy_(eps, non_blocking=True)     # the captured step reads its noise from this buffer
                 cap["graph"].replay()
                 self.last_loss, self.last_terms, self.last_out = cap["results"]
                 self.replays += 1
@@ -587,6 +630,8 @@ class Trainer:
         if self.fused:
             a = self.arena
             rank, self._rank_step = self._rank_step, None
+            if rank and not torch.cuda.is_current_stream_capturing():
+                self.last_rank_step = rank                   # kept for bench.py's optimiser timing (holds the operand rows)
             lo = self._rank_hi if rank else 0                # [0, lo): gradients that exist only as operand rows
             _lib.call("cgv_optim_prepare_extra", a.g.data_ptr() + 4 * lo, a.numel - lo,
                       _lib.ptr(self._rank_sumsq) if rank else None,

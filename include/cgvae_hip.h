@@ -17,7 +17,9 @@
  *     library never synchronises the device;
  *   - return value: 0 = success; < 0 = CGV_E_* argument error; > 0 = hipError_t of a launch;
  *     cgv_last_error_string() gives a thread-local description;
- *   - re-entrant, no global mutable state (autograd calls backward from worker threads).
+ *   - re-entrant (autograd calls backward from worker threads).  The ONLY process-wide mutable state is the explicit
+ *     option table below (cgv_set_option): nothing is read from the environment, and a call's result depends on its
+ *     arguments and on that table alone.
  *
  * Notation: F = n_basis, R = n_rbf, E = directed edges, Nd / Ns = destination / source
  * node counts (equal for the atom and bead graphs; Nd = beads, Ns = atoms for the
@@ -50,6 +52,32 @@ extern "C" {
 
 int cgv_version(void);
 const char* cgv_last_error_string(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Option table: A/B switches of the launchers (no reference counterpart -- the reference has no kernels to choose
+ * between).  Every option has a fixed default under which the library behaves as documented per entry point; the
+ * alternatives exist for measurements and for the parity tests that cover the non-default kernels.
+ * Thread semantics: the table is process wide; cgv_set_option is an atomic store, every launcher reads the options it
+ * uses once (relaxed atomic load) at the top of the call.  Set options before issuing the launches they should
+ * affect; concurrent launches from other threads see either the old or the new value.  Values do not change WHAT is
+ * computed, only which kernel computes it (summation order may differ within the documented tolerance).
+ * ------------------------------------------------------------------------------------- */
+enum {
+  CGV_OPT_MSG_FWD_SPLIT = 0,   /* cgv_equi_msg_fwd: 4 waves share a receiver's segment: -1 auto (>= 16 edges/receiver), 0, 1 */
+  CGV_OPT_MSG_BWD_SPLIT = 1,   /* cgv_equi_msg_bwd: waves split a source's segment: -1 auto (>= 48 edges/source), 0, 1 */
+  CGV_OPT_MSG_FWD_KERNEL = 2,  /* cgv_equi_msg_fwd: 0 packed-fp32 VALU kernel (default), 1 MFMA filter-evaluation variant */
+  CGV_OPT_GRP_WAVES = 3,       /* cgv_equi_msg_fwd_grouped: waves per block, 4 (default) or 8 */
+  CGV_OPT_GRP_RECORDS = 4,     /* cgv_equi_msg_fwd_grouped: record stream 0 scalar loads (default), 1 through an LDS ring */
+  CGV_OPT_CSR_BUILD = 5,       /* cgv_csr_build: 0 by rows (default), 1 two-radix-pass construction */
+  CGV_OPT_PSEUDO_CHUNKS = 6,   /* cgv_pseudo_msg_bwd: cap on node chunks, 0 = built-in rule */
+  CGV_OPT_WGRAD_TILING = 7,    /* cgv_wgrad_plan: 0 balanced column tiles (default), 1 widest tile */
+  CGV_OPT_TILE_FWD_LDS_MIN = 8,/* cgv_tile_linear_fwd: minimum 64x64 tile count for the LDS-staged kernel (default 448; 1 = always) */
+  CGV_OPT_BWD_INPUT_WAVES = 9, /* cgv_tile_linear_bwd_input*: waves per block, 0 = built-in rule */
+  CGV_OPT_COUNT = 10
+};
+int cgv_set_option(int option, int value);   /* 0, or CGV_E_BADARG for an unknown option */
+int cgv_get_option(int option);              /* current value (INT32_MIN for an unknown option) */
+int cgv_reset_options(void);                 /* every option back to its default */
 
 /* n_rbf values with a compiled kernel: returns 1 if supported. */
 int cgv_rbf_supported(int n_rbf);

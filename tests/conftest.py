@@ -26,6 +26,14 @@ def load_golden(name):
         return {k: z[k] for k in z.files}
 
 
+@pytest.fixture
+def options():
+    """The explicit A/B switches (coarsegrainingvae_amd/options.py, cgv_set_option); reset to defaults afterwards."""
+    from coarsegrainingvae_amd import options as opts
+    yield opts
+    opts.reset()
+
+
 @pytest.fixture(scope="session")
 def golden():
     return load_golden

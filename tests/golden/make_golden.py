@@ -244,17 +244,52 @@ def synthetic_frames(data, n_frames, n_atoms, n_cgs, box, atom_cutoff, cg_cutoff
     return per_frame, batch
 
 
+_REF_LOSS = None
+
+
+def _reference_loss_code():
+    """The reference's OWN loss text, taken from scripts/utils.py by ``ast`` (the module itself cannot be imported:
+    sampling.py / mdtraj / ... are absent): the ``EPS`` assignment (utils.py:15), the ``KL`` function (utils.py:81-86)
+    and, out of ``loop``'s body (utils.py:117-141), the first assignment to each of loss_kl, loss_recon, edge_list,
+    xyz, gen_dist, data_dist, loss_graph, loss -- compiled from the parsed nodes, in source order, nothing retyped."""
+    global _REF_LOSS
+    if _REF_LOSS is not None:
+        return _REF_LOSS
+    import ast
+    path = os.path.join(REF, "scripts", "utils.py")
+    tree = ast.parse(open(path).read(), filename=path)
+    top = [n for n in tree.body
+           if (isinstance(n, ast.Assign) and any(getattr(t, "id", None) == "EPS" for t in n.targets))
+           or (isinstance(n, ast.FunctionDef) and n.name == "KL")]
+    assert len(top) == 2, "EPS / KL not found in scripts/utils.py"
+    loop = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "loop")
+    wanted = ("loss_kl", "loss_recon", "edge_list", "xyz", "gen_dist", "data_dist", "loss_graph", "loss")
+    first = {}
+    for node in ast.walk(loop):
+        if (isinstance(node, ast.Assign) and len(node.targets) == 1 and isinstance(node.targets[0], ast.Name)
+                and node.targets[0].id in wanted):
+            name = node.targets[0].id
+            if name not in first or node.lineno < first[name].lineno:
+                first[name] = node
+    assert set(first) == set(wanted), sorted(set(wanted) - set(first))
+    body = sorted(first.values(), key=lambda n: n.lineno)
+    defs = compile(ast.Module(body=top, type_ignores=[]), path, "exec")
+    stmts = compile(ast.Module(body=body, type_ignores=[]), path, "exec")
+    _REF_LOSS = (defs, stmts)
+    return _REF_LOSS
+
+
 def ref_loss(out, batch, beta, gamma):
-    """scripts/utils.py:81-86,117-141 (scripts/ cannot be imported: formulas re-typed in the harness)."""
-    mu, sigma, pmu, pstd, xyz, xr = out
-    kl = 0.5 * ((sigma.pow(2) / pstd.pow(2)).sum(-1) + ((mu - pmu).pow(2) / pstd).sum(-1)
-                + torch.log(pstd.pow(2)).sum(-1) - torch.log(sigma.pow(2)).sum(-1) - sigma.shape[-1]).mean()
-    recon = (xr - xyz).pow(2).mean()
-    e = batch["bond_edge_list"]
-    gen = ((xr[e[:, 0]] - xr[e[:, 1]]).pow(2).sum(-1) + 1e-6).sqrt()
-    dat = ((xyz[e[:, 0]] - xyz[e[:, 1]]).pow(2).sum(-1) + 1e-6).sqrt()
-    graph = (gen - dat).pow(2).mean()
-    return recon + kl * beta + graph * gamma, kl, recon, graph
+    """scripts/utils.py:81-86,117-141 -- executed from the reference's own source text (see _reference_loss_code)."""
+    defs, stmts = _reference_loss_code()
+    ns = {"torch": torch, "np": np}
+    exec(defs, ns)
+    assert ns["EPS"] == 1e-6
+    S_mu, S_sigma, H_prior_mu, H_prior_sigma, xyz, xyz_recon = out
+    ns.update(S_mu=S_mu, S_sigma=S_sigma, H_prior_mu=H_prior_mu, H_prior_sigma=H_prior_sigma, xyz=xyz,
+              xyz_recon=xyz_recon, batch=batch, beta=beta, gamma=gamma, device="cpu")
+    exec(stmts, ns)
+    return ns["loss"], ns["loss_kl"], ns["loss_recon"], ns["loss_graph"]
 
 
 def g2_model(cgvae, data):

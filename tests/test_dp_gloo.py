@@ -280,3 +280,54 @@ def test_operand_gather_is_rank_major_and_shape_check_catches_unequal_shards():
     for rank, recv, same, differ in res:
         assert np.array_equal(recv, want)
         assert same is True and differ is False
+
+
+def _loop_worker(rank, world, port, n_epochs, lr, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from coarsegrainingvae_amd.train import loop
+        from coarsegrainingvae_amd.trainer import GradSync
+        model = OracleModule()
+        opt = torch.optim.Adam(model.parameters(), lr=lr)
+        fr = frames(4)
+        loader = [dict(CG_collate(fr[2 * rank: 2 * rank + 2]), _graph=None)]      # "_graph" present: loop() does not plan on CPU
+        out = [loop(loader, opt, "cpu", model, BETA, e, GAMMA, train=True, tqdm_flag=False, grad_sync=GradSync(world))[0]
+               for e in range(n_epochs)]
+        q.put((rank, [p.detach().clone().numpy() for p in model.plist], out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_reference_style_loop_with_grad_sync_equals_single_rank():
+    """train.loop(..., grad_sync=GradSync(world)) -- the reference-shaped loop (scripts/utils.py:89-191) under data
+    parallelism: gradients are averaged across ranks before clip + Adam, so two ranks on two frames each reproduce one
+    rank on the four frames."""
+    from coarsegrainingvae_amd.train import loop
+    torch.set_num_threads(1)
+    ref = OracleModule()
+    opt = torch.optim.Adam(ref.parameters(), lr=1e-3)
+    loader = [dict(CG_collate(frames(4)), _graph=None)]
+    ref_losses = [loop(loader, opt, "cpu", ref, BETA, e, GAMMA, train=True, tqdm_flag=False)[0] for e in range(3)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_loop_worker, args=(r, 2, port, 3, 1e-3, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, p0, l0), (_, p1, l1) = res
+    for a, b in zip(p0, p1):
+        assert np.array_equal(a, b)                # replicas in lock-step
+    worst = 0.0
+    for a, r in zip(p0, ref.plist):
+        r = r.detach().numpy()
+        worst = max(worst, float(np.abs(a - r).max() / max(np.abs(r).max(), 1e-12)))
+    assert worst < 2e-5, worst
+    assert abs(0.5 * (l0[0] + l1[0]) - ref_losses[0]) <= 1e-5 * abs(ref_losses[0])

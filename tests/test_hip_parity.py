@@ -107,6 +107,37 @@ def test_edge_geometry_matches_oracle(R, cutoff):
     assert (want[:, :R].abs().sum(1) == 0).any() or cutoff > 4.5      # beyond-cutoff rows exercised for cutoff 3.0
 
 
+@pytest.mark.parametrize("tag", ["F8R8", "F24R10"])
+def test_distance_embed_golden_through_the_fused_kernel(tag):
+    """a7 ``DistanceEmbed`` (modules.py:175-197) standalone against the reference's own output: the filter
+    w = (rbf Wd^T + bd) * env exists only inside the fused edge kernels, so it is read back through K2 on a star graph
+    (receiver i <- one source, edge vector of length dist_i along x): with phi = 1 and v_src = (0, 1, 0),
+    ds_i = w[F:2F], dv_i[:, y] = w[0:F], dv_i[:, x] = w[2F:3F] * unit_x.  The golden's special distances (0, cutoff,
+    1.5 cutoff) are covered: d = sqrt(r_x^2 + 3e-8) reproduces them within an ulp, where the outputs are continuous
+    (limits n pi / cut at 0, zero from the cutoff on)."""
+    g = load_golden(f"g1_distance_embed_{tag}")
+    R, cutoff = int(g["R"]), float(g["cutoff"])
+    dist, want = t(g["dist"]).double(), t(g["out"])
+    E, F = dist.shape[0], want.shape[1] // 3
+    rx = (dist ** 2 - 3e-8).clamp_min(0).sqrt().float()
+    r = torch.stack([rx, torch.zeros(E), torch.zeros(E)], dim=1)
+    nbrs = torch.stack([torch.arange(E), torch.full((E,), E)], dim=1)             # receiver i <- source E
+    plan = EdgePlan.from_nbrs(nbrs.to(DEV), E + 1)
+    geom = EdgeGeometry(plan, R, cutoff, r_edges=r.to(DEV))
+    phi = torch.ones(E + 1, 3 * F, device=DEV)
+    v = torch.zeros(E + 1, F, 3, device=DEV)
+    v[E, :, 1] = 1.0
+    ds, dv = cg.ops.equi_message(phi, v, dev(g["p.block.1.weight"]), dev(g["p.block.1.bias"]), plan, geom, True)
+    assert_close(ds[:E], want[:, F:2 * F], "filter slice 1")
+    assert_close(dv[:E, :, 1], want[:, :F], "filter slice 0")
+    d32 = (rx.double() ** 2 + 3e-8).sqrt()
+    ux = (rx.double() / d32).float()
+    assert_close(dv[:E, :, 0], want[:, 2 * F:] * ux[:, None], "filter slice 2 (times unit_x)")
+    assert float(ds[E].abs().max()) == 0.0 and float(dv[E].abs().max()) == 0.0      # a receiver without edges
+    beyond = dist >= cutoff * 1.2
+    assert bool(beyond.any()) and float(ds[:E][beyond].abs().max()) == 0.0           # exactly zero past the cutoff
+
+
 def test_scatter_matches_reference_semantics():
     g = load_golden("g5_scatter")
     idx = dev(g["index"])
@@ -396,8 +427,11 @@ def test_rotation_equivariance_and_translation_invariance():
 
 # --------------------------------------------------------------------------- trainer: arena + fused clip/Adam + hipGraph
 def test_trainer_trajectory_matches_oracle_training():
-    """Five full training steps (3 eager, then the captured hipGraph replayed twice) against the
-    oracle's reference-style loop (zero_grad, backward, clip_grad_norm_(0.01), torch Adam)."""
+    """Five full training steps (3 eager, then the captured hipGraph replayed twice) against the oracle's
+    reference-style loop (zero_grad, backward, clip_grad_norm_(0.01), torch Adam), step by step:
+    loss, gradient norm and clip coefficient at every step; Adam's moments and the parameters after the first step
+    (tight: they are linear / quadratic in the clipped gradient) and after the last one."""
+    from test_full_size_parity import OracleTraining, _check_moments, _check_norm_and_clip, _check_parameters
     from coarsegrainingvae_amd.trainer import Trainer
     w = cg.data.WORKLOADS["dipeptide"]
     F, frames, lr = 64, 4, 1e-3
@@ -405,29 +439,30 @@ def test_trainer_trajectory_matches_oracle_training():
     model = cg.build_model(F, w["n_rbf"], w["atom_cutoff"], w["cg_cutoff"], 2, 2, w["n_cgs"], det=True, seed=123)
     hp = O.Hyper(F, w["n_rbf"], w["atom_cutoff"], w["cg_cutoff"], 2, 2, w["n_cgs"], det=True)
     P = _oracle_params_from(model)
+    P0 = {k: v.detach().clone() for k, v in P.items()}
     cpu_batch = {k: v.cpu() for k, v in batch.items() if torch.is_tensor(v)}
-    opt = torch.optim.Adam([p for p in P.values() if p.requires_grad], lr=lr)
-    ref_losses = [float(O.train_step(cpu_batch, P, hp, opt, w["beta"], w["gamma"])[0]) for _ in range(5)]
-
+    oracle = OracleTraining(cpu_batch, P, hp, w, lr)
     model = model.to(DEV)
     tr = Trainer(model, lr=lr, beta=w["beta"], gamma=w["gamma"])
-    losses = [float(tr.step(batch)) for _ in range(3)]
-    tr.capture(batch, warmup=0)                                # capture itself runs no extra optimiser step...
-    # ...but capturing executes nothing on the device: the next two replays are steps 4 and 5
-    for _ in range(2):
+    ref_losses, losses = [], []
+    for k in range(5):
+        if k == 3:
+            tr.capture(batch, warmup=0)        # capturing executes nothing on the device: the replays are steps 4 and 5
+        ref = oracle.step(None)
         tr.step(batch)
+        ref_losses.append(float(ref["loss"]))
         losses.append(float(tr.last_loss))
-    assert int(tr.state[0].item()) == 5 and tr.skipped_steps() == 0
-    for a, b in zip(losses, ref_losses):
-        assert abs(a - b) <= 2e-3 * abs(b), (losses, ref_losses)
+        # the loss of step k sees parameters that took k Adam steps; where |clipped g| ~ 1e-8 (Adam's eps) an update
+        # is ill-conditioned (test_full_size_parity._check_parameters), so the bound grows with k: 1e-4 (north_star)
+        # on the first step, 1e-4 * (1 + k) afterwards
+        assert abs(losses[-1] - ref_losses[-1]) <= 1e-4 * (1 + k) * abs(ref_losses[-1]), (k, losses, ref_losses)
+        _check_norm_and_clip(tr, ref, f"step {k + 1}")
+        if k == 0:
+            _check_moments(tr, model, oracle, "step 1")
+            _check_parameters(tr, model, oracle, P0, 1, lr, "step 1")
+    assert tr.replays == 2 and int(tr.state[0].item()) == 5 and tr.skipped_steps() == 0
     assert ref_losses[-1] < ref_losses[0]                      # it actually trains
-    # parameters after 5 steps: Adam moves each weight by at most ~lr per step
-    worst = 0.0
-    for name, p in model.named_parameters():
-        ref = P[name]
-        if ref.grad is not None:
-            worst = max(worst, float((p.detach().cpu() - ref.detach()).abs().max()))
-    assert worst <= 2.5 * lr * 5, worst
+    _check_parameters(tr, model, oracle, P0, 5, lr, "step 5")
 
 
 def test_direct_gradient_writes_equal_autograd_accumulation():
@@ -744,9 +779,9 @@ def test_batched_radius_graph_dataset_path():
 
 @pytest.mark.parametrize("F,R", [(7, 8), (24, 10), (129, 10), (600, 10), (66, 16), (34, 20), (20, 4)])
 @pytest.mark.parametrize("with_gv", [True, False])
-def test_equi_message_matrix_core_forward(F, R, with_gv, monkeypatch):
-    """The MFMA variant of the fused forward, forced on (CGV_FWD_KERNEL is an A/B switch of the launcher)."""
-    monkeypatch.setenv("CGV_FWD_KERNEL", "mfma")
+def test_equi_message_matrix_core_forward(F, R, with_gv, options):
+    """The MFMA variant of the fused forward, forced on (CGV_OPT_MSG_FWD_KERNEL is an A/B switch of the launcher)."""
+    options.set("msg_fwd_kernel", 1)
     gen = torch.Generator().manual_seed(F * 3 + R)
     n = 40
     xyz = torch.rand(n, 3, generator=gen) * 4.0
@@ -965,12 +1000,12 @@ def test_shared_source_forward_matches_fp64_and_plain_kernel(F, R, n, box, cut, 
         assert_close(x.grad, y.grad, "grad " + name, 1e-6)
 
 
-def test_batch_graph_uses_receiver_groups_on_dense_atom_graphs(monkeypatch):
+def test_batch_graph_uses_receiver_groups_on_dense_atom_graphs(options):
     batch = cg.synthetic_batch("chignolin", n_frames=1, seed=3, device=DEV)
     g = batch["_graph"]
     assert g.atom.group_rb == 2 and g.cg.group_rb == 0 and g.a2b.group_rb == 0
     assert g.geometry("atom", 10, 25.0).geom_g is not None
-    monkeypatch.setenv("CGV_FWD_GROUP", "0")
+    options.set("fwd_group", 0)
     g0 = cg.synthetic_batch("chignolin", n_frames=1, seed=3, device=DEV)["_graph"]
     assert g0.atom.group_rb == 0 and g0.geometry("atom", 10, 25.0).geom_g is None
 
@@ -1141,7 +1176,7 @@ def test_shared_source_forward_at_full_size_properties():
 
 
 @pytest.mark.parametrize("n,E", [(37, 900), (5, 0), (3, 5000), (400, 300), (166, 21000)])
-def test_csr_by_rows_equals_the_radix_construction(n, E, monkeypatch):
+def test_csr_by_rows_equals_the_radix_construction(n, E, options):
     """K7: the few-launch by-rows construction and the two-radix-pass one give identical arrays (dense rows beyond the
     LDS key budget, empty rows, no edges, mapping plans)."""
     gen = torch.Generator().manual_seed(n * 7 + E)
@@ -1149,7 +1184,7 @@ def test_csr_by_rows_equals_the_radix_construction(n, E, monkeypatch):
     mapping = torch.randint(0, max(n // 3, 1), (n,), generator=gen).to(DEV)
     fields = ("rowptr_d", "eid_d", "dst_d", "src_d", "rowptr_s", "eid_s", "dst_s", "src_s")
     rows = (EdgePlan.from_nbrs(nbrs, n), EdgePlan.from_mapping(mapping, max(n // 3, 1)))
-    monkeypatch.setenv("CGV_CSR_BUILD", "radix")
+    options.set("csr_build", 1)
     radix = (EdgePlan.from_nbrs(nbrs, n), EdgePlan.from_mapping(mapping, max(n // 3, 1)))
     for a, b in zip(rows, radix):
         for f in fields:

@@ -142,3 +142,22 @@ def test_random_rotation_matrices_are_proper_rotations_about_the_origin():
     assert float((ang - ang.round()).abs().max()) < 1e-2
     assert torch.equal(random_rotation_matrices(5, torch.Generator().manual_seed(3)),
                        random_rotation_matrices(5, torch.Generator().manual_seed(3)))
+
+
+def test_option_table_is_explicit_and_resets():
+    """The launchers' A/B switches are an explicit table behind cgv_set_option (no environment reads in the ABI)."""
+    from coarsegrainingvae_amd import _lib, options
+    lib = _lib.load()
+    options.reset()
+    assert options.get("tile_fwd_lds_min") == 448 and options.get("msg_fwd_kernel") == 0 and options.get("grp_waves") == 4
+    options.set("msg_fwd_kernel", 1)
+    options.set("fwd_group", 4)
+    assert lib.cgv_get_option(_lib.OPTIONS["msg_fwd_kernel"]) == 1 and options.get("fwd_group") == 4
+    assert lib.cgv_set_option(999, 1) < 0 and b"unknown option" in lib.cgv_last_error_string()
+    with pytest.raises(KeyError):
+        options.set("no_such_switch", 1)
+    options.reset()
+    assert options.get("msg_fwd_kernel") == 0 and options.get("fwd_group") == -1
+    import subprocess
+    src = subprocess.run(["grep", "-rl", "getenv", os.path.join(os.path.dirname(_lib.LIB_PATH), "csrc")], capture_output=True, text=True)
+    assert src.stdout.strip() == "", "the C ABI must not read the environment: " + src.stdout

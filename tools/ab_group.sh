@@ -1,10 +1,10 @@
 #!/bin/bash
-# A/B of the shared-source forward: CGV_FWD_GROUP = 0 / 2 / 4 receivers per group, CGV_GRP_RECORDS = scalar / lds
+# A/B of the shared-source forward: fwd_group = 0 / 2 / 4 receivers per group, grp_records = 0 scalar / 1 lds
 for w in ${WORKLOADS:-chignolin dipeptide protein2000}; do
-  CGV_FWD_GROUP=0 python tools/kbench.py $w 2>/dev/null | head -2 | tr '\n' ' '; echo
+  python tools/kbench.py $w --option fwd_group=0 2>/dev/null | head -2 | tr '\n' ' '; echo
   for g in 2 4; do
-    for rec in scalar lds; do
-      echo -n "[group=$g records=$rec] "; CGV_GRP_RECORDS=$rec CGV_FWD_GROUP=$g python tools/kbench.py $w 2>/dev/null | sed -n 2,2p
+    for rec in 0 1; do
+      echo -n "[group=$g records=$rec] "; python tools/kbench.py $w --option fwd_group=$g --option grp_records=$rec 2>/dev/null | sed -n 2,2p
     done
   done
 done

@@ -3,7 +3,8 @@
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from coarsegrainingvae_amd import _lib
+from coarsegrainingvae_amd import _lib, options
+sys.argv[1:] = options.pop_cli(sys.argv[1:])           # --option name=value (explicit A/B switches)
 
 def timeit(fn, reps=100):
     for _ in range(10): fn()

@@ -1,3 +1,3 @@
 #!/bin/bash
 # usage: tools/fwd_lds_ab.sh  -> forward tile kernel per shape with the LDS-staged kernel off (threshold out of reach) and on
-for v in 1000000 1; do echo "CGV_TILE_FWD_LDS_MIN=$v"; CGV_TILE_FWD_LDS_MIN=$v python tools/fwd_bench.py 96 332 704 2000; done
+for v in 1000000 1; do echo "tile_fwd_lds_min=$v"; python tools/fwd_bench.py 96 332 704 2000 --option tile_fwd_lds_min=$v; done

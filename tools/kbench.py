@@ -25,6 +25,8 @@ def timeit(fn, reps=50, warm=5):
 
 
 def main():
+    from coarsegrainingvae_amd import options
+    sys.argv[1:] = options.pop_cli(sys.argv[1:])           # --option name=value (explicit A/B switches)
     workload = sys.argv[1] if len(sys.argv) > 1 else "chignolin"
     F = int(sys.argv[2]) if len(sys.argv) > 2 else 600
     w = cg.data.WORKLOADS[workload]

@@ -25,7 +25,8 @@ for rows, N, K, count in problems:
         items.append((gy, x, z, 1, gW, gb, False))
         out_bytes += 4 * N * K
 for variant in os.environ.get("VARIANTS", "valu,mfma").split(","):
-    q.kernel = variant
+    from coarsegrainingvae_amd import options
+    options.set("wgrad_kernel", 1 if variant == "mfma" else 0)
     for _ in range(3):
         q.launch(items)
     torch.cuda.synchronize()
