@@ -69,6 +69,12 @@ PROTOTYPES = {
     "cgv_skinny_bwd_input_supported": (_i, [_i, _i, _i]),
     "cgv_skinny_bwd_input_workspace_bytes": (_sz, [_i, _i, _i]),
     "cgv_skinny_linear_bwd_input": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
+    "cgv_skinny_bwd_input_plan": (_i, [_i, _i, _i, _p, _p]),
+    "cgv_skinny_linear_bwd_input_slices": (_i, [_p, _p, _i, C.c_int64, _p, _p, _p, _p, _sz, _i, _i, _i, _i, _p]),
+    "cgv_slice_sum": (_i, [_p, _p, _i, C.c_int64, _p, C.c_int64, _p]),
+    "cgv_update_vec_from_rows_slices": (_i, [_p, _i, C.c_int64, _p, _p, _i, _i, _p]),
+    "cgv_update_norm_stack_bwd_slices": (_i, [_p, _i, C.c_int64, _p, _p, _p, _p, _i, C.c_int64, _p, _p, _i, _i, _i, _i, _p]),
+    "cgv_update_gate_bwd_slices": (_i, [_p, _p, _p, _p, _p, _i, C.c_int64, _p, _p, _p, _p, _i, _i, _i, _p]),
     "cgv_dense_grad_prepare": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "cgv_tile_supported": (_i, [_i, _i, _i]),
     "cgv_tile_linear_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),

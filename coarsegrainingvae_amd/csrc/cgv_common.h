@@ -98,6 +98,30 @@ __device__ __forceinline__ float act_bwd(float z, int act) {
 }
 
 
+// ------------------------------------------------------------------ slice sums
+// A gradient operand handed over as "base + row-slice partial sums": value(i) = base[i] + sum_s slices[s * stride + i],
+// s ascending (deterministic).  This is how the split backward-input products (skinny_gemm.hip: the row slices of one
+// product each leave a partial [M, K] matrix) reach their consumers without a reduction launch in between: the consumer
+// adds the slices while it loads its operand.  base or slices may be NULL (n = 0 when slices is NULL).
+struct SliceSum {
+  const float* base;
+  const float* slices;
+  int n;
+  long long stride;       // floats between consecutive slices
+};
+__device__ __forceinline__ float slice_sum_at(const SliceSum& ss, size_t i) {
+  float acc = ss.base ? ss.base[i] : 0.f;
+  constexpr int SB = 8;                                     // slices whose loads are in flight together
+  for (int s0 = 0; s0 < ss.n; s0 += SB) {
+    float v[SB];
+#pragma unroll
+    for (int u = 0; u < SB; ++u) v[u] = ss.slices[(size_t)min(s0 + u, ss.n - 1) * ss.stride + i];
+#pragma unroll
+    for (int u = 0; u < SB; ++u) acc += (s0 + u < ss.n) ? v[u] : 0.f;
+  }
+  return acc;
+}
+
 // ------------------------------------------------------------------ fused optimiser (optim.hip, skinny_gemm.hip)
 // state[] layout (device floats) written by optim_finalize, read by every parameter pass
 enum { ST_STEP = 0, ST_NORM = 1, ST_CLIP = 2, ST_BC1 = 3, ST_BC2SQRT = 4, ST_SKIP = 5, ST_NSKIPPED = 6 };

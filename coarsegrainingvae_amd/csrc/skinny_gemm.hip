@@ -137,11 +137,14 @@ constexpr int BI_COLS = 64;       // weight columns per block
 constexpr int BI_ROUND = 64;      // weight rows per staging round (4 waves x 4 steps x 4 rows)
 constexpr int BI_LD = 68;         // LDS row stride of the g stage
 
-template <int MB>
+// LAZY: gy arrives as row-slice partial sums of the product that produced it (SliceSum: no reduction launch in
+// between); the kt = 0 blocks also write the summed g[:, their rows] to g_dense (the weight-gradient launch reads it).
+template <int MB, bool LAZY = false>
 __global__ __launch_bounds__(256) void skinny_bwd_input_k(const float* __restrict__ gy, const float* __restrict__ z,
                                                           const float* __restrict__ W, float* __restrict__ gx,
                                                           float* __restrict__ part, int M, int N, int K, int act, int KT,
-                                                          int NS, int rpb) {
+                                                          int NS, int rpb, SliceSum gsum = SliceSum{nullptr, nullptr, 0, 0},
+                                                          float* __restrict__ g_dense = nullptr) {
   // g stage [16 MB rows][BI_LD], then the wave reduction: up to 4 row blocks all three partner waves deposit at once,
   // beyond that (MB 5..8: 65-128 rows) one wave at a time through a third of the space
   constexpr int SM_RED = (MB <= 4 ? 3 : 1) * MB * 16 * 64, SM_G = MB * 16 * BI_LD;
@@ -167,12 +170,48 @@ __global__ __launch_bounds__(256) void skinny_bwd_input_k(const float* __restric
       wv[s] = ldg4_or_zero(W + (size_t)(ok ? row : 0) * K + (ok ? kcol : 0), ok);
     }
     float g[MB * 4], zz[MB * 4];
+    if constexpr (LAZY) {
+      constexpr int SC = MB == 1 ? 8 : (MB == 2 ? 4 : 2);                  // slices in flight per element
 #pragma unroll
-    for (int t = 0; t < MB * 4; ++t) {                                     // g[:, nb .. nb+63], row m = 4t + wave
-      const int m = 4 * t + wave, n = nb + lane;
-      const bool ok = m < M && n < n_end;
-      g[t] = ok ? gy[(size_t)m * N + n] : 0.f;
-      zz[t] = (ok && act) ? z[(size_t)m * N + n] : 0.f;
+      for (int t = 0; t < MB * 4; ++t) {
+        const int m = 4 * t + wave, n = nb + lane;
+        const bool ok = m < M && n < n_end;
+        g[t] = (ok && gsum.base) ? gsum.base[(size_t)m * N + n] : 0.f;
+        zz[t] = (ok && act) ? z[(size_t)m * N + n] : 0.f;
+      }
+      for (int s0 = 0; s0 < gsum.n; s0 += SC) {
+        float v[MB * 4][SC];
+#pragma unroll
+        for (int t = 0; t < MB * 4; ++t) {
+          const int m = min(4 * t + wave, M - 1), n = min(nb + lane, n_end - 1);      // clamped: always-valid addresses
+#pragma unroll
+          for (int u = 0; u < SC; ++u) v[t][u] = gsum.slices[(size_t)min(s0 + u, gsum.n - 1) * gsum.stride + (size_t)m * N + n];
+        }
+#pragma unroll
+        for (int t = 0; t < MB * 4; ++t)
+#pragma unroll
+          for (int u = 0; u < SC; ++u) g[t] += (s0 + u < gsum.n) ? v[t][u] : 0.f;
+      }
+      if (g_dense && kt == 0) {
+#pragma unroll
+        for (int t = 0; t < MB * 4; ++t) {
+          const int m = 4 * t + wave, n = nb + lane;
+          if (m < M && n < n_end) g_dense[(size_t)m * N + n] = g[t];
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < MB * 4; ++t) {
+        const int m = 4 * t + wave, n = nb + lane;
+        if (!(m < M && n < n_end)) g[t] = 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < MB * 4; ++t) {                                   // g[:, nb .. nb+63], row m = 4t + wave
+        const int m = 4 * t + wave, n = nb + lane;
+        const bool ok = m < M && n < n_end;
+        g[t] = ok ? gy[(size_t)m * N + n] : 0.f;
+        zz[t] = (ok && act) ? z[(size_t)m * N + n] : 0.f;
+      }
     }
     if (nb != n_beg) __syncthreads();                                      // readers of the previous round
 #pragma unroll
@@ -242,7 +281,7 @@ __global__ __launch_bounds__(256) void skinny_bwd_input_k(const float* __restric
 #pragma unroll
       for (int r = 0; r < 4; ++r) tot[mb][r] = make_float4(acc[mb][0][r], acc[mb][1][r], acc[mb][2][r], acc[mb][3][r]);
   }
-  if (NS > 1) {                     // row slices meet in skinny_bwd_input_reduce_k (next launch on the stream)
+  if (NS > 1 || (part && !gx)) {    // row slices meet in the next launch on the stream (reduce kernel or a SliceSum consumer)
     float* mine = part + ((size_t)ns * M) * K;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
@@ -266,10 +305,12 @@ __global__ __launch_bounds__(256) void skinny_bwd_input_k(const float* __restric
 // gx[i] = sum_p part[p][i] (i over M*K/4 float4s), p ascending: deterministic.  4 lanes share one output
 // float4 and take every 4th slice, then combine by two xor-shuffles.
 __global__ __launch_bounds__(256) void skinny_bwd_input_reduce_k(const float* __restrict__ part, float* __restrict__ gx,
-                                                                 int n4, int NS) {
+                                                                 int n4, int NS, const float* __restrict__ base = nullptr,
+                                                                 long long slice_stride4 = 0) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   const int i = t >> 2, sub = t & 3;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4 && base && sub == 0) acc = reinterpret_cast<const float4*>(base)[i];
   if (i < n4) {
     const float4* p4 = reinterpret_cast<const float4*>(part) + i;
     // a lane's 5 - 8 slices are loaded together (slice index clamped, the surplus zeroed afterwards): the runtime-bounded
@@ -278,7 +319,7 @@ __global__ __launch_bounds__(256) void skinny_bwd_input_reduce_k(const float* __
     for (int p0 = sub; p0 < NS; p0 += 4 * RB) {
       float4 v[RB];
 #pragma unroll
-      for (int u = 0; u < RB; ++u) v[u] = p4[(size_t)min(p0 + 4 * u, NS - 1) * n4];
+      for (int u = 0; u < RB; ++u) v[u] = p4[(size_t)min(p0 + 4 * u, NS - 1) * (slice_stride4 ? (size_t)slice_stride4 : (size_t)n4)];
 #pragma unroll
       for (int u = 0; u < RB; ++u) {
         const bool ok = p0 + 4 * u < NS;
@@ -1038,6 +1079,62 @@ int cgv_skinny_linear_bwd_input(const float* gy, const float* z, const float* W,
     default: cgv::launch_bwd_input<8>(st, gy, z, W, gx, part, M, N, K, act, KT, NS, rpb); break;
   }
   return cgv::check_launch("cgv_skinny_linear_bwd_input");
+}
+
+/* Row slicing of the split product for this shape: n_slices partial matrices of slice_floats = M * K floats each. */
+int cgv_skinny_bwd_input_plan(int M, int N, int K, int* n_slices, int64_t* slice_floats) {
+  CGV_REQUIRE(n_slices && slice_floats, "null pointer");
+  CGV_REQUIRE(cgv_skinny_bwd_input_supported(M, N, K) && M <= 64, "unsupported shape (need M <= 64, N % 4 == 0, K % 4 == 0)");
+  int KT, NS, rpb;
+  cgv::bwd_input_plan(N, K, true, &KT, &NS, &rpb);
+  *n_slices = NS;
+  *slice_floats = (int64_t)M * K;
+  return 0;
+}
+
+int cgv_skinny_linear_bwd_input_slices(const float* gy_base, const float* gy_slices, int gy_n_slices, int64_t gy_slice_stride,
+                                       float* g_dense, const float* z, const float* W, float* part, size_t part_bytes, int M,
+                                       int N, int K, int act, void* stream) {
+  CGV_REQUIRE((gy_base || gy_slices) && W && part, "null pointer");
+  CGV_REQUIRE(gy_n_slices >= 0 && (gy_n_slices == 0 || (gy_slices && gy_slice_stride >= (int64_t)M * N)), "bad slices");
+  CGV_REQUIRE(act == 0 || (act >= 1 && act <= cgv::CGV_ACT_MAX && z), "act != 0 needs the saved pre-activation z");
+  CGV_REQUIRE(cgv_skinny_bwd_input_supported(M, N, K) && M <= 64, "unsupported shape (need M <= 64, N % 4 == 0, K % 4 == 0)");
+  CGV_REQUIRE(((((uintptr_t)part) | ((uintptr_t)W)) & 15) == 0, "part, W must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  int KT, NS, rpb;
+  cgv::bwd_input_plan(N, K, true, &KT, &NS, &rpb);
+  CGV_REQUIRE(part_bytes >= sizeof(float) * (size_t)NS * M * K, "partial buffer too small");
+  const cgv::SliceSum gs{gy_base, gy_slices, gy_slices ? gy_n_slices : 0, gy_slice_stride};
+  const bool lazy = gy_n_slices > 0 || g_dense != nullptr;
+#define CGV_BI_SLICES(MBV)                                                                                          \
+  if (lazy)                                                                                                         \
+    hipLaunchKernelGGL((cgv::skinny_bwd_input_k<MBV, true>), dim3(KT * NS), dim3(256), 0, st, gy_base, z, W, (float*)nullptr, \
+                       part, M, N, K, act, KT, NS, rpb, gs, g_dense);                                               \
+  else                                                                                                              \
+    hipLaunchKernelGGL((cgv::skinny_bwd_input_k<MBV, false>), dim3(KT * NS), dim3(256), 0, st, gy_base, z, W,       \
+                       (float*)nullptr, part, M, N, K, act, KT, NS, rpb, gs, (float*)nullptr)
+  switch ((M + 15) / 16) {
+    case 1: CGV_BI_SLICES(1); break;
+    case 2: CGV_BI_SLICES(2); break;
+    case 3: CGV_BI_SLICES(3); break;
+    default: CGV_BI_SLICES(4); break;
+  }
+#undef CGV_BI_SLICES
+  return cgv::check_launch("cgv_skinny_linear_bwd_input_slices");
+}
+
+/* out[i] = base[i] + sum_s slices[s * stride + i] over n_floats (multiple of 4) floats: the reduction launch for a
+ * slice sum whose consumer is not one of the kernels that add the slices themselves. */
+int cgv_slice_sum(const float* base, const float* slices, int n_slices, int64_t slice_stride, float* out, int64_t n_floats,
+                  void* stream) {
+  CGV_REQUIRE(slices && out && n_slices >= 1 && n_floats >= 0, "bad argument");
+  CGV_REQUIRE((n_floats % 4) == 0 && (slice_stride % 4) == 0 && slice_stride >= n_floats, "need multiples of 4 floats");
+  CGV_REQUIRE(((((uintptr_t)base) | ((uintptr_t)slices) | ((uintptr_t)out)) & 15) == 0, "16-byte alignment");
+  if (n_floats == 0) return 0;
+  const int n4 = (int)(n_floats / 4);
+  hipLaunchKernelGGL(cgv::skinny_bwd_input_reduce_k, dim3((4 * n4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, slices, out,
+                     n4, n_slices, base, (long long)(slice_stride / 4));
+  return cgv::check_launch("cgv_slice_sum");
 }
 
 int cgv_dense_grad_prepare(const float* gy, const float* z, float* g_out, float* gb, int M, int N, int act, int accumulate,

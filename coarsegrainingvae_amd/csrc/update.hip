@@ -24,13 +24,13 @@ __global__ __launch_bounds__(256) void update_rows_from_vec(const float* __restr
 
 // rows [N,3,F] (+ res [N,F,3]) -> vec [N,F,3]: the transposed copy of the backward, with the
 // pass-through gradient of the fused residual added in the same launch
-__global__ __launch_bounds__(256) void update_vec_from_rows(const float* __restrict__ rows, const float* __restrict__ res,
+__global__ __launch_bounds__(256) void update_vec_from_rows(SliceSum rows, const float* __restrict__ res,
                                                             float* __restrict__ vec, int N, int F) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= N * F) return;
   const int n = idx / F, f = idx - n * F;
-  const float* r = rows + (size_t)n * 3 * F + f;
-  float x = r[0], y = r[F], z = r[2 * F];
+  const size_t r = (size_t)n * 3 * F + f;
+  float x = slice_sum_at(rows, r), y = slice_sum_at(rows, r + F), z = slice_sum_at(rows, r + 2 * F);
   if (res) { const f3 t = ld3(res + (size_t)idx * 3); x += t.x; y += t.y; z += t.z; }
   st3(vec + (size_t)idx * 3, x, y, z);
 }
@@ -48,19 +48,19 @@ __global__ __launch_bounds__(256) void update_norm_stack_fwd(const float* __rest
 }
 
 // g_s = gstack[:, :F] (+ g_res);  gVv (+)= gstack[:, F:] * Vv / vnorm
-__global__ __launch_bounds__(256) void update_norm_stack_bwd(const float* __restrict__ gstack,
+__global__ __launch_bounds__(256) void update_norm_stack_bwd(SliceSum gstack,
                                                              const float* __restrict__ Vv,
                                                              const float* __restrict__ stack,
-                                                             const float* __restrict__ g_res, float* __restrict__ g_s,
+                                                             SliceSum g_res, float* __restrict__ g_s,
                                                              float* __restrict__ gVv, int N, int F, int ld,
                                                              int accumulate) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= N * F) return;
   const int n = idx / F, f = idx - n * F;
-  float gs = gstack[(size_t)n * 2 * F + f];
-  if (g_res) gs += g_res[idx];
+  float gs = slice_sum_at(gstack, (size_t)n * 2 * F + f);
+  gs += slice_sum_at(g_res, idx);                            // 0 when no residual gradient is given
   g_s[idx] = gs;
-  const float t = gstack[(size_t)n * 2 * F + F + f] / stack[(size_t)n * 2 * F + F + f];
+  const float t = slice_sum_at(gstack, (size_t)n * 2 * F + F + f) / stack[(size_t)n * 2 * F + F + f];
   const float* vv = Vv + (size_t)n * 3 * ld + f;
   float* o = gVv + (size_t)n * 3 * ld + f;
   if (accumulate) {
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void update_gate_fwd(const float* __restrict__
 }
 
 __global__ __launch_bounds__(256) void update_gate_bwd(const float* __restrict__ U, const float* __restrict__ Vv,
-                                                       const float* __restrict__ a, const float* __restrict__ g_ds,
+                                                       const float* __restrict__ a, SliceSum g_ds,
                                                        const float* __restrict__ g_dv, float* __restrict__ gU,
                                                        float* __restrict__ gVv, float* __restrict__ ga, int N, int F,
                                                        int ld) {
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void update_gate_bwd(const float* __restrict__
   const float ux = U[b], uy = U[b + ld], uz = U[b + 2 * ld];
   const float vx = Vv[b], vy = Vv[b + ld], vz = Vv[b + 2 * ld];
   const float a_vv = a[c], a_sv = a[c + F];
-  const float gs = g_ds ? g_ds[idx] : 0.f;
+  const float gs = slice_sum_at(g_ds, idx);                  // 0 when neither base nor slices are given
   float gx = 0.f, gy = 0.f, gz = 0.f;
   if (g_dv) { const f3 t = ld3(g_dv + (size_t)idx * 3); gx = t.x; gy = t.y; gz = t.z; }
   const float inner = ux * vx + uy * vy + uz * vz;
@@ -138,7 +138,13 @@ int cgv_update_rows_from_vec(const float* v, float* rows, int n_nodes, int n_fea
 
 int cgv_update_vec_from_rows(const float* rows, const float* res, float* vec, int n_nodes, int n_feat, void* stream) {
   CGV_REQUIRE(rows && vec, "null pointer");
-  CGV_EW_LAUNCH(cgv::update_vec_from_rows, rows, res, vec, n_nodes, n_feat);
+  CGV_EW_LAUNCH(cgv::update_vec_from_rows, (cgv::SliceSum{rows, nullptr, 0, 0}), res, vec, n_nodes, n_feat);
+}
+
+int cgv_update_vec_from_rows_slices(const float* rows_slices, int n_slices, int64_t slice_stride, const float* res, float* vec,
+                                    int n_nodes, int n_feat, void* stream) {
+  CGV_REQUIRE(rows_slices && vec && n_slices >= 1 && slice_stride >= (int64_t)3 * n_nodes * n_feat, "bad argument");
+  CGV_EW_LAUNCH(cgv::update_vec_from_rows, (cgv::SliceSum{nullptr, rows_slices, n_slices, slice_stride}), res, vec, n_nodes, n_feat);
 }
 
 int cgv_update_norm_stack_fwd(const float* s, const float* Vv, float* stack, int n_nodes, int n_feat, int ld, void* stream) {
@@ -149,7 +155,21 @@ int cgv_update_norm_stack_fwd(const float* s, const float* Vv, float* stack, int
 int cgv_update_norm_stack_bwd(const float* gstack, const float* Vv, const float* stack, const float* g_res, float* g_s,
                               float* gVv, int n_nodes, int n_feat, int ld, int accumulate, void* stream) {
   CGV_REQUIRE(gstack && Vv && stack && g_s && gVv && ld >= n_feat, "bad argument");
-  CGV_EW_LAUNCH(cgv::update_norm_stack_bwd, gstack, Vv, stack, g_res, g_s, gVv, n_nodes, n_feat, ld, accumulate);
+  CGV_EW_LAUNCH(cgv::update_norm_stack_bwd, (cgv::SliceSum{gstack, nullptr, 0, 0}), Vv, stack, (cgv::SliceSum{g_res, nullptr, 0, 0}),
+                g_s, gVv, n_nodes, n_feat, ld, accumulate);
+}
+
+int cgv_update_norm_stack_bwd_slices(const float* gstack_slices, int n_slices, int64_t slice_stride, const float* Vv,
+                                     const float* stack, const float* g_res_base, const float* g_res_slices, int n_res_slices,
+                                     int64_t res_slice_stride, float* g_s, float* gVv, int n_nodes, int n_feat, int ld,
+                                     int accumulate, void* stream) {
+  CGV_REQUIRE(gstack_slices && Vv && stack && g_s && gVv && ld >= n_feat, "bad argument");
+  CGV_REQUIRE(n_slices >= 1 && slice_stride >= (int64_t)2 * n_nodes * n_feat, "bad slices");
+  CGV_REQUIRE(n_res_slices >= 0 && (n_res_slices == 0 || (g_res_slices && res_slice_stride >= (int64_t)n_nodes * n_feat)),
+              "bad residual slices");
+  CGV_EW_LAUNCH(cgv::update_norm_stack_bwd, (cgv::SliceSum{nullptr, gstack_slices, n_slices, slice_stride}), Vv, stack,
+                (cgv::SliceSum{g_res_base, g_res_slices, g_res_slices ? n_res_slices : 0, res_slice_stride}), g_s, gVv, n_nodes,
+                n_feat, ld, accumulate);
 }
 
 int cgv_update_gate_fwd(const float* U, const float* Vv, const float* a, const float* s_res, const float* v_res, float* ds,
@@ -162,7 +182,16 @@ int cgv_update_gate_fwd(const float* U, const float* Vv, const float* a, const f
 int cgv_update_gate_bwd(const float* U, const float* Vv, const float* a, const float* g_ds, const float* g_dv,
                         float* gU, float* gVv, float* ga, int n_nodes, int n_feat, int ld, void* stream) {
   CGV_REQUIRE(U && Vv && a && gU && gVv && ga && ld >= n_feat, "bad argument");
-  CGV_EW_LAUNCH(cgv::update_gate_bwd, U, Vv, a, g_ds, g_dv, gU, gVv, ga, n_nodes, n_feat, ld);
+  CGV_EW_LAUNCH(cgv::update_gate_bwd, U, Vv, a, (cgv::SliceSum{g_ds, nullptr, 0, 0}), g_dv, gU, gVv, ga, n_nodes, n_feat, ld);
+}
+
+int cgv_update_gate_bwd_slices(const float* U, const float* Vv, const float* a, const float* g_ds_base,
+                               const float* g_ds_slices, int n_slices, int64_t slice_stride, const float* g_dv, float* gU,
+                               float* gVv, float* ga, int n_nodes, int n_feat, int ld, void* stream) {
+  CGV_REQUIRE(U && Vv && a && gU && gVv && ga && ld >= n_feat, "bad argument");
+  CGV_REQUIRE(n_slices >= 0 && (n_slices == 0 || (g_ds_slices && slice_stride >= (int64_t)n_nodes * n_feat)), "bad slices");
+  CGV_EW_LAUNCH(cgv::update_gate_bwd, U, Vv, a, (cgv::SliceSum{g_ds_base, g_ds_slices, n_slices, slice_stride}), g_dv, gU, gVv, ga,
+                n_nodes, n_feat, ld);
 }
 
 }  // extern "C"

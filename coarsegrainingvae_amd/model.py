@@ -95,6 +95,7 @@ class EquivariantPsuedoDecoder(nn.Module):
         self.breaksym = breaksym
         self.n_atom_basis = n_atom_basis
         self.n_rbf, self.cutoff = n_rbf, cutoff
+        self.fused_loop = True          # decoder_fused: one autograd node for the loop when shapes / parameters allow
 
     def forward(self, cg_xyz, CG_nbr_list, mapping, S, graph: Optional[BatchGraph] = None, layer_hooks=None):
         """``layer_hooks``: {layer index L: callable} -- called from the autograd thread when the backward of
@@ -113,6 +114,11 @@ class EquivariantPsuedoDecoder(nn.Module):
         V = _constant((n, F, 3), 0.0, S.device)
         Sbar = _constant((n, F), 1.0 if self.breaksym else 0.0, S.device)
         Vbar = V
+        if self.fused_loop and geom is not None and S.requires_grad:
+            from . import decoder_fused
+            if decoder_fused.usable(self, S, plan, geom):
+                # the whole loop as one autograd node (slice-sum backward, no reduction / accumulation launches)
+                return decoder_fused.pseudo_decoder(self, S, Sbar, V, plan, geom, layer_hooks)
         for layer, (message_block, update_block) in enumerate(zip(self.message_blocks, self.update_blocks)):
             if layer_hooks and layer in layer_hooks and S.requires_grad:
                 S = S.view_as(S)                              # private node: its hook sees the total gradient of S

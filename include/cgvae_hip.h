@@ -281,6 +281,17 @@ int cgv_update_gate_fwd(const float* U, const float* Vv, const float* a, const f
                         int n_nodes, int n_feat, int ld, void* stream);
 int cgv_update_gate_bwd(const float* U, const float* Vv, const float* a, const float* g_ds, const float* g_dv,
                         float* gU, float* gVv, float* ga, int n_nodes, int n_feat, int ld, void* stream);
+/* The same kernels with a slice-sum operand (see cgv_skinny_linear_bwd_input_slices): rows / gstack / g_ds arrive as
+ * row-slice partials of the backward-input product that produced them (g_ds: base + slices). */
+int cgv_update_vec_from_rows_slices(const float* rows_slices, int n_slices, int64_t slice_stride, const float* res, float* vec,
+                                    int n_nodes, int n_feat, void* stream);
+int cgv_update_norm_stack_bwd_slices(const float* gstack_slices, int n_slices, int64_t slice_stride, const float* Vv,
+                                     const float* stack, const float* g_res_base /*or NULL*/, const float* g_res_slices /*or NULL*/,
+                                     int n_res_slices, int64_t res_slice_stride, float* g_s, float* gVv, int n_nodes, int n_feat,
+                                     int ld, int accumulate, void* stream);
+int cgv_update_gate_bwd_slices(const float* U, const float* Vv, const float* a, const float* g_ds_base /*or NULL*/,
+                               const float* g_ds_slices /*or NULL*/, int n_slices, int64_t slice_stride, const float* g_dv,
+                               float* gU, float* gVv, float* ga, int n_nodes, int n_feat, int ld, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Skinny fp32 GEMMs for the node-level Dense / nn.Linear layers on the bead graph
@@ -310,6 +321,23 @@ int cgv_skinny_bwd_input_supported(int M, int N, int K);      /* bwd_input alone
 size_t cgv_skinny_bwd_input_workspace_bytes(int M, int N, int K);
 int cgv_skinny_linear_bwd_input(const float* gy, const float* z /*or NULL*/, const float* W, float* gx, int M, int N, int K,
                                 int act, void* ws /*or NULL*/, size_t ws_bytes, void* stream);
+/* Slice sums ("base + row-slice partials"): the split backward-input product leaves one partial [M, K] matrix per row
+ * slice of the weight; instead of a reduction launch per product (57 a step on the chignolin config) the NEXT kernel on
+ * the autograd chain adds the slices while it loads its operand -- in slice order, so results are deterministic.
+ * Replaces the same autograd steps as cgv_skinny_linear_bwd_input (Dense backward, modules.py:103-114) plus the
+ * gradient-accumulation adds autograd inserts where a state feeds two consumers (cgvae.py:100-123).
+ *   cgv_skinny_bwd_input_plan          number of slices / floats per slice of the product (M <= 64)
+ *   cgv_skinny_linear_bwd_input_slices part[s] = (g * act'(z))[:, rows of slice s] W[rows of slice s, :],
+ *                                      g = gy_base + sum_s gy_slices[s]; g_dense (or NULL) receives g itself, [M, N]
+ *                                      (the weight-gradient launch needs it as a plain matrix)
+ *   cgv_slice_sum                      out = base + sum_s slices[s]: the plain reduction, for consumers outside this library */
+int cgv_skinny_bwd_input_plan(int M, int N, int K, int* n_slices /*[host]*/, int64_t* slice_floats /*[host]*/);
+int cgv_skinny_linear_bwd_input_slices(const float* gy_base /*[M,N] or NULL*/, const float* gy_slices /*or NULL*/,
+                                       int gy_n_slices, int64_t gy_slice_stride, float* g_dense /*[M,N] or NULL*/,
+                                       const float* z /*or NULL*/, const float* W, float* part /*[n_slices, M, K]*/,
+                                       size_t part_bytes, int M, int N, int K, int act, void* stream);
+int cgv_slice_sum(const float* base /*or NULL*/, const float* slices, int n_slices, int64_t slice_stride, float* out,
+                  int64_t n_floats, void* stream);
 /* Dense backward prologue for any row count (the library-GEMM path of the atom-level layers):
  *   g = gy * act'(z)  (stored to g_out [M,N] when act != 0 and g_out != NULL)  and
  *   gb[n] (+)= sum_m g[m,n]  (gb may be NULL) -- one launch, fixed summation order.

@@ -229,3 +229,29 @@ def test_protein2000_reduced_width_vs_oracle():
             assert e <= REL, f"protein2000: grad {name} relative error {e:.3e}"
     assert n_live > 40
     _check_norm_and_clip(tr, ref, "protein2000")
+
+
+@pytest.mark.parametrize("workload,frames,F,dec", [("chignolin", 2, 600, 3), ("dipeptide", 4, 64, 2), ("chignolin", 1, 36, 2)])
+def test_fused_decoder_loop_equals_per_block_path(workload, frames, F, dec):
+    """decoder_fused (one autograd node for the decoder loop, slice-sum backward) against the per-block path it
+    replaces (blocks.py: one node per block, reduction launches, autograd's accumulation adds): every gradient of the
+    second step (all materialised), the loss, and the parameters after three steps."""
+    w = cg.data.WORKLOADS[workload]
+    batch = cg.synthetic_batch(workload, n_frames=frames, seed=2, device=DEV)
+    eps = [torch.randn(batch["CG_nxyz"].shape[0], F, generator=torch.Generator().manual_seed(k)).to(DEV) for k in range(3)]
+    runs = []
+    for fused in (True, False):
+        model = cg.build_model(F, w["n_rbf"], w["atom_cutoff"], w["cg_cutoff"], 1, dec, w["n_cgs"], seed=123).to(DEV)
+        model.equivaraintconv.fused_loop = fused
+        tr = Trainer(model, lr=1e-4, beta=w["beta"], gamma=w["gamma"], rank_update=False)
+        losses, grads = [], None
+        for k in range(3):
+            losses.append(float(tr.step(batch, eps=eps[k])))
+            if k == 1:
+                grads = tr.arena.g.clone()
+        runs.append((losses, grads, tr.arena.p.clone(), [n for n, _ in model.named_parameters()]))
+    (l1, g1, p1, _), (l0, g0, p0, _) = runs
+    for a, b in zip(l1, l0):
+        assert abs(a - b) <= 1e-6 * abs(b), (l1, l0)
+    assert rel_err(g1, g0) <= 1e-5
+    assert float((p1 - p0).abs().max()) <= 2e-2 * 1e-4 * 3 or rel_err(p1, p0) <= 1e-6
