@@ -28,6 +28,8 @@ _p, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 PROTOTYPES = {
     "cgv_version": (_i, []),
     "cgv_last_error_string": (C.c_char_p, []),
+    "cgv_timestamp": (_i, [_p, _p]),
+    "cgv_timestamp_hz": (_i, []),
     "cgv_set_option": (_i, [_i, _i]),
     "cgv_get_option": (_i, [_i]),
     "cgv_reset_options": (_i, []),
@@ -75,6 +77,16 @@ PROTOTYPES = {
     "cgv_update_vec_from_rows_slices": (_i, [_p, _i, C.c_int64, _p, _p, _i, _i, _p]),
     "cgv_update_norm_stack_bwd_slices": (_i, [_p, _i, C.c_int64, _p, _p, _p, _p, _i, C.c_int64, _p, _p, _i, _i, _i, _i, _p]),
     "cgv_update_gate_bwd_slices": (_i, [_p, _p, _p, _p, _p, _i, C.c_int64, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "cgv_decoder_layer_supported": (_i, [_i, _i, _i]),
+    "cgv_decoder_slice_floats": (C.c_int64, [_i, _i]),
+    "cgv_decoder_msg_fwd": (_i, [_p] * 18 + [_i, _i, _i, _p]),
+    "cgv_decoder_uv_fwd": (_i, [_p, _p, _p, _p, _i, _i, _p]),
+    "cgv_decoder_gate_fwd": (_i, [_p] * 9 + [_i, _i, _p]),
+    "cgv_decoder_gate_bwd": (_i, [_p, _p, _p, _p, _i, C.c_int64, _p, _p, _p, _p, _p, _p, C.c_int64, _i, _i, _p]),
+    "cgv_decoder_dense_bwd": (_i, [_p, _i, C.c_int64, _p, _i, _p, _p, _p, C.c_int64, _i, _i, _i, _p]),
+    "cgv_decoder_uv_bwd": (_i, [_p, _i, C.c_int64, _p, _p, _p, _p, _p, _p, _p, C.c_int64, _i, _i, _p]),
+    "cgv_decoder_msg_bwd": (_i, [_p] * 15 + [_p, _i, C.c_int64, _p, _p, _p] + [_p] * 8 + [C.c_int64, _i, _i, _i, _p]),
+    "cgv_decoder_slices_to_dense": (_i, [_p, _p, _i, C.c_int64, _p, _i, _i, _p]),
     "cgv_dense_grad_prepare": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "cgv_tile_supported": (_i, [_i, _i, _i]),
     "cgv_tile_linear_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),

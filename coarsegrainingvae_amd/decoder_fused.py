@@ -1,62 +1,41 @@
 """The pseudo-vector decoder loop (cgvae.py:100-123: per layer ``EquiMessagePsuedo`` conv.py:180-242 + ``UpdateBlock``
-conv.py:588-616 + the residual adds) as ONE autograd node with a hand-written backward.
+conv.py:588-616 + the residual adds) as ONE autograd node driving the channel-group kernels of
+csrc/decoder_layer.hip: 5 launches per layer forward, 5 backward (the per-block path: 8 + 21).
 
-Why: on the bead graph every kernel of this loop is a 12-row product or a 12 x 600 element-wise pass -- each sits at
-its launch / memory-round-trip floor, so the step pays per LAUNCH (profiles/r01z_step_sequence_chignolin.txt: the
-decoder is 65 % of the chignolin step).  As separate autograd nodes the backward needed, per layer, five reduction
-launches behind the row-split backward-input products, a gradient-accumulation add where a state feeds two consumers,
-and whatever copies autograd inserts.  Here the chain is driven directly:
+Why: on the bead graph every kernel of this loop is a 12-row product or a 12 x 600 element-wise pass; each sits at
+its launch + memory-round-trip floor (in-graph timestamps, tools/section_times.py: ~5.4 us per kernel whatever it
+does), so the decoder -- half of the chignolin step -- costs per DEPENDENT PHASE.  Everything between two Dense
+products is local in the channel, so it runs in the epilogue of the product that feeds it (forward) or in the prologue
+of the backward-input product it feeds (backward); the row-split partial sums of a backward-input product travel to the
+next phase as *slices* (``Slices``: base + one partial per block) and are added there while the weights stream in.
 
-  * a split backward-input product hands its row-slice partial sums to its consumer as a *slice sum* (``Slices``:
-    base + partials, csrc/cgv_common.h ``SliceSum``); the consumer -- the next backward-input product, the norm / gate /
-    transpose kernels -- adds the slices while loading its operand.  No reduction launches, no accumulation adds;
-  * nothing is allocated or hooked per autograd node; the data-parallel layer hooks are called between layers.
-
-Numerics are those of the per-block path (same kernels, same operand order inside a kernel; the slice sums add in
-slice order).  Used when the layer shapes fit the weight-streaming kernels and every parameter is arena-managed (under
-``Trainer`` from the second step on); the per-block path (blocks.py) remains the reference implementation and the
-fallback -- tests compare the two.
+Numerics: the same formulas in the same per-edge order as the per-block kernels; products are exact-fp32 MFMA chains;
+slice sums add in a fixed order.  Used for bead graphs of at most 16 nodes when every parameter is arena-managed
+(under ``Trainer`` from the second step on); the per-block path (blocks.py) remains the reference implementation and
+the fallback -- ``tests/test_full_size_parity.py::test_fused_decoder_loop_equals_per_block_path`` compares the two.
 """
 from __future__ import annotations
 
-import ctypes as C
 from typing import Optional
 
 import torch
 
 from . import _lib
+from .ktimer import mark
 from .primitives import ACT_NONE, ACT_SWISH, Swish, _grad_target, _is_direct, wgrad_queue
 
 _F32 = torch.float32
 PER_LAYER = 12          # W1 b1 W2 b2 Wd bd Wu Wv W0 b0 W1p b1p
+calls = 0               # how often the fused loop ran (tests assert that it did)
 
 
 class Slices:
-    """A gradient held as ``base + sum_s part[s]`` (either may be missing)."""
+    """A gradient held as ``base + sum_s part[s]`` (either may be missing); ``part`` holds quad-major slices
+    (csrc/decoder_layer.hip) of ``stride`` floats each."""
     __slots__ = ("base", "part", "n", "stride")
 
     def __init__(self, base: Optional[torch.Tensor] = None, part: Optional[torch.Tensor] = None, n: int = 0, stride: int = 0):
         self.base, self.part, self.n, self.stride = base, part, (n if part is not None else 0), stride
-
-    def args(self):
-        """(base ptr, slices ptr, n, stride) for the C ABI."""
-        return _lib.ptr(self.base), _lib.ptr(self.part), self.n, self.stride
-
-
-def _plan_slices(M: int, N: int, K: int):
-    ns, fl = C.c_int(), C.c_int64()
-    _lib.call("cgv_skinny_bwd_input_plan", M, N, K, C.byref(ns), C.byref(fl))
-    return ns.value, fl.value
-
-
-def _bwd_input_slices(g: Slices, g_dense, z, W, M, N, K, act, dev, st) -> Slices:
-    """Row-slice partials of (g * act'(z)) W; ``g_dense`` (or None) receives g as a plain [M, N] matrix."""
-    ns, fl = _plan_slices(M, N, K)
-    part = torch.empty(ns * fl, dtype=_F32, device=dev)
-    base, sl, n, stride = g.args()
-    _lib.call("cgv_skinny_linear_bwd_input_slices", base, sl, n, stride, _lib.ptr(g_dense), _lib.ptr(z), _lib.ptr(W), _lib.ptr(part),
-              part.numel() * 4, M, N, K, act, st)
-    return Slices(None, part, ns, fl)
 
 
 def layer_params(decoder):
@@ -77,8 +56,10 @@ def usable(decoder, S: torch.Tensor, plan, geom) -> bool:
         return False
     n, F = S.shape
     lib = _lib.load()
+    if not lib.cgv_decoder_layer_supported(n, F, geom.n_rbf):
+        return False
     ok = lambda M, N, K: bool(lib.cgv_skinny_supported(M, N, K))
-    if not (3 * n <= 64 and ok(n, F, F) and ok(n, 9 * F, F) and ok(3 * n, 2 * F, F) and ok(n, F, 2 * F) and ok(n, 3 * F, F)):
+    if not (ok(n, F, F) and ok(n, F, 2 * F)):
         return False
     if plan.n_dst != n or plan.n_src != n:
         return False
@@ -88,7 +69,7 @@ def usable(decoder, S: torch.Tensor, plan, geom) -> bool:
         if not (isinstance(d[0].activation, Swish) and d[1].activation is None and isinstance(d[2].activation, Swish)
                 and d[3].activation is None and all(x.dropout_rate == 0.0 for x in d)):
             return False
-        if im.n_rbf != geom.n_rbf:
+        if im.n_rbf != geom.n_rbf or any(x.bias is None for x in d) or ub.u_mat.bias is not None or ub.v_mat.bias is not None:
             return False
     params = layer_params(decoder)
     if not all(_is_direct(p) and p.grad.is_contiguous() and p.is_contiguous() and p.data_ptr() % 16 == 0 for p in params):
@@ -101,6 +82,8 @@ def usable(decoder, S: torch.Tensor, plan, geom) -> bool:
 
 
 class _PseudoDecoderFn(torch.autograd.Function):
+    """Forward: per layer skinny(a1) -> msg_fwd -> uv_fwd -> skinny(a0) -> gate_fwd (5 launches);
+    backward: gate_bwd -> dense_bwd(W0) -> uv_bwd -> msg_bwd -> dense_bwd(W1) (5 launches)."""
 
     @staticmethod
     def forward(ctx, S, Sbar0, V0, plan, geom, hooks, n_layers, *flat):
@@ -115,26 +98,23 @@ class _PseudoDecoderFn(torch.autograd.Function):
         for l in range(n_layers):
             W1, b1, W2, b2, Wd, bd, Wu, Wv, W0, b0, W1p, b1p = (t.detach() for t in flat[PER_LAYER * l: PER_LAYER * (l + 1)])
             Wuv = torch.as_strided(Wu, (2 * F, F), (F, 1))
-            a1, z1, phi = new(n, F), new(n, F), new(n, 9 * F)
+            a1, z1, phi, stack = new(n, F), new(n, F), new(n, 9 * F), new(n, 2 * F)
             _dense_fwd(S, W1, b1, a1, z1, n, F, F, ACT_SWISH, st)
-            _dense_fwd(a1, W2, b2, phi, None, n, 9 * F, F, ACT_NONE, st)
-            S2, Sbar2, V2, Vbar2, rows = new(n, F), new(n, F), new(n, F, 3), new(n, F, 3), new(3 * n, F)
-            _lib.call("cgv_pseudo_msg_fwd_rows", _lib.ptr(phi), _lib.ptr(S), _lib.ptr(Sbar), _lib.ptr(V), _lib.ptr(Vbar),
-                      _lib.ptr(geom.geom_d), _lib.ptr(plan.rowptr_d), _lib.ptr(plan.src_d), _lib.ptr(Wd), _lib.ptr(bd),
-                      _lib.ptr(S2), _lib.ptr(Sbar2), _lib.ptr(V2), _lib.ptr(Vbar2), _lib.ptr(rows), n, F, R, 1, st,
-                      tag=f"pseudo_msg_fwd:Nd{n}:E{plan.n_edges}:dv1")
-            UV, stack = new(3 * n, 2 * F), new(n, 2 * F)
-            _dense_fwd(rows, Wuv, None, UV, None, 3 * n, 2 * F, F, ACT_NONE, st)
-            U_ptr, Vv_ptr = UV.data_ptr(), UV.data_ptr() + 4 * F
-            _lib.call("cgv_update_norm_stack_fwd", _lib.ptr(S2), Vv_ptr, _lib.ptr(stack), n, F, 2 * F, st)
+            Sbar2, V2, Vbar2, rows = new(n, F), new(n, F, 3), new(n, F, 3), new(3 * n, F)
+            _lib.call("cgv_decoder_msg_fwd", _lib.ptr(a1), _lib.ptr(W2), _lib.ptr(b2), _lib.ptr(S), _lib.ptr(Sbar), _lib.ptr(V),
+                      _lib.ptr(Vbar), _lib.ptr(geom.geom_d), _lib.ptr(plan.rowptr_d), _lib.ptr(plan.src_d), _lib.ptr(Wd),
+                      _lib.ptr(bd), _lib.ptr(phi), _lib.ptr(stack), _lib.ptr(Sbar2), _lib.ptr(V2), _lib.ptr(Vbar2), _lib.ptr(rows),
+                      n, F, R, st, tag=f"pseudo_msg_fwd:Nd{n}:E{plan.n_edges}:dv1")
+            UV = new(3 * n, 2 * F)
+            _lib.call("cgv_decoder_uv_fwd", _lib.ptr(rows), _lib.ptr(Wuv), _lib.ptr(UV), _lib.ptr(stack), n, F, st)
             z0, a0, a = new(n, F), new(n, F), new(n, 3 * F)
             _dense_fwd(stack, W0, b0, a0, z0, n, F, 2 * F, ACT_SWISH, st)
-            _dense_fwd(a0, W1p, b1p, a, None, n, 3 * F, F, ACT_NONE, st)
             S3, V3 = new(n, F), new(n, F, 3)
-            _lib.call("cgv_update_gate_fwd", U_ptr, Vv_ptr, _lib.ptr(a), _lib.ptr(S2), _lib.ptr(V2), _lib.ptr(S3), _lib.ptr(V3),
-                      n, F, 2 * F, st)
+            _lib.call("cgv_decoder_gate_fwd", _lib.ptr(a0), _lib.ptr(W1p), _lib.ptr(b1p), _lib.ptr(UV), _lib.ptr(stack),
+                      _lib.ptr(V2), _lib.ptr(a), _lib.ptr(S3), _lib.ptr(V3), n, F, st)
             saved.append((S, Sbar, V, Vbar, z1, a1, phi, rows, UV, stack, z0, a0, a))
             S, Sbar, V, Vbar = S3, Sbar2, V3, Vbar2
+            mark(f"decoder:fwd{l}")
         ctx.saved, ctx.flat, ctx.plan, ctx.geom, ctx.hooks, ctx.n_layers = saved, flat, plan, geom, hooks, n_layers
         ctx.set_materialize_grads(False)
         return S, V
@@ -150,58 +130,61 @@ class _PseudoDecoderFn(torch.autograd.Function):
         dev, st = saved[0][0].device, _lib.stream_ptr()
         new = lambda *shape: torch.empty(*shape, dtype=_F32, device=dev)
         lib = _lib.load()
+        nb = F // 4                                             # blocks = slices of every phase (N / 4 for the dense phases)
+        fl16 = lambda K: int(lib.cgv_decoder_slice_floats(K, 0))
+        fl48 = int(lib.cgv_decoder_slice_floats(F, 1))
         gS = Slices(gS_out.contiguous() if gS_out is not None else None)
         gV = gV_out.contiguous() if gV_out is not None else None
         gSbar = gVbar = None
-        ws_bytes = int(lib.cgv_pseudo_msg_bwd_workspace_bytes(n, F, R))
+        mark("backward:loss+tail")
         for l in range(n_layers - 1, -1, -1):
             pW1, pb1, pW2, pb2, pWd, pbd, pWu, pWv, pW0, pb0, pW1p, pb1p = flat[PER_LAYER * l: PER_LAYER * (l + 1)]
             S_in, Sbar_in, V_in, Vbar_in, z1, a1, phi, rows, UV, stack, z0, a0, a = saved[l]
             saved[l] = None
             Wuv = torch.as_strided(pWu.detach(), (2 * F, F), (F, 1))
-            U_ptr, Vv_ptr = UV.data_ptr(), UV.data_ptr() + 4 * F
-            # ---- UpdateBlock backward (outputs S3 = S2 + ds, V3 = V2 + dv)
-            gUV, ga = new(3 * n, 2 * F), new(n, 3 * F)
-            gU_ptr, gVv_ptr = gUV.data_ptr(), gUV.data_ptr() + 4 * F
-            b, sl, ns, stride = gS.args()
-            _lib.call("cgv_update_gate_bwd_slices", U_ptr, Vv_ptr, _lib.ptr(a), b, sl, ns, stride, _lib.ptr(gV), gU_ptr, gVv_ptr,
-                      _lib.ptr(ga), n, F, 2 * F, st)
+            # B1: gate backward, rows of s_dense.1
+            ga, gUV, gs_sum = new(n, 3 * F), new(3 * n, 2 * F), new(n, F)
+            p1 = new(nb * fl16(F))
+            _lib.call("cgv_decoder_gate_bwd", _lib.ptr(UV), _lib.ptr(a), _lib.ptr(gS.base), _lib.ptr(gS.part), gS.n, gS.stride,
+                      _lib.ptr(gV), _lib.ptr(pW1p.detach()), _lib.ptr(ga), _lib.ptr(gUV), _lib.ptr(gs_sum), _lib.ptr(p1), fl16(F),
+                      n, F, st)
+            # B2: s_dense.0 (swish'), K = 2F
             g_a0 = new(n, F)
-            p_a0 = _bwd_input_slices(Slices(ga), None, None, pW1p.detach(), n, 3 * F, F, ACT_NONE, dev, st)
-            p_stack = _bwd_input_slices(p_a0, g_a0, z0, pW0.detach(), n, F, 2 * F, ACT_SWISH, dev, st)
+            p2 = new(nb * fl16(2 * F))
+            _lib.call("cgv_decoder_dense_bwd", _lib.ptr(p1), nb, fl16(F), _lib.ptr(z0), ACT_SWISH, _lib.ptr(pW0.detach()),
+                      _lib.ptr(g_a0), _lib.ptr(p2), fl16(2 * F), n, F, 2 * F, st)
+            # B3: norm backward, rows of [u_mat; v_mat]
             g_s2 = new(n, F)
-            _lib.call("cgv_update_norm_stack_bwd_slices", _lib.ptr(p_stack.part), p_stack.n, p_stack.stride, Vv_ptr, _lib.ptr(stack),
-                      b, sl, ns, stride, _lib.ptr(g_s2), gVv_ptr, n, F, 2 * F, 1, st)
-            p_vt = _bwd_input_slices(Slices(gUV), None, None, Wuv, 3 * n, 2 * F, F, ACT_NONE, dev, st)
-            g_v2 = new(n, F, 3)
-            _lib.call("cgv_update_vec_from_rows_slices", _lib.ptr(p_vt.part), p_vt.n, p_vt.stride, _lib.ptr(gV), _lib.ptr(g_v2), n, F, st)
-            # ---- EquiMessagePsuedo backward (outputs are the updated states: residual pass-through inside the kernel)
+            p3 = new(nb * fl48)
+            _lib.call("cgv_decoder_uv_bwd", _lib.ptr(p2), nb, fl16(2 * F), _lib.ptr(UV), _lib.ptr(stack), _lib.ptr(gs_sum),
+                      _lib.ptr(Wuv), _lib.ptr(gUV), _lib.ptr(g_s2), _lib.ptr(p3), fl48, n, F, st)
+            # B4: message backward, rows of inv_dense.1
             g_phi = new(n, 9 * F)
             g_s, g_sbar, g_v, g_vbar = new(n, F), new(n, F), new(n, F, 3), new(n, F, 3)
             tWd, accWd, _ = _grad_target(pWd, pWd)
             tbd, accbd, _ = _grad_target(pbd, pbd)
             if accWd or accbd:
                 raise RuntimeError("a decoder layer's filter parameters received a second gradient in one step")
-            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-            _lib.call("cgv_pseudo_msg_bwd", _lib.ptr(phi), _lib.ptr(S_in), _lib.ptr(Sbar_in), _lib.ptr(V_in), _lib.ptr(Vbar_in),
-                      _lib.ptr(geom.geom_d), _lib.ptr(plan.rowptr_d), _lib.ptr(plan.src_d),
-                      _lib.ptr(geom.geom_s), _lib.ptr(plan.rowptr_s), _lib.ptr(plan.dst_s), _lib.ptr(pWd.detach()), _lib.ptr(pbd.detach()),
-                      _lib.ptr(g_s2), _lib.ptr(gSbar), _lib.ptr(g_v2), _lib.ptr(gVbar),
-                      _lib.ptr(g_phi), _lib.ptr(g_s), _lib.ptr(g_sbar), _lib.ptr(g_v), _lib.ptr(g_vbar),
-                      _lib.ptr(tWd), _lib.ptr(tbd), n, F, R, 1, _lib.ptr(ws), ws_bytes, st,
-                      tag=f"pseudo_msg_bwd:Nd{n}:E{plan.n_edges}:gv1")
+            p4 = new(nb * fl16(F))
+            _lib.call("cgv_decoder_msg_bwd", _lib.ptr(phi), _lib.ptr(S_in), _lib.ptr(Sbar_in), _lib.ptr(V_in), _lib.ptr(Vbar_in),
+                      _lib.ptr(geom.geom_d), _lib.ptr(plan.rowptr_d), _lib.ptr(plan.src_d), _lib.ptr(geom.geom_s),
+                      _lib.ptr(plan.rowptr_s), _lib.ptr(plan.dst_s), _lib.ptr(pWd.detach()), _lib.ptr(pbd.detach()),
+                      _lib.ptr(g_s2), _lib.ptr(gSbar), _lib.ptr(p3), nb, fl48, _lib.ptr(gV), _lib.ptr(gVbar), _lib.ptr(pW2.detach()),
+                      _lib.ptr(g_phi), _lib.ptr(g_s), _lib.ptr(g_sbar), _lib.ptr(g_v), _lib.ptr(g_vbar), _lib.ptr(tWd), _lib.ptr(tbd),
+                      _lib.ptr(p4), fl16(F), n, F, R, st, tag=f"pseudo_msg_bwd:Nd{n}:E{plan.n_edges}:gv1")
+            # B5: inv_dense.0 (swish')
             g_a1 = new(n, F)
-            p_a1 = _bwd_input_slices(Slices(g_phi), None, None, pW2.detach(), n, 9 * F, F, ACT_NONE, dev, st)
-            p_S = _bwd_input_slices(p_a1, g_a1, z1, pW1.detach(), n, F, F, ACT_SWISH, dev, st)
+            p5 = new(nb * fl16(F))
+            _lib.call("cgv_decoder_dense_bwd", _lib.ptr(p4), nb, fl16(F), _lib.ptr(z1), ACT_SWISH, _lib.ptr(pW1.detach()),
+                      _lib.ptr(g_a1), _lib.ptr(p5), fl16(F), n, F, F, st)
+
             # ---- weight gradients -> the grouped launch (direct arena targets)
-            def enqueue(gy, x, z, act, pw, pb, target_view=None):
+            def enqueue(gy, x, z, act, pw, pb):
                 tw, acc_w, _ = _grad_target(pw, pw)
-                tb, acc_b = None, acc_w
-                if pb is not None:
-                    tb, acc_b, _ = _grad_target(pb, pb)
+                tb, acc_b, _ = _grad_target(pb, pb)
                 if acc_b != acc_w:
                     raise RuntimeError("weight and bias of one layer disagree on first-write / accumulate state")
-                wgrad_queue.enqueue(gy, x, z, act, target_view(tw) if target_view else tw, tb, acc_w)
+                wgrad_queue.enqueue(gy, x, z, act, tw, tb, acc_w)
             enqueue(ga, a0, None, ACT_NONE, pW1p, pb1p)
             enqueue(g_a0, stack, z0, ACT_SWISH, pW0, pb0)
             tu, acc_u, _ = _grad_target(pWu, pWu)
@@ -217,12 +200,13 @@ class _PseudoDecoderFn(torch.autograd.Function):
                 pw._cgv_exch = pw._cgv_rank = shape
                 pb._cgv_exch = shape
             # ---- gradients of this layer's inputs = of the layer below's outputs
-            gS = Slices(g_s, p_S.part, p_S.n, p_S.stride)
+            gS = Slices(g_s, p5, nb, fl16(F))
             gV, gSbar, gVbar = g_v, g_sbar, g_vbar
+            mark(f"decoder:bwd{l}")
             if ctx.hooks and l in ctx.hooks:
                 ctx.hooks[l]()                         # data parallel: the gradients of layers >= l are final
         gS_in = new(n, F)
-        _lib.call("cgv_slice_sum", _lib.ptr(gS.base), _lib.ptr(gS.part), gS.n, gS.stride, _lib.ptr(gS_in), n * F, st)
+        _lib.call("cgv_decoder_slices_to_dense", _lib.ptr(gS.base), _lib.ptr(gS.part), gS.n, gS.stride, _lib.ptr(gS_in), n, F, st)
         if not wgrad_queue.active:
             wgrad_queue.flush()
         return (gS_in, None, None, None, None, None, None) + (None,) * len(flat)
@@ -230,5 +214,7 @@ class _PseudoDecoderFn(torch.autograd.Function):
 
 def pseudo_decoder(decoder, S, Sbar0, V0, plan, geom, layer_hooks=None):
     """(S, V) after all layers of ``EquivariantPsuedoDecoder`` (cgvae.py:100-123)."""
+    global calls
+    calls += 1
     flat = layer_params(decoder)
     return _PseudoDecoderFn.apply(S, Sbar0, V0, plan, geom, layer_hooks or None, len(decoder.message_blocks), *flat)

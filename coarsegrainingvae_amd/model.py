@@ -15,6 +15,7 @@ import torch
 from torch import nn
 
 from . import ops
+from .ktimer import mark
 from .blocks import (ContractiveMessageBlock, EquiMessageBlock, EquiMessageCross, EquiMessagePsuedo, PseudoUpdateBlock,
                      UpdateBlock)
 from .graph import BatchGraph, EdgePlan, make_directed
@@ -354,7 +355,9 @@ class CGequiVAE(nn.Module):
         if self.bucket_done is not None:
             first = len(self._decoder_groups())
             enc_hooks = {l: self._fire_bucket(first + k) for k, l in enumerate(self._encoder_layers())}
+        mark("forward:start")
         S_I, s_i = self.encoder(z, xyz, cg_xyz, mapping, nbr_list, CG_nbr_list, graph=graph, layer_hooks=enc_hooks)
+        mark("forward:encoder")
         if side is not None:
             main.wait_stream(side)
             H_prior_mu.record_stream(main)
@@ -369,6 +372,7 @@ class CGequiVAE(nn.Module):
         else:
             sigma = 1e-12 + torch.exp(self.atom_sigmanet(S_I) / 2)
         z_sample = S_I if self.det else self.reparametrize(mu, sigma, eps)
+        mark("forward:prior+heads+sample")
         layer_hooks = None
         if self.bucket_done is not None and z_sample.requires_grad:
             groups = self._decoder_groups()
@@ -382,4 +386,5 @@ class CGequiVAE(nn.Module):
             self.before_decoder = None
         xyz_recon = self.decoder(cg_xyz, CG_nbr_list, z_sample, s_i, mapping, num_CGs, graph=graph,
                                  layer_hooks=layer_hooks)
+        mark("forward:decoder")
         return mu, sigma, H_prior_mu, H_prior_sigma, xyz, xyz_recon

@@ -21,6 +21,7 @@ from typing import List, Optional
 import torch
 
 from . import _lib
+from .ktimer import mark
 from .primitives import wgrad_queue
 from .train import CLIP_NORM, loss_terms
 
@@ -589,6 +590,7 @@ class Trainer:
             self.model.bucket_done = self._bucket_done if overlap else None
         out = self.model(batch, eps=eps) if eps is not None else self.model(batch)
         loss, kl, recon, graph = loss_terms(out, batch, self.beta, self.gamma)
+        mark("loss")
         self.last_loss, self.last_terms = loss.detach(), (kl.detach(), recon.detach(), graph.detach())
         # detached: a retained autograd graph would pin AccumulateGrad nodes to this step's stream
         self.last_out = tuple(o.detach() if o is not None else None for o in out)
@@ -611,7 +613,9 @@ class Trainer:
                 self.exchange.begin_step()
             with wgrad_queue.collect():          # bead-level weight gradients: queued, then ONE grouped launch
                 loss.backward()
+            mark("backward:encoder+prior")
             self._flush_queue(use_ex, rank=train and self.fused and self.sync is None)
+            mark("weight-gradients")
             if hasattr(self.model, "bucket_done"):
                 self.model.bucket_done = None
         if not train:                                               # validation: backward only (utils.py:160)
@@ -654,6 +658,7 @@ class Trainer:
                 self.arena.g.mul_(scale)
             torch.nn.utils.clip_grad_norm_(self.arena.params, self.max_norm)
             self.torch_opt.step()
+        mark("optimizer")
         return self.last_loss
 
     EARLY_MIN_FLOATS = 1 << 18      # ranges below 1 MiB are not worth a collective of their own: they go at the end

@@ -75,6 +75,9 @@ enum {
   CGV_OPT_BWD_INPUT_WAVES = 9, /* cgv_tile_linear_bwd_input*: waves per block, 0 = built-in rule */
   CGV_OPT_COUNT = 10
 };
+/* Measurement: store the GPU wall clock (cgv_timestamp_hz ticks per second) into *slot, in stream order; capturable. */
+int cgv_timestamp(uint64_t* slot /*device*/, void* stream);
+int cgv_timestamp_hz(void);
 int cgv_set_option(int option, int value);   /* 0, or CGV_E_BADARG for an unknown option */
 int cgv_get_option(int option);              /* current value (INT32_MIN for an unknown option) */
 int cgv_reset_options(void);                 /* every option back to its default */
@@ -256,6 +259,54 @@ int cgv_pseudo_msg_bwd(const float* phi, const float* s, const float* sbar, cons
                        float* g_phi /*[N,9F]*/, float* g_s, float* g_sbar, float* g_v, float* g_vbar,
                        float* gWd /*[9F,R]*/, float* gbd /*[9F]*/, int n_nodes, int n_feat, int n_rbf,
                        int residual, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Decoder layer as channel-group kernels (csrc/decoder_layer.hip) -- replaces, for bead graphs of at most 16 nodes, the
+ * per-layer launch chain of the pseudo-vector decoder loop cgvae.py:100-123: EquiMessagePsuedo (conv.py:180-242) with
+ * its inv_dense.1 product (conv.py:63-75), UpdateBlock (conv.py:588-616) with the u_mat / v_mat and s_dense.1 products,
+ * the residual adds (cgvae.py:108-111, 122-123) and their autograd backward.  A block owns 4 channels f0..f0+3 and the
+ * weight rows {g F + f} that feed them; grid = F / 4 blocks of 576 threads.
+ * Slices (outputs of the backward phases; inputs of the next one): slice s = block s's row-split partial product,
+ * QUAD-MAJOR [K/4][16 or 48][4] floats, cgv_decoder_slice_floats(K, rows48) each; n_slices = F/4 (N/4 for dense_bwd).
+ *   forward   msg_fwd   phi = a1 W2^T + b2 -> message -> stack[:, :F] = S', Sbar', V', Vbar', V' as rows [3n, F]
+ *             uv_fwd    UV [3n, 2F] = rows [Wu; Wv]^T ; stack[:, F:] = sqrt(sum_xyz (Vv^2 + 1e-10))
+ *             gate_fwd  a [n, 3F] = a0 W1'^T + b1' ; S'' = S' + (U.Vv) a_sv + a_ss ; V'' = V' + U a_vv
+ *   backward  gate_bwd  gS = gs_base + sum gs_slices (written to gs_sum) ; ga, gUV (gU | gVv) ; slices = ga W1'
+ *             dense_bwd g = sum g_slices (written to g_dense) ; slices = (g act'(z)) W      (W [N, K], grid N/4)
+ *             uv_bwd    g_stack = sum slices ; g_s2 = g_stack[:, :F] + gs_res ; gUV[:, F:] += g_stack[:, F:] Vv / norm ;
+ *                       slices [.., 48 rows ..] = gUV [Wu; Wv]
+ *             msg_bwd   gV' = sum gvrows_slices (rows 3i+xyz) + gv_res ; full EquiMessagePsuedo backward (g_s, g_sbar,
+ *                       g_v, g_vbar, g_phi, gWd, gbd written completely) ; slices = g_phi W2
+ *             slices_to_dense  out [n, F] = base + sum slices (16-row slices)
+ * ------------------------------------------------------------------------------------- */
+int cgv_decoder_layer_supported(int n_nodes, int n_feat, int n_rbf);
+int64_t cgv_decoder_slice_floats(int K, int rows48);
+int cgv_decoder_msg_fwd(const float* a1, const float* W2, const float* b2, const float* s, const float* sbar, const float* v,
+                        const float* vbar, const float* geom_d, const int32_t* rowptr_d, const int32_t* src_d, const float* Wd,
+                        const float* bd, float* phi, float* stack, float* sbar_out, float* v_out, float* vbar_out,
+                        float* rows_out, int n_nodes, int n_feat, int n_rbf, void* stream);
+int cgv_decoder_uv_fwd(const float* rows, const float* Wuv, float* UV, float* stack, int n_nodes, int n_feat, void* stream);
+int cgv_decoder_gate_fwd(const float* a0, const float* W1p, const float* b1p, const float* UV, const float* stack,
+                         const float* v2, float* a, float* s3, float* v3, int n_nodes, int n_feat, void* stream);
+int cgv_decoder_gate_bwd(const float* UV, const float* a, const float* gs_base /*or NULL*/, const float* gs_slices /*or NULL*/,
+                         int gs_n_slices, int64_t gs_slice_stride, const float* gv /*or NULL*/, const float* W1p, float* ga,
+                         float* gUV, float* gs_sum, float* slices_out, int64_t out_slice_stride, int n_nodes, int n_feat,
+                         void* stream);
+int cgv_decoder_dense_bwd(const float* g_slices, int g_n_slices, int64_t g_slice_stride, const float* z /*or NULL*/, int act,
+                          const float* W, float* g_dense, float* slices_out, int64_t out_slice_stride, int n_nodes, int N, int K,
+                          void* stream);
+int cgv_decoder_uv_bwd(const float* gstack_slices, int n_slices, int64_t slice_stride, const float* UV, const float* stack,
+                       const float* gs_res, const float* Wuv, float* gUV, float* g_s2, float* slices_out,
+                       int64_t out_slice_stride, int n_nodes, int n_feat, void* stream);
+int cgv_decoder_msg_bwd(const float* phi, const float* s, const float* sbar, const float* v, const float* vbar,
+                        const float* geom_d, const int32_t* rowptr_d, const int32_t* src_d, const float* geom_s,
+                        const int32_t* rowptr_s, const int32_t* dst_s, const float* Wd, const float* bd, const float* gh,
+                        const float* ghb /*or NULL*/, const float* gvrows_slices, int n_slices, int64_t slice_stride,
+                        const float* gv_res /*or NULL*/, const float* gvb /*or NULL*/, const float* W2, float* g_phi, float* g_s,
+                        float* g_sbar, float* g_v, float* g_vbar, float* gWd, float* gbd, float* slices_out,
+                        int64_t out_slice_stride, int n_nodes, int n_feat, int n_rbf, void* stream);
+int cgv_decoder_slices_to_dense(const float* base /*or NULL*/, const float* slices, int n_slices, int64_t slice_stride,
+                                float* out, int n_nodes, int n_feat, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * K5  UpdateBlock element-wise core (conv.py:588-616); the K=F products are separate launches
