@@ -79,13 +79,15 @@ PROTOTYPES = {
     "cgv_update_gate_bwd_slices": (_i, [_p, _p, _p, _p, _p, _i, C.c_int64, _p, _p, _p, _p, _i, _i, _i, _p]),
     "cgv_decoder_layer_supported": (_i, [_i, _i, _i]),
     "cgv_decoder_slice_floats": (C.c_int64, [_i, _i]),
-    "cgv_decoder_msg_fwd": (_i, [_p] * 18 + [_i, _i, _i, _p]),
+    "cgv_decoder_max_edges": (_i, []),
+    "cgv_decoder_debug_clock": (_i, [_p]),
+    "cgv_decoder_msg_fwd": (_i, [_p] * 18 + [_i, _i, _i, _i, _p]),
     "cgv_decoder_uv_fwd": (_i, [_p, _p, _p, _p, _i, _i, _p]),
     "cgv_decoder_gate_fwd": (_i, [_p] * 9 + [_i, _i, _p]),
     "cgv_decoder_gate_bwd": (_i, [_p, _p, _p, _p, _i, C.c_int64, _p, _p, _p, _p, _p, _p, C.c_int64, _i, _i, _p]),
     "cgv_decoder_dense_bwd": (_i, [_p, _i, C.c_int64, _p, _i, _p, _p, _p, C.c_int64, _i, _i, _i, _p]),
     "cgv_decoder_uv_bwd": (_i, [_p, _i, C.c_int64, _p, _p, _p, _p, _p, _p, _p, C.c_int64, _i, _i, _p]),
-    "cgv_decoder_msg_bwd": (_i, [_p] * 15 + [_p, _i, C.c_int64, _p, _p, _p] + [_p] * 8 + [C.c_int64, _i, _i, _i, _p]),
+    "cgv_decoder_msg_bwd": (_i, [_p] * 15 + [_p, _i, C.c_int64, _p, _p, _p] + [_p] * 8 + [C.c_int64, _i, _i, _i, _i, _p]),
     "cgv_decoder_slices_to_dense": (_i, [_p, _p, _i, C.c_int64, _p, _i, _i, _p]),
     "cgv_dense_grad_prepare": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "cgv_tile_supported": (_i, [_i, _i, _i]),

@@ -35,6 +35,10 @@ namespace cgv {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// phase clock of block 0 (measurement only: cgv_decoder_debug_clock); NULL in normal operation
+__device__ unsigned long long* g_dl_clock = nullptr;
+#define DL_TICK(i) do { if (g_dl_clock && blockIdx.x == 0 && threadIdx.x == 0) g_dl_clock[i] = wall_clock64(); } while (0)
+
 constexpr int DL_CB = 4;                 // channels per block
 constexpr int DL_WAVES = 9;
 constexpr int DL_THREADS = 64 * DL_WAVES;
@@ -57,41 +61,72 @@ __device__ __forceinline__ float dfilt(const float (&W)[R + 1], const float* __r
   return w;
 }
 
+// ---------------------------------------------------------------------------------------------- LDS carving
+// All kernels take their LDS from one dynamic allocation (one block per CU: up to 160 KB are free to use).
+extern __shared__ __attribute__((aligned(16))) unsigned char dl_smem[];
+struct Carve {
+  size_t off = 0;
+  __device__ __forceinline__ float* take(size_t floats) {
+    float* p = reinterpret_cast<float*>(dl_smem + off);
+    off += ((floats * 4 + 15) / 16) * 16;
+    return p;
+  }
+};
+
 // ---------------------------------------------------------------------------------------------- slice sums (quad-major)
-// tile[m][c] (m < 16 MB, c < 4) = sum_s slices[s][kq][m][c]; all threads take part; the result is valid after the
-// trailing __syncthreads().  scratch: 36 * 16 * MB float4.
-template <int MB>
-__device__ __forceinline__ void quad_sum(float4* __restrict__ tile, float4* __restrict__ scratch,
-                                         const float* __restrict__ slices, int n_slices, long long stride, int kq) {
-  constexpr int MP = 16 * MB;
+// Slice layout: [K/4 column quads][rows][4] floats, rows = n (16-row phases) or 3 n (the [u_mat; v_mat] phase).
+// tile[q][m][c] = sum_s slices[s][kq[q]][m][c] for NQ quads at once (one batch of loads); all threads take part; valid
+// after the trailing __syncthreads().  scratch: NQ * 36 * 16 * MB float4.  Order: per class ascending s, then classes.
+constexpr int DL_QS = 6;                  // slices per lane class: 36 * 6 = 216 >= F / 4 for F <= 864
+template <int MB, int NQ>
+struct QuadRegs { float4 v[DL_QS][NQ][MB]; };
+
+// Issue every load of the slice sum (straight-line, one batch: the compiler can count them, so that the weight prefetch
+// issued afterwards stays in flight while these are consumed -- vmcnt returns in order).
+template <int MB, int NQ>
+__device__ __forceinline__ void quad_issue(QuadRegs<MB, NQ>& r, const float* __restrict__ slices, int n_slices, long long stride,
+                                           int rows, const int (&kq)[NQ]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m = lane & 15, cls = wave * 4 + (lane >> 4);                 // 36 slice classes
-  constexpr int SB = 5;                                                   // loads in flight per row tile (150 slices: one batch)
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb) {
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s0 = cls; s0 < n_slices; s0 += 36 * SB) {
-      float4 v[SB];
+  for (int u = 0; u < DL_QS; ++u) {
+    const int s = min(cls + 36 * u, n_slices - 1);
 #pragma unroll
-      for (int u = 0; u < SB; ++u) {
-        const int s = min(s0 + 36 * u, n_slices - 1);
-        v[u] = *reinterpret_cast<const float4*>(slices + (size_t)s * stride + ((size_t)kq * MP + mb * 16 + m) * 4);
-      }
+    for (int q = 0; q < NQ; ++q)
 #pragma unroll
-      for (int u = 0; u < SB; ++u)
-        if (s0 + 36 * u < n_slices) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
-    }
-    scratch[(cls * MB + mb) * 16 + m] = acc;
+      for (int mb = 0; mb < MB; ++mb)
+        r.v[u][q][mb] = *reinterpret_cast<const float4*>(slices + (size_t)s * stride + ((size_t)kq[q] * rows + min(mb * 16 + m, rows - 1)) * 4);
   }
+}
+
+// Sum: per class ascending slice index, then the 36 classes in order.  tile[q][m] valid after the trailing barrier.
+template <int MB, int NQ>
+__device__ __forceinline__ void quad_finish(const QuadRegs<MB, NQ>& r, float4* __restrict__ tile /*[NQ][16 MB]*/,
+                                            float4* __restrict__ scratch /*NQ * 36 * 16 MB*/, int n_slices, int rows) {
+  constexpr int MP = 16 * MB;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = lane & 15, cls = wave * 4 + (lane >> 4);
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < DL_QS; ++u)
+        if (cls + 36 * u < n_slices) { acc.x += r.v[u][q][mb].x; acc.y += r.v[u][q][mb].y; acc.z += r.v[u][q][mb].z; acc.w += r.v[u][q][mb].w; }
+      scratch[((q * 36 + cls) * MB + mb) * 16 + m] = acc;
+    }
   __syncthreads();
-  if (threadIdx.x < MP) {
-    const int mm = threadIdx.x;
+  if (threadIdx.x < NQ * MP) {
+    const int q = threadIdx.x / MP, mm = threadIdx.x - q * MP;
     float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
     for (int c = 0; c < 36; ++c) {
-      const float4 v = scratch[(c * MB + mm / 16) * 16 + (mm & 15)];
+      const float4 v = scratch[((q * 36 + c) * MB + mm / 16) * 16 + (mm & 15)];
       t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
     }
-    tile[mm] = t;
+    if (mm >= rows) t = make_float4(0.f, 0.f, 0.f, 0.f);
+    tile[q * MP + mm] = t;
   }
   __syncthreads();
 }
@@ -99,7 +134,8 @@ __device__ __forceinline__ void quad_sum(float4* __restrict__ tile, float4* __re
 // ---------------------------------------------------------------------------------------------- backward-input core
 // The block's G row groups (4 consecutive weight rows each, first row row0[g]) times g_tile[m][g*4 + q] -> this block's
 // slice, quad-major.  Wave w takes column tiles w, w + 9, ... of 64 columns.  The weight registers are loaded by
-// bi_prefetch at the top of the kernel (independent of the prologue).
+// bi_prefetch at the top of the kernel (independent of the prologue).  The tile leaves through an LDS stage so that a
+// wave's stores are contiguous (16 quads x rows x 16 bytes per tile) instead of 16-byte pieces 64 bytes apart.
 template <int G, int NT>
 struct BiRegs { float4 w[NT][G]; };
 
@@ -116,24 +152,39 @@ __device__ __forceinline__ void bi_prefetch(BiRegs<G, NT>& r, const float* __res
   }
 }
 
-template <int MB, int G, int NT>
-__device__ __forceinline__ void bi_core(const BiRegs<G, NT>& r, const float* __restrict__ g_tile /*[16 MB][G*4] LDS*/,
-                                        float* __restrict__ slice /*[K/4][16 MB][4]*/, int K) {
+template <int MB>
+__host__ __device__ constexpr size_t bi_stage_floats() { return (size_t)DL_WAVES * 16 * 16 * MB * 4; }
+
+// NPRE of the NT column tiles per wave come from bi_prefetch's registers; the others (register budget: the message
+// kernel keeps 9 row groups per tile) are loaded where they are used -- only wave 0 has a second tile at K = 600.
+template <int MB, int G, int NT, int NPRE = NT>
+__device__ __forceinline__ void bi_core(const BiRegs<G, NPRE>& r, const float* __restrict__ g_tile /*[16 MB][G*4] LDS*/,
+                                        float* __restrict__ stage /*bi_stage_floats<MB>() LDS*/,
+                                        float* __restrict__ slice /*[K/4][rows][4]*/, int K, int rows,
+                                        const float* __restrict__ W = nullptr, const int* row0 = nullptr) {
   constexpr int MP = 16 * MB;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, q = lane >> 4;
+  float4* st = reinterpret_cast<float4*>(stage) + (size_t)wave * 16 * MP;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    const int col = (wave + DL_WAVES * t) * 64 + 4 * j;
-    if ((wave + DL_WAVES * t) * 64 >= K) break;                           // wave-uniform
+    const int tile = wave + DL_WAVES * t;
+    if (tile * 64 >= K) break;                                            // wave-uniform
     f32x4 acc[MB][4];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc[mb][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 late[G];
+    if (t >= NPRE) {
+      const int col = tile * 64 + 4 * j;
+      const int cc = col < K ? col : 0;
+#pragma unroll
+      for (int g = 0; g < G; ++g) late[g] = *reinterpret_cast<const float4*>(W + (size_t)(row0[g] + q) * K + cc);
+    }
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      const float4 w = r.w[t][g];
+      const float4 w = t < NPRE ? r.w[t < NPRE ? t : 0][g] : late[g];
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
         const float a = g_tile[(mb * 16 + j) * (G * 4) + g * 4 + q];
@@ -143,16 +194,18 @@ __device__ __forceinline__ void bi_core(const BiRegs<G, NT>& r, const float* __r
         acc[mb][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w.w, acc[mb][3], 0, 0, 0);
       }
     }
-    if (col < K) {
-      const int kq = col >> 2;
+    // lane holds rows m = 16 mb + 4 q + rr of column quad j of this tile
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
+    for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const int m = mb * 16 + 4 * q + rr;
-          *reinterpret_cast<float4*>(slice + ((size_t)kq * MP + m) * 4) =
-              make_float4(acc[mb][0][rr], acc[mb][1][rr], acc[mb][2][rr], acc[mb][3][rr]);
-        }
+      for (int rr = 0; rr < 4; ++rr)
+        st[j * MP + mb * 16 + 4 * q + rr] = make_float4(acc[mb][0][rr], acc[mb][1][rr], acc[mb][2][rr], acc[mb][3][rr]);
+    // (same wave wrote, same wave reads: wave-synchronous through LDS)
+    const int quads = min(16, (K - tile * 64) / 4);                       // K % 4 == 0
+    float4* out = reinterpret_cast<float4*>(slice) + (size_t)tile * 16 * rows;
+    for (int idx = lane; idx < quads * rows; idx += 64) {
+      const int jj = idx / rows, m = idx - jj * rows;
+      out[idx] = st[jj * MP + m];
     }
   }
 }
@@ -161,6 +214,9 @@ __device__ __forceinline__ void bi_core(const BiRegs<G, NT>& r, const float* __r
 // out[m][g][c] = sum_k x[m][k] W[row0[g] + c][k] for the block's G row groups, m < M (<= 16 MB).  16-row tiles hold four
 // groups; the 9 waves split K in whole 16-float steps and meet in LDS (wave order).  red: 9 * T * MB * 256 floats,
 // out: 16 MB * G * 4 floats.  Valid after the trailing __syncthreads().
+template <int MB, int G>
+__host__ __device__ constexpr size_t fwd_red_floats() { return (size_t)DL_WAVES * ((G + 3) / 4) * MB * 256; }
+
 template <int MB, int G>
 __device__ __forceinline__ void fwd_core(float* __restrict__ out, float* __restrict__ red, const float* __restrict__ x,
                                          int M, int K, const float* __restrict__ W, const int (&row0)[G]) {
@@ -183,6 +239,8 @@ __device__ __forceinline__ void fwd_core(float* __restrict__ out, float* __restr
   for (int t = 0; t < T; ++t)
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) acc[t][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // (tried: 32- and 64-float steps so that a row's four q-lanes read whole 128 / 256-byte lines instead of 64-byte pieces
+  // -- not faster: 13.2 / 14.6 us against 13.1 for the message kernel; these products are latency-, not sector-bound)
   constexpr int SB = (T * MB >= 3) ? 3 : 5;                               // steps whose loads are issued together
   for (int s0 = s_beg; s0 < s_end; s0 += SB) {
     float4 a[SB][T], b[SB][MB];
@@ -233,6 +291,32 @@ __device__ __forceinline__ void fwd_core(float* __restrict__ out, float* __restr
   __syncthreads();
 }
 
+// ---------------------------------------------------------------------------------------------- staging of the bead graph
+// Edge records, CSR arrays and the node state of the block's 4 channels go to LDS in one batch of loads at the top of a
+// message kernel: the edge loops then touch no global memory (they were chains of dependent gathers: index -> row).
+constexpr int DL_MAX_EDGES = 240;          // 16 nodes, no self loops / duplicates
+__device__ __forceinline__ void stage_copy4(float* __restrict__ dst, const float* __restrict__ src, int n4) {
+  for (int i = threadIdx.x; i < n4; i += DL_THREADS) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+}
+__device__ __forceinline__ void stage_ints(int* __restrict__ dst, const int* __restrict__ src, int n) {
+  for (int i = threadIdx.x; i < n; i += DL_THREADS) dst[i] = src[i];
+}
+// node-major [n][4] float4 of a [n][F] array at channels f0..f0+3
+__device__ __forceinline__ void stage_scalar(float* __restrict__ dst, const float* __restrict__ src, int n, int F, int f0) {
+  if (threadIdx.x < n)
+    reinterpret_cast<float4*>(dst)[threadIdx.x] = src ? *reinterpret_cast<const float4*>(src + (size_t)threadIdx.x * F + f0)
+                                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+// [n][4][3] of a [n][F][3] array (12 contiguous floats per node)
+__device__ __forceinline__ void stage_vector(float* __restrict__ dst, const float* __restrict__ src, int n, int F, int f0) {
+  if (threadIdx.x < 3 * n) {
+    const int m = threadIdx.x / 3, part = threadIdx.x - 3 * m;
+    reinterpret_cast<float4*>(dst)[threadIdx.x] =
+        src ? *reinterpret_cast<const float4*>(src + ((size_t)m * F + f0) * 3 + 4 * part) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+__device__ __forceinline__ dv3 lds_v3(const float* p) { return dv3{p[0], p[1], p[2]}; }
+
 // ============================================================================================== F2: phi + message forward
 template <int R>
 __global__ __launch_bounds__(DL_THREADS) void dec_msg_fwd_k(
@@ -241,26 +325,33 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_fwd_k(
     const float* __restrict__ geom, const int* __restrict__ rowptr, const int* __restrict__ src,
     const float* __restrict__ Wd, const float* __restrict__ bd, float* __restrict__ phi_out, float* __restrict__ stack,
     float* __restrict__ sbar_out, float* __restrict__ v_out, float* __restrict__ vbar_out, float* __restrict__ rows_out,
-    int n, int F) {
+    int n, int F, int E) {
   constexpr int GS = geom_stride(R), U = geom_unit_offset(R);
-  __shared__ __attribute__((aligned(16))) float red[DL_WAVES * 3 * 256];
-  __shared__ __attribute__((aligned(16))) float phi_l[16 * 9 * 4];
-  __shared__ float red2[8][3][64];
+  Carve cv;
+  float* red = cv.take(fwd_red_floats<1, 9>());
+  float* phi_l = cv.take(16 * 9 * 4);
+  float* red2 = cv.take(8 * 3 * 64);
+  float* geom_l = cv.take((size_t)DL_MAX_EDGES * GS);
+  int* rp_l = reinterpret_cast<int*>(cv.take(20));
+  int* src_l = reinterpret_cast<int*>(cv.take(DL_MAX_EDGES));
+  float* s_l = cv.take(64); float* sb_l = cv.take(64);
+  float* v_l = cv.take(192); float* vb_l = cv.take(192);
   const int f0 = blockIdx.x * DL_CB;
   const int lane = threadIdx.x & 63;
   const int k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane >> 2, c = lane & 3;
   const bool live = i < n;
-  const int ic = live ? i : 0;
   const int f = f0 + c;
-  // receiver state and this wave's filter row: requested before the product so that they arrive behind it
+  // bead graph + node state of these channels -> LDS (requested before the product, consumed after it)
+  stage_copy4(geom_l, geom, E * GS / 4);
+  stage_ints(rp_l, rowptr, n + 1);
+  stage_ints(src_l, src, E);
+  stage_scalar(s_l, s, n, F, f0); stage_scalar(sb_l, sbar, n, F, f0);
+  stage_vector(v_l, v, n, F, f0); stage_vector(vb_l, vbar, n, F, f0);
   float W[R + 1];
 #pragma unroll
   for (int nn = 0; nn < R; ++nn) W[nn] = Wd[((size_t)k * F + f) * R + nn];
   W[R] = bd[(size_t)k * F + f];
-  const size_t nf = (size_t)ic * F + f;
-  const float s_i = s[nf], sb_i = sbar[nf];
-  const dv3 v_i = dldv(v + nf * 3), vb_i = dldv(vbar + nf * 3);
   int row0[9];
 #pragma unroll
   for (int g = 0; g < 9; ++g) row0[g] = g * F + f0;
@@ -276,49 +367,43 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_fwd_k(
   }
   __syncthreads();
   // EquiMessagePsuedo, wave k = filter k (pseudo_msg.hip: pseudo_fwd_k), lane = (receiver i, channel c)
+  const int ic = live ? i : 0;
+  const float s_i = s_l[ic * 4 + c], sb_i = sb_l[ic * 4 + c];
+  const dv3 v_i = lds_v3(v_l + (ic * 4 + c) * 3), vb_i = lds_v3(vb_l + (ic * 4 + c) * 3);
   float ah = 0.f, ahb = 0.f;
   dv3 acc{0.f, 0.f, 0.f};
-  const float* __restrict__ vsrc = (k == 2 || k == 6 || k == 7) ? v : vbar;
-  const int e_beg = live ? rowptr[i] : 0, e_end = live ? rowptr[i + 1] : 0;
-  constexpr int EB = 8;
-  for (int eb = e_beg; eb < e_end; eb += EB) {
-    int jj[EB];
-    dv3 vj[EB];
-#pragma unroll
-    for (int u = 0; u < EB; ++u) jj[u] = src[min(eb + u, e_end - 1)];
-#pragma unroll
-    for (int u = 0; u < EB; ++u) vj[u] = dldv(vsrc + ((size_t)jj[u] * F + f) * 3);
-#pragma unroll
-    for (int u = 0; u < EB; ++u) {
-      if (eb + u < e_end) {
-        const float* __restrict__ g = geom + (size_t)(eb + u) * GS;
-        const float q = phi_l[(jj[u] * 9 + k) * 4 + c] * dfilt<R>(W, g);
-        switch (k) {                                   // wave-uniform
-          case 0: ah = fmaf(q, s_i, ah); ahb += ddot(v_i, vj[u]); break;
-          case 1: daxpy(acc, q, dv3{g[U], g[U + 1], g[U + 2]}); break;
-          case 2: daxpy(acc, q, vj[u]); break;
-          case 3: daxpy(acc, q, dcross(v_i, vj[u])); break;
-          case 4: daxpy(acc, q * sb_i, vj[u]); break;
-          case 5: daxpy(acc, q, vj[u]); break;
-          case 6: daxpy(acc, q * sb_i, vj[u]); break;
-          case 7: daxpy(acc, q, dcross(v_i, vj[u])); break;
-          default: daxpy(acc, q, dcross(vb_i, vj[u])); break;
-        }
-      }
+  const float* __restrict__ vsrc = (k == 2 || k == 6 || k == 7) ? v_l : vb_l;
+  const int e_beg = live ? rp_l[i] : 0, e_end = live ? rp_l[i + 1] : 0;
+  for (int e = e_beg; e < e_end; ++e) {
+    const int j = src_l[e];
+    const float* __restrict__ g = geom_l + (size_t)e * GS;
+    const dv3 vj = lds_v3(vsrc + (j * 4 + c) * 3);
+    const float q = phi_l[(j * 9 + k) * 4 + c] * dfilt<R>(W, g);
+    switch (k) {                                   // wave-uniform
+      case 0: ah = fmaf(q, s_i, ah); ahb += ddot(v_i, vj); break;
+      case 1: daxpy(acc, q, dv3{g[U], g[U + 1], g[U + 2]}); break;
+      case 2: daxpy(acc, q, vj); break;
+      case 3: daxpy(acc, q, dcross(v_i, vj)); break;
+      case 4: daxpy(acc, q * sb_i, vj); break;
+      case 5: daxpy(acc, q, vj); break;
+      case 6: daxpy(acc, q * sb_i, vj); break;
+      case 7: daxpy(acc, q, dcross(v_i, vj)); break;
+      default: daxpy(acc, q, dcross(vb_i, vj)); break;
     }
   }
-  if (k > 0) { red2[k - 1][0][lane] = acc.x; red2[k - 1][1][lane] = acc.y; red2[k - 1][2][lane] = acc.z; }
+  if (k > 0) { red2[((k - 1) * 3 + 0) * 64 + lane] = acc.x; red2[((k - 1) * 3 + 1) * 64 + lane] = acc.y; red2[((k - 1) * 3 + 2) * 64 + lane] = acc.z; }
   __syncthreads();
   if (k != 0 || !live) return;
   dv3 av{0.f, 0.f, 0.f}, avb{0.f, 0.f, 0.f};
 #pragma unroll
-  for (int w = 0; w < 4; ++w) { av.x += red2[w][0][lane]; av.y += red2[w][1][lane]; av.z += red2[w][2][lane]; }
+  for (int w = 0; w < 4; ++w) { av.x += red2[(w * 3 + 0) * 64 + lane]; av.y += red2[(w * 3 + 1) * 64 + lane]; av.z += red2[(w * 3 + 2) * 64 + lane]; }
 #pragma unroll
-  for (int w = 4; w < 8; ++w) { avb.x += red2[w][0][lane]; avb.y += red2[w][1][lane]; avb.z += red2[w][2][lane]; }
+  for (int w = 4; w < 8; ++w) { avb.x += red2[(w * 3 + 0) * 64 + lane]; avb.y += red2[(w * 3 + 1) * 64 + lane]; avb.z += red2[(w * 3 + 2) * 64 + lane]; }
   // updated states (cgvae.py:108-111)
   ah += s_i; ahb += sb_i;
   av.x += v_i.x; av.y += v_i.y; av.z += v_i.z;
   avb.x += vb_i.x; avb.y += vb_i.y; avb.z += vb_i.z;
+  const size_t nf = (size_t)i * F + f;
   stack[(size_t)i * 2 * F + f] = ah;                    // S' is the first half of the update block's stack (conv.py:601)
   sbar_out[nf] = ahb;
   st3(v_out + nf * 3, av.x, av.y, av.z);
@@ -331,8 +416,9 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_fwd_k(
 // ============================================================================================== F3: [U | Vv] + norm
 __global__ __launch_bounds__(DL_THREADS) void dec_uv_fwd_k(const float* __restrict__ rows, const float* __restrict__ Wuv,
                                                            float* __restrict__ UV, float* __restrict__ stack, int n, int F) {
-  __shared__ __attribute__((aligned(16))) float red[DL_WAVES * 3 * 256];
-  __shared__ __attribute__((aligned(16))) float uv_l[48 * 2 * 4];
+  Carve cv;
+  float* red = cv.take(fwd_red_floats<3, 2>());
+  float* uv_l = cv.take(48 * 2 * 4);
   const int f0 = blockIdx.x * DL_CB;
   const int row0[2] = {f0, F + f0};
   fwd_core<3, 2>(uv_l, red, rows, 3 * n, F, Wuv, row0);
@@ -353,24 +439,32 @@ __global__ __launch_bounds__(DL_THREADS) void dec_gate_fwd_k(const float* __rest
                                                              const float* __restrict__ stack, const float* __restrict__ v2,
                                                              float* __restrict__ a_out, float* __restrict__ s3,
                                                              float* __restrict__ v3, int n, int F) {
-  __shared__ __attribute__((aligned(16))) float red[DL_WAVES * 256];
-  __shared__ __attribute__((aligned(16))) float a_l[16 * 3 * 4];
+  Carve cv;
+  float* red = cv.take(fwd_red_floats<1, 3>());
+  float* a_l = cv.take(16 * 3 * 4);
   const int f0 = blockIdx.x * DL_CB;
   const int row0[3] = {f0, F + f0, 2 * F + f0};
+  // the gate's other operands: requested before the product
+  float ux = 0.f, uy = 0.f, uz = 0.f, vx = 0.f, vy = 0.f, vz = 0.f, s2 = 0.f, bvv = 0.f, bsv = 0.f, bss = 0.f;
+  f3 r{0.f, 0.f, 0.f};
+  const bool mine = threadIdx.x < n * 4;
+  const int i = threadIdx.x >> 2, c = threadIdx.x & 3, f = f0 + c;
+  if (mine) {
+    const size_t b = (size_t)i * 3 * 2 * F + f;
+    ux = UV[b]; uy = UV[b + 2 * F]; uz = UV[b + 4 * F];
+    vx = UV[b + F]; vy = UV[b + 2 * F + F]; vz = UV[b + 4 * F + F];
+    r = ld3(v2 + ((size_t)i * F + f) * 3);
+    s2 = stack[(size_t)i * 2 * F + f];
+    bvv = b1p[f]; bsv = b1p[F + f]; bss = b1p[2 * F + f];
+  }
   fwd_core<1, 3>(a_l, red, a0, n, F, W1p, row0);
-  if (threadIdx.x < n * 4) {
-    const int i = threadIdx.x >> 2, c = threadIdx.x & 3, f = f0 + c;
-    const float a_vv = a_l[(i * 3 + 0) * 4 + c] + b1p[f], a_sv = a_l[(i * 3 + 1) * 4 + c] + b1p[F + f],
-                a_ss = a_l[(i * 3 + 2) * 4 + c] + b1p[2 * F + f];
+  if (mine) {
+    const float a_vv = a_l[(i * 3 + 0) * 4 + c] + bvv, a_sv = a_l[(i * 3 + 1) * 4 + c] + bsv, a_ss = a_l[(i * 3 + 2) * 4 + c] + bss;
     float* ao = a_out + (size_t)i * 3 * F + f;
     ao[0] = a_vv; ao[F] = a_sv; ao[2 * F] = a_ss;
-    const size_t b = (size_t)i * 3 * 2 * F + f;
-    const float ux = UV[b], uy = UV[b + 2 * F], uz = UV[b + 4 * F];
-    const float vx = UV[b + F], vy = UV[b + 2 * F + F], vz = UV[b + 4 * F + F];
     const size_t nf = (size_t)i * F + f;
-    const f3 r = ld3(v2 + nf * 3);
     st3(v3 + nf * 3, ux * a_vv + r.x, uy * a_vv + r.y, uz * a_vv + r.z);                  // conv.py:607, cgvae.py:123
-    s3[nf] = ((ux * vx + uy * vy + uz * vz) * a_sv + a_ss) + stack[(size_t)i * 2 * F + f];    // conv.py:612-614, cgvae.py:122
+    s3[nf] = ((ux * vx + uy * vy + uz * vz) * a_sv + a_ss) + s2;                           // conv.py:612-614, cgvae.py:122
   }
 }
 
@@ -380,29 +474,37 @@ __global__ __launch_bounds__(DL_THREADS) void dec_gate_bwd_k(
     const float* __restrict__ gs_slices, int gs_n, long long gs_stride, const float* __restrict__ gv,
     const float* __restrict__ W1p, float* __restrict__ ga, float* __restrict__ gUV, float* __restrict__ gs_sum,
     float* __restrict__ slices_out, long long out_stride, int n, int F) {
-  __shared__ __attribute__((aligned(16))) float4 scratch[36 * 16];
-  __shared__ __attribute__((aligned(16))) float4 gs_l[16];
-  __shared__ __attribute__((aligned(16))) float g_l[16 * 3 * 4];
+  Carve cv;
+  float* stage = cv.take(bi_stage_floats<1>());
+  float4* scratch = reinterpret_cast<float4*>(cv.take(36 * 16 * 4));
+  float4* gs_l = reinterpret_cast<float4*>(cv.take(16 * 4));
+  float* g_l = cv.take(16 * 3 * 4);
   const int f0 = blockIdx.x * DL_CB;
   const int row0[3] = {f0, F + f0, 2 * F + f0};
+  // order of requests: the slices and the prologue's own operands first, the weights behind them
+  const bool have_slices = gs_slices && gs_n > 0;
+  const int kq[1] = {(int)blockIdx.x};
+  QuadRegs<1, 1> qr;
+  quad_issue<1, 1>(qr, have_slices ? gs_slices : UV, have_slices ? gs_n : 1, have_slices ? gs_stride : 0, have_slices ? n : 1, kq);
+  const bool mine = threadIdx.x < n * 4;
+  const int i = threadIdx.x >> 2, c = threadIdx.x & 3, f = f0 + c;
+  const size_t nf = (size_t)i * F + f;
+  const size_t b = (size_t)i * 3 * 2 * F + f, cc = (size_t)i * 3 * F + f;
+  float ux = 0.f, uy = 0.f, uz = 0.f, vx = 0.f, vy = 0.f, vz = 0.f, a_vv = 0.f, a_sv = 0.f, gsb = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
+  if (mine) {
+    ux = UV[b]; uy = UV[b + 2 * F]; uz = UV[b + 4 * F];
+    vx = UV[b + F]; vy = UV[b + 2 * F + F]; vz = UV[b + 4 * F + F];
+    a_vv = a[cc]; a_sv = a[cc + F];
+    if (gs_base) gsb = gs_base[nf];
+    if (gv) { const f3 t = ld3(gv + nf * 3); gx = t.x; gy = t.y; gz = t.z; }
+  }
   BiRegs<3, 2> wr;
   bi_prefetch<3, 2>(wr, W1p, F, row0);
-  if (gs_slices && gs_n > 0) quad_sum<1>(gs_l, scratch, gs_slices, gs_n, gs_stride, blockIdx.x);
-  else { if (threadIdx.x < 16) gs_l[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f); __syncthreads(); }
   for (int o = threadIdx.x; o < 16 * 12; o += DL_THREADS) g_l[o] = 0.f;
-  __syncthreads();
-  if (threadIdx.x < n * 4) {
-    const int i = threadIdx.x >> 2, c = threadIdx.x & 3, f = f0 + c;
-    const size_t nf = (size_t)i * F + f;
-    float gs = reinterpret_cast<const float*>(gs_l)[i * 4 + c];
-    if (gs_base) gs += gs_base[nf];
+  quad_finish<1, 1>(qr, gs_l, scratch, have_slices ? gs_n : 0, n);           // no slices: every class empty -> zeros
+  if (mine) {
+    const float gs = reinterpret_cast<const float*>(gs_l)[i * 4 + c] + gsb;
     gs_sum[nf] = gs;
-    float gx = 0.f, gy = 0.f, gz = 0.f;
-    if (gv) { const f3 t = ld3(gv + nf * 3); gx = t.x; gy = t.y; gz = t.z; }
-    const size_t b = (size_t)i * 3 * 2 * F + f, cc = (size_t)i * 3 * F + f;
-    const float ux = UV[b], uy = UV[b + 2 * F], uz = UV[b + 4 * F];
-    const float vx = UV[b + F], vy = UV[b + 2 * F + F], vz = UV[b + 4 * F + F];
-    const float a_vv = a[cc], a_sv = a[cc + F];
     const float inner = ux * vx + uy * vy + uz * vz;
     const float cs = gs * a_sv;
     const float g0 = gx * ux + gy * uy + gz * uz, g1 = gs * inner, g2 = gs;
@@ -412,7 +514,7 @@ __global__ __launch_bounds__(DL_THREADS) void dec_gate_bwd_k(
     gUV[b + F] = cs * ux; gUV[b + 2 * F + F] = cs * uy; gUV[b + 4 * F + F] = cs * uz;
   }
   __syncthreads();
-  bi_core<1, 3, 2>(wr, g_l, slices_out + (size_t)blockIdx.x * out_stride, F);
+  bi_core<1, 3, 2>(wr, g_l, stage, slices_out + (size_t)blockIdx.x * out_stride, F, n);
 }
 
 // ============================================================================================== B2 / B5: slice sum, act', one row group
@@ -421,27 +523,34 @@ __global__ __launch_bounds__(DL_THREADS) void dec_dense_bwd_k(const float* __res
                                                               const float* __restrict__ z, int act, const float* __restrict__ W,
                                                               float* __restrict__ g_dense, float* __restrict__ slices_out,
                                                               long long out_stride, int n, int N, int K) {
-  __shared__ __attribute__((aligned(16))) float4 scratch[36 * 16];
-  __shared__ __attribute__((aligned(16))) float4 sum_l[16];
-  __shared__ __attribute__((aligned(16))) float g_l[16 * 4];
+  Carve cv;
+  float* stage = cv.take(bi_stage_floats<1>());
+  float4* scratch = reinterpret_cast<float4*>(cv.take(36 * 16 * 4));
+  float4* sum_l = reinterpret_cast<float4*>(cv.take(16 * 4));
+  float* g_l = cv.take(16 * 4);
   const int n0 = blockIdx.x * DL_CB;
   const int row0[1] = {n0};
+  const int kq[1] = {(int)blockIdx.x};
+  QuadRegs<1, 1> qr;
+  quad_issue<1, 1>(qr, g_slices, g_n, g_stride, n, kq);
+  const int i = threadIdx.x >> 2, c = threadIdx.x & 3;
+  const size_t at = (size_t)i * N + n0 + c;
+  float zz = 0.f;
+  if (threadIdx.x < 64 && i < n && act) zz = z[at];
   BiRegs<1, NT> wr;
   bi_prefetch<1, NT>(wr, W, K, row0);
-  quad_sum<1>(sum_l, scratch, g_slices, g_n, g_stride, blockIdx.x);
+  quad_finish<1, 1>(qr, sum_l, scratch, g_n, n);
   if (threadIdx.x < 64) {
-    const int i = threadIdx.x >> 2, c = threadIdx.x & 3;
     float g = 0.f;
     if (i < n) {
       g = reinterpret_cast<const float*>(sum_l)[i * 4 + c];
-      const size_t at = (size_t)i * N + n0 + c;
       g_dense[at] = g;                                                    // the weight-gradient launch applies act'(z) itself
-      if (act) g *= act_bwd(z[at], act);
+      if (act) g *= act_bwd(zz, act);
     }
     g_l[i * 4 + c] = g;
   }
   __syncthreads();
-  bi_core<1, 1, NT>(wr, g_l, slices_out + (size_t)blockIdx.x * out_stride, K);
+  bi_core<1, 1, NT>(wr, g_l, stage, slices_out + (size_t)blockIdx.x * out_stride, K, n);
 }
 
 // ============================================================================================== B3: norm backward + [Wu; Wv] rows
@@ -450,34 +559,47 @@ __global__ __launch_bounds__(DL_THREADS) void dec_uv_bwd_k(const float* __restri
                                                            const float* __restrict__ gs_res, const float* __restrict__ Wuv,
                                                            float* __restrict__ gUV, float* __restrict__ g_s2,
                                                            float* __restrict__ slices_out, long long out_stride, int n, int F) {
-  __shared__ __attribute__((aligned(16))) float4 scratch[36 * 16];
-  __shared__ __attribute__((aligned(16))) float4 gss_l[16], gsn_l[16];
-  __shared__ __attribute__((aligned(16))) float g_l[48 * 2 * 4];
+  Carve cv;
+  float* stage = cv.take(bi_stage_floats<3>());
+  float4* scratch = reinterpret_cast<float4*>(cv.take(2 * 36 * 16 * 4));
+  float4* gsum_l = reinterpret_cast<float4*>(cv.take(2 * 16 * 4));       // [0]: columns f0.. of g_stack, [1]: the norm half
+  float* g_l = cv.take(48 * 2 * 4);
   const int f0 = blockIdx.x * DL_CB;
   const int row0[2] = {f0, F + f0};
-  BiRegs<2, 2> wr;
-  bi_prefetch<2, 2>(wr, Wuv, F, row0);
-  quad_sum<1>(gss_l, scratch, gstack_slices, gs_n, gs_stride, blockIdx.x);             // columns f0 .. f0+3 of g_stack
-  quad_sum<1>(gsn_l, scratch, gstack_slices, gs_n, gs_stride, F / 4 + blockIdx.x);     // columns F + f0 .. (the norm half)
-  for (int o = threadIdx.x; o < 48 * 8; o += DL_THREADS) g_l[o] = 0.f;
-  __syncthreads();
-  if (threadIdx.x < n * 4) {
-    const int i = threadIdx.x >> 2, c = threadIdx.x & 3, f = f0 + c;
-    const size_t nf = (size_t)i * F + f;
-    g_s2[nf] = reinterpret_cast<const float*>(gss_l)[i * 4 + c] + gs_res[nf];         // S' also reaches S'' directly
-    const float t = reinterpret_cast<const float*>(gsn_l)[i * 4 + c] / stack[(size_t)i * 2 * F + F + f];
-    const size_t b = (size_t)i * 3 * 2 * F + f;
+  const int kq[2] = {(int)blockIdx.x, F / 4 + (int)blockIdx.x};
+  QuadRegs<1, 2> qr;
+  quad_issue<1, 2>(qr, gstack_slices, gs_n, gs_stride, n, kq);
+  const bool mine = threadIdx.x < n * 4;
+  const int i = threadIdx.x >> 2, c = threadIdx.x & 3, f = f0 + c;
+  const size_t nf = (size_t)i * F + f;
+  const size_t b = (size_t)i * 3 * 2 * F + f;
+  float gu[3] = {0.f, 0.f, 0.f}, gvv[3] = {0.f, 0.f, 0.f}, vv[3] = {0.f, 0.f, 0.f}, res = 0.f, nrm = 1.f;
+  if (mine) {
 #pragma unroll
     for (int xyz = 0; xyz < 3; ++xyz) {
       const size_t at = b + (size_t)xyz * 2 * F;
-      const float gvv = gUV[at + F] + t * UV[at + F];
-      gUV[at + F] = gvv;                                                  // the weight-gradient launch reads the total
-      g_l[((3 * i + xyz) * 2 + 0) * 4 + c] = gUV[at];
-      g_l[((3 * i + xyz) * 2 + 1) * 4 + c] = gvv;
+      gu[xyz] = gUV[at]; gvv[xyz] = gUV[at + F]; vv[xyz] = UV[at + F];
+    }
+    res = gs_res[nf];
+    nrm = stack[(size_t)i * 2 * F + F + f];
+  }
+  BiRegs<2, 2> wr;
+  bi_prefetch<2, 2>(wr, Wuv, F, row0);
+  for (int o = threadIdx.x; o < 48 * 8; o += DL_THREADS) g_l[o] = 0.f;
+  quad_finish<1, 2>(qr, gsum_l, scratch, gs_n, n);
+  if (mine) {
+    g_s2[nf] = reinterpret_cast<const float*>(gsum_l)[i * 4 + c] + res;              // S' also reaches S'' directly
+    const float t = reinterpret_cast<const float*>(gsum_l + 16)[i * 4 + c] / nrm;
+#pragma unroll
+    for (int xyz = 0; xyz < 3; ++xyz) {
+      const float tot = gvv[xyz] + t * vv[xyz];
+      gUV[b + (size_t)xyz * 2 * F + F] = tot;                             // the weight-gradient launch reads the total
+      g_l[((3 * i + xyz) * 2 + 0) * 4 + c] = gu[xyz];
+      g_l[((3 * i + xyz) * 2 + 1) * 4 + c] = tot;
     }
   }
   __syncthreads();
-  bi_core<3, 2, 2>(wr, g_l, slices_out + (size_t)blockIdx.x * out_stride, F);
+  bi_core<3, 2, 2>(wr, g_l, stage, slices_out + (size_t)blockIdx.x * out_stride, F, 3 * n);
 }
 
 // ============================================================================================== B4: message backward + W2 rows
@@ -491,76 +613,100 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_bwd_k(
     long long gvr_stride, const float* __restrict__ gv_res, const float* __restrict__ gvb, const float* __restrict__ W2,
     float* __restrict__ g_phi, float* __restrict__ g_s, float* __restrict__ g_sbar, float* __restrict__ g_v,
     float* __restrict__ g_vbar, float* __restrict__ gWd, float* __restrict__ gbd, float* __restrict__ slices_out,
-    long long out_stride, int n, int F) {
+    long long out_stride, int n, int F, int E) {
   constexpr int GS = geom_stride(R), U = geom_unit_offset(R);
-  __shared__ __attribute__((aligned(16))) float4 scratch[36 * 16 * 3];
-  __shared__ __attribute__((aligned(16))) float4 gvr_l[48];             // gV' rows [3 i + xyz][c]
-  __shared__ __attribute__((aligned(16))) float gphi_l[16 * 9 * 4];
-  __shared__ float gv_l[16][4][3];                                       // upstream gv at every node (receivers of other lanes' edges)
-  __shared__ float red_src[8][6][64];                                    // waves 1..8: source-side (av, avb) of the lane's node
-  __shared__ float red_rcv[9][8][64];                                    // receiver-side partials (as, asb, av, avb)
+  Carve cv;
+  float* stage = cv.take(bi_stage_floats<1>());
+  float4* scratch = reinterpret_cast<float4*>(stage);                    // the slice sum is over before the product stages its tiles
+  static_assert(bi_stage_floats<1>() >= 36 * 16 * 3 * 4, "scratch aliases the stage");
+  float4* gvr_l = reinterpret_cast<float4*>(cv.take(48 * 4));           // gV' rows [3 i + xyz][c]
+  float* gphi_l = cv.take(16 * 9 * 4);
+  float* phi_l = cv.take(16 * 9 * 4);
+  float* red_src = cv.take(8 * 6 * 64);                                  // waves 1..8: source-side (av, avb) of the lane's node
+  float* red_rcv = cv.take(9 * 8 * 64);                                  // receiver-side partials (as, asb, av, avb)
+  float* geomd_l = cv.take((size_t)DL_MAX_EDGES * GS);
+  float* geoms_l = cv.take((size_t)DL_MAX_EDGES * GS);
+  int* rpd_l = reinterpret_cast<int*>(cv.take(20)); int* rps_l = reinterpret_cast<int*>(cv.take(20));
+  int* srcd_l = reinterpret_cast<int*>(cv.take(DL_MAX_EDGES)); int* dsts_l = reinterpret_cast<int*>(cv.take(DL_MAX_EDGES));
+  float* s_l = cv.take(64); float* sb_l = cv.take(64); float* gh_l = cv.take(64); float* ghb_l = cv.take(64);
+  float* v_l = cv.take(192); float* vb_l = cv.take(192); float* gv_l = cv.take(192); float* gvb_l = cv.take(192);
+  float* gvres_l = cv.take(192);
   const int f0 = blockIdx.x * DL_CB;
   int row0[9];
 #pragma unroll
   for (int g = 0; g < 9; ++g) row0[g] = g * F + f0;
-  BiRegs<9, 2> wr;
-  bi_prefetch<9, 2>(wr, W2, F, row0);
+  DL_TICK(0);
+  // order of requests: slices, then the bead graph / node state (consumed right away), the weights last
+  QuadRegs<3, 1> qr;
+  { const int kq[1] = {(int)blockIdx.x}; quad_issue<3, 1>(qr, gvrows_slices, gvr_n, gvr_stride, 3 * n, kq); }
   const int lane = threadIdx.x & 63;
   const int k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int node = lane >> 2, c = lane & 3, f = f0 + c;
   const bool live = node < n;
   const int nc = live ? node : 0;
-  const size_t jf = (size_t)nc * F + f;
+  // bead graph, node state and upstream gradients of these channels -> LDS, one batch
+  stage_copy4(geomd_l, geom_d, E * GS / 4);
+  stage_copy4(geoms_l, geom_s, E * GS / 4);
+  stage_ints(rpd_l, rowptr_d, n + 1); stage_ints(rps_l, rowptr_s, n + 1);
+  stage_ints(srcd_l, src_d, E); stage_ints(dsts_l, dst_s, E);
+  stage_scalar(s_l, s, n, F, f0); stage_scalar(sb_l, sbar, n, F, f0);
+  stage_scalar(gh_l, gh, n, F, f0); stage_scalar(ghb_l, ghb, n, F, f0);
+  stage_vector(v_l, v, n, F, f0); stage_vector(vb_l, vbar, n, F, f0);
+  stage_vector(gvb_l, gvb, n, F, f0); stage_vector(gvres_l, gv_res, n, F, f0);
+  for (int o = threadIdx.x; o < n * 9; o += DL_THREADS) {
+    const int m = o / 9, g = o - m * 9;
+    *reinterpret_cast<float4*>(phi_l + (m * 9 + g) * 4) = *reinterpret_cast<const float4*>(phi + (size_t)m * 9 * F + (size_t)g * F + f0);
+  }
   float W[R + 1], G[R + 1];
 #pragma unroll
   for (int nn = 0; nn < R; ++nn) W[nn] = Wd[((size_t)k * F + f) * R + nn];
   W[R] = bd[(size_t)k * F + f];
 #pragma unroll
   for (int nn = 0; nn <= R; ++nn) G[nn] = 0.f;
-  // this lane's node as SOURCE j and as RECEIVER i (state of channel f)
-  const float p_j = phi[(size_t)nc * 9 * F + (size_t)k * F + f];
-  const float s_n = s[jf], sb_n = sbar[jf];
-  const dv3 v_n = dldv(v + jf * 3), vb_n = dldv(vbar + jf * 3);
-  const float gh_n = gh ? gh[jf] : 0.f, ghb_n = ghb ? ghb[jf] : 0.f;
-  const dv3 gvb_n = gvb ? dldv(gvb + jf * 3) : dv3{0.f, 0.f, 0.f};
+  DL_TICK(1);
+  BiRegs<9, 1> wr;
+  bi_prefetch<9, 1>(wr, W2, F, row0);
   // gV' = sum of the slices of B3 (rows 3 i + xyz) + the residual path V' -> V''
-  quad_sum<3>(gvr_l, scratch, gvrows_slices, gvr_n, gvr_stride, blockIdx.x);
+  quad_finish<3, 1>(qr, gvr_l, scratch, gvr_n, 3 * n);
   if (threadIdx.x < 64) {
-    dv3 t{0.f, 0.f, 0.f};
-    if (live) {
-      const float* gr = reinterpret_cast<const float*>(gvr_l);
-      t = dv3{gr[(3 * node + 0) * 4 + c], gr[(3 * node + 1) * 4 + c], gr[(3 * node + 2) * 4 + c]};
-      if (gv_res) { const f3 r = ld3(gv_res + jf * 3); t.x += r.x; t.y += r.y; t.z += r.z; }
-    }
-    gv_l[node][c][0] = t.x; gv_l[node][c][1] = t.y; gv_l[node][c][2] = t.z;
+    const float* gr = reinterpret_cast<const float*>(gvr_l);
+#pragma unroll
+    for (int xyz = 0; xyz < 3; ++xyz)
+      gv_l[(node * 4 + c) * 3 + xyz] = live ? gr[(3 * node + xyz) * 4 + c] + gvres_l[(node * 4 + c) * 3 + xyz] : 0.f;
   }
   __syncthreads();
-  const dv3 gv_n{gv_l[node][c][0], gv_l[node][c][1], gv_l[node][c][2]};
+  DL_TICK(2);
+  const float p_j = phi_l[(nc * 9 + k) * 4 + c];
+  const float s_n = s_l[nc * 4 + c], sb_n = sb_l[nc * 4 + c];
+  const dv3 v_n = lds_v3(v_l + (nc * 4 + c) * 3), vb_n = lds_v3(vb_l + (nc * 4 + c) * 3);
+  const float gh_n = gh_l[nc * 4 + c], ghb_n = ghb_l[nc * 4 + c];
+  const dv3 gvb_n = lds_v3(gvb_l + (nc * 4 + c) * 3), gv_n = lds_v3(gv_l + (nc * 4 + c) * 3);
+  (void)s_n;
   // ---- pass B: the lane's node as source j, edges of the src-sorted view (pseudo_msg.hip: pseudo_bwd_src_k)
   float a = 0.f;
   dv3 av{0.f, 0.f, 0.f}, avb{0.f, 0.f, 0.f};
   {
-    const int e_beg = live ? rowptr_s[node] : 0, e_end = live ? rowptr_s[node + 1] : 0;
+    const int e_beg = live ? rps_l[node] : 0, e_end = live ? rps_l[node + 1] : 0;
     for (int e = e_beg; e < e_end; ++e) {
-      const float* __restrict__ g = geom_s + (size_t)e * GS;
-      const int i = dst_s[e];
-      const size_t nf = (size_t)i * F + f;
+      const float* __restrict__ g = geoms_l + (size_t)e * GS;
+      const int i = dsts_l[e];
+      const int ic = i * 4 + c;
       const dv3 zero{0.f, 0.f, 0.f};
-      const dv3 gv_i{gv_l[i][c][0], gv_l[i][c][1], gv_l[i][c][2]};
+      const dv3 gv_i = lds_v3(gv_l + ic * 3);
       float gq = 0.f;
       dv3 cav = zero, cavb = zero;
       switch (k) {                                   // wave-uniform
-        case 0: gq = (gh ? gh[nf] : 0.f) * s[nf]; break;
+        case 0: gq = gh_l[ic] * s_l[ic]; break;
         case 1: gq = ddot(gv_i, dv3{g[U], g[U + 1], g[U + 2]}); break;
         case 2: gq = ddot(gv_i, v_n); cav = gv_i; break;
-        case 3: { const dv3 v_i = dldv(v + nf * 3); gq = ddot(gv_i, dcross(v_i, vb_n)); cavb = dcross(gv_i, v_i); break; }
-        case 4: { const float sb_i = sbar[nf]; gq = sb_i * ddot(gv_i, vb_n); cavb = dv3{sb_i * gv_i.x, sb_i * gv_i.y, sb_i * gv_i.z}; break; }
-        case 5: { const dv3 gvb_i = gvb ? dldv(gvb + nf * 3) : zero; gq = ddot(gvb_i, vb_n); cavb = gvb_i; break; }
-        case 6: { const dv3 gvb_i = gvb ? dldv(gvb + nf * 3) : zero; const float sb_i = sbar[nf];
+        case 3: { const dv3 v_i = lds_v3(v_l + ic * 3); gq = ddot(gv_i, dcross(v_i, vb_n)); cavb = dcross(gv_i, v_i); break; }
+        case 4: { const float sb_i = sb_l[ic]; gq = sb_i * ddot(gv_i, vb_n); cavb = dv3{sb_i * gv_i.x, sb_i * gv_i.y, sb_i * gv_i.z}; break; }
+        case 5: { const dv3 gvb_i = lds_v3(gvb_l + ic * 3); gq = ddot(gvb_i, vb_n); cavb = gvb_i; break; }
+        case 6: { const dv3 gvb_i = lds_v3(gvb_l + ic * 3); const float sb_i = sb_l[ic];
                   gq = sb_i * ddot(gvb_i, v_n); cav = dv3{sb_i * gvb_i.x, sb_i * gvb_i.y, sb_i * gvb_i.z}; break; }
-        case 7: { const dv3 gvb_i = gvb ? dldv(gvb + nf * 3) : zero; const dv3 v_i = dldv(v + nf * 3);
+        case 7: { const dv3 gvb_i = lds_v3(gvb_l + ic * 3); const dv3 v_i = lds_v3(v_l + ic * 3);
                   gq = ddot(gvb_i, dcross(v_i, v_n)); cav = dcross(gvb_i, v_i); break; }
-        default: { const dv3 gvb_i = gvb ? dldv(gvb + nf * 3) : zero; const dv3 vb_i = dldv(vbar + nf * 3);
+        default: { const dv3 gvb_i = lds_v3(gvb_l + ic * 3); const dv3 vb_i = lds_v3(vb_l + ic * 3);
                    gq = ddot(gvb_i, dcross(vb_i, vb_n)); cavb = dcross(gvb_i, vb_i); break; }
       }
       const float w = dfilt<R>(W, g);
@@ -571,12 +717,13 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_bwd_k(
       const float q = p_j * w;
       daxpy(av, q, cav);
       daxpy(avb, q, cavb);
-      if (k == 0 && ghb) daxpy(avb, ghb[nf], dldv(v + nf * 3));            // the filter-free term ghb_i v_i
+      if (k == 0) daxpy(avb, ghb_l[ic], lds_v3(v_l + ic * 3));            // the filter-free term ghb_i v_i
     }
   }
+  DL_TICK(3);
   gphi_l[(node * 9 + k) * 4 + c] = live ? a : 0.f;
   if (k > 0) {
-    float* r = &red_src[k - 1][0][lane];
+    float* r = red_src + (size_t)(k - 1) * 6 * 64 + lane;
     r[0] = av.x; r[64] = av.y; r[128] = av.z; r[192] = avb.x; r[256] = avb.y; r[320] = avb.z;
   }
   // filter gradients: sum over the source nodes (lanes node*4 + c, fixed butterfly order), written once per block
@@ -596,27 +743,29 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_bwd_k(
   float as = 0.f, asb = 0.f;
   dv3 rv{0.f, 0.f, 0.f}, rvb{0.f, 0.f, 0.f};
   if (k == 0 || k == 1 || k == 3 || k == 4 || k == 6 || k == 7 || k == 8) {
-    const int e_beg = live ? rowptr_d[node] : 0, e_end = live ? rowptr_d[node + 1] : 0;
+    const int e_beg = live ? rpd_l[node] : 0, e_end = live ? rpd_l[node + 1] : 0;
     for (int e = e_beg; e < e_end; ++e) {
-      const int j = src_d[e];
-      if (k == 1) { daxpy(rv, ghb_n, dldv(vbar + ((size_t)j * F + f) * 3)); continue; }
-      const float* __restrict__ g = geom_d + (size_t)e * GS;
-      const float q = phi[(size_t)j * 9 * F + (size_t)k * F + f] * dfilt<R>(W, g);
+      const int jc = srcd_l[e] * 4 + c;
+      if (k == 1) { daxpy(rv, ghb_n, lds_v3(vb_l + jc * 3)); continue; }
+      const float* __restrict__ g = geomd_l + (size_t)e * GS;
+      const float q = phi_l[(srcd_l[e] * 9 + k) * 4 + c] * dfilt<R>(W, g);
       switch (k) {
         case 0: as = fmaf(gh_n, q, as); break;
-        case 3: daxpy(rv, q, dcross(dldv(vbar + ((size_t)j * F + f) * 3), gv_n)); break;
-        case 4: asb = fmaf(q, ddot(gv_n, dldv(vbar + ((size_t)j * F + f) * 3)), asb); break;
-        case 6: asb = fmaf(q, ddot(gvb_n, dldv(v + ((size_t)j * F + f) * 3)), asb); break;
-        case 7: daxpy(rv, q, dcross(dldv(v + ((size_t)j * F + f) * 3), gvb_n)); break;
-        default: daxpy(rvb, q, dcross(dldv(vbar + ((size_t)j * F + f) * 3), gvb_n)); break;
+        case 3: daxpy(rv, q, dcross(lds_v3(vb_l + jc * 3), gv_n)); break;
+        case 4: asb = fmaf(q, ddot(gv_n, lds_v3(vb_l + jc * 3)), asb); break;
+        case 6: asb = fmaf(q, ddot(gvb_n, lds_v3(v_l + jc * 3)), asb); break;
+        case 7: daxpy(rv, q, dcross(lds_v3(v_l + jc * 3), gvb_n)); break;
+        default: daxpy(rvb, q, dcross(lds_v3(vb_l + jc * 3), gvb_n)); break;
       }
     }
   }
   {
-    float* r = &red_rcv[k][0][lane];
+    float* r = red_rcv + (size_t)k * 8 * 64 + lane;
     r[0] = as; r[64] = asb; r[128] = rv.x; r[192] = rv.y; r[256] = rv.z; r[320] = rvb.x; r[384] = rvb.y; r[448] = rvb.z;
   }
+  DL_TICK(4);
   __syncthreads();
+  DL_TICK(5);
   // g_phi: dense copy for the weight-gradient launch
   for (int o = threadIdx.x; o < n * 9; o += DL_THREADS) {
     const int m = o / 9, g = o - m * 9;
@@ -628,7 +777,7 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_bwd_k(
     dv3 tv = gv_n, tvb = gvb_n;
 #pragma unroll
     for (int w = 0; w < 9; ++w) {
-      const float* r = &red_rcv[w][0][lane];
+      const float* r = red_rcv + (size_t)w * 8 * 64 + lane;
       ts += r[0]; tsb += r[64];
       tv.x += r[128]; tv.y += r[192]; tv.z += r[256];
       tvb.x += r[320]; tvb.y += r[384]; tvb.z += r[448];
@@ -637,39 +786,53 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_bwd_k(
     tvb.x += avb.x; tvb.y += avb.y; tvb.z += avb.z;
 #pragma unroll
     for (int w = 0; w < 8; ++w) {
-      const float* r = &red_src[w][0][lane];
+      const float* r = red_src + (size_t)w * 6 * 64 + lane;
       tv.x += r[0]; tv.y += r[64]; tv.z += r[128]; tvb.x += r[192]; tvb.y += r[256]; tvb.z += r[320];
     }
+    const size_t jf = (size_t)node * F + f;
     g_s[jf] = ts;
     g_sbar[jf] = tsb;
     st3(g_v + jf * 3, tv.x, tv.y, tv.z);
     st3(g_vbar + jf * 3, tvb.x, tvb.y, tvb.z);
   }
-  bi_core<1, 9, 2>(wr, gphi_l, slices_out + (size_t)blockIdx.x * out_stride, F);
+  DL_TICK(6);
+  bi_core<1, 9, 2, 1>(wr, gphi_l, stage, slices_out + (size_t)blockIdx.x * out_stride, F, n, W2, row0);
+  DL_TICK(7);
 }
 
-// out[m][f] = base[m][f] + sum_s slices[s][f/4][m][f%4]: the decoder input's gradient leaves the slice format here
-__global__ __launch_bounds__(256) void dec_quad_to_dense_k(const float* __restrict__ base, const float* __restrict__ slices,
-                                                           int n_slices, long long stride, float* __restrict__ out, int n,
-                                                           int F) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;          // (kq, m): one float4 of the output
-  const int Fq = F / 4;
-  if (idx >= Fq * n) return;
-  const int kq = idx / n, m = idx - kq * n;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (base) acc = *reinterpret_cast<const float4*>(base + (size_t)m * F + 4 * kq);
-  constexpr int SB = 8;
-  for (int s0 = 0; s0 < n_slices; s0 += SB) {
-    float4 v[SB];
-#pragma unroll
-    for (int u = 0; u < SB; ++u) v[u] = *reinterpret_cast<const float4*>(slices + (size_t)min(s0 + u, n_slices - 1) * stride + ((size_t)kq * 16 + m) * 4);
-#pragma unroll
-    for (int u = 0; u < SB; ++u)
-      if (s0 + u < n_slices) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+// out[m][4 kq ..] = base + sum_s slices[s][kq][m][:]: the decoder input's gradient leaves the slice format here
+__global__ __launch_bounds__(DL_THREADS) void dec_quad_to_dense_k(const float* __restrict__ base, const float* __restrict__ slices,
+                                                                  int n_slices, long long stride, float* __restrict__ out, int n,
+                                                                  int F) {
+  Carve cv;
+  float4* scratch = reinterpret_cast<float4*>(cv.take(36 * 16 * 4));
+  float4* sum_l = reinterpret_cast<float4*>(cv.take(16 * 4));
+  const int kq[1] = {(int)blockIdx.x};
+  QuadRegs<1, 1> qr;
+  quad_issue<1, 1>(qr, slices, n_slices, stride, n, kq);
+  quad_finish<1, 1>(qr, sum_l, scratch, n_slices, n);
+  if (threadIdx.x < n) {
+    float4 t = sum_l[threadIdx.x];
+    if (base) {
+      const float4 b = *reinterpret_cast<const float4*>(base + (size_t)threadIdx.x * F + 4 * blockIdx.x);
+      t.x += b.x; t.y += b.y; t.z += b.z; t.w += b.w;
+    }
+    *reinterpret_cast<float4*>(out + (size_t)threadIdx.x * F + 4 * blockIdx.x) = t;
   }
-  *reinterpret_cast<float4*>(out + (size_t)m * F + 4 * kq) = acc;
 }
 
+}  // namespace cgv
+
+namespace cgv {
+// dynamic LDS per kernel (floats, mirroring the Carve sequence of each kernel) + slack for the 16-byte rounding
+static size_t lds_bytes(size_t floats) { return floats * 4 + 512; }
+template <typename Kern>
+static int allow_lds(Kern kern, size_t bytes) {
+  if (bytes <= 64 * 1024) return 0;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) { cgv::set_error("hipFuncSetAttribute(%zu bytes of LDS): %s", bytes, hipGetErrorString(e)); return (int)e; }
+  return 0;
+}
 }  // namespace cgv
 
 extern "C" {
@@ -678,11 +841,19 @@ int cgv_decoder_layer_supported(int n_nodes, int n_feat, int n_rbf) {
   return n_nodes >= 1 && n_nodes <= cgv::DL_MAX_NODES && n_feat >= 16 && (n_feat % 4) == 0 && n_feat <= 864 &&
          cgv_rbf_supported(n_rbf);
 }
+int cgv_decoder_max_edges(void) { return cgv::DL_MAX_EDGES; }
+/* measurement: block 0 of cgv_decoder_msg_bwd stores the GPU wall clock at its phase boundaries into buf[0..7] (NULL: off) */
+int cgv_decoder_debug_clock(uint64_t* buf) {
+  unsigned long long* p = reinterpret_cast<unsigned long long*>(buf);
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(cgv::g_dl_clock), &p, sizeof(p));
+  return e == hipSuccess ? 0 : (int)e;
+}
 
-/* floats of one slice of a phase's output: (K / 4) column quads x 16 (or 48) rows x 4 */
-int64_t cgv_decoder_slice_floats(int K, int rows48) { return (int64_t)(K / 4) * (rows48 ? 48 : 16) * 4; }
+/* floats of one slice of a phase's output: (K / 4) column quads x rows x 4 */
+int64_t cgv_decoder_slice_floats(int K, int rows) { return (int64_t)K * rows; }
 
-#define CGV_DL_CHECK(name)                                                                                    \
+
+#define CGV_DL_CHECK()                                                                                        \
   CGV_REQUIRE(cgv_decoder_layer_supported(n_nodes, n_feat, n_rbf), "unsupported shape (n <= 16 nodes, F % 4 == 0, 16 <= F <= 864)"); \
   hipStream_t st = (hipStream_t)stream;                                                                       \
   const int blocks = n_feat / cgv::DL_CB
@@ -690,13 +861,18 @@ int64_t cgv_decoder_slice_floats(int K, int rows48) { return (int64_t)(K / 4) * 
 int cgv_decoder_msg_fwd(const float* a1, const float* W2, const float* b2, const float* s, const float* sbar, const float* v,
                         const float* vbar, const float* geom_d, const int32_t* rowptr_d, const int32_t* src_d, const float* Wd,
                         const float* bd, float* phi, float* stack, float* sbar_out, float* v_out, float* vbar_out,
-                        float* rows_out, int n_nodes, int n_feat, int n_rbf, void* stream) {
+                        float* rows_out, int n_nodes, int n_feat, int n_rbf, int n_edges, void* stream) {
   CGV_REQUIRE(a1 && W2 && b2 && s && sbar && v && vbar && geom_d && rowptr_d && src_d && Wd && bd, "null input");
   CGV_REQUIRE(phi && stack && sbar_out && v_out && vbar_out && rows_out, "null output");
+  CGV_REQUIRE(n_edges >= 0 && n_edges <= cgv::DL_MAX_EDGES, "too many edges for the staged bead graph");
   CGV_DL_CHECK();
-  CGV_DISPATCH_RBF(n_rbf, hipLaunchKernelGGL((cgv::dec_msg_fwd_k<RBF>), dim3(blocks), dim3(cgv::DL_THREADS), 0, st, a1, W2, b2,
-                                             s, sbar, v, vbar, geom_d, rowptr_d, src_d, Wd, bd, phi, stack, sbar_out, v_out,
-                                             vbar_out, rows_out, n_nodes, n_feat));
+  const size_t lds = cgv::lds_bytes(cgv::fwd_red_floats<1, 9>() + 576 + 1536 + (size_t)cgv::DL_MAX_EDGES * cgv::geom_stride(n_rbf) + 20 +
+                               cgv::DL_MAX_EDGES + 128 + 384);
+  CGV_DISPATCH_RBF(n_rbf, {
+    if (int rc = cgv::allow_lds(cgv::dec_msg_fwd_k<RBF>, lds)) return rc;
+    hipLaunchKernelGGL((cgv::dec_msg_fwd_k<RBF>), dim3(blocks), dim3(cgv::DL_THREADS), lds, st, a1, W2, b2, s, sbar, v, vbar, geom_d,
+                       rowptr_d, src_d, Wd, bd, phi, stack, sbar_out, v_out, vbar_out, rows_out, n_nodes, n_feat, n_edges);
+  });
   return cgv::check_launch("cgv_decoder_msg_fwd");
 }
 
@@ -704,7 +880,8 @@ int cgv_decoder_uv_fwd(const float* rows, const float* Wuv, float* UV, float* st
   CGV_REQUIRE(rows && Wuv && UV && stack, "null pointer");
   const int n_rbf = 8;
   CGV_DL_CHECK();
-  hipLaunchKernelGGL(cgv::dec_uv_fwd_k, dim3(blocks), dim3(cgv::DL_THREADS), 0, st, rows, Wuv, UV, stack, n_nodes, n_feat);
+  hipLaunchKernelGGL(cgv::dec_uv_fwd_k, dim3(blocks), dim3(cgv::DL_THREADS), cgv::lds_bytes(cgv::fwd_red_floats<3, 2>() + 384), st, rows,
+                     Wuv, UV, stack, n_nodes, n_feat);
   return cgv::check_launch("cgv_decoder_uv_fwd");
 }
 
@@ -713,8 +890,8 @@ int cgv_decoder_gate_fwd(const float* a0, const float* W1p, const float* b1p, co
   CGV_REQUIRE(a0 && W1p && b1p && UV && stack && v2 && a && s3 && v3, "null pointer");
   const int n_rbf = 8;
   CGV_DL_CHECK();
-  hipLaunchKernelGGL(cgv::dec_gate_fwd_k, dim3(blocks), dim3(cgv::DL_THREADS), 0, st, a0, W1p, b1p, UV, stack, v2, a, s3, v3,
-                     n_nodes, n_feat);
+  hipLaunchKernelGGL(cgv::dec_gate_fwd_k, dim3(blocks), dim3(cgv::DL_THREADS), cgv::lds_bytes(cgv::fwd_red_floats<1, 3>() + 192), st, a0,
+                     W1p, b1p, UV, stack, v2, a, s3, v3, n_nodes, n_feat);
   return cgv::check_launch("cgv_decoder_gate_fwd");
 }
 
@@ -722,10 +899,11 @@ int cgv_decoder_gate_bwd(const float* UV, const float* a, const float* gs_base, 
                          int64_t gs_slice_stride, const float* gv, const float* W1p, float* ga, float* gUV, float* gs_sum,
                          float* slices_out, int64_t out_slice_stride, int n_nodes, int n_feat, void* stream) {
   CGV_REQUIRE(UV && a && W1p && ga && gUV && gs_sum && slices_out, "null pointer");
-  CGV_REQUIRE(gs_n_slices >= 0 && out_slice_stride >= cgv_decoder_slice_floats(n_feat, 0), "bad slices");
+  CGV_REQUIRE(gs_n_slices >= 0 && out_slice_stride >= cgv_decoder_slice_floats(n_feat, n_nodes), "bad slices");
   const int n_rbf = 8;
   CGV_DL_CHECK();
-  hipLaunchKernelGGL(cgv::dec_gate_bwd_k, dim3(blocks), dim3(cgv::DL_THREADS), 0, st, UV, a, gs_base, gs_slices, gs_n_slices,
+  hipLaunchKernelGGL(cgv::dec_gate_bwd_k, dim3(blocks), dim3(cgv::DL_THREADS),
+                     cgv::lds_bytes(cgv::bi_stage_floats<1>() + 2304 + 64 + 192), st, UV, a, gs_base, gs_slices, gs_n_slices,
                      (long long)gs_slice_stride, gv, W1p, ga, gUV, gs_sum, slices_out, (long long)out_slice_stride, n_nodes,
                      n_feat);
   return cgv::check_launch("cgv_decoder_gate_bwd");
@@ -736,12 +914,13 @@ int cgv_decoder_dense_bwd(const float* g_slices, int g_n_slices, int64_t g_slice
   CGV_REQUIRE(g_slices && W && g_dense && slices_out && g_n_slices >= 1, "null pointer");
   CGV_REQUIRE(act == 0 || (act >= 1 && act <= cgv::CGV_ACT_MAX && z), "act != 0 needs the saved pre-activation z");
   CGV_REQUIRE(n_nodes >= 1 && n_nodes <= cgv::DL_MAX_NODES && (N % 4) == 0 && (K % 4) == 0 && K <= 64 * 27 && N >= 4, "unsupported shape");
-  CGV_REQUIRE(out_slice_stride >= cgv_decoder_slice_floats(K, 0), "bad slices");
+  CGV_REQUIRE(out_slice_stride >= cgv_decoder_slice_floats(K, n_nodes), "bad slices");
   hipStream_t st = (hipStream_t)stream;
   const int blocks = N / cgv::DL_CB;
   const int tiles = (K + 63) / 64;
+  const size_t lds = cgv::lds_bytes(cgv::bi_stage_floats<1>() + 2304 + 64 + 64);
 #define CGV_DL_DENSE(NTV)                                                                                                \
-  hipLaunchKernelGGL((cgv::dec_dense_bwd_k<NTV>), dim3(blocks), dim3(cgv::DL_THREADS), 0, st, g_slices, g_n_slices,       \
+  hipLaunchKernelGGL((cgv::dec_dense_bwd_k<NTV>), dim3(blocks), dim3(cgv::DL_THREADS), lds, st, g_slices, g_n_slices,     \
                      (long long)g_slice_stride, z, act, W, g_dense, slices_out, (long long)out_slice_stride, n_nodes, N, K)
   if (tiles <= 9) CGV_DL_DENSE(1); else if (tiles <= 18) CGV_DL_DENSE(2); else CGV_DL_DENSE(3);
 #undef CGV_DL_DENSE
@@ -752,10 +931,12 @@ int cgv_decoder_uv_bwd(const float* gstack_slices, int n_slices, int64_t slice_s
                        const float* gs_res, const float* Wuv, float* gUV, float* g_s2, float* slices_out,
                        int64_t out_slice_stride, int n_nodes, int n_feat, void* stream) {
   CGV_REQUIRE(gstack_slices && UV && stack && gs_res && Wuv && gUV && g_s2 && slices_out && n_slices >= 1, "null pointer");
-  CGV_REQUIRE(out_slice_stride >= cgv_decoder_slice_floats(n_feat, 1), "bad slices");
+  CGV_REQUIRE(out_slice_stride >= cgv_decoder_slice_floats(n_feat, 3 * n_nodes), "bad slices");
   const int n_rbf = 8;
   CGV_DL_CHECK();
-  hipLaunchKernelGGL(cgv::dec_uv_bwd_k, dim3(blocks), dim3(cgv::DL_THREADS), 0, st, gstack_slices, n_slices,
+  const size_t lds = cgv::lds_bytes(cgv::bi_stage_floats<3>() + 4608 + 128 + 384);
+  if (int rc = cgv::allow_lds(cgv::dec_uv_bwd_k, lds)) return rc;
+  hipLaunchKernelGGL(cgv::dec_uv_bwd_k, dim3(blocks), dim3(cgv::DL_THREADS), lds, st, gstack_slices, n_slices,
                      (long long)slice_stride, UV, stack, gs_res, Wuv, gUV, g_s2, slices_out, (long long)out_slice_stride,
                      n_nodes, n_feat);
   return cgv::check_launch("cgv_decoder_uv_bwd");
@@ -767,26 +948,30 @@ int cgv_decoder_msg_bwd(const float* phi, const float* s, const float* sbar, con
                         const float* ghb, const float* gvrows_slices, int n_slices, int64_t slice_stride, const float* gv_res,
                         const float* gvb, const float* W2, float* g_phi, float* g_s, float* g_sbar, float* g_v, float* g_vbar,
                         float* gWd, float* gbd, float* slices_out, int64_t out_slice_stride, int n_nodes, int n_feat, int n_rbf,
-                        void* stream) {
+                        int n_edges, void* stream) {
   CGV_REQUIRE(phi && s && sbar && v && vbar && geom_d && rowptr_d && src_d && geom_s && rowptr_s && dst_s && Wd && bd && W2,
               "null input");
   CGV_REQUIRE(gvrows_slices && n_slices >= 1 && g_phi && g_s && g_sbar && g_v && g_vbar && gWd && gbd && slices_out, "null pointer");
-  CGV_REQUIRE(out_slice_stride >= cgv_decoder_slice_floats(n_feat, 0), "bad slices");
+  CGV_REQUIRE(out_slice_stride >= cgv_decoder_slice_floats(n_feat, n_nodes), "bad slices");
+  CGV_REQUIRE(n_edges >= 0 && n_edges <= cgv::DL_MAX_EDGES, "too many edges for the staged bead graph");
   CGV_DL_CHECK();
-  CGV_DISPATCH_RBF(n_rbf, hipLaunchKernelGGL((cgv::dec_msg_bwd_k<RBF>), dim3(blocks), dim3(cgv::DL_THREADS), 0, st, phi, s, sbar,
-                                             v, vbar, geom_d, rowptr_d, src_d, geom_s, rowptr_s, dst_s, Wd, bd, gh, ghb,
-                                             gvrows_slices, n_slices, (long long)slice_stride, gv_res, gvb, W2, g_phi, g_s,
-                                             g_sbar, g_v, g_vbar, gWd, gbd, slices_out, (long long)out_slice_stride, n_nodes,
-                                             n_feat));
+  const size_t lds = cgv::lds_bytes(cgv::bi_stage_floats<1>() + 192 + 576 + 576 + 3072 + 4608 +
+                               2 * (size_t)cgv::DL_MAX_EDGES * cgv::geom_stride(n_rbf) + 40 + 2 * cgv::DL_MAX_EDGES + 256 + 960);
+  CGV_DISPATCH_RBF(n_rbf, {
+    if (int rc = cgv::allow_lds(cgv::dec_msg_bwd_k<RBF>, lds)) return rc;
+    hipLaunchKernelGGL((cgv::dec_msg_bwd_k<RBF>), dim3(blocks), dim3(cgv::DL_THREADS), lds, st, phi, s, sbar, v, vbar, geom_d,
+                       rowptr_d, src_d, geom_s, rowptr_s, dst_s, Wd, bd, gh, ghb, gvrows_slices, n_slices, (long long)slice_stride,
+                       gv_res, gvb, W2, g_phi, g_s, g_sbar, g_v, g_vbar, gWd, gbd, slices_out, (long long)out_slice_stride,
+                       n_nodes, n_feat, n_edges);
+  });
   return cgv::check_launch("cgv_decoder_msg_bwd");
 }
 
 int cgv_decoder_slices_to_dense(const float* base, const float* slices, int n_slices, int64_t slice_stride, float* out,
                                 int n_nodes, int n_feat, void* stream) {
   CGV_REQUIRE(slices && out && n_slices >= 1 && n_nodes >= 1 && n_nodes <= 16 && (n_feat % 4) == 0, "bad argument");
-  const int total = (n_feat / 4) * n_nodes;
-  hipLaunchKernelGGL(cgv::dec_quad_to_dense_k, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, base, slices,
-                     n_slices, (long long)slice_stride, out, n_nodes, n_feat);
+  hipLaunchKernelGGL(cgv::dec_quad_to_dense_k, dim3(n_feat / 4), dim3(cgv::DL_THREADS), cgv::lds_bytes(2304 + 64),
+                     (hipStream_t)stream, base, slices, n_slices, (long long)slice_stride, out, n_nodes, n_feat);
   return cgv::check_launch("cgv_decoder_slices_to_dense");
 }
 

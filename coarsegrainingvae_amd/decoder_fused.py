@@ -61,7 +61,7 @@ def usable(decoder, S: torch.Tensor, plan, geom) -> bool:
     ok = lambda M, N, K: bool(lib.cgv_skinny_supported(M, N, K))
     if not (ok(n, F, F) and ok(n, F, 2 * F)):
         return False
-    if plan.n_dst != n or plan.n_src != n:
+    if plan.n_dst != n or plan.n_src != n or plan.n_edges > lib.cgv_decoder_max_edges():
         return False
     for mb, ub in zip(decoder.message_blocks, decoder.update_blocks):
         im = mb.inv_message
@@ -104,7 +104,7 @@ class _PseudoDecoderFn(torch.autograd.Function):
             _lib.call("cgv_decoder_msg_fwd", _lib.ptr(a1), _lib.ptr(W2), _lib.ptr(b2), _lib.ptr(S), _lib.ptr(Sbar), _lib.ptr(V),
                       _lib.ptr(Vbar), _lib.ptr(geom.geom_d), _lib.ptr(plan.rowptr_d), _lib.ptr(plan.src_d), _lib.ptr(Wd),
                       _lib.ptr(bd), _lib.ptr(phi), _lib.ptr(stack), _lib.ptr(Sbar2), _lib.ptr(V2), _lib.ptr(Vbar2), _lib.ptr(rows),
-                      n, F, R, st, tag=f"pseudo_msg_fwd:Nd{n}:E{plan.n_edges}:dv1")
+                      n, F, R, plan.n_edges, st, tag=f"pseudo_msg_fwd:Nd{n}:E{plan.n_edges}:dv1")
             UV = new(3 * n, 2 * F)
             _lib.call("cgv_decoder_uv_fwd", _lib.ptr(rows), _lib.ptr(Wuv), _lib.ptr(UV), _lib.ptr(stack), n, F, st)
             z0, a0, a = new(n, F), new(n, F), new(n, 3 * F)
@@ -131,8 +131,8 @@ class _PseudoDecoderFn(torch.autograd.Function):
         new = lambda *shape: torch.empty(*shape, dtype=_F32, device=dev)
         lib = _lib.load()
         nb = F // 4                                             # blocks = slices of every phase (N / 4 for the dense phases)
-        fl16 = lambda K: int(lib.cgv_decoder_slice_floats(K, 0))
-        fl48 = int(lib.cgv_decoder_slice_floats(F, 1))
+        fl16 = lambda K: int(lib.cgv_decoder_slice_floats(K, n))
+        fl48 = int(lib.cgv_decoder_slice_floats(F, 3 * n))
         gS = Slices(gS_out.contiguous() if gS_out is not None else None)
         gV = gV_out.contiguous() if gV_out is not None else None
         gSbar = gVbar = None
@@ -171,7 +171,7 @@ class _PseudoDecoderFn(torch.autograd.Function):
                       _lib.ptr(plan.rowptr_s), _lib.ptr(plan.dst_s), _lib.ptr(pWd.detach()), _lib.ptr(pbd.detach()),
                       _lib.ptr(g_s2), _lib.ptr(gSbar), _lib.ptr(p3), nb, fl48, _lib.ptr(gV), _lib.ptr(gVbar), _lib.ptr(pW2.detach()),
                       _lib.ptr(g_phi), _lib.ptr(g_s), _lib.ptr(g_sbar), _lib.ptr(g_v), _lib.ptr(g_vbar), _lib.ptr(tWd), _lib.ptr(tbd),
-                      _lib.ptr(p4), fl16(F), n, F, R, st, tag=f"pseudo_msg_bwd:Nd{n}:E{plan.n_edges}:gv1")
+                      _lib.ptr(p4), fl16(F), n, F, R, plan.n_edges, st, tag=f"pseudo_msg_bwd:Nd{n}:E{plan.n_edges}:gv1")
             # B5: inv_dense.0 (swish')
             g_a1 = new(n, F)
             p5 = new(nb * fl16(F))

@@ -267,7 +267,9 @@ int cgv_pseudo_msg_bwd(const float* phi, const float* s, const float* sbar, cons
  * the residual adds (cgvae.py:108-111, 122-123) and their autograd backward.  A block owns 4 channels f0..f0+3 and the
  * weight rows {g F + f} that feed them; grid = F / 4 blocks of 576 threads.
  * Slices (outputs of the backward phases; inputs of the next one): slice s = block s's row-split partial product,
- * QUAD-MAJOR [K/4][16 or 48][4] floats, cgv_decoder_slice_floats(K, rows48) each; n_slices = F/4 (N/4 for dense_bwd).
+ * QUAD-MAJOR [K/4][rows][4] floats (rows = n, or 3 n behind uv_bwd), cgv_decoder_slice_floats(K, rows) each;
+ * n_slices = F/4 (N/4 for dense_bwd).  The message kernels stage the bead graph in LDS: at most cgv_decoder_max_edges()
+ * directed edges.
  *   forward   msg_fwd   phi = a1 W2^T + b2 -> message -> stack[:, :F] = S', Sbar', V', Vbar', V' as rows [3n, F]
  *             uv_fwd    UV [3n, 2F] = rows [Wu; Wv]^T ; stack[:, F:] = sqrt(sum_xyz (Vv^2 + 1e-10))
  *             gate_fwd  a [n, 3F] = a0 W1'^T + b1' ; S'' = S' + (U.Vv) a_sv + a_ss ; V'' = V' + U a_vv
@@ -280,11 +282,13 @@ int cgv_pseudo_msg_bwd(const float* phi, const float* s, const float* sbar, cons
  *             slices_to_dense  out [n, F] = base + sum slices (16-row slices)
  * ------------------------------------------------------------------------------------- */
 int cgv_decoder_layer_supported(int n_nodes, int n_feat, int n_rbf);
-int64_t cgv_decoder_slice_floats(int K, int rows48);
+int64_t cgv_decoder_slice_floats(int K, int rows);
+int cgv_decoder_max_edges(void);
+int cgv_decoder_debug_clock(uint64_t* buf /*device, 8 slots, or NULL*/);   /* measurement only */
 int cgv_decoder_msg_fwd(const float* a1, const float* W2, const float* b2, const float* s, const float* sbar, const float* v,
                         const float* vbar, const float* geom_d, const int32_t* rowptr_d, const int32_t* src_d, const float* Wd,
                         const float* bd, float* phi, float* stack, float* sbar_out, float* v_out, float* vbar_out,
-                        float* rows_out, int n_nodes, int n_feat, int n_rbf, void* stream);
+                        float* rows_out, int n_nodes, int n_feat, int n_rbf, int n_edges, void* stream);
 int cgv_decoder_uv_fwd(const float* rows, const float* Wuv, float* UV, float* stack, int n_nodes, int n_feat, void* stream);
 int cgv_decoder_gate_fwd(const float* a0, const float* W1p, const float* b1p, const float* UV, const float* stack,
                          const float* v2, float* a, float* s3, float* v3, int n_nodes, int n_feat, void* stream);
@@ -304,7 +308,7 @@ int cgv_decoder_msg_bwd(const float* phi, const float* s, const float* sbar, con
                         const float* ghb /*or NULL*/, const float* gvrows_slices, int n_slices, int64_t slice_stride,
                         const float* gv_res /*or NULL*/, const float* gvb /*or NULL*/, const float* W2, float* g_phi, float* g_s,
                         float* g_sbar, float* g_v, float* g_vbar, float* gWd, float* gbd, float* slices_out,
-                        int64_t out_slice_stride, int n_nodes, int n_feat, int n_rbf, void* stream);
+                        int64_t out_slice_stride, int n_nodes, int n_feat, int n_rbf, int n_edges, void* stream);
 int cgv_decoder_slices_to_dense(const float* base /*or NULL*/, const float* slices, int n_slices, int64_t slice_stride,
                                 float* out, int n_nodes, int n_feat, void* stream);
 
