@@ -42,6 +42,15 @@ __host__ __device__ constexpr int geom_stride(int R) { return (geom_unit_offset(
 __host__ __device__ constexpr int geom_group_unit_offset(int R) { return R + 2; }
 __host__ __device__ constexpr int geom_group_stride(int R) { return (R + 6 + 3) & ~3; }
 
+// Nontemporal 16-byte load.  (Tried on the weight rows of the bead-level weight-streaming products, so that they would not
+// displace activations / slices / code from the L2: the decoder got SLOWER -- 352 -> 408 us forward, 527 -> 556 us backward
+// on chignolin -- the 243 MB of bead-level weights just fit the 256 MB memory-side cache, which nt loads bypass.)
+__device__ __forceinline__ float4 ldg4_nt(const float* p) {
+  typedef float nt_f4 __attribute__((ext_vector_type(4)));
+  const nt_f4 t = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(p));
+  return make_float4(t.x, t.y, t.z, t.w);
+}
+
 // 12-byte vector with 4-byte alignment: one global_load_dwordx3 / global_store_dwordx3.
 struct __attribute__((packed, aligned(4))) f3 {
   float x, y, z;

@@ -342,6 +342,7 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_fwd_k(
   const int i = lane >> 2, c = lane & 3;
   const bool live = i < n;
   const int f = f0 + c;
+  DL_TICK(8);
   // bead graph + node state of these channels -> LDS (requested before the product, consumed after it)
   stage_copy4(geom_l, geom, E * GS / 4);
   stage_ints(rp_l, rowptr, n + 1);
@@ -355,7 +356,9 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_fwd_k(
   int row0[9];
 #pragma unroll
   for (int g = 0; g < 9; ++g) row0[g] = g * F + f0;
+  DL_TICK(9);
   fwd_core<1, 9>(phi_l, red, a1, n, F, W2, row0);
+  DL_TICK(10);
   // bias, dense copy for the backward pass (phi[m][g F + f0 .. +3])
   for (int o = threadIdx.x; o < 16 * 9; o += DL_THREADS) {
     const int m = o / 9, g = o - m * 9;
@@ -366,6 +369,7 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_fwd_k(
     if (m < n) *reinterpret_cast<float4*>(phi_out + (size_t)m * 9 * F + (size_t)g * F + f0) = p;
   }
   __syncthreads();
+  DL_TICK(11);
   // EquiMessagePsuedo, wave k = filter k (pseudo_msg.hip: pseudo_fwd_k), lane = (receiver i, channel c)
   const int ic = live ? i : 0;
   const float s_i = s_l[ic * 4 + c], sb_i = sb_l[ic * 4 + c];
@@ -391,6 +395,7 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_fwd_k(
       default: daxpy(acc, q, dcross(vb_i, vj)); break;
     }
   }
+  DL_TICK(12);
   if (k > 0) { red2[((k - 1) * 3 + 0) * 64 + lane] = acc.x; red2[((k - 1) * 3 + 1) * 64 + lane] = acc.y; red2[((k - 1) * 3 + 2) * 64 + lane] = acc.z; }
   __syncthreads();
   if (k != 0 || !live) return;
@@ -411,6 +416,7 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_fwd_k(
   rows_out[((size_t)3 * i + 0) * F + f] = av.x;
   rows_out[((size_t)3 * i + 1) * F + f] = av.y;
   rows_out[((size_t)3 * i + 2) * F + f] = av.z;
+  DL_TICK(13);
 }
 
 // ============================================================================================== F3: [U | Vv] + norm
@@ -842,7 +848,7 @@ int cgv_decoder_layer_supported(int n_nodes, int n_feat, int n_rbf) {
          cgv_rbf_supported(n_rbf);
 }
 int cgv_decoder_max_edges(void) { return cgv::DL_MAX_EDGES; }
-/* measurement: block 0 of cgv_decoder_msg_bwd stores the GPU wall clock at its phase boundaries into buf[0..7] (NULL: off) */
+/* measurement: block 0 of cgv_decoder_msg_bwd stores the GPU wall clock at its phase boundaries into buf[0..7], of cgv_decoder_msg_fwd into buf[8..13] (NULL: off) */
 int cgv_decoder_debug_clock(uint64_t* buf) {
   unsigned long long* p = reinterpret_cast<unsigned long long*>(buf);
   hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(cgv::g_dl_clock), &p, sizeof(p));

@@ -635,7 +635,10 @@ class Trainer:
             a = self.arena
             rank, self._rank_step = self._rank_step, None
             if rank and not torch.cuda.is_current_stream_capturing():
-                self.last_rank_step = rank                   # kept for bench.py's optimiser timing (holds the operand rows)
+                # kept for bench.py's optimiser timing: the table points at the operand rows, so they must stay alive --
+                # DETACHED (a retained autograd graph would pin its AccumulateGrad nodes to this step's stream, and a
+                # later capture on another stream then dies in hipStreamEndCapture)
+                self.last_rank_step = rank[:4] + ([tuple(t.detach() if torch.is_tensor(t) else t for t in it) for it in rank[4]],)
             lo = self._rank_hi if rank else 0                # [0, lo): gradients that exist only as operand rows
             _lib.call("cgv_optim_prepare_extra", a.g.data_ptr() + 4 * lo, a.numel - lo,
                       _lib.ptr(self._rank_sumsq) if rank else None,

@@ -284,7 +284,7 @@ int cgv_pseudo_msg_bwd(const float* phi, const float* s, const float* sbar, cons
 int cgv_decoder_layer_supported(int n_nodes, int n_feat, int n_rbf);
 int64_t cgv_decoder_slice_floats(int K, int rows);
 int cgv_decoder_max_edges(void);
-int cgv_decoder_debug_clock(uint64_t* buf /*device, 8 slots, or NULL*/);   /* measurement only */
+int cgv_decoder_debug_clock(uint64_t* buf /*device, 16 slots, or NULL*/);   /* measurement only */
 int cgv_decoder_msg_fwd(const float* a1, const float* W2, const float* b2, const float* s, const float* sbar, const float* v,
                         const float* vbar, const float* geom_d, const int32_t* rowptr_d, const int32_t* src_d, const float* Wd,
                         const float* bd, float* phi, float* stack, float* sbar_out, float* v_out, float* vbar_out,

@@ -12,18 +12,22 @@ model = cg.build_model(600, w["n_rbf"], w["atom_cutoff"], w["cg_cutoff"], w["enc
 tr = Trainer(model, lr=1e-4, beta=w["beta"], gamma=w["gamma"])
 for _ in range(3):
     tr.step(batch)
-buf = torch.zeros(8, dtype=torch.int64, device="cuda")
+buf = torch.zeros(16, dtype=torch.int64, device="cuda")
 _lib.call("cgv_decoder_debug_clock", buf.data_ptr())
 hz = _lib.load().cgv_timestamp_hz()
 tr.capture(batch, warmup=0)
-acc = []
+acc, accf = [], []
 for _ in range(20):
     tr.step(batch)
     torch.cuda.synchronize()
     t = buf.cpu().tolist()
     acc.append([(t[i] - t[i - 1]) / hz * 1e6 for i in range(1, 8)])
+    accf.append([(t[i] - t[i - 1]) / hz * 1e6 for i in range(9, 14)])
 _lib.call("cgv_decoder_debug_clock", None)
 names = ["prefetch+staging issue", "quad_sum", "tail of staging -> state in regs", "pass B (source side)", "shuffles + pass A", "sync", "g_phi dense + final sums", ]
 import statistics
 for i, nm in enumerate(["stage loads -> LDS", "slice sum (quad_sum<3>) + gv", "pass B", "filter-grad shuffles + pass A", "barrier", "dense g_phi + node sums", "product + slice store"]):
     print(f"{statistics.median(a[i] for a in acc):8.2f} us  {nm}")
+print("-- cgv_decoder_msg_fwd, block 0")
+for i, nm in enumerate(["stage loads -> LDS + filter row", "product (fwd_core)", "bias + dense phi + barrier", "edge loop", "wave sums + stores"]):
+    print(f"{statistics.median(a[i] for a in accf):8.2f} us  {nm}")
