@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="only the headline loop (profiling runs)")
     ap.add_argument("--cpu-steps", type=int, default=None)
     ap.add_argument("--optimizer", default="fused", choices=["fused", "torch"])
+    ap.add_argument("--prefetch", action="store_true",
+                    help="load the next batch into a second buffer set on a side stream while the step runs "
+                         "(Trainer.enable_prefetch; measured slower than loading on the main stream: DESIGN.md)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one captured hipGraph per step")
     ap.add_argument("--deferred-update", action="store_true",
                     help="apply each step's Adam pass at the start of the next step, beside the encoder forward "
@@ -401,8 +404,20 @@ def main():
             torch.cuda.synchronize()
 
     # ---------------------------------------------------------------- headline: rotation of resident batches
+    # double-buffered: while step i runs, batch i+1 is loaded into the second buffer set on a side stream (its graph
+    # plans and edge records are still computed once per step, inside the timed loop -- off the critical path)
+    prefetching = False
+    if use_graph and args.prefetch:
+        try:
+            trainer.enable_prefetch()
+            prefetching = True
+        except Exception as exc:
+            print(f"[bench] prefetch (second buffer set) unavailable on rank {rank}: {exc!r}", file=sys.stderr)
     replays0 = trainer.replays
-    step_rot = lambda i: trainer.step(rotation[i % n_rot])
+    if prefetching:
+        step_rot = lambda i: trainer.step(rotation[i % n_rot], prefetch=rotation[(i + 1) % n_rot])
+    else:
+        step_rot = lambda i: trainer.step(rotation[i % n_rot])
     for i in range(args.warmup):
         step_rot(i)
     secs = timed_loop(step_rot, args.steps, args.reps, barrier, dist, dev)
@@ -426,9 +441,16 @@ def main():
         # in-place re-plan + edge records, replay
         host_sets = [ds for ds, _ in rot_sets]
 
+        collate = lambda i: cg.data.CG_collate([host_sets[i % n_rot][j] for j in range(frames)])
+        pending = {"i": -1, "batch": None}
+
         def step_host(i):
-            ds = host_sets[i % n_rot]
-            trainer.step(cg.data.CG_collate([ds[j] for j in range(frames)]))
+            hb = pending["batch"] if pending["i"] == i else collate(i)
+            if prefetching:                                  # collate batch i+1 now; its H2D + re-plan overlap step i
+                pending["i"], pending["batch"] = i + 1, collate(i + 1)
+                trainer.step(hb, prefetch=pending["batch"])
+            else:
+                trainer.step(hb)
         for i in range(3):
             step_host(i)
         s = timed_loop(step_host, args.steps, 3, barrier, dist, dev)
@@ -544,7 +566,7 @@ def main():
                        "global_batch": world * frames, "directed_edges_rank0": int(batch["_graph"].atom.n_edges),
                        "optimizer": args.optimizer, "deferred_update": bool(trainer.defer_update),
                        "rank_update": bool(trainer._rank_hi), "hip_graph": bool(use_graph),
-                       "graph_replays_in_timed_loops": int(rot_replayed),
+                       "graph_replays_in_timed_loops": int(rot_replayed), "prefetch_next_batch": bool(prefetching),
                        "skip_dead_vector_channel": bool(args.skip_dead_vector_channel), "parallelism": f"dp{world}"},
             "timing": {"repetitions": args.reps, "ms_per_step_median": ms, "ms_per_step_min": 1e3 * min(secs) / args.steps,
                        "ms_per_step_max": 1e3 * max(secs) / args.steps,

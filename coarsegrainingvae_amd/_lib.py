@@ -48,6 +48,12 @@ PROTOTYPES = {
     "cgv_geom_group_unit_offset": (_i, [_i]),
     "cgv_edge_geometry_grouped": (_i, [_p, _p, _p, _p, _p, _i, _i, _f, _p, _p, _p]),
     "cgv_edge_geometry": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _f, _p, _p, _p]),
+    "cgv_plan_jobs_max": (_i, []),
+    "cgv_plan_job_bytes": (_i, []),
+    "cgv_plan_jobs_build": (_i, [_p, _i, _p]),
+    "cgv_geom_jobs_max": (_i, []),
+    "cgv_geom_job_bytes": (_i, []),
+    "cgv_geom_jobs_build": (_i, [_p, _i, _p]),
     "cgv_segment_reduce": (_i, [_p, _p, _p, _i, _i, _i, _p, _p]),
     "cgv_segment_broadcast": (_i, [_p, _p, _p, _i, _i, _i, _p, _p]),
     "cgv_equi_msg_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, C.c_int64, C.c_int64, _p, _p, _p]),

@@ -1,0 +1,243 @@
+// Per-batch graph work in a handful of launches (K7 / K6 over job tables).
+//
+// What the reference does inside every forward -- make_directed (conv.py:10-20), preprocess_r / PainnRadialBasis /
+// CosineEnvelope per block (conv.py:25-29, modules.py:148-172, 52-58) -- is, here, the in-place re-plan of a batch's
+// sorted edge views and the recomputation of its edge records (graph.py: BatchGraph.update).  As separate calls that is
+// 5 launches per sorted view (6 views per batch) + one per record array (9): ~56 launches whose ISSUE alone costs the
+// host 0.33 ms per step on the chignolin config (tools/prefetch_probe.py).  Here every view / record array is a JOB in a
+// table passed by value: count, scan, drop, row-sort run once over all views, the records once over all arrays:
+// 5 launches per batch.  The kernels are those of graph.hip / geometry.hip with a job lookup in front.
+#include <cstring>
+#include "cgv_common.h"
+
+namespace cgv {
+
+constexpr int PJ_MAX = 8;
+struct PlanJob {            // one sorted view: edges ordered by (key, other, edge id)
+  const int64_t* key;       // NULL: key = edge id (the source side of a mapping plan)
+  const int64_t* other;     // NULL: partner = edge id
+  const float* ids_f32;     // non-NULL: the plan's index column is (int) ids_f32[e * stride] with `pad` mapped to `pad_to`
+                            // (type ids of an nn.Embedding with padding_idx, read straight from nxyz[:, 0]); it replaces
+                            // whichever of key / other is marked by ids_is_key
+  int* rowptr;              // [n_rows + 1]
+  int* eid;
+  int* key_sorted;
+  int* other_sorted;
+  int* count;               // [n_rows + 1] scratch, ZERO on entry and on exit (every edge is counted once, dropped once)
+  int* tmp;                 // [E] scratch
+  unsigned long long* spill;  // [E] scratch (rows longer than the LDS key budget)
+  int stride, E, n_rows;
+  int edge_begin, row_begin;  // prefixes over the jobs
+  int ids_is_key, pad, pad_to;
+};
+struct PlanJobs { int n, total_edges, total_rows, pad; PlanJob job[PJ_MAX]; };
+
+__device__ __forceinline__ int pj_ids(const PlanJob& p, int e) {
+  const int t = (int)p.ids_f32[(int64_t)e * p.stride];
+  return t == p.pad ? p.pad_to : t;
+}
+__device__ __forceinline__ int pj_key(const PlanJob& p, int e) {
+  if (p.ids_f32 && p.ids_is_key) return pj_ids(p, e);
+  return p.key ? (int)p.key[(int64_t)e * p.stride] : e;
+}
+__device__ __forceinline__ int pj_other(const PlanJob& p, int e) {
+  if (p.ids_f32 && !p.ids_is_key) return pj_ids(p, e);
+  return p.other ? (int)p.other[(int64_t)e * p.stride] : e;
+}
+
+__device__ __forceinline__ int pj_find_edge(const PlanJobs& J, int e) {
+  int j = 0;
+#pragma unroll
+  for (int t = 1; t < PJ_MAX; ++t) if (t < J.n && J.job[t].edge_begin <= e) j = t;
+  return j;
+}
+
+__global__ __launch_bounds__(256) void pj_count_k(PlanJobs J) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= J.total_edges) return;
+  const PlanJob& p = J.job[pj_find_edge(J, e)];
+  atomicAdd(p.count + pj_key(p, e - p.edge_begin), 1);
+}
+
+__global__ __launch_bounds__(1024) void pj_scan_k(PlanJobs J) {        // block b: exclusive scan of job b's counts
+  const PlanJob& p = J.job[blockIdx.x];
+  const int* in = p.count;
+  int* out = p.rowptr;
+  const int n = p.n_rows;
+  __shared__ int wave_tot[16];
+  __shared__ int carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + tid;
+    const int x = (i < n) ? in[i] : 0;
+    int incl = x;
+    for (int d = 1; d < 64; d <<= 1) {
+      const int y = __shfl_up(incl, d);
+      if (lane >= d) incl += y;
+    }
+    if (lane == 63) wave_tot[w] = incl;
+    __syncthreads();
+    int wave_off = 0;
+    for (int k = 0; k < w; ++k) wave_off += wave_tot[k];
+    const int carry = carry_s;
+    if (i < n) out[i] = carry + wave_off + incl - x;
+    __syncthreads();
+    if (tid == 1023) carry_s = carry + wave_off + incl;
+    __syncthreads();
+  }
+  if (tid == 0) out[n] = carry_s;
+}
+
+__global__ __launch_bounds__(256) void pj_drop_k(PlanJobs J) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= J.total_edges) return;
+  const PlanJob& p = J.job[pj_find_edge(J, e)];
+  const int le = e - p.edge_begin;
+  const int r = pj_key(p, le);
+  p.tmp[p.rowptr[r] + atomicSub(p.count + r, 1) - 1] = le;         // the row's slots are handed out last to first
+}
+
+constexpr int PJ_LDS_KEYS = 2048;
+__global__ __launch_bounds__(128) void pj_row_sort_k(PlanJobs J) {   // block: one row of one job
+  __shared__ unsigned long long keys[PJ_LDS_KEYS];
+  int j = 0;
+#pragma unroll
+  for (int t = 1; t < PJ_MAX; ++t) if (t < J.n && J.job[t].row_begin <= (int)blockIdx.x) j = t;
+  const PlanJob& p = J.job[j];
+  const int r = blockIdx.x - p.row_begin;
+  const int beg = p.rowptr[r], L = p.rowptr[r + 1] - beg;
+  if (L <= 0) return;
+  unsigned long long* k = L <= PJ_LDS_KEYS ? keys : p.spill + beg;
+  for (int t = threadIdx.x; t < L; t += blockDim.x) {
+    const int e = p.tmp[beg + t];
+    const unsigned partner = (unsigned)pj_other(p, e);
+    k[t] = ((unsigned long long)partner << 32) | (unsigned)e;
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < L; t += blockDim.x) {
+    const unsigned long long mine = k[t];
+    int rank = 0;
+    for (int u = 0; u < L; ++u) rank += k[u] < mine;
+    p.eid[beg + rank] = (int)(unsigned)(mine & 0xffffffffull);
+    p.other_sorted[beg + rank] = (int)(mine >> 32);
+    p.key_sorted[beg + rank] = r;
+  }
+}
+
+// ------------------------------------------------------------------ edge records of several (view, cutoff) pairs
+constexpr int GJ_MAX = 12;
+struct GeomJob {
+  const float* pos_dst; const float* pos_src;
+  const int* dst; const int* src;
+  const int2* meta;          // receiver-group records when non-NULL
+  const float* coef;         // n pi / cutoff, n = 1..R
+  float* geom;
+  float cutoff;
+  int E, R, GS, edge_begin;
+};
+struct GeomJobs { int n, total_edges; GeomJob job[GJ_MAX]; };
+
+__global__ __launch_bounds__(256) void gj_records_k(GeomJobs J) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= J.total_edges) return;
+  int j = 0;
+#pragma unroll
+  for (int t = 1; t < GJ_MAX; ++t) if (t < J.n && J.job[t].edge_begin <= e) j = t;
+  const GeomJob& q = J.job[j];
+  const int p = e - q.edge_begin;
+  const int R = q.R, GS = q.GS;
+  const float cutoff = q.cutoff;
+  const float pi_f = 3.14159265358979323846f;
+  // geometry.hip: edge_geometry, same expressions in the same order (conv.py:25-29, modules.py:148-172, 52-58)
+  const float* a = q.pos_src + 3 * (size_t)q.src[p];
+  const float* b = q.pos_dst + 3 * (size_t)q.dst[p];
+  const float rx = __fsub_rn(a[0], b[0]), ry = __fsub_rn(a[1], b[1]), rz = __fsub_rn(a[2], b[2]);
+  const float sx = __fadd_rn(__fmul_rn(rx, rx), 1e-8f);
+  const float sy = __fadd_rn(__fmul_rn(ry, ry), 1e-8f);
+  const float sz = __fadd_rn(__fmul_rn(rz, rz), 1e-8f);
+  const float d = __fsqrt_rn(__fadd_rn(__fadd_rn(sx, sy), sz));
+  float* g = q.geom + (size_t)p * GS;
+  float env = 0.5f * (cosf(__fdiv_rn(__fmul_rn(pi_f, d), cutoff)) + 1.0f);
+  const bool outside = d >= cutoff;
+  if (outside) env = 0.0f;
+  for (int n = 0; n < R; ++n) {
+    const float c = q.coef[n];
+    float val = (d == 0.0f) ? c : __fdiv_rn(sinf(__fmul_rn(c, d)), d);
+    if (outside) val = 0.0f;
+    g[n] = val * env;
+  }
+  g[R] = env;
+  const float ux = __fdiv_rn(rx, d), uy = __fdiv_rn(ry, d), uz = __fdiv_rn(rz, d);
+  if (q.meta) {
+    const int2 m = q.meta[p];
+    g[R + 1] = __int_as_float(m.x);
+    g[R + 2] = ux; g[R + 3] = uy; g[R + 4] = uz;
+    g[R + 5] = __int_as_float(m.y);
+    for (int k = R + 6; k < GS; ++k) g[k] = 0.0f;
+    return;
+  }
+  const int U = geom_unit_offset(R);
+  for (int k = R + 1; k < U; ++k) g[k] = 0.0f;
+  g[U + 0] = ux; g[U + 1] = uy; g[U + 2] = uz;
+  g[U + 3] = ux; g[U + 4] = uy; g[U + 5] = uz;
+  for (int k = U + 6; k < GS; ++k) g[k] = 0.0f;
+}
+
+}  // namespace cgv
+
+extern "C" {
+
+int cgv_plan_jobs_max(void) { return cgv::PJ_MAX; }
+int cgv_plan_job_bytes(void) { return (int)sizeof(cgv::PlanJob); }
+int cgv_geom_jobs_max(void) { return cgv::GJ_MAX; }
+int cgv_geom_job_bytes(void) { return (int)sizeof(cgv::GeomJob); }
+
+/* jobs_host: n records laid out as cgv::PlanJob (edge_begin / row_begin are filled in here). */
+int cgv_plan_jobs_build(const void* jobs_host, int n_jobs, void* stream) {
+  CGV_REQUIRE(jobs_host && n_jobs >= 1 && n_jobs <= cgv::PJ_MAX, "bad job table");
+  cgv::PlanJobs J;
+  std::memset(static_cast<void*>(&J), 0, sizeof(J));
+  std::memcpy(static_cast<void*>(J.job), jobs_host, sizeof(cgv::PlanJob) * (size_t)n_jobs);
+  J.n = n_jobs;
+  int e = 0, r = 0;
+  for (int j = 0; j < n_jobs; ++j) {
+    cgv::PlanJob& p = J.job[j];
+    CGV_REQUIRE(p.E >= 0 && p.n_rows >= 0 && p.stride >= 1 && p.rowptr && p.count, "bad job");
+    CGV_REQUIRE(p.E == 0 || (p.eid && p.key_sorted && p.other_sorted && p.tmp && p.spill), "null edge array");
+    p.edge_begin = e; p.row_begin = r;
+    e += p.E; r += p.n_rows;
+  }
+  J.total_edges = e; J.total_rows = r;
+  hipStream_t st = (hipStream_t)stream;
+  if (e > 0) hipLaunchKernelGGL(cgv::pj_count_k, dim3((e + 255) / 256), dim3(256), 0, st, J);
+  hipLaunchKernelGGL(cgv::pj_scan_k, dim3(n_jobs), dim3(1024), 0, st, J);
+  if (e > 0) {
+    hipLaunchKernelGGL(cgv::pj_drop_k, dim3((e + 255) / 256), dim3(256), 0, st, J);
+    if (r > 0) hipLaunchKernelGGL(cgv::pj_row_sort_k, dim3(r), dim3(128), 0, st, J);
+  }
+  return cgv::check_launch("cgv_plan_jobs_build");
+}
+
+int cgv_geom_jobs_build(const void* jobs_host, int n_jobs, void* stream) {
+  CGV_REQUIRE(jobs_host && n_jobs >= 1 && n_jobs <= cgv::GJ_MAX, "bad job table");
+  cgv::GeomJobs J;
+  std::memset(static_cast<void*>(&J), 0, sizeof(J));
+  std::memcpy(static_cast<void*>(J.job), jobs_host, sizeof(cgv::GeomJob) * (size_t)n_jobs);
+  J.n = n_jobs;
+  int e = 0;
+  for (int j = 0; j < n_jobs; ++j) {
+    cgv::GeomJob& q = J.job[j];
+    CGV_REQUIRE(q.E >= 0 && q.R > 0 && cgv_rbf_supported(q.R) && q.coef && q.geom && q.pos_dst && q.pos_src && q.dst && q.src, "bad job");
+    q.GS = q.meta ? cgv::geom_group_stride(q.R) : cgv::geom_stride(q.R);
+    q.edge_begin = e;
+    e += q.E;
+  }
+  J.total_edges = e;
+  if (e == 0) return 0;
+  hipLaunchKernelGGL(cgv::gj_records_k, dim3((e + 255) / 256), dim3(256), 0, (hipStream_t)stream, J);
+  return cgv::check_launch("cgv_geom_jobs_build");
+}
+
+}  // extern "C"

@@ -43,15 +43,28 @@ def CG_collate(dicts: List[Dict[str, torch.Tensor]]) -> Dict[str, torch.Tensor]:
     return batch
 
 
-def prepare_batch(batch: Dict[str, torch.Tensor], device=None, edge_slack: float = 0.0) -> Dict[str, torch.Tensor]:
+def prepare_batch(batch: Dict[str, torch.Tensor], device=None, edge_slack: float = 0.0, edge_capacity=None) -> Dict[str, torch.Tensor]:
     """Move a collated batch to the device and attach its :class:`BatchGraph` (directed lists,
     CSR plans, bead ranks) under ``'_graph'`` so ``CGequiVAE.forward`` runs without host syncs.
-    ``edge_slack`` > 0 reserves that fraction of extra edge capacity (see :func:`copy_batch_into`)."""
+    ``edge_slack`` > 0 reserves that fraction of extra edge capacity (see :func:`copy_batch_into`);
+    ``edge_capacity`` = (atom edges, bead edges) sets the capacities outright."""
     if device is not None:
         batch = batch_to(batch, device)
     batch["_graph"] = BatchGraph(batch["nxyz"][:, 1:], batch["CG_nxyz"][:, 1:], batch["CG_mapping"],
-                                 batch["nbr_list"], batch["CG_nbr_list"], edge_slack=edge_slack)
+                                 batch["nbr_list"], batch["CG_nbr_list"], edge_slack=edge_slack, edge_capacity=edge_capacity)
     return batch
+
+
+def clone_prepared(batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """A second, independent copy of a prepared batch: own tensors, own graph bundle with the same edge capacities and
+    the same cached geometries (``Trainer.enable_prefetch``: the buffer set the next batch is loaded into while the
+    current step runs)."""
+    g = batch["_graph"]
+    twin = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items() if not k.startswith("_")}
+    twin = prepare_batch(twin, edge_capacity=(g.atom.capacity, g.cg.capacity))
+    for (which, n_rbf, cutoff) in list(g._geom):
+        twin["_graph"].geometry(which, n_rbf, cutoff)
+    return twin
 
 
 _STATIC_KEYS = ("nxyz", "CG_nxyz", "num_atoms", "num_CGs", "CG_mapping", "bond_edge_list")

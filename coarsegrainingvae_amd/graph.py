@@ -10,12 +10,29 @@ from __future__ import annotations
 
 from typing import Optional, Tuple
 
+import ctypes as C
+
 import numpy as np
 import torch
 
 from . import _lib
 
 _I32 = torch.int32
+
+
+class PlanJob(C.Structure):
+    """csrc/batch_plans.hip: cgv::PlanJob -- one sorted view of one plan (device pointers)."""
+    _fields_ = [("key", C.c_void_p), ("other", C.c_void_p), ("ids_f32", C.c_void_p), ("rowptr", C.c_void_p), ("eid", C.c_void_p),
+                ("key_sorted", C.c_void_p), ("other_sorted", C.c_void_p), ("count", C.c_void_p), ("tmp", C.c_void_p),
+                ("spill", C.c_void_p), ("stride", C.c_int), ("E", C.c_int), ("n_rows", C.c_int), ("edge_begin", C.c_int),
+                ("row_begin", C.c_int), ("ids_is_key", C.c_int), ("pad", C.c_int), ("pad_to", C.c_int)]
+
+
+class GeomJob(C.Structure):
+    """csrc/batch_plans.hip: cgv::GeomJob -- the edge records of one (view, cutoff)."""
+    _fields_ = [("pos_dst", C.c_void_p), ("pos_src", C.c_void_p), ("dst", C.c_void_p), ("src", C.c_void_p),
+                ("meta", C.c_void_p), ("coef", C.c_void_p), ("geom", C.c_void_p), ("cutoff", C.c_float), ("E", C.c_int),
+                ("R", C.c_int), ("GS", C.c_int), ("edge_begin", C.c_int)]
 
 
 # ----------------------------------------------------------------------------- K0
@@ -102,7 +119,8 @@ class EdgePlan:
     """
 
     __slots__ = ("n_dst", "n_src", "n_edges", "capacity", "rowptr_d", "eid_d", "dst_d", "src_d", "rowptr_s", "eid_s",
-                 "dst_s", "src_s", "device", "group_rb", "dst_g", "src_g", "pos_g", "meta_g", "__weakref__")
+                 "dst_s", "src_s", "device", "group_rb", "dst_g", "src_g", "pos_g", "meta_g", "_job_ws", "_job_keep",
+                 "_grp_ws", "__weakref__")
 
     def __init__(self, dst: torch.Tensor, src: Optional[torch.Tensor], stride: int, n_edges: int, n_dst: int,
                  n_src: int, capacity: int = 0):
@@ -116,6 +134,7 @@ class EdgePlan:
         self.eid_d, self.dst_d, self.src_d = mk(E), mk(E), mk(E)
         self.eid_s, self.dst_s, self.src_s = mk(E), mk(E), mk(E)
         self.group_rb, self.dst_g, self.src_g, self.pos_g, self.meta_g = 0, None, None, None, None
+        self._job_ws, self._job_keep, self._grp_ws = None, None, None
         self._build(dst, src, stride)
 
     def _build(self, dst, src, stride):
@@ -154,11 +173,60 @@ class EdgePlan:
                       self.n_src, self.group_rb, _lib.ptr(self.dst_g), _lib.ptr(self.src_g), _lib.ptr(self.pos_g),
                       _lib.ptr(self.meta_g), _lib.ptr(ws), ws_bytes, _lib.stream_ptr())
             return
-        ws_bytes = int(lib.cgv_group_plan_workspace_bytes(self.n_edges))
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
+        ws_bytes = int(lib.cgv_group_plan_workspace_bytes(self.capacity))
+        if self._grp_ws is None or self._grp_ws.numel() < ws_bytes:
+            self._grp_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
+        ws = self._grp_ws
         _lib.call("cgv_group_plan_build", _lib.ptr(self.rowptr_d), _lib.ptr(self.dst_d), _lib.ptr(self.src_d), self.n_edges,
                   self.n_dst, self.n_src, self.group_rb, _lib.ptr(self.dst_g), _lib.ptr(self.src_g), _lib.ptr(self.pos_g),
                   _lib.ptr(self.meta_g), _lib.ptr(ws), ws_bytes, _lib.stream_ptr())
+
+    # -- job-table rebuild (cgv_plan_jobs_build: every view of a batch in 4 launches; BatchGraph.update)
+    def view_jobs(self, dst: torch.Tensor, src: Optional[torch.Tensor], stride: int, n_edges: int):
+        """The two PlanJob records (destination- and source-sorted view) that re-plan this plan IN PLACE for the directed
+        edges (dst[e * stride], src[e * stride]) (``src`` None: a mapping plan, partner = edge id).  The scratch
+        (row counters, zero between builds, + slot / spill arrays) lives with the plan."""
+        if n_edges > self.capacity:
+            raise ValueError(f"{n_edges} edges exceed the plan's capacity of {self.capacity}")
+        if self._job_ws is None:
+            E, dev = self.capacity, self.device
+            mk = lambda n, dt=_I32: torch.zeros(n, dtype=dt, device=dev)
+            self._job_ws = [(mk(rows + 1), mk(E), mk(E, torch.int64)) for rows in (self.n_dst, self.n_src)]
+        self.n_edges = int(n_edges)
+        self._job_keep = (dst, src)                       # the launches read them in stream order
+        d_ptr, s_ptr = dst.data_ptr(), (src.data_ptr() if src is not None else None)
+        (cd, td, sd), (cs, ts, ss) = self._job_ws
+        jd = PlanJob(d_ptr, s_ptr, None, self.rowptr_d.data_ptr(), self.eid_d.data_ptr(), self.dst_d.data_ptr(), self.src_d.data_ptr(),
+                     cd.data_ptr(), td.data_ptr(), sd.data_ptr(), stride, self.n_edges, self.n_dst, 0, 0, 0, 0, 0)
+        js = PlanJob(s_ptr, d_ptr, None, self.rowptr_s.data_ptr(), self.eid_s.data_ptr(), self.src_s.data_ptr(), self.dst_s.data_ptr(),
+                     cs.data_ptr(), ts.data_ptr(), ss.data_ptr(), stride, self.n_edges, self.n_src, 0, 0, 0, 0, 0)
+        return [jd, js]
+
+    def nbrs_jobs(self, nbrs: torch.Tensor):
+        nbrs = nbrs.long().contiguous()
+        if nbrs.shape[0] == 0:
+            dummy = torch.zeros(2, dtype=torch.int64, device=self.device)
+            return self.view_jobs(dummy, dummy[1:], 2, 0)
+        flat = nbrs.view(-1)
+        return self.view_jobs(flat, flat[1:], 2, nbrs.shape[0])
+
+    def mapping_jobs(self, mapping: torch.Tensor):
+        mapping = mapping.long().contiguous()
+        if mapping.shape[0] != self.n_edges:
+            raise ValueError("a mapping plan keeps its length")
+        return self.view_jobs(mapping, None, 1, mapping.shape[0])
+
+    def type_id_jobs(self, ids_f32: torch.Tensor, pad, pad_to: int):
+        """Mapping-plan jobs whose index is read in the kernel from a float column (``nxyz[:, 0]``: element stride taken
+        from the view) with ``pad`` -> ``pad_to``: the embedding groupings, with no conversion / where launches."""
+        if ids_f32.dtype != torch.float32 or ids_f32.dim() != 1 or ids_f32.shape[0] != self.n_edges:
+            raise ValueError("type ids must be a float32 column of the plan's length")
+        jobs = self.view_jobs(ids_f32, None, int(ids_f32.stride(0)), ids_f32.shape[0])
+        for k, job in enumerate(jobs):
+            job.key, job.other, job.ids_f32 = None, None, ids_f32.data_ptr()
+            job.ids_is_key = 1 if k == 0 else 0
+            job.pad, job.pad_to = (int(pad), int(pad_to)) if pad is not None else (-1, -1)
+        return jobs
 
     def rebuild_from_nbrs(self, nbrs: torch.Tensor):
         """Re-plan IN PLACE for another directed edge list on the same nodes (at most ``capacity`` edges)."""
@@ -251,6 +319,18 @@ class EdgeGeometry:
         self.coef = rbf_coefficients(n_rbf, cutoff, dev)
         self.rebuild(plan, r_edges=r_edges, pos_dst=pos_dst, pos_src=pos_src)
 
+    def jobs(self, plan: EdgePlan, pos_dst: torch.Tensor, pos_src: torch.Tensor):
+        """GeomJob records (cgv_geom_jobs_build) that recompute this geometry's record arrays for ``plan``'s current edges."""
+        out = []
+        views = [(plan.dst_d, plan.src_d, None, self.geom_d), (plan.dst_s, plan.src_s, None, self.geom_s)]
+        if self.geom_g is not None and plan.group_rb:
+            views.insert(0, (plan.dst_g, plan.src_g, plan.meta_g, self.geom_g))
+        for dst, src, meta, geom in views:
+            out.append(GeomJob(pos_dst.data_ptr(), pos_src.data_ptr(), dst.data_ptr(), src.data_ptr(),
+                               meta.data_ptr() if meta is not None else None, self.coef.data_ptr(), geom.data_ptr(),
+                               self.cutoff, plan.n_edges, self.n_rbf, 0, 0))
+        return out
+
     def rebuild(self, plan: EdgePlan, r_edges: Optional[torch.Tensor] = None, pos_dst: Optional[torch.Tensor] = None,
                 pos_src: Optional[torch.Tensor] = None):
         """(Re)compute the records of ``plan``'s current edges into the same buffers."""
@@ -287,7 +367,7 @@ class BatchGraph:
     decoder use different RBF cutoffs on the same edges (run_ala.py:196-206).
     """
 
-    def __init__(self, xyz, cg_xyz, mapping, nbr_list, cg_nbr_list, edge_slack: float = 0.0):
+    def __init__(self, xyz, cg_xyz, mapping, nbr_list, cg_nbr_list, edge_slack: float = 0.0, edge_capacity=None):
         """``edge_slack``: fraction of extra edge capacity in the atom / bead plans and their geometry records, so
         that ``update`` can re-plan another batch of the same molecules in place (hipGraph replay)."""
         self.xyz = xyz.detach().contiguous().float().clone()
@@ -298,11 +378,14 @@ class BatchGraph:
         self.atom_nbrs, _ = make_directed(nbr_list)
         self.cg_nbrs, _ = make_directed(cg_nbr_list)
         cap = lambda e: int(e * (1.0 + edge_slack)) + (64 if edge_slack > 0 else 0)
-        self.atom = EdgePlan.from_nbrs(self.atom_nbrs, n, capacity=cap(self.atom_nbrs.shape[0]))
+        cap_atom, cap_cg = cap(self.atom_nbrs.shape[0]), cap(self.cg_nbrs.shape[0])
+        if edge_capacity is not None:                 # explicit capacities (a twin of another bundle: data.clone_prepared)
+            cap_atom, cap_cg = int(edge_capacity[0]), int(edge_capacity[1])
+        self.atom = EdgePlan.from_nbrs(self.atom_nbrs, n, capacity=cap_atom)
         rb = receiver_group_size(self.atom)
         if rb:
             self.atom.enable_groups(rb)
-        self.cg = EdgePlan.from_nbrs(self.cg_nbrs, n_cg, capacity=cap(self.cg_nbrs.shape[0]))
+        self.cg = EdgePlan.from_nbrs(self.cg_nbrs, n_cg, capacity=cap_cg)
         self.a2b = EdgePlan.from_mapping(self.mapping, n_cg)
         # rank inside the bead = position in the (stable) bead-sorted order minus the bead's start
         p = self.a2b
@@ -349,6 +432,8 @@ class BatchGraph:
         else:
             self.atom_nbrs = make_directed(nbr_list)[0].to(dev)
             self.cg_nbrs = make_directed(cg_nbr_list)[0].to(dev)
+        if self._update_by_jobs():
+            return
         self.atom.rebuild_from_nbrs(self.atom_nbrs)
         self.cg.rebuild_from_nbrs(self.cg_nbrs)
         for (which, _r, _c), g in self._geom.items():
@@ -360,6 +445,38 @@ class BatchGraph:
             if pad is not None:
                 ids = torch.where(ids == pad, torch.full_like(ids, n_types), ids)
             plan.rebuild_from_mapping(ids)
+
+    def _update_by_jobs(self) -> bool:
+        """The re-plan of ``update`` as job tables: every sorted view of the batch (atom, bead, the two embedding
+        groupings) in 4 launches, the receiver-group order in 1, every cached record array in 1 -- instead of ~56
+        launches whose issue alone costs the host 0.33 ms per chignolin batch.  False: not applicable (caller falls back)."""
+        lib = _lib.load()
+        if self.xyz.device.type != "cuda" or lib.cgv_plan_job_bytes() != C.sizeof(PlanJob) or lib.cgv_geom_job_bytes() != C.sizeof(GeomJob):
+            return False
+        plan_jobs = self.atom.nbrs_jobs(self.atom_nbrs) + self.cg.nbrs_jobs(self.cg_nbrs)
+        for (_which, n_types, pad), (plan, idx) in self._embed.items():
+            if idx.dtype == torch.float32 and idx.dim() == 1:
+                plan_jobs += plan.type_id_jobs(idx, pad, n_types)          # ids read in the kernel from nxyz[:, 0]
+            else:
+                ids = idx.long()
+                if pad is not None:
+                    ids = torch.where(ids == pad, torch.full_like(ids, n_types), ids)
+                plan_jobs += plan.mapping_jobs(ids)
+        geom_jobs = []
+        for (which, _r, _c), g in self._geom.items():
+            plan, pd, ps = self._positions(which)
+            geom_jobs += g.jobs(plan, pd, ps)
+        if len(plan_jobs) > lib.cgv_plan_jobs_max() or len(geom_jobs) > lib.cgv_geom_jobs_max():
+            return False
+        st = _lib.stream_ptr()
+        table = (PlanJob * len(plan_jobs))(*plan_jobs)
+        _lib.call("cgv_plan_jobs_build", C.addressof(table), len(plan_jobs), st)
+        if self.atom.group_rb:
+            self.atom._build_groups()
+        if geom_jobs:
+            gt = (GeomJob * len(geom_jobs))(*geom_jobs)
+            _lib.call("cgv_geom_jobs_build", C.addressof(gt), len(geom_jobs), st)
+        return True
 
     def embed_plan(self, which: str, idx: torch.Tensor, module) -> EdgePlan:
         """Type-id grouping of the atoms (``"atom"``) or beads (``"cg"``) for the embedding weight gradient; cached:

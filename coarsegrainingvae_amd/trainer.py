@@ -346,6 +346,7 @@ class Trainer:
         self.last_terms = None
         self.steps_skipped_host = 0
         self._graphs = {}             # train flag -> captured hipGraph of one full step (capture())
+        self._pre_stream = None       # side stream of enable_prefetch()
         self.replays = 0
 
     @property
@@ -474,7 +475,7 @@ class Trainer:
             self.torch_opt = torch.optim.Adam(live, lr=self.lr, betas=self.betas, eps=self.eps)
 
     # ------------------------------------------------------------------ hipGraph capture of the whole step
-    def capture(self, batch, warmup: int = 2, train: bool = True, eps: Optional[torch.Tensor] = None):
+    def capture(self, batch, warmup: int = 2, train: bool = True, eps: Optional[torch.Tensor] = None, _twin_of=None):
         """Capture forward + loss + backward (+ all-reduce) + clip/Adam on ``batch`` into one
         hipGraph.  Every kernel of the step reads sizes that are fixed for a given molecule
         (N atoms, beads, bonds) and takes its edge structure from device memory (CSR plans), so
@@ -533,9 +534,35 @@ class Trainer:
         tables = wgrad_queue.finish_capture()               # record tables: on the device before the first replay
         self._pending = pending_at_start                    # recorded, not run: the update it opens with is still due
         # the step's result tensors live in the graph's pool: a replay refreshes them in place
-        self._graphs[self._graph_key(train, pending_at_start)] = {"graph": graph, "batch": batch, "lr": self.lr, "eps": eps_buf, "tables": tables,
-                                                                  "results": (self.last_loss, self.last_terms, self.last_out)}
+        record = {"graph": graph, "batch": batch, "lr": self.lr, "eps": eps_buf, "tables": tables,
+                  "results": (self.last_loss, self.last_terms, self.last_out), "done": None}
+        if _twin_of is not None:
+            _twin_of["twin"] = record                       # the same step on a second set of batch buffers (enable_prefetch)
+        else:
+            self._graphs[self._graph_key(train, pending_at_start)] = record
         return graph
+
+    def enable_prefetch(self, train: bool = True):
+        """Double-buffer the captured step: a second capture of the same step on a second set of batch buffers, so that
+        ``step(batch, prefetch=next_batch)`` can load the NEXT batch (copies, make_directed, in-place re-plan of the CSR
+        views, edge records: ~50 small launches) on a side stream while the current step's graph runs -- the per-batch
+        graph work leaves the critical path without leaving the step.  Parameters, optimiser state and the random
+        stream are shared by the two graphs; they replay in program order on the main stream."""
+        from .data import clone_prepared
+        key = self._graph_key(train, self._pending)
+        cap = self._graphs.get(key)
+        if cap is None:
+            raise RuntimeError("capture() the step before enabling prefetch")
+        if "twin" in cap:
+            return
+        if cap["eps"] is not None:
+            raise RuntimeError("prefetch is for training on drawn noise (no static eps buffer)")
+        twin_batch = clone_prepared(cap["batch"])
+        self.capture(twin_batch, warmup=0, train=train, _twin_of=cap)
+        cap["cur"] = 0                                      # slot the next step uses
+        cap["pre"] = None                                   # (batch object, slot, load-complete event) of a prefetched batch
+        if self._pre_stream is None:
+            self._pre_stream = torch.cuda.Stream(device=self.arena.p.device)
 
     def _graph_key(self, train: bool, pending: bool):
         """One graph per mode; with deferred updates also per 'does an update open the step' (train steps follow train
@@ -551,18 +578,30 @@ class Trainer:
         """Is a captured step available for the NEXT step of this mode?"""
         return self._graph_key(train, self._pending) in self._graphs
 
-    def step(self, batch, eps: Optional[torch.Tensor] = None, train: bool = True):
+    def step(self, batch, eps: Optional[torch.Tensor] = None, train: bool = True, prefetch=None):
+        """One training (or validation) step.  ``prefetch``: the batch the NEXT call will be given (only with
+        ``enable_prefetch()``): it is loaded into the idle buffer set on a side stream while this step runs."""
         key = self._graph_key(train, self._pending)
         cap = self._graphs.get(key)
         if cap is not None and (eps is None) == (cap["eps"] is None):
             if cap["lr"] != self.lr and (train or self.defer_update):    # the learning rate is a launch argument: re-capture
+                twin = "twin" in cap
+                if twin and cap["pre"] is not None:
+                    torch.cuda.current_stream().wait_event(cap["pre"][2])
                 self.capture(cap["batch"], warmup=0, train=train, eps=cap["eps"])
                 cap = self._graphs[key]
-            if batch is cap["batch"] or self._load(cap["batch"], batch):
-                if eps is not None:
-                    cap["eps"].copy_(eps, non_blocking=True)     # the captured step reads its noise from this buffer
-                cap["graph"].replay()
-                self.last_loss, self.last_terms, self.last_out = cap["results"]
+                if twin:
+                    self.enable_prefetch(train)
+            if "twin" in cap:
+                done = self._step_double_buffered(cap, batch, prefetch)
+            else:
+                done = batch is cap["batch"] or self._load(cap["batch"], batch)
+                if done:
+                    if eps is not None:
+                        cap["eps"].copy_(eps, non_blocking=True)     # the captured step reads its noise from this buffer
+                    cap["graph"].replay()
+                    self.last_loss, self.last_terms, self.last_out = cap["results"]
+            if done:
                 self.replays += 1
                 if self.defer_update:
                     self._pending = bool(train)              # a training step leaves its update for the next step
@@ -578,6 +617,44 @@ class Trainer:
     def _load(captured, batch) -> bool:
         from .data import copy_batch_into
         return copy_batch_into(captured, batch)
+
+    def _step_double_buffered(self, cap, batch, prefetch) -> bool:
+        """Replay on the buffer set that holds ``batch`` (prefetched by the previous call, or loaded now), then start
+        loading ``prefetch`` into the other set on the side stream.  False: the batch does not fit (caller runs it eagerly)."""
+        slots = (cap, cap["twin"])
+        main = torch.cuda.current_stream()
+        pre, cap["pre"] = cap["pre"], None
+        if pre is not None and pre[0] is batch:
+            slot = pre[1]
+            main.wait_event(pre[2])                          # the side stream's load of this batch
+        else:
+            if pre is not None:
+                main.wait_event(pre[2])                      # an unused prefetch: its writes must land before the set is reused
+            slot = cap["cur"]
+            for k, r in enumerate(slots):                    # one of the captured batches themselves: nothing to load
+                if batch is r["batch"]:
+                    slot = k
+            rec = slots[slot]
+            if not (batch is rec["batch"] or self._load(rec["batch"], batch)):
+                return False
+        rec = slots[slot]
+        rec["graph"].replay()
+        rec["done"] = torch.cuda.Event()
+        rec["done"].record(main)
+        self.last_loss, self.last_terms, self.last_out = rec["results"]
+        cap["cur"] = 1 - slot
+        if prefetch is not None:
+            other = slots[1 - slot]
+            side = self._pre_stream
+            if other["done"] is not None:
+                side.wait_event(other["done"])               # the last replay that read the other set
+            with torch.cuda.stream(side):
+                ok = self._load(other["batch"], prefetch)
+                if ok:
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    cap["pre"] = (prefetch, 1 - slot, ev)
+        return True
 
     # ------------------------------------------------------------------ one iteration
     def _step_eager(self, batch, eps: Optional[torch.Tensor] = None, train: bool = True):

@@ -229,6 +229,21 @@ int cgv_equi_msg_bwd(const float* phi, const float* v, const float* geom_s, cons
                      size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Per-batch graph work over job tables (csrc/batch_plans.hip): what cgv_csr_build and cgv_edge_geometry[_grouped] do,
+ * for ALL sorted views / record arrays of a batch in 4 + 1 launches (replaces make_directed's consumers and the
+ * per-block preprocess_r / rbf / envelope of conv.py:10-29, modules.py:148-197 for a whole batch at once).
+ * jobs_host [host]: n records with the layout of cgv::PlanJob / cgv::GeomJob (csrc/batch_plans.hip; sizes from
+ * cgv_plan_job_bytes / cgv_geom_job_bytes), device pointers inside, copied into the kernel arguments by value.
+ * PlanJob.count must be ZERO on entry ([n_rows + 1] ints) and is zero again on exit.
+ * ------------------------------------------------------------------------------------- */
+int cgv_plan_jobs_max(void);
+int cgv_plan_job_bytes(void);
+int cgv_plan_jobs_build(const void* jobs_host, int n_jobs, void* stream);
+int cgv_geom_jobs_max(void);
+int cgv_geom_job_bytes(void);
+int cgv_geom_jobs_build(const void* jobs_host, int n_jobs, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * K3  fused EquiMessagePsuedo (conv.py:180-242), i = dst (receiver), j = src, q_k = phi[j,kF+f] w_k
  * with k = 0..8 (phi is [N,9F]), u = unit_e:
  *   dh    = sum q0 s_i                 dhbar = sum (v_i . vbar_j)      (no filter, conv.py:206)

@@ -1429,3 +1429,76 @@ def test_rank_update_kernels_on_random_shapes():
         big = gflat.abs() > 1e-3
         assert torch.allclose(arena_p[sl].double()[big], want[big], rtol=1e-5, atol=1e-5), (k, shapes[k])
     assert float(arena_g.abs().max()) == 0.0                               # never written
+
+
+def test_prefetched_double_buffered_steps_equal_plain_replays():
+    """``Trainer.enable_prefetch``: the next batch is loaded into a second buffer set on a side stream while the current
+    step's graph runs.  Same batches, same order => the same losses and parameters as loading each batch on the main
+    stream right before its step (det=True: no random stream involved), bit for bit."""
+    from coarsegrainingvae_amd.trainer import Trainer
+    w = cg.data.WORKLOADS["dipeptide"]
+    F = 64
+    batches = [cg.synthetic_batch("dipeptide", n_frames=4, seed=40 + k, device=DEV) for k in range(4)]
+    runs = []
+    for prefetch in (False, True):
+        first = cg.data.prepare_batch({k: v.clone() for k, v in batches[0].items() if not k.startswith("_")}, edge_slack=0.25)
+        model = cg.build_model(F, w["n_rbf"], w["atom_cutoff"], w["cg_cutoff"], 2, 2, w["n_cgs"], det=True, seed=123).to(DEV)
+        tr = Trainer(model, lr=1e-3, beta=w["beta"], gamma=w["gamma"])
+        tr.step(first)
+        tr.step(first)
+        tr.capture(first, warmup=0)
+        if prefetch:
+            tr.enable_prefetch()
+        losses = []
+        for i in range(9):
+            nxt = batches[(i + 1) % 4] if prefetch else None
+            tr.step(batches[i % 4], prefetch=nxt)
+            losses.append(tr.last_loss.clone())
+        assert tr.replays == 9
+        runs.append((torch.stack(losses).cpu(), tr.arena.p.clone().cpu()))
+    assert torch.equal(runs[0][0], runs[1][0])
+    assert torch.equal(runs[0][1], runs[1][1])
+
+
+def test_in_place_batch_update_by_job_tables_is_bit_exact():
+    """``BatchGraph.update`` through the job tables (cgv_plan_jobs_build / cgv_geom_jobs_build: all sorted views in 4
+    launches, all record arrays in 1) leaves exactly the arrays a freshly prepared batch has: both CSR views of the atom
+    and bead plans, the receiver-group order, the embedding groupings, every cached edge-record array."""
+    w = cg.data.WORKLOADS["chignolin"]
+    model = cg.build_model(32, w["n_rbf"], w["atom_cutoff"], w["cg_cutoff"], 1, 1, w["n_cgs"], det=True, seed=1).to(DEV)
+    raw = lambda seed: {k: v for k, v in cg.synthetic_batch("chignolin", n_frames=2, seed=seed, device=DEV).items() if not k.startswith("_")}
+    held = cg.data.prepare_batch(raw(1), edge_slack=0.25)
+    with torch.no_grad():
+        model(held)                                  # creates the geometries / embedding plans the model uses
+    for seed in (2, 3):
+        fresh = cg.data.prepare_batch(raw(seed))
+        with torch.no_grad():
+            out_fresh = model(fresh)
+        assert cg.data.copy_batch_into(held, fresh)
+        a, b = held["_graph"], fresh["_graph"]
+        for name in ("atom", "cg"):
+            pa, pb = getattr(a, name), getattr(b, name)
+            E = pb.n_edges
+            assert pa.n_edges == E
+            for f in ("rowptr_d", "rowptr_s"):
+                assert torch.equal(getattr(pa, f), getattr(pb, f)), (name, f)
+            for f in ("eid_d", "dst_d", "src_d", "eid_s", "dst_s", "src_s"):
+                assert torch.equal(getattr(pa, f)[:E], getattr(pb, f)[:E]), (name, f)
+        E = b.atom.n_edges
+        for f in ("dst_g", "src_g", "pos_g"):
+            assert torch.equal(getattr(a.atom, f)[:E], getattr(b.atom, f)[:E]), f
+        assert torch.equal(a.atom.meta_g[:2 * E], b.atom.meta_g[:2 * E])
+        for key, ga in a._geom.items():
+            gb = b._geom[key]
+            plan = a._positions(key[0])[0]
+            n = plan.n_edges
+            assert torch.equal(ga.geom_d[:n], gb.geom_d[:n]) and torch.equal(ga.geom_s[:n], gb.geom_s[:n]), key
+            if ga.geom_g is not None:
+                assert torch.equal(ga.geom_g[:n], gb.geom_g[:n]), key
+        for key, (pa, _idx) in a._embed.items():
+            pb = b._embed[key][0]
+            assert torch.equal(pa.rowptr_d, pb.rowptr_d) and torch.equal(pa.eid_d, pb.eid_d), key
+        with torch.no_grad():
+            out_held = model(held)
+        for x, y in zip(out_held, out_fresh):
+            assert torch.equal(x, y)
