@@ -62,9 +62,9 @@ PROTOTYPES = {
     "cgv_equi_msg_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "cgv_equi_msg_bwd": (_i, [_p] * 13 + [_i, _i, _i, C.c_int64, C.c_int64, _p, _sz, _p]),
     "cgv_pseudo_msg_fwd": (_i, [_p] * 14 + [_i, _i, _i, _i, _p]),
-    "cgv_pseudo_msg_fwd_rows": (_i, [_p] * 15 + [_i, _i, _i, _i, _p]),
+    "cgv_pseudo_msg_fwd_rows": (_i, [_p] * 15 + [_i, _i, _i, _i, C.c_int64, _p]),
     "cgv_pseudo_msg_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
-    "cgv_pseudo_msg_bwd": (_i, [_p] * 24 + [_i, _i, _i, _i, _p, _sz, _p]),
+    "cgv_pseudo_msg_bwd": (_i, [_p] * 24 + [_i, _i, _i, _i, C.c_int64, _p, _sz, _p]),
     "cgv_update_rows_from_vec": (_i, [_p, _p, _i, _i, _p]),
     "cgv_update_vec_from_rows": (_i, [_p, _p, _p, _i, _i, _p]),
     "cgv_update_norm_stack_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
@@ -132,7 +132,7 @@ PROTOTYPES = {
 
 # include/cgvae_hip.h: CGV_OPT_* (A/B switches of the launchers; defaults in csrc/api.cpp)
 OPTIONS = {"msg_fwd_split": 0, "msg_bwd_split": 1, "msg_fwd_kernel": 2, "grp_waves": 3, "grp_records": 4, "csr_build": 5,
-           "pseudo_chunks": 6, "wgrad_tiling": 7, "tile_fwd_lds_min": 8, "bwd_input_waves": 9}
+           "pseudo_chunks": 6, "wgrad_tiling": 7, "tile_fwd_lds_min": 8, "bwd_input_waves": 9, "pseudo_fwd": 10}
 
 
 def set_option(name: str, value: int) -> None:

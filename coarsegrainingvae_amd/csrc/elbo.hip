@@ -45,6 +45,83 @@ __global__ __launch_bounds__(256) void elbo_kl_k(const float* __restrict__ mu, c
   if (threadIdx.x == 0) part[blockIdx.x] = kl;
 }
 
+// Bond-graph term of a large molecule on many blocks (2000 atoms / 1999 bonds: the single block's atom x bond scan was
+// 200 of that kernel's 220 us).  Block b owns atoms [64 b, 64 b + 64): every block stages all bonds chunk by chunk
+// (value and d / d xr_a0 per bond: cheap, recomputed per block), wave g of 16 scans slice g of the chunk for the
+// block's atoms (lane = atom), the waves' sums meet in LDS in wave order.  g_xr receives the COMPLETE gradient
+// (reconstruction part + bond part); block 0 also leaves sum_b diff_b^2 (double) for elbo_fwd.
+constexpr int BOND_ATOMS = 64, BOND_WAVES = 16, BOND_CH = 2048;
+__global__ __launch_bounds__(1024) void elbo_bond_k(const float* __restrict__ xyz, const float* __restrict__ xr,
+                                                    const int64_t* __restrict__ bonds, int n_atoms, int n_bonds, float gamma,
+                                                    float* __restrict__ g_xr, double* __restrict__ gr_out) {
+  __shared__ double sh[16];
+  __shared__ __attribute__((aligned(16))) int sb_a0[BOND_CH], sb_a1[BOND_CH];
+  __shared__ __attribute__((aligned(16))) float sb_cx[BOND_CH], sb_cy[BOND_CH], sb_cz[BOND_CH];
+  __shared__ float part[BOND_WAVES][3][BOND_ATOMS];
+  const int t = threadIdx.x, T = blockDim.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int a = blockIdx.x * BOND_ATOMS + lane;
+  const float cg = n_bonds > 0 ? gamma * 2.f / (float)n_bonds : 0.f;
+  const int nr = n_atoms * 3;
+  double gr = 0.0;
+  float gx = 0.f, gy = 0.f, gz = 0.f;
+  for (int base = 0; base < n_bonds; base += BOND_CH) {
+    const int cnt = min(BOND_CH, n_bonds - base);
+    __syncthreads();
+    for (int b = t; b < cnt; b += T) {
+      const int a0 = (int)bonds[2 * (size_t)(base + b)], a1 = (int)bonds[2 * (size_t)(base + b) + 1];
+      const float ex = xr[3 * a0] - xr[3 * a1], ey = xr[3 * a0 + 1] - xr[3 * a1 + 1], ez = xr[3 * a0 + 2] - xr[3 * a1 + 2];
+      const float fx = xyz[3 * a0] - xyz[3 * a1], fy = xyz[3 * a0 + 1] - xyz[3 * a1 + 1], fz = xyz[3 * a0 + 2] - xyz[3 * a1 + 2];
+      const float lg = sqrtf(1e-6f + ex * ex + ey * ey + ez * ez), ld = sqrtf(1e-6f + fx * fx + fy * fy + fz * fz);
+      const float diff = lg - ld;
+      gr += (double)(diff * diff);
+      const float c = (a0 == a1) ? 0.f : cg * diff / lg;
+      sb_a0[b] = a0; sb_a1[b] = a1;
+      sb_cx[b] = c * ex; sb_cy[b] = c * ey; sb_cz[b] = c * ez;
+    }
+    for (int b = cnt + t; b < ((cnt + 15) & ~15); b += T) { sb_a0[b] = sb_a1[b] = -1; sb_cx[b] = sb_cy[b] = sb_cz[b] = 0.f; }
+    __syncthreads();
+    const int trips = (cnt + 15) / 16, tper = (trips + BOND_WAVES - 1) / BOND_WAVES;
+    const int b_lo = 16 * tper * wave, b_hi = min(cnt, 16 * tper * (wave + 1));
+    for (int b0 = b_lo; b0 < b_hi; b0 += 16) {           // branch-free, all reads of a trip issued together (see elbo_fwd)
+      int4 i0[4], i1[4];
+      float4 cx[4], cy[4], cz[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int b = b0 + 4 * u;
+        i0[u] = *reinterpret_cast<const int4*>(sb_a0 + b); i1[u] = *reinterpret_cast<const int4*>(sb_a1 + b);
+        cx[u] = *reinterpret_cast<const float4*>(sb_cx + b); cy[u] = *reinterpret_cast<const float4*>(sb_cy + b);
+        cz[u] = *reinterpret_cast<const float4*>(sb_cz + b);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float w0 = i0[u].x == a ? 1.f : (i1[u].x == a ? -1.f : 0.f);
+        const float w1 = i0[u].y == a ? 1.f : (i1[u].y == a ? -1.f : 0.f);
+        const float w2 = i0[u].z == a ? 1.f : (i1[u].z == a ? -1.f : 0.f);
+        const float w3 = i0[u].w == a ? 1.f : (i1[u].w == a ? -1.f : 0.f);
+        gx = fmaf(w3, cx[u].w, fmaf(w2, cx[u].z, fmaf(w1, cx[u].y, fmaf(w0, cx[u].x, gx))));
+        gy = fmaf(w3, cy[u].w, fmaf(w2, cy[u].z, fmaf(w1, cy[u].y, fmaf(w0, cy[u].x, gy))));
+        gz = fmaf(w3, cz[u].w, fmaf(w2, cz[u].z, fmaf(w1, cz[u].y, fmaf(w0, cz[u].x, gz))));
+      }
+    }
+  }
+  part[wave][0][lane] = gx; part[wave][1][lane] = gy; part[wave][2][lane] = gz;
+  __syncthreads();
+  if (wave == 0 && a < n_atoms) {
+    float tx = 0.f, ty = 0.f, tz = 0.f;
+#pragma unroll
+    for (int w = 0; w < BOND_WAVES; ++w) { tx += part[w][0][lane]; ty += part[w][1][lane]; tz += part[w][2][lane]; }
+    const float sc = 2.f / (float)nr;                                    // reconstruction part: 2 (xr - x) / nr
+    g_xr[3 * a] = sc * (xr[3 * a] - xyz[3 * a]) + tx;
+    g_xr[3 * a + 1] = sc * (xr[3 * a + 1] - xyz[3 * a + 1]) + ty;
+    g_xr[3 * a + 2] = sc * (xr[3 * a + 2] - xyz[3 * a + 2]) + tz;
+  }
+  if (blockIdx.x == 0) {
+    gr = block_sum(gr, sh);
+    if (t == 0) *gr_out = gr;
+  }
+}
+
 __global__ __launch_bounds__(1024) void elbo_fwd(const float* __restrict__ mu, const float* __restrict__ sigma,
                                                  const float* __restrict__ pmu, const float* __restrict__ pstd,
                                                  const float* __restrict__ xyz, const float* __restrict__ xr,
@@ -53,7 +130,7 @@ __global__ __launch_bounds__(1024) void elbo_fwd(const float* __restrict__ mu, c
                                                  float* __restrict__ g_mu, float* __restrict__ g_sigma,
                                                  float* __restrict__ g_pmu, float* __restrict__ g_pstd,
                                                  float* __restrict__ g_xr, const double* __restrict__ kl_part,
-                                                 int n_kl_part) {
+                                                 int n_kl_part, const double* __restrict__ bond_sum) {
   __shared__ double sh[16];
   const int t = threadIdx.x, T = blockDim.x;
   // ---- KL and its gradients (mean over beads of per-bead sums); for large bead batches elbo_kl_k has already
@@ -94,7 +171,7 @@ __global__ __launch_bounds__(1024) void elbo_fwd(const float* __restrict__ mu, c
   for (int idx = t; idx < nr; idx += T) {
     const float d = xr[idx] - xyz[idx];
     rec += (double)(d * d);
-    g_xr[idx] = 2.f * d / (float)nr;
+    if (!bond_sum) g_xr[idx] = 2.f * d / (float)nr;          // (elbo_bond_k has written the complete gradient otherwise)
   }
   rec = block_sum(rec, sh);
   const double rec_val = rec / (double)(nr > 0 ? nr : 1);
@@ -109,7 +186,7 @@ __global__ __launch_bounds__(1024) void elbo_fwd(const float* __restrict__ mu, c
   const bool want_grad = gamma != 0.f && n_bonds > 0;
   const float cg = n_bonds > 0 ? gamma * 2.f / (float)n_bonds : 0.f;
   double gr = 0.0;
-  for (int base = 0; base < n_bonds; base += CH) {
+  for (int base = 0; base < (bond_sum ? 0 : n_bonds); base += CH) {
     const int cnt = min(CH, n_bonds - base);
     __syncthreads();                       // previous chunk fully scanned; first round: g_xr holds the recon part
     for (int b = t; b < cnt; b += T) {
@@ -177,6 +254,7 @@ __global__ __launch_bounds__(1024) void elbo_fwd(const float* __restrict__ mu, c
     }
   }
   gr = block_sum(gr, sh);
+  if (bond_sum) gr = *bond_sum;
   const double gr_val = n_bonds > 0 ? gr / (double)n_bonds : 0.0;
   if (t == 0) {
     out[0] = (float)(rec_val + (double)beta * kl_val + (double)gamma * gr_val);
@@ -207,7 +285,8 @@ static inline int elbo_kl_blocks(int n_beads, int n_feat) {
   return (int)(b > 128 ? 128 : b);
 }
 
-size_t cgv_elbo_workspace_bytes(int n_beads, int n_feat) { return sizeof(double) * (size_t)elbo_kl_blocks(n_beads, n_feat); }
+// one double per KL block + one for the bond sum of the multi-block bond kernel
+size_t cgv_elbo_workspace_bytes(int n_beads, int n_feat) { return sizeof(double) * ((size_t)elbo_kl_blocks(n_beads, n_feat) + 1); }
 
 int cgv_elbo_fwd(const float* mu, const float* sigma, const float* prior_mu, const float* prior_std, const float* xyz,
                  const float* xyz_recon, const int64_t* bonds, int n_beads, int n_feat, int n_atoms, int n_bonds,
@@ -218,14 +297,22 @@ int cgv_elbo_fwd(const float* mu, const float* sigma, const float* prior_mu, con
   CGV_REQUIRE(n_beads > 0 && n_feat > 0 && n_atoms > 0 && n_bonds >= 0 && (n_bonds == 0 || bonds), "bad size");
   hipStream_t st = (hipStream_t)stream;
   int nb = elbo_kl_blocks(n_beads, n_feat);
-  if (nb > 0 && (!workspace || workspace_bytes < sizeof(double) * (size_t)nb || (((uintptr_t)workspace) & 7))) nb = 0;
+  const bool ws_ok = workspace && workspace_bytes >= sizeof(double) * ((size_t)nb + 1) && (((uintptr_t)workspace) & 7) == 0;
+  if (!ws_ok) nb = 0;
   double* part = reinterpret_cast<double*>(workspace);
+  // atoms x bonds beyond what one block scans in a few microseconds: the bond term on its own multi-block launch
+  double* bond_sum = nullptr;
+  if (ws_ok && gamma != 0.f && n_bonds > 0 && (long long)n_atoms * n_bonds >= 512LL * 1024) {
+    bond_sum = part + nb;
+    hipLaunchKernelGGL(cgv::elbo_bond_k, dim3((n_atoms + cgv::BOND_ATOMS - 1) / cgv::BOND_ATOMS), dim3(1024), 0, st, xyz,
+                       xyz_recon, bonds, n_atoms, n_bonds, gamma, g_xyz_recon, bond_sum);
+  }
   if (nb > 0)
     hipLaunchKernelGGL(cgv::elbo_kl_k, dim3(nb), dim3(256), 0, st, mu, sigma, prior_mu, prior_std, n_beads * n_feat,
                        0.5f * beta / (float)n_beads, g_mu, g_sigma, g_prior_mu, g_prior_std, part);
   hipLaunchKernelGGL(cgv::elbo_fwd, dim3(1), dim3(1024), 0, st, mu, sigma, prior_mu, prior_std, xyz, xyz_recon, bonds,
                      n_beads, n_feat, n_atoms, n_bonds, beta, gamma, out4, g_mu, g_sigma, g_prior_mu, g_prior_std,
-                     g_xyz_recon, (const double*)part, nb);
+                     g_xyz_recon, (const double*)part, nb, (const double*)bond_sum);
   return cgv::check_launch("cgv_elbo_fwd");
 }
 

@@ -101,7 +101,11 @@ __device__ __forceinline__ void read_row(float (&W)[R + 1], const float* __restr
 // Wave k owns filter k: q_k = phi[j, kF+f] w_k and the one output term that carries it (k = 0: T_h and the
 // filter-free T_hbar; k = 1..4: the four terms of T_v; k = 5..8: those of T_vb).  The waves' vectors meet in LDS
 // in wave order.  (One wave doing all nine filters: 99 weights per lane, 10.4 us; this: see DESIGN.md.)
-template <int R, int PSEUDO_EB>
+// STAGE (dense bead graphs: 61 edges per node on the 2000-atom config): the receiver's edge records and source indices
+// are copied to LDS in chunks of SEG_LDS edges by all nine waves (coalesced 16-byte loads) before they are walked -- per
+// edge they were a dependent scalar load of 80 bytes (`s_waitcnt lgkmcnt(0)` before every use): 57 us per layer there.
+constexpr int SEG_LDS = 128;
+template <int R, int PSEUDO_EB, bool STAGE = false>
 __global__ __launch_bounds__(576) void pseudo_fwd_k(const float* __restrict__ phi, const float* __restrict__ s,
                                                     const float* __restrict__ sbar, const float* __restrict__ v,
                                                     const float* __restrict__ vbar, const float* __restrict__ geom,
@@ -112,6 +116,8 @@ __global__ __launch_bounds__(576) void pseudo_fwd_k(const float* __restrict__ ph
                                                     int residual, float* __restrict__ dv_rows) {
   constexpr int GS = geom_stride(R), U = geom_unit_offset(R);
   __shared__ float red[8][3][64];
+  __shared__ __attribute__((aligned(16))) float seg_geom[STAGE ? SEG_LDS * GS : 4];
+  __shared__ int seg_src[STAGE ? SEG_LDS : 1];
   const int i = blockIdx.x;
   const int lane = threadIdx.x & 63;
   const int k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -130,32 +136,45 @@ __global__ __launch_bounds__(576) void pseudo_fwd_k(const float* __restrict__ ph
   // one per edge pair); the terms are still added in edge order
   const float* __restrict__ vsrc = (k == 2 || k == 6 || k == 7) ? v : vbar;      // the one vector this wave's term reads
   const int e_beg = rowptr[i], e_end = rowptr[i + 1];
-  for (int eb = e_beg; eb < e_end; eb += PSEUDO_EB) {
-    int jj[PSEUDO_EB];
-    float ph[PSEUDO_EB];
-    v3 vj[PSEUDO_EB];
-#pragma unroll
-    for (int u = 0; u < PSEUDO_EB; ++u) jj[u] = src[min(eb + u, e_end - 1)];
-#pragma unroll
-    for (int u = 0; u < PSEUDO_EB; ++u) {
-      ph[u] = phi[(size_t)jj[u] * 9 * F + (size_t)k * F + f];
-      vj[u] = ldv(vsrc + ((size_t)jj[u] * F + f) * 3);
+  for (int c_beg = e_beg; c_beg < e_end; c_beg += STAGE ? SEG_LDS : (e_end - e_beg)) {
+    const int c_end = STAGE ? min(c_beg + SEG_LDS, e_end) : e_end;
+    if (STAGE) {
+      if (c_beg != e_beg) __syncthreads();                               // readers of the previous chunk
+      const float4* gsrc = reinterpret_cast<const float4*>(geom + (size_t)c_beg * GS);
+      for (int t = threadIdx.x; t < (c_end - c_beg) * (GS / 4); t += 576) reinterpret_cast<float4*>(seg_geom)[t] = gsrc[t];
+      for (int t = threadIdx.x; t < c_end - c_beg; t += 576) seg_src[t] = src[c_beg + t];
+      __syncthreads();
     }
+    for (int eb = c_beg; eb < c_end; eb += PSEUDO_EB) {
+      int jj[PSEUDO_EB];
+      float ph[PSEUDO_EB];
+      v3 vj[PSEUDO_EB];
 #pragma unroll
-    for (int u = 0; u < PSEUDO_EB; ++u) {
-      if (eb + u < e_end) {
-        const float* __restrict__ g = geom + (size_t)(eb + u) * GS;
-        const float q = ph[u] * filt<R>(W, g);
-        switch (k) {                                   // wave-uniform
-          case 0: ah = fmaf(q, s_i, ah); ahb += dot(v_i, vj[u]); break;
-          case 1: axpy(acc, q, v3{g[U], g[U + 1], g[U + 2]}); break;
-          case 2: axpy(acc, q, vj[u]); break;
-          case 3: axpy(acc, q, cross(v_i, vj[u])); break;
-          case 4: axpy(acc, q * sb_i, vj[u]); break;
-          case 5: axpy(acc, q, vj[u]); break;
-          case 6: axpy(acc, q * sb_i, vj[u]); break;
-          case 7: axpy(acc, q, cross(v_i, vj[u])); break;
-          default: axpy(acc, q, cross(vb_i, vj[u])); break;
+      for (int u = 0; u < PSEUDO_EB; ++u) {
+        const int e = min(eb + u, c_end - 1);
+        jj[u] = STAGE ? seg_src[e - c_beg] : src[e];
+      }
+#pragma unroll
+      for (int u = 0; u < PSEUDO_EB; ++u) {
+        ph[u] = phi[(size_t)jj[u] * 9 * F + (size_t)k * F + f];
+        vj[u] = ldv(vsrc + ((size_t)jj[u] * F + f) * 3);
+      }
+#pragma unroll
+      for (int u = 0; u < PSEUDO_EB; ++u) {
+        if (eb + u < c_end) {
+          const float* __restrict__ g = STAGE ? seg_geom + (size_t)(eb + u - c_beg) * GS : geom + (size_t)(eb + u) * GS;
+          const float q = ph[u] * filt<R>(W, g);
+          switch (k) {                                   // wave-uniform
+            case 0: ah = fmaf(q, s_i, ah); ahb += dot(v_i, vj[u]); break;
+            case 1: axpy(acc, q, v3{g[U], g[U + 1], g[U + 2]}); break;
+            case 2: axpy(acc, q, vj[u]); break;
+            case 3: axpy(acc, q, cross(v_i, vj[u])); break;
+            case 4: axpy(acc, q * sb_i, vj[u]); break;
+            case 5: axpy(acc, q, vj[u]); break;
+            case 6: axpy(acc, q * sb_i, vj[u]); break;
+            case 7: axpy(acc, q, cross(v_i, vj[u])); break;
+            default: axpy(acc, q, cross(vb_i, vj[u])); break;
+          }
         }
       }
     }
@@ -282,7 +301,7 @@ __global__ __launch_bounds__(64) void pseudo_bwd_recv_k(const float* __restrict_
 // one-wave version kept 99 accumulators + 99 weights per lane and walked the edges alone (14 us per call on
 // the 60-edge bead graph, the longest kernel of a decoder layer's backward); here a lane holds 2(R+1) values
 // and nine waves hide each other's gather latency.  The waves' partial vector sums meet in LDS in wave order.
-template <int R>
+template <int R, int SRC_EB>
 __global__ __launch_bounds__(576) void pseudo_bwd_src_k(
     const float* __restrict__ phi, const float* __restrict__ s, const float* __restrict__ sbar,
     const float* __restrict__ v, const float* __restrict__ vbar, const float* __restrict__ geom,
@@ -309,39 +328,58 @@ __global__ __launch_bounds__(576) void pseudo_bwd_src_k(
     const v3 v_j = ldv(v + jf * 3), vb_j = ldv(vbar + jf * 3);
     float a = 0.f;
     v3 av{0.f, 0.f, 0.f}, avb{0.f, 0.f, 0.f};
-#pragma unroll 2
-    for (int e = rowptr[j]; e < rowptr[j + 1]; ++e) {
-      const float* __restrict__ g = geom + (size_t)e * GS;
-      const int i = dst[e];
-      const size_t nf = (size_t)i * F + f;
-      const v3 zero{0.f, 0.f, 0.f};
-      float gq = 0.f;
-      v3 cav = zero, cavb = zero;                    // source-side vectors that get multiplied by q_k
-      switch (k) {                                   // wave-uniform
-        case 0: gq = (gh ? gh[nf] : 0.f) * s[nf]; break;
-        case 1: { const v3 gv_i = gv ? ldv(gv + nf * 3) : zero; gq = dot(gv_i, v3{g[U], g[U + 1], g[U + 2]}); break; }
-        case 2: { const v3 gv_i = gv ? ldv(gv + nf * 3) : zero; gq = dot(gv_i, v_j); cav = gv_i; break; }
-        case 3: { const v3 gv_i = gv ? ldv(gv + nf * 3) : zero; const v3 v_i = ldv(v + nf * 3);
-                  gq = dot(gv_i, cross(v_i, vb_j)); cavb = cross(gv_i, v_i); break; }
-        case 4: { const v3 gv_i = gv ? ldv(gv + nf * 3) : zero; const float sb_i = sbar[nf];
-                  gq = sb_i * dot(gv_i, vb_j); cavb = v3{sb_i * gv_i.x, sb_i * gv_i.y, sb_i * gv_i.z}; break; }
-        case 5: { const v3 gvb_i = gvb ? ldv(gvb + nf * 3) : zero; gq = dot(gvb_i, vb_j); cavb = gvb_i; break; }
-        case 6: { const v3 gvb_i = gvb ? ldv(gvb + nf * 3) : zero; const float sb_i = sbar[nf];
-                  gq = sb_i * dot(gvb_i, v_j); cav = v3{sb_i * gvb_i.x, sb_i * gvb_i.y, sb_i * gvb_i.z}; break; }
-        case 7: { const v3 gvb_i = gvb ? ldv(gvb + nf * 3) : zero; const v3 v_i = ldv(v + nf * 3);
-                  gq = dot(gvb_i, cross(v_i, v_j)); cav = cross(gvb_i, v_i); break; }
-        default: { const v3 gvb_i = gvb ? ldv(gvb + nf * 3) : zero; const v3 vb_i = ldv(vbar + nf * 3);
-                   gq = dot(gvb_i, cross(vb_i, vb_j)); cavb = cross(gvb_i, vb_i); break; }
-      }
-      const float w = filt<R>(W, g);
-      a = fmaf(gq, w, a);
-      const float t = gq * p;
+    // The receiver-side operands of an edge hang on its receiver index: indices, then gathers, are issued for SRC_EB
+    // edges at once (the 64-bead graph of the 2000-atom config has 61 edges per node: one dependent round trip per edge
+    // made this the longest kernel of a decoder layer there); the terms are still added in edge order.
+    const float* __restrict__ vecA = (k >= 1 && k <= 4) ? gv : (k >= 5 ? gvb : nullptr);          // upstream vector of this filter
+    const float* __restrict__ vecB = (k == 3 || k == 7 || k == 0) ? v : (k == 8 ? vbar : nullptr);  // receiver state vector
+    const float* __restrict__ scaA = (k == 0) ? gh : ((k == 4 || k == 6) ? sbar : nullptr);
+    const int e_beg = rowptr[j], e_end = rowptr[j + 1];
+    for (int eb = e_beg; eb < e_end; eb += SRC_EB) {
+      int ii[SRC_EB];
+      v3 A[SRC_EB], B[SRC_EB];
+      float sA[SRC_EB], sB[SRC_EB], hb[SRC_EB];
 #pragma unroll
-      for (int n = 0; n <= R; ++n) G[n] = fmaf(t, g[n], G[n]);
-      const float q = p * w;
-      axpy(av, q, cav);
-      axpy(avb, q, cavb);
-      if (k == 0 && ghb) axpy(avb, ghb[nf], ldv(v + nf * 3));            // the filter-free term ghb_i v_i
+      for (int u = 0; u < SRC_EB; ++u) ii[u] = dst[min(eb + u, e_end - 1)];
+#pragma unroll
+      for (int u = 0; u < SRC_EB; ++u) {
+        const size_t nf = (size_t)ii[u] * F + f;
+        const v3 zero{0.f, 0.f, 0.f};
+        A[u] = vecA ? ldv(vecA + nf * 3) : zero;
+        B[u] = vecB ? ldv(vecB + nf * 3) : zero;
+        sA[u] = scaA ? scaA[nf] : 0.f;
+        sB[u] = (k == 0) ? s[nf] : 0.f;
+        hb[u] = (k == 0 && ghb) ? ghb[nf] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < SRC_EB; ++u) {
+        if (eb + u < e_end) {
+          const float* __restrict__ g = geom + (size_t)(eb + u) * GS;
+          const v3 zero{0.f, 0.f, 0.f};
+          float gq = 0.f;
+          v3 cav = zero, cavb = zero;                    // source-side vectors that get multiplied by q_k
+          switch (k) {                                   // wave-uniform
+            case 0: gq = sA[u] * sB[u]; break;                                             // gh_i s_i
+            case 1: gq = dot(A[u], v3{g[U], g[U + 1], g[U + 2]}); break;
+            case 2: gq = dot(A[u], v_j); cav = A[u]; break;
+            case 3: gq = dot(A[u], cross(B[u], vb_j)); cavb = cross(A[u], B[u]); break;
+            case 4: gq = sA[u] * dot(A[u], vb_j); cavb = v3{sA[u] * A[u].x, sA[u] * A[u].y, sA[u] * A[u].z}; break;
+            case 5: gq = dot(A[u], vb_j); cavb = A[u]; break;
+            case 6: gq = sA[u] * dot(A[u], v_j); cav = v3{sA[u] * A[u].x, sA[u] * A[u].y, sA[u] * A[u].z}; break;
+            case 7: gq = dot(A[u], cross(B[u], v_j)); cav = cross(A[u], B[u]); break;
+            default: gq = dot(A[u], cross(B[u], vb_j)); cavb = cross(A[u], B[u]); break;
+          }
+          const float w = filt<R>(W, g);
+          a = fmaf(gq, w, a);
+          const float t = gq * p;
+#pragma unroll
+          for (int n = 0; n <= R; ++n) G[n] = fmaf(t, g[n], G[n]);
+          const float q = p * w;
+          axpy(av, q, cav);
+          axpy(avb, q, cavb);
+          if (k == 0 && ghb) axpy(avb, hb[u], B[u]);                                      // the filter-free term ghb_i v_i
+        }
+      }
     }
     if (k > 0) {
       float* r = &red[k - 1][0][lane];
@@ -424,7 +462,7 @@ int cgv_pseudo_msg_fwd(const float* phi, const float* s, const float* sbar, cons
                        const float* bd, float* dh, float* dhbar, float* dv, float* dvbar, int n_nodes, int n_feat,
                        int n_rbf, int residual, void* stream) {
   return cgv_pseudo_msg_fwd_rows(phi, s, sbar, v, vbar, geom_d, rowptr_d, src_d, Wd, bd, dh, dhbar, dv, dvbar, nullptr,
-                                 n_nodes, n_feat, n_rbf, residual, stream);
+                                 n_nodes, n_feat, n_rbf, residual, 0, stream);
 }
 
 /* As cgv_pseudo_msg_fwd; dv_rows (or NULL) [3 N, F] additionally receives dv as rows 3 i + xyz -- the operand layout
@@ -432,14 +470,28 @@ int cgv_pseudo_msg_fwd(const float* phi, const float* s, const float* sbar, cons
 int cgv_pseudo_msg_fwd_rows(const float* phi, const float* s, const float* sbar, const float* v, const float* vbar,
                             const float* geom_d, const int32_t* rowptr_d, const int32_t* src_d, const float* Wd,
                             const float* bd, float* dh, float* dhbar, float* dv, float* dvbar, float* dv_rows,
-                            int n_nodes, int n_feat, int n_rbf, int residual, void* stream) {
+                            int n_nodes, int n_feat, int n_rbf, int residual, int64_t n_edges_hint, void* stream) {
   CGV_REQUIRE(n_nodes >= 0 && n_feat > 0, "bad size");
   if (n_nodes == 0) return 0;
   CGV_REQUIRE(phi && s && sbar && v && vbar && rowptr_d && Wd && bd && dh && dhbar && dv && dvbar, "null pointer");
   dim3 grid(n_nodes, (n_feat + 63) / 64);
   hipStream_t st = (hipStream_t)stream;
+  // n_edges_hint (0 = unknown) only picks the variant: >= 16 edges per node -> 8 edges' gathers in flight (long segments:
+  // gather latency, not registers, sets the pace); results do not depend on it
+  const bool dense = n_edges_hint >= 16LL * n_nodes;
   CGV_DISPATCH_RBF(n_rbf, {
-    if ((long)grid.x * grid.y <= 256)
+#define CGV_PF(EBV, STV) hipLaunchKernelGGL((cgv::pseudo_fwd_k<RBF, EBV, STV>), grid, dim3(576), 0, st, phi, s, sbar, v, vbar, geom_d, \
+                         rowptr_d, src_d, Wd, bd, dh, dhbar, dv, dvbar, n_feat, residual, dv_rows)
+    const int variant = cgv::option(CGV_OPT_PSEUDO_FWD);
+    if (variant == 1) CGV_PF(2, false);
+    else if (variant == 2) CGV_PF(2, true);
+    else if (variant == 3) CGV_PF(4, true);
+    else if (variant == 4) CGV_PF(8, true);
+    else if (variant == 5) CGV_PF(8, false);
+    else if (variant == 6) CGV_PF(1, true);
+    else if (dense)        // 2000-atom config (64 beads, 61 edges each), per layer: EB 2 staged 56 us, EB 2 59, EB 4 / 8 staged 73 / 71,
+      CGV_PF(2, true);     // EB 8 80 -- the walk is bound by VALU issue (9 x 11 dependent FMAs per edge and channel), not by its loads
+    else if ((long)grid.x * grid.y <= 256)
       hipLaunchKernelGGL((cgv::pseudo_fwd_k<RBF, cgv::PSEUDO_EB_WIDE>), grid, dim3(576), 0, st, phi, s, sbar, v, vbar, geom_d,
                          rowptr_d, src_d, Wd, bd, dh, dhbar, dv, dvbar, n_feat, residual, dv_rows);
     else
@@ -458,7 +510,7 @@ int cgv_pseudo_msg_bwd(const float* phi, const float* s, const float* sbar, cons
                        const int32_t* rowptr_s, const int32_t* dst_s, const float* Wd, const float* bd, const float* gh,
                        const float* ghbar, const float* gv, const float* gvbar, float* g_phi, float* g_s, float* g_sbar,
                        float* g_v, float* g_vbar, float* gWd, float* gbd, int n_nodes, int n_feat, int n_rbf,
-                       int residual, void* workspace, size_t workspace_bytes, void* stream) {
+                       int residual, int64_t n_edges_hint, void* workspace, size_t workspace_bytes, void* stream) {
   CGV_REQUIRE(n_nodes >= 0 && n_feat > 0, "bad size");
   CGV_REQUIRE(phi && s && sbar && v && vbar && rowptr_d && rowptr_s && Wd && bd, "null input");
   CGV_REQUIRE(g_phi && g_s && g_sbar && g_v && g_vbar && gWd && gbd && workspace, "null output");
@@ -471,6 +523,7 @@ int cgv_pseudo_msg_bwd(const float* phi, const float* s, const float* sbar, cons
   const int npc = n_nodes > 0 ? (n_nodes + chunks - 1) / chunks : 1;
   float* part = reinterpret_cast<float*>(workspace);
   dim3 gridA(n_nodes > 0 ? n_nodes : 1, (n_feat + 63) / 64), gridB(chunks, (n_feat + 63) / 64);
+  const bool dense = n_edges_hint >= 16LL * n_nodes;
   CGV_DISPATCH_RBF(n_rbf, {
     if (n_nodes > 0 && (long)gridA.x * gridA.y <= 256)
       hipLaunchKernelGGL((cgv::pseudo_bwd_recv_k<RBF, cgv::PSEUDO_EB_WIDE>), gridA, dim3(64), 0, st, phi, v, vbar, geom_d,
@@ -478,8 +531,12 @@ int cgv_pseudo_msg_bwd(const float* phi, const float* s, const float* sbar, cons
     else if (n_nodes > 0)
       hipLaunchKernelGGL((cgv::pseudo_bwd_recv_k<RBF, cgv::PSEUDO_EB_NARROW>), gridA, dim3(64), 0, st, phi, v, vbar, geom_d,
                          rowptr_d, src_d, Wd, bd, gh, ghbar, gv, gvbar, g_s, g_sbar, g_v, g_vbar, n_feat, residual);
-    hipLaunchKernelGGL((cgv::pseudo_bwd_src_k<RBF>), gridB, dim3(576), 0, st, phi, s, sbar, v, vbar, geom_s, rowptr_s,
-                       dst_s, Wd, bd, gh, ghbar, gv, gvbar, g_phi, g_v, g_vbar, part, n_feat, n_nodes, npc);
+    if (dense && cgv::option(CGV_OPT_PSEUDO_FWD) == 4)     // (8 edges' gathers in flight: 119.7 us against 119.1 with 2 -- not the limiter)
+      hipLaunchKernelGGL((cgv::pseudo_bwd_src_k<RBF, 8>), gridB, dim3(576), 0, st, phi, s, sbar, v, vbar, geom_s, rowptr_s,
+                         dst_s, Wd, bd, gh, ghbar, gv, gvbar, g_phi, g_v, g_vbar, part, n_feat, n_nodes, npc);
+    else
+      hipLaunchKernelGGL((cgv::pseudo_bwd_src_k<RBF, 2>), gridB, dim3(576), 0, st, phi, s, sbar, v, vbar, geom_s, rowptr_s,
+                         dst_s, Wd, bd, gh, ghbar, gv, gvbar, g_phi, g_v, g_vbar, part, n_feat, n_nodes, npc);
   });
   dim3 rgrid((n_feat + 63) / 64, n_rbf + 1, 9);
   hipLaunchKernelGGL(cgv::pseudo_bwd_reduce, rgrid, dim3(64, cgv::PRED_SLICES), 0, st, part, chunks, n_rbf, n_feat, gWd, gbd);

@@ -283,7 +283,7 @@ class _PseudoMessage(torch.autograd.Function):
         _lib.call("cgv_pseudo_msg_fwd_rows", _lib.ptr(phi), _lib.ptr(s), _lib.ptr(sbar), _lib.ptr(v), _lib.ptr(vbar),
                   _lib.ptr(geom.geom_d), _lib.ptr(plan.rowptr_d), _lib.ptr(plan.src_d), _lib.ptr(Wd), _lib.ptr(bd),
                   _lib.ptr(dh), _lib.ptr(dhbar), _lib.ptr(dv), _lib.ptr(dvbar), _lib.ptr(rows) if rows is not None else None,
-                  n, F, geom.n_rbf, int(residual), _lib.stream_ptr(),
+                  n, F, geom.n_rbf, int(residual), plan.n_edges, _lib.stream_ptr(),
                   tag=f"pseudo_msg_fwd:Nd{n}:E{plan.n_edges}:dv1")
         ctx.save_for_backward(phi, s, sbar, v, vbar, Wd, bd)
         ctx.plan, ctx.geom = plan, geom
@@ -310,7 +310,7 @@ class _PseudoMessage(torch.autograd.Function):
                   _lib.ptr(geom.geom_s), _lib.ptr(plan.rowptr_s), _lib.ptr(plan.dst_s), _lib.ptr(Wd), _lib.ptr(bd),
                   _lib.ptr(gh), _lib.ptr(ghb), _lib.ptr(gv), _lib.ptr(gvb),
                   _lib.ptr(g_phi), _lib.ptr(g_s), _lib.ptr(g_sbar), _lib.ptr(g_v), _lib.ptr(g_vbar),
-                  _lib.ptr(gWd), _lib.ptr(gbd), n, F, geom.n_rbf, int(ctx.residual), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(),
+                  _lib.ptr(gWd), _lib.ptr(gbd), n, F, geom.n_rbf, int(ctx.residual), plan.n_edges, _lib.ptr(ws), ws_bytes, _lib.stream_ptr(),
                   tag=f"pseudo_msg_bwd:Nd{n}:E{plan.n_edges}:gv1")
         return g_phi, g_s, g_sbar, g_v, g_vbar, ret_W, ret_b, None, None, None
 

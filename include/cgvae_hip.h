@@ -73,7 +73,8 @@ enum {
   CGV_OPT_WGRAD_TILING = 7,    /* cgv_wgrad_plan: 0 balanced column tiles (default), 1 widest tile */
   CGV_OPT_TILE_FWD_LDS_MIN = 8,/* cgv_tile_linear_fwd: minimum 64x64 tile count for the LDS-staged kernel (default 448; 1 = always) */
   CGV_OPT_BWD_INPUT_WAVES = 9, /* cgv_tile_linear_bwd_input*: waves per block, 0 = built-in rule */
-  CGV_OPT_COUNT = 10
+  CGV_OPT_PSEUDO_FWD = 10,     /* cgv_pseudo_msg_fwd*: 0 built-in rule; 1..6 = (edges in flight, records staged in LDS) variants */
+  CGV_OPT_COUNT = 11
 };
 /* Measurement: store the GPU wall clock (cgv_timestamp_hz ticks per second) into *slot, in stream order; capturable. */
 int cgv_timestamp(uint64_t* slot /*device*/, void* stream);
@@ -264,7 +265,8 @@ int cgv_pseudo_msg_fwd(const float* phi /*[N,9F]*/, const float* s, const float*
 int cgv_pseudo_msg_fwd_rows(const float* phi, const float* s, const float* sbar, const float* v, const float* vbar,
                             const float* geom_d, const int32_t* rowptr_d, const int32_t* src_d, const float* Wd,
                             const float* bd, float* dh, float* dhbar, float* dv, float* dvbar, float* dv_rows,
-                            int n_nodes, int n_feat, int n_rbf, int residual, void* stream);
+                            int n_nodes, int n_feat, int n_rbf, int residual, int64_t n_edges_hint /*0: unknown; dispatch only*/,
+                            void* stream);
 size_t cgv_pseudo_msg_bwd_workspace_bytes(int n_nodes, int n_feat, int n_rbf);
 int cgv_pseudo_msg_bwd(const float* phi, const float* s, const float* sbar, const float* v, const float* vbar,
                        const float* geom_d, const int32_t* rowptr_d, const int32_t* src_d,
@@ -273,7 +275,8 @@ int cgv_pseudo_msg_bwd(const float* phi, const float* s, const float* sbar, cons
                        const float* gh, const float* ghbar, const float* gv, const float* gvbar,
                        float* g_phi /*[N,9F]*/, float* g_s, float* g_sbar, float* g_v, float* g_vbar,
                        float* gWd /*[9F,R]*/, float* gbd /*[9F]*/, int n_nodes, int n_feat, int n_rbf,
-                       int residual, void* workspace, size_t workspace_bytes, void* stream);
+                       int residual, int64_t n_edges_hint /*0: unknown; dispatch only*/, void* workspace,
+                       size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Decoder layer as channel-group kernels (csrc/decoder_layer.hip) -- replaces, for bead graphs of at most 16 nodes, the
