@@ -52,11 +52,32 @@ __device__ __forceinline__ int pj_find_edge(const PlanJobs& J, int e) {
   return j;
 }
 
+// Wave-aggregated counter updates: the edge lists of a radius graph arrive (mostly) sorted by row, so the 64 lanes of a
+// wave hit a handful of counters -- 125 atomics per counter on the chignolin atom graph, 43 / 49 us for the two kernels.
+// Lanes that address the same counter elect a leader which issues ONE atomic for all of them.
+__device__ __forceinline__ unsigned long long pj_same_counter(int* addr, bool active, int& leader) {
+  const unsigned long long act = __ballot(active);
+  leader = __ffsll((long long)act) - 1;
+  const unsigned long long a = (unsigned long long)(uintptr_t)addr;
+  const unsigned lo = __shfl((unsigned)a, leader), hi = __shfl((unsigned)(a >> 32), leader);
+  return __ballot(active && (unsigned)a == lo && (unsigned)(a >> 32) == hi);
+}
+
 __global__ __launch_bounds__(256) void pj_count_k(PlanJobs J) {
   const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= J.total_edges) return;
-  const PlanJob& p = J.job[pj_find_edge(J, e)];
-  atomicAdd(p.count + pj_key(p, e - p.edge_begin), 1);
+  bool active = e < J.total_edges;
+  int* addr = nullptr;
+  if (active) {
+    const PlanJob& p = J.job[pj_find_edge(J, e)];
+    addr = p.count + pj_key(p, e - p.edge_begin);
+  }
+  const int lane = threadIdx.x & 63;
+  while (__ballot(active)) {
+    int leader;
+    const unsigned long long grp = pj_same_counter(addr, active, leader);
+    if (lane == leader) atomicAdd(addr, __popcll(grp));
+    if ((grp >> lane) & 1ull) active = false;
+  }
 }
 
 __global__ __launch_bounds__(1024) void pj_scan_k(PlanJobs J) {        // block b: exclusive scan of job b's counts
@@ -92,11 +113,31 @@ __global__ __launch_bounds__(1024) void pj_scan_k(PlanJobs J) {        // block 
 
 __global__ __launch_bounds__(256) void pj_drop_k(PlanJobs J) {
   const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= J.total_edges) return;
-  const PlanJob& p = J.job[pj_find_edge(J, e)];
-  const int le = e - p.edge_begin;
-  const int r = pj_key(p, le);
-  p.tmp[p.rowptr[r] + atomicSub(p.count + r, 1) - 1] = le;         // the row's slots are handed out last to first
+  bool active = e < J.total_edges;
+  int* addr = nullptr;
+  int* tmp = nullptr;
+  int le = 0, row_begin = 0;
+  if (active) {
+    const PlanJob& p = J.job[pj_find_edge(J, e)];
+    le = e - p.edge_begin;
+    const int r = pj_key(p, le);
+    addr = p.count + r;
+    tmp = p.tmp;
+    row_begin = p.rowptr[r];
+  }
+  const int lane = threadIdx.x & 63;
+  while (__ballot(active)) {
+    int leader;
+    const unsigned long long grp = pj_same_counter(addr, active, leader);
+    int base = 0;
+    if (lane == leader) base = atomicSub(addr, __popcll(grp));       // the row's slots are handed out last to first
+    base = __shfl(base, leader);
+    if ((grp >> lane) & 1ull) {
+      const int rank = __popcll(grp & ((1ull << lane) - 1ull));
+      tmp[row_begin + base - 1 - rank] = le;                          // any order inside the row: the row sort fixes it
+      active = false;
+    }
+  }
 }
 
 constexpr int PJ_LDS_KEYS = 2048;

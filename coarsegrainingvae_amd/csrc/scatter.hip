@@ -89,6 +89,16 @@ __global__ __launch_bounds__(BLOCK) void segment_broadcast_k(const float* __rest
   }
 }
 
+__global__ __launch_bounds__(256) void embedding_rows_k(const float* __restrict__ weight, const float* __restrict__ ids,
+                                                        int id_stride, int n_types, int channels, float* __restrict__ out) {
+  const int i = blockIdx.x;
+  const int c4 = blockIdx.y * 256 + threadIdx.x;
+  if (c4 * 4 >= channels) return;
+  int t = (int)ids[(size_t)i * id_stride];
+  t = t < 0 ? 0 : (t >= n_types ? n_types - 1 : t);                       // (nn.Embedding would raise: ids are validated on the host once)
+  reinterpret_cast<float4*>(out + (size_t)i * channels)[c4] = reinterpret_cast<const float4*>(weight + (size_t)t * channels)[c4];
+}
+
 }  // namespace cgv
 
 extern "C" {
@@ -111,6 +121,20 @@ int cgv_segment_reduce(const float* src, const int32_t* rowptr, const int32_t* p
                        mean, out);
   }
   return cgv::check_launch("cgv_segment_reduce");
+}
+
+/* nn.Embedding lookup with the type ids read as they sit in the batch (cgvae.py:268, 381: ids = nxyz[:, 0], a float
+ * column): out[i, :] = weight[(int) ids[i * id_stride], :] in one launch (the tensor-op route: cast, fills, gather). */
+int cgv_embedding_rows(const float* weight, const float* ids_f32, int id_stride, int n_rows, int n_types, int channels,
+                       float* out, void* stream) {
+  CGV_REQUIRE(n_rows >= 0 && channels > 0 && n_types > 0 && id_stride >= 1, "bad size");
+  if (n_rows == 0) return 0;
+  CGV_REQUIRE(weight && ids_f32 && out, "null pointer");
+  CGV_REQUIRE((channels % 4) == 0 && ((((uintptr_t)weight) | ((uintptr_t)out)) & 15) == 0, "need channels % 4 == 0, 16-byte aligned");
+  dim3 grid(n_rows, (channels / 4 + 255) / 256);
+  hipLaunchKernelGGL(cgv::embedding_rows_k, grid, dim3(256), 0, (hipStream_t)stream, weight, ids_f32, id_stride, n_types,
+                     channels, out);
+  return cgv::check_launch("cgv_embedding_rows");
 }
 
 int cgv_segment_broadcast(const float* gout, const int32_t* rowptr, const int32_t* perm, int n_seg, int channels,

@@ -312,7 +312,7 @@ class CGequiVAE(nn.Module):
         on the host generator); otherwise it is drawn on the device."""
         if eps is None:
             eps = torch.randn_like(sigma)
-        return eps.mul(sigma).add_(mu)
+        return torch.addcmul(mu, eps, sigma)              # one launch (and one in backward) instead of mul + add
 
     def CG2ChannelIdx(self, CG_mapping):
         """Rank of each atom inside its bead (cgvae.py:451-460) without the per-bead host loop."""

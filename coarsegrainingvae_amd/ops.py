@@ -161,7 +161,13 @@ class _Embedding(torch.autograd.Function):
     @staticmethod
     def forward(ctx, weight, idx, plan: EdgePlan):
         ctx.plan, ctx.param = plan, weight
-        return weight.index_select(0, idx)
+        if idx.dtype == torch.float32 and idx.dim() == 1 and weight.shape[1] % 4 == 0:
+            # ids as they sit in the batch (nxyz[:, 0]): one launch, no cast / fill / gather chain
+            out = torch.empty(idx.shape[0], weight.shape[1], dtype=_F32, device=weight.device)
+            _lib.call("cgv_embedding_rows", _lib.ptr(weight.detach()), idx.data_ptr(), int(idx.stride(0)), idx.shape[0],
+                      weight.shape[0], weight.shape[1], _lib.ptr(out), _lib.stream_ptr())
+            return out
+        return weight.index_select(0, idx.long())
 
     @staticmethod
     def backward(ctx, g):
@@ -187,14 +193,16 @@ def embedding_plan(idx: torch.Tensor, n_types: int, padding_idx: Optional[int]) 
 
 
 def embedding(module, idx: torch.Tensor, plan: Optional[EdgePlan] = None) -> torch.Tensor:
-    """``module(idx)`` for an nn.Embedding, with the plan-based weight gradient on device tensors."""
-    idx = idx.long()
+    """``module(idx)`` for an nn.Embedding, with the plan-based weight gradient on device tensors.  ``idx`` may be the
+    float column the reference indexes with after ``.long()`` (cgvae.py:268): it is then read as is."""
+    if not (idx.dtype == torch.float32 and idx.dim() == 1 and idx.is_cuda):
+        idx = idx.long()
     w = module.weight
     if not (w.is_cuda and w.is_contiguous() and w.dtype == torch.float32 and module.max_norm is None
             and not module.sparse):
         if getattr(w, "_cgv_direct", False):
             raise RuntimeError("this embedding's gradient is arena-managed: it needs the device path")
-        return module(idx)
+        return module(idx.long())
     if plan is None:
         plan = embedding_plan(idx, w.shape[0], module.padding_idx)
     return _Embedding.apply(w, idx, plan)

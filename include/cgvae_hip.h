@@ -183,6 +183,10 @@ int cgv_segment_reduce(const float* src, const int32_t* rowptr, const int32_t* p
 /* backward of the above: gsrc[perm?perm[p]:p, :] = gout[seg(p), :] (* 1/max(len,1) if mean) */
 int cgv_segment_broadcast(const float* gout, const int32_t* rowptr, const int32_t* perm, int n_seg, int channels,
                           int mean, float* gsrc /*[n_rows,C]*/, void* stream);
+/* nn.Embedding lookup (cgvae.py:268, 381) with the ids read from a float column (nxyz[:, 0], element stride id_stride):
+ * out[i, :] = weight[(int) ids[i * id_stride], :]; ids are clamped to [0, n_types). */
+int cgv_embedding_rows(const float* weight /*[n_types,C]*/, const float* ids_f32, int id_stride, int n_rows, int n_types,
+                       int channels, float* out /*[n_rows,C]*/, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * K2 / K4  fused EquiMessageBlock (conv.py:505-563 incl. InvariantMessage 63-75 and
