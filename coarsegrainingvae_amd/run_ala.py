@@ -5,9 +5,13 @@ training loop of one fold: model wiring (run_ala.py:184-209), Adam + ReduceLROnP
 early stopping (211-215, 232-284) and the CSV log columns (228-229, 252-258).
 
 Out of scope: trajectory download / mdtraj loading, CG-mapping
-learners, k-fold evaluation metrics.  Since no trajectories exist offline, frames come from
-``--synthetic`` (uniform random coordinates of the dataset's shape) -- the only
-flag added, together with ``-device`` accepting ``cuda:N`` strings besides the reference's int.
+learners, k-fold evaluation metrics.  Frames come either from ``--synthetic`` (uniform random
+coordinates of the dataset's shape) or from ``-traj file.npz`` -- a trajectory
+converted offline by ``tools/traj_to_npz.py`` (xyz [T,n,3] in Angstrom, z [n], bonds, optional
+atom -> bead ``mapping``), which goes through the on-device ``build_dataset`` (datasets.py:459-506:
+random rotation per frame, bead coordinates = scatter_mean, higher-order bond edges, batched
+radius graphs).  Added flags: ``--synthetic``, ``-traj``, ``--no_hip_graph``; ``-device`` also
+accepts ``cuda:N`` strings besides the reference's int.
 
     python -m coarsegrainingvae_amd.run_ala -logdir out -device 0 -dataset chignolin -n_cgs 6 \
         -batch_size 2 -ndata 64 -nepochs 3 -atom_cutoff 12.0 -cg_cutoff 25.0 -beta 0.05 -gamma 50.0 \
@@ -76,6 +80,8 @@ def build_parser() -> argparse.ArgumentParser:
                    help="launch every kernel of every step eagerly instead of replaying one captured hipGraph per step")
     p.add_argument("--synthetic", action="store_true", default=False,
                    help="random-coordinate frames of the dataset's shape (no trajectories offline)")
+    p.add_argument("-traj", type=str, default=None,
+                   help="trajectory file from tools/traj_to_npz.py (xyz [T,n,3], z [n], bonds [Eb,2], optional mapping [n])")
     return p
 
 
@@ -112,6 +118,33 @@ class EarlyStopping:
             self.counter += 1
             if self.counter >= self.patience:
                 self.early_stop = True
+
+
+def load_trajectory_dataset(params, device):
+    """The non-synthetic branch of run_ala.py:124-181 for a file written by tools/traj_to_npz.py: frames (Angstrom),
+    atomic numbers and the bond graph come from the file; the atom -> bead map is the file's ``mapping`` or, without
+    one, contiguous equal blocks of atoms (the reference's mapping learners -- cgae / newman / backbone partition,
+    datasets.py:252-330 -- are out of scope); then ``build_dataset`` on the device (datasets.py:459-506)."""
+    with np.load(params["traj"]) as f:
+        need = {"xyz", "z", "bonds"}
+        if not need.issubset(f.files):
+            raise SystemExit(f"{params['traj']}: missing {sorted(need - set(f.files))} (see tools/traj_to_npz.py)")
+        xyz, z, bonds = f["xyz"], f["z"], f["bonds"]
+        mapping = f["mapping"] if "mapping" in f.files else None
+    xyz = xyz[: params["ndata"]]
+    n_atoms = xyz.shape[1]
+    if mapping is None:
+        if not params["n_cgs"]:
+            raise SystemExit("the trajectory file has no mapping: pass -n_cgs (contiguous equal blocks of atoms)")
+        mapping = (np.arange(n_atoms) * params["n_cgs"]) // n_atoms
+    n_cgs = int(mapping.max()) + 1
+    if params["n_cgs"] and params["n_cgs"] != n_cgs:
+        raise SystemExit(f"-n_cgs {params['n_cgs']} but the file's mapping has {n_cgs} beads")
+    params["n_cgs"] = n_cgs
+    gen = torch.Generator().manual_seed(123)
+    dataset = cgdata.build_dataset(mapping, xyz, params["atom_cutoff"], params["cg_cutoff"], z, bonds,
+                                   order=params["edgeorder"], rotate=True, generator=gen, device=device)
+    return dataset, torch.as_tensor(mapping).long()
 
 
 def _device(arg: str) -> torch.device:
@@ -154,19 +187,24 @@ def run(params) -> dict:
         dist.init_process_group("nccl", device_id=device)
         if params["batch_size"] % world:
             raise SystemExit("-batch_size must be divisible by the number of GPUs (equal-size shards)")
-    if not params["synthetic"]:
-        raise SystemExit("only --synthetic data is available in this build: trajectory ingestion "
-                         "(mdtraj/mdshare, datasets.py) is outside the hot path (SURVEY.md 2.1 row 7)")
-    if params["dataset"] not in DATASET_SHAPES:
-        raise SystemExit(f"unknown -dataset {params['dataset']}; known shapes: {sorted(DATASET_SHAPES)}")
+    if not params["synthetic"] and not params.get("traj"):
+        raise SystemExit("pass -traj file.npz (a trajectory converted by tools/traj_to_npz.py) or --synthetic: the "
+                         "reference's mdtraj / mdshare ingestion (datasets.py:170-187) is outside the hot path "
+                         "(SURVEY.md 2.1 row 7)")
     seed = 123                                                          # run_ala.py:36-41
     torch.manual_seed(seed)
     np.random.seed(seed)
     beta = 0.0 if params["det"] else params["beta"]                      # run_ala.py:117-121
-    n_atoms = DATASET_SHAPES[params["dataset"]]
-    box = {"dipeptide": 6.0, "chignolin": 14.0, "pentapeptide": 11.0}[params["dataset"]]
-    props = cgdata.synthetic_frames(params["ndata"], n_atoms, params["n_cgs"], box, seed=0)
-    dataset = cgdata.CGDataset(props)
+    if params.get("traj"):
+        dataset, mapping = load_trajectory_dataset(params, device)
+    else:
+        if params["dataset"] not in DATASET_SHAPES:
+            raise SystemExit(f"unknown -dataset {params['dataset']}; known shapes: {sorted(DATASET_SHAPES)}")
+        n_atoms = DATASET_SHAPES[params["dataset"]]
+        box = {"dipeptide": 6.0, "chignolin": 14.0, "pentapeptide": 11.0}[params["dataset"]]
+        dataset = cgdata.CGDataset(cgdata.synthetic_frames(params["ndata"], n_atoms, params["n_cgs"], box, seed=0))
+        mapping = dataset.props["CG_mapping"][0]
+    props = dataset.props
     # --cg_radius_graph has the reference's inverted sense: set => CG graph from bonds (run_ala.py:64-67)
     dataset.generate_neighbor_list(params["atom_cutoff"], None if params["cg_radius_graph"] else params["cg_cutoff"],
                                    device=device, undirected=True)
@@ -189,7 +227,7 @@ def run(params) -> dict:
     if rank == 0 and logdir:
         os.makedirs(logdir, exist_ok=True)
         with open(os.path.join(logdir, "modelparams.json"), "w") as f:
-            json.dump({**params, "mapping": props["CG_mapping"][0].tolist()}, f, indent=4)
+            json.dump({**params, "mapping": torch.as_tensor(mapping).tolist()}, f, indent=4)
     log_rows, failed = [], False
     columns = ["epoch", "lr", "train_loss", "val_loss", "train_recon", "val_recon", "train_KL", "val_KL",
                "train_graph", "val_graph"]
