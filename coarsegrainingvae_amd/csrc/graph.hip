@@ -236,16 +236,24 @@ __global__ __launch_bounds__(256) void grp_build_k(const int* __restrict__ rowpt
   }
   __syncthreads();
   // sorted position of every element, then the sorted keys replace the unsorted ones
-  for (int t0 = 0; t0 < L; t0 += blockDim.x) {
-    const int t = t0 + threadIdx.x;
-    unsigned long long mine = 0;
-    int rank = 0;
-    if (t < L) {
-      mine = k[t];
-      for (int u = 0; u < L; ++u) rank += k[u] < mine;
-      pos_g[beg + rank] = (int)(unsigned)(mine & 0xffffffffull);          // scratch: the key's low word, in sorted order
-      dst_g[beg + rank] = (int)(mine >> 32);                              // scratch: the key's high word
+  // four keys per thread are ranked against every key read (850 keys per group on the 2000-atom graph: 666 us per batch
+  // with one key per pass)
+  for (int t0 = threadIdx.x; t0 < L; t0 += 4 * blockDim.x) {
+    unsigned long long mine[4];
+    int rank[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) mine[q] = k[min(t0 + q * (int)blockDim.x, L - 1)];
+    for (int u = 0; u < L; ++u) {
+      const unsigned long long other = k[u];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) rank[q] += other < mine[q];
     }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (t0 + q * (int)blockDim.x < L) {
+        pos_g[beg + rank[q]] = (int)(unsigned)(mine[q] & 0xffffffffull);  // scratch: the key's low word, in sorted order
+        dst_g[beg + rank[q]] = (int)(mine[q] >> 32);                      // scratch: the key's high word
+      }
   }
   __threadfence_block();
   __syncthreads();

@@ -83,11 +83,13 @@ class GradSync:
         self.dist, self.world, self.group = dist, world_size, group
         self.bucket = max(bucket_bytes // 4, 1)
         self.pending = []
+        self.issued = []              # every asynchronous collective since the last drain() (handles, for drain())
 
     def all_reduce_range(self, flat: torch.Tensor, lo: int, hi: int):
         for start in range(lo, hi, self.bucket):
             self.pending.append(self.dist.all_reduce(flat[start:min(start + self.bucket, hi)],
                                                      op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._remember(self.pending[-1])
 
     def wait(self):
         for w in self.pending:
@@ -97,7 +99,15 @@ class GradSync:
     def all_gather(self, recv: torch.Tensor, send: torch.Tensor):
         """Asynchronous all-gather of equally sized ``send`` buffers into ``recv`` ([world * send.numel()], rank
         major); returns the work handle (``.wait()`` makes the current stream wait for the result)."""
-        return self.dist.all_gather_into_tensor(recv, send, group=self.group, async_op=True)
+        work = self.dist.all_gather_into_tensor(recv, send, group=self.group, async_op=True)
+        self._remember(work)
+        return work
+
+    def _remember(self, work):
+        if not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):      # captured collectives are graph nodes
+            self.issued.append(work)
+            if len(self.issued) > 4096:                           # long eager runs: completed handles need not be kept
+                self.issued = [w for w in self.issued[-1024:]]
 
     def same_on_all_ranks(self, value: int) -> bool:
         t = torch.tensor([value, -value], dtype=torch.int64, device=self._device())
@@ -134,17 +144,24 @@ class GradSync:
         self.all_reduce_range(flat, 0, flat.numel())
         self.wait()
 
-    def drain(self):
-        """Before stream capture: the process group's watchdog thread polls the events of eager
-        collectives; an event query from another thread while a stream captures aborts the process.
-        Wait until nothing is left for it to poll."""
+    def drain(self, timeout_s: float = 30.0):
+        """Before stream capture: every eager collective this object issued must be COMPLETE, not merely ordered -- the
+        process group's watchdog thread polls the events of unfinished work, and the step is captured with
+        ``capture_error_mode="thread_local"`` precisely so that such foreign-thread queries are legal, but a collective
+        still in flight would also run concurrently with the capture's warm-up state.  Explicit: wait on each returned
+        work handle, synchronise the device, then poll the handles' completion flags (bounded)."""
         import time
-        pg = self.group if self.group is not None else self.dist.group.WORLD
-        try:
-            pg._wait_for_pending_works()
-        except Exception:
-            time.sleep(1.0)
-        time.sleep(0.3)
+        for w in self.issued:
+            w.wait()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        deadline = time.monotonic() + timeout_s
+        for w in self.issued:
+            while not w.is_completed():
+                if time.monotonic() > deadline:
+                    raise RuntimeError("a collective issued before the capture did not complete")
+                time.sleep(0.001)
+        self.issued = []
 
     def mean_scalar(self, x: torch.Tensor) -> torch.Tensor:
         y = x.detach().clone().reshape(1)

@@ -1,0 +1,23 @@
+#!/bin/bash
+# usage (on the GPU box): tools/collect_profiles.sh <tag>   -> gpurun_out/<tag>_*: bench lines, rocprofv3 kernel stats of the same
+# commands, one replayed step in launch order, in-graph section times, PMC passes (separate runs) of the decoder / message kernels
+tag=${1:-r02}
+cd /tmp && export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out
+for w in chignolin dipeptide protein2000; do
+  cpu=""; [ "$w" = "protein2000" ] && cpu="--no-cpu-baseline"
+  python bench.py --workload $w $cpu > gpurun_out/${tag}_bench_$w.json 2> gpurun_out/${tag}_bench_$w.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$w -o bench -- python bench.py --workload $w --no-cpu-baseline --no-parity > /tmp/prof_$w.log 2>&1
+  cp /tmp/prof_$w/bench_kernel_stats.csv gpurun_out/${tag}_${w}_kernel_stats.csv
+  python tools/section_times.py $w > gpurun_out/${tag}_section_times_$w.txt 2>&1
+done
+bash tools/step_sequence.sh --no-extras --no-parity > /dev/null 2>&1
+cp gpurun_out/step_sequence.txt gpurun_out/${tag}_step_sequence_chignolin.txt
+python tools/dec_phase_probe.py > gpurun_out/${tag}_decoder_phase_clock.txt 2>&1
+# PMC: counters in their own runs (eager launches so that kernels appear as dispatches), chignolin
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -o p -- python bench.py --no-graph --no-cpu-baseline --no-parity --no-extras --steps 4 --warmup 2 --reps 1 > /tmp/pmc_$c.log 2>&1
+  python tools/pmc_summary.py /tmp/pmc_$c/p_counter_collection.csv equi_msg dec_ grouped_wgrad adam_update segment_reduce skinny_fwd > gpurun_out/${tag}_pmc_${c}_eager.txt 2>&1
+done
+ls -la gpurun_out | grep ${tag}_ | wc -l
