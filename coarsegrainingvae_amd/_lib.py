@@ -87,8 +87,10 @@ PROTOTYPES = {
     "cgv_decoder_layer_supported": (_i, [_i, _i, _i]),
     "cgv_decoder_slice_floats": (C.c_int64, [_i, _i]),
     "cgv_decoder_max_edges": (_i, []),
+    "cgv_decoder_block_channels": (_i, [_i]),
     "cgv_decoder_debug_clock": (_i, [_p]),
     "cgv_decoder_msg_fwd": (_i, [_p] * 18 + [_i, _i, _i, _i, _p]),
+    "cgv_decoder_dense_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "cgv_decoder_uv_fwd": (_i, [_p, _p, _p, _p, _i, _i, _p]),
     "cgv_decoder_gate_fwd": (_i, [_p] * 9 + [_i, _i, _p]),
     "cgv_decoder_gate_bwd": (_i, [_p, _p, _p, _p, _i, C.c_int64, _p, _p, _p, _p, _p, _p, C.c_int64, _i, _i, _p]),
@@ -133,7 +135,7 @@ PROTOTYPES = {
 
 # include/cgvae_hip.h: CGV_OPT_* (A/B switches of the launchers; defaults in csrc/api.cpp)
 OPTIONS = {"msg_fwd_split": 0, "msg_bwd_split": 1, "msg_fwd_kernel": 2, "grp_waves": 3, "grp_records": 4, "csr_build": 5,
-           "pseudo_chunks": 6, "wgrad_tiling": 7, "tile_fwd_lds_min": 8, "bwd_input_waves": 9, "pseudo_fwd": 10}
+           "pseudo_chunks": 6, "wgrad_tiling": 7, "tile_fwd_lds_min": 8, "bwd_input_waves": 9, "pseudo_fwd": 10, "decoder_fat": 11}
 
 
 def set_option(name: str, value: int) -> None:

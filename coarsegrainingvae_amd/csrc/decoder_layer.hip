@@ -419,6 +419,28 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_fwd_k(
   DL_TICK(13);
 }
 
+// ============================================================================================== F1 / F4: full-width Dense
+// y = act(x W^T + b), z = pre-activation, for M <= 16 rows: N / 4 blocks of 4 output columns each (150 CUs pull the
+// weight instead of the 38 of skinny_fwd_k's 16-column blocks).
+__global__ __launch_bounds__(DL_THREADS) void dec_dense_fwd_k(const float* __restrict__ x, const float* __restrict__ W,
+                                                              const float* __restrict__ bias, float* __restrict__ y,
+                                                              float* __restrict__ zout, int n, int N, int K, int act) {
+  Carve cv;
+  float* red = cv.take(fwd_red_floats<1, 1>());
+  float* o_l = cv.take(16 * 4);
+  const int n0 = blockIdx.x * DL_CB;
+  const int row0[1] = {n0};
+  const bool mine = threadIdx.x < n * 4;
+  const int i = threadIdx.x >> 2, c = threadIdx.x & 3;
+  const float b = (mine && bias) ? bias[n0 + c] : 0.f;
+  fwd_core<1, 1>(o_l, red, x, n, K, W, row0);
+  if (mine) {
+    const float zv = o_l[i * 4 + c] + b;
+    const size_t at = (size_t)i * N + n0 + c;
+    if (act) { if (zout) zout[at] = zv; y[at] = act_fwd(zv, act); } else y[at] = zv;
+  }
+}
+
 // ============================================================================================== F3: [U | Vv] + norm
 __global__ __launch_bounds__(DL_THREADS) void dec_uv_fwd_k(const float* __restrict__ rows, const float* __restrict__ Wuv,
                                                            float* __restrict__ UV, float* __restrict__ stack, int n, int F) {
@@ -475,25 +497,35 @@ __global__ __launch_bounds__(DL_THREADS) void dec_gate_fwd_k(const float* __rest
 }
 
 // ============================================================================================== B1: gate backward + W1' rows
+// CBQ = channel quads per block (1: 4 channels, F / 4 blocks; 2: 8 channels, F / 8 blocks -- half as many, twice as fat
+// slices: a phase's slice volume is blocks x rows x K, so fatter blocks halve what the next phase reads back).
+template <int CBQ>
 __global__ __launch_bounds__(DL_THREADS) void dec_gate_bwd_k(
     const float* __restrict__ UV, const float* __restrict__ a, const float* __restrict__ gs_base,
     const float* __restrict__ gs_slices, int gs_n, long long gs_stride, const float* __restrict__ gv,
     const float* __restrict__ W1p, float* __restrict__ ga, float* __restrict__ gUV, float* __restrict__ gs_sum,
     float* __restrict__ slices_out, long long out_stride, int n, int F) {
+  constexpr int C = 4 * CBQ, G = 3 * CBQ;
   Carve cv;
   float* stage = cv.take(bi_stage_floats<1>());
-  float4* scratch = reinterpret_cast<float4*>(cv.take(36 * 16 * 4));
-  float4* gs_l = reinterpret_cast<float4*>(cv.take(16 * 4));
-  float* g_l = cv.take(16 * 3 * 4);
-  const int f0 = blockIdx.x * DL_CB;
-  const int row0[3] = {f0, F + f0, 2 * F + f0};
+  float4* scratch = reinterpret_cast<float4*>(cv.take(CBQ * 36 * 16 * 4));
+  float4* gs_l = reinterpret_cast<float4*>(cv.take(CBQ * 16 * 4));
+  float* g_l = cv.take(16 * G * 4);
+  const int f0 = blockIdx.x * C;
+  int row0[G];
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+#pragma unroll
+    for (int q = 0; q < CBQ; ++q) row0[g * CBQ + q] = g * F + f0 + 4 * q;
   // order of requests: the slices and the prologue's own operands first, the weights behind them
   const bool have_slices = gs_slices && gs_n > 0;
-  const int kq[1] = {(int)blockIdx.x};
-  QuadRegs<1, 1> qr;
-  quad_issue<1, 1>(qr, have_slices ? gs_slices : UV, have_slices ? gs_n : 1, have_slices ? gs_stride : 0, have_slices ? n : 1, kq);
-  const bool mine = threadIdx.x < n * 4;
-  const int i = threadIdx.x >> 2, c = threadIdx.x & 3, f = f0 + c;
+  int kq[CBQ];
+#pragma unroll
+  for (int q = 0; q < CBQ; ++q) kq[q] = have_slices ? (int)blockIdx.x * CBQ + q : 0;
+  QuadRegs<1, CBQ> qr;
+  quad_issue<1, CBQ>(qr, have_slices ? gs_slices : UV, have_slices ? gs_n : 1, have_slices ? gs_stride : 0, have_slices ? n : 1, kq);
+  const bool mine = threadIdx.x < n * C;
+  const int i = threadIdx.x / C, c = threadIdx.x - i * C, f = f0 + c;
   const size_t nf = (size_t)i * F + f;
   const size_t b = (size_t)i * 3 * 2 * F + f, cc = (size_t)i * 3 * F + f;
   float ux = 0.f, uy = 0.f, uz = 0.f, vx = 0.f, vy = 0.f, vz = 0.f, a_vv = 0.f, a_sv = 0.f, gsb = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
@@ -504,79 +536,89 @@ __global__ __launch_bounds__(DL_THREADS) void dec_gate_bwd_k(
     if (gs_base) gsb = gs_base[nf];
     if (gv) { const f3 t = ld3(gv + nf * 3); gx = t.x; gy = t.y; gz = t.z; }
   }
-  BiRegs<3, 2> wr;
-  bi_prefetch<3, 2>(wr, W1p, F, row0);
-  for (int o = threadIdx.x; o < 16 * 12; o += DL_THREADS) g_l[o] = 0.f;
-  quad_finish<1, 1>(qr, gs_l, scratch, have_slices ? gs_n : 0, n);           // no slices: every class empty -> zeros
+  BiRegs<G, 2> wr;
+  bi_prefetch<G, 2>(wr, W1p, F, row0);
+  for (int o = threadIdx.x; o < 16 * G * 4; o += DL_THREADS) g_l[o] = 0.f;
+  quad_finish<1, CBQ>(qr, gs_l, scratch, have_slices ? gs_n : 0, n);         // no slices: every class empty -> zeros
   if (mine) {
-    const float gs = reinterpret_cast<const float*>(gs_l)[i * 4 + c] + gsb;
+    const int q = c >> 2, c4 = c & 3;
+    const float gs = reinterpret_cast<const float*>(gs_l + q * 16)[i * 4 + c4] + gsb;
     gs_sum[nf] = gs;
     const float inner = ux * vx + uy * vy + uz * vz;
     const float cs = gs * a_sv;
     const float g0 = gx * ux + gy * uy + gz * uz, g1 = gs * inner, g2 = gs;
     ga[cc] = g0; ga[cc + F] = g1; ga[cc + 2 * F] = g2;
-    g_l[(i * 3 + 0) * 4 + c] = g0; g_l[(i * 3 + 1) * 4 + c] = g1; g_l[(i * 3 + 2) * 4 + c] = g2;
+    g_l[(i * G + 0 * CBQ + q) * 4 + c4] = g0; g_l[(i * G + 1 * CBQ + q) * 4 + c4] = g1; g_l[(i * G + 2 * CBQ + q) * 4 + c4] = g2;
     gUV[b] = fmaf(gx, a_vv, cs * vx); gUV[b + 2 * F] = fmaf(gy, a_vv, cs * vy); gUV[b + 4 * F] = fmaf(gz, a_vv, cs * vz);
     gUV[b + F] = cs * ux; gUV[b + 2 * F + F] = cs * uy; gUV[b + 4 * F + F] = cs * uz;
   }
   __syncthreads();
-  bi_core<1, 3, 2>(wr, g_l, stage, slices_out + (size_t)blockIdx.x * out_stride, F, n);
+  bi_core<1, G, 2>(wr, g_l, stage, slices_out + (size_t)blockIdx.x * out_stride, F, n);
 }
 
-// ============================================================================================== B2 / B5: slice sum, act', one row group
-template <int NT>
+// ============================================================================================== B2 / B5: slice sum, act', CBQ row groups
+template <int NT, int CBQ>
 __global__ __launch_bounds__(DL_THREADS) void dec_dense_bwd_k(const float* __restrict__ g_slices, int g_n, long long g_stride,
                                                               const float* __restrict__ z, int act, const float* __restrict__ W,
                                                               float* __restrict__ g_dense, float* __restrict__ slices_out,
                                                               long long out_stride, int n, int N, int K) {
+  constexpr int C = 4 * CBQ;
   Carve cv;
   float* stage = cv.take(bi_stage_floats<1>());
-  float4* scratch = reinterpret_cast<float4*>(cv.take(36 * 16 * 4));
-  float4* sum_l = reinterpret_cast<float4*>(cv.take(16 * 4));
-  float* g_l = cv.take(16 * 4);
-  const int n0 = blockIdx.x * DL_CB;
-  const int row0[1] = {n0};
-  const int kq[1] = {(int)blockIdx.x};
-  QuadRegs<1, 1> qr;
-  quad_issue<1, 1>(qr, g_slices, g_n, g_stride, n, kq);
-  const int i = threadIdx.x >> 2, c = threadIdx.x & 3;
+  float4* scratch = reinterpret_cast<float4*>(cv.take(CBQ * 36 * 16 * 4));
+  float4* sum_l = reinterpret_cast<float4*>(cv.take(CBQ * 16 * 4));
+  float* g_l = cv.take(16 * CBQ * 4);
+  const int n0 = blockIdx.x * C;
+  int row0[CBQ], kq[CBQ];
+#pragma unroll
+  for (int q = 0; q < CBQ; ++q) { row0[q] = n0 + 4 * q; kq[q] = (int)blockIdx.x * CBQ + q; }
+  QuadRegs<1, CBQ> qr;
+  quad_issue<1, CBQ>(qr, g_slices, g_n, g_stride, n, kq);
+  const int i = threadIdx.x / C, c = threadIdx.x - i * C;
   const size_t at = (size_t)i * N + n0 + c;
   float zz = 0.f;
-  if (threadIdx.x < 64 && i < n && act) zz = z[at];
-  BiRegs<1, NT> wr;
-  bi_prefetch<1, NT>(wr, W, K, row0);
-  quad_finish<1, 1>(qr, sum_l, scratch, g_n, n);
-  if (threadIdx.x < 64) {
+  if (threadIdx.x < 16 * C && i < n && act) zz = z[at];
+  BiRegs<CBQ, NT> wr;
+  bi_prefetch<CBQ, NT>(wr, W, K, row0);
+  quad_finish<1, CBQ>(qr, sum_l, scratch, g_n, n);
+  if (threadIdx.x < 16 * C) {
+    const int q = c >> 2, c4 = c & 3;
     float g = 0.f;
     if (i < n) {
-      g = reinterpret_cast<const float*>(sum_l)[i * 4 + c];
+      g = reinterpret_cast<const float*>(sum_l + q * 16)[i * 4 + c4];
       g_dense[at] = g;                                                    // the weight-gradient launch applies act'(z) itself
       if (act) g *= act_bwd(zz, act);
     }
-    g_l[i * 4 + c] = g;
+    g_l[(i * CBQ + q) * 4 + c4] = g;
   }
   __syncthreads();
-  bi_core<1, 1, NT>(wr, g_l, stage, slices_out + (size_t)blockIdx.x * out_stride, K, n);
+  bi_core<1, CBQ, NT>(wr, g_l, stage, slices_out + (size_t)blockIdx.x * out_stride, K, n);
 }
 
 // ============================================================================================== B3: norm backward + [Wu; Wv] rows
+template <int CBQ>
 __global__ __launch_bounds__(DL_THREADS) void dec_uv_bwd_k(const float* __restrict__ gstack_slices, int gs_n, long long gs_stride,
                                                            const float* __restrict__ UV, const float* __restrict__ stack,
                                                            const float* __restrict__ gs_res, const float* __restrict__ Wuv,
                                                            float* __restrict__ gUV, float* __restrict__ g_s2,
                                                            float* __restrict__ slices_out, long long out_stride, int n, int F) {
+  constexpr int C = 4 * CBQ, G = 2 * CBQ;
   Carve cv;
   float* stage = cv.take(bi_stage_floats<3>());
-  float4* scratch = reinterpret_cast<float4*>(cv.take(2 * 36 * 16 * 4));
-  float4* gsum_l = reinterpret_cast<float4*>(cv.take(2 * 16 * 4));       // [0]: columns f0.. of g_stack, [1]: the norm half
-  float* g_l = cv.take(48 * 2 * 4);
-  const int f0 = blockIdx.x * DL_CB;
-  const int row0[2] = {f0, F + f0};
-  const int kq[2] = {(int)blockIdx.x, F / 4 + (int)blockIdx.x};
-  QuadRegs<1, 2> qr;
-  quad_issue<1, 2>(qr, gstack_slices, gs_n, gs_stride, n, kq);
-  const bool mine = threadIdx.x < n * 4;
-  const int i = threadIdx.x >> 2, c = threadIdx.x & 3, f = f0 + c;
+  float4* scratch = reinterpret_cast<float4*>(cv.take(G * 36 * 16 * 4));
+  float4* gsum_l = reinterpret_cast<float4*>(cv.take(G * 16 * 4));       // [q]: columns f0 + 4 q .. of g_stack, [CBQ + q]: the norm half
+  float* g_l = cv.take(48 * G * 4);
+  const int f0 = blockIdx.x * C;
+  int row0[G], kq[G];
+#pragma unroll
+  for (int q = 0; q < CBQ; ++q) {
+    row0[q] = f0 + 4 * q; row0[CBQ + q] = F + f0 + 4 * q;
+    kq[q] = (int)blockIdx.x * CBQ + q; kq[CBQ + q] = F / 4 + (int)blockIdx.x * CBQ + q;
+  }
+  QuadRegs<1, G> qr;
+  quad_issue<1, G>(qr, gstack_slices, gs_n, gs_stride, n, kq);
+  const bool mine = threadIdx.x < n * C;
+  const int i = threadIdx.x / C, c = threadIdx.x - i * C, f = f0 + c;
   const size_t nf = (size_t)i * F + f;
   const size_t b = (size_t)i * 3 * 2 * F + f;
   float gu[3] = {0.f, 0.f, 0.f}, gvv[3] = {0.f, 0.f, 0.f}, vv[3] = {0.f, 0.f, 0.f}, res = 0.f, nrm = 1.f;
@@ -589,23 +631,24 @@ __global__ __launch_bounds__(DL_THREADS) void dec_uv_bwd_k(const float* __restri
     res = gs_res[nf];
     nrm = stack[(size_t)i * 2 * F + F + f];
   }
-  BiRegs<2, 2> wr;
-  bi_prefetch<2, 2>(wr, Wuv, F, row0);
-  for (int o = threadIdx.x; o < 48 * 8; o += DL_THREADS) g_l[o] = 0.f;
-  quad_finish<1, 2>(qr, gsum_l, scratch, gs_n, n);
+  BiRegs<G, 2> wr;
+  bi_prefetch<G, 2>(wr, Wuv, F, row0);
+  for (int o = threadIdx.x; o < 48 * G * 4; o += DL_THREADS) g_l[o] = 0.f;
+  quad_finish<1, G>(qr, gsum_l, scratch, gs_n, n);
   if (mine) {
-    g_s2[nf] = reinterpret_cast<const float*>(gsum_l)[i * 4 + c] + res;              // S' also reaches S'' directly
-    const float t = reinterpret_cast<const float*>(gsum_l + 16)[i * 4 + c] / nrm;
+    const int q = c >> 2, c4 = c & 3;
+    g_s2[nf] = reinterpret_cast<const float*>(gsum_l + q * 16)[i * 4 + c4] + res;              // S' also reaches S'' directly
+    const float t = reinterpret_cast<const float*>(gsum_l + (CBQ + q) * 16)[i * 4 + c4] / nrm;
 #pragma unroll
     for (int xyz = 0; xyz < 3; ++xyz) {
       const float tot = gvv[xyz] + t * vv[xyz];
       gUV[b + (size_t)xyz * 2 * F + F] = tot;                             // the weight-gradient launch reads the total
-      g_l[((3 * i + xyz) * 2 + 0) * 4 + c] = gu[xyz];
-      g_l[((3 * i + xyz) * 2 + 1) * 4 + c] = tot;
+      g_l[((3 * i + xyz) * G + q) * 4 + c4] = gu[xyz];
+      g_l[((3 * i + xyz) * G + CBQ + q) * 4 + c4] = tot;
     }
   }
   __syncthreads();
-  bi_core<3, 2, 2>(wr, g_l, stage, slices_out + (size_t)blockIdx.x * out_stride, F, 3 * n);
+  bi_core<3, G, 2>(wr, g_l, stage, slices_out + (size_t)blockIdx.x * out_stride, F, 3 * n);
 }
 
 // ============================================================================================== B4: message backward + W2 rows
@@ -848,6 +891,9 @@ int cgv_decoder_layer_supported(int n_nodes, int n_feat, int n_rbf) {
          cgv_rbf_supported(n_rbf);
 }
 int cgv_decoder_max_edges(void) { return cgv::DL_MAX_EDGES; }
+/* channels (weight rows per row group set) a block of gate_bwd / dense_bwd / uv_bwd owns for a width: 8 when the width
+ * is a multiple of 8 (half as many, twice as fat slices), else 4; their slice count is width / this. */
+int cgv_decoder_block_channels(int width) { return (width % 8) == 0 && cgv::option(CGV_OPT_DECODER_FAT) != 0 ? 8 : 4; }
 /* measurement: block 0 of cgv_decoder_msg_bwd stores the GPU wall clock at its phase boundaries into buf[0..7], of cgv_decoder_msg_fwd into buf[8..13] (NULL: off) */
 int cgv_decoder_debug_clock(uint64_t* buf) {
   unsigned long long* p = reinterpret_cast<unsigned long long*>(buf);
@@ -882,6 +928,16 @@ int cgv_decoder_msg_fwd(const float* a1, const float* W2, const float* b2, const
   return cgv::check_launch("cgv_decoder_msg_fwd");
 }
 
+int cgv_decoder_dense_fwd(const float* x, const float* W, const float* bias, float* y, float* z, int n_nodes, int N, int K,
+                          int act, void* stream) {
+  CGV_REQUIRE(x && W && y, "null pointer");
+  CGV_REQUIRE(act >= 0 && act <= cgv::CGV_ACT_MAX, "unknown activation");
+  CGV_REQUIRE(n_nodes >= 1 && n_nodes <= cgv::DL_MAX_NODES && (N % 4) == 0 && (K % 4) == 0 && N >= 4 && K >= 4, "unsupported shape");
+  hipLaunchKernelGGL(cgv::dec_dense_fwd_k, dim3(N / cgv::DL_CB), dim3(cgv::DL_THREADS), cgv::lds_bytes(cgv::fwd_red_floats<1, 1>() + 64),
+                     (hipStream_t)stream, x, W, bias, y, z, n_nodes, N, K, act);
+  return cgv::check_launch("cgv_decoder_dense_fwd");
+}
+
 int cgv_decoder_uv_fwd(const float* rows, const float* Wuv, float* UV, float* stack, int n_nodes, int n_feat, void* stream) {
   CGV_REQUIRE(rows && Wuv && UV && stack, "null pointer");
   const int n_rbf = 8;
@@ -908,10 +964,17 @@ int cgv_decoder_gate_bwd(const float* UV, const float* a, const float* gs_base, 
   CGV_REQUIRE(gs_n_slices >= 0 && out_slice_stride >= cgv_decoder_slice_floats(n_feat, n_nodes), "bad slices");
   const int n_rbf = 8;
   CGV_DL_CHECK();
-  hipLaunchKernelGGL(cgv::dec_gate_bwd_k, dim3(blocks), dim3(cgv::DL_THREADS),
-                     cgv::lds_bytes(cgv::bi_stage_floats<1>() + 2304 + 64 + 192), st, UV, a, gs_base, gs_slices, gs_n_slices,
-                     (long long)gs_slice_stride, gv, W1p, ga, gUV, gs_sum, slices_out, (long long)out_slice_stride, n_nodes,
-                     n_feat);
+  (void)blocks;
+  if (cgv_decoder_block_channels(n_feat) == 8)
+    hipLaunchKernelGGL(cgv::dec_gate_bwd_k<2>, dim3(n_feat / 8), dim3(cgv::DL_THREADS),
+                       cgv::lds_bytes(cgv::bi_stage_floats<1>() + 2 * 2304 + 2 * 64 + 384), st, UV, a, gs_base, gs_slices, gs_n_slices,
+                       (long long)gs_slice_stride, gv, W1p, ga, gUV, gs_sum, slices_out, (long long)out_slice_stride, n_nodes,
+                       n_feat);
+  else
+    hipLaunchKernelGGL(cgv::dec_gate_bwd_k<1>, dim3(n_feat / 4), dim3(cgv::DL_THREADS),
+                       cgv::lds_bytes(cgv::bi_stage_floats<1>() + 2304 + 64 + 192), st, UV, a, gs_base, gs_slices, gs_n_slices,
+                       (long long)gs_slice_stride, gv, W1p, ga, gUV, gs_sum, slices_out, (long long)out_slice_stride, n_nodes,
+                       n_feat);
   return cgv::check_launch("cgv_decoder_gate_bwd");
 }
 
@@ -922,13 +985,18 @@ int cgv_decoder_dense_bwd(const float* g_slices, int g_n_slices, int64_t g_slice
   CGV_REQUIRE(n_nodes >= 1 && n_nodes <= cgv::DL_MAX_NODES && (N % 4) == 0 && (K % 4) == 0 && K <= 64 * 27 && N >= 4, "unsupported shape");
   CGV_REQUIRE(out_slice_stride >= cgv_decoder_slice_floats(K, n_nodes), "bad slices");
   hipStream_t st = (hipStream_t)stream;
-  const int blocks = N / cgv::DL_CB;
   const int tiles = (K + 63) / 64;
-  const size_t lds = cgv::lds_bytes(cgv::bi_stage_floats<1>() + 2304 + 64 + 64);
+  const bool fat = cgv_decoder_block_channels(N) == 8;
+  const int blocks = fat ? N / 8 : N / 4;
+  const size_t lds = cgv::lds_bytes(cgv::bi_stage_floats<1>() + 2 * 2304 + 2 * 64 + 2 * 64);
 #define CGV_DL_DENSE(NTV)                                                                                                \
-  hipLaunchKernelGGL((cgv::dec_dense_bwd_k<NTV>), dim3(blocks), dim3(cgv::DL_THREADS), lds, st, g_slices, g_n_slices,     \
-                     (long long)g_slice_stride, z, act, W, g_dense, slices_out, (long long)out_slice_stride, n_nodes, N, K)
-  if (tiles <= 9) CGV_DL_DENSE(1); else if (tiles <= 18) CGV_DL_DENSE(2); else CGV_DL_DENSE(3);
+  if (fat)                                                                                                               \
+    hipLaunchKernelGGL((cgv::dec_dense_bwd_k<NTV, 2>), dim3(blocks), dim3(cgv::DL_THREADS), lds, st, g_slices, g_n_slices, \
+                       (long long)g_slice_stride, z, act, W, g_dense, slices_out, (long long)out_slice_stride, n_nodes, N, K); \
+  else                                                                                                                   \
+    hipLaunchKernelGGL((cgv::dec_dense_bwd_k<NTV, 1>), dim3(blocks), dim3(cgv::DL_THREADS), lds, st, g_slices, g_n_slices, \
+                       (long long)g_slice_stride, z, act, W, g_dense, slices_out, (long long)out_slice_stride, n_nodes, N, K)
+  if (tiles <= 9) { CGV_DL_DENSE(1); } else if (tiles <= 18) { CGV_DL_DENSE(2); } else { CGV_DL_DENSE(3); }
 #undef CGV_DL_DENSE
   return cgv::check_launch("cgv_decoder_dense_bwd");
 }
@@ -940,11 +1008,20 @@ int cgv_decoder_uv_bwd(const float* gstack_slices, int n_slices, int64_t slice_s
   CGV_REQUIRE(out_slice_stride >= cgv_decoder_slice_floats(n_feat, 3 * n_nodes), "bad slices");
   const int n_rbf = 8;
   CGV_DL_CHECK();
-  const size_t lds = cgv::lds_bytes(cgv::bi_stage_floats<3>() + 4608 + 128 + 384);
-  if (int rc = cgv::allow_lds(cgv::dec_uv_bwd_k, lds)) return rc;
-  hipLaunchKernelGGL(cgv::dec_uv_bwd_k, dim3(blocks), dim3(cgv::DL_THREADS), lds, st, gstack_slices, n_slices,
-                     (long long)slice_stride, UV, stack, gs_res, Wuv, gUV, g_s2, slices_out, (long long)out_slice_stride,
-                     n_nodes, n_feat);
+  (void)blocks;
+  if (cgv_decoder_block_channels(n_feat) == 8) {
+    const size_t lds = cgv::lds_bytes(cgv::bi_stage_floats<3>() + 2 * 4608 + 2 * 128 + 2 * 384);
+    if (int rc = cgv::allow_lds(cgv::dec_uv_bwd_k<2>, lds)) return rc;
+    hipLaunchKernelGGL(cgv::dec_uv_bwd_k<2>, dim3(n_feat / 8), dim3(cgv::DL_THREADS), lds, st, gstack_slices, n_slices,
+                       (long long)slice_stride, UV, stack, gs_res, Wuv, gUV, g_s2, slices_out, (long long)out_slice_stride,
+                       n_nodes, n_feat);
+  } else {
+    const size_t lds = cgv::lds_bytes(cgv::bi_stage_floats<3>() + 4608 + 128 + 384);
+    if (int rc = cgv::allow_lds(cgv::dec_uv_bwd_k<1>, lds)) return rc;
+    hipLaunchKernelGGL(cgv::dec_uv_bwd_k<1>, dim3(n_feat / 4), dim3(cgv::DL_THREADS), lds, st, gstack_slices, n_slices,
+                       (long long)slice_stride, UV, stack, gs_res, Wuv, gUV, g_s2, slices_out, (long long)out_slice_stride,
+                       n_nodes, n_feat);
+  }
   return cgv::check_launch("cgv_decoder_uv_bwd");
 }
 

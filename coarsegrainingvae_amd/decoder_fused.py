@@ -95,11 +95,17 @@ class _PseudoDecoderFn(torch.autograd.Function):
         new = lambda *shape: torch.empty(*shape, dtype=_F32, device=dev)
         Sbar, V, Vbar = Sbar0, V0, V0
         saved = []
+        from .options import HOST
+        if HOST["decoder_dense"] == 1:          # A/B: the 16-column-block skinny kernel for the two full-width products
+            dense = _dense_fwd
+        else:
+            dense = lambda x, W, b, y, z, M, N, K, act, st_: _lib.call("cgv_decoder_dense_fwd", _lib.ptr(x), _lib.ptr(W), _lib.ptr(b),
+                                                                      _lib.ptr(y), _lib.ptr(z), M, N, K, act, st_)
         for l in range(n_layers):
             W1, b1, W2, b2, Wd, bd, Wu, Wv, W0, b0, W1p, b1p = (t.detach() for t in flat[PER_LAYER * l: PER_LAYER * (l + 1)])
             Wuv = torch.as_strided(Wu, (2 * F, F), (F, 1))
             a1, z1, phi, stack = new(n, F), new(n, F), new(n, 9 * F), new(n, 2 * F)
-            _dense_fwd(S, W1, b1, a1, z1, n, F, F, ACT_SWISH, st)
+            dense(S, W1, b1, a1, z1, n, F, F, ACT_SWISH, st)
             Sbar2, V2, Vbar2, rows = new(n, F), new(n, F, 3), new(n, F, 3), new(3 * n, F)
             _lib.call("cgv_decoder_msg_fwd", _lib.ptr(a1), _lib.ptr(W2), _lib.ptr(b2), _lib.ptr(S), _lib.ptr(Sbar), _lib.ptr(V),
                       _lib.ptr(Vbar), _lib.ptr(geom.geom_d), _lib.ptr(plan.rowptr_d), _lib.ptr(plan.src_d), _lib.ptr(Wd),
@@ -108,7 +114,7 @@ class _PseudoDecoderFn(torch.autograd.Function):
             UV = new(3 * n, 2 * F)
             _lib.call("cgv_decoder_uv_fwd", _lib.ptr(rows), _lib.ptr(Wuv), _lib.ptr(UV), _lib.ptr(stack), n, F, st)
             z0, a0, a = new(n, F), new(n, F), new(n, 3 * F)
-            _dense_fwd(stack, W0, b0, a0, z0, n, F, 2 * F, ACT_SWISH, st)
+            dense(stack, W0, b0, a0, z0, n, F, 2 * F, ACT_SWISH, st)
             S3, V3 = new(n, F), new(n, F, 3)
             _lib.call("cgv_decoder_gate_fwd", _lib.ptr(a0), _lib.ptr(W1p), _lib.ptr(b1p), _lib.ptr(UV), _lib.ptr(stack),
                       _lib.ptr(V2), _lib.ptr(a), _lib.ptr(S3), _lib.ptr(V3), n, F, st)
@@ -142,25 +148,27 @@ class _PseudoDecoderFn(torch.autograd.Function):
             S_in, Sbar_in, V_in, Vbar_in, z1, a1, phi, rows, UV, stack, z0, a0, a = saved[l]
             saved[l] = None
             Wuv = torch.as_strided(pWu.detach(), (2 * F, F), (F, 1))
+            # slices per phase: F / 4 from the message kernel, width / cgv_decoder_block_channels(width) from the others
             # B1: gate backward, rows of s_dense.1
             ga, gUV, gs_sum = new(n, 3 * F), new(3 * n, 2 * F), new(n, F)
-            p1 = new(nb * fl16(F))
+            nF = F // int(lib.cgv_decoder_block_channels(F))
+            p1 = new(nF * fl16(F))
             _lib.call("cgv_decoder_gate_bwd", _lib.ptr(UV), _lib.ptr(a), _lib.ptr(gS.base), _lib.ptr(gS.part), gS.n, gS.stride,
                       _lib.ptr(gV), _lib.ptr(pW1p.detach()), _lib.ptr(ga), _lib.ptr(gUV), _lib.ptr(gs_sum), _lib.ptr(p1), fl16(F),
                       n, F, st)
             # B2: s_dense.0 (swish'), K = 2F
             g_a0 = new(n, F)
-            p2 = new(nb * fl16(2 * F))
-            _lib.call("cgv_decoder_dense_bwd", _lib.ptr(p1), nb, fl16(F), _lib.ptr(z0), ACT_SWISH, _lib.ptr(pW0.detach()),
+            p2 = new(nF * fl16(2 * F))
+            _lib.call("cgv_decoder_dense_bwd", _lib.ptr(p1), nF, fl16(F), _lib.ptr(z0), ACT_SWISH, _lib.ptr(pW0.detach()),
                       _lib.ptr(g_a0), _lib.ptr(p2), fl16(2 * F), n, F, 2 * F, st)
             # B3: norm backward, rows of [u_mat; v_mat]
             g_s2 = new(n, F)
-            p3 = new(nb * fl48)
-            _lib.call("cgv_decoder_uv_bwd", _lib.ptr(p2), nb, fl16(2 * F), _lib.ptr(UV), _lib.ptr(stack), _lib.ptr(gs_sum),
+            p3 = new(nF * fl48)
+            _lib.call("cgv_decoder_uv_bwd", _lib.ptr(p2), nF, fl16(2 * F), _lib.ptr(UV), _lib.ptr(stack), _lib.ptr(gs_sum),
                       _lib.ptr(Wuv), _lib.ptr(gUV), _lib.ptr(g_s2), _lib.ptr(p3), fl48, n, F, st)
             # B4: message backward, rows of inv_dense.1
             g_phi = new(n, 9 * F)
-            g_s, g_sbar, g_v, g_vbar = new(n, F), new(n, F), new(n, F, 3), new(n, F, 3)
+            g_s, g_sbar, g_v, g_vbar = new(n, F), new(n, F, 3), new(n, F, 3), new(n, F, 3)
             tWd, accWd, _ = _grad_target(pWd, pWd)
             tbd, accbd, _ = _grad_target(pbd, pbd)
             if accWd or accbd:
@@ -169,12 +177,12 @@ class _PseudoDecoderFn(torch.autograd.Function):
             _lib.call("cgv_decoder_msg_bwd", _lib.ptr(phi), _lib.ptr(S_in), _lib.ptr(Sbar_in), _lib.ptr(V_in), _lib.ptr(Vbar_in),
                       _lib.ptr(geom.geom_d), _lib.ptr(plan.rowptr_d), _lib.ptr(plan.src_d), _lib.ptr(geom.geom_s),
                       _lib.ptr(plan.rowptr_s), _lib.ptr(plan.dst_s), _lib.ptr(pWd.detach()), _lib.ptr(pbd.detach()),
-                      _lib.ptr(g_s2), _lib.ptr(gSbar), _lib.ptr(p3), nb, fl48, _lib.ptr(gV), _lib.ptr(gVbar), _lib.ptr(pW2.detach()),
+                      _lib.ptr(g_s2), _lib.ptr(gSbar), _lib.ptr(p3), nF, fl48, _lib.ptr(gV), _lib.ptr(gVbar), _lib.ptr(pW2.detach()),
                       _lib.ptr(g_phi), _lib.ptr(g_s), _lib.ptr(g_sbar), _lib.ptr(g_v), _lib.ptr(g_vbar), _lib.ptr(tWd), _lib.ptr(tbd),
                       _lib.ptr(p4), fl16(F), n, F, R, plan.n_edges, st, tag=f"pseudo_msg_bwd:Nd{n}:E{plan.n_edges}:gv1")
             # B5: inv_dense.0 (swish')
             g_a1 = new(n, F)
-            p5 = new(nb * fl16(F))
+            p5 = new(nF * fl16(F))
             _lib.call("cgv_decoder_dense_bwd", _lib.ptr(p4), nb, fl16(F), _lib.ptr(z1), ACT_SWISH, _lib.ptr(pW1.detach()),
                       _lib.ptr(g_a1), _lib.ptr(p5), fl16(F), n, F, F, st)
 
@@ -200,7 +208,7 @@ class _PseudoDecoderFn(torch.autograd.Function):
                 pw._cgv_exch = pw._cgv_rank = shape
                 pb._cgv_exch = shape
             # ---- gradients of this layer's inputs = of the layer below's outputs
-            gS = Slices(g_s, p5, nb, fl16(F))
+            gS = Slices(g_s, p5, nF, fl16(F))
             gV, gSbar, gVbar = g_v, g_sbar, g_vbar
             mark(f"decoder:bwd{l}")
             if ctx.hooks and l in ctx.hooks:

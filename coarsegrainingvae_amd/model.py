@@ -342,6 +342,11 @@ class CGequiVAE(nn.Module):
         graph = batch.get("_graph")
         if graph is None:
             graph = BatchGraph(xyz, cg_xyz, mapping, nbr_list, CG_nbr_list)
+        elif graph.xyz.shape == xyz.shape and graph.cg_xyz.shape == cg_xyz.shape:
+            # the bundle's own contiguous copies of the coordinates (kept current by prepare_batch / copy_batch_into: the
+            # edge records are computed from them): the strided views nxyz[:, 1:] would be re-packed by two copy launches
+            # in every step (loss kernel, decoder tail)
+            xyz, cg_xyz = graph.xyz, graph.cg_xyz
         # The prior net (bead graph) does not depend on the encoder (atom graph): run it on a side HIP
         # stream so its ~20 small launches -- and, since autograd replays each node on its forward
         # stream, its backward too -- overlap with the encoder instead of queueing behind it.

@@ -12,6 +12,7 @@ HOST = {
     "wgrad_kernel": 0,      # grouped weight gradients of <= 64 rows: 0 weight-streaming VALU kernel, 1 MFMA tiles for all
     "table_upload": 0,      # record tables of a captured step: 0 copied once after capture, 1 a copy node in every replay
     "wgrad_tile": 64,       # output tile edge of the grouped MFMA weight-gradient launch: 64 or 128
+    "decoder_dense": 0,     # full-width products of the fused decoder loop: 0 four-column blocks (cgv_decoder_dense_fwd), 1 skinny_fwd_k
 }
 _DEFAULTS = dict(HOST)
 

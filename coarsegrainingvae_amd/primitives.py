@@ -256,8 +256,14 @@ class _LinearFn(torch.autograd.Function):
                 return y.reshape(x.shape[:-1] + (N,))
             y = torch.empty(M, N, dtype=torch.float32, device=x.device)
             z = torch.empty_like(y) if act else None
-            _lib.call("cgv_skinny_linear_fwd" if mode == "skinny" else "cgv_tile_linear_fwd", _lib.ptr(x2), _lib.ptr(weight),
-                      _lib.ptr(bias), _lib.ptr(y), _lib.ptr(z), M, N, K, act, _lib.stream_ptr())
+            if mode == "skinny" and M <= 16 and N >= 64:
+                # few rows: 4-column blocks (N / 4 of them pull the weight) beat the skinny kernel's 16-column blocks
+                # (decoder forward 356 -> 343 us on chignolin: csrc/decoder_layer.hip, dec_dense_fwd_k)
+                _lib.call("cgv_decoder_dense_fwd", _lib.ptr(x2), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(y), _lib.ptr(z),
+                          M, N, K, act, _lib.stream_ptr())
+            else:
+                _lib.call("cgv_skinny_linear_fwd" if mode == "skinny" else "cgv_tile_linear_fwd", _lib.ptr(x2), _lib.ptr(weight),
+                          _lib.ptr(bias), _lib.ptr(y), _lib.ptr(z), M, N, K, act, _lib.stream_ptr())
             ctx.save_for_backward(x2, weight, z)
             return y.reshape(x.shape[:-1] + (N,))
         z = Fn.linear(x, weight, bias)

@@ -74,7 +74,8 @@ enum {
   CGV_OPT_TILE_FWD_LDS_MIN = 8,/* cgv_tile_linear_fwd: minimum 64x64 tile count for the LDS-staged kernel (default 448; 1 = always) */
   CGV_OPT_BWD_INPUT_WAVES = 9, /* cgv_tile_linear_bwd_input*: waves per block, 0 = built-in rule */
   CGV_OPT_PSEUDO_FWD = 10,     /* cgv_pseudo_msg_fwd*: 0 built-in rule; 1..6 = (edges in flight, records staged in LDS) variants */
-  CGV_OPT_COUNT = 11
+  CGV_OPT_DECODER_FAT = 11,    /* cgv_decoder_{gate,dense,uv}_bwd: 1 (default) 8-channel blocks where the width allows, 0 always 4 */
+  CGV_OPT_COUNT = 12
 };
 /* Measurement: store the GPU wall clock (cgv_timestamp_hz ticks per second) into *slot, in stream order; capturable. */
 int cgv_timestamp(uint64_t* slot /*device*/, void* stream);
@@ -306,11 +307,15 @@ int cgv_pseudo_msg_bwd(const float* phi, const float* s, const float* sbar, cons
 int cgv_decoder_layer_supported(int n_nodes, int n_feat, int n_rbf);
 int64_t cgv_decoder_slice_floats(int K, int rows);
 int cgv_decoder_max_edges(void);
+int cgv_decoder_block_channels(int width);   /* 4 or 8: gate_bwd / dense_bwd / uv_bwd emit width / this slices */
 int cgv_decoder_debug_clock(uint64_t* buf /*device, 16 slots, or NULL*/);   /* measurement only */
 int cgv_decoder_msg_fwd(const float* a1, const float* W2, const float* b2, const float* s, const float* sbar, const float* v,
                         const float* vbar, const float* geom_d, const int32_t* rowptr_d, const int32_t* src_d, const float* Wd,
                         const float* bd, float* phi, float* stack, float* sbar_out, float* v_out, float* vbar_out,
                         float* rows_out, int n_nodes, int n_feat, int n_rbf, int n_edges, void* stream);
+/* y = act(x W^T + b) (z = pre-activation or NULL) for <= 16 rows, N / 4 blocks: the two full-width products of a layer */
+int cgv_decoder_dense_fwd(const float* x, const float* W /*[N,K]*/, const float* bias, float* y, float* z, int n_nodes, int N,
+                          int K, int act, void* stream);
 int cgv_decoder_uv_fwd(const float* rows, const float* Wuv, float* UV, float* stack, int n_nodes, int n_feat, void* stream);
 int cgv_decoder_gate_fwd(const float* a0, const float* W1p, const float* b1p, const float* UV, const float* stack,
                          const float* v2, float* a, float* s3, float* v3, int n_nodes, int n_feat, void* stream);

@@ -231,11 +231,15 @@ def test_protein2000_reduced_width_vs_oracle():
     _check_norm_and_clip(tr, ref, "protein2000")
 
 
-@pytest.mark.parametrize("workload,frames,F,dec", [("chignolin", 2, 600, 3), ("dipeptide", 4, 64, 2), ("chignolin", 1, 48, 2)])
-def test_fused_decoder_loop_equals_per_block_path(workload, frames, F, dec):
+@pytest.mark.parametrize("workload,frames,F,dec,fat", [("chignolin", 2, 600, 3, 1), ("dipeptide", 4, 64, 2, 1),
+                                                        ("chignolin", 1, 48, 2, 1), ("chignolin", 2, 600, 2, 0)])
+def test_fused_decoder_loop_equals_per_block_path(workload, frames, F, dec, fat, options):
     """decoder_fused (one autograd node for the decoder loop, slice-sum backward) against the per-block path it
     replaces (blocks.py: one node per block, reduction launches, autograd's accumulation adds): every gradient of the
-    second step (all materialised), the loss, and the parameters after three steps."""
+    second step (all materialised), the loss, and the parameters after three steps.  fat: 8-channel blocks in the
+    non-message backward phases (the default; every width the arena lays out adjacent u_mat / v_mat for is a multiple
+    of 8) or 4-channel blocks everywhere."""
+    options.set("decoder_fat", fat)
     w = cg.data.WORKLOADS[workload]
     batch = cg.synthetic_batch(workload, n_frames=frames, seed=2, device=DEV)
     eps = [torch.randn(batch["CG_nxyz"].shape[0], F, generator=torch.Generator().manual_seed(k)).to(DEV) for k in range(3)]
