@@ -36,8 +36,19 @@ namespace cgv {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // phase clock of block 0 (measurement only: cgv_decoder_debug_clock); NULL in normal operation
-__device__ unsigned long long* g_dl_clock = nullptr;
+// (__constant__: read by ONE scalar load per kernel; as a __device__ variable every tick was a vector load followed by
+// s_waitcnt vmcnt(0) -- which also drained every prefetch in flight at that point)
+__constant__ unsigned long long* g_dl_clock = nullptr;
 #define DL_TICK(i) do { if (g_dl_clock && blockIdx.x == 0 && threadIdx.x == 0) g_dl_clock[i] = wall_clock64(); } while (0)
+// launch spans for a layer's timeline: slots 32 + 4 id + {0, 1}: first block's begin / end, {2, 3}: last block's
+// (ids: 0 F1 dense, 1 F2 message, 2 F3 uv, 3 F4 dense, 4 F5 gate, 5 B1 gate, 6 B2 dense, 7 B3 uv, 8 B4 message, 9 B5 dense)
+#define DL_SPAN(id, end)                                                                                    \
+  do {                                                                                                      \
+    if (g_dl_clock && threadIdx.x == 0) {                                                                   \
+      if (blockIdx.x == 0) g_dl_clock[32 + 4 * (id) + (end)] = wall_clock64();                              \
+      if (blockIdx.x == gridDim.x - 1) g_dl_clock[32 + 4 * (id) + 2 + (end)] = wall_clock64();              \
+    }                                                                                                       \
+  } while (0)
 
 constexpr int DL_CB = 4;                 // channels per block
 constexpr int DL_WAVES = 9;
@@ -73,35 +84,70 @@ struct Carve {
   }
 };
 
+// ---------------------------------------------------------------------------------------------- pinned requests
+// A prefetch must stay where it is written.  The operands are __restrict__ const data, so the compiler is free to sink
+// an ordinary load down to its first use -- into the branch that stores it to LDS (one vmcnt(0) round trip per staged
+// array) or in front of the product (a full HBM round trip there); it does both.  (volatile loads are no way out: the
+// backend waits vmcnt(0) after each one.)  Instead: the kernel reads such arrays through LAUNDERED pointers (no longer
+// provably distinct from what an opaque asm may write) and closes each batch of requests with pin_loads(), an empty asm
+// that clobbers memory: a load cannot move below something that may overwrite its source.
+// (The laundered pointer keeps its address space in its type: a generic pointer of unknown origin would compile to
+// flat_load.)
+#define CGV_GLOBAL_AS __attribute__((address_space(1)))
+typedef const CGV_GLOBAL_AS float* gcf;
+typedef const CGV_GLOBAL_AS int* gci;
+__device__ __forceinline__ gcf launder(const float* p) {                                    // kernel arguments: uniform
+  unsigned long long a = reinterpret_cast<unsigned long long>(p);
+  asm volatile("" : "+s"(a));
+  return reinterpret_cast<gcf>(a);
+}
+__device__ __forceinline__ gci launder(const int* p) {
+  unsigned long long a = reinterpret_cast<unsigned long long>(p);
+  asm volatile("" : "+s"(a));
+  return reinterpret_cast<gci>(a);
+}
+__device__ __forceinline__ const float* generic(gcf p) { return (const float*)p; }
+__device__ __forceinline__ void pin_loads() { asm volatile("" ::: "memory"); }
+__device__ __forceinline__ float4 ldg4_pinned(gcf p) {
+  const f32x4 t = *reinterpret_cast<const CGV_GLOBAL_AS f32x4*>(p);
+  return make_float4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ float ldg_pinned(gcf p) { return *p; }
+__device__ __forceinline__ int ldgi_pinned(gci p) { return *p; }
+__device__ __forceinline__ f3 ld3_pinned(gcf p) { return f3{p[0], p[1], p[2]}; }
+
 // ---------------------------------------------------------------------------------------------- slice sums (quad-major)
 // Slice layout: [K/4 column quads][rows][4] floats, rows = n (16-row phases) or 3 n (the [u_mat; v_mat] phase).
 // tile[q][m][c] = sum_s slices[s][kq[q]][m][c] for NQ quads at once (one batch of loads); all threads take part; valid
-// after the trailing __syncthreads().  scratch: NQ * 36 * 16 * MB float4.  Order: per class ascending s, then classes.
-constexpr int DL_QS = 6;                  // slices per lane class: 36 * 6 = 216 >= F / 4 for F <= 864
-template <int MB, int NQ>
-struct QuadRegs { float4 v[DL_QS][NQ][MB]; };
+// after the trailing __syncthreads().  scratch: NQ * 36 * 16 * MB float4 (the first NQ * 9 * 16 MB are used).  Order:
+// per lane class ascending s; the wave's four classes as (c0 + c1) + (c2 + c3); then the 9 waves in order.
+// QS = slices per lane class: 36 QS >= the number of slices (6: 216 >= F / 4 for F <= 864; 3: the 75 slices of the
+// 8-channel phases at F = 600 -- half the registers and no clamped duplicate loads).
+constexpr int DL_QS = 6;
+template <int MB, int NQ, int QS = DL_QS>
+struct QuadRegs { float4 v[QS][NQ][MB]; };
 
 // Issue every load of the slice sum (straight-line, one batch: the compiler can count them, so that the weight prefetch
 // issued afterwards stays in flight while these are consumed -- vmcnt returns in order).
-template <int MB, int NQ>
-__device__ __forceinline__ void quad_issue(QuadRegs<MB, NQ>& r, const float* __restrict__ slices, int n_slices, long long stride,
+template <int MB, int NQ, int QS>
+__device__ __forceinline__ void quad_issue(QuadRegs<MB, NQ, QS>& r, gcf slices, int n_slices, long long stride,
                                            int rows, const int (&kq)[NQ]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m = lane & 15, cls = wave * 4 + (lane >> 4);                 // 36 slice classes
 #pragma unroll
-  for (int u = 0; u < DL_QS; ++u) {
+  for (int u = 0; u < QS; ++u) {
     const int s = min(cls + 36 * u, n_slices - 1);
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb)
-        r.v[u][q][mb] = *reinterpret_cast<const float4*>(slices + (size_t)s * stride + ((size_t)kq[q] * rows + min(mb * 16 + m, rows - 1)) * 4);
+        r.v[u][q][mb] = ldg4_pinned(slices + (size_t)s * stride + ((size_t)kq[q] * rows + min(mb * 16 + m, rows - 1)) * 4);
   }
 }
 
 // Sum: per class ascending slice index, then the 36 classes in order.  tile[q][m] valid after the trailing barrier.
-template <int MB, int NQ>
-__device__ __forceinline__ void quad_finish(const QuadRegs<MB, NQ>& r, float4* __restrict__ tile /*[NQ][16 MB]*/,
+template <int MB, int NQ, int QS>
+__device__ __forceinline__ void quad_finish(const QuadRegs<MB, NQ, QS>& r, float4* __restrict__ tile /*[NQ][16 MB]*/,
                                             float4* __restrict__ scratch /*NQ * 36 * 16 MB*/, int n_slices, int rows) {
   constexpr int MP = 16 * MB;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -112,17 +158,19 @@ __device__ __forceinline__ void quad_finish(const QuadRegs<MB, NQ>& r, float4* _
     for (int mb = 0; mb < MB; ++mb) {
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-      for (int u = 0; u < DL_QS; ++u)
+      for (int u = 0; u < QS; ++u)
         if (cls + 36 * u < n_slices) { acc.x += r.v[u][q][mb].x; acc.y += r.v[u][q][mb].y; acc.z += r.v[u][q][mb].z; acc.w += r.v[u][q][mb].w; }
-      scratch[((q * 36 + cls) * MB + mb) * 16 + m] = acc;
+      acc.x += __shfl_xor(acc.x, 16); acc.y += __shfl_xor(acc.y, 16); acc.z += __shfl_xor(acc.z, 16); acc.w += __shfl_xor(acc.w, 16);
+      acc.x += __shfl_xor(acc.x, 32); acc.y += __shfl_xor(acc.y, 32); acc.z += __shfl_xor(acc.z, 32); acc.w += __shfl_xor(acc.w, 32);
+      if (lane < 16) scratch[((q * DL_WAVES + wave) * MB + mb) * 16 + m] = acc;
     }
   __syncthreads();
   if (threadIdx.x < NQ * MP) {
     const int q = threadIdx.x / MP, mm = threadIdx.x - q * MP;
     float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 4
-    for (int c = 0; c < 36; ++c) {
-      const float4 v = scratch[((q * 36 + c) * MB + mm / 16) * 16 + (mm & 15)];
+#pragma unroll
+    for (int c = 0; c < DL_WAVES; ++c) {
+      const float4 v = scratch[((q * DL_WAVES + c) * MB + mm / 16) * 16 + (mm & 15)];
       t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
     }
     if (mm >= rows) t = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -140,7 +188,7 @@ template <int G, int NT>
 struct BiRegs { float4 w[NT][G]; };
 
 template <int G, int NT>
-__device__ __forceinline__ void bi_prefetch(BiRegs<G, NT>& r, const float* __restrict__ W, int K, const int (&row0)[G]) {
+__device__ __forceinline__ void bi_prefetch(BiRegs<G, NT>& r, gcf W, int K, const int (&row0)[G]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, q = lane >> 4;
 #pragma unroll
@@ -148,8 +196,19 @@ __device__ __forceinline__ void bi_prefetch(BiRegs<G, NT>& r, const float* __res
     const int col = (wave + DL_WAVES * t) * 64 + 4 * j;
     const int cc = col < K ? col : 0;                                     // clamped: always-valid address, result unused
 #pragma unroll
-    for (int g = 0; g < G; ++g) r.w[t][g] = *reinterpret_cast<const float4*>(W + (size_t)(row0[g] + q) * K + cc);
+    for (int g = 0; g < G; ++g) r.w[t][g] = ldg4_pinned(W + (size_t)(row0[g] + q) * K + cc);
   }
+}
+
+// one column tile (wave-uniform, in range) into slot SLOT of the registers
+template <int SLOT, int G, int NT>
+__device__ __forceinline__ void bi_prefetch_slot(BiRegs<G, NT>& r, gcf W, int K, const int (&row0)[G], int tile) {
+  const int lane = threadIdx.x & 63;
+  const int j = lane & 15, q = lane >> 4;
+  const int col = tile * 64 + 4 * j;
+  const int cc = col < K ? col : 0;
+#pragma unroll
+  for (int g = 0; g < G; ++g) r.w[SLOT][g] = ldg4_pinned(W + (size_t)(row0[g] + q) * K + cc);
 }
 
 template <int MB>
@@ -217,9 +276,13 @@ __device__ __forceinline__ void bi_core(const BiRegs<G, NPRE>& r, const float* _
 template <int MB, int G>
 __host__ __device__ constexpr size_t fwd_red_floats() { return (size_t)DL_WAVES * ((G + 3) / 4) * MB * 256; }
 
-template <int MB, int G>
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+// SB = 16-float steps whose loads are issued together (a wave has ceil(ceil(K / 16) / 9) steps: 5 at K = 600, so SB >= 5
+// makes the product ONE round trip); after_issue() runs behind the first batch's loads, before they are consumed.
+template <int MB, int G, int SB = (((G + 3) / 4) * MB >= 3 ? 5 : 9), typename Hook = NoHook>
 __device__ __forceinline__ void fwd_core(float* __restrict__ out, float* __restrict__ red, const float* __restrict__ x,
-                                         int M, int K, const float* __restrict__ W, const int (&row0)[G]) {
+                                         int M, int K, const float* __restrict__ W, const int (&row0)[G],
+                                         Hook after_issue = Hook()) {
   constexpr int T = (G + 3) / 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, q = lane >> 4;
@@ -241,8 +304,8 @@ __device__ __forceinline__ void fwd_core(float* __restrict__ out, float* __restr
     for (int mb = 0; mb < MB; ++mb) acc[t][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
   // (tried: 32- and 64-float steps so that a row's four q-lanes read whole 128 / 256-byte lines instead of 64-byte pieces
   // -- not faster: 13.2 / 14.6 us against 13.1 for the message kernel; these products are latency-, not sector-bound)
-  constexpr int SB = (T * MB >= 3) ? 3 : 5;                               // steps whose loads are issued together
-  for (int s0 = s_beg; s0 < s_end; s0 += SB) {
+  bool first = true;
+  for (int s0 = s_beg; first || s0 < s_end; s0 += SB) {
     float4 a[SB][T], b[SB][MB];
 #pragma unroll
     for (int u = 0; u < SB; ++u) {
@@ -253,6 +316,7 @@ __device__ __forceinline__ void fwd_core(float* __restrict__ out, float* __restr
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) b[u][mb] = *reinterpret_cast<const float4*>(xrow[mb] + kc);
     }
+    if (first) { after_issue(); first = false; }
 #pragma unroll
     for (int u = 0; u < SB; ++u) {
       if (s0 + u < s_end) {
@@ -295,6 +359,39 @@ __device__ __forceinline__ void fwd_core(float* __restrict__ out, float* __restr
 // Edge records, CSR arrays and the node state of the block's 4 channels go to LDS in one batch of loads at the top of a
 // message kernel: the edge loops then touch no global memory (they were chains of dependent gathers: index -> row).
 constexpr int DL_MAX_EDGES = 240;          // 16 nodes, no self loops / duplicates
+// The *_issue / *_commit pairs keep a kernel's staging loads in ONE batch: every load is unconditional (index clamped to
+// a valid element; counts >= 1), straight-line, and the LDS stores come later -- a loop or a branch per array would put a
+// vmcnt(0) between the arrays (each store waits for its own load, and loads return in order).
+template <int SLOTS> struct Slots4 { float4 v[SLOTS]; };
+template <int SLOTS>
+__device__ __forceinline__ void copy4_issue(Slots4<SLOTS>& r, gcf src, int n4) {
+#pragma unroll
+  for (int u = 0; u < SLOTS; ++u) r.v[u] = ldg4_pinned(src + 4 * (size_t)min((int)threadIdx.x + u * DL_THREADS, n4 - 1));
+}
+template <int SLOTS>
+__device__ __forceinline__ void copy4_commit(const Slots4<SLOTS>& r, float* __restrict__ dst, int n4) {
+#pragma unroll
+  for (int u = 0; u < SLOTS; ++u)
+    if ((int)threadIdx.x + u * DL_THREADS < n4) reinterpret_cast<float4*>(dst)[threadIdx.x + u * DL_THREADS] = r.v[u];
+}
+__device__ __forceinline__ int int_issue(gci src, int n) { return ldgi_pinned(src + min((int)threadIdx.x, n - 1)); }
+__device__ __forceinline__ void int_commit(int v, int* __restrict__ dst, int n) { if ((int)threadIdx.x < n) dst[threadIdx.x] = v; }
+// [n][F] array at channels f0..f0+3 -> node-major [n][4]; src == NULL reads `valid` (same shape) and commits zeros
+__device__ __forceinline__ float4 scalar_issue(gcf src, gcf valid, int n, int F, int f0) {
+  return ldg4_pinned((src ? src : valid) + (size_t)min((int)threadIdx.x, n - 1) * F + f0);
+}
+__device__ __forceinline__ void scalar_commit(float4 v, bool have, float* __restrict__ dst, int n) {
+  if ((int)threadIdx.x < n) reinterpret_cast<float4*>(dst)[threadIdx.x] = have ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+// [n][F][3] array -> [n][4][3] (12 contiguous floats per node = 3 float4)
+__device__ __forceinline__ float4 vector_issue(gcf src, gcf valid, int n, int F, int f0) {
+  const int t = min((int)threadIdx.x, 3 * n - 1), m = t / 3, part = t - 3 * m;
+  return ldg4_pinned((src ? src : valid) + ((size_t)m * F + f0) * 3 + 4 * part);
+}
+__device__ __forceinline__ void vector_commit(float4 v, bool have, float* __restrict__ dst, int n) {
+  if ((int)threadIdx.x < 3 * n) reinterpret_cast<float4*>(dst)[threadIdx.x] = have ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+constexpr int geom_slots(int R) { return (DL_MAX_EDGES * geom_stride(R) / 4 + DL_THREADS - 1) / DL_THREADS; }
 __device__ __forceinline__ void stage_copy4(float* __restrict__ dst, const float* __restrict__ src, int n4) {
   for (int i = threadIdx.x; i < n4; i += DL_THREADS) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
 }
@@ -320,10 +417,10 @@ __device__ __forceinline__ dv3 lds_v3(const float* p) { return dv3{p[0], p[1], p
 // ============================================================================================== F2: phi + message forward
 template <int R>
 __global__ __launch_bounds__(DL_THREADS) void dec_msg_fwd_k(
-    const float* __restrict__ a1, const float* __restrict__ W2, const float* __restrict__ b2, const float* __restrict__ s,
-    const float* __restrict__ sbar, const float* __restrict__ v, const float* __restrict__ vbar,
-    const float* __restrict__ geom, const int* __restrict__ rowptr, const int* __restrict__ src,
-    const float* __restrict__ Wd, const float* __restrict__ bd, float* __restrict__ phi_out, float* __restrict__ stack,
+    const float* __restrict__ a1, const float* __restrict__ W2, const float* __restrict__ b2, const float* __restrict__ s_,
+    const float* __restrict__ sbar_, const float* __restrict__ v_, const float* __restrict__ vbar_,
+    const float* __restrict__ geom_, const int* __restrict__ rowptr_, const int* __restrict__ src_,
+    const float* __restrict__ Wd_, const float* __restrict__ bd_, float* __restrict__ phi_out, float* __restrict__ stack,
     float* __restrict__ sbar_out, float* __restrict__ v_out, float* __restrict__ vbar_out, float* __restrict__ rows_out,
     int n, int F, int E) {
   constexpr int GS = geom_stride(R), U = geom_unit_offset(R);
@@ -343,21 +440,32 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_fwd_k(
   const bool live = i < n;
   const int f = f0 + c;
   DL_TICK(8);
-  // bead graph + node state of these channels -> LDS (requested before the product, consumed after it)
-  stage_copy4(geom_l, geom, E * GS / 4);
-  stage_ints(rp_l, rowptr, n + 1);
-  stage_ints(src_l, src, E);
-  stage_scalar(s_l, s, n, F, f0); stage_scalar(sb_l, sbar, n, F, f0);
-  stage_vector(v_l, v, n, F, f0); stage_vector(vb_l, vbar, n, F, f0);
+  DL_SPAN(1, 0);
+  const gcf geom = launder(geom_); const gci rowptr = launder(rowptr_); const gci src = launder(src_);
+  const gcf s = launder(s_); const gcf sbar = launder(sbar_); const gcf v = launder(v_);
+  const gcf vbar = launder(vbar_); const gcf Wd = launder(Wd_); const gcf bd = launder(bd_);
+  // bead graph + node state of these channels: requested in one batch with the product's operands, stored to LDS behind
+  // the product's own requests (consumed after the product)
+  Slots4<geom_slots(R)> r_geom;
+  copy4_issue(r_geom, geom, E * GS / 4);
+  const int r_rp = int_issue(rowptr, n + 1), r_src = int_issue(src, E);
+  const float4 r_s = scalar_issue(s, s, n, F, f0), r_sb = scalar_issue(sbar, s, n, F, f0);
+  const float4 r_v = vector_issue(v, v, n, F, f0), r_vb = vector_issue(vbar, v, n, F, f0);
   float W[R + 1];
 #pragma unroll
-  for (int nn = 0; nn < R; ++nn) W[nn] = Wd[((size_t)k * F + f) * R + nn];
-  W[R] = bd[(size_t)k * F + f];
+  for (int nn = 0; nn < R; ++nn) W[nn] = ldg_pinned(Wd + ((size_t)k * F + f) * R + nn);
+  W[R] = ldg_pinned(bd + (size_t)k * F + f);
   int row0[9];
 #pragma unroll
   for (int g = 0; g < 9; ++g) row0[g] = g * F + f0;
+  pin_loads();
   DL_TICK(9);
-  fwd_core<1, 9>(phi_l, red, a1, n, F, W2, row0);
+  fwd_core<1, 9, 5>(phi_l, red, a1, n, F, W2, row0, [&]() {
+    copy4_commit(r_geom, geom_l, E * GS / 4);
+    int_commit(r_rp, rp_l, n + 1); int_commit(r_src, src_l, E);
+    scalar_commit(r_s, true, s_l, n); scalar_commit(r_sb, true, sb_l, n);
+    vector_commit(r_v, true, v_l, n); vector_commit(r_vb, true, vb_l, n);
+  });
   DL_TICK(10);
   // bias, dense copy for the backward pass (phi[m][g F + f0 .. +3])
   for (int o = threadIdx.x; o < 16 * 9; o += DL_THREADS) {
@@ -398,7 +506,7 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_fwd_k(
   DL_TICK(12);
   if (k > 0) { red2[((k - 1) * 3 + 0) * 64 + lane] = acc.x; red2[((k - 1) * 3 + 1) * 64 + lane] = acc.y; red2[((k - 1) * 3 + 2) * 64 + lane] = acc.z; }
   __syncthreads();
-  if (k != 0 || !live) return;
+  if (k != 0 || !live) { DL_SPAN(1, 1); return; }
   dv3 av{0.f, 0.f, 0.f}, avb{0.f, 0.f, 0.f};
 #pragma unroll
   for (int w = 0; w < 4; ++w) { av.x += red2[(w * 3 + 0) * 64 + lane]; av.y += red2[(w * 3 + 1) * 64 + lane]; av.z += red2[(w * 3 + 2) * 64 + lane]; }
@@ -417,13 +525,14 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_fwd_k(
   rows_out[((size_t)3 * i + 1) * F + f] = av.y;
   rows_out[((size_t)3 * i + 2) * F + f] = av.z;
   DL_TICK(13);
+  DL_SPAN(1, 1);
 }
 
 // ============================================================================================== F1 / F4: full-width Dense
 // y = act(x W^T + b), z = pre-activation, for M <= 16 rows: N / 4 blocks of 4 output columns each (150 CUs pull the
 // weight instead of the 38 of skinny_fwd_k's 16-column blocks).
 __global__ __launch_bounds__(DL_THREADS) void dec_dense_fwd_k(const float* __restrict__ x, const float* __restrict__ W,
-                                                              const float* __restrict__ bias, float* __restrict__ y,
+                                                              const float* __restrict__ bias_, float* __restrict__ y,
                                                               float* __restrict__ zout, int n, int N, int K, int act) {
   Carve cv;
   float* red = cv.take(fwd_red_floats<1, 1>());
@@ -432,13 +541,17 @@ __global__ __launch_bounds__(DL_THREADS) void dec_dense_fwd_k(const float* __res
   const int row0[1] = {n0};
   const bool mine = threadIdx.x < n * 4;
   const int i = threadIdx.x >> 2, c = threadIdx.x & 3;
-  const float b = (mine && bias) ? bias[n0 + c] : 0.f;
+  const gcf bias = launder(bias_);
+  const float b = (mine && bias) ? ldg_pinned(bias + n0 + c) : 0.f;
+  pin_loads();
+  DL_SPAN(K > N ? 3 : 0, 0);
   fwd_core<1, 1>(o_l, red, x, n, K, W, row0);
   if (mine) {
     const float zv = o_l[i * 4 + c] + b;
     const size_t at = (size_t)i * N + n0 + c;
     if (act) { if (zout) zout[at] = zv; y[at] = act_fwd(zv, act); } else y[at] = zv;
   }
+  DL_SPAN(K > N ? 3 : 0, 1);
 }
 
 // ============================================================================================== F3: [U | Vv] + norm
@@ -449,6 +562,7 @@ __global__ __launch_bounds__(DL_THREADS) void dec_uv_fwd_k(const float* __restri
   float* uv_l = cv.take(48 * 2 * 4);
   const int f0 = blockIdx.x * DL_CB;
   const int row0[2] = {f0, F + f0};
+  DL_SPAN(2, 0);
   fwd_core<3, 2>(uv_l, red, rows, 3 * n, F, Wuv, row0);
   for (int o = threadIdx.x; o < 3 * n * 2; o += DL_THREADS) {
     const int m = o >> 1, g = o & 1;
@@ -459,12 +573,13 @@ __global__ __launch_bounds__(DL_THREADS) void dec_uv_fwd_k(const float* __restri
     const float x = uv_l[((3 * i + 0) * 2 + 1) * 4 + c], y = uv_l[((3 * i + 1) * 2 + 1) * 4 + c], z = uv_l[((3 * i + 2) * 2 + 1) * 4 + c];
     stack[(size_t)i * 2 * F + F + f0 + c] = sqrtf(((x * x + 1e-10f) + (y * y + 1e-10f)) + (z * z + 1e-10f));      // conv.py:600
   }
+  DL_SPAN(2, 1);
 }
 
 // ============================================================================================== F5: a + gate
 __global__ __launch_bounds__(DL_THREADS) void dec_gate_fwd_k(const float* __restrict__ a0, const float* __restrict__ W1p,
-                                                             const float* __restrict__ b1p, const float* __restrict__ UV,
-                                                             const float* __restrict__ stack, const float* __restrict__ v2,
+                                                             const float* __restrict__ b1p_, const float* __restrict__ UV_,
+                                                             const float* __restrict__ stack_, const float* __restrict__ v2_,
                                                              float* __restrict__ a_out, float* __restrict__ s3,
                                                              float* __restrict__ v3, int n, int F) {
   Carve cv;
@@ -477,14 +592,18 @@ __global__ __launch_bounds__(DL_THREADS) void dec_gate_fwd_k(const float* __rest
   f3 r{0.f, 0.f, 0.f};
   const bool mine = threadIdx.x < n * 4;
   const int i = threadIdx.x >> 2, c = threadIdx.x & 3, f = f0 + c;
+  DL_SPAN(4, 0);
+  const gcf UV = launder(UV_); const gcf v2 = launder(v2_); const gcf stack = launder(stack_);
+  const gcf b1p = launder(b1p_);
   if (mine) {
     const size_t b = (size_t)i * 3 * 2 * F + f;
-    ux = UV[b]; uy = UV[b + 2 * F]; uz = UV[b + 4 * F];
-    vx = UV[b + F]; vy = UV[b + 2 * F + F]; vz = UV[b + 4 * F + F];
-    r = ld3(v2 + ((size_t)i * F + f) * 3);
-    s2 = stack[(size_t)i * 2 * F + f];
-    bvv = b1p[f]; bsv = b1p[F + f]; bss = b1p[2 * F + f];
+    ux = ldg_pinned(UV + b); uy = ldg_pinned(UV + b + 2 * F); uz = ldg_pinned(UV + b + 4 * F);
+    vx = ldg_pinned(UV + b + F); vy = ldg_pinned(UV + b + 2 * F + F); vz = ldg_pinned(UV + b + 4 * F + F);
+    r = ld3_pinned(v2 + ((size_t)i * F + f) * 3);
+    s2 = ldg_pinned(stack + (size_t)i * 2 * F + f);
+    bvv = ldg_pinned(b1p + f); bsv = ldg_pinned(b1p + F + f); bss = ldg_pinned(b1p + 2 * F + f);
   }
+  pin_loads();
   fwd_core<1, 3>(a_l, red, a0, n, F, W1p, row0);
   if (mine) {
     const float a_vv = a_l[(i * 3 + 0) * 4 + c] + bvv, a_sv = a_l[(i * 3 + 1) * 4 + c] + bsv, a_ss = a_l[(i * 3 + 2) * 4 + c] + bss;
@@ -494,16 +613,17 @@ __global__ __launch_bounds__(DL_THREADS) void dec_gate_fwd_k(const float* __rest
     st3(v3 + nf * 3, ux * a_vv + r.x, uy * a_vv + r.y, uz * a_vv + r.z);                  // conv.py:607, cgvae.py:123
     s3[nf] = ((ux * vx + uy * vy + uz * vz) * a_sv + a_ss) + s2;                           // conv.py:612-614, cgvae.py:122
   }
+  DL_SPAN(4, 1);
 }
 
 // ============================================================================================== B1: gate backward + W1' rows
 // CBQ = channel quads per block (1: 4 channels, F / 4 blocks; 2: 8 channels, F / 8 blocks -- half as many, twice as fat
 // slices: a phase's slice volume is blocks x rows x K, so fatter blocks halve what the next phase reads back).
-template <int CBQ>
+template <int CBQ, int QS>
 __global__ __launch_bounds__(DL_THREADS) void dec_gate_bwd_k(
-    const float* __restrict__ UV, const float* __restrict__ a, const float* __restrict__ gs_base,
-    const float* __restrict__ gs_slices, int gs_n, long long gs_stride, const float* __restrict__ gv,
-    const float* __restrict__ W1p, float* __restrict__ ga, float* __restrict__ gUV, float* __restrict__ gs_sum,
+    const float* __restrict__ UV_, const float* __restrict__ a_, const float* __restrict__ gs_base_,
+    const float* __restrict__ gs_slices_, int gs_n, long long gs_stride, const float* __restrict__ gv_,
+    const float* __restrict__ W1p_, float* __restrict__ ga, float* __restrict__ gUV, float* __restrict__ gs_sum,
     float* __restrict__ slices_out, long long out_stride, int n, int F) {
   constexpr int C = 4 * CBQ, G = 3 * CBQ;
   Carve cv;
@@ -517,12 +637,15 @@ __global__ __launch_bounds__(DL_THREADS) void dec_gate_bwd_k(
   for (int g = 0; g < 3; ++g)
 #pragma unroll
     for (int q = 0; q < CBQ; ++q) row0[g * CBQ + q] = g * F + f0 + 4 * q;
+  DL_SPAN(5, 0);
+  const gcf UV = launder(UV_); const gcf a = launder(a_); const gcf gs_base = launder(gs_base_);
+  const gcf gs_slices = launder(gs_slices_); const gcf gv = launder(gv_); const gcf W1p = launder(W1p_);
   // order of requests: the slices and the prologue's own operands first, the weights behind them
   const bool have_slices = gs_slices && gs_n > 0;
   int kq[CBQ];
 #pragma unroll
   for (int q = 0; q < CBQ; ++q) kq[q] = have_slices ? (int)blockIdx.x * CBQ + q : 0;
-  QuadRegs<1, CBQ> qr;
+  QuadRegs<1, CBQ, QS> qr;
   quad_issue<1, CBQ>(qr, have_slices ? gs_slices : UV, have_slices ? gs_n : 1, have_slices ? gs_stride : 0, have_slices ? n : 1, kq);
   const bool mine = threadIdx.x < n * C;
   const int i = threadIdx.x / C, c = threadIdx.x - i * C, f = f0 + c;
@@ -530,14 +653,15 @@ __global__ __launch_bounds__(DL_THREADS) void dec_gate_bwd_k(
   const size_t b = (size_t)i * 3 * 2 * F + f, cc = (size_t)i * 3 * F + f;
   float ux = 0.f, uy = 0.f, uz = 0.f, vx = 0.f, vy = 0.f, vz = 0.f, a_vv = 0.f, a_sv = 0.f, gsb = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
   if (mine) {
-    ux = UV[b]; uy = UV[b + 2 * F]; uz = UV[b + 4 * F];
-    vx = UV[b + F]; vy = UV[b + 2 * F + F]; vz = UV[b + 4 * F + F];
-    a_vv = a[cc]; a_sv = a[cc + F];
-    if (gs_base) gsb = gs_base[nf];
-    if (gv) { const f3 t = ld3(gv + nf * 3); gx = t.x; gy = t.y; gz = t.z; }
+    ux = ldg_pinned(UV + b); uy = ldg_pinned(UV + b + 2 * F); uz = ldg_pinned(UV + b + 4 * F);
+    vx = ldg_pinned(UV + b + F); vy = ldg_pinned(UV + b + 2 * F + F); vz = ldg_pinned(UV + b + 4 * F + F);
+    a_vv = ldg_pinned(a + cc); a_sv = ldg_pinned(a + cc + F);
+    if (gs_base) gsb = ldg_pinned(gs_base + nf);
+    if (gv) { const f3 t = ld3_pinned(gv + nf * 3); gx = t.x; gy = t.y; gz = t.z; }
   }
   BiRegs<G, 2> wr;
   bi_prefetch<G, 2>(wr, W1p, F, row0);
+  pin_loads();
   for (int o = threadIdx.x; o < 16 * G * 4; o += DL_THREADS) g_l[o] = 0.f;
   quad_finish<1, CBQ>(qr, gs_l, scratch, have_slices ? gs_n : 0, n);         // no slices: every class empty -> zeros
   if (mine) {
@@ -554,12 +678,13 @@ __global__ __launch_bounds__(DL_THREADS) void dec_gate_bwd_k(
   }
   __syncthreads();
   bi_core<1, G, 2>(wr, g_l, stage, slices_out + (size_t)blockIdx.x * out_stride, F, n);
+  DL_SPAN(5, 1);
 }
 
 // ============================================================================================== B2 / B5: slice sum, act', CBQ row groups
-template <int NT, int CBQ>
-__global__ __launch_bounds__(DL_THREADS) void dec_dense_bwd_k(const float* __restrict__ g_slices, int g_n, long long g_stride,
-                                                              const float* __restrict__ z, int act, const float* __restrict__ W,
+template <int NT, int CBQ, int QS>
+__global__ __launch_bounds__(DL_THREADS) void dec_dense_bwd_k(const float* __restrict__ g_slices_, int g_n, long long g_stride,
+                                                              const float* __restrict__ z_, int act, const float* __restrict__ W_,
                                                               float* __restrict__ g_dense, float* __restrict__ slices_out,
                                                               long long out_stride, int n, int N, int K) {
   constexpr int C = 4 * CBQ;
@@ -569,17 +694,20 @@ __global__ __launch_bounds__(DL_THREADS) void dec_dense_bwd_k(const float* __res
   float4* sum_l = reinterpret_cast<float4*>(cv.take(CBQ * 16 * 4));
   float* g_l = cv.take(16 * CBQ * 4);
   const int n0 = blockIdx.x * C;
+  DL_SPAN(K > N ? 6 : 9, 0);
+  const gcf g_slices = launder(g_slices_); const gcf z = launder(z_); const gcf W = launder(W_);
   int row0[CBQ], kq[CBQ];
 #pragma unroll
   for (int q = 0; q < CBQ; ++q) { row0[q] = n0 + 4 * q; kq[q] = (int)blockIdx.x * CBQ + q; }
-  QuadRegs<1, CBQ> qr;
+  QuadRegs<1, CBQ, QS> qr;
   quad_issue<1, CBQ>(qr, g_slices, g_n, g_stride, n, kq);
   const int i = threadIdx.x / C, c = threadIdx.x - i * C;
   const size_t at = (size_t)i * N + n0 + c;
   float zz = 0.f;
-  if (threadIdx.x < 16 * C && i < n && act) zz = z[at];
+  if (threadIdx.x < 16 * C && i < n && act) zz = ldg_pinned(z + at);
   BiRegs<CBQ, NT> wr;
   bi_prefetch<CBQ, NT>(wr, W, K, row0);
+  pin_loads();
   quad_finish<1, CBQ>(qr, sum_l, scratch, g_n, n);
   if (threadIdx.x < 16 * C) {
     const int q = c >> 2, c4 = c & 3;
@@ -593,13 +721,14 @@ __global__ __launch_bounds__(DL_THREADS) void dec_dense_bwd_k(const float* __res
   }
   __syncthreads();
   bi_core<1, CBQ, NT>(wr, g_l, stage, slices_out + (size_t)blockIdx.x * out_stride, K, n);
+  DL_SPAN(K > N ? 6 : 9, 1);
 }
 
 // ============================================================================================== B3: norm backward + [Wu; Wv] rows
-template <int CBQ>
-__global__ __launch_bounds__(DL_THREADS) void dec_uv_bwd_k(const float* __restrict__ gstack_slices, int gs_n, long long gs_stride,
-                                                           const float* __restrict__ UV, const float* __restrict__ stack,
-                                                           const float* __restrict__ gs_res, const float* __restrict__ Wuv,
+template <int CBQ, int QS>
+__global__ __launch_bounds__(DL_THREADS) void dec_uv_bwd_k(const float* __restrict__ gstack_slices_, int gs_n, long long gs_stride,
+                                                           const float* __restrict__ UV_, const float* __restrict__ stack_,
+                                                           const float* __restrict__ gs_res_, const float* __restrict__ Wuv_,
                                                            float* __restrict__ gUV, float* __restrict__ g_s2,
                                                            float* __restrict__ slices_out, long long out_stride, int n, int F) {
   constexpr int C = 4 * CBQ, G = 2 * CBQ;
@@ -609,13 +738,17 @@ __global__ __launch_bounds__(DL_THREADS) void dec_uv_bwd_k(const float* __restri
   float4* gsum_l = reinterpret_cast<float4*>(cv.take(G * 16 * 4));       // [q]: columns f0 + 4 q .. of g_stack, [CBQ + q]: the norm half
   float* g_l = cv.take(48 * G * 4);
   const int f0 = blockIdx.x * C;
+  DL_SPAN(7, 0);
+  const gcf gstack_slices = launder(gstack_slices_); const gcf UV = launder(UV_); const gcf stack = launder(stack_);
+  const gcf gs_res = launder(gs_res_); const gcf Wuv = launder(Wuv_);
+  const gcf gUV_in = launder(static_cast<const float*>(gUV));
   int row0[G], kq[G];
 #pragma unroll
   for (int q = 0; q < CBQ; ++q) {
     row0[q] = f0 + 4 * q; row0[CBQ + q] = F + f0 + 4 * q;
     kq[q] = (int)blockIdx.x * CBQ + q; kq[CBQ + q] = F / 4 + (int)blockIdx.x * CBQ + q;
   }
-  QuadRegs<1, G> qr;
+  QuadRegs<1, G, QS> qr;
   quad_issue<1, G>(qr, gstack_slices, gs_n, gs_stride, n, kq);
   const bool mine = threadIdx.x < n * C;
   const int i = threadIdx.x / C, c = threadIdx.x - i * C, f = f0 + c;
@@ -626,13 +759,14 @@ __global__ __launch_bounds__(DL_THREADS) void dec_uv_bwd_k(const float* __restri
 #pragma unroll
     for (int xyz = 0; xyz < 3; ++xyz) {
       const size_t at = b + (size_t)xyz * 2 * F;
-      gu[xyz] = gUV[at]; gvv[xyz] = gUV[at + F]; vv[xyz] = UV[at + F];
+      gu[xyz] = ldg_pinned(gUV_in + at); gvv[xyz] = ldg_pinned(gUV_in + at + F); vv[xyz] = ldg_pinned(UV + at + F);
     }
-    res = gs_res[nf];
-    nrm = stack[(size_t)i * 2 * F + F + f];
+    res = ldg_pinned(gs_res + nf);
+    nrm = ldg_pinned(stack + (size_t)i * 2 * F + F + f);
   }
   BiRegs<G, 2> wr;
   bi_prefetch<G, 2>(wr, Wuv, F, row0);
+  pin_loads();
   for (int o = threadIdx.x; o < 48 * G * 4; o += DL_THREADS) g_l[o] = 0.f;
   quad_finish<1, G>(qr, gsum_l, scratch, gs_n, n);
   if (mine) {
@@ -649,17 +783,18 @@ __global__ __launch_bounds__(DL_THREADS) void dec_uv_bwd_k(const float* __restri
   }
   __syncthreads();
   bi_core<3, G, 2>(wr, g_l, stage, slices_out + (size_t)blockIdx.x * out_stride, F, 3 * n);
+  DL_SPAN(7, 1);
 }
 
 // ============================================================================================== B4: message backward + W2 rows
-template <int R>
+template <int R, int QS>
 __global__ __launch_bounds__(DL_THREADS) void dec_msg_bwd_k(
-    const float* __restrict__ phi, const float* __restrict__ s, const float* __restrict__ sbar, const float* __restrict__ v,
-    const float* __restrict__ vbar, const float* __restrict__ geom_d, const int* __restrict__ rowptr_d,
-    const int* __restrict__ src_d, const float* __restrict__ geom_s, const int* __restrict__ rowptr_s,
-    const int* __restrict__ dst_s, const float* __restrict__ Wd, const float* __restrict__ bd,
-    const float* __restrict__ gh, const float* __restrict__ ghb, const float* __restrict__ gvrows_slices, int gvr_n,
-    long long gvr_stride, const float* __restrict__ gv_res, const float* __restrict__ gvb, const float* __restrict__ W2,
+    const float* __restrict__ phi_, const float* __restrict__ s_, const float* __restrict__ sbar_, const float* __restrict__ v_,
+    const float* __restrict__ vbar_, const float* __restrict__ geom_d_, const int* __restrict__ rowptr_d_,
+    const int* __restrict__ src_d_, const float* __restrict__ geom_s_, const int* __restrict__ rowptr_s_,
+    const int* __restrict__ dst_s_, const float* __restrict__ Wd_, const float* __restrict__ bd_,
+    const float* __restrict__ gh_, const float* __restrict__ ghb_, const float* __restrict__ gvrows_slices_, int gvr_n,
+    long long gvr_stride, const float* __restrict__ gv_res_, const float* __restrict__ gvb_, const float* __restrict__ W2_,
     float* __restrict__ g_phi, float* __restrict__ g_s, float* __restrict__ g_sbar, float* __restrict__ g_v,
     float* __restrict__ g_vbar, float* __restrict__ gWd, float* __restrict__ gbd, float* __restrict__ slices_out,
     long long out_stride, int n, int F, int E) {
@@ -671,7 +806,7 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_bwd_k(
   float4* gvr_l = reinterpret_cast<float4*>(cv.take(48 * 4));           // gV' rows [3 i + xyz][c]
   float* gphi_l = cv.take(16 * 9 * 4);
   float* phi_l = cv.take(16 * 9 * 4);
-  float* red_src = cv.take(8 * 6 * 64);                                  // waves 1..8: source-side (av, avb) of the lane's node
+  float* red_src = cv.take(9 * 6 * 64);                                  // source-side (av, avb) of the lane's node, per wave
   float* red_rcv = cv.take(9 * 8 * 64);                                  // receiver-side partials (as, asb, av, avb)
   float* geomd_l = cv.take((size_t)DL_MAX_EDGES * GS);
   float* geoms_l = cv.take((size_t)DL_MAX_EDGES * GS);
@@ -685,36 +820,58 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_bwd_k(
 #pragma unroll
   for (int g = 0; g < 9; ++g) row0[g] = g * F + f0;
   DL_TICK(0);
-  // order of requests: slices, then the bead graph / node state (consumed right away), the weights last
-  QuadRegs<3, 1> qr;
-  { const int kq[1] = {(int)blockIdx.x}; quad_issue<3, 1>(qr, gvrows_slices, gvr_n, gvr_stride, 3 * n, kq); }
+  DL_SPAN(8, 0);
+  const gcf geom_d = launder(geom_d_); const gcf geom_s = launder(geom_s_); const gci rowptr_d = launder(rowptr_d_);
+  const gci rowptr_s = launder(rowptr_s_); const gci src_d = launder(src_d_); const gci dst_s = launder(dst_s_);
+  const gcf s = launder(s_); const gcf sbar = launder(sbar_); const gcf v = launder(v_);
+  const gcf vbar = launder(vbar_); const gcf gh = launder(gh_); const gcf ghb = launder(ghb_);
+  const gcf gvb = launder(gvb_); const gcf gv_res = launder(gv_res_); const gcf phi = launder(phi_);
+  const gcf Wd = launder(Wd_); const gcf bd = launder(bd_); const gcf gvrows_slices = launder(gvrows_slices_);
+  const gcf W2 = launder(W2_);
   const int lane = threadIdx.x & 63;
   const int k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int node = lane >> 2, c = lane & 3, f = f0 + c;
   const bool live = node < n;
   const int nc = live ? node : 0;
-  // bead graph, node state and upstream gradients of these channels -> LDS, one batch
-  stage_copy4(geomd_l, geom_d, E * GS / 4);
-  stage_copy4(geoms_l, geom_s, E * GS / 4);
-  stage_ints(rpd_l, rowptr_d, n + 1); stage_ints(rps_l, rowptr_s, n + 1);
-  stage_ints(srcd_l, src_d, E); stage_ints(dsts_l, dst_s, E);
-  stage_scalar(s_l, s, n, F, f0); stage_scalar(sb_l, sbar, n, F, f0);
-  stage_scalar(gh_l, gh, n, F, f0); stage_scalar(ghb_l, ghb, n, F, f0);
-  stage_vector(v_l, v, n, F, f0); stage_vector(vb_l, vbar, n, F, f0);
-  stage_vector(gvb_l, gvb, n, F, f0); stage_vector(gvres_l, gv_res, n, F, f0);
-  for (int o = threadIdx.x; o < n * 9; o += DL_THREADS) {
-    const int m = o / 9, g = o - m * 9;
-    *reinterpret_cast<float4*>(phi_l + (m * 9 + g) * 4) = *reinterpret_cast<const float4*>(phi + (size_t)m * 9 * F + (size_t)g * F + f0);
+  // order of requests, all in one batch: the bead graph / node state / upstream gradients of these channels (small,
+  // stored to LDS as soon as they land), the slices, and -- once the staging registers are free -- the weights, which
+  // have the two edge passes to arrive in
+  Slots4<geom_slots(R)> r_gd, r_gs;
+  copy4_issue(r_gd, geom_d, E * GS / 4);
+  copy4_issue(r_gs, geom_s, E * GS / 4);
+  const int r_rpd = int_issue(rowptr_d, n + 1), r_rps = int_issue(rowptr_s, n + 1);
+  const int r_srcd = int_issue(src_d, E), r_dsts = int_issue(dst_s, E);
+  const float4 r_s = scalar_issue(s, s, n, F, f0), r_sb = scalar_issue(sbar, s, n, F, f0);
+  const float4 r_gh = scalar_issue(gh, s, n, F, f0), r_ghb = scalar_issue(ghb, s, n, F, f0);
+  const float4 r_v = vector_issue(v, v, n, F, f0), r_vb = vector_issue(vbar, v, n, F, f0);
+  const float4 r_gvb = vector_issue(gvb, v, n, F, f0), r_gvres = vector_issue(gv_res, v, n, F, f0);
+  float4 r_phi;
+  {
+    const int o = min((int)threadIdx.x, n * 9 - 1), m = o / 9, g = o - m * 9;
+    r_phi = ldg4_pinned(phi + (size_t)m * 9 * F + (size_t)g * F + f0);
   }
   float W[R + 1], G[R + 1];
 #pragma unroll
-  for (int nn = 0; nn < R; ++nn) W[nn] = Wd[((size_t)k * F + f) * R + nn];
-  W[R] = bd[(size_t)k * F + f];
+  for (int nn = 0; nn < R; ++nn) W[nn] = ldg_pinned(Wd + ((size_t)k * F + f) * R + nn);
+  W[R] = ldg_pinned(bd + (size_t)k * F + f);
 #pragma unroll
   for (int nn = 0; nn <= R; ++nn) G[nn] = 0.f;
+  QuadRegs<3, 1, QS> qr;
+  { const int kq[1] = {(int)blockIdx.x}; quad_issue<3, 1>(qr, gvrows_slices, gvr_n, gvr_stride, 3 * n, kq); }
+  pin_loads();
+  copy4_commit(r_gd, geomd_l, E * GS / 4);
+  copy4_commit(r_gs, geoms_l, E * GS / 4);
+  int_commit(r_rpd, rpd_l, n + 1); int_commit(r_rps, rps_l, n + 1);
+  int_commit(r_srcd, srcd_l, E); int_commit(r_dsts, dsts_l, E);
+  scalar_commit(r_s, true, s_l, n); scalar_commit(r_sb, true, sb_l, n);
+  scalar_commit(r_gh, gh != nullptr, gh_l, n); scalar_commit(r_ghb, ghb != nullptr, ghb_l, n);
+  vector_commit(r_v, true, v_l, n); vector_commit(r_vb, true, vb_l, n);
+  vector_commit(r_gvb, gvb != nullptr, gvb_l, n); vector_commit(r_gvres, gv_res != nullptr, gvres_l, n);
+  if ((int)threadIdx.x < n * 9) reinterpret_cast<float4*>(phi_l)[threadIdx.x] = r_phi;
   DL_TICK(1);
-  BiRegs<9, 1> wr;
-  bi_prefetch<9, 1>(wr, W2, F, row0);
+  BiRegs<9, 2> wr;                                                       // slot 1: the late tile, requested below
+  bi_prefetch_slot<0>(wr, W2, F, row0, k);
+  pin_loads();
   // gV' = sum of the slices of B3 (rows 3 i + xyz) + the residual path V' -> V''
   quad_finish<3, 1>(qr, gvr_l, scratch, gvr_n, 3 * n);
   if (threadIdx.x < 64) {
@@ -725,6 +882,14 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_bwd_k(
   }
   __syncthreads();
   DL_TICK(2);
+  // the 10th.. column tiles (K = 600: 24 columns, wave 0 only): requested now, used after the passes
+  if ((k + DL_WAVES) * 64 < F) {                                          // wave-uniform
+    bi_prefetch_slot<1>(wr, W2, F, row0, k + DL_WAVES);
+  } else {
+#pragma unroll
+    for (int g = 0; g < 9; ++g) wr.w[1][g] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  pin_loads();
   const float p_j = phi_l[(nc * 9 + k) * 4 + c];
   const float s_n = s_l[nc * 4 + c], sb_n = sb_l[nc * 4 + c];
   const dv3 v_n = lds_v3(v_l + (nc * 4 + c) * 3), vb_n = lds_v3(vb_l + (nc * 4 + c) * 3);
@@ -771,8 +936,8 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_bwd_k(
   }
   DL_TICK(3);
   gphi_l[(node * 9 + k) * 4 + c] = live ? a : 0.f;
-  if (k > 0) {
-    float* r = red_src + (size_t)(k - 1) * 6 * 64 + lane;
+  {
+    float* r = red_src + (size_t)k * 6 * 64 + lane;
     r[0] = av.x; r[64] = av.y; r[128] = av.z; r[192] = avb.x; r[256] = avb.y; r[320] = avb.z;
   }
   // filter gradients: sum over the source nodes (lanes node*4 + c, fixed butterfly order), written once per block
@@ -820,36 +985,31 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_bwd_k(
     const int m = o / 9, g = o - m * 9;
     *reinterpret_cast<float4*>(g_phi + (size_t)m * 9 * F + (size_t)g * F + f0) = *reinterpret_cast<const float4*>(gphi_l + (m * 9 + g) * 4);
   }
-  if (k == 0 && live) {
-    // receiver-side sums in wave order, source-side sums in wave order, residual pass-through (outputs were state + delta)
-    float ts = gh_n, tsb = ghb_n;
-    dv3 tv = gv_n, tvb = gvb_n;
+  if (k < 8 && live) {
+    // wave k sums output component k of (g_s, g_sbar, g_v.xyz, g_vbar.xyz): the residual pass-through (outputs were
+    // state + delta), the receiver-side partials in wave order, then the source-side partials in wave order
+    float t = k == 0 ? gh_n : k == 1 ? ghb_n : k == 2 ? gv_n.x : k == 3 ? gv_n.y : k == 4 ? gv_n.z
+            : k == 5 ? gvb_n.x : k == 6 ? gvb_n.y : gvb_n.z;
 #pragma unroll
-    for (int w = 0; w < 9; ++w) {
-      const float* r = red_rcv + (size_t)w * 8 * 64 + lane;
-      ts += r[0]; tsb += r[64];
-      tv.x += r[128]; tv.y += r[192]; tv.z += r[256];
-      tvb.x += r[320]; tvb.y += r[384]; tvb.z += r[448];
-    }
-    tv.x += av.x; tv.y += av.y; tv.z += av.z;
-    tvb.x += avb.x; tvb.y += avb.y; tvb.z += avb.z;
+    for (int w = 0; w < 9; ++w) t += red_rcv[((size_t)w * 8 + k) * 64 + lane];
+    if (k >= 2) {
 #pragma unroll
-    for (int w = 0; w < 8; ++w) {
-      const float* r = red_src + (size_t)w * 6 * 64 + lane;
-      tv.x += r[0]; tv.y += r[64]; tv.z += r[128]; tvb.x += r[192]; tvb.y += r[256]; tvb.z += r[320];
+      for (int w = 0; w < 9; ++w) t += red_src[((size_t)w * 6 + (k - 2)) * 64 + lane];
     }
     const size_t jf = (size_t)node * F + f;
-    g_s[jf] = ts;
-    g_sbar[jf] = tsb;
-    st3(g_v + jf * 3, tv.x, tv.y, tv.z);
-    st3(g_vbar + jf * 3, tvb.x, tvb.y, tvb.z);
+    if (k == 0) g_s[jf] = t;
+    else if (k == 1) g_sbar[jf] = t;
+    else if (k < 5) g_v[jf * 3 + (k - 2)] = t;
+    else g_vbar[jf * 3 + (k - 5)] = t;
   }
   DL_TICK(6);
-  bi_core<1, 9, 2, 1>(wr, gphi_l, stage, slices_out + (size_t)blockIdx.x * out_stride, F, n, W2, row0);
+  bi_core<1, 9, 2>(wr, gphi_l, stage, slices_out + (size_t)blockIdx.x * out_stride, F, n);
   DL_TICK(7);
+  DL_SPAN(8, 1);
 }
 
 // out[m][4 kq ..] = base + sum_s slices[s][kq][m][:]: the decoder input's gradient leaves the slice format here
+template <int QS>
 __global__ __launch_bounds__(DL_THREADS) void dec_quad_to_dense_k(const float* __restrict__ base, const float* __restrict__ slices,
                                                                   int n_slices, long long stride, float* __restrict__ out, int n,
                                                                   int F) {
@@ -857,8 +1017,8 @@ __global__ __launch_bounds__(DL_THREADS) void dec_quad_to_dense_k(const float* _
   float4* scratch = reinterpret_cast<float4*>(cv.take(36 * 16 * 4));
   float4* sum_l = reinterpret_cast<float4*>(cv.take(16 * 4));
   const int kq[1] = {(int)blockIdx.x};
-  QuadRegs<1, 1> qr;
-  quad_issue<1, 1>(qr, slices, n_slices, stride, n, kq);
+  QuadRegs<1, 1, QS> qr;
+  quad_issue<1, 1>(qr, launder(slices), n_slices, stride, n, kq);
   quad_finish<1, 1>(qr, sum_l, scratch, n_slices, n);
   if (threadIdx.x < n) {
     float4 t = sum_l[threadIdx.x];
@@ -894,7 +1054,9 @@ int cgv_decoder_max_edges(void) { return cgv::DL_MAX_EDGES; }
 /* channels (weight rows per row group set) a block of gate_bwd / dense_bwd / uv_bwd owns for a width: 8 when the width
  * is a multiple of 8 (half as many, twice as fat slices), else 4; their slice count is width / this. */
 int cgv_decoder_block_channels(int width) { return (width % 8) == 0 && cgv::option(CGV_OPT_DECODER_FAT) != 0 ? 8 : 4; }
-/* measurement: block 0 of cgv_decoder_msg_bwd stores the GPU wall clock at its phase boundaries into buf[0..7], of cgv_decoder_msg_fwd into buf[8..13] (NULL: off) */
+/* measurement: block 0 of cgv_decoder_msg_bwd stores the GPU wall clock at its phase boundaries into buf[0..7], of
+ * cgv_decoder_msg_fwd into buf[8..13]; every decoder kernel stores begin / end of its first and last block into
+ * buf[32 + 4 id ..] (ids in decoder_layer.hip).  buf: 72 uint64.  NULL: off */
 int cgv_decoder_debug_clock(uint64_t* buf) {
   unsigned long long* p = reinterpret_cast<unsigned long long*>(buf);
   hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(cgv::g_dl_clock), &p, sizeof(p));
@@ -904,6 +1066,13 @@ int cgv_decoder_debug_clock(uint64_t* buf) {
 /* floats of one slice of a phase's output: (K / 4) column quads x rows x 4 */
 int64_t cgv_decoder_slice_floats(int K, int rows) { return (int64_t)K * rows; }
 
+
+/* slices per lane class of a slice sum: 3 up to 108 slices, else 6 (up to 216) */
+#define CGV_DL_QS(n_slices, ...)                                           \
+  do {                                                                     \
+    if ((n_slices) <= 108) { constexpr int QS = 3; __VA_ARGS__ }           \
+    else { constexpr int QS = 6; __VA_ARGS__ }                             \
+  } while (0)
 
 #define CGV_DL_CHECK()                                                                                        \
   CGV_REQUIRE(cgv_decoder_layer_supported(n_nodes, n_feat, n_rbf), "unsupported shape (n <= 16 nodes, F % 4 == 0, 16 <= F <= 864)"); \
@@ -916,7 +1085,7 @@ int cgv_decoder_msg_fwd(const float* a1, const float* W2, const float* b2, const
                         float* rows_out, int n_nodes, int n_feat, int n_rbf, int n_edges, void* stream) {
   CGV_REQUIRE(a1 && W2 && b2 && s && sbar && v && vbar && geom_d && rowptr_d && src_d && Wd && bd, "null input");
   CGV_REQUIRE(phi && stack && sbar_out && v_out && vbar_out && rows_out, "null output");
-  CGV_REQUIRE(n_edges >= 0 && n_edges <= cgv::DL_MAX_EDGES, "too many edges for the staged bead graph");
+  CGV_REQUIRE(n_edges >= 1 && n_edges <= cgv::DL_MAX_EDGES, "the staged bead graph holds 1..cgv_decoder_max_edges() edges");
   CGV_DL_CHECK();
   const size_t lds = cgv::lds_bytes(cgv::fwd_red_floats<1, 9>() + 576 + 1536 + (size_t)cgv::DL_MAX_EDGES * cgv::geom_stride(n_rbf) + 20 +
                                cgv::DL_MAX_EDGES + 128 + 384);
@@ -961,26 +1130,28 @@ int cgv_decoder_gate_bwd(const float* UV, const float* a, const float* gs_base, 
                          int64_t gs_slice_stride, const float* gv, const float* W1p, float* ga, float* gUV, float* gs_sum,
                          float* slices_out, int64_t out_slice_stride, int n_nodes, int n_feat, void* stream) {
   CGV_REQUIRE(UV && a && W1p && ga && gUV && gs_sum && slices_out, "null pointer");
-  CGV_REQUIRE(gs_n_slices >= 0 && out_slice_stride >= cgv_decoder_slice_floats(n_feat, n_nodes), "bad slices");
+  CGV_REQUIRE(gs_n_slices >= 0 && gs_n_slices <= 216 && out_slice_stride >= cgv_decoder_slice_floats(n_feat, n_nodes), "bad slices");
   const int n_rbf = 8;
   CGV_DL_CHECK();
   (void)blocks;
-  if (cgv_decoder_block_channels(n_feat) == 8)
-    hipLaunchKernelGGL(cgv::dec_gate_bwd_k<2>, dim3(n_feat / 8), dim3(cgv::DL_THREADS),
-                       cgv::lds_bytes(cgv::bi_stage_floats<1>() + 2 * 2304 + 2 * 64 + 384), st, UV, a, gs_base, gs_slices, gs_n_slices,
-                       (long long)gs_slice_stride, gv, W1p, ga, gUV, gs_sum, slices_out, (long long)out_slice_stride, n_nodes,
-                       n_feat);
-  else
-    hipLaunchKernelGGL(cgv::dec_gate_bwd_k<1>, dim3(n_feat / 4), dim3(cgv::DL_THREADS),
-                       cgv::lds_bytes(cgv::bi_stage_floats<1>() + 2304 + 64 + 192), st, UV, a, gs_base, gs_slices, gs_n_slices,
-                       (long long)gs_slice_stride, gv, W1p, ga, gUV, gs_sum, slices_out, (long long)out_slice_stride, n_nodes,
-                       n_feat);
+  CGV_DL_QS(gs_n_slices, {
+    if (cgv_decoder_block_channels(n_feat) == 8)
+      hipLaunchKernelGGL((cgv::dec_gate_bwd_k<2, QS>), dim3(n_feat / 8), dim3(cgv::DL_THREADS),
+                         cgv::lds_bytes(cgv::bi_stage_floats<1>() + 2 * 2304 + 2 * 64 + 384), st, UV, a, gs_base, gs_slices,
+                         gs_n_slices, (long long)gs_slice_stride, gv, W1p, ga, gUV, gs_sum, slices_out,
+                         (long long)out_slice_stride, n_nodes, n_feat);
+    else
+      hipLaunchKernelGGL((cgv::dec_gate_bwd_k<1, QS>), dim3(n_feat / 4), dim3(cgv::DL_THREADS),
+                         cgv::lds_bytes(cgv::bi_stage_floats<1>() + 2304 + 64 + 192), st, UV, a, gs_base, gs_slices, gs_n_slices,
+                         (long long)gs_slice_stride, gv, W1p, ga, gUV, gs_sum, slices_out, (long long)out_slice_stride, n_nodes,
+                         n_feat);
+  });
   return cgv::check_launch("cgv_decoder_gate_bwd");
 }
 
 int cgv_decoder_dense_bwd(const float* g_slices, int g_n_slices, int64_t g_slice_stride, const float* z, int act, const float* W,
                           float* g_dense, float* slices_out, int64_t out_slice_stride, int n_nodes, int N, int K, void* stream) {
-  CGV_REQUIRE(g_slices && W && g_dense && slices_out && g_n_slices >= 1, "null pointer");
+  CGV_REQUIRE(g_slices && W && g_dense && slices_out && g_n_slices >= 1 && g_n_slices <= 216, "null pointer / slice count");
   CGV_REQUIRE(act == 0 || (act >= 1 && act <= cgv::CGV_ACT_MAX && z), "act != 0 needs the saved pre-activation z");
   CGV_REQUIRE(n_nodes >= 1 && n_nodes <= cgv::DL_MAX_NODES && (N % 4) == 0 && (K % 4) == 0 && K <= 64 * 27 && N >= 4, "unsupported shape");
   CGV_REQUIRE(out_slice_stride >= cgv_decoder_slice_floats(K, n_nodes), "bad slices");
@@ -989,13 +1160,17 @@ int cgv_decoder_dense_bwd(const float* g_slices, int g_n_slices, int64_t g_slice
   const bool fat = cgv_decoder_block_channels(N) == 8;
   const int blocks = fat ? N / 8 : N / 4;
   const size_t lds = cgv::lds_bytes(cgv::bi_stage_floats<1>() + 2 * 2304 + 2 * 64 + 2 * 64);
-#define CGV_DL_DENSE(NTV)                                                                                                \
-  if (fat)                                                                                                               \
-    hipLaunchKernelGGL((cgv::dec_dense_bwd_k<NTV, 2>), dim3(blocks), dim3(cgv::DL_THREADS), lds, st, g_slices, g_n_slices, \
-                       (long long)g_slice_stride, z, act, W, g_dense, slices_out, (long long)out_slice_stride, n_nodes, N, K); \
-  else                                                                                                                   \
-    hipLaunchKernelGGL((cgv::dec_dense_bwd_k<NTV, 1>), dim3(blocks), dim3(cgv::DL_THREADS), lds, st, g_slices, g_n_slices, \
-                       (long long)g_slice_stride, z, act, W, g_dense, slices_out, (long long)out_slice_stride, n_nodes, N, K)
+#define CGV_DL_DENSE(NTV)                                                                                                  \
+  CGV_DL_QS(g_n_slices, {                                                                                                  \
+    if (fat)                                                                                                               \
+      hipLaunchKernelGGL((cgv::dec_dense_bwd_k<NTV, 2, QS>), dim3(blocks), dim3(cgv::DL_THREADS), lds, st, g_slices,       \
+                         g_n_slices, (long long)g_slice_stride, z, act, W, g_dense, slices_out, (long long)out_slice_stride, \
+                         n_nodes, N, K);                                                                                   \
+    else                                                                                                                   \
+      hipLaunchKernelGGL((cgv::dec_dense_bwd_k<NTV, 1, QS>), dim3(blocks), dim3(cgv::DL_THREADS), lds, st, g_slices,       \
+                         g_n_slices, (long long)g_slice_stride, z, act, W, g_dense, slices_out, (long long)out_slice_stride, \
+                         n_nodes, N, K);                                                                                   \
+  })
   if (tiles <= 9) { CGV_DL_DENSE(1); } else if (tiles <= 18) { CGV_DL_DENSE(2); } else { CGV_DL_DENSE(3); }
 #undef CGV_DL_DENSE
   return cgv::check_launch("cgv_decoder_dense_bwd");
@@ -1004,24 +1179,27 @@ int cgv_decoder_dense_bwd(const float* g_slices, int g_n_slices, int64_t g_slice
 int cgv_decoder_uv_bwd(const float* gstack_slices, int n_slices, int64_t slice_stride, const float* UV, const float* stack,
                        const float* gs_res, const float* Wuv, float* gUV, float* g_s2, float* slices_out,
                        int64_t out_slice_stride, int n_nodes, int n_feat, void* stream) {
-  CGV_REQUIRE(gstack_slices && UV && stack && gs_res && Wuv && gUV && g_s2 && slices_out && n_slices >= 1, "null pointer");
+  CGV_REQUIRE(gstack_slices && UV && stack && gs_res && Wuv && gUV && g_s2 && slices_out && n_slices >= 1 && n_slices <= 216,
+              "null pointer / slice count");
   CGV_REQUIRE(out_slice_stride >= cgv_decoder_slice_floats(n_feat, 3 * n_nodes), "bad slices");
   const int n_rbf = 8;
   CGV_DL_CHECK();
   (void)blocks;
-  if (cgv_decoder_block_channels(n_feat) == 8) {
-    const size_t lds = cgv::lds_bytes(cgv::bi_stage_floats<3>() + 2 * 4608 + 2 * 128 + 2 * 384);
-    if (int rc = cgv::allow_lds(cgv::dec_uv_bwd_k<2>, lds)) return rc;
-    hipLaunchKernelGGL(cgv::dec_uv_bwd_k<2>, dim3(n_feat / 8), dim3(cgv::DL_THREADS), lds, st, gstack_slices, n_slices,
-                       (long long)slice_stride, UV, stack, gs_res, Wuv, gUV, g_s2, slices_out, (long long)out_slice_stride,
-                       n_nodes, n_feat);
-  } else {
-    const size_t lds = cgv::lds_bytes(cgv::bi_stage_floats<3>() + 4608 + 128 + 384);
-    if (int rc = cgv::allow_lds(cgv::dec_uv_bwd_k<1>, lds)) return rc;
-    hipLaunchKernelGGL(cgv::dec_uv_bwd_k<1>, dim3(n_feat / 4), dim3(cgv::DL_THREADS), lds, st, gstack_slices, n_slices,
-                       (long long)slice_stride, UV, stack, gs_res, Wuv, gUV, g_s2, slices_out, (long long)out_slice_stride,
-                       n_nodes, n_feat);
-  }
+  CGV_DL_QS(n_slices, {
+    if (cgv_decoder_block_channels(n_feat) == 8) {
+      const size_t lds = cgv::lds_bytes(cgv::bi_stage_floats<3>() + 2 * 4608 + 2 * 128 + 2 * 384);
+      if (int rc = cgv::allow_lds(cgv::dec_uv_bwd_k<2, QS>, lds)) return rc;
+      hipLaunchKernelGGL((cgv::dec_uv_bwd_k<2, QS>), dim3(n_feat / 8), dim3(cgv::DL_THREADS), lds, st, gstack_slices, n_slices,
+                         (long long)slice_stride, UV, stack, gs_res, Wuv, gUV, g_s2, slices_out, (long long)out_slice_stride,
+                         n_nodes, n_feat);
+    } else {
+      const size_t lds = cgv::lds_bytes(cgv::bi_stage_floats<3>() + 4608 + 128 + 384);
+      if (int rc = cgv::allow_lds(cgv::dec_uv_bwd_k<1, QS>, lds)) return rc;
+      hipLaunchKernelGGL((cgv::dec_uv_bwd_k<1, QS>), dim3(n_feat / 4), dim3(cgv::DL_THREADS), lds, st, gstack_slices, n_slices,
+                         (long long)slice_stride, UV, stack, gs_res, Wuv, gUV, g_s2, slices_out, (long long)out_slice_stride,
+                         n_nodes, n_feat);
+    }
+  });
   return cgv::check_launch("cgv_decoder_uv_bwd");
 }
 
@@ -1034,27 +1212,32 @@ int cgv_decoder_msg_bwd(const float* phi, const float* s, const float* sbar, con
                         int n_edges, void* stream) {
   CGV_REQUIRE(phi && s && sbar && v && vbar && geom_d && rowptr_d && src_d && geom_s && rowptr_s && dst_s && Wd && bd && W2,
               "null input");
-  CGV_REQUIRE(gvrows_slices && n_slices >= 1 && g_phi && g_s && g_sbar && g_v && g_vbar && gWd && gbd && slices_out, "null pointer");
+  CGV_REQUIRE(gvrows_slices && n_slices >= 1 && n_slices <= 216 && g_phi && g_s && g_sbar && g_v && g_vbar && gWd && gbd && slices_out,
+              "null pointer / slice count");
   CGV_REQUIRE(out_slice_stride >= cgv_decoder_slice_floats(n_feat, n_nodes), "bad slices");
-  CGV_REQUIRE(n_edges >= 0 && n_edges <= cgv::DL_MAX_EDGES, "too many edges for the staged bead graph");
+  CGV_REQUIRE(n_edges >= 1 && n_edges <= cgv::DL_MAX_EDGES, "the staged bead graph holds 1..cgv_decoder_max_edges() edges");
   CGV_DL_CHECK();
-  const size_t lds = cgv::lds_bytes(cgv::bi_stage_floats<1>() + 192 + 576 + 576 + 3072 + 4608 +
+  const size_t lds = cgv::lds_bytes(cgv::bi_stage_floats<1>() + 192 + 576 + 576 + 3456 + 4608 +
                                2 * (size_t)cgv::DL_MAX_EDGES * cgv::geom_stride(n_rbf) + 40 + 2 * cgv::DL_MAX_EDGES + 256 + 960);
   CGV_DISPATCH_RBF(n_rbf, {
-    if (int rc = cgv::allow_lds(cgv::dec_msg_bwd_k<RBF>, lds)) return rc;
-    hipLaunchKernelGGL((cgv::dec_msg_bwd_k<RBF>), dim3(blocks), dim3(cgv::DL_THREADS), lds, st, phi, s, sbar, v, vbar, geom_d,
-                       rowptr_d, src_d, geom_s, rowptr_s, dst_s, Wd, bd, gh, ghb, gvrows_slices, n_slices, (long long)slice_stride,
-                       gv_res, gvb, W2, g_phi, g_s, g_sbar, g_v, g_vbar, gWd, gbd, slices_out, (long long)out_slice_stride,
-                       n_nodes, n_feat, n_edges);
+    CGV_DL_QS(n_slices, {
+      if (int rc = cgv::allow_lds(cgv::dec_msg_bwd_k<RBF, QS>, lds)) return rc;
+      hipLaunchKernelGGL((cgv::dec_msg_bwd_k<RBF, QS>), dim3(blocks), dim3(cgv::DL_THREADS), lds, st, phi, s, sbar, v, vbar, geom_d,
+                         rowptr_d, src_d, geom_s, rowptr_s, dst_s, Wd, bd, gh, ghb, gvrows_slices, n_slices,
+                         (long long)slice_stride, gv_res, gvb, W2, g_phi, g_s, g_sbar, g_v, g_vbar, gWd, gbd, slices_out,
+                         (long long)out_slice_stride, n_nodes, n_feat, n_edges);
+    });
   });
   return cgv::check_launch("cgv_decoder_msg_bwd");
 }
 
 int cgv_decoder_slices_to_dense(const float* base, const float* slices, int n_slices, int64_t slice_stride, float* out,
                                 int n_nodes, int n_feat, void* stream) {
-  CGV_REQUIRE(slices && out && n_slices >= 1 && n_nodes >= 1 && n_nodes <= 16 && (n_feat % 4) == 0, "bad argument");
-  hipLaunchKernelGGL(cgv::dec_quad_to_dense_k, dim3(n_feat / 4), dim3(cgv::DL_THREADS), cgv::lds_bytes(2304 + 64),
-                     (hipStream_t)stream, base, slices, n_slices, (long long)slice_stride, out, n_nodes, n_feat);
+  CGV_REQUIRE(slices && out && n_slices >= 1 && n_slices <= 216 && n_nodes >= 1 && n_nodes <= 16 && (n_feat % 4) == 0, "bad argument");
+  CGV_DL_QS(n_slices, {
+    hipLaunchKernelGGL((cgv::dec_quad_to_dense_k<QS>), dim3(n_feat / 4), dim3(cgv::DL_THREADS), cgv::lds_bytes(2304 + 64),
+                       (hipStream_t)stream, base, slices, n_slices, (long long)slice_stride, out, n_nodes, n_feat);
+  });
   return cgv::check_launch("cgv_decoder_slices_to_dense");
 }
 

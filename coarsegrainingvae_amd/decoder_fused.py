@@ -61,7 +61,7 @@ def usable(decoder, S: torch.Tensor, plan, geom) -> bool:
     ok = lambda M, N, K: bool(lib.cgv_skinny_supported(M, N, K))
     if not (ok(n, F, F) and ok(n, F, 2 * F)):
         return False
-    if plan.n_dst != n or plan.n_src != n or plan.n_edges > lib.cgv_decoder_max_edges():
+    if plan.n_dst != n or plan.n_src != n or not 1 <= plan.n_edges <= lib.cgv_decoder_max_edges():
         return False
     for mb, ub in zip(decoder.message_blocks, decoder.update_blocks):
         im = mb.inv_message
