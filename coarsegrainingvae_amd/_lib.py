@@ -86,6 +86,7 @@ PROTOTYPES = {
     "cgv_update_gate_bwd_slices": (_i, [_p, _p, _p, _p, _p, _i, C.c_int64, _p, _p, _p, _p, _i, _i, _i, _p]),
     "cgv_decoder_layer_supported": (_i, [_i, _i, _i]),
     "cgv_decoder_slice_floats": (C.c_int64, [_i, _i]),
+    "cgv_batch_load_rows": (_i, [_p, _p, _p, _i, _p, _p, _p, _i, _p]),
     "cgv_decoder_max_edges": (_i, []),
     "cgv_decoder_block_channels": (_i, [_i]),
     "cgv_decoder_debug_clock": (_i, [_p]),
@@ -135,7 +136,7 @@ PROTOTYPES = {
 
 # include/cgvae_hip.h: CGV_OPT_* (A/B switches of the launchers; defaults in csrc/api.cpp)
 OPTIONS = {"msg_fwd_split": 0, "msg_bwd_split": 1, "msg_fwd_kernel": 2, "grp_waves": 3, "grp_records": 4, "csr_build": 5,
-           "pseudo_chunks": 6, "wgrad_tiling": 7, "tile_fwd_lds_min": 8, "bwd_input_waves": 9, "pseudo_fwd": 10, "decoder_fat": 11}
+           "pseudo_chunks": 6, "wgrad_tiling": 7, "tile_fwd_lds_min": 8, "bwd_input_waves": 9, "pseudo_fwd": 10, "decoder_fat": 11, "decoder_wlds": 12}
 
 
 def set_option(name: str, value: int) -> None:

@@ -52,32 +52,42 @@ __device__ __forceinline__ int pj_find_edge(const PlanJobs& J, int e) {
   return j;
 }
 
-// Wave-aggregated counter updates: the edge lists of a radius graph arrive (mostly) sorted by row, so the 64 lanes of a
-// wave hit a handful of counters -- 125 atomics per counter on the chignolin atom graph, 43 / 49 us for the two kernels.
-// Lanes that address the same counter elect a leader which issues ONE atomic for all of them.
-__device__ __forceinline__ unsigned long long pj_same_counter(int* addr, bool active, int& leader) {
-  const unsigned long long act = __ballot(active);
-  leader = __ffsll((long long)act) - 1;
-  const unsigned long long a = (unsigned long long)(uintptr_t)addr;
-  const unsigned lo = __shfl((unsigned)a, leader), hi = __shfl((unsigned)(a >> 32), leader);
-  return __ballot(active && (unsigned)a == lo && (unsigned)(a >> 32) == hi);
+// Run-aggregated counter updates.  The edge lists of a radius graph arrive (mostly) sorted by one end, so in the view
+// keyed by that end the 64 lanes of a wave address a handful of counters (125 edges per atom on the chignolin graph: 43 /
+// 49 us for the two kernels with one atomic per edge) -- and in the view keyed by the OTHER end 64 different ones.  Lanes
+// are grouped into RUNS of consecutive equal (job, key): a run's first lane issues one atomic for the whole run, and the
+// runs are found with one shuffle and one ballot, no loop (a leader-election loop ran once per distinct counter of the
+// wave: 64 rounds in the other-end view).  Equal keys in separate runs are simply two atomics.
+struct PjRun { int head_lane, len; bool head; };
+__device__ __forceinline__ PjRun pj_run(int tag /* >= 0 for an active lane, -1 otherwise */) {
+  const int lane = threadIdx.x & 63;
+  const int prev = __shfl_up(tag, 1);
+  const bool head = lane == 0 || tag != prev;
+  const unsigned long long heads = __ballot(head);
+  const unsigned long long below = heads & ((2ull << lane) - 1ull);        // lane 63: 2 << 63 wraps to 0, mask = all ones
+  const unsigned long long above = lane == 63 ? 0ull : heads & ~((2ull << lane) - 1ull);
+  PjRun r;
+  r.head = head;
+  r.head_lane = 63 - __clzll((long long)below);
+  const int end = above ? __ffsll((long long)above) - 1 : 64;
+  r.len = end - r.head_lane;
+  return r;
 }
 
 __global__ __launch_bounds__(256) void pj_count_k(PlanJobs J) {
   const int e = blockIdx.x * 256 + threadIdx.x;
-  bool active = e < J.total_edges;
+  const bool active = e < J.total_edges;
   int* addr = nullptr;
+  int tag = -1;
   if (active) {
-    const PlanJob& p = J.job[pj_find_edge(J, e)];
-    addr = p.count + pj_key(p, e - p.edge_begin);
+    const int j = pj_find_edge(J, e);
+    const PlanJob& p = J.job[j];
+    const int r = pj_key(p, e - p.edge_begin);
+    addr = p.count + r;
+    tag = (j << 27) | r;                                                   // PJ_MAX = 8 jobs, rows < 2^27
   }
-  const int lane = threadIdx.x & 63;
-  while (__ballot(active)) {
-    int leader;
-    const unsigned long long grp = pj_same_counter(addr, active, leader);
-    if (lane == leader) atomicAdd(addr, __popcll(grp));
-    if ((grp >> lane) & 1ull) active = false;
-  }
+  const PjRun run = pj_run(tag);
+  if (active && run.head) atomicAdd(addr, run.len);
 }
 
 __global__ __launch_bounds__(1024) void pj_scan_k(PlanJobs J) {        // block b: exclusive scan of job b's counts
@@ -113,31 +123,25 @@ __global__ __launch_bounds__(1024) void pj_scan_k(PlanJobs J) {        // block 
 
 __global__ __launch_bounds__(256) void pj_drop_k(PlanJobs J) {
   const int e = blockIdx.x * 256 + threadIdx.x;
-  bool active = e < J.total_edges;
+  const bool active = e < J.total_edges;
   int* addr = nullptr;
   int* tmp = nullptr;
-  int le = 0, row_begin = 0;
+  int le = 0, row_begin = 0, tag = -1;
   if (active) {
-    const PlanJob& p = J.job[pj_find_edge(J, e)];
+    const int j = pj_find_edge(J, e);
+    const PlanJob& p = J.job[j];
     le = e - p.edge_begin;
     const int r = pj_key(p, le);
     addr = p.count + r;
     tmp = p.tmp;
     row_begin = p.rowptr[r];
+    tag = (j << 27) | r;
   }
-  const int lane = threadIdx.x & 63;
-  while (__ballot(active)) {
-    int leader;
-    const unsigned long long grp = pj_same_counter(addr, active, leader);
-    int base = 0;
-    if (lane == leader) base = atomicSub(addr, __popcll(grp));       // the row's slots are handed out last to first
-    base = __shfl(base, leader);
-    if ((grp >> lane) & 1ull) {
-      const int rank = __popcll(grp & ((1ull << lane) - 1ull));
-      tmp[row_begin + base - 1 - rank] = le;                          // any order inside the row: the row sort fixes it
-      active = false;
-    }
-  }
+  const PjRun run = pj_run(tag);
+  int base = 0;
+  if (active && run.head) base = atomicSub(addr, run.len);              // the row's slots are handed out last to first
+  base = __shfl(base, run.head_lane);
+  if (active) tmp[row_begin + base - 1 - ((int)(threadIdx.x & 63) - run.head_lane)] = le;     // any order inside the row: the row sort fixes it
 }
 
 constexpr int PJ_LDS_KEYS = 2048;
@@ -244,9 +248,36 @@ __global__ __launch_bounds__(256) void gj_records_k(GeomJobs J) {
   for (int k4 = 0; k4 < GS / 4; ++k4) dst4[k4] = reinterpret_cast<const float4*>(g)[k4];       // own record: no barrier needed
 }
 
+// ------------------------------------------------------------------ loading a prepared batch into the captured buffers
+// [n][4] rows (type id, x, y, z) of the atoms and of the beads: copied into the step's batch tensors and, as contiguous
+// [n][3] coordinates, into the graph bundle -- one launch instead of four copies and two strided extractions.
+__global__ __launch_bounds__(256) void batch_rows_k(const float4* __restrict__ src_a, float4* __restrict__ dst_a,
+                                                    float* __restrict__ xyz_a, int n_a, const float4* __restrict__ src_b,
+                                                    float4* __restrict__ dst_b, float* __restrict__ xyz_b, int n_b) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  const float4* src = src_a; float4* dst = dst_a; float* xyz = xyz_a;
+  if (i >= n_a) { i -= n_a; src = src_b; dst = dst_b; xyz = xyz_b; if (i >= n_b) return; }
+  const float4 r = src[i];
+  dst[i] = r;
+  xyz[3 * (size_t)i + 0] = r.y; xyz[3 * (size_t)i + 1] = r.z; xyz[3 * (size_t)i + 2] = r.w;
+}
+
 }  // namespace cgv
 
 extern "C" {
+
+/* nxyz / CG_nxyz of a prepared batch -> the captured step's tensors + the bundle's coordinate arrays (data.py:
+ * copy_batch_into; reference: the DataLoader handing the next batch to cgvae.py:486). */
+int cgv_batch_load_rows(const float* src_atoms, float* dst_atoms, float* xyz_atoms, int n_atoms, const float* src_beads,
+                        float* dst_beads, float* xyz_beads, int n_beads, void* stream) {
+  CGV_REQUIRE(src_atoms && dst_atoms && xyz_atoms && src_beads && dst_beads && xyz_beads && n_atoms >= 0 && n_beads >= 0, "bad argument");
+  const int n = n_atoms + n_beads;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(cgv::batch_rows_k, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float4*>(src_atoms), reinterpret_cast<float4*>(dst_atoms), xyz_atoms, n_atoms,
+                     reinterpret_cast<const float4*>(src_beads), reinterpret_cast<float4*>(dst_beads), xyz_beads, n_beads);
+  return cgv::check_launch("cgv_batch_load_rows");
+}
 
 int cgv_plan_jobs_max(void) { return cgv::PJ_MAX; }
 int cgv_plan_job_bytes(void) { return (int)sizeof(cgv::PlanJob); }
@@ -263,7 +294,7 @@ int cgv_plan_jobs_build(const void* jobs_host, int n_jobs, void* stream) {
   int e = 0, r = 0;
   for (int j = 0; j < n_jobs; ++j) {
     cgv::PlanJob& p = J.job[j];
-    CGV_REQUIRE(p.E >= 0 && p.n_rows >= 0 && p.stride >= 1 && p.rowptr && p.count, "bad job");
+    CGV_REQUIRE(p.E >= 0 && p.n_rows >= 0 && p.n_rows < (1 << 27) && p.stride >= 1 && p.rowptr && p.count, "bad job");
     CGV_REQUIRE(p.E == 0 || (p.eid && p.key_sorted && p.other_sorted && p.tmp && p.spill), "null edge array");
     p.edge_begin = e; p.row_begin = r;
     e += p.E; r += p.n_rows;

@@ -112,6 +112,20 @@ __device__ __forceinline__ float4 ldg4_pinned(gcf p) {
   const f32x4 t = *reinterpret_cast<const CGV_GLOBAL_AS f32x4*>(p);
   return make_float4(t.x, t.y, t.z, t.w);
 }
+// streamed weights in whole 256-byte row pieces (the backward products).  Nontemporal loads pull 13 MB in 3.57 against
+// 4.15 us in an isolated dependent chain (tools/probes/stream_probe.hip) but the decoder backward got no faster with them
+// (468.9 against 460.6 us) -- off.  (Never for the forward products' 64-byte pieces: 7.98 against 6.22 us.)
+#ifndef CGV_DL_NT_WEIGHTS
+#define CGV_DL_NT_WEIGHTS 0
+#endif
+__device__ __forceinline__ float4 ldg4_stream(gcf p) {
+#if CGV_DL_NT_WEIGHTS
+  const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const CGV_GLOBAL_AS f32x4*>(p));
+#else
+  const f32x4 t = *reinterpret_cast<const CGV_GLOBAL_AS f32x4*>(p);
+#endif
+  return make_float4(t.x, t.y, t.z, t.w);
+}
 __device__ __forceinline__ float ldg_pinned(gcf p) { return *p; }
 __device__ __forceinline__ int ldgi_pinned(gci p) { return *p; }
 __device__ __forceinline__ f3 ld3_pinned(gcf p) { return f3{p[0], p[1], p[2]}; }
@@ -132,7 +146,7 @@ struct QuadRegs { float4 v[QS][NQ][MB]; };
 template <int MB, int NQ, int QS>
 __device__ __forceinline__ void quad_issue(QuadRegs<MB, NQ, QS>& r, gcf slices, int n_slices, long long stride,
                                            int rows, const int (&kq)[NQ]) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int m = lane & 15, cls = wave * 4 + (lane >> 4);                 // 36 slice classes
 #pragma unroll
   for (int u = 0; u < QS; ++u) {
@@ -150,7 +164,7 @@ template <int MB, int NQ, int QS>
 __device__ __forceinline__ void quad_finish(const QuadRegs<MB, NQ, QS>& r, float4* __restrict__ tile /*[NQ][16 MB]*/,
                                             float4* __restrict__ scratch /*NQ * 36 * 16 MB*/, int n_slices, int rows) {
   constexpr int MP = 16 * MB;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int m = lane & 15, cls = wave * 4 + (lane >> 4);
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
@@ -189,14 +203,14 @@ struct BiRegs { float4 w[NT][G]; };
 
 template <int G, int NT>
 __device__ __forceinline__ void bi_prefetch(BiRegs<G, NT>& r, gcf W, int K, const int (&row0)[G]) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 15, q = lane >> 4;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int col = (wave + DL_WAVES * t) * 64 + 4 * j;
     const int cc = col < K ? col : 0;                                     // clamped: always-valid address, result unused
 #pragma unroll
-    for (int g = 0; g < G; ++g) r.w[t][g] = ldg4_pinned(W + (size_t)(row0[g] + q) * K + cc);
+    for (int g = 0; g < G; ++g) r.w[t][g] = ldg4_stream(W + (size_t)(row0[g] + q) * K + cc);
   }
 }
 
@@ -208,7 +222,7 @@ __device__ __forceinline__ void bi_prefetch_slot(BiRegs<G, NT>& r, gcf W, int K,
   const int col = tile * 64 + 4 * j;
   const int cc = col < K ? col : 0;
 #pragma unroll
-  for (int g = 0; g < G; ++g) r.w[SLOT][g] = ldg4_pinned(W + (size_t)(row0[g] + q) * K + cc);
+  for (int g = 0; g < G; ++g) r.w[SLOT][g] = ldg4_stream(W + (size_t)(row0[g] + q) * K + cc);
 }
 
 template <int MB>
@@ -222,7 +236,7 @@ __device__ __forceinline__ void bi_core(const BiRegs<G, NPRE>& r, const float* _
                                         float* __restrict__ slice /*[K/4][rows][4]*/, int K, int rows,
                                         const float* __restrict__ W = nullptr, const int* row0 = nullptr) {
   constexpr int MP = 16 * MB;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 15, q = lane >> 4;
   float4* st = reinterpret_cast<float4*>(stage) + (size_t)wave * 16 * MP;
 #pragma unroll
@@ -279,12 +293,12 @@ __host__ __device__ constexpr size_t fwd_red_floats() { return (size_t)DL_WAVES 
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // SB = 16-float steps whose loads are issued together (a wave has ceil(ceil(K / 16) / 9) steps: 5 at K = 600, so SB >= 5
 // makes the product ONE round trip); after_issue() runs behind the first batch's loads, before they are consumed.
-template <int MB, int G, int SB = (((G + 3) / 4) * MB >= 3 ? 5 : 9), typename Hook = NoHook>
+template <int MB, int G, int SB = (((G + 3) / 4) * MB >= 3 ? 5 : 9), typename Hook = NoHook, int TK = -1>
 __device__ __forceinline__ void fwd_core(float* __restrict__ out, float* __restrict__ red, const float* __restrict__ x,
                                          int M, int K, const float* __restrict__ W, const int (&row0)[G],
                                          Hook after_issue = Hook()) {
   constexpr int T = (G + 3) / 4;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, q = lane >> 4;
   const int steps = (K + 15) / 16, per = (steps + DL_WAVES - 1) / DL_WAVES;
   const int s_beg = wave * per, s_end = min(s_beg + per, steps);
@@ -316,7 +330,7 @@ __device__ __forceinline__ void fwd_core(float* __restrict__ out, float* __restr
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) b[u][mb] = *reinterpret_cast<const float4*>(xrow[mb] + kc);
     }
-    if (first) { after_issue(); first = false; }
+    if (first) { after_issue(); first = false; if (TK >= 0) DL_TICK(TK); }
 #pragma unroll
     for (int u = 0; u < SB; ++u) {
       if (s0 + u < s_end) {
@@ -342,7 +356,9 @@ __device__ __forceinline__ void fwd_core(float* __restrict__ out, float* __restr
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) red[(((wave * T + t) * MB + mb) * 4 + r) * 64 + lane] = acc[t][mb][r];
+  if (TK >= 0) DL_TICK(TK + 1);
   __syncthreads();
+  if (TK >= 0) DL_TICK(TK + 2);
   for (int o = threadIdx.x; o < T * MB * 256; o += DL_THREADS) {
     const int l = o & 63, r = (o >> 6) & 3, rest = o >> 8;              // rest = t * MB + mb
     const int mb = rest % MB, t = rest / MB;
@@ -350,6 +366,87 @@ __device__ __forceinline__ void fwd_core(float* __restrict__ out, float* __restr
     float v = 0.f;
 #pragma unroll
     for (int w = 0; w < DL_WAVES; ++w) v += red[(((w * T + t) * MB + mb) * 4 + r) * 64 + l];
+    if (g < G) out[(m * G + g) * 4 + r] = v;
+  }
+  __syncthreads();
+  if (TK >= 0) DL_TICK(TK + 3);
+}
+
+// ---------------------------------------------------------------------------------------------- forward core, weights by LDS-DMA
+// The same product with the block's weight rows brought to LDS by global_load_lds_dwordx4: no registers, every request
+// a whole contiguous kilobyte of a 4-row group (wave w moves groups w, w + 9, ..), all of them in flight from the first
+// instruction of the kernel.  (The register path reads 16 rows x 64 bytes per instruction, the operand layout of the
+// MFMA: 6.2 us for the message product's 13 MB against 4.15 us in contiguous pieces, tools/probes/stream_probe.hip.)
+// w_l: [G][4][K] floats.
+template <int G>
+__device__ __forceinline__ void wlds_issue(float* __restrict__ w_l, const float* __restrict__ W, int K, const int (&row0)[G]) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    if ((g % DL_WAVES) != wave) continue;                                 // wave-uniform
+    const float* src = W + (size_t)row0[g] * K;
+    for (int u = 0; u * 64 < K; ++u) {                                    // K float4 = 4 rows of K floats
+      const int idx = u * 64 + lane;
+      if (idx < K)
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const CGV_GLOBAL_AS void*>(reinterpret_cast<unsigned long long>(src + 4 * (size_t)idx)),
+                                         (__attribute__((address_space(3))) void*)(w_l + (size_t)g * 4 * K + u * 256), 16, 0, 0);
+    }
+  }
+}
+
+// MB = 1; K <= 16 * 6 * 9 (one batch of steps per wave).  after_issue() runs behind the x requests, before the barrier
+// that publishes the DMA'd weights.
+template <int G, typename Hook>
+__device__ __forceinline__ void fwd_core_wlds(float* __restrict__ out, float* __restrict__ red, const float* __restrict__ x,
+                                              int M, int K, const float* __restrict__ w_l, Hook after_issue) {
+  constexpr int T = (G + 3) / 4, SB = 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, q = lane >> 4;
+  const int steps = (K + 15) / 16, per = (steps + DL_WAVES - 1) / DL_WAVES;
+  const int s_beg = wave * per, s_end = min(s_beg + per, steps);
+  const float* xrow = x + (size_t)min(i, M - 1) * K;
+  float4 b[SB];
+#pragma unroll
+  for (int u = 0; u < SB; ++u) {
+    const int k = (s_beg + u) * 16 + 4 * q;
+    b[u] = *reinterpret_cast<const float4*>(xrow + ((s_beg + u < s_end && k < K) ? k : 0));
+  }
+  after_issue();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  f32x4 acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int wrow[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) wrow[t] = (min(t * 4 + (i >> 2), G - 1) * 4 + (i & 3)) * K;      // surplus rows: clamped, unused
+#pragma unroll
+  for (int u = 0; u < SB; ++u) {
+    const int k = (s_beg + u) * 16 + 4 * q;
+    const bool kok = s_beg + u < s_end && k < K;
+    if (s_beg + u < s_end) {                                              // wave-uniform
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        float4 w = *reinterpret_cast<const float4*>(w_l + wrow[t] + (kok ? k : 0));
+        if (!kok) w = make_float4(0.f, 0.f, 0.f, 0.f);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, b[u].x, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, b[u].y, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, b[u].z, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, b[u].w, acc[t], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[((wave * T + t) * 4 + r) * 64 + lane] = acc[t][r];
+  __syncthreads();
+  for (int o = threadIdx.x; o < T * 256; o += DL_THREADS) {
+    const int l = o & 63, r = (o >> 6) & 3, t = o >> 8;
+    const int g = t * 4 + (l >> 4), m = l & 15;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < DL_WAVES; ++w) v += red[((w * T + t) * 4 + r) * 64 + l];
     if (g < G) out[(m * G + g) * 4 + r] = v;
   }
   __syncthreads();
@@ -415,7 +512,7 @@ __device__ __forceinline__ void stage_vector(float* __restrict__ dst, const floa
 __device__ __forceinline__ dv3 lds_v3(const float* p) { return dv3{p[0], p[1], p[2]}; }
 
 // ============================================================================================== F2: phi + message forward
-template <int R>
+template <int R, bool WLDS>
 __global__ __launch_bounds__(DL_THREADS) void dec_msg_fwd_k(
     const float* __restrict__ a1, const float* __restrict__ W2, const float* __restrict__ b2, const float* __restrict__ s_,
     const float* __restrict__ sbar_, const float* __restrict__ v_, const float* __restrict__ vbar_,
@@ -433,12 +530,17 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_fwd_k(
   int* src_l = reinterpret_cast<int*>(cv.take(DL_MAX_EDGES));
   float* s_l = cv.take(64); float* sb_l = cv.take(64);
   float* v_l = cv.take(192); float* vb_l = cv.take(192);
+  float* w_l = cv.take(WLDS ? (size_t)36 * F : 0);
   const int f0 = blockIdx.x * DL_CB;
   const int lane = threadIdx.x & 63;
   const int k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane >> 2, c = lane & 3;
   const bool live = i < n;
   const int f = f0 + c;
+  int row0[9];
+#pragma unroll
+  for (int g = 0; g < 9; ++g) row0[g] = g * F + f0;
+  if (WLDS) wlds_issue<9>(w_l, W2, F, row0);
   DL_TICK(8);
   DL_SPAN(1, 0);
   const gcf geom = launder(geom_); const gci rowptr = launder(rowptr_); const gci src = launder(src_);
@@ -455,17 +557,16 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_fwd_k(
 #pragma unroll
   for (int nn = 0; nn < R; ++nn) W[nn] = ldg_pinned(Wd + ((size_t)k * F + f) * R + nn);
   W[R] = ldg_pinned(bd + (size_t)k * F + f);
-  int row0[9];
-#pragma unroll
-  for (int g = 0; g < 9; ++g) row0[g] = g * F + f0;
   pin_loads();
   DL_TICK(9);
-  fwd_core<1, 9, 5>(phi_l, red, a1, n, F, W2, row0, [&]() {
+  auto commit = [&]() {
     copy4_commit(r_geom, geom_l, E * GS / 4);
     int_commit(r_rp, rp_l, n + 1); int_commit(r_src, src_l, E);
     scalar_commit(r_s, true, s_l, n); scalar_commit(r_sb, true, sb_l, n);
     vector_commit(r_v, true, v_l, n); vector_commit(r_vb, true, vb_l, n);
-  });
+  };
+  if (WLDS) fwd_core_wlds<9>(phi_l, red, a1, n, F, w_l, commit);
+  else fwd_core<1, 9, 5>(phi_l, red, a1, n, F, W2, row0, commit);
   DL_TICK(10);
   // bias, dense copy for the backward pass (phi[m][g F + f0 .. +3])
   for (int o = threadIdx.x; o < 16 * 9; o += DL_THREADS) {
@@ -545,12 +646,16 @@ __global__ __launch_bounds__(DL_THREADS) void dec_dense_fwd_k(const float* __res
   const float b = (mine && bias) ? ldg_pinned(bias + n0 + c) : 0.f;
   pin_loads();
   DL_SPAN(K > N ? 3 : 0, 0);
-  fwd_core<1, 1>(o_l, red, x, n, K, W, row0);
+  DL_TICK(14);
+  // one batch of requests per wave either way; the narrower batch issues no clamped surplus loads at K <= 720
+  if (K <= 16 * DL_WAVES * 5) fwd_core<1, 1, 5, NoHook, 15>(o_l, red, x, n, K, W, row0);
+  else fwd_core<1, 1, 9>(o_l, red, x, n, K, W, row0);
   if (mine) {
     const float zv = o_l[i * 4 + c] + b;
     const size_t at = (size_t)i * N + n0 + c;
     if (act) { if (zout) zout[at] = zv; y[at] = act_fwd(zv, act); } else y[at] = zv;
   }
+  DL_TICK(19);
   DL_SPAN(K > N ? 3 : 0, 1);
 }
 
@@ -604,7 +709,8 @@ __global__ __launch_bounds__(DL_THREADS) void dec_gate_fwd_k(const float* __rest
     bvv = ldg_pinned(b1p + f); bsv = ldg_pinned(b1p + F + f); bss = ldg_pinned(b1p + 2 * F + f);
   }
   pin_loads();
-  fwd_core<1, 3>(a_l, red, a0, n, F, W1p, row0);
+  if (F <= 16 * DL_WAVES * 5) fwd_core<1, 3, 5>(a_l, red, a0, n, F, W1p, row0);
+  else fwd_core<1, 3, 9>(a_l, red, a0, n, F, W1p, row0);
   if (mine) {
     const float a_vv = a_l[(i * 3 + 0) * 4 + c] + bvv, a_sv = a_l[(i * 3 + 1) * 4 + c] + bsv, a_ss = a_l[(i * 3 + 2) * 4 + c] + bss;
     float* ao = a_out + (size_t)i * 3 * F + f;
@@ -1087,12 +1193,21 @@ int cgv_decoder_msg_fwd(const float* a1, const float* W2, const float* b2, const
   CGV_REQUIRE(phi && stack && sbar_out && v_out && vbar_out && rows_out, "null output");
   CGV_REQUIRE(n_edges >= 1 && n_edges <= cgv::DL_MAX_EDGES, "the staged bead graph holds 1..cgv_decoder_max_edges() edges");
   CGV_DL_CHECK();
-  const size_t lds = cgv::lds_bytes(cgv::fwd_red_floats<1, 9>() + 576 + 1536 + (size_t)cgv::DL_MAX_EDGES * cgv::geom_stride(n_rbf) + 20 +
-                               cgv::DL_MAX_EDGES + 128 + 384);
+  const size_t base_floats = cgv::fwd_red_floats<1, 9>() + 576 + 1536 + (size_t)cgv::DL_MAX_EDGES * cgv::geom_stride(n_rbf) + 20 +
+                             cgv::DL_MAX_EDGES + 128 + 384;
+  /* the block's 36 weight rows by LDS-DMA when they fit beside the rest (F <= 672 at n_rbf = 10) */
+  const bool wlds = cgv::option(CGV_OPT_DECODER_WLDS) != 0 && cgv::lds_bytes(base_floats + (size_t)36 * n_feat) <= 160 * 1024;
+  const size_t lds = cgv::lds_bytes(base_floats + (wlds ? (size_t)36 * n_feat : 0));
   CGV_DISPATCH_RBF(n_rbf, {
-    if (int rc = cgv::allow_lds(cgv::dec_msg_fwd_k<RBF>, lds)) return rc;
-    hipLaunchKernelGGL((cgv::dec_msg_fwd_k<RBF>), dim3(blocks), dim3(cgv::DL_THREADS), lds, st, a1, W2, b2, s, sbar, v, vbar, geom_d,
-                       rowptr_d, src_d, Wd, bd, phi, stack, sbar_out, v_out, vbar_out, rows_out, n_nodes, n_feat, n_edges);
+    if (wlds) {
+      if (int rc = cgv::allow_lds(cgv::dec_msg_fwd_k<RBF, true>, lds)) return rc;
+      hipLaunchKernelGGL((cgv::dec_msg_fwd_k<RBF, true>), dim3(blocks), dim3(cgv::DL_THREADS), lds, st, a1, W2, b2, s, sbar, v, vbar,
+                         geom_d, rowptr_d, src_d, Wd, bd, phi, stack, sbar_out, v_out, vbar_out, rows_out, n_nodes, n_feat, n_edges);
+    } else {
+      if (int rc = cgv::allow_lds(cgv::dec_msg_fwd_k<RBF, false>, lds)) return rc;
+      hipLaunchKernelGGL((cgv::dec_msg_fwd_k<RBF, false>), dim3(blocks), dim3(cgv::DL_THREADS), lds, st, a1, W2, b2, s, sbar, v, vbar,
+                         geom_d, rowptr_d, src_d, Wd, bd, phi, stack, sbar_out, v_out, vbar_out, rows_out, n_nodes, n_feat, n_edges);
+    }
   });
   return cgv::check_launch("cgv_decoder_msg_fwd");
 }

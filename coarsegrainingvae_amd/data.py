@@ -129,14 +129,24 @@ def _copy_prepared_into(dst, src, g, sg) -> bool:
         ok = ok and src["nxyz"].device == dst["nxyz"].device
         ok = ok and bool(torch.equal(src["bond_edge_list"], dst["bond_edge_list"]))
         ok = ok and bool(torch.equal(sg.mapping, g.mapping))
+        ok = ok and bool(torch.equal(src["num_atoms"], dst["num_atoms"])) and bool(torch.equal(src["num_CGs"], dst["num_CGs"]))
         accepted[id(src)] = hit = (src, ok)                  # holds ``src``: its id cannot be recycled
     if not hit[1]:
         return False
     if sg.atom_nbrs.shape[0] > g.atom.capacity or sg.cg_nbrs.shape[0] > g.cg.capacity:
         return False
-    for k in _MOVING_KEYS:
-        dst[k].copy_(src[k], non_blocking=True)
-    g.update(dst["nxyz"][:, 1:], dst["CG_nxyz"][:, 1:], sg.atom_nbrs, sg.cg_nbrs, directed=True)
+    rows = (src["nxyz"], dst["nxyz"], src["CG_nxyz"], dst["CG_nxyz"])
+    if all(t.dtype == torch.float32 and t.is_contiguous() and t.dim() == 2 and t.shape[1] == 4 for t in rows) \
+            and g.xyz.is_contiguous() and g.cg_xyz.is_contiguous():
+        # rows + contiguous coordinates of atoms and beads in ONE launch (num_atoms / num_CGs were compared above)
+        from . import _lib
+        _lib.call("cgv_batch_load_rows", _lib.ptr(rows[0]), _lib.ptr(rows[1]), _lib.ptr(g.xyz), int(rows[0].shape[0]),
+                  _lib.ptr(rows[2]), _lib.ptr(rows[3]), _lib.ptr(g.cg_xyz), int(rows[2].shape[0]), _lib.stream_ptr())
+        g.update(g.xyz, g.cg_xyz, sg.atom_nbrs, sg.cg_nbrs, directed=True)
+    else:
+        for k in _MOVING_KEYS:
+            dst[k].copy_(src[k], non_blocking=True)
+        g.update(dst["nxyz"][:, 1:], dst["CG_nxyz"][:, 1:], sg.atom_nbrs, sg.cg_nbrs, directed=True)
     dst["nbr_list"], dst["CG_nbr_list"] = src["nbr_list"], src["CG_nbr_list"]
     return True
 

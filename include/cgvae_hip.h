@@ -75,7 +75,8 @@ enum {
   CGV_OPT_BWD_INPUT_WAVES = 9, /* cgv_tile_linear_bwd_input*: waves per block, 0 = built-in rule */
   CGV_OPT_PSEUDO_FWD = 10,     /* cgv_pseudo_msg_fwd*: 0 built-in rule; 1..6 = (edges in flight, records staged in LDS) variants */
   CGV_OPT_DECODER_FAT = 11,    /* cgv_decoder_{gate,dense,uv}_bwd: 1 (default) 8-channel blocks where the width allows, 0 always 4 */
-  CGV_OPT_COUNT = 12
+  CGV_OPT_DECODER_WLDS = 12,   /* cgv_decoder_msg_fwd: 1 (default) weight rows by LDS-DMA when they fit in LDS, 0 register path */
+  CGV_OPT_COUNT = 13
 };
 /* Measurement: store the GPU wall clock (cgv_timestamp_hz ticks per second) into *slot, in stream order; capturable. */
 int cgv_timestamp(uint64_t* slot /*device*/, void* stream);
@@ -242,6 +243,11 @@ int cgv_equi_msg_bwd(const float* phi, const float* v, const float* geom_s, cons
  * cgv_plan_job_bytes / cgv_geom_job_bytes), device pointers inside, copied into the kernel arguments by value.
  * PlanJob.count must be ZERO on entry ([n_rows + 1] ints) and is zero again on exit.
  * ------------------------------------------------------------------------------------- */
+/* Rows [n][4] = (type id, x, y, z) of a prepared batch's atoms and beads into the captured step's tensors and, as
+ * contiguous [n][3] coordinates, into the graph bundle: one launch (replaces the reference DataLoader's hand-over of the
+ * next batch, cgvae.py:486 / scripts/utils.py:131). */
+int cgv_batch_load_rows(const float* src_atoms, float* dst_atoms, float* xyz_atoms, int n_atoms, const float* src_beads,
+                        float* dst_beads, float* xyz_beads, int n_beads, void* stream);
 int cgv_plan_jobs_max(void);
 int cgv_plan_job_bytes(void);
 int cgv_plan_jobs_build(const void* jobs_host, int n_jobs, void* stream);

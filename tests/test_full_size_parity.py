@@ -240,6 +240,7 @@ def test_fused_decoder_loop_equals_per_block_path(workload, frames, F, dec, fat,
     non-message backward phases (the default; every width the arena lays out adjacent u_mat / v_mat for is a multiple
     of 8) or 4-channel blocks everywhere."""
     options.set("decoder_fat", fat)
+    options.set("decoder_wlds", fat)                               # the register-path message product rides with fat = 0
     w = cg.data.WORKLOADS[workload]
     batch = cg.synthetic_batch(workload, n_frames=frames, seed=2, device=DEV)
     eps = [torch.randn(batch["CG_nxyz"].shape[0], F, generator=torch.Generator().manual_seed(k)).to(DEV) for k in range(3)]

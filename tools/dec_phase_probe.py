@@ -16,7 +16,7 @@ buf = torch.zeros(72, dtype=torch.int64, device="cuda")
 _lib.call("cgv_decoder_debug_clock", buf.data_ptr())
 hz = _lib.load().cgv_timestamp_hz()
 tr.capture(batch, warmup=0)
-acc, accf, spans = [], [], []
+acc, accf, accd, spans = [], [], [], []
 for _ in range(20):
     tr.step(batch)
     torch.cuda.synchronize()
@@ -24,6 +24,7 @@ for _ in range(20):
     acc.append([(t[i] - t[i - 1]) / hz * 1e6 for i in range(1, 8)])
     accf.append([(t[i] - t[i - 1]) / hz * 1e6 for i in range(9, 14)])
     spans.append(t[32:72])
+    accd.append([(t[i] - t[i - 1]) / hz * 1e6 for i in range(15, 20)])
 _lib.call("cgv_decoder_debug_clock", None)
 names = ["prefetch+staging issue", "quad_sum", "tail of staging -> state in regs", "pass B (source side)", "shuffles + pass A", "sync", "g_phi dense + final sums", ]
 import statistics
@@ -32,6 +33,9 @@ for i, nm in enumerate(["stage loads -> LDS", "slice sum (quad_sum<3>) + gv", "p
 print("-- cgv_decoder_msg_fwd, block 0")
 for i, nm in enumerate(["stage loads -> LDS + filter row", "product (fwd_core)", "bias + dense phi + barrier", "edge loop", "wave sums + stores"]):
     print(f"{statistics.median(a[i] for a in accf):8.2f} us  {nm}")
+print("-- cgv_decoder_dense_fwd (F1), block 0")
+for i, nm in enumerate(["address math + requests issued", "requests landed + MFMAs + partials to LDS", "barrier", "cross-wave sum + barrier", "bias + act + store"]):
+    print(f"{statistics.median(a[i] for a in accd):8.2f} us  {nm}")
 
 # timeline of one layer (forward: the last layer's launches; backward: the first layer's = the last executed)
 KERN = ["F1 dense a1", "F2 message", "F3 uv+norm", "F4 dense a0", "F5 gate", "B1 gate", "B2 dense W0", "B3 uv+norm", "B4 message", "B5 dense W1"]

@@ -42,6 +42,30 @@ __global__ __launch_bounds__(576) void pull_k(const float* __restrict__ W, float
       size_t off = (size_t)(g * 4 + q) * K + (size_t)((tile * 64 < K ? tile : 0) * 64) + 4 * j;
       r[u] = ld(base + off);
     }
+  } else if (PATTERN == 3) {
+    // 8 rows x 128 B per instruction: lane (i, q): row (i & 7) (+8 for odd instructions), k-quad q + 4 (i >> 3) of a 32-float step
+    const int i = lane & 15, q = lane >> 4;
+    const int tiles = rows_per_block / 16 > 0 ? rows_per_block / 16 : 1;
+    const int steps32 = K / 32, per = (steps32 + 8) / 9;
+#pragma unroll
+    for (int u = 0; u < NLOAD; ++u) {
+      const int half = u & 1, v = u >> 1;
+      const int t = v % tiles, s = wave * per + v / tiles;
+      size_t off = (size_t)((t * 16 + half * 8 + (i & 7)) % rows_per_block) * K + (size_t)(s < steps32 ? s : 0) * 32 + 4 * (q + 4 * (i >> 3));
+      r[u] = ld(base + off);
+    }
+  } else if (PATTERN == 4) {
+    // 4 rows x 256 B per instruction (64-float steps)
+    const int i = lane & 15, q = lane >> 4;
+    const int tiles = rows_per_block / 16 > 0 ? rows_per_block / 16 : 1;
+    const int steps64 = K / 64, per = (steps64 + 8) / 9;
+#pragma unroll
+    for (int u = 0; u < NLOAD; ++u) {
+      const int part = u & 3, v = u >> 2;
+      const int t = v % tiles, s = wave * per + v / tiles;
+      size_t off = (size_t)((t * 16 + part * 4 + (i & 3)) % rows_per_block) * K + (size_t)(s < steps64 ? s : 0) * 64 + 4 * (q + 4 * (i >> 2));
+      r[u] = ld(base + off);
+    }
   } else {
 #pragma unroll
     for (int u = 0; u < NLOAD; ++u) {
@@ -55,6 +79,33 @@ __global__ __launch_bounds__(576) void pull_k(const float* __restrict__ W, float
   for (int u = 0; u < NLOAD; ++u) acc += r[u].x + r[u].y + r[u].z + r[u].w;
   if (acc == 123.456f) out[blockIdx.x * 576 + threadIdx.x] = acc;
 }
+
+// the same flat pull as 32 distinct kernels (different code addresses, ~equal code): a chain that cycles through them
+// runs every launch with a cold instruction cache, like the training step does
+template <int ID>
+__global__ __launch_bounds__(576) void pull_id_k(const float* __restrict__ W, float* __restrict__ out, int rows_per_block, int K) {
+  const float* base = W + (size_t)blockIdx.x * rows_per_block * K;
+  const size_t block_floats = (size_t)rows_per_block * K;
+  float4 r[10];
+#pragma unroll
+  for (int u = 0; u < 10; ++u) {
+    size_t off = ((size_t)u * 576 + threadIdx.x) * 4;
+    if (off >= block_floats) off = 0;
+    r[u] = *reinterpret_cast<const float4*>(base + off);
+  }
+  float acc = (float)ID;
+#pragma unroll
+  for (int u = 0; u < 10; ++u) acc += r[u].x * (ID + 1) + r[u].y + r[u].z + r[u].w;
+  // ballast: ID-dependent arithmetic so that the variants are not merged and have a few KB of code
+#pragma unroll
+  for (int u = 0; u < 200; ++u) acc = acc * (1.0f + 1e-7f * (ID + u)) + (float)(u ^ ID);
+  if (acc == 123.456f) out[blockIdx.x * 576 + threadIdx.x] = acc;
+}
+typedef void (*pull_fn)(const float*, float*, int, int);
+template <int... IDS> struct IdList {};
+template <int N, int... IDS> struct MakeIds : MakeIds<N - 1, N - 1, IDS...> {};
+template <int... IDS> struct MakeIds<0, IDS...> { typedef IdList<IDS...> type; };
+template <int... IDS> static std::vector<pull_fn> all_ids(IdList<IDS...>) { return {pull_id_k<IDS>...}; }
 
 __global__ void tiny_k(float* out) { if (threadIdx.x == 1234567) out[0] = 1.f; }
 
@@ -104,8 +155,23 @@ int main() {
   RUN(15, 0, false, 150, 36, "msg-like  150 blk x 36 rows, fwd_core pattern, 15 ld/lane");
   RUN(15, 0, true, 150, 36, "msg-like  150 blk x 36 rows, fwd_core pattern, nt");
   RUN(9, 1, false, 150, 36, "msg-like  150 blk x 36 rows, bi_core pattern (first tile only)");
+  RUN(15, 3, false, 150, 36, "msg-like  150 blk x 36 rows, 8 rows x 128 B per instr");
+  RUN(15, 4, false, 150, 36, "msg-like  150 blk x 36 rows, 4 rows x 256 B per instr");
+  RUN(15, 0, false, 150, 36, "msg-like  150 blk x 36 rows, fwd_core pattern (again)");
   RUN(10, 2, false, 150, 36, "msg-like  150 blk x 86 KB flat");
   RUN(10, 2, true, 150, 36, "msg-like  150 blk x 86 KB flat, nt");
+  {
+    std::vector<pull_fn> fns = all_ids(MakeIds<48>::type());
+    const size_t fl = (size_t)150 * 36 * K;
+    for (int nv : {1, 2, 8, 48}) {
+      float t = chain_us([&](int c) { hipLaunchKernelGGL(fns[c % nv], dim3(150), dim3(576), 0, st, buf(fl), out, 36, K); }, 96, 5, st);
+      printf("flat pull + ballast, chain cycling through %2d distinct kernels       %7.2f us per launch\n", nv, t);
+    }
+    for (int nv : {1, 48}) {
+      float t = chain_us([&](int c) { hipLaunchKernelGGL(fns[c % nv], dim3(150), dim3(576), 0, st, buf(4 * 150 * K), out, 4, K); }, 96, 5, st);
+      printf("dense-size pull + ballast, chain cycling through %2d distinct kernels %7.2f us per launch\n", nv, t);
+    }
+  }
   RUN(6, 2, false, 256, 21, "same bytes over 256 blk flat (21 rows)");
   RUN(6, 2, true, 256, 21, "same bytes over 256 blk flat (21 rows), nt");
   RUN(3, 2, false, 512, 10, "same bytes over 512 blk flat (10 rows)");
