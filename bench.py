@@ -184,8 +184,8 @@ def optimizer_roofline(trainer, reps=5):
 
     def run():
         if rank:
-            table, nprob, blocks, lds, _items = rank
-            _lib.call("cgv_wgrad_gram", _lib.ptr(table), nprob, _lib.ptr(trainer._rank_sumsq), _lib.ptr(trainer._rank_ws),
+            table, nprob, blocks, lds, _items, max_rows = rank
+            _lib.call("cgv_wgrad_gram", _lib.ptr(table), nprob, max_rows, _lib.ptr(trainer._rank_sumsq), _lib.ptr(trainer._rank_ws),
                       trainer._rank_ws.numel(), _lib.stream_ptr())
         _lib.call("cgv_optim_prepare_extra", a.g.data_ptr() + 4 * lo, n - lo, _lib.ptr(trainer._rank_sumsq) if rank else None,
                   rank[1] if rank else 0, 0.9, 0.999, 0.01, 1.0, _lib.ptr(loss), 1e30, _lib.ptr(state),
@@ -193,7 +193,7 @@ def optimizer_roofline(trainer, reps=5):
         _lib.call("cgv_adam_apply", sp.data_ptr() + 4 * lo, a.g.data_ptr() + 4 * lo, sm.data_ptr() + 4 * lo,
                   sv.data_ptr() + 4 * lo, n - lo, 1e-4, 0.9, 0.999, 1e-8, _lib.ptr(state), _lib.stream_ptr())
         if rank:
-            table, nprob, blocks, lds, _items = rank
+            table, nprob, blocks, lds, _items, _rows = rank
             _lib.call("cgv_grouped_wgrad_adam", _lib.ptr(table), nprob, blocks, lds, _lib.ptr(a.g), _lib.ptr(sp), _lib.ptr(sm),
                       _lib.ptr(sv), 1e-4, 0.9, 0.999, 1e-8, _lib.ptr(state), _lib.stream_ptr())
     run()

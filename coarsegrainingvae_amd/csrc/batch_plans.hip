@@ -168,7 +168,18 @@ __global__ __launch_bounds__(128) void pj_row_sort_k(PlanJobs J) {   // block: o
     int rank[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int q = 0; q < 4; ++q) mine[q] = k[min(t0 + q * (int)blockDim.x, L - 1)];
-    for (int u = 0; u < L; ++u) {
+    // (eight keys per trip: one key per trip waits a full LDS round trip for each of them)
+    int u = 0;
+    for (; u + 8 <= L; u += 8) {
+      unsigned long long other[8];
+#pragma unroll
+      for (int w = 0; w < 8; ++w) other[w] = k[u + w];
+#pragma unroll
+      for (int w = 0; w < 8; ++w)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rank[q] += other[w] < mine[q];
+    }
+    for (; u < L; ++u) {
       const unsigned long long other = k[u];
 #pragma unroll
       for (int q = 0; q < 4; ++q) rank[q] += other < mine[q];

@@ -216,34 +216,61 @@ __global__ void grp_meta(const int* __restrict__ dst_g, const int* __restrict__ 
 // block ranks them by (source, receiver, position) -- keys are unique, rank = number of smaller keys -- and writes
 // dst_g / src_g / pos_g / meta_g of its range.  Keys sit in LDS up to GRP_LDS_KEYS edges per group (850 on the
 // 2000-atom graph at rb = 2), beyond that they are re-read from global memory.
-constexpr int GRP_LDS_KEYS = 4096;
+constexpr int GRP_LDS_KEYS = 3072;
+
+// slot / head / mask / next source of position q of a group's sorted (source * rb + slot) sequence hi[0..L), as in grp_meta
+template <typename HiAt>
+__device__ __forceinline__ int2 grp_meta_of(HiAt hi_at, int q, int L, int rb) {
+  auto src_of = [&](int t) { return (int)(hi_at(t) / (unsigned)rb); };
+  auto slot_of = [&](int t) { const unsigned h = hi_at(t); return (int)(h - (h / (unsigned)rb) * (unsigned)rb); };
+  auto joins = [&](int t) { return t > 0 && src_of(t - 1) == src_of(t) && slot_of(t - 1) < slot_of(t); };
+  const int s = src_of(q), sl = slot_of(q);
+  int mask = 1 << sl;
+  for (int t = q; joins(t); --t) mask |= 1 << slot_of(t - 1);
+  int t = q + 1;
+  for (; t < L && joins(t); ++t) mask |= 1 << slot_of(t);
+  const int next = t < L ? src_of(t) : s;
+  return make_int2(sl | (joins(q) ? 0 : 0x100) | (mask << 16), next);
+}
 
 __global__ __launch_bounds__(256) void grp_build_k(const int* __restrict__ rowptr_d, const int* __restrict__ dst_d,
                                                    const int* __restrict__ src_d, int n_dst, int rb,
                                                    int* dst_g, int* src_g, int* pos_g, int2* __restrict__ meta,
                                                    unsigned long long* spill) {
-  // (dst_g / src_g are written and read back by other threads of the block between barriers: not __restrict__)
+  // (dst_g / src_g are written and read back by other threads of the block between barriers on the spill path: not __restrict__)
   __shared__ unsigned long long keys[GRP_LDS_KEYS];
+  __shared__ unsigned long long sorted[GRP_LDS_KEYS];
   const int g = blockIdx.x, node0 = g * rb;
   const int beg = rowptr_d[node0], end = rowptr_d[min(node0 + rb, n_dst)];
   const int L = end - beg;
   if (L <= 0) return;
-  unsigned long long* k = L <= GRP_LDS_KEYS ? keys : spill + beg;          // spill: E keys, each group its own range
+  const bool in_lds = L <= GRP_LDS_KEYS;
+  unsigned long long* k = in_lds ? keys : spill + beg;                     // spill: E keys, each group its own range
   for (int t = threadIdx.x; t < L; t += blockDim.x) {
     const int p = beg + t;
     const unsigned hi = (unsigned)src_d[p] * (unsigned)rb + (unsigned)(dst_d[p] - node0);
     k[t] = ((unsigned long long)hi << 32) | (unsigned)p;
   }
   __syncthreads();
-  // sorted position of every element, then the sorted keys replace the unsorted ones
-  // four keys per thread are ranked against every key read (850 keys per group on the 2000-atom graph: 666 us per batch
-  // with one key per pass)
+  // sorted position of every element: four keys per thread are ranked against every key read (850 keys per group on
+  // the 2000-atom graph: 666 us per batch with one key per pass)
   for (int t0 = threadIdx.x; t0 < L; t0 += 4 * blockDim.x) {
     unsigned long long mine[4];
     int rank[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int q = 0; q < 4; ++q) mine[q] = k[min(t0 + q * (int)blockDim.x, L - 1)];
-    for (int u = 0; u < L; ++u) {
+    // (eight keys per trip: one key per trip waits a full LDS round trip for each of them)
+    int u = 0;
+    for (; u + 8 <= L; u += 8) {
+      unsigned long long other[8];
+#pragma unroll
+      for (int w = 0; w < 8; ++w) other[w] = k[u + w];
+#pragma unroll
+      for (int w = 0; w < 8; ++w)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rank[q] += other[w] < mine[q];
+    }
+    for (; u < L; ++u) {
       const unsigned long long other = k[u];
 #pragma unroll
       for (int q = 0; q < 4; ++q) rank[q] += other < mine[q];
@@ -251,28 +278,36 @@ __global__ __launch_bounds__(256) void grp_build_k(const int* __restrict__ rowpt
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       if (t0 + q * (int)blockDim.x < L) {
-        pos_g[beg + rank[q]] = (int)(unsigned)(mine[q] & 0xffffffffull);  // scratch: the key's low word, in sorted order
-        dst_g[beg + rank[q]] = (int)(mine[q] >> 32);                      // scratch: the key's high word
+        if (in_lds) {
+          sorted[rank[q]] = mine[q];
+        } else {
+          pos_g[beg + rank[q]] = (int)(unsigned)(mine[q] & 0xffffffffull);  // scratch: the key's low word, in sorted order
+          dst_g[beg + rank[q]] = (int)(mine[q] >> 32);                      // scratch: the key's high word
+        }
       }
+  }
+  if (in_lds) {
+    // the sorted keys stay in LDS: every output of a position is written once, no round trip through global memory
+    __syncthreads();
+    for (int q = threadIdx.x; q < L; q += blockDim.x) {
+      const unsigned long long key = sorted[q];
+      const unsigned hi = (unsigned)(key >> 32);
+      const int s = (int)(hi / (unsigned)rb);
+      pos_g[beg + q] = (int)(unsigned)(key & 0xffffffffull);
+      src_g[beg + q] = s;
+      dst_g[beg + q] = node0 + (int)(hi - (unsigned)s * (unsigned)rb);
+      meta[beg + q] = grp_meta_of([&](int t) { return (unsigned)(sorted[t] >> 32); }, q, L, rb);
+    }
+    return;
   }
   __threadfence_block();
   __syncthreads();
   for (int q = beg + threadIdx.x; q < end; q += blockDim.x) src_g[q] = (int)((unsigned)dst_g[q] / (unsigned)rb);
   __threadfence_block();
   __syncthreads();
-  // slot / head / mask / next source from the sorted (source, slot) sequence, as in grp_meta
-  for (int q = beg + threadIdx.x; q < end; q += blockDim.x) {
-    const int s = src_g[q];
-    auto slot_of = [&](int t) { return (int)((unsigned)dst_g[t] - (unsigned)src_g[t] * (unsigned)rb); };
-    auto joins = [&](int t) { return t > beg && src_g[t - 1] == src_g[t] && slot_of(t - 1) < slot_of(t); };
-    const int sl = slot_of(q);
-    int mask = 1 << sl;
-    for (int t = q; joins(t); --t) mask |= 1 << slot_of(t - 1);
-    int t = q + 1;
-    for (; t < end && joins(t); ++t) mask |= 1 << slot_of(t);
-    const int next = t < end ? src_g[t] : s;
-    meta[q] = make_int2(sl | (joins(q) ? 0 : 0x100) | (mask << 16), next);
-  }
+  // slot / head / mask / next source from the sorted (source, slot) sequence
+  for (int q = beg + threadIdx.x; q < end; q += blockDim.x)
+    meta[q] = grp_meta_of([&](int t) { return (unsigned)dst_g[beg + t]; }, q - beg, L, rb);
   __syncthreads();                                                         // every reader of the key words is done
   for (int q = beg + threadIdx.x; q < end; q += blockDim.x) {
     const int sl = (int)((unsigned)dst_g[q] - (unsigned)src_g[q] * (unsigned)rb);

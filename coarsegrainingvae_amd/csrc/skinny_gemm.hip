@@ -372,6 +372,13 @@ struct WgradProblem {       // mirrors the 88-byte host record built in python (
   int pad;
 };
 static_assert(sizeof(WgradProblem) == 88, "host/device record layout");
+// float offset of operand row m (rows of `width` floats): one plain [M, width] block, or -- gathered operands -- rank
+// segment m / seg_rows of the all-gathered buffer
+__device__ __forceinline__ size_t wg_row(const WgradProblem& pr, int m, int width) {
+  if (pr.seg_rows <= 0) return (size_t)m * width;
+  const int seg = m / pr.seg_rows;
+  return (size_t)seg * pr.seg_stride + (size_t)(m - seg * pr.seg_rows) * width;
+}
 
 // Rank update (ADAM = true): the tile of gW is never stored -- it goes, clipped, straight into the Adam update of the
 // weights it belongs to.  A bead-level layer sees M = 12 rows against 0.36 - 3.2 M weights: its gradient g^T x has rank
@@ -415,7 +422,7 @@ __global__ __launch_bounds__(256) void grouped_wgrad_t(const WgradProblem* __res
     for (int u = 0; u < 4; ++u) {
       const int idx = base + u * 256 + t;
       const int m = idx / t4, c = idx - m * t4;
-      val[u] = ldg4_or_zero(pr.x + (size_t)(idx < M * t4 ? m : 0) * K + kbase + 4 * c, idx < M * t4 && kbase + 4 * c < K);
+      val[u] = ldg4_or_zero(pr.x + wg_row(pr, idx < M * t4 ? m : 0, K) + kbase + 4 * c, idx < M * t4 && kbase + 4 * c < K);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -431,7 +438,7 @@ __global__ __launch_bounds__(256) void grouped_wgrad_t(const WgradProblem* __res
     for (int u = 0; u < 4; ++u) {
       const int idx = min(base + 256 * u + t, M * WG_BLOCK_ROWS - 1);
       const int m = idx / WG_BLOCK_ROWS, r = idx - m * WG_BLOCK_ROWS;
-      const size_t at = (size_t)m * N + min(n0 + r, N - 1);
+      const size_t at = wg_row(pr, m, N) + min(n0 + r, N - 1);
       gv[u] = pr.gy[at];
       zv[u] = pr.act ? pr.z[at] : 0.f;                           // block-uniform
     }
@@ -546,38 +553,44 @@ constexpr int GRAM_WAVES = 8;
 constexpr int GRAM_THREADS = 64 * GRAM_WAVES;
 constexpr int GRAM_F4_PER_THREAD = 6;                                // staged float4 per thread and slice (<= 3072)
 constexpr int GRAM_TILE_F4 = 3200;                                   // rows are padded by one float4 (bank spread)
-constexpr int GRAM_MAX_ROWS = 40;     // beyond, re-forming the tiles and walking M^2 / 2 row pairs stops paying (cgv_rank_update_supported)
-constexpr int GRAM_MAX_PAIRS = GRAM_MAX_ROWS * (GRAM_MAX_ROWS + 1) / 2;                         // 820
+// Rows: a single GPU's bead-level layers have 12 (<= 40: the LDS request stays below 64 KB, two blocks per CU); the
+// gathered operands of the data-parallel exchange have world x 12 -- up to 64 (cgv_rank_update_supported), beyond
+// which walking M^2 / 2 row pairs and re-forming the tiles stops paying against materialising the gradient.
+constexpr int GRAM_MAX_ROWS = 64;
+constexpr int GRAM_MAX_PAIRS = GRAM_MAX_ROWS * (GRAM_MAX_ROWS + 1) / 2;                         // 2080
 constexpr size_t GRAM_WS_DOUBLES = (size_t)GRAM_SLICES * 2 * GRAM_MAX_PAIRS;                    // per problem
-constexpr size_t GRAM_LDS_BYTES = sizeof(float4) * GRAM_TILE_F4 + sizeof(double) * 2 * GRAM_MAX_PAIRS;   // 64320
+static size_t gram_lds_bytes(int max_rows) { return sizeof(float4) * GRAM_TILE_F4 + sizeof(double) * (size_t)max_rows * (max_rows + 1); }
 
-__global__ __launch_bounds__(GRAM_THREADS) void wgrad_gram_k(const WgradProblem* __restrict__ table, double* __restrict__ ws) {
+__global__ __launch_bounds__(GRAM_THREADS) void wgrad_gram_k(const WgradProblem* __restrict__ table, double* __restrict__ ws,
+                                                             int pair_cap /* pairs the LDS sums hold per operand */) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float4* tile = reinterpret_cast<float4*>(smem);                // [M][C4 + 1]
-  double* sums = reinterpret_cast<double*>(tile + GRAM_TILE_F4); // [g | x][pair]: this block's slices, summed
+  double* sums = reinterpret_cast<double*>(tile + GRAM_TILE_F4); // [g | x][pair_cap]: this block's slices, summed
   const WgradProblem pr = table[blockIdx.y];
   const int sl = blockIdx.x;
   const int M = pr.M, N = pr.N, K = pr.K, act = pr.act;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   double* mine = ws + (size_t)blockIdx.y * GRAM_WS_DOUBLES + (size_t)sl * 2 * GRAM_MAX_PAIRS;
-  for (int i = t; i < 2 * GRAM_MAX_PAIRS; i += GRAM_THREADS) sums[i] = 0.0;
+  for (int i = t; i < 2 * pair_cap; i += GRAM_THREADS) sums[i] = 0.0;
   if (pr.gb) {                                                  // bias gradient: a column slice per block
     for (int n = sl * GRAM_THREADS + t; n < N; n += GRAM_SLICES * GRAM_THREADS) {
       float sum = 0.f;
 #pragma unroll 4
       for (int m = 0; m < M; ++m) {
-        float g = pr.gy[(size_t)m * N + n];
-        if (act) g *= act_bwd(pr.z[(size_t)m * N + n], act);
+        const size_t at = wg_row(pr, m, N) + n;
+        float g = pr.gy[at];
+        if (act) g *= act_bwd(pr.z[at], act);
         sum += g;
       }
       pr.gb[n] = pr.accumulate ? pr.gb[n] + sum : sum;
     }
   }
-  if (M > GRAM_MAX_ROWS) {                                      // unsupported (cgv_rank_update_supported): poison the norm
+  if (M > GRAM_MAX_ROWS || M * (M + 1) / 2 > pair_cap) {        // unsupported (cgv_rank_update_supported): poison the norm
     if (t == 0) mine[0] = __builtin_nan("");
     return;
   }
   int C4 = (GRAM_TILE_F4 / M - 1) & ~63;
+  if (C4 == 0) C4 = (GRAM_TILE_F4 / M - 1) & ~15;                // more than 49 rows: 48 / 32 float4 per row and slice
   C4 = C4 > 256 ? 256 : C4;
   const int RS = C4 + 1;                                         // row stride (float4)
   const int n4 = N >> 2, k4 = K >> 2;
@@ -594,14 +607,14 @@ __global__ __launch_bounds__(GRAM_THREADS) void wgrad_gram_k(const WgradProblem*
       buf[u] = zero4;
       if (m < M && col4 < cols4) {
         if (is_g) {
-          float4 g = *reinterpret_cast<const float4*>(pr.gy + (size_t)m * N + 4 * col4);
+          float4 g = *reinterpret_cast<const float4*>(pr.gy + wg_row(pr, m, N) + 4 * col4);
           if (act) {
-            const float4 z = *reinterpret_cast<const float4*>(pr.z + (size_t)m * N + 4 * col4);
+            const float4 z = *reinterpret_cast<const float4*>(pr.z + wg_row(pr, m, N) + 4 * col4);
             g.x *= act_bwd(z.x, act); g.y *= act_bwd(z.y, act); g.z *= act_bwd(z.z, act); g.w *= act_bwd(z.w, act);
           }
           buf[u] = g;
         } else {
-          buf[u] = *reinterpret_cast<const float4*>(pr.x + (size_t)m * K + 4 * col4);
+          buf[u] = *reinterpret_cast<const float4*>(pr.x + wg_row(pr, m, K) + 4 * col4);
         }
       }
     }
@@ -620,7 +633,7 @@ __global__ __launch_bounds__(GRAM_THREADS) void wgrad_gram_k(const WgradProblem*
     }
     if (slice + GRAM_SLICES < slices) fetch(slice + GRAM_SLICES, buf);       // in flight while this slice is used
     __syncthreads();
-    double* row = sums + (slice < g_slices ? 0 : GRAM_MAX_PAIRS);
+    double* row = sums + (slice < g_slices ? 0 : pair_cap);
     for (int base = 8 * w; base < pairs; base += 8 * GRAM_WAVES) {
       const int pidx = base + pl;
       const bool live = pidx < pairs;
@@ -646,7 +659,7 @@ __global__ __launch_bounds__(GRAM_THREADS) void wgrad_gram_k(const WgradProblem*
     }
   }
   __syncthreads();
-  for (int i = t; i < 2 * GRAM_MAX_PAIRS; i += GRAM_THREADS) mine[i] = sums[i];
+  for (int i = t; i < pairs; i += GRAM_THREADS) { mine[i] = sums[i]; mine[GRAM_MAX_PAIRS + i] = sums[pair_cap + i]; }
 }
 
 __global__ __launch_bounds__(256) void wgrad_gram_reduce_k(const WgradProblem* __restrict__ table, const double* __restrict__ ws,
@@ -1174,17 +1187,24 @@ int cgv_grouped_wgrad(const void* table_dev, int n_problems, int total_blocks, i
 }
 
 /* Rank-update layers, first half: sumsq[i] = ||gW_i||_F^2 from the operands of record i; bias gradients written.
- * Records must satisfy cgv_rank_update_supported (M <= 40); workspace: cgv_wgrad_gram_workspace_bytes(n_problems). */
-int cgv_wgrad_gram(const void* table_dev, int n_problems, double* sumsq, void* workspace, size_t workspace_bytes,
+ * Records must satisfy cgv_rank_update_supported (M <= max_rows <= 64; records may address gathered operands through
+ * seg_rows / seg_stride); workspace: cgv_wgrad_gram_workspace_bytes(n_problems). */
+int cgv_wgrad_gram(const void* table_dev, int n_problems, int max_rows, double* sumsq, void* workspace, size_t workspace_bytes,
                    void* stream) {
   CGV_REQUIRE(n_problems >= 0, "bad size");
   if (n_problems == 0) return 0;
+  CGV_REQUIRE(max_rows >= 1 && max_rows <= cgv::GRAM_MAX_ROWS, "max_rows out of range (1..64)");
   CGV_REQUIRE(table_dev && sumsq && workspace, "null pointer");
   CGV_REQUIRE(workspace_bytes >= cgv_wgrad_gram_workspace_bytes(n_problems), "workspace too small");
   CGV_REQUIRE((((uintptr_t)workspace) & 7) == 0, "workspace must be 8-byte aligned");
   const cgv::WgradProblem* table = reinterpret_cast<const cgv::WgradProblem*>(table_dev);
-  hipLaunchKernelGGL(cgv::wgrad_gram_k, dim3(cgv::GRAM_SLICES, n_problems), dim3(cgv::GRAM_THREADS),
-                     cgv::GRAM_LDS_BYTES, (hipStream_t)stream, table, reinterpret_cast<double*>(workspace));
+  const size_t lds = cgv::gram_lds_bytes(max_rows);
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cgv::wgrad_gram_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { cgv::set_error("cgv_wgrad_gram: %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return (int)e; }
+  }
+  hipLaunchKernelGGL(cgv::wgrad_gram_k, dim3(cgv::GRAM_SLICES, n_problems), dim3(cgv::GRAM_THREADS), lds,
+                     (hipStream_t)stream, table, reinterpret_cast<double*>(workspace), max_rows * (max_rows + 1) / 2);
   hipLaunchKernelGGL(cgv::wgrad_gram_reduce_k, dim3(n_problems), dim3(256), 0, (hipStream_t)stream, table,
                      reinterpret_cast<const double*>(workspace), sumsq);
   return cgv::check_launch("cgv_wgrad_gram");
@@ -1194,7 +1214,7 @@ size_t cgv_wgrad_gram_workspace_bytes(int n_problems) {
   return n_problems > 0 ? (size_t)n_problems * cgv::GRAM_WS_DOUBLES * sizeof(double) : 0;
 }
 
-/* Shapes the rank update takes: the weight-streaming tiling (cgv_skinny_supported) with at most 40 operand rows. */
+/* Shapes the rank update takes: the weight-streaming tiling (cgv_skinny_supported, at most 64 operand rows). */
 int cgv_rank_update_supported(int M, int N, int K) { return cgv_skinny_supported(M, N, K) && M <= cgv::GRAM_MAX_ROWS; }
 
 /* Rank-update layers, second half: the table of cgv_grouped_wgrad, but every gW tile goes through the clipped Adam

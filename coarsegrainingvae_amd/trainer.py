@@ -214,8 +214,10 @@ class OperandExchange:
 
     PACK = struct.Struct("<5Q5i4x")             # cgv::PackProblem, 64 bytes
 
-    def __init__(self, sync: "GradSync", arena: "ParamArena", queue):
+    def __init__(self, sync: "GradSync", arena: "ParamArena", queue, rank_hi: int = 0):
         self.sync, self.world, self.arena, self.queue = sync, sync.world, arena, queue
+        self.rank_hi = rank_hi                  # weights in arena [0, rank_hi): never materialised (Trainer._start_gathered_rank_update)
+        self.ranked = []                        # this step's gathered problems kept back for the rank update
         self.inflight = []
         self.done_ranges = []                   # arena ranges whose global gradient this step came from gathered rows
         self._mode = {}                         # gW pointer -> "exchange" | "local" within the current step
@@ -234,7 +236,7 @@ class OperandExchange:
         return self.world * M * (N + K) <= N * K            # gathered rows vs the two passes an all-reduce makes
 
     def begin_step(self):
-        self.done_ranges, self._mode, self.bytes_gathered = [], {}, 0
+        self.done_ranges, self._mode, self.bytes_gathered, self.ranked = [], {}, 0, []
 
     def split(self, items):
         """(exchanged, local) -- a parameter keeps ONE mode within a step."""
@@ -289,29 +291,38 @@ class OperandExchange:
     def complete(self):
         if not self.inflight:
             return
-        lib = _lib.load()
-        rec = self.queue.RECORD
-        buf, block_begin, n = bytearray(), 0, 0
-        tk, nb = C.c_int(), C.c_int()
-        dev = self.inflight[0][2].device
-        from .primitives import wgrad_tile
-        tile = wgrad_tile([(self.world * m[0], m[1], m[2]) for _w, metas, *_r in self.inflight for m in metas])
+        now = []
         for work, metas, recv, _send, total in self.inflight:
             work.wait()                                      # the current stream now waits for the gather
-            for M, N, K, off_g, off_x, gW, gb, accumulate in metas:
-                if lib.cgv_wgrad_gathered_plan_tile(self.world * M, N, K, M, tile, C.byref(tk), C.byref(nb)) != 0:
-                    raise RuntimeError(lib.cgv_last_error_string().decode())
-                buf += rec.pack(recv.data_ptr() + 4 * off_g, recv.data_ptr() + 4 * off_x, 0, gW.data_ptr(),
-                                gb.data_ptr() if gb is not None else 0, self.world * M, N, K, int(accumulate), 0,
-                                block_begin, tk.value, 0, M, total, 0)
-                block_begin += nb.value
-                n += 1
-        if n > self.queue.MAX_PROBLEMS:
-            raise RuntimeError("too many gathered weight-gradient problems")
-        table = self.queue.upload(bytes(buf), dev)
-        _lib.call("cgv_grouped_wgrad_gathered_tile", _lib.ptr(table), n, block_begin, tile, _lib.stream_ptr(),
-                  tag="gathered_wgrad")
+            for meta in metas:
+                r = self.arena.range_of(meta[5])
+                keep = self.rank_hi and r is not None and r[1] <= self.rank_hi
+                (self.ranked if keep else now).append(meta + (recv, total))
         self.inflight = []                                   # buffers: stream order protects their reuse
+        self.materialise(now)
+
+    def materialise(self, problems):
+        """gW / gb of gathered problems (meta + (recv buffer, floats per rank segment)) into the gradient arena."""
+        if not problems:
+            return
+        lib = _lib.load()
+        rec = self.queue.RECORD
+        buf, block_begin = bytearray(), 0
+        tk, nb = C.c_int(), C.c_int()
+        from .primitives import wgrad_tile
+        tile = wgrad_tile([(self.world * m[0], m[1], m[2]) for m in problems])
+        for M, N, K, off_g, off_x, gW, gb, accumulate, recv, total in problems:
+            if lib.cgv_wgrad_gathered_plan_tile(self.world * M, N, K, M, tile, C.byref(tk), C.byref(nb)) != 0:
+                raise RuntimeError(lib.cgv_last_error_string().decode())
+            buf += rec.pack(recv.data_ptr() + 4 * off_g, recv.data_ptr() + 4 * off_x, 0, gW.data_ptr(),
+                            gb.data_ptr() if gb is not None else 0, self.world * M, N, K, int(accumulate), 0,
+                            block_begin, tk.value, 0, M, total, 0)
+            block_begin += nb.value
+        if len(problems) > self.queue.MAX_PROBLEMS:
+            raise RuntimeError("too many gathered weight-gradient problems")
+        table = self.queue.upload(bytes(buf), problems[0][8].device)
+        _lib.call("cgv_grouped_wgrad_gathered_tile", _lib.ptr(table), len(problems), block_begin, tile, _lib.stream_ptr(),
+                  tag="gathered_wgrad")
 
 
 class Trainer:
@@ -332,14 +343,16 @@ class Trainer:
         # optimiser pass is HBM-bound while those forwards are chains of tiny latency-bound launches, so the two share
         # the chip.  ``flush()`` applies a pending update (end of training, before reading parameters, lr changes).
         self.defer_update = bool(defer_update) and fused_optimizer
-        # rank_update (single process, fused optimiser): the weight gradients of the bead-level layers (<= 64 operand
-        # rows) are never written -- their norm comes from the operands (cgv_wgrad_gram) and each tile of g^T x goes
-        # straight through the Adam update of its weights (cgv_grouped_wgrad_adam).  ``p.grad`` of those weights then
-        # holds stale data; pass rank_update=False to materialise every gradient.
+        # rank_update (fused optimiser): the weight gradients of the bead-level layers (<= RANK_ROWS_PAY operand rows) are
+        # never written -- their norm comes from the operands (cgv_wgrad_gram) and each tile of g^T x goes straight
+        # through the Adam update of its weights (cgv_grouped_wgrad_adam).  Data parallel, the same two launches run on
+        # the all-gathered rows of the operand exchange (world x rows per rank: _start_gathered_rank_update), so no rank
+        # materialises these gradients either.  ``p.grad`` of those weights then holds stale data; pass
+        # rank_update=False to materialise every gradient.
         self.rank_update = bool(rank_update) and fused_optimizer and not self.defer_update
         self._rank_hi = 0             # arena floats [0, _rank_hi) belong to rank-update weights
         self._rank_numel = 0
-        self._rank_step = None        # this step's (table, problems, blocks, lds, items) once the Gram launch is out
+        self._rank_step = None        # this step's (table, problems, blocks, lds, items, max rows) once the Gram launch is out
         self.last_rank_step = None
         self.rank_steps = 0           # steps that took the rank-update path / fell back to materialised gradients
         self.rank_fallbacks = 0
@@ -443,12 +456,16 @@ class Trainer:
                 return t is not None and t[0] % 4 == 0 and world * t[0] * (t[1] + t[2]) <= t[1] * t[2]
             live = sorted(live, key=lambda p: 0 if exchanged(p) else 1)
         n_rank = 0
-        if self.rank_update and self.sync is None and on_device:
+        if self.rank_update and on_device and (self.sync is None or use_exchange):
             lib = _lib.load()
+            world = 1 if self.sync is None else self.sync.world
 
             def ranked(p):
-                t = getattr(p, "_cgv_rank", None)
-                return t is not None and p.dim() == 2 and bool(lib.cgv_rank_update_supported(t[0], t[1], t[2]))
+                # single process: the layer's own rows; data parallel: an exchanged layer's gathered rows (world x M)
+                t = getattr(p, "_cgv_rank" if self.sync is None else "_cgv_exch", None)
+                if t is None or p.dim() != 2 or (self.sync is not None and not exchanged(p)):
+                    return False
+                return world * t[0] <= self.RANK_ROWS_PAY and bool(lib.cgv_rank_update_supported(world * t[0], t[1], t[2]))
             live = sorted(live, key=lambda p: 0 if ranked(p) else 1)       # stable: u_mat / v_mat pairs stay adjacent
             n_rank = sum(1 for p in live if ranked(p))
         self.arena = ParamArena(live)
@@ -459,7 +476,7 @@ class Trainer:
             self._rank_sumsq = torch.zeros(wgrad_queue.MAX_PROBLEMS, dtype=torch.float64, device=dev)
             # Gram workspace: a queued problem covers at least one rank-update weight
             self._rank_ws = torch.empty(int(lib.cgv_wgrad_gram_workspace_bytes(n_rank)), dtype=torch.uint8, device=dev)
-        self.exchange = OperandExchange(self.sync, self.arena, wgrad_queue) if use_exchange else None
+        self.exchange = OperandExchange(self.sync, self.arena, wgrad_queue, rank_hi=self._rank_hi if n_rank else 0) if use_exchange else None
         # arena ranges of the model's backward buckets (decoder layer groups, in the order their gradients become
         # final): each is all-reduced as soon as it is, under the rest of backward
         self.early_ranges = []
@@ -723,6 +740,8 @@ class Trainer:
                 self.sync.all_reduce_range(a.g, lo, hi)
             if self.exchange is not None:
                 self.exchange.complete()
+                if self.exchange.rank_hi:
+                    self._start_gathered_rank_update()
             self.sync.wait()
         scale = 1.0 / self.world
         if self.fused:
@@ -732,7 +751,7 @@ class Trainer:
                 # kept for bench.py's optimiser timing: the table points at the operand rows, so they must stay alive --
                 # DETACHED (a retained autograd graph would pin its AccumulateGrad nodes to this step's stream, and a
                 # later capture on another stream then dies in hipStreamEndCapture)
-                self.last_rank_step = rank[:4] + ([tuple(t.detach() if torch.is_tensor(t) else t for t in it) for it in rank[4]],)
+                self.last_rank_step = rank[:4] + ([tuple(t.detach() if torch.is_tensor(t) else t for t in it) for it in rank[4]], rank[5])
             lo = self._rank_hi if rank else 0                # [0, lo): gradients that exist only as operand rows
             _lib.call("cgv_optim_prepare_extra", a.g.data_ptr() + 4 * lo, a.numel - lo,
                       _lib.ptr(self._rank_sumsq) if rank else None,
@@ -745,7 +764,7 @@ class Trainer:
             else:
                 self._adam_apply(lo, a.numel)
                 if rank:
-                    table, n, blocks, lds, _items = rank
+                    table, n, blocks, lds, _items, _rows = rank
                     _lib.call("cgv_grouped_wgrad_adam", _lib.ptr(table), n, blocks, lds, _lib.ptr(a.g), _lib.ptr(a.p),
                               _lib.ptr(self.m), _lib.ptr(self.v), self.lr, self.betas[0], self.betas[1], self.eps,
                               _lib.ptr(self.state), _lib.stream_ptr(), tag="grouped_wgrad_adam")
@@ -758,6 +777,11 @@ class Trainer:
         mark("optimizer")
         return self.last_loss
 
+    # Rows up to which the rank update beats materialising a layer's gradient.  The fused kernel forms each weight's
+    # gradient with one FMA per operand row: at 24 rows it hides under the p / m / v traffic (chignolin, 2 stand-in ranks:
+    # 241 us for 46 M weights), at 48 rows it is VALU bound (330 us) and only ties with the gathered MFMA launch + the
+    # three extra passes over a materialised gradient (profiles/r02c_dp_cost_probe.txt).  The kernels take up to 64.
+    RANK_ROWS_PAY = 40
     EARLY_MIN_FLOATS = 1 << 18      # ranges below 1 MiB are not worth a collective of their own: they go at the end
 
     def _padded(self, r):
@@ -799,10 +823,48 @@ class Trainer:
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("run one eager step before capturing (rank-update workspace)")
             self._rank_ws = torch.empty(need, dtype=torch.uint8, device=self.arena.p.device)
-        _lib.call("cgv_wgrad_gram", _lib.ptr(table), len(ranked), _lib.ptr(self._rank_sumsq), _lib.ptr(self._rank_ws),
+        rows = max(it[0].shape[0] for it in ranked)
+        _lib.call("cgv_wgrad_gram", _lib.ptr(table), len(ranked), rows, _lib.ptr(self._rank_sumsq), _lib.ptr(self._rank_ws),
                   self._rank_ws.numel(), _lib.stream_ptr(), tag="wgrad_gram")
-        self._rank_step = (table, len(ranked), blocks, lds, ranked)
+        self._rank_step = (table, len(ranked), blocks, lds, ranked, rows)
         return rest
+
+    def _start_gathered_rank_update(self):
+        """Data parallel: the rank update over the GATHERED operand rows (OperandExchange.ranked: what ``complete`` kept
+        back instead of materialising).  Same two launches as ``_start_rank_update`` -- Gram norm + bias gradients now,
+        the fused weight-gradient / Adam launch after the decision pass -- on records that address the rank segments of
+        the all-gathered buffers, so every rank applies the whole batch's update without ever writing these gradients.
+        Materialises them after all when the kept problems do not cover the rank-update weights exactly once."""
+        ex = self.exchange
+        kept, ex.ranked = ex.ranked, []
+        if not kept:
+            return
+        lib = _lib.load()
+        if sum(m[5].numel() for m in kept) != self._rank_numel or any(m[7] for m in kept):
+            self.rank_fallbacks += 1
+            ex.materialise(kept)
+            return
+        rec, world = wgrad_queue.RECORD, self.world
+        tk, tw, nb = C.c_int(), C.c_int(), C.c_int()
+        buf, block_begin, max_lds, rows = bytearray(), 0, 0, 0
+        for M, N, K, off_g, off_x, gW, gb, _acc, recv, total in kept:
+            if lib.cgv_wgrad_plan(world * M, N, K, C.byref(tk), C.byref(tw), C.byref(nb)) != 0:
+                raise RuntimeError(lib.cgv_last_error_string().decode())
+            buf += rec.pack(recv.data_ptr() + 4 * off_g, recv.data_ptr() + 4 * off_x, 0, gW.data_ptr(),
+                            gb.data_ptr() if gb is not None else 0, world * M, N, K, 0, 0, block_begin, tk.value, tw.value,
+                            M, total, 0)
+            block_begin += nb.value
+            max_lds = max(max_lds, lib.cgv_wgrad_lds_floats(world * M, tw.value))
+            rows = max(rows, world * M)
+        table = wgrad_queue.upload(bytes(buf), kept[0][8].device)
+        need = int(lib.cgv_wgrad_gram_workspace_bytes(len(kept)))
+        if self._rank_ws is None or self._rank_ws.numel() < need:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("run one eager step before capturing (rank-update workspace)")
+            self._rank_ws = torch.empty(need, dtype=torch.uint8, device=self.arena.p.device)
+        _lib.call("cgv_wgrad_gram", _lib.ptr(table), len(kept), rows, _lib.ptr(self._rank_sumsq), _lib.ptr(self._rank_ws),
+                  self._rank_ws.numel(), _lib.stream_ptr(), tag="wgrad_gram")
+        self._rank_step = (table, len(kept), block_begin, max_lds, kept, rows)
 
     def _bucket_done(self, index: int):
         """Autograd-thread callback (model.bucket_done): the gradients of backward bucket ``index`` are final.

@@ -535,11 +535,14 @@ int cgv_adam_apply(float* p, const float* g, float* m, float* v, int64_t n, floa
  * cgv_grouped_wgrad_adam re-forms each gW tile (the table and tiling of cgv_grouped_wgrad) and applies the clipped Adam
  * update to the weights, moments addressed through gW's offset in the gradient arena.  Replaces, for these layers,
  * Dense's autograd weight gradient (CoarseGrainingVAE/modules.py:103-114) + clip_grad_norm_ + Adam.step
- * (scripts/utils.py:150-157) with 24 instead of 36 bytes of HBM traffic per weight.  Records must have accumulate = 0. */
-int cgv_wgrad_gram(const void* table_dev, int n_problems, double* sumsq, void* workspace, size_t workspace_bytes,
-                   void* stream);
+ * (scripts/utils.py:150-157) with 24 instead of 36 bytes of HBM traffic per weight.  Records must have accumulate = 0.
+ * The records may address GATHERED operands (seg_rows / seg_stride as for cgv_grouped_wgrad_gathered: the rows of all
+ * data-parallel ranks, M = world x rows per rank): the update every rank then applies is the whole batch's, and no
+ * rank ever materialises these gradients either.  max_rows: the largest M in the table (sizes the kernel's LDS). */
+int cgv_wgrad_gram(const void* table_dev, int n_problems, int max_rows, double* sumsq, void* workspace,
+                   size_t workspace_bytes, void* stream);
 size_t cgv_wgrad_gram_workspace_bytes(int n_problems);
-int cgv_rank_update_supported(int M, int N, int K);   /* 1 when a layer with M operand rows can take this path (M <= 40) */
+int cgv_rank_update_supported(int M, int N, int K);   /* 1 when a layer with M operand rows can take this path (M <= 64) */
 int cgv_optim_prepare_extra(const float* g, int64_t n, const double* extra, int n_extra, float beta1, float beta2,
                             float max_norm, float grad_scale, const float* loss, float skip_threshold, float* state,
                             float* partial, void* stream);

@@ -1263,8 +1263,8 @@ def test_wgrad_gram_norm_and_fused_adam_vs_fp64():
     table, blocks, lds = q.small_table(items)
     sumsq = torch.zeros(len(items), dtype=torch.float64, device=DEV)
     ws = torch.empty(int(lib.cgv_wgrad_gram_workspace_bytes(len(items))), dtype=torch.uint8, device=DEV)
-    cg._lib.call("cgv_wgrad_gram", cg._lib.ptr(table), len(items), cg._lib.ptr(sumsq), cg._lib.ptr(ws), ws.numel(),
-                 cg._lib.stream_ptr())
+    cg._lib.call("cgv_wgrad_gram", cg._lib.ptr(table), len(items), max(it[0].shape[0] for it in items), cg._lib.ptr(sumsq),
+                 cg._lib.ptr(ws), ws.numel(), cg._lib.stream_ptr())
     for k, (gw, gbias, _) in enumerate(refs):
         assert abs(float(sumsq[k]) - float((gw ** 2).sum())) <= 1e-6 * float((gw ** 2).sum())
         if items[k][5] is not None:
@@ -1405,8 +1405,8 @@ def test_rank_update_kernels_on_random_shapes():
     table, blocks, lds = WeightGradQueue().small_table(items)
     sumsq = torch.zeros(len(items), dtype=torch.float64, device=DEV)
     ws = torch.empty(int(lib.cgv_wgrad_gram_workspace_bytes(len(items))), dtype=torch.uint8, device=DEV)
-    cg._lib.call("cgv_wgrad_gram", cg._lib.ptr(table), len(items), cg._lib.ptr(sumsq), cg._lib.ptr(ws), ws.numel(),
-                 cg._lib.stream_ptr())
+    cg._lib.call("cgv_wgrad_gram", cg._lib.ptr(table), len(items), max(it[0].shape[0] for it in items), cg._lib.ptr(sumsq),
+                 cg._lib.ptr(ws), ws.numel(), cg._lib.stream_ptr())
     for k, (gw, gbias, _) in enumerate(refs):
         want = float((gw ** 2).sum())
         assert abs(float(sumsq[k]) - want) <= 2e-6 * want + 1e-12, (k, shapes[k])

@@ -56,7 +56,7 @@ if os.environ.get("RANK", "1") == "1":
         e1.record()
         torch.cuda.synchronize()
         return 1e3 * e0.elapsed_time(e1) / reps
-    us = timed(lambda: _lib.call("cgv_wgrad_gram", _lib.ptr(table), len(items), _lib.ptr(sumsq), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+    us = timed(lambda: _lib.call("cgv_wgrad_gram", _lib.ptr(table), len(items), max(it[0].shape[0] for it in items), _lib.ptr(sumsq), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
     print(f"gram: {us:.1f} us/launch over {len(items)} problems")
 # check one problem against torch
 gy, x, z, act, gW, gb, _ = items[-1]
