@@ -225,6 +225,20 @@ __device__ __forceinline__ void bi_prefetch_slot(BiRegs<G, NT>& r, gcf W, int K,
   for (int g = 0; g < G; ++g) r.w[SLOT][g] = ldg4_stream(W + (size_t)(row0[g] + q) * K + cc);
 }
 
+// A slice is read by other CUs in the next launch and never again by this one.  CGV_DL_SLICE_STORE 1: write-through
+// (sc1) stores -- the kernel then ends without a slab of dirty L2 lines to write back before the next launch may start.
+#ifndef CGV_DL_SLICE_STORE
+#define CGV_DL_SLICE_STORE 1
+#endif
+__device__ __forceinline__ void st4_slice(float4* p, const float4& v) {
+#if CGV_DL_SLICE_STORE == 1
+  const f32x4 t = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(t) : "memory");
+#else
+  *p = v;
+#endif
+}
+
 template <int MB>
 __host__ __device__ constexpr size_t bi_stage_floats() { return (size_t)DL_WAVES * 16 * 16 * MB * 4; }
 
@@ -278,7 +292,7 @@ __device__ __forceinline__ void bi_core(const BiRegs<G, NPRE>& r, const float* _
     float4* out = reinterpret_cast<float4*>(slice) + (size_t)tile * 16 * rows;
     for (int idx = lane; idx < quads * rows; idx += 64) {
       const int jj = idx / rows, m = idx - jj * rows;
-      out[idx] = st[jj * MP + m];
+      st4_slice(out + idx, st[jj * MP + m]);
     }
   }
 }

@@ -301,7 +301,9 @@ __global__ __launch_bounds__(64) void pseudo_bwd_recv_k(const float* __restrict_
 // one-wave version kept 99 accumulators + 99 weights per lane and walked the edges alone (14 us per call on
 // the 60-edge bead graph, the longest kernel of a decoder layer's backward); here a lane holds 2(R+1) values
 // and nine waves hide each other's gather latency.  The waves' partial vector sums meet in LDS in wave order.
-template <int R, int SRC_EB>
+// STAGE: as in pseudo_fwd_k -- the node's edge records and receiver indices go to LDS in chunks of SEG_LDS edges (the
+// per-edge record was a dependent 80-byte scalar load in front of every edge of every wave).
+template <int R, int SRC_EB, bool STAGE = false>
 __global__ __launch_bounds__(576) void pseudo_bwd_src_k(
     const float* __restrict__ phi, const float* __restrict__ s, const float* __restrict__ sbar,
     const float* __restrict__ v, const float* __restrict__ vbar, const float* __restrict__ geom,
@@ -311,6 +313,8 @@ __global__ __launch_bounds__(576) void pseudo_bwd_src_k(
     float* __restrict__ g_v, float* __restrict__ g_vbar, float* __restrict__ part, int F, int N, int nodes_per_chunk) {
   constexpr int GS = geom_stride(R), U = geom_unit_offset(R);
   __shared__ float red[8][6][64];                    // waves 1..8: (av, avb) partials of the current node
+  __shared__ __attribute__((aligned(16))) float seg_geom[STAGE ? SEG_LDS * GS : 4];
+  __shared__ int seg_dst[STAGE ? SEG_LDS : 1];
   const int lane = threadIdx.x & 63;
   const int k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);          // this wave's filter
   const int f_raw = blockIdx.y * 64 + lane;
@@ -335,12 +339,22 @@ __global__ __launch_bounds__(576) void pseudo_bwd_src_k(
     const float* __restrict__ vecB = (k == 3 || k == 7 || k == 0) ? v : (k == 8 ? vbar : nullptr);  // receiver state vector
     const float* __restrict__ scaA = (k == 0) ? gh : ((k == 4 || k == 6) ? sbar : nullptr);
     const int e_beg = rowptr[j], e_end = rowptr[j + 1];
-    for (int eb = e_beg; eb < e_end; eb += SRC_EB) {
+    for (int c_beg = e_beg; c_beg < e_end; c_beg += STAGE ? SEG_LDS : (e_end - e_beg)) {
+    const int c_end = STAGE ? min(c_beg + SEG_LDS, e_end) : e_end;
+    if (STAGE) {
+      if (c_beg != e_beg) __syncthreads();                               // readers of the previous chunk (the previous node's
+                                                                         // are behind the barrier that closes its turn)
+      const float4* gsrc = reinterpret_cast<const float4*>(geom + (size_t)c_beg * GS);
+      for (int t = threadIdx.x; t < (c_end - c_beg) * (GS / 4); t += 576) reinterpret_cast<float4*>(seg_geom)[t] = gsrc[t];
+      for (int t = threadIdx.x; t < c_end - c_beg; t += 576) seg_dst[t] = dst[c_beg + t];
+      __syncthreads();
+    }
+    for (int eb = c_beg; eb < c_end; eb += SRC_EB) {
       int ii[SRC_EB];
       v3 A[SRC_EB], B[SRC_EB];
       float sA[SRC_EB], sB[SRC_EB], hb[SRC_EB];
 #pragma unroll
-      for (int u = 0; u < SRC_EB; ++u) ii[u] = dst[min(eb + u, e_end - 1)];
+      for (int u = 0; u < SRC_EB; ++u) ii[u] = STAGE ? seg_dst[min(eb + u, c_end - 1) - c_beg] : dst[min(eb + u, e_end - 1)];
 #pragma unroll
       for (int u = 0; u < SRC_EB; ++u) {
         const size_t nf = (size_t)ii[u] * F + f;
@@ -353,8 +367,8 @@ __global__ __launch_bounds__(576) void pseudo_bwd_src_k(
       }
 #pragma unroll
       for (int u = 0; u < SRC_EB; ++u) {
-        if (eb + u < e_end) {
-          const float* __restrict__ g = geom + (size_t)(eb + u) * GS;
+        if (eb + u < c_end) {
+          const float* __restrict__ g = STAGE ? seg_geom + (size_t)(eb + u - c_beg) * GS : geom + (size_t)(eb + u) * GS;
           const v3 zero{0.f, 0.f, 0.f};
           float gq = 0.f;
           v3 cav = zero, cavb = zero;                    // source-side vectors that get multiplied by q_k
@@ -380,6 +394,7 @@ __global__ __launch_bounds__(576) void pseudo_bwd_src_k(
           if (k == 0 && ghb) axpy(avb, hb[u], B[u]);                                      // the filter-free term ghb_i v_i
         }
       }
+    }
     }
     if (k > 0) {
       float* r = &red[k - 1][0][lane];
@@ -533,6 +548,9 @@ int cgv_pseudo_msg_bwd(const float* phi, const float* s, const float* sbar, cons
                          rowptr_d, src_d, Wd, bd, gh, ghbar, gv, gvbar, g_s, g_sbar, g_v, g_vbar, n_feat, residual);
     if (dense && cgv::option(CGV_OPT_PSEUDO_FWD) == 4)     // (8 edges' gathers in flight: 119.7 us against 119.1 with 2 -- not the limiter)
       hipLaunchKernelGGL((cgv::pseudo_bwd_src_k<RBF, 8>), gridB, dim3(576), 0, st, phi, s, sbar, v, vbar, geom_s, rowptr_s,
+                         dst_s, Wd, bd, gh, ghbar, gv, gvbar, g_phi, g_v, g_vbar, part, n_feat, n_nodes, npc);
+    else if (dense && cgv::option(CGV_OPT_PSEUDO_FWD) != 5)           // records + receiver indices staged in LDS (5: the plain walk, A/B)
+      hipLaunchKernelGGL((cgv::pseudo_bwd_src_k<RBF, 2, true>), gridB, dim3(576), 0, st, phi, s, sbar, v, vbar, geom_s, rowptr_s,
                          dst_s, Wd, bd, gh, ghbar, gv, gvbar, g_phi, g_v, g_vbar, part, n_feat, n_nodes, npc);
     else
       hipLaunchKernelGGL((cgv::pseudo_bwd_src_k<RBF, 2>), gridB, dim3(576), 0, st, phi, s, sbar, v, vbar, geom_s, rowptr_s,

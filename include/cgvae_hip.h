@@ -73,7 +73,7 @@ enum {
   CGV_OPT_WGRAD_TILING = 7,    /* cgv_wgrad_plan: 0 balanced column tiles (default), 1 widest tile */
   CGV_OPT_TILE_FWD_LDS_MIN = 8,/* cgv_tile_linear_fwd: minimum 64x64 tile count for the LDS-staged kernel (default 448; 1 = always) */
   CGV_OPT_BWD_INPUT_WAVES = 9, /* cgv_tile_linear_bwd_input*: waves per block, 0 = built-in rule */
-  CGV_OPT_PSEUDO_FWD = 10,     /* cgv_pseudo_msg_fwd*: 0 built-in rule; 1..6 = (edges in flight, records staged in LDS) variants */
+  CGV_OPT_PSEUDO_FWD = 10,     /* cgv_pseudo_msg_fwd*: 0 built-in rule; 1..6 = (edges in flight, records staged in LDS) variants; cgv_pseudo_msg_bwd on dense bead graphs: 4 = 8 edges in flight, 5 = records not staged in LDS */
   CGV_OPT_DECODER_FAT = 11,    /* cgv_decoder_{gate,dense,uv}_bwd: 1 (default) 8-channel blocks where the width allows, 0 always 4 */
   CGV_OPT_DECODER_WLDS = 12,   /* cgv_decoder_msg_fwd: 1 (default) weight rows by LDS-DMA when they fit in LDS, 0 register path */
   CGV_OPT_COUNT = 13
