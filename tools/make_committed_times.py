@@ -7,7 +7,7 @@ tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = {}
 GROUPS = [
-    ("decoder layer (channel-group kernels + the two full-width products per layer)", r"dec_|skinny_fwd_k<1, 16>"),
+    ("decoder layer (channel-group kernels incl. the 4-column-block Dense forward, which the prior / heads share: 12 of its 30 launches)", r"dec_|skinny_fwd_k<1, 16>"),
     ("optimizer (rank update of the bead-level layers, norm, Adam)", r"grouped_wgrad_t<true>|adam_update|sumsq_partial|optim_finalize|wgrad_gram"),
     ("atom-graph message passing (K2g / K2 / K2b + reductions)", r"equi_msg_|segment_reduce|segment_broadcast"),
     ("atom-level Dense (tile GEMMs) and their weight gradients", r"tile_|gathered_wgrad|grouped_wgrad_t<false>"),
