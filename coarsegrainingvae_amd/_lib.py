@@ -113,6 +113,8 @@ PROTOTYPES = {
     "cgv_grouped_wgrad_gathered": (_i, [_p, _i, _i, _p]),
     "cgv_wgrad_gathered_plan_tile": (_i, [_i, _i, _i, _i, _i, _p, _p]),
     "cgv_grouped_wgrad_gathered_tile": (_i, [_p, _i, _i, _i, _p]),
+    "cgv_grouped_wgrad_gathered_sumsq": (_i, [_p, _i, _i, _p, _p, _p]),
+    "cgv_grouped_wgrad_gathered_adam": (_i, [_p, _i, _i, _p, _p, _p, _p, _f, _f, _f, _f, _p, _p]),
     "cgv_pack_record_bytes": (_i, []),
     "cgv_pack_plan": (_i, [_i, _i, _i, _p]),
     "cgv_pack_operands": (_i, [_p, _i, _i, _p]),

@@ -709,9 +709,19 @@ __global__ __launch_bounds__(256) void wgrad_gram_reduce_k(const WgradProblem* _
 constexpr int GW_CHUNK = CGV_GW_CHUNK;
 constexpr int GW_GS = 80, GW_XS = 64;
 
-__global__ __launch_bounds__(256) void gathered_wgrad_k(const WgradProblem* __restrict__ table, int n_problems) {
+// MODE: GW_STORE writes the tile (and the bias gradient); the other two are the halves of a RANK UPDATE over gathered
+// rows too many for the FMA-per-row kernel (grouped_wgrad_t<true>: VALU bound from ~48 rows): GW_SUMSQ forms the tile,
+// leaves its sum of squares as this block's entry of `partial` (double; summed per problem in block order by
+// gathered_sumsq_reduce_k) and writes the bias gradient; GW_ADAM forms the tile again and runs it, clipped, through
+// the Adam update of its weights (p / m / v addressed through gW's offset in the gradient arena) -- the gradient itself
+// is never stored.
+enum { GW_STORE = 0, GW_SUMSQ = 1, GW_ADAM = 2 };
+template <int MODE>
+__global__ __launch_bounds__(256) void gathered_wgrad_k(const WgradProblem* __restrict__ table, int n_problems,
+                                                        double* __restrict__ partial, RankUpdateArgs ra) {
   __shared__ __attribute__((aligned(16))) float gs[GW_CHUNK * GW_GS];
   __shared__ __attribute__((aligned(16))) float xs[GW_CHUNK * GW_XS];
+  if (MODE == GW_ADAM && ra.state[ST_SKIP] != 0.f) return;    // skipped step (utils.py:145): parameters stay
   int lo = 0, hi = n_problems - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -786,22 +796,86 @@ __global__ __launch_bounds__(256) void gathered_wgrad_k(const WgradProblem* __re
     __syncthreads();
   }
   const int n = n0 + 16 * wave + i, kcol = k0 + 4 * i;
-  if (kcol < K) {
+  if (MODE == GW_STORE) {
+    if (kcol < K) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = n0 + 16 * wave + 4 * q + r;
-      if (row >= N) continue;
-      float4* dst = reinterpret_cast<float4*>(pr.gW + (size_t)row * K + kcol);
-      float4 o = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
-      if (pr.accumulate) { const float4 old = *dst; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
-      *dst = o;
+      for (int r = 0; r < 4; ++r) {
+        const int row = n0 + 16 * wave + 4 * q + r;
+        if (row >= N) continue;
+        float4* dst = reinterpret_cast<float4*>(pr.gW + (size_t)row * K + kcol);
+        float4 o = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+        if (pr.accumulate) { const float4 old = *dst; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+        *dst = o;
+      }
     }
+  } else if (MODE == GW_SUMSQ) {
+    double sq = 0.0;
+    if (kcol < K) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (n0 + 16 * wave + 4 * q + r >= N) continue;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sq += (double)acc[c][r] * (double)acc[c][r];
+      }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) sq += __shfl_xor(sq, d);
+    __shared__ double wave_sq[4];
+    if (lane == 0) wave_sq[wave] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (wave_sq[0] + wave_sq[1]) + (wave_sq[2] + wave_sq[3]);
+  } else {
+    if (kcol < K) {
+      typedef float f4v __attribute__((ext_vector_type(4)));
+      const AdamStep a = adam_step_of(ra.state, ra.lr, ra.beta1, ra.beta2, ra.eps);
+      const size_t at0 = (size_t)(pr.gW - ra.arena_g) + kcol;
+      float4 pp[4], mm[4], vv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = n0 + 16 * wave + 4 * q + r;
+        const size_t o = at0 + (size_t)(row < N ? row : 0) * K;
+        pp[r] = *reinterpret_cast<const float4*>(ra.arena_p + o);
+        const f4v tm = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(ra.arena_m + o));
+        const f4v tv = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(ra.arena_v + o));
+        mm[r] = make_float4(tm.x, tm.y, tm.z, tm.w);
+        vv[r] = make_float4(tv.x, tv.y, tv.z, tv.w);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = n0 + 16 * wave + 4 * q + r;
+        if (row >= N) continue;
+        const size_t o = at0 + (size_t)row * K;
+        adam_elem(a, pp[r].x, acc[0][r], mm[r].x, vv[r].x); adam_elem(a, pp[r].y, acc[1][r], mm[r].y, vv[r].y);
+        adam_elem(a, pp[r].z, acc[2][r], mm[r].z, vv[r].z); adam_elem(a, pp[r].w, acc[3][r], mm[r].w, vv[r].w);
+        *reinterpret_cast<float4*>(ra.arena_p + o) = pp[r];
+        __builtin_nontemporal_store(f4v{mm[r].x, mm[r].y, mm[r].z, mm[r].w}, reinterpret_cast<f4v*>(ra.arena_m + o));
+        __builtin_nontemporal_store(f4v{vv[r].x, vv[r].y, vv[r].z, vv[r].w}, reinterpret_cast<f4v*>(ra.arena_v + o));
+      }
+    }
+    return;                                                         // the bias gradient was written by the GW_SUMSQ pass
   }
   if (pr.gb && kt == 0) {                                           // bias: the 4 row groups q of a step meet by shuffle
     bsum += __shfl_xor(bsum, 16);
     bsum += __shfl_xor(bsum, 32);
     if (q == 0 && n < N) pr.gb[n] = pr.accumulate ? pr.gb[n] + bsum : bsum;
   }
+}
+
+// sumsq[problem] = sum of its blocks' partial sums of squares, block order (deterministic)
+__global__ __launch_bounds__(256) void gathered_sumsq_reduce_k(const WgradProblem* __restrict__ table, int n_problems, int total_blocks,
+                                                               const double* __restrict__ partial, double* __restrict__ out) {
+  __shared__ double part[256];
+  const int pr = blockIdx.x;
+  const int beg = table[pr].block_begin, end = pr + 1 < n_problems ? table[pr + 1].block_begin : total_blocks;
+  double local = 0.0;
+  for (int b = beg + (int)threadIdx.x; b < end; b += 256) local += partial[b];
+  part[threadIdx.x] = local;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) {
+    if ((int)threadIdx.x < d) part[threadIdx.x] += part[threadIdx.x + d];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[pr] = part[0];
 }
 
 // The same with 128 x 128 output tiles (waves as a 2 x 2 grid of 64 x 64 quadrants: 4 row tiles x one 64-column group
@@ -1264,9 +1338,42 @@ int cgv_grouped_wgrad_gathered_tile(const void* table_dev, int n_problems, int t
     hipLaunchKernelGGL(cgv::gathered_wgrad128_k, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const cgv::WgradProblem*>(table_dev), n_problems);
   else
-    hipLaunchKernelGGL(cgv::gathered_wgrad_k, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const cgv::WgradProblem*>(table_dev), n_problems);
+    hipLaunchKernelGGL(cgv::gathered_wgrad_k<cgv::GW_STORE>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const cgv::WgradProblem*>(table_dev), n_problems, (double*)nullptr, cgv::RankUpdateArgs{});
   return cgv::check_launch("cgv_grouped_wgrad_gathered");
+}
+
+/* Rank update over (gathered) operand rows with MFMA tiles, for row counts beyond the FMA-per-row kernel's range
+ * (cgv_grouped_wgrad_adam): the table and plan of cgv_grouped_wgrad_gathered (tile 64), accumulate = 0.
+ *   _sumsq: sumsq[i] = ||gW_i||_F^2 for record i (tiles formed, squared, never stored; block partials in `partial`,
+ *           total_blocks doubles) and the bias gradients written;
+ *   _adam:  the tiles formed again and run through the clipped Adam update of their weights (state from
+ *           cgv_optim_prepare_extra with those norms); every gW must lie inside the gradient arena. */
+int cgv_grouped_wgrad_gathered_sumsq(const void* table_dev, int n_problems, int total_blocks, double* partial, double* sumsq,
+                                     void* stream) {
+  CGV_REQUIRE(n_problems >= 0 && total_blocks >= 0, "bad size");
+  if (n_problems == 0 || total_blocks == 0) return 0;
+  CGV_REQUIRE(table_dev && partial && sumsq, "null pointer");
+  const cgv::WgradProblem* table = reinterpret_cast<const cgv::WgradProblem*>(table_dev);
+  hipLaunchKernelGGL(cgv::gathered_wgrad_k<cgv::GW_SUMSQ>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, table,
+                     n_problems, partial, cgv::RankUpdateArgs{});
+  hipLaunchKernelGGL(cgv::gathered_sumsq_reduce_k, dim3(n_problems), dim3(256), 0, (hipStream_t)stream, table, n_problems,
+                     total_blocks, partial, sumsq);
+  return cgv::check_launch("cgv_grouped_wgrad_gathered_sumsq");
+}
+
+int cgv_grouped_wgrad_gathered_adam(const void* table_dev, int n_problems, int total_blocks, const float* arena_g,
+                                    float* arena_p, float* arena_m, float* arena_v, float lr, float beta1, float beta2,
+                                    float eps, const float* state, void* stream) {
+  CGV_REQUIRE(n_problems >= 0 && total_blocks >= 0, "bad size");
+  if (n_problems == 0 || total_blocks == 0) return 0;
+  CGV_REQUIRE(table_dev && arena_g && arena_p && arena_m && arena_v && state, "null pointer");
+  CGV_REQUIRE(((((uintptr_t)arena_g | (uintptr_t)arena_p | (uintptr_t)arena_m | (uintptr_t)arena_v)) & 15) == 0,
+              "arenas must be 16-byte aligned");
+  hipLaunchKernelGGL(cgv::gathered_wgrad_k<cgv::GW_ADAM>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const cgv::WgradProblem*>(table_dev), n_problems, (double*)nullptr,
+                     cgv::RankUpdateArgs{arena_g, arena_p, arena_m, arena_v, state, lr, beta1, beta2, eps});
+  return cgv::check_launch("cgv_grouped_wgrad_gathered_adam");
 }
 
 int cgv_pack_record_bytes(void) { return (int)sizeof(cgv::PackProblem); }

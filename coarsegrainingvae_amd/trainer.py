@@ -353,9 +353,12 @@ class Trainer:
         self._rank_hi = 0             # arena floats [0, _rank_hi) belong to rank-update weights
         self._rank_numel = 0
         self._rank_step = None        # this step's (table, problems, blocks, lds, items, max rows) once the Gram launch is out
+        self._rank_mfma = None        # data parallel: (table, problems, blocks, items) of the layers on the MFMA tile kernel
+        self._mfma_partial = None
         self.last_rank_step = None
         self.rank_steps = 0           # steps that took the rank-update path / fell back to materialised gradients
         self.rank_fallbacks = 0
+        self.rank_steps_mfma = 0      # data-parallel steps whose many-row layers took the MFMA tile rank update
         self._pending = False
         self._side = None
         self._dec_ranges = None
@@ -465,7 +468,9 @@ class Trainer:
                 t = getattr(p, "_cgv_rank" if self.sync is None else "_cgv_exch", None)
                 if t is None or p.dim() != 2 or (self.sync is not None and not exchanged(p)):
                     return False
-                return world * t[0] <= self.RANK_ROWS_PAY and bool(lib.cgv_rank_update_supported(world * t[0], t[1], t[2]))
+                if self.sync is not None:
+                    return True                                      # FMA-per-row kernel or MFMA tiles, by gathered rows
+                return t[0] <= self.RANK_ROWS_PAY and bool(lib.cgv_rank_update_supported(t[0], t[1], t[2]))
             live = sorted(live, key=lambda p: 0 if ranked(p) else 1)       # stable: u_mat / v_mat pairs stay adjacent
             n_rank = sum(1 for p in live if ranked(p))
         self.arena = ParamArena(live)
@@ -747,15 +752,16 @@ class Trainer:
         if self.fused:
             a = self.arena
             rank, self._rank_step = self._rank_step, None
+            mfma, self._rank_mfma = self._rank_mfma, None
             if rank and not torch.cuda.is_current_stream_capturing():
                 # kept for bench.py's optimiser timing: the table points at the operand rows, so they must stay alive --
                 # DETACHED (a retained autograd graph would pin its AccumulateGrad nodes to this step's stream, and a
                 # later capture on another stream then dies in hipStreamEndCapture)
                 self.last_rank_step = rank[:4] + ([tuple(t.detach() if torch.is_tensor(t) else t for t in it) for it in rank[4]], rank[5])
-            lo = self._rank_hi if rank else 0                # [0, lo): gradients that exist only as operand rows
+            lo = self._rank_hi if (rank or mfma) else 0      # [0, lo): gradients that exist only as operand rows
             _lib.call("cgv_optim_prepare_extra", a.g.data_ptr() + 4 * lo, a.numel - lo,
-                      _lib.ptr(self._rank_sumsq) if rank else None,
-                      rank[1] if rank else 0,
+                      _lib.ptr(self._rank_sumsq) if (rank or mfma) else None,
+                      (rank[1] if rank else 0) + (mfma[1] if mfma else 0),
                       self.betas[0], self.betas[1], self.max_norm, scale,
                       _lib.ptr(decision.reshape(1).float().contiguous()), threshold, _lib.ptr(self.state),
                       _lib.ptr(self.partial), _lib.stream_ptr())
@@ -769,6 +775,12 @@ class Trainer:
                               _lib.ptr(self.m), _lib.ptr(self.v), self.lr, self.betas[0], self.betas[1], self.eps,
                               _lib.ptr(self.state), _lib.stream_ptr(), tag="grouped_wgrad_adam")
                     self.rank_steps += 1
+                if mfma:
+                    table, n, blocks, _items = mfma
+                    _lib.call("cgv_grouped_wgrad_gathered_adam", _lib.ptr(table), n, blocks, _lib.ptr(a.g), _lib.ptr(a.p),
+                              _lib.ptr(self.m), _lib.ptr(self.v), self.lr, self.betas[0], self.betas[1], self.eps,
+                              _lib.ptr(self.state), _lib.stream_ptr(), tag="gathered_wgrad_adam")
+                    self.rank_steps_mfma += 1
         else:
             if self.world > 1:
                 self.arena.g.mul_(scale)
@@ -831,12 +843,15 @@ class Trainer:
 
     def _start_gathered_rank_update(self):
         """Data parallel: the rank update over the GATHERED operand rows (OperandExchange.ranked: what ``complete`` kept
-        back instead of materialising).  Same two launches as ``_start_rank_update`` -- Gram norm + bias gradients now,
-        the fused weight-gradient / Adam launch after the decision pass -- on records that address the rank segments of
-        the all-gathered buffers, so every rank applies the whole batch's update without ever writing these gradients.
-        Materialises them after all when the kept problems do not cover the rank-update weights exactly once."""
+        back instead of materialising), so that no rank ever writes these gradients.  Layers with at most RANK_ROWS_PAY
+        gathered rows take the two launches of ``_start_rank_update`` (Gram norm + bias gradients now, the fused
+        FMA-per-row weight-gradient / Adam launch after the decision pass) on records that address the rank segments of
+        the all-gathered buffers; layers with more rows take the MFMA tile kernel twice -- now for the norm (tiles
+        squared, never stored; bias gradients written), after the decision pass with the Adam epilogue.
+        Materialises everything after all when the kept problems do not cover the rank-update weights exactly once."""
         ex = self.exchange
         kept, ex.ranked = ex.ranked, []
+        self._rank_mfma = None
         if not kept:
             return
         lib = _lib.load()
@@ -845,26 +860,48 @@ class Trainer:
             ex.materialise(kept)
             return
         rec, world = wgrad_queue.RECORD, self.world
+        small = [m for m in kept if world * m[0] <= self.RANK_ROWS_PAY and lib.cgv_rank_update_supported(world * m[0], m[1], m[2])]
+        ids = {id(m) for m in small}
+        large = [m for m in kept if id(m) not in ids]
+        dev = kept[0][8].device
         tk, tw, nb = C.c_int(), C.c_int(), C.c_int()
-        buf, block_begin, max_lds, rows = bytearray(), 0, 0, 0
-        for M, N, K, off_g, off_x, gW, gb, _acc, recv, total in kept:
-            if lib.cgv_wgrad_plan(world * M, N, K, C.byref(tk), C.byref(tw), C.byref(nb)) != 0:
-                raise RuntimeError(lib.cgv_last_error_string().decode())
-            buf += rec.pack(recv.data_ptr() + 4 * off_g, recv.data_ptr() + 4 * off_x, 0, gW.data_ptr(),
-                            gb.data_ptr() if gb is not None else 0, world * M, N, K, 0, 0, block_begin, tk.value, tw.value,
-                            M, total, 0)
-            block_begin += nb.value
-            max_lds = max(max_lds, lib.cgv_wgrad_lds_floats(world * M, tw.value))
-            rows = max(rows, world * M)
-        table = wgrad_queue.upload(bytes(buf), kept[0][8].device)
-        need = int(lib.cgv_wgrad_gram_workspace_bytes(len(kept)))
-        if self._rank_ws is None or self._rank_ws.numel() < need:
-            if torch.cuda.is_current_stream_capturing():
-                raise RuntimeError("run one eager step before capturing (rank-update workspace)")
-            self._rank_ws = torch.empty(need, dtype=torch.uint8, device=self.arena.p.device)
-        _lib.call("cgv_wgrad_gram", _lib.ptr(table), len(kept), rows, _lib.ptr(self._rank_sumsq), _lib.ptr(self._rank_ws),
-                  self._rank_ws.numel(), _lib.stream_ptr(), tag="wgrad_gram")
-        self._rank_step = (table, len(kept), block_begin, max_lds, kept, rows)
+        if small:
+            buf, block_begin, max_lds, rows = bytearray(), 0, 0, 0
+            for M, N, K, off_g, off_x, gW, gb, _acc, recv, total in small:
+                if lib.cgv_wgrad_plan(world * M, N, K, C.byref(tk), C.byref(tw), C.byref(nb)) != 0:
+                    raise RuntimeError(lib.cgv_last_error_string().decode())
+                buf += rec.pack(recv.data_ptr() + 4 * off_g, recv.data_ptr() + 4 * off_x, 0, gW.data_ptr(),
+                                gb.data_ptr() if gb is not None else 0, world * M, N, K, 0, 0, block_begin, tk.value, tw.value,
+                                M, total, 0)
+                block_begin += nb.value
+                max_lds = max(max_lds, lib.cgv_wgrad_lds_floats(world * M, tw.value))
+                rows = max(rows, world * M)
+            table = wgrad_queue.upload(bytes(buf), dev)
+            need = int(lib.cgv_wgrad_gram_workspace_bytes(len(small)))
+            if self._rank_ws is None or self._rank_ws.numel() < need:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("run one eager step before capturing (rank-update workspace)")
+                self._rank_ws = torch.empty(need, dtype=torch.uint8, device=self.arena.p.device)
+            _lib.call("cgv_wgrad_gram", _lib.ptr(table), len(small), rows, _lib.ptr(self._rank_sumsq), _lib.ptr(self._rank_ws),
+                      self._rank_ws.numel(), _lib.stream_ptr(), tag="wgrad_gram")
+            self._rank_step = (table, len(small), block_begin, max_lds, small, rows)
+        if large:
+            buf, block_begin = bytearray(), 0
+            for M, N, K, off_g, off_x, gW, gb, _acc, recv, total in large:
+                if lib.cgv_wgrad_gathered_plan_tile(world * M, N, K, M, 64, C.byref(tk), C.byref(nb)) != 0:
+                    raise RuntimeError(lib.cgv_last_error_string().decode())
+                buf += rec.pack(recv.data_ptr() + 4 * off_g, recv.data_ptr() + 4 * off_x, 0, gW.data_ptr(),
+                                gb.data_ptr() if gb is not None else 0, world * M, N, K, 0, 0, block_begin, tk.value, 0,
+                                M, total, 0)
+                block_begin += nb.value
+            table = wgrad_queue.upload(bytes(buf), dev)
+            if self._mfma_partial is None or self._mfma_partial.numel() < block_begin:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("run one eager step before capturing (rank-update workspace)")
+                self._mfma_partial = torch.empty(block_begin, dtype=torch.float64, device=dev)
+            _lib.call("cgv_grouped_wgrad_gathered_sumsq", _lib.ptr(table), len(large), block_begin, _lib.ptr(self._mfma_partial),
+                      self._rank_sumsq.data_ptr() + 8 * len(small), _lib.stream_ptr(), tag="gathered_wgrad_sumsq")
+            self._rank_mfma = (table, len(large), block_begin, large)
 
     def _bucket_done(self, index: int):
         """Autograd-thread callback (model.bucket_done): the gradients of backward bucket ``index`` are final.

@@ -468,6 +468,20 @@ int cgv_grouped_wgrad_gathered(const void* table_dev, int n_problems, int total_
  * per gW element but measured slower on the shapes of this model -- an opt-in variant */
 int cgv_wgrad_gathered_plan_tile(int M, int N, int K, int seg_rows, int tile, int* tiles_k /*[host]*/, int* n_blocks /*[host]*/);
 int cgv_grouped_wgrad_gathered_tile(const void* table_dev, int n_problems, int total_blocks, int tile, void* stream);
+/* Rank update over gathered operand rows with MFMA tiles -- for layers whose gathered row count is beyond the range in
+ * which the FMA-per-row kernel (cgv_grouped_wgrad_adam) pays (~40 rows: 4+ data-parallel ranks of 12 bead rows, or the
+ * 36-row [u_mat; v_mat] layers at 2+).  Same records and plan as cgv_grouped_wgrad_gathered (tile 64; accumulate = 0).
+ * _sumsq: the tiles are formed and squared, never stored: sumsq[i] = ||gW_i||_F^2 (block partials in `partial`:
+ * total_blocks doubles, summed per record in block order); the bias gradients are written.  _adam: the tiles are
+ * formed again and go, clipped, through the Adam update of their weights (state from cgv_optim_prepare_extra over
+ * those norms); every gW must lie inside the gradient arena, p / m / v are addressed through its offset there.
+ * Replaces, for those layers and data-parallel training, Dense's weight gradient (modules.py:103-114) +
+ * clip_grad_norm_ + Adam.step (scripts/utils.py:150-157) on the all-gathered batch. */
+int cgv_grouped_wgrad_gathered_sumsq(const void* table_dev, int n_problems, int total_blocks, double* partial, double* sumsq,
+                                     void* stream);
+int cgv_grouped_wgrad_gathered_adam(const void* table_dev, int n_problems, int total_blocks, const float* arena_g,
+                                    float* arena_p, float* arena_m, float* arena_v, float lr, float beta1, float beta2,
+                                    float eps, const float* state, void* stream);
 int cgv_pack_record_bytes(void);
 int cgv_pack_plan(int M, int N, int K, int* n_blocks /*[host]*/);
 int cgv_pack_operands(const void* table_dev, int n_problems, int total_blocks, void* stream);

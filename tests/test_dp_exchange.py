@@ -92,12 +92,12 @@ def test_operand_exchange_reproduces_single_rank_training(world):
     tr, got = _train(world, "operands", F=F)
     assert tr.exchange is not None and tr.sync.gathered > 0
     assert _worst(got, ref) < 2e-5
-    # up to Trainer.RANK_ROWS_PAY gathered rows (2 ranks x 12 bead rows) the exchanged weights take the rank update: their
-    # gradients are never materialised on any rank; more rows go through the gathered MFMA launch
-    if world * 12 <= Trainer.RANK_ROWS_PAY:
-        assert tr.rank_steps >= 2 and tr.rank_fallbacks == 0 and tr._rank_hi > 0 and tr.exchange.rank_hi == tr._rank_hi
-    else:
-        assert tr.rank_steps == 0 and tr._rank_hi == 0
+    # no rank materialises the exchanged weights' gradients: up to Trainer.RANK_ROWS_PAY gathered rows (2 ranks x 12 bead
+    # rows) they take the FMA-per-row rank update, with more rows (the 36-row [u_mat; v_mat] layers; everything at 4 / 8
+    # ranks) the MFMA tile kernel's norm and Adam passes
+    assert tr.rank_fallbacks == 0 and tr._rank_hi > 0 and tr.exchange.rank_hi == tr._rank_hi
+    assert (tr.rank_steps >= 2) == (world * 12 <= Trainer.RANK_ROWS_PAY)
+    assert (tr.rank_steps_mfma >= 2) == (world * 12 > Trainer.RANK_ROWS_PAY)     # (at these widths the 36-row layers are not exchanged)
     # the exchanged layers sit at the front of the arena: what is left for the all-reduce is a handful of ranges
     a = tr.arena
     done = sorted(tr._padded(r) for r in tr.exchange.done_ranges)
@@ -229,5 +229,70 @@ def test_rank_update_over_gathered_rows_vs_fp64(world, M, N, K, bias):
     p1 = p0 - (lr / (1 - b1)) * m1 / (v1.sqrt() / (1 - b2) ** 0.5 + eps)
     assert torch.isnan(arena_g).all()
     assert torch.allclose(arena_m.double().cpu(), m1, rtol=2e-5, atol=1e-9)
+    assert torch.allclose(arena_v.double().cpu(), v1, rtol=2e-5, atol=1e-12)
+    assert float((arena_p.double().cpu() - p1).abs().max()) <= 5e-6
+
+
+@pytest.mark.parametrize("world,M,N,K,bias", [(8, 12, 600, 600, True), (2, 36, 1200, 600, False), (4, 12, 1800, 600, True),
+                                              (3, 20, 68, 132, True), (8, 12, 5400, 600, True)])
+def test_mfma_rank_update_over_gathered_rows_vs_fp64(world, M, N, K, bias):
+    """cgv_grouped_wgrad_gathered_sumsq + cgv_grouped_wgrad_gathered_adam (the MFMA tile kernel's norm and Adam passes) on
+    rank-segmented rows, different on every 'rank': norm, bias gradient and the Adam update against the fp64 gradient of
+    the concatenated rows; the gradient arena is never written."""
+    import ctypes as C
+    from coarsegrainingvae_amd.primitives import wgrad_queue
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(world * 31 + M + N + K)
+    pad = lambda n: (n + 63) // 64 * 64
+    off_x, total = pad(M * N) + 64, pad(M * N) + 64 + pad(M * K) + 128
+    recv = torch.full((world * total,), float("nan"))
+    gs, xs = [], []
+    for r in range(world):
+        g, x = torch.randn(M, N, generator=gen), torch.randn(M, K, generator=gen)
+        gs.append(g); xs.append(x)
+        recv[r * total:r * total + M * N] = g.reshape(-1)
+        recv[r * total + off_x:r * total + off_x + M * K] = x.reshape(-1)
+    recv = recv.to(DEV)
+    gw = torch.cat(gs).double().T @ torch.cat(xs).double()
+    gbias = torch.cat(gs).double().sum(0)
+    lead = 256                                                           # the weights do not start the arena
+    arena_g = torch.full((lead + N * K,), float("nan"), device=DEV)
+    dgen = torch.Generator(device=DEV).manual_seed(3)
+    arena_p = torch.randn(lead + N * K, device=DEV, generator=dgen)
+    arena_m = 0.1 * torch.randn(lead + N * K, device=DEV, generator=dgen)
+    arena_v = 0.01 * (0.1 + torch.rand(lead + N * K, device=DEV, generator=dgen))
+    p0, m0, v0 = arena_p.double().cpu(), arena_m.double().cpu(), arena_v.double().cpu()
+    gb = torch.full((N,), float("nan"), device=DEV) if bias else None
+    tk, nb = C.c_int(), C.c_int()
+    assert lib.cgv_wgrad_gathered_plan_tile(world * M, N, K, M, 64, C.byref(tk), C.byref(nb)) == 0
+    rec = wgrad_queue.RECORD.pack(recv.data_ptr(), recv.data_ptr() + 4 * off_x, 0, arena_g.data_ptr() + 4 * lead,
+                                  gb.data_ptr() if bias else 0, world * M, N, K, 0, 0, 0, tk.value, 0, M, total, 0)
+    table = wgrad_queue.upload(rec, torch.device(DEV))
+    sumsq = torch.zeros(1, dtype=torch.float64, device=DEV)
+    partial = torch.empty(nb.value, dtype=torch.float64, device=DEV)
+    _lib.call("cgv_grouped_wgrad_gathered_sumsq", _lib.ptr(table), 1, nb.value, _lib.ptr(partial), _lib.ptr(sumsq), _lib.stream_ptr())
+    want = float((gw ** 2).sum())
+    assert abs(float(sumsq[0]) - want) <= 2e-6 * want
+    if bias:
+        assert torch.allclose(gb.double().cpu(), gbias, rtol=1e-5, atol=1e-5)
+    state = torch.zeros(lib.cgv_optim_state_floats(), device=DEV)
+    part = torch.empty(lib.cgv_optim_partial_floats(), device=DEV)
+    lr, b1, b2, eps, max_norm, scale = 1e-3, 0.9, 0.999, 1e-8, 0.01, 1.0 / world
+    _lib.call("cgv_optim_prepare_extra", arena_g.data_ptr(), 0, _lib.ptr(sumsq), 1, b1, b2, max_norm, scale, None, 0.0,
+              _lib.ptr(state), _lib.ptr(part), _lib.stream_ptr())
+    _lib.call("cgv_grouped_wgrad_gathered_adam", _lib.ptr(table), 1, nb.value, _lib.ptr(arena_g), _lib.ptr(arena_p),
+              _lib.ptr(arena_m), _lib.ptr(arena_v), lr, b1, b2, eps, _lib.ptr(state), _lib.stream_ptr())
+    torch.cuda.synchronize()
+    g_mean = gw * scale
+    norm = float((g_mean ** 2).sum()) ** 0.5
+    clip = min(1.0, max_norm / (norm + 1e-6))
+    gflat = (g_mean * clip).reshape(-1)
+    sl = slice(lead, lead + N * K)
+    m1, v1, p1 = m0.clone(), v0.clone(), p0.clone()
+    m1[sl] = b1 * m0[sl] + (1 - b1) * gflat
+    v1[sl] = b2 * v0[sl] + (1 - b2) * gflat * gflat
+    p1[sl] = p0[sl] - (lr / (1 - b1)) * m1[sl] / (v1[sl].sqrt() / (1 - b2) ** 0.5 + eps)
+    assert torch.isnan(arena_g).all()
+    assert torch.allclose(arena_m.double().cpu(), m1, rtol=2e-5, atol=1e-9)               # incl. the untouched lead
     assert torch.allclose(arena_v.double().cpu(), v1, rtol=2e-5, atol=1e-12)
     assert float((arena_p.double().cpu() - p1).abs().max()) <= 5e-6
