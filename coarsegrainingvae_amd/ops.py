@@ -554,10 +554,68 @@ class _Elbo(torch.autograd.Function):
     def backward(ctx, g_loss, _g_terms):
         g = ctx.grads
         ctx.grads = None
+        if g_loss.data_ptr() == _UNIT_SEED.get(g_loss.device):
+            # the caller seeded backward with its registered constant 1 (unit_seed): the gradients of the forward launch
+            # are final as they are -- no scale launch, and no ones_like fill in front of it
+            return g[0], g[1], g[2], g[3], None, g[4], None, None, None
         gl = _c(g_loss.reshape(1))
         _lib.call("cgv_elbo_scale", _lib.ptr(gl), _lib.ptr(g[0]), _lib.ptr(g[1]), _lib.ptr(g[2]), _lib.ptr(g[3]),
                   g[0].numel(), _lib.ptr(g[4]), g[4].numel(), _lib.stream_ptr())
         return g[0], g[1], g[2], g[3], None, g[4], None, None, None
+
+
+class _ReparamSample(torch.autograd.Function):
+    """z = mu + sigma * eps with eps ~ N(0, 1) drawn inside the launch (csrc/sample.hip) instead of randn_like + addcmul
+    (five launches inside a captured step, with the generator's offset fills); backward: (g, g * eps)."""
+
+    @staticmethod
+    def forward(ctx, mu, sigma):
+        mu, sigma = _c(mu), _c(sigma)
+        eps, z = torch.empty_like(sigma), torch.empty_like(sigma)
+        _lib.call("cgv_reparam_sample", _lib.ptr(mu), _lib.ptr(sigma), _lib.ptr(eps), _lib.ptr(z), sigma.numel(),
+                  _lib.ptr(_rng_block(sigma.device)), _lib.stream_ptr())
+        ctx.save_for_backward(eps)
+        return z
+
+    @staticmethod
+    def backward(ctx, g):
+        (eps,) = ctx.saved_tensors
+        return g, g * eps
+
+
+_RNG = {}
+
+
+def _rng_block(device) -> torch.Tensor:
+    """{seed, draw number, ticket} of the device-side generator of ``reparam_sample``: seeded from torch's default
+    generator on first use (``torch.manual_seed`` before the first step fixes the stream), advanced by the launches."""
+    device = torch.device(device)
+    t = _RNG.get(device)
+    if t is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+        t = _RNG[device] = torch.tensor([seed, 0, 0], dtype=torch.int64, device=device)
+    return t
+
+
+def reparam_sample(mu, sigma):
+    """cgvae.py:445-449 with device-drawn noise, one launch."""
+    return _ReparamSample.apply(mu, sigma)
+
+
+_UNIT_SEED = {}          # device -> data_ptr of the registered constant-1 seed
+_UNIT_SEED_KEEP = {}     # device -> the tensor (kept alive: its address identifies it)
+
+
+def unit_seed(device) -> torch.Tensor:
+    """A persistent scalar 1.0 on ``device`` to seed ``torch.autograd.backward(loss, grad_tensors=unit_seed(dev))`` with:
+    ``_Elbo.backward`` recognises it by address and returns the forward launch's gradients without scaling them by 1
+    (``loss.backward()`` costs a ones_like fill and the scale launch per step)."""
+    device = torch.device(device)
+    t = _UNIT_SEED_KEEP.get(device)
+    if t is None:
+        t = _UNIT_SEED_KEEP[device] = torch.ones((), dtype=_F32, device=device)
+        _UNIT_SEED[device] = t.data_ptr()
+    return t
 
 
 def elbo_loss(mu, sigma, prior_mu, prior_std, xyz, xyz_recon, bonds, beta, gamma):

@@ -728,7 +728,11 @@ class Trainer:
             if self.exchange is not None:
                 self.exchange.begin_step()
             with wgrad_queue.collect():          # bead-level weight gradients: queued, then ONE grouped launch
-                loss.backward()
+                if loss.is_cuda:
+                    from .ops import unit_seed
+                    torch.autograd.backward(loss, grad_tensors=unit_seed(loss.device))      # no ones_like fill, no scale launch
+                else:
+                    loss.backward()
             mark("backward:encoder+prior")
             self._flush_queue(use_ex, rank=train and self.fused and self.sync is None)
             mark("weight-gradients")

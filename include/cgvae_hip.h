@@ -185,6 +185,12 @@ int cgv_segment_reduce(const float* src, const int32_t* rowptr, const int32_t* p
 /* backward of the above: gsrc[perm?perm[p]:p, :] = gout[seg(p), :] (* 1/max(len,1) if mean) */
 int cgv_segment_broadcast(const float* gout, const int32_t* rowptr, const int32_t* perm, int n_seg, int channels,
                           int mean, float* gsrc /*[n_rows,C]*/, void* stream);
+/* CGequiVAE.reparametrize (cgvae.py:445-449: eps = randn_like(sigma); z = mu + eps * sigma) with the noise drawn in the
+ * launch: z = mu + sigma * eps, eps ~ N(0, 1) from Philox4x32-10 + Box-Muller, stored (the backward pass needs it:
+ * dz/dsigma = eps).  rng: 3 x uint64 in device memory {seed, draw number, 0}; the launch advances the draw number, so a
+ * replayed hipGraph draws fresh noise each step.  Same distribution as torch.randn_like, different numbers: runs that
+ * must reproduce a given eps pass it in and do not call this. */
+int cgv_reparam_sample(const float* mu, const float* sigma, float* eps, float* z, int64_t n, uint64_t* rng, void* stream);
 /* nn.Embedding lookup (cgvae.py:268, 381) with the ids read from a float column (nxyz[:, 0], element stride id_stride):
  * out[i, :] = weight[(int) ids[i * id_stride], :]; ids are clamped to [0, n_types). */
 int cgv_embedding_rows(const float* weight /*[n_types,C]*/, const float* ids_f32, int id_stride, int n_rows, int n_types,

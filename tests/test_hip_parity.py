@@ -1502,3 +1502,40 @@ def test_in_place_batch_update_by_job_tables_is_bit_exact():
             out_held = model(held)
         for x, y in zip(out_held, out_fresh):
             assert torch.equal(x, y)
+
+
+def test_reparam_sample_draws_standard_normals_in_the_launch():
+    """cgv_reparam_sample: z = mu + sigma * eps with eps drawn in the launch (Philox4x32-10 + Box-Muller): moments and
+    tails of a standard normal, a fresh draw per launch, the same draw for the same {seed, draw number}, eps stored, and
+    the backward of the autograd wrapper."""
+    from coarsegrainingvae_amd import ops
+    n = 1 << 20
+    mu = torch.randn(n, device=DEV)
+    sigma = torch.rand(n, device=DEV) + 0.5
+    rng = torch.tensor([1234567, 0, 0], dtype=torch.int64, device=DEV)
+    eps, z = torch.empty_like(mu), torch.empty_like(mu)
+    call = lambda e, zz, r: cg._lib.call("cgv_reparam_sample", cg._lib.ptr(mu), cg._lib.ptr(sigma), cg._lib.ptr(e), cg._lib.ptr(zz),
+                                         n, cg._lib.ptr(r), cg._lib.stream_ptr())
+    call(eps, z, rng)
+    torch.cuda.synchronize()
+    assert rng.tolist() == [1234567, 1, 0]                               # draw number advanced, ticket re-armed
+    assert torch.allclose(z, mu + eps * sigma, rtol=1e-6, atol=1e-6)     # one fma here, mul + add there
+    e = eps.double()
+    assert abs(float(e.mean())) < 4e-3 and abs(float(e.var()) - 1.0) < 6e-3
+    assert abs(float((e ** 3).mean())) < 2e-2 and abs(float((e ** 4).mean()) - 3.0) < 5e-2
+    assert 0.6815 < float((e.abs() < 1).double().mean()) < 0.6840 and 0.0024 < float((e.abs() > 3).double().mean()) < 0.0030
+    assert abs(float((e[:-1] * e[1:]).mean())) < 4e-3 and abs(float((e[:-4:4] * e[2::4][:e[:-4:4].numel()]).mean())) < 8e-3
+    eps2, z2 = torch.empty_like(mu), torch.empty_like(mu)
+    call(eps2, z2, rng)                                                  # next draw
+    assert not torch.equal(eps2, eps) and abs(float((eps2.double() * e).mean())) < 4e-3
+    rng_again = torch.tensor([1234567, 0, 0], dtype=torch.int64, device=DEV)
+    eps3, z3 = torch.empty_like(mu), torch.empty_like(mu)
+    call(eps3, z3, rng_again)
+    assert torch.equal(eps3, eps) and torch.equal(z3, z)                 # same seed, same draw number: same numbers
+    m = torch.randn(12, 600, device=DEV, requires_grad=True)
+    s = (torch.rand(12, 600, device=DEV) + 0.5).requires_grad_()
+    out = ops.reparam_sample(m, s)
+    g = torch.randn_like(out)
+    gm, gs = torch.autograd.grad(out, (m, s), g)
+    eps_used = (out.detach() - m.detach()) / s.detach()
+    assert torch.equal(gm, g) and torch.allclose(gs, g * eps_used, rtol=1e-4, atol=1e-5)
