@@ -88,6 +88,8 @@ PROTOTYPES = {
     "cgv_decoder_slice_floats": (C.c_int64, [_i, _i]),
     "cgv_batch_load_rows": (_i, [_p, _p, _p, _i, _p, _p, _p, _i, _p]),
     "cgv_reparam_sample": (_i, [_p, _p, _p, _p, C.c_int64, _p, _p]),
+    "cgv_pair_linear_fwd": (_i, [_p] * 10 + [_i] * 5 + [_p]),
+    "cgv_pair_linear_bwd_input": (_i, [_p] * 6 + [_i, _i, _p, _p, _i, _i, _i, _p, C.c_size_t, _p]),
     "cgv_decoder_max_edges": (_i, []),
     "cgv_decoder_block_channels": (_i, [_i]),
     "cgv_decoder_debug_clock": (_i, [_p]),

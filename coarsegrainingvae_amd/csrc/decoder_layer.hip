@@ -673,6 +673,39 @@ __global__ __launch_bounds__(DL_THREADS) void dec_dense_fwd_k(const float* __res
   DL_SPAN(K > N ? 3 : 0, 1);
 }
 
+// Two Dense layers of one shape in one launch (blockIdx.y picks the layer): the mu / sigma heads are independent of each
+// other (cgvae.py:366-371, 502-503); x may be the same for both.
+struct DensePair {
+  const float* x[2]; const float* W[2]; const float* bias[2];
+  float* y[2]; float* z[2];
+  int act[2];
+};
+__global__ __launch_bounds__(DL_THREADS) void dec_dense_fwd_pair_k(DensePair p, int n, int N, int K) {
+  Carve cv;
+  float* red = cv.take(fwd_red_floats<1, 1>());
+  float* o_l = cv.take(16 * 4);
+  const int j = blockIdx.y;
+  const float* __restrict__ x = p.x[j];
+  const float* __restrict__ W = p.W[j];
+  float* __restrict__ y = p.y[j];
+  float* __restrict__ zout = p.z[j];
+  const int act = p.act[j];
+  const int n0 = blockIdx.x * DL_CB;
+  const int row0[1] = {n0};
+  const bool mine = threadIdx.x < n * 4;
+  const int i = threadIdx.x >> 2, c = threadIdx.x & 3;
+  const gcf bias = launder(p.bias[j]);
+  const float b = (mine && bias) ? ldg_pinned(bias + n0 + c) : 0.f;
+  pin_loads();
+  if (K <= 16 * DL_WAVES * 5) fwd_core<1, 1, 5>(o_l, red, x, n, K, W, row0);
+  else fwd_core<1, 1, 9>(o_l, red, x, n, K, W, row0);
+  if (mine) {
+    const float zv = o_l[i * 4 + c] + b;
+    const size_t at = (size_t)i * N + n0 + c;
+    if (act) { if (zout) zout[at] = zv; y[at] = act_fwd(zv, act); } else y[at] = zv;
+  }
+}
+
 // ============================================================================================== F3: [U | Vv] + norm
 __global__ __launch_bounds__(DL_THREADS) void dec_uv_fwd_k(const float* __restrict__ rows, const float* __restrict__ Wuv,
                                                            float* __restrict__ UV, float* __restrict__ stack, int n, int F) {
@@ -1234,6 +1267,18 @@ int cgv_decoder_dense_fwd(const float* x, const float* W, const float* bias, flo
   hipLaunchKernelGGL(cgv::dec_dense_fwd_k, dim3(N / cgv::DL_CB), dim3(cgv::DL_THREADS), cgv::lds_bytes(cgv::fwd_red_floats<1, 1>() + 64),
                      (hipStream_t)stream, x, W, bias, y, z, n_nodes, N, K, act);
   return cgv::check_launch("cgv_decoder_dense_fwd");
+}
+
+int cgv_pair_linear_fwd(const float* x0, const float* x1, const float* W0, const float* W1, const float* bias0,
+                        const float* bias1, float* y0, float* y1, float* z0, float* z1, int act0, int act1, int n_rows, int N,
+                        int K, void* stream) {
+  CGV_REQUIRE(x0 && x1 && W0 && W1 && y0 && y1, "null pointer");
+  CGV_REQUIRE(act0 >= 0 && act0 <= cgv::CGV_ACT_MAX && act1 >= 0 && act1 <= cgv::CGV_ACT_MAX, "unknown activation");
+  CGV_REQUIRE(n_rows >= 1 && n_rows <= cgv::DL_MAX_NODES && (N % 4) == 0 && (K % 4) == 0 && N >= 4 && K >= 4, "unsupported shape");
+  cgv::DensePair p{{x0, x1}, {W0, W1}, {bias0, bias1}, {y0, y1}, {z0, z1}, {act0, act1}};
+  hipLaunchKernelGGL(cgv::dec_dense_fwd_pair_k, dim3(N / cgv::DL_CB, 2), dim3(cgv::DL_THREADS),
+                     cgv::lds_bytes(cgv::fwd_red_floats<1, 1>() + 64), (hipStream_t)stream, p, n_rows, N, K);
+  return cgv::check_launch("cgv_pair_linear_fwd");
 }
 
 int cgv_decoder_uv_fwd(const float* rows, const float* Wuv, float* UV, float* stack, int n_nodes, int n_feat, void* stream) {

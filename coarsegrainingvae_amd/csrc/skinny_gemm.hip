@@ -140,16 +140,17 @@ constexpr int BI_LD = 68;         // LDS row stride of the g stage
 // LAZY: gy arrives as row-slice partial sums of the product that produced it (SliceSum: no reduction launch in
 // between); the kt = 0 blocks also write the summed g[:, their rows] to g_dense (the weight-gradient launch reads it).
 template <int MB, bool LAZY = false>
-__global__ __launch_bounds__(256) void skinny_bwd_input_k(const float* __restrict__ gy, const float* __restrict__ z,
-                                                          const float* __restrict__ W, float* __restrict__ gx,
-                                                          float* __restrict__ part, int M, int N, int K, int act, int KT,
-                                                          int NS, int rpb, SliceSum gsum = SliceSum{nullptr, nullptr, 0, 0},
-                                                          float* __restrict__ g_dense = nullptr) {
+__device__ __forceinline__ void skinny_bwd_input_body(const int bx /* block index within the problem */,
+                                                      const float* __restrict__ gy, const float* __restrict__ z,
+                                                      const float* __restrict__ W, float* __restrict__ gx,
+                                                      float* __restrict__ part, int M, int N, int K, int act, int KT,
+                                                      int NS, int rpb, SliceSum gsum = SliceSum{nullptr, nullptr, 0, 0},
+                                                      float* __restrict__ g_dense = nullptr) {
   // g stage [16 MB rows][BI_LD], then the wave reduction: up to 4 row blocks all three partner waves deposit at once,
   // beyond that (MB 5..8: 65-128 rows) one wave at a time through a third of the space
   constexpr int SM_RED = (MB <= 4 ? 3 : 1) * MB * 16 * 64, SM_G = MB * 16 * BI_LD;
   __shared__ __attribute__((aligned(16))) float sm[SM_RED > SM_G ? SM_RED : SM_G];
-  const int kt = blockIdx.x % KT, ns = blockIdx.x / KT;
+  const int kt = bx % KT, ns = bx / KT;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 15, q = lane >> 4;
@@ -300,6 +301,28 @@ __global__ __launch_bounds__(256) void skinny_bwd_input_k(const float* __restric
       const int m = mb * 16 + 4 * q + r;
       if (m < M) *reinterpret_cast<float4*>(gx + (size_t)m * K + kcol) = tot[mb][r];
     }
+}
+
+template <int MB, bool LAZY = false>
+__global__ __launch_bounds__(256) void skinny_bwd_input_k(const float* __restrict__ gy, const float* __restrict__ z,
+                                                          const float* __restrict__ W, float* __restrict__ gx,
+                                                          float* __restrict__ part, int M, int N, int K, int act, int KT,
+                                                          int NS, int rpb, SliceSum gsum = SliceSum{nullptr, nullptr, 0, 0},
+                                                          float* __restrict__ g_dense = nullptr) {
+  skinny_bwd_input_body<MB, LAZY>(blockIdx.x, gy, z, W, gx, part, M, N, K, act, KT, NS, rpb, gsum, g_dense);
+}
+
+// Two products of one shape in one launch (blockIdx.y picks the problem): the two heads of an MLP pair (mu / sigma:
+// cgvae.py:366-371) are independent of each other, as separate launches they are two more dependent links in the chain.
+struct BiPair {
+  const float* gy[2]; const float* z[2]; const float* W[2];
+  float* gx[2]; float* part[2];
+  int act[2];
+};
+template <int MB>
+__global__ __launch_bounds__(256) void skinny_bwd_input_pair_k(BiPair p, int M, int N, int K, int KT, int NS, int rpb) {
+  const int y = blockIdx.y;
+  skinny_bwd_input_body<MB, false>(blockIdx.x, p.gy[y], p.z[y], p.W[y], p.gx[y], p.part[y], M, N, K, p.act[y], KT, NS, rpb);
 }
 
 // gx[i] = sum_p part[p][i] (i over M*K/4 float4s), p ascending: deterministic.  4 lanes share one output
@@ -1084,6 +1107,33 @@ __global__ __launch_bounds__(1024) void dense_grad_prepare_k(const float* __rest
   }
 }
 
+// the reduction launch of a pair with two outputs: blockIdx.y picks (partials, output)
+__global__ __launch_bounds__(256) void skinny_bwd_input_reduce_pair_k(const float* __restrict__ part0, const float* __restrict__ part1,
+                                                                      float* __restrict__ gx0, float* __restrict__ gx1, int n4, int NS) {
+  const float* part = blockIdx.y ? part1 : part0;
+  float* gx = blockIdx.y ? gx1 : gx0;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int i = t >> 2, sub = t & 3;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4) {
+    const float4* p4 = reinterpret_cast<const float4*>(part) + i;
+    constexpr int RB = 8;
+    for (int p0 = sub; p0 < NS; p0 += 4 * RB) {
+      float4 v[RB];
+#pragma unroll
+      for (int u = 0; u < RB; ++u) v[u] = p4[(size_t)min(p0 + 4 * u, NS - 1) * (size_t)n4];
+#pragma unroll
+      for (int u = 0; u < RB; ++u) {
+        const bool ok = p0 + 4 * u < NS;
+        acc.x += ok ? v[u].x : 0.f; acc.y += ok ? v[u].y : 0.f; acc.z += ok ? v[u].z : 0.f; acc.w += ok ? v[u].w : 0.f;
+      }
+    }
+  }
+  acc.x += __shfl_xor(acc.x, 1); acc.y += __shfl_xor(acc.y, 1); acc.z += __shfl_xor(acc.z, 1); acc.w += __shfl_xor(acc.w, 1);
+  acc.x += __shfl_xor(acc.x, 2); acc.y += __shfl_xor(acc.y, 2); acc.z += __shfl_xor(acc.z, 2); acc.w += __shfl_xor(acc.w, 2);
+  if (i < n4 && sub == 0) reinterpret_cast<float4*>(gx)[i] = acc;
+}
+
 template <int MB>
 static void launch_fwd(dim3 grid, int waves, hipStream_t st, const float* x, const float* W, const float* bias, float* y,
                        float* z, int M, int N, int K, int act) {
@@ -1166,6 +1216,42 @@ int cgv_skinny_linear_bwd_input(const float* gy, const float* z, const float* W,
     default: cgv::launch_bwd_input<8>(st, gy, z, W, gx, part, M, N, K, act, KT, NS, rpb); break;
   }
   return cgv::check_launch("cgv_skinny_linear_bwd_input");
+}
+
+/* Two backward-input products of ONE shape in one launch pair (+ one reduction launch): gx_j = (gy_j * act_j'(z_j)) W_j for
+ * j = 0, 1 -- or, with gx1 == NULL, their SUM in gx0 (two layers that read the same input: the gradient accumulation is
+ * part of the reduction).  M <= 64 rows.  ws: 2 x cgv_skinny_bwd_input_workspace_bytes(M, N, K). */
+int cgv_pair_linear_bwd_input(const float* gy0, const float* gy1, const float* z0, const float* z1, const float* W0,
+                              const float* W1, int act0, int act1, float* gx0, float* gx1, int M, int N, int K, void* ws,
+                              size_t ws_bytes, void* stream) {
+  CGV_REQUIRE(gy0 && gy1 && W0 && W1 && gx0 && ws, "null pointer");
+  CGV_REQUIRE((act0 == 0 || (act0 >= 1 && act0 <= cgv::CGV_ACT_MAX && z0)) && (act1 == 0 || (act1 >= 1 && act1 <= cgv::CGV_ACT_MAX && z1)),
+              "act != 0 needs the saved pre-activation z");
+  CGV_REQUIRE(cgv_skinny_bwd_input_supported(M, N, K) && M <= 64, "unsupported shape (need M <= 64, N % 4 == 0, K % 4 == 0)");
+  CGV_REQUIRE(((((uintptr_t)gx0) | ((uintptr_t)gx1) | ((uintptr_t)W0) | ((uintptr_t)W1) | ((uintptr_t)ws)) & 15) == 0, "16-byte alignment");
+  hipStream_t st = (hipStream_t)stream;
+  int KT, NS, rpb;
+  cgv::bwd_input_plan(N, K, true, &KT, &NS, &rpb);
+  const size_t one = sizeof(float) * (size_t)NS * M * K;
+  CGV_REQUIRE(ws_bytes >= 2 * one, "workspace too small");
+  float* part0 = reinterpret_cast<float*>(ws);
+  float* part1 = part0 + (size_t)NS * M * K;
+  // partial products always go through the workspace (also at NS == 1): the reduction launch writes / sums the outputs
+  cgv::BiPair p{{gy0, gy1}, {z0, z1}, {W0, W1}, {nullptr, nullptr}, {part0, part1}, {act0, act1}};
+  const dim3 grid(KT * NS, 2);
+  switch ((M + 15) / 16) {
+    case 1: hipLaunchKernelGGL((cgv::skinny_bwd_input_pair_k<1>), grid, dim3(256), 0, st, p, M, N, K, KT, NS, rpb); break;
+    case 2: hipLaunchKernelGGL((cgv::skinny_bwd_input_pair_k<2>), grid, dim3(256), 0, st, p, M, N, K, KT, NS, rpb); break;
+    case 3: hipLaunchKernelGGL((cgv::skinny_bwd_input_pair_k<3>), grid, dim3(256), 0, st, p, M, N, K, KT, NS, rpb); break;
+    default: hipLaunchKernelGGL((cgv::skinny_bwd_input_pair_k<4>), grid, dim3(256), 0, st, p, M, N, K, KT, NS, rpb); break;
+  }
+  const int n4 = M * K / 4;
+  if (gx1)
+    hipLaunchKernelGGL(cgv::skinny_bwd_input_reduce_pair_k, dim3((4 * n4 + 255) / 256, 2), dim3(256), 0, st, part0, part1, gx0,
+                       gx1, n4, NS);
+  else        // one output: the 2 NS slices of both problems are adjacent in the workspace
+    hipLaunchKernelGGL(cgv::skinny_bwd_input_reduce_k, dim3((4 * n4 + 255) / 256), dim3(256), 0, st, part0, gx0, n4, 2 * NS);
+  return cgv::check_launch("cgv_pair_linear_bwd_input");
 }
 
 /* Row slicing of the split product for this shape: n_slices partial matrices of slice_floats = M * K floats each. */

@@ -19,7 +19,7 @@ from .ktimer import mark
 from .blocks import (ContractiveMessageBlock, EquiMessageBlock, EquiMessageCross, EquiMessagePsuedo, PseudoUpdateBlock,
                      UpdateBlock)
 from .graph import BatchGraph, EdgePlan, make_directed
-from .primitives import ACT_STD_ENC, ACT_STD_PRIOR, Dense, DistanceEmbed, Linear, MLPHead, mark_direct_grad, to_module
+from .primitives import ACT_STD_ENC, ACT_STD_PRIOR, Dense, DistanceEmbed, Linear, MLPHead, dual_heads, mark_direct_grad, to_module
 
 
 def _call_then_pass(fn):
@@ -232,9 +232,12 @@ class CGprior(nn.Module):
         v = _constant((h.shape[0], h.shape[1], 3), 0.0, h.device)
         for blk in self.message_blocks:
             h, v = blk(h, v, None, nbrs, plan=plan, geom=geom, residual=True)      # h += ds, v += dv fused (cgvae.py:391-392)
+        if isinstance(self.sigma, MLPHead) and isinstance(self.mu, MLPHead):
+            # layer j of both heads in one launch, forward and backward; 1e-9 + exp(. / 2) in the product's epilogue (cgvae.py:401)
+            return dual_heads(self.mu, self.sigma, h, out_act_b=ACT_STD_PRIOR)
         H_mu = self.mu(h)
         if isinstance(self.sigma, MLPHead):
-            H_std = self.sigma(h, out_act=ACT_STD_PRIOR)              # 1e-9 + exp(. / 2) in the product's epilogue (cgvae.py:401)
+            H_std = self.sigma(h, out_act=ACT_STD_PRIOR)
         else:
             H_std = 1e-9 + torch.exp(self.sigma(h) / 2)
         return H_mu, H_std
@@ -374,11 +377,14 @@ class CGequiVAE(nn.Module):
             H_prior_mu, H_prior_sigma = self.prior_net(cg_z, cg_xyz, CG_nbr_list, graph=graph)
         else:
             H_prior_mu, H_prior_sigma = None, None
-        mu = self.atom_munet(S_I)
-        if isinstance(self.atom_sigmanet, MLPHead):
-            sigma = self.atom_sigmanet(S_I, out_act=ACT_STD_ENC)      # 1e-12 + exp(logvar / 2) fused (cgvae.py:502-503)
+        if isinstance(self.atom_sigmanet, MLPHead) and isinstance(self.atom_munet, MLPHead):
+            mu, sigma = dual_heads(self.atom_munet, self.atom_sigmanet, S_I, out_act_b=ACT_STD_ENC)   # 1e-12 + exp(logvar / 2) fused (cgvae.py:502-503)
         else:
-            sigma = 1e-12 + torch.exp(self.atom_sigmanet(S_I) / 2)
+            mu = self.atom_munet(S_I)
+            if isinstance(self.atom_sigmanet, MLPHead):
+                sigma = self.atom_sigmanet(S_I, out_act=ACT_STD_ENC)
+            else:
+                sigma = 1e-12 + torch.exp(self.atom_sigmanet(S_I) / 2)
         z_sample = S_I if self.det else self.reparametrize(mu, sigma, eps)
         mark("forward:prior+heads+sample")
         layer_hooks = None

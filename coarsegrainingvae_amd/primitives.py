@@ -369,6 +369,98 @@ class _LinearFn(torch.autograd.Function):
         return gx, gw, gb, None
 
 
+class _PairLinearFn(torch.autograd.Function):
+    """(act_a(x_a W_a^T + b_a), act_b(x_b W_b^T + b_b)) for two Dense layers of ONE shape with at most 16 rows, as one
+    forward launch and one backward-input launch pair (``cgv_pair_linear_fwd`` / ``cgv_pair_linear_bwd_input``) -- the two
+    heads of a (mu, sigma) pair are independent of each other; as separate layers they are 2 + 4 launches and, when both
+    read the same input, an accumulation add.  Weight / bias gradients go to the trainer's grouped queue exactly as
+    ``_LinearFn`` sends them."""
+
+    @staticmethod
+    def forward(ctx, x_a, x_b, w_a, b_a, w_b, b_b, act_a, act_b):
+        xa = x_a.reshape(-1, x_a.shape[-1]).contiguous()
+        xb = xa if x_b is x_a else x_b.reshape(-1, x_b.shape[-1]).contiguous()
+        M, K = xa.shape
+        N = w_a.shape[0]
+        ya, yb = torch.empty(M, N, dtype=torch.float32, device=xa.device), torch.empty(M, N, dtype=torch.float32, device=xa.device)
+        za = torch.empty_like(ya) if act_a else None
+        zb = torch.empty_like(yb) if act_b else None
+        _lib.call("cgv_pair_linear_fwd", _lib.ptr(xa), _lib.ptr(xb), _lib.ptr(w_a), _lib.ptr(w_b), _lib.ptr(b_a), _lib.ptr(b_b),
+                  _lib.ptr(ya), _lib.ptr(yb), _lib.ptr(za), _lib.ptr(zb), int(act_a), int(act_b), M, N, K, _lib.stream_ptr())
+        ctx.params = (w_a, b_a, w_b, b_b)
+        ctx.acts = (int(act_a), int(act_b))
+        ctx.same_x = x_b is x_a
+        ctx.save_for_backward(xa, xb, w_a, w_b, za, zb)
+        return ya.reshape(x_a.shape[:-1] + (N,)), yb.reshape(x_b.shape[:-1] + (N,))
+
+    @staticmethod
+    def backward(ctx, g_a, g_b):
+        xa, xb, wa, wb, za, zb = ctx.saved_tensors
+        pa_w, pa_b, pb_w, pb_b = ctx.params
+        act_a, act_b = ctx.acts
+        M, K = xa.shape
+        N = wa.shape[0]
+        ga = (g_a if g_a is not None else torch.zeros(M, N, dtype=torch.float32, device=xa.device)).reshape(M, N).contiguous()
+        gb = (g_b if g_b is not None else torch.zeros(M, N, dtype=torch.float32, device=xa.device)).reshape(M, N).contiguous()
+        need_xa, need_xb = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        gxa = gxb = None
+        if need_xa or need_xb:
+            lib = _lib.load()
+            nbytes = 2 * int(lib.cgv_skinny_bwd_input_workspace_bytes(M, N, K)) or 2 * 4 * M * K
+            nbytes = max(nbytes, 2 * 4 * M * K)                   # a single row slice still travels through the workspace
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=xa.device)
+            gxa = torch.empty(M, K, dtype=torch.float32, device=xa.device)
+            gxb = None if ctx.same_x else torch.empty(M, K, dtype=torch.float32, device=xa.device)
+            _lib.call("cgv_pair_linear_bwd_input", _lib.ptr(ga), _lib.ptr(gb), _lib.ptr(za), _lib.ptr(zb), _lib.ptr(wa), _lib.ptr(wb),
+                      act_a, act_b, _lib.ptr(gxa), _lib.ptr(gxb), M, N, K, ws.data_ptr(), nbytes, _lib.stream_ptr())
+        grads_w = []
+        for g2, x2, z, act, w_param, b_param, need_w, need_b in (
+                (ga, xa, za, act_a, pa_w, pa_b, ctx.needs_input_grad[2], pa_b is not None and ctx.needs_input_grad[3]),
+                (gb, xb, zb, act_b, pb_w, pb_b, ctx.needs_input_grad[4], pb_b is not None and ctx.needs_input_grad[5])):
+            gw = gbias = None
+            if need_w:
+                w_param._cgv_exch = w_param._cgv_rank = (M, N, K)
+                if b_param is not None:
+                    b_param._cgv_exch = (M, N, K)
+                tw, acc_w, gw = _grad_target(w_param, w_param)
+                tb, acc_b, gbias = _grad_target(b_param, b_param) if need_b else (None, acc_w, None)
+                if tb is not None and acc_b != acc_w:
+                    raise RuntimeError("weight and bias of one layer disagree on first-write / accumulate state")
+                wgrad_queue.enqueue(g2, x2, z if act != ACT_NONE else None, act, tw, tb, acc_w)
+                if not (wgrad_queue.active and gw is None and gbias is None):
+                    wgrad_queue.flush()
+            grads_w += [gw, gbias]
+        shape_a = None if gxa is None else gxa.reshape(xa.shape)
+        return (shape_a if need_xa else None, (gxb if need_xb else None), grads_w[0], grads_w[1], grads_w[2], grads_w[3], None, None)
+
+
+def pair_linear_usable(x_a, x_b, lin_a, lin_b) -> bool:
+    """Two nn.Linear / Dense layers that ``_PairLinearFn`` takes: device tensors, one shape, at most 16 rows."""
+    if not (x_a.is_cuda and x_a.dtype == torch.float32 and x_b.dtype == torch.float32 and x_a.shape == x_b.shape):
+        return False
+    wa, wb = lin_a.weight, lin_b.weight
+    if wa.shape != wb.shape or (lin_a.bias is None) != (lin_b.bias is None):
+        return False
+    M = x_a.numel() // x_a.shape[-1]
+    N, K = wa.shape
+    return 1 <= M <= 16 and N % 4 == 0 and K % 4 == 0 and N >= 64 and x_a.shape[-1] == K and wa.is_contiguous() and wb.is_contiguous()
+
+
+def dual_heads(head_a, head_b, x, out_act_a: int = ACT_NONE, out_act_b: int = ACT_NONE):
+    """``(head_a(x), head_b(x, out_act))`` for two ``MLPHead``s of one shape (the mu / sigma heads: cgvae.py:366-371 applied
+    as in cgvae.py:500-503 and 226-229) with layer j of both heads in ONE launch, forward and backward."""
+    ma, mb = list(head_a), list(head_b)
+    codes = MLPHead._CODES
+    if (len(ma) == 3 and len(mb) == 3 and isinstance(ma[0], nn.Linear) and isinstance(mb[0], nn.Linear)
+            and type(ma[1]) in codes and type(mb[1]) in codes and isinstance(ma[2], nn.Linear) and isinstance(mb[2], nn.Linear)
+            and pair_linear_usable(x, x, ma[0], mb[0])):
+        ha, hb = _PairLinearFn.apply(x, x, ma[0].weight, ma[0].bias, mb[0].weight, mb[0].bias, codes[type(ma[1])], codes[type(mb[1])])
+        if pair_linear_usable(ha, hb, ma[2], mb[2]):
+            return _PairLinearFn.apply(ha, hb, ma[2].weight, ma[2].bias, mb[2].weight, mb[2].bias, out_act_a, out_act_b)
+        return _LinearFn.apply(ha, ma[2].weight, ma[2].bias, out_act_a), _LinearFn.apply(hb, mb[2].weight, mb[2].bias, out_act_b)
+    return head_a(x, out_act=out_act_a), head_b(x, out_act=out_act_b)
+
+
 def wgrad_tile(shapes) -> int:
     """Output tile edge of one grouped MFMA weight-gradient launch: 64.  The 128 x 128 variant (gathered_wgrad128_k: half
     the operand traffic per gW element, 3 instead of 5 blocks per CU) measured slower on every workload -- gathered

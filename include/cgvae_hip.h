@@ -185,6 +185,18 @@ int cgv_segment_reduce(const float* src, const int32_t* rowptr, const int32_t* p
 /* backward of the above: gsrc[perm?perm[p]:p, :] = gout[seg(p), :] (* 1/max(len,1) if mean) */
 int cgv_segment_broadcast(const float* gout, const int32_t* rowptr, const int32_t* perm, int n_seg, int channels,
                           int mean, float* gsrc /*[n_rows,C]*/, void* stream);
+/* The two heads of a (mu, sigma) pair -- nn.Sequential(Linear, act, Linear) each, cgvae.py:366-371 / run_ala.py:184-189,
+ * applied to the same features (cgvae.py:500-503, 226-229) -- as PAIRS of launches: layer j of both heads in one launch
+ * (two Dense layers of one shape; x0 may equal x1), forward and backward-input, instead of one launch (forward) or two
+ * (backward: row-split product + reduction) per layer.  Rows <= 16 (forward) / 64 (backward).  With gx1 == NULL the
+ * backward returns the SUM of both products in gx0 (both layers read the same input: autograd's accumulation add is
+ * part of the reduction launch).  ws: 2 x cgv_skinny_bwd_input_workspace_bytes(M, N, K). */
+int cgv_pair_linear_fwd(const float* x0, const float* x1, const float* W0, const float* W1, const float* bias0,
+                        const float* bias1, float* y0, float* y1, float* z0, float* z1, int act0, int act1, int n_rows, int N,
+                        int K, void* stream);
+int cgv_pair_linear_bwd_input(const float* gy0, const float* gy1, const float* z0, const float* z1, const float* W0,
+                              const float* W1, int act0, int act1, float* gx0, float* gx1, int M, int N, int K, void* ws,
+                              size_t ws_bytes, void* stream);
 /* CGequiVAE.reparametrize (cgvae.py:445-449: eps = randn_like(sigma); z = mu + eps * sigma) with the noise drawn in the
  * launch: z = mu + sigma * eps, eps ~ N(0, 1) from Philox4x32-10 + Box-Muller, stored (the backward pass needs it:
  * dz/dsigma = eps).  rng: 3 x uint64 in device memory {seed, draw number, 0}; the launch advances the draw number, so a

@@ -1539,3 +1539,26 @@ def test_reparam_sample_draws_standard_normals_in_the_launch():
     gm, gs = torch.autograd.grad(out, (m, s), g)
     eps_used = (out.detach() - m.detach()) / s.detach()
     assert torch.equal(gm, g) and torch.allclose(gs, g * eps_used, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("M,N,K,same_x,acts", [(12, 600, 600, True, (2, 2)), (12, 600, 600, False, (0, 4)), (7, 64, 132, True, (3, 3)),
+                                                (16, 128, 64, False, (1, 0)), (12, 600, 1200, True, (2, 5))])
+def test_pair_linear_equals_two_linear_layers(M, N, K, same_x, acts):
+    """_PairLinearFn (layer j of a mu / sigma head pair in one launch, forward and backward-input) against two
+    _LinearFn calls: outputs, input gradients (summed when both read the same input), weight / bias gradients."""
+    from coarsegrainingvae_amd.primitives import _LinearFn, _PairLinearFn
+    g = torch.Generator(device=DEV).manual_seed(M * 1000 + N + K)
+    mk = lambda *s: torch.randn(*s, device=DEV, generator=g)
+    xa = mk(M, K).requires_grad_()
+    xb = xa if same_x else mk(M, K).requires_grad_()
+    wa, wb = (0.05 * mk(N, K)).requires_grad_(), (0.05 * mk(N, K)).requires_grad_()
+    ba, bb = mk(N).requires_grad_(), mk(N).requires_grad_()
+    ga, gb = mk(M, N), mk(M, N)
+    ya, yb = _PairLinearFn.apply(xa, xb, wa, ba, wb, bb, acts[0], acts[1])
+    ins = (xa, wa, ba, wb, bb) if same_x else (xa, xb, wa, ba, wb, bb)
+    got = torch.autograd.grad((ya, yb), ins, (ga, gb))
+    ra, rb = _LinearFn.apply(xa, wa, ba, acts[0]), _LinearFn.apply(xb, wb, bb, acts[1])
+    want = torch.autograd.grad((ra, rb), ins, (ga, gb))
+    assert rel_err(ya, ra) <= 1e-6 and rel_err(yb, rb) <= 1e-6
+    for a, b in zip(got, want):
+        assert rel_err(a, b) <= 2e-6, (a.shape, rel_err(a, b))
