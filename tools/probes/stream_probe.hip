@@ -143,6 +143,15 @@ int main() {
   const int chain = 90;
   float t0 = chain_us([&](int) { hipLaunchKernelGGL(tiny_k, dim3(150), dim3(576), 0, st, out); }, chain, 5, st);
   printf("%-64s %7.2f us per launch\n", "empty kernel, 150 x 576 (boundary)", t0);
+  {
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(tiny_k), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    struct { int blocks, threads, lds; } cfg[] = {{1, 64, 0}, {75, 576, 0}, {150, 256, 0}, {256, 256, 0}, {150, 1024, 0}, {1024, 256, 0},
+                                                  {150, 576, 64 * 1024}, {150, 576, 120 * 1024}, {150, 576, 150 * 1024}};
+    for (auto& c : cfg) {
+      float t = chain_us([&](int) { hipLaunchKernelGGL(tiny_k, dim3(c.blocks), dim3(c.threads), c.lds, st, out); }, chain, 5, st);
+      printf("empty kernel, %4d x %4d, %3d KB dynamic LDS                       %7.2f us per launch\n", c.blocks, c.threads, c.lds / 1024, t);
+    }
+  }
   size_t cursor = 0;
   auto buf = [&](size_t floats) { if (cursor + floats > pool_floats) cursor = 0; float* p = pool + cursor; cursor += floats; return p; };
 #define RUN(NLOAD, PATTERN, NT, BLOCKS, ROWS, LABEL)                                                                    \
