@@ -89,6 +89,10 @@ PROTOTYPES = {
     "cgv_batch_load_rows": (_i, [_p, _p, _p, _i, _p, _p, _p, _i, _p]),
     "cgv_reparam_sample": (_i, [_p, _p, _p, _p, C.c_int64, _p, _p]),
     "cgv_pair_linear_fwd": (_i, [_p] * 10 + [_i] * 5 + [_p]),
+    "cgv_equi_msg_bwd_deferred": (_i, [_p] * 11 + [_i, _i, _i, C.c_int64, C.c_int64, _p, C.c_size_t, _p, _p, _p]),
+    "cgv_filter_reduce_jobs_max": (_i, []),
+    "cgv_filter_reduce_job_bytes": (_i, []),
+    "cgv_filter_reduce_jobs": (_i, [_p, _i, _p]),
     "cgv_pair_linear_bwd_input": (_i, [_p] * 6 + [_i, _i, _p, _p, _i, _i, _i, _p, C.c_size_t, _p]),
     "cgv_decoder_max_edges": (_i, []),
     "cgv_decoder_block_channels": (_i, [_i]),

@@ -25,6 +25,7 @@
 // gathers stay inside a few frames and its phi/v working set fits the 4 MiB L2); on high-degree
 // graphs the 4 waves of a block split one node's segment and meet in LDS.
 #include <stdlib.h>
+#include <cstring>
 #include "cgv_common.h"
 #include "equi_msg_dev.h"
 
@@ -611,6 +612,45 @@ __global__ __launch_bounds__(64 * RED_SLICES) void equi_msg_bwd_reduce(const flo
   if (n < R) gWd[(size_t)c_out * R + n] = tot; else gbd[c_out] = tot;
 }
 
+// The same second stage for SEVERAL backward launches at once (blockIdx.z = 3 job + kk): the filter gradients are wanted
+// by the optimiser only, so a training step defers the second stages of all its message blocks (7 on the chignolin
+// config, one ~3 us link each in the backward chain) to one launch at the end of backward.
+constexpr int FR_MAX = 16;
+struct FilterReduceJob { const float* part; float* gWd; float* gbd; int n_chunks, K, R, F; };
+struct FilterReduceJobs { int n, pad; FilterReduceJob job[FR_MAX]; };
+__global__ __launch_bounds__(64 * RED_SLICES) void equi_msg_bwd_reduce_jobs_k(FilterReduceJobs J) {
+  __shared__ float red[RED_SLICES][64];
+  const int jz = blockIdx.z / 3, kk = blockIdx.z - 3 * jz;
+  const FilterReduceJob& q = J.job[jz];
+  const int F = q.F, R = q.R, K = q.K, n_chunks = q.n_chunks;
+  const int f = blockIdx.x * 64 + threadIdx.x;
+  const int s = threadIdx.y;
+  const int n = blockIdx.y;        // 0..R  (R = bias)
+  if (n > R) return;               // (block-uniform)
+  const int k = (K == 3) ? kk : (kk == 1 ? 0 : -1);
+  float acc = 0.f;
+  if (k >= 0 && f < F) {
+    const size_t stride = (size_t)K * (R + 1) * F;
+    const float* p = q.part + ((size_t)k * (R + 1) + n) * F + f;
+    constexpr int CB = 8;
+    for (int c0 = s; c0 < n_chunks; c0 += RED_SLICES * CB) {
+      float v[CB];
+#pragma unroll
+      for (int u = 0; u < CB; ++u) v[u] = p[(size_t)min(c0 + RED_SLICES * u, n_chunks - 1) * stride];
+#pragma unroll
+      for (int u = 0; u < CB; ++u) acc += c0 + RED_SLICES * u < n_chunks ? v[u] : 0.f;
+    }
+  }
+  red[s][threadIdx.x] = acc;
+  __syncthreads();
+  if (s != 0 || f >= F) return;
+  float tot = 0.f;
+#pragma unroll
+  for (int w = 0; w < RED_SLICES; ++w) tot += red[w][threadIdx.x];
+  const int c_out = kk * F + f;
+  if (n < R) q.gWd[(size_t)c_out * R + n] = tot; else q.gbd[c_out] = tot;
+}
+
 constexpr int BWD_MAX_CHUNKS = 384;
 
 struct BwdShape {
@@ -695,12 +735,63 @@ size_t cgv_equi_msg_bwd_workspace_bytes(int n_src, int n_feat, int n_rbf) {
   return sizeof(float) * (size_t)(cgv::BWD_MAX_CHUNKS + 8) * 3 * (n_rbf + 1) * n_feat + 256;
 }
 
+static int equi_msg_bwd_impl(const float* phi, const float* v, const float* geom_s, const int32_t* rowptr_s,
+                             const int32_t* dst_s, const float* Wd, const float* bd, const float* gs, const float* gv,
+                             float* g_phi, float* g_v, float* gWd, float* gbd, int n_src, int n_feat, int n_rbf,
+                             int64_t n_edges_hint, int64_t n_rows_hint, void* workspace, size_t workspace_bytes, void* stream,
+                             int* n_chunks_out, int* k_live_out);
+
 int cgv_equi_msg_bwd(const float* phi, const float* v, const float* geom_s, const int32_t* rowptr_s,
                      const int32_t* dst_s, const float* Wd, const float* bd, const float* gs, const float* gv,
                      float* g_phi, float* g_v, float* gWd, float* gbd, int n_src, int n_feat, int n_rbf,
                      int64_t n_edges_hint, int64_t n_rows_hint, void* workspace, size_t workspace_bytes, void* stream) {
+  CGV_REQUIRE(gWd && gbd, "null pointer");
+  return equi_msg_bwd_impl(phi, v, geom_s, rowptr_s, dst_s, Wd, bd, gs, gv, g_phi, g_v, gWd, gbd, n_src, n_feat, n_rbf,
+                           n_edges_hint, n_rows_hint, workspace, workspace_bytes, stream, nullptr, nullptr);
+}
+
+/* cgv_equi_msg_bwd without its second stage: g_phi / g_v are final, the filter gradients stay as per-chunk partial sums
+ * in `workspace` (which must then live until cgv_filter_reduce_jobs has consumed it); *n_chunks / *k_live describe them. */
+int cgv_equi_msg_bwd_deferred(const float* phi, const float* v, const float* geom_s, const int32_t* rowptr_s,
+                              const int32_t* dst_s, const float* Wd, const float* bd, const float* gs, const float* gv,
+                              float* g_phi, float* g_v, int n_src, int n_feat, int n_rbf, int64_t n_edges_hint,
+                              int64_t n_rows_hint, void* workspace, size_t workspace_bytes, int* n_chunks, int* k_live,
+                              void* stream) {
+  CGV_REQUIRE(n_chunks && k_live, "null pointer");
+  return equi_msg_bwd_impl(phi, v, geom_s, rowptr_s, dst_s, Wd, bd, gs, gv, g_phi, g_v, nullptr, nullptr, n_src, n_feat, n_rbf,
+                           n_edges_hint, n_rows_hint, workspace, workspace_bytes, stream, n_chunks, k_live);
+}
+
+int cgv_filter_reduce_jobs_max(void) { return cgv::FR_MAX; }
+int cgv_filter_reduce_job_bytes(void) { return (int)sizeof(cgv::FilterReduceJob); }
+
+/* The deferred second stages of up to cgv_filter_reduce_jobs_max() message-block backward launches in one launch.
+ * jobs_host: n records laid out as cgv::FilterReduceJob {part, gWd, gbd, n_chunks, K (live slices: 1 or 3), R, F}. */
+int cgv_filter_reduce_jobs(const void* jobs_host, int n_jobs, void* stream) {
+  CGV_REQUIRE(jobs_host && n_jobs >= 1 && n_jobs <= cgv::FR_MAX, "bad job table");
+  cgv::FilterReduceJobs J;
+  std::memset(static_cast<void*>(&J), 0, sizeof(J));
+  std::memcpy(static_cast<void*>(J.job), jobs_host, sizeof(cgv::FilterReduceJob) * (size_t)n_jobs);
+  J.n = n_jobs;
+  int fmax = 0, rmax = 0;
+  for (int j = 0; j < n_jobs; ++j) {
+    const cgv::FilterReduceJob& q = J.job[j];
+    CGV_REQUIRE(q.part && q.gWd && q.gbd && q.n_chunks >= 1 && (q.K == 1 || q.K == 3) && q.R >= 1 && q.F >= 1, "bad job");
+    fmax = q.F > fmax ? q.F : fmax;
+    rmax = q.R > rmax ? q.R : rmax;
+  }
+  dim3 rgrid((fmax + 63) / 64, rmax + 1, 3 * n_jobs);
+  hipLaunchKernelGGL(cgv::equi_msg_bwd_reduce_jobs_k, rgrid, dim3(64, cgv::RED_SLICES), 0, (hipStream_t)stream, J);
+  return cgv::check_launch("cgv_filter_reduce_jobs");
+}
+
+static int equi_msg_bwd_impl(const float* phi, const float* v, const float* geom_s, const int32_t* rowptr_s,
+                             const int32_t* dst_s, const float* Wd, const float* bd, const float* gs, const float* gv,
+                             float* g_phi, float* g_v, float* gWd, float* gbd, int n_src, int n_feat, int n_rbf,
+                             int64_t n_edges_hint, int64_t n_rows_hint, void* workspace, size_t workspace_bytes, void* stream,
+                             int* n_chunks_out, int* k_live_out) {
   CGV_REQUIRE(n_src >= 0 && n_feat > 0, "bad size");
-  CGV_REQUIRE(phi && rowptr_s && Wd && bd && g_phi && gWd && gbd && workspace, "null pointer");
+  CGV_REQUIRE(phi && rowptr_s && Wd && bd && g_phi && workspace, "null pointer");
   CGV_REQUIRE(!gv || (v && g_v), "gv needs v and g_v");
   if (workspace_bytes < cgv_equi_msg_bwd_workspace_bytes(n_src, n_feat, n_rbf)) {
     cgv::set_error("cgv_equi_msg_bwd: workspace too small");
@@ -728,6 +819,11 @@ int cgv_equi_msg_bwd(const float* phi, const float* v, const float* geom_s, cons
 #undef CGV_BWD_PICK
 #undef CGV_BWD_LAUNCH
   // chunks beyond sh.chunks (padding to a multiple of 8) still write zero partials: sum them all
+  if (n_chunks_out) {                    // deferred second stage (cgv_filter_reduce_jobs)
+    *n_chunks_out = 8 * sh.cpx;
+    *k_live_out = gv ? 3 : 1;
+    return cgv::check_launch("cgv_equi_msg_bwd_deferred");
+  }
   dim3 rgrid((n_feat + 63) / 64, n_rbf + 1, 3);
   hipLaunchKernelGGL(cgv::equi_msg_bwd_reduce, rgrid, dim3(64, cgv::RED_SLICES), 0, st, part, 8 * sh.cpx, gv ? 3 : 1, n_rbf,
                      n_feat, gWd, gbd);

@@ -9,6 +9,8 @@ from __future__ import annotations
 
 from typing import Optional
 
+import ctypes as C
+
 import torch
 
 from . import _lib
@@ -108,6 +110,17 @@ class _EquiMessage(torch.autograd.Function):
         lib = _lib.load()
         ws_bytes = int(lib.cgv_equi_msg_bwd_workspace_bytes(plan.n_src, F, geom.n_rbf))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        from .primitives import wgrad_queue
+        if wgrad_queue.active and ret_W is None and ret_b is None:
+            # under the trainer: the filter gradients feed the optimiser only -- their reduction joins those of the
+            # step's other message blocks in one launch when the queue is flushed (primitives.flush_filters)
+            nc, kl = C.c_int(), C.c_int()
+            _lib.call("cgv_equi_msg_bwd_deferred", _lib.ptr(phi), _lib.ptr(v), _lib.ptr(geom.geom_s), _lib.ptr(plan.rowptr_s),
+                      _lib.ptr(plan.dst_s), _lib.ptr(Wd), _lib.ptr(bd), _lib.ptr(gs), _lib.ptr(gv), _lib.ptr(g_phi), _lib.ptr(g_v),
+                      plan.n_src, F, geom.n_rbf, plan.n_edges, plan.n_dst, _lib.ptr(ws), ws_bytes, C.byref(nc), C.byref(kl),
+                      _lib.stream_ptr(), tag=f"equi_msg_bwd:Nd{plan.n_dst}:E{plan.n_edges}:gv{int(gv is not None)}")
+            wgrad_queue.enqueue_filter(ws, nc.value, kl.value, geom.n_rbf, F, gWd, gbd)
+            return g_phi, g_v, ret_W, ret_b, None, None, None, g_sres, g_vres
         _lib.call("cgv_equi_msg_bwd", _lib.ptr(phi), _lib.ptr(v), _lib.ptr(geom.geom_s), _lib.ptr(plan.rowptr_s),
                   _lib.ptr(plan.dst_s), _lib.ptr(Wd), _lib.ptr(bd), _lib.ptr(gs), _lib.ptr(gv), _lib.ptr(g_phi),
                   _lib.ptr(g_v), _lib.ptr(gWd), _lib.ptr(gbd), plan.n_src, F, geom.n_rbf, plan.n_edges, plan.n_dst, _lib.ptr(ws), ws_bytes,

@@ -84,6 +84,7 @@ class WeightGradQueue:
         self._captured = []     # (pinned, device) pairs used by the capture in progress (handed over by finish_capture)
         self._capture_slots = []
         self._deferred = []
+        self.filters = []       # deferred second stages of message-block backward launches (enqueue_filter)
 
     @property
     def kernel(self):                   # options.set("wgrad_kernel", 1): MFMA tiles for every problem (A/B switch, see launch())
@@ -117,6 +118,27 @@ class WeightGradQueue:
 
     def flush(self):
         self.launch(self.take())
+        self.flush_filters()
+
+    # -- filter gradients of the message blocks: their per-chunk partial sums are finished in ONE launch per flush
+    def enqueue_filter(self, ws, n_chunks, k_live, n_rbf, F, gWd, gbd):
+        self.filters.append((ws, int(n_chunks), int(k_live), int(n_rbf), int(F), gWd, gbd))
+
+    def flush_filters(self):
+        jobs, self.filters = self.filters, []
+        if not jobs:
+            return
+        lib = _lib.load()
+
+        class Job(C.Structure):
+            _fields_ = [("part", C.c_void_p), ("gWd", C.c_void_p), ("gbd", C.c_void_p), ("n_chunks", C.c_int), ("K", C.c_int),
+                        ("R", C.c_int), ("F", C.c_int)]
+        assert C.sizeof(Job) == lib.cgv_filter_reduce_job_bytes()
+        cap = int(lib.cgv_filter_reduce_jobs_max())
+        for at in range(0, len(jobs), cap):
+            part = jobs[at:at + cap]
+            table = (Job * len(part))(*[Job(ws.data_ptr(), gW.data_ptr(), gb.data_ptr(), nc, k, r, f) for ws, nc, k, r, f, gW, gb in part])
+            _lib.call("cgv_filter_reduce_jobs", C.addressof(table), len(part), _lib.stream_ptr(), tag="filter_reduce_jobs")
 
     def upload(self, buf: bytes, device):
         """Device copy of a host-built record table.  Inside a stream capture the (pinned, device) pair comes from
@@ -221,6 +243,7 @@ class _QueueScope:
     def __enter__(self):
         self.q.active = True
         self.q.items = []
+        self.q.filters = []
         return self.q
 
     def __exit__(self, *exc):

@@ -808,6 +808,7 @@ class Trainer:
         """Materialise the queued bead-level weight gradients: locally (one grouped launch), or -- data parallel --
         by starting the operand exchange for the layers it pays for (OperandExchange) and launching the rest."""
         items = wgrad_queue.take()
+        wgrad_queue.flush_filters()                 # the message blocks' filter gradients: one reduction launch for all
         if use_exchange:
             exchanged, local = self.exchange.split(items)
             wgrad_queue.launch(local)

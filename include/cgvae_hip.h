@@ -252,6 +252,20 @@ int cgv_equi_msg_bwd(const float* phi, const float* v, const float* geom_s, cons
                      const float* gv /*[Nd,F,3] or NULL*/, float* g_phi, float* g_v, float* gWd, float* gbd,
                      int n_src, int n_feat, int n_rbf, int64_t n_edges_hint, int64_t n_rows_hint, void* workspace,
                      size_t workspace_bytes, void* stream);
+/* The same without its second stage, for a training step that wants the filter gradients only at its end: g_phi / g_v
+ * are final, gWd / gbd stay as per-chunk partial sums in `workspace` (keep it alive) and are finished -- for up to
+ * cgv_filter_reduce_jobs_max() such launches at once -- by cgv_filter_reduce_jobs.  jobs_host: records
+ * {const float* part; float* gWd; float* gbd; int n_chunks, K, R, F;} with part = the launch's workspace, n_chunks /
+ * K = what it returned in *n_chunks / *k_live, R = n_rbf, F = n_feat.  (The filter gradients feed the optimiser only:
+ * their seven reduction launches per chignolin step were seven links in the backward chain.) */
+int cgv_equi_msg_bwd_deferred(const float* phi, const float* v, const float* geom_s, const int32_t* rowptr_s,
+                              const int32_t* dst_s, const float* Wd, const float* bd, const float* gs, const float* gv,
+                              float* g_phi, float* g_v, int n_src, int n_feat, int n_rbf, int64_t n_edges_hint,
+                              int64_t n_rows_hint, void* workspace, size_t workspace_bytes, int* n_chunks, int* k_live,
+                              void* stream);
+int cgv_filter_reduce_jobs_max(void);
+int cgv_filter_reduce_job_bytes(void);
+int cgv_filter_reduce_jobs(const void* jobs_host, int n_jobs, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Per-batch graph work over job tables (csrc/batch_plans.hip): what cgv_csr_build and cgv_edge_geometry[_grouped] do,
