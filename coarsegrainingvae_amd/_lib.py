@@ -88,6 +88,7 @@ PROTOTYPES = {
     "cgv_decoder_slice_floats": (C.c_int64, [_i, _i]),
     "cgv_batch_load_rows": (_i, [_p, _p, _p, _i, _p, _p, _p, _i, _p]),
     "cgv_reparam_sample": (_i, [_p, _p, _p, _p, C.c_int64, _p, _p]),
+    "cgv_reparam_bwd": (_i, [_p, _p, _p, _p, _p, _p, C.c_int64, _p]),
     "cgv_pair_linear_fwd": (_i, [_p] * 10 + [_i] * 5 + [_p]),
     "cgv_equi_msg_bwd_deferred": (_i, [_p] * 11 + [_i, _i, _i, C.c_int64, C.c_int64, _p, C.c_size_t, _p, _p, _p]),
     "cgv_filter_reduce_jobs_max": (_i, []),
@@ -128,7 +129,7 @@ PROTOTYPES = {
     "cgv_reconstruct_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p]),
     "cgv_reconstruct_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p, _p]),
     "cgv_elbo_workspace_bytes": (_sz, [_i, _i]),
-    "cgv_elbo_fwd": (_i, [_p] * 7 + [_i, _i, _i, _i, _f, _f] + [_p] * 6 + [_p, _sz, _p]),
+    "cgv_elbo_fwd": (_i, [_p] * 7 + [_i, _i, _i, _i, _f, _f] + [_p] * 7 + [_p, _sz, _p]),
     "cgv_elbo_scale": (_i, [_p, _p, _p, _p, _p, _i, _p, _i, _p]),
     "cgv_optim_state_floats": (_i, []),
     "cgv_optim_partial_floats": (_i, []),

@@ -127,6 +127,7 @@ __global__ __launch_bounds__(1024) void elbo_fwd(const float* __restrict__ mu, c
                                                  const float* __restrict__ xyz, const float* __restrict__ xr,
                                                  const int64_t* __restrict__ bonds, int n_beads, int F, int n_atoms,
                                                  int n_bonds, float beta, float gamma, float* __restrict__ out /*[4]*/,
+                                                 float* __restrict__ loss_out /*[1] or NULL: a second copy of out[0]*/,
                                                  float* __restrict__ g_mu, float* __restrict__ g_sigma,
                                                  float* __restrict__ g_pmu, float* __restrict__ g_pstd,
                                                  float* __restrict__ g_xr, const double* __restrict__ kl_part,
@@ -258,6 +259,7 @@ __global__ __launch_bounds__(1024) void elbo_fwd(const float* __restrict__ mu, c
   const double gr_val = n_bonds > 0 ? gr / (double)n_bonds : 0.0;
   if (t == 0) {
     out[0] = (float)(rec_val + (double)beta * kl_val + (double)gamma * gr_val);
+    if (loss_out) loss_out[0] = out[0];
     out[1] = (float)kl_val;
     out[2] = (float)rec_val;
     out[3] = gamma != 0.f ? (float)gr_val : 0.f;          // utils.py:134-135: zero when gamma == 0
@@ -290,8 +292,8 @@ size_t cgv_elbo_workspace_bytes(int n_beads, int n_feat) { return sizeof(double)
 
 int cgv_elbo_fwd(const float* mu, const float* sigma, const float* prior_mu, const float* prior_std, const float* xyz,
                  const float* xyz_recon, const int64_t* bonds, int n_beads, int n_feat, int n_atoms, int n_bonds,
-                 float beta, float gamma, float* out4, float* g_mu, float* g_sigma, float* g_prior_mu, float* g_prior_std,
-                 float* g_xyz_recon, void* workspace, size_t workspace_bytes, void* stream) {
+                 float beta, float gamma, float* out4, float* loss_out, float* g_mu, float* g_sigma, float* g_prior_mu,
+                 float* g_prior_std, float* g_xyz_recon, void* workspace, size_t workspace_bytes, void* stream) {
   CGV_REQUIRE(mu && sigma && prior_mu && prior_std && xyz && xyz_recon && out4, "null input");
   CGV_REQUIRE(g_mu && g_sigma && g_prior_mu && g_prior_std && g_xyz_recon, "null gradient buffer");
   CGV_REQUIRE(n_beads > 0 && n_feat > 0 && n_atoms > 0 && n_bonds >= 0 && (n_bonds == 0 || bonds), "bad size");
@@ -311,7 +313,7 @@ int cgv_elbo_fwd(const float* mu, const float* sigma, const float* prior_mu, con
     hipLaunchKernelGGL(cgv::elbo_kl_k, dim3(nb), dim3(256), 0, st, mu, sigma, prior_mu, prior_std, n_beads * n_feat,
                        0.5f * beta / (float)n_beads, g_mu, g_sigma, g_prior_mu, g_prior_std, part);
   hipLaunchKernelGGL(cgv::elbo_fwd, dim3(1), dim3(1024), 0, st, mu, sigma, prior_mu, prior_std, xyz, xyz_recon, bonds,
-                     n_beads, n_feat, n_atoms, n_bonds, beta, gamma, out4, g_mu, g_sigma, g_prior_mu, g_prior_std,
+                     n_beads, n_feat, n_atoms, n_bonds, beta, gamma, out4, loss_out, g_mu, g_sigma, g_prior_mu, g_prior_std,
                      g_xyz_recon, (const double*)part, nb, (const double*)bond_sum);
   return cgv::check_launch("cgv_elbo_fwd");
 }

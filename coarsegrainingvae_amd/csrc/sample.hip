@@ -68,9 +68,38 @@ __global__ __launch_bounds__(256) void reparam_sample_k(const float* __restrict_
   }
 }
 
+// backward of the above with the KL term's gradients folded in: g_mu = g + k_mu, g_sigma = g * eps + k_sigma
+// (k_* = d(beta KL)/d{mu, sigma} from the ELBO launch; as separate autograd contributions they cost a mul and two adds)
+__global__ __launch_bounds__(256) void reparam_bwd_k(const float4* __restrict__ g, const float4* __restrict__ eps,
+                                                     const float4* __restrict__ k_mu, const float4* __restrict__ k_sigma,
+                                                     float4* __restrict__ g_mu, float4* __restrict__ g_sigma, int n4) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const float4 a = g[i], e = eps[i], km = k_mu[i], ks = k_sigma[i];
+  g_mu[i] = make_float4(a.x + km.x, a.y + km.y, a.z + km.z, a.w + km.w);
+  g_sigma[i] = make_float4(__fadd_rn(__fmul_rn(a.x, e.x), ks.x), __fadd_rn(__fmul_rn(a.y, e.y), ks.y),
+                           __fadd_rn(__fmul_rn(a.z, e.z), ks.z), __fadd_rn(__fmul_rn(a.w, e.w), ks.w));
+}
+
 }  // namespace cgv
 
 extern "C" {
+
+/* g_mu = g + k_mu, g_sigma = g * eps + k_sigma over n floats (n % 4 == 0, 16-byte aligned): the backward of
+ * cgv_reparam_sample with the KL gradients of the ELBO launch (cgv_elbo_fwd's g_mu / g_sigma) added in the same launch. */
+int cgv_reparam_bwd(const float* g, const float* eps, const float* k_mu, const float* k_sigma, float* g_mu, float* g_sigma,
+                    int64_t n, void* stream) {
+  CGV_REQUIRE(n >= 0 && n < (1ll << 31) && (n % 4) == 0, "bad size (need n % 4 == 0)");
+  if (n == 0) return 0;
+  CGV_REQUIRE(g && eps && k_mu && k_sigma && g_mu && g_sigma, "null pointer");
+  CGV_REQUIRE(((((uintptr_t)g | (uintptr_t)eps | (uintptr_t)k_mu | (uintptr_t)k_sigma | (uintptr_t)g_mu | (uintptr_t)g_sigma)) & 15) == 0,
+              "16-byte alignment");
+  const int n4 = (int)(n / 4);
+  hipLaunchKernelGGL(cgv::reparam_bwd_k, dim3((n4 + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float4*>(g), reinterpret_cast<const float4*>(eps), reinterpret_cast<const float4*>(k_mu),
+                     reinterpret_cast<const float4*>(k_sigma), reinterpret_cast<float4*>(g_mu), reinterpret_cast<float4*>(g_sigma), n4);
+  return cgv::check_launch("cgv_reparam_bwd");
+}
 
 /* z = mu + sigma * eps with eps ~ N(0, 1) drawn in the launch and stored (n floats each).  rng: 3 x uint64 in device
  * memory {seed, draw number, 0}; the launch advances the draw number by one.  Launches that share an rng block must be

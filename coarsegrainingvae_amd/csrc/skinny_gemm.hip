@@ -403,6 +403,22 @@ __device__ __forceinline__ size_t wg_row(const WgradProblem& pr, int m, int widt
   return (size_t)seg * pr.seg_stride + (size_t)(m - seg * pr.seg_rows) * width;
 }
 
+// The record of this block: block_begin is ascending, so the index is the number of records that begin at or before
+// blockIdx.x, minus one -- every lane reads one record's block_begin (64 records per round trip) and a ballot counts.
+// (The binary search this replaces was log2(n) DEPENDENT global loads in front of every block's work: 6 at the 57
+// problems of a chignolin step.)
+template <typename Problem>
+__device__ __forceinline__ int wg_find_problem(const Problem* __restrict__ table, int n_problems) {
+  const int lane = threadIdx.x & 63;
+  int count = 0;
+  for (int base = 0; base < n_problems; base += 64) {
+    const int i = base + lane;
+    const int bb = i < n_problems ? table[i].block_begin : 0x7fffffff;
+    count += __popcll(__ballot(bb <= (int)blockIdx.x));
+  }
+  return __builtin_amdgcn_readfirstlane(count > 0 ? count - 1 : 0);
+}
+
 // Rank update (ADAM = true): the tile of gW is never stored -- it goes, clipped, straight into the Adam update of the
 // weights it belongs to.  A bead-level layer sees M = 12 rows against 0.36 - 3.2 M weights: its gradient g^T x has rank
 // <= 12 and costs 12 FMAs per weight to form, against 12 bytes per weight to write it, read it for the norm and read it
@@ -423,11 +439,7 @@ __global__ __launch_bounds__(256) void grouped_wgrad_t(const WgradProblem* __res
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (ADAM && ra.state[ST_SKIP] != 0.f) return;              // skipped step (utils.py:145): parameters stay
   // locate the problem of this block (table is tiny; block_begin ascending)
-  int lo = 0, hi = n_problems - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (table[mid].block_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
-  }
+  const int lo = wg_find_problem(table, n_problems);
   const WgradProblem pr = table[lo];
   const int local = blockIdx.x - pr.block_begin;
   const int rb = local / pr.tiles_k, kt = local - rb * pr.tiles_k;
@@ -745,11 +757,7 @@ __global__ __launch_bounds__(256) void gathered_wgrad_k(const WgradProblem* __re
   __shared__ __attribute__((aligned(16))) float gs[GW_CHUNK * GW_GS];
   __shared__ __attribute__((aligned(16))) float xs[GW_CHUNK * GW_XS];
   if (MODE == GW_ADAM && ra.state[ST_SKIP] != 0.f) return;    // skipped step (utils.py:145): parameters stay
-  int lo = 0, hi = n_problems - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (table[mid].block_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
-  }
+  const int lo = wg_find_problem(table, n_problems);
   const WgradProblem pr = table[lo];
   const int local = blockIdx.x - pr.block_begin;
   const int nb = local / pr.tiles_k, kt = local - nb * pr.tiles_k;
@@ -910,11 +918,7 @@ constexpr int GW2_GS = 144, GW2_XS = 128;
 __global__ __launch_bounds__(256) void gathered_wgrad128_k(const WgradProblem* __restrict__ table, int n_problems) {
   __shared__ __attribute__((aligned(16))) float gs[GW2_CHUNK * GW2_GS];
   __shared__ __attribute__((aligned(16))) float xs[GW2_CHUNK * GW2_XS];
-  int lo = 0, hi = n_problems - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (table[mid].block_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
-  }
+  const int lo = wg_find_problem(table, n_problems);
   const WgradProblem pr = table[lo];
   const int local = blockIdx.x - pr.block_begin;
   const int nb = local / pr.tiles_k, kt = local - nb * pr.tiles_k;
@@ -1022,11 +1026,7 @@ static_assert(sizeof(PackProblem) == 64, "host/device record layout");
 constexpr int PACK_F4_PER_BLOCK = 1024;
 
 __global__ __launch_bounds__(256) void pack_operands_k(const PackProblem* __restrict__ table, int n_problems) {
-  int lo = 0, hi = n_problems - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (table[mid].block_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
-  }
+  const int lo = wg_find_problem(table, n_problems);
   const PackProblem pr = table[lo];
   const int ng4 = pr.M * pr.N / 4, nx4 = pr.M * pr.K / 4;
   const int base = (blockIdx.x - pr.block_begin) * PACK_F4_PER_BLOCK;

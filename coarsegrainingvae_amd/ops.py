@@ -544,7 +544,7 @@ class _Elbo(torch.autograd.Function):
     """(loss, KL, recon, graph) of scripts/utils.py:117-141 in one launch; gradients come from the same launch."""
 
     @staticmethod
-    def forward(ctx, mu, sigma, pmu, pstd, xyz, xyz_recon, bonds, beta, gamma):
+    def forward(ctx, mu, sigma, pmu, pstd, xyz, xyz_recon, bonds, beta, gamma, slot=None):
         mu, sigma, pmu, pstd, xyz, xr = (_c(t) for t in (mu, sigma, pmu, pstd, xyz, xyz_recon))
         bonds = bonds.contiguous()
         if bonds.dtype != torch.int64:
@@ -552,29 +552,36 @@ class _Elbo(torch.autograd.Function):
         n_beads, F = mu.shape
         n_atoms = xr.shape[0]
         out = torch.empty(4, dtype=_F32, device=mu.device)
+        loss = torch.empty((), dtype=_F32, device=mu.device)        # the differentiable output, written by the same launch
         grads = [torch.empty_like(t) for t in (mu, sigma, pmu, pstd, xr)]
         nbytes = int(_lib.load().cgv_elbo_workspace_bytes(n_beads, F))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=mu.device) if nbytes else None
         _lib.call("cgv_elbo_fwd", _lib.ptr(mu), _lib.ptr(sigma), _lib.ptr(pmu), _lib.ptr(pstd), _lib.ptr(xyz), _lib.ptr(xr),
                   _lib.ptr(bonds) if bonds.shape[0] else None, n_beads, F, n_atoms, bonds.shape[0], float(beta),
-                  float(gamma), _lib.ptr(out), *[_lib.ptr(g) for g in grads], _lib.ptr(ws), nbytes, _lib.stream_ptr())
+                  float(gamma), _lib.ptr(out), _lib.ptr(loss), *[_lib.ptr(g) for g in grads], _lib.ptr(ws), nbytes, _lib.stream_ptr())
         ctx.grads = grads
+        ctx.slot = slot
         ctx.mark_non_differentiable(out)
-        loss = out[0].clone()
         return loss, out
 
     @staticmethod
     def backward(ctx, g_loss, _g_terms):
         g = ctx.grads
         ctx.grads = None
+        slot, ctx.slot = ctx.slot, None
+        # with a slot, d loss / d{mu, sigma} travel to the reparametrisation's backward (which adds them to its own
+        # contribution in one launch) instead of to autograd's accumulation
+        to_autograd = (lambda: (g[0], g[1])) if slot is None else (lambda: (None, None))
+        if slot is not None:
+            slot.g_mu, slot.g_sigma = g[0], g[1]
         if g_loss.data_ptr() == _UNIT_SEED.get(g_loss.device):
             # the caller seeded backward with its registered constant 1 (unit_seed): the gradients of the forward launch
             # are final as they are -- no scale launch, and no ones_like fill in front of it
-            return g[0], g[1], g[2], g[3], None, g[4], None, None, None
+            return to_autograd() + (g[2], g[3], None, g[4], None, None, None, None)
         gl = _c(g_loss.reshape(1))
         _lib.call("cgv_elbo_scale", _lib.ptr(gl), _lib.ptr(g[0]), _lib.ptr(g[1]), _lib.ptr(g[2]), _lib.ptr(g[3]),
                   g[0].numel(), _lib.ptr(g[4]), g[4].numel(), _lib.stream_ptr())
-        return g[0], g[1], g[2], g[3], None, g[4], None, None, None
+        return to_autograd() + (g[2], g[3], None, g[4], None, None, None, None)
 
 
 class _ReparamSample(torch.autograd.Function):
@@ -582,18 +589,38 @@ class _ReparamSample(torch.autograd.Function):
     (five launches inside a captured step, with the generator's offset fills); backward: (g, g * eps)."""
 
     @staticmethod
-    def forward(ctx, mu, sigma):
+    def forward(ctx, mu, sigma, slot):
         mu, sigma = _c(mu), _c(sigma)
         eps, z = torch.empty_like(sigma), torch.empty_like(sigma)
         _lib.call("cgv_reparam_sample", _lib.ptr(mu), _lib.ptr(sigma), _lib.ptr(eps), _lib.ptr(z), sigma.numel(),
                   _lib.ptr(_rng_block(sigma.device)), _lib.stream_ptr())
         ctx.save_for_backward(eps)
+        ctx.slot = slot
         return z
 
     @staticmethod
     def backward(ctx, g):
         (eps,) = ctx.saved_tensors
-        return g, g * eps
+        slot, ctx.slot = ctx.slot, None
+        if slot is not None and slot.g_mu is not None and g.numel() % 4 == 0:
+            # the ELBO launch left its KL gradients of mu / sigma here instead of returning them to autograd: one launch
+            # for g + k_mu and g * eps + k_sigma (the separate contributions cost a mul and two accumulation adds)
+            g = _c(g)
+            k_mu, k_sigma, slot.g_mu, slot.g_sigma = slot.g_mu, slot.g_sigma, None, None
+            g_mu, g_sigma = torch.empty_like(g), torch.empty_like(g)
+            _lib.call("cgv_reparam_bwd", _lib.ptr(g), _lib.ptr(eps), _lib.ptr(k_mu), _lib.ptr(k_sigma), _lib.ptr(g_mu),
+                      _lib.ptr(g_sigma), g.numel(), _lib.stream_ptr())
+            return g_mu, g_sigma, None
+        return g, g * eps, None
+
+
+class _KLSlot:
+    """Hand-over of d(beta KL)/d{mu, sigma} from the ELBO launch to the backward of the reparametrisation that consumed
+    the same mu / sigma (attached to ``mu`` by ``reparam_sample``, filled by ``_Elbo.forward``)."""
+    __slots__ = ("g_mu", "g_sigma")
+
+    def __init__(self):
+        self.g_mu = self.g_sigma = None
 
 
 _RNG = {}
@@ -612,7 +639,11 @@ def _rng_block(device) -> torch.Tensor:
 
 def reparam_sample(mu, sigma):
     """cgvae.py:445-449 with device-drawn noise, one launch."""
-    return _ReparamSample.apply(mu, sigma)
+    slot = None
+    if mu.requires_grad and sigma.requires_grad and mu.shape == sigma.shape:
+        slot = _KLSlot()
+        mu._cgv_kl_slot = (slot, sigma)          # elbo_loss(mu, sigma, ...) finds it on the very tensors it is given
+    return _ReparamSample.apply(mu, sigma, slot)
 
 
 _UNIT_SEED = {}          # device -> data_ptr of the registered constant-1 seed
@@ -633,4 +664,8 @@ def unit_seed(device) -> torch.Tensor:
 
 def elbo_loss(mu, sigma, prior_mu, prior_std, xyz, xyz_recon, bonds, beta, gamma):
     """Returns (loss, terms) with terms = [loss, KL, recon, graph] (detached)."""
-    return _Elbo.apply(mu, sigma, prior_mu, prior_std, xyz, xyz_recon, bonds, beta, gamma)
+    slot = None
+    tag = getattr(mu, "_cgv_kl_slot", None)
+    if tag is not None and tag[1] is sigma and torch.is_grad_enabled():
+        slot = tag[0]                              # this (mu, sigma) pair went through reparam_sample: see _KLSlot
+    return _Elbo.apply(mu, sigma, prior_mu, prior_std, xyz, xyz_recon, bonds, beta, gamma, slot)

@@ -203,6 +203,10 @@ int cgv_pair_linear_bwd_input(const float* gy0, const float* gy1, const float* z
  * replayed hipGraph draws fresh noise each step.  Same distribution as torch.randn_like, different numbers: runs that
  * must reproduce a given eps pass it in and do not call this. */
 int cgv_reparam_sample(const float* mu, const float* sigma, float* eps, float* z, int64_t n, uint64_t* rng, void* stream);
+/* Its backward with the KL term's gradients (cgv_elbo_fwd's g_mu / g_sigma: the other consumer of mu and sigma,
+ * scripts/utils.py:121) folded in: g_mu = g + k_mu, g_sigma = g * eps + k_sigma; n % 4 == 0. */
+int cgv_reparam_bwd(const float* g, const float* eps, const float* k_mu, const float* k_sigma, float* g_mu, float* g_sigma,
+                    int64_t n, void* stream);
 /* nn.Embedding lookup (cgvae.py:268, 381) with the ids read from a float column (nxyz[:, 0], element stride id_stride):
  * out[i, :] = weight[(int) ids[i * id_stride], :]; ids are clamped to [0, n_types). */
 int cgv_embedding_rows(const float* weight /*[n_types,C]*/, const float* ids_f32, int id_stride, int n_rows, int n_types,
@@ -543,8 +547,10 @@ int cgv_reconstruct_bwd(const float* g_xyz, const int32_t* rowptr, const int32_t
 size_t cgv_elbo_workspace_bytes(int n_beads, int n_feat);
 int cgv_elbo_fwd(const float* mu, const float* sigma, const float* prior_mu, const float* prior_std, const float* xyz,
                  const float* xyz_recon, const int64_t* bonds, int n_beads, int n_feat, int n_atoms, int n_bonds,
-                 float beta, float gamma, float* out4, float* g_mu, float* g_sigma, float* g_prior_mu, float* g_prior_std,
-                 float* g_xyz_recon, void* workspace /*or NULL*/, size_t workspace_bytes, void* stream);
+                 float beta, float gamma, float* out4, float* loss_out /*[1] or NULL: the loss once more, as a tensor of
+                 its own (an autograd output that is not a view of the non-differentiable terms: saves the clone)*/,
+                 float* g_mu, float* g_sigma, float* g_prior_mu, float* g_prior_std, float* g_xyz_recon,
+                 void* workspace /*or NULL*/, size_t workspace_bytes, void* stream);
 int cgv_elbo_scale(const float* g_loss, float* g_mu, float* g_sigma, float* g_prior_mu, float* g_prior_std, int n_bead_elems,
                    float* g_xyz_recon, int n_atom_elems, void* stream);
 

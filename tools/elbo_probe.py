@@ -16,7 +16,7 @@ def run(n_beads, F, n_atoms, n_bonds, gamma, reps=200):
     st = _lib.stream_ptr()
     def call():
         _lib.call("cgv_elbo_fwd", *(t.data_ptr() for t in (mu, sg, pm, ps, xyz, xr, bonds)), n_beads, F, n_atoms, n_bonds,
-                  1.0, gamma, out.data_ptr(), *(t.data_ptr() for t in gs), None, 0, st)
+                  1.0, gamma, out.data_ptr(), None, *(t.data_ptr() for t in gs), None, 0, st)
     for _ in range(10): call()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); a.record()
