@@ -263,3 +263,49 @@ def test_fused_decoder_loop_equals_per_block_path(workload, frames, F, dec, fat,
         assert abs(a - b) <= 1e-6 * abs(b), (l1, l0)
     assert rel_err(g1, g0) <= 1e-5
     assert float((p1 - p0).abs().max()) <= 2e-2 * 1e-4 * 3 or rel_err(p1, p0) <= 1e-6
+
+
+@pytest.mark.parametrize("n_atoms,n_cgs,frames,F,n_rbf,cg_cutoff,dec", [
+    (64, 16, 1, 64, 10, 50.0, 2),        # 16 bead nodes, fully connected: 240 edges = the staged graph's capacity
+    (64, 8, 2, 864, 10, 50.0, 1),        # widest supported layer (F = 864: 6-slice lane classes in the message backward)
+    (40, 5, 1, 16, 4, 50.0, 2),          # narrowest layer, n_rbf = 4, an odd number of beads
+    (48, 4, 3, 128, 20, 50.0, 2),        # n_rbf = 20 (largest record), 12 nodes in three frames
+    (60, 10, 1, 64, 8, 4.5, 2),          # sparse bead graph: a short cutoff leaves beads with one or two neighbours
+])
+def test_channel_group_decoder_at_its_limits(n_atoms, n_cgs, frames, F, n_rbf, cg_cutoff, dec):
+    """decoder_fused against the per-block path at the edges of cgv_decoder_layer_supported: node / edge capacity, the
+    smallest and the largest width, the smallest and the largest radial basis, a sparse bead graph."""
+    from coarsegrainingvae_amd import decoder_fused
+    name = f"_limits_{n_atoms}_{n_cgs}_{n_rbf}"
+    cg.data.WORKLOADS[name] = dict(n_atoms=n_atoms, n_cgs=n_cgs, box=6.0, atom_cutoff=5.0, cg_cutoff=cg_cutoff, enc_nconv=1,
+                                   dec_nconv=dec, n_rbf=n_rbf, batch=frames, beta=0.05, gamma=10.0)
+    try:
+        w = cg.data.WORKLOADS[name]
+        batch = cg.synthetic_batch(name, n_frames=frames, seed=3, device=DEV)
+        n_beads = batch["CG_nxyz"].shape[0]
+        assert n_beads <= 16
+        eps = [torch.randn(n_beads, F, generator=torch.Generator().manual_seed(k)).to(DEV) for k in range(3)]
+        runs = []
+        for fused in (True, False):
+            model = cg.build_model(F, n_rbf, w["atom_cutoff"], w["cg_cutoff"], 1, dec, n_cgs, seed=11).to(DEV)
+            model.equivaraintconv.fused_loop = fused
+            calls0 = decoder_fused.calls
+            tr = Trainer(model, lr=1e-4, beta=w["beta"], gamma=w["gamma"], rank_update=False)
+            losses, grads = [], None
+            for k in range(3):
+                losses.append(float(tr.step(batch, eps=eps[k])))
+                if k == 1:
+                    grads = tr.arena.g.clone()
+            n_edges = int(batch["_graph"].cg.n_edges)
+            if fused and n_edges >= 1:
+                assert decoder_fused.calls - calls0 == 2, (n_edges, n_beads)      # the channel-group path did run
+            runs.append((losses, grads, tr.arena.p.clone(), n_edges))
+        (l1, g1, p1, n_edges), (l0, g0, p0, _) = runs
+        if (n_cgs, frames) == (16, 1):
+            assert n_edges == 240
+        for a, b in zip(l1, l0):
+            assert abs(a - b) <= 2e-6 * abs(b), (l1, l0)
+        assert rel_err(g1, g0) <= 2e-5
+        assert float((p1 - p0).abs().max()) <= 2e-2 * 1e-4 * 3 or rel_err(p1, p0) <= 1e-6
+    finally:
+        cg.data.WORKLOADS.pop(name, None)
