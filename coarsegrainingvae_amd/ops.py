@@ -630,6 +630,8 @@ def _rng_block(device) -> torch.Tensor:
     """{seed, draw number, ticket} of the device-side generator of ``reparam_sample``: seeded from torch's default
     generator on first use (``torch.manual_seed`` before the first step fixes the stream), advanced by the launches."""
     device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
     t = _RNG.get(device)
     if t is None:
         seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
@@ -655,6 +657,8 @@ def unit_seed(device) -> torch.Tensor:
     ``_Elbo.backward`` recognises it by address and returns the forward launch's gradients without scaling them by 1
     (``loss.backward()`` costs a ones_like fill and the scale launch per step)."""
     device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
     t = _UNIT_SEED_KEEP.get(device)
     if t is None:
         t = _UNIT_SEED_KEEP[device] = torch.ones((), dtype=_F32, device=device)

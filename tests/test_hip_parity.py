@@ -1562,3 +1562,42 @@ def test_pair_linear_equals_two_linear_layers(M, N, K, same_x, acts):
     assert rel_err(ya, ra) <= 1e-6 and rel_err(yb, rb) <= 1e-6
     for a, b in zip(got, want):
         assert rel_err(a, b) <= 2e-6, (a.shape, rel_err(a, b))
+
+
+def test_device_drawn_noise_path_equals_supplied_noise_path():
+    """The training step with the noise drawn inside the reparametrisation launch (cgv_reparam_sample; KL gradients handed
+    to its backward, cgv_reparam_bwd) against the same step with that very noise supplied as ``eps`` (torch.addcmul,
+    separate autograd contributions): same loss, same gradients.  The generator is deterministic in {seed, draw number},
+    so the noise of the first run is drawn again by a direct call."""
+    from coarsegrainingvae_amd import ops
+    from coarsegrainingvae_amd.train import loss_terms
+    w = cg.data.WORKLOADS["chignolin"]
+    F = 64
+    batch = cg.synthetic_batch("chignolin", n_frames=2, seed=9, device=DEV)
+    model = cg.build_model(F, w["n_rbf"], w["atom_cutoff"], w["cg_cutoff"], 1, 2, w["n_cgs"], seed=5).to(DEV)
+    n = batch["CG_nxyz"].shape[0]
+    rng = ops._rng_block(torch.device(DEV))
+    seed, draw = 424242, 7
+    # what the launch will draw for this {seed, draw number}
+    probe = torch.tensor([seed, draw, 0], dtype=torch.int64, device=DEV)
+    zeros, ones = torch.zeros(n * F, device=DEV), torch.ones(n * F, device=DEV)
+    eps, z = torch.empty(n * F, device=DEV), torch.empty(n * F, device=DEV)
+    cg._lib.call("cgv_reparam_sample", cg._lib.ptr(zeros), cg._lib.ptr(ones), cg._lib.ptr(eps), cg._lib.ptr(z), n * F,
+                 cg._lib.ptr(probe), cg._lib.stream_ptr())
+    eps = eps.view(n, F)
+
+    def run(supplied):
+        model.zero_grad(set_to_none=True)
+        rng.copy_(torch.tensor([seed, draw, 0], dtype=torch.int64))
+        out = model(batch, eps=eps if supplied else None)
+        loss, *_ = loss_terms(out, batch, w["beta"], w["gamma"])
+        loss.backward()
+        return float(loss), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    l_dev, g_dev = run(False)
+    assert rng.tolist()[1] == draw + 1                                   # the step did draw
+    l_sup, g_sup = run(True)
+    assert abs(l_dev - l_sup) <= 1e-6 * abs(l_sup)
+    assert g_dev.keys() == g_sup.keys() and len(g_dev) > 30
+    for k in g_sup:
+        assert rel_err(g_dev[k], g_sup[k]) <= 5e-5, k                   # z is one fma there, a rounded product + sum here
