@@ -328,6 +328,8 @@ class _LinearFn(torch.autograd.Function):
         if ctx.mode == "tile":
             if gy2.data_ptr() % 16:
                 gy2 = gy2.clone()
+            if need_w:
+                w_param._cgv_rank = (M, N, K)            # rows of this layer's weight-gradient problem (Trainer: rank update)
             if (need_w and wgrad_queue.active and _is_direct(w_param) and w_param.grad.is_contiguous()
                     and (not need_b or (_is_direct(b_param) and b_param.grad.is_contiguous())) and lib_has_rows(M, N, K)):
                 # under the trainer: no prologue launch -- act'(z) is applied in the operand loads of bwd_input and of the

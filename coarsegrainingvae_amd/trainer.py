@@ -470,7 +470,9 @@ class Trainer:
                     return False
                 if self.sync is not None:
                     return True                                      # FMA-per-row kernel or MFMA tiles, by gathered rows
-                return t[0] <= self.RANK_ROWS_PAY and bool(lib.cgv_rank_update_supported(t[0], t[1], t[2]))
+                if t[0] <= self.RANK_ROWS_PAY and bool(lib.cgv_rank_update_supported(t[0], t[1], t[2])):
+                    return True
+                return self.RANK_ROWS_PAY < t[0] <= self.RANK_ROWS_MFMA and t[1] % 4 == 0 and t[2] % 4 == 0
             live = sorted(live, key=lambda p: 0 if ranked(p) else 1)       # stable: u_mat / v_mat pairs stay adjacent
             n_rank = sum(1 for p in live if ranked(p))
         self.arena = ParamArena(live)
@@ -798,6 +800,14 @@ class Trainer:
     # 241 us for 46 M weights), at 48 rows it is VALU bound (330 us) and only ties with the gathered MFMA launch + the
     # three extra passes over a materialised gradient (profiles/r02c_dp_cost_probe.txt).  The kernels take up to 64.
     RANK_ROWS_PAY = 40
+    # Single process: rows up to which a layer beyond RANK_ROWS_PAY takes the rank update as two passes of the MFMA tile
+    # kernel (norm pass, Adam-epilogue pass: cgv_grouped_wgrad_gathered_sumsq / _adam).  0 = off: measured on the dipeptide
+    # batch (96 bead rows) the second forming of the tiles costs more than the passes over a stored gradient it saves
+    # (2.917 against 2.870 ms per step; weight gradients 378 -> 389 us, optimiser 254 -> 283 us).  The data-parallel path
+    # uses the same two passes for its gathered rows, where they tie with materialising (section 6 of DESIGN.md) and keep
+    # every rank from writing the gradients; tests/test_full_size_parity.py turns this on (128) to pin the path against
+    # the oracle at full size.
+    RANK_ROWS_MFMA = 0
     EARLY_MIN_FLOATS = 1 << 18      # ranges below 1 MiB are not worth a collective of their own: they go at the end
 
     def _padded(self, r):
@@ -830,20 +840,46 @@ class Trainer:
             (ranked if r is not None and r[1] <= self._rank_hi and not it[6] else rest).append(it)
         in_range = [it for it in rest if (self.arena.range_of(it[4]) or (self._rank_hi, 0))[0] < self._rank_hi]
         lib = _lib.load()
-        fits = all(lib.cgv_rank_update_supported(it[0].shape[0], it[0].shape[1], it[1].shape[1]) for it in ranked)
+        self._rank_mfma = None
+        small = [it for it in ranked if it[0].shape[0] <= self.RANK_ROWS_PAY
+                 and lib.cgv_rank_update_supported(it[0].shape[0], it[0].shape[1], it[1].shape[1])]
+        ids = {id(it) for it in small}
+        large = [it for it in ranked if id(it) not in ids]        # more rows (dipeptide: 96, 2000-atom graph: 64): MFMA tiles, two passes
+        fits = all(it[0].shape[0] <= self.RANK_ROWS_MFMA and it[0].shape[1] % 4 == 0 and it[1].shape[1] % 4 == 0 for it in large)
         if in_range or not fits or sum(it[4].numel() for it in ranked) != self._rank_numel:
             self.rank_fallbacks += 1
             return items
-        table, blocks, lds = wgrad_queue.small_table(ranked)
-        need = int(lib.cgv_wgrad_gram_workspace_bytes(len(ranked)))
-        if self._rank_ws is None or self._rank_ws.numel() < need:
-            if torch.cuda.is_current_stream_capturing():
-                raise RuntimeError("run one eager step before capturing (rank-update workspace)")
-            self._rank_ws = torch.empty(need, dtype=torch.uint8, device=self.arena.p.device)
-        rows = max(it[0].shape[0] for it in ranked)
-        _lib.call("cgv_wgrad_gram", _lib.ptr(table), len(ranked), rows, _lib.ptr(self._rank_sumsq), _lib.ptr(self._rank_ws),
-                  self._rank_ws.numel(), _lib.stream_ptr(), tag="wgrad_gram")
-        self._rank_step = (table, len(ranked), blocks, lds, ranked, rows)
+        if small:
+            table, blocks, lds = wgrad_queue.small_table(small)
+            need = int(lib.cgv_wgrad_gram_workspace_bytes(len(small)))
+            if self._rank_ws is None or self._rank_ws.numel() < need:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("run one eager step before capturing (rank-update workspace)")
+                self._rank_ws = torch.empty(need, dtype=torch.uint8, device=self.arena.p.device)
+            rows = max(it[0].shape[0] for it in small)
+            _lib.call("cgv_wgrad_gram", _lib.ptr(table), len(small), rows, _lib.ptr(self._rank_sumsq), _lib.ptr(self._rank_ws),
+                      self._rank_ws.numel(), _lib.stream_ptr(), tag="wgrad_gram")
+            self._rank_step = (table, len(small), blocks, lds, small, rows)
+        if large:
+            rec = wgrad_queue.RECORD
+            tk, nb = C.c_int(), C.c_int()
+            buf, block_begin = bytearray(), 0
+            for gy, x, z, act, gW, gb, _acc in large:
+                M, N = gy.shape
+                K = x.shape[1]
+                if lib.cgv_wgrad_gathered_plan_tile(M, N, K, 0, 64, C.byref(tk), C.byref(nb)) != 0:
+                    raise RuntimeError(lib.cgv_last_error_string().decode())
+                buf += rec.pack(gy.data_ptr(), x.data_ptr(), z.data_ptr() if z is not None else 0, gW.data_ptr(),
+                                gb.data_ptr() if gb is not None else 0, M, N, K, 0, int(act), block_begin, tk.value, 0, 0, 0, 0)
+                block_begin += nb.value
+            table = wgrad_queue.upload(bytes(buf), large[0][0].device)
+            if self._mfma_partial is None or self._mfma_partial.numel() < block_begin:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("run one eager step before capturing (rank-update workspace)")
+                self._mfma_partial = torch.empty(block_begin, dtype=torch.float64, device=large[0][0].device)
+            _lib.call("cgv_grouped_wgrad_gathered_sumsq", _lib.ptr(table), len(large), block_begin, _lib.ptr(self._mfma_partial),
+                      self._rank_sumsq.data_ptr() + 8 * len(small), _lib.stream_ptr(), tag="gathered_wgrad_sumsq")
+            self._rank_mfma = (table, len(large), block_begin, large)
         return rest
 
     def _start_gathered_rank_update(self):

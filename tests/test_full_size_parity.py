@@ -200,8 +200,16 @@ def test_chignolin_bench_configuration_vs_oracle():
 
 def test_dipeptide_32_frames_vs_oracle():
     """BASELINE configs[1]: F=600, 32 frames => 704 atoms, 96 bead rows: the tile GEMMs, the row-split bwd_input on the
-    5400-wide layer and the library-GEMM branches (primitives._library_pays) instead of the skinny kernels."""
-    _full_config_vs_oracle("dipeptide", 32, 600)
+    5400-wide layer and the library-GEMM branches (primitives._library_pays) instead of the skinny kernels.  Its
+    bead-level layers (96 rows) take the rank update as two passes of the MFMA tile kernel: the moments and parameters
+    compared with the oracle's come from gradients that were never stored."""
+    old = Trainer.RANK_ROWS_MFMA
+    Trainer.RANK_ROWS_MFMA = 128                  # off by default in a single process (it does not pay there): pinned here
+    try:
+        tr = _full_config_vs_oracle("dipeptide", 32, 600)
+    finally:
+        Trainer.RANK_ROWS_MFMA = old
+    assert tr._rank_hi > 0 and tr.rank_steps_mfma >= 1 and tr.rank_fallbacks == 0
 
 
 def test_protein2000_reduced_width_vs_oracle():
