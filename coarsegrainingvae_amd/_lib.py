@@ -123,6 +123,11 @@ PROTOTYPES = {
     "cgv_grouped_wgrad_gathered_tile": (_i, [_p, _i, _i, _i, _p]),
     "cgv_grouped_wgrad_gathered_sumsq": (_i, [_p, _i, _i, _p, _p, _p]),
     "cgv_grouped_wgrad_gathered_adam": (_i, [_p, _i, _i, _p, _p, _p, _p, _f, _f, _f, _f, _p, _p]),
+    "cgv_wgrad_strip_max_rows": (_i, []),
+    "cgv_wgrad_strip_plan": (_i, [_i, _i, _i, _i, _p]),
+    "cgv_grouped_wgrad_strip": (_i, [_p, _i, _i, _i, _p]),
+    "cgv_grouped_wgrad_strip_sumsq": (_i, [_p, _i, _i, _i, _p, _p, _p]),
+    "cgv_grouped_wgrad_strip_adam": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _f, _f, _f, _f, _p, _p]),
     "cgv_pack_record_bytes": (_i, []),
     "cgv_pack_plan": (_i, [_i, _i, _i, _p]),
     "cgv_pack_operands": (_i, [_p, _i, _i, _p]),

@@ -909,6 +909,222 @@ __global__ __launch_bounds__(256) void gathered_sumsq_reduce_k(const WgradProble
   if (threadIdx.x == 0) out[pr] = part[0];
 }
 
+// STRIP variant for few operand rows (M <= 128: bead-level layers of a large bead batch, gathered rows of 4 - 8 ranks).
+// gathered_wgrad_k gives every 64 x 64 tile its own block, which stages BOTH operand tiles and spends most of its short
+// life on the problem lookup and the first loads (PMC at 96 rows: MFMA pipe 55 % busy in the norm pass, 39 % in the
+// store pass with act').  Here a block owns a 64-row STRIP of gW: the g columns of those rows are staged (and multiplied
+// by act'(z)) ONCE, then the block walks the strip's K / 64 column tiles with the x tile of the next one loading while
+// the MFMAs of the current one run (two LDS buffers, one barrier per tile).  Same lane maps, same per-element FMA order
+// as gathered_wgrad_k (rows ascending), so results are bit-identical to it.
+constexpr int GS_MAX_ROWS = 128;
+#ifndef CGV_GS_SINGLE_FROM
+#define CGV_GS_SINGLE_FROM 7
+#endif
+// row classes (NP) from which the x tile has ONE LDS buffer (a second barrier per tile, more blocks per CU)
+constexpr int GS_SINGLE_FROM = CGV_GS_SINGLE_FROM;
+// Straight-line staging: every request goes to a valid (clamped) address and is zeroed by a select afterwards -- with
+// predicated loads the compiler builds a branch and a vmcnt(0) per request.  The clobber keeps the requests above the
+// MFMA loop they are meant to travel under (LLVM otherwise sinks them to their first use behind it).
+__device__ __forceinline__ void strip_pin() { asm volatile("" ::: "memory"); }
+// Operand pointers come out of the record (generic address space): as they are, the requests become flat_load, which
+// counts on lgkmcnt as well -- the first LDS wait of the MFMA loop would then wait for the whole next x tile.
+typedef const float __attribute__((address_space(1)))* strip_gptr;
+__device__ __forceinline__ float4 strip_ldg4(const float* p) {
+  const f32x4 t = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>((strip_gptr)p);
+  return make_float4(t.x, t.y, t.z, t.w);
+}
+template <int MODE, int NP>   // NP: staging passes of 16 rows (M <= 16 NP)
+__global__ __launch_bounds__(256) void gathered_wgrad_strip_k(const WgradProblem* __restrict__ table, int n_problems,
+                                                              double* __restrict__ partial, RankUpdateArgs ra) {
+  extern __shared__ __attribute__((aligned(16))) float strip_smem[];
+  constexpr int MP = 16 * NP;
+  float* gs = strip_smem;                              // [MP][GW_GS]
+  constexpr bool DB = NP < GS_SINGLE_FROM;
+  float* xs0 = gs + MP * GW_GS;                        // [MP][GW_XS] x 2
+  float* xs1 = DB ? xs0 + MP * GW_XS : xs0;
+  if (MODE == GW_ADAM && ra.state[ST_SKIP] != 0.f) return;
+  const int lo = wg_find_problem(table, n_problems);
+  const WgradProblem pr = table[lo];
+  const int nb = blockIdx.x - pr.block_begin;
+  const int M = pr.M, N = pr.N, K = pr.K;
+  const int n0 = nb * 64;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, q = lane >> 4;
+  const int c4 = threadIdx.x & 15, rr = threadIdx.x >> 4;          // staging: 16 float4 columns x 16 rows per pass
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  size_t xrow[NP], grow[NP];                                        // operand row offsets (rank segments resolved once, branch-free)
+  bool live[NP];
+  {
+    const int seg_rows = pr.seg_rows > 0 ? pr.seg_rows : 0x7fffffff;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int m = rr + 16 * p;
+      live[p] = m < M;
+      const int mm = live[p] ? m : 0;
+      const int seg = mm / seg_rows, in_seg = mm - seg * seg_rows;
+      xrow[p] = (size_t)seg * pr.seg_stride + (size_t)in_seg * K;
+      grow[p] = (size_t)seg * pr.seg_stride + (size_t)in_seg * N;
+    }
+  }
+  const int tiles_k = (K + 63) / 64;
+  float4 xq[NP];
+  auto x_load = [&](int kt) {
+    const int kc = kt * 64 + 4 * c4;
+    const int col = kc < K ? kc : 0;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) xq[p] = strip_ldg4(pr.x + xrow[p] + col);
+  };
+  auto x_store = [&](float* xs, int kt) {
+    const bool xcol = kt * 64 + 4 * c4 < K;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const bool ok = live[p] && xcol;
+      *reinterpret_cast<float4*>(xs + (rr + 16 * p) * GW_XS + 4 * c4) =
+          make_float4(ok ? xq[p].x : 0.f, ok ? xq[p].y : 0.f, ok ? xq[p].z : 0.f, ok ? xq[p].w : 0.f);
+    }
+  };
+  // ---- the strip's g columns, once
+  {
+    const bool gcol = n0 + 4 * c4 < N;
+    const int col = gcol ? n0 + 4 * c4 : 0;
+    const float* zsrc = pr.act ? pr.z : pr.gy;                      // (no activation: a second look at g instead of a branch)
+    float4 gq[NP], zq[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      gq[p] = strip_ldg4(pr.gy + grow[p] + col);
+      zq[p] = strip_ldg4(zsrc + grow[p] + col);
+    }
+    x_load(0);                                                      // first x tile: arrives while act'(z) is applied
+    strip_pin();
+    if (pr.act == 1) {                                              // Swish: the model's activation, kept free of the switch
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        gq[p].x *= act_bwd(zq[p].x, 1); gq[p].y *= act_bwd(zq[p].y, 1);
+        gq[p].z *= act_bwd(zq[p].z, 1); gq[p].w *= act_bwd(zq[p].w, 1);
+      }
+    } else if (pr.act) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        gq[p].x *= act_bwd(zq[p].x, pr.act); gq[p].y *= act_bwd(zq[p].y, pr.act);
+        gq[p].z *= act_bwd(zq[p].z, pr.act); gq[p].w *= act_bwd(zq[p].w, pr.act);
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const bool ok = live[p] && gcol;
+      *reinterpret_cast<float4*>(gs + (rr + 16 * p) * GW_GS + 4 * c4) =
+          make_float4(ok ? gq[p].x : 0.f, ok ? gq[p].y : 0.f, ok ? gq[p].z : 0.f, ok ? gq[p].w : 0.f);
+    }
+  }
+  x_store(xs0, 0);
+  __syncthreads();
+  double sq = 0.0;
+  for (int kt = 0; kt < tiles_k; ++kt) {
+    const float* xs = (kt & 1) ? xs1 : xs0;
+    const int kcol = kt * 64 + 4 * i;
+    const int kn = kt + 1 < tiles_k ? kt + 1 : kt;                  // (the last trip requests its own tile again: no branch)
+    x_load(kn);                                                     // travels under this tile's MFMAs
+    // Adam: p / m / v of this tile are requested before its MFMAs
+    float4 pp[4], mm[4], vv[4];
+    size_t at0 = 0;
+    if (MODE == GW_ADAM) {
+      at0 = (size_t)(pr.gW - ra.arena_g) + (kcol < K ? kcol : 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = n0 + 16 * wave + 4 * q + r;
+        const size_t o = at0 + (size_t)(row < N ? row : 0) * K;
+        pp[r] = strip_ldg4(ra.arena_p + o);
+        const f4v tm = __builtin_nontemporal_load(reinterpret_cast<const __attribute__((address_space(1))) f4v*>((strip_gptr)(ra.arena_m + o)));
+        const f4v tv = __builtin_nontemporal_load(reinterpret_cast<const __attribute__((address_space(1))) f4v*>((strip_gptr)(ra.arena_v + o)));
+        mm[r] = make_float4(tm.x, tm.y, tm.z, tm.w);
+        vv[r] = make_float4(tv.x, tv.y, tv.z, tv.w);
+      }
+    }
+    strip_pin();
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* ga = gs + q * GW_GS + 16 * wave + i;
+    const float* xb = xs + q * GW_XS + 4 * i;
+    // whole trip count of the row class (rows M .. 16 NP - 1 are zeros in LDS): unrolled, so that the LDS reads are
+    // scheduled ahead of the MFMAs that use them (a rolled loop waits for each pair of reads in front of its MFMAs)
+#pragma unroll
+    for (int st = 0; st < 4 * NP; ++st) {
+      const float a = ga[(4 * st) * GW_GS];
+      const float4 b = *reinterpret_cast<const float4*>(xb + (4 * st) * GW_XS);
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.y, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.z, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.w, acc[3], 0, 0, 0);
+    }
+    // issue order: the reads of two steps, then { 4 MFMAs, the reads of the step after next } -- the scheduler on its own
+    // reuses one register set and waits for every read right in front of its MFMAs
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+    for (int st = 0; st < 4 * NP - 2; ++st) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+    if (kcol < K) {
+      if (MODE == GW_STORE) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = n0 + 16 * wave + 4 * q + r;
+          if (row >= N) continue;
+          float4* dst = reinterpret_cast<float4*>(pr.gW + (size_t)row * K + kcol);
+          float4 o = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+          if (pr.accumulate) { const float4 old = *dst; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+          *dst = o;
+        }
+      } else if (MODE == GW_SUMSQ) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (n0 + 16 * wave + 4 * q + r >= N) continue;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) sq += (double)acc[c][r] * (double)acc[c][r];
+        }
+      } else {
+        const AdamStep a = adam_step_of(ra.state, ra.lr, ra.beta1, ra.beta2, ra.eps);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = n0 + 16 * wave + 4 * q + r;
+          if (row >= N) continue;
+          const size_t o = at0 + (size_t)row * K;
+          adam_elem(a, pp[r].x, acc[0][r], mm[r].x, vv[r].x); adam_elem(a, pp[r].y, acc[1][r], mm[r].y, vv[r].y);
+          adam_elem(a, pp[r].z, acc[2][r], mm[r].z, vv[r].z); adam_elem(a, pp[r].w, acc[3][r], mm[r].w, vv[r].w);
+          *reinterpret_cast<float4*>(ra.arena_p + o) = pp[r];
+          __builtin_nontemporal_store(f4v{mm[r].x, mm[r].y, mm[r].z, mm[r].w}, reinterpret_cast<f4v*>(ra.arena_m + o));
+          __builtin_nontemporal_store(f4v{vv[r].x, vv[r].y, vv[r].z, vv[r].w}, reinterpret_cast<f4v*>(ra.arena_v + o));
+        }
+      }
+    }
+    if (!DB) __syncthreads();
+    x_store((kt & 1) ? xs0 : xs1, kn);                             // that buffer was last read one trip ago, behind a barrier
+    __syncthreads();
+  }
+  if (MODE == GW_SUMSQ) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) sq += __shfl_xor(sq, d);
+    __shared__ double wave_sq[4];
+    if (lane == 0) wave_sq[wave] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (wave_sq[0] + wave_sq[1]) + (wave_sq[2] + wave_sq[3]);
+  }
+  if (MODE != GW_ADAM && pr.gb && threadIdx.x < 64 && n0 + (int)threadIdx.x < N) {   // bias gradient: column sums of the staged strip
+    float b4[4] = {0.f, 0.f, 0.f, 0.f};                            // rows 4 t + q per group q, groups paired as in the tile layout
+    for (int t = 0; t < (M + 3) / 4; ++t) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) b4[g] += gs[(4 * t + g) * GW_GS + threadIdx.x];
+    }
+    const float bsum = (b4[0] + b4[1]) + (b4[2] + b4[3]);
+    float* dst = pr.gb + n0 + threadIdx.x;
+    *dst = pr.accumulate ? *dst + bsum : bsum;
+  }
+}
+
 // The same with 128 x 128 output tiles (waves as a 2 x 2 grid of 64 x 64 quadrants: 4 row tiles x one 64-column group
 // each): every staged operand row feeds twice the MFMAs, so the L2 -> LDS traffic per gW element halves.  Measured
 // SLOWER than the 64 x 64 kernel on every workload (fewer, bigger blocks: 3 per CU; see primitives.wgrad_tile): opt-in.
@@ -1152,6 +1368,28 @@ static void launch_bwd_input(hipStream_t st, const float* gy, const float* z, co
   }
 }
 
+template <int MODE, int NP>
+static int strip_launch_np(const void* table_dev, int n_problems, int total_blocks, double* partial, RankUpdateArgs ra,
+                           hipStream_t st, const char* what) {
+  const size_t lds = sizeof(float) * (size_t)(16 * NP) * (GW_GS + (NP < GS_SINGLE_FROM ? 2 : 1) * GW_XS);
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gathered_wgrad_strip_k<MODE, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("%s: %zu bytes of LDS: %s", what, lds, hipGetErrorString(e)); return (int)e; }
+  }
+  hipLaunchKernelGGL((gathered_wgrad_strip_k<MODE, NP>), dim3(total_blocks), dim3(256), lds, st,
+                     reinterpret_cast<const WgradProblem*>(table_dev), n_problems, partial, ra);
+  return check_launch(what);
+}
+template <int MODE>
+static int strip_launch(const void* table_dev, int n_problems, int total_blocks, int max_rows, double* partial, RankUpdateArgs ra,
+                        hipStream_t st, const char* what) {
+  if (max_rows <= 32) return strip_launch_np<MODE, 2>(table_dev, n_problems, total_blocks, partial, ra, st, what);
+  if (max_rows <= 48) return strip_launch_np<MODE, 3>(table_dev, n_problems, total_blocks, partial, ra, st, what);
+  if (max_rows <= 64) return strip_launch_np<MODE, 4>(table_dev, n_problems, total_blocks, partial, ra, st, what);
+  if (max_rows <= 80) return strip_launch_np<MODE, 5>(table_dev, n_problems, total_blocks, partial, ra, st, what);
+  if (max_rows <= 96) return strip_launch_np<MODE, 6>(table_dev, n_problems, total_blocks, partial, ra, st, what);
+  return strip_launch_np<MODE, 8>(table_dev, n_problems, total_blocks, partial, ra, st, what);
+}
 }  // namespace cgv
 
 extern "C" {
@@ -1460,6 +1698,51 @@ int cgv_grouped_wgrad_gathered_adam(const void* table_dev, int n_problems, int t
                      reinterpret_cast<const cgv::WgradProblem*>(table_dev), n_problems, (double*)nullptr,
                      cgv::RankUpdateArgs{arena_g, arena_p, arena_m, arena_v, state, lr, beta1, beta2, eps});
   return cgv::check_launch("cgv_grouped_wgrad_gathered_adam");
+}
+
+/* The strip layout of the gathered launches for problems of at most 128 operand rows (csrc: gathered_wgrad_strip_k): a
+ * block per 64 ROWS of gW (it walks that strip's column tiles itself).  Plan: n_blocks = ceil(N / 64); records as for
+ * cgv_grouped_wgrad_gathered with block_begin counted in these blocks.  Results are bit-identical to the tile layout. */
+int cgv_wgrad_strip_max_rows(void) { return cgv::GS_MAX_ROWS; }
+int cgv_wgrad_strip_plan(int M, int N, int K, int seg_rows, int* n_blocks) {
+  CGV_REQUIRE(n_blocks, "null pointer");
+  CGV_REQUIRE(M >= 1 && M <= cgv::GS_MAX_ROWS && N >= 4 && K >= 4 && (N % 4) == 0 && (K % 4) == 0, "unsupported shape (need M <= 128, N % 4 == 0, K % 4 == 0)");
+  CGV_REQUIRE(seg_rows == 0 || (seg_rows > 0 && seg_rows % 4 == 0), "rank segments must hold a multiple of 4 rows");
+  *n_blocks = (N + 63) / 64;
+  return 0;
+}
+
+int cgv_grouped_wgrad_strip(const void* table_dev, int n_problems, int total_blocks, int max_rows, void* stream) {
+  CGV_REQUIRE(n_problems >= 0 && total_blocks >= 0, "bad size");
+  if (n_problems == 0 || total_blocks == 0) return 0;
+  CGV_REQUIRE(table_dev && max_rows >= 1 && max_rows <= cgv::GS_MAX_ROWS, "bad argument");
+  return cgv::strip_launch<cgv::GW_STORE>(table_dev, n_problems, total_blocks, max_rows, nullptr, cgv::RankUpdateArgs{},
+                                          (hipStream_t)stream, "cgv_grouped_wgrad_strip");
+}
+
+int cgv_grouped_wgrad_strip_sumsq(const void* table_dev, int n_problems, int total_blocks, int max_rows, double* partial,
+                                  double* sumsq, void* stream) {
+  CGV_REQUIRE(n_problems >= 0 && total_blocks >= 0, "bad size");
+  if (n_problems == 0 || total_blocks == 0) return 0;
+  CGV_REQUIRE(table_dev && partial && sumsq && max_rows >= 1 && max_rows <= cgv::GS_MAX_ROWS, "bad argument");
+  if (int rc = cgv::strip_launch<cgv::GW_SUMSQ>(table_dev, n_problems, total_blocks, max_rows, partial, cgv::RankUpdateArgs{},
+                                                (hipStream_t)stream, "cgv_grouped_wgrad_strip_sumsq")) return rc;
+  hipLaunchKernelGGL(cgv::gathered_sumsq_reduce_k, dim3(n_problems), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const cgv::WgradProblem*>(table_dev), n_problems, total_blocks, partial, sumsq);
+  return cgv::check_launch("cgv_grouped_wgrad_strip_sumsq");
+}
+
+int cgv_grouped_wgrad_strip_adam(const void* table_dev, int n_problems, int total_blocks, int max_rows, const float* arena_g,
+                                 float* arena_p, float* arena_m, float* arena_v, float lr, float beta1, float beta2, float eps,
+                                 const float* state, void* stream) {
+  CGV_REQUIRE(n_problems >= 0 && total_blocks >= 0, "bad size");
+  if (n_problems == 0 || total_blocks == 0) return 0;
+  CGV_REQUIRE(table_dev && arena_g && arena_p && arena_m && arena_v && state && max_rows >= 1 && max_rows <= cgv::GS_MAX_ROWS, "bad argument");
+  CGV_REQUIRE(((((uintptr_t)arena_g | (uintptr_t)arena_p | (uintptr_t)arena_m | (uintptr_t)arena_v)) & 15) == 0,
+              "arenas must be 16-byte aligned");
+  return cgv::strip_launch<cgv::GW_ADAM>(table_dev, n_problems, total_blocks, max_rows, nullptr,
+                                         cgv::RankUpdateArgs{arena_g, arena_p, arena_m, arena_v, state, lr, beta1, beta2, eps},
+                                         (hipStream_t)stream, "cgv_grouped_wgrad_strip_adam");
 }
 
 int cgv_pack_record_bytes(void) { return (int)sizeof(cgv::PackProblem); }

@@ -198,19 +198,60 @@ class WeightGradQueue:
             max_lds = max(max_lds, lib.cgv_wgrad_lds_floats(M, tw.value))
         return self.upload(bytes(buf), items[0][0].device), block_begin, max_lds
 
+    # Operand rows from which the strip layout of the MFMA launch beats the weight-streaming VALU kernel (same 57
+    # bead-level problems of a chignolin step, tools/wgrad_strip_bench.py: 12 rows 46 against 76 us, 24 rows 72 / 80,
+    # 36 rows 113 / 94, 64 rows 252 / 108); it takes at most cgv_wgrad_strip_max_rows() = 128.
+    STRIP_MIN_ROWS = 32
+
+    def strip_rows(self, M, N, K):
+        return self.STRIP_MIN_ROWS <= M <= 128 and N % 4 == 0 and K % 4 == 0 and N >= 4 and K >= 4
+
+    def strip_table(self, items, seg=None):
+        """(device record table, total blocks, largest row count) of the strip-layout launches (gathered_wgrad_strip_k).
+        ``items``: tuples as queued by ``enqueue``; with ``seg`` = (world), tuples of OperandExchange.ranked
+        (M rows per rank at offsets of the all-gathered buffer)."""
+        lib = _lib.load()
+        nb = C.c_int()
+        buf, block_begin, rows = bytearray(), 0, 0
+        for it in items:
+            if seg is None:
+                gy, x, z, act, gW, gb, accumulate = it
+                M, N = gy.shape
+                K = x.shape[1]
+                rec = (gy.data_ptr(), x.data_ptr(), z.data_ptr() if z is not None else 0, gW.data_ptr(),
+                       gb.data_ptr() if gb is not None else 0, M, N, K, int(accumulate), int(act))
+                tail = (0, 0, 0)
+                per_rank = 0
+            else:
+                per_rank, N, K, off_g, off_x, gW, gb, _acc, recv, total = it
+                M = seg * per_rank
+                rec = (recv.data_ptr() + 4 * off_g, recv.data_ptr() + 4 * off_x, 0, gW.data_ptr(),
+                       gb.data_ptr() if gb is not None else 0, M, N, K, 0, 0)
+                tail = (per_rank, total, 0)
+            if lib.cgv_wgrad_strip_plan(M, N, K, per_rank, C.byref(nb)) != 0:
+                raise RuntimeError(lib.cgv_last_error_string().decode())
+            buf += self.RECORD.pack(*rec, block_begin, 0, 0, *tail)
+            block_begin += nb.value
+            rows = max(rows, M)
+        dev = items[0][0].device if seg is None else items[0][8].device
+        return self.upload(bytes(buf), dev), block_begin, rows
+
     def launch(self, items):
         """Grouped launches for ``items`` (tuples as queued by ``enqueue``), writing into their gW / gb targets: ONE for
-        the problems of at most 64 rows (weight-streaming VALU kernel, grouped_wgrad_k) and ONE for those with more
-        (64 x 64 MFMA tiles over LDS-staged operand rows, gathered_wgrad_k -- the atom-level layers, and every
-        bead-level layer of a large batch)."""
+        the problems of few rows (weight-streaming VALU kernel, grouped_wgrad_k), ONE for those of 32 - 128 rows (MFMA,
+        a block per 64-row strip of gW: gathered_wgrad_strip_k -- the bead-level layers of a large batch) and ONE for
+        those with more (64 x 64 MFMA tiles over LDS-staged operand rows, gathered_wgrad_k -- the atom-level layers)."""
         if not items:
             return
         lib = _lib.load()
         assert lib.cgv_wgrad_record_bytes() == self.RECORD.size
         if len(items) > self.MAX_PROBLEMS:
             raise RuntimeError("too many queued weight-gradient problems")
-        small = [it for it in items if self.kernel != "mfma" and lib.cgv_skinny_supported(it[0].shape[0], it[0].shape[1], it[1].shape[1])]
-        ids = {id(it) for it in small}
+        strips = [it for it in items if self.strip_rows(it[0].shape[0], it[0].shape[1], it[1].shape[1])]
+        ids = {id(it) for it in strips}
+        small = [it for it in items if id(it) not in ids and self.kernel != "mfma"
+                 and lib.cgv_skinny_supported(it[0].shape[0], it[0].shape[1], it[1].shape[1])]
+        ids |= {id(it) for it in small}
         large = [it for it in items if id(it) not in ids]
         dev = items[0][0].device
         tk, tw, nb = C.c_int(), C.c_int(), C.c_int()
@@ -218,6 +259,10 @@ class WeightGradQueue:
             table, block_begin, max_lds = self.small_table(small)
             _lib.call("cgv_grouped_wgrad", _lib.ptr(table), len(small), block_begin, max_lds, _lib.stream_ptr(),
                       tag="grouped_wgrad")
+        if strips:
+            table, block_begin, rows = self.strip_table(strips)
+            _lib.call("cgv_grouped_wgrad_strip", _lib.ptr(table), len(strips), block_begin, rows, _lib.stream_ptr(),
+                      tag="grouped_wgrad_strip")
         if large:
             buf, block_begin = bytearray(), 0
             tile = wgrad_tile([(gy.shape[0], gy.shape[1], x.shape[1]) for gy, x, *_rest in large])

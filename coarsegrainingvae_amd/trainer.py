@@ -353,7 +353,7 @@ class Trainer:
         self._rank_hi = 0             # arena floats [0, _rank_hi) belong to rank-update weights
         self._rank_numel = 0
         self._rank_step = None        # this step's (table, problems, blocks, lds, items, max rows) once the Gram launch is out
-        self._rank_mfma = None        # data parallel: (table, problems, blocks, items) of the layers on the MFMA tile kernel
+        self._rank_mfma = None        # ([(kind, table, problems, blocks, rows)], problems, items) of the layers on the two-pass MFMA rank update
         self._mfma_partial = None
         self.last_rank_step = None
         self.rank_steps = 0           # steps that took the rank-update path / fell back to materialised gradients
@@ -782,10 +782,15 @@ class Trainer:
                               _lib.ptr(self.state), _lib.stream_ptr(), tag="grouped_wgrad_adam")
                     self.rank_steps += 1
                 if mfma:
-                    table, n, blocks, _items = mfma
-                    _lib.call("cgv_grouped_wgrad_gathered_adam", _lib.ptr(table), n, blocks, _lib.ptr(a.g), _lib.ptr(a.p),
-                              _lib.ptr(self.m), _lib.ptr(self.v), self.lr, self.betas[0], self.betas[1], self.eps,
-                              _lib.ptr(self.state), _lib.stream_ptr(), tag="gathered_wgrad_adam")
+                    for kind, table, n, blocks, rows in mfma[0]:
+                        if kind == "strip":
+                            _lib.call("cgv_grouped_wgrad_strip_adam", _lib.ptr(table), n, blocks, rows, _lib.ptr(a.g), _lib.ptr(a.p),
+                                      _lib.ptr(self.m), _lib.ptr(self.v), self.lr, self.betas[0], self.betas[1], self.eps,
+                                      _lib.ptr(self.state), _lib.stream_ptr(), tag="strip_wgrad_adam")
+                        else:
+                            _lib.call("cgv_grouped_wgrad_gathered_adam", _lib.ptr(table), n, blocks, _lib.ptr(a.g), _lib.ptr(a.p),
+                                      _lib.ptr(self.m), _lib.ptr(self.v), self.lr, self.betas[0], self.betas[1], self.eps,
+                                      _lib.ptr(self.state), _lib.stream_ptr(), tag="gathered_wgrad_adam")
                     self.rank_steps_mfma += 1
         else:
             if self.world > 1:
@@ -861,25 +866,7 @@ class Trainer:
                       self._rank_ws.numel(), _lib.stream_ptr(), tag="wgrad_gram")
             self._rank_step = (table, len(small), blocks, lds, small, rows)
         if large:
-            rec = wgrad_queue.RECORD
-            tk, nb = C.c_int(), C.c_int()
-            buf, block_begin = bytearray(), 0
-            for gy, x, z, act, gW, gb, _acc in large:
-                M, N = gy.shape
-                K = x.shape[1]
-                if lib.cgv_wgrad_gathered_plan_tile(M, N, K, 0, 64, C.byref(tk), C.byref(nb)) != 0:
-                    raise RuntimeError(lib.cgv_last_error_string().decode())
-                buf += rec.pack(gy.data_ptr(), x.data_ptr(), z.data_ptr() if z is not None else 0, gW.data_ptr(),
-                                gb.data_ptr() if gb is not None else 0, M, N, K, 0, int(act), block_begin, tk.value, 0, 0, 0, 0)
-                block_begin += nb.value
-            table = wgrad_queue.upload(bytes(buf), large[0][0].device)
-            if self._mfma_partial is None or self._mfma_partial.numel() < block_begin:
-                if torch.cuda.is_current_stream_capturing():
-                    raise RuntimeError("run one eager step before capturing (rank-update workspace)")
-                self._mfma_partial = torch.empty(block_begin, dtype=torch.float64, device=large[0][0].device)
-            _lib.call("cgv_grouped_wgrad_gathered_sumsq", _lib.ptr(table), len(large), block_begin, _lib.ptr(self._mfma_partial),
-                      self._rank_sumsq.data_ptr() + 8 * len(small), _lib.stream_ptr(), tag="gathered_wgrad_sumsq")
-            self._rank_mfma = (table, len(large), block_begin, large)
+            self._start_mfma_rank_update(large, None, len(small))
         return rest
 
     def _start_gathered_rank_update(self):
@@ -927,22 +914,63 @@ class Trainer:
                       self._rank_ws.numel(), _lib.stream_ptr(), tag="wgrad_gram")
             self._rank_step = (table, len(small), block_begin, max_lds, small, rows)
         if large:
-            buf, block_begin = bytearray(), 0
-            for M, N, K, off_g, off_x, gW, gb, _acc, recv, total in large:
-                if lib.cgv_wgrad_gathered_plan_tile(world * M, N, K, M, 64, C.byref(tk), C.byref(nb)) != 0:
+            self._start_mfma_rank_update(large, world, len(small))
+
+    def _start_mfma_rank_update(self, large, world, slot0):
+        """Norm pass of the two-pass MFMA rank update for the layers ``large`` (queue tuples; with ``world``, tuples of
+        OperandExchange.ranked): gradient tiles formed and squared, never stored; bias gradients written.  Layers of at
+        most 128 (gathered) rows take the strip layout (a block per 64 rows of gW, gathered_wgrad_strip_k), the others
+        64 x 64 tiles (gathered_wgrad_k); the Adam pass repeats the same launches with the update as epilogue.
+        Norms go to slots ``slot0``.. of the rank-update norm buffer."""
+        lib = _lib.load()
+        rec = wgrad_queue.RECORD
+        rows_of = (lambda it: it[0].shape[0]) if world is None else (lambda it: world * it[0])
+        shape_of = (lambda it: (it[0].shape[1], it[1].shape[1])) if world is None else (lambda it: (it[1], it[2]))
+        strips = [it for it in large if wgrad_queue.strip_rows(rows_of(it), *shape_of(it))]
+        ids = {id(it) for it in strips}
+        tiles = [it for it in large if id(it) not in ids]
+        dev = large[0][0].device if world is None else large[0][8].device
+        launches = []
+        if strips:
+            table, blocks, rows = wgrad_queue.strip_table(strips, seg=world)
+            launches.append(("strip", table, len(strips), blocks, rows))
+        if tiles:
+            tk, nb = C.c_int(), C.c_int()
+            buf, blocks = bytearray(), 0
+            for it in tiles:
+                if world is None:
+                    gy, x, z, act, gW, gb, _acc = it
+                    M, (N, K) = gy.shape[0], shape_of(it)
+                    head = (gy.data_ptr(), x.data_ptr(), z.data_ptr() if z is not None else 0, gW.data_ptr(),
+                            gb.data_ptr() if gb is not None else 0, M, N, K, 0, int(act))
+                    per_rank, tail = 0, (0, 0, 0)
+                else:
+                    per_rank, N, K, off_g, off_x, gW, gb, _acc, recv, total = it
+                    M = world * per_rank
+                    head = (recv.data_ptr() + 4 * off_g, recv.data_ptr() + 4 * off_x, 0, gW.data_ptr(),
+                            gb.data_ptr() if gb is not None else 0, M, N, K, 0, 0)
+                    tail = (per_rank, total, 0)
+                if lib.cgv_wgrad_gathered_plan_tile(M, N, K, per_rank, 64, C.byref(tk), C.byref(nb)) != 0:
                     raise RuntimeError(lib.cgv_last_error_string().decode())
-                buf += rec.pack(recv.data_ptr() + 4 * off_g, recv.data_ptr() + 4 * off_x, 0, gW.data_ptr(),
-                                gb.data_ptr() if gb is not None else 0, world * M, N, K, 0, 0, block_begin, tk.value, 0,
-                                M, total, 0)
-                block_begin += nb.value
-            table = wgrad_queue.upload(bytes(buf), dev)
-            if self._mfma_partial is None or self._mfma_partial.numel() < block_begin:
-                if torch.cuda.is_current_stream_capturing():
-                    raise RuntimeError("run one eager step before capturing (rank-update workspace)")
-                self._mfma_partial = torch.empty(block_begin, dtype=torch.float64, device=dev)
-            _lib.call("cgv_grouped_wgrad_gathered_sumsq", _lib.ptr(table), len(large), block_begin, _lib.ptr(self._mfma_partial),
-                      self._rank_sumsq.data_ptr() + 8 * len(small), _lib.stream_ptr(), tag="gathered_wgrad_sumsq")
-            self._rank_mfma = (table, len(large), block_begin, large)
+                buf += rec.pack(*head, blocks, tk.value, 0, *tail)
+                blocks += nb.value
+            launches.append(("tile", wgrad_queue.upload(bytes(buf), dev), len(tiles), blocks, 0))
+        need = max(l[3] for l in launches)
+        if self._mfma_partial is None or self._mfma_partial.numel() < need:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("run one eager step before capturing (rank-update workspace)")
+            self._mfma_partial = torch.empty(need, dtype=torch.float64, device=dev)
+        slot = slot0
+        for kind, table, n, blocks, rows in launches:           # (stream order: the second launch reuses the partials)
+            out = self._rank_sumsq.data_ptr() + 8 * slot
+            if kind == "strip":
+                _lib.call("cgv_grouped_wgrad_strip_sumsq", _lib.ptr(table), n, blocks, rows, _lib.ptr(self._mfma_partial), out,
+                          _lib.stream_ptr(), tag="strip_wgrad_sumsq")
+            else:
+                _lib.call("cgv_grouped_wgrad_gathered_sumsq", _lib.ptr(table), n, blocks, _lib.ptr(self._mfma_partial), out,
+                          _lib.stream_ptr(), tag="gathered_wgrad_sumsq")
+            slot += n
+        self._rank_mfma = (launches, len(large), strips + tiles)
 
     def _bucket_done(self, index: int):
         """Autograd-thread callback (model.bucket_done): the gradients of backward bucket ``index`` are final.

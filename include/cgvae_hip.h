@@ -518,6 +518,20 @@ int cgv_grouped_wgrad_gathered_sumsq(const void* table_dev, int n_problems, int 
 int cgv_grouped_wgrad_gathered_adam(const void* table_dev, int n_problems, int total_blocks, const float* arena_g,
                                     float* arena_p, float* arena_m, float* arena_v, float lr, float beta1, float beta2,
                                     float eps, const float* state, void* stream);
+/* Strip layout of the three gathered launches, for records of at most cgv_wgrad_strip_max_rows() (128) operand rows:
+ * one block per 64 ROWS of gW, which stages its g columns once and walks the strip's K / 64 column tiles with the next
+ * x tile loading under the current tile's MFMAs (the tile layout above gives each 64 x 64 tile a block of its own that
+ * spends most of its life on its first loads).  Records as above with block_begin counted in strip blocks
+ * (cgv_wgrad_strip_plan: ceil(N / 64)); tiles_k / tile_w unused.  max_rows = the largest M of the table (sizes the LDS).
+ * Bit-identical to the tile layout: same MFMA chains in the same row order. */
+int cgv_wgrad_strip_max_rows(void);
+int cgv_wgrad_strip_plan(int M, int N, int K, int seg_rows, int* n_blocks /*[host]*/);
+int cgv_grouped_wgrad_strip(const void* table_dev, int n_problems, int total_blocks, int max_rows, void* stream);
+int cgv_grouped_wgrad_strip_sumsq(const void* table_dev, int n_problems, int total_blocks, int max_rows, double* partial,
+                                  double* sumsq, void* stream);
+int cgv_grouped_wgrad_strip_adam(const void* table_dev, int n_problems, int total_blocks, int max_rows, const float* arena_g,
+                                 float* arena_p, float* arena_m, float* arena_v, float lr, float beta1, float beta2,
+                                 float eps, const float* state, void* stream);
 int cgv_pack_record_bytes(void);
 int cgv_pack_plan(int M, int N, int K, int* n_blocks /*[host]*/);
 int cgv_pack_operands(const void* table_dev, int n_problems, int total_blocks, void* stream);

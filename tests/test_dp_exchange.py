@@ -233,12 +233,15 @@ def test_rank_update_over_gathered_rows_vs_fp64(world, M, N, K, bias):
     assert float((arena_p.double().cpu() - p1).abs().max()) <= 5e-6
 
 
+@pytest.mark.parametrize("layout", ["tile", "strip"])
 @pytest.mark.parametrize("world,M,N,K,bias", [(8, 12, 600, 600, True), (2, 36, 1200, 600, False), (4, 12, 1800, 600, True),
-                                              (3, 20, 68, 132, True), (8, 12, 5400, 600, True)])
-def test_mfma_rank_update_over_gathered_rows_vs_fp64(world, M, N, K, bias):
-    """cgv_grouped_wgrad_gathered_sumsq + cgv_grouped_wgrad_gathered_adam (the MFMA tile kernel's norm and Adam passes) on
-    rank-segmented rows, different on every 'rank': norm, bias gradient and the Adam update against the fp64 gradient of
-    the concatenated rows; the gradient arena is never written."""
+                                              (3, 20, 68, 132, True), (8, 12, 5400, 600, True), (2, 64, 100, 76, True),
+                                              (1, 44, 64, 64, True)])
+def test_mfma_rank_update_over_gathered_rows_vs_fp64(world, M, N, K, bias, layout):
+    """cgv_grouped_wgrad_gathered_sumsq + cgv_grouped_wgrad_gathered_adam (the MFMA tile kernel's norm and Adam passes) and
+    their strip layout (cgv_grouped_wgrad_strip_sumsq / _adam: a block per 64 rows of gW) on rank-segmented rows, different
+    on every 'rank': norm, bias gradient and the Adam update against the fp64 gradient of the concatenated rows; the
+    gradient arena is never written."""
     import ctypes as C
     from coarsegrainingvae_amd.primitives import wgrad_queue
     lib = _lib.load()
@@ -264,13 +267,20 @@ def test_mfma_rank_update_over_gathered_rows_vs_fp64(world, M, N, K, bias):
     p0, m0, v0 = arena_p.double().cpu(), arena_m.double().cpu(), arena_v.double().cpu()
     gb = torch.full((N,), float("nan"), device=DEV) if bias else None
     tk, nb = C.c_int(), C.c_int()
-    assert lib.cgv_wgrad_gathered_plan_tile(world * M, N, K, M, 64, C.byref(tk), C.byref(nb)) == 0
+    strip = layout == "strip"
+    if strip:
+        assert lib.cgv_wgrad_strip_plan(world * M, N, K, M, C.byref(nb)) == 0 and nb.value == (N + 63) // 64
+    else:
+        assert lib.cgv_wgrad_gathered_plan_tile(world * M, N, K, M, 64, C.byref(tk), C.byref(nb)) == 0
     rec = wgrad_queue.RECORD.pack(recv.data_ptr(), recv.data_ptr() + 4 * off_x, 0, arena_g.data_ptr() + 4 * lead,
                                   gb.data_ptr() if bias else 0, world * M, N, K, 0, 0, 0, tk.value, 0, M, total, 0)
     table = wgrad_queue.upload(rec, torch.device(DEV))
     sumsq = torch.zeros(1, dtype=torch.float64, device=DEV)
     partial = torch.empty(nb.value, dtype=torch.float64, device=DEV)
-    _lib.call("cgv_grouped_wgrad_gathered_sumsq", _lib.ptr(table), 1, nb.value, _lib.ptr(partial), _lib.ptr(sumsq), _lib.stream_ptr())
+    if strip:
+        _lib.call("cgv_grouped_wgrad_strip_sumsq", _lib.ptr(table), 1, nb.value, world * M, _lib.ptr(partial), _lib.ptr(sumsq), _lib.stream_ptr())
+    else:
+        _lib.call("cgv_grouped_wgrad_gathered_sumsq", _lib.ptr(table), 1, nb.value, _lib.ptr(partial), _lib.ptr(sumsq), _lib.stream_ptr())
     want = float((gw ** 2).sum())
     assert abs(float(sumsq[0]) - want) <= 2e-6 * want
     if bias:
@@ -280,8 +290,12 @@ def test_mfma_rank_update_over_gathered_rows_vs_fp64(world, M, N, K, bias):
     lr, b1, b2, eps, max_norm, scale = 1e-3, 0.9, 0.999, 1e-8, 0.01, 1.0 / world
     _lib.call("cgv_optim_prepare_extra", arena_g.data_ptr(), 0, _lib.ptr(sumsq), 1, b1, b2, max_norm, scale, None, 0.0,
               _lib.ptr(state), _lib.ptr(part), _lib.stream_ptr())
-    _lib.call("cgv_grouped_wgrad_gathered_adam", _lib.ptr(table), 1, nb.value, _lib.ptr(arena_g), _lib.ptr(arena_p),
-              _lib.ptr(arena_m), _lib.ptr(arena_v), lr, b1, b2, eps, _lib.ptr(state), _lib.stream_ptr())
+    if strip:
+        _lib.call("cgv_grouped_wgrad_strip_adam", _lib.ptr(table), 1, nb.value, world * M, _lib.ptr(arena_g), _lib.ptr(arena_p),
+                  _lib.ptr(arena_m), _lib.ptr(arena_v), lr, b1, b2, eps, _lib.ptr(state), _lib.stream_ptr())
+    else:
+        _lib.call("cgv_grouped_wgrad_gathered_adam", _lib.ptr(table), 1, nb.value, _lib.ptr(arena_g), _lib.ptr(arena_p),
+                  _lib.ptr(arena_m), _lib.ptr(arena_v), lr, b1, b2, eps, _lib.ptr(state), _lib.stream_ptr())
     torch.cuda.synchronize()
     g_mean = gw * scale
     norm = float((g_mean ** 2).sum()) ** 0.5
@@ -296,3 +310,63 @@ def test_mfma_rank_update_over_gathered_rows_vs_fp64(world, M, N, K, bias):
     assert torch.allclose(arena_m.double().cpu(), m1, rtol=2e-5, atol=1e-9)               # incl. the untouched lead
     assert torch.allclose(arena_v.double().cpu(), v1, rtol=2e-5, atol=1e-12)
     assert float((arena_p.double().cpu() - p1).abs().max()) <= 5e-6
+
+
+def test_strip_layout_writes_what_the_tile_layout_writes():
+    """cgv_grouped_wgrad_strip against cgv_grouped_wgrad_gathered_tile on one table of mixed problems (12 - 128 rows, ragged
+    N / K, with and without activation derivative / bias / accumulation, one rank-segmented): bit-identical weight and bias
+    gradients, and within fp32 rounding of the fp64 product."""
+    import ctypes as C
+    from coarsegrainingvae_amd.primitives import wgrad_queue
+    lib = _lib.load()
+    assert lib.cgv_wgrad_strip_max_rows() == 128
+    dev = torch.device(DEV)
+    gen = torch.Generator(device=dev).manual_seed(11)
+    shapes = [(12, 600, 600, 1, True, False, 0), (36, 1200, 600, 0, True, False, 0), (96, 68, 132, 1, False, True, 0),
+              (128, 200, 64, 1, True, True, 0), (47, 64, 260, 0, True, False, 0), (40, 128, 128, 0, True, False, 20)]
+    problems = []
+    for M, N, K, act, bias, acc, seg in shapes:
+        gy = torch.randn(M, N, device=dev, generator=gen)
+        x = torch.randn(M, K, device=dev, generator=gen)
+        z = torch.randn(M, N, device=dev, generator=gen) if act else None
+        base_w = torch.randn(N, K, device=dev, generator=gen)
+        base_b = torch.randn(N, device=dev, generator=gen)
+        problems.append((gy, x, z, act, bias, acc, seg, base_w, base_b))
+    outs = {}
+    for layout in ("tile", "strip"):
+        tk, nb = C.c_int(), C.c_int()
+        buf, begin, targets = bytearray(), 0, []
+        for gy, x, z, act, bias, acc, seg, base_w, base_b in problems:
+            M, N = gy.shape
+            K = x.shape[1]
+            gW, gb = base_w.clone(), base_b.clone()
+            targets.append((gW, gb))
+            if layout == "strip":
+                assert lib.cgv_wgrad_strip_plan(M, N, K, seg, C.byref(nb)) == 0
+            else:
+                assert lib.cgv_wgrad_gathered_plan_tile(M, N, K, seg, 64, C.byref(tk), C.byref(nb)) == 0
+            # the segmented problem: two "ranks" of 20 rows, the second one's seg_stride = 20 * 128 floats on (N == K)
+            buf += wgrad_queue.RECORD.pack(gy.data_ptr(), x.data_ptr(), z.data_ptr() if z is not None else 0, gW.data_ptr(),
+                                           gb.data_ptr() if bias else 0, M, N, K, int(acc), act, begin, tk.value, 0,
+                                           seg, seg * N if seg else 0, 0)
+            begin += nb.value
+        table = wgrad_queue.upload(bytes(buf), dev)
+        if layout == "strip":
+            _lib.call("cgv_grouped_wgrad_strip", _lib.ptr(table), len(problems), begin, 128, _lib.stream_ptr())
+        else:
+            _lib.call("cgv_grouped_wgrad_gathered_tile", _lib.ptr(table), len(problems), begin, 64, _lib.stream_ptr())
+        torch.cuda.synchronize()
+        outs[layout] = targets
+    for (gy, x, z, act, bias, acc, seg, base_w, base_b), (tw, tb), (sw, sb) in zip(problems, outs["tile"], outs["strip"]):
+        assert torch.equal(tw, sw) and torch.equal(tb, sb)
+        g = gy.double()
+        if act:
+            sg = torch.sigmoid(z.double())
+            g = g * (sg * (1 + z.double() * (1 - sg)))
+        want = g.T @ x.double() + (base_w.double() if acc else 0)
+        assert float((sw.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+        if bias:
+            wb = g.sum(0) + (base_b.double() if acc else 0)
+            assert torch.allclose(sb.double(), wb, rtol=1e-5, atol=1e-4)
+        else:
+            assert torch.equal(sb, base_b)

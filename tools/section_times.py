@@ -23,6 +23,8 @@ batch = cg.synthetic_batch(workload, seed=0, device="cuda")
 model = cg.build_model(F, w["n_rbf"], w["atom_cutoff"], w["cg_cutoff"], w["enc_nconv"], w["dec_nconv"], w["n_cgs"], seed=123).cuda()
 if per_block:
     model.equivaraintconv.fused_loop = False
+if os.environ.get("RANK_ROWS_MFMA"):
+    Trainer.RANK_ROWS_MFMA = int(os.environ["RANK_ROWS_MFMA"])
 tr = Trainer(model, lr=1e-4, beta=w["beta"], gamma=w["gamma"])
 for _ in range(4):
     tr.step(batch)
