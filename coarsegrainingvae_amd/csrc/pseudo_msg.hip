@@ -22,6 +22,7 @@
 // summation order is fixed).  The bead graph is tiny (60..4k edges): the point of fusing is
 // launch count (1 + 3 launches instead of ~120 ATen kernels per layer), not bandwidth.
 #include <stdlib.h>
+#include <type_traits>
 #include "cgv_common.h"
 
 namespace cgv {
@@ -197,6 +198,201 @@ __global__ __launch_bounds__(576) void pseudo_fwd_k(const float* __restrict__ ph
   st3(dv + nf * 3, av.x, av.y, av.z);
   st3(dvbar + nf * 3, avb.x, avb.y, avb.z);
   if (dv_rows) {       // the same vector as rows [3 i + xyz][f]: the layout the update block's channel mixing reads
+    dv_rows[((size_t)3 * i + 0) * F + f] = av.x;
+    dv_rows[((size_t)3 * i + 1) * F + f] = av.y;
+    dv_rows[((size_t)3 * i + 2) * F + f] = av.z;
+  }
+}
+
+// ------------------------------------------------------------------ dense bead graphs (>= 16 edges per node): forward
+// The kernels above walk a node's edges with one code path for all nine waves: per edge a ladder of wave-uniform
+// branches (the switch over k), 64-bit address arithmetic per gather and a wait right behind every request -- ~100
+// instructions and two exposed round trips per edge and wave.  With 61 edges per node (64 beads, 2000-atom config) that
+// walk is the whole kernel (54 us per layer against ~10 us of FMAs).  Here every wave runs a body compiled for ITS
+// filter (template K), gathers go out as base + 32-bit offset four edges at a time with the next four already in flight
+// (two register sets), and the staged segment is padded to whole batches (last source index repeated, zero records:
+// w = 0, so a padded edge adds 0) so the walk has no tail code.  Same per-edge operations in the same order as
+// pseudo_fwd_k: results are identical.
+constexpr int PD_EB = 4;
+// Gather bases are laundered through an empty asm (address space 1 kept in the type): loads through a `const __restrict__`
+// kernel argument are free to sink below pd_pin() to their first use, which puts every round trip back in front of its FMAs.
+#define CGV_PD_GLOBAL __attribute__((address_space(1)))
+typedef const CGV_PD_GLOBAL char* pd_base;
+__device__ __forceinline__ pd_base pd_launder(const float* p) {
+  unsigned long long a = reinterpret_cast<unsigned long long>(p);
+  asm volatile("" : "+s"(a));
+  return reinterpret_cast<pd_base>(a);
+}
+__device__ __forceinline__ v3 ldv_at(pd_base base, unsigned byte_off) {
+  const CGV_PD_GLOBAL float* q = reinterpret_cast<const CGV_PD_GLOBAL float*>(base + byte_off);
+  return v3{q[0], q[1], q[2]};
+}
+__device__ __forceinline__ float ldf_at(pd_base base, unsigned byte_off) {
+  return *reinterpret_cast<const CGV_PD_GLOBAL float*>(base + byte_off);
+}
+__device__ __forceinline__ void pd_pin() { asm volatile("" ::: "memory"); }
+
+// Staged: the segment's node indices, padded to whole double batches with the last one repeated (a padded edge gathers
+// valid rows and is skipped by a wave-uniform test).  The edge RECORDS are not staged: every lane reading the same LDS
+// words costs the LDS pipe a full 64-lane access (3 x ds_read_b128 per edge and wave: 432 pipe cycles per edge of a
+// 9-wave block, which was the pace of the first version of this kernel); addressed wave-uniformly in global memory they
+// come through the scalar cache into SGPRs and cost the vector side nothing.
+__device__ __forceinline__ int pd_stage_indices(int* __restrict__ seg_idx, const int* __restrict__ idx, int c_beg, int n, int threads) {
+  const int n_pad = (n + 2 * PD_EB - 1) / (2 * PD_EB) * (2 * PD_EB);
+  for (int t = threadIdx.x; t < n_pad; t += threads) seg_idx[t] = idx[c_beg + min(t, n - 1)];
+  return n_pad;
+}
+
+// The filter value as two interleaved partial sums (even / odd n) in one register pair: R / 2 packed FMAs + 2 instead of
+// R + 1 (the walk is VALU-issue bound once its loads are out of the way).  Differs from filt() by summation order only.
+typedef float pd_f2 __attribute__((ext_vector_type(2)));
+template <int R>
+__device__ __forceinline__ float filt_pk(const float (&W)[R + 1], const float* __restrict__ g) {
+  static_assert((R & 1) == 0, "pairs");
+  pd_f2 w2 = pd_f2{W[R] * g[R], 0.f};
+#pragma unroll
+  for (int n = 0; n < R; n += 2) w2 = __builtin_elementwise_fma(pd_f2{W[n], W[n + 1]}, pd_f2{g[n], g[n + 1]}, w2);
+  return w2.x + w2.y;
+}
+
+struct PdFwdBatch {
+  float ph[PD_EB];
+  v3 vj[PD_EB];
+};
+
+template <int R, int K>
+__device__ __forceinline__ void pseudo_fwd_dense_walk(const float* __restrict__ phi, const float* __restrict__ v,
+                                                      const float* __restrict__ vbar, const float* __restrict__ geom_c,
+                                                      const int* __restrict__ seg_src, int n, int n_pad, int F, int f,
+                                                      const float (&W)[R + 1], const float* __restrict__ s,
+                                                      const float* __restrict__ sbar, size_t nf, float& ah, float& ahb, v3& acc) {
+  constexpr int GS = geom_stride(R), U = geom_unit_offset(R);
+  // the receiver's own values, only those this filter's term reads (the epilogue reads them again: not live across the walk)
+  const float s_i = K == 0 ? s[nf] : 0.f, sb_i = (K == 4 || K == 6) ? sbar[nf] : 0.f;
+  const v3 zero3{0.f, 0.f, 0.f};
+  const v3 v_i = (K == 0 || K == 3 || K == 7) ? ldv(v + nf * 3) : zero3, vb_i = K == 8 ? ldv(vbar + nf * 3) : zero3;
+  const pd_base vsrc = pd_launder((K == 2 || K == 6 || K == 7) ? v : vbar), phib = pd_launder(phi);
+  const unsigned phi_c = (unsigned)(K * F + f) * 4u, phi_s = 9u * (unsigned)F * 4u;
+  const unsigned vec_c = (unsigned)f * 12u, vec_s = (unsigned)F * 12u;
+  auto issue = [&](PdFwdBatch& b, int e0) {
+    static_assert(PD_EB == 4, "one 16-byte index read per batch");
+    const int4 j4 = *reinterpret_cast<const int4*>(seg_src + e0);
+    const int js[4] = {j4.x, j4.y, j4.z, j4.w};
+#pragma unroll
+    for (int u = 0; u < PD_EB; ++u) {
+      unsigned j = (unsigned)js[u];
+      asm volatile("" : "+v"(j));     // kept in a vector register: known uniform, each gather address is otherwise built
+                                      // on the scalar unit (readfirstlane + 64-bit multiply-add: ~10 SALU per edge) -- here 1 v_mad_u32_u24
+      b.ph[u] = ldf_at(phib, __umul24(j, phi_s) + phi_c);        // (24-bit multiply: full rate; a 32-bit one is a quarter)
+      if (K != 1) b.vj[u] = ldv_at(vsrc, __umul24(j, vec_s) + vec_c);
+    }
+  };
+  auto compute = [&](const PdFwdBatch& b, int e0, auto tail) {
+    const float* __restrict__ gb = geom_c + (size_t)e0 * GS;
+#pragma unroll
+    for (int u = 0; u < PD_EB; ++u) {
+      if (decltype(tail)::value && e0 + u >= n) break;                 // wave-uniform (padding of the last trip only: a test
+                                                                       // per edge keeps each record load behind its branch)
+      const float* __restrict__ g = gb + u * GS;                      // wave-uniform address: scalar loads, constant offsets
+      const float q = b.ph[u] * filt_pk<R>(W, g);
+      switch (K) {
+        case 0: ah = fmaf(q, s_i, ah); ahb += dot(v_i, b.vj[u]); break;
+        case 1: axpy(acc, q, v3{g[U], g[U + 1], g[U + 2]}); break;
+        case 2: axpy(acc, q, b.vj[u]); break;
+        case 3: axpy(acc, q, cross(v_i, b.vj[u])); break;
+        case 4: axpy(acc, q * sb_i, b.vj[u]); break;
+        case 5: axpy(acc, q, b.vj[u]); break;
+        case 6: axpy(acc, q * sb_i, b.vj[u]); break;
+        case 7: axpy(acc, q, cross(v_i, b.vj[u])); break;
+        default: axpy(acc, q, cross(vb_i, b.vj[u])); break;
+      }
+    }
+  };
+  PdFwdBatch b0, b1;
+  issue(b0, 0);
+  int e0 = 0;
+  for (; e0 + 2 * PD_EB <= n; e0 += 2 * PD_EB) {
+    issue(b1, e0 + PD_EB);
+    pd_pin();
+    compute(b0, e0, std::false_type{});
+    issue(b0, min(e0 + 2 * PD_EB, n_pad - PD_EB));          // (the last trip asks for its own second half again: no branch)
+    pd_pin();
+    compute(b1, e0 + PD_EB, std::false_type{});
+  }
+  if (e0 < n) {
+    issue(b1, e0 + PD_EB);
+    pd_pin();
+    compute(b0, e0, std::true_type{});
+    compute(b1, e0 + PD_EB, std::true_type{});
+  }
+}
+
+__device__ __forceinline__ int pd_filter_of_wave(int wave) {
+  //                     wave: 0  1  2  3  4  5  6  7  8
+  constexpr unsigned table = (1u << 0) | (3u << 4) | (7u << 8) | (8u << 12) | (2u << 16) | (0u << 20) | (4u << 24) | (6u << 28);
+  return wave == 8 ? 5 : (int)((table >> (4 * wave)) & 15u);
+}
+
+template <int R>
+__global__ __launch_bounds__(576) void pseudo_fwd_dense_k(const float* __restrict__ phi, const float* __restrict__ s,
+                                                          const float* __restrict__ sbar, const float* __restrict__ v,
+                                                          const float* __restrict__ vbar, const float* __restrict__ geom,
+                                                          const int* __restrict__ rowptr, const int* __restrict__ src,
+                                                          const float* __restrict__ Wd, const float* __restrict__ bd,
+                                                          float* __restrict__ dh, float* __restrict__ dhbar,
+                                                          float* __restrict__ dv, float* __restrict__ dvbar, int F,
+                                                          int residual, float* __restrict__ dv_rows) {
+  constexpr int GS = geom_stride(R);
+  __shared__ float red[8][3][64];
+  __shared__ __attribute__((aligned(16))) int seg_src[SEG_LDS];
+  const int i = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  // Nine waves on four SIMDs (wave w on SIMD w % 4): the SIMD that gets three is given the three cheapest terms
+  // (k = 1, 2, 5: one axpy), the others a cross-product term and a scaled one each -- per-edge instruction totals
+  // 42 / 35 / 35 / 35 instead of 50 / 28 / 29 / 40 with wave w = filter w.
+  const int k = pd_filter_of_wave(__builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
+  const int f_raw = blockIdx.y * 64 + lane;
+  const bool live = f_raw < F;
+  const int f = live ? f_raw : F - 1;
+  float W[R + 1];
+  load_row<R>(W, Wd, bd, k * F + f);
+  const size_t nf = (size_t)i * F + f;
+  float ah = 0.f, ahb = 0.f;
+  v3 acc{0.f, 0.f, 0.f};
+  const int e_beg = rowptr[i], e_end = rowptr[i + 1];
+  for (int c_beg = e_beg; c_beg < e_end; c_beg += SEG_LDS) {
+    const int n = min(SEG_LDS, e_end - c_beg);
+    if (c_beg != e_beg) __syncthreads();                                 // readers of the previous chunk
+    const int n_pad = pd_stage_indices(seg_src, src, c_beg, n, 576);
+    const float* __restrict__ geom_c = geom + (size_t)c_beg * GS;
+    __syncthreads();
+    switch (k) {                                                         // wave-uniform: each wave runs the body of its filter
+#define CGV_PD_FWD(KV) case KV: pseudo_fwd_dense_walk<R, KV>(phi, v, vbar, geom_c, seg_src, n, n_pad, F, f, W, s, sbar, nf, ah, ahb, acc); break
+      CGV_PD_FWD(0); CGV_PD_FWD(1); CGV_PD_FWD(2); CGV_PD_FWD(3); CGV_PD_FWD(4);
+      CGV_PD_FWD(5); CGV_PD_FWD(6); CGV_PD_FWD(7);
+      default: pseudo_fwd_dense_walk<R, 8>(phi, v, vbar, geom_c, seg_src, n, n_pad, F, f, W, s, sbar, nf, ah, ahb, acc); break;
+#undef CGV_PD_FWD
+    }
+  }
+  if (k > 0) { red[k - 1][0][lane] = acc.x; red[k - 1][1][lane] = acc.y; red[k - 1][2][lane] = acc.z; }
+  __syncthreads();
+  if (k != 0 || !live) return;
+  v3 av{0.f, 0.f, 0.f}, avb{0.f, 0.f, 0.f};
+#pragma unroll
+  for (int w = 0; w < 4; ++w) { av.x += red[w][0][lane]; av.y += red[w][1][lane]; av.z += red[w][2][lane]; }
+#pragma unroll
+  for (int w = 4; w < 8; ++w) { avb.x += red[w][0][lane]; avb.y += red[w][1][lane]; avb.z += red[w][2][lane]; }
+  if (residual) {
+    const v3 v_i = ldv(v + nf * 3), vb_i = ldv(vbar + nf * 3);
+    ah += s[nf]; ahb += sbar[nf];
+    av.x += v_i.x; av.y += v_i.y; av.z += v_i.z;
+    avb.x += vb_i.x; avb.y += vb_i.y; avb.z += vb_i.z;
+  }
+  dh[nf] = ah;
+  dhbar[nf] = ahb;
+  st3(dv + nf * 3, av.x, av.y, av.z);
+  st3(dvbar + nf * 3, avb.x, avb.y, avb.z);
+  if (dv_rows) {
     dv_rows[((size_t)3 * i + 0) * F + f] = av.x;
     dv_rows[((size_t)3 * i + 1) * F + f] = av.y;
     dv_rows[((size_t)3 * i + 2) * F + f] = av.z;
@@ -423,6 +619,303 @@ __global__ __launch_bounds__(576) void pseudo_bwd_src_k(
   }
 }
 
+// ------------------------------------------------------------------ dense bead graphs: backward
+// Same recipe as pseudo_fwd_dense_k (a body per filter, pipelined 32-bit-offset gathers, records through the scalar cache,
+// packed filter sums).  Both passes require all four upstream gradients (the launcher falls back otherwise).
+//
+// Pass A (receiver side): the general kernel gives a receiver's 64 channels to ONE wave that evaluates six filters per edge
+// (66 weights per lane; 640 one-wave blocks on the 64-bead graph = 0.6 waves per SIMD).  Here six waves take one filter
+// each (k = 0, 3, 4, 6, 7, 8) and their partial sums meet in LDS in filter order.
+struct PdRecvBatch {
+  float ph[PD_EB];
+  v3 vj[PD_EB];
+};
+template <int R, int K>
+__device__ __forceinline__ void pseudo_bwd_recv_dense_walk(const float* __restrict__ phi, const float* __restrict__ v,
+                                                           const float* __restrict__ vbar, const float* __restrict__ geom_c,
+                                                           const int* __restrict__ seg_src, int n, int n_pad, int F, int f,
+                                                           const float (&W)[R + 1], float gh_i, float ghb_i, const v3& gv_i,
+                                                           const v3& gvb_i, float& sc, v3& vec) {
+  constexpr int GS = geom_stride(R);
+  const pd_base vsrc = pd_launder((K == 6 || K == 7) ? v : vbar), phib = pd_launder(phi);
+  const unsigned phi_c = (unsigned)(K * F + f) * 4u, phi_s = 9u * (unsigned)F * 4u;
+  const unsigned vec_c = (unsigned)f * 12u, vec_s = (unsigned)F * 12u;
+  auto issue = [&](PdRecvBatch& b, int e0) {
+    const int4 j4 = *reinterpret_cast<const int4*>(seg_src + e0);
+    const int js[4] = {j4.x, j4.y, j4.z, j4.w};
+#pragma unroll
+    for (int u = 0; u < PD_EB; ++u) {
+      unsigned j = (unsigned)js[u];
+      asm volatile("" : "+v"(j));
+      b.ph[u] = ldf_at(phib, __umul24(j, phi_s) + phi_c);
+      b.vj[u] = ldv_at(vsrc, __umul24(j, vec_s) + vec_c);
+    }
+  };
+  auto compute = [&](const PdRecvBatch& b, int e0, auto tail) {
+    const float* __restrict__ gb = geom_c + (size_t)e0 * GS;
+#pragma unroll
+    for (int u = 0; u < PD_EB; ++u) {
+      if (decltype(tail)::value && e0 + u >= n) break;
+      const float q = b.ph[u] * filt_pk<R>(W, gb + u * GS);
+      switch (K) {
+        case 0: sc = fmaf(gh_i, q, sc); axpy(vec, ghb_i, b.vj[u]); break;           // g_s ; the filter-free ghb_i vbar_j of g_v
+        case 3: axpy(vec, q, cross(b.vj[u], gv_i)); break;                          // g_v
+        case 4: sc = fmaf(q, dot(gv_i, b.vj[u]), sc); break;                        // g_sbar
+        case 6: sc = fmaf(q, dot(gvb_i, b.vj[u]), sc); break;                       // g_sbar
+        case 7: axpy(vec, q, cross(b.vj[u], gvb_i)); break;                         // g_v
+        default: axpy(vec, q, cross(b.vj[u], gvb_i)); break;                        // g_vbar (k = 8)
+      }
+    }
+  };
+  PdRecvBatch b0, b1;
+  issue(b0, 0);
+  int e0 = 0;
+  for (; e0 + 2 * PD_EB <= n; e0 += 2 * PD_EB) {
+    issue(b1, e0 + PD_EB);
+    pd_pin();
+    compute(b0, e0, std::false_type{});
+    issue(b0, min(e0 + 2 * PD_EB, n_pad - PD_EB));
+    pd_pin();
+    compute(b1, e0 + PD_EB, std::false_type{});
+  }
+  if (e0 < n) {
+    issue(b1, e0 + PD_EB);
+    pd_pin();
+    compute(b0, e0, std::true_type{});
+    compute(b1, e0 + PD_EB, std::true_type{});
+  }
+}
+
+template <int R>
+__global__ __launch_bounds__(384) void pseudo_bwd_recv_dense_k(const float* __restrict__ phi, const float* __restrict__ v,
+                                                               const float* __restrict__ vbar, const float* __restrict__ geom,
+                                                               const int* __restrict__ rowptr, const int* __restrict__ src,
+                                                               const float* __restrict__ Wd, const float* __restrict__ bd,
+                                                               const float* __restrict__ gh, const float* __restrict__ ghb,
+                                                               const float* __restrict__ gv, const float* __restrict__ gvb,
+                                                               float* __restrict__ g_s, float* __restrict__ g_sbar,
+                                                               float* __restrict__ g_v, float* __restrict__ g_vbar, int F,
+                                                               int residual) {
+  constexpr int GS = geom_stride(R);
+  __shared__ float red[6][4][64];                       // per wave: scalar sum, vector sum
+  __shared__ __attribute__((aligned(16))) int seg_src[SEG_LDS];
+  const int i = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // waves 0..5 -> filters 0, 3, 4, 6, 7, 8
+  const int k = wave == 0 ? 0 : (wave == 1 ? 3 : (wave == 2 ? 4 : wave + 3));
+  const int f_raw = blockIdx.y * 64 + lane;
+  const bool live = f_raw < F;
+  const int f = live ? f_raw : F - 1;
+  float W[R + 1];
+  load_row<R>(W, Wd, bd, k * F + f);
+  const size_t nf = (size_t)i * F + f;
+  const float gh_i = gh[nf], ghb_i = ghb[nf];
+  const v3 gv_i = ldv(gv + nf * 3), gvb_i = ldv(gvb + nf * 3);
+  float sc = 0.f;
+  v3 vec{0.f, 0.f, 0.f};
+  const int e_beg = rowptr[i], e_end = rowptr[i + 1];
+  for (int c_beg = e_beg; c_beg < e_end; c_beg += SEG_LDS) {
+    const int n = min(SEG_LDS, e_end - c_beg);
+    if (c_beg != e_beg) __syncthreads();
+    const int n_pad = pd_stage_indices(seg_src, src, c_beg, n, 384);
+    const float* __restrict__ geom_c = geom + (size_t)c_beg * GS;
+    __syncthreads();
+    switch (k) {
+#define CGV_PD_RECV(KV) case KV: pseudo_bwd_recv_dense_walk<R, KV>(phi, v, vbar, geom_c, seg_src, n, n_pad, F, f, W, gh_i, ghb_i, gv_i, gvb_i, sc, vec); break
+      CGV_PD_RECV(0); CGV_PD_RECV(3); CGV_PD_RECV(4); CGV_PD_RECV(6); CGV_PD_RECV(7);
+      default: pseudo_bwd_recv_dense_walk<R, 8>(phi, v, vbar, geom_c, seg_src, n, n_pad, F, f, W, gh_i, ghb_i, gv_i, gvb_i, sc, vec); break;
+#undef CGV_PD_RECV
+    }
+  }
+  red[wave][0][lane] = sc; red[wave][1][lane] = vec.x; red[wave][2][lane] = vec.y; red[wave][3][lane] = vec.z;
+  __syncthreads();
+  if (wave != 0 || !live) return;
+  // wave order: 0 (k 0: g_s, ghb part of g_v), 1 (k 3: g_v), 2 (k 4: g_sbar), 3 (k 6: g_sbar), 4 (k 7: g_v), 5 (k 8: g_vbar)
+  float as = sc, asb = red[2][0][lane] + red[3][0][lane];
+  v3 av{vec.x + red[1][1][lane] + red[4][1][lane], vec.y + red[1][2][lane] + red[4][2][lane], vec.z + red[1][3][lane] + red[4][3][lane]};
+  v3 avb{red[5][1][lane], red[5][2][lane], red[5][3][lane]};
+  if (residual) {
+    as += gh_i; asb += ghb_i;
+    av.x += gv_i.x; av.y += gv_i.y; av.z += gv_i.z;
+    avb.x += gvb_i.x; avb.y += gvb_i.y; avb.z += gvb_i.z;
+  }
+  g_s[nf] = as;
+  g_sbar[nf] = asb;
+  st3(g_v + nf * 3, av.x, av.y, av.z);
+  st3(g_vbar + nf * 3, avb.x, avb.y, avb.z);
+}
+
+// Pass B (source side + filter gradients): as pseudo_bwd_src_k, one body per filter.  The (R + 1) filter-gradient
+// accumulators of a lane are kept as pairs and take packed FMAs; the gathers of a wave are exactly the receiver-side
+// operands its filter's terms read (3 - 7 values per edge).
+constexpr int PD_SRC_EB = 2;          // (four edges' operands in flight: with PD_EB = 4 the cross-product bodies spill)
+struct PdSrcBatch {
+  v3 A[PD_SRC_EB], B[PD_SRC_EB];
+  float sA[PD_SRC_EB], sB[PD_SRC_EB], hb[PD_SRC_EB];
+};
+template <int R, int K>
+__device__ __forceinline__ void pseudo_bwd_src_dense_walk(const float* __restrict__ s, const float* __restrict__ sbar,
+                                                          const float* __restrict__ v, const float* __restrict__ vbar,
+                                                          const float* __restrict__ gh, const float* __restrict__ ghb,
+                                                          const float* __restrict__ gv, const float* __restrict__ gvb,
+                                                          const float* __restrict__ geom_c, const int* __restrict__ seg_dst,
+                                                          int n, int n_pad, int F, int f, const float (&W)[R + 1], float p,
+                                                          const v3& v_j, const v3& vb_j, float& a, pd_f2 (&G2)[R / 2], float& GR,
+                                                          v3& av, v3& avb) {
+  constexpr int GS = geom_stride(R), U = geom_unit_offset(R);
+  const pd_base vecA = pd_launder(K <= 4 ? gv : gvb);                                 // K >= 1
+  const pd_base vecB = pd_launder(K == 8 ? vbar : v);                                 // K = 0, 3, 7, 8
+  const pd_base scaA = pd_launder(K == 0 ? gh : sbar);                                // K = 0, 4, 6
+  const pd_base sBb = pd_launder(s), hbb = pd_launder(ghb);                           // K = 0
+  const unsigned sc_c = (unsigned)f * 4u, sc_s = (unsigned)F * 4u;
+  const unsigned vec_c = (unsigned)f * 12u, vec_s = (unsigned)F * 12u;
+  constexpr bool hasA = K >= 1, hasB = K == 0 || K == 3 || K == 7 || K == 8, hasS = K == 0 || K == 4 || K == 6;
+  auto issue = [&](PdSrcBatch& b, int e0) {
+    const int2 i2 = *reinterpret_cast<const int2*>(seg_dst + e0);
+    const int is[2] = {i2.x, i2.y};
+#pragma unroll
+    for (int u = 0; u < PD_SRC_EB; ++u) {
+      unsigned ii = (unsigned)is[u];
+      asm volatile("" : "+v"(ii));
+      const unsigned vo = __umul24(ii, vec_s) + vec_c, so = __umul24(ii, sc_s) + sc_c;
+      if (hasA) b.A[u] = ldv_at(vecA, vo);
+      if (hasB) b.B[u] = ldv_at(vecB, vo);
+      if (hasS) b.sA[u] = ldf_at(scaA, so);
+      if (K == 0) { b.sB[u] = ldf_at(sBb, so); b.hb[u] = ldf_at(hbb, so); }
+    }
+  };
+  auto compute = [&](const PdSrcBatch& b, int e0, auto tail) {
+    const float* __restrict__ gb = geom_c + (size_t)e0 * GS;
+#pragma unroll
+    for (int u = 0; u < PD_SRC_EB; ++u) {
+      if (decltype(tail)::value && e0 + u >= n) break;
+      const float* __restrict__ g = gb + u * GS;
+      const v3 zero{0.f, 0.f, 0.f};
+      float gq;
+      v3 cav = zero, cavb = zero;
+      switch (K) {
+        case 0: gq = b.sA[u] * b.sB[u]; break;
+        case 1: gq = dot(b.A[u], v3{g[U], g[U + 1], g[U + 2]}); break;
+        case 2: gq = dot(b.A[u], v_j); cav = b.A[u]; break;
+        case 3: gq = dot(b.A[u], cross(b.B[u], vb_j)); cavb = cross(b.A[u], b.B[u]); break;
+        case 4: gq = b.sA[u] * dot(b.A[u], vb_j); cavb = v3{b.sA[u] * b.A[u].x, b.sA[u] * b.A[u].y, b.sA[u] * b.A[u].z}; break;
+        case 5: gq = dot(b.A[u], vb_j); cavb = b.A[u]; break;
+        case 6: gq = b.sA[u] * dot(b.A[u], v_j); cav = v3{b.sA[u] * b.A[u].x, b.sA[u] * b.A[u].y, b.sA[u] * b.A[u].z}; break;
+        case 7: gq = dot(b.A[u], cross(b.B[u], v_j)); cav = cross(b.A[u], b.B[u]); break;
+        default: gq = dot(b.A[u], cross(b.B[u], vb_j)); cavb = cross(b.A[u], b.B[u]); break;
+      }
+      const float w = filt_pk<R>(W, g);
+      a = fmaf(gq, w, a);
+      const float t = gq * p;
+#pragma unroll
+      for (int m = 0; m < R / 2; ++m) G2[m] = __builtin_elementwise_fma(pd_f2{t, t}, pd_f2{g[2 * m], g[2 * m + 1]}, G2[m]);
+      GR = fmaf(t, g[R], GR);
+      const float q = p * w;
+      if (K == 2 || K == 6 || K == 7) axpy(av, q, cav);
+      if (K == 3 || K == 4 || K == 5 || K == 8) axpy(avb, q, cavb);
+      if (K == 0) axpy(avb, b.hb[u], b.B[u]);                                          // the filter-free term ghb_i v_i
+    }
+  };
+  PdSrcBatch b0, b1;
+  issue(b0, 0);
+  int e0 = 0;
+  for (; e0 + 2 * PD_SRC_EB <= n; e0 += 2 * PD_SRC_EB) {
+    issue(b1, e0 + PD_SRC_EB);
+    pd_pin();
+    compute(b0, e0, std::false_type{});
+    issue(b0, min(e0 + 2 * PD_SRC_EB, n_pad - PD_SRC_EB));
+    pd_pin();
+    compute(b1, e0 + PD_SRC_EB, std::false_type{});
+  }
+  if (e0 < n) {
+    issue(b1, e0 + PD_SRC_EB);
+    pd_pin();
+    compute(b0, e0, std::true_type{});
+    compute(b1, e0 + PD_SRC_EB, std::true_type{});
+  }
+}
+
+__device__ __forceinline__ int pd_src_filter_of_wave(int wave) {
+  // the SIMD with three waves (0, 4, 8) gets the three cheapest bodies (k = 1, 0, 2); the others a cross-product body
+  // (k = 3, 7, 8) and a lighter one (k = 4, 6, 5) each.      wave: 0  1  2  3  4  5  6  7  (8 -> 2)
+  constexpr unsigned table = (1u << 0) | (3u << 4) | (7u << 8) | (8u << 12) | (0u << 16) | (4u << 20) | (6u << 24) | (5u << 28);
+  return wave == 8 ? 2 : (int)((table >> (4 * wave)) & 15u);
+}
+
+template <int R>
+__global__ __launch_bounds__(576) void pseudo_bwd_src_dense_k(
+    const float* __restrict__ phi, const float* __restrict__ s, const float* __restrict__ sbar,
+    const float* __restrict__ v, const float* __restrict__ vbar, const float* __restrict__ geom,
+    const int* __restrict__ rowptr, const int* __restrict__ dst, const float* __restrict__ Wd,
+    const float* __restrict__ bd, const float* __restrict__ gh, const float* __restrict__ ghb,
+    const float* __restrict__ gv, const float* __restrict__ gvb, float* __restrict__ g_phi,
+    float* __restrict__ g_v, float* __restrict__ g_vbar, float* __restrict__ part, int F, int N, int nodes_per_chunk) {
+  constexpr int GS = geom_stride(R);
+  __shared__ float red[8][6][64];
+  __shared__ __attribute__((aligned(16))) int seg_dst[SEG_LDS];
+  const int lane = threadIdx.x & 63;
+  const int k = pd_src_filter_of_wave(__builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
+  const int f_raw = blockIdx.y * 64 + lane;
+  const bool live = f_raw < F;
+  const int f = live ? f_raw : F - 1;
+  float W[R + 1], GR = 0.f;
+  pd_f2 G2[R / 2];
+  load_row<R>(W, Wd, bd, k * F + f);
+#pragma unroll
+  for (int m = 0; m < R / 2; ++m) G2[m] = pd_f2{0.f, 0.f};
+  const int n_beg = blockIdx.x * nodes_per_chunk, n_end = min(n_beg + nodes_per_chunk, N);
+  for (int j = n_beg; j < n_end; ++j) {
+    const float p = phi[(size_t)j * 9 * F + (size_t)k * F + f];
+    const size_t jf = (size_t)j * F + f;
+    const v3 v_j = ldv(v + jf * 3), vb_j = ldv(vbar + jf * 3);
+    float a = 0.f;
+    v3 av{0.f, 0.f, 0.f}, avb{0.f, 0.f, 0.f};
+    const int e_beg = rowptr[j], e_end = rowptr[j + 1];
+    for (int c_beg = e_beg; c_beg < e_end; c_beg += SEG_LDS) {
+      const int n = min(SEG_LDS, e_end - c_beg);
+      __syncthreads();                                                   // readers of the previous chunk / node
+      const int n_pad = pd_stage_indices(seg_dst, dst, c_beg, n, 576);
+      const float* __restrict__ geom_c = geom + (size_t)c_beg * GS;
+      __syncthreads();
+      switch (k) {
+#define CGV_PD_SRC(KV) case KV: pseudo_bwd_src_dense_walk<R, KV>(s, sbar, v, vbar, gh, ghb, gv, gvb, geom_c, seg_dst, n, n_pad, F, f, W, p, v_j, vb_j, a, G2, GR, av, avb); break
+        CGV_PD_SRC(0); CGV_PD_SRC(1); CGV_PD_SRC(2); CGV_PD_SRC(3); CGV_PD_SRC(4); CGV_PD_SRC(5); CGV_PD_SRC(6); CGV_PD_SRC(7);
+        default: pseudo_bwd_src_dense_walk<R, 8>(s, sbar, v, vbar, gh, ghb, gv, gvb, geom_c, seg_dst, n, n_pad, F, f, W, p, v_j, vb_j, a, G2, GR, av, avb); break;
+#undef CGV_PD_SRC
+      }
+    }
+    if (k > 0) {
+      float* r = &red[k - 1][0][lane];
+      r[0] = av.x; r[64] = av.y; r[128] = av.z; r[192] = avb.x; r[256] = avb.y; r[320] = avb.z;
+    }
+    __syncthreads();
+    if (live) g_phi[(size_t)j * 9 * F + (size_t)k * F + f] = a;
+    if (k == 0) {
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8) {
+        const float* r = &red[w8][0][lane];
+        av.x += r[0]; av.y += r[64]; av.z += r[128]; avb.x += r[192]; avb.y += r[256]; avb.z += r[320];
+      }
+      if (live) {
+        const v3 r0 = ldv(g_v + jf * 3), r1 = ldv(g_vbar + jf * 3);        // pass A's receiver-side part
+        st3(g_v + jf * 3, r0.x + av.x, r0.y + av.y, r0.z + av.z);
+        st3(g_vbar + jf * 3, r1.x + avb.x, r1.y + avb.y, r1.z + avb.z);
+      }
+    }
+    __syncthreads();                                 // red is reused by the next node
+  }
+  if (live) {
+    float* __restrict__ out = part + (size_t)blockIdx.x * 9 * (R + 1) * F;
+#pragma unroll
+    for (int m = 0; m < R / 2; ++m) {
+      out[(size_t)(k * (R + 1) + 2 * m) * F + f] = G2[m].x;
+      out[(size_t)(k * (R + 1) + 2 * m + 1) * F + f] = G2[m].y;
+    }
+    out[(size_t)(k * (R + 1) + R) * F + f] = GR;
+  }
+}
+
 // gWd[c][n] = sum over chunks of part[chunk][k][n][f] (c = k F + f), gbd likewise for n = R.  Block = 64 channels x 4
 // chunk slices: slice s sums chunks s, s+4, ... and the four partial sums meet in LDS in slice order (deterministic);
 // the serial version (one thread per output walking all 64 chunks of a 96-bead batch) took 17.8 us per layer.
@@ -504,8 +997,11 @@ int cgv_pseudo_msg_fwd_rows(const float* phi, const float* s, const float* sbar,
     else if (variant == 4) CGV_PF(8, true);
     else if (variant == 5) CGV_PF(8, false);
     else if (variant == 6) CGV_PF(1, true);
-    else if (dense)        // 2000-atom config (64 beads, 61 edges each), per layer: EB 2 staged 56 us, EB 2 59, EB 4 / 8 staged 73 / 71,
-      CGV_PF(2, true);     // EB 8 80 -- the walk is bound by VALU issue (9 x 11 dependent FMAs per edge and channel), not by its loads
+    else if (dense && n_nodes < (1 << 24) && 9L * n_feat * 4 < (1L << 24) && (long)n_nodes * 9 * n_feat * 4 < (1L << 31))   // (32-bit gather offsets from 24-bit factors)
+      hipLaunchKernelGGL((cgv::pseudo_fwd_dense_k<RBF>), grid, dim3(576), 0, st, phi, s, sbar, v, vbar, geom_d, rowptr_d, src_d,
+                         Wd, bd, dh, dhbar, dv, dvbar, n_feat, residual, dv_rows);
+    else if (dense)        // 2000-atom config (64 beads, 61 edges each), per layer: EB 2 staged 56 us, EB 2 59, EB 4 / 8 staged 73 / 71, EB 8 80
+      CGV_PF(2, true);
     else if ((long)grid.x * grid.y <= 256)
       hipLaunchKernelGGL((cgv::pseudo_fwd_k<RBF, cgv::PSEUDO_EB_WIDE>), grid, dim3(576), 0, st, phi, s, sbar, v, vbar, geom_d,
                          rowptr_d, src_d, Wd, bd, dh, dhbar, dv, dvbar, n_feat, residual, dv_rows);
@@ -539,7 +1035,16 @@ int cgv_pseudo_msg_bwd(const float* phi, const float* s, const float* sbar, cons
   float* part = reinterpret_cast<float*>(workspace);
   dim3 gridA(n_nodes > 0 ? n_nodes : 1, (n_feat + 63) / 64), gridB(chunks, (n_feat + 63) / 64);
   const bool dense = n_edges_hint >= 16LL * n_nodes;
+  // dense bead graph, all four upstream gradients present, 32-bit gather offsets from 24-bit factors: the per-filter kernels
+  const bool lean = dense && gh && ghbar && gv && gvbar && cgv::option(CGV_OPT_PSEUDO_FWD) == 0 && n_nodes < (1 << 24) &&
+                    9L * n_feat * 4 < (1L << 24) && (long)n_nodes * 9 * n_feat * 4 < (1L << 31);
   CGV_DISPATCH_RBF(n_rbf, {
+    if (lean) {
+      hipLaunchKernelGGL((cgv::pseudo_bwd_recv_dense_k<RBF>), gridA, dim3(384), 0, st, phi, v, vbar, geom_d, rowptr_d, src_d, Wd, bd,
+                         gh, ghbar, gv, gvbar, g_s, g_sbar, g_v, g_vbar, n_feat, residual);
+      hipLaunchKernelGGL((cgv::pseudo_bwd_src_dense_k<RBF>), gridB, dim3(576), 0, st, phi, s, sbar, v, vbar, geom_s, rowptr_s, dst_s,
+                         Wd, bd, gh, ghbar, gv, gvbar, g_phi, g_v, g_vbar, part, n_feat, n_nodes, npc);
+    } else {
     if (n_nodes > 0 && (long)gridA.x * gridA.y <= 256)
       hipLaunchKernelGGL((cgv::pseudo_bwd_recv_k<RBF, cgv::PSEUDO_EB_WIDE>), gridA, dim3(64), 0, st, phi, v, vbar, geom_d,
                          rowptr_d, src_d, Wd, bd, gh, ghbar, gv, gvbar, g_s, g_sbar, g_v, g_vbar, n_feat, residual);
@@ -555,6 +1060,7 @@ int cgv_pseudo_msg_bwd(const float* phi, const float* s, const float* sbar, cons
     else
       hipLaunchKernelGGL((cgv::pseudo_bwd_src_k<RBF, 2>), gridB, dim3(576), 0, st, phi, s, sbar, v, vbar, geom_s, rowptr_s,
                          dst_s, Wd, bd, gh, ghbar, gv, gvbar, g_phi, g_v, g_vbar, part, n_feat, n_nodes, npc);
+    }
   });
   dim3 rgrid((n_feat + 63) / 64, n_rbf + 1, 9);
   hipLaunchKernelGGL(cgv::pseudo_bwd_reduce, rgrid, dim3(64, cgv::PRED_SLICES), 0, st, part, chunks, n_rbf, n_feat, gWd, gbd);
