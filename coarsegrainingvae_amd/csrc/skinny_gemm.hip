@@ -42,6 +42,12 @@ __global__ __launch_bounds__(64 * WAVES) void skinny_fwd_k(const float* __restri
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, q = lane >> 4;
   const int n0 = blockIdx.x * 16;
+  {                                     // blockIdx.y: this block's 16 MB rows (more, smaller blocks when there are few column blocks)
+    const int m0 = blockIdx.y * 16 * MB;
+    x += (size_t)m0 * K; y += (size_t)m0 * N;
+    if (zout) zout += (size_t)m0 * N;
+    M = min(M - m0, 16 * MB);
+  }
   const int nrow = n0 + i;
   const bool nok = nrow < N;
   const float* wrow = W + (size_t)(nok ? nrow : 0) * K;
@@ -1408,10 +1414,19 @@ int cgv_skinny_linear_fwd(const float* x, const float* W, const float* bias, flo
   CGV_REQUIRE(((((uintptr_t)x | (uintptr_t)W | (uintptr_t)y | (uintptr_t)bias | (uintptr_t)z)) & 15) == 0,
               "operands must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid((N + 15) / 16);
-  // enough waves to fill the chip: few column blocks -> split K over more waves per block
-  const int waves = grid.x >= 256 ? 4 : (grid.x >= 96 ? 8 : 16);
-  switch ((M + 15) / 16) {
+  dim3 grid((N + 15) / 16);
+  // row blocks (of 16 rows) per thread block: all of them, or -- when that leaves the chip mostly idle -- fewer, in more blocks
+  const int row_blocks = (M + 15) / 16;
+  // (64 bead rows, 2000-atom config: 600 x 600 8.98 -> 4.65 us, 1800 x 600 9.43 -> 6.02, 600 x 1200 13.3 -> 6.1 with one
+  //  row block per thread block; 5400 x 600, 338 column blocks: 14.2 -> 16.0, left alone)
+  int mb = cgv::option(CGV_OPT_SKINNY_ROWS);
+  if (mb <= 0 || mb > 4) mb = (long)grid.x * row_blocks <= 512 ? 1 : row_blocks;
+  if (mb > row_blocks) mb = row_blocks;
+  grid.y = (row_blocks + mb - 1) / mb;
+  // enough waves to fill the chip: few blocks -> split K over more waves per block
+  const long blocks = (long)grid.x * grid.y;
+  const int waves = blocks >= 256 ? 4 : (blocks >= 96 ? 8 : 16);
+  switch (mb) {
     case 1: cgv::launch_fwd<1>(grid, waves, st, x, W, bias, y, z, M, N, K, act); break;
     case 2: cgv::launch_fwd<2>(grid, waves, st, x, W, bias, y, z, M, N, K, act); break;
     case 3: cgv::launch_fwd<3>(grid, waves, st, x, W, bias, y, z, M, N, K, act); break;

@@ -421,7 +421,14 @@ class _LinearFn(torch.autograd.Function):
             return gx, gw, gb, None
         if need_x:
             gx = torch.empty(M, K, dtype=torch.float32, device=gy.device)
-            skinny_bwd_input(gy2, z, weight, gx, M, N, K, act)
+            if M > 32 and N <= 1024 and gy2.data_ptr() % 16 == 0 and _lib.load().cgv_tile_supported(M, N, K):
+                # many bead rows, a short reduction (64 beads of the 2000-atom config, 600 outputs): one launch of the tile
+                # kernel (8.7 us; 6.2 without activation) against the row-split kernel + its reduction (12.9 / 12.1 us;
+                # tools/bwd_input_bench.py) -- from 1200 outputs on the row split wins again (13.0 against 13.8 us)
+                _lib.call("cgv_tile_linear_bwd_input_act", _lib.ptr(gy2), _lib.ptr(z) if act != ACT_NONE else None,
+                          _lib.ptr(weight), _lib.ptr(gx), M, N, K, act, st)
+            else:
+                skinny_bwd_input(gy2, z, weight, gx, M, N, K, act)
             gx = gx.reshape(gy.shape[:-1] + (K,))
         if need_w:
             # row count / shape of this layer's weight-gradient problem: the data-parallel trainer sorts the layers

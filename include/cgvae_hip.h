@@ -76,7 +76,8 @@ enum {
   CGV_OPT_PSEUDO_FWD = 10,     /* cgv_pseudo_msg_fwd*: 0 built-in rule; 1..6 = (edges in flight, records staged in LDS) variants; cgv_pseudo_msg_bwd on dense bead graphs: 4 = 8 edges in flight, 5 = records not staged in LDS */
   CGV_OPT_DECODER_FAT = 11,    /* cgv_decoder_{gate,dense,uv}_bwd: 1 (default) 8-channel blocks where the width allows, 0 always 4 */
   CGV_OPT_DECODER_WLDS = 12,   /* cgv_decoder_msg_fwd: 1 (default) weight rows by LDS-DMA when they fit in LDS, 0 register path */
-  CGV_OPT_COUNT = 13
+  CGV_OPT_SKINNY_ROWS = 13,    /* cgv_skinny_linear_fwd: row blocks (of 16) per thread block; 0 = built-in rule, 1..4 */
+  CGV_OPT_COUNT = 14
 };
 /* Measurement: store the GPU wall clock (cgv_timestamp_hz ticks per second) into *slot, in stream order; capturable. */
 int cgv_timestamp(uint64_t* slot /*device*/, void* stream);
