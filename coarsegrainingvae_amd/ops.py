@@ -319,6 +319,13 @@ class _PseudoMessage(torch.autograd.Function):
             return (None,) * 10
         gh, ghb, gv, gvb = _c(gh), _c(ghb), _c(gv), _c(gvb)
         n, F = s.shape
+        if plan.n_edges >= 16 * n:
+            # dense bead graph: the per-filter kernels want all four upstream gradients (a layer whose scalar outputs go
+            # unused -- the decoder's last -- would otherwise take the general kernels: 112 against ~65 us there)
+            gh = gh if gh is not None else torch.zeros_like(s)
+            ghb = ghb if ghb is not None else torch.zeros_like(s)
+            gv = gv if gv is not None else torch.zeros_like(v)
+            gvb = gvb if gvb is not None else torch.zeros_like(v)
         g_phi = torch.empty_like(phi)
         g_s, g_sbar = torch.empty_like(s), torch.empty_like(s)
         g_v, g_vbar = torch.empty_like(v), torch.empty_like(v)

@@ -1601,3 +1601,45 @@ def test_device_drawn_noise_path_equals_supplied_noise_path():
     assert g_dev.keys() == g_sup.keys() and len(g_dev) > 30
     for k in g_sup:
         assert rel_err(g_dev[k], g_sup[k]) <= 5e-5, k                   # z is one fma there, a rounded product + sum here
+
+
+@pytest.mark.parametrize("n,F,R,full,drop", [(40, 100, 10, False, None), (150, 64, 8, True, None), (24, 600, 10, True, "scalars"),
+                                             (33, 132, 12, False, "vectors")])
+def test_dense_bead_graph_message_kernels_equal_the_general_ones(n, F, R, full, drop, options):
+    """K3 on dense bead graphs (>= 16 edges per node: the per-filter kernels pseudo_*_dense_k) against the general
+    kernels (option pseudo_fwd = 2; themselves pinned to the golden vectors): ragged segments, a partial channel wave,
+    segments longer than the staged index chunk (150 fully connected nodes), and a layer whose scalar or vector outputs
+    go unused (upstream gradients absent).  Same operations, another summation order: fp32 rounding apart."""
+    from coarsegrainingvae_amd import ops
+    gen = torch.Generator().manual_seed(n * 7 + F)
+    pos = 3.0 * torch.randn(n, 3, generator=gen)
+    if full:
+        pairs = [(i, j) for i in range(n) for j in range(n) if i != j]
+    else:                                                # ragged: every node keeps 17 .. n - 1 random neighbours
+        pairs = []
+        for i in range(n):
+            k = int(torch.randint(17, n, (1,), generator=gen))
+            others = [j for j in torch.randperm(n, generator=gen).tolist() if j != i][:k]
+            pairs += [(i, j) for j in others]
+    nbrs = torch.tensor(pairs, dtype=torch.long)
+    plan = EdgePlan.from_nbrs(nbrs.to(DEV), n)
+    assert plan.n_edges >= 16 * n
+    geom = EdgeGeometry(plan, R, 12.0, pos_dst=pos.to(DEV), pos_src=pos.to(DEV))
+    rn = lambda *shape: torch.randn(*shape, generator=gen).to(DEV)
+    base = [rn(n, 9 * F), rn(n, F), rn(n, F), rn(n, F, 3), rn(n, F, 3), 0.3 * rn(9 * F, R), 0.3 * rn(9 * F)]
+    gouts = [rn(n, F), rn(n, F), rn(n, F, 3), rn(n, F, 3)]
+    used = {"scalars": (2, 3), "vectors": (0, 1)}.get(drop, (0, 1, 2, 3))
+
+    def run(variant, residual):
+        options.set("pseudo_fwd", variant)
+        ins = [t.clone().requires_grad_(True) for t in base]
+        outs = ops.pseudo_message(*ins, plan, geom, residual)
+        torch.autograd.backward([outs[k] for k in used], [gouts[k] for k in used])
+        return [o.detach() for o in outs], [t.grad for t in ins]
+
+    for residual in (False, True):
+        o_gen, g_gen = run(2, residual)
+        o_dense, g_dense = run(0, residual)
+        names = ["dh", "dhbar", "dv", "dvbar", "g_phi", "g_s", "g_sbar", "g_v", "g_vbar", "gWd", "gbd"]
+        for name, a, b in zip(names, o_gen + g_gen, o_dense + g_dense):
+            assert_close(b, a, f"{name} (residual={residual})", 3e-6)

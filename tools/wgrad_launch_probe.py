@@ -12,6 +12,11 @@ from coarsegrainingvae_amd.trainer import Trainer       # noqa: E402
 wl = sys.argv[1] if len(sys.argv) > 1 else "dipeptide"
 if os.environ.get("RANK_ROWS_MFMA"):
     Trainer.RANK_ROWS_MFMA = int(os.environ["RANK_ROWS_MFMA"])
+if os.environ.get("RANK_ROWS_PAY"):
+    Trainer.RANK_ROWS_PAY = int(os.environ["RANK_ROWS_PAY"])
+if os.environ.get("STRIP_MIN_ROWS"):
+    from coarsegrainingvae_amd.primitives import WeightGradQueue
+    WeightGradQueue.STRIP_MIN_ROWS = int(os.environ["STRIP_MIN_ROWS"])
 w = cg.data.WORKLOADS[wl]
 model = cg.build_model(600, w["n_rbf"], w["atom_cutoff"], w["cg_cutoff"], w["enc_nconv"], w["dec_nconv"], w["n_cgs"], seed=123).cuda()
 batch = cg.synthetic_batch(wl, seed=0, device="cuda")
