@@ -74,6 +74,7 @@ PROTOTYPES = {
     "cgv_update_gate_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "cgv_skinny_max_rows": (_i, []),
     "cgv_skinny_supported": (_i, [_i, _i, _i]),
+    "cgv_skinny_fwd_supported": (_i, [_i, _i, _i]),
     "cgv_skinny_linear_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "cgv_skinny_bwd_input_supported": (_i, [_i, _i, _i]),
     "cgv_skinny_bwd_input_workspace_bytes": (_sz, [_i, _i, _i]),

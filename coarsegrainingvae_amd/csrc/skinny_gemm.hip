@@ -1406,11 +1406,16 @@ int cgv_skinny_supported(int M, int N, int K) {
   return M >= 1 && M <= 64 && N >= 4 && K >= 4 && (N % 4) == 0 && (K % 4) == 0;
 }
 
+/* the forward alone takes any row count: a thread block owns 16 - 64 rows (blockIdx.y), cgv_skinny_linear_fwd picks how many */
+int cgv_skinny_fwd_supported(int M, int N, int K) {
+  return M >= 1 && (M + 15) / 16 <= 65535 && N >= 4 && K >= 4 && (N % 4) == 0 && (K % 4) == 0;
+}
+
 int cgv_skinny_linear_fwd(const float* x, const float* W, const float* bias, float* y, float* z, int M, int N, int K,
                           int act, void* stream) {
   CGV_REQUIRE(x && W && y, "null pointer");
   CGV_REQUIRE(act >= 0 && act <= cgv::CGV_ACT_MAX, "act must be 0 (identity), 1 (swish), 2 (tanh), 3 (relu), 4 / 5 (c + exp(z/2))");
-  CGV_REQUIRE(cgv_skinny_supported(M, N, K), "unsupported shape (need M <= 64, N % 4 == 0, K % 4 == 0)");
+  CGV_REQUIRE(cgv_skinny_fwd_supported(M, N, K), "unsupported shape (need N % 4 == 0, K % 4 == 0, at most 65535 row blocks)");
   CGV_REQUIRE(((((uintptr_t)x | (uintptr_t)W | (uintptr_t)y | (uintptr_t)bias | (uintptr_t)z)) & 15) == 0,
               "operands must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
@@ -1420,7 +1425,7 @@ int cgv_skinny_linear_fwd(const float* x, const float* W, const float* bias, flo
   // (64 bead rows, 2000-atom config: 600 x 600 8.98 -> 4.65 us, 1800 x 600 9.43 -> 6.02, 600 x 1200 13.3 -> 6.1 with one
   //  row block per thread block; 5400 x 600, 338 column blocks: 14.2 -> 16.0, left alone)
   int mb = cgv::option(CGV_OPT_SKINNY_ROWS);
-  if (mb <= 0 || mb > 4) mb = (long)grid.x * row_blocks <= 512 ? 1 : row_blocks;
+  if (mb <= 0 || mb > 4) mb = (long)grid.x * row_blocks <= 512 ? 1 : 4;
   if (mb > row_blocks) mb = row_blocks;
   grid.y = (row_blocks + mb - 1) / mb;
   // enough waves to fill the chip: few blocks -> split K over more waves per block

@@ -330,8 +330,12 @@ class _LinearFn(torch.autograd.Function):
                 _lib.call("cgv_decoder_dense_fwd", _lib.ptr(x2), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(y), _lib.ptr(z),
                           M, N, K, act, _lib.stream_ptr())
             else:
-                _lib.call("cgv_skinny_linear_fwd" if mode == "skinny" else "cgv_tile_linear_fwd", _lib.ptr(x2), _lib.ptr(weight),
-                          _lib.ptr(bias), _lib.ptr(y), _lib.ptr(z), M, N, K, act, _lib.stream_ptr())
+                # 65 - 128 rows (a big bead batch) and at most 1200 outputs: the weight-streaming kernel with one 16-row block
+                # per thread block still beats the tiles (96 rows: 600 x 600 4.8 against 6.7 us, 600 x 1200 6.3 / 10.5,
+                # 1200 x 600 5.9 / 6.7; from 1800 outputs on the tiles win: tools/fwd_bench.py)
+                few_rows = mode == "tile" and M <= 128 and N <= 1200 and (bias is None or bias.data_ptr() % 16 == 0)
+                _lib.call("cgv_skinny_linear_fwd" if (mode == "skinny" or few_rows) else "cgv_tile_linear_fwd", _lib.ptr(x2),
+                          _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(y), _lib.ptr(z), M, N, K, act, _lib.stream_ptr())
             ctx.save_for_backward(x2, weight, z)
             return y.reshape(x.shape[:-1] + (N,))
         z = Fn.linear(x, weight, bias)

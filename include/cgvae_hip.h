@@ -440,6 +440,7 @@ int cgv_update_gate_bwd_slices(const float* U, const float* Vv, const float* a, 
  * ------------------------------------------------------------------------------------- */
 int cgv_skinny_max_rows(void);
 int cgv_skinny_supported(int M, int N, int K);
+int cgv_skinny_fwd_supported(int M, int N, int K);   /* cgv_skinny_linear_fwd alone: any row count (row blocks over blockIdx.y) */
 int cgv_skinny_linear_fwd(const float* x, const float* W, const float* bias, float* y, float* z /*or NULL*/, int M, int N,
                           int K, int act, void* stream);
 int cgv_skinny_bwd_input_supported(int M, int N, int K);      /* bwd_input alone takes up to 128 rows */

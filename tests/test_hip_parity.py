@@ -1643,3 +1643,24 @@ def test_dense_bead_graph_message_kernels_equal_the_general_ones(n, F, R, full, 
         names = ["dh", "dhbar", "dv", "dvbar", "g_phi", "g_s", "g_sbar", "g_v", "g_vbar", "gWd", "gbd"]
         for name, a, b in zip(names, o_gen + g_gen, o_dense + g_dense):
             assert_close(b, a, f"{name} (residual={residual})", 3e-6)
+
+
+@pytest.mark.parametrize("rows_per_block", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("M,N,K", [(130, 52, 100), (64, 600, 600), (7, 20, 36), (300, 1800, 64)])
+def test_skinny_forward_row_blocks(M, N, K, rows_per_block, options):
+    """cgv_skinny_linear_fwd with its thread blocks owning 16 .. 64 rows each (blockIdx.y; option skinny_rows, 0 = the
+    built-in rule), any row count: y = swish(x W^T + b) and the saved pre-activation against fp64."""
+    from coarsegrainingvae_amd import _lib
+    lib = _lib.load()
+    assert lib.cgv_skinny_fwd_supported(M, N, K) and not lib.cgv_skinny_fwd_supported(M, N + 2, K)
+    options.set("skinny_rows", rows_per_block)
+    gen = torch.Generator().manual_seed(M + N + K)
+    x, W, b = torch.randn(M, K, generator=gen), torch.randn(N, K, generator=gen) / K ** 0.5, torch.randn(N, generator=gen)
+    y = torch.full((M + 1, N), float("nan"), device=DEV)                  # one guard row behind the output
+    z = torch.full((M + 1, N), float("nan"), device=DEV)
+    xg, Wg, bg = x.to(DEV), W.to(DEV), b.to(DEV)
+    _lib.call("cgv_skinny_linear_fwd", _lib.ptr(xg), _lib.ptr(Wg), _lib.ptr(bg), _lib.ptr(y), _lib.ptr(z), M, N, K, 1, _lib.stream_ptr())
+    zd = x.double() @ W.double().t() + b.double()
+    assert_close(z[:M], zd, "z", 2e-6)
+    assert_close(y[:M], zd * torch.sigmoid(zd), "y", 2e-6)
+    assert torch.isnan(y[M]).all() and torch.isnan(z[M]).all()
