@@ -798,20 +798,21 @@ __device__ __forceinline__ void pseudo_bwd_src_dense_walk(const float* __restric
         case 0: gq = b.sA[u] * b.sB[u]; break;
         case 1: gq = dot(b.A[u], v3{g[U], g[U + 1], g[U + 2]}); break;
         case 2: gq = dot(b.A[u], v_j); cav = b.A[u]; break;
-        case 3: gq = dot(b.A[u], cross(b.B[u], vb_j)); cavb = cross(b.A[u], b.B[u]); break;
-        case 4: gq = b.sA[u] * dot(b.A[u], vb_j); cavb = v3{b.sA[u] * b.A[u].x, b.sA[u] * b.A[u].y, b.sA[u] * b.A[u].z}; break;
+        // cross-product bodies: a . (b x c) = c . (a x b), so the cross product the source-side sum needs anyway also gives gq
+        case 3: cavb = cross(b.A[u], b.B[u]); gq = dot(vb_j, cavb); break;
+        case 4: gq = b.sA[u] * dot(b.A[u], vb_j); cavb = b.A[u]; break;                 // (sbar_i joins q below)
         case 5: gq = dot(b.A[u], vb_j); cavb = b.A[u]; break;
-        case 6: gq = b.sA[u] * dot(b.A[u], v_j); cav = v3{b.sA[u] * b.A[u].x, b.sA[u] * b.A[u].y, b.sA[u] * b.A[u].z}; break;
-        case 7: gq = dot(b.A[u], cross(b.B[u], v_j)); cav = cross(b.A[u], b.B[u]); break;
-        default: gq = dot(b.A[u], cross(b.B[u], vb_j)); cavb = cross(b.A[u], b.B[u]); break;
+        case 6: gq = b.sA[u] * dot(b.A[u], v_j); cav = b.A[u]; break;
+        case 7: cav = cross(b.A[u], b.B[u]); gq = dot(v_j, cav); break;
+        default: cavb = cross(b.A[u], b.B[u]); gq = dot(vb_j, cavb); break;
       }
       const float w = filt_pk<R>(W, g);
       a = fmaf(gq, w, a);
-      const float t = gq * p;
+      // (the filter-gradient sums leave out the node's phi: it multiplies them once, when the node is done)
 #pragma unroll
-      for (int m = 0; m < R / 2; ++m) G2[m] = __builtin_elementwise_fma(pd_f2{t, t}, pd_f2{g[2 * m], g[2 * m + 1]}, G2[m]);
-      GR = fmaf(t, g[R], GR);
-      const float q = p * w;
+      for (int m = 0; m < R / 2; ++m) G2[m] = __builtin_elementwise_fma(pd_f2{gq, gq}, pd_f2{g[2 * m], g[2 * m + 1]}, G2[m]);
+      GR = fmaf(gq, g[R], GR);
+      const float q = (K == 4 || K == 6) ? p * w * b.sA[u] : p * w;
       if (K == 2 || K == 6 || K == 7) axpy(av, q, cav);
       if (K == 3 || K == 4 || K == 5 || K == 8) axpy(avb, q, cavb);
       if (K == 0) axpy(avb, b.hb[u], b.B[u]);                                          // the filter-free term ghb_i v_i
@@ -871,6 +872,10 @@ __global__ __launch_bounds__(576) void pseudo_bwd_src_dense_k(
     const v3 v_j = ldv(v + jf * 3), vb_j = ldv(vbar + jf * 3);
     float a = 0.f;
     v3 av{0.f, 0.f, 0.f}, avb{0.f, 0.f, 0.f};
+    pd_f2 N2[R / 2];                                                     // this node's filter-gradient sums, without phi
+    float NR = 0.f;
+#pragma unroll
+    for (int m = 0; m < R / 2; ++m) N2[m] = pd_f2{0.f, 0.f};
     const int e_beg = rowptr[j], e_end = rowptr[j + 1];
     for (int c_beg = e_beg; c_beg < e_end; c_beg += SEG_LDS) {
       const int n = min(SEG_LDS, e_end - c_beg);
@@ -879,12 +884,15 @@ __global__ __launch_bounds__(576) void pseudo_bwd_src_dense_k(
       const float* __restrict__ geom_c = geom + (size_t)c_beg * GS;
       __syncthreads();
       switch (k) {
-#define CGV_PD_SRC(KV) case KV: pseudo_bwd_src_dense_walk<R, KV>(s, sbar, v, vbar, gh, ghb, gv, gvb, geom_c, seg_dst, n, n_pad, F, f, W, p, v_j, vb_j, a, G2, GR, av, avb); break
+#define CGV_PD_SRC(KV) case KV: pseudo_bwd_src_dense_walk<R, KV>(s, sbar, v, vbar, gh, ghb, gv, gvb, geom_c, seg_dst, n, n_pad, F, f, W, p, v_j, vb_j, a, N2, NR, av, avb); break
         CGV_PD_SRC(0); CGV_PD_SRC(1); CGV_PD_SRC(2); CGV_PD_SRC(3); CGV_PD_SRC(4); CGV_PD_SRC(5); CGV_PD_SRC(6); CGV_PD_SRC(7);
-        default: pseudo_bwd_src_dense_walk<R, 8>(s, sbar, v, vbar, gh, ghb, gv, gvb, geom_c, seg_dst, n, n_pad, F, f, W, p, v_j, vb_j, a, G2, GR, av, avb); break;
+        default: pseudo_bwd_src_dense_walk<R, 8>(s, sbar, v, vbar, gh, ghb, gv, gvb, geom_c, seg_dst, n, n_pad, F, f, W, p, v_j, vb_j, a, N2, NR, av, avb); break;
 #undef CGV_PD_SRC
       }
     }
+#pragma unroll
+    for (int m = 0; m < R / 2; ++m) G2[m] = __builtin_elementwise_fma(pd_f2{p, p}, N2[m], G2[m]);
+    GR = fmaf(p, NR, GR);
     if (k > 0) {
       float* r = &red[k - 1][0][lane];
       r[0] = av.x; r[64] = av.y; r[128] = av.z; r[192] = avb.x; r[256] = avb.y; r[320] = avb.z;
