@@ -24,6 +24,7 @@
 #include <stdlib.h>
 #include <type_traits>
 #include "cgv_common.h"
+#include "equi_msg_dev.h"
 
 namespace cgv {
 
@@ -260,67 +261,77 @@ struct PdFwdBatch {
   v3 vj[PD_EB];
 };
 
+// Gathers as buffer loads: address = descriptor base + lane byte offset (VGPR, loop invariant) + row byte offset (SGPR, one
+// s_mul per gather) -- the node index comes from a wave-uniform scalar load of the index array, so a gather costs the
+// vector unit nothing but the load itself (the walk is bound by VALU issue: ~15 -> ~11 instructions per edge and wave).
+// The indices of a batch are requested one batch ahead (the scalar unit's loads return out of order: every wait is for
+// all of them, so nothing may be requested right in front of its use).
+__device__ __forceinline__ float pd_ldf_buf(rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ v3 pd_ldv_buf(rsrc_t r, unsigned voff, unsigned soff) {
+  const f3v x = __builtin_bit_cast(f3v, __builtin_amdgcn_raw_buffer_load_b96(r, voff, soff, 0));
+  return v3{x.x, x.y, x.z};
+}
+struct PdIdx { int j[PD_EB]; };
+__device__ __forceinline__ PdIdx pd_indices(const int* __restrict__ idx_c, int e0, int n) {   // wave-uniform: scalar loads
+  PdIdx r;
+#pragma unroll
+  for (int u = 0; u < PD_EB; ++u) r.j[u] = idx_c[min(e0 + u, n - 1)];
+  return r;
+}
+
 template <int R, int K>
 __device__ __forceinline__ void pseudo_fwd_dense_walk(const float* __restrict__ phi, const float* __restrict__ v,
                                                       const float* __restrict__ vbar, const float* __restrict__ geom_c,
-                                                      const int* __restrict__ seg_src, int n, int n_pad, int F, int f,
-                                                      const float (&W)[R + 1], const float* __restrict__ s,
-                                                      const float* __restrict__ sbar, size_t nf, float& ah, float& ahb, v3& acc) {
+                                                      const int* __restrict__ src_c, int n, int F, int f,
+                                                      const float (&W)[R + 1], float& ah, v3& acc) {
   constexpr int GS = geom_stride(R), U = geom_unit_offset(R);
-  // the receiver's own values, only those this filter's term reads (the epilogue reads them again: not live across the walk)
-  const float s_i = K == 0 ? s[nf] : 0.f, sb_i = (K == 4 || K == 6) ? sbar[nf] : 0.f;
-  const v3 zero3{0.f, 0.f, 0.f};
-  const v3 v_i = (K == 0 || K == 3 || K == 7) ? ldv(v + nf * 3) : zero3, vb_i = K == 8 ? ldv(vbar + nf * 3) : zero3;
-  const pd_base vsrc = pd_launder((K == 2 || K == 6 || K == 7) ? v : vbar), phib = pd_launder(phi);
+  // Every term is linear in the receiver's own values (s_i q, v_i . vbar_j, q v_i x vbar_j, q sbar_i vbar_j, ...): the walk
+  // only sums q and q * (the gathered vector); the receiver's factor -- a product, a dot or ONE cross product -- is applied
+  // by the kernel when the segment is done (6 instructions per edge less in the three cross-product bodies, and the
+  // receiver's values are not live across the walk).  ah: sum of q; acc: sum of q x_j (k = 0: sum of vbar_j for hbar).
+  const rsrc_t r_vec = make_rsrc((K == 2 || K == 6 || K == 7) ? v : vbar), r_phi = make_rsrc(phi);
   const unsigned phi_c = (unsigned)(K * F + f) * 4u, phi_s = 9u * (unsigned)F * 4u;
   const unsigned vec_c = (unsigned)f * 12u, vec_s = (unsigned)F * 12u;
-  auto issue = [&](PdFwdBatch& b, int e0) {
-    static_assert(PD_EB == 4, "one 16-byte index read per batch");
-    const int4 j4 = *reinterpret_cast<const int4*>(seg_src + e0);
-    const int js[4] = {j4.x, j4.y, j4.z, j4.w};
+  auto issue = [&](PdFwdBatch& b, const PdIdx& ix) {
 #pragma unroll
     for (int u = 0; u < PD_EB; ++u) {
-      unsigned j = (unsigned)js[u];
-      asm volatile("" : "+v"(j));     // kept in a vector register: known uniform, each gather address is otherwise built
-                                      // on the scalar unit (readfirstlane + 64-bit multiply-add: ~10 SALU per edge) -- here 1 v_mad_u32_u24
-      b.ph[u] = ldf_at(phib, __umul24(j, phi_s) + phi_c);        // (24-bit multiply: full rate; a 32-bit one is a quarter)
-      if (K != 1) b.vj[u] = ldv_at(vsrc, __umul24(j, vec_s) + vec_c);
+      const unsigned j = (unsigned)ix.j[u];
+      b.ph[u] = pd_ldf_buf(r_phi, phi_c, j * phi_s);
+      if (K != 1) b.vj[u] = pd_ldv_buf(r_vec, vec_c, j * vec_s);
     }
   };
   auto compute = [&](const PdFwdBatch& b, int e0, auto tail) {
     const float* __restrict__ gb = geom_c + (size_t)e0 * GS;
 #pragma unroll
     for (int u = 0; u < PD_EB; ++u) {
-      if (decltype(tail)::value && e0 + u >= n) break;                 // wave-uniform (padding of the last trip only: a test
-                                                                       // per edge keeps each record load behind its branch)
+      if (decltype(tail)::value && e0 + u >= n) break;                 // wave-uniform (the last trip only: a test per edge
+                                                                       // keeps each record load behind its branch)
       const float* __restrict__ g = gb + u * GS;                      // wave-uniform address: scalar loads, constant offsets
       const float q = b.ph[u] * filt_pk<R>(W, g);
-      switch (K) {
-        case 0: ah = fmaf(q, s_i, ah); ahb += dot(v_i, b.vj[u]); break;
-        case 1: axpy(acc, q, v3{g[U], g[U + 1], g[U + 2]}); break;
-        case 2: axpy(acc, q, b.vj[u]); break;
-        case 3: axpy(acc, q, cross(v_i, b.vj[u])); break;
-        case 4: axpy(acc, q * sb_i, b.vj[u]); break;
-        case 5: axpy(acc, q, b.vj[u]); break;
-        case 6: axpy(acc, q * sb_i, b.vj[u]); break;
-        case 7: axpy(acc, q, cross(v_i, b.vj[u])); break;
-        default: axpy(acc, q, cross(vb_i, b.vj[u])); break;
-      }
+      if (K == 0) { ah += q; acc.x += b.vj[u].x; acc.y += b.vj[u].y; acc.z += b.vj[u].z; }
+      else if (K == 1) axpy(acc, q, v3{g[U], g[U + 1], g[U + 2]});
+      else axpy(acc, q, b.vj[u]);
     }
   };
   PdFwdBatch b0, b1;
-  issue(b0, 0);
+  PdIdx ix = pd_indices(src_c, 0, n);
+  issue(b0, ix);
+  ix = pd_indices(src_c, PD_EB, n);
   int e0 = 0;
   for (; e0 + 2 * PD_EB <= n; e0 += 2 * PD_EB) {
-    issue(b1, e0 + PD_EB);
+    issue(b1, ix);
+    ix = pd_indices(src_c, e0 + 2 * PD_EB, n);
     pd_pin();
     compute(b0, e0, std::false_type{});
-    issue(b0, min(e0 + 2 * PD_EB, n_pad - PD_EB));          // (the last trip asks for its own second half again: no branch)
+    issue(b0, ix);
+    ix = pd_indices(src_c, e0 + 3 * PD_EB, n);
     pd_pin();
     compute(b1, e0 + PD_EB, std::false_type{});
   }
   if (e0 < n) {
-    issue(b1, e0 + PD_EB);
+    issue(b1, ix);
     pd_pin();
     compute(b0, e0, std::true_type{});
     compute(b1, e0 + PD_EB, std::true_type{});
@@ -344,7 +355,6 @@ __global__ __launch_bounds__(576) void pseudo_fwd_dense_k(const float* __restric
                                                           int residual, float* __restrict__ dv_rows) {
   constexpr int GS = geom_stride(R);
   __shared__ float red[8][3][64];
-  __shared__ __attribute__((aligned(16))) int seg_src[SEG_LDS];
   const int i = blockIdx.x;
   const int lane = threadIdx.x & 63;
   // Nine waves on four SIMDs (wave w on SIMD w % 4): the SIMD that gets three is given the three cheapest terms
@@ -360,19 +370,23 @@ __global__ __launch_bounds__(576) void pseudo_fwd_dense_k(const float* __restric
   float ah = 0.f, ahb = 0.f;
   v3 acc{0.f, 0.f, 0.f};
   const int e_beg = rowptr[i], e_end = rowptr[i + 1];
-  for (int c_beg = e_beg; c_beg < e_end; c_beg += SEG_LDS) {
-    const int n = min(SEG_LDS, e_end - c_beg);
-    if (c_beg != e_beg) __syncthreads();                                 // readers of the previous chunk
-    const int n_pad = pd_stage_indices(seg_src, src, c_beg, n, 576);
-    const float* __restrict__ geom_c = geom + (size_t)c_beg * GS;
-    __syncthreads();
+  if (e_end > e_beg) {
+    const int n = e_end - e_beg;
+    const float* __restrict__ geom_c = geom + (size_t)e_beg * GS;
+    const int* __restrict__ src_c = src + e_beg;
     switch (k) {                                                         // wave-uniform: each wave runs the body of its filter
-#define CGV_PD_FWD(KV) case KV: pseudo_fwd_dense_walk<R, KV>(phi, v, vbar, geom_c, seg_src, n, n_pad, F, f, W, s, sbar, nf, ah, ahb, acc); break
+#define CGV_PD_FWD(KV) case KV: pseudo_fwd_dense_walk<R, KV>(phi, v, vbar, geom_c, src_c, n, F, f, W, ah, acc); break
       CGV_PD_FWD(0); CGV_PD_FWD(1); CGV_PD_FWD(2); CGV_PD_FWD(3); CGV_PD_FWD(4);
       CGV_PD_FWD(5); CGV_PD_FWD(6); CGV_PD_FWD(7);
-      default: pseudo_fwd_dense_walk<R, 8>(phi, v, vbar, geom_c, seg_src, n, n_pad, F, f, W, s, sbar, nf, ah, ahb, acc); break;
+      default: pseudo_fwd_dense_walk<R, 8>(phi, v, vbar, geom_c, src_c, n, F, f, W, ah, acc); break;
 #undef CGV_PD_FWD
     }
+  }
+  {                                                                      // the receiver's factor of this wave's term
+    if (k == 0) { ahb = dot(ldv(v + nf * 3), acc); ah *= s[nf]; }
+    else if (k == 3 || k == 7) acc = cross(ldv(v + nf * 3), acc);
+    else if (k == 8) acc = cross(ldv(vbar + nf * 3), acc);
+    else if (k == 4 || k == 6) { const float sb_i = sbar[nf]; acc.x *= sb_i; acc.y *= sb_i; acc.z *= sb_i; }
   }
   if (k > 0) { red[k - 1][0][lane] = acc.x; red[k - 1][1][lane] = acc.y; red[k - 1][2][lane] = acc.z; }
   __syncthreads();
@@ -634,8 +648,7 @@ template <int R, int K>
 __device__ __forceinline__ void pseudo_bwd_recv_dense_walk(const float* __restrict__ phi, const float* __restrict__ v,
                                                            const float* __restrict__ vbar, const float* __restrict__ geom_c,
                                                            const int* __restrict__ seg_src, int n, int n_pad, int F, int f,
-                                                           const float (&W)[R + 1], float gh_i, float ghb_i, const v3& gv_i,
-                                                           const v3& gvb_i, float& sc, v3& vec) {
+                                                           const float (&W)[R + 1], float& sc, v3& vec) {
   constexpr int GS = geom_stride(R);
   const pd_base vsrc = pd_launder((K == 6 || K == 7) ? v : vbar), phib = pd_launder(phi);
   const unsigned phi_c = (unsigned)(K * F + f) * 4u, phi_s = 9u * (unsigned)F * 4u;
@@ -657,14 +670,10 @@ __device__ __forceinline__ void pseudo_bwd_recv_dense_walk(const float* __restri
     for (int u = 0; u < PD_EB; ++u) {
       if (decltype(tail)::value && e0 + u >= n) break;
       const float q = b.ph[u] * filt_pk<R>(W, gb + u * GS);
-      switch (K) {
-        case 0: sc = fmaf(gh_i, q, sc); axpy(vec, ghb_i, b.vj[u]); break;           // g_s ; the filter-free ghb_i vbar_j of g_v
-        case 3: axpy(vec, q, cross(b.vj[u], gv_i)); break;                          // g_v
-        case 4: sc = fmaf(q, dot(gv_i, b.vj[u]), sc); break;                        // g_sbar
-        case 6: sc = fmaf(q, dot(gvb_i, b.vj[u]), sc); break;                       // g_sbar
-        case 7: axpy(vec, q, cross(b.vj[u], gvb_i)); break;                         // g_v
-        default: axpy(vec, q, cross(b.vj[u], gvb_i)); break;                        // g_vbar (k = 8)
-      }
+      // linear in the receiver's upstream gradients: the walk sums q (k = 0, with the plain sum of vbar_j) or q x_j; the
+      // kernel applies gh_i / ghb_i, the dot or the cross product with gv_i / gvb_i once, behind the segment
+      if (K == 0) { sc += q; vec.x += b.vj[u].x; vec.y += b.vj[u].y; vec.z += b.vj[u].z; }
+      else axpy(vec, q, b.vj[u]);
     }
   };
   PdRecvBatch b0, b1;
@@ -710,8 +719,6 @@ __global__ __launch_bounds__(384) void pseudo_bwd_recv_dense_k(const float* __re
   float W[R + 1];
   load_row<R>(W, Wd, bd, k * F + f);
   const size_t nf = (size_t)i * F + f;
-  const float gh_i = gh[nf], ghb_i = ghb[nf];
-  const v3 gv_i = ldv(gv + nf * 3), gvb_i = ldv(gvb + nf * 3);
   float sc = 0.f;
   v3 vec{0.f, 0.f, 0.f};
   const int e_beg = rowptr[i], e_end = rowptr[i + 1];
@@ -722,11 +729,20 @@ __global__ __launch_bounds__(384) void pseudo_bwd_recv_dense_k(const float* __re
     const float* __restrict__ geom_c = geom + (size_t)c_beg * GS;
     __syncthreads();
     switch (k) {
-#define CGV_PD_RECV(KV) case KV: pseudo_bwd_recv_dense_walk<R, KV>(phi, v, vbar, geom_c, seg_src, n, n_pad, F, f, W, gh_i, ghb_i, gv_i, gvb_i, sc, vec); break
+#define CGV_PD_RECV(KV) case KV: pseudo_bwd_recv_dense_walk<R, KV>(phi, v, vbar, geom_c, seg_src, n, n_pad, F, f, W, sc, vec); break
       CGV_PD_RECV(0); CGV_PD_RECV(3); CGV_PD_RECV(4); CGV_PD_RECV(6); CGV_PD_RECV(7);
-      default: pseudo_bwd_recv_dense_walk<R, 8>(phi, v, vbar, geom_c, seg_src, n, n_pad, F, f, W, gh_i, ghb_i, gv_i, gvb_i, sc, vec); break;
+      default: pseudo_bwd_recv_dense_walk<R, 8>(phi, v, vbar, geom_c, seg_src, n, n_pad, F, f, W, sc, vec); break;
 #undef CGV_PD_RECV
     }
+  }
+  const float gh_i = gh[nf], ghb_i = ghb[nf];
+  const v3 gv_i = ldv(gv + nf * 3), gvb_i = ldv(gvb + nf * 3);
+  switch (k) {                                                           // the receiver's factor of this wave's term
+    case 0: sc *= gh_i; vec.x *= ghb_i; vec.y *= ghb_i; vec.z *= ghb_i; break;          // g_s ; the filter-free ghb_i vbar_j of g_v
+    case 3: vec = cross(vec, gv_i); break;                                              // g_v
+    case 4: sc = dot(gv_i, vec); break;                                                 // g_sbar
+    case 6: sc = dot(gvb_i, vec); break;                                                // g_sbar
+    default: vec = cross(vec, gvb_i); break;                                            // g_v (k = 7), g_vbar (k = 8)
   }
   red[wave][0][lane] = sc; red[wave][1][lane] = vec.x; red[wave][2][lane] = vec.y; red[wave][3][lane] = vec.z;
   __syncthreads();
@@ -806,15 +822,18 @@ __device__ __forceinline__ void pseudo_bwd_src_dense_walk(const float* __restric
         case 7: cav = cross(b.A[u], b.B[u]); gq = dot(v_j, cav); break;
         default: cavb = cross(b.A[u], b.B[u]); gq = dot(vb_j, cavb); break;
       }
-      const float w = filt_pk<R>(W, g);
-      a = fmaf(gq, w, a);
       // (the filter-gradient sums leave out the node's phi: it multiplies them once, when the node is done)
 #pragma unroll
       for (int m = 0; m < R / 2; ++m) G2[m] = __builtin_elementwise_fma(pd_f2{gq, gq}, pd_f2{g[2 * m], g[2 * m + 1]}, G2[m]);
       GR = fmaf(gq, g[R], GR);
-      const float q = (K == 4 || K == 6) ? p * w * b.sA[u] : p * w;
-      if (K == 2 || K == 6 || K == 7) axpy(av, q, cav);
-      if (K == 3 || K == 4 || K == 5 || K == 8) axpy(avb, q, cavb);
+      // (g_phi = sum_e gq_e w_e = W . (sum_e gq_e g_e): from the node's sums, once per node -- the bodies without a
+      //  source-side vector term, k = 0 and 1, never evaluate their filter)
+      if (K >= 2) {
+        const float w = filt_pk<R>(W, g);
+        const float q = (K == 4 || K == 6) ? p * w * b.sA[u] : p * w;
+        if (K == 2 || K == 6 || K == 7) axpy(av, q, cav);
+        if (K == 3 || K == 4 || K == 5 || K == 8) axpy(avb, q, cavb);
+      }
       if (K == 0) axpy(avb, b.hb[u], b.B[u]);                                          // the filter-free term ghb_i v_i
     }
   };
@@ -889,6 +908,12 @@ __global__ __launch_bounds__(576) void pseudo_bwd_src_dense_k(
         default: pseudo_bwd_src_dense_walk<R, 8>(s, sbar, v, vbar, gh, ghb, gv, gvb, geom_c, seg_dst, n, n_pad, F, f, W, p, v_j, vb_j, a, N2, NR, av, avb); break;
 #undef CGV_PD_SRC
       }
+    }
+    {                                                                    // g_phi[j, k, f] = W_k[f] . N (env term first, as filt())
+      pd_f2 a2 = pd_f2{W[R] * NR, 0.f};
+#pragma unroll
+      for (int m = 0; m < R / 2; ++m) a2 = __builtin_elementwise_fma(pd_f2{W[2 * m], W[2 * m + 1]}, N2[m], a2);
+      a = a2.x + a2.y;
     }
 #pragma unroll
     for (int m = 0; m < R / 2; ++m) G2[m] = __builtin_elementwise_fma(pd_f2{p, p}, N2[m], G2[m]);
