@@ -66,6 +66,7 @@ PROTOTYPES = {
     "cgv_pseudo_msg_fwd_rows": (_i, [_p] * 15 + [_i, _i, _i, _i, C.c_int64, _p]),
     "cgv_pseudo_msg_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "cgv_pseudo_msg_bwd": (_i, [_p] * 24 + [_i, _i, _i, _i, C.c_int64, _p, _sz, _p]),
+    "cgv_pseudo_msg_bwd_deferred": (_i, [_p] * 22 + [_i, _i, _i, _i, C.c_int64, _p, _sz, _p, _p]),
     "cgv_update_rows_from_vec": (_i, [_p, _p, _i, _i, _p]),
     "cgv_update_vec_from_rows": (_i, [_p, _p, _p, _i, _i, _p]),
     "cgv_update_norm_stack_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),

@@ -620,14 +620,15 @@ struct FilterReduceJob { const float* part; float* gWd; float* gbd; int n_chunks
 struct FilterReduceJobs { int n, pad; FilterReduceJob job[FR_MAX]; };
 __global__ __launch_bounds__(64 * RED_SLICES) void equi_msg_bwd_reduce_jobs_k(FilterReduceJobs J) {
   __shared__ float red[RED_SLICES][64];
-  const int jz = blockIdx.z / 3, kk = blockIdx.z - 3 * jz;
+  const int KZ = J.pad;            // z blocks per job: 3, or 9 when the table holds a nine-filter (EquiMessagePsuedo) job
+  const int jz = blockIdx.z / KZ, kk = blockIdx.z - KZ * jz;
   const FilterReduceJob& q = J.job[jz];
   const int F = q.F, R = q.R, K = q.K, n_chunks = q.n_chunks;
   const int f = blockIdx.x * 64 + threadIdx.x;
   const int s = threadIdx.y;
   const int n = blockIdx.y;        // 0..R  (R = bias)
-  if (n > R) return;               // (block-uniform)
-  const int k = (K == 3) ? kk : (kk == 1 ? 0 : -1);
+  if (n > R || kk >= (K == 9 ? 9 : 3)) return;               // (block-uniform)
+  const int k = (K != 1) ? kk : (kk == 1 ? 0 : -1);
   float acc = 0.f;
   if (k >= 0 && f < F) {
     const size_t stride = (size_t)K * (R + 1) * F;
@@ -766,21 +767,24 @@ int cgv_filter_reduce_jobs_max(void) { return cgv::FR_MAX; }
 int cgv_filter_reduce_job_bytes(void) { return (int)sizeof(cgv::FilterReduceJob); }
 
 /* The deferred second stages of up to cgv_filter_reduce_jobs_max() message-block backward launches in one launch.
- * jobs_host: n records laid out as cgv::FilterReduceJob {part, gWd, gbd, n_chunks, K (live slices: 1 or 3), R, F}. */
+ * jobs_host: n records laid out as cgv::FilterReduceJob {part, gWd, gbd, n_chunks, K (live slices: 1 or 3; 9: the partial
+ * sums of cgv_pseudo_msg_bwd_deferred), R, F}. */
 int cgv_filter_reduce_jobs(const void* jobs_host, int n_jobs, void* stream) {
   CGV_REQUIRE(jobs_host && n_jobs >= 1 && n_jobs <= cgv::FR_MAX, "bad job table");
   cgv::FilterReduceJobs J;
   std::memset(static_cast<void*>(&J), 0, sizeof(J));
   std::memcpy(static_cast<void*>(J.job), jobs_host, sizeof(cgv::FilterReduceJob) * (size_t)n_jobs);
   J.n = n_jobs;
-  int fmax = 0, rmax = 0;
+  int fmax = 0, rmax = 0, kz = 3;
   for (int j = 0; j < n_jobs; ++j) {
     const cgv::FilterReduceJob& q = J.job[j];
-    CGV_REQUIRE(q.part && q.gWd && q.gbd && q.n_chunks >= 1 && (q.K == 1 || q.K == 3) && q.R >= 1 && q.F >= 1, "bad job");
+    CGV_REQUIRE(q.part && q.gWd && q.gbd && q.n_chunks >= 1 && (q.K == 1 || q.K == 3 || q.K == 9) && q.R >= 1 && q.F >= 1, "bad job");
     fmax = q.F > fmax ? q.F : fmax;
     rmax = q.R > rmax ? q.R : rmax;
+    if (q.K == 9) kz = 9;
   }
-  dim3 rgrid((fmax + 63) / 64, rmax + 1, 3 * n_jobs);
+  J.pad = kz;
+  dim3 rgrid((fmax + 63) / 64, rmax + 1, kz * n_jobs);
   hipLaunchKernelGGL(cgv::equi_msg_bwd_reduce_jobs_k, rgrid, dim3(64, cgv::RED_SLICES), 0, (hipStream_t)stream, J);
   return cgv::check_launch("cgv_filter_reduce_jobs");
 }

@@ -1049,15 +1049,16 @@ size_t cgv_pseudo_msg_bwd_workspace_bytes(int n_nodes, int n_feat, int n_rbf) {
   return sizeof(float) * (size_t)cgv::pseudo_chunks(n_nodes) * 9 * (n_rbf + 1) * n_feat + 256;
 }
 
-int cgv_pseudo_msg_bwd(const float* phi, const float* s, const float* sbar, const float* v, const float* vbar,
+static int pseudo_msg_bwd_impl(const float* phi, const float* s, const float* sbar, const float* v, const float* vbar,
                        const float* geom_d, const int32_t* rowptr_d, const int32_t* src_d, const float* geom_s,
                        const int32_t* rowptr_s, const int32_t* dst_s, const float* Wd, const float* bd, const float* gh,
                        const float* ghbar, const float* gv, const float* gvbar, float* g_phi, float* g_s, float* g_sbar,
                        float* g_v, float* g_vbar, float* gWd, float* gbd, int n_nodes, int n_feat, int n_rbf,
-                       int residual, int64_t n_edges_hint, void* workspace, size_t workspace_bytes, void* stream) {
+                       int residual, int64_t n_edges_hint, void* workspace, size_t workspace_bytes, void* stream,
+                       int* n_chunks_out) {
   CGV_REQUIRE(n_nodes >= 0 && n_feat > 0, "bad size");
   CGV_REQUIRE(phi && s && sbar && v && vbar && rowptr_d && rowptr_s && Wd && bd, "null input");
-  CGV_REQUIRE(g_phi && g_s && g_sbar && g_v && g_vbar && gWd && gbd && workspace, "null output");
+  CGV_REQUIRE(g_phi && g_s && g_sbar && g_v && g_vbar && (n_chunks_out || (gWd && gbd)) && workspace, "null output");
   if (workspace_bytes < cgv_pseudo_msg_bwd_workspace_bytes(n_nodes, n_feat, n_rbf)) {
     cgv::set_error("cgv_pseudo_msg_bwd: workspace too small");
     return CGV_E_WORKSPACE;
@@ -1095,9 +1096,39 @@ int cgv_pseudo_msg_bwd(const float* phi, const float* s, const float* sbar, cons
                          dst_s, Wd, bd, gh, ghbar, gv, gvbar, g_phi, g_v, g_vbar, part, n_feat, n_nodes, npc);
     }
   });
+  if (n_chunks_out) {               // the caller finishes the filter gradients (cgv_filter_reduce_jobs, K = 9)
+    *n_chunks_out = chunks;
+    return cgv::check_launch("cgv_pseudo_msg_bwd_deferred");
+  }
   dim3 rgrid((n_feat + 63) / 64, n_rbf + 1, 9);
   hipLaunchKernelGGL(cgv::pseudo_bwd_reduce, rgrid, dim3(64, cgv::PRED_SLICES), 0, st, part, chunks, n_rbf, n_feat, gWd, gbd);
   return cgv::check_launch("cgv_pseudo_msg_bwd");
+}
+
+int cgv_pseudo_msg_bwd(const float* phi, const float* s, const float* sbar, const float* v, const float* vbar,
+                       const float* geom_d, const int32_t* rowptr_d, const int32_t* src_d, const float* geom_s,
+                       const int32_t* rowptr_s, const int32_t* dst_s, const float* Wd, const float* bd, const float* gh,
+                       const float* ghbar, const float* gv, const float* gvbar, float* g_phi, float* g_s, float* g_sbar,
+                       float* g_v, float* g_vbar, float* gWd, float* gbd, int n_nodes, int n_feat, int n_rbf,
+                       int residual, int64_t n_edges_hint, void* workspace, size_t workspace_bytes, void* stream) {
+  return pseudo_msg_bwd_impl(phi, s, sbar, v, vbar, geom_d, rowptr_d, src_d, geom_s, rowptr_s, dst_s, Wd, bd, gh, ghbar, gv, gvbar,
+                             g_phi, g_s, g_sbar, g_v, g_vbar, gWd, gbd, n_nodes, n_feat, n_rbf, residual, n_edges_hint, workspace,
+                             workspace_bytes, stream, nullptr);
+}
+
+/* As cgv_pseudo_msg_bwd without its last launch: the per-chunk partial sums of the filter gradients stay in `workspace`
+ * ([n_chunks][9][n_rbf + 1][F]); a training step hands them, with those of its other message blocks, to ONE
+ * cgv_filter_reduce_jobs launch at the end of backward (job {workspace, gWd, gbd, *n_chunks, K = 9, n_rbf, F}). */
+int cgv_pseudo_msg_bwd_deferred(const float* phi, const float* s, const float* sbar, const float* v, const float* vbar,
+                                const float* geom_d, const int32_t* rowptr_d, const int32_t* src_d, const float* geom_s,
+                                const int32_t* rowptr_s, const int32_t* dst_s, const float* Wd, const float* bd, const float* gh,
+                                const float* ghbar, const float* gv, const float* gvbar, float* g_phi, float* g_s, float* g_sbar,
+                                float* g_v, float* g_vbar, int n_nodes, int n_feat, int n_rbf, int residual,
+                                int64_t n_edges_hint, void* workspace, size_t workspace_bytes, int* n_chunks, void* stream) {
+  CGV_REQUIRE(n_chunks, "null pointer");
+  return pseudo_msg_bwd_impl(phi, s, sbar, v, vbar, geom_d, rowptr_d, src_d, geom_s, rowptr_s, dst_s, Wd, bd, gh, ghbar, gv, gvbar,
+                             g_phi, g_s, g_sbar, g_v, g_vbar, nullptr, nullptr, n_nodes, n_feat, n_rbf, residual, n_edges_hint,
+                             workspace, workspace_bytes, stream, n_chunks);
 }
 
 }  // extern "C"

@@ -333,6 +333,20 @@ class _PseudoMessage(torch.autograd.Function):
         lib = _lib.load()
         ws_bytes = int(lib.cgv_pseudo_msg_bwd_workspace_bytes(n, F, geom.n_rbf))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=s.device)
+        from .primitives import wgrad_queue
+        if wgrad_queue.active and ret_W is None and ret_b is None:
+            # under the trainer: the reduction of the filter-gradient partial sums joins the step's other message blocks in
+            # one launch when the queue is flushed (one link less in every decoder layer's backward chain)
+            nc = C.c_int()
+            _lib.call("cgv_pseudo_msg_bwd_deferred", _lib.ptr(phi), _lib.ptr(s), _lib.ptr(sbar), _lib.ptr(v), _lib.ptr(vbar),
+                      _lib.ptr(geom.geom_d), _lib.ptr(plan.rowptr_d), _lib.ptr(plan.src_d),
+                      _lib.ptr(geom.geom_s), _lib.ptr(plan.rowptr_s), _lib.ptr(plan.dst_s), _lib.ptr(Wd), _lib.ptr(bd),
+                      _lib.ptr(gh), _lib.ptr(ghb), _lib.ptr(gv), _lib.ptr(gvb),
+                      _lib.ptr(g_phi), _lib.ptr(g_s), _lib.ptr(g_sbar), _lib.ptr(g_v), _lib.ptr(g_vbar),
+                      n, F, geom.n_rbf, int(ctx.residual), plan.n_edges, _lib.ptr(ws), ws_bytes, C.byref(nc), _lib.stream_ptr(),
+                      tag=f"pseudo_msg_bwd:Nd{n}:E{plan.n_edges}:gv1")
+            wgrad_queue.enqueue_filter(ws, nc.value, 9, geom.n_rbf, F, gWd, gbd)
+            return g_phi, g_s, g_sbar, g_v, g_vbar, ret_W, ret_b, None, None, None
         _lib.call("cgv_pseudo_msg_bwd", _lib.ptr(phi), _lib.ptr(s), _lib.ptr(sbar), _lib.ptr(v), _lib.ptr(vbar),
                   _lib.ptr(geom.geom_d), _lib.ptr(plan.rowptr_d), _lib.ptr(plan.src_d),
                   _lib.ptr(geom.geom_s), _lib.ptr(plan.rowptr_s), _lib.ptr(plan.dst_s), _lib.ptr(Wd), _lib.ptr(bd),

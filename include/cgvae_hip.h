@@ -325,6 +325,15 @@ int cgv_pseudo_msg_bwd(const float* phi, const float* s, const float* sbar, cons
                        float* gWd /*[9F,R]*/, float* gbd /*[9F]*/, int n_nodes, int n_feat, int n_rbf,
                        int residual, int64_t n_edges_hint /*0: unknown; dispatch only*/, void* workspace,
                        size_t workspace_bytes, void* stream);
+/* cgv_pseudo_msg_bwd without its last launch (the filter-gradient reduction over chunks): the partial sums stay in
+ * `workspace`; one cgv_filter_reduce_jobs launch (job K = 9, *n_chunks) finishes them together with the step's other
+ * message blocks.  Replaces the same autograd as cgv_pseudo_msg_bwd (conv.py:180-242). */
+int cgv_pseudo_msg_bwd_deferred(const float* phi, const float* s, const float* sbar, const float* v, const float* vbar,
+                                const float* geom_d, const int32_t* rowptr_d, const int32_t* src_d, const float* geom_s,
+                                const int32_t* rowptr_s, const int32_t* dst_s, const float* Wd, const float* bd, const float* gh,
+                                const float* ghbar, const float* gv, const float* gvbar, float* g_phi, float* g_s, float* g_sbar,
+                                float* g_v, float* g_vbar, int n_nodes, int n_feat, int n_rbf, int residual,
+                                int64_t n_edges_hint, void* workspace, size_t workspace_bytes, int* n_chunks /*[host]*/, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Decoder layer as channel-group kernels (csrc/decoder_layer.hip) -- replaces, for bead graphs of at most 16 nodes, the
