@@ -742,6 +742,17 @@ __global__ __launch_bounds__(256) void wgrad_gram_reduce_k(const WgradProblem* _
 // bound by the gW stores).  MFMA 16x16x4 f32 steps over 4 rows: lane (i = l&15, q = l>>4) supplies
 // A = g[m0+q][16w+i] and B_s = x[m0+q][4i+s], so that D_s holds gW[n0+16w+4q+r][k0+4i+s] and leaves as 16-byte
 // stores.  LDS strides 80 / 64 floats keep the b32 / b128 reads conflict free.  Exact fp32 FMA chains, fixed order.
+// Straight-line staging: every request goes to a valid (clamped) address and is zeroed by a select afterwards -- with
+// predicated loads the compiler builds a branch and a vmcnt(0) per request.  The clobber keeps the requests above the
+// MFMA loop they are meant to travel under (LLVM otherwise sinks them to their first use behind it).
+__device__ __forceinline__ void strip_pin() { asm volatile("" ::: "memory"); }
+// Operand pointers come out of the record (generic address space): as they are, the requests become flat_load, which
+// counts on lgkmcnt as well -- the first LDS wait of the MFMA loop would then wait for the whole next x tile.
+typedef const float __attribute__((address_space(1)))* strip_gptr;
+__device__ __forceinline__ float4 strip_ldg4(const float* p) {
+  const f32x4 t = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>((strip_gptr)p);
+  return make_float4(t.x, t.y, t.z, t.w);
+}
 #ifndef CGV_GW_CHUNK
 #define CGV_GW_CHUNK 48
 #endif
@@ -783,53 +794,74 @@ __global__ __launch_bounds__(256) void gathered_wgrad_k(const WgradProblem* __re
   constexpr int NP = GW_CHUNK / 16;                                  // staging passes per chunk
   float4 gq[NP], zq[NP], xq[NP];
   // operand rows of one chunk into registers: the loads only -- g is multiplied by act'(z) when the chunk is stored to
-  // LDS (chunk_finish), so that the next chunk's loads really travel under this chunk's MFMAs (a multiply right behind
-  // the load made the prefetch wait for its data before the first MFMA)
+  // LDS (chunk_finish), so that the next chunk's loads really travel under this chunk's MFMAs.  Straight line: every
+  // request goes to a valid (clamped) address through a global-address-space pointer and is zeroed by a select when it
+  // is stored (a predicated load is a branch with a wait for everything outstanding; a generic-pointer load is a
+  // flat_load, which also counts on lgkmcnt and made the MFMA loop's first LDS wait a wait for the whole next chunk).
+  const int gcol_at = gcol ? n0 + 4 * c4 : 0, xcol_at = xcol ? k0 + 4 * c4 : 0;
+  const float* zsrc = pr.act ? pr.z : pr.gy;                          // (no activation: a second look at g instead of a branch)
   auto chunk_load = [&](int m0) {
-    const int rows = min(GW_CHUNK, M - m0);
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-      const int r = rr + 16 * p;
-      const bool ok = r < rows;
-      const int m = m0 + (ok ? r : 0);
+      const int m = min(m0 + rr + 16 * p, M - 1);
       const int seg = m / sr, row = m - seg * sr;
       const size_t base = (size_t)seg * pr.seg_stride;
-      gq[p] = ldg4_or_zero(pr.gy + base + (size_t)row * N + (gcol ? n0 + 4 * c4 : 0), ok && gcol);
-      if (pr.act) zq[p] = ldg4_or_zero(pr.z + base + (size_t)row * N + (gcol ? n0 + 4 * c4 : 0), ok && gcol);
-      xq[p] = ldg4_or_zero(pr.x + base + (size_t)row * K + (xcol ? k0 + 4 * c4 : 0), ok && xcol);
+      gq[p] = strip_ldg4(pr.gy + base + (size_t)row * N + gcol_at);
+      zq[p] = strip_ldg4(zsrc + base + (size_t)row * N + gcol_at);
+      xq[p] = strip_ldg4(pr.x + base + (size_t)row * K + xcol_at);
     }
+    strip_pin();
   };
-  auto chunk_finish = [&]() {
-    if (pr.act) {
+  auto chunk_store = [&](int m0) {
+    if (pr.act == 1) {                                                // Swish: the model's activation, kept free of the switch
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        gq[p].x *= act_bwd(zq[p].x, 1); gq[p].y *= act_bwd(zq[p].y, 1);
+        gq[p].z *= act_bwd(zq[p].z, 1); gq[p].w *= act_bwd(zq[p].w, 1);
+      }
+    } else if (pr.act) {
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         gq[p].x *= act_bwd(zq[p].x, pr.act); gq[p].y *= act_bwd(zq[p].y, pr.act);
         gq[p].z *= act_bwd(zq[p].z, pr.act); gq[p].w *= act_bwd(zq[p].w, pr.act);
       }
     }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {                                   // rows beyond M and columns beyond N / K: zeros
+      const bool live = m0 + rr + 16 * p < M;
+      const bool gk = live && gcol, xk = live && xcol;
+      *reinterpret_cast<float4*>(gs + (rr + 16 * p) * GW_GS + 4 * c4) =
+          make_float4(gk ? gq[p].x : 0.f, gk ? gq[p].y : 0.f, gk ? gq[p].z : 0.f, gk ? gq[p].w : 0.f);
+      *reinterpret_cast<float4*>(xs + (rr + 16 * p) * GW_XS + 4 * c4) =
+          make_float4(xk ? xq[p].x : 0.f, xk ? xq[p].y : 0.f, xk ? xq[p].z : 0.f, xk ? xq[p].w : 0.f);
+    }
   };
   chunk_load(0);
   for (int m0 = 0; m0 < M; m0 += GW_CHUNK) {
-    const int rows = min(GW_CHUNK, M - m0);
-    chunk_finish();
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {                                   // rows beyond the chunk arrive as zeros
-      *reinterpret_cast<float4*>(gs + (rr + 16 * p) * GW_GS + 4 * c4) = gq[p];
-      *reinterpret_cast<float4*>(xs + (rr + 16 * p) * GW_XS + 4 * c4) = xq[p];
-    }
+    chunk_store(m0);
     __syncthreads();
-    if (m0 + GW_CHUNK < M) chunk_load(m0 + GW_CHUNK);                // the next chunk travels under this chunk's MFMAs
-    const int steps = (rows + 3) / 4;
-#pragma unroll 4
-    for (int st = 0; st < steps; ++st) {
-      const float a = gs[(4 * st + q) * GW_GS + 16 * wave + i];
-      const float4 b = *reinterpret_cast<const float4*>(xs + (4 * st + q) * GW_XS + 4 * i);
+    chunk_load(min(m0 + GW_CHUNK, M - 1));                           // the next chunk travels under this chunk's MFMAs
+                                                                     // (the last trip asks for the last row again: no branch)
+    const float* ga = gs + q * GW_GS + 16 * wave + i;
+    const float* xb = xs + q * GW_XS + 4 * i;
+    // whole trip count (the rows beyond the chunk are zeros): unrolled, LDS reads issued two steps ahead of their MFMAs
+#pragma unroll
+    for (int st = 0; st < GW_CHUNK / 4; ++st) {
+      const float a = ga[(4 * st) * GW_GS];
+      const float4 b = *reinterpret_cast<const float4*>(xb + (4 * st) * GW_XS);
       bsum += a;
       acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.x, acc[0], 0, 0, 0);
       acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.y, acc[1], 0, 0, 0);
       acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.z, acc[2], 0, 0, 0);
       acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.w, acc[3], 0, 0, 0);
     }
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+    for (int st = 0; st < GW_CHUNK / 4 - 2; ++st) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
     __syncthreads();
   }
   const int n = n0 + 16 * wave + i, kcol = k0 + 4 * i;
@@ -928,17 +960,6 @@ constexpr int GS_MAX_ROWS = 128;
 #endif
 // row classes (NP) from which the x tile has ONE LDS buffer (a second barrier per tile, more blocks per CU)
 constexpr int GS_SINGLE_FROM = CGV_GS_SINGLE_FROM;
-// Straight-line staging: every request goes to a valid (clamped) address and is zeroed by a select afterwards -- with
-// predicated loads the compiler builds a branch and a vmcnt(0) per request.  The clobber keeps the requests above the
-// MFMA loop they are meant to travel under (LLVM otherwise sinks them to their first use behind it).
-__device__ __forceinline__ void strip_pin() { asm volatile("" ::: "memory"); }
-// Operand pointers come out of the record (generic address space): as they are, the requests become flat_load, which
-// counts on lgkmcnt as well -- the first LDS wait of the MFMA loop would then wait for the whole next x tile.
-typedef const float __attribute__((address_space(1)))* strip_gptr;
-__device__ __forceinline__ float4 strip_ldg4(const float* p) {
-  const f32x4 t = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>((strip_gptr)p);
-  return make_float4(t.x, t.y, t.z, t.w);
-}
 template <int MODE, int NP>   // NP: staging passes of 16 rows (M <= 16 NP)
 __global__ __launch_bounds__(256) void gathered_wgrad_strip_k(const WgradProblem* __restrict__ table, int n_problems,
                                                               double* __restrict__ partial, RankUpdateArgs ra) {
