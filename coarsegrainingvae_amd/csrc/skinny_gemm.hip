@@ -29,6 +29,23 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 ldg4_or_zero(const float* p, bool ok) {
   return ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
 }
+__device__ __forceinline__ float4 ldg4g_or_zero(const float* p, bool ok);   // the same through address space 1 (below)
+// Pointers that come out of a record table are generic to the compiler: loads and stores through them are flat_*, which
+// count on lgkmcnt as well as vmcnt -- an LDS wait then also waits for them.  These go through address space 1 (global_*).
+typedef float gf32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ldg4_global(const float* p) {
+  const gf32x4 t = *reinterpret_cast<const __attribute__((address_space(1))) gf32x4*>((const __attribute__((address_space(1))) float*)p);
+  return make_float4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ float ldg_global(const float* p) {
+  return *((const __attribute__((address_space(1))) float*)p);
+}
+__device__ __forceinline__ float4 ldg4g_or_zero(const float* p, bool ok) {
+  return ok ? ldg4_global(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__device__ __forceinline__ void stg4_global(float* p, const float4& v) {
+  *reinterpret_cast<__attribute__((address_space(1))) gf32x4*>((__attribute__((address_space(1))) float*)p) = gf32x4{v.x, v.y, v.z, v.w};
+}
 // ------------------------------------------------------------------ fwd
 // Block = 16 output columns n0..n0+15, WAVES waves splitting K in whole 16-float steps.  Lane
 // (i = l&15, q = l>>4) loads W[n0+i, 16 s + 4 q .. +3] (16 rows x 64 contiguous bytes per wave
@@ -463,7 +480,7 @@ __global__ __launch_bounds__(256) void grouped_wgrad_t(const WgradProblem* __res
     for (int u = 0; u < 4; ++u) {
       const int idx = base + u * 256 + t;
       const int m = idx / t4, c = idx - m * t4;
-      val[u] = ldg4_or_zero(pr.x + wg_row(pr, idx < M * t4 ? m : 0, K) + kbase + 4 * c, idx < M * t4 && kbase + 4 * c < K);
+      val[u] = ldg4g_or_zero(pr.x + wg_row(pr, idx < M * t4 ? m : 0, K) + kbase + 4 * c, idx < M * t4 && kbase + 4 * c < K);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -480,8 +497,8 @@ __global__ __launch_bounds__(256) void grouped_wgrad_t(const WgradProblem* __res
       const int idx = min(base + 256 * u + t, M * WG_BLOCK_ROWS - 1);
       const int m = idx / WG_BLOCK_ROWS, r = idx - m * WG_BLOCK_ROWS;
       const size_t at = wg_row(pr, m, N) + min(n0 + r, N - 1);
-      gv[u] = pr.gy[at];
-      zv[u] = pr.act ? pr.z[at] : 0.f;                           // block-uniform
+      gv[u] = ldg_global(pr.gy + at);
+      zv[u] = pr.act ? ldg_global(pr.z + at) : 0.f;              // block-uniform
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -561,10 +578,10 @@ __global__ __launch_bounds__(256) void grouped_wgrad_t(const WgradProblem* __res
 #pragma unroll
         for (int r = 0; r < WG_ROWS; ++r) {
           if (nr + r < N) {
-            float4* dst = reinterpret_cast<float4*>(pr.gW + (size_t)(nr + r) * K + k);
+            float* dst = pr.gW + (size_t)(nr + r) * K + k;
             float4 o = acc[r];
-            if (pr.accumulate) { const float4 old = *dst; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
-            *dst = o;
+            if (pr.accumulate) { const float4 old = ldg4_global(dst); o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+            stg4_global(dst, o);
           }
         }
       }
@@ -619,8 +636,8 @@ __global__ __launch_bounds__(GRAM_THREADS) void wgrad_gram_k(const WgradProblem*
 #pragma unroll 4
       for (int m = 0; m < M; ++m) {
         const size_t at = wg_row(pr, m, N) + n;
-        float g = pr.gy[at];
-        if (act) g *= act_bwd(pr.z[at], act);
+        float g = ldg_global(pr.gy + at);
+        if (act) g *= act_bwd(ldg_global(pr.z + at), act);
         sum += g;
       }
       pr.gb[n] = pr.accumulate ? pr.gb[n] + sum : sum;
@@ -648,14 +665,14 @@ __global__ __launch_bounds__(GRAM_THREADS) void wgrad_gram_k(const WgradProblem*
       buf[u] = zero4;
       if (m < M && col4 < cols4) {
         if (is_g) {
-          float4 g = *reinterpret_cast<const float4*>(pr.gy + wg_row(pr, m, N) + 4 * col4);
+          float4 g = ldg4_global(pr.gy + wg_row(pr, m, N) + 4 * col4);
           if (act) {
-            const float4 z = *reinterpret_cast<const float4*>(pr.z + wg_row(pr, m, N) + 4 * col4);
+            const float4 z = ldg4_global(pr.z + wg_row(pr, m, N) + 4 * col4);
             g.x *= act_bwd(z.x, act); g.y *= act_bwd(z.y, act); g.z *= act_bwd(z.z, act); g.w *= act_bwd(z.w, act);
           }
           buf[u] = g;
         } else {
-          buf[u] = *reinterpret_cast<const float4*>(pr.x + wg_row(pr, m, K) + 4 * col4);
+          buf[u] = ldg4_global(pr.x + wg_row(pr, m, K) + 4 * col4);
         }
       }
     }
@@ -871,10 +888,10 @@ __global__ __launch_bounds__(256) void gathered_wgrad_k(const WgradProblem* __re
       for (int r = 0; r < 4; ++r) {
         const int row = n0 + 16 * wave + 4 * q + r;
         if (row >= N) continue;
-        float4* dst = reinterpret_cast<float4*>(pr.gW + (size_t)row * K + kcol);
+        float* dst = pr.gW + (size_t)row * K + kcol;
         float4 o = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
-        if (pr.accumulate) { const float4 old = *dst; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
-        *dst = o;
+        if (pr.accumulate) { const float4 old = ldg4_global(dst); o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+        stg4_global(dst, o);
       }
     }
   } else if (MODE == GW_SUMSQ) {
@@ -1101,10 +1118,10 @@ __global__ __launch_bounds__(256) void gathered_wgrad_strip_k(const WgradProblem
         for (int r = 0; r < 4; ++r) {
           const int row = n0 + 16 * wave + 4 * q + r;
           if (row >= N) continue;
-          float4* dst = reinterpret_cast<float4*>(pr.gW + (size_t)row * K + kcol);
+          float* dst = pr.gW + (size_t)row * K + kcol;
           float4 o = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
-          if (pr.accumulate) { const float4 old = *dst; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
-          *dst = o;
+          if (pr.accumulate) { const float4 old = ldg4_global(dst); o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+          stg4_global(dst, o);
         }
       } else if (MODE == GW_SUMSQ) {
 #pragma unroll
