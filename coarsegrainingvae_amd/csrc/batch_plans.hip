@@ -29,6 +29,7 @@ struct PlanJob {            // one sorted view: edges ordered by (key, other, ed
   int stride, E, n_rows;
   int edge_begin, row_begin;  // prefixes over the jobs
   int ids_is_key, pad, pad_to;
+  int n_other;              // partners are in [0, n_other) (0: unknown -- rows are ranked by comparisons only)
 };
 struct PlanJobs { int n, total_edges, total_rows, pad; PlanJob job[PJ_MAX]; };
 
@@ -145,16 +146,11 @@ __global__ __launch_bounds__(256) void pj_drop_k(PlanJobs J) {
 }
 
 constexpr int PJ_LDS_KEYS = 2048;
-__global__ __launch_bounds__(128) void pj_row_sort_k(PlanJobs J) {   // block: one row of one job
-  __shared__ unsigned long long keys[PJ_LDS_KEYS];
-  int j = 0;
-#pragma unroll
-  for (int t = 1; t < PJ_MAX; ++t) if (t < J.n && J.job[t].row_begin <= (int)blockIdx.x) j = t;
-  const PlanJob& p = J.job[j];
-  const int r = blockIdx.x - p.row_begin;
-  const int beg = p.rowptr[r], L = p.rowptr[r + 1] - beg;
-  if (L <= 0) return;
-  unsigned long long* k = L <= PJ_LDS_KEYS ? keys : p.spill + beg;
+// The body takes the key array as its own argument and is instantiated twice -- keys in LDS (every row that fits) or in
+// the job's global spill array: one pointer selected at run time between the two is a GENERIC pointer, and every key
+// read of the rank loop then is a flat_load (routed through the vector memory path even when it lands in LDS, and
+// counted on both wait counters) instead of a ds_read.
+__device__ __forceinline__ void pj_rank_row(unsigned long long* __restrict__ k, const PlanJob& p, int r, int beg, int L) {
   for (int t = threadIdx.x; t < L; t += blockDim.x) {
     const int e = p.tmp[beg + t];
     const unsigned partner = (unsigned)pj_other(p, e);
@@ -192,6 +188,68 @@ __global__ __launch_bounds__(128) void pj_row_sort_k(PlanJobs J) {   // block: o
         p.key_sorted[beg + rank[q]] = r;
       }
   }
+}
+
+// Long rows whose partners come from a small range (the atom graph of the 2000-atom config: 425 edges per row, 2000
+// nodes) are placed by COUNTING instead: a histogram of the row's partners in LDS, its exclusive scan, and an edge's
+// position is the offset of its partner -- plus, only where a partner occurs more than once in the row, its rank by
+// edge id among those (exactly the (partner, edge id) order of the comparison ranking, which costs L^2 64-bit compares
+// per row: 118 us per batch there).
+constexpr int PJ_HIST_MAX = 4096, PJ_COUNT_FROM = 96;
+__device__ __forceinline__ void pj_count_row(unsigned long long* __restrict__ k, int* __restrict__ hist, const PlanJob& p, int r,
+                                             int beg, int L) {
+  const int nb = p.n_other, tid = threadIdx.x;
+  __shared__ int wave_tot[2];
+  for (int b = tid; b <= nb; b += 128) hist[b] = 0;
+  __syncthreads();
+  for (int t = tid; t < L; t += 128) {
+    const int e = p.tmp[beg + t];
+    const unsigned partner = min((unsigned)pj_other(p, e), (unsigned)nb - 1u);     // (in range by construction; an LDS guard)
+    k[t] = ((unsigned long long)partner << 32) | (unsigned)e;
+    atomicAdd(&hist[partner], 1);
+  }
+  __syncthreads();
+  // exclusive scan of hist[0 .. nb): thread t owns the bins [t C, (t + 1) C)
+  const int C = (nb + 127) / 128;
+  int sum = 0;
+  for (int b = tid * C; b < min((tid + 1) * C, nb); ++b) sum += hist[b];
+  int incl = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int up = __shfl_up(incl, d);
+    if ((tid & 63) >= d) incl += up;
+  }
+  if ((tid & 63) == 63) wave_tot[tid >> 6] = incl;
+  __syncthreads();
+  int run = incl - sum + (tid >= 64 ? wave_tot[0] : 0);
+  for (int b = tid * C; b < min((tid + 1) * C, nb); ++b) { const int c = hist[b]; hist[b] = run; run += c; }
+  if (tid == 127) hist[nb] = L;
+  __syncthreads();
+  for (int t = tid; t < L; t += 128) {
+    const unsigned long long mine = k[t];
+    const unsigned partner = (unsigned)(mine >> 32);
+    int pos = hist[partner];
+    if (hist[partner + 1] - pos > 1)                                 // the partner occurs again in this row: order by edge id
+      for (int u = 0; u < L; ++u) pos += (k[u] >> 32) == partner && k[u] < mine;
+    p.eid[beg + pos] = (int)(unsigned)(mine & 0xffffffffull);
+    p.other_sorted[beg + pos] = (int)partner;
+    p.key_sorted[beg + pos] = r;
+  }
+}
+
+__global__ __launch_bounds__(128) void pj_row_sort_k(PlanJobs J) {   // block: one row of one job
+  __shared__ unsigned long long keys[PJ_LDS_KEYS];
+  __shared__ int hist[PJ_HIST_MAX + 1];
+  int j = 0;
+#pragma unroll
+  for (int t = 1; t < PJ_MAX; ++t) if (t < J.n && J.job[t].row_begin <= (int)blockIdx.x) j = t;
+  const PlanJob& p = J.job[j];
+  const int r = blockIdx.x - p.row_begin;
+  const int beg = p.rowptr[r], L = p.rowptr[r + 1] - beg;
+  if (L <= 0) return;
+  if (L <= PJ_LDS_KEYS && L >= PJ_COUNT_FROM && p.n_other > 0 && p.n_other <= PJ_HIST_MAX) pj_count_row(keys, hist, p, r, beg, L);
+  else if (L <= PJ_LDS_KEYS) pj_rank_row(keys, p, r, beg, L);
+  else pj_rank_row(p.spill + beg, p, r, beg, L);
 }
 
 // ------------------------------------------------------------------ edge records of several (view, cutoff) pairs
@@ -307,6 +365,7 @@ int cgv_plan_jobs_build(const void* jobs_host, int n_jobs, void* stream) {
     cgv::PlanJob& p = J.job[j];
     CGV_REQUIRE(p.E >= 0 && p.n_rows >= 0 && p.n_rows < (1 << 27) && p.stride >= 1 && p.rowptr && p.count, "bad job");
     CGV_REQUIRE(p.E == 0 || (p.eid && p.key_sorted && p.other_sorted && p.tmp && p.spill), "null edge array");
+    CGV_REQUIRE(p.n_other >= 0, "bad partner range");
     p.edge_begin = e; p.row_begin = r;
     e += p.E; r += p.n_rows;
   }

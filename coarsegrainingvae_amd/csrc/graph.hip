@@ -7,6 +7,7 @@
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <stdlib.h>
+#include <type_traits>
 #include "cgv_common.h"
 
 namespace cgv {
@@ -216,7 +217,8 @@ __global__ void grp_meta(const int* __restrict__ dst_g, const int* __restrict__ 
 // block ranks them by (source, receiver, position) -- keys are unique, rank = number of smaller keys -- and writes
 // dst_g / src_g / pos_g / meta_g of its range.  Keys sit in LDS up to GRP_LDS_KEYS edges per group (850 on the
 // 2000-atom graph at rb = 2), beyond that they are re-read from global memory.
-constexpr int GRP_LDS_KEYS = 3072;
+constexpr int GRP_LDS_KEYS = 2816;        // (with the 16 KB partner histogram: 61 KB of LDS)
+constexpr int GRP_HIST_MAX = 4096, GRP_COUNT_FROM = 96;
 
 // slot / head / mask / next source of position q of a group's sorted (source * rb + slot) sequence hi[0..L), as in grp_meta
 template <typename HiAt>
@@ -236,7 +238,7 @@ __device__ __forceinline__ int2 grp_meta_of(HiAt hi_at, int q, int L, int rb) {
 __global__ __launch_bounds__(256) void grp_build_k(const int* __restrict__ rowptr_d, const int* __restrict__ dst_d,
                                                    const int* __restrict__ src_d, int n_dst, int rb,
                                                    int* dst_g, int* src_g, int* pos_g, int2* __restrict__ meta,
-                                                   unsigned long long* spill) {
+                                                   unsigned long long* spill, int n_bins /* n_src * rb */) {
   // (dst_g / src_g are written and read back by other threads of the block between barriers on the spill path: not __restrict__)
   __shared__ unsigned long long keys[GRP_LDS_KEYS];
   __shared__ unsigned long long sorted[GRP_LDS_KEYS];
@@ -245,47 +247,94 @@ __global__ __launch_bounds__(256) void grp_build_k(const int* __restrict__ rowpt
   const int L = end - beg;
   if (L <= 0) return;
   const bool in_lds = L <= GRP_LDS_KEYS;
-  unsigned long long* k = in_lds ? keys : spill + beg;                     // spill: E keys, each group its own range
-  for (int t = threadIdx.x; t < L; t += blockDim.x) {
-    const int p = beg + t;
-    const unsigned hi = (unsigned)src_d[p] * (unsigned)rb + (unsigned)(dst_d[p] - node0);
-    k[t] = ((unsigned long long)hi << 32) | (unsigned)p;
-  }
-  __syncthreads();
-  // sorted position of every element: four keys per thread are ranked against every key read (850 keys per group on
-  // the 2000-atom graph: 666 us per batch with one key per pass)
-  for (int t0 = threadIdx.x; t0 < L; t0 += 4 * blockDim.x) {
-    unsigned long long mine[4];
-    int rank[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) mine[q] = k[min(t0 + q * (int)blockDim.x, L - 1)];
-    // (eight keys per trip: one key per trip waits a full LDS round trip for each of them)
-    int u = 0;
-    for (; u + 8 <= L; u += 8) {
-      unsigned long long other[8];
-#pragma unroll
-      for (int w = 0; w < 8; ++w) other[w] = k[u + w];
-#pragma unroll
-      for (int w = 0; w < 8; ++w)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) rank[q] += other[w] < mine[q];
+  // The fill + rank passes are instantiated for each home of the keys (LDS, or the global spill range of a longer group): a
+  // pointer chosen between the two at run time is generic, and the rank loop's key reads then are flat loads -- through
+  // the vector memory path even when they land in LDS, and counted on both wait counters -- instead of ds_reads.
+  auto fill_and_rank = [&](unsigned long long* __restrict__ k, auto lds_tag) {
+    constexpr bool IN_LDS = decltype(lds_tag)::value;
+    for (int t = threadIdx.x; t < L; t += blockDim.x) {
+      const int p = beg + t;
+      const unsigned hi = (unsigned)src_d[p] * (unsigned)rb + (unsigned)(dst_d[p] - node0);
+      k[t] = ((unsigned long long)hi << 32) | (unsigned)p;
     }
-    for (; u < L; ++u) {
-      const unsigned long long other = k[u];
+    __syncthreads();
+    // sorted position of every element: four keys per thread are ranked against every key read (850 keys per group on
+    // the 2000-atom graph: 666 us per batch with one key per pass)
+    for (int t0 = threadIdx.x; t0 < L; t0 += 4 * blockDim.x) {
+      unsigned long long mine[4];
+      int rank[4] = {0, 0, 0, 0};
 #pragma unroll
-      for (int q = 0; q < 4; ++q) rank[q] += other < mine[q];
-    }
+      for (int q = 0; q < 4; ++q) mine[q] = k[min(t0 + q * (int)blockDim.x, L - 1)];
+      // (eight keys per trip: one key per trip waits a full LDS round trip for each of them)
+      int u = 0;
+      for (; u + 8 <= L; u += 8) {
+        unsigned long long other[8];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (t0 + q * (int)blockDim.x < L) {
-        if (in_lds) {
-          sorted[rank[q]] = mine[q];
-        } else {
-          pos_g[beg + rank[q]] = (int)(unsigned)(mine[q] & 0xffffffffull);  // scratch: the key's low word, in sorted order
-          dst_g[beg + rank[q]] = (int)(mine[q] >> 32);                      // scratch: the key's high word
-        }
+        for (int w = 0; w < 8; ++w) other[w] = k[u + w];
+#pragma unroll
+        for (int w = 0; w < 8; ++w)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) rank[q] += other[w] < mine[q];
       }
-  }
+      for (; u < L; ++u) {
+        const unsigned long long other = k[u];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rank[q] += other < mine[q];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (t0 + q * (int)blockDim.x < L) {
+          if (IN_LDS) {
+            sorted[rank[q]] = mine[q];
+          } else {
+            pos_g[beg + rank[q]] = (int)(unsigned)(mine[q] & 0xffffffffull);  // scratch: the key's low word, in sorted order
+            dst_g[beg + rank[q]] = (int)(mine[q] >> 32);                      // scratch: the key's high word
+          }
+        }
+    }
+  };
+  // Long groups whose (source, slot) words fit the LDS histogram are placed by counting (as pj_row_sort_k's long rows):
+  // offset of the word + rank by position among equal words; 850 keys per group on the 2000-atom graph made the comparison
+  // ranking 136 us per batch.
+  __shared__ int hist[GRP_HIST_MAX + 1];
+  __shared__ int wave_tot[4];
+  if (in_lds && L >= GRP_COUNT_FROM && n_bins <= GRP_HIST_MAX) {
+    const int tid = threadIdx.x;
+    for (int b = tid; b <= n_bins; b += 256) hist[b] = 0;
+    __syncthreads();
+    for (int t = tid; t < L; t += 256) {
+      const int p = beg + t;
+      const unsigned hi = min((unsigned)src_d[p] * (unsigned)rb + (unsigned)(dst_d[p] - node0), (unsigned)n_bins - 1u);
+      keys[t] = ((unsigned long long)hi << 32) | (unsigned)p;
+      atomicAdd(&hist[hi], 1);
+    }
+    __syncthreads();
+    const int C = (n_bins + 255) / 256;
+    int sum = 0;
+    for (int b = tid * C; b < min((tid + 1) * C, n_bins); ++b) sum += hist[b];
+    int incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int up = __shfl_up(incl, d);
+      if ((tid & 63) >= d) incl += up;
+    }
+    if ((tid & 63) == 63) wave_tot[tid >> 6] = incl;
+    __syncthreads();
+    int run = incl - sum;
+    for (int w = 0; w < (tid >> 6); ++w) run += wave_tot[w];
+    for (int b = tid * C; b < min((tid + 1) * C, n_bins); ++b) { const int c = hist[b]; hist[b] = run; run += c; }
+    if (tid == 255) hist[n_bins] = L;
+    __syncthreads();
+    for (int t = tid; t < L; t += 256) {
+      const unsigned long long mine = keys[t];
+      const unsigned hi = (unsigned)(mine >> 32);
+      int pos = hist[hi];
+      if (hist[hi + 1] - pos > 1)
+        for (int u = 0; u < L; ++u) pos += (keys[u] >> 32) == hi && keys[u] < mine;
+      sorted[pos] = mine;
+    }
+  } else if (in_lds) fill_and_rank(keys, std::true_type{});
+  else fill_and_rank(spill + beg, std::false_type{});
   if (in_lds) {
     // the sorted keys stay in LDS: every output of a position is written once, no round trip through global memory
     __syncthreads();
@@ -343,21 +392,25 @@ __global__ __launch_bounds__(128) void csr_row_sort_k(const int64_t* __restrict_
   const int r = blockIdx.x;
   const int beg = rowptr[r], L = rowptr[r + 1] - beg;
   if (L <= 0) return;
-  unsigned long long* k = L <= CSR_LDS_KEYS ? keys : spill + beg;
-  for (int t = threadIdx.x; t < L; t += blockDim.x) {
-    const int e = tmp[beg + t];
-    const unsigned partner = (unsigned)(other ? (int)other[(int64_t)e * stride] : e);
-    k[t] = ((unsigned long long)partner << 32) | (unsigned)e;
-  }
-  __syncthreads();
-  for (int t = threadIdx.x; t < L; t += blockDim.x) {
-    const unsigned long long mine = k[t];
-    int rank = 0;
-    for (int u = 0; u < L; ++u) rank += k[u] < mine;
-    eid[beg + rank] = (int)(unsigned)(mine & 0xffffffffull);
-    other_sorted[beg + rank] = (int)(mine >> 32);
-    key_sorted[beg + rank] = r;
-  }
+  // (instantiated per home of the keys: see grp_build_k)
+  auto rank_row = [&](unsigned long long* __restrict__ k) {
+    for (int t = threadIdx.x; t < L; t += blockDim.x) {
+      const int e = tmp[beg + t];
+      const unsigned partner = (unsigned)(other ? (int)other[(int64_t)e * stride] : e);
+      k[t] = ((unsigned long long)partner << 32) | (unsigned)e;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < L; t += blockDim.x) {
+      const unsigned long long mine = k[t];
+      int rank = 0;
+      for (int u = 0; u < L; ++u) rank += k[u] < mine;
+      eid[beg + rank] = (int)(unsigned)(mine & 0xffffffffull);
+      other_sorted[beg + rank] = (int)(mine >> 32);
+      key_sorted[beg + rank] = r;
+    }
+  };
+  if (L <= CSR_LDS_KEYS) rank_row(keys);
+  else rank_row(spill + beg);
 }
 
 static size_t rows_view_bytes(int E, int n_rows_max) {
@@ -507,7 +560,8 @@ int cgv_group_plan_build(const int32_t* rowptr_d, const int32_t* dst_d, const in
   }
   const int groups = (n_dst + rb - 1) / rb;
   hipLaunchKernelGGL(cgv::grp_build_k, dim3(groups), dim3(256), 0, (hipStream_t)stream, rowptr_d, dst_d, src_d, n_dst, rb,
-                     dst_g, src_g, pos_g, reinterpret_cast<int2*>(meta_g), reinterpret_cast<unsigned long long*>(workspace));
+                     dst_g, src_g, pos_g, reinterpret_cast<int2*>(meta_g), reinterpret_cast<unsigned long long*>(workspace),
+                     (int)((uint64_t)n_src * (uint64_t)rb > 0x7fffffffull ? 0x7fffffff : (uint64_t)n_src * (uint64_t)rb));
   return cgv::check_launch("cgv_group_plan_build");
 }
 

@@ -25,7 +25,7 @@ class PlanJob(C.Structure):
     _fields_ = [("key", C.c_void_p), ("other", C.c_void_p), ("ids_f32", C.c_void_p), ("rowptr", C.c_void_p), ("eid", C.c_void_p),
                 ("key_sorted", C.c_void_p), ("other_sorted", C.c_void_p), ("count", C.c_void_p), ("tmp", C.c_void_p),
                 ("spill", C.c_void_p), ("stride", C.c_int), ("E", C.c_int), ("n_rows", C.c_int), ("edge_begin", C.c_int),
-                ("row_begin", C.c_int), ("ids_is_key", C.c_int), ("pad", C.c_int), ("pad_to", C.c_int)]
+                ("row_begin", C.c_int), ("ids_is_key", C.c_int), ("pad", C.c_int), ("pad_to", C.c_int), ("n_other", C.c_int)]
 
 
 class GeomJob(C.Structure):
@@ -197,9 +197,10 @@ class EdgePlan:
         d_ptr, s_ptr = dst.data_ptr(), (src.data_ptr() if src is not None else None)
         (cd, td, sd), (cs, ts, ss) = self._job_ws
         jd = PlanJob(d_ptr, s_ptr, None, self.rowptr_d.data_ptr(), self.eid_d.data_ptr(), self.dst_d.data_ptr(), self.src_d.data_ptr(),
-                     cd.data_ptr(), td.data_ptr(), sd.data_ptr(), stride, self.n_edges, self.n_dst, 0, 0, 0, 0, 0)
+                     cd.data_ptr(), td.data_ptr(), sd.data_ptr(), stride, self.n_edges, self.n_dst, 0, 0, 0, 0, 0,
+                     self.n_src if src is not None else 0)      # partners of the destination view: source nodes (or edge ids)
         js = PlanJob(s_ptr, d_ptr, None, self.rowptr_s.data_ptr(), self.eid_s.data_ptr(), self.src_s.data_ptr(), self.dst_s.data_ptr(),
-                     cs.data_ptr(), ts.data_ptr(), ss.data_ptr(), stride, self.n_edges, self.n_src, 0, 0, 0, 0, 0)
+                     cs.data_ptr(), ts.data_ptr(), ss.data_ptr(), stride, self.n_edges, self.n_src, 0, 0, 0, 0, 0, self.n_dst)
         return [jd, js]
 
     def nbrs_jobs(self, nbrs: torch.Tensor):
@@ -223,7 +224,7 @@ class EdgePlan:
             raise ValueError("type ids must be a float32 column of the plan's length")
         jobs = self.view_jobs(ids_f32, None, int(ids_f32.stride(0)), ids_f32.shape[0])
         for k, job in enumerate(jobs):
-            job.key, job.other, job.ids_f32 = None, None, ids_f32.data_ptr()
+            job.key, job.other, job.ids_f32, job.n_other = None, None, ids_f32.data_ptr(), 0
             job.ids_is_key = 1 if k == 0 else 0
             job.pad, job.pad_to = (int(pad), int(pad_to)) if pad is not None else (-1, -1)
         return jobs

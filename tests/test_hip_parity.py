@@ -1664,3 +1664,27 @@ def test_skinny_forward_row_blocks(M, N, K, rows_per_block, options):
     assert_close(z[:M], zd, "z", 2e-6)
     assert_close(y[:M], zd * torch.sigmoid(zd), "y", 2e-6)
     assert torch.isnan(y[M]).all() and torch.isnan(z[M]).all()
+
+
+@pytest.mark.parametrize("n,E", [(40, 20000), (300, 45000), (7, 700), (5000, 60000)])
+def test_job_table_replan_equals_fresh_plan_on_long_rows_with_repeats(n, E):
+    """cgv_plan_jobs_build on rows long enough for the counting placement (>= 96 edges, partners from a range that fits
+    the LDS histogram) -- random directed edges WITH repeated (dst, src) pairs, which the counting path orders by edge id
+    -- and on rows / ranges that keep the comparison ranking: every array equals the freshly constructed plan's."""
+    import ctypes as C
+    from coarsegrainingvae_amd import _lib
+    from coarsegrainingvae_amd.graph import PlanJob
+    gen = torch.Generator().manual_seed(n + E)
+    nbrs = torch.randint(0, n, (E, 2), generator=gen).to(DEV)
+    fresh = EdgePlan.from_nbrs(nbrs, n)
+    other = torch.randint(0, n, (E // 2, 2), generator=gen).to(DEV)
+    held = EdgePlan.from_nbrs(other, n, capacity=E + 8)
+    jobs = held.nbrs_jobs(nbrs)
+    table = (PlanJob * len(jobs))(*jobs)
+    _lib.call("cgv_plan_jobs_build", C.addressof(table), len(jobs), _lib.stream_ptr())
+    torch.cuda.synchronize()
+    assert held.n_edges == E
+    for f in ("rowptr_d", "rowptr_s"):
+        assert torch.equal(getattr(held, f), getattr(fresh, f)), f
+    for f in ("eid_d", "dst_d", "src_d", "eid_s", "dst_s", "src_s"):
+        assert torch.equal(getattr(held, f)[:E], getattr(fresh, f)[:E]), f
