@@ -777,6 +777,10 @@ __device__ __forceinline__ float4 strip_ldg4(const float* p) {
 // (chignolin 72 / 76 / 74 us, dipeptide 365 / 360 / 371 us), 96 is 20 % slower (two blocks per CU)
 constexpr int GW_CHUNK = CGV_GW_CHUNK;
 constexpr int GW_GS = 80, GW_XS = 64;
+// gathered_wgrad_k's tile is 64 rows x GW_TW columns of gW: the g columns of a staged chunk (with z: two thirds of the
+// staged bytes of an activated layer) serve twice as many FMAs as in a 64 x 64 tile -- 8 instead of 5.3 FMAs per staged
+// byte; the kernel is bound by the L2 -> LDS traffic of its four blocks per CU, not by the MFMA pipe.
+constexpr int GW_TW = 128, GW_XW = 128;          // tile width in k; LDS row stride of the x chunk
 
 // MODE: GW_STORE writes the tile (and the bias gradient); the other two are the halves of a RANK UPDATE over gathered
 // rows too many for the FMA-per-row kernel (grouped_wgrad_t<true>: VALU bound from ~48 rows): GW_SUMSQ forms the tile,
@@ -789,7 +793,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void gathered_wgrad_k(const WgradProblem* __restrict__ table, int n_problems,
                                                         double* __restrict__ partial, RankUpdateArgs ra) {
   __shared__ __attribute__((aligned(16))) float gs[GW_CHUNK * GW_GS];
-  __shared__ __attribute__((aligned(16))) float xs[GW_CHUNK * GW_XS];
+  __shared__ __attribute__((aligned(16))) float xs[GW_CHUNK * GW_XW];
   if (MODE == GW_ADAM && ra.state[ST_SKIP] != 0.f) return;    // skipped step (utils.py:145): parameters stay
   const int lo = wg_find_problem(table, n_problems);
   const WgradProblem pr = table[lo];
@@ -797,25 +801,25 @@ __global__ __launch_bounds__(256) void gathered_wgrad_k(const WgradProblem* __re
   const int nb = local / pr.tiles_k, kt = local - nb * pr.tiles_k;
   const int M = pr.M, N = pr.N, K = pr.K;
   const int sr = pr.seg_rows > 0 ? pr.seg_rows : M;
-  const int n0 = nb * 64, k0 = kt * 64;
+  const int n0 = nb * 64, k0 = kt * GW_TW;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, q = lane >> 4;
   typedef float f32x4 __attribute__((ext_vector_type(4)));
-  f32x4 acc[4];
+  f32x4 acc[8];                                                      // [half h of the tile's columns][component]
 #pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < 8; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
   const int c4 = threadIdx.x & 15, rr = threadIdx.x >> 4;          // staging: 16 float4 columns x 16 rows per pass
-  const bool gcol = n0 + 4 * c4 < N, xcol = k0 + 4 * c4 < K;
+  const bool gcol = n0 + 4 * c4 < N, xcol0 = k0 + 4 * c4 < K, xcol1 = k0 + 64 + 4 * c4 < K;
   constexpr int NP = GW_CHUNK / 16;                                  // staging passes per chunk
-  float4 gq[NP], zq[NP], xq[NP];
+  float4 gq[NP], zq[NP], xq[NP][2];
   // operand rows of one chunk into registers: the loads only -- g is multiplied by act'(z) when the chunk is stored to
-  // LDS (chunk_finish), so that the next chunk's loads really travel under this chunk's MFMAs.  Straight line: every
+  // LDS (chunk_store), so that the next chunk's loads really travel under this chunk's MFMAs.  Straight line: every
   // request goes to a valid (clamped) address through a global-address-space pointer and is zeroed by a select when it
   // is stored (a predicated load is a branch with a wait for everything outstanding; a generic-pointer load is a
   // flat_load, which also counts on lgkmcnt and made the MFMA loop's first LDS wait a wait for the whole next chunk).
-  const int gcol_at = gcol ? n0 + 4 * c4 : 0, xcol_at = xcol ? k0 + 4 * c4 : 0;
+  const int gcol_at = gcol ? n0 + 4 * c4 : 0, xcol0_at = xcol0 ? k0 + 4 * c4 : 0, xcol1_at = xcol1 ? k0 + 64 + 4 * c4 : 0;
   const float* zsrc = pr.act ? pr.z : pr.gy;                          // (no activation: a second look at g instead of a branch)
   auto chunk_load = [&](int m0) {
 #pragma unroll
@@ -825,7 +829,8 @@ __global__ __launch_bounds__(256) void gathered_wgrad_k(const WgradProblem* __re
       const size_t base = (size_t)seg * pr.seg_stride;
       gq[p] = strip_ldg4(pr.gy + base + (size_t)row * N + gcol_at);
       zq[p] = strip_ldg4(zsrc + base + (size_t)row * N + gcol_at);
-      xq[p] = strip_ldg4(pr.x + base + (size_t)row * K + xcol_at);
+      xq[p][0] = strip_ldg4(pr.x + base + (size_t)row * K + xcol0_at);
+      xq[p][1] = strip_ldg4(pr.x + base + (size_t)row * K + xcol1_at);
     }
     strip_pin();
   };
@@ -846,11 +851,13 @@ __global__ __launch_bounds__(256) void gathered_wgrad_k(const WgradProblem* __re
 #pragma unroll
     for (int p = 0; p < NP; ++p) {                                   // rows beyond M and columns beyond N / K: zeros
       const bool live = m0 + rr + 16 * p < M;
-      const bool gk = live && gcol, xk = live && xcol;
+      const bool gk = live && gcol, xk0 = live && xcol0, xk1 = live && xcol1;
       *reinterpret_cast<float4*>(gs + (rr + 16 * p) * GW_GS + 4 * c4) =
           make_float4(gk ? gq[p].x : 0.f, gk ? gq[p].y : 0.f, gk ? gq[p].z : 0.f, gk ? gq[p].w : 0.f);
-      *reinterpret_cast<float4*>(xs + (rr + 16 * p) * GW_XS + 4 * c4) =
-          make_float4(xk ? xq[p].x : 0.f, xk ? xq[p].y : 0.f, xk ? xq[p].z : 0.f, xk ? xq[p].w : 0.f);
+      *reinterpret_cast<float4*>(xs + (rr + 16 * p) * GW_XW + 4 * c4) =
+          make_float4(xk0 ? xq[p][0].x : 0.f, xk0 ? xq[p][0].y : 0.f, xk0 ? xq[p][0].z : 0.f, xk0 ? xq[p][0].w : 0.f);
+      *reinterpret_cast<float4*>(xs + (rr + 16 * p) * GW_XW + 64 + 4 * c4) =
+          make_float4(xk1 ? xq[p][1].x : 0.f, xk1 ? xq[p][1].y : 0.f, xk1 ? xq[p][1].z : 0.f, xk1 ? xq[p][1].w : 0.f);
     }
   };
   chunk_load(0);
@@ -860,48 +867,58 @@ __global__ __launch_bounds__(256) void gathered_wgrad_k(const WgradProblem* __re
     chunk_load(min(m0 + GW_CHUNK, M - 1));                           // the next chunk travels under this chunk's MFMAs
                                                                      // (the last trip asks for the last row again: no branch)
     const float* ga = gs + q * GW_GS + 16 * wave + i;
-    const float* xb = xs + q * GW_XS + 4 * i;
+    const float* xb = xs + q * GW_XW + 4 * i;
     // whole trip count (the rows beyond the chunk are zeros): unrolled, LDS reads issued two steps ahead of their MFMAs
 #pragma unroll
     for (int st = 0; st < GW_CHUNK / 4; ++st) {
       const float a = ga[(4 * st) * GW_GS];
-      const float4 b = *reinterpret_cast<const float4*>(xb + (4 * st) * GW_XS);
+      const float4 b0 = *reinterpret_cast<const float4*>(xb + (4 * st) * GW_XW);
+      const float4 b1 = *reinterpret_cast<const float4*>(xb + (4 * st) * GW_XW + 64);
       bsum += a;
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.x, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.y, acc[1], 0, 0, 0);
-      acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.z, acc[2], 0, 0, 0);
-      acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.w, acc[3], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0.x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0.y, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0.z, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0.w, acc[3], 0, 0, 0);
+      acc[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1.x, acc[4], 0, 0, 0);
+      acc[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1.y, acc[5], 0, 0, 0);
+      acc[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1.z, acc[6], 0, 0, 0);
+      acc[7] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1.w, acc[7], 0, 0, 0);
     }
-    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
 #pragma unroll
     for (int st = 0; st < GW_CHUNK / 4 - 2; ++st) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
     }
-    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
     __syncthreads();
   }
-  const int n = n0 + 16 * wave + i, kcol = k0 + 4 * i;
+  const int n = n0 + 16 * wave + i;
   if (MODE == GW_STORE) {
-    if (kcol < K) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int kcol = k0 + 64 * h + 4 * i;
+      if (kcol >= K) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = n0 + 16 * wave + 4 * q + r;
         if (row >= N) continue;
         float* dst = pr.gW + (size_t)row * K + kcol;
-        float4 o = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+        float4 o = make_float4(acc[4 * h][r], acc[4 * h + 1][r], acc[4 * h + 2][r], acc[4 * h + 3][r]);
         if (pr.accumulate) { const float4 old = ldg4_global(dst); o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
         stg4_global(dst, o);
       }
     }
   } else if (MODE == GW_SUMSQ) {
     double sq = 0.0;
-    if (kcol < K) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (k0 + 64 * h + 4 * i >= K) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if (n0 + 16 * wave + 4 * q + r >= N) continue;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) sq += (double)acc[c][r] * (double)acc[c][r];
+        for (int c = 0; c < 4; ++c) sq += (double)acc[4 * h + c][r] * (double)acc[4 * h + c][r];
       }
     }
 #pragma unroll
@@ -911,9 +928,12 @@ __global__ __launch_bounds__(256) void gathered_wgrad_k(const WgradProblem* __re
     __syncthreads();
     if (threadIdx.x == 0) partial[blockIdx.x] = (wave_sq[0] + wave_sq[1]) + (wave_sq[2] + wave_sq[3]);
   } else {
-    if (kcol < K) {
-      typedef float f4v __attribute__((ext_vector_type(4)));
-      const AdamStep a = adam_step_of(ra.state, ra.lr, ra.beta1, ra.beta2, ra.eps);
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const AdamStep a = adam_step_of(ra.state, ra.lr, ra.beta1, ra.beta2, ra.eps);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int kcol = k0 + 64 * h + 4 * i;
+      if (kcol >= K) continue;
       const size_t at0 = (size_t)(pr.gW - ra.arena_g) + kcol;
       float4 pp[4], mm[4], vv[4];
 #pragma unroll
@@ -931,8 +951,8 @@ __global__ __launch_bounds__(256) void gathered_wgrad_k(const WgradProblem* __re
         const int row = n0 + 16 * wave + 4 * q + r;
         if (row >= N) continue;
         const size_t o = at0 + (size_t)row * K;
-        adam_elem(a, pp[r].x, acc[0][r], mm[r].x, vv[r].x); adam_elem(a, pp[r].y, acc[1][r], mm[r].y, vv[r].y);
-        adam_elem(a, pp[r].z, acc[2][r], mm[r].z, vv[r].z); adam_elem(a, pp[r].w, acc[3][r], mm[r].w, vv[r].w);
+        adam_elem(a, pp[r].x, acc[4 * h][r], mm[r].x, vv[r].x); adam_elem(a, pp[r].y, acc[4 * h + 1][r], mm[r].y, vv[r].y);
+        adam_elem(a, pp[r].z, acc[4 * h + 2][r], mm[r].z, vv[r].z); adam_elem(a, pp[r].w, acc[4 * h + 3][r], mm[r].w, vv[r].w);
         *reinterpret_cast<float4*>(ra.arena_p + o) = pp[r];
         __builtin_nontemporal_store(f4v{mm[r].x, mm[r].y, mm[r].z, mm[r].w}, reinterpret_cast<f4v*>(ra.arena_m + o));
         __builtin_nontemporal_store(f4v{vv[r].x, vv[r].y, vv[r].z, vv[r].w}, reinterpret_cast<f4v*>(ra.arena_v + o));
@@ -947,7 +967,7 @@ __global__ __launch_bounds__(256) void gathered_wgrad_k(const WgradProblem* __re
   }
 }
 
-// sumsq[problem] = sum of its blocks' partial sums of squares, block order (deterministic)
+// block partials of gathered_wgrad_k<GW_SUMSQ> -> one double per problem, summed in block order
 __global__ __launch_bounds__(256) void gathered_sumsq_reduce_k(const WgradProblem* __restrict__ table, int n_problems, int total_blocks,
                                                                const double* __restrict__ partial, double* __restrict__ out) {
   __shared__ double part[256];
@@ -1702,7 +1722,8 @@ int cgv_wgrad_gathered_plan_tile(int M, int N, int K, int seg_rows, int tile, in
   CGV_REQUIRE(M >= 1 && N >= 4 && K >= 4 && (N % 4) == 0 && (K % 4) == 0, "unsupported shape (need N % 4 == 0, K % 4 == 0)");
   CGV_REQUIRE(seg_rows == 0 || (seg_rows > 0 && seg_rows % 4 == 0), "rank segments must hold a multiple of 4 rows");
   CGV_REQUIRE(tile == 64 || tile == 128, "tile must be 64 or 128");
-  *tiles_k = (K + tile - 1) / tile;
+  const int tile_k = tile == 64 ? cgv::GW_TW : tile;        // (the 64-row tiles are GW_TW = 128 columns wide)
+  *tiles_k = (K + tile_k - 1) / tile_k;
   *n_blocks = ((N + tile - 1) / tile) * *tiles_k;
   return 0;
 }

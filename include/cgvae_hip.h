@@ -507,7 +507,7 @@ int cgv_grouped_wgrad(const void* table_dev, int n_problems, int total_blocks, i
  *   cgv_grouped_wgrad_gathered: the 88-byte record of cgv_grouped_wgrad with act = 0, z = NULL and
  *     seg_rows (rows per rank, a multiple of 4) / seg_stride (floats between the rank segments of the gathered
  *     buffer): row m of the problem is row m % seg_rows of segment m / seg_rows; M = ranks * seg_rows (any size).
- *     tiles_k / the block count come from cgv_wgrad_gathered_plan; tile_w is unused.  64 x 64 output tiles, exact
+ *     tiles_k / the block count come from cgv_wgrad_gathered_plan; tile_w is unused.  Output tiles of 64 rows x 128 columns, exact
  *     fp32 MFMA chains in a fixed order: every rank obtains bit-identical gradients. */
 int cgv_wgrad_gathered_plan(int M, int N, int K, int seg_rows, int* tiles_k /*[host]*/, int* n_blocks /*[host]*/);
 int cgv_grouped_wgrad_gathered(const void* table_dev, int n_problems, int total_blocks, void* stream);
