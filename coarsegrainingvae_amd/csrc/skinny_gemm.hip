@@ -517,35 +517,37 @@ __global__ __launch_bounds__(256) void grouped_wgrad_t(const WgradProblem* __res
   const int tc = t & (lanes - 1), grp = t / lanes;
   const int k = kbase + 4 * tc;
   if (tc < t4 && k < K) {
-    for (int pass = grp; pass < WG_PASSES; pass += groups) {
-      const int nr = n0 + pass * WG_ROWS;
+    // rank update: 8 rows per pass, and the p / m / v of ALL of them are requested before the tile is formed (two register
+    // sets of 4 rows): with 16 rows per pass only the first 4 rows' requests travelled under the FMAs and each later group
+    // of 4 paid a whole memory round trip in front of its update
+    constexpr int ROWS = ADAM ? 8 : WG_ROWS, PASSES = WG_BLOCK_ROWS / ROWS;
+    for (int pass = grp; pass < PASSES; pass += groups) {
+      const int nr = n0 + pass * ROWS;
       if (nr >= N) break;
-      float4 acc[WG_ROWS];
+      float4 acc[ROWS];
 #pragma unroll
-      for (int r = 0; r < WG_ROWS; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-      // rank update: p / m / v of 4 rows at a time; the first 4 rows' loads are issued before the tile is formed
+      for (int r = 0; r < ROWS; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
       typedef float f4v __attribute__((ext_vector_type(4)));
-      float4 pp[4], mm[4], vv[4];
+      float4 pp[ADAM ? ROWS : 1], mm[ADAM ? ROWS : 1], vv[ADAM ? ROWS : 1];
       const size_t at = ADAM ? (size_t)(pr.gW - ra.arena_g) + (size_t)nr * K + k : 0;
-      auto load_rows = [&](int r0) {
+      if (ADAM) {
+        // rows beyond N are clamped onto the last one (their results are not stored): no branch around a request
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (nr + r0 + r < N) {
-            const size_t o = at + (size_t)(r0 + r) * K;
-            pp[r] = *reinterpret_cast<const float4*>(ra.arena_p + o);
-            const f4v tm = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(ra.arena_m + o));
-            const f4v tv = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(ra.arena_v + o));
-            mm[r] = make_float4(tm.x, tm.y, tm.z, tm.w);
-            vv[r] = make_float4(tv.x, tv.y, tv.z, tv.w);
-          }
+        for (int r = 0; r < ROWS; ++r) {
+          const size_t o = at + (size_t)min(r, N - 1 - nr) * K;
+          pp[r] = ldg4_global(ra.arena_p + o);
+          const f4v tm = __builtin_nontemporal_load(reinterpret_cast<const __attribute__((address_space(1))) f4v*>((const __attribute__((address_space(1))) float*)(ra.arena_m + o)));
+          const f4v tv = __builtin_nontemporal_load(reinterpret_cast<const __attribute__((address_space(1))) f4v*>((const __attribute__((address_space(1))) float*)(ra.arena_v + o)));
+          mm[r] = make_float4(tm.x, tm.y, tm.z, tm.w);
+          vv[r] = make_float4(tv.x, tv.y, tv.z, tv.w);
         }
-      };
-      if (ADAM) load_rows(0);
+        asm volatile("" ::: "memory");                            // the requests stay in front of the FMAs
+      }
       for (int m = 0; m < M; ++m) {
         const float4 xv = *reinterpret_cast<const float4*>(xs + (size_t)m * tile_w + 4 * tc);
-        const float4* g4 = reinterpret_cast<const float4*>(gs + m * WG_BLOCK_ROWS + pass * WG_ROWS);   // LDS broadcast
+        const float4* g4 = reinterpret_cast<const float4*>(gs + m * WG_BLOCK_ROWS + pass * ROWS);   // LDS broadcast
 #pragma unroll
-        for (int i = 0; i < WG_ROWS / 4; ++i) {
+        for (int i = 0; i < ROWS / 4; ++i) {
           const float4 gv = g4[i];
           const float gg[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
@@ -559,24 +561,20 @@ __global__ __launch_bounds__(256) void grouped_wgrad_t(const WgradProblem* __res
       if (ADAM) {
         const AdamStep a = adam_step_of(ra.state, ra.lr, ra.beta1, ra.beta2, ra.eps);
 #pragma unroll
-        for (int r0 = 0; r0 < WG_ROWS; r0 += 4) {
-          if (r0) load_rows(r0);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            if (nr + r0 + r < N) {
-              const size_t o = at + (size_t)(r0 + r) * K;
-              const float4 g = acc[r0 + r];
-              adam_elem(a, pp[r].x, g.x, mm[r].x, vv[r].x); adam_elem(a, pp[r].y, g.y, mm[r].y, vv[r].y);
-              adam_elem(a, pp[r].z, g.z, mm[r].z, vv[r].z); adam_elem(a, pp[r].w, g.w, mm[r].w, vv[r].w);
-              *reinterpret_cast<float4*>(ra.arena_p + o) = pp[r];
-              __builtin_nontemporal_store(f4v{mm[r].x, mm[r].y, mm[r].z, mm[r].w}, reinterpret_cast<f4v*>(ra.arena_m + o));
-              __builtin_nontemporal_store(f4v{vv[r].x, vv[r].y, vv[r].z, vv[r].w}, reinterpret_cast<f4v*>(ra.arena_v + o));
-            }
+        for (int r = 0; r < ROWS; ++r) {
+          if (nr + r < N) {
+            const size_t o = at + (size_t)r * K;
+            const float4 g = acc[r];
+            adam_elem(a, pp[r].x, g.x, mm[r].x, vv[r].x); adam_elem(a, pp[r].y, g.y, mm[r].y, vv[r].y);
+            adam_elem(a, pp[r].z, g.z, mm[r].z, vv[r].z); adam_elem(a, pp[r].w, g.w, mm[r].w, vv[r].w);
+            *reinterpret_cast<float4*>(ra.arena_p + o) = pp[r];
+            __builtin_nontemporal_store(f4v{mm[r].x, mm[r].y, mm[r].z, mm[r].w}, reinterpret_cast<f4v*>(ra.arena_m + o));
+            __builtin_nontemporal_store(f4v{vv[r].x, vv[r].y, vv[r].z, vv[r].w}, reinterpret_cast<f4v*>(ra.arena_v + o));
           }
         }
       } else {
 #pragma unroll
-        for (int r = 0; r < WG_ROWS; ++r) {
+        for (int r = 0; r < ROWS; ++r) {
           if (nr + r < N) {
             float* dst = pr.gW + (size_t)(nr + r) * K + k;
             float4 o = acc[r];
