@@ -334,7 +334,9 @@ class _LinearFn(torch.autograd.Function):
                 # per thread block still beats the tiles (96 rows: 600 x 600 4.8 against 6.7 us, 600 x 1200 6.3 / 10.5,
                 # 1200 x 600 5.9 / 6.7; from 1800 outputs on the tiles win: tools/fwd_bench.py)
                 few_rows = mode == "tile" and M <= 128 and N <= 1200 and (bias is None or bias.data_ptr() % 16 == 0)
-                _lib.call("cgv_skinny_linear_fwd" if (mode == "skinny" or few_rows) else "cgv_tile_linear_fwd", _lib.ptr(x2),
+                # 33 - 64 rows and a very wide layer (64 beads x 5400 outputs): the tiles win (11.7 against 14.2 us)
+                wide = mode == "skinny" and M > 32 and N >= 4096 and lib_tile_ok(M, N, K)
+                _lib.call("cgv_skinny_linear_fwd" if ((mode == "skinny" and not wide) or few_rows) else "cgv_tile_linear_fwd", _lib.ptr(x2),
                           _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(y), _lib.ptr(z), M, N, K, act, _lib.stream_ptr())
             ctx.save_for_backward(x2, weight, z)
             return y.reshape(x.shape[:-1] + (N,))
@@ -563,6 +565,10 @@ def _library_pays(M, N, K, forward: bool) -> bool:
 def lib_has_rows(M, N, K) -> bool:
     """Shapes the grouped MFMA weight-gradient launch takes (any row count; widths in multiples of 4)."""
     return M >= 1 and N >= 4 and K >= 4 and N % 4 == 0 and K % 4 == 0
+
+
+def lib_tile_ok(M, N, K) -> bool:
+    return bool(_lib.load().cgv_tile_supported(M, N, K))
 
 
 def skinny_bwd_input(gy2, z, weight, gx, M, N, K, act, stream=None):
