@@ -428,6 +428,12 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void equi_msg_bwd_k(
       if (gs != nullptr && beg < end) {
         constexpr int NGB = R + 1;                                     // a_n and env; the unit vector is not needed
         float gc[NGB], gn[NGB];
+        // Per edge only  N[n] += gs_i a_n(e)  is accumulated (R + 1 packed FMAs): both sums of the node follow from it
+        // when its segment is done --  g_phi[j] = sum_e gs_i w(e) = W . N  and  gWd += phi[j] N  -- instead of a filter
+        // evaluation AND a filter-gradient update per edge (2 (R + 1) + 2 packed FMAs).
+        f2 Nn[R + 1];
+#pragma unroll
+        for (int n = 0; n <= R; ++n) Nn[n] = splat(0.f);
 #pragma unroll
         for (int t = 0; t < NGB; ++t) gc[t] = geom[(size_t)beg * GS + t];
         const unsigned og = 4u * (unsigned)cp.c, rowb = 4u * (unsigned)F;
@@ -452,16 +458,19 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void equi_msg_bwd_k(
             for (int t = 0; t < NGB; ++t) gn[t] = geom[(size_t)e1 * GS + t];
             const unsigned so_nn = (unsigned)dst[e2] * rowb;
             const f2 n_q = ld2_buf(r_gs, og, so_n);
-            a1 = fma2(c_q, filter2<R>(W[0], gc), a1);
-            const f2 t1 = c_q * p1;
 #pragma unroll
-            for (int n = 0; n <= R; ++n) G[0][n] = fma2(t1, splat(gc[n]), G[0][n]);
+            for (int n = 0; n <= R; ++n) Nn[n] = fma2(c_q, splat(gc[n]), Nn[n]);
 #pragma unroll
             for (int t = 0; t < NGB; ++t) gc[t] = gn[t];
             so_n = so_nn;
             c_q = n_q;
           }
         }
+        a1 = W[0][R] * Nn[R];                                          // (env term first, as filter2)
+#pragma unroll
+        for (int n = 0; n < R; ++n) a1 = fma2(W[0][n], Nn[n], a1);
+#pragma unroll
+        for (int n = 0; n <= R; ++n) G[0][n] = fma2(p1, Nn[n], G[0][n]);
       }
     } else {
 #pragma unroll 2
