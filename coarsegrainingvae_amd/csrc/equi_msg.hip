@@ -434,36 +434,49 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void equi_msg_bwd_k(
         f2 Nn[R + 1];
 #pragma unroll
         for (int n = 0; n <= R; ++n) Nn[n] = splat(0.f);
-#pragma unroll
-        for (int t = 0; t < NGB; ++t) gc[t] = geom[(size_t)beg * GS + t];
         const unsigned og = 4u * (unsigned)cp.c, rowb = 4u * (unsigned)F;
-        unsigned so_n = (unsigned)dst[min(beg + 1, end - 1)] * rowb;
-        f2 c_q = ld2_buf(r_gs, og, (unsigned)dst[beg] * rowb);
-        // The records and receiver indices are streamed exactly once per (node, channel tile) by SCALAR loads, which
-        // wait for all outstanding requests at every use: a deeper scalar prefetch cannot hide more than one edge of
-        // latency, and on graphs whose record array is far beyond L2 (2000 atoms: 68 MB) each of those loads went to
-        // HBM.  Every 64 edges the lanes touch one dword of the 64 records (and receiver indices) that follow the
-        // next 64 -- vector loads, in order, nobody waits for them -- so the scalar loads find their lines in L2.
-        const int e_last = n_edges_total - 1;
+        // Batches of EB edges: the scalar unit's loads return out of order, so every use waits for all of them -- one
+        // wait per BATCH (its EB records and the receiver indices of the next batch) instead of one per edge; the gs
+        // gathers of a batch are issued one batch ahead (vector loads: in order, waited for individually).
+        // The records and receiver indices are streamed exactly once per (node, channel tile); on graphs whose record
+        // array is far beyond L2 (2000 atoms: 68 MB) each scalar load went to HBM: every 64 edges the lanes touch one dword
+        // of the 64 records (and receiver indices) that follow the next 64 -- vector loads nobody waits for -- so the
+        // scalar loads find their lines in L2.
+        constexpr int EB = 4;
+        const int e_last = n_edges_total - 1, seg_last = end - 1;
+        f2 q_cur[EB], q_nxt[EB];
+        int i_nxt[EB];
+#pragma unroll
+        for (int u = 0; u < EB; ++u) q_cur[u] = ld2_buf(r_gs, og, (unsigned)dst[min(beg + u, seg_last)] * rowb);
+#pragma unroll
+        for (int u = 0; u < EB; ++u) i_nxt[u] = dst[min(beg + EB + u, seg_last)];
+        (void)gc; (void)gn;
         for (int eb = beg; eb < end; eb += 64) {
           const int ew = min(eb + 64 + lane, e_last);
           warm = fmaf(pend_g, 0.f, warm) + (float)(pend_i & 0);
           pend_g = geom[(size_t)ew * GS];
           pend_i = dst[ew];
           const int ee = min(eb + 64, end);
-#pragma unroll 2
-          for (int e = eb; e < ee; ++e) {
-            const int e1 = min(e + 1, end - 1), e2 = min(e + 2, end - 1);
+          for (int e = eb; e < ee; e += EB) {
+            float rec[EB][NGB];
 #pragma unroll
-            for (int t = 0; t < NGB; ++t) gn[t] = geom[(size_t)e1 * GS + t];
-            const unsigned so_nn = (unsigned)dst[e2] * rowb;
-            const f2 n_q = ld2_buf(r_gs, og, so_n);
+            for (int u = 0; u < EB; ++u) {
+              const float* __restrict__ gp = geom + (size_t)min(e + u, seg_last) * GS;
 #pragma unroll
-            for (int n = 0; n <= R; ++n) Nn[n] = fma2(c_q, splat(gc[n]), Nn[n]);
+              for (int t = 0; t < NGB; ++t) rec[u][t] = gp[t];
+            }
 #pragma unroll
-            for (int t = 0; t < NGB; ++t) gc[t] = gn[t];
-            so_n = so_nn;
-            c_q = n_q;
+            for (int u = 0; u < EB; ++u) q_nxt[u] = ld2_buf(r_gs, og, (unsigned)i_nxt[u] * rowb);
+#pragma unroll
+            for (int u = 0; u < EB; ++u) i_nxt[u] = dst[min(e + 2 * EB + u, seg_last)];
+#pragma unroll
+            for (int u = 0; u < EB; ++u) {
+              const f2 cq = e + u < ee ? q_cur[u] : splat(0.f);          // (wave-uniform: the last batch of a 64-edge piece)
+#pragma unroll
+              for (int n = 0; n <= R; ++n) Nn[n] = fma2(cq, splat(rec[u][n]), Nn[n]);
+            }
+#pragma unroll
+            for (int u = 0; u < EB; ++u) q_cur[u] = q_nxt[u];
           }
         }
         a1 = W[0][R] * Nn[R];                                          // (env term first, as filter2)
