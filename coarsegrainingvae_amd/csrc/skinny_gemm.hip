@@ -628,7 +628,8 @@ __global__ __launch_bounds__(GRAM_THREADS) void wgrad_gram_k(const WgradProblem*
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   double* mine = ws + (size_t)blockIdx.y * GRAM_WS_DOUBLES + (size_t)sl * 2 * GRAM_MAX_PAIRS;
   for (int i = t; i < 2 * pair_cap; i += GRAM_THREADS) sums[i] = 0.0;
-  if (pr.gb) {                                                  // bias gradient: a column slice per block
+  const bool unsupported = M > GRAM_MAX_ROWS || M * (M + 1) / 2 > pair_cap;
+  if (pr.gb && unsupported) {                                   // bias gradient (supported shapes: from the staged slices, below)
     for (int n = sl * GRAM_THREADS + t; n < N; n += GRAM_SLICES * GRAM_THREADS) {
       float sum = 0.f;
 #pragma unroll 4
@@ -641,7 +642,7 @@ __global__ __launch_bounds__(GRAM_THREADS) void wgrad_gram_k(const WgradProblem*
       pr.gb[n] = pr.accumulate ? pr.gb[n] + sum : sum;
     }
   }
-  if (M > GRAM_MAX_ROWS || M * (M + 1) / 2 > pair_cap) {        // unsupported (cgv_rank_update_supported): poison the norm
+  if (unsupported) {                                            // (cgv_rank_update_supported): poison the norm
     if (t == 0) mine[0] = __builtin_nan("");
     return;
   }
@@ -689,6 +690,27 @@ __global__ __launch_bounds__(GRAM_THREADS) void wgrad_gram_k(const WgradProblem*
     }
     if (slice + GRAM_SLICES < slices) fetch(slice + GRAM_SLICES, buf);       // in flight while this slice is used
     __syncthreads();
+    if (pr.gb && slice < g_slices) {
+      // bias gradient of this slice's columns: column sums of the staged g (rows ascending) -- as a loop over global
+      // memory in front of the first fetch it was M dependent row loads per column, ~6 round trips before the block started
+      const int c0 = slice * C4;
+      for (int c = t; c < C4 && c0 + c < n4; c += GRAM_THREADS) {
+        float4 sum = zero4;
+        for (int m = 0; m < M; ++m) {
+          const float4 g = tile[m * RS + c];
+          sum.x += g.x; sum.y += g.y; sum.z += g.z; sum.w += g.w;
+        }
+        float* dst = pr.gb + 4 * (c0 + c);
+        if ((reinterpret_cast<uintptr_t>(pr.gb) & 15) == 0) {             // (block-uniform; arena slots are 256-byte aligned)
+          if (pr.accumulate) { const float4 old = ldg4_global(dst); sum.x += old.x; sum.y += old.y; sum.z += old.z; sum.w += old.w; }
+          stg4_global(dst, sum);
+        } else {
+          const float v4[4] = {sum.x, sum.y, sum.z, sum.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dst[e] = pr.accumulate ? dst[e] + v4[e] : v4[e];
+        }
+      }
+    }
     double* row = sums + (slice < g_slices ? 0 : pair_cap);
     for (int base = 8 * w; base < pairs; base += 8 * GRAM_WAVES) {
       const int pidx = base + pl;
