@@ -67,11 +67,31 @@ def parse():
     return ap.parse_args()
 
 
+def visible_gpus() -> int:
+    """GPUs of this node, counted WITHOUT touching the HIP / HSA runtime: the KFD topology lists every agent; a GPU node
+    has a non-zero ``simd_count`` (CPU nodes report 0).  HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES narrow the count."""
+    n = 0
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for node in os.listdir(base):
+            try:
+                props = dict(line.split()[:2] for line in open(os.path.join(base, node, "properties")) if len(line.split()) >= 2)
+            except OSError:
+                continue
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except OSError:
+        return 0
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        if os.environ.get(var, "").strip():
+            n = min(n, len([t for t in os.environ[var].split(",") if t.strip()]))
+    return n
+
+
 def spawn_ranks(n: int) -> int:
     """``bench.py --gpus N`` outside torchrun: start the N ranks as children of this process, which has not touched the
-    GPU (``device_count`` does not initialise it) and never will; their output is passed through."""
-    import torch
-    have = torch.cuda.device_count()
+    GPU runtime (devices are counted from sysfs, torch is not imported) and never will; their output is passed through."""
+    have = visible_gpus()
     if have < n:
         print(f"[bench] --gpus {n} requested but this node exposes {have} GPU(s)", file=sys.stderr)
         return 2

@@ -600,7 +600,7 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_fwd_k(
   float ah = 0.f, ahb = 0.f;
   dv3 acc{0.f, 0.f, 0.f};
   const float* __restrict__ vsrc = (k == 2 || k == 6 || k == 7) ? v_l : vb_l;
-  const int e_beg = live ? rp_l[i] : 0, e_end = live ? rp_l[i + 1] : 0;
+  const int e_beg = live ? rp_l[i] : 0, e_end = live ? min(rp_l[i + 1], E) : 0;      // E = records staged (>= the graph's edges)
   for (int e = e_beg; e < e_end; ++e) {
     const int j = src_l[e];
     const float* __restrict__ g = geom_l + (size_t)e * GS;
@@ -1053,7 +1053,7 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_bwd_k(
   float a = 0.f;
   dv3 av{0.f, 0.f, 0.f}, avb{0.f, 0.f, 0.f};
   {
-    const int e_beg = live ? rps_l[node] : 0, e_end = live ? rps_l[node + 1] : 0;
+    const int e_beg = live ? rps_l[node] : 0, e_end = live ? min(rps_l[node + 1], E) : 0;
     for (int e = e_beg; e < e_end; ++e) {
       const float* __restrict__ g = geoms_l + (size_t)e * GS;
       const int i = dsts_l[e];
@@ -1110,7 +1110,7 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_bwd_k(
   float as = 0.f, asb = 0.f;
   dv3 rv{0.f, 0.f, 0.f}, rvb{0.f, 0.f, 0.f};
   if (k == 0 || k == 1 || k == 3 || k == 4 || k == 6 || k == 7 || k == 8) {
-    const int e_beg = live ? rpd_l[node] : 0, e_end = live ? rpd_l[node + 1] : 0;
+    const int e_beg = live ? rpd_l[node] : 0, e_end = live ? min(rpd_l[node + 1], E) : 0;
     for (int e = e_beg; e < e_end; ++e) {
       const int jc = srcd_l[e] * 4 + c;
       if (k == 1) { daxpy(rv, ghb_n, lds_v3(vb_l + jc * 3)); continue; }

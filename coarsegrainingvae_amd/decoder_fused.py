@@ -50,6 +50,14 @@ def layer_params(decoder):
     return flat
 
 
+def staged_edges(plan) -> int:
+    """Edge records the message kernels stage in LDS: the plan's CAPACITY (clamped to what the kernels hold), not the
+    current batch's edge count -- like every other kernel they take the edge structure from ``rowptr`` on the device, so
+    a captured step replays on batches with other bead-edge counts (``Trainer.capture`` / ``data.copy_batch_into``;
+    16 nodes have at most 240 directed edges, so the clamp never cuts a real edge)."""
+    return max(1, min(int(plan.capacity), int(_lib.load().cgv_decoder_max_edges())))
+
+
 def usable(decoder, S: torch.Tensor, plan, geom) -> bool:
     from .ops import _adjacent
     if not (S.is_cuda and S.dtype == _F32 and len(decoder.message_blocks) > 0 and geom is not None):
@@ -95,6 +103,7 @@ class _PseudoDecoderFn(torch.autograd.Function):
         new = lambda *shape: torch.empty(*shape, dtype=_F32, device=dev)
         Sbar, V, Vbar = Sbar0, V0, V0
         saved = []
+        n_stage = staged_edges(plan)
         from .options import HOST
         if HOST["decoder_dense"] == 1:          # A/B: the 16-column-block skinny kernel for the two full-width products
             dense = _dense_fwd
@@ -110,7 +119,7 @@ class _PseudoDecoderFn(torch.autograd.Function):
             _lib.call("cgv_decoder_msg_fwd", _lib.ptr(a1), _lib.ptr(W2), _lib.ptr(b2), _lib.ptr(S), _lib.ptr(Sbar), _lib.ptr(V),
                       _lib.ptr(Vbar), _lib.ptr(geom.geom_d), _lib.ptr(plan.rowptr_d), _lib.ptr(plan.src_d), _lib.ptr(Wd),
                       _lib.ptr(bd), _lib.ptr(phi), _lib.ptr(stack), _lib.ptr(Sbar2), _lib.ptr(V2), _lib.ptr(Vbar2), _lib.ptr(rows),
-                      n, F, R, plan.n_edges, st, tag=f"pseudo_msg_fwd:Nd{n}:E{plan.n_edges}:dv1")
+                      n, F, R, n_stage, st, tag=f"pseudo_msg_fwd:Nd{n}:E{plan.n_edges}:dv1")
             UV = new(3 * n, 2 * F)
             _lib.call("cgv_decoder_uv_fwd", _lib.ptr(rows), _lib.ptr(Wuv), _lib.ptr(UV), _lib.ptr(stack), n, F, st)
             z0, a0, a = new(n, F), new(n, F), new(n, 3 * F)
@@ -142,6 +151,7 @@ class _PseudoDecoderFn(torch.autograd.Function):
         gS = Slices(gS_out.contiguous() if gS_out is not None else None)
         gV = gV_out.contiguous() if gV_out is not None else None
         gSbar = gVbar = None
+        n_stage = staged_edges(plan)
         mark("backward:loss+tail")
         for l in range(n_layers - 1, -1, -1):
             pW1, pb1, pW2, pb2, pWd, pbd, pWu, pWv, pW0, pb0, pW1p, pb1p = flat[PER_LAYER * l: PER_LAYER * (l + 1)]
@@ -168,7 +178,7 @@ class _PseudoDecoderFn(torch.autograd.Function):
                       _lib.ptr(Wuv), _lib.ptr(gUV), _lib.ptr(g_s2), _lib.ptr(p3), fl48, n, F, st)
             # B4: message backward, rows of inv_dense.1
             g_phi = new(n, 9 * F)
-            g_s, g_sbar, g_v, g_vbar = new(n, F), new(n, F, 3), new(n, F, 3), new(n, F, 3)
+            g_s, g_sbar, g_v, g_vbar = new(n, F), new(n, F), new(n, F, 3), new(n, F, 3)
             tWd, accWd, _ = _grad_target(pWd, pWd)
             tbd, accbd, _ = _grad_target(pbd, pbd)
             if accWd or accbd:
@@ -179,7 +189,7 @@ class _PseudoDecoderFn(torch.autograd.Function):
                       _lib.ptr(plan.rowptr_s), _lib.ptr(plan.dst_s), _lib.ptr(pWd.detach()), _lib.ptr(pbd.detach()),
                       _lib.ptr(g_s2), _lib.ptr(gSbar), _lib.ptr(p3), nF, fl48, _lib.ptr(gV), _lib.ptr(gVbar), _lib.ptr(pW2.detach()),
                       _lib.ptr(g_phi), _lib.ptr(g_s), _lib.ptr(g_sbar), _lib.ptr(g_v), _lib.ptr(g_vbar), _lib.ptr(tWd), _lib.ptr(tbd),
-                      _lib.ptr(p4), fl16(F), n, F, R, plan.n_edges, st, tag=f"pseudo_msg_bwd:Nd{n}:E{plan.n_edges}:gv1")
+                      _lib.ptr(p4), fl16(F), n, F, R, n_stage, st, tag=f"pseudo_msg_bwd:Nd{n}:E{plan.n_edges}:gv1")
             # B5: inv_dense.0 (swish')
             g_a1 = new(n, F)
             p5 = new(nF * fl16(F))

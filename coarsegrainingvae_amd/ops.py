@@ -623,11 +623,13 @@ class _ReparamSample(torch.autograd.Function):
     def backward(ctx, g):
         (eps,) = ctx.saved_tensors
         slot, ctx.slot = ctx.slot, None
-        if slot is not None and slot.g_mu is not None and g.numel() % 4 == 0:
+        if slot is not None and slot.g_mu is not None:
             # the ELBO launch left its KL gradients of mu / sigma here instead of returning them to autograd: one launch
             # for g + k_mu and g * eps + k_sigma (the separate contributions cost a mul and two accumulation adds)
             g = _c(g)
             k_mu, k_sigma, slot.g_mu, slot.g_sigma = slot.g_mu, slot.g_sigma, None, None
+            if g.numel() % 4 or any(t.data_ptr() % 16 for t in (g, eps, k_mu, k_sigma)):
+                return g + k_mu, torch.addcmul(k_sigma, g, eps), None        # the kernel works on aligned quads: same sums, unfused
             g_mu, g_sigma = torch.empty_like(g), torch.empty_like(g)
             _lib.call("cgv_reparam_bwd", _lib.ptr(g), _lib.ptr(eps), _lib.ptr(k_mu), _lib.ptr(k_sigma), _lib.ptr(g_mu),
                       _lib.ptr(g_sigma), g.numel(), _lib.stream_ptr())
@@ -655,9 +657,24 @@ def _rng_block(device) -> torch.Tensor:
         device = torch.device("cuda", torch.cuda.current_device())
     t = _RNG.get(device)
     if t is None:
-        seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+        # derived from the seed of torch's default generator WITHOUT drawing from it (host-side consumers -- shuffling --
+        # keep their stream): splitmix64 of torch.initial_seed()
+        x = (int(torch.initial_seed()) + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+        x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        seed = (x ^ (x >> 31)) & ((1 << 62) - 1)
         t = _RNG[device] = torch.tensor([seed, 0, 0], dtype=torch.int64, device=device)
     return t
+
+
+def get_sample_rng_state(device) -> torch.Tensor:
+    """{seed, draw number, ticket} of ``reparam_sample``'s device generator as a host tensor -- NOT part of
+    ``torch.cuda.get_rng_state``: store it in checkpoints next to the optimiser state to resume with the same noise."""
+    return _rng_block(device).detach().cpu().clone()
+
+
+def set_sample_rng_state(device, state: torch.Tensor) -> None:
+    _rng_block(device).copy_(torch.as_tensor(state, dtype=torch.int64).reshape(3))
 
 
 def reparam_sample(mu, sigma):

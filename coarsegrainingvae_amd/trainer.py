@@ -107,7 +107,7 @@ class GradSync:
         if not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):      # captured collectives are graph nodes
             self.issued.append(work)
             if len(self.issued) > 4096:                           # long eager runs: completed handles need not be kept
-                self.issued = [w for w in self.issued[-1024:]]
+                self.issued = [w for w in self.issued if not w.is_completed()]
 
     def same_on_all_ranks(self, value: int) -> bool:
         t = torch.tensor([value, -value], dtype=torch.int64, device=self._device())
@@ -210,7 +210,9 @@ class OperandExchange:
     Protocol per backward bucket: ``submit`` packs the queued problems' operands into one send buffer (one launch)
     and starts the all-gather on the communication stream; ``complete`` (called at the next bucket boundary, i.e.
     after ~3 decoder layers of backward, and at the end) waits for the gathers and runs the gathered launches.
-    Needs equally shaped shards on every rank (checked once per buffer size)."""
+    Needs equally shaped shards on every rank: ``Trainer._check_shards`` compares them at the start of every eager
+    step and before a capture (never behind a per-rank cache -- a rank that skipped the comparison would leave the
+    others waiting in it)."""
 
     PACK = struct.Struct("<5Q5i4x")             # cgv::PackProblem, 64 bytes
 
@@ -221,7 +223,6 @@ class OperandExchange:
         self.inflight = []
         self.done_ranges = []                   # arena ranges whose global gradient this step came from gathered rows
         self._mode = {}                         # gW pointer -> "exchange" | "local" within the current step
-        self._checked = set()
         self.bytes_gathered = 0                 # per step, this rank's send bytes x world (for reporting)
 
     # -- which problems are exchanged
@@ -264,10 +265,6 @@ class OperandExchange:
             off_x = off_g + (M * N + 63) // 64 * 64
             total = off_x + (M * K + 63) // 64 * 64
             metas.append((M, N, K, off_g, off_x, gW, gb, bool(accumulate)))
-        if total not in self._checked and not torch.cuda.is_current_stream_capturing():
-            if not self.sync.same_on_all_ranks(total):
-                raise RuntimeError("operand exchange needs equally shaped shards on every rank")
-            self._checked.add(total)
         send = torch.empty(total, dtype=torch.float32, device=dev)
         recv = torch.empty(self.world * total, dtype=torch.float32, device=dev)
         buf, block_begin, nb = bytearray(), 0, C.c_int()
@@ -542,11 +539,14 @@ class Trainer:
         if warmup == 0:
             # nothing may be built lazily inside the capture (geometry records of this batch: H2D copies): one
             # forward without gradients, random stream restored, leaves the parameters and the sampling untouched
+            from .ops import _rng_block
             dev = self.arena.p.device
             rng = torch.cuda.get_rng_state(dev)
+            sample_rng = _rng_block(dev).clone()          # reparam_sample's own generator (not in torch's state)
             with torch.no_grad():
                 self.model(batch) if eps_buf is None else self.model(batch, eps=eps_buf)
             torch.cuda.set_rng_state(rng, dev)
+            _rng_block(dev).copy_(sample_rng)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -556,12 +556,9 @@ class Trainer:
         torch.cuda.synchronize()
         if self.sync is not None:
             if self.exchange is not None:
-                # the operand exchange all-gathers equally sized buffers; inside the capture nothing can be checked
-                # (OperandExchange.submit skips its test while capturing) and the eager step that built the arena ran
-                # without the exchange -- so compare the shard shapes (rows per layer derive from them) here, eagerly
-                sig = int(batch["nxyz"].shape[0]) * (1 << 24) + int(batch["CG_nxyz"].shape[0])
-                if not self.sync.same_on_all_ranks(sig):
-                    raise RuntimeError("operand exchange needs equally shaped shards on every rank")
+                # inside the capture nothing can be checked, and the eager step that built the arena ran without the
+                # exchange: compare the shard shapes here, eagerly
+                self._check_shards(batch)
             self.sync.drain()
         graph = torch.cuda.CUDAGraph()
         pending_at_start = self._pending              # a deferred update opens the captured step (or does not)
@@ -697,8 +694,19 @@ class Trainer:
                     cap["pre"] = (prefetch, 1 - slot, ev)
         return True
 
+    def _check_shards(self, batch):
+        """The operand exchange all-gathers equally sized buffers and decides per layer, from its rows, whether it is
+        exchanged at all: ranks holding differently shaped shards would issue different collectives and wait for each
+        other forever.  Every rank compares (atoms, beads) of its shard with the others' -- one tiny collective, issued
+        unconditionally by all ranks -- and all of them refuse together."""
+        sig = int(batch["nxyz"].shape[0]) * (1 << 24) + int(batch["CG_nxyz"].shape[0])
+        if not self.sync.same_on_all_ranks(sig):
+            raise RuntimeError("operand exchange needs equally shaped shards on every rank")
+
     # ------------------------------------------------------------------ one iteration
     def _step_eager(self, batch, eps: Optional[torch.Tensor] = None, train: bool = True):
+        if self.exchange is not None and train and self.sync is not None and not torch.cuda.is_current_stream_capturing():
+            self._check_shards(batch)
         # data parallel: ask the model to signal the end of the decoder's backward (hook registered in forward)
         if self._pending:
             self._apply_pending(overlap=True)               # the previous step's update, beside this step's encoder

@@ -343,8 +343,10 @@ int cgv_pseudo_msg_bwd_deferred(const float* phi, const float* s, const float* s
  * weight rows {g F + f} that feed them; grid = F / 4 blocks of 576 threads.
  * Slices (outputs of the backward phases; inputs of the next one): slice s = block s's row-split partial product,
  * QUAD-MAJOR [K/4][rows][4] floats (rows = n, or 3 n behind uv_bwd), cgv_decoder_slice_floats(K, rows) each;
- * n_slices = F/4 (N/4 for dense_bwd).  The message kernels stage the bead graph in LDS: at most cgv_decoder_max_edges()
- * directed edges.
+ * n_slices = F/4 (N/4 for dense_bwd).  The message kernels stage the bead graph in LDS: their `n_edges` argument is the
+ * number of edge RECORDS TO STAGE (1..cgv_decoder_max_edges(); the record / index arrays must hold that many) -- pass the
+ * arrays' capacity, not a batch's edge count: the edge structure itself is read from rowptr on the device, so the same
+ * launch (a captured graph node) serves batches with other edge counts; edges beyond the staged records are ignored.
  *   forward   msg_fwd   phi = a1 W2^T + b2 -> message -> stack[:, :F] = S', Sbar', V', Vbar', V' as rows [3n, F]
  *             uv_fwd    UV [3n, 2F] = rows [Wu; Wv]^T ; stack[:, F:] = sqrt(sum_xyz (Vv^2 + 1e-10))
  *             gate_fwd  a [n, 3F] = a0 W1'^T + b1' ; S'' = S' + (U.Vv) a_sv + a_ss ; V'' = V' + U a_vv

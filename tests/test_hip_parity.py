@@ -887,6 +887,52 @@ def test_captured_step_replays_on_other_batches():
         assert_close(p, q, "parameter after replayed steps", 1e-5)
 
 
+def test_captured_fused_decoder_replays_on_other_bead_edge_counts():
+    """The channel-group decoder kernels (csrc/decoder_layer.hip) stage the bead graph in LDS.  They stage the plan's
+    CAPACITY of records and take the edge structure from rowptr on the device, so a captured step replays on batches
+    whose BEAD graph has fewer or MORE edges than the captured batch's (a short cg_cutoff leaves it sparse and
+    different per frame).  Must equal an eager trainer fed the same sequence."""
+    from coarsegrainingvae_amd import decoder_fused
+    from coarsegrainingvae_amd.trainer import Trainer
+    n_atoms, n_cgs, F, R, atom_cut, cg_cut = 60, 10, 64, 8, 5.0, 1.5
+
+    def make(seed):
+        ds = cg.CGDataset(cg.data.synthetic_frames(1, n_atoms, n_cgs, 6.0, seed=seed))
+        ds.generate_neighbor_list(atom_cut, cg_cut, device=DEV, undirected=True)
+        return cg.CG_collate([ds[0]])
+
+    pool = [make(s) for s in range(1, 40)]
+    counts = [b["CG_nbr_list"].shape[0] for b in pool]
+    order = sorted(range(len(pool)), key=lambda k: counts[k])
+    first = pool[order[len(order) // 2]]                       # captured on a median batch ...
+    seqs = [pool[order[0]], pool[order[-1]], pool[order[len(order) // 3]], pool[order[-2]]]      # ... replayed on sparser and denser ones
+    n_first = first["CG_nbr_list"].shape[0]
+    assert min(b["CG_nbr_list"].shape[0] for b in seqs) < n_first < max(b["CG_nbr_list"].shape[0] for b in seqs)
+    assert min(counts) >= 1
+
+    def run(use_graph):
+        model = cg.build_model(F, R, atom_cut, cg_cut, 1, 2, n_cgs, det=True, seed=7).to(DEV)
+        tr = Trainer(model, lr=1e-3, beta=0.05, gamma=10.0)
+        cap = cg.data.prepare_batch({k: v.clone() for k, v in first.items()}, DEV, edge_slack=1.0)
+        losses = [float(tr.step(cap))]                        # builds the arena (per-block decoder path)
+        losses.append(float(tr.step(cap)))                    # fused decoder loop from here on
+        calls0 = decoder_fused.calls
+        if use_graph:
+            tr.capture(cap, warmup=0)
+        for b in seqs:
+            losses.append(float(tr.step({k: v.clone() for k, v in b.items()})))
+        assert decoder_fused.calls > calls0                   # the channel-group path did run
+        return losses, [p.detach().clone() for p in model.parameters()], tr
+
+    ref_losses, ref_params, _ = run(False)
+    losses, params, tr = run(True)
+    assert tr.replays == len(seqs)
+    for a, b in zip(losses, ref_losses):
+        assert abs(a - b) <= 1e-5 * abs(b), (losses, ref_losses)
+    for p, q in zip(params, ref_params):
+        assert_close(p, q, "parameter after replayed steps", 1e-5)
+
+
 # --------------------------------------------------------------------------- K7b / K2g: receiver groups, shared-source forward
 def _group_order_reference(dst_d, src_d, rb):
     """Restatement of the receiver-group order (include/cgvae_hip.h, K7b): positions of the dst-sorted view sorted,
@@ -1601,6 +1647,46 @@ def test_device_drawn_noise_path_equals_supplied_noise_path():
     assert g_dev.keys() == g_sup.keys() and len(g_dev) > 30
     for k in g_sup:
         assert rel_err(g_dev[k], g_sup[k]) <= 5e-5, k                   # z is one fma there, a rounded product + sum here
+
+
+@pytest.mark.parametrize("n,F", [(3, 30), (3, 32), (5, 6)])
+def test_kl_gradients_survive_the_reparametrisation_backward_at_any_size(n, F):
+    """``reparam_sample`` parks d(beta KL)/d{mu, sigma} of the ELBO launch for its own backward, which adds them in one
+    launch on aligned quads.  When n * F is not a multiple of 4 (F = 30, 3 beads) that launch cannot run: the parked
+    terms must still reach mu and sigma.  Against the same loss with the very same noise supplied (plain autograd)."""
+    from coarsegrainingvae_amd import ops
+    gen = torch.Generator().manual_seed(n * 100 + F)
+    mk = lambda *shape: torch.randn(*shape, generator=gen).to(DEV)
+    mu0, ls0, pmu0, pls0 = mk(n, F), mk(n, F), mk(n, F), mk(n, F)
+    n_atoms = 2 * n
+    proj, xyz = mk(F, 6), mk(n_atoms, 3)
+    bonds = torch.stack([torch.arange(n_atoms - 1), torch.arange(1, n_atoms)], dim=1).to(DEV)
+    rng = ops._rng_block(torch.device(DEV))
+    seed, draw = 99, 3
+    probe = torch.tensor([seed, draw, 0], dtype=torch.int64, device=DEV)
+    pad = (n * F + 3) // 4 * 4
+    zeros, ones = torch.zeros(pad, device=DEV), torch.ones(pad, device=DEV)
+    eps, z = torch.empty(pad, device=DEV), torch.empty(pad, device=DEV)
+    cg._lib.call("cgv_reparam_sample", cg._lib.ptr(zeros), cg._lib.ptr(ones), cg._lib.ptr(eps), cg._lib.ptr(z), n * F,
+                 cg._lib.ptr(probe), cg._lib.stream_ptr())
+    eps = eps[:n * F].view(n, F).clone()
+
+    def run(supplied):
+        leaves = [t.clone().requires_grad_(True) for t in (mu0, ls0, pmu0, pls0)]
+        mu, pmu = leaves[0] * 1.0, leaves[2] * 1.0
+        sigma, pstd = torch.exp(leaves[1] / 2), torch.exp(leaves[3] / 2)
+        rng.copy_(torch.tensor([seed, draw, 0], dtype=torch.int64))
+        zs = torch.addcmul(mu, eps, sigma) if supplied else ops.reparam_sample(mu, sigma)
+        recon = (zs @ proj).reshape(n_atoms, 3)
+        loss, _terms = ops.elbo_loss(mu, sigma, pmu, pstd, xyz, recon, bonds, 0.7, 3.0)
+        loss.backward()
+        return float(loss), [t.grad.clone() for t in leaves]
+
+    l_dev, g_dev = run(False)
+    l_sup, g_sup = run(True)
+    assert abs(l_dev - l_sup) <= 1e-6 * abs(l_sup)
+    for a, b, name in zip(g_dev, g_sup, ("mu", "log var", "prior mu", "prior log var")):
+        assert rel_err(a, b) <= 1e-5, (name, rel_err(a, b))
 
 
 @pytest.mark.parametrize("n,F,R,full,drop", [(40, 100, 10, False, None), (150, 64, 8, True, None), (24, 600, 10, True, "scalars"),
