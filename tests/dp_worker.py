@@ -94,7 +94,8 @@ def main():
         rec["loss"].append(float(tr.last_loss))
         kl, recon, graph = tr.last_terms
         rec["kl"].append(float(kl)); rec["recon_term"].append(float(recon)); rec["graph"].append(float(graph))
-        rec["norm"].append(float(st[ST_NORM])); rec["coef"].append(float(st[ST_CLIP]))
+        # state[ST_CLIP] is the factor applied to the SUMMED gradient: clip coefficient x 1 / world (csrc/optim.hip)
+        rec["norm"].append(float(st[ST_NORM])); rec["coef"].append(float(st[ST_CLIP]) * world)
         rec["recon"].append(tr.last_out[5].detach().clone())
 
     t0 = time.time()

@@ -107,18 +107,22 @@ def test_wire_collectives_inside_a_captured_graph_single_rank():
             x.mul_(1.0)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        n0 = sync.collectives()
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        def body():
             x.add_(1.0)
             sync.all_reduce_range(x, 0, x.numel())
             sync.all_gather(y, x)
             y.mul_(2.0)
+        body()                                              # eagerly once: the pinned staging of these sizes exists now
+        torch.cuda.synchronize()
+        n0 = sync.collectives()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            body()
         assert sync.collectives() == n0                     # captured, not run
         for k in range(3):
             g.replay()
         torch.cuda.synchronize()
         assert sync.collectives() == n0 + 6
-        assert torch.equal(y, 2.0 * (torch.arange(100000, dtype=torch.float32, device="cuda") + 3.0))
+        assert torch.equal(y, 2.0 * (torch.arange(100000, dtype=torch.float32, device="cuda") + 4.0))
         assert sync.same_on_all_ranks(123456789012345)
         sync.close()
     finally:

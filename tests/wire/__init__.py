@@ -86,6 +86,9 @@ class ShmSync:
         key = (role, n)
         buf = self._host.get(key)
         if buf is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("a collective of a new size inside a capture: run the step eagerly once first "
+                                   "(pinned staging cannot be allocated while capturing)")
             buf = torch.empty(max(n, 1), dtype=torch.float32).pin_memory()
             self._host[key] = buf
         return buf
