@@ -328,7 +328,7 @@ class _LinearFn(torch.autograd.Function):
                 # few rows: 4-column blocks (N / 4 of them pull the weight) beat the skinny kernel's 16-column blocks
                 # (decoder forward 356 -> 343 us on chignolin: csrc/decoder_layer.hip, dec_dense_fwd_k)
                 _lib.call("cgv_decoder_dense_fwd", _lib.ptr(x2), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(y), _lib.ptr(z),
-                          M, N, K, act, _lib.stream_ptr())
+                          M, N, K, act, None, _lib.stream_ptr())
             else:
                 # 65 - 128 rows (a big bead batch) and at most 1200 outputs: the weight-streaming kernel with one 16-row block
                 # per thread block still beats the tiles (96 rows: 600 x 600 4.8 against 6.7 us, 600 x 1200 6.3 / 10.5,

@@ -4,7 +4,8 @@ import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import coarsegrainingvae_amd as cg
-from coarsegrainingvae_amd import _lib
+from coarsegrainingvae_amd import _lib, options
+options.pop_cli(sys.argv[1:])
 from coarsegrainingvae_amd.trainer import Trainer
 w = cg.data.WORKLOADS["chignolin"]
 batch = cg.synthetic_batch("chignolin", seed=0, device="cuda")

@@ -17,7 +17,12 @@ lo, hi = [sg for sg in segs if sg[1] - sg[0] == mode][-1]
 t0 = int(rows[lo]["Start_Timestamp"]); prev_end = t0
 for r in rows[lo:hi]:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    print(f"{(s - t0) / 1e3:9.1f} gap {(s - prev_end) / 1e3:6.2f} dur {(e - s) / 1e3:7.2f} grid={int(r['Grid_Size_X'])//max(int(r['Workgroup_Size_X']),1):>6}x{r['Workgroup_Size_X']:>4} {r['Kernel_Name'][:100]}")
+    # blocks = the whole grid (x * y * z workgroups), then threads per block
+    blocks = 1
+    for ax in "XYZ":
+        blocks *= max(int(r.get(f'Grid_Size_{ax}', 1) or 1) // max(int(r.get(f'Workgroup_Size_{ax}', 1) or 1), 1), 1)
+    threads = int(r['Workgroup_Size_X']) * max(int(r.get('Workgroup_Size_Y', 1) or 1), 1) * max(int(r.get('Workgroup_Size_Z', 1) or 1), 1)
+    print(f"{(s - t0) / 1e3:9.1f} gap {(s - prev_end) / 1e3:6.2f} dur {(e - s) / 1e3:7.2f} blocks={blocks:>6} x{threads:>4} {r['Kernel_Name'][:100]}")
     prev_end = e
 print(f"# {hi - lo} launches, span {(int(rows[hi-1]['End_Timestamp']) - t0) / 1e3:.1f} us")
 PY
