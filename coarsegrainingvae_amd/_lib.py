@@ -100,14 +100,14 @@ PROTOTYPES = {
     "cgv_decoder_max_edges": (_i, []),
     "cgv_decoder_block_channels": (_i, [_i]),
     "cgv_decoder_debug_clock": (_i, [_p]),
-    "cgv_decoder_msg_fwd": (_i, [_p] * 18 + [_i, _i, _i, _i, _p, _p]),
-    "cgv_decoder_dense_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
-    "cgv_decoder_uv_fwd": (_i, [_p, _p, _p, _p, _i, _i, _p, _p]),
-    "cgv_decoder_gate_fwd": (_i, [_p] * 9 + [_i, _i, _p, _p]),
-    "cgv_decoder_gate_bwd": (_i, [_p, _p, _p, _p, _i, C.c_int64, _p, _p, _p, _p, _p, _p, C.c_int64, _i, _i, _p, _p]),
-    "cgv_decoder_dense_bwd": (_i, [_p, _i, C.c_int64, _p, _i, _p, _p, _p, C.c_int64, _i, _i, _i, _p, _p]),
-    "cgv_decoder_uv_bwd": (_i, [_p, _i, C.c_int64, _p, _p, _p, _p, _p, _p, _p, C.c_int64, _i, _i, _p, _p]),
-    "cgv_decoder_msg_bwd": (_i, [_p] * 15 + [_p, _i, C.c_int64, _p, _p, _p] + [_p] * 8 + [C.c_int64, _i, _i, _i, _i, _p, _p]),
+    "cgv_decoder_msg_fwd": (_i, [_p] * 18 + [_i, _i, _i, _i, _p]),
+    "cgv_decoder_dense_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "cgv_decoder_uv_fwd": (_i, [_p, _p, _p, _p, _i, _i, _p]),
+    "cgv_decoder_gate_fwd": (_i, [_p] * 9 + [_i, _i, _p]),
+    "cgv_decoder_gate_bwd": (_i, [_p, _p, _p, _p, _i, C.c_int64, _p, _p, _p, _p, _p, _p, C.c_int64, _i, _i, _p]),
+    "cgv_decoder_dense_bwd": (_i, [_p, _i, C.c_int64, _p, _i, _p, _p, _p, C.c_int64, _i, _i, _i, _p]),
+    "cgv_decoder_uv_bwd": (_i, [_p, _i, C.c_int64, _p, _p, _p, _p, _p, _p, _p, C.c_int64, _i, _i, _p]),
+    "cgv_decoder_msg_bwd": (_i, [_p] * 15 + [_p, _i, C.c_int64, _p, _p, _p] + [_p] * 8 + [C.c_int64, _i, _i, _i, _i, _p]),
     "cgv_decoder_slices_to_dense": (_i, [_p, _p, _i, C.c_int64, _p, _i, _i, _p]),
     "cgv_dense_grad_prepare": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "cgv_tile_supported": (_i, [_i, _i, _i]),
@@ -153,31 +153,7 @@ PROTOTYPES = {
 
 # include/cgvae_hip.h: CGV_OPT_* (A/B switches of the launchers; defaults in csrc/api.cpp)
 OPTIONS = {"msg_fwd_split": 0, "msg_bwd_split": 1, "msg_fwd_kernel": 2, "grp_waves": 3, "grp_records": 4, "csr_build": 5,
-           "pseudo_chunks": 6, "wgrad_tiling": 7, "tile_fwd_lds_min": 8, "bwd_input_waves": 9, "pseudo_fwd": 10, "decoder_fat": 11, "decoder_wlds": 12, "skinny_rows": 13, "decoder_touch": 14}
-
-
-class TouchJob(C.Structure):
-    """cgv_touch_job (include/cgvae_hip.h)."""
-    _fields_ = [("W", C.c_void_p), ("K", C.c_int32), ("n_groups", C.c_int32), ("group_stride", C.c_int32), ("rows", C.c_int32),
-                ("blocks", C.c_int32), ("part", C.c_int32), ("parts", C.c_int32)]
-
-
-class Touch(C.Structure):
-    """cgv_touch: up to two L2-prefetch jobs carried by a decoder launch's extra blocks."""
-    _fields_ = [("n", C.c_int32), ("job", TouchJob * 2)]
-
-
-def touch(*jobs):
-    """Address of a ``cgv_touch`` holding ``jobs`` -- tuples (W tensor, K, n_groups, group_stride, rows, blocks, part, parts) --
-    and the struct itself (keep it alive across the call); (None, None) for no jobs."""
-    jobs = [j for j in jobs if j is not None]
-    if not jobs:
-        return None, None
-    t = Touch()
-    t.n = len(jobs)
-    for k, (W, K, n_groups, group_stride, rows, blocks, part, parts) in enumerate(jobs):
-        t.job[k] = TouchJob(W.data_ptr(), K, n_groups, group_stride, rows, blocks, part, parts)
-    return C.addressof(t), t
+           "pseudo_chunks": 6, "wgrad_tiling": 7, "tile_fwd_lds_min": 8, "bwd_input_waves": 9, "pseudo_fwd": 10, "decoder_fat": 11, "decoder_wlds": 12, "skinny_rows": 13}
 
 
 def set_option(name: str, value: int) -> None:

@@ -29,7 +29,6 @@
 // Geometry: 576 threads = 9 waves; in the message kernels wave k owns filter k and lane = node * 4 + channel (so at most
 // 16 nodes: this path serves small bead graphs -- chignolin: 12 beads; larger ones keep the per-block kernels).
 // Products use v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains) with the operand maps of skinny_gemm.hip.
-#include <string.h>
 #include "cgv_common.h"
 
 namespace cgv {
@@ -47,7 +46,7 @@ __constant__ unsigned long long* g_dl_clock = nullptr;
   do {                                                                                                      \
     if (g_dl_clock && threadIdx.x == 0) {                                                                   \
       if (blockIdx.x == 0) g_dl_clock[32 + 4 * (id) + (end)] = wall_clock64();                              \
-      if ((int)blockIdx.x == dl_main - 1) g_dl_clock[32 + 4 * (id) + 2 + (end)] = wall_clock64();            \
+      if (blockIdx.x == gridDim.x - 1) g_dl_clock[32 + 4 * (id) + 2 + (end)] = wall_clock64();              \
     }                                                                                                       \
   } while (0)
 
@@ -84,64 +83,6 @@ struct Carve {
     return p;
   }
 };
-
-// ---------------------------------------------------------------------------------------------- L2 prefetch blocks
-// The grids of this file leave 40 % of the chip idle (F / 4 = 150 blocks at F = 600 on 256 CUs) and every kernel opens
-// with a cold stream of its weight rows: 17 GB/s per CU from HBM, twice that from the XCD's L2
-// (tools/probes/warm_probe.hip: the message product's 13 MB in 2.1 us L2-warm, 3.5 us Infinity-Cache-warm, 4.1 us cold).
-// So a launch may carry EXTRA blocks (blockIdx.x >= main) that do nothing but touch -- one dword per 128-byte line --
-// the weight rows a LATER launch of the chain will stream, on the XCD whose block will stream them: workgroups go round
-// robin over the 8 XCDs (block b -> XCD b % 8; each XCD has its own L2), consumer block c therefore runs on XCD c % 8, and
-// the touch blocks of XCD x split the consumer blocks of XCD x between them.  Pure prefetch: nothing is computed or stored.
-struct TouchJob {
-  const float* W;          // [rows, K] weight matrix
-  int K;                   // floats per row
-  int n_groups;            // row groups per consumer block
-  int group_stride;        // rows between consecutive groups of one consumer block
-  int rows;                // consecutive rows per group
-  int blocks;              // consumer blocks: block c streams rows g * group_stride + rows * c .. + rows - 1, g < n_groups
-  int part, parts;         // this launch touches the consumer blocks whose index within their XCD is = part mod parts
-};
-struct Touch {
-  int n;
-  TouchJob job[2];
-};
-constexpr int DL_CUS = 256;                                               // MI355X
-
-__device__ __forceinline__ void touch_block(const Touch& t, int main) {
-  const int extra = (int)gridDim.x - main, tb = (int)blockIdx.x - main;
-  const int x = blockIdx.x & 7;
-  const int first = (x - (main & 7) + 8) & 7;                             // first touch block on this XCD
-  if (first >= extra) return;
-  const int n_x = (extra - first + 7) >> 3, r = (tb - first) >> 3;        // touch blocks on this XCD, my rank among them
-  float acc = 0.f;
-  for (int j = 0; j < t.n; ++j) {
-    const TouchJob& job = t.job[j];
-    const int cons_x = (job.blocks - x + 7) >> 3;                         // consumer blocks on this XCD: c = x + 8 ci
-    const long long group_bytes = (long long)job.rows * job.K * 4;
-    const int lines = (int)((group_bytes + 127) >> 7) + 1;               // per group, incl. a straddled first line
-    const int per_cons = job.n_groups * lines;
-    for (int ci = job.part + job.parts * r; ci < cons_x; ci += job.parts * n_x) {
-      const int c = x + 8 * ci;
-      // every lane's requests of a consumer block in flight together: straight-line, unconditional (clamped) loads
-      for (int i0 = threadIdx.x; i0 < per_cons; i0 += 4 * DL_THREADS) {
-        float v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int id = min(i0 + u * DL_THREADS, per_cons - 1), g = id / lines, l = id - g * lines;
-          const char* b0 = reinterpret_cast<const char*>(job.W + ((size_t)g * job.group_stride + (size_t)job.rows * c) * job.K);
-          const char* lo = reinterpret_cast<const char*>(reinterpret_cast<unsigned long long>(b0) & ~127ull);
-          const char* at = lo + ((size_t)l << 7);
-          const char* last = b0 + group_bytes - 4;
-          v[u] = *reinterpret_cast<const float*>(at < b0 ? b0 : (at > last ? last : at));
-        }
-        acc += (v[0] + v[1]) + (v[2] + v[3]);
-      }
-    }
-  }
-  asm volatile("" ::"v"(acc));                                            // the loads are the point; their sum goes nowhere
-}
-#define DL_TOUCH_BLOCKS(t, main) do { if ((int)blockIdx.x >= (main)) { touch_block((t), (main)); return; } } while (0)
 
 // ---------------------------------------------------------------------------------------------- pinned requests
 // A prefetch must stay where it is written.  The operands are __restrict__ const data, so the compiler is free to sink
@@ -592,8 +533,7 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_fwd_k(
     const float* __restrict__ geom_, const int* __restrict__ rowptr_, const int* __restrict__ src_,
     const float* __restrict__ Wd_, const float* __restrict__ bd_, float* __restrict__ phi_out, float* __restrict__ stack,
     float* __restrict__ sbar_out, float* __restrict__ v_out, float* __restrict__ vbar_out, float* __restrict__ rows_out,
-    int n, int F, int E, Touch touch, int dl_main) {
-  DL_TOUCH_BLOCKS(touch, dl_main);
+    int n, int F, int E) {
   constexpr int GS = geom_stride(R), U = geom_unit_offset(R);
   Carve cv;
   float* red = cv.take(fwd_red_floats<1, 9>());
@@ -708,9 +648,7 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_fwd_k(
 // weight instead of the 38 of skinny_fwd_k's 16-column blocks).
 __global__ __launch_bounds__(DL_THREADS) void dec_dense_fwd_k(const float* __restrict__ x, const float* __restrict__ W,
                                                               const float* __restrict__ bias_, float* __restrict__ y,
-                                                              float* __restrict__ zout, int n, int N, int K, int act, Touch touch,
-                                                              int dl_main) {
-  DL_TOUCH_BLOCKS(touch, dl_main);
+                                                              float* __restrict__ zout, int n, int N, int K, int act) {
   Carve cv;
   float* red = cv.take(fwd_red_floats<1, 1>());
   float* o_l = cv.take(16 * 4);
@@ -770,9 +708,7 @@ __global__ __launch_bounds__(DL_THREADS) void dec_dense_fwd_pair_k(DensePair p, 
 
 // ============================================================================================== F3: [U | Vv] + norm
 __global__ __launch_bounds__(DL_THREADS) void dec_uv_fwd_k(const float* __restrict__ rows, const float* __restrict__ Wuv,
-                                                           float* __restrict__ UV, float* __restrict__ stack, int n, int F,
-                                                           Touch touch, int dl_main) {
-  DL_TOUCH_BLOCKS(touch, dl_main);
+                                                           float* __restrict__ UV, float* __restrict__ stack, int n, int F) {
   Carve cv;
   float* red = cv.take(fwd_red_floats<3, 2>());
   float* uv_l = cv.take(48 * 2 * 4);
@@ -797,8 +733,7 @@ __global__ __launch_bounds__(DL_THREADS) void dec_gate_fwd_k(const float* __rest
                                                              const float* __restrict__ b1p_, const float* __restrict__ UV_,
                                                              const float* __restrict__ stack_, const float* __restrict__ v2_,
                                                              float* __restrict__ a_out, float* __restrict__ s3,
-                                                             float* __restrict__ v3, int n, int F, Touch touch, int dl_main) {
-  DL_TOUCH_BLOCKS(touch, dl_main);
+                                                             float* __restrict__ v3, int n, int F) {
   Carve cv;
   float* red = cv.take(fwd_red_floats<1, 3>());
   float* a_l = cv.take(16 * 3 * 4);
@@ -842,9 +777,8 @@ __global__ __launch_bounds__(DL_THREADS) void dec_gate_bwd_k(
     const float* __restrict__ UV_, const float* __restrict__ a_, const float* __restrict__ gs_base_,
     const float* __restrict__ gs_slices_, int gs_n, long long gs_stride, const float* __restrict__ gv_,
     const float* __restrict__ W1p_, float* __restrict__ ga, float* __restrict__ gUV, float* __restrict__ gs_sum,
-    float* __restrict__ slices_out, long long out_stride, int n, int F, Touch touch, int dl_main) {
+    float* __restrict__ slices_out, long long out_stride, int n, int F) {
   constexpr int C = 4 * CBQ, G = 3 * CBQ;
-  DL_TOUCH_BLOCKS(touch, dl_main);
   Carve cv;
   float* stage = cv.take(bi_stage_floats<1>());
   float4* scratch = reinterpret_cast<float4*>(cv.take(CBQ * 36 * 16 * 4));
@@ -905,10 +839,8 @@ template <int NT, int CBQ, int QS>
 __global__ __launch_bounds__(DL_THREADS) void dec_dense_bwd_k(const float* __restrict__ g_slices_, int g_n, long long g_stride,
                                                               const float* __restrict__ z_, int act, const float* __restrict__ W_,
                                                               float* __restrict__ g_dense, float* __restrict__ slices_out,
-                                                              long long out_stride, int n, int N, int K, Touch touch,
-                                                              int dl_main) {
+                                                              long long out_stride, int n, int N, int K) {
   constexpr int C = 4 * CBQ;
-  DL_TOUCH_BLOCKS(touch, dl_main);
   Carve cv;
   float* stage = cv.take(bi_stage_floats<1>());
   float4* scratch = reinterpret_cast<float4*>(cv.take(CBQ * 36 * 16 * 4));
@@ -951,10 +883,8 @@ __global__ __launch_bounds__(DL_THREADS) void dec_uv_bwd_k(const float* __restri
                                                            const float* __restrict__ UV_, const float* __restrict__ stack_,
                                                            const float* __restrict__ gs_res_, const float* __restrict__ Wuv_,
                                                            float* __restrict__ gUV, float* __restrict__ g_s2,
-                                                           float* __restrict__ slices_out, long long out_stride, int n, int F,
-                                                           Touch touch, int dl_main) {
+                                                           float* __restrict__ slices_out, long long out_stride, int n, int F) {
   constexpr int C = 4 * CBQ, G = 2 * CBQ;
-  DL_TOUCH_BLOCKS(touch, dl_main);
   Carve cv;
   float* stage = cv.take(bi_stage_floats<3>());
   float4* scratch = reinterpret_cast<float4*>(cv.take(G * 36 * 16 * 4));
@@ -1020,9 +950,8 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_bwd_k(
     long long gvr_stride, const float* __restrict__ gv_res_, const float* __restrict__ gvb_, const float* __restrict__ W2_,
     float* __restrict__ g_phi, float* __restrict__ g_s, float* __restrict__ g_sbar, float* __restrict__ g_v,
     float* __restrict__ g_vbar, float* __restrict__ gWd, float* __restrict__ gbd, float* __restrict__ slices_out,
-    long long out_stride, int n, int F, int E, Touch touch, int dl_main) {
+    long long out_stride, int n, int F, int E) {
   constexpr int GS = geom_stride(R), U = geom_unit_offset(R);
-  DL_TOUCH_BLOCKS(touch, dl_main);
   Carve cv;
   float* stage = cv.take(bi_stage_floats<1>());
   float4* scratch = reinterpret_cast<float4*>(stage);                    // the slice sum is over before the product stages its tiles
@@ -1266,25 +1195,6 @@ static int allow_lds(Kern kern, size_t bytes) {
   if (e != hipSuccess) { cgv::set_error("hipFuncSetAttribute(%zu bytes of LDS): %s", bytes, hipGetErrorString(e)); return (int)e; }
   return 0;
 }
-// Touch blocks of a launch (see "L2 prefetch blocks"): the caller's jobs, validated, and how many extra blocks carry them.
-static_assert(sizeof(Touch) == sizeof(cgv_touch) && sizeof(TouchJob) == sizeof(cgv_touch_job), "cgv_touch mirrors cgv::Touch");
-static int make_touch(const cgv_touch* t, int main_blocks, Touch* out, int* extra) {
-  memset(out, 0, sizeof(*out));
-  *extra = 0;
-  if (!t || t->n == 0 || option(CGV_OPT_DECODER_TOUCH) == 0 || main_blocks + 8 > DL_CUS) return 0;
-  if (t->n < 0 || t->n > 2) { set_error("cgv_touch: 0..2 jobs"); return CGV_E_BADARG; }
-  memcpy(out, t, sizeof(*out));
-  for (int j = 0; j < out->n; ++j) {
-    const TouchJob& job = out->job[j];
-    if (!job.W || job.K < 1 || job.n_groups < 1 || job.rows < 1 || job.blocks < 1 || job.group_stride < 0 || job.parts < 1 ||
-        job.part < 0 || job.part >= job.parts) {
-      set_error("cgv_touch: bad job %d", j);
-      return CGV_E_BADARG;
-    }
-  }
-  *extra = DL_CUS - main_blocks;          // one block per CU at most: the touch blocks take the CUs the launch leaves idle
-  return 0;
-}
 }  // namespace cgv
 
 extern "C" {
@@ -1325,8 +1235,7 @@ int64_t cgv_decoder_slice_floats(int K, int rows) { return (int64_t)K * rows; }
 int cgv_decoder_msg_fwd(const float* a1, const float* W2, const float* b2, const float* s, const float* sbar, const float* v,
                         const float* vbar, const float* geom_d, const int32_t* rowptr_d, const int32_t* src_d, const float* Wd,
                         const float* bd, float* phi, float* stack, float* sbar_out, float* v_out, float* vbar_out,
-                        float* rows_out, int n_nodes, int n_feat, int n_rbf, int n_edges, const cgv_touch* touch,
-                        void* stream) {
+                        float* rows_out, int n_nodes, int n_feat, int n_rbf, int n_edges, void* stream) {
   CGV_REQUIRE(a1 && W2 && b2 && s && sbar && v && vbar && geom_d && rowptr_d && src_d && Wd && bd, "null input");
   CGV_REQUIRE(phi && stack && sbar_out && v_out && vbar_out && rows_out, "null output");
   CGV_REQUIRE(n_edges >= 1 && n_edges <= cgv::DL_MAX_EDGES, "the staged bead graph holds 1..cgv_decoder_max_edges() edges");
@@ -1336,34 +1245,27 @@ int cgv_decoder_msg_fwd(const float* a1, const float* W2, const float* b2, const
   /* the block's 36 weight rows by LDS-DMA when they fit beside the rest (F <= 672 at n_rbf = 10) */
   const bool wlds = cgv::option(CGV_OPT_DECODER_WLDS) != 0 && cgv::lds_bytes(base_floats + (size_t)36 * n_feat) <= 160 * 1024;
   const size_t lds = cgv::lds_bytes(base_floats + (wlds ? (size_t)36 * n_feat : 0));
-  cgv::Touch tj; int extra;
-  if (int rc = cgv::make_touch(touch, blocks, &tj, &extra)) return rc;
   CGV_DISPATCH_RBF(n_rbf, {
     if (wlds) {
       if (int rc = cgv::allow_lds(cgv::dec_msg_fwd_k<RBF, true>, lds)) return rc;
-      hipLaunchKernelGGL((cgv::dec_msg_fwd_k<RBF, true>), dim3(blocks + extra), dim3(cgv::DL_THREADS), lds, st, a1, W2, b2, s, sbar, v, vbar,
-                         geom_d, rowptr_d, src_d, Wd, bd, phi, stack, sbar_out, v_out, vbar_out, rows_out, n_nodes, n_feat, n_edges,
-                         tj, blocks);
+      hipLaunchKernelGGL((cgv::dec_msg_fwd_k<RBF, true>), dim3(blocks), dim3(cgv::DL_THREADS), lds, st, a1, W2, b2, s, sbar, v, vbar,
+                         geom_d, rowptr_d, src_d, Wd, bd, phi, stack, sbar_out, v_out, vbar_out, rows_out, n_nodes, n_feat, n_edges);
     } else {
       if (int rc = cgv::allow_lds(cgv::dec_msg_fwd_k<RBF, false>, lds)) return rc;
-      hipLaunchKernelGGL((cgv::dec_msg_fwd_k<RBF, false>), dim3(blocks + extra), dim3(cgv::DL_THREADS), lds, st, a1, W2, b2, s, sbar, v, vbar,
-                         geom_d, rowptr_d, src_d, Wd, bd, phi, stack, sbar_out, v_out, vbar_out, rows_out, n_nodes, n_feat, n_edges,
-                         tj, blocks);
+      hipLaunchKernelGGL((cgv::dec_msg_fwd_k<RBF, false>), dim3(blocks), dim3(cgv::DL_THREADS), lds, st, a1, W2, b2, s, sbar, v, vbar,
+                         geom_d, rowptr_d, src_d, Wd, bd, phi, stack, sbar_out, v_out, vbar_out, rows_out, n_nodes, n_feat, n_edges);
     }
   });
   return cgv::check_launch("cgv_decoder_msg_fwd");
 }
 
 int cgv_decoder_dense_fwd(const float* x, const float* W, const float* bias, float* y, float* z, int n_nodes, int N, int K,
-                          int act, const cgv_touch* touch, void* stream) {
+                          int act, void* stream) {
   CGV_REQUIRE(x && W && y, "null pointer");
   CGV_REQUIRE(act >= 0 && act <= cgv::CGV_ACT_MAX, "unknown activation");
   CGV_REQUIRE(n_nodes >= 1 && n_nodes <= cgv::DL_MAX_NODES && (N % 4) == 0 && (K % 4) == 0 && N >= 4 && K >= 4, "unsupported shape");
-  cgv::Touch tj; int extra;
-  if (int rc = cgv::make_touch(touch, N / cgv::DL_CB, &tj, &extra)) return rc;
-  hipLaunchKernelGGL(cgv::dec_dense_fwd_k, dim3(N / cgv::DL_CB + extra), dim3(cgv::DL_THREADS),
-                     cgv::lds_bytes(cgv::fwd_red_floats<1, 1>() + 64), (hipStream_t)stream, x, W, bias, y, z, n_nodes, N, K, act, tj,
-                     N / cgv::DL_CB);
+  hipLaunchKernelGGL(cgv::dec_dense_fwd_k, dim3(N / cgv::DL_CB), dim3(cgv::DL_THREADS), cgv::lds_bytes(cgv::fwd_red_floats<1, 1>() + 64),
+                     (hipStream_t)stream, x, W, bias, y, z, n_nodes, N, K, act);
   return cgv::check_launch("cgv_decoder_dense_fwd");
 }
 
@@ -1379,61 +1281,50 @@ int cgv_pair_linear_fwd(const float* x0, const float* x1, const float* W0, const
   return cgv::check_launch("cgv_pair_linear_fwd");
 }
 
-int cgv_decoder_uv_fwd(const float* rows, const float* Wuv, float* UV, float* stack, int n_nodes, int n_feat,
-                       const cgv_touch* touch, void* stream) {
+int cgv_decoder_uv_fwd(const float* rows, const float* Wuv, float* UV, float* stack, int n_nodes, int n_feat, void* stream) {
   CGV_REQUIRE(rows && Wuv && UV && stack, "null pointer");
   const int n_rbf = 8;
   CGV_DL_CHECK();
-  cgv::Touch tj; int extra;
-  if (int rc = cgv::make_touch(touch, blocks, &tj, &extra)) return rc;
-  hipLaunchKernelGGL(cgv::dec_uv_fwd_k, dim3(blocks + extra), dim3(cgv::DL_THREADS), cgv::lds_bytes(cgv::fwd_red_floats<3, 2>() + 384),
-                     st, rows, Wuv, UV, stack, n_nodes, n_feat, tj, blocks);
+  hipLaunchKernelGGL(cgv::dec_uv_fwd_k, dim3(blocks), dim3(cgv::DL_THREADS), cgv::lds_bytes(cgv::fwd_red_floats<3, 2>() + 384), st, rows,
+                     Wuv, UV, stack, n_nodes, n_feat);
   return cgv::check_launch("cgv_decoder_uv_fwd");
 }
 
 int cgv_decoder_gate_fwd(const float* a0, const float* W1p, const float* b1p, const float* UV, const float* stack,
-                         const float* v2, float* a, float* s3, float* v3, int n_nodes, int n_feat, const cgv_touch* touch,
-                         void* stream) {
+                         const float* v2, float* a, float* s3, float* v3, int n_nodes, int n_feat, void* stream) {
   CGV_REQUIRE(a0 && W1p && b1p && UV && stack && v2 && a && s3 && v3, "null pointer");
   const int n_rbf = 8;
   CGV_DL_CHECK();
-  cgv::Touch tj; int extra;
-  if (int rc = cgv::make_touch(touch, blocks, &tj, &extra)) return rc;
-  hipLaunchKernelGGL(cgv::dec_gate_fwd_k, dim3(blocks + extra), dim3(cgv::DL_THREADS), cgv::lds_bytes(cgv::fwd_red_floats<1, 3>() + 192),
-                     st, a0, W1p, b1p, UV, stack, v2, a, s3, v3, n_nodes, n_feat, tj, blocks);
+  hipLaunchKernelGGL(cgv::dec_gate_fwd_k, dim3(blocks), dim3(cgv::DL_THREADS), cgv::lds_bytes(cgv::fwd_red_floats<1, 3>() + 192), st, a0,
+                     W1p, b1p, UV, stack, v2, a, s3, v3, n_nodes, n_feat);
   return cgv::check_launch("cgv_decoder_gate_fwd");
 }
 
 int cgv_decoder_gate_bwd(const float* UV, const float* a, const float* gs_base, const float* gs_slices, int gs_n_slices,
                          int64_t gs_slice_stride, const float* gv, const float* W1p, float* ga, float* gUV, float* gs_sum,
-                         float* slices_out, int64_t out_slice_stride, int n_nodes, int n_feat, const cgv_touch* touch,
-                         void* stream) {
+                         float* slices_out, int64_t out_slice_stride, int n_nodes, int n_feat, void* stream) {
   CGV_REQUIRE(UV && a && W1p && ga && gUV && gs_sum && slices_out, "null pointer");
   CGV_REQUIRE(gs_n_slices >= 0 && gs_n_slices <= 216 && out_slice_stride >= cgv_decoder_slice_floats(n_feat, n_nodes), "bad slices");
   const int n_rbf = 8;
   CGV_DL_CHECK();
   (void)blocks;
-  const int mainb = cgv_decoder_block_channels(n_feat) == 8 ? n_feat / 8 : n_feat / 4;
-  cgv::Touch tj; int extra;
-  if (int rc = cgv::make_touch(touch, mainb, &tj, &extra)) return rc;
   CGV_DL_QS(gs_n_slices, {
     if (cgv_decoder_block_channels(n_feat) == 8)
-      hipLaunchKernelGGL((cgv::dec_gate_bwd_k<2, QS>), dim3(mainb + extra), dim3(cgv::DL_THREADS),
+      hipLaunchKernelGGL((cgv::dec_gate_bwd_k<2, QS>), dim3(n_feat / 8), dim3(cgv::DL_THREADS),
                          cgv::lds_bytes(cgv::bi_stage_floats<1>() + 2 * 2304 + 2 * 64 + 384), st, UV, a, gs_base, gs_slices,
                          gs_n_slices, (long long)gs_slice_stride, gv, W1p, ga, gUV, gs_sum, slices_out,
-                         (long long)out_slice_stride, n_nodes, n_feat, tj, mainb);
+                         (long long)out_slice_stride, n_nodes, n_feat);
     else
-      hipLaunchKernelGGL((cgv::dec_gate_bwd_k<1, QS>), dim3(mainb + extra), dim3(cgv::DL_THREADS),
+      hipLaunchKernelGGL((cgv::dec_gate_bwd_k<1, QS>), dim3(n_feat / 4), dim3(cgv::DL_THREADS),
                          cgv::lds_bytes(cgv::bi_stage_floats<1>() + 2304 + 64 + 192), st, UV, a, gs_base, gs_slices, gs_n_slices,
                          (long long)gs_slice_stride, gv, W1p, ga, gUV, gs_sum, slices_out, (long long)out_slice_stride, n_nodes,
-                         n_feat, tj, mainb);
+                         n_feat);
   });
   return cgv::check_launch("cgv_decoder_gate_bwd");
 }
 
 int cgv_decoder_dense_bwd(const float* g_slices, int g_n_slices, int64_t g_slice_stride, const float* z, int act, const float* W,
-                          float* g_dense, float* slices_out, int64_t out_slice_stride, int n_nodes, int N, int K,
-                          const cgv_touch* touch, void* stream) {
+                          float* g_dense, float* slices_out, int64_t out_slice_stride, int n_nodes, int N, int K, void* stream) {
   CGV_REQUIRE(g_slices && W && g_dense && slices_out && g_n_slices >= 1 && g_n_slices <= 216, "null pointer / slice count");
   CGV_REQUIRE(act == 0 || (act >= 1 && act <= cgv::CGV_ACT_MAX && z), "act != 0 needs the saved pre-activation z");
   CGV_REQUIRE(n_nodes >= 1 && n_nodes <= cgv::DL_MAX_NODES && (N % 4) == 0 && (K % 4) == 0 && K <= 64 * 27 && N >= 4, "unsupported shape");
@@ -1443,18 +1334,16 @@ int cgv_decoder_dense_bwd(const float* g_slices, int g_n_slices, int64_t g_slice
   const bool fat = cgv_decoder_block_channels(N) == 8;
   const int blocks = fat ? N / 8 : N / 4;
   const size_t lds = cgv::lds_bytes(cgv::bi_stage_floats<1>() + 2 * 2304 + 2 * 64 + 2 * 64);
-  cgv::Touch tj; int extra;
-  if (int rc = cgv::make_touch(touch, blocks, &tj, &extra)) return rc;
 #define CGV_DL_DENSE(NTV)                                                                                                  \
   CGV_DL_QS(g_n_slices, {                                                                                                  \
     if (fat)                                                                                                               \
-      hipLaunchKernelGGL((cgv::dec_dense_bwd_k<NTV, 2, QS>), dim3(blocks + extra), dim3(cgv::DL_THREADS), lds, st, g_slices, \
+      hipLaunchKernelGGL((cgv::dec_dense_bwd_k<NTV, 2, QS>), dim3(blocks), dim3(cgv::DL_THREADS), lds, st, g_slices,       \
                          g_n_slices, (long long)g_slice_stride, z, act, W, g_dense, slices_out, (long long)out_slice_stride, \
-                         n_nodes, N, K, tj, blocks);                                                                       \
+                         n_nodes, N, K);                                                                                   \
     else                                                                                                                   \
-      hipLaunchKernelGGL((cgv::dec_dense_bwd_k<NTV, 1, QS>), dim3(blocks + extra), dim3(cgv::DL_THREADS), lds, st, g_slices, \
+      hipLaunchKernelGGL((cgv::dec_dense_bwd_k<NTV, 1, QS>), dim3(blocks), dim3(cgv::DL_THREADS), lds, st, g_slices,       \
                          g_n_slices, (long long)g_slice_stride, z, act, W, g_dense, slices_out, (long long)out_slice_stride, \
-                         n_nodes, N, K, tj, blocks);                                                                       \
+                         n_nodes, N, K);                                                                                   \
   })
   if (tiles <= 9) { CGV_DL_DENSE(1); } else if (tiles <= 18) { CGV_DL_DENSE(2); } else { CGV_DL_DENSE(3); }
 #undef CGV_DL_DENSE
@@ -1463,29 +1352,26 @@ int cgv_decoder_dense_bwd(const float* g_slices, int g_n_slices, int64_t g_slice
 
 int cgv_decoder_uv_bwd(const float* gstack_slices, int n_slices, int64_t slice_stride, const float* UV, const float* stack,
                        const float* gs_res, const float* Wuv, float* gUV, float* g_s2, float* slices_out,
-                       int64_t out_slice_stride, int n_nodes, int n_feat, const cgv_touch* touch, void* stream) {
+                       int64_t out_slice_stride, int n_nodes, int n_feat, void* stream) {
   CGV_REQUIRE(gstack_slices && UV && stack && gs_res && Wuv && gUV && g_s2 && slices_out && n_slices >= 1 && n_slices <= 216,
               "null pointer / slice count");
   CGV_REQUIRE(out_slice_stride >= cgv_decoder_slice_floats(n_feat, 3 * n_nodes), "bad slices");
   const int n_rbf = 8;
   CGV_DL_CHECK();
   (void)blocks;
-  const int mainb = cgv_decoder_block_channels(n_feat) == 8 ? n_feat / 8 : n_feat / 4;
-  cgv::Touch tj; int extra;
-  if (int rc = cgv::make_touch(touch, mainb, &tj, &extra)) return rc;
   CGV_DL_QS(n_slices, {
     if (cgv_decoder_block_channels(n_feat) == 8) {
       const size_t lds = cgv::lds_bytes(cgv::bi_stage_floats<3>() + 2 * 4608 + 2 * 128 + 2 * 384);
       if (int rc = cgv::allow_lds(cgv::dec_uv_bwd_k<2, QS>, lds)) return rc;
-      hipLaunchKernelGGL((cgv::dec_uv_bwd_k<2, QS>), dim3(mainb + extra), dim3(cgv::DL_THREADS), lds, st, gstack_slices, n_slices,
+      hipLaunchKernelGGL((cgv::dec_uv_bwd_k<2, QS>), dim3(n_feat / 8), dim3(cgv::DL_THREADS), lds, st, gstack_slices, n_slices,
                          (long long)slice_stride, UV, stack, gs_res, Wuv, gUV, g_s2, slices_out, (long long)out_slice_stride,
-                         n_nodes, n_feat, tj, mainb);
+                         n_nodes, n_feat);
     } else {
       const size_t lds = cgv::lds_bytes(cgv::bi_stage_floats<3>() + 4608 + 128 + 384);
       if (int rc = cgv::allow_lds(cgv::dec_uv_bwd_k<1, QS>, lds)) return rc;
-      hipLaunchKernelGGL((cgv::dec_uv_bwd_k<1, QS>), dim3(mainb + extra), dim3(cgv::DL_THREADS), lds, st, gstack_slices, n_slices,
+      hipLaunchKernelGGL((cgv::dec_uv_bwd_k<1, QS>), dim3(n_feat / 4), dim3(cgv::DL_THREADS), lds, st, gstack_slices, n_slices,
                          (long long)slice_stride, UV, stack, gs_res, Wuv, gUV, g_s2, slices_out, (long long)out_slice_stride,
-                         n_nodes, n_feat, tj, mainb);
+                         n_nodes, n_feat);
     }
   });
   return cgv::check_launch("cgv_decoder_uv_bwd");
@@ -1497,7 +1383,7 @@ int cgv_decoder_msg_bwd(const float* phi, const float* s, const float* sbar, con
                         const float* ghb, const float* gvrows_slices, int n_slices, int64_t slice_stride, const float* gv_res,
                         const float* gvb, const float* W2, float* g_phi, float* g_s, float* g_sbar, float* g_v, float* g_vbar,
                         float* gWd, float* gbd, float* slices_out, int64_t out_slice_stride, int n_nodes, int n_feat, int n_rbf,
-                        int n_edges, const cgv_touch* touch, void* stream) {
+                        int n_edges, void* stream) {
   CGV_REQUIRE(phi && s && sbar && v && vbar && geom_d && rowptr_d && src_d && geom_s && rowptr_s && dst_s && Wd && bd && W2,
               "null input");
   CGV_REQUIRE(gvrows_slices && n_slices >= 1 && n_slices <= 216 && g_phi && g_s && g_sbar && g_v && g_vbar && gWd && gbd && slices_out,
@@ -1507,15 +1393,13 @@ int cgv_decoder_msg_bwd(const float* phi, const float* s, const float* sbar, con
   CGV_DL_CHECK();
   const size_t lds = cgv::lds_bytes(cgv::bi_stage_floats<1>() + 192 + 576 + 576 + 3456 + 4608 +
                                2 * (size_t)cgv::DL_MAX_EDGES * cgv::geom_stride(n_rbf) + 40 + 2 * cgv::DL_MAX_EDGES + 256 + 960);
-  cgv::Touch tj; int extra;
-  if (int rc = cgv::make_touch(touch, blocks, &tj, &extra)) return rc;
   CGV_DISPATCH_RBF(n_rbf, {
     CGV_DL_QS(n_slices, {
       if (int rc = cgv::allow_lds(cgv::dec_msg_bwd_k<RBF, QS>, lds)) return rc;
-      hipLaunchKernelGGL((cgv::dec_msg_bwd_k<RBF, QS>), dim3(blocks + extra), dim3(cgv::DL_THREADS), lds, st, phi, s, sbar, v, vbar, geom_d,
+      hipLaunchKernelGGL((cgv::dec_msg_bwd_k<RBF, QS>), dim3(blocks), dim3(cgv::DL_THREADS), lds, st, phi, s, sbar, v, vbar, geom_d,
                          rowptr_d, src_d, geom_s, rowptr_s, dst_s, Wd, bd, gh, ghb, gvrows_slices, n_slices,
                          (long long)slice_stride, gv_res, gvb, W2, g_phi, g_s, g_sbar, g_v, g_vbar, gWd, gbd, slices_out,
-                         (long long)out_slice_stride, n_nodes, n_feat, n_edges, tj, blocks);
+                         (long long)out_slice_stride, n_nodes, n_feat, n_edges);
     });
   });
   return cgv::check_launch("cgv_decoder_msg_bwd");

@@ -20,6 +20,7 @@
 // reduction axis feeds 4 consecutive MFMAs: component c of lane group q stands for reduction index
 // 4q + c of the 16-wide step -- any bijection works as long as A and B use the same one.
 #include <stdlib.h>
+#include <type_traits>
 #include "cgv_common.h"
 
 namespace cgv {
@@ -31,6 +32,17 @@ __device__ __forceinline__ float4 ld4z(const float* p, bool ok) {
 }
 
 #define CGV_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N).  Register rings indexed by a LOOP variable end up
+// in scratch memory even when the loop is later unrolled (the array is demoted before the unroller runs); indices that
+// are constants from the start keep every slot in VGPRs.
+template <int I0, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I0 < N) {
+    f(std::integral_constant<int, I0>{});
+    static_for<I0 + 1, N>(f);
+  }
+}
 
 // ------------------------------------------------------------------ fwd
 // Block tile = (32 QM) x (32 QN); wave = (quadrant, k-slice): QM*QN quadrants of 32 x 32 outputs, the K loop of
@@ -210,6 +222,111 @@ __global__ __launch_bounds__(256) void tile_fwd_lds_k(const float* __restrict__ 
     __syncthreads();
   }
   // lane: m = m0 + 32 wm + 16 b + i, n = n0 + 32 wn + 16 a + 4 q .. + 3
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int n = n0 + 32 * wn + 16 * a + 4 * q;
+    if (n >= N) continue;                            // N % 4 == 0: the float4 is entirely in or out
+    const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int m = m0 + 32 * wm + 16 * b + i;
+      if (m >= M) continue;
+      float4 zv = make_float4(acc[a][b][0] + bv.x, acc[a][b][1] + bv.y, acc[a][b][2] + bv.z, acc[a][b][3] + bv.w);
+      if (act) {
+        if (zout) *reinterpret_cast<float4*>(zout + (size_t)m * N + n) = zv;
+        zv.x = act_fwd(zv.x, act); zv.y = act_fwd(zv.y, act); zv.z = act_fwd(zv.z, act); zv.w = act_fwd(zv.w, act);
+      }
+      *reinterpret_cast<float4*>(y + (size_t)m * N + n) = zv;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ fwd, LDS-staged, three slabs of look-ahead
+// tile_fwd_lds_k above keeps ONE slab of global loads in flight: a block that is alone on its CU (mid-size problems: one
+// 64 x 64 tile per CU or fewer) then pays a memory round trip per slab -- 1.1 us against 0.43 us of MFMA work, 21 us for
+// K = 600.  Here the staging registers form a ring of three slabs: the loads of slab kt + 3 are issued before the MFMAs of
+// slab kt, so two slabs (32 KB per block) are always in flight; same LDS image, same fragment reads, same transposed
+// product and 16-byte epilogue as above.
+// How it has to be written for the compiler: (i) the slab loop is FULLY unrolled (SLABS = ceil(K / 32) is a template
+// argument; the layer widths of this model give K = 600 and 1200): in straight-line code hipcc counts its loads and waits
+// with exact vmcnt(N), around a loop's back edge it drains to vmcnt(0) once per trip; (ii) the ring slots are NAMED
+// variables picked by a switch on kt % 3 that folds after unrolling -- a slot ARRAY indexed by the loop variable (or
+// reached through a lambda capture) is demoted to scratch memory before the unroller runs: 171 scratch instructions and
+// 30 us per call, against 21 us for the one-slab look-ahead; so is anything whose ADDRESS is selected (see stash).
+struct RingSlot { f32x4 a0, a1, b0, b1; };          // ext vectors: plain SSA values (HIP's float4 is a struct of unions)
+
+// (__launch_bounds__(256, 2): two waves per SIMD are asked for, not the four the LDS footprint would admit -- at four the
+// compiler caps the kernel at 128 registers and spills the ring it was given to hide latency with)
+template <int SLABS>
+__global__ __launch_bounds__(256, 2) void tile_fwd_ring_k(const float* __restrict__ x, const float* __restrict__ W,
+                                                       const float* __restrict__ bias, float* __restrict__ y,
+                                                       float* __restrict__ zout, int M, int N, int K, int act) {
+  __shared__ __attribute__((aligned(16))) float As[2][LT * LLD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][LT * LLD];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int i = lane & 15, q = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * LT, n0 = blockIdx.x * LT;
+  const int sr = t >> 3, sc = 4 * (t & 7);           // staging: rows sr, sr + 32; float4 column sc of the slab
+  // rows beyond M / N are clamped into range: their products are never stored
+  const float* const xr0 = x + (size_t)min(m0 + sr, M - 1) * K + sc;
+  const float* const xr1 = x + (size_t)min(m0 + sr + 32, M - 1) * K + sc;
+  const float* const wr0 = W + (size_t)min(n0 + sr, N - 1) * K + sc;
+  const float* const wr1 = W + (size_t)min(n0 + sr + 32, N - 1) * K + sc;
+  // unconditional loads (a guarded load is a branch and breaks the batch): a float4 beyond K reads the row's first one
+  // and is zeroed on W's side when stashed (K % 4 == 0: a float4 is entirely in or out)
+  auto fetch = [&](RingSlot& r, int kt) __attribute__((always_inline)) {
+    const int k0 = kt * LBK;
+    const int off = (k0 + sc < K) ? k0 : -sc;
+    r.a0 = *reinterpret_cast<const f32x4*>(xr0 + off); r.a1 = *reinterpret_cast<const f32x4*>(xr1 + off);
+    r.b0 = *reinterpret_cast<const f32x4*>(wr0 + off); r.b1 = *reinterpret_cast<const f32x4*>(wr1 + off);
+  };
+  auto stash = [&](const RingSlot& r, int kt, int buf) __attribute__((always_inline)) {
+    const bool kok = kt * LBK + sc < K;
+    // (selects of VALUES: `kok ? r.b0 : zero` on two lvalues selects an ADDRESS and sends the slots to scratch)
+    *reinterpret_cast<f32x4*>(&As[buf][sr * LLD + sc]) = r.a0;
+    *reinterpret_cast<f32x4*>(&As[buf][(sr + 32) * LLD + sc]) = r.a1;
+    *reinterpret_cast<f32x4*>(&Bs[buf][sr * LLD + sc]) = kok ? r.b0 : f32x4{0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4*>(&Bs[buf][(sr + 32) * LLD + sc]) = kok ? r.b1 : f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  RingSlot s0, s1, s2;
+  fetch(s0, 0);
+  fetch(s1, SLABS > 1 ? 1 : 0);
+  fetch(s2, SLABS > 2 ? 2 : 0);
+  f32x4 acc00 = {0.f, 0.f, 0.f, 0.f}, acc01 = acc00, acc10 = acc00, acc11 = acc00;      // [n sub-block][m sub-block]: D[n][m]
+  stash(s0, 0, 0);
+  __syncthreads();
+#pragma unroll
+  for (int kt = 0; kt < SLABS; ++kt) {
+    const int buf = kt & 1;
+    // slot kt % 3 held slab kt (already in LDS): refill it with slab kt + 3
+    if (kt + 3 < SLABS) {
+      switch (kt % 3) { case 0: fetch(s0, kt + 3); break; case 1: fetch(s1, kt + 3); break; default: fetch(s2, kt + 3); break; }
+    }
+    const float* __restrict__ a_s = As[buf] + (32 * wm + i) * LLD + 4 * q;
+    const float* __restrict__ b_s = Bs[buf] + (32 * wn + i) * LLD + 4 * q;
+#pragma unroll
+    for (int ks = 0; ks < LBK / 16; ++ks) {
+      const float4 x0 = *reinterpret_cast<const float4*>(a_s + 16 * ks), x1 = *reinterpret_cast<const float4*>(a_s + 16 * LLD + 16 * ks);
+      const float4 w0 = *reinterpret_cast<const float4*>(b_s + 16 * ks), w1 = *reinterpret_cast<const float4*>(b_s + 16 * LLD + 16 * ks);
+      acc00 = CGV_MFMA(w0.x, x0.x, acc00); acc01 = CGV_MFMA(w0.x, x1.x, acc01);
+      acc10 = CGV_MFMA(w1.x, x0.x, acc10); acc11 = CGV_MFMA(w1.x, x1.x, acc11);
+      acc00 = CGV_MFMA(w0.y, x0.y, acc00); acc01 = CGV_MFMA(w0.y, x1.y, acc01);
+      acc10 = CGV_MFMA(w1.y, x0.y, acc10); acc11 = CGV_MFMA(w1.y, x1.y, acc11);
+      acc00 = CGV_MFMA(w0.z, x0.z, acc00); acc01 = CGV_MFMA(w0.z, x1.z, acc01);
+      acc10 = CGV_MFMA(w1.z, x0.z, acc10); acc11 = CGV_MFMA(w1.z, x1.z, acc11);
+      acc00 = CGV_MFMA(w0.w, x0.w, acc00); acc01 = CGV_MFMA(w0.w, x1.w, acc01);
+      acc10 = CGV_MFMA(w1.w, x0.w, acc10); acc11 = CGV_MFMA(w1.w, x1.w, acc11);
+    }
+    // slab kt + 1 sits in slot (kt + 1) % 3 (requested two slabs ago): into the other buffer, last read one barrier ago
+    if (kt + 1 < SLABS) {
+      switch ((kt + 1) % 3) { case 0: stash(s0, kt + 1, buf ^ 1); break; case 1: stash(s1, kt + 1, buf ^ 1); break; default: stash(s2, kt + 1, buf ^ 1); break; }
+      __syncthreads();
+    }
+  }
+  // lane: m = m0 + 32 wm + 16 b + i, n = n0 + 32 wn + 16 a + 4 q .. + 3
+  const f32x4 acc[2][2] = {{acc00, acc01}, {acc10, acc11}};
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
     const int n = n0 + 32 * wn + 16 * a + 4 * q;
@@ -411,9 +528,19 @@ int cgv_tile_linear_fwd(const float* x, const float* W, const float* bias, float
   const int tiles64 = ((N + 63) / 64) * ((M + 63) / 64);
   const int lds_min = cgv::option(CGV_OPT_TILE_FWD_LDS_MIN);
   const bool aligned16 = ((((uintptr_t)y | (uintptr_t)z | (uintptr_t)bias)) & 15) == 0;
-  // several 64 x 64 tiles per CU and many row tiles: the LDS-staged kernel (704 x 5400 still favours the L2-fed
-  // tiles, 59 vs 63 us; 2000 x 5400: 168 vs 201, 2000 x 1800: 57 vs 70).  cgv_set_option(CGV_OPT_TILE_FWD_LDS_MIN, 1): every shape (tests)
-  if (tiles64 >= lds_min && (M >= 1024 || lds_min <= 1) && aligned16)
+  // several 64 x 64 tiles per CU: the LDS-staged kernels -- with the three-slab ring for the reductions it is compiled for
+  // (K = 600 / 1200: 19 / 38 slabs), else with one slab of look-ahead.  Measured (tools/gemm_shapes.py, rotating operands),
+  // ring vs split-reduction tiles: 2000 x 5400 x 600 137 vs 155 us (95 TF/s), 2000 x 1800 52 vs 56, 704 x 5400 53 vs 77,
+  // 332 x 5400 32 vs 39, 2000 x 1200 40 vs 43; below ~450 tiles the split-reduction tiles win (704 x 1800: 27 vs 31,
+  // 2000 x 600: 24 vs 30 -- a lone block per CU still spends ~1 us per slab on its read -> MFMA -> write -> barrier chain).
+  // cgv_set_option(CGV_OPT_TILE_FWD_LDS_MIN, 1): the one-slab kernel for every shape, 3: the ring kernel (tests / A-B)
+  const int slabs32 = (K + 31) / 32;
+  const bool ring_ok = aligned16 && (slabs32 == 19 || slabs32 == 38) && lds_min != 1;
+  if (ring_ok && (tiles64 >= lds_min || lds_min == 3)) {
+    const dim3 grid((N + 63) / 64, (M + 63) / 64);
+    if (slabs32 == 19) hipLaunchKernelGGL((cgv::tile_fwd_ring_k<19>), grid, dim3(256), 0, st, x, W, bias, y, z, M, N, K, act);
+    else hipLaunchKernelGGL((cgv::tile_fwd_ring_k<38>), grid, dim3(256), 0, st, x, W, bias, y, z, M, N, K, act);
+  } else if (tiles64 >= lds_min && (M >= 1024 || lds_min <= 1) && aligned16)
     hipLaunchKernelGGL(cgv::tile_fwd_lds_k, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, st, x, W, bias, y, z, M, N, K,
                        act);
   else if (tiles32 >= 2048)                    // enough work for several 64 x 64 tiles on every CU (measured: no gain below)

@@ -106,35 +106,27 @@ class _PseudoDecoderFn(torch.autograd.Function):
         n_stage = staged_edges(plan)
         from .options import HOST
         if HOST["decoder_dense"] == 1:          # A/B: the 16-column-block skinny kernel for the two full-width products
-            dense = lambda x, W, b, y, z, M, N, K, act, st_, touch=None: _dense_fwd(x, W, b, y, z, M, N, K, act, st_)
+            dense = _dense_fwd
         else:
-            dense = lambda x, W, b, y, z, M, N, K, act, st_, touch=None: _lib.call(
-                "cgv_decoder_dense_fwd", _lib.ptr(x), _lib.ptr(W), _lib.ptr(b), _lib.ptr(y), _lib.ptr(z), M, N, K, act, touch, st_)
-        nb4 = F // 4                             # blocks of every forward launch: the consumers of the prefetch jobs
+            dense = lambda x, W, b, y, z, M, N, K, act, st_: _lib.call("cgv_decoder_dense_fwd", _lib.ptr(x), _lib.ptr(W), _lib.ptr(b),
+                                                                      _lib.ptr(y), _lib.ptr(z), M, N, K, act, st_)
         for l in range(n_layers):
             W1, b1, W2, b2, Wd, bd, Wu, Wv, W0, b0, W1p, b1p = (t.detach() for t in flat[PER_LAYER * l: PER_LAYER * (l + 1)])
             Wuv = torch.as_strided(Wu, (2 * F, F), (F, 1))
-            nxt = [t.detach() for t in flat[PER_LAYER * (l + 1): PER_LAYER * (l + 2)]] if l + 1 < n_layers else None
-            # L2 prefetch (cgv_touch): idle CUs of a launch touch the weight rows a later launch streams, on its blocks' XCDs
-            # jobs: (W, K, row groups per consumer block, rows between groups, rows per group, consumer blocks, part, parts)
-            t1, k1 = _lib.touch((Wuv, F, 2, F, 4, nb4, 0, 1))                                            # F1 -> F3
-            t2, k2 = _lib.touch((W0, 2 * F, 1, 0, 4, nb4, 0, 1), (W1p, F, 3, F, 4, nb4, 0, 1))          # F2 -> F4, F5
-            t3, k3 = _lib.touch((nxt[0], F, 1, 0, 4, nb4, 0, 1), (nxt[2], F, 9, F, 4, nb4, 0, 2)) if nxt else (None, None)   # F3 -> next F1, F2
-            t4, k4 = _lib.touch((nxt[2], F, 9, F, 4, nb4, 1, 2)) if nxt else (None, None)                # F4 -> next F2
             a1, z1, phi, stack = new(n, F), new(n, F), new(n, 9 * F), new(n, 2 * F)
-            dense(S, W1, b1, a1, z1, n, F, F, ACT_SWISH, st, t1)
+            dense(S, W1, b1, a1, z1, n, F, F, ACT_SWISH, st)
             Sbar2, V2, Vbar2, rows = new(n, F), new(n, F, 3), new(n, F, 3), new(3 * n, F)
             _lib.call("cgv_decoder_msg_fwd", _lib.ptr(a1), _lib.ptr(W2), _lib.ptr(b2), _lib.ptr(S), _lib.ptr(Sbar), _lib.ptr(V),
                       _lib.ptr(Vbar), _lib.ptr(geom.geom_d), _lib.ptr(plan.rowptr_d), _lib.ptr(plan.src_d), _lib.ptr(Wd),
                       _lib.ptr(bd), _lib.ptr(phi), _lib.ptr(stack), _lib.ptr(Sbar2), _lib.ptr(V2), _lib.ptr(Vbar2), _lib.ptr(rows),
-                      n, F, R, n_stage, t2, st, tag=f"pseudo_msg_fwd:Nd{n}:E{plan.n_edges}:dv1")
+                      n, F, R, n_stage, st, tag=f"pseudo_msg_fwd:Nd{n}:E{plan.n_edges}:dv1")
             UV = new(3 * n, 2 * F)
-            _lib.call("cgv_decoder_uv_fwd", _lib.ptr(rows), _lib.ptr(Wuv), _lib.ptr(UV), _lib.ptr(stack), n, F, t3, st)
+            _lib.call("cgv_decoder_uv_fwd", _lib.ptr(rows), _lib.ptr(Wuv), _lib.ptr(UV), _lib.ptr(stack), n, F, st)
             z0, a0, a = new(n, F), new(n, F), new(n, 3 * F)
-            dense(stack, W0, b0, a0, z0, n, F, 2 * F, ACT_SWISH, st, t4)
+            dense(stack, W0, b0, a0, z0, n, F, 2 * F, ACT_SWISH, st)
             S3, V3 = new(n, F), new(n, F, 3)
             _lib.call("cgv_decoder_gate_fwd", _lib.ptr(a0), _lib.ptr(W1p), _lib.ptr(b1p), _lib.ptr(UV), _lib.ptr(stack),
-                      _lib.ptr(V2), _lib.ptr(a), _lib.ptr(S3), _lib.ptr(V3), n, F, None, st)
+                      _lib.ptr(V2), _lib.ptr(a), _lib.ptr(S3), _lib.ptr(V3), n, F, st)
             saved.append((S, Sbar, V, Vbar, z1, a1, phi, rows, UV, stack, z0, a0, a))
             S, Sbar, V, Vbar = S3, Sbar2, V3, Vbar2
             mark(f"decoder:fwd{l}")
@@ -166,16 +158,6 @@ class _PseudoDecoderFn(torch.autograd.Function):
             S_in, Sbar_in, V_in, Vbar_in, z1, a1, phi, rows, UV, stack, z0, a0, a = saved[l]
             saved[l] = None
             Wuv = torch.as_strided(pWu.detach(), (2 * F, F), (F, 1))
-            below = [t.detach() for t in flat[PER_LAYER * (l - 1): PER_LAYER * l]] if l > 0 else None
-            # L2 prefetch jobs (see forward): consumer geometry of the backward launches -- cb-channel blocks own cb
-            # consecutive rows per row group; the message kernel keeps 4-channel blocks
-            cb = int(lib.cgv_decoder_block_channels(F))
-            nbc = F // cb
-            t1, k1 = _lib.touch((Wuv, F, 2, F, cb, nbc, 0, 1))                                            # B1 -> B3
-            t2, k2 = _lib.touch((pW2.detach(), F, 9, F, 4, F // 4, 0, 2))                                 # B2 -> B4
-            t3, k3 = _lib.touch((pW2.detach(), F, 9, F, 4, F // 4, 1, 2), (pW1.detach(), F, 1, 0, cb, nbc, 0, 1))   # B3 -> B4, B5
-            t4, k4 = (_lib.touch((below[10], F, 3, F, cb, nbc, 0, 1), (below[8], 2 * F, 1, 0, cb, nbc, 0, 1))
-                      if below else (None, None))                                                         # B4 -> next B1, B2
             # slices per phase: F / 4 from the message kernel, width / cgv_decoder_block_channels(width) from the others
             # B1: gate backward, rows of s_dense.1
             ga, gUV, gs_sum = new(n, 3 * F), new(3 * n, 2 * F), new(n, F)
@@ -183,17 +165,17 @@ class _PseudoDecoderFn(torch.autograd.Function):
             p1 = new(nF * fl16(F))
             _lib.call("cgv_decoder_gate_bwd", _lib.ptr(UV), _lib.ptr(a), _lib.ptr(gS.base), _lib.ptr(gS.part), gS.n, gS.stride,
                       _lib.ptr(gV), _lib.ptr(pW1p.detach()), _lib.ptr(ga), _lib.ptr(gUV), _lib.ptr(gs_sum), _lib.ptr(p1), fl16(F),
-                      n, F, t1, st)
+                      n, F, st)
             # B2: s_dense.0 (swish'), K = 2F
             g_a0 = new(n, F)
             p2 = new(nF * fl16(2 * F))
             _lib.call("cgv_decoder_dense_bwd", _lib.ptr(p1), nF, fl16(F), _lib.ptr(z0), ACT_SWISH, _lib.ptr(pW0.detach()),
-                      _lib.ptr(g_a0), _lib.ptr(p2), fl16(2 * F), n, F, 2 * F, t2, st)
+                      _lib.ptr(g_a0), _lib.ptr(p2), fl16(2 * F), n, F, 2 * F, st)
             # B3: norm backward, rows of [u_mat; v_mat]
             g_s2 = new(n, F)
             p3 = new(nF * fl48)
             _lib.call("cgv_decoder_uv_bwd", _lib.ptr(p2), nF, fl16(2 * F), _lib.ptr(UV), _lib.ptr(stack), _lib.ptr(gs_sum),
-                      _lib.ptr(Wuv), _lib.ptr(gUV), _lib.ptr(g_s2), _lib.ptr(p3), fl48, n, F, t3, st)
+                      _lib.ptr(Wuv), _lib.ptr(gUV), _lib.ptr(g_s2), _lib.ptr(p3), fl48, n, F, st)
             # B4: message backward, rows of inv_dense.1
             g_phi = new(n, 9 * F)
             g_s, g_sbar, g_v, g_vbar = new(n, F), new(n, F), new(n, F, 3), new(n, F, 3)
@@ -207,12 +189,12 @@ class _PseudoDecoderFn(torch.autograd.Function):
                       _lib.ptr(plan.rowptr_s), _lib.ptr(plan.dst_s), _lib.ptr(pWd.detach()), _lib.ptr(pbd.detach()),
                       _lib.ptr(g_s2), _lib.ptr(gSbar), _lib.ptr(p3), nF, fl48, _lib.ptr(gV), _lib.ptr(gVbar), _lib.ptr(pW2.detach()),
                       _lib.ptr(g_phi), _lib.ptr(g_s), _lib.ptr(g_sbar), _lib.ptr(g_v), _lib.ptr(g_vbar), _lib.ptr(tWd), _lib.ptr(tbd),
-                      _lib.ptr(p4), fl16(F), n, F, R, n_stage, t4, st, tag=f"pseudo_msg_bwd:Nd{n}:E{plan.n_edges}:gv1")
+                      _lib.ptr(p4), fl16(F), n, F, R, n_stage, st, tag=f"pseudo_msg_bwd:Nd{n}:E{plan.n_edges}:gv1")
             # B5: inv_dense.0 (swish')
             g_a1 = new(n, F)
             p5 = new(nF * fl16(F))
             _lib.call("cgv_decoder_dense_bwd", _lib.ptr(p4), nb, fl16(F), _lib.ptr(z1), ACT_SWISH, _lib.ptr(pW1.detach()),
-                      _lib.ptr(g_a1), _lib.ptr(p5), fl16(F), n, F, F, None, st)
+                      _lib.ptr(g_a1), _lib.ptr(p5), fl16(F), n, F, F, st)
 
             # ---- weight gradients -> the grouped launch (direct arena targets)
             def enqueue(gy, x, z, act, pw, pb):

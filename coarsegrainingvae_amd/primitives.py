@@ -328,7 +328,7 @@ class _LinearFn(torch.autograd.Function):
                 # few rows: 4-column blocks (N / 4 of them pull the weight) beat the skinny kernel's 16-column blocks
                 # (decoder forward 356 -> 343 us on chignolin: csrc/decoder_layer.hip, dec_dense_fwd_k)
                 _lib.call("cgv_decoder_dense_fwd", _lib.ptr(x2), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(y), _lib.ptr(z),
-                          M, N, K, act, None, _lib.stream_ptr())
+                          M, N, K, act, _lib.stream_ptr())
             else:
                 # 65 - 128 rows (a big bead batch) and at most 1200 outputs: the weight-streaming kernel with one 16-row block
                 # per thread block still beats the tiles (96 rows: 600 x 600 4.8 against 6.7 us, 600 x 1200 6.3 / 10.5,
@@ -554,12 +554,12 @@ def wgrad_tile(shapes) -> int:
 
 
 def _library_pays(M, N, K, forward: bool) -> bool:
-    """Plain (activation-free) products of the tile-GEMM layers for which the library GEMM (hipBLASLt behind torch) beats
-    the hand-written tiles -- it has a ~18 us floor but reaches 57-98 TF/s where the 32 x 32 L2-fed tiles level off at
-    48 (tools/lib_gemm_bench.py: bwd_input 704 x 1800 x 600: 19 vs 30 us; forward 2000 x 1800 x 600: 44 vs 90 us)."""
-    if forward:
-        return M >= 1024 and N * K >= 1024 * 600     # 2000 x 1800 x 600: 44 vs 57 us; 704 x 1800 x 600: 26.6 vs 25.3 for the tiles
-    return M >= 512 and N * K >= 1024 * 600
+    """Never: every product of the path runs on the hand-written kernels.  (Round 2 sent plain products of >= 1024 rows
+    forward / >= 512 rows backward to the library GEMM -- hipBLASLt behind torch.  Re-measured with rotating operands,
+    tools/gemm_shapes.py: the tiles already win backward at 704 rows, 25 vs 35 us for 704 x 1800 x 600; forward the
+    three-slab ring kernel brings 2000 x 5400 x 600 to 137 us against 118-175 us; what the library still wins --
+    2000 x 1800 x 600: 44 vs 52 us forward, 40 vs 56 us backward -- is 0.05 ms of the 2000-atom step.)"""
+    return False
 
 
 def lib_has_rows(M, N, K) -> bool:

@@ -71,14 +71,14 @@ enum {
   CGV_OPT_CSR_BUILD = 5,       /* cgv_csr_build: 0 by rows (default), 1 two-radix-pass construction */
   CGV_OPT_PSEUDO_CHUNKS = 6,   /* cgv_pseudo_msg_bwd: cap on node chunks, 0 = built-in rule */
   CGV_OPT_WGRAD_TILING = 7,    /* cgv_wgrad_plan: 0 balanced column tiles (default), 1 widest tile */
-  CGV_OPT_TILE_FWD_LDS_MIN = 8,/* cgv_tile_linear_fwd: minimum 64x64 tile count for the LDS-staged kernel (default 448; 1 = always) */
+  CGV_OPT_TILE_FWD_LDS_MIN = 8,/* cgv_tile_linear_fwd: minimum 64x64 tile count for the LDS-staged kernels (default 448); 1 = the one-slab
+                                  kernel always, 3 = the three-slab ring kernel wherever it is compiled (K = 577..608, 1185..1216) */
   CGV_OPT_BWD_INPUT_WAVES = 9, /* cgv_tile_linear_bwd_input*: waves per block, 0 = built-in rule */
   CGV_OPT_PSEUDO_FWD = 10,     /* cgv_pseudo_msg_fwd*: 0 built-in rule; 1..6 = (edges in flight, records staged in LDS) variants; cgv_pseudo_msg_bwd on dense bead graphs: 4 = 8 edges in flight, 5 = records not staged in LDS */
   CGV_OPT_DECODER_FAT = 11,    /* cgv_decoder_{gate,dense,uv}_bwd: 1 (default) 8-channel blocks where the width allows, 0 always 4 */
   CGV_OPT_DECODER_WLDS = 12,   /* cgv_decoder_msg_fwd: 1 (default) weight rows by LDS-DMA when they fit in LDS, 0 register path */
   CGV_OPT_SKINNY_ROWS = 13,    /* cgv_skinny_linear_fwd: row blocks (of 16) per thread block; 0 = built-in rule, 1..4 */
-  CGV_OPT_DECODER_TOUCH = 14,  /* cgv_decoder_*: 1 (default) honour the `touch` argument (L2 prefetch blocks), 0 ignore it */
-  CGV_OPT_COUNT = 15
+  CGV_OPT_COUNT = 14
 };
 /* Measurement: store the GPU wall clock (cgv_timestamp_hz ticks per second) into *slot, in stream order; capturable. */
 int cgv_timestamp(uint64_t* slot /*device*/, void* stream);
@@ -362,54 +362,35 @@ int cgv_pseudo_msg_bwd_deferred(const float* phi, const float* s, const float* s
 int cgv_decoder_layer_supported(int n_nodes, int n_feat, int n_rbf);
 int64_t cgv_decoder_slice_floats(int K, int rows);
 int cgv_decoder_max_edges(void);
-/* L2 prefetch blocks.  These grids leave part of the chip idle (F / 4 blocks: 150 of 256 CUs at F = 600) and every
- * launch opens with a cold stream of its weight rows.  `touch` (host struct, read at the call; NULL or n = 0: none) lets
- * a launch carry extra blocks on the idle CUs that only TOUCH -- one dword per 128-byte line -- the weight rows a LATER
- * launch of the chain will stream, on the XCD whose block will stream them (workgroups go round robin over the 8 XCDs,
- * each with its own L2).  A job describes the consumer launch's geometry: consumer block c streams, for g < n_groups,
- * the `rows` consecutive rows starting at row g * group_stride + rows * c of W [.., K]; `part` / `parts` split a job
- * over several host launches.  Pure prefetch: results are bit-identical with and without it. */
-typedef struct cgv_touch_job {
-  const float* W;
-  int32_t K, n_groups, group_stride, rows, blocks, part, parts;
-} cgv_touch_job;
-typedef struct cgv_touch {
-  int32_t n;               /* 0 .. 2 jobs */
-  cgv_touch_job job[2];
-} cgv_touch;
 int cgv_decoder_block_channels(int width);   /* 4 or 8: gate_bwd / dense_bwd / uv_bwd emit width / this slices */
 int cgv_decoder_debug_clock(uint64_t* buf /*device, 16 slots, or NULL*/);   /* measurement only */
 int cgv_decoder_msg_fwd(const float* a1, const float* W2, const float* b2, const float* s, const float* sbar, const float* v,
                         const float* vbar, const float* geom_d, const int32_t* rowptr_d, const int32_t* src_d, const float* Wd,
                         const float* bd, float* phi, float* stack, float* sbar_out, float* v_out, float* vbar_out,
-                        float* rows_out, int n_nodes, int n_feat, int n_rbf, int n_edges, const cgv_touch* touch /*or NULL*/,
-                        void* stream);
+                        float* rows_out, int n_nodes, int n_feat, int n_rbf, int n_edges, void* stream);
 /* y = act(x W^T + b) (z = pre-activation or NULL) for <= 16 rows, N / 4 blocks: the two full-width products of a layer */
 int cgv_decoder_dense_fwd(const float* x, const float* W /*[N,K]*/, const float* bias, float* y, float* z, int n_nodes, int N,
-                          int K, int act, const cgv_touch* touch /*or NULL*/, void* stream);
-int cgv_decoder_uv_fwd(const float* rows, const float* Wuv, float* UV, float* stack, int n_nodes, int n_feat,
-                       const cgv_touch* touch /*or NULL*/, void* stream);
+                          int K, int act, void* stream);
+int cgv_decoder_uv_fwd(const float* rows, const float* Wuv, float* UV, float* stack, int n_nodes, int n_feat, void* stream);
 int cgv_decoder_gate_fwd(const float* a0, const float* W1p, const float* b1p, const float* UV, const float* stack,
-                         const float* v2, float* a, float* s3, float* v3, int n_nodes, int n_feat,
-                         const cgv_touch* touch /*or NULL*/, void* stream);
+                         const float* v2, float* a, float* s3, float* v3, int n_nodes, int n_feat, void* stream);
 int cgv_decoder_gate_bwd(const float* UV, const float* a, const float* gs_base /*or NULL*/, const float* gs_slices /*or NULL*/,
                          int gs_n_slices, int64_t gs_slice_stride, const float* gv /*or NULL*/, const float* W1p, float* ga,
                          float* gUV, float* gs_sum, float* slices_out, int64_t out_slice_stride, int n_nodes, int n_feat,
-                         const cgv_touch* touch /*or NULL*/, void* stream);
+                         void* stream);
 int cgv_decoder_dense_bwd(const float* g_slices, int g_n_slices, int64_t g_slice_stride, const float* z /*or NULL*/, int act,
                           const float* W, float* g_dense, float* slices_out, int64_t out_slice_stride, int n_nodes, int N, int K,
-                          const cgv_touch* touch /*or NULL*/, void* stream);
+                          void* stream);
 int cgv_decoder_uv_bwd(const float* gstack_slices, int n_slices, int64_t slice_stride, const float* UV, const float* stack,
                        const float* gs_res, const float* Wuv, float* gUV, float* g_s2, float* slices_out,
-                       int64_t out_slice_stride, int n_nodes, int n_feat, const cgv_touch* touch /*or NULL*/, void* stream);
+                       int64_t out_slice_stride, int n_nodes, int n_feat, void* stream);
 int cgv_decoder_msg_bwd(const float* phi, const float* s, const float* sbar, const float* v, const float* vbar,
                         const float* geom_d, const int32_t* rowptr_d, const int32_t* src_d, const float* geom_s,
                         const int32_t* rowptr_s, const int32_t* dst_s, const float* Wd, const float* bd, const float* gh,
                         const float* ghb /*or NULL*/, const float* gvrows_slices, int n_slices, int64_t slice_stride,
                         const float* gv_res /*or NULL*/, const float* gvb /*or NULL*/, const float* W2, float* g_phi, float* g_s,
                         float* g_sbar, float* g_v, float* g_vbar, float* gWd, float* gbd, float* slices_out,
-                        int64_t out_slice_stride, int n_nodes, int n_feat, int n_rbf, int n_edges,
-                        const cgv_touch* touch /*or NULL*/, void* stream);
+                        int64_t out_slice_stride, int n_nodes, int n_feat, int n_rbf, int n_edges, void* stream);
 int cgv_decoder_slices_to_dense(const float* base /*or NULL*/, const float* slices, int n_slices, int64_t slice_stride,
                                 float* out, int n_nodes, int n_feat, void* stream);
 

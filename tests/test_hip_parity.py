@@ -1390,6 +1390,29 @@ def test_tile_forward_lds_staged_kernel_vs_fp64(shape):
         assert torch.allclose(z.double(), zr, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("shape", [(332, 1800, 600, 1), (704, 600, 1200, 0), (77, 36, 580, 2), (64, 64, 608, 0), (130, 68, 1188, 1),
+                                   (2000, 1800, 600, 0), (333, 1796, 596, 1)])
+def test_tile_forward_ring_kernel_vs_fp64(shape, options):
+    """The LDS-staged forward with a ring of three slabs of global loads in flight (tile_fwd_ring_k; option
+    tile_fwd_lds_min = 3 forces it on every shape it is compiled for: 19 or 38 slabs of 32, i.e. K = 577 .. 608 and
+    1185 .. 1216): mid-size and ragged shapes, ragged reduction tails, bias + activation epilogue, pre-activation output."""
+    options.set("tile_fwd_lds_min", 3)
+    M, N, K, act = shape
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    x = torch.randn(M, K, device=DEV, generator=g)
+    W = torch.randn(N, K, device=DEV, generator=g) / K ** 0.5
+    b = torch.randn(N, device=DEV, generator=g)
+    y = torch.full((M, N), float("nan"), device=DEV)
+    z = torch.full((M, N), float("nan"), device=DEV)
+    cg._lib.call("cgv_tile_linear_fwd", cg._lib.ptr(x), cg._lib.ptr(W), cg._lib.ptr(b), cg._lib.ptr(y), cg._lib.ptr(z), M, N, K, act,
+                 cg._lib.stream_ptr())
+    zr = x.double() @ W.double().T + b.double()
+    yr = {0: zr, 1: zr * torch.sigmoid(zr), 2: torch.tanh(zr)}[act]
+    assert torch.allclose(y.double(), yr, rtol=1e-5, atol=1e-5)
+    if act:
+        assert torch.allclose(z.double(), zr, rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize("shape", [(100, 8, 8), (70, 12, 4), (333, 20, 8), (96, 4, 24)])
 def test_tile_gemms_with_reductions_shorter_than_a_step(shape):
     """Tile forward / bwd_input with K (resp. N) below the 16-float step of the kernels: the lanes beyond the reduction
