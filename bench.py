@@ -513,7 +513,28 @@ def main():
                             "peak_GBps": HBM_PEAK_GBS, "frac": by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}}
 
         roofline, extra = None, {}
-        committed = {}
+        committed, stale = {}, []
+
+        def fresh(name, entry):
+            """A figure read back from profiles/ counts only while the kernel it was measured on is unchanged: every entry
+            carries the sha256 of its kernel source files (tools/make_committed.py); recomputed here (the GPU box has no
+            git -- the file contents are the identity).  Stale or unstamped entries are dropped and listed."""
+            import hashlib
+            files, want = entry.get("source_files"), entry.get("source_sha256")
+            if not files or not want:
+                stale.append(f"{name}: no source hash")
+                return False
+            h = hashlib.sha256()
+            try:
+                for f in files:
+                    h.update(open(os.path.join(ROOT, "coarsegrainingvae_amd", "csrc", f), "rb").read())
+            except OSError:
+                stale.append(f"{name}: source file missing")
+                return False
+            if h.hexdigest()[:16] != want:
+                stale.append(f"{name}: {', '.join(files)} changed since the measurement")
+                return False
+            return True
         try:
             committed = json.load(open(os.path.join(ROOT, "profiles", "committed_kernel_times.json"))).get(args.workload, {})
         except (OSError, ValueError):
@@ -532,7 +553,7 @@ def main():
                                    "plans / record sets / operand sets (no launch re-reads its own inputs from L2)" % (n_rot + 1))
             roofline["hbm"].update(achieved_GBps=by / (us * 1e-6) / 1e9, frac=by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS)
             c = committed.get("message_forward")
-            if c:
+            if c and fresh("committed_kernel_times.message_forward", c):
                 roofline["rocprofv3_committed"] = c      # {"avg_us": .., "source": "profiles/..."} of the same command
                 roofline["frac_at_rocprofv3_duration"] = fl / (c["avg_us"] * 1e-6) / 1e12 / F32_PEAK_TFLOPS
             extra["kernels"] = {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv)
@@ -549,8 +570,9 @@ def main():
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.workload, {})
             if F == 600 and frames == w["batch"]:
                 for obj in (roofline, extra.get("scatter_add"), extra.get("optimizer_step")):
-                    if obj and obj["kernel"] in pmc:
+                    if obj and obj["kernel"] in pmc and fresh("pmc_traffic." + obj["kernel"], pmc[obj["kernel"]]):
                         obj["traffic"] = pmc[obj["kernel"]]["traffic_bytes"]
+                        obj["traffic_source"] = pmc[obj["kernel"]].get("source", "profiles/pmc_traffic.json")
         except (OSError, ValueError):
             pass
         step_bytes = None
@@ -600,6 +622,8 @@ def main():
         if cpu:
             line["speedup_vs_cpu_baseline"] = value / cpu["value"]
         line.update(extra)
+        if stale:
+            line["stale_committed_entries_dropped"] = stale
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()

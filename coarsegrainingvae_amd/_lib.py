@@ -143,6 +143,7 @@ PROTOTYPES = {
     "cgv_adam_clip_step": (_i, [_p, _p, _p, _p, C.c_int64, _f, _f, _f, _f, _f, _f, _p, _f, _p, _p, _p]),
     "cgv_optim_prepare": (_i, [_p, C.c_int64, _f, _f, _f, _f, _p, _f, _p, _p, _p]),
     "cgv_adam_apply": (_i, [_p, _p, _p, _p, C.c_int64, _f, _f, _f, _f, _p, _p]),
+    "cgv_sgd_apply": (_i, [_p, _p, C.c_int64, _f, _p, _p]),
     "cgv_wgrad_gram": (_i, [_p, _i, _i, _p, _p, C.c_size_t, _p]),
     "cgv_wgrad_gram_workspace_bytes": (C.c_size_t, [_i]),
     "cgv_rank_update_supported": (_i, [_i, _i, _i]),

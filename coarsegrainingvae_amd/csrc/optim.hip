@@ -113,6 +113,25 @@ __global__ __launch_bounds__(256) void adam_update(float* __restrict__ p, const 
   }
 }
 
+__global__ __launch_bounds__(256) void sgd_update(float* __restrict__ p, const float* __restrict__ g, int64_t n, float lr,
+                                                  const float* __restrict__ state) {
+  if (state[ST_SKIP] != 0.f) return;
+  const float step = lr * state[ST_CLIP];                      // clip coefficient x gradient scale (1 / world)
+  const int64_t n4 = n >> 2;
+  float4* p4 = reinterpret_cast<float4*>(p);
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 pp = p4[i];
+    const float4 gg = g4[i];
+    pp.x = fmaf(-step, gg.x, pp.x); pp.y = fmaf(-step, gg.y, pp.y); pp.z = fmaf(-step, gg.z, pp.z); pp.w = fmaf(-step, gg.w, pp.w);
+    p4[i] = pp;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t j = (n4 << 2) + threadIdx.x;
+    p[j] = fmaf(-step, g[j], p[j]);
+  }
+}
+
 }  // namespace cgv
 
 extern "C" {
@@ -170,6 +189,17 @@ int cgv_adam_apply(float* p, const float* g, float* m, float* v, int64_t n, floa
   if (n == 0) return 0;
   launch_adam(p, g, m, v, n, lr, beta1, beta2, eps, state, (hipStream_t)stream);
   return cgv::check_launch("cgv_adam_apply");
+}
+
+/* torch.optim.SGD defaults (no momentum / weight decay; run_ala.py:43 `-optimizer sgd`): p -= lr * clip * g over one range,
+ * with the clip coefficient and the skip decision of cgv_optim_prepare's state (scripts/utils.py:145-157). */
+int cgv_sgd_apply(float* p, const float* g, int64_t n, float lr, const float* state, void* stream) {
+  CGV_REQUIRE(p && g && state && n >= 0, "bad argument");
+  CGV_REQUIRE(((((uintptr_t)p | (uintptr_t)g)) & 15) == 0, "range must be 16-byte aligned");
+  if (n == 0) return 0;
+  const int nb = (int)((((n + 3) >> 2) + 255) / 256 < 4096 ? (((n + 3) >> 2) + 255) / 256 : 4096);
+  hipLaunchKernelGGL(cgv::sgd_update, dim3(nb < 1 ? 1 : nb), dim3(256), 0, (hipStream_t)stream, p, g, n, lr, state);
+  return cgv::check_launch("cgv_sgd_apply");
 }
 
 }  // extern "C"

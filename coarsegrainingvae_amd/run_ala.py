@@ -217,9 +217,7 @@ def run(params) -> dict:
                         det=params["det"], invariantdec=params["invariantdec"], cg_mp=params["cg_mp"], seed=seed).to(device)
     if params["optimizer"] not in optim_dict:
         raise SystemExit("-optimizer must be one of " + ", ".join(optim_dict))
-    if params["optimizer"] != "adam":
-        raise SystemExit("the fused optimiser step implements Adam (the reference's documented runs use adam)")
-    trainer = Trainer(model, lr=params["lr"], beta=beta, gamma=params["gamma"], world_size=world)
+    trainer = Trainer(model, lr=params["lr"], beta=beta, gamma=params["gamma"], world_size=world, optimizer=params["optimizer"])
     use_graph = not params.get("no_hip_graph", False)                     # capture the step once, replay it on every batch
     min_lr, best, bad_epochs = 5e-8, None, 0                              # ReduceLROnPlateau(patience=2), run_ala.py:212-214
     early = EarlyStopping(patience=params["patience"])

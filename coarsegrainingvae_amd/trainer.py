@@ -328,12 +328,17 @@ class Trainer:
     def __init__(self, model, lr: float, beta: float, gamma: float, world_size: int = 1, group=None,
                  fused_optimizer: bool = True, betas=(0.9, 0.999), eps: float = 1e-8, max_norm: float = CLIP_NORM,
                  always_sync: bool = False, exchange: str = "auto", sync=None, defer_update: bool = False,
-                 rank_update: bool = True):
+                 rank_update: bool = True, optimizer: str = "adam"):
         """``exchange``: what the ranks exchange for the bead-level linear layers -- "operands" (all-gather of the
         rows that form the weight gradients, see OperandExchange), "gradients" (all-reduce everything), or "auto"
         (operands on the HIP path).  ``sync``: a GradSync-compatible object to use instead of one built from
         ``world_size`` / ``group`` (tests substitute a single-process stand-in for N ranks)."""
         self.model, self._lr, self.beta, self.gamma = model, lr, beta, gamma
+        if optimizer not in ("adam", "sgd"):
+            raise ValueError("optimizer must be 'adam' or 'sgd' (scripts/run_ala.py:43)")
+        # "sgd": torch.optim.SGD defaults (no momentum) through the same clip / skip machinery; every gradient is
+        # materialised (the rank update fuses ADAM's moment pass into the weight-gradient tiles)
+        self.optimizer = optimizer
         # defer_update: a step ends with the global norm / clip / skip decision (cgv_optim_prepare); the parameter pass
         # (cgv_adam_apply) opens the NEXT step -- the non-decoder ranges first, the decoder's range (82 % of the
         # parameters) on a side stream beside the prior / encoder forward, joined right before the decoder runs.  The
@@ -346,7 +351,7 @@ class Trainer:
         # the all-gathered rows of the operand exchange (world x rows per rank: _start_gathered_rank_update), so no rank
         # materialises these gradients either.  ``p.grad`` of those weights then holds stale data; pass
         # rank_update=False to materialise every gradient.
-        self.rank_update = bool(rank_update) and fused_optimizer and not self.defer_update
+        self.rank_update = bool(rank_update) and fused_optimizer and not self.defer_update and optimizer == "adam"
         self._rank_hi = 0             # arena floats [0, _rank_hi) belong to rank-update weights
         self._rank_numel = 0
         self._rank_step = None        # this step's (table, problems, blocks, lds, items, max rows) once the Gram launch is out
@@ -399,6 +404,10 @@ class Trainer:
 
     def _adam_apply(self, lo: int, hi: int):
         a = self.arena
+        if self.optimizer == "sgd":
+            _lib.call("cgv_sgd_apply", a.p.data_ptr() + 4 * lo, a.g.data_ptr() + 4 * lo, hi - lo, self._lr, _lib.ptr(self.state),
+                      _lib.stream_ptr())
+            return
         _lib.call("cgv_adam_apply", a.p.data_ptr() + 4 * lo, a.g.data_ptr() + 4 * lo, self.m.data_ptr() + 4 * lo,
                   self.v.data_ptr() + 4 * lo, hi - lo, self._lr, self.betas[0], self.betas[1], self.eps, _lib.ptr(self.state),
                   _lib.stream_ptr())
@@ -505,12 +514,18 @@ class Trainer:
             if dev.type != "cuda":
                 raise RuntimeError("the fused optimiser is a HIP kernel: it needs device tensors")
             lib = _lib.load()
-            self.m = torch.zeros_like(self.arena.p)
-            self.v = torch.zeros_like(self.arena.p)
+            if self.optimizer == "adam":
+                self.m = torch.zeros_like(self.arena.p)
+                self.v = torch.zeros_like(self.arena.p)
+            else:
+                self.m = self.v = None                       # plain SGD keeps no state
             self.state = torch.zeros(lib.cgv_optim_state_floats(), dtype=torch.float32, device=dev)
             self.partial = torch.empty(lib.cgv_optim_partial_floats(), dtype=torch.float32, device=dev)
         else:
-            self.torch_opt = torch.optim.Adam(live, lr=self.lr, betas=self.betas, eps=self.eps)
+            if self.optimizer == "sgd":
+                self.torch_opt = torch.optim.SGD(live, lr=self.lr)
+            else:
+                self.torch_opt = torch.optim.Adam(live, lr=self.lr, betas=self.betas, eps=self.eps)
 
     # ------------------------------------------------------------------ hipGraph capture of the whole step
     def capture(self, batch, warmup: int = 2, train: bool = True, eps: Optional[torch.Tensor] = None, _twin_of=None):

@@ -607,6 +607,9 @@ int cgv_optim_prepare(const float* g, int64_t n, float beta1, float beta2, float
                       void* stream);
 int cgv_adam_apply(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                    const float* state, void* stream);
+/* torch.optim.SGD defaults (scripts/run_ala.py:43, `-optimizer sgd`): p -= lr * clip * g over one range, clip coefficient and
+ * skip decision taken from the state cgv_optim_prepare wrote (scripts/utils.py:145-157). */
+int cgv_sgd_apply(float* p, const float* g, int64_t n, float lr, const float* state, void* stream);
 
 /* Rank-update layers (bead-level Dense / nn.Linear weights: M <= 64 operand rows against 0.36 - 3.2 M weights).  Their
  * weight gradient gW = g^T x is never written: cgv_wgrad_gram gives its squared Frobenius norm from the operands

@@ -887,6 +887,35 @@ def test_captured_step_replays_on_other_batches():
         assert_close(p, q, "parameter after replayed steps", 1e-5)
 
 
+def test_sgd_through_the_fused_step_equals_torch_sgd():
+    """Trainer(optimizer="sgd"): clip_grad_norm_(0.01) + torch.optim.SGD(lr) (scripts/run_ala.py:43, utils.py:151-157) as
+    cgv_optim_prepare + cgv_sgd_apply over the arena -- eager steps, then the captured step -- against the same trainer with
+    the library's clip + SGD (fused_optimizer=False)."""
+    from coarsegrainingvae_amd.trainer import Trainer
+    w = cg.data.WORKLOADS["dipeptide"]
+    batch = cg.synthetic_batch("dipeptide", n_frames=4, seed=3, device=DEV)
+
+    def run(fused):
+        model = cg.build_model(32, w["n_rbf"], w["atom_cutoff"], w["cg_cutoff"], 2, 2, w["n_cgs"], det=True, seed=11).to(DEV)
+        tr = Trainer(model, lr=0.05, beta=w["beta"], gamma=w["gamma"], fused_optimizer=fused, optimizer="sgd")
+        losses = [float(tr.step(batch)) for _ in range(3)]
+        if fused:
+            assert tr.m is None and tr._rank_hi == 0
+            tr.capture(batch, warmup=0)
+        losses += [float(tr.step(batch)) for _ in range(2)]
+        if fused:
+            assert tr.replays == 2
+        return losses, {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+    l_ref, p_ref = run(False)
+    l_fused, p_fused = run(True)
+    for a, b in zip(l_fused, l_ref):
+        assert abs(a - b) <= 1e-5 * abs(b), (l_fused, l_ref)
+    assert l_ref[-1] < l_ref[0]
+    for k in p_ref:
+        assert_close(p_fused[k], p_ref[k], k, 1e-5)
+
+
 def test_captured_fused_decoder_replays_on_other_bead_edge_counts():
     """The channel-group decoder kernels (csrc/decoder_layer.hip) stage the bead graph in LDS.  They stage the plan's
     CAPACITY of records and take the edge structure from rowptr on the device, so a captured step replays on batches

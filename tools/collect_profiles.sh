@@ -12,12 +12,24 @@ for w in chignolin dipeptide protein2000; do
   cp /tmp/prof_$w/bench_kernel_stats.csv gpurun_out/${tag}_${w}_kernel_stats.csv
   python tools/section_times.py $w > gpurun_out/${tag}_section_times_$w.txt 2>&1
 done
-bash tools/step_sequence.sh --no-extras --no-parity > /dev/null 2>&1
-cp gpurun_out/step_sequence.txt gpurun_out/${tag}_step_sequence_chignolin.txt
-python tools/dec_phase_probe.py > gpurun_out/${tag}_decoder_phase_clock.txt 2>&1
-# PMC: counters in their own runs (eager launches so that kernels appear as dispatches), chignolin
-for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -o p -- python bench.py --no-graph --no-cpu-baseline --no-parity --no-extras --steps 4 --warmup 2 --reps 1 > /tmp/pmc_$c.log 2>&1
-  python tools/pmc_summary.py /tmp/pmc_$c/p_counter_collection.csv equi_msg dec_ grouped_wgrad adam_update segment_reduce skinny_fwd > gpurun_out/${tag}_pmc_${c}_eager.txt 2>&1
+for w in chignolin dipeptide protein2000; do
+  bash tools/step_sequence.sh --workload $w --no-extras --no-parity > /dev/null 2>&1
+  cp gpurun_out/step_sequence.txt gpurun_out/${tag}_step_sequence_$w.txt
 done
+python tools/dec_phase_probe.py > gpurun_out/${tag}_decoder_phase_clock.txt 2>&1
+# PMC: counters in their own runs (eager launches so that kernels appear as dispatches), every workload
+for w in chignolin dipeptide protein2000; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_${c}_$w -o p -- python bench.py --workload $w --no-graph --no-cpu-baseline --no-parity --no-extras --steps 4 --warmup 2 --reps 1 > /tmp/pmc_${c}_$w.log 2>&1
+    python tools/pmc_summary.py /tmp/pmc_${c}_$w/p_counter_collection.csv equi_msg dec_ grouped_wgrad adam_update sumsq_partial optim_finalize segment_reduce skinny_fwd tile_ pseudo_ > gpurun_out/${tag}_pmc_${c}_$w.txt 2>&1
+  done
+done
+# FETCH_SIZE / WRITE_SIZE against known byte counts, by access width (tools/probes/fetch_calib.hip)
+if [ -x tools/probes/fetch_calib ]; then
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $c --output-format csv -d /tmp/fc_$c -o p -- tools/probes/fetch_calib > /tmp/fc_$c.log 2>&1
+    { grep "known bytes" /tmp/fc_$c.log; python tools/pmc_summary.py /tmp/fc_$c/p_counter_collection.csv; } >> gpurun_out/${tag}_fetch_calibration.txt
+  done
+fi
+python tools/dp_cost_probe.py > gpurun_out/${tag}_dp_cost_probe.txt 2>&1
 ls -la gpurun_out | grep ${tag}_ | wc -l
