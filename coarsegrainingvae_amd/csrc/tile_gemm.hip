@@ -535,14 +535,20 @@ int cgv_tile_linear_fwd(const float* x, const float* W, const float* bias, float
   // 2000 x 600: 24 vs 30 -- a lone block per CU still spends ~1 us per slab on its read -> MFMA -> write -> barrier chain).
   // cgv_set_option(CGV_OPT_TILE_FWD_LDS_MIN, 1): the one-slab kernel for every shape, 3: the ring kernel (tests / A-B)
   const int slabs32 = (K + 31) / 32;
-  const bool ring_ok = aligned16 && (slabs32 == 19 || slabs32 == 38) && lds_min != 1;
+  const bool ring_ok = aligned16 && (slabs32 == 19 || slabs32 == 38) && lds_min != 1 && !(lds_min >= 5 && lds_min <= 7);
   if (ring_ok && (tiles64 >= lds_min || lds_min == 3)) {
     const dim3 grid((N + 63) / 64, (M + 63) / 64);
     if (slabs32 == 19) hipLaunchKernelGGL((cgv::tile_fwd_ring_k<19>), grid, dim3(256), 0, st, x, W, bias, y, z, M, N, K, act);
     else hipLaunchKernelGGL((cgv::tile_fwd_ring_k<38>), grid, dim3(256), 0, st, x, W, bias, y, z, M, N, K, act);
-  } else if (tiles64 >= lds_min && (M >= 1024 || lds_min <= 1) && aligned16)
+  } else if (tiles64 >= lds_min && (M >= 1024 || lds_min <= 1) && aligned16 && !(lds_min >= 5 && lds_min <= 7))
     hipLaunchKernelGGL(cgv::tile_fwd_lds_k, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, st, x, W, bias, y, z, M, N, K,
                        act);
+  else if (lds_min == 5)                       /* A/B: 32 x 64 tiles, 16 waves */
+    hipLaunchKernelGGL((cgv::tile_fwd_k<1, 2, 8>), dim3((N + 63) / 64, (M + 31) / 32), dim3(1024), 0, st, x, W, bias, y, z, M, N, K, act);
+  else if (lds_min == 6)                       /* A/B: 64 x 32 tiles, 16 waves */
+    hipLaunchKernelGGL((cgv::tile_fwd_k<2, 1, 8>), dim3((N + 31) / 32, (M + 63) / 64), dim3(1024), 0, st, x, W, bias, y, z, M, N, K, act);
+  else if (lds_min == 7)                       /* A/B: 64 x 64 tiles, 16 waves */
+    hipLaunchKernelGGL((cgv::tile_fwd_k<2, 2, 4>), dim3((N + 63) / 64, (M + 63) / 64), dim3(1024), 0, st, x, W, bias, y, z, M, N, K, act);
   else if (tiles32 >= 2048)                    // enough work for several 64 x 64 tiles on every CU (measured: no gain below)
     hipLaunchKernelGGL((cgv::tile_fwd_k<2, 2, 4>), dim3((N + 63) / 64, (M + 63) / 64), dim3(1024), 0, st, x, W, bias, y, z, M,
                        N, K, act);
@@ -559,9 +565,16 @@ static int tile_bwd_input_launch(const float* g, const float* z, int act, const 
   const int blocks32 = kt * ((M + 31) / 32);
   const int blocks16 = kt * ((M + 15) / 16);
   int waves = 8;
-  if (const int o = cgv::option(CGV_OPT_BWD_INPUT_WAVES); o > 0) waves = o;          // experiments only
+  if (const int o = cgv::option(CGV_OPT_BWD_INPUT_WAVES); o > 0 && o != 32) waves = o;          // experiments only
   else if (blocks16 < 128 && N >= 1024) waves = 16;
-  if (blocks32 >= 512)                    // enough 32-row tiles to fill the chip: halve the weight re-reads
+  if (cgv::option(CGV_OPT_BWD_INPUT_WAVES) == 32)          /* A/B: 32-row tiles, 8 waves */
+    hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 8>), dim3(kt, (M + 31) / 32), dim3(512), 0, st, g, W, gx, M, N, K, z, act);
+  else if (blocks32 >= 200 && blocks32 < 512 && waves == 8)
+    // 200 .. 511 32-row tiles (704 rows x 600 / 1200 columns): still 32-row tiles, with the reduction split over 8 waves --
+    // half the weight re-reads of the 16-row tiles (704 x 1800 x 600: 22.9 against 25.0 us, 704 x 5400: 54.6 / 64.1;
+    // at 332 rows the 16-row tiles win, 14.5 against 22.1 us: tools/gemm_shapes.py)
+    hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 8>), dim3(kt, (M + 31) / 32), dim3(512), 0, st, g, W, gx, M, N, K, z, act);
+  else if (blocks32 >= 512)               // enough 32-row tiles to fill the chip: halve the weight re-reads
     hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 4>), dim3(kt, (M + 31) / 32), dim3(256), 0, st, g, W, gx, M, N, K, z, act);
   else if (waves == 16)                   // few output tiles and a long reduction (96 bead rows x 5400 columns: 60 blocks):
     // 16 waves per block split it -- 60 blocks of 8 waves left three quarters of the chip idle (17.8 us per call)

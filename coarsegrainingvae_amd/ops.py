@@ -429,7 +429,10 @@ def _adjacent(first, second):
 def _dense_fwd(x, W, b, y, z, M, N, K, act, st):
     """z = x W^T + b, y = act(z) on the kernel the Dense layers would pick for this shape (primitives._gemm_mode)."""
     lib = _lib.load()
-    name = "cgv_skinny_linear_fwd" if lib.cgv_skinny_supported(M, N, K) else "cgv_tile_linear_fwd"
+    # up to 64 rows the weight-streaming kernel; 65 - 128 rows and at most 1200 outputs it still beats the tiles (96 rows:
+    # 600 x 1200 6.3 against 10.5 - 13 us -- the rule of primitives._LinearFn.forward, which the fused UpdateBlock missed)
+    few_rows = M <= 128 and N <= 1200 and lib.cgv_skinny_fwd_supported(M, N, K) and (b is None or b.data_ptr() % 16 == 0)
+    name = "cgv_skinny_linear_fwd" if (lib.cgv_skinny_supported(M, N, K) or few_rows) else "cgv_tile_linear_fwd"
     _lib.call(name, _lib.ptr(x) if torch.is_tensor(x) else x, _lib.ptr(W), _lib.ptr(b), _lib.ptr(y) if torch.is_tensor(y) else y,
               _lib.ptr(z), M, N, K, act, st)
 

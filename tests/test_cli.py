@@ -112,6 +112,6 @@ def test_cli_optimizer_sgd_runs_through_the_fused_step(tmp_path, capsys, monkeyp
     """``-optimizer sgd`` (scripts/run_ala.py:43): plain SGD through the fused clip / skip machinery (cgv_sgd_apply), captured."""
     monkeypatch.chdir(tmp_path)
     run_ala.main("-logdir run -device 0 -dataset dipeptide -n_cgs 3 -batch_size 8 -ndata 40 -nepochs 2 -atom_cutoff 8.5 "
-                 "-cg_cutoff 9.5 -beta 0.05 -gamma 25.0 -dec_nconv 2 -enc_nconv 2 -lr 0.01 -n_basis 32 -n_rbf 8 -optimizer sgd".split())
+                 "-cg_cutoff 9.5 -beta 0.05 -gamma 25.0 -dec_nconv 2 -enc_nconv 2 -lr 0.01 -n_basis 32 -n_rbf 8 -optimizer sgd --synthetic".split())
     summary = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
     assert summary["epochs"] == 2 and not summary["failed"] and summary["graph_replays"] > 0
