@@ -114,6 +114,8 @@ PROTOTYPES = {
     "cgv_tile_linear_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "cgv_tile_linear_bwd_input": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "cgv_tile_linear_bwd_input_act": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "cgv_tile_linear_bwd_input_act_add": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "cgv_skinny_linear_bwd_input_add": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
     "cgv_tile_linear_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "cgv_wgrad_record_bytes": (_i, []),
     "cgv_wgrad_plan": (_i, [_i, _i, _i, _p, _p, _p]),

@@ -47,6 +47,12 @@ class InvariantMessage(nn.Module):
     def node_features(self, s_j):
         return self.inv_dense(s_j)
 
+    def node_features_fork(self, s_j):
+        """(inv_dense(s_j), alias of s_j): the block's edge kernel reads the state through the alias, so that both of its
+        gradients meet inside the first Dense's backward-input kernel (primitives.Dense.forward_fork)."""
+        a, s_alias = self.inv_dense[0].forward_fork(s_j)
+        return self.inv_dense[1](a), s_alias
+
     def forward(self, s_j, dist, nbrs):
         return self.inv_dense(s_j)[nbrs[:, 1]] * self.dist_embed(dist)
 
@@ -79,8 +85,11 @@ class EquiMessageBlock(nn.Module):
         im = self.inv_message
         plan, geom = _resolve(plan, geom, nbrs, s_j.shape[0], r_ij, im.n_rbf, im.cutoff)
         Wd, bd = im.dist_embed.filter_params()
-        return ops.equi_message(im.node_features(s_j), v_j, Wd, bd, plan, geom, self.with_dv,
-                                s_j if residual else None, v_j if residual else None)
+        if residual:
+            phi, s_res = im.node_features_fork(s_j)              # the residual reads the state through the fork
+        else:
+            phi, s_res = im.node_features(s_j), None
+        return ops.equi_message(phi, v_j, Wd, bd, plan, geom, self.with_dv, s_res, v_j if residual else None)
 
 
 class EquiMessageCross(nn.Module):
@@ -130,8 +139,10 @@ class ContractiveMessageBlock(nn.Module):
         self.with_dv = True
 
     def forward(self, s_i, v_i, r_iI, mapping, plan: Optional[EdgePlan] = None,
-                geom: Optional[EdgeGeometry] = None, residual=None):
-        """``residual=(H, V)`` (bead-shaped) returns (H + dS, V + dV) from the same launch."""
+                geom: Optional[EdgeGeometry] = None, residual=None, chain: bool = False):
+        """``residual=(H, V)`` (bead-shaped) returns (H + dS, V + dV) from the same launch.  ``chain=True`` also returns an
+        alias of ``s_i`` for the NEXT consumer of the atom state (the following layer's message block): the gradients of a
+        state that feeds several blocks then travel along the chain of first-Dense forks, no accumulation launches."""
         if plan is None:
             n_beads = int(mapping.max().item()) + 1      # dim_size inferred like torch_scatter does
             plan = EdgePlan.from_mapping(mapping, n_beads)
@@ -139,6 +150,9 @@ class ContractiveMessageBlock(nn.Module):
             geom = EdgeGeometry(plan, self.n_rbf, self.cutoff, r_edges=r_iI)
         Wd, bd = self.dist_embed.filter_params()
         s_res, v_res = residual if residual is not None else (None, None)
+        if chain:
+            a, s_alias = self.inv_dense[0].forward_fork(s_i)
+            return ops.equi_message(self.inv_dense[1](a), v_i, Wd, bd, plan, geom, self.with_dv, s_res, v_res) + (s_alias,)
         return ops.equi_message(self.inv_dense(s_i), v_i, Wd, bd, plan, geom, self.with_dv, s_res, v_res)
 
 
@@ -159,7 +173,8 @@ class EquiMessagePsuedo(nn.Module):
         im = self.inv_message
         plan, geom = _resolve(plan, geom, nbrs, s_j.shape[0], r_ij, im.n_rbf, im.cutoff)
         Wd, bd = im.dist_embed.filter_params()
-        return ops.pseudo_message(im.node_features(s_j), s_j, sbar_j, v_j, vbar_j, Wd, bd, plan, geom, residual)
+        phi, s_alias = im.node_features_fork(s_j)                # the edge kernel (q_0 s_i, residual) reads s_j through the fork
+        return ops.pseudo_message(phi, s_alias, sbar_j, v_j, vbar_j, Wd, bd, plan, geom, residual)
 
 
 class UpdateBlock(nn.Module):

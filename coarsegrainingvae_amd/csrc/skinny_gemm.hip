@@ -1443,12 +1443,12 @@ static void launch_fwd(dim3 grid, int waves, hipStream_t st, const float* x, con
 }
 template <int MB>
 static void launch_bwd_input(hipStream_t st, const float* gy, const float* z, const float* W, float* gx, float* part,
-                             int M, int N, int K, int act, int KT, int NS, int rpb) {
+                             int M, int N, int K, int act, int KT, int NS, int rpb, const float* add = nullptr) {
   hipLaunchKernelGGL((skinny_bwd_input_k<MB>), dim3(KT * NS), dim3(256), 0, st, gy, z, W, gx, part, M, N, K, act, KT, NS,
                      rpb);
   if (NS > 1) {
     const int n4 = M * K / 4;
-    hipLaunchKernelGGL(skinny_bwd_input_reduce_k, dim3((4 * n4 + 255) / 256), dim3(256), 0, st, part, gx, n4, NS);
+    hipLaunchKernelGGL(skinny_bwd_input_reduce_k, dim3((4 * n4 + 255) / 256), dim3(256), 0, st, part, gx, n4, NS, add, 0ll);
   }
 }
 
@@ -1552,6 +1552,33 @@ int cgv_skinny_linear_bwd_input(const float* gy, const float* z, const float* W,
     default: cgv::launch_bwd_input<8>(st, gy, z, W, gx, part, M, N, K, act, KT, NS, rpb); break;
   }
   return cgv::check_launch("cgv_skinny_linear_bwd_input");
+}
+
+/* gx = add + (gy * act'(z)) W: the accumulation of a second gradient of the layer's input (the input also feeds the
+ * message kernel / the residual: blocks.py) rides in the reduction launch of the row-split product.  Only where that
+ * launch exists (more than one row slice): CGV_E_UNSUPPORTED otherwise -- the caller then adds separately. */
+int cgv_skinny_linear_bwd_input_add(const float* gy, const float* z, const float* W, const float* add, float* gx, int M, int N,
+                                    int K, int act, void* ws, size_t ws_bytes, void* stream) {
+  CGV_REQUIRE(gy && W && gx && add && ws, "null pointer");
+  CGV_REQUIRE(act == 0 || (act >= 1 && act <= cgv::CGV_ACT_MAX && z), "act != 0 needs the saved pre-activation z");
+  CGV_REQUIRE(cgv_skinny_bwd_input_supported(M, N, K), "unsupported shape (need M <= 128, N % 4 == 0, K % 4 == 0)");
+  CGV_REQUIRE(((((uintptr_t)gx) | ((uintptr_t)W) | ((uintptr_t)ws) | ((uintptr_t)add)) & 15) == 0, "gx, W, ws, add must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  int KT, NS, rpb;
+  cgv::bwd_input_plan(N, K, true, &KT, &NS, &rpb);
+  if (NS <= 1) { cgv::set_error("cgv_skinny_linear_bwd_input_add: one row slice, no reduction launch to carry the add"); return CGV_E_UNSUPPORTED; }
+  CGV_REQUIRE(ws_bytes >= cgv_skinny_bwd_input_workspace_bytes(M, N, K), "workspace too small");
+  float* part = reinterpret_cast<float*>(ws);
+  switch ((M + 15) / 16) {
+    case 1: cgv::launch_bwd_input<1>(st, gy, z, W, gx, part, M, N, K, act, KT, NS, rpb, add); break;
+    case 2: cgv::launch_bwd_input<2>(st, gy, z, W, gx, part, M, N, K, act, KT, NS, rpb, add); break;
+    case 3: cgv::launch_bwd_input<3>(st, gy, z, W, gx, part, M, N, K, act, KT, NS, rpb, add); break;
+    case 4: cgv::launch_bwd_input<4>(st, gy, z, W, gx, part, M, N, K, act, KT, NS, rpb, add); break;
+    case 5:
+    case 6: cgv::launch_bwd_input<6>(st, gy, z, W, gx, part, M, N, K, act, KT, NS, rpb, add); break;
+    default: cgv::launch_bwd_input<8>(st, gy, z, W, gx, part, M, N, K, act, KT, NS, rpb, add); break;
+  }
+  return cgv::check_launch("cgv_skinny_linear_bwd_input_add");
 }
 
 /* Two backward-input products of ONE shape in one launch pair (+ one reduction launch): gx_j = (gy_j * act_j'(z_j)) W_j for

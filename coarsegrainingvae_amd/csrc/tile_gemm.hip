@@ -354,7 +354,8 @@ __global__ __launch_bounds__(256, 2) void tile_fwd_ring_k(const float* __restric
 template <int MB, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void tile_bwd_input_k(const float* __restrict__ g, const float* __restrict__ W,
                                                         float* __restrict__ gx, int M, int N, int K,
-                                                        const float* __restrict__ z, int act) {
+                                                        const float* __restrict__ z, int act,
+                                                        const float* __restrict__ add = nullptr) {
   __shared__ float red[WAVES - 1][MB * 4][4][64];    // [wave-1][mb*4 + s][reg][lane]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -446,6 +447,10 @@ __global__ __launch_bounds__(64 * WAVES) void tile_bwd_input_k(const float* __re
         o[s] = acc[mb][s][r];
 #pragma unroll
         for (int w = 0; w < WAVES - 1; ++w) o[s] += red[w][t][r][lane];
+      }
+      if (add) {                                     // a second gradient of the same input (blocks.py: fork of the first Dense)
+        const float4 a4 = *reinterpret_cast<const float4*>(add + (size_t)m * K + kcol);
+        o[0] += a4.x; o[1] += a4.y; o[2] += a4.z; o[3] += a4.w;
       }
       *reinterpret_cast<float4*>(gx + (size_t)m * K + kcol) = make_float4(o[0], o[1], o[2], o[3]);
     }
@@ -559,7 +564,7 @@ int cgv_tile_linear_fwd(const float* x, const float* W, const float* bias, float
 }
 
 static int tile_bwd_input_launch(const float* g, const float* z, int act, const float* W, float* gx, int M, int N, int K,
-                                 void* stream, const char* what) {
+                                 void* stream, const char* what, const float* add = nullptr) {
   hipStream_t st = (hipStream_t)stream;
   const int kt = (K + 63) / 64;
   const int blocks32 = kt * ((M + 31) / 32);
@@ -568,19 +573,19 @@ static int tile_bwd_input_launch(const float* g, const float* z, int act, const 
   if (const int o = cgv::option(CGV_OPT_BWD_INPUT_WAVES); o > 0 && o != 32) waves = o;          // experiments only
   else if (blocks16 < 128 && N >= 1024) waves = 16;
   if (cgv::option(CGV_OPT_BWD_INPUT_WAVES) == 32)          /* A/B: 32-row tiles, 8 waves */
-    hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 8>), dim3(kt, (M + 31) / 32), dim3(512), 0, st, g, W, gx, M, N, K, z, act);
+    hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 8>), dim3(kt, (M + 31) / 32), dim3(512), 0, st, g, W, gx, M, N, K, z, act, add);
   else if (blocks32 >= 200 && blocks32 < 512 && waves == 8)
     // 200 .. 511 32-row tiles (704 rows x 600 / 1200 columns): still 32-row tiles, with the reduction split over 8 waves --
     // half the weight re-reads of the 16-row tiles (704 x 1800 x 600: 22.9 against 25.0 us, 704 x 5400: 54.6 / 64.1;
     // at 332 rows the 16-row tiles win, 14.5 against 22.1 us: tools/gemm_shapes.py)
-    hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 8>), dim3(kt, (M + 31) / 32), dim3(512), 0, st, g, W, gx, M, N, K, z, act);
+    hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 8>), dim3(kt, (M + 31) / 32), dim3(512), 0, st, g, W, gx, M, N, K, z, act, add);
   else if (blocks32 >= 512)               // enough 32-row tiles to fill the chip: halve the weight re-reads
-    hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 4>), dim3(kt, (M + 31) / 32), dim3(256), 0, st, g, W, gx, M, N, K, z, act);
+    hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 4>), dim3(kt, (M + 31) / 32), dim3(256), 0, st, g, W, gx, M, N, K, z, act, add);
   else if (waves == 16)                   // few output tiles and a long reduction (96 bead rows x 5400 columns: 60 blocks):
     // 16 waves per block split it -- 60 blocks of 8 waves left three quarters of the chip idle (17.8 us per call)
-    hipLaunchKernelGGL((cgv::tile_bwd_input_k<1, 16>), dim3(kt, (M + 15) / 16), dim3(1024), 0, st, g, W, gx, M, N, K, z, act);
+    hipLaunchKernelGGL((cgv::tile_bwd_input_k<1, 16>), dim3(kt, (M + 15) / 16), dim3(1024), 0, st, g, W, gx, M, N, K, z, act, add);
   else
-    hipLaunchKernelGGL((cgv::tile_bwd_input_k<1, 8>), dim3(kt, (M + 15) / 16), dim3(512), 0, st, g, W, gx, M, N, K, z, act);
+    hipLaunchKernelGGL((cgv::tile_bwd_input_k<1, 8>), dim3(kt, (M + 15) / 16), dim3(512), 0, st, g, W, gx, M, N, K, z, act, add);
   return cgv::check_launch(what);
 }
 
@@ -599,6 +604,16 @@ int cgv_tile_linear_bwd_input_act(const float* gy, const float* z, const float* 
   CGV_REQUIRE(cgv_tile_supported(M, N, K), "unsupported shape (need N % 4 == 0, K % 4 == 0)");
   CGV_REQUIRE(((((uintptr_t)gy | (uintptr_t)z | (uintptr_t)W | (uintptr_t)gx)) & 15) == 0, "operands must be 16-byte aligned");
   return tile_bwd_input_launch(gy, act ? z : nullptr, act, W, gx, M, N, K, stream, "cgv_tile_linear_bwd_input_act");
+}
+
+/* gx = add + (gy * act'(z)) W: as above with a second gradient of the same input added in the store epilogue. */
+int cgv_tile_linear_bwd_input_act_add(const float* gy, const float* z, const float* W, const float* add, float* gx, int M, int N,
+                                      int K, int act, void* stream) {
+  CGV_REQUIRE(gy && W && gx && add, "null pointer");
+  CGV_REQUIRE(act == 0 || (act >= 1 && act <= cgv::CGV_ACT_MAX && z), "act != 0 needs the saved pre-activation z");
+  CGV_REQUIRE(cgv_tile_supported(M, N, K), "unsupported shape (need N % 4 == 0, K % 4 == 0)");
+  CGV_REQUIRE(((((uintptr_t)gy | (uintptr_t)z | (uintptr_t)W | (uintptr_t)gx | (uintptr_t)add)) & 15) == 0, "operands must be 16-byte aligned");
+  return tile_bwd_input_launch(gy, act ? z : nullptr, act, W, gx, M, N, K, stream, "cgv_tile_linear_bwd_input_act_add", add);
 }
 
 int cgv_tile_linear_wgrad(const float* g, const float* x, float* gW, int M, int N, int K, int accumulate, void* stream) {

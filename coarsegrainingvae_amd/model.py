@@ -192,7 +192,9 @@ class EquiEncoder(nn.Module):
             if i == 0:
                 H = ops.scatter_mean(h, graph.mapping, plan=graph.a2b)
                 V = ops.scatter_mean(v, graph.mapping, plan=graph.a2b)
-            H, V = self.cgmessage_layers[i](h, v, None, graph.mapping, plan=graph.a2b, geom=geom_c, residual=(H, V))
+            # chain: the atom state also feeds the next layer's message block -- it goes on through the fork of this block's
+            # first Dense, so its gradients meet inside that layer's backward-input kernel (blocks.ContractiveMessageBlock)
+            H, V, h = self.cgmessage_layers[i](h, v, None, graph.mapping, plan=graph.a2b, geom=geom_c, residual=(H, V), chain=True)
         return H, h
 
 

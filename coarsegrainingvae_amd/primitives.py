@@ -306,7 +306,19 @@ class _LinearFn(torch.autograd.Function):
     it, trainer.py) -- deferred to ONE grouped launch per step when the trainer's queue is active."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act):
+    def forward(ctx, x, weight, bias, act, fork=False):
+        """``fork=True`` returns (y, x_alias): the layer's input handed on to a second consumer (the block's message kernel /
+        residual, or the next block of a chain).  Its gradient then comes back HERE and is summed with this layer's own
+        input gradient in the epilogue of the backward-input product -- autograd would run a separate add launch for a
+        state that feeds two nodes (6 per chignolin step, ~20 per dipeptide step)."""
+        y = _LinearFn._forward(ctx, x, weight, bias, act)
+        ctx.set_materialize_grads(False)
+        if fork:
+            return y, x.view_as(x)
+        return y
+
+    @staticmethod
+    def _forward(ctx, x, weight, bias, act):
         x2 = x.reshape(-1, x.shape[-1])
         ctx.params = (weight, bias)
         ctx.act = act
@@ -350,10 +362,33 @@ class _LinearFn(torch.autograd.Function):
         return z
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, g_alias=None):
+        if gy is None:                                       # only the forked alias was used downstream
+            return g_alias, None, None, None, None
+        out = _LinearFn._backward(ctx, gy, g_alias)
+        return out + (None,)
+
+    @staticmethod
+    def _backward(ctx, gy, add):
+        """``add``: gradient of the forked input alias (same shape as x) or None; every path below either hands it to
+        its backward-input kernel (``fused``) or adds it at the end."""
+        gx, gw, gb, _none = _LinearFn._backward_core(ctx, gy, add)
+        return gx, gw, gb, None
+
+    @staticmethod
+    def _backward_core(ctx, gy, add):
         x, weight, z = ctx.saved_tensors
         w_param, b_param = ctx.params
         act = ctx.act
+        add2 = add.reshape(-1, add.shape[-1]) if add is not None else None
+        if add2 is not None and not (add2.is_contiguous() and add2.data_ptr() % 16 == 0 and add2.dtype == torch.float32):
+            add2 = add2.contiguous().float()
+        fused = [False]                                      # did a kernel take ``add``?
+
+        def finish(gx):
+            if gx is not None and add is not None and not fused[0]:
+                gx = gx + add.reshape(gx.shape)
+            return gx
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         need_b = b_param is not None and ctx.needs_input_grad[2]
         if ctx.mode == "library":
@@ -370,7 +405,7 @@ class _LinearFn(torch.autograd.Function):
             gx = gy.matmul(weight) if need_x else None
             gw = _direct_grad(w_param, lambda out: torch.mm(gy2.t(), x2, out=out), lambda: gy2.t().mm(x2)) if need_w else None
             gb = _direct_grad(b_param, lambda out: torch.sum(gy2, 0, out=out), lambda: gy2.sum(0)) if need_b else None
-            return gx, gw, gb, None
+            return finish(gx) if need_x else add, gw, gb, None
         gy2 = gy.reshape(-1, gy.shape[-1]).contiguous()
         M, K = x.shape
         N = weight.shape[0]
@@ -392,11 +427,15 @@ class _LinearFn(torch.autograd.Function):
                     elif M <= 128 and N >= 4096 and _lib.load().cgv_skinny_bwd_input_supported(M, N, K):
                         # few rows, a very long reduction (96 bead rows x 5400 columns): the row-split kernel spreads the
                         # weight over ~300 blocks (28.5 us + reduce against 43.6 us; tools/bwd_input_bench.py)
-                        skinny_bwd_input(gy2, z if act != ACT_NONE else None, weight, gx, M, N, K, act)
+                        fused[0] = skinny_bwd_input(gy2, z if act != ACT_NONE else None, weight, gx, M, N, K, act, add=add2)
+                    elif add2 is not None:
+                        _lib.call("cgv_tile_linear_bwd_input_act_add", _lib.ptr(gy2), _lib.ptr(z) if act != ACT_NONE else None,
+                                  _lib.ptr(weight), _lib.ptr(add2), _lib.ptr(gx), M, N, K, act, st)
+                        fused[0] = True
                     else:
                         _lib.call("cgv_tile_linear_bwd_input_act", _lib.ptr(gy2), _lib.ptr(z) if act != ACT_NONE else None,
                                   _lib.ptr(weight), _lib.ptr(gx), M, N, K, act, st)
-                    gx = gx.reshape(gy.shape[:-1] + (K,))
+                    gx = finish(gx.reshape(gy.shape[:-1] + (K,)))
                 w_param._cgv_exch = w_param._cgv_rank = (M, N, K)
                 tw, acc_w, _ = _grad_target(w_param, weight)
                 tb, acc_b = None, acc_w
@@ -406,7 +445,7 @@ class _LinearFn(torch.autograd.Function):
                 if acc_b != acc_w:
                     raise RuntimeError("weight and bias of one layer disagree on first-write / accumulate state")
                 wgrad_queue.enqueue(gy2, x, z if act != ACT_NONE else None, act, tw, tb, acc_w)
-                return gx, None, None, None
+                return (gx if need_x else add), None, None, None
             # g = gy * Swish'(z) and the bias column sums in one launch, then two reduction-split MFMA GEMMs
             g2 = torch.empty_like(gy2) if act != ACT_NONE else gy2
             tb, acc_b, gb = _grad_target(b_param, b_param) if need_b else (None, False, None)
@@ -416,7 +455,7 @@ class _LinearFn(torch.autograd.Function):
             if need_x:
                 gx = torch.empty(M, K, dtype=torch.float32, device=gy.device)
                 _lib.call("cgv_tile_linear_bwd_input", _lib.ptr(g2), _lib.ptr(weight), _lib.ptr(gx), M, N, K, st)
-                gx = gx.reshape(gy.shape[:-1] + (K,))
+                gx = finish(gx.reshape(gy.shape[:-1] + (K,)))
             if need_w:
                 tw, acc_w, gw = _grad_target(w_param, weight)
                 if wgrad_queue.active and gw is None and lib_has_rows(M, N, K):
@@ -424,18 +463,23 @@ class _LinearFn(torch.autograd.Function):
                     wgrad_queue.enqueue(g2, x, None, ACT_NONE, tw, None, acc_w)
                 else:
                     _lib.call("cgv_tile_linear_wgrad", _lib.ptr(g2), _lib.ptr(x), _lib.ptr(tw), M, N, K, int(acc_w), st)
-            return gx, gw, gb, None
+            return (gx if need_x else add), gw, gb, None
         if need_x:
             gx = torch.empty(M, K, dtype=torch.float32, device=gy.device)
             if M > 32 and N <= 1024 and gy2.data_ptr() % 16 == 0 and _lib.load().cgv_tile_supported(M, N, K):
                 # many bead rows, a short reduction (64 beads of the 2000-atom config, 600 outputs): one launch of the tile
                 # kernel (8.7 us; 6.2 without activation) against the row-split kernel + its reduction (12.9 / 12.1 us;
                 # tools/bwd_input_bench.py) -- from 1200 outputs on the row split wins again (13.0 against 13.8 us)
-                _lib.call("cgv_tile_linear_bwd_input_act", _lib.ptr(gy2), _lib.ptr(z) if act != ACT_NONE else None,
-                          _lib.ptr(weight), _lib.ptr(gx), M, N, K, act, st)
+                if add2 is not None:
+                    _lib.call("cgv_tile_linear_bwd_input_act_add", _lib.ptr(gy2), _lib.ptr(z) if act != ACT_NONE else None,
+                              _lib.ptr(weight), _lib.ptr(add2), _lib.ptr(gx), M, N, K, act, st)
+                    fused[0] = True
+                else:
+                    _lib.call("cgv_tile_linear_bwd_input_act", _lib.ptr(gy2), _lib.ptr(z) if act != ACT_NONE else None,
+                              _lib.ptr(weight), _lib.ptr(gx), M, N, K, act, st)
             else:
-                skinny_bwd_input(gy2, z, weight, gx, M, N, K, act)
-            gx = gx.reshape(gy.shape[:-1] + (K,))
+                fused[0] = skinny_bwd_input(gy2, z, weight, gx, M, N, K, act, add=add2)
+            gx = finish(gx.reshape(gy.shape[:-1] + (K,)))
         if need_w:
             # row count / shape of this layer's weight-gradient problem: the data-parallel trainer sorts the layers
             # whose operand rows are cheaper to exchange than their gradients to the front of the arena
@@ -449,7 +493,7 @@ class _LinearFn(torch.autograd.Function):
             wgrad_queue.enqueue(gy2, x, z, act, tw, tb, acc_w)
             if not (wgrad_queue.active and gw is None and gb is None):
                 wgrad_queue.flush()                          # immediate mode (no trainer / not arena-managed)
-        return gx, gw, gb, None
+        return (gx if need_x else add), gw, gb, None
 
 
 class _PairLinearFn(torch.autograd.Function):
@@ -571,13 +615,24 @@ def lib_tile_ok(M, N, K) -> bool:
     return bool(_lib.load().cgv_tile_supported(M, N, K))
 
 
-def skinny_bwd_input(gy2, z, weight, gx, M, N, K, act, stream=None):
-    """gx[M,K] = (gy2 * act'(z)) @ weight through cgv_skinny_linear_bwd_input with its row-split workspace."""
+def skinny_bwd_input(gy2, z, weight, gx, M, N, K, act, stream=None, add=None) -> bool:
+    """gx[M,K] = (gy2 * act'(z)) @ weight through cgv_skinny_linear_bwd_input with its row-split workspace.  ``add``
+    [M,K]: a second gradient of the same input, summed in the product's reduction launch where there is one -- returns
+    True when ``add`` went in (False: the caller still has to add it)."""
     lib = _lib.load()
     nbytes = lib.cgv_skinny_bwd_input_workspace_bytes(M, N, K)
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=gx.device)
+    if add is not None and add.is_contiguous() and add.data_ptr() % 16 == 0 and nbytes > 0:
+        rc = lib.cgv_skinny_linear_bwd_input_add(_lib.ptr(gy2), _lib.ptr(z) if z is not None else None, _lib.ptr(weight), _lib.ptr(add),
+                                                 _lib.ptr(gx), M, N, K, act, ws.data_ptr(), nbytes,
+                                                 stream if stream is not None else _lib.stream_ptr())
+        if rc == 0:
+            return True
+        if rc != -2:                                       # CGV_E_UNSUPPORTED: one row slice, no reduction launch
+            raise RuntimeError(f"cgv_skinny_linear_bwd_input_add failed with code {rc}: {lib.cgv_last_error_string().decode()}")
     _lib.call("cgv_skinny_linear_bwd_input", _lib.ptr(gy2), _lib.ptr(z) if z is not None else None, _lib.ptr(weight),
               _lib.ptr(gx), M, N, K, act, ws.data_ptr(), nbytes, stream if stream is not None else _lib.stream_ptr())
+    return False
 
 
 def _is_direct(param):
@@ -666,6 +721,15 @@ class Dense(nn.Linear):
         nn.init.xavier_uniform_(self.weight)
         if self.bias is not None:
             nn.init.zeros_(self.bias)
+
+    def forward_fork(self, inputs):
+        """(layer output, alias of ``inputs``).  Hand the alias to whatever else consumes the same state (the block's
+        message kernel / residual, the next block): its gradient is then summed with this layer's input gradient in the
+        backward-input kernel instead of by an accumulation launch of autograd (``_LinearFn.forward(fork=True)``)."""
+        if (isinstance(self.activation, Swish) and self.dropout_rate == 0.0 and torch.is_tensor(inputs) and inputs.is_cuda
+                and inputs.requires_grad and torch.is_grad_enabled()):
+            return _LinearFn.apply(inputs, self.weight, self.bias, ACT_SWISH, True)
+        return self.forward(inputs), inputs
 
     def forward(self, inputs):
         if isinstance(self.activation, Swish) and self.dropout_rate == 0.0:

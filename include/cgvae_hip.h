@@ -459,6 +459,10 @@ int cgv_skinny_bwd_input_supported(int M, int N, int K);      /* bwd_input alone
 size_t cgv_skinny_bwd_input_workspace_bytes(int M, int N, int K);
 int cgv_skinny_linear_bwd_input(const float* gy, const float* z /*or NULL*/, const float* W, float* gx, int M, int N, int K,
                                 int act, void* ws /*or NULL*/, size_t ws_bytes, void* stream);
+/* the same with a second gradient of the input added in the reduction launch of the row-split product; returns
+ * CGV_E_UNSUPPORTED when the product has one row slice only (no reduction launch): add separately then. */
+int cgv_skinny_linear_bwd_input_add(const float* gy, const float* z /*or NULL*/, const float* W, const float* add, float* gx,
+                                    int M, int N, int K, int act, void* workspace, size_t workspace_bytes, void* stream);
 /* Slice sums ("base + row-slice partials"): the split backward-input product leaves one partial [M, K] matrix per row
  * slice of the weight; instead of a reduction launch per product (57 a step on the chignolin config) the NEXT kernel on
  * the autograd chain adds the slices while it loads its operand -- in slice order, so results are deterministic.
@@ -495,6 +499,11 @@ int cgv_tile_linear_bwd_input(const float* g, const float* W, float* gx, int M, 
  * bias gradients go to the grouped launch, which applies act' and sums the bias itself) */
 int cgv_tile_linear_bwd_input_act(const float* gy, const float* z /*or NULL*/, const float* W, float* gx, int M, int N, int K,
                                   int act, void* stream);
+/* gx = add + (gy * act'(z)) W  (add [M, K]: a second gradient of the layer's input, e.g. the residual / message-kernel path of
+ * a block whose first Dense reads the same state -- conv.py:63-75 + 553-561: the accumulation autograd would do with a
+ * separate add launch rides in the store epilogue). */
+int cgv_tile_linear_bwd_input_act_add(const float* gy, const float* z /*or NULL*/, const float* W, const float* add, float* gx,
+                                      int M, int N, int K, int act, void* stream);
 int cgv_tile_linear_wgrad(const float* g, const float* x, float* gW, int M, int N, int K, int accumulate, void* stream);
 int cgv_wgrad_record_bytes(void);
 int cgv_wgrad_plan(int M, int N, int K, int* tiles_k /*[host]*/, int* tile_w /*[host]*/, int* n_blocks /*[host]*/);
