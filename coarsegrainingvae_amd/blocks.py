@@ -57,11 +57,13 @@ class InvariantMessage(nn.Module):
         return self.inv_dense(s_j)[nbrs[:, 1]] * self.dist_embed(dist)
 
 
-def _resolve(plan, geom, nbrs, n_nodes, r_ij, n_rbf, cutoff):
+def _resolve(plan, geom, nbrs, n_nodes, r_ij, n_rbf, cutoff, edge_wgt=None):
     if plan is None:
         plan = EdgePlan.from_nbrs(nbrs, n_nodes)
     if geom is None:
         geom = EdgeGeometry(plan, n_rbf, cutoff, r_edges=r_ij)
+    if edge_wgt is not None:
+        geom = geom.scaled(plan, edge_wgt)               # per-edge weight folded into the filter inputs of the records
     return plan, geom
 
 
@@ -79,11 +81,10 @@ class EquiMessageBlock(nn.Module):
 
     def forward(self, s_j, v_j, r_ij, nbrs, edge_wgt=None, plan: Optional[EdgePlan] = None,
                 geom: Optional[EdgeGeometry] = None, residual: bool = False):
-        """``residual=True`` returns the updated states (s_j + ds, v_j + dv) from the same launch."""
-        if edge_wgt is not None:
-            raise NotImplementedError("edge_wgt is never passed on the run_ala path (conv.py:527-533)")
+        """``residual=True`` returns the updated states (s_j + ds, v_j + dv) from the same launch.  ``edge_wgt`` [E]
+        (conv.py:527-533; never passed on the run_ala path) weights every edge's message: ``EdgeGeometry.scaled``."""
         im = self.inv_message
-        plan, geom = _resolve(plan, geom, nbrs, s_j.shape[0], r_ij, im.n_rbf, im.cutoff)
+        plan, geom = _resolve(plan, geom, nbrs, s_j.shape[0], r_ij, im.n_rbf, im.cutoff, edge_wgt)
         Wd, bd = im.dist_embed.filter_params()
         if residual:
             phi, s_res = im.node_features_fork(s_j)              # the residual reads the state through the fork
@@ -110,10 +111,8 @@ class EquiMessageCross(nn.Module):
 
     def forward(self, s_j, v_j, r_ij, nbrs, edge_wgt=None, plan: Optional[EdgePlan] = None,
                 geom: Optional[EdgeGeometry] = None, residual: bool = False):
-        if edge_wgt is not None:
-            raise NotImplementedError("edge_wgt is always None where the reference calls this block (cgvae.py:182)")
-        im = self.inv_message
-        plan, geom = _resolve(plan, geom, nbrs, s_j.shape[0], r_ij, im.n_rbf, im.cutoff)
+        im = self.inv_message                                  # edge_wgt: conv.py:384-397 (None where the reference calls it, cgvae.py:180)
+        plan, geom = _resolve(plan, geom, nbrs, s_j.shape[0], r_ij, im.n_rbf, im.cutoff, edge_wgt)
         Wd, bd = im.dist_embed.filter_params()
         phi = im.node_features(s_j)                                   # [N, 4F]
         F = s_j.shape[1]
@@ -168,8 +167,7 @@ class EquiMessagePsuedo(nn.Module):
                 geom: Optional[EdgeGeometry] = None, residual: bool = False):
         """``residual=True`` (used by the decoder loop) returns the updated states
         ``(S + dS, Sbar + dSbar, V + dV, Vbar + dVbar)`` from the same launch instead of the deltas."""
-        if edge_wgt is not None:
-            raise NotImplementedError("edge_wgt is never passed on the run_ala path")
+        # edge_wgt: accepted and IGNORED, exactly like the reference (conv.py:187-242 never reads it)
         im = self.inv_message
         plan, geom = _resolve(plan, geom, nbrs, s_j.shape[0], r_ij, im.n_rbf, im.cutoff)
         Wd, bd = im.dist_embed.filter_params()

@@ -320,6 +320,31 @@ class EdgeGeometry:
         self.coef = rbf_coefficients(n_rbf, cutoff, dev)
         self.rebuild(plan, r_edges=r_edges, pos_dst=pos_dst, pos_src=pos_src)
 
+    def scaled(self, plan: EdgePlan, edge_wgt: torch.Tensor) -> "EdgeGeometry":
+        """Records for a per-edge weight (conv.py:527-533, 384-389: ``delta_s_ij * edge_wgt``, ``delta_v_ij * edge_wgt``).
+        Every term of a message is linear in the filter ``w(e) = Wd (rbf env)(e) + bd env(e)``, so weighting an edge is
+        scaling the (R + 1) filter inputs of its record -- in each of the three record orders, by the weight of the edge
+        the record belongs to -- and the kernels (forward, backward, filter gradients) run unchanged.  ``edge_wgt`` is
+        data: [E] in the order of the directed edge list the plan was built from; no gradient flows to it."""
+        if edge_wgt.requires_grad:
+            raise RuntimeError("edge weights are data on this path (no gradient w.r.t. edge_wgt)")
+        E = plan.n_edges
+        w = edge_wgt.detach().reshape(-1).to(device=self.geom_d.device, dtype=torch.float32)
+        if w.shape[0] != E:
+            raise ValueError(f"edge_wgt has {w.shape[0]} entries for {E} directed edges")
+        out = EdgeGeometry.__new__(EdgeGeometry)
+        for name in ("n_rbf", "cutoff", "stride", "unit_offset", "group_stride", "group_unit_offset", "coef"):
+            setattr(out, name, getattr(self, name))
+        R = self.n_rbf
+        out.geom_d, out.geom_s = self.geom_d.clone(), self.geom_s.clone()
+        out.geom_d[:E, :R + 1] *= w[plan.eid_d[:E].long()].unsqueeze(1)
+        out.geom_s[:E, :R + 1] *= w[plan.eid_s[:E].long()].unsqueeze(1)
+        out.geom_g = None
+        if self.geom_g is not None and plan.pos_g is not None:
+            out.geom_g = self.geom_g.clone()
+            out.geom_g[:E, :R + 1] *= w[plan.eid_d[plan.pos_g[:E].long()].long()].unsqueeze(1)
+        return out
+
     def jobs(self, plan: EdgePlan, pos_dst: torch.Tensor, pos_src: torch.Tensor):
         """GeomJob records (cgv_geom_jobs_build) that recompute this geometry's record arrays for ``plan``'s current edges."""
         out = []

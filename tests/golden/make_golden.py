@@ -479,9 +479,35 @@ def g9_high_order_edges(data):
     save("g9_high_order_edges", **out)
 
 
+def g10_edge_wgt(conv):
+    """EquiMessageBlock / EquiMessageCross with a per-edge weight (conv.py:527-533, 384-397)."""
+    F, R, N, cutoff = 8, 8, 30, 6.0
+    gen = torch.Generator().manual_seed(4242)
+    xyz = torch.rand(N, 3, generator=gen) * 5.0
+    nbrs, _ = conv.make_directed(random_graph(N, 0.3, gen))
+    r_ij = xyz[nbrs[:, 1]] - xyz[nbrs[:, 0]]
+    wgt = torch.rand(nbrs.shape[0], generator=gen) + 0.25
+    for name, cls, seed in (("block", conv.EquiMessageBlock, 31), ("cross", conv.EquiMessageCross, 37)):
+        torch.manual_seed(seed)
+        blk = cls(feat_dim=F, activation="swish", n_rbf=R, cutoff=cutoff, dropout=0.0)
+        for p in blk.parameters():
+            if p.dim() == 1:
+                p.data.normal_(0, 0.3)
+        s = torch.randn(N, F, generator=gen, requires_grad=True)
+        v = torch.randn(N, F, 3, generator=gen, requires_grad=True)
+        ds, dv = blk(s, v, r_ij, nbrs, edge_wgt=wgt)
+        gs, gv = torch.randn(ds.shape, generator=gen), torch.randn(dv.shape, generator=gen)
+        (ds * gs).sum().add((dv * gv).sum()).backward()
+        save(f"g10_edge_wgt_{name}", s=s, v=v, r_ij=r_ij, nbrs=nbrs, edge_wgt=wgt, cutoff=cutoff, R=R, ds=ds, dv=dv, gout_s=gs,
+             gout_v=gv, gin_s=s.grad, gin_v=v.grad, **params_of(blk), **grads_of(blk))
+
+
 def main():
     modules, conv, cgvae, data = load_reference()
     torch.set_num_threads(1)          # bit-stable sums
+    if len(sys.argv) > 1 and sys.argv[1] == "g10":
+        g10_edge_wgt(conv)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "g8":     # only the G8 set (leaves the other files untouched)
         g8_cross(conv, cgvae)
         return
@@ -496,6 +522,7 @@ def main():
     g7_init(cgvae)
     g8_cross(conv, cgvae)
     g9_high_order_edges(data)
+    g10_edge_wgt(conv)
 
 
 if __name__ == "__main__":

@@ -1101,6 +1101,31 @@ def test_equi_message_cross_golden(tag):
     check_param_grads(blk, g)
 
 
+@pytest.mark.parametrize("name", ["block", "cross"])
+def test_edge_weighted_message_blocks_golden(name):
+    """``edge_wgt`` (conv.py:527-533, 384-397): per-edge weights folded into the filter inputs of the edge records
+    (EdgeGeometry.scaled) -- forward, input gradients and every parameter gradient against the reference's own outputs."""
+    g = load_golden(f"g10_edge_wgt_{name}")
+    F, R = g["s"].shape[1], int(g["R"])
+    cls = cg.EquiMessageBlock if name == "block" else cg.EquiMessageCross
+    blk = load_block(cls(F, "swish", R, float(g["cutoff"]), 0.0), g)
+    s, v = dev(g["s"]).requires_grad_(True), dev(g["v"]).requires_grad_(True)
+    ds, dv = blk(s, v, dev(g["r_ij"]), dev(g["nbrs"]), edge_wgt=dev(g["edge_wgt"]))
+    assert_close(ds, g["ds"], "ds")
+    assert_close(dv, g["dv"], "dv")
+    ((ds * dev(g["gout_s"])).sum() + (dv * dev(g["gout_v"])).sum()).backward()
+    assert_close(s.grad, g["gin_s"], "grad s")
+    assert_close(v.grad, g["gin_v"], "grad v")
+    check_param_grads(blk, g)
+    # and the pseudo-vector block takes the argument and ignores it, like the reference (conv.py:187-242)
+    if name == "block":
+        gp = load_golden("g1_equi_pseudo_F8R8")
+        pb = load_block(cg.EquiMessagePsuedo(gp["s"].shape[1], "swish", int(gp["R"]), float(gp["cutoff"]), 0.0), gp)
+        args = [dev(gp[k]) for k in ("s", "sbar", "v", "vbar", "r_ij", "nbrs")]
+        out = pb(*args, edge_wgt=torch.rand(gp["nbrs"].shape[0], device=DEV))
+        assert_close(out[0], gp["dh"], "dh with an (ignored) edge_wgt")
+
+
 @pytest.mark.parametrize("flavour", ["cross", "plain"])
 def test_equivariant_decoder_golden(flavour):
     g = load_golden(f"g8_equivariant_decoder_{flavour}")
