@@ -43,15 +43,18 @@ def CG_collate(dicts: List[Dict[str, torch.Tensor]]) -> Dict[str, torch.Tensor]:
     return batch
 
 
-def prepare_batch(batch: Dict[str, torch.Tensor], device=None, edge_slack: float = 0.0, edge_capacity=None) -> Dict[str, torch.Tensor]:
+def prepare_batch(batch: Dict[str, torch.Tensor], device=None, edge_slack: float = 0.0, edge_capacity=None,
+                  dir_mp: bool = False) -> Dict[str, torch.Tensor]:
     """Move a collated batch to the device and attach its :class:`BatchGraph` (directed lists,
     CSR plans, bead ranks) under ``'_graph'`` so ``CGequiVAE.forward`` runs without host syncs.
     ``edge_slack`` > 0 reserves that fraction of extra edge capacity (see :func:`copy_batch_into`);
-    ``edge_capacity`` = (atom edges, bead edges) sets the capacities outright."""
+    ``edge_capacity`` = (atom edges, bead edges) sets the capacities outright.  ``dir_mp``: for a model whose encoder
+    was built with ``dir_mp=True`` (cgvae.py:270-271): the atom list is used as given, not symmetrised."""
     if device is not None:
         batch = batch_to(batch, device)
     batch["_graph"] = BatchGraph(batch["nxyz"][:, 1:], batch["CG_nxyz"][:, 1:], batch["CG_mapping"],
-                                 batch["nbr_list"], batch["CG_nbr_list"], edge_slack=edge_slack, edge_capacity=edge_capacity)
+                                 batch["nbr_list"], batch["CG_nbr_list"], edge_slack=edge_slack, edge_capacity=edge_capacity,
+                                 dir_mp=dir_mp)
     return batch
 
 

@@ -393,15 +393,19 @@ class BatchGraph:
     decoder use different RBF cutoffs on the same edges (run_ala.py:196-206).
     """
 
-    def __init__(self, xyz, cg_xyz, mapping, nbr_list, cg_nbr_list, edge_slack: float = 0.0, edge_capacity=None):
+    def __init__(self, xyz, cg_xyz, mapping, nbr_list, cg_nbr_list, edge_slack: float = 0.0, edge_capacity=None,
+                 dir_mp: bool = False):
         """``edge_slack``: fraction of extra edge capacity in the atom / bead plans and their geometry records, so
-        that ``update`` can re-plan another batch of the same molecules in place (hipGraph replay)."""
+        that ``update`` can re-plan another batch of the same molecules in place (hipGraph replay).
+        ``dir_mp``: the encoder's ``dir_mp=True`` (cgvae.py:270-271): the ATOM list is taken as the directed edge list it
+        is given as, not symmetrised (the bead list always is, cgvae.py:272, 378); such a bundle is not re-planned in place."""
+        self.dir_mp = bool(dir_mp)
         self.xyz = xyz.detach().contiguous().float().clone()
         self.cg_xyz = cg_xyz.detach().contiguous().float().clone()
         n, n_cg = self.xyz.shape[0], self.cg_xyz.shape[0]
         self.mapping = mapping.long()
         self.mapping_cpu = None                       # host copy, made on the first ``fits`` that needs it
-        self.atom_nbrs, _ = make_directed(nbr_list)
+        self.atom_nbrs = nbr_list.long().contiguous() if self.dir_mp else make_directed(nbr_list)[0]
         self.cg_nbrs, _ = make_directed(cg_nbr_list)
         cap = lambda e: int(e * (1.0 + edge_slack)) + (64 if edge_slack > 0 else 0)
         cap_atom, cap_cg = cap(self.atom_nbrs.shape[0]), cap(self.cg_nbrs.shape[0])
@@ -433,6 +437,8 @@ class BatchGraph:
     def fits(self, xyz, cg_xyz, mapping, nbr_list, cg_nbr_list) -> bool:
         """Can ``update`` take this batch?  Same molecules (node counts, atom -> bead map) and edge counts within
         the capacity reserved by ``edge_slack``.  (Compares the mapping on the device: one small sync.)"""
+        if self.dir_mp:
+            return False                                  # dir_mp bundles are not re-planned in place (off the run_ala path)
         if not (tuple(xyz.shape) == tuple(self.xyz.shape) and tuple(cg_xyz.shape) == tuple(self.cg_xyz.shape)
                 and 2 * nbr_list.shape[0] <= self.atom.capacity and 2 * cg_nbr_list.shape[0] <= self.cg.capacity
                 and tuple(mapping.shape) == tuple(self.mapping.shape)):
@@ -448,6 +454,8 @@ class BatchGraph:
         into their existing arrays and every cached geometry is recomputed into its existing records.  Addresses
         do not change, so a hipGraph captured on this bundle can be replayed afterwards.  ``directed=True``: the
         lists are device tensors that already hold both directions (``make_directed`` done by the caller)."""
+        if self.dir_mp:
+            raise RuntimeError("a dir_mp bundle is not re-planned in place: prepare the new batch with prepare_batch(dir_mp=True)")
         dev = self.xyz.device
         if xyz.data_ptr() != self.xyz.data_ptr():
             self.xyz.copy_(xyz.detach().float(), non_blocking=True)

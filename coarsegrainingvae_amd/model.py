@@ -174,9 +174,10 @@ class EquiEncoder(nn.Module):
         encoder layers >= L is complete (tensor hook on the atom state entering layer L's message block); the
         data-parallel trainer all-reduces those layers' gradients while the lower layers' backward still runs."""
         if graph is None:
-            if self.dir_mp:
-                raise NotImplementedError("dir_mp=True is never used by run_ala.py (run_ala.py:201)")
-            graph = BatchGraph(xyz, cg_xyz, mapping, nbr_list, cg_nbr_list)
+            graph = BatchGraph(xyz, cg_xyz, mapping, nbr_list, cg_nbr_list, dir_mp=self.dir_mp)
+        elif bool(self.dir_mp) != bool(getattr(graph, "dir_mp", False)):
+            # cgvae.py:270-271: with dir_mp the atom list is NOT symmetrised -- the prepared bundle must have been built so
+            raise RuntimeError(f"this encoder has dir_mp={self.dir_mp}: prepare the batch with prepare_batch(..., dir_mp={self.dir_mp})")
         geom = graph.geometry("atom", self.n_rbf, self.cutoff)
         geom_c = graph.geometry("a2b", self.n_rbf, 20.0)
         h = ops.embedding(self.atom_embed, z, graph.embed_plan("atom", z, self.atom_embed) if graph is not None else None)
@@ -349,7 +350,7 @@ class CGequiVAE(nn.Module):
         z, cg_z, xyz, cg_xyz, nbr_list, CG_nbr_list, mapping, num_CGs = self.get_inputs(batch)
         graph = batch.get("_graph")
         if graph is None:
-            graph = BatchGraph(xyz, cg_xyz, mapping, nbr_list, CG_nbr_list)
+            graph = BatchGraph(xyz, cg_xyz, mapping, nbr_list, CG_nbr_list, dir_mp=bool(getattr(self.encoder, "dir_mp", False)))
         elif graph.xyz.shape == xyz.shape and graph.cg_xyz.shape == cg_xyz.shape:
             # the bundle's own contiguous copies of the coordinates (kept current by prepare_batch / copy_batch_into: the
             # edge records are computed from them): the strided views nxyz[:, 1:] would be re-packed by two copy launches

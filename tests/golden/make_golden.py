@@ -502,11 +502,36 @@ def g10_edge_wgt(conv):
              gout_v=gv, gin_s=s.grad, gin_v=v.grad, **params_of(blk), **grads_of(blk))
 
 
+def g11_encoder_dir_mp(cgvae):
+    """EquiEncoder(dir_mp=True) (cgvae.py:266-331): the atom list is used as the directed list it is given as."""
+    F, R, N, n_cg = 8, 8, 26, 4
+    gen = torch.Generator().manual_seed(777)
+    xyz = torch.rand(N, 3, generator=gen) * 5.0
+    z = torch.randint(1, 9, (N,), generator=gen).float()
+    mapping = (torch.arange(N) * n_cg) // N
+    cg_xyz = torch.stack([xyz[mapping == b].mean(0) for b in range(n_cg)])
+    nbr_list = random_graph(N, 0.35, gen)                 # i < j pairs only: one direction per pair
+    cg_nbr_list = random_graph(n_cg, 0.9, gen)
+    torch.manual_seed(41)
+    enc = cgvae.EquiEncoder(n_conv=2, n_atom_basis=F, n_rbf=R, activation="swish", cutoff=6.0, dir_mp=True, cg_mp=False)
+    for p in enc.parameters():
+        if p.dim() == 1:
+            p.data.normal_(0, 0.3)
+    H, h = enc(z, xyz, cg_xyz, mapping, nbr_list, cg_nbr_list)
+    gH, gh = torch.randn(H.shape, generator=gen), torch.randn(h.shape, generator=gen)
+    (H * gH).sum().add((h * gh).sum()).backward()
+    save("g11_encoder_dir_mp", z=z, xyz=xyz, cg_xyz=cg_xyz, mapping=mapping, nbr_list=nbr_list, cg_nbr_list=cg_nbr_list, F=F, R=R,
+         cutoff=6.0, H=H, h=h, gout_H=gH, gout_h=gh, **params_of(enc), **grads_of(enc))
+
+
 def main():
     modules, conv, cgvae, data = load_reference()
     torch.set_num_threads(1)          # bit-stable sums
     if len(sys.argv) > 1 and sys.argv[1] == "g10":
         g10_edge_wgt(conv)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "g11":
+        g11_encoder_dir_mp(cgvae)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "g8":     # only the G8 set (leaves the other files untouched)
         g8_cross(conv, cgvae)
@@ -523,6 +548,7 @@ def main():
     g8_cross(conv, cgvae)
     g9_high_order_edges(data)
     g10_edge_wgt(conv)
+    g11_encoder_dir_mp(cgvae)
 
 
 if __name__ == "__main__":

@@ -1126,6 +1126,30 @@ def test_edge_weighted_message_blocks_golden(name):
         assert_close(out[0], gp["dh"], "dh with an (ignored) edge_wgt")
 
 
+def test_encoder_dir_mp_golden():
+    """``EquiEncoder(dir_mp=True)`` (cgvae.py:266-331): the atom list -- here one direction per pair -- is the directed
+    edge list as given, the bead list is still symmetrised.  Outputs, and every parameter gradient, against the
+    reference's own; a bundle prepared without the flag is refused."""
+    g = load_golden("g11_encoder_dir_mp")
+    F, R = int(g["F"]), int(g["R"])
+    enc = load_block(cg.EquiEncoder(n_conv=2, n_atom_basis=F, n_rbf=R, activation="swish", cutoff=float(g["cutoff"]), dir_mp=True), g)
+    args = [dev(g[k]) for k in ("z", "xyz", "cg_xyz", "mapping", "nbr_list", "cg_nbr_list")]
+    H, h = enc(*args)
+    assert_close(H, g["H"], "H")
+    assert_close(h, g["h"], "h")
+    ((H * dev(g["gout_H"])).sum() + (h * dev(g["gout_h"])).sum()).backward()
+    check_param_grads(enc, g)
+    from coarsegrainingvae_amd.graph import BatchGraph
+    sym = BatchGraph(args[1], args[2], args[3], args[4], args[5])                     # symmetrised atom list
+    assert sym.atom.n_edges == 2 * g["nbr_list"].shape[0]
+    with pytest.raises(RuntimeError, match="dir_mp"):
+        enc(*args, graph=sym)
+    one_way = BatchGraph(args[1], args[2], args[3], args[4], args[5], dir_mp=True)
+    assert one_way.atom.n_edges == g["nbr_list"].shape[0] and one_way.cg.n_edges == 2 * g["cg_nbr_list"].shape[0]
+    H2, _ = enc(*args, graph=one_way)
+    assert_close(H2, g["H"], "H through a prepared dir_mp bundle")
+
+
 @pytest.mark.parametrize("flavour", ["cross", "plain"])
 def test_equivariant_decoder_golden(flavour):
     g = load_golden(f"g8_equivariant_decoder_{flavour}")
