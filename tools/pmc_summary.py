@@ -14,5 +14,6 @@ for r in rows:
         continue
     acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for name, counters in sorted(acc.items(), key=lambda kv: -sum(sum(v) for v in kv[1].values())):
-    parts = [f"{c}: n={len(v)} mean={sum(v)/len(v):.1f} max={max(v):.1f}" for c, v in counters.items()]
+    # med = the typical dispatch of a training step (the mean mixes in the first step's launches over the whole arena)
+    parts = [f"{c}: n={len(v)} mean={sum(v)/len(v):.1f} max={max(v):.1f} med={sorted(v)[len(v) // 2]:.1f}" for c, v in counters.items()]
     print(name[:110], "|", " ; ".join(parts))
