@@ -49,9 +49,9 @@ def pmc_means(path):
     if not path:
         return out
     for line in open(path):
-        m = re.match(r"(.*?) \| (\w+): n=(\d+) mean=([0-9.]+)(?: max=[0-9.]+ med=([0-9.]+))?", line)
-        if m:                                             # the median dispatch where the summary has it
-            out[m.group(1).strip()] = (float(m.group(5) or m.group(4)), int(m.group(3)))
+        m = re.match(r"(.*?) \| (\w+): n=(\d+) mean=([0-9.]+)(?: max=([0-9.]+) med=([0-9.]+))?", line)
+        if m:                                             # (median dispatch where the summary has it, count, largest dispatch)
+            out[m.group(1).strip()] = (float(m.group(6) or m.group(4)), int(m.group(3)), float(m.group(5) or m.group(4)))
     return out
 
 
@@ -105,12 +105,13 @@ for w in ("chignolin", "dipeptide", "protein2000"):
     # ---- PMC traffic
     fetch, write = pmc_means(src(f"{tag}_pmc_FETCH_SIZE_{w}.txt")), pmc_means(src(f"{tag}_pmc_WRITE_SIZE_{w}.txt"))
 
-    def pick(pattern):
+    def pick(pattern, largest=False):
         ks = [k for k in fetch if re.search(pattern, k)]
         if not ks:
             return None
         k = max(ks, key=lambda k: fetch[k][0] * fetch[k][1])
-        return k, fetch[k][0], write.get(k, (0.0, 0))[0]
+        i = 2 if largest else 0
+        return k, fetch[k][i], write.get(k, (0.0, 0, 0.0))[i]
     rk = line and line.get("roofline", {}).get("kernel")
     hit = pick(r"equi_msg_fwd_grp_k|equi_msg_fwd_k")
     if rk and hit:
@@ -118,10 +119,11 @@ for w in ("chignolin", "dipeptide", "protein2000"):
         tr[rk] = {"fetch_KiB": f_kib, "fetch_factor": 2, "write_KiB": w_kib, "traffic_bytes": int(1024 * (2 * f_kib + w_kib)),
                   "kernel_symbol": sym.split("(")[0].replace("void ", ""), "source": f"profiles/{tag}_pmc_*_{w}.txt",
                   "source_sha256": source_hash(SOURCES["equi_msg_fwd"]), "source_files": SOURCES["equi_msg_fwd"]}
-    hit = pick(r"segment_reduce_k")
+    hit = pick(r"segment_reduce_k", largest=True)
     if hit:
         tr["segment_reduce_k<4,256,8>"] = {"fetch_KiB": hit[1], "fetch_factor": 2, "write_KiB": hit[2], "traffic_bytes": int(1024 * (2 * hit[1] + hit[2])),
-                                           "note": "largest segment_reduce launch of the step (not the standalone [E,F,3] reduction bench.py times)",
+                                           "note": "LARGEST segment_reduce dispatch of the run = the standalone [E,F,3] -> [N,F,3] reduction bench.py times as `scatter_add` (the PMC passes run bench.py with its extras on)",
+                                           "source": f"profiles/{tag}_pmc_*_{w}.txt",
                                            "source_sha256": source_hash(SOURCES["segment_reduce"]), "source_files": SOURCES["segment_reduce"]}
     hit = pick(r"grouped_wgrad_t<true>")
     if hit:
