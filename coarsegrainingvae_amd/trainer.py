@@ -364,6 +364,7 @@ class Trainer:
         self._pending = False
         self._side = None
         self._dec_ranges = None
+        self._shard_sigs = set()      # shard shapes already compared across the ranks (_check_shards)
         self.betas, self.eps, self.max_norm = betas, eps, max_norm
         self.world = world_size
         # always_sync: run the collective path even with one rank (exercises RCCL + graph capture in tests)
@@ -573,7 +574,8 @@ class Trainer:
             if self.exchange is not None:
                 # inside the capture nothing can be checked, and the eager step that built the arena ran without the
                 # exchange: compare the shard shapes here, eagerly
-                self._check_shards(batch)
+                self._shard_sigs.discard(int(batch["nxyz"].shape[0]) * (1 << 24) + int(batch["CG_nxyz"].shape[0]))
+                self._check_shards(batch)                   # all ranks capture together: always compared here
             self.sync.drain()
         graph = torch.cuda.CUDAGraph()
         pending_at_start = self._pending              # a deferred update opens the captured step (or does not)
@@ -712,11 +714,17 @@ class Trainer:
     def _check_shards(self, batch):
         """The operand exchange all-gathers equally sized buffers and decides per layer, from its rows, whether it is
         exchanged at all: ranks holding differently shaped shards would issue different collectives and wait for each
-        other forever.  Every rank compares (atoms, beads) of its shard with the others' -- one tiny collective, issued
-        unconditionally by all ranks -- and all of them refuse together."""
+        other forever.  Every rank compares (atoms, beads) of its shard with the others' -- one tiny collective -- the
+        first time it meets a shard shape (at the start of the step, before any data-path collective; a training run
+        meets its shapes on the same steps on every rank), and all ranks refuse together.  Not on every step: a rank
+        whose batch does not fit its captured buffers runs that step eagerly while the others replay, and the eager
+        step must then issue exactly the collectives the replayed graph holds."""
         sig = int(batch["nxyz"].shape[0]) * (1 << 24) + int(batch["CG_nxyz"].shape[0])
+        if sig in self._shard_sigs:
+            return
         if not self.sync.same_on_all_ranks(sig):
             raise RuntimeError("operand exchange needs equally shaped shards on every rank")
+        self._shard_sigs.add(sig)
 
     # ------------------------------------------------------------------ one iteration
     def _step_eager(self, batch, eps: Optional[torch.Tensor] = None, train: bool = True):
