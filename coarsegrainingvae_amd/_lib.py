@@ -148,6 +148,9 @@ PROTOTYPES = {
     "cgv_sgd_apply": (_i, [_p, _p, C.c_int64, _f, _p, _p]),
     "cgv_wgrad_gram": (_i, [_p, _i, _i, _p, _p, C.c_size_t, _p]),
     "cgv_wgrad_gram_workspace_bytes": (C.c_size_t, [_i]),
+    "cgv_wgrad_gram_mfma": (_i, [_p, _i, _i, _p, _p, C.c_size_t, _p]),
+    "cgv_wgrad_gram_mfma_workspace_bytes": (C.c_size_t, [_i, _i]),
+    "cgv_wgrad_gram_mfma_max_rows": (_i, []),
     "cgv_rank_update_supported": (_i, [_i, _i, _i]),
     "cgv_optim_prepare_extra": (_i, [_p, C.c_int64, _p, _i, _f, _f, _f, _f, _p, _f, _p, _p, _p]),
     "cgv_grouped_wgrad_adam": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _f, _f, _f, _f, _p, _p]),

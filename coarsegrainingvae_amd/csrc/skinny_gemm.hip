@@ -765,6 +765,184 @@ __global__ __launch_bounds__(256) void wgrad_gram_reduce_k(const WgradProblem* _
   if (threadIdx.x == 0) out[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
 }
 
+// The same norm for MANY operand rows (41 .. 128: gathered rows of 4 - 8 ranks, bead rows of a large batch), where walking
+// M^2 / 2 row pairs on the vector ALU costs more than forming the gradient tiles (48 rows: 140 us against 82 us for the
+// tile pass with a squaring epilogue).  The two Gram matrices G = g g^T and X = x x^T are built from 16 x 16 tiles of
+// the upper triangle with v_mfma_f64_16x16x4_f64 -- operands widened on the way out of LDS, so products and sums are the
+// doubles of wgrad_gram_k -- and ||g^T x||^2 = sum_ab G_ab X_ab (off-diagonal tiles count twice).
+//   wgrad_gram_mfma_k     grid (GRAMM_BLOCKS, problems), the column slices and LDS layout of wgrad_gram_k (rows M .. 16 NT - 1
+//                         stay zero); block s takes the slices s, s + GRAMM_BLOCKS, ... -- one or two for the model's
+//                         layers: the instruction runs at a quarter of the fp32 rate, the work has to be spread by
+//                         columns (with 8 blocks per problem the 5400-column layers' blocks set the launch's length) --
+//                         and wave w keeps the tiles w, w + 8, ... in registers over them.  They leave as
+//                         ws[problem][block][G | X][tile][lane][4] (G when the block's slices turn from g to x, X at the end).
+//                         Bias gradients as in wgrad_gram_k.
+//   wgrad_gram_mfma_dot_k grid (tiles, problems): blocks' parts summed per element (fixed order), tile's sum of G_ab X_ab
+//   wgrad_gram_mfma_sum_k one thread per problem: the tiles' sums in fixed order.
+// A tile's 256 elements sit in the same lanes / registers for G and for X (same instruction), and both operands of a
+// step read column c + (lane >> 4) of row (lane & 15), so the result does not depend on the instruction's register map.
+constexpr int GRAMM_MAX_ROWS = 128;
+constexpr int GRAMM_MAX_TILES = 36;                                  // upper triangle of 8 x 8 row groups
+constexpr int GRAMM_BLOCKS = 32;
+constexpr int GRAMM_LDS_BYTES = 52 * 1024;
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+// workspace doubles per problem for a launch whose largest problem has `tiles` tiles: the blocks' parts, then the tiles' sums
+__device__ __host__ inline size_t gramm_ws_doubles(int tiles) { return (size_t)GRAMM_BLOCKS * 2 * tiles * 256 + GRAMM_MAX_TILES; }
+// columns per slice: 16 NT rows x C / 4 float4 <= 3072 (six per thread), rows padded by one float4, at most 52 KB
+__device__ __host__ inline int gramm_cols(int MP) { const int c = (12288 / MP) & ~31; return c > 256 ? 256 : c; }
+__device__ __forceinline__ void gramm_tile_of(int tt, int NT, int& a, int& b) {
+  a = 0;
+  while (tt >= NT - a) { tt -= NT - a; ++a; }
+  b = a + tt;
+}
+
+template <int TPW>   // tiles per wave: 3 up to 96 rows (21 tiles), 5 up to 128 (36)
+__global__ __launch_bounds__(GRAM_THREADS) void wgrad_gram_mfma_k(const WgradProblem* __restrict__ table, double* __restrict__ ws,
+                                                                  int launch_tiles) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float4* tile = reinterpret_cast<float4*>(smem);                // [16 NT][C4 + 1]
+  const WgradProblem pr = table[blockIdx.y];
+  const int sl = blockIdx.x;
+  const int M = pr.M, N = pr.N, K = pr.K, act = pr.act;
+  const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int NT = (M + 15) >> 4, MP = 16 * NT, T = NT * (NT + 1) / 2;
+  if (M > GRAMM_MAX_ROWS || T > launch_tiles || T > TPW * GRAM_WAVES) return;          // (wgrad_gram_mfma_dot_k poisons the norm)
+  const int C4 = gramm_cols(MP) >> 2, RS = C4 + 1;
+  const int n4 = N >> 2, k4 = K >> 2;
+  const int g_slices = (n4 + C4 - 1) / C4, slices = g_slices + (k4 + C4 - 1) / C4;
+  if (sl >= slices) return;
+  double* mine = ws + (size_t)blockIdx.y * gramm_ws_doubles(launch_tiles) + (size_t)sl * 2 * launch_tiles * 256;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int idx = t; idx < (MP - M) * RS; idx += GRAM_THREADS) tile[M * RS + idx] = zero4;     // never written again
+  auto fetch = [&](int slice, float4 (&buf)[GRAM_F4_PER_THREAD]) {
+    const bool is_g = slice < g_slices;
+    const int c0 = (is_g ? slice : slice - g_slices) * C4, cols4 = is_g ? n4 : k4;
+#pragma unroll
+    for (int u = 0; u < GRAM_F4_PER_THREAD; ++u) {
+      const int idx = t + GRAM_THREADS * u;
+      const int m = idx / C4, col4 = c0 + idx - m * C4;
+      buf[u] = zero4;
+      if (m < M && col4 < cols4) {
+        if (is_g) {
+          float4 g = ldg4_global(pr.gy + wg_row(pr, m, N) + 4 * col4);
+          if (act) {
+            const float4 z = ldg4_global(pr.z + wg_row(pr, m, N) + 4 * col4);
+            g.x *= act_bwd(z.x, act); g.y *= act_bwd(z.y, act); g.z *= act_bwd(z.z, act); g.w *= act_bwd(z.w, act);
+          }
+          buf[u] = g;
+        } else {
+          buf[u] = ldg4_global(pr.x + wg_row(pr, m, K) + 4 * col4);
+        }
+      }
+    }
+  };
+  int ta[TPW], tb[TPW];
+  f64x4 acc[TPW];
+#pragma unroll
+  for (int u = 0; u < TPW; ++u) {
+    const int tt = w + GRAM_WAVES * u;
+    gramm_tile_of(tt < T ? tt : 0, NT, ta[u], tb[u]);
+    acc[u] = f64x4{0.0, 0.0, 0.0, 0.0};
+  }
+  const int i = lane & 15, q = lane >> 4;
+  const float* tf = reinterpret_cast<const float*>(tile);
+  const int RSf = 4 * RS, C = 4 * C4;
+  float4 buf[GRAM_F4_PER_THREAD];
+  fetch(sl, buf);
+  for (int slice = sl; slice < slices; slice += GRAMM_BLOCKS) {
+    __syncthreads();                                             // previous slice consumed (and the zero rows written)
+#pragma unroll
+    for (int u = 0; u < GRAM_F4_PER_THREAD; ++u) {
+      const int idx = t + GRAM_THREADS * u;
+      const int m = idx / C4;
+      if (m < M) tile[m * RS + idx - m * C4] = buf[u];
+    }
+    if (slice + GRAMM_BLOCKS < slices) fetch(slice + GRAMM_BLOCKS, buf);     // in flight while this slice is used
+    __syncthreads();
+    if (pr.gb && slice < g_slices) {                             // bias gradient: column sums of the staged g (rows ascending)
+      const int c0 = slice * C4;
+      for (int c = t; c < C4 && c0 + c < n4; c += GRAM_THREADS) {
+        float4 sum = zero4;
+        for (int m = 0; m < M; ++m) {
+          const float4 g = tile[m * RS + c];
+          sum.x += g.x; sum.y += g.y; sum.z += g.z; sum.w += g.w;
+        }
+        float* dst = pr.gb + 4 * (c0 + c);
+        if ((reinterpret_cast<uintptr_t>(pr.gb) & 15) == 0) {
+          if (pr.accumulate) { const float4 old = ldg4_global(dst); sum.x += old.x; sum.y += old.y; sum.z += old.z; sum.w += old.w; }
+          stg4_global(dst, sum);
+        } else {
+          const float v4[4] = {sum.x, sum.y, sum.z, sum.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dst[e] = pr.accumulate ? dst[e] + v4[e] : v4[e];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+      if (w + GRAM_WAVES * u < T) {                                // (wave-uniform)
+        const float* pa = tf + (16 * ta[u] + i) * RSf + q;
+        const float* pb = tf + (16 * tb[u] + i) * RSf + q;
+        f64x4 c = acc[u];
+#pragma unroll 4
+        for (int col = 0; col < C; col += 4)
+          c = __builtin_amdgcn_mfma_f64_16x16x4f64((double)pa[col], (double)pb[col], c, 0, 0, 0);
+        acc[u] = c;
+      }
+    }
+    // the block's g slices are done: their tiles leave as its G part (the x slices start from zero)
+    const bool last_g = slice < g_slices && slice + GRAMM_BLOCKS >= g_slices;
+    const bool last = slice + GRAMM_BLOCKS >= slices;
+    if (last_g || last) {
+      double* dst = mine + (slice < g_slices ? 0 : (size_t)launch_tiles * 256);
+#pragma unroll
+      for (int u = 0; u < TPW; ++u) {
+        const int tt = w + GRAM_WAVES * u;
+        if (tt < T) *reinterpret_cast<f64x4*>(dst + (size_t)tt * 256 + 4 * lane) = acc[u];
+        acc[u] = f64x4{0.0, 0.0, 0.0, 0.0};
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void wgrad_gram_mfma_dot_k(const WgradProblem* __restrict__ table, double* __restrict__ ws,
+                                                             int launch_tiles) {
+  __shared__ double part[4];
+  const WgradProblem pr = table[blockIdx.y];
+  const int M = pr.M;
+  double* mine = ws + (size_t)blockIdx.y * gramm_ws_doubles(launch_tiles);
+  double* sums = mine + (size_t)GRAMM_BLOCKS * 2 * launch_tiles * 256;
+  const int tt = blockIdx.x;
+  const int NT = (M + 15) >> 4, T = NT * (NT + 1) / 2;
+  if (M > GRAMM_MAX_ROWS || T > launch_tiles) { if (threadIdx.x == 0) sums[tt] = __builtin_nan(""); return; }
+  if (tt >= T) { if (threadIdx.x == 0) sums[tt] = 0.0; return; }
+  const int C4 = gramm_cols(16 * NT) >> 2;
+  const int g_slices = ((pr.N >> 2) + C4 - 1) / C4, slices = g_slices + ((pr.K >> 2) + C4 - 1) / C4;
+  int a, b;
+  gramm_tile_of(tt, NT, a, b);
+  double gg = 0.0, xx = 0.0;
+  for (int s = 0; s < GRAMM_BLOCKS && s < slices; ++s) {
+    const double* blk = mine + (size_t)s * 2 * launch_tiles * 256 + (size_t)tt * 256 + threadIdx.x;
+    const int last_slice = s + (slices - 1 - s) / GRAMM_BLOCKS * GRAMM_BLOCKS;      // of block s
+    if (s < g_slices) gg += blk[0];
+    if (last_slice >= g_slices) xx += blk[(size_t)launch_tiles * 256];
+  }
+  double local = (a == b ? 1.0 : 2.0) * gg * xx;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) local += __shfl_xor(local, d);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) sums[tt] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+__global__ __launch_bounds__(64) void wgrad_gram_mfma_sum_k(const double* __restrict__ ws, double* __restrict__ out, int launch_tiles) {
+  if (threadIdx.x != 0) return;
+  const double* sums = ws + (size_t)blockIdx.x * gramm_ws_doubles(launch_tiles) + (size_t)GRAMM_BLOCKS * 2 * launch_tiles * 256;
+  double sum = 0.0;
+  for (int tt = 0; tt < launch_tiles; ++tt) sum += sums[tt];
+  out[blockIdx.x] = sum;
+}
+
 // ------------------------------------------------------------------ grouped weight gradient over GATHERED operands
 // Data-parallel exchange of the bead-level layers (trainer.OperandExchange): a weight gradient g^T x has rank <= rows,
 // and the bead-level layers see 12 rows per GPU against 0.36 - 3.2 M weights, so the ranks all-gather their operand
@@ -1105,27 +1283,34 @@ __global__ __launch_bounds__(256) void gathered_wgrad_strip_k(const WgradProblem
   x_store(xs0, 0);
   __syncthreads();
   double sq = 0.0;
-  for (int kt = 0; kt < tiles_k; ++kt) {
+  // Adam: p / m / v of a tile are requested ONE TILE AHEAD (two named register sets, the loop below alternates them): with
+  // the requests in front of the tile's own MFMAs a block had 48 KB in flight for about a third of its time and the pass
+  // ran at 3 TB/s whatever the row count (365 / 378 us at 48 / 96 rows for 46 M weights).  The last tile requests itself again.
+  float4 pA[4], mA[4], vA[4], pB[4], mB[4], vB[4];
+  size_t atA = 0, atB = 0;
+  // (the step's constants once, in front of the loop: read per tile they put a vmcnt(0) -- every request in flight -- into each trip)
+  const AdamStep a = MODE == GW_ADAM ? adam_step_of(ra.state, ra.lr, ra.beta1, ra.beta2, ra.eps) : AdamStep{};
+  auto pmv_load = [&](int kt, float4 (&pp)[4], float4 (&mm)[4], float4 (&vv)[4], size_t& at0) {
+    const int kc = (kt < tiles_k ? kt : tiles_k - 1) * 64 + 4 * i;
+    at0 = (size_t)(pr.gW - ra.arena_g) + (kc < K ? kc : 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = n0 + 16 * wave + 4 * q + r;
+      const size_t o = at0 + (size_t)(row < N ? row : 0) * K;
+      pp[r] = strip_ldg4(ra.arena_p + o);
+      const f4v tm = __builtin_nontemporal_load(reinterpret_cast<const __attribute__((address_space(1))) f4v*>((strip_gptr)(ra.arena_m + o)));
+      const f4v tv = __builtin_nontemporal_load(reinterpret_cast<const __attribute__((address_space(1))) f4v*>((strip_gptr)(ra.arena_v + o)));
+      mm[r] = make_float4(tm.x, tm.y, tm.z, tm.w);
+      vv[r] = make_float4(tv.x, tv.y, tv.z, tv.w);
+    }
+  };
+  auto tile_step = [&](int kt, float4 (&pp)[4], float4 (&mm)[4], float4 (&vv)[4], size_t at0,
+                       float4 (&pn)[4], float4 (&mn)[4], float4 (&vn)[4], size_t& atn) {
     const float* xs = (kt & 1) ? xs1 : xs0;
     const int kcol = kt * 64 + 4 * i;
     const int kn = kt + 1 < tiles_k ? kt + 1 : kt;                  // (the last trip requests its own tile again: no branch)
     x_load(kn);                                                     // travels under this tile's MFMAs
-    // Adam: p / m / v of this tile are requested before its MFMAs
-    float4 pp[4], mm[4], vv[4];
-    size_t at0 = 0;
-    if (MODE == GW_ADAM) {
-      at0 = (size_t)(pr.gW - ra.arena_g) + (kcol < K ? kcol : 0);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = n0 + 16 * wave + 4 * q + r;
-        const size_t o = at0 + (size_t)(row < N ? row : 0) * K;
-        pp[r] = strip_ldg4(ra.arena_p + o);
-        const f4v tm = __builtin_nontemporal_load(reinterpret_cast<const __attribute__((address_space(1))) f4v*>((strip_gptr)(ra.arena_m + o)));
-        const f4v tv = __builtin_nontemporal_load(reinterpret_cast<const __attribute__((address_space(1))) f4v*>((strip_gptr)(ra.arena_v + o)));
-        mm[r] = make_float4(tm.x, tm.y, tm.z, tm.w);
-        vv[r] = make_float4(tv.x, tv.y, tv.z, tv.w);
-      }
-    }
+    if (MODE == GW_ADAM) pmv_load(kt + 1, pn, mn, vn, atn);         // used one trip from now
     strip_pin();
     f32x4 acc[4];
 #pragma unroll
@@ -1171,7 +1356,6 @@ __global__ __launch_bounds__(256) void gathered_wgrad_strip_k(const WgradProblem
           for (int c = 0; c < 4; ++c) sq += (double)acc[c][r] * (double)acc[c][r];
         }
       } else {
-        const AdamStep a = adam_step_of(ra.state, ra.lr, ra.beta1, ra.beta2, ra.eps);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = n0 + 16 * wave + 4 * q + r;
@@ -1188,6 +1372,11 @@ __global__ __launch_bounds__(256) void gathered_wgrad_strip_k(const WgradProblem
     if (!DB) __syncthreads();
     x_store((kt & 1) ? xs0 : xs1, kn);                             // that buffer was last read one trip ago, behind a barrier
     __syncthreads();
+  };
+  if (MODE == GW_ADAM) pmv_load(0, pA, mA, vA, atA);
+  for (int kt = 0; kt < tiles_k; kt += 2) {
+    tile_step(kt, pA, mA, vA, atA, pB, mB, vB, atB);
+    if (kt + 1 < tiles_k) tile_step(kt + 1, pB, mB, vB, atB, pA, mA, vA, atA);
   }
   if (MODE == GW_SUMSQ) {
 #pragma unroll
@@ -1735,6 +1924,42 @@ int cgv_wgrad_gram(const void* table_dev, int n_problems, int max_rows, double* 
 
 size_t cgv_wgrad_gram_workspace_bytes(int n_problems) {
   return n_problems > 0 ? (size_t)n_problems * cgv::GRAM_WS_DOUBLES * sizeof(double) : 0;
+}
+
+/* The same for records of up to 128 rows (cgv_wgrad_gram_mfma_max_rows): Gram matrices by fp64 MFMA tiles (csrc:
+ * wgrad_gram_mfma_k).  N % 4 == 0 and K % 4 == 0; workspace: cgv_wgrad_gram_mfma_workspace_bytes(n_problems, max_rows). */
+int cgv_wgrad_gram_mfma_max_rows(void) { return cgv::GRAMM_MAX_ROWS; }
+size_t cgv_wgrad_gram_mfma_workspace_bytes(int n_problems, int max_rows) {
+  if (n_problems <= 0 || max_rows < 1 || max_rows > cgv::GRAMM_MAX_ROWS) return 0;
+  const int nt = (max_rows + 15) / 16;
+  return (size_t)n_problems * cgv::gramm_ws_doubles(nt * (nt + 1) / 2) * sizeof(double);
+}
+int cgv_wgrad_gram_mfma(const void* table_dev, int n_problems, int max_rows, double* sumsq, void* workspace, size_t workspace_bytes,
+                        void* stream) {
+  CGV_REQUIRE(n_problems >= 0, "bad size");
+  if (n_problems == 0) return 0;
+  CGV_REQUIRE(max_rows >= 1 && max_rows <= cgv::GRAMM_MAX_ROWS, "max_rows out of range (1..128)");
+  CGV_REQUIRE(table_dev && sumsq && workspace, "null pointer");
+  CGV_REQUIRE(workspace_bytes >= cgv_wgrad_gram_mfma_workspace_bytes(n_problems, max_rows), "workspace too small");
+  CGV_REQUIRE((((uintptr_t)workspace) & 31) == 0, "workspace must be 32-byte aligned");
+  const cgv::WgradProblem* table = reinterpret_cast<const cgv::WgradProblem*>(table_dev);
+  const int nt = (max_rows + 15) / 16, tiles = nt * (nt + 1) / 2;
+  const bool few = tiles <= 3 * cgv::GRAM_WAVES;
+  const void* fn = few ? reinterpret_cast<const void*>(cgv::wgrad_gram_mfma_k<3>) : reinterpret_cast<const void*>(cgv::wgrad_gram_mfma_k<5>);
+  static bool lds_set[2] = {false, false};
+  if (!lds_set[few]) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, cgv::GRAMM_LDS_BYTES);
+    if (e != hipSuccess) { cgv::set_error("cgv_wgrad_gram_mfma: LDS request: %s", hipGetErrorString(e)); return (int)e; }
+    lds_set[few] = true;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  double* ws = reinterpret_cast<double*>(workspace);
+  const dim3 grid(cgv::GRAMM_BLOCKS, n_problems);
+  if (few) hipLaunchKernelGGL(cgv::wgrad_gram_mfma_k<3>, grid, dim3(cgv::GRAM_THREADS), cgv::GRAMM_LDS_BYTES, st, table, ws, tiles);
+  else hipLaunchKernelGGL(cgv::wgrad_gram_mfma_k<5>, grid, dim3(cgv::GRAM_THREADS), cgv::GRAMM_LDS_BYTES, st, table, ws, tiles);
+  hipLaunchKernelGGL(cgv::wgrad_gram_mfma_dot_k, dim3(tiles, n_problems), dim3(256), 0, st, table, ws, tiles);
+  hipLaunchKernelGGL(cgv::wgrad_gram_mfma_sum_k, dim3(n_problems), dim3(64), 0, st, ws, sumsq, tiles);
+  return cgv::check_launch("cgv_wgrad_gram_mfma");
 }
 
 /* Shapes the rank update takes: the weight-streaming tiling (cgv_skinny_supported, at most 64 operand rows). */

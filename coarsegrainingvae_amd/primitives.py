@@ -226,7 +226,7 @@ class WeightGradQueue:
                 per_rank, N, K, off_g, off_x, gW, gb, _acc, recv, total = it
                 M = seg * per_rank
                 rec = (recv.data_ptr() + 4 * off_g, recv.data_ptr() + 4 * off_x, 0, gW.data_ptr(),
-                       gb.data_ptr() if gb is not None else 0, M, N, K, 0, 0)
+                       gb.data_ptr() if gb is not None else 0, M, N, K, int(bool(_acc)), 0)
                 tail = (per_rank, total, 0)
             if lib.cgv_wgrad_strip_plan(M, N, K, per_rank, C.byref(nb)) != 0:
                 raise RuntimeError(lib.cgv_last_error_string().decode())

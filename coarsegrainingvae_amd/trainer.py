@@ -220,6 +220,7 @@ class OperandExchange:
         self.sync, self.world, self.arena, self.queue = sync, sync.world, arena, queue
         self.rank_hi = rank_hi                  # weights in arena [0, rank_hi): never materialised (Trainer._start_gathered_rank_update)
         self.ranked = []                        # this step's gathered problems kept back for the rank update
+        self.pending = []                       # ... and those waiting for the step's one materialise() launch
         self.inflight = []
         self.done_ranges = []                   # arena ranges whose global gradient this step came from gathered rows
         self._mode = {}                         # gW pointer -> "exchange" | "local" within the current step
@@ -237,7 +238,7 @@ class OperandExchange:
         return self.world * M * (N + K) <= N * K            # gathered rows vs the two passes an all-reduce makes
 
     def begin_step(self):
-        self.done_ranges, self._mode, self.bytes_gathered, self.ranked = [], {}, 0, []
+        self.done_ranges, self._mode, self.bytes_gathered, self.ranked, self.pending = [], {}, 0, [], []
 
     def split(self, items):
         """(exchanged, local) -- a parameter keeps ONE mode within a step."""
@@ -285,24 +286,46 @@ class OperandExchange:
                 self.done_ranges.append(self.arena.range_of(gb))
 
     # -- gathered weight gradients
-    def complete(self):
-        if not self.inflight:
-            return
-        now = []
+    def complete(self, final: bool = False):
+        """Wait for the gathers in flight.  Their problems are formed by ONE materialise() at the end of backward
+        (``final``): a launch per backward bucket was 4 x 52 us for the strips of a chignolin step at 8 ranks where the
+        single launch takes about 100 (blocks of few problems leave the chip half empty at both ends)."""
         for work, metas, recv, _send, total in self.inflight:
             work.wait()                                      # the current stream now waits for the gather
             for meta in metas:
                 r = self.arena.range_of(meta[5])
                 keep = self.rank_hi and r is not None and r[1] <= self.rank_hi
-                (self.ranked if keep else now).append(meta + (recv, total))
-        self.inflight = []                                   # buffers: stream order protects their reuse
-        self.materialise(now)
+                (self.ranked if keep else self.pending).append(meta + (recv, total))
+        self.inflight = []                                   # buffers: the problem tuples hold them until they are used
+        if final:
+            now, self.pending = self.pending, []
+            # a problem that ADDS to its gW (a layer applied twice in a step) must not share a launch with the one that wrote it
+            group = []
+            for m in now:
+                if m[7] and group:
+                    self.materialise(group)
+                    group = []
+                group.append(m)
+            self.materialise(group)
 
     def materialise(self, problems):
         """gW / gb of gathered problems (meta + (recv buffer, floats per rank segment)) into the gradient arena."""
         if not problems:
             return
         lib = _lib.load()
+        if len(problems) > self.queue.MAX_PROBLEMS:
+            raise RuntimeError("too many gathered weight-gradient problems")
+        # 32 - 128 gathered rows (4 - 8 ranks x 12 bead rows): a block per 64-row strip of gW, the strip's g columns staged
+        # once (gathered_wgrad_strip_k); 46 M weights from 96 rows: 101 us against 245 us for a block per 64 x 64 tile
+        strips = [m for m in problems if self.queue.strip_rows(self.world * m[0], m[1], m[2])]
+        if strips:
+            table, blocks, rows = self.queue.strip_table(strips, seg=self.world)
+            _lib.call("cgv_grouped_wgrad_strip", _lib.ptr(table), len(strips), blocks, rows, _lib.stream_ptr(),
+                      tag="gathered_wgrad_strip")
+            ids = {id(m) for m in strips}
+            problems = [m for m in problems if id(m) not in ids]
+            if not problems:
+                return
         rec = self.queue.RECORD
         buf, block_begin = bytearray(), 0
         tk, nb = C.c_int(), C.c_int()
@@ -315,8 +338,6 @@ class OperandExchange:
                             gb.data_ptr() if gb is not None else 0, self.world * M, N, K, int(accumulate), 0,
                             block_begin, tk.value, 0, M, total, 0)
             block_begin += nb.value
-        if len(problems) > self.queue.MAX_PROBLEMS:
-            raise RuntimeError("too many gathered weight-gradient problems")
         table = self.queue.upload(bytes(buf), problems[0][8].device)
         _lib.call("cgv_grouped_wgrad_gathered_tile", _lib.ptr(table), len(problems), block_begin, tile, _lib.stream_ptr(),
                   tag="gathered_wgrad")
@@ -354,6 +375,7 @@ class Trainer:
         self.rank_update = bool(rank_update) and fused_optimizer and not self.defer_update and optimizer == "adam"
         self._rank_hi = 0             # arena floats [0, _rank_hi) belong to rank-update weights
         self._rank_numel = 0
+        self._rank_ws2 = None         # Gram workspace of the MFMA rank update's norm launch
         self._rank_step = None        # this step's (table, problems, blocks, lds, items, max rows) once the Gram launch is out
         self._rank_mfma = None        # ([(kind, table, problems, blocks, rows)], problems, items) of the layers on the two-pass MFMA rank update
         self._mfma_partial = None
@@ -475,11 +497,10 @@ class Trainer:
                 t = getattr(p, "_cgv_rank" if self.sync is None else "_cgv_exch", None)
                 if t is None or p.dim() != 2 or (self.sync is not None and not exchanged(p)):
                     return False
-                if self.sync is not None:
-                    return True                                      # FMA-per-row kernel or MFMA tiles, by gathered rows
-                if t[0] <= self.RANK_ROWS_PAY and bool(lib.cgv_rank_update_supported(t[0], t[1], t[2])):
-                    return True
-                return self.RANK_ROWS_PAY < t[0] <= self.RANK_ROWS_MFMA and t[1] % 4 == 0 and t[2] % 4 == 0
+                rows = world * t[0]
+                if rows <= self.RANK_ROWS_PAY and bool(lib.cgv_rank_update_supported(rows, t[1], t[2])):
+                    return True                                      # FMA-per-row kernel
+                return self.RANK_ROWS_PAY < rows <= self._rank_rows_mfma() and t[1] % 4 == 0 and t[2] % 4 == 0
             live = sorted(live, key=lambda p: 0 if ranked(p) else 1)       # stable: u_mat / v_mat pairs stay adjacent
             n_rank = sum(1 for p in live if ranked(p))
         self.arena = ParamArena(live)
@@ -781,7 +802,7 @@ class Trainer:
             for lo, hi in complement_ranges(done, a.numel):         # everything not already in flight or gathered
                 self.sync.all_reduce_range(a.g, lo, hi)
             if self.exchange is not None:
-                self.exchange.complete()
+                self.exchange.complete(final=True)
                 if self.exchange.rank_hi:
                     self._start_gathered_rank_update()
             self.sync.wait()
@@ -836,15 +857,28 @@ class Trainer:
     # 241 us for 46 M weights), at 48 rows it is VALU bound (330 us) and only ties with the gathered MFMA launch + the
     # three extra passes over a materialised gradient (profiles/r02c_dp_cost_probe.txt).  The kernels take up to 64.
     RANK_ROWS_PAY = 40
-    # Single process: rows up to which a layer beyond RANK_ROWS_PAY takes the rank update as two passes of the MFMA tile
-    # kernel (norm pass, Adam-epilogue pass: cgv_grouped_wgrad_gathered_sumsq / _adam).  0 = off: measured on the dipeptide
-    # batch (96 bead rows) the second forming of the tiles costs more than the passes over a stored gradient it saves
-    # (2.917 against 2.870 ms per step; weight gradients 378 -> 389 us, optimiser 254 -> 283 us).  The data-parallel path
-    # uses the same two passes for its gathered rows, where they tie with materialising (section 6 of DESIGN.md) and keep
-    # every rank from writing the gradients; tests/test_full_size_parity.py turns this on (128) to pin the path against
-    # the oracle at full size.
+    # Rows (single process: a layer's own; data parallel: world x rows, gathered) up to which a layer beyond RANK_ROWS_PAY takes
+    # the rank update as two passes of the MFMA tile kernel (norm pass -- or the Gram launch, RANK_GRAM_ROWS -- and the
+    # Adam-epilogue pass: cgv_grouped_wgrad_strip_sumsq / _adam).  0 = off, such layers are materialised (data parallel: by
+    # every rank from the gathered rows, OperandExchange.materialise) and the flat norm / Adam passes follow.  Measured:
+    # dipeptide (96 bead rows) 2.917 against 2.870 ms per step; 4 / 8 stand-in ranks on the chignolin step 2.09 / 2.19 against
+    # 1.96 / 1.97 ms (profiles/r03_dp_cost_probe.txt).  The Adam-epilogue pass visits p / m / v as 64 rows x 256 bytes per
+    # step of a block, which streams at 4.1 TB/s against 7.0 TB/s for the flat pass (tools/probes/adam_pattern_probe.hip),
+    # so forming the tiles there costs more than the 12 bytes per weight it saves.  tests/test_full_size_parity.py and
+    # tests/test_dp_exchange.py turn the path on (128) to keep it pinned.
     RANK_ROWS_MFMA = 0
+    # MFMA rank update: rows up to which the norm pass is the Gram launch (row-pair dot products of the operands, no
+    # tiles formed) instead of the tile kernel with a squaring epilogue; the tiles are then formed once, by the Adam pass.
+    RANK_GRAM_ROWS = 0
     EARLY_MIN_FLOATS = 1 << 18      # ranges below 1 MiB are not worth a collective of their own: they go at the end
+
+    def _rank_rows_mfma(self):
+        from .options import HOST
+        return self.RANK_ROWS_MFMA if HOST["rank_rows_mfma"] < 0 else HOST["rank_rows_mfma"]
+
+    def _rank_gram_rows(self):
+        from .options import HOST
+        return self.RANK_GRAM_ROWS if HOST["rank_gram_rows"] < 0 else HOST["rank_gram_rows"]
 
     def _padded(self, r):
         """A parameter's range extended over its alignment padding (zeros), so that neighbours merge."""
@@ -881,7 +915,7 @@ class Trainer:
                  and lib.cgv_rank_update_supported(it[0].shape[0], it[0].shape[1], it[1].shape[1])]
         ids = {id(it) for it in small}
         large = [it for it in ranked if id(it) not in ids]        # more rows (dipeptide: 96, 2000-atom graph: 64): MFMA tiles, two passes
-        fits = all(it[0].shape[0] <= self.RANK_ROWS_MFMA and it[0].shape[1] % 4 == 0 and it[1].shape[1] % 4 == 0 for it in large)
+        fits = all(it[0].shape[0] <= self._rank_rows_mfma() and it[0].shape[1] % 4 == 0 and it[1].shape[1] % 4 == 0 for it in large)
         if in_range or not fits or sum(it[4].numel() for it in ranked) != self._rank_numel:
             self.rank_fallbacks += 1
             return items
@@ -994,7 +1028,15 @@ class Trainer:
         slot = slot0
         for kind, table, n, blocks, rows in launches:           # (stream order: the second launch reuses the partials)
             out = self._rank_sumsq.data_ptr() + 8 * slot
-            if kind == "strip":
+            if kind == "strip" and rows <= min(self._rank_gram_rows(), int(lib.cgv_wgrad_gram_mfma_max_rows())):
+                need = int(lib.cgv_wgrad_gram_mfma_workspace_bytes(n, rows))
+                if self._rank_ws2 is None or self._rank_ws2.numel() < need:
+                    if torch.cuda.is_current_stream_capturing():
+                        raise RuntimeError("run one eager step before capturing (rank-update workspace)")
+                    self._rank_ws2 = torch.empty(need, dtype=torch.uint8, device=dev)
+                _lib.call("cgv_wgrad_gram_mfma", _lib.ptr(table), n, rows, out, _lib.ptr(self._rank_ws2), self._rank_ws2.numel(),
+                          _lib.stream_ptr(), tag="wgrad_gram_mfma")
+            elif kind == "strip":
                 _lib.call("cgv_grouped_wgrad_strip_sumsq", _lib.ptr(table), n, blocks, rows, _lib.ptr(self._mfma_partial), out,
                           _lib.stream_ptr(), tag="strip_wgrad_sumsq")
             else:

@@ -634,6 +634,12 @@ int cgv_sgd_apply(float* p, const float* g, int64_t n, float lr, const float* st
 int cgv_wgrad_gram(const void* table_dev, int n_problems, int max_rows, double* sumsq, void* workspace,
                    size_t workspace_bytes, void* stream);
 size_t cgv_wgrad_gram_workspace_bytes(int n_problems);
+/* cgv_wgrad_gram for records of up to cgv_wgrad_gram_mfma_max_rows() = 128 rows (gathered rows of 4 - 8 ranks, bead rows
+ * of a large batch): the Gram matrices come from fp64 MFMA tiles instead of a walk over row pairs (same doubles). */
+int cgv_wgrad_gram_mfma(const void* table_dev, int n_problems, int max_rows, double* sumsq, void* workspace,
+                        size_t workspace_bytes, void* stream);
+size_t cgv_wgrad_gram_mfma_workspace_bytes(int n_problems, int max_rows);
+int cgv_wgrad_gram_mfma_max_rows(void);
 int cgv_rank_update_supported(int M, int N, int K);   /* 1 when a layer with M operand rows can take this path (M <= 64) */
 int cgv_optim_prepare_extra(const float* g, int64_t n, const double* extra, int n_extra, float beta1, float beta2,
                             float max_norm, float grad_scale, const float* loss, float skip_threshold, float* state,

@@ -115,10 +115,12 @@ def main():
     moved = (sync.gathered, sync.reduced)                # floats through the wire as counted at enqueue / capture time
     assert int(tr.state[ST_STEP].item()) == n_steps and tr.skipped_steps() == 0
     if args.mode == "operands":
-        assert tr.exchange is not None and tr.exchange.rank_hi == tr._rank_hi > 0 and tr.rank_fallbacks == 0
+        assert tr.exchange is not None and tr.rank_fallbacks == 0 and tr.rank_steps_mfma == 0
         rows = world * n_beads_rank
-        assert (tr.rank_steps >= 2) == (rows <= Trainer.RANK_ROWS_PAY), (tr.rank_steps, rows)
-        assert tr.rank_steps_mfma >= 2 or rows <= Trainer.RANK_ROWS_PAY     # MFMA strips: everything at 8 ranks x 12 rows
+        if rows <= Trainer.RANK_ROWS_PAY:                # 2 ranks: rank update over the gathered rows, nothing materialised
+            assert tr.exchange.rank_hi == tr._rank_hi > 0 and tr.rank_steps >= 2, (tr.rank_steps, rows)
+        else:                                            # 8 ranks x 12 rows: every rank forms the gradients from the gathered rows
+            assert tr.exchange.rank_hi == tr._rank_hi == 0 and tr.rank_steps == 0
     else:
         assert tr.exchange is None
 

@@ -92,12 +92,15 @@ def test_operand_exchange_reproduces_single_rank_training(world):
     tr, got = _train(world, "operands", F=F)
     assert tr.exchange is not None and tr.sync.gathered > 0
     assert _worst(got, ref) < 2e-5
-    # no rank materialises the exchanged weights' gradients: up to Trainer.RANK_ROWS_PAY gathered rows (2 ranks x 12 bead
-    # rows) they take the FMA-per-row rank update, with more rows (the 36-row [u_mat; v_mat] layers; everything at 4 / 8
-    # ranks) the MFMA tile kernel's norm and Adam passes
-    assert tr.rank_fallbacks == 0 and tr._rank_hi > 0 and tr.exchange.rank_hi == tr._rank_hi
-    assert (tr.rank_steps >= 2) == (world * 12 <= Trainer.RANK_ROWS_PAY)
-    assert (tr.rank_steps_mfma >= 2) == (world * 12 > Trainer.RANK_ROWS_PAY)     # (at these widths the 36-row layers are not exchanged)
+    # up to Trainer.RANK_ROWS_PAY gathered rows (2 ranks x 12 bead rows) no rank materialises the exchanged weights' gradients
+    # (FMA-per-row rank update on the gathered rows); with more (4 / 8 ranks) every rank forms them from the gathered rows
+    # by the strip launch and the flat norm / Adam passes follow (test_gathered_mfma_rank_update_* keeps the two-pass MFMA
+    # rank update of those row counts covered)
+    assert tr.rank_fallbacks == 0 and tr.rank_steps_mfma == 0
+    if world * 12 <= Trainer.RANK_ROWS_PAY:
+        assert tr._rank_hi > 0 and tr.exchange.rank_hi == tr._rank_hi and tr.rank_steps >= 2
+    else:
+        assert tr._rank_hi == 0 and tr.exchange.rank_hi == 0 and tr.rank_steps == 0
     # the exchanged layers sit at the front of the arena: what is left for the all-reduce is a handful of ranges
     a = tr.arena
     done = sorted(tr._padded(r) for r in tr.exchange.done_ranges)
@@ -110,6 +113,26 @@ def test_operand_exchange_reproduces_single_rank_training(world):
     tr2, got2 = _train(world, "gradients", F=F)
     assert tr2.exchange is None and tr2.sync.gathered == 0
     assert _worst(got2, ref) < 2e-5
+
+
+@pytest.mark.parametrize("gram_rows", [0, 128])
+@pytest.mark.parametrize("world", [4, 8])
+def test_gathered_mfma_rank_update_reproduces_single_rank_training(world, gram_rows):
+    """options rank_rows_mfma=128: the exchanged layers of 4 / 8 ranks (48 / 96 gathered rows) take the two-pass MFMA rank
+    update -- norm from a tile pass (rank_gram_rows=0) or from the fp64-MFMA Gram launch (128), then the Adam-epilogue
+    pass -- instead of being materialised; same training as a single rank."""
+    from coarsegrainingvae_amd import options
+    F = {4: 128, 8: 256}[world]
+    _, ref = _train(1, "auto", F=F)
+    options.set("rank_rows_mfma", 128)
+    options.set("rank_gram_rows", gram_rows)
+    try:
+        tr, got = _train(world, "operands", F=F)
+    finally:
+        options.reset()
+    assert tr.rank_fallbacks == 0 and tr._rank_hi > 0 and tr.exchange.rank_hi == tr._rank_hi
+    assert tr.rank_steps_mfma >= 2 and tr.rank_steps == 0
+    assert _worst(got, ref) < 2e-5
 
 
 def test_operand_exchange_inside_a_captured_step():

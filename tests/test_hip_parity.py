@@ -1420,6 +1420,60 @@ def test_wgrad_gram_norm_and_fused_adam_vs_fp64():
     assert float(err.max()) <= 5e-6, (float(err.max()), int(err.argmax()), [r[2] for r in refs])
 
 
+def test_wgrad_gram_mfma_norm_vs_fp64():
+    """cgv_wgrad_gram_mfma: ||g^T x||_F^2 and the bias gradient from up to 128 operand rows (fp64 MFMA tiles of the two
+    Gram matrices), against fp64 torch -- row counts on and off the 16-row tile grid, ragged column slices, with and
+    without an activation derivative, and records that address rank segments of a gathered buffer."""
+    from coarsegrainingvae_amd.primitives import WeightGradQueue
+    lib = cg._lib.load()
+    assert lib.cgv_wgrad_gram_mfma_max_rows() == 128
+    g = torch.Generator(device=DEV).manual_seed(11)
+    shapes = [(48, 600, 600, 1, True), (96, 1800, 600, 0, True), (64, 5400, 600, 0, False), (128, 200, 328, 2, True),
+              (41, 76, 52, 1, True), (100, 1204, 36, 0, True), (12, 600, 600, 1, True)]
+    items, refs = [], []
+    for M, N, K, act, bias in shapes:
+        gy = torch.randn(M, N, device=DEV, generator=g)
+        x = torch.randn(M, K, device=DEV, generator=g)
+        z = torch.randn(M, N, device=DEV, generator=g) if act else None
+        gb = torch.full((N,), float("nan"), device=DEV) if bias else None
+        items.append((gy, x, z, act, torch.empty(N, K, device=DEV), gb, False))
+        gd = gy.double()
+        if act:
+            zd = z.double()
+            sg = torch.sigmoid(zd)
+            gd = gd * {1: sg * (1 + zd * (1 - sg)), 2: 1 - torch.tanh(zd) ** 2}[act]
+        refs.append((float(((gd.T @ x.double()) ** 2).sum()), gd.sum(0)))
+    q = WeightGradQueue()
+    table, _blocks, rows = q.strip_table([it for it in items if it[0].shape[0] >= 32])
+    small, _b, _l = q.small_table([it for it in items if it[0].shape[0] < 32])
+    ws = torch.empty(int(lib.cgv_wgrad_gram_mfma_workspace_bytes(len(items), 128)), dtype=torch.uint8, device=DEV)
+    n_big = sum(1 for it in items if it[0].shape[0] >= 32)
+    sumsq = torch.zeros(len(items), dtype=torch.float64, device=DEV)
+    cg._lib.call("cgv_wgrad_gram_mfma", cg._lib.ptr(table), n_big, rows, cg._lib.ptr(sumsq), cg._lib.ptr(ws), ws.numel(),
+                 cg._lib.stream_ptr())
+    cg._lib.call("cgv_wgrad_gram_mfma", cg._lib.ptr(small), len(items) - n_big, 12, sumsq.data_ptr() + 8 * n_big, cg._lib.ptr(ws),
+                 ws.numel(), cg._lib.stream_ptr())
+    for k, (ref, gbias) in enumerate(refs):
+        assert abs(float(sumsq[k]) - ref) <= 1e-7 * ref, (shapes[k], float(sumsq[k]), ref)     # (act' is applied in fp32)
+        if items[k][5] is not None:
+            assert torch.allclose(items[k][5].double(), gbias, rtol=1e-5, atol=2e-5), shapes[k]
+    # gathered operands: 8 rank segments of 12 rows each, [g | x | other layers' rows] per segment
+    world, M, N, K = 8, 12, 1800, 600
+    total = M * (N + K) + 128
+    recv = torch.randn(world * total, device=DEV, generator=g)
+    gb = torch.full((N,), float("nan"), device=DEV)
+    seg = recv.view(world, total)
+    gd = seg[:, :M * N].reshape(world * M, N).double()
+    xd = seg[:, M * N:M * (N + K)].reshape(world * M, K).double()
+    table, _blocks, rows = q.strip_table([(M, N, K, 0, M * N, torch.empty(N, K, device=DEV), gb, False, recv, total)], seg=world)
+    assert rows == world * M
+    cg._lib.call("cgv_wgrad_gram_mfma", cg._lib.ptr(table), 1, rows, cg._lib.ptr(sumsq), cg._lib.ptr(ws), ws.numel(),
+                 cg._lib.stream_ptr())
+    ref = float(((gd.T @ xd) ** 2).sum())
+    assert abs(float(sumsq[0]) - ref) <= 1e-9 * ref
+    assert torch.allclose(gb.double(), gd.sum(0), rtol=1e-5, atol=2e-5)
+
+
 @pytest.mark.parametrize("captured", [False, True])
 def test_rank_update_training_matches_materialised_gradients(captured):
     """Trainer(rank_update=True) -- bead-level weight gradients never written -- against rank_update=False: same losses,

@@ -17,15 +17,18 @@ from coarsegrainingvae_amd.trainer import Trainer       # noqa: E402
 from test_dp_exchange import LoopbackSync               # noqa: E402
 
 
+RANK_UPDATE = True
+
+
 def run(workload, world, mode, steps=50):
     w = cg.data.WORKLOADS[workload]
     model = cg.build_model(600, w["n_rbf"], w["atom_cutoff"], w["cg_cutoff"], w["enc_nconv"], w["dec_nconv"], w["n_cgs"],
                            seed=123).cuda()
     batch = cg.synthetic_batch(workload, seed=0, device="cuda")
     sync = LoopbackSync(world) if world > 1 else None
-    tr = Trainer(model, lr=1e-4, beta=w["beta"], gamma=w["gamma"], world_size=world, exchange=mode, sync=sync)
+    tr = Trainer(model, lr=1e-4, beta=w["beta"], gamma=w["gamma"], world_size=world, exchange=mode, sync=sync, rank_update=RANK_UPDATE)
     tr.step(batch)
-    with ktimer.KernelTimer(("gathered_wgrad", "grouped_wgrad", "strip_wgrad", "pack_operands")) as kt:
+    with ktimer.KernelTimer(("gathered_wgrad", "grouped_wgrad", "strip_wgrad", "pack_operands", "wgrad_gram")) as kt:
         for _ in range(3):
             tr.step(batch)
         ks = kt.summary()
@@ -54,6 +57,11 @@ def run(workload, world, mode, steps=50):
 
 
 if __name__ == "__main__":
+    from coarsegrainingvae_amd import options
+    sys.argv = [sys.argv[0]] + options.pop_cli(sys.argv[1:])
+    if "--no-rank-update" in sys.argv:                      # operand exchange, but every gathered gradient is materialised
+        sys.argv.remove("--no-rank-update")
+        RANK_UPDATE = False
     wl = sys.argv[1] if len(sys.argv) > 1 else "chignolin"
     if len(sys.argv) > 2:                                   # one configuration only (for a rocprofv3 --kernel-trace run)
         run(wl, int(sys.argv[2]), sys.argv[3] if len(sys.argv) > 3 else ("operands" if int(sys.argv[2]) > 1 else "auto"))
