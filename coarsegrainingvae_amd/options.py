@@ -12,6 +12,7 @@ HOST = {
     "wgrad_kernel": 0,      # grouped weight gradients of <= 64 rows: 0 weight-streaming VALU kernel, 1 MFMA tiles for all
     "table_upload": 0,      # record tables of a captured step: 0 copied once after capture, 1 a copy node in every replay
     "wgrad_tile": 64,       # output tile edge of the grouped MFMA weight-gradient launch: 64 or 128
+    "rank_update": 1,       # Trainer: 1 rank update of the bead-level layers where it pays, 0 every gradient materialised (A/B)
     "rank_rows_mfma": -1,   # single process: rows up to which layers beyond 40 rows take the MFMA rank update (-1: Trainer.RANK_ROWS_MFMA)
     "rank_gram_rows": -1,   # MFMA rank update: rows up to which the norm comes from the Gram launch instead of a tile pass (-1: Trainer.RANK_GRAM_ROWS)
     "decoder_dense": 0,     # full-width products of the fused decoder loop: 0 four-column blocks (cgv_decoder_dense_fwd), 1 skinny_fwd_k

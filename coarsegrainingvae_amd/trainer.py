@@ -372,7 +372,9 @@ class Trainer:
         # the all-gathered rows of the operand exchange (world x rows per rank: _start_gathered_rank_update), so no rank
         # materialises these gradients either.  ``p.grad`` of those weights then holds stale data; pass
         # rank_update=False to materialise every gradient.
-        self.rank_update = bool(rank_update) and fused_optimizer and not self.defer_update and optimizer == "adam"
+        from .options import HOST
+        self.rank_update = (bool(rank_update) and fused_optimizer and not self.defer_update and optimizer == "adam"
+                            and HOST["rank_update"] != 0)
         self._rank_hi = 0             # arena floats [0, _rank_hi) belong to rank-update weights
         self._rank_numel = 0
         self._rank_ws2 = None         # Gram workspace of the MFMA rank update's norm launch
