@@ -422,6 +422,15 @@ def main():
             print(f"[bench] hipGraph capture failed on rank {rank}: {exc!r}; falling back to eager steps", file=sys.stderr)
             use_graph = False
             torch.cuda.synchronize()
+        if dist is not None:
+            # all ranks replay, or none does: a rank that runs eagerly beside replaying ranks would still issue the same
+            # collectives, but the run would no longer measure one thing
+            ok = torch.tensor([1 if use_graph else 0], device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if use_graph and int(ok.item()) == 0:
+                print(f"[bench] another rank could not capture the step: rank {rank} drops its graph too", file=sys.stderr)
+                trainer._graphs.clear()
+                use_graph = False
 
     # ---------------------------------------------------------------- headline: rotation of resident batches
     # double-buffered: while step i runs, batch i+1 is loaded into the second buffer set on a side stream (its graph
