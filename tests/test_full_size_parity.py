@@ -354,3 +354,72 @@ def test_channel_group_decoder_at_its_limits(n_atoms, n_cgs, frames, F, n_rbf, c
         assert float((p1 - p0).abs().max()) <= 2e-2 * 1e-4 * 3 or rel_err(p1, p0) <= 1e-6
     finally:
         cg.data.WORKLOADS.pop(name, None)
+
+
+# --------------------------------------------------------------------------- size-independent properties at full size
+def _frames(workload, n_frames, seed=0):
+    """Per-frame dicts (reference format) of a synthetic workload with their neighbour lists."""
+    w = cg.data.WORKLOADS[workload]
+    ds = cg.data.CGDataset(cg.data.synthetic_frames(n_frames, w["n_atoms"], w["n_cgs"], w["box"], seed,
+                                                    spatial_sort=(workload == "protein2000")))
+    ds.generate_neighbor_list(w["atom_cutoff"], w["cg_cutoff"], device=DEV, undirected=True)
+    return [ds[i] for i in range(n_frames)]
+
+
+def _forward(model, frames, eps):
+    batch = cg.prepare_batch(cg.data.CG_collate(frames), DEV)
+    with torch.no_grad():
+        out = model(batch, eps=eps)
+    loss = cg.train.loss_terms(out, batch, 0.05, 50.0)
+    return [o.detach() for o in out], [float(t) for t in loss]
+
+
+@pytest.mark.parametrize("workload,frames", [("chignolin", 2), ("protein2000", 1)])
+def test_full_size_rotation_translation_properties(workload, frames):
+    """BASELINE sizes (F = 600, enc 2 / dec 9; 2 x 166 atoms and 1 x 2000 atoms), full forward through the default
+    dispatch: a rigid motion x -> Q x + t of every frame leaves mu / sigma / prior and all three ELBO terms unchanged
+    and moves xyz_recon with the frame (SO(3) equivariance of the decoder, cgvae.py:462-484) -- 1e-4 relative, norm-wise."""
+    w = cg.data.WORKLOADS[workload]
+    model = cg.build_model(600, w["n_rbf"], w["atom_cutoff"], w["cg_cutoff"], w["enc_nconv"], w["dec_nconv"], w["n_cgs"], seed=123).to(DEV)
+    fr = _frames(workload, frames)
+    n_beads = frames * w["n_cgs"]
+    eps = torch.randn(n_beads, 600, generator=torch.Generator().manual_seed(11)).to(DEV)
+    out, loss = _forward(model, fr, eps)
+    Q, _ = torch.linalg.qr(torch.randn(3, 3, generator=torch.Generator().manual_seed(1)))
+    if torch.det(Q) < 0:
+        Q[:, 0] = -Q[:, 0]
+    shift = torch.tensor([1.5, -2.0, 0.7])
+    moved = []
+    for f in fr:
+        g = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in f.items()}
+        g["nxyz"][:, 1:] = f["nxyz"][:, 1:] @ Q.T + shift
+        g["CG_nxyz"][:, 1:] = f["CG_nxyz"][:, 1:] @ Q.T + shift
+        moved.append(g)
+    out2, loss2 = _forward(model, moved, eps)
+    for k in range(4):
+        assert rel_err(out2[k], out[k]) < REL, NAMES[k]
+    Qd, sd = Q.to(DEV), shift.to(DEV)
+    assert rel_err(out2[5] - sd, out[5] @ Qd.T) < REL                  # (compared about the origin: the shift is not part of the scale)
+    assert rel_err(out2[4], out[4] @ Qd.T + sd) < 1e-6
+    for a, b, name in zip(loss2, loss, ("loss", "kl", "recon", "graph")):
+        assert abs(a - b) <= 2e-4 * max(abs(b), 1e-6), (name, a, b)
+
+
+def test_full_size_frames_are_independent_and_order_free():
+    """Chignolin at the bench configuration: a batch is a disjoint union of frames (data.py:255-289), so (i) swapping the
+    two frames swaps the outputs' halves and leaves the ELBO terms unchanged, (ii) frame 0 alone gives the first half of
+    the two-frame outputs.  Exercises plans, groups and segment kernels at full size with another row order."""
+    w = cg.data.WORKLOADS["chignolin"]
+    model = cg.build_model(600, w["n_rbf"], w["atom_cutoff"], w["cg_cutoff"], w["enc_nconv"], w["dec_nconv"], w["n_cgs"], seed=123).to(DEV)
+    fr = _frames("chignolin", 2)
+    nb, na = w["n_cgs"], w["n_atoms"]
+    eps = torch.randn(2 * nb, 600, generator=torch.Generator().manual_seed(12)).to(DEV)
+    out, loss = _forward(model, fr, eps)
+    swapped, loss_s = _forward(model, [fr[1], fr[0]], torch.cat([eps[nb:], eps[:nb]]))
+    alone, _ = _forward(model, [fr[0]], eps[:nb])
+    for k, name in enumerate(NAMES):
+        n = nb if k < 4 else na
+        assert rel_err(torch.cat([swapped[k][n:], swapped[k][:n]]), out[k]) < REL, name
+        assert rel_err(alone[k], out[k][:n]) < REL, name
+    for a, b, name in zip(loss_s, loss, ("loss", "kl", "recon", "graph")):
+        assert abs(a - b) <= 2e-4 * max(abs(b), 1e-6), (name, a, b)
