@@ -586,6 +586,7 @@ class _Elbo(torch.autograd.Function):
         ctx.grads = grads
         ctx.slot = slot
         ctx.mark_non_differentiable(out)
+        ctx.set_materialize_grads(False)           # (no zeros(4) fill launch for the terms' never-used gradient)
         return loss, out
 
     @staticmethod
@@ -598,6 +599,8 @@ class _Elbo(torch.autograd.Function):
         to_autograd = (lambda: (g[0], g[1])) if slot is None else (lambda: (None, None))
         if slot is not None:
             slot.g_mu, slot.g_sigma = g[0], g[1]
+        if g_loss is None:
+            return (None,) * 10
         if g_loss.data_ptr() == _UNIT_SEED.get(g_loss.device):
             # the caller seeded backward with its registered constant 1 (unit_seed): the gradients of the forward launch
             # are final as they are -- no scale launch, and no ones_like fill in front of it

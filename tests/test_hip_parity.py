@@ -1353,10 +1353,20 @@ def test_deferred_update_equals_in_step_update(captured):
     assert torch.equal(m0, m1)
 
 
-def test_wgrad_gram_norm_and_fused_adam_vs_fp64():
+@pytest.fixture
+def wgrad_tiling(request):
+    from coarsegrainingvae_amd import options
+    options.set("wgrad_tiling", request.param)
+    yield request.param
+    options.reset()
+
+
+@pytest.mark.parametrize("wgrad_tiling", [0, 1], indirect=True)
+def test_wgrad_gram_norm_and_fused_adam_vs_fp64(wgrad_tiling):
     """cgv_wgrad_gram: ||g^T x||_F^2 from the operand rows (+ bias gradient); cgv_grouped_wgrad_adam: the Adam update of
     the weights from tiles of g^T x that are never stored.  Checked against fp64 torch on the shapes the chignolin and
-    update block produce (12 / 36 / 40 rows, with and without an activation derivative)."""
+    update block produce (12 / 36 / 40 rows, with and without an activation derivative), under both column tilings of
+    the fused update (option wgrad_tiling: balanced or widest tiles)."""
     from coarsegrainingvae_amd.primitives import WeightGradQueue
     lib = cg._lib.load()
     g = torch.Generator(device=DEV).manual_seed(5)
