@@ -208,11 +208,10 @@ class OperandExchange:
     batches) and every other parameter keep the gradient all-reduce.
 
     Protocol per backward bucket: ``submit`` packs the queued problems' operands into one send buffer (one launch)
-    and starts the all-gather on the communication stream; ``complete`` (called at the next bucket boundary, i.e.
-    after ~3 decoder layers of backward, and at the end) waits for the gathers and runs the gathered launches.
-    Needs equally shaped shards on every rank: ``Trainer._check_shards`` compares them at the start of every eager
-    step and before a capture (never behind a per-rank cache -- a rank that skipped the comparison would leave the
-    others waiting in it)."""
+    and starts the all-gather on the communication stream; ``complete(final=True)``, at the end of backward, waits for
+    the step's gathers and forms every gathered gradient in one launch (or hands the rows to the rank update).
+    Needs equally shaped shards on every rank: ``Trainer._check_shards`` compares them the first time a rank meets a
+    shape and before every capture."""
 
     PACK = struct.Struct("<5Q5i4x")             # cgv::PackProblem, 64 bytes
 
@@ -287,9 +286,13 @@ class OperandExchange:
 
     # -- gathered weight gradients
     def complete(self, final: bool = False):
-        """Wait for the gathers in flight.  Their problems are formed by ONE materialise() at the end of backward
-        (``final``): a launch per backward bucket was 4 x 52 us for the strips of a chignolin step at 8 ranks where the
-        single launch takes about 100 (blocks of few problems leave the chip half empty at both ends)."""
+        """End of backward (``final``): wait for every gather of the step and form their problems' gradients by ONE
+        materialise() -- a launch per backward bucket was 4 x 52 us for the strips of a chignolin step at 8 ranks where the
+        single launch takes about 100 (launches of few problems leave the chip half empty at both ends).  At a bucket
+        boundary (not ``final``) nothing is done: nobody needs the rows yet, and a wait there would only stall backward
+        behind a gather that is still travelling."""
+        if not final:
+            return
         for work, metas, recv, _send, total in self.inflight:
             work.wait()                                      # the current stream now waits for the gather
             for meta in metas:
@@ -297,16 +300,15 @@ class OperandExchange:
                 keep = self.rank_hi and r is not None and r[1] <= self.rank_hi
                 (self.ranked if keep else self.pending).append(meta + (recv, total))
         self.inflight = []                                   # buffers: the problem tuples hold them until they are used
-        if final:
-            now, self.pending = self.pending, []
-            # a problem that ADDS to its gW (a layer applied twice in a step) must not share a launch with the one that wrote it
-            group = []
-            for m in now:
-                if m[7] and group:
-                    self.materialise(group)
-                    group = []
-                group.append(m)
-            self.materialise(group)
+        now, self.pending = self.pending, []
+        # a problem that ADDS to its gW (a layer applied twice in a step) must not share a launch with the one that wrote it
+        group = []
+        for m in now:
+            if m[7] and group:
+                self.materialise(group)
+                group = []
+            group.append(m)
+        self.materialise(group)
 
     def materialise(self, problems):
         """gW / gb of gathered problems (meta + (recv buffer, floats per rank segment)) into the gradient arena."""
@@ -1049,14 +1051,13 @@ class Trainer:
 
     def _bucket_done(self, index: int):
         """Autograd-thread callback (model.bucket_done): the gradients of backward bucket ``index`` are final.
-        Finish the previous bucket's operand exchange, start this one's, and all-reduce what the exchange does not
-        cover; backward continues."""
+        Start this bucket's operand exchange (pack + all-gather; the rows are used at the end of backward) and all-reduce
+        what the exchange does not cover; backward continues."""
         if index in self._sent or index >= len(self.early_ranges):
             return
         self._sent.add(index)
         ranges = self.early_ranges[index]
         if self.exchange is not None:
-            self.exchange.complete()                 # the gather started one bucket ago has had time to finish
             self._flush_queue(True)
             ranges = subtract_ranges(ranges, [self._padded(r) for r in self.exchange.done_ranges])
         else:
