@@ -267,7 +267,10 @@ class CGequiVAE(nn.Module):
         # set by the trainer when the previous step's update of the decoder's parameters is still running on a side
         # stream (Trainer(defer_update=True)): called once, right before the decoder first touches its weights
         self.before_decoder = None
-        self.bucket_layers = 3             # decoder layers per early all-reduce bucket
+        # decoder layers per backward bucket (data parallel: one operand all-gather per bucket).  9 layers -> two gathers
+        # (layers 8..4, 3..0): every collective node costs the replayed step 7 - 40 us whatever it carries, and the second
+        # half's rows still travel under the prior's and the encoder's backward
+        self.bucket_layers = 5
         self.concurrent_prior = False      # measured: cross-stream joins cost more than the overlap saves (3.72 vs 3.53 ms)
         self._streams = {}
         if not equivariant:

@@ -40,7 +40,9 @@ class ParamArena:
             total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
         self.offsets, self.numel = offs, total
         self.p = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.g = torch.zeros(total, dtype=torch.float32, device=dev)
+        # _ALIGN spare floats behind the gradients: g[numel] carries the step's loss through the LAST gradient all-reduce of a
+        # data-parallel step (the skip decision, utils.py:145, must be the same on every rank) -- no collective of its own
+        self.g = torch.zeros(total + _ALIGN, dtype=torch.float32, device=dev)
         for p, o in zip(params, offs):
             n = p.numel()
             self.p[o:o + n].copy_(p.data.reshape(-1))
@@ -379,6 +381,7 @@ class Trainer:
                             and HOST["rank_update"] != 0)
         self._rank_hi = 0             # arena floats [0, _rank_hi) belong to rank-update weights
         self._rank_numel = 0
+        self._early_carry = []        # ranges of finished buckets below EARLY_MIN_FLOATS, waiting for the next boundary
         self._rank_ws2 = None         # Gram workspace of the MFMA rank update's norm launch
         self._rank_step = None        # this step's (table, problems, blocks, lds, items, max rows) once the Gram launch is out
         self._rank_mfma = None        # ([(kind, table, problems, blocks, rows)], problems, items) of the layers on the two-pass MFMA rank update
@@ -482,6 +485,16 @@ class Trainer:
             raise RuntimeError("no parameter received a gradient")
         on_device = live[0].device.type == "cuda"
         use_exchange = (self.sync is not None and self.fused and on_device and self.exchange_mode != "gradients")
+        if self.sync is not None and hasattr(self.model, "backward_buckets"):
+            # data parallel: parameters in the order their gradients become final (bucket by bucket, the rest last), so that
+            # what a bucket boundary all-reduces is ONE contiguous range that starts where the previous one ended, and what
+            # is left at the end of backward is one range too (a collective costs tens of microseconds whatever it carries)
+            order = {}
+            buckets = self.model.backward_buckets()
+            for k, params in enumerate(buckets):
+                for p in params:
+                    order.setdefault(id(p), k)
+            live = sorted(live, key=lambda p: order.get(id(p), len(buckets)))          # stable: module order inside a bucket
         if use_exchange:
             # layers whose operand rows will be exchanged go to the front of the arena, so that what is left for the
             # gradient all-reduce is a few large contiguous ranges (tags: primitives._LinearFn.backward)
@@ -768,8 +781,19 @@ class Trainer:
         self.last_loss, self.last_terms = loss.detach(), (kl.detach(), recon.detach(), graph.detach())
         # detached: a retained autograd graph would pin AccumulateGrad nodes to this step's stream
         self.last_out = tuple(o.detach() if o is not None else None for o in out)
-        decision = self.last_loss if self.sync is None else self.sync.mean_scalar(self.last_loss)
         threshold = self.gamma * 200.0
+        fold = self.sync is not None and self.fused and self.arena is not None and train
+        if self.sync is None:
+            decision = self.last_loss
+        elif fold:
+            # the loss rides in the spare slot of the gradient arena through the step's last all-reduce (SUM: the threshold
+            # is scaled instead of the sum divided); a collective of its own in front of backward made every rank's
+            # backward wait for the slowest rank's forward
+            decision = self.arena.g[self.arena.numel:self.arena.numel + 1]
+            decision.copy_(self.last_loss.detach().reshape(1))
+            threshold *= self.world
+        else:
+            decision = self.sync.mean_scalar(self.last_loss)
 
         if not self.fused:
             lv = float(decision)                                     # host sync, like utils.py:145
@@ -783,6 +807,7 @@ class Trainer:
             self.arena.zero_grad()
             use_ex = self.exchange is not None and train and self.sync is not None
             self._early_done = []
+            self._early_carry = []
             if self.exchange is not None:
                 self.exchange.begin_step()
             with wgrad_queue.collect():          # bead-level weight gradients: queued, then ONE grouped launch
@@ -803,7 +828,8 @@ class Trainer:
             done = list(getattr(self, "_early_done", []))
             if self.exchange is not None:
                 done += [self._padded(r) for r in self.exchange.done_ranges]
-            for lo, hi in complement_ranges(done, a.numel):         # everything not already in flight or gathered
+            # everything not already in flight or gathered (+ the slot that carries the loss: it extends the last range)
+            for lo, hi in complement_ranges(done, a.numel + (_ALIGN if fold else 0)):
                 self.sync.all_reduce_range(a.g, lo, hi)
             if self.exchange is not None:
                 self.exchange.complete(final=True)
@@ -874,7 +900,9 @@ class Trainer:
     # MFMA rank update: rows up to which the norm pass is the Gram launch (row-pair dot products of the operands, no
     # tiles formed) instead of the tile kernel with a squaring epilogue; the tiles are then formed once, by the Adam pass.
     RANK_GRAM_ROWS = 0
-    EARLY_MIN_FLOATS = 1 << 18      # ranges below 1 MiB are not worth a collective of their own: they go at the end
+    # ranges below 4 MiB are not worth a collective of their own (a collective node costs the replayed step 7 - 40 us even on a
+    # 1-rank group, tools/dp_rccl1_probe.py): they wait for the next bucket boundary, whose range continues theirs
+    EARLY_MIN_FLOATS = 1 << 20
 
     def _rank_rows_mfma(self):
         from .options import HOST
@@ -1062,10 +1090,21 @@ class Trainer:
             ranges = subtract_ranges(ranges, [self._padded(r) for r in self.exchange.done_ranges])
         else:
             wgrad_queue.flush()
-        for lo, hi in ranges:
+        # ranges too small for a collective of their own wait for the next boundary: the arena is in bucket order, so they
+        # are neighbours of that bucket's ranges and travel as part of them
+        merged = []
+        for lo, hi in sorted(self._early_carry + list(ranges)):
+            if merged and merged[-1][1] == lo:
+                merged[-1] = (merged[-1][0], hi)
+            else:
+                merged.append((lo, hi))
+        self._early_carry = []
+        for lo, hi in merged:
             if hi - lo >= self.EARLY_MIN_FLOATS:
                 self.sync.all_reduce_range(self.arena.g, lo, hi)
                 self._early_done.append((lo, hi))
+            else:
+                self._early_carry.append((lo, hi))
 
     def _unsent_ranges(self):
         """Ranges of the arena that neither an early all-reduce nor the operand exchange has covered in this step."""

@@ -70,6 +70,7 @@ def main():
 
     model = build()
     tr = Trainer(model, lr=args.lr, beta=w["beta"], gamma=w["gamma"], world_size=world, exchange=args.mode, sync=sync)
+    tr.EARLY_MIN_FLOATS = 4096                      # (test-sized layers: keep the early all-reduces in play)
 
     if args.uneven:
         tr.step(batch, eps=my_eps(0))                    # builds the arena (plain all-reduce: shapes do not matter yet)

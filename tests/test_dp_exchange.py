@@ -63,6 +63,7 @@ def _train(world, mode, steps=3, capture=False, F=64):
     model, batch, w = _setup(F=F)
     sync = LoopbackSync(world) if world > 1 else None
     tr = Trainer(model, lr=1e-3, beta=w["beta"], gamma=w["gamma"], world_size=world, exchange=mode, sync=sync)
+    tr.EARLY_MIN_FLOATS = 4096                      # (test-sized layers: keep the early all-reduces in play)
     eps = torch.randn(batch["CG_nxyz"].shape[0], F, generator=torch.Generator().manual_seed(1)).to(DEV)
     if capture:
         model.det = True                       # a captured step draws no eps; det keeps the runs comparable

@@ -113,6 +113,7 @@ def _worker(rank, world, port, n_steps, lr, gamma, q):
     try:
         model = OracleModule()
         tr = Trainer(model, lr=lr, beta=BETA, gamma=gamma, world_size=world, fused_optimizer=False)
+        tr.EARLY_MIN_FLOATS = 1024                  # (test-sized layers: keep the early all-reduces in play)
         fr = frames(4)
         batch = CG_collate(fr[2 * rank: 2 * rank + 2])
         losses = [float(tr.step(batch)) for _ in range(n_steps)]

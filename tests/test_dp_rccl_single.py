@@ -25,6 +25,7 @@ def run(always_sync, graph, exchange="auto"):
     model = cg.build_model(64, w["n_rbf"], w["atom_cutoff"], w["cg_cutoff"], 2, 2, w["n_cgs"], det=True, seed=123).cuda()
     model.bucket_layers = 1                      # two decoder layers -> two early all-reduce buckets
     tr = Trainer(model, lr=1e-3, beta=w["beta"], gamma=w["gamma"], world_size=1, always_sync=always_sync, exchange=exchange)
+    tr.EARLY_MIN_FLOATS = 4096                   # (test-sized layers: keep the early all-reduces in play)
     losses = [float(tr.step(batch)) for _ in range(3)]
     if graph:
         tr.capture(batch, warmup=0)
