@@ -429,7 +429,7 @@ def main():
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if use_graph and int(ok.item()) == 0:
                 print(f"[bench] another rank could not capture the step: rank {rank} drops its graph too", file=sys.stderr)
-                trainer._graphs.clear()
+                trainer.drop_graphs()
                 use_graph = False
 
     # ---------------------------------------------------------------- headline: rotation of resident batches

@@ -80,6 +80,8 @@ class GradSync:
     Averaging is folded into the optimiser kernel's ``grad_scale`` (or applied by the caller for
     the unfused path)."""
 
+    WATCHDOG_GRACE_S = 0.35       # see drain()
+
     def __init__(self, world_size: int, group=None, bucket_bytes: int = 64 << 20):
         import torch.distributed as dist
         self.dist, self.world, self.group = dist, world_size, group
@@ -164,6 +166,13 @@ class GradSync:
                     raise RuntimeError("a collective issued before the capture did not complete")
                 time.sleep(0.001)
         self.issued = []
+        if torch.cuda.is_available() and self.dist.get_backend(self.group) == "nccl":
+            # Completed is not yet FORGOTTEN: the watchdog drops a finished work from its list only on its next pass (every
+            # 100 ms), and until then it queries the work's end event -- recorded on RCCL's stream, which the capture is about
+            # to pull in.  HIP refuses a query on an event whose stream is capturing (hipErrorCapturedEvent), the watchdog
+            # thread throws and the process aborts: seen once in ~30 captures of tests/test_dp_rccl_single.py.  That includes
+            # the synchronous collectives (same_on_all_ranks, mean_scalar) this object does not keep handles of.
+            time.sleep(self.WATCHDOG_GRACE_S)
 
     def mean_scalar(self, x: torch.Tensor) -> torch.Tensor:
         y = x.detach().clone().reshape(1)
@@ -411,6 +420,7 @@ class Trainer:
         self.last_terms = None
         self.steps_skipped_host = 0
         self._graphs = {}             # train flag -> captured hipGraph of one full step (capture())
+        self._retired = []            # replaced captures of a data-parallel trainer (_retire)
         self._pre_stream = None       # side stream of enable_prefetch()
         self.replays = 0
 
@@ -632,8 +642,24 @@ class Trainer:
         if _twin_of is not None:
             _twin_of["twin"] = record                       # the same step on a second set of batch buffers (enable_prefetch)
         else:
-            self._graphs[self._graph_key(train, pending_at_start)] = record
+            key = self._graph_key(train, pending_at_start)
+            self._retire(self._graphs.get(key))
+            self._graphs[key] = record
         return graph
+
+    def _retire(self, record):
+        """A replaced captured step.  With collectives inside, the graph is PARKED, not destroyed: destroying hipGraphs
+        that hold RCCL nodes corrupts the heap after a few dozen of them (tools/capture_stress.py: `free(): invalid pointer`
+        around the 25th re-capture on a 1-rank group; 60 re-captures pass with the old graphs kept, and 60 pass without a
+        process group).  A training run re-captures only when the learning rate changes, so a handful stay parked."""
+        if record is not None and self.sync is not None:
+            self._retired.append(record)
+
+    def drop_graphs(self):
+        """Forget every captured step (the next ``step`` runs eagerly until ``capture`` is called again)."""
+        for record in self._graphs.values():
+            self._retire(record)
+        self._graphs = {}
 
     def enable_prefetch(self, train: bool = True):
         """Double-buffer the captured step: a second capture of the same step on a second set of batch buffers, so that

@@ -62,3 +62,20 @@ def test_rccl_gradient_exchange_eager_and_captured():
         if "RCCL_PATH_OK" not in res.stdout and "assert" in res.stderr.lower() and "Address already in use" not in res.stderr:
             break                                # a real failure of the path: do not mask it
     assert res.returncode == 0 and "RCCL_PATH_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_repeated_capture_with_collectives_is_stable():
+    """40 x (eager data-parallel step -> re-capture -> replay) on a 1-rank RCCL group (tools/capture_stress.py).  Two ways
+    this used to abort the process: the process group's watchdog querying a finished eager collective's event while the
+    capture has pulled RCCL's stream in (hipErrorCapturedEvent: GradSync.drain now lets the watchdog forget them), and
+    destroying replaced hipGraphs that hold RCCL nodes (`free(): invalid pointer`: Trainer parks them)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "capture_stress.py"), "40", "0.35", "keep"], env=env,
+                         capture_output=True, text=True, timeout=800)
+    assert res.returncode == 0 and "STRESS_OK 40" in res.stdout, res.stdout[-1500:] + res.stderr[-3000:]
