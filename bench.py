@@ -62,6 +62,9 @@ def parse():
                          "(A/B switch; the forked graph replays slower than the in-step update)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="explicit A/B switch (coarsegrainingvae_amd/options.py, cgv_set_option), repeatable")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the multi-rank code path (process group, collectives in the captured step, barriers) on a 1-rank "
+                         "group: the part of a --gpus N run that one GPU can execute (rehearsal of the driver's scaling runs)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "operands", "gradients"],
                     help="N > 1: all-gather the bead-level layers' operand rows (default) or all-reduce every gradient")
     return ap.parse_args()
@@ -343,15 +346,27 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and rank == 0:
         print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: running {world} rank(s)", file=sys.stderr)
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    real_stdout = None
+    if multi:
+        # RCCL prints a version banner on the C stdout of every rank; on a pipe it sits in the stdio buffer until the process
+        # exits, i.e. it lands AFTER the JSON line.  The contract is ONE JSON line on stdout: everything any library writes to
+        # file descriptor 1 goes to stderr instead, and the line itself is written to the saved descriptor at the end.
+        sys.stdout.flush()
+        real_stdout = os.dup(1)
+        os.dup2(2, 1)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29581")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     else:
         dist = None
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local if world > 1 else 0)
+    dev = torch.device("cuda", local if multi else 0)
     # the host side of a step is a handful of tiny tensor ops: keep torch's intra-op pool small (run_ala.py does the same)
     torch.set_num_threads(min(torch.get_num_threads(), 8))
     w = WORKLOADS[args.workload]
@@ -376,7 +391,7 @@ def main():
         if args.skip_dead_vector_channel:
             m.encoder.set_skip_dead_vector_channel(True)
             m.prior_net.set_skip_dead_vector_channel(True)
-        return m, Trainer(m, lr=1e-4, beta=w["beta"], gamma=w["gamma"], world_size=world,
+        return m, Trainer(m, lr=1e-4, beta=w["beta"], gamma=w["gamma"], world_size=world, always_sync=multi,
                           fused_optimizer=(args.optimizer == "fused"), exchange=exchange, defer_update=args.deferred_update)
 
     parity = None
@@ -385,7 +400,7 @@ def main():
         nonlocal parity
         # the very first step doubles as the parity check (rank 0 of a single-process run: weights still at their
         # seeded initialisation, host-drawn noise, compared with the CPU oracle)
-        if world == 1 and not args.no_parity and parity is None:
+        if not multi and not args.no_parity and parity is None:
             parity = parity_check(cg, m, tr, batch, args.workload, F, frames)
         else:
             tr.step(batch)
@@ -402,7 +417,7 @@ def main():
     except Exception as exc:
         # every rank runs the same code on equally shaped shards, so a failure of the operand exchange hits all of
         # them at the same point: measure with the plain gradient all-reduce rather than lose the run
-        if world == 1 or args.exchange == "gradients":
+        if not multi or args.exchange == "gradients":
             raise
         print(f"[bench] operand exchange failed on rank {rank}: {exc!r}; falling back to --exchange gradients", file=sys.stderr)
         torch.cuda.synchronize()
@@ -452,6 +467,19 @@ def main():
     secs = timed_loop(step_rot, args.steps, args.reps, barrier, dist, dev)
     trainer.flush()                                  # the update of the last timed step (the first one applied a pre-timed one)
     rot_replayed = trainer.replays - replays0
+    # what the data-parallel step moved, read NOW: the side measurements below capture other flavours of the step (a
+    # forward+backward-only step exchanges nothing) and would leave their own bookkeeping behind
+    dp_step, dp_info = "+allreduce", None
+    if multi and trainer.arena is not None:
+        left = sum(hi - lo for lo, hi in trainer._unsent_ranges()) * 4
+        early = sum(hi - lo for lo, hi in getattr(trainer, "_early_done", [])) * 4
+        if trainer.exchange is not None and trainer.exchange.bytes_gathered:
+            dp_step = "+operand-allgather+allreduce"
+        dp_info = {"exchange": "operands" if trainer.exchange is not None else "gradients",
+                   "gradient_arena_bytes": trainer.arena.numel * 4,
+                   "allgathered_operand_bytes_per_rank": (trainer.exchange.bytes_gathered // world
+                                                          if trainer.exchange is not None else 0),
+                   "allreduced_bytes": left + early, "allreduced_early_bytes": early}
     med = statistics.median(secs)
     ms = 1e3 * med / args.steps
     value = world * frames * args.steps / med
@@ -591,20 +619,9 @@ def main():
             step_bytes = {"bound": "hbm", "algorithmic_bytes": sb, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": gbs / HBM_PEAK_GBS}
         cpu = None
-        if world == 1 and not args.no_cpu_baseline:
+        if not multi and not args.no_cpu_baseline:
             steps_cpu = args.cpu_steps or (4 if args.workload == "chignolin" else 6)
             cpu = cpu_baseline(cg, args.workload, F, frames, steps_cpu)
-        dp_step, dp_info = "+allreduce", None
-        if world > 1 and trainer.arena is not None:
-            left = sum(hi - lo for lo, hi in trainer._unsent_ranges()) * 4
-            early = sum(hi - lo for lo, hi in getattr(trainer, "_early_done", [])) * 4
-            if trainer.exchange is not None and trainer.exchange.bytes_gathered:
-                dp_step = "+operand-allgather+allreduce"
-            dp_info = {"exchange": "operands" if trainer.exchange is not None else "gradients",
-                       "gradient_arena_bytes": trainer.arena.numel * 4,
-                       "allgathered_operand_bytes_per_rank": (trainer.exchange.bytes_gathered // world
-                                                              if trainer.exchange is not None else 0),
-                       "allreduced_bytes": left + early, "allreduced_early_bytes": early}
         line = {
             "metric": "train_step_frames_per_sec", "value": value, "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
@@ -612,7 +629,7 @@ def main():
             "config": {"workload": f"{args.workload}: {frames} frames/GPU x {w['n_atoms']} atoms, n_cgs={w['n_cgs']}, "
                                    f"enc_nconv={w['enc_nconv']}, dec_nconv={w['dec_nconv']}, n_basis={F}, n_rbf={R}, "
                                    f"cutoffs {w['atom_cutoff']}/{w['cg_cutoff']}",
-                       "step": "per-batch graph plans + edge records + fwd+loss+bwd" + (dp_step if world > 1 else "") + "+clip+adam",
+                       "step": "per-batch graph plans + edge records + fwd+loss+bwd" + (dp_step if multi else "") + "+clip+adam",
                        "inputs": f"rotation of {n_rot} different batches resident in HBM (coordinates + neighbour lists)",
                        "global_batch": world * frames, "directed_edges_rank0": int(batch["_graph"].atom.n_edges),
                        "optimizer": args.optimizer, "deferred_update": bool(trainer.defer_update),
@@ -633,7 +650,10 @@ def main():
         line.update(extra)
         if stale:
             line["stale_committed_entries_dropped"] = stale
-        print(json.dumps(line))
+        if real_stdout is not None:
+            os.write(real_stdout, (json.dumps(line) + "\n").encode())
+        else:
+            print(json.dumps(line))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
