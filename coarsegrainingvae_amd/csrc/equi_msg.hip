@@ -709,8 +709,10 @@ int cgv_equi_msg_fwd(const float* phi, const float* v, const float* geom_d, cons
   const int tiles = (n_feat + 127) / 128;
   const int npx = (n_dst + 7) / 8;
   const dim3 grid(8 * npx * tiles);
-  // >= 16 edges per receiver on average: 4 waves share a (node, tile) (the atom graph: 125; atom -> bead: 28)
-  bool split = n_edges_hint >= 16LL * n_dst;
+  // >= 16 edges per receiver on average: 4 waves share a (node, tile) (the atom graph: 125; atom -> bead: 28).  Also on
+  // tiny graphs with a few edges per receiver (the prior's 12 beads x 5): the launch is a chain of dependent round trips
+  // per edge, and four waves walk a row of 5 in two trips instead of five (9.6 -> 6.4 us per launch)
+  bool split = n_edges_hint >= 16LL * n_dst || (n_dst <= 64 && n_edges_hint >= 3LL * n_dst);
   if (const int o = cgv::option(CGV_OPT_MSG_FWD_SPLIT); o >= 0) split = o != 0;   // experiments only
   // 8-byte vector accesses need an even channel count and 8-byte aligned bases; the buffer-descriptor
   // gathers need every row within 2 GiB of the base (n_rows_hint = rows of phi / v, 0 = unknown)
