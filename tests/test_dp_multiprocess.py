@@ -65,7 +65,7 @@ def _report(codes, logs):
 
 
 @pytest.mark.timeout(1500)
-@pytest.mark.parametrize("world,mode,oracle", [(2, "operands", True), (2, "gradients", False),
+@pytest.mark.parametrize("world,mode,oracle", [(2, "operands", True), (2, "gradients", False), (4, "operands", False),
                                                (8, "operands", True), (8, "gradients", False)])
 def test_product_model_under_real_ranks_with_different_shards(world, mode, oracle):
     codes, logs, result = _run_ranks(world, mode, extra=("--oracle",) if oracle else ())
