@@ -362,7 +362,8 @@ class CGequiVAE(nn.Module):
         # The prior net (bead graph) does not depend on the encoder (atom graph): run it on a side HIP
         # stream so its ~20 small launches -- and, since autograd replays each node on its forward
         # stream, its backward too -- overlap with the encoder instead of queueing behind it.
-        side = self._side_stream(xyz.device) if (self.prior_net and self.concurrent_prior and xyz.is_cuda) else None
+        from .options import HOST
+        side = self._side_stream(xyz.device) if (self.prior_net and (self.concurrent_prior or HOST["concurrent_prior"]) and xyz.is_cuda) else None
         if side is not None:
             main = torch.cuda.current_stream()
             side.wait_stream(main)

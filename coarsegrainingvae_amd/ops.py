@@ -653,24 +653,59 @@ class _KLSlot:
 
 
 _RNG = {}
+_M64 = 0xFFFFFFFFFFFFFFFF
+
+
+def _splitmix64(x: int) -> int:
+    x = (x + 0x9E3779B97F4A7C15) & _M64
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & _M64
+    return x ^ (x >> 31)
+
+
+def sample_seed(initial_seed: int, rank: int = 0) -> int:
+    """Seed of ``reparam_sample``'s device generator: splitmix64 of torch's default-generator seed, with the process's
+    rank folded in.  ``run_ala.py`` calls ``torch.manual_seed(123)`` on EVERY rank; without the rank, row i of every
+    shard of a data-parallel batch would draw the same noise -- W copies of one noise block instead of the W blocks a
+    single process draws for the concatenated batch.  Rank 0 keeps the single-process stream."""
+    x = int(initial_seed) & _M64
+    if rank:
+        x ^= _splitmix64(0xD1B54A32D192ED03 * int(rank) & _M64)
+    return _splitmix64(x) & ((1 << 62) - 1)
+
+
+def _process_rank() -> int:
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return int(dist.get_rank())
+    except Exception:                                     # noqa: BLE001  (no process group: single process)
+        pass
+    return 0
 
 
 def _rng_block(device) -> torch.Tensor:
     """{seed, draw number, ticket} of the device-side generator of ``reparam_sample``: seeded from torch's default
-    generator on first use (``torch.manual_seed`` before the first step fixes the stream), advanced by the launches."""
+    generator (and this process's rank, ``sample_seed``) on first use -- ``torch.manual_seed`` and
+    ``init_process_group`` before the first step fix the stream -- advanced by the launches."""
     device = torch.device(device)
     if device.type == "cuda" and device.index is None:
         device = torch.device("cuda", torch.cuda.current_device())
     t = _RNG.get(device)
     if t is None:
         # derived from the seed of torch's default generator WITHOUT drawing from it (host-side consumers -- shuffling --
-        # keep their stream): splitmix64 of torch.initial_seed()
-        x = (int(torch.initial_seed()) + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
-        x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
-        x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
-        seed = (x ^ (x >> 31)) & ((1 << 62) - 1)
+        # keep their stream)
+        seed = sample_seed(torch.initial_seed(), _process_rank())
         t = _RNG[device] = torch.tensor([seed, 0, 0], dtype=torch.int64, device=device)
     return t
+
+
+def reseed_sample_rng(device, rank=None) -> None:
+    """Re-derive the device generator's seed from ``torch.initial_seed()`` and ``rank`` (default: this process's rank in
+    the initialised process group) and restart its draw counter.  Call after ``init_process_group`` when a sample was
+    already drawn before it."""
+    seed = sample_seed(torch.initial_seed(), _process_rank() if rank is None else rank)
+    _rng_block(device).copy_(torch.tensor([seed, 0, 0], dtype=torch.int64))
 
 
 def get_sample_rng_state(device) -> torch.Tensor:

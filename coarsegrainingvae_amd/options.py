@@ -15,6 +15,7 @@ HOST = {
     "rank_update": 1,       # Trainer: 1 rank update of the bead-level layers where it pays, 0 every gradient materialised (A/B)
     "rank_rows_mfma": -1,   # single process: rows up to which layers beyond 40 rows take the MFMA rank update (-1: Trainer.RANK_ROWS_MFMA)
     "rank_gram_rows": -1,   # MFMA rank update: rows up to which the norm comes from the Gram launch instead of a tile pass (-1: Trainer.RANK_GRAM_ROWS)
+    "concurrent_prior": 0,  # CGequiVAE.forward: 1 the prior net (bead graph) on a side stream beside the encoder -- a forked branch of the captured step
     "decoder_dense": 0,     # full-width products of the fused decoder loop: 0 four-column blocks (cgv_decoder_dense_fwd), 1 skinny_fwd_k
 }
 _DEFAULTS = dict(HOST)

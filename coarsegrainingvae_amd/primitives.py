@@ -364,6 +364,13 @@ class _LinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy, g_alias=None):
         if gy is None:                                       # only the forked alias was used downstream
+            # the layer's output left the loss: its weight / bias gradient is zero.  Arena-managed (direct-write)
+            # parameters get no zero fill at the start of a step (ParamArena.zero_grad only flags them pending), so the
+            # zero has to be written here -- otherwise last step's gradient would enter the norm, the clip and the update
+            for prm in ctx.params:
+                if _is_direct(prm) and prm._cgv_pending and ctx.needs_input_grad[1]:
+                    prm.grad.zero_()
+                    prm._cgv_pending = False
             return g_alias, None, None, None, None
         out = _LinearFn._backward(ctx, gy, g_alias)
         return out + (None,)

@@ -70,6 +70,19 @@ class ParamArena:
         for p in self.accumulated:
             p.grad.zero_()
 
+    def zero_unwritten(self) -> int:
+        """End of backward: a direct-write parameter that is STILL flagged pending received no gradient in this step (its
+        layer's output left the loss, or an upstream node returned None) -- its arena slice holds the previous step's
+        gradient, which would enter the norm, the clip, the update and the data-parallel reduction.  Written as zeros
+        here (no launch at all in a normal step: every flag has been cleared by then).  Returns the number filled."""
+        n = 0
+        for p in self.params:
+            if p._cgv_direct and p._cgv_pending:
+                p.grad.zero_()
+                p._cgv_pending = False
+                n += 1
+        return n
+
 
 class GradSync:
     """SUM all-reduce of gradient-arena ranges in large buckets (default 64 MiB: a handful of
@@ -402,7 +415,6 @@ class Trainer:
         self._pending = False
         self._side = None
         self._dec_ranges = None
-        self._shard_sigs = set()      # shard shapes already compared across the ranks (_check_shards)
         self.betas, self.eps, self.max_norm = betas, eps, max_norm
         self.world = world_size
         # always_sync: run the collective path even with one rank (exercises RCCL + graph capture in tests)
@@ -622,8 +634,8 @@ class Trainer:
             if self.exchange is not None:
                 # inside the capture nothing can be checked, and the eager step that built the arena ran without the
                 # exchange: compare the shard shapes here, eagerly
-                self._shard_sigs.discard(int(batch["nxyz"].shape[0]) * (1 << 24) + int(batch["CG_nxyz"].shape[0]))
-                self._check_shards(batch)                   # all ranks capture together: always compared here
+                if not self.sync.same_on_all_ranks(self._shard_sig(batch)):      # all ranks capture together: always compared here
+                    raise RuntimeError("operand exchange needs equally shaped shards on every rank")
             self.sync.drain()
         graph = torch.cuda.CUDAGraph()
         pending_at_start = self._pending              # a deferred update opens the captured step (or does not)
@@ -647,13 +659,24 @@ class Trainer:
             self._graphs[key] = record
         return graph
 
+    PARKED_WARN_AT = (16, 64, 256)
+
     def _retire(self, record):
         """A replaced captured step.  With collectives inside, the graph is PARKED, not destroyed: destroying hipGraphs
         that hold RCCL nodes corrupts the heap after a few dozen of them (tools/capture_stress.py: `free(): invalid pointer`
         around the 25th re-capture on a 1-rank group; 60 re-captures pass with the old graphs kept, and 60 pass without a
         process group).  A training run re-captures only when the learning rate changes, so a handful stay parked."""
         if record is not None and self.sync is not None:
-            self._retired.append(record)
+            # only the graph handles stay (a parked hipGraph keeps its own activation pool alive -- that part of the leak is
+            # the known issue; the batch buffers, record tables, result tensors and noise buffer are released)
+            for rec in (record, record.get("twin")):
+                if rec is not None:
+                    self._retired.append(rec["graph"])
+            record.clear()
+            if len(self._retired) in self.PARKED_WARN_AT:
+                import warnings
+                warnings.warn(f"{len(self._retired)} replaced hipGraphs with RCCL nodes are parked (not destroyed: known heap "
+                              f"corruption in their destruction); each keeps its activation pool -- re-capture less often")
 
     def drop_graphs(self):
         """Forget every captured step (the next ``step`` runs eagerly until ``capture`` is called again)."""
@@ -775,20 +798,34 @@ class Trainer:
                     cap["pre"] = (prefetch, 1 - slot, ev)
         return True
 
+    @staticmethod
+    def _shard_sig(batch) -> int:
+        return int(batch["nxyz"].shape[0]) * (1 << 24) + int(batch["CG_nxyz"].shape[0])
+
     def _check_shards(self, batch):
         """The operand exchange all-gathers equally sized buffers and decides per layer, from its rows, whether it is
         exchanged at all: ranks holding differently shaped shards would issue different collectives and wait for each
-        other forever.  Every rank compares (atoms, beads) of its shard with the others' -- one tiny collective -- the
-        first time it meets a shard shape (at the start of the step, before any data-path collective; a training run
-        meets its shapes on the same steps on every rank), and all ranks refuse together.  Not on every step: a rank
-        whose batch does not fit its captured buffers runs that step eagerly while the others replay, and the eager
-        step must then issue exactly the collectives the replayed graph holds."""
-        sig = int(batch["nxyz"].shape[0]) * (1 << 24) + int(batch["CG_nxyz"].shape[0])
-        if sig in self._shard_sigs:
+        other forever.  The comparison is itself a collective, so it must be SYMMETRIC -- reached by every rank at the same
+        point of the program, whatever its own batch looks like:
+
+          * while no captured step exists, every rank runs every step eagerly and every eager step compares (atoms, beads)
+            with the other ranks first (one tiny MAX all-reduce; eager steps are the slow path anyway);
+          * every capture compares (all ranks capture together);
+          * once a captured step exists, peers may be REPLAYING while this rank runs a step eagerly (its batch has more
+            edges than the captured buffers hold): no collective of its own is allowed there -- the eager step must issue
+            exactly what the replayed graphs hold.  What can be checked locally is: the batch has the captured batch's
+            (atoms, beads), i.e. the same exchange buffers; anything else raises here, on this rank, before any
+            collective is issued (the other ranks then time out in RCCL instead of exchanging garbage)."""
+        sig = self._shard_sig(batch)
+        caps = [c for c in self._graphs.values() if c.get("batch") is not None]
+        if caps and not torch.cuda.is_current_stream_capturing():
+            want = {self._shard_sig(c["batch"]) for c in caps}
+            if sig not in want:
+                raise RuntimeError("operand exchange needs equally shaped shards on every rank: this batch's (atoms, beads) differ "
+                                   "from the captured step's -- drop_graphs() and re-capture on ALL ranks for a new shard shape")
             return
         if not self.sync.same_on_all_ranks(sig):
             raise RuntimeError("operand exchange needs equally shaped shards on every rank")
-        self._shard_sigs.add(sig)
 
     # ------------------------------------------------------------------ one iteration
     def _step_eager(self, batch, eps: Optional[torch.Tensor] = None, train: bool = True):
@@ -843,6 +880,7 @@ class Trainer:
                 else:
                     loss.backward()
             mark("backward:encoder+prior")
+            self.arena.zero_unwritten()                 # parameters no backward node reached in this step: gradient zero, not last step's
             self._flush_queue(use_ex, rank=train and self.fused and self.sync is None)
             mark("weight-gradients")
             if hasattr(self.model, "bucket_done"):

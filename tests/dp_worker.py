@@ -127,9 +127,15 @@ def main():
 
     # lock step: parameters and moments are bit-identical on every rank
     def bits(t):
-        return int(t.view(torch.int32).to(torch.int64).sum().item()) & ((1 << 62) - 1)
+        """Position-dependent 62-bit digest of the tensor's BIT patterns: sum_i bits_i * w_i (mod 2^64) with odd multipliers
+        w_i = 2 * hash(i) + 1 -- a permutation of the values, or two compensating changes, move it (a plain sum of the int32
+        views would not see either)."""
+        v = t.view(torch.int32).to(torch.int64)
+        i = torch.arange(v.numel(), device=v.device, dtype=torch.int64)
+        w = ((i * 0x9E3779B1 + 0x7F4A7C15) ^ (i >> 7)) * 2 + 1
+        return int(((v * w).sum() ^ (v.sum() << 1)).item()) & ((1 << 62) - 1)
     same = [sync.same_on_all_ranks(bits(t)) for t in (tr.arena.p, tr.m, tr.v)]
-    assert all(same), f"ranks left lock step (p, m, v bit sums equal: {same})"
+    assert all(same), f"ranks left lock step (p, m, v digests equal: {same})"
     # gather the per-step records on every rank (rank 0 uses them)
     losses = sync.gather_host(torch.tensor(rec["loss"]))                       # [world, steps]
     terms = {k: sync.gather_host(torch.tensor(rec[k])) for k in ("kl", "recon_term", "graph")}

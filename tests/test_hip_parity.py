@@ -1939,3 +1939,59 @@ def test_job_table_replan_equals_fresh_plan_on_long_rows_with_repeats(n, E):
         assert torch.equal(getattr(held, f), getattr(fresh, f)), f
     for f in ("eid_d", "dst_d", "src_d", "eid_s", "dst_s", "src_s"):
         assert torch.equal(getattr(held, f)[:E], getattr(fresh, f)[:E]), f
+
+
+# --------------------------------------------------------------------------- round-4 advisor findings
+def test_device_noise_differs_between_ranks_and_repeats_within_one():
+    """Data parallel: every rank seeds torch with 123 (run_ala.py:36-41); the device generator folds the rank in
+    (ops.sample_seed), so the ranks' shards draw different eps (cgvae.py:445-449 on the concatenated batch) while one
+    rank's stream is reproducible."""
+    from coarsegrainingvae_amd import ops
+    mu, sigma = torch.zeros(12, 64, device=DEV), torch.ones(12, 64, device=DEV)
+    state0 = ops.get_sample_rng_state(DEV)
+    try:
+        torch.manual_seed(123)
+        draws = {}
+        for rank in (0, 1, 7, 0):
+            ops.reseed_sample_rng(DEV, rank=rank)
+            draws.setdefault(rank, []).append(ops.reparam_sample(mu, sigma).clone())
+        assert torch.equal(draws[0][0], draws[0][1])
+        for a, b in ((0, 1), (0, 7), (1, 7)):
+            x, y = draws[a][0], draws[b][0]
+            assert not torch.equal(x, y)
+            assert float((x == y).float().mean()) < 0.01                  # not a shifted copy of the same block either
+            assert abs(float(torch.corrcoef(torch.stack([x.flatten(), y.flatten()]))[0, 1])) < 0.15
+    finally:
+        ops.set_sample_rng_state(DEV, state0)
+
+
+def test_layer_whose_output_leaves_the_loss_gets_a_zero_gradient_not_last_steps():
+    """Arena-managed (direct-write) parameters get no zero fill at the start of a step.  When a Dense's output does not
+    reach the loss (only its forked input alias does: primitives._LinearFn.backward with gy None) the arena slice must
+    not keep the previous step's gradient -- torch would have materialised a zero (modules.py:103-114 under autograd)."""
+    from coarsegrainingvae_amd.primitives import Dense, Swish
+    from coarsegrainingvae_amd.trainer import ParamArena
+    torch.manual_seed(0)
+    lin = Dense(64, 64, bias=True, activation=Swish()).to(DEV)
+    x = torch.randn(12, 64, device=DEV, requires_grad=True)
+    y, alias = lin.forward_fork(x)
+    (y.sum() + alias.sum()).backward()                                    # first backward: ordinary gradients exist
+    arena = ParamArena([lin.weight, lin.bias])
+    # step 1: both outputs used -> real gradient, written in place
+    arena.zero_grad()
+    y, alias = lin.forward_fork(x)
+    (y * y).sum().add(alias.sum()).backward()
+    assert arena.zero_unwritten() == 0
+    g1 = lin.weight.grad.clone()
+    assert float(g1.abs().max()) > 0
+    # step 2: only the alias reaches the loss
+    arena.zero_grad()
+    y, alias = lin.forward_fork(x)
+    alias.sum().backward()
+    arena.zero_unwritten()
+    assert float(lin.weight.grad.abs().max()) == 0.0 and float(lin.bias.grad.abs().max()) == 0.0
+    # step 3: a layer no backward node reaches at all (module unused in this step): zero_unwritten fills it
+    arena.zero_grad()
+    lin.weight.grad.copy_(g1)
+    assert arena.zero_unwritten() == 2
+    assert float(lin.weight.grad.abs().max()) == 0.0

@@ -161,3 +161,18 @@ def test_option_table_is_explicit_and_resets():
     import subprocess
     src = subprocess.run(["grep", "-rl", "getenv", os.path.join(os.path.dirname(_lib.LIB_PATH), "csrc")], capture_output=True, text=True)
     assert src.stdout.strip() == "", "the C ABI must not read the environment: " + src.stdout
+
+
+def test_sample_seed_differs_per_rank_and_rank0_keeps_the_single_process_stream():
+    """Data parallel: every rank calls torch.manual_seed(123) (run_ala.py:36-41); the device generator of reparam_sample
+    must still draw DIFFERENT noise on every rank (cgvae.py:445-449 on the concatenated batch draws one block per bead)."""
+    from coarsegrainingvae_amd.ops import sample_seed
+    seeds = [sample_seed(123, r) for r in range(16)]
+    assert len(set(seeds)) == 16
+    assert all(0 <= s < (1 << 62) for s in seeds)
+    assert sample_seed(123, 0) == sample_seed(123) and sample_seed(123) != sample_seed(124)
+    # value pinned: checkpoints store the generator state (get_sample_rng_state), the derivation must not drift
+    x = (123 + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    assert sample_seed(123, 0) == (x ^ (x >> 31)) & ((1 << 62) - 1)
