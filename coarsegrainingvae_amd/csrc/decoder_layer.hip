@@ -673,12 +673,13 @@ __global__ __launch_bounds__(DL_THREADS) void dec_dense_fwd_k(const float* __res
   DL_SPAN(K > N ? 3 : 0, 1);
 }
 
-// Two Dense layers of one shape in one launch (blockIdx.y picks the layer): the mu / sigma heads are independent of each
-// other (cgvae.py:366-371, 502-503); x may be the same for both.
+// Up to four Dense layers of one shape in one launch (blockIdx.y picks the layer): the mu / sigma heads are independent of
+// each other (cgvae.py:366-371, 502-503) and the prior's pair (cgvae.py:398-401) of the encoder's; x may be shared.
+constexpr int DL_MULTI_MAX = 4;            // (the four heads of a step: prior mu / sigma, encoder mu / sigma)
 struct DensePair {
-  const float* x[2]; const float* W[2]; const float* bias[2];
-  float* y[2]; float* z[2];
-  int act[2];
+  const float* x[DL_MULTI_MAX]; const float* W[DL_MULTI_MAX]; const float* bias[DL_MULTI_MAX];
+  float* y[DL_MULTI_MAX]; float* z[DL_MULTI_MAX];
+  int act[DL_MULTI_MAX];
 };
 __global__ __launch_bounds__(DL_THREADS) void dec_dense_fwd_pair_k(DensePair p, int n, int N, int K) {
   Carve cv;
@@ -1279,6 +1280,23 @@ int cgv_pair_linear_fwd(const float* x0, const float* x1, const float* W0, const
   hipLaunchKernelGGL(cgv::dec_dense_fwd_pair_k, dim3(N / cgv::DL_CB, 2), dim3(cgv::DL_THREADS),
                      cgv::lds_bytes(cgv::fwd_red_floats<1, 1>() + 64), (hipStream_t)stream, p, n_rows, N, K);
   return cgv::check_launch("cgv_pair_linear_fwd");
+}
+
+int cgv_multi_linear_max(void) { return cgv::DL_MULTI_MAX; }
+
+int cgv_multi_linear_fwd(int n, const float* const* x, const float* const* W, const float* const* bias, float* const* y,
+                         float* const* z, const int* act, int n_rows, int N, int K, void* stream) {
+  CGV_REQUIRE(n >= 1 && n <= cgv::DL_MULTI_MAX && x && W && y && act, "1 .. 4 problems, non-null tables");
+  CGV_REQUIRE(n_rows >= 1 && n_rows <= cgv::DL_MAX_NODES && (N % 4) == 0 && (K % 4) == 0 && N >= 4 && K >= 4, "unsupported shape");
+  cgv::DensePair p{};
+  for (int j = 0; j < n; ++j) {
+    CGV_REQUIRE(x[j] && W[j] && y[j], "null pointer");
+    CGV_REQUIRE(act[j] >= 0 && act[j] <= cgv::CGV_ACT_MAX && (act[j] == 0 || (z && z[j])), "activation needs its pre-activation buffer");
+    p.x[j] = x[j]; p.W[j] = W[j]; p.bias[j] = bias ? bias[j] : nullptr; p.y[j] = y[j]; p.z[j] = z ? z[j] : nullptr; p.act[j] = act[j];
+  }
+  hipLaunchKernelGGL(cgv::dec_dense_fwd_pair_k, dim3(N / cgv::DL_CB, n), dim3(cgv::DL_THREADS),
+                     cgv::lds_bytes(cgv::fwd_red_floats<1, 1>() + 64), (hipStream_t)stream, p, n_rows, N, K);
+  return cgv::check_launch("cgv_multi_linear_fwd");
 }
 
 int cgv_decoder_uv_fwd(const float* rows, const float* Wuv, float* UV, float* stack, int n_nodes, int n_feat, void* stream) {

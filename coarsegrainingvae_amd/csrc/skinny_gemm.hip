@@ -337,10 +337,11 @@ __global__ __launch_bounds__(256) void skinny_bwd_input_k(const float* __restric
 
 // Two products of one shape in one launch (blockIdx.y picks the problem): the two heads of an MLP pair (mu / sigma:
 // cgvae.py:366-371) are independent of each other, as separate launches they are two more dependent links in the chain.
+constexpr int BI_MULTI_MAX = 4;
 struct BiPair {
-  const float* gy[2]; const float* z[2]; const float* W[2];
-  float* gx[2]; float* part[2];
-  int act[2];
+  const float* gy[BI_MULTI_MAX]; const float* z[BI_MULTI_MAX]; const float* W[BI_MULTI_MAX];
+  float* gx[BI_MULTI_MAX]; float* part[BI_MULTI_MAX];
+  int act[BI_MULTI_MAX];
 };
 template <int MB>
 __global__ __launch_bounds__(256) void skinny_bwd_input_pair_k(BiPair p, int M, int N, int K, int KT, int NS, int rpb) {
@@ -1596,6 +1597,33 @@ __global__ __launch_bounds__(1024) void dense_grad_prepare_k(const float* __rest
   }
 }
 
+// the reduction launch of up to four outputs: blockIdx.y picks (partials, output); NS slices each
+struct ReduceMulti { const float* part[BI_MULTI_MAX]; float* gx[BI_MULTI_MAX]; };
+__global__ __launch_bounds__(256) void skinny_bwd_input_reduce_multi_k(ReduceMulti rm, int n4, int NS) {
+  const float* __restrict__ part = rm.part[blockIdx.y];
+  float* __restrict__ gx = rm.gx[blockIdx.y];
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int i = t >> 2, sub = t & 3;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4) {
+    const float4* p4 = reinterpret_cast<const float4*>(part) + i;
+    constexpr int RB = 8;
+    for (int p0 = sub; p0 < NS; p0 += 4 * RB) {
+      float4 v[RB];
+#pragma unroll
+      for (int u = 0; u < RB; ++u) v[u] = p4[(size_t)min(p0 + 4 * u, NS - 1) * (size_t)n4];
+#pragma unroll
+      for (int u = 0; u < RB; ++u) {
+        const bool ok = p0 + 4 * u < NS;
+        acc.x += ok ? v[u].x : 0.f; acc.y += ok ? v[u].y : 0.f; acc.z += ok ? v[u].z : 0.f; acc.w += ok ? v[u].w : 0.f;
+      }
+    }
+  }
+  acc.x += __shfl_xor(acc.x, 1); acc.y += __shfl_xor(acc.y, 1); acc.z += __shfl_xor(acc.z, 1); acc.w += __shfl_xor(acc.w, 1);
+  acc.x += __shfl_xor(acc.x, 2); acc.y += __shfl_xor(acc.y, 2); acc.z += __shfl_xor(acc.z, 2); acc.w += __shfl_xor(acc.w, 2);
+  if (i < n4 && sub == 0) reinterpret_cast<float4*>(gx)[i] = acc;
+}
+
 // the reduction launch of a pair with two outputs: blockIdx.y picks (partials, output)
 __global__ __launch_bounds__(256) void skinny_bwd_input_reduce_pair_k(const float* __restrict__ part0, const float* __restrict__ part1,
                                                                       float* __restrict__ gx0, float* __restrict__ gx1, int n4, int NS) {
@@ -1804,6 +1832,47 @@ int cgv_pair_linear_bwd_input(const float* gy0, const float* gy1, const float* z
   else        // one output: the 2 NS slices of both problems are adjacent in the workspace
     hipLaunchKernelGGL(cgv::skinny_bwd_input_reduce_k, dim3((4 * n4 + 255) / 256), dim3(256), 0, st, part0, gx0, n4, 2 * NS);
   return cgv::check_launch("cgv_pair_linear_bwd_input");
+}
+
+/* Up to four backward-input products of ONE shape in one launch + one reduction launch: gx_j = (gy_j * act_j'(z_j)) W_j.
+ * ``group`` = 1: one output per problem (gx[0 .. n-1]); ``group`` = 2: problems 2o and 2o + 1 read the same input and
+ * their products are SUMMED into gx[o] (n / 2 outputs) -- the accumulation is part of the reduction.  M <= 64 rows.
+ * ws: n x cgv_skinny_bwd_input_workspace_bytes(M, N, K) (at least n x 4 M K bytes). */
+int cgv_multi_linear_bwd_input(int n, int group, const float* const* gy, const float* const* z, const float* const* W,
+                               const int* act, float* const* gx, int M, int N, int K, void* ws, size_t ws_bytes, void* stream) {
+  CGV_REQUIRE(n >= 1 && n <= cgv::BI_MULTI_MAX && (group == 1 || group == 2) && n % group == 0, "1 .. 4 problems, group 1 or 2");
+  CGV_REQUIRE(gy && W && act && gx && ws, "null pointer");
+  CGV_REQUIRE(cgv_skinny_bwd_input_supported(M, N, K) && M <= 64, "unsupported shape (need M <= 64, N % 4 == 0, K % 4 == 0)");
+  CGV_REQUIRE((((uintptr_t)ws) & 15) == 0, "16-byte alignment");
+  hipStream_t st = (hipStream_t)stream;
+  int KT, NS, rpb;
+  cgv::bwd_input_plan(N, K, true, &KT, &NS, &rpb);
+  const size_t one = (size_t)NS * M * K;
+  CGV_REQUIRE(ws_bytes >= sizeof(float) * one * n, "workspace too small");
+  cgv::BiPair p{};
+  for (int j = 0; j < n; ++j) {
+    CGV_REQUIRE(gy[j] && W[j] && ((((uintptr_t)W[j]) & 15) == 0), "null / unaligned operand");
+    CGV_REQUIRE(act[j] == 0 || (act[j] >= 1 && act[j] <= cgv::CGV_ACT_MAX && z && z[j]), "act != 0 needs the saved pre-activation z");
+    p.gy[j] = gy[j]; p.z[j] = z ? z[j] : nullptr; p.W[j] = W[j]; p.gx[j] = nullptr;
+    p.part[j] = reinterpret_cast<float*>(ws) + one * j;      // partial products always go through the workspace
+    p.act[j] = act[j];
+  }
+  const dim3 grid(KT * NS, n);
+  switch ((M + 15) / 16) {
+    case 1: hipLaunchKernelGGL((cgv::skinny_bwd_input_pair_k<1>), grid, dim3(256), 0, st, p, M, N, K, KT, NS, rpb); break;
+    case 2: hipLaunchKernelGGL((cgv::skinny_bwd_input_pair_k<2>), grid, dim3(256), 0, st, p, M, N, K, KT, NS, rpb); break;
+    case 3: hipLaunchKernelGGL((cgv::skinny_bwd_input_pair_k<3>), grid, dim3(256), 0, st, p, M, N, K, KT, NS, rpb); break;
+    default: hipLaunchKernelGGL((cgv::skinny_bwd_input_pair_k<4>), grid, dim3(256), 0, st, p, M, N, K, KT, NS, rpb); break;
+  }
+  const int n4 = M * K / 4, outs = n / group;
+  cgv::ReduceMulti rm{};
+  for (int o = 0; o < outs; ++o) {
+    CGV_REQUIRE(gx[o] && ((((uintptr_t)gx[o]) & 15) == 0), "null / unaligned output");
+    rm.part[o] = reinterpret_cast<float*>(ws) + one * group * o;       // the slices of a group's problems are adjacent
+    rm.gx[o] = gx[o];
+  }
+  hipLaunchKernelGGL(cgv::skinny_bwd_input_reduce_multi_k, dim3((4 * n4 + 255) / 256, outs), dim3(256), 0, st, rm, n4, group * NS);
+  return cgv::check_launch("cgv_multi_linear_bwd_input");
 }
 
 /* Row slicing of the split product for this shape: n_slices partial matrices of slice_floats = M * K floats each. */

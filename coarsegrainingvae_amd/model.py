@@ -19,7 +19,8 @@ from .ktimer import mark
 from .blocks import (ContractiveMessageBlock, EquiMessageBlock, EquiMessageCross, EquiMessagePsuedo, PseudoUpdateBlock,
                      UpdateBlock)
 from .graph import BatchGraph, EdgePlan, make_directed
-from .primitives import ACT_STD_ENC, ACT_STD_PRIOR, Dense, DistanceEmbed, Linear, MLPHead, dual_heads, mark_direct_grad, to_module
+from .primitives import (ACT_STD_ENC, ACT_STD_PRIOR, Dense, DistanceEmbed, Linear, MLPHead, dual_heads, mark_direct_grad, quad_heads,
+                         to_module)
 
 
 def _call_then_pass(fn):
@@ -231,10 +232,19 @@ class CGprior(nn.Module):
             nbrs, _ = make_directed(cg_nbr_list)
             plan = EdgePlan.from_nbrs(nbrs, cg_xyz.shape[0])
             geom = EdgeGeometry(plan, self.n_rbf, self.cutoff, pos_dst=cg_xyz, pos_src=cg_xyz)
+        h = self.features(cg_z, nbrs, plan, geom, graph)
+        return self.heads(h)
+
+    def features(self, cg_z, nbrs, plan, geom, graph=None):
+        """The bead state after the message blocks (cgvae.py:381-396): what the mu / sigma heads are applied to."""
         h = ops.embedding(self.atom_embed, cg_z, graph.embed_plan("cg", cg_z, self.atom_embed) if graph is not None else None)
         v = _constant((h.shape[0], h.shape[1], 3), 0.0, h.device)
         for blk in self.message_blocks:
             h, v = blk(h, v, None, nbrs, plan=plan, geom=geom, residual=True)      # h += ds, v += dv fused (cgvae.py:391-392)
+        return h
+
+    def heads(self, h):
+        """(H_mu, H_std) = (mu(h), 1e-9 + exp(sigma(h) / 2)) (cgvae.py:398-401)."""
         if isinstance(self.sigma, MLPHead) and isinstance(self.mu, MLPHead):
             # layer j of both heads in one launch, forward and backward; 1e-9 + exp(. / 2) in the product's epilogue (cgvae.py:401)
             return dual_heads(self.mu, self.sigma, h, out_act_b=ACT_STD_PRIOR)
@@ -370,6 +380,7 @@ class CGequiVAE(nn.Module):
             with torch.cuda.stream(side):
                 H_prior_mu, H_prior_sigma = self.prior_net(cg_z, cg_xyz, CG_nbr_list, graph=graph)
         enc_hooks = None
+        quad = None
         if self.bucket_done is not None:
             first = len(self._decoder_groups())
             enc_hooks = {l: self._fire_bucket(first + k) for k, l in enumerate(self._encoder_layers())}
@@ -381,10 +392,23 @@ class CGequiVAE(nn.Module):
             H_prior_mu.record_stream(main)
             H_prior_sigma.record_stream(main)
         elif self.prior_net:
-            H_prior_mu, H_prior_sigma = self.prior_net(cg_z, cg_xyz, CG_nbr_list, graph=graph)
+            if (graph is not None and isinstance(self.prior_net, CGprior) and isinstance(self.atom_sigmanet, MLPHead)
+                    and isinstance(self.atom_munet, MLPHead) and S_I.is_cuda and HOST["quad_heads"]):
+                # the prior's (mu, sigma) heads and the encoder's are four independent two-layer chains of one shape:
+                # layer j of all four in ONE launch, forward and backward (primitives.quad_heads)
+                pn = self.prior_net
+                h_prior = pn.features(cg_z, graph.cg_nbrs, graph.cg, graph.geometry("cg", pn.n_rbf, pn.cutoff), graph)
+                if isinstance(pn.mu, MLPHead) and isinstance(pn.sigma, MLPHead) and h_prior.shape == S_I.shape:
+                    quad = quad_heads((pn.mu, pn.sigma, h_prior, ACT_STD_PRIOR), (self.atom_munet, self.atom_sigmanet, S_I, ACT_STD_ENC))
+                if quad is None:
+                    H_prior_mu, H_prior_sigma = pn.heads(h_prior)
+            else:
+                H_prior_mu, H_prior_sigma = self.prior_net(cg_z, cg_xyz, CG_nbr_list, graph=graph)
         else:
             H_prior_mu, H_prior_sigma = None, None
-        if isinstance(self.atom_sigmanet, MLPHead) and isinstance(self.atom_munet, MLPHead):
+        if self.prior_net and side is None and quad is not None:
+            H_prior_mu, H_prior_sigma, mu, sigma = quad
+        elif isinstance(self.atom_sigmanet, MLPHead) and isinstance(self.atom_munet, MLPHead):
             mu, sigma = dual_heads(self.atom_munet, self.atom_sigmanet, S_I, out_act_b=ACT_STD_ENC)   # 1e-12 + exp(logvar / 2) fused (cgvae.py:502-503)
         else:
             mu = self.atom_munet(S_I)

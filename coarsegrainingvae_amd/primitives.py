@@ -568,6 +568,146 @@ class _PairLinearFn(torch.autograd.Function):
         return (shape_a if need_xa else None, (gxb if need_xb else None), grads_w[0], grads_w[1], grads_w[2], grads_w[3], None, None)
 
 
+def _ptr_table(tensors):
+    """Host array of device pointers (None -> NULL) for the cgv_multi_* entry points."""
+    return (C.c_void_p * len(tensors))(*[(t.data_ptr() if t is not None else None) for t in tensors])
+
+
+class _MultiLinearFn(torch.autograd.Function):
+    """``act_j(x_j W_j^T + b_j)`` for up to four Dense layers of ONE shape with at most 16 rows as one forward launch and
+    one backward-input launch pair (``cgv_multi_linear_fwd`` / ``cgv_multi_linear_bwd_input``): layer j of the prior's and
+    the encoder's (mu, sigma) heads (cgvae.py:398-401, 500-503) -- four independent chains of two layers each, as
+    separate layers 8 + 16 launches per step.  ``group`` = 2: problems 2o and 2o + 1 read the SAME input tensor (passed
+    once per problem) and their input gradients are summed in the reduction launch.  Weight / bias gradients go to the
+    trainer's grouped queue exactly as ``_LinearFn`` sends them.
+    Arguments: acts (tuple of n codes), group, then x_0..x_{n-1}, then (w_0, b_0), .., (w_{n-1}, b_{n-1}) flattened."""
+
+    @staticmethod
+    def forward(ctx, acts, group, *args):
+        n = len(acts)
+        xs, wb = args[:n], args[n:]
+        ws, bs = wb[0::2], wb[1::2]
+        x2 = []
+        for j, x in enumerate(xs):
+            if group == 2 and j % 2 == 1 and x is xs[j - 1]:
+                x2.append(x2[-1])
+            else:
+                x2.append(x.reshape(-1, x.shape[-1]).contiguous())
+        M, K = x2[0].shape
+        N = ws[0].shape[0]
+        dev = x2[0].device
+        ys = [torch.empty(M, N, dtype=torch.float32, device=dev) for _ in range(n)]
+        zs = [torch.empty(M, N, dtype=torch.float32, device=dev) if acts[j] else None for j in range(n)]
+        act_arr = (C.c_int * n)(*[int(a) for a in acts])
+        _lib.call("cgv_multi_linear_fwd", n, _ptr_table(x2), _ptr_table(ws), _ptr_table(bs), _ptr_table(ys), _ptr_table(zs),
+                  act_arr, M, N, K, _lib.stream_ptr())
+        ctx.params = (ws, bs)
+        ctx.acts, ctx.group, ctx.n = tuple(int(a) for a in acts), int(group), n
+        ctx.shape = xs[0].shape
+        ctx.save_for_backward(*x2, *[w for w in ws], *[z if z is not None else x2[0].new_empty(0) for z in zs])
+        return tuple(y.reshape(xs[0].shape[:-1] + (N,)) for y in ys)
+
+    @staticmethod
+    def backward(ctx, *gys):
+        n, group, acts = ctx.n, ctx.group, ctx.acts
+        saved = ctx.saved_tensors
+        x2, wd, zs = saved[:n], saved[n:2 * n], [z if z.numel() else None for z in saved[2 * n:]]
+        pws, pbs = ctx.params
+        M, K = x2[0].shape
+        N = wd[0].shape[0]
+        dev = x2[0].device
+        g2 = [(g if g is not None else torch.zeros(M, N, dtype=torch.float32, device=dev)).reshape(M, N).contiguous() for g in gys]
+        need_x = [ctx.needs_input_grad[2 + j] for j in range(n)]
+        gxs = [None] * n
+        if any(need_x):
+            lib = _lib.load()
+            per = max(int(lib.cgv_skinny_bwd_input_workspace_bytes(M, N, K)), 4 * M * K)
+            ws = torch.empty(n * per, dtype=torch.uint8, device=dev)
+            outs = [torch.empty(M, K, dtype=torch.float32, device=dev) for _ in range(n // group)]
+            act_arr = (C.c_int * n)(*acts)
+            _lib.call("cgv_multi_linear_bwd_input", n, group, _ptr_table(g2), _ptr_table(zs), _ptr_table(wd), act_arr,
+                      _ptr_table(outs), M, N, K, ws.data_ptr(), n * per, _lib.stream_ptr())
+            for j in range(n):
+                if group == 2:
+                    gxs[j] = outs[j // 2].reshape(ctx.shape) if (j % 2 == 0 and need_x[j]) else None     # the pair's sum, returned once
+                else:
+                    gxs[j] = outs[j].reshape(ctx.shape) if need_x[j] else None
+        grads_wb = []
+        for j in range(n):
+            w_param, b_param = pws[j], pbs[j]
+            need_w = ctx.needs_input_grad[2 + n + 2 * j]
+            need_b = b_param is not None and ctx.needs_input_grad[2 + n + 2 * j + 1]
+            gw = gbias = None
+            if need_w:
+                w_param._cgv_exch = w_param._cgv_rank = (M, N, K)
+                if b_param is not None:
+                    b_param._cgv_exch = (M, N, K)
+                tw, acc_w, gw = _grad_target(w_param, w_param)
+                tb, acc_b, gbias = _grad_target(b_param, b_param) if need_b else (None, acc_w, None)
+                if tb is not None and acc_b != acc_w:
+                    raise RuntimeError("weight and bias of one layer disagree on first-write / accumulate state")
+                wgrad_queue.enqueue(g2[j], x2[j], zs[j] if acts[j] != ACT_NONE else None, acts[j], tw, tb, acc_w)
+                if not (wgrad_queue.active and gw is None and gbias is None):
+                    wgrad_queue.flush()
+            grads_wb += [gw, gbias]
+        return (None, None, *gxs, *grads_wb)
+
+
+def multi_linear_usable(xs, lins) -> bool:
+    """Dense / nn.Linear layers that ``_MultiLinearFn`` takes: device fp32 tensors, ONE shape, at most 16 rows, <= 4 layers."""
+    if not (1 <= len(lins) <= int(_lib.load().cgv_multi_linear_max()) and len(xs) == len(lins)):
+        return False
+    x0, w0 = xs[0], lins[0].weight
+    N, K = w0.shape
+    M = x0.numel() // x0.shape[-1]
+    if not (x0.is_cuda and 1 <= M <= 16 and N % 4 == 0 and K % 4 == 0 and N >= 64):
+        return False
+    for x, lin in zip(xs, lins):
+        if not (x.is_cuda and x.dtype == torch.float32 and x.shape == x0.shape and x.shape[-1] == K):
+            return False
+        if lin.weight.shape != w0.shape or (lin.bias is None) != (lins[0].bias is None) or not lin.weight.is_contiguous():
+            return False
+        if lin.weight.data_ptr() % 16 or (lin.bias is not None and lin.bias.data_ptr() % 16):
+            return False
+    return True
+
+
+def _head_layers(head):
+    """(first Linear, activation code, second Linear) of an ``MLPHead``-shaped module, or None."""
+    mods = list(head)
+    if (len(mods) == 3 and isinstance(mods[0], nn.Linear) and type(mods[1]) in MLPHead._CODES and isinstance(mods[2], nn.Linear)):
+        return mods[0], MLPHead._CODES[type(mods[1])], mods[2]
+    return None
+
+
+def quad_heads(pair_a, pair_b):
+    """``(mu_a, sigma_a, mu_b, sigma_b)`` for two (mu, sigma) head pairs -- each ``(head_mu, head_sigma, x, out_act_sigma)`` --
+    with layer j of all FOUR heads in one launch, forward and backward (the prior's heads, cgvae.py:398-401, and the
+    encoder's, cgvae.py:500-503, are independent).  Returns None when the shapes do not allow it (callers fall back to
+    ``dual_heads`` per pair)."""
+    heads, xs, out_acts = [], [], []
+    for head_mu, head_sigma, x, act_sigma in (pair_a, pair_b):
+        la, lb = _head_layers(head_mu), _head_layers(head_sigma)
+        if la is None or lb is None:
+            return None
+        heads += [la, lb]
+        xs += [x, x]
+        out_acts += [ACT_NONE, act_sigma]
+    first, second = [h[0] for h in heads], [h[2] for h in heads]
+    if not multi_linear_usable(xs, first):
+        return None
+    # the second layers take the first layers' outputs: same checks on their own shapes, decided before anything runs
+    w2 = second[0].weight
+    if w2.shape[1] != first[0].weight.shape[0] or w2.shape[0] % 4 or w2.shape[0] < 64:
+        return None
+    for lin in second:
+        if (lin.weight.shape != w2.shape or (lin.bias is None) != (second[0].bias is None) or not lin.weight.is_contiguous()
+                or lin.weight.data_ptr() % 16 or (lin.bias is not None and lin.bias.data_ptr() % 16)):
+            return None
+    hid = _MultiLinearFn.apply(tuple(h[1] for h in heads), 2, *xs, *[t for lin in first for t in (lin.weight, lin.bias)])
+    return _MultiLinearFn.apply(tuple(out_acts), 1, *hid, *[t for lin in second for t in (lin.weight, lin.bias)])
+
+
 def pair_linear_usable(x_a, x_b, lin_a, lin_b) -> bool:
     """Two nn.Linear / Dense layers that ``_PairLinearFn`` takes: device tensors, one shape, at most 16 rows."""
     if not (x_a.is_cuda and x_a.dtype == torch.float32 and x_b.dtype == torch.float32 and x_a.shape == x_b.shape):

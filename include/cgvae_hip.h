@@ -199,6 +199,16 @@ int cgv_pair_linear_fwd(const float* x0, const float* x1, const float* W0, const
 int cgv_pair_linear_bwd_input(const float* gy0, const float* gy1, const float* z0, const float* z1, const float* W0,
                               const float* W1, int act0, int act1, float* gx0, float* gx1, int M, int N, int K, void* ws,
                               size_t ws_bytes, void* stream);
+/* The same for up to cgv_multi_linear_max() = 4 layers of one shape per launch -- the prior's (mu, sigma) heads
+ * (cgvae.py:398-401) and the encoder's (cgvae.py:500-503) are independent of each other too: layer j of all four heads in
+ * one launch.  Tables are HOST arrays of n device pointers (read at call time).  bwd_input: ``group`` = 1 gives n outputs
+ * gx[j]; ``group`` = 2 sums the products of problems 2o, 2o + 1 (two layers that read one input) into gx[o].
+ * ws: n x max(cgv_skinny_bwd_input_workspace_bytes(M, N, K), 4 M K) bytes. */
+int cgv_multi_linear_max(void);
+int cgv_multi_linear_fwd(int n, const float* const* x, const float* const* W, const float* const* bias, float* const* y,
+                         float* const* z, const int* act, int n_rows, int N, int K, void* stream);
+int cgv_multi_linear_bwd_input(int n, int group, const float* const* gy, const float* const* z, const float* const* W,
+                               const int* act, float* const* gx, int M, int N, int K, void* ws, size_t ws_bytes, void* stream);
 /* CGequiVAE.reparametrize (cgvae.py:445-449: eps = randn_like(sigma); z = mu + eps * sigma) with the noise drawn in the
  * launch: z = mu + sigma * eps, eps ~ N(0, 1) from Philox4x32-10 + Box-Muller, stored (the backward pass needs it:
  * dz/dsigma = eps).  rng: 3 x uint64 in device memory {seed, draw number, 0}; the launch advances the draw number, so a

@@ -1995,3 +1995,38 @@ def test_layer_whose_output_leaves_the_loss_gets_a_zero_gradient_not_last_steps(
     lin.weight.grad.copy_(g1)
     assert arena.zero_unwritten() == 2
     assert float(lin.weight.grad.abs().max()) == 0.0
+
+
+def test_quad_heads_equal_the_separate_heads():
+    """Layer j of the prior's and the encoder's (mu, sigma) heads in one launch (cgv_multi_linear_fwd / _bwd_input) against
+    the four heads applied one by one (cgvae.py:398-401, 500-503): outputs, input gradients and weight gradients."""
+    from coarsegrainingvae_amd.primitives import (ACT_STD_ENC, ACT_STD_PRIOR, Linear, MLPHead, quad_heads)
+    from torch import nn
+    torch.manual_seed(3)
+    F, n = 64, 12
+    mk = lambda: MLPHead(Linear(F, F), nn.Tanh(), Linear(F, F)).to(DEV)
+    heads = [mk() for _ in range(4)]
+    xp = (0.3 * torch.randn(n, F, device=DEV)).requires_grad_()
+    xe = (0.3 * torch.randn(n, F, device=DEV)).requires_grad_()
+    up = [torch.randn(n, F, device=DEV) for _ in range(4)]
+    out = quad_heads((heads[0], heads[1], xp, ACT_STD_PRIOR), (heads[2], heads[3], xe, ACT_STD_ENC))
+    assert out is not None
+    sum((o * u).sum() for o, u in zip(out, up)).backward()
+    got = [o.detach().clone() for o in out] + [xp.grad.clone(), xe.grad.clone()]
+    got_w = [p.grad.clone() for h in heads for p in h.parameters()]
+    xp.grad = xe.grad = None
+    for h in heads:
+        h.zero_grad(set_to_none=True)
+    # the same with torch ops in fp64
+    ref_heads = [nn.Sequential(nn.Linear(F, F), nn.Tanh(), nn.Linear(F, F)).double().to(DEV) for _ in range(4)]
+    for r, h in zip(ref_heads, heads):
+        r.load_state_dict({k: v.double() for k, v in h.state_dict().items()})
+    xpd, xed = xp.detach().double().requires_grad_(), xe.detach().double().requires_grad_()
+    ref = [ref_heads[0](xpd), 1e-9 + torch.exp(ref_heads[1](xpd) / 2), ref_heads[2](xed), 1e-12 + torch.exp(ref_heads[3](xed) / 2)]
+    sum((o * u.double()).sum() for o, u in zip(ref, up)).backward()
+    want = [o.detach() for o in ref] + [xpd.grad, xed.grad]
+    want_w = [p.grad for r in ref_heads for p in r.parameters()]
+    for k, (a, b) in enumerate(zip(got, want)):
+        assert_close(a, b, f"quad heads output / input gradient {k}", 1e-5)
+    for k, (a, b) in enumerate(zip(got_w, want_w)):
+        assert_close(a, b, f"quad heads parameter gradient {k}", 1e-5)
