@@ -97,6 +97,9 @@ PROTOTYPES = {
     "cgv_filter_reduce_job_bytes": (_i, []),
     "cgv_filter_reduce_jobs": (_i, [_p, _i, _p]),
     "cgv_pair_linear_bwd_input": (_i, [_p] * 6 + [_i, _i, _p, _p, _i, _i, _i, _p, C.c_size_t, _p]),
+    "cgv_loss_tail_supported": (_i, [_i, _i, _i, _i]),
+    "cgv_loss_tail_workspace_bytes": (_sz, [_i]),
+    "cgv_loss_tail": (_i, [_p] * 12 + [_i, _i, _i, _i, _i, _f, _f] + [_p] * 9 + [_p, _sz, _p]),
     "cgv_multi_linear_max": (_i, []),
     "cgv_multi_linear_fwd": (_i, [_i] + [_p] * 6 + [_i, _i, _i, _p]),
     "cgv_multi_linear_bwd_input": (_i, [_i, _i] + [_p] * 5 + [_i, _i, _i, _p, C.c_size_t, _p]),

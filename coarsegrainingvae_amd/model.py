@@ -281,6 +281,9 @@ class CGequiVAE(nn.Module):
         # (layers 8..4, 3..0): every collective node costs the replayed step 7 - 40 us whatever it carries, and the second
         # half's rows still travel under the prior's and the encoder's backward
         self.bucket_layers = 5
+        # set by the Trainer (which always evaluates the ELBO right after the forward): the decoder tail is NOT launched by
+        # forward -- xyz_recon is filled by the loss launch (ops.reconstruct(lazy=True), csrc/loss_tail.hip)
+        self.lazy_tail = False
         self.concurrent_prior = False      # measured: cross-stream joins cost more than the overlap saves (3.72 vs 3.53 ms)
         self._streams = {}
         if not equivariant:
@@ -357,7 +360,7 @@ class CGequiVAE(nn.Module):
         if not self.equivariant:
             cg_v = self.euclidean(cg_s).reshape(cg_s.shape[0], cg_s.shape[1], 3)
         # xyz_rel = cg_v[mapping, chan]; -= scatter_mean(xyz_rel, mapping)[mapping] (offset); += cg_xyz[mapping]
-        return ops.reconstruct(cg_v, cg_xyz, chan, plan, self.offset)
+        return ops.reconstruct(cg_v, cg_xyz, chan, plan, self.offset, lazy=self.lazy_tail)
 
     def forward(self, batch, eps: Optional[torch.Tensor] = None):
         z, cg_z, xyz, cg_xyz, nbr_list, CG_nbr_list, mapping, num_CGs = self.get_inputs(batch)

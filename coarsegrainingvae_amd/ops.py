@@ -250,22 +250,41 @@ def scatter_mean(src: torch.Tensor, index: torch.Tensor, dim: int = 0, dim_size:
 
 
 # ----------------------------------------------------------------------------- decoder tail
+class _TailSlot:
+    """Hand-over between a LAZY ``reconstruct`` (no launch: the coordinates are produced by the loss launch) and the fused
+    decoder-tail + ELBO launch (``_Elbo`` with ``tail``): the tail's inputs one way, d loss / d V the other way."""
+    __slots__ = ("v", "cg_xyz", "chan", "plan", "offset", "out", "g_V", "filled")
+
+    def __init__(self):
+        self.v = self.cg_xyz = self.chan = self.plan = self.out = self.g_V = None
+        self.offset, self.filled = True, False
+
+
 class _Reconstruct(torch.autograd.Function):
-    """xyz_recon from the bead vector channels (cgvae.py:462-481) in one launch each way."""
+    """xyz_recon from the bead vector channels (cgvae.py:462-481) in one launch each way.  With a ``slot`` (lazy): no
+    launch at all -- the tensor returned is filled by the loss launch that consumes it (``elbo_loss`` ->
+    ``cgv_loss_tail``, which also leaves d loss / d V in the slot), or by ``materialise_reconstruct``."""
 
     @staticmethod
-    def forward(ctx, v, cg_xyz, chan, plan: EdgePlan, offset: bool):
+    def forward(ctx, v, cg_xyz, chan, plan: EdgePlan, offset: bool, slot=None):
         v, cg_xyz = _c(v), _c(cg_xyz)
         n_beads, F = v.shape[0], v.shape[1]
         n_atoms = chan.shape[0]
         xyz = torch.empty(n_atoms, 3, dtype=torch.float32, device=v.device)
+        ctx.plan, ctx.chan, ctx.offset, ctx.shape, ctx.slot = plan, chan, offset, (n_beads, F), slot
+        if slot is not None:
+            slot.v, slot.cg_xyz, slot.chan, slot.plan, slot.offset, slot.out = v, cg_xyz, chan, plan, bool(offset), xyz
+            return xyz
         _lib.call("cgv_reconstruct_fwd", _lib.ptr(v), _lib.ptr(cg_xyz), _lib.ptr(plan.rowptr_d), _lib.ptr(plan.eid_d),
                   _lib.ptr(chan), n_beads, F, int(offset), _lib.ptr(xyz), _lib.stream_ptr())
-        ctx.plan, ctx.chan, ctx.offset, ctx.shape = plan, chan, offset, (n_beads, F)
         return xyz
 
     @staticmethod
     def backward(ctx, g):
+        slot, ctx.slot = ctx.slot, None
+        if slot is not None and slot.g_V is not None and not ctx.needs_input_grad[1]:
+            g_v, slot.g_V = slot.g_V, None                 # d loss / d V came out of the fused loss launch
+            return g_v, None, None, None, None, None
         g = _c(g)
         n_beads, F = ctx.shape
         g_v = torch.empty(n_beads, F, 3, dtype=torch.float32, device=g.device)
@@ -273,14 +292,47 @@ class _Reconstruct(torch.autograd.Function):
         plan = ctx.plan
         _lib.call("cgv_reconstruct_bwd", _lib.ptr(g), _lib.ptr(plan.rowptr_d), _lib.ptr(plan.eid_d), _lib.ptr(ctx.chan),
                   n_beads, F, int(ctx.offset), _lib.ptr(g_v), _lib.ptr(g_cg), _lib.stream_ptr())
-        return g_v, g_cg, None, None, None
+        return g_v, g_cg, None, None, None, None
 
 
-def reconstruct(v, cg_xyz, chan, plan: EdgePlan, offset: bool = True):
-    """``v[mapping, chan] - scatter_mean(...)[mapping] + cg_xyz[mapping]`` (``plan`` = EdgePlan.from_mapping(mapping))."""
+def reconstruct(v, cg_xyz, chan, plan: EdgePlan, offset: bool = True, lazy: bool = False):
+    """``v[mapping, chan] - scatter_mean(...)[mapping] + cg_xyz[mapping]`` (``plan`` = EdgePlan.from_mapping(mapping)).
+    ``lazy=True`` (set by the Trainer, which always evaluates the ELBO next): the coordinates are NOT computed here --
+    the tensor returned is filled by ``elbo_loss`` (one launch for tail + loss + both backward tails, csrc/loss_tail.hip);
+    anything else that reads it first must call ``materialise_reconstruct`` on it."""
     if int(plan.n_dst) != v.shape[0] or chan.dtype != torch.int64 or not chan.is_contiguous():
         raise ValueError("reconstruct: plan / chan do not match the bead tensor")
+    if (lazy and v.is_cuda and v.requires_grad and torch.is_grad_enabled() and not cg_xyz.requires_grad and v.dtype == _F32
+            and getattr(plan, "dst_d", None) is not None):
+        slot = _TailSlot()
+        out = _Reconstruct.apply(v, cg_xyz, chan, plan, bool(offset), slot)
+        out._cgv_tail = slot
+        return out
     return _Reconstruct.apply(v, cg_xyz, chan, plan, bool(offset))
+
+
+def materialise_reconstruct(xyz_recon):
+    """Fill a lazily reconstructed tensor now (no-op for ordinary tensors or when the loss launch has filled it)."""
+    slot = getattr(xyz_recon, "_cgv_tail", None)
+    if slot is None or slot.filled:
+        return xyz_recon
+    plan = slot.plan
+    _lib.call("cgv_reconstruct_fwd", _lib.ptr(slot.v), _lib.ptr(slot.cg_xyz), _lib.ptr(plan.rowptr_d), _lib.ptr(plan.eid_d),
+              _lib.ptr(slot.chan), slot.v.shape[0], slot.v.shape[1], int(slot.offset), _lib.ptr(slot.out), _lib.stream_ptr())
+    slot.filled = True
+    return xyz_recon
+
+
+_TAIL_WS = {}
+
+
+def _tail_workspace(device, n_beads):
+    """Partial sums + the ticket word of cgv_loss_tail: zeroed ONCE (every launch leaves the ticket at zero)."""
+    key = (str(device), int(n_beads))
+    ws = _TAIL_WS.get(key)
+    if ws is None:
+        ws = _TAIL_WS[key] = torch.zeros(int(_lib.load().cgv_loss_tail_workspace_bytes(int(n_beads))), dtype=torch.uint8, device=device)
+    return ws
 
 
 # ----------------------------------------------------------------------------- K3
@@ -568,7 +620,7 @@ class _Elbo(torch.autograd.Function):
     """(loss, KL, recon, graph) of scripts/utils.py:117-141 in one launch; gradients come from the same launch."""
 
     @staticmethod
-    def forward(ctx, mu, sigma, pmu, pstd, xyz, xyz_recon, bonds, beta, gamma, slot=None):
+    def forward(ctx, mu, sigma, pmu, pstd, xyz, xyz_recon, bonds, beta, gamma, slot=None, tail=None):
         mu, sigma, pmu, pstd, xyz, xr = (_c(t) for t in (mu, sigma, pmu, pstd, xyz, xyz_recon))
         bonds = bonds.contiguous()
         if bonds.dtype != torch.int64:
@@ -578,11 +630,26 @@ class _Elbo(torch.autograd.Function):
         out = torch.empty(4, dtype=_F32, device=mu.device)
         loss = torch.empty((), dtype=_F32, device=mu.device)        # the differentiable output, written by the same launch
         grads = [torch.empty_like(t) for t in (mu, sigma, pmu, pstd, xr)]
-        nbytes = int(_lib.load().cgv_elbo_workspace_bytes(n_beads, F))
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=mu.device) if nbytes else None
-        _lib.call("cgv_elbo_fwd", _lib.ptr(mu), _lib.ptr(sigma), _lib.ptr(pmu), _lib.ptr(pstd), _lib.ptr(xyz), _lib.ptr(xr),
-                  _lib.ptr(bonds) if bonds.shape[0] else None, n_beads, F, n_atoms, bonds.shape[0], float(beta),
-                  float(gamma), _lib.ptr(out), _lib.ptr(loss), *[_lib.ptr(g) for g in grads], _lib.ptr(ws), nbytes, _lib.stream_ptr())
+        if tail is not None and xr.data_ptr() == tail.out.data_ptr():
+            # decoder tail + ELBO + both backward tails in one launch: xyz_recon (the lazy tensor we were given) is WRITTEN
+            # here, d loss / d V goes back through the slot to _Reconstruct.backward
+            plan = tail.plan
+            g_V = torch.empty_like(tail.v)
+            ws = _tail_workspace(mu.device, n_beads)
+            _lib.call("cgv_loss_tail", _lib.ptr(tail.v), _lib.ptr(tail.cg_xyz), _lib.ptr(plan.rowptr_d), _lib.ptr(plan.eid_d),
+                      _lib.ptr(plan.dst_d), _lib.ptr(tail.chan), _lib.ptr(mu), _lib.ptr(sigma), _lib.ptr(pmu), _lib.ptr(pstd),
+                      _lib.ptr(xyz), _lib.ptr(bonds) if bonds.shape[0] else None, n_beads, F, n_atoms, bonds.shape[0],
+                      int(tail.offset), float(beta), float(gamma), _lib.ptr(xr), _lib.ptr(out), _lib.ptr(loss),
+                      *[_lib.ptr(g) for g in grads], _lib.ptr(g_V), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+            tail.g_V, tail.filled = g_V, True
+            ctx.tail = tail
+        else:
+            ctx.tail = None
+            nbytes = int(_lib.load().cgv_elbo_workspace_bytes(n_beads, F))
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=mu.device) if nbytes else None
+            _lib.call("cgv_elbo_fwd", _lib.ptr(mu), _lib.ptr(sigma), _lib.ptr(pmu), _lib.ptr(pstd), _lib.ptr(xyz), _lib.ptr(xr),
+                      _lib.ptr(bonds) if bonds.shape[0] else None, n_beads, F, n_atoms, bonds.shape[0], float(beta),
+                      float(gamma), _lib.ptr(out), _lib.ptr(loss), *[_lib.ptr(g) for g in grads], _lib.ptr(ws), nbytes, _lib.stream_ptr())
         ctx.grads = grads
         ctx.slot = slot
         ctx.mark_non_differentiable(out)
@@ -594,21 +661,24 @@ class _Elbo(torch.autograd.Function):
         g = ctx.grads
         ctx.grads = None
         slot, ctx.slot = ctx.slot, None
+        tail, ctx.tail = ctx.tail, None
         # with a slot, d loss / d{mu, sigma} travel to the reparametrisation's backward (which adds them to its own
         # contribution in one launch) instead of to autograd's accumulation
         to_autograd = (lambda: (g[0], g[1])) if slot is None else (lambda: (None, None))
         if slot is not None:
             slot.g_mu, slot.g_sigma = g[0], g[1]
         if g_loss is None:
-            return (None,) * 10
+            return (None,) * 11
         if g_loss.data_ptr() == _UNIT_SEED.get(g_loss.device):
             # the caller seeded backward with its registered constant 1 (unit_seed): the gradients of the forward launch
             # are final as they are -- no scale launch, and no ones_like fill in front of it
-            return to_autograd() + (g[2], g[3], None, g[4], None, None, None, None)
+            return to_autograd() + (g[2], g[3], None, g[4], None, None, None, None, None)
         gl = _c(g_loss.reshape(1))
         _lib.call("cgv_elbo_scale", _lib.ptr(gl), _lib.ptr(g[0]), _lib.ptr(g[1]), _lib.ptr(g[2]), _lib.ptr(g[3]),
                   g[0].numel(), _lib.ptr(g[4]), g[4].numel(), _lib.stream_ptr())
-        return to_autograd() + (g[2], g[3], None, g[4], None, None, None, None)
+        if tail is not None and tail.g_V is not None:
+            tail.g_V = tail.g_V * gl                        # (rare path: backward seeded with something else than the unit seed)
+        return to_autograd() + (g[2], g[3], None, g[4], None, None, None, None, None)
 
 
 class _ReparamSample(torch.autograd.Function):
@@ -751,4 +821,9 @@ def elbo_loss(mu, sigma, prior_mu, prior_std, xyz, xyz_recon, bonds, beta, gamma
     tag = getattr(mu, "_cgv_kl_slot", None)
     if tag is not None and tag[1] is sigma and torch.is_grad_enabled():
         slot = tag[0]                              # this (mu, sigma) pair went through reparam_sample: see _KLSlot
-    return _Elbo.apply(mu, sigma, prior_mu, prior_std, xyz, xyz_recon, bonds, beta, gamma, slot)
+    tail = getattr(xyz_recon, "_cgv_tail", None)
+    if tail is not None and (tail.filled or not torch.is_grad_enabled() or not xyz_recon.is_contiguous()
+                             or not _lib.load().cgv_loss_tail_supported(mu.shape[0], mu.shape[1], xyz_recon.shape[0], bonds.shape[0])):
+        materialise_reconstruct(xyz_recon)
+        tail = None
+    return _Elbo.apply(mu, sigma, prior_mu, prior_std, xyz, xyz_recon, bonds, beta, gamma, slot, tail)

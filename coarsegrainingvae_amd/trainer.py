@@ -431,6 +431,10 @@ class Trainer:
         self.last_loss = None
         self.last_terms = None
         self.steps_skipped_host = 0
+        from .options import HOST as _H
+        if hasattr(model, "lazy_tail"):
+            # the ELBO always follows the forward here: the decoder tail runs inside the loss launch (csrc/loss_tail.hip)
+            model.lazy_tail = bool(_H["fused_loss_tail"]) and fused_optimizer
         self._graphs = {}             # train flag -> captured hipGraph of one full step (capture())
         self._retired = []            # replaced captures of a data-parallel trainer (_retire)
         self._pre_stream = None       # side stream of enable_prefetch()

@@ -600,6 +600,21 @@ int cgv_elbo_fwd(const float* mu, const float* sigma, const float* prior_mu, con
                  void* workspace /*or NULL*/, size_t workspace_bytes, void* stream);
 int cgv_elbo_scale(const float* g_loss, float* g_mu, float* g_sigma, float* g_prior_mu, float* g_prior_std, int n_bead_elems,
                    float* g_xyz_recon, int n_atom_elems, void* stream);
+/* Decoder tail (cgv_reconstruct_fwd: cgvae.py:462-481) + the ELBO above + BOTH their gradients in ONE launch, one block
+ * per bead: xyz_recon is an OUTPUT here, and besides d loss / d{mu, sigma, prior_mu, prior_std, xyz_recon} the launch
+ * leaves g_V [n_beads, F, 3] = d loss / d V (what cgv_reconstruct_bwd would compute from g_xyz_recon).  rowptr / atom_of /
+ * bead_of: the atom -> bead plan (CSR by bead, atom ids and bead ids in bead-sorted order).  Sums in double, block
+ * partials added in block order by the block that arrives last (device-scope ticket): deterministic.
+ * workspace: cgv_loss_tail_workspace_bytes(n_beads) bytes, 16-byte aligned, ZERO before the first launch (every launch
+ * leaves its ticket word at zero again).  Limits: cgv_loss_tail_supported (atoms <= 8192, beads <= 2048). */
+int cgv_loss_tail_supported(int n_beads, int n_feat, int n_atoms, int n_bonds);
+size_t cgv_loss_tail_workspace_bytes(int n_beads);
+int cgv_loss_tail(const float* V, const float* cg_xyz, const int32_t* rowptr, const int32_t* atom_of, const int32_t* bead_of,
+                  const int64_t* chan, const float* mu, const float* sigma, const float* prior_mu, const float* prior_std,
+                  const float* xyz, const int64_t* bonds, int n_beads, int n_feat, int n_atoms, int n_bonds, int offset,
+                  float beta, float gamma, float* xyz_recon, float* out4, float* loss_out, float* g_mu, float* g_sigma,
+                  float* g_prior_mu, float* g_prior_std, float* g_xyz_recon, float* g_V, void* workspace, size_t workspace_bytes,
+                  void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Fused optimiser step over a flat fp32 arena of the parameters that receive gradients --

@@ -2030,3 +2030,78 @@ def test_quad_heads_equal_the_separate_heads():
         assert_close(a, b, f"quad heads output / input gradient {k}", 1e-5)
     for k, (a, b) in enumerate(zip(got_w, want_w)):
         assert_close(a, b, f"quad heads parameter gradient {k}", 1e-5)
+
+
+@pytest.mark.parametrize("n_frames,n_atoms,n_cgs,F,gamma,offset", [(2, 166, 6, 64, 50.0, True), (8, 22, 3, 32, 25.0, True),
+                                                                     (1, 2000, 64, 64, 50.0, True), (1, 150, 2, 128, 0.0, True),
+                                                                     (2, 40, 4, 16, 5.0, False)])
+def test_fused_loss_tail_equals_reconstruct_plus_elbo(n_frames, n_atoms, n_cgs, F, gamma, offset):
+    """cgv_loss_tail (decoder tail + ELBO + both backward tails, one launch) against the three launches it replaces
+    (cgv_reconstruct_fwd, cgv_elbo_fwd, cgv_reconstruct_bwd: cgvae.py:462-481, scripts/utils.py:81-86, 117-141) and, through
+    them, against the oracle's formulas: coordinates, the four scalars and every gradient."""
+    from coarsegrainingvae_amd import ops
+    gen = torch.Generator().manual_seed(n_atoms + F)
+    N, nb = n_frames * n_atoms, n_frames * n_cgs
+    per = [sorted(torch.randint(0, n_cgs, (n_atoms,), generator=gen).tolist()) for _ in range(n_frames)]
+    for m in per:                                                     # every bead of a frame owns at least one atom
+        for k in range(n_cgs):
+            m[k] = k
+        m.sort()
+    mapping = torch.tensor([k + f * n_cgs for f, m in enumerate(per) for k in m])
+    mapping = mapping[torch.randperm(N, generator=gen)] if n_atoms < 100 else mapping       # unsorted mappings too
+    plan = EdgePlan.from_mapping(mapping.to(DEV), nb)
+    if max(np.bincount(mapping.numpy(), minlength=nb)) > F:
+        pytest.skip("a bead holds more atoms than channels")
+    model = cg.CGequiVAE.__new__(cg.CGequiVAE)
+    chan = cg.CGequiVAE.CG2ChannelIdx(model, mapping.to(DEV))
+    bonds = torch.tensor([[a + f * n_atoms, a + 1 + f * n_atoms] for f in range(n_frames) for a in range(n_atoms - 1)] +
+                         [[0, 0], [3, 1]]).to(DEV)
+    mk = lambda *shape, s=1.0: (s * torch.randn(*shape, generator=gen)).to(DEV)
+    cg_xyz, xyz = mk(nb, 3, s=4.0), mk(N, 3, s=4.0)
+    beta = 0.05
+    results = []
+    for lazy in (False, True):
+        V = mk(nb, F, 3).requires_grad_()
+        mu, pmu = mk(nb, F).requires_grad_(), mk(nb, F).requires_grad_()
+        sigma, pstd = (0.5 + torch.rand(nb, F, generator=gen)).to(DEV).requires_grad_(), (0.5 + torch.rand(nb, F, generator=gen)).to(DEV).requires_grad_()
+        gen.manual_seed(n_atoms + F + 1)                              # the same numbers in both passes
+        if lazy is False:
+            keep = [t.detach().clone() for t in (V, mu, pmu, sigma, pstd)]
+        else:
+            with torch.no_grad():
+                for t, k in zip((V, mu, pmu, sigma, pstd), keep):
+                    t.copy_(k)
+        xr = ops.reconstruct(V, cg_xyz, chan, plan, offset, lazy=lazy)
+        assert (getattr(xr, "_cgv_tail", None) is not None) == lazy
+        loss, terms = ops.elbo_loss(mu, sigma, pmu, pstd, xyz, xr, bonds, beta, gamma)
+        if lazy:
+            assert xr._cgv_tail.filled
+        (3.0 * loss).backward()                                       # (not the unit seed: the scale path too)
+        results.append([xr.detach().clone(), terms.clone(), V.grad.clone(), mu.grad.clone(), sigma.grad.clone(), pmu.grad.clone(), pstd.grad.clone()])
+    names = ["xyz_recon", "terms", "g_V", "g_mu", "g_sigma", "g_prior_mu", "g_prior_std"]
+    for name, a, b in zip(names, results[1], results[0]):
+        assert_close(a, b, f"fused loss tail: {name}", 2e-6)
+    assert float(results[1][2].abs().max()) > 0
+
+
+def test_lazy_reconstruct_is_materialised_when_no_loss_launch_fills_it():
+    """A lazily reconstructed tensor that reaches the tensor-op loss (no prior net) or ``materialise_reconstruct`` is
+    filled by the ordinary tail launch (cgvae.py:462-481)."""
+    from coarsegrainingvae_amd import ops
+    torch.manual_seed(0)
+    mapping = torch.tensor([0, 0, 1, 1, 1, 2, 2, 0]).to(DEV)
+    plan = EdgePlan.from_mapping(mapping, 3)
+    model = cg.CGequiVAE.__new__(cg.CGequiVAE)
+    chan = cg.CGequiVAE.CG2ChannelIdx(model, mapping)
+    V = torch.randn(3, 8, 3, device=DEV, requires_grad=True)
+    cgx = torch.randn(3, 3, device=DEV)
+    ref = ops.reconstruct(V, cgx, chan, plan, True)
+    lazy = ops.reconstruct(V, cgx, chan, plan, True, lazy=True)
+    assert not lazy._cgv_tail.filled
+    ops.materialise_reconstruct(lazy)
+    assert torch.equal(lazy, ref)
+    lazy.sum().backward()                                             # the ordinary backward launch (no slot gradient)
+    g = V.grad.clone()
+    V.grad = None
+    ref.sum().backward()
+    assert torch.equal(g, V.grad)
