@@ -140,6 +140,147 @@ __global__ __launch_bounds__(64 * QM * QN * KW) void tile_fwd_k(const float* __r
   }
 }
 
+// ------------------------------------------------------------------ fwd, ONE register tile per CU (round 4)
+// What bounds these products is how fast a CU pulls its operand rows (~25 GB/s per CU in the 64-byte fragments of the MFMA
+// layout -- the same figure explains every measured time of the kernels above and below: 32 x 32 tiles of 332 x 1800 x 600
+// = 3 tiles x 154 KB per CU = 18 us, the 64 x 64 ring on 2000 x 5400 = 11 tiles x 307 KB = 135 us), so the time is the
+// BYTES PER CU: (tile rows + tile columns) x K x 4 x tiles per CU.  This kernel computes a (16 MT) x (16 NT) tile per block
+// with the whole tile in every wave's accumulators -- each loaded fragment feeds MT or NT MFMAs from registers -- the
+// reduction split over 8 waves as above, and the launcher picks MT x NT so that the shape gives AT MOST one tile per CU
+// (332 x 1800: 32 x 80 -> 253 tiles x 269 KB; 704 x 1800: 64 x 80 -> 253 x 346 KB; 704 x 600: 64 x 32 -> 209 x 230 KB).
+// Tile order is XCD-aware: workgroup L runs on XCD L % 8, and XCD c is given run c of the tiles in (column tile, row tile)
+// order, so the weight rows an XCD's L2 holds (~1/8 of W) are shared by all its row tiles and x (<= 1.7 MB) stays resident.
+// What it bought (same tool): 7 - 17 % on the wide layers, nothing at 600 outputs -- NOT the 2 x the bytes-per-CU
+// picture promises: with all of a CU's 280 KB requested up front the chip still delivers ~6.4 TB/s in aggregate
+// (~30 GB/s per CU), i.e. the limit is the rate at which a CU's 64-byte row fragments are served (16 separate half lines
+// per load instruction in the MFMA operand layout), not their number in flight.
+template <int MT, int NT>
+__global__ __launch_bounds__(512) void tile_fwd_bal_k(const float* __restrict__ x, const float* __restrict__ W,
+                                                      const float* __restrict__ bias, float* __restrict__ y,
+                                                      float* __restrict__ zout, int M, int N, int K, int act, int MB, int NB) {
+  constexpr int KW = 8, TT = MT * NT;
+  // LDS for the cross-wave sum: two rounds (waves 4-7 hand over, then waves 0-3) keep it at 4 x TT KB
+  extern __shared__ __attribute__((aligned(16))) float bal_red[];      // [4][TT][4][64]
+  const int lane = threadIdx.x & 63;
+  const int kq = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, q = lane >> 4;
+  // tiles in (column tile, row tile) order, cut into 8 equal runs: XCD c (= workgroups c, c + 8, ..) works through run c
+  const int L = blockIdx.x, xcd = L & 7, chunk = (MB * NB + 7) >> 3;
+  const int pos = xcd * chunk + (L >> 3);
+  if (pos >= MB * NB) return;                                          // block-uniform: at most 7 surplus blocks
+  const int nt = pos / MB, mt = pos - nt * MB;
+  const int m0 = mt * 16 * MT, n0 = nt * 16 * NT;
+  const float* xr[MT];
+  const float* wr[NT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a) { const int m = m0 + 16 * a + i; xr[a] = x + (size_t)(m < M ? m : 0) * K + 4 * q; }
+#pragma unroll
+  for (int b = 0; b < NT; ++b) { const int n = n0 + 16 * b + i; wr[b] = W + (size_t)(n < N ? n : 0) * K + 4 * q; }
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int steps = (K + 15) / 16, per = (steps + KW - 1) / KW;
+  const int s_end = min((kq + 1) * per, steps);
+  // steps whose loads are in flight together: ALL of a wave's five steps at K = 600 where the registers allow it (a lone
+  // block per CU has nobody to hide a second round trip behind)
+  constexpr int SB = ((MT + NT) * 20 + MT * NT * 4 <= 228) ? 5 : 4;
+  for (int s0 = kq * per; s0 < s_end; s0 += SB) {
+    float4 av[SB][MT], bv[SB][NT];
+#pragma unroll
+    for (int u = 0; u < SB; ++u) {
+      const int k = 16 * (s0 + u);
+      const int kc = (s0 + u < s_end && k + 4 * q < K) ? k : -4 * q;   // out of range: the row's first float4 (never used)
+#pragma unroll
+      for (int a = 0; a < MT; ++a) av[u][a] = *reinterpret_cast<const float4*>(xr[a] + kc);
+#pragma unroll
+      for (int b = 0; b < NT; ++b) bv[u][b] = *reinterpret_cast<const float4*>(wr[b] + kc);
+    }
+#pragma unroll
+    for (int u = 0; u < SB; ++u) {
+      if (s0 + u >= s_end) break;                  // wave-uniform
+      const bool kok = 16 * (s0 + u) + 4 * q < K;
+      // the reduction tail is zeroed on W's side; consecutive MFMAs go to DIFFERENT accumulators (no dependent chains)
+#pragma unroll
+      for (int b = 0; b < NT; ++b)
+        if (!kok) bv[u][b] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int b = 0; b < NT; ++b)
+#pragma unroll
+        for (int a = 0; a < MT; ++a) acc[a][b] = CGV_MFMA(av[u][a].x, bv[u][b].x, acc[a][b]);
+#pragma unroll
+      for (int b = 0; b < NT; ++b)
+#pragma unroll
+        for (int a = 0; a < MT; ++a) acc[a][b] = CGV_MFMA(av[u][a].y, bv[u][b].y, acc[a][b]);
+#pragma unroll
+      for (int b = 0; b < NT; ++b)
+#pragma unroll
+        for (int a = 0; a < MT; ++a) acc[a][b] = CGV_MFMA(av[u][a].z, bv[u][b].z, acc[a][b]);
+#pragma unroll
+      for (int b = 0; b < NT; ++b)
+#pragma unroll
+        for (int a = 0; a < MT; ++a) acc[a][b] = CGV_MFMA(av[u][a].w, bv[u][b].w, acc[a][b]);
+    }
+  }
+  // round 1: waves 4..7 park their tiles, waves 0..3 add them (wave w takes wave w + 4's)
+  if (kq >= 4) {
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+      for (int b = 0; b < NT; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bal_red[(((kq - 4) * TT + a * NT + b) * 4 + r) * 64 + lane] = acc[a][b][r];
+  }
+  __syncthreads();
+  if (kq < 4) {
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+      for (int b = 0; b < NT; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[a][b][r] += bal_red[((kq * TT + a * NT + b) * 4 + r) * 64 + lane];
+  }
+  __syncthreads();
+  // round 2: waves 0..3 park the pair sums; all 512 threads finish the outputs (4 partials each, fixed order)
+  if (kq < 4) {
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+      for (int b = 0; b < NT; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bal_red[((kq * TT + a * NT + b) * 4 + r) * 64 + lane] = acc[a][b][r];
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < TT * 256; o += 512) {
+    const int l = o & 63, r = (o >> 6) & 3, t = o >> 8;
+    const int n = n0 + 16 * (t % NT) + (l & 15), m = m0 + 16 * (t / NT) + 4 * (l >> 4) + r;
+    if (n >= N || m >= M) continue;
+    float zv = bal_red[((0 * TT + t) * 4 + r) * 64 + l] + bal_red[((1 * TT + t) * 4 + r) * 64 + l] +
+               bal_red[((2 * TT + t) * 4 + r) * 64 + l] + bal_red[((3 * TT + t) * 4 + r) * 64 + l];
+    zv += bias ? bias[n] : 0.f;
+    if (act) {
+      if (zout) zout[(size_t)m * N + n] = zv;
+      zv = act_fwd(zv, act);
+    }
+    y[(size_t)m * N + n] = zv;
+  }
+}
+
+// (MT, NT) of the balanced kernel for a shape: at most one tile per CU (256), the fewest operand bytes per tile; 0 when no
+// compiled tile gives <= 256 tiles (large shapes: the LDS-staged kernels) or the shape already has one 32 x 32 tile per CU
+static inline int bal_pick(int M, int N, int* mt_out, int* nt_out) {
+  static const int cand[][2] = {{2, 2}, {2, 3}, {3, 2}, {3, 3}, {2, 4}, {4, 2}, {2, 5}, {3, 4}, {4, 3}, {4, 4}, {4, 5}, {3, 5}, {2, 6}, {4, 6}};
+  long long best = -1;
+  for (const auto& c : cand) {
+    const int mb = (M + 16 * c[0] - 1) / (16 * c[0]), nb = (N + 16 * c[1] - 1) / (16 * c[1]);
+    if ((long long)mb * nb > 256) continue;
+    const long long cost = 16 * (c[0] + c[1]);                          // operand rows per tile (x K x 4 bytes)
+    if (best < 0 || cost < best) { best = cost; *mt_out = c[0]; *nt_out = c[1]; }
+  }
+  return best >= 0;
+}
+
 // ------------------------------------------------------------------ fwd, LDS-staged (shapes with many output tiles)
 // The L2-fed tiles above level off near 50 TF/s: every wave pulls its own operand fragments through the L1 (256 bytes
 // per MFMA).  With several 64 x 64 output tiles per CU there is no need to split the reduction for parallelism, so the
@@ -539,6 +680,28 @@ int cgv_tile_linear_fwd(const float* x, const float* W, const float* bias, float
   // 332 x 5400 32 vs 39, 2000 x 1200 40 vs 43; below ~450 tiles the split-reduction tiles win (704 x 1800: 27 vs 31,
   // 2000 x 600: 24 vs 30 -- a lone block per CU still spends ~1 us per slab on its read -> MFMA -> write -> barrier chain).
   // cgv_set_option(CGV_OPT_TILE_FWD_LDS_MIN, 1): the one-slab kernel for every shape, 3: the ring kernel (tests / A-B)
+  if (const int bal = cgv::option(CGV_OPT_TILE_FWD_BAL); bal == 2 || (bal == 1 && tiles32 > 256 && N >= 1200)) {
+    // wide layers with more than one 32 x 32 tile per CU: one larger register tile per CU instead.  Measured
+    // (tools/gemm_ab.py, rotating operands): 332 x 1800 x 600 17.7 -> 15.7 us, 704 x 1800 26.9 -> 25.0, 288 x 1200 11.8 -> 10.8,
+    // 64 x 5400 12.8 -> 10.6, 2000 x 1800 51.7 -> 51.0; NOT at 600 outputs (704 x 600: 12.6 -> 13.3, 2000 x 600: 24.8 -> 26.3).
+    // (bal == 2: every shape a compiled tile fits, for tests / A-B)
+    int mt = 0, nt = 0;
+    if (cgv::bal_pick(M, N, &mt, &nt)) {
+      const int MB = (M + 16 * mt - 1) / (16 * mt), NB = (N + 16 * nt - 1) / (16 * nt);
+      const dim3 grid(8 * ((MB * NB + 7) / 8));
+      const size_t lds = (size_t)4 * mt * nt * 1024;
+#define CGV_BAL(A, B)                                                                                                      \
+  if (mt == A && nt == B) {                                                                                                \
+    if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(cgv::tile_fwd_bal_k<A, B>),                     \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
+    hipLaunchKernelGGL((cgv::tile_fwd_bal_k<A, B>), grid, dim3(512), lds, st, x, W, bias, y, z, M, N, K, act, MB, NB);     \
+    return cgv::check_launch("cgv_tile_linear_fwd");                                                                       \
+  }
+      CGV_BAL(2, 2) CGV_BAL(2, 3) CGV_BAL(3, 2) CGV_BAL(3, 3) CGV_BAL(2, 4) CGV_BAL(4, 2) CGV_BAL(2, 5) CGV_BAL(3, 4)
+      CGV_BAL(4, 3) CGV_BAL(4, 4) CGV_BAL(4, 5) CGV_BAL(3, 5) CGV_BAL(2, 6) CGV_BAL(4, 6)
+#undef CGV_BAL
+    }
+  }
   const int slabs32 = (K + 31) / 32;
   const bool ring_ok = aligned16 && (slabs32 == 19 || slabs32 == 38) && lds_min != 1 && !(lds_min >= 5 && lds_min <= 7);
   if (ring_ok && (tiles64 >= lds_min || lds_min == 3)) {

@@ -78,7 +78,8 @@ enum {
   CGV_OPT_DECODER_FAT = 11,    /* cgv_decoder_{gate,dense,uv}_bwd: 1 (default) 8-channel blocks where the width allows, 0 always 4 */
   CGV_OPT_DECODER_WLDS = 12,   /* cgv_decoder_msg_fwd: 1 (default) weight rows by LDS-DMA when they fit in LDS, 0 register path */
   CGV_OPT_SKINNY_ROWS = 13,    /* cgv_skinny_linear_fwd: row blocks (of 16) per thread block; 0 = built-in rule, 1..4 */
-  CGV_OPT_COUNT = 14
+  CGV_OPT_TILE_FWD_BAL = 14,   /* cgv_tile_linear_fwd: 1 (default) layers of >= 1200 outputs with more than one 32 x 32 tile per CU run as ONE larger register tile per CU where a compiled tile fits (XCD-aware tile order), 0 off, 2 every shape (tests / A-B) */
+  CGV_OPT_COUNT = 15
 };
 /* Measurement: store the GPU wall clock (cgv_timestamp_hz ticks per second) into *slot, in stream order; capturable. */
 int cgv_timestamp(uint64_t* slot /*device*/, void* stream);

@@ -2105,3 +2105,26 @@ def test_lazy_reconstruct_is_materialised_when_no_loss_launch_fills_it():
     V.grad = None
     ref.sum().backward()
     assert torch.equal(g, V.grad)
+
+
+@pytest.mark.parametrize("shape", [(332, 1800, 600, 1), (704, 1800, 600, 1), (704, 600, 600, 1), (332, 600, 600, 0), (333, 1796, 596, 2),
+                                   (96, 5400, 600, 0), (288, 1200, 600, 1), (50, 36, 20, 1), (17, 100, 8, 0), (1000, 340, 1200, 1)])
+def test_tile_forward_one_register_tile_per_cu_vs_fp64(shape, options):
+    """tile_fwd_bal_k (option tile_fwd_bal: one (16 MT) x (16 NT) register tile per CU, reduction split over 8 waves with a
+    two-round LDS sum, XCD-aware tile order): Dense forward modules.py:103-114 on the atom-level and ragged shapes, bias +
+    activation epilogue, pre-activation output, rows / columns / reduction tails that do not fill a tile."""
+    options.set("tile_fwd_bal", 2)
+    M, N, K, act = shape
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    x = torch.randn(M, K, device=DEV, generator=g)
+    W = torch.randn(N, K, device=DEV, generator=g) / K ** 0.5
+    b = torch.randn(N, device=DEV, generator=g)
+    y = torch.full((M, N), float("nan"), device=DEV)
+    z = torch.full((M, N), float("nan"), device=DEV)
+    cg._lib.call("cgv_tile_linear_fwd", cg._lib.ptr(x), cg._lib.ptr(W), cg._lib.ptr(b), cg._lib.ptr(y), cg._lib.ptr(z), M, N, K, act,
+                 cg._lib.stream_ptr())
+    zr = x.double() @ W.double().T + b.double()
+    yr = {0: zr, 1: zr * torch.sigmoid(zr), 2: torch.tanh(zr)}[act]
+    assert torch.allclose(y.double(), yr, rtol=1e-5, atol=1e-5)
+    if act:
+        assert torch.allclose(z.double(), zr, rtol=1e-5, atol=1e-5)
