@@ -67,6 +67,11 @@ def parse():
                          "group: the part of a --gpus N run that one GPU can execute (rehearsal of the driver's scaling runs)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "operands", "gradients"],
                     help="N > 1: all-gather the bead-level layers' operand rows (default) or all-reduce every gradient")
+    ap.add_argument("--attempt-timeout", type=float, default=420.0,
+                    help="multi-rank runs: seconds one attempt of the fallback ladder may take before its worker is killed and "
+                         "the next rung starts in a FRESH process (operands + graph -> gradients + graph -> gradients eager)")
+    ap.add_argument("--no-supervisor", action="store_true",
+                    help="multi-rank runs: measure in this process (no per-attempt timeout, no ladder) -- what a worker runs")
     return ap.parse_args()
 
 
@@ -106,6 +111,64 @@ def spawn_ranks(n: int) -> int:
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
     return subprocess.run(cmd, env=env).returncode
+
+
+# ---------------------------------------------------------------------------------------------- multi-rank supervisor
+# A multi-rank run must not be lost to a hang: a collective stuck inside a replayed graph never raises.  Every rank that
+# torchrun (or the driver) starts is therefore only a SUPERVISOR -- it never touches the GPU -- and runs the measurement
+# in a fresh worker process per attempt, with a deadline.  All ranks walk the same ladder with the same deadlines, so they
+# change rungs together; the workers of attempt k meet on MASTER_PORT + 17 + k.
+LADDER = [("operands+graph", []), ("gradients+graph", ["--exchange", "gradients"]),
+          ("gradients+eager", ["--exchange", "gradients", "--no-graph"])]
+
+
+def supervise(args) -> int:
+    import signal
+    rank = int(os.environ.get("RANK", "0"))
+    base_port = int(os.environ.get("MASTER_PORT", "29581"))
+    ladder = [r for r in LADDER if not (args.exchange == "gradients" and r[0].startswith("operands"))]
+    if args.no_graph:
+        ladder = ladder[-1:]
+    argv = [a for a in sys.argv[1:]]
+    reason = ""
+    for k, (name, extra) in enumerate(ladder):
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("MASTER_ADDR", "127.0.0.1")
+        env.setdefault("RANK", "0")
+        env.setdefault("LOCAL_RANK", env["RANK"])
+        env.setdefault("WORLD_SIZE", "1")
+        for key in [key for key in env if key.startswith("TORCHELASTIC_")]:
+            del env[key]                                    # the workers host their own store (not the launcher agent's)
+        env.update({"CGV_BENCH_WORKER": "1", "CGV_BENCH_ATTEMPT": str(k), "CGV_BENCH_RUNG": name, "CGV_BENCH_REASON": reason,
+                    "MASTER_PORT": str(base_port + 17 + k)})
+        cmd = [sys.executable, os.path.abspath(__file__), *argv, *extra, "--no-supervisor"]
+        t0 = time.time()
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, start_new_session=True)
+        deadline = args.attempt_timeout
+        if os.environ.get("CGV_BENCH_TEST_HANG_ATTEMPT") == str(k) and os.environ.get("CGV_BENCH_TEST_HANG_TIMEOUT"):
+            deadline = float(os.environ["CGV_BENCH_TEST_HANG_TIMEOUT"])       # (rehearsal of the kill path only)
+        try:
+            out, _ = proc.communicate(timeout=deadline)
+            rc, why = proc.returncode, ""
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)             # the worker's own process group: nothing else matches
+            except ProcessLookupError:
+                pass
+            out, _ = proc.communicate()
+            rc, why = -9, f"timeout after {deadline:.0f} s"
+        lines = [ln for ln in (out or b"").decode(errors="replace").splitlines() if ln.startswith("{") and ln.rstrip().endswith("}")]
+        ok = rc == 0 and (rank != 0 or len(lines) == 1)
+        print(f"[bench] rank {rank} attempt {k} ({name}): rc {rc} {why} in {time.time() - t0:.0f} s", file=sys.stderr)
+        if ok:
+            if rank == 0:
+                sys.stdout.write(lines[0] + "\n")
+                sys.stdout.flush()
+            return 0
+        reason = f"attempt {k} ({name}): " + (why or f"exit code {rc}" + ("" if len(lines) <= 1 else f", {len(lines)} JSON lines"))
+    print(f"[bench] rank {rank}: every rung of the ladder failed ({reason})", file=sys.stderr)
+    return 1
 
 
 def parse_tag(tag: str):
@@ -332,6 +395,15 @@ def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args.gpus))
+    if not args.no_supervisor and (int(os.environ.get("WORLD_SIZE", "1")) > 1 or args.force_dist):
+        sys.exit(supervise(args))                   # (this process never imports torch / touches the GPU)
+
+    # rehearsal hooks of the ladder (tests/test_bench_ladder.py): a worker of the named rung fails / hangs before it
+    # touches the GPU
+    if os.environ.get("CGV_BENCH_WORKER") and os.environ.get("CGV_BENCH_ATTEMPT") == os.environ.get("CGV_BENCH_TEST_FAIL_ATTEMPT", "x"):
+        sys.exit(3)
+    if os.environ.get("CGV_BENCH_WORKER") and os.environ.get("CGV_BENCH_ATTEMPT") == os.environ.get("CGV_BENCH_TEST_HANG_ATTEMPT", "x"):
+        time.sleep(3600)
 
     import torch
     import coarsegrainingvae_amd as cg
@@ -415,14 +487,11 @@ def main():
     try:
         ksum = first_steps(model, trainer)
     except Exception as exc:
-        # every rank runs the same code on equally shaped shards, so a failure of the operand exchange hits all of
-        # them at the same point: measure with the plain gradient all-reduce rather than lose the run
-        if not multi or args.exchange == "gradients":
-            raise
-        print(f"[bench] operand exchange failed on rank {rank}: {exc!r}; falling back to --exchange gradients", file=sys.stderr)
-        torch.cuda.synchronize()
-        model, trainer = build("gradients")
-        ksum = first_steps(model, trainer)
+        # multi-rank: NO one-sided fallback inside the process -- the peers may already sit in a collective this rank will
+        # never issue, and an agreement collective could not be reached either.  The worker fails; the supervisors of all
+        # ranks then start the next rung of the ladder (gradients + graph) in fresh processes.
+        print(f"[bench] first steps failed on rank {rank}: {exc!r}", file=sys.stderr)
+        raise
 
     def barrier():
         if dist is not None:
@@ -464,7 +533,13 @@ def main():
         step_rot = lambda i: trainer.step(rotation[i % n_rot])
     for i in range(args.warmup):
         step_rot(i)
-    secs = timed_loop(step_rot, args.steps, args.reps, barrier, dist, dev)
+    host_enqueue = []
+
+    def step_clocked(i):                             # host time of one step() call: what the CPU spends enqueueing a replay
+        t0 = time.perf_counter()
+        step_rot(i)
+        host_enqueue.append(time.perf_counter() - t0)
+    secs = timed_loop(step_clocked, args.steps, args.reps, barrier, dist, dev)
     trainer.flush()                                  # the update of the last timed step (the first one applied a pre-timed one)
     rot_replayed = trainer.replays - replays0
     # what the data-parallel step moved, read NOW: the side measurements below capture other flavours of the step (a
@@ -482,6 +557,17 @@ def main():
                    "allreduced_bytes": left + early, "allreduced_early_bytes": early}
     med = statistics.median(secs)
     ms = 1e3 * med / args.steps
+    dist_info = None
+    if dist is not None:
+        # what the ranks saw: every rank contributes a 1 (the sum is the number of RCCL ranks that really took part), its own
+        # median step time (un-reduced: timed_loop reports the max over ranks) and its host enqueue time per step
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        mine = torch.tensor([statistics.median(host_enqueue) * 1e6 if host_enqueue else 0.0], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        dist_info = {"rccl_ranks_seen": int(round(float(ones.item()))),
+                     "host_enqueue_us_per_step_by_rank": [round(float(t.item()), 1) for t in every]}
     value = world * frames * args.steps / med
     loss_end = float(trainer.last_loss)
 
@@ -645,6 +731,13 @@ def main():
         line.update(side)
         if dp_info:
             line["data_parallel"] = dp_info
+        if host_enqueue:
+            line["host_enqueue_us_per_step"] = round(statistics.median(host_enqueue) * 1e6, 1)
+        if multi:
+            line["attempt"] = int(os.environ.get("CGV_BENCH_ATTEMPT", "0"))
+            line["rung"] = os.environ.get("CGV_BENCH_RUNG", "unsupervised")
+            line["fallback_reason"] = os.environ.get("CGV_BENCH_REASON", "") or None
+            line.update(dist_info or {})
         if cpu:
             line["speedup_vs_cpu_baseline"] = value / cpu["value"]
         line.update(extra)
