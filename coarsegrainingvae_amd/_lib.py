@@ -108,6 +108,8 @@ PROTOTYPES = {
     "cgv_decoder_debug_clock": (_i, [_p]),
     "cgv_decoder_msg_fwd": (_i, [_p] * 18 + [_i, _i, _i, _i, _p]),
     "cgv_decoder_dense_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "cgv_prior_msg_fwd": (_i, [_p] * 13 + [_i, _i, _i, _i, _i, _p]),
+    "cgv_prior_msg_bwd": (_i, [_p] * 8 + [_i, C.c_int64] + [_p] * 6 + [C.c_int64, _i, _i, _i, _i, _p]),
     "cgv_decoder_uv_fwd": (_i, [_p, _p, _p, _p, _i, _i, _p]),
     "cgv_decoder_gate_fwd": (_i, [_p] * 9 + [_i, _i, _p]),
     "cgv_decoder_gate_bwd": (_i, [_p, _p, _p, _p, _i, C.c_int64, _p, _p, _p, _p, _p, _p, C.c_int64, _i, _i, _p]),

@@ -2,7 +2,8 @@
 signatures and parameter names (CoarseGrainingVAE/conv.py), running on the fused HIP kernels.
 
 Per block the reference launches ~40 ATen kernels over materialised ``[E,3F]`` / ``[E,F,3]``
-tensors; here a block is: two node-level GEMMs (hipBLASLt through ``F.linear``) + ONE fused
+tensors; here a block is: two node-level products on the hand-written exact-fp32 MFMA kernels
+(csrc/skinny_gemm.hip, tile_gemm.hip -- no library GEMM, primitives._gemm_mode) + ONE fused
 edge kernel (gather -> filter -> product -> segmented reduction).  The ``plan`` / ``geom``
 keyword arguments let the model build the CSR views and edge geometry once per batch and
 share them across layers; without them the blocks build them on the fly, so the reference

@@ -1184,6 +1184,198 @@ __global__ __launch_bounds__(DL_THREADS) void dec_quad_to_dense_k(const float* _
   }
 }
 
+// ============================================================================================== prior / small-graph EquiMessageBlock
+// The same channel-group scheme for an EquiMessageBlock layer on a small bead graph (CGprior.forward, cgvae.py:391-392:
+// h += ds, v += dv with (ds, dv) = EquiMessageBlock(h, v), conv.py:505-563) -- 12 nodes / 60 edges on chignolin, where the
+// per-block path spends 3 + 5 launches per layer on six dependent round trips each:
+//   forward   P1  a1 = swish(h W1^T + b1)                                    (dec_dense_fwd_k)
+//             P2  phi = a1 W2^T + b2 (3 x CB rows) -> message on the block's channels -> h' = h + ds, v' = v + dv
+//   backward  Q1  g_h' = sum of the slices from the layer above (+ base) ; the SCALAR path of the message backward (the
+//                 vector channel of the prior / encoder never reaches an output, cgvae.py:393-396: no gradient arrives for
+//                 v', so g_q0 = g_q2 = 0 and g_v = 0) ; slice = g_phi1 W2[F + rows]
+//             Q2  g_a1 = sum of Q1's slices ; slice = (g_a1 swish'(z1)) W1[rows]          (dec_dense_bwd_k)
+// Filter slices: q0 = phi[:, f] (v_j term), q1 = phi[:, F + f] (ds), q2 = phi[:, 2F + f] (unit term).
+template <int R>
+__global__ __launch_bounds__(DL_THREADS) void prior_msg_fwd_k(
+    const float* __restrict__ a1, const float* __restrict__ W2, const float* __restrict__ b2, const float* __restrict__ s_,
+    const float* __restrict__ v_, const float* __restrict__ geom_, const int* __restrict__ rowptr_, const int* __restrict__ src_,
+    const float* __restrict__ Wd_, const float* __restrict__ bd_, float* __restrict__ phi_out, float* __restrict__ s_out,
+    float* __restrict__ v_out, int n, int F, int E, int with_dv) {
+  constexpr int GS = geom_stride(R), U = geom_unit_offset(R);
+  Carve cv;
+  float* red = cv.take(fwd_red_floats<1, 3>());
+  float* phi_l = cv.take(16 * 3 * 4);
+  float* red2 = cv.take(2 * 3 * 64);
+  float* geom_l = cv.take((size_t)DL_MAX_EDGES * GS);
+  int* rp_l = reinterpret_cast<int*>(cv.take(20));
+  int* src_l = reinterpret_cast<int*>(cv.take(DL_MAX_EDGES));
+  float* s_l = cv.take(64);
+  float* v_l = cv.take(192);
+  const int f0 = blockIdx.x * DL_CB;
+  const int lane = threadIdx.x & 63;
+  const int k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int kf = k < 3 ? k : 0;                                          // waves 3..8 only take part in the product
+  const int i = lane >> 2, c = lane & 3;
+  const bool live = i < n;
+  const int f = f0 + c;
+  const int row0[3] = {f0, F + f0, 2 * F + f0};
+  const gcf geom = launder(geom_); const gci rowptr = launder(rowptr_); const gci src = launder(src_);
+  const gcf s = launder(s_); const gcf v = launder(v_); const gcf Wd = launder(Wd_); const gcf bd = launder(bd_);
+  Slots4<geom_slots(R)> r_geom;
+  copy4_issue(r_geom, geom, E * GS / 4);
+  const int r_rp = int_issue(rowptr, n + 1), r_src = int_issue(src, E);
+  const float4 r_s = scalar_issue(s, s, n, F, f0);
+  const float4 r_v = vector_issue(v, v, n, F, f0);
+  float W[R + 1];
+#pragma unroll
+  for (int nn = 0; nn < R; ++nn) W[nn] = ldg_pinned(Wd + ((size_t)kf * F + f) * R + nn);
+  W[R] = ldg_pinned(bd + (size_t)kf * F + f);
+  pin_loads();
+  auto commit = [&]() {
+    copy4_commit(r_geom, geom_l, E * GS / 4);
+    int_commit(r_rp, rp_l, n + 1); int_commit(r_src, src_l, E);
+    scalar_commit(r_s, true, s_l, n);
+    vector_commit(r_v, true, v_l, n);
+  };
+  fwd_core<1, 3, 5>(phi_l, red, a1, n, F, W2, row0, commit);
+  for (int o = threadIdx.x; o < 16 * 3; o += DL_THREADS) {
+    const int m = o / 3, g = o - m * 3;
+    float4 p = *reinterpret_cast<float4*>(phi_l + (m * 3 + g) * 4);
+    const float4 b = *reinterpret_cast<const float4*>(b2 + (size_t)g * F + f0);
+    p.x += b.x; p.y += b.y; p.z += b.z; p.w += b.w;
+    *reinterpret_cast<float4*>(phi_l + (m * 3 + g) * 4) = p;
+    if (m < n) *reinterpret_cast<float4*>(phi_out + (size_t)m * 3 * F + (size_t)g * F + f0) = p;
+  }
+  __syncthreads();
+  // EquiMessageBlock, wave k = filter k (k < 3), lane = (receiver i, channel c); edges in the plan's order (equi_msg.hip)
+  float as = 0.f;
+  dv3 acc{0.f, 0.f, 0.f};
+  if (k < 3 && (k == 1 || with_dv)) {
+    const int e_beg = live ? rp_l[i] : 0, e_end = live ? min(rp_l[i + 1], E) : 0;
+    for (int e = e_beg; e < e_end; ++e) {
+      const int j = src_l[e];
+      const float* __restrict__ g = geom_l + (size_t)e * GS;
+      const float q = phi_l[(j * 3 + k) * 4 + c] * dfilt<R>(W, g);
+      if (k == 1) as += q;
+      else if (k == 2) daxpy(acc, q, dv3{g[U], g[U + 1], g[U + 2]});
+      else daxpy(acc, q, lds_v3(v_l + (j * 4 + c) * 3));
+    }
+  }
+  if (k == 0 || k == 2) {
+    float* r = red2 + (size_t)(k >> 1) * 3 * 64 + lane;
+    r[0] = acc.x; r[64] = acc.y; r[128] = acc.z;
+  }
+  __syncthreads();
+  if (k != 1 || !live) return;
+  const size_t nf = (size_t)i * F + f;
+  s_out[nf] = s_l[i * 4 + c] + as;
+  const dv3 v_i = lds_v3(v_l + (i * 4 + c) * 3);
+  // dv = (unit term: wave 2) + (v_j term: wave 0), the order of equi_msg.hip's per-edge sum is NOT reproduced (two partial
+  // sums over the same edges instead of one interleaved sum: rounding-level difference)
+  st3(v_out + nf * 3, v_i.x + (red2[3 * 64 + lane] + red2[lane]), v_i.y + (red2[4 * 64 + lane] + red2[64 + lane]),
+      v_i.z + (red2[5 * 64 + lane] + red2[128 + lane]));
+}
+
+template <int R, int QS>
+__global__ __launch_bounds__(DL_THREADS) void prior_msg_bwd_k(
+    const float* __restrict__ phi_, const float* __restrict__ geom_s_, const int* __restrict__ rowptr_s_,
+    const int* __restrict__ dst_s_, const float* __restrict__ Wd_, const float* __restrict__ bd_,
+    const float* __restrict__ gh_base_, const float* __restrict__ gh_slices_, int gh_n, long long gh_stride,
+    const float* __restrict__ W2_, float* __restrict__ g_phi, float* __restrict__ g_h, float* __restrict__ gWd,
+    float* __restrict__ gbd, float* __restrict__ slices_out, long long out_stride, int n, int F, int E) {
+  constexpr int GS = geom_stride(R);
+  Carve cv;
+  float* stage = cv.take(bi_stage_floats<1>());
+  float4* scratch = reinterpret_cast<float4*>(stage);                    // the slice sum is over before the product stages its tiles
+  float4* sum_l = reinterpret_cast<float4*>(cv.take(16 * 4));
+  float* gphi_l = cv.take(16 * 4);
+  float* gh_l = cv.take(64);
+  float* p1_l = cv.take(64);
+  float* geoms_l = cv.take((size_t)DL_MAX_EDGES * GS);
+  int* rps_l = reinterpret_cast<int*>(cv.take(20));
+  int* dsts_l = reinterpret_cast<int*>(cv.take(DL_MAX_EDGES));
+  const int f0 = blockIdx.x * DL_CB;
+  const int row0[1] = {F + f0};
+  const gcf geom_s = launder(geom_s_); const gci rowptr_s = launder(rowptr_s_); const gci dst_s = launder(dst_s_);
+  const gcf phi = launder(phi_); const gcf Wd = launder(Wd_); const gcf bd = launder(bd_);
+  const gcf gh_base = launder(gh_base_); const gcf gh_slices = launder(gh_slices_); const gcf W2 = launder(W2_);
+  const int lane = threadIdx.x & 63;
+  const int k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int node = lane >> 2, c = lane & 3, f = f0 + c;
+  const bool live = node < n;
+  Slots4<geom_slots(R)> r_gs;
+  copy4_issue(r_gs, geom_s, E * GS / 4);
+  const int r_rps = int_issue(rowptr_s, n + 1), r_dsts = int_issue(dst_s, E);
+  const float4 r_p1 = ldg4_pinned(phi + (size_t)min((int)threadIdx.x, n - 1) * 3 * F + F + f0);
+  const float4 r_base = ldg4_pinned((gh_base ? gh_base : phi) + (size_t)min((int)threadIdx.x, n - 1) * (gh_base ? F : 3 * F) + f0);
+  float W[R + 1], G[R + 1];
+#pragma unroll
+  for (int nn = 0; nn < R; ++nn) W[nn] = ldg_pinned(Wd + ((size_t)F + f) * R + nn);
+  W[R] = ldg_pinned(bd + (size_t)F + f);
+#pragma unroll
+  for (int nn = 0; nn <= R; ++nn) G[nn] = 0.f;
+  QuadRegs<1, 1, QS> qr;
+  { const int kq[1] = {(int)blockIdx.x}; quad_issue<1, 1>(qr, gh_slices ? gh_slices : phi, gh_slices ? gh_n : 0, gh_stride, n, kq); }
+  BiRegs<1, 2> wr;
+  bi_prefetch<1, 2>(wr, W2, F, row0);
+  pin_loads();
+  copy4_commit(r_gs, geoms_l, E * GS / 4);
+  int_commit(r_rps, rps_l, n + 1); int_commit(r_dsts, dsts_l, E);
+  if ((int)threadIdx.x < n) reinterpret_cast<float4*>(p1_l)[threadIdx.x] = r_p1;
+  quad_finish<1, 1>(qr, sum_l, scratch, gh_slices ? gh_n : 0, n);        // (no slices: the tile comes out zero)
+  if ((int)threadIdx.x < n) {
+    float4 t = sum_l[threadIdx.x];
+    if (gh_base) { t.x += r_base.x; t.y += r_base.y; t.z += r_base.z; t.w += r_base.w; }
+    reinterpret_cast<float4*>(gh_l)[threadIdx.x] = t;
+    // h' = h + ds: the gradient of h' reaches h directly too (the residual); dense, for the layer below
+    *reinterpret_cast<float4*>(g_h + (size_t)threadIdx.x * F + f0) = t;
+  }
+  __syncthreads();
+  // scalar path of the message backward, the lane's node as SOURCE j (edges of the source-sorted view): g_q1 = g_h'[i]
+  if (k == 0) {
+    float a = 0.f;
+    const float p_j = live ? p1_l[node * 4 + c] : 0.f;
+    const int e_beg = live ? rps_l[node] : 0, e_end = live ? min(rps_l[node + 1], E) : 0;
+    for (int e = e_beg; e < e_end; ++e) {
+      const float* __restrict__ g = geoms_l + (size_t)e * GS;
+      const float gq = gh_l[dsts_l[e] * 4 + c];
+      a = fmaf(gq, dfilt<R>(W, g), a);
+      const float t = gq * p_j;
+#pragma unroll
+      for (int nn = 0; nn <= R; ++nn) G[nn] = fmaf(t, g[nn], G[nn]);
+    }
+    gphi_l[node * 4 + c] = live ? a : 0.f;
+#pragma unroll
+    for (int nn = 0; nn <= R; ++nn) {
+      float x = G[nn];
+      x += __shfl_xor(x, 4); x += __shfl_xor(x, 8); x += __shfl_xor(x, 16); x += __shfl_xor(x, 32);
+      G[nn] = x;
+    }
+    if (lane < 4) {
+#pragma unroll
+      for (int nn = 0; nn < R; ++nn) gWd[((size_t)F + f) * R + nn] = G[nn];
+      gbd[(size_t)F + f] = G[R];
+    }
+  } else if (k == 1 || k == 2) {
+    // the dead filter slices (q0, q2: no gradient reaches the vector channel) get explicit zeros: these parameters'
+    // arena slices are written, not accumulated
+    const int kk = k == 1 ? 0 : 2;
+    if (lane < 4) {
+#pragma unroll
+      for (int nn = 0; nn < R; ++nn) gWd[((size_t)kk * F + f) * R + nn] = 0.f;
+      gbd[(size_t)kk * F + f] = 0.f;
+    }
+  }
+  __syncthreads();
+  // g_phi: dense copy for the weight-gradient launch (zeros in the dead slices)
+  for (int o = threadIdx.x; o < n * 3; o += DL_THREADS) {
+    const int m = o / 3, g = o - m * 3;
+    const float4 val = g == 1 ? *reinterpret_cast<const float4*>(gphi_l + m * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(g_phi + (size_t)m * 3 * F + (size_t)g * F + f0) = val;
+  }
+  bi_core<1, 1, 2>(wr, gphi_l, stage, slices_out + (size_t)blockIdx.x * out_stride, F, n);
+}
+
 }  // namespace cgv
 
 namespace cgv {
@@ -1258,6 +1450,43 @@ int cgv_decoder_msg_fwd(const float* a1, const float* W2, const float* b2, const
     }
   });
   return cgv::check_launch("cgv_decoder_msg_fwd");
+}
+
+int cgv_prior_msg_fwd(const float* a1, const float* W2, const float* b2, const float* s, const float* v, const float* geom_d,
+                      const int32_t* rowptr_d, const int32_t* src_d, const float* Wd, const float* bd, float* phi, float* s_out,
+                      float* v_out, int n_nodes, int n_feat, int n_rbf, int n_edges, int with_dv, void* stream) {
+  CGV_REQUIRE(a1 && W2 && b2 && s && v && geom_d && rowptr_d && src_d && Wd && bd && phi && s_out && v_out, "null pointer");
+  CGV_REQUIRE(n_edges >= 1 && n_edges <= cgv::DL_MAX_EDGES, "the staged bead graph holds 1..cgv_decoder_max_edges() edges");
+  CGV_DL_CHECK();
+  const size_t lds = cgv::lds_bytes(cgv::fwd_red_floats<1, 3>() + 192 + 384 + (size_t)cgv::DL_MAX_EDGES * cgv::geom_stride(n_rbf) + 20 +
+                                    cgv::DL_MAX_EDGES + 64 + 192);
+  CGV_DISPATCH_RBF(n_rbf, {
+    if (int rc = cgv::allow_lds(cgv::prior_msg_fwd_k<RBF>, lds)) return rc;
+    hipLaunchKernelGGL((cgv::prior_msg_fwd_k<RBF>), dim3(blocks), dim3(cgv::DL_THREADS), lds, st, a1, W2, b2, s, v, geom_d, rowptr_d,
+                       src_d, Wd, bd, phi, s_out, v_out, n_nodes, n_feat, n_edges, with_dv);
+  });
+  return cgv::check_launch("cgv_prior_msg_fwd");
+}
+
+int cgv_prior_msg_bwd(const float* phi, const float* geom_s, const int32_t* rowptr_s, const int32_t* dst_s, const float* Wd,
+                      const float* bd, const float* gh_base, const float* gh_slices, int gh_n_slices, int64_t gh_slice_floats,
+                      const float* W2, float* g_phi, float* g_h, float* gWd, float* gbd, float* slices_out,
+                      int64_t out_slice_floats, int n_nodes, int n_feat, int n_rbf, int n_edges, void* stream) {
+  CGV_REQUIRE(phi && geom_s && rowptr_s && dst_s && Wd && bd && W2 && g_phi && g_h && gWd && gbd && slices_out, "null pointer");
+  CGV_REQUIRE((gh_base || gh_slices) && (gh_slices ? gh_n_slices >= 1 && gh_n_slices <= 216 : true), "the upstream gradient: base and / or 1 .. 216 slices");
+  CGV_REQUIRE(n_edges >= 1 && n_edges <= cgv::DL_MAX_EDGES, "the staged bead graph holds 1..cgv_decoder_max_edges() edges");
+  CGV_DL_CHECK();
+  const size_t lds = cgv::lds_bytes(cgv::bi_stage_floats<1>() + 64 + 64 + 64 + 64 + (size_t)cgv::DL_MAX_EDGES * cgv::geom_stride(n_rbf) +
+                                    20 + cgv::DL_MAX_EDGES);
+  CGV_DISPATCH_RBF(n_rbf, {
+    CGV_DL_QS(gh_slices ? gh_n_slices : 1, {
+      if (int rc = cgv::allow_lds(cgv::prior_msg_bwd_k<RBF, QS>, lds)) return rc;
+      hipLaunchKernelGGL((cgv::prior_msg_bwd_k<RBF, QS>), dim3(blocks), dim3(cgv::DL_THREADS), lds, st, phi, geom_s, rowptr_s, dst_s,
+                         Wd, bd, gh_base, gh_slices, gh_n_slices, (long long)gh_slice_floats, W2, g_phi, g_h, gWd, gbd, slices_out,
+                         (long long)out_slice_floats, n_nodes, n_feat, n_edges);
+    });
+  });
+  return cgv::check_launch("cgv_prior_msg_bwd");
 }
 
 int cgv_decoder_dense_fwd(const float* x, const float* W, const float* bias, float* y, float* z, int n_nodes, int N, int K,

@@ -218,6 +218,7 @@ class CGprior(nn.Module):
         self.sigma = MLPHead(Linear(F, F), nn.Tanh(), Linear(F, F))
         self.n_conv, self.dir_mp = n_conv, dir_mp
         self.n_rbf, self.cutoff = n_rbf, cutoff
+        self.fused_loop = True          # prior_fused: one autograd node for the message-block loop when shapes / parameters allow
 
     def set_skip_dead_vector_channel(self, flag: bool):
         for blk in self.message_blocks:
@@ -239,6 +240,11 @@ class CGprior(nn.Module):
         """The bead state after the message blocks (cgvae.py:381-396): what the mu / sigma heads are applied to."""
         h = ops.embedding(self.atom_embed, cg_z, graph.embed_plan("cg", cg_z, self.atom_embed) if graph is not None else None)
         v = _constant((h.shape[0], h.shape[1], 3), 0.0, h.device)
+        if self.fused_loop and h.is_cuda:
+            from . import prior_fused
+            if prior_fused.usable(self, h, plan, geom):
+                # small bead graph: the loop as one autograd node on the channel-group kernels (2 + 2 launches per layer)
+                return prior_fused.prior_loop(self, h, v, plan, geom, with_dv=all(b.with_dv for b in self.message_blocks))
         for blk in self.message_blocks:
             h, v = blk(h, v, None, nbrs, plan=plan, geom=geom, residual=True)      # h += ds, v += dv fused (cgvae.py:391-392)
         return h

@@ -320,6 +320,7 @@ def materialise_reconstruct(xyz_recon):
     _lib.call("cgv_reconstruct_fwd", _lib.ptr(slot.v), _lib.ptr(slot.cg_xyz), _lib.ptr(plan.rowptr_d), _lib.ptr(plan.eid_d),
               _lib.ptr(slot.chan), slot.v.shape[0], slot.v.shape[1], int(slot.offset), _lib.ptr(slot.out), _lib.stream_ptr())
     slot.filled = True
+    slot.v = slot.cg_xyz = slot.chan = slot.plan = slot.out = None       # (no reference cycle through the carrying tensor)
     return xyz_recon
 
 
@@ -642,6 +643,10 @@ class _Elbo(torch.autograd.Function):
                       int(tail.offset), float(beta), float(gamma), _lib.ptr(xr), _lib.ptr(out), _lib.ptr(loss),
                       *[_lib.ptr(g) for g in grads], _lib.ptr(g_V), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
             tail.g_V, tail.filled = g_V, True
+            # the tail's inputs are spent: drop them NOW -- slot.out is the very tensor that carries the slot (a reference
+            # cycle through a tensor with a grad_fn would keep this step's autograd graph alive until the cyclic collector
+            # runs; a graph retained across steps pins its nodes to this stream and a later capture dies in EndCapture)
+            tail.v = tail.cg_xyz = tail.chan = tail.plan = tail.out = None
             ctx.tail = tail
         else:
             ctx.tail = None

@@ -46,12 +46,16 @@ def to_module(activation: str) -> nn.Module:
 def _gemm_mode(x2, weight, bias):
     """Which kernels a Dense / Linear product runs on:
     "skinny"  M <= 64 rows (bead level): weight-streaming HIP kernels, csrc/skinny_gemm.hip;
-    "tile"    more rows (atom level, or big bead batches): reduction-split MFMA tiles, csrc/tile_gemm.hip;
-    "library" shapes neither takes (widths not a multiple of 4, unaligned views) or CPU tensors: torch ops."""
-    if not (x2.is_cuda and x2.dtype == torch.float32 and weight.dtype == torch.float32):
-        return "library"
+    "tile"    more rows (atom level, or big bead batches): reduction-split MFMA tiles, csrc/tile_gemm.hip.
+    There is no third way: CPU tensors, other dtypes and widths the kernels do not take (not a multiple of 4) RAISE --
+    no product runs on a library GEMM or on torch ops."""
+    if not (x2.is_cuda and weight.is_cuda):
+        raise RuntimeError("Dense / Linear run on the HIP kernels only: move the module and its input to the device "
+                           "(there is no CPU / library fallback)")
+    if x2.dtype != torch.float32 or weight.dtype != torch.float32:
+        raise RuntimeError("the HIP path computes in fp32 only")
     if not (weight.is_contiguous() and weight.data_ptr() % 16 == 0):
-        return "library"
+        raise RuntimeError("Dense / Linear: the weight must be contiguous and 16-byte aligned")
     M, K = x2.shape
     N = weight.shape[0]
     lib = _lib.load()
@@ -59,7 +63,8 @@ def _gemm_mode(x2, weight, bias):
         return "skinny"
     if M > 0 and lib.cgv_tile_supported(M, N, K):
         return "tile"
-    return "library"
+    raise RuntimeError(f"Dense / Linear {M} x {N} x {K}: the HIP kernels need in / out widths that are multiples of 4 "
+                       f"(e.g. -n_basis 600); no library GEMM stands in for other widths")
 
 
 ACT_NONE, ACT_SWISH, ACT_TANH, ACT_RELU = 0, 1, 2, 3      # cgv_common.h: act_fwd / act_bwd
@@ -324,42 +329,28 @@ class _LinearFn(torch.autograd.Function):
         ctx.act = act
         ctx.mode = mode = _gemm_mode(x2, weight, bias)
         N = weight.shape[0]
-        if mode != "library":
-            x2 = x2.contiguous()
-            if x2.data_ptr() % 16:
-                x2 = x2.clone()
-            M, K = x2.shape
-            if mode == "tile" and act == ACT_NONE and _library_pays(M, N, K, forward=True):
-                # a plain product (bias in the library's epilogue) big enough for the library GEMM to win
-                y = Fn.linear(x2, weight, bias)
-                ctx.save_for_backward(x2, weight, None)
-                return y.reshape(x.shape[:-1] + (N,))
-            y = torch.empty(M, N, dtype=torch.float32, device=x.device)
-            z = torch.empty_like(y) if act else None
-            if mode == "skinny" and M <= 16 and N >= 64:
-                # few rows: 4-column blocks (N / 4 of them pull the weight) beat the skinny kernel's 16-column blocks
-                # (decoder forward 356 -> 343 us on chignolin: csrc/decoder_layer.hip, dec_dense_fwd_k)
-                _lib.call("cgv_decoder_dense_fwd", _lib.ptr(x2), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(y), _lib.ptr(z),
-                          M, N, K, act, _lib.stream_ptr())
-            else:
-                # 65 - 128 rows (a big bead batch) and at most 1200 outputs: the weight-streaming kernel with one 16-row block
-                # per thread block still beats the tiles (96 rows: 600 x 600 4.8 against 6.7 us, 600 x 1200 6.3 / 10.5,
-                # 1200 x 600 5.9 / 6.7; from 1800 outputs on the tiles win: tools/fwd_bench.py)
-                few_rows = mode == "tile" and M <= 128 and N <= 1200 and (bias is None or bias.data_ptr() % 16 == 0)
-                # 33 - 64 rows and a very wide layer (64 beads x 5400 outputs): the tiles win (11.7 against 14.2 us)
-                wide = mode == "skinny" and M > 32 and N >= 4096 and lib_tile_ok(M, N, K)
-                _lib.call("cgv_skinny_linear_fwd" if ((mode == "skinny" and not wide) or few_rows) else "cgv_tile_linear_fwd", _lib.ptr(x2),
-                          _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(y), _lib.ptr(z), M, N, K, act, _lib.stream_ptr())
-            ctx.save_for_backward(x2, weight, z)
-            return y.reshape(x.shape[:-1] + (N,))
-        z = Fn.linear(x, weight, bias)
-        if act != ACT_NONE:
-            ctx.save_for_backward(x, weight, z)
-            if act in _STD_EPS:
-                return _STD_EPS[act] + torch.exp(z / 2)
-            return {ACT_SWISH: Fn.silu, ACT_TANH: torch.tanh, ACT_RELU: torch.relu}[act](z)
-        ctx.save_for_backward(x, weight, None)
-        return z
+        x2 = x2.contiguous()
+        if x2.data_ptr() % 16:
+            x2 = x2.clone()
+        M, K = x2.shape
+        y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        z = torch.empty_like(y) if act else None
+        if mode == "skinny" and M <= 16 and N >= 64:
+            # few rows: 4-column blocks (N / 4 of them pull the weight) beat the skinny kernel's 16-column blocks
+            # (decoder forward 356 -> 343 us on chignolin: csrc/decoder_layer.hip, dec_dense_fwd_k)
+            _lib.call("cgv_decoder_dense_fwd", _lib.ptr(x2), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(y), _lib.ptr(z),
+                      M, N, K, act, _lib.stream_ptr())
+        else:
+            # 65 - 128 rows (a big bead batch) and at most 1200 outputs: the weight-streaming kernel with one 16-row block
+            # per thread block still beats the tiles (96 rows: 600 x 600 4.8 against 6.7 us, 600 x 1200 6.3 / 10.5,
+            # 1200 x 600 5.9 / 6.7; from 1800 outputs on the tiles win: tools/fwd_bench.py)
+            few_rows = mode == "tile" and M <= 128 and N <= 1200 and (bias is None or bias.data_ptr() % 16 == 0)
+            # 33 - 64 rows and a very wide layer (64 beads x 5400 outputs): the tiles win (11.7 against 14.2 us)
+            wide = mode == "skinny" and M > 32 and N >= 4096 and lib_tile_ok(M, N, K)
+            _lib.call("cgv_skinny_linear_fwd" if ((mode == "skinny" and not wide) or few_rows) else "cgv_tile_linear_fwd", _lib.ptr(x2),
+                      _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(y), _lib.ptr(z), M, N, K, act, _lib.stream_ptr())
+        ctx.save_for_backward(x2, weight, z)
+        return y.reshape(x.shape[:-1] + (N,))
 
     @staticmethod
     def backward(ctx, gy, g_alias=None):
@@ -398,21 +389,6 @@ class _LinearFn(torch.autograd.Function):
             return gx
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         need_b = b_param is not None and ctx.needs_input_grad[2]
-        if ctx.mode == "library":
-            if act == ACT_SWISH:
-                sg = torch.sigmoid(z)
-                gy = gy * (sg * (1 + z * (1 - sg)))
-            elif act == ACT_TANH:
-                gy = gy * (1 - torch.tanh(z) ** 2)
-            elif act == ACT_RELU:
-                gy = gy * (z > 0).to(gy.dtype)
-            elif act in _STD_EPS:
-                gy = gy * (0.5 * torch.exp(z / 2))
-            x2, gy2 = x.reshape(-1, x.shape[-1]), gy.reshape(-1, gy.shape[-1])
-            gx = gy.matmul(weight) if need_x else None
-            gw = _direct_grad(w_param, lambda out: torch.mm(gy2.t(), x2, out=out), lambda: gy2.t().mm(x2)) if need_w else None
-            gb = _direct_grad(b_param, lambda out: torch.sum(gy2, 0, out=out), lambda: gy2.sum(0)) if need_b else None
-            return finish(gx) if need_x else add, gw, gb, None
         gy2 = gy.reshape(-1, gy.shape[-1]).contiguous()
         M, K = x.shape
         N = weight.shape[0]
@@ -429,9 +405,7 @@ class _LinearFn(torch.autograd.Function):
                 # grouped weight-gradient launch, which also sums the bias (primitives.WeightGradQueue.launch)
                 if need_x:
                     gx = torch.empty(M, K, dtype=torch.float32, device=gy.device)
-                    if act == ACT_NONE and _library_pays(M, N, K, forward=False):
-                        torch.mm(gy2, weight, out=gx)        # plain product, big enough for the library GEMM to win
-                    elif M <= 128 and N >= 4096 and _lib.load().cgv_skinny_bwd_input_supported(M, N, K):
+                    if M <= 128 and N >= 4096 and _lib.load().cgv_skinny_bwd_input_supported(M, N, K):
                         # few rows, a very long reduction (96 bead rows x 5400 columns): the row-split kernel spreads the
                         # weight over ~300 blocks (28.5 us + reduce against 43.6 us; tools/bwd_input_bench.py)
                         fused[0] = skinny_bwd_input(gy2, z if act != ACT_NONE else None, weight, gx, M, N, K, act, add=add2)
@@ -742,15 +716,6 @@ def wgrad_tile(shapes) -> int:
     ``options.set("wgrad_tile", 128)`` with its parity test."""
     from .options import HOST
     return 128 if HOST["wgrad_tile"] == 128 else 64
-
-
-def _library_pays(M, N, K, forward: bool) -> bool:
-    """Never: every product of the path runs on the hand-written kernels.  (Round 2 sent plain products of >= 1024 rows
-    forward / >= 512 rows backward to the library GEMM -- hipBLASLt behind torch.  Re-measured with rotating operands,
-    tools/gemm_shapes.py: the tiles already win backward at 704 rows, 25 vs 35 us for 704 x 1800 x 600; forward the
-    three-slab ring kernel brings 2000 x 5400 x 600 to 137 us against 118-175 us; what the library still wins --
-    2000 x 1800 x 600: 44 vs 52 us forward, 40 vs 56 us backward -- is 0.05 ms of the 2000-atom step.)"""
-    return False
 
 
 def lib_has_rows(M, N, K) -> bool:

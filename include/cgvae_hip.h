@@ -379,6 +379,22 @@ int cgv_decoder_msg_fwd(const float* a1, const float* W2, const float* b2, const
                         const float* vbar, const float* geom_d, const int32_t* rowptr_d, const int32_t* src_d, const float* Wd,
                         const float* bd, float* phi, float* stack, float* sbar_out, float* v_out, float* vbar_out,
                         float* rows_out, int n_nodes, int n_feat, int n_rbf, int n_edges, void* stream);
+/* An EquiMessageBlock layer (conv.py:505-563 with the residual adds of CGprior.forward, cgvae.py:391-392: h += ds, v += dv)
+ * on a SMALL graph (<= 16 nodes, <= cgv_decoder_max_edges() edges: the prior's bead graph) in the channel-group scheme of the
+ * decoder layer: forward = cgv_decoder_dense_fwd (a1 = swish(h W1^T + b1)) + cgv_prior_msg_fwd (phi = a1 W2^T + b2 for the
+ * block's 3 x 4 rows, then the message on its channels: s_out = s + ds, v_out = v + dv; with_dv = 0 leaves v_out = v);
+ * backward = cgv_prior_msg_bwd + cgv_decoder_dense_bwd.  The backward is the SCALAR path only: it is for callers that never
+ * use v_out's gradient (the prior and the encoder discard the vector channel, cgvae.py:393-396), so g_q0 = g_q2 = 0 and
+ * the dead filter slices get explicit zero gradients.  The upstream gradient d loss / d s_out arrives as base (dense, or
+ * NULL) + quad-major slices (or NULL) like every slice consumer here; g_h = their sum (dense: the residual path), g_phi
+ * [n, 3F] dense for the weight-gradient launch, slices_out: n_feat / 4 slices of cgv_decoder_slice_floats(n_feat, n). */
+int cgv_prior_msg_fwd(const float* a1, const float* W2, const float* b2, const float* s, const float* v, const float* geom_d,
+                      const int32_t* rowptr_d, const int32_t* src_d, const float* Wd, const float* bd, float* phi, float* s_out,
+                      float* v_out, int n_nodes, int n_feat, int n_rbf, int n_edges, int with_dv, void* stream);
+int cgv_prior_msg_bwd(const float* phi, const float* geom_s, const int32_t* rowptr_s, const int32_t* dst_s, const float* Wd,
+                      const float* bd, const float* gh_base, const float* gh_slices, int gh_n_slices, int64_t gh_slice_floats,
+                      const float* W2, float* g_phi, float* g_h, float* gWd, float* gbd, float* slices_out,
+                      int64_t out_slice_floats, int n_nodes, int n_feat, int n_rbf, int n_edges, void* stream);
 /* y = act(x W^T + b) (z = pre-activation or NULL) for <= 16 rows, N / 4 blocks: the two full-width products of a layer */
 int cgv_decoder_dense_fwd(const float* x, const float* W /*[N,K]*/, const float* bias, float* y, float* z, int n_nodes, int N,
                           int K, int act, void* stream);

@@ -170,8 +170,37 @@ def invariant_message(s, dist, nbrs, P, prefix, act, n_rbf, cutoff) -> Tensor:
     return phi * w
 
 
+# Tests may set this (edges per chunk) to evaluate the atom-graph message block of a LARGE graph in edge chunks under
+# activation checkpointing: the block materialises ~10 tensors of [E, 3F] (6.1 GB each at 2000 atoms / 851 k edges /
+# F = 600) and autograd keeps them all; chunked, only one chunk's worth is alive at a time and backward recomputes it.
+# Same statements per edge (conv.py:505-563), the per-chunk scatter sums added chunk by chunk (a different summation
+# order only).  None (default): the block as the reference runs it.
+EDGE_CHUNK: Optional[int] = None
+
+
+def _equi_message_block_chunked(s, v, r_ij, nbrs, P, prefix, act, n_rbf, cutoff, chunk):
+    from torch.utils.checkpoint import checkpoint
+    n, F = s.shape[0], s.shape[-1]
+    phi = inv_dense(s, P, prefix + ".inv_message.inv_dense", act)     # node level: computed once (conv.py:69)
+
+    def part(phi_, v_, r_c, nb_c):
+        dist, unit = preprocess_r(r_c)
+        w = distance_embed(dist, P, prefix + ".inv_message.dist_embed", n_rbf, cutoff)
+        out = (phi_[nb_c[:, 1]] * w).reshape(-1, 3, F)
+        m0, m1, m2 = out[:, 0, :].unsqueeze(-1), out[:, 1, :], out[:, 2, :].unsqueeze(-1)
+        dv_ij = m2 * unit.unsqueeze(1) + m0 * v_[nb_c[:, 1]]
+        return scatter_add(m1 * 1, nb_c[:, 0], 0, n), scatter_add(dv_ij * 1, nb_c[:, 0], 0, n)
+    ds = dv = None
+    for lo in range(0, nbrs.shape[0], chunk):
+        a, b = checkpoint(part, phi, v, r_ij[lo:lo + chunk], nbrs[lo:lo + chunk], use_reentrant=False)
+        ds, dv = (a, b) if ds is None else (ds + a, dv + b)
+    return ds, dv
+
+
 def equi_message_block(s, v, r_ij, nbrs, P, prefix, act, n_rbf, cutoff):
     """conv.py:505-563 (EquiMessageBlock.forward, edge_wgt=None)."""
+    if EDGE_CHUNK and nbrs.shape[0] > EDGE_CHUNK:
+        return _equi_message_block_chunked(s, v, r_ij, nbrs, P, prefix, act, n_rbf, cutoff, int(EDGE_CHUNK))
     dist, unit = preprocess_r(r_ij)
     out = invariant_message(s, dist, nbrs, P, prefix + ".inv_message", act, n_rbf, cutoff)
     n, F = s.shape[0], s.shape[-1]

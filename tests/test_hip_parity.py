@@ -681,6 +681,13 @@ def _block_vs_oracle(F, R, n, nbrs, xyz, with_gv=True, seed=0, tol=REL):
     s0, v0 = s.clone().requires_grad_(True), v.clone().requires_grad_(True)
     ds0, dv0 = O.equi_message_block(s0, v0, r, nbrs, P, "b", O.swish, R, cutoff)
     ((ds0 * gs).sum() + ((dv0 * gv).sum() if with_gv else 0.0)).backward()
+    if F % 4:
+        # widths the Dense kernels do not take (they raise: no library fallback): the node MLP of THIS test runs on torch
+        # ops with the same parameters -- the subject here is the edge kernel's odd-width (scalar-access) instantiation
+        d0, d1 = blk.inv_message.inv_dense[0], blk.inv_message.inv_dense[1]
+        l0, l1 = torch.nn.Linear(F, F), torch.nn.Linear(F, 3 * F)
+        l0.weight, l0.bias, l1.weight, l1.bias = d0.weight, d0.bias, d1.weight, d1.bias
+        blk.inv_message.inv_dense = torch.nn.Sequential(l0, torch.nn.Sequential(torch.nn.SiLU(), l1))     # keys 0.* and 1.1.*
     blk = blk.to(DEV)
     s1, v1 = s.to(DEV).requires_grad_(True), v.to(DEV).requires_grad_(True)
     ds1, dv1 = blk(s1, v1, r.to(DEV), nbrs.to(DEV))
@@ -691,7 +698,7 @@ def _block_vs_oracle(F, R, n, nbrs, xyz, with_gv=True, seed=0, tol=REL):
     if with_gv and float(v0.grad.abs().max()) > 0:
         assert_close(v1.grad, v0.grad, "grad v", tol)
     for name, p in blk.named_parameters():
-        ref = P["b." + name].grad
+        ref = P["b." + name.replace("inv_dense.1.1.", "inv_dense.1.")].grad
         if ref is not None and float(ref.abs().max()) > 0:
             assert_close(p.grad, ref, "grad " + name, tol)
     return ds1, dv1
@@ -2128,3 +2135,67 @@ def test_tile_forward_one_register_tile_per_cu_vs_fp64(shape, options):
     assert torch.allclose(y.double(), yr, rtol=1e-5, atol=1e-5)
     if act:
         assert torch.allclose(z.double(), zr, rtol=1e-5, atol=1e-5)
+
+
+def test_dense_has_no_library_or_cpu_fallback():
+    """no product of the path runs on a library GEMM or on torch ops -- widths the kernels do not take and CPU
+    tensors raise (modules.py:103-114 is replaced, not shadowed)."""
+    odd = cg.Dense(30, 30, activation=cg.Swish()).to(DEV)
+    with pytest.raises(RuntimeError, match="multiples of 4"):
+        odd(torch.randn(12, 30, device=DEV))
+    with pytest.raises(RuntimeError, match="multiples of 4"):
+        cg.Dense(600, 30).to(DEV)(torch.randn(332, 600, device=DEV))
+    cpu = cg.Dense(32, 32, activation=cg.Swish())
+    with pytest.raises(RuntimeError, match="HIP kernels only"):
+        cpu(torch.randn(4, 32))
+    from coarsegrainingvae_amd.primitives import Linear
+    with pytest.raises(RuntimeError, match="HIP kernels only"):
+        Linear(32, 32)(torch.randn(4, 32))
+
+
+@pytest.mark.parametrize("n_beads,F,R,layers,with_dv", [(12, 600, 10, 2, True), (3, 64, 8, 3, True), (16, 48, 10, 1, True), (12, 128, 8, 2, False)])
+def test_fused_prior_loop_equals_per_block_path(n_beads, F, R, layers, with_dv, options):
+    """prior_fused (the prior's EquiMessageBlock loop, cgvae.py:381-396 / conv.py:505-563, as one autograd node on the
+    channel-group kernels) against the per-block path it replaces: the scalar state, the input gradient and every
+    parameter gradient -- incl. the explicit zeros of the two dead filter slices."""
+    from coarsegrainingvae_amd import prior_fused
+    from coarsegrainingvae_amd.model import CGprior
+    from coarsegrainingvae_amd.trainer import ParamArena
+    gen = torch.Generator().manual_seed(n_beads + F)
+    xyz = torch.rand(n_beads, 3, generator=gen) * 6.0
+    nbrs, _ = O.make_directed(O.get_neighbor_list(xyz, 25.0, True))
+    if nbrs.shape[0] == 0:
+        pytest.skip("no edges")
+    torch.manual_seed(5)
+    prior = CGprior(n_conv=layers, n_atom_basis=F, n_rbf=R, activation="swish", cutoff=9.5).to(DEV)
+    prior.set_skip_dead_vector_channel(not with_dv)
+    plan = EdgePlan.from_nbrs(nbrs.to(DEV), n_beads)
+    geom = EdgeGeometry(plan, R, 9.5, pos_dst=xyz.to(DEV), pos_src=xyz.to(DEV))
+    cg_z = torch.arange(n_beads).float().to(DEV) % 6
+    up = torch.randn(n_beads, F, generator=gen).to(DEV)
+    params = [p for blk in prior.message_blocks for p in blk.inv_message.parameters() if "dist_filter" not in ""]
+    live = [p for p in prior_fused.layer_params(prior)] + [prior.atom_embed.weight]
+
+    def run(fused):
+        options.set("fused_prior", int(fused))
+        calls0 = prior_fused.calls
+        h = prior.features(cg_z, nbrs.to(DEV), plan, geom)
+        assert (prior_fused.calls > calls0) == fused
+        (h * up).sum().backward()
+        return h.detach().clone(), [p.grad.clone() for p in live]
+    # first backward builds plain gradients; then an arena makes the parameters direct-write (the fused path's condition)
+    run(False)
+    arena = ParamArena(live)
+    arena.g.fill_(float("nan"))
+    arena.zero_grad()
+    h0, g0 = run(False)
+    arena.g.fill_(float("nan"))
+    arena.zero_grad()
+    h1, g1 = run(True)
+    assert_close(h1, h0, "prior state", 2e-6)
+    for k, (a, b) in enumerate(zip(g1, g0)):
+        assert bool(torch.isfinite(a).all()), f"parameter gradient {k} has unwritten entries"
+        if float(b.abs().max()) == 0.0:
+            assert float(a.abs().max()) == 0.0, f"parameter gradient {k} must be exactly zero"
+        else:
+            assert_close(a, b, f"prior parameter gradient {k}", 2e-5)

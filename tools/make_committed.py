@@ -112,7 +112,7 @@ for w in ("chignolin", "dipeptide", "protein2000"):
         k = max(ks, key=lambda k: fetch[k][0] * fetch[k][1])
         i = 2 if largest else 0
         return k, fetch[k][i], write.get(k, (0.0, 0, 0.0))[i]
-    rk = line and line.get("roofline", {}).get("kernel")
+    rk = "message_forward"                                # bench.py: roofline["pmc_key"]
     hit = pick(r"equi_msg_fwd_grp_k|equi_msg_fwd_k")
     if rk and hit:
         sym, f_kib, w_kib = hit
