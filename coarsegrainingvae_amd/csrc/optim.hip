@@ -38,6 +38,82 @@ __global__ __launch_bounds__(256) void sumsq_partial(const float* __restrict__ g
   if (threadIdx.x == 0) partial[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
 }
 
+// The decision pass proper (one block's worth of work), shared by the stand-alone launch and by the LAST block of
+// sumsq_decide_k.  ``partial`` may have been written by other XCDs in this same launch: read with agent scope there.
+template <bool AGENT>
+__device__ __forceinline__ void optim_decide(const float* __restrict__ partial, int nb, const double* __restrict__ extra, int n_extra,
+                                             float grad_scale, float max_norm, float beta1, float beta2,
+                                             const float* __restrict__ loss, float skip_threshold, float* __restrict__ state,
+                                             double* ws /*[4] LDS*/) {
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nb; i += blockDim.x)
+    acc += (double)(AGENT ? __hip_atomic_load(partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : partial[i]);
+  for (int i = threadIdx.x; i < n_extra; i += blockDim.x) acc += extra[i];     // ||gW||^2 of never-materialised gradients
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  const double total = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+  const float norm = (float)sqrt(total) * fabsf(grad_scale);
+  bool skip = false;
+  if (loss) {
+    const float l = *loss;
+    skip = (l >= skip_threshold) || (l != l);                 // utils.py:145
+  }
+  state[ST_NORM] = norm;
+  state[ST_SKIP] = skip ? 1.f : 0.f;
+  if (skip) {
+    state[ST_NSKIPPED] += 1.f;
+    return;
+  }
+  float coef = max_norm / (norm + 1e-6f);                      // torch.nn.utils.clip_grad_norm_
+  if (coef > 1.f) coef = 1.f;
+  state[ST_CLIP] = coef * grad_scale;
+  const double step = (double)state[ST_STEP] + 1.0;
+  state[ST_STEP] = (float)step;
+  state[ST_BC1] = (float)(1.0 - pow((double)beta1, step));
+  state[ST_BC2SQRT] = (float)sqrt(1.0 - pow((double)beta2, step));
+}
+
+// Norm pass AND decision in one launch: every block leaves its partial sum (write-through), the block that arrives last
+// at the ticket (device scope) runs the decision pass over all partials in block order -- the same sums in the same
+// order as sumsq_partial + optim_finalize, one launch boundary (~6 us of a 1.8 ms step) less.  ticket: one word, zero
+// before the first launch; the last block leaves it zero.
+__global__ __launch_bounds__(256) void sumsq_decide_k(const float* __restrict__ g, int64_t n, float* __restrict__ partial,
+                                                      unsigned int* __restrict__ ticket, const double* __restrict__ extra, int n_extra,
+                                                      float grad_scale, float max_norm, float beta1, float beta2,
+                                                      const float* __restrict__ loss, float skip_threshold, float* __restrict__ state) {
+  __shared__ float ws[4];
+  __shared__ double wd[4];
+  __shared__ unsigned int s_last;
+  float acc = 0.f;
+  const int64_t n4 = n >> 2;
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 x = g4[i];
+    acc = fmaf(x.x, x.x, fmaf(x.y, x.y, fmaf(x.z, x.z, fmaf(x.w, x.w, acc))));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    float x = g[(n4 << 2) + threadIdx.x];
+    acc = fmaf(x, x, acc);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(partial + blockIdx.x, (ws[0] + ws[1]) + (ws[2] + ws[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  optim_decide<true>(partial, (int)gridDim.x, extra, n_extra, grad_scale, max_norm, beta1, beta2, loss, skip_threshold, state, wd);
+  if (threadIdx.x == 0) *ticket = 0u;
+}
+
 __global__ __launch_bounds__(256) void optim_finalize(const float* __restrict__ partial, int nb,
                                                       const double* __restrict__ extra, int n_extra, float grad_scale,
                                                       float max_norm, float beta1, float beta2,
@@ -137,7 +213,7 @@ __global__ __launch_bounds__(256) void sgd_update(float* __restrict__ p, const f
 extern "C" {
 
 int cgv_optim_state_floats(void) { return 8; }
-int cgv_optim_partial_floats(void) { return 2048; }
+int cgv_optim_partial_floats(void) { return 2048 + 16; }      /* 2048 partial sums + the ticket word of the one-launch decision pass (ZERO it once) */
 
 static void launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                         float eps, const float* state, hipStream_t st) {
@@ -176,6 +252,14 @@ int cgv_optim_prepare_extra(const float* g, int64_t n, const double* extra, int 
   // 2048 blocks (= cgv_optim_partial_floats()) for a whole arena -- more measured slower; fewer for a short range
   const int64_t want = ((n >> 2) + 1023) / 1024;
   const int nb = (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+  if (cgv::option(CGV_OPT_OPTIM_ONE_LAUNCH) != 0) {
+    // the ticket word sits behind the 2048 partial sums (cgv_optim_partial_floats() = 2048 + 16; the caller zeroes the
+    // buffer once, every launch leaves the word zero)
+    unsigned int* ticket = reinterpret_cast<unsigned int*>(partial + 2048);
+    hipLaunchKernelGGL(cgv::sumsq_decide_k, dim3(nb), dim3(256), 0, st, g, n, partial, ticket, extra, n_extra, grad_scale, max_norm,
+                       beta1, beta2, loss, skip_threshold, state);
+    return cgv::check_launch("cgv_optim_prepare");
+  }
   hipLaunchKernelGGL(cgv::sumsq_partial, dim3(nb), dim3(256), 0, st, g, n, partial);
   hipLaunchKernelGGL(cgv::optim_finalize, dim3(1), dim3(256), 0, st, partial, nb, extra, n_extra, grad_scale, max_norm,
                      beta1, beta2, loss, skip_threshold, state);

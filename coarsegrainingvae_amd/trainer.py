@@ -585,7 +585,7 @@ class Trainer:
             else:
                 self.m = self.v = None                       # plain SGD keeps no state
             self.state = torch.zeros(lib.cgv_optim_state_floats(), dtype=torch.float32, device=dev)
-            self.partial = torch.empty(lib.cgv_optim_partial_floats(), dtype=torch.float32, device=dev)
+            self.partial = torch.zeros(lib.cgv_optim_partial_floats(), dtype=torch.float32, device=dev)      # (its ticket word must start at zero)
         else:
             if self.optimizer == "sgd":
                 self.torch_opt = torch.optim.SGD(live, lr=self.lr)

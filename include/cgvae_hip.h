@@ -79,7 +79,8 @@ enum {
   CGV_OPT_DECODER_WLDS = 12,   /* cgv_decoder_msg_fwd: 1 (default) weight rows by LDS-DMA when they fit in LDS, 0 register path */
   CGV_OPT_SKINNY_ROWS = 13,    /* cgv_skinny_linear_fwd: row blocks (of 16) per thread block; 0 = built-in rule, 1..4 */
   CGV_OPT_TILE_FWD_BAL = 14,   /* cgv_tile_linear_fwd: 1 (default) layers of >= 1200 outputs with more than one 32 x 32 tile per CU run as ONE larger register tile per CU where a compiled tile fits (XCD-aware tile order), 0 off, 2 every shape (tests / A-B) */
-  CGV_OPT_COUNT = 15
+  CGV_OPT_OPTIM_ONE_LAUNCH = 15, /* cgv_optim_prepare*: 1 (default) norm pass + decision in ONE launch (the last block decides), 0 two launches */
+  CGV_OPT_COUNT = 16
 };
 /* Measurement: store the GPU wall clock (cgv_timestamp_hz ticks per second) into *slot, in stream order; capturable. */
 int cgv_timestamp(uint64_t* slot /*device*/, void* stream);
@@ -642,7 +643,8 @@ int cgv_loss_tail(const float* V, const float* cg_xyz, const int32_t* rowptr, co
  *   g' = g * coef * grad_scale ; m,v,p updated as Adam does ; step counter += 1
  * `state` is cgv_optim_state_floats() device floats, zero-initialised by the caller once:
  *   [0] step  [1] last grad norm  [2] clip*scale  [3] 1-b1^t  [4] sqrt(1-b2^t)  [5] skipped?  [6] #skipped
- * `partial` is cgv_optim_partial_floats() device floats of scratch.  No host synchronisation.
+ * `partial` is cgv_optim_partial_floats() device floats of scratch, ZEROED once by the caller (its last 16 floats hold the
+ * ticket word of the one-launch norm + decision pass; every launch leaves it zero).  No host synchronisation.
  * ------------------------------------------------------------------------------------- */
 int cgv_optim_state_floats(void);
 int cgv_optim_partial_floats(void);

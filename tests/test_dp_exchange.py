@@ -236,7 +236,7 @@ def test_rank_update_over_gathered_rows_vs_fp64(world, M, N, K, bias):
     if bias:
         assert torch.allclose(gb.double().cpu(), gbias, rtol=1e-5, atol=1e-5)
     state = torch.zeros(lib.cgv_optim_state_floats(), device=DEV)
-    partial = torch.empty(lib.cgv_optim_partial_floats(), device=DEV)
+    partial = torch.zeros(lib.cgv_optim_partial_floats(), device=DEV)
     lr, b1, b2, eps, max_norm, scale = 1e-3, 0.9, 0.999, 1e-8, 0.01, 1.0 / world
     _lib.call("cgv_optim_prepare_extra", arena_g.data_ptr(), 0, _lib.ptr(sumsq), 1, b1, b2, max_norm, scale, None, 0.0,
               _lib.ptr(state), _lib.ptr(partial), _lib.stream_ptr())
@@ -310,7 +310,7 @@ def test_mfma_rank_update_over_gathered_rows_vs_fp64(world, M, N, K, bias, layou
     if bias:
         assert torch.allclose(gb.double().cpu(), gbias, rtol=1e-5, atol=1e-5)
     state = torch.zeros(lib.cgv_optim_state_floats(), device=DEV)
-    part = torch.empty(lib.cgv_optim_partial_floats(), device=DEV)
+    part = torch.zeros(lib.cgv_optim_partial_floats(), device=DEV)
     lr, b1, b2, eps, max_norm, scale = 1e-3, 0.9, 0.999, 1e-8, 0.01, 1.0 / world
     _lib.call("cgv_optim_prepare_extra", arena_g.data_ptr(), 0, _lib.ptr(sumsq), 1, b1, b2, max_norm, scale, None, 0.0,
               _lib.ptr(state), _lib.ptr(part), _lib.stream_ptr())

@@ -1412,7 +1412,7 @@ def test_wgrad_gram_norm_and_fused_adam_vs_fp64(wgrad_tiling):
             assert torch.allclose(items[k][5].double(), gbias, rtol=1e-5, atol=1e-5)
     # the decision pass on an empty materialised range + these norms, then the fused update
     state = torch.zeros(lib.cgv_optim_state_floats(), device=DEV)
-    partial = torch.empty(lib.cgv_optim_partial_floats(), device=DEV)
+    partial = torch.zeros(lib.cgv_optim_partial_floats(), device=DEV)
     lr, b1, b2, eps, max_norm = 1e-3, 0.9, 0.999, 1e-8, 0.01
     for step in range(2):
         cg._lib.call("cgv_optim_prepare_extra", arena_g.data_ptr(), 0, cg._lib.ptr(sumsq), len(items), b1, b2, max_norm, 1.0,
@@ -1631,7 +1631,7 @@ def test_rank_update_kernels_on_random_shapes():
         if items[k][5] is not None:
             assert torch.allclose(items[k][5].double(), gbias, rtol=1e-5, atol=1e-5), (k, shapes[k])
     state = torch.zeros(lib.cgv_optim_state_floats(), device=DEV)
-    partial = torch.empty(lib.cgv_optim_partial_floats(), device=DEV)
+    partial = torch.zeros(lib.cgv_optim_partial_floats(), device=DEV)
     lr, b1, b2, eps, max_norm = 1e-2, 0.9, 0.999, 1e-8, 1e9                  # no clipping: the update is lr * sign-like
     cg._lib.call("cgv_optim_prepare_extra", arena_g.data_ptr(), 0, cg._lib.ptr(sumsq), len(items), b1, b2, max_norm, 1.0,
                  None, 0.0, cg._lib.ptr(state), cg._lib.ptr(partial), cg._lib.stream_ptr())
