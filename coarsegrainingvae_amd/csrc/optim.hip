@@ -78,8 +78,10 @@ __device__ __forceinline__ void optim_decide(const float* __restrict__ partial, 
 
 // Norm pass AND decision in one launch: every block leaves its partial sum (write-through), the block that arrives last
 // at the ticket (device scope) runs the decision pass over all partials in block order -- the same sums in the same
-// order as sumsq_partial + optim_finalize, one launch boundary (~6 us of a 1.8 ms step) less.  ticket: one word, zero
-// before the first launch; the last block leaves it zero.
+// order as sumsq_partial + optim_finalize, one launch boundary less.  ticket: one word, zero before the first launch; the
+// last block leaves it zero.  NOT the default: with the 1620 blocks the norm pass wants, the arrivals at the one ticket
+// word (~12 ns each, MI355X_MICROARCH.md "fanin") cost more than the boundary: 1.774 against 1.763 ms per chignolin step.
+// (The same pattern pays where few blocks arrive: csrc/loss_tail.hip, 12 - 96 blocks.)
 __global__ __launch_bounds__(256) void sumsq_decide_k(const float* __restrict__ g, int64_t n, float* __restrict__ partial,
                                                       unsigned int* __restrict__ ticket, const double* __restrict__ extra, int n_extra,
                                                       float grad_scale, float max_norm, float beta1, float beta2,

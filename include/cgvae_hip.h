@@ -79,7 +79,7 @@ enum {
   CGV_OPT_DECODER_WLDS = 12,   /* cgv_decoder_msg_fwd: 1 (default) weight rows by LDS-DMA when they fit in LDS, 0 register path */
   CGV_OPT_SKINNY_ROWS = 13,    /* cgv_skinny_linear_fwd: row blocks (of 16) per thread block; 0 = built-in rule, 1..4 */
   CGV_OPT_TILE_FWD_BAL = 14,   /* cgv_tile_linear_fwd: 1 (default) layers of >= 1200 outputs with more than one 32 x 32 tile per CU run as ONE larger register tile per CU where a compiled tile fits (XCD-aware tile order), 0 off, 2 every shape (tests / A-B) */
-  CGV_OPT_OPTIM_ONE_LAUNCH = 15, /* cgv_optim_prepare*: 1 (default) norm pass + decision in ONE launch (the last block decides), 0 two launches */
+  CGV_OPT_OPTIM_ONE_LAUNCH = 15, /* cgv_optim_prepare*: 0 (default) norm pass, then the decision launch; 1 both in ONE launch (the last block decides) -- measured SLOWER on the chignolin step (1.774 against 1.763 ms): 1620 blocks arriving at one device-scope ticket cost more (~12 ns each) than the launch boundary saved */
   CGV_OPT_COUNT = 16
 };
 /* Measurement: store the GPU wall clock (cgv_timestamp_hz ticks per second) into *slot, in stream order; capturable. */
