@@ -624,7 +624,7 @@ int cgv_elbo_scale(const float* g_loss, float* g_mu, float* g_sigma, float* g_pr
  * bead_of: the atom -> bead plan (CSR by bead, atom ids and bead ids in bead-sorted order).  Sums in double, block
  * partials added in block order by the block that arrives last (device-scope ticket): deterministic.
  * workspace: cgv_loss_tail_workspace_bytes(n_beads) bytes, 16-byte aligned, ZERO before the first launch (every launch
- * leaves its ticket word at zero again).  Limits: cgv_loss_tail_supported (atoms <= 8192, beads <= 2048). */
+ * leaves its ticket word at zero again).  Limits: cgv_loss_tail_supported (atoms + beads <= 3072: both coordinate sets live in LDS). */
 int cgv_loss_tail_supported(int n_beads, int n_feat, int n_atoms, int n_bonds);
 size_t cgv_loss_tail_workspace_bytes(int n_beads);
 int cgv_loss_tail(const float* V, const float* cg_xyz, const int32_t* rowptr, const int32_t* atom_of, const int32_t* bead_of,
