@@ -139,10 +139,13 @@ class ContractiveMessageBlock(nn.Module):
         self.with_dv = True
 
     def forward(self, s_i, v_i, r_iI, mapping, plan: Optional[EdgePlan] = None,
-                geom: Optional[EdgeGeometry] = None, residual=None, chain: bool = False):
+                geom: Optional[EdgeGeometry] = None, residual=None, chain: bool = False, mean_init: bool = False):
         """``residual=(H, V)`` (bead-shaped) returns (H + dS, V + dV) from the same launch.  ``chain=True`` also returns an
         alias of ``s_i`` for the NEXT consumer of the atom state (the following layer's message block): the gradients of a
-        state that feeds several blocks then travel along the chain of first-Dense forks, no accumulation launches."""
+        state that feeds several blocks then travel along the chain of first-Dense forks, no accumulation launches.
+        ``mean_init=True`` (with ``chain``) starts the bead state HERE: residual = (scatter_mean(s_i), scatter_mean(v_i)) over
+        ``mapping`` (cgvae.py:297-298) from one launch, whose gradient comes back through this block's first Dense
+        (ops.SegmentGradSlot) instead of a broadcast launch and an accumulation add."""
         if plan is None:
             n_beads = int(mapping.max().item()) + 1      # dim_size inferred like torch_scatter does
             plan = EdgePlan.from_mapping(mapping, n_beads)
@@ -151,7 +154,13 @@ class ContractiveMessageBlock(nn.Module):
         Wd, bd = self.dist_embed.filter_params()
         s_res, v_res = residual if residual is not None else (None, None)
         if chain:
-            a, s_alias = self.inv_dense[0].forward_fork(s_i)
+            slot = None
+            if mean_init:
+                slot = ops.SegmentGradSlot(plan, mapping, mean=True)
+                slot = slot if slot.usable() else None
+            a, s_alias = self.inv_dense[0].forward_fork(s_i, slot)
+            if mean_init:                                # created AFTER the fork: its backward then runs before the Dense's
+                s_res, v_res = ops.segment_reduce2(s_i, v_i, plan, mean=True, slot=slot)
             return ops.equi_message(self.inv_dense[1](a), v_i, Wd, bd, plan, geom, self.with_dv, s_res, v_res) + (s_alias,)
         return ops.equi_message(self.inv_dense(s_i), v_i, Wd, bd, plan, geom, self.with_dv, s_res, v_res)
 

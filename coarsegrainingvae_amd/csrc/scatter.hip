@@ -68,6 +68,41 @@ __global__ __launch_bounds__(BLOCK) void segment_reduce_k(const float* __restric
   *reinterpret_cast<V*>(out + (size_t)seg * C + c) = acc;
 }
 
+// Two reductions over ONE index in one launch (the encoder's H = scatter_mean(h), V = scatter_mean(v), cgvae.py:297-298):
+// blockIdx.y < tiles_a serves (src_a, C_a), the rest (src_b, C_b).  Same per-segment order as segment_reduce_k.
+template <int BLOCK, int UNROLL>
+__global__ __launch_bounds__(BLOCK) void segment_reduce2_k(const float* __restrict__ src_a, int C_a, float* __restrict__ out_a,
+                                                           const float* __restrict__ src_b, int C_b, float* __restrict__ out_b,
+                                                           int tiles_a, const int* __restrict__ rowptr,
+                                                           const int* __restrict__ perm, int mean) {
+  const bool second = (int)blockIdx.y >= tiles_a;
+  const float* __restrict__ src = second ? src_b : src_a;
+  float* __restrict__ out = second ? out_b : out_a;
+  const int C = second ? C_b : C_a;
+  const int seg = blockIdx.x;
+  const int c = (((int)blockIdx.y - (second ? tiles_a : 0)) * BLOCK + threadIdx.x) * 4;
+  if (c >= C) return;
+  const int beg = rowptr[seg], end = rowptr[seg + 1];
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int p = beg; p < end; p += UNROLL) {
+    float4 x[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int pp = min(p + u, end - 1);
+      const int row = perm ? perm[pp] : pp;
+      x[u] = *reinterpret_cast<const float4*>(src + (size_t)row * C + c);
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u)
+      if (p + u < end) vadd(acc, x[u]);
+  }
+  if (mean) {
+    const int len = end - beg;
+    vscale(acc, 1.0f / (float)(len > 1 ? len : 1));
+  }
+  *reinterpret_cast<float4*>(out + (size_t)seg * C + c) = acc;
+}
+
 template <int VEC, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void segment_broadcast_k(const float* __restrict__ gout,
                                                              const int* __restrict__ rowptr,
@@ -121,6 +156,21 @@ int cgv_segment_reduce(const float* src, const int32_t* rowptr, const int32_t* p
                        mean, out);
   }
   return cgv::check_launch("cgv_segment_reduce");
+}
+
+int cgv_segment_reduce2(const float* src_a, int channels_a, float* out_a, const float* src_b, int channels_b, float* out_b,
+                        const int32_t* rowptr, const int32_t* perm, int n_seg, int mean, void* stream) {
+  CGV_REQUIRE(n_seg >= 0 && channels_a > 0 && channels_b > 0, "bad size");
+  if (n_seg == 0) return 0;
+  CGV_REQUIRE(src_a && src_b && out_a && out_b && rowptr, "null pointer");
+  CGV_REQUIRE((channels_a % 4) == 0 && (channels_b % 4) == 0 &&
+              ((((uintptr_t)src_a) | ((uintptr_t)src_b) | ((uintptr_t)out_a) | ((uintptr_t)out_b)) & 15) == 0,
+              "need channel counts that are multiples of 4 and 16-byte aligned operands");
+  constexpr int BLOCK = 256, UNROLL = 8;
+  const int ta = (channels_a / 4 + BLOCK - 1) / BLOCK, tb = (channels_b / 4 + BLOCK - 1) / BLOCK;
+  hipLaunchKernelGGL((cgv::segment_reduce2_k<BLOCK, UNROLL>), dim3(n_seg, ta + tb), dim3(BLOCK), 0, (hipStream_t)stream, src_a,
+                     channels_a, out_a, src_b, channels_b, out_b, ta, rowptr, perm, mean);
+  return cgv::check_launch("cgv_segment_reduce2");
 }
 
 /* nn.Embedding lookup with the type ids read as they sit in the batch (cgvae.py:268, 381: ids = nxyz[:, 0], a float

@@ -492,11 +492,22 @@ __global__ __launch_bounds__(256, 2) void tile_fwd_ring_k(const float* __restric
 // w, w+4, ... (16 rows of W each).  Lane (j = l&15, q = l>>4): A_mb = g[m0 + 16 mb + j][n + 4q ..+3];
 // for c = 0..3 one float4 B_c = W[n + 4q + c][k0 + 4j ..+3] (4 rows x 256 contiguous bytes per
 // instruction); MFMA (c, s) uses A.comp(c) and B_c.comp(s) and accumulates D_s = gx[..][k0 + 4j + s].
+// A THIRD gradient of the same input, held as one row per SEGMENT of the rows (the backward of
+// scatter_mean / scatter_add of this very input, cgvae.py:297: g[m, :] += src[seg(m), :] (/ len(seg(m)) for the mean)):
+// added in the store epilogue instead of by a broadcast launch + an accumulation add.
+struct BcastAdd {
+  const float* src;          // [n_seg, K] or NULL
+  const int64_t* row2seg;    // [M] segment of every row (the CG mapping)
+  const int* rowptr;         // [n_seg + 1] CSR of the segments (their lengths)
+  int mean;
+};
+
 template <int MB, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void tile_bwd_input_k(const float* __restrict__ g, const float* __restrict__ W,
                                                         float* __restrict__ gx, int M, int N, int K,
                                                         const float* __restrict__ z, int act,
-                                                        const float* __restrict__ add = nullptr) {
+                                                        const float* __restrict__ add = nullptr,
+                                                        BcastAdd bc = BcastAdd{nullptr, nullptr, nullptr, 0}) {
   __shared__ float red[WAVES - 1][MB * 4][4][64];    // [wave-1][mb*4 + s][reg][lane]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -592,6 +603,13 @@ __global__ __launch_bounds__(64 * WAVES) void tile_bwd_input_k(const float* __re
       if (add) {                                     // a second gradient of the same input (blocks.py: fork of the first Dense)
         const float4 a4 = *reinterpret_cast<const float4*>(add + (size_t)m * K + kcol);
         o[0] += a4.x; o[1] += a4.y; o[2] += a4.z; o[3] += a4.w;
+      }
+      if (bc.src) {                                  // ... and a third, one row per segment of the rows
+        const int sg = (int)bc.row2seg[m];
+        const float4 b4 = *reinterpret_cast<const float4*>(bc.src + (size_t)sg * K + kcol);
+        const int len = bc.rowptr[sg + 1] - bc.rowptr[sg];
+        const float sc = bc.mean ? 1.0f / (float)(len > 1 ? len : 1) : 1.0f;
+        o[0] = fmaf(b4.x, sc, o[0]); o[1] = fmaf(b4.y, sc, o[1]); o[2] = fmaf(b4.z, sc, o[2]); o[3] = fmaf(b4.w, sc, o[3]);
       }
       *reinterpret_cast<float4*>(gx + (size_t)m * K + kcol) = make_float4(o[0], o[1], o[2], o[3]);
     }
@@ -727,7 +745,8 @@ int cgv_tile_linear_fwd(const float* x, const float* W, const float* bias, float
 }
 
 static int tile_bwd_input_launch(const float* g, const float* z, int act, const float* W, float* gx, int M, int N, int K,
-                                 void* stream, const char* what, const float* add = nullptr) {
+                                 void* stream, const char* what, const float* add = nullptr,
+                                 cgv::BcastAdd bc = cgv::BcastAdd{nullptr, nullptr, nullptr, 0}) {
   hipStream_t st = (hipStream_t)stream;
   const int kt = (K + 63) / 64;
   const int blocks32 = kt * ((M + 31) / 32);
@@ -736,19 +755,19 @@ static int tile_bwd_input_launch(const float* g, const float* z, int act, const 
   if (const int o = cgv::option(CGV_OPT_BWD_INPUT_WAVES); o > 0 && o != 32) waves = o;          // experiments only
   else if (blocks16 < 128 && N >= 1024) waves = 16;
   if (cgv::option(CGV_OPT_BWD_INPUT_WAVES) == 32)          /* A/B: 32-row tiles, 8 waves */
-    hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 8>), dim3(kt, (M + 31) / 32), dim3(512), 0, st, g, W, gx, M, N, K, z, act, add);
+    hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 8>), dim3(kt, (M + 31) / 32), dim3(512), 0, st, g, W, gx, M, N, K, z, act, add, bc);
   else if (blocks32 >= 200 && blocks32 < 512 && waves == 8)
     // 200 .. 511 32-row tiles (704 rows x 600 / 1200 columns): still 32-row tiles, with the reduction split over 8 waves --
     // half the weight re-reads of the 16-row tiles (704 x 1800 x 600: 22.9 against 25.0 us, 704 x 5400: 54.6 / 64.1;
     // at 332 rows the 16-row tiles win, 14.5 against 22.1 us: tools/gemm_shapes.py)
-    hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 8>), dim3(kt, (M + 31) / 32), dim3(512), 0, st, g, W, gx, M, N, K, z, act, add);
+    hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 8>), dim3(kt, (M + 31) / 32), dim3(512), 0, st, g, W, gx, M, N, K, z, act, add, bc);
   else if (blocks32 >= 512)               // enough 32-row tiles to fill the chip: halve the weight re-reads
-    hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 4>), dim3(kt, (M + 31) / 32), dim3(256), 0, st, g, W, gx, M, N, K, z, act, add);
+    hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 4>), dim3(kt, (M + 31) / 32), dim3(256), 0, st, g, W, gx, M, N, K, z, act, add, bc);
   else if (waves == 16)                   // few output tiles and a long reduction (96 bead rows x 5400 columns: 60 blocks):
     // 16 waves per block split it -- 60 blocks of 8 waves left three quarters of the chip idle (17.8 us per call)
-    hipLaunchKernelGGL((cgv::tile_bwd_input_k<1, 16>), dim3(kt, (M + 15) / 16), dim3(1024), 0, st, g, W, gx, M, N, K, z, act, add);
+    hipLaunchKernelGGL((cgv::tile_bwd_input_k<1, 16>), dim3(kt, (M + 15) / 16), dim3(1024), 0, st, g, W, gx, M, N, K, z, act, add, bc);
   else
-    hipLaunchKernelGGL((cgv::tile_bwd_input_k<1, 8>), dim3(kt, (M + 15) / 16), dim3(512), 0, st, g, W, gx, M, N, K, z, act, add);
+    hipLaunchKernelGGL((cgv::tile_bwd_input_k<1, 8>), dim3(kt, (M + 15) / 16), dim3(512), 0, st, g, W, gx, M, N, K, z, act, add, bc);
   return cgv::check_launch(what);
 }
 
@@ -777,6 +796,20 @@ int cgv_tile_linear_bwd_input_act_add(const float* gy, const float* z, const flo
   CGV_REQUIRE(cgv_tile_supported(M, N, K), "unsupported shape (need N % 4 == 0, K % 4 == 0)");
   CGV_REQUIRE(((((uintptr_t)gy | (uintptr_t)z | (uintptr_t)W | (uintptr_t)gx | (uintptr_t)add)) & 15) == 0, "operands must be 16-byte aligned");
   return tile_bwd_input_launch(gy, act ? z : nullptr, act, W, gx, M, N, K, stream, "cgv_tile_linear_bwd_input_act_add", add);
+}
+
+/* ... plus a gradient that lives as ONE ROW PER SEGMENT of the rows (the backward of a scatter_mean / scatter_add of the
+ * same input): gx[m, :] += seg_grad[row2seg[m], :] (/ max(len(segment), 1) when mean).  add may be NULL here. */
+int cgv_tile_linear_bwd_input_act_add_bcast(const float* gy, const float* z, const float* W, const float* add, const float* seg_grad,
+                                            const int64_t* row2seg, const int32_t* seg_rowptr, int mean, float* gx, int M, int N,
+                                            int K, int act, void* stream) {
+  CGV_REQUIRE(gy && W && gx && seg_grad && row2seg && seg_rowptr, "null pointer");
+  CGV_REQUIRE(act == 0 || (act >= 1 && act <= cgv::CGV_ACT_MAX && z), "act != 0 needs the saved pre-activation z");
+  CGV_REQUIRE(cgv_tile_supported(M, N, K), "unsupported shape (need N % 4 == 0, K % 4 == 0)");
+  CGV_REQUIRE(((((uintptr_t)gy | (uintptr_t)z | (uintptr_t)W | (uintptr_t)gx | (uintptr_t)add | (uintptr_t)seg_grad)) & 15) == 0,
+              "operands must be 16-byte aligned");
+  return tile_bwd_input_launch(gy, act ? z : nullptr, act, W, gx, M, N, K, stream, "cgv_tile_linear_bwd_input_act_add_bcast", add,
+                               cgv::BcastAdd{seg_grad, row2seg, seg_rowptr, mean});
 }
 
 int cgv_tile_linear_wgrad(const float* g, const float* x, float* gW, int M, int N, int K, int accumulate, void* stream) {

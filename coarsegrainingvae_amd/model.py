@@ -16,6 +16,7 @@ from torch import nn
 
 from . import ops
 from .ktimer import mark
+from .options import HOST
 from .blocks import (ContractiveMessageBlock, EquiMessageBlock, EquiMessageCross, EquiMessagePsuedo, PseudoUpdateBlock,
                      UpdateBlock)
 from .graph import BatchGraph, EdgePlan, make_directed
@@ -191,12 +192,14 @@ class EquiEncoder(nn.Module):
                 h_in = h.view_as(h)                       # private node: its gradient is the last one of layers >= i
                 h_in.register_hook(_call_then_pass(layer_hooks[i]))
             h, v = self.message_blocks[i](h_in, v, None, graph.atom_nbrs, plan=graph.atom, geom=geom, residual=True)
-            if i == 0:
+            if i == 0 and not HOST["fused_bead_mean"]:
                 H = ops.scatter_mean(h, graph.mapping, plan=graph.a2b)
                 V = ops.scatter_mean(v, graph.mapping, plan=graph.a2b)
             # chain: the atom state also feeds the next layer's message block -- it goes on through the fork of this block's
             # first Dense, so its gradients meet inside that layer's backward-input kernel (blocks.ContractiveMessageBlock)
-            H, V, h = self.cgmessage_layers[i](h, v, None, graph.mapping, plan=graph.a2b, geom=geom_c, residual=(H, V), chain=True)
+            # layer 0 with H is None: the bead state starts inside the block (H, V = scatter_mean(h), scatter_mean(v), one launch)
+            H, V, h = self.cgmessage_layers[i](h, v, None, graph.mapping, plan=graph.a2b, geom=geom_c,
+                                               residual=(H, V) if H is not None else None, chain=True, mean_init=H is None)
         return H, h
 
 

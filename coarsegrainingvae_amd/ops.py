@@ -221,6 +221,83 @@ def embedding(module, idx: torch.Tensor, plan: Optional[EdgePlan] = None) -> tor
     return _Embedding.apply(w, idx, plan)
 
 
+class SegmentGradSlot:
+    """Hand-over from the backward of a segment reduction of a state to the backward of the Dense layer that ALSO reads
+    that state (encoder layer 0: H = scatter_mean(h) and the contractive block's first Dense, cgvae.py:297-305): the
+    reduction parks its output gradient here instead of broadcasting it to the rows, and the Dense's backward-input kernel
+    adds ``g[mapping[m]] / len`` in its store epilogue (csrc/tile_gemm.hip ``BcastAdd``) -- no broadcast launch, no
+    accumulation add.  Order-robust: the reduction parks only while the Dense has accepted the slot (``armed``) and has
+    not run its backward yet (``linear_done``); in any other case it broadcasts as usual."""
+    __slots__ = ("armed", "linear_done", "g", "plan", "mapping", "mean")
+
+    def __init__(self, plan, mapping, mean):
+        self.armed = self.linear_done = False
+        self.g = None
+        self.plan, self.mapping, self.mean = plan, mapping, bool(mean)
+
+    def usable(self) -> bool:
+        m, p = self.mapping, self.plan
+        return (torch.is_tensor(m) and m.dtype == torch.int64 and m.is_cuda and m.is_contiguous() and m.numel() == p.n_edges)
+
+    def take(self):
+        g, self.g = self.g, None
+        return g
+
+    def broadcast(self, g):
+        """The parked gradient spread to the rows by the ordinary launch (any consumer without the fused epilogue)."""
+        plan = self.plan
+        g = _c(g).reshape(plan.n_dst, -1)
+        out = torch.empty((plan.n_edges, g.shape[1]), dtype=_F32, device=g.device)
+        _lib.call("cgv_segment_broadcast", _lib.ptr(g), _lib.ptr(plan.rowptr_d), _lib.ptr(plan.eid_d), plan.n_dst,
+                  g.shape[1], int(self.mean), _lib.ptr(out), _lib.stream_ptr())
+        return out
+
+
+class _SegmentReduce2(torch.autograd.Function):
+    """(reduce(a), reduce(b)) over one plan in ONE launch; the gradient of ``a`` may be parked in ``slot``."""
+
+    @staticmethod
+    def forward(ctx, a, b, plan: EdgePlan, mean: bool, slot):
+        a, b = _c(a), _c(b)
+        rows = a.shape[0]
+        if rows != plan.n_edges or b.shape[0] != rows:
+            raise RuntimeError("index plan and src disagree on the number of rows")
+        Ca, Cb = a.reshape(rows, -1).shape[1], b.reshape(rows, -1).shape[1]
+        oa = torch.empty((plan.n_dst, Ca), dtype=_F32, device=a.device)
+        ob = torch.empty((plan.n_dst, Cb), dtype=_F32, device=a.device)
+        _lib.call("cgv_segment_reduce2", _lib.ptr(a), Ca, _lib.ptr(oa), _lib.ptr(b), Cb, _lib.ptr(ob), _lib.ptr(plan.rowptr_d),
+                  _lib.ptr(plan.eid_d), plan.n_dst, int(mean), _lib.stream_ptr())
+        ctx.plan, ctx.mean, ctx.shapes, ctx.slot = plan, mean, (tuple(a.shape), tuple(b.shape)), slot
+        ctx.set_materialize_grads(False)
+        return oa.reshape((plan.n_dst,) + tuple(a.shape[1:])), ob.reshape((plan.n_dst,) + tuple(b.shape[1:]))
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        plan, slot = ctx.plan, ctx.slot
+        outs = []
+        for g, shape, may_park in ((ga, ctx.shapes[0], True), (gb, ctx.shapes[1], False)):
+            if g is None:
+                outs.append(None)
+                continue
+            if may_park and slot is not None and slot.armed and not slot.linear_done and slot.g is None:
+                slot.g = _c(g).reshape(plan.n_dst, -1)              # the Dense's backward-input epilogue adds it
+                outs.append(None)
+                continue
+            g = _c(g).reshape(plan.n_dst, -1)
+            gsrc = torch.empty((plan.n_edges, g.shape[1]), dtype=_F32, device=g.device)
+            _lib.call("cgv_segment_broadcast", _lib.ptr(g), _lib.ptr(plan.rowptr_d), _lib.ptr(plan.eid_d), plan.n_dst,
+                      g.shape[1], int(ctx.mean), _lib.ptr(gsrc), _lib.stream_ptr())
+            outs.append(gsrc.reshape(shape))
+        return outs[0], outs[1], None, None, None
+
+
+def segment_reduce2(a: torch.Tensor, b: torch.Tensor, plan: EdgePlan, mean: bool = False, slot=None):
+    """(reduce(a), reduce(b)) over the same index plan from one launch (the encoder's H, V of cgvae.py:297-298)."""
+    if (a.is_cuda and a.dtype == _F32 and b.dtype == _F32 and a[0].numel() % 4 == 0 and b[0].numel() % 4 == 0 and plan.n_dst > 0):
+        return _SegmentReduce2.apply(a, b, plan, mean, slot)
+    return _SegmentReduce.apply(a, plan, mean), _SegmentReduce.apply(b, plan, mean)
+
+
 def segment_reduce(src: torch.Tensor, plan: EdgePlan, mean: bool = False) -> torch.Tensor:
     """out[s] = sum (or mean) of the rows of ``src`` whose index is s, using a prebuilt plan."""
     return _SegmentReduce.apply(src, plan, mean)

@@ -311,13 +311,17 @@ class _LinearFn(torch.autograd.Function):
     it, trainer.py) -- deferred to ONE grouped launch per step when the trainer's queue is active."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act, fork=False):
-        """``fork=True`` returns (y, x_alias): the layer's input handed on to a second consumer (the block's message kernel /
+    def forward(ctx, x, weight, bias, act, fork=False, slot=None):
+        """``slot`` (ops.SegmentGradSlot): a segment reduction of the same input parks its gradient there and this layer's
+        backward-input kernel adds it, spread to the rows, in its store epilogue.  ``fork=True`` returns (y, x_alias): the layer's input handed on to a second consumer (the block's message kernel /
         residual, or the next block of a chain).  Its gradient then comes back HERE and is summed with this layer's own
         input gradient in the epilogue of the backward-input product -- autograd would run a separate add launch for a
         state that feeds two nodes (6 per chignolin step, ~20 per dipeptide step)."""
         y = _LinearFn._forward(ctx, x, weight, bias, act)
         ctx.set_materialize_grads(False)
+        ctx.slot = slot
+        if slot is not None:
+            slot.armed = True
         if fork:
             return y, x.view_as(x)
         return y
@@ -362,15 +366,30 @@ class _LinearFn(torch.autograd.Function):
                 if _is_direct(prm) and prm._cgv_pending and ctx.needs_input_grad[1]:
                     prm.grad.zero_()
                     prm._cgv_pending = False
-            return g_alias, None, None, None, None
+            return _LinearFn._with_parked(ctx, g_alias), None, None, None, None, None
         out = _LinearFn._backward(ctx, gy, g_alias)
-        return out + (None,)
+        return out + (None, None)
+
+    @staticmethod
+    def _with_parked(ctx, gx):
+        """Close the slot; a parked segment gradient no kernel took is spread and added by ordinary launches."""
+        slot = getattr(ctx, "slot", None)
+        if slot is None:
+            return gx
+        slot.linear_done = True
+        g = slot.take()
+        if g is None:
+            return gx
+        spread = slot.broadcast(g)
+        return spread.reshape(gx.shape) + gx if gx is not None else spread.reshape(ctx.saved_tensors[0].shape)
 
     @staticmethod
     def _backward(ctx, gy, add):
         """``add``: gradient of the forked input alias (same shape as x) or None; every path below either hands it to
         its backward-input kernel (``fused``) or adds it at the end."""
         gx, gw, gb, _none = _LinearFn._backward_core(ctx, gy, add)
+        if getattr(ctx, "slot", None) is not None and ctx.needs_input_grad[0]:
+            gx = _LinearFn._with_parked(ctx, gx)
         return gx, gw, gb, None
 
     @staticmethod
@@ -382,6 +401,15 @@ class _LinearFn(torch.autograd.Function):
         if add2 is not None and not (add2.is_contiguous() and add2.data_ptr() % 16 == 0 and add2.dtype == torch.float32):
             add2 = add2.contiguous().float()
         fused = [False]                                      # did a kernel take ``add``?
+
+        def parked():
+            """The segment gradient waiting in this layer's slot, if the fused epilogue can take it (K columns, fp32)."""
+            slot = getattr(ctx, "slot", None)
+            g = slot.g if slot is not None else None
+            if g is None or not (g.dtype == torch.float32 and g.is_contiguous() and g.data_ptr() % 16 == 0 and g.dim() == 2
+                                 and g.shape[1] == x.shape[1] and slot.mapping.numel() == x.shape[0]):
+                return None
+            return g
 
         def finish(gx):
             if gx is not None and add is not None and not fused[0]:
@@ -409,6 +437,13 @@ class _LinearFn(torch.autograd.Function):
                         # few rows, a very long reduction (96 bead rows x 5400 columns): the row-split kernel spreads the
                         # weight over ~300 blocks (28.5 us + reduce against 43.6 us; tools/bwd_input_bench.py)
                         fused[0] = skinny_bwd_input(gy2, z if act != ACT_NONE else None, weight, gx, M, N, K, act, add=add2)
+                    elif parked() is not None:
+                        slot = ctx.slot
+                        g_seg = slot.take()
+                        _lib.call("cgv_tile_linear_bwd_input_act_add_bcast", _lib.ptr(gy2), _lib.ptr(z) if act != ACT_NONE else None,
+                                  _lib.ptr(weight), _lib.ptr(add2), _lib.ptr(g_seg), _lib.ptr(slot.mapping), _lib.ptr(slot.plan.rowptr_d),
+                                  int(slot.mean), _lib.ptr(gx), M, N, K, act, st)
+                        fused[0] = True
                     elif add2 is not None:
                         _lib.call("cgv_tile_linear_bwd_input_act_add", _lib.ptr(gy2), _lib.ptr(z) if act != ACT_NONE else None,
                                   _lib.ptr(weight), _lib.ptr(add2), _lib.ptr(gx), M, N, K, act, st)
@@ -834,13 +869,13 @@ class Dense(nn.Linear):
         if self.bias is not None:
             nn.init.zeros_(self.bias)
 
-    def forward_fork(self, inputs):
+    def forward_fork(self, inputs, slot=None):
         """(layer output, alias of ``inputs``).  Hand the alias to whatever else consumes the same state (the block's
         message kernel / residual, the next block): its gradient is then summed with this layer's input gradient in the
         backward-input kernel instead of by an accumulation launch of autograd (``_LinearFn.forward(fork=True)``)."""
         if (isinstance(self.activation, Swish) and self.dropout_rate == 0.0 and torch.is_tensor(inputs) and inputs.is_cuda
                 and inputs.requires_grad and torch.is_grad_enabled()):
-            return _LinearFn.apply(inputs, self.weight, self.bias, ACT_SWISH, True)
+            return _LinearFn.apply(inputs, self.weight, self.bias, ACT_SWISH, True, slot)
         return self.forward(inputs), inputs
 
     def forward(self, inputs):

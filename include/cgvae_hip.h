@@ -186,6 +186,9 @@ int cgv_edge_geometry_grouped(const float* pos_dst /*[Nd,3]*/, const float* pos_
  * ------------------------------------------------------------------------------------- */
 int cgv_segment_reduce(const float* src, const int32_t* rowptr, const int32_t* perm, int n_seg, int channels,
                        int mean, float* out /*[n_seg,C]*/, void* stream);
+/* Two reductions over one index in one launch: the encoder's H = scatter_mean(h), V = scatter_mean(v) (cgvae.py:297-298). */
+int cgv_segment_reduce2(const float* src_a, int channels_a, float* out_a, const float* src_b, int channels_b, float* out_b,
+                        const int32_t* rowptr, const int32_t* perm, int n_seg, int mean, void* stream);
 /* backward of the above: gsrc[perm?perm[p]:p, :] = gout[seg(p), :] (* 1/max(len,1) if mean) */
 int cgv_segment_broadcast(const float* gout, const int32_t* rowptr, const int32_t* perm, int n_seg, int channels,
                           int mean, float* gsrc /*[n_rows,C]*/, void* stream);
@@ -532,6 +535,12 @@ int cgv_tile_linear_bwd_input_act(const float* gy, const float* z /*or NULL*/, c
  * separate add launch rides in the store epilogue). */
 int cgv_tile_linear_bwd_input_act_add(const float* gy, const float* z /*or NULL*/, const float* W, const float* add, float* gx,
                                       int M, int N, int K, int act, void* stream);
+/* ... and a third gradient held as ONE ROW PER SEGMENT of the rows -- the backward of scatter_mean / scatter_add of this
+ * very input (cgvae.py:297): gx[m, :] += seg_grad[row2seg[m], :] (/ max(len(segment), 1) when mean) in the store epilogue,
+ * instead of cgv_segment_broadcast + an accumulation add.  add may be NULL. */
+int cgv_tile_linear_bwd_input_act_add_bcast(const float* gy, const float* z, const float* W, const float* add, const float* seg_grad,
+                                            const int64_t* row2seg, const int32_t* seg_rowptr, int mean, float* gx, int M, int N,
+                                            int K, int act, void* stream);
 int cgv_tile_linear_wgrad(const float* g, const float* x, float* gW, int M, int N, int K, int accumulate, void* stream);
 int cgv_wgrad_record_bytes(void);
 int cgv_wgrad_plan(int M, int N, int K, int* tiles_k /*[host]*/, int* tile_w /*[host]*/, int* n_blocks /*[host]*/);

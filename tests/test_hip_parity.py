@@ -2,6 +2,7 @@
 reference, (b) the CPU oracle on the same seeded inputs, (c) size-independent properties.
 Tolerance: north_star's 1e-4 relative fp32 (norm-relative, written below); integer/index
 work (edge lists, CSR plans) is bit-exact."""
+import contextlib
 import numpy as np
 import pytest
 import torch
@@ -2199,3 +2200,76 @@ def test_fused_prior_loop_equals_per_block_path(n_beads, F, R, layers, with_dv, 
             assert float(a.abs().max()) == 0.0, f"parameter gradient {k} must be exactly zero"
         else:
             assert_close(a, b, f"prior parameter gradient {k}", 2e-5)
+
+
+@pytest.mark.parametrize("queued", [False, True])
+@pytest.mark.parametrize("workload,F,frames", [("chignolin", 64, 1), ("dipeptide", 32, 5)])
+def test_bead_mean_inside_the_contractive_block_equals_separate_launches(workload, F, frames, queued, options):
+    """Encoder layer 0 (cgvae.py:297-305): H, V = scatter_mean(h), scatter_mean(v) from ONE launch, whose gradient reaches h
+    through the store epilogue of the contractive block's first Dense (csrc/tile_gemm.hip BcastAdd) -- against the path it
+    replaces (two reductions, a broadcast launch, an accumulation add).  ``queued``: under the trainer's arena + weight
+    gradient queue (the fused epilogue) or plain autograd (the slot's ordinary broadcast)."""
+    from coarsegrainingvae_amd import ops
+    from coarsegrainingvae_amd.primitives import wgrad_queue
+    from coarsegrainingvae_amd.trainer import ParamArena
+    w = cg.data.WORKLOADS[workload]
+    torch.manual_seed(17)
+    enc = cg.EquiEncoder(n_conv=2, n_atom_basis=F, n_rbf=w["n_rbf"], activation="swish", cutoff=w["cg_cutoff"], dir_mp=False,
+                         cg_mp=False).to(DEV)
+    batch = cg.synthetic_batch(workload, n_frames=frames, seed=4, device=DEV)
+    g = batch["_graph"]
+    gen = torch.Generator().manual_seed(1)
+    uH = torch.randn(g.a2b.n_dst, F, generator=gen).to(DEV)
+    uh = torch.randn(batch["nxyz"].shape[0], F, generator=gen).to(DEV)
+    params = [p for p in enc.parameters()]
+    calls = []
+    real = ops._lib.call
+
+    def spy(name, *a, **k):
+        calls.append(name)
+        return real(name, *a, **k)
+
+    def run(fused):
+        options.set("fused_bead_mean", int(fused))
+        del calls[:]
+        ops._lib.call = spy
+        try:
+            ctx = wgrad_queue.collect() if queued else contextlib.nullcontext()
+            with ctx:
+                H, h = enc(batch["nxyz"][:, 0], batch["nxyz"][:, 1:], batch["CG_nxyz"][:, 1:], batch["CG_mapping"],
+                           batch["nbr_list"], batch["CG_nbr_list"], graph=g)
+                ((H * uH).sum() + (h * uh).sum()).backward()
+            if queued:
+                wgrad_queue.flush()
+        finally:
+            ops._lib.call = real
+        return H.detach().clone(), h.detach().clone(), [None if p.grad is None else p.grad.clone() for p in params], list(calls)
+    run(False)
+    arena = None
+    if queued:
+        live = [p for p in params if p.grad is not None]
+        arena = ParamArena(live)
+    outs = []
+    for fused in (False, True):
+        if arena is not None:
+            arena.g.fill_(float("nan"))
+            arena.zero_grad()
+        else:
+            for p in params:
+                p.grad = None
+        outs.append(run(fused))
+    (H0, h0, g0, c0), (H1, h1, g1, c1) = outs
+    assert "cgv_segment_reduce2" in c1 and "cgv_segment_reduce2" not in c0
+    assert c1.count("cgv_segment_broadcast") == (0 if queued else 1) and c0.count("cgv_segment_broadcast") == 1
+    if queued:
+        assert "cgv_tile_linear_bwd_input_act_add_bcast" in c1
+    assert torch.equal(H1, H0) and torch.equal(h1, h0)            # same per-segment order: bit-identical forward
+    n_live = 0
+    for k, (a, b) in enumerate(zip(g1, g0)):
+        assert (a is None) == (b is None)
+        if a is None:
+            continue
+        assert bool(torch.isfinite(a).all()), f"parameter gradient {k} has unwritten entries"
+        assert_close(a, b, f"encoder parameter gradient {k}", 2e-6)
+        n_live += float(b.abs().max()) > 0
+    assert n_live >= 10
