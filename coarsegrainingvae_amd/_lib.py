@@ -135,6 +135,7 @@ PROTOTYPES = {
     "cgv_grouped_wgrad_gathered": (_i, [_p, _i, _i, _p]),
     "cgv_wgrad_gathered_plan_tile": (_i, [_i, _i, _i, _i, _i, _p, _p]),
     "cgv_grouped_wgrad_gathered_tile": (_i, [_p, _i, _i, _i, _p]),
+    "cgv_grouped_wgrad_split": (_i, [_p, _i, _i, _p]),
     "cgv_grouped_wgrad_gathered_sumsq": (_i, [_p, _i, _i, _p, _p, _p]),
     "cgv_grouped_wgrad_gathered_adam": (_i, [_p, _i, _i, _p, _p, _p, _p, _f, _f, _f, _f, _p, _p]),
     "cgv_wgrad_strip_max_rows": (_i, []),

@@ -432,15 +432,19 @@ __device__ __forceinline__ size_t wg_row(const WgradProblem& pr, int m, int widt
 // (The binary search this replaces was log2(n) DEPENDENT global loads in front of every block's work: 6 at the 57
 // problems of a chignolin step.)
 template <typename Problem>
-__device__ __forceinline__ int wg_find_problem(const Problem* __restrict__ table, int n_problems) {
+__device__ __forceinline__ int wg_find_problem(const Problem* __restrict__ table, int n_problems, int block) {
   const int lane = threadIdx.x & 63;
   int count = 0;
   for (int base = 0; base < n_problems; base += 64) {
     const int i = base + lane;
     const int bb = i < n_problems ? table[i].block_begin : 0x7fffffff;
-    count += __popcll(__ballot(bb <= (int)blockIdx.x));
+    count += __popcll(__ballot(bb <= block));
   }
   return __builtin_amdgcn_readfirstlane(count > 0 ? count - 1 : 0);
+}
+template <typename Problem>
+__device__ __forceinline__ int wg_find_problem(const Problem* __restrict__ table, int n_problems) {
+  return wg_find_problem(table, n_problems, (int)blockIdx.x);
 }
 
 // Rank update (ADAM = true): the tile of gW is never stored -- it goes, clipped, straight into the Adam update of the
@@ -1500,6 +1504,190 @@ __global__ __launch_bounds__(256) void gathered_wgrad128_k(const WgradProblem* _
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same 128 x 128 tiles on the bf16 matrix path at fp32 accuracy ("split operands").  Every fp32 operand value is
+// written as the EXACT sum of three bf16 numbers, x = x1 + x2 + x3 (round-to-nearest splits: |x2| <= 2^-8 |x|,
+// |x3| <= 2^-16 |x|; each residual is exactly representable, so nothing is lost in the operands), and a product
+// sum_m g[m] x[m] is taken as six bf16 MFMA products with fp32 accumulation,
+//     g1 x1 + (g1 x2 + g2 x1) + (g1 x3 + g2 x2 + g3 x1)
+// -- every bf16 x bf16 product is exact in fp32; the dropped terms (g2 x3, g3 x2, g3 x3) are below 2^-23 of the product,
+// i.e. under the rounding of the fp32 accumulation itself.  v_mfma_f32_16x16x32_bf16 retires 16x the MACs per cycle of
+// v_mfma_f32_16x16x4_f32, so six of them cost 3/8 of the one fp32 instruction they replace.  The fp32 kernels above
+// spend 60 % of their time in the MFMA pipe on the atom-level layers (704 - 2000 operand rows); this one is bound by
+// LDS traffic and the split arithmetic instead: three planes per operand mean 3 (T + C) fragment reads per 6 T C MFMAs of a
+// wave tile of T x C 16-blocks (0.25 reads per MFMA at 64 x 64) against the 0.5 an LDS of 128 B/clk can deliver per MFMA
+// slot, plus the staging writes -- measured 1.15 - 1.3x the fp32 kernel, not the 2.7x of the MFMA rates.
+// Measured error against fp64: the same as the fp32 MFMA kernel's
+// (tests/test_hip_parity.py::test_split_bf16_weight_gradients_have_fp32_accuracy).
+//
+// Operands are staged TRANSPOSED ([column][m], 32 rows of m per chunk = one MFMA k step) because a lane's fragment is 8
+// consecutive m of one column: a thread loads one float4 of 4 consecutive rows and writes, per column and per split,
+// one 8-byte group of 4 bf16.  Rows of x are stored permuted (column 4 i + c of a 64-column group at row 16 c + i) so
+// that lane i of the B fragment for c reads row 16 c + i: accumulator c of a lane is then column 4 i + c -- float4 stores.
+typedef __bf16 sp_bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 sp_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float sp_f32x2 __attribute__((ext_vector_type(2)));
+constexpr int SP_CHUNK = 32;                 // rows of m per chunk
+constexpr int SP_LD = 40;                    // bf16 per LDS row (80 bytes: 16 consecutive rows hit 16 distinct bank groups)
+
+__device__ __forceinline__ void sp_split(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+  const sp_f32x2 v = {a, b};
+  const sp_bf16x2 h = __builtin_convertvector(v, sp_bf16x2);
+  const sp_f32x2 r = v - __builtin_convertvector(h, sp_f32x2);        // exact
+  const sp_bf16x2 m = __builtin_convertvector(r, sp_bf16x2);
+  const sp_f32x2 r2 = r - __builtin_convertvector(m, sp_f32x2);       // exact, at most 8 significant bits
+  const sp_bf16x2 l = __builtin_convertvector(r2, sp_bf16x2);
+  hi = __builtin_bit_cast(unsigned, h);
+  mid = __builtin_bit_cast(unsigned, m);
+  lo = __builtin_bit_cast(unsigned, l);
+}
+// four consecutive m of one column -> the three 8-byte groups at dst (split s at dst + s * plane)
+__device__ __forceinline__ void sp_store4(unsigned short* dst, int plane, float v0, float v1, float v2, float v3) {
+  unsigned h0, m0, l0, h1, m1, l1;
+  sp_split(v0, v1, h0, m0, l0);
+  sp_split(v2, v3, h1, m1, l1);
+  *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+  *reinterpret_cast<uint2*>(dst + plane) = make_uint2(m0, m1);
+  *reinterpret_cast<uint2*>(dst + 2 * plane) = make_uint2(l0, l1);
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_split128_k(const WgradProblem* __restrict__ table, int n_problems) {
+  constexpr int PLANE = 128 * SP_LD;
+  __shared__ __attribute__((aligned(16))) unsigned short gs[3 * PLANE];
+  __shared__ __attribute__((aligned(16))) unsigned short xs[3 * PLANE];
+  const int item = blockIdx.x;
+  const int lo = wg_find_problem(table, n_problems, item);
+  const WgradProblem pr = table[lo];
+  const int local = item - pr.block_begin;
+  const int nb = local / pr.tiles_k, kt = local - nb * pr.tiles_k;
+  const int M = pr.M, N = pr.N, K = pr.K;
+  const int sr = pr.seg_rows > 0 ? pr.seg_rows : M;
+  const int n0 = nb * 128, k0 = kt * 128;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wn = wave >> 1, wk = wave & 1;                          // quadrant: rows n0 + 64 wn .., columns k0 + 64 wk ..
+  const int i = lane & 15, q = lane >> 4;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // staging unit of a thread: float4 column c4 (of 32), rows 4 rq .. 4 rq + 3 of the chunk
+  const int c4 = 8 * wave + (lane & 7), rq = lane >> 3;
+  const bool gcol = n0 + 4 * c4 < N, xcol = k0 + 4 * c4 < K;
+  const int gcol_at = gcol ? n0 + 4 * c4 : 0, xcol_at = xcol ? k0 + 4 * c4 : 0;
+  const float* zsrc = pr.act ? pr.z : pr.gy;
+  float4 gq[4], zq[4], xq[4];
+  float bs[4] = {0.f, 0.f, 0.f, 0.f};
+  auto chunk_load = [&](int m0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = min(m0 + 4 * rq + r, M - 1);
+      const int seg = m / sr, row = m - seg * sr;
+      const size_t base = (size_t)seg * pr.seg_stride;
+      gq[r] = strip_ldg4(pr.gy + base + (size_t)row * N + gcol_at);
+      zq[r] = strip_ldg4(zsrc + base + (size_t)row * N + gcol_at);
+      xq[r] = strip_ldg4(pr.x + base + (size_t)row * K + xcol_at);
+    }
+    strip_pin();
+  };
+  unsigned short* gdst = gs + (4 * c4) * SP_LD + 4 * rq;
+  unsigned short* xdst = xs + (64 * (c4 >> 4) + (c4 & 15)) * SP_LD + 4 * rq;          // + 16 j rows for component j
+  auto chunk_store = [&](int m0) {
+    if (pr.act == 1) {                                                // Swish: the model's activation, kept free of the switch
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        gq[r].x *= act_bwd(zq[r].x, 1); gq[r].y *= act_bwd(zq[r].y, 1);
+        gq[r].z *= act_bwd(zq[r].z, 1); gq[r].w *= act_bwd(zq[r].w, 1);
+      }
+    } else if (pr.act) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        gq[r].x *= act_bwd(zq[r].x, pr.act); gq[r].y *= act_bwd(zq[r].y, pr.act);
+        gq[r].z *= act_bwd(zq[r].z, pr.act); gq[r].w *= act_bwd(zq[r].w, pr.act);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                                    // rows beyond M, columns beyond N / K: zeros
+      const bool live = m0 + 4 * rq + r < M;
+      if (!(live && gcol)) gq[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!(live && xcol)) xq[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    bs[0] += (gq[0].x + gq[1].x) + (gq[2].x + gq[3].x);
+    bs[1] += (gq[0].y + gq[1].y) + (gq[2].y + gq[3].y);
+    bs[2] += (gq[0].z + gq[1].z) + (gq[2].z + gq[3].z);
+    bs[3] += (gq[0].w + gq[1].w) + (gq[2].w + gq[3].w);
+    sp_store4(gdst, PLANE, gq[0].x, gq[1].x, gq[2].x, gq[3].x);
+    sp_store4(gdst + SP_LD, PLANE, gq[0].y, gq[1].y, gq[2].y, gq[3].y);
+    sp_store4(gdst + 2 * SP_LD, PLANE, gq[0].z, gq[1].z, gq[2].z, gq[3].z);
+    sp_store4(gdst + 3 * SP_LD, PLANE, gq[0].w, gq[1].w, gq[2].w, gq[3].w);
+    sp_store4(xdst, PLANE, xq[0].x, xq[1].x, xq[2].x, xq[3].x);
+    sp_store4(xdst + 16 * SP_LD, PLANE, xq[0].y, xq[1].y, xq[2].y, xq[3].y);
+    sp_store4(xdst + 32 * SP_LD, PLANE, xq[0].z, xq[1].z, xq[2].z, xq[3].z);
+    sp_store4(xdst + 48 * SP_LD, PLANE, xq[0].w, xq[1].w, xq[2].w, xq[3].w);
+  };
+  const unsigned short* ga = gs + (64 * wn + i) * SP_LD + 8 * q;      // + 16 t rows, + s planes
+  const unsigned short* xb = xs + (64 * wk + i) * SP_LD + 8 * q;      // + 16 c rows, + s planes
+  chunk_load(0);
+  for (int m0 = 0; m0 < M; m0 += SP_CHUNK) {
+    chunk_store(m0);
+    __syncthreads();
+    chunk_load(min(m0 + SP_CHUNK, M - 1));                           // the next chunk travels under this chunk's MFMAs
+    sp_bf16x8 a[3][4];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a[s][t] = *reinterpret_cast<const sp_bf16x8*>(ga + s * PLANE + 16 * t * SP_LD);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      sp_bf16x8 b[3];
+#pragma unroll
+      for (int s = 0; s < 3; ++s) b[s] = *reinterpret_cast<const sp_bf16x8*>(xb + s * PLANE + 16 * c * SP_LD);
+      // small terms first; four independent accumulators between two uses of one
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][t], b[2], acc[t][c], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2][t], b[0], acc[t][c], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][t], b[1], acc[t][c], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][t], b[1], acc[t][c], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][t], b[0], acc[t][c], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][t], b[0], acc[t][c], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const int kcol = k0 + 64 * wk + 4 * i;
+  if (kcol < K) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = n0 + 64 * wn + 16 * t + 4 * q + r;
+        if (row >= N) continue;
+        float* dst = pr.gW + (size_t)row * K + kcol;
+        float4 o = make_float4(acc[t][0][r], acc[t][1][r], acc[t][2][r], acc[t][3][r]);
+        if (pr.accumulate) { const float4 old = ldg4_global(dst); o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+        stg4_global(dst, o);
+      }
+  }
+  if (pr.gb && kt == 0) {                                           // bias: the 8 row groups of a column meet by shuffle
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float b = bs[j];
+      b += __shfl_xor(b, 8);
+      b += __shfl_xor(b, 16);
+      b += __shfl_xor(b, 32);
+      const int n = n0 + 4 * c4 + j;
+      if (rq == 0 && n < N) pr.gb[n] = pr.accumulate ? pr.gb[n] + b : b;
+    }
+  }
+}
+
+
 // Packs the operands of queued weight-gradient problems into one contiguous send buffer:
 //   dst_g[M,N] = gy * act'(z)      dst_x[M,K] = x        (float4 granularity; N % 4 == 0, K % 4 == 0)
 struct PackProblem {        // mirrors the 64-byte host record built in python (trainer.OperandExchange)
@@ -2067,6 +2255,18 @@ int cgv_wgrad_gathered_plan_tile(int M, int N, int K, int seg_rows, int tile, in
   *tiles_k = (K + tile_k - 1) / tile_k;
   *n_blocks = ((N + tile - 1) / tile) * *tiles_k;
   return 0;
+}
+
+/* The grouped weight gradients of cgv_grouped_wgrad_gathered_tile(tile = 128: same table, same plan) on the bf16 matrix
+ * path with split operands (three bf16 terms per fp32 value, six products, fp32 accumulation: fp32-class accuracy at
+ * 3/8 of the fp32 MFMA time; wgrad_split128_k). */
+int cgv_grouped_wgrad_split(const void* table_dev, int n_problems, int total_blocks, void* stream) {
+  CGV_REQUIRE(n_problems >= 0 && total_blocks >= 0, "bad size");
+  if (n_problems == 0 || total_blocks == 0) return 0;
+  CGV_REQUIRE(table_dev, "null table");
+  hipLaunchKernelGGL(cgv::wgrad_split128_k, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const cgv::WgradProblem*>(table_dev), n_problems);
+  return cgv::check_launch("cgv_grouped_wgrad_split");
 }
 
 int cgv_grouped_wgrad_gathered(const void* table_dev, int n_problems, int total_blocks, void* stream) {

@@ -270,7 +270,9 @@ class WeightGradQueue:
                       tag="grouped_wgrad_strip")
         if large:
             buf, block_begin = bytearray(), 0
-            tile = wgrad_tile([(gy.shape[0], gy.shape[1], x.shape[1]) for gy, x, *_rest in large])
+            from .options import HOST
+            split = HOST["wgrad_split"] == 1
+            tile = 128 if split else wgrad_tile([(gy.shape[0], gy.shape[1], x.shape[1]) for gy, x, *_rest in large])
             for gy, x, z, act, gW, gb, accumulate in large:
                 M, N = gy.shape
                 K = x.shape[1]
@@ -281,8 +283,13 @@ class WeightGradQueue:
                                         block_begin, tk.value, 0, 0, 0, 0)
                 block_begin += nb.value
             table = self.upload(bytes(buf), dev)
-            _lib.call("cgv_grouped_wgrad_gathered_tile", _lib.ptr(table), len(large), block_begin, tile, _lib.stream_ptr(),
-                      tag="grouped_wgrad_tiles")
+            if split:
+                # bf16 matrix path with split operands (fp32-class accuracy, csrc/skinny_gemm.hip wgrad_split128_k)
+                _lib.call("cgv_grouped_wgrad_split", _lib.ptr(table), len(large), block_begin, _lib.stream_ptr(),
+                          tag="grouped_wgrad_tiles")
+            else:
+                _lib.call("cgv_grouped_wgrad_gathered_tile", _lib.ptr(table), len(large), block_begin, tile, _lib.stream_ptr(),
+                          tag="grouped_wgrad_tiles")
         # the operand tensors stay referenced by ``items`` until here; stream order protects their reuse
 
 

@@ -564,6 +564,11 @@ int cgv_grouped_wgrad_gathered(const void* table_dev, int n_problems, int total_
  * per gW element but measured slower on the shapes of this model -- an opt-in variant */
 int cgv_wgrad_gathered_plan_tile(int M, int N, int K, int seg_rows, int tile, int* tiles_k /*[host]*/, int* n_blocks /*[host]*/);
 int cgv_grouped_wgrad_gathered_tile(const void* table_dev, int n_problems, int total_blocks, int tile, void* stream);
+/* The same grouped weight gradients (table and plan of tile = 128) on the bf16 matrix path with SPLIT operands: every fp32
+ * operand value as the exact sum of three bf16 terms, six bf16 MFMA products per fp32 product, fp32 accumulation --
+ * fp32-class accuracy (dropped terms < 2^-23 of a product) at 3/8 of the fp32 MFMA time.  Replaces the autograd weight
+ * gradients of nn.Linear / Dense (modules.py Dense, conv.py:505-563 inv_dense) on layers with more than 128 operand rows. */
+int cgv_grouped_wgrad_split(const void* table_dev, int n_problems, int total_blocks, void* stream);
 /* Rank update over gathered operand rows with MFMA tiles -- for layers whose gathered row count is beyond the range in
  * which the FMA-per-row kernel (cgv_grouped_wgrad_adam) pays (~40 rows: 4+ data-parallel ranks of 12 bead rows, or the
  * 36-row [u_mat; v_mat] layers at 2+).  Same records and plan as cgv_grouped_wgrad_gathered (tile 64; accumulate = 0).

@@ -2273,3 +2273,36 @@ def test_bead_mean_inside_the_contractive_block_equals_separate_launches(workloa
         assert_close(a, b, f"encoder parameter gradient {k}", 2e-6)
         n_live += float(b.abs().max()) > 0
     assert n_live >= 10
+
+
+@pytest.mark.parametrize("M,N,K,act", [(332, 600, 600, 1), (704, 1800, 600, 1), (129, 132, 260, 0), (2000, 64, 600, 1), (161, 600, 36, 0)])
+def test_split_bf16_weight_gradients_have_fp32_accuracy(M, N, K, act, options):
+    """Weight gradients of layers with more than 128 operand rows (autograd of nn.Linear / Dense, modules.py; conv.py:505-563)
+    on the bf16 matrix path with SPLIT operands (csrc/skinny_gemm.hip wgrad_split128_k: three bf16 terms per fp32 value,
+    six products, fp32 accumulation) against fp64 -- and against the fp32 MFMA tiles: the error has to be of the same class
+    (north_star's tolerance is 1e-4; fp32 kernels sit at 1e-7).  Operands span 12 orders of magnitude (gradients are tiny,
+    activations are not): bf16 keeps the fp32 exponent range, nothing is scaled.  Write and accumulate."""
+    from coarsegrainingvae_amd.primitives import WeightGradQueue
+    gen = torch.Generator().manual_seed(M + N + K)
+    scale_rows = torch.logspace(-9, 0, M).unsqueeze(1)                      # per-row gradient magnitudes 1e-9 .. 1
+    gy = (torch.randn(M, N, generator=gen) * scale_rows).to(DEV)
+    x = (torch.randn(M, K, generator=gen) * torch.logspace(-3, 2, K).unsqueeze(0)).to(DEV)
+    z = torch.randn(M, N, generator=gen).to(DEV) if act else None
+    g64 = gy.double().cpu()
+    if act:
+        s = torch.sigmoid(z.double().cpu())
+        g64 = g64 * (s * (1 + z.double().cpu() * (1 - s)))
+    ref_W, ref_b = g64.t() @ x.double().cpu(), g64.sum(0)
+    q = WeightGradQueue()
+    errs = {}
+    for split in (0, 1):
+        options.set("wgrad_split", split)
+        gW, gb = torch.full((N, K), float("nan"), device=DEV), torch.full((N,), float("nan"), device=DEV)
+        q.launch([(gy, x, z, act, gW, gb, False)])
+        q.launch([(gy, x, z, act, gW, gb, True)])                            # accumulate: twice the gradient
+        # column-wise norm-relative error: every column of gW has its own magnitude (x's columns span 5 orders)
+        eW = ((gW.double().cpu() - 2 * ref_W).abs().amax(0) / (2 * ref_W).abs().amax(0)).max()
+        eb = (gb.double().cpu() - 2 * ref_b).abs().max() / (2 * ref_b).abs().max()
+        errs[split] = (float(eW), float(eb))
+    assert errs[1][0] < 2e-6 and errs[1][1] < 2e-6, errs
+    assert errs[1][0] < 4 * errs[0][0] + 1e-7, f"split path is not in the fp32 error class: {errs}"
