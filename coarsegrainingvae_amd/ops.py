@@ -452,10 +452,11 @@ class _PseudoMessage(torch.autograd.Function):
         if plan.n_edges >= 16 * n:
             # dense bead graph: the per-filter kernels want all four upstream gradients (a layer whose scalar outputs go
             # unused -- the decoder's last -- would otherwise take the general kernels: 112 against ~65 us there)
-            gh = gh if gh is not None else torch.zeros_like(s)
-            ghb = ghb if ghb is not None else torch.zeros_like(s)
-            gv = gv if gv is not None else torch.zeros_like(v)
-            gvb = gvb if gvb is not None else torch.zeros_like(v)
+            # (read-only: one cached zero tensor per shape instead of a fill launch per step)
+            gh = gh if gh is not None else _zeros_const(s)
+            ghb = ghb if ghb is not None else _zeros_const(s)
+            gv = gv if gv is not None else _zeros_const(v)
+            gvb = gvb if gvb is not None else _zeros_const(v)
         g_phi = torch.empty_like(phi)
         g_s, g_sbar = torch.empty_like(s), torch.empty_like(s)
         g_v, g_vbar = torch.empty_like(v), torch.empty_like(v)
@@ -485,6 +486,18 @@ class _PseudoMessage(torch.autograd.Function):
                   _lib.ptr(gWd), _lib.ptr(gbd), n, F, geom.n_rbf, int(ctx.residual), plan.n_edges, _lib.ptr(ws), ws_bytes, _lib.stream_ptr(),
                   tag=f"pseudo_msg_bwd:Nd{n}:E{plan.n_edges}:gv1")
         return g_phi, g_s, g_sbar, g_v, g_vbar, ret_W, ret_b, None, None, None
+
+
+_ZEROS = {}
+
+
+def _zeros_const(like: torch.Tensor) -> torch.Tensor:
+    """A cached all-zero tensor of ``like``'s shape for kernels that only READ it (an absent upstream gradient)."""
+    key = (tuple(like.shape), str(like.device))
+    t = _ZEROS.get(key)
+    if t is None:
+        t = _ZEROS[key] = torch.zeros(like.shape, dtype=_F32, device=like.device)
+    return t
 
 
 def pseudo_message(phi, s, sbar, v, vbar, Wd, bd, plan: EdgePlan, geom: EdgeGeometry, residual: bool = False):

@@ -748,7 +748,9 @@ def dual_heads(head_a, head_b, x, out_act_a: int = ACT_NONE, out_act_b: int = AC
         if pair_linear_usable(ha, hb, ma[2], mb[2]):
             return _PairLinearFn.apply(ha, hb, ma[2].weight, ma[2].bias, mb[2].weight, mb[2].bias, out_act_a, out_act_b)
         return _LinearFn.apply(ha, ma[2].weight, ma[2].bias, out_act_a), _LinearFn.apply(hb, mb[2].weight, mb[2].bias, out_act_b)
-    return head_a(x, out_act=out_act_a), head_b(x, out_act=out_act_b)
+    # too many rows for the paired kernels (a large bead batch): the second head reads x through the first head's fork
+    ya, x_alias = head_a(x, out_act=out_act_a, fork=True)
+    return ya, head_b(x_alias, out_act=out_act_b)
 
 
 def wgrad_tile(shapes) -> int:
@@ -846,16 +848,24 @@ class MLPHead(nn.Sequential):
     product's epilogue and into its backward (no tanh / relu / their-backward launches)."""
     _CODES = {nn.Tanh: ACT_TANH, nn.ReLU: ACT_RELU, Swish: ACT_SWISH}
 
-    def forward(self, x, out_act: int = ACT_NONE):
+    def forward(self, x, out_act: int = ACT_NONE, fork: bool = False):
         """``out_act``: activation fused into the LAST product's epilogue and backward -- the ``c + exp(z/2)`` of the
-        sigma / prior-std heads (ACT_STD_ENC / ACT_STD_PRIOR), which as tensor ops cost six launches per head and step."""
+        sigma / prior-std heads (ACT_STD_ENC / ACT_STD_PRIOR), which as tensor ops cost six launches per head and step.
+        ``fork=True`` returns (output, alias of ``x``) for a second head on the same state: its gradient comes back through
+        this head's first backward-input product instead of an accumulation launch (``_LinearFn.forward(fork=True)``)."""
         mods = list(self)
         if (len(mods) == 3 and isinstance(mods[0], nn.Linear) and type(mods[1]) in self._CODES
                 and isinstance(mods[2], nn.Linear) and x.is_cuda):
-            y = _LinearFn.apply(x, mods[0].weight, mods[0].bias, self._CODES[type(mods[1])])
-            return _LinearFn.apply(y, mods[2].weight, mods[2].bias, out_act)
+            alias = x
+            if fork and x.requires_grad and torch.is_grad_enabled():
+                y, alias = _LinearFn.apply(x, mods[0].weight, mods[0].bias, self._CODES[type(mods[1])], True)
+            else:
+                y = _LinearFn.apply(x, mods[0].weight, mods[0].bias, self._CODES[type(mods[1])])
+            out = _LinearFn.apply(y, mods[2].weight, mods[2].bias, out_act)
+            return (out, alias) if fork else out
         y = super().forward(x)
-        return y if out_act == ACT_NONE else _STD_EPS[out_act] + torch.exp(y / 2)
+        y = y if out_act == ACT_NONE else _STD_EPS[out_act] + torch.exp(y / 2)
+        return (y, x) if fork else y
 
 
 class Dense(nn.Linear):

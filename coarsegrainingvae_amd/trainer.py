@@ -356,7 +356,9 @@ class OperandExchange:
         buf, block_begin = bytearray(), 0
         tk, nb = C.c_int(), C.c_int()
         from .primitives import wgrad_tile
-        tile = wgrad_tile([(self.world * m[0], m[1], m[2]) for m in problems])
+        from .options import HOST
+        split = HOST["wgrad_split"] == 1                      # bf16 matrix path with split operands (primitives.WeightGradQueue.launch)
+        tile = 128 if split else wgrad_tile([(self.world * m[0], m[1], m[2]) for m in problems])
         for M, N, K, off_g, off_x, gW, gb, accumulate, recv, total in problems:
             if lib.cgv_wgrad_gathered_plan_tile(self.world * M, N, K, M, tile, C.byref(tk), C.byref(nb)) != 0:
                 raise RuntimeError(lib.cgv_last_error_string().decode())
@@ -365,8 +367,11 @@ class OperandExchange:
                             block_begin, tk.value, 0, M, total, 0)
             block_begin += nb.value
         table = self.queue.upload(bytes(buf), problems[0][8].device)
-        _lib.call("cgv_grouped_wgrad_gathered_tile", _lib.ptr(table), len(problems), block_begin, tile, _lib.stream_ptr(),
-                  tag="gathered_wgrad")
+        if split:
+            _lib.call("cgv_grouped_wgrad_split", _lib.ptr(table), len(problems), block_begin, _lib.stream_ptr(), tag="gathered_wgrad")
+        else:
+            _lib.call("cgv_grouped_wgrad_gathered_tile", _lib.ptr(table), len(problems), block_begin, tile, _lib.stream_ptr(),
+                      tag="gathered_wgrad")
 
 
 class Trainer:
