@@ -94,6 +94,7 @@ class GradSync:
     the unfused path)."""
 
     WATCHDOG_GRACE_S = 0.35       # see drain()
+    _grace_logged = False
 
     def __init__(self, world_size: int, group=None, bucket_bytes: int = 64 << 20):
         import torch.distributed as dist
@@ -185,6 +186,14 @@ class GradSync:
             # to pull in.  HIP refuses a query on an event whose stream is capturing (hipErrorCapturedEvent), the watchdog
             # thread throws and the process aborts: seen once in ~30 captures of tests/test_dp_rccl_single.py.  That includes
             # the synchronous collectives (same_on_all_ranks, mean_scalar) this object does not keep handles of.
+            # Bounded and logged: 3.5 of the watchdog's 100 ms passes (torch's kWatchdogThreadSleepMillis; there is no call
+            # that waits for a pass, and the thread can only be configured through the environment before the group exists).
+            if not GradSync._grace_logged:
+                GradSync._grace_logged = True
+                import logging
+                logging.getLogger("coarsegrainingvae_amd").info(
+                    "capture with RCCL collectives: waiting %.2f s for the process group's watchdog to drop finished work "
+                    "(GradSync.WATCHDOG_GRACE_S; once per capture, never inside a step)", self.WATCHDOG_GRACE_S)
             time.sleep(self.WATCHDOG_GRACE_S)
 
     def mean_scalar(self, x: torch.Tensor) -> torch.Tensor:
