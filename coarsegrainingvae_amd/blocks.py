@@ -81,12 +81,16 @@ class EquiMessageBlock(nn.Module):
         self.with_dv = True     # set False to skip the (dead) vector channel explicitly
 
     def forward(self, s_j, v_j, r_ij, nbrs, edge_wgt=None, plan: Optional[EdgePlan] = None,
-                geom: Optional[EdgeGeometry] = None, residual: bool = False):
+                geom: Optional[EdgeGeometry] = None, residual: bool = False, phi=None):
         """``residual=True`` returns the updated states (s_j + ds, v_j + dv) from the same launch.  ``edge_wgt`` [E]
-        (conv.py:527-533; never passed on the run_ala path) weights every edge's message: ``EdgeGeometry.scaled``."""
+        (conv.py:527-533; never passed on the run_ala path) weights every edge's message: ``EdgeGeometry.scaled``.
+        ``phi``: the node features ``inv_dense(s_j)`` computed by the caller (a pair launch with the previous contractive
+        block's node MLP, model.EquiEncoder); ``s_j`` is then the alias that launch returned."""
         im = self.inv_message
         plan, geom = _resolve(plan, geom, nbrs, s_j.shape[0], r_ij, im.n_rbf, im.cutoff, edge_wgt)
         Wd, bd = im.dist_embed.filter_params()
+        if phi is not None:
+            return ops.equi_message(phi, v_j, Wd, bd, plan, geom, self.with_dv, s_j if residual else None, v_j if residual else None)
         if residual:
             phi, s_res = im.node_features_fork(s_j)              # the residual reads the state through the fork
         else:
@@ -163,6 +167,33 @@ class ContractiveMessageBlock(nn.Module):
                 s_res, v_res = ops.segment_reduce2(s_i, v_i, plan, mean=True, slot=slot)
             return ops.equi_message(self.inv_dense[1](a), v_i, Wd, bd, plan, geom, self.with_dv, s_res, v_res) + (s_alias,)
         return ops.equi_message(self.inv_dense(s_i), v_i, Wd, bd, plan, geom, self.with_dv, s_res, v_res)
+
+
+def contractive_pair(cblock, mblock, s_i, v_i, mapping, plan, geom, residual, mean_init: bool):
+    """ContractiveMessageBlock ``cblock`` on (s_i, v_i) with its node MLP paired, layer by layer, with the node MLP of the
+    NEXT message block ``mblock`` on the same atom state (cgvae.py:286-305: both read h after message block i).  Returns
+    (H, V, alias of s_i, phi of ``mblock``) -- or None when the pair launch does not apply (the caller takes the blocks
+    one by one)."""
+    from .primitives import tile_pair, tile_pair_usable
+    c0, c1 = cblock.inv_dense[0], cblock.inv_dense[1]
+    m0, m1 = mblock.inv_message.inv_dense[0], mblock.inv_message.inv_dense[1]
+    if not (s_i.requires_grad and torch.is_grad_enabled() and tile_pair_usable(s_i, s_i, c0, m0)):
+        return None
+    slot = None
+    if mean_init:
+        slot = ops.SegmentGradSlot(plan, mapping, mean=True)
+        slot = slot if slot.usable() else None
+    a_c, a_m, s_alias = tile_pair(s_i, s_i, c0, m0, slot)
+    if not tile_pair_usable(a_c, a_m, c1, m1):
+        phi_c, phi_m = c1(a_c), m1(a_m)
+    else:
+        phi_c, phi_m, _unused = tile_pair(a_c, a_m, c1, m1)
+    s_res, v_res = residual if residual is not None else (None, None)
+    if mean_init:                                        # created after the node MLP: its backward runs before the MLP's
+        s_res, v_res = ops.segment_reduce2(s_i, v_i, plan, mean=True, slot=slot)
+    Wd, bd = cblock.dist_embed.filter_params()
+    H, V = ops.equi_message(phi_c, v_i, Wd, bd, plan, geom, cblock.with_dv, s_res, v_res)
+    return H, V, s_alias, phi_m
 
 
 class EquiMessagePsuedo(nn.Module):

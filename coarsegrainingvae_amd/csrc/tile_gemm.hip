@@ -51,11 +51,19 @@ __device__ __forceinline__ void static_for(F&& f) {
 // problems with few tiles (every SIMD needs loads in flight); <2,2,4>: 64 x 64 tiles when there are enough of
 // them -- the four quadrants share operand rows through L1, halving the L2 traffic per flop.
 // Epilogue: all waves drop their accumulators in LDS, then wave kq of a quadrant finishes sub-tile kq (KW >= 4).
+// The SECOND problem of a pair launch: two layers of one shape (M, N, K, act) in one grid -- the extra grid dimension
+// selects the operands.  Two atom-level layers that are ready at the same time (the first Dense of contractive block i and
+// of message block i + 1 read the same state, cgvae.py:286-305; their second layers follow together) then cost one launch
+// boundary, and the launch has twice the tiles to fill the chip with.  All pointers NULL: an ordinary single launch.
+struct TileSecond { const float* x; const float* W; const float* bias; float* y; float* z; };
+
 template <int QM, int QN, int KW>
 __global__ __launch_bounds__(64 * QM * QN * KW) void tile_fwd_k(const float* __restrict__ x, const float* __restrict__ W,
                                                                  const float* __restrict__ bias, float* __restrict__ y,
-                                                                 float* __restrict__ zout, int M, int N, int K, int act) {
+                                                                 float* __restrict__ zout, int M, int N, int K, int act,
+                                                                 TileSecond s2 = TileSecond{nullptr, nullptr, nullptr, nullptr, nullptr}) {
   static_assert(KW >= 4, "the epilogue spreads the 4 sub-tiles of a quadrant over the k-slice waves");
+  if (blockIdx.z) { x = s2.x; W = s2.W; bias = s2.bias; y = s2.y; zout = s2.z; }
   __shared__ float red[QM * QN][KW][4][4][64];       // [quadrant][k-slice][sub-tile][reg][lane]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -157,8 +165,10 @@ __global__ __launch_bounds__(64 * QM * QN * KW) void tile_fwd_k(const float* __r
 template <int MT, int NT>
 __global__ __launch_bounds__(512) void tile_fwd_bal_k(const float* __restrict__ x, const float* __restrict__ W,
                                                       const float* __restrict__ bias, float* __restrict__ y,
-                                                      float* __restrict__ zout, int M, int N, int K, int act, int MB, int NB) {
+                                                      float* __restrict__ zout, int M, int N, int K, int act, int MB, int NB,
+                                                      TileSecond s2 = TileSecond{nullptr, nullptr, nullptr, nullptr, nullptr}) {
   constexpr int KW = 8, TT = MT * NT;
+  if (blockIdx.y) { x = s2.x; W = s2.W; bias = s2.bias; y = s2.y; zout = s2.z; }
   // LDS for the cross-wave sum: two rounds (waves 4-7 hand over, then waves 0-3) keep it at 4 x TT KB
   extern __shared__ __attribute__((aligned(16))) float bal_red[];      // [4][TT][4][64]
   const int lane = threadIdx.x & 63;
@@ -495,6 +505,7 @@ __global__ __launch_bounds__(256, 2) void tile_fwd_ring_k(const float* __restric
 // A THIRD gradient of the same input, held as one row per SEGMENT of the rows (the backward of
 // scatter_mean / scatter_add of this very input, cgvae.py:297: g[m, :] += src[seg(m), :] (/ len(seg(m)) for the mean)):
 // added in the store epilogue instead of by a broadcast launch + an accumulation add.
+struct BwdSecond { const float* g; const float* W; float* gx; const float* z; const float* add; };   // see TileSecond
 struct BcastAdd {
   const float* src;          // [n_seg, K] or NULL
   const int64_t* row2seg;    // [M] segment of every row (the CG mapping)
@@ -507,7 +518,9 @@ __global__ __launch_bounds__(64 * WAVES) void tile_bwd_input_k(const float* __re
                                                         float* __restrict__ gx, int M, int N, int K,
                                                         const float* __restrict__ z, int act,
                                                         const float* __restrict__ add = nullptr,
-                                                        BcastAdd bc = BcastAdd{nullptr, nullptr, nullptr, 0}) {
+                                                        BcastAdd bc = BcastAdd{nullptr, nullptr, nullptr, 0},
+                                                        BwdSecond s2 = BwdSecond{nullptr, nullptr, nullptr, nullptr, nullptr}) {
+  if (blockIdx.z) { g = s2.g; W = s2.W; gx = s2.gx; z = s2.z; add = s2.add; bc.src = nullptr; }
   __shared__ float red[WAVES - 1][MB * 4][4][64];    // [wave-1][mb*4 + s][reg][lane]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -681,13 +694,14 @@ int cgv_tile_supported(int M, int N, int K) {
          (int64_t)M * K < (1ll << 31) && (int64_t)N * K < (1ll << 31);
 }
 
-int cgv_tile_linear_fwd(const float* x, const float* W, const float* bias, float* y, float* z, int M, int N, int K, int act,
-                        void* stream) {
-  CGV_REQUIRE(x && W && y, "null pointer");
-  CGV_REQUIRE(act >= 0 && act <= cgv::CGV_ACT_MAX, "act must be 0 (identity), 1 (swish), 2 (tanh), 3 (relu), 4 / 5 (c + exp(z/2))");
-  CGV_REQUIRE(cgv_tile_supported(M, N, K), "unsupported shape (need N % 4 == 0, K % 4 == 0)");
-  CGV_REQUIRE(((((uintptr_t)x | (uintptr_t)W)) & 15) == 0, "x and W must be 16-byte aligned");
+/* ``second`` != NULL: a pair launch (TileSecond).  Only the register-tile kernels take one; *pair_ok = 0 (nothing launched)
+ * tells the caller that this shape runs on the LDS-staged kernels. */
+static int tile_fwd_launch(const float* x, const float* W, const float* bias, float* y, float* z, int M, int N, int K, int act,
+                           void* stream, const cgv::TileSecond* second, int* pair_ok) {
   hipStream_t st = (hipStream_t)stream;
+  const cgv::TileSecond s2 = second ? *second : cgv::TileSecond{nullptr, nullptr, nullptr, nullptr, nullptr};
+  const unsigned np = second ? 2u : 1u;
+  if (pair_ok) *pair_ok = 1;
   const int tiles32 = ((N + 31) / 32) * ((M + 31) / 32);
   const int tiles64 = ((N + 63) / 64) * ((M + 63) / 64);
   const int lds_min = cgv::option(CGV_OPT_TILE_FWD_LDS_MIN);
@@ -706,13 +720,13 @@ int cgv_tile_linear_fwd(const float* x, const float* W, const float* bias, float
     int mt = 0, nt = 0;
     if (cgv::bal_pick(M, N, &mt, &nt)) {
       const int MB = (M + 16 * mt - 1) / (16 * mt), NB = (N + 16 * nt - 1) / (16 * nt);
-      const dim3 grid(8 * ((MB * NB + 7) / 8));
+      const dim3 grid(8 * ((MB * NB + 7) / 8), np);
       const size_t lds = (size_t)4 * mt * nt * 1024;
 #define CGV_BAL(A, B)                                                                                                      \
   if (mt == A && nt == B) {                                                                                                \
     if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(cgv::tile_fwd_bal_k<A, B>),                     \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
-    hipLaunchKernelGGL((cgv::tile_fwd_bal_k<A, B>), grid, dim3(512), lds, st, x, W, bias, y, z, M, N, K, act, MB, NB);     \
+    hipLaunchKernelGGL((cgv::tile_fwd_bal_k<A, B>), grid, dim3(512), lds, st, x, W, bias, y, z, M, N, K, act, MB, NB, s2); \
     return cgv::check_launch("cgv_tile_linear_fwd");                                                                       \
   }
       CGV_BAL(2, 2) CGV_BAL(2, 3) CGV_BAL(3, 2) CGV_BAL(3, 3) CGV_BAL(2, 4) CGV_BAL(4, 2) CGV_BAL(2, 5) CGV_BAL(3, 4)
@@ -722,6 +736,10 @@ int cgv_tile_linear_fwd(const float* x, const float* W, const float* bias, float
   }
   const int slabs32 = (K + 31) / 32;
   const bool ring_ok = aligned16 && (slabs32 == 19 || slabs32 == 38) && lds_min != 1 && !(lds_min >= 5 && lds_min <= 7);
+  const bool staged = (ring_ok && (tiles64 >= lds_min || lds_min == 3)) ||
+                      (tiles64 >= lds_min && (M >= 1024 || lds_min <= 1) && aligned16 && !(lds_min >= 5 && lds_min <= 7)) ||
+                      (lds_min >= 5 && lds_min <= 7);
+  if (second && staged) { *pair_ok = 0; return 0; }
   if (ring_ok && (tiles64 >= lds_min || lds_min == 3)) {
     const dim3 grid((N + 63) / 64, (M + 63) / 64);
     if (slabs32 == 19) hipLaunchKernelGGL((cgv::tile_fwd_ring_k<19>), grid, dim3(256), 0, st, x, W, bias, y, z, M, N, K, act);
@@ -736,18 +754,64 @@ int cgv_tile_linear_fwd(const float* x, const float* W, const float* bias, float
   else if (lds_min == 7)                       /* A/B: 64 x 64 tiles, 16 waves */
     hipLaunchKernelGGL((cgv::tile_fwd_k<2, 2, 4>), dim3((N + 63) / 64, (M + 63) / 64), dim3(1024), 0, st, x, W, bias, y, z, M, N, K, act);
   else if (tiles32 >= 2048)                    // enough work for several 64 x 64 tiles on every CU (measured: no gain below)
-    hipLaunchKernelGGL((cgv::tile_fwd_k<2, 2, 4>), dim3((N + 63) / 64, (M + 63) / 64), dim3(1024), 0, st, x, W, bias, y, z, M,
-                       N, K, act);
+    hipLaunchKernelGGL((cgv::tile_fwd_k<2, 2, 4>), dim3((N + 63) / 64, (M + 63) / 64, np), dim3(1024), 0, st, x, W, bias, y, z, M,
+                       N, K, act, s2);
   else                                    // few tiles: 32 x 32, reduction split 8 ways so every SIMD has loads in flight
-    hipLaunchKernelGGL((cgv::tile_fwd_k<1, 1, 8>), dim3((N + 31) / 32, (M + 31) / 32), dim3(512), 0, st, x, W, bias, y, z, M,
-                       N, K, act);
+    hipLaunchKernelGGL((cgv::tile_fwd_k<1, 1, 8>), dim3((N + 31) / 32, (M + 31) / 32, np), dim3(512), 0, st, x, W, bias, y, z, M,
+                       N, K, act, s2);
   return cgv::check_launch("cgv_tile_linear_fwd");
+}
+
+int cgv_tile_linear_fwd(const float* x, const float* W, const float* bias, float* y, float* z, int M, int N, int K, int act,
+                        void* stream) {
+  CGV_REQUIRE(x && W && y, "null pointer");
+  CGV_REQUIRE(act >= 0 && act <= cgv::CGV_ACT_MAX, "act must be 0 (identity), 1 (swish), 2 (tanh), 3 (relu), 4 / 5 (c + exp(z/2))");
+  CGV_REQUIRE(cgv_tile_supported(M, N, K), "unsupported shape (need N % 4 == 0, K % 4 == 0)");
+  CGV_REQUIRE(((((uintptr_t)x | (uintptr_t)W)) & 15) == 0, "x and W must be 16-byte aligned");
+  return tile_fwd_launch(x, W, bias, y, z, M, N, K, act, stream, nullptr, nullptr);
+}
+
+/* Two layers of ONE shape in one launch: y_a = act(x_a W_a^T + b_a), y_b = act(x_b W_b^T + b_b) (x_a may equal x_b).
+ * Returns CGV_E_UNSUPPORTED-style non-zero with nothing launched when the shape runs on the LDS-staged kernels
+ * (cgv_tile_pair_supported tells beforehand). */
+int cgv_tile_pair_supported(int M, int N, int K) {
+  if (!cgv_tile_supported(M, N, K)) return 0;
+  const int tiles64 = ((N + 63) / 64) * ((M + 63) / 64);
+  const int lds_min = cgv::option(CGV_OPT_TILE_FWD_LDS_MIN);
+  const int tiles32 = ((N + 31) / 32) * ((M + 31) / 32);
+  if (const int bal = cgv::option(CGV_OPT_TILE_FWD_BAL); bal == 2 || (bal == 1 && tiles32 > 256 && N >= 1200)) {
+    int mt = 0, nt = 0;
+    if (cgv::bal_pick(M, N, &mt, &nt)) return 1;
+  }
+  const int slabs32 = (K + 31) / 32;
+  const bool ring = (slabs32 == 19 || slabs32 == 38) && lds_min != 1 && (tiles64 >= lds_min || lds_min == 3);
+  const bool lds1 = tiles64 >= lds_min && (M >= 1024 || lds_min <= 1);
+  return !(ring || lds1 || (lds_min >= 5 && lds_min <= 7));
+}
+
+int cgv_tile_pair_linear_fwd(const float* x_a, const float* W_a, const float* bias_a, float* y_a, float* z_a, const float* x_b,
+                             const float* W_b, const float* bias_b, float* y_b, float* z_b, int M, int N, int K, int act,
+                             void* stream) {
+  CGV_REQUIRE(x_a && W_a && y_a && x_b && W_b && y_b, "null pointer");
+  CGV_REQUIRE(act >= 0 && act <= cgv::CGV_ACT_MAX, "act must be 0 (identity), 1 (swish), 2 (tanh), 3 (relu), 4 / 5 (c + exp(z/2))");
+  CGV_REQUIRE(act == 0 || (z_a && z_b), "act != 0 needs both pre-activation outputs");
+  CGV_REQUIRE(cgv_tile_supported(M, N, K), "unsupported shape (need N % 4 == 0, K % 4 == 0)");
+  CGV_REQUIRE(((((uintptr_t)x_a | (uintptr_t)W_a | (uintptr_t)x_b | (uintptr_t)W_b | (uintptr_t)y_a | (uintptr_t)y_b |
+                 (uintptr_t)z_a | (uintptr_t)z_b | (uintptr_t)bias_a | (uintptr_t)bias_b)) & 15) == 0, "operands must be 16-byte aligned");
+  const cgv::TileSecond s2{x_b, W_b, bias_b, y_b, z_b};
+  int ok = 1;
+  const int rc = tile_fwd_launch(x_a, W_a, bias_a, y_a, z_a, M, N, K, act, stream, &s2, &ok);
+  if (!ok) { cgv::set_error("cgv_tile_pair_linear_fwd: this shape runs on the LDS-staged kernels (no pair launch)"); return CGV_E_UNSUPPORTED; }
+  return rc;
 }
 
 static int tile_bwd_input_launch(const float* g, const float* z, int act, const float* W, float* gx, int M, int N, int K,
                                  void* stream, const char* what, const float* add = nullptr,
-                                 cgv::BcastAdd bc = cgv::BcastAdd{nullptr, nullptr, nullptr, 0}) {
+                                 cgv::BcastAdd bc = cgv::BcastAdd{nullptr, nullptr, nullptr, 0},
+                                 const cgv::BwdSecond* second = nullptr) {
   hipStream_t st = (hipStream_t)stream;
+  const cgv::BwdSecond s2 = second ? *second : cgv::BwdSecond{nullptr, nullptr, nullptr, nullptr, nullptr};
+  const unsigned np = second ? 2u : 1u;
   const int kt = (K + 63) / 64;
   const int blocks32 = kt * ((M + 31) / 32);
   const int blocks16 = kt * ((M + 15) / 16);
@@ -755,19 +819,19 @@ static int tile_bwd_input_launch(const float* g, const float* z, int act, const 
   if (const int o = cgv::option(CGV_OPT_BWD_INPUT_WAVES); o > 0 && o != 32) waves = o;          // experiments only
   else if (blocks16 < 128 && N >= 1024) waves = 16;
   if (cgv::option(CGV_OPT_BWD_INPUT_WAVES) == 32)          /* A/B: 32-row tiles, 8 waves */
-    hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 8>), dim3(kt, (M + 31) / 32), dim3(512), 0, st, g, W, gx, M, N, K, z, act, add, bc);
+    hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 8>), dim3(kt, (M + 31) / 32, np), dim3(512), 0, st, g, W, gx, M, N, K, z, act, add, bc, s2);
   else if (blocks32 >= 200 && blocks32 < 512 && waves == 8)
     // 200 .. 511 32-row tiles (704 rows x 600 / 1200 columns): still 32-row tiles, with the reduction split over 8 waves --
     // half the weight re-reads of the 16-row tiles (704 x 1800 x 600: 22.9 against 25.0 us, 704 x 5400: 54.6 / 64.1;
     // at 332 rows the 16-row tiles win, 14.5 against 22.1 us: tools/gemm_shapes.py)
-    hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 8>), dim3(kt, (M + 31) / 32), dim3(512), 0, st, g, W, gx, M, N, K, z, act, add, bc);
+    hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 8>), dim3(kt, (M + 31) / 32, np), dim3(512), 0, st, g, W, gx, M, N, K, z, act, add, bc, s2);
   else if (blocks32 >= 512)               // enough 32-row tiles to fill the chip: halve the weight re-reads
-    hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 4>), dim3(kt, (M + 31) / 32), dim3(256), 0, st, g, W, gx, M, N, K, z, act, add, bc);
+    hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 4>), dim3(kt, (M + 31) / 32, np), dim3(256), 0, st, g, W, gx, M, N, K, z, act, add, bc, s2);
   else if (waves == 16)                   // few output tiles and a long reduction (96 bead rows x 5400 columns: 60 blocks):
     // 16 waves per block split it -- 60 blocks of 8 waves left three quarters of the chip idle (17.8 us per call)
-    hipLaunchKernelGGL((cgv::tile_bwd_input_k<1, 16>), dim3(kt, (M + 15) / 16), dim3(1024), 0, st, g, W, gx, M, N, K, z, act, add, bc);
+    hipLaunchKernelGGL((cgv::tile_bwd_input_k<1, 16>), dim3(kt, (M + 15) / 16, np), dim3(1024), 0, st, g, W, gx, M, N, K, z, act, add, bc, s2);
   else
-    hipLaunchKernelGGL((cgv::tile_bwd_input_k<1, 8>), dim3(kt, (M + 15) / 16), dim3(512), 0, st, g, W, gx, M, N, K, z, act, add, bc);
+    hipLaunchKernelGGL((cgv::tile_bwd_input_k<1, 8>), dim3(kt, (M + 15) / 16, np), dim3(512), 0, st, g, W, gx, M, N, K, z, act, add, bc, s2);
   return cgv::check_launch(what);
 }
 
@@ -810,6 +874,21 @@ int cgv_tile_linear_bwd_input_act_add_bcast(const float* gy, const float* z, con
               "operands must be 16-byte aligned");
   return tile_bwd_input_launch(gy, act ? z : nullptr, act, W, gx, M, N, K, stream, "cgv_tile_linear_bwd_input_act_add_bcast", add,
                                cgv::BcastAdd{seg_grad, row2seg, seg_rowptr, mean});
+}
+
+/* The backward-input products of two layers of ONE shape in one launch: gx_a = add_a + (gy_a * act'(z_a)) W_a, likewise b
+ * (add_* may be NULL; outputs must not alias). */
+int cgv_tile_pair_linear_bwd_input(const float* gy_a, const float* z_a, const float* W_a, const float* add_a, float* gx_a,
+                                   const float* gy_b, const float* z_b, const float* W_b, const float* add_b, float* gx_b, int M,
+                                   int N, int K, int act, void* stream) {
+  CGV_REQUIRE(gy_a && W_a && gx_a && gy_b && W_b && gx_b && gx_a != gx_b, "null pointer / aliased outputs");
+  CGV_REQUIRE(act == 0 || (act >= 1 && act <= cgv::CGV_ACT_MAX && z_a && z_b), "act != 0 needs the saved pre-activations");
+  CGV_REQUIRE(cgv_tile_supported(M, N, K), "unsupported shape (need N % 4 == 0, K % 4 == 0)");
+  CGV_REQUIRE(((((uintptr_t)gy_a | (uintptr_t)z_a | (uintptr_t)W_a | (uintptr_t)gx_a | (uintptr_t)add_a | (uintptr_t)gy_b |
+                 (uintptr_t)z_b | (uintptr_t)W_b | (uintptr_t)gx_b | (uintptr_t)add_b)) & 15) == 0, "operands must be 16-byte aligned");
+  const cgv::BwdSecond s2{gy_b, W_b, gx_b, act ? z_b : nullptr, add_b};
+  return tile_bwd_input_launch(gy_a, act ? z_a : nullptr, act, W_a, gx_a, M, N, K, stream, "cgv_tile_pair_linear_bwd_input", add_a,
+                               cgv::BcastAdd{nullptr, nullptr, nullptr, 0}, &s2);
 }
 
 int cgv_tile_linear_wgrad(const float* g, const float* x, float* gW, int M, int N, int K, int accumulate, void* stream) {

@@ -17,7 +17,7 @@ from torch import nn
 from . import ops
 from .ktimer import mark
 from .options import HOST
-from .blocks import (ContractiveMessageBlock, EquiMessageBlock, EquiMessageCross, EquiMessagePsuedo, PseudoUpdateBlock,
+from .blocks import (ContractiveMessageBlock, contractive_pair, EquiMessageBlock, EquiMessageCross, EquiMessagePsuedo, PseudoUpdateBlock,
                      UpdateBlock)
 from .graph import BatchGraph, EdgePlan, make_directed
 from .primitives import (ACT_STD_ENC, ACT_STD_PRIOR, Dense, DistanceEmbed, Linear, MLPHead, dual_heads, mark_direct_grad, quad_heads,
@@ -185,13 +185,22 @@ class EquiEncoder(nn.Module):
         h = ops.embedding(self.atom_embed, z, graph.embed_plan("atom", z, self.atom_embed) if graph is not None else None)
         v = _constant((h.shape[0], h.shape[1], 3), 0.0, h.device)
         H = V = None
+        phi_next = None                                   # node features of message block i, from a pair launch of layer i - 1
         for i in range(self.n_conv):
             # h += ds, v += dv (cgvae.py:287-288) and H += dH, V += dV (cgvae.py:309-310) fused into the kernels
             h_in = h
             if layer_hooks and i in layer_hooks and h.requires_grad:
                 h_in = h.view_as(h)                       # private node: its gradient is the last one of layers >= i
                 h_in.register_hook(_call_then_pass(layer_hooks[i]))
-            h, v = self.message_blocks[i](h_in, v, None, graph.atom_nbrs, plan=graph.atom, geom=geom, residual=True)
+            h, v = self.message_blocks[i](h_in, v, None, graph.atom_nbrs, plan=graph.atom, geom=geom, residual=True, phi=phi_next)
+            phi_next = None
+            if HOST["encoder_pairs"] and not layer_hooks and i + 1 < self.n_conv and (i > 0 or HOST["fused_bead_mean"]):
+                # contractive block i and message block i + 1 read the same h: their node MLPs as pair launches
+                out = contractive_pair(self.cgmessage_layers[i], self.message_blocks[i + 1], h, v, graph.mapping, graph.a2b, geom_c,
+                                       (H, V) if H is not None else None, mean_init=H is None)
+                if out is not None:
+                    H, V, h, phi_next = out
+                    continue
             if i == 0 and not HOST["fused_bead_mean"]:
                 H = ops.scatter_mean(h, graph.mapping, plan=graph.a2b)
                 V = ops.scatter_mean(v, graph.mapping, plan=graph.a2b)

@@ -584,6 +584,136 @@ class _PairLinearFn(torch.autograd.Function):
         return (shape_a if need_xa else None, (gxb if need_xb else None), grads_w[0], grads_w[1], grads_w[2], grads_w[3], None, None)
 
 
+class _TilePairFn(torch.autograd.Function):
+    """Two Dense layers of ONE shape with more rows than the skinny kernels take (the atom level) as one forward launch
+    (``cgv_tile_pair_linear_fwd``): the first Dense of contractive block i and of message block i + 1 read the same state
+    (cgvae.py:286-305), their second layers follow together.  ``x_b is x_a`` (first layers): backward sums both input
+    gradients, the alias's and a parked segment gradient (``slot``) through the chain of backward-input epilogues -- two
+    launches, no accumulation add; different inputs (second layers): ONE backward-input launch for both
+    (``cgv_tile_pair_linear_bwd_input``).  Weight / bias gradients go to the trainer's grouped queue as ``_LinearFn``'s do.
+    Returns (y_a, y_b, alias of x_a): hand the alias to whatever else consumes the state."""
+
+    @staticmethod
+    def forward(ctx, x_a, x_b, w_a, b_a, w_b, b_b, act, slot):
+        same = x_b is x_a
+        xa = x_a.reshape(-1, x_a.shape[-1]).contiguous()
+        xb = xa if same else x_b.reshape(-1, x_b.shape[-1]).contiguous()
+        M, K = xa.shape
+        N = w_a.shape[0]
+        new = lambda: torch.empty(M, N, dtype=torch.float32, device=xa.device)
+        ya, yb = new(), new()
+        za, zb = (new(), new()) if act else (None, None)
+        _lib.call("cgv_tile_pair_linear_fwd", _lib.ptr(xa), _lib.ptr(w_a), _lib.ptr(b_a), _lib.ptr(ya), _lib.ptr(za), _lib.ptr(xb),
+                  _lib.ptr(w_b), _lib.ptr(b_b), _lib.ptr(yb), _lib.ptr(zb), M, N, K, int(act), _lib.stream_ptr())
+        ctx.params, ctx.act, ctx.same, ctx.slot = (w_a, b_a, w_b, b_b), int(act), same, slot
+        if slot is not None:
+            slot.armed = True
+        ctx.save_for_backward(xa, xb, w_a, w_b, za, zb)
+        ctx.set_materialize_grads(False)
+        return ya.reshape(x_a.shape[:-1] + (N,)), yb.reshape(x_b.shape[:-1] + (N,)), x_a.view_as(x_a)
+
+    @staticmethod
+    def backward(ctx, g_a, g_b, g_alias):
+        xa, xb, wa, wb, za, zb = ctx.saved_tensors
+        pa_w, pa_b, pb_w, pb_b = ctx.params
+        act, slot = ctx.act, ctx.slot
+        M, K = xa.shape
+        N = wa.shape[0]
+        st = _lib.stream_ptr()
+        prep = lambda g: None if g is None else g.reshape(M, N).contiguous()
+        ga, gb = prep(g_a), prep(g_b)
+        zp = lambda z: _lib.ptr(z) if act != ACT_NONE else None
+        new = lambda: torch.empty(M, K, dtype=torch.float32, device=xa.device)
+
+        def single(g, z, w, add):
+            gx = new()
+            if add is not None:
+                _lib.call("cgv_tile_linear_bwd_input_act_add", _lib.ptr(g), zp(z), _lib.ptr(w), _lib.ptr(add), _lib.ptr(gx), M, N, K, act, st)
+            else:
+                _lib.call("cgv_tile_linear_bwd_input_act", _lib.ptr(g), zp(z), _lib.ptr(w), _lib.ptr(gx), M, N, K, act, st)
+            return gx
+        gxa = gxb = None
+        need_a, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if ctx.same:
+            if need_a:
+                add = None if g_alias is None else g_alias.reshape(M, K).contiguous()
+                if gb is not None:
+                    add = single(gb, zb, wb, add)
+                parked = None
+                if slot is not None:
+                    slot.linear_done = True
+                    parked = slot.take()
+                if ga is not None and parked is not None and parked.dtype == torch.float32 and parked.is_contiguous() and parked.shape[1] == K:
+                    gxa = new()
+                    _lib.call("cgv_tile_linear_bwd_input_act_add_bcast", _lib.ptr(ga), zp(za), _lib.ptr(wa), _lib.ptr(add), _lib.ptr(parked),
+                              _lib.ptr(slot.mapping), _lib.ptr(slot.plan.rowptr_d), int(slot.mean), _lib.ptr(gxa), M, N, K, act, st)
+                else:
+                    gxa = single(ga, za, wa, add) if ga is not None else add
+                    if parked is not None:
+                        spread = slot.broadcast(parked)
+                        gxa = spread if gxa is None else gxa + spread
+                if gxa is not None:
+                    gxa = gxa.reshape(xa.shape)
+        else:
+            if ga is not None and gb is not None and need_a and need_b:
+                gxa, gxb = new(), new()
+                _lib.call("cgv_tile_pair_linear_bwd_input", _lib.ptr(ga), zp(za), _lib.ptr(wa), None, _lib.ptr(gxa), _lib.ptr(gb), zp(zb),
+                          _lib.ptr(wb), None, _lib.ptr(gxb), M, N, K, act, st)
+            else:
+                gxa = single(ga, za, wa, None) if (ga is not None and need_a) else None
+                gxb = single(gb, zb, wb, None) if (gb is not None and need_b) else None
+        grads_w = []
+        for g2, x2, z, w_param, b_param, need_w, need_bias in (
+                (ga, xa, za, pa_w, pa_b, ctx.needs_input_grad[2], pa_b is not None and ctx.needs_input_grad[3]),
+                (gb, xb, zb, pb_w, pb_b, ctx.needs_input_grad[4], pb_b is not None and ctx.needs_input_grad[5])):
+            gw = gbias = None
+            if need_w and g2 is None:
+                # this layer's output left the loss: an arena-managed gradient is not pre-zeroed (see _LinearFn.backward)
+                for prm in (w_param, b_param):
+                    if prm is not None and _is_direct(prm) and prm._cgv_pending:
+                        prm.grad.zero_()
+                        prm._cgv_pending = False
+            elif need_w:
+                w_param._cgv_exch = w_param._cgv_rank = (M, N, K)
+                if b_param is not None:
+                    b_param._cgv_exch = (M, N, K)
+                tw, acc_w, gw = _grad_target(w_param, w_param)
+                tb, acc_b, gbias = _grad_target(b_param, b_param) if need_bias else (None, acc_w, None)
+                if tb is not None and acc_b != acc_w:
+                    raise RuntimeError("weight and bias of one layer disagree on first-write / accumulate state")
+                wgrad_queue.enqueue(g2, x2, z if act != ACT_NONE else None, act, tw, tb, acc_w)
+                if not (wgrad_queue.active and gw is None and gbias is None):
+                    wgrad_queue.flush()
+            grads_w += [gw, gbias]
+        return (gxa if need_a else None, None if ctx.same else (gxb if need_b else None), grads_w[0], grads_w[1], grads_w[2], grads_w[3],
+                None, None)
+
+
+def tile_pair_usable(x_a, x_b, la, lb) -> bool:
+    """Two ``Dense`` layers of one shape on the tile kernels' pair launch: arena-managed parameters (under the trainer), fp32,
+    Swish or no activation on both, a shape the register-tile kernels take."""
+    if not (isinstance(la, Dense) and isinstance(lb, Dense) and x_a.is_cuda and x_a.dtype == torch.float32 and x_b.dtype == torch.float32):
+        return False
+    if la.weight.shape != lb.weight.shape or x_a.shape != x_b.shape or x_a.dim() != 2 or la.bias is None or lb.bias is None:
+        return False
+    acts = (isinstance(la.activation, Swish), isinstance(lb.activation, Swish))
+    if acts[0] != acts[1] or (not acts[0] and (la.activation is not None or lb.activation is not None)) or la.dropout_rate or lb.dropout_rate:
+        return False
+    M, K = x_a.shape
+    N = la.weight.shape[0]
+    if _gemm_mode(x_a, la.weight, la.bias) != "tile" or not _lib.load().cgv_tile_pair_supported(M, N, K):
+        return False
+    tens = (x_a, x_b, la.weight, lb.weight, la.bias, lb.bias)
+    return (all(_is_direct(p) and p.grad.is_contiguous() for p in (la.weight, lb.weight, la.bias, lb.bias))
+            and all(t.is_contiguous() and t.data_ptr() % 16 == 0 for t in tens) and lib_has_rows(M, N, K))
+
+
+def tile_pair(x_a, x_b, la, lb, slot=None):
+    """(la(x_a), lb(x_b), alias of x_a) from one launch -- see ``_TilePairFn``."""
+    act = ACT_SWISH if isinstance(la.activation, Swish) else ACT_NONE
+    return _TilePairFn.apply(x_a, x_b, la.weight, la.bias, lb.weight, lb.bias, act, slot)
+
+
 def _ptr_table(tensors):
     """Host array of device pointers (None -> NULL) for the cgv_multi_* entry points."""
     return (C.c_void_p * len(tensors))(*[(t.data_ptr() if t is not None else None) for t in tensors])

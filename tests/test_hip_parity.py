@@ -2306,3 +2306,65 @@ def test_split_bf16_weight_gradients_have_fp32_accuracy(M, N, K, act, options):
         errs[split] = (float(eW), float(eb))
     assert errs[1][0] < 2e-6 and errs[1][1] < 2e-6, errs
     assert errs[1][0] < 4 * errs[0][0] + 1e-7, f"split path is not in the fp32 error class: {errs}"
+
+
+@pytest.mark.parametrize("workload,F,frames,layers", [("chignolin", 64, 2, 2), ("dipeptide", 32, 12, 4), ("chignolin", 600, 2, 3)])
+def test_encoder_node_mlps_as_pair_launches_equal_the_layer_by_layer_path(workload, F, frames, layers, options):
+    """Contractive block i and message block i + 1 read the same atom state (cgvae.py:286-305): their node MLPs run as pair
+    launches of the tile kernels (primitives._TilePairFn: one forward launch per MLP layer, one backward-input launch for the
+    two second layers, the first layers' input gradients chained through the epilogues together with the parked bead-mean
+    gradient of layer 0).  Against the layer-by-layer path under the trainer's arena + queue: outputs bit for bit (the same
+    kernels compute them), every parameter gradient to 2e-6."""
+    from coarsegrainingvae_amd import ops
+    from coarsegrainingvae_amd.primitives import wgrad_queue
+    from coarsegrainingvae_amd.trainer import ParamArena
+    w = cg.data.WORKLOADS[workload]
+    torch.manual_seed(29)
+    enc = cg.EquiEncoder(n_conv=layers, n_atom_basis=F, n_rbf=w["n_rbf"], activation="swish", cutoff=w["cg_cutoff"], dir_mp=False,
+                         cg_mp=False).to(DEV)
+    batch = cg.synthetic_batch(workload, n_frames=frames, seed=5, device=DEV)
+    g = batch["_graph"]
+    gen = torch.Generator().manual_seed(2)
+    uH = torch.randn(g.a2b.n_dst, F, generator=gen).to(DEV)
+    uh = torch.randn(batch["nxyz"].shape[0], F, generator=gen).to(DEV)
+    params = [p for p in enc.parameters()]
+    calls = []
+    real = ops._lib.call
+
+    def spy(name, *a, **k):
+        calls.append(name)
+        return real(name, *a, **k)
+
+    def run(pairs):
+        options.set("encoder_pairs", int(pairs))
+        del calls[:]
+        ops._lib.call = spy
+        try:
+            with wgrad_queue.collect():
+                H, h = enc(batch["nxyz"][:, 0], batch["nxyz"][:, 1:], batch["CG_nxyz"][:, 1:], batch["CG_mapping"],
+                           batch["nbr_list"], batch["CG_nbr_list"], graph=g)
+                ((H * uH).sum() + (h * uh).sum()).backward()
+            wgrad_queue.flush()
+        finally:
+            ops._lib.call = real
+        return H.detach().clone(), h.detach().clone(), [None if p.grad is None else p.grad.clone() for p in params], list(calls)
+    run(False)
+    arena = ParamArena([p for p in params if p.grad is not None])
+    outs = []
+    for pairs in (False, True):
+        arena.g.fill_(float("nan"))
+        arena.zero_grad()
+        outs.append(run(pairs))
+    (H0, h0, g0, c0), (H1, h1, g1, c1) = outs
+    n_pairs = layers - 1
+    assert c1.count("cgv_tile_pair_linear_fwd") == 2 * n_pairs and "cgv_tile_pair_linear_fwd" not in c0
+    assert c1.count("cgv_tile_pair_linear_bwd_input") == n_pairs
+    assert len(c1) == len(c0) - 3 * n_pairs, (len(c0), len(c1))                  # two forward launches and one backward launch per pair
+    assert "cgv_segment_broadcast" not in c1                                      # the bead-mean gradient still rides an epilogue
+    assert torch.equal(H1, H0) and torch.equal(h1, h0)
+    for k, (a, b) in enumerate(zip(g1, g0)):
+        assert (a is None) == (b is None)
+        if a is None:
+            continue
+        assert bool(torch.isfinite(a).all()), f"parameter gradient {k} has unwritten entries"
+        assert_close(a, b, f"encoder parameter gradient {k}", 2e-6)
