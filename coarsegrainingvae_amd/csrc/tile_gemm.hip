@@ -55,15 +55,15 @@ __device__ __forceinline__ void static_for(F&& f) {
 // selects the operands.  Two atom-level layers that are ready at the same time (the first Dense of contractive block i and
 // of message block i + 1 read the same state, cgvae.py:286-305; their second layers follow together) then cost one launch
 // boundary, and the launch has twice the tiles to fill the chip with.  All pointers NULL: an ordinary single launch.
-struct TileSecond { const float* x; const float* W; const float* bias; float* y; float* z; };
+struct TileSecond { const float* x; const float* W; const float* bias; float* y; float* z; int act; };
 
 template <int QM, int QN, int KW>
 __global__ __launch_bounds__(64 * QM * QN * KW) void tile_fwd_k(const float* __restrict__ x, const float* __restrict__ W,
                                                                  const float* __restrict__ bias, float* __restrict__ y,
                                                                  float* __restrict__ zout, int M, int N, int K, int act,
-                                                                 TileSecond s2 = TileSecond{nullptr, nullptr, nullptr, nullptr, nullptr}) {
+                                                                 TileSecond s2 = TileSecond{nullptr, nullptr, nullptr, nullptr, nullptr, 0}) {
   static_assert(KW >= 4, "the epilogue spreads the 4 sub-tiles of a quadrant over the k-slice waves");
-  if (blockIdx.z) { x = s2.x; W = s2.W; bias = s2.bias; y = s2.y; zout = s2.z; }
+  if (blockIdx.z) { x = s2.x; W = s2.W; bias = s2.bias; y = s2.y; zout = s2.z; act = s2.act; }
   __shared__ float red[QM * QN][KW][4][4][64];       // [quadrant][k-slice][sub-tile][reg][lane]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -166,9 +166,9 @@ template <int MT, int NT>
 __global__ __launch_bounds__(512) void tile_fwd_bal_k(const float* __restrict__ x, const float* __restrict__ W,
                                                       const float* __restrict__ bias, float* __restrict__ y,
                                                       float* __restrict__ zout, int M, int N, int K, int act, int MB, int NB,
-                                                      TileSecond s2 = TileSecond{nullptr, nullptr, nullptr, nullptr, nullptr}) {
+                                                      TileSecond s2 = TileSecond{nullptr, nullptr, nullptr, nullptr, nullptr, 0}) {
   constexpr int KW = 8, TT = MT * NT;
-  if (blockIdx.y) { x = s2.x; W = s2.W; bias = s2.bias; y = s2.y; zout = s2.z; }
+  if (blockIdx.y) { x = s2.x; W = s2.W; bias = s2.bias; y = s2.y; zout = s2.z; act = s2.act; }
   // LDS for the cross-wave sum: two rounds (waves 4-7 hand over, then waves 0-3) keep it at 4 x TT KB
   extern __shared__ __attribute__((aligned(16))) float bal_red[];      // [4][TT][4][64]
   const int lane = threadIdx.x & 63;
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(256, 2) void tile_fwd_ring_k(const float* __restric
 // A THIRD gradient of the same input, held as one row per SEGMENT of the rows (the backward of
 // scatter_mean / scatter_add of this very input, cgvae.py:297: g[m, :] += src[seg(m), :] (/ len(seg(m)) for the mean)):
 // added in the store epilogue instead of by a broadcast launch + an accumulation add.
-struct BwdSecond { const float* g; const float* W; float* gx; const float* z; const float* add; };   // see TileSecond
+struct BwdSecond { const float* g; const float* W; float* gx; const float* z; const float* add; int act; };   // see TileSecond
 struct BcastAdd {
   const float* src;          // [n_seg, K] or NULL
   const int64_t* row2seg;    // [M] segment of every row (the CG mapping)
@@ -519,8 +519,8 @@ __global__ __launch_bounds__(64 * WAVES) void tile_bwd_input_k(const float* __re
                                                         const float* __restrict__ z, int act,
                                                         const float* __restrict__ add = nullptr,
                                                         BcastAdd bc = BcastAdd{nullptr, nullptr, nullptr, 0},
-                                                        BwdSecond s2 = BwdSecond{nullptr, nullptr, nullptr, nullptr, nullptr}) {
-  if (blockIdx.z) { g = s2.g; W = s2.W; gx = s2.gx; z = s2.z; add = s2.add; bc.src = nullptr; }
+                                                        BwdSecond s2 = BwdSecond{nullptr, nullptr, nullptr, nullptr, nullptr, 0}) {
+  if (blockIdx.z) { g = s2.g; W = s2.W; gx = s2.gx; z = s2.z; add = s2.add; act = s2.act; bc.src = nullptr; }
   __shared__ float red[WAVES - 1][MB * 4][4][64];    // [wave-1][mb*4 + s][reg][lane]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -699,7 +699,7 @@ int cgv_tile_supported(int M, int N, int K) {
 static int tile_fwd_launch(const float* x, const float* W, const float* bias, float* y, float* z, int M, int N, int K, int act,
                            void* stream, const cgv::TileSecond* second, int* pair_ok) {
   hipStream_t st = (hipStream_t)stream;
-  const cgv::TileSecond s2 = second ? *second : cgv::TileSecond{nullptr, nullptr, nullptr, nullptr, nullptr};
+  const cgv::TileSecond s2 = second ? *second : cgv::TileSecond{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
   const unsigned np = second ? 2u : 1u;
   if (pair_ok) *pair_ok = 1;
   const int tiles32 = ((N + 31) / 32) * ((M + 31) / 32);
@@ -790,15 +790,17 @@ int cgv_tile_pair_supported(int M, int N, int K) {
 }
 
 int cgv_tile_pair_linear_fwd(const float* x_a, const float* W_a, const float* bias_a, float* y_a, float* z_a, const float* x_b,
-                             const float* W_b, const float* bias_b, float* y_b, float* z_b, int M, int N, int K, int act,
-                             void* stream) {
+                             const float* W_b, const float* bias_b, float* y_b, float* z_b, int M, int N, int K, int act_a,
+                             int act_b, void* stream) {
+  const int act = act_a;
   CGV_REQUIRE(x_a && W_a && y_a && x_b && W_b && y_b, "null pointer");
-  CGV_REQUIRE(act >= 0 && act <= cgv::CGV_ACT_MAX, "act must be 0 (identity), 1 (swish), 2 (tanh), 3 (relu), 4 / 5 (c + exp(z/2))");
-  CGV_REQUIRE(act == 0 || (z_a && z_b), "act != 0 needs both pre-activation outputs");
+  CGV_REQUIRE(act_a >= 0 && act_a <= cgv::CGV_ACT_MAX && act_b >= 0 && act_b <= cgv::CGV_ACT_MAX,
+              "act must be 0 (identity), 1 (swish), 2 (tanh), 3 (relu), 4 / 5 (c + exp(z/2))");
+  CGV_REQUIRE((act_a == 0 || z_a) && (act_b == 0 || z_b), "act != 0 needs the pre-activation output");
   CGV_REQUIRE(cgv_tile_supported(M, N, K), "unsupported shape (need N % 4 == 0, K % 4 == 0)");
   CGV_REQUIRE(((((uintptr_t)x_a | (uintptr_t)W_a | (uintptr_t)x_b | (uintptr_t)W_b | (uintptr_t)y_a | (uintptr_t)y_b |
                  (uintptr_t)z_a | (uintptr_t)z_b | (uintptr_t)bias_a | (uintptr_t)bias_b)) & 15) == 0, "operands must be 16-byte aligned");
-  const cgv::TileSecond s2{x_b, W_b, bias_b, y_b, z_b};
+  const cgv::TileSecond s2{x_b, W_b, bias_b, y_b, z_b, act_b};
   int ok = 1;
   const int rc = tile_fwd_launch(x_a, W_a, bias_a, y_a, z_a, M, N, K, act, stream, &s2, &ok);
   if (!ok) { cgv::set_error("cgv_tile_pair_linear_fwd: this shape runs on the LDS-staged kernels (no pair launch)"); return CGV_E_UNSUPPORTED; }
@@ -810,7 +812,7 @@ static int tile_bwd_input_launch(const float* g, const float* z, int act, const 
                                  cgv::BcastAdd bc = cgv::BcastAdd{nullptr, nullptr, nullptr, 0},
                                  const cgv::BwdSecond* second = nullptr) {
   hipStream_t st = (hipStream_t)stream;
-  const cgv::BwdSecond s2 = second ? *second : cgv::BwdSecond{nullptr, nullptr, nullptr, nullptr, nullptr};
+  const cgv::BwdSecond s2 = second ? *second : cgv::BwdSecond{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
   const unsigned np = second ? 2u : 1u;
   const int kt = (K + 63) / 64;
   const int blocks32 = kt * ((M + 31) / 32);
@@ -880,13 +882,15 @@ int cgv_tile_linear_bwd_input_act_add_bcast(const float* gy, const float* z, con
  * (add_* may be NULL; outputs must not alias). */
 int cgv_tile_pair_linear_bwd_input(const float* gy_a, const float* z_a, const float* W_a, const float* add_a, float* gx_a,
                                    const float* gy_b, const float* z_b, const float* W_b, const float* add_b, float* gx_b, int M,
-                                   int N, int K, int act, void* stream) {
+                                   int N, int K, int act_a, int act_b, void* stream) {
+  const int act = act_a;
   CGV_REQUIRE(gy_a && W_a && gx_a && gy_b && W_b && gx_b && gx_a != gx_b, "null pointer / aliased outputs");
-  CGV_REQUIRE(act == 0 || (act >= 1 && act <= cgv::CGV_ACT_MAX && z_a && z_b), "act != 0 needs the saved pre-activations");
+  CGV_REQUIRE((act_a == 0 || (act_a >= 1 && act_a <= cgv::CGV_ACT_MAX && z_a)) && (act_b == 0 || (act_b >= 1 && act_b <= cgv::CGV_ACT_MAX && z_b)),
+              "act != 0 needs the saved pre-activation");
   CGV_REQUIRE(cgv_tile_supported(M, N, K), "unsupported shape (need N % 4 == 0, K % 4 == 0)");
   CGV_REQUIRE(((((uintptr_t)gy_a | (uintptr_t)z_a | (uintptr_t)W_a | (uintptr_t)gx_a | (uintptr_t)add_a | (uintptr_t)gy_b |
                  (uintptr_t)z_b | (uintptr_t)W_b | (uintptr_t)gx_b | (uintptr_t)add_b)) & 15) == 0, "operands must be 16-byte aligned");
-  const cgv::BwdSecond s2{gy_b, W_b, gx_b, act ? z_b : nullptr, add_b};
+  const cgv::BwdSecond s2{gy_b, W_b, gx_b, act_b ? z_b : nullptr, add_b, act_b};
   return tile_bwd_input_launch(gy_a, act ? z_a : nullptr, act, W_a, gx_a, M, N, K, stream, "cgv_tile_pair_linear_bwd_input", add_a,
                                cgv::BcastAdd{nullptr, nullptr, nullptr, 0}, &s2);
 }

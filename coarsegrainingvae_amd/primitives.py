@@ -594,18 +594,19 @@ class _TilePairFn(torch.autograd.Function):
     Returns (y_a, y_b, alias of x_a): hand the alias to whatever else consumes the state."""
 
     @staticmethod
-    def forward(ctx, x_a, x_b, w_a, b_a, w_b, b_b, act, slot):
+    def forward(ctx, x_a, x_b, w_a, b_a, w_b, b_b, acts, slot):
         same = x_b is x_a
+        act_a, act_b = int(acts[0]), int(acts[1])
         xa = x_a.reshape(-1, x_a.shape[-1]).contiguous()
         xb = xa if same else x_b.reshape(-1, x_b.shape[-1]).contiguous()
         M, K = xa.shape
         N = w_a.shape[0]
         new = lambda: torch.empty(M, N, dtype=torch.float32, device=xa.device)
         ya, yb = new(), new()
-        za, zb = (new(), new()) if act else (None, None)
+        za, zb = (new() if act_a else None), (new() if act_b else None)
         _lib.call("cgv_tile_pair_linear_fwd", _lib.ptr(xa), _lib.ptr(w_a), _lib.ptr(b_a), _lib.ptr(ya), _lib.ptr(za), _lib.ptr(xb),
-                  _lib.ptr(w_b), _lib.ptr(b_b), _lib.ptr(yb), _lib.ptr(zb), M, N, K, int(act), _lib.stream_ptr())
-        ctx.params, ctx.act, ctx.same, ctx.slot = (w_a, b_a, w_b, b_b), int(act), same, slot
+                  _lib.ptr(w_b), _lib.ptr(b_b), _lib.ptr(yb), _lib.ptr(zb), M, N, K, act_a, act_b, _lib.stream_ptr())
+        ctx.params, ctx.acts, ctx.same, ctx.slot = (w_a, b_a, w_b, b_b), (act_a, act_b), same, slot
         if slot is not None:
             slot.armed = True
         ctx.save_for_backward(xa, xb, w_a, w_b, za, zb)
@@ -616,21 +617,21 @@ class _TilePairFn(torch.autograd.Function):
     def backward(ctx, g_a, g_b, g_alias):
         xa, xb, wa, wb, za, zb = ctx.saved_tensors
         pa_w, pa_b, pb_w, pb_b = ctx.params
-        act, slot = ctx.act, ctx.slot
+        (act_a, act_b), slot = ctx.acts, ctx.slot
         M, K = xa.shape
         N = wa.shape[0]
         st = _lib.stream_ptr()
         prep = lambda g: None if g is None else g.reshape(M, N).contiguous()
         ga, gb = prep(g_a), prep(g_b)
-        zp = lambda z: _lib.ptr(z) if act != ACT_NONE else None
         new = lambda: torch.empty(M, K, dtype=torch.float32, device=xa.device)
 
-        def single(g, z, w, add):
+        def single(g, z, w, add, act):
             gx = new()
+            zp = _lib.ptr(z) if act != ACT_NONE else None
             if add is not None:
-                _lib.call("cgv_tile_linear_bwd_input_act_add", _lib.ptr(g), zp(z), _lib.ptr(w), _lib.ptr(add), _lib.ptr(gx), M, N, K, act, st)
+                _lib.call("cgv_tile_linear_bwd_input_act_add", _lib.ptr(g), zp, _lib.ptr(w), _lib.ptr(add), _lib.ptr(gx), M, N, K, act, st)
             else:
-                _lib.call("cgv_tile_linear_bwd_input_act", _lib.ptr(g), zp(z), _lib.ptr(w), _lib.ptr(gx), M, N, K, act, st)
+                _lib.call("cgv_tile_linear_bwd_input_act", _lib.ptr(g), zp, _lib.ptr(w), _lib.ptr(gx), M, N, K, act, st)
             return gx
         gxa = gxb = None
         need_a, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
@@ -638,17 +639,18 @@ class _TilePairFn(torch.autograd.Function):
             if need_a:
                 add = None if g_alias is None else g_alias.reshape(M, K).contiguous()
                 if gb is not None:
-                    add = single(gb, zb, wb, add)
+                    add = single(gb, zb, wb, add, act_b)
                 parked = None
                 if slot is not None:
                     slot.linear_done = True
                     parked = slot.take()
                 if ga is not None and parked is not None and parked.dtype == torch.float32 and parked.is_contiguous() and parked.shape[1] == K:
                     gxa = new()
-                    _lib.call("cgv_tile_linear_bwd_input_act_add_bcast", _lib.ptr(ga), zp(za), _lib.ptr(wa), _lib.ptr(add), _lib.ptr(parked),
-                              _lib.ptr(slot.mapping), _lib.ptr(slot.plan.rowptr_d), int(slot.mean), _lib.ptr(gxa), M, N, K, act, st)
+                    _lib.call("cgv_tile_linear_bwd_input_act_add_bcast", _lib.ptr(ga), _lib.ptr(za) if act_a != ACT_NONE else None, _lib.ptr(wa),
+                              _lib.ptr(add), _lib.ptr(parked), _lib.ptr(slot.mapping), _lib.ptr(slot.plan.rowptr_d), int(slot.mean),
+                              _lib.ptr(gxa), M, N, K, act_a, st)
                 else:
-                    gxa = single(ga, za, wa, add) if ga is not None else add
+                    gxa = single(ga, za, wa, add, act_a) if ga is not None else add
                     if parked is not None:
                         spread = slot.broadcast(parked)
                         gxa = spread if gxa is None else gxa + spread
@@ -657,15 +659,16 @@ class _TilePairFn(torch.autograd.Function):
         else:
             if ga is not None and gb is not None and need_a and need_b:
                 gxa, gxb = new(), new()
-                _lib.call("cgv_tile_pair_linear_bwd_input", _lib.ptr(ga), zp(za), _lib.ptr(wa), None, _lib.ptr(gxa), _lib.ptr(gb), zp(zb),
-                          _lib.ptr(wb), None, _lib.ptr(gxb), M, N, K, act, st)
+                _lib.call("cgv_tile_pair_linear_bwd_input", _lib.ptr(ga), _lib.ptr(za) if act_a != ACT_NONE else None, _lib.ptr(wa), None,
+                          _lib.ptr(gxa), _lib.ptr(gb), _lib.ptr(zb) if act_b != ACT_NONE else None, _lib.ptr(wb), None, _lib.ptr(gxb),
+                          M, N, K, act_a, act_b, st)
             else:
-                gxa = single(ga, za, wa, None) if (ga is not None and need_a) else None
-                gxb = single(gb, zb, wb, None) if (gb is not None and need_b) else None
+                gxa = single(ga, za, wa, None, act_a) if (ga is not None and need_a) else None
+                gxb = single(gb, zb, wb, None, act_b) if (gb is not None and need_b) else None
         grads_w = []
-        for g2, x2, z, w_param, b_param, need_w, need_bias in (
-                (ga, xa, za, pa_w, pa_b, ctx.needs_input_grad[2], pa_b is not None and ctx.needs_input_grad[3]),
-                (gb, xb, zb, pb_w, pb_b, ctx.needs_input_grad[4], pb_b is not None and ctx.needs_input_grad[5])):
+        for g2, x2, z, act, w_param, b_param, need_w, need_bias in (
+                (ga, xa, za, act_a, pa_w, pa_b, ctx.needs_input_grad[2], pa_b is not None and ctx.needs_input_grad[3]),
+                (gb, xb, zb, act_b, pb_w, pb_b, ctx.needs_input_grad[4], pb_b is not None and ctx.needs_input_grad[5])):
             gw = gbias = None
             if need_w and g2 is None:
                 # this layer's output left the loss: an arena-managed gradient is not pre-zeroed (see _LinearFn.backward)
@@ -689,29 +692,39 @@ class _TilePairFn(torch.autograd.Function):
                 None, None)
 
 
-def tile_pair_usable(x_a, x_b, la, lb) -> bool:
-    """Two ``Dense`` layers of one shape on the tile kernels' pair launch: arena-managed parameters (under the trainer), fp32,
-    Swish or no activation on both, a shape the register-tile kernels take."""
-    if not (isinstance(la, Dense) and isinstance(lb, Dense) and x_a.is_cuda and x_a.dtype == torch.float32 and x_b.dtype == torch.float32):
+def _dense_act(layer):
+    """Activation code of a ``Dense`` the pair launch can fuse (Swish / none, no dropout), else None."""
+    if not isinstance(layer, Dense) or layer.dropout_rate:
+        return None
+    if isinstance(layer.activation, Swish):
+        return ACT_SWISH
+    return ACT_NONE if layer.activation is None else None
+
+
+def tile_pair_usable_raw(x_a, x_b, w_a, b_a, w_b, b_b) -> bool:
+    """Two linear layers of one shape on the tile kernels' pair launch: arena-managed parameters (under the trainer), fp32,
+    a shape the register-tile kernels take."""
+    if not (x_a.is_cuda and x_a.dtype == torch.float32 and x_b.dtype == torch.float32 and b_a is not None and b_b is not None):
         return False
-    if la.weight.shape != lb.weight.shape or x_a.shape != x_b.shape or x_a.dim() != 2 or la.bias is None or lb.bias is None:
-        return False
-    acts = (isinstance(la.activation, Swish), isinstance(lb.activation, Swish))
-    if acts[0] != acts[1] or (not acts[0] and (la.activation is not None or lb.activation is not None)) or la.dropout_rate or lb.dropout_rate:
+    if w_a.shape != w_b.shape or x_a.shape != x_b.shape or x_a.dim() != 2:
         return False
     M, K = x_a.shape
-    N = la.weight.shape[0]
-    if _gemm_mode(x_a, la.weight, la.bias) != "tile" or not _lib.load().cgv_tile_pair_supported(M, N, K):
+    N = w_a.shape[0]
+    if _gemm_mode(x_a, w_a, b_a) != "tile" or not _lib.load().cgv_tile_pair_supported(M, N, K):
         return False
-    tens = (x_a, x_b, la.weight, lb.weight, la.bias, lb.bias)
-    return (all(_is_direct(p) and p.grad.is_contiguous() for p in (la.weight, lb.weight, la.bias, lb.bias))
+    tens = (x_a, x_b, w_a, w_b, b_a, b_b)
+    return (all(_is_direct(p) and p.grad.is_contiguous() for p in (w_a, w_b, b_a, b_b))
             and all(t.is_contiguous() and t.data_ptr() % 16 == 0 for t in tens) and lib_has_rows(M, N, K))
+
+
+def tile_pair_usable(x_a, x_b, la, lb) -> bool:
+    return (_dense_act(la) is not None and _dense_act(lb) is not None
+            and tile_pair_usable_raw(x_a, x_b, la.weight, la.bias, lb.weight, lb.bias))
 
 
 def tile_pair(x_a, x_b, la, lb, slot=None):
     """(la(x_a), lb(x_b), alias of x_a) from one launch -- see ``_TilePairFn``."""
-    act = ACT_SWISH if isinstance(la.activation, Swish) else ACT_NONE
-    return _TilePairFn.apply(x_a, x_b, la.weight, la.bias, lb.weight, lb.bias, act, slot)
+    return _TilePairFn.apply(x_a, x_b, la.weight, la.bias, lb.weight, lb.bias, (_dense_act(la), _dense_act(lb)), slot)
 
 
 def _ptr_table(tensors):
@@ -866,6 +879,11 @@ def pair_linear_usable(x_a, x_b, lin_a, lin_b) -> bool:
     return 1 <= M <= 16 and N % 4 == 0 and K % 4 == 0 and N >= 64 and x_a.shape[-1] == K and wa.is_contiguous() and wb.is_contiguous()
 
 
+def HOST_OPTION(name):
+    from .options import HOST
+    return HOST[name]
+
+
 def dual_heads(head_a, head_b, x, out_act_a: int = ACT_NONE, out_act_b: int = ACT_NONE):
     """``(head_a(x), head_b(x, out_act))`` for two ``MLPHead``s of one shape (the mu / sigma heads: cgvae.py:366-371 applied
     as in cgvae.py:500-503 and 226-229) with layer j of both heads in ONE launch, forward and backward."""
@@ -878,7 +896,18 @@ def dual_heads(head_a, head_b, x, out_act_a: int = ACT_NONE, out_act_b: int = AC
         if pair_linear_usable(ha, hb, ma[2], mb[2]):
             return _PairLinearFn.apply(ha, hb, ma[2].weight, ma[2].bias, mb[2].weight, mb[2].bias, out_act_a, out_act_b)
         return _LinearFn.apply(ha, ma[2].weight, ma[2].bias, out_act_a), _LinearFn.apply(hb, mb[2].weight, mb[2].bias, out_act_b)
-    # too many rows for the paired kernels (a large bead batch): the second head reads x through the first head's fork
+    # too many rows for the skinny pair kernels (a large bead batch): layer j of both heads as a pair launch of the tile
+    # kernels (the shared input's two gradients meet in the chain of backward-input epilogues) ...
+    if (len(ma) == 3 and len(mb) == 3 and isinstance(ma[0], nn.Linear) and isinstance(mb[0], nn.Linear) and type(ma[1]) in codes
+            and type(mb[1]) in codes and isinstance(ma[2], nn.Linear) and isinstance(mb[2], nn.Linear) and x.dim() == 2
+            and x.requires_grad and torch.is_grad_enabled() and HOST_OPTION("head_pairs")
+            and tile_pair_usable_raw(x, x, ma[0].weight, ma[0].bias, mb[0].weight, mb[0].bias)):
+        ha, hb, _alias = _TilePairFn.apply(x, x, ma[0].weight, ma[0].bias, mb[0].weight, mb[0].bias, (codes[type(ma[1])], codes[type(mb[1])]), None)
+        if tile_pair_usable_raw(ha, hb, ma[2].weight, ma[2].bias, mb[2].weight, mb[2].bias):
+            ya, yb, _alias = _TilePairFn.apply(ha, hb, ma[2].weight, ma[2].bias, mb[2].weight, mb[2].bias, (int(out_act_a), int(out_act_b)), None)
+            return ya, yb
+        return _LinearFn.apply(ha, ma[2].weight, ma[2].bias, out_act_a), _LinearFn.apply(hb, mb[2].weight, mb[2].bias, out_act_b)
+    # ... or, one by one, the second head reading x through the first head's fork
     ya, x_alias = head_a(x, out_act=out_act_a, fork=True)
     return ya, head_b(x_alias, out_act=out_act_b)
 

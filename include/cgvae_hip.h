@@ -542,18 +542,18 @@ int cgv_tile_linear_bwd_input_act_add_bcast(const float* gy, const float* z, con
                                             const int64_t* row2seg, const int32_t* seg_rowptr, int mean, float* gx, int M, int N,
                                             int K, int act, void* stream);
 
-/* PAIR launches of the tile kernels: two Dense layers of ONE shape (M, N, K, act) in one grid (the extra grid dimension
+/* PAIR launches of the tile kernels: two Dense layers of ONE shape (M, N, K; each with its own activation code) in one grid (the extra grid dimension
  * selects the operands).  Replaces two consecutive layer launches whose inputs are ready at the same time: the first Dense
  * of ContractiveMessageBlock i and of EquiMessageBlock i + 1 read the same atom state (cgvae.py:286-305, conv.py:512-516 /
  * 709-713), their second Dense layers follow together; in backward the two second layers' input gradients.
  * cgv_tile_pair_supported: does this shape run on the register-tile kernels (the LDS-staged ones of big shapes take no pair)? */
 int cgv_tile_pair_supported(int M, int N, int K);
 int cgv_tile_pair_linear_fwd(const float* x_a, const float* W_a, const float* bias_a, float* y_a, float* z_a, const float* x_b,
-                             const float* W_b, const float* bias_b, float* y_b, float* z_b, int M, int N, int K, int act,
-                             void* stream);
+                             const float* W_b, const float* bias_b, float* y_b, float* z_b, int M, int N, int K, int act_a,
+                             int act_b, void* stream);
 int cgv_tile_pair_linear_bwd_input(const float* gy_a, const float* z_a, const float* W_a, const float* add_a, float* gx_a,
                                    const float* gy_b, const float* z_b, const float* W_b, const float* add_b, float* gx_b, int M,
-                                   int N, int K, int act, void* stream);
+                                   int N, int K, int act_a, int act_b, void* stream);
 int cgv_tile_linear_wgrad(const float* g, const float* x, float* gW, int M, int N, int K, int accumulate, void* stream);
 int cgv_wgrad_record_bytes(void);
 int cgv_wgrad_plan(int M, int N, int K, int* tiles_k /*[host]*/, int* tile_w /*[host]*/, int* n_blocks /*[host]*/);

@@ -80,7 +80,12 @@ def elementwise_err(got, ref, floor=1e-2):
     return float(((got - ref).abs() / ref.abs().clamp_min(floor)).max())
 
 
-def _check_outputs(tr, ref, what):
+def _check_outputs(tr, ref, what, updates: int = 0):
+    """``updates``: Adam steps behind these outputs.  After an update the two sides' parameters agree only as far as
+    ``_check_parameters`` says (an Adam step on a ~1e-8 gradient is +-lr whatever the gradient's last bits are), so the
+    element-wise bound on the latents' SMALL entries -- the one check here that looks two decades below a tensor's peak --
+    is held at 1e-4 for the first step (pure forward parity) and at 2e-4 afterwards; every other bound stays at 1e-4."""
+    lat_tol = REL if updates == 0 else 2 * REL
     for a, b, k in zip(tr.last_out, ref["out"], NAMES):
         e = rel_err(a, b)
         assert e <= REL, f"{what}: {k} relative error {e:.3e}"
@@ -95,7 +100,7 @@ def _check_outputs(tr, ref, what):
             continue
         floor = 1e-2 * float(ref["out"][k].abs().max())
         e = elementwise_err(tr.last_out[k], ref["out"][k], floor=floor)
-        assert e <= REL, f"{what}: {NAMES[k]} element-wise error {e:.3e} (floor {floor:.3e})"
+        assert e <= lat_tol, f"{what}: {NAMES[k]} element-wise error {e:.3e} (floor {floor:.3e})"
     kl, recon, graph = tr.last_terms
     for a, b, k in ((tr.last_loss, ref["loss"], "loss"), (kl, ref["kl"], "kl"), (recon, ref["recon"], "recon"),
                     (graph, ref["graph"], "graph")):
@@ -192,7 +197,7 @@ def _full_config_vs_oracle(workload, frames, F, n_replays=2, lr=1e-4):
     eps = draw()
     ref = oracle.step(eps)
     tr.step(batch, eps=eps.to(DEV))
-    _check_outputs(tr, ref, "step 2")
+    _check_outputs(tr, ref, "step 2", updates=1)
     _check_norm_and_clip(tr, ref, "step 2")
     _check_moments(tr, model, oracle, "step 2")
 
@@ -204,7 +209,7 @@ def _full_config_vs_oracle(workload, frames, F, n_replays=2, lr=1e-4):
         replays = tr.replays
         tr.step(batch, eps=eps.to(DEV))
         assert tr.replays == replays + 1                     # it really was the graph
-        _check_outputs(tr, ref, f"step {3 + k} (replay)")
+        _check_outputs(tr, ref, f"step {3 + k} (replay)", updates=2 + k)
         _check_norm_and_clip(tr, ref, f"step {3 + k} (replay)")
     n_steps = 2 + n_replays
     assert int(tr.state[ST_STEP].item()) == n_steps and tr.skipped_steps() == 0

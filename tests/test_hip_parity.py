@@ -2368,3 +2368,65 @@ def test_encoder_node_mlps_as_pair_launches_equal_the_layer_by_layer_path(worklo
             continue
         assert bool(torch.isfinite(a).all()), f"parameter gradient {k} has unwritten entries"
         assert_close(a, b, f"encoder parameter gradient {k}", 2e-6)
+
+
+@pytest.mark.parametrize("M,act", [(96, "tanh"), (288, "relu"), (65, "tanh")])
+def test_head_layers_as_tile_pair_launches_vs_fp64(M, act, options):
+    """The (mu, sigma) heads (cgvae.py:366-371 applied at 398-401 / 500-503) on more bead rows than the skinny pair kernels
+    take: layer j of both heads as ONE launch of the tile kernels (different activation codes per problem: the sigma head
+    ends in c + exp(z / 2)), backward-input of the second layers as one launch, the shared input's gradients chained
+    through the first layers' epilogues.  Against fp64 autograd and against the one-by-one path."""
+    from coarsegrainingvae_amd.primitives import ACT_STD_ENC, MLPHead, Linear, dual_heads, wgrad_queue
+    from coarsegrainingvae_amd.trainer import ParamArena
+    from coarsegrainingvae_amd import ops
+    F = 600
+    torch.manual_seed(M)
+    mk = lambda: MLPHead(Linear(F, F), torch.nn.Tanh() if act == "tanh" else torch.nn.ReLU(), Linear(F, F)).to(DEV)
+    mu, sg = mk(), mk()
+    x0 = torch.randn(M, F, device=DEV)
+    ua, ub = torch.randn(M, F, device=DEV), torch.randn(M, F, device=DEV) * 0.1
+    params = list(mu.parameters()) + list(sg.parameters())
+    calls = []
+    real = ops._lib.call
+
+    def spy(name, *a, **k):
+        calls.append(name)
+        return real(name, *a, **k)
+
+    def run(pairs):
+        options.set("head_pairs", int(pairs))
+        del calls[:]
+        x = x0.clone().requires_grad_(True)
+        ops._lib.call = spy
+        try:
+            with wgrad_queue.collect():
+                ya, yb = dual_heads(mu, sg, x, out_act_b=ACT_STD_ENC)
+                ((ya * ua).sum() + (yb * ub).sum()).backward()
+            wgrad_queue.flush()
+        finally:
+            ops._lib.call = real
+        return ya.detach().clone(), yb.detach().clone(), x.grad.clone(), [p.grad.clone() for p in params], list(calls)
+    run(False)
+    arena = ParamArena(params)
+    res = []
+    for pairs in (False, True):
+        arena.g.fill_(float("nan"))
+        arena.zero_grad()
+        res.append(run(pairs))
+    (ya0, yb0, gx0, gp0, c0), (ya1, yb1, gx1, gp1, c1) = res
+    assert c1.count("cgv_tile_pair_linear_fwd") == 2 and c1.count("cgv_tile_pair_linear_bwd_input") == 1 and len(c1) == len(c0) - 3
+    assert torch.equal(ya1, ya0) and torch.equal(yb1, yb0)
+    # fp64 reference
+    d = lambda t: t.detach().double().cpu()
+    xd = d(x0).requires_grad_(True)
+    P = [d(p).requires_grad_(True) for p in params]
+    f = torch.tanh if act == "tanh" else torch.relu
+    ya64 = f(xd @ P[0].t() + P[1]) @ P[2].t() + P[3]
+    yb64 = 1e-12 + torch.exp((f(xd @ P[4].t() + P[5]) @ P[6].t() + P[7]) / 2)
+    ((ya64 * d(ua)).sum() + (yb64 * d(ub)).sum()).backward()
+    assert_close(ya1, ya64.detach(), "mu head", 2e-6)
+    assert_close(yb1, yb64.detach(), "sigma head", 2e-6)
+    assert_close(gx1, xd.grad, "grad x", 5e-6)
+    assert_close(gx1, gx0, "grad x vs one-by-one", 2e-6)
+    for k, (a, b) in enumerate(zip(gp1, P)):
+        assert_close(a, b.grad, f"parameter gradient {k}", 5e-6)
