@@ -56,6 +56,8 @@ PROTOTYPES = {
     "cgv_geom_jobs_build": (_i, [_p, _i, _p]),
     "cgv_segment_reduce": (_i, [_p, _p, _p, _i, _i, _i, _p, _p]),
     "cgv_embedding_rows": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
+    "cgv_embedding_rows2": (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _i, _i, _i, _p, _i, _p]),
+    "cgv_segment_reduce_pair": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _i, _p, _i, _p]),
     "cgv_segment_broadcast": (_i, [_p, _p, _p, _i, _i, _i, _p, _p]),
     "cgv_equi_msg_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, C.c_int64, C.c_int64, _p, _p, _p]),
     "cgv_equi_msg_grouped_supported": (_i, [_i, _i, _i]),

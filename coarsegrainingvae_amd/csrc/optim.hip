@@ -104,14 +104,14 @@ __global__ __launch_bounds__(256) void sumsq_decide_k(const float* __restrict__ 
   if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) {
+    // (no __threadfence: an agent-scope release writes back the XCD's whole L2 -- 30-85 us behind the backward pass; the
+    // partial travels as an agent-scope atomic, coherent across the XCDs by itself, and is acknowledged before the ticket)
     __hip_atomic_store(partial + blockIdx.x, (ws[0] + ws[1]) + (ws[2] + ws[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
   }
   __syncthreads();
   if (!s_last) return;
-  __threadfence();
   optim_decide<true>(partial, (int)gridDim.x, extra, n_extra, grad_scale, max_norm, beta1, beta2, loss, skip_threshold, state, wd);
   if (threadIdx.x == 0) *ticket = 0u;
 }

@@ -134,9 +134,77 @@ __global__ __launch_bounds__(256) void embedding_rows_k(const float* __restrict_
   reinterpret_cast<float4*>(out + (size_t)i * channels)[c4] = reinterpret_cast<const float4*>(weight + (size_t)t * channels)[c4];
 }
 
+// Two embedding lookups in one launch (the encoder's atom types and the prior's bead types, cgvae.py:268 / 381): rows
+// [0, a.n_rows) belong to job a, the rest to job b.  And their weight gradients: two segment sums over their own plans.
+struct EmbJob { const float* weight; const float* ids; int id_stride, n_types, n_rows; float* out; };
+__global__ __launch_bounds__(256) void embedding_rows2_k(EmbJob a, EmbJob b, int channels) {
+  const bool second = (int)blockIdx.x >= a.n_rows;
+  const EmbJob j = second ? b : a;
+  const int i = (int)blockIdx.x - (second ? a.n_rows : 0);
+  const int c4 = blockIdx.y * 256 + threadIdx.x;
+  if (c4 * 4 >= channels) return;
+  int t = (int)j.ids[(size_t)i * j.id_stride];
+  t = t < 0 ? 0 : (t >= j.n_types ? j.n_types - 1 : t);
+  reinterpret_cast<float4*>(j.out + (size_t)i * channels)[c4] = reinterpret_cast<const float4*>(j.weight + (size_t)t * channels)[c4];
+}
+
+struct SegJob { const float* src; const int* rowptr; const int* perm; int n_seg; float* out; };
+template <int BLOCK, int UNROLL>
+__global__ __launch_bounds__(BLOCK) void segment_reduce_jobs2_k(SegJob a, SegJob b, int C) {
+  const bool second = (int)blockIdx.x >= a.n_seg;
+  const SegJob j = second ? b : a;
+  const int seg = (int)blockIdx.x - (second ? a.n_seg : 0);
+  const int c = (blockIdx.y * BLOCK + threadIdx.x) * 4;
+  if (c >= C) return;
+  const int beg = j.rowptr[seg], end = j.rowptr[seg + 1];
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int p = beg; p < end; p += UNROLL) {                          // (same per-segment order as segment_reduce_k)
+    float4 x[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int pp = min(p + u, end - 1);
+      const int row = j.perm ? j.perm[pp] : pp;
+      x[u] = *reinterpret_cast<const float4*>(j.src + (size_t)row * C + c);
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u)
+      if (p + u < end) vadd(acc, x[u]);
+  }
+  *reinterpret_cast<float4*>(j.out + (size_t)seg * C + c) = acc;
+}
+
 }  // namespace cgv
 
 extern "C" {
+
+int cgv_embedding_rows2(const float* weight_a, const float* ids_a, int id_stride_a, int n_rows_a, int n_types_a, float* out_a,
+                        const float* weight_b, const float* ids_b, int id_stride_b, int n_rows_b, int n_types_b, float* out_b,
+                        int channels, void* stream) {
+  CGV_REQUIRE(n_rows_a >= 1 && n_rows_b >= 1 && channels > 0 && n_types_a > 0 && n_types_b > 0 && id_stride_a >= 1 && id_stride_b >= 1, "bad size");
+  CGV_REQUIRE(weight_a && ids_a && out_a && weight_b && ids_b && out_b, "null pointer");
+  CGV_REQUIRE((channels % 4) == 0 && ((((uintptr_t)weight_a) | ((uintptr_t)out_a) | ((uintptr_t)weight_b) | ((uintptr_t)out_b)) & 15) == 0,
+              "need channels % 4 == 0, 16-byte aligned");
+  const cgv::EmbJob a{weight_a, ids_a, id_stride_a, n_types_a, n_rows_a, out_a}, b{weight_b, ids_b, id_stride_b, n_types_b, n_rows_b, out_b};
+  hipLaunchKernelGGL(cgv::embedding_rows2_k, dim3(n_rows_a + n_rows_b, (channels / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, b,
+                     channels);
+  return cgv::check_launch("cgv_embedding_rows2");
+}
+
+/* out_a[s] = sum of the rows of src_a in segment s of (rowptr_a, perm_a), likewise b: two segment sums over their own plans
+ * in one launch (the weight gradients of the two embeddings of a step); channels % 4 == 0, 16-byte aligned. */
+int cgv_segment_reduce_pair(const float* src_a, const int32_t* rowptr_a, const int32_t* perm_a, int n_seg_a, float* out_a,
+                            const float* src_b, const int32_t* rowptr_b, const int32_t* perm_b, int n_seg_b, float* out_b,
+                            int channels, void* stream) {
+  CGV_REQUIRE(n_seg_a >= 1 && n_seg_b >= 1 && channels > 0, "bad size");
+  CGV_REQUIRE(src_a && rowptr_a && out_a && src_b && rowptr_b && out_b, "null pointer");
+  CGV_REQUIRE((channels % 4) == 0 && ((((uintptr_t)src_a) | ((uintptr_t)out_a) | ((uintptr_t)src_b) | ((uintptr_t)out_b)) & 15) == 0,
+              "need channels % 4 == 0, 16-byte aligned");
+  constexpr int BLOCK = 256, UNROLL = 8;
+  const cgv::SegJob a{src_a, rowptr_a, perm_a, n_seg_a, out_a}, b{src_b, rowptr_b, perm_b, n_seg_b, out_b};
+  hipLaunchKernelGGL((cgv::segment_reduce_jobs2_k<BLOCK, UNROLL>), dim3(n_seg_a + n_seg_b, (channels / 4 + BLOCK - 1) / BLOCK), dim3(BLOCK), 0,
+                     (hipStream_t)stream, a, b, channels);
+  return cgv::check_launch("cgv_segment_reduce_pair");
+}
 
 int cgv_segment_reduce(const float* src, const int32_t* rowptr, const int32_t* perm, int n_seg, int channels, int mean,
                        float* out, void* stream) {

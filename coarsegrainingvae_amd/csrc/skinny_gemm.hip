@@ -622,8 +622,12 @@ constexpr int GRAM_MAX_PAIRS = GRAM_MAX_ROWS * (GRAM_MAX_ROWS + 1) / 2;         
 constexpr size_t GRAM_WS_DOUBLES = (size_t)GRAM_SLICES * 2 * GRAM_MAX_PAIRS;                    // per problem
 static size_t gram_lds_bytes(int max_rows) { return sizeof(float4) * GRAM_TILE_F4 + sizeof(double) * (size_t)max_rows * (max_rows + 1); }
 
+constexpr int GRAM_TICKETS = 512;                                    // >= primitives.WeightGradQueue.MAX_PROBLEMS
+__device__ unsigned gram_tickets[GRAM_TICKETS];                      // zero at load, every launch leaves them zero
+
 __global__ __launch_bounds__(GRAM_THREADS) void wgrad_gram_k(const WgradProblem* __restrict__ table, double* __restrict__ ws,
-                                                             int pair_cap /* pairs the LDS sums hold per operand */) {
+                                                             int pair_cap /* pairs the LDS sums hold per operand */,
+                                                             double* __restrict__ out /* [problems] or NULL */) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float4* tile = reinterpret_cast<float4*>(smem);                // [M][C4 + 1]
   double* sums = reinterpret_cast<double*>(tile + GRAM_TILE_F4); // [g | x][pair_cap]: this block's slices, summed
@@ -742,7 +746,49 @@ __global__ __launch_bounds__(GRAM_THREADS) void wgrad_gram_k(const WgradProblem*
     }
   }
   __syncthreads();
-  for (int i = t; i < pairs; i += GRAM_THREADS) { mine[i] = sums[i]; mine[GRAM_MAX_PAIRS + i] = sums[pair_cap + i]; }
+  // agent-scope stores: the block that arrives LAST at this problem's ticket sums all slices (below)
+  for (int i = t; i < pairs; i += GRAM_THREADS) {
+    __hip_atomic_store(mine + i, sums[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(mine + GRAM_MAX_PAIRS + i, sums[pair_cap + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (out == nullptr) return;                                     // (two-launch form: wgrad_gram_reduce_k follows)
+  // One launch instead of two: the eight slice blocks of a problem meet at a ticket (eight arrivals -- the pattern that is
+  // too slow for the 1620 blocks of the flat norm pass pays here); atomicInc wraps to zero at the eighth, so the tickets
+  // need no reset and a launch that never finished cannot wedge the next one.
+  // (No __threadfence: an agent-scope release writes back the WHOLE L2 -- right behind the backward pass that is 60 us per
+  // launch, measured.  The partials travel as agent-scope atomics, which are coherent across the XCDs by themselves; every
+  // thread waits for its own stores to be acknowledged before the barrier that precedes the ticket.)
+  __shared__ unsigned s_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (t == 0) {
+    s_last = atomicInc(gram_tickets + (blockIdx.y % GRAM_TICKETS), (unsigned)GRAM_SLICES - 1u) == (unsigned)GRAM_SLICES - 1u ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  const double* all = ws + (size_t)blockIdx.y * GRAM_WS_DOUBLES;
+  double local = 0.0;
+  for (int p = t; p < pairs; p += GRAM_THREADS) {
+    double gg = 0.0, xx = 0.0;
+    for (int s2 = 0; s2 < GRAM_SLICES; ++s2) {
+      gg += __hip_atomic_load(all + (size_t)s2 * 2 * GRAM_MAX_PAIRS + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      xx += __hip_atomic_load(all + (size_t)s2 * 2 * GRAM_MAX_PAIRS + GRAM_MAX_PAIRS + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    int a = 0, rem = p;                                           // diagonal pairs (a, a) count once (see wgrad_gram_reduce_k)
+    while (rem >= M - a) { rem -= M - a; ++a; }
+    local += (rem == 0 ? 1.0 : 2.0) * gg * xx;
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) local += __shfl_xor(local, d);
+  __shared__ double wsum[GRAM_WAVES];
+  if (lane == 0) wsum[w] = local;
+  __syncthreads();
+  if (t == 0) {
+    double tot = 0.0;
+#pragma unroll
+    for (int k = 0; k < GRAM_WAVES; ++k) tot += wsum[k];
+    out[blockIdx.y] = tot;
+  }
 }
 
 __global__ __launch_bounds__(256) void wgrad_gram_reduce_k(const WgradProblem* __restrict__ table, const double* __restrict__ ws,
@@ -2172,10 +2218,14 @@ int cgv_wgrad_gram(const void* table_dev, int n_problems, int max_rows, double* 
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cgv::wgrad_gram_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { cgv::set_error("cgv_wgrad_gram: %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return (int)e; }
   }
+  // one launch (the last slice block of a problem sums its slices) up to GRAM_TICKETS problems, else the reduce launch follows
+  const bool one = n_problems <= cgv::GRAM_TICKETS && cgv::option(CGV_OPT_OPTIM_ONE_LAUNCH) != 2;
   hipLaunchKernelGGL(cgv::wgrad_gram_k, dim3(cgv::GRAM_SLICES, n_problems), dim3(cgv::GRAM_THREADS), lds,
-                     (hipStream_t)stream, table, reinterpret_cast<double*>(workspace), max_rows * (max_rows + 1) / 2);
-  hipLaunchKernelGGL(cgv::wgrad_gram_reduce_k, dim3(n_problems), dim3(256), 0, (hipStream_t)stream, table,
-                     reinterpret_cast<const double*>(workspace), sumsq);
+                     (hipStream_t)stream, table, reinterpret_cast<double*>(workspace), max_rows * (max_rows + 1) / 2,
+                     one ? sumsq : (double*)nullptr);
+  if (!one)
+    hipLaunchKernelGGL(cgv::wgrad_gram_reduce_k, dim3(n_problems), dim3(256), 0, (hipStream_t)stream, table,
+                       reinterpret_cast<const double*>(workspace), sumsq);
   return cgv::check_launch("cgv_wgrad_gram");
 }
 

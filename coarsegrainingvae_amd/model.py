@@ -171,7 +171,7 @@ class EquiEncoder(nn.Module):
         for blk in list(self.message_blocks) + list(self.cgmessage_layers):
             blk.with_dv = not flag
 
-    def forward(self, z, xyz, cg_xyz, mapping, nbr_list, cg_nbr_list, graph: Optional[BatchGraph] = None, layer_hooks=None):
+    def forward(self, z, xyz, cg_xyz, mapping, nbr_list, cg_nbr_list, graph: Optional[BatchGraph] = None, layer_hooks=None, h0=None):
         """``layer_hooks``: {layer index L >= 1: callable} -- called from the autograd thread when the backward of the
         encoder layers >= L is complete (tensor hook on the atom state entering layer L's message block); the
         data-parallel trainer all-reduces those layers' gradients while the lower layers' backward still runs."""
@@ -182,7 +182,8 @@ class EquiEncoder(nn.Module):
             raise RuntimeError(f"this encoder has dir_mp={self.dir_mp}: prepare the batch with prepare_batch(..., dir_mp={self.dir_mp})")
         geom = graph.geometry("atom", self.n_rbf, self.cutoff)
         geom_c = graph.geometry("a2b", self.n_rbf, 20.0)
-        h = ops.embedding(self.atom_embed, z, graph.embed_plan("atom", z, self.atom_embed) if graph is not None else None)
+        # ``h0``: the embedded atom types, when the caller looked them up together with the prior's (CGequiVAE.forward)
+        h = h0 if h0 is not None else ops.embedding(self.atom_embed, z, graph.embed_plan("atom", z, self.atom_embed) if graph is not None else None)
         v = _constant((h.shape[0], h.shape[1], 3), 0.0, h.device)
         H = V = None
         phi_next = None                                   # node features of message block i, from a pair launch of layer i - 1
@@ -236,7 +237,7 @@ class CGprior(nn.Module):
         for blk in self.message_blocks:
             blk.with_dv = not flag
 
-    def forward(self, cg_z, cg_xyz, cg_nbr_list, graph: Optional[BatchGraph] = None):
+    def forward(self, cg_z, cg_xyz, cg_nbr_list, graph: Optional[BatchGraph] = None, h0=None):
         if graph is not None:
             nbrs, plan = graph.cg_nbrs, graph.cg
             geom = graph.geometry("cg", self.n_rbf, self.cutoff)
@@ -245,12 +246,12 @@ class CGprior(nn.Module):
             nbrs, _ = make_directed(cg_nbr_list)
             plan = EdgePlan.from_nbrs(nbrs, cg_xyz.shape[0])
             geom = EdgeGeometry(plan, self.n_rbf, self.cutoff, pos_dst=cg_xyz, pos_src=cg_xyz)
-        h = self.features(cg_z, nbrs, plan, geom, graph)
+        h = self.features(cg_z, nbrs, plan, geom, graph, h0=h0)
         return self.heads(h)
 
-    def features(self, cg_z, nbrs, plan, geom, graph=None):
+    def features(self, cg_z, nbrs, plan, geom, graph=None, h0=None):
         """The bead state after the message blocks (cgvae.py:381-396): what the mu / sigma heads are applied to."""
-        h = ops.embedding(self.atom_embed, cg_z, graph.embed_plan("cg", cg_z, self.atom_embed) if graph is not None else None)
+        h = h0 if h0 is not None else ops.embedding(self.atom_embed, cg_z, graph.embed_plan("cg", cg_z, self.atom_embed) if graph is not None else None)
         v = _constant((h.shape[0], h.shape[1], 3), 0.0, h.device)
         if self.fused_loop and h.is_cuda:
             from . import prior_fused
@@ -402,11 +403,19 @@ class CGequiVAE(nn.Module):
                 H_prior_mu, H_prior_sigma = self.prior_net(cg_z, cg_xyz, CG_nbr_list, graph=graph)
         enc_hooks = None
         quad = None
+        h0_enc = h0_prior = None
+        if (side is None and graph is not None and isinstance(self.prior_net, CGprior) and isinstance(self.encoder, EquiEncoder)
+                and HOST["paired_embeddings"]):
+            # the two embedding lookups of a step (atom types, bead types) in one launch; so are their weight gradients
+            both = ops.embedding2(self.encoder.atom_embed, z, graph.embed_plan("atom", z, self.encoder.atom_embed),
+                                  self.prior_net.atom_embed, cg_z, graph.embed_plan("cg", cg_z, self.prior_net.atom_embed))
+            if both is not None:
+                h0_enc, h0_prior = both
         if self.bucket_done is not None:
             first = len(self._decoder_groups())
             enc_hooks = {l: self._fire_bucket(first + k) for k, l in enumerate(self._encoder_layers())}
         mark("forward:start")
-        S_I, s_i = self.encoder(z, xyz, cg_xyz, mapping, nbr_list, CG_nbr_list, graph=graph, layer_hooks=enc_hooks)
+        S_I, s_i = self.encoder(z, xyz, cg_xyz, mapping, nbr_list, CG_nbr_list, graph=graph, layer_hooks=enc_hooks, **({'h0': h0_enc} if h0_enc is not None else {}))
         mark("forward:encoder")
         if side is not None:
             main.wait_stream(side)
@@ -418,13 +427,13 @@ class CGequiVAE(nn.Module):
                 # the prior's (mu, sigma) heads and the encoder's are four independent two-layer chains of one shape:
                 # layer j of all four in ONE launch, forward and backward (primitives.quad_heads)
                 pn = self.prior_net
-                h_prior = pn.features(cg_z, graph.cg_nbrs, graph.cg, graph.geometry("cg", pn.n_rbf, pn.cutoff), graph)
+                h_prior = pn.features(cg_z, graph.cg_nbrs, graph.cg, graph.geometry("cg", pn.n_rbf, pn.cutoff), graph, h0=h0_prior)
                 if isinstance(pn.mu, MLPHead) and isinstance(pn.sigma, MLPHead) and h_prior.shape == S_I.shape:
                     quad = quad_heads((pn.mu, pn.sigma, h_prior, ACT_STD_PRIOR), (self.atom_munet, self.atom_sigmanet, S_I, ACT_STD_ENC))
                 if quad is None:
                     H_prior_mu, H_prior_sigma = pn.heads(h_prior)
             else:
-                H_prior_mu, H_prior_sigma = self.prior_net(cg_z, cg_xyz, CG_nbr_list, graph=graph)
+                H_prior_mu, H_prior_sigma = self.prior_net(cg_z, cg_xyz, CG_nbr_list, graph=graph, **({'h0': h0_prior} if h0_prior is not None else {}))
         else:
             H_prior_mu, H_prior_sigma = None, None
         if self.prior_net and side is None and quad is not None:

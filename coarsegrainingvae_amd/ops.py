@@ -197,6 +197,60 @@ class _Embedding(torch.autograd.Function):
         return ret, None, None
 
 
+class _Embedding2(torch.autograd.Function):
+    """Two ``nn.Embedding`` lookups in one launch (the encoder's atom types and the prior's bead types, cgvae.py:268 / 381)
+    and, when both gradients arrive, their weight gradients in one launch (``cgv_segment_reduce_pair``)."""
+
+    @staticmethod
+    def forward(ctx, w_a, idx_a, plan_a, w_b, idx_b, plan_b):
+        F = w_a.shape[1]
+        out_a = torch.empty(idx_a.shape[0], F, dtype=_F32, device=w_a.device)
+        out_b = torch.empty(idx_b.shape[0], F, dtype=_F32, device=w_a.device)
+        _lib.call("cgv_embedding_rows2", _lib.ptr(w_a.detach()), idx_a.data_ptr(), int(idx_a.stride(0)), idx_a.shape[0], w_a.shape[0],
+                  _lib.ptr(out_a), _lib.ptr(w_b.detach()), idx_b.data_ptr(), int(idx_b.stride(0)), idx_b.shape[0], w_b.shape[0],
+                  _lib.ptr(out_b), F, _lib.stream_ptr())
+        ctx.plans, ctx.params = (plan_a, plan_b), (w_a, w_b)
+        ctx.set_materialize_grads(False)
+        return out_a, out_b
+
+    @staticmethod
+    def backward(ctx, g_a, g_b):
+        from .primitives import _grad_target
+        (plan_a, plan_b), (w_a, w_b) = ctx.plans, ctx.params
+        rets = [None, None]
+        jobs = []
+        for k, (g, plan, w) in enumerate(((g_a, plan_a, w_a), (g_b, plan_b, w_b))):
+            if g is None or not ctx.needs_input_grad[3 * k]:
+                continue
+            target, accumulate, ret = _grad_target(w, w)
+            rets[k] = ret
+            jobs.append((_c(g), plan, w, target, accumulate))
+        if len(jobs) == 2 and not jobs[0][4] and not jobs[1][4]:
+            (ga, pa, wa, ta, _), (gb, pb, wb, tb, _) = jobs
+            _lib.call("cgv_segment_reduce_pair", _lib.ptr(ga), _lib.ptr(pa.rowptr_d), _lib.ptr(pa.eid_d), wa.shape[0], _lib.ptr(ta),
+                      _lib.ptr(gb), _lib.ptr(pb.rowptr_d), _lib.ptr(pb.eid_d), wb.shape[0], _lib.ptr(tb), wa.shape[1], _lib.stream_ptr())
+        else:
+            for g, plan, w, target, accumulate in jobs:
+                out = torch.empty_like(target) if accumulate else target
+                _lib.call("cgv_segment_reduce", _lib.ptr(g), _lib.ptr(plan.rowptr_d), _lib.ptr(plan.eid_d), w.shape[0], w.shape[1], 0,
+                          _lib.ptr(out), _lib.stream_ptr())
+                if accumulate:
+                    target.add_(out)
+        return rets[0], None, None, rets[1], None, None
+
+
+def embedding2(mod_a, idx_a, plan_a, mod_b, idx_b, plan_b):
+    """(mod_a(idx_a), mod_b(idx_b)) from one launch, or None when the paired path does not apply (float type-id columns as
+    they sit in the batch, contiguous fp32 weights of one width)."""
+    wa, wb = mod_a.weight, mod_b.weight
+    ok = lambda i: i.dtype == torch.float32 and i.dim() == 1 and i.is_cuda and i.shape[0] >= 1
+    okw = lambda m, w: w.is_cuda and w.is_contiguous() and w.dtype == torch.float32 and m.max_norm is None and not m.sparse
+    if not (ok(idx_a) and ok(idx_b) and okw(mod_a, wa) and okw(mod_b, wb) and wa.shape[1] == wb.shape[1] and wa.shape[1] % 4 == 0
+            and plan_a is not None and plan_b is not None):
+        return None
+    return _Embedding2.apply(wa, idx_a, plan_a, wb, idx_b, plan_b)
+
+
 def embedding_plan(idx: torch.Tensor, n_types: int, padding_idx: Optional[int]) -> EdgePlan:
     """Rows grouped by type id for :func:`embedding`; ``padding_idx`` rows go to segment ``n_types``."""
     idx = idx.long()

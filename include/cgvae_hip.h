@@ -79,7 +79,7 @@ enum {
   CGV_OPT_DECODER_WLDS = 12,   /* cgv_decoder_msg_fwd: 1 (default) weight rows by LDS-DMA when they fit in LDS, 0 register path */
   CGV_OPT_SKINNY_ROWS = 13,    /* cgv_skinny_linear_fwd: row blocks (of 16) per thread block; 0 = built-in rule, 1..4 */
   CGV_OPT_TILE_FWD_BAL = 14,   /* cgv_tile_linear_fwd: 1 (default) layers of >= 1200 outputs with more than one 32 x 32 tile per CU run as ONE larger register tile per CU where a compiled tile fits (XCD-aware tile order), 0 off, 2 every shape (tests / A-B) */
-  CGV_OPT_OPTIM_ONE_LAUNCH = 15, /* cgv_optim_prepare*: 0 (default) norm pass, then the decision launch; 1 both in ONE launch (the last block decides) -- measured SLOWER on the chignolin step (1.774 against 1.763 ms): 1620 blocks arriving at one device-scope ticket cost more (~12 ns each) than the launch boundary saved */
+  CGV_OPT_OPTIM_ONE_LAUNCH = 15, /* cgv_optim_prepare*: 0 (default) norm pass, then the decision launch; 1 both in ONE launch (the last block decides) -- measured SLOWER on the chignolin step (1.774 against 1.763 ms): 1620 blocks arriving at one device-scope ticket cost more (~12 ns each) than the launch boundary saved; 2: as 0, and cgv_wgrad_gram keeps its separate reduce launch too (A/B: by default the LAST of a problem's eight slice blocks sums them) */
   CGV_OPT_COUNT = 16
 };
 /* Measurement: store the GPU wall clock (cgv_timestamp_hz ticks per second) into *slot, in stream order; capturable. */
@@ -228,6 +228,14 @@ int cgv_reparam_bwd(const float* g, const float* eps, const float* k_mu, const f
  * out[i, :] = weight[(int) ids[i * id_stride], :]; ids are clamped to [0, n_types). */
 int cgv_embedding_rows(const float* weight /*[n_types,C]*/, const float* ids_f32, int id_stride, int n_rows, int n_types,
                        int channels, float* out /*[n_rows,C]*/, void* stream);
+/* The two embedding lookups of a step (encoder: atom types, cgvae.py:268; prior: bead types, cgvae.py:381) in one launch,
+ * and their weight gradients (two segment sums over the type-id plans) in one launch. */
+int cgv_embedding_rows2(const float* weight_a, const float* ids_a, int id_stride_a, int n_rows_a, int n_types_a, float* out_a,
+                        const float* weight_b, const float* ids_b, int id_stride_b, int n_rows_b, int n_types_b, float* out_b,
+                        int channels, void* stream);
+int cgv_segment_reduce_pair(const float* src_a, const int32_t* rowptr_a, const int32_t* perm_a, int n_seg_a, float* out_a,
+                            const float* src_b, const int32_t* rowptr_b, const int32_t* perm_b, int n_seg_b, float* out_b,
+                            int channels, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * K2 / K4  fused EquiMessageBlock (conv.py:505-563 incl. InvariantMessage 63-75 and
