@@ -257,13 +257,13 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_k(
     lt_store_agent(part + b, kl);
     lt_store_agent(part + n_beads + b, rec);
     lt_store_agent(part + 2 * n_beads + b, gr);
-    __threadfence();
+    // (no __threadfence: an agent-scope release writes back the XCD's whole L2; the partials are agent-scope atomics --
+    // coherent across XCDs by themselves -- and acknowledged before the ticket)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
   }
   __syncthreads();
   if (!s_last) return;
-  __threadfence();
   double k2 = 0.0, r2 = 0.0, g2 = 0.0;
   for (int m = t; m < n_beads; m += T) { k2 += lt_load_agent(part + m); r2 += lt_load_agent(part + n_beads + m); g2 += lt_load_agent(part + 2 * n_beads + m); }
   lt_block_sum3(k2, r2, g2, sh);
