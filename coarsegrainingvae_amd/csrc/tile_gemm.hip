@@ -505,6 +505,10 @@ __global__ __launch_bounds__(256, 2) void tile_fwd_ring_k(const float* __restric
 // A THIRD gradient of the same input, held as one row per SEGMENT of the rows (the backward of
 // scatter_mean / scatter_add of this very input, cgvae.py:297: g[m, :] += src[seg(m), :] (/ len(seg(m)) for the mean)):
 // added in the store epilogue instead of by a broadcast launch + an accumulation add.
+// A second SOURCE of one output: gx = (g * act'(z)) W + (g2 * act2'(z2)) W2 (+ add ...), both reductions in one launch --
+// two layers that read the same input (the first Dense of contractive block i and of message block i + 1) return their
+// input gradients as one product instead of a chain of two launches.  Same N, K.
+struct BwdSource { const float* g; const float* W; const float* z; int act; };
 struct BwdSecond { const float* g; const float* W; float* gx; const float* z; const float* add; int act; };   // see TileSecond
 struct BcastAdd {
   const float* src;          // [n_seg, K] or NULL
@@ -519,7 +523,8 @@ __global__ __launch_bounds__(64 * WAVES) void tile_bwd_input_k(const float* __re
                                                         const float* __restrict__ z, int act,
                                                         const float* __restrict__ add = nullptr,
                                                         BcastAdd bc = BcastAdd{nullptr, nullptr, nullptr, 0},
-                                                        BwdSecond s2 = BwdSecond{nullptr, nullptr, nullptr, nullptr, nullptr, 0}) {
+                                                        BwdSecond s2 = BwdSecond{nullptr, nullptr, nullptr, nullptr, nullptr, 0},
+                                                        BwdSource more = BwdSource{nullptr, nullptr, nullptr, 0}) {
   if (blockIdx.z) { g = s2.g; W = s2.W; gx = s2.gx; z = s2.z; add = s2.add; act = s2.act; bc.src = nullptr; }
   __shared__ float red[WAVES - 1][MB * 4][4][64];    // [wave-1][mb*4 + s][reg][lane]
   const int lane = threadIdx.x & 63;
@@ -551,6 +556,16 @@ __global__ __launch_bounds__(64 * WAVES) void tile_bwd_input_k(const float* __re
   // resident block per CU (132 VGPRs; 704 rows: 12.7 -> 13.2 us per call, while 332 rows gained)
   constexpr int SB = WAVES >= 16 ? 3 : 2;
   const float* wcol = W + (kok ? kcol : 0);
+  ptrdiff_t zo = zoff;
+  const int n_src = more.g ? 2 : 1;
+  for (int src = 0; src < n_src; ++src) {
+  if (src == 1) {                                    // the second source: same rows / columns, other operands
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) gr[mb] = more.g + (gr[mb] - g);
+    act = more.act;
+    zo = act ? more.z - more.g : 0;
+    wcol = more.W + (kok ? kcol : 0);
+  }
   for (int st0 = wave * per; st0 < st_end; st0 += SB) {
     float4 a[SB][MB], zz[SB][MB], b[SB][4];
 #pragma unroll
@@ -563,7 +578,7 @@ __global__ __launch_bounds__(64 * WAVES) void tile_bwd_input_k(const float* __re
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
         a[u][mb] = *reinterpret_cast<const float4*>(gr[mb] + ng);
-        if (act) zz[u][mb] = *reinterpret_cast<const float4*>(gr[mb] + zoff + ng);     // wave-uniform
+        if (act) zz[u][mb] = *reinterpret_cast<const float4*>(gr[mb] + zo + ng);       // wave-uniform
       }
 #pragma unroll
       for (int c = 0; c < 4; ++c) b[u][c] = *reinterpret_cast<const float4*>(wcol + (size_t)(nw + c) * K);
@@ -589,6 +604,7 @@ __global__ __launch_bounds__(64 * WAVES) void tile_bwd_input_k(const float* __re
         }
       }
     }
+  }
   }
   if (wave > 0) {
 #pragma unroll
@@ -810,7 +826,8 @@ int cgv_tile_pair_linear_fwd(const float* x_a, const float* W_a, const float* bi
 static int tile_bwd_input_launch(const float* g, const float* z, int act, const float* W, float* gx, int M, int N, int K,
                                  void* stream, const char* what, const float* add = nullptr,
                                  cgv::BcastAdd bc = cgv::BcastAdd{nullptr, nullptr, nullptr, 0},
-                                 const cgv::BwdSecond* second = nullptr) {
+                                 const cgv::BwdSecond* second = nullptr,
+                                 cgv::BwdSource more = cgv::BwdSource{nullptr, nullptr, nullptr, 0}) {
   hipStream_t st = (hipStream_t)stream;
   const cgv::BwdSecond s2 = second ? *second : cgv::BwdSecond{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
   const unsigned np = second ? 2u : 1u;
@@ -821,19 +838,19 @@ static int tile_bwd_input_launch(const float* g, const float* z, int act, const 
   if (const int o = cgv::option(CGV_OPT_BWD_INPUT_WAVES); o > 0 && o != 32) waves = o;          // experiments only
   else if (blocks16 < 128 && N >= 1024) waves = 16;
   if (cgv::option(CGV_OPT_BWD_INPUT_WAVES) == 32)          /* A/B: 32-row tiles, 8 waves */
-    hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 8>), dim3(kt, (M + 31) / 32, np), dim3(512), 0, st, g, W, gx, M, N, K, z, act, add, bc, s2);
+    hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 8>), dim3(kt, (M + 31) / 32, np), dim3(512), 0, st, g, W, gx, M, N, K, z, act, add, bc, s2, more);
   else if (blocks32 >= 200 && blocks32 < 512 && waves == 8)
     // 200 .. 511 32-row tiles (704 rows x 600 / 1200 columns): still 32-row tiles, with the reduction split over 8 waves --
     // half the weight re-reads of the 16-row tiles (704 x 1800 x 600: 22.9 against 25.0 us, 704 x 5400: 54.6 / 64.1;
     // at 332 rows the 16-row tiles win, 14.5 against 22.1 us: tools/gemm_shapes.py)
-    hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 8>), dim3(kt, (M + 31) / 32, np), dim3(512), 0, st, g, W, gx, M, N, K, z, act, add, bc, s2);
+    hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 8>), dim3(kt, (M + 31) / 32, np), dim3(512), 0, st, g, W, gx, M, N, K, z, act, add, bc, s2, more);
   else if (blocks32 >= 512)               // enough 32-row tiles to fill the chip: halve the weight re-reads
-    hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 4>), dim3(kt, (M + 31) / 32, np), dim3(256), 0, st, g, W, gx, M, N, K, z, act, add, bc, s2);
+    hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 4>), dim3(kt, (M + 31) / 32, np), dim3(256), 0, st, g, W, gx, M, N, K, z, act, add, bc, s2, more);
   else if (waves == 16)                   // few output tiles and a long reduction (96 bead rows x 5400 columns: 60 blocks):
     // 16 waves per block split it -- 60 blocks of 8 waves left three quarters of the chip idle (17.8 us per call)
-    hipLaunchKernelGGL((cgv::tile_bwd_input_k<1, 16>), dim3(kt, (M + 15) / 16, np), dim3(1024), 0, st, g, W, gx, M, N, K, z, act, add, bc, s2);
+    hipLaunchKernelGGL((cgv::tile_bwd_input_k<1, 16>), dim3(kt, (M + 15) / 16, np), dim3(1024), 0, st, g, W, gx, M, N, K, z, act, add, bc, s2, more);
   else
-    hipLaunchKernelGGL((cgv::tile_bwd_input_k<1, 8>), dim3(kt, (M + 15) / 16, np), dim3(512), 0, st, g, W, gx, M, N, K, z, act, add, bc, s2);
+    hipLaunchKernelGGL((cgv::tile_bwd_input_k<1, 8>), dim3(kt, (M + 15) / 16, np), dim3(512), 0, st, g, W, gx, M, N, K, z, act, add, bc, s2, more);
   return cgv::check_launch(what);
 }
 
@@ -876,6 +893,25 @@ int cgv_tile_linear_bwd_input_act_add_bcast(const float* gy, const float* z, con
               "operands must be 16-byte aligned");
   return tile_bwd_input_launch(gy, act ? z : nullptr, act, W, gx, M, N, K, stream, "cgv_tile_linear_bwd_input_act_add_bcast", add,
                                cgv::BcastAdd{seg_grad, row2seg, seg_rowptr, mean});
+}
+
+/* gx = add + (gy_a * act_a'(z_a)) W_a + (gy_b * act_b'(z_b)) W_b [+ seg_grad spread over the rows]: the input gradient of TWO
+ * layers of one shape that read the same input, as one product (add, seg_grad may be NULL; seg_* as in
+ * cgv_tile_linear_bwd_input_act_add_bcast). */
+int cgv_tile_linear_bwd_input_sum2(const float* gy_a, const float* z_a, const float* W_a, const float* gy_b, const float* z_b,
+                                   const float* W_b, const float* add, const float* seg_grad, const int64_t* row2seg,
+                                   const int32_t* seg_rowptr, int mean, float* gx, int M, int N, int K, int act_a, int act_b,
+                                   void* stream) {
+  CGV_REQUIRE(gy_a && W_a && gy_b && W_b && gx, "null pointer");
+  CGV_REQUIRE((act_a == 0 || (act_a >= 1 && act_a <= cgv::CGV_ACT_MAX && z_a)) && (act_b == 0 || (act_b >= 1 && act_b <= cgv::CGV_ACT_MAX && z_b)),
+              "act != 0 needs the saved pre-activation");
+  CGV_REQUIRE(!seg_grad || (row2seg && seg_rowptr), "seg_grad needs its row -> segment map and the segments' row pointers");
+  CGV_REQUIRE(cgv_tile_supported(M, N, K), "unsupported shape (need N % 4 == 0, K % 4 == 0)");
+  CGV_REQUIRE(((((uintptr_t)gy_a | (uintptr_t)z_a | (uintptr_t)W_a | (uintptr_t)gy_b | (uintptr_t)z_b | (uintptr_t)W_b | (uintptr_t)gx |
+                 (uintptr_t)add | (uintptr_t)seg_grad)) & 15) == 0, "operands must be 16-byte aligned");
+  return tile_bwd_input_launch(gy_a, act_a ? z_a : nullptr, act_a, W_a, gx, M, N, K, stream, "cgv_tile_linear_bwd_input_sum2", add,
+                               cgv::BcastAdd{seg_grad, row2seg, seg_rowptr, mean}, nullptr,
+                               cgv::BwdSource{gy_b, W_b, act_b ? z_b : nullptr, act_b});
 }
 
 /* The backward-input products of two layers of ONE shape in one launch: gx_a = add_a + (gy_a * act'(z_a)) W_a, likewise b

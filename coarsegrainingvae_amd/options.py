@@ -19,6 +19,7 @@ HOST = {
     "quad_heads": 1,        # CGequiVAE.forward: 1 layer j of the prior's and the encoder's four heads in one launch, 0 one launch pair per (mu, sigma) pair
     "fused_loss_tail": 1,   # Trainer: 1 decoder tail + ELBO + their backward in one launch (cgv_loss_tail), 0 reconstruct_fwd / elbo_fwd / reconstruct_bwd
     "paired_embeddings": 1, # CGequiVAE.forward: 1 the encoder's and the prior's embedding lookups in one launch (and their weight gradients in one), 0 one launch each
+    "pair_sum2": 1,         # pair launches, shared input: 1 both layers' input gradients (+ alias, + parked segment gradient) as ONE two-source product, 0 a chain of two backward-input launches
     "head_pairs": 1,        # (mu, sigma) heads on more than 16 bead rows: 1 layer j of both heads as a pair launch of the tile kernels, 0 one launch per layer (second head through the first one's fork)
     "encoder_pairs": 1,     # EquiEncoder: 1 node MLPs of contractive block i and message block i + 1 (same input) as pair launches of the tile kernels (layer by layer), 0 one launch per layer
     "wgrad_split": 1,       # weight gradients of layers with > 128 operand rows: 1 bf16 matrix path with split operands (3 bf16 terms per fp32 value, 6 products, fp32 accumulation: fp32-class accuracy), 0 fp32 MFMA tiles

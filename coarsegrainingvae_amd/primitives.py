@@ -638,13 +638,30 @@ class _TilePairFn(torch.autograd.Function):
         if ctx.same:
             if need_a:
                 add = None if g_alias is None else g_alias.reshape(M, K).contiguous()
-                if gb is not None:
-                    add = single(gb, zb, wb, add, act_b)
                 parked = None
                 if slot is not None:
                     slot.linear_done = True
                     parked = slot.take()
-                if ga is not None and parked is not None and parked.dtype == torch.float32 and parked.is_contiguous() and parked.shape[1] == K:
+                par_ok = parked is None or (parked.dtype == torch.float32 and parked.is_contiguous() and parked.shape[1] == K
+                                            and parked.data_ptr() % 16 == 0)
+                if (ga is not None and gb is not None and par_ok and HOST_OPTION("pair_sum2")
+                        and (add is None or (add.dtype == torch.float32 and add.data_ptr() % 16 == 0))):
+                    # both layers' input gradients, the alias's and the parked segment gradient as ONE product with two sources
+                    gxa = new()
+                    _lib.call("cgv_tile_linear_bwd_input_sum2", _lib.ptr(ga), _lib.ptr(za) if act_a != ACT_NONE else None, _lib.ptr(wa),
+                              _lib.ptr(gb), _lib.ptr(zb) if act_b != ACT_NONE else None, _lib.ptr(wb), _lib.ptr(add), _lib.ptr(parked),
+                              _lib.ptr(slot.mapping) if parked is not None else None,
+                              _lib.ptr(slot.plan.rowptr_d) if parked is not None else None, int(slot.mean) if parked is not None else 0,
+                              _lib.ptr(gxa), M, N, K, act_a, act_b, st)
+                    parked = None
+                    gb_done = True
+                else:
+                    gb_done = False
+                if not gb_done and gb is not None:
+                    add = single(gb, zb, wb, add, act_b)
+                if gb_done:
+                    pass
+                elif ga is not None and parked is not None and parked.dtype == torch.float32 and parked.is_contiguous() and parked.shape[1] == K:
                     gxa = new()
                     _lib.call("cgv_tile_linear_bwd_input_act_add_bcast", _lib.ptr(ga), _lib.ptr(za) if act_a != ACT_NONE else None, _lib.ptr(wa),
                               _lib.ptr(add), _lib.ptr(parked), _lib.ptr(slot.mapping), _lib.ptr(slot.plan.rowptr_d), int(slot.mean),

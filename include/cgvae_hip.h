@@ -562,6 +562,14 @@ int cgv_tile_pair_linear_fwd(const float* x_a, const float* W_a, const float* bi
 int cgv_tile_pair_linear_bwd_input(const float* gy_a, const float* z_a, const float* W_a, const float* add_a, float* gx_a,
                                    const float* gy_b, const float* z_b, const float* W_b, const float* add_b, float* gx_b, int M,
                                    int N, int K, int act_a, int act_b, void* stream);
+/* gx = add + (gy_a * act_a'(z_a)) W_a + (gy_b * act_b'(z_b)) W_b [+ seg_grad spread over the rows]: the input gradient of two
+ * layers of one shape that read the SAME input, as one product with two sources (the first Dense of ContractiveMessageBlock i
+ * and of EquiMessageBlock i + 1, cgvae.py:286-305); add / seg_grad may be NULL, seg_* as in
+ * cgv_tile_linear_bwd_input_act_add_bcast. */
+int cgv_tile_linear_bwd_input_sum2(const float* gy_a, const float* z_a, const float* W_a, const float* gy_b, const float* z_b,
+                                   const float* W_b, const float* add, const float* seg_grad, const int64_t* row2seg,
+                                   const int32_t* seg_rowptr, int mean, float* gx, int M, int N, int K, int act_a, int act_b,
+                                   void* stream);
 int cgv_tile_linear_wgrad(const float* g, const float* x, float* gW, int M, int N, int K, int accumulate, void* stream);
 int cgv_wgrad_record_bytes(void);
 int cgv_wgrad_plan(int M, int N, int K, int* tiles_k /*[host]*/, int* tile_w /*[host]*/, int* n_blocks /*[host]*/);

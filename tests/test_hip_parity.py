@@ -2261,8 +2261,8 @@ def test_bead_mean_inside_the_contractive_block_equals_separate_launches(workloa
     (H0, h0, g0, c0), (H1, h1, g1, c1) = outs
     assert "cgv_segment_reduce2" in c1 and "cgv_segment_reduce2" not in c0
     assert c1.count("cgv_segment_broadcast") == (0 if queued else 1) and c0.count("cgv_segment_broadcast") == 1
-    if queued:
-        assert "cgv_tile_linear_bwd_input_act_add_bcast" in c1
+    if queued:                  # the parked gradient rode a backward-input epilogue (pair launches: the two-source product)
+        assert "cgv_tile_linear_bwd_input_act_add_bcast" in c1 or "cgv_tile_linear_bwd_input_sum2" in c1
     assert torch.equal(H1, H0) and torch.equal(h1, h0)            # same per-segment order: bit-identical forward
     n_live = 0
     for k, (a, b) in enumerate(zip(g1, g0)):
@@ -2359,7 +2359,7 @@ def test_encoder_node_mlps_as_pair_launches_equal_the_layer_by_layer_path(worklo
     n_pairs = layers - 1
     assert c1.count("cgv_tile_pair_linear_fwd") == 2 * n_pairs and "cgv_tile_pair_linear_fwd" not in c0
     assert c1.count("cgv_tile_pair_linear_bwd_input") == n_pairs
-    assert len(c1) == len(c0) - 3 * n_pairs, (len(c0), len(c1))                  # two forward launches and one backward launch per pair
+    assert len(c1) == len(c0) - 4 * n_pairs, (len(c0), len(c1))                  # two forward launches and two backward launches per pair
     assert "cgv_segment_broadcast" not in c1                                      # the bead-mean gradient still rides an epilogue
     assert torch.equal(H1, H0) and torch.equal(h1, h0)
     for k, (a, b) in enumerate(zip(g1, g0)):
@@ -2414,7 +2414,7 @@ def test_head_layers_as_tile_pair_launches_vs_fp64(M, act, options):
         arena.zero_grad()
         res.append(run(pairs))
     (ya0, yb0, gx0, gp0, c0), (ya1, yb1, gx1, gp1, c1) = res
-    assert c1.count("cgv_tile_pair_linear_fwd") == 2 and c1.count("cgv_tile_pair_linear_bwd_input") == 1 and len(c1) == len(c0) - 3
+    assert c1.count("cgv_tile_pair_linear_fwd") == 2 and c1.count("cgv_tile_pair_linear_bwd_input") == 1 and len(c1) == len(c0) - 4
     assert torch.equal(ya1, ya0) and torch.equal(yb1, yb0)
     # fp64 reference
     d = lambda t: t.detach().double().cpu()
