@@ -2454,3 +2454,50 @@ def test_paired_embedding_lookups_and_their_weight_gradients():
     assert torch.equal(oa, ra) and torch.equal(ob, rb)
     assert torch.equal(ga, ea.weight.grad) and torch.equal(gb, eb.weight.grad)
     assert float(ga[0].abs().max()) == 0.0 and float(ga.abs().max()) > 0
+
+
+@pytest.mark.parametrize("M,N,K", [(70, 52, 36), (129, 132, 260), (332, 1800, 600), (33, 1200, 64)])
+def test_tile_pair_entry_points_on_ragged_shapes_vs_fp64(M, N, K):
+    """The C-ABI pair launches of the tile kernels called directly (cgv_tile_pair_linear_fwd, cgv_tile_pair_linear_bwd_input,
+    cgv_tile_linear_bwd_input_sum2): row / column counts that are no multiples of the 16 / 32 / 64-wide tiles, a different
+    activation code per problem, NULL and non-NULL `add`, with and without a per-segment gradient -- against fp64."""
+    L = cg._lib
+    if not L.load().cgv_tile_pair_supported(M, N, K):
+        pytest.skip("this shape runs on the LDS-staged kernels (no pair launch)")
+    gen = torch.Generator().manual_seed(M * 7 + N)
+    mk = lambda *s: torch.randn(*s, generator=gen).to(DEV)
+    xa, xb, Wa, Wb, ba, bb = mk(M, K), mk(M, K), mk(N, K) * 0.1, mk(N, K) * 0.1, mk(N), mk(N)
+    ya, yb, za, zb = (torch.full((M, N), float("nan"), device=DEV) for _ in range(4))
+    st = L.stream_ptr()
+    L.call("cgv_tile_pair_linear_fwd", L.ptr(xa), L.ptr(Wa), L.ptr(ba), L.ptr(ya), L.ptr(za), L.ptr(xb), L.ptr(Wb), L.ptr(bb), L.ptr(yb),
+           L.ptr(zb), M, N, K, 1, 2, st)                                     # swish / tanh
+    d = lambda t: t.double().cpu()
+    za64, zb64 = d(xa) @ d(Wa).t() + d(ba), d(xb) @ d(Wb).t() + d(bb)
+    assert_close(za, za64, "z_a", 2e-6)
+    assert_close(ya, za64 * torch.sigmoid(za64), "y_a", 5e-6)
+    assert_close(yb, torch.tanh(zb64), "y_b", 5e-6)               # (the fp32 tanh itself is good to a few ulp)
+    # backward-input of both (different outputs), one with an `add`
+    ga, gb, add_b = mk(M, N), mk(M, N), mk(M, K)
+    gxa, gxb = torch.full((M, K), float("nan"), device=DEV), torch.full((M, K), float("nan"), device=DEV)
+    L.call("cgv_tile_pair_linear_bwd_input", L.ptr(ga), L.ptr(za), L.ptr(Wa), None, L.ptr(gxa), L.ptr(gb), L.ptr(zb), L.ptr(Wb), L.ptr(add_b),
+           L.ptr(gxb), M, N, K, 1, 2, st)
+    s = torch.sigmoid(za64)
+    da = d(ga) * (s * (1 + za64 * (1 - s)))
+    db = d(gb) * (1 - torch.tanh(zb64) ** 2)
+    assert_close(gxa, da @ d(Wa), "gx_a", 5e-6)
+    assert_close(gxb, db @ d(Wb) + d(add_b), "gx_b", 5e-6)
+    # both sources into ONE output, + add, + a gradient held per segment of the rows (mean)
+    n_seg = 5
+    mapping = (torch.arange(M) % n_seg).to(DEV)
+    plan = EdgePlan.from_mapping(mapping, n_seg)
+    seg = mk(n_seg, K)
+    for with_seg in (False, True):
+        gx = torch.full((M, K), float("nan"), device=DEV)
+        L.call("cgv_tile_linear_bwd_input_sum2", L.ptr(ga), L.ptr(za), L.ptr(Wa), L.ptr(gb), L.ptr(zb), L.ptr(Wb), L.ptr(add_b),
+               L.ptr(seg) if with_seg else None, L.ptr(mapping) if with_seg else None, L.ptr(plan.rowptr_d) if with_seg else None, 1,
+               L.ptr(gx), M, N, K, 1, 2, st)
+        ref = da @ d(Wa) + db @ d(Wb) + d(add_b)
+        if with_seg:
+            counts = torch.bincount(mapping.cpu(), minlength=n_seg).clamp_min(1).double()
+            ref = ref + (d(seg) / counts.unsqueeze(1))[mapping.cpu()]
+        assert_close(gx, ref, f"sum2 (segment gradient: {with_seg})", 5e-6)
