@@ -116,7 +116,7 @@ PROTOTYPES = {
     "cgv_decoder_gate_fwd": (_i, [_p] * 9 + [_i, _i, _p]),
     "cgv_decoder_gate_bwd": (_i, [_p, _p, _p, _p, _i, C.c_int64, _p, _p, _p, _p, _p, _p, C.c_int64, _i, _i, _p]),
     "cgv_decoder_dense_bwd": (_i, [_p, _i, C.c_int64, _p, _i, _p, _p, _p, C.c_int64, _i, _i, _i, _p]),
-    "cgv_decoder_uv_bwd": (_i, [_p, _i, C.c_int64, _p, _p, _p, _p, _p, _p, _p, C.c_int64, _i, _i, _p]),
+    "cgv_decoder_uv_bwd": (_i, [_p, _i, C.c_int64, _p, _p, _p, _p, _p, _p, _p, _p, C.c_int64, _i, _i, _p]),
     "cgv_decoder_msg_bwd": (_i, [_p] * 15 + [_p, _i, C.c_int64, _p, _p, _p] + [_p] * 8 + [C.c_int64, _i, _i, _i, _i, _p]),
     "cgv_decoder_slices_to_dense": (_i, [_p, _p, _i, C.c_int64, _p, _i, _i, _p]),
     "cgv_dense_grad_prepare": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
@@ -177,7 +177,7 @@ PROTOTYPES = {
 # include/cgvae_hip.h: CGV_OPT_* (A/B switches of the launchers; defaults in csrc/api.cpp)
 OPTIONS = {"msg_fwd_split": 0, "msg_bwd_split": 1, "msg_fwd_kernel": 2, "grp_waves": 3, "grp_records": 4, "csr_build": 5,
            "pseudo_chunks": 6, "wgrad_tiling": 7, "tile_fwd_lds_min": 8, "bwd_input_waves": 9, "pseudo_fwd": 10, "decoder_fat": 11, "decoder_wlds": 12, "skinny_rows": 13,
-           "tile_fwd_bal": 14, "optim_one_launch": 15}
+           "tile_fwd_bal": 14, "optim_one_launch": 15, "decoder_colsplit": 16}
 
 
 def set_option(name: str, value: int) -> None:

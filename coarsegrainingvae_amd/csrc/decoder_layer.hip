@@ -39,7 +39,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // (__constant__: read by ONE scalar load per kernel; as a __device__ variable every tick was a vector load followed by
 // s_waitcnt vmcnt(0) -- which also drained every prefetch in flight at that point)
 __constant__ unsigned long long* g_dl_clock = nullptr;
-#define DL_TICK(i) do { if (g_dl_clock && blockIdx.x == 0 && threadIdx.x == 0) g_dl_clock[i] = wall_clock64(); } while (0)
 // launch spans for a layer's timeline: slots 32 + 4 id + {0, 1}: first block's begin / end, {2, 3}: last block's
 // (ids: 0 F1 dense, 1 F2 message, 2 F3 uv, 3 F4 dense, 4 F5 gate, 5 B1 gate, 6 B2 dense, 7 B3 uv, 8 B4 message, 9 B5 dense)
 #define DL_SPAN(id, end)                                                                                    \
@@ -49,6 +48,9 @@ __constant__ unsigned long long* g_dl_clock = nullptr;
       if (blockIdx.x == gridDim.x - 1) g_dl_clock[32 + 4 * (id) + 2 + (end)] = wall_clock64();              \
     }                                                                                                       \
   } while (0)
+
+// per-phase ticks of block 0 of EVERY decoder launch: slots 80 + 10 id + i (ids as above, i < 10); buf: 192 uint64
+#define DL_PH(id, i) do { if (g_dl_clock && blockIdx.x == 0 && threadIdx.x == 0) g_dl_clock[80 + 10 * (id) + (i)] = wall_clock64(); } while (0)
 
 constexpr int DL_CB = 4;                 // channels per block
 constexpr int DL_WAVES = 9;
@@ -162,7 +164,7 @@ __device__ __forceinline__ void quad_issue(QuadRegs<MB, NQ, QS>& r, gcf slices, 
 // Sum: per class ascending slice index, then the 36 classes in order.  tile[q][m] valid after the trailing barrier.
 template <int MB, int NQ, int QS>
 __device__ __forceinline__ void quad_finish(const QuadRegs<MB, NQ, QS>& r, float4* __restrict__ tile /*[NQ][16 MB]*/,
-                                            float4* __restrict__ scratch /*NQ * 36 * 16 MB*/, int n_slices, int rows) {
+                                            float4* __restrict__ scratch /*NQ * 36 * 16 MB*/, int n_slices, int rows, int ph = -1) {
   constexpr int MP = 16 * MB;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int m = lane & 15, cls = wave * 4 + (lane >> 4);
@@ -178,7 +180,9 @@ __device__ __forceinline__ void quad_finish(const QuadRegs<MB, NQ, QS>& r, float
       acc.x += __shfl_xor(acc.x, 32); acc.y += __shfl_xor(acc.y, 32); acc.z += __shfl_xor(acc.z, 32); acc.w += __shfl_xor(acc.w, 32);
       if (lane < 16) scratch[((q * DL_WAVES + wave) * MB + mb) * 16 + m] = acc;
     }
+  if (ph >= 0) DL_PH(ph, 2);                                              // this wave's slices landed and summed
   __syncthreads();
+  if (ph >= 0) DL_PH(ph, 3);                                              // every wave's
   if (threadIdx.x < NQ * MP) {
     const int q = threadIdx.x / MP, mm = threadIdx.x - q * MP;
     float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -201,14 +205,32 @@ __device__ __forceinline__ void quad_finish(const QuadRegs<MB, NQ, QS>& r, float
 template <int G, int NT>
 struct BiRegs { float4 w[NT][G]; };
 
+// Column tiles of a backward-input product.  These products are bound by the fp32 MFMA pipe of the block's CU (16x16x4:
+// 32 cycles each; a 64-column tile of G row groups over MB row blocks is 4 G MB of them), so (i) the grid's y dimension
+// splits the tiles of one channel group over gridDim.y blocks = CUs (each part repeats the prologue and writes its own
+// columns of the group's slice; dense outputs are written by part 0) and (ii) a block's tiles go to its 9 waves in an
+// order that keeps SIMD 0 -- which hosts waves 0, 4 and 8 -- from taking the surplus tiles of a round as well.
+struct TileRange { int beg, end; };
+__device__ __forceinline__ TileRange dl_tile_range(int K) {
+  const int tiles = (K + 63) / 64, per = (tiles + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int beg = (int)blockIdx.y * per;
+  return TileRange{beg, min(beg + per, tiles)};
+}
+// tile of wave `wave` in round t: round 0 in wave order, later rounds in the order 1, 2, 3, 5, 6, 7, 0, 4, 8
+__device__ __forceinline__ int dl_tile_of(const TileRange& tr, int wave, int t) {
+  const int pos = t == 0 ? wave : (int)((0x854372106ull >> (4 * wave)) & 15);
+  return tr.beg + DL_WAVES * t + pos;
+}
+
 template <int G, int NT>
-__device__ __forceinline__ void bi_prefetch(BiRegs<G, NT>& r, gcf W, int K, const int (&row0)[G]) {
+__device__ __forceinline__ void bi_prefetch(BiRegs<G, NT>& r, gcf W, int K, const int (&row0)[G], const TileRange& tr) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 15, q = lane >> 4;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    const int col = (wave + DL_WAVES * t) * 64 + 4 * j;
-    const int cc = col < K ? col : 0;                                     // clamped: always-valid address, result unused
+    const int tile = dl_tile_of(tr, wave, t);
+    const int col = tile * 64 + 4 * j;
+    const int cc = (tile < tr.end && col < K) ? col : 0;                  // clamped: always-valid address, result unused
 #pragma unroll
     for (int g = 0; g < G; ++g) r.w[t][g] = ldg4_stream(W + (size_t)(row0[g] + q) * K + cc);
   }
@@ -247,16 +269,16 @@ __host__ __device__ constexpr size_t bi_stage_floats() { return (size_t)DL_WAVES
 template <int MB, int G, int NT, int NPRE = NT>
 __device__ __forceinline__ void bi_core(const BiRegs<G, NPRE>& r, const float* __restrict__ g_tile /*[16 MB][G*4] LDS*/,
                                         float* __restrict__ stage /*bi_stage_floats<MB>() LDS*/,
-                                        float* __restrict__ slice /*[K/4][rows][4]*/, int K, int rows,
-                                        const float* __restrict__ W = nullptr, const int* row0 = nullptr) {
+                                        float* __restrict__ slice /*[K/4][rows][4]*/, int K, int rows, const TileRange& tr,
+                                        const float* __restrict__ W = nullptr, const int* row0 = nullptr, int ph = -1) {
   constexpr int MP = 16 * MB;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 15, q = lane >> 4;
   float4* st = reinterpret_cast<float4*>(stage) + (size_t)wave * 16 * MP;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    const int tile = wave + DL_WAVES * t;
-    if (tile * 64 >= K) break;                                            // wave-uniform
+    const int tile = dl_tile_of(tr, wave, t);
+    if (tile >= tr.end) continue;                                         // wave-uniform
     f32x4 acc[MB][4];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
@@ -287,6 +309,7 @@ __device__ __forceinline__ void bi_core(const BiRegs<G, NPRE>& r, const float* _
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr)
         st[j * MP + mb * 16 + 4 * q + rr] = make_float4(acc[mb][0][rr], acc[mb][1][rr], acc[mb][2][rr], acc[mb][3][rr]);
+    if (ph >= 0 && t == 0) DL_PH(ph, 7);                                 // first tile: weights landed, MFMAs done, staged
     // (same wave wrote, same wave reads: wave-synchronous through LDS)
     const int quads = min(16, (K - tile * 64) / 4);                       // K % 4 == 0
     float4* out = reinterpret_cast<float4*>(slice) + (size_t)tile * 16 * rows;
@@ -307,10 +330,12 @@ __host__ __device__ constexpr size_t fwd_red_floats() { return (size_t)DL_WAVES 
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // SB = 16-float steps whose loads are issued together (a wave has ceil(ceil(K / 16) / 9) steps: 5 at K = 600, so SB >= 5
 // makes the product ONE round trip); after_issue() runs behind the first batch's loads, before they are consumed.
-template <int MB, int G, int SB = (((G + 3) / 4) * MB >= 3 ? 5 : 9), typename Hook = NoHook, int TK = -1>
+// ph: phase-clock id of the calling kernel (ticks 1: requests issued, 2: MFMAs done + partials in LDS, 3: barrier,
+// 4: cross-wave sum + barrier), -1: none
+template <int MB, int G, int SB = (((G + 3) / 4) * MB >= 3 ? 5 : 9), typename Hook = NoHook>
 __device__ __forceinline__ void fwd_core(float* __restrict__ out, float* __restrict__ red, const float* __restrict__ x,
                                          int M, int K, const float* __restrict__ W, const int (&row0)[G],
-                                         Hook after_issue = Hook()) {
+                                         Hook after_issue = Hook(), int ph = -1) {
   constexpr int T = (G + 3) / 4;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, q = lane >> 4;
@@ -344,7 +369,7 @@ __device__ __forceinline__ void fwd_core(float* __restrict__ out, float* __restr
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) b[u][mb] = *reinterpret_cast<const float4*>(xrow[mb] + kc);
     }
-    if (first) { after_issue(); first = false; if (TK >= 0) DL_TICK(TK); }
+    if (first) { after_issue(); first = false; if (ph >= 0) DL_PH(ph, 1); }
 #pragma unroll
     for (int u = 0; u < SB; ++u) {
       if (s0 + u < s_end) {
@@ -370,9 +395,9 @@ __device__ __forceinline__ void fwd_core(float* __restrict__ out, float* __restr
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) red[(((wave * T + t) * MB + mb) * 4 + r) * 64 + lane] = acc[t][mb][r];
-  if (TK >= 0) DL_TICK(TK + 1);
+  if (ph >= 0) DL_PH(ph, 2);
   __syncthreads();
-  if (TK >= 0) DL_TICK(TK + 2);
+  if (ph >= 0) DL_PH(ph, 3);
   for (int o = threadIdx.x; o < T * MB * 256; o += DL_THREADS) {
     const int l = o & 63, r = (o >> 6) & 3, rest = o >> 8;              // rest = t * MB + mb
     const int mb = rest % MB, t = rest / MB;
@@ -383,7 +408,7 @@ __device__ __forceinline__ void fwd_core(float* __restrict__ out, float* __restr
     if (g < G) out[(m * G + g) * 4 + r] = v;
   }
   __syncthreads();
-  if (TK >= 0) DL_TICK(TK + 3);
+  if (ph >= 0) DL_PH(ph, 4);
 }
 
 // ---------------------------------------------------------------------------------------------- forward core, weights by LDS-DMA
@@ -412,7 +437,7 @@ __device__ __forceinline__ void wlds_issue(float* __restrict__ w_l, const float*
 // that publishes the DMA'd weights.
 template <int G, typename Hook>
 __device__ __forceinline__ void fwd_core_wlds(float* __restrict__ out, float* __restrict__ red, const float* __restrict__ x,
-                                              int M, int K, const float* __restrict__ w_l, Hook after_issue) {
+                                              int M, int K, const float* __restrict__ w_l, Hook after_issue, int ph = -1) {
   constexpr int T = (G + 3) / 4, SB = 6;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, q = lane >> 4;
@@ -426,8 +451,10 @@ __device__ __forceinline__ void fwd_core_wlds(float* __restrict__ out, float* __
     b[u] = *reinterpret_cast<const float4*>(xrow + ((s_beg + u < s_end && k < K) ? k : 0));
   }
   after_issue();
+  if (ph >= 0) DL_PH(ph, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if (ph >= 0) DL_PH(ph, 2);
   f32x4 acc[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -454,6 +481,7 @@ __device__ __forceinline__ void fwd_core_wlds(float* __restrict__ out, float* __
   for (int t = 0; t < T; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[((wave * T + t) * 4 + r) * 64 + lane] = acc[t][r];
+  if (ph >= 0) DL_PH(ph, 3);
   __syncthreads();
   for (int o = threadIdx.x; o < T * 256; o += DL_THREADS) {
     const int l = o & 63, r = (o >> 6) & 3, t = o >> 8;
@@ -464,6 +492,7 @@ __device__ __forceinline__ void fwd_core_wlds(float* __restrict__ out, float* __
     if (g < G) out[(m * G + g) * 4 + r] = v;
   }
   __syncthreads();
+  if (ph >= 0) DL_PH(ph, 4);
 }
 
 // ---------------------------------------------------------------------------------------------- staging of the bead graph
@@ -555,7 +584,7 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_fwd_k(
 #pragma unroll
   for (int g = 0; g < 9; ++g) row0[g] = g * F + f0;
   if (WLDS) wlds_issue<9>(w_l, W2, F, row0);
-  DL_TICK(8);
+  DL_PH(1, 0);
   DL_SPAN(1, 0);
   const gcf geom = launder(geom_); const gci rowptr = launder(rowptr_); const gci src = launder(src_);
   const gcf s = launder(s_); const gcf sbar = launder(sbar_); const gcf v = launder(v_);
@@ -572,16 +601,14 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_fwd_k(
   for (int nn = 0; nn < R; ++nn) W[nn] = ldg_pinned(Wd + ((size_t)k * F + f) * R + nn);
   W[R] = ldg_pinned(bd + (size_t)k * F + f);
   pin_loads();
-  DL_TICK(9);
   auto commit = [&]() {
     copy4_commit(r_geom, geom_l, E * GS / 4);
     int_commit(r_rp, rp_l, n + 1); int_commit(r_src, src_l, E);
     scalar_commit(r_s, true, s_l, n); scalar_commit(r_sb, true, sb_l, n);
     vector_commit(r_v, true, v_l, n); vector_commit(r_vb, true, vb_l, n);
   };
-  if (WLDS) fwd_core_wlds<9>(phi_l, red, a1, n, F, w_l, commit);
-  else fwd_core<1, 9, 5>(phi_l, red, a1, n, F, W2, row0, commit);
-  DL_TICK(10);
+  if (WLDS) fwd_core_wlds<9>(phi_l, red, a1, n, F, w_l, commit, 1);
+  else fwd_core<1, 9, 5>(phi_l, red, a1, n, F, W2, row0, commit, 1);
   // bias, dense copy for the backward pass (phi[m][g F + f0 .. +3])
   for (int o = threadIdx.x; o < 16 * 9; o += DL_THREADS) {
     const int m = o / 9, g = o - m * 9;
@@ -592,7 +619,7 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_fwd_k(
     if (m < n) *reinterpret_cast<float4*>(phi_out + (size_t)m * 9 * F + (size_t)g * F + f0) = p;
   }
   __syncthreads();
-  DL_TICK(11);
+  DL_PH(1, 5);
   // EquiMessagePsuedo, wave k = filter k (pseudo_msg.hip: pseudo_fwd_k), lane = (receiver i, channel c)
   const int ic = live ? i : 0;
   const float s_i = s_l[ic * 4 + c], sb_i = sb_l[ic * 4 + c];
@@ -618,7 +645,7 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_fwd_k(
       default: daxpy(acc, q, dcross(vb_i, vj)); break;
     }
   }
-  DL_TICK(12);
+  DL_PH(1, 6);
   if (k > 0) { red2[((k - 1) * 3 + 0) * 64 + lane] = acc.x; red2[((k - 1) * 3 + 1) * 64 + lane] = acc.y; red2[((k - 1) * 3 + 2) * 64 + lane] = acc.z; }
   __syncthreads();
   if (k != 0 || !live) { DL_SPAN(1, 1); return; }
@@ -639,7 +666,7 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_fwd_k(
   rows_out[((size_t)3 * i + 0) * F + f] = av.x;
   rows_out[((size_t)3 * i + 1) * F + f] = av.y;
   rows_out[((size_t)3 * i + 2) * F + f] = av.z;
-  DL_TICK(13);
+  DL_PH(1, 7);
   DL_SPAN(1, 1);
 }
 
@@ -659,18 +686,19 @@ __global__ __launch_bounds__(DL_THREADS) void dec_dense_fwd_k(const float* __res
   const gcf bias = launder(bias_);
   const float b = (mine && bias) ? ldg_pinned(bias + n0 + c) : 0.f;
   pin_loads();
-  DL_SPAN(K > N ? 3 : 0, 0);
-  DL_TICK(14);
+  const int ph = K > N ? 3 : 0;
+  DL_SPAN(ph, 0);
+  DL_PH(ph, 0);
   // one batch of requests per wave either way; the narrower batch issues no clamped surplus loads at K <= 720
-  if (K <= 16 * DL_WAVES * 5) fwd_core<1, 1, 5, NoHook, 15>(o_l, red, x, n, K, W, row0);
-  else fwd_core<1, 1, 9>(o_l, red, x, n, K, W, row0);
+  if (K <= 16 * DL_WAVES * 5) fwd_core<1, 1, 5>(o_l, red, x, n, K, W, row0, NoHook(), ph);
+  else fwd_core<1, 1, 9>(o_l, red, x, n, K, W, row0, NoHook(), ph);
   if (mine) {
     const float zv = o_l[i * 4 + c] + b;
     const size_t at = (size_t)i * N + n0 + c;
     if (act) { if (zout) zout[at] = zv; y[at] = act_fwd(zv, act); } else y[at] = zv;
   }
-  DL_TICK(19);
-  DL_SPAN(K > N ? 3 : 0, 1);
+  DL_PH(ph, 5);
+  DL_SPAN(ph, 1);
 }
 
 // Up to four Dense layers of one shape in one launch (blockIdx.y picks the layer): the mu / sigma heads are independent of
@@ -716,7 +744,8 @@ __global__ __launch_bounds__(DL_THREADS) void dec_uv_fwd_k(const float* __restri
   const int f0 = blockIdx.x * DL_CB;
   const int row0[2] = {f0, F + f0};
   DL_SPAN(2, 0);
-  fwd_core<3, 2>(uv_l, red, rows, 3 * n, F, Wuv, row0);
+  DL_PH(2, 0);
+  fwd_core<3, 2>(uv_l, red, rows, 3 * n, F, Wuv, row0, NoHook(), 2);
   for (int o = threadIdx.x; o < 3 * n * 2; o += DL_THREADS) {
     const int m = o >> 1, g = o & 1;
     *reinterpret_cast<float4*>(UV + (size_t)m * 2 * F + (size_t)g * F + f0) = *reinterpret_cast<const float4*>(uv_l + (m * 2 + g) * 4);
@@ -726,6 +755,7 @@ __global__ __launch_bounds__(DL_THREADS) void dec_uv_fwd_k(const float* __restri
     const float x = uv_l[((3 * i + 0) * 2 + 1) * 4 + c], y = uv_l[((3 * i + 1) * 2 + 1) * 4 + c], z = uv_l[((3 * i + 2) * 2 + 1) * 4 + c];
     stack[(size_t)i * 2 * F + F + f0 + c] = sqrtf(((x * x + 1e-10f) + (y * y + 1e-10f)) + (z * z + 1e-10f));      // conv.py:600
   }
+  DL_PH(2, 5);
   DL_SPAN(2, 1);
 }
 
@@ -746,6 +776,7 @@ __global__ __launch_bounds__(DL_THREADS) void dec_gate_fwd_k(const float* __rest
   const bool mine = threadIdx.x < n * 4;
   const int i = threadIdx.x >> 2, c = threadIdx.x & 3, f = f0 + c;
   DL_SPAN(4, 0);
+  DL_PH(4, 0);
   const gcf UV = launder(UV_); const gcf v2 = launder(v2_); const gcf stack = launder(stack_);
   const gcf b1p = launder(b1p_);
   if (mine) {
@@ -757,8 +788,8 @@ __global__ __launch_bounds__(DL_THREADS) void dec_gate_fwd_k(const float* __rest
     bvv = ldg_pinned(b1p + f); bsv = ldg_pinned(b1p + F + f); bss = ldg_pinned(b1p + 2 * F + f);
   }
   pin_loads();
-  if (F <= 16 * DL_WAVES * 5) fwd_core<1, 3, 5>(a_l, red, a0, n, F, W1p, row0);
-  else fwd_core<1, 3, 9>(a_l, red, a0, n, F, W1p, row0);
+  if (F <= 16 * DL_WAVES * 5) fwd_core<1, 3, 5>(a_l, red, a0, n, F, W1p, row0, NoHook(), 4);
+  else fwd_core<1, 3, 9>(a_l, red, a0, n, F, W1p, row0, NoHook(), 4);
   if (mine) {
     const float a_vv = a_l[(i * 3 + 0) * 4 + c] + bvv, a_sv = a_l[(i * 3 + 1) * 4 + c] + bsv, a_ss = a_l[(i * 3 + 2) * 4 + c] + bss;
     float* ao = a_out + (size_t)i * 3 * F + f;
@@ -767,6 +798,7 @@ __global__ __launch_bounds__(DL_THREADS) void dec_gate_fwd_k(const float* __rest
     st3(v3 + nf * 3, ux * a_vv + r.x, uy * a_vv + r.y, uz * a_vv + r.z);                  // conv.py:607, cgvae.py:123
     s3[nf] = ((ux * vx + uy * vy + uz * vz) * a_sv + a_ss) + s2;                           // conv.py:612-614, cgvae.py:122
   }
+  DL_PH(4, 5);
   DL_SPAN(4, 1);
 }
 
@@ -792,6 +824,7 @@ __global__ __launch_bounds__(DL_THREADS) void dec_gate_bwd_k(
 #pragma unroll
     for (int q = 0; q < CBQ; ++q) row0[g * CBQ + q] = g * F + f0 + 4 * q;
   DL_SPAN(5, 0);
+  DL_PH(5, 0);
   const gcf UV = launder(UV_); const gcf a = launder(a_); const gcf gs_base = launder(gs_base_);
   const gcf gs_slices = launder(gs_slices_); const gcf gv = launder(gv_); const gcf W1p = launder(W1p_);
   // order of requests: the slices and the prologue's own operands first, the weights behind them
@@ -813,25 +846,33 @@ __global__ __launch_bounds__(DL_THREADS) void dec_gate_bwd_k(
     if (gs_base) gsb = ldg_pinned(gs_base + nf);
     if (gv) { const f3 t = ld3_pinned(gv + nf * 3); gx = t.x; gy = t.y; gz = t.z; }
   }
+  const TileRange tr = dl_tile_range(F);
+  const bool part0 = blockIdx.y == 0;                                   // dense outputs: written once per channel group
   BiRegs<G, 2> wr;
-  bi_prefetch<G, 2>(wr, W1p, F, row0);
+  bi_prefetch<G, 2>(wr, W1p, F, row0, tr);
   pin_loads();
+  DL_PH(5, 1);
   for (int o = threadIdx.x; o < 16 * G * 4; o += DL_THREADS) g_l[o] = 0.f;
-  quad_finish<1, CBQ>(qr, gs_l, scratch, have_slices ? gs_n : 0, n);         // no slices: every class empty -> zeros
+  quad_finish<1, CBQ>(qr, gs_l, scratch, have_slices ? gs_n : 0, n, 5);      // no slices: every class empty -> zeros
+  DL_PH(5, 4);
   if (mine) {
     const int q = c >> 2, c4 = c & 3;
     const float gs = reinterpret_cast<const float*>(gs_l + q * 16)[i * 4 + c4] + gsb;
-    gs_sum[nf] = gs;
     const float inner = ux * vx + uy * vy + uz * vz;
     const float cs = gs * a_sv;
     const float g0 = gx * ux + gy * uy + gz * uz, g1 = gs * inner, g2 = gs;
-    ga[cc] = g0; ga[cc + F] = g1; ga[cc + 2 * F] = g2;
     g_l[(i * G + 0 * CBQ + q) * 4 + c4] = g0; g_l[(i * G + 1 * CBQ + q) * 4 + c4] = g1; g_l[(i * G + 2 * CBQ + q) * 4 + c4] = g2;
-    gUV[b] = fmaf(gx, a_vv, cs * vx); gUV[b + 2 * F] = fmaf(gy, a_vv, cs * vy); gUV[b + 4 * F] = fmaf(gz, a_vv, cs * vz);
-    gUV[b + F] = cs * ux; gUV[b + 2 * F + F] = cs * uy; gUV[b + 4 * F + F] = cs * uz;
+    if (part0) {
+      gs_sum[nf] = gs;
+      ga[cc] = g0; ga[cc + F] = g1; ga[cc + 2 * F] = g2;
+      gUV[b] = fmaf(gx, a_vv, cs * vx); gUV[b + 2 * F] = fmaf(gy, a_vv, cs * vy); gUV[b + 4 * F] = fmaf(gz, a_vv, cs * vz);
+      gUV[b + F] = cs * ux; gUV[b + 2 * F + F] = cs * uy; gUV[b + 4 * F + F] = cs * uz;
+    }
   }
   __syncthreads();
-  bi_core<1, G, 2>(wr, g_l, stage, slices_out + (size_t)blockIdx.x * out_stride, F, n);
+  DL_PH(5, 6);
+  bi_core<1, G, 2>(wr, g_l, stage, slices_out + (size_t)blockIdx.x * out_stride, F, n, tr, nullptr, nullptr, 5);
+  DL_PH(5, 8);
   DL_SPAN(5, 1);
 }
 
@@ -848,7 +889,9 @@ __global__ __launch_bounds__(DL_THREADS) void dec_dense_bwd_k(const float* __res
   float4* sum_l = reinterpret_cast<float4*>(cv.take(CBQ * 16 * 4));
   float* g_l = cv.take(16 * CBQ * 4);
   const int n0 = blockIdx.x * C;
-  DL_SPAN(K > N ? 6 : 9, 0);
+  const int ph = K > N ? 6 : 9;
+  DL_SPAN(ph, 0);
+  DL_PH(ph, 0);
   const gcf g_slices = launder(g_slices_); const gcf z = launder(z_); const gcf W = launder(W_);
   int row0[CBQ], kq[CBQ];
 #pragma unroll
@@ -859,23 +902,28 @@ __global__ __launch_bounds__(DL_THREADS) void dec_dense_bwd_k(const float* __res
   const size_t at = (size_t)i * N + n0 + c;
   float zz = 0.f;
   if (threadIdx.x < 16 * C && i < n && act) zz = ldg_pinned(z + at);
+  const TileRange tr = dl_tile_range(K);
   BiRegs<CBQ, NT> wr;
-  bi_prefetch<CBQ, NT>(wr, W, K, row0);
+  bi_prefetch<CBQ, NT>(wr, W, K, row0, tr);
   pin_loads();
-  quad_finish<1, CBQ>(qr, sum_l, scratch, g_n, n);
+  DL_PH(ph, 1);
+  quad_finish<1, CBQ>(qr, sum_l, scratch, g_n, n, ph);
+  DL_PH(ph, 4);
   if (threadIdx.x < 16 * C) {
     const int q = c >> 2, c4 = c & 3;
     float g = 0.f;
     if (i < n) {
       g = reinterpret_cast<const float*>(sum_l + q * 16)[i * 4 + c4];
-      g_dense[at] = g;                                                    // the weight-gradient launch applies act'(z) itself
+      if (blockIdx.y == 0) g_dense[at] = g;                               // the weight-gradient launch applies act'(z) itself
       if (act) g *= act_bwd(zz, act);
     }
     g_l[(i * CBQ + q) * 4 + c4] = g;
   }
   __syncthreads();
-  bi_core<1, CBQ, NT>(wr, g_l, stage, slices_out + (size_t)blockIdx.x * out_stride, K, n);
-  DL_SPAN(K > N ? 6 : 9, 1);
+  DL_PH(ph, 6);
+  bi_core<1, CBQ, NT>(wr, g_l, stage, slices_out + (size_t)blockIdx.x * out_stride, K, n, tr, nullptr, nullptr, ph);
+  DL_PH(ph, 8);
+  DL_SPAN(ph, 1);
 }
 
 // ============================================================================================== B3: norm backward + [Wu; Wv] rows
@@ -883,7 +931,7 @@ template <int CBQ, int QS>
 __global__ __launch_bounds__(DL_THREADS) void dec_uv_bwd_k(const float* __restrict__ gstack_slices_, int gs_n, long long gs_stride,
                                                            const float* __restrict__ UV_, const float* __restrict__ stack_,
                                                            const float* __restrict__ gs_res_, const float* __restrict__ Wuv_,
-                                                           float* __restrict__ gUV, float* __restrict__ g_s2,
+                                                           const float* gUV_in_, float* gUV_out, float* __restrict__ g_s2,
                                                            float* __restrict__ slices_out, long long out_stride, int n, int F) {
   constexpr int C = 4 * CBQ, G = 2 * CBQ;
   Carve cv;
@@ -893,9 +941,10 @@ __global__ __launch_bounds__(DL_THREADS) void dec_uv_bwd_k(const float* __restri
   float* g_l = cv.take(48 * G * 4);
   const int f0 = blockIdx.x * C;
   DL_SPAN(7, 0);
+  DL_PH(7, 0);
   const gcf gstack_slices = launder(gstack_slices_); const gcf UV = launder(UV_); const gcf stack = launder(stack_);
   const gcf gs_res = launder(gs_res_); const gcf Wuv = launder(Wuv_);
-  const gcf gUV_in = launder(static_cast<const float*>(gUV));
+  const gcf gUV_in = launder(gUV_in_);
   int row0[G], kq[G];
 #pragma unroll
   for (int q = 0; q < CBQ; ++q) {
@@ -918,25 +967,33 @@ __global__ __launch_bounds__(DL_THREADS) void dec_uv_bwd_k(const float* __restri
     res = ldg_pinned(gs_res + nf);
     nrm = ldg_pinned(stack + (size_t)i * 2 * F + F + f);
   }
+  const TileRange tr = dl_tile_range(F);
   BiRegs<G, 2> wr;
-  bi_prefetch<G, 2>(wr, Wuv, F, row0);
+  bi_prefetch<G, 2>(wr, Wuv, F, row0, tr);
   pin_loads();
+  DL_PH(7, 1);
   for (int o = threadIdx.x; o < 48 * G * 4; o += DL_THREADS) g_l[o] = 0.f;
-  quad_finish<1, G>(qr, gsum_l, scratch, gs_n, n);
+  quad_finish<1, G>(qr, gsum_l, scratch, gs_n, n, 7);
+  DL_PH(7, 4);
   if (mine) {
     const int q = c >> 2, c4 = c & 3;
-    g_s2[nf] = reinterpret_cast<const float*>(gsum_l + q * 16)[i * 4 + c4] + res;              // S' also reaches S'' directly
+    if (blockIdx.y == 0) g_s2[nf] = reinterpret_cast<const float*>(gsum_l + q * 16)[i * 4 + c4] + res;   // S' also reaches S'' directly
     const float t = reinterpret_cast<const float*>(gsum_l + (CBQ + q) * 16)[i * 4 + c4] / nrm;
 #pragma unroll
     for (int xyz = 0; xyz < 3; ++xyz) {
       const float tot = gvv[xyz] + t * vv[xyz];
-      gUV[b + (size_t)xyz * 2 * F + F] = tot;                             // the weight-gradient launch reads the total
+      if (blockIdx.y == 0) {                                              // [gU | gVv total]: the weight-gradient launch's operand
+        if (gUV_out != gUV_in_) gUV_out[b + (size_t)xyz * 2 * F] = gu[xyz];
+        gUV_out[b + (size_t)xyz * 2 * F + F] = tot;
+      }
       g_l[((3 * i + xyz) * G + q) * 4 + c4] = gu[xyz];
       g_l[((3 * i + xyz) * G + CBQ + q) * 4 + c4] = tot;
     }
   }
   __syncthreads();
-  bi_core<3, G, 2>(wr, g_l, stage, slices_out + (size_t)blockIdx.x * out_stride, F, 3 * n);
+  DL_PH(7, 6);
+  bi_core<3, G, 2>(wr, g_l, stage, slices_out + (size_t)blockIdx.x * out_stride, F, 3 * n, tr, nullptr, nullptr, 7);
+  DL_PH(7, 8);
   DL_SPAN(7, 1);
 }
 
@@ -973,7 +1030,7 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_bwd_k(
   int row0[9];
 #pragma unroll
   for (int g = 0; g < 9; ++g) row0[g] = g * F + f0;
-  DL_TICK(0);
+  DL_PH(8, 0);
   DL_SPAN(8, 0);
   const gcf geom_d = launder(geom_d_); const gcf geom_s = launder(geom_s_); const gci rowptr_d = launder(rowptr_d_);
   const gci rowptr_s = launder(rowptr_s_); const gci src_d = launder(src_d_); const gci dst_s = launder(dst_s_);
@@ -1022,12 +1079,13 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_bwd_k(
   vector_commit(r_v, true, v_l, n); vector_commit(r_vb, true, vb_l, n);
   vector_commit(r_gvb, gvb != nullptr, gvb_l, n); vector_commit(r_gvres, gv_res != nullptr, gvres_l, n);
   if ((int)threadIdx.x < n * 9) reinterpret_cast<float4*>(phi_l)[threadIdx.x] = r_phi;
-  DL_TICK(1);
+  DL_PH(8, 1);
   BiRegs<9, 2> wr;                                                       // slot 1: the late tile, requested below
-  bi_prefetch_slot<0>(wr, W2, F, row0, k);
+  const TileRange tr{0, (F + 63) / 64};
+  bi_prefetch_slot<0>(wr, W2, F, row0, dl_tile_of(tr, k, 0));
   pin_loads();
   // gV' = sum of the slices of B3 (rows 3 i + xyz) + the residual path V' -> V''
-  quad_finish<3, 1>(qr, gvr_l, scratch, gvr_n, 3 * n);
+  quad_finish<3, 1>(qr, gvr_l, scratch, gvr_n, 3 * n, 8);
   if (threadIdx.x < 64) {
     const float* gr = reinterpret_cast<const float*>(gvr_l);
 #pragma unroll
@@ -1035,10 +1093,10 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_bwd_k(
       gv_l[(node * 4 + c) * 3 + xyz] = live ? gr[(3 * node + xyz) * 4 + c] + gvres_l[(node * 4 + c) * 3 + xyz] : 0.f;
   }
   __syncthreads();
-  DL_TICK(2);
+  DL_PH(8, 4);
   // the 10th.. column tiles (K = 600: 24 columns, wave 0 only): requested now, used after the passes
-  if ((k + DL_WAVES) * 64 < F) {                                          // wave-uniform
-    bi_prefetch_slot<1>(wr, W2, F, row0, k + DL_WAVES);
+  if (dl_tile_of(tr, k, 1) < tr.end) {                                    // wave-uniform
+    bi_prefetch_slot<1>(wr, W2, F, row0, dl_tile_of(tr, k, 1));
   } else {
 #pragma unroll
     for (int g = 0; g < 9; ++g) wr.w[1][g] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1088,7 +1146,7 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_bwd_k(
       if (k == 0) daxpy(avb, ghb_l[ic], lds_v3(v_l + ic * 3));            // the filter-free term ghb_i v_i
     }
   }
-  DL_TICK(3);
+  DL_PH(8, 5);
   gphi_l[(node * 9 + k) * 4 + c] = live ? a : 0.f;
   {
     float* r = red_src + (size_t)k * 6 * 64 + lane;
@@ -1131,9 +1189,9 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_bwd_k(
     float* r = red_rcv + (size_t)k * 8 * 64 + lane;
     r[0] = as; r[64] = asb; r[128] = rv.x; r[192] = rv.y; r[256] = rv.z; r[320] = rvb.x; r[384] = rvb.y; r[448] = rvb.z;
   }
-  DL_TICK(4);
+  DL_PH(8, 6);
   __syncthreads();
-  DL_TICK(5);
+  DL_PH(8, 9);
   // g_phi: dense copy for the weight-gradient launch
   for (int o = threadIdx.x; o < n * 9; o += DL_THREADS) {
     const int m = o / 9, g = o - m * 9;
@@ -1156,9 +1214,8 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_bwd_k(
     else if (k < 5) g_v[jf * 3 + (k - 2)] = t;
     else g_vbar[jf * 3 + (k - 5)] = t;
   }
-  DL_TICK(6);
-  bi_core<1, 9, 2>(wr, gphi_l, stage, slices_out + (size_t)blockIdx.x * out_stride, F, n);
-  DL_TICK(7);
+  bi_core<1, 9, 2>(wr, gphi_l, stage, slices_out + (size_t)blockIdx.x * out_stride, F, n, tr, nullptr, nullptr, 8);
+  DL_PH(8, 8);
   DL_SPAN(8, 1);
 }
 
@@ -1317,7 +1374,8 @@ __global__ __launch_bounds__(DL_THREADS) void prior_msg_bwd_k(
   QuadRegs<1, 1, QS> qr;
   { const int kq[1] = {(int)blockIdx.x}; quad_issue<1, 1>(qr, gh_slices ? gh_slices : phi, gh_slices ? gh_n : 0, gh_stride, n, kq); }
   BiRegs<1, 2> wr;
-  bi_prefetch<1, 2>(wr, W2, F, row0);
+  const TileRange tr{0, (F + 63) / 64};
+  bi_prefetch<1, 2>(wr, W2, F, row0, tr);
   pin_loads();
   copy4_commit(r_gs, geoms_l, E * GS / 4);
   int_commit(r_rps, rps_l, n + 1); int_commit(r_dsts, dsts_l, E);
@@ -1373,7 +1431,7 @@ __global__ __launch_bounds__(DL_THREADS) void prior_msg_bwd_k(
     const float4 val = g == 1 ? *reinterpret_cast<const float4*>(gphi_l + m * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     *reinterpret_cast<float4*>(g_phi + (size_t)m * 3 * F + (size_t)g * F + f0) = val;
   }
-  bi_core<1, 1, 2>(wr, gphi_l, stage, slices_out + (size_t)blockIdx.x * out_stride, F, n);
+  bi_core<1, 1, 2>(wr, gphi_l, stage, slices_out + (size_t)blockIdx.x * out_stride, F, n, tr);
 }
 
 }  // namespace cgv
@@ -1400,9 +1458,14 @@ int cgv_decoder_max_edges(void) { return cgv::DL_MAX_EDGES; }
 /* channels (weight rows per row group set) a block of gate_bwd / dense_bwd / uv_bwd owns for a width: 8 when the width
  * is a multiple of 8 (half as many, twice as fat slices), else 4; their slice count is width / this. */
 int cgv_decoder_block_channels(int width) { return (width % 8) == 0 && cgv::option(CGV_OPT_DECODER_FAT) != 0 ? 8 : 4; }
-/* measurement: block 0 of cgv_decoder_msg_bwd stores the GPU wall clock at its phase boundaries into buf[0..7], of
- * cgv_decoder_msg_fwd into buf[8..13]; every decoder kernel stores begin / end of its first and last block into
- * buf[32 + 4 id ..] (ids in decoder_layer.hip).  buf: 72 uint64.  NULL: off */
+/* blocks (grid y) that share one channel group's backward-input product by column tiles: 2 when there are tiles to share */
+static int cgv_decoder_column_parts(int K, bool heavy = false) {
+  const int o = cgv::option(CGV_OPT_DECODER_COLSPLIT), tiles = (K + 63) / 64;
+  const int want = o <= 0 ? 1 : o == 1 ? 2 : o == 2 ? (heavy ? 3 : 2) : 3;
+  return want < tiles ? want : tiles;
+}
+/* measurement: every decoder kernel stores begin / end of its first and last block into buf[32 + 4 id ..] and block 0's
+ * phase boundaries into buf[80 + 10 id + i] (ids and phases in decoder_layer.hip).  buf: 192 uint64.  NULL: off */
 int cgv_decoder_debug_clock(uint64_t* buf) {
   unsigned long long* p = reinterpret_cast<unsigned long long*>(buf);
   hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(cgv::g_dl_clock), &p, sizeof(p));
@@ -1557,12 +1620,12 @@ int cgv_decoder_gate_bwd(const float* UV, const float* a, const float* gs_base, 
   (void)blocks;
   CGV_DL_QS(gs_n_slices, {
     if (cgv_decoder_block_channels(n_feat) == 8)
-      hipLaunchKernelGGL((cgv::dec_gate_bwd_k<2, QS>), dim3(n_feat / 8), dim3(cgv::DL_THREADS),
+      hipLaunchKernelGGL((cgv::dec_gate_bwd_k<2, QS>), dim3(n_feat / 8, cgv_decoder_column_parts(n_feat)), dim3(cgv::DL_THREADS),
                          cgv::lds_bytes(cgv::bi_stage_floats<1>() + 2 * 2304 + 2 * 64 + 384), st, UV, a, gs_base, gs_slices,
                          gs_n_slices, (long long)gs_slice_stride, gv, W1p, ga, gUV, gs_sum, slices_out,
                          (long long)out_slice_stride, n_nodes, n_feat);
     else
-      hipLaunchKernelGGL((cgv::dec_gate_bwd_k<1, QS>), dim3(n_feat / 4), dim3(cgv::DL_THREADS),
+      hipLaunchKernelGGL((cgv::dec_gate_bwd_k<1, QS>), dim3(n_feat / 4, cgv_decoder_column_parts(n_feat)), dim3(cgv::DL_THREADS),
                          cgv::lds_bytes(cgv::bi_stage_floats<1>() + 2304 + 64 + 192), st, UV, a, gs_base, gs_slices, gs_n_slices,
                          (long long)gs_slice_stride, gv, W1p, ga, gUV, gs_sum, slices_out, (long long)out_slice_stride, n_nodes,
                          n_feat);
@@ -1577,18 +1640,19 @@ int cgv_decoder_dense_bwd(const float* g_slices, int g_n_slices, int64_t g_slice
   CGV_REQUIRE(n_nodes >= 1 && n_nodes <= cgv::DL_MAX_NODES && (N % 4) == 0 && (K % 4) == 0 && K <= 64 * 27 && N >= 4, "unsupported shape");
   CGV_REQUIRE(out_slice_stride >= cgv_decoder_slice_floats(K, n_nodes), "bad slices");
   hipStream_t st = (hipStream_t)stream;
-  const int tiles = (K + 63) / 64;
+  const int parts = cgv_decoder_column_parts(K);
+  const int tiles = ((K + 63) / 64 + parts - 1) / parts;                  /* per block */
   const bool fat = cgv_decoder_block_channels(N) == 8;
-  const int blocks = fat ? N / 8 : N / 4;
+  const dim3 blocks(fat ? N / 8 : N / 4, parts);
   const size_t lds = cgv::lds_bytes(cgv::bi_stage_floats<1>() + 2 * 2304 + 2 * 64 + 2 * 64);
 #define CGV_DL_DENSE(NTV)                                                                                                  \
   CGV_DL_QS(g_n_slices, {                                                                                                  \
     if (fat)                                                                                                               \
-      hipLaunchKernelGGL((cgv::dec_dense_bwd_k<NTV, 2, QS>), dim3(blocks), dim3(cgv::DL_THREADS), lds, st, g_slices,       \
+      hipLaunchKernelGGL((cgv::dec_dense_bwd_k<NTV, 2, QS>), blocks, dim3(cgv::DL_THREADS), lds, st, g_slices,             \
                          g_n_slices, (long long)g_slice_stride, z, act, W, g_dense, slices_out, (long long)out_slice_stride, \
                          n_nodes, N, K);                                                                                   \
     else                                                                                                                   \
-      hipLaunchKernelGGL((cgv::dec_dense_bwd_k<NTV, 1, QS>), dim3(blocks), dim3(cgv::DL_THREADS), lds, st, g_slices,       \
+      hipLaunchKernelGGL((cgv::dec_dense_bwd_k<NTV, 1, QS>), blocks, dim3(cgv::DL_THREADS), lds, st, g_slices,             \
                          g_n_slices, (long long)g_slice_stride, z, act, W, g_dense, slices_out, (long long)out_slice_stride, \
                          n_nodes, N, K);                                                                                   \
   })
@@ -1598,10 +1662,12 @@ int cgv_decoder_dense_bwd(const float* g_slices, int g_n_slices, int64_t g_slice
 }
 
 int cgv_decoder_uv_bwd(const float* gstack_slices, int n_slices, int64_t slice_stride, const float* UV, const float* stack,
-                       const float* gs_res, const float* Wuv, float* gUV, float* g_s2, float* slices_out,
+                       const float* gs_res, const float* Wuv, const float* gUV, float* gUV_out, float* g_s2, float* slices_out,
                        int64_t out_slice_stride, int n_nodes, int n_feat, void* stream) {
-  CGV_REQUIRE(gstack_slices && UV && stack && gs_res && Wuv && gUV && g_s2 && slices_out && n_slices >= 1 && n_slices <= 216,
+  CGV_REQUIRE(gstack_slices && UV && stack && gs_res && Wuv && gUV && gUV_out && g_s2 && slices_out && n_slices >= 1 && n_slices <= 216,
               "null pointer / slice count");
+  const int parts = cgv_decoder_column_parts(n_feat, true);
+  CGV_REQUIRE(parts == 1 || gUV_out != gUV, "gUV_out may alias gUV only with one block per channel group (CGV_OPT_DECODER_COLSPLIT = 0)");
   CGV_REQUIRE(out_slice_stride >= cgv_decoder_slice_floats(n_feat, 3 * n_nodes), "bad slices");
   const int n_rbf = 8;
   CGV_DL_CHECK();
@@ -1610,14 +1676,14 @@ int cgv_decoder_uv_bwd(const float* gstack_slices, int n_slices, int64_t slice_s
     if (cgv_decoder_block_channels(n_feat) == 8) {
       const size_t lds = cgv::lds_bytes(cgv::bi_stage_floats<3>() + 2 * 4608 + 2 * 128 + 2 * 384);
       if (int rc = cgv::allow_lds(cgv::dec_uv_bwd_k<2, QS>, lds)) return rc;
-      hipLaunchKernelGGL((cgv::dec_uv_bwd_k<2, QS>), dim3(n_feat / 8), dim3(cgv::DL_THREADS), lds, st, gstack_slices, n_slices,
-                         (long long)slice_stride, UV, stack, gs_res, Wuv, gUV, g_s2, slices_out, (long long)out_slice_stride,
+      hipLaunchKernelGGL((cgv::dec_uv_bwd_k<2, QS>), dim3(n_feat / 8, parts), dim3(cgv::DL_THREADS), lds, st, gstack_slices, n_slices,
+                         (long long)slice_stride, UV, stack, gs_res, Wuv, gUV, gUV_out, g_s2, slices_out, (long long)out_slice_stride,
                          n_nodes, n_feat);
     } else {
       const size_t lds = cgv::lds_bytes(cgv::bi_stage_floats<3>() + 4608 + 128 + 384);
       if (int rc = cgv::allow_lds(cgv::dec_uv_bwd_k<1, QS>, lds)) return rc;
-      hipLaunchKernelGGL((cgv::dec_uv_bwd_k<1, QS>), dim3(n_feat / 4), dim3(cgv::DL_THREADS), lds, st, gstack_slices, n_slices,
-                         (long long)slice_stride, UV, stack, gs_res, Wuv, gUV, g_s2, slices_out, (long long)out_slice_stride,
+      hipLaunchKernelGGL((cgv::dec_uv_bwd_k<1, QS>), dim3(n_feat / 4, parts), dim3(cgv::DL_THREADS), lds, st, gstack_slices, n_slices,
+                         (long long)slice_stride, UV, stack, gs_res, Wuv, gUV, gUV_out, g_s2, slices_out, (long long)out_slice_stride,
                          n_nodes, n_feat);
     }
   });

@@ -12,6 +12,12 @@
 // own bead, and owns the KL terms of its bead's F channels.  The three partial sums of a block leave as doubles; the
 // block that arrives last (device-scope ticket) adds them in block order -- deterministic -- and writes the scalars.
 #include "cgv_common.h"
+// The last-block hand-over below (relaxed agent-scope stores, an explicit `s_waitcnt vmcnt(0)`, then a relaxed ticket
+// atomic) relies on stores being counted by vmcnt -- true on the gfx9 family this library is written for, not part of the
+// HIP memory model.  Refuse to build for anything else.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "ticket hand-over ordered by s_waitcnt vmcnt(0): gfx942 / gfx950 only"
+#endif
 
 namespace cgv {
 

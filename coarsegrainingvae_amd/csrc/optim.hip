@@ -10,6 +10,12 @@
 // instead of ~17 for separate clip (read, read+write) and multi-pass foreach Adam.
 #include <stdlib.h>
 #include "cgv_common.h"
+// The last-block hand-over below (relaxed agent-scope stores, an explicit `s_waitcnt vmcnt(0)`, then a relaxed ticket
+// atomic) relies on stores being counted by vmcnt -- true on the gfx9 family this library is written for, not part of the
+// HIP memory model.  Refuse to build for anything else.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "ticket hand-over ordered by s_waitcnt vmcnt(0): gfx942 / gfx950 only"
+#endif
 
 namespace cgv {
 

@@ -50,6 +50,13 @@ def prepare_batch(batch: Dict[str, torch.Tensor], device=None, edge_slack: float
     ``edge_slack`` > 0 reserves that fraction of extra edge capacity (see :func:`copy_batch_into`);
     ``edge_capacity`` = (atom edges, bead edges) sets the capacities outright.  ``dir_mp``: for a model whose encoder
     was built with ``dir_mp=True`` (cgvae.py:270-271): the atom list is used as given, not symmetrised."""
+    bonds = batch.get("bond_edge_list")
+    if torch.is_tensor(bonds) and bonds.numel():
+        # once per batch, where the reference's indexing would raise (utils.py:127-133): the fused loss launch addresses its
+        # staged coordinates by these ids without a range check per bond (csrc/loss_tail.hip)
+        lo, hi = int(bonds.min()), int(bonds.max())
+        if lo < 0 or hi >= int(batch["nxyz"].shape[0]):
+            raise IndexError(f"bond_edge_list holds atom ids in [{lo}, {hi}] for a batch of {int(batch['nxyz'].shape[0])} atoms")
     if device is not None:
         batch = batch_to(batch, device)
     batch["_graph"] = BatchGraph(batch["nxyz"][:, 1:], batch["CG_nxyz"][:, 1:], batch["CG_mapping"],

@@ -160,11 +160,11 @@ class _PseudoDecoderFn(torch.autograd.Function):
             Wuv = torch.as_strided(pWu.detach(), (2 * F, F), (F, 1))
             # slices per phase: F / 4 from the message kernel, width / cgv_decoder_block_channels(width) from the others
             # B1: gate backward, rows of s_dense.1
-            ga, gUV, gs_sum = new(n, 3 * F), new(3 * n, 2 * F), new(n, F)
+            ga, gUV1, gs_sum = new(n, 3 * F), new(3 * n, 2 * F), new(n, F)
             nF = F // int(lib.cgv_decoder_block_channels(F))
             p1 = new(nF * fl16(F))
             _lib.call("cgv_decoder_gate_bwd", _lib.ptr(UV), _lib.ptr(a), _lib.ptr(gS.base), _lib.ptr(gS.part), gS.n, gS.stride,
-                      _lib.ptr(gV), _lib.ptr(pW1p.detach()), _lib.ptr(ga), _lib.ptr(gUV), _lib.ptr(gs_sum), _lib.ptr(p1), fl16(F),
+                      _lib.ptr(gV), _lib.ptr(pW1p.detach()), _lib.ptr(ga), _lib.ptr(gUV1), _lib.ptr(gs_sum), _lib.ptr(p1), fl16(F),
                       n, F, st)
             # B2: s_dense.0 (swish'), K = 2F
             g_a0 = new(n, F)
@@ -172,10 +172,12 @@ class _PseudoDecoderFn(torch.autograd.Function):
             _lib.call("cgv_decoder_dense_bwd", _lib.ptr(p1), nF, fl16(F), _lib.ptr(z0), ACT_SWISH, _lib.ptr(pW0.detach()),
                       _lib.ptr(g_a0), _lib.ptr(p2), fl16(2 * F), n, F, 2 * F, st)
             # B3: norm backward, rows of [u_mat; v_mat]
-            g_s2 = new(n, F)
+            # (gUV1 = [gU | the gate's part of gVv] is read by BOTH column parts of a channel group: the completed operand
+            # matrix [gU | gVv] of the weight-gradient launch goes to a buffer of its own)
+            g_s2, gUV = new(n, F), new(3 * n, 2 * F)
             p3 = new(nF * fl48)
             _lib.call("cgv_decoder_uv_bwd", _lib.ptr(p2), nF, fl16(2 * F), _lib.ptr(UV), _lib.ptr(stack), _lib.ptr(gs_sum),
-                      _lib.ptr(Wuv), _lib.ptr(gUV), _lib.ptr(g_s2), _lib.ptr(p3), fl48, n, F, st)
+                      _lib.ptr(Wuv), _lib.ptr(gUV1), _lib.ptr(gUV), _lib.ptr(g_s2), _lib.ptr(p3), fl48, n, F, st)
             # B4: message backward, rows of inv_dense.1
             g_phi = new(n, 9 * F)
             g_s, g_sbar, g_v, g_vbar = new(n, F), new(n, F), new(n, F, 3), new(n, F, 3)

@@ -384,10 +384,10 @@ def scatter_mean(src: torch.Tensor, index: torch.Tensor, dim: int = 0, dim_size:
 class _TailSlot:
     """Hand-over between a LAZY ``reconstruct`` (no launch: the coordinates are produced by the loss launch) and the fused
     decoder-tail + ELBO launch (``_Elbo`` with ``tail``): the tail's inputs one way, d loss / d V the other way."""
-    __slots__ = ("v", "cg_xyz", "chan", "plan", "offset", "out", "g_V", "filled")
+    __slots__ = ("v", "cg_xyz", "chan", "plan", "offset", "out", "g_V", "g_xr", "filled")
 
     def __init__(self):
-        self.v = self.cg_xyz = self.chan = self.plan = self.out = self.g_V = None
+        self.v = self.cg_xyz = self.chan = self.plan = self.out = self.g_V = self.g_xr = None
         self.offset, self.filled = True, False
 
 
@@ -413,9 +413,14 @@ class _Reconstruct(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         slot, ctx.slot = ctx.slot, None
-        if slot is not None and slot.g_V is not None and not ctx.needs_input_grad[1]:
-            g_v, slot.g_V = slot.g_V, None                 # d loss / d V came out of the fused loss launch
-            return g_v, None, None, None, None, None
+        if slot is not None:
+            g_v, g_xr, slot.g_V, slot.g_xr = slot.g_V, slot.g_xr, None, None
+            # the shortcut holds only when the gradient arriving here IS the fused launch's d loss / d xyz_recon: a second
+            # consumer of xyz_recon (an extra loss term, a metric with a gradient) makes autograd hand over the SUM in a new
+            # tensor -- then the tail's backward runs on that sum like for any other reconstruction
+            if (g_v is not None and g_xr is not None and g is not None and g.data_ptr() == g_xr.data_ptr()
+                    and g.shape == g_xr.shape and not ctx.needs_input_grad[1]):
+                return g_v, None, None, None, None, None   # d loss / d V came out of the fused loss launch
         g = _c(g)
         n_beads, F = ctx.shape
         g_v = torch.empty(n_beads, F, 3, dtype=torch.float32, device=g.device)
@@ -459,11 +464,18 @@ _TAIL_WS = {}
 
 
 def _tail_workspace(device, n_beads):
-    """Partial sums + the ticket word of cgv_loss_tail: zeroed ONCE (every launch leaves the ticket at zero)."""
+    """Partial sums + the ticket word of cgv_loss_tail: zeroed ONCE per (device, bead count) -- every launch leaves the
+    ticket at zero.  Never cached from inside a stream capture: a buffer born there lives in the graph's private pool and
+    its zero fill is a captured node that has not run yet, so an eager step (or a second capture) before the first replay
+    would meet a garbage ticket; a capture that is the first to need a shape gets a buffer of its own whose fill is
+    replayed with it (``Trainer.capture`` creates the entry BEFORE it starts capturing, so its graphs hold no such node).
+    One word per (device, bead count): launches that share it must be ordered (one stream, or streams joined by events)."""
     key = (str(device), int(n_beads))
     ws = _TAIL_WS.get(key)
     if ws is None:
-        ws = _TAIL_WS[key] = torch.zeros(int(_lib.load().cgv_loss_tail_workspace_bytes(int(n_beads))), dtype=torch.uint8, device=device)
+        ws = torch.zeros(int(_lib.load().cgv_loss_tail_workspace_bytes(int(n_beads))), dtype=torch.uint8, device=device)
+        if not torch.cuda.is_current_stream_capturing():
+            _TAIL_WS[key] = ws
     return ws
 
 
@@ -546,11 +558,14 @@ _ZEROS = {}
 
 
 def _zeros_const(like: torch.Tensor) -> torch.Tensor:
-    """A cached all-zero tensor of ``like``'s shape for kernels that only READ it (an absent upstream gradient)."""
+    """A cached all-zero tensor of ``like``'s shape for kernels that only READ it (an absent upstream gradient).  Not cached
+    when first needed inside a stream capture (the fill would be a captured node that has not run: see _tail_workspace)."""
     key = (tuple(like.shape), str(like.device))
     t = _ZEROS.get(key)
     if t is None:
-        t = _ZEROS[key] = torch.zeros(like.shape, dtype=_F32, device=like.device)
+        t = torch.zeros(like.shape, dtype=_F32, device=like.device)
+        if not (like.is_cuda and torch.cuda.is_current_stream_capturing()):
+            _ZEROS[key] = t
     return t
 
 
@@ -786,7 +801,7 @@ class _Elbo(torch.autograd.Function):
                       _lib.ptr(xyz), _lib.ptr(bonds) if bonds.shape[0] else None, n_beads, F, n_atoms, bonds.shape[0],
                       int(tail.offset), float(beta), float(gamma), _lib.ptr(xr), _lib.ptr(out), _lib.ptr(loss),
                       *[_lib.ptr(g) for g in grads], _lib.ptr(g_V), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
-            tail.g_V, tail.filled = g_V, True
+            tail.g_V, tail.g_xr, tail.filled = g_V, grads[4], True
             # the tail's inputs are spent: drop them NOW -- slot.out is the very tensor that carries the slot (a reference
             # cycle through a tensor with a grad_fn would keep this step's autograd graph alive until the cyclic collector
             # runs; a graph retained across steps pins its nodes to this stream and a later capture dies in EndCapture)

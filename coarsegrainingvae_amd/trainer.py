@@ -446,13 +446,27 @@ class Trainer:
         self.last_terms = None
         self.steps_skipped_host = 0
         from .options import HOST as _H
-        if hasattr(model, "lazy_tail"):
-            # the ELBO always follows the forward here: the decoder tail runs inside the loss launch (csrc/loss_tail.hip)
-            model.lazy_tail = bool(_H["fused_loss_tail"]) and fused_optimizer
+        # the ELBO always follows the trainer's OWN forward: there the decoder tail runs inside the loss launch
+        # (csrc/loss_tail.hip).  The model itself is left alone -- ``model.decoder(...)`` / ``model(batch)`` called by anybody
+        # else (sampling scripts, a custom loss or metric) computes xyz_recon as the reference does (``_forward`` sets the
+        # flag for the duration of the trainer's call and restores it)
+        self._lazy_tail = hasattr(model, "lazy_tail") and bool(_H["fused_loss_tail"]) and fused_optimizer
         self._graphs = {}             # train flag -> captured hipGraph of one full step (capture())
         self._retired = []            # replaced captures of a data-parallel trainer (_retire)
         self._pre_stream = None       # side stream of enable_prefetch()
         self.replays = 0
+
+    def _forward(self, batch, eps=None):
+        """The model's forward as the trainer runs it: with the lazy decoder tail (the loss launch that follows fills
+        xyz_recon), a setting that lives exactly as long as this call."""
+        model = self.model
+        if not self._lazy_tail:
+            return model(batch, eps=eps) if eps is not None else model(batch)
+        before, model.lazy_tail = model.lazy_tail, True
+        try:
+            return model(batch, eps=eps) if eps is not None else model(batch)
+        finally:
+            model.lazy_tail = before
 
     @property
     def lr(self):
@@ -630,6 +644,11 @@ class Trainer:
             eps_buf = eps.detach().to(device=next(self.model.parameters()).device, dtype=torch.float32).clone()
         if self.arena is None:
             self._step_eager(batch, eps_buf)               # builds the arena (first backward)
+        if self._lazy_tail and torch.is_tensor(batch.get("CG_nxyz")):
+            # the fused loss launch's ticket / partial-sum words exist (and are zero) BEFORE the capture begins: a buffer
+            # first created inside it would live in the graph's pool with a zero fill that has not run (ops._tail_workspace)
+            from .ops import _tail_workspace
+            _tail_workspace(batch["CG_nxyz"].device, batch["CG_nxyz"].shape[0])
         if warmup == 0:
             # nothing may be built lazily inside the capture (geometry records of this batch: H2D copies): one
             # forward without gradients, random stream restored, leaves the parameters and the sampling untouched
@@ -638,7 +657,7 @@ class Trainer:
             rng = torch.cuda.get_rng_state(dev)
             sample_rng = _rng_block(dev).clone()          # reparam_sample's own generator (not in torch's state)
             with torch.no_grad():
-                self.model(batch) if eps_buf is None else self.model(batch, eps=eps_buf)
+                self._forward(batch, eps_buf)
             torch.cuda.set_rng_state(rng, dev)
             _rng_block(dev).copy_(sample_rng)
         side = torch.cuda.Stream()
@@ -856,7 +875,7 @@ class Trainer:
         self._sent = set()
         if hasattr(self.model, "bucket_done"):
             self.model.bucket_done = self._bucket_done if overlap else None
-        out = self.model(batch, eps=eps) if eps is not None else self.model(batch)
+        out = self._forward(batch, eps)
         loss, kl, recon, graph = loss_terms(out, batch, self.beta, self.gamma)
         mark("loss")
         self.last_loss, self.last_terms = loss.detach(), (kl.detach(), recon.detach(), graph.detach())

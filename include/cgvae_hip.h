@@ -80,7 +80,11 @@ enum {
   CGV_OPT_SKINNY_ROWS = 13,    /* cgv_skinny_linear_fwd: row blocks (of 16) per thread block; 0 = built-in rule, 1..4 */
   CGV_OPT_TILE_FWD_BAL = 14,   /* cgv_tile_linear_fwd: 1 (default) layers of >= 1200 outputs with more than one 32 x 32 tile per CU run as ONE larger register tile per CU where a compiled tile fits (XCD-aware tile order), 0 off, 2 every shape (tests / A-B) */
   CGV_OPT_OPTIM_ONE_LAUNCH = 15, /* cgv_optim_prepare*: 0 (default) norm pass, then the decision launch; 1 both in ONE launch (the last block decides) -- measured SLOWER on the chignolin step (1.774 against 1.763 ms): 1620 blocks arriving at one device-scope ticket cost more (~12 ns each) than the launch boundary saved; 2: as 0, and cgv_wgrad_gram keeps its separate reduce launch too (A/B: by default the LAST of a problem's eight slice blocks sums them) */
-  CGV_OPT_COUNT = 16
+  CGV_OPT_DECODER_COLSPLIT = 16, /* cgv_decoder_{gate,dense,uv}_bwd: the column tiles of a channel group's backward-input product are split over
+                                  several blocks (= CUs; grid y): these products are bound by the fp32 MFMA pipe of ONE CU -- each part repeats the
+                                  prologue and writes its own columns of the group's slice.  0 one block per channel group, 1 two, 2 (default) two,
+                                  three for uv_bwd (48-row tiles), 3 three everywhere */
+  CGV_OPT_COUNT = 17
 };
 /* Measurement: store the GPU wall clock (cgv_timestamp_hz ticks per second) into *slot, in stream order; capturable. */
 int cgv_timestamp(uint64_t* slot /*device*/, void* stream);
@@ -376,8 +380,8 @@ int cgv_pseudo_msg_bwd_deferred(const float* phi, const float* s, const float* s
  *             gate_fwd  a [n, 3F] = a0 W1'^T + b1' ; S'' = S' + (U.Vv) a_sv + a_ss ; V'' = V' + U a_vv
  *   backward  gate_bwd  gS = gs_base + sum gs_slices (written to gs_sum) ; ga, gUV (gU | gVv) ; slices = ga W1'
  *             dense_bwd g = sum g_slices (written to g_dense) ; slices = (g act'(z)) W      (W [N, K], grid N/4)
- *             uv_bwd    g_stack = sum slices ; g_s2 = g_stack[:, :F] + gs_res ; gUV[:, F:] += g_stack[:, F:] Vv / norm ;
- *                       slices [.., 48 rows ..] = gUV [Wu; Wv]
+ *             uv_bwd    g_stack = sum slices ; g_s2 = g_stack[:, :F] + gs_res ; gUV_out = [gUV[:, :F] | gUV[:, F:] + g_stack[:, F:] Vv / norm]
+ *                       (gUV_out may be gUV itself only with CGV_OPT_DECODER_COLSPLIT = 0) ; slices [.., 48 rows ..] = gUV_out [Wu; Wv]
  *             msg_bwd   gV' = sum gvrows_slices (rows 3i+xyz) + gv_res ; full EquiMessagePsuedo backward (g_s, g_sbar,
  *                       g_v, g_vbar, g_phi, gWd, gbd written completely) ; slices = g_phi W2
  *             slices_to_dense  out [n, F] = base + sum slices (16-row slices)
@@ -386,7 +390,7 @@ int cgv_decoder_layer_supported(int n_nodes, int n_feat, int n_rbf);
 int64_t cgv_decoder_slice_floats(int K, int rows);
 int cgv_decoder_max_edges(void);
 int cgv_decoder_block_channels(int width);   /* 4 or 8: gate_bwd / dense_bwd / uv_bwd emit width / this slices */
-int cgv_decoder_debug_clock(uint64_t* buf /*device, 16 slots, or NULL*/);   /* measurement only */
+int cgv_decoder_debug_clock(uint64_t* buf /*device, 192 slots, or NULL*/);   /* measurement only */
 int cgv_decoder_msg_fwd(const float* a1, const float* W2, const float* b2, const float* s, const float* sbar, const float* v,
                         const float* vbar, const float* geom_d, const int32_t* rowptr_d, const int32_t* src_d, const float* Wd,
                         const float* bd, float* phi, float* stack, float* sbar_out, float* v_out, float* vbar_out,
@@ -421,7 +425,7 @@ int cgv_decoder_dense_bwd(const float* g_slices, int g_n_slices, int64_t g_slice
                           const float* W, float* g_dense, float* slices_out, int64_t out_slice_stride, int n_nodes, int N, int K,
                           void* stream);
 int cgv_decoder_uv_bwd(const float* gstack_slices, int n_slices, int64_t slice_stride, const float* UV, const float* stack,
-                       const float* gs_res, const float* Wuv, float* gUV, float* g_s2, float* slices_out,
+                       const float* gs_res, const float* Wuv, const float* gUV, float* gUV_out, float* g_s2, float* slices_out,
                        int64_t out_slice_stride, int n_nodes, int n_feat, void* stream);
 int cgv_decoder_msg_bwd(const float* phi, const float* s, const float* sbar, const float* v, const float* vbar,
                         const float* geom_d, const int32_t* rowptr_d, const int32_t* src_d, const float* geom_s,

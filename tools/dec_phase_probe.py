@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Phase clock of block 0 of cgv_decoder_msg_bwd inside a real training step (eager launches)."""
-import os, sys
+"""Phase clock of block 0 of ALL TEN decoder-layer launches inside a real (replayed) training step, plus the launch
+timeline of one layer.  [--option name=value ...]"""
+import os, sys, statistics
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import coarsegrainingvae_amd as cg
@@ -13,38 +14,46 @@ model = cg.build_model(600, w["n_rbf"], w["atom_cutoff"], w["cg_cutoff"], w["enc
 tr = Trainer(model, lr=1e-4, beta=w["beta"], gamma=w["gamma"])
 for _ in range(3):
     tr.step(batch)
-buf = torch.zeros(72, dtype=torch.int64, device="cuda")
+buf = torch.zeros(192, dtype=torch.int64, device="cuda")
 _lib.call("cgv_decoder_debug_clock", buf.data_ptr())
 hz = _lib.load().cgv_timestamp_hz()
 tr.capture(batch, warmup=0)
-acc, accf, accd, spans = [], [], [], []
-for _ in range(20):
+snaps = []
+for _ in range(30):
     tr.step(batch)
     torch.cuda.synchronize()
-    t = buf.cpu().tolist()
-    acc.append([(t[i] - t[i - 1]) / hz * 1e6 for i in range(1, 8)])
-    accf.append([(t[i] - t[i - 1]) / hz * 1e6 for i in range(9, 14)])
-    spans.append(t[32:72])
-    accd.append([(t[i] - t[i - 1]) / hz * 1e6 for i in range(15, 20)])
+    snaps.append(buf.cpu().tolist())
 _lib.call("cgv_decoder_debug_clock", None)
-names = ["prefetch+staging issue", "quad_sum", "tail of staging -> state in regs", "pass B (source side)", "shuffles + pass A", "sync", "g_phi dense + final sums", ]
-import statistics
-for i, nm in enumerate(["stage loads -> LDS", "slice sum (quad_sum<3>) + gv", "pass B", "filter-grad shuffles + pass A", "barrier", "dense g_phi + node sums", "product + slice store"]):
-    print(f"{statistics.median(a[i] for a in acc):8.2f} us  {nm}")
-print("-- cgv_decoder_msg_fwd, block 0")
-for i, nm in enumerate(["stage loads -> LDS + filter row", "product (fwd_core)", "bias + dense phi + barrier", "edge loop", "wave sums + stores"]):
-    print(f"{statistics.median(a[i] for a in accf):8.2f} us  {nm}")
-print("-- cgv_decoder_dense_fwd (F1), block 0")
-for i, nm in enumerate(["address math + requests issued", "requests landed + MFMAs + partials to LDS", "barrier", "cross-wave sum + barrier", "bias + act + store"]):
-    print(f"{statistics.median(a[i] for a in accd):8.2f} us  {nm}")
-
-# timeline of one layer (forward: the last layer's launches; backward: the first layer's = the last executed)
+snaps = snaps[5:]
 KERN = ["F1 dense a1", "F2 message", "F3 uv+norm", "F4 dense a0", "F5 gate", "B1 gate", "B2 dense W0", "B3 uv+norm", "B4 message", "B5 dense W1"]
+FWD = [(0, 1, "entry -> requests issued"), (1, 2, "requests landed + MFMAs + partials to LDS"), (2, 3, "barrier"),
+       (3, 4, "cross-wave sum + barrier"), (4, 5, "epilogue (bias / act / local math) + stores issued")]
+F2 = [(0, 1, "LDS-DMA of 36 weight rows issued -> staging + x requests issued, staged arrays committed"),
+      (1, 2, "everything landed (vmcnt 0) + barrier"), (2, 3, "MFMAs from LDS + partials to LDS"), (3, 4, "barrier + cross-wave sum + barrier"),
+      (4, 5, "bias + dense phi store + barrier"), (5, 6, "edge loop"), (6, 7, "wave sums + stores issued")]
+BWD = [(0, 1, "entry -> slices / operands / weights requested"), (1, 2, "this wave's slices landed + lane sums + shuffles"),
+       (2, 3, "barrier (every wave's)"), (3, 4, "cross-wave sum + barrier"), (4, 6, "local math + barrier"),
+       (6, 7, "first tile: weights landed + MFMAs + staged"), (7, 8, "slice stores issued (all tiles)")]
+B4 = [(0, 1, "entry -> staged arrays landed + committed to LDS"), (1, 2, "W2 tile requested; this wave's slices landed + sums"),
+      (2, 3, "barrier"), (3, 4, "cross-wave sum + barrier + gV' + barrier"), (4, 5, "late tile requested + node state to registers + pass B (source side)"),
+      (5, 6, "filter-gradient shuffles + stores + pass A (receiver side)"), (6, 9, "barrier"),
+      (9, 7, "dense g_phi + node sums + first tile MFMAs + staged"), (7, 8, "slice stores issued (all tiles)")]
+TABLE = {0: FWD, 1: F2, 2: FWD, 3: FWD, 4: FWD, 5: BWD, 6: BWD, 7: BWD, 8: B4, 9: BWD}
+print(f"phase clock of block 0, us (median of {len(snaps)} replays; the last layer's launches forward, layer 0's backward)")
+for kid in range(10):
+    print(f"-- {KERN[kid]}")
+    tot = 0.0
+    for a, b, nm in TABLE[kid]:
+        d = statistics.median((t[80 + 10 * kid + b] - t[80 + 10 * kid + a]) / hz * 1e6 for t in snaps)
+        tot += d
+        print(f"  {d:7.2f}  {nm}")
+    print(f"  {tot:7.2f}  = block 0, first to last tick")
 for group, ids in (("forward", range(0, 5)), ("backward", range(5, 10))):
-    print(f"-- {group} layer timeline (us from the first launch's first block; median of 20 replays)")
+    print(f"-- {group} layer timeline (us from the first launch's first block; median)")
     print("                 first block: begin    end | last block: begin    end | gap to next launch")
     rows = []
-    for sp in spans:
+    for t in snaps:
+        sp = t[32:72]
         t0 = sp[4 * ids[0]]
         rows.append([[(sp[4 * i + j] - t0) / hz * 1e6 for j in range(4)] for i in ids])
     for n_, i in enumerate(ids):
