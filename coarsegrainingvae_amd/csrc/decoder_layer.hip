@@ -52,6 +52,11 @@ __constant__ unsigned long long* g_dl_clock = nullptr;
 // per-phase ticks of block 0 of EVERY decoder launch: slots 80 + 10 id + i (ids as above, i < 10); buf: 192 uint64
 #define DL_PH(id, i) do { if (g_dl_clock && blockIdx.x == 0 && threadIdx.x == 0) g_dl_clock[80 + 10 * (id) + (i)] = wall_clock64(); } while (0)
 
+// per-WAVE ticks of block 0 of the message backward (B4): slots 192 + 8 wave + i; buf: 272 uint64
+#define DL_WV(i) do { if (g_dl_clock && blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_dl_clock[192 + 8 * (threadIdx.x >> 6) + (i)] = wall_clock64(); } while (0)
+#ifndef CGV_DL_FILTER_PERM
+#define CGV_DL_FILTER_PERM 1
+#endif
 constexpr int DL_CB = 4;                 // channels per block
 constexpr int DL_WAVES = 9;
 constexpr int DL_THREADS = 64 * DL_WAVES;
@@ -65,6 +70,23 @@ __device__ __forceinline__ dv3 dcross(const dv3& a, const dv3& b) {
 __device__ __forceinline__ float ddot(const dv3& a, const dv3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 __device__ __forceinline__ void daxpy(dv3& acc, float a, const dv3& x) {
   acc.x = fmaf(a, x.x, acc.x); acc.y = fmaf(a, x.y, acc.y); acc.z = fmaf(a, x.z, acc.z);
+}
+// Cross-lane sums without the LDS crossbar (__shfl_xor compiles to ds_bpermute_b32: an LDS round trip per step of a
+// butterfly).  x + x[lane ^ 32], x + x[lane ^ 16]: gfx950's v_permlane32_swap / v_permlane16_swap on two copies of x --
+// both halves of a pair compute own + partner or partner + own, the same bits as the shuffle form.  Sum over the four
+// lanes {l, l + 4, l + 8, l + 12} of a 16-lane row: two DPP row rotations, (x_l + x_{l+8}) + (x_{l+4} + x_{l+12}).
+__device__ __forceinline__ float add_xor32(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float add_xor16(float x) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float add_row_stride4(float x) {
+  x += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(x), 0x128 /*row_ror:8*/, 0xf, 0xf, false));
+  x += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(x), 0x124 /*row_ror:4*/, 0xf, 0xf, false));
+  return x;
 }
 template <int R>
 __device__ __forceinline__ float dfilt(const float (&W)[R + 1], const float* __restrict__ g) {
@@ -176,11 +198,12 @@ __device__ __forceinline__ void quad_finish(const QuadRegs<MB, NQ, QS>& r, float
 #pragma unroll
       for (int u = 0; u < QS; ++u)
         if (cls + 36 * u < n_slices) { acc.x += r.v[u][q][mb].x; acc.y += r.v[u][q][mb].y; acc.z += r.v[u][q][mb].z; acc.w += r.v[u][q][mb].w; }
-      acc.x += __shfl_xor(acc.x, 16); acc.y += __shfl_xor(acc.y, 16); acc.z += __shfl_xor(acc.z, 16); acc.w += __shfl_xor(acc.w, 16);
-      acc.x += __shfl_xor(acc.x, 32); acc.y += __shfl_xor(acc.y, 32); acc.z += __shfl_xor(acc.z, 32); acc.w += __shfl_xor(acc.w, 32);
+      acc.x = add_xor16(acc.x); acc.y = add_xor16(acc.y); acc.z = add_xor16(acc.z); acc.w = add_xor16(acc.w);
+      acc.x = add_xor32(acc.x); acc.y = add_xor32(acc.y); acc.z = add_xor32(acc.z); acc.w = add_xor32(acc.w);
       if (lane < 16) scratch[((q * DL_WAVES + wave) * MB + mb) * 16 + m] = acc;
     }
   if (ph >= 0) DL_PH(ph, 2);                                              // this wave's slices landed and summed
+  if (ph == 8) DL_WV(3);
   __syncthreads();
   if (ph >= 0) DL_PH(ph, 3);                                              // every wave's
   if (threadIdx.x < NQ * MP) {
@@ -628,8 +651,10 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_fwd_k(
   dv3 acc{0.f, 0.f, 0.f};
   const float* __restrict__ vsrc = (k == 2 || k == 6 || k == 7) ? v_l : vb_l;
   const int e_beg = live ? rp_l[i] : 0, e_end = live ? min(rp_l[i + 1], E) : 0;      // E = records staged (>= the graph's edges)
+  int j_nx = e_beg < e_end ? src_l[e_beg] : 0;                            // (the next edge's source id travels with this edge's operands)
   for (int e = e_beg; e < e_end; ++e) {
-    const int j = src_l[e];
+    const int j = j_nx;
+    j_nx = src_l[min(e + 1, e_end - 1)];
     const float* __restrict__ g = geom_l + (size_t)e * GS;
     const dv3 vj = lds_v3(vsrc + (j * 4 + c) * 3);
     const float q = phi_l[(j * 9 + k) * 4 + c] * dfilt<R>(W, g);
@@ -754,6 +779,38 @@ __global__ __launch_bounds__(DL_THREADS) void dec_uv_fwd_k(const float* __restri
     const int i = threadIdx.x >> 2, c = threadIdx.x & 3;
     const float x = uv_l[((3 * i + 0) * 2 + 1) * 4 + c], y = uv_l[((3 * i + 1) * 2 + 1) * 4 + c], z = uv_l[((3 * i + 2) * 2 + 1) * 4 + c];
     stack[(size_t)i * 2 * F + F + f0 + c] = sqrtf(((x * x + 1e-10f) + (y * y + 1e-10f)) + (z * z + 1e-10f));      // conv.py:600
+  }
+  DL_PH(2, 5);
+  DL_SPAN(2, 1);
+}
+
+// The same by NODE GROUPS (grid y) of 8-channel blocks: the 48-row form above is bound by the fp32 MFMA pipe of its CU (three
+// 16-row blocks x 8 of 16 weight rows per tile: 37 % of the instruction's outputs used, 1.8 us of MFMAs on the SIMD that
+// hosts the most waves).  A part takes npp nodes (3 npp <= 16 rows: one row block) and 16 weight rows (a full tile): a
+// third of the MFMAs per block, a third of the x rows; the norm is local to a node, so parts never meet.
+__global__ __launch_bounds__(DL_THREADS) void dec_uv_fwd_nodes_k(const float* __restrict__ rows, const float* __restrict__ Wuv,
+                                                                 float* __restrict__ UV, float* __restrict__ stack, int n, int F,
+                                                                 int npp) {
+  Carve cv;
+  float* red = cv.take(fwd_red_floats<1, 4>());
+  float* uv_l = cv.take(16 * 4 * 4);
+  const int f0 = blockIdx.x * 8;
+  const int row0[4] = {f0, f0 + 4, F + f0, F + f0 + 4};
+  const int i0 = blockIdx.y * npp, ni = min(npp, n - i0);                // this part's nodes i0 .. i0 + ni - 1
+  DL_SPAN(2, 0);
+  DL_PH(2, 0);
+  const float* x = rows + (size_t)3 * i0 * F;
+  if (F <= 16 * DL_WAVES * 5) fwd_core<1, 4, 5>(uv_l, red, x, 3 * ni, F, Wuv, row0, NoHook(), 2);
+  else fwd_core<1, 4, 9>(uv_l, red, x, 3 * ni, F, Wuv, row0, NoHook(), 2);
+  for (int o = threadIdx.x; o < 3 * ni * 4; o += DL_THREADS) {
+    const int m = o >> 2, g = o & 3;
+    *reinterpret_cast<float4*>(UV + (size_t)(3 * i0 + m) * 2 * F + (size_t)(g >> 1) * F + f0 + 4 * (g & 1)) =
+        *reinterpret_cast<const float4*>(uv_l + (m * 4 + g) * 4);
+  }
+  if (threadIdx.x < ni * 8) {
+    const int il = threadIdx.x >> 3, c = threadIdx.x & 7, g = 2 + (c >> 2), c4 = c & 3;
+    const float x_ = uv_l[((3 * il + 0) * 4 + g) * 4 + c4], y_ = uv_l[((3 * il + 1) * 4 + g) * 4 + c4], z_ = uv_l[((3 * il + 2) * 4 + g) * 4 + c4];
+    stack[(size_t)(i0 + il) * 2 * F + F + f0 + c] = sqrtf(((x_ * x_ + 1e-10f) + (y_ * y_ + 1e-10f)) + (z_ * z_ + 1e-10f));      // conv.py:600
   }
   DL_PH(2, 5);
   DL_SPAN(2, 1);
@@ -1031,6 +1088,7 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_bwd_k(
 #pragma unroll
   for (int g = 0; g < 9; ++g) row0[g] = g * F + f0;
   DL_PH(8, 0);
+  DL_WV(0);
   DL_SPAN(8, 0);
   const gcf geom_d = launder(geom_d_); const gcf geom_s = launder(geom_s_); const gci rowptr_d = launder(rowptr_d_);
   const gci rowptr_s = launder(rowptr_s_); const gci src_d = launder(src_d_); const gci dst_s = launder(dst_s_);
@@ -1040,7 +1098,15 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_bwd_k(
   const gcf Wd = launder(Wd_); const gcf bd = launder(bd_); const gcf gvrows_slices = launder(gvrows_slices_);
   const gcf W2 = launder(W2_);
   const int lane = threadIdx.x & 63;
-  const int k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // filter of this wave.  The receiver-side pass has work for filters 0, 3, 4, 6, 7, 8 (and one line for 1); SIMD 0 hosts
+  // three of the nine waves (0, 4, 8), so it gets the filters with nothing to do there (2, 5, 1) and every other SIMD one
+  // cross-product filter and one light one: wave -> 2, 3, 7, 8, 5, 0, 4, 6, 1
+#if CGV_DL_FILTER_PERM
+  const int k = (int)((0x164058732ull >> (4 * wave)) & 15);
+#else
+  const int k = wave;
+#endif
   const int node = lane >> 2, c = lane & 3, f = f0 + c;
   const bool live = node < n;
   const int nc = live ? node : 0;
@@ -1070,6 +1136,7 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_bwd_k(
   QuadRegs<3, 1, QS> qr;
   { const int kq[1] = {(int)blockIdx.x}; quad_issue<3, 1>(qr, gvrows_slices, gvr_n, gvr_stride, 3 * n, kq); }
   pin_loads();
+  DL_WV(1);
   copy4_commit(r_gd, geomd_l, E * GS / 4);
   copy4_commit(r_gs, geoms_l, E * GS / 4);
   int_commit(r_rpd, rpd_l, n + 1); int_commit(r_rps, rps_l, n + 1);
@@ -1080,9 +1147,10 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_bwd_k(
   vector_commit(r_gvb, gvb != nullptr, gvb_l, n); vector_commit(r_gvres, gv_res != nullptr, gvres_l, n);
   if ((int)threadIdx.x < n * 9) reinterpret_cast<float4*>(phi_l)[threadIdx.x] = r_phi;
   DL_PH(8, 1);
+  DL_WV(2);
   BiRegs<9, 2> wr;                                                       // slot 1: the late tile, requested below
   const TileRange tr{0, (F + 63) / 64};
-  bi_prefetch_slot<0>(wr, W2, F, row0, dl_tile_of(tr, k, 0));
+  bi_prefetch_slot<0>(wr, W2, F, row0, dl_tile_of(tr, wave, 0));
   pin_loads();
   // gV' = sum of the slices of B3 (rows 3 i + xyz) + the residual path V' -> V''
   quad_finish<3, 1>(qr, gvr_l, scratch, gvr_n, 3 * n, 8);
@@ -1095,8 +1163,8 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_bwd_k(
   __syncthreads();
   DL_PH(8, 4);
   // the 10th.. column tiles (K = 600: 24 columns, wave 0 only): requested now, used after the passes
-  if (dl_tile_of(tr, k, 1) < tr.end) {                                    // wave-uniform
-    bi_prefetch_slot<1>(wr, W2, F, row0, dl_tile_of(tr, k, 1));
+  if (dl_tile_of(tr, wave, 1) < tr.end) {                                 // wave-uniform
+    bi_prefetch_slot<1>(wr, W2, F, row0, dl_tile_of(tr, wave, 1));
   } else {
 #pragma unroll
     for (int g = 0; g < 9; ++g) wr.w[1][g] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1112,41 +1180,52 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_bwd_k(
   float a = 0.f;
   dv3 av{0.f, 0.f, 0.f}, avb{0.f, 0.f, 0.f};
   {
+    // One LDS round trip per edge: the receiver id of the NEXT edge is requested with this edge's operands, and every
+    // filter reads the same set of arrays through wave-uniform base pointers (a load inside the filter switch would be a
+    // second dependent trip: index -> operand -> switch -> operand was four of them, ~0.3 us per edge with nine waves).
+    DL_WV(4);
+    const float* __restrict__ pA = k >= 5 ? gvb_l : gv_l;                 // the gradient the filter's term carries
+    const float* __restrict__ pB = k == 8 ? vb_l : v_l;                   // the receiver-side state in its cross product (k = 0: v_i of the filter-free term)
+    const float* __restrict__ pS = k == 0 ? gh_l : sb_l;
     const int e_beg = live ? rps_l[node] : 0, e_end = live ? min(rps_l[node + 1], E) : 0;
+    int i_nx = e_beg < e_end ? dsts_l[e_beg] : 0;
     for (int e = e_beg; e < e_end; ++e) {
       const float* __restrict__ g = geoms_l + (size_t)e * GS;
-      const int i = dsts_l[e];
-      const int ic = i * 4 + c;
+      const int ic = i_nx * 4 + c;
+      i_nx = dsts_l[min(e + 1, e_end - 1)];
+      const dv3 gA = lds_v3(pA + ic * 3), sB = lds_v3(pB + ic * 3);
+      const float sc = pS[ic], s_i = s_l[ic], ghb_i = ghb_l[ic];
+      float gr[R + 1];
+#pragma unroll
+      for (int nn = 0; nn <= R; ++nn) gr[nn] = g[nn];
+      const dv3 unit{g[U], g[U + 1], g[U + 2]};
       const dv3 zero{0.f, 0.f, 0.f};
-      const dv3 gv_i = lds_v3(gv_l + ic * 3);
       float gq = 0.f;
       dv3 cav = zero, cavb = zero;
-      switch (k) {                                   // wave-uniform
-        case 0: gq = gh_l[ic] * s_l[ic]; break;
-        case 1: gq = ddot(gv_i, dv3{g[U], g[U + 1], g[U + 2]}); break;
-        case 2: gq = ddot(gv_i, v_n); cav = gv_i; break;
-        case 3: { const dv3 v_i = lds_v3(v_l + ic * 3); gq = ddot(gv_i, dcross(v_i, vb_n)); cavb = dcross(gv_i, v_i); break; }
-        case 4: { const float sb_i = sb_l[ic]; gq = sb_i * ddot(gv_i, vb_n); cavb = dv3{sb_i * gv_i.x, sb_i * gv_i.y, sb_i * gv_i.z}; break; }
-        case 5: { const dv3 gvb_i = lds_v3(gvb_l + ic * 3); gq = ddot(gvb_i, vb_n); cavb = gvb_i; break; }
-        case 6: { const dv3 gvb_i = lds_v3(gvb_l + ic * 3); const float sb_i = sb_l[ic];
-                  gq = sb_i * ddot(gvb_i, v_n); cav = dv3{sb_i * gvb_i.x, sb_i * gvb_i.y, sb_i * gvb_i.z}; break; }
-        case 7: { const dv3 gvb_i = lds_v3(gvb_l + ic * 3); const dv3 v_i = lds_v3(v_l + ic * 3);
-                  gq = ddot(gvb_i, dcross(v_i, v_n)); cav = dcross(gvb_i, v_i); break; }
-        default: { const dv3 gvb_i = lds_v3(gvb_l + ic * 3); const dv3 vb_i = lds_v3(vb_l + ic * 3);
-                   gq = ddot(gvb_i, dcross(vb_i, vb_n)); cavb = dcross(gvb_i, vb_i); break; }
+      switch (k) {                                   // wave-uniform; registers only
+        case 0: gq = sc * s_i; break;
+        case 1: gq = ddot(gA, unit); break;
+        case 2: gq = ddot(gA, v_n); cav = gA; break;
+        case 3: gq = ddot(gA, dcross(sB, vb_n)); cavb = dcross(gA, sB); break;
+        case 4: gq = sc * ddot(gA, vb_n); cavb = dv3{sc * gA.x, sc * gA.y, sc * gA.z}; break;
+        case 5: gq = ddot(gA, vb_n); cavb = gA; break;
+        case 6: gq = sc * ddot(gA, v_n); cav = dv3{sc * gA.x, sc * gA.y, sc * gA.z}; break;
+        case 7: gq = ddot(gA, dcross(sB, v_n)); cav = dcross(gA, sB); break;
+        default: gq = ddot(gA, dcross(sB, vb_n)); cavb = dcross(gA, sB); break;
       }
-      const float w = dfilt<R>(W, g);
+      const float w = dfilt<R>(W, gr);
       a = fmaf(gq, w, a);
       const float t = gq * p_j;
 #pragma unroll
-      for (int nn = 0; nn <= R; ++nn) G[nn] = fmaf(t, g[nn], G[nn]);
+      for (int nn = 0; nn <= R; ++nn) G[nn] = fmaf(t, gr[nn], G[nn]);
       const float q = p_j * w;
       daxpy(av, q, cav);
       daxpy(avb, q, cavb);
-      if (k == 0) daxpy(avb, ghb_l[ic], lds_v3(v_l + ic * 3));            // the filter-free term ghb_i v_i
+      if (k == 0) daxpy(avb, ghb_i, sB);                                  // the filter-free term ghb_i v_i
     }
   }
   DL_PH(8, 5);
+  DL_WV(5);
   gphi_l[(node * 9 + k) * 4 + c] = live ? a : 0.f;
   {
     float* r = red_src + (size_t)k * 6 * 64 + lane;
@@ -1156,7 +1235,7 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_bwd_k(
 #pragma unroll
   for (int nn = 0; nn <= R; ++nn) {
     float x = G[nn];
-    x += __shfl_xor(x, 4); x += __shfl_xor(x, 8); x += __shfl_xor(x, 16); x += __shfl_xor(x, 32);
+    x = add_xor32(add_xor16(add_row_stride4(x)));
     G[nn] = x;
   }
   if (lane < 4) {
@@ -1169,19 +1248,23 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_bwd_k(
   float as = 0.f, asb = 0.f;
   dv3 rv{0.f, 0.f, 0.f}, rvb{0.f, 0.f, 0.f};
   if (k == 0 || k == 1 || k == 3 || k == 4 || k == 6 || k == 7 || k == 8) {
+    const float* __restrict__ pV = (k == 6 || k == 7) ? v_l : vb_l;       // (one LDS round trip per edge, as in pass B)
     const int e_beg = live ? rpd_l[node] : 0, e_end = live ? min(rpd_l[node + 1], E) : 0;
+    int j_nx = e_beg < e_end ? srcd_l[e_beg] : 0;
     for (int e = e_beg; e < e_end; ++e) {
-      const int jc = srcd_l[e] * 4 + c;
-      if (k == 1) { daxpy(rv, ghb_n, lds_v3(vb_l + jc * 3)); continue; }
+      const int j = j_nx;
+      j_nx = srcd_l[min(e + 1, e_end - 1)];
+      const dv3 vj = lds_v3(pV + (j * 4 + c) * 3);
+      if (k == 1) { daxpy(rv, ghb_n, vj); continue; }
       const float* __restrict__ g = geomd_l + (size_t)e * GS;
-      const float q = phi_l[(srcd_l[e] * 9 + k) * 4 + c] * dfilt<R>(W, g);
-      switch (k) {
+      const float q = phi_l[(j * 9 + k) * 4 + c] * dfilt<R>(W, g);
+      switch (k) {                                   // registers only
         case 0: as = fmaf(gh_n, q, as); break;
-        case 3: daxpy(rv, q, dcross(lds_v3(vb_l + jc * 3), gv_n)); break;
-        case 4: asb = fmaf(q, ddot(gv_n, lds_v3(vb_l + jc * 3)), asb); break;
-        case 6: asb = fmaf(q, ddot(gvb_n, lds_v3(v_l + jc * 3)), asb); break;
-        case 7: daxpy(rv, q, dcross(lds_v3(v_l + jc * 3), gvb_n)); break;
-        default: daxpy(rvb, q, dcross(lds_v3(vb_l + jc * 3), gvb_n)); break;
+        case 3: daxpy(rv, q, dcross(vj, gv_n)); break;
+        case 4: asb = fmaf(q, ddot(gv_n, vj), asb); break;
+        case 6: asb = fmaf(q, ddot(gvb_n, vj), asb); break;
+        case 7: daxpy(rv, q, dcross(vj, gvb_n)); break;
+        default: daxpy(rvb, q, dcross(vj, gvb_n)); break;
       }
     }
   }
@@ -1190,6 +1273,7 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_bwd_k(
     r[0] = as; r[64] = asb; r[128] = rv.x; r[192] = rv.y; r[256] = rv.z; r[320] = rvb.x; r[384] = rvb.y; r[448] = rvb.z;
   }
   DL_PH(8, 6);
+  DL_WV(6);
   __syncthreads();
   DL_PH(8, 9);
   // g_phi: dense copy for the weight-gradient launch
@@ -1215,6 +1299,7 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_bwd_k(
     else g_vbar[jf * 3 + (k - 5)] = t;
   }
   bi_core<1, 9, 2>(wr, gphi_l, stage, slices_out + (size_t)blockIdx.x * out_stride, F, n, tr, nullptr, nullptr, 8);
+  DL_WV(7);
   DL_PH(8, 8);
   DL_SPAN(8, 1);
 }
@@ -1406,7 +1491,7 @@ __global__ __launch_bounds__(DL_THREADS) void prior_msg_bwd_k(
 #pragma unroll
     for (int nn = 0; nn <= R; ++nn) {
       float x = G[nn];
-      x += __shfl_xor(x, 4); x += __shfl_xor(x, 8); x += __shfl_xor(x, 16); x += __shfl_xor(x, 32);
+      x = add_xor32(add_xor16(add_row_stride4(x)));
       G[nn] = x;
     }
     if (lane < 4) {
@@ -1465,7 +1550,7 @@ static int cgv_decoder_column_parts(int K, bool heavy = false) {
   return want < tiles ? want : tiles;
 }
 /* measurement: every decoder kernel stores begin / end of its first and last block into buf[32 + 4 id ..] and block 0's
- * phase boundaries into buf[80 + 10 id + i] (ids and phases in decoder_layer.hip).  buf: 192 uint64.  NULL: off */
+ * phase boundaries into buf[80 + 10 id + i] (ids and phases in decoder_layer.hip), per-wave ticks of msg_bwd into buf[192 + 8 wave + i].  buf: 272 uint64.  NULL: off */
 int cgv_decoder_debug_clock(uint64_t* buf) {
   unsigned long long* p = reinterpret_cast<unsigned long long*>(buf);
   hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(cgv::g_dl_clock), &p, sizeof(p));
@@ -1595,6 +1680,13 @@ int cgv_decoder_uv_fwd(const float* rows, const float* Wuv, float* UV, float* st
   CGV_REQUIRE(rows && Wuv && UV && stack, "null pointer");
   const int n_rbf = 8;
   CGV_DL_CHECK();
+  if ((n_feat % 8) == 0 && cgv::option(CGV_OPT_DECODER_NODESPLIT) != 0) {
+    /* node groups of at most 5 nodes (15 rows), as equal as possible: 12 nodes -> 3 x 4, 16 -> 4 x 4 */
+    const int parts = (n_nodes + 4) / 5, npp = (n_nodes + parts - 1) / parts;
+    hipLaunchKernelGGL(cgv::dec_uv_fwd_nodes_k, dim3(n_feat / 8, (n_nodes + npp - 1) / npp), dim3(cgv::DL_THREADS),
+                       cgv::lds_bytes(cgv::fwd_red_floats<1, 4>() + 256), st, rows, Wuv, UV, stack, n_nodes, n_feat, npp);
+    return cgv::check_launch("cgv_decoder_uv_fwd");
+  }
   hipLaunchKernelGGL(cgv::dec_uv_fwd_k, dim3(blocks), dim3(cgv::DL_THREADS), cgv::lds_bytes(cgv::fwd_red_floats<3, 2>() + 384), st, rows,
                      Wuv, UV, stack, n_nodes, n_feat);
   return cgv::check_launch("cgv_decoder_uv_fwd");

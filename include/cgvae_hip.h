@@ -84,7 +84,9 @@ enum {
                                   several blocks (= CUs; grid y): these products are bound by the fp32 MFMA pipe of ONE CU -- each part repeats the
                                   prologue and writes its own columns of the group's slice.  0 one block per channel group, 1 two, 2 (default) two,
                                   three for uv_bwd (48-row tiles), 3 three everywhere */
-  CGV_OPT_COUNT = 17
+  CGV_OPT_DECODER_NODESPLIT = 17, /* cgv_decoder_uv_fwd (and uv_bwd, see there): 1 (default) 8-channel blocks by node groups of <= 5 nodes (grid y) --
+                                   a third of the MFMAs and of the x rows per block; 0 one 4-channel block over all 3 n rows */
+  CGV_OPT_COUNT = 18
 };
 /* Measurement: store the GPU wall clock (cgv_timestamp_hz ticks per second) into *slot, in stream order; capturable. */
 int cgv_timestamp(uint64_t* slot /*device*/, void* stream);
@@ -390,7 +392,7 @@ int cgv_decoder_layer_supported(int n_nodes, int n_feat, int n_rbf);
 int64_t cgv_decoder_slice_floats(int K, int rows);
 int cgv_decoder_max_edges(void);
 int cgv_decoder_block_channels(int width);   /* 4 or 8: gate_bwd / dense_bwd / uv_bwd emit width / this slices */
-int cgv_decoder_debug_clock(uint64_t* buf /*device, 192 slots, or NULL*/);   /* measurement only */
+int cgv_decoder_debug_clock(uint64_t* buf /*device, 272 slots, or NULL*/);   /* measurement only */
 int cgv_decoder_msg_fwd(const float* a1, const float* W2, const float* b2, const float* s, const float* sbar, const float* v,
                         const float* vbar, const float* geom_d, const int32_t* rowptr_d, const int32_t* src_d, const float* Wd,
                         const float* bd, float* phi, float* stack, float* sbar_out, float* v_out, float* vbar_out,

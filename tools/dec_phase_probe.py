@@ -14,7 +14,7 @@ model = cg.build_model(600, w["n_rbf"], w["atom_cutoff"], w["cg_cutoff"], w["enc
 tr = Trainer(model, lr=1e-4, beta=w["beta"], gamma=w["gamma"])
 for _ in range(3):
     tr.step(batch)
-buf = torch.zeros(192, dtype=torch.int64, device="cuda")
+buf = torch.zeros(272, dtype=torch.int64, device="cuda")
 _lib.call("cgv_decoder_debug_clock", buf.data_ptr())
 hz = _lib.load().cgv_timestamp_hz()
 tr.capture(batch, warmup=0)
@@ -60,3 +60,8 @@ for group, ids in (("forward", range(0, 5)), ("backward", range(5, 10))):
         med = [statistics.median(r[n_][j] for r in rows) for j in range(4)]
         nxt = statistics.median(r[n_ + 1][0] - max(r[n_][1], r[n_][3]) for r in rows) if n_ + 1 < len(ids) else float("nan")
         print(f"  {KERN[i]:14s} {med[0]:12.2f} {med[1]:6.2f} | {med[2]:17.2f} {med[3]:6.2f} | {nxt:6.2f}")
+
+print("-- B4 per wave (block 0), us from wave 0's entry: entry, requests issued, staged arrays committed, slices landed + lane sums | pass B start, end | pass A end | product + stores end")
+for wv in range(9):
+    vals = [statistics.median((t[192 + 8 * wv + i] - t[192]) / hz * 1e6 for t in snaps) for i in range(8)]
+    print(f"  wave {wv}: " + " ".join(f"{v:6.2f}" for v in vals))
