@@ -1112,21 +1112,44 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_bwd_k(
   const int nc = live ? node : 0;
   // order of requests, all in one batch: the bead graph / node state / upstream gradients of these channels (small,
   // stored to LDS as soon as they land), the slices, and -- once the staging registers are free -- the weights, which
-  // have the two edge passes to arrive in
+  // have the two edge passes to arrive in.
+  // Every request of a wave costs its SIMD the address arithmetic and the CU's one address unit 4 - 16 cycles whether the
+  // lanes' data are wanted or not (nine waves x 21 staging requests each, most of them clamped duplicates, kept this
+  // kernel's first five microseconds busy ISSUING): the small arrays are requested by ONE wave each -- a wave-uniform
+  // role -- and a slot of the record copy only by the waves whose threads it reaches.
+  const int n4 = E * GS / 4;
   Slots4<geom_slots(R)> r_gd, r_gs;
-  copy4_issue(r_gd, geom_d, E * GS / 4);
-  copy4_issue(r_gs, geom_s, E * GS / 4);
-  const int r_rpd = int_issue(rowptr_d, n + 1), r_rps = int_issue(rowptr_s, n + 1);
-  const int r_srcd = int_issue(src_d, E), r_dsts = int_issue(dst_s, E);
-  const float4 r_s = scalar_issue(s, s, n, F, f0), r_sb = scalar_issue(sbar, s, n, F, f0);
-  const float4 r_gh = scalar_issue(gh, s, n, F, f0), r_ghb = scalar_issue(ghb, s, n, F, f0);
-  const float4 r_v = vector_issue(v, v, n, F, f0), r_vb = vector_issue(vbar, v, n, F, f0);
-  const float4 r_gvb = vector_issue(gvb, v, n, F, f0), r_gvres = vector_issue(gv_res, v, n, F, f0);
-  float4 r_phi;
-  {
-    const int o = min((int)threadIdx.x, n * 9 - 1), m = o / 9, g = o - m * 9;
-    r_phi = ldg4_pinned(phi + (size_t)m * 9 * F + (size_t)g * F + f0);
+#pragma unroll
+  for (int u = 0; u < geom_slots(R); ++u) {
+    if (wave * 64 + u * DL_THREADS < n4) {                                // wave-uniform; the commit below is guarded alike
+      const int at = min((int)threadIdx.x + u * DL_THREADS, n4 - 1);
+      r_gd.v[u] = ldg4_pinned(geom_d + 4 * (size_t)at);
+      r_gs.v[u] = ldg4_pinned(geom_s + 4 * (size_t)at);
+    }
   }
+  // Roles, branch-free (a branch per role makes the compiler wait for loads of OTHER roles' registers at the joins): every
+  // wave issues ONE float4 request and ONE index request; what differs per wave are uniform parameters.
+  //   float4:  wave 0 [s | sbar | gh | ghb] (16 lanes each), 1..4 v, vbar, gvb, gv_res (3 n lanes each), 5..7 phi (9 n
+  //            float4 in chunks of 64); element = array[m * A + part * B + C] with (m, part) = divmod(item, D)
+  //   index:   waves 0..3 src_d, 4..7 dst_s (64 ids each), 8 rowptr_d (lanes 0..31) | rowptr_s (lanes 32..63)
+  const int quarter = wave == 0 ? lane >> 4 : 0;
+  const gcf cand = wave == 0 ? (quarter == 0 ? s : quarter == 1 ? sbar : quarter == 2 ? gh : ghb)
+                 : wave == 1 ? v : wave == 2 ? vbar : wave == 3 ? gvb : wave == 4 ? gv_res : phi;
+  const bool small_have = cand != nullptr;                                // an absent array (NULL) is committed as zeros
+  const int sm_D = wave == 0 ? 1 : wave <= 4 ? 3 : 9;
+  const int sm_cnt = wave == 0 ? n : wave <= 4 ? 3 * n : n * 9;
+  const int sm_A = wave == 0 ? F : wave <= 4 ? 3 * F : 9 * F, sm_B = wave == 0 ? 0 : wave <= 4 ? 4 : F;
+  const int sm_C = wave <= 4 && wave >= 1 ? 3 * f0 : f0;
+  const int sm_item = wave == 0 ? (lane & 15) : wave <= 4 ? lane : (wave - 5) * 64 + lane;
+  float4 r_small;
+  {
+    const int it = min(sm_item, sm_cnt - 1);
+    const int m = (it * (sm_D == 1 ? 65536 : sm_D == 3 ? 21846 : 7282)) >> 16, part = it - m * sm_D;     // it < 144
+    r_small = ldg4_pinned((small_have ? cand : (wave >= 1 && wave <= 4 ? v : s)) + ((size_t)m * sm_A + part * sm_B + sm_C));   // absent: any valid address of that shape
+  }
+  const int id_item = wave < 8 ? (wave & 3) * 64 + lane : (lane & 31), id_cnt = wave < 8 ? E : n + 1;
+  const gci id_src = wave < 4 ? src_d : wave < 8 ? dst_s : (lane < 32 ? rowptr_d : rowptr_s);
+  const int r_ids = ldgi_pinned(id_src + min(id_item, id_cnt - 1));
   float W[R + 1], G[R + 1];
 #pragma unroll
   for (int nn = 0; nn < R; ++nn) W[nn] = ldg_pinned(Wd + ((size_t)k * F + f) * R + nn);
@@ -1137,15 +1160,19 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_bwd_k(
   { const int kq[1] = {(int)blockIdx.x}; quad_issue<3, 1>(qr, gvrows_slices, gvr_n, gvr_stride, 3 * n, kq); }
   pin_loads();
   DL_WV(1);
-  copy4_commit(r_gd, geomd_l, E * GS / 4);
-  copy4_commit(r_gs, geoms_l, E * GS / 4);
-  int_commit(r_rpd, rpd_l, n + 1); int_commit(r_rps, rps_l, n + 1);
-  int_commit(r_srcd, srcd_l, E); int_commit(r_dsts, dsts_l, E);
-  scalar_commit(r_s, true, s_l, n); scalar_commit(r_sb, true, sb_l, n);
-  scalar_commit(r_gh, gh != nullptr, gh_l, n); scalar_commit(r_ghb, ghb != nullptr, ghb_l, n);
-  vector_commit(r_v, true, v_l, n); vector_commit(r_vb, true, vb_l, n);
-  vector_commit(r_gvb, gvb != nullptr, gvb_l, n); vector_commit(r_gvres, gv_res != nullptr, gvres_l, n);
-  if ((int)threadIdx.x < n * 9) reinterpret_cast<float4*>(phi_l)[threadIdx.x] = r_phi;
+#pragma unroll
+  for (int u = 0; u < geom_slots(R); ++u)
+    if ((int)threadIdx.x + u * DL_THREADS < n4) {
+      reinterpret_cast<float4*>(geomd_l)[threadIdx.x + u * DL_THREADS] = r_gd.v[u];
+      reinterpret_cast<float4*>(geoms_l)[threadIdx.x + u * DL_THREADS] = r_gs.v[u];
+    }
+  {
+    float* dst = wave == 0 ? (quarter == 0 ? s_l : quarter == 1 ? sb_l : quarter == 2 ? gh_l : ghb_l)
+               : wave == 1 ? v_l : wave == 2 ? vb_l : wave == 3 ? gvb_l : wave == 4 ? gvres_l : phi_l;
+    if (sm_item < sm_cnt && wave <= 7) reinterpret_cast<float4*>(dst)[sm_item] = small_have ? r_small : make_float4(0.f, 0.f, 0.f, 0.f);
+    int* idst = wave < 4 ? srcd_l : wave < 8 ? dsts_l : (lane < 32 ? rpd_l : rps_l);
+    if (id_item < id_cnt) idst[id_item] = r_ids;
+  }
   DL_PH(8, 1);
   DL_WV(2);
   BiRegs<9, 2> wr;                                                       // slot 1: the late tile, requested below
