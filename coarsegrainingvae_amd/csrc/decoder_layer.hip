@@ -458,22 +458,29 @@ __device__ __forceinline__ void wlds_issue(float* __restrict__ w_l, const float*
 
 // MB = 1; K <= 16 * 6 * 9 (one batch of steps per wave).  after_issue() runs behind the x requests, before the barrier
 // that publishes the DMA'd weights.
-template <int G, typename Hook>
-__device__ __forceinline__ void fwd_core_wlds(float* __restrict__ out, float* __restrict__ red, const float* __restrict__ x,
-                                              int M, int K, const float* __restrict__ w_l, Hook after_issue, int ph = -1) {
-  constexpr int T = (G + 3) / 4, SB = 6;
+// Two halves, so that the caller's own code (the commit of its staged arrays) runs between the x requests and the wait --
+// as a callable handed through here it was kept in scratch memory once it captured more than a handful of registers.
+constexpr int WLDS_SB = 6;
+__device__ __forceinline__ void wlds_x_issue(float4 (&b)[WLDS_SB], const float* __restrict__ x, int M, int K) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, q = lane >> 4;
   const int steps = (K + 15) / 16, per = (steps + DL_WAVES - 1) / DL_WAVES;
   const int s_beg = wave * per, s_end = min(s_beg + per, steps);
   const float* xrow = x + (size_t)min(i, M - 1) * K;
-  float4 b[SB];
 #pragma unroll
-  for (int u = 0; u < SB; ++u) {
+  for (int u = 0; u < WLDS_SB; ++u) {
     const int k = (s_beg + u) * 16 + 4 * q;
     b[u] = *reinterpret_cast<const float4*>(xrow + ((s_beg + u < s_end && k < K) ? k : 0));
   }
-  after_issue();
+}
+template <int G>
+__device__ __forceinline__ void fwd_core_wlds_finish(float* __restrict__ out, float* __restrict__ red, const float4 (&b)[WLDS_SB],
+                                                     int K, const float* __restrict__ w_l, int ph = -1) {
+  constexpr int T = (G + 3) / 4, SB = WLDS_SB;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, q = lane >> 4;
+  const int steps = (K + 15) / 16, per = (steps + DL_WAVES - 1) / DL_WAVES;
+  const int s_beg = wave * per, s_end = min(s_beg + per, steps);
   if (ph >= 0) DL_PH(ph, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -614,24 +621,41 @@ __global__ __launch_bounds__(DL_THREADS) void dec_msg_fwd_k(
   const gcf vbar = launder(vbar_); const gcf Wd = launder(Wd_); const gcf bd = launder(bd_);
   // bead graph + node state of these channels: requested in one batch with the product's operands, stored to LDS behind
   // the product's own requests (consumed after the product)
+  // (one wave per small array, branch-free roles: see dec_msg_bwd_k.  float4: wave 0 [s | sbar] (32 lanes each), 1 v,
+  //  2 vbar (3 n lanes); ids: waves 0..3 src (64 each), 4 rowptr)
+  const int n4 = E * GS / 4;
+  // (the record copy stays unconditional here: its registers are captured by the commit hook below, and a conditionally
+  //  written capture is kept in scratch memory)
   Slots4<geom_slots(R)> r_geom;
-  copy4_issue(r_geom, geom, E * GS / 4);
-  const int r_rp = int_issue(rowptr, n + 1), r_src = int_issue(src, E);
-  const float4 r_s = scalar_issue(s, s, n, F, f0), r_sb = scalar_issue(sbar, s, n, F, f0);
-  const float4 r_v = vector_issue(v, v, n, F, f0), r_vb = vector_issue(vbar, v, n, F, f0);
+  copy4_issue(r_geom, geom, n4);
+  const int half = k == 0 ? lane >> 5 : 0;
+  const gcf cand = k == 0 ? (half == 0 ? s : sbar) : k == 1 ? v : vbar;
+  const int sm_D = k == 0 ? 1 : 3, sm_cnt = k == 0 ? n : 3 * n, sm_A = k == 0 ? F : 3 * F, sm_B = k == 0 ? 0 : 4;
+  const int sm_C = k == 0 ? f0 : 3 * f0, sm_item = k == 0 ? (lane & 31) : lane;
+  float4 r_small;
+  {
+    const int it = min(sm_item, sm_cnt - 1);
+    const int m = (it * (sm_D == 1 ? 65536 : 21846)) >> 16, part = it - m * sm_D;                       // it < 48
+    r_small = ldg4_pinned(cand + ((size_t)m * sm_A + part * sm_B + sm_C));
+  }
+  const int id_item = k < 4 ? k * 64 + lane : lane, id_cnt = k < 4 ? E : n + 1;
+  const int r_ids = ldgi_pinned((k < 4 ? src : rowptr) + min(id_item, id_cnt - 1));
   float W[R + 1];
 #pragma unroll
   for (int nn = 0; nn < R; ++nn) W[nn] = ldg_pinned(Wd + ((size_t)k * F + f) * R + nn);
   W[R] = ldg_pinned(bd + (size_t)k * F + f);
   pin_loads();
-  auto commit = [&]() {
-    copy4_commit(r_geom, geom_l, E * GS / 4);
-    int_commit(r_rp, rp_l, n + 1); int_commit(r_src, src_l, E);
-    scalar_commit(r_s, true, s_l, n); scalar_commit(r_sb, true, sb_l, n);
-    vector_commit(r_v, true, v_l, n); vector_commit(r_vb, true, vb_l, n);
-  };
-  if (WLDS) fwd_core_wlds<9>(phi_l, red, a1, n, F, w_l, commit, 1);
-  else fwd_core<1, 9, 5>(phi_l, red, a1, n, F, W2, row0, commit, 1);
+  // (the commit is written out at its place: as a callable it was kept in scratch memory)
+  float4 xb[WLDS_SB];
+  if (WLDS) wlds_x_issue(xb, a1, n, F);
+  else fwd_core<1, 9, 5>(phi_l, red, a1, n, F, W2, row0, NoHook(), 1);  // (register path: whole product first; the bias pass's barrier publishes the commit)
+  {
+    copy4_commit(r_geom, geom_l, n4);
+    float* dst = k == 0 ? (half == 0 ? s_l : sb_l) : k == 1 ? v_l : vb_l;
+    if (k <= 2 && sm_item < sm_cnt) reinterpret_cast<float4*>(dst)[sm_item] = r_small;
+    if (k <= 4 && id_item < id_cnt) (k < 4 ? src_l : rp_l)[id_item] = r_ids;
+  }
+  if (WLDS) fwd_core_wlds_finish<9>(phi_l, red, xb, F, w_l, 1);
   // bias, dense copy for the backward pass (phi[m][g F + f0 .. +3])
   for (int o = threadIdx.x; o < 16 * 9; o += DL_THREADS) {
     const int m = o / 9, g = o - m * 9;
