@@ -116,10 +116,58 @@ def spawn_ranks(n: int) -> int:
 # ---------------------------------------------------------------------------------------------- multi-rank supervisor
 # A multi-rank run must not be lost to a hang: a collective stuck inside a replayed graph never raises.  Every rank that
 # torchrun (or the driver) starts is therefore only a SUPERVISOR -- it never touches the GPU -- and runs the measurement
-# in a fresh worker process per attempt, with a deadline.  All ranks walk the same ladder with the same deadlines, so they
-# change rungs together; the workers of attempt k meet on MASTER_PORT + 17 + k.
+# in a fresh worker process per attempt, with a deadline.  All ranks walk the same ladder on the SAME CLOCK: rung k starts
+# at t0 + k * (deadline + grace) on every rank, t0 being one wall-clock value the supervisors of a launch agree on through a
+# file their common parent's pid names (they run on one node, beside each other).  A rank whose worker fails early -- it raised
+# while its peers hang in a collective until their deadline kills them -- WAITS for the next slot instead of starting the next
+# rung alone, whose rendezvous would time out about when the peers arrive (and so on down the ladder).  The workers of
+# attempt k meet on MASTER_PORT + 17 + k.
+RUNG_GRACE_S = 15.0          # kill + teardown of a timed-out worker before the next slot opens
 LADDER = [("operands+graph", []), ("gradients+graph", ["--exchange", "gradients"]),
           ("gradients+eager", ["--exchange", "gradients", "--no-graph"])]
+
+
+def ladder_path(base_port: int) -> str:
+    return os.path.join(os.environ.get("TMPDIR", "/tmp"), f"cgv_bench_t0_{os.getppid()}_{base_port}")
+
+
+def ladder_wait(base_port: int, k: int, world: int, until: float) -> None:
+    """Before attempt k: wait until EVERY rank has posted the end of attempt k - 1 (then all move on at once, early) or
+    until the slot opens (a hung peer is killed before that and posts), whichever comes first."""
+    path = ladder_path(base_port)
+    while time.time() < until:
+        if all(os.path.exists(f"{path}.{k - 1}.{r}") for r in range(world)):
+            return
+        time.sleep(0.1)
+
+
+def ladder_t0(base_port: int, slot_s: float, n_rungs: int) -> float:
+    """One wall-clock origin for all supervisors of this launch: the first to create the file writes its clock, the others
+    read it.  The name carries the common parent (torchrun's agent, or bench.py's own rank spawner) and the port; a file
+    older than a whole ladder is a stale leftover of a recycled pid and is replaced."""
+    path = ladder_path(base_port)
+    horizon = slot_s * (n_rungs + 1)
+    for _ in range(200):
+        try:
+            fd = os.open(path, os.O_CREAT | os.O_EXCL | os.O_WRONLY, 0o600)
+            with os.fdopen(fd, "w") as f:
+                f.write(repr(time.time()))
+            break
+        except FileExistsError:
+            try:
+                if time.time() - os.path.getmtime(path) > horizon:
+                    os.unlink(path)                          # stale: an earlier launch with the same parent pid and port
+                    continue
+                txt = open(path).read().strip()
+                if txt:
+                    return float(txt)
+            except (OSError, ValueError):
+                pass
+            time.sleep(0.01)
+    try:
+        return float(open(path).read().strip())
+    except (OSError, ValueError):
+        return time.time()
 
 
 def supervise(args) -> int:
@@ -131,7 +179,14 @@ def supervise(args) -> int:
         ladder = ladder[-1:]
     argv = [a for a in sys.argv[1:]]
     reason = ""
+    slot_s = args.attempt_timeout + RUNG_GRACE_S
+    if os.environ.get("CGV_BENCH_TEST_SLOT_S"):              # (rehearsals: short slots)
+        slot_s = float(os.environ["CGV_BENCH_TEST_SLOT_S"])
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    t0 = ladder_t0(base_port, slot_s, len(ladder)) if world > 1 else time.time()
     for k, (name, extra) in enumerate(ladder):
+        if k > 0 and world > 1:
+            ladder_wait(base_port, k, world, t0 + k * slot_s)
         env = dict(os.environ)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         env.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -143,9 +198,11 @@ def supervise(args) -> int:
         env.update({"CGV_BENCH_WORKER": "1", "CGV_BENCH_ATTEMPT": str(k), "CGV_BENCH_RUNG": name, "CGV_BENCH_REASON": reason,
                     "MASTER_PORT": str(base_port + 17 + k)})
         cmd = [sys.executable, os.path.abspath(__file__), *argv, *extra, "--no-supervisor"]
-        t0 = time.time()
+        if os.environ.get("CGV_BENCH_TEST_WORKER"):         # (rehearsals of the ladder itself: a stand-in worker, no GPU)
+            cmd = [sys.executable, os.environ["CGV_BENCH_TEST_WORKER"]]
+        t_start = time.time()
         proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, start_new_session=True)
-        deadline = args.attempt_timeout
+        deadline = min(args.attempt_timeout, slot_s - 1.0) if world > 1 else args.attempt_timeout
         if os.environ.get("CGV_BENCH_TEST_HANG_ATTEMPT") == str(k) and os.environ.get("CGV_BENCH_TEST_HANG_TIMEOUT"):
             deadline = float(os.environ["CGV_BENCH_TEST_HANG_TIMEOUT"])       # (rehearsal of the kill path only)
         try:
@@ -160,7 +217,12 @@ def supervise(args) -> int:
             rc, why = -9, f"timeout after {deadline:.0f} s"
         lines = [ln for ln in (out or b"").decode(errors="replace").splitlines() if ln.startswith("{") and ln.rstrip().endswith("}")]
         ok = rc == 0 and (rank != 0 or len(lines) == 1)
-        print(f"[bench] rank {rank} attempt {k} ({name}): rc {rc} {why} in {time.time() - t0:.0f} s", file=sys.stderr)
+        print(f"[bench] rank {rank} attempt {k} ({name}): rc {rc} {why} in {time.time() - t_start:.0f} s", file=sys.stderr)
+        if world > 1:
+            try:
+                open(f"{ladder_path(base_port)}.{k}.{rank}", "w").close()     # posted: this rank is through with attempt k
+            except OSError:
+                pass
         if ok:
             if rank == 0:
                 sys.stdout.write(lines[0] + "\n")

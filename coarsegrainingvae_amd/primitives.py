@@ -43,28 +43,37 @@ def to_module(activation: str) -> nn.Module:
     return layer_types[activation]()
 
 
-def _gemm_mode(x2, weight, bias):
-    """Which kernels a Dense / Linear product runs on:
-    "skinny"  M <= 64 rows (bead level): weight-streaming HIP kernels, csrc/skinny_gemm.hip;
-    "tile"    more rows (atom level, or big bead batches): reduction-split MFMA tiles, csrc/tile_gemm.hip.
-    There is no third way: CPU tensors, other dtypes and widths the kernels do not take (not a multiple of 4) RAISE --
-    no product runs on a library GEMM or on torch ops (DESIGN.md 1)."""
+def gemm_mode_or_none(x2, weight, bias):
+    """The kernel family a Dense / Linear product would run on -- "skinny" (M <= 64 rows, bead level: weight-streaming HIP
+    kernels, csrc/skinny_gemm.hip) or "tile" (more rows: reduction-split MFMA tiles, csrc/tile_gemm.hip) -- or ``None`` with
+    the reason when no HIP kernel takes these operands.  Never raises: the predicate of the pair / fusion dispatch."""
     if not (x2.is_cuda and weight.is_cuda):
-        raise RuntimeError("Dense / Linear run on the HIP kernels only: move the module and its input to the device "
-                           "(there is no CPU / library fallback)")
+        return None, ("Dense / Linear run on the HIP kernels only: move the module and its input to the device "
+                      "(there is no CPU / library fallback)")
     if x2.dtype != torch.float32 or weight.dtype != torch.float32:
-        raise RuntimeError("the HIP path computes in fp32 only")
+        return None, "the HIP path computes in fp32 only"
     if not (weight.is_contiguous() and weight.data_ptr() % 16 == 0):
-        raise RuntimeError("Dense / Linear: the weight must be contiguous and 16-byte aligned")
+        return None, "Dense / Linear: the weight must be contiguous and 16-byte aligned"
     M, K = x2.shape
     N = weight.shape[0]
+    if M == 0:
+        return None, f"Dense / Linear on an input without rows (0 x {K})"
     lib = _lib.load()
     if lib.cgv_skinny_supported(M, N, K) and (bias is None or bias.data_ptr() % 16 == 0):
-        return "skinny"
-    if M > 0 and lib.cgv_tile_supported(M, N, K):
-        return "tile"
-    raise RuntimeError(f"Dense / Linear {M} x {N} x {K}: the HIP kernels need in / out widths that are multiples of 4 "
-                       f"(e.g. -n_basis 600); no library GEMM stands in for other widths")
+        return "skinny", None
+    if lib.cgv_tile_supported(M, N, K):
+        return "tile", None
+    return None, (f"Dense / Linear {M} x {N} x {K}: the HIP kernels take in / out widths that are multiples of 4 "
+                  f"(other widths are zero-padded by primitives.linear_fn before they get here)")
+
+
+def _gemm_mode(x2, weight, bias):
+    """``gemm_mode_or_none`` for EXECUTION: there is no third way -- CPU tensors, other dtypes, unaligned operands RAISE;
+    no product runs on a library GEMM or on torch ops (DESIGN.md 1)."""
+    mode, why = gemm_mode_or_none(x2, weight, bias)
+    if mode is None:
+        raise RuntimeError(why)
+    return mode
 
 
 ACT_NONE, ACT_SWISH, ACT_TANH, ACT_RELU = 0, 1, 2, 3      # cgv_common.h: act_fwd / act_bwd
@@ -727,7 +736,7 @@ def tile_pair_usable_raw(x_a, x_b, w_a, b_a, w_b, b_b) -> bool:
         return False
     M, K = x_a.shape
     N = w_a.shape[0]
-    if _gemm_mode(x_a, w_a, b_a) != "tile" or not _lib.load().cgv_tile_pair_supported(M, N, K):
+    if gemm_mode_or_none(x_a, w_a, b_a)[0] != "tile" or not _lib.load().cgv_tile_pair_supported(M, N, K):
         return False
     tens = (x_a, x_b, w_a, w_b, b_a, b_b)
     return (all(_is_direct(p) and p.grad.is_contiguous() for p in (w_a, w_b, b_a, b_b))
@@ -912,7 +921,7 @@ def dual_heads(head_a, head_b, x, out_act_a: int = ACT_NONE, out_act_b: int = AC
         ha, hb = _PairLinearFn.apply(x, x, ma[0].weight, ma[0].bias, mb[0].weight, mb[0].bias, codes[type(ma[1])], codes[type(mb[1])])
         if pair_linear_usable(ha, hb, ma[2], mb[2]):
             return _PairLinearFn.apply(ha, hb, ma[2].weight, ma[2].bias, mb[2].weight, mb[2].bias, out_act_a, out_act_b)
-        return _LinearFn.apply(ha, ma[2].weight, ma[2].bias, out_act_a), _LinearFn.apply(hb, mb[2].weight, mb[2].bias, out_act_b)
+        return linear_fn(ha, ma[2].weight, ma[2].bias, out_act_a), linear_fn(hb, mb[2].weight, mb[2].bias, out_act_b)
     # too many rows for the skinny pair kernels (a large bead batch): layer j of both heads as a pair launch of the tile
     # kernels (the shared input's two gradients meet in the chain of backward-input epilogues) ...
     if (len(ma) == 3 and len(mb) == 3 and isinstance(ma[0], nn.Linear) and isinstance(mb[0], nn.Linear) and type(ma[1]) in codes
@@ -923,7 +932,7 @@ def dual_heads(head_a, head_b, x, out_act_a: int = ACT_NONE, out_act_b: int = AC
         if tile_pair_usable_raw(ha, hb, ma[2].weight, ma[2].bias, mb[2].weight, mb[2].bias):
             ya, yb, _alias = _TilePairFn.apply(ha, hb, ma[2].weight, ma[2].bias, mb[2].weight, mb[2].bias, (int(out_act_a), int(out_act_b)), None)
             return ya, yb
-        return _LinearFn.apply(ha, ma[2].weight, ma[2].bias, out_act_a), _LinearFn.apply(hb, mb[2].weight, mb[2].bias, out_act_b)
+        return linear_fn(ha, ma[2].weight, ma[2].bias, out_act_a), linear_fn(hb, mb[2].weight, mb[2].bias, out_act_b)
     # ... or, one by one, the second head reading x through the first head's fork
     ya, x_alias = head_a(x, out_act=out_act_a, fork=True)
     return ya, head_b(x_alias, out_act=out_act_b)
@@ -1003,8 +1012,26 @@ def mark_direct_grad(*params):
             p._cgv_direct_ok = True
 
 
+def linear_fn(x, weight, bias, act, fork=False, slot=None):
+    """``_LinearFn`` for every width.  The kernels take in / out widths that are multiples of 4; the reference takes any
+    ``-n_basis`` (run_ala.py:419-461), so other widths are ZERO-PADDED here -- x by columns, W by rows and columns, b by
+    entries -- run through the same kernels and sliced on output (the padded columns multiply zeros; the padded outputs are
+    cut off before anything reads them; autograd slices the gradients back).  The padded operands are not arena-managed:
+    this is the compatibility path, the documented widths (512, 600) never take it."""
+    N, K = weight.shape
+    if (N % 4 == 0 and K % 4 == 0) or not x.is_cuda:
+        return _LinearFn.apply(x, weight, bias, act, fork, slot) if (fork or slot is not None) else _LinearFn.apply(x, weight, bias, act)
+    if x.shape[0:-1].numel() == 0:
+        y = x.new_zeros(x.shape[:-1] + (N,))
+        return (y, x) if fork else y
+    pn, pk = (-N) % 4, (-K) % 4
+    y = _LinearFn.apply(Fn.pad(x, (0, pk)), Fn.pad(weight, (0, pk, 0, pn)), Fn.pad(bias, (0, pn)) if bias is not None else None, act)
+    y = y[..., :N]
+    return (y, x) if fork else y          # (fork: a plain alias -- autograd adds the second consumer's gradient)
+
+
 def linear(x, weight, bias=None, act=ACT_NONE):
-    return _LinearFn.apply(x, weight, bias, act)
+    return linear_fn(x, weight, bias, act)
 
 
 class Linear(nn.Linear):
@@ -1015,7 +1042,7 @@ class Linear(nn.Linear):
         mark_direct_grad(self.weight, self.bias)
 
     def forward(self, x):
-        return _LinearFn.apply(x, self.weight, self.bias, ACT_NONE)
+        return linear_fn(x, self.weight, self.bias, ACT_NONE)
 
 
 class MLPHead(nn.Sequential):
@@ -1034,10 +1061,10 @@ class MLPHead(nn.Sequential):
                 and isinstance(mods[2], nn.Linear) and x.is_cuda):
             alias = x
             if fork and x.requires_grad and torch.is_grad_enabled():
-                y, alias = _LinearFn.apply(x, mods[0].weight, mods[0].bias, self._CODES[type(mods[1])], True)
+                y, alias = linear_fn(x, mods[0].weight, mods[0].bias, self._CODES[type(mods[1])], True)
             else:
-                y = _LinearFn.apply(x, mods[0].weight, mods[0].bias, self._CODES[type(mods[1])])
-            out = _LinearFn.apply(y, mods[2].weight, mods[2].bias, out_act)
+                y = linear_fn(x, mods[0].weight, mods[0].bias, self._CODES[type(mods[1])])
+            out = linear_fn(y, mods[2].weight, mods[2].bias, out_act)
             return (out, alias) if fork else out
         y = super().forward(x)
         y = y if out_act == ACT_NONE else _STD_EPS[out_act] + torch.exp(y / 2)
@@ -1068,13 +1095,13 @@ class Dense(nn.Linear):
         backward-input kernel instead of by an accumulation launch of autograd (``_LinearFn.forward(fork=True)``)."""
         if (isinstance(self.activation, Swish) and self.dropout_rate == 0.0 and torch.is_tensor(inputs) and inputs.is_cuda
                 and inputs.requires_grad and torch.is_grad_enabled()):
-            return _LinearFn.apply(inputs, self.weight, self.bias, ACT_SWISH, True, slot)
+            return linear_fn(inputs, self.weight, self.bias, ACT_SWISH, True, slot)
         return self.forward(inputs), inputs
 
     def forward(self, inputs):
         if isinstance(self.activation, Swish) and self.dropout_rate == 0.0:
-            return _LinearFn.apply(inputs, self.weight, self.bias, ACT_SWISH)      # bias + Swish fused
-        y = _LinearFn.apply(inputs, self.weight, self.bias, ACT_NONE)
+            return linear_fn(inputs, self.weight, self.bias, ACT_SWISH)      # bias + Swish fused
+        y = linear_fn(inputs, self.weight, self.bias, ACT_NONE)
         if self.dropout_rate > 0.0:
             y = self.dropout(y)
         return self.activation(y) if self.activation is not None else y

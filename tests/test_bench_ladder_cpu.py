@@ -1,0 +1,33 @@
+"""bench.py's supervisor ladder with a ONE-SIDED failure, two real processes, no GPU (the supervisor never touches one; the
+worker is a stand-in, tests/ladder_stand_in_worker.py): rank 1's attempt 0 fails at once while rank 0's hangs until its
+deadline.  All rungs must stay aligned: both ranks start attempt 1 together (inside the stand-in's 3 s rendezvous window)
+and rank 0 prints exactly one JSON line from attempt 1.  With per-rank clocks (the previous scheme) rank 1 reached attempt 1
+a whole deadline early, its rendezvous timed out about when rank 0 arrived, and every rung failed."""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_one_sided_failure_keeps_the_rungs_aligned():
+    with tempfile.TemporaryDirectory() as tmp:
+        env = dict(os.environ)
+        env.update({"WORLD_SIZE": "2", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29911", "TMPDIR": tmp,
+                    "CGV_BENCH_TEST_WORKER": os.path.join(ROOT, "tests", "ladder_stand_in_worker.py"),
+                    "CGV_BENCH_TEST_SLOT_S": "9", "CGV_TEST_RDV_DIR": tmp, "CGV_TEST_RDV_WINDOW": "3"})
+        procs = []
+        for rank in (0, 1):
+            e = dict(env, RANK=str(rank), LOCAL_RANK=str(rank))
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--attempt-timeout", "6"],
+                                          env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        outs = [p.communicate(timeout=120) for p in procs]
+        assert [p.returncode for p in procs] == [0, 0], [o[1][-1500:] for o in outs]
+        lines = [ln for ln in outs[0][0].splitlines() if ln.strip()]
+        assert len(lines) == 1 and not outs[1][0].strip(), (outs[0][0], outs[1][0])
+        d = json.loads(lines[0])
+        assert d["attempt"] == 1 and d["rung"] == "gradients+graph" and d["spread_s"] < 2.0, d
+        # rank 1 failed in a fraction of a second and WAITED for rank 0's kill instead of starting attempt 1 alone
+        assert "attempt 0 (operands+graph): rc 3" in outs[1][1] and "rc -9 timeout" in outs[0][1], (outs[0][1], outs[1][1])

@@ -80,6 +80,18 @@ def elementwise_err(got, ref, floor=1e-2):
     return float(((got - ref).abs() / ref.abs().clamp_min(floor)).max())
 
 
+OBSERVED = []          # (what, latent, Adam updates behind it, element-wise error): `pytest -s` prints the maxima at exit
+
+
+def teardown_module(module):
+    if OBSERVED:
+        for upd in (0, 1):
+            rows = [r for r in OBSERVED if (r[2] > 0) == bool(upd)]
+            if rows:
+                worst = max(rows, key=lambda r: r[3])
+                print(f"\n[latents, element-wise, {'behind Adam updates' if upd else 'first step'}] worst {worst[3]:.3e} ({worst[0]}: {worst[1]}) over {len(rows)} checks")
+
+
 def _check_outputs(tr, ref, what, updates: int = 0):
     """``updates``: Adam steps behind these outputs.  After an update the two sides' parameters agree only as far as
     ``_check_parameters`` says (an Adam step on a ~1e-8 gradient is +-lr whatever the gradient's last bits are), so the
@@ -100,6 +112,7 @@ def _check_outputs(tr, ref, what, updates: int = 0):
             continue
         floor = 1e-2 * float(ref["out"][k].abs().max())
         e = elementwise_err(tr.last_out[k], ref["out"][k], floor=floor)
+        OBSERVED.append((what, NAMES[k], updates, e))
         assert e <= lat_tol, f"{what}: {NAMES[k]} element-wise error {e:.3e} (floor {floor:.3e})"
     kl, recon, graph = tr.last_terms
     for a, b, k in ((tr.last_loss, ref["loss"], "loss"), (kl, ref["kl"], "kl"), (recon, ref["recon"], "recon"),
@@ -245,7 +258,7 @@ def test_dipeptide_32_frames_vs_oracle(rank_rows_mfma):
         assert tr.rank_steps_mfma == 0 and tr.rank_steps == 0 and tr._rank_hi == 0      # every gradient materialised
 
 
-@pytest.mark.timeout(900)
+@pytest.mark.timeout(1800)
 def test_protein2000_full_width_step_vs_chunked_oracle():
     """BASELINE configs[4] at FULL width (F=600, enc 2 / dec 9; 2000 atoms, ~851 k directed edges, 64 beads): one whole
     training step -- forward, ELBO, EVERY live gradient (K2b over 851 k edges x 5 channel tiles, the 64 x 64 weight-gradient
@@ -282,6 +295,29 @@ def test_protein2000_full_width_step_vs_chunked_oracle():
     assert n_live > 100
     _check_norm_and_clip(tr, ref, "protein2000 F=600")
     _check_moments(tr, model, oracle, "protein2000 F=600")
+    # step 2, eager, and step 3, the captured hipGraph: the DEFAULT dispatch of every later step at this size -- gradients
+    # written straight into the arena, wgrad_split128_k on the 2000-row operands, strip launches for the 64 bead rows, the
+    # flat norm + Adam over all live parameters -- against the oracle's next two steps (same chunked message blocks)
+    gen = torch.Generator().manual_seed(10)
+    P0 = None
+    for step in (2, 3):
+        eps = torch.randn(cpu_batch["CG_nxyz"].shape[0], F, generator=gen)
+        O.EDGE_CHUNK = 65536
+        try:
+            ref = oracle.step(eps)
+        finally:
+            O.EDGE_CHUNK = None
+        if step == 3:
+            tr.capture(batch, warmup=0, eps=eps.to(DEV))
+            replays = tr.replays
+        tr.step(batch, eps=eps.to(DEV))
+        if step == 3:
+            assert tr.replays == replays + 1                          # it really was the graph
+        what = f"protein2000 F=600 step {step}" + (" (replay)" if step == 3 else "")
+        _check_outputs(tr, ref, what, updates=step - 1)
+        _check_norm_and_clip(tr, ref, what)
+        _check_moments(tr, model, oracle, what)
+    assert int(tr.state[ST_STEP].item()) == 3 and tr.skipped_steps() == 0 and tr.rank_fallbacks == 0
 
 
 def test_protein2000_reduced_width_vs_oracle():

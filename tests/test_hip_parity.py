@@ -284,7 +284,7 @@ def test_model_forward_loss_and_grads_golden(tag, prepared):
     for name, p in model.named_parameters():
         if name in live:
             assert p.grad is not None, name
-            assert_close(p.grad, g["g." + name], "grad " + name, 2e-4)
+            assert_close(p.grad, g["g." + name], "grad " + name)            # observed <= 2.3e-6 (tools/grad_err_probe.py)
         else:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
     det = _golden_model(g, det=True)
@@ -403,7 +403,7 @@ def test_model_step_vs_live_oracle(workload, n_frames, F):
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
         else:
             n_live += 1
-            assert_close(p.grad, ref, "grad " + name, 5e-4)
+            assert_close(p.grad, ref, "grad " + name)                      # REL: observed <= 1.8e-5, u_mat / v_mat of the decoder (tools/grad_err_probe.py)
     assert n_live > 50
 
 
@@ -770,7 +770,7 @@ def test_ragged_batch_model_parity():
     for name, p in model.named_parameters():
         ref = P[name].grad
         if ref is not None and float(ref.abs().max()) > 0:
-            assert_close(p.grad, ref, "grad " + name, 5e-4)
+            assert_close(p.grad, ref, "grad " + name)                      # REL: observed <= 1.8e-5, u_mat / v_mat of the decoder (tools/grad_err_probe.py)
 
 
 def test_batched_radius_graph_dataset_path():
@@ -2139,19 +2139,71 @@ def test_tile_forward_one_register_tile_per_cu_vs_fp64(shape, options):
 
 
 def test_dense_has_no_library_or_cpu_fallback():
-    """no product of the path runs on a library GEMM or on torch ops -- widths the kernels do not take and CPU
-    tensors raise (modules.py:103-114 is replaced, not shadowed)."""
-    odd = cg.Dense(30, 30, activation=cg.Swish()).to(DEV)
-    with pytest.raises(RuntimeError, match="multiples of 4"):
-        odd(torch.randn(12, 30, device=DEV))
-    with pytest.raises(RuntimeError, match="multiples of 4"):
-        cg.Dense(600, 30).to(DEV)(torch.randn(332, 600, device=DEV))
+    """no product of the path runs on a library GEMM or on a CPU branch -- CPU tensors raise (modules.py:103-114
+    is replaced, not shadowed).  Widths that are not multiples of 4 no longer raise: see the next test."""
     cpu = cg.Dense(32, 32, activation=cg.Swish())
     with pytest.raises(RuntimeError, match="HIP kernels only"):
         cpu(torch.randn(4, 32))
-    from coarsegrainingvae_amd.primitives import Linear
+    from coarsegrainingvae_amd.primitives import Linear, gemm_mode_or_none
     with pytest.raises(RuntimeError, match="HIP kernels only"):
         Linear(32, 32)(torch.randn(4, 32))
+    # the dispatch predicate never raises (it used to, and took the pair / fusion selection down with it)
+    w = torch.randn(30, 30, device=DEV)
+    assert gemm_mode_or_none(torch.randn(12, 30, device=DEV), w, None)[0] is None
+    assert gemm_mode_or_none(torch.randn(0, 32, device=DEV), torch.randn(32, 32, device=DEV), None) == (None, "Dense / Linear on an input without rows (0 x 32)")
+    assert gemm_mode_or_none(torch.randn(12, 32), torch.randn(32, 32), None)[0] is None
+
+
+@pytest.mark.parametrize("M,K,N,act", [(12, 30, 30, "swish"), (332, 600, 30, None), (96, 30, 90, "swish"), (704, 30, 62, None), (5, 7, 3, None)])
+def test_dense_pads_widths_that_are_not_multiples_of_four(M, K, N, act):
+    """The reference takes any -n_basis (run_ala.py:419-461); the kernels take widths that are multiples of 4.  Dense /
+    Linear zero-pad the others (primitives.linear_fn) and slice the result: output, input gradient, weight and bias
+    gradients against fp64 (modules.py:103-114)."""
+    torch.manual_seed(M + K + N)
+    layer = cg.Dense(K, N, activation=cg.Swish() if act else None).to(DEV)
+    layer.bias.data.normal_()
+    x = torch.randn(M, K, device=DEV, requires_grad=True)
+    gy = torch.randn(M, N, device=DEV)
+    y = layer(x)
+    assert y.shape == (M, N)
+    y.backward(gy)
+    x64 = x.detach().double().requires_grad_(True)
+    W64, b64 = layer.weight.detach().double().requires_grad_(True), layer.bias.detach().double().requires_grad_(True)
+    z64 = x64 @ W64.t() + b64
+    y64 = z64 * torch.sigmoid(z64) if act else z64
+    y64.backward(gy.double())
+    assert_close(y, y64, "y")
+    assert_close(x.grad, x64.grad, "grad x")
+    assert_close(layer.weight.grad, W64.grad, "grad W")
+    assert_close(layer.bias.grad, b64.grad, "grad b")
+
+
+def test_trainer_step_at_n_basis_30_vs_oracle():
+    """`-n_basis 30` (a width the reference accepts and the kernels do not take directly): two Trainer steps of the
+    dipeptide model -- forward, ELBO, every live gradient of the first step, norm, clip, and the outputs behind the first
+    Adam update -- against the oracle's reference-style step (cgvae.py:486-513, scripts/utils.py:117-157)."""
+    from coarsegrainingvae_amd.trainer import Trainer
+    from test_full_size_parity import OracleTraining, _check_outputs, _check_norm_and_clip, _setup
+    F = 30
+    w, batch, cpu_batch, model, hp, P = _setup("dipeptide", 4, F, enc=2, dec=2)
+    oracle = OracleTraining(cpu_batch, P, hp, w, 1e-4)
+    tr = Trainer(model, lr=1e-4, beta=w["beta"], gamma=w["gamma"])
+    gen = torch.Generator().manual_seed(3)
+    for step in (1, 2):
+        eps = torch.randn(cpu_batch["CG_nxyz"].shape[0], F, generator=gen)
+        ref = oracle.step(eps)
+        tr.step(batch, eps=eps.to(DEV))
+        _check_outputs(tr, ref, f"n_basis 30, step {step}", updates=step - 1)
+        _check_norm_and_clip(tr, ref, f"n_basis 30, step {step}")
+        if step == 1:
+            n_live = 0
+            for name, p in model.named_parameters():
+                g0 = ref["grads"].get(name)
+                if g0 is not None and float(g0.abs().max()) > 0.0:
+                    n_live += 1
+                    assert_close(p.grad, g0, "grad " + name)
+            assert n_live > 50
+    assert tr.skipped_steps() == 0
 
 
 @pytest.mark.parametrize("n_beads,F,R,layers,with_dv", [(12, 600, 10, 2, True), (3, 64, 8, 3, True), (16, 48, 10, 1, True), (12, 128, 8, 2, False)])
