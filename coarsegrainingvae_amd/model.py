@@ -187,21 +187,34 @@ class EquiEncoder(nn.Module):
         v = _constant((h.shape[0], h.shape[1], 3), 0.0, h.device)
         H = V = None
         phi_next = None                                   # node features of message block i, from a pair launch of layer i - 1
+        hooked = False                                    # layer i's bucket hook already sits on the pair that computed phi_next
         for i in range(self.n_conv):
             # h += ds, v += dv (cgvae.py:287-288) and H += dH, V += dV (cgvae.py:309-310) fused into the kernels
             h_in = h
-            if layer_hooks and i in layer_hooks and h.requires_grad:
+            if layer_hooks and i in layer_hooks and h.requires_grad and not hooked:
                 h_in = h.view_as(h)                       # private node: its gradient is the last one of layers >= i
                 h_in.register_hook(_call_then_pass(layer_hooks[i]))
+            hooked = False
             h, v = self.message_blocks[i](h_in, v, None, graph.atom_nbrs, plan=graph.atom, geom=geom, residual=True, phi=phi_next)
             phi_next = None
-            if HOST["encoder_pairs"] and not layer_hooks and i + 1 < self.n_conv and (i > 0 or HOST["fused_bead_mean"]):
-                # contractive block i and message block i + 1 read the same h: their node MLPs as pair launches
-                out = contractive_pair(self.cgmessage_layers[i], self.message_blocks[i + 1], h, v, graph.mapping, graph.a2b, geom_c,
+            if HOST["encoder_pairs"] and i + 1 < self.n_conv and (i > 0 or HOST["fused_bead_mean"]):
+                # contractive block i and message block i + 1 read the same h: their node MLPs as pair launches.
+                # Data parallel: "the state entering layer i + 1" is this h -- message block i + 1's node MLP is half of the
+                # pair -- so the bucket hook of layer i + 1 sits on the pair's input (its gradient is final when the pair's
+                # two-source backward-input product has run: layers >= i + 1 are complete)
+                h_pair = h
+                if layer_hooks and (i + 1) in layer_hooks and h.requires_grad:
+                    h_pair = h.view_as(h)
+                    h_pair.register_hook(_call_then_pass(layer_hooks[i + 1]))
+                out = contractive_pair(self.cgmessage_layers[i], self.message_blocks[i + 1], h_pair, v, graph.mapping, graph.a2b, geom_c,
                                        (H, V) if H is not None else None, mean_init=H is None)
                 if out is not None:
                     H, V, h, phi_next = out
+                    hooked = h_pair is not h_in and layer_hooks is not None and (i + 1) in layer_hooks
                     continue
+                # (no pair for these shapes: the hook just registered stays where it is -- same tensor, same meaning)
+                if h_pair is not h:
+                    h, hooked = h_pair, True
             if i == 0 and not HOST["fused_bead_mean"]:
                 H = ops.scatter_mean(h, graph.mapping, plan=graph.a2b)
                 V = ops.scatter_mean(v, graph.mapping, plan=graph.a2b)

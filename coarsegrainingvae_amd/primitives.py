@@ -1012,6 +1012,21 @@ def mark_direct_grad(*params):
             p._cgv_direct_ok = True
 
 
+class _DirectSink(torch.autograd.Function):
+    """Identity on a parameter whose gradient leaves autograd here: an arena-managed parameter's first gradient of a step
+    OVERWRITES its arena slice (which is not zeroed between steps), later ones add -- the protocol every kernel backward
+    follows (``_direct_grad``); a plain AccumulateGrad would add to last step's values."""
+
+    @staticmethod
+    def forward(ctx, param):
+        ctx.param = param
+        return param.view_as(param)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _direct_grad(ctx.param, lambda t: t.copy_(g.reshape(t.shape)), lambda: g)
+
+
 def linear_fn(x, weight, bias, act, fork=False, slot=None):
     """``_LinearFn`` for every width.  The kernels take in / out widths that are multiples of 4; the reference takes any
     ``-n_basis`` (run_ala.py:419-461), so other widths are ZERO-PADDED here -- x by columns, W by rows and columns, b by
@@ -1025,7 +1040,9 @@ def linear_fn(x, weight, bias, act, fork=False, slot=None):
         y = x.new_zeros(x.shape[:-1] + (N,))
         return (y, x) if fork else y
     pn, pk = (-N) % 4, (-K) % 4
-    y = _LinearFn.apply(Fn.pad(x, (0, pk)), Fn.pad(weight, (0, pk, 0, pn)), Fn.pad(bias, (0, pn)) if bias is not None else None, act)
+    sink = lambda p: _DirectSink.apply(p) if (p.requires_grad and torch.is_grad_enabled()) else p
+    y = _LinearFn.apply(Fn.pad(x, (0, pk)), Fn.pad(sink(weight), (0, pk, 0, pn)),
+                        Fn.pad(sink(bias), (0, pn)) if bias is not None else None, act)
     y = y[..., :N]
     return (y, x) if fork else y          # (fork: a plain alias -- autograd adds the second consumer's gradient)
 

@@ -92,12 +92,42 @@ def teardown_module(module):
                 print(f"\n[latents, element-wise, {'behind Adam updates' if upd else 'first step'}] worst {worst[3]:.3e} ({worst[0]}: {worst[1]}) over {len(rows)} checks")
 
 
-def _check_outputs(tr, ref, what, updates: int = 0):
+def _snapshot(model):
+    """The model's parameters as the NEXT forward will read them (host copies, oracle naming)."""
+    return {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+
+
+def _oracle_forward_on(snapshot, cpu_batch, hp, eps, chunk=None):
+    """The oracle's forward (cgvae.py:486-513) on a snapshot of the DEVICE model's parameters."""
+    O.EDGE_CHUNK = chunk
+    try:
+        with torch.no_grad():
+            return [o.detach() for o in O.model_forward(cpu_batch, snapshot, hp, eps=eps)]
+    finally:
+        O.EDGE_CHUNK = None
+
+
+def _check_outputs(tr, ref, what, updates: int = 0, own=None):
     """``updates``: Adam steps behind these outputs.  After an update the two sides' parameters agree only as far as
     ``_check_parameters`` says (an Adam step on a ~1e-8 gradient is +-lr whatever the gradient's last bits are), so the
-    element-wise bound on the latents' SMALL entries -- the one check here that looks two decades below a tensor's peak --
-    is held at 1e-4 for the first step (pure forward parity) and at 2e-4 afterwards; every other bound stays at 1e-4."""
-    lat_tol = REL if updates == 0 else 2 * REL
+    TRAJECTORIES drift apart in the small entries of the latents -- the one check here that looks two decades below a
+    tensor's peak: measured 1.0e-4 ... 2.1e-4 after one update (chignolin / dipeptide / 2000 atoms), the norm-wise figures
+    stay at 1e-7 ... 1e-6.  That drift says nothing about the kernels.  So behind an update the element-wise bound is
+    applied where it is exact -- against ``own``, the oracle's forward on a snapshot of the DEVICE model's own parameters
+    (same weights both sides: pure forward parity, held to 1e-4 like the first step) -- and the comparison with the
+    oracle's own trajectory keeps the norm-wise 1e-4 plus a loose element-wise 1e-3 as a sanity bound (the agreement of
+    the trajectories is what ``_check_moments`` / ``_check_parameters`` / the norm and clip checks establish)."""
+    lat_tol = REL if updates == 0 else 10 * REL
+    if own is not None:
+        for k in range(6):
+            if tr.last_out[k] is None:
+                continue
+            e = rel_err(tr.last_out[k], own[k])
+            assert e <= REL, f"{what}: {NAMES[k]} against the oracle on the device's own parameters: relative error {e:.3e}"
+            floor = 1e-2 * float(own[k].abs().max()) if k < 4 else 1e-2
+            e = elementwise_err(tr.last_out[k], own[k], floor=floor)
+            OBSERVED.append((what + " [own parameters]", NAMES[k], 0, e))
+            assert e <= REL, f"{what}: {NAMES[k]} element-wise error {e:.3e} against the oracle on the device's own parameters"
     for a, b, k in zip(tr.last_out, ref["out"], NAMES):
         e = rel_err(a, b)
         assert e <= REL, f"{what}: {k} relative error {e:.3e}"
@@ -209,8 +239,9 @@ def _full_config_vs_oracle(workload, frames, F, n_replays=2, lr=1e-4):
     # step 2, eager: single-process training now takes the rank update (bead-level gradients never written)
     eps = draw()
     ref = oracle.step(eps)
+    snap = _snapshot(model)
     tr.step(batch, eps=eps.to(DEV))
-    _check_outputs(tr, ref, "step 2", updates=1)
+    _check_outputs(tr, ref, "step 2", updates=1, own=_oracle_forward_on(snap, cpu_batch, hp, eps))
     _check_norm_and_clip(tr, ref, "step 2")
     _check_moments(tr, model, oracle, "step 2")
 
@@ -220,9 +251,10 @@ def _full_config_vs_oracle(workload, frames, F, n_replays=2, lr=1e-4):
         eps = draw()
         ref = oracle.step(eps)
         replays = tr.replays
+        snap = _snapshot(model)
         tr.step(batch, eps=eps.to(DEV))
         assert tr.replays == replays + 1                     # it really was the graph
-        _check_outputs(tr, ref, f"step {3 + k} (replay)", updates=2 + k)
+        _check_outputs(tr, ref, f"step {3 + k} (replay)", updates=2 + k, own=_oracle_forward_on(snap, cpu_batch, hp, eps))
         _check_norm_and_clip(tr, ref, f"step {3 + k} (replay)")
     n_steps = 2 + n_replays
     assert int(tr.state[ST_STEP].item()) == n_steps and tr.skipped_steps() == 0
@@ -307,14 +339,17 @@ def test_protein2000_full_width_step_vs_chunked_oracle():
             ref = oracle.step(eps)
         finally:
             O.EDGE_CHUNK = None
+        own = None
         if step == 3:
             tr.capture(batch, warmup=0, eps=eps.to(DEV))
             replays = tr.replays
+            snap = _snapshot(model)                                   # what the replay's forward reads
         tr.step(batch, eps=eps.to(DEV))
         if step == 3:
             assert tr.replays == replays + 1                          # it really was the graph
+            own = _oracle_forward_on(snap, cpu_batch, hp, eps, chunk=65536)   # (~46 s: the strict forward check, on the replay)
         what = f"protein2000 F=600 step {step}" + (" (replay)" if step == 3 else "")
-        _check_outputs(tr, ref, what, updates=step - 1)
+        _check_outputs(tr, ref, what, updates=step - 1, own=own)
         _check_norm_and_clip(tr, ref, what)
         _check_moments(tr, model, oracle, what)
     assert int(tr.state[ST_STEP].item()) == 3 and tr.skipped_steps() == 0 and tr.rank_fallbacks == 0

@@ -2183,7 +2183,7 @@ def test_trainer_step_at_n_basis_30_vs_oracle():
     dipeptide model -- forward, ELBO, every live gradient of the first step, norm, clip, and the outputs behind the first
     Adam update -- against the oracle's reference-style step (cgvae.py:486-513, scripts/utils.py:117-157)."""
     from coarsegrainingvae_amd.trainer import Trainer
-    from test_full_size_parity import OracleTraining, _check_outputs, _check_norm_and_clip, _setup
+    from test_full_size_parity import OracleTraining, _check_outputs, _check_norm_and_clip, _oracle_forward_on, _setup, _snapshot
     F = 30
     w, batch, cpu_batch, model, hp, P = _setup("dipeptide", 4, F, enc=2, dec=2)
     oracle = OracleTraining(cpu_batch, P, hp, w, 1e-4)
@@ -2192,8 +2192,9 @@ def test_trainer_step_at_n_basis_30_vs_oracle():
     for step in (1, 2):
         eps = torch.randn(cpu_batch["CG_nxyz"].shape[0], F, generator=gen)
         ref = oracle.step(eps)
+        snap = _snapshot(model)
         tr.step(batch, eps=eps.to(DEV))
-        _check_outputs(tr, ref, f"n_basis 30, step {step}", updates=step - 1)
+        _check_outputs(tr, ref, f"n_basis 30, step {step}", updates=step - 1, own=_oracle_forward_on(snap, cpu_batch, hp, eps))
         _check_norm_and_clip(tr, ref, f"n_basis 30, step {step}")
         if step == 1:
             n_live = 0

@@ -37,9 +37,9 @@ GROUPS = [
     ("decoder layer (channel-group kernels incl. the 4-column-block Dense forward, which the prior / heads share)", r"dec_|skinny_fwd_k<1, 16>"),
     ("optimizer (rank update of the bead-level layers, norm, Adam)", r"grouped_wgrad_t<true>|adam_update|sumsq_partial|optim_finalize|wgrad_gram"),
     ("atom-graph message passing (K2g / K2 / K2b + reductions)", r"equi_msg_|segment_reduce|segment_broadcast"),
-    ("atom-level Dense (tile GEMMs) and their weight gradients", r"tile_|gathered_wgrad|grouped_wgrad_t<false>"),
+    ("atom-level Dense (tile GEMMs) and their weight gradients", r"tile_|gathered_wgrad|grouped_wgrad_t<false>|wgrad_split"),
     ("per-batch graph plans + edge records", r"pj_|grp_build|gj_records|csr_|edge_geometry|copyBuffer|fillBuffer|batch_rows"),
-    ("prior / heads / loss / decoder tail / bead-level blocks", r"skinny_|elbo|reconstruct|embedding_rows|pseudo_|update_|reparam"),
+    ("prior / heads / loss / decoder tail / bead-level blocks", r"skinny_|elbo|loss_tail|reconstruct|embedding_rows|pseudo_|update_|reparam|prior_msg"),
 ]
 
 
@@ -97,7 +97,7 @@ for w in ("chignolin", "dipeptide", "protein2000"):
             else:
                 other[0] += dur; other[1] += 1
         groups = [{"group": g, "us": round(v[0], 1), "launches": v[1], "share": round(v[0] / tot, 3)} for g, v in per.items()]
-        groups.append({"group": "other (tensor-op launches)", "us": round(other[0], 1), "launches": other[1], "share": round(other[0] / tot, 3)})
+        groups.append({"group": "unclassified", "us": round(other[0], 1), "launches": other[1], "share": round(other[0] / tot, 3)})
         entry["kernel_groups"] = {"source": f"profiles/{tag}_step_sequence_{w}.txt (one replayed step incl. the per-batch graph work, rocprofv3 kernel trace)",
                                   "kernel_time_us": round(tot, 1), "groups": sorted(groups, key=lambda g: -g["us"])}
     if entry:
