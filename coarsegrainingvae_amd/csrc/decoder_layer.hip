@@ -39,8 +39,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // (__constant__: read by ONE scalar load per kernel; as a __device__ variable every tick was a vector load followed by
 // s_waitcnt vmcnt(0) -- which also drained every prefetch in flight at that point)
 __constant__ unsigned long long* g_dl_clock = nullptr;
+// Compiled OUT by default: the ticks' scalar branches alone cost the decoder backward 12 us per chignolin step (same-box
+// A/B of the two builds, tools/ab_lib.sh: 395.7 / 395.4 against 382.5 / 384.0 us).  The phase clock is measured on the
+// variant build `tools/build_variant.sh decoder_layer -DCGV_DL_CLOCK=1` (tools/phase_clock.sh).
+#ifndef CGV_DL_CLOCK
+#define CGV_DL_CLOCK 0
+#endif
 // launch spans for a layer's timeline: slots 32 + 4 id + {0, 1}: first block's begin / end, {2, 3}: last block's
 // (ids: 0 F1 dense, 1 F2 message, 2 F3 uv, 3 F4 dense, 4 F5 gate, 5 B1 gate, 6 B2 dense, 7 B3 uv, 8 B4 message, 9 B5 dense)
+#if CGV_DL_CLOCK
 #define DL_SPAN(id, end)                                                                                    \
   do {                                                                                                      \
     if (g_dl_clock && threadIdx.x == 0) {                                                                   \
@@ -51,9 +58,17 @@ __constant__ unsigned long long* g_dl_clock = nullptr;
 
 // per-phase ticks of block 0 of EVERY decoder launch: slots 80 + 10 id + i (ids as above, i < 10); buf: 192 uint64
 #define DL_PH(id, i) do { if (g_dl_clock && blockIdx.x == 0 && threadIdx.x == 0) g_dl_clock[80 + 10 * (id) + (i)] = wall_clock64(); } while (0)
+#else
+#define DL_SPAN(id, end) do { } while (0)
+#define DL_PH(id, i) do { } while (0)
+#endif
 
 // per-WAVE ticks of block 0 of the message backward (B4): slots 192 + 8 wave + i; buf: 272 uint64
+#if CGV_DL_CLOCK
 #define DL_WV(i) do { if (g_dl_clock && blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_dl_clock[192 + 8 * (threadIdx.x >> 6) + (i)] = wall_clock64(); } while (0)
+#else
+#define DL_WV(i) do { } while (0)
+#endif
 #ifndef CGV_DL_FILTER_PERM
 #define CGV_DL_FILTER_PERM 1
 #endif
@@ -1603,6 +1618,9 @@ static int cgv_decoder_column_parts(int K, bool heavy = false) {
 /* measurement: every decoder kernel stores begin / end of its first and last block into buf[32 + 4 id ..] and block 0's
  * phase boundaries into buf[80 + 10 id + i] (ids and phases in decoder_layer.hip), per-wave ticks of msg_bwd into buf[192 + 8 wave + i].  buf: 272 uint64.  NULL: off */
 int cgv_decoder_debug_clock(uint64_t* buf) {
+#if !CGV_DL_CLOCK
+  if (buf) { cgv::set_error("this build has no phase clock: rebuild csrc/decoder_layer.hip with -DCGV_DL_CLOCK=1"); return CGV_E_UNSUPPORTED; }
+#endif
   unsigned long long* p = reinterpret_cast<unsigned long long*>(buf);
   hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(cgv::g_dl_clock), &p, sizeof(p));
   return e == hipSuccess ? 0 : (int)e;

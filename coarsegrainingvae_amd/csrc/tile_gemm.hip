@@ -517,6 +517,9 @@ struct BcastAdd {
   int mean;
 };
 
+#ifndef CGV_BWD_INPUT_PIPELINE
+#define CGV_BWD_INPUT_PIPELINE 0   /* measured SLOWER (tools/gemm_shapes.py, same box): 332 x 600 x 600 8.7 against 7.3 us, 704 x 600 x 1200 23.2 / 17.2 -- two batches in registers cost the second resident block per CU, which hides the round trips better */
+#endif
 template <int MB, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void tile_bwd_input_k(const float* __restrict__ g, const float* __restrict__ W,
                                                         float* __restrict__ gx, int M, int N, int K,
@@ -566,8 +569,13 @@ __global__ __launch_bounds__(64 * WAVES) void tile_bwd_input_k(const float* __re
     zo = act ? more.z - more.g : 0;
     wcol = more.W + (kok ? kcol : 0);
   }
-  for (int st0 = wave * per; st0 < st_end; st0 += SB) {
-    float4 a[SB][MB], zz[SB][MB], b[SB][4];
+  // Software pipeline over batches of SB steps: the requests of batch i + 1 are issued BEFORE batch i is multiplied, so a
+  // wave's memory round trip hides behind its own MFMAs (each batch used to wait out its round trip with nothing of this
+  // wave in flight: 7 round trips per wave at N = 1800, 16 - 20 us against 7 us of MFMAs for 332 x 600 x 1800).  Two named
+  // buffers, loop unrolled by two; every batch is requested unconditionally (steps beyond the wave's range are clamped to
+  // valid addresses and never multiplied), so the counters the compiler waits on are the same on every path.
+  struct Batch { float4 a[SB][MB], zz[SB][MB], b[SB][4]; };
+  auto request = [&](Batch& B, int st0) __attribute__((always_inline)) {
 #pragma unroll
     for (int u = 0; u < SB; ++u) {
       const int n = 16 * (st0 + u);
@@ -577,32 +585,51 @@ __global__ __launch_bounds__(64 * WAVES) void tile_bwd_input_k(const float* __re
       const int ng = in ? n : -4 * q, nw = in ? n + 4 * q : 0;
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
-        a[u][mb] = *reinterpret_cast<const float4*>(gr[mb] + ng);
-        if (act) zz[u][mb] = *reinterpret_cast<const float4*>(gr[mb] + zo + ng);       // wave-uniform
+        B.a[u][mb] = *reinterpret_cast<const float4*>(gr[mb] + ng);
+        if (act) B.zz[u][mb] = *reinterpret_cast<const float4*>(gr[mb] + zo + ng);       // wave-uniform
       }
 #pragma unroll
-      for (int c = 0; c < 4; ++c) b[u][c] = *reinterpret_cast<const float4*>(wcol + (size_t)(nw + c) * K);
+      for (int c = 0; c < 4; ++c) B.b[u][c] = *reinterpret_cast<const float4*>(wcol + (size_t)(nw + c) * K);
     }
+  };
+  auto multiply = [&](const Batch& B, int st0) __attribute__((always_inline)) {
 #pragma unroll
     for (int u = 0; u < SB; ++u) {
       if (st0 + u >= st_end) break;                  // wave-uniform
       const bool nok = 16 * (st0 + u) + 4 * q < N;
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
-        float4 av = a[u][mb];
+        float4 av = B.a[u][mb];
         if (act) {                                   // g = gy * act'(z) (cgv_dense_grad_prepare's job, without its launch)
-          av.x *= act_bwd(zz[u][mb].x, act); av.y *= act_bwd(zz[u][mb].y, act);
-          av.z *= act_bwd(zz[u][mb].z, act); av.w *= act_bwd(zz[u][mb].w, act);
+          av.x *= act_bwd(B.zz[u][mb].x, act); av.y *= act_bwd(B.zz[u][mb].y, act);
+          av.z *= act_bwd(B.zz[u][mb].z, act); av.w *= act_bwd(B.zz[u][mb].w, act);
         }
         const float ac[4] = {nok ? av.x : 0.f, nok ? av.y : 0.f, nok ? av.z : 0.f, nok ? av.w : 0.f};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          acc[mb][0] = CGV_MFMA(ac[c], b[u][c].x, acc[mb][0]);
-          acc[mb][1] = CGV_MFMA(ac[c], b[u][c].y, acc[mb][1]);
-          acc[mb][2] = CGV_MFMA(ac[c], b[u][c].z, acc[mb][2]);
-          acc[mb][3] = CGV_MFMA(ac[c], b[u][c].w, acc[mb][3]);
+          acc[mb][0] = CGV_MFMA(ac[c], B.b[u][c].x, acc[mb][0]);
+          acc[mb][1] = CGV_MFMA(ac[c], B.b[u][c].y, acc[mb][1]);
+          acc[mb][2] = CGV_MFMA(ac[c], B.b[u][c].z, acc[mb][2]);
+          acc[mb][3] = CGV_MFMA(ac[c], B.b[u][c].w, acc[mb][3]);
         }
       }
+    }
+  };
+  if constexpr (CGV_BWD_INPUT_PIPELINE && WAVES < 16) {          // (16 waves = 1024 threads: 128 registers, no room for two batches)
+    Batch b0, b1;
+    int st0 = wave * per;
+    request(b0, st0);
+    for (; st0 < st_end; st0 += 2 * SB) {
+      request(b1, st0 + SB);
+      multiply(b0, st0);
+      request(b0, st0 + 2 * SB);
+      multiply(b1, st0 + SB);
+    }
+  } else {
+    for (int st0 = wave * per; st0 < st_end; st0 += SB) {
+      Batch b0;
+      request(b0, st0);
+      multiply(b0, st0);
     }
   }
   }
