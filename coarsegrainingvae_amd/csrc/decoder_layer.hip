@@ -267,10 +267,15 @@ __device__ __forceinline__ void bi_prefetch(BiRegs<G, NT>& r, gcf W, int K, cons
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int tile = dl_tile_of(tr, wave, t);
-    const int col = tile * 64 + 4 * j;
-    const int cc = (tile < tr.end && col < K) ? col : 0;                  // clamped: always-valid address, result unused
+    if (tile < tr.end) {                                                  // wave-uniform: a wave without a tile in this round requests nothing
+      const int col = tile * 64 + 4 * j;
+      const int cc = col < K ? col : 0;                                   // clamped: always-valid address, result unused
 #pragma unroll
-    for (int g = 0; g < G; ++g) r.w[t][g] = ldg4_stream(W + (size_t)(row0[g] + q) * K + cc);
+      for (int g = 0; g < G; ++g) r.w[t][g] = ldg4_stream(W + (size_t)(row0[g] + q) * K + cc);
+    } else {
+#pragma unroll
+      for (int g = 0; g < G; ++g) r.w[t][g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
 }
 
@@ -773,27 +778,33 @@ struct DensePair {
   float* y[DL_MULTI_MAX]; float* z[DL_MULTI_MAX];
   int act[DL_MULTI_MAX];
 };
+// CQ = column quads per block: 1 (N / 4 blocks per problem) while the launch fits the chip in one round, 2 when three or
+// four problems would need more than 256 blocks -- the product of a block is one 16-row MFMA tile either way, so the
+// 8-column block costs what the 4-column block costs and the launch takes one round instead of 2.3.
+template <int CQ>
 __global__ __launch_bounds__(DL_THREADS) void dec_dense_fwd_pair_k(DensePair p, int n, int N, int K) {
   Carve cv;
-  float* red = cv.take(fwd_red_floats<1, 1>());
-  float* o_l = cv.take(16 * 4);
+  float* red = cv.take(fwd_red_floats<1, CQ>());
+  float* o_l = cv.take(16 * CQ * 4);
   const int j = blockIdx.y;
   const float* __restrict__ x = p.x[j];
   const float* __restrict__ W = p.W[j];
   float* __restrict__ y = p.y[j];
   float* __restrict__ zout = p.z[j];
   const int act = p.act[j];
-  const int n0 = blockIdx.x * DL_CB;
-  const int row0[1] = {n0};
-  const bool mine = threadIdx.x < n * 4;
-  const int i = threadIdx.x >> 2, c = threadIdx.x & 3;
+  const int n0 = blockIdx.x * DL_CB * CQ;
+  int row0[CQ];
+#pragma unroll
+  for (int g = 0; g < CQ; ++g) row0[g] = n0 + 4 * g;
+  const bool mine = threadIdx.x < n * 4 * CQ;
+  const int i = threadIdx.x / (4 * CQ), c = threadIdx.x - i * 4 * CQ;      // column n0 + c of row i
   const gcf bias = launder(p.bias[j]);
   const float b = (mine && bias) ? ldg_pinned(bias + n0 + c) : 0.f;
   pin_loads();
-  if (K <= 16 * DL_WAVES * 5) fwd_core<1, 1, 5>(o_l, red, x, n, K, W, row0);
-  else fwd_core<1, 1, 9>(o_l, red, x, n, K, W, row0);
+  if (K <= 16 * DL_WAVES * 5) fwd_core<1, CQ, 5>(o_l, red, x, n, K, W, row0);
+  else fwd_core<1, CQ, 9>(o_l, red, x, n, K, W, row0);
   if (mine) {
-    const float zv = o_l[i * 4 + c] + b;
+    const float zv = o_l[(i * CQ + (c >> 2)) * 4 + (c & 3)] + b;
     const size_t at = (size_t)i * N + n0 + c;
     if (act) { if (zout) zout[at] = zv; y[at] = act_fwd(zv, act); } else y[at] = zv;
   }
@@ -901,7 +912,7 @@ __global__ __launch_bounds__(DL_THREADS) void dec_gate_fwd_k(const float* __rest
 // ============================================================================================== B1: gate backward + W1' rows
 // CBQ = channel quads per block (1: 4 channels, F / 4 blocks; 2: 8 channels, F / 8 blocks -- half as many, twice as fat
 // slices: a phase's slice volume is blocks x rows x K, so fatter blocks halve what the next phase reads back).
-template <int CBQ, int QS>
+template <int CBQ, int QS, int NT>
 __global__ __launch_bounds__(DL_THREADS) void dec_gate_bwd_k(
     const float* __restrict__ UV_, const float* __restrict__ a_, const float* __restrict__ gs_base_,
     const float* __restrict__ gs_slices_, int gs_n, long long gs_stride, const float* __restrict__ gv_,
@@ -944,8 +955,8 @@ __global__ __launch_bounds__(DL_THREADS) void dec_gate_bwd_k(
   }
   const TileRange tr = dl_tile_range(F);
   const bool part0 = blockIdx.y == 0;                                   // dense outputs: written once per channel group
-  BiRegs<G, 2> wr;
-  bi_prefetch<G, 2>(wr, W1p, F, row0, tr);
+  BiRegs<G, NT> wr;
+  bi_prefetch<G, NT>(wr, W1p, F, row0, tr);
   pin_loads();
   DL_PH(5, 1);
   for (int o = threadIdx.x; o < 16 * G * 4; o += DL_THREADS) g_l[o] = 0.f;
@@ -967,7 +978,7 @@ __global__ __launch_bounds__(DL_THREADS) void dec_gate_bwd_k(
   }
   __syncthreads();
   DL_PH(5, 6);
-  bi_core<1, G, 2>(wr, g_l, stage, slices_out + (size_t)blockIdx.x * out_stride, F, n, tr, nullptr, nullptr, 5);
+  bi_core<1, G, NT>(wr, g_l, stage, slices_out + (size_t)blockIdx.x * out_stride, F, n, tr, nullptr, nullptr, 5);
   DL_PH(5, 8);
   DL_SPAN(5, 1);
 }
@@ -1023,7 +1034,7 @@ __global__ __launch_bounds__(DL_THREADS) void dec_dense_bwd_k(const float* __res
 }
 
 // ============================================================================================== B3: norm backward + [Wu; Wv] rows
-template <int CBQ, int QS>
+template <int CBQ, int QS, int NT>
 __global__ __launch_bounds__(DL_THREADS) void dec_uv_bwd_k(const float* __restrict__ gstack_slices_, int gs_n, long long gs_stride,
                                                            const float* __restrict__ UV_, const float* __restrict__ stack_,
                                                            const float* __restrict__ gs_res_, const float* __restrict__ Wuv_,
@@ -1064,8 +1075,8 @@ __global__ __launch_bounds__(DL_THREADS) void dec_uv_bwd_k(const float* __restri
     nrm = ldg_pinned(stack + (size_t)i * 2 * F + F + f);
   }
   const TileRange tr = dl_tile_range(F);
-  BiRegs<G, 2> wr;
-  bi_prefetch<G, 2>(wr, Wuv, F, row0, tr);
+  BiRegs<G, NT> wr;
+  bi_prefetch<G, NT>(wr, Wuv, F, row0, tr);
   pin_loads();
   DL_PH(7, 1);
   for (int o = threadIdx.x; o < 48 * G * 4; o += DL_THREADS) g_l[o] = 0.f;
@@ -1088,7 +1099,7 @@ __global__ __launch_bounds__(DL_THREADS) void dec_uv_bwd_k(const float* __restri
   }
   __syncthreads();
   DL_PH(7, 6);
-  bi_core<3, G, 2>(wr, g_l, stage, slices_out + (size_t)blockIdx.x * out_stride, F, 3 * n, tr, nullptr, nullptr, 7);
+  bi_core<3, G, NT>(wr, g_l, stage, slices_out + (size_t)blockIdx.x * out_stride, F, 3 * n, tr, nullptr, nullptr, 7);
   DL_PH(7, 8);
   DL_SPAN(7, 1);
 }
@@ -1723,7 +1734,7 @@ int cgv_pair_linear_fwd(const float* x0, const float* x1, const float* W0, const
   CGV_REQUIRE(act0 >= 0 && act0 <= cgv::CGV_ACT_MAX && act1 >= 0 && act1 <= cgv::CGV_ACT_MAX, "unknown activation");
   CGV_REQUIRE(n_rows >= 1 && n_rows <= cgv::DL_MAX_NODES && (N % 4) == 0 && (K % 4) == 0 && N >= 4 && K >= 4, "unsupported shape");
   cgv::DensePair p{{x0, x1}, {W0, W1}, {bias0, bias1}, {y0, y1}, {z0, z1}, {act0, act1}};
-  hipLaunchKernelGGL(cgv::dec_dense_fwd_pair_k, dim3(N / cgv::DL_CB, 2), dim3(cgv::DL_THREADS),
+  hipLaunchKernelGGL(cgv::dec_dense_fwd_pair_k<1>, dim3(N / cgv::DL_CB, 2), dim3(cgv::DL_THREADS),
                      cgv::lds_bytes(cgv::fwd_red_floats<1, 1>() + 64), (hipStream_t)stream, p, n_rows, N, K);
   return cgv::check_launch("cgv_pair_linear_fwd");
 }
@@ -1740,8 +1751,12 @@ int cgv_multi_linear_fwd(int n, const float* const* x, const float* const* W, co
     CGV_REQUIRE(act[j] >= 0 && act[j] <= cgv::CGV_ACT_MAX && (act[j] == 0 || (z && z[j])), "activation needs its pre-activation buffer");
     p.x[j] = x[j]; p.W[j] = W[j]; p.bias[j] = bias ? bias[j] : nullptr; p.y[j] = y[j]; p.z[j] = z ? z[j] : nullptr; p.act[j] = act[j];
   }
-  hipLaunchKernelGGL(cgv::dec_dense_fwd_pair_k, dim3(N / cgv::DL_CB, n), dim3(cgv::DL_THREADS),
-                     cgv::lds_bytes(cgv::fwd_red_floats<1, 1>() + 64), (hipStream_t)stream, p, n_rows, N, K);
+  if ((N % 8) == 0 && (N / cgv::DL_CB) * n > 256)       /* more blocks than CUs: 8-column blocks, one round */
+    hipLaunchKernelGGL(cgv::dec_dense_fwd_pair_k<2>, dim3(N / (2 * cgv::DL_CB), n), dim3(cgv::DL_THREADS),
+                       cgv::lds_bytes(cgv::fwd_red_floats<1, 2>() + 128), (hipStream_t)stream, p, n_rows, N, K);
+  else
+    hipLaunchKernelGGL(cgv::dec_dense_fwd_pair_k<1>, dim3(N / cgv::DL_CB, n), dim3(cgv::DL_THREADS),
+                       cgv::lds_bytes(cgv::fwd_red_floats<1, 1>() + 64), (hipStream_t)stream, p, n_rows, N, K);
   return cgv::check_launch("cgv_multi_linear_fwd");
 }
 
@@ -1779,21 +1794,25 @@ int cgv_decoder_gate_bwd(const float* UV, const float* a, const float* gs_base, 
   const int n_rbf = 8;
   CGV_DL_CHECK();
   (void)blocks;
-  CGV_DL_QS(gs_n_slices, {
-    if (cgv_decoder_block_channels(n_feat) == 8)
-      hipLaunchKernelGGL((cgv::dec_gate_bwd_k<2, QS>), dim3(n_feat / 8, cgv_decoder_column_parts(n_feat)), dim3(cgv::DL_THREADS),
-                         cgv::lds_bytes(cgv::bi_stage_floats<1>() + 2 * 2304 + 2 * 64 + 384), st, UV, a, gs_base, gs_slices,
-                         gs_n_slices, (long long)gs_slice_stride, gv, W1p, ga, gUV, gs_sum, slices_out,
-                         (long long)out_slice_stride, n_nodes, n_feat);
-    else
-      hipLaunchKernelGGL((cgv::dec_gate_bwd_k<1, QS>), dim3(n_feat / 4, cgv_decoder_column_parts(n_feat)), dim3(cgv::DL_THREADS),
-                         cgv::lds_bytes(cgv::bi_stage_floats<1>() + 2304 + 64 + 192), st, UV, a, gs_base, gs_slices, gs_n_slices,
-                         (long long)gs_slice_stride, gv, W1p, ga, gUV, gs_sum, slices_out, (long long)out_slice_stride, n_nodes,
-                         n_feat);
-  });
+  const int parts = cgv_decoder_column_parts(n_feat);
+  const bool one_round = (((n_feat + 63) / 64 + parts - 1) / parts) <= cgv::DL_WAVES;     /* tiles per block <= waves */
+#define CGV_DL_GATE(NTV)                                                                                                        \
+  CGV_DL_QS(gs_n_slices, {                                                                                                      \
+    if (cgv_decoder_block_channels(n_feat) == 8)                                                                                \
+      hipLaunchKernelGGL((cgv::dec_gate_bwd_k<2, QS, NTV>), dim3(n_feat / 8, parts), dim3(cgv::DL_THREADS),                     \
+                         cgv::lds_bytes(cgv::bi_stage_floats<1>() + 2 * 2304 + 2 * 64 + 384), st, UV, a, gs_base, gs_slices,   \
+                         gs_n_slices, (long long)gs_slice_stride, gv, W1p, ga, gUV, gs_sum, slices_out,                        \
+                         (long long)out_slice_stride, n_nodes, n_feat);                                                        \
+    else                                                                                                                        \
+      hipLaunchKernelGGL((cgv::dec_gate_bwd_k<1, QS, NTV>), dim3(n_feat / 4, parts), dim3(cgv::DL_THREADS),                     \
+                         cgv::lds_bytes(cgv::bi_stage_floats<1>() + 2304 + 64 + 192), st, UV, a, gs_base, gs_slices, gs_n_slices, \
+                         (long long)gs_slice_stride, gv, W1p, ga, gUV, gs_sum, slices_out, (long long)out_slice_stride, n_nodes, \
+                         n_feat);                                                                                               \
+  })
+  if (one_round) { CGV_DL_GATE(1); } else { CGV_DL_GATE(2); }
+#undef CGV_DL_GATE
   return cgv::check_launch("cgv_decoder_gate_bwd");
 }
-
 int cgv_decoder_dense_bwd(const float* g_slices, int g_n_slices, int64_t g_slice_stride, const float* z, int act, const float* W,
                           float* g_dense, float* slices_out, int64_t out_slice_stride, int n_nodes, int N, int K, void* stream) {
   CGV_REQUIRE(g_slices && W && g_dense && slices_out && g_n_slices >= 1 && g_n_slices <= 216, "null pointer / slice count");
@@ -1833,21 +1852,25 @@ int cgv_decoder_uv_bwd(const float* gstack_slices, int n_slices, int64_t slice_s
   const int n_rbf = 8;
   CGV_DL_CHECK();
   (void)blocks;
-  CGV_DL_QS(n_slices, {
-    if (cgv_decoder_block_channels(n_feat) == 8) {
-      const size_t lds = cgv::lds_bytes(cgv::bi_stage_floats<3>() + 2 * 4608 + 2 * 128 + 2 * 384);
-      if (int rc = cgv::allow_lds(cgv::dec_uv_bwd_k<2, QS>, lds)) return rc;
-      hipLaunchKernelGGL((cgv::dec_uv_bwd_k<2, QS>), dim3(n_feat / 8, parts), dim3(cgv::DL_THREADS), lds, st, gstack_slices, n_slices,
-                         (long long)slice_stride, UV, stack, gs_res, Wuv, gUV, gUV_out, g_s2, slices_out, (long long)out_slice_stride,
-                         n_nodes, n_feat);
-    } else {
-      const size_t lds = cgv::lds_bytes(cgv::bi_stage_floats<3>() + 4608 + 128 + 384);
-      if (int rc = cgv::allow_lds(cgv::dec_uv_bwd_k<1, QS>, lds)) return rc;
-      hipLaunchKernelGGL((cgv::dec_uv_bwd_k<1, QS>), dim3(n_feat / 4, parts), dim3(cgv::DL_THREADS), lds, st, gstack_slices, n_slices,
-                         (long long)slice_stride, UV, stack, gs_res, Wuv, gUV, gUV_out, g_s2, slices_out, (long long)out_slice_stride,
-                         n_nodes, n_feat);
-    }
-  });
+  const bool one_round = (((n_feat + 63) / 64 + parts - 1) / parts) <= cgv::DL_WAVES;     /* tiles per block <= waves */
+#define CGV_DL_UV(NTV)                                                                                                          \
+  CGV_DL_QS(n_slices, {                                                                                                         \
+    if (cgv_decoder_block_channels(n_feat) == 8) {                                                                              \
+      const size_t lds = cgv::lds_bytes(cgv::bi_stage_floats<3>() + 2 * 4608 + 2 * 128 + 2 * 384);                              \
+      if (int rc = cgv::allow_lds(cgv::dec_uv_bwd_k<2, QS, NTV>, lds)) return rc;                                               \
+      hipLaunchKernelGGL((cgv::dec_uv_bwd_k<2, QS, NTV>), dim3(n_feat / 8, parts), dim3(cgv::DL_THREADS), lds, st, gstack_slices, \
+                         n_slices, (long long)slice_stride, UV, stack, gs_res, Wuv, gUV, gUV_out, g_s2, slices_out,             \
+                         (long long)out_slice_stride, n_nodes, n_feat);                                                        \
+    } else {                                                                                                                    \
+      const size_t lds = cgv::lds_bytes(cgv::bi_stage_floats<3>() + 4608 + 128 + 384);                                          \
+      if (int rc = cgv::allow_lds(cgv::dec_uv_bwd_k<1, QS, NTV>, lds)) return rc;                                               \
+      hipLaunchKernelGGL((cgv::dec_uv_bwd_k<1, QS, NTV>), dim3(n_feat / 4, parts), dim3(cgv::DL_THREADS), lds, st, gstack_slices, \
+                         n_slices, (long long)slice_stride, UV, stack, gs_res, Wuv, gUV, gUV_out, g_s2, slices_out,             \
+                         (long long)out_slice_stride, n_nodes, n_feat);                                                        \
+    }                                                                                                                           \
+  })
+  if (one_round) { CGV_DL_UV(1); } else { CGV_DL_UV(2); }
+#undef CGV_DL_UV
   return cgv::check_launch("cgv_decoder_uv_bwd");
 }
 
