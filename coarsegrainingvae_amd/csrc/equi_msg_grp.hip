@@ -23,6 +23,22 @@
 
 namespace cgv {
 
+// Wave timeline of a few blocks (measurement only, compiled in with -DCGV_K2G_CLOCK=1; tools/k2g_clock_probe.py): slots
+// [(sample * SPLIT + wave) * 8 + i], sample = one of 8 blocks spread over the grid; i: 0 entry, 1 first records + rows
+// requested, 2 filter tile staged + rows in registers, 3 edge loop done, 4 partials exchanged, 5 stores issued, 6 edges walked
+#ifndef CGV_K2G_CLOCK
+#define CGV_K2G_CLOCK 0
+#endif
+#if CGV_K2G_CLOCK
+__constant__ unsigned long long* g_k2g_clock = nullptr;
+#define K2G_TICK(i, val)                                                                                      \
+  do {                                                                                                        \
+    if (g_k2g_clock && (threadIdx.x & 63) == 0 && (blockIdx.x % (gridDim.x / 8)) == 3 && blockIdx.x / (gridDim.x / 8) < 8) \
+      g_k2g_clock[((blockIdx.x / (gridDim.x / 8)) * SPLIT + (threadIdx.x >> 6)) * 8 + (i)] = (val);             \
+  } while (0)
+#else
+#define K2G_TICK(i, val) do { } while (0)
+#endif
 struct RowBuf { f2 p0, p1, p2, A, B, C; };
 struct Acc { f2 s, A, B, C; };
 
@@ -73,6 +89,7 @@ __global__ __launch_bounds__(64 * SPLIT) void equi_msg_fwd_grp_k(
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform -> record loads stay scalar
   const ChanPair cp = chan_pair(tile, lane, F);
+  K2G_TICK(0, wall_clock64());
 
   int beg = rowptr[node0], end = rowptr[node1];
   {
@@ -80,6 +97,7 @@ __global__ __launch_bounds__(64 * SPLIT) void equi_msg_fwd_grp_k(
     beg = min(beg + wave * len, end);
     end = min(beg + len, end);
   }
+  K2G_TICK(6, (unsigned long long)(end - beg));
   const unsigned row_bytes = 12u * (unsigned)F;              // bytes per node row of phi [3F] AND of v [F,3]
   const unsigned oc = 4u * (unsigned)cp.c, oF = 4u * (unsigned)F, ov = 12u * (unsigned)cp.c;
   const rsrc_t r_phi = make_rsrc(phi), r_v = make_rsrc(v);
@@ -104,6 +122,7 @@ __global__ __launch_bounds__(64 * SPLIT) void equi_msg_fwd_grp_k(
     for (int t = 0; t < NG; ++t) g1[t] = geom[(size_t)min(beg + 1, last) * GS + t];
     gather_row(bufA, r_phi, r_v, oc, oF, ov, (unsigned)src_g[beg] * row_bytes);
   }
+  K2G_TICK(1, wall_clock64());
 
   f2 W0[R + 1], W1[R + 1], W2[R + 1];
   {
@@ -114,6 +133,7 @@ __global__ __launch_bounds__(64 * SPLIT) void equi_msg_fwd_grp_k(
     read_filter_rows2<R>(W1, smem + 128 * R, bd, cl, F + cp.c);
     read_filter_rows2<R>(W2, smem + 2 * 128 * R, bd, cl, 2 * F + cp.c);
   }
+  K2G_TICK(2, wall_clock64());
 
   Acc acc[RB];
 #pragma unroll
@@ -160,6 +180,7 @@ __global__ __launch_bounds__(64 * SPLIT) void equi_msg_fwd_grp_k(
   }
 
   // every wave deposits its partial sums; wave w then finishes receivers w, w + SPLIT, ... in a fixed order
+  K2G_TICK(3, wall_clock64());
   __syncthreads();                                   // all filter reads of the shared buffer are done
 #pragma unroll
   for (int k = 0; k < RB; ++k) {
@@ -168,6 +189,7 @@ __global__ __launch_bounds__(64 * SPLIT) void equi_msg_fwd_grp_k(
     r[256] = acc[k].B.x; r[320] = acc[k].B.y; r[384] = acc[k].C.x; r[448] = acc[k].C.y;
   }
   __syncthreads();
+  K2G_TICK(4, wall_clock64());
   for (int k = wave; k < node1 - node0; k += SPLIT) {
     f2 s = splat(0.f), A = splat(0.f), B = splat(0.f), C = splat(0.f);
 #pragma unroll
@@ -187,6 +209,7 @@ __global__ __launch_bounds__(64 * SPLIT) void equi_msg_fwd_grp_k(
       stvec<true>(dv + (size_t)node * F * 3, cp, A, B, C);
     }
   }
+  K2G_TICK(5, wall_clock64());
 }
 
 // ------------------------------------------------------------------ records through LDS
@@ -417,3 +440,12 @@ int cgv_equi_msg_fwd_grouped(const float* phi, const float* v, const float* geom
 }
 
 }  // extern "C"
+
+#if CGV_K2G_CLOCK
+/* measurement builds only (tools/build_variant.sh equi_msg_grp -DCGV_K2G_CLOCK=1): wave timeline buffer, 8 x 4 x 8 uint64 */
+extern "C" int cgv_k2g_debug_clock(uint64_t* buf) {
+  unsigned long long* p = reinterpret_cast<unsigned long long*>(buf);
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(cgv::g_k2g_clock), &p, sizeof(p));
+  return e == hipSuccess ? 0 : (int)e;
+}
+#endif

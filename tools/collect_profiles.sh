@@ -16,7 +16,7 @@ for w in chignolin dipeptide protein2000; do
   bash tools/step_sequence.sh --workload $w --no-extras --no-parity > /dev/null 2>&1
   cp gpurun_out/step_sequence.txt gpurun_out/${tag}_step_sequence_$w.txt
 done
-python tools/dec_phase_probe.py > gpurun_out/${tag}_decoder_phase_clock.txt 2>&1
+bash tools/phase_clock.sh > gpurun_out/${tag}_decoder_phase_clock.txt 2>&1   # (needs libcgvae_hip_b.so = tools/build_variant.sh decoder_layer "-DCGV_DL_CLOCK=1")
 # PMC: counters in their own runs (eager launches so that kernels appear as dispatches), every workload
 for w in chignolin dipeptide protein2000; do
   for c in FETCH_SIZE WRITE_SIZE; do
