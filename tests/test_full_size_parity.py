@@ -327,32 +327,27 @@ def test_protein2000_full_width_step_vs_chunked_oracle():
     assert n_live > 100
     _check_norm_and_clip(tr, ref, "protein2000 F=600")
     _check_moments(tr, model, oracle, "protein2000 F=600")
-    # step 2, eager, and step 3, the captured hipGraph: the DEFAULT dispatch of every later step at this size -- gradients
-    # written straight into the arena, wgrad_split128_k on the 2000-row operands, strip launches for the 64 bead rows, the
-    # flat norm + Adam over all live parameters -- against the oracle's next two steps (same chunked message blocks)
-    gen = torch.Generator().manual_seed(10)
-    P0 = None
-    for step in (2, 3):
-        eps = torch.randn(cpu_batch["CG_nxyz"].shape[0], F, generator=gen)
-        O.EDGE_CHUNK = 65536
-        try:
-            ref = oracle.step(eps)
-        finally:
-            O.EDGE_CHUNK = None
-        own = None
-        if step == 3:
-            tr.capture(batch, warmup=0, eps=eps.to(DEV))
-            replays = tr.replays
-            snap = _snapshot(model)                                   # what the replay's forward reads
-        tr.step(batch, eps=eps.to(DEV))
-        if step == 3:
-            assert tr.replays == replays + 1                          # it really was the graph
-            own = _oracle_forward_on(snap, cpu_batch, hp, eps, chunk=65536)   # (~46 s: the strict forward check, on the replay)
-        what = f"protein2000 F=600 step {step}" + (" (replay)" if step == 3 else "")
-        _check_outputs(tr, ref, what, updates=step - 1, own=own)
-        _check_norm_and_clip(tr, ref, what)
-        _check_moments(tr, model, oracle, what)
-    assert int(tr.state[ST_STEP].item()) == 3 and tr.skipped_steps() == 0 and tr.rank_fallbacks == 0
+    # step 2 as ONE captured replay: the DEFAULT dispatch of every later step at this size -- gradients written straight into
+    # the arena, wgrad_split128_k on the 2000-row operands, strip launches for the 64 bead rows, the flat norm + Adam over all
+    # live parameters -- and the hipGraph, against the oracle's next step (same chunked message blocks; ~100 s) and, for the
+    # forward, against the oracle on the device model's own parameters (~46 s)
+    eps = torch.randn(cpu_batch["CG_nxyz"].shape[0], F, generator=torch.Generator().manual_seed(10))
+    O.EDGE_CHUNK = 65536
+    try:
+        ref = oracle.step(eps)
+    finally:
+        O.EDGE_CHUNK = None
+    tr.capture(batch, warmup=0, eps=eps.to(DEV))
+    replays = tr.replays
+    snap = _snapshot(model)                                           # what the replay's forward reads
+    tr.step(batch, eps=eps.to(DEV))
+    assert tr.replays == replays + 1                                  # it really was the graph
+    own = _oracle_forward_on(snap, cpu_batch, hp, eps, chunk=65536)
+    what = "protein2000 F=600 step 2 (replay)"
+    _check_outputs(tr, ref, what, updates=1, own=own)
+    _check_norm_and_clip(tr, ref, what)
+    _check_moments(tr, model, oracle, what)
+    assert int(tr.state[ST_STEP].item()) == 2 and tr.skipped_steps() == 0 and tr.rank_fallbacks == 0
 
 
 def test_protein2000_reduced_width_vs_oracle():
@@ -382,16 +377,25 @@ def test_protein2000_reduced_width_vs_oracle():
     _check_norm_and_clip(tr, ref, "protein2000")
 
 
-@pytest.mark.parametrize("workload,frames,F,dec,fat", [("chignolin", 2, 600, 3, 1), ("dipeptide", 4, 64, 2, 1),
-                                                        ("chignolin", 1, 48, 2, 1), ("chignolin", 2, 600, 2, 0)])
-def test_fused_decoder_loop_equals_per_block_path(workload, frames, F, dec, fat, options):
+@pytest.mark.parametrize("workload,frames,F,dec,fat,colsplit,nodesplit",
+                         [("chignolin", 2, 600, 3, 1, 2, 1), ("dipeptide", 4, 64, 2, 1, 2, 1), ("chignolin", 1, 48, 2, 1, 2, 1),
+                          ("chignolin", 2, 600, 2, 0, 2, 1),
+                          # round 5's grids one by one: one block per channel group (the round-4 kernels), two, three
+                          # everywhere; uv_fwd over all rows in 4-channel blocks; an odd tile count (F = 200: 4 tiles over 3 parts)
+                          ("chignolin", 2, 600, 2, 1, 0, 0), ("chignolin", 2, 600, 2, 1, 1, 1), ("chignolin", 2, 600, 2, 1, 3, 0),
+                          ("chignolin", 2, 200, 2, 1, 3, 1), ("chignolin", 2, 200, 2, 0, 2, 1)])
+def test_fused_decoder_loop_equals_per_block_path(workload, frames, F, dec, fat, colsplit, nodesplit, options):
     """decoder_fused (one autograd node for the decoder loop, slice-sum backward) against the per-block path it
     replaces (blocks.py: one node per block, reduction launches, autograd's accumulation adds): every gradient of the
     second step (all materialised), the loss, and the parameters after three steps.  fat: 8-channel blocks in the
     non-message backward phases (the default; every width the arena lays out adjacent u_mat / v_mat for is a multiple
-    of 8) or 4-channel blocks everywhere."""
+    of 8) or 4-channel blocks everywhere.  colsplit / nodesplit: the grids of round 5 (column tiles of a channel group on
+    1 / 2 / 3 blocks, ``uv_fwd`` by node groups) -- every combination computes the same sums in the same order per element
+    except the message backward's filter-gradient butterflies, so all of them must agree with the per-block path alike."""
     options.set("decoder_fat", fat)
     options.set("decoder_wlds", fat)                               # the register-path message product rides with fat = 0
+    options.set("decoder_colsplit", colsplit)
+    options.set("decoder_nodesplit", nodesplit)
     w = cg.data.WORKLOADS[workload]
     batch = cg.synthetic_batch(workload, n_frames=frames, seed=2, device=DEV)
     eps = [torch.randn(batch["CG_nxyz"].shape[0], F, generator=torch.Generator().manual_seed(k)).to(DEV) for k in range(3)]
