@@ -114,6 +114,9 @@ PROTOTYPES = {
     "cgv_prior_msg_bwd": (_i, [_p] * 8 + [_i, C.c_int64] + [_p] * 6 + [C.c_int64, _i, _i, _i, _i, _p]),
     "cgv_decoder_uv_fwd": (_i, [_p, _p, _p, _p, _i, _i, _p]),
     "cgv_decoder_gate_fwd": (_i, [_p] * 9 + [_i, _i, _p]),
+    "cgv_update_rows_fused_supported": (_i, [_i, _i]),
+    "cgv_update_uv_norm_fwd_fused": (_i, [_p] * 5 + [_i, _i, _p]),
+    "cgv_update_gate_fwd_fused": (_i, [_p] * 9 + [_i, _i, _p]),
     "cgv_decoder_gate_bwd": (_i, [_p, _p, _p, _p, _i, C.c_int64, _p, _p, _p, _p, _p, _p, C.c_int64, _i, _i, _p]),
     "cgv_decoder_dense_bwd": (_i, [_p, _i, C.c_int64, _p, _i, _p, _p, _p, C.c_int64, _i, _i, _i, _p]),
     "cgv_decoder_uv_bwd": (_i, [_p, _i, C.c_int64, _p, _p, _p, _p, _p, _p, _p, _p, C.c_int64, _i, _i, _p]),

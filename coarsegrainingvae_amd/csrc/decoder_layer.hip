@@ -909,6 +909,73 @@ __global__ __launch_bounds__(DL_THREADS) void dec_gate_fwd_k(const float* __rest
   DL_SPAN(4, 1);
 }
 
+// ============================================================================================== UpdateBlock forward for 17 .. 96 bead rows
+// The two epilogues above for bead graphs BEYOND the channel-group decoder's 16 nodes (dipeptide 96 beads, the 2000-atom
+// graph 64): the per-block path ran the product (tile / skinny kernel), then an element-wise launch (update_gate_fwd,
+// update_norm_stack_fwd: 4.6 - 4.9 us each, a boundary and two round trips for a pass over n x 600 values).  The gate and
+// the norm are local in the channel (gate: and in the row; norm: in the node), so the same channel-group blocks compute
+// them in the product's epilogue at any row count: MB row blocks of 16 (reference: conv.py:593-616).
+// (Forward only: the backward of the per-block path exchanges dense tensors, not slices.)
+// MEASURED SLOWER than what it replaces and therefore off by default (options.HOST["update_fused_fwd"]): dipeptide 2.645 /
+// 2.675 against 2.636 / 2.637 ms per step, the 2000-atom graph 5.996 against 5.968 -- a 96-row channel-group block is
+// ~900 fp32 MFMAs on ONE CU (3.7 us on its busiest SIMD), the tile kernels spread the same product over the whole chip and
+// the element-wise launch behind them costs less than that difference.  Kept for the A/B and its parity tests.
+template <int MB>
+__global__ __launch_bounds__(DL_THREADS) void upd_gate_fwd_rows_k(const float* __restrict__ a0, const float* __restrict__ W1p,
+                                                                  const float* __restrict__ b1p, const float* __restrict__ UV,
+                                                                  const float* __restrict__ s_res, const float* __restrict__ v_res,
+                                                                  float* __restrict__ a_out, float* __restrict__ s_out,
+                                                                  float* __restrict__ v_out, int n, int F) {
+  Carve cv;
+  float* red = cv.take(fwd_red_floats<MB, 3>());
+  float* a_l = cv.take(16 * MB * 3 * 4);
+  const int f0 = blockIdx.x * DL_CB;
+  const int row0[3] = {f0, F + f0, 2 * F + f0};
+  fwd_core<MB, 3, (MB == 1 ? 5 : 2)>(a_l, red, a0, n, F, W1p, row0);
+  for (int o = threadIdx.x; o < n * 4; o += DL_THREADS) {
+    const int i = o >> 2, c = o & 3, f = f0 + c;
+    const float a_vv = a_l[(i * 3 + 0) * 4 + c] + b1p[f], a_sv = a_l[(i * 3 + 1) * 4 + c] + b1p[F + f],
+                a_ss = a_l[(i * 3 + 2) * 4 + c] + b1p[2 * F + f];
+    float* ao = a_out + (size_t)i * 3 * F + f;
+    ao[0] = a_vv; ao[F] = a_sv; ao[2 * F] = a_ss;
+    const size_t b = (size_t)i * 3 * 2 * F + f, nf = (size_t)i * F + f;
+    const float ux = UV[b], uy = UV[b + 2 * F], uz = UV[b + 4 * F];
+    const float vx = UV[b + F], vy = UV[b + 3 * F], vz = UV[b + 5 * F];
+    f3 r{0.f, 0.f, 0.f};
+    if (v_res) r = ld3(v_res + nf * 3);
+    st3(v_out + nf * 3, ux * a_vv + r.x, uy * a_vv + r.y, uz * a_vv + r.z);                // conv.py:607 (+ cgvae.py:123)
+    s_out[nf] = ((ux * vx + uy * vy + uz * vz) * a_sv + a_ss) + (s_res ? s_res[nf] : 0.f);  // conv.py:612-614 (+ cgvae.py:122)
+  }
+}
+
+// [U | Vv] = rows [u_mat; v_mat]^T for the block's 8 channels and its node group (npp nodes: 3 npp <= 16 MB rows), the norm
+// of Vv and -- the update block's stack is [s | norm] (conv.py:601) -- the copy of s into the stack's first half.
+template <int MB>
+__global__ __launch_bounds__(DL_THREADS) void upd_uv_norm_fwd_rows_k(const float* __restrict__ rows, const float* __restrict__ Wuv,
+                                                                     const float* __restrict__ s_in, float* __restrict__ UV,
+                                                                     float* __restrict__ stack, int n, int F, int npp) {
+  Carve cv;
+  float* red = cv.take(fwd_red_floats<MB, 4>());
+  float* uv_l = cv.take(16 * MB * 4 * 4);
+  const int f0 = blockIdx.x * 8;
+  const int row0[4] = {f0, f0 + 4, F + f0, F + f0 + 4};
+  const int i0 = blockIdx.y * npp, ni = min(npp, n - i0);
+  const float* x = rows + (size_t)3 * i0 * F;
+  fwd_core<MB, 4, (MB == 1 ? 5 : 2)>(uv_l, red, x, 3 * ni, F, Wuv, row0);
+  for (int o = threadIdx.x; o < 3 * ni * 4; o += DL_THREADS) {
+    const int m = o >> 2, g = o & 3;
+    *reinterpret_cast<float4*>(UV + (size_t)(3 * i0 + m) * 2 * F + (size_t)(g >> 1) * F + f0 + 4 * (g & 1)) =
+        *reinterpret_cast<const float4*>(uv_l + (m * 4 + g) * 4);
+  }
+  for (int o = threadIdx.x; o < ni * 8; o += DL_THREADS) {
+    const int il = o >> 3, c = o & 7, g = 2 + (c >> 2), c4 = c & 3;
+    const float x_ = uv_l[((3 * il + 0) * 4 + g) * 4 + c4], y_ = uv_l[((3 * il + 1) * 4 + g) * 4 + c4], z_ = uv_l[((3 * il + 2) * 4 + g) * 4 + c4];
+    float* st = stack + (size_t)(i0 + il) * 2 * F;
+    st[F + f0 + c] = sqrtf(((x_ * x_ + 1e-10f) + (y_ * y_ + 1e-10f)) + (z_ * z_ + 1e-10f));       // conv.py:600
+    if (s_in) st[f0 + c] = s_in[(size_t)(i0 + il) * F + f0 + c];
+  }
+}
+
 // ============================================================================================== B1: gate backward + W1' rows
 // CBQ = channel quads per block (1: 4 channels, F / 4 blocks; 2: 8 channels, F / 8 blocks -- half as many, twice as fat
 // slices: a phase's slice volume is blocks x rows x K, so fatter blocks halve what the next phase reads back).
@@ -1784,6 +1851,51 @@ int cgv_decoder_gate_fwd(const float* a0, const float* W1p, const float* b1p, co
   hipLaunchKernelGGL(cgv::dec_gate_fwd_k, dim3(blocks), dim3(cgv::DL_THREADS), cgv::lds_bytes(cgv::fwd_red_floats<1, 3>() + 192), st, a0,
                      W1p, b1p, UV, stack, v2, a, s3, v3, n_nodes, n_feat);
   return cgv::check_launch("cgv_decoder_gate_fwd");
+}
+
+int cgv_update_rows_fused_supported(int n_rows, int n_feat) {
+  return n_rows >= 1 && n_rows <= 96 && n_feat >= 16 && (n_feat % 8) == 0 && n_feat <= 864;
+}
+
+int cgv_update_gate_fwd_fused(const float* a0, const float* W1, const float* b1, const float* UV, const float* s_res,
+                              const float* v_res, float* a, float* s_out, float* v_out, int n_rows, int n_feat, void* stream) {
+  CGV_REQUIRE(a0 && W1 && b1 && UV && a && s_out && v_out, "null pointer");
+  CGV_REQUIRE(cgv_update_rows_fused_supported(n_rows, n_feat), "unsupported shape (1..96 rows, F % 8 == 0, 16 <= F <= 864)");
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(n_feat / cgv::DL_CB);
+#define CGV_UG(MBV)                                                                                                           \
+  {                                                                                                                          \
+    const size_t lds = cgv::lds_bytes(cgv::fwd_red_floats<MBV, 3>() + 16 * MBV * 12);                                         \
+    if (int rc = cgv::allow_lds(cgv::upd_gate_fwd_rows_k<MBV>, lds)) return rc;                                               \
+    hipLaunchKernelGGL((cgv::upd_gate_fwd_rows_k<MBV>), grid, dim3(cgv::DL_THREADS), lds, st, a0, W1, b1, UV, s_res, v_res, a, \
+                       s_out, v_out, n_rows, n_feat);                                                                        \
+  }
+  switch ((n_rows + 15) / 16) {
+    case 1: CGV_UG(1) break; case 2: CGV_UG(2) break; case 3: CGV_UG(3) break;
+    case 4: CGV_UG(4) break; case 5: CGV_UG(5) break; default: CGV_UG(6) break;
+  }
+#undef CGV_UG
+  return cgv::check_launch("cgv_update_gate_fwd_fused");
+}
+
+int cgv_update_uv_norm_fwd_fused(const float* rows, const float* Wuv, const float* s, float* UV, float* stack, int n_nodes,
+                                 int n_feat, void* stream) {
+  CGV_REQUIRE(rows && Wuv && UV && stack, "null pointer");
+  CGV_REQUIRE(cgv_update_rows_fused_supported(n_nodes, n_feat), "unsupported shape (1..96 nodes, F % 8 == 0, 16 <= F <= 864)");
+  hipStream_t st = (hipStream_t)stream;
+  /* node groups of at most 16 nodes (48 rows = three row blocks), as equal as possible */
+  const int parts = (n_nodes + 15) / 16, npp = (n_nodes + parts - 1) / parts, mb = (3 * npp + 15) / 16;
+  const dim3 grid(n_feat / 8, (n_nodes + npp - 1) / npp);
+#define CGV_UU(MBV)                                                                                                           \
+  {                                                                                                                          \
+    const size_t lds = cgv::lds_bytes(cgv::fwd_red_floats<MBV, 4>() + 16 * MBV * 16);                                         \
+    if (int rc = cgv::allow_lds(cgv::upd_uv_norm_fwd_rows_k<MBV>, lds)) return rc;                                            \
+    hipLaunchKernelGGL((cgv::upd_uv_norm_fwd_rows_k<MBV>), grid, dim3(cgv::DL_THREADS), lds, st, rows, Wuv, s, UV, stack,     \
+                       n_nodes, n_feat, npp);                                                                                \
+  }
+  switch (mb) { case 1: CGV_UU(1) break; case 2: CGV_UU(2) break; default: CGV_UU(3) break; }
+#undef CGV_UU
+  return cgv::check_launch("cgv_update_uv_norm_fwd_fused");
 }
 
 int cgv_decoder_gate_bwd(const float* UV, const float* a, const float* gs_base, const float* gs_slices, int gs_n_slices,

@@ -699,13 +699,25 @@ class _UpdateBlockFused(torch.autograd.Function):
         if vt is None or vt.shape != (3 * n, F) or vt.device != dev or not vt.is_contiguous():
             vt = new(3 * n, F)
             _lib.call("cgv_update_rows_from_vec", _lib.ptr(v), _lib.ptr(vt), n, F, st)
-        _dense_fwd(vt, Wuv, None, UV, None, 3 * n, 2 * F, F, 0, st)
+        from .options import HOST
+        # 17 .. 96 bead rows: the norm and the gate in the epilogues of channel-group products (3 launches for 5)
+        fused = (HOST["update_fused_fwd"] and n > 16 and _lib.load().cgv_update_rows_fused_supported(n, F)
+                 and b1 is not None and all(t.data_ptr() % 16 == 0 for t in (vt, Wuv, a0, W1, UV, stack)))
         U_ptr, Vv_ptr = UV.data_ptr(), UV.data_ptr() + 4 * F
-        _lib.call("cgv_update_norm_stack_fwd", _lib.ptr(s), Vv_ptr, _lib.ptr(stack), n, F, 2 * F, st)
+        if fused:
+            _lib.call("cgv_update_uv_norm_fwd_fused", _lib.ptr(vt), _lib.ptr(Wuv), _lib.ptr(s), _lib.ptr(UV), _lib.ptr(stack), n, F, st)
+        else:
+            _dense_fwd(vt, Wuv, None, UV, None, 3 * n, 2 * F, F, 0, st)
+            _lib.call("cgv_update_norm_stack_fwd", _lib.ptr(s), Vv_ptr, _lib.ptr(stack), n, F, 2 * F, st)
         _dense_fwd(stack, W0, b0, a0, z0, n, F, 2 * F, 1, st)
-        _dense_fwd(a0, W1, b1, a, None, n, 3 * F, F, 0, st)
-        _lib.call("cgv_update_gate_fwd", U_ptr, Vv_ptr, _lib.ptr(a), _lib.ptr(s) if residual else None,
-                  _lib.ptr(v) if residual else None, _lib.ptr(ds), _lib.ptr(dv), n, F, 2 * F, st)
+        if fused:
+            _lib.call("cgv_update_gate_fwd_fused", _lib.ptr(a0), _lib.ptr(W1), _lib.ptr(b1), _lib.ptr(UV),
+                      _lib.ptr(s) if residual else None, _lib.ptr(v) if residual else None, _lib.ptr(a), _lib.ptr(ds), _lib.ptr(dv),
+                      n, F, st)
+        else:
+            _dense_fwd(a0, W1, b1, a, None, n, 3 * F, F, 0, st)
+            _lib.call("cgv_update_gate_fwd", U_ptr, Vv_ptr, _lib.ptr(a), _lib.ptr(s) if residual else None,
+                      _lib.ptr(v) if residual else None, _lib.ptr(ds), _lib.ptr(dv), n, F, 2 * F, st)
         ctx.save_for_backward(vt, UV, stack, z0, a0, a, W0, W1)
         ctx.params = (u_w, v_w, W0, b0, W1, b1)
         ctx.residual = bool(residual)

@@ -25,6 +25,7 @@ HOST = {
     "wgrad_split": 1,       # weight gradients of layers with > 128 operand rows: 1 bf16 matrix path with split operands (3 bf16 terms per fp32 value, 6 products, fp32 accumulation: fp32-class accuracy), 0 fp32 MFMA tiles
     "fused_bead_mean": 1,   # EquiEncoder layer 0: 1 H, V = scatter_mean(h), scatter_mean(v) from one launch inside the contractive block, gradient through its first Dense's epilogue; 0 two launches + broadcast + add
     "fused_prior": 1,       # CGprior: 1 the message-block loop of a small bead graph on the channel-group kernels (prior_fused.py), 0 per-block path
+    "update_fused_fwd": 0,  # UpdateBlock forward on 17..96 bead rows: 0 (default) product + element-wise launch each (5 launches), 1 norm / gate in the epilogues of channel-group products (cgv_update_*_fwd_fused: 3 launches) -- measured SLOWER: dipeptide 2.645 / 2.675 against 2.636 / 2.637 ms, 2000 atoms 5.996 / 5.968 (a 96-row channel-group block is 900 fp32 MFMAs on one CU; the tile kernels spread the same product over the chip)
     "decoder_dense": 0,     # full-width products of the fused decoder loop: 0 four-column blocks (cgv_decoder_dense_fwd), 1 skinny_fwd_k
 }
 _DEFAULTS = dict(HOST)

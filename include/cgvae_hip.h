@@ -419,6 +419,17 @@ int cgv_decoder_dense_fwd(const float* x, const float* W /*[N,K]*/, const float*
 int cgv_decoder_uv_fwd(const float* rows, const float* Wuv, float* UV, float* stack, int n_nodes, int n_feat, void* stream);
 int cgv_decoder_gate_fwd(const float* a0, const float* W1p, const float* b1p, const float* UV, const float* stack,
                          const float* v2, float* a, float* s3, float* v3, int n_nodes, int n_feat, void* stream);
+/* UpdateBlock forward (conv.py:593-616) with the element-wise halves in the products' epilogues, for 1..96 bead rows -- the
+ * per-block path beyond the channel-group decoder's 16 nodes (cgv_update_rows_fused_supported):
+ *   uv_norm   UV [3n, 2F] = rows [u_mat; v_mat]^T ; stack [n, 2F] = [s | sqrt(sum_xyz (Vv^2 + 1e-10))]   (s NULL: first half untouched)
+ *   gate      a [n, 3F] = a0 W1^T + b1 ; s_out = (U.Vv) a_sv + a_ss (+ s_res) ; v_out = U a_vv (+ v_res)  (residual adds of
+ *             cgvae.py:122-123 when s_res / v_res are given)
+ * replacing cgv_skinny / tile_linear_fwd + cgv_update_norm_stack_fwd and + cgv_update_gate_fwd (two launches each). */
+int cgv_update_rows_fused_supported(int n_rows, int n_feat);
+int cgv_update_uv_norm_fwd_fused(const float* rows, const float* Wuv /*[2F, F]*/, const float* s /*or NULL*/, float* UV, float* stack,
+                                 int n_nodes, int n_feat, void* stream);
+int cgv_update_gate_fwd_fused(const float* a0, const float* W1 /*[3F, F]*/, const float* b1, const float* UV, const float* s_res /*or NULL*/,
+                              const float* v_res /*or NULL*/, float* a, float* s_out, float* v_out, int n_rows, int n_feat, void* stream);
 int cgv_decoder_gate_bwd(const float* UV, const float* a, const float* gs_base /*or NULL*/, const float* gs_slices /*or NULL*/,
                          int gs_n_slices, int64_t gs_slice_stride, const float* gv /*or NULL*/, const float* W1p, float* ga,
                          float* gUV, float* gs_sum, float* slices_out, int64_t out_slice_stride, int n_nodes, int n_feat,

@@ -624,13 +624,16 @@ def test_dense_with_fused_swish_vs_fp64(M, F):
     assert_close(dense.bias.grad, bd_.grad, "gb", 3e-6)
 
 
-@pytest.mark.parametrize("n,F", [(12, 600), (96, 600), (64, 128)])
-def test_fused_update_block_equals_composition(n, F):
+@pytest.mark.parametrize("n,F,fused_fwd", [(12, 600, 0), (96, 600, 0), (64, 128, 0), (96, 600, 1), (64, 128, 1), (37, 200, 1), (17, 64, 1)])
+def test_fused_update_block_equals_composition(n, F, fused_fwd, options):
     """The single-node UpdateBlock path (arena-managed parameters, merged [u_mat; v_mat] product, grouped
     weight gradients) against the tensor-op composition and the fp64 oracle formulas; 12 beads run on the skinny
     kernels, 64 / 96 beads (3n = 192 / 288 rows) on the tile kernels."""
     from coarsegrainingvae_amd.trainer import ParamArena
     from coarsegrainingvae_amd.ops import _UpdateBlockFused
+    # fused_fwd: beyond 16 rows the norm / gate run in the epilogues of channel-group products (cgv_update_*_fwd_fused,
+    # round 5) or, with 0, as element-wise launches behind the tile / skinny products (rounds 2-4)
+    options.set("update_fused_fwd", fused_fwd)
     torch.manual_seed(3)
     blk = cg.UpdateBlock(F, "swish", 0.0).to(DEV)
     with torch.no_grad():
