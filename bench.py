@@ -150,6 +150,12 @@ def ladder_t0(base_port: int, slot_s: float, n_rungs: int) -> float:
     for _ in range(200):
         try:
             fd = os.open(path, os.O_CREAT | os.O_EXCL | os.O_WRONLY, 0o600)
+            import glob
+            for old in glob.glob(path + ".*"):               # "attempt k is over" marks of an earlier launch under this name
+                try:
+                    os.unlink(old)
+                except OSError:
+                    pass
             with os.fdopen(fd, "w") as f:
                 f.write(repr(time.time()))
             break
@@ -227,6 +233,11 @@ def supervise(args) -> int:
             if rank == 0:
                 sys.stdout.write(lines[0] + "\n")
                 sys.stdout.flush()
+                if world > 1:                                 # best effort: leave no clock file behind for a recycled pid
+                    try:
+                        os.unlink(ladder_path(base_port))
+                    except OSError:
+                        pass
             return 0
         reason = f"attempt {k} ({name}): " + (why or f"exit code {rc}" + ("" if len(lines) <= 1 else f", {len(lines)} JSON lines"))
     print(f"[bench] rank {rank}: every rung of the ladder failed ({reason})", file=sys.stderr)

@@ -31,3 +31,35 @@ def test_one_sided_failure_keeps_the_rungs_aligned():
         assert d["attempt"] == 1 and d["rung"] == "gradients+graph" and d["spread_s"] < 2.0, d
         # rank 1 failed in a fraction of a second and WAITED for rank 0's kill instead of starting attempt 1 alone
         assert "attempt 0 (operands+graph): rc 3" in outs[1][1] and "rc -9 timeout" in outs[0][1], (outs[0][1], outs[1][1])
+
+
+def _run(tmp, extra_env, world=2, timeout=120):
+    env = dict(os.environ)
+    env.update({"WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29917", "TMPDIR": tmp,
+                "CGV_BENCH_TEST_WORKER": os.path.join(ROOT, "tests", "ladder_stand_in_worker.py"),
+                "CGV_BENCH_TEST_SLOT_S": "9", "CGV_TEST_RDV_DIR": tmp, "CGV_TEST_RDV_WINDOW": "3"})
+    env.update(extra_env)
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--attempt-timeout", "6"],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(world)]
+    outs = [p.communicate(timeout=timeout) for p in procs]
+    return [p.returncode for p in procs], outs
+
+
+def test_all_ranks_succeed_on_the_first_rung_and_leave_no_clock_file():
+    with tempfile.TemporaryDirectory() as tmp:
+        rcs, outs = _run(tmp, {"CGV_TEST_FAIL_RANK": "-1"}, world=4)
+        assert rcs == [0, 0, 0, 0], [o[1][-800:] for o in outs]
+        lines = [ln for ln in outs[0][0].splitlines() if ln.strip()]
+        assert len(lines) == 1 and all(not o[0].strip() for o in outs[1:])
+        d = json.loads(lines[0])
+        assert d["attempt"] == 0 and d["rung"] == "operands+graph"
+        assert not [f for f in os.listdir(tmp) if f.startswith("cgv_bench_t0_") and "." not in f[len("cgv_bench_t0_"):]]
+
+
+def test_rank_zero_failing_alone_is_waited_for_too():
+    with tempfile.TemporaryDirectory() as tmp:
+        rcs, outs = _run(tmp, {"CGV_TEST_FAIL_RANK": "0"}, world=3)
+        assert rcs == [0, 0, 0], [o[1][-800:] for o in outs]
+        d = json.loads([ln for ln in outs[0][0].splitlines() if ln.strip()][0])
+        assert d["attempt"] == 1 and d["spread_s"] < 2.0, d
