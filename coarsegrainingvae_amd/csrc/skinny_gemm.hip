@@ -187,14 +187,29 @@ __device__ __forceinline__ void skinny_bwd_input_body(const int bx /* block inde
     for (int c = 0; c < 4; ++c) acc[mb][c] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int nb = n_beg; nb < n_end; nb += BI_ROUND) {
     float4 wv[4];                                                          // weights first: the long latency
+    bool wok[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int row = nb + 16 * s + 4 * wave + q;
-      const bool ok = row < n_end && kok;
-      wv[s] = ldg4_or_zero(W + (size_t)(ok ? row : 0) * K + (ok ? kcol : 0), ok);
+    for (int s = 0; s < 4; ++s) {                                          // unconditional (clamped) requests, zeroed below:
+      const int row = nb + 16 * s + 4 * wave + q;                          // a guarded load is a branch and ten instructions
+      wok[s] = row < n_end && kok;
+      wv[s] = *reinterpret_cast<const float4*>(W + (size_t)(wok[s] ? row : 0) * K + (wok[s] ? kcol : 0));
     }
     float g[MB * 4], zz[MB * 4];
-    if constexpr (LAZY) {
+    // Plain operands, 16-byte aligned: the [16 MB x 64] tile of g as MB float4 per thread (row = unit / 16, 4 columns),
+    // requested unconditionally -- 6 requests for the 24 + 24 guarded dword loads of a 96-row round, whose address
+    // arithmetic alone was ~500 instructions per wave and round (a round took 4 us for 1.5 us of MFMAs)
+    const bool vec = !LAZY && (((uintptr_t)gy | (uintptr_t)(act ? z : gy)) & 15) == 0;
+    float4 g4[MB], z4[MB];
+    if (vec) {
+#pragma unroll
+      for (int u = 0; u < MB; ++u) {
+        const int unit = u * 256 + (int)threadIdx.x, m = unit >> 4, n = nb + 4 * (unit & 15);
+        const bool ok = m < M && n < n_end;                                // N % 4 == 0, rounds of 64: a float4 is all in or all out
+        const size_t at = ok ? (size_t)m * N + n : 0;
+        g4[u] = *reinterpret_cast<const float4*>(gy + at);
+        if (act) z4[u] = *reinterpret_cast<const float4*>(z + at);         // wave-uniform
+      }
+    } else if constexpr (LAZY) {
       constexpr int SC = MB == 1 ? 8 : (MB == 2 ? 4 : 2);                  // slices in flight per element
 #pragma unroll
       for (int t = 0; t < MB * 4; ++t) {
@@ -237,9 +252,23 @@ __device__ __forceinline__ void skinny_bwd_input_body(const int bx /* block inde
         zz[t] = (ok && act) ? z[(size_t)m * N + n] : 0.f;
       }
     }
-    if (nb != n_beg) __syncthreads();                                      // readers of the previous round
 #pragma unroll
-    for (int t = 0; t < MB * 4; ++t) sm[(4 * t + wave) * BI_LD + lane] = act ? g[t] * act_bwd(zz[t], act) : g[t];
+    for (int s = 0; s < 4; ++s)
+      if (!wok[s]) wv[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (nb != n_beg) __syncthreads();                                      // readers of the previous round
+    if (vec) {
+#pragma unroll
+      for (int u = 0; u < MB; ++u) {
+        const int unit = u * 256 + (int)threadIdx.x, m = unit >> 4, n = nb + 4 * (unit & 15);
+        float4 v = g4[u];
+        if (act) { v.x *= act_bwd(z4[u].x, act); v.y *= act_bwd(z4[u].y, act); v.z *= act_bwd(z4[u].z, act); v.w *= act_bwd(z4[u].w, act); }
+        if (!(m < M && n < n_end)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(sm + m * BI_LD + 4 * (unit & 15)) = v;
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < MB * 4; ++t) sm[(4 * t + wave) * BI_LD + lane] = act ? g[t] * act_bwd(zz[t], act) : g[t];
+    }
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < 4; ++s)
@@ -386,7 +415,10 @@ __global__ __launch_bounds__(256) void skinny_bwd_input_reduce_k(const float* __
 static inline void bwd_input_plan(int N, int K, bool split, int* KT, int* NS, int* rpb) {
   *KT = (K + BI_COLS - 1) / BI_COLS;
   if (!split) { *NS = 1; *rpb = N; return; }
-  const int want = (320 + *KT - 1) / *KT;
+#ifndef CGV_BI_WANT
+#define CGV_BI_WANT 250   /* one round of blocks on 256 CUs: 96 x 5400 x 600 21.9 against 31.7 us at 320 (tools/bwd_input_bench.py), 64 rows 15.4 / 17.1 */
+#endif
+  const int want = (CGV_BI_WANT + *KT - 1) / *KT;
   int r = (N + want - 1) / want;
   r = (r + 15) / 16 * 16;
   if (r < 32) r = 32;
