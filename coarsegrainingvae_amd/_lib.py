@@ -62,6 +62,11 @@ PROTOTYPES = {
     "cgv_equi_msg_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, C.c_int64, C.c_int64, _p, _p, _p]),
     "cgv_equi_msg_grouped_supported": (_i, [_i, _i, _i]),
     "cgv_equi_msg_fwd_grouped": (_i, [_p] * 9 + [_i, _i, _i, _i, C.c_int64, C.c_int64, _p, _p, _p]),
+    "cgv_equi_msg_grouped_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i]),
+    "cgv_equi_msg_fwd_grouped_parts": (_i, [_p] * 9 + [_i, _i, _i, _i, C.c_int64, C.c_int64, _p, _p, _i, _p, C.c_size_t, _p]),
+    "cgv_equi_msg_balanced_supported": (_i, [_i, _i, _i]),
+    "cgv_equi_msg_balanced_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
+    "cgv_equi_msg_fwd_balanced": (_i, [_p] * 10 + [_i, _i, _i, _i, C.c_int64, _p, _p, _p, C.c_size_t, _p]),
     "cgv_equi_msg_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "cgv_equi_msg_bwd": (_i, [_p] * 13 + [_i, _i, _i, C.c_int64, C.c_int64, _p, _sz, _p]),
     "cgv_pseudo_msg_fwd": (_i, [_p] * 14 + [_i, _i, _i, _i, _p]),
@@ -180,7 +185,8 @@ PROTOTYPES = {
 # include/cgvae_hip.h: CGV_OPT_* (A/B switches of the launchers; defaults in csrc/api.cpp)
 OPTIONS = {"msg_fwd_split": 0, "msg_bwd_split": 1, "msg_fwd_kernel": 2, "grp_waves": 3, "grp_records": 4, "csr_build": 5,
            "pseudo_chunks": 6, "wgrad_tiling": 7, "tile_fwd_lds_min": 8, "bwd_input_waves": 9, "pseudo_fwd": 10, "decoder_fat": 11, "decoder_wlds": 12, "skinny_rows": 13,
-           "tile_fwd_bal": 14, "optim_one_launch": 15, "decoder_colsplit": 16, "decoder_nodesplit": 17}
+           "tile_fwd_bal": 14, "optim_one_launch": 15, "decoder_colsplit": 16, "decoder_nodesplit": 17,
+           "msg_fwd_balanced": 18}
 
 
 def set_option(name: str, value: int) -> None:

@@ -136,4 +136,30 @@ __device__ __forceinline__ void stpair(float* base, const ChanPair& cp, f2 x) {
   else { base[cp.c] = x.x; if (cp.live1) base[cp.c1] = x.y; }
 }
 
+// ---- the shared-source walk's per-wave state and edge math (equi_msg_grp.hip, equi_msg_bal.hip)
+struct RowBuf { f2 p0, p1, p2, A, B, C; };
+struct Acc { f2 s, A, B, C; };
+
+__device__ __forceinline__ void gather_row(RowBuf& b, rsrc_t r_phi, rsrc_t r_v, unsigned oc, unsigned oF, unsigned ov,
+                                           unsigned so) {
+  b.p1 = ld2_buf(r_phi, oc + oF, so);
+  b.p0 = ld2_buf(r_phi, oc, so);
+  b.p2 = ld2_buf(r_phi, oc + 2u * oF, so);
+  ldvec_buf(r_v, ov, so, b.A, b.B, b.C);
+}
+
+template <int R>
+__device__ __forceinline__ void edge_math(const f2 (&W0)[R + 1], const f2 (&W1)[R + 1], const f2 (&W2)[R + 1],
+                                          const float* __restrict__ gc /* group record: a_n, env, -, ux, uy, uz */,
+                                          const RowBuf& b, Acc& a) {
+  constexpr int U = geom_group_unit_offset(R);
+  a.s = fma2(b.p1, filter2<R>(W1, gc), a.s);
+  const f2 m0 = b.p0 * filter2<R>(W0, gc);
+  const f2 m2 = b.p2 * filter2<R>(W2, gc);
+  const f2 u01 = f2{gc[U], gc[U + 1]}, u20 = f2{gc[U + 2], gc[U]}, u12 = f2{gc[U + 1], gc[U + 2]};
+  a.A = fma2(lo2(m2), u01, fma2(lo2(m0), b.A, a.A));
+  a.B = fma2(m2, u20, fma2(m0, b.B, a.B));
+  a.C = fma2(hi2(m2), u12, fma2(hi2(m0), b.C, a.C));
+}
+
 }  // namespace cgv

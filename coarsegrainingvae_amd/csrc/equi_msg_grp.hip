@@ -23,9 +23,13 @@
 
 namespace cgv {
 
+typedef float q4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u4v __attribute__((__vector_size__(16)));
+constexpr int GRP_SC1 = 16;                          // buffer cache policy: agent scope (sc1) -- past the XCD's own L2
+
 // Wave timeline of a few blocks (measurement only, compiled in with -DCGV_K2G_CLOCK=1; tools/k2g_clock_probe.py): slots
 // [(sample * SPLIT + wave) * 8 + i], sample = one of 8 blocks spread over the grid; i: 0 entry, 1 first records + rows
-// requested, 2 filter tile staged + rows in registers, 3 edge loop done, 4 partials exchanged, 5 stores issued, 6 edges walked
+// requested, 2 filter tile staged + rows in registers, 3 edge loop done, 4 partials exchanged, 5 stores issued, 6 edges walked, 7 shader cycles of the edge loop
 #ifndef CGV_K2G_CLOCK
 #define CGV_K2G_CLOCK 0
 #endif
@@ -39,49 +43,30 @@ __constant__ unsigned long long* g_k2g_clock = nullptr;
 #else
 #define K2G_TICK(i, val) do { } while (0)
 #endif
-struct RowBuf { f2 p0, p1, p2, A, B, C; };
-struct Acc { f2 s, A, B, C; };
-
-__device__ __forceinline__ void gather_row(RowBuf& b, rsrc_t r_phi, rsrc_t r_v, unsigned oc, unsigned oF, unsigned ov,
-                                           unsigned so) {
-  b.p1 = ld2_buf(r_phi, oc + oF, so);
-  b.p0 = ld2_buf(r_phi, oc, so);
-  b.p2 = ld2_buf(r_phi, oc + 2u * oF, so);
-  ldvec_buf(r_v, ov, so, b.A, b.B, b.C);
-}
-
-template <int R>
-__device__ __forceinline__ void edge_math(const f2 (&W0)[R + 1], const f2 (&W1)[R + 1], const f2 (&W2)[R + 1],
-                                          const float* __restrict__ gc /* group record: a_n, env, -, ux, uy, uz */,
-                                          const RowBuf& b, Acc& a) {
-  constexpr int U = geom_group_unit_offset(R);
-  a.s = fma2(b.p1, filter2<R>(W1, gc), a.s);
-  const f2 m0 = b.p0 * filter2<R>(W0, gc);
-  const f2 m2 = b.p2 * filter2<R>(W2, gc);
-  const f2 u01 = f2{gc[U], gc[U + 1]}, u20 = f2{gc[U + 2], gc[U]}, u12 = f2{gc[U + 1], gc[U + 2]};
-  a.A = fma2(lo2(m2), u01, fma2(lo2(m0), b.A, a.A));
-  a.B = fma2(m2, u20, fma2(m0, b.B, a.B));
-  a.C = fma2(hi2(m2), u12, fma2(hi2(m0), b.C, a.C));
-}
-
 // grid = 8 * items_per_xcd blocks (items = groups x channel tiles of 128), block = 64 * SPLIT threads: the SPLIT waves
 // of a block take contiguous slices of the group's edge range and meet in LDS.
-template <int R, int RB, int SPLIT>
+template <int R, int RB, int SPLIT, int PARTS>
 __global__ __launch_bounds__(64 * SPLIT) void equi_msg_fwd_grp_k(
     const float* __restrict__ phi, const float* __restrict__ v, const float* __restrict__ geom /* group order */,
     const int* __restrict__ rowptr /* destination CSR */, const int* __restrict__ src_g,
     const float* __restrict__ Wd, const float* __restrict__ bd, float* __restrict__ ds, float* __restrict__ dv, int F,
-    int n_dst, int items_per_xcd, int tiles, const float* __restrict__ s_res, const float* __restrict__ v_res) {
+    int n_dst, int items_per_xcd, int tiles, const float* __restrict__ s_res, const float* __restrict__ v_res,
+    float* __restrict__ ws /* parts > 1: tickets + partial sums, cgv_equi_msg_grouped_workspace_bytes */) {
   constexpr int GS = geom_group_stride(R), NG = R + 6, MX = R + 1, MY = R + 5;   // record floats used; meta words
   constexpr int FILT = 3 * 128 * R, RED = SPLIT * RB * 8 * 64;
   __shared__ __attribute__((aligned(16))) float smem[FILT > RED ? FILT : RED];
-  // work item = (channel tile, group), tile-major; XCD x (= blockIdx % 8) takes items [x * items_per_xcd, ...): an XCD
+  // work item = (channel tile, group, part), tile-major; XCD x (= blockIdx % 8) takes items [x * items_per_xcd, ...): an XCD
   // sweeps consecutive groups of ONE channel tile (at most two), so the rows its L2 must hold are one 3 KB tile slice of
-  // the sources around ~100 consecutive groups, not all five slices (2000-atom graph: L2 hit rate 46 % -> see DESIGN.md)
+  // the sources around ~100 consecutive groups, not all five slices (2000-atom graph: L2 hit rate 46 % -> see DESIGN.md).
+  // PARTS blocks share a group's edge range (cut into PARTS x SPLIT wave slices): shorter
+  // blocks in larger number spread evenly over the CUs where one block per (group, tile) is 3.25 blocks per CU
+  // (chignolin) or lives 20-145 us depending on the group's degree (2000 atoms); their sums meet in ws (see the end).
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int n_groups = (n_dst + RB - 1) / RB;
-  const int item = xcd * items_per_xcd + slot;
-  if (slot >= items_per_xcd || item >= n_groups * tiles) return;
+  int item = xcd * items_per_xcd + slot;
+  if (slot >= items_per_xcd || item >= n_groups * tiles * PARTS) return;
+  const int part = item % PARTS;
+  item /= PARTS;
   const int tile = item / n_groups;
   const int group = item - tile * n_groups;
   const int node0 = group * RB;
@@ -93,8 +78,8 @@ __global__ __launch_bounds__(64 * SPLIT) void equi_msg_fwd_grp_k(
 
   int beg = rowptr[node0], end = rowptr[node1];
   {
-    const int len = (end - beg + SPLIT - 1) / SPLIT;
-    beg = min(beg + wave * len, end);
+    const int len = (end - beg + SPLIT * PARTS - 1) / (SPLIT * PARTS);
+    beg = min(beg + (part * SPLIT + wave) * len, end);
     end = min(beg + len, end);
   }
   K2G_TICK(6, (unsigned long long)(end - beg));
@@ -134,6 +119,9 @@ __global__ __launch_bounds__(64 * SPLIT) void equi_msg_fwd_grp_k(
     read_filter_rows2<R>(W2, smem + 2 * 128 * R, bd, cl, 2 * F + cp.c);
   }
   K2G_TICK(2, wall_clock64());
+#if CGV_K2G_CLOCK
+  const unsigned long long cyc0 = __builtin_readcyclecounter();      // shader clock (s_memtime)
+#endif
 
   Acc acc[RB];
 #pragma unroll
@@ -181,6 +169,9 @@ __global__ __launch_bounds__(64 * SPLIT) void equi_msg_fwd_grp_k(
 
   // every wave deposits its partial sums; wave w then finishes receivers w, w + SPLIT, ... in a fixed order
   K2G_TICK(3, wall_clock64());
+#if CGV_K2G_CLOCK
+  K2G_TICK(7, __builtin_readcyclecounter() - cyc0);
+#endif
   __syncthreads();                                   // all filter reads of the shared buffer are done
 #pragma unroll
   for (int k = 0; k < RB; ++k) {
@@ -190,23 +181,78 @@ __global__ __launch_bounds__(64 * SPLIT) void equi_msg_fwd_grp_k(
   }
   __syncthreads();
   K2G_TICK(4, wall_clock64());
-  for (int k = wave; k < node1 - node0; k += SPLIT) {
-    f2 s = splat(0.f), A = splat(0.f), B = splat(0.f), C = splat(0.f);
+  if constexpr (PARTS == 1) {
+    for (int k = wave; k < node1 - node0; k += SPLIT) {
+      f2 s = splat(0.f), A = splat(0.f), B = splat(0.f), C = splat(0.f);
 #pragma unroll
-    for (int w = 0; w < SPLIT; ++w) {
-      const float* r = smem + ((w * RB + k) * 8) * 64 + lane;
-      s += f2{r[0], r[64]}; A += f2{r[128], r[192]}; B += f2{r[256], r[320]}; C += f2{r[384], r[448]};
-    }
-    if (cp.live) {
-      const int node = node0 + k;
-      if (s_res) s += ldpair<true>(s_res + (size_t)node * F, cp);          // emit h + ds (cgvae.py:287, 309, 391)
-      stpair<true>(ds + (size_t)node * F, cp, s);
-      if (v_res) {
-        f2 rA, rB, rC;
-        ldvec<true>(v_res + (size_t)node * F * 3, cp, rA, rB, rC);
-        A += rA; B += rB; C += rC;
+      for (int w = 0; w < SPLIT; ++w) {
+        const float* r = smem + ((w * RB + k) * 8) * 64 + lane;
+        s += f2{r[0], r[64]}; A += f2{r[128], r[192]}; B += f2{r[256], r[320]}; C += f2{r[384], r[448]};
       }
-      stvec<true>(dv + (size_t)node * F * 3, cp, A, B, C);
+      if (cp.live) {
+        const int node = node0 + k;
+        if (s_res) s += ldpair<true>(s_res + (size_t)node * F, cp);          // emit h + ds (cgvae.py:287, 309, 391)
+        stpair<true>(ds + (size_t)node * F, cp, s);
+        if (v_res) {
+          f2 rA, rB, rC;
+          ldvec<true>(v_res + (size_t)node * F * 3, cp, rA, rB, rC);
+          A += rA; B += rB; C += rC;
+        }
+        stvec<true>(dv + (size_t)node * F * 3, cp, A, B, C);
+      }
+    }
+  } else {
+    // PARTS blocks hold the group's sums between them: each leaves its own in its slot of the workspace -- agent-scope
+    // write-through stores, acknowledged (vmcnt(0)) before its ticket is drawn: the hand-over of loss_tail.hip, valid
+    // where stores count on vmcnt -- and the block that draws the group's LAST ticket adds the slots in part order
+    // (the result does not depend on who arrives last) and stores.  Tickets reset themselves.
+    // ws: [tiles * n_groups] tickets (padded to 256 bytes), then [tiles * n_groups][PARTS][RB][2][64][4] floats
+    unsigned* ticket = reinterpret_cast<unsigned*>(ws) + (size_t)tile * n_groups + group;
+    const size_t head = (((size_t)tiles * n_groups * sizeof(unsigned) + 255) & ~(size_t)255) / sizeof(float);
+    const rsrc_t r_part = make_rsrc(ws + head + ((size_t)tile * n_groups + group) * (PARTS * RB * 512));
+    for (int k = wave; k < RB; k += SPLIT) {
+      f2 s = splat(0.f), A = splat(0.f), B = splat(0.f), C = splat(0.f);
+#pragma unroll
+      for (int w = 0; w < SPLIT; ++w) {
+        const float* r = smem + ((w * RB + k) * 8) * 64 + lane;
+        s += f2{r[0], r[64]}; A += f2{r[128], r[192]}; B += f2{r[256], r[320]}; C += f2{r[384], r[448]};
+      }
+      const unsigned at = (unsigned)((part * RB + k) * 2048) + 16u * (unsigned)lane;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, q4{s.x, s.y, A.x, A.y}), r_part, at, 0, GRP_SC1);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, q4{B.x, B.y, C.x, C.y}), r_part, at + 1024u, 0, GRP_SC1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                 // every wave's slot stores are acknowledged
+    __shared__ unsigned s_last;
+    if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1u) == (unsigned)(PARTS - 1) ? 1u : 0u;
+    __syncthreads();
+    if (s_last) {
+      if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int k = wave; k < node1 - node0; k += SPLIT) {
+        f2 s = splat(0.f), A = splat(0.f), B = splat(0.f), C = splat(0.f);
+        q4 x[PARTS], y[PARTS];
+#pragma unroll
+        for (int p = 0; p < PARTS; ++p) {
+          const unsigned at = (unsigned)((p * RB + k) * 2048) + 16u * (unsigned)lane;
+          x[p] = __builtin_bit_cast(q4, __builtin_amdgcn_raw_buffer_load_b128(r_part, at, 0, GRP_SC1));
+          y[p] = __builtin_bit_cast(q4, __builtin_amdgcn_raw_buffer_load_b128(r_part, at + 1024u, 0, GRP_SC1));
+        }
+#pragma unroll
+        for (int p = 0; p < PARTS; ++p) {
+          s += f2{x[p].x, x[p].y}; A += f2{x[p].z, x[p].w}; B += f2{y[p].x, y[p].y}; C += f2{y[p].z, y[p].w};
+        }
+        if (cp.live) {
+          const int node = node0 + k;
+          if (s_res) s += ldpair<true>(s_res + (size_t)node * F, cp);
+          stpair<true>(ds + (size_t)node * F, cp, s);
+          if (v_res) {
+            f2 rA, rB, rC;
+            ldvec<true>(v_res + (size_t)node * F * 3, cp, rA, rB, rC);
+            A += rA; B += rB; C += rC;
+          }
+          stvec<true>(dv + (size_t)node * F * 3, cp, A, B, C);
+        }
+      }
     }
   }
   K2G_TICK(5, wall_clock64());
@@ -393,10 +439,19 @@ int cgv_equi_msg_grouped_supported(int n_feat, int n_rbf, int rb) {
   return r_ok && (n_feat % 2 == 0) && (n_rbf % 2 == 0) && (rb == 2 || rb == 4);
 }
 
-int cgv_equi_msg_fwd_grouped(const float* phi, const float* v, const float* geom_g, const int32_t* rowptr_d,
-                             const int32_t* src_g, const float* Wd, const float* bd, float* ds,
-                             float* dv, int n_dst, int n_feat, int n_rbf, int rb, int64_t n_rows, int64_t n_edges,
-                             const float* s_res, const float* v_res, void* stream) {
+constexpr int CGV_GRP_PARTS_MAX = 4;
+
+size_t cgv_equi_msg_grouped_workspace_bytes(int n_dst, int n_feat, int rb, int parts) {
+  if (n_dst <= 0 || n_feat <= 0 || rb <= 0 || parts <= 1) return 0;
+  const size_t items = (((size_t)n_feat + 127) / 128) * (((size_t)n_dst + rb - 1) / rb);
+  return ((items * sizeof(unsigned) + 255) & ~(size_t)255) + items * (size_t)parts * (size_t)rb * 2048;
+}
+
+int cgv_equi_msg_fwd_grouped_parts(const float* phi, const float* v, const float* geom_g, const int32_t* rowptr_d,
+                                   const int32_t* src_g, const float* Wd, const float* bd, float* ds,
+                                   float* dv, int n_dst, int n_feat, int n_rbf, int rb, int64_t n_rows, int64_t n_edges,
+                                   const float* s_res, const float* v_res, int parts, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
   CGV_REQUIRE(n_dst >= 0 && n_feat > 0, "bad size");
   if (n_dst == 0) return 0;
   CGV_REQUIRE(phi && v && geom_g && rowptr_d && src_g && Wd && bd && ds && dv, "null pointer");
@@ -405,22 +460,30 @@ int cgv_equi_msg_fwd_grouped(const float* phi, const float* v, const float* geom
   CGV_REQUIRE((((uintptr_t)phi | (uintptr_t)v | (uintptr_t)ds | (uintptr_t)dv | (uintptr_t)s_res | (uintptr_t)v_res |
                 (uintptr_t)bd) & 7) == 0 && ((((uintptr_t)Wd) | ((uintptr_t)geom_g)) & 15) == 0,
               "operands must be 8-byte (Wd, geom_g: 16-byte) aligned");
+  CGV_REQUIRE(parts >= 1 && parts <= CGV_GRP_PARTS_MAX, "parts must be 1..4");
   hipStream_t st = (hipStream_t)stream;
-  const int tiles = (n_feat + 127) / 128;
-  const int groups = (n_dst + rb - 1) / rb;
-  const int gpx = (groups * tiles + 7) / 8;           // work items per XCD
-  const dim3 grid(8 * gpx);
   // waves per block: 4 (measured on the 2000-atom graph: 4 -> 654 us, 8 -> 942 us: one 8-wave block per CU leaves two
   // waves per SIMD; 6 -> 1194 us: a wave count that is not a multiple of the 4 SIMDs loads them unevenly).
   // cgv_set_option(CGV_OPT_GRP_WAVES, 8) is kept for A/B runs.
   const int split = cgv::option(CGV_OPT_GRP_WAVES);
-#define CGV_GRP_LAUNCH(RBV, SP)                                                                                  \
-  hipLaunchKernelGGL((cgv::equi_msg_fwd_grp_k<RBF, RBV, SP>), grid, dim3(64 * SP), 0, st, phi, v, geom_g, rowptr_d, src_g, \
-                     Wd, bd, ds, dv, n_feat, n_dst, gpx, tiles, s_res, v_res)
-#define CGV_GRP_PICK(RBV) \
-  if (split == 8) CGV_GRP_LAUNCH(RBV, 8); else CGV_GRP_LAUNCH(RBV, 4)
   // record stream: "lds" (vector loads -> LDS ring -> VGPR operands; 16-float records: n_rbf 8 / 10) or "scalar"
   const bool lds = cgv::option(CGV_OPT_GRP_RECORDS) == 1;
+  if (rb != 2 || split == 8 || lds) parts = 1;        // (several blocks per group: the default kernel only)
+  float* ws = reinterpret_cast<float*>(workspace);
+  if (parts > 1) {
+    CGV_REQUIRE(workspace && ((uintptr_t)workspace & 15) == 0 &&
+                    workspace_bytes >= cgv_equi_msg_grouped_workspace_bytes(n_dst, n_feat, rb, parts),
+                "parts > 1 needs a zero-filled workspace of cgv_equi_msg_grouped_workspace_bytes bytes");
+  }
+  const int tiles = (n_feat + 127) / 128;
+  const int groups = (n_dst + rb - 1) / rb;
+  const int gpx = (groups * tiles * parts + 7) / 8;   // work items per XCD
+  const dim3 grid(8 * gpx);
+#define CGV_GRP_LAUNCH(RBV, SP, PT)                                                                              \
+  hipLaunchKernelGGL((cgv::equi_msg_fwd_grp_k<RBF, RBV, SP, PT>), grid, dim3(64 * SP), 0, st, phi, v, geom_g, rowptr_d, src_g, \
+                     Wd, bd, ds, dv, n_feat, n_dst, gpx, tiles, s_res, v_res, ws)
+#define CGV_GRP_PICK(RBV) \
+  if (split == 8) CGV_GRP_LAUNCH(RBV, 8, 1); else CGV_GRP_LAUNCH(RBV, 4, 1)
   if (lds && (n_rbf == 8 || n_rbf == 10) && n_edges > 0 && n_edges < (1ll << 28)) {
     const int ne = (int)n_edges;
 #define CGV_GRP_LDS(RV, RBV)                                                                                       \
@@ -432,11 +495,23 @@ int cgv_equi_msg_fwd_grouped(const float* phi, const float* v, const float* geom
     return cgv::check_launch("cgv_equi_msg_fwd_grouped");
   }
   CGV_DISPATCH_RBF(n_rbf, {
-    if (rb == 2) { CGV_GRP_PICK(2); } else { CGV_GRP_PICK(4); }
+    if (parts == 2) { CGV_GRP_LAUNCH(2, 4, 2); }
+    else if (parts == 3) { CGV_GRP_LAUNCH(2, 4, 3); }
+    else if (parts == 4) { CGV_GRP_LAUNCH(2, 4, 4); }
+    else if (rb == 2) { CGV_GRP_PICK(2); }
+    else { CGV_GRP_PICK(4); }
   });
 #undef CGV_GRP_PICK
 #undef CGV_GRP_LAUNCH
   return cgv::check_launch("cgv_equi_msg_fwd_grouped");
+}
+
+int cgv_equi_msg_fwd_grouped(const float* phi, const float* v, const float* geom_g, const int32_t* rowptr_d,
+                             const int32_t* src_g, const float* Wd, const float* bd, float* ds,
+                             float* dv, int n_dst, int n_feat, int n_rbf, int rb, int64_t n_rows, int64_t n_edges,
+                             const float* s_res, const float* v_res, void* stream) {
+  return cgv_equi_msg_fwd_grouped_parts(phi, v, geom_g, rowptr_d, src_g, Wd, bd, ds, dv, n_dst, n_feat, n_rbf, rb, n_rows,
+                                        n_edges, s_res, v_res, 1, nullptr, 0, stream);
 }
 
 }  // extern "C"

@@ -192,10 +192,10 @@ __global__ void grp_gather(const int* __restrict__ dst_d, const int* __restrict_
   src_g[q] = src_d[p];
   if (pos_g) pos_g[q] = p;
 }
-// meta[q] = { slot | head << 8 | mask << 16 , source of the NEXT step of this group (own source at the last step) }
+// meta[q] = { slot | head << 8 | last << 9 | mask << 16 , source of the NEXT step of this group (own source at the last step) }
 // slot = receiver - group base; a step = a maximal run of edges of one (group, source) pair with strictly increasing
 // receivers (at most RB edges; a duplicated edge opens a new step on the same source), mask = its slots,
-// head = first edge of the step.
+// head = first edge of the step, last = the step is the group's last one.
 __global__ void grp_meta(const int* __restrict__ dst_g, const int* __restrict__ src_g, int n, int rb,
                          int2* __restrict__ meta) {
   int q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -207,8 +207,9 @@ __global__ void grp_meta(const int* __restrict__ dst_g, const int* __restrict__ 
   for (int t = q; joins(t); --t) mask |= 1 << (dst_g[t - 1] - g * rb);
   int t = q + 1;
   for (; t < n && joins(t); ++t) mask |= 1 << (dst_g[t] - g * rb);
-  const int next = (t < n && dst_g[t] / rb == g) ? src_g[t] : s;
-  meta[q] = make_int2((d - g * rb) | (joins(q) ? 0 : 0x100) | (mask << 16), next);
+  const bool more = t < n && dst_g[t] / rb == g;           // the group has another step behind this one
+  const int next = more ? src_g[t] : s;
+  meta[q] = make_int2((d - g * rb) | (joins(q) ? 0 : 0x100) | (more ? 0 : 0x200) | (mask << 16), next);
 }
 
 
@@ -232,7 +233,7 @@ __device__ __forceinline__ int2 grp_meta_of(HiAt hi_at, int q, int L, int rb) {
   int t = q + 1;
   for (; t < L && joins(t); ++t) mask |= 1 << slot_of(t);
   const int next = t < L ? src_of(t) : s;
-  return make_int2(sl | (joins(q) ? 0 : 0x100) | (mask << 16), next);
+  return make_int2(sl | (joins(q) ? 0 : 0x100) | (t < L ? 0 : 0x200) | (mask << 16), next);
 }
 
 __global__ __launch_bounds__(256) void grp_build_k(const int* __restrict__ rowptr_d, const int* __restrict__ dst_d,

@@ -13,7 +13,7 @@ import ctypes as C
 
 import torch
 
-from . import _lib
+from . import _lib, options
 from .graph import EdgeGeometry, EdgePlan
 from .primitives import linear as _linear, skinny_bwd_input
 
@@ -53,6 +53,46 @@ def _grouped_forward_usable(plan, geom, F, tensors8, Wd) -> bool:
     return all(t is None or t.data_ptr() % 8 == 0 for t in tensors8)
 
 
+_BAL_WS = {}
+_GRP_WS = {}
+
+
+def grouped_parts(plan) -> int:
+    """Blocks per (group, channel tile) of the shared-source forward.  1: several blocks per group measured level with one
+    on every workload (chignolin 43.9 / 41.9 / 43.4 / 47.8 us for 1 / 2 / 3 / 4 parts, 2000 atoms 605 / 605 / 618 / 632,
+    dipeptide 22 / 29 / 36 / 47: profiles/r05_k2_parts_ab.txt) -- the launch is bound by packed-FMA issue at the clock the
+    chip sustains under it, not by how its blocks are cut; ``fwd_parts`` keeps the alternative for A/B runs."""
+    p = options.HOST["fwd_parts"]
+    return min(int(p), 4) if p >= 1 and plan.group_rb == 2 else 1
+
+
+def _grouped_workspace(device, n_dst, F, rb, parts):
+    """Tickets + partial-sum slots of cgv_equi_msg_fwd_grouped_parts: zeroed ONCE per (device, stream, shape); same rules
+    as ``_balanced_workspace`` below."""
+    key = (str(device), int(torch.cuda.current_stream(device).cuda_stream), int(n_dst), int(F), int(rb), int(parts))
+    ws = _GRP_WS.get(key)
+    if ws is None:
+        ws = torch.zeros(int(_lib.load().cgv_equi_msg_grouped_workspace_bytes(int(n_dst), int(F), int(rb), int(parts))),
+                         dtype=torch.uint8, device=device)
+        if not torch.cuda.is_current_stream_capturing():
+            _GRP_WS[key] = ws
+    return ws
+
+
+def _balanced_workspace(device, n_dst, F, rb):
+    """Tickets + partial-sum slots of cgv_equi_msg_fwd_balanced: zeroed ONCE per (device, stream, shape) -- every launch
+    leaves its tickets at zero.  One workspace serves the launches of one stream (they are ordered); never cached from
+    inside a stream capture (see ``_tail_workspace``: the zero fill would be a captured node that has not run)."""
+    key = (str(device), int(torch.cuda.current_stream(device).cuda_stream), int(n_dst), int(F), int(rb))
+    ws = _BAL_WS.get(key)
+    if ws is None:
+        ws = torch.zeros(int(_lib.load().cgv_equi_msg_balanced_workspace_bytes(int(n_dst), int(F), int(rb))),
+                         dtype=torch.uint8, device=device)
+        if not torch.cuda.is_current_stream_capturing():
+            _BAL_WS[key] = ws
+    return ws
+
+
 # ----------------------------------------------------------------------------- K2 / K4
 class _EquiMessage(torch.autograd.Function):
     """ds, dv of EquiMessageBlock / ContractiveMessageBlock from phi = inv_dense(s)
@@ -72,12 +112,23 @@ class _EquiMessage(torch.autograd.Function):
         else:       # vector channel skipped: delta = 0, i.e. the residual passes through unchanged
             dv = v_res.clone() if v_res is not None else torch.zeros(plan.n_dst, F, 3, dtype=_F32, device=phi.device)
         tag = f"equi_msg_fwd:Nd{plan.n_dst}:E{plan.n_edges}:dv{int(with_dv)}"
-        if with_dv and _grouped_forward_usable(plan, geom, F, (phi, v, ds, dv, s_res, v_res, bd), Wd):
-            # shared-source walk: groups of plan.group_rb receivers gather every source row once (K2g)
-            _lib.call("cgv_equi_msg_fwd_grouped", _lib.ptr(phi), _lib.ptr(v), _lib.ptr(geom.geom_g), _lib.ptr(plan.rowptr_d),
+        grouped = with_dv and _grouped_forward_usable(plan, geom, F, (phi, v, ds, dv, s_res, v_res, bd), Wd)
+        if grouped and options.HOST["fwd_balanced"] and _lib.load().cgv_equi_msg_balanced_supported(F, geom.n_rbf, plan.group_rb):
+            # the same walk over equal edge ranges, one block per CU (K2e): cut groups meet in the workspace
+            ws = _balanced_workspace(phi.device, plan.n_dst, F, plan.group_rb)
+            _lib.call("cgv_equi_msg_fwd_balanced", _lib.ptr(phi), _lib.ptr(v), _lib.ptr(geom.geom_g), _lib.ptr(plan.rowptr_d),
+                      _lib.ptr(plan.src_g), _lib.ptr(plan.dst_g), _lib.ptr(Wd), _lib.ptr(bd), _lib.ptr(ds), _lib.ptr(dv),
+                      plan.n_dst, F, geom.n_rbf, plan.group_rb, plan.n_src, _lib.ptr(s_res), _lib.ptr(v_res),
+                      _lib.ptr(ws), ws.numel(), _lib.stream_ptr(), tag=tag)
+        elif grouped:
+            # shared-source walk: groups of plan.group_rb receivers gather every source row once (K2g), several blocks per
+            # group where its edge range is long enough (their sums meet in the workspace)
+            parts = grouped_parts(plan)
+            ws = _grouped_workspace(phi.device, plan.n_dst, F, plan.group_rb, parts) if parts > 1 else None
+            _lib.call("cgv_equi_msg_fwd_grouped_parts", _lib.ptr(phi), _lib.ptr(v), _lib.ptr(geom.geom_g), _lib.ptr(plan.rowptr_d),
                       _lib.ptr(plan.src_g), _lib.ptr(Wd), _lib.ptr(bd), _lib.ptr(ds), _lib.ptr(dv),
                       plan.n_dst, F, geom.n_rbf, plan.group_rb, plan.n_src, plan.n_edges, _lib.ptr(s_res), _lib.ptr(v_res),
-                      _lib.stream_ptr(), tag=tag)
+                      parts, _lib.ptr(ws), ws.numel() if ws is not None else 0, _lib.stream_ptr(), tag=tag)
         else:
             _lib.call("cgv_equi_msg_fwd", _lib.ptr(phi), _lib.ptr(v), _lib.ptr(geom.geom_d), _lib.ptr(plan.rowptr_d),
                       _lib.ptr(plan.src_d), _lib.ptr(Wd), _lib.ptr(bd), _lib.ptr(ds), _lib.ptr(dv), plan.n_dst, F,

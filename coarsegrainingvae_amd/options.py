@@ -26,6 +26,8 @@ HOST = {
     "fused_bead_mean": 1,   # EquiEncoder layer 0: 1 H, V = scatter_mean(h), scatter_mean(v) from one launch inside the contractive block, gradient through its first Dense's epilogue; 0 two launches + broadcast + add
     "fused_prior": 1,       # CGprior: 1 the message-block loop of a small bead graph on the channel-group kernels (prior_fused.py), 0 per-block path
     "update_fused_fwd": 0,  # UpdateBlock forward on 17..96 bead rows: 0 (default) product + element-wise launch each (5 launches), 1 norm / gate in the epilogues of channel-group products (cgv_update_*_fwd_fused: 3 launches) -- measured SLOWER: dipeptide 2.645 / 2.675 against 2.636 / 2.637 ms, 2000 atoms 5.996 / 5.968 (a 96-row channel-group block is 900 fp32 MFMAs on one CU; the tile kernels spread the same product over the chip)
+    "fwd_parts": 1,         # shared-source message forward (rb = 2): blocks per (group, channel tile), 1 (default) .. 4 (cgv_equi_msg_fwd_grouped_parts; measured level with 1 or slower)
+    "fwd_balanced": 0,      # shared-source message forward (rb = 2): 0 (default) one block per (group, channel tile) (cgv_equi_msg_fwd_grouped), 1 equal edge ranges per wave on a resident grid (cgv_equi_msg_fwd_balanced) -- measured slower: chignolin 45.6 against 42.7 us, 2000 atoms 678 / 600
     "decoder_dense": 0,     # full-width products of the fused decoder loop: 0 four-column blocks (cgv_decoder_dense_fwd), 1 skinny_fwd_k
 }
 _DEFAULTS = dict(HOST)

@@ -86,7 +86,8 @@ enum {
                                   three for uv_bwd (48-row tiles), 3 three everywhere */
   CGV_OPT_DECODER_NODESPLIT = 17, /* cgv_decoder_uv_fwd (and uv_bwd, see there): 1 (default) 8-channel blocks by node groups of <= 5 nodes (grid y) --
                                    a third of the MFMAs and of the x rows per block; 0 one 4-channel block over all 3 n rows */
-  CGV_OPT_COUNT = 18
+  CGV_OPT_MSG_FWD_BALANCED = 18, /* cgv_equi_msg_fwd_balanced: four-wave blocks per CU, 3 (default: what the kernel's registers admit, all resident) or 1..4 */
+  CGV_OPT_COUNT = 19
 };
 /* Measurement: store the GPU wall clock (cgv_timestamp_hz ticks per second) into *slot, in stream order; capturable. */
 int cgv_timestamp(uint64_t* slot /*device*/, void* stream);
@@ -145,10 +146,10 @@ int cgv_csr_build(const int64_t* dst, const int64_t* src, int stride, int n_edge
  * rb consecutive receivers form a group; the group's edges (one contiguous range of the dst-sorted view, so
  * rowptr_d still delimits it) are re-ordered by (source, receiver).  Outputs, all [E] in group order:
  *   dst_g, src_g  receiver / source of the edge      pos_g  its position in the dst-sorted view
- *   meta_g [E,2]  { slot | head << 8 | mask << 16 , source of the group's NEXT step }: slot = receiver - group
+ *   meta_g [E,2]  { slot | head << 8 | last << 9 | mask << 16 , source of the group's NEXT step }: slot = receiver - group
  *                 base; a step = a maximal run of edges of one (group, source) pair with strictly increasing receivers
- *                 (a duplicated edge opens a new step); mask = the step's slots; head = first edge of the step; the
- *                 last step of a group names its own source.
+ *                 (a duplicated edge opens a new step); mask = the step's slots; head = first edge of the step; last =
+ *                 the step is its group's last one (it names its own source as the next).
  * One launch: a block per group ranks the group's edges by (source, receiver, position) -- at most 2 x degree keys,
  * in LDS up to 4096 per group.  Edge records for this order come from cgv_edge_geometry_grouped (below), which folds
  * meta_g into them. */
@@ -277,6 +278,38 @@ int cgv_equi_msg_fwd_grouped(const float* phi /*[Ns,3F]*/, const float* v /*[Ns,
                              float* dv /*[Nd,F,3]*/, int n_dst, int n_feat, int n_rbf, int rb, int64_t n_rows,
                              int64_t n_edges /* records in geom_g */, const float* s_res /*[Nd,F] or NULL*/, const float* v_res /*[Nd,F,3] or NULL*/,
                              void* stream);
+/* cgv_equi_msg_fwd_grouped with `parts` (1..4) blocks per (group, channel tile): the group's edge range is cut into
+ * parts x 4 wave slices instead of 4 -- shorter blocks in larger number, which the dispatcher spreads evenly over the CUs
+ * where one block per item gives 3.25 blocks per CU (chignolin graph: a quarter of the CUs carry a fourth block) or
+ * blocks that live 20-145 us depending on their group's degree (2000-atom graph: the launch ends with a few long ones).
+ * The parts' sums meet in the workspace: every block leaves its own in its slot, the block that draws the group's last
+ * ticket adds the slots in part order and stores -- results do not depend on timing.  rb = 2, default kernel only
+ * (otherwise parts is taken as 1).  workspace: cgv_equi_msg_grouped_workspace_bytes bytes, 16-byte aligned, ZERO-FILLED
+ * once by the caller (self-resetting tickets at its head); one workspace serves the launches of one stream. */
+size_t cgv_equi_msg_grouped_workspace_bytes(int n_dst, int n_feat, int rb, int parts);
+int cgv_equi_msg_fwd_grouped_parts(const float* phi /*[Ns,3F]*/, const float* v /*[Ns,F,3]*/, const float* geom_g,
+                                   const int32_t* rowptr_d, const int32_t* src_g,
+                                   const float* Wd /*[3F,R]*/, const float* bd /*[3F]*/, float* ds /*[Nd,F]*/,
+                                   float* dv /*[Nd,F,3]*/, int n_dst, int n_feat, int n_rbf, int rb, int64_t n_rows,
+                                   int64_t n_edges, const float* s_res /*[Nd,F] or NULL*/,
+                                   const float* v_res /*[Nd,F,3] or NULL*/, int parts, void* workspace,
+                                   size_t workspace_bytes, void* stream);
+/* The same shared-source walk with the work cut into EQUAL EDGE RANGES instead of (group, channel tile) blocks:
+ * every wave walks the same number of edges of its channel tile's group-ordered edge array, whatever the groups'
+ * sizes, on a grid that is resident at once (cgv_equi_msg_fwd_grouped: 3.25 blocks per CU on the chignolin graph, block lifetimes 20-145 us on the 2000-atom
+ * graph).  A group cut by a range boundary is finished by the last contributing wave to arrive, which adds the
+ * contributors' partial sums (workspace) in range order: results do not depend on timing.  rb = 2 only; dst_g = the
+ * plan's receiver ids in group order.  The edge count is read from rowptr_d[n_dst] on the device.
+ * workspace: cgv_equi_msg_balanced_workspace_bytes bytes, 16-byte aligned, ZERO-FILLED once by the caller (its head holds
+ * self-resetting tickets); one workspace serves every launch of one stream, launches on concurrent streams need their own. */
+int cgv_equi_msg_balanced_supported(int n_feat, int n_rbf, int rb);   /* even n_feat / n_rbf, rb = 2 */
+size_t cgv_equi_msg_balanced_workspace_bytes(int n_dst, int n_feat, int rb);
+int cgv_equi_msg_fwd_balanced(const float* phi /*[Ns,3F]*/, const float* v /*[Ns,F,3]*/, const float* geom_g,
+                              const int32_t* rowptr_d, const int32_t* src_g, const int32_t* dst_g,
+                              const float* Wd /*[3F,R]*/, const float* bd /*[3F]*/, float* ds /*[Nd,F]*/,
+                              float* dv /*[Nd,F,3]*/, int n_dst, int n_feat, int n_rbf, int rb, int64_t n_rows,
+                              const float* s_res /*[Nd,F] or NULL*/, const float* v_res /*[Nd,F,3] or NULL*/,
+                              void* workspace, size_t workspace_bytes, void* stream);
 /* Backward.  gs / gv are the upstream gradients at the receivers (gv == NULL when dv is not
  * consumed).  Traverses the src-sorted view; writes g_phi [Ns,3F], g_v [Ns,F,3] (only if gv),
  * gWd [3F,R], gbd [3F] completely (zeros where nothing flows).  Deterministic two-stage

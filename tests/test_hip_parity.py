@@ -976,7 +976,7 @@ def test_captured_fused_decoder_replays_on_other_bead_edge_counts():
 # --------------------------------------------------------------------------- K7b / K2g: receiver groups, shared-source forward
 def _group_order_reference(dst_d, src_d, rb):
     """Restatement of the receiver-group order (include/cgvae_hip.h, K7b): positions of the dst-sorted view sorted,
-    stably, by (receiver // rb, source); meta = (slot | head << 8 | step mask << 16, next step's source); a
+    stably, by (receiver // rb, source); meta = (slot | head << 8 | last step of the group << 9 | step mask << 16, next step's source); a
     duplicated edge opens a new step."""
     E = len(dst_d)
     pos = np.lexsort((np.arange(E), src_d, dst_d // rb))
@@ -991,9 +991,10 @@ def _group_order_reference(dst_d, src_d, rb):
         mask = 0
         for u in range(q, r):
             mask |= 1 << int(dg[u] - grp[u] * rb)
-        nxt = sg[r] if r < E and grp[r] == grp[q] else sg[q]
+        more = r < E and grp[r] == grp[q]
+        nxt = sg[r] if more else sg[q]
         for u in range(q, r):
-            meta[u, 0] = int(dg[u] - grp[u] * rb) | (0x100 if u == q else 0) | (mask << 16)
+            meta[u, 0] = int(dg[u] - grp[u] * rb) | (0x100 if u == q else 0) | (0 if more else 0x200) | (mask << 16)
             meta[u, 1] = nxt
         q = r
     return pos, dg, sg, meta
@@ -1084,6 +1085,73 @@ def test_shared_source_forward_matches_fp64_and_plain_kernel(F, R, n, box, cut, 
         ((o[0] * gs).sum() + (o[1] * gv).sum()).backward()
     for x, y, name in zip(a, b, ("phi", "v", "Wd", "bd")):
         assert_close(x.grad, y.grad, "grad " + name, 1e-6)
+
+
+@pytest.mark.parametrize("wpb", [3, 2])
+@pytest.mark.parametrize("F,R,n,kind", [(600, 10, 83, "dense"), (600, 10, 332, "dense"), (130, 6, 41, "holes"), (24, 8, 10, "tiny"),
+                                        (256, 10, 64, "one_edge"), (64, 8, 29, "holes"), (600, 10, 200, "hub")])
+def test_balanced_forward_ranges_cut_groups_anywhere(F, R, n, kind, wpb, options):
+    """K2e (cgv_equi_msg_fwd_balanced): equal edge ranges per wave whatever the groups' sizes.  Against fp64 and, bit for
+    bit, against itself over repeated launches (the tickets reset themselves; the sum order of a cut group is the range
+    order, not the arrival order).  Graphs: dense; receivers without edges ahead of, between and behind the others;
+    fewer edges than ranges (most waves idle, every group cut or whole at random); one edge; one hub receiver holding
+    most edges (its group spans hundreds of ranges)."""
+    from coarsegrainingvae_amd import ops
+    gen = torch.Generator().manual_seed(F + n + wpb)
+    xyz = torch.rand(n, 3, generator=gen) * 5.0
+    if kind == "dense":
+        nbrs, _ = O.make_directed(O.get_neighbor_list(xyz, 9.0, True))
+    elif kind == "holes":                                   # receivers 0-3, a middle run and the last five have no edges
+        dst = torch.randint(4, n - 5, (40 * n,), generator=gen)
+        dst = dst[(dst < n // 2) | (dst > n // 2 + 6)]
+        nbrs = torch.stack([dst, torch.randint(0, n, (len(dst),), generator=gen)], dim=1)
+    elif kind == "tiny":
+        nbrs = torch.tensor([[2, 1], [2, 3], [3, 1], [7, 0], [7, 1], [7, 2], [7, 7]])
+    elif kind == "one_edge":
+        nbrs = torch.tensor([[37, 5]])
+    else:                                                   # hub: receiver 100 sees everybody 40 times over (duplicates: new steps)
+        hub = torch.stack([torch.full((40 * n,), 100), torch.arange(40 * n) % n], dim=1)
+        rest = torch.randint(0, n, (300, 2), generator=gen)
+        nbrs = torch.cat([hub, rest])
+    plan = EdgePlan.from_nbrs(nbrs.to(DEV), n).enable_groups(2)
+    xd = xyz.to(DEV)
+    geom = EdgeGeometry(plan, R, 6.0, pos_dst=xd, pos_src=xd)
+    E = plan.n_edges
+    phi, v = torch.randn(n, 3 * F, generator=gen), torch.randn(n, F, 3, generator=gen)
+    Wd, bd = torch.randn(3 * F, R, generator=gen), torch.randn(3 * F, generator=gen)
+    s_res, v_res = torch.randn(n, F, generator=gen), torch.randn(n, F, 3, generator=gen)
+    ds64, dv64 = _equi_message_fp64(phi, v, Wd, bd, geom.geom_g[:E].cpu(), plan.dst_g[:E].cpu().long(),
+                                    plan.src_g[:E].cpu().long(), R, geom.group_unit_offset, n)
+    args = [x.to(DEV) for x in (phi, v, Wd, bd)]
+    options.set("msg_fwd_balanced", wpb)
+    options.set("fwd_balanced", 1)
+    ds, dv = ops.equi_message(*args, plan, geom, True)
+    tol = 2e-6 if kind != "hub" else 2e-5                      # (8000 terms per sum on the hub)
+    assert_close(ds, ds64, "ds vs fp64", tol)
+    assert_close(dv, dv64, "dv vs fp64", tol)
+    ds_r, dv_r = ops.equi_message(*args, plan, geom, True, s_res.to(DEV), v_res.to(DEV))
+    assert_close(ds_r, ds64 + s_res.double(), "residual s", tol)
+    assert_close(dv_r, dv64 + v_res.double(), "residual v", tol)
+    deg = torch.bincount(plan.dst_g[:E].cpu().long(), minlength=n)
+    for i in torch.nonzero(deg == 0).flatten().tolist():       # no edges: exactly the residual (or zero)
+        assert float(ds[i].abs().max()) == 0.0 and float(dv[i].abs().max()) == 0.0
+        assert torch.equal(ds_r[i].cpu(), s_res[i]) and torch.equal(dv_r[i].cpu(), v_res[i])
+    for _ in range(5):                                          # repeated launches: same bits
+        ds2, dv2 = ops.equi_message(*args, plan, geom, True)
+        assert torch.equal(ds2, ds) and torch.equal(dv2, dv)
+    options.set("fwd_balanced", 0)                              # the per-group kernel on the same plan
+    ds_g, dv_g = ops.equi_message(*args, plan, geom, True)
+    assert_close(ds, ds_g, "ds vs per-group kernel", tol)
+    assert_close(dv, dv_g, "dv vs per-group kernel", tol)
+    # ... and with 2 - 4 blocks per (group, channel tile) whose sums meet in the workspace (cgv_equi_msg_fwd_grouped_parts)
+    for parts in (2, 3, 4):
+        options.set("fwd_parts", parts)
+        ds_p, dv_p = ops.equi_message(*args, plan, geom, True, s_res.to(DEV), v_res.to(DEV))
+        assert_close(ds_p, ds64 + s_res.double(), f"{parts} parts: residual s", tol)
+        assert_close(dv_p, dv64 + v_res.double(), f"{parts} parts: residual v", tol)
+        for _ in range(3):
+            ds_q, dv_q = ops.equi_message(*args, plan, geom, True, s_res.to(DEV), v_res.to(DEV))
+            assert torch.equal(ds_q, ds_p) and torch.equal(dv_q, dv_p)
 
 
 def test_batch_graph_uses_receiver_groups_on_dense_atom_graphs(options):

@@ -34,6 +34,10 @@ for _ in range(20):
 lib.cgv_k2g_debug_clock(None)
 print(f"{workload}: N={N} E={E} group_rb={plan.group_rb}; launch {statistics.median(s[1] for s in snaps):.1f} us (events, incl. launch overhead)")
 print("per wave of 8 sampled blocks (one per eighth of the grid), us from the block's first wave entry; median of 20 launches")
+t00 = [min(s[0][b][x][0] for b in range(8) for x in range(4)) for s in snaps]
+print("sampled blocks (block index = k * grid / 8 + 3): first wave entry / last store, us from the earliest sampled entry: " +
+      "  ".join(f"{statistics.median((min(s[0][b][x][0] for x in range(4)) - t) / hz * 1e6 for s, t in zip(snaps, t00)):.1f}/"
+                f"{statistics.median((max(s[0][b][x][5] for x in range(4)) - t) / hz * 1e6 for s, t in zip(snaps, t00)):.1f}" for b in range(8)))
 print(" block wave edges | records+rows requested | filter tile staged | edge loop done (us/edge) | partials exchanged | stored")
 for b in range(8):
     for wv in range(4):
@@ -42,4 +46,6 @@ for b in range(8):
         med = lambda i: statistics.median((c - t0) / hz * 1e6 for c, t0 in zip(col(i), t0s))
         edges = snaps[-1][0][b][wv][6]
         loop = med(3) - med(2)
-        print(f"  {b:3d} {wv:3d} {edges:6d} | {med(1):7.2f} | {med(2):7.2f} | {med(3):7.2f} ({loop / max(edges, 1):5.3f}) | {med(4):7.2f} | {med(5):7.2f}")
+        cyc = statistics.median(col(7))
+        print(f"  {b:3d} {wv:3d} {edges:6d} | {med(1):7.2f} | {med(2):7.2f} | {med(3):7.2f} ({loop / max(edges, 1):5.3f}) | {med(4):7.2f} | {med(5):7.2f}"
+              f" | {cyc / max(edges, 1):6.0f} shader cycles per edge, {cyc / max(loop, 1e-9) / 1e3:5.2f} GHz")
