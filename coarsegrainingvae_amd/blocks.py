@@ -52,7 +52,7 @@ class InvariantMessage(nn.Module):
         """(inv_dense(s_j), alias of s_j): the block's edge kernel reads the state through the alias, so that both of its
         gradients meet inside the first Dense's backward-input kernel (primitives.Dense.forward_fork)."""
         a, s_alias = self.inv_dense[0].forward_fork(s_j)
-        return self.inv_dense[1](a), s_alias
+        return self.inv_dense[1](a, sole_consumer=True), s_alias
 
     def forward(self, s_j, dist, nbrs):
         return self.inv_dense(s_j)[nbrs[:, 1]] * self.dist_embed(dist)
@@ -165,7 +165,7 @@ class ContractiveMessageBlock(nn.Module):
             a, s_alias = self.inv_dense[0].forward_fork(s_i, slot)
             if mean_init:                                # created AFTER the fork: its backward then runs before the Dense's
                 s_res, v_res = ops.segment_reduce2(s_i, v_i, plan, mean=True, slot=slot)
-            return ops.equi_message(self.inv_dense[1](a), v_i, Wd, bd, plan, geom, self.with_dv, s_res, v_res) + (s_alias,)
+            return ops.equi_message(self.inv_dense[1](a, sole_consumer=True), v_i, Wd, bd, plan, geom, self.with_dv, s_res, v_res) + (s_alias,)
         return ops.equi_message(self.inv_dense(s_i), v_i, Wd, bd, plan, geom, self.with_dv, s_res, v_res)
 
 
@@ -185,9 +185,9 @@ def contractive_pair(cblock, mblock, s_i, v_i, mapping, plan, geom, residual, me
         slot = slot if slot.usable() else None
     a_c, a_m, s_alias = tile_pair(s_i, s_i, c0, m0, slot)
     if not tile_pair_usable(a_c, a_m, c1, m1):
-        phi_c, phi_m = c1(a_c), m1(a_m)
+        phi_c, phi_m = c1(a_c), m1(a_m)                  # (plain layers: their producer is a pair node, no downstream activation)
     else:
-        phi_c, phi_m, _unused = tile_pair(a_c, a_m, c1, m1)
+        phi_c, phi_m, _unused = tile_pair(a_c, a_m, c1, m1, producer=a_c.grad_fn)   # (a_c, a_m feed nothing else)
     s_res, v_res = residual if residual is not None else (None, None)
     if mean_init:                                        # created after the node MLP: its backward runs before the MLP's
         s_res, v_res = ops.segment_reduce2(s_i, v_i, plan, mean=True, slot=slot)

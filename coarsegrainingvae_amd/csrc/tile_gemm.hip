@@ -510,6 +510,11 @@ __global__ __launch_bounds__(256, 2) void tile_fwd_ring_k(const float* __restric
 // input gradients as one product instead of a chain of two launches.  Same N, K.
 struct BwdSource { const float* g; const float* W; const float* z; int act; };
 struct BwdSecond { const float* g; const float* W; float* gx; const float* z; const float* add; int act; };   // see TileSecond
+// The output is the gradient of y = act(zo) of the layer BEFORE this one (this layer's input): with zo given the stored
+// value is the gradient of zo, gx * act'(zo) -- applied once per element here instead of by that layer's backward-input /
+// weight-gradient launches in their operand loads, where every one of the K / 64 column-tile blocks that share a row tile
+// evaluates it again (704 x 600 x 600: 17.7 against 11.2 us per product, tools/bwd_act_bench.py).
+struct OutAct { const float* z; int act; const float* z2; int act2; };      // z2 / act2: the second problem of a pair launch
 struct BcastAdd {
   const float* src;          // [n_seg, K] or NULL
   const int64_t* row2seg;    // [M] segment of every row (the CG mapping)
@@ -527,8 +532,9 @@ __global__ __launch_bounds__(64 * WAVES) void tile_bwd_input_k(const float* __re
                                                         const float* __restrict__ add = nullptr,
                                                         BcastAdd bc = BcastAdd{nullptr, nullptr, nullptr, 0},
                                                         BwdSecond s2 = BwdSecond{nullptr, nullptr, nullptr, nullptr, nullptr, 0},
-                                                        BwdSource more = BwdSource{nullptr, nullptr, nullptr, 0}) {
-  if (blockIdx.z) { g = s2.g; W = s2.W; gx = s2.gx; z = s2.z; add = s2.add; act = s2.act; bc.src = nullptr; }
+                                                        BwdSource more = BwdSource{nullptr, nullptr, nullptr, 0},
+                                                        OutAct oa = OutAct{nullptr, 0, nullptr, 0}) {
+  if (blockIdx.z) { g = s2.g; W = s2.W; gx = s2.gx; z = s2.z; add = s2.add; act = s2.act; bc.src = nullptr; oa.z = oa.z2; oa.act = oa.act2; }
   __shared__ float red[WAVES - 1][MB * 4][4][64];    // [wave-1][mb*4 + s][reg][lane]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -666,6 +672,10 @@ __global__ __launch_bounds__(64 * WAVES) void tile_bwd_input_k(const float* __re
         const int len = bc.rowptr[sg + 1] - bc.rowptr[sg];
         const float sc = bc.mean ? 1.0f / (float)(len > 1 ? len : 1) : 1.0f;
         o[0] = fmaf(b4.x, sc, o[0]); o[1] = fmaf(b4.y, sc, o[1]); o[2] = fmaf(b4.z, sc, o[2]); o[3] = fmaf(b4.w, sc, o[3]);
+      }
+      if (oa.z) {                                    // gradient of the previous layer's pre-activation (see OutAct)
+        const float4 z4 = *reinterpret_cast<const float4*>(oa.z + (size_t)m * K + kcol);
+        o[0] *= act_bwd(z4.x, oa.act); o[1] *= act_bwd(z4.y, oa.act); o[2] *= act_bwd(z4.z, oa.act); o[3] *= act_bwd(z4.w, oa.act);
       }
       *reinterpret_cast<float4*>(gx + (size_t)m * K + kcol) = make_float4(o[0], o[1], o[2], o[3]);
     }
@@ -854,7 +864,8 @@ static int tile_bwd_input_launch(const float* g, const float* z, int act, const 
                                  void* stream, const char* what, const float* add = nullptr,
                                  cgv::BcastAdd bc = cgv::BcastAdd{nullptr, nullptr, nullptr, 0},
                                  const cgv::BwdSecond* second = nullptr,
-                                 cgv::BwdSource more = cgv::BwdSource{nullptr, nullptr, nullptr, 0}) {
+                                 cgv::BwdSource more = cgv::BwdSource{nullptr, nullptr, nullptr, 0},
+                                 cgv::OutAct oa = cgv::OutAct{nullptr, 0, nullptr, 0}) {
   hipStream_t st = (hipStream_t)stream;
   const cgv::BwdSecond s2 = second ? *second : cgv::BwdSecond{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
   const unsigned np = second ? 2u : 1u;
@@ -865,19 +876,19 @@ static int tile_bwd_input_launch(const float* g, const float* z, int act, const 
   if (const int o = cgv::option(CGV_OPT_BWD_INPUT_WAVES); o > 0 && o != 32) waves = o;          // experiments only
   else if (blocks16 < 128 && N >= 1024) waves = 16;
   if (cgv::option(CGV_OPT_BWD_INPUT_WAVES) == 32)          /* A/B: 32-row tiles, 8 waves */
-    hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 8>), dim3(kt, (M + 31) / 32, np), dim3(512), 0, st, g, W, gx, M, N, K, z, act, add, bc, s2, more);
+    hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 8>), dim3(kt, (M + 31) / 32, np), dim3(512), 0, st, g, W, gx, M, N, K, z, act, add, bc, s2, more, oa);
   else if (blocks32 >= 200 && blocks32 < 512 && waves == 8)
     // 200 .. 511 32-row tiles (704 rows x 600 / 1200 columns): still 32-row tiles, with the reduction split over 8 waves --
     // half the weight re-reads of the 16-row tiles (704 x 1800 x 600: 22.9 against 25.0 us, 704 x 5400: 54.6 / 64.1;
     // at 332 rows the 16-row tiles win, 14.5 against 22.1 us: tools/gemm_shapes.py)
-    hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 8>), dim3(kt, (M + 31) / 32, np), dim3(512), 0, st, g, W, gx, M, N, K, z, act, add, bc, s2, more);
+    hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 8>), dim3(kt, (M + 31) / 32, np), dim3(512), 0, st, g, W, gx, M, N, K, z, act, add, bc, s2, more, oa);
   else if (blocks32 >= 512)               // enough 32-row tiles to fill the chip: halve the weight re-reads
-    hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 4>), dim3(kt, (M + 31) / 32, np), dim3(256), 0, st, g, W, gx, M, N, K, z, act, add, bc, s2, more);
+    hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 4>), dim3(kt, (M + 31) / 32, np), dim3(256), 0, st, g, W, gx, M, N, K, z, act, add, bc, s2, more, oa);
   else if (waves == 16)                   // few output tiles and a long reduction (96 bead rows x 5400 columns: 60 blocks):
     // 16 waves per block split it -- 60 blocks of 8 waves left three quarters of the chip idle (17.8 us per call)
-    hipLaunchKernelGGL((cgv::tile_bwd_input_k<1, 16>), dim3(kt, (M + 15) / 16, np), dim3(1024), 0, st, g, W, gx, M, N, K, z, act, add, bc, s2, more);
+    hipLaunchKernelGGL((cgv::tile_bwd_input_k<1, 16>), dim3(kt, (M + 15) / 16, np), dim3(1024), 0, st, g, W, gx, M, N, K, z, act, add, bc, s2, more, oa);
   else
-    hipLaunchKernelGGL((cgv::tile_bwd_input_k<1, 8>), dim3(kt, (M + 15) / 16, np), dim3(512), 0, st, g, W, gx, M, N, K, z, act, add, bc, s2, more);
+    hipLaunchKernelGGL((cgv::tile_bwd_input_k<1, 8>), dim3(kt, (M + 15) / 16, np), dim3(512), 0, st, g, W, gx, M, N, K, z, act, add, bc, s2, more, oa);
   return cgv::check_launch(what);
 }
 
@@ -956,6 +967,44 @@ int cgv_tile_pair_linear_bwd_input(const float* gy_a, const float* z_a, const fl
   const cgv::BwdSecond s2{gy_b, W_b, gx_b, act_b ? z_b : nullptr, add_b, act_b};
   return tile_bwd_input_launch(gy_a, act ? z_a : nullptr, act, W_a, gx_a, M, N, K, stream, "cgv_tile_pair_linear_bwd_input", add_a,
                                cgv::BcastAdd{nullptr, nullptr, nullptr, 0}, &s2);
+}
+
+/* cgv_tile_linear_bwd_input_act[_add] (add may be NULL) whose OUTPUT is multiplied by act_out'(z_out), z_out [M, K] the
+ * pre-activation of the layer that produced this layer's input: the stored gx is the gradient of that pre-activation, and
+ * the producing layer's backward then runs with act = 0 (no activation derivative in its operand loads). */
+int cgv_tile_linear_bwd_input_out(const float* gy, const float* z, const float* W, const float* add, float* gx, int M, int N,
+                                  int K, int act, const float* z_out, int act_out, void* stream) {
+  CGV_REQUIRE(gy && W && gx && z_out, "null pointer");
+  CGV_REQUIRE(act == 0 || (act >= 1 && act <= cgv::CGV_ACT_MAX && z), "act != 0 needs the saved pre-activation z");
+  CGV_REQUIRE(act_out >= 1 && act_out <= cgv::CGV_ACT_MAX, "act_out must name an activation");
+  CGV_REQUIRE(cgv_tile_supported(M, N, K), "unsupported shape (need N % 4 == 0, K % 4 == 0)");
+  CGV_REQUIRE(((((uintptr_t)gy | (uintptr_t)z | (uintptr_t)W | (uintptr_t)gx | (uintptr_t)add | (uintptr_t)z_out)) & 15) == 0,
+              "operands must be 16-byte aligned");
+  return tile_bwd_input_launch(gy, act ? z : nullptr, act, W, gx, M, N, K, stream, "cgv_tile_linear_bwd_input_out", add,
+                               cgv::BcastAdd{nullptr, nullptr, nullptr, 0}, nullptr, cgv::BwdSource{nullptr, nullptr, nullptr, 0},
+                               cgv::OutAct{z_out, act_out, nullptr, 0});
+}
+
+/* cgv_tile_pair_linear_bwd_input with the outputs multiplied by act_out_*'(z_out_*) (either may be NULL / 0: that output
+ * is stored as it is). */
+int cgv_tile_pair_linear_bwd_input_out(const float* gy_a, const float* z_a, const float* W_a, const float* add_a, float* gx_a,
+                                       const float* gy_b, const float* z_b, const float* W_b, const float* add_b, float* gx_b,
+                                       int M, int N, int K, int act_a, int act_b, const float* z_out_a, int act_out_a,
+                                       const float* z_out_b, int act_out_b, void* stream) {
+  const int act = act_a;
+  CGV_REQUIRE(gy_a && W_a && gx_a && gy_b && W_b && gx_b && gx_a != gx_b, "null pointer / aliased outputs");
+  CGV_REQUIRE((act_a == 0 || (act_a >= 1 && act_a <= cgv::CGV_ACT_MAX && z_a)) && (act_b == 0 || (act_b >= 1 && act_b <= cgv::CGV_ACT_MAX && z_b)),
+              "act != 0 needs the saved pre-activation");
+  CGV_REQUIRE((!z_out_a || (act_out_a >= 1 && act_out_a <= cgv::CGV_ACT_MAX)) && (!z_out_b || (act_out_b >= 1 && act_out_b <= cgv::CGV_ACT_MAX)),
+              "z_out needs its activation code");
+  CGV_REQUIRE(cgv_tile_supported(M, N, K), "unsupported shape (need N % 4 == 0, K % 4 == 0)");
+  CGV_REQUIRE(((((uintptr_t)gy_a | (uintptr_t)z_a | (uintptr_t)W_a | (uintptr_t)gx_a | (uintptr_t)add_a | (uintptr_t)gy_b |
+                 (uintptr_t)z_b | (uintptr_t)W_b | (uintptr_t)gx_b | (uintptr_t)add_b | (uintptr_t)z_out_a | (uintptr_t)z_out_b)) & 15) == 0,
+              "operands must be 16-byte aligned");
+  const cgv::BwdSecond s2{gy_b, W_b, gx_b, act_b ? z_b : nullptr, add_b, act_b};
+  return tile_bwd_input_launch(gy_a, act ? z_a : nullptr, act, W_a, gx_a, M, N, K, stream, "cgv_tile_pair_linear_bwd_input_out", add_a,
+                               cgv::BcastAdd{nullptr, nullptr, nullptr, 0}, &s2, cgv::BwdSource{nullptr, nullptr, nullptr, 0},
+                               cgv::OutAct{z_out_a, z_out_a ? act_out_a : 0, z_out_b, z_out_b ? act_out_b : 0});
 }
 
 int cgv_tile_linear_wgrad(const float* g, const float* x, float* gW, int M, int N, int K, int accumulate, void* stream) {

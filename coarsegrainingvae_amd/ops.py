@@ -700,14 +700,22 @@ def _dense_fwd(x, W, b, y, z, M, N, K, act, st):
               _lib.ptr(z), M, N, K, act, st)
 
 
-def _dense_bwd_input(gy, z, W, gx, M, N, K, act, st):
-    """gx = (gy * act'(z)) W: row-split kernel up to 64 rows (and for few rows x very long reductions), tile kernel above."""
+def _dense_bwd_input(gy, z, W, gx, M, N, K, act, st, z_out=None, act_out=0) -> bool:
+    """gx = (gy * act'(z)) W: row-split kernel up to 64 rows (and for few rows x very long reductions), tile kernel above.
+    ``z_out`` [M, K]: the pre-activation of the layer that produced this layer's input -- the tile kernel then stores
+    gx * act_out'(z_out) (returns True: the producing layer's backward runs without an activation); the row-split kernel has
+    no such epilogue (returns False, gx as it is)."""
     lib = _lib.load()
     if lib.cgv_skinny_supported(M, N, K) or (M <= 128 and N >= 4096 and lib.cgv_skinny_bwd_input_supported(M, N, K)):
         skinny_bwd_input(gy, z, W, gx, M, N, K, act, st)
-    else:
-        _lib.call("cgv_tile_linear_bwd_input_act", _lib.ptr(gy), _lib.ptr(z) if act else None, _lib.ptr(W), _lib.ptr(gx),
-                  M, N, K, act, st)
+        return False
+    if z_out is not None and act_out and options.HOST["act_downstream"]:
+        _lib.call("cgv_tile_linear_bwd_input_out", _lib.ptr(gy), _lib.ptr(z) if act else None, _lib.ptr(W), None, _lib.ptr(gx),
+                  M, N, K, act, _lib.ptr(z_out), int(act_out), st)
+        return True
+    _lib.call("cgv_tile_linear_bwd_input_act", _lib.ptr(gy), _lib.ptr(z) if act else None, _lib.ptr(W), _lib.ptr(gx),
+              M, N, K, act, st)
+    return False
 
 
 class _UpdateBlockFused(torch.autograd.Function):
@@ -792,8 +800,9 @@ class _UpdateBlockFused(torch.autograd.Function):
         _lib.call("cgv_update_gate_bwd", U_ptr, Vv_ptr, _lib.ptr(a), _lib.ptr(g_ds), _lib.ptr(g_dv), gU_ptr, gVv_ptr,
                   _lib.ptr(ga), n, F, 2 * F, st)
         g_a0, g_stack, g_s, g_vt, g_v = new(n, F), new(n, 2 * F), new(n, F), new(3 * n, F), new(n, F, 3)
-        _dense_bwd_input(ga, None, W1d, g_a0, n, 3 * F, F, 0, st)
-        _dense_bwd_input(g_a0, z0, W0d, g_stack, n, F, 2 * F, 1, st)
+        # (tile kernels: the second layer's product leaves g_a0 * Swish'(z0), the first layer's launches run without an activation)
+        act0 = 0 if _dense_bwd_input(ga, None, W1d, g_a0, n, 3 * F, F, 0, st, z0, 1) else 1
+        _dense_bwd_input(g_a0, z0 if act0 else None, W0d, g_stack, n, F, 2 * F, act0, st)
         _lib.call("cgv_update_norm_stack_bwd", _lib.ptr(g_stack), Vv_ptr, _lib.ptr(stack),
                   _lib.ptr(g_ds) if ctx.residual else None, _lib.ptr(g_s), gVv_ptr, n, F, 2 * F, 1, st)
         Wuv = torch.as_strided(u_w.detach(), (2 * F, F), (F, 1))
@@ -811,7 +820,7 @@ class _UpdateBlockFused(torch.autograd.Function):
         wgrad_queue.enqueue(ga, a0, None, 0, t1, tb1, acc1)
         t0, acc0, _ = _grad_target(W0, W0)
         tb0, accb0, _ = _grad_target(b0, b0)
-        wgrad_queue.enqueue(g_a0, stack, z0, 1, t0, tb0, acc0)
+        wgrad_queue.enqueue(g_a0, stack, z0 if act0 else None, act0, t0, tb0, acc0)
         # operand rows of these weights' gradient problems (trainer: rank-update layers go to the front of the arena)
         u_w._cgv_rank = v_w._cgv_rank = (3 * n, 2 * F, F)
         W1._cgv_rank, W0._cgv_rank = (n, W1.shape[0], W1.shape[1]), (n, W0.shape[0], W0.shape[1])

@@ -28,6 +28,7 @@ HOST = {
     "update_fused_fwd": 0,  # UpdateBlock forward on 17..96 bead rows: 0 (default) product + element-wise launch each (5 launches), 1 norm / gate in the epilogues of channel-group products (cgv_update_*_fwd_fused: 3 launches) -- measured SLOWER: dipeptide 2.645 / 2.675 against 2.636 / 2.637 ms, 2000 atoms 5.996 / 5.968 (a 96-row channel-group block is 900 fp32 MFMAs on one CU; the tile kernels spread the same product over the chip)
     "fwd_parts": 1,         # shared-source message forward (rb = 2): blocks per (group, channel tile), 1 (default) .. 4 (cgv_equi_msg_fwd_grouped_parts; measured level with 1 or slower)
     "fwd_balanced": 0,      # shared-source message forward (rb = 2): 0 (default) one block per (group, channel tile) (cgv_equi_msg_fwd_grouped), 1 equal edge ranges per wave on a resident grid (cgv_equi_msg_fwd_balanced) -- measured slower: chignolin 45.6 against 42.7 us, 2000 atoms 678 / 600
+    "act_downstream": 1,    # Dense(act) -> Dense chains on the tile kernels (> 64 rows): 1 the second layer's backward-input launch multiplies its output by act'(z) of the first (once per element), whose own backward then runs without an activation; 0 act'(z) in the operand loads of the first layer's backward launches (every column-tile block evaluates it again: 704 x 600 x 600 17.7 against 11.2 us)
     "decoder_dense": 0,     # full-width products of the fused decoder loop: 0 four-column blocks (cgv_decoder_dense_fwd), 1 skinny_fwd_k
 }
 _DEFAULTS = dict(HOST)

@@ -327,8 +327,11 @@ class _LinearFn(torch.autograd.Function):
     it, trainer.py) -- deferred to ONE grouped launch per step when the trainer's queue is active."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act, fork=False, slot=None):
-        """``slot`` (ops.SegmentGradSlot): a segment reduction of the same input parks its gradient there and this layer's
+    def forward(ctx, x, weight, bias, act, fork=False, slot=None, producer=None):
+        """``producer``: the ``_LinearFn`` node whose ACTIVATED output is exactly ``x`` and feeds nothing else -- this layer's
+        backward-input launch (tile kernels) then stores gx * act'(z) of that node and tells it so (``act_done``): its own
+        backward launches run without an activation (``_TilePairFn.forward`` has the two-layer form).
+        ``slot`` (ops.SegmentGradSlot): a segment reduction of the same input parks its gradient there and this layer's
         backward-input kernel adds it, spread to the rows, in its store epilogue.  ``fork=True`` returns (y, x_alias): the layer's input handed on to a second consumer (the block's message kernel /
         residual, or the next block of a chain).  Its gradient then comes back HERE and is summed with this layer's own
         input gradient in the epilogue of the backward-input product -- autograd would run a separate add launch for a
@@ -336,6 +339,10 @@ class _LinearFn(torch.autograd.Function):
         y = _LinearFn._forward(ctx, x, weight, bias, act)
         ctx.set_materialize_grads(False)
         ctx.slot = slot
+        ctx.producer = None
+        if (producer is not None and HOST_OPTION("act_downstream") and x.grad_fn is producer and ctx.mode == "tile"
+                and getattr(producer, "act", ACT_NONE) != ACT_NONE and getattr(producer, "mode", None) == "tile"):
+            ctx.producer = producer
         if slot is not None:
             slot.armed = True
         if fork:
@@ -382,9 +389,9 @@ class _LinearFn(torch.autograd.Function):
                 if _is_direct(prm) and prm._cgv_pending and ctx.needs_input_grad[1]:
                     prm.grad.zero_()
                     prm._cgv_pending = False
-            return _LinearFn._with_parked(ctx, g_alias), None, None, None, None, None
+            return _LinearFn._with_parked(ctx, g_alias), None, None, None, None, None, None
         out = _LinearFn._backward(ctx, gy, g_alias)
-        return out + (None, None)
+        return out + (None, None, None)
 
     @staticmethod
     def _with_parked(ctx, gx):
@@ -412,7 +419,7 @@ class _LinearFn(torch.autograd.Function):
     def _backward_core(ctx, gy, add):
         x, weight, z = ctx.saved_tensors
         w_param, b_param = ctx.params
-        act = ctx.act
+        act = ACT_NONE if getattr(ctx, "act_done", False) else ctx.act      # (the consuming layer already multiplied gy by act'(z))
         add2 = add.reshape(-1, add.shape[-1]) if add is not None else None
         if add2 is not None and not (add2.is_contiguous() and add2.data_ptr() % 16 == 0 and add2.dtype == torch.float32):
             add2 = add2.contiguous().float()
@@ -459,6 +466,14 @@ class _LinearFn(torch.autograd.Function):
                         _lib.call("cgv_tile_linear_bwd_input_act_add_bcast", _lib.ptr(gy2), _lib.ptr(z) if act != ACT_NONE else None,
                                   _lib.ptr(weight), _lib.ptr(add2), _lib.ptr(g_seg), _lib.ptr(slot.mapping), _lib.ptr(slot.plan.rowptr_d),
                                   int(slot.mean), _lib.ptr(gx), M, N, K, act, st)
+                        fused[0] = True
+                    elif getattr(ctx, "producer", None) is not None:
+                        # the stored gradient is the one of the producing layer's PRE-activation (see forward)
+                        prod = ctx.producer
+                        _lib.call("cgv_tile_linear_bwd_input_out", _lib.ptr(gy2), _lib.ptr(z) if act != ACT_NONE else None,
+                                  _lib.ptr(weight), _lib.ptr(add2), _lib.ptr(gx), M, N, K, act, _lib.ptr(prod.saved_tensors[2]),
+                                  int(prod.act), st)
+                        prod.act_done = True
                         fused[0] = True
                     elif add2 is not None:
                         _lib.call("cgv_tile_linear_bwd_input_act_add", _lib.ptr(gy2), _lib.ptr(z) if act != ACT_NONE else None,
@@ -603,8 +618,15 @@ class _TilePairFn(torch.autograd.Function):
     Returns (y_a, y_b, alias of x_a): hand the alias to whatever else consumes the state."""
 
     @staticmethod
-    def forward(ctx, x_a, x_b, w_a, b_a, w_b, b_b, acts, slot):
+    def forward(ctx, x_a, x_b, w_a, b_a, w_b, b_b, acts, slot, producer=None):
+        """``producer``: the ``_TilePairFn`` node whose two ACTIVATED outputs are exactly (x_a, x_b) and feed nothing else --
+        this launch's backward then multiplies its outputs by act'(z) of that node (``cgv_tile_pair_linear_bwd_input_out``)
+        and tells it so (``act_done``): its own backward launches run without an activation."""
         same = x_b is x_a
+        ctx.producer = None
+        if (producer is not None and not same and HOST_OPTION("act_downstream") and getattr(producer, "acts", None) is not None
+                and x_a.grad_fn is producer and x_b.grad_fn is producer and all(a != ACT_NONE for a in producer.acts)):
+            ctx.producer = producer
         act_a, act_b = int(acts[0]), int(acts[1])
         xa = x_a.reshape(-1, x_a.shape[-1]).contiguous()
         xb = xa if same else x_b.reshape(-1, x_b.shape[-1]).contiguous()
@@ -627,6 +649,9 @@ class _TilePairFn(torch.autograd.Function):
         xa, xb, wa, wb, za, zb = ctx.saved_tensors
         pa_w, pa_b, pb_w, pb_b = ctx.params
         (act_a, act_b), slot = ctx.acts, ctx.slot
+        done = getattr(ctx, "act_done", (False, False))     # the consuming pair already multiplied g by act'(z): see forward
+        act_a = ACT_NONE if done[0] else act_a
+        act_b = ACT_NONE if done[1] else act_b
         M, K = xa.shape
         N = wa.shape[0]
         st = _lib.stream_ptr()
@@ -685,9 +710,18 @@ class _TilePairFn(torch.autograd.Function):
         else:
             if ga is not None and gb is not None and need_a and need_b:
                 gxa, gxb = new(), new()
-                _lib.call("cgv_tile_pair_linear_bwd_input", _lib.ptr(ga), _lib.ptr(za) if act_a != ACT_NONE else None, _lib.ptr(wa), None,
-                          _lib.ptr(gxa), _lib.ptr(gb), _lib.ptr(zb) if act_b != ACT_NONE else None, _lib.ptr(wb), None, _lib.ptr(gxb),
-                          M, N, K, act_a, act_b, st)
+                prod = ctx.producer
+                if prod is not None:
+                    pz = prod.saved_tensors
+                    _lib.call("cgv_tile_pair_linear_bwd_input_out", _lib.ptr(ga), _lib.ptr(za) if act_a != ACT_NONE else None, _lib.ptr(wa),
+                              None, _lib.ptr(gxa), _lib.ptr(gb), _lib.ptr(zb) if act_b != ACT_NONE else None, _lib.ptr(wb), None,
+                              _lib.ptr(gxb), M, N, K, act_a, act_b, _lib.ptr(pz[4]), int(prod.acts[0]), _lib.ptr(pz[5]),
+                              int(prod.acts[1]), st)
+                    prod.act_done = (True, True)
+                else:
+                    _lib.call("cgv_tile_pair_linear_bwd_input", _lib.ptr(ga), _lib.ptr(za) if act_a != ACT_NONE else None, _lib.ptr(wa), None,
+                              _lib.ptr(gxa), _lib.ptr(gb), _lib.ptr(zb) if act_b != ACT_NONE else None, _lib.ptr(wb), None, _lib.ptr(gxb),
+                              M, N, K, act_a, act_b, st)
             else:
                 gxa = single(ga, za, wa, None, act_a) if (ga is not None and need_a) else None
                 gxb = single(gb, zb, wb, None, act_b) if (gb is not None and need_b) else None
@@ -715,7 +749,7 @@ class _TilePairFn(torch.autograd.Function):
                     wgrad_queue.flush()
             grads_w += [gw, gbias]
         return (gxa if need_a else None, None if ctx.same else (gxb if need_b else None), grads_w[0], grads_w[1], grads_w[2], grads_w[3],
-                None, None)
+                None, None, None)
 
 
 def _dense_act(layer):
@@ -748,9 +782,9 @@ def tile_pair_usable(x_a, x_b, la, lb) -> bool:
             and tile_pair_usable_raw(x_a, x_b, la.weight, la.bias, lb.weight, lb.bias))
 
 
-def tile_pair(x_a, x_b, la, lb, slot=None):
-    """(la(x_a), lb(x_b), alias of x_a) from one launch -- see ``_TilePairFn``."""
-    return _TilePairFn.apply(x_a, x_b, la.weight, la.bias, lb.weight, lb.bias, (_dense_act(la), _dense_act(lb)), slot)
+def tile_pair(x_a, x_b, la, lb, slot=None, producer=None):
+    """(la(x_a), lb(x_b), alias of x_a) from one launch -- see ``_TilePairFn`` (``producer``: its forward)."""
+    return _TilePairFn.apply(x_a, x_b, la.weight, la.bias, lb.weight, lb.bias, (_dense_act(la), _dense_act(lb)), slot, producer)
 
 
 def _ptr_table(tensors):
@@ -1027,7 +1061,7 @@ class _DirectSink(torch.autograd.Function):
         return _direct_grad(ctx.param, lambda t: t.copy_(g.reshape(t.shape)), lambda: g)
 
 
-def linear_fn(x, weight, bias, act, fork=False, slot=None):
+def linear_fn(x, weight, bias, act, fork=False, slot=None, producer=None):
     """``_LinearFn`` for every width.  The kernels take in / out widths that are multiples of 4; the reference takes any
     ``-n_basis`` (run_ala.py:419-461), so other widths are ZERO-PADDED here -- x by columns, W by rows and columns, b by
     entries -- run through the same kernels and sliced on output (the padded columns multiply zeros; the padded outputs are
@@ -1035,6 +1069,8 @@ def linear_fn(x, weight, bias, act, fork=False, slot=None):
     this is the compatibility path, the documented widths (512, 600) never take it."""
     N, K = weight.shape
     if (N % 4 == 0 and K % 4 == 0) or not x.is_cuda:
+        if producer is not None:
+            return _LinearFn.apply(x, weight, bias, act, fork, slot, producer)
         return _LinearFn.apply(x, weight, bias, act, fork, slot) if (fork or slot is not None) else _LinearFn.apply(x, weight, bias, act)
     if x.shape[0:-1].numel() == 0:
         y = x.new_zeros(x.shape[:-1] + (N,))
@@ -1115,10 +1151,14 @@ class Dense(nn.Linear):
             return linear_fn(inputs, self.weight, self.bias, ACT_SWISH, True, slot)
         return self.forward(inputs), inputs
 
-    def forward(self, inputs):
+    def forward(self, inputs, sole_consumer: bool = False):
+        """``sole_consumer=True``: ``inputs`` is the output of an activating ``Dense`` and feeds nothing but this layer (the
+        second layer of an ``inv_dense`` chain) -- see ``_LinearFn.forward(producer=...)``."""
         if isinstance(self.activation, Swish) and self.dropout_rate == 0.0:
             return linear_fn(inputs, self.weight, self.bias, ACT_SWISH)      # bias + Swish fused
-        y = linear_fn(inputs, self.weight, self.bias, ACT_NONE)
+        producer = inputs.grad_fn if (sole_consumer and torch.is_tensor(inputs) and inputs.is_cuda and self.dropout_rate == 0.0
+                                      and type(inputs.grad_fn).__name__ == "_LinearFnBackward") else None
+        y = linear_fn(inputs, self.weight, self.bias, ACT_NONE, producer=producer)
         if self.dropout_rate > 0.0:
             y = self.dropout(y)
         return self.activation(y) if self.activation is not None else y

@@ -612,6 +612,17 @@ int cgv_tile_pair_linear_fwd(const float* x_a, const float* W_a, const float* bi
 int cgv_tile_pair_linear_bwd_input(const float* gy_a, const float* z_a, const float* W_a, const float* add_a, float* gx_a,
                                    const float* gy_b, const float* z_b, const float* W_b, const float* add_b, float* gx_b, int M,
                                    int N, int K, int act_a, int act_b, void* stream);
+/* The two entry points above whose OUTPUT is multiplied by act_out'(z_out) -- z_out [M, K] = the pre-activation of the layer
+ * that produced this layer's input (modules.py:103-114: y = act(z)), so the stored gx is that layer's g = gy * act'(z)
+ * and its own backward runs with act = 0.  Applied once per element in the store epilogue instead of in the operand loads
+ * of the producing layer's backward-input and weight-gradient launches (every column-tile block of a row tile evaluates
+ * it again there).  add may be NULL; in the pair form either z_out may be NULL (that output is stored as it is). */
+int cgv_tile_linear_bwd_input_out(const float* gy, const float* z, const float* W, const float* add, float* gx, int M, int N,
+                                  int K, int act, const float* z_out, int act_out, void* stream);
+int cgv_tile_pair_linear_bwd_input_out(const float* gy_a, const float* z_a, const float* W_a, const float* add_a, float* gx_a,
+                                       const float* gy_b, const float* z_b, const float* W_b, const float* add_b, float* gx_b,
+                                       int M, int N, int K, int act_a, int act_b, const float* z_out_a, int act_out_a,
+                                       const float* z_out_b, int act_out_b, void* stream);
 /* gx = add + (gy_a * act_a'(z_a)) W_a + (gy_b * act_b'(z_b)) W_b [+ seg_grad spread over the rows]: the input gradient of two
  * layers of one shape that read the SAME input, as one product with two sources (the first Dense of ContractiveMessageBlock i
  * and of EquiMessageBlock i + 1, cgvae.py:286-305); add / seg_grad may be NULL, seg_* as in

@@ -1591,6 +1591,86 @@ def test_rank_update_training_matches_materialised_gradients(captured):
         assert torch.allclose(p0[k], p1[k], rtol=1e-4, atol=1e-6), k
 
 
+@pytest.mark.parametrize("captured", [False, True])
+@pytest.mark.parametrize("workload,F,enc", [("chignolin", 64, 2), ("dipeptide", 32, 3)])
+def test_activation_derivative_applied_downstream_trains_alike(workload, F, enc, captured, options):
+    """``act_downstream`` 1: the second layer of a Dense(Swish) -> Dense chain on the tile kernels stores its input
+    gradient times Swish'(z) of the first (cgv_tile_linear_bwd_input_out / cgv_tile_pair_linear_bwd_input_out: encoder
+    pair launches, unpaired message / contractive blocks, the atom-level update blocks), whose backward launches then run
+    without an activation -- against 0 (Swish'(z) in the first layer's operand loads): the same products of the same
+    operands, so losses, norms and parameters agree to rounding of the weight-gradient sums."""
+    from coarsegrainingvae_amd.trainer import Trainer
+    from coarsegrainingvae_amd import primitives
+    w = cg.data.WORKLOADS[workload]
+    calls = {"n": 0}
+    real = cg._lib.call
+
+    def counting(name, *a, **k):
+        if name in ("cgv_tile_linear_bwd_input_out", "cgv_tile_pair_linear_bwd_input_out"):
+            calls["n"] += 1
+        return real(name, *a, **k)
+
+    def run(flag):
+        options.set("act_downstream", flag)
+        model = cg.build_model(F, w["n_rbf"], w["atom_cutoff"], w["cg_cutoff"], enc, 2, w["n_cgs"], seed=123).to(DEV)
+        batch = cg.synthetic_batch(workload, seed=4, device=DEV)
+        tr = Trainer(model, lr=1e-3, beta=w["beta"], gamma=w["gamma"])
+        gen = torch.Generator(device=DEV).manual_seed(1)
+        eps = torch.randn(batch["CG_nxyz"].shape[0], F, device=DEV, generator=gen)
+        losses = [float(tr.step(batch, eps=eps)) for _ in range(3)]
+        if captured:
+            tr.capture(batch, eps=eps, warmup=0, train=True)
+        losses += [float(tr.step(batch, eps=eps)) for _ in range(3)]
+        return losses, {k: v.clone() for k, v in model.state_dict().items()}, float(tr.state[1])
+
+    l0, p0, n0 = run(0)
+    cg._lib.call = counting
+    try:
+        l1, p1, n1 = run(1)
+    finally:
+        cg._lib.call = real
+    assert calls["n"] >= 3 * (enc + 1)                       # the epilogue form did run (every eager step, every chain)
+    assert np.allclose(l0, l1, rtol=2e-6), (l0, l1)
+    assert abs(n0 - n1) <= 2e-6 * n0
+    for k in p0:
+        assert torch.allclose(p0[k], p1[k], rtol=1e-5, atol=1e-7), k
+
+
+@pytest.mark.parametrize("M,N,K,act_out,with_add", [(332, 1800, 600, 1, False), (704, 600, 1200, 1, True), (97, 604, 52, 2, False)])
+def test_backward_input_with_the_downstream_activation_epilogue_vs_fp64(M, N, K, act_out, with_add):
+    """cgv_tile_linear_bwd_input_out / cgv_tile_pair_linear_bwd_input_out: gx = (add + (gy * act'(z)) W) * act_out'(z_out),
+    ragged tiles, with and without the added gradient, one NULL z_out in the pair form."""
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    rnd = lambda *sh: torch.randn(*sh, device=DEV, generator=g)
+    gy, z, W, zo, add = rnd(M, N), rnd(M, N), rnd(N, K) / N ** 0.5, rnd(M, K), rnd(M, K)
+    gy2, z2, W2, zo2 = rnd(M, N), rnd(M, N), rnd(N, K) / N ** 0.5, rnd(M, K)
+
+    def act_bwd(t, code):
+        t = t.double()
+        if code == 1:
+            sg = torch.sigmoid(t)
+            return sg * (1 + t * (1 - sg))
+        return 1 - torch.tanh(t) ** 2
+
+    ref = ((gy.double() * act_bwd(z, 1)) @ W.double() + (add.double() if with_add else 0)) * act_bwd(zo, act_out)
+    gx = torch.empty(M, K, device=DEV)
+    cg._lib.call("cgv_tile_linear_bwd_input_out", cg._lib.ptr(gy), cg._lib.ptr(z), cg._lib.ptr(W), cg._lib.ptr(add) if with_add else None,
+                 cg._lib.ptr(gx), M, N, K, 1, cg._lib.ptr(zo), act_out, cg._lib.stream_ptr())
+    assert_close(gx, ref, "single", 5e-6)
+    ref2 = gy2.double() @ W2.double()                        # second problem: no activations at all, NULL z_out
+    ref1 = (gy.double() @ W.double()) * act_bwd(zo, act_out)
+    ga, gb = torch.empty(M, K, device=DEV), torch.empty(M, K, device=DEV)
+    cg._lib.call("cgv_tile_pair_linear_bwd_input_out", cg._lib.ptr(gy), None, cg._lib.ptr(W), None, cg._lib.ptr(ga), cg._lib.ptr(gy2), None,
+                 cg._lib.ptr(W2), None, cg._lib.ptr(gb), M, N, K, 0, 0, cg._lib.ptr(zo), act_out, None, 0, cg._lib.stream_ptr())
+    assert_close(ga, ref1, "pair a", 5e-6)
+    assert_close(gb, ref2, "pair b", 5e-6)
+    cg._lib.call("cgv_tile_pair_linear_bwd_input_out", cg._lib.ptr(gy), cg._lib.ptr(z), cg._lib.ptr(W), None, cg._lib.ptr(ga), cg._lib.ptr(gy2),
+                 cg._lib.ptr(z2), cg._lib.ptr(W2), None, cg._lib.ptr(gb), M, N, K, 1, 1, cg._lib.ptr(zo), act_out, cg._lib.ptr(zo2), 1,
+                 cg._lib.stream_ptr())
+    assert_close(ga, ((gy.double() * act_bwd(z, 1)) @ W.double()) * act_bwd(zo, act_out), "pair a, both activations", 5e-6)
+    assert_close(gb, ((gy2.double() * act_bwd(z2, 1)) @ W2.double()) * act_bwd(zo2, 1), "pair b, both activations", 5e-6)
+
+
 @pytest.mark.parametrize("shape", [(1500, 1400, 600, 1), (1411, 1796, 52, 0), (2000, 1800, 600, 2)])
 def test_tile_forward_lds_staged_kernel_vs_fp64(shape):
     """cgv_tile_linear_fwd on shapes with >= 448 output tiles of 64 x 64 takes the LDS-staged kernel (tile_fwd_lds_k):
@@ -2482,7 +2562,9 @@ def test_encoder_node_mlps_as_pair_launches_equal_the_layer_by_layer_path(worklo
     (H0, h0, g0, c0), (H1, h1, g1, c1) = outs
     n_pairs = layers - 1
     assert c1.count("cgv_tile_pair_linear_fwd") == 2 * n_pairs and "cgv_tile_pair_linear_fwd" not in c0
-    assert c1.count("cgv_tile_pair_linear_bwd_input") == n_pairs
+    # (with act_downstream the second layers' launch is the _out form: Swish' of the first layers in its store epilogue)
+    assert c1.count("cgv_tile_pair_linear_bwd_input") + c1.count("cgv_tile_pair_linear_bwd_input_out") == n_pairs
+    assert c1.count("cgv_tile_pair_linear_bwd_input_out") == n_pairs
     assert len(c1) == len(c0) - 4 * n_pairs, (len(c0), len(c1))                  # two forward launches and two backward launches per pair
     assert "cgv_segment_broadcast" not in c1                                      # the bead-mean gradient still rides an epilogue
     assert torch.equal(H1, H0) and torch.equal(h1, h0)
