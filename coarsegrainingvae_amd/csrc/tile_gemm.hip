@@ -121,17 +121,18 @@ __global__ __launch_bounds__(64 * QM * QN * KW) void tile_fwd_k(const float* __r
       acc[1][0] = CGV_MFMA(x1.w, w0.w, acc[1][0]); acc[1][1] = CGV_MFMA(x1.w, w1.w, acc[1][1]);
     }
   }
+  // sub-tile t = kq = (mb, nb) is finished by wave kq: lane holds y[m0 + 16 mb + 4 q + r][n0 + 16 nb + i].  Its bias is
+  // requested ahead of the barrier (behind it the load is one more exposed round trip at the end of every launch)
+  const int t = kq & 3, mb = t >> 1, nb = t & 1;
+  const int n = n0 + 16 * nb + i;
+  const float bv = (bias && kq < 4 && n < N) ? bias[n] : 0.f;
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[quad][kq][t][r][lane] = acc[t >> 1][t & 1][r];
+    for (int r = 0; r < 4; ++r) red[quad][kq][tt][r][lane] = acc[tt >> 1][tt & 1][r];
   __syncthreads();
   if (kq >= 4) return;
-  // sub-tile t = kq = (mb, nb): lane holds y[m0 + 16 mb + 4 q + r][n0 + 16 nb + i]
-  const int t = kq, mb = t >> 1, nb = t & 1;
-  const int n = n0 + 16 * nb + i;
   if (n >= N) return;
-  const float bv = bias ? bias[n] : 0.f;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int m = m0 + 16 * mb + 4 * q + r;
@@ -639,6 +640,23 @@ __global__ __launch_bounds__(64 * WAVES) void tile_bwd_input_k(const float* __re
     }
   }
   }
+  // what the store epilogue adds / multiplies is requested HERE by the wave that stores, ahead of the barrier: behind it
+  // each would be one more exposed round trip at the end of a launch of 60 - 220 blocks (96 x 1800 x 600 with the
+  // downstream activation: 19.4 us with the loads in the epilogue against 16.0 without the epilogue's work)
+  // (16-row tiles only: with 32-row tiles the 64 extra registers take the kernel from 123 to 134 and cost it its second
+  // resident block per CU; those launches have 220+ blocks and hide the tail behind each other)
+  constexpr bool PRE = MB == 1;
+  float4 pre_add[MB][4], pre_z[MB][4];
+  if (PRE && wave == 0 && kok && (add || oa.z)) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const size_t at = (size_t)min(m0 + 16 * mb + 4 * q + r, M - 1) * K + kcol;
+        if (add) pre_add[mb][r] = *reinterpret_cast<const float4*>(add + at);
+        if (oa.z) pre_z[mb][r] = *reinterpret_cast<const float4*>(oa.z + at);
+      }
+  }
   if (wave > 0) {
 #pragma unroll
     for (int t = 0; t < MB * 4; ++t)
@@ -663,7 +681,7 @@ __global__ __launch_bounds__(64 * WAVES) void tile_bwd_input_k(const float* __re
         for (int w = 0; w < WAVES - 1; ++w) o[s] += red[w][t][r][lane];
       }
       if (add) {                                     // a second gradient of the same input (blocks.py: fork of the first Dense)
-        const float4 a4 = *reinterpret_cast<const float4*>(add + (size_t)m * K + kcol);
+        const float4 a4 = PRE ? pre_add[mb][r] : *reinterpret_cast<const float4*>(add + (size_t)m * K + kcol);
         o[0] += a4.x; o[1] += a4.y; o[2] += a4.z; o[3] += a4.w;
       }
       if (bc.src) {                                  // ... and a third, one row per segment of the rows
@@ -674,7 +692,7 @@ __global__ __launch_bounds__(64 * WAVES) void tile_bwd_input_k(const float* __re
         o[0] = fmaf(b4.x, sc, o[0]); o[1] = fmaf(b4.y, sc, o[1]); o[2] = fmaf(b4.z, sc, o[2]); o[3] = fmaf(b4.w, sc, o[3]);
       }
       if (oa.z) {                                    // gradient of the previous layer's pre-activation (see OutAct)
-        const float4 z4 = *reinterpret_cast<const float4*>(oa.z + (size_t)m * K + kcol);
+        const float4 z4 = PRE ? pre_z[mb][r] : *reinterpret_cast<const float4*>(oa.z + (size_t)m * K + kcol);
         o[0] *= act_bwd(z4.x, oa.act); o[1] *= act_bwd(z4.y, oa.act); o[2] *= act_bwd(z4.z, oa.act); o[3] *= act_bwd(z4.w, oa.act);
       }
       *reinterpret_cast<float4*>(gx + (size_t)m * K + kcol) = make_float4(o[0], o[1], o[2], o[3]);
