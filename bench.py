@@ -785,6 +785,25 @@ def main():
                             timing="48 launches between two HIP events on the launch stream, cycling over %d different "
                                    "plans / record sets / operand sets (no launch re-reads its own inputs from L2)" % (n_rot + 1))
             roofline["hbm"].update(achieved_GBps=by / (us * 1e-6) / 1e9, frac=by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS)
+            # The peak above is the 2.4 GHz figure; under packed-FMA load the chip sustains less (DVFS).  Measured live:
+            # shader cycles against wall-clock ticks of one wave while 4 waves per SIMD issue packed FMAs back to back.
+            try:
+                probe = torch.zeros(2, dtype=torch.int64, device=dev)
+                sink = torch.zeros(1, dtype=torch.float32, device=dev)
+                n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+                for _ in range(3):
+                    cg._lib.call("cgv_sustained_clock_probe", probe.data_ptr(), sink.data_ptr(), 4 * n_cu, 600, cg._lib.stream_ptr())
+                torch.cuda.synchronize()
+                cyc, ticks = (int(x) for x in probe.tolist())
+                ghz = cyc / (ticks / cg._lib.load().cgv_timestamp_hz()) / 1e9
+                roofline["sustained_clock"] = {
+                    "ghz_under_packed_fma": round(ghz, 3), "peak_ghz": 2.4,
+                    "peak_at_sustained_clock": round(F32_PEAK_TFLOPS * ghz / 2.4, 1),
+                    "frac_at_sustained_clock": round(roofline["frac"] * 2.4 / ghz, 4),
+                    "how": "cgv_sustained_clock_probe: s_memtime / s_memrealtime over ~45 us of v_pk_fma_f32 on every SIMD; "
+                           "the kernel's own waves read 1.67-1.85 GHz (profiles/r05_k2g_shader_cycles.txt)"}
+            except Exception as e:                                            # measurement only: never fails the line
+                roofline["sustained_clock"] = {"error": str(e)[:200]}
             c = committed.get("message_forward")
             if c and fresh("committed_kernel_times.message_forward", c):
                 roofline["rocprofv3_committed"] = c      # {"avg_us": .., "source": "profiles/..."} of the same command

@@ -30,6 +30,7 @@ PROTOTYPES = {
     "cgv_last_error_string": (C.c_char_p, []),
     "cgv_timestamp": (_i, [_p, _p]),
     "cgv_timestamp_hz": (_i, []),
+    "cgv_sustained_clock_probe": (_i, [_p, _p, _i, _i, _p]),
     "cgv_set_option": (_i, [_i, _i]),
     "cgv_get_option": (_i, [_i]),
     "cgv_reset_options": (_i, []),

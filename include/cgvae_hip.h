@@ -92,6 +92,9 @@ enum {
 /* Measurement: store the GPU wall clock (cgv_timestamp_hz ticks per second) into *slot, in stream order; capturable. */
 int cgv_timestamp(uint64_t* slot /*device*/, void* stream);
 int cgv_timestamp_hz(void);
+/* Measurement: the shader clock sustained under packed fp32 FMAs on `blocks` x 4 waves: out[0] = shader cycles, out[1] =
+ * wall-clock ticks of one wave's span of iters x 32 FMAs (the fused message forward's peak is quoted at 2.4 GHz; it runs at this). */
+int cgv_sustained_clock_probe(uint64_t* out /*device [2]*/, float* sink /*device [1]*/, int blocks, int iters, void* stream);
 int cgv_set_option(int option, int value);   /* 0, or CGV_E_BADARG for an unknown option */
 int cgv_get_option(int option);              /* current value (INT32_MIN for an unknown option) */
 int cgv_reset_options(void);                 /* every option back to its default */
