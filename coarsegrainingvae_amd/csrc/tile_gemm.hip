@@ -536,7 +536,7 @@ __global__ __launch_bounds__(64 * WAVES) void tile_bwd_input_k(const float* __re
                                                         BwdSource more = BwdSource{nullptr, nullptr, nullptr, 0},
                                                         OutAct oa = OutAct{nullptr, 0, nullptr, 0}) {
   if (blockIdx.z) { g = s2.g; W = s2.W; gx = s2.gx; z = s2.z; add = s2.add; act = s2.act; bc.src = nullptr; oa.z = oa.z2; oa.act = oa.act2; }
-  __shared__ float red[WAVES - 1][MB * 4][4][64];    // [wave-1][mb*4 + s][reg][lane]
+  __shared__ float red[WAVES][MB * 4][4][64];        // [wave][mb*4 + s][reg][lane]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 15, q = lane >> 4;
@@ -640,63 +640,64 @@ __global__ __launch_bounds__(64 * WAVES) void tile_bwd_input_k(const float* __re
     }
   }
   }
-  // what the store epilogue adds / multiplies is requested HERE by the wave that stores, ahead of the barrier: behind it
-  // each would be one more exposed round trip at the end of a launch of 60 - 220 blocks (96 x 1800 x 600 with the
-  // downstream activation: 19.4 us with the loads in the epilogue against 16.0 without the epilogue's work)
-  // (16-row tiles only: with 32-row tiles the 64 extra registers take the kernel from 123 to 134 and cost it its second
-  // resident block per CU; those launches have 220+ blocks and hide the tail behind each other)
-  constexpr bool PRE = MB == 1;
-  float4 pre_add[MB][4], pre_z[MB][4];
-  if (PRE && wave == 0 && kok && (add || oa.z)) {
+  // The tile is FINISHED by as many waves as it has (m-block, accumulator row) pairs -- wave c takes pair c, c + WAVES, ..:
+  // it adds the WAVES partial sums of its 4 output columns (wave order: the same sum as ever) and runs the store epilogue.
+  // With wave 0 finishing the whole tile alone (rounds 1-5) every launch ended in a serial tail of (WAVES - 1) x 16 MB LDS
+  // reads and adds per lane plus, since the downstream activation, 16 MB exp / rcp evaluations: 41 -> 49 us on the 440-block
+  // pair launch of dipeptide.  What the epilogue adds / multiplies is requested by the finishing wave ahead of the barrier
+  // (one float4 each now): behind it each would be one more exposed round trip at the end of the launch.
+  constexpr int PAIRS = MB * 4, PER = (PAIRS + WAVES - 1) / WAVES;
+  float4 pre_add[PER], pre_z[PER];
+  if (kok && (add || oa.z)) {
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const size_t at = (size_t)min(m0 + 16 * mb + 4 * q + r, M - 1) * K + kcol;
-        if (add) pre_add[mb][r] = *reinterpret_cast<const float4*>(add + at);
-        if (oa.z) pre_z[mb][r] = *reinterpret_cast<const float4*>(oa.z + at);
+    for (int u = 0; u < PER; ++u) {
+      const int c = wave + u * WAVES;
+      if (c < PAIRS) {
+        const size_t at = (size_t)min(m0 + 16 * (c >> 2) + 4 * q + (c & 3), M - 1) * K + kcol;
+        if (add) pre_add[u] = *reinterpret_cast<const float4*>(add + at);
+        if (oa.z) pre_z[u] = *reinterpret_cast<const float4*>(oa.z + at);
       }
+    }
   }
-  if (wave > 0) {
 #pragma unroll
-    for (int t = 0; t < MB * 4; ++t)
+  for (int t = 0; t < MB * 4; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) red[wave - 1][t][r][lane] = acc[t >> 2][t & 3][r];
-  }
+    for (int r = 0; r < 4; ++r) red[wave][t][r][lane] = acc[t >> 2][t & 3][r];
   __syncthreads();
-  if (wave != 0 || !kok) return;
+  if (!kok) return;
   // D_s of m-block mb: lane holds gx[m0 + 16 mb + 4 q + r][k0 + 4 j + s] -> one float4 (s = 0..3) per r
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb)
+  for (int u = 0; u < PER; ++u) {
+    const int c = wave + u * WAVES;
+    if (c >= PAIRS) break;                           // wave-uniform
+    const int mb = c >> 2, r = c & 3;
+    const int m = m0 + 16 * mb + 4 * q + r;
+    if (m >= M) continue;
+    float o[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = m0 + 16 * mb + 4 * q + r;
-      if (m >= M) continue;
-      float o[4];
+    for (int sI = 0; sI < 4; ++sI) {
+      const int t = mb * 4 + sI;
+      o[sI] = red[0][t][r][lane];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int t = mb * 4 + s;
-        o[s] = acc[mb][s][r];
-#pragma unroll
-        for (int w = 0; w < WAVES - 1; ++w) o[s] += red[w][t][r][lane];
-      }
-      if (add) {                                     // a second gradient of the same input (blocks.py: fork of the first Dense)
-        const float4 a4 = PRE ? pre_add[mb][r] : *reinterpret_cast<const float4*>(add + (size_t)m * K + kcol);
-        o[0] += a4.x; o[1] += a4.y; o[2] += a4.z; o[3] += a4.w;
-      }
-      if (bc.src) {                                  // ... and a third, one row per segment of the rows
-        const int sg = (int)bc.row2seg[m];
-        const float4 b4 = *reinterpret_cast<const float4*>(bc.src + (size_t)sg * K + kcol);
-        const int len = bc.rowptr[sg + 1] - bc.rowptr[sg];
-        const float sc = bc.mean ? 1.0f / (float)(len > 1 ? len : 1) : 1.0f;
-        o[0] = fmaf(b4.x, sc, o[0]); o[1] = fmaf(b4.y, sc, o[1]); o[2] = fmaf(b4.z, sc, o[2]); o[3] = fmaf(b4.w, sc, o[3]);
-      }
-      if (oa.z) {                                    // gradient of the previous layer's pre-activation (see OutAct)
-        const float4 z4 = PRE ? pre_z[mb][r] : *reinterpret_cast<const float4*>(oa.z + (size_t)m * K + kcol);
-        o[0] *= act_bwd(z4.x, oa.act); o[1] *= act_bwd(z4.y, oa.act); o[2] *= act_bwd(z4.z, oa.act); o[3] *= act_bwd(z4.w, oa.act);
-      }
-      *reinterpret_cast<float4*>(gx + (size_t)m * K + kcol) = make_float4(o[0], o[1], o[2], o[3]);
+      for (int w = 1; w < WAVES; ++w) o[sI] += red[w][t][r][lane];
     }
+    if (add) {                                       // a second gradient of the same input (blocks.py: fork of the first Dense)
+      const float4 a4 = pre_add[u];
+      o[0] += a4.x; o[1] += a4.y; o[2] += a4.z; o[3] += a4.w;
+    }
+    if (bc.src) {                                    // ... and a third, one row per segment of the rows
+      const int sg = (int)bc.row2seg[m];
+      const float4 b4 = *reinterpret_cast<const float4*>(bc.src + (size_t)sg * K + kcol);
+      const int len = bc.rowptr[sg + 1] - bc.rowptr[sg];
+      const float sc = bc.mean ? 1.0f / (float)(len > 1 ? len : 1) : 1.0f;
+      o[0] = fmaf(b4.x, sc, o[0]); o[1] = fmaf(b4.y, sc, o[1]); o[2] = fmaf(b4.z, sc, o[2]); o[3] = fmaf(b4.w, sc, o[3]);
+    }
+    if (oa.z) {                                      // gradient of the previous layer's pre-activation (see OutAct)
+      const float4 z4 = pre_z[u];
+      o[0] *= act_bwd(z4.x, oa.act); o[1] *= act_bwd(z4.y, oa.act); o[2] *= act_bwd(z4.z, oa.act); o[3] *= act_bwd(z4.w, oa.act);
+    }
+    *reinterpret_cast<float4*>(gx + (size_t)m * K + kcol) = make_float4(o[0], o[1], o[2], o[3]);
+  }
 }
 
 // ------------------------------------------------------------------ wgrad
