@@ -171,7 +171,7 @@ __device__ __forceinline__ void skinny_bwd_input_body(const int bx /* block inde
                                                       float* __restrict__ g_dense = nullptr) {
   // g stage [16 MB rows][BI_LD], then the wave reduction: up to 4 row blocks all three partner waves deposit at once,
   // beyond that (MB 5..8: 65-128 rows) one wave at a time through a third of the space
-  constexpr int SM_RED = (MB <= 4 ? 3 : 1) * MB * 16 * 64, SM_G = MB * 16 * BI_LD;
+  constexpr int SM_RED = (MB <= 4 ? 4 : 1) * MB * 16 * 64, SM_G = MB * 16 * BI_LD;
   __shared__ __attribute__((aligned(16))) float sm[SM_RED > SM_G ? SM_RED : SM_G];
   const int kt = bx % KT, ns = bx / KT;
   const int lane = threadIdx.x & 63;
@@ -283,30 +283,34 @@ __device__ __forceinline__ void skinny_bwd_input_body(const int bx /* block inde
   }
   __syncthreads();
   float4 tot[MB][4];                                                       // [mb][r] = gx[16 mb + 4 q + r][kcol .. +3]
+  // Up to 4 row blocks: every wave deposits its partial sums and wave w FINISHES row block w (sums the four partials in
+  // wave order -- the same sum as ever -- and stores) instead of wave 0 finishing all of them alone: 192 LDS reads and
+  // adds per lane at the end of every launch at 64 rows (the tile kernels' tail of rounds 1-5, see tile_bwd_input_k).
+  constexpr bool SHARED_FINISH = MB <= 4;
   if constexpr (MB <= 4) {
-    if (wave > 0) {
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) sm[((((wave - 1) * MB + mb) * 4 + r) * 4 + c) * 64 + lane] = acc[mb][c][r];
-    }
-    __syncthreads();
-    if (wave != 0) return;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sm[(((wave * MB + mb) * 4 + r) * 4 + c) * 64 + lane] = acc[mb][c][r];
+    __syncthreads();
+    if (wave >= MB) return;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      if (mb != wave) continue;                                            // wave-uniform
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float t[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          t[c] = acc[mb][c][r];
+          t[c] = sm[(((0 * MB + mb) * 4 + r) * 4 + c) * 64 + lane];
 #pragma unroll
-          for (int w = 0; w < 3; ++w) t[c] += sm[(((w * MB + mb) * 4 + r) * 4 + c) * 64 + lane];
+          for (int w = 1; w < 4; ++w) t[c] += sm[(((w * MB + mb) * 4 + r) * 4 + c) * 64 + lane];
         }
         tot[mb][r] = make_float4(t[0], t[1], t[2], t[3]);
       }
+    }
   } else {
     for (int w = 1; w < 4; ++w) {                                          // waves 1, 2, 3 in turn (same summation order)
       if (wave == w) {
@@ -337,22 +341,26 @@ __device__ __forceinline__ void skinny_bwd_input_body(const int bx /* block inde
   if (NS > 1 || (part && !gx)) {    // row slices meet in the next launch on the stream (reduce kernel or a SliceSum consumer)
     float* mine = part + ((size_t)ns * M) * K;
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
+    for (int mb = 0; mb < MB; ++mb) {
+      if (SHARED_FINISH && mb != wave) continue;                           // wave-uniform: this wave's row block
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = mb * 16 + 4 * q + r;
         if (m < M && kok) *reinterpret_cast<float4*>(mine + (size_t)m * K + kcol) = tot[mb][r];
       }
+    }
     return;
   }
   if (!kok) return;
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb)
+  for (int mb = 0; mb < MB; ++mb) {
+    if (SHARED_FINISH && mb != wave) continue;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int m = mb * 16 + 4 * q + r;
       if (m < M) *reinterpret_cast<float4*>(gx + (size_t)m * K + kcol) = tot[mb][r];
     }
+  }
 }
 
 template <int MB, bool LAZY = false>
