@@ -143,6 +143,7 @@ PROTOTYPES = {
     "cgv_tile_linear_bwd_input_sum2": (_i, [_p] * 10 + [_i, _p, _i, _i, _i, _i, _i, _p]),
     "cgv_segment_reduce2": (_i, [_p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _p]),
     "cgv_skinny_linear_bwd_input_add": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
+    "cgv_skinny_linear_bwd_input_out": (_i, [_p] * 5 + [_i, _i, _i, _i, _p, _i, _p, _sz, _p]),
     "cgv_tile_linear_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "cgv_wgrad_record_bytes": (_i, []),
     "cgv_wgrad_plan": (_i, [_i, _i, _i, _p, _p, _p]),

@@ -388,9 +388,12 @@ __global__ __launch_bounds__(256) void skinny_bwd_input_pair_k(BiPair p, int M, 
 
 // gx[i] = sum_p part[p][i] (i over M*K/4 float4s), p ascending: deterministic.  4 lanes share one output
 // float4 and take every 4th slice, then combine by two xor-shuffles.
+// z_out: the stored sum is multiplied by act_out'(z_out) -- the gradient of the pre-activation of the layer that produced
+// this product's input (see OutAct in tile_gemm.hip: that layer's own backward then runs without an activation).
 __global__ __launch_bounds__(256) void skinny_bwd_input_reduce_k(const float* __restrict__ part, float* __restrict__ gx,
                                                                  int n4, int NS, const float* __restrict__ base = nullptr,
-                                                                 long long slice_stride4 = 0) {
+                                                                 long long slice_stride4 = 0,
+                                                                 const float* __restrict__ z_out = nullptr, int act_out = 0) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   const int i = t >> 2, sub = t & 3;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -416,7 +419,13 @@ __global__ __launch_bounds__(256) void skinny_bwd_input_reduce_k(const float* __
     acc.x += __shfl_xor(acc.x, d); acc.y += __shfl_xor(acc.y, d);
     acc.z += __shfl_xor(acc.z, d); acc.w += __shfl_xor(acc.w, d);
   }
-  if (i < n4 && sub == 0) reinterpret_cast<float4*>(gx)[i] = acc;
+  if (i < n4 && sub == 0) {
+    if (z_out) {
+      const float4 z4 = reinterpret_cast<const float4*>(z_out)[i];
+      acc.x *= act_bwd(z4.x, act_out); acc.y *= act_bwd(z4.y, act_out); acc.z *= act_bwd(z4.z, act_out); acc.w *= act_bwd(z4.w, act_out);
+    }
+    reinterpret_cast<float4*>(gx)[i] = acc;
+  }
 }
 
 // row slicing of one bwd_input problem: ~320 blocks when a workspace is available
@@ -1934,12 +1943,14 @@ static void launch_fwd(dim3 grid, int waves, hipStream_t st, const float* x, con
 }
 template <int MB>
 static void launch_bwd_input(hipStream_t st, const float* gy, const float* z, const float* W, float* gx, float* part,
-                             int M, int N, int K, int act, int KT, int NS, int rpb, const float* add = nullptr) {
+                             int M, int N, int K, int act, int KT, int NS, int rpb, const float* add = nullptr,
+                             const float* z_out = nullptr, int act_out = 0) {
   hipLaunchKernelGGL((skinny_bwd_input_k<MB>), dim3(KT * NS), dim3(256), 0, st, gy, z, W, gx, part, M, N, K, act, KT, NS,
                      rpb);
   if (NS > 1) {
     const int n4 = M * K / 4;
-    hipLaunchKernelGGL(skinny_bwd_input_reduce_k, dim3((4 * n4 + 255) / 256), dim3(256), 0, st, part, gx, n4, NS, add, 0ll);
+    hipLaunchKernelGGL(skinny_bwd_input_reduce_k, dim3((4 * n4 + 255) / 256), dim3(256), 0, st, part, gx, n4, NS, add, 0ll,
+                       z_out, act_out);
   }
 }
 
@@ -2070,6 +2081,35 @@ int cgv_skinny_linear_bwd_input_add(const float* gy, const float* z, const float
     default: cgv::launch_bwd_input<8>(st, gy, z, W, gx, part, M, N, K, act, KT, NS, rpb, add); break;
   }
   return cgv::check_launch("cgv_skinny_linear_bwd_input_add");
+}
+
+/* gx = (add + (gy * act'(z)) W) * act_out'(z_out) (add may be NULL): the reduction launch of the row-split product also
+ * multiplies by the activation derivative of the layer that produced this layer's input (cgv_tile_linear_bwd_input_out for
+ * few rows x very long reductions).  CGV_E_UNSUPPORTED when the product has one row slice only. */
+int cgv_skinny_linear_bwd_input_out(const float* gy, const float* z, const float* W, const float* add, float* gx, int M, int N,
+                                    int K, int act, const float* z_out, int act_out, void* ws, size_t ws_bytes, void* stream) {
+  CGV_REQUIRE(gy && W && gx && z_out && ws, "null pointer");
+  CGV_REQUIRE(act == 0 || (act >= 1 && act <= cgv::CGV_ACT_MAX && z), "act != 0 needs the saved pre-activation z");
+  CGV_REQUIRE(act_out >= 1 && act_out <= cgv::CGV_ACT_MAX, "act_out must name an activation");
+  CGV_REQUIRE(cgv_skinny_bwd_input_supported(M, N, K), "unsupported shape (need M <= 128, N % 4 == 0, K % 4 == 0)");
+  CGV_REQUIRE(((((uintptr_t)gx) | ((uintptr_t)W) | ((uintptr_t)ws) | ((uintptr_t)add) | ((uintptr_t)z_out)) & 15) == 0,
+              "gx, W, ws, add, z_out must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  int KT, NS, rpb;
+  cgv::bwd_input_plan(N, K, true, &KT, &NS, &rpb);
+  if (NS <= 1) { cgv::set_error("cgv_skinny_linear_bwd_input_out: one row slice, no reduction launch to carry the epilogue"); return CGV_E_UNSUPPORTED; }
+  CGV_REQUIRE(ws_bytes >= cgv_skinny_bwd_input_workspace_bytes(M, N, K), "workspace too small");
+  float* part = reinterpret_cast<float*>(ws);
+  switch ((M + 15) / 16) {
+    case 1: cgv::launch_bwd_input<1>(st, gy, z, W, gx, part, M, N, K, act, KT, NS, rpb, add, z_out, act_out); break;
+    case 2: cgv::launch_bwd_input<2>(st, gy, z, W, gx, part, M, N, K, act, KT, NS, rpb, add, z_out, act_out); break;
+    case 3: cgv::launch_bwd_input<3>(st, gy, z, W, gx, part, M, N, K, act, KT, NS, rpb, add, z_out, act_out); break;
+    case 4: cgv::launch_bwd_input<4>(st, gy, z, W, gx, part, M, N, K, act, KT, NS, rpb, add, z_out, act_out); break;
+    case 5:
+    case 6: cgv::launch_bwd_input<6>(st, gy, z, W, gx, part, M, N, K, act, KT, NS, rpb, add, z_out, act_out); break;
+    default: cgv::launch_bwd_input<8>(st, gy, z, W, gx, part, M, N, K, act, KT, NS, rpb, add, z_out, act_out); break;
+  }
+  return cgv::check_launch("cgv_skinny_linear_bwd_input_out");
 }
 
 /* Two backward-input products of ONE shape in one launch pair (+ one reduction launch): gx_j = (gy_j * act_j'(z_j)) W_j for

@@ -459,7 +459,13 @@ class _LinearFn(torch.autograd.Function):
                     if M <= 128 and N >= 4096 and _lib.load().cgv_skinny_bwd_input_supported(M, N, K):
                         # few rows, a very long reduction (96 bead rows x 5400 columns): the row-split kernel spreads the
                         # weight over ~300 blocks (28.5 us + reduce against 43.6 us; tools/bwd_input_bench.py)
-                        fused[0] = skinny_bwd_input(gy2, z if act != ACT_NONE else None, weight, gx, M, N, K, act, add=add2)
+                        prod = getattr(ctx, "producer", None)
+                        if prod is not None and skinny_bwd_input_out(gy2, z if act != ACT_NONE else None, weight, add2, gx, M, N, K,
+                                                                     act, prod.saved_tensors[2], int(prod.act)):
+                            prod.act_done = True           # (its reduction launch stored the producing layer's g: see forward)
+                            fused[0] = True
+                        else:
+                            fused[0] = skinny_bwd_input(gy2, z if act != ACT_NONE else None, weight, gx, M, N, K, act, add=add2)
                     elif parked() is not None:
                         slot = ctx.slot
                         g_seg = slot.take()
@@ -1007,6 +1013,24 @@ def skinny_bwd_input(gy2, z, weight, gx, M, N, K, act, stream=None, add=None) ->
             raise RuntimeError(f"cgv_skinny_linear_bwd_input_add failed with code {rc}: {lib.cgv_last_error_string().decode()}")
     _lib.call("cgv_skinny_linear_bwd_input", _lib.ptr(gy2), _lib.ptr(z) if z is not None else None, _lib.ptr(weight),
               _lib.ptr(gx), M, N, K, act, ws.data_ptr(), nbytes, stream if stream is not None else _lib.stream_ptr())
+    return False
+
+
+def skinny_bwd_input_out(gy2, z, weight, add, gx, M, N, K, act, z_out, act_out) -> bool:
+    """gx = (add + (gy2 * act'(z)) @ weight) * act_out'(z_out) through the row-split product's reduction launch; False when
+    the product has a single row slice (nothing launched: the caller takes the plain path)."""
+    lib = _lib.load()
+    nbytes = lib.cgv_skinny_bwd_input_workspace_bytes(M, N, K)
+    if nbytes <= 0 or (add is not None and not (add.is_contiguous() and add.data_ptr() % 16 == 0)) or z_out.data_ptr() % 16:
+        return False
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=gx.device)
+    rc = lib.cgv_skinny_linear_bwd_input_out(_lib.ptr(gy2), _lib.ptr(z) if z is not None else None, _lib.ptr(weight), _lib.ptr(add),
+                                             _lib.ptr(gx), M, N, K, act, _lib.ptr(z_out), int(act_out), ws.data_ptr(), nbytes,
+                                             _lib.stream_ptr())
+    if rc == 0:
+        return True
+    if rc != -2:                                           # CGV_E_UNSUPPORTED: one row slice
+        raise RuntimeError(f"cgv_skinny_linear_bwd_input_out failed with code {rc}: {lib.cgv_last_error_string().decode()}")
     return False
 
 

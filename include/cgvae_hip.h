@@ -555,6 +555,11 @@ int cgv_skinny_linear_bwd_input(const float* gy, const float* z /*or NULL*/, con
  * CGV_E_UNSUPPORTED when the product has one row slice only (no reduction launch): add separately then. */
 int cgv_skinny_linear_bwd_input_add(const float* gy, const float* z /*or NULL*/, const float* W, const float* add, float* gx,
                                     int M, int N, int K, int act, void* workspace, size_t workspace_bytes, void* stream);
+/* ... and with the result multiplied by act_out'(z_out), z_out [M, K] the pre-activation of the layer that produced this
+ * layer's input (add may be NULL): see cgv_tile_linear_bwd_input_out.  CGV_E_UNSUPPORTED for a single row slice. */
+int cgv_skinny_linear_bwd_input_out(const float* gy, const float* z /*or NULL*/, const float* W, const float* add /*or NULL*/,
+                                    float* gx, int M, int N, int K, int act, const float* z_out, int act_out, void* workspace,
+                                    size_t workspace_bytes, void* stream);
 /* Slice sums ("base + row-slice partials"): the split backward-input product leaves one partial [M, K] matrix per row
  * slice of the weight; instead of a reduction launch per product (57 a step on the chignolin config) the NEXT kernel on
  * the autograd chain adds the slices while it loads its operand -- in slice order, so results are deterministic.

@@ -1671,6 +1671,24 @@ def test_backward_input_with_the_downstream_activation_epilogue_vs_fp64(M, N, K,
     assert_close(gb, ((gy2.double() * act_bwd(z2, 1)) @ W2.double()) * act_bwd(zo2, 1), "pair b, both activations", 5e-6)
 
 
+@pytest.mark.parametrize("M,N,K,with_add", [(96, 5400, 600, False), (64, 4096, 200, True), (17, 4800, 64, True)])
+def test_row_split_backward_input_with_the_downstream_activation_vs_fp64(M, N, K, with_add):
+    """cgv_skinny_linear_bwd_input_out: the reduction launch of the row-split product (few rows x a very long reduction:
+    the decoder's Dense(F -> 9 F) at 96 bead rows) multiplies the sum by Swish'(z_out) of the layer before."""
+    from coarsegrainingvae_amd.primitives import skinny_bwd_input_out
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    rnd = lambda *sh: torch.randn(*sh, device=DEV, generator=g)
+    gy, z, W, zo, add = rnd(M, N), rnd(M, N), rnd(N, K) / N ** 0.5, rnd(M, K), rnd(M, K)
+    sw = lambda t: torch.sigmoid(t.double()) * (1 + t.double() * (1 - torch.sigmoid(t.double())))
+    ref = ((gy.double() * sw(z)) @ W.double() + (add.double() if with_add else 0)) * sw(zo)
+    gx = torch.empty(M, K, device=DEV)
+    assert skinny_bwd_input_out(gy, z, W, add if with_add else None, gx, M, N, K, 1, zo, 1)
+    assert_close(gx, ref, "row-split product, Swish' downstream", 5e-6)
+    ref0 = (gy.double() @ W.double()) * sw(zo)
+    assert skinny_bwd_input_out(gy, None, W, None, gx, M, N, K, 0, zo, 1)
+    assert_close(gx, ref0, "no activation of its own", 5e-6)
+
+
 @pytest.mark.parametrize("shape", [(1500, 1400, 600, 1), (1411, 1796, 52, 0), (2000, 1800, 600, 2)])
 def test_tile_forward_lds_staged_kernel_vs_fp64(shape):
     """cgv_tile_linear_fwd on shapes with >= 448 output tiles of 64 x 64 takes the LDS-staged kernel (tile_fwd_lds_k):
