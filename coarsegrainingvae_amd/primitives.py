@@ -340,8 +340,8 @@ class _LinearFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         ctx.slot = slot
         ctx.producer = None
-        if (producer is not None and HOST_OPTION("act_downstream") and x.grad_fn is producer and ctx.mode == "tile"
-                and getattr(producer, "act", ACT_NONE) != ACT_NONE and getattr(producer, "mode", None) == "tile"):
+        if (producer is not None and HOST_OPTION("act_downstream") and x.grad_fn is producer and ctx.mode in ("tile", "skinny")
+                and getattr(producer, "act", ACT_NONE) != ACT_NONE and getattr(producer, "mode", None) == ctx.mode):
             ctx.producer = producer
         if slot is not None:
             slot.armed = True
@@ -531,7 +531,13 @@ class _LinearFn(torch.autograd.Function):
                     _lib.call("cgv_tile_linear_bwd_input_act", _lib.ptr(gy2), _lib.ptr(z) if act != ACT_NONE else None,
                               _lib.ptr(weight), _lib.ptr(gx), M, N, K, act, st)
             else:
-                fused[0] = skinny_bwd_input(gy2, z, weight, gx, M, N, K, act, add=add2)
+                prod = getattr(ctx, "producer", None)
+                if prod is not None and skinny_bwd_input_out(gy2, z if act != ACT_NONE else None, weight, add2, gx, M, N, K, act,
+                                                             prod.saved_tensors[2], int(prod.act)):
+                    prod.act_done = True                   # (see forward: the producing layer's launches run without an activation)
+                    fused[0] = True
+                else:
+                    fused[0] = skinny_bwd_input(gy2, z if act != ACT_NONE else None, weight, gx, M, N, K, act, add=add2)
             gx = finish(gx.reshape(gy.shape[:-1] + (K,)))
         if need_w:
             # row count / shape of this layer's weight-gradient problem: the data-parallel trainer sorts the layers
@@ -543,7 +549,7 @@ class _LinearFn(torch.autograd.Function):
             tb, acc_b, gb = _grad_target(b_param, b_param) if need_b else (None, acc_w, None)
             if tb is not None and acc_b != acc_w:            # never on this model; keep semantics anyway
                 raise RuntimeError("weight and bias of one layer disagree on first-write / accumulate state")
-            wgrad_queue.enqueue(gy2, x, z, act, tw, tb, acc_w)
+            wgrad_queue.enqueue(gy2, x, z if act != ACT_NONE else None, act, tw, tb, acc_w)
             if not (wgrad_queue.active and gw is None and gb is None):
                 wgrad_queue.flush()                          # immediate mode (no trainer / not arena-managed)
         return (gx if need_x else add), gw, gb, None
