@@ -139,6 +139,7 @@ PROTOTYPES = {
     "cgv_tile_pair_linear_fwd": (_i, [_p] * 10 + [_i, _i, _i, _i, _i, _p]),
     "cgv_tile_pair_linear_bwd_input": (_i, [_p] * 10 + [_i, _i, _i, _i, _i, _p]),
     "cgv_tile_linear_bwd_input_out": (_i, [_p] * 5 + [_i, _i, _i, _i, _p, _i, _p]),
+    "cgv_tile_bwd_input_split": (_i, [_p, _sz, _p]),
     "cgv_tile_pair_linear_bwd_input_out": (_i, [_p] * 10 + [_i, _i, _i, _i, _i, _p, _i, _p, _i, _p]),
     "cgv_tile_linear_bwd_input_sum2": (_i, [_p] * 10 + [_i, _p, _i, _i, _i, _i, _i, _p]),
     "cgv_segment_reduce2": (_i, [_p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _p]),
@@ -190,7 +191,7 @@ PROTOTYPES = {
 OPTIONS = {"msg_fwd_split": 0, "msg_bwd_split": 1, "msg_fwd_kernel": 2, "grp_waves": 3, "grp_records": 4, "csr_build": 5,
            "pseudo_chunks": 6, "wgrad_tiling": 7, "tile_fwd_lds_min": 8, "bwd_input_waves": 9, "pseudo_fwd": 10, "decoder_fat": 11, "decoder_wlds": 12, "skinny_rows": 13,
            "tile_fwd_bal": 14, "optim_one_launch": 15, "decoder_colsplit": 16, "decoder_nodesplit": 17,
-           "msg_fwd_balanced": 18}
+           "msg_fwd_balanced": 18, "bwd_input_split": 19}
 
 
 def set_option(name: str, value: int) -> None:
@@ -251,10 +252,57 @@ def ptr(t):
     return t.data_ptr()
 
 
+_SPLIT_WS = {}                       # (device, stream) -> the split reduction's workspace (cgv_tile_bwd_input_split)
+_SPLIT_TLS = threading.local()       # the C side keeps the registration per calling thread (autograd runs its own)
+_SPLIT_BYTES = 64 * 1024 + 8 * 1024 * 1024
+
+
+def prepare_split_workspace(stream=None):
+    """Create (zero-filled, once) the split reduction's workspace of ``stream`` (default: the current one).  Called before a
+    stream capture for the capture stream: a workspace cannot be created inside one (its zero fill would be a recorded node
+    that has not run), and a capture without one runs its backward-input products unsplit."""
+    st = torch.cuda.current_stream() if stream is None else stream
+    key = (st.device.index if st.device.index is not None else torch.cuda.current_device(), int(st.cuda_stream))
+    if key not in _SPLIT_WS:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        _SPLIT_WS[key] = torch.zeros(_SPLIT_BYTES, dtype=torch.uint8, device=f"cuda:{key[0]}")
+    return _SPLIT_WS[key]
+
+
+def split_workspace_ready() -> bool:
+    """True when the next backward-input launch of the tile kernels on the current stream may split its reduction (the
+    dispatch between the tile and the row-split kernels looks at this: primitives._LinearFn, ops._dense_bwd_input)."""
+    if load().cgv_get_option(OPTIONS["bwd_input_split"]) == 1:
+        return False
+    key = (torch.cuda.current_device(), int(torch.cuda.current_stream().cuda_stream))
+    return key in _SPLIT_WS or not torch.cuda.is_current_stream_capturing()
+
+
+def _register_split_workspace(lib):
+    """The backward-input launches of the tile kernels split few-tile / long-reduction products over several blocks when the
+    calling thread has registered a workspace for the launch stream: one zero-filled buffer per (device, stream).  The
+    launches of one stream are ordered, so they share it; a graph captured with it must not replay concurrently with other
+    work of the stream it was captured on."""
+    key = (torch.cuda.current_device(), int(torch.cuda.current_stream().cuda_stream))
+    if getattr(_SPLIT_TLS, "cur", None) == key:
+        return
+    ws = prepare_split_workspace()
+    if ws is None:
+        lib.cgv_tile_bwd_input_split(None, 0, key[1])
+        _SPLIT_TLS.cur = None
+        return
+    if lib.cgv_tile_bwd_input_split(ws.data_ptr(), ws.numel(), key[1]) != 0:
+        raise RuntimeError("cgv_tile_bwd_input_split failed: " + lib.cgv_last_error_string().decode("utf-8", "replace"))
+    _SPLIT_TLS.cur = key
+
+
 def call(name: str, *args, tag=None):
     """Invoke a status-returning entry point; raise RuntimeError on any non-zero code.
     ``tag`` names the launch for the optional HIP-event timer (ktimer.py)."""
     lib = load()
+    if name.startswith("cgv_tile_") and "bwd_input" in name:
+        _register_split_workspace(lib)
     tok = ktimer.begin(tag) if tag is not None else None
     rc = getattr(lib, name)(*args)
     ktimer.end(tok)

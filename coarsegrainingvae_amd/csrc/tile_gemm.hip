@@ -516,6 +516,13 @@ struct BwdSecond { const float* g; const float* W; float* gx; const float* z; co
 // weight-gradient launches in their operand loads, where every one of the K / 64 column-tile blocks that share a row tile
 // evaluates it again (704 x 600 x 600: 17.7 against 11.2 us per product, tools/bwd_act_bench.py).
 struct OutAct { const float* z; int act; const float* z2; int act2; };      // z2 / act2: the second problem of a pair launch
+// The reduction of ONE output tile over several blocks (grid y = row tiles x n): few output tiles and a long reduction (96 bead
+// rows x 1800 columns = 60 tiles: 60 of 256 CUs busy, each streaming 460 KB of weight rows through three dependent batches
+// of requests per wave).  Block zs takes the zs-th share of the reduction steps, leaves its partial tile in `part`
+// (agent-scope write-through stores, acknowledged before its ticket is drawn: the hand-over of loss_tail.hip / equi_msg_grp.hip)
+// and the block that draws the tile's LAST ticket adds the n partial tiles in share order and runs the store epilogue: the
+// result does not depend on who arrives last.  Tickets reset themselves; part / ticket: cgv_tile_bwd_input_split.
+struct SplitN { float* part; unsigned* ticket; int n; };
 struct BcastAdd {
   const float* src;          // [n_seg, K] or NULL
   const int64_t* row2seg;    // [M] segment of every row (the CG mapping)
@@ -534,13 +541,15 @@ __global__ __launch_bounds__(64 * WAVES) void tile_bwd_input_k(const float* __re
                                                         BcastAdd bc = BcastAdd{nullptr, nullptr, nullptr, 0},
                                                         BwdSecond s2 = BwdSecond{nullptr, nullptr, nullptr, nullptr, nullptr, 0},
                                                         BwdSource more = BwdSource{nullptr, nullptr, nullptr, 0},
-                                                        OutAct oa = OutAct{nullptr, 0, nullptr, 0}) {
+                                                        OutAct oa = OutAct{nullptr, 0, nullptr, 0},
+                                                        SplitN sp = SplitN{nullptr, nullptr, 1}) {
   if (blockIdx.z) { g = s2.g; W = s2.W; gx = s2.gx; z = s2.z; add = s2.add; act = s2.act; bc.src = nullptr; oa.z = oa.z2; oa.act = oa.act2; }
   __shared__ float red[WAVES][MB * 4][4][64];        // [wave][mb*4 + s][reg][lane]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 15, q = lane >> 4;
-  const int k0 = blockIdx.x * 64, m0 = blockIdx.y * (16 * MB);
+  const int ry = (int)blockIdx.y / sp.n, zs = (int)blockIdx.y - ry * sp.n;          // row tile, share of the reduction
+  const int k0 = blockIdx.x * 64, m0 = ry * (16 * MB);
   const int kcol = k0 + 4 * j;
   const bool kok = kcol < K;
   const float* gr[MB];
@@ -557,8 +566,10 @@ __global__ __launch_bounds__(64 * WAVES) void tile_bwd_input_k(const float* __re
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
     for (int s = 0; s < 4; ++s) acc[mb][s] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int steps = (N + 15) / 16, per = (steps + WAVES - 1) / WAVES;       // contiguous n range per wave (see fwd)
-  const int st_end = min((wave + 1) * per, steps);
+  const int steps_all = (N + 15) / 16, zper = (steps_all + sp.n - 1) / sp.n;
+  const int z_beg = min(zs * zper, steps_all), steps = min(z_beg + zper, steps_all);   // this block's steps [z_beg, steps)
+  const int per = (steps - z_beg + WAVES - 1) / WAVES;                                // contiguous n range per wave (see fwd)
+  const int st_beg = min(z_beg + wave * per, steps), st_end = min(st_beg + per, steps);
   // SB steps' loads are issued together and unconditionally (see tile_fwd_k: a guarded load is a branch, and a wave's
   // 14 - 21 steps each waited out their own memory round trip).  Rows beyond M and columns beyond K are clamped into
   // range -- their products are never stored -- and the reduction tail (n >= N) is zeroed on g's side.
@@ -624,7 +635,7 @@ __global__ __launch_bounds__(64 * WAVES) void tile_bwd_input_k(const float* __re
   };
   if constexpr (CGV_BWD_INPUT_PIPELINE && WAVES < 16) {          // (16 waves = 1024 threads: 128 registers, no room for two batches)
     Batch b0, b1;
-    int st0 = wave * per;
+    int st0 = st_beg;
     request(b0, st0);
     for (; st0 < st_end; st0 += 2 * SB) {
       request(b1, st0 + SB);
@@ -633,7 +644,7 @@ __global__ __launch_bounds__(64 * WAVES) void tile_bwd_input_k(const float* __re
       multiply(b1, st0 + SB);
     }
   } else {
-    for (int st0 = wave * per; st0 < st_end; st0 += SB) {
+    for (int st0 = st_beg; st0 < st_end; st0 += SB) {
       Batch b0;
       request(b0, st0);
       multiply(b0, st0);
@@ -664,6 +675,36 @@ __global__ __launch_bounds__(64 * WAVES) void tile_bwd_input_k(const float* __re
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wave][t][r][lane] = acc[t >> 2][t & 3][r];
   __syncthreads();
+  float* tile_part = nullptr;
+  if (sp.n > 1) {
+    // this block's partial tile -> part[tile][zs][16 MB rows][64], then the ticket; only the last arriver goes on
+    unsigned* s_last = reinterpret_cast<unsigned*>(&red[0][0][0][0]);      // (red is spent behind the barrier below; LDS is full)
+    const size_t tid = ((size_t)blockIdx.z * (gridDim.y / sp.n) + ry) * gridDim.x + blockIdx.x;
+    tile_part = sp.part + tid * sp.n * (size_t)(MB * 16 * 64);
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int c = wave + u * WAVES;
+      if (c >= PAIRS) break;
+      const int mb = c >> 2, r = c & 3;
+      f32x4 o;
+#pragma unroll
+      for (int sI = 0; sI < 4; ++sI) {
+        const int t = mb * 4 + sI;
+        float a = red[0][t][r][lane];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) a += red[w][t][r][lane];
+        o[sI] = a;
+      }
+      float* dst = tile_part + (size_t)zs * (MB * 16 * 64) + (16 * mb + 4 * q + r) * 64 + 4 * j;
+      asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(o) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) *s_last = atomicAdd(sp.ticket + tid, 1u) == (unsigned)(sp.n - 1) ? 1u : 0u;
+    __syncthreads();
+    if (!*s_last) return;
+    if (threadIdx.x == 0) __hip_atomic_store(sp.ticket + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   if (!kok) return;
   // D_s of m-block mb: lane holds gx[m0 + 16 mb + 4 q + r][k0 + 4 j + s] -> one float4 (s = 0..3) per r
 #pragma unroll
@@ -674,12 +715,22 @@ __global__ __launch_bounds__(64 * WAVES) void tile_bwd_input_k(const float* __re
     const int m = m0 + 16 * mb + 4 * q + r;
     if (m >= M) continue;
     float o[4];
+    if (sp.n > 1) {                                  // the shares' partial tiles, in share order (agent-scope loads)
+      const float* src = tile_part + (16 * mb + 4 * q + r) * 64 + 4 * j;
+#pragma unroll
+      for (int sI = 0; sI < 4; ++sI) o[sI] = __hip_atomic_load(src + sI, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int zz = 1; zz < sp.n; ++zz)
+#pragma unroll
+        for (int sI = 0; sI < 4; ++sI)
+          o[sI] += __hip_atomic_load(src + (size_t)zz * (MB * 16 * 64) + sI, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
 #pragma unroll
     for (int sI = 0; sI < 4; ++sI) {
       const int t = mb * 4 + sI;
       o[sI] = red[0][t][r][lane];
 #pragma unroll
       for (int w = 1; w < WAVES; ++w) o[sI] += red[w][t][r][lane];
+    }
     }
     if (add) {                                       // a second gradient of the same input (blocks.py: fork of the first Dense)
       const float4 a4 = pre_add[u];
@@ -879,6 +930,13 @@ int cgv_tile_pair_linear_fwd(const float* x_a, const float* W_a, const float* bi
   return rc;
 }
 
+// workspace of the split reduction (cgv_tile_bwd_input_split): per host thread, for launches on ONE stream
+namespace cgv {
+struct SplitWs { void* ws; size_t bytes; void* stream; };
+static thread_local SplitWs g_split_ws = {nullptr, 0, nullptr};
+constexpr size_t SPLIT_TICKET_BYTES = 64 * 1024;       // head of the workspace: one ticket per output tile
+}  // namespace cgv
+
 static int tile_bwd_input_launch(const float* g, const float* z, int act, const float* W, float* gx, int M, int N, int K,
                                  void* stream, const char* what, const float* add = nullptr,
                                  cgv::BcastAdd bc = cgv::BcastAdd{nullptr, nullptr, nullptr, 0},
@@ -903,12 +961,38 @@ static int tile_bwd_input_launch(const float* g, const float* z, int act, const 
     hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 8>), dim3(kt, (M + 31) / 32, np), dim3(512), 0, st, g, W, gx, M, N, K, z, act, add, bc, s2, more, oa);
   else if (blocks32 >= 512)               // enough 32-row tiles to fill the chip: halve the weight re-reads
     hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 4>), dim3(kt, (M + 31) / 32, np), dim3(256), 0, st, g, W, gx, M, N, K, z, act, add, bc, s2, more, oa);
-  else if (waves == 16)                   // few output tiles and a long reduction (96 bead rows x 5400 columns: 60 blocks):
-    // 16 waves per block split it -- 60 blocks of 8 waves left three quarters of the chip idle (17.8 us per call)
-    hipLaunchKernelGGL((cgv::tile_bwd_input_k<1, 16>), dim3(kt, (M + 15) / 16, np), dim3(1024), 0, st, g, W, gx, M, N, K, z, act, add, bc, s2, more, oa);
+  else if (waves == 16) {                 // few output tiles and a long reduction (96 bead rows x 5400 columns: 60 blocks):
+    // 16 waves per block split it -- 60 blocks of 8 waves left three quarters of the chip idle (17.8 us per call) -- and,
+    // with a registered workspace, 2 - 4 blocks per tile split it further (SplitN)
+    cgv::SplitN sp{nullptr, nullptr, 1};
+    const int tiles = blocks16 * (int)np;
+    const int opt = cgv::option(CGV_OPT_BWD_INPUT_SPLIT);
+    const cgv::SplitWs& w = cgv::g_split_ws;
+    if (opt != 1 && w.ws && w.stream == stream && tiles <= 128) {
+      int n = opt >= 2 ? opt : 256 / tiles;
+      n = n > 4 ? 4 : n;
+      while (n > 1 && (N + 15) / 16 / n < 16) --n;                        // at least one step per wave and share
+      const size_t need = cgv::SPLIT_TICKET_BYTES + (size_t)tiles * n * (16 * 64) * sizeof(float);
+      if (n > 1 && need <= w.bytes && (size_t)tiles * sizeof(unsigned) <= cgv::SPLIT_TICKET_BYTES) {
+        sp.ticket = reinterpret_cast<unsigned*>(w.ws);
+        sp.part = reinterpret_cast<float*>(reinterpret_cast<char*>(w.ws) + cgv::SPLIT_TICKET_BYTES);
+        sp.n = n;
+      }
+    }
+    hipLaunchKernelGGL((cgv::tile_bwd_input_k<1, 16>), dim3(kt, ((M + 15) / 16) * sp.n, np), dim3(1024), 0, st, g, W, gx, M, N, K, z, act,
+                       add, bc, s2, more, oa, sp);
+  }
   else
     hipLaunchKernelGGL((cgv::tile_bwd_input_k<1, 8>), dim3(kt, (M + 15) / 16, np), dim3(512), 0, st, g, W, gx, M, N, K, z, act, add, bc, s2, more, oa);
   return cgv::check_launch(what);
+}
+
+/* Registers the workspace of the split reduction for the CALLING host thread's launches on `stream` (ws = NULL: none).
+ * ws: zero-filled once by the caller (its first 64 KB are self-resetting tickets), 16-byte aligned, >= 64 KB + 2 MB. */
+int cgv_tile_bwd_input_split(void* ws, size_t bytes, void* stream) {
+  CGV_REQUIRE(!ws || ((((uintptr_t)ws) & 15) == 0 && bytes >= cgv::SPLIT_TICKET_BYTES + (2u << 20)), "workspace too small / misaligned");
+  cgv::g_split_ws = cgv::SplitWs{ws, ws ? bytes : 0, stream};
+  return 0;
 }
 
 int cgv_tile_linear_bwd_input(const float* g, const float* W, float* gx, int M, int N, int K, void* stream) {

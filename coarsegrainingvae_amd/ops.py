@@ -706,7 +706,8 @@ def _dense_bwd_input(gy, z, W, gx, M, N, K, act, st, z_out=None, act_out=0) -> b
     gx * act_out'(z_out) (returns True: the producing layer's backward runs without an activation); the row-split kernel has
     no such epilogue (returns False, gx as it is)."""
     lib = _lib.load()
-    if lib.cgv_skinny_supported(M, N, K) or (M <= 128 and N >= 4096 and lib.cgv_skinny_bwd_input_supported(M, N, K)):
+    if lib.cgv_skinny_supported(M, N, K) or (M <= 128 and N >= 4096 and lib.cgv_skinny_bwd_input_supported(M, N, K)
+                                             and not (M > 64 and _lib.split_workspace_ready())):
         skinny_bwd_input(gy, z, W, gx, M, N, K, act, st)
         return False
     if z_out is not None and act_out and options.HOST["act_downstream"]:

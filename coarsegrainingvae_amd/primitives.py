@@ -456,9 +456,12 @@ class _LinearFn(torch.autograd.Function):
                 # grouped weight-gradient launch, which also sums the bias (primitives.WeightGradQueue.launch)
                 if need_x:
                     gx = torch.empty(M, K, dtype=torch.float32, device=gy.device)
-                    if M <= 128 and N >= 4096 and _lib.load().cgv_skinny_bwd_input_supported(M, N, K):
-                        # few rows, a very long reduction (96 bead rows x 5400 columns): the row-split kernel spreads the
-                        # weight over ~300 blocks (28.5 us + reduce against 43.6 us; tools/bwd_input_bench.py)
+                    if (M <= 128 and N >= 4096 and _lib.load().cgv_skinny_bwd_input_supported(M, N, K)
+                            and not (M > 64 and _lib.split_workspace_ready())):
+                        # few rows, a very long reduction: the row-split kernel spreads the weight over ~300 blocks (64 bead
+                        # rows x 5400 columns: 13.8 us with its reduce against 14.3 us of the tile kernel).  From 65 rows
+                        # on the tile kernel wins once it splits each tile's reduction over 2-4 blocks (96 x 5400: 15.1
+                        # against 21.2 us, 128 x 5400: 20.0 / 26.0; unsplit 34.9: tools/bwd_input_bench.py)
                         prod = getattr(ctx, "producer", None)
                         if prod is not None and skinny_bwd_input_out(gy2, z if act != ACT_NONE else None, weight, add2, gx, M, N, K,
                                                                      act, prod.saved_tensors[2], int(prod.act)):

@@ -681,7 +681,13 @@ class Trainer:
         wgrad_queue.prepare_capture(self.arena.p.device, flushes=4 * (len(self.early_ranges) + 2))
         # with RCCL in the step, other threads (the process group's watchdog) legitimately touch the runtime
         mode = "thread_local" if self.sync is not None else "global"
-        with torch.cuda.graph(graph, capture_error_mode=mode):
+        recording = torch.cuda.graph(graph, capture_error_mode=mode)
+        cap_stream = getattr(recording, "capture_stream", None)
+        if cap_stream is not None:
+            # the split backward-input products keep tickets + partial tiles per stream: those of the capture stream exist
+            # (zeroed) before the capture begins, like the loss launch's words above
+            _lib.prepare_split_workspace(cap_stream)
+        with recording:
             self._step_eager(batch, eps_buf, train=train)
         tables = wgrad_queue.finish_capture()               # record tables: on the device before the first replay
         self._pending = pending_at_start                    # recorded, not run: the update it opens with is still due

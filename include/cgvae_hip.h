@@ -87,7 +87,9 @@ enum {
   CGV_OPT_DECODER_NODESPLIT = 17, /* cgv_decoder_uv_fwd (and uv_bwd, see there): 1 (default) 8-channel blocks by node groups of <= 5 nodes (grid y) --
                                    a third of the MFMAs and of the x rows per block; 0 one 4-channel block over all 3 n rows */
   CGV_OPT_MSG_FWD_BALANCED = 18, /* cgv_equi_msg_fwd_balanced: four-wave blocks per CU, 3 (default: what the kernel's registers admit, all resident) or 1..4 */
-  CGV_OPT_COUNT = 19
+  CGV_OPT_BWD_INPUT_SPLIT = 19, /* cgv_tile_linear_bwd_input*: few output tiles and a long reduction: -1 (default) 2 - 4 blocks per tile
+                                   when a workspace is registered (cgv_tile_bwd_input_split), 1 never, 2..4 that many */
+  CGV_OPT_COUNT = 20
 };
 /* Measurement: store the GPU wall clock (cgv_timestamp_hz ticks per second) into *slot, in stream order; capturable. */
 int cgv_timestamp(uint64_t* slot /*device*/, void* stream);
@@ -625,6 +627,12 @@ int cgv_tile_pair_linear_bwd_input(const float* gy_a, const float* z_a, const fl
  * and its own backward runs with act = 0.  Applied once per element in the store epilogue instead of in the operand loads
  * of the producing layer's backward-input and weight-gradient launches (every column-tile block of a row tile evaluates
  * it again there).  add may be NULL; in the pair form either z_out may be NULL (that output is stored as it is). */
+/* Few output tiles and a long reduction (96 bead rows x 1800 columns: 60 tiles on 256 CUs): with a workspace registered the
+ * backward-input launches of the CALLING host thread on `stream` give such a tile to 2 - 4 blocks, each with a share of the
+ * reduction; their partial tiles meet in the workspace and the last block to arrive adds them in share order and runs the
+ * store epilogue (results do not depend on timing).  ws: >= 64 KB + 2 MB, 16-byte aligned, ZERO-FILLED once by the caller
+ * (self-resetting tickets at its head), used by one stream at a time; NULL unregisters. */
+int cgv_tile_bwd_input_split(void* workspace, size_t workspace_bytes, void* stream);
 int cgv_tile_linear_bwd_input_out(const float* gy, const float* z, const float* W, const float* add, float* gx, int M, int N,
                                   int K, int act, const float* z_out, int act_out, void* stream);
 int cgv_tile_pair_linear_bwd_input_out(const float* gy_a, const float* z_a, const float* W_a, const float* add_a, float* gx_a,

@@ -1689,6 +1689,72 @@ def test_row_split_backward_input_with_the_downstream_activation_vs_fp64(M, N, K
     assert_close(gx, ref0, "no activation of its own", 5e-6)
 
 
+@pytest.mark.parametrize("M,N,K", [(96, 1800, 600), (96, 5400, 600), (128, 5400, 600), (70, 1036, 204), (33, 4100, 64),
+                                   (16, 2048, 64)])
+def test_backward_input_reduction_split_over_blocks_is_deterministic_and_exact(M, N, K, options):
+    """cgv_tile_bwd_input_split + CGV_OPT_BWD_INPUT_SPLIT: few output tiles x a long reduction run as 2-4 blocks per tile, the
+    last block to arrive adding the partial tiles in share order.  Every share count against fp64 and against the unsplit
+    launch, repeated launches bit-identical (the tickets reset themselves), the epilogues (added gradient, Swish' of the
+    layer before, the pair form with one NULL z_out) applied once by the combining block; a stream without a registered
+    workspace runs unsplit."""
+    g = torch.Generator(device=DEV).manual_seed(M * 7 + N + K)
+    rnd = lambda *sh: torch.randn(*sh, device=DEV, generator=g)
+    gy, z, W, zo, add = rnd(M, N), rnd(M, N), rnd(N, K) / N ** 0.5, rnd(M, K), rnd(M, K)
+    gy2, W2 = rnd(M, N), rnd(N, K) / N ** 0.5
+    sw = lambda t: torch.sigmoid(t.double()) * (1 + t.double() * (1 - torch.sigmoid(t.double())))
+    ref = ((gy.double() * sw(z)) @ W.double() + add.double()) * sw(zo)
+    ref_plain, ref2 = gy.double() @ W.double(), gy2.double() @ W2.double()
+    P = cg._lib.ptr
+
+    def single():
+        gx = torch.empty(M, K, device=DEV)
+        cg._lib.call("cgv_tile_linear_bwd_input_out", P(gy), P(z), P(W), P(add), P(gx), M, N, K, 1, P(zo), 1, cg._lib.stream_ptr())
+        return gx
+
+    def pair():
+        ga, gb = torch.empty(M, K, device=DEV), torch.empty(M, K, device=DEV)
+        cg._lib.call("cgv_tile_pair_linear_bwd_input_out", P(gy), None, P(W), None, P(ga), P(gy2), None, P(W2), P(add), P(gb), M, N, K,
+                     0, 0, P(zo), 1, None, 0, cg._lib.stream_ptr())
+        return ga, gb
+
+    options.set("bwd_input_split", 1)
+    unsplit, (ua, ub) = single(), pair()
+    assert_close(unsplit, ref, "unsplit", 5e-6)
+    for shares in (-1, 2, 3, 4):
+        options.set("bwd_input_split", shares)
+        first = single()
+        assert_close(first, ref, f"shares {shares}", 5e-6)
+        assert_close(first, unsplit.double(), f"shares {shares} against the unsplit launch", 2e-6)
+        for _ in range(3):
+            assert torch.equal(single(), first), f"shares {shares}: repeated launches differ"
+        ga, gb = pair()
+        assert_close(ga, ref_plain * sw(zo), f"pair a, shares {shares}", 5e-6)
+        assert_close(gb, ref2 + add.double(), f"pair b, shares {shares}", 5e-6)
+        assert_close(ga, ua.double(), f"pair a against the unsplit launch, shares {shares}", 2e-6)
+        ga2, gb2 = pair()
+        assert torch.equal(ga, ga2) and torch.equal(gb, gb2)
+    # another stream of the same thread: no workspace registered for it inside ... the host mirror registers one per stream
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        other = single()
+    side.synchronize()
+    assert torch.equal(other, first)
+    # the C ABI refuses a workspace that is too small or misaligned, and NULL unregisters
+    lib = cg._lib.load()
+    small = torch.zeros(1024, dtype=torch.uint8, device=DEV)
+    assert lib.cgv_tile_bwd_input_split(small.data_ptr(), small.numel(), cg._lib.stream_ptr()) != 0
+    big = torch.zeros(64 * 1024 + 4 * 1024 * 1024 + 16, dtype=torch.uint8, device=DEV)
+    assert lib.cgv_tile_bwd_input_split(big.data_ptr() + 4, big.numel() - 16, cg._lib.stream_ptr()) != 0
+    assert lib.cgv_tile_bwd_input_split(None, 0, cg._lib.stream_ptr()) == 0
+    cg._lib._SPLIT_TLS.cur = None                             # (this thread's registration was replaced just above)
+    gx = torch.empty(M, K, device=DEV)
+    rc = lib.cgv_tile_linear_bwd_input_out(P(gy), P(z), P(W), P(add), P(gx), M, N, K, 1, P(zo), 1, cg._lib.stream_ptr())
+    assert rc == 0
+    assert torch.equal(gx, unsplit), "no workspace registered: the unsplit launch"
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("shape", [(1500, 1400, 600, 1), (1411, 1796, 52, 0), (2000, 1800, 600, 2)])
 def test_tile_forward_lds_staged_kernel_vs_fp64(shape):
     """cgv_tile_linear_fwd on shapes with >= 448 output tiles of 64 x 64 takes the LDS-staged kernel (tile_fwd_lds_k):
