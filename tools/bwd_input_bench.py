@@ -16,6 +16,8 @@ def timeit(fn, reps=100):
     return 1e3 * a.elapsed_time(b) / reps
 
 ACT = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+if os.environ.get("CGV_SPLIT"):                       # CGV_OPT_BWD_INPUT_SPLIT: 1 never, 2..4 forced shares
+    _lib.set_option("bwd_input_split", int(os.environ["CGV_SPLIT"]))
 for M in (tuple(int(a) for a in sys.argv[2:]) or (96, 128, 64)):
     for N, K in ((5400, 600), (600, 600), (1800, 600), (600, 1200), (1200, 600)):
         gy, z = torch.randn(M, N, device="cuda"), torch.randn(M, N, device="cuda")
@@ -23,6 +25,9 @@ for M in (tuple(int(a) for a in sys.argv[2:]) or (96, 128, 64)):
         gx1, gx2 = torch.empty(M, K, device="cuda"), torch.empty(M, K, device="cuda")
         st = _lib.stream_ptr()
         t_tile = timeit(lambda: _lib.call("cgv_tile_linear_bwd_input_act", _lib.ptr(gy), _lib.ptr(z), _lib.ptr(W), _lib.ptr(gx1), M, N, K, ACT, st))
-        t_sk = timeit(lambda: skinny_bwd_input(gy, z if ACT else None, W, gx2, M, N, K, ACT))
+        if M <= 128:
+            t_sk = timeit(lambda: skinny_bwd_input(gy, z if ACT else None, W, gx2, M, N, K, ACT))
+        else:                                             # (the row-split kernel takes up to 128 rows)
+            t_sk, gx2 = float("nan"), ((gy * (torch.sigmoid(z) * (1 + z * (1 - torch.sigmoid(z)))) if ACT == 1 else gy) @ W)
         err = float((gx1 - gx2).abs().max() / gx1.abs().max())
         print(f"M={M:4d} N={N:5d} K={K:5d}: tile {t_tile:6.2f} us   row-split + reduce {t_sk:6.2f} us   rel diff {err:.1e}")
