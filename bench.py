@@ -347,7 +347,7 @@ def optimizer_roofline(trainer, reps=5):
 
     def run():
         if rank:
-            table, nprob, blocks, lds, _items, max_rows = rank
+            table, nprob, max_rows = rank[0], rank[1], rank[5]
             _lib.call("cgv_wgrad_gram", _lib.ptr(table), nprob, max_rows, _lib.ptr(trainer._rank_sumsq), _lib.ptr(trainer._rank_ws),
                       trainer._rank_ws.numel(), _lib.stream_ptr())
         _lib.call("cgv_optim_prepare_extra", a.g.data_ptr() + 4 * lo, n - lo, _lib.ptr(trainer._rank_sumsq) if rank else None,
@@ -356,9 +356,7 @@ def optimizer_roofline(trainer, reps=5):
         _lib.call("cgv_adam_apply", sp.data_ptr() + 4 * lo, a.g.data_ptr() + 4 * lo, sm.data_ptr() + 4 * lo,
                   sv.data_ptr() + 4 * lo, n - lo, 1e-4, 0.9, 0.999, 1e-8, _lib.ptr(state), _lib.stream_ptr())
         if rank:
-            table, nprob, blocks, lds, _items, _rows = rank
-            _lib.call("cgv_grouped_wgrad_adam", _lib.ptr(table), nprob, blocks, lds, _lib.ptr(a.g), _lib.ptr(sp), _lib.ptr(sm),
-                      _lib.ptr(sv), 1e-4, 0.9, 0.999, 1e-8, _lib.ptr(state), _lib.stream_ptr())
+            trainer.rank_update_launch(rank, sp, sm, sv, 1e-4, 0.9, 0.999, 1e-8, state)
     run()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
     for s, e in ev:
@@ -369,7 +367,7 @@ def optimizer_roofline(trainer, reps=5):
     us = 1e3 * sum(s.elapsed_time(e) for s, e in ev) / reps
     n_rank = trainer._rank_numel if rank else 0
     by = 4 * (6 * n_rank + 7 * (n - lo))
-    return {"kernel": ("wgrad_gram+optim_finalize+adam_update+grouped_wgrad_t<true>" if rank
+    return {"kernel": (("wgrad_gram+optim_finalize+adam_update+" + ("rank_update_mixed_k" if rank[6][0] else "grouped_wgrad_t<true>")) if rank
                        else "sumsq_partial+optim_finalize+adam_update"),
             "params": n, "rank_update_weights": n_rank, "bound": "hbm", "achieved": by / (us * 1e-6) / 1e9,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "avg_us": us,

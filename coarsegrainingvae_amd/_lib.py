@@ -184,6 +184,10 @@ PROTOTYPES = {
     "cgv_rank_update_supported": (_i, [_i, _i, _i]),
     "cgv_optim_prepare_extra": (_i, [_p, C.c_int64, _p, _i, _f, _f, _f, _f, _p, _f, _p, _p, _p]),
     "cgv_grouped_wgrad_adam": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _f, _f, _f, _f, _p, _p]),
+    "cgv_rank_flat_quantum": (_i, []),
+    "cgv_rank_flat_plan": (_i, [_i, _i, _i, _i, _p, _p]),
+    "cgv_grouped_wgrad_adam_flat": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _f, _f, _f, _f, _p, _p]),
+    "cgv_grouped_wgrad_adam_mixed": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _f, _f, _f, _f, _p, _p]),
 }
 
 

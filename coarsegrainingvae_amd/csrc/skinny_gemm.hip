@@ -564,13 +564,13 @@ struct RankUpdateArgs {
 };
 
 template <bool ADAM>
-__global__ __launch_bounds__(256) void grouped_wgrad_t(const WgradProblem* __restrict__ table, int n_problems, RankUpdateArgs ra) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void grouped_wgrad_body(const WgradProblem* __restrict__ table, int n_problems, const RankUpdateArgs& ra,
+                                                   int block, float* smem) {
   if (ADAM && ra.state[ST_SKIP] != 0.f) return;              // skipped step (utils.py:145): parameters stay
   // locate the problem of this block (table is tiny; block_begin ascending)
-  const int lo = wg_find_problem(table, n_problems);
+  const int lo = wg_find_problem(table, n_problems, block);
   const WgradProblem pr = table[lo];
-  const int local = blockIdx.x - pr.block_begin;
+  const int local = block - pr.block_begin;
   const int rb = local / pr.tiles_k, kt = local - rb * pr.tiles_k;
   const int M = pr.M, N = pr.N, K = pr.K, tile_w = pr.tile_w;
   float* xs = smem;                          // [M][tile_w]
@@ -697,6 +697,188 @@ __global__ __launch_bounds__(256) void grouped_wgrad_t(const WgradProblem* __res
     for (int m = 0; m < M; ++m) sum += gs[m * WG_BLOCK_ROWS + t];
     pr.gb[n0 + t] = pr.accumulate ? pr.gb[n0 + t] + sum : sum;
   }
+}
+
+template <bool ADAM>
+__global__ __launch_bounds__(256) void grouped_wgrad_t(const WgradProblem* __restrict__ table, int n_problems, RankUpdateArgs ra) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  grouped_wgrad_body<ADAM>(table, n_problems, ra, (int)blockIdx.x, smem);
+}
+
+// Rank update, FLAT layout (few operand rows: M <= RF_MAX_ROWS).  The update is elementwise over the weight's [N, K] array,
+// which is contiguous: a block takes a contiguous range of q4 float4 of it -- whole 128-byte lines of p, m and v, each read
+// and written exactly once -- instead of 64 rows x one k tile.  (K = 600 is cut into 3 tiles of 200 columns there: row
+// segments of 800 bytes at a stride of 2400, 6.25 lines each, so the three blocks of a row block -- on three XCDs --
+// fetch the lines at the tile borders twice: 860 MB read for 730 MB of p / m / v on the chignolin step, FETCH_SIZE.)
+// Each thread's 8 float4 of a round lie 256 float4 apart, each with its own (row n, column k): the operand tile in LDS is
+// x for ALL K columns plus g for the rows the range touches, and an output reads one float4 of x and one float of g per
+// operand row.  The sum over the operand rows runs in the same order as in grouped_wgrad_t<true>: bit-identical results.
+constexpr int RF_MAX_ROWS = 16;          // LDS reads per FMA grow with the rows: beyond this the tiled kernel's shared x / g reads win
+#ifndef CGV_RF_UNR
+#define CGV_RF_UNR 4
+#endif
+#ifndef CGV_RF_PIPE
+#define CGV_RF_PIPE 0
+#endif
+constexpr int RF_UNR = CGV_RF_UNR;       // float4 per thread and round (3 x RF_UNR requests of 16 bytes in flight)
+constexpr bool RF_PIPE = CGV_RF_PIPE;    // the next round's p / m / v requested before this round's tile is formed
+constexpr int RF_ROUND_F4 = 256 * RF_UNR;
+constexpr int RF_QUANTUM_F4 = 2048;      // q4 is a multiple of this (and of RF_ROUND_F4)
+static_assert(RF_QUANTUM_F4 % RF_ROUND_F4 == 0, "rounds tile the quantum");
+
+__device__ __forceinline__ void rank_update_flat_body(const WgradProblem* __restrict__ table, int n_problems, const RankUpdateArgs& ra,
+                                                      int q4 /* float4 per block: a multiple of RF_QUANTUM_F4 */, int block, float* smem) {
+  if (ra.state[ST_SKIP] != 0.f) return;                          // skipped step (utils.py:145): parameters stay
+  const int lo = wg_find_problem(table, n_problems, block);
+  const WgradProblem pr = table[lo];
+  const int local = block - pr.block_begin;
+  const int M = pr.M, N = pr.N, K = pr.K, K4 = K >> 2;
+  const int total4 = N * K4;
+  const int f_lo = local * q4, f_hi = min(total4, f_lo + q4);
+  if (f_lo >= f_hi) return;
+  const int r_lo = f_lo / K4;
+  const int G = min(q4 / K4 + 2, N);                              // rows of g staged: the range touches at most that many
+  float* xs = smem;                                              // [M][K]
+  float* gs = smem + (size_t)M * K;                              // [M][G]
+  const int t = threadIdx.x;
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  typedef const __attribute__((address_space(1))) f4v* gptr;
+  const size_t arena0 = (size_t)(pr.gW - ra.arena_g);
+  const int dq = 256 / K4, dr = 256 - dq * K4;                    // (n, k4) of an index 256 float4 further on
+  const int n_last = (f_hi - 1) / K4, k_last = (f_hi - 1) - n_last * K4;
+
+  // p / m / v of round c (thread t: float4 c + t + 256 i) requested, with the LDS offsets of each float4's x and g
+  auto request = [&](int c, float4 (&pp)[RF_UNR], float4 (&mm)[RF_UNR], float4 (&vv)[RF_UNR], int (&xo)[RF_UNR], int (&go)[RF_UNR]) {
+    const int i0 = min(c + t, f_hi - 1);
+    int n = i0 / K4, k4 = i0 - n * K4;
+#pragma unroll
+    for (int i = 0; i < RF_UNR; ++i) {
+      // indices beyond the range are clamped onto its last float4 (their results are not stored): no branch around a request
+      const bool in = c + t + 256 * i < f_hi;
+      const int nn = in ? n : n_last, kk = in ? k4 : k_last;
+      xo[i] = 4 * kk;
+      go[i] = nn - r_lo;
+      const size_t o = arena0 + 4 * ((size_t)nn * K4 + kk);
+      pp[i] = ldg4_global(ra.arena_p + o);
+      const f4v tm = __builtin_nontemporal_load(reinterpret_cast<gptr>((const __attribute__((address_space(1))) float*)(ra.arena_m + o)));
+      const f4v tv = __builtin_nontemporal_load(reinterpret_cast<gptr>((const __attribute__((address_space(1))) float*)(ra.arena_v + o)));
+      mm[i] = make_float4(tm.x, tm.y, tm.z, tm.w);
+      vv[i] = make_float4(tv.x, tv.y, tv.z, tv.w);
+      k4 += dr; n += dq;
+      if (k4 >= K4) { k4 -= K4; ++n; }
+    }
+  };
+  float4 pa[RF_UNR], ma[RF_UNR], va[RF_UNR];
+  int xa[RF_UNR], ga[RF_UNR];
+  request(f_lo, pa, ma, va, xa, ga);                              // ... under the staging of the operand rows
+  asm volatile("" ::: "memory");
+
+  for (int base = 0; base < M * K4; base += 1024) {
+    float4 val[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = min(base + u * 256 + t, M * K4 - 1);
+      const int m = idx / K4, c = idx - m * K4;
+      val[u] = ldg4_global(pr.x + wg_row(pr, m, K) + 4 * c);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = base + u * 256 + t;
+      if (idx < M * K4) reinterpret_cast<float4*>(xs)[idx] = val[u];
+    }
+  }
+  const int rows = min(G, N - r_lo);
+  for (int base = 0; base < M * rows; base += 1024) {
+    float gv[4], zv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = min(base + 256 * u + t, M * rows - 1);
+      const int m = idx / rows, r = idx - m * rows;
+      const size_t at = wg_row(pr, m, N) + r_lo + r;
+      gv[u] = ldg_global(pr.gy + at);
+      zv[u] = pr.act ? ldg_global(pr.z + at) : 0.f;              // block-uniform
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = base + 256 * u + t;
+      if (idx < M * rows) {
+        const int m = idx / rows, r = idx - m * rows;
+        gs[m * G + r] = pr.act ? gv[u] * act_bwd(zv[u], pr.act) : gv[u];
+      }
+    }
+  }
+  __syncthreads();
+  const AdamStep a = adam_step_of(ra.state, ra.lr, ra.beta1, ra.beta2, ra.eps);
+  // tile of round c formed (operand rows in ascending order, as in grouped_wgrad_t), through Adam, stored
+  auto finish = [&](int c, float4 (&pp)[RF_UNR], float4 (&mm)[RF_UNR], float4 (&vv)[RF_UNR], const int (&xo)[RF_UNR], const int (&go)[RF_UNR]) {
+    float4 acc[RF_UNR];
+#pragma unroll
+    for (int i = 0; i < RF_UNR; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int m = 0; m < M; ++m) {
+      const float* xr = xs + (size_t)m * K;
+      const float* gr = gs + m * G;
+#pragma unroll
+      for (int i = 0; i < RF_UNR; ++i) {
+        const float4 xv = *reinterpret_cast<const float4*>(xr + xo[i]);
+        const float g = gr[go[i]];
+        acc[i].x = fmaf(g, xv.x, acc[i].x); acc[i].y = fmaf(g, xv.y, acc[i].y);
+        acc[i].z = fmaf(g, xv.z, acc[i].z); acc[i].w = fmaf(g, xv.w, acc[i].w);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RF_UNR; ++i) {
+      if (c + t + 256 * i < f_hi) {
+        const size_t o = arena0 + 4 * (size_t)(c + t + 256 * i);
+        const float4 g = acc[i];
+        adam_elem(a, pp[i].x, g.x, mm[i].x, vv[i].x); adam_elem(a, pp[i].y, g.y, mm[i].y, vv[i].y);
+        adam_elem(a, pp[i].z, g.z, mm[i].z, vv[i].z); adam_elem(a, pp[i].w, g.w, mm[i].w, vv[i].w);
+        *reinterpret_cast<float4*>(ra.arena_p + o) = pp[i];
+        __builtin_nontemporal_store(f4v{mm[i].x, mm[i].y, mm[i].z, mm[i].w}, reinterpret_cast<f4v*>(ra.arena_m + o));
+        __builtin_nontemporal_store(f4v{vv[i].x, vv[i].y, vv[i].z, vv[i].w}, reinterpret_cast<f4v*>(ra.arena_v + o));
+      }
+    }
+  };
+  if constexpr (!RF_PIPE) {
+    for (int c = f_lo; c < f_hi; c += RF_ROUND_F4) {
+      if (c != f_lo) { request(c, pa, ma, va, xa, ga); asm volatile("" ::: "memory"); }   // the requests stay in front of the FMAs
+      finish(c, pa, ma, va, xa, ga);
+    }
+  } else {
+    float4 pb[RF_UNR], mb[RF_UNR], vb[RF_UNR];
+    int xb[RF_UNR], gb[RF_UNR];
+    for (int c = f_lo; c < f_hi; c += 2 * RF_ROUND_F4) {
+      const bool second = c + RF_ROUND_F4 < f_hi;                 // block-uniform
+      if (second) request(c + RF_ROUND_F4, pb, mb, vb, xb, gb);
+      asm volatile("" ::: "memory");
+      finish(c, pa, ma, va, xa, ga);
+      if (second) {
+        if (c + 2 * RF_ROUND_F4 < f_hi) request(c + 2 * RF_ROUND_F4, pa, ma, va, xa, ga);
+        asm volatile("" ::: "memory");
+        finish(c + RF_ROUND_F4, pb, mb, vb, xb, gb);
+      }
+    }
+  }
+}
+
+// One launch for a table whose first n_flat records take the flat layout (f_blocks blocks) and whose other records the
+// tiled one (t_blocks blocks, their own block prefix).  The tiled records are the layers of more rows (36: the three
+// stacked heads), whose blocks are bound by the FMAs of forming the tile, not by p / m / v: dealt evenly among the flat
+// blocks -- every P-th block of the launch -- they run beside blocks that wait for memory instead of after them.
+__global__ __launch_bounds__(256) void rank_update_mixed_k(const WgradProblem* __restrict__ table, int n_flat, int n_problems,
+                                                           RankUpdateArgs ra, int q4, int t_blocks) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x;
+  if (t_blocks > 0) {
+    const int P = (int)gridDim.x / t_blocks;                      // >= 1
+    const int q = b / P, r = b - q * P;
+    if (r == 0 && q < t_blocks) {
+      grouped_wgrad_body<true>(table + n_flat, n_problems - n_flat, ra, q, smem);
+      return;
+    }
+    rank_update_flat_body(table, n_flat, ra, q4, b - min(q + 1, t_blocks), smem);
+    return;
+  }
+  rank_update_flat_body(table, n_flat, ra, q4, b, smem);
 }
 
 // ------------------------------------------------------------------ norm of a weight gradient from its operands
@@ -2420,6 +2602,72 @@ int cgv_grouped_wgrad_adam(const void* table_dev, int n_problems, int total_bloc
                      (hipStream_t)stream, reinterpret_cast<const cgv::WgradProblem*>(table_dev), n_problems,
                      cgv::RankUpdateArgs{arena_g, arena_p, arena_m, arena_v, state, lr, beta1, beta2, eps});
   return cgv::check_launch("cgv_grouped_wgrad_adam");
+}
+
+/* The same update with the FLAT block layout (rank_update_flat_body: every block a contiguous range of a weight's p / m / v,
+ * whole lines, read and written once).  cgv_rank_flat_plan: blocks + LDS floats of one record, non-zero when the shape
+ * does not take it (more than 16 operand rows, or x [M, K] + the g rows beyond the LDS budget) -- then the whole launch
+ * stays with cgv_grouped_wgrad_adam.  The records' block_begin must be the prefix of THESE block counts; tiles_k / tile_w
+ * are unused.  q4: float4 per block, a multiple of 2048 (0: the default). */
+int cgv_rank_flat_quantum(void) { return 2 * cgv::RF_QUANTUM_F4; }
+
+int cgv_rank_flat_plan(int M, int N, int K, int q4, int* n_blocks, int* lds_floats) {
+  CGV_REQUIRE(n_blocks && lds_floats, "null pointer");
+  if (q4 <= 0) q4 = cgv_rank_flat_quantum();
+  CGV_REQUIRE(q4 % cgv::RF_QUANTUM_F4 == 0, "q4 must be a multiple of 2048 float4");
+  if (!cgv_rank_update_supported(M, N, K) || M > cgv::RF_MAX_ROWS) return CGV_E_UNSUPPORTED;
+  const int K4 = K / 4;
+  const int g_rows = q4 / K4 + 2 < N ? q4 / K4 + 2 : N;
+  const long lds = (long)M * (K + g_rows);
+  if (lds > 16000 || (long)N * K4 > 0x7fffffffL - q4) return CGV_E_UNSUPPORTED;
+  *n_blocks = (int)(((long)N * K4 + q4 - 1) / q4);
+  *lds_floats = (int)lds;
+  return 0;
+}
+
+int cgv_grouped_wgrad_adam_flat(const void* table_dev, int n_problems, int total_blocks, int max_lds_floats, int q4,
+                                const float* arena_g, float* arena_p, float* arena_m, float* arena_v, float lr, float beta1,
+                                float beta2, float eps, const float* state, void* stream) {
+  CGV_REQUIRE(n_problems >= 0 && total_blocks >= 0, "bad size");
+  if (n_problems == 0 || total_blocks == 0) return 0;
+  if (q4 <= 0) q4 = cgv_rank_flat_quantum();
+  CGV_REQUIRE(q4 % cgv::RF_QUANTUM_F4 == 0, "q4 must be a multiple of 2048 float4");
+  CGV_REQUIRE(table_dev && arena_g && arena_p && arena_m && arena_v && state, "null pointer");
+  CGV_REQUIRE(max_lds_floats > 0 && max_lds_floats <= 16000, "LDS request out of range");
+  CGV_REQUIRE(((((uintptr_t)arena_g | (uintptr_t)arena_p | (uintptr_t)arena_m | (uintptr_t)arena_v)) & 15) == 0,
+              "arenas must be 16-byte aligned");
+  hipLaunchKernelGGL(cgv::rank_update_mixed_k, dim3(total_blocks), dim3(256), sizeof(float) * (size_t)max_lds_floats,
+                     (hipStream_t)stream, reinterpret_cast<const cgv::WgradProblem*>(table_dev), n_problems, n_problems,
+                     cgv::RankUpdateArgs{arena_g, arena_p, arena_m, arena_v, state, lr, beta1, beta2, eps}, q4, 0);
+  return cgv::check_launch("cgv_grouped_wgrad_adam_flat");
+}
+
+/* One launch for BOTH layouts: records [0, n_flat) of the table flat (flat_blocks blocks, prefix from 0), records
+ * [n_flat, n_problems) tiled as for cgv_grouped_wgrad_adam (tiled_blocks blocks, their own prefix from 0).  The tiled
+ * blocks -- layers of more operand rows, bound by forming the tile rather than by p / m / v -- are dealt evenly among the
+ * flat ones.  max_lds_floats: the larger of the two layouts' requests. */
+int cgv_grouped_wgrad_adam_mixed(const void* table_dev, int n_flat, int n_problems, int flat_blocks, int tiled_blocks,
+                                 int max_lds_floats, int q4, const float* arena_g, float* arena_p, float* arena_m,
+                                 float* arena_v, float lr, float beta1, float beta2, float eps, const float* state,
+                                 void* stream) {
+  CGV_REQUIRE(n_flat >= 0 && n_problems >= n_flat && flat_blocks >= 0 && tiled_blocks >= 0, "bad size");
+  CGV_REQUIRE((n_flat > 0) == (flat_blocks > 0) && (n_problems > n_flat) == (tiled_blocks > 0), "records and blocks disagree");
+  if (n_problems == 0) return 0;
+  if (q4 <= 0) q4 = cgv_rank_flat_quantum();
+  CGV_REQUIRE(q4 % cgv::RF_QUANTUM_F4 == 0, "q4 must be a multiple of 2048 float4");
+  CGV_REQUIRE(table_dev && arena_g && arena_p && arena_m && arena_v && state, "null pointer");
+  CGV_REQUIRE(max_lds_floats > 0 && max_lds_floats <= 16000, "LDS request out of range");
+  CGV_REQUIRE(((((uintptr_t)arena_g | (uintptr_t)arena_p | (uintptr_t)arena_m | (uintptr_t)arena_v)) & 15) == 0,
+              "arenas must be 16-byte aligned");
+  const cgv::RankUpdateArgs ra{arena_g, arena_p, arena_m, arena_v, state, lr, beta1, beta2, eps};
+  const cgv::WgradProblem* table = reinterpret_cast<const cgv::WgradProblem*>(table_dev);
+  if (n_flat == 0)
+    hipLaunchKernelGGL(cgv::grouped_wgrad_t<true>, dim3(tiled_blocks), dim3(256), sizeof(float) * (size_t)max_lds_floats,
+                       (hipStream_t)stream, table, n_problems, ra);
+  else
+    hipLaunchKernelGGL(cgv::rank_update_mixed_k, dim3(flat_blocks + tiled_blocks), dim3(256), sizeof(float) * (size_t)max_lds_floats,
+                       (hipStream_t)stream, table, n_flat, n_problems, ra, q4, tiled_blocks);
+  return cgv::check_launch("cgv_grouped_wgrad_adam_mixed");
 }
 
 /* Weight gradients over gathered operand rows (include/cgvae_hip.h: data-parallel operand exchange). */

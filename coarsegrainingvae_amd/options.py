@@ -13,6 +13,8 @@ HOST = {
     "table_upload": 0,      # record tables of a captured step: 0 copied once after capture, 1 a copy node in every replay
     "wgrad_tile": 64,       # output tile edge of the grouped MFMA weight-gradient launch: 64 or 128
     "rank_update": 1,       # Trainer: 1 rank update of the bead-level layers where it pays, 0 every gradient materialised (A/B)
+    "rank_flat": 2,         # rank update of <= 16-row layers: contiguous ranges of rank_flat x 2048 float4 of a weight per block (0: 64 rows x one k tile)
+    "rank_mixed": 1,        # ... and the layers that stay tiled (more rows) in the SAME launch, their blocks dealt among the flat ones (0: a second launch)
     "rank_rows_mfma": -1,   # single process: rows up to which layers beyond 40 rows take the MFMA rank update (-1: Trainer.RANK_ROWS_MFMA)
     "rank_gram_rows": -1,   # MFMA rank update: rows up to which the norm comes from the Gram launch instead of a tile pass (-1: Trainer.RANK_GRAM_ROWS)
     "concurrent_prior": 0,  # CGequiVAE.forward: 1 the prior net (bead graph) on a side stream beside the encoder -- a forked branch of the captured step

@@ -212,6 +212,43 @@ class WeightGradQueue:
             max_lds = max(max_lds, lib.cgv_wgrad_lds_floats(M, tw.value))
         return self.upload(bytes(buf), items[0][0].device), block_begin, max_lds
 
+    def rank_table(self, items, q4=0):
+        """Records of the rank-update launches for ``items`` (at most 64 rows each), the layers that take the FLAT layout
+        (cgv_rank_flat_plan: <= 16 rows, x [M, K] + g within the LDS budget; contiguous ranges of q4 float4 of a weight per
+        block) first, the others (64 rows x one k tile per block) behind them -- each part with its own block prefix, so
+        the flat launch reads records [0, n_flat) and the tiled launch the rest of ONE uploaded table; the Gram-norm
+        launch reads all of it (it does not look at the block fields).  q4 < 0: every record tiled.
+        Returns (table, ordered items, (n_flat, blocks, lds floats, q4), (n_tiled, blocks, lds floats))."""
+        lib = _lib.load()
+        q4 = int(lib.cgv_rank_flat_quantum()) if q4 == 0 else int(q4)
+        nb, lds, tk, tw = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        flat, tiled = [], []
+        for it in items:
+            M, N = it[0].shape
+            ok = q4 > 0 and not it[6] and lib.cgv_rank_flat_plan(M, N, it[1].shape[1], q4, C.byref(nb), C.byref(lds)) == 0
+            (flat if ok else tiled).append((it, nb.value, lds.value) if ok else (it, 0, 0))
+        buf = bytearray()
+        f_blocks = f_lds = t_blocks = t_lds = 0
+        for (gy, x, z, act, gW, gb, accumulate), n_blocks, n_lds in flat:
+            buf += self.RECORD.pack(gy.data_ptr(), x.data_ptr(), z.data_ptr() if z is not None else 0, gW.data_ptr(),
+                                    gb.data_ptr() if gb is not None else 0, gy.shape[0], gy.shape[1], x.shape[1], 0, int(act),
+                                    f_blocks, 0, 0, 0, 0, 0)
+            f_blocks += n_blocks
+            f_lds = max(f_lds, n_lds)
+        for (gy, x, z, act, gW, gb, accumulate), _b, _l in tiled:
+            M, N = gy.shape
+            K = x.shape[1]
+            if lib.cgv_wgrad_plan(M, N, K, C.byref(tk), C.byref(tw), C.byref(nb)) != 0:
+                raise RuntimeError(lib.cgv_last_error_string().decode())
+            buf += self.RECORD.pack(gy.data_ptr(), x.data_ptr(), z.data_ptr() if z is not None else 0, gW.data_ptr(),
+                                    gb.data_ptr() if gb is not None else 0, M, N, K, int(accumulate), int(act),
+                                    t_blocks, tk.value, tw.value, 0, 0, 0)
+            t_blocks += nb.value
+            t_lds = max(t_lds, lib.cgv_wgrad_lds_floats(M, tw.value))
+        ordered = [f[0] for f in flat] + [t[0] for t in tiled]
+        return (self.upload(bytes(buf), items[0][0].device), ordered, (len(flat), f_blocks, f_lds, q4 if flat else 0),
+                (len(tiled), t_blocks, t_lds))
+
     # Operand rows from which the strip layout of the MFMA launch beats the weight-streaming VALU kernel (same 57
     # bead-level problems of a chignolin step, tools/wgrad_strip_bench.py: 12 rows 46 against 76 us, 24 rows 72 / 80,
     # 36 rows 113 / 94, 64 rows 252 / 108); it takes at most cgv_wgrad_strip_max_rows() = 128.

@@ -952,7 +952,7 @@ class Trainer:
                 # kept for bench.py's optimiser timing: the table points at the operand rows, so they must stay alive --
                 # DETACHED (a retained autograd graph would pin its AccumulateGrad nodes to this step's stream, and a
                 # later capture on another stream then dies in hipStreamEndCapture)
-                self.last_rank_step = rank[:4] + ([tuple(t.detach() if torch.is_tensor(t) else t for t in it) for it in rank[4]], rank[5])
+                self.last_rank_step = rank[:4] + ([tuple(t.detach() if torch.is_tensor(t) else t for t in it) for it in rank[4]],) + rank[5:]
             lo = self._rank_hi if (rank or mfma) else 0      # [0, lo): gradients that exist only as operand rows
             _lib.call("cgv_optim_prepare_extra", a.g.data_ptr() + 4 * lo, a.numel - lo,
                       _lib.ptr(self._rank_sumsq) if (rank or mfma) else None,
@@ -965,10 +965,7 @@ class Trainer:
             else:
                 self._adam_apply(lo, a.numel)
                 if rank:
-                    table, n, blocks, lds, _items, _rows = rank
-                    _lib.call("cgv_grouped_wgrad_adam", _lib.ptr(table), n, blocks, lds, _lib.ptr(a.g), _lib.ptr(a.p),
-                              _lib.ptr(self.m), _lib.ptr(self.v), self.lr, self.betas[0], self.betas[1], self.eps,
-                              _lib.ptr(self.state), _lib.stream_ptr(), tag="grouped_wgrad_adam")
+                    self.rank_update_launch(rank, a.p, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.state)
                     self.rank_steps += 1
                 if mfma:
                     for kind, table, n, blocks, rows in mfma[0]:
@@ -1010,6 +1007,26 @@ class Trainer:
     # ranges below 4 MiB are not worth a collective of their own (a collective node costs the replayed step 7 - 40 us even on a
     # 1-rank group, tools/dp_rccl1_probe.py): they wait for the next bucket boundary, whose range continues theirs
     EARLY_MIN_FLOATS = 1 << 20
+
+    def rank_update_launch(self, rank, p, m, v, lr, beta1, beta2, eps, state):
+        """The fused weight-gradient / Adam launches of a rank step ``(table, records, tiled blocks, tiled lds, items, rows,
+        (n_flat, flat blocks, flat lds, q4))`` on the arenas p / m / v: records [0, n_flat) with the flat layout, the rest
+        as 64 rows x one k tile per block (primitives.WeightGradQueue.rank_table)."""
+        table, n, blocks, lds, _items, _rows, (n_flat, f_blocks, f_lds, q4) = rank
+        from .options import HOST
+        if n_flat and (n == n_flat or HOST["rank_mixed"]):
+            # one launch: the tiled blocks (layers of more rows, bound by forming their tiles) dealt among the flat ones
+            _lib.call("cgv_grouped_wgrad_adam_mixed", _lib.ptr(table), n_flat, n, f_blocks, blocks if n > n_flat else 0, max(lds, f_lds), q4,
+                      _lib.ptr(self.arena.g), _lib.ptr(p), _lib.ptr(m), _lib.ptr(v), lr, beta1, beta2, eps, _lib.ptr(state),
+                      _lib.stream_ptr(), tag="grouped_wgrad_adam")
+            return
+        if n_flat:
+            _lib.call("cgv_grouped_wgrad_adam_flat", _lib.ptr(table), n_flat, f_blocks, f_lds, q4, _lib.ptr(self.arena.g), _lib.ptr(p),
+                      _lib.ptr(m), _lib.ptr(v), lr, beta1, beta2, eps, _lib.ptr(state), _lib.stream_ptr(), tag="grouped_wgrad_adam")
+        if n > n_flat:
+            _lib.call("cgv_grouped_wgrad_adam", table.data_ptr() + wgrad_queue.RECORD.size * n_flat, n - n_flat, blocks, lds,
+                      _lib.ptr(self.arena.g), _lib.ptr(p), _lib.ptr(m), _lib.ptr(v), lr, beta1, beta2, eps, _lib.ptr(state),
+                      _lib.stream_ptr(), tag="grouped_wgrad_adam")
 
     def _rank_rows_mfma(self):
         from .options import HOST
@@ -1059,7 +1076,10 @@ class Trainer:
             self.rank_fallbacks += 1
             return items
         if small:
-            table, blocks, lds = wgrad_queue.small_table(small)
+            # the update launch: flat layout for the layers that take it (<= 16 operand rows: a single process' bead rows),
+            # 64 rows x one k tile per block for the others (the 36-row layer of the three stacked heads)
+            from .options import HOST
+            table, small, flat, (_n_tiled, blocks, lds) = wgrad_queue.rank_table(small, HOST["rank_flat"] * 2048 if HOST["rank_flat"] > 0 else -1)
             need = int(lib.cgv_wgrad_gram_workspace_bytes(len(small)))
             if self._rank_ws is None or self._rank_ws.numel() < need:
                 if torch.cuda.is_current_stream_capturing():
@@ -1068,7 +1088,7 @@ class Trainer:
             rows = max(it[0].shape[0] for it in small)
             _lib.call("cgv_wgrad_gram", _lib.ptr(table), len(small), rows, _lib.ptr(self._rank_sumsq), _lib.ptr(self._rank_ws),
                       self._rank_ws.numel(), _lib.stream_ptr(), tag="wgrad_gram")
-            self._rank_step = (table, len(small), blocks, lds, small, rows)
+            self._rank_step = (table, len(small), blocks, lds, small, rows, flat)
         if large:
             self._start_mfma_rank_update(large, None, len(small))
         return rest
@@ -1116,7 +1136,7 @@ class Trainer:
                 self._rank_ws = torch.empty(need, dtype=torch.uint8, device=self.arena.p.device)
             _lib.call("cgv_wgrad_gram", _lib.ptr(table), len(small), rows, _lib.ptr(self._rank_sumsq), _lib.ptr(self._rank_ws),
                       self._rank_ws.numel(), _lib.stream_ptr(), tag="wgrad_gram")
-            self._rank_step = (table, len(small), block_begin, max_lds, small, rows)
+            self._rank_step = (table, len(small), block_begin, max_lds, small, rows, (0, 0, 0, 0))
         if large:
             self._start_mfma_rank_update(large, world, len(small))
 

@@ -811,6 +811,30 @@ int cgv_optim_prepare_extra(const float* g, int64_t n, const double* extra, int 
 int cgv_grouped_wgrad_adam(const void* table_dev, int n_problems, int total_blocks, int max_lds_floats,
                            const float* arena_g, float* arena_p, float* arena_m, float* arena_v, float lr, float beta1,
                            float beta2, float eps, const float* state, void* stream);
+/* cgv_grouped_wgrad_adam with the FLAT block layout, for records of at most 16 operand rows: the update is elementwise over
+ * a weight's contiguous [N, K] array, so a block takes a contiguous range of q4 float4 of it (whole 128-byte lines of
+ * p / m / v, each read and written exactly once) with x for all K columns and the g rows of its range in LDS, instead of
+ * 64 rows x one k tile (row segments at a stride of K floats, whose border lines neighbouring blocks fetch twice).  Same
+ * sum order over the operand rows: results are bit-identical to cgv_grouped_wgrad_adam.
+ *   cgv_rank_flat_quantum   default q4 (float4 per block; any multiple of 2048 is accepted, 0 = this default)
+ *   cgv_rank_flat_plan      blocks / LDS floats of one record; CGV_E_UNSUPPORTED when the shape does not take the layout
+ *                           (more than 16 rows, or x [M, K] + g beyond the LDS budget) -- the launch then stays with
+ *                           cgv_grouped_wgrad_adam.  A table's block_begin is the prefix of THESE block counts.
+ * Replaces, like cgv_grouped_wgrad_adam, the autograd weight gradient of the bead-level nn.Linear / Dense layers
+ * (modules.py Dense) + torch.optim.Adam.step on them (scripts/run_ala.py:147, utils.py:157). */
+int cgv_rank_flat_quantum(void);
+int cgv_rank_flat_plan(int M, int N, int K, int q4, int* n_blocks /*[host]*/, int* lds_floats /*[host]*/);
+int cgv_grouped_wgrad_adam_flat(const void* table_dev, int n_problems, int total_blocks, int max_lds_floats, int q4,
+                                const float* arena_g, float* arena_p, float* arena_m, float* arena_v, float lr, float beta1,
+                                float beta2, float eps, const float* state, void* stream);
+/* Both layouts in ONE launch: records [0, n_flat) flat (flat_blocks blocks, block prefix from 0), records [n_flat, n_problems)
+ * tiled as for cgv_grouped_wgrad_adam (tiled_blocks blocks, their own prefix from 0).  The tiled records are layers of
+ * more operand rows (36: three stacked heads), bound by the FMAs that form a tile rather than by p / m / v: their blocks are
+ * dealt evenly among the flat ones, so they run beside blocks that wait for memory.  max_lds_floats: the larger request. */
+int cgv_grouped_wgrad_adam_mixed(const void* table_dev, int n_flat, int n_problems, int flat_blocks, int tiled_blocks,
+                                 int max_lds_floats, int q4, const float* arena_g, float* arena_p, float* arena_m,
+                                 float* arena_v, float lr, float beta1, float beta2, float eps, const float* state,
+                                 void* stream);
 
 #ifdef __cplusplus
 }

@@ -1885,6 +1885,81 @@ def test_rank_update_kernels_on_random_shapes():
     assert float(arena_g.abs().max()) == 0.0                               # never written
 
 
+@pytest.mark.parametrize("rounds,mixed", [(1, 1), (2, 1), (2, 0), (5, 1)])
+def test_flat_rank_update_equals_the_tiled_launch_bit_for_bit(rounds, mixed, options):
+    """cgv_grouped_wgrad_adam_flat (contiguous ranges of a weight's p / m / v per block, x for all K columns + the g rows of
+    the range in LDS) against cgv_grouped_wgrad_adam (64 rows x one k tile per block) on the same records: the operand rows
+    are summed in the same order, so p, m and v agree BIT FOR BIT after two updates -- ragged sizes (a weight smaller
+    than one block, K of 4, ranges that end mid row), activations, 1 - 16 rows, and a 36-row layer that stays tiled in the
+    same table (WeightGradQueue.rank_table: flat records first, each part with its own block prefix) -- as a second launch
+    or, ``rank_mixed``, in the same launch with its blocks dealt among the flat ones; a skipped step
+    leaves the arenas alone; shapes beyond the layout (17 rows, x beyond the LDS budget) are refused by the plan."""
+    import ctypes as C
+    from coarsegrainingvae_amd.primitives import WeightGradQueue
+    from coarsegrainingvae_amd.trainer import Trainer
+    lib = cg._lib.load()
+    options.set("rank_mixed", mixed)
+    g = torch.Generator(device=DEV).manual_seed(77 + rounds)
+    shapes = [(12, 600, 600, 1), (36, 1200, 600, 1), (12, 1800, 600, 0), (12, 600, 1200, 1), (16, 52, 900, 2), (1, 4, 700, 0),
+              (7, 700, 4, 1), (3, 333 * 4, 36, 3), (12, 5400, 600, 0), (5, 8, 8, 1)]
+    n_total = sum(N * K for _, N, K, _ in shapes)
+    arena_g = torch.zeros(n_total, device=DEV)
+    p0 = torch.randn(n_total, device=DEV, generator=g)
+    items, off = [], 0
+    for M, N, K, act in shapes:
+        gy, x = torch.randn(M, N, device=DEV, generator=g), torch.randn(M, K, device=DEV, generator=g)
+        z = torch.randn(M, N, device=DEV, generator=g) if act else None
+        items.append((gy, x, z, act, arena_g[off:off + N * K].view(N, K), None, False))
+        off += N * K
+    q = WeightGradQueue()
+    t_table, t_items, t_flat, t_tiled = q.rank_table(items, -1)
+    f_table, f_items, f_flat, f_tiled = q.rank_table(items, rounds * 2048)
+    assert t_flat[0] == 0 and t_tiled[0] == len(items) and [id(a) for a in t_items] == [id(a) for a in items]
+    assert f_flat[0] == len(items) - 1 and f_flat[3] == rounds * 2048 and f_tiled[0] == 1 and f_items[-1][0].shape[0] == 36
+    ws = torch.empty(int(lib.cgv_wgrad_gram_workspace_bytes(len(items))), dtype=torch.uint8, device=DEV)
+    sums = []
+    for table in (t_table, f_table):                  # the norm launch reads either table (block fields unused)
+        sumsq = torch.zeros(len(items), dtype=torch.float64, device=DEV)
+        cg._lib.call("cgv_wgrad_gram", cg._lib.ptr(table), len(items), 36, cg._lib.ptr(sumsq), cg._lib.ptr(ws), ws.numel(), cg._lib.stream_ptr())
+        sums.append(sumsq)
+    order = [[id(a) for a in f_items].index(id(a)) for a in items]
+    assert torch.equal(sums[0], sums[1][order])
+    state = torch.zeros(lib.cgv_optim_state_floats(), device=DEV)
+    partial = torch.zeros(lib.cgv_optim_partial_floats(), device=DEV)
+    lr, b1, b2, eps = 1e-2, 0.9, 0.999, 1e-8
+
+    class Arena:                                        # what Trainer.rank_update_launch reads of its trainer
+        pass
+    holder = Arena()
+    holder.arena = Arena()
+    holder.arena.g = arena_g
+    out = []
+    for table, ordered, flat, tiled, sq in ((t_table, t_items, t_flat, t_tiled, sums[0]), (f_table, f_items, f_flat, f_tiled, sums[1])):
+        p, m, v = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+        state.zero_()
+        rank = (table, len(items), tiled[1], tiled[2], ordered, 36, flat)
+        for _step in range(2):
+            cg._lib.call("cgv_optim_prepare_extra", arena_g.data_ptr(), 0, cg._lib.ptr(sq), len(items), b1, b2, 0.5, 1.0,
+                         None, 0.0, cg._lib.ptr(state), cg._lib.ptr(partial), cg._lib.stream_ptr())       # clipped: ||g|| >> 0.5
+            Trainer.rank_update_launch(holder, rank, p, m, v, lr, b1, b2, eps, state)
+        out.append((p, m, v))
+    for a, b, name in zip(out[0], out[1], "pmv"):
+        assert torch.equal(a, b), f"{name}: flat and tiled layouts differ (max {float((a - b).abs().max()):.3e})"
+    assert float((out[1][0] != p0).float().mean()) > 0.9 and float(out[1][2].min()) >= 0.0     # (a relu layer with every row off stays)
+    assert float(arena_g.abs().max()) == 0.0                               # never written
+    # a skipped step (loss above the threshold): nothing moves
+    p, m, v = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    loss = torch.full((1,), 10.0, device=DEV)
+    cg._lib.call("cgv_optim_prepare_extra", arena_g.data_ptr(), 0, cg._lib.ptr(sums[1]), len(items), b1, b2, 0.5, 1.0, cg._lib.ptr(loss), 1.0,
+                 cg._lib.ptr(state), cg._lib.ptr(partial), cg._lib.stream_ptr())
+    Trainer.rank_update_launch(holder, (f_table, len(items), f_tiled[1], f_tiled[2], f_items, 36, f_flat), p, m, v, lr, b1, b2, eps, state)
+    assert torch.equal(p, p0) and float(m.abs().max()) == 0.0
+    nb, lds = C.c_int(), C.c_int()
+    assert lib.cgv_rank_flat_plan(17, 600, 600, 0, C.byref(nb), C.byref(lds)) != 0          # more than 16 rows
+    assert lib.cgv_rank_flat_plan(12, 600, 1800, 0, C.byref(nb), C.byref(lds)) != 0         # x [12, 1800] beyond the LDS budget
+    assert lib.cgv_rank_flat_plan(12, 600, 600, 0, C.byref(nb), C.byref(lds)) == 0 and nb.value == (600 * 150 + 4095) // 4096
+
+
 def test_prefetched_double_buffered_steps_equal_plain_replays():
     """``Trainer.enable_prefetch``: the next batch is loaded into a second buffer set on a side stream while the current
     step's graph runs.  Same batches, same order => the same losses and parameters as loading each batch on the main
