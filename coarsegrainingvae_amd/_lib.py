@@ -195,7 +195,7 @@ PROTOTYPES = {
 OPTIONS = {"msg_fwd_split": 0, "msg_bwd_split": 1, "msg_fwd_kernel": 2, "grp_waves": 3, "grp_records": 4, "csr_build": 5,
            "pseudo_chunks": 6, "wgrad_tiling": 7, "tile_fwd_lds_min": 8, "bwd_input_waves": 9, "pseudo_fwd": 10, "decoder_fat": 11, "decoder_wlds": 12, "skinny_rows": 13,
            "tile_fwd_bal": 14, "optim_one_launch": 15, "decoder_colsplit": 16, "decoder_nodesplit": 17,
-           "msg_fwd_balanced": 18, "bwd_input_split": 19}
+           "msg_fwd_balanced": 18, "bwd_input_split": 19, "msg_bwd_mfma": 20}
 
 
 def set_option(name: str, value: int) -> None:

@@ -597,6 +597,176 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void equi_msg_bwd_k(
   }
 }
 
+// ------------------------------------------------------------------ backward, scalar-only upstream, on the matrix cores
+// Without a vector gradient the edge loop of equi_msg_bwd_k accumulates only  N[n][c] += a_n(e) gs[dst(e)][c]  per source
+// node (R + 1 packed FMAs per edge and 128-channel wave) -- but each edge costs that wave a record through the scalar cache
+// (three loads, ~20 scalar instructions of addressing) and a row gather, and the loop runs at 187 cycles per edge where
+// its FMAs need 44 (2000-atom graph: 390 us per launch).  N is a product: A^T [16 x edges] (the record's first 16 floats:
+// a_0 .. a_{R-1}, env; the rows beyond R are never read) times the gathered rows [edges x channels], summed over the node's
+// edges -- v_mfma_f32_16x16x4_f32 takes 4 edges per instruction, its A operand is ONE coalesced dword load per lane (lane
+// (k, n): float n of edge k's record), its B operand the receivers' rows as 16-byte pieces (lane (k, col): channels
+// c0 + 64 h + 4 col .. + 3 of edge k's receiver; a tile T = 4 h + t holds channel 4 col + t of half h), no scalar stream, no
+// broadcast.  The fp32 MFMA is an fmaf chain over k: the edge order of the sums is the one of the FMA loop.
+// A block = (chunk of source nodes, 128 channels), its 4 waves share each node's segment; every wave deposits its 8 tiles
+// and wave w finishes tiles 2 w, 2 w + 1 (g_phi = W . N over the rows it holds, then across the four row groups; the filter
+// gradient p1 N accumulated over the chunk), so no wave runs a tail alone.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int R>
+__global__ __launch_bounds__(64 * BWD_WAVES) void equi_msg_bwd_mfma_k(
+    const float* __restrict__ phi, const float* __restrict__ geom, const int* __restrict__ rowptr, const int* __restrict__ dst,
+    const float* __restrict__ Wd, const float* __restrict__ bd, const float* __restrict__ gs, float* __restrict__ g_phi,
+    float* __restrict__ part, int F, int n_src, int nodes_per_chunk, int chunks_per_xcd, int tiles) {
+  constexpr int GS = geom_stride(R);
+  __shared__ float red[BWD_WAVES * 32 * 64];
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int n_chunks = 8 * chunks_per_xcd;
+  const int item = xcd * chunks_per_xcd * tiles + slot;
+  const int tile = item / n_chunks;
+  const int chunk = item - tile * n_chunks;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = lane >> 4, col = lane & 15;
+  const int c0 = tile * 128;
+  // columns gathered (clamped into the row: surplus columns are computed and never stored)
+  const int cb0 = min(c0 + 4 * col, F - 4), cb1 = min(c0 + 64 + 4 * col, F - 4);
+  // the two channels this lane finishes: tiles 2 wave, 2 wave + 1 of its column
+  const int cf = c0 + 64 * (wave >> 1) + 4 * col + 2 * (wave & 1);
+  const bool live = cf < F;                                         // (F is even: cf + 1 < F as well)
+  float Wl[2][4], Gl[2][4];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = 4 * q + r;
+      Gl[u][r] = 0.f;
+      Wl[u][r] = (live && n <= R) ? (n < R ? Wd[(size_t)(F + cf + u) * R + n] : bd[F + cf + u]) : 0.f;
+    }
+  const int n_beg = chunk * nodes_per_chunk;
+  const int n_end = min(n_beg + nodes_per_chunk, n_src);
+#ifndef CGV_K2BM_DEPTH
+#define CGV_K2BM_DEPTH 1
+#endif
+#ifndef CGV_K2BM_RDEPTH
+#define CGV_K2BM_RDEPTH (CGV_K2BM_DEPTH + 2)
+#endif
+  constexpr int DG = CGV_K2BM_DEPTH, DR = CGV_K2BM_RDEPTH;         // rows DG batches ahead of the products, records DR
+  // lane (k = q, n = col) of a batch of 4 edges: the receiver of edge k and float n of its record; edges beyond the slice
+  // [b, e_end) contribute a zero row of A (their loads go to the slice's first edge)
+  auto rec = [&](int e0, int b, int e_end, int& idx, float& a) {
+    const int e = e0 + q;
+    const bool ok = e < e_end;
+    const int ec = ok ? e : b;
+    idx = dst[ec];
+    const float t = geom[(size_t)ec * GS + col];
+    a = ok ? t : 0.f;
+  };
+  auto gather = [&](int idx, f32x4& B0, f32x4& B1) {
+    const float* __restrict__ row = gs + (size_t)idx * F;
+    B0 = *reinterpret_cast<const f32x4*>(row + cb0);
+    B1 = *reinterpret_cast<const f32x4*>(row + cb1);
+  };
+  auto slice_of = [&](int j, int& b, int& e_end) {
+    const int beg = rowptr[j], end = rowptr[j + 1];
+    const int len = (end - beg + BWD_WAVES - 1) / BWD_WAVES;
+    b = min(beg + wave * len, end);
+    e_end = min(b + len, end);
+  };
+  int ii[DR];
+  float aa[DR];
+  f32x4 Bq0[DG + 1], Bq1[DG + 1];
+  // first records and rows of a slice: requested before the PREVIOUS node's sums are exchanged and finished, so the two
+  // dependent round trips (receiver index -> row) of a node's start run under that tail
+  auto open_slice = [&](int b, int e_end) {
+    if (b < e_end) {
+#pragma unroll
+      for (int k = 0; k < DR; ++k) rec(b + 4 * k, b, e_end, ii[k], aa[k]);
+#pragma unroll
+      for (int k = 0; k < DG; ++k) gather(ii[k], Bq0[k], Bq1[k]);
+    }
+  };
+  int b = 0, e_end = 0;
+  if (n_beg < n_end) {
+    slice_of(n_beg, b, e_end);
+    open_slice(b, e_end);
+  }
+  for (int j = n_beg; j < n_end; ++j) {
+    f32x4 acc[8];
+#pragma unroll
+    for (int T = 0; T < 8; ++T) acc[T] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int e0 = b; e0 < e_end; e0 += 4) {
+      int i_new;
+      float a_new;
+      rec(e0 + 4 * DR, b, e_end, i_new, a_new);
+      gather(ii[DG], Bq0[DG], Bq1[DG]);
+      const float a0 = aa[0];
+      const f32x4 B0 = Bq0[0], B1 = Bq1[0];
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, B0.x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, B0.y, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, B0.z, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, B0.w, acc[3], 0, 0, 0);
+      acc[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, B1.x, acc[4], 0, 0, 0);
+      acc[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, B1.y, acc[5], 0, 0, 0);
+      acc[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, B1.z, acc[6], 0, 0, 0);
+      acc[7] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, B1.w, acc[7], 0, 0, 0);
+#pragma unroll
+      for (int k = 0; k + 1 < DR; ++k) { ii[k] = ii[k + 1]; aa[k] = aa[k + 1]; }
+      ii[DR - 1] = i_new; aa[DR - 1] = a_new;
+#pragma unroll
+      for (int k = 0; k < DG; ++k) { Bq0[k] = Bq0[k + 1]; Bq1[k] = Bq1[k + 1]; }
+    }
+    if (j + 1 < n_end) {
+      slice_of(j + 1, b, e_end);
+      open_slice(b, e_end);
+    }
+    // every wave deposits its tiles (register r of tile T: row 4 q + r, column col); wave w sums tiles 2 w, 2 w + 1 in wave order
+#pragma unroll
+    for (int T = 0; T < 8; ++T)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[((wave * 8 + T) * 4 + r) * 64 + lane] = acc[T][r];
+    // p1 of the finished channels: requested ahead of the barrier
+    float2 p1 = make_float2(0.f, 0.f);
+    if (live) p1 = *reinterpret_cast<const float2*>(phi + (size_t)j * 3 * F + F + cf);
+    __syncthreads();
+    float Nn[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < BWD_WAVES; ++w) sum += red[((w * 8 + 2 * wave + u) * 4 + r) * 64 + lane];
+        Nn[u][r] = sum;
+      }
+    __syncthreads();                                   // (the deposits of the next node overwrite red)
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      s0 = fmaf(Wl[0][r], Nn[0][r], s0);
+      s1 = fmaf(Wl[1][r], Nn[1][r], s1);
+      Gl[0][r] = fmaf(p1.x, Nn[0][r], Gl[0][r]);
+      Gl[1][r] = fmaf(p1.y, Nn[1][r], Gl[1][r]);
+    }
+    s0 += __shfl_xor(s0, 16); s0 += __shfl_xor(s0, 32);
+    s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+    if (live) {
+      float* __restrict__ grow = g_phi + (size_t)j * 3 * F + cf;
+      if (q == 0) *reinterpret_cast<float2*>(grow + F) = make_float2(s0, s1);
+      else if (q == 1) *reinterpret_cast<float2*>(grow) = make_float2(0.f, 0.f);            // slices 0 and 2: no vector gradient
+      else if (q == 2) *reinterpret_cast<float2*>(grow + 2 * F) = make_float2(0.f, 0.f);
+    }
+  }
+  // block partial of the filter-weight gradient: part[chunk][n][F]
+  if (live) {
+    float* __restrict__ out = part + (size_t)chunk * (R + 1) * F + cf;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = 4 * q + r;
+      if (n <= R) *reinterpret_cast<float2*>(out + (size_t)n * F) = make_float2(Gl[0][r], Gl[1][r]);
+    }
+  }
+}
+
 // second stage: gWd[c][n] = sum_chunk part[chunk][k][n][f]; c = kk*F + f over all 3 slices.
 // K live slices: K == 3 -> kk = k; K == 1 -> only kk == 1 is live, the rest is written as 0.
 // block = (64 channels, 16 chunk slices): slice s sums chunks s, s+16, ... and the 16 partial sums
@@ -835,6 +1005,15 @@ static int equi_msg_bwd_impl(const float* phi, const float* v, const float* geom
                     ((((uintptr_t)phi | (uintptr_t)v | (uintptr_t)gs | (uintptr_t)gv | (uintptr_t)g_phi |
                        (uintptr_t)g_v | (uintptr_t)part) & 7) == 0) &&
                     ((((uintptr_t)Wd) & 15) == 0) && ((((uintptr_t)bd) & 7) == 0);
+  // scalar-only upstream on a high-degree graph: the matrix-core kernel (cgv_set_option(CGV_OPT_MSG_BWD_MFMA, 0) keeps the
+  // packed-FMA walk for A/B runs)
+  if (!gv && gs && sh.split && n_rbf + 1 <= 16 && (n_feat % 4) == 0 && cgv::option(CGV_OPT_MSG_BWD_MFMA) != 0 &&
+      ((((uintptr_t)gs) & 15) == 0) && ((((uintptr_t)phi | (uintptr_t)g_phi | (uintptr_t)part) & 7) == 0)) {
+    CGV_DISPATCH_RBF(n_rbf, {
+      hipLaunchKernelGGL((cgv::equi_msg_bwd_mfma_k<RBF>), grid, block, 0, st, phi, geom_s, rowptr_s, dst_s, Wd, bd, gs, g_phi, part,
+                         n_feat, n_src, sh.npc, sh.cpx, tiles);
+    });
+  } else {
 #define CGV_BWD_LAUNCH(GV, SP, PR)                                                                                 \
   hipLaunchKernelGGL((cgv::equi_msg_bwd_k<RBF, GV, SP, PR>), grid, block, 0, st, phi, v, geom_s, rowptr_s, dst_s, Wd, \
                      bd, gs, gv, g_phi, g_v, part, n_feat, n_src, sh.npc, sh.cpx, tiles)
@@ -846,6 +1025,7 @@ static int equi_msg_bwd_impl(const float* phi, const float* v, const float* geom
   });
 #undef CGV_BWD_PICK
 #undef CGV_BWD_LAUNCH
+  }
   // chunks beyond sh.chunks (padding to a multiple of 8) still write zero partials: sum them all
   if (n_chunks_out) {                    // deferred second stage (cgv_filter_reduce_jobs)
     *n_chunks_out = 8 * sh.cpx;
