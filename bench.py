@@ -377,7 +377,9 @@ def optimizer_roofline(trainer, reps=5):
             "timed_as": "the four launch groups back to back on scratch copies of p / m / v, INCLUDING the Gram-norm launches "
                         "(wgrad_gram_k + reduce, ~27 us on chignolin) that the step's section clock books under "
                         "'weight-gradients' -- profiles/*_section_times_*.txt 'optimizer' (finalize + adam_update + rank update) "
-                        "is that much shorter; the scratch copies also start colder than the step's own arenas",
+                        "is that much shorter; the scratch copies also start colder than the step's own arenas (the flat-layout rank "
+                        "update of round 5 runs 249 us inside the step -- profiles/*_chignolin_kernel_stats.csv -- and ~275 us here, "
+                        "where the tiled launch it replaced ran 255 / 250)",
             "traffic": None}
 
 

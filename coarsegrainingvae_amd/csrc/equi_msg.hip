@@ -658,7 +658,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void equi_msg_bwd_mfma_k(
     const bool ok = e < e_end;
     const int ec = ok ? e : b;
     idx = dst[ec];
-    const float t = geom[(size_t)ec * GS + col];
+    const float t = geom[(size_t)ec * GS + (col < GS ? col : 0)];     // (n_rbf = 4: a record has 12 floats)
     a = ok ? t : 0.f;
   };
   auto gather = [&](int idx, f32x4& B0, f32x4& B1) {
@@ -1005,9 +1005,13 @@ static int equi_msg_bwd_impl(const float* phi, const float* v, const float* geom
                     ((((uintptr_t)phi | (uintptr_t)v | (uintptr_t)gs | (uintptr_t)gv | (uintptr_t)g_phi |
                        (uintptr_t)g_v | (uintptr_t)part) & 7) == 0) &&
                     ((((uintptr_t)Wd) & 15) == 0) && ((((uintptr_t)bd) & 7) == 0);
-  // scalar-only upstream on a high-degree graph: the matrix-core kernel (cgv_set_option(CGV_OPT_MSG_BWD_MFMA, 0) keeps the
-  // packed-FMA walk for A/B runs)
-  if (!gv && gs && sh.split && n_rbf + 1 <= 16 && (n_feat % 4) == 0 && cgv::option(CGV_OPT_MSG_BWD_MFMA) != 0 &&
+  // scalar-only upstream on a high-degree graph: the matrix-core kernel.  From ~200 edges per node on (the 2000-atom graph:
+  // 425, 390 -> 265 us per launch); at chignolin's 123 -- 8 batches of 4 edges per wave and node -- the exchange of the
+  // tiles at the end of every node outweighs it (27.0 against 24.0 us).  cgv_set_option(CGV_OPT_MSG_BWD_MFMA, 0 | 1): never /
+  // wherever it applies (A/B runs, tests).
+  const int mfma_opt = cgv::option(CGV_OPT_MSG_BWD_MFMA);
+  const bool mfma_pays = mfma_opt == 1 || (mfma_opt < 0 && n_edges_hint >= 200LL * (n_src > 0 ? n_src : 1));
+  if (!gv && gs && sh.split && n_rbf + 1 <= 16 && (n_feat % 4) == 0 && mfma_pays &&
       ((((uintptr_t)gs) & 15) == 0) && ((((uintptr_t)phi | (uintptr_t)g_phi | (uintptr_t)part) & 7) == 0)) {
     CGV_DISPATCH_RBF(n_rbf, {
       hipLaunchKernelGGL((cgv::equi_msg_bwd_mfma_k<RBF>), grid, block, 0, st, phi, geom_s, rowptr_s, dst_s, Wd, bd, gs, g_phi, part,

@@ -89,8 +89,9 @@ enum {
   CGV_OPT_MSG_FWD_BALANCED = 18, /* cgv_equi_msg_fwd_balanced: four-wave blocks per CU, 3 (default: what the kernel's registers admit, all resident) or 1..4 */
   CGV_OPT_BWD_INPUT_SPLIT = 19, /* cgv_tile_linear_bwd_input*: few output tiles and a long reduction: -1 (default) 2 - 4 blocks per tile
                                    when a workspace is registered (cgv_tile_bwd_input_split), 1 never, 2..4 that many */
-  CGV_OPT_MSG_BWD_MFMA = 20,    /* cgv_equi_msg_bwd*, scalar-only upstream on a high-degree graph: 1 (default) the matrix-core kernel
-                                   (4 edges per fp32 MFMA, records and rows through vector loads), 0 the packed-FMA walk */
+  CGV_OPT_MSG_BWD_MFMA = 20,    /* cgv_equi_msg_bwd*, scalar-only upstream: the matrix-core kernel (4 edges per fp32 MFMA, records and
+                                   rows through vector loads) -1 (default) from 200 edges per node on, 1 wherever it applies
+                                   (>= 48 edges per node, n_rbf <= 15, n_feat % 4 == 0), 0 never (the packed-FMA walk) */
   CGV_OPT_COUNT = 21
 };
 /* Measurement: store the GPU wall clock (cgv_timestamp_hz ticks per second) into *slot, in stream order; capturable. */

@@ -670,7 +670,7 @@ def test_fused_update_block_equals_composition(n, F, fused_fwd, options):
 
 
 # --------------------------------------------------------------------------- edge cases the fused kernels must survive
-def _block_vs_oracle(F, R, n, nbrs, xyz, with_gv=True, seed=0, tol=REL):
+def _block_vs_oracle(F, R, n, nbrs, xyz, with_gv=True, seed=0, tol=REL, grads=None):
     gen = torch.Generator().manual_seed(seed)
     cutoff = 6.0
     r = xyz[nbrs[:, 1]] - xyz[nbrs[:, 0]] if nbrs.shape[0] else torch.zeros(0, 3)
@@ -705,6 +705,8 @@ def _block_vs_oracle(F, R, n, nbrs, xyz, with_gv=True, seed=0, tol=REL):
         ref = P["b." + name.replace("inv_dense.1.1.", "inv_dense.1.")].grad
         if ref is not None and float(ref.abs().max()) > 0:
             assert_close(p.grad, ref, "grad " + name, tol)
+    if grads is not None:
+        grads.append({"s": s1.grad.clone(), **{name: p.grad.clone() for name, p in blk.named_parameters() if p.grad is not None}})
     return ds1, dv1
 
 
@@ -810,6 +812,33 @@ def test_equi_message_high_degree_split_path():
     assert nbrs.shape[0] >= 48 * n
     _block_vs_oracle(48, 10, n, nbrs, xyz, True, seed=1)
     _block_vs_oracle(48, 10, n, nbrs, xyz, False, seed=2)
+
+
+@pytest.mark.parametrize("F,R", [(600, 10), (88, 8), (132, 12), (4, 10), (52, 4), (600, 16)])
+def test_scalar_only_backward_on_the_matrix_cores(F, R, options):
+    """equi_msg_bwd_mfma_k (no vector gradient upstream, >= 48 edges per node, n_rbf + 1 <= 16): N = A^T x gathered rows
+    with 4 edges per fp32 MFMA, against the oracle's autograd AND against the packed-FMA walk of the same launch
+    (CGV_OPT_MSG_BWD_MFMA = 0) -- ragged segments (lengths that are no multiple of 4 or of the 4 waves' slices), an
+    isolated node, an asymmetric edge set, a channel count that leaves the last 128-channel tile mostly empty, a width of a
+    single 16-byte piece.  n_rbf = 16 does not fit the 16 rows of a tile and stays on the FMA walk."""
+    gen = torch.Generator().manual_seed(F + R)
+    n = 90
+    xyz = torch.rand(n, 3, generator=gen) * 3.0
+    nbrs, _ = O.make_directed(O.get_neighbor_list(xyz, 9.0, True))
+    keep = torch.rand(nbrs.shape[0], generator=gen) < 0.8                   # ragged, asymmetric
+    keep &= (nbrs[:, 0] != 5) & (nbrs[:, 1] != 5)                           # node 5: no edges at all
+    nbrs = nbrs[keep]
+    assert nbrs.shape[0] >= 48 * n
+    got = []
+    for mode in (1, 0):
+        options.set("msg_bwd_mfma", mode)
+        torch.manual_seed(11)                                                # (the block draws its weights from the global generator)
+        _block_vs_oracle(F, R, n, nbrs, xyz, False, seed=3, grads=got)
+    a, b = got
+    for key in a:
+        assert_close(a[key], b[key].double(), "both kernels: " + key, 2e-5)
+    differs = any(not torch.equal(a[key], b[key]) for key in a)
+    assert differs == (R + 1 <= 16), "the option must select between two kernels exactly where the matrix-core one applies"
 
 
 @pytest.mark.parametrize("M", [12, 332])

@@ -21,7 +21,7 @@ bash tools/phase_clock.sh > gpurun_out/${tag}_decoder_phase_clock.txt 2>&1   # (
 for w in chignolin dipeptide protein2000; do
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_${c}_$w -o p -- python bench.py --workload $w --no-graph --no-cpu-baseline --no-parity --steps 4 --warmup 2 --reps 1 > /tmp/pmc_${c}_$w.log 2>&1
-    python tools/pmc_summary.py /tmp/pmc_${c}_$w/p_counter_collection.csv equi_msg dec_ grouped_wgrad adam_update sumsq_partial optim_finalize segment_reduce skinny_fwd tile_ pseudo_ wgrad_gram > gpurun_out/${tag}_pmc_${c}_$w.txt 2>&1
+    python tools/pmc_summary.py /tmp/pmc_${c}_$w/p_counter_collection.csv equi_msg dec_ grouped_wgrad rank_update adam_update sumsq_partial optim_finalize segment_reduce skinny_fwd tile_ pseudo_ wgrad_gram > gpurun_out/${tag}_pmc_${c}_$w.txt 2>&1
   done
 done
 # FETCH_SIZE / WRITE_SIZE against known byte counts, by access width (tools/probes/fetch_calib.hip)

@@ -35,7 +35,7 @@ def src(path):
 
 GROUPS = [
     ("decoder layer (channel-group kernels incl. the 4-column-block Dense forward, which the prior / heads share)", r"dec_|skinny_fwd_k<1, 16>"),
-    ("optimizer (rank update of the bead-level layers, norm, Adam)", r"grouped_wgrad_t<true>|adam_update|sumsq_partial|optim_finalize|wgrad_gram"),
+    ("optimizer (rank update of the bead-level layers, norm, Adam)", r"rank_update_mixed_k|grouped_wgrad_t<true>|adam_update|sumsq_partial|optim_finalize|wgrad_gram"),
     ("atom-graph message passing (K2g / K2 / K2b + reductions)", r"equi_msg_|segment_reduce|segment_broadcast"),
     ("atom-level Dense (tile GEMMs) and their weight gradients", r"tile_|gathered_wgrad|grouped_wgrad_t<false>|wgrad_split"),
     ("per-batch graph plans + edge records", r"pj_|grp_build|gj_records|csr_|edge_geometry|copyBuffer|fillBuffer|batch_rows"),
@@ -125,19 +125,20 @@ for w in ("chignolin", "dipeptide", "protein2000"):
                                            "note": "LARGEST segment_reduce dispatch of the run = the standalone [E,F,3] -> [N,F,3] reduction bench.py times as `scatter_add` (the PMC passes run bench.py with its extras on)",
                                            "source": f"profiles/{tag}_pmc_*_{w}.txt",
                                            "source_sha256": source_hash(SOURCES["segment_reduce"]), "source_files": SOURCES["segment_reduce"]}
-    hit = pick(r"grouped_wgrad_t<true>")
+    rank_kernel = "rank_update_mixed_k" if pick(r"rank_update_mixed_k") else "grouped_wgrad_t<true>"
+    hit = pick(re.escape(rank_kernel))
     if hit:
-        tr["grouped_wgrad_t<true>"] = {"fetch_KiB": hit[1], "fetch_factor": 2, "write_KiB": hit[2], "traffic_bytes": int(1024 * (2 * hit[1] + hit[2])),
+        tr[rank_kernel] = {"fetch_KiB": hit[1], "fetch_factor": 2, "write_KiB": hit[2], "traffic_bytes": int(1024 * (2 * hit[1] + hit[2])),
                                        "source": f"profiles/{tag}_pmc_*_{w}.txt", "source_sha256": source_hash(SOURCES["rank_update"]),
                                        "source_files": SOURCES["rank_update"]}
     opt = [pick(p) for p in (r"sumsq_partial", r"optim_finalize", r"adam_update")]
-    rank = [pick(p) for p in (r"wgrad_gram_k", r"wgrad_gram_reduce_k", r"grouped_wgrad_t<true>")]
+    rank = [pick(p) for p in (r"wgrad_gram_k", r"wgrad_gram_reduce_k", re.escape(rank_kernel))]
     if all(opt):
         f_kib, w_kib = sum(o[1] for o in opt), sum(o[2] for o in opt)
         key, files = "sumsq_partial+optim_finalize+adam_update", SOURCES["optimizer"]
         if all(rank):                                     # the rank-update step (bench.py: optimizer_roofline's kernel name)
             f_kib += sum(o[1] for o in rank); w_kib += sum(o[2] for o in rank)
-            key, files = "wgrad_gram+optim_finalize+adam_update+grouped_wgrad_t<true>", SOURCES["optimizer"] + SOURCES["rank_update"]
+            key, files = "wgrad_gram+optim_finalize+adam_update+" + rank_kernel, SOURCES["optimizer"] + SOURCES["rank_update"]
         tr[key] = {"fetch_KiB": f_kib, "fetch_factor": 2, "write_KiB": w_kib, "traffic_bytes": int(1024 * (2 * f_kib + w_kib)),
                    "note": "median dispatch of each kernel of the optimiser step, summed", "source": f"profiles/{tag}_pmc_*_{w}.txt",
                    "source_sha256": source_hash(files), "source_files": files}
