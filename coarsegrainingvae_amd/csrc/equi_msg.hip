@@ -1010,7 +1010,9 @@ static int equi_msg_bwd_impl(const float* phi, const float* v, const float* geom
   // tiles at the end of every node outweighs it (27.0 against 24.0 us).  cgv_set_option(CGV_OPT_MSG_BWD_MFMA, 0 | 1): never /
   // wherever it applies (A/B runs, tests).
   const int mfma_opt = cgv::option(CGV_OPT_MSG_BWD_MFMA);
-  const bool mfma_pays = mfma_opt == 1 || (mfma_opt < 0 && n_edges_hint >= 200LL * (n_src > 0 ? n_src : 1));
+  // (and on graphs of at most two blocks per CU -- the 64 beads of the 2000-atom config, 61 edges each: 7.5 against 10.4 us,
+  // the launch is a chain of round trips there and the matrix-core kernel has fewer)
+  const bool mfma_pays = mfma_opt == 1 || (mfma_opt < 0 && (n_edges_hint >= 200LL * (n_src > 0 ? n_src : 1) || 8 * sh.cpx * tiles <= 512));
   if (!gv && gs && sh.split && n_rbf + 1 <= 16 && (n_feat % 4) == 0 && mfma_pays &&
       ((((uintptr_t)gs) & 15) == 0) && ((((uintptr_t)phi | (uintptr_t)g_phi | (uintptr_t)part) & 7) == 0)) {
     CGV_DISPATCH_RBF(n_rbf, {
