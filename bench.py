@@ -365,13 +365,33 @@ def optimizer_roofline(trainer, reps=5):
         e.record()
     torch.cuda.synchronize()
     us = 1e3 * sum(s.elapsed_time(e) for s, e in ev) / reps
+    rank_alone = None
+    if rank:
+        # the rank-update launch alone: back to back (the tail of p / m / v still sits in the Infinity Cache from the launch
+        # before) and behind a 1 GB fill (every byte from HBM).  Inside the step it runs between the two: a whole forward /
+        # backward separates two updates (profiles/*_kernel_stats.csv has that figure).
+        flush = torch.empty(256 << 20, dtype=torch.float32, device=a.p.device)
+        rank_alone = {}
+        for key, cold in (("back_to_back_us", False), ("after_cache_flush_us", True)):
+            ts = []
+            for _ in range(reps):
+                if cold:
+                    flush.fill_(1.0)
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                trainer.rank_update_launch(rank, sp, sm, sv, 1e-4, 0.9, 0.999, 1e-8, state)
+                e.record()
+                torch.cuda.synchronize()
+                ts.append(1e3 * s.elapsed_time(e))
+            rank_alone[key] = sorted(ts)[len(ts) // 2]
+        del flush
     n_rank = trainer._rank_numel if rank else 0
     by = 4 * (6 * n_rank + 7 * (n - lo))
     return {"kernel": (("wgrad_gram+optim_finalize+adam_update+" + ("rank_update_mixed_k" if rank[6][0] else "grouped_wgrad_t<true>")) if rank
                        else "sumsq_partial+optim_finalize+adam_update"),
             "params": n, "rank_update_weights": n_rank, "bound": "hbm", "achieved": by / (us * 1e-6) / 1e9,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "avg_us": us,
-            "algorithmic_bytes": by,
+            "algorithmic_bytes": by, "rank_update_launch_alone": rank_alone,
             "accounting": "6 floats per rank-update weight (p, m, v read + written; gradient never stored), 7 per other "
                           "parameter (g counted once: its second read hits the caches)",
             "timed_as": "the four launch groups back to back on scratch copies of p / m / v, INCLUDING the Gram-norm launches "

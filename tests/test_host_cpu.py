@@ -163,6 +163,39 @@ def test_option_table_is_explicit_and_resets():
     assert src.stdout.strip() == "", "the C ABI must not read the environment: " + src.stdout
 
 
+def test_host_side_plans_of_the_round_5_launches_without_a_gpu():
+    """The host helpers of the flat rank update and of the split backward-input reduction decide on the CPU: block counts /
+    LDS requests / refusals of cgv_rank_flat_plan against the tiling of cgv_wgrad_plan, the argument checks of
+    cgv_tile_bwd_input_split (per-thread registration: nothing is launched), the defaults of the three new switches."""
+    import ctypes as C
+    from coarsegrainingvae_amd import _lib, options
+    lib = _lib.load()
+    options.reset()
+    assert options.get("bwd_input_split") == -1 and options.get("msg_bwd_mfma") == -1
+    assert options.get("rank_flat") == 2 and options.get("rank_mixed") == 1
+    q = lib.cgv_rank_flat_quantum()
+    assert q == 4096
+    nb, lds, tk, tw, nt = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    for M, N, K in ((12, 600, 600), (12, 1800, 600), (12, 600, 1200), (12, 5400, 600), (16, 52, 900), (1, 4, 700), (7, 700, 4)):
+        assert lib.cgv_rank_flat_plan(M, N, K, 0, C.byref(nb), C.byref(lds)) == 0, (M, N, K)
+        assert nb.value == (N * (K // 4) + q - 1) // q
+        assert lds.value == M * (K + min(q // (K // 4) + 2, N)) and lds.value <= 16000
+        assert lib.cgv_wgrad_plan(M, N, K, C.byref(tk), C.byref(tw), C.byref(nt)) == 0
+        assert nt.value == ((N + 63) // 64) * tk.value and tk.value * tw.value >= K     # the tiled layout of the same record
+        assert lib.cgv_rank_flat_plan(M, N, K, 2048, C.byref(nb), C.byref(lds)) == 0 and nb.value == (N * (K // 4) + 2047) // 2048
+    assert lib.cgv_rank_flat_plan(17, 600, 600, 0, C.byref(nb), C.byref(lds)) != 0          # more than 16 operand rows
+    assert lib.cgv_rank_flat_plan(36, 1200, 600, 0, C.byref(nb), C.byref(lds)) != 0         # (the three stacked heads: stays tiled)
+    assert lib.cgv_rank_flat_plan(12, 600, 1800, 0, C.byref(nb), C.byref(lds)) != 0         # x [12, 1800] + g beyond the LDS budget
+    assert lib.cgv_rank_flat_plan(12, 600, 602, 0, C.byref(nb), C.byref(lds)) != 0          # K % 4
+    assert lib.cgv_rank_flat_plan(12, 600, 600, 1000, C.byref(nb), C.byref(lds)) != 0 and b"2048" in lib.cgv_last_error_string()
+    # the split reduction's workspace: >= 64 KB + 2 MB, 16-byte aligned; NULL unregisters (host state only)
+    assert lib.cgv_tile_bwd_input_split(None, 0, None) == 0
+    assert lib.cgv_tile_bwd_input_split(C.c_void_p(4096), 1024, None) != 0 and b"workspace" in lib.cgv_last_error_string()
+    assert lib.cgv_tile_bwd_input_split(C.c_void_p(4100), 64 * 1024 + (2 << 20), None) != 0
+    assert lib.cgv_tile_bwd_input_split(C.c_void_p(4096), 64 * 1024 + (2 << 20), None) == 0
+    assert lib.cgv_tile_bwd_input_split(None, 0, None) == 0
+
+
 def test_sample_seed_differs_per_rank_and_rank0_keeps_the_single_process_stream():
     """Data parallel: every rank calls torch.manual_seed(123) (run_ala.py:36-41); the device generator of reparam_sample
     must still draw DIFFERENT noise on every rank (cgvae.py:445-449 on the concatenated batch draws one block per bead)."""
