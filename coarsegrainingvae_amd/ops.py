@@ -706,8 +706,12 @@ def _dense_bwd_input(gy, z, W, gx, M, N, K, act, st, z_out=None, act_out=0) -> b
     gx * act_out'(z_out) (returns True: the producing layer's backward runs without an activation); the row-split kernel has
     no such epilogue (returns False, gx as it is)."""
     lib = _lib.load()
-    if lib.cgv_skinny_supported(M, N, K) or (M <= 128 and N >= 4096 and lib.cgv_skinny_bwd_input_supported(M, N, K)
-                                             and not (M > 64 and _lib.split_workspace_ready())):
+    # (33 - 64 rows below 4096 columns: the tile kernel, whose reduction splits over 2-4 blocks per tile, beats the row-split
+    # kernel + its reduction launch: 8.0 - 8.7 against 11.7 - 12.0 us at 64 x 1200 / 1800, primitives._LinearFn)
+    tile_wins = 32 < M <= 64 and N < 4096 and _lib.split_workspace_ready() and lib.cgv_tile_supported(M, N, K) \
+        and gy.data_ptr() % 16 == 0
+    if (lib.cgv_skinny_supported(M, N, K) and not tile_wins) or (M <= 128 and N >= 4096 and lib.cgv_skinny_bwd_input_supported(M, N, K)
+                                                                 and not (M > 64 and _lib.split_workspace_ready())):
         skinny_bwd_input(gy, z, W, gx, M, N, K, act, st)
         return False
     if z_out is not None and act_out and options.HOST["act_downstream"]:

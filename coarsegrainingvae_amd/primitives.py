@@ -559,11 +559,21 @@ class _LinearFn(torch.autograd.Function):
             return (gx if need_x else add), gw, gb, None
         if need_x:
             gx = torch.empty(M, K, dtype=torch.float32, device=gy.device)
-            if M > 32 and N <= 1024 and gy2.data_ptr() % 16 == 0 and _lib.load().cgv_tile_supported(M, N, K):
-                # many bead rows, a short reduction (64 beads of the 2000-atom config, 600 outputs): one launch of the tile
-                # kernel (8.7 us; 6.2 without activation) against the row-split kernel + its reduction (12.9 / 12.1 us;
-                # tools/bwd_input_bench.py) -- from 1200 outputs on the row split wins again (13.0 against 13.8 us)
-                if add2 is not None:
+            if (M > 32 and (N <= 1024 or (N < 4096 and _lib.split_workspace_ready())) and gy2.data_ptr() % 16 == 0
+                    and _lib.load().cgv_tile_supported(M, N, K)):
+                # many bead rows (64 beads of the 2000-atom config): one launch of the tile kernel against the row-split
+                # kernel + its reduction -- 600 outputs 7.8 against 11.4 us, and, since the tile kernel splits a long
+                # reduction over 2-4 blocks per tile, 1200 / 1800 outputs 8.0 / 8.7 against 11.7 / 12.0 us (with an
+                # activation 10.6 / 15.2 at 1800); at 5400 the row split keeps the shape (13.8 against 14.3;
+                # tools/bwd_input_bench.py 0 64)
+                prod = getattr(ctx, "producer", None)
+                if prod is not None and prod.saved_tensors[2] is not None:
+                    _lib.call("cgv_tile_linear_bwd_input_out", _lib.ptr(gy2), _lib.ptr(z) if act != ACT_NONE else None,
+                              _lib.ptr(weight), _lib.ptr(add2), _lib.ptr(gx), M, N, K, act, _lib.ptr(prod.saved_tensors[2]),
+                              int(prod.act), st)
+                    prod.act_done = True                   # (see forward: the producing layer's launches run without an activation)
+                    fused[0] = True
+                elif add2 is not None:
                     _lib.call("cgv_tile_linear_bwd_input_act_add", _lib.ptr(gy2), _lib.ptr(z) if act != ACT_NONE else None,
                               _lib.ptr(weight), _lib.ptr(add2), _lib.ptr(gx), M, N, K, act, st)
                     fused[0] = True
