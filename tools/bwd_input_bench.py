@@ -16,6 +16,8 @@ def timeit(fn, reps=100):
     return 1e3 * a.elapsed_time(b) / reps
 
 ACT = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+for kv in filter(None, os.environ.get("CGV_OPTS", "").split(",")):     # CGV_OPTS=name=value,... : any launcher switch
+    _lib.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 if os.environ.get("CGV_SPLIT"):                       # CGV_OPT_BWD_INPUT_SPLIT: 1 never, 2..4 forced shares
     _lib.set_option("bwd_input_split", int(os.environ["CGV_SPLIT"]))
 for M in (tuple(int(a) for a in sys.argv[2:]) or (96, 128, 64)):
