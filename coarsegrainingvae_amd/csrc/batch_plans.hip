@@ -270,11 +270,25 @@ struct GeomJobs { int n, total_edges; GeomJob job[GJ_MAX]; };
 constexpr int GJ_REC_MAX = 28;           // geom_stride(20)
 __global__ __launch_bounds__(256) void gj_records_k(GeomJobs J) {
   __shared__ __attribute__((aligned(16))) float recs[256][GJ_REC_MAX];
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= J.total_edges) return;
+  const int e_first = blockIdx.x * 256;
+  const int e_raw = e_first + threadIdx.x;
+  const bool valid = e_raw < J.total_edges;
+  const int e = valid ? e_raw : J.total_edges - 1;                  // (surplus threads rebuild the last record: no divergent barrier)
   int j = 0;
 #pragma unroll
   for (int t = 1; t < GJ_MAX; ++t) if (t < J.n && J.job[t].edge_begin <= e) j = t;
+  // a block whose 256 edges belong to ONE job (all but a handful) writes its records -- one contiguous range of the job's
+  // array -- as consecutive 16-byte pieces over the lanes (whole lines); a block across a job border keeps a thread's own stores
+  int j_first = 0, j_last = 0;
+  {
+    const int e_last = min(e_first + 255, J.total_edges - 1);
+#pragma unroll
+    for (int t = 1; t < GJ_MAX; ++t) {
+      if (t < J.n && J.job[t].edge_begin <= e_first) j_first = t;
+      if (t < J.n && J.job[t].edge_begin <= e_last) j_last = t;
+    }
+  }
+  const bool one_job = j_first == j_last;
   const GeomJob& q = J.job[j];
   const int p = e - q.edge_begin;
   const int R = q.R, GS = q.GS;
@@ -314,7 +328,18 @@ __global__ __launch_bounds__(256) void gj_records_k(GeomJobs J) {
     g[U + 3] = ux; g[U + 4] = uy; g[U + 5] = uz;
     for (int k = U + 6; k < GS; ++k) g[k] = 0.0f;
   }
-  for (int k4 = 0; k4 < GS / 4; ++k4) dst4[k4] = reinterpret_cast<const float4*>(g)[k4];       // own record: no barrier needed
+  if (!one_job) {
+    if (valid)
+      for (int k4 = 0; k4 < GS / 4; ++k4) dst4[k4] = reinterpret_cast<const float4*>(g)[k4];     // own record: no barrier needed
+    return;
+  }
+  __syncthreads();
+  const int n_rec = min(256, J.total_edges - e_first), GS4 = GS >> 2;
+  float4* out4 = reinterpret_cast<float4*>(q.geom + (size_t)(e_first - q.edge_begin) * GS);
+  for (int idx = threadIdx.x; idx < n_rec * GS4; idx += 256) {
+    const int r = idx / GS4, k4 = idx - r * GS4;
+    out4[idx] = reinterpret_cast<const float4*>(recs[r])[k4];
+  }
 }
 
 // ------------------------------------------------------------------ loading a prepared batch into the captured buffers
