@@ -118,7 +118,7 @@ def spawn_ranks(n: int) -> int:
 # torchrun (or the driver) starts is therefore only a SUPERVISOR -- it never touches the GPU -- and runs the measurement
 # in a fresh worker process per attempt, with a deadline.  All ranks walk the same ladder on the SAME CLOCK: rung k starts
 # at t0 + k * (deadline + grace) on every rank, t0 being one wall-clock value the supervisors of a launch agree on through a
-# file their common parent's pid names (they run on one node, beside each other).  A rank whose worker fails early -- it raised
+# file named by the launch's rendezvous address / port / run id (``ladder_path``: they run on one node, beside each other).  A rank whose worker fails early -- it raised
 # while its peers hang in a collective until their deadline kills them -- WAITS for the next slot instead of starting the next
 # rung alone, whose rendezvous would time out about when the peers arrive (and so on down the ladder).  The workers of
 # attempt k meet on MASTER_PORT + 17 + k.
@@ -128,7 +128,33 @@ LADDER = [("operands+graph", []), ("gradients+graph", ["--exchange", "gradients"
 
 
 def ladder_path(base_port: int) -> str:
-    return os.path.join(os.environ.get("TMPDIR", "/tmp"), f"cgv_bench_t0_{os.getppid()}_{base_port}")
+    """Name of the launch's clock file, built ONLY from what every rank of a launch shares whoever started it (one shell or
+    srun task per rank have different parents and may have different TMPDIRs): the rendezvous address and port, plus the
+    launcher's run id when it sets a real one (torchrun's static rendezvous says "none").  ``CGV_BENCH_LADDER_ID`` /
+    ``CGV_BENCH_LADDER_DIR`` override the id and the directory (default /tmp: the ranks of a launch run on one node)."""
+    run_id = os.environ.get("CGV_BENCH_LADDER_ID") or os.environ.get("TORCHELASTIC_RUN_ID") or ""
+    ident = f"{os.environ.get('MASTER_ADDR', '127.0.0.1')}_{base_port}" + (f"_{run_id}" if run_id and run_id != "none" else "")
+    ident = "".join(c if (c.isalnum() or c in "_.-") else "_" for c in ident)
+    return os.path.join(os.environ.get("CGV_BENCH_LADDER_DIR") or "/tmp", "cgv_bench_t0_" + ident)
+
+
+def ladder_cleanup(base_port: int, rank: int, world: int, last_attempt: int) -> None:
+    """On EVERY exit path of a supervisor: rank 0 waits a moment for the other ranks' mark of the last attempt (they post it
+    before they leave), then removes the clock file and every mark of this launch; a rank whose peers are still on the
+    ladder leaves the files to them (a stale name is replaced by the next launch, ``ladder_t0``)."""
+    import glob
+    path = ladder_path(base_port)
+    if rank != 0:
+        return
+    until = time.time() + 3.0
+    while time.time() < until and not all(os.path.exists(f"{path}.{last_attempt}.{r}") for r in range(world)):
+        time.sleep(0.05)
+    if all(os.path.exists(f"{path}.{last_attempt}.{r}") for r in range(world)):
+        for f in [path] + glob.glob(path + ".*"):
+            try:
+                os.unlink(f)
+            except OSError:
+                pass
 
 
 def ladder_wait(base_port: int, k: int, world: int, until: float) -> None:
@@ -143,8 +169,8 @@ def ladder_wait(base_port: int, k: int, world: int, until: float) -> None:
 
 def ladder_t0(base_port: int, slot_s: float, n_rungs: int) -> float:
     """One wall-clock origin for all supervisors of this launch: the first to create the file writes its clock, the others
-    read it.  The name carries the common parent (torchrun's agent, or bench.py's own rank spawner) and the port; a file
-    older than a whole ladder is a stale leftover of a recycled pid and is replaced."""
+    read it.  The name carries the rendezvous address, port and run id (``ladder_path``); a file older than a whole ladder is a
+    stale leftover of an earlier launch under the same name and is replaced."""
     path = ladder_path(base_port)
     horizon = slot_s * (n_rungs + 1)
     for _ in range(200):
@@ -177,9 +203,19 @@ def ladder_t0(base_port: int, slot_s: float, n_rungs: int) -> float:
 
 
 def supervise(args) -> int:
-    import signal
     rank = int(os.environ.get("RANK", "0"))
     base_port = int(os.environ.get("MASTER_PORT", "29581"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    progress = {"attempt": 0}
+    try:
+        return _supervise(args, rank, base_port, world, progress)
+    finally:
+        if world > 1:
+            ladder_cleanup(base_port, rank, world, progress["attempt"])
+
+
+def _supervise(args, rank: int, base_port: int, world: int, progress: dict) -> int:
+    import signal
     ladder = [r for r in LADDER if not (args.exchange == "gradients" and r[0].startswith("operands"))]
     if args.no_graph:
         ladder = ladder[-1:]
@@ -188,9 +224,9 @@ def supervise(args) -> int:
     slot_s = args.attempt_timeout + RUNG_GRACE_S
     if os.environ.get("CGV_BENCH_TEST_SLOT_S"):              # (rehearsals: short slots)
         slot_s = float(os.environ["CGV_BENCH_TEST_SLOT_S"])
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     t0 = ladder_t0(base_port, slot_s, len(ladder)) if world > 1 else time.time()
     for k, (name, extra) in enumerate(ladder):
+        progress["attempt"] = k
         if k > 0 and world > 1:
             ladder_wait(base_port, k, world, t0 + k * slot_s)
         env = dict(os.environ)
@@ -233,11 +269,6 @@ def supervise(args) -> int:
             if rank == 0:
                 sys.stdout.write(lines[0] + "\n")
                 sys.stdout.flush()
-                if world > 1:                                 # best effort: leave no clock file behind for a recycled pid
-                    try:
-                        os.unlink(ladder_path(base_port))
-                    except OSError:
-                        pass
             return 0
         reason = f"attempt {k} ({name}): " + (why or f"exit code {rc}" + ("" if len(lines) <= 1 else f", {len(lines)} JSON lines"))
     print(f"[bench] rank {rank}: every rung of the ladder failed ({reason})", file=sys.stderr)

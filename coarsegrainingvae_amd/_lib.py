@@ -16,7 +16,10 @@ import torch
 from . import ktimer
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libcgvae_hip.so")
+# CGV_LIB: path of ANOTHER BUILD of the same library (an instrumented or A/B variant made by tools/build_variant.sh) to load
+# in place of the shipped one -- so that no tool ever has to copy a variant over the shipped file.  Still no fallback:
+# whatever this names must exist and export every symbol of include/cgvae_hip.h.
+LIB_PATH = os.environ.get("CGV_LIB") or os.path.join(_PKG, "libcgvae_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "cgvae_hip.h")
 
 _lock = threading.Lock()
@@ -195,7 +198,7 @@ PROTOTYPES = {
 OPTIONS = {"msg_fwd_split": 0, "msg_bwd_split": 1, "msg_fwd_kernel": 2, "grp_waves": 3, "grp_records": 4, "csr_build": 5,
            "pseudo_chunks": 6, "wgrad_tiling": 7, "tile_fwd_lds_min": 8, "bwd_input_waves": 9, "pseudo_fwd": 10, "decoder_fat": 11, "decoder_wlds": 12, "skinny_rows": 13,
            "tile_fwd_bal": 14, "optim_one_launch": 15, "decoder_colsplit": 16, "decoder_nodesplit": 17,
-           "msg_fwd_balanced": 18, "bwd_input_split": 19, "msg_bwd_mfma": 20}
+           "msg_fwd_balanced": 18, "bwd_input_split": 19, "msg_bwd_mfma": 20, "streamk": 21}
 
 
 def set_option(name: str, value: int) -> None:
@@ -258,7 +261,9 @@ def ptr(t):
 
 _SPLIT_WS = {}                       # (device, stream) -> the split reduction's workspace (cgv_tile_bwd_input_split)
 _SPLIT_TLS = threading.local()       # the C side keeps the registration per calling thread (autograd runs its own)
-_SPLIT_BYTES = 64 * 1024 + 8 * 1024 * 1024
+# 64 KB of self-resetting tickets + partial tiles: the split reduction of tile_bwd_input_k needs <= 8 MB, the stream-K kernel
+# (csrc/streamk_gemm.hip) two 64 KB partial tiles per block of its grid of <= 512
+_SPLIT_BYTES = 64 * 1024 + 64 * 1024 * 1024
 
 
 def prepare_split_workspace(stream=None):
@@ -305,7 +310,7 @@ def call(name: str, *args, tag=None):
     """Invoke a status-returning entry point; raise RuntimeError on any non-zero code.
     ``tag`` names the launch for the optional HIP-event timer (ktimer.py)."""
     lib = load()
-    if name.startswith("cgv_tile_") and "bwd_input" in name:
+    if name.startswith("cgv_tile_") and ("bwd_input" in name or "linear_fwd" in name):
         _register_split_workspace(lib)
     tok = ktimer.begin(tag) if tag is not None else None
     rc = getattr(lib, name)(*args)

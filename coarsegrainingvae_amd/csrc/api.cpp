@@ -22,8 +22,8 @@ static const int g_opt_default[CGV_OPT_COUNT] = {
     /* CGV_OPT_BWD_INPUT_WAVES */ 0, /* CGV_OPT_PSEUDO_FWD */ 0, /* CGV_OPT_DECODER_FAT */ 1, /* CGV_OPT_DECODER_WLDS */ 1,
     /* CGV_OPT_SKINNY_ROWS */ 0, /* CGV_OPT_TILE_FWD_BAL */ 1, /* CGV_OPT_OPTIM_ONE_LAUNCH */ 0, /* CGV_OPT_DECODER_COLSPLIT */ 2, /* CGV_OPT_DECODER_NODESPLIT */ 1,
     /* CGV_OPT_MSG_FWD_BALANCED */ 3, /* CGV_OPT_BWD_INPUT_SPLIT */ -1,
-    /* CGV_OPT_MSG_BWD_MFMA */ -1};
-static std::atomic<int> g_opt[CGV_OPT_COUNT] = {{-1}, {-1}, {0}, {4}, {0}, {0}, {0}, {0}, {448}, {0}, {0}, {1}, {1}, {0}, {1}, {0}, {2}, {1}, {3}, {-1}, {-1}};
+    /* CGV_OPT_MSG_BWD_MFMA */ -1, /* CGV_OPT_STREAMK */ 0};
+static std::atomic<int> g_opt[CGV_OPT_COUNT] = {{-1}, {-1}, {0}, {4}, {0}, {0}, {0}, {0}, {448}, {0}, {0}, {1}, {1}, {0}, {1}, {0}, {2}, {1}, {3}, {-1}, {-1}, {0}};
 int option(int id) { return g_opt[id].load(std::memory_order_relaxed); }
 }  // namespace cgv
 

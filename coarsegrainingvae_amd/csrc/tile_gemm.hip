@@ -20,8 +20,10 @@
 // reduction axis feeds 4 consecutive MFMAs: component c of lane group q stands for reduction index
 // 4q + c of the 16-wide step -- any bijection works as long as A and B use the same one.
 #include <stdlib.h>
+#include <initializer_list>
 #include <type_traits>
 #include "cgv_common.h"
+#include "streamk_gemm.h"
 
 namespace cgv {
 
@@ -810,6 +812,30 @@ __global__ __launch_bounds__(64 * WAVES) void tile_wgrad_k(const float* __restri
 
 }  // namespace cgv
 
+// workspace of the split reduction / the stream-K kernel (cgv_tile_bwd_input_split): per host thread, for launches on ONE
+// stream, which are ordered -- they share its tickets (self-resetting) and its partial tiles
+namespace cgv {
+struct SplitWs { void* ws; size_t bytes; void* stream; };
+static thread_local SplitWs g_split_ws = {nullptr, 0, nullptr};
+constexpr size_t SPLIT_TICKET_BYTES = 64 * 1024;       // head of the workspace: one ticket per output tile
+
+/* Blocks per CU of the stream-K launch that should compute np problems of `rows` x `cols` outputs over a `red`-deep
+ * reduction, or 0: the register-tile kernels.  CGV_OPT_STREAMK: 0 the measured rule, 1 never, 2 / 3 always (1 / 2 per CU). */
+static int sk_wanted(int rows, int cols, int red, int np, void* stream) {
+  const int opt = option(CGV_OPT_STREAMK);
+  if (opt == 1 || !g_split_ws.ws || g_split_ws.stream != stream) return 0;
+  if (opt == 2) return 1;
+  if (opt == 3) return 2;
+  (void)cols; (void)red; (void)np;
+  return rows >= 512 ? 1 : 0;
+}
+static bool sk_aligned(std::initializer_list<const void*> ptrs) {
+  uintptr_t u = 0;
+  for (const void* p : ptrs) u |= (uintptr_t)p;
+  return (u & 15) == 0;
+}
+}  // namespace cgv
+
 extern "C" {
 
 int cgv_tile_supported(int M, int N, int K) {
@@ -825,6 +851,15 @@ static int tile_fwd_launch(const float* x, const float* W, const float* bias, fl
   const cgv::TileSecond s2 = second ? *second : cgv::TileSecond{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
   const unsigned np = second ? 2u : 1u;
   if (pair_ok) *pair_ok = 1;
+  if (const int bpc = cgv::sk_wanted(M, N, K, (int)np, stream);
+      bpc > 0 && cgv::sk_aligned({x, W, bias, y, z, s2.x, s2.W, s2.bias, s2.y, s2.z})) {
+    cgv::SkArgs a{};
+    a.np = (int)np; a.M = M; a.N = N;
+    a.p[0].A[0] = x; a.p[0].B[0] = W; a.p[0].R[0] = K; a.p[0].out = y; a.p[0].bias = bias; a.p[0].zout = z; a.p[0].act = act;
+    if (second) { a.p[1].A[0] = s2.x; a.p[1].B[0] = s2.W; a.p[1].R[0] = K; a.p[1].out = s2.y; a.p[1].bias = s2.bias; a.p[1].zout = s2.z; a.p[1].act = s2.act; }
+    if (cgv::sk_launch(a, false, cgv::g_split_ws.ws, cgv::g_split_ws.bytes, cgv::SPLIT_TICKET_BYTES, st, bpc) == 0)
+      return cgv::check_launch("cgv_tile_linear_fwd");
+  }
   const int tiles32 = ((N + 31) / 32) * ((M + 31) / 32);
   const int tiles64 = ((N + 63) / 64) * ((M + 63) / 64);
   const int lds_min = cgv::option(CGV_OPT_TILE_FWD_LDS_MIN);
@@ -862,7 +897,10 @@ static int tile_fwd_launch(const float* x, const float* W, const float* bias, fl
   const bool staged = (ring_ok && (tiles64 >= lds_min || lds_min == 3)) ||
                       (tiles64 >= lds_min && (M >= 1024 || lds_min <= 1) && aligned16 && !(lds_min >= 5 && lds_min <= 7)) ||
                       (lds_min >= 5 && lds_min <= 7);
-  if (second && staged) { *pair_ok = 0; return 0; }
+  if (second && staged) {                       // the LDS-staged kernels take one problem: the pair as two launches of them
+    const int rc = tile_fwd_launch(x, W, bias, y, z, M, N, K, act, stream, nullptr, nullptr);
+    return rc ? rc : tile_fwd_launch(s2.x, s2.W, s2.bias, s2.y, s2.z, M, N, K, s2.act, stream, nullptr, nullptr);
+  }
   if (ring_ok && (tiles64 >= lds_min || lds_min == 3)) {
     const dim3 grid((N + 63) / 64, (M + 63) / 64);
     if (slabs32 == 19) hipLaunchKernelGGL((cgv::tile_fwd_ring_k<19>), grid, dim3(256), 0, st, x, W, bias, y, z, M, N, K, act);
@@ -898,18 +936,9 @@ int cgv_tile_linear_fwd(const float* x, const float* W, const float* bias, float
  * Returns CGV_E_UNSUPPORTED-style non-zero with nothing launched when the shape runs on the LDS-staged kernels
  * (cgv_tile_pair_supported tells beforehand). */
 int cgv_tile_pair_supported(int M, int N, int K) {
-  if (!cgv_tile_supported(M, N, K)) return 0;
-  const int tiles64 = ((N + 63) / 64) * ((M + 63) / 64);
-  const int lds_min = cgv::option(CGV_OPT_TILE_FWD_LDS_MIN);
-  const int tiles32 = ((N + 31) / 32) * ((M + 31) / 32);
-  if (const int bal = cgv::option(CGV_OPT_TILE_FWD_BAL); bal == 2 || (bal == 1 && tiles32 > 256 && N >= 1200)) {
-    int mt = 0, nt = 0;
-    if (cgv::bal_pick(M, N, &mt, &nt)) return 1;
-  }
-  const int slabs32 = (K + 31) / 32;
-  const bool ring = (slabs32 == 19 || slabs32 == 38) && lds_min != 1 && (tiles64 >= lds_min || lds_min == 3);
-  const bool lds1 = tiles64 >= lds_min && (M >= 1024 || lds_min <= 1);
-  return !(ring || lds1 || (lds_min >= 5 && lds_min <= 7));
+  /* every tile-supported shape: the stream-K kernel and the register-tile kernels take the second problem in the same
+   * launch, the LDS-staged single-problem kernels run the pair as two launches inside the one call */
+  return cgv_tile_supported(M, N, K);
 }
 
 int cgv_tile_pair_linear_fwd(const float* x_a, const float* W_a, const float* bias_a, float* y_a, float* z_a, const float* x_b,
@@ -930,12 +959,6 @@ int cgv_tile_pair_linear_fwd(const float* x_a, const float* W_a, const float* bi
   return rc;
 }
 
-// workspace of the split reduction (cgv_tile_bwd_input_split): per host thread, for launches on ONE stream
-namespace cgv {
-struct SplitWs { void* ws; size_t bytes; void* stream; };
-static thread_local SplitWs g_split_ws = {nullptr, 0, nullptr};
-constexpr size_t SPLIT_TICKET_BYTES = 64 * 1024;       // head of the workspace: one ticket per output tile
-}  // namespace cgv
 
 static int tile_bwd_input_launch(const float* g, const float* z, int act, const float* W, float* gx, int M, int N, int K,
                                  void* stream, const char* what, const float* add = nullptr,
@@ -946,6 +969,24 @@ static int tile_bwd_input_launch(const float* g, const float* z, int act, const 
   hipStream_t st = (hipStream_t)stream;
   const cgv::BwdSecond s2 = second ? *second : cgv::BwdSecond{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
   const unsigned np = second ? 2u : 1u;
+  // no activation in the operand loads (act_downstream chains carry none), operands 16-byte aligned: the stream-K kernel
+  if (const int bpc = cgv::sk_wanted(M, K, N, (int)np, stream);
+      bpc > 0 && act == 0 && (!more.g || more.act == 0) && (!second || s2.act == 0) &&
+      cgv::sk_aligned({g, W, gx, add, bc.src, more.g, more.W, oa.z, oa.z2, s2.g, s2.W, s2.gx, s2.add})) {
+    cgv::SkArgs a{};
+    a.np = (int)np; a.M = M; a.N = K;
+    cgv::SkProblem& p0 = a.p[0];
+    p0.A[0] = g; p0.B[0] = W; p0.R[0] = N; p0.out = gx; p0.add = add;
+    if (more.g) { p0.A[1] = more.g; p0.B[1] = more.W; p0.R[1] = N; }
+    p0.bc_src = bc.src; p0.bc_row2seg = bc.row2seg; p0.bc_rowptr = bc.rowptr; p0.bc_mean = bc.mean;
+    p0.oz = oa.z; p0.oact = oa.act;
+    if (second) {
+      cgv::SkProblem& p1 = a.p[1];
+      p1.A[0] = s2.g; p1.B[0] = s2.W; p1.R[0] = N; p1.out = s2.gx; p1.add = s2.add; p1.oz = oa.z2; p1.oact = oa.act2;
+    }
+    if (cgv::sk_launch(a, true, cgv::g_split_ws.ws, cgv::g_split_ws.bytes, cgv::SPLIT_TICKET_BYTES, st, bpc) == 0)
+      return cgv::check_launch(what);
+  }
   const int kt = (K + 63) / 64;
   const int blocks32 = kt * ((M + 31) / 32);
   const int blocks16 = kt * ((M + 15) / 16);

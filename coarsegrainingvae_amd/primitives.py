@@ -356,6 +356,24 @@ class _QueueScope:
 wgrad_queue = WeightGradQueue()
 
 
+def _claim_producer(producer, consumer):
+    """The downstream activation derivative (``act_downstream``) hands the producing node dL/dz where autograd expects
+    dL/da: right only while ONE fused consumer reads the activated tensor.  The first consumer claims the node; a second
+    fused consumer of the same tensor un-claims it for both (each then returns the plain dL/da, the producer applies
+    act'(z) itself).  A consumer that is NOT one of these layers cannot be seen from here: ``sole_consumer=True`` /
+    ``producer=`` remain the caller's statement that none exists."""
+    import weakref
+    prev = getattr(producer, "_cgv_claim", None)
+    if prev is None:
+        producer._cgv_claim = weakref.ref(consumer)          # weak: no reference cycle between the two nodes
+        return producer
+    first = prev() if callable(prev) else None
+    if first is not None:
+        first.producer = None
+    producer._cgv_claim = False                              # contested: nobody fuses
+    return None
+
+
 class _LinearFn(torch.autograd.Function):
     """y = act(x W^T + b), act in {identity, Swish}.  Small row counts run on the skinny-GEMM kernels
     (bias / activation fused; activation backward fused into the operand loads), larger ones on the
@@ -379,7 +397,7 @@ class _LinearFn(torch.autograd.Function):
         ctx.producer = None
         if (producer is not None and HOST_OPTION("act_downstream") and x.grad_fn is producer and ctx.mode in ("tile", "skinny")
                 and getattr(producer, "act", ACT_NONE) != ACT_NONE and getattr(producer, "mode", None) == ctx.mode):
-            ctx.producer = producer
+            ctx.producer = _claim_producer(producer, ctx)
         if slot is not None:
             slot.armed = True
         if fork:
@@ -456,7 +474,13 @@ class _LinearFn(torch.autograd.Function):
     def _backward_core(ctx, gy, add):
         x, weight, z = ctx.saved_tensors
         w_param, b_param = ctx.params
-        act = ACT_NONE if getattr(ctx, "act_done", False) else ctx.act      # (the consuming layer already multiplied gy by act'(z))
+        # ``act_done`` lives for ONE backward: the consuming layer sets it right before this node runs (it has then multiplied
+        # gy by act'(z) in its store epilogue); reading it clears it, so a later backward of a retained graph in which the
+        # consumer takes another launch (no fused epilogue) finds it unset and applies act'(z) here again
+        act = ctx.act
+        if getattr(ctx, "act_done", False):
+            ctx.act_done = False
+            act = ACT_NONE
         add2 = add.reshape(-1, add.shape[-1]) if add is not None else None
         if add2 is not None and not (add2.is_contiguous() and add2.data_ptr() % 16 == 0 and add2.dtype == torch.float32):
             add2 = add2.contiguous().float()
@@ -688,7 +712,7 @@ class _TilePairFn(torch.autograd.Function):
         ctx.producer = None
         if (producer is not None and not same and HOST_OPTION("act_downstream") and getattr(producer, "acts", None) is not None
                 and x_a.grad_fn is producer and x_b.grad_fn is producer and all(a != ACT_NONE for a in producer.acts)):
-            ctx.producer = producer
+            ctx.producer = _claim_producer(producer, ctx)
         act_a, act_b = int(acts[0]), int(acts[1])
         xa = x_a.reshape(-1, x_a.shape[-1]).contiguous()
         xb = xa if same else x_b.reshape(-1, x_b.shape[-1]).contiguous()
@@ -712,6 +736,7 @@ class _TilePairFn(torch.autograd.Function):
         pa_w, pa_b, pb_w, pb_b = ctx.params
         (act_a, act_b), slot = ctx.acts, ctx.slot
         done = getattr(ctx, "act_done", (False, False))     # the consuming pair already multiplied g by act'(z): see forward
+        ctx.act_done = (False, False)                       # (valid for this backward only: the consumer sets it every time it applies it)
         act_a = ACT_NONE if done[0] else act_a
         act_b = ACT_NONE if done[1] else act_b
         M, K = xa.shape

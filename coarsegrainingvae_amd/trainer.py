@@ -43,6 +43,7 @@ class ParamArena:
         # _ALIGN spare floats behind the gradients: g[numel] carries the step's loss through the LAST gradient all-reduce of a
         # data-parallel step (the skip decision, utils.py:145, must be the same on every rank) -- no collective of its own
         self.g = torch.zeros(total + _ALIGN, dtype=torch.float32, device=dev)
+        self.grad_views = []
         for p, o in zip(params, offs):
             n = p.numel()
             self.p[o:o + n].copy_(p.data.reshape(-1))
@@ -50,6 +51,7 @@ class ParamArena:
                 self.g[o:o + n].copy_(p.grad.reshape(-1))
             p.data = self.p[o:o + n].view_as(p)
             p.grad = self.g[o:o + n].view_as(p)
+            self.grad_views.append(p.grad)
             # parameters whose backward writes .grad in place (primitives._direct_grad) need no zero-fill
             p._cgv_direct = bool(getattr(p, "_cgv_direct_ok", False))
             p._cgv_pending = True
@@ -65,10 +67,22 @@ class ParamArena:
     def zero_grad(self):
         """Start of a step: direct-write parameters are only flagged 'pending' (their first
         gradient overwrites); the few autograd-accumulated ones (embeddings) are zeroed."""
+        self.attach()
         for p in self.params:
             p._cgv_pending = True
         for p in self.accumulated:
             p.grad.zero_()
+
+    def attach(self):
+        """Point every ``p.grad`` at its arena view again.  Somebody else's ``model.zero_grad()`` (``set_to_none`` is torch's
+        default) or own backward between two steps -- a sampling / evaluation script, scripts/sampling.py:252-311 -- leaves
+        ``p.grad`` None or a tensor of its own, while the kernels write through ``p.grad`` and the norm / clip / update read
+        the arena.  Called when a step OPENS (the forward's dispatch looks at ``p.grad`` too: fused decoder / prior loops and
+        pair launches are taken only for arena-managed parameters) and again before backward."""
+        for p, view in zip(self.params, self.grad_views):
+            g = p.grad
+            if g is not view and (g is None or g.data_ptr() != view.data_ptr()):
+                p.grad = view
 
     def zero_unwritten(self) -> int:
         """End of backward: a direct-write parameter that is STILL flagged pending received no gradient in this step (its
@@ -877,6 +891,8 @@ class Trainer:
         # data parallel: ask the model to signal the end of the decoder's backward (hook registered in forward)
         if self._pending:
             self._apply_pending(overlap=True)               # the previous step's update, beside this step's encoder
+        if self.arena is not None:
+            self.arena.attach()
         overlap = self.sync is not None and train and self.arena is not None and any(self.early_ranges)
         self._sent = set()
         if hasattr(self.model, "bucket_done"):

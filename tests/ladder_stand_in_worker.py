@@ -12,6 +12,8 @@ attempt = int(os.environ["CGV_BENCH_ATTEMPT"])
 base = os.environ["CGV_TEST_RDV_DIR"]
 window = float(os.environ.get("CGV_TEST_RDV_WINDOW", "3"))
 fail_rank = int(os.environ.get("CGV_TEST_FAIL_RANK", "1"))      # -1: nobody fails, attempt 0 is the rendezvous
+if os.environ.get("CGV_TEST_FAIL_ALWAYS"):                       # every rung fails on every rank (the all-rungs-failed exit path)
+    sys.exit(3)
 if attempt == 0 and fail_rank >= 0:
     if rank == fail_rank:
         sys.exit(3)

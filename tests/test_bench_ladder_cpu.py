@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_one_sided_failure_keeps_the_rungs_aligned():
     with tempfile.TemporaryDirectory() as tmp:
         env = dict(os.environ)
-        env.update({"WORLD_SIZE": "2", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29911", "TMPDIR": tmp,
+        env.update({"WORLD_SIZE": "2", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29911", "TMPDIR": tmp, "CGV_BENCH_LADDER_DIR": tmp,
                     "CGV_BENCH_TEST_WORKER": os.path.join(ROOT, "tests", "ladder_stand_in_worker.py"),
                     "CGV_BENCH_TEST_SLOT_S": "9", "CGV_TEST_RDV_DIR": tmp, "CGV_TEST_RDV_WINDOW": "3"})
         procs = []
@@ -35,7 +35,7 @@ def test_one_sided_failure_keeps_the_rungs_aligned():
 
 def _run(tmp, extra_env, world=2, timeout=120):
     env = dict(os.environ)
-    env.update({"WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29917", "TMPDIR": tmp,
+    env.update({"WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29917", "TMPDIR": tmp, "CGV_BENCH_LADDER_DIR": tmp,
                 "CGV_BENCH_TEST_WORKER": os.path.join(ROOT, "tests", "ladder_stand_in_worker.py"),
                 "CGV_BENCH_TEST_SLOT_S": "9", "CGV_TEST_RDV_DIR": tmp, "CGV_TEST_RDV_WINDOW": "3"})
     env.update(extra_env)
@@ -54,7 +54,7 @@ def test_all_ranks_succeed_on_the_first_rung_and_leave_no_clock_file():
         assert len(lines) == 1 and all(not o[0].strip() for o in outs[1:])
         d = json.loads(lines[0])
         assert d["attempt"] == 0 and d["rung"] == "operands+graph"
-        assert not [f for f in os.listdir(tmp) if f.startswith("cgv_bench_t0_") and "." not in f[len("cgv_bench_t0_"):]]
+        assert not [f for f in os.listdir(tmp) if f.startswith("cgv_bench_t0_")]        # neither the clock file nor a mark
 
 
 def test_rank_zero_failing_alone_is_waited_for_too():
@@ -63,3 +63,31 @@ def test_rank_zero_failing_alone_is_waited_for_too():
         assert rcs == [0, 0, 0], [o[1][-800:] for o in outs]
         d = json.loads([ln for ln in outs[0][0].splitlines() if ln.strip()][0])
         assert d["attempt"] == 1 and d["spread_s"] < 2.0, d
+
+
+def test_supervisors_started_by_different_parents_with_different_tmpdirs_share_one_clock():
+    """One launcher process per rank (a shell or srun task each: different parent pids) and a TMPDIR of its own per rank: the
+    clock file's name comes from MASTER_ADDR / MASTER_PORT (+ run id), so the rungs still align after a one-sided failure;
+    and when EVERY rung fails the files are removed all the same."""
+    relay = "import subprocess, sys; sys.exit(subprocess.call(sys.argv[1:]))"
+    with tempfile.TemporaryDirectory() as tmp:
+        for fail_all, want_rc in ((False, 0), (True, 1)):
+            env = dict(os.environ)
+            env.update({"WORLD_SIZE": "2", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29923", "CGV_BENCH_LADDER_DIR": tmp,
+                        "CGV_BENCH_TEST_WORKER": os.path.join(ROOT, "tests", "ladder_stand_in_worker.py"),
+                        "CGV_BENCH_TEST_SLOT_S": "9", "CGV_TEST_RDV_DIR": tmp, "CGV_TEST_RDV_WINDOW": "3", "TORCHELASTIC_RUN_ID": "none"})
+            if fail_all:
+                env["CGV_TEST_FAIL_ALWAYS"] = "1"
+            procs = []
+            for rank in (0, 1):
+                own_tmp = os.path.join(tmp, f"tmp{rank}")
+                os.makedirs(own_tmp, exist_ok=True)
+                e = dict(env, RANK=str(rank), LOCAL_RANK=str(rank), TMPDIR=own_tmp)
+                procs.append(subprocess.Popen([sys.executable, "-c", relay, sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2",
+                                               "--attempt-timeout", "6"], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+            outs = [p.communicate(timeout=180) for p in procs]
+            assert [p.returncode for p in procs] == [want_rc, want_rc], [o[1][-1500:] for o in outs]
+            if not fail_all:
+                d = json.loads([ln for ln in outs[0][0].splitlines() if ln.strip()][0])
+                assert d["attempt"] == 1 and d["spread_s"] < 2.0, d
+            assert not [f for f in os.listdir(tmp) if f.startswith("cgv_bench_t0_")], os.listdir(tmp)

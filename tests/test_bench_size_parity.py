@@ -1,0 +1,240 @@
+"""GPU parity at the sizes ``bench.py`` itself runs, for the pieces that the full-size step tests take from the product:
+
+* the radius graph (K0, data.py:65-82) and the destination- / source-sorted edge plans (K7) of the bench's OWN frames
+  (``synthetic_frames`` seeds 0..7 of every workload, atom and bead graphs at their cutoffs) against BOTH oracles --
+  ``O.get_neighbor_list`` (torch restatement) and ``orc_radius_graph`` / ``orc_csr_sorted`` (plain C) -- bit for bit,
+  directed and undirected, one frame at a time and as the batched launch ``synthetic_batch`` uses;
+* the public API the way the reference's sampler calls it (scripts/sampling.py:252-311): raw one-frame batch ->
+  ``get_inputs`` -> ``prior_net(cg_z, cg_xyz, CG_nbr_list)`` -> ``z = mu + eps * sigma`` -> ``decoder(cg_xyz,
+  CG_nbr_list, z, z, mapping, num_CGs)`` on a model that has been through a ``Trainer``, with and without grad;
+* the five largest gradients of the chignolin bench step element by element.
+
+Integer work is bit-exact; floating point 1e-4 relative (north_star), element-wise where said."""
+import numpy as np
+import pytest
+import torch
+
+import coarsegrainingvae_amd as cg
+from coarsegrainingvae_amd.trainer import Trainer
+from oracle import cgvae_oracle as O
+from test_oracle_c import _load as load_orc, radius_c
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+REL = 1e-4
+
+
+def _frames(workload, seed, n_frames=None):
+    w = cg.data.WORKLOADS[workload]
+    n_frames = n_frames or w["batch"]
+    return w, cg.data.synthetic_frames(n_frames, w["n_atoms"], w["n_cgs"], w["box"], seed,
+                                       spatial_sort=(workload == "protein2000"))
+
+
+def _csr_c(orc, nbrs, n, key_col):
+    """(rowptr, perm) of the C oracle: edges ordered by (column ``key_col``, the other column, edge id)."""
+    nb = np.ascontiguousarray(nbrs, dtype=np.int64)
+    E = nb.shape[0]
+    rp, perm = np.zeros(n + 1, dtype=np.int32), np.zeros(max(E, 1), dtype=np.int32)
+    key = nb[:, key_col:] if key_col else nb
+    other = nb[:, 1:] if key_col == 0 else nb
+    orc.orc_csr_sorted(key.ctypes.data, other.ctypes.data, 2, E, n, n, rp.ctypes.data, perm.ctypes.data)
+    return rp, perm[:E]
+
+
+@pytest.mark.parametrize("workload,seeds", [("dipeptide", range(8)), ("chignolin", range(8)), ("protein2000", range(8))])
+def test_radius_graphs_of_the_bench_frames_are_bit_exact_against_both_oracles(workload, seeds):
+    """data.py:65-82 on every frame the bench replays (``bench.py::make_batch`` seeds 0..7): the atom graph at the atom
+    cutoff and the bead graph at the CG cutoff, undirected (what ``generate_neighbor_list`` stores) and directed.
+    At 2000 atoms that is 4 M pair tests per frame with ~425 k pairs inside the cutoff -- where a threshold that is one
+    ulp off would show."""
+    orc = load_orc()
+    n_edges = 0
+    for seed in seeds:
+        w, props = _frames(workload, seed)
+        for key, cutoff in (("nxyz", w["atom_cutoff"]), ("CG_nxyz", w["cg_cutoff"])):
+            for f, nxyz in enumerate(props[key]):
+                xyz = nxyz[:, 1:4].contiguous()
+                for und in (True, False):
+                    got = cg.get_neighbor_list(xyz, DEV, cutoff, undirected=und).cpu()
+                    want_c = torch.from_numpy(radius_c(orc, xyz.numpy(), cutoff, und))
+                    assert got.dtype == torch.int64 and torch.equal(got, want_c), (workload, seed, key, f, und, "C oracle")
+                    want = O.get_neighbor_list(xyz, cutoff, und)
+                    assert torch.equal(got, want), (workload, seed, key, f, und, "torch oracle")
+                    n_edges += got.shape[0]
+            # ... and the batched launch over all frames of the batch (what synthetic_batch / the dataset path call)
+            sizes = [int(t.shape[0]) for t in props[key]]
+            fp = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32)
+            allxyz = torch.cat([t[:, 1:4] for t in props[key]]).contiguous()
+            got = cg.radius_graph(allxyz.to(DEV), fp.to(DEV), cutoff, True).cpu()
+            want = torch.cat([O.get_neighbor_list(t[:, 1:4], cutoff, True) + int(o) for t, o in zip(props[key], fp[:-1])])
+            assert torch.equal(got, want), (workload, seed, key, "batched")
+    assert n_edges > 0
+
+
+@pytest.mark.parametrize("workload", ["dipeptide", "chignolin", "protein2000"])
+def test_prepared_bench_batches_carry_the_oracles_edge_lists_and_plans(workload):
+    """``synthetic_batch`` (what ``bench.py`` and the full-size step tests feed the model) against the oracle END TO END:
+    the collated undirected lists equal the oracle's per-frame lists + ``CG_collate`` offsets (data.py:65-82, 262-270),
+    the directed lists equal ``make_directed`` (conv.py:10-20) of them, and both sorted views of both plans -- ``rowptr`` /
+    edge permutation by destination and by source -- equal ``orc_csr_sorted`` on the ORACLE's list (851 k directed edges on
+    the 2000-atom graph, 41.5 k on chignolin)."""
+    orc = load_orc()
+    for seed in ((0, 1, 2, 3, 4, 5, 6, 7) if workload != "protein2000" else (0, 3, 7)):
+        w, props = _frames(workload, seed)
+        batch = cg.synthetic_batch(workload, seed=seed, device=DEV)
+        g = batch["_graph"]
+        for key, cutoff, lst, plan, got_dir in (("nxyz", w["atom_cutoff"], "nbr_list", g.atom, g.atom_nbrs),
+                                                ("CG_nxyz", w["cg_cutoff"], "CG_nbr_list", g.cg, g.cg_nbrs)):
+            sizes = [int(t.shape[0]) for t in props[key]]
+            offs = np.concatenate([[0], np.cumsum(sizes)])
+            und = torch.cat([torch.from_numpy(radius_c(orc, t[:, 1:4].contiguous().numpy(), cutoff, True)) + int(o)
+                             for t, o in zip(props[key], offs[:-1])])
+            assert torch.equal(batch[lst].cpu(), und), (workload, seed, lst)
+            want_dir, _ = O.make_directed(und)
+            assert torch.equal(got_dir.cpu(), want_dir), (workload, seed, lst, "directed")
+            n, E = int(offs[-1]), int(want_dir.shape[0])
+            assert plan.n_edges == E
+            for key_col, rowptr, eid in ((0, plan.rowptr_d, plan.eid_d), (1, plan.rowptr_s, plan.eid_s)):
+                rp, perm = _csr_c(orc, want_dir.numpy(), n, key_col)
+                assert np.array_equal(rowptr.cpu().numpy()[: n + 1], rp), (workload, seed, lst, key_col, "rowptr")
+                assert np.array_equal(eid.cpu().numpy()[:E], perm), (workload, seed, lst, key_col, "perm")
+            d = want_dir.numpy()
+            _, perm = _csr_c(orc, d, n, 0)
+            assert np.array_equal(plan.dst_d.cpu().numpy()[:E], d[perm, 0]) and np.array_equal(plan.src_d.cpu().numpy()[:E], d[perm, 1])
+        if workload == "protein2000":
+            assert g.atom.n_edges > 800_000
+
+
+def _elementwise(got, ref, floor):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    return float(((got - ref).abs() / ref.abs().clamp_min(floor)).max())
+
+
+def _rel(got, ref):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    assert got.shape == ref.shape
+    return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("workload,F", [("chignolin", 600), ("dipeptide", 600), ("dipeptide", 64)])
+def test_sampler_call_pattern_prior_then_decoder_on_a_trained_model(workload, F):
+    """scripts/sampling.py:252-311 (``sample_single``): ONE frame, collated and moved to the device but NOT prepared,
+    ``model.get_inputs`` -> ``model.prior_net(cg_z, cg_xyz, CG_nbr_list)`` -> ``H = mu + eps * sigma`` ->
+    ``model.decoder(cg_xyz, CG_nbr_list, H, H, mapping, num_CGs)``; the model has taken Trainer steps before (its
+    parameters are arena views, the Trainer's forward ran with the lazy decoder tail).  Checked against the oracle's
+    ``prior_forward`` / ``decode`` on the SAME parameters: under ``no_grad`` and with grad (d sum(xyz_decode^2) / d H and
+    two decoder weight gradients), ``xyz_decode`` element-wise; then ``model(batch)`` as the sampler calls it afterwards."""
+    w, props = _frames(workload, 11, n_frames=3)
+    ds = cg.data.CGDataset(props)
+    ds.generate_neighbor_list(w["atom_cutoff"], w["cg_cutoff"], device=DEV, undirected=True)
+    enc, dec = (2, 9) if workload == "chignolin" else (w["enc_nconv"], w["dec_nconv"])
+    model = cg.build_model(F, w["n_rbf"], w["atom_cutoff"], w["cg_cutoff"], enc, dec, w["n_cgs"], seed=123).to(DEV)
+    hp = O.Hyper(F, w["n_rbf"], w["atom_cutoff"], w["cg_cutoff"], enc, dec, w["n_cgs"])
+    train_batch = cg.prepare_batch(cg.CG_collate([ds[0], ds[1]]), DEV)
+    tr = Trainer(model, lr=1e-4, beta=w["beta"], gamma=w["gamma"])
+    step_eps = [torch.randn(train_batch["CG_nxyz"].shape[0], F, generator=torch.Generator().manual_seed(20 + k)).to(DEV) for k in range(3)]
+    for k in range(2):
+        tr.step(train_batch, eps=step_eps[k])
+    torch.cuda.synchronize()
+    assert int(tr.state[0].item()) == 2
+
+    raw = cg.CG_collate([ds[2]])                              # CG_collate of one frame, as the sampler's loader yields it
+    cpu_batch = {k: v.clone() for k, v in raw.items() if torch.is_tensor(v)}
+    batch = cg.data.batch_to(raw, DEV)
+    assert "_graph" not in batch
+    P = {k: v.detach().cpu().clone().requires_grad_(v.dtype == torch.float32) for k, v in model.state_dict().items()}
+    z_, cg_z_, xyz_, cg_xyz_, nbr_, cg_nbr_, mapping_, _n = (cpu_batch["nxyz"][:, 0], cpu_batch["CG_nxyz"][:, 0],
+                                                            cpu_batch["nxyz"][:, 1:], cpu_batch["CG_nxyz"][:, 1:], cpu_batch["nbr_list"],
+                                                            cpu_batch["CG_nbr_list"], cpu_batch["CG_mapping"], None)
+    eps = torch.randn(cg_xyz_.shape[0], F, generator=torch.Generator().manual_seed(5))
+
+    # ---- no grad, exactly the sampler's statements
+    with torch.no_grad():
+        z, cg_z, xyz, cg_xyz, nbr_list, CG_nbr_list, mapping, num_CGs = model.get_inputs(batch)
+        H_mu, H_sigma = model.prior_net(cg_z, cg_xyz, CG_nbr_list)
+        H = eps.to(DEV).mul(H_sigma).add_(H_mu)               # sample_normal, sampling.py:247-250
+        xyz_decode = model.decoder(cg_xyz, CG_nbr_list, H, H, mapping, num_CGs)
+        assert type(xyz_decode) is torch.Tensor and xyz_decode.shape == xyz.shape      # a real tensor, not a lazy slot
+        ref_mu, ref_sigma = O.prior_forward(cg_z_, cg_xyz_, cg_nbr_, P, hp)
+        ref_H = eps.mul(ref_sigma).add_(ref_mu)
+        ref_xyz = O.decode(cg_xyz_, cg_nbr_, ref_H, mapping_, P, hp)
+    for got, ref, name in ((H_mu, ref_mu, "prior mu"), (H_sigma, ref_sigma, "prior sigma"), (xyz_decode, ref_xyz, "xyz_decode")):
+        assert _rel(got, ref) <= REL, (name, _rel(got, ref))
+    assert _elementwise(xyz_decode, ref_xyz, 1e-2) <= REL
+    for got, ref in ((H_mu, ref_mu), (H_sigma, ref_sigma)):
+        assert _elementwise(got, ref, 1e-2 * float(ref.abs().max())) <= REL
+
+    # ---- with grad: the same calls, then a backward through decoder and prior
+    model.zero_grad(set_to_none=True)
+    z, cg_z, xyz, cg_xyz, nbr_list, CG_nbr_list, mapping, num_CGs = model.get_inputs(batch)
+    H_mu, H_sigma = model.prior_net(cg_z, cg_xyz, CG_nbr_list)
+    H = torch.addcmul(H_mu, eps.to(DEV), H_sigma)
+    H.retain_grad()
+    xyz_decode = model.decoder(cg_xyz, CG_nbr_list, H, H, mapping, num_CGs)
+    (xyz_decode - xyz).pow(2).mean().backward()
+    ref_mu, ref_sigma = O.prior_forward(cg_z_, cg_xyz_, cg_nbr_, P, hp)
+    ref_H = torch.addcmul(ref_mu, eps, ref_sigma)
+    ref_H.retain_grad()
+    ref_xyz = O.decode(cg_xyz_, cg_nbr_, ref_H, mapping_, P, hp)
+    (ref_xyz - xyz_).pow(2).mean().backward()
+    assert _rel(xyz_decode, ref_xyz) <= REL and _elementwise(xyz_decode, ref_xyz, 1e-2) <= REL
+    assert _rel(H.grad, ref_H.grad) <= REL
+    grads = dict(model.named_parameters())
+    last = dec - 1
+    for name in (f"equivaraintconv.message_blocks.{last}.inv_message.inv_dense.1.weight",
+                 "equivaraintconv.update_blocks.0.u_mat.weight",
+                 "equivaraintconv.message_blocks.0.inv_message.dist_embed.block.1.weight",
+                 "prior_net.mu.0.weight", "prior_net.message_blocks.0.inv_message.inv_dense.0.weight"):
+        got, ref = grads[name].grad, P[name].grad
+        assert got is not None and ref is not None, name
+        assert _rel(got, ref) <= REL, (name, _rel(got, ref))
+
+    # ---- and the full forward the sampler runs afterwards on the same un-prepared batch (sampling.py:292)
+    with torch.no_grad():
+        out = model(batch, eps=eps.to(DEV))
+        ref_out = O.model_forward(cpu_batch, P, hp, eps=eps)
+    assert type(out[5]) is torch.Tensor
+    for k, name in enumerate(("mu", "sigma", "prior_mu", "prior_sigma", "xyz", "xyz_recon")):
+        assert _rel(out[k], ref_out[k]) <= REL, (name, _rel(out[k], ref_out[k]))
+    assert _elementwise(out[5], ref_out[5], 1e-2) <= REL
+    # the model still trains afterwards exactly as if nobody had called it in between: the sampler's own backward and its
+    # ``zero_grad(set_to_none=True)`` took ``p.grad`` away from the trainer's arena (ParamArena.zero_grad points it back)
+    model.zero_grad(set_to_none=True)
+    tr.step(train_batch, eps=step_eps[2])
+    torch.cuda.synchronize()
+    assert int(tr.state[0].item()) == 3 and tr.skipped_steps() == 0
+    twin = cg.build_model(F, w["n_rbf"], w["atom_cutoff"], w["cg_cutoff"], enc, dec, w["n_cgs"], seed=123).to(DEV)
+    tr2 = Trainer(twin, lr=1e-4, beta=w["beta"], gamma=w["gamma"])
+    for k in range(3):
+        tr2.step(train_batch, eps=step_eps[k])
+    torch.cuda.synchronize()
+    assert float(tr.last_loss) == float(tr2.last_loss)
+    for (name, a), (_n, b) in zip(model.state_dict().items(), twin.state_dict().items()):
+        assert torch.equal(a, b), f"{name}: training with a sampling call in between differs from training without"
+
+
+def test_largest_gradients_of_the_chignolin_bench_step_element_by_element():
+    """The chignolin bench configuration's first step (F = 600, 2 frames, enc 2 / dec 9): the five largest live gradient
+    tensors (and the five with the largest peak entries) against the oracle ELEMENT-WISE,
+    ``|d| <= 1e-4 * max(|ref|, 1 % of the tensor's peak)`` -- the norm-wise bound of the full-size tests lets an entry two
+    decades below the peak be off by 100 % of itself, this one holds it to 1e-4 of its own size."""
+    from test_full_size_parity import _setup, OracleTraining
+    F = 600
+    w, batch, cpu_batch, model, hp, P = _setup("chignolin", 2, F)
+    oracle = OracleTraining(cpu_batch, P, hp, w, 1e-4)
+    eps = torch.randn(cpu_batch["CG_nxyz"].shape[0], F, generator=torch.Generator().manual_seed(9))
+    ref = oracle.step(eps)
+    tr = Trainer(model, lr=1e-4, beta=w["beta"], gamma=w["gamma"])
+    tr.step(batch, eps=eps.to(DEV))                      # first step: every gradient materialised
+    named = dict(model.named_parameters())
+    live = {k: g for k, g in ref["grads"].items() if float(g.abs().max()) > 0.0}
+    by_size = sorted(live, key=lambda k: -live[k].numel())[:5]
+    by_peak = sorted(live, key=lambda k: -float(live[k].abs().max()))[:5]
+    worst = 0.0
+    for name in dict.fromkeys(by_size + by_peak):
+        g0 = live[name]
+        e = _elementwise(named[name].grad, g0, 1e-2 * float(g0.abs().max()))
+        worst = max(worst, e)
+        assert e <= REL, f"grad {name} ({g0.numel()} entries): element-wise error {e:.3e}"
+    print(f"\n[chignolin step 1, {len(set(by_size + by_peak))} largest gradients] worst element-wise error {worst:.3e}")

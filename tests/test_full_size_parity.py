@@ -115,9 +115,11 @@ def _check_outputs(tr, ref, what, updates: int = 0, own=None):
     stay at 1e-7 ... 1e-6.  That drift says nothing about the kernels.  So behind an update the element-wise bound is
     applied where it is exact -- against ``own``, the oracle's forward on a snapshot of the DEVICE model's own parameters
     (same weights both sides: pure forward parity, held to 1e-4 like the first step) -- and the comparison with the
-    oracle's own trajectory keeps the norm-wise 1e-4 plus a loose element-wise 1e-3 as a sanity bound (the agreement of
-    the trajectories is what ``_check_moments`` / ``_check_parameters`` / the norm and clip checks establish)."""
-    lat_tol = REL if updates == 0 else 10 * REL
+    oracle's own trajectory keeps the norm-wise 1e-4 plus an element-wise bound at the measured drift (3e-4 behind one
+    update, 5e-4 / 7e-4 behind two / three; the agreement of the trajectories is what ``_check_moments`` / ``_check_parameters`` / the norm and clip checks establish)."""
+    # measured drift of the two trajectories' small latent entries: 1.0e-4 ... 2.1e-4 after one update; the bound follows it
+    # (3e-4 behind one update, + 2e-4 per further update) instead of a flat 1e-3
+    lat_tol = REL * (1 + 2 * updates)
     if own is not None:
         for k in range(6):
             if tr.last_out[k] is None:

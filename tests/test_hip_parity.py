@@ -1665,6 +1665,71 @@ def test_activation_derivative_applied_downstream_trains_alike(workload, F, enc,
         assert torch.allclose(p0[k], p1[k], rtol=1e-5, atol=1e-7), k
 
 
+def _two_layer_fp64(x, l1, l2s, gos):
+    """fp64 gradients of sum_k <l2s[k](swish(l1(x))), gos[k]> w.r.t. x, l1.weight, l1.bias and every l2 weight."""
+    x64 = x.detach().double().cpu().requires_grad_(True)
+    W1, b1 = l1.weight.detach().double().cpu().requires_grad_(True), l1.bias.detach().double().cpu().requires_grad_(True)
+    z = x64 @ W1.t() + b1
+    a = z * torch.sigmoid(z)
+    W2 = [l.weight.detach().double().cpu().requires_grad_(True) for l in l2s]
+    total = sum(((a @ w.t() + l.bias.detach().double().cpu()) * go.double().cpu()).sum() for w, l, go in zip(W2, l2s, gos))
+    total.backward()
+    return x64.grad, W1.grad, b1.grad, [w.grad for w in W2]
+
+
+@pytest.mark.parametrize("M,N", [(332, 600), (64, 600), (96, 5400), (12, 600)])
+def test_downstream_activation_flag_lives_for_one_backward_of_a_retained_graph(M, N, options):
+    """Dense(Swish) -> Dense(sole_consumer=True) (modules.py:103-114; the ``inv_dense`` chains of conv.py:31-61): the second
+    layer's backward-input launch may store gx * Swish'(z) of the first and flag that node (``act_done``).  The flag is
+    valid for the backward that set it only: backward a retained graph twice, the second time with the consumer's fused
+    epilogue taken away (what a different dispatch -- row split refused, split workspace not ready inside a capture --
+    amounts to); the first layer must then apply Swish'(z) itself again.  Both backwards against fp64."""
+    from coarsegrainingvae_amd.primitives import Dense, Swish
+    options.set("act_downstream", 1)
+    torch.manual_seed(3)
+    K = 600
+    l1, l2 = Dense(K, K, activation=Swish()).to(DEV), Dense(K, N).to(DEV)
+    x = torch.randn(M, K, device=DEV, requires_grad=True)
+    go = torch.randn(M, N, device=DEV)
+    out = l2(l1(x), sole_consumer=True)
+    consumer = out.grad_fn
+    fused_with = consumer.producer
+    ref = _two_layer_fp64(x, l1, [l2], [go])
+    for attempt in range(3):
+        for t in (x, l1.weight, l1.bias, l2.weight):
+            t.grad = None
+        # second backward: the consumer does not apply the epilogue; third: it does again
+        consumer.producer = None if attempt == 1 else fused_with
+        out.backward(go, retain_graph=True)
+        assert_close(x.grad, ref[0], f"gx, backward {attempt}", 2e-5)
+        assert_close(l1.weight.grad, ref[1], f"gW1, backward {attempt}", 2e-5)
+        assert_close(l1.bias.grad, ref[2], f"gb1, backward {attempt}", 2e-5)
+        assert_close(l2.weight.grad, ref[3][0], f"gW2, backward {attempt}", 2e-5)
+
+
+@pytest.mark.parametrize("M", [332, 12])
+def test_two_fused_consumers_of_one_activated_tensor_unclaim_the_producer(M, options):
+    """``sole_consumer=True`` twice on the SAME activated tensor: neither layer may hand the producer dL/dz (autograd would
+    add one consumer's dL/dz to the other's dL/da).  ``_claim_producer`` lets the first claim, the second un-claims for
+    both; the gradients are the plain ones (fp64)."""
+    from coarsegrainingvae_amd.primitives import Dense, Swish
+    options.set("act_downstream", 1)
+    torch.manual_seed(4)
+    K = 600
+    l1, l2, l3 = Dense(K, K, activation=Swish()).to(DEV), Dense(K, K).to(DEV), Dense(K, 1800).to(DEV)
+    x = torch.randn(M, K, device=DEV, requires_grad=True)
+    a = l1(x)
+    o2, o3 = l2(a, sole_consumer=True), l3(a, sole_consumer=True)
+    assert o2.grad_fn.producer is None and o3.grad_fn.producer is None
+    g2, g3 = torch.randn_like(o2), torch.randn_like(o3)
+    ref = _two_layer_fp64(x, l1, [l2, l3], [g2, g3])
+    torch.autograd.backward([o2, o3], [g2, g3])
+    assert_close(x.grad, ref[0], "gx", 2e-5)
+    assert_close(l1.weight.grad, ref[1], "gW1", 2e-5)
+    assert_close(l2.weight.grad, ref[3][0], "gW2", 2e-5)
+    assert_close(l3.weight.grad, ref[3][1], "gW3", 2e-5)
+
+
 @pytest.mark.parametrize("M,N,K,act_out,with_add", [(332, 1800, 600, 1, False), (704, 600, 1200, 1, True), (97, 604, 52, 2, False)])
 def test_backward_input_with_the_downstream_activation_epilogue_vs_fp64(M, N, K, act_out, with_add):
     """cgv_tile_linear_bwd_input_out / cgv_tile_pair_linear_bwd_input_out: gx = (add + (gy * act'(z)) W) * act_out'(z_out),

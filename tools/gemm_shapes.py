@@ -32,6 +32,14 @@ for M in (tuple(int(a) for a in sys.argv[1:]) or (96, 288, 332, 704, 2000)):
         t_fl = timeit(lambda i: torch.nn.functional.linear(xs[i % NB], Ws[i % NB], bs[i % NB]))
         t_b = timeit(lambda i: _lib.call("cgv_tile_linear_bwd_input", _lib.ptr(gs[i % NB]), _lib.ptr(Ws[i % NB]), _lib.ptr(gx), M, N, K, st))
         t_bl = timeit(lambda i: torch.mm(gs[i % NB], Ws[i % NB]))
+        # numerics of the timed kernels against fp64 (max-abs error over max-abs)
+        _lib.call("cgv_tile_linear_fwd", _lib.ptr(xs[0]), _lib.ptr(Ws[0]), _lib.ptr(bs[0]), _lib.ptr(y), _lib.ptr(z), M, N, K, 1, st)
+        z64 = xs[0].double() @ Ws[0].double().t() + bs[0].double()
+        e_f = float((z.double() - z64).abs().max() / z64.abs().max())
+        e_y = float((y.double() - z64 * torch.sigmoid(z64)).abs().max() / z64.abs().max())
+        _lib.call("cgv_tile_linear_bwd_input", _lib.ptr(gs[0]), _lib.ptr(Ws[0]), _lib.ptr(gx), M, N, K, st)
+        g64 = gs[0].double() @ Ws[0].double()
+        e_b = float((gx.double() - g64).abs().max() / g64.abs().max())
         gf = 2 * M * N * K / 1e9
         print(f"M={M:5d} N={N:5d} K={K:5d} ({gf:5.2f} GF): fwd tile {t_f:7.2f} us {gf / t_f * 1e3:6.1f} TF/s | lib {t_fl:7.2f} us {gf / t_fl * 1e3:6.1f} | "
-              f"bwd_input tile {t_b:7.2f} us {gf / t_b * 1e3:6.1f} TF/s | lib {t_bl:7.2f} us {gf / t_bl * 1e3:6.1f}", flush=True)
+              f"bwd_input tile {t_b:7.2f} us {gf / t_b * 1e3:6.1f} TF/s | lib {t_bl:7.2f} us {gf / t_bl * 1e3:6.1f} | err {max(e_f, e_y):.1e} {e_b:.1e}", flush=True)
