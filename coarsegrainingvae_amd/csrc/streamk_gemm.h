@@ -6,12 +6,12 @@
 
 namespace cgv {
 
-constexpr int SK_BM = 128, SK_BN = 128, SK_BK = 32;
+constexpr int SK_BM = 128, SK_BN = 128, SK_BK = 32, SK_THREADS = 512;
 constexpr int SK_LDA = SK_BK + 4;                  // [row][k] slabs: 36 floats per row (conflict-free ds_read_b128, tile_gemm.hip)
 constexpr int SK_LDB = SK_BN + 4;                  // NN: [k][n] slab, 132 floats per row
 constexpr int SK_A_FLOATS = SK_BM * SK_LDA;        // 4608
 constexpr int SK_B_FLOATS = SK_BN * SK_LDA;        // NT 4608 (NN needs 32 * 132 = 4224)
-constexpr int SK_LDS_BYTES = 2 * (SK_A_FLOATS + SK_B_FLOATS) * 4 + 16;       // + the "last arriver" word
+constexpr int SK_LDS_BYTES = 2 * (SK_A_FLOATS + SK_B_FLOATS) * 4;
 constexpr int SK_PART_FLOATS = SK_BM * SK_BN;      // one partial tile
 constexpr int SK_MAX_GRID = 512;
 
@@ -41,7 +41,7 @@ struct SkArgs {
   int slabs0, slabs;           // slabs of source 0, of both sources
   long long units;             // np * tiles_m * tiles_n * slabs
   float* part;                 // [2 * grid][SK_PART_FLOATS]
-  unsigned* ticket;            // [np * tiles], zero between launches (self-resetting)
+  unsigned* ticket;            // [np * tiles], zero between launches (self-resetting): low half = parts published, high half = shares finished
 };
 
 size_t sk_workspace_part_bytes(int grid);

@@ -826,8 +826,14 @@ static int sk_wanted(int rows, int cols, int red, int np, void* stream) {
   if (opt == 1 || !g_split_ws.ws || g_split_ws.stream != stream) return 0;
   if (opt == 2) return 1;
   if (opt == 3) return 2;
-  (void)cols; (void)red; (void)np;
-  return rows >= 512 ? 1 : 0;
+  if (opt >= 16) return -opt;                            /* experiments: a grid of exactly `opt` blocks */
+  // Measured against the register-tile kernels (tools/probes/sk_ab.py, rotating operands, profiles/r06_gemm_shapes.txt): the
+  // stream-K kernel wins where the output is small and the reduction long at many rows -- 2000 x 1800 -> 600: 52.4 against
+  // 56.2 us, 2000 x 5400 -> 600: 136 / 158, 2000 x 1200 -> 600 forward: 41.9 / 46.5 -- and loses everywhere else (its parts
+  // cost ~10 us per launch: store, ticket, wait, read are four dependent trips to memory; at 704 rows that is half a launch).
+  // Pair launches stay on the register tiles (two problems double the operands in flight: 2000 x 5400 pair 382 against 276 us).
+  if (np != 1 || rows < 1536) return 0;
+  return (cols <= 640 && red >= 1200) ? 1 : 0;
 }
 static bool sk_aligned(std::initializer_list<const void*> ptrs) {
   uintptr_t u = 0;
@@ -852,7 +858,7 @@ static int tile_fwd_launch(const float* x, const float* W, const float* bias, fl
   const unsigned np = second ? 2u : 1u;
   if (pair_ok) *pair_ok = 1;
   if (const int bpc = cgv::sk_wanted(M, N, K, (int)np, stream);
-      bpc > 0 && cgv::sk_aligned({x, W, bias, y, z, s2.x, s2.W, s2.bias, s2.y, s2.z})) {
+      bpc != 0 && cgv::sk_aligned({x, W, bias, y, z, s2.x, s2.W, s2.bias, s2.y, s2.z})) {
     cgv::SkArgs a{};
     a.np = (int)np; a.M = M; a.N = N;
     a.p[0].A[0] = x; a.p[0].B[0] = W; a.p[0].R[0] = K; a.p[0].out = y; a.p[0].bias = bias; a.p[0].zout = z; a.p[0].act = act;
@@ -971,7 +977,7 @@ static int tile_bwd_input_launch(const float* g, const float* z, int act, const 
   const unsigned np = second ? 2u : 1u;
   // no activation in the operand loads (act_downstream chains carry none), operands 16-byte aligned: the stream-K kernel
   if (const int bpc = cgv::sk_wanted(M, K, N, (int)np, stream);
-      bpc > 0 && act == 0 && (!more.g || more.act == 0) && (!second || s2.act == 0) &&
+      bpc != 0 && act == 0 && (!more.g || more.act == 0) && (!second || s2.act == 0) &&
       cgv::sk_aligned({g, W, gx, add, bc.src, more.g, more.W, oa.z, oa.z2, s2.g, s2.W, s2.gx, s2.add})) {
     cgv::SkArgs a{};
     a.np = (int)np; a.M = M; a.N = K;

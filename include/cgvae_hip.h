@@ -94,9 +94,10 @@ enum {
                                    (>= 48 edges per node, n_rbf <= 15, n_feat % 4 == 0), 0 never (the packed-FMA walk) */
   CGV_OPT_STREAMK = 21,         /* cgv_tile_linear_fwd / cgv_tile_*bwd_input* (and their pair / two-source forms): the LDS-staged stream-K
                                    kernel (csrc/streamk_gemm.hip: 128 x 128 tiles, the (tile, 32-deep slab) units of a launch cut into equal
-                                   ranges, one or two blocks per CU; needs the workspace of cgv_tile_bwd_input_split).  0 (default) where it
-                                   wins: from 512 rows on (see tile_gemm.hip: sk_wanted); 1 never; 2 / 3 wherever the operands allow, with
-                                   one / two blocks per CU (tests, A-B) */
+                                   ranges, one block per CU; needs the workspace of cgv_tile_bwd_input_split).  0 (default) where it
+                                   wins: single launches of >= 1536 rows with <= 640 outputs over a >= 1200-deep reduction (see
+                                   tile_gemm.hip: sk_wanted); 1 never; 2 / 3 wherever the operands allow, with one / two blocks per CU
+                                   (tests, A-B); >= 16: a grid of exactly that many blocks (experiments) */
   CGV_OPT_COUNT = 22
 };
 /* Measurement: store the GPU wall clock (cgv_timestamp_hz ticks per second) into *slot, in stream order; capturable. */

@@ -2921,8 +2921,7 @@ def test_tile_pair_entry_points_on_ragged_shapes_vs_fp64(M, N, K):
     cgv_tile_linear_bwd_input_sum2): row / column counts that are no multiples of the 16 / 32 / 64-wide tiles, a different
     activation code per problem, NULL and non-NULL `add`, with and without a per-segment gradient -- against fp64."""
     L = cg._lib
-    if not L.load().cgv_tile_pair_supported(M, N, K):
-        pytest.skip("this shape runs on the LDS-staged kernels (no pair launch)")
+    assert L.load().cgv_tile_pair_supported(M, N, K)           # every tile-supported shape (staged kernels: two launches inside the call)
     gen = torch.Generator().manual_seed(M * 7 + N)
     mk = lambda *s: torch.randn(*s, generator=gen).to(DEV)
     xa, xb, Wa, Wb, ba, bb = mk(M, K), mk(M, K), mk(N, K) * 0.1, mk(N, K) * 0.1, mk(N), mk(N)
@@ -2960,3 +2959,99 @@ def test_tile_pair_entry_points_on_ragged_shapes_vs_fp64(M, N, K):
             counts = torch.bincount(mapping.cpu(), minlength=n_seg).clamp_min(1).double()
             ref = ref + (d(seg) / counts.unsqueeze(1))[mapping.cpu()]
         assert_close(gx, ref, f"sum2 (segment gradient: {with_seg})", 5e-6)
+
+
+@pytest.mark.parametrize("M,N,K", [(2000, 600, 1800), (704, 1800, 600), (129, 132, 260), (333, 604, 36), (1537, 68, 1204)])
+@pytest.mark.parametrize("streamk", [2, 3, 37])
+def test_stream_k_gemm_every_entry_point_vs_fp64(M, N, K, streamk, options):
+    """csrc/streamk_gemm.hip forced onto every tile entry point (``streamk`` = 2: one block per CU, 3: two, 37: a grid of 37
+    blocks -- ranges that cut tiles anywhere, some tiles shared by many blocks): forward with bias / Swish / z output, single
+    and pair; backward-input plain, + add, + per-segment gradient, times the downstream activation derivative, pair, and
+    the two-source product -- ragged row / column / reduction counts (no multiples of the 128 x 128 x 32 units; modules.py:
+    103-114 and its autograd) against fp64, and bit-identical over repeated launches (parts are summed in range order,
+    whoever arrives last)."""
+    L = cg._lib
+    options.set("streamk", streamk)
+    gen = torch.Generator().manual_seed(M * 3 + N + K)
+    mk = lambda *s: torch.randn(*s, generator=gen).to(DEV)
+    d = lambda t: t.double().cpu()
+    st = L.stream_ptr()
+    xa, xb, Wa, Wb, ba, bb = mk(M, K), mk(M, K), mk(N, K) * 0.1, mk(N, K) * 0.1, mk(N), mk(N)
+    nan = lambda *s: torch.full(s, float("nan"), device=DEV)
+    # forward, single (Swish, z kept) and without bias / activation
+    y, z = nan(M, N), nan(M, N)
+    L.call("cgv_tile_linear_fwd", L.ptr(xa), L.ptr(Wa), L.ptr(ba), L.ptr(y), L.ptr(z), M, N, K, 1, st)
+    za64 = d(xa) @ d(Wa).t() + d(ba)
+    assert_close(z, za64, "z", 2e-6)
+    assert_close(y, za64 * torch.sigmoid(za64), "y", 5e-6)
+    y_again = nan(M, N)
+    L.call("cgv_tile_linear_fwd", L.ptr(xa), L.ptr(Wa), L.ptr(ba), L.ptr(y_again), L.ptr(z), M, N, K, 1, st)
+    assert torch.equal(y, y_again)                           # deterministic
+    y0 = nan(M, N)
+    L.call("cgv_tile_linear_fwd", L.ptr(xa), L.ptr(Wa), None, L.ptr(y0), None, M, N, K, 0, st)
+    assert_close(y0, d(xa) @ d(Wa).t(), "y, no bias / activation", 2e-6)
+    # forward pair: swish / tanh
+    ya, yb, za, zb = nan(M, N), nan(M, N), nan(M, N), nan(M, N)
+    L.call("cgv_tile_pair_linear_fwd", L.ptr(xa), L.ptr(Wa), L.ptr(ba), L.ptr(ya), L.ptr(za), L.ptr(xb), L.ptr(Wb), L.ptr(bb), L.ptr(yb),
+           L.ptr(zb), M, N, K, 1, 2, st)
+    zb64 = d(xb) @ d(Wb).t() + d(bb)
+    assert_close(ya, za64 * torch.sigmoid(za64), "pair y_a", 5e-6)
+    assert_close(zb, zb64, "pair z_b", 2e-6)
+    # (|z| reaches ~20 at K = 1800: z's own 2e-6 of its maximum is 4e-5 absolute where tanh' is ~1)
+    assert_close(yb, torch.tanh(zb64), "pair y_b", 5e-5)
+    # backward-input: plain, + add, * act'(z_out), + per-segment gradient
+    ga, gb, add, zo = mk(M, N), mk(M, N), mk(M, K), mk(M, K)
+    gx = nan(M, K)
+    L.call("cgv_tile_linear_bwd_input", L.ptr(ga), L.ptr(Wa), L.ptr(gx), M, N, K, st)
+    assert_close(gx, d(ga) @ d(Wa), "gx", 5e-6)
+    gx2 = nan(M, K)
+    L.call("cgv_tile_linear_bwd_input", L.ptr(ga), L.ptr(Wa), L.ptr(gx2), M, N, K, st)
+    assert torch.equal(gx, gx2)
+    L.call("cgv_tile_linear_bwd_input_out", L.ptr(ga), None, L.ptr(Wa), L.ptr(add), L.ptr(gx), M, N, K, 0, L.ptr(zo), 1, st)
+    s = torch.sigmoid(d(zo))
+    assert_close(gx, (d(ga) @ d(Wa) + d(add)) * (s * (1 + d(zo) * (1 - s))), "gx + add, times Swish'(z_out)", 5e-6)
+    n_seg = 7
+    mapping = (torch.arange(M) % n_seg).to(DEV)
+    plan = EdgePlan.from_mapping(mapping, n_seg)
+    seg = mk(n_seg, K)
+    counts = torch.bincount(mapping.cpu(), minlength=n_seg).clamp_min(1).double()
+    L.call("cgv_tile_linear_bwd_input_act_add_bcast", L.ptr(ga), None, L.ptr(Wa), L.ptr(add), L.ptr(seg), L.ptr(mapping), L.ptr(plan.rowptr_d), 1,
+           L.ptr(gx), M, N, K, 0, st)
+    assert_close(gx, d(ga) @ d(Wa) + d(add) + (d(seg) / counts.unsqueeze(1))[mapping.cpu()], "gx + add + segment mean", 5e-6)
+    # pair, and both sources into one output
+    gxa, gxb = nan(M, K), nan(M, K)
+    L.call("cgv_tile_pair_linear_bwd_input", L.ptr(ga), None, L.ptr(Wa), None, L.ptr(gxa), L.ptr(gb), None, L.ptr(Wb), L.ptr(add),
+           L.ptr(gxb), M, N, K, 0, 0, st)
+    assert_close(gxa, d(ga) @ d(Wa), "pair gx_a", 5e-6)
+    assert_close(gxb, d(gb) @ d(Wb) + d(add), "pair gx_b", 5e-6)
+    for with_seg in (False, True):
+        L.call("cgv_tile_linear_bwd_input_sum2", L.ptr(ga), None, L.ptr(Wa), L.ptr(gb), None, L.ptr(Wb), L.ptr(add),
+               L.ptr(seg) if with_seg else None, L.ptr(mapping) if with_seg else None, L.ptr(plan.rowptr_d) if with_seg else None, 1,
+               L.ptr(gx), M, N, K, 0, 0, st)
+        ref = d(ga) @ d(Wa) + d(gb) @ d(Wb) + d(add)
+        if with_seg:
+            ref = ref + (d(seg) / counts.unsqueeze(1))[mapping.cpu()]
+        assert_close(gx, ref, f"two sources (segment gradient: {with_seg})", 5e-6)
+    # the tickets are back at zero (the split reduction of tile_bwd_input_k shares them)
+    ws = L._SPLIT_WS[(torch.cuda.current_device(), int(torch.cuda.current_stream().cuda_stream))]
+    torch.cuda.synchronize()
+    assert int(ws[: 64 * 1024].view(torch.int32).abs().max()) == 0
+
+
+def test_stream_k_default_dispatch_takes_the_many_row_long_reduction_products(options):
+    """The default rule (CGV_OPT_STREAMK = 0): a single 2000 x 1800 -> 600 backward-input product runs on the stream-K
+    kernel, the 704-row products and every pair launch on the register tiles -- the same numbers either way (fp64)."""
+    L = cg._lib
+    gen = torch.Generator().manual_seed(5)
+    mk = lambda *s: torch.randn(*s, generator=gen).to(DEV)
+    for M, N, K in ((2000, 1800, 600), (704, 1800, 600)):
+        g, W = mk(M, N), mk(N, K) * 0.1
+        out = {}
+        for opt in (0, 1, 2):
+            options.set("streamk", opt)
+            gx = torch.empty(M, K, device=DEV)
+            L.call("cgv_tile_linear_bwd_input", L.ptr(g), L.ptr(W), L.ptr(gx), M, N, K, L.stream_ptr())
+            assert_close(gx, g.double().cpu() @ W.double().cpu(), f"{M} rows, streamk {opt}", 5e-6)
+            out[opt] = gx
+        same_as_sk = torch.equal(out[0], out[2])
+        assert same_as_sk == (M >= 1536), (M, same_as_sk)    # (the two kernels sum in different orders: bit-equality names the kernel)
