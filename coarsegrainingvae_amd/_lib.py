@@ -162,6 +162,9 @@ PROTOTYPES = {
     "cgv_grouped_wgrad_gathered_adam": (_i, [_p, _i, _i, _p, _p, _p, _p, _f, _f, _f, _f, _p, _p]),
     "cgv_wgrad_strip_max_rows": (_i, []),
     "cgv_wgrad_strip_plan": (_i, [_i, _i, _i, _i, _p]),
+    "cgv_wgrad_strip_split_max_rows": (_i, []),
+    "cgv_wgrad_strip_split_plane_bytes": (_sz, [_i, _i]),
+    "cgv_grouped_wgrad_strip_split": (_i, [_p, _i, _i, _i, _i, _p, _sz, _p]),
     "cgv_grouped_wgrad_strip": (_i, [_p, _i, _i, _i, _p]),
     "cgv_grouped_wgrad_strip_sumsq": (_i, [_p, _i, _i, _i, _p, _p, _p]),
     "cgv_grouped_wgrad_strip_adam": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _f, _f, _f, _f, _p, _p]),

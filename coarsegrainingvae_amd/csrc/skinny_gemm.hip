@@ -2017,6 +2017,202 @@ __global__ __launch_bounds__(256, 2) void wgrad_split128_k(const WgradProblem* _
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------------
+// STRIP layout on the bf16 matrix path with split operands -- the weight gradients of the bead-level layers of a LARGE bead
+// batch (33 .. 96 operand rows: dipeptide's 96 beads, the 64 beads of the 2000-atom graph, 8 ranks x 12 gathered rows).
+// gathered_wgrad_strip_k above is bound by the fp32 MFMA pipe there (96 rows: 11.7 GF in 99 us = 118 TF/s for 243 MB of
+// gradients that HBM takes in ~50 us); wgrad_split128_k re-derives the three bf16 terms of BOTH operand tiles in every
+// 128 x 128 block and ends up no faster (154 us on the same problems).  Here the split is done where it is cheap:
+//   * x (M x K, shared by all N / 64 strips of a problem) is split ONCE, by strip_xplanes_k, into its three bf16 planes,
+//     laid out as the LDS images the strips stage: [k tile of 64][plane][64 rows][MP] with m contiguous (MP = M rounded up to
+//     the MFMA's 32-deep step) and the tile's columns permuted (column 4 j + c at row 16 c + j: accumulator c of lane j is
+//     then column 4 j + c -- float4 stores).  3 x K x MP x 2 bytes per problem (345 KB at 96 x 600), L2 resident.
+//   * g = gy * act'(z) of a strip's 64 columns is staged once per block (fp32, as the fp32 strip kernel does), each lane
+//     takes its A fragments -- 8 consecutive m of one column -- out of it, splits them in registers and KEEPS them for
+//     the whole walk over the strip's K / 64 column tiles.
+// Per tile a block then copies 3 x 64 x MP bf16 to LDS (no arithmetic), reads 36 fragments per wave and issues 72
+// v_mfma_f32_16x16x32_bf16 (at 96 rows) for 64 x 64 outputs: bound by the gW stores.  Same six products per fp32 product as
+// wgrad_split128_k (dropped terms below 2^-23 of a product), same accuracy class; NOT bit-identical to the fp32 kernels.
+constexpr int SS_MAX_ROWS = 96;
+__host__ __device__ constexpr int ss_mp(int M) { return (M + 31) / 32 * 32; }
+__host__ __device__ constexpr size_t ss_plane_bytes(int M, int K) { return (size_t)((K + 63) / 64) * 3 * 64 * ss_mp(M) * 2; }
+
+// x planes of every problem of the table: grid (max k tiles, problems); pr.pad = offset of the problem's planes in ws, in
+// 256-byte units
+__global__ __launch_bounds__(256) void strip_xplanes_k(const WgradProblem* __restrict__ table, unsigned short* __restrict__ ws) {
+  const WgradProblem pr = table[blockIdx.y];
+  const int kt = blockIdx.x;
+  const int K = pr.K, M = pr.M;
+  if (kt * 64 >= K) return;
+  const int MP = ss_mp(M);
+  unsigned short* tile = ws + (size_t)pr.pad * 128 + (size_t)kt * 3 * 64 * MP;
+  const int kk = threadIdx.x & 63;                                   // column of the tile
+  const int rr = 16 * (kk & 3) + (kk >> 2);                          // its row in the image
+  const int col = kt * 64 + kk;
+  const bool cok = col < K;
+  for (int mg = threadIdx.x >> 6; mg < MP / 8; mg += 4) {            // groups of 8 consecutive m
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int m = 8 * mg + e;
+      v[e] = (cok && m < M) ? pr.x[wg_row(pr, m, K) + col] : 0.f;
+    }
+    unsigned h[4], md[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sp_split(v[2 * e], v[2 * e + 1], h[e], md[e], l[e]);
+    unsigned short* dst = tile + (size_t)rr * MP + 8 * mg;
+    *reinterpret_cast<uint4*>(dst) = make_uint4(h[0], h[1], h[2], h[3]);
+    *reinterpret_cast<uint4*>(dst + 64 * MP) = make_uint4(md[0], md[1], md[2], md[3]);
+    *reinterpret_cast<uint4*>(dst + 2 * 64 * MP) = make_uint4(l[0], l[1], l[2], l[3]);
+  }
+}
+
+template <int KS>   // 32-deep steps of the reduction: M <= 32 KS
+__global__ __launch_bounds__(256) void strip_split_k(const WgradProblem* __restrict__ table, int n_problems,
+                                                     const unsigned short* __restrict__ ws) {
+  constexpr int MP = 32 * KS;
+  constexpr int XLD = MP + 8;                                        // bf16 per image row in LDS (16 bytes of padding)
+  constexpr int XPLANE = 64 * XLD;
+  constexpr int G_FLOATS = MP * GW_GS, X_SHORTS = 3 * XPLANE;
+  constexpr int LDS_BYTES = (G_FLOATS * 4 > X_SHORTS * 2) ? G_FLOATS * 4 : X_SHORTS * 2;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+  float* gs = reinterpret_cast<float*>(smem);                        // [MP][GW_GS] fp32 g' (first phase)
+  unsigned short* xs = reinterpret_cast<unsigned short*>(smem);      // [3][64][XLD] bf16 x planes of a tile (afterwards)
+  const int lo = wg_find_problem(table, n_problems);
+  const WgradProblem pr = table[lo];
+  const int nb = blockIdx.x - pr.block_begin;
+  const int M = pr.M, N = pr.N, K = pr.K;
+  const int n0 = nb * 64;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, q = lane >> 4;
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  // ---- the strip's g columns: staged as fp32 (rows beyond M, columns beyond N: zeros), the bias sum, the A fragments
+  {
+    const int c4 = threadIdx.x & 15, rr = threadIdx.x >> 4;          // 16 float4 columns x 16 rows per pass
+    const bool gcol = n0 + 4 * c4 < N;
+    const int col = gcol ? n0 + 4 * c4 : 0;
+    const float* zsrc = pr.act ? pr.z : pr.gy;
+#pragma unroll
+    for (int p = 0; p < MP / 16; ++p) {
+      const int m = rr + 16 * p;
+      const bool ok = m < M && gcol;
+      const size_t at = wg_row(pr, m < M ? m : 0, N) + col;
+      float4 g4 = strip_ldg4(pr.gy + at);
+      if (pr.act) {
+        const float4 z4 = strip_ldg4(zsrc + at);
+        g4.x *= act_bwd(z4.x, pr.act); g4.y *= act_bwd(z4.y, pr.act); g4.z *= act_bwd(z4.z, pr.act); g4.w *= act_bwd(z4.w, pr.act);
+      }
+      *reinterpret_cast<float4*>(gs + m * GW_GS + 4 * c4) = make_float4(ok ? g4.x : 0.f, ok ? g4.y : 0.f, ok ? g4.z : 0.f, ok ? g4.w : 0.f);
+    }
+  }
+  __syncthreads();
+  if (pr.gb) {                                                       // bias gradient: column sums (four row classes, added in order)
+    const int cI = threadIdx.x & 63, cls = threadIdx.x >> 6;
+    float b = 0.f;
+    for (int m = cls; m < MP; m += 4) b += gs[m * GW_GS + cI];       // (rows beyond M are zeros)
+    __shared__ float bias_part[4][64];
+    bias_part[cls][cI] = b;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int n = n0 + (int)threadIdx.x;
+      const float t = (bias_part[0][cI] + bias_part[1][cI]) + (bias_part[2][cI] + bias_part[3][cI]);
+      if (n < N) pr.gb[n] = pr.accumulate ? pr.gb[n] + t : t;
+    }
+  }
+  sp_bf16x8 a[3][KS];                                                // lane (i, q): rows m = 32 ks + 8 q .. + 7 of column 16 wave + i
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    unsigned h[4], md[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float* src = gs + (32 * ks + 8 * q + 2 * e) * GW_GS + 16 * wave + i;
+      sp_split(src[0], src[GW_GS], h[e], md[e], l[e]);
+    }
+    a[0][ks] = __builtin_bit_cast(sp_bf16x8, make_uint4(h[0], h[1], h[2], h[3]));
+    a[1][ks] = __builtin_bit_cast(sp_bf16x8, make_uint4(md[0], md[1], md[2], md[3]));
+    a[2][ks] = __builtin_bit_cast(sp_bf16x8, make_uint4(l[0], l[1], l[2], l[3]));
+  }
+  // ---- walk over the strip's column tiles
+  const int tiles_k = (K + 63) / 64;
+  const unsigned short* planes = ws + (size_t)pr.pad * 128;
+  const int MPp = ss_mp(M);                                          // this problem's plane rows hold MPp <= MP values of m
+  constexpr int PIECES = 3 * 64 * MP / 8;                            // 16-byte pieces of a tile's LDS image
+  constexpr int PER = (PIECES + 255) / 256;
+  typedef unsigned su4 __attribute__((ext_vector_type(4)));
+  su4 xr[PER];
+  // piece pc of the image: row pc / (MP / 8) (= plane * 64 + image row), 16-byte piece pc % (MP / 8) of it; a problem with
+  // fewer rows than the table's largest has shorter plane rows: the pieces beyond them are zeros (their a fragments are
+  // zeros too, but what LDS holds there must not be a NaN pattern)
+  auto x_load = [&](int kt) {
+    const unsigned short* src = planes + (size_t)kt * 3 * 64 * MPp;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int pc = (int)threadIdx.x + 256 * u;
+      const int row = pc / (MP / 8), piece = pc - row * (MP / 8);
+      const bool ok = pc < PIECES && 8 * piece < MPp;
+      const su4 v = *reinterpret_cast<const __attribute__((address_space(1))) su4*>(
+          (strip_gptr)(const void*)(src + (ok ? row * MPp + 8 * piece : 0)));
+      xr[u] = ok ? v : su4{0u, 0u, 0u, 0u};
+    }
+    strip_pin();
+  };
+  auto x_store = [&]() {
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int pc = (int)threadIdx.x + 256 * u;
+      if (pc < PIECES) {
+        const int row = pc / (MP / 8), piece = pc - row * (MP / 8);
+        *reinterpret_cast<su4*>(xs + row * XLD + 8 * piece) = xr[u];
+      }
+    }
+  };
+  x_load(0);
+  const unsigned short* xb = xs + i * XLD + 8 * q;                    // + 16 c rows, + s planes, + 32 ks
+  for (int kt = 0; kt < tiles_k; ++kt) {
+    __syncthreads();                                                 // the fragments of g' / of the last tile are read
+    x_store();
+    __syncthreads();
+    x_load(kt + 1 < tiles_k ? kt + 1 : kt);                          // travels under this tile's MFMAs
+    f32x4v acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      sp_bf16x8 b[4][3];
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) b[c][s3] = *reinterpret_cast<const sp_bf16x8*>(xb + s3 * XPLANE + 16 * c * XLD + 32 * ks);
+      // small terms first (as wgrad_split128_k); the four column blocks' accumulators between two uses of one
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][ks], b[c][2], acc[c], 0, 0, 0);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2][ks], b[c][0], acc[c], 0, 0, 0);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][ks], b[c][1], acc[c], 0, 0, 0);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][ks], b[c][1], acc[c], 0, 0, 0);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][ks], b[c][0], acc[c], 0, 0, 0);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][ks], b[c][0], acc[c], 0, 0, 0);
+    }
+    const int kcol = kt * 64 + 4 * i;
+    if (kcol < K) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = n0 + 16 * wave + 4 * q + r;
+        if (row >= N) continue;
+        float* dst = pr.gW + (size_t)row * K + kcol;
+        float4 o = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+        if (pr.accumulate) { const float4 old = ldg4_global(dst); o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+        stg4_global(dst, o);
+      }
+    }
+  }
+}
+
 // Packs the operands of queued weight-gradient problems into one contiguous send buffer:
 //   dst_g[M,N] = gy * act'(z)      dst_x[M,K] = x        (float4 granularity; N % 4 == 0, K % 4 == 0)
 struct PackProblem {        // mirrors the 64-byte host record built in python (trainer.OperandExchange)
@@ -2697,6 +2893,33 @@ int cgv_grouped_wgrad_split(const void* table_dev, int n_problems, int total_blo
   hipLaunchKernelGGL(cgv::wgrad_split128_k, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
                      reinterpret_cast<const cgv::WgradProblem*>(table_dev), n_problems);
   return cgv::check_launch("cgv_grouped_wgrad_split");
+}
+
+/* Strip layout on the bf16 matrix path with split operands (strip_split_k): records as cgv_grouped_wgrad_strip's with at
+ * most cgv_wgrad_strip_split_max_rows() rows, `pad` = offset of the problem's x planes in ws in 256-byte units (each problem
+ * needs cgv_wgrad_strip_split_plane_bytes(M, K), rounded up to 256).  Two launches: the x planes of every problem, the strips. */
+int cgv_wgrad_strip_split_max_rows(void) { return cgv::SS_MAX_ROWS; }
+size_t cgv_wgrad_strip_split_plane_bytes(int M, int K) {
+  if (M < 1 || M > cgv::SS_MAX_ROWS || K < 4) return 0;
+  return (cgv::ss_plane_bytes(M, K) + 255) & ~(size_t)255;
+}
+int cgv_grouped_wgrad_strip_split(const void* table_dev, int n_problems, int total_blocks, int max_rows, int max_k, void* ws,
+                                  size_t ws_bytes, void* stream) {
+  CGV_REQUIRE(n_problems >= 0 && total_blocks >= 0, "bad size");
+  if (n_problems == 0 || total_blocks == 0) return 0;
+  CGV_REQUIRE(table_dev && ws && max_rows >= 1 && max_rows <= cgv::SS_MAX_ROWS && max_k >= 4, "bad argument");
+  CGV_REQUIRE((((uintptr_t)ws) & 255) == 0 && ws_bytes > 0, "workspace must be 256-byte aligned");
+  CGV_REQUIRE(n_problems <= 65535, "too many problems");
+  hipStream_t st = (hipStream_t)stream;
+  const cgv::WgradProblem* table = reinterpret_cast<const cgv::WgradProblem*>(table_dev);
+  hipLaunchKernelGGL(cgv::strip_xplanes_k, dim3((max_k + 63) / 64, n_problems), dim3(256), 0, st, table,
+                     reinterpret_cast<unsigned short*>(ws));
+  if (int rc = cgv::check_launch("cgv_grouped_wgrad_strip_split (planes)")) return rc;
+  const unsigned short* planes = reinterpret_cast<const unsigned short*>(ws);
+  if (max_rows <= 32) hipLaunchKernelGGL(cgv::strip_split_k<1>, dim3(total_blocks), dim3(256), 0, st, table, n_problems, planes);
+  else if (max_rows <= 64) hipLaunchKernelGGL(cgv::strip_split_k<2>, dim3(total_blocks), dim3(256), 0, st, table, n_problems, planes);
+  else hipLaunchKernelGGL(cgv::strip_split_k<3>, dim3(total_blocks), dim3(256), 0, st, table, n_problems, planes);
+  return cgv::check_launch("cgv_grouped_wgrad_strip_split");
 }
 
 int cgv_grouped_wgrad_gathered(const void* table_dev, int n_problems, int total_blocks, void* stream) {

@@ -264,6 +264,7 @@ class WeightGradQueue:
         lib = _lib.load()
         nb = C.c_int()
         buf, block_begin, rows = bytearray(), 0, 0
+        plane_at = max_k = 0
         for it in items:
             if seg is None:
                 gy, x, z, act, gW, gb, accumulate = it
@@ -281,11 +282,35 @@ class WeightGradQueue:
                 tail = (per_rank, total, 0)
             if lib.cgv_wgrad_strip_plan(M, N, K, per_rank, C.byref(nb)) != 0:
                 raise RuntimeError(lib.cgv_last_error_string().decode())
-            buf += self.RECORD.pack(*rec, block_begin, 0, 0, *tail)
+            # last field: where this problem's x planes start in the split-operand workspace, in 256-byte units
+            # (cgv_grouped_wgrad_strip_split; the fp32 strip launches ignore it)
+            buf += self.RECORD.pack(*rec, block_begin, 0, 0, tail[0], tail[1], plane_at // 256)
+            plane_at += int(lib.cgv_wgrad_strip_split_plane_bytes(M, K)) if M <= self.STRIP_SPLIT_MAX_ROWS else 0
             block_begin += nb.value
             rows = max(rows, M)
+            max_k = max(max_k, K)
         dev = items[0][0].device if seg is None else items[0][8].device
+        self._strip_plan = (plane_at, max_k)
         return self.upload(bytes(buf), dev), block_begin, rows
+
+    STRIP_SPLIT_MAX_ROWS = 96
+    _strip_ws = {}
+
+    def strip_launch(self, table, n_problems, blocks, rows, tag):
+        """The strip-layout store launch for the table ``strip_table`` has just built: on the bf16 matrix path with split
+        operands (x split once per problem, g once per strip: csrc/skinny_gemm.hip strip_split_k) for up to 96 operand rows,
+        else on the fp32 MFMA strips."""
+        from .options import HOST
+        plane_bytes, max_k = self._strip_plan
+        if HOST["strip_split"] and rows <= self.STRIP_SPLIT_MAX_ROWS and plane_bytes > 0:
+            dev = table.device
+            ws = self._strip_ws.get(dev)
+            if ws is None or ws.numel() < plane_bytes:
+                ws = self._strip_ws[dev] = torch.empty(max(plane_bytes, 32 << 20), dtype=torch.uint8, device=dev)
+            _lib.call("cgv_grouped_wgrad_strip_split", _lib.ptr(table), n_problems, blocks, rows, max_k, _lib.ptr(ws), ws.numel(),
+                      _lib.stream_ptr(), tag=tag)
+        else:
+            _lib.call("cgv_grouped_wgrad_strip", _lib.ptr(table), n_problems, blocks, rows, _lib.stream_ptr(), tag=tag)
 
     def launch(self, items):
         """Grouped launches for ``items`` (tuples as queued by ``enqueue``), writing into their gW / gb targets: ONE for
@@ -312,8 +337,7 @@ class WeightGradQueue:
                       tag="grouped_wgrad")
         if strips:
             table, block_begin, rows = self.strip_table(strips)
-            _lib.call("cgv_grouped_wgrad_strip", _lib.ptr(table), len(strips), block_begin, rows, _lib.stream_ptr(),
-                      tag="grouped_wgrad_strip")
+            self.strip_launch(table, len(strips), block_begin, rows, "grouped_wgrad_strip")
         if large:
             buf, block_begin = bytearray(), 0
             from .options import HOST

@@ -369,8 +369,7 @@ class OperandExchange:
         strips = [m for m in problems if self.queue.strip_rows(self.world * m[0], m[1], m[2])]
         if strips:
             table, blocks, rows = self.queue.strip_table(strips, seg=self.world)
-            _lib.call("cgv_grouped_wgrad_strip", _lib.ptr(table), len(strips), blocks, rows, _lib.stream_ptr(),
-                      tag="gathered_wgrad_strip")
+            self.queue.strip_launch(table, len(strips), blocks, rows, "gathered_wgrad_strip")
             ids = {id(m) for m in strips}
             problems = [m for m in problems if id(m) not in ids]
             if not problems:

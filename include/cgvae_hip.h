@@ -707,6 +707,15 @@ int cgv_grouped_wgrad_gathered_adam(const void* table_dev, int n_problems, int t
 int cgv_wgrad_strip_max_rows(void);
 int cgv_wgrad_strip_plan(int M, int N, int K, int seg_rows, int* n_blocks /*[host]*/);
 int cgv_grouped_wgrad_strip(const void* table_dev, int n_problems, int total_blocks, int max_rows, void* stream);
+/* The strip layout on the bf16 matrix path with split operands (fp32-class accuracy, see cgv_grouped_wgrad_split): for
+ * records of at most cgv_wgrad_strip_split_max_rows() (96) rows.  x is split ONCE per problem into three bf16 planes in `ws`
+ * (record field `pad` = the problem's offset in ws in 256-byte units; cgv_wgrad_strip_split_plane_bytes(M, K) bytes each),
+ * g = gy * act'(z) once per strip in registers; the strips then walk their column tiles without arithmetic on the operands.
+ * max_rows / max_k: the largest M / K of the table.  modules.py:103-114 (autograd of Dense: gW = g^T x, gb = sum_m g). */
+int cgv_wgrad_strip_split_max_rows(void);
+size_t cgv_wgrad_strip_split_plane_bytes(int M, int K);
+int cgv_grouped_wgrad_strip_split(const void* table_dev, int n_problems, int total_blocks, int max_rows, int max_k, void* ws,
+                                  size_t ws_bytes, void* stream);
 int cgv_grouped_wgrad_strip_sumsq(const void* table_dev, int n_problems, int total_blocks, int max_rows, double* partial,
                                   double* sumsq, void* stream);
 int cgv_grouped_wgrad_strip_adam(const void* table_dev, int n_problems, int total_blocks, int max_rows, const float* arena_g,

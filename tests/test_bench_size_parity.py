@@ -216,14 +216,22 @@ def test_sampler_call_pattern_prior_then_decoder_on_a_trained_model(workload, F)
 
 def test_largest_gradients_of_the_chignolin_bench_step_element_by_element():
     """The chignolin bench configuration's first step (F = 600, 2 frames, enc 2 / dec 9): the five largest live gradient
-    tensors (and the five with the largest peak entries) against the oracle ELEMENT-WISE,
-    ``|d| <= 1e-4 * max(|ref|, 1 % of the tensor's peak)`` -- the norm-wise bound of the full-size tests lets an entry two
-    decades below the peak be off by 100 % of itself, this one holds it to 1e-4 of its own size."""
+    tensors and the five with the largest peak entries, ELEMENT-WISE with the floor at 1 % of the tensor's peak --
+    ``|d| / max(|ref|, 0.01 max|ref|)``: the norm-wise bound of the full-size tests lets an entry two decades below the peak be
+    off by 100 % of itself.  At that depth fp32 itself is the limit: the reference's own arithmetic (the fp32 oracle) differs
+    from the same statements in fp64 by ~1e-4 on the decoder's first layers (nine layers of backward behind them).  So the
+    yardstick is the fp64 oracle: the device's gradients are held to 1e-4 of it element-wise, or -- where fp32 in the
+    reference's own order of operations does not reach that -- to 1.5 x what the fp32 oracle itself loses against fp64."""
     from test_full_size_parity import _setup, OracleTraining
     F = 600
     w, batch, cpu_batch, model, hp, P = _setup("chignolin", 2, F)
     oracle = OracleTraining(cpu_batch, P, hp, w, 1e-4)
     eps = torch.randn(cpu_batch["CG_nxyz"].shape[0], F, generator=torch.Generator().manual_seed(9))
+    # the same statements in fp64 (same parameters, same noise)
+    P64 = {k: (v.detach().double().requires_grad_(True) if v.dtype == torch.float32 else v.detach().clone()) for k, v in P.items()}
+    b64 = {k: (v.double() if v.dtype == torch.float32 else v) for k, v in cpu_batch.items()}
+    out64 = O.model_forward(b64, P64, hp, eps=eps.double())
+    O.loss_terms(out64, b64, w["beta"], w["gamma"])[0].backward()
     ref = oracle.step(eps)
     tr = Trainer(model, lr=1e-4, beta=w["beta"], gamma=w["gamma"])
     tr.step(batch, eps=eps.to(DEV))                      # first step: every gradient materialised
@@ -231,10 +239,17 @@ def test_largest_gradients_of_the_chignolin_bench_step_element_by_element():
     live = {k: g for k, g in ref["grads"].items() if float(g.abs().max()) > 0.0}
     by_size = sorted(live, key=lambda k: -live[k].numel())[:5]
     by_peak = sorted(live, key=lambda k: -float(live[k].abs().max()))[:5]
-    worst = 0.0
+    rows = []
     for name in dict.fromkeys(by_size + by_peak):
-        g0 = live[name]
-        e = _elementwise(named[name].grad, g0, 1e-2 * float(g0.abs().max()))
-        worst = max(worst, e)
-        assert e <= REL, f"grad {name} ({g0.numel()} entries): element-wise error {e:.3e}"
-    print(f"\n[chignolin step 1, {len(set(by_size + by_peak))} largest gradients] worst element-wise error {worst:.3e}")
+        g64 = P64[name].grad
+        floor = 1e-2 * float(g64.abs().max())
+        e_dev = _elementwise(named[name].grad, g64, floor)
+        e_ref = _elementwise(live[name], g64, floor)
+        rows.append((name, live[name].numel(), e_dev, e_ref))
+        assert e_dev <= max(REL, 1.5 * e_ref), (f"grad {name} ({live[name].numel()} entries): element-wise error {e_dev:.3e} against the fp64 "
+                                                f"oracle; the fp32 oracle itself: {e_ref:.3e}")
+        # ... and norm-wise the device is as close to fp64 as the reference's fp32 (both ~1e-6)
+        assert _rel(named[name].grad, g64) <= REL
+    print("\n[chignolin step 1: element-wise error against the fp64 oracle, floor 1 % of the peak]")
+    for name, n, e_dev, e_ref in rows:
+        print(f"  {name:75s} {n:9d} entries: device {e_dev:.2e}   fp32 oracle {e_ref:.2e}")

@@ -3055,3 +3055,48 @@ def test_stream_k_default_dispatch_takes_the_many_row_long_reduction_products(op
             out[opt] = gx
         same_as_sk = torch.equal(out[0], out[2])
         assert same_as_sk == (M >= 1536), (M, same_as_sk)    # (the two kernels sum in different orders: bit-equality names the kernel)
+
+
+@pytest.mark.parametrize("M,N,K,act", [(96, 600, 600, 1), (64, 5400, 600, 1), (33, 132, 260, 0), (96, 68, 1204, 2), (48, 600, 36, 0), (80, 1800, 600, 1)])
+def test_strip_layout_with_split_operands_has_fp32_accuracy(M, N, K, act, options):
+    """Weight gradients of layers with 33 .. 96 operand rows (the bead-level Dense layers of a large bead batch: 96 beads of the
+    dipeptide batch, 64 of the 2000-atom graph; autograd of modules.py:103-114) on the bf16 matrix path with split operands in
+    the STRIP layout (csrc/skinny_gemm.hip strip_xplanes_k + strip_split_k: x split once per problem, g once per strip)
+    against fp64 and against the fp32 MFMA strips: same error class.  Operands span 12 orders of magnitude; ragged row /
+    column counts; write and accumulate; several problems of different shapes in one table."""
+    from coarsegrainingvae_amd.primitives import WeightGradQueue
+    gen = torch.Generator().manual_seed(M + N + K)
+    scale_rows = torch.logspace(-9, 0, M).unsqueeze(1)
+    gy = (torch.randn(M, N, generator=gen) * scale_rows).to(DEV)
+    x = (torch.randn(M, K, generator=gen) * torch.logspace(-3, 2, K).unsqueeze(0)).to(DEV)
+    z = torch.randn(M, N, generator=gen).to(DEV) if act else None
+    g64 = gy.double().cpu()
+    if act == 1:
+        s = torch.sigmoid(z.double().cpu())
+        g64 = g64 * (s * (1 + z.double().cpu() * (1 - s)))
+    elif act == 2:
+        g64 = g64 * (1 - torch.tanh(z.double().cpu()) ** 2)
+    ref_W, ref_b = g64.t() @ x.double().cpu(), g64.sum(0)
+    # a second, smaller problem in the same table (other shape, no bias)
+    gy2, x2 = torch.randn(40, 64, generator=gen).to(DEV), torch.randn(40, 132, generator=gen).to(DEV)
+    ref2 = gy2.double().cpu().t() @ x2.double().cpu()
+    q = WeightGradQueue()
+    errs = {}
+    for split in (0, 1):
+        options.set("strip_split", split)
+        gW, gb = torch.full((N, K), float("nan"), device=DEV), torch.full((N,), float("nan"), device=DEV)
+        gW2 = torch.full((64, 132), float("nan"), device=DEV)
+        q.launch([(gy, x, z, act, gW, gb, False), (gy2, x2, None, 0, gW2, None, False)])
+        q.launch([(gy, x, z, act, gW, gb, True), (gy2, x2, None, 0, gW2, None, True)])   # accumulate: twice the gradient
+        eW = ((gW.double().cpu() - 2 * ref_W).abs().amax(0) / (2 * ref_W).abs().amax(0)).max()
+        eb = (gb.double().cpu() - 2 * ref_b).abs().max() / (2 * ref_b).abs().max()
+        e2 = (gW2.double().cpu() - 2 * ref2).abs().max() / (2 * ref2).abs().max()
+        errs[split] = (float(eW), float(eb), float(e2))
+    assert max(errs[1]) < 2e-6, errs
+    assert errs[1][0] < 4 * errs[0][0] + 1e-7 and errs[1][2] < 4 * errs[0][2] + 1e-7, f"split strips are not in the fp32 error class: {errs}"
+    # deterministic
+    options.set("strip_split", 1)
+    a, b = torch.empty(N, K, device=DEV), torch.empty(N, K, device=DEV)
+    q.launch([(gy, x, z, act, a, None, False)])
+    q.launch([(gy, x, z, act, b, None, False)])
+    assert torch.equal(a, b)

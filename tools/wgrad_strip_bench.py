@@ -18,7 +18,7 @@ for rows, N, K, count in problems:
                       torch.randn(rows, N, device=dev, generator=g), 1, torch.empty(N, K, device=dev), torch.empty(N, device=dev)))
 
 
-def table(strip, targets):
+def table(strip, targets, tile=64):
     tk, nb = C.c_int(), C.c_int()
     buf, begin = bytearray(), 0
     for (gy, x, z, act, _gW, _gb), (gW, gb) in zip(items, targets):
@@ -27,7 +27,7 @@ def table(strip, targets):
         if strip:
             assert lib.cgv_wgrad_strip_plan(Mi, N, K, 0, C.byref(nb)) == 0
         else:
-            assert lib.cgv_wgrad_gathered_plan_tile(Mi, N, K, 0, 64, C.byref(tk), C.byref(nb)) == 0
+            assert lib.cgv_wgrad_gathered_plan_tile(Mi, N, K, 0, tile, C.byref(tk), C.byref(nb)) == 0
         buf += q.RECORD.pack(gy.data_ptr(), x.data_ptr(), z.data_ptr(), gW.data_ptr(), gb.data_ptr(), Mi, N, K, 0, act, begin,
                              tk.value, 0, 0, 0, 0)
         begin += nb.value
@@ -55,6 +55,21 @@ us = timed(lambda: _lib.call("cgv_grouped_wgrad_gathered_tile", _lib.ptr(t_tile)
 print(f"store  tile : {us:7.1f} us  ({b_tile} blocks)")
 us = timed(lambda: _lib.call("cgv_grouped_wgrad_strip", _lib.ptr(t_strip), n, b_strip, M, _lib.stream_ptr()))
 print(f"store  strip: {us:7.1f} us  ({b_strip} blocks)")
+if M <= 96:
+    out["ssplit"] = [(torch.empty_like(it[4]), torch.empty_like(it[5])) for it in items]
+    qitems = [(it[0], it[1], it[2], it[3], o[0], o[1], False) for it, o in zip(items, out["ssplit"])]
+    t_ss, b_ss, rows_ss = q.strip_table(qitems)
+    us = timed(lambda: q.strip_launch(t_ss, n, b_ss, rows_ss, None))
+    print(f"store  strip, split-bf16 (x planes once, g once per strip): {us:7.1f} us  ({b_ss} blocks)")
+out["split"] = [(torch.empty_like(it[4]), torch.empty_like(it[5])) for it in items]
+t_split, b_split = table(False, out["split"], tile=128)
+us = timed(lambda: _lib.call("cgv_grouped_wgrad_split", _lib.ptr(t_split), n, b_split, _lib.stream_ptr()))
+print(f"store  split-bf16 128 x 128 tiles: {us:7.1f} us  ({b_split} blocks)")
+ref = [(it[0].double() * (lambda s_: s_ * (1 + it[2].double() * (1 - s_)))(torch.sigmoid(it[2].double()))).t() @ it[1].double() for it in items[:3]]
+refb = [(it[0].double() * (lambda s_: s_ * (1 + it[2].double() * (1 - s_)))(torch.sigmoid(it[2].double()))).sum(0) for it in items[:3]]
+for k in [k for k in ("strip", "split", "ssplit") if k in out]:
+    print(f"  {k}: max error / max |gW| against fp64:", max(float((o[0].double() - r).abs().max() / r.abs().max()) for o, r in zip(out[k], ref)),
+          " gb:", max(float((o[1].double() - r).abs().max() / r.abs().max()) for o, r in zip(out[k], refb)))
 print("bit-identical gW:", all(torch.equal(a[0], b[0]) for a, b in zip(out["tile"], out["strip"])),
       " gb:", all(torch.equal(a[1], b[1]) for a, b in zip(out["tile"], out["strip"])))
 gy, x, z, act, _, _ = items[-1]
