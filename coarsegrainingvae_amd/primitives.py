@@ -294,6 +294,7 @@ class WeightGradQueue:
         return self.upload(bytes(buf), dev), block_begin, rows
 
     STRIP_SPLIT_MAX_ROWS = 96
+    STRIP_SPLIT_MIN_ROWS = 64
     _strip_ws = {}
 
     def strip_launch(self, table, n_problems, blocks, rows, tag):
@@ -302,7 +303,9 @@ class WeightGradQueue:
         else on the fp32 MFMA strips."""
         from .options import HOST
         plane_bytes, max_k = self._strip_plan
-        if HOST["strip_split"] and rows <= self.STRIP_SPLIT_MAX_ROWS and plane_bytes > 0:
+        # (from 64 rows on: 64 rows 92 against 107 us, 96 rows 126 against 156 on the bead-level problems of a step,
+        # tools/wgrad_strip_bench.py; at 36 / 48 rows the fp32 strips are level or ahead -- 8-rank stand-in, tools/dp_cost_probe.py)
+        if (HOST["strip_split"] and self.STRIP_SPLIT_MIN_ROWS <= rows <= self.STRIP_SPLIT_MAX_ROWS and plane_bytes > 0) or HOST["strip_split"] == 2:
             dev = table.device
             ws = self._strip_ws.get(dev)
             if ws is None or ws.numel() < plane_bytes:
