@@ -17,7 +17,7 @@ for w in $workloads; do
   bash tools/step_sequence.sh --workload $w --no-extras --no-parity > /dev/null 2>&1
   cp gpurun_out/step_sequence.txt gpurun_out/${tag}_step_sequence_$w.txt
 done
-bash tools/phase_clock.sh > gpurun_out/${tag}_decoder_phase_clock.txt 2>&1   # (needs libcgvae_hip_b.so = tools/build_variant.sh decoder_layer "-DCGV_DL_CLOCK=1")
+[ -f coarsegrainingvae_amd/libcgvae_hip_b.so ] && bash tools/phase_clock.sh > gpurun_out/${tag}_decoder_phase_clock.txt 2>&1   # (needs libcgvae_hip_b.so = tools/build_variant.sh decoder_layer "-DCGV_DL_CLOCK=1")
 # PMC: counters in their own runs (eager launches so that kernels appear as dispatches), every workload
 for w in $workloads; do
   for c in FETCH_SIZE WRITE_SIZE; do
@@ -32,5 +32,7 @@ if [ -x tools/probes/fetch_calib ]; then
     { grep "known bytes" /tmp/fc_$c.log; python tools/pmc_summary.py /tmp/fc_$c/p_counter_collection.csv; } >> gpurun_out/${tag}_fetch_calibration.txt
   done
 fi
-python tools/dp_cost_probe.py > gpurun_out/${tag}_dp_cost_probe.txt 2>&1
+python tools/dp_cost_probe.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_dp_cost_probe.txt
+python tools/probes/sk_ab.py 332 704 2000 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_gemm_shapes.txt
+for M in 64 96; do echo "== $M operand rows"; python tools/wgrad_strip_bench.py $M 2>&1 | grep -v amdgpu.ids | head -9; done > gpurun_out/${tag}_wgrad_strip_bench.txt
 ls -la gpurun_out | grep ${tag}_ | wc -l
