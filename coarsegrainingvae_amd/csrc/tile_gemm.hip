@@ -525,6 +525,11 @@ struct OutAct { const float* z; int act; const float* z2; int act2; };      // z
 // and the block that draws the tile's LAST ticket adds the n partial tiles in share order and runs the store epilogue: the
 // result does not depend on who arrives last.  Tickets reset themselves; part / ticket: cgv_tile_bwd_input_split.
 struct SplitN { float* part; unsigned* ticket; int n; };
+// The output is g_stack of UpdateBlock's s_dense.0 (conv.py:600-603: stack = [s | ||Vv||]) and goes straight through the backward
+// of the norm / stack step instead of to memory (update.hip: update_norm_stack_bwd, one launch less per layer):
+//   columns k < F:   g_s[m, k]  = o + g_res[m, k]                        (g_res: the residual's gradient or NULL)
+//   columns F + f:   gVv[3 m + xyz, f] (+)= o / stack[m, F + f] * Vv[3 m + xyz, f]      (rows of `ld` floats)
+struct NormStackOut { const float* stack; const float* Vv; const float* g_res; float* g_s; float* gVv; int F; int ld; int accumulate; };
 struct BcastAdd {
   const float* src;          // [n_seg, K] or NULL
   const int64_t* row2seg;    // [M] segment of every row (the CG mapping)
@@ -544,7 +549,8 @@ __global__ __launch_bounds__(64 * WAVES) void tile_bwd_input_k(const float* __re
                                                         BwdSecond s2 = BwdSecond{nullptr, nullptr, nullptr, nullptr, nullptr, 0},
                                                         BwdSource more = BwdSource{nullptr, nullptr, nullptr, 0},
                                                         OutAct oa = OutAct{nullptr, 0, nullptr, 0},
-                                                        SplitN sp = SplitN{nullptr, nullptr, 1}) {
+                                                        SplitN sp = SplitN{nullptr, nullptr, 1},
+                                                        NormStackOut ns = NormStackOut{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0}) {
   if (blockIdx.z) { g = s2.g; W = s2.W; gx = s2.gx; z = s2.z; add = s2.add; act = s2.act; bc.src = nullptr; oa.z = oa.z2; oa.act = oa.act2; }
   __shared__ float red[WAVES][MB * 4][4][64];        // [wave][mb*4 + s][reg][lane]
   const int lane = threadIdx.x & 63;
@@ -748,6 +754,28 @@ __global__ __launch_bounds__(64 * WAVES) void tile_bwd_input_k(const float* __re
     if (oa.z) {                                      // gradient of the previous layer's pre-activation (see OutAct)
       const float4 z4 = pre_z[u];
       o[0] *= act_bwd(z4.x, oa.act); o[1] *= act_bwd(z4.y, oa.act); o[2] *= act_bwd(z4.z, oa.act); o[3] *= act_bwd(z4.w, oa.act);
+    }
+    if (ns.stack) {                                  // UpdateBlock: through the norm / stack backward instead of to memory
+      if (kcol < ns.F) {
+        if (ns.g_res) {
+          const float4 r4 = *reinterpret_cast<const float4*>(ns.g_res + (size_t)m * ns.F + kcol);
+          o[0] += r4.x; o[1] += r4.y; o[2] += r4.z; o[3] += r4.w;
+        }
+        *reinterpret_cast<float4*>(ns.g_s + (size_t)m * ns.F + kcol) = make_float4(o[0], o[1], o[2], o[3]);
+      } else {
+        const int f = kcol - ns.F;
+        const float4 nr = *reinterpret_cast<const float4*>(ns.stack + (size_t)m * 2 * ns.F + kcol);
+        const float t0 = o[0] / nr.x, t1 = o[1] / nr.y, t2 = o[2] / nr.z, t3 = o[3] / nr.w;
+#pragma unroll
+        for (int xyz = 0; xyz < 3; ++xyz) {
+          const size_t at = (size_t)(3 * m + xyz) * ns.ld + f;
+          const float4 v4 = *reinterpret_cast<const float4*>(ns.Vv + at);
+          float4 w = make_float4(t0 * v4.x, t1 * v4.y, t2 * v4.z, t3 * v4.w);
+          if (ns.accumulate) { const float4 old = *reinterpret_cast<const float4*>(ns.gVv + at); w.x += old.x; w.y += old.y; w.z += old.z; w.w += old.w; }
+          *reinterpret_cast<float4*>(ns.gVv + at) = w;
+        }
+      }
+      continue;
     }
     *reinterpret_cast<float4*>(gx + (size_t)m * K + kcol) = make_float4(o[0], o[1], o[2], o[3]);
   }
@@ -971,13 +999,14 @@ static int tile_bwd_input_launch(const float* g, const float* z, int act, const 
                                  cgv::BcastAdd bc = cgv::BcastAdd{nullptr, nullptr, nullptr, 0},
                                  const cgv::BwdSecond* second = nullptr,
                                  cgv::BwdSource more = cgv::BwdSource{nullptr, nullptr, nullptr, 0},
-                                 cgv::OutAct oa = cgv::OutAct{nullptr, 0, nullptr, 0}) {
+                                 cgv::OutAct oa = cgv::OutAct{nullptr, 0, nullptr, 0},
+                                 cgv::NormStackOut ns = cgv::NormStackOut{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0}) {
   hipStream_t st = (hipStream_t)stream;
   const cgv::BwdSecond s2 = second ? *second : cgv::BwdSecond{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
   const unsigned np = second ? 2u : 1u;
   // no activation in the operand loads (act_downstream chains carry none), operands 16-byte aligned: the stream-K kernel
   if (const int bpc = cgv::sk_wanted(M, K, N, (int)np, stream);
-      bpc != 0 && act == 0 && (!more.g || more.act == 0) && (!second || s2.act == 0) &&
+      bpc != 0 && !ns.stack && act == 0 && (!more.g || more.act == 0) && (!second || s2.act == 0) &&
       cgv::sk_aligned({g, W, gx, add, bc.src, more.g, more.W, oa.z, oa.z2, s2.g, s2.W, s2.gx, s2.add})) {
     cgv::SkArgs a{};
     a.np = (int)np; a.M = M; a.N = K;
@@ -1000,14 +1029,14 @@ static int tile_bwd_input_launch(const float* g, const float* z, int act, const 
   if (const int o = cgv::option(CGV_OPT_BWD_INPUT_WAVES); o > 0 && o != 32) waves = o;          // experiments only
   else if (blocks16 < 128 && N >= 1024) waves = 16;
   if (cgv::option(CGV_OPT_BWD_INPUT_WAVES) == 32)          /* A/B: 32-row tiles, 8 waves */
-    hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 8>), dim3(kt, (M + 31) / 32, np), dim3(512), 0, st, g, W, gx, M, N, K, z, act, add, bc, s2, more, oa);
+    hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 8>), dim3(kt, (M + 31) / 32, np), dim3(512), 0, st, g, W, gx, M, N, K, z, act, add, bc, s2, more, oa, cgv::SplitN{nullptr, nullptr, 1}, ns);
   else if (blocks32 >= 200 && blocks32 < 512 && waves == 8)
     // 200 .. 511 32-row tiles (704 rows x 600 / 1200 columns): still 32-row tiles, with the reduction split over 8 waves --
     // half the weight re-reads of the 16-row tiles (704 x 1800 x 600: 22.9 against 25.0 us, 704 x 5400: 54.6 / 64.1;
     // at 332 rows the 16-row tiles win, 14.5 against 22.1 us: tools/gemm_shapes.py)
-    hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 8>), dim3(kt, (M + 31) / 32, np), dim3(512), 0, st, g, W, gx, M, N, K, z, act, add, bc, s2, more, oa);
+    hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 8>), dim3(kt, (M + 31) / 32, np), dim3(512), 0, st, g, W, gx, M, N, K, z, act, add, bc, s2, more, oa, cgv::SplitN{nullptr, nullptr, 1}, ns);
   else if (blocks32 >= 512)               // enough 32-row tiles to fill the chip: halve the weight re-reads
-    hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 4>), dim3(kt, (M + 31) / 32, np), dim3(256), 0, st, g, W, gx, M, N, K, z, act, add, bc, s2, more, oa);
+    hipLaunchKernelGGL((cgv::tile_bwd_input_k<2, 4>), dim3(kt, (M + 31) / 32, np), dim3(256), 0, st, g, W, gx, M, N, K, z, act, add, bc, s2, more, oa, cgv::SplitN{nullptr, nullptr, 1}, ns);
   else if (waves == 16) {                 // few output tiles and a long reduction (96 bead rows x 5400 columns: 60 blocks):
     // 16 waves per block split it -- 60 blocks of 8 waves left three quarters of the chip idle (17.8 us per call) -- and,
     // with a registered workspace, 2 - 4 blocks per tile split it further (SplitN)
@@ -1027,10 +1056,10 @@ static int tile_bwd_input_launch(const float* g, const float* z, int act, const 
       }
     }
     hipLaunchKernelGGL((cgv::tile_bwd_input_k<1, 16>), dim3(kt, ((M + 15) / 16) * sp.n, np), dim3(1024), 0, st, g, W, gx, M, N, K, z, act,
-                       add, bc, s2, more, oa, sp);
+                       add, bc, s2, more, oa, sp, ns);
   }
   else
-    hipLaunchKernelGGL((cgv::tile_bwd_input_k<1, 8>), dim3(kt, (M + 15) / 16, np), dim3(512), 0, st, g, W, gx, M, N, K, z, act, add, bc, s2, more, oa);
+    hipLaunchKernelGGL((cgv::tile_bwd_input_k<1, 8>), dim3(kt, (M + 15) / 16, np), dim3(512), 0, st, g, W, gx, M, N, K, z, act, add, bc, s2, more, oa, cgv::SplitN{nullptr, nullptr, 1}, ns);
   return cgv::check_launch(what);
 }
 
@@ -1133,6 +1162,24 @@ int cgv_tile_linear_bwd_input_out(const float* gy, const float* z, const float* 
   return tile_bwd_input_launch(gy, act ? z : nullptr, act, W, gx, M, N, K, stream, "cgv_tile_linear_bwd_input_out", add,
                                cgv::BcastAdd{nullptr, nullptr, nullptr, 0}, nullptr, cgv::BwdSource{nullptr, nullptr, nullptr, 0},
                                cgv::OutAct{z_out, act_out, nullptr, 0});
+}
+
+/* UpdateBlock's backward through s_dense.0 AND the norm / stack step in one launch (conv.py:600-603): the product
+ * g_stack = (gy * act'(z)) W (M beads, K = 2 F columns) is not stored; its columns k < F become g_s = g_stack + g_res (g_res
+ * may be NULL), its columns F + f go through d ||Vv|| / d Vv into gVv[3 m + xyz, f] (rows of ld floats; accumulate != 0 adds
+ * to what update_gate_bwd left there).  stack [M, 2 F] as cgv_update_norm_stack_fwd wrote it, Vv rows of ld floats. */
+int cgv_tile_linear_bwd_input_norm_stack(const float* gy, const float* z, const float* W, int M, int N, int K, int act,
+                                         const float* stack, const float* Vv, const float* g_res, float* g_s, float* gVv, int ld,
+                                         int accumulate, void* stream) {
+  CGV_REQUIRE(gy && W && stack && Vv && g_s && gVv, "null pointer");
+  CGV_REQUIRE(act == 0 || (act >= 1 && act <= cgv::CGV_ACT_MAX && z), "act != 0 needs the saved pre-activation z");
+  CGV_REQUIRE(cgv_tile_supported(M, N, K) && K % 8 == 0 && ld >= K / 2 && ld % 4 == 0, "unsupported shape (need K = 2 F, F % 4 == 0, ld % 4 == 0)");
+  CGV_REQUIRE(((((uintptr_t)gy | (uintptr_t)z | (uintptr_t)W | (uintptr_t)stack | (uintptr_t)Vv | (uintptr_t)g_res | (uintptr_t)g_s |
+                 (uintptr_t)gVv)) & 15) == 0, "operands must be 16-byte aligned");
+  return tile_bwd_input_launch(gy, act ? z : nullptr, act, W, g_s /* never written as gx */, M, N, K, stream,
+                               "cgv_tile_linear_bwd_input_norm_stack", nullptr, cgv::BcastAdd{nullptr, nullptr, nullptr, 0}, nullptr,
+                               cgv::BwdSource{nullptr, nullptr, nullptr, 0}, cgv::OutAct{nullptr, 0, nullptr, 0},
+                               cgv::NormStackOut{stack, Vv, g_res, g_s, gVv, K / 2, ld, accumulate});
 }
 
 /* cgv_tile_pair_linear_bwd_input with the outputs multiplied by act_out_*'(z_out_*) (either may be NULL / 0: that output

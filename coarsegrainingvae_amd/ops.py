@@ -807,9 +807,17 @@ class _UpdateBlockFused(torch.autograd.Function):
         g_a0, g_stack, g_s, g_vt, g_v = new(n, F), new(n, 2 * F), new(n, F), new(3 * n, F), new(n, F, 3)
         # (tile kernels: the second layer's product leaves g_a0 * Swish'(z0), the first layer's launches run without an activation)
         act0 = 0 if _dense_bwd_input(ga, None, W1d, g_a0, n, 3 * F, F, 0, st, z0, 1) else 1
-        _dense_bwd_input(g_a0, z0 if act0 else None, W0d, g_stack, n, F, 2 * F, act0, st)
-        _lib.call("cgv_update_norm_stack_bwd", _lib.ptr(g_stack), Vv_ptr, _lib.ptr(stack),
-                  _lib.ptr(g_ds) if ctx.residual else None, _lib.ptr(g_s), gVv_ptr, n, F, 2 * F, 1, st)
+        lib = _lib.load()
+        if (options.HOST["update_fused_bwd"] and n > 32 and lib.cgv_tile_supported(n, F, 2 * F) and F % 4 == 0
+                and (n > 64 or _lib.split_workspace_ready()) and all(t.data_ptr() % 16 == 0 for t in (g_a0, W0d, stack, UV, gUV, g_s))
+                and (not ctx.residual or g_ds is None or g_ds.data_ptr() % 16 == 0)):
+            # more than 32 bead rows (the tile kernel's shapes): the norm / stack backward in the store epilogue of the product
+            _lib.call("cgv_tile_linear_bwd_input_norm_stack", _lib.ptr(g_a0), _lib.ptr(z0) if act0 else None, _lib.ptr(W0d), n, F, 2 * F,
+                      act0, _lib.ptr(stack), Vv_ptr, _lib.ptr(g_ds) if ctx.residual else None, _lib.ptr(g_s), gVv_ptr, 2 * F, 1, st)
+        else:
+            _dense_bwd_input(g_a0, z0 if act0 else None, W0d, g_stack, n, F, 2 * F, act0, st)
+            _lib.call("cgv_update_norm_stack_bwd", _lib.ptr(g_stack), Vv_ptr, _lib.ptr(stack),
+                      _lib.ptr(g_ds) if ctx.residual else None, _lib.ptr(g_s), gVv_ptr, n, F, 2 * F, 1, st)
         Wuv = torch.as_strided(u_w.detach(), (2 * F, F), (F, 1))
         _dense_bwd_input(gUV, None, Wuv, g_vt, 3 * n, 2 * F, F, 0, st)
         _lib.call("cgv_update_vec_from_rows", _lib.ptr(g_vt), _lib.ptr(g_dv) if ctx.residual else None, _lib.ptr(g_v),

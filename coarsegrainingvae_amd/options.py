@@ -31,6 +31,7 @@ HOST = {
     "fwd_parts": 1,         # shared-source message forward (rb = 2): blocks per (group, channel tile), 1 (default) .. 4 (cgv_equi_msg_fwd_grouped_parts; measured level with 1 or slower)
     "fwd_balanced": 0,      # shared-source message forward (rb = 2): 0 (default) one block per (group, channel tile) (cgv_equi_msg_fwd_grouped), 1 equal edge ranges per wave on a resident grid (cgv_equi_msg_fwd_balanced) -- measured slower: chignolin 45.6 against 42.7 us, 2000 atoms 678 / 600
     "act_downstream": 1,    # Dense(act) -> Dense chains on the tile kernels (> 64 rows): 1 the second layer's backward-input launch multiplies its output by act'(z) of the first (once per element), whose own backward then runs without an activation; 0 act'(z) in the operand loads of the first layer's backward launches (every column-tile block evaluates it again: 704 x 600 x 600 17.7 against 11.2 us)
+    "update_fused_bwd": 1,  # UpdateBlock backward on more than 32 bead rows: 1 the norm / stack backward in the store epilogue of s_dense.0's backward-input product (cgv_tile_linear_bwd_input_norm_stack: one launch less per layer), 0 product + element-wise launch
     "strip_split": 1,       # weight gradients of layers with 32 .. 96 operand rows (bead-level layers of a large bead batch, gathered rows of 4 - 8 ranks): 1 from 64 rows on strips on the bf16 matrix path with split operands (x split once per problem, g once per strip), 0 fp32 MFMA strips, 2 split strips at every row count (tests)
     "decoder_dense": 0,     # full-width products of the fused decoder loop: 0 four-column blocks (cgv_decoder_dense_fwd), 1 skinny_fwd_k
 }

@@ -636,6 +636,14 @@ int cgv_tile_pair_linear_bwd_input(const float* gy_a, const float* z_a, const fl
  * and its own backward runs with act = 0.  Applied once per element in the store epilogue instead of in the operand loads
  * of the producing layer's backward-input and weight-gradient launches (every column-tile block of a row tile evaluates
  * it again there).  add may be NULL; in the pair form either z_out may be NULL (that output is stored as it is). */
+/* UpdateBlock.forward's backward (conv.py:600-603) through s_dense.0 AND the norm / stack step in ONE launch: the product
+ * g_stack = (gy * act'(z)) W over M beads (K = 2 F columns) is not stored; columns k < F become g_s = g_stack + g_res (g_res
+ * may be NULL), columns F + f go through d ||Vv|| / d Vv: gVv[3 m + xyz, f] (+)= g_stack / stack[m, F + f] * Vv[3 m + xyz, f]
+ * (rows of ld floats; accumulate != 0 adds to what cgv_update_gate_bwd left there).  Replaces cgv_tile_linear_bwd_input_act +
+ * cgv_update_norm_stack_bwd. */
+int cgv_tile_linear_bwd_input_norm_stack(const float* gy, const float* z, const float* W, int M, int N, int K, int act,
+                                         const float* stack, const float* Vv, const float* g_res, float* g_s, float* gVv, int ld,
+                                         int accumulate, void* stream);
 /* Few output tiles and a long reduction (96 bead rows x 1800 columns: 60 tiles on 256 CUs): with a workspace registered the
  * backward-input launches of the CALLING host thread on `stream` give such a tile to 2 - 4 blocks, each with a share of the
  * reduction; their partial tiles meet in the workspace and the last block to arrive adds them in share order and runs the
