@@ -79,6 +79,7 @@ PROTOTYPES = {
     "cgv_pseudo_msg_bwd": (_i, [_p] * 24 + [_i, _i, _i, _i, C.c_int64, _p, _sz, _p]),
     "cgv_pseudo_msg_bwd_deferred": (_i, [_p] * 22 + [_i, _i, _i, _i, C.c_int64, _p, _sz, _p, _p]),
     "cgv_update_rows_from_vec": (_i, [_p, _p, _i, _i, _p]),
+    "cgv_tile_bwd_input_plan": (_i, [_i, _i, _i, _i, _p, _p]),
     "cgv_tile_linear_bwd_input_norm_stack": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _p]),
     "cgv_update_vec_from_rows": (_i, [_p, _p, _p, _i, _i, _p]),
     "cgv_update_norm_stack_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),

@@ -994,6 +994,17 @@ int cgv_tile_pair_linear_fwd(const float* x_a, const float* W_a, const float* bi
 }
 
 
+/* blocks per output tile of the split reduction for `tiles` 16-row tiles over an N-deep reduction (1: unsplit) -- ONE rule
+ * for the launcher and for cgv_tile_bwd_input_plan */
+static int split_shares(int tiles, int N) {
+  const int opt = cgv::option(CGV_OPT_BWD_INPUT_SPLIT);
+  if (opt == 1 || tiles > 128 || tiles < 1) return 1;
+  int n = opt >= 2 ? opt : 256 / tiles;
+  n = n > 4 ? 4 : n;
+  while (n > 1 && (N + 15) / 16 / n < 16) --n;                            // at least one step per wave and share
+  return n < 1 ? 1 : n;
+}
+
 static int tile_bwd_input_launch(const float* g, const float* z, int act, const float* W, float* gx, int M, int N, int K,
                                  void* stream, const char* what, const float* add = nullptr,
                                  cgv::BcastAdd bc = cgv::BcastAdd{nullptr, nullptr, nullptr, 0},
@@ -1042,12 +1053,9 @@ static int tile_bwd_input_launch(const float* g, const float* z, int act, const 
     // with a registered workspace, 2 - 4 blocks per tile split it further (SplitN)
     cgv::SplitN sp{nullptr, nullptr, 1};
     const int tiles = blocks16 * (int)np;
-    const int opt = cgv::option(CGV_OPT_BWD_INPUT_SPLIT);
     const cgv::SplitWs& w = cgv::g_split_ws;
-    if (opt != 1 && w.ws && w.stream == stream && tiles <= 128) {
-      int n = opt >= 2 ? opt : 256 / tiles;
-      n = n > 4 ? 4 : n;
-      while (n > 1 && (N + 15) / 16 / n < 16) --n;                        // at least one step per wave and share
+    if (w.ws && w.stream == stream) {
+      const int n = split_shares(tiles, N);
       const size_t need = cgv::SPLIT_TICKET_BYTES + (size_t)tiles * n * (16 * 64) * sizeof(float);
       if (n > 1 && need <= w.bytes && (size_t)tiles * sizeof(unsigned) <= cgv::SPLIT_TICKET_BYTES) {
         sp.ticket = reinterpret_cast<unsigned*>(w.ws);
@@ -1061,6 +1069,26 @@ static int tile_bwd_input_launch(const float* g, const float* z, int act, const 
   else
     hipLaunchKernelGGL((cgv::tile_bwd_input_k<1, 8>), dim3(kt, (M + 15) / 16, np), dim3(512), 0, st, g, W, gx, M, N, K, z, act, add, bc, s2, more, oa, cgv::SplitN{nullptr, nullptr, 1}, ns);
   return cgv::check_launch(what);
+}
+
+/* What a backward-input launch of this shape does with a registered workspace: *shares = blocks per output tile of the
+ * split reduction (1: unsplit), *streamk = 1 when the stream-K kernel takes it (np = 1 single launch, 2 pair launch).
+ * The dispatch rules of tile_bwd_input_launch, for callers that choose between this entry point and the row-split kernel
+ * (primitives._LinearFn, ops._dense_bwd_input): the workspace is per (host thread, stream) state the call itself cannot see. */
+int cgv_tile_bwd_input_plan(int M, int N, int K, int np, int* shares, int* streamk) {
+  CGV_REQUIRE(shares && streamk && np >= 1 && np <= 2, "bad argument");
+  CGV_REQUIRE(cgv_tile_supported(M, N, K), "unsupported shape (need N % 4 == 0, K % 4 == 0)");
+  *shares = 1;
+  const int opt_sk = cgv::option(CGV_OPT_STREAMK);
+  *streamk = (opt_sk == 2 || opt_sk == 3 || opt_sk >= 16) ? 1 : (opt_sk == 1 ? 0 : (np == 1 && M >= 1536 && K <= 640 && N >= 1200));
+  if (*streamk) return 0;
+  const int kt = (K + 63) / 64, blocks16 = kt * ((M + 15) / 16);
+  const int ow = cgv::option(CGV_OPT_BWD_INPUT_WAVES);
+  const bool waves16 = (ow > 0 && ow != 32) ? ow == 16 : (blocks16 < 128 && N >= 1024);
+  const int blocks32 = kt * ((M + 31) / 32);
+  if (ow == 32 || (blocks32 >= 200 && !waves16) || !waves16) return 0;      // (the 8-wave / 32-row kernels never split)
+  *shares = split_shares(blocks16 * np, N);
+  return 0;
 }
 
 /* Registers the workspace of the split reduction for the CALLING host thread's launches on `stream` (ws = NULL: none).

@@ -644,6 +644,11 @@ int cgv_tile_pair_linear_bwd_input(const float* gy_a, const float* z_a, const fl
 int cgv_tile_linear_bwd_input_norm_stack(const float* gy, const float* z, const float* W, int M, int N, int K, int act,
                                          const float* stack, const float* Vv, const float* g_res, float* g_s, float* gVv, int ld,
                                          int accumulate, void* stream);
+/* What cgv_tile_linear_bwd_input* would do for this shape GIVEN a registered workspace (the workspace is per (host thread,
+ * stream) state a single call cannot see): *shares = blocks per output tile of the split reduction (1 = unsplit), *streamk = 1 when
+ * the stream-K kernel takes the launch (np = 1: single, 2: pair launch).  For callers that choose between these entry points and
+ * the row-split kernel of cgv_skinny_linear_bwd_input. */
+int cgv_tile_bwd_input_plan(int M, int N, int K, int np, int* shares /*[host]*/, int* streamk /*[host]*/);
 /* Few output tiles and a long reduction (96 bead rows x 1800 columns: 60 tiles on 256 CUs): with a workspace registered the
  * backward-input launches of the CALLING host thread on `stream` give such a tile to 2 - 4 blocks, each with a share of the
  * reduction; their partial tiles meet in the workspace and the last block to arrive adds them in share order and runs the

@@ -209,3 +209,24 @@ def test_sample_seed_differs_per_rank_and_rank0_keeps_the_single_process_stream(
     x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
     x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
     assert sample_seed(123, 0) == (x ^ (x >> 31)) & ((1 << 62) - 1)
+
+
+def test_backward_input_plan_matches_what_the_mirror_assumes():
+    """The mirror picks the tile kernel over the row-split kernel for 33-64 bead rows below 4096 columns, and for 65-128 rows
+    at >= 4096 columns, ON THE PROMISE that the tile kernel splits each tile's reduction over 2-4 blocks there
+    (primitives._LinearFn._backward_core, ops._dense_bwd_input); ``cgv_tile_bwd_input_plan`` states the launcher's own
+    conditions (csrc/tile_gemm.hip: tile_bwd_input_launch) so that the promise is checkable without a GPU."""
+    import ctypes as C
+    from coarsegrainingvae_amd import _lib
+    lib = _lib.load()
+    shares, sk = C.c_int(), C.c_int()
+
+    def plan(M, N, K, np_=1):
+        assert lib.cgv_tile_bwd_input_plan(M, N, K, np_, C.byref(shares), C.byref(sk)) == 0
+        return shares.value, sk.value
+    for M, N, K in ((64, 1800, 600), (64, 1200, 600), (96, 5400, 600), (128, 5400, 600), (96, 1800, 600), (48, 1800, 600)):
+        assert plan(M, N, K)[0] >= 2, (M, N, K)                       # the shapes the mirror sends to the tile kernel for its split
+    assert plan(64, 600, 600) == (1, 0)                              # short reduction: 8 waves, unsplit (and still ahead of the row split)
+    assert plan(332, 1800, 600) == (1, 0) and plan(704, 1800, 600) == (1, 0)
+    assert plan(2000, 1800, 600) == (1, 1) and plan(2000, 5400, 600) == (1, 1)      # stream-K: many rows, small output, long reduction
+    assert plan(2000, 1800, 600, 2) == (1, 0) and plan(2000, 600, 600) == (1, 0)    # pairs and short reductions stay on the tiles
