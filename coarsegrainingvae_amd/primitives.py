@@ -309,9 +309,9 @@ class WeightGradQueue:
             dev = table.device
             ws = self._strip_ws.get(dev)
             if ws is None or ws.numel() < plane_bytes:
-                if torch.cuda.is_current_stream_capturing():
-                    # (a buffer created inside a capture belongs to the graph's pool; the trainer always steps eagerly first)
-                    raise RuntimeError("run one eager step before capturing (split-operand workspace of the strip weight gradients)")
+                # (the first strip launch of a run may be the captured step's -- the first eager step has no arena yet and takes
+                # other launches: the buffer then comes from the graph's pool and stays referenced here, like every other
+                # tensor a captured step allocates)
                 ws = self._strip_ws[dev] = torch.empty(max(plane_bytes, 32 << 20), dtype=torch.uint8, device=dev)
             _lib.call("cgv_grouped_wgrad_strip_split", _lib.ptr(table), n_problems, blocks, rows, max_k, _lib.ptr(ws), ws.numel(),
                       _lib.stream_ptr(), tag=tag)
